@@ -1,0 +1,185 @@
+/*
+ * squarna_hip.h -- C ABI of libsquarna_hip.so, the MI355X (gfx950) folding core
+ * that replaces the single-sequence hot path of febos/SQUARNA v3.2.2.
+ *
+ * The reference is pure Python and has no FFI of its own; the
+ * boundary a maintainer would bind is the Python function surface of
+ * src/SQUARNA/SQRNdbnseq.py.  Each entry point below names the reference
+ * function(s) it replaces (file:line).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions across the boundary.
+ *   - Every function returns 0 on success, <0 for an invalid argument / capacity
+ *     problem, >0 for a HIP error code; sq_last_error() gives the message.
+ *   - The caller owns all DEVICE memory: a single workspace (e.g. a torch uint8
+ *     tensor) whose size sq_batch_workspace_bytes() reports.  The library never
+ *     allocates or frees device memory; it keeps small pinned host staging
+ *     buffers per batch.
+ *   - All device work is enqueued on the caller's stream (hipStream_t passed as
+ *     void*); entry points that return host results synchronise that stream.
+ *   - Sequences are passed pre-encoded by the host layer (upper-cased, T->U,
+ *     gap-free: SQRNdbnseq.py:1004,1023): code 0..25 = 'A'..'Z', 26 = ';',
+ *     27 = '&', 28 = any other symbol.
+ */
+#ifndef SQUARNA_HIP_H
+#define SQUARNA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQ_API __attribute__((visibility("default")))
+
+#define SQ_ALPHABET 32
+#define SQ_CODE_SEP1 26   /* ';' */
+#define SQ_CODE_SEP2 27   /* '&' */
+#define SQ_CODE_OTHER 28
+
+/* position flags (ParseRestraints, SQRNdbnseq.py:370-376) */
+#define SQ_FLAG_RX 1      /* '_' or '+': forced unpaired           */
+#define SQ_FLAG_RLEFT 2   /* '/' : may not be the 3' partner (j)    */
+#define SQ_FLAG_RRIGHT 4  /* '\': may not be the 5' partner (i)     */
+
+/* algorithms bitmask (config key "algorithms", SQUARNA.py:62-63) */
+#define SQ_ALGO_G 1
+#define SQ_ALGO_N 2
+#define SQ_ALGO_H 4
+#define SQ_ALGO_E 8
+
+/* One parameter set of a .conf file (SQUARNA.py:15-77; read at SQRNdbnseq.py:1050-1062). */
+typedef struct sq_paramset {
+    double bpweight[SQ_ALPHABET * SQ_ALPHABET]; /* weight of pair (a,b), both orientations filled (SQRNdbnseq.py:282-284) */
+    uint8_t inbps[SQ_ALPHABET * SQ_ALPHABET];   /* 1 iff the pair is a key of bpweights (either orientation)          */
+    double bpp;                /* must be 0 (ViennaRNA branch SQRNdbnseq.py:341-364 not built; rejected)  */
+    double suboptmax, suboptmin, suboptsteps;
+    double minlen, minbpscore, minfinscorefactor;
+    double bracketweight, distcoef, orderpenalty, loopbonus;
+    double maxstemnum;
+    uint32_t algorithms;       /* SQ_ALGO_* */
+    uint32_t reserved;
+} sq_paramset;
+
+/* Host-side description of a batch: sequences, per-position inputs, jobs.
+ * A job = one (sequence, paramset) pair = one pass of SQRNdbnseq.py:1048-1199. */
+typedef struct sq_batch_desc {
+    int32_t nseq;
+    const int32_t *seq_off;     /* [nseq+1] offsets into the per-position arrays                */
+    const uint8_t *codes;       /* letter codes                                                  */
+    const uint8_t *flags;       /* SQ_FLAG_*                                                     */
+    const double *reacts;       /* per-position reactivities after ProcessReacts (SQRNdbnseq.py:32-59), never NULL */
+    const int32_t *rbp_off;     /* [nseq+1] offsets (in pairs) into rbps                         */
+    const int32_t *rbps;        /* restraint base pairs (v,w), v<w, gap-free coordinates         */
+    int32_t npset;
+    const sq_paramset *psets;
+    int32_t njobs;
+    const int32_t *job_seq;     /* [njobs] */
+    const int32_t *job_pset;    /* [njobs] */
+    /* optional dense fp64 inputs, one N x N row-major matrix per job (NULL entries allowed, array may be NULL): */
+    const double *const *ext_bool;   /* AnnotateStems/OptimalStems shims: caller-supplied bpboolmatrix   */
+    const double *const *ext_score;  /* ... and bpscorematrix (SQRNdbnseq.py:427-428,792-797)            */
+    const double *const *mul_score;  /* alignment step-2 weighting, bpscorematrix *= shortsmat (SQRNdbnseq.py:1084-1085) */
+    int32_t interchainonly;     /* SQRNdbnseq.py:264-271,301 */
+    int32_t max_structs;        /* structures evaluated per round chunk (0 = default 4096)      */
+    int32_t cand_per_nt;        /* candidate capacity per structure = cand_per_nt * N (0 = 32)  */
+    int32_t reserved;
+} sq_batch_desc;
+
+typedef struct sq_batch sq_batch;   /* opaque */
+
+/* One stem as the reference's [bps, len, bpscore, finalscore] record
+ * (SQRNdbnseq.py:417,747): bps = (i+k, j-k), k = 0..len-1. */
+typedef struct sq_stem {
+    int32_t i, j, len, reserved;
+    double bpscore;
+    double finscore;
+} sq_stem;
+
+/* Options of the SQRNdbnseq tail (SQRNdbnseq.py:973-980). */
+typedef struct sq_fold_opts {
+    int32_t poollim;        /* SQRNdbnseq.py:1147,1191 */
+    int32_t conslim;        /* :1236 */
+    int32_t toplim;         /* :1282 */
+    int32_t hardrest;       /* :1226-1228 */
+    int32_t rankbydiff;     /* :917-955 */
+    int32_t rankby[3];      /* :907 */
+    int32_t levellimit;     /* <0: default 3 - (N > 500)  (:1043-1044) */
+    uint32_t algos;         /* SQ_ALGO_* override, 0 = use each paramset's own (:1065-1066) */
+    uint64_t priority_mask; /* bit p set: paramset p is prioritised (:912-913) */
+} sq_fold_opts;
+
+/* ---- library -------------------------------------------------------------- */
+SQ_API int sq_version(void);
+SQ_API const char *sq_last_error(void);
+
+/* ---- batch lifecycle ------------------------------------------------------- */
+/* Bytes of device workspace sq_batch_create() needs for this description. */
+SQ_API int sq_batch_workspace_bytes(const sq_batch_desc *desc, size_t *bytes);
+/* Uploads the O(N) inputs; the N x N matrices are produced on device by sq_bpmatrix_fill. */
+SQ_API int sq_batch_create(sq_batch **out, const sq_batch_desc *desc, void *dev_workspace, size_t workspace_bytes,
+                    void *hip_stream);
+SQ_API void sq_batch_destroy(sq_batch *b);
+
+/* ---- a-1  BPMatrix (SQRNdbnseq.py:258-367) -------------------------------------
+ * Fills the fp32 scan matrix of every job (row pitch ld = 32*ceil((N-1)/32)+1 floats,
+ * quiet-NaN sentinel where bpboolmatrix == 0).  Asynchronous on the stream. */
+SQ_API int sq_bpmatrix_fill(sq_batch *b);
+/* Returns job's (bpboolmatrix, bpscorematrix) exactly as the reference would:
+ * dense N x N fp64, computed on device in fp64.  Synchronises. */
+SQ_API int sq_bpmatrix_read(sq_batch *b, int32_t job, double *boolmat, double *scoremat);
+
+/* ---- a-2..a-6  AnnotateStems / ScoreStems / ChooseStems / OptimalStems ------------
+ * (SQRNdbnseq.py:427-495, 607-751, 754-789, 792-833)
+ * Evaluates one greedy round for `nstruct` partial structures at once.
+ * struct s belongs to job struct_job[s]; its already-selected stems are
+ * stems[stem_off[s] .. stem_off[s+1]) (only i, j, len are read).
+ * mode 0 (OptimalStems): out receives the stems ChooseStems would return for
+ *        subopt[s], in its order, with bpscore and finalscore.
+ * mode 1 (AnnotateStems): out receives every stem with len >= minlen and
+ *        bpscore >= minbpscore in the reference's emission order
+ *        (anti-diagonal i+j ascending, then i ascending); finscore = 0.
+ * out_off[nstruct+1] delimits each structure's slice of out[0..out_cap).
+ * Synchronises the stream. */
+SQ_API int sq_optimal_stems(sq_batch *b, int32_t nstruct, const int32_t *struct_job, const int32_t *stem_off,
+                     const sq_stem *stems, const double *subopt, int32_t mode,
+                     sq_stem *out, int32_t out_cap, int32_t *out_off);
+
+/* ---- a-7 + a-10  greedy pool loop and the ranking tail of SQRNdbnseq ---------------
+ * (SQRNdbnseq.py:1048-1286).  Folds every sequence of the batch under its jobs and
+ * keeps the per-sequence results inside the batch for the getters below.
+ * refs: optional per-sequence known structure as pairs (NULL = no metrics). */
+SQ_API int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref_off, const int32_t *ref_pairs,
+            const uint8_t *has_ref);
+
+/* Result getters (valid after sq_fold until the next sq_fold / destroy). */
+SQ_API int32_t sq_result_nstruct(const sq_batch *b, int32_t seq);
+/* levels: per position, 0 = unpaired, +L = opening bracket of level L, -L = closing. */
+SQ_API int sq_result_consensus(const sq_batch *b, int32_t seq, int16_t *levels);
+SQ_API int sq_result_struct(const sq_batch *b, int32_t seq, int32_t k, int16_t *levels, double scores[3],
+                     uint64_t *pset_mask);
+SQ_API int sq_result_metrics(const sq_batch *b, int32_t seq, double cons[6], double best[7]);
+/* Bulk form of the getters: one buffer per sequence, little-endian, 8-byte aligned sections:
+ *   int64  nstruct, n, has_ref, evals
+ *   double cons_metrics[6], best_metrics[7]
+ *   double scores[nstruct][3]
+ *   uint64 pset_mask[nstruct]
+ *   int16  levels[1 + nstruct][n]      (row 0 = consensus)
+ * sq_result_pack_size returns the bytes needed. */
+SQ_API int64_t sq_result_pack_size(const sq_batch *b, int32_t seq);
+SQ_API int sq_result_pack(const sq_batch *b, int32_t seq, void *buf, int64_t cap);
+/* R = number of AnnotateStems evaluations the reference algorithm performs for this sequence. */
+SQ_API int64_t sq_result_evals(const sq_batch *b, int32_t seq);
+
+/* ---- measurement ------------------------------------------------------------
+ * Kernel ids: 0 fill, 1 state, 2 stem_scan, 3 stem_score.  When enabled, every
+ * launch is bracketed by hipEvents on the batch stream. */
+SQ_API int sq_profile_enable(sq_batch *b, int32_t on);
+SQ_API int sq_profile_get(sq_batch *b, int32_t kernel, double *total_ms, int64_t *launches, double *alg_bytes);
+SQ_API int sq_profile_reset(sq_batch *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQUARNA_HIP_H */

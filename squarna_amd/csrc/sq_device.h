@@ -1,0 +1,39 @@
+// sq_device.h -- kernel argument bundles (passed by value) and kernel prototypes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sq_internal.h"
+
+struct SqDevCtx {
+    const SqJob *jobs;
+    const SqPsetDev *psets;
+    const uint8_t *codes;    // per position
+    const uint8_t *flags;
+    const uint8_t *inc4;     // minimal j - i for a pair starting at i (SQRNdbnseq.py:294-297)
+    const int16_t *chain;    // chain ordinal (interchainonly, :264-271)
+    const int16_t *e0;       // restraint mask code: -1 free, v >= 0 shared id of restraint bp (v,w) (:438-443)
+    const double *reacts;
+    float *mat32;            // fp32 scan-matrix arena
+    double *mat64;           // dense fp64 arena (external / weighted matrices only)
+    const double *sdftab;    // pow tables
+};
+
+struct SqState {             // per-structure-slot arrays, `stride` int16 elements per slot
+    int16_t *P, *E, *U, *SU;
+    int32_t stride;
+};
+
+struct SqScanArgs {
+    SqCand *cands;
+    uint32_t *cand_cnt;      // per slot
+    SqCounters *ctr;
+};
+
+extern "C" {
+__global__ void sq_fill_kernel(SqDevCtx c);
+__global__ void sq_dense64_kernel(SqDevCtx c, int job, double *boolmat, double *scoremat);
+__global__ void sq_import_kernel(SqDevCtx c);
+__global__ void sq_state_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState st);
+__global__ void sq_scan_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
+__global__ void sq_score_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
+                                SqScanArgs a, SqOut *out, uint32_t out_cap, int mode);
+}

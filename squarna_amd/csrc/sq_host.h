@@ -1,0 +1,97 @@
+// sq_host.h -- host-side batch object (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/squarna_hip.h"
+#include "sq_device.h"
+#include "sq_internal.h"
+
+struct HStem {            // host stem record: bps (i+k, j-k), k < len
+    int32_t i, j, len;
+    double bps, fin;
+};
+
+struct HStruct {          // partial structure evaluated in a round
+    int32_t job;
+    double subopt;
+    std::vector<HStem> stems;
+};
+
+struct SeqResult {        // SQRNdbnseq return tuple of one sequence (SQRNdbnseq.py:1285-1286)
+    struct Pred {
+        std::vector<int16_t> levels;   // signed bracket level per position
+        double scores[3];
+        uint64_t pset_mask;
+    };
+    std::vector<int16_t> cons;
+    std::vector<Pred> preds;
+    double cons_metrics[6], best_metrics[7];
+    bool has_ref = false;
+    int64_t evals = 0;
+};
+
+struct ProfSlot {
+    double ms = 0;
+    int64_t launches = 0;
+    double bytes = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+struct sq_batch {
+    hipStream_t stream = nullptr;
+    // host copies
+    int32_t nseq = 0, npset = 0, njobs = 0, maxn = 0;
+    int64_t ltot = 0;
+    std::vector<int32_t> seq_off, rbp_off, rbps, job_seq, job_pset;
+    std::vector<uint8_t> codes, flags;
+    std::vector<double> reacts;
+    std::vector<sq_paramset> psets;
+    std::vector<SqJob> jobs;
+    int32_t interchainonly = 0;
+    int32_t max_structs = 4096;
+    int32_t cand_per_nt = 32;
+    // device carve
+    SqDevCtx ctx{};
+    SqState state{};
+    SqScanArgs scan{};
+    SqStruct *d_structs = nullptr;
+    SqStrand *d_strands = nullptr;
+    SqOut *d_out = nullptr;
+    int64_t cand_records = 0;
+    uint32_t out_cap = 0;
+    int32_t strand_cap = 0;
+    size_t mat32_bytes = 0;
+    bool filled = false;
+    // pinned staging
+    SqStruct *h_structs = nullptr;
+    SqStrand *h_strands = nullptr;
+    SqCounters *h_ctr = nullptr;
+    SqOut *h_out = nullptr;
+    uint32_t h_out_cap = 0;
+    std::vector<SqOut> big_out;
+    // results
+    std::vector<SeqResult> results;
+    // profiling
+    bool prof_on = false;
+    ProfSlot prof[4];
+};
+
+void sq_set_error(const std::string &msg);
+int sq_check(hipError_t e, const char *what);
+
+// one greedy round (or a raw AnnotateStems pass) for a list of structures; results per structure
+int sq_run_round(sq_batch *b, const std::vector<HStruct> &structs, int mode, std::vector<std::vector<HStem>> &out);
+
+// host tail: SQRNdbnseq.py:1201-1286
+void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
+             const std::vector<std::vector<std::vector<HStem>>> &per_job_structs,   // [job-of-seq][structure][stem]
+             const std::vector<int32_t> &job_ids, const int32_t *ref_pairs, int nref, bool has_ref,
+             SeqResult &res);
+
+// pseudoknot levels at pair level (PairsToDBN, SQRNdbnseq.py:104-150); pairs sorted & unique
+int sq_pair_levels(const std::vector<std::pair<int, int>> &pairs, std::vector<int> &level);
+// same at stem level (exactly equivalent for the stems of one structure)
+void sq_stem_levels(const std::vector<HStem> &stems, std::vector<int> &level);

@@ -1,0 +1,724 @@
+// sq_host.hip -- host driver of libsquarna_hip.so: batch set-up, kernel launches, the
+// round driver and the greedy pool loop (SQRNdbnseq.py:1102-1199).  Device memory is
+// the caller's workspace; the host only orchestrates (one small H2D + D2H per round).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "sq_host.h"
+
+static thread_local std::string g_err;
+void sq_set_error(const std::string &msg) { g_err = msg; }
+int sq_check(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return 0;
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return (int)e;
+}
+#define HIPCK(x) do { int _r = sq_check((x), #x); if (_r) return _r; } while (0)
+
+extern "C" int sq_version(void) { return 100; }
+extern "C" const char *sq_last_error(void) { return g_err.c_str(); }
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int32_t ld_of(int n) { return 32 * ((std::max(n, 1) - 1 + 31) / 32) + 1; }
+
+namespace {
+struct Layout {
+    size_t off_codes, off_flags, off_inc4, off_chain, off_e0, off_reacts, off_jobs, off_psets, off_sdf;
+    size_t off_mat32, off_mat64, off_structs, off_strands, off_state, off_cnt, off_ctr, off_cands, off_out;
+    size_t total;
+    int64_t ltot, sdf_len, mat32_floats, mat64_doubles, cand_records;
+    int32_t maxn, stride, max_structs, strand_cap, cpn;
+    uint32_t out_cap;
+};
+
+int plan(const sq_batch_desc *d, Layout &L)
+{
+    if (!d || d->nseq <= 0 || d->njobs <= 0 || d->npset <= 0) { sq_set_error("empty batch"); return -1; }
+    L.ltot = d->seq_off[d->nseq];
+    L.maxn = 0;
+    for (int s = 0; s < d->nseq; s++) L.maxn = std::max(L.maxn, d->seq_off[s + 1] - d->seq_off[s]);
+    if (L.maxn > 32000) { sq_set_error("sequence longer than 32000 nt"); return -1; }
+    L.max_structs = d->max_structs > 0 ? d->max_structs : 4096;
+    L.cpn = d->cand_per_nt > 0 ? d->cand_per_nt : 32;
+    L.mat32_floats = 0; L.mat64_doubles = 0;
+    for (int j = 0; j < d->njobs; j++) {
+        const int s = d->job_seq[j];
+        if (s < 0 || s >= d->nseq || d->job_pset[j] < 0 || d->job_pset[j] >= d->npset) { sq_set_error("bad job"); return -1; }
+        const int64_t n = d->seq_off[s + 1] - d->seq_off[s];
+        L.mat32_floats += (int64_t)align_up((size_t)(n * ld_of((int)n)), 64);
+        const bool ext = d->ext_score && d->ext_score[j];
+        const bool mul = d->mul_score && d->mul_score[j];
+        if (ext) L.mat64_doubles += 2 * n * n;
+        else if (mul) L.mat64_doubles += n * n;
+    }
+    L.mat32_floats += 1024;
+    L.sdf_len = 0;
+    for (int p = 0; p < d->npset; p++) {
+        const double bw = d->psets[p].bracketweight;
+        if (bw == std::floor(bw) && std::fabs(bw) <= 64) L.sdf_len += (int64_t)std::max(1.0, std::fabs(bw)) * L.maxn + 16;
+    }
+    L.stride = (int32_t)align_up((size_t)L.maxn + 2, 32);
+    L.strand_cap = (int32_t)std::min<int64_t>((int64_t)L.max_structs * 64 + L.maxn, 1 << 24);
+    L.cand_records = std::min<int64_t>((int64_t)L.max_structs * L.cpn * L.maxn, (int64_t)64 << 20);
+    L.cand_records = std::max<int64_t>(L.cand_records, (int64_t)L.cpn * L.maxn + 256);
+    // the dense fp64 read-back (sq_bpmatrix_read) borrows the candidate arena
+    L.cand_records = std::max<int64_t>(L.cand_records, (int64_t)(2 * (int64_t)L.maxn * L.maxn * 8 / sizeof(SqCand)) + 16);
+    L.out_cap = (uint32_t)std::min<int64_t>(L.cand_records, (int64_t)4 << 20);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    L.off_codes = take(L.ltot); L.off_flags = take(L.ltot); L.off_inc4 = take(L.ltot);
+    L.off_chain = take(L.ltot * 2); L.off_e0 = take(L.ltot * 2); L.off_reacts = take(L.ltot * 8);
+    L.off_jobs = take(sizeof(SqJob) * d->njobs); L.off_psets = take(sizeof(SqPsetDev) * d->npset);
+    L.off_sdf = take(8 * (size_t)std::max<int64_t>(L.sdf_len, 1));
+    L.off_mat32 = take(4 * (size_t)L.mat32_floats);
+    L.off_mat64 = take(8 * (size_t)std::max<int64_t>(L.mat64_doubles, 1));
+    L.off_structs = take(sizeof(SqStruct) * L.max_structs);
+    L.off_strands = take(sizeof(SqStrand) * (size_t)L.strand_cap);
+    L.off_state = take((size_t)4 * 2 * L.stride * L.max_structs);
+    L.off_cnt = take(4 * (size_t)L.max_structs);
+    L.off_ctr = take(sizeof(SqCounters));
+    L.off_cands = take(sizeof(SqCand) * (size_t)L.cand_records);
+    L.off_out = take(sizeof(SqOut) * (size_t)L.out_cap);
+    L.total = o;
+    return 0;
+}
+}  // namespace
+
+extern "C" int sq_batch_workspace_bytes(const sq_batch_desc *desc, size_t *bytes)
+{
+    Layout L;
+    int r = plan(desc, L);
+    if (r) return r;
+    *bytes = L.total;
+    return 0;
+}
+
+extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws, size_t ws_bytes, void *hip_stream)
+{
+    Layout L;
+    int r = plan(d, L);
+    if (r) return r;
+    if (!ws || ws_bytes < L.total) { sq_set_error("workspace too small"); return -2; }
+    if (((uintptr_t)ws & 255) != 0) { sq_set_error("workspace must be 256-byte aligned"); return -2; }
+    for (int p = 0; p < d->npset; p++)
+        if (d->psets[p].bpp != 0) {
+            sq_set_error("bpp != 0 needs ViennaRNA base-pair probabilities (SQRNdbnseq.py:341-364); not supported");
+            return -4;
+        }
+    sq_batch *b = new sq_batch();
+    b->stream = (hipStream_t)hip_stream;
+    b->nseq = d->nseq; b->npset = d->npset; b->njobs = d->njobs; b->maxn = L.maxn; b->ltot = L.ltot;
+    b->seq_off.assign(d->seq_off, d->seq_off + d->nseq + 1);
+    b->codes.assign(d->codes, d->codes + L.ltot);
+    b->flags.assign(d->flags, d->flags + L.ltot);
+    b->reacts.assign(d->reacts, d->reacts + L.ltot);
+    b->rbp_off.assign(d->rbp_off, d->rbp_off + d->nseq + 1);
+    b->rbps.assign(d->rbps, d->rbps + 2 * (size_t)d->rbp_off[d->nseq]);
+    b->job_seq.assign(d->job_seq, d->job_seq + d->njobs);
+    b->job_pset.assign(d->job_pset, d->job_pset + d->njobs);
+    b->psets.assign(d->psets, d->psets + d->npset);
+    b->interchainonly = d->interchainonly;
+    b->max_structs = L.max_structs; b->cand_per_nt = L.cpn;
+    b->cand_records = L.cand_records; b->out_cap = L.out_cap; b->strand_cap = L.strand_cap;
+    b->mat32_bytes = 4 * (size_t)L.mat32_floats;
+
+    char *base = (char *)ws;
+    // ---- per-position derived arrays (host, O(N)) ----
+    std::vector<uint8_t> inc4(L.ltot);
+    std::vector<int16_t> chain(L.ltot, 0), e0(L.ltot, -1);
+    for (int s = 0; s < d->nseq; s++) {
+        const int off = d->seq_off[s], n = d->seq_off[s + 1] - off;
+        auto sep = [&](int p) { return b->codes[off + p] == SQ_CODE_SEP1 || b->codes[off + p] == SQ_CODE_SEP2; };
+        int curr = 0;
+        for (int i = 0; i < n; i++) {
+            int v = 4;                                   // SQRNdbnseq.py:294-297
+            for (int chk = 1; chk <= 2; chk++)
+                if (i + chk < n && sep(i + chk)) v = chk + 1;
+            inc4[off + i] = (uint8_t)v;
+            if (sep(i)) curr++;                          // :264-271
+            else chain[off + i] = (int16_t)curr;
+        }
+        for (int k = d->rbp_off[s]; k < d->rbp_off[s + 1]; k++) {
+            const int v = d->rbps[2 * k], w = d->rbps[2 * k + 1];
+            if (v < 0 || w >= n || v >= w) { delete b; sq_set_error("bad restraint pair"); return -1; }
+            e0[off + v] = (int16_t)v; e0[off + w] = (int16_t)v;
+        }
+    }
+    // ---- paramsets with host-libm pow tables ----
+    std::vector<SqPsetDev> pd(d->npset);
+    std::vector<double> sdf;
+    for (int p = 0; p < d->npset; p++) {
+        const sq_paramset &ps = d->psets[p];
+        SqPsetDev &x = pd[p];
+        memset(&x, 0, sizeof x);
+        memcpy(x.w, ps.bpweight, sizeof x.w);
+        memcpy(x.inbps, ps.inbps, sizeof x.inbps);
+        x.minlen = ps.minlen; x.minbpscore = ps.minbpscore;
+        x.minfinscore = ps.minbpscore * ps.minfinscorefactor;          // SQRNdbnseq.py:1073
+        x.bracketweight = ps.bracketweight; x.distcoef = ps.distcoef;
+        x.orderpenalty = ps.orderpenalty; x.loopbonus = ps.loopbonus;
+        for (int k = 0; k <= SQ_MAXLEVELS; k++) x.oftab[k] = pow(1.0 / (1 + k), ps.orderpenalty);   // :729
+        const double bw = ps.bracketweight;
+        x.bw_integral = (bw == std::floor(bw) && std::fabs(bw) <= 64) ? 1 : 0;
+        x.sdf_off = (int32_t)sdf.size(); x.sdf_len = 0;
+        if (x.bw_integral) {
+            x.sdf_len = (int32_t)(std::max(1.0, std::fabs(bw)) * L.maxn + 16);
+            for (int k = 0; k < x.sdf_len; k++) sdf.push_back(pow(1.0 / (1.0 + (double)k), ps.distcoef));   // :726
+        }
+    }
+    // ---- jobs ----
+    b->jobs.resize(d->njobs);
+    int64_t m32 = 0, m64 = 0;
+    std::vector<std::pair<int, int64_t>> ext_uploads;   // (job, mat64 offset)
+    for (int j = 0; j < d->njobs; j++) {
+        SqJob &J = b->jobs[j];
+        const int s = d->job_seq[j];
+        J.n = d->seq_off[s + 1] - d->seq_off[s];
+        J.ld = ld_of(J.n); J.seq = s; J.pset = d->job_pset[j];
+        J.pos_off = d->seq_off[s];
+        J.mat_off = m32; m32 += (int64_t)align_up((size_t)J.n * J.ld, 64);
+        J.mat64_off = -1; J.has_ext = 0;
+        const bool ext = d->ext_score && d->ext_score[j];
+        const bool mul = d->mul_score && d->mul_score[j];
+        if (ext) { J.mat64_off = m64; J.has_ext = 1; m64 += 2 * (int64_t)J.n * J.n; }
+        else if (mul) { J.mat64_off = m64; J.has_ext = 2; m64 += (int64_t)J.n * J.n; }
+        bool def = true;                                  // SQRNdbnseq.py:273
+        for (int i = 0; i < J.n; i++) if (d->reacts[J.pos_off + i] != 0.5) { def = false; break; }
+        J.default_reacts = def ? 1 : 0;
+        J.interchainonly = d->interchainonly;
+        J.cand_cap = (int32_t)std::max<int64_t>(256, (int64_t)L.cpn * J.n);
+    }
+    // ---- device carve + uploads ----
+    b->ctx.codes = (uint8_t *)(base + L.off_codes); b->ctx.flags = (uint8_t *)(base + L.off_flags);
+    b->ctx.inc4 = (uint8_t *)(base + L.off_inc4); b->ctx.chain = (int16_t *)(base + L.off_chain);
+    b->ctx.e0 = (int16_t *)(base + L.off_e0); b->ctx.reacts = (double *)(base + L.off_reacts);
+    b->ctx.jobs = (SqJob *)(base + L.off_jobs); b->ctx.psets = (SqPsetDev *)(base + L.off_psets);
+    b->ctx.sdftab = (double *)(base + L.off_sdf);
+    b->ctx.mat32 = (float *)(base + L.off_mat32); b->ctx.mat64 = (double *)(base + L.off_mat64);
+    b->d_structs = (SqStruct *)(base + L.off_structs); b->d_strands = (SqStrand *)(base + L.off_strands);
+    int16_t *stbase = (int16_t *)(base + L.off_state);
+    const size_t plane = (size_t)L.stride * L.max_structs;
+    b->state.P = stbase; b->state.E = stbase + plane; b->state.U = stbase + 2 * plane; b->state.SU = stbase + 3 * plane;
+    b->state.stride = L.stride;
+    b->scan.cand_cnt = (uint32_t *)(base + L.off_cnt); b->scan.ctr = (SqCounters *)(base + L.off_ctr);
+    b->scan.cands = (SqCand *)(base + L.off_cands);
+    b->d_out = (SqOut *)(base + L.off_out);
+
+    hipStream_t st = b->stream;
+#define UP(dst, src, bytes) do { int _r = sq_check(hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, st), "upload"); \
+                                 if (_r) { hipStreamSynchronize(st); delete b; return _r; } } while (0)
+    UP(b->ctx.codes, b->codes.data(), L.ltot); UP(b->ctx.flags, b->flags.data(), L.ltot);
+    UP(b->ctx.inc4, inc4.data(), L.ltot); UP(b->ctx.chain, chain.data(), L.ltot * 2);
+    UP(b->ctx.e0, e0.data(), L.ltot * 2); UP(b->ctx.reacts, b->reacts.data(), L.ltot * 8);
+    UP(b->ctx.jobs, b->jobs.data(), sizeof(SqJob) * d->njobs);
+    UP(b->ctx.psets, pd.data(), sizeof(SqPsetDev) * d->npset);
+    if (!sdf.empty()) UP(b->ctx.sdftab, sdf.data(), 8 * sdf.size());
+    for (int j = 0; j < d->njobs; j++) {
+        const SqJob &J = b->jobs[j];
+        const size_t nn = (size_t)J.n * J.n * 8;
+        if (J.has_ext == 1) {
+            if (!d->ext_bool || !d->ext_bool[j]) { hipStreamSynchronize(st); delete b; sq_set_error("ext_score without ext_bool"); return -1; }
+            UP(b->ctx.mat64 + J.mat64_off, d->ext_score[j], nn);
+            UP(b->ctx.mat64 + J.mat64_off + (int64_t)J.n * J.n, d->ext_bool[j], nn);
+        } else if (J.has_ext == 2) {
+            UP(b->ctx.mat64 + J.mat64_off, d->mul_score[j], nn);
+        }
+    }
+#undef UP
+    // pinned staging
+    if (sq_check(hipHostMalloc((void **)&b->h_structs, sizeof(SqStruct) * L.max_structs), "hipHostMalloc") ||
+        sq_check(hipHostMalloc((void **)&b->h_strands, sizeof(SqStrand) * (size_t)L.strand_cap), "hipHostMalloc") ||
+        sq_check(hipHostMalloc((void **)&b->h_ctr, sizeof(SqCounters)), "hipHostMalloc")) { delete b; return 2; }
+    b->h_out_cap = 1u << 16;
+    if (sq_check(hipHostMalloc((void **)&b->h_out, sizeof(SqOut) * (size_t)b->h_out_cap), "hipHostMalloc")) { delete b; return 2; }
+    int rr = sq_check(hipStreamSynchronize(st), "sync after upload");   // host vectors above go out of scope
+    if (rr) { delete b; return rr; }
+    b->results.resize(d->nseq);
+    *out = b;
+    return 0;
+}
+
+extern "C" void sq_batch_destroy(sq_batch *b)
+{
+    if (!b) return;
+    if (b->stream || true) hipStreamSynchronize(b->stream);
+    if (b->h_structs) hipHostFree(b->h_structs);
+    if (b->h_strands) hipHostFree(b->h_strands);
+    if (b->h_ctr) hipHostFree(b->h_ctr);
+    if (b->h_out) hipHostFree(b->h_out);
+    for (auto &p : b->prof) {
+        for (auto &e : p.pending) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+        for (auto &e : p.pool) hipEventDestroy(e);
+    }
+    delete b;
+}
+
+// ---- profiling (HIP events on the batch stream) ----------------------------------------
+namespace {
+struct ProfScope {
+    sq_batch *b; int k; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(sq_batch *b_, int k_, double bytes) : b(b_), k(k_)
+    {
+        if (!b->prof_on) return;
+        ProfSlot &p = b->prof[k];
+        auto get = [&]() { hipEvent_t e; if (!p.pool.empty()) { e = p.pool.back(); p.pool.pop_back(); } else hipEventCreate(&e); return e; };
+        e0 = get(); e1 = get();
+        p.launches++; p.bytes += bytes;
+        hipEventRecord(e0, b->stream);
+    }
+    ~ProfScope()
+    {
+        if (!e0) return;
+        hipEventRecord(e1, b->stream);
+        b->prof[k].pending.emplace_back(e0, e1);
+    }
+};
+void prof_collect(sq_batch *b)
+{
+    for (auto &p : b->prof) {
+        for (auto &e : p.pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) p.ms += ms;
+            p.pool.push_back(e.first); p.pool.push_back(e.second);
+        }
+        p.pending.clear();
+    }
+}
+}  // namespace
+
+extern "C" int sq_profile_enable(sq_batch *b, int32_t on) { b->prof_on = on != 0; return 0; }
+extern "C" int sq_profile_reset(sq_batch *b)
+{
+    hipStreamSynchronize(b->stream);
+    prof_collect(b);
+    for (auto &p : b->prof) { p.ms = 0; p.launches = 0; p.bytes = 0; }
+    return 0;
+}
+extern "C" int sq_profile_get(sq_batch *b, int32_t k, double *ms, int64_t *launches, double *bytes)
+{
+    if (k < 0 || k > 3) return -1;
+    hipStreamSynchronize(b->stream);
+    prof_collect(b);
+    *ms = b->prof[k].ms; *launches = b->prof[k].launches; *bytes = b->prof[k].bytes;
+    return 0;
+}
+
+// ---- a-1 -----------------------------------------------------------------------------------
+extern "C" int sq_bpmatrix_fill(sq_batch *b)
+{
+    int64_t maxq = 0; double bytes = 0; bool any_ext = false;
+    for (const SqJob &J : b->jobs) {
+        maxq = std::max<int64_t>(maxq, ((int64_t)J.n * J.ld + 3) / 4);
+        bytes += 4.0 * J.n * J.n;                                       // algorithmic: one fp32 N x N write
+        any_ext |= J.has_ext == 1;
+    }
+    for (int j0 = 0; j0 < b->njobs; j0 += 32768) {
+        const int nj = std::min(32768, b->njobs - j0);
+        SqDevCtx c = b->ctx; c.jobs = b->ctx.jobs + j0;
+        dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>((maxq + 255) / 256, 1), 1024), (unsigned)nj);
+        {
+            ProfScope ps(b, 0, j0 == 0 ? bytes : 0);
+            hipLaunchKernelGGL(sq_fill_kernel, grid, dim3(256), 0, b->stream, c);
+        }
+        if (any_ext) hipLaunchKernelGGL(sq_import_kernel, grid, dim3(256), 0, b->stream, c);
+    }
+    HIPCK(hipGetLastError());
+    b->filled = true;
+    return 0;
+}
+
+extern "C" int sq_bpmatrix_read(sq_batch *b, int32_t job, double *boolmat, double *scoremat)
+{
+    if (job < 0 || job >= b->njobs) { sq_set_error("bad job index"); return -1; }
+    const SqJob &J = b->jobs[job];
+    const size_t nn = (size_t)J.n * J.n;
+    if (J.has_ext == 1) { sq_set_error("job uses caller matrices"); return -1; }
+    double *tmp = (double *)b->scan.cands;                  // borrowed: idle between rounds
+    hipLaunchKernelGGL(sq_dense64_kernel, dim3((unsigned)std::min<size_t>((nn + 255) / 256 + 1, 2048)), dim3(256), 0,
+                       b->stream, b->ctx, job, tmp, tmp + nn);
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(boolmat, tmp, nn * 8, hipMemcpyDeviceToHost, b->stream));
+    HIPCK(hipMemcpyAsync(scoremat, tmp + nn, nn * 8, hipMemcpyDeviceToHost, b->stream));
+    HIPCK(hipStreamSynchronize(b->stream));
+    if (J.has_ext == 2 && b->filled) {                      // weighted matrix lives in the dense arena
+        HIPCK(hipMemcpy(scoremat, b->ctx.mat64 + J.mat64_off, nn * 8, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// ---- stem-level pseudoknot levels (== PairsToDBN(returnlevels) on the stems' bps) -----------
+static inline bool stems_cross(const HStem &a, const HStem &b)
+{
+    return (a.i < b.i && b.i < a.j && a.j < b.j) || (b.i < a.i && a.i < b.j && b.j < a.j);   // SQRNdbnseq.py:114-116
+}
+
+void sq_stem_levels(const std::vector<HStem> &stems, std::vector<int> &level)
+{
+    const int T = (int)stems.size();
+    level.assign(T, 1);
+    if (T < 2) return;
+    std::vector<int> cc(T, 0);
+    bool any = false;
+    for (int a = 0; a < T; a++)
+        for (int b = 0; b < T; b++)
+            if (a != b && stems_cross(stems[a], stems[b])) { cc[a] += stems[b].len; any = true; }
+    if (!any) return;                                       // one group holds everything
+    std::vector<int> order(T);
+    for (int a = 0; a < T; a++) order[a] = a;
+    std::sort(order.begin(), order.end(), [&](int a, int b) {   // :125 key (cross_count, p[0])
+        if (cc[a] != cc[b]) return cc[a] < cc[b];
+        return stems[a].i < stems[b].i;
+    });
+    std::vector<int> grp(T, -1), gsize;
+    for (int t = 0; t < T; t++) {                           // :130-136 first fit
+        const int p = order[t];
+        int placed = -1;
+        for (int g = 0; g < (int)gsize.size() && placed < 0; g++) {
+            bool ok = true;
+            for (int u = 0; u < t && ok; u++)
+                if (grp[order[u]] == g && stems_cross(stems[p], stems[order[u]])) ok = false;
+            if (ok) placed = g;
+        }
+        if (placed < 0) { placed = (int)gsize.size(); gsize.push_back(0); }
+        grp[p] = placed; gsize[placed] += stems[p].len;
+    }
+    std::vector<int> gord(gsize.size());
+    for (size_t g = 0; g < gsize.size(); g++) gord[g] = (int)g;
+    std::stable_sort(gord.begin(), gord.end(), [&](int a, int b) { return gsize[a] > gsize[b]; });   // :139
+    std::vector<int> rank(gsize.size());
+    for (size_t r = 0; r < gord.size(); r++) rank[gord[r]] = (int)r;
+    for (int a = 0; a < T; a++) level[a] = rank[grp[a]] + 1;
+}
+
+// ---- round driver ---------------------------------------------------------------------------
+static inline bool shares_base(const HStem &a, const HStem &b)       // SQRNdbnseq.py:783-786
+{
+    const int as0 = a.i, as1 = a.i + a.len - 1, at0 = a.j - a.len + 1, at1 = a.j;
+    const int bs0 = b.i, bs1 = b.i + b.len - 1, bt0 = b.j - b.len + 1, bt1 = b.j;
+    auto ov = [](int x0, int x1, int y0, int y1) { return x0 <= y1 && y0 <= x1; };
+    return ov(as0, as1, bs0, bs1) || ov(as0, as1, bt0, bt1) || ov(at0, at1, bs0, bs1) || ov(at0, at1, bt0, bt1);
+}
+
+static int run_chunk(sq_batch *b, const std::vector<HStruct> &structs, size_t lo, size_t hi, int mode,
+                     std::vector<std::vector<HStem>> &out)
+{
+    const int S = (int)(hi - lo);
+    int nstrand = 0, maxn = 0; int64_t cand_off = 0; double scan_bytes = 0;
+    std::vector<int> level;
+    for (int s = 0; s < S; s++) {
+        const HStruct &hs = structs[lo + s];
+        const SqJob &J = b->jobs[hs.job];
+        SqStruct &d = b->h_structs[s];
+        d.job = hs.job; d.slot = s; d.subopt = hs.subopt; d.cand_off = cand_off;
+        cand_off += J.cand_cap;
+        d.strand_off = nstrand; d.nstrand = 2 * (int)hs.stems.size();
+        sq_stem_levels(hs.stems, level);
+        SqStrand *sd = b->h_strands + nstrand;
+        for (size_t k = 0; k < hs.stems.size(); k++) {
+            const HStem &st = hs.stems[k];
+            const uint8_t lv = (uint8_t)std::min(level[k], 255);
+            sd[2 * k] = SqStrand{(int16_t)st.i, (int16_t)st.len, (int16_t)st.j, lv, 1};
+            sd[2 * k + 1] = SqStrand{(int16_t)(st.j - st.len + 1), (int16_t)st.len, (int16_t)(st.i + st.len - 1), lv, 0};
+        }
+        std::sort(sd, sd + d.nstrand, [](const SqStrand &x, const SqStrand &y) { return x.start < y.start; });
+        nstrand += d.nstrand;
+        maxn = std::max(maxn, J.n);
+        scan_bytes += 2.0 * J.n * J.n;                     // algorithmic: fp32 upper triangle, N^2/2 cells
+    }
+    hipStream_t st = b->stream;
+    HIPCK(hipMemcpyAsync(b->d_structs, b->h_structs, sizeof(SqStruct) * S, hipMemcpyHostToDevice, st));
+    if (nstrand) HIPCK(hipMemcpyAsync(b->d_strands, b->h_strands, sizeof(SqStrand) * nstrand, hipMemcpyHostToDevice, st));
+    HIPCK(hipMemsetAsync(b->scan.cand_cnt, 0, 4 * (size_t)S, st));
+    HIPCK(hipMemsetAsync(b->scan.ctr, 0, sizeof(SqCounters), st));
+    {
+        ProfScope ps(b, 1, 0);
+        hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(256), 0, st, b->ctx, b->d_structs, b->d_strands, b->state);
+    }
+    if (maxn >= 5) {
+        const int nband = (2 * maxn - 5 + 255) >> 8;
+        const int nseg = ((maxn >> 1) + 130 + 63) / 64;
+        const int nsg = (nseg + 3) >> 2;
+        ProfScope ps(b, 2, scan_bytes);
+        hipLaunchKernelGGL(sq_scan_kernel, dim3(S, nband * nsg), dim3(256), (size_t)2 * maxn + 64, st, b->ctx,
+                           b->d_structs, b->state, b->scan);
+    }
+    {
+        ProfScope ps(b, 3, 0);
+        hipLaunchKernelGGL(sq_score_kernel, dim3(S), dim3(256), 0, st, b->ctx, b->d_structs, b->d_strands, b->state,
+                           b->scan, b->d_out, b->out_cap, mode);
+    }
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(b->h_ctr, b->scan.ctr, sizeof(SqCounters), hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    const SqCounters ctr = *b->h_ctr;
+    if (ctr.cand_ovf) { sq_set_error("candidate capacity exceeded (raise cand_per_nt)"); return -3; }
+    if (ctr.out_ovf) { sq_set_error("round output capacity exceeded (lower max_structs)"); return -3; }
+    if (ctr.level_ovf) { sq_set_error("more than 64 pseudoknot levels"); return -3; }
+    const uint32_t nout = ctr.nout;
+    const SqOut *ho = b->h_out;
+    if (nout) {
+        if (nout <= b->h_out_cap) {
+            HIPCK(hipMemcpyAsync(b->h_out, b->d_out, sizeof(SqOut) * (size_t)nout, hipMemcpyDeviceToHost, st));
+            HIPCK(hipStreamSynchronize(st));
+        } else {
+            b->big_out.resize(nout);
+            HIPCK(hipMemcpy(b->big_out.data(), b->d_out, sizeof(SqOut) * (size_t)nout, hipMemcpyDeviceToHost));
+            ho = b->big_out.data();
+        }
+    }
+    // bucket by structure
+    std::vector<uint32_t> cnt(S + 1, 0);
+    for (uint32_t k = 0; k < nout; k++) cnt[ho[k].st + 1]++;
+    for (int s = 0; s < S; s++) cnt[s + 1] += cnt[s];
+    std::vector<uint32_t> idx(nout), fillp(cnt.begin(), cnt.end() - 1);
+    for (uint32_t k = 0; k < nout; k++) idx[fillp[ho[k].st]++] = k;
+    for (int s = 0; s < S; s++) {
+        uint32_t *p0 = idx.data() + cnt[s], *p1 = idx.data() + cnt[s + 1];
+        std::vector<HStem> &res = out[lo + s];
+        res.clear();
+        if (p0 == p1) continue;
+        auto mk = [&](uint32_t k) {
+            const SqOut &o = ho[k];
+            const int i0 = (int)(o.key & 0xFFFFu), sdiag = (int)(o.key >> 16);
+            return HStem{i0, sdiag - i0, o.len, o.bps, o.fin};
+        };
+        if (mode == 1) {                                    // emission order: (s, i) ascending
+            std::sort(p0, p1, [&](uint32_t x, uint32_t y) { return ho[x].key < ho[y].key; });
+            for (uint32_t *p = p0; p < p1; p++) res.push_back(mk(*p));
+            continue;
+        }
+        // ChooseStems (SQRNdbnseq.py:754-789): stable descending sort == (fin desc, emission key asc)
+        std::sort(p0, p1, [&](uint32_t x, uint32_t y) {
+            if (ho[x].fin != ho[y].fin) return ho[x].fin > ho[y].fin;
+            return ho[x].key < ho[y].key;
+        });
+        res.push_back(mk(*p0));
+        for (uint32_t *p = p0 + 1; p < p1; p++) {           // range filter already applied on device (:778)
+            const HStem cand = mk(*p);
+            bool all_conf = true;
+            for (const HStem &r : res) if (!shares_base(cand, r)) { all_conf = false; break; }
+            if (all_conf) res.push_back(cand);
+        }
+    }
+    return 0;
+}
+
+int sq_run_round(sq_batch *b, const std::vector<HStruct> &structs, int mode, std::vector<std::vector<HStem>> &out)
+{
+    if (!b->filled) { int r = sq_bpmatrix_fill(b); if (r) return r; }
+    out.resize(structs.size());
+    size_t lo = 0;
+    while (lo < structs.size()) {
+        size_t hi = lo; int64_t cands = 0, strands = 0;
+        while (hi < structs.size() && (int)(hi - lo) < b->max_structs) {
+            const SqJob &J = b->jobs[structs[hi].job];
+            const int64_t ns = 2 * (int64_t)structs[hi].stems.size();
+            if (hi > lo && (cands + J.cand_cap > b->cand_records || strands + ns > b->strand_cap)) break;
+            cands += J.cand_cap; strands += ns; hi++;
+        }
+        if (cands > b->cand_records || strands > b->strand_cap) { sq_set_error("structure does not fit the round buffers"); return -3; }
+        int r = run_chunk(b, structs, lo, hi, mode, out);
+        if (r) return r;
+        lo = hi;
+    }
+    return 0;
+}
+
+// ---- a-2..a-6 C ABI ---------------------------------------------------------------------------
+extern "C" int sq_optimal_stems(sq_batch *b, int32_t nstruct, const int32_t *struct_job, const int32_t *stem_off,
+                                const sq_stem *stems, const double *subopt, int32_t mode,
+                                sq_stem *out, int32_t out_cap, int32_t *out_off)
+{
+    if (!b || nstruct < 0 || (mode != 0 && mode != 1)) { sq_set_error("bad argument"); return -1; }
+    std::vector<HStruct> hs(nstruct);
+    for (int s = 0; s < nstruct; s++) {
+        if (struct_job[s] < 0 || struct_job[s] >= b->njobs) { sq_set_error("bad job index"); return -1; }
+        hs[s].job = struct_job[s];
+        hs[s].subopt = subopt ? subopt[s] : 1.0;
+        const int n = b->jobs[hs[s].job].n;
+        for (int k = stem_off[s]; k < stem_off[s + 1]; k++) {
+            const sq_stem &t = stems[k];
+            if (t.len < 1 || t.i < 0 || t.j >= n || t.i + t.len - 1 >= t.j - t.len + 1) { sq_set_error("bad stem"); return -1; }
+            hs[s].stems.push_back(HStem{t.i, t.j, t.len, t.bpscore, t.finscore});
+        }
+    }
+    std::vector<std::vector<HStem>> res;
+    int r = sq_run_round(b, hs, mode, res);
+    if (r) return r;
+    int32_t o = 0;
+    for (int s = 0; s < nstruct; s++) {
+        out_off[s] = o;
+        for (const HStem &t : res[s]) {
+            if (o >= out_cap) { sq_set_error("out_cap too small"); return -3; }
+            out[o++] = sq_stem{t.i, t.j, t.len, 0, t.bps, t.fin};
+        }
+    }
+    out_off[nstruct] = o;
+    return 0;
+}
+
+// ---- a-7: greedy pool loop for every job at once (SQRNdbnseq.py:1102-1199) ----------------------
+namespace {
+struct JobPool {
+    std::vector<std::vector<HStem>> cur;     // curstemsets
+    std::vector<std::vector<HStem>> fin;     // finstemsets (greedy part)
+    double cursubopt = 0, suboptinc = 0, suboptmax = 0, maxstemnum = 0;
+    size_t cursize = 1;
+    int64_t evals = 0;
+};
+}  // namespace
+
+extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref_off, const int32_t *ref_pairs,
+                       const uint8_t *has_ref)
+{
+    if (!b || !opts) { sq_set_error("bad argument"); return -1; }
+    const sq_fold_opts &o = *opts;
+    if (o.poollim < 1) { sq_set_error("poollim must be positive"); return -1; }
+    int r = sq_bpmatrix_fill(b);                            // a-1, once per job (:1076)
+    if (r) return r;
+    std::vector<JobPool> pools(b->njobs);
+    std::vector<uint32_t> algos(b->njobs);
+    for (int j = 0; j < b->njobs; j++) {
+        const sq_paramset &ps = b->psets[b->job_pset[j]];
+        algos[j] = o.algos ? o.algos : ps.algorithms;       // :1065-1066
+        if (algos[j] & ~(uint32_t)SQ_ALGO_G) {
+            sq_set_error("algorithms N/H/E are not available in this build of libsquarna_hip");
+            return -4;
+        }
+        JobPool &P = pools[j];
+        P.cursubopt = ps.suboptmin;                         // :1069
+        P.suboptinc = (ps.suboptmax - ps.suboptmin) / ps.suboptsteps;   // :1071
+        P.suboptmax = ps.suboptmax; P.maxstemnum = ps.maxstemnum;
+        if (algos[j] & SQ_ALGO_G) P.cur.emplace_back();     // :1105 one empty structure
+    }
+    std::vector<HStruct> round;
+    std::vector<std::pair<int, int>> owner;                 // (job, index in cur)
+    std::vector<std::vector<HStem>> res;
+    for (;;) {
+        round.clear(); owner.clear();
+        for (int j = 0; j < b->njobs; j++) {
+            JobPool &P = pools[j];
+            if (P.cur.empty()) continue;
+            if (P.cur.size() > P.cursize) {                 // :1162-1165
+                P.cursize = P.cur.size();
+                if (P.cursubopt < P.suboptmax) P.cursubopt += P.suboptinc;
+            }
+            std::vector<std::vector<HStem>> keep;           // :1168-1174
+            for (auto &s : P.cur) {
+                if ((double)s.size() == P.maxstemnum) P.fin.push_back(std::move(s));
+                else keep.push_back(std::move(s));
+            }
+            P.cur.swap(keep);
+            for (size_t k = 0; k < P.cur.size(); k++) {
+                round.push_back(HStruct{j, P.cursubopt, P.cur[k]});
+                owner.emplace_back(j, (int)k);
+            }
+            P.evals += (int64_t)P.cur.size();
+        }
+        if (round.empty()) break;
+        r = sq_run_round(b, round, 0, res);
+        if (r) return r;
+        std::vector<std::vector<std::vector<HStem>>> next(b->njobs);
+        for (size_t q = 0; q < round.size(); q++) {         // :1179-1196, in order
+            const int j = owner[q].first;
+            JobPool &P = pools[j];
+            const std::vector<HStem> &news = res[q];
+            if (!news.empty()) {
+                const size_t stopper = P.cursize >= (size_t)o.poollim ? 1 : news.size();
+                for (size_t k = 0; k < stopper; k++) {
+                    std::vector<HStem> child = round[q].stems;
+                    child.push_back(news[k]);
+                    next[j].push_back(std::move(child));
+                }
+            } else {
+                P.fin.push_back(round[q].stems);
+            }
+        }
+        for (int j = 0; j < b->njobs; j++) pools[j].cur.swap(next[j]);
+    }
+    // a-10 tail per sequence
+    std::vector<std::vector<int32_t>> seq_jobs(b->nseq);
+    for (int j = 0; j < b->njobs; j++) seq_jobs[b->job_seq[j]].push_back(j);
+    for (int s = 0; s < b->nseq; s++) {
+        std::vector<std::vector<std::vector<HStem>>> per_job;
+        int64_t ev = 0;
+        for (int j : seq_jobs[s]) { per_job.push_back(std::move(pools[j].fin)); ev += pools[j].evals; }
+        const bool hr = has_ref && has_ref[s];
+        const int32_t *rp = hr ? ref_pairs + 2 * (size_t)ref_off[s] : nullptr;
+        const int nref = hr ? ref_off[s + 1] - ref_off[s] : 0;
+        b->results[s] = SeqResult();
+        sq_tail(b, s, o, per_job, seq_jobs[s], rp, nref, hr, b->results[s]);
+        b->results[s].evals = ev;
+    }
+    return 0;
+}
+
+// ---- result getters ------------------------------------------------------------------------------
+extern "C" int32_t sq_result_nstruct(const sq_batch *b, int32_t seq)
+{
+    if (!b || seq < 0 || seq >= b->nseq) return -1;
+    return (int32_t)b->results[seq].preds.size();
+}
+extern "C" int sq_result_consensus(const sq_batch *b, int32_t seq, int16_t *levels)
+{
+    if (!b || seq < 0 || seq >= b->nseq) return -1;
+    const auto &c = b->results[seq].cons;
+    memcpy(levels, c.data(), c.size() * sizeof(int16_t));
+    return 0;
+}
+extern "C" int sq_result_struct(const sq_batch *b, int32_t seq, int32_t k, int16_t *levels, double scores[3],
+                                uint64_t *pset_mask)
+{
+    if (!b || seq < 0 || seq >= b->nseq) return -1;
+    const auto &R = b->results[seq];
+    if (k < 0 || k >= (int)R.preds.size()) return -1;
+    memcpy(levels, R.preds[k].levels.data(), R.preds[k].levels.size() * sizeof(int16_t));
+    for (int t = 0; t < 3; t++) scores[t] = R.preds[k].scores[t];
+    *pset_mask = R.preds[k].pset_mask;
+    return 0;
+}
+extern "C" int sq_result_metrics(const sq_batch *b, int32_t seq, double cons[6], double best[7])
+{
+    if (!b || seq < 0 || seq >= b->nseq) return -1;
+    const auto &R = b->results[seq];
+    if (!R.has_ref) return 1;
+    for (int t = 0; t < 6; t++) cons[t] = R.cons_metrics[t];
+    for (int t = 0; t < 7; t++) best[t] = R.best_metrics[t];
+    return 0;
+}
+extern "C" int64_t sq_result_evals(const sq_batch *b, int32_t seq)
+{
+    if (!b || seq < 0 || seq >= b->nseq) return -1;
+    return b->results[seq].evals;
+}
+
+extern "C" int64_t sq_result_pack_size(const sq_batch *b, int32_t seq)
+{
+    if (!b || seq < 0 || seq >= b->nseq) return -1;
+    const auto &R = b->results[seq];
+    const int64_t ns = (int64_t)R.preds.size(), n = (int64_t)R.cons.size();
+    return 8 * 4 + 8 * 13 + 8 * 3 * ns + 8 * ns + 2 * (1 + ns) * n;
+}
+extern "C" int sq_result_pack(const sq_batch *b, int32_t seq, void *buf, int64_t cap)
+{
+    const int64_t need = sq_result_pack_size(b, seq);
+    if (need < 0 || cap < need) { sq_set_error("result buffer too small"); return -1; }
+    const auto &R = b->results[seq];
+    const int64_t ns = (int64_t)R.preds.size(), n = (int64_t)R.cons.size();
+    char *p = (char *)buf;
+    int64_t hdr[4] = {ns, n, R.has_ref ? 1 : 0, R.evals};
+    memcpy(p, hdr, 32); p += 32;
+    double met[13];
+    for (int t = 0; t < 6; t++) met[t] = R.has_ref ? R.cons_metrics[t] : NAN;
+    for (int t = 0; t < 7; t++) met[6 + t] = R.has_ref ? R.best_metrics[t] : NAN;
+    memcpy(p, met, 104); p += 104;
+    for (int64_t k = 0; k < ns; k++) { memcpy(p, R.preds[k].scores, 24); p += 24; }
+    for (int64_t k = 0; k < ns; k++) { memcpy(p, &R.preds[k].pset_mask, 8); p += 8; }
+    memcpy(p, R.cons.data(), 2 * n); p += 2 * n;
+    for (int64_t k = 0; k < ns; k++) { memcpy(p, R.preds[k].levels.data(), 2 * n); p += 2 * n; }
+    return 0;
+}

@@ -1,0 +1,80 @@
+// sq_internal.h -- device-visible records shared by the host driver and the kernels.
+#pragma once
+#include <stdint.h>
+
+#define SQ_SENT_BITS 0x7FC00000u  // quiet NaN in the fp32 scan matrix == "bpboolmatrix cell is 0"
+#define SQ_MAXLEVELS 64           // pseudoknot levels tracked in a 64-bit set
+
+// One (sequence, paramset) fold job.
+struct SqJob {
+    int32_t n;          // gap-free sequence length
+    int32_t ld;         // row pitch (floats) of the scan matrix, ld % 32 == 1
+    int32_t seq;        // sequence index
+    int32_t pset;       // paramset index
+    int64_t pos_off;    // offset of the sequence in the per-position arrays
+    int64_t mat_off;    // offset (floats) of the scan matrix in the fp32 arena
+    int64_t mat64_off;  // offset (doubles) of the dense N x N exact matrix, -1: recompute from O(N) inputs
+    int32_t default_reacts;  // set(reacts) == {0.5}  (SQRNdbnseq.py:273)
+    int32_t interchainonly;
+    int32_t has_ext;    // scan matrix comes from caller matrices (ext_bool/ext_score) or mul_score
+    int32_t cand_cap;   // candidate capacity per structure of this job
+};
+
+// Device image of a paramset (+ host-built pow tables so every pow() is the host libm's).
+struct SqPsetDev {
+    double w[32 * 32];
+    uint8_t inbps[32 * 32];
+    double minlen, minbpscore, minfinscore;
+    double bracketweight, distcoef, orderpenalty, loopbonus;
+    double oftab[SQ_MAXLEVELS + 1];   // (1/(1+k))**orderpenalty   (SQRNdbnseq.py:729)
+    int32_t bw_integral;              // bracketweight is an integer -> stemdist index into sdftab
+    int32_t sdf_off, sdf_len;         // (1/(1+d))**distcoef table   (SQRNdbnseq.py:726)
+    int32_t pad;
+};
+
+// One strand (half of a selected stem) of a partial structure, sorted by start.
+struct SqStrand {
+    int16_t start;    // first position of the strand
+    int16_t len;
+    int16_t pstart;   // partner of `start`; partner(start+t) = pstart - t
+    uint8_t level;    // pseudoknot level (1-based) of the stem
+    uint8_t left;     // 1: 5' strand (start = i), 0: 3' strand
+};
+
+// One partial structure evaluated in a round.
+struct SqStruct {
+    int32_t job;
+    int32_t strand_off;   // into the round's strand array
+    int32_t nstrand;
+    int32_t slot;         // state / candidate slot
+    double subopt;
+    int64_t cand_off;     // into the candidate arena (records)
+};
+
+// Candidate stem emitted by the scan, completed by the scoring kernel.
+struct SqCand {
+    uint32_t key;     // (s << 16) | i_outer, s = i + j: the reference's emission order
+    uint32_t len;
+    float sum32;
+    uint32_t flags;   // bit0: passes exact bpscore + finscore thresholds
+    double bps;
+    double fin;
+};
+
+// Output record of a round (device -> host).
+struct SqOut {
+    int32_t st;       // structure index in the round
+    uint32_t key;
+    int32_t len;
+    int32_t pad;
+    double bps;
+    double fin;
+};
+
+// Round-level counters.
+struct SqCounters {
+    uint32_t nout;        // records appended to the out list
+    uint32_t cand_ovf;    // some structure exceeded its candidate capacity
+    uint32_t out_ovf;     // out list overflowed
+    uint32_t level_ovf;   // a level above SQ_MAXLEVELS was seen
+};

@@ -1,0 +1,250 @@
+// sq_tail.cpp -- host tail of SQRNdbnseq (a-10): structure dedupe, ScoreStruct, RankStructs,
+// consensus, pseudoknot bracket levels and the TP/FP/FN metrics.  SQRNdbnseq.py:861-955,1201-1286.
+// Plain host C++ (the reference does this part in Python; it is O(#structures * N)).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <set>
+#include <vector>
+#include "sq_host.h"
+
+typedef std::pair<int, int> BP;
+
+// Python round(x, 3): correctly rounded decimal, ties to even on the exact binary value.
+static double py_round3(double x)
+{
+    if (!std::isfinite(x)) return x;
+    char buf[512];
+    snprintf(buf, sizeof buf, "%.3f", x);
+    return strtod(buf, nullptr);
+}
+
+static inline bool crosses(const BP &p, const BP &q)                   // :114-116
+{
+    return (p.first < q.first && q.first < p.second && p.second < q.second) ||
+           (q.first < p.first && p.first < q.second && q.second < p.second);
+}
+
+// PairsToDBN level assignment (:119-150) for sorted unique pairs.  Returns #groups.
+int sq_pair_levels(const std::vector<BP> &pairs, std::vector<int> &level)
+{
+    const int np = (int)pairs.size();
+    level.assign(np, 0);
+    if (!np) return 0;
+    std::vector<int> cc(np, 0), order(np);
+    for (int a = 0; a < np; a++) {
+        for (int b = 0; b < np; b++)
+            if (a != b && crosses(pairs[a], pairs[b])) cc[a]++;
+        order[a] = a;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {  // :125
+        if (cc[a] != cc[b]) return cc[a] < cc[b];
+        return pairs[a].first < pairs[b].first;
+    });
+    std::vector<std::vector<int>> groups;
+    std::vector<int> grp(np);
+    for (int t = 0; t < np; t++) {                                     // :130-136
+        const int p = order[t];
+        int placed = -1;
+        for (size_t g = 0; g < groups.size() && placed < 0; g++) {
+            bool ok = true;
+            if (cc[p])
+                for (int q : groups[g]) if (crosses(pairs[p], pairs[q])) { ok = false; break; }
+            if (ok) placed = (int)g;
+        }
+        if (placed < 0) { placed = (int)groups.size(); groups.emplace_back(); }
+        groups[placed].push_back(p); grp[p] = placed;
+    }
+    std::vector<int> gord(groups.size());
+    for (size_t g = 0; g < groups.size(); g++) gord[g] = (int)g;
+    std::stable_sort(gord.begin(), gord.end(), [&](int a, int b) { return groups[a].size() > groups[b].size(); });  // :139
+    std::vector<int> rank(groups.size());
+    for (size_t r = 0; r < gord.size(); r++) rank[gord[r]] = (int)r;
+    for (int a = 0; a < np; a++) level[a] = rank[grp[a]] + 1;
+    return (int)groups.size();
+}
+
+static void levels_of(const std::set<BP> &bps, int n, int levellimit, std::vector<int16_t> &out)
+{
+    std::vector<BP> pairs(bps.begin(), bps.end());                    // sorted, unique, v < w
+    std::vector<int> lv;
+    sq_pair_levels(pairs, lv);
+    out.assign(n, 0);
+    for (size_t k = 0; k < pairs.size(); k++) {
+        if (levellimit >= 0 && lv[k] > levellimit) continue;           // :153-154
+        out[pairs[k].first] = (int16_t)lv[k];
+        out[pairs[k].second] = (int16_t)-lv[k];
+    }
+}
+
+namespace {
+struct Entry {
+    std::vector<HStem> stems;
+    std::set<BP> bps;
+    double scores[3];
+    uint64_t mask;
+};
+}  // namespace
+
+static void add_bps(const std::vector<HStem> &stems, std::set<BP> &out)
+{
+    for (const HStem &s : stems)
+        for (int k = 0; k < s.len; k++) out.insert(BP(s.i + k, s.j - k));
+}
+
+// ScoreStruct (:861-899)
+static void score_struct(const uint8_t *codes, const double *reacts, int n, const std::vector<HStem> &stems,
+                         double out[3])
+{
+    auto bpscore = [](int a, int b) -> double {
+        const int A = 0, C = 2, G = 6, U = 20;
+        if ((a == G && b == U) || (a == U && b == G)) return -0.5;
+        if ((a == A && b == U) || (a == U && b == A)) return 1.5;
+        if ((a == G && b == C) || (a == C && b == G)) return 4.0;
+        return 0.0;
+    };
+    double thescore = 0;
+    std::vector<char> paired(n, 0);
+    for (const HStem &s : stems) {
+        double bpsum = 0;
+        for (int k = 0; k < s.len; k++) {
+            const int v = s.i + k, w = s.j - k;
+            bpsum += bpscore(codes[v], codes[w]);
+            paired[v] = paired[w] = 1;
+        }
+        if (bpsum > 0) thescore += pow(bpsum, 1.7);                    // :884
+    }
+    int sepnum = 0;
+    double acc = 0;                                                    // :894-896 (sum() from int 0)
+    for (int i = 0; i < n; i++) {
+        if (codes[i] == SQ_CODE_SEP1 || codes[i] == SQ_CODE_SEP2) { sepnum++; continue; }
+        acc += paired[i] ? reacts[i] : 1 - reacts[i];
+    }
+    const double reactscore = 1 - acc / (n - sepnum);
+    out[0] = py_round3(thescore * reactscore);
+    out[1] = py_round3(thescore);
+    out[2] = py_round3(reactscore);
+}
+
+static void prf(const std::set<BP> &pred, const std::set<BP> &known, double m[6])   // :1252-1258
+{
+    int tp = 0;
+    for (const BP &p : pred) tp += known.count(p);
+    const int fp = (int)pred.size() - tp, fn = (int)known.size() - tp;
+    m[0] = tp; m[1] = fp; m[2] = fn;
+    m[3] = (2 * tp + fp + fn) ? py_round3(2.0 * tp / (2 * tp + fp + fn)) : 1;
+    m[4] = (tp + fp) ? py_round3((double)tp / (tp + fp)) : 1;
+    m[5] = (tp + fn) ? py_round3((double)tp / (tp + fn)) : 1;
+}
+
+void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
+             const std::vector<std::vector<std::vector<HStem>>> &per_job, const std::vector<int32_t> &job_ids,
+             const int32_t *ref_pairs, int nref, bool has_ref, SeqResult &res)
+{
+    const int off = b->seq_off[seq], n = b->seq_off[seq + 1] - off;
+    const uint8_t *codes = b->codes.data() + off;
+    const double *reacts = b->reacts.data() + off;
+
+    // :1201-1220 dedupe across paramsets; the first producer scores the structure
+    std::vector<Entry> fins;
+    std::map<std::vector<BP>, int> seen;
+    for (size_t k = 0; k < per_job.size(); k++) {
+        for (const auto &stems : per_job[k]) {
+            std::set<BP> bps;
+            add_bps(stems, bps);
+            std::vector<BP> key(bps.begin(), bps.end());
+            auto it = seen.find(key);
+            if (it == seen.end()) {
+                Entry e;
+                e.stems = stems; e.bps = std::move(bps); e.mask = 1ull << k;
+                score_struct(codes, reacts, n, stems, e.scores);
+                seen.emplace(std::move(key), (int)fins.size());
+                fins.push_back(std::move(e));
+            } else {
+                fins[it->second].mask |= 1ull << k;
+            }
+        }
+    }
+    // RankStructs (:902-955)
+    auto keyless = [&](const Entry &x, const Entry &y) {               // true when x sorts before y (descending)
+        for (int t = 0; t < 3; t++) {
+            const double a = x.scores[o.rankby[t]], c = y.scores[o.rankby[t]];
+            if (a != c) return a > c;
+        }
+        return false;
+    };
+    std::stable_sort(fins.begin(), fins.end(), keyless);               // :907-909
+    std::stable_partition(fins.begin(), fins.end(), [&](const Entry &e) { return (e.mask & o.priority_mask) != 0; });  // :912-913
+    if (o.rankbydiff && fins.size() >= 3) {                            // :917-955
+        std::set<BP> allbps, seenbps;
+        for (const Entry &e : fins) allbps.insert(e.bps.begin(), e.bps.end());
+        seenbps = fins[0].bps;
+        size_t cur = 1;
+        while (seenbps != allbps && cur < fins.size() - 1) {
+            std::vector<size_t> novel(fins.size(), 0);
+            std::stable_sort(fins.begin() + cur, fins.end(), [&](const Entry &x, const Entry &y) {
+                size_t nx = 0, ny = 0;
+                for (const BP &p : x.bps) nx += !seenbps.count(p);
+                for (const BP &p : y.bps) ny += !seenbps.count(p);
+                if (nx != ny) return nx > ny;
+                return keyless(x, y);
+            });
+            seenbps.insert(fins[cur].bps.begin(), fins[cur].bps.end());
+            cur++;
+        }
+        std::stable_sort(fins.begin() + cur, fins.end(), keyless);
+    }
+    // hardrest: restraint bps whose letters form an allowed pair of the LAST paramset (:1226-1228)
+    std::set<BP> forced;
+    if (o.hardrest && !job_ids.empty()) {
+        const sq_paramset &ps = b->psets[b->job_pset[job_ids.back()]];
+        for (int k = b->rbp_off[seq]; k < b->rbp_off[seq + 1]; k++) {
+            const int v = b->rbps[2 * k], w = b->rbps[2 * k + 1];
+            if (ps.inbps[codes[v] * 32 + codes[w]]) forced.insert(BP(v, w));
+        }
+    }
+    res.preds.clear();
+    for (const Entry &e : fins) {                                      // :1232-1234
+        SeqResult::Pred p;
+        std::set<BP> all = e.bps;
+        all.insert(forced.begin(), forced.end());
+        levels_of(all, n, -1, p.levels);
+        for (int t = 0; t < 3; t++) p.scores[t] = e.scores[t];
+        p.pset_mask = e.mask;
+        res.preds.push_back(std::move(p));
+    }
+    std::set<BP> cons;                                                 // :845-858,1236
+    const size_t top = std::min<size_t>(fins.size(), (size_t)std::max(o.conslim, 0));
+    if (top) {
+        cons = fins[0].bps;
+        for (size_t k = 1; k < top; k++) {
+            std::set<BP> nx;
+            for (const BP &p : cons) if (fins[k].bps.count(p)) nx.insert(p);
+            cons.swap(nx);
+        }
+    }
+    cons.insert(forced.begin(), forced.end());
+    levels_of(cons, n, -1, res.cons);
+    res.has_ref = has_ref;
+    if (has_ref) {                                                     // :1249-1285
+        std::set<BP> known;
+        for (int k = 0; k < nref; k++) known.insert(BP(ref_pairs[2 * k], ref_pairs[2 * k + 1]));
+        prf(cons, known, res.cons_metrics);
+        double best = -1;
+        for (int t = 0; t < 7; t++) res.best_metrics[t] = NAN;
+        for (size_t rank = 0; rank < fins.size(); rank++) {
+            std::set<BP> all = fins[rank].bps;
+            all.insert(forced.begin(), forced.end());
+            double m[6];
+            prf(all, known, m);
+            if (m[3] > best) {
+                best = m[3];
+                for (int t = 0; t < 6; t++) res.best_metrics[t] = m[t];
+                res.best_metrics[6] = (double)(rank + 1);
+            }
+            if ((int)rank + 1 >= o.toplim) break;
+        }
+    }
+}

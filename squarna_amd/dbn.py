@@ -1,0 +1,136 @@
+"""Pure helpers of the host layer (strings <-> pairs, reactivity pre-processing).
+
+Host-side mirror of the L0 helpers of the reference (SQRNdbnseq.py:12-255,370-376);
+they are O(N) string work that stays on the host by design.
+"""
+import math
+
+GAPS = {'-', '.', '~'}          # SQRNdbnseq.py:12
+SEPS = {';', '&'}               # SQRNdbnseq.py:14
+
+#: reactivity alphabet (SQRNdbnseq.py:17-30): 3-level, 10-level and 26-level encodings
+ReactDict = {"_": 0.00, "+": 0.50, "#": 1.00, "?": -999}
+ReactDict.update({str(d): float("0.%d5" % d) for d in range(10)})
+ReactDict.update({c: float("%.2f" % (0.04 * k)) for k, c in enumerate("abcdefghijklmnopqrstuvwxyz")})
+
+#: bracket alphabet for pseudoknot levels (SQRNdbnseq.py:108-112)
+BRACKETS = ['()', '[]', '{}', '<>'] + [c + c.lower() for c in "ABCDEFGHIJKLMNOPQRSTUVWXYZ"] + \
+           [c + c.lower() for c in "БГДЁЖЙЛПФЦЧШЩЬЫЪЭЮЯ"]
+_OPEN = {b[0]: b[1] for b in BRACKETS}
+_CLOSE = {b[1]: b[0] for b in BRACKETS}
+
+
+def ProcessReacts(reacts, missing_threshold=-10, middle=0.5, reverse=False, M=1.8, B=1.6):
+    """Normalise raw reactivities to [0,1] around the neutral point (SQRNdbnseq.py:32-59)."""
+    neutral = math.exp(-B / M) - 1
+    if reverse:
+        neutral, middle = middle, neutral
+    if not reacts:
+        return []
+    out = []
+    for x in reacts:
+        if x <= missing_threshold or x != x:        # missing value or NaN
+            x = neutral
+        else:
+            x = min(max(0, x), 1)
+        if x <= neutral:
+            out.append((middle / neutral) * x)
+        else:
+            out.append(middle + ((x - neutral) / (1 - neutral)) * (1 - middle))
+    return out
+
+
+def EncodedReactivities(seq, reacts, reactformat):
+    """Floats -> one character per position (SQRNdbnseq.py:82-101)."""
+    clipped = [x if 0 <= x <= 1 else 0 if x < 0 else 1 for x in reacts]
+    if reactformat == 3:
+        line = ["_+##"[int(x * 3)] for x in clipped]
+    elif reactformat == 10:
+        line = ['01234567899'[int(x * 10)] for x in clipped]
+    else:
+        line = ['abcdefghijklmnopqrstuvwxyz'[int(x * 25 + 0.5)] for x in clipped]
+    return ''.join(seq[i] if seq[i] in SEPS else line[i] for i in range(len(seq)))
+
+
+def DBNToPairs(dbn):
+    """Dot-bracket string -> sorted list of pairs; unmatched closers are ignored
+    (SQRNdbnseq.py:172-207)."""
+    stacks, pairs = {}, set()
+    for i, ch in enumerate(dbn):
+        if ch in _OPEN:
+            stacks.setdefault(ch, []).append(i)
+        elif ch in _CLOSE:
+            st = stacks.get(_CLOSE[ch])
+            if st:
+                pairs.add((st.pop(), i))
+    return sorted(pairs)
+
+
+def levels_to_dbn(levels):
+    """Signed per-position levels (+L open, -L close, 0 dot) -> dot-bracket string.
+    Levels beyond the alphabet print as dots (SQRNdbnseq.py:142-143)."""
+    nb = len(BRACKETS)
+    out = []
+    for v in levels:
+        if v == 0:
+            out.append('.')
+        elif v > 0:
+            out.append(BRACKETS[v - 1][0] if v <= nb else '.')
+        else:
+            out.append(BRACKETS[-v - 1][1] if -v <= nb else '.')
+    return ''.join(out)
+
+
+def UnAlign(seq, dbn):
+    """Drop gap columns; pairs touching a gap become dots first (SQRNdbnseq.py:236-255)."""
+    clean = list(dbn)
+    for v, w in DBNToPairs(dbn):
+        if seq[v] in GAPS or seq[w] in GAPS:
+            clean[v] = clean[w] = '.'
+    keep = [i for i in range(len(seq)) if seq[i] not in GAPS]
+    return ''.join(seq[i] for i in keep), ''.join(clean[i] for i in keep)
+
+
+def ReAlign(shortdbn, longseq, seqmode=False):
+    """Re-insert the gap columns of longseq into shortdbn (SQRNdbnseq.py:210-233)."""
+    assert len(shortdbn) + sum(longseq.count(g) for g in GAPS) == len(longseq), \
+        "Cannot ReAlign dbn string - wrong number of gaps:\n{}\n{}".format(longseq, shortdbn)
+    it = iter(shortdbn)
+    return ''.join(('-' if seqmode else '.') if ch in GAPS else next(it) for ch in longseq)
+
+
+def ParseRestraints(restraints):
+    """Restraint line -> (bps, unpaired, no-left, no-right) (SQRNdbnseq.py:370-376)."""
+    rbps = DBNToPairs(restraints)
+    rxs = {i for i, c in enumerate(restraints) if c in '_+'}
+    rlefts = {i for i, c in enumerate(restraints) if c == '/'}
+    rrights = {i for i, c in enumerate(restraints) if c == '\\'}
+    return rbps, rxs, rlefts, rrights
+
+
+def PairsToStems(sorted_pairs):
+    """Group consecutive stacked pairs into [[bps], len] records (SQRNdbnseq.py:498-517)."""
+    stems = []
+    for k, (v, w) in enumerate(sorted_pairs):
+        if k and sorted_pairs[k - 1][0] + 1 == v and sorted_pairs[k - 1][1] == w + 1:
+            stems[-1][0].append((v, w))
+            stems[-1][1] += 1
+        else:
+            stems.append([[(v, w)], 1])
+    return stems
+
+
+def encode_seq(seq):
+    """Letter codes of include/squarna_hip.h: 'A'..'Z' -> 0..25, ';' -> 26, '&' -> 27, other -> 28."""
+    out = bytearray(len(seq))
+    for i, ch in enumerate(seq):
+        o = ord(ch)
+        if 65 <= o <= 90:
+            out[i] = o - 65
+        elif ch == ';':
+            out[i] = 26
+        elif ch == '&':
+            out[i] = 27
+        else:
+            out[i] = 28
+    return bytes(out)

@@ -1,0 +1,360 @@
+"""HIP engine: batches sequences, owns the device workspace (a torch uint8 tensor) and
+drives libsquarna_hip.so through its C ABI.  PyTorch is plumbing here (device memory,
+stream, torch.distributed); all arithmetic runs in the hand-written gfx950 kernels.
+
+There is NO CPU fallback: without the built library or without a GPU the engine raises.
+Tests may install another engine with :func:`use_engine` (tests/ only use that to check
+the host-side text layer on CPU against the oracle).
+"""
+import ctypes as C
+import contextlib
+
+import numpy as np
+
+from . import _lib
+from .dbn import (GAPS, SEPS, ReactDict, ProcessReacts, DBNToPairs, UnAlign, ReAlign,
+                  ParseRestraints, levels_to_dbn, encode_seq)
+
+
+class Prepared:
+    """One input record after the host pre-processing of SQRNdbnseq.py:1001-1037."""
+    __slots__ = ("seq", "shortseq", "shortrest", "shortreacts", "shortdbn", "rbps", "rxs",
+                 "rlefts", "rrights", "gapidx")
+
+    def __init__(self, seq, reacts=None, restraints=None, dbn=None):
+        seq = seq.upper().replace("T", "U")                          # :1004
+        if not restraints:
+            restraints = '.' * len(seq)                              # :1007-1008
+        assert len(seq) == len(restraints), "Invalid restraints given"
+        if not reacts:
+            reacts = [0.5 for _ in range(len(seq))]                  # :1013-1014
+        assert len(reacts) == len(seq), "Invalid reactivities given"
+        if type(reacts) == str:                                      # :1019-1020 (default B = 1.6)
+            reacts = ProcessReacts([ReactDict[ch] for ch in reacts])
+        self.seq = seq
+        self.shortseq, self.shortrest = UnAlign(seq, restraints)     # :1023
+        self.gapidx = [i for i in range(len(seq)) if seq[i] in GAPS]
+        self.shortreacts = [reacts[i] for i in range(len(seq)) if seq[i] not in GAPS]
+        self.shortdbn = None
+        if dbn:
+            assert len(seq) == len(dbn)
+            self.shortseq, self.shortdbn = UnAlign(seq, dbn)         # :1026-1028
+        self.rbps, self.rxs, self.rlefts, self.rrights = ParseRestraints(self.shortrest)   # :1037
+
+
+def _pset_struct(ps):
+    out = _lib.ParamSet()
+    for key, val in ps["bpweights"].items():                         # SQRNdbnseq.py:282-284
+        a, b = encode_seq(key)
+        if a > 25 or b > 25:
+            raise ValueError("bpweights keys must be two letters: %r" % key)
+        out.bpweight[a * 32 + b] = val
+        out.inbps[a * 32 + b] = 1
+        out.bpweight[b * 32 + a] = val
+        out.inbps[b * 32 + a] = 1
+    out.bpp = float(ps.get("bpp", 0))
+    for k in ("suboptmax", "suboptmin", "suboptsteps", "minlen", "minbpscore", "minfinscorefactor",
+              "bracketweight", "distcoef", "orderpenalty", "loopbonus", "maxstemnum"):
+        setattr(out, k, float(ps[k]))
+    out.algorithms = sum(_lib.ALGO_BITS[a] for a in ps["algorithms"])
+    return out
+
+
+def _ptr(a, t=C.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+class Batch:
+    """A device-resident batch of fold jobs (one per (record, paramset))."""
+
+    def __init__(self, prepared, psets_per_record, interchainonly=False, ext=None, mul=None,
+                 max_structs=0, cand_per_nt=0, device=None):
+        import torch
+        L = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("squarna_amd needs an AMD GPU (MI355X / gfx950): torch.cuda is not "
+                               "available and there is no CPU fallback")
+        self.torch = torch
+        self.L = L
+        self.prepared = prepared
+        nseq = len(prepared)
+        self.seq_off = np.zeros(nseq + 1, np.int32)
+        for k, p in enumerate(prepared):
+            self.seq_off[k + 1] = self.seq_off[k] + len(p.shortseq)
+        ltot = int(self.seq_off[-1])
+        self.codes = np.frombuffer(b''.join(encode_seq(p.shortseq) for p in prepared), np.uint8).copy() \
+            if ltot else np.zeros(1, np.uint8)
+        self.flags = np.zeros(max(ltot, 1), np.uint8)
+        self.reacts = np.zeros(max(ltot, 1), np.float64)
+        rbp_off = [0]
+        rbps = []
+        for k, p in enumerate(prepared):
+            o = int(self.seq_off[k])
+            for i in p.rxs:
+                self.flags[o + i] |= 1
+            for i in p.rlefts:
+                self.flags[o + i] |= 2
+            for i in p.rrights:
+                self.flags[o + i] |= 4
+            self.reacts[o:o + len(p.shortseq)] = p.shortreacts
+            rbps.extend(p.rbps)
+            rbp_off.append(len(rbps))
+        self.rbp_off = np.array(rbp_off, np.int32)
+        self.rbps = np.array(rbps, np.int32).reshape(-1) if rbps else np.zeros(2, np.int32)
+        # unique paramsets by identity
+        uniq, self.psets_py = {}, []
+        job_seq, job_pset = [], []
+        self.seq_jobs = []
+        for k, plist in enumerate(psets_per_record):
+            mine = []
+            for ps in plist:
+                if id(ps) not in uniq:
+                    uniq[id(ps)] = len(self.psets_py)
+                    self.psets_py.append(ps)
+                mine.append(len(job_seq))
+                job_seq.append(k)
+                job_pset.append(uniq[id(ps)])
+            self.seq_jobs.append(mine)
+        self.psets_c = (_lib.ParamSet * len(self.psets_py))(*[_pset_struct(p) for p in self.psets_py])
+        self.job_seq = np.array(job_seq, np.int32)
+        self.job_pset = np.array(job_pset, np.int32)
+        njobs = len(job_seq)
+        d = _lib.BatchDesc()
+        d.nseq = nseq
+        d.seq_off = _ptr(self.seq_off, C.POINTER(C.c_int32))
+        d.codes = _ptr(self.codes, C.POINTER(C.c_uint8))
+        d.flags = _ptr(self.flags, C.POINTER(C.c_uint8))
+        d.reacts = _ptr(self.reacts, C.POINTER(C.c_double))
+        d.rbp_off = _ptr(self.rbp_off, C.POINTER(C.c_int32))
+        d.rbps = _ptr(self.rbps, C.POINTER(C.c_int32))
+        d.npset = len(self.psets_py)
+        d.psets = self.psets_c
+        d.njobs = njobs
+        d.job_seq = _ptr(self.job_seq, C.POINTER(C.c_int32))
+        d.job_pset = _ptr(self.job_pset, C.POINTER(C.c_int32))
+        self._keep = []
+
+        def ptr_array(mats):
+            arr = (C.c_void_p * njobs)()
+            for j, m in enumerate(mats):
+                if m is not None:
+                    m = np.ascontiguousarray(m, dtype=np.float64)
+                    self._keep.append(m)
+                    arr[j] = m.ctypes.data
+            return arr
+
+        if ext is not None:
+            self._eb = ptr_array([e[0] if e is not None else None for e in ext])
+            self._es = ptr_array([e[1] if e is not None else None for e in ext])
+            d.ext_bool = C.cast(self._eb, C.POINTER(C.c_void_p))
+            d.ext_score = C.cast(self._es, C.POINTER(C.c_void_p))
+        if mul is not None:
+            self._mul = ptr_array(mul)
+            d.mul_score = C.cast(self._mul, C.POINTER(C.c_void_p))
+        d.interchainonly = int(bool(interchainonly))
+        d.max_structs = int(max_structs)
+        d.cand_per_nt = int(cand_per_nt)
+        self.desc = d
+        nbytes = C.c_size_t(0)
+        _lib.check(L.sq_batch_workspace_bytes(C.byref(d), C.byref(nbytes)))
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
+        base = self.workspace.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        _lib.check(L.sq_batch_create(C.byref(h), C.byref(d), C.c_void_p(aligned),
+                                     C.c_size_t(nbytes.value), C.c_void_p(self.stream.cuda_stream)))
+        self.h = h
+        self.njobs = njobs
+        self.nseq = nseq
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sq_batch_destroy(self.h)
+            self.h = None
+            self.workspace = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- a-1
+    def fill(self):
+        _lib.check(self.L.sq_bpmatrix_fill(self.h))
+
+    def bpmatrix(self, job):
+        n = int(self.seq_off[self.job_seq[job] + 1] - self.seq_off[self.job_seq[job]])
+        b = np.zeros((n, n)); s = np.zeros((n, n))
+        _lib.check(self.L.sq_bpmatrix_read(self.h, job, _ptr(b), _ptr(s)))
+        return b, s
+
+    # -- a-2..a-6
+    def optimal(self, struct_job, struct_stems, subopt=None, mode=0, out_cap=None):
+        """struct_stems: list (per structure) of (i, j, len) tuples -> list of lists of
+        (i, j, len, bpscore, finalscore)."""
+        ns = len(struct_job)
+        sj = np.array(struct_job, np.int32)
+        off = np.zeros(ns + 1, np.int32)
+        flat = []
+        for k, st in enumerate(struct_stems):
+            flat.extend(st)
+            off[k + 1] = len(flat)
+        stems = (_lib.Stem * max(len(flat), 1))()
+        for k, t in enumerate(flat):
+            stems[k].i, stems[k].j, stems[k].len = int(t[0]), int(t[1]), int(t[2])
+        so = np.array(subopt if subopt is not None else [1.0] * ns, np.float64)
+        if out_cap is None:
+            out_cap = 1 << 16 if mode == 0 else 1 << 20
+        out = (_lib.Stem * out_cap)()
+        out_off = np.zeros(ns + 1, np.int32)
+        _lib.check(self.L.sq_optimal_stems(self.h, ns, _ptr(sj), _ptr(off), stems, _ptr(so), mode,
+                                           out, out_cap, _ptr(out_off)))
+        res = []
+        for k in range(ns):
+            res.append([(out[q].i, out[q].j, out[q].len, out[q].bpscore, out[q].finscore)
+                        for q in range(out_off[k], out_off[k + 1])])
+        return res
+
+    # -- a-7 + a-10
+    def fold(self, poollim=1000, conslim=1, toplim=5, hardrest=False, rankbydiff=False,
+             rankby=(0, 2, 1), levellimit=None, algos=frozenset(), priority=None):
+        """priority: per record, set of local paramset indices (or one set for all)."""
+        o = _lib.FoldOpts()
+        o.poollim, o.conslim, o.toplim = int(poollim), int(conslim), int(toplim)
+        o.hardrest, o.rankbydiff = int(bool(hardrest)), int(bool(rankbydiff))
+        for t in range(3):
+            o.rankby[t] = int(rankby[t])
+        o.levellimit = -1 if levellimit is None else int(levellimit)
+        o.algos = sum(_lib.ALGO_BITS[a] for a in algos)
+        mask = 0
+        for p in (priority or ()):
+            mask |= 1 << int(p)
+        o.priority_mask = mask
+        ref_off = np.zeros(self.nseq + 1, np.int32)
+        has = np.zeros(max(self.nseq, 1), np.uint8)
+        refs = []
+        for k, p in enumerate(self.prepared):
+            if p.shortdbn:
+                has[k] = 1
+                refs.extend(DBNToPairs(p.shortdbn))
+            ref_off[k + 1] = len(refs)
+        rp = np.array(refs, np.int32).reshape(-1) if refs else np.zeros(2, np.int32)
+        _lib.check(self.L.sq_fold(self.h, C.byref(o), _ptr(ref_off), _ptr(rp), _ptr(has)))
+
+    def result(self, k):
+        """SQRNdbnseq return tuple of record k (SQRNdbnseq.py:1285-1286)."""
+        L = self.L
+        nbytes = L.sq_result_pack_size(self.h, k)
+        buf = np.zeros(nbytes // 8 + 1, np.int64)
+        _lib.check(L.sq_result_pack(self.h, k, _ptr(buf), nbytes))
+        raw = buf.view(np.uint8)
+        ns, n, has_ref, evals = (int(x) for x in buf[:4])
+        met = raw[32:136].view(np.float64)
+        o = 136
+        scores = raw[o:o + 24 * ns].view(np.float64).reshape(ns, 3); o += 24 * ns
+        masks = raw[o:o + 8 * ns].view(np.uint64); o += 8 * ns
+        lev = raw[o:o + 2 * (ns + 1) * n].view(np.int16).reshape(ns + 1, n)
+        p = self.prepared[k]
+        seq = p.seq
+
+        def finish(levels):
+            s = ReAlign(levels_to_dbn(levels.tolist()), seq)                        # :1239-1240
+            return ''.join(s[i] if seq[i] not in SEPS else seq[i] for i in range(len(seq)))   # :1243-1246
+
+        cons = finish(lev[0])
+        preds = []
+        for t in range(ns):
+            m = int(masks[t])
+            preds.append((finish(lev[t + 1]), tuple(float(x) for x in scores[t]),
+                          [q for q in range(64) if (m >> q) & 1]))
+        if has_ref:
+            consres = _metrics(met[:6])
+            res = _metrics(met[6:12]) + [int(met[12])]
+            return cons, preds, consres, res
+        return cons, preds, [np.nan] * 6, [np.nan] * 7
+
+    def evals(self, k):
+        return int(self.L.sq_result_evals(self.h, k))
+
+    # -- measurement
+    def profile(self, on=True):
+        self.L.sq_profile_enable(self.h, int(on))
+
+    def profile_reset(self):
+        self.L.sq_profile_reset(self.h)
+
+    def profile_get(self, kernel):
+        ms, n, by = C.c_double(), C.c_int64(), C.c_double()
+        _lib.check(self.L.sq_profile_get(self.h, kernel, C.byref(ms), C.byref(n), C.byref(by)))
+        return ms.value, n.value, by.value
+
+
+def _metrics(m):
+    """[TP, FP, FN, FS, PR, RC] with the reference's int/float types: a ratio whose
+    denominator is empty is the int 1, everything else a rounded float
+    (SQRNdbnseq.py:1256-1258,1273-1275)."""
+    tp, fp, fn = int(m[0]), int(m[1]), int(m[2])
+    fs = float(m[3]) if 2 * tp + fp + fn else 1
+    pr = float(m[4]) if tp + fp else 1
+    rc = float(m[5]) if tp + fn else 1
+    return [tp, fp, fn, fs, pr, rc]
+
+
+class HipEngine:
+    """Default engine: everything on the GPU through libsquarna_hip.so."""
+    name = "hip"
+
+    def __init__(self, max_structs=0, cand_per_nt=0):
+        self.max_structs = max_structs
+        self.cand_per_nt = cand_per_nt
+
+    def fold_records(self, records, **opts):
+        """records: list of (seq, reacts, restraints, dbn, paramsets, stemmatrix);
+        returns the list of SQRNdbnseq return tuples, in order."""
+        interchainonly = opts.pop("interchainonly", False)
+        prepared = [Prepared(r[0], r[1], r[2], r[3]) for r in records]
+        psets = [r[4] for r in records]
+        mul = None
+        if any(len(r) > 5 and r[5] is not None for r in records):
+            mul = []
+            for r, p in zip(records, prepared):
+                sm = r[5] if len(r) > 5 else None
+                if sm is not None:                                   # :1031-1034
+                    sm = np.delete(np.delete(np.asarray(sm, dtype=np.float64), p.gapidx, 0), p.gapidx, 1)
+                mul.extend([sm] * len(r[4]))
+        with Batch(prepared, psets, interchainonly=interchainonly, mul=mul,
+                   max_structs=self.max_structs, cand_per_nt=self.cand_per_nt) as b:
+            b.fold(**opts)
+            return [b.result(k) for k in range(len(records))]
+
+
+_engine = None
+
+
+def get_engine():
+    global _engine
+    if _engine is None:
+        _engine = HipEngine()
+    return _engine
+
+
+@contextlib.contextmanager
+def use_engine(engine):
+    """Temporarily install another engine (tests only)."""
+    global _engine
+    old = _engine
+    _engine = engine
+    try:
+        yield engine
+    finally:
+        _engine = old

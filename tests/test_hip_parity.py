@@ -1,0 +1,186 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference's golden vectors
+and against the CPU oracle on seeded random inputs.
+
+Bars (north_star): stem indices bit-identical; float stem scores within 1e-5
+(in practice exact: decisions are taken in fp64 in the reference's operation order).
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-5
+
+
+def load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def conf(name):
+    from squarna_amd.config import ParseConfig, builtin_config
+    return ParseConfig(builtin_config(name))
+
+
+def mk_pset(weights, minlen=2, minbpscore=4.5, **kw):
+    ps = dict(bpweights=weights, bpp=0, algorithms={"G"}, suboptmax=1.0, suboptmin=1.0, suboptsteps=1.0,
+              minlen=minlen, minbpscore=minbpscore, minfinscorefactor=1.0, bracketweight=-2.0,
+              distcoef=0.09, orderpenalty=1.0, loopbonus=0.125, maxstemnum=1e6)
+    ps.update(kw)
+    return ps
+
+
+def prep(seq, reacts=None, restraints=None, dbn=None):
+    from squarna_amd.engine import Prepared
+    return Prepared(seq, reacts, restraints, dbn)
+
+
+def close_stems(got, exp, what=""):
+    assert len(got) == len(exp), (what, got, exp)
+    for g, e in zip(got, exp):
+        assert list(g[:3]) == list(e[:3]), (what, g, e)
+        for a, b in zip(g[3:], e[3:]):
+            assert abs(a - b) <= TOL * max(1.0, abs(b)), (what, g, e)
+
+
+def test_bpmatrix_golden():
+    from squarna_amd.engine import Batch
+    cases = load("bpmatrix.json")
+    # interchainonly is a batch-level switch: two batches
+    for ico in (False, True):
+        sel = [c for c in cases if bool(c["interchainonly"]) == ico]
+        preps = [prep(c["seq"], c["reacts"], c["restraints"]) for c in sel]
+        psets = [[mk_pset(c["weights"])] for c in sel]
+        with Batch(preps, psets, interchainonly=ico) as b:
+            b.fill()
+            for k, c in enumerate(sel):
+                bm, sm = b.bpmatrix(k)
+                got_b = [[int(i), int(j)] for i, j in zip(*np.nonzero(bm))]
+                assert got_b == c["bool"], c["seq"]
+                exp = np.zeros_like(sm)
+                for i, j, v in c["score"]:
+                    exp[i, j] = v
+                assert np.allclose(sm, exp, rtol=1e-12, atol=0), c["seq"]
+                nz = [[int(i), int(j)] for i, j in zip(*np.nonzero(sm))]
+                assert nz == [[i, j] for i, j, _ in c["score"]]
+
+
+def test_annotate_golden():
+    from squarna_amd.engine import Batch
+    cases = load("annotate.json")
+    preps = [prep(c["seq"], c["reacts"], c["restraints"]) for c in cases]
+    psets = [[mk_pset(c["weights"], c["minlen"], c["minscore"])] for c in cases]
+    with Batch(preps, psets) as b:
+        sj, ss, exp = [], [], []
+        for k, c in enumerate(cases):
+            for rnd in c["rounds"]:
+                sj.append(k)
+                ss.append([tuple(x) for x in rnd["rstems"]])
+                exp.append(rnd["stems"])
+        got = b.optimal(sj, ss, mode=1)
+        for g, e, k in zip(got, exp, sj):
+            close_stems([x[:4] for x in g], e, cases[k]["seq"])
+
+
+def test_optimalstems_trace_golden():
+    from squarna_amd.engine import Batch
+    ncalls = 0
+    for tr in load("optimal.json"):
+        names, psets = conf(tr["config"])
+        gsets = [p for p in psets if "G" in p["algorithms"]]
+        p = prep(tr["seq"], tr["reacts"], tr["restraints"])
+        with Batch([p], [gsets], interchainonly=tr["kw"].get("interchainonly", False)) as b:
+            sj = [c["g"] for c in tr["calls"]]
+            ss = [[tuple(x) for x in c["rstems"]] for c in tr["calls"]]
+            so = [c["subopt"] for c in tr["calls"]]
+            got = b.optimal(sj, ss, subopt=so, mode=0)
+            for g, c in zip(got, tr["calls"]):
+                close_stems(g, c["out"], (tr["tag"], tr["config"], c["rstems"]))
+                ncalls += 1
+    assert ncalls > 1000
+
+
+def _same_fold(got, exp, tag):
+    assert got[0] == exp[0], (tag, "consensus", got[0], exp[0])
+    assert len(got[1]) == len(exp[1]), (tag, len(got[1]), len(exp[1]))
+    for g, e in zip(got[1], exp[1]):
+        assert g[0] == e[0], (tag, g, e)
+        assert all(abs(a - b) <= TOL for a, b in zip(g[1], e[1])), (tag, g, e)
+        assert list(g[2]) == list(e[2]), (tag, g, e)
+    for g, e in zip(list(got[2]) + list(got[3]), list(exp[2]) + list(exp[3])):
+        if e == "nan":
+            assert g != g, tag
+        else:
+            assert abs(g - e) <= TOL, (tag, got[2], got[3], exp[2], exp[3])
+
+
+def test_fold_golden_greedy_configs():
+    from squarna_amd.engine import HipEngine
+    eng = HipEngine()
+    n = 0
+    for c in load("fold.json"):
+        names, psets = conf(c["config"])
+        if any(p["algorithms"] != {"G"} for p in psets):
+            continue
+        kw = dict(c["kw"])
+        if "rankby" in kw:
+            kw["rankby"] = tuple(kw["rankby"])
+        out = eng.fold_records([(c["seq"], c["reacts"], c["restraints"], c["reference"], psets, None)], **kw)[0]
+        _same_fold(out, c["out"], (c["tag"], c["config"]))
+        n += 1
+    assert n > 50
+
+
+def _rand_case(rng, n):
+    seq = "".join(rng.choice("ACGU") for _ in range(n))
+    kind = rng.randrange(4)
+    reacts = restr = None
+    if kind == 1:
+        from squarna_amd.dbn import ProcessReacts, ReactDict
+        reacts = ProcessReacts([ReactDict[rng.choice("_+#")] for _ in range(n)], M=1.8, B=-0.6)
+    if kind == 2:
+        restr = "".join(rng.choice("..........._/\\") for _ in range(n))
+    if kind == 3:
+        from squarna_amd.dbn import ProcessReacts
+        reacts = ProcessReacts([rng.random() * 1.4 - 0.2 for _ in range(n)], M=1.8, B=-0.6)
+    return seq, reacts, restr
+
+
+@pytest.mark.parametrize("cfg,sizes", [("greedynobpp", (40, 77, 150)), ("alt", (33, 90)),
+                                       ("fastest", (300, 513, 700))])
+def test_fold_vs_oracle_random(cfg, sizes):
+    """Seeded random inputs, sizes beyond the goldens, checked against the CPU oracle."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import HipEngine
+    names, psets = conf(cfg)
+    rng = random.Random({"greedynobpp": 101, "alt": 202, "fastest": 303}[cfg])
+    recs = []
+    for n in sizes:
+        for _ in range(3):
+            seq, reacts, restr = _rand_case(rng, n)
+            recs.append((seq, reacts, restr, None, psets, None))
+    got = HipEngine().fold_records(recs, poollim=100, rankby=(2, 0, 1))
+    for r, g in zip(recs, got):
+        exp = O.SQRNdbnseq(r[0], r[1], r[2], None, psets, poollim=100, rankby=(2, 0, 1))
+        exp = [exp[0], [[d, list(s), list(p)] for d, s, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(g, exp, (cfg, len(r[0])))
+
+
+def test_edge_cases():
+    """Empty-ish and degenerate inputs the reference handles (N < 5 has no diagonals)."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import HipEngine
+    names, psets = conf("greedynobpp")
+    recs = [(s, None, None, None, psets, None) for s in
+            ("A", "GC", "GGCC", "GGGCC", "AAAAAAAAAA", "GGGG;CCCC", "GC&GC", "GGGGAAAACCCC", "N" * 12,
+             "GGGGG-AAAA--CCCCC")]
+    got = HipEngine().fold_records(recs)
+    for r, g in zip(recs, got):
+        exp = O.SQRNdbnseq(r[0], None, None, None, psets)
+        exp = [exp[0], [[d, list(s), list(p)] for d, s, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(g, exp, r[0])
