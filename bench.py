@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X folding core.
+
+metric  : sequences/sec on SRtest150 (219 records, 8-150 nt, if=qf), whole job
+          (score-matrix fill + greedy stem loop + ranking tail), inputs resident in HBM
+step    : one fold of the whole workload batch on every GPU (weak scaling: each rank folds
+          its own copy of the batch; independent sequences, no data-path collective)
+roofline: the stem-scan kernel (sq_scan_kernel) on synthetic S1000 (random ACGU, N=1000,
+          c=fastest pl=1), algorithmic bytes 2*N^2 per AnnotateStems evaluation, timed with
+          HIP events on the kernel's own stream inside libsquarna_hip
+cpu_baseline: the CPU oracle (oracle/, a C port of the reference algorithm) on the same
+          workload, one process per host core
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 via torch.distributed.run.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def load_srtest150():
+    from squarna_amd.inputs import ParseDefaultInput
+    path = os.path.join(ROOT, "squarna_amd", "data", "datasets", "SRtest150.fas")
+    return list(ParseDefaultInput(path, "qf"))
+
+
+def _oracle_init(cfg):
+    global _O, _PSETS
+    sys.path.insert(0, ROOT)
+    from oracle import sqrn_oracle as O
+    from squarna_amd.config import ParseConfig, builtin_config
+    _O = O
+    _PSETS = ParseConfig(builtin_config(cfg))[1]
+    O.lib()
+
+
+def _oracle_one(rec):
+    """cpu_baseline worker task: fold one record with the CPU oracle."""
+    name, seq, reacts, restr, ref = rec
+    t0 = time.perf_counter()
+    _O.SQRNdbnseq(seq, reacts, restr, ref, _PSETS, poollim=1000)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(recs, cfg, target_s=12.0):
+    """Times the oracle on the GPU box's host cores (one process per core, records handed
+    out dynamically, longest first) on a bounded sample; must run BEFORE this process
+    touches the GPU (it spawns workers)."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    _oracle_init(cfg)
+    t1 = sum(_oracle_one(r) for r in recs[::8])            # calibrate on a slice
+    per_pass = t1 * 8
+    reps = int(min(max(1, target_s * cores / max(per_pass, 1e-9)), 200))
+    tasks = sorted(recs, key=lambda r: -len(r[1])) * reps
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(cores, initializer=_oracle_init, initargs=(cfg,)) as pool:
+        pool.map(_oracle_one, recs[:cores])               # warm the workers (imports, dlopen)
+        t0 = time.perf_counter()
+        busy = sum(pool.imap_unordered(_oracle_one, tasks, chunksize=4))
+        wall = time.perf_counter() - t0
+    return dict(value=round(len(tasks) / wall, 1), unit="seq/s", cores=cores, kind="port",
+                sample="SRtest150 (219 records) x %d passes, c=%s, C oracle (oracle/sqrn_oracle.c + Python tail), "
+                       "one process per core, wall %.2fs, summed worker time %.1fs" % (reps, cfg, wall, busy))
+
+
+def mean_fs(results):
+    fs_c = [r[2][3] for r in results]
+    fs_b = [r[3][3] for r in results]
+    return sum(fs_c) / len(fs_c), sum(fs_b) / len(fs_b)
+
+
+def roofline_leg(nseq, n, seed=1000):
+    """S1000: nseq random ACGU sequences of length n, c=fastest pl=1; returns the roofline
+    object of the stem-scan kernel measured with HIP events inside the library."""
+    import numpy as np
+    from squarna_amd.config import ParseConfig, builtin_config
+    from squarna_amd.engine import Batch, Prepared
+    names, psets = ParseConfig(builtin_config("fastest"))
+    rng = np.random.default_rng(seed)
+    seqs = ["".join(rng.choice(list("ACGU"), n)) for _ in range(nseq)]
+    prepared = [Prepared(s) for s in seqs]
+    with Batch(prepared, [psets] * nseq, max_structs=nseq) as b:
+        b.fold(poollim=1)                      # warm-up (also page-in)
+        b.profile(True)
+        b.profile_reset()
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        b.fold(poollim=1)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        ms, launches, alg_bytes = b.profile_get(2)
+        fms, flaunches, fbytes = b.profile_get(0)
+        sms, slaunches, _ = b.profile_get(1)
+        cms, claunches, _ = b.profile_get(3)
+        evals = sum(b.evals(k) for k in range(nseq))
+    achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("sq_scan_kernel_bytes_per_launch")
+    return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                kernel="sq_scan_kernel", workload="S1000: %d random-ACGU seqs N=%d seed %d c=fastest pl=1" % (nseq, n, seed),
+                launches=int(launches), avg_launch_ms=round(ms / max(launches, 1), 4),
+                alg_bytes_per_launch=round(alg_bytes / max(launches, 1)),
+                evals_R=int(evals), whole_fold_seq_per_s=round(nseq / wall, 1), whole_fold_ms=round(wall * 1e3, 2),
+                kernel_ms=dict(fill=round(fms, 3), state=round(sms, 3), scan=round(ms, 3), score=round(cms, 3)),
+                fill=dict(achieved=round(fbytes / (fms * 1e-3) / 1e9, 1) if fms > 0 else 0.0,
+                          unit="GB/s", launches=int(flaunches)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="greedynobpp")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the S1000 roofline leg")
+    ap.add_argument("--roofline-seqs", type=int, default=512)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    recs = load_srtest150()
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(recs, args.config)       # before any GPU initialisation
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from squarna_amd.config import ParseConfig, builtin_config
+    from squarna_amd.engine import Batch, Prepared
+    names, psets = ParseConfig(builtin_config(args.config))
+    prepared = [Prepared(seq, reacts, restr, ref) for _, seq, reacts, restr, ref in recs]
+    batch = Batch(prepared, [psets] * len(prepared))     # inputs now resident in HBM
+
+    def step():
+        batch.fold(poollim=1000)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    results = [batch.result(k) for k in range(len(prepared))]
+    fs_c, fs_b = mean_fs(results)
+    evals = sum(batch.evals(k) for k in range(len(prepared)))
+    batch.close()
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        roof = roofline_leg(args.roofline_seqs, 1000)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    total_seqs = len(prepared) * world * args.steps
+    line = {
+        "metric": "sequences/sec (SRtest150, single-sequence mode)",
+        "value": round(total_seqs / dt, 1),
+        "unit": "seq/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 scan matrix, f64 decisions",
+        "data": "SRtest150.fas shipped with the reference (219 records, 8-150 nt, reference dbn per record)",
+        "config": {"workload": "SRtest150 if=qf c=%s poollim=1000, one batch of 219 records per GPU" % args.config,
+                   "seqs_per_gpu_per_step": len(prepared), "paramsets": names,
+                   "evals_R_per_step": int(evals)},
+        "f1": {"mean_FS_consensus": round(fs_c, 4), "mean_FS_best_of_top5": round(fs_b, 4)},
+        "roofline": roof,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

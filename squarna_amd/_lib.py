@@ -18,8 +18,8 @@ SYMBOLS = ["sq_version", "sq_last_error", "sq_batch_workspace_bytes", "sq_batch_
            "sq_batch_destroy", "sq_bpmatrix_fill", "sq_bpmatrix_read", "sq_optimal_stems",
            "sq_fold", "sq_result_nstruct", "sq_result_consensus", "sq_result_struct",
            "sq_result_metrics", "sq_result_evals", "sq_result_pack_size", "sq_result_pack",
-           "sq_profile_enable", "sq_profile_get", "sq_profile_reset",
-           "sq_lsap", "sq_mwm", "sq_nussinov"]
+           "sq_profile_enable", "sq_profile_get", "sq_profile_reset"
+           ]
 
 
 class ParamSet(C.Structure):

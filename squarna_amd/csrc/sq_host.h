@@ -13,11 +13,25 @@ struct HStem {            // host stem record: bps (i+k, j-k), k < len
     double bps, fin;
 };
 
-struct HStruct {          // partial structure evaluated in a round
+struct HStruct {          // partial structure of the greedy pool
+    int32_t job = 0;
+    double subopt = 1.0;
+    std::vector<HStem> stems;
+    std::vector<SqStrand> strands;   // both halves of every stem, sorted by start, with levels
+    bool anycross = false;           // some pair of stems crosses (pseudoknot): levels need the full rule
+};
+
+// view of a structure handed to the round driver (no copies per round)
+struct SView {
     int32_t job;
     double subopt;
-    std::vector<HStem> stems;
+    const HStruct *st;
 };
+
+// (re)build strands + levels of a structure from its stems
+void sq_build_strands(HStruct &s);
+// child = parent + one stem, strands/levels maintained incrementally
+void sq_extend_struct(const HStruct &parent, const HStem &stem, HStruct &child);
 
 struct SeqResult {        // SQRNdbnseq return tuple of one sequence (SQRNdbnseq.py:1285-1286)
     struct Pred {
@@ -83,7 +97,7 @@ void sq_set_error(const std::string &msg);
 int sq_check(hipError_t e, const char *what);
 
 // one greedy round (or a raw AnnotateStems pass) for a list of structures; results per structure
-int sq_run_round(sq_batch *b, const std::vector<HStruct> &structs, int mode, std::vector<std::vector<HStem>> &out);
+int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out);
 
 // host tail: SQRNdbnseq.py:1201-1286
 void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,

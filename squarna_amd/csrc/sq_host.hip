@@ -2,14 +2,22 @@
 // round driver and the greedy pool loop (SQRNdbnseq.py:1102-1199).  Device memory is
 // the caller's workspace; the host only orchestrates (one small H2D + D2H per round).
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include "sq_host.h"
 
 static thread_local std::string g_err;
+
+// host phase timers (printed to stderr when SQ_TIMING is set)
+static double g_t[8];
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct TScope { int k; double t0; TScope(int k_) : k(k_), t0(now_s()) {} ~TScope() { g_t[k] += now_s() - t0; } };
 void sq_set_error(const std::string &msg) { g_err = msg; }
 int sq_check(hipError_t e, const char *what)
 {
@@ -394,6 +402,62 @@ void sq_stem_levels(const std::vector<HStem> &stems, std::vector<int> &level)
     for (int a = 0; a < T; a++) level[a] = rank[grp[a]] + 1;
 }
 
+static inline void set_levels(HStruct &s, const std::vector<int> &level)
+{
+    for (size_t k = 0; k < s.stems.size(); k++) {
+        const HStem &st = s.stems[k];
+        const uint8_t lv = (uint8_t)std::min(level[k], 255);
+        for (int half = 0; half < 2; half++) {
+            const int16_t start = (int16_t)(half == 0 ? st.i : st.j - st.len + 1);
+            auto it = std::lower_bound(s.strands.begin(), s.strands.end(), start,
+                                       [](const SqStrand &x, int16_t v) { return x.start < v; });
+            it->level = lv;
+        }
+    }
+}
+
+void sq_build_strands(HStruct &s)
+{
+    s.strands.clear();
+    s.anycross = false;
+    for (const HStem &st : s.stems) {
+        s.strands.push_back(SqStrand{(int16_t)st.i, (int16_t)st.len, (int16_t)st.j, 1, 1});
+        s.strands.push_back(SqStrand{(int16_t)(st.j - st.len + 1), (int16_t)st.len, (int16_t)(st.i + st.len - 1), 1, 0});
+    }
+    std::sort(s.strands.begin(), s.strands.end(), [](const SqStrand &x, const SqStrand &y) { return x.start < y.start; });
+    for (size_t a = 0; a < s.stems.size() && !s.anycross; a++)
+        for (size_t b = a + 1; b < s.stems.size(); b++)
+            if (stems_cross(s.stems[a], s.stems[b])) { s.anycross = true; break; }
+    if (s.anycross) {
+        std::vector<int> level;
+        sq_stem_levels(s.stems, level);
+        set_levels(s, level);
+    }
+}
+
+void sq_extend_struct(const HStruct &parent, const HStem &stem, HStruct &child)
+{
+    child.job = parent.job;
+    child.stems.reserve(parent.stems.size() + 1);
+    child.stems = parent.stems;
+    child.stems.push_back(stem);
+    child.strands.reserve(parent.strands.size() + 2);
+    child.strands = parent.strands;
+    const SqStrand l{(int16_t)stem.i, (int16_t)stem.len, (int16_t)stem.j, 1, 1};
+    const SqStrand r{(int16_t)(stem.j - stem.len + 1), (int16_t)stem.len, (int16_t)(stem.i + stem.len - 1), 1, 0};
+    auto cmp = [](const SqStrand &x, const SqStrand &y) { return x.start < y.start; };
+    child.strands.insert(std::upper_bound(child.strands.begin(), child.strands.end(), l, cmp), l);
+    child.strands.insert(std::upper_bound(child.strands.begin(), child.strands.end(), r, cmp), r);
+    child.anycross = parent.anycross;
+    if (!child.anycross)
+        for (const HStem &t : parent.stems) if (stems_cross(t, stem)) { child.anycross = true; break; }
+    if (child.anycross) {                                  // levels can change globally: full rule
+        std::vector<int> level;
+        sq_stem_levels(child.stems, level);
+        set_levels(child, level);
+    }
+}
+
 // ---- round driver ---------------------------------------------------------------------------
 static inline bool shares_base(const HStem &a, const HStem &b)       // SQRNdbnseq.py:783-786
 {
@@ -403,33 +467,26 @@ static inline bool shares_base(const HStem &a, const HStem &b)       // SQRNdbns
     return ov(as0, as1, bs0, bs1) || ov(as0, as1, bt0, bt1) || ov(at0, at1, bs0, bs1) || ov(at0, at1, bt0, bt1);
 }
 
-static int run_chunk(sq_batch *b, const std::vector<HStruct> &structs, size_t lo, size_t hi, int mode,
+static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, size_t hi, int mode,
                      std::vector<std::vector<HStem>> &out)
 {
     const int S = (int)(hi - lo);
     int nstrand = 0, maxn = 0; int64_t cand_off = 0; double scan_bytes = 0;
-    std::vector<int> level;
+    double tp0 = now_s();
     for (int s = 0; s < S; s++) {
-        const HStruct &hs = structs[lo + s];
+        const SView &hs = structs[lo + s];
         const SqJob &J = b->jobs[hs.job];
         SqStruct &d = b->h_structs[s];
         d.job = hs.job; d.slot = s; d.subopt = hs.subopt; d.cand_off = cand_off;
         cand_off += J.cand_cap;
-        d.strand_off = nstrand; d.nstrand = 2 * (int)hs.stems.size();
-        sq_stem_levels(hs.stems, level);
-        SqStrand *sd = b->h_strands + nstrand;
-        for (size_t k = 0; k < hs.stems.size(); k++) {
-            const HStem &st = hs.stems[k];
-            const uint8_t lv = (uint8_t)std::min(level[k], 255);
-            sd[2 * k] = SqStrand{(int16_t)st.i, (int16_t)st.len, (int16_t)st.j, lv, 1};
-            sd[2 * k + 1] = SqStrand{(int16_t)(st.j - st.len + 1), (int16_t)st.len, (int16_t)(st.i + st.len - 1), lv, 0};
-        }
-        std::sort(sd, sd + d.nstrand, [](const SqStrand &x, const SqStrand &y) { return x.start < y.start; });
+        d.strand_off = nstrand; d.nstrand = (int)hs.st->strands.size();
+        if (d.nstrand) memcpy(b->h_strands + nstrand, hs.st->strands.data(), sizeof(SqStrand) * (size_t)d.nstrand);
         nstrand += d.nstrand;
         maxn = std::max(maxn, J.n);
         scan_bytes += 2.0 * J.n * J.n;                     // algorithmic: fp32 upper triangle, N^2/2 cells
     }
     hipStream_t st = b->stream;
+    g_t[0] += now_s() - tp0; tp0 = now_s();
     HIPCK(hipMemcpyAsync(b->d_structs, b->h_structs, sizeof(SqStruct) * S, hipMemcpyHostToDevice, st));
     if (nstrand) HIPCK(hipMemcpyAsync(b->d_strands, b->h_strands, sizeof(SqStrand) * nstrand, hipMemcpyHostToDevice, st));
     HIPCK(hipMemsetAsync(b->scan.cand_cnt, 0, 4 * (size_t)S, st));
@@ -470,6 +527,8 @@ static int run_chunk(sq_batch *b, const std::vector<HStruct> &structs, size_t lo
             ho = b->big_out.data();
         }
     }
+    g_t[1] += now_s() - tp0;
+    TScope tpost(2);
     // bucket by structure
     std::vector<uint32_t> cnt(S + 1, 0);
     for (uint32_t k = 0; k < nout; k++) cnt[ho[k].st + 1]++;
@@ -507,7 +566,7 @@ static int run_chunk(sq_batch *b, const std::vector<HStruct> &structs, size_t lo
     return 0;
 }
 
-int sq_run_round(sq_batch *b, const std::vector<HStruct> &structs, int mode, std::vector<std::vector<HStem>> &out)
+int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out)
 {
     if (!b->filled) { int r = sq_bpmatrix_fill(b); if (r) return r; }
     out.resize(structs.size());
@@ -516,7 +575,7 @@ int sq_run_round(sq_batch *b, const std::vector<HStruct> &structs, int mode, std
         size_t hi = lo; int64_t cands = 0, strands = 0;
         while (hi < structs.size() && (int)(hi - lo) < b->max_structs) {
             const SqJob &J = b->jobs[structs[hi].job];
-            const int64_t ns = 2 * (int64_t)structs[hi].stems.size();
+            const int64_t ns = (int64_t)structs[hi].st->strands.size();
             if (hi > lo && (cands + J.cand_cap > b->cand_records || strands + ns > b->strand_cap)) break;
             cands += J.cand_cap; strands += ns; hi++;
         }
@@ -535,6 +594,7 @@ extern "C" int sq_optimal_stems(sq_batch *b, int32_t nstruct, const int32_t *str
 {
     if (!b || nstruct < 0 || (mode != 0 && mode != 1)) { sq_set_error("bad argument"); return -1; }
     std::vector<HStruct> hs(nstruct);
+    std::vector<SView> views(nstruct);
     for (int s = 0; s < nstruct; s++) {
         if (struct_job[s] < 0 || struct_job[s] >= b->njobs) { sq_set_error("bad job index"); return -1; }
         hs[s].job = struct_job[s];
@@ -545,9 +605,11 @@ extern "C" int sq_optimal_stems(sq_batch *b, int32_t nstruct, const int32_t *str
             if (t.len < 1 || t.i < 0 || t.j >= n || t.i + t.len - 1 >= t.j - t.len + 1) { sq_set_error("bad stem"); return -1; }
             hs[s].stems.push_back(HStem{t.i, t.j, t.len, t.bpscore, t.finscore});
         }
+        sq_build_strands(hs[s]);
+        views[s] = SView{hs[s].job, hs[s].subopt, &hs[s]};
     }
     std::vector<std::vector<HStem>> res;
-    int r = sq_run_round(b, hs, mode, res);
+    int r = sq_run_round(b, views, mode, res);
     if (r) return r;
     int32_t o = 0;
     for (int s = 0; s < nstruct; s++) {
@@ -564,7 +626,7 @@ extern "C" int sq_optimal_stems(sq_batch *b, int32_t nstruct, const int32_t *str
 // ---- a-7: greedy pool loop for every job at once (SQRNdbnseq.py:1102-1199) ----------------------
 namespace {
 struct JobPool {
-    std::vector<std::vector<HStem>> cur;     // curstemsets
+    std::vector<HStruct> cur;                // curstemsets
     std::vector<std::vector<HStem>> fin;     // finstemsets (greedy part)
     double cursubopt = 0, suboptinc = 0, suboptmax = 0, maxstemnum = 0;
     size_t cursize = 1;
@@ -593,11 +655,15 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         P.cursubopt = ps.suboptmin;                         // :1069
         P.suboptinc = (ps.suboptmax - ps.suboptmin) / ps.suboptsteps;   // :1071
         P.suboptmax = ps.suboptmax; P.maxstemnum = ps.maxstemnum;
-        if (algos[j] & SQ_ALGO_G) P.cur.emplace_back();     // :1105 one empty structure
+        if (algos[j] & SQ_ALGO_G) { P.cur.emplace_back(); P.cur.back().job = j; }   // :1105 one empty structure
     }
-    std::vector<HStruct> round;
-    std::vector<std::pair<int, int>> owner;                 // (job, index in cur)
+    std::vector<SView> round;
+    std::vector<int> owner;                                 // job of each view
     std::vector<std::vector<HStem>> res;
+    const double tfold0 = now_s();
+    double tround = 0;
+    for (int k = 0; k < 8; k++) g_t[k] = 0;
+    int nrounds = 0;
     for (;;) {
         round.clear(); owner.clear();
         for (int j = 0; j < b->njobs; j++) {
@@ -607,43 +673,49 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 P.cursize = P.cur.size();
                 if (P.cursubopt < P.suboptmax) P.cursubopt += P.suboptinc;
             }
-            std::vector<std::vector<HStem>> keep;           // :1168-1174
-            for (auto &s : P.cur) {
-                if ((double)s.size() == P.maxstemnum) P.fin.push_back(std::move(s));
-                else keep.push_back(std::move(s));
+            bool anyfull = false;                           // :1168-1174
+            for (auto &s : P.cur) if ((double)s.stems.size() == P.maxstemnum) { anyfull = true; break; }
+            if (anyfull) {
+                std::vector<HStruct> keep;
+                for (auto &s : P.cur) {
+                    if ((double)s.stems.size() == P.maxstemnum) P.fin.push_back(std::move(s.stems));
+                    else keep.push_back(std::move(s));
+                }
+                P.cur.swap(keep);
             }
-            P.cur.swap(keep);
             for (size_t k = 0; k < P.cur.size(); k++) {
-                round.push_back(HStruct{j, P.cursubopt, P.cur[k]});
-                owner.emplace_back(j, (int)k);
+                round.push_back(SView{j, P.cursubopt, &P.cur[k]});
+                owner.push_back(j);
             }
             P.evals += (int64_t)P.cur.size();
         }
         if (round.empty()) break;
-        r = sq_run_round(b, round, 0, res);
+        { const double t0 = now_s(); r = sq_run_round(b, round, 0, res); tround += now_s() - t0; nrounds++; }
         if (r) return r;
-        std::vector<std::vector<std::vector<HStem>>> next(b->njobs);
+        std::vector<std::vector<HStruct>> next(b->njobs);
         for (size_t q = 0; q < round.size(); q++) {         // :1179-1196, in order
-            const int j = owner[q].first;
+            const int j = owner[q];
             JobPool &P = pools[j];
             const std::vector<HStem> &news = res[q];
+            const HStruct &parent = *round[q].st;
             if (!news.empty()) {
                 const size_t stopper = P.cursize >= (size_t)o.poollim ? 1 : news.size();
                 for (size_t k = 0; k < stopper; k++) {
-                    std::vector<HStem> child = round[q].stems;
-                    child.push_back(news[k]);
-                    next[j].push_back(std::move(child));
+                    next[j].emplace_back();
+                    sq_extend_struct(parent, news[k], next[j].back());
                 }
             } else {
-                P.fin.push_back(round[q].stems);
+                P.fin.push_back(parent.stems);
             }
         }
         for (int j = 0; j < b->njobs; j++) pools[j].cur.swap(next[j]);
     }
+    const double tloop = now_s() - tfold0;
+    const double ttail0 = now_s();
     // a-10 tail per sequence
     std::vector<std::vector<int32_t>> seq_jobs(b->nseq);
     for (int j = 0; j < b->njobs; j++) seq_jobs[b->job_seq[j]].push_back(j);
-    for (int s = 0; s < b->nseq; s++) {
+    auto tail_one = [&](int s) {
         std::vector<std::vector<std::vector<HStem>>> per_job;
         int64_t ev = 0;
         for (int j : seq_jobs[s]) { per_job.push_back(std::move(pools[j].fin)); ev += pools[j].evals; }
@@ -653,7 +725,24 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         b->results[s] = SeqResult();
         sq_tail(b, s, o, per_job, seq_jobs[s], rp, nref, hr, b->results[s]);
         b->results[s].evals = ev;
+    };
+    // sequences are independent: a few host threads share the tail (bounded, deterministic output)
+    int nthr = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    if (const char *e = getenv("SQ_HOST_THREADS")) nthr = std::max(1, atoi(e));
+    nthr = std::min(nthr, std::max(1, b->nseq / 16));
+    if (nthr <= 1) {
+        for (int s = 0; s < b->nseq; s++) tail_one(s);
+    } else {
+        std::atomic<int> next{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthr; t++)
+            th.emplace_back([&]() { for (int s; (s = next.fetch_add(1)) < b->nseq;) tail_one(s); });
+        for (auto &t : th) t.join();
     }
+    if (getenv("SQ_TIMING"))
+        fprintf(stderr, "[sq_fold] rounds=%d loop=%.3fms (round driver %.3f: prep %.3f gpu+wait %.3f post %.3f; pool %.3f) tail=%.3fms\n",
+                nrounds, tloop * 1e3, tround * 1e3, g_t[0] * 1e3, g_t[1] * 1e3, g_t[2] * 1e3, (tloop - tround) * 1e3,
+                (now_s() - ttail0) * 1e3);
     return 0;
 }
 

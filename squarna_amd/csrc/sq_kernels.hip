@@ -200,26 +200,60 @@ extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, co
 #define SQ_SEG 64
 #define SQ_UNR 8
 
-__device__ __forceinline__ void sq_emit(const SqScanArgs &a, const SqStruct &st, int cap, int s, int rend, int len,
-                                        float sum, float asum, double minlen, double minscore)
+#define SQ_STAGE 96   // candidates staged in LDS per wave before one aggregated global append
+
+struct SqStage {        // per-wave LDS staging of emitted candidates (no returning global atomics in the row loop)
+    uint32_t key[SQ_STAGE];
+    uint32_t len[SQ_STAGE];
+    float sum[SQ_STAGE];
+    uint32_t count;
+};
+
+__device__ __forceinline__ void sq_emit_global(const SqScanArgs &a, const SqStruct &st, int cap, uint32_t key,
+                                               uint32_t len, float sum)
+{
+    const uint32_t slot = atomicAdd(a.cand_cnt + st.slot, 1u);
+    if (slot >= (uint32_t)cap) { a.ctr->cand_ovf = 1; return; }
+    SqCand cd;
+    cd.key = key; cd.len = len; cd.sum32 = sum; cd.flags = 0; cd.bps = 0; cd.fin = 0;
+    a.cands[st.cand_off + slot] = cd;
+}
+
+__device__ __forceinline__ void sq_emit(SqStage *sg, const SqScanArgs &a, const SqStruct &st, int cap, int s, int rend,
+                                        int len, float sum, float asum, double minlen, double minscore)
 {
     if ((double)len < minlen) return;                                   // :492
     // fp32 prefilter with a rigorous rounding margin; the exact fp64 test is in sq_score_kernel
     const double ub = (double)sum + (double)asum * (double)(len + 2) * 1.1920928955078125e-07;
     if (!(ub >= minscore)) return;
-    const uint32_t slot = atomicAdd(a.cand_cnt + st.slot, 1u);
-    if (slot >= (uint32_t)cap) { a.ctr->cand_ovf = 1; return; }
-    SqCand cd;
-    cd.key = ((uint32_t)s << 16) | (uint32_t)(rend - len);
-    cd.len = (uint32_t)len;
-    cd.sum32 = sum;
-    cd.flags = 0; cd.bps = 0; cd.fin = 0;
-    a.cands[st.cand_off + slot] = cd;
+    const uint32_t key = ((uint32_t)s << 16) | (uint32_t)(rend - len);
+    const uint32_t slot = atomicAdd(&sg->count, 1u);                    // LDS atomic
+    if (slot < SQ_STAGE) { sg->key[slot] = key; sg->len[slot] = (uint32_t)len; sg->sum[slot] = sum; }
+    else sq_emit_global(a, st, cap, key, (uint32_t)len, sum);          // staging full: rare direct append
+}
+
+// whole wave: append the staged candidates with ONE global atomic
+__device__ __forceinline__ void sq_flush(SqStage *sg, const SqScanArgs &a, const SqStruct &st, int cap, int lane)
+{
+    uint32_t n = sg->count;
+    if (n > SQ_STAGE) n = SQ_STAGE;
+    if (n == 0) return;
+    uint32_t b0 = 0;
+    if (lane == 0) b0 = atomicAdd(a.cand_cnt + st.slot, n);
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+    for (uint32_t k = lane; k < n; k += 64) {
+        const uint32_t slot = base + k;
+        if (slot >= (uint32_t)cap) { a.ctr->cand_ovf = 1; continue; }
+        SqCand cd;
+        cd.key = sg->key[k]; cd.len = sg->len[k]; cd.sum32 = sg->sum[k]; cd.flags = 0; cd.bps = 0; cd.fin = 0;
+        a.cands[st.cand_off + slot] = cd;
+    }
 }
 
 extern "C" __global__ __launch_bounds__(256) void sq_scan_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
 {
     extern __shared__ int16_t e_lds[];
+    __shared__ SqStage s_stage[4];
     const SqStruct st = structs[blockIdx.x];
     const SqJob jb = c.jobs[st.job];
     const int n = jb.n, ld = jb.ld;
@@ -239,9 +273,11 @@ extern "C" __global__ __launch_bounds__(256) void sq_scan_kernel(SqDevCtx c, con
 
     const int16_t *eg = stt.E + (int64_t)st.slot * stt.stride;
     for (int p = threadIdx.x; p < n; p += 256) e_lds[p] = eg[p];
+    if (threadIdx.x < 4) s_stage[threadIdx.x].count = 0;
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    SqStage *stg = &s_stage[wave];
     const int rbeg = rblk + wave * SQ_SEG;
     if (rbeg > rmax) return;
     const int rend = min(rbeg + SQ_SEG, rmax + 1);
@@ -295,7 +331,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_scan_kernel(SqDevCtx c, con
                 if (!skip[k]) { len[k]++; sum[k] += vv[k]; asum[k] += fabsf(vv[k]); }
             } else {
                 if (len[k] > 0) {
-                    sq_emit(a, st, cap, sl + k, r, len[k], sum[k], asum[k], minlen, minscore);
+                    sq_emit(stg, a, st, cap, sl + k, r, len[k], sum[k], asum[k], minlen, minscore);
                     len[k] = 0; sum[k] = 0.f; asum[k] = 0.f;
                 }
                 skip[k] = false;
@@ -334,6 +370,8 @@ extern "C" __global__ __launch_bounds__(256) void sq_scan_kernel(SqDevCtx c, con
         do_row(r, er, v, true);
         r++;
     }
+    __builtin_amdgcn_wave_barrier();
+    sq_flush(stg, a, st, cap, lane);
 }
 
 // ------------------------------------------------------------------------------------

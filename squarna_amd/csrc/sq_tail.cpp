@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <iterator>
 #include <map>
 #include <set>
 #include <vector>
@@ -66,9 +67,10 @@ int sq_pair_levels(const std::vector<BP> &pairs, std::vector<int> &level)
     return (int)groups.size();
 }
 
-static void levels_of(const std::set<BP> &bps, int n, int levellimit, std::vector<int16_t> &out)
+typedef std::vector<BP> BPV;   // sorted, unique
+
+static void levels_of(const BPV &pairs, int n, int levellimit, std::vector<int16_t> &out)
 {
-    std::vector<BP> pairs(bps.begin(), bps.end());                    // sorted, unique, v < w
     std::vector<int> lv;
     sq_pair_levels(pairs, lv);
     out.assign(n, 0);
@@ -79,19 +81,53 @@ static void levels_of(const std::set<BP> &bps, int n, int levellimit, std::vecto
     }
 }
 
+// same result as levels_of() on the stems' bps, computed per stem
+static void levels_of_stems(const std::vector<HStem> &stems, int n, std::vector<int16_t> &out)
+{
+    std::vector<int> lv;
+    sq_stem_levels(stems, lv);
+    out.assign(n, 0);
+    for (size_t k = 0; k < stems.size(); k++)
+        for (int t = 0; t < stems[k].len; t++) {
+            out[stems[k].i + t] = (int16_t)lv[k];
+            out[stems[k].j - t] = (int16_t)-lv[k];
+        }
+}
+
 namespace {
 struct Entry {
     std::vector<HStem> stems;
-    std::set<BP> bps;
+    BPV bps;
     double scores[3];
     uint64_t mask;
 };
 }  // namespace
 
-static void add_bps(const std::vector<HStem> &stems, std::set<BP> &out)
+static void bps_of(const std::vector<HStem> &stems, BPV &out)
 {
+    out.clear();
     for (const HStem &s : stems)
-        for (int k = 0; k < s.len; k++) out.insert(BP(s.i + k, s.j - k));
+        for (int k = 0; k < s.len; k++) out.push_back(BP(s.i + k, s.j - k));
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+}
+
+static inline size_t count_common(const BPV &a, const BPV &b)
+{
+    size_t i = 0, j = 0, c = 0;
+    while (i < a.size() && j < b.size()) {
+        if (a[i] < b[j]) i++;
+        else if (b[j] < a[i]) j++;
+        else { c++; i++; j++; }
+    }
+    return c;
+}
+
+static BPV merged(const BPV &a, const BPV &b)
+{
+    BPV out;
+    std::set_union(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(out));
+    return out;
 }
 
 // ScoreStruct (:861-899)
@@ -128,10 +164,9 @@ static void score_struct(const uint8_t *codes, const double *reacts, int n, cons
     out[2] = py_round3(reactscore);
 }
 
-static void prf(const std::set<BP> &pred, const std::set<BP> &known, double m[6])   // :1252-1258
+static void prf(const BPV &pred, const BPV &known, double m[6])       // :1252-1258
 {
-    int tp = 0;
-    for (const BP &p : pred) tp += known.count(p);
+    const int tp = (int)count_common(pred, known);
     const int fp = (int)pred.size() - tp, fn = (int)known.size() - tp;
     m[0] = tp; m[1] = fp; m[2] = fn;
     m[3] = (2 * tp + fp + fn) ? py_round3(2.0 * tp / (2 * tp + fp + fn)) : 1;
@@ -149,18 +184,17 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
 
     // :1201-1220 dedupe across paramsets; the first producer scores the structure
     std::vector<Entry> fins;
-    std::map<std::vector<BP>, int> seen;
+    std::map<BPV, int> seen;
+    BPV key;
     for (size_t k = 0; k < per_job.size(); k++) {
         for (const auto &stems : per_job[k]) {
-            std::set<BP> bps;
-            add_bps(stems, bps);
-            std::vector<BP> key(bps.begin(), bps.end());
+            bps_of(stems, key);
             auto it = seen.find(key);
             if (it == seen.end()) {
                 Entry e;
-                e.stems = stems; e.bps = std::move(bps); e.mask = 1ull << k;
+                e.stems = stems; e.bps = key; e.mask = 1ull << k;
                 score_struct(codes, reacts, n, stems, e.scores);
-                seen.emplace(std::move(key), (int)fins.size());
+                seen.emplace(key, (int)fins.size());
                 fins.push_back(std::move(e));
             } else {
                 fins[it->second].mask |= 1ull << k;
@@ -176,69 +210,74 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
         return false;
     };
     std::stable_sort(fins.begin(), fins.end(), keyless);               // :907-909
-    std::stable_partition(fins.begin(), fins.end(), [&](const Entry &e) { return (e.mask & o.priority_mask) != 0; });  // :912-913
+    if (o.priority_mask)
+        std::stable_partition(fins.begin(), fins.end(), [&](const Entry &e) { return (e.mask & o.priority_mask) != 0; });  // :912-913
     if (o.rankbydiff && fins.size() >= 3) {                            // :917-955
-        std::set<BP> allbps, seenbps;
-        for (const Entry &e : fins) allbps.insert(e.bps.begin(), e.bps.end());
+        BPV allbps, seenbps;
+        for (const Entry &e : fins) allbps = merged(allbps, e.bps);
         seenbps = fins[0].bps;
         size_t cur = 1;
         while (seenbps != allbps && cur < fins.size() - 1) {
-            std::vector<size_t> novel(fins.size(), 0);
-            std::stable_sort(fins.begin() + cur, fins.end(), [&](const Entry &x, const Entry &y) {
-                size_t nx = 0, ny = 0;
-                for (const BP &p : x.bps) nx += !seenbps.count(p);
-                for (const BP &p : y.bps) ny += !seenbps.count(p);
-                if (nx != ny) return nx > ny;
-                return keyless(x, y);
+            std::vector<std::pair<size_t, size_t>> novel;              // (#new bps, original position)
+            std::vector<Entry> tailv(std::make_move_iterator(fins.begin() + cur), std::make_move_iterator(fins.end()));
+            std::vector<size_t> nov(tailv.size()), idx(tailv.size());
+            for (size_t t = 0; t < tailv.size(); t++) { nov[t] = tailv[t].bps.size() - count_common(tailv[t].bps, seenbps); idx[t] = t; }
+            std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) {
+                if (nov[x] != nov[y]) return nov[x] > nov[y];
+                return keyless(tailv[x], tailv[y]);
             });
-            seenbps.insert(fins[cur].bps.begin(), fins[cur].bps.end());
+            for (size_t t = 0; t < tailv.size(); t++) fins[cur + t] = std::move(tailv[idx[t]]);
+            seenbps = merged(seenbps, fins[cur].bps);
             cur++;
         }
         std::stable_sort(fins.begin() + cur, fins.end(), keyless);
     }
     // hardrest: restraint bps whose letters form an allowed pair of the LAST paramset (:1226-1228)
-    std::set<BP> forced;
+    BPV forced;
     if (o.hardrest && !job_ids.empty()) {
         const sq_paramset &ps = b->psets[b->job_pset[job_ids.back()]];
         for (int k = b->rbp_off[seq]; k < b->rbp_off[seq + 1]; k++) {
             const int v = b->rbps[2 * k], w = b->rbps[2 * k + 1];
-            if (ps.inbps[codes[v] * 32 + codes[w]]) forced.insert(BP(v, w));
+            if (ps.inbps[codes[v] * 32 + codes[w]]) forced.push_back(BP(v, w));
         }
+        std::sort(forced.begin(), forced.end());
     }
     res.preds.clear();
+    res.preds.reserve(fins.size());
     for (const Entry &e : fins) {                                      // :1232-1234
-        SeqResult::Pred p;
-        std::set<BP> all = e.bps;
-        all.insert(forced.begin(), forced.end());
-        levels_of(all, n, -1, p.levels);
+        res.preds.emplace_back();
+        SeqResult::Pred &p = res.preds.back();
+        if (forced.empty()) levels_of_stems(e.stems, n, p.levels);
+        else levels_of(merged(e.bps, forced), n, -1, p.levels);
         for (int t = 0; t < 3; t++) p.scores[t] = e.scores[t];
         p.pset_mask = e.mask;
-        res.preds.push_back(std::move(p));
     }
-    std::set<BP> cons;                                                 // :845-858,1236
+    BPV cons;                                                          // :845-858,1236
     const size_t top = std::min<size_t>(fins.size(), (size_t)std::max(o.conslim, 0));
     if (top) {
         cons = fins[0].bps;
         for (size_t k = 1; k < top; k++) {
-            std::set<BP> nx;
-            for (const BP &p : cons) if (fins[k].bps.count(p)) nx.insert(p);
+            BPV nx;
+            std::set_intersection(cons.begin(), cons.end(), fins[k].bps.begin(), fins[k].bps.end(), std::back_inserter(nx));
             cons.swap(nx);
         }
     }
-    cons.insert(forced.begin(), forced.end());
-    levels_of(cons, n, -1, res.cons);
+    if (!forced.empty()) cons = merged(cons, forced);
+    if (top == 1 && forced.empty()) res.cons = res.preds[0].levels;
+    else levels_of(cons, n, -1, res.cons);
     res.has_ref = has_ref;
     if (has_ref) {                                                     // :1249-1285
-        std::set<BP> known;
-        for (int k = 0; k < nref; k++) known.insert(BP(ref_pairs[2 * k], ref_pairs[2 * k + 1]));
+        BPV known;
+        for (int k = 0; k < nref; k++) known.push_back(BP(ref_pairs[2 * k], ref_pairs[2 * k + 1]));
+        std::sort(known.begin(), known.end());
+        known.erase(std::unique(known.begin(), known.end()), known.end());
         prf(cons, known, res.cons_metrics);
         double best = -1;
         for (int t = 0; t < 7; t++) res.best_metrics[t] = NAN;
         for (size_t rank = 0; rank < fins.size(); rank++) {
-            std::set<BP> all = fins[rank].bps;
-            all.insert(forced.begin(), forced.end());
             double m[6];
-            prf(all, known, m);
+            if (forced.empty()) prf(fins[rank].bps, known, m);
+            else prf(merged(fins[rank].bps, forced), known, m);
             if (m[3] > best) {
                 best = m[3];
                 for (int t = 0; t < 6; t++) res.best_metrics[t] = m[t];

@@ -166,6 +166,7 @@ class Batch:
         _lib.check(L.sq_batch_create(C.byref(h), C.byref(d), C.c_void_p(aligned),
                                      C.c_size_t(nbytes.value), C.c_void_p(self.stream.cuda_stream)))
         self.h = h
+        self._refs = None
         self.njobs = njobs
         self.nseq = nseq
 
@@ -240,15 +241,18 @@ class Batch:
         for p in (priority or ()):
             mask |= 1 << int(p)
         o.priority_mask = mask
-        ref_off = np.zeros(self.nseq + 1, np.int32)
-        has = np.zeros(max(self.nseq, 1), np.uint8)
-        refs = []
-        for k, p in enumerate(self.prepared):
-            if p.shortdbn:
-                has[k] = 1
-                refs.extend(DBNToPairs(p.shortdbn))
-            ref_off[k + 1] = len(refs)
-        rp = np.array(refs, np.int32).reshape(-1) if refs else np.zeros(2, np.int32)
+        if self._refs is None:                       # reference pairs are static per batch
+            ref_off = np.zeros(self.nseq + 1, np.int32)
+            has = np.zeros(max(self.nseq, 1), np.uint8)
+            refs = []
+            for k, p in enumerate(self.prepared):
+                if p.shortdbn:
+                    has[k] = 1
+                    refs.extend(DBNToPairs(p.shortdbn))
+                ref_off[k + 1] = len(refs)
+            rp = np.array(refs, np.int32).reshape(-1) if refs else np.zeros(2, np.int32)
+            self._refs = (ref_off, rp, has)
+        ref_off, rp, has = self._refs
         _lib.check(self.L.sq_fold(self.h, C.byref(o), _ptr(ref_off), _ptr(rp), _ptr(has)))
 
     def result(self, k):
