@@ -38,7 +38,7 @@ def build_library(force=False, verbose=False):
             continue
         obj = os.path.join(bdir, src.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+        cmd = [hipcc] + FLAGS + os.environ.get("SQ_DEFS", "").split() + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -10,15 +10,16 @@ struct SqDevCtx {
     const uint8_t *flags;
     const uint8_t *inc4;     // minimal j - i for a pair starting at i (SQRNdbnseq.py:294-297)
     const int16_t *chain;    // chain ordinal (interchainonly, :264-271)
-    const int16_t *e0;       // restraint mask code: -1 free, v >= 0 shared id of restraint bp (v,w) (:438-443)
+    const uint8_t *e0c;      // restraint mask code: 0 free, k+1 = k-th restraint bp (v,w) of the sequence (:438-443)
     const double *reacts;
     float *mat32;            // fp32 scan-matrix arena
     double *mat64;           // dense fp64 arena (external / weighted matrices only)
     const double *sdftab;    // pow tables
 };
 
-struct SqState {             // per-structure-slot arrays, `stride` int16 elements per slot
-    int16_t *P, *E, *U, *SU;
+struct SqState {             // per-structure-slot arrays, `stride` elements per slot
+    int16_t *P, *U, *SU;     // partner, prefix #unpaired, prefix #unpaired separators
+    uint8_t *E8;             // scan mask code per position: 0 free, 255 masked, k+1 restraint bp k
     int32_t stride;
 };
 
@@ -27,6 +28,9 @@ struct SqScanArgs {
     uint32_t *cand_cnt;      // per slot
     SqCounters *ctr;
 };
+
+size_t sq_scan_lds_fixed();   // bytes of static LDS of sq_scan_kernel
+int sq_scan_seg();            // rows per wave of sq_scan_kernel
 
 extern "C" {
 __global__ void sq_fill_kernel(SqDevCtx c);

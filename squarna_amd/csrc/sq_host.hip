@@ -137,7 +137,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     char *base = (char *)ws;
     // ---- per-position derived arrays (host, O(N)) ----
     std::vector<uint8_t> inc4(L.ltot);
-    std::vector<int16_t> chain(L.ltot, 0), e0(L.ltot, -1);
+    std::vector<int16_t> chain(L.ltot, 0);
+    std::vector<uint8_t> e0(L.ltot, 0);
     for (int s = 0; s < d->nseq; s++) {
         const int off = d->seq_off[s], n = d->seq_off[s + 1] - off;
         auto sep = [&](int p) { return b->codes[off + p] == SQ_CODE_SEP1 || b->codes[off + p] == SQ_CODE_SEP2; };
@@ -153,7 +154,9 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         for (int k = d->rbp_off[s]; k < d->rbp_off[s + 1]; k++) {
             const int v = d->rbps[2 * k], w = d->rbps[2 * k + 1];
             if (v < 0 || w >= n || v >= w) { delete b; sq_set_error("bad restraint pair"); return -1; }
-            e0[off + v] = (int16_t)v; e0[off + w] = (int16_t)v;
+            const int code = k - d->rbp_off[s] + 1;
+            if (code > 254) { delete b; sq_set_error("more than 254 restraint base pairs in one sequence"); return -1; }
+            e0[off + v] = (uint8_t)code; e0[off + w] = (uint8_t)code;
         }
     }
     // ---- paramsets with host-libm pow tables ----
@@ -199,18 +202,38 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         J.default_reacts = def ? 1 : 0;
         J.interchainonly = d->interchainonly;
         J.cand_cap = (int32_t)std::max<int64_t>(256, (int64_t)L.cpn * J.n);
+        // bound of |cell| for the scan's fp32 prefilter margin
+        double mx = 0;
+        const size_t nn = (size_t)J.n * J.n;
+        if (ext) {
+            for (size_t q = 0; q < nn; q++) if (d->ext_bool[j] && d->ext_bool[j][q] != 0) mx = std::max(mx, std::fabs(d->ext_score[j][q]));
+        } else {
+            const sq_paramset &ps = d->psets[J.pset];
+            for (int q = 0; q < 32 * 32; q++) {
+                if (!ps.inbps[q]) continue;
+                const double w = ps.bpweight[q];
+                const double rfmax = def ? 1.0 : (w > 0 ? 1.4142135623730951 : 100.0);   // SQRNdbnseq.py:333-336
+                mx = std::max(mx, std::fabs(w) * rfmax);
+            }
+            if (mul) {
+                double mm = 0;
+                for (size_t q = 0; q < nn; q++) mm = std::max(mm, std::fabs(d->mul_score[j][q]));
+                mx *= mm;
+            }
+        }
+        J.maxabs = (float)(mx * 1.0000002) ; J.pad = 0;
     }
     // ---- device carve + uploads ----
     b->ctx.codes = (uint8_t *)(base + L.off_codes); b->ctx.flags = (uint8_t *)(base + L.off_flags);
     b->ctx.inc4 = (uint8_t *)(base + L.off_inc4); b->ctx.chain = (int16_t *)(base + L.off_chain);
-    b->ctx.e0 = (int16_t *)(base + L.off_e0); b->ctx.reacts = (double *)(base + L.off_reacts);
+    b->ctx.e0c = (uint8_t *)(base + L.off_e0); b->ctx.reacts = (double *)(base + L.off_reacts);
     b->ctx.jobs = (SqJob *)(base + L.off_jobs); b->ctx.psets = (SqPsetDev *)(base + L.off_psets);
     b->ctx.sdftab = (double *)(base + L.off_sdf);
     b->ctx.mat32 = (float *)(base + L.off_mat32); b->ctx.mat64 = (double *)(base + L.off_mat64);
     b->d_structs = (SqStruct *)(base + L.off_structs); b->d_strands = (SqStrand *)(base + L.off_strands);
     int16_t *stbase = (int16_t *)(base + L.off_state);
     const size_t plane = (size_t)L.stride * L.max_structs;
-    b->state.P = stbase; b->state.E = stbase + plane; b->state.U = stbase + 2 * plane; b->state.SU = stbase + 3 * plane;
+    b->state.P = stbase; b->state.E8 = (uint8_t *)(stbase + plane); b->state.U = stbase + 2 * plane; b->state.SU = stbase + 3 * plane;
     b->state.stride = L.stride;
     b->scan.cand_cnt = (uint32_t *)(base + L.off_cnt); b->scan.ctr = (SqCounters *)(base + L.off_ctr);
     b->scan.cands = (SqCand *)(base + L.off_cands);
@@ -221,7 +244,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
                                  if (_r) { hipStreamSynchronize(st); delete b; return _r; } } while (0)
     UP(b->ctx.codes, b->codes.data(), L.ltot); UP(b->ctx.flags, b->flags.data(), L.ltot);
     UP(b->ctx.inc4, inc4.data(), L.ltot); UP(b->ctx.chain, chain.data(), L.ltot * 2);
-    UP(b->ctx.e0, e0.data(), L.ltot * 2); UP(b->ctx.reacts, b->reacts.data(), L.ltot * 8);
+    UP(b->ctx.e0c, e0.data(), L.ltot); UP(b->ctx.reacts, b->reacts.data(), L.ltot * 8);
     UP(b->ctx.jobs, b->jobs.data(), sizeof(SqJob) * d->njobs);
     UP(b->ctx.psets, pd.data(), sizeof(SqPsetDev) * d->npset);
     if (!sdf.empty()) UP(b->ctx.sdftab, sdf.data(), 8 * sdf.size());
@@ -497,11 +520,10 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
     }
     if (maxn >= 5) {
         const int nband = (2 * maxn - 5 + 255) >> 8;
-        const int nseg = ((maxn >> 1) + 130 + 63) / 64;
-        const int nsg = (nseg + 3) >> 2;
+        const int seg = sq_scan_seg();
+        const int nseg = ((maxn >> 1) + 130 + seg - 1) / seg;
         ProfScope ps(b, 2, scan_bytes);
-        hipLaunchKernelGGL(sq_scan_kernel, dim3(S, nband * nsg), dim3(256), (size_t)2 * maxn + 64, st, b->ctx,
-                           b->d_structs, b->state, b->scan);
+        hipLaunchKernelGGL(sq_scan_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, b->d_structs, b->state, b->scan);
     }
     {
         ProfScope ps(b, 3, 0);

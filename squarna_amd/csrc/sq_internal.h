@@ -18,6 +18,8 @@ struct SqJob {
     int32_t interchainonly;
     int32_t has_ext;    // scan matrix comes from caller matrices (ext_bool/ext_score) or mul_score
     int32_t cand_cap;   // candidate capacity per structure of this job
+    float maxabs;       // upper bound of |scoremat cell| (fp32 prefilter margin of the scan)
+    int32_t pad;
 };
 
 // Device image of a paramset (+ host-built pow tables so every pow() is the host libm's).

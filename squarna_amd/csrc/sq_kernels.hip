@@ -146,10 +146,10 @@ extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, co
     const SqJob jb = c.jobs[s.job];
     const int n = jb.n;
     int16_t *P = st.P + (int64_t)s.slot * st.stride;
-    int16_t *E = st.E + (int64_t)s.slot * st.stride;
+    uint8_t *E = st.E8 + (int64_t)s.slot * st.stride * 2;
     int16_t *U = st.U + (int64_t)s.slot * st.stride;
     int16_t *SU = st.SU + (int64_t)s.slot * st.stride;
-    const int16_t *e0 = c.e0 + jb.pos_off;
+    const uint8_t *e0 = c.e0c + jb.pos_off;
     const uint8_t *codes = c.codes + jb.pos_off;
     const int tid = threadIdx.x;
     for (int p = tid; p < n; p += 256) { P[p] = -1; E[p] = e0[p]; }
@@ -160,7 +160,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, co
         for (int t = 0; t < x.len; t++) {
             const int pos = x.start + t;
             P[pos] = (int16_t)(x.pstart - t);           // :634-635
-            E[pos] = (int16_t)(-2 - pos);               // :446-451 row+column of a paired base are masked
+            E[pos] = 255;                               // :446-451 row+column of a paired base are masked
         }
     }
     __syncthreads();
@@ -192,21 +192,48 @@ extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, co
 }
 
 // ------------------------------------------------------------------------------------
-// a-2  stem scan.  block = 4 waves; wave = 256 anti-diagonals (4 per lane) x SEG rows.
-// A run is owned by the wave whose row segment contains its first cell; that wave
-// keeps reading past its segment until the run ends (runs are short), and skips a
-// run that was already open in the row above its segment.
+// a-2  stem scan.  One wave (64-thread block) = 256 anti-diagonals (4 per lane) x SQ_SEG rows.
+//
+//  * rows of the segment that the current structure masks are dropped up front (a masked
+//    row only ends every open run); the remaining rows are streamed HBM -> LDS with LDS-DMA
+//    (global_load_lds_dwordx4: 1 KiB per row, SQ_RING rows in flight, counted vmcnt), lanes
+//    whose four diagonals do not reach a row skip their 16 bytes;
+//  * the column mask codes of the wave's window live in LDS as four byte-shifted copies, so
+//    the four codes a lane needs for a row are ONE aligned ds_read_b32;
+//  * the run state (len, sum) of the four diagonals stays in registers; a run belongs to the
+//    wave whose segment holds its first cell: the wave reads SQ_TAILROWS rows past its
+//    segment inside the same pipeline (longer runs finish in a rare serial loop) and ignores
+//    runs that are already open in the row above its segment;
+//  * candidates go to lane-private LDS slots (no atomics), overflow to a shared LDS list,
+//    and are appended to the structure's candidate array with one global atomic per wave.
 // ------------------------------------------------------------------------------------
-#define SQ_SEG 64
-#define SQ_UNR 8
+#ifndef SQ_SEG
+#define SQ_SEG 128
+#endif
+#ifndef SQ_RING
+#define SQ_RING 4
+#endif
+#ifndef SQ_TAILROWS
+#define SQ_TAILROWS 4
+#endif
+#define SQ_MAXROWS (SQ_SEG + SQ_TAILROWS + 1)        // + the row above the segment
+#define SQ_ROWCAP (SQ_MAXROWS + 3)
+#ifndef SQ_KPRIV
+#define SQ_KPRIV 2
+#endif
+#define SQ_OVF 32
+#define SQ_COLW ((256 + SQ_MAXROWS + 3) / 4 + 3)       // dwords per shifted copy of the column codes
+#define SQ_FOREIGN (-(1 << 24))                       // len of a run owned by another wave
 
-#define SQ_STAGE 96   // candidates staged in LDS per wave before one aggregated global append
+struct SqRec { uint32_t key, len; float sum; uint32_t pad; };
 
-struct SqStage {        // per-wave LDS staging of emitted candidates (no returning global atomics in the row loop)
-    uint32_t key[SQ_STAGE];
-    uint32_t len[SQ_STAGE];
-    float sum[SQ_STAGE];
-    uint32_t count;
+struct SqScanLds {      // LDS of one wave
+    float ring[SQ_RING][256];            // 8 KiB   DMA ring, one row per slot
+    SqRec priv[SQ_KPRIV][64];            // 2 KiB   lane-private candidate slots
+    SqRec ovf[SQ_OVF];                   // 512 B   shared overflow list
+    uint32_t ovf_count, pad0[3];
+    uint32_t rows[SQ_ROWCAP];            // (row << 8) | mask code of the row
+    uint32_t ecol[4][SQ_COLW];           // byte-shifted copies of the column mask codes
 };
 
 __device__ __forceinline__ void sq_emit_global(const SqScanArgs &a, const SqStruct &st, int cap, uint32_t key,
@@ -219,160 +246,274 @@ __device__ __forceinline__ void sq_emit_global(const SqScanArgs &a, const SqStru
     a.cands[st.cand_off + slot] = cd;
 }
 
-__device__ __forceinline__ void sq_emit(SqStage *sg, const SqScanArgs &a, const SqStruct &st, int cap, int s, int rend,
-                                        int len, float sum, float asum, double minlen, double minscore)
-{
-    if ((double)len < minlen) return;                                   // :492
-    // fp32 prefilter with a rigorous rounding margin; the exact fp64 test is in sq_score_kernel
-    const double ub = (double)sum + (double)asum * (double)(len + 2) * 1.1920928955078125e-07;
-    if (!(ub >= minscore)) return;
-    const uint32_t key = ((uint32_t)s << 16) | (uint32_t)(rend - len);
-    const uint32_t slot = atomicAdd(&sg->count, 1u);                    // LDS atomic
-    if (slot < SQ_STAGE) { sg->key[slot] = key; sg->len[slot] = (uint32_t)len; sg->sum[slot] = sum; }
-    else sq_emit_global(a, st, cap, key, (uint32_t)len, sum);          // staging full: rare direct append
-}
+struct SqScanCtx {      // per-wave constants of the row walk
+    uint32_t lds_priv, lds_ovf, lds_ovfcnt;   // LDS byte addresses (inline-asm DS ops, see sq_emit)
+    int sl, n, cap, minlen_i, lane;
+    float maxabs, minscore_f;
+};
 
-// whole wave: append the staged candidates with ONE global atomic
-__device__ __forceinline__ void sq_flush(SqStage *sg, const SqScanArgs &a, const SqStruct &st, int cap, int lane)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// run [rend-len, rend) on diagonal s ended with len >= minlen.  fp32 prefilter with a rigorous
+// rounding margin (|fp32 sum - exact| <= len^2 * maxabs * 2^-24); the exact fp64 test of
+// SQRNdbnseq.py:492 is in sq_score_kernel.  All LDS traffic here is inline asm: hipcc would
+// otherwise drain the LDS-DMA queue (s_waitcnt vmcnt(0)) in front of every LDS access it
+// cannot prove disjoint from the ring.
+__device__ __forceinline__ void sq_emit(const SqScanCtx &x, const SqScanArgs &a, const SqStruct &st, int &pc, int s,
+                                        int rend, int len, float sum)
 {
-    uint32_t n = sg->count;
-    if (n > SQ_STAGE) n = SQ_STAGE;
-    if (n == 0) return;
-    uint32_t b0 = 0;
-    if (lane == 0) b0 = atomicAdd(a.cand_cnt + st.slot, n);
-    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
-    for (uint32_t k = lane; k < n; k += 64) {
-        const uint32_t slot = base + k;
-        if (slot >= (uint32_t)cap) { a.ctr->cand_ovf = 1; continue; }
-        SqCand cd;
-        cd.key = sg->key[k]; cd.len = sg->len[k]; cd.sum32 = sg->sum[k]; cd.flags = 0; cd.bps = 0; cd.fin = 0;
-        a.cands[st.cand_off + slot] = cd;
+    const float ll = (float)len * (float)len;
+    const float ub = fmaf(ll * x.maxabs, 2.4e-07f, sum);
+    if (!(ub >= x.minscore_f)) return;
+    const uint32_t key = ((uint32_t)s << 16) | (uint32_t)(rend - len);
+    const u32x4 rec = {key, (uint32_t)len, __float_as_uint(sum), 0u};
+    if (pc < SQ_KPRIV) {
+        const uint32_t addr = x.lds_priv + ((uint32_t)pc * 64u + (uint32_t)x.lane) * 16u;
+        asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(rec) : "memory");
+        pc++;
+        return;
+    }
+    uint32_t slot;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(x.lds_ovfcnt), "v"(1u) : "memory");
+    if (slot < SQ_OVF) {
+        const uint32_t addr = x.lds_ovf + slot * 16u;
+        asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(rec) : "memory");
+    } else {
+        sq_emit_global(a, st, x.cap, key, (uint32_t)len, sum);
     }
 }
 
-extern "C" __global__ __launch_bounds__(256) void sq_scan_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
+// MODE 0: row inside the segment; 1: row past the segment (runs may continue, not start);
+// 2: the row above the segment (only marks runs that are already open there).
+// EDGE: some cells of the row lie outside their diagonal (band staircases) -> per-cell range test.
+template <int MODE, bool EDGE>
+__device__ __forceinline__ void sq_row(const SqScanCtx &x, const SqScanArgs &a, const SqStruct &st, int &pc, int r,
+                                       uint32_t er, uint32_t ecodes, const float4 &v, const int (&lo)[4],
+                                       const unsigned (&span)[4], int (&len)[4], float (&sum)[4])
 {
-    extern __shared__ int16_t e_lds[];
-    __shared__ SqStage s_stage[4];
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    bool act[4];
+    bool want = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t ej = (ecodes >> (8 * k)) & 0xFFu;
+        act[k] = (ej == er) & (__float_as_uint(vv[k]) != SQ_SENT_BITS);            // :438-451 mask, :300-304 bool
+        if (EDGE) act[k] = act[k] & ((unsigned)(r - lo[k]) <= span[k]);           // cell (r, s-r) exists
+        if (MODE != 2) want |= (!act[k]) & (len[k] >= x.minlen_i);
+    }
+    if (MODE != 2 && __ballot(want) != 0ull) {                          // some run of useful length ended here
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (!act[k] && len[k] >= x.minlen_i) sq_emit(x, a, st, pc, x.sl + k, r, len[k], sum[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (MODE == 2) {
+            len[k] = act[k] ? SQ_FOREIGN : 0;
+        } else if (MODE == 0) {
+            sum[k] = act[k] ? sum[k] + vv[k] : 0.f;                     // garbage while len < 0: never emitted
+            len[k] = act[k] ? len[k] + 1 : 0;
+        } else {
+            const bool cont = act[k] & (len[k] > 0);
+            sum[k] = cont ? sum[k] + vv[k] : 0.f;
+            len[k] = cont ? len[k] + 1 : (act[k] ? SQ_FOREIGN : 0);
+        }
+    }
+}
+
+// every open run ends in row `r` (a masked row, or the end of the diagonals)
+__device__ __forceinline__ void sq_end_all(const SqScanCtx &x, const SqScanArgs &a, const SqStruct &st, int &pc, int r,
+                                           int (&len)[4], float (&sum)[4])
+{
+    const bool want = (len[0] >= x.minlen_i) | (len[1] >= x.minlen_i) | (len[2] >= x.minlen_i) | (len[3] >= x.minlen_i);
+    if (__ballot(want) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (len[k] >= x.minlen_i) sq_emit(x, a, st, pc, x.sl + k, r, len[k], sum[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { len[k] = 0; sum[k] = 0.f; }
+}
+
+__device__ __forceinline__ void sq_dma_row(const float *gsrc, float *lds_row, bool lane_on)
+{
+    // LDS-DMA: lane l's 16 bytes land at lds_row + 16*l (wave-uniform base in M0); lanes whose
+    // diagonals do not reach the row are masked off and fetch nothing.  At least one lane is
+    // always on for a row of the band, so the instruction is issued and counted by vmcnt.
+    if (lane_on)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                         (__attribute__((address_space(3))) void *)lds_row, 16, 0, 0);
+}
+
+extern "C" __global__ __launch_bounds__(64) void sq_scan_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) SqScanLds L;
     const SqStruct st = structs[blockIdx.x];
     const SqJob jb = c.jobs[st.job];
     const int n = jb.n, ld = jb.ld;
     if (n < 5) return;                                                  // :456-457 no diagonals
     const int nband = (2 * n - 5 + 255) >> 8;
     const int nseg = ((n >> 1) + 130 + SQ_SEG - 1) / SQ_SEG;
-    const int nsg = (nseg + 3) >> 2;
     const int tile = blockIdx.y;
-    if (tile >= nband * nsg) return;
-    const int band = tile / nsg, sg = tile - band * nsg;
+    if (tile >= nband * nseg) return;
+    const int band = tile / nseg, seg = tile - band * nseg;
     const int s0 = band << 8;
     const int smin = max(s0, 4), smax = min(s0 + 255, 2 * n - 6);       // :456-457 s in [4, 2N-6]
     if (smin > smax) return;
     const int rmin = max(0, smin - (n - 1)), rmax = (smax - 1) >> 1;    // :486 i <= j-1
-    const int rblk = rmin + sg * 4 * SQ_SEG;
-    if (rblk > rmax) return;
-
-    const int16_t *eg = stt.E + (int64_t)st.slot * stt.stride;
-    for (int p = threadIdx.x; p < n; p += 256) e_lds[p] = eg[p];
-    if (threadIdx.x < 4) s_stage[threadIdx.x].count = 0;
-    __syncthreads();
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    SqStage *stg = &s_stage[wave];
-    const int rbeg = rblk + wave * SQ_SEG;
+    const int rbeg = rmin + seg * SQ_SEG;
     if (rbeg > rmax) return;
     const int rend = min(rbeg + SQ_SEG, rmax + 1);
+    const int lane = threadIdx.x;
 
     const SqPsetDev *ps = c.psets + jb.pset;
-    const double minlen = ps->minlen, minscore = ps->minbpscore;
-    const int cap = jb.cand_cap;
+    SqScanCtx x;
+    x.lds_priv = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) SqRec *)&L.priv[0][0];
+    x.lds_ovf = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) SqRec *)&L.ovf[0];
+    x.lds_ovfcnt = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&L.ovf_count;
+    x.sl = s0 + 4 * lane; x.n = n; x.cap = jb.cand_cap; x.lane = lane;
+    x.minlen_i = max(1, (int)ceil(ps->minlen)); x.maxabs = jb.maxabs;
+    {
+        const float ms = (float)ps->minbpscore;
+        x.minscore_f = ms - fabsf(ms) * 4.8e-07f - 1e-30f;
+    }
 
-    int lo[4], hi[4], len[4];
-    float sum[4], asum[4];
-    bool skip[4];
-    const int sl = s0 + 4 * lane;
+    int lo[4], len[4];
+    unsigned span[4];
+    float sum[4];
+    int llo = 0x3fffffff, lhi = -1;                                     // rows some diagonal of this lane reaches
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int s = sl + k;
+        const int s = x.sl + k;
         const bool ok = s >= 4 && s <= 2 * n - 6;
         lo[k] = ok ? max(0, s - (n - 1)) : 0x3fffffff;
-        hi[k] = ok ? (s - 1) >> 1 : -1;
-        len[k] = 0; sum[k] = 0.f; asum[k] = 0.f; skip[k] = false;
+        span[k] = ok ? (unsigned)(((s - 1) >> 1) - lo[k]) : 0u;
+        if (ok) { llo = min(llo, lo[k]); lhi = max(lhi, (s - 1) >> 1); }
+        len[k] = 0; sum[k] = 0.f;
     }
-    // float offset of cell (r, sl - r) is r*(ld-1) + sl
-    const float *base = c.mat32 + jb.mat_off + sl;
-    const int64_t pitch = ld - 1;
+    const unsigned lspan = lhi >= llo ? (unsigned)(lhi - llo) : 0u;
+    // rows where every cell of the wave exists (no staircase): lo of the last diagonal .. hi of the first
+    const bool fullband = s0 >= 4 && s0 + 255 <= 2 * n - 6;
+    const int wlo = fullband ? max(0, s0 + 255 - (n - 1)) : 0x3fffffff;
+    const int whi = fullband ? (s0 - 1) >> 1 : -1;
 
-    auto cell_active = [&](int r, int k, int er, float v) -> bool {
-        const bool valid = (r >= lo[k]) & (r <= hi[k]);
-        const int j = valid ? sl + k - r : 0;
-        const int ej = e_lds[j];
-        return valid & (ej == er) & (__float_as_uint(v) != SQ_SENT_BITS);   // :438-451 mask + bool
-    };
-
-    // row above the segment: a run that is already open there belongs to another wave
-    if (rbeg > rmin) {
-        const int r = rbeg - 1;
-        const int er = __builtin_amdgcn_readfirstlane((int)e_lds[r]);
-        if (er > -2) {
-            const float4 v = *reinterpret_cast<const float4 *>(base + (int64_t)r * pitch);
-            const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) skip[k] = cell_active(r, k, er, vv[k]);
-        }
+    // ---- compact the unmasked rows: [row above the segment] + segment + pipelined tail rows
+    const uint8_t *eg = stt.E8 + (int64_t)st.slot * stt.stride * 2;
+    const int r0 = rbeg > rmin ? rbeg - 1 : rbeg;
+    const int rhi = min(rmax, rend + SQ_TAILROWS - 1);
+    if (lane == 0) L.ovf_count = 0;
+    int cnt = 0;
+    for (int c0 = r0; c0 <= rhi; c0 += 64) {
+        const int row = c0 + lane;
+        const uint32_t code = row <= rhi ? (uint32_t)eg[row] : 255u;
+        const bool ok = code != 255u;
+        const unsigned long long m = __ballot(ok);
+        if (ok) L.rows[cnt + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)row << 8) | code;
+        cnt += __popcll(m);
     }
-
-    auto do_row = [&](int r, int er, const float4 &v, bool tail) {
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    // ---- column mask codes of the window [jb0, jb0 + 4*SQ_COLW): copy c, dword m = codes jb0+4m+c .. +3
+    const int jb0 = s0 - rhi;
+    for (int idx = lane; idx < 4 * SQ_COLW; idx += 64) {
+        const int cpy = idx / SQ_COLW, m = idx - cpy * SQ_COLW;
+        uint32_t w = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const bool act = (er > -2) && cell_active(r, k, er, vv[k]);
-            if (act) {
-                if (tail && len[k] == 0) skip[k] = true;             // starts in the next wave's segment
-                if (!skip[k]) { len[k]++; sum[k] += vv[k]; asum[k] += fabsf(vv[k]); }
-            } else {
-                if (len[k] > 0) {
-                    sq_emit(stg, a, st, cap, sl + k, r, len[k], sum[k], asum[k], minlen, minscore);
-                    len[k] = 0; sum[k] = 0.f; asum[k] = 0.f;
-                }
-                skip[k] = false;
-            }
+            const int j = jb0 + 4 * m + cpy + k;
+            const uint32_t code = (j >= 0 && j < n) ? (uint32_t)eg[j] : 255u;
+            w |= code << (8 * k);
         }
-    };
+        L.ecol[cpy][m] = w;
+    }
+    __syncthreads();      // single wave: orders the LDS writes above before the reads below
 
-    int r = rbeg;
-    for (; r + SQ_UNR <= rend; r += SQ_UNR) {
-        float4 v[SQ_UNR];
-        int er[SQ_UNR];
-#pragma unroll
-        for (int u = 0; u < SQ_UNR; u++) {
-            er[u] = __builtin_amdgcn_readfirstlane((int)e_lds[r + u]);
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (er[u] > -2)                                            // masked row: nothing to read
-                v[u] = *reinterpret_cast<const float4 *>(base + (int64_t)(r + u) * pitch);
-        }
-#pragma unroll
-        for (int u = 0; u < SQ_UNR; u++) do_row(r + u, er[u], v[u], false);
+    const float *base = c.mat32 + jb.mat_off + x.sl;     // cell (r, sl - r) at float offset r*(ld-1) + sl: 16-B aligned
+    const int64_t pitch = ld - 1;
+    float *ring = &L.ring[0][0];
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)ring + (uint32_t)lane * 16u;
+    const uint32_t rows_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&L.rows[0];
+    const uint32_t ecol_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&L.ecol[0][0] + (uint32_t)lane * 4u;
+
+    auto row_at = [&](int q) -> uint32_t {             // uniform LDS read through asm (see sq_emit)
+        uint32_t w;
+        const uint32_t ad = rows_lds + (uint32_t)q * 4u;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(ad) : "memory");
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+    };
+    auto issue = [&](int q) {
+        const int row = (int)(row_at(q) >> 8);
+        sq_dma_row(base + (int64_t)row * pitch, ring + (q & (SQ_RING - 1)) * 256, (unsigned)(row - llo) <= lspan);
+    };
+    for (int q = 0; q < SQ_RING && q < cnt; q++) issue(q);
+
+    int pc = 0;                       // lane-private candidates staged so far
+    int prev = r0 - 1;
+    for (int q = 0; q < cnt; q++) {
+        const uint32_t rc = row_at(q);
+        const int row = (int)(rc >> 8);
+        const uint32_t er = rc & 0xFFu;
+        // entry q has landed once at most SQ_RING-1 younger DMAs are outstanding (in-order completion)
+        if (q + SQ_RING <= cnt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SQ_RING - 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float4 v;
+        uint32_t ecodes;
+        const uint32_t addr = ring_lds + (uint32_t)(q & (SQ_RING - 1)) * 1024u;
+        const int d = rhi - row;
+        const uint32_t eaddr = ecol_lds + (uint32_t)(d & 3) * (SQ_COLW * 4u) + (uint32_t)(d >> 2) * 4u;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v), "=&v"(ecodes) : "v"(addr), "v"(eaddr) : "memory");
+        if (q + SQ_RING < cnt) issue(q + SQ_RING);                      // slot is free again: keep the ring full
+        if (row != prev + 1) sq_end_all(x, a, st, pc, prev + 1, len, sum);   // masked rows in between (:446-451)
+        const bool interior = row >= wlo && row <= whi;
+        if (row < rbeg) sq_row<2, true>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
+        else if (row < rend) {
+            if (interior) sq_row<0, false>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
+            else sq_row<0, true>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
+        } else sq_row<1, true>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
+        prev = row;
     }
-    for (; r < rend; r++) {
-        const int er = __builtin_amdgcn_readfirstlane((int)e_lds[r]);
+    if (prev != rhi) sq_end_all(x, a, st, pc, prev + 1, len, sum);       // trailing masked rows
+    // runs that are still open: beyond the pipelined tail (rare) or at the end of the diagonals
+    int r = rhi + 1;
+    while (__ballot((len[0] > 0) | (len[1] > 0) | (len[2] > 0) | (len[3] > 0)) != 0ull) {
+        uint32_t er = 255u;
+        if (r <= rmax) er = (uint32_t)__builtin_amdgcn_readfirstlane((int)eg[r]);
+        if (er == 255u) { sq_end_all(x, a, st, pc, r, len, sum); break; }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (er > -2) v = *reinterpret_cast<const float4 *>(base + (int64_t)r * pitch);
-        do_row(r, er, v, false);
-    }
-    // finish the runs that started in this segment (also flushes at r == rmax + 1)
-    while (r <= rmax + 1 && __ballot((len[0] | len[1] | len[2] | len[3]) > 0) != 0ull) {
-        int er = -2;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r <= rmax) {
-            er = __builtin_amdgcn_readfirstlane((int)e_lds[r]);
-            if (er > -2) v = *reinterpret_cast<const float4 *>(base + (int64_t)r * pitch);
+        if ((unsigned)(r - llo) <= lspan) v = *reinterpret_cast<const float4 *>(base + (int64_t)r * pitch);
+        uint32_t ecodes = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = x.sl + k - r;
+            ecodes |= ((j >= 0 && j < n) ? (uint32_t)eg[j] : 255u) << (8 * k);
         }
-        do_row(r, er, v, true);
+        sq_row<1, true>(x, a, st, pc, r, er, ecodes, v, lo, span, len, sum);
         r++;
     }
-    __builtin_amdgcn_wave_barrier();
-    sq_flush(stg, a, st, cap, lane);
+    // ---- flush: lane-private slots + overflow list -> one global append
+    __syncthreads();
+    const unsigned long long m1 = __ballot(pc >= 1), m2 = __ballot(pc >= 2);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
+    uint32_t novf = L.ovf_count;
+    if (novf > SQ_OVF) novf = SQ_OVF;
+    const uint32_t total = n1 + n2 + novf;
+    if (total == 0) return;
+    uint32_t b0 = 0;
+    if (lane == 0) b0 = atomicAdd(a.cand_cnt + st.slot, total);
+    const uint32_t gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+    auto put = [&](uint32_t slot, const SqRec &rec) {
+        if (slot >= (uint32_t)x.cap) { a.ctr->cand_ovf = 1; return; }
+        SqCand cd;
+        cd.key = rec.key; cd.len = rec.len; cd.sum32 = rec.sum; cd.flags = 0; cd.bps = 0; cd.fin = 0;
+        a.cands[st.cand_off + slot] = cd;
+    };
+    if (pc >= 1) put(gbase + (uint32_t)__popcll(m1 & lt), L.priv[0][lane]);
+    if (pc >= 2) put(gbase + n1 + (uint32_t)__popcll(m2 & lt), L.priv[1][lane]);
+    for (uint32_t k = lane; k < novf; k += 64) put(gbase + n1 + n2 + k, L.ovf[k]);
 }
+
+size_t sq_scan_lds_fixed() { return sizeof(SqScanLds); }
+int sq_scan_seg() { return SQ_SEG; }
 
 // ------------------------------------------------------------------------------------
 // a-4..a-6  exact rescoring + ScoreStems closed form + range filter (one block per structure)

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Small driver for profiling: folds NSEQ random sequences of length N (c=fastest pl=1) once or
+twice so rocprofv3 sees the scan kernel in its HBM-streaming regime."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from squarna_amd.config import ParseConfig, builtin_config
+from squarna_amd.engine import Batch, Prepared
+
+nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+names, psets = ParseConfig(builtin_config("fastest"))
+rng = np.random.default_rng(1000)
+seqs = ["".join(rng.choice(list("ACGU"), n)) for _ in range(nseq)]
+with Batch([Prepared(s) for s in seqs], [psets] * nseq, max_structs=nseq) as b:
+    b.profile(True)
+    for r in range(reps):
+        b.profile_reset()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        b.fold(poollim=1)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        ms, launches, by = b.profile_get(2)
+        print("fold %.2f ms; scan %.3f ms over %d launches, %.1f GB/s algorithmic" % (dt * 1e3, ms, launches, by / ms / 1e6))
