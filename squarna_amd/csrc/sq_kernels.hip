@@ -194,10 +194,14 @@ extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, co
 // ------------------------------------------------------------------------------------
 // a-2  stem scan.  One wave (64-thread block) = 256 anti-diagonals (4 per lane) x SQ_SEG rows.
 //
+//  * the kernel is bound by per-wave instruction latency, not by HBM latency (rocprof:
+//    profiles/), so everything is arranged for OCCUPANCY: <= 64 VGPRs and ~4.5 KiB of LDS per
+//    wave (8 waves per SIMD); rows are prefetched SQ_DEPTH deep straight into registers with
+//    16-byte aligned global_load_dwordx4 (hipcc's counted vmcnt), no LDS staging of the matrix;
 //  * rows of the segment that the current structure masks are dropped up front (a masked
-//    row only ends every open run); the remaining rows are streamed HBM -> LDS with LDS-DMA
-//    (global_load_lds_dwordx4: 1 KiB per row, SQ_RING rows in flight, counted vmcnt), lanes
-//    whose four diagonals do not reach a row skip their 16 bytes;
+//    row only ends every open run); the compacted row list lives in two VGPRs (row q is read
+//    with v_readlane), lanes whose diagonals do not reach a row re-read a neighbour's address
+//    (coalesced away), so HBM traffic stays ~1.05x the algorithmic N^2/2 cells;
 //  * the column mask codes of the wave's window live in LDS as four byte-shifted copies, so
 //    the four codes a lane needs for a row are ONE aligned ds_read_b32;
 //  * the run state (len, sum) of the four diagonals stays in registers; a run belongs to the
@@ -208,31 +212,26 @@ extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, co
 //    and are appended to the structure's candidate array with one global atomic per wave.
 // ------------------------------------------------------------------------------------
 #ifndef SQ_SEG
-#define SQ_SEG 128
+#define SQ_SEG 120
 #endif
-#ifndef SQ_RING
-#define SQ_RING 4
+#ifndef SQ_DEPTH
+#define SQ_DEPTH 3                                    // rows in flight per wave
 #endif
 #ifndef SQ_TAILROWS
 #define SQ_TAILROWS 4
 #endif
-#define SQ_MAXROWS (SQ_SEG + SQ_TAILROWS + 1)        // + the row above the segment
-#define SQ_ROWCAP (SQ_MAXROWS + 3)
-#ifndef SQ_KPRIV
+#define SQ_MAXROWS (SQ_SEG + SQ_TAILROWS + 1)        // + the row above the segment; must be <= 128
 #define SQ_KPRIV 2
-#endif
 #define SQ_OVF 32
-#define SQ_COLW ((256 + SQ_MAXROWS + 3) / 4 + 3)       // dwords per shifted copy of the column codes
+#define SQ_COLW ((256 + SQ_MAXROWS + 3) / 4 + 3)      // dwords per shifted copy of the column codes
 #define SQ_FOREIGN (-(1 << 24))                       // len of a run owned by another wave
 
 struct SqRec { uint32_t key, len; float sum; uint32_t pad; };
 
 struct SqScanLds {      // LDS of one wave
-    float ring[SQ_RING][256];            // 8 KiB   DMA ring, one row per slot
-    SqRec priv[SQ_KPRIV][64];            // 2 KiB   lane-private candidate slots
+    SqRec priv[SQ_KPRIV][64];            // 2 KiB   lane-private candidate slots (rows list during set-up)
     SqRec ovf[SQ_OVF];                   // 512 B   shared overflow list
     uint32_t ovf_count, pad0[3];
-    uint32_t rows[SQ_ROWCAP];            // (row << 8) | mask code of the row
     uint32_t ecol[4][SQ_COLW];           // byte-shifted copies of the column mask codes
 };
 
@@ -247,40 +246,31 @@ __device__ __forceinline__ void sq_emit_global(const SqScanArgs &a, const SqStru
 }
 
 struct SqScanCtx {      // per-wave constants of the row walk
-    uint32_t lds_priv, lds_ovf, lds_ovfcnt;   // LDS byte addresses (inline-asm DS ops, see sq_emit)
+    SqScanLds *L;
     int sl, n, cap, minlen_i, lane;
     float maxabs, minscore_f;
 };
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
 // run [rend-len, rend) on diagonal s ended with len >= minlen.  fp32 prefilter with a rigorous
 // rounding margin (|fp32 sum - exact| <= len^2 * maxabs * 2^-24); the exact fp64 test of
-// SQRNdbnseq.py:492 is in sq_score_kernel.  All LDS traffic here is inline asm: hipcc would
-// otherwise drain the LDS-DMA queue (s_waitcnt vmcnt(0)) in front of every LDS access it
-// cannot prove disjoint from the ring.
+// SQRNdbnseq.py:492 is in sq_score_kernel.
 __device__ __forceinline__ void sq_emit(const SqScanCtx &x, const SqScanArgs &a, const SqStruct &st, int &pc, int s,
                                         int rend, int len, float sum)
 {
     const float ll = (float)len * (float)len;
     const float ub = fmaf(ll * x.maxabs, 2.4e-07f, sum);
     if (!(ub >= x.minscore_f)) return;
-    const uint32_t key = ((uint32_t)s << 16) | (uint32_t)(rend - len);
-    const u32x4 rec = {key, (uint32_t)len, __float_as_uint(sum), 0u};
+    SqRec rec;
+    rec.key = ((uint32_t)s << 16) | (uint32_t)(rend - len);
+    rec.len = (uint32_t)len; rec.sum = sum; rec.pad = 0;
     if (pc < SQ_KPRIV) {
-        const uint32_t addr = x.lds_priv + ((uint32_t)pc * 64u + (uint32_t)x.lane) * 16u;
-        asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(rec) : "memory");
+        x.L->priv[pc][x.lane] = rec;
         pc++;
         return;
     }
-    uint32_t slot;
-    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(x.lds_ovfcnt), "v"(1u) : "memory");
-    if (slot < SQ_OVF) {
-        const uint32_t addr = x.lds_ovf + slot * 16u;
-        asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(rec) : "memory");
-    } else {
-        sq_emit_global(a, st, x.cap, key, (uint32_t)len, sum);
-    }
+    const uint32_t slot = atomicAdd(&x.L->ovf_count, 1u);              // LDS atomic
+    if (slot < SQ_OVF) x.L->ovf[slot] = rec;
+    else sq_emit_global(a, st, x.cap, rec.key, rec.len, sum);
 }
 
 // MODE 0: row inside the segment; 1: row past the segment (runs may continue, not start);
@@ -335,18 +325,12 @@ __device__ __forceinline__ void sq_end_all(const SqScanCtx &x, const SqScanArgs 
     for (int k = 0; k < 4; k++) { len[k] = 0; sum[k] = 0.f; }
 }
 
-__device__ __forceinline__ void sq_dma_row(const float *gsrc, float *lds_row, bool lane_on)
+#ifndef SQ_WPS
+#define SQ_WPS 6
+#endif
+extern "C" __global__ __launch_bounds__(64, SQ_WPS) void sq_scan_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
 {
-    // LDS-DMA: lane l's 16 bytes land at lds_row + 16*l (wave-uniform base in M0); lanes whose
-    // diagonals do not reach the row are masked off and fetch nothing.  At least one lane is
-    // always on for a row of the band, so the instruction is issued and counted by vmcnt.
-    if (lane_on)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                         (__attribute__((address_space(3))) void *)lds_row, 16, 0, 0);
-}
-
-extern "C" __global__ __launch_bounds__(64) void sq_scan_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
-{
+    static_assert(SQ_MAXROWS <= 128, "row list is kept in two VGPRs");
     __shared__ __attribute__((aligned(16))) SqScanLds L;
     const SqStruct st = structs[blockIdx.x];
     const SqJob jb = c.jobs[st.job];
@@ -368,10 +352,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan_kernel(SqDevCtx c, cons
 
     const SqPsetDev *ps = c.psets + jb.pset;
     SqScanCtx x;
-    x.lds_priv = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) SqRec *)&L.priv[0][0];
-    x.lds_ovf = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) SqRec *)&L.ovf[0];
-    x.lds_ovfcnt = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&L.ovf_count;
-    x.sl = s0 + 4 * lane; x.n = n; x.cap = jb.cand_cap; x.lane = lane;
+    x.L = &L; x.sl = s0 + 4 * lane; x.n = n; x.cap = jb.cand_cap; x.lane = lane;
     x.minlen_i = max(1, (int)ceil(ps->minlen)); x.maxabs = jb.maxabs;
     {
         const float ms = (float)ps->minbpscore;
@@ -381,17 +362,14 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan_kernel(SqDevCtx c, cons
     int lo[4], len[4];
     unsigned span[4];
     float sum[4];
-    int llo = 0x3fffffff, lhi = -1;                                     // rows some diagonal of this lane reaches
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int s = x.sl + k;
         const bool ok = s >= 4 && s <= 2 * n - 6;
         lo[k] = ok ? max(0, s - (n - 1)) : 0x3fffffff;
         span[k] = ok ? (unsigned)(((s - 1) >> 1) - lo[k]) : 0u;
-        if (ok) { llo = min(llo, lo[k]); lhi = max(lhi, (s - 1) >> 1); }
         len[k] = 0; sum[k] = 0.f;
     }
-    const unsigned lspan = lhi >= llo ? (unsigned)(lhi - llo) : 0u;
     // rows where every cell of the wave exists (no staircase): lo of the last diagonal .. hi of the first
     const bool fullband = s0 >= 4 && s0 + 255 <= 2 * n - 6;
     const int wlo = fullband ? max(0, s0 + 255 - (n - 1)) : 0x3fffffff;
@@ -401,14 +379,16 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan_kernel(SqDevCtx c, cons
     const uint8_t *eg = stt.E8 + (int64_t)st.slot * stt.stride * 2;
     const int r0 = rbeg > rmin ? rbeg - 1 : rbeg;
     const int rhi = min(rmax, rend + SQ_TAILROWS - 1);
+    uint32_t *rowlist = reinterpret_cast<uint32_t *>(&L.priv[0][0]);    // borrowed until the first candidate
     if (lane == 0) L.ovf_count = 0;
     int cnt = 0;
-    for (int c0 = r0; c0 <= rhi; c0 += 64) {
-        const int row = c0 + lane;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int row = r0 + 64 * h + lane;
         const uint32_t code = row <= rhi ? (uint32_t)eg[row] : 255u;
         const bool ok = code != 255u;
         const unsigned long long m = __ballot(ok);
-        if (ok) L.rows[cnt + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)row << 8) | code;
+        if (ok) rowlist[cnt + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)row << 8) | code;
         cnt += __popcll(m);
     }
     // ---- column mask codes of the window [jb0, jb0 + 4*SQ_COLW): copy c, dword m = codes jb0+4m+c .. +3
@@ -425,51 +405,53 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan_kernel(SqDevCtx c, cons
         L.ecol[cpy][m] = w;
     }
     __syncthreads();      // single wave: orders the LDS writes above before the reads below
-
-    const float *base = c.mat32 + jb.mat_off + x.sl;     // cell (r, sl - r) at float offset r*(ld-1) + sl: 16-B aligned
-    const int64_t pitch = ld - 1;
-    float *ring = &L.ring[0][0];
-    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)ring + (uint32_t)lane * 16u;
-    const uint32_t rows_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&L.rows[0];
-    const uint32_t ecol_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&L.ecol[0][0] + (uint32_t)lane * 4u;
-
-    auto row_at = [&](int q) -> uint32_t {             // uniform LDS read through asm (see sq_emit)
-        uint32_t w;
-        const uint32_t ad = rows_lds + (uint32_t)q * 4u;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(ad) : "memory");
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+    const uint32_t rowsA = lane < cnt ? rowlist[lane] : 0u;             // entry q lives in lane q & 63
+    const uint32_t rowsB = lane + 64 < cnt ? rowlist[lane + 64] : 0u;
+    __syncthreads();      // rowlist (aliases priv) is dead from here on
+    auto row_at = [&](int q) -> uint32_t {
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)rowsA, q & 63);
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_readlane((int)rowsB, q & 63);
+        return q < 64 ? lo_ : hi_;
     };
-    auto issue = [&](int q) {
-        const int row = (int)(row_at(q) >> 8);
-        sq_dma_row(base + (int64_t)row * pitch, ring + (q & (SQ_RING - 1)) * 256, (unsigned)(row - llo) <= lspan);
+
+    // cell (r, sl - r) sits at float offset r*(ld-1) + sl: 16-byte aligned for every row.  A lane whose
+    // four diagonals miss row r reads the nearest 16-byte group that does reach it (same cache line as
+    // a neighbour lane: no extra traffic, value unused).
+    const float *mat = c.mat32 + jb.mat_off;
+    const int pitch = ld - 1;
+    auto load_row = [&](int q) -> float4 {
+        const int row = (int)(row_at(min(q, cnt - 1)) >> 8);
+        const int sfirst = max((2 * row + 1) & ~3, s0), slast = min((row + n - 1) & ~3, s0 + 252);
+        const int sc = min(max(x.sl, sfirst), slast);
+        return *reinterpret_cast<const float4 *>(mat + (int64_t)row * pitch + sc);
     };
-    for (int q = 0; q < SQ_RING && q < cnt; q++) issue(q);
 
     int pc = 0;                       // lane-private candidates staged so far
     int prev = r0 - 1;
-    for (int q = 0; q < cnt; q++) {
-        const uint32_t rc = row_at(q);
-        const int row = (int)(rc >> 8);
-        const uint32_t er = rc & 0xFFu;
-        // entry q has landed once at most SQ_RING-1 younger DMAs are outstanding (in-order completion)
-        if (q + SQ_RING <= cnt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SQ_RING - 1) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float4 v;
-        uint32_t ecodes;
-        const uint32_t addr = ring_lds + (uint32_t)(q & (SQ_RING - 1)) * 1024u;
-        const int d = rhi - row;
-        const uint32_t eaddr = ecol_lds + (uint32_t)(d & 3) * (SQ_COLW * 4u) + (uint32_t)(d >> 2) * 4u;
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(v), "=&v"(ecodes) : "v"(addr), "v"(eaddr) : "memory");
-        if (q + SQ_RING < cnt) issue(q + SQ_RING);                      // slot is free again: keep the ring full
-        if (row != prev + 1) sq_end_all(x, a, st, pc, prev + 1, len, sum);   // masked rows in between (:446-451)
-        const bool interior = row >= wlo && row <= whi;
-        if (row < rbeg) sq_row<2, true>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
-        else if (row < rend) {
-            if (interior) sq_row<0, false>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
-            else sq_row<0, true>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
-        } else sq_row<1, true>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
-        prev = row;
+    float4 buf[SQ_DEPTH];
+#pragma unroll
+    for (int u = 0; u < SQ_DEPTH; u++) buf[u] = load_row(u);
+    for (int q0 = 0; q0 < cnt; q0 += SQ_DEPTH) {
+#pragma unroll
+        for (int u = 0; u < SQ_DEPTH; u++) {
+            const int q = q0 + u;
+            if (q >= cnt) break;
+            const float4 v = buf[u];
+            buf[u] = load_row(q + SQ_DEPTH);                            // keep SQ_DEPTH rows in flight
+            const uint32_t rc = row_at(q);
+            const int row = (int)(rc >> 8);
+            const uint32_t er = rc & 0xFFu;
+            const int d = rhi - row;
+            const uint32_t ecodes = L.ecol[d & 3][(d >> 2) + lane];
+            if (row != prev + 1) sq_end_all(x, a, st, pc, prev + 1, len, sum);   // masked rows in between (:446-451)
+            const bool interior = row >= wlo && row <= whi;
+            if (row < rbeg) sq_row<2, true>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
+            else if (row < rend) {
+                if (interior) sq_row<0, false>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
+                else sq_row<0, true>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
+            } else sq_row<1, true>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
+            prev = row;
+        }
     }
     if (prev != rhi) sq_end_all(x, a, st, pc, prev + 1, len, sum);       // trailing masked rows
     // runs that are still open: beyond the pipelined tail (rare) or at the end of the diagonals
@@ -478,8 +460,9 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan_kernel(SqDevCtx c, cons
         uint32_t er = 255u;
         if (r <= rmax) er = (uint32_t)__builtin_amdgcn_readfirstlane((int)eg[r]);
         if (er == 255u) { sq_end_all(x, a, st, pc, r, len, sum); break; }
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)(r - llo) <= lspan) v = *reinterpret_cast<const float4 *>(base + (int64_t)r * pitch);
+        const int sfirst = max((2 * r + 1) & ~3, s0), slast = min((r + n - 1) & ~3, s0 + 252);
+        const int sc = min(max(x.sl, sfirst), slast);
+        const float4 v = *reinterpret_cast<const float4 *>(mat + (int64_t)r * pitch + sc);
         uint32_t ecodes = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
