@@ -342,6 +342,30 @@ class HipEngine:
             return [b.result(k) for k in range(len(records))]
 
 
+    def entropy(self, record, interchainonly=False):
+        """Mean row entropy of the stem matrix under the FIRST paramset, as a string
+        (SQRNdbnseq.py:520-545, 1087-1089); the stems come from the GPU scan (mode 1)."""
+        seq, reacts, restraints, dbn, paramsets = record[:5]
+        p = Prepared(seq, reacts, restraints, dbn)
+        ps = paramsets[0]
+        with Batch([p], [[ps]], interchainonly=interchainonly, max_structs=self.max_structs,
+                   cand_per_nt=max(self.cand_per_nt, 64)) as b:
+            stems = b.optimal([0], [[]], mode=1)[0]
+        n = len(p.shortseq)
+        sm = np.zeros((n, n))
+        for i, j, ln, sc, _ in stems:
+            for k in range(ln):
+                sm[i + k, j - k] = sc
+                sm[j - k, i + k] = sc
+        ent = 0
+        for i in range(n):
+            row = sm[i, :]
+            if row.sum():
+                probs = [q for q in row / row.sum() if q]
+                ent += sum(-(probs * np.log2(probs)))
+        return str(round(ent / n, 3))
+
+
 _engine = None
 
 

@@ -1,0 +1,22 @@
+"""Test-only engine: same interface as squarna_amd.engine.HipEngine, answers come from the
+CPU oracle.  Installed with squarna_amd.engine.use_engine() by CPU tests to check the
+host-side text layer (parsers, Predict, RunSQRNdbnseq printing) against the golden texts.
+The product never imports this."""
+from oracle import sqrn_oracle as O
+
+
+class OracleEngine:
+    name = "oracle"
+
+    def fold_records(self, records, **opts):
+        out = []
+        for rec in records:
+            seq, reacts, restraints, dbn, paramsets = rec[:5]
+            sm = rec[5] if len(rec) > 5 else None
+            out.append(O.SQRNdbnseq(seq, reacts, restraints, dbn, paramsets, stemmatrix=sm, **opts))
+        return out
+
+    def entropy(self, record, interchainonly=False):
+        seq, reacts, restraints, dbn, paramsets = record[:5]
+        return O.SQRNdbnseq(seq, reacts, restraints, dbn, paramsets, entropy=True,
+                            interchainonly=interchainonly)

@@ -184,3 +184,49 @@ def test_edge_cases():
         exp = O.SQRNdbnseq(r[0], None, None, None, psets)
         exp = [exp[0], [[d, list(s), list(p)] for d, s, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
         _same_fold(g, exp, r[0])
+
+
+# ---- end-to-end text: Predict() on the HIP engine == the reference's own output, byte for byte
+GPU_TEXT = ["s16_fastest", "shape_input_fastest", "shape_input_alt_rf26", "seq_input_entropy",
+            "seq_input_ico", "seq_input_greedynobpp_rf10", "seq_input_evalonly", "SRtest150_fastest",
+            "SRtest150_fastest_pl1", "SRtest150_alt", "SRtest150_greedynobpp"]
+
+
+@pytest.mark.parametrize("tag", GPU_TEXT)
+def test_predict_text_matches_reference_on_gpu(tag):
+    import hashlib
+    import io
+    from squarna_amd import Predict
+    with open(os.path.join(GOLDEN, "digests.json")) as f:
+        dig = json.load(f)[tag]
+    kw = dict(dig["args"])
+    if "inputfile" in kw:
+        kw["inputfile"] = os.path.join(os.path.dirname(GOLDEN), "..", "squarna_amd", "data", kw["inputfile"])
+    buf = io.StringIO()
+    Predict(write_to=buf, **kw)
+    txt = buf.getvalue()
+    with open(os.path.join(GOLDEN, "text", tag + ".txt")) as f:
+        exp = f.read()
+    if txt != exp:
+        tl, el = txt.split("\n"), exp.split("\n")
+        bad = [(k, a, b) for k, (a, b) in enumerate(zip(tl, el)) if a != b][:3]
+        raise AssertionError("text differs (%d vs %d lines): %r" % (len(tl), len(el), bad))
+    assert hashlib.sha256(txt.encode()).hexdigest() == dig["sha256"]
+
+
+def test_api_shims_match_oracle():
+    """BPMatrix / AnnotateStems / OptimalStems with the reference's signatures."""
+    import squarna_amd as S
+    from oracle import sqrn_oracle as O
+    w = {"GC": 3.25, "AU": 1.25, "GU": -1.25}
+    seq = "GGGAAAUCCCGCGAAAGCGUUUACGC"
+    b, s = S.BPMatrix(seq, w, {3}, {20}, set())
+    ob, os_ = O.BPMatrix(seq, w, {3}, {20}, set())
+    assert (b == ob).all() and np.allclose(s, os_, rtol=1e-12, atol=0)
+    stems = S.AnnotateStems(ob, os_, set(), [], 2, 0)
+    exp = O.AnnotateStems(ob, os_, set(), [], 2, 0)
+    assert [(st[0][0][0], st[0][0][1], st[1], st[2]) for st in stems] == exp
+    got = S.OptimalStems(seq, [], ob, os_, [0.5] * len(seq), set(), 0.8, 2, 4.5, 4.5, -2.0, 0.09, 1.0, 0.125)
+    exp = O.OptimalStems(seq, [], ob, os_, [0.5] * len(seq), set(), 0.8, 2, 4.5, 4.5, -2.0, 0.09, 1.0, 0.125)
+    assert [(st[0][0][0], st[0][0][1], st[1]) for st in got] == [e[:3] for e in exp]
+    assert all(abs(st[3] - e[4]) <= TOL for st, e in zip(got, exp))
