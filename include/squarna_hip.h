@@ -146,6 +146,16 @@ SQ_API int sq_optimal_stems(sq_batch *b, int32_t nstruct, const int32_t *struct_
                      const sq_stem *stems, const double *subopt, int32_t mode,
                      sq_stem *out, int32_t out_cap, int32_t *out_off);
 
+/* ---- a-8 / a-9 (+ Nussinov)  RunAlgo with Hungarian / Edmonds / Nussinov -------------------
+ * (SQRNdbnseq.py:548-595, SQRNalgos.py:44-135).  For each listed job: AnnotateStems with no
+ * selected stems, then the matching / DP on the device -- scipy's linear_sum_assignment and
+ * networkx's max_weight_matching restated step by step, so ties resolve as in the reference --
+ * then RunAlgo's stem filters.  algo is ONE of SQ_ALGO_E / SQ_ALGO_H / SQ_ALGO_N;
+ * levellimit < 0 selects the default 3 - (N > 500).  out gets each job's stemset
+ * (bpscore = finscore = raw stem score).  Synchronises the stream. */
+SQ_API int sq_run_algos(sq_batch *b, int32_t njob, const int32_t *job_ids, int32_t algo, int32_t levellimit,
+                        sq_stem *out, int32_t out_cap, int32_t *out_off);
+
 /* ---- a-7 + a-10  greedy pool loop and the ranking tail of SQRNdbnseq ---------------
  * (SQRNdbnseq.py:1048-1286).  Folds every sequence of the batch under its jobs and
  * keeps the per-sequence results inside the batch for the getters below.

@@ -18,8 +18,7 @@ SYMBOLS = ["sq_version", "sq_last_error", "sq_batch_workspace_bytes", "sq_batch_
            "sq_batch_destroy", "sq_bpmatrix_fill", "sq_bpmatrix_read", "sq_optimal_stems",
            "sq_fold", "sq_result_nstruct", "sq_result_consensus", "sq_result_struct",
            "sq_result_metrics", "sq_result_evals", "sq_result_pack_size", "sq_result_pack",
-           "sq_profile_enable", "sq_profile_get", "sq_profile_reset"
-           ]
+           "sq_profile_enable", "sq_profile_get", "sq_profile_reset", "sq_run_algos"]
 
 
 class ParamSet(C.Structure):
@@ -102,6 +101,8 @@ def load():
     L.sq_profile_get.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                  C.POINTER(C.c_double)]
     L.sq_profile_reset.argtypes = [C.c_void_p]
+    L.sq_run_algos.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                               C.c_void_p]
     _lib = L
     return L
 

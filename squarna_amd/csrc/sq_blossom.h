@@ -1,0 +1,506 @@
+// sq_blossom.h -- Edmonds maximum-weight matching for a-9 (SQRNalgos.py:96-110).
+//
+// The reference calls networkx.max_weight_matching(G) (networkx 3.4.2, pure Python, not
+// vendored: Galil's O(n^3) blossom algorithm with dual variables, maxcardinality=False).
+// 43 % of the SRtest150 inputs have a non-unique optimum, so this is a
+// step-exact restatement: same vertex order (insertion order of the edge list), same
+// neighbour order, same LIFO queue, same traversal of blossom leaves, same strict-< tie
+// rules and the same fp64 operation order for slacks and deltas.  Python's insertion-ordered
+// dicts become arrays + an ordered list of live blossoms; the two recursive generators
+// (expandBlossom, augmentBlossom) become explicit stacks; a blossom's childs/edges lists are
+// a cyclic doubly linked list through its children (rotation == moving `first`).
+//
+// Host+device inline code: the product runs it in sq_mwm_kernel (one thread per job); the
+// test suite also compiles it on the host to compare with networkx directly.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "sq_match.h"
+
+#ifdef __HIPCC__
+#define SQ_HD __host__ __device__
+#else
+#define SQ_HD
+#endif
+
+struct SqBlossom {
+    // graph
+    int n, m;                 // vertices (graph order), undirected edges
+    const SqMatchEdge *E;     // E[e] = (v, w, weight), vertex ids in graph order
+    int *adj_off, *adj;       // CSR, directed edge codes (2e | dir) in neighbour insertion order
+    // state (index: vertex 0..n-1, blossom n..2n-1)
+    int *mate;                // mate vertex or -1 (output)
+    int *mate_de;             // directed edge v -> mate[v]
+    int8_t *label;            // 0 none, 1 S, 2 T, 5 scanned mark
+    int *labeledge, *inblossom, *parent, *base, *bestedge;
+    double *dualvar, *bdual;
+    uint8_t *allow;           // per undirected edge
+    int *queue; int qn, qcap;
+    // blossoms
+    int *sib_next, *sib_prev, *edge_after, *first, *nchild;
+    int *mbe_off, *mbe_cnt;   // mybestedges (cnt < 0: None)
+    int *pool; int pool_n, pool_cap;
+    int *live; int nlive;     // live blossoms in creation order (dict order of blossomparent/blossomdual)
+    int *freeb; int nfree;
+    // temporaries
+    int *tmp_leaves, *tmp_stack, *tmp_path, *tmp_edges, *beto, *beto_keys, *frames;
+    int error;
+
+    SQ_HD static size_t scratch_bytes(int n, int m)
+    {
+        const size_t N2 = 2 * (size_t)n + 2;
+        size_t ints = (size_t)n + 1 + 2 * (size_t)m            // adj_off, adj
+                      + 2 * (size_t)n                           // mate, mate_de
+                      + 4 * N2 + (size_t)n                      // labeledge, parent, base, bestedge, inblossom
+                      + (8 * (size_t)n + 2 * (size_t)m + 16)    // queue
+                      + 7 * N2                                  // sib_next, sib_prev, edge_after, first, nchild, mbe_off, mbe_cnt
+                      + ((size_t)n * 32 + 2 * (size_t)m + 1024) // pool
+                      + 2 * (size_t)n + 2                       // live, freeb
+                      + 2 * N2 + 4 * N2 + 2 * N2                // tmp_leaves, tmp_stack | tmp_path, tmp_edges (2 each) | beto, beto_keys
+                      + 10 * N2;                                // frames
+        return ints * 4 + ((size_t)n + N2) * 8 + N2 + (size_t)m + 256;
+    }
+
+    SQ_HD void init(int n_, int m_, const SqMatchEdge *edges, char *scratch)
+    {
+        n = n_; m = m_; E = edges; error = 0;
+        const int N2 = 2 * n + 2;
+        char *p = scratch;
+        auto take_d = [&](size_t k) { p = (char *)(((uintptr_t)p + 7) & ~(uintptr_t)7); double *r = (double *)p; p += k * 8; return r; };
+        auto take_i = [&](size_t k) { p = (char *)(((uintptr_t)p + 3) & ~(uintptr_t)3); int *r = (int *)p; p += k * 4; return r; };
+        dualvar = take_d(n); bdual = take_d(N2);
+        adj_off = take_i(n + 1); adj = take_i(2 * (size_t)m);
+        mate = take_i(n); mate_de = take_i(n);
+        labeledge = take_i(N2); parent = take_i(N2); base = take_i(N2); bestedge = take_i(N2); inblossom = take_i(n);
+        qcap = 8 * n + 2 * m + 16; queue = take_i(qcap); qn = 0;
+        sib_next = take_i(N2); sib_prev = take_i(N2); edge_after = take_i(N2); first = take_i(N2); nchild = take_i(N2);
+        mbe_off = take_i(N2); mbe_cnt = take_i(N2);
+        pool_cap = n * 32 + 2 * m + 1024; pool = take_i(pool_cap); pool_n = 0;
+        live = take_i(n + 1); freeb = take_i(n + 1);
+        tmp_leaves = take_i(N2); tmp_stack = take_i(N2); tmp_path = take_i(2 * (size_t)N2); tmp_edges = take_i(2 * (size_t)N2);
+        beto = take_i(N2); beto_keys = take_i(N2); frames = take_i(10 * (size_t)N2);
+        label = (int8_t *)p; p += N2; allow = (uint8_t *)p; p += m;
+        // adjacency in insertion order: edge e = (v, w) appends w to adj[v] and v to adj[w]
+        for (int v = 0; v <= n; v++) adj_off[v] = 0;
+        for (int e = 0; e < m; e++) { adj_off[E[e].v + 1]++; adj_off[E[e].w + 1]++; }
+        for (int v = 0; v < n; v++) adj_off[v + 1] += adj_off[v];
+        for (int v = 0; v < n; v++) mate[v] = 0;                 // used as fill cursor
+        for (int e = 0; e < m; e++) {
+            adj[adj_off[E[e].v] + mate[E[e].v]++] = 2 * e;
+            adj[adj_off[E[e].w] + mate[E[e].w]++] = 2 * e + 1;
+        }
+    }
+
+    SQ_HD int tail(int de) const { return (de & 1) ? E[de >> 1].w : E[de >> 1].v; }
+    SQ_HD int head(int de) const { return (de & 1) ? E[de >> 1].v : E[de >> 1].w; }
+    SQ_HD double slack(int de) const { return dualvar[tail(de)] + dualvar[head(de)] - 2 * E[de >> 1].weight; }
+    SQ_HD bool is_blossom(int x) const { return x >= n; }
+    SQ_HD void qpush(int v) { if (qn < qcap) queue[qn++] = v; else error = 1; }
+
+    // Blossom.leaves(): stack = [*childs]; pop from the end; sub-blossoms push their childs
+    SQ_HD int leaves(int b, int *out)
+    {
+        int sn = 0, cnt = 0;
+        int c = first[b];
+        for (int k = 0; k < nchild[b]; k++) { tmp_stack[sn++] = c; c = sib_next[c]; }
+        while (sn) {
+            const int t = tmp_stack[--sn];
+            if (is_blossom(t)) {
+                int cc = first[t];
+                for (int k = 0; k < nchild[t]; k++) { tmp_stack[sn++] = cc; cc = sib_next[cc]; }
+            } else out[cnt++] = t;
+        }
+        return cnt;
+    }
+
+    SQ_HD void assignLabel(int w, int t, int de)       // de: labeledge (v, w) or -1
+    {
+        for (;;) {
+            const int b = inblossom[w];
+            label[w] = label[b] = (int8_t)t;
+            labeledge[w] = labeledge[b] = de;
+            bestedge[w] = bestedge[b] = -1;
+            if (t == 1) {
+                if (is_blossom(b)) {
+                    const int c = leaves(b, tmp_leaves);
+                    for (int k = 0; k < c; k++) qpush(tmp_leaves[k]);
+                } else qpush(b);
+                return;
+            }
+            // t == 2: the mate of the base becomes an S-vertex
+            const int bs = base[b];
+            de = mate_de[bs];                            // (base, mate[base])
+            w = mate[bs]; t = 1;
+        }
+    }
+
+    SQ_HD int scanBlossom(int v, int w)
+    {
+        int pn = 0, bs = -1;
+        while (v != -1) {
+            int b = inblossom[v];
+            if (label[b] & 4) { bs = base[b]; break; }
+            tmp_path[pn++] = b;
+            label[b] = 5;
+            if (labeledge[b] == -1) v = -1;
+            else {
+                v = tail(labeledge[b]);
+                b = inblossom[v];
+                v = tail(labeledge[b]);
+            }
+            if (w != -1) { const int t = v; v = w; w = t; }
+        }
+        for (int k = 0; k < pn; k++) label[tmp_path[k]] = 1;
+        return bs;
+    }
+
+    SQ_HD int new_blossom() { if (nfree == 0) { error = 2; return n; } return freeb[--nfree]; }
+
+    SQ_HD void addBlossom(int bs, int de)               // de = (v, w)
+    {
+        int v = tail(de), w = head(de);
+        const int bb = inblossom[bs];
+        int bv = inblossom[v], bw = inblossom[w];
+        const int b = new_blossom();
+        base[b] = bs; parent[b] = -1; parent[bb] = b;
+        live[nlive++] = b;
+        int *path = tmp_path, *edgs = tmp_edges;          // python lists
+        int pn = 0, en = 0;
+        edgs[en++] = de;
+        while (bv != bb) {
+            parent[bv] = b;
+            path[pn++] = bv;
+            edgs[en++] = labeledge[bv];
+            v = tail(labeledge[bv]);
+            bv = inblossom[v];
+        }
+        path[pn++] = bb;
+        for (int a = 0, z = pn - 1; a < z; a++, z--) { const int t = path[a]; path[a] = path[z]; path[z] = t; }
+        for (int a = 0, z = en - 1; a < z; a++, z--) { const int t = edgs[a]; edgs[a] = edgs[z]; edgs[z] = t; }
+        while (bw != bb) {
+            parent[bw] = b;
+            path[pn++] = bw;
+            edgs[en++] = labeledge[bw] ^ 1;                // (labeledge[bw][1], labeledge[bw][0])
+            w = tail(labeledge[bw]);
+            bw = inblossom[w];
+        }
+        // childs = path, edges = edgs (edges[i] joins childs[i] -> childs[i+1], cyclically)
+        nchild[b] = pn; first[b] = path[0];
+        for (int k = 0; k < pn; k++) {
+            sib_next[path[k]] = path[(k + 1) % pn];
+            sib_prev[path[k]] = path[(k + pn - 1) % pn];
+            edge_after[path[k]] = edgs[k];
+        }
+        label[b] = 1;
+        labeledge[b] = labeledge[bb];
+        bdual[b] = 0;
+        {
+            const int c = leaves(b, tmp_leaves);
+            for (int k = 0; k < c; k++) {
+                const int x = tmp_leaves[k];
+                if (label[inblossom[x]] == 2) qpush(x);
+                inblossom[x] = b;
+            }
+        }
+        // bestedgeto: dict bj -> edge (insertion ordered)
+        int nk = 0;
+        for (int k = 0; k < pn; k++) {
+            const int cv = path[k];
+            // nblist
+            int lstart = pool_n, lcount = 0; bool from_pool = false;
+            if (is_blossom(cv) && mbe_cnt[cv] >= 0) {
+                lstart = mbe_off[cv]; lcount = mbe_cnt[cv]; from_pool = true;
+                mbe_cnt[cv] = -1;
+            }
+            int nleaf = 1;
+            if (!from_pool) {
+                if (is_blossom(cv)) nleaf = leaves(cv, tmp_leaves); else tmp_leaves[0] = cv;
+            }
+            int li = 0, ai = 0;                             // iterate nblist lazily
+            for (;;) {
+                int kde;
+                if (from_pool) {
+                    if (li >= lcount) break;
+                    kde = pool[lstart + li++];
+                } else {
+                    if (li >= nleaf) break;
+                    const int x = tmp_leaves[li];
+                    if (ai >= adj_off[x + 1] - adj_off[x]) { li++; ai = 0; continue; }
+                    kde = adj[adj_off[x] + ai++];
+                }
+                int i = tail(kde), j = head(kde);
+                if (inblossom[j] == b) { const int t = i; i = j; j = t; }
+                const int bj = inblossom[j];
+                if (bj != b && label[bj] == 1) {
+                    const int ide = (tail(kde) == i) ? kde : (kde ^ 1);   // slack(i, j)
+                    if (beto[bj] == -1) { beto[bj] = kde; beto_keys[nk++] = bj; }
+                    else if (slack(ide) < slack(beto[bj])) beto[bj] = kde;
+                }
+            }
+            bestedge[cv] = -1;
+        }
+        // b.mybestedges = list(bestedgeto.values())
+        mbe_off[b] = pool_n; mbe_cnt[b] = nk;
+        int mybest = -1; double mybestslack = 0;
+        for (int k = 0; k < nk; k++) {
+            const int kde = beto[beto_keys[k]];
+            beto[beto_keys[k]] = -1;
+            if (pool_n < pool_cap) pool[pool_n++] = kde; else error = 3;
+            const double ks = slack(kde);
+            if (mybest == -1 || ks < mybestslack) { mybest = kde; mybestslack = ks; }
+        }
+        bestedge[b] = mybest;
+    }
+
+    SQ_HD void remove_live(int b)
+    {
+        int k = 0;
+        while (k < nlive && live[k] != b) k++;
+        for (; k + 1 < nlive; k++) live[k] = live[k + 1];
+        nlive--;
+        freeb[nfree++] = b;
+    }
+
+    // expandBlossom(b, endstage) with the recursion of _recurse made explicit
+    SQ_HD void expandBlossom(int b0, bool endstage)
+    {
+        int *fr = frames;                                  // frame: (b, next child, remaining)
+        int sp = 0;
+        fr[0] = b0; fr[1] = first[b0]; fr[2] = nchild[b0]; sp = 1;
+        while (sp) {
+            int *f = fr + 3 * (sp - 1);
+            const int b = f[0];
+            if (f[2] > 0) {
+                const int s = f[1];
+                f[1] = sib_next[s]; f[2]--;
+                parent[s] = -1;
+                if (is_blossom(s)) {
+                    if (endstage && bdual[s] == 0) {       // yield s: expand it now, then continue with the next child
+                        int *g = fr + 3 * sp;
+                        g[0] = s; g[1] = first[s]; g[2] = nchild[s]; sp++;
+                    } else {
+                        const int c = leaves(s, tmp_leaves);
+                        for (int k = 0; k < c; k++) inblossom[tmp_leaves[k]] = s;
+                    }
+                } else inblossom[s] = s;
+                continue;
+            }
+            if (!endstage && label[b] == 2) {
+                const int entry = inblossom[head(labeledge[b])];
+                int j = 0;
+                { int c = first[b]; while (c != entry) { c = sib_next[c]; j++; } }
+                int c = entry, jstep;
+                if (j & 1) { j -= nchild[b]; jstep = 1; } else jstep = -1;
+                int de = labeledge[b];                     // (v, w)
+                while (j != 0) {
+                    int pq;                                // directed (p, q)
+                    if (jstep == 1) pq = edge_after[c]; else pq = edge_after[sib_prev[c]] ^ 1;
+                    const int w = head(de), q = head(pq);
+                    label[w] = 0; label[q] = 0;
+                    assignLabel(w, 2, de);
+                    allow[pq >> 1] = 1;
+                    j += jstep; c = (jstep == 1) ? sib_next[c] : sib_prev[c];
+                    if (jstep == 1) de = edge_after[c]; else de = edge_after[sib_prev[c]] ^ 1;
+                    allow[de >> 1] = 1;
+                    j += jstep; c = (jstep == 1) ? sib_next[c] : sib_prev[c];
+                }
+                const int bw = c;                           // b.childs[0]
+                const int w = head(de);
+                label[w] = label[bw] = 2;
+                labeledge[w] = labeledge[bw] = de;
+                bestedge[bw] = -1;
+                c = (jstep == 1) ? sib_next[c] : sib_prev[c];
+                while (c != entry) {
+                    const int bv = c;
+                    if (label[bv] == 1) { c = (jstep == 1) ? sib_next[c] : sib_prev[c]; continue; }
+                    int v;
+                    if (is_blossom(bv)) {
+                        const int cn = leaves(bv, tmp_leaves);
+                        v = tmp_leaves[cn - 1];
+                        for (int k = 0; k < cn; k++) if (label[tmp_leaves[k]]) { v = tmp_leaves[k]; break; }
+                    } else v = bv;
+                    if (label[v]) {
+                        label[v] = 0;
+                        label[mate[base[bv]]] = 0;
+                        assignLabel(v, 2, labeledge[v]);
+                    }
+                    c = (jstep == 1) ? sib_next[c] : sib_prev[c];
+                }
+            }
+            label[b] = 0; labeledge[b] = -1; bestedge[b] = -1;
+            parent[b] = -1; base[b] = -1; bdual[b] = 0; mbe_cnt[b] = -1;
+            remove_live(b);
+            sp--;
+        }
+    }
+
+    // augmentBlossom(b, v) with explicit frames: (b, v, phase, t0, j, jstep, c, de_wx)
+    SQ_HD void augmentBlossom(int b0, int v0)
+    {
+        int *fr = frames;
+        int sp = 1;
+        fr[0] = b0; fr[1] = v0; fr[2] = 0;
+        while (sp) {
+            int *f = fr + 8 * (sp - 1);
+            const int b = f[0], v = f[1];
+            if (f[2] == 0) {
+                int t = v;
+                while (parent[t] != b) t = parent[t];
+                f[3] = t;
+                int j = 0;
+                { int c = first[b]; while (c != t) { c = sib_next[c]; j++; } }
+                if (j & 1) { f[4] = j - nchild[b]; f[5] = 1; } else { f[4] = j; f[5] = -1; }
+                f[6] = t; f[2] = 1;
+                if (is_blossom(t)) { int *g = fr + 8 * sp; g[0] = t; g[1] = v; g[2] = 0; sp++; continue; }
+            }
+            if (f[2] == 1) {                                // top of `while j != 0`
+                if (f[4] == 0) {
+                    first[b] = f[3];                        // childs = childs[i:] + childs[:i]
+                    base[b] = base[first[b]];
+                    sp--;
+                    continue;
+                }
+                const int jstep = f[5];
+                f[4] += jstep; f[6] = (jstep == 1) ? sib_next[f[6]] : sib_prev[f[6]];
+                const int t = f[6];
+                f[7] = (jstep == 1) ? edge_after[t] : (edge_after[sib_prev[t]] ^ 1);   // (w, x)
+                f[2] = 2;
+                if (is_blossom(t)) { int *g = fr + 8 * sp; g[0] = t; g[1] = tail(f[7]); g[2] = 0; sp++; continue; }
+            }
+            if (f[2] == 2) {
+                const int jstep = f[5];
+                f[4] += jstep; f[6] = (jstep == 1) ? sib_next[f[6]] : sib_prev[f[6]];
+                const int t = f[6];
+                f[2] = 3;
+                if (is_blossom(t)) { int *g = fr + 8 * sp; g[0] = t; g[1] = head(f[7]); g[2] = 0; sp++; continue; }
+            }
+            if (f[2] == 3) {
+                const int w = tail(f[7]), x = head(f[7]);
+                mate[w] = x; mate_de[w] = f[7];
+                mate[x] = w; mate_de[x] = f[7] ^ 1;
+                f[2] = 1;
+            }
+        }
+    }
+
+    SQ_HD void augmentMatching(int de)                     // (v, w)
+    {
+        for (int side = 0; side < 2; side++) {
+            int sj = side == 0 ? de : (de ^ 1);            // (s, j)
+            for (;;) {
+                const int s = tail(sj), j = head(sj);
+                const int bs = inblossom[s];
+                if (is_blossom(bs)) augmentBlossom(bs, s);
+                mate[s] = j; mate_de[s] = sj;
+                if (labeledge[bs] == -1) break;
+                const int t = tail(labeledge[bs]);
+                const int bt = inblossom[t];
+                sj = labeledge[bt];                         // s, j = labeledge[bt]
+                const int s2 = tail(sj), j2 = head(sj);
+                if (is_blossom(bt)) augmentBlossom(bt, j2);
+                mate[j2] = s2; mate_de[j2] = sj ^ 1;
+            }
+        }
+    }
+
+    SQ_HD void run()
+    {
+        const int N2 = 2 * n + 2;
+        for (int v = 0; v < n; v++) { mate[v] = -1; mate_de[v] = -1; inblossom[v] = v; }
+        for (int x = 0; x < N2; x++) {
+            label[x] = 0; labeledge[x] = -1; parent[x] = -1; base[x] = x < n ? x : -1; bestedge[x] = -1;
+            bdual[x] = 0; mbe_cnt[x] = -1; mbe_off[x] = 0; beto[x] = -1; nchild[x] = 0; first[x] = -1;
+        }
+        nlive = 0; nfree = 0;
+        for (int b = 2 * n - 1; b >= n; b--) freeb[nfree++] = b;
+        if (n == 0) return;
+        double maxweight = 0;
+        for (int e = 0; e < m; e++) if (E[e].v != E[e].w && E[e].weight > maxweight) maxweight = E[e].weight;
+        for (int v = 0; v < n; v++) dualvar[v] = maxweight;
+        for (;;) {                                          // stages
+            for (int x = 0; x < N2; x++) { label[x] = 0; labeledge[x] = -1; bestedge[x] = -1; }
+            for (int k = 0; k < nlive; k++) mbe_cnt[live[k]] = -1;
+            pool_n = 0;
+            for (int e = 0; e < m; e++) allow[e] = 0;
+            qn = 0;
+            for (int v = 0; v < n; v++)
+                if (mate[v] == -1 && label[inblossom[v]] == 0) assignLabel(v, 1, -1);
+            bool augmented = false;
+            for (;;) {                                      // substages
+                while (qn && !augmented) {
+                    const int v = queue[--qn];
+                    for (int a = adj_off[v]; a < adj_off[v + 1]; a++) {
+                        const int de = adj[a];
+                        const int w = head(de);
+                        if (w == v) continue;
+                        const int bv = inblossom[v], bw = inblossom[w];
+                        if (bv == bw) continue;
+                        double kslack = 0;
+                        if (!allow[de >> 1]) {
+                            kslack = slack(de);
+                            if (kslack <= 0) allow[de >> 1] = 1;
+                        }
+                        if (allow[de >> 1]) {
+                            if (label[bw] == 0) assignLabel(w, 2, de);
+                            else if (label[bw] == 1) {
+                                const int bs = scanBlossom(v, w);
+                                if (bs != -1) addBlossom(bs, de);
+                                else { augmentMatching(de); augmented = true; break; }
+                            } else if (label[w] == 0) {
+                                label[w] = 2; labeledge[w] = de;
+                            }
+                        } else if (label[bw] == 1) {
+                            if (bestedge[bv] == -1 || kslack < slack(bestedge[bv])) bestedge[bv] = de;
+                        } else if (label[w] == 0) {
+                            if (bestedge[w] == -1 || kslack < slack(bestedge[w])) bestedge[w] = de;
+                        }
+                    }
+                }
+                if (augmented) break;
+                int deltatype = 1, deltaedge = -1, deltablossom = -1;
+                double delta = dualvar[0];
+                for (int v = 1; v < n; v++) if (dualvar[v] < delta) delta = dualvar[v];
+                for (int v = 0; v < n; v++)
+                    if (label[inblossom[v]] == 0 && bestedge[v] != -1) {
+                        const double d = slack(bestedge[v]);
+                        if (d < delta) { delta = d; deltatype = 2; deltaedge = bestedge[v]; }
+                    }
+                for (int k = 0; k < n + nlive; k++) {        // `for b in blossomparent`: vertices, then blossoms
+                    const int b = k < n ? k : live[k - n];
+                    if (parent[b] == -1 && label[b] == 1 && bestedge[b] != -1) {
+                        const double d = slack(bestedge[b]) / 2.0;
+                        if (d < delta) { delta = d; deltatype = 3; deltaedge = bestedge[b]; }
+                    }
+                }
+                for (int k = 0; k < nlive; k++) {
+                    const int b = live[k];
+                    if (parent[b] == -1 && label[b] == 2 && bdual[b] < delta) { delta = bdual[b]; deltatype = 4; deltablossom = b; }
+                }
+                for (int v = 0; v < n; v++) {
+                    const int lb = label[inblossom[v]];
+                    if (lb == 1) dualvar[v] -= delta; else if (lb == 2) dualvar[v] += delta;
+                }
+                for (int k = 0; k < nlive; k++) {
+                    const int b = live[k];
+                    if (parent[b] == -1) { if (label[b] == 1) bdual[b] += delta; else if (label[b] == 2) bdual[b] -= delta; }
+                }
+                if (deltatype == 1) break;
+                if (deltatype == 2 || deltatype == 3) { allow[deltaedge >> 1] = 1; qpush(tail(deltaedge)); }
+                else expandBlossom(deltablossom, false);
+                if (error) return;
+            }
+            if (!augmented) break;
+            // end of stage: expand S-blossoms with zero dual (snapshot of the dict keys)
+            int snap = nlive;
+            for (int k = 0; k < snap; k++) tmp_path[k] = live[k];
+            for (int k = 0; k < snap; k++) {
+                const int b = tmp_path[k];
+                bool alive = false;
+                for (int q = 0; q < nlive; q++) if (live[q] == b) { alive = true; break; }
+                if (!alive) continue;
+                if (parent[b] == -1 && label[b] == 1 && bdual[b] == 0) expandBlossom(b, true);
+            }
+            if (error) return;
+        }
+    }
+};

@@ -99,6 +99,10 @@ int sq_check(hipError_t e, const char *what);
 // one greedy round (or a raw AnnotateStems pass) for a list of structures; results per structure
 int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out);
 
+// RunAlgo (SQRNdbnseq.py:548-595) for one of SQ_ALGO_E / H / N over a list of jobs
+int sq_run_algo(sq_batch *b, const std::vector<int> &jobs, int algo, int levellimit_opt,
+                std::vector<std::vector<HStem>> &out);
+
 // host tail: SQRNdbnseq.py:1201-1286
 void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
              const std::vector<std::vector<std::vector<HStem>>> &per_job_structs,   // [job-of-seq][structure][stem]

@@ -669,15 +669,22 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     for (int j = 0; j < b->njobs; j++) {
         const sq_paramset &ps = b->psets[b->job_pset[j]];
         algos[j] = o.algos ? o.algos : ps.algorithms;       // :1065-1066
-        if (algos[j] & ~(uint32_t)SQ_ALGO_G) {
-            sq_set_error("algorithms N/H/E are not available in this build of libsquarna_hip");
-            return -4;
-        }
         JobPool &P = pools[j];
         P.cursubopt = ps.suboptmin;                         // :1069
         P.suboptinc = (ps.suboptmax - ps.suboptmin) / ps.suboptsteps;   // :1071
         P.suboptmax = ps.suboptmax; P.maxstemnum = ps.maxstemnum;
         if (algos[j] & SQ_ALGO_G) { P.cur.emplace_back(); P.cur.back().job = j; }   // :1105 one empty structure
+    }
+    // Edmonds / Hungarian / Nussinov paramsets (:1094-1100); their stemsets precede the greedy ones.
+    // The reference iterates a Python set of letters (unspecified order); we use E, H, N.
+    for (int algo : {SQ_ALGO_E, SQ_ALGO_H, SQ_ALGO_N}) {
+        std::vector<int> js;
+        for (int j = 0; j < b->njobs; j++) if (algos[j] & (uint32_t)algo) js.push_back(j);
+        if (js.empty()) continue;
+        std::vector<std::vector<HStem>> sets;
+        r = sq_run_algo(b, js, algo, o.levellimit, sets);
+        if (r) return r;
+        for (size_t k = 0; k < js.size(); k++) { pools[js[k]].fin.push_back(std::move(sets[k])); pools[js[k]].evals++; }
     }
     std::vector<SView> round;
     std::vector<int> owner;                                 // job of each view

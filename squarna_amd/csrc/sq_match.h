@@ -1,0 +1,31 @@
+// sq_match.h -- job records of the on-device matching step (a-8, a-9, Nussinov).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+struct SqMatchEdge {      // one cell (v, w), v < w, of a stem with its weight
+    int32_t v, w;         // LSAP / Nussinov: sequence positions; blossom: vertex ids in graph order
+    double weight;        // H, E: stemscore ** 1.7 (host libm);  N: stemscore
+};
+
+struct SqMatchJob {
+    int32_t n;            // LSAP / Nussinov: sequence length; blossom: number of graph vertices
+    int32_t nedges;
+    int64_t edge_off;     // into the edge array
+    int64_t scratch_off;  // bytes into the scratch arena
+    int64_t out_off;      // ints into the output array (pairs: 2 ints each for Nussinov)
+    int64_t pos_off;      // sequence offset into the per-position arrays (Nussinov separators)
+};
+
+size_t sq_lsap_scratch_bytes(int n);
+size_t sq_nussinov_scratch_bytes(int n);
+size_t sq_mwm_scratch_bytes(int n, int nedges);
+
+#ifdef __HIPCC__
+extern "C" {
+__global__ void sq_lsap_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch, int32_t *col4row_out);
+__global__ void sq_nussinov_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, const uint8_t *codes,
+                                   char *scratch, int32_t *pairs_out, int32_t *count_out);
+__global__ void sq_mwm_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch, int32_t *mate_out);
+}
+#endif

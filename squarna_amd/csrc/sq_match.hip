@@ -1,0 +1,216 @@
+// sq_match.hip -- a-8 / a-9 / Nussinov on device: the matching step of RunAlgo
+// (SQRNdbnseq.py:548-595) for the paramsets whose `algorithms` are H, E or N.
+//
+//   sq_lsap_kernel      Hungarian (SQRNalgos.py:113-135).  The reference calls
+//                       scipy.optimize.linear_sum_assignment (scipy 1.15.3, un-vendored C++:
+//                       Crouse 2016 shortest augmenting path).  Restated step by step -- same
+//                       column order, same tie-break towards unassigned columns -- so the
+//                       assignment is the one scipy returns, not just an optimal one.
+//                       One wave per job; the column scan of every augmentation step is
+//                       parallel over the lanes, everything else is scalar work on lane 0.
+//   sq_nussinov_kernel  Nussinov DP + BackTrack (SQRNalgos.py:6-93): anti-diagonal wavefront,
+//                       one block per job, fp64, first-best-k tie rule.
+//   sq_mwm_kernel       Edmonds (SQRNalgos.py:96-110): networkx 3.4.2 max_weight_matching
+//                       restated in sq_blossom.h, one thread per job.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "sq_match.h"
+#include "sq_blossom.h"
+
+// ------------------------------------------------------------------------------------
+// LSAP: one wave per job.  Layout of the job's scratch (doubles then ints), nc = n:
+//   cost[n*n] u[n] v[n] spc[n] | path[n] col4row[n] row4col[n] remaining[n] | SR[n] SC[n] (bytes)
+// ------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(64) void sq_lsap_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges,
+                                                                char *scratch, int32_t *col4row_out)
+{
+    const SqMatchJob jb = jobs[blockIdx.x];
+    const int n = jb.n, lane = threadIdx.x;
+    if (n <= 0) return;
+    double *cost = reinterpret_cast<double *>(scratch + jb.scratch_off);
+    double *u = cost + (size_t)n * n, *v = u + n, *spc = v + n;
+    int32_t *path = reinterpret_cast<int32_t *>(spc + n);
+    int32_t *col4row = path + n, *row4col = col4row + n, *remaining = row4col + n;
+    uint8_t *SR = reinterpret_cast<uint8_t *>(remaining + n), *SC = SR + n;
+
+    // mat = zeros; mat[v,w] = mat[w,v] = -(score**power)   (SQRNalgos.py:119-123)
+    for (size_t q = lane; q < (size_t)n * n; q += 64) cost[q] = 0.0;
+    for (int q = lane; q < n; q += 64) { u[q] = 0.0; v[q] = 0.0; path[q] = -1; col4row[q] = -1; row4col[q] = -1; }
+    __syncthreads();
+    for (int e = lane; e < jb.nedges; e += 64) {
+        const SqMatchEdge ed = edges[jb.edge_off + e];
+        cost[(size_t)ed.v * n + ed.w] = -ed.weight;
+        cost[(size_t)ed.w * n + ed.v] = -ed.weight;
+    }
+    __syncthreads();
+
+    __shared__ int s_i, s_sink, s_nrem, s_index;
+    __shared__ double s_minval;
+    for (int cur = 0; cur < n; cur++) {
+        // ---- augmenting_path(cur)
+        for (int q = lane; q < n; q += 64) { remaining[q] = n - q - 1; SR[q] = 0; SC[q] = 0; spc[q] = INFINITY; }
+        if (lane == 0) { s_i = cur; s_sink = -1; s_nrem = n; s_minval = 0.0; }
+        __syncthreads();
+        while (s_sink == -1) {
+            const int i = s_i, nrem = s_nrem;
+            const double minval = s_minval, ui = u[i];
+            double lowest = INFINITY;
+            int first = -1, lastun = -1;
+            for (int it = lane; it < nrem; it += 64) {
+                const int j = remaining[it];
+                const double r = minval + cost[(size_t)i * n + j] - ui - v[j];
+                double sp = spc[j];
+                if (r < sp) { path[j] = i; spc[j] = r; sp = r; }
+                const bool un = row4col[j] == -1;
+                if (sp < lowest) { lowest = sp; first = it; lastun = un ? it : -1; }
+                else if (sp == lowest && un) lastun = it;           // sequential rule: later unassigned ties win
+            }
+            // wave combine == the sequential scan over it = 0..nrem-1
+            double m = lowest;
+            for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off));
+            int f = (lowest == m && first >= 0) ? first : 0x7fffffff;
+            int lu = (lowest == m) ? lastun : -1;
+            for (int off = 32; off > 0; off >>= 1) { f = min(f, __shfl_xor(f, off)); lu = max(lu, __shfl_xor(lu, off)); }
+            if (lane == 0) {
+                SR[i] = 1;
+                s_minval = m;
+                if (m == INFINITY) { s_sink = -2; }                 // infeasible (cannot happen: finite costs)
+                else {
+                    const int index = lu >= 0 ? lu : f;
+                    const int j = remaining[index];
+                    if (row4col[j] == -1) s_sink = j; else s_i = row4col[j];
+                    SC[j] = 1;
+                    remaining[index] = remaining[nrem - 1];
+                    s_nrem = nrem - 1;
+                }
+            }
+            __syncthreads();
+        }
+        if (s_sink < 0) break;
+        // ---- dual update
+        const double minval = s_minval;
+        __syncthreads();
+        if (lane == 0) u[cur] += minval;
+        for (int q = lane; q < n; q += 64) {
+            if (SR[q] && q != cur) u[q] += minval - spc[col4row[q]];
+            if (SC[q]) v[q] -= minval - spc[q];
+        }
+        __syncthreads();
+        // ---- augment
+        if (lane == 0) {
+            int j = s_sink;
+            for (;;) {
+                const int i = path[j];
+                row4col[j] = i;
+                const int t = col4row[i]; col4row[i] = j; j = t;
+                if (i == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+    for (int q = lane; q < n; q += 64) col4row_out[jb.out_off + q] = col4row[q];
+}
+
+// ------------------------------------------------------------------------------------
+// Nussinov (SQRNalgos.py:44-93).  scratch: S[n*n] D[n*n] (doubles) | K[n*n] (int32) | has[n*n] (bytes)
+// out: pairs (k, j) appended to pairs_out[out_off..], count in count_out[job]
+// ------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges,
+                                                                     const uint8_t *codes, char *scratch,
+                                                                     int32_t *pairs_out, int32_t *count_out)
+{
+    const SqMatchJob jb = jobs[blockIdx.x];
+    const int n = jb.n, tid = threadIdx.x;
+    if (n <= 0) { if (tid == 0) count_out[blockIdx.x] = 0; return; }
+    double *S = reinterpret_cast<double *>(scratch + jb.scratch_off);
+    double *D = S + (size_t)n * n;
+    int32_t *K = reinterpret_cast<int32_t *>(D + (size_t)n * n);
+    uint8_t *has = reinterpret_cast<uint8_t *>(K + (size_t)n * n);
+    const uint8_t *cd = codes + jb.pos_off;
+    for (size_t q = tid; q < (size_t)n * n; q += 256) { D[q] = 0.0; K[q] = -2; has[q] = 0; }
+    __syncthreads();
+    for (int e = tid; e < jb.nedges; e += 256) {                       // SCORES[(v,w)] = -stem[2]  (:49)
+        const SqMatchEdge ed = edges[jb.edge_off + e];
+        S[(size_t)ed.v * n + ed.w] = -ed.weight; has[(size_t)ed.v * n + ed.w] = 1;
+    }
+    __syncthreads();
+    for (int h = 1; h < n; h++) {                                       // :65
+        for (int i = tid; i < n - h; i += 256) {
+            const int j = i + h;
+            int bestk = -1; double best = 1e9;                          // :70
+            for (int k = i; k < j - 1; k++) {                           // :73
+                if (!has[(size_t)k * n + j]) continue;
+                // D[i, k-1] with k == i is numpy's D[i, -1] = D[i, n-1], still 0 at this point (:76)
+                const double dik = k > i ? D[(size_t)i * n + (k - 1)] : D[(size_t)i * n + (n - 1)];
+                const double sc = dik + D[(size_t)(k + 1) * n + (j - 1)] + S[(size_t)k * n + j];
+                if (sc < best) { bestk = k; best = sc; }
+            }
+            const double dprev = D[(size_t)i * n + (j - 1)];
+            if (best <= dprev) { K[(size_t)i * n + j] = bestk; D[(size_t)i * n + j] = best; }   // :80-83
+            else D[(size_t)i * n + j] = dprev;
+        }
+        __syncthreads();
+    }
+    // BackTrack(0, N-1) (:6-41): level-synchronous set of cells; one thread, O(N) cells
+    if (tid == 0) {
+        const int minloop = 3;
+        int32_t *out = pairs_out + 2 * (size_t)jb.out_off;
+        // queue storage: the tail of the job's scratch (two arrays of (i, j) cells)
+        int32_t *cur = reinterpret_cast<int32_t *>(has + (((size_t)n * n + 15) & ~(size_t)15)), *nxt = cur + 2 * (size_t)(n + 2);
+        uint8_t *inq = has;            // has[] no longer needed
+        for (size_t t = 0; t < (size_t)n * n; t++) inq[t] = 0;
+        int qn = 1, np = 0;
+        cur[0] = 0; cur[1] = n - 1;
+        auto sep = [&](int p) { return cd[p] == 26 || cd[p] == 27; };
+        auto anysep = [&](int a, int b) { for (int x = a; x < b; x++) if (x >= 0 && x < n && sep(x)) return true; return false; };
+        while (qn) {
+            int nn = 0;
+            for (int t = 0; t < qn; t++) {
+                const int i = cur[2 * t], j = cur[2 * t + 1];
+                if (i < 0 || j < 0 || i >= n || j >= n) continue;
+                auto push = [&](int a, int b) {
+                    if (!inq[(size_t)a * n + b]) { inq[(size_t)a * n + b] = 1; nxt[2 * nn] = a; nxt[2 * nn + 1] = b; nn++; }
+                };
+                const int kk = K[(size_t)i * n + j];
+                if (kk != -2) {
+                    const int k = kk;
+                    if (((k - 1) - i > minloop) || ((k - 1) - i > 0 && anysep(i + 1, k - 1))) push(i, k - 1);
+                    if (((j - 1) - (k + 1) > minloop) || ((j - 1) - (k + 1) > 0 && anysep(k + 2, j - 1))) push(k + 1, j - 1);
+                    out[2 * np] = k; out[2 * np + 1] = j; np++;
+                } else {
+                    if (((j - 1) - i > minloop) || ((j - 1) - i > 0 && anysep(i + 1, j - 1))) push(i, j - 1);
+                }
+            }
+            for (int t = 0; t < nn; t++) inq[(size_t)nxt[2 * t] * n + nxt[2 * t + 1]] = 0;
+            for (int t = 0; t < 2 * nn; t++) cur[t] = nxt[t];
+            qn = nn;
+        }
+        count_out[blockIdx.x] = np;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Edmonds: one thread per job runs the restated networkx blossom algorithm (sq_blossom.h)
+// ------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges,
+                                                               char *scratch, int32_t *mate_out)
+{
+    if (threadIdx.x != 0) return;     // one thread per job; one job per block (spreads jobs over the CUs)
+    const SqMatchJob *jp = jobs + blockIdx.x;
+    if (jp->n <= 0) return;
+    SqBlossom bl;
+    bl.init(jp->n, jp->nedges, edges + jp->edge_off, scratch + jp->scratch_off);
+    bl.run();
+    for (int q = 0; q < jp->n; q++) mate_out[jp->out_off + q] = bl.mate[q];
+}
+
+size_t sq_lsap_scratch_bytes(int n)
+{
+    return ((size_t)n * n + 3 * (size_t)n) * 8 + 4 * (size_t)n * 4 + 2 * (size_t)n + 64;
+}
+size_t sq_nussinov_scratch_bytes(int n)
+{
+    return 2 * (size_t)n * n * 8 + (size_t)n * n * 4 + (((size_t)n * n + 15) & ~(size_t)15) + 4 * (size_t)(n + 2) * 4 + 64;
+}
+size_t sq_mwm_scratch_bytes(int n, int nedges) { return SqBlossom::scratch_bytes(n, nedges); }

@@ -226,6 +226,19 @@ class Batch:
                         for q in range(out_off[k], out_off[k + 1])])
         return res
 
+    # -- a-8 / a-9 / Nussinov
+    def run_algo(self, jobs, algo, levellimit=None, out_cap=1 << 16):
+        """RunAlgo (SQRNdbnseq.py:548-595) for the listed jobs under 'E', 'H' or 'N':
+        list (per job) of (i, j, len, score, score)."""
+        nj = len(jobs)
+        ja = np.array(jobs, np.int32)
+        out = (_lib.Stem * out_cap)()
+        off = np.zeros(nj + 1, np.int32)
+        _lib.check(self.L.sq_run_algos(self.h, nj, _ptr(ja), _lib.ALGO_BITS[algo],
+                                       -1 if levellimit is None else int(levellimit), out, out_cap, _ptr(off)))
+        return [[(out[q].i, out[q].j, out[q].len, out[q].bpscore, out[q].finscore)
+                 for q in range(off[k], off[k + 1])] for k in range(nj)]
+
     # -- a-7 + a-10
     def fold(self, poollim=1000, conslim=1, toplim=5, hardrest=False, rankbydiff=False,
              rankby=(0, 2, 1), levellimit=None, algos=frozenset(), priority=None):

@@ -119,14 +119,12 @@ def _same_fold(got, exp, tag):
             assert abs(g - e) <= TOL, (tag, got[2], got[3], exp[2], exp[3])
 
 
-def test_fold_golden_greedy_configs():
+def test_fold_golden_all_configs():
     from squarna_amd.engine import HipEngine
     eng = HipEngine()
     n = 0
     for c in load("fold.json"):
         names, psets = conf(c["config"])
-        if any(p["algorithms"] != {"G"} for p in psets):
-            continue
         kw = dict(c["kw"])
         if "rankby" in kw:
             kw["rankby"] = tuple(kw["rankby"])
@@ -187,7 +185,7 @@ def test_edge_cases():
 
 
 # ---- end-to-end text: Predict() on the HIP engine == the reference's own output, byte for byte
-GPU_TEXT = ["s16_fastest", "shape_input_fastest", "shape_input_alt_rf26", "seq_input_entropy",
+GPU_TEXT = ["s16_nobpp", "seq_input_nobpp", "SRtest150_nobpp", "s16_fastest", "shape_input_fastest", "shape_input_alt_rf26", "seq_input_entropy",
             "seq_input_ico", "seq_input_greedynobpp_rf10", "seq_input_evalonly", "SRtest150_fastest",
             "SRtest150_fastest_pl1", "SRtest150_alt", "SRtest150_greedynobpp"]
 
@@ -230,3 +228,37 @@ def test_api_shims_match_oracle():
     exp = O.OptimalStems(seq, [], ob, os_, [0.5] * len(seq), set(), 0.8, 2, 4.5, 4.5, -2.0, 0.09, 1.0, 0.125)
     assert [(st[0][0][0], st[0][0][1], st[1]) for st in got] == [e[:3] for e in exp]
     assert all(abs(st[3] - e[4]) <= TOL for st, e in zip(got, exp))
+
+
+def test_runalgo_golden():
+    """a-8 / a-9 / Nussinov: RunAlgo stemsets for E, H, N against the reference (scipy / networkx)."""
+    from squarna_amd.engine import Batch
+    names, psets = conf("nobpp")
+    ps = dict(zip(names, psets))
+    cases = load("algos.json")
+    for algo in "EHN":
+        sel = [c for c in cases if c["algo"] == algo]
+        preps = [prep(c["seq"], c["reacts"], c["restraints"]) for c in sel]
+        with Batch(preps, [[ps[c["paramset"]]] for c in sel]) as b:
+            got = b.run_algo(list(range(len(sel))), algo)
+        for g, c in zip(got, sel):
+            close_stems([x[:4] for x in g], c["stemset"], (c["name"], algo))
+
+
+def test_runalgo_vs_oracle_random():
+    """E / H / N on seeded random sequences (ties everywhere) against the oracle's scipy/networkx calls."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import Batch
+    names, psets = conf("nobpp")
+    ps = dict(zip(names, psets))
+    rng = random.Random(77)
+    seqs = ["".join(rng.choice("ACGU") for _ in range(n)) for n in (20, 35, 50, 64, 80, 100, 120, 150, 200, 260)]
+    seqs += ["GGGGAAAACCCC" * 6, "GCGCGCGCAAAAGCGCGCGC" * 4, "ACGU" * 30]
+    for algo, pname in (("E", "defE"), ("H", "defH"), ("N", "defN")):
+        p = ps[pname]
+        with Batch([prep(s) for s in seqs], [[p]] * len(seqs)) as b:
+            got = b.run_algo(list(range(len(seqs))), algo)
+        for s, g in zip(seqs, got):
+            bm, sm = O.BPMatrix(s, p["bpweights"], set(), set(), set(), False, [0.5] * len(s))
+            exp = O.RunAlgo(s, bm, sm, [], p["minlen"], p["minbpscore"], algo=algo, levellimit=3 - int(len(s) > 500))
+            close_stems([x[:4] for x in g], [e[:4] for e in exp], (algo, len(s)))
