@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="greedynobpp")
+    ap.add_argument("--config", default="nobpp")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true", help="skip the S1000 roofline leg")
     ap.add_argument("--roofline-seqs", type=int, default=512)

@@ -8,6 +8,7 @@
 #include <vector>
 #include "sq_host.h"
 #include "sq_match.h"
+#include "sq_blossom.h"
 
 #define HIPCK(x) do { int _r = sq_check((x), #x); if (_r) return _r; } while (0)
 
@@ -157,9 +158,22 @@ int sq_run_algo(sq_batch *b, const std::vector<int> &jobs, int algo, int levelli
         HIPCK(hipMemcpyAsync(d_jobs, mj.data(), mj.size() * sizeof(SqMatchJob), hipMemcpyHostToDevice, st));
         if (!me.empty()) HIPCK(hipMemcpyAsync(d_edges, me.data(), me.size() * sizeof(SqMatchEdge), hipMemcpyHostToDevice, st));
         const int nj = (int)mj.size();
-        if (algo == SQ_ALGO_H) hipLaunchKernelGGL(sq_lsap_kernel, dim3(nj), dim3(64), 0, st, d_jobs, d_edges, d_scr, d_out);
+        int maxn = 0, maxm = 0;
+        for (const SqMatchJob &m : mj) { maxn = std::max(maxn, m.n); maxm = std::max(maxm, m.nedges); }
+        if (algo == SQ_ALGO_H) {
+            const int lds = (int)std::min<size_t>((size_t)maxn * 42 + 64, 64 * 1024);
+            hipLaunchKernelGGL(sq_lsap_kernel, dim3(nj), dim3(64), lds, st, d_jobs, d_edges, d_scr, d_out, lds);
+        }
         else if (algo == SQ_ALGO_N) hipLaunchKernelGGL(sq_nussinov_kernel, dim3(nj), dim3(256), 0, st, d_jobs, d_edges, b->ctx.codes, d_scr, d_out, d_cnt);
-        else hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), 0, st, d_jobs, d_edges, d_scr, d_out);
+        else {
+            static bool attr_set = false;
+            if (!attr_set) { hipFuncSetAttribute((const void *)sq_mwm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr_set = true; }
+            // LDS-resident state did not pay for the one-thread-per-job form (generic-pointer LDS access is as slow
+            // as an L2 hit); the wave-cooperative form is the next step.  0 = keep the state in global memory.
+            const size_t want = getenv("SQ_MWM_LDS") ? SqBlossom::scratch_bytes(maxn, maxm, 1) + (size_t)maxm * sizeof(SqMatchEdge) + 64 : 0;
+            const int lds = (int)std::min<size_t>(want, 160 * 1024 - 256);
+            hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), lds, st, d_jobs, d_edges, d_scr, d_out, lds);
+        }
         HIPCK(hipGetLastError());
         std::vector<int32_t> h_out(outints + 4), h_cnt(mj.size() + 1);
         HIPCK(hipMemcpyAsync(h_out.data(), d_out, outints * 4, hipMemcpyDeviceToHost, st));
@@ -173,6 +187,7 @@ int sq_run_algo(sq_batch *b, const std::vector<int> &jobs, int algo, int levelli
             std::vector<BP> pairs;
             if (algo == SQ_ALGO_E) {
                 const int32_t *mate = h_out.data() + mj[q].out_off;
+                if (mj[q].n > 0 && mate[0] == -2) { sq_set_error("blossom capacity exceeded"); return -3; }
                 for (int v = 0; v < mj[q].n; v++)
                     if (mate[v] > v) pairs.push_back(BP(vid2pos[q][v], vid2pos[q][mate[v]]));
             } else if (algo == SQ_ALGO_N) {

@@ -44,24 +44,30 @@ struct SqBlossom {
     int *freeb; int nfree;
     // temporaries
     int *tmp_leaves, *tmp_stack, *tmp_path, *tmp_edges, *beto, *beto_keys, *frames;
+    int frame_cap;
     int error;
 
-    SQ_HD static size_t scratch_bytes(int n, int m)
+    // tight = 1: capacities that fit LDS for typical stem graphs (overflow sets `error`, the
+    // caller then reruns the job with tight = 0 in global memory)
+    SQ_HD static int queue_cap(int n, int m, int tight) { return tight ? 4 * n + m + 16 : 8 * n + 2 * m + 16; }
+    SQ_HD static int pool_capacity(int n, int m, int tight) { return tight ? 4 * n + m + 256 : n * 32 + 2 * m + 1024; }
+    SQ_HD static int frame_ints(int n, int tight) { return tight ? 8 * (n / 2 + 4) : 10 * (2 * n + 2); }
+    SQ_HD static size_t scratch_bytes(int n, int m, int tight = 0)
     {
         const size_t N2 = 2 * (size_t)n + 2;
         size_t ints = (size_t)n + 1 + 2 * (size_t)m            // adj_off, adj
                       + 2 * (size_t)n                           // mate, mate_de
                       + 4 * N2 + (size_t)n                      // labeledge, parent, base, bestedge, inblossom
-                      + (8 * (size_t)n + 2 * (size_t)m + 16)    // queue
+                      + (size_t)queue_cap(n, m, tight)          // queue
                       + 7 * N2                                  // sib_next, sib_prev, edge_after, first, nchild, mbe_off, mbe_cnt
-                      + ((size_t)n * 32 + 2 * (size_t)m + 1024) // pool
+                      + (size_t)pool_capacity(n, m, tight)      // pool
                       + 2 * (size_t)n + 2                       // live, freeb
                       + 2 * N2 + 4 * N2 + 2 * N2                // tmp_leaves, tmp_stack | tmp_path, tmp_edges (2 each) | beto, beto_keys
-                      + 10 * N2;                                // frames
+                      + (size_t)frame_ints(n, tight);           // frames
         return ints * 4 + ((size_t)n + N2) * 8 + N2 + (size_t)m + 256;
     }
 
-    SQ_HD void init(int n_, int m_, const SqMatchEdge *edges, char *scratch)
+    SQ_HD void init(int n_, int m_, const SqMatchEdge *edges, char *scratch, int tight = 0)
     {
         n = n_; m = m_; E = edges; error = 0;
         const int N2 = 2 * n + 2;
@@ -72,13 +78,13 @@ struct SqBlossom {
         adj_off = take_i(n + 1); adj = take_i(2 * (size_t)m);
         mate = take_i(n); mate_de = take_i(n);
         labeledge = take_i(N2); parent = take_i(N2); base = take_i(N2); bestedge = take_i(N2); inblossom = take_i(n);
-        qcap = 8 * n + 2 * m + 16; queue = take_i(qcap); qn = 0;
+        qcap = queue_cap(n, m, tight); queue = take_i(qcap); qn = 0;
         sib_next = take_i(N2); sib_prev = take_i(N2); edge_after = take_i(N2); first = take_i(N2); nchild = take_i(N2);
         mbe_off = take_i(N2); mbe_cnt = take_i(N2);
-        pool_cap = n * 32 + 2 * m + 1024; pool = take_i(pool_cap); pool_n = 0;
+        pool_cap = pool_capacity(n, m, tight); pool = take_i(pool_cap); pool_n = 0;
         live = take_i(n + 1); freeb = take_i(n + 1);
         tmp_leaves = take_i(N2); tmp_stack = take_i(N2); tmp_path = take_i(2 * (size_t)N2); tmp_edges = take_i(2 * (size_t)N2);
-        beto = take_i(N2); beto_keys = take_i(N2); frames = take_i(10 * (size_t)N2);
+        beto = take_i(N2); beto_keys = take_i(N2); frame_cap = frame_ints(n, tight); frames = take_i((size_t)frame_cap);
         label = (int8_t *)p; p += N2; allow = (uint8_t *)p; p += m;
         // adjacency in insertion order: edge e = (v, w) appends w to adj[v] and v to adj[w]
         for (int v = 0; v <= n; v++) adj_off[v] = 0;
@@ -276,6 +282,7 @@ struct SqBlossom {
                 parent[s] = -1;
                 if (is_blossom(s)) {
                     if (endstage && bdual[s] == 0) {       // yield s: expand it now, then continue with the next child
+                        if (3 * (sp + 1) > frame_cap) { error = 4; return; }
                         int *g = fr + 3 * sp;
                         g[0] = s; g[1] = first[s]; g[2] = nchild[s]; sp++;
                     } else {
@@ -341,6 +348,7 @@ struct SqBlossom {
         int sp = 1;
         fr[0] = b0; fr[1] = v0; fr[2] = 0;
         while (sp) {
+            if (8 * (sp + 1) > frame_cap) { error = 4; return; }
             int *f = fr + 8 * (sp - 1);
             const int b = f[0], v = f[1];
             if (f[2] == 0) {

@@ -682,8 +682,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         for (int j = 0; j < b->njobs; j++) if (algos[j] & (uint32_t)algo) js.push_back(j);
         if (js.empty()) continue;
         std::vector<std::vector<HStem>> sets;
+        const double ta = now_s();
         r = sq_run_algo(b, js, algo, o.levellimit, sets);
         if (r) return r;
+        if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_fold] algo %d: %zu jobs %.3f ms\n", algo, js.size(), (now_s() - ta) * 1e3);
         for (size_t k = 0; k < js.size(); k++) { pools[js[k]].fin.push_back(std::move(sets[k])); pools[js[k]].evals++; }
     }
     std::vector<SView> round;

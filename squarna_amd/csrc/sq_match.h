@@ -23,9 +23,11 @@ size_t sq_mwm_scratch_bytes(int n, int nedges);
 
 #ifdef __HIPCC__
 extern "C" {
-__global__ void sq_lsap_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch, int32_t *col4row_out);
+__global__ void sq_lsap_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch, int32_t *col4row_out,
+                               int lds_bytes);
 __global__ void sq_nussinov_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, const uint8_t *codes,
                                    char *scratch, int32_t *pairs_out, int32_t *count_out);
-__global__ void sq_mwm_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch, int32_t *mate_out);
+__global__ void sq_mwm_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch, int32_t *mate_out,
+                              int lds_bytes);
 }
 #endif

@@ -23,13 +23,17 @@
 //   cost[n*n] u[n] v[n] spc[n] | path[n] col4row[n] row4col[n] remaining[n] | SR[n] SC[n] (bytes)
 // ------------------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(64) void sq_lsap_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges,
-                                                                char *scratch, int32_t *col4row_out)
+                                                                char *scratch, int32_t *col4row_out, int lds_bytes)
 {
+    extern __shared__ __attribute__((aligned(16))) char lsap_lds[];
     const SqMatchJob jb = jobs[blockIdx.x];
     const int n = jb.n, lane = threadIdx.x;
     if (n <= 0) return;
     double *cost = reinterpret_cast<double *>(scratch + jb.scratch_off);
-    double *u = cost + (size_t)n * n, *v = u + n, *spc = v + n;
+    double *u = cost + (size_t)n * n;
+    // the per-row/column vectors are touched in every step of the augmenting path: LDS when they fit
+    if ((size_t)n * (3 * 8 + 4 * 4 + 2) + 64 <= (size_t)lds_bytes) u = reinterpret_cast<double *>(lsap_lds);
+    double *v = u + n, *spc = v + n;
     int32_t *path = reinterpret_cast<int32_t *>(spc + n);
     int32_t *col4row = path + n, *row4col = col4row + n, *remaining = row4col + n;
     uint8_t *SR = reinterpret_cast<uint8_t *>(remaining + n), *SC = SR + n;
@@ -194,15 +198,34 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
 // Edmonds: one thread per job runs the restated networkx blossom algorithm (sq_blossom.h)
 // ------------------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges,
-                                                               char *scratch, int32_t *mate_out)
+                                                               char *scratch, int32_t *mate_out, int lds_bytes)
 {
-    if (threadIdx.x != 0) return;     // one thread per job; one job per block (spreads jobs over the CUs)
+    extern __shared__ __attribute__((aligned(16))) char mwm_lds[];
     const SqMatchJob *jp = jobs + blockIdx.x;
-    if (jp->n <= 0) return;
+    const int n = jp->n, m = jp->nedges;
+    if (n <= 0) return;
+    // The algorithm is a chain of dependent loads: keep the whole state (and the edge list) in LDS
+    // when it fits, with tight capacities; on a capacity overflow rerun the job in global memory.
+    const size_t tight = SqBlossom::scratch_bytes(n, m, 1), ebytes = (size_t)m * sizeof(SqMatchEdge);
+    const bool in_lds = tight + ebytes + 16 <= (size_t)lds_bytes;
+    const SqMatchEdge *E = edges + jp->edge_off;
+    if (in_lds) {
+        SqMatchEdge *le = reinterpret_cast<SqMatchEdge *>(mwm_lds);
+        for (int e = threadIdx.x; e < m; e += 64) le[e] = E[e];
+        __syncthreads();
+        E = le;
+    }
+    if (threadIdx.x != 0) return;     // one thread per job; one job per block spreads the jobs over the CUs
     SqBlossom bl;
-    bl.init(jp->n, jp->nedges, edges + jp->edge_off, scratch + jp->scratch_off);
-    bl.run();
-    for (int q = 0; q < jp->n; q++) mate_out[jp->out_off + q] = bl.mate[q];
+    if (in_lds) {
+        bl.init(n, m, E, mwm_lds + ((ebytes + 15) & ~(size_t)15), 1);
+        bl.run();
+        if (bl.error) { bl.init(n, m, edges + jp->edge_off, scratch + jp->scratch_off, 0); bl.run(); }
+    } else {
+        bl.init(n, m, E, scratch + jp->scratch_off, 0);
+        bl.run();
+    }
+    for (int q = 0; q < n; q++) mate_out[jp->out_off + q] = bl.error ? -2 : bl.mate[q];
 }
 
 size_t sq_lsap_scratch_bytes(int n)
