@@ -31,6 +31,7 @@ struct SqScanArgs {
 
 size_t sq_scan_lds_fixed();   // bytes of static LDS of sq_scan_kernel
 int sq_scan_seg();            // rows per wave of sq_scan_kernel
+int sq_scan5_seg();           // rows per wave of sq_scan5_kernel
 
 extern "C" {
 __global__ void sq_fill_kernel(SqDevCtx c);
@@ -38,6 +39,7 @@ __global__ void sq_dense64_kernel(SqDevCtx c, int job, double *boolmat, double *
 __global__ void sq_import_kernel(SqDevCtx c);
 __global__ void sq_state_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState st);
 __global__ void sq_scan_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
+__global__ void sq_scan5_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
 __global__ void sq_score_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
-                                SqScanArgs a, SqOut *out, uint32_t out_cap, int mode);
+                                SqScanArgs a, SqOut *out, uint32_t out_cap, int mode, int lds_n, int lds_n_reacts);
 }

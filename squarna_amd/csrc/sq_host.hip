@@ -31,7 +31,15 @@ extern "C" int sq_version(void) { return 100; }
 extern "C" const char *sq_last_error(void) { return g_err.c_str(); }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-static inline int32_t ld_of(int n) { return 32 * ((std::max(n, 1) - 1 + 31) / 32) + 1; }
+// row pitch of the scan matrix: ld == 1 (mod 32) (aligned anti-diagonal walk, see sq_kernels.hip) and
+// (ld - 1) / 32 odd, so that the byte stride between rows is an odd multiple of 128 B and consecutive rows
+// of a wave rotate through all memory channels instead of camping on a power-of-two stride
+static inline int32_t ld_of(int n)
+{
+    int k = (std::max(n, 1) - 1 + 31) / 32;
+    if (!getenv("SQ_LD_POW2") && (k & 1) == 0) k++;
+    return 32 * k + 1;
+}
 
 namespace {
 struct Layout {
@@ -63,7 +71,7 @@ int plan(const sq_batch_desc *d, Layout &L)
         if (ext) L.mat64_doubles += 2 * n * n;
         else if (mul) L.mat64_doubles += n * n;
     }
-    L.mat32_floats += 1024;
+    L.mat32_floats += 1024 + (int64_t)160 * ld_of(L.maxn);     // reads of rows past a short segment stay inside the arena
     L.sdf_len = 0;
     for (int p = 0; p < d->npset; p++) {
         const double bw = d->psets[p].bracketweight;
@@ -71,8 +79,15 @@ int plan(const sq_batch_desc *d, Layout &L)
     }
     L.stride = (int32_t)align_up((size_t)L.maxn + 2, 32);
     L.strand_cap = (int32_t)std::min<int64_t>((int64_t)L.max_structs * 64 + L.maxn, 1 << 24);
-    L.cand_records = std::min<int64_t>((int64_t)L.max_structs * L.cpn * L.maxn, (int64_t)64 << 20);
-    L.cand_records = std::max<int64_t>(L.cand_records, (int64_t)L.cpn * L.maxn + 256);
+    int64_t maxcap = (int64_t)L.cpn * L.maxn + 256;
+    for (int j = 0; j < d->njobs; j++) {
+        const int sq = d->job_seq[j];
+        const double nn = d->seq_off[sq + 1] - d->seq_off[sq];
+        const double ml = std::max(1.0, std::ceil(d->psets[d->job_pset[j]].minlen));
+        maxcap = std::max<int64_t>(maxcap, (int64_t)(0.117 * nn * nn * std::pow(0.375, ml - 1.0) * 1.6 + 256));
+    }
+    L.cand_records = std::min<int64_t>((int64_t)L.max_structs * maxcap, (int64_t)64 << 20);
+    L.cand_records = std::max<int64_t>(L.cand_records, maxcap);
     // the dense fp64 read-back (sq_bpmatrix_read) borrows the candidate arena
     L.cand_records = std::max<int64_t>(L.cand_records, (int64_t)(2 * (int64_t)L.maxn * L.maxn * 8 / sizeof(SqCand)) + 16);
     L.out_cap = (uint32_t)std::min<int64_t>(L.cand_records, (int64_t)4 << 20);
@@ -201,7 +216,11 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         for (int i = 0; i < J.n; i++) if (d->reacts[J.pos_off + i] != 0.5) { def = false; break; }
         J.default_reacts = def ? 1 : 0;
         J.interchainonly = d->interchainonly;
-        J.cand_cap = (int32_t)std::max<int64_t>(256, (int64_t)L.cpn * J.n);
+        {
+            const double ml = std::max(1.0, std::ceil(d->psets[J.pset].minlen));
+            const double est = 0.117 * (double)J.n * J.n * std::pow(0.375, ml - 1.0) * 1.6 + 256;   // maximal runs with len >= minlen
+            J.cand_cap = (int32_t)std::max<int64_t>((int64_t)L.cpn * J.n, (int64_t)est);
+        }
         // bound of |cell| for the scan's fp32 prefilter margin
         double mx = 0;
         const size_t nn = (size_t)J.n * J.n;
@@ -520,15 +539,26 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
     }
     if (maxn >= 5) {
         const int nband = (2 * maxn - 5 + 255) >> 8;
-        const int seg = sq_scan_seg();
+        static const int scan_version = getenv("SQ_SCAN") ? atoi(getenv("SQ_SCAN")) : 5;
+        const int seg = scan_version == 4 ? sq_scan_seg() : sq_scan5_seg();
         const int nseg = ((maxn >> 1) + 130 + seg - 1) / seg;
         ProfScope ps(b, 2, scan_bytes);
-        hipLaunchKernelGGL(sq_scan_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, b->d_structs, b->state, b->scan);
+        if (scan_version == 4)
+            hipLaunchKernelGGL(sq_scan_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, b->d_structs, b->state, b->scan);
+        else
+            hipLaunchKernelGGL(sq_scan5_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, b->d_structs, b->state, b->scan);
     }
     {
         ProfScope ps(b, 3, 0);
-        hipLaunchKernelGGL(sq_score_kernel, dim3(S), dim3(256), 0, st, b->ctx, b->d_structs, b->d_strands, b->state,
-                           b->scan, b->d_out, b->out_cap, mode);
+        // dynamic LDS: letter codes of the longest sequence, plus its reactivities when they fit in 32 KiB
+        const int lds_n = maxn <= 16384 ? maxn : 0;
+        const int lds_nr = maxn <= 4096 ? maxn : 0;
+        const size_t dyn = lds_n ? (size_t)((lds_n + 15) & ~15) + (size_t)8 * lds_nr + 16 : 0;
+        // few structures: more threads per structure hide the latency of the candidate stream
+        static const int score_threads = getenv("SQ_SCORE_THREADS") ? atoi(getenv("SQ_SCORE_THREADS")) : 0;
+        const int thr = score_threads ? score_threads : (S >= 2048 ? 256 : 512);
+        hipLaunchKernelGGL(sq_score_kernel, dim3(S), dim3(thr), dyn, st, b->ctx, b->d_structs, b->d_strands, b->state,
+                           b->scan, b->d_out, b->out_cap, mode, lds_n, lds_nr);
     }
     HIPCK(hipGetLastError());
     HIPCK(hipMemcpyAsync(b->h_ctr, b->scan.ctr, sizeof(SqCounters), hipMemcpyDeviceToHost, st));

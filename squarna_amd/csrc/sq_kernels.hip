@@ -332,6 +332,8 @@ extern "C" __global__ __launch_bounds__(64, SQ_WPS) void sq_scan_kernel(SqDevCtx
 {
     static_assert(SQ_MAXROWS <= 128, "row list is kept in two VGPRs");
     __shared__ __attribute__((aligned(16))) SqScanLds L;
+    // grid = (structures, tiles): concurrently running waves work on DIFFERENT matrices (measured: dispatching
+    // the tiles of one matrix together pins every XCD to one 1-KiB column of each 4-KiB row and loses 25-35 %)
     const SqStruct st = structs[blockIdx.x];
     const SqJob jb = c.jobs[st.job];
     const int n = jb.n, ld = jb.ld;
@@ -340,7 +342,7 @@ extern "C" __global__ __launch_bounds__(64, SQ_WPS) void sq_scan_kernel(SqDevCtx
     const int nseg = ((n >> 1) + 130 + SQ_SEG - 1) / SQ_SEG;
     const int tile = blockIdx.y;
     if (tile >= nband * nseg) return;
-    const int band = tile / nseg, seg = tile - band * nseg;
+    const int seg = tile / nband, band = tile - seg * nband;
     const int s0 = band << 8;
     const int smin = max(s0, 4), smax = min(s0 + 255, 2 * n - 6);       // :456-457 s in [4, 2N-6]
     if (smin > smax) return;
@@ -495,6 +497,336 @@ extern "C" __global__ __launch_bounds__(64, SQ_WPS) void sq_scan_kernel(SqDevCtx
     for (uint32_t k = lane; k < novf; k += 64) put(gbase + n1 + n2 + k, L.ovf[k]);
 }
 
+// ------------------------------------------------------------------------------------
+// a-2  stem scan, bit-history form ("v5").  Same geometry as sq_scan_kernel (one wave = 256
+// anti-diagonals x a row segment), but the per-cell work is 3 VALU: two compares and one
+// add-with-carry that shifts the cell's activity bit into a 32-bit history per diagonal.
+// Runs are extracted from the histories once per 32 rows with bit tricks (only runs with
+// len >= minlen are ever touched); their fp32 sums are NOT tracked -- sq_score_kernel
+// recomputes every candidate exactly in fp64 anyway and applies minbpscore there.
+//   bit p of a chunk history <-> row  cbase + nrows-1 - p   (bit 0 = newest row)
+// ------------------------------------------------------------------------------------
+#ifndef SQ5_SEG
+#define SQ5_SEG 124                                   // owned rows per wave
+#endif
+#define SQ5_TAIL 4                                    // extra rows read past the segment
+#define SQ5_ROWS (SQ5_SEG + SQ5_TAIL)                 // 128 = 4 chunks of 32 (must be a multiple of 32)
+#define SQ5_STAGE 256
+#ifndef SQ5_G
+#define SQ5_G 4                                      // rows per load group (two groups in flight)
+#endif
+#ifndef SQ5_WPS
+#define SQ5_WPS 4
+#endif
+#define SQ5_COLW ((256 + SQ5_ROWS + 4) / 4 + 3)
+
+struct SqScan5Lds {
+    uint32_t ecol[4][SQ5_COLW];          // byte-shifted copies of the column mask codes
+    uint2 stage[SQ5_STAGE];              // (key, len) of emitted candidates
+    uint32_t stage_count, pad[3];
+};
+
+__device__ __forceinline__ void sq5_flush(SqScan5Lds &L, const SqScanArgs &a, const SqStruct &st, int cap, int lane)
+{
+    uint32_t n = L.stage_count;
+    if (n > SQ5_STAGE) n = SQ5_STAGE;
+    if (n) {
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(a.cand_cnt + st.slot, n);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+        for (uint32_t k = lane; k < n; k += 64) {
+            const uint32_t slot = base + k;
+            if (slot >= (uint32_t)cap) { a.ctr->cand_ovf = 1; continue; }
+            SqCand cd;
+            cd.key = L.stage[k].x; cd.len = L.stage[k].y; cd.sum32 = 0.f; cd.flags = 0; cd.bps = 0; cd.fin = 0;
+            a.cands[st.cand_off + slot] = cd;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) L.stage_count = 0;
+    __syncthreads();
+}
+
+__device__ __forceinline__ void sq5_emit(SqScan5Lds &L, const SqScanArgs &a, const SqStruct &st, int cap, uint32_t key, uint32_t len)
+{
+    const uint32_t slot = atomicAdd(&L.stage_count, 1u);
+    if (slot < SQ5_STAGE) L.stage[slot] = make_uint2(key, len);
+    else sq_emit_global(a, st, cap, key, len, 0.f);
+}
+
+// analyse one chunk history of one diagonal.  A: activity bits (nrows valid, bit 0 newest),
+// carry: length of the run open at the chunk's top (SQ_FOREIGN if it belongs to another wave),
+// rtop: row of bit nrows-1, rown: first row a run of this wave may NOT start in (rend).
+__device__ __forceinline__ void sq5_analyse(SqScan5Lds &L, const SqScanArgs &a, const SqStruct &st, int cap, int s,
+                                            uint32_t A, int nrows, int rtop, int rown, int minlen, int &carry)
+{
+    const int top = nrows - 1;
+    const uint32_t full = nrows == 32 ? 0xFFFFFFFFu : ((1u << nrows) - 1u);
+    // the run touching the top bit continues the carried run
+    int toplen = 0;                                   // ones from bit `top` downwards
+    if ((A >> top) & 1u) toplen = __clz(~(A << (31 - top)) | 0u) ;
+    if (toplen > nrows) toplen = nrows;
+    uint32_t rest = A;                                // runs that start inside this chunk
+    if (toplen) {
+        if (toplen < nrows) {                         // ended inside the chunk
+            const int p = nrows - toplen;             // newest bit of the top run
+            const int rendrow = rtop + (top - p) + 1; // first inactive row after it
+            const int len = carry + toplen;
+            if ((carry > 0 || (carry == 0 && rtop < rown)) && len >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(rendrow - len), (uint32_t)len);
+            rest &= ~(full & ~((1u << p) - 1u));      // drop the top run's bits
+            carry = 0;
+        } else {                                      // whole chunk active: run stays open
+            if (carry > 0 || (carry == 0 && rtop < rown)) carry += nrows;
+            else carry = SQ_FOREIGN;
+            return;
+        }
+    } else {
+        // the carried run ended exactly at the chunk boundary (row rtop is its first inactive row)
+        if (carry >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(rtop - carry), (uint32_t)carry);
+        carry = 0;
+    }
+    // runs inside: newest ends N = rest & ~(rest << 1); ended ones have p > 0
+    const uint32_t N = rest & ~(rest << 1);
+    uint32_t Y = rest;                                // Y[p]: rest[p .. p+minlen-1] all ones
+    for (int t = 1; t < minlen && t < 32; t++) Y &= rest >> t;
+    uint32_t bits = N & Y & ~1u;
+    while (bits) {
+        const int p = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        const int len = __ffs((int)~(rest >> p)) - 1; // consecutive ones from p upwards (never reaches the top run)
+        const int rstart = rtop + (top - (p + len - 1));
+        if (rstart < rown)                            // runs that start past the segment belong to the next wave
+            sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)rstart, (uint32_t)len);
+    }
+    // run still open at the newest end
+    if (rest & 1u) {
+        const int len = __ffs((int)~rest) - 1;        // trailing ones (< nrows here)
+        const int rstart = rtop + (top - (len - 1));
+        carry = rstart < rown ? len : SQ_FOREIGN;
+    }
+}
+
+// One 32-row chunk, fully unrolled and branch-free: per row one 16-byte load, one ds_read_b32 with
+// an immediate offset, one v_readlane for the row code, and per cell two compares + one add that
+// shifts the activity bit into the history.  A masked row has row code 0x100, which no column
+// code equals, so it shifts in zeros without any branch (its data is still fetched: the kernel is
+// instruction-bound, not HBM-bound).
+template <bool EDGE>
+__device__ __forceinline__ void sq5_chunk(const float *rowptr, int pitch, int sl, int s0, int n, int cb,
+                                          const uint32_t *ecol_row0, uint32_t cc, uint32_t (&hist)[4])
+{
+    // rows are fetched in groups of SQ5_G, two groups in flight (hipcc counts vmcnt statically); the
+    // sched_barriers keep the scheduler from hoisting later groups' LDS reads (register pressure: the
+    // kernel must stay at 64 VGPRs so that 8 waves per SIMD keep ~256 KB per CU in flight)
+    float4 buf[2][SQ5_G];
+    auto load_group = [&](int g, float4 (&dst)[SQ5_G]) {
+#pragma unroll
+        for (int u = 0; u < SQ5_G; u++) {
+            const int t = g * SQ5_G + u;
+            int sc = sl;
+            if (EDGE) {                                                  // staircase lanes re-read a neighbour's group
+                const int row = cb + t;
+                const int sfirst = max((2 * row + 1) & ~3, s0), slast = min((row + n - 1) & ~3, s0 + 252);
+                sc = min(max(sl, sfirst), slast);
+            }
+            dst[u] = *reinterpret_cast<const float4 *>(rowptr + (int64_t)t * pitch + sc);
+        }
+    };
+    load_group(0, buf[0]);
+    load_group(1, buf[1]);
+#ifdef SQ5_SCHEDBAR
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int g = 0; g < 32 / SQ5_G; g++) {
+#pragma unroll
+        for (int u = 0; u < SQ5_G; u++) {
+            const int t = g * SQ5_G + u;
+            // column codes of row cb+t: copy (3 - t%4), dword -(t/4) relative to the chunk base (the window
+            // is anchored at row rbeg+127, so the copy index is a compile-time constant)
+            const uint32_t ec = ecol_row0[(3 - (t & 3)) * SQ5_COLW - (t >> 2)];
+            const uint32_t er = (uint32_t)__builtin_amdgcn_readlane((int)cc, t);
+            const float4 v = buf[g & 1][u];
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool act = (((ec >> (8 * k)) & 0xFFu) == er) & (__float_as_uint(vv[k]) != SQ_SENT_BITS);   // :438-451, :300-304
+                hist[k] = hist[k] + hist[k] + (act ? 1u : 0u);
+            }
+        }
+#ifdef SQ5_SCHEDBAR
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (g + 2 < 32 / SQ5_G) load_group(g + 2, buf[g & 1]);
+#ifdef SQ5_SCHEDBAR
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+
+extern "C" __global__ __launch_bounds__(64, SQ5_WPS) void sq_scan5_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) SqScan5Lds L;
+    const SqStruct st = structs[blockIdx.x];                            // grid = (structures, tiles), see sq_scan_kernel
+    const SqJob jb = c.jobs[st.job];
+    const int n = jb.n, ld = jb.ld;
+    if (n < 5) return;                                                  // :456-457 no diagonals
+    const int nband = (2 * n - 5 + 255) >> 8;
+    const int nseg = ((n >> 1) + 130 + SQ5_SEG - 1) / SQ5_SEG;
+    const int tile = blockIdx.y;
+    if (tile >= nband * nseg) return;
+    const int seg = tile / nband, band = tile - seg * nband;
+    const int s0 = band << 8;
+    const int smin = max(s0, 4), smax = min(s0 + 255, 2 * n - 6);       // :456-457 s in [4, 2N-6]
+    if (smin > smax) return;
+    const int rmin = max(0, smin - (n - 1)), rmax = (smax - 1) >> 1;    // :486 i <= j-1
+    const int rbeg = rmin + seg * SQ5_SEG;
+    if (rbeg > rmax) return;
+    const int rend = min(rbeg + SQ5_SEG, rmax + 1);
+    const int rhi = min(rmax, rend + SQ5_TAIL - 1);                     // last row that matters
+    const int lane = threadIdx.x;
+    const SqPsetDev *ps = c.psets + jb.pset;
+    const int minlen = max(1, (int)ceil(ps->minlen));
+    const int cap = jb.cand_cap;
+    const int sl = s0 + 4 * lane;
+
+    int lo[4], carry[4];
+    unsigned span[4];
+    uint32_t hist[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int s = sl + k;
+        const bool ok = s >= 4 && s <= 2 * n - 6;
+        lo[k] = ok ? max(0, s - (n - 1)) : 0x3fffffff;
+        span[k] = ok ? (unsigned)(((s - 1) >> 1) - lo[k]) : 0u;
+        carry[k] = 0; hist[k] = 0;
+    }
+    const bool fullband = s0 >= 4 && s0 + 255 <= 2 * n - 6;
+    const int wlo = fullband ? max(0, s0 + 255 - (n - 1)) : 0x3fffffff;  // rows where every cell of the wave exists
+    const int whi = fullband ? (s0 - 1) >> 1 : -1;
+
+    const uint8_t *eg = stt.E8 + (int64_t)st.slot * stt.stride * 2;
+    auto rowcode = [&](int row) -> uint32_t {                            // 0x100: masked or outside -> matches nothing
+        const uint32_t cde = (row >= 0 && row <= rhi) ? (uint32_t)eg[row] : 255u;
+        return cde == 255u ? 0x100u : cde;
+    };
+    if (lane == 0) L.stage_count = 0;
+    // column codes of the window anchored at row rref = rbeg + 127: copy c, dword m = codes jb0+4m+c .. +3
+    const int rref = rbeg + SQ5_ROWS - 1;
+    const int jb0 = s0 - rref;
+    for (int idx = lane; idx < 4 * SQ5_COLW; idx += 64) {
+        const int cpy = idx / SQ5_COLW, m = idx - cpy * SQ5_COLW;
+        uint32_t w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = jb0 + 4 * m + cpy + k;
+            const uint32_t code = (j >= 0 && j < n) ? (uint32_t)eg[j] : 255u;
+            w |= code << (8 * k);
+        }
+        L.ecol[cpy][m] = w;
+    }
+    __syncthreads();
+
+    const float *mat = c.mat32 + jb.mat_off;
+    const int pitch = ld - 1;
+
+    // ---- the row above the segment: runs already open there belong to the previous wave
+    if (rbeg > rmin) {
+        const int row = rbeg - 1;
+        const uint32_t er = rowcode(row);
+        const int sfirst = max((2 * row + 1) & ~3, s0), slast = min((row + n - 1) & ~3, s0 + 252);
+        const float4 v = *reinterpret_cast<const float4 *>(mat + (int64_t)row * pitch + min(max(sl, sfirst), slast));
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = sl + k - row;
+            const uint32_t ej = (j >= 0 && j < n) ? (uint32_t)eg[j] : 255u;
+            const bool act = (ej == er) & (__float_as_uint(vv[k]) != SQ_SENT_BITS) & ((unsigned)(row - lo[k]) <= span[k]);
+            carry[k] = act ? SQ_FOREIGN : 0;
+        }
+    }
+    // ---- chunks of 32 rows
+    const int nch = (rhi - rbeg) / 32 + 1;
+    for (int ch = 0; ch < nch; ch++) {
+        const int cb = rbeg + 32 * ch;
+        const uint32_t cc = rowcode(cb + lane);                          // lane t: code of row cb + t
+#pragma unroll
+        for (int k = 0; k < 4; k++) hist[k] = 0;
+        // d = rref - row = 127 - 32 ch - t  ->  dword (d >> 2) = 31 - 8 ch - (t >> 2), copy d & 3 = 3 - (t & 3)
+        const uint32_t *ecol_row0 = &L.ecol[0][0] + (SQ5_ROWS / 4 - 1 - 8 * ch) + lane;
+        const float *rowptr = mat + (int64_t)cb * pitch;
+        if (cb >= wlo && cb + 31 <= whi) sq5_chunk<false>(rowptr, pitch, sl, s0, n, cb, ecol_row0, cc, hist);
+        else {
+            sq5_chunk<true>(rowptr, pitch, sl, s0, n, cb, ecol_row0, cc, hist);
+            // staircase chunk: drop the bits of cells that lie outside their diagonal (rows lo..hi of
+            // diagonal s; bit p <-> row cb + 31 - p) -- one AND per diagonal instead of a test per cell
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int s = sl + k;
+                const int lo_ = max(0, s - (n - 1)), hi_ = (s - 1) >> 1;
+                const int plo = max(0, cb + 31 - hi_), phi = min(31, cb + 31 - lo_);
+                uint32_t m = 0;
+                if (s >= 4 && s <= 2 * n - 6 && plo <= phi) m = ((2u << phi) - 1u) & ~((1u << plo) - 1u);
+                hist[k] &= m;
+            }
+        }
+        // ---- extract the runs of this chunk (bit 0 = row cb + 31)
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) any |= (hist[k] != 0u) | (carry[k] > 0);
+#ifdef SQ5_ABLATE_ANALYSE
+        asm volatile("" ::"v"(hist[0]), "v"(hist[1]), "v"(hist[2]), "v"(hist[3]));
+        any = false;
+#endif
+        if (__ballot(any) != 0ull) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) sq5_analyse(L, a, st, cap, sl + k, hist[k], 32, cb, rend, minlen, carry[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) carry[k] = 0;
+        }
+        if (L.stage_count > SQ5_STAGE / 2) sq5_flush(L, a, st, cap, lane);
+    }
+    // ---- runs still open after the pipelined rows: finish them row by row (rare)
+    int r = rbeg + 32 * nch;
+    for (;;) {
+        bool open = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) open |= carry[k] > 0;
+        if (__ballot(open) == 0ull) break;
+        uint32_t er = 0x100u;
+        if (r <= rmax) { const uint32_t cde = (uint32_t)__builtin_amdgcn_readfirstlane((int)eg[r]); er = cde == 255u ? 0x100u : cde; }
+        bool act[4] = {false, false, false, false};
+        if (er != 0x100u) {
+            const int sfirst = max((2 * r + 1) & ~3, s0), slast = min((r + n - 1) & ~3, s0 + 252);
+            const float4 v = *reinterpret_cast<const float4 *>(mat + (int64_t)r * pitch + min(max(sl, sfirst), slast));
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = sl + k - r;
+                const uint32_t ej = (j >= 0 && j < n) ? (uint32_t)eg[j] : 255u;
+                act[k] = (ej == er) & (__float_as_uint(vv[k]) != SQ_SENT_BITS) & ((unsigned)(r - lo[k]) <= span[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (carry[k] > 0) {
+                if (act[k]) carry[k]++;
+                else {
+                    if (carry[k] >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)(sl + k) << 16) | (uint32_t)(r - carry[k]), (uint32_t)carry[k]);
+                    carry[k] = 0;
+                }
+            }
+        }
+        if (r > rmax) break;
+        r++;
+    }
+    __syncthreads();
+    sq5_flush(L, a, st, cap, lane);
+}
+
+int sq_scan5_seg() { return SQ5_SEG; }
+
 size_t sq_scan_lds_fixed() { return sizeof(SqScanLds); }
 int sq_scan_seg() { return SQ_SEG; }
 
@@ -512,43 +844,69 @@ __device__ __forceinline__ bool sq_goodloop(int x, int y)             // :615-62
     return (tab[x] >> y) & 1u;
 }
 
-extern "C" __global__ __launch_bounds__(256) void sq_score_kernel(SqDevCtx c, const SqStruct *structs,
+extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, const SqStruct *structs,
                                                                   const SqStrand *strands, SqState stt, SqScanArgs a,
-                                                                  SqOut *out, uint32_t out_cap, int mode)
+                                                                  SqOut *out, uint32_t out_cap, int mode, int lds_n,
+                                                                  int lds_n_reacts)
 {
     __shared__ SqStrand s_str[SQ_LDS_STRANDS];
-    __shared__ double r_fin[4];
-    __shared__ uint32_t r_key[4];
-    __shared__ int r_any[4];
+    __shared__ double s_w[32 * 32];               // pair weights of the job's paramset
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];   // letter codes [n] (+ reactivities [n] when they fit)
+    __shared__ double r_fin[16];
+    __shared__ uint32_t r_key[16];
+    __shared__ int r_any[16];
     const SqStruct st = structs[blockIdx.x];
     const SqJob jb = c.jobs[st.job];
     const SqPsetDev *ps = c.psets + jb.pset;
     const int n = jb.n;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     uint32_t ncand = a.cand_cnt[st.slot];
     if (ncand > (uint32_t)jb.cand_cap) ncand = jb.cand_cap;
     const SqStrand *S = strands + st.strand_off;
     if (st.nstrand <= SQ_LDS_STRANDS) {
-        for (int k = tid; k < st.nstrand; k += 256) s_str[k] = S[k];
+        for (int k = tid; k < st.nstrand; k += nthr) s_str[k] = S[k];
         S = s_str;
     }
     __syncthreads();
     const int16_t *P = stt.P + (int64_t)st.slot * stt.stride;
     const int16_t *U = stt.U + (int64_t)st.slot * stt.stride;
     const int16_t *SU = stt.SU + (int64_t)st.slot * stt.stride;
+    // the exact re-scoring touches codes / weights / reactivities once per cell: keep them in LDS
+    uint8_t *l_codes = reinterpret_cast<uint8_t *>(s_dyn);
+    double *l_reacts = reinterpret_cast<double *>(s_dyn + ((n + 15) & ~15));
+    const bool lds_cells = jb.mat64_off < 0 && lds_n >= n;
+    const bool lds_reacts = lds_cells && !jb.default_reacts && lds_n_reacts >= n;
+    if (lds_cells) {
+        for (int p = tid; p < n; p += nthr) l_codes[p] = c.codes[jb.pos_off + p];
+        for (int p = tid; p < 32 * 32; p += nthr) s_w[p] = ps->w[p];
+        if (lds_reacts) for (int p = tid; p < n; p += nthr) l_reacts[p] = c.reacts[jb.pos_off + p];
+    }
+    __syncthreads();
     const uint8_t *codes = c.codes + jb.pos_off;
     SqCand *cands = a.cands + st.cand_off;
     const double minbps = ps->minbpscore, minfin = ps->minfinscore;
+    auto cell_exact = [&](int i, int j) -> double {
+        if (!lds_cells) return sq_cell_exact(c, jb, ps, i, j);
+        const double w = s_w[l_codes[i] * 32 + l_codes[j]];             // same expression as sq_cell_score
+        double rf = 1.0;
+        if (!jb.default_reacts) {
+            const double ri = lds_reacts ? l_reacts[i] : c.reacts[jb.pos_off + i];
+            const double rj = lds_reacts ? l_reacts[j] : c.reacts[jb.pos_off + j];
+            rf = sqrt((1.0 - (ri + rj) / 2.0) * 2.0);
+        }
+        if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
+        return w * rf;
+    };
 
     double best = 0.0; uint32_t bestkey = 0xFFFFFFFFu; int any = 0;
 
-    for (uint32_t q = tid; q < ncand; q += 256) {
+    for (uint32_t q = tid; q < ncand; q += nthr) {
         SqCand cd = cands[q];
         const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), L = (int)cd.len, j0 = s - i0;
         // exact bpscore: sum(...) left to right starting from int 0  (:416)
         double bps = 0.0;
         for (int t = 0; t < L; t++) {
-            const double v = sq_cell_exact(c, jb, ps, i0 + t, j0 - t);
+            const double v = cell_exact(i0 + t, j0 - t);
             bps = bps + v;
         }
         bool ok = bps >= minbps;                                        // :492
@@ -621,8 +979,8 @@ extern "C" __global__ __launch_bounds__(256) void sq_score_kernel(SqDevCtx c, co
             ok = fin >= minfin;                                         // :751
         }
         cd.bps = bps; cd.fin = fin; cd.flags = ok ? 1u : 0u;
-        cands[q].bps = bps; cands[q].fin = fin; cands[q].flags = cd.flags;
-        if (ok) {
+        if (ok) {                                                        // flags were zeroed by the scan: nothing to write otherwise
+            cands[q].bps = bps; cands[q].fin = fin; cands[q].flags = 1u;
             if (mode == 1) {
                 const uint32_t o = atomicAdd(&a.ctr->nout, 1u);
                 if (o < out_cap) { SqOut r = {(int32_t)blockIdx.x, cd.key, L, 0, bps, 0.0}; out[o] = r; }
@@ -644,13 +1002,13 @@ extern "C" __global__ __launch_bounds__(256) void sq_score_kernel(SqDevCtx c, co
     if ((tid & 63) == 0) { r_fin[tid >> 6] = best; r_key[tid >> 6] = bestkey; r_any[tid >> 6] = any; }
     __syncthreads();
     any = 0; best = 0.0; bestkey = 0xFFFFFFFFu;
-    for (int w = 0; w < 4; w++)
+    for (int w = 0; w < (nthr >> 6); w++)
         if (r_any[w] && (!any || r_fin[w] > best || (r_fin[w] == best && r_key[w] < bestkey))) {
             any = 1; best = r_fin[w]; bestkey = r_key[w];
         }
     if (!any) return;
     const double range = st.subopt * best;                              // :769
-    for (uint32_t q = tid; q < ncand; q += 256) {
+    for (uint32_t q = tid; q < ncand; q += nthr) {
         const SqCand cd = cands[q];
         if (cd.flags && !(cd.fin < range)) {                            // :778
             const uint32_t o = atomicAdd(&a.ctr->nout, 1u);

@@ -1,0 +1,98 @@
+// Micro-benchmark: what does the scan's address stream cost with NO compute?
+//  lin : every wave streams contiguous 1-KiB pieces
+//  col : the scan's geometry: wave = 1 KiB x 128 rows of one of S matrices (pitch P floats), rows
+//        pipelined 8 deep; grid (S, tiles) like sq_scan_kernel
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__global__ __launch_bounds__(64) void lin(const float4 *p, size_t n4, float *out)
+{
+    float acc = 0;
+    size_t per = 128;                                 // 128 x 1 KiB per wave
+    size_t base = (size_t)blockIdx.x * per * 64;
+    for (size_t r = 0; r < per; r += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p[(base + (r + u) * 64 + threadIdx.x) % n4];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+
+template <bool CLAMP>
+__global__ __launch_bounds__(64) void col(const float *mat, size_t matstride, int n, int pitch, float *out)
+{
+    const int S = blockIdx.x, tile = blockIdx.y;
+    const int nband = (2 * n - 5 + 255) >> 8, nseg = ((n >> 1) + 130 + 123) / 124;
+    if (tile >= nband * nseg) return;
+    const int seg = tile / nband, band = tile - seg * nband;
+    const int s0 = band << 8;
+    const int smin = max(s0, 4), smax = min(s0 + 255, 2 * n - 6);
+    if (smin > smax) return;
+    const int rmin = max(0, smin - (n - 1)), rmax = (smax - 1) >> 1;
+    const int rbeg = rmin + seg * 124;
+    if (rbeg > rmax) return;
+    const int rhi = min(rmax, rbeg + 127);
+    const float *base = mat + (size_t)S * matstride;
+    const int sl = s0 + 4 * threadIdx.x;
+    float acc = 0;
+    for (int r = rbeg; r <= rhi; r += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int row = min(r + u, rhi);
+            int sc = sl;
+            if (CLAMP) { const int sfirst = max((2 * row + 1) & ~3, s0), slast = min((row + n - 1) & ~3, s0 + 252); sc = min(max(sl, sfirst), slast); }
+            v[u] = *reinterpret_cast<const float4 *>(base + (size_t)row * pitch + sc);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+
+int main(int argc, char **argv)
+{
+    const int S = argc > 1 ? atoi(argv[1]) : 512, n = argc > 2 ? atoi(argv[2]) : 1000;
+    for (int odd = 0; odd < 2; odd++) {
+        int k = (n - 1 + 31) / 32;
+        if (odd && (k & 1) == 0) k++;
+        const int ld = 32 * k + 1, pitch = ld - 1;
+        const size_t matstride = ((size_t)n * ld + 63) / 64 * 64;
+        const size_t floats = matstride * S + 200 * ld + 4096;
+        float *d, *out;
+        CK(hipMalloc(&d, floats * 4)); CK(hipMalloc(&out, 64));
+        CK(hipMemset(d, 0, floats * 4));
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const int nband = (2 * n - 5 + 255) >> 8, nseg = ((n >> 1) + 130 + 123) / 124;
+        for (int rep = 0; rep < 3; rep++) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(col<false>, dim3(S, nband * nseg), dim3(64), 0, 0, d, matstride, n, pitch, out);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("col  ld=%d: %.3f ms  %.1f GB/s algorithmic (2N^2 per matrix)\n", ld, ms, 2.0 * n * n * S / ms / 1e6);
+        }
+        for (int rep = 0; rep < 3; rep++) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(col<true>, dim3(S, nband * nseg), dim3(64), 0, 0, d, matstride, n, pitch, out);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("colC ld=%d: %.3f ms  %.1f GB/s algorithmic (staircase lanes clamped)\n", ld, ms, 2.0 * n * n * S / ms / 1e6);
+        }
+        const size_t n4 = floats / 4;
+        const size_t waves = (size_t)S * n * n * 2 / (128 * 1024);      // same byte count as the algorithmic figure
+        for (int rep = 0; rep < 3; rep++) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(lin, dim3((unsigned)waves), dim3(64), 0, 0, (const float4 *)d, n4, out);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("lin        : %.3f ms  %.1f GB/s\n", ms, (double)waves * 128 * 1024 / ms / 1e6);
+        }
+        CK(hipFree(d)); CK(hipFree(out));
+    }
+    return 0;
+}
