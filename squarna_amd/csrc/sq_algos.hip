@@ -166,13 +166,13 @@ int sq_run_algo(sq_batch *b, const std::vector<int> &jobs, int algo, int levelli
         }
         else if (algo == SQ_ALGO_N) hipLaunchKernelGGL(sq_nussinov_kernel, dim3(nj), dim3(256), 0, st, d_jobs, d_edges, b->ctx.codes, d_scr, d_out, d_cnt);
         else {
+            // dynamic LDS for the blossom state of the largest job (up to 150 KiB of the CU's 160)
+            size_t want = SqBlossom::scratch_bytes(maxn, maxm, 1) + (((size_t)maxm * sizeof(SqMatchEdge) + 15) & ~(size_t)15) + 64;
             static bool attr_set = false;
-            if (!attr_set) { hipFuncSetAttribute((const void *)sq_mwm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr_set = true; }
-            // LDS-resident state did not pay for the one-thread-per-job form (generic-pointer LDS access is as slow
-            // as an L2 hit); the wave-cooperative form is the next step.  0 = keep the state in global memory.
-            const size_t want = getenv("SQ_MWM_LDS") ? SqBlossom::scratch_bytes(maxn, maxm, 1) + (size_t)maxm * sizeof(SqMatchEdge) + 64 : 0;
-            const int lds = (int)std::min<size_t>(want, 160 * 1024 - 256);
-            hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), lds, st, d_jobs, d_edges, d_scr, d_out, lds);
+            if (!attr_set) { hipFuncSetAttribute((const void *)sq_mwm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+            want = std::min<size_t>(want, 150 * 1024);             // jobs that do not fit run in global memory
+            if (getenv("SQ_MWM_NOLDS")) want = 0;
+            hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), want, st, d_jobs, d_edges, d_scr, d_out, (int)want);
         }
         HIPCK(hipGetLastError());
         std::vector<int32_t> h_out(outints + 4), h_cnt(mj.size() + 1);

@@ -411,104 +411,171 @@ struct SqBlossom {
         }
     }
 
-    SQ_HD void run()
+    // cooperative form: every lane of a wave (or the single host thread: lane 0 of 1) calls run() on the
+    // SAME object.  The order-dependent work stays on lane 0; the O(n) sweeps of every substage (label
+    // clears, the four delta minima, the dual updates) are strided over the lanes.  Minima keep the
+    // sequential rule "first strictly smaller wins": per lane the first minimum of its stride, then
+    // across lanes the smallest value and, among equals, the smallest iteration index.
+    int f_augmented, f_stop, f_break;
+    double red_v[64][4];
+    int red_i[64][4];
+
+    template <class Sync>
+    SQ_HD void run(int lane, int nl, Sync sync)
     {
         const int N2 = 2 * n + 2;
-        for (int v = 0; v < n; v++) { mate[v] = -1; mate_de[v] = -1; inblossom[v] = v; }
-        for (int x = 0; x < N2; x++) {
+        for (int v = lane; v < n; v += nl) { mate[v] = -1; mate_de[v] = -1; inblossom[v] = v; }
+        for (int x = lane; x < N2; x += nl) {
             label[x] = 0; labeledge[x] = -1; parent[x] = -1; base[x] = x < n ? x : -1; bestedge[x] = -1;
             bdual[x] = 0; mbe_cnt[x] = -1; mbe_off[x] = 0; beto[x] = -1; nchild[x] = 0; first[x] = -1;
         }
-        nlive = 0; nfree = 0;
-        for (int b = 2 * n - 1; b >= n; b--) freeb[nfree++] = b;
-        if (n == 0) return;
-        double maxweight = 0;
-        for (int e = 0; e < m; e++) if (E[e].v != E[e].w && E[e].weight > maxweight) maxweight = E[e].weight;
-        for (int v = 0; v < n; v++) dualvar[v] = maxweight;
-        for (;;) {                                          // stages
-            for (int x = 0; x < N2; x++) { label[x] = 0; labeledge[x] = -1; bestedge[x] = -1; }
-            for (int k = 0; k < nlive; k++) mbe_cnt[live[k]] = -1;
-            pool_n = 0;
-            for (int e = 0; e < m; e++) allow[e] = 0;
-            qn = 0;
-            for (int v = 0; v < n; v++)
-                if (mate[v] == -1 && label[inblossom[v]] == 0) assignLabel(v, 1, -1);
-            bool augmented = false;
-            for (;;) {                                      // substages
-                while (qn && !augmented) {
-                    const int v = queue[--qn];
-                    for (int a = adj_off[v]; a < adj_off[v + 1]; a++) {
-                        const int de = adj[a];
-                        const int w = head(de);
-                        if (w == v) continue;
-                        const int bv = inblossom[v], bw = inblossom[w];
-                        if (bv == bw) continue;
-                        double kslack = 0;
-                        if (!allow[de >> 1]) {
-                            kslack = slack(de);
-                            if (kslack <= 0) allow[de >> 1] = 1;
-                        }
-                        if (allow[de >> 1]) {
-                            if (label[bw] == 0) assignLabel(w, 2, de);
-                            else if (label[bw] == 1) {
-                                const int bs = scanBlossom(v, w);
-                                if (bs != -1) addBlossom(bs, de);
-                                else { augmentMatching(de); augmented = true; break; }
-                            } else if (label[w] == 0) {
-                                label[w] = 2; labeledge[w] = de;
-                            }
-                        } else if (label[bw] == 1) {
-                            if (bestedge[bv] == -1 || kslack < slack(bestedge[bv])) bestedge[bv] = de;
-                        } else if (label[w] == 0) {
-                            if (bestedge[w] == -1 || kslack < slack(bestedge[w])) bestedge[w] = de;
-                        }
-                    }
-                }
-                if (augmented) break;
-                int deltatype = 1, deltaedge = -1, deltablossom = -1;
-                double delta = dualvar[0];
-                for (int v = 1; v < n; v++) if (dualvar[v] < delta) delta = dualvar[v];
-                for (int v = 0; v < n; v++)
-                    if (label[inblossom[v]] == 0 && bestedge[v] != -1) {
-                        const double d = slack(bestedge[v]);
-                        if (d < delta) { delta = d; deltatype = 2; deltaedge = bestedge[v]; }
-                    }
-                for (int k = 0; k < n + nlive; k++) {        // `for b in blossomparent`: vertices, then blossoms
-                    const int b = k < n ? k : live[k - n];
-                    if (parent[b] == -1 && label[b] == 1 && bestedge[b] != -1) {
-                        const double d = slack(bestedge[b]) / 2.0;
-                        if (d < delta) { delta = d; deltatype = 3; deltaedge = bestedge[b]; }
-                    }
-                }
-                for (int k = 0; k < nlive; k++) {
-                    const int b = live[k];
-                    if (parent[b] == -1 && label[b] == 2 && bdual[b] < delta) { delta = bdual[b]; deltatype = 4; deltablossom = b; }
-                }
-                for (int v = 0; v < n; v++) {
-                    const int lb = label[inblossom[v]];
-                    if (lb == 1) dualvar[v] -= delta; else if (lb == 2) dualvar[v] += delta;
-                }
-                for (int k = 0; k < nlive; k++) {
-                    const int b = live[k];
-                    if (parent[b] == -1) { if (label[b] == 1) bdual[b] += delta; else if (label[b] == 2) bdual[b] -= delta; }
-                }
-                if (deltatype == 1) break;
-                if (deltatype == 2 || deltatype == 3) { allow[deltaedge >> 1] = 1; qpush(tail(deltaedge)); }
-                else expandBlossom(deltablossom, false);
-                if (error) return;
-            }
-            if (!augmented) break;
-            // end of stage: expand S-blossoms with zero dual (snapshot of the dict keys)
-            int snap = nlive;
-            for (int k = 0; k < snap; k++) tmp_path[k] = live[k];
-            for (int k = 0; k < snap; k++) {
-                const int b = tmp_path[k];
-                bool alive = false;
-                for (int q = 0; q < nlive; q++) if (live[q] == b) { alive = true; break; }
-                if (!alive) continue;
-                if (parent[b] == -1 && label[b] == 1 && bdual[b] == 0) expandBlossom(b, true);
-            }
-            if (error) return;
+        if (lane == 0) {
+            nlive = 0; nfree = 0;
+            for (int b = 2 * n - 1; b >= n; b--) freeb[nfree++] = b;
         }
+        sync();
+        if (n == 0) return;
+        {
+            double maxweight = 0;                               // every lane computes the same value
+            for (int e = 0; e < m; e++) if (E[e].v != E[e].w && E[e].weight > maxweight) maxweight = E[e].weight;
+            for (int v = lane; v < n; v += nl) dualvar[v] = maxweight;
+        }
+        sync();
+        for (;;) {                                              // stages
+            for (int x = lane; x < N2; x += nl) { label[x] = 0; labeledge[x] = -1; bestedge[x] = -1; }
+            for (int k = lane; k < nlive; k += nl) mbe_cnt[live[k]] = -1;
+            for (int e = lane; e < m; e += nl) allow[e] = 0;
+            sync();
+            if (lane == 0) {
+                pool_n = 0; qn = 0;
+                for (int v = 0; v < n; v++)
+                    if (mate[v] == -1 && label[inblossom[v]] == 0) assignLabel(v, 1, -1);
+                f_augmented = 0;
+            }
+            sync();
+            for (;;) {                                          // substages
+                if (lane == 0) {
+                    bool augmented = false;
+                    while (qn && !augmented) {
+                        const int v = queue[--qn];
+                        for (int a = adj_off[v]; a < adj_off[v + 1]; a++) {
+                            const int de = adj[a];
+                            const int w = head(de);
+                            if (w == v) continue;
+                            const int bv = inblossom[v], bw = inblossom[w];
+                            if (bv == bw) continue;
+                            double kslack = 0;
+                            if (!allow[de >> 1]) {
+                                kslack = slack(de);
+                                if (kslack <= 0) allow[de >> 1] = 1;
+                            }
+                            if (allow[de >> 1]) {
+                                if (label[bw] == 0) assignLabel(w, 2, de);
+                                else if (label[bw] == 1) {
+                                    const int bs = scanBlossom(v, w);
+                                    if (bs != -1) addBlossom(bs, de);
+                                    else { augmentMatching(de); augmented = true; break; }
+                                } else if (label[w] == 0) {
+                                    label[w] = 2; labeledge[w] = de;
+                                }
+                            } else if (label[bw] == 1) {
+                                if (bestedge[bv] == -1 || kslack < slack(bestedge[bv])) bestedge[bv] = de;
+                            } else if (label[w] == 0) {
+                                if (bestedge[w] == -1 || kslack < slack(bestedge[w])) bestedge[w] = de;
+                            }
+                        }
+                    }
+                    f_augmented = augmented ? 1 : 0;
+                }
+                sync();
+                if (f_augmented || error) break;
+                // ---- the four delta candidates, strided over the lanes
+                {
+                    double m1 = 1e300; double m2 = 1e300, m3 = 1e300, m4 = 1e300;
+                    int i2 = -1, i3 = -1, i4 = -1;
+                    for (int v = lane; v < n; v += nl) {
+                        if (dualvar[v] < m1) m1 = dualvar[v];
+                        if (label[inblossom[v]] == 0 && bestedge[v] != -1) {
+                            const double d = slack(bestedge[v]);
+                            if (i2 == -1 || d < m2) { m2 = d; i2 = v; }
+                        }
+                    }
+                    for (int k = lane; k < n + nlive; k += nl) {   // `for b in blossomparent`: vertices, then blossoms
+                        const int b = k < n ? k : live[k - n];
+                        if (parent[b] == -1 && label[b] == 1 && bestedge[b] != -1) {
+                            const double d = slack(bestedge[b]) / 2.0;
+                            if (i3 == -1 || d < m3) { m3 = d; i3 = k; }
+                        }
+                    }
+                    for (int k = lane; k < nlive; k += nl) {
+                        const int b = live[k];
+                        if (parent[b] == -1 && label[b] == 2 && (i4 == -1 || bdual[b] < m4)) { m4 = bdual[b]; i4 = k; }
+                    }
+                    red_v[lane][0] = m1; red_v[lane][1] = m2; red_v[lane][2] = m3; red_v[lane][3] = m4;
+                    red_i[lane][1] = i2; red_i[lane][2] = i3; red_i[lane][3] = i4;
+                }
+                sync();
+                if (lane == 0) {
+                    double m1 = red_v[0][0];
+                    double mm[4] = {0, 0, 0, 0}; int ii[4] = {-1, -1, -1, -1};
+                    for (int l = 0; l < nl; l++) {
+                        if (red_v[l][0] < m1) m1 = red_v[l][0];
+                        for (int t = 1; t < 4; t++) {
+                            const int idx = red_i[l][t];
+                            if (idx == -1) continue;
+                            if (ii[t] == -1 || red_v[l][t] < mm[t] || (red_v[l][t] == mm[t] && idx < ii[t])) { mm[t] = red_v[l][t]; ii[t] = idx; }
+                        }
+                    }
+                    int deltatype = 1, deltaedge = -1, deltablossom = -1;
+                    double delta = m1;
+                    if (ii[1] != -1 && mm[1] < delta) { delta = mm[1]; deltatype = 2; deltaedge = bestedge[ii[1]]; }
+                    if (ii[2] != -1 && mm[2] < delta) { delta = mm[2]; deltatype = 3; const int b = ii[2] < n ? ii[2] : live[ii[2] - n]; deltaedge = bestedge[b]; }
+                    if (ii[3] != -1 && mm[3] < delta) { delta = mm[3]; deltatype = 4; deltablossom = live[ii[3]]; }
+                    red_v[0][0] = delta; red_i[0][0] = deltatype; red_i[0][1] = deltaedge; red_i[0][2] = deltablossom;
+                }
+                sync();
+                {
+                    const double delta = red_v[0][0];
+                    for (int v = lane; v < n; v += nl) {
+                        const int lb = label[inblossom[v]];
+                        if (lb == 1) dualvar[v] -= delta; else if (lb == 2) dualvar[v] += delta;
+                    }
+                    for (int k = lane; k < nlive; k += nl) {
+                        const int b = live[k];
+                        if (parent[b] == -1) { if (label[b] == 1) bdual[b] += delta; else if (label[b] == 2) bdual[b] -= delta; }
+                    }
+                }
+                sync();
+                if (lane == 0) {
+                    const int deltatype = red_i[0][0], deltaedge = red_i[0][1], deltablossom = red_i[0][2];
+                    f_stop = 0;
+                    if (deltatype == 1) f_stop = 1;
+                    else if (deltatype == 2 || deltatype == 3) { allow[deltaedge >> 1] = 1; qpush(tail(deltaedge)); }
+                    else expandBlossom(deltablossom, false);
+                }
+                sync();
+                if (f_stop || error) break;
+            }
+            if (!f_augmented || error) break;
+            // end of stage: expand S-blossoms with zero dual (snapshot of the dict keys)
+            if (lane == 0) {
+                int snap = nlive;
+                for (int k = 0; k < snap; k++) tmp_path[k] = live[k];
+                for (int k = 0; k < snap; k++) {
+                    const int b = tmp_path[k];
+                    bool alive = false;
+                    for (int q = 0; q < nlive; q++) if (live[q] == b) { alive = true; break; }
+                    if (!alive) continue;
+                    if (parent[b] == -1 && label[b] == 1 && bdual[b] == 0) expandBlossom(b, true);
+                }
+            }
+            sync();
+            if (error) break;
+        }
+    }
+
+    SQ_HD void run()
+    {
+        run(0, 1, [] {});
     }
 };

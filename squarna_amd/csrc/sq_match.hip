@@ -200,32 +200,35 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
 extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges,
                                                                char *scratch, int32_t *mate_out, int lds_bytes)
 {
+    __shared__ SqBlossom bl;          // one wave per job shares the algorithm state
     extern __shared__ __attribute__((aligned(16))) char mwm_lds[];
     const SqMatchJob *jp = jobs + blockIdx.x;
-    const int n = jp->n, m = jp->nedges;
+    const int n = jp->n, m = jp->nedges, lane = threadIdx.x;
     if (n <= 0) return;
-    // The algorithm is a chain of dependent loads: keep the whole state (and the edge list) in LDS
-    // when it fits, with tight capacities; on a capacity overflow rerun the job in global memory.
-    const size_t tight = SqBlossom::scratch_bytes(n, m, 1), ebytes = (size_t)m * sizeof(SqMatchEdge);
-    const bool in_lds = tight + ebytes + 16 <= (size_t)lds_bytes;
-    const SqMatchEdge *E = edges + jp->edge_off;
+    // The algorithm is a long chain of dependent loads on lane 0: keep its arrays and the edge list in LDS
+    // when they fit (tight capacities); on a capacity overflow rerun the job in global memory.
+    const size_t ebytes = ((size_t)m * sizeof(SqMatchEdge) + 15) & ~(size_t)15;
+    const bool in_lds = SqBlossom::scratch_bytes(n, m, 1) + ebytes + 16 <= (size_t)lds_bytes;
     if (in_lds) {
         SqMatchEdge *le = reinterpret_cast<SqMatchEdge *>(mwm_lds);
-        for (int e = threadIdx.x; e < m; e += 64) le[e] = E[e];
+        for (int e = lane; e < m; e += 64) le[e] = edges[jp->edge_off + e];
         __syncthreads();
-        E = le;
+        if (lane == 0) bl.init(n, m, le, mwm_lds + ebytes, 1);
+        __syncthreads();
+        bl.run(lane, 64, [] { __syncthreads(); });
+        __syncthreads();
+        if (!bl.error) {
+            for (int q = lane; q < n; q += 64) mate_out[jp->out_off + q] = bl.mate[q];
+            return;
+        }
+        __syncthreads();
     }
-    if (threadIdx.x != 0) return;     // one thread per job; one job per block spreads the jobs over the CUs
-    SqBlossom bl;
-    if (in_lds) {
-        bl.init(n, m, E, mwm_lds + ((ebytes + 15) & ~(size_t)15), 1);
-        bl.run();
-        if (bl.error) { bl.init(n, m, edges + jp->edge_off, scratch + jp->scratch_off, 0); bl.run(); }
-    } else {
-        bl.init(n, m, E, scratch + jp->scratch_off, 0);
-        bl.run();
-    }
-    for (int q = 0; q < n; q++) mate_out[jp->out_off + q] = bl.error ? -2 : bl.mate[q];
+    if (lane == 0) bl.init(n, m, edges + jp->edge_off, scratch + jp->scratch_off, 0);
+    __syncthreads();
+    // lane 0 runs the order-dependent part; all 64 lanes share the O(n) sweeps of every substage
+    bl.run(lane, 64, [] { __syncthreads(); });
+    __syncthreads();
+    for (int q = lane; q < n; q += 64) mate_out[jp->out_off + q] = bl.error ? -2 : bl.mate[q];
 }
 
 size_t sq_lsap_scratch_bytes(int n)

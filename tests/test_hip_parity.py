@@ -262,3 +262,52 @@ def test_runalgo_vs_oracle_random():
             bm, sm = O.BPMatrix(s, p["bpweights"], set(), set(), set(), False, [0.5] * len(s))
             exp = O.RunAlgo(s, bm, sm, [], p["minlen"], p["minbpscore"], algo=algo, levellimit=3 - int(len(s) > 500))
             close_stems([x[:4] for x in g], [e[:4] for e in exp], (algo, len(s)))
+
+
+# ---- BASELINE.json sizes: synthetic S300 / S1000 / S2000, against the oracle on a
+#      sample, plus size-independent properties on the whole batch
+def _synthetic(n, count, seed, reacts=False):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        seq = "".join(rng.choice(list("ACGU"), n))
+        rc = None
+        if reacts:                                   # C4: reactivity line drawn from "_+#" with p = (0.5, 0.3, 0.2)
+            from squarna_amd.dbn import ProcessReacts, ReactDict
+            line = "".join(rng.choice(list("_+#"), n, p=[0.5, 0.3, 0.2]))
+            rc = ProcessReacts([ReactDict[c] for c in line], M=1.8, B=-0.6)
+        out.append((seq, rc))
+    return out
+
+
+@pytest.mark.parametrize("n,count,seed,reacts,sample", [(300, 64, 300, False, 6), (1000, 24, 1000, False, 3),
+                                                        (2000, 6, 2000, True, 2)])
+def test_baseline_sizes_vs_oracle_and_properties(n, count, seed, reacts, sample):
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import HipEngine
+    names, psets = conf("fastest")
+    data = _synthetic(n, count, seed, reacts)
+    recs = [(s, rc, None, None, psets, None) for s, rc in data]
+    got = HipEngine().fold_records(recs, poollim=1)
+    # (1) a sample against the CPU oracle: structures identical, scores within 1e-5
+    for k in range(sample):
+        s, rc = data[k]
+        exp = O.SQRNdbnseq(s, rc, None, None, psets, poollim=1)
+        exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(got[k], exp, ("S%d" % n, k))
+    # (2) batch independence + determinism: folding a record alone gives the same answer as in the batch
+    for k in (0, count - 1):
+        alone = HipEngine().fold_records([recs[k]], poollim=1)[0]
+        assert alone[0] == got[k][0] and alone[1] == got[k][1], ("alone vs batch", n, k)
+    again = HipEngine().fold_records(recs[:4], poollim=1)
+    assert [g[:2] for g in again] == [g[:2] for g in got[:4]]
+    # (3) every predicted structure is a valid matching of allowed pairs (GC/AU/GU, i < j - 3)
+    from squarna_amd.dbn import DBNToPairs
+    ok = {"GC", "CG", "AU", "UA", "GU", "UG"}
+    for (s, rc), g in zip(data, got):
+        for dbn, sc, ps_ in g[1]:
+            assert len(dbn) == n
+            pairs = DBNToPairs(dbn)
+            used = [p for bp in pairs for p in bp]
+            assert len(used) == len(set(used))
+            assert all(s[i] + s[j] in ok and j - i >= 4 for i, j in pairs)
