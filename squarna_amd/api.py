@@ -142,9 +142,8 @@ def Predict(inputfile=None, fileformat="unknown", inputseq=None, configfile=None
     elif "s" in rankby:
         rankby = (1, 2, 0)
 
-    if alignment:
-        raise NotImplementedError("alignment mode (SQRNdbnali.py) is outside the accelerated hot path of this "
-                                  "build; see DESIGN.md 'next rows'")
+    if alignment and not configfileset:                          # SQUARNA.py:822-824
+        configfile = os.path.join(HOME_DIR, "ali.conf")
     if rfam or g4 or rbp:
         raise NotImplementedError("Rfam / G4 / RBP restraint discovery (SQRNrfam.py) is out of scope of this build")
 
@@ -160,6 +159,31 @@ def Predict(inputfile=None, fileformat="unknown", inputseq=None, configfile=None
 
     inputs, fmt, single_input = ParseInput(inputseq, inputfile, inputformat, fmt=fileformat,
                                            ignore=ignorewarn, inputrestr=inputrestr, M=M, B=B)
+    if alignment:                                                # SQUARNA.py:938-991
+        from .align import RunSQRNdbnali
+        from .dbn import ReactDict, ProcessReacts
+        defR, defS, defF = ParseInput(inputseq, inputfile, inputformat, returndefaults=True, fmt=fmt,
+                                      ignore=ignorewarn, M=M, B=B)[0]
+        objs = [obj for obj in inputs]
+        N = len(objs[0][1])
+        assert all(len(obj[1]) == N for obj in objs), 'The sequences are not aligned'
+        try:
+            if defR:
+                if len(defR) != N:
+                    defR = ProcessReacts(list(map(float, defR.split())), M=M, B=B)
+                else:
+                    defR = ProcessReacts([ReactDict[ch] for ch in defR], M=M, B=B)
+            assert not defR or len(defR) == N
+        except Exception:
+            raise ValueError('Inappropriate default reactivities line:\n {}'.format(defR))
+        assert not defS or len(defS) == N, 'Inappropriate default restraints line:\n {}'.format(defS)
+        assert not defF or len(defF) == N, 'Inappropriate default reference line:\n {}'.format(defF)
+        if levellimit is None:
+            levellimit = 3 - int(N > 500)
+        RunSQRNdbnali(objs, defR, defS, defF, levellimit, freqlimit, verbose, step3, paramsetnames, paramsets,
+                      threads, rankbydiff, rankby, hardrest, interchainonly, toplim, outplim, conslim, reactformat,
+                      poollim, entropy=entropy, algos=algos, sink=write_to, M=M, B=B)
+        return
 
     def config_for(seq):                                        # autoconfig, SQUARNA.py:868-878
         if configfileset:

@@ -720,7 +720,11 @@ extern "C" __global__ __launch_bounds__(64, SQ5_WPS) void sq_scan5_kernel(SqDevC
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = jb0 + 4 * m + cpy + k;
+#ifdef SQ5_ABLATE_PROLOGUE
+            const uint32_t code = (j >= 0 && j < n) ? 0u : 255u;
+#else
             const uint32_t code = (j >= 0 && j < n) ? (uint32_t)eg[j] : 255u;
+#endif
             w |= code << (8 * k);
         }
         L.ecol[cpy][m] = w;
@@ -731,6 +735,7 @@ extern "C" __global__ __launch_bounds__(64, SQ5_WPS) void sq_scan5_kernel(SqDevC
     const int pitch = ld - 1;
 
     // ---- the row above the segment: runs already open there belong to the previous wave
+#ifndef SQ5_ABLATE_PREROW
     if (rbeg > rmin) {
         const int row = rbeg - 1;
         const uint32_t er = rowcode(row);
@@ -745,11 +750,16 @@ extern "C" __global__ __launch_bounds__(64, SQ5_WPS) void sq_scan5_kernel(SqDevC
             carry[k] = act ? SQ_FOREIGN : 0;
         }
     }
+#endif
     // ---- chunks of 32 rows
     const int nch = (rhi - rbeg) / 32 + 1;
     for (int ch = 0; ch < nch; ch++) {
         const int cb = rbeg + 32 * ch;
+#ifdef SQ5_ABLATE_PROLOGUE
+        const uint32_t cc = 0;
+#else
         const uint32_t cc = rowcode(cb + lane);                          // lane t: code of row cb + t
+#endif
 #pragma unroll
         for (int k = 0; k < 4; k++) hist[k] = 0;
         // d = rref - row = 127 - 32 ch - t  ->  dword (d >> 2) = 31 - 8 ch - (t >> 2), copy d & 3 = 3 - (t & 3)

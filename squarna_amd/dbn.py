@@ -134,3 +134,34 @@ def encode_seq(seq):
         else:
             out[i] = 28
     return bytes(out)
+
+
+def PairsToDBN(newpairs, length=0, returnlevels=False, levellimit=-1):
+    """Pairs -> dot-bracket string with pseudoknot levels (SQRNdbnseq.py:104-163): pairs sorted by
+    (crossing count, i) are first-fitted into conflict-free groups, the largest group gets '()'.
+    Host-side helper of the alignment layer (the fold path computes levels in C++)."""
+    pairs = sorted(set((min(v, w), max(v, w)) for v, w in newpairs))
+
+    def crosses(p, q):
+        return (p[0] < q[0] < p[1] < q[1]) or (q[0] < p[0] < q[1] < p[1])
+
+    count = {p: sum(1 for q in pairs if p != q and crosses(p, q)) for p in pairs}
+    groups = []
+    for pair in sorted(pairs, key=lambda p: (count[p], p[0])):
+        for group in groups:
+            if not count[pair] or not any(crosses(pair, q) for q in group):
+                group.append(pair)
+                break
+        else:
+            groups.append([pair])
+    groups.sort(key=len, reverse=True)
+    if returnlevels:
+        return {bp: lev + 1 for lev, group in enumerate(groups) for bp in group}
+    if levellimit >= 0:
+        groups = groups[:levellimit]
+    glyphs = BRACKETS + ['..'] * max(0, len(groups) - len(BRACKETS))
+    dbn = ['.'] * length
+    for k, group in enumerate(groups):
+        for v, w in group:
+            dbn[v], dbn[w] = glyphs[k][0], glyphs[k][1]
+    return ''.join(dbn)

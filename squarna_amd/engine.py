@@ -16,6 +16,10 @@ from .dbn import (GAPS, SEPS, ReactDict, ProcessReacts, DBNToPairs, UnAlign, ReA
                   ParseRestraints, levels_to_dbn, encode_seq)
 
 
+_STEM_DT = np.dtype([("i", "<i4"), ("j", "<i4"), ("len", "<i4"), ("reserved", "<i4"),
+                     ("bpscore", "<f8"), ("finscore", "<f8")])
+
+
 class Prepared:
     """One input record after the host pre-processing of SQRNdbnseq.py:1001-1037."""
     __slots__ = ("seq", "shortseq", "shortrest", "shortreacts", "shortdbn", "rbps", "rxs",
@@ -200,7 +204,7 @@ class Batch:
         return b, s
 
     # -- a-2..a-6
-    def optimal(self, struct_job, struct_stems, subopt=None, mode=0, out_cap=None):
+    def optimal(self, struct_job, struct_stems, subopt=None, mode=0, out_cap=None, as_array=False):
         """struct_stems: list (per structure) of (i, j, len) tuples -> list of lists of
         (i, j, len, bpscore, finalscore)."""
         ns = len(struct_job)
@@ -220,6 +224,9 @@ class Batch:
         out_off = np.zeros(ns + 1, np.int32)
         _lib.check(self.L.sq_optimal_stems(self.h, ns, _ptr(sj), _ptr(off), stems, _ptr(so), mode,
                                            out, out_cap, _ptr(out_off)))
+        if as_array:                                                   # structured views, no per-stem objects
+            arr = np.frombuffer(out, dtype=_STEM_DT, count=int(out_off[ns])).copy()
+            return [arr[out_off[k]:out_off[k + 1]] for k in range(ns)]
         res = []
         for k in range(ns):
             res.append([(out[q].i, out[q].j, out[q].len, out[q].bpscore, out[q].finscore)
@@ -354,6 +361,35 @@ class HipEngine:
             b.fold(**opts)
             return [b.result(k) for k in range(len(records))]
 
+
+    def yield_stems(self, records, bpweights, minlen, minbpscore, interchainonly=False):
+        """Alignment step 1 (SQRNdbnali.py:60-108): for every (seq, reacts, restraints) the stems of
+        the gap-free sequence in emission order.  Returns [(shortseq, [(i, j, len, score), ...])]."""
+        ps = dict(bpweights=bpweights, bpp=0, algorithms={"G"}, suboptmax=1.0, suboptmin=1.0, suboptsteps=1.0,
+                  minlen=minlen, minbpscore=minbpscore, minfinscorefactor=1.0, bracketweight=-2.0, distcoef=0.09,
+                  orderpenalty=1.0, loopbonus=0.125, maxstemnum=1e6)
+        prepared = []
+        for seq, reacts, restraints in records:
+            p = Prepared(seq, reacts if reacts else None, restraints, None)
+            if not reacts:
+                p.shortreacts = [0.5] * len(p.shortseq)                # YieldStems passes reacts=None (:83)
+            prepared.append(p)
+        out, cap = [], 1 << 21
+        est = [int(0.25 * len(p.shortseq) ** 2 * 0.375 ** (max(minlen, 1) - 1)) + 256 for p in prepared]
+        lo = 0
+        while lo < len(prepared):                                      # chunks sized to the stem buffer
+            hi, tot = lo, 0
+            while hi < len(prepared) and (hi == lo or tot + est[hi] <= cap):
+                tot += est[hi]
+                hi += 1
+            chunk = prepared[lo:hi]
+            with Batch(chunk, [[ps]] * len(chunk), interchainonly=interchainonly, max_structs=self.max_structs,
+                       cand_per_nt=max(self.cand_per_nt, 64)) as b:
+                res = b.optimal(list(range(len(chunk))), [[] for _ in chunk], mode=1, out_cap=max(cap, tot),
+                                as_array=True)
+            out.extend((p.shortseq, st) for p, st in zip(chunk, res))
+            lo = hi
+        return out
 
     def entropy(self, record, interchainonly=False):
         """Mean row entropy of the stem matrix under the FIRST paramset, as a string

@@ -345,7 +345,17 @@ def gen_text():
         ("seq_input_evalonly", dict(inputfile=os.path.join(REF, "examples/seq_input.fas"), configfile="fastest", evalonly=True)),
         ("seq_input_entropy", dict(inputfile=os.path.join(REF, "examples/seq_input.fas"), configfile="alt", entropy=True)),
         ("seq_input_ico", dict(inputfile=os.path.join(REF, "examples/seq_input.fas"), configfile="alt", interchainonly=True, algorithms="g")),
+        ("ali_input_a", dict(inputfile=os.path.join(REF, "examples/ali_input.afa"), alignment=True)),
+        ("ali_input_a_verbose", dict(inputfile=os.path.join(REF, "examples/ali_input.afa"), alignment=True, verbose=True)),
+        ("ali_input_a_s3i", dict(inputfile=os.path.join(REF, "examples/ali_input.afa"), alignment=True, step3="i", levellimit=1)),
+        ("ali_input_a_s31", dict(inputfile=os.path.join(REF, "examples/ali_input.afa"), alignment=True, step3="1", freqlimit=0.5)),
+        ("demo_afa_a", dict(inputfile=os.path.join(REF, "examples/demo.afa"), alignment=True, step3="2", reactformat=10)),
     ]
+    only = os.environ.get("GOLDEN_ONLY")
+    if only:
+        jobs = [j for j in jobs if j[0].startswith(only)]
+        with open(os.path.join(HERE, "digests.json")) as f:
+            digests = json.load(f)
     for tag, kw in jobs:
         buf = io.StringIO()
         RC.Predict(write_to=buf, byseq=True, threads=8, **kw)

@@ -20,3 +20,15 @@ class OracleEngine:
         seq, reacts, restraints, dbn, paramsets = record[:5]
         return O.SQRNdbnseq(seq, reacts, restraints, dbn, paramsets, entropy=True,
                             interchainonly=interchainonly)
+
+    def yield_stems(self, records, bpweights, minlen, minbpscore, interchainonly=False):
+        out = []
+        for seq, reacts, restraints in records:
+            seq = seq.upper().replace("T", "U")
+            restraints = restraints or "." * len(seq)
+            shortseq, shortrest = O.UnAlign(seq, restraints)
+            rc = [reacts[i] for i in range(len(seq)) if seq[i] not in O.GAPS] if reacts else None
+            rbps, rxs, rl, rr = O.ParseRestraints(shortrest)
+            b, s = O.BPMatrix(shortseq, bpweights, rxs, rl, rr, interchainonly, rc)
+            out.append((shortseq, O.AnnotateStems(b, s, rbps, [], minlen, minbpscore)))
+        return out

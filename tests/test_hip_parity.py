@@ -187,7 +187,8 @@ def test_edge_cases():
 # ---- end-to-end text: Predict() on the HIP engine == the reference's own output, byte for byte
 GPU_TEXT = ["s16_nobpp", "seq_input_nobpp", "SRtest150_nobpp", "s16_fastest", "shape_input_fastest", "shape_input_alt_rf26", "seq_input_entropy",
             "seq_input_ico", "seq_input_greedynobpp_rf10", "seq_input_evalonly", "SRtest150_fastest",
-            "SRtest150_fastest_pl1", "SRtest150_alt", "SRtest150_greedynobpp"]
+            "SRtest150_fastest_pl1", "SRtest150_alt", "SRtest150_greedynobpp", "ali_input_a", "ali_input_a_verbose",
+            "ali_input_a_s3i", "ali_input_a_s31", "demo_afa_a"]
 
 
 @pytest.mark.parametrize("tag", GPU_TEXT)

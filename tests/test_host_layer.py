@@ -19,7 +19,8 @@ with open(os.path.join(GOLDEN, "digests.json")) as f:
 
 FAST = ["s16_nobpp", "s16_fastest", "shape_input_fastest", "shape_input_alt_rf26", "seq_input_evalonly",
         "seq_input_entropy", "seq_input_ico", "seq_input_nobpp", "seq_input_greedynobpp_rf10",
-        "SRtest150_fastest", "SRtest150_fastest_pl1"]
+        "SRtest150_fastest", "SRtest150_fastest_pl1", "ali_input_a", "ali_input_a_verbose", "ali_input_a_s3i",
+        "ali_input_a_s31", "demo_afa_a"]
 
 
 def run_predict(args, engine):
@@ -66,7 +67,7 @@ def test_validation_messages():
     with pytest.raises(AssertionError, match="Config file does not exist"):
         Predict(inputseq="ACGU", configfile="nope")
     with pytest.raises(NotImplementedError):
-        Predict(inputseq="ACGU", configfile="fastest", alignment=True)
+        Predict(inputseq="ACGU", configfile="fastest", rfam=True)
 
 
 def test_main_cli_forms(capsys, monkeypatch):

@@ -23,9 +23,11 @@ __global__ __launch_bounds__(64) void lin(const float4 *p, size_t n4, float *out
     if (acc == 12345.678f) out[0] = acc;
 }
 
-template <bool CLAMP>
+template <bool CLAMP, int LDSB>
 __global__ __launch_bounds__(64) void col(const float *mat, size_t matstride, int n, int pitch, float *out)
 {
+    __shared__ char occupancy_limiter[LDSB];
+    if (n < 0) out[1] = occupancy_limiter[threadIdx.x];
     const int S = blockIdx.x, tile = blockIdx.y;
     const int nband = (2 * n - 5 + 255) >> 8, nseg = ((n >> 1) + 130 + 123) / 124;
     if (tile >= nband * nseg) return;
@@ -71,17 +73,31 @@ int main(int argc, char **argv)
         const int nband = (2 * n - 5 + 255) >> 8, nseg = ((n >> 1) + 130 + 123) / 124;
         for (int rep = 0; rep < 3; rep++) {
             hipEventRecord(e0);
-            hipLaunchKernelGGL(col<false>, dim3(S, nband * nseg), dim3(64), 0, 0, d, matstride, n, pitch, out);
+            hipLaunchKernelGGL((col<false, 64>), dim3(S, nband * nseg), dim3(64), 0, 0, d, matstride, n, pitch, out);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             printf("col  ld=%d: %.3f ms  %.1f GB/s algorithmic (2N^2 per matrix)\n", ld, ms, 2.0 * n * n * S / ms / 1e6);
         }
         for (int rep = 0; rep < 3; rep++) {
             hipEventRecord(e0);
-            hipLaunchKernelGGL(col<true>, dim3(S, nband * nseg), dim3(64), 0, 0, d, matstride, n, pitch, out);
+            hipLaunchKernelGGL((col<true, 64>), dim3(S, nband * nseg), dim3(64), 0, 0, d, matstride, n, pitch, out);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             printf("colC ld=%d: %.3f ms  %.1f GB/s algorithmic (staircase lanes clamped)\n", ld, ms, 2.0 * n * n * S / ms / 1e6);
+        }
+        for (int rep = 0; rep < 2; rep++) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL((col<true, 10000>), dim3(S, nband * nseg), dim3(64), 0, 0, d, matstride, n, pitch, out);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("colC 4 waves/SIMD: %.3f ms  %.1f GB/s\n", ms, 2.0 * n * n * S / ms / 1e6);
+        }
+        for (int rep = 0; rep < 2; rep++) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL((col<true, 20000>), dim3(S, nband * nseg), dim3(64), 0, 0, d, matstride, n, pitch, out);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("colC 2 waves/SIMD: %.3f ms  %.1f GB/s\n", ms, 2.0 * n * n * S / ms / 1e6);
         }
         const size_t n4 = floats / 4;
         const size_t waves = (size_t)S * n * n * 2 / (128 * 1024);      // same byte count as the algorithmic figure
