@@ -15,13 +15,18 @@ struct SqDevCtx {
     float *mat32;            // fp32 scan-matrix arena
     double *mat64;           // dense fp64 arena (external / weighted matrices only)
     const double *sdftab;    // pow tables
+    uint32_t *bits;          // diagonal bit matrices (activity of the unmasked BPMatrix, 1 bit per cell)
+    const uint32_t *rbpk;    // restraint base pairs, v | (w << 16), per sequence (SqJob::rb_off, nrb)
 };
 
 struct SqState {             // per-structure-slot arrays, `stride` elements per slot
     int16_t *P, *U, *SU;     // partner, prefix #unpaired, prefix #unpaired separators
     uint8_t *E8;             // scan mask code per position: 0 free, 255 masked, k+1 restraint bp k
     int32_t stride;
+    uint32_t *FB;            // per slot: free-position bit words, forward [0, fbstride/2) and reversed + padded
+    int32_t fbstride;        // words per slot (even)
 };
+#define SQ_GPAD 128          // bit offset of the reversed free-position array (window starts never go negative)
 
 struct SqScanArgs {
     SqCand *cands;
@@ -40,6 +45,8 @@ __global__ void sq_import_kernel(SqDevCtx c);
 __global__ void sq_state_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState st);
 __global__ void sq_scan_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
 __global__ void sq_scan5_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
+__global__ void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
+__global__ void sq_bits_kernel(SqDevCtx c);
 __global__ void sq_score_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
                                 SqScanArgs a, SqOut *out, uint32_t out_cap, int mode, int lds_n, int lds_n_reacts);
 }

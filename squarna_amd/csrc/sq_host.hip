@@ -34,6 +34,9 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // row pitch of the scan matrix: ld == 1 (mod 32) (aligned anti-diagonal walk, see sq_kernels.hip) and
 // (ld - 1) / 32 odd, so that the byte stride between rows is an odd multiple of 128 B and consecutive rows
 // of a wave rotate through all memory channels instead of camping on a power-of-two stride
+// diagonal bit matrix of a job (sq_bits_kernel): nw word-rows of bpitch words
+static inline int32_t bits_nw(int n) { return (n + 31) / 32; }
+static inline int32_t bits_pitch(int n) { return (int32_t)align_up((size_t)2 * n, 64) + 64; }
 static inline int32_t ld_of(int n)
 {
     int k = (std::max(n, 1) - 1 + 31) / 32;
@@ -45,9 +48,10 @@ namespace {
 struct Layout {
     size_t off_codes, off_flags, off_inc4, off_chain, off_e0, off_reacts, off_jobs, off_psets, off_sdf;
     size_t off_mat32, off_mat64, off_structs, off_strands, off_state, off_cnt, off_ctr, off_cands, off_out;
+    size_t off_bits, off_rbpk, off_fb;
     size_t total;
-    int64_t ltot, sdf_len, mat32_floats, mat64_doubles, cand_records;
-    int32_t maxn, stride, max_structs, strand_cap, cpn;
+    int64_t ltot, sdf_len, mat32_floats, mat64_doubles, cand_records, bits_words;
+    int32_t maxn, stride, max_structs, strand_cap, cpn, fbstride;
     uint32_t out_cap;
 };
 
@@ -60,12 +64,13 @@ int plan(const sq_batch_desc *d, Layout &L)
     if (L.maxn > 32000) { sq_set_error("sequence longer than 32000 nt"); return -1; }
     L.max_structs = d->max_structs > 0 ? d->max_structs : 4096;
     L.cpn = d->cand_per_nt > 0 ? d->cand_per_nt : 32;
-    L.mat32_floats = 0; L.mat64_doubles = 0;
+    L.mat32_floats = 0; L.mat64_doubles = 0; L.bits_words = 0;
     for (int j = 0; j < d->njobs; j++) {
         const int s = d->job_seq[j];
         if (s < 0 || s >= d->nseq || d->job_pset[j] < 0 || d->job_pset[j] >= d->npset) { sq_set_error("bad job"); return -1; }
         const int64_t n = d->seq_off[s + 1] - d->seq_off[s];
         L.mat32_floats += (int64_t)align_up((size_t)(n * ld_of((int)n)), 64);
+        L.bits_words += (int64_t)bits_nw((int)n) * bits_pitch((int)n);
         const bool ext = d->ext_score && d->ext_score[j];
         const bool mul = d->mul_score && d->mul_score[j];
         if (ext) L.mat64_doubles += 2 * n * n;
@@ -78,6 +83,7 @@ int plan(const sq_batch_desc *d, Layout &L)
         if (bw == std::floor(bw) && std::fabs(bw) <= 64) L.sdf_len += (int64_t)std::max(1.0, std::fabs(bw)) * L.maxn + 16;
     }
     L.stride = (int32_t)align_up((size_t)L.maxn + 2, 32);
+    L.fbstride = 2 * (L.stride / 32 + 8);
     L.strand_cap = (int32_t)std::min<int64_t>((int64_t)L.max_structs * 64 + L.maxn, 1 << 24);
     int64_t maxcap = (int64_t)L.cpn * L.maxn + 256;
     for (int j = 0; j < d->njobs; j++) {
@@ -106,6 +112,9 @@ int plan(const sq_batch_desc *d, Layout &L)
     L.off_ctr = take(sizeof(SqCounters));
     L.off_cands = take(sizeof(SqCand) * (size_t)L.cand_records);
     L.off_out = take(sizeof(SqOut) * (size_t)L.out_cap);
+    L.off_bits = take(4 * (size_t)std::max<int64_t>(L.bits_words, 1));
+    L.off_rbpk = take(4 * (size_t)std::max<int>(d->rbp_off[d->nseq], 1));
+    L.off_fb = take(4 * (size_t)L.fbstride * L.max_structs);
     L.total = o;
     return 0;
 }
@@ -198,8 +207,9 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     }
     // ---- jobs ----
     b->jobs.resize(d->njobs);
-    int64_t m32 = 0, m64 = 0;
-    std::vector<std::pair<int, int64_t>> ext_uploads;   // (job, mat64 offset)
+    int64_t m32 = 0, m64 = 0, mbits = 0;
+    std::vector<uint32_t> rbpk((size_t)d->rbp_off[d->nseq]);
+    for (size_t k = 0; k < rbpk.size(); k++) rbpk[k] = (uint32_t)d->rbps[2 * k] | ((uint32_t)d->rbps[2 * k + 1] << 16);
     for (int j = 0; j < d->njobs; j++) {
         SqJob &J = b->jobs[j];
         const int s = d->job_seq[j];
@@ -208,6 +218,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         J.pos_off = d->seq_off[s];
         J.mat_off = m32; m32 += (int64_t)align_up((size_t)J.n * J.ld, 64);
         J.mat64_off = -1; J.has_ext = 0;
+        J.nw = bits_nw(J.n); J.bpitch = bits_pitch(J.n); J.bits_off = mbits; mbits += (int64_t)J.nw * J.bpitch;
+        J.rb_off = d->rbp_off[s]; J.nrb = d->rbp_off[s + 1] - d->rbp_off[s];
         const bool ext = d->ext_score && d->ext_score[j];
         const bool mul = d->mul_score && d->mul_score[j];
         if (ext) { J.mat64_off = m64; J.has_ext = 1; m64 += 2 * (int64_t)J.n * J.n; }
@@ -254,6 +266,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     const size_t plane = (size_t)L.stride * L.max_structs;
     b->state.P = stbase; b->state.E8 = (uint8_t *)(stbase + plane); b->state.U = stbase + 2 * plane; b->state.SU = stbase + 3 * plane;
     b->state.stride = L.stride;
+    b->state.FB = (uint32_t *)(base + L.off_fb); b->state.fbstride = L.fbstride;
+    b->ctx.bits = (uint32_t *)(base + L.off_bits); b->ctx.rbpk = (uint32_t *)(base + L.off_rbpk);
     b->scan.cand_cnt = (uint32_t *)(base + L.off_cnt); b->scan.ctr = (SqCounters *)(base + L.off_ctr);
     b->scan.cands = (SqCand *)(base + L.off_cands);
     b->d_out = (SqOut *)(base + L.off_out);
@@ -267,6 +281,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     UP(b->ctx.jobs, b->jobs.data(), sizeof(SqJob) * d->njobs);
     UP(b->ctx.psets, pd.data(), sizeof(SqPsetDev) * d->npset);
     if (!sdf.empty()) UP(b->ctx.sdftab, sdf.data(), 8 * sdf.size());
+    if (!rbpk.empty()) UP(b->ctx.rbpk, rbpk.data(), 4 * rbpk.size());
     for (int j = 0; j < d->njobs; j++) {
         const SqJob &J = b->jobs[j];
         const size_t nn = (size_t)J.n * J.n * 8;
@@ -375,6 +390,7 @@ extern "C" int sq_bpmatrix_fill(sq_batch *b)
             hipLaunchKernelGGL(sq_fill_kernel, grid, dim3(256), 0, b->stream, c);
         }
         if (any_ext) hipLaunchKernelGGL(sq_import_kernel, grid, dim3(256), 0, b->stream, c);
+        hipLaunchKernelGGL(sq_bits_kernel, grid, dim3(256), 0, b->stream, c);
     }
     HIPCK(hipGetLastError());
     b->filled = true;
@@ -539,14 +555,19 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
     }
     if (maxn >= 5) {
         const int nband = (2 * maxn - 5 + 255) >> 8;
-        static const int scan_version = getenv("SQ_SCAN") ? atoi(getenv("SQ_SCAN")) : 5;
-        const int seg = scan_version == 4 ? sq_scan_seg() : sq_scan5_seg();
-        const int nseg = ((maxn >> 1) + 130 + seg - 1) / seg;
+        static const int scan_version = getenv("SQ_SCAN") ? atoi(getenv("SQ_SCAN")) : 6;
         ProfScope ps(b, 2, scan_bytes);
-        if (scan_version == 4)
-            hipLaunchKernelGGL(sq_scan_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, b->d_structs, b->state, b->scan);
-        else
-            hipLaunchKernelGGL(sq_scan5_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, b->d_structs, b->state, b->scan);
+        if (scan_version == 6) {                          // bit-diagonal scan: one wave = 64 anti-diagonals
+            hipLaunchKernelGGL(sq_scan6_kernel, dim3(S, (2 * maxn - 5 + 63) / 64 + 1), dim3(64), 4 * (size_t)b->state.fbstride, st,
+                               b->ctx, b->d_structs, b->state, b->scan);
+        } else {
+            const int seg = scan_version == 4 ? sq_scan_seg() : sq_scan5_seg();
+            const int nseg = ((maxn >> 1) + 130 + seg - 1) / seg;
+            if (scan_version == 4)
+                hipLaunchKernelGGL(sq_scan_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, b->d_structs, b->state, b->scan);
+            else
+                hipLaunchKernelGGL(sq_scan5_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, b->d_structs, b->state, b->scan);
+        }
     }
     {
         ProfScope ps(b, 3, 0);

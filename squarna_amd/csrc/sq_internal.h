@@ -19,6 +19,11 @@ struct SqJob {
     int32_t has_ext;    // scan matrix comes from caller matrices (ext_bool/ext_score) or mul_score
     int32_t cand_cap;   // candidate capacity per structure of this job
     float maxabs;       // upper bound of |scoremat cell| (fp32 prefilter margin of the scan)
+    int32_t nrb;        // restraint base pairs of the sequence
+    int64_t bits_off;   // offset (words) of the diagonal bit matrix: word (w, s) at bits_off + w * bpitch + s
+    int32_t bpitch;     // words per word-row (>= 2N + 64, multiple of 64)
+    int32_t nw;         // word-rows: ceil(N / 32); bit b of word (w, s) <-> cell (32w + b, s - 32w - b)
+    int32_t rb_off;     // into the packed restraint pair list
     int32_t pad;
 };
 

@@ -136,6 +136,32 @@ extern "C" __global__ __launch_bounds__(256) void sq_import_kernel(SqDevCtx c)
     }
 }
 
+// Diagonal bit matrix of a job: bit b of word (w, s) <-> bpboolmatrix[i, s - i] with i = 32 w + b, for the
+// cells AnnotateStems visits (4 <= s <= 2N-6, i < j; :456-457, :486).  Word-row major (pitch bpitch >= 2N),
+// so the 64 lanes of a scan wave -- 64 consecutive diagonals -- read 64 consecutive words.  Built once
+// per job from the filled fp32 matrix (one more pass over N^2/2 cells); every later AnnotateStems
+// evaluation reads 1 bit per cell instead of 4 bytes.
+extern "C" __global__ __launch_bounds__(256) void sq_bits_kernel(SqDevCtx c)
+{
+    const SqJob jb = c.jobs[blockIdx.y];
+    const int n = jb.n, ld = jb.ld, bp = jb.bpitch;
+    const float *mat = c.mat32 + jb.mat_off;
+    uint32_t *bits = c.bits + jb.bits_off;
+    const int64_t total = (int64_t)jb.nw * bp;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int w = (int)(q / bp), s = (int)(q - (int64_t)w * bp);
+        uint32_t word = 0;
+        if (s >= 4 && s <= 2 * n - 6) {
+#pragma unroll 8
+            for (int b = 0; b < 32; b++) {
+                const int i = 32 * w + b, j = s - i;
+                if (j > i && j < n && __float_as_uint(mat[(int64_t)i * ld + j]) != SQ_SENT_BITS) word |= 1u << b;
+            }
+        }
+        bits[q] = word;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // per-structure state: partner P, mask code E, prefix counts U (unpaired), SU (unpaired separators)
 // ------------------------------------------------------------------------------------
@@ -189,6 +215,19 @@ extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, co
         cs += un && (codes[p] == 26 || codes[p] == 27);
     }
     if (hi == n && lo <= n) { U[n] = (int16_t)cu; SU[n] = (int16_t)cs; }
+    // free-position bit words for the bit-diagonal scan: F bit p = (E[p] == 0); G bit k + SQ_GPAD = F[n-1-k]
+    const int fbh = st.fbstride >> 1;
+    uint32_t *FBs = st.FB + (int64_t)s.slot * st.fbstride;
+    for (int m = tid; m < 2 * fbh; m += 256) {
+        const bool rev = m >= fbh;
+        const int m0 = rev ? m - fbh : m;
+        uint32_t word = 0;
+        for (int b = 0; b < 32; b++) {
+            const int p = rev ? n - 1 - (32 * m0 + b - SQ_GPAD) : 32 * m0 + b;
+            if (p >= 0 && p < n && E[p] == 0) word |= 1u << b;
+        }
+        FBs[m] = word;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -526,7 +565,8 @@ struct SqScan5Lds {
     uint32_t stage_count, pad[3];
 };
 
-__device__ __forceinline__ void sq5_flush(SqScan5Lds &L, const SqScanArgs &a, const SqStruct &st, int cap, int lane)
+template <class LDS>
+__device__ __forceinline__ void sq5_flush(LDS &L, const SqScanArgs &a, const SqStruct &st, int cap, int lane)
 {
     uint32_t n = L.stage_count;
     if (n > SQ5_STAGE) n = SQ5_STAGE;
@@ -547,7 +587,8 @@ __device__ __forceinline__ void sq5_flush(SqScan5Lds &L, const SqScanArgs &a, co
     __syncthreads();
 }
 
-__device__ __forceinline__ void sq5_emit(SqScan5Lds &L, const SqScanArgs &a, const SqStruct &st, int cap, uint32_t key, uint32_t len)
+template <class LDS>
+__device__ __forceinline__ void sq5_emit(LDS &L, const SqScanArgs &a, const SqStruct &st, int cap, uint32_t key, uint32_t len)
 {
     const uint32_t slot = atomicAdd(&L.stage_count, 1u);
     if (slot < SQ5_STAGE) L.stage[slot] = make_uint2(key, len);
@@ -557,7 +598,8 @@ __device__ __forceinline__ void sq5_emit(SqScan5Lds &L, const SqScanArgs &a, con
 // analyse one chunk history of one diagonal.  A: activity bits (nrows valid, bit 0 newest),
 // carry: length of the run open at the chunk's top (SQ_FOREIGN if it belongs to another wave),
 // rtop: row of bit nrows-1, rown: first row a run of this wave may NOT start in (rend).
-__device__ __forceinline__ void sq5_analyse(SqScan5Lds &L, const SqScanArgs &a, const SqStruct &st, int cap, int s,
+template <class LDS>
+__device__ __forceinline__ void sq5_analyse(LDS &L, const SqScanArgs &a, const SqStruct &st, int cap, int s,
                                             uint32_t A, int nrows, int rtop, int rown, int minlen, int &carry)
 {
     const int top = nrows - 1;
@@ -831,6 +873,101 @@ extern "C" __global__ __launch_bounds__(64, SQ5_WPS) void sq_scan5_kernel(SqDevC
         if (r > rmax) break;
         r++;
     }
+    __syncthreads();
+    sq5_flush(L, a, st, cap, lane);
+}
+
+
+// ------------------------------------------------------------------------------------
+// a-2  stem scan, bit-diagonal form ("v6", default).  AnnotateStems only needs to know WHERE the
+// unmasked cells are -- every candidate's score is recomputed exactly in fp64 by sq_score_kernel --
+// so the scan reads the job's diagonal bit matrix (sq_bits_kernel) instead of the fp32 matrix:
+//   active(s, i) = base(s, i)  &  free[i]  &  free[s - i]       (+ the live restraint pairs)
+// One lane = one anti-diagonal, one loop step = 32 rows:
+//   base word   one coalesced 4-byte load per lane (64 consecutive diagonals = 256 B per wave);
+//   row word    wave-uniform LDS read of the free-position bit array F;
+//   column word a 32-bit window of the REVERSED array G (bit k <-> position n-1-k) starting at
+//               n-1-s+32w: it advances by exactly one word per step, so each step reads one new LDS
+//               word and funnel-shifts it against the previous one (v_alignbit);
+// and the runs of the 32 rows come out of sq5_analyse's bit tricks.  Per structure the scan touches
+// N^2/16 bytes of (L2-resident) bits instead of 2 N^2 bytes of HBM.
+// ------------------------------------------------------------------------------------
+#define SQ6_RL 256
+struct SqScan6Lds {
+    uint2 stage[SQ5_STAGE];
+    uint32_t stage_count, nrl, pad[2];
+    uint32_t rl[SQ6_RL];                 // live restraint cells of this wave's diagonals: v | (w << 16)
+};
+
+extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) SqScan6Lds L;
+    extern __shared__ uint32_t sq6_fg[];                                // F words then G words of the structure
+    const SqStruct st = structs[blockIdx.x];
+    const SqJob jb = c.jobs[st.job];
+    const int n = jb.n;
+    if (n < 5) return;                                                  // :456-457 no diagonals
+    const int s0 = blockIdx.y << 6;
+    const int smin = max(s0, 4), smax = min(s0 + 63, 2 * n - 6);        // :456-457 s in [4, 2N-6]
+    if (smin > smax) return;
+    const int rmin = max(0, smin - (n - 1)), rmax = (smax - 1) >> 1;    // :486 i <= j-1
+    const int wlo = rmin >> 5, whi = rmax >> 5;
+    const int lane = threadIdx.x;
+    const int s = s0 + lane;
+    const SqPsetDev *ps = c.psets + jb.pset;
+    const int minlen = max(1, (int)ceil(ps->minlen));
+    const int cap = jb.cand_cap;
+    const int fbh = stt.fbstride >> 1;
+    const uint32_t *FBg = stt.FB + (int64_t)st.slot * stt.fbstride;
+    uint32_t *F = sq6_fg, *G = sq6_fg + fbh;
+    // window of the reversed array for (s, wlo): first bit n-1-s+32 wlo (+pad); lanes outside the valid
+    // diagonals have zero base words, their window only has to stay inside the array
+    const int q0 = min(max(n - 1 - s + 32 * wlo + SQ_GPAD, 0), 32 * (fbh - (whi - wlo) - 3));
+    const int gidx = q0 >> 5, gsh = q0 & 31;
+    if (lane == 0) { L.stage_count = 0; L.nrl = 0; }
+    for (int m = lane; m < 2 * fbh; m += 64) sq6_fg[m] = FBg[m];
+    __syncthreads();
+    if (jb.nrb) {                                                       // restraint pairs both ends of which are still free
+        const uint8_t *eg = stt.E8 + (int64_t)st.slot * stt.stride * 2;
+        for (int k = lane; k < jb.nrb; k += 64) {
+            const uint32_t pk = c.rbpk[jb.rb_off + k];
+            const int v = (int)(pk & 0xFFFFu), w = (int)(pk >> 16);
+            if (eg[v] == (uint8_t)(k + 1) && eg[w] == (uint8_t)(k + 1) && v + w >= s0 && v + w <= s0 + 63) {
+                const uint32_t slot = atomicAdd(&L.nrl, 1u);
+                if (slot < SQ6_RL) L.rl[slot] = pk;
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t nrl = min(L.nrl, (uint32_t)SQ6_RL);
+    const uint32_t *bp = c.bits + jb.bits_off + s;
+    const int bpitch = jb.bpitch;
+
+    int carry = 0;
+    uint32_t glo = G[gidx];
+    uint32_t base = bp[(int64_t)wlo * bpitch];
+    for (int w = wlo; w <= whi; w++) {
+        const uint32_t nxt = w < whi ? bp[(int64_t)(w + 1) * bpitch] : 0u;     // next step's word is in flight
+        const uint32_t ghi = G[gidx + 1 + (w - wlo)];
+        const uint32_t gw = __builtin_amdgcn_alignbit(ghi, glo, gsh);   // columns s-32w-b, b = 0..31
+        glo = ghi;
+        uint32_t A = base & F[w] & gw;                                  // :438-451 free row and column
+        if (nrl) {
+            for (uint32_t k = 0; k < nrl; k++) {
+                const uint32_t pk = L.rl[k];
+                const int v = (int)(pk & 0xFFFFu), ww = (int)(pk >> 16);
+                if (v + ww == s && (v >> 5) == w) A |= base & (1u << (v & 31));   // :438-443 restraint bp stays pairable
+            }
+        }
+        base = nxt;
+        const uint32_t hist = __brev(A);                                // bit 0 = newest row, as sq5_analyse expects
+        if (__ballot((hist != 0u) | (carry > 0)) != 0ull)
+            sq5_analyse(L, a, st, cap, s, hist, 32, 32 * w, 0x3fffffff, minlen, carry);
+        else
+            carry = 0;
+        if (L.stage_count > SQ5_STAGE / 2) sq5_flush(L, a, st, cap, lane);
+    }
+    if (carry >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(32 * (whi + 1) - carry), (uint32_t)carry);
     __syncthreads();
     sq5_flush(L, a, st, cap, lane);
 }
