@@ -14,6 +14,9 @@
 
 typedef std::pair<int, int> BP;
 
+#include <chrono>
+static inline double sq_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // exact scoremat cell on the host: the same fp64 expression as sq_cell_score (sq_kernels.hip)
 static double cell_score_host(const sq_batch *b, const SqJob &J, int i, int j)
 {
@@ -80,144 +83,288 @@ static void filter_stemset(const sq_batch *b, const SqJob &J, std::vector<BP> pa
     }
 }
 
+// ---- one chunk of matching work: staged (uploads + kernel, asynchronous) and collected later ------
+struct SqAlgoChunk {
+    int algo = 0;
+    size_t k0 = 0, k1 = 0;                       // jobs[k0, k1) of the caller's list
+    std::vector<SqMatchJob> mj;
+    std::vector<SqMatchEdge> me;
+    std::vector<std::vector<int>> vid2pos;       // Edmonds: graph vertex -> position
+    size_t outints = 0, scratch = 0, bytes = 0;  // device bytes used from the region's base
+    int32_t *d_out = nullptr, *d_cnt = nullptr;
+    hipStream_t st = nullptr;
+};
+
+// Host part: edges and scratch layout of jobs[k0..) of `algo`, as many as fit into region_bytes (ck.k1, ck.bytes).
+static void algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vector<std::vector<HStem>> &stems, size_t k0,
+                       int algo, size_t region_bytes, SqAlgoChunk &ck)
+{
+    ck = SqAlgoChunk();
+    ck.algo = algo; ck.k0 = k0;
+    std::vector<SqMatchJob> &mj = ck.mj;
+    std::vector<SqMatchEdge> &me = ck.me;
+    size_t scratch = 0, outints = 0, k1 = k0;
+    for (; k1 < jobs.size(); k1++) {
+        const SqJob &J = b->jobs[jobs[k1]];
+        const std::vector<HStem> &st_ = stems[k1];
+        SqMatchJob m;
+        m.edge_off = (int64_t)me.size(); m.pos_off = J.pos_off;
+        std::vector<int> ids;
+        size_t need, nout;
+        size_t ncell = 0;
+        for (const HStem &s : st_) ncell += (size_t)s.len;
+        if (algo == SQ_ALGO_E) {
+            std::vector<int> pos2id(J.n, -1);
+            for (const HStem &s : st_) {
+                const double wt = pow(s.bps, 1.7);                   // SQRNalgos.py:101
+                for (int t = 0; t < s.len; t++) {
+                    const int v = s.i + t, w = s.j - t;
+                    if (pos2id[v] < 0) { pos2id[v] = (int)ids.size(); ids.push_back(v); }   // node order = first appearance
+                    if (pos2id[w] < 0) { pos2id[w] = (int)ids.size(); ids.push_back(w); }
+                    me.push_back(SqMatchEdge{pos2id[v], pos2id[w], wt});
+                }
+            }
+            m.n = (int)ids.size(); need = sq_mwm_scratch_bytes(m.n, (int)ncell); nout = (size_t)m.n;
+        } else {
+            for (const HStem &s : st_) {
+                const double wt = algo == SQ_ALGO_H ? pow(s.bps, 1.7) : s.bps;   // SQRNalgos.py:122 / :49
+                for (int t = 0; t < s.len; t++) me.push_back(SqMatchEdge{s.i + t, s.j - t, wt});
+            }
+            m.n = J.n;
+            need = algo == SQ_ALGO_H ? sq_lsap_scratch_bytes(J.n) : sq_nussinov_scratch_bytes(J.n);
+            nout = algo == SQ_ALGO_H ? (size_t)J.n : 2 * ((size_t)J.n + 4);
+        }
+        m.nedges = (int32_t)ncell;
+        need = (need + 255) & ~(size_t)255;
+        const size_t fixed = (mj.size() + 1) * sizeof(SqMatchJob) + me.size() * sizeof(SqMatchEdge) +
+                             (outints + nout + mj.size() + 1) * 4 + 4096;
+        if (fixed + scratch + need > region_bytes) { me.resize((size_t)m.edge_off); break; }
+        m.scratch_off = (int64_t)scratch; scratch += need;
+        m.out_off = (int64_t)(algo == SQ_ALGO_N ? outints / 2 : outints); outints += nout;
+        mj.push_back(m);
+        ck.vid2pos.push_back(std::move(ids));
+    }
+    ck.k1 = k1; ck.outints = outints; ck.scratch = scratch;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t rr = o; o = (o + bytes + 255) & ~(size_t)255; return rr; };
+    take(mj.size() * sizeof(SqMatchJob)); take(me.size() * sizeof(SqMatchEdge) + 16);
+    take(outints * 4 + 16); take(mj.size() * 4 + 16);
+    ck.bytes = o + scratch;
+}
+
+// Device part: uploads + kernel of a built chunk into [region, region + ck.bytes) on stream st.  Nothing is waited for.
+static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t st)
+{
+    ck.st = st;
+    const std::vector<SqMatchJob> &mj = ck.mj;
+    const std::vector<SqMatchEdge> &me = ck.me;
+    const int algo = ck.algo;
+    if (mj.empty()) return 0;
+    // carve: [jobs][edges][out ints][counts][scratch]
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t rr = o; o = (o + bytes + 255) & ~(size_t)255; return rr; };
+    const size_t o_jobs = take(mj.size() * sizeof(SqMatchJob)), o_edges = take(me.size() * sizeof(SqMatchEdge) + 16);
+    const size_t o_out = take(ck.outints * 4 + 16), o_cnt = take(mj.size() * 4 + 16), o_scr = take(0);
+    SqMatchJob *d_jobs = (SqMatchJob *)(region + o_jobs);
+    SqMatchEdge *d_edges = (SqMatchEdge *)(region + o_edges);
+    ck.d_out = (int32_t *)(region + o_out); ck.d_cnt = (int32_t *)(region + o_cnt);
+    char *d_scr = region + o_scr;
+    HIPCK(hipMemcpyAsync(d_jobs, mj.data(), mj.size() * sizeof(SqMatchJob), hipMemcpyHostToDevice, st));
+    if (!me.empty()) HIPCK(hipMemcpyAsync(d_edges, me.data(), me.size() * sizeof(SqMatchEdge), hipMemcpyHostToDevice, st));
+    const int nj = (int)mj.size();
+    int maxn = 0, maxm = 0;
+    for (const SqMatchJob &m : mj) { maxn = std::max(maxn, m.n); maxm = std::max(maxm, m.nedges); }
+    if (algo == SQ_ALGO_H) {
+        // LDS: the row/column vectors and, when it fits, the cost matrix as 16-bit edge ids + the edge weights
+        size_t lds = (size_t)maxn * 42 + 64 + 16 + (size_t)maxm * 8 + (size_t)maxn * maxn * 2 + 64;
+        if (lds > 64 * 1024) {
+            static bool attr_set = false;
+            if (!attr_set) { hipFuncSetAttribute((const void *)sq_lsap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        }
+        if (lds > 150 * 1024) lds = std::min<size_t>((size_t)maxn * 42 + 64 + 16, 150 * 1024);   // vectors only
+        hipLaunchKernelGGL(sq_lsap_kernel, dim3(nj), dim3(64), lds, st, d_jobs, d_edges, d_scr, ck.d_out, (int)lds);
+    }
+    else if (algo == SQ_ALGO_N) hipLaunchKernelGGL(sq_nussinov_kernel, dim3(nj), dim3(256), 0, st, d_jobs, d_edges, b->ctx.codes, d_scr, ck.d_out, ck.d_cnt);
+    else {
+        // dynamic LDS for the blossom state of the largest job (up to 150 KiB of the CU's 160)
+        size_t want = SqBlossom::scratch_bytes(maxn, maxm, 1) + (((size_t)maxm * sizeof(SqMatchEdge) + 15) & ~(size_t)15) + 64;
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute((const void *)sq_mwm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        want = std::min<size_t>(want, 150 * 1024);             // jobs that do not fit run in global memory
+        if (getenv("SQ_MWM_NOLDS")) want = 0;
+        hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), want, st, d_jobs, d_edges, d_scr, ck.d_out, (int)want);
+    }
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+// Wait for a staged chunk, read its result and apply the reference's stem filters (:570-595).
+static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::vector<std::vector<HStem>> &stems,
+                        SqAlgoChunk &ck, int levellimit_opt, std::vector<std::vector<HStem>> &out)
+{
+    if (ck.mj.empty()) return 0;
+    const std::vector<SqMatchJob> &mj = ck.mj;
+    const int algo = ck.algo;
+    std::vector<int32_t> h_out(ck.outints + 4), h_cnt(mj.size() + 1);
+    HIPCK(hipMemcpyAsync(h_out.data(), ck.d_out, ck.outints * 4, hipMemcpyDeviceToHost, ck.st));
+    if (algo == SQ_ALGO_N) HIPCK(hipMemcpyAsync(h_cnt.data(), ck.d_cnt, mj.size() * 4, hipMemcpyDeviceToHost, ck.st));
+    const double tw0 = sq_now();
+    HIPCK(hipStreamSynchronize(ck.st));
+    const double tw1 = sq_now();
+    struct Rep { int algo; double t0, t1; ~Rep() { if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] algo %d: wait %.3f ms, host filters %.3f ms\n", algo, (t1 - t0) * 1e3, (sq_now() - t1) * 1e3); } } rep{algo, tw0, tw1};
+    for (size_t q = 0; q < mj.size(); q++) {
+        const size_t k = ck.k0 + q;
+        const SqJob &J = b->jobs[jobs[k]];
+        const int levellimit = levellimit_opt >= 0 ? levellimit_opt : 3 - (J.n > 500 ? 1 : 0);   // :1043-1044
+        std::vector<BP> pairs;
+        if (algo == SQ_ALGO_E) {
+            const int32_t *mate = h_out.data() + mj[q].out_off;
+            if (mj[q].n > 0 && mate[0] == -2) { sq_set_error("blossom capacity exceeded"); return -3; }
+            for (int v = 0; v < mj[q].n; v++)
+                if (mate[v] > v) pairs.push_back(BP(ck.vid2pos[q][v], ck.vid2pos[q][mate[v]]));
+        } else if (algo == SQ_ALGO_N) {
+            const int32_t *pp = h_out.data() + 2 * mj[q].out_off;
+            for (int t = 0; t < h_cnt[q]; t++) pairs.push_back(BP(pp[2 * t], pp[2 * t + 1]));
+        } else {
+            const int32_t *sol = h_out.data() + mj[q].out_off;
+            const uint8_t *codes = b->codes.data() + J.pos_off;
+            std::vector<int64_t> cells;                               // cells with mat[v,w] != 0, SQRNalgos.py:119-123
+            for (const HStem &s : stems[k]) {
+                if (-pow(s.bps, 1.7) == 0) continue;
+                for (int t = 0; t < s.len; t++) cells.push_back((int64_t)(s.i + t) * J.n + (s.j - t));
+            }
+            std::sort(cells.begin(), cells.end());
+            for (int kk = 0; kk < J.n; kk++) {                        // SQRNalgos.py:130-133
+                const int sk = sol[kk];
+                if (sk < 0 || !(kk < sk)) continue;
+                bool far = kk < sk - 3;
+                if (!far) for (int x = kk + 1; x < sk; x++) if (codes[x] == SQ_CODE_SEP1 || codes[x] == SQ_CODE_SEP2) { far = true; break; }
+                if (!far) continue;
+                if (sol[sk] != kk) continue;
+                if (!std::binary_search(cells.begin(), cells.end(), (int64_t)kk * J.n + sk)) continue;
+                pairs.push_back(BP(kk, sk));
+            }
+        }
+        filter_stemset(b, J, pairs, levellimit, out[k]);
+    }
+    return 0;
+}
+
+static int algo_annotate(sq_batch *b, const std::vector<int> &jobs, std::vector<std::vector<HStem>> &stems)
+{
+    for (int j : jobs)
+        if (b->jobs[j].has_ext) { sq_set_error("E/H/N algorithms need the library's own score matrix"); return -4; }
+    // AnnotateStems(bool, score, rbps, [], minlen, minbpscore)  (:553)
+    std::vector<HStruct> hs(jobs.size());
+    std::vector<SView> views(jobs.size());
+    for (size_t k = 0; k < jobs.size(); k++) { hs[k].job = jobs[k]; views[k] = SView{jobs[k], 1.0, &hs[k]}; }
+    return sq_run_round(b, views, 1, stems);
+}
+
 int sq_run_algo(sq_batch *b, const std::vector<int> &jobs, int algo, int levellimit_opt,
                 std::vector<std::vector<HStem>> &out)
 {
     out.assign(jobs.size(), {});
     if (jobs.empty()) return 0;
-    for (int j : jobs)
-        if (b->jobs[j].has_ext) { sq_set_error("E/H/N algorithms need the library's own score matrix"); return -4; }
-    // 1. AnnotateStems(bool, score, rbps, [], minlen, minbpscore)  (:553)
-    std::vector<HStruct> hs(jobs.size());
-    std::vector<SView> views(jobs.size());
-    for (size_t k = 0; k < jobs.size(); k++) { hs[k].job = jobs[k]; views[k] = SView{jobs[k], 1.0, &hs[k]}; }
     std::vector<std::vector<HStem>> stems;
-    int r = sq_run_round(b, views, 1, stems);
+    int r = algo_annotate(b, jobs, stems);
     if (r) return r;
-    // 2. matching on the device, in chunks that fit the (idle) candidate arena
-    const size_t arena = (size_t)b->cand_records * sizeof(SqCand);
-    char *abase = (char *)b->scan.cands;
+    // matching on the device, in chunks that fit the (idle) candidate arena
+    const size_t arena = (size_t)(b->cand_records - b->cand_reserved) * sizeof(SqCand);
     size_t k0 = 0;
     while (k0 < jobs.size()) {
-        std::vector<SqMatchJob> mj;
-        std::vector<SqMatchEdge> me;
-        std::vector<std::vector<int>> vid2pos;                           // Edmonds: graph vertex -> position
-        size_t scratch = 0, outints = 0, k1 = k0;
-        for (; k1 < jobs.size(); k1++) {
-            const SqJob &J = b->jobs[jobs[k1]];
-            const std::vector<HStem> &st = stems[k1];
-            SqMatchJob m;
-            m.edge_off = (int64_t)me.size(); m.pos_off = J.pos_off;
-            std::vector<int> ids;
-            size_t need, nout;
-            size_t ncell = 0;
-            for (const HStem &s : st) ncell += (size_t)s.len;
-            if (algo == SQ_ALGO_E) {
-                std::vector<int> pos2id(J.n, -1);
-                for (const HStem &s : st) {
-                    const double wt = pow(s.bps, 1.7);                   // SQRNalgos.py:101
-                    for (int t = 0; t < s.len; t++) {
-                        const int v = s.i + t, w = s.j - t;
-                        if (pos2id[v] < 0) { pos2id[v] = (int)ids.size(); ids.push_back(v); }   // node order = first appearance
-                        if (pos2id[w] < 0) { pos2id[w] = (int)ids.size(); ids.push_back(w); }
-                        me.push_back(SqMatchEdge{pos2id[v], pos2id[w], wt});
-                    }
-                }
-                m.n = (int)ids.size(); need = sq_mwm_scratch_bytes(m.n, (int)ncell); nout = (size_t)m.n;
-            } else {
-                for (const HStem &s : st) {
-                    const double wt = algo == SQ_ALGO_H ? pow(s.bps, 1.7) : s.bps;   // SQRNalgos.py:122 / :49
-                    for (int t = 0; t < s.len; t++) me.push_back(SqMatchEdge{s.i + t, s.j - t, wt});
-                }
-                m.n = J.n;
-                need = algo == SQ_ALGO_H ? sq_lsap_scratch_bytes(J.n) : sq_nussinov_scratch_bytes(J.n);
-                nout = algo == SQ_ALGO_H ? (size_t)J.n : 2 * ((size_t)J.n + 4);
-            }
-            m.nedges = (int32_t)ncell;
-            need = (need + 255) & ~(size_t)255;
-            const size_t fixed = (mj.size() + 1) * sizeof(SqMatchJob) + me.size() * sizeof(SqMatchEdge) +
-                                 (outints + nout + mj.size() + 1) * 4 + 4096;
-            if (!mj.empty() && fixed + scratch + need > arena) { me.resize((size_t)m.edge_off); break; }
-            if (fixed + scratch + need > arena) { sq_set_error("sequence too long for the matching scratch"); return -3; }
-            m.scratch_off = (int64_t)scratch; scratch += need;
-            m.out_off = (int64_t)(algo == SQ_ALGO_N ? outints / 2 : outints); outints += nout;
-            mj.push_back(m);
-            vid2pos.push_back(std::move(ids));
-        }
-        // carve: [jobs][edges][out ints][counts][scratch]
-        size_t o = 0;
-        auto take = [&](size_t bytes) { size_t rr = o; o = (o + bytes + 255) & ~(size_t)255; return rr; };
-        const size_t o_jobs = take(mj.size() * sizeof(SqMatchJob)), o_edges = take(me.size() * sizeof(SqMatchEdge) + 16);
-        const size_t o_out = take(outints * 4 + 16), o_cnt = take(mj.size() * 4 + 16), o_scr = take(0);
-        if (o_scr + scratch > arena) { sq_set_error("matching scratch does not fit"); return -3; }
-        SqMatchJob *d_jobs = (SqMatchJob *)(abase + o_jobs);
-        SqMatchEdge *d_edges = (SqMatchEdge *)(abase + o_edges);
-        int32_t *d_out = (int32_t *)(abase + o_out), *d_cnt = (int32_t *)(abase + o_cnt);
-        char *d_scr = abase + o_scr;
-        hipStream_t st = b->stream;
-        HIPCK(hipMemcpyAsync(d_jobs, mj.data(), mj.size() * sizeof(SqMatchJob), hipMemcpyHostToDevice, st));
-        if (!me.empty()) HIPCK(hipMemcpyAsync(d_edges, me.data(), me.size() * sizeof(SqMatchEdge), hipMemcpyHostToDevice, st));
-        const int nj = (int)mj.size();
-        int maxn = 0, maxm = 0;
-        for (const SqMatchJob &m : mj) { maxn = std::max(maxn, m.n); maxm = std::max(maxm, m.nedges); }
-        if (algo == SQ_ALGO_H) {
-            const int lds = (int)std::min<size_t>((size_t)maxn * 42 + 64, 64 * 1024);
-            hipLaunchKernelGGL(sq_lsap_kernel, dim3(nj), dim3(64), lds, st, d_jobs, d_edges, d_scr, d_out, lds);
-        }
-        else if (algo == SQ_ALGO_N) hipLaunchKernelGGL(sq_nussinov_kernel, dim3(nj), dim3(256), 0, st, d_jobs, d_edges, b->ctx.codes, d_scr, d_out, d_cnt);
-        else {
-            // dynamic LDS for the blossom state of the largest job (up to 150 KiB of the CU's 160)
-            size_t want = SqBlossom::scratch_bytes(maxn, maxm, 1) + (((size_t)maxm * sizeof(SqMatchEdge) + 15) & ~(size_t)15) + 64;
-            static bool attr_set = false;
-            if (!attr_set) { hipFuncSetAttribute((const void *)sq_mwm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-            want = std::min<size_t>(want, 150 * 1024);             // jobs that do not fit run in global memory
-            if (getenv("SQ_MWM_NOLDS")) want = 0;
-            hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), want, st, d_jobs, d_edges, d_scr, d_out, (int)want);
-        }
-        HIPCK(hipGetLastError());
-        std::vector<int32_t> h_out(outints + 4), h_cnt(mj.size() + 1);
-        HIPCK(hipMemcpyAsync(h_out.data(), d_out, outints * 4, hipMemcpyDeviceToHost, st));
-        if (algo == SQ_ALGO_N) HIPCK(hipMemcpyAsync(h_cnt.data(), d_cnt, mj.size() * 4, hipMemcpyDeviceToHost, st));
-        HIPCK(hipStreamSynchronize(st));
-        // 3. pairs -> filtered stemset
-        for (size_t q = 0; q < mj.size(); q++) {
-            const size_t k = k0 + q;
-            const SqJob &J = b->jobs[jobs[k]];
-            const int levellimit = levellimit_opt >= 0 ? levellimit_opt : 3 - (J.n > 500 ? 1 : 0);   // :1043-1044
-            std::vector<BP> pairs;
-            if (algo == SQ_ALGO_E) {
-                const int32_t *mate = h_out.data() + mj[q].out_off;
-                if (mj[q].n > 0 && mate[0] == -2) { sq_set_error("blossom capacity exceeded"); return -3; }
-                for (int v = 0; v < mj[q].n; v++)
-                    if (mate[v] > v) pairs.push_back(BP(vid2pos[q][v], vid2pos[q][mate[v]]));
-            } else if (algo == SQ_ALGO_N) {
-                const int32_t *pp = h_out.data() + 2 * mj[q].out_off;
-                for (int t = 0; t < h_cnt[q]; t++) pairs.push_back(BP(pp[2 * t], pp[2 * t + 1]));
-            } else {
-                const int32_t *sol = h_out.data() + mj[q].out_off;
-                const uint8_t *codes = b->codes.data() + J.pos_off;
-                std::map<BP, double> cells;                               // mat[v,w] (both orientations), SQRNalgos.py:119-123
-                for (const HStem &s : stems[k]) {
-                    const double wt = -pow(s.bps, 1.7);
-                    for (int t = 0; t < s.len; t++) { cells[BP(s.i + t, s.j - t)] = wt; cells[BP(s.j - t, s.i + t)] = wt; }
-                }
-                for (int kk = 0; kk < J.n; kk++) {                        // SQRNalgos.py:130-133
-                    const int sk = sol[kk];
-                    if (sk < 0 || !(kk < sk)) continue;
-                    bool far = kk < sk - 3;
-                    if (!far) for (int x = kk + 1; x < sk; x++) if (codes[x] == SQ_CODE_SEP1 || codes[x] == SQ_CODE_SEP2) { far = true; break; }
-                    if (!far) continue;
-                    if (sol[sk] != kk) continue;
-                    auto it = cells.find(BP(kk, sk));
-                    if (it == cells.end() || it->second == 0) continue;
-                    pairs.push_back(BP(kk, sk));
-                }
-            }
-            filter_stemset(b, J, pairs, levellimit, out[k]);
-        }
-        k0 = k1;
+        SqAlgoChunk ck;
+        algo_build(b, jobs, stems, k0, algo, arena, ck);
+        if (ck.k1 == k0) { sq_set_error("sequence too long for the matching scratch"); return -3; }
+        r = algo_launch(b, ck, (char *)b->scan.cands, b->stream);
+        if (r) return r;
+        r = algo_collect(b, jobs, stems, ck, levellimit_opt, out);
+        if (r) return r;
+        k0 = ck.k1;
     }
     return 0;
+}
+
+// ---- asynchronous form used by sq_fold: E, H and N run on side streams, in scratch reserved at the end of
+// the candidate arena, while the greedy rounds proceed on the batch stream ------------------------------
+struct SqAlgoAsync {
+    struct Item { int algo; std::vector<int> jobs; std::vector<std::vector<HStem>> stems; SqAlgoChunk ck; bool staged = false; };
+    std::vector<Item> items;
+};
+
+int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync *&pa)
+{
+    pa = new SqAlgoAsync();
+    std::vector<int> all;                                   // one AnnotateStems pass for every E/H/N job
+    for (int algo : {SQ_ALGO_E, SQ_ALGO_H, SQ_ALGO_N}) {
+        SqAlgoAsync::Item it;
+        it.algo = algo;
+        for (int j = 0; j < b->njobs; j++) if (algos[j] & (uint32_t)algo) it.jobs.push_back(j);
+        if (it.jobs.empty()) continue;
+        all.insert(all.end(), it.jobs.begin(), it.jobs.end());
+        pa->items.push_back(std::move(it));
+    }
+    if (all.empty()) return 0;
+    std::vector<std::vector<HStem>> stems;
+    const double ta0 = sq_now();
+    int r = algo_annotate(b, all, stems);
+    if (r) return r;
+    if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] annotate %zu jobs %.3f ms\n", all.size(), (sq_now() - ta0) * 1e3);
+    size_t pos = 0;
+    for (auto &it : pa->items) {
+        it.stems.assign(std::make_move_iterator(stems.begin() + pos), std::make_move_iterator(stems.begin() + pos + it.jobs.size()));
+        pos += it.jobs.size();
+    }
+    if (getenv("SQ_ALGO_SYNC")) return 0;
+    // stage what fits into (at most) half of the arena, carved downwards from its end; the rest runs synchronously later
+    const int64_t half = b->cand_records / 2;
+    int sidx = 0;
+    for (auto &it : pa->items) {
+        const int64_t free_rec = half - b->cand_reserved;
+        if (free_rec <= 0 || sidx >= 3) break;
+        algo_build(b, it.jobs, it.stems, 0, it.algo, (size_t)free_rec * sizeof(SqCand), it.ck);
+        if (it.ck.k1 != it.jobs.size()) { it.ck = SqAlgoChunk(); continue; }   // does not fit as one chunk
+        if (!b->side[sidx]) { if (sq_check(hipStreamCreateWithFlags(&b->side[sidx], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
+        const int64_t used_rec = (int64_t)((it.ck.bytes + 256 + sizeof(SqCand) - 1) / sizeof(SqCand));
+        b->cand_reserved += used_rec;
+        char *region = (char *)(b->scan.cands + (b->cand_records - b->cand_reserved));
+        region = (char *)(((uintptr_t)region + 255) & ~(uintptr_t)255);
+        r = algo_launch(b, it.ck, region, b->side[sidx]);
+        if (r) return r;
+        it.staged = true;
+        sidx++;
+    }
+    return 0;
+}
+
+int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<JobSets> &sets)
+{
+    int r = 0;
+    // collect staged work first, release the reservation, then run what was not staged
+    for (auto &it : pa->items) {
+        JobSets js; js.algo = it.algo; js.jobs = it.jobs; js.sets.assign(it.jobs.size(), {});
+        if (it.staged && !r) r = algo_collect(b, it.jobs, it.stems, it.ck, levellimit_opt, js.sets);
+        sets.push_back(std::move(js));
+    }
+    for (int k = 0; k < 3; k++) if (b->side[k]) hipStreamSynchronize(b->side[k]);
+    b->cand_reserved = 0;
+    size_t q = 0;
+    for (auto &it : pa->items) {
+        JobSets &js = sets[q++];
+        if (it.staged || r) continue;
+        size_t k0 = 0;
+        const size_t arena = (size_t)b->cand_records * sizeof(SqCand);
+        while (k0 < it.jobs.size() && !r) {
+            SqAlgoChunk ck;
+            algo_build(b, it.jobs, it.stems, k0, it.algo, arena, ck);
+            if (ck.k1 == k0) { sq_set_error("sequence too long for the matching scratch"); r = -3; }
+            if (!r) r = algo_launch(b, ck, (char *)b->scan.cands, b->stream);
+            if (!r) r = algo_collect(b, it.jobs, it.stems, ck, levellimit_opt, js.sets);
+            k0 = ck.k1;
+        }
+    }
+    delete pa;
+    return r;
 }
 
 extern "C" int sq_run_algos(sq_batch *b, int32_t njob, const int32_t *job_ids, int32_t algo, int32_t levellimit,

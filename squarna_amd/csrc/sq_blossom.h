@@ -23,6 +23,46 @@
 #define SQ_HD
 #endif
 
+// cross-lane helpers of the cooperative run(): one lane (host, tests) ...
+struct SqCoopSingle {
+    SQ_HD int first_true(bool p, int nl) const { return p ? 0 : nl; }
+    SQ_HD void min_first(double &, int &, int) const {}
+    SQ_HD void min_plain(double &) const {}
+    SQ_HD int excl_scan(int cnt, int &total) const { total = cnt; return 0; }
+};
+#ifdef __HIPCC__
+// ... or the 64 lanes of a wave.  first_true: lowest lane whose predicate holds (nl if none);
+// min_first: lexicographic minimum of (value, index) over the lanes with index < nl, broadcast to all.
+struct SqCoopWave {
+    __device__ int first_true(bool p, int nl) const
+    {
+        const unsigned long long b = __ballot(p);
+        return b ? (int)__ffsll((long long)b) - 1 : nl;
+    }
+    __device__ void min_first(double &v, int &i, int nl) const
+    {
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(v, off);
+            const int oi = __shfl_xor(i, off);
+            const bool take = oi < nl && (i >= nl || ov < v || (ov == v && oi < i));
+            if (take) { v = ov; i = oi; }
+        }
+    }
+    __device__ void min_plain(double &v) const
+    {
+        for (int off = 32; off > 0; off >>= 1) { const double ov = __shfl_xor(v, off); if (ov < v) v = ov; }
+    }
+    __device__ int excl_scan(int cnt, int &total) const       // exclusive prefix sum over the lanes + wave total
+    {
+        const int lane = (int)(threadIdx.x & 63);
+        int inc = cnt;
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+        total = __shfl(inc, 63);
+        return inc - cnt;
+    }
+};
+#endif
+
 struct SqBlossom {
     // graph
     int n, m;                 // vertices (graph order), undirected edges
@@ -37,7 +77,7 @@ struct SqBlossom {
     uint8_t *allow;           // per undirected edge
     int *queue; int qn, qcap;
     // blossoms
-    int *sib_next, *sib_prev, *edge_after, *first, *nchild;
+    int *sib_next, *sib_prev, *edge_after, *first, *nchild, *nleaf;
     int *mbe_off, *mbe_cnt;   // mybestedges (cnt < 0: None)
     int *pool; int pool_n, pool_cap;
     int *live; int nlive;     // live blossoms in creation order (dict order of blossomparent/blossomdual)
@@ -59,7 +99,7 @@ struct SqBlossom {
                       + 2 * (size_t)n                           // mate, mate_de
                       + 4 * N2 + (size_t)n                      // labeledge, parent, base, bestedge, inblossom
                       + (size_t)queue_cap(n, m, tight)          // queue
-                      + 7 * N2                                  // sib_next, sib_prev, edge_after, first, nchild, mbe_off, mbe_cnt
+                      + 8 * N2                                  // sib_next, sib_prev, edge_after, first, nchild, nleaf, mbe_off, mbe_cnt
                       + (size_t)pool_capacity(n, m, tight)      // pool
                       + 2 * (size_t)n + 2                       // live, freeb
                       + 2 * N2 + 4 * N2 + 2 * N2                // tmp_leaves, tmp_stack | tmp_path, tmp_edges (2 each) | beto, beto_keys
@@ -79,7 +119,7 @@ struct SqBlossom {
         mate = take_i(n); mate_de = take_i(n);
         labeledge = take_i(N2); parent = take_i(N2); base = take_i(N2); bestedge = take_i(N2); inblossom = take_i(n);
         qcap = queue_cap(n, m, tight); queue = take_i(qcap); qn = 0;
-        sib_next = take_i(N2); sib_prev = take_i(N2); edge_after = take_i(N2); first = take_i(N2); nchild = take_i(N2);
+        sib_next = take_i(N2); sib_prev = take_i(N2); edge_after = take_i(N2); first = take_i(N2); nchild = take_i(N2); nleaf = take_i(N2);
         mbe_off = take_i(N2); mbe_cnt = take_i(N2);
         pool_cap = pool_capacity(n, m, tight); pool = take_i(pool_cap); pool_n = 0;
         live = take_i(n + 1); freeb = take_i(n + 1);
@@ -202,6 +242,7 @@ struct SqBlossom {
         bdual[b] = 0;
         {
             const int c = leaves(b, tmp_leaves);
+            nleaf[b] = c;                                   // fixed for the blossom's lifetime
             for (int k = 0; k < c; k++) {
                 const int x = tmp_leaves[k];
                 if (label[inblossom[x]] == 2) qpush(x);
@@ -417,11 +458,17 @@ struct SqBlossom {
     // sequential rule "first strictly smaller wins": per lane the first minimum of its stride, then
     // across lanes the smallest value and, among equals, the smallest iteration index.
     int f_augmented, f_stop, f_break;
+#ifdef SQ_MWM_PROF
+    long long pt[8]; long long pc[8];
+#define SQ_PT(k, expr) do { const long long _t0 = wall_clock64(); expr; pt[k] += wall_clock64() - _t0; } while (0)
+#else
+#define SQ_PT(k, expr) do { expr; } while (0)
+#endif
     double red_v[64][4];
     int red_i[64][4];
 
-    template <class Sync>
-    SQ_HD void run(int lane, int nl, Sync sync)
+    template <class Sync, class Coop>
+    SQ_HD void run(int lane, int nl, Sync sync, Coop coop)
     {
         const int N2 = 2 * n + 2;
         for (int v = lane; v < n; v += nl) { mate[v] = -1; mate_de[v] = -1; inblossom[v] = v; }
@@ -441,53 +488,152 @@ struct SqBlossom {
             for (int v = lane; v < n; v += nl) dualvar[v] = maxweight;
         }
         sync();
+#ifdef SQ_MWM_PROF
+        long long _tp = wall_clock64();
+        if (lane == 0) for (int k = 0; k < 8; k++) { pt[k] = 0; pc[k] = 0; }
+#endif
         for (;;) {                                              // stages
+#ifdef SQ_MWM_PROF
+            if (lane == 0) pc[3]++;
+#endif
             for (int x = lane; x < N2; x += nl) { label[x] = 0; labeledge[x] = -1; bestedge[x] = -1; }
             for (int k = lane; k < nlive; k += nl) mbe_cnt[live[k]] = -1;
             for (int e = lane; e < m; e += nl) allow[e] = 0;
             sync();
-            if (lane == 0) {
-                pool_n = 0; qn = 0;
-                for (int v = 0; v < n; v++)
-                    if (mate[v] == -1 && label[inblossom[v]] == 0) assignLabel(v, 1, -1);
-                f_augmented = 0;
-            }
-            sync();
-            for (;;) {                                          // substages
-                if (lane == 0) {
-                    bool augmented = false;
-                    while (qn && !augmented) {
-                        const int v = queue[--qn];
-                        for (int a = adj_off[v]; a < adj_off[v + 1]; a++) {
-                            const int de = adj[a];
-                            const int w = head(de);
-                            if (w == v) continue;
-                            const int bv = inblossom[v], bw = inblossom[w];
-                            if (bv == bw) continue;
-                            double kslack = 0;
-                            if (!allow[de >> 1]) {
-                                kslack = slack(de);
-                                if (kslack <= 0) allow[de >> 1] = 1;
-                            }
-                            if (allow[de >> 1]) {
-                                if (label[bw] == 0) assignLabel(w, 2, de);
-                                else if (label[bw] == 1) {
-                                    const int bs = scanBlossom(v, w);
-                                    if (bs != -1) addBlossom(bs, de);
-                                    else { augmentMatching(de); augmented = true; break; }
-                                } else if (label[w] == 0) {
-                                    label[w] = 2; labeledge[w] = de;
-                                }
-                            } else if (label[bw] == 1) {
-                                if (bestedge[bv] == -1 || kslack < slack(bestedge[bv])) bestedge[bv] = de;
-                            } else if (label[w] == 0) {
-                                if (bestedge[w] == -1 || kslack < slack(bestedge[w])) bestedge[w] = de;
-                            }
+            // every free vertex becomes an S-vertex: assignLabel(v, 1, None) in vertex order.  Free vertices sit in
+            // distinct top-level blossoms, so the label writes are independent; only the queue order is sequential
+            // (prefix sum over leaf counts; the leaves of a non-trivial blossom are listed by lane 0).
+            {
+                if (lane == 0) { pool_n = 0; f_augmented = 0; }
+                int qbase = 0;
+                for (int v0 = 0; v0 < n; v0 += nl) {
+                    const int v = v0 + lane;
+                    const bool q = v < n && mate[v] == -1 && label[inblossom[v]] == 0;
+                    const int b = q ? inblossom[v] : -1;
+                    const int cnt = q ? (b >= n ? nleaf[b] : 1) : 0;
+                    int total = 0;
+                    const int pos = qbase + coop.excl_scan(cnt, total);
+                    red_i[lane][0] = -1;
+                    if (q) {
+                        if (pos + cnt > qcap) error = 1;
+                        else {
+                            label[v] = label[b] = 1; labeledge[v] = labeledge[b] = -1; bestedge[v] = bestedge[b] = -1;
+                            if (b < n) queue[pos] = b;
+                            else { red_i[lane][0] = b; red_i[lane][1] = pos; }
                         }
                     }
-                    f_augmented = augmented ? 1 : 0;
+                    const int anyb = coop.first_true(q && b >= n, nl);
+                    if (anyb < nl) {
+                        sync();
+                        if (lane == 0 && !error)
+                            for (int l = anyb; l < nl; l++) if (red_i[l][0] != -1) leaves(red_i[l][0], queue + red_i[l][1]);
+                        sync();
+                    }
+                    qbase += total;
+                }
+                if (lane == 0) qn = qbase;
+            }
+            sync();
+#ifdef SQ_MWM_PROF
+                if (lane == 0) { const long long _n = wall_clock64(); pt[5] += _n - _tp; _tp = _n; }
+#endif
+            for (;;) {                                          // substages
+                if (lane == 0) {
+#ifdef SQ_MWM_PROF
+                    pc[2]++;
+#endif
+                    f_augmented = 0;
+                }
+                // ---- queue of S-vertices.  One vertex at a time (LIFO order matters), its neighbours 64 at a
+                // time: every lane classifies one neighbour against the current state; the neighbours before the
+                // first one that changes shared state (a label assignment, a new blossom, an augmentation) only
+                // touch their own w (allowedge, label[w], bestedge[w]) or compete for bestedge[bv] (first strictly
+                // smaller slack wins == lexicographic (slack, position) minimum), so they are applied in parallel;
+                // the state-changing neighbour is then handled by lane 0 with the sequential code and the rest of
+                // the list is re-classified.
+                for (;;) {
+                    sync();
+                    if (qn == 0 || f_augmented || error) break;
+                    const int v = queue[qn - 1];
+                    sync();
+                    if (lane == 0) qn--;
+                    int a0 = adj_off[v];
+                    const int aend = adj_off[v + 1];
+#ifdef SQ_MWM_PROF
+                    if (lane == 0) { pc[1]++; pc[0] += aend - a0; }
+#endif
+                    while (a0 < aend) {
+                        const int a = a0 + lane;
+                        const int bv = inblossom[v];
+                        int cat = 0, de = -1, w = -1;          // 0 none, 1 event, 2 label[w] := T, 3 bestedge[w], 4 bestedge[bv]
+                        bool becomes = false;
+                        double ks = 0;
+                        if (a < aend) {
+                            de = adj[a];
+                            w = head(de);
+                            const int bw = inblossom[w];
+                            if (w != v && bw != bv) {
+                                bool allowed = allow[de >> 1] != 0;
+                                if (!allowed) {
+                                    ks = slack(de);
+                                    if (ks <= 0) { becomes = true; allowed = true; }
+                                }
+                                const int lbw = label[bw];
+                                if (allowed) {
+                                    if (lbw == 0 || lbw == 1) cat = 1;
+                                    else if (label[w] == 0) cat = 2;
+                                } else if (lbw == 1) cat = 4;
+                                else if (label[w] == 0) cat = 3;
+                            }
+                        }
+                        const int f = coop.first_true(cat == 1, nl);        // first state-changing neighbour of the chunk
+                        if (lane < f && a < aend) {
+                            if (becomes) allow[de >> 1] = 1;
+                            if (cat == 2) { label[w] = 2; labeledge[w] = de; }
+                            else if (cat == 3) { if (bestedge[w] == -1 || ks < slack(bestedge[w])) bestedge[w] = de; }
+                        }
+                        double mv = ks; int mi = (lane < f && cat == 4) ? lane : nl;
+                        coop.min_first(mv, mi, nl);
+                        if (lane == 0 && mi < nl) {
+                            if (bestedge[bv] == -1 || mv < slack(bestedge[bv])) bestedge[bv] = adj[a0 + mi];
+                        }
+                        if (f >= nl) { a0 += nl; continue; }
+                        sync();
+                        if (lane == 0) {                        // the sequential body for neighbour a0 + f
+                            const int de1 = adj[a0 + f];
+                            const int w1 = head(de1);
+                            const int bv1 = inblossom[v], bw1 = inblossom[w1];
+                            if (w1 != v && bv1 != bw1) {
+                                double kslack = 0;
+                                if (!allow[de1 >> 1]) {
+                                    kslack = slack(de1);
+                                    if (kslack <= 0) allow[de1 >> 1] = 1;
+                                }
+                                if (allow[de1 >> 1]) {
+                                    if (label[bw1] == 0) assignLabel(w1, 2, de1);
+                                    else if (label[bw1] == 1) {
+                                        const int bs = scanBlossom(v, w1);
+                                        if (bs != -1) addBlossom(bs, de1);
+                                        else { augmentMatching(de1); f_augmented = 1; }
+                                    } else if (label[w1] == 0) {
+                                        label[w1] = 2; labeledge[w1] = de1;
+                                    }
+                                } else if (label[bw1] == 1) {
+                                    if (bestedge[bv1] == -1 || kslack < slack(bestedge[bv1])) bestedge[bv1] = de1;
+                                } else if (label[w1] == 0) {
+                                    if (bestedge[w1] == -1 || kslack < slack(bestedge[w1])) bestedge[w1] = de1;
+                                }
+                            }
+                        }
+                        sync();
+                        if (f_augmented || error) break;
+                        a0 += f + 1;
+                    }
                 }
                 sync();
+#ifdef SQ_MWM_PROF
+                if (lane == 0) { const long long _n = wall_clock64(); pt[0] += _n - _tp; _tp = _n; }
+#endif
                 if (f_augmented || error) break;
                 // ---- the four delta candidates, strided over the lanes
                 {
@@ -511,27 +657,17 @@ struct SqBlossom {
                         const int b = live[k];
                         if (parent[b] == -1 && label[b] == 2 && (i4 == -1 || bdual[b] < m4)) { m4 = bdual[b]; i4 = k; }
                     }
-                    red_v[lane][0] = m1; red_v[lane][1] = m2; red_v[lane][2] = m3; red_v[lane][3] = m4;
-                    red_i[lane][1] = i2; red_i[lane][2] = i3; red_i[lane][3] = i4;
-                }
-                sync();
-                if (lane == 0) {
-                    double m1 = red_v[0][0];
-                    double mm[4] = {0, 0, 0, 0}; int ii[4] = {-1, -1, -1, -1};
-                    for (int l = 0; l < nl; l++) {
-                        if (red_v[l][0] < m1) m1 = red_v[l][0];
-                        for (int t = 1; t < 4; t++) {
-                            const int idx = red_i[l][t];
-                            if (idx == -1) continue;
-                            if (ii[t] == -1 || red_v[l][t] < mm[t] || (red_v[l][t] == mm[t] && idx < ii[t])) { mm[t] = red_v[l][t]; ii[t] = idx; }
-                        }
-                    }
+                    // combine across the lanes: (value, iteration index) lexicographic minima == "first strictly smaller wins"
+                    const int NONE = 0x7fffffff;
+                    coop.min_plain(m1);
+                    if (i2 == -1) i2 = NONE; if (i3 == -1) i3 = NONE; if (i4 == -1) i4 = NONE;
+                    coop.min_first(m2, i2, NONE); coop.min_first(m3, i3, NONE); coop.min_first(m4, i4, NONE);
                     int deltatype = 1, deltaedge = -1, deltablossom = -1;
                     double delta = m1;
-                    if (ii[1] != -1 && mm[1] < delta) { delta = mm[1]; deltatype = 2; deltaedge = bestedge[ii[1]]; }
-                    if (ii[2] != -1 && mm[2] < delta) { delta = mm[2]; deltatype = 3; const int b = ii[2] < n ? ii[2] : live[ii[2] - n]; deltaedge = bestedge[b]; }
-                    if (ii[3] != -1 && mm[3] < delta) { delta = mm[3]; deltatype = 4; deltablossom = live[ii[3]]; }
-                    red_v[0][0] = delta; red_i[0][0] = deltatype; red_i[0][1] = deltaedge; red_i[0][2] = deltablossom;
+                    if (i2 != NONE && m2 < delta) { delta = m2; deltatype = 2; deltaedge = bestedge[i2]; }
+                    if (i3 != NONE && m3 < delta) { delta = m3; deltatype = 3; const int b = i3 < n ? i3 : live[i3 - n]; deltaedge = bestedge[b]; }
+                    if (i4 != NONE && m4 < delta) { delta = m4; deltatype = 4; deltablossom = live[i4]; }
+                    if (lane == 0) { red_v[0][0] = delta; red_i[0][0] = deltatype; red_i[0][1] = deltaedge; red_i[0][2] = deltablossom; }
                 }
                 sync();
                 {
@@ -546,6 +682,9 @@ struct SqBlossom {
                     }
                 }
                 sync();
+#ifdef SQ_MWM_PROF
+                if (lane == 0) { const long long _n = wall_clock64(); pt[3] += _n - _tp; _tp = _n; }
+#endif
                 if (lane == 0) {
                     const int deltatype = red_i[0][0], deltaedge = red_i[0][1], deltablossom = red_i[0][2];
                     f_stop = 0;
@@ -554,6 +693,9 @@ struct SqBlossom {
                     else expandBlossom(deltablossom, false);
                 }
                 sync();
+#ifdef SQ_MWM_PROF
+                if (lane == 0) { const long long _n = wall_clock64(); pt[4] += _n - _tp; _tp = _n; }
+#endif
                 if (f_stop || error) break;
             }
             if (!f_augmented || error) break;
@@ -570,12 +712,22 @@ struct SqBlossom {
                 }
             }
             sync();
+#ifdef SQ_MWM_PROF
+                if (lane == 0) { const long long _n = wall_clock64(); pt[6] += _n - _tp; _tp = _n; }
+#endif
             if (error) break;
         }
+#ifdef SQ_MWM_PROF
+#ifdef __HIP_DEVICE_COMPILE__
+        if (lane == 0 && n >= 140)
+            printf("mwm n=%d m=%d stages=%lld substages=%lld popped=%lld visits=%lld | us: queue %.0f delta %.0f combine %.0f update %.0f act %.0f stageinit %.0f endstage %.0f\n",
+                   n, m, pc[3], pc[2], pc[1], pc[0], pt[0] * 0.01, pt[1] * 0.01, pt[2] * 0.01, pt[3] * 0.01, pt[4] * 0.01, pt[5] * 0.01, pt[6] * 0.01);
+#endif
+#endif
     }
 
     SQ_HD void run()
     {
-        run(0, 1, [] {});
+        run(0, 1, [] {}, SqCoopSingle());
     }
 };

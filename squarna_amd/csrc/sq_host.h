@@ -75,6 +75,8 @@ struct sq_batch {
     SqStrand *d_strands = nullptr;
     SqOut *d_out = nullptr;
     int64_t cand_records = 0;
+    int64_t cand_reserved = 0;            // records at the END of the arena lent to matching kernels in flight
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
     uint32_t out_cap = 0;
     int32_t strand_cap = 0;
     size_t mat32_bytes = 0;
@@ -102,6 +104,12 @@ int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::
 // RunAlgo (SQRNdbnseq.py:548-595) for one of SQ_ALGO_E / H / N over a list of jobs
 int sq_run_algo(sq_batch *b, const std::vector<int> &jobs, int algo, int levellimit_opt,
                 std::vector<std::vector<HStem>> &out);
+
+// asynchronous E/H/N for sq_fold: begin() annotates + launches on side streams, end() collects
+struct SqAlgoAsync;
+struct JobSets { int algo; std::vector<int> jobs; std::vector<std::vector<HStem>> sets; };
+int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync *&pa);
+int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<JobSets> &sets);
 
 // host tail: SQRNdbnseq.py:1201-1286
 void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,

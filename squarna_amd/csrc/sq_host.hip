@@ -315,6 +315,7 @@ extern "C" void sq_batch_destroy(sq_batch *b)
     if (b->h_strands) hipHostFree(b->h_strands);
     if (b->h_ctr) hipHostFree(b->h_ctr);
     if (b->h_out) hipHostFree(b->h_out);
+    for (int k = 0; k < 3; k++) if (b->side[k]) { hipStreamSynchronize(b->side[k]); hipStreamDestroy(b->side[k]); }
     for (auto &p : b->prof) {
         for (auto &e : p.pending) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
         for (auto &e : p.pool) hipEventDestroy(e);
@@ -649,10 +650,10 @@ int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::
         while (hi < structs.size() && (int)(hi - lo) < b->max_structs) {
             const SqJob &J = b->jobs[structs[hi].job];
             const int64_t ns = (int64_t)structs[hi].st->strands.size();
-            if (hi > lo && (cands + J.cand_cap > b->cand_records || strands + ns > b->strand_cap)) break;
+            if (hi > lo && (cands + J.cand_cap > b->cand_records - b->cand_reserved || strands + ns > b->strand_cap)) break;
             cands += J.cand_cap; strands += ns; hi++;
         }
-        if (cands > b->cand_records || strands > b->strand_cap) { sq_set_error("structure does not fit the round buffers"); return -3; }
+        if (cands > b->cand_records - b->cand_reserved || strands > b->strand_cap) { sq_set_error("structure does not fit the round buffers"); return -3; }
         int r = run_chunk(b, structs, lo, hi, mode, out);
         if (r) return r;
         lo = hi;
@@ -728,17 +729,15 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     }
     // Edmonds / Hungarian / Nussinov paramsets (:1094-1100); their stemsets precede the greedy ones.
     // The reference iterates a Python set of letters (unspecified order); we use E, H, N.
-    for (int algo : {SQ_ALGO_E, SQ_ALGO_H, SQ_ALGO_N}) {
-        std::vector<int> js;
-        for (int j = 0; j < b->njobs; j++) if (algos[j] & (uint32_t)algo) js.push_back(j);
-        if (js.empty()) continue;
-        std::vector<std::vector<HStem>> sets;
-        const double ta = now_s();
-        r = sq_run_algo(b, js, algo, o.levellimit, sets);
-        if (r) return r;
-        if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_fold] algo %d: %zu jobs %.3f ms\n", algo, js.size(), (now_s() - ta) * 1e3);
-        for (size_t k = 0; k < js.size(); k++) { pools[js[k]].fin.push_back(std::move(sets[k])); pools[js[k]].evals++; }
-    }
+    SqAlgoAsync *pending = nullptr;
+    const double ta = now_s();
+    r = sq_algos_begin(b, algos, pending);                  // AnnotateStems + matching kernels on side streams
+    struct PendGuard {                                      // error paths: wait for the side streams, release the arena
+        sq_batch *b; SqAlgoAsync *&p;
+        ~PendGuard() { if (p) { std::vector<JobSets> d; sq_algos_end(b, p, -1, d); p = nullptr; } }
+    } guard{b, pending};
+    if (r) return r;
+    const double tbegin = now_s() - ta;
     std::vector<SView> round;
     std::vector<int> owner;                                 // job of each view
     std::vector<std::vector<HStem>> res;
@@ -793,6 +792,21 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         for (int j = 0; j < b->njobs; j++) pools[j].cur.swap(next[j]);
     }
     const double tloop = now_s() - tfold0;
+    {
+        const double t0 = now_s();
+        std::vector<JobSets> sets;
+        r = sq_algos_end(b, pending, o.levellimit, sets);
+        pending = nullptr;
+        if (r) return r;
+        // their stemsets precede the greedy ones (:1094-1100): E, H, N order
+        for (auto it = sets.rbegin(); it != sets.rend(); ++it)
+            for (size_t k = 0; k < it->jobs.size(); k++) {
+                JobPool &P = pools[it->jobs[k]];
+                P.fin.insert(P.fin.begin(), std::move(it->sets[k]));
+                P.evals++;
+            }
+        if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_fold] E/H/N: begin %.3f ms, wait+collect after the greedy loop %.3f ms\n", tbegin * 1e3, (now_s() - t0) * 1e3);
+    }
     const double ttail0 = now_s();
     // a-10 tail per sequence
     std::vector<std::vector<int32_t>> seq_jobs(b->nseq);

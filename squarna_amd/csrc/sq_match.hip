@@ -32,20 +32,42 @@ extern "C" __global__ __launch_bounds__(64) void sq_lsap_kernel(const SqMatchJob
     double *cost = reinterpret_cast<double *>(scratch + jb.scratch_off);
     double *u = cost + (size_t)n * n;
     // the per-row/column vectors are touched in every step of the augmenting path: LDS when they fit
-    if ((size_t)n * (3 * 8 + 4 * 4 + 2) + 64 <= (size_t)lds_bytes) u = reinterpret_cast<double *>(lsap_lds);
+    const size_t vec_bytes = ((size_t)n * (3 * 8 + 4 * 4 + 2) + 15) & ~(size_t)15;
+    const bool vec_lds = vec_bytes + 64 <= (size_t)lds_bytes;
+    if (vec_lds) u = reinterpret_cast<double *>(lsap_lds);
     double *v = u + n, *spc = v + n;
     int32_t *path = reinterpret_cast<int32_t *>(spc + n);
     int32_t *col4row = path + n, *row4col = col4row + n, *remaining = row4col + n;
     uint8_t *SR = reinterpret_cast<uint8_t *>(remaining + n), *SC = SR + n;
+    // the cost matrix is zero except for the 2m stem cells: when it fits, LDS holds it as 16-bit edge ids
+    // (+ the edge weights), so a step of the shortest-path scan never leaves the CU
+    const int m = jb.nedges;
+    const bool mat_lds = vec_lds && m < 65535 && vec_bytes + (size_t)m * 8 + (size_t)n * n * 2 + 64 <= (size_t)lds_bytes;
+    double *wts = reinterpret_cast<double *>(lsap_lds + vec_bytes);
+    uint16_t *ids = reinterpret_cast<uint16_t *>(wts + m);
 
     // mat = zeros; mat[v,w] = mat[w,v] = -(score**power)   (SQRNalgos.py:119-123)
-    for (size_t q = lane; q < (size_t)n * n; q += 64) cost[q] = 0.0;
+    if (mat_lds) {
+        for (size_t q = lane; q < ((size_t)n * n + 1) / 2; q += 64) reinterpret_cast<uint32_t *>(ids)[q] = 0u;
+    } else {
+        for (size_t q = lane; q < (size_t)n * n; q += 64) cost[q] = 0.0;
+    }
     for (int q = lane; q < n; q += 64) { u[q] = 0.0; v[q] = 0.0; path[q] = -1; col4row[q] = -1; row4col[q] = -1; }
     __syncthreads();
-    for (int e = lane; e < jb.nedges; e += 64) {
-        const SqMatchEdge ed = edges[jb.edge_off + e];
-        cost[(size_t)ed.v * n + ed.w] = -ed.weight;
-        cost[(size_t)ed.w * n + ed.v] = -ed.weight;
+    // (the cells of the stems are distinct, so the order of these writes does not matter)
+    if (mat_lds) {
+        for (int e = lane; e < m; e += 64) {
+            const SqMatchEdge ed = edges[jb.edge_off + e];
+            wts[e] = ed.weight;
+            ids[(size_t)ed.v * n + ed.w] = (uint16_t)(e + 1);
+            ids[(size_t)ed.w * n + ed.v] = (uint16_t)(e + 1);
+        }
+    } else {
+        for (int e = lane; e < m; e += 64) {
+            const SqMatchEdge ed = edges[jb.edge_off + e];
+            cost[(size_t)ed.v * n + ed.w] = -ed.weight;
+            cost[(size_t)ed.w * n + ed.v] = -ed.weight;
+        }
     }
     __syncthreads();
 
@@ -63,7 +85,10 @@ extern "C" __global__ __launch_bounds__(64) void sq_lsap_kernel(const SqMatchJob
             int first = -1, lastun = -1;
             for (int it = lane; it < nrem; it += 64) {
                 const int j = remaining[it];
-                const double r = minval + cost[(size_t)i * n + j] - ui - v[j];
+                double cij;
+                if (mat_lds) { const uint16_t id = ids[(size_t)i * n + j]; cij = id ? -wts[id - 1] : 0.0; }
+                else cij = cost[(size_t)i * n + j];
+                const double r = minval + cij - ui - v[j];
                 double sp = spc[j];
                 if (r < sp) { path[j] = i; spc[j] = r; sp = r; }
                 const bool un = row4col[j] == -1;
@@ -215,7 +240,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
         __syncthreads();
         if (lane == 0) bl.init(n, m, le, mwm_lds + ebytes, 1);
         __syncthreads();
-        bl.run(lane, 64, [] { __syncthreads(); });
+        bl.run(lane, 64, [] { __syncthreads(); }, SqCoopWave());
         __syncthreads();
         if (!bl.error) {
             for (int q = lane; q < n; q += 64) mate_out[jp->out_off + q] = bl.mate[q];
@@ -226,7 +251,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
     if (lane == 0) bl.init(n, m, edges + jp->edge_off, scratch + jp->scratch_off, 0);
     __syncthreads();
     // lane 0 runs the order-dependent part; all 64 lanes share the O(n) sweeps of every substage
-    bl.run(lane, 64, [] { __syncthreads(); });
+    bl.run(lane, 64, [] { __syncthreads(); }, SqCoopWave());
     __syncthreads();
     for (int q = lane; q < n; q += 64) mate_out[jp->out_off + q] = bl.error ? -2 : bl.mate[q];
 }

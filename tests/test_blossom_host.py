@@ -1,0 +1,62 @@
+"""The product's blossom restatement (squarna_amd/csrc/sq_blossom.h), compiled for the host, against
+networkx.max_weight_matching on random graphs with many ties (the reference's a-9 dependency)."""
+import os
+import random
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "native", "blossom_host.cpp")
+EXE = os.path.join(HERE, "native", "_build", "blossom_host")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", EXE, SRC])
+    return EXE
+
+
+def _graphs(seed, count):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(count):
+        n = rng.randint(2, 22)
+        m = rng.randint(1, min(60, n * (n - 1) // 2))
+        pairs = set()
+        while len(pairs) < m:
+            a, b = rng.sample(range(n), 2)
+            pairs.add((min(a, b), max(a, b)))
+        pairs = list(pairs)
+        rng.shuffle(pairs)
+        small = rng.random() < 0.6                        # few distinct weights -> non-unique optima
+        edges = [(a, b, float(rng.randint(1, 4)) if small else round(rng.uniform(1, 30), 3) ** 1.7) for a, b in pairs]
+        out.append(edges)
+    return out
+
+
+def test_blossom_matches_networkx(exe):
+    nx = pytest.importorskip("networkx")
+    graphs = _graphs(7, 400)
+    lines, idmaps = [str(len(graphs))], []
+    for edges in graphs:
+        ids = {}
+        for a, b, _ in edges:                              # vertex ids in first-appearance order == nx node order
+            ids.setdefault(a, len(ids))
+            ids.setdefault(b, len(ids))
+        idmaps.append(ids)
+        lines.append("%d %d" % (len(ids), len(edges)))
+        lines += ["%d %d %r" % (ids[a], ids[b], w) for a, b, w in edges]
+    res = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True)
+    rows = res.stdout.strip().split("\n")
+    assert len(rows) == len(graphs)
+    for edges, ids, row in zip(graphs, idmaps, rows):
+        G = nx.Graph()
+        for a, b, w in edges:
+            G.add_edge(a, b, weight=w)
+        exp = {tuple(sorted(p)) for p in nx.max_weight_matching(G)}
+        mate = list(map(int, row.split()))
+        inv = {v: k for k, v in ids.items()}
+        got = {tuple(sorted((inv[v], inv[mate[v]]))) for v in range(len(mate)) if mate[v] > v}
+        assert got == exp, (edges, got, exp)

@@ -23,3 +23,4 @@ with Batch([Prepared(s) for s in seqs], [psets] * nseq, max_structs=nseq) as b:
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         ms, launches, by = b.profile_get(2)
         print("fold %.2f ms; scan %.3f ms over %d launches, %.1f GB/s algorithmic" % (dt * 1e3, ms, launches, by / ms / 1e6))
+        print("   " + "  ".join("%s %.3f ms/%d" % (nm, *b.profile_get(k)[:2]) for k, nm in enumerate(["fill", "state", "scan", "score"])))
