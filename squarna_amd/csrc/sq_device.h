@@ -31,6 +31,7 @@ struct SqState {             // per-structure-slot arrays, `stride` elements per
 struct SqScanArgs {
     SqCand *cands;
     uint32_t *cand_cnt;      // per slot
+    unsigned long long *best; // per slot: order-preserving image of the round's best finalscore (0: none yet)
     SqCounters *ctr;
 };
 
@@ -49,4 +50,5 @@ __global__ void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt
 __global__ void sq_bits_kernel(SqDevCtx c);
 __global__ void sq_score_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
                                 SqScanArgs a, SqOut *out, uint32_t out_cap, int mode, int lds_n, int lds_n_reacts);
+__global__ void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqOut *out, uint32_t out_cap);
 }

@@ -108,7 +108,7 @@ int plan(const sq_batch_desc *d, Layout &L)
     L.off_structs = take(sizeof(SqStruct) * L.max_structs);
     L.off_strands = take(sizeof(SqStrand) * (size_t)L.strand_cap);
     L.off_state = take((size_t)4 * 2 * L.stride * L.max_structs);
-    L.off_cnt = take(4 * (size_t)L.max_structs);
+    L.off_cnt = take(12 * (size_t)align_up((size_t)L.max_structs, 2));   // cand_cnt (u32) then best (u64) per slot
     L.off_ctr = take(sizeof(SqCounters));
     L.off_cands = take(sizeof(SqCand) * (size_t)L.cand_records);
     L.off_out = take(sizeof(SqOut) * (size_t)L.out_cap);
@@ -269,6 +269,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->state.FB = (uint32_t *)(base + L.off_fb); b->state.fbstride = L.fbstride;
     b->ctx.bits = (uint32_t *)(base + L.off_bits); b->ctx.rbpk = (uint32_t *)(base + L.off_rbpk);
     b->scan.cand_cnt = (uint32_t *)(base + L.off_cnt); b->scan.ctr = (SqCounters *)(base + L.off_ctr);
+    b->scan.best = (unsigned long long *)(base + L.off_cnt + 4 * align_up((size_t)L.max_structs, 2));
     b->scan.cands = (SqCand *)(base + L.off_cands);
     b->d_out = (SqOut *)(base + L.off_out);
 
@@ -530,14 +531,14 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
                      std::vector<std::vector<HStem>> &out)
 {
     const int S = (int)(hi - lo);
-    int nstrand = 0, maxn = 0; int64_t cand_off = 0; double scan_bytes = 0;
+    int nstrand = 0, maxn = 0; int64_t cand_off = 0, maxcap = 0; double scan_bytes = 0;
     double tp0 = now_s();
     for (int s = 0; s < S; s++) {
         const SView &hs = structs[lo + s];
         const SqJob &J = b->jobs[hs.job];
         SqStruct &d = b->h_structs[s];
         d.job = hs.job; d.slot = s; d.subopt = hs.subopt; d.cand_off = cand_off;
-        cand_off += J.cand_cap;
+        cand_off += J.cand_cap; maxcap = std::max<int64_t>(maxcap, J.cand_cap);
         d.strand_off = nstrand; d.nstrand = (int)hs.st->strands.size();
         if (d.nstrand) memcpy(b->h_strands + nstrand, hs.st->strands.data(), sizeof(SqStrand) * (size_t)d.nstrand);
         nstrand += d.nstrand;
@@ -548,7 +549,7 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
     g_t[0] += now_s() - tp0; tp0 = now_s();
     HIPCK(hipMemcpyAsync(b->d_structs, b->h_structs, sizeof(SqStruct) * S, hipMemcpyHostToDevice, st));
     if (nstrand) HIPCK(hipMemcpyAsync(b->d_strands, b->h_strands, sizeof(SqStrand) * nstrand, hipMemcpyHostToDevice, st));
-    HIPCK(hipMemsetAsync(b->scan.cand_cnt, 0, 4 * (size_t)S, st));
+    HIPCK(hipMemsetAsync(b->scan.cand_cnt, 0, 12 * align_up((size_t)b->max_structs, 2), st));   // counts + best images
     HIPCK(hipMemsetAsync(b->scan.ctr, 0, sizeof(SqCounters), st));
     {
         ProfScope ps(b, 1, 0);
@@ -576,11 +577,17 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
         const int lds_n = maxn <= 16384 ? maxn : 0;
         const int lds_nr = maxn <= 4096 ? maxn : 0;
         const size_t dyn = lds_n ? (size_t)((lds_n + 15) & ~15) + (size_t)8 * lds_nr + 16 : 0;
-        // few structures: more threads per structure hide the latency of the candidate stream
+        // few structures: deal each structure's candidates to several blocks so that the launch still fills the chip
         static const int score_threads = getenv("SQ_SCORE_THREADS") ? atoi(getenv("SQ_SCORE_THREADS")) : 0;
-        const int thr = score_threads ? score_threads : (S >= 2048 ? 256 : 512);
-        hipLaunchKernelGGL(sq_score_kernel, dim3(S), dim3(thr), dyn, st, b->ctx, b->d_structs, b->d_strands, b->state,
+        static const int score_parts = getenv("SQ_SCORE_PARTS") ? atoi(getenv("SQ_SCORE_PARTS")) : 0;
+        int parts = std::max(1, std::min({16, (1536 + S - 1) / S, (int)(maxcap / 1024)}));
+        if (score_parts) parts = score_parts;
+        const int thr = score_threads ? score_threads : (parts == 1 && S < 2048 ? 512 : 256);
+        hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, b->d_structs, b->d_strands, b->state,
                            b->scan, b->d_out, b->out_cap, mode, lds_n, lds_nr);
+        if (mode == 0)
+            hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, b->d_structs, b->scan,
+                               b->d_out, b->out_cap);
     }
     HIPCK(hipGetLastError());
     HIPCK(hipMemcpyAsync(b->h_ctr, b->scan.ctr, sizeof(SqCounters), hipMemcpyDeviceToHost, st));

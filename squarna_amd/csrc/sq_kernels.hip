@@ -991,6 +991,19 @@ __device__ __forceinline__ bool sq_goodloop(int x, int y)             // :615-62
     return (tab[x] >> y) & 1u;
 }
 
+// order-preserving map double -> uint64 (never 0 for a real number), so a per-structure maximum is one atomicMax
+__device__ __forceinline__ unsigned long long sq_ord(double x)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double sq_unord(unsigned long long o)
+{
+    return __longlong_as_double((long long)((o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFull) : ~o));
+}
+
+// grid = (structures, parts): the candidates of a structure are dealt to `parts` blocks; the round's best
+// finalscore of the structure is combined with atomicMax, the range filter (:769-778) runs in sq_select_kernel.
 extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, const SqStruct *structs,
                                                                   const SqStrand *strands, SqState stt, SqScanArgs a,
                                                                   SqOut *out, uint32_t out_cap, int mode, int lds_n,
@@ -999,9 +1012,6 @@ extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, c
     __shared__ SqStrand s_str[SQ_LDS_STRANDS];
     __shared__ double s_w[32 * 32];               // pair weights of the job's paramset
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];   // letter codes [n] (+ reactivities [n] when they fit)
-    __shared__ double r_fin[16];
-    __shared__ uint32_t r_key[16];
-    __shared__ int r_any[16];
     const SqStruct st = structs[blockIdx.x];
     const SqJob jb = c.jobs[st.job];
     const SqPsetDev *ps = c.psets + jb.pset;
@@ -1009,6 +1019,7 @@ extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, c
     const int tid = threadIdx.x, nthr = blockDim.x;
     uint32_t ncand = a.cand_cnt[st.slot];
     if (ncand > (uint32_t)jb.cand_cap) ncand = jb.cand_cap;
+    if ((uint32_t)blockIdx.y * (uint32_t)nthr >= ncand) return;         // this part has no candidates
     const SqStrand *S = strands + st.strand_off;
     if (st.nstrand <= SQ_LDS_STRANDS) {
         for (int k = tid; k < st.nstrand; k += nthr) s_str[k] = S[k];
@@ -1045,9 +1056,9 @@ extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, c
         return w * rf;
     };
 
-    double best = 0.0; uint32_t bestkey = 0xFFFFFFFFu; int any = 0;
+    double best = 0.0; int any = 0;
 
-    for (uint32_t q = tid; q < ncand; q += nthr) {
+    for (uint32_t q = blockIdx.y * nthr + tid; q < ncand; q += gridDim.y * nthr) {
         SqCand cd = cands[q];
         const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), L = (int)cd.len, j0 = s - i0;
         // exact bpscore: sum(...) left to right starting from int 0  (:416)
@@ -1132,32 +1143,38 @@ extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, c
                 const uint32_t o = atomicAdd(&a.ctr->nout, 1u);
                 if (o < out_cap) { SqOut r = {(int32_t)blockIdx.x, cd.key, L, 0, bps, 0.0}; out[o] = r; }
                 else a.ctr->out_ovf = 1;
-            } else if (!any || fin > best || (fin == best && cd.key < bestkey)) {
-                any = 1; best = fin; bestkey = cd.key;                   // :758 stable sort: ties keep emission order
+            } else if (!any || fin > best) {
+                any = 1; best = fin;                                     // :769 only the best VALUE matters for the range
             }
         }
     }
     if (mode == 1) return;
 
-    // block argmax (finalscore desc, key asc)
+    // wave maximum, then one atomicMax per wave on the structure's slot
     for (int off = 32; off > 0; off >>= 1) {
         const double ob = __shfl_xor(best, off);
-        const uint32_t ok_ = __shfl_xor(bestkey, off);
         const int oa = __shfl_xor(any, off);
-        if (oa && (!any || ob > best || (ob == best && ok_ < bestkey))) { any = 1; best = ob; bestkey = ok_; }
+        if (oa && (!any || ob > best)) { any = 1; best = ob; }
     }
-    if ((tid & 63) == 0) { r_fin[tid >> 6] = best; r_key[tid >> 6] = bestkey; r_any[tid >> 6] = any; }
-    __syncthreads();
-    any = 0; best = 0.0; bestkey = 0xFFFFFFFFu;
-    for (int w = 0; w < (nthr >> 6); w++)
-        if (r_any[w] && (!any || r_fin[w] > best || (r_fin[w] == best && r_key[w] < bestkey))) {
-            any = 1; best = r_fin[w]; bestkey = r_key[w];
-        }
-    if (!any) return;
-    const double range = st.subopt * best;                              // :769
-    for (uint32_t q = tid; q < ncand; q += nthr) {
+    if ((tid & 63) == 0 && any) atomicMax(a.best + st.slot, sq_ord(best));
+}
+
+// ChooseStems range filter (:769-778): candidates within subopt * best of the structure's best finalscore
+extern "C" __global__ __launch_bounds__(256) void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a,
+                                                                 SqOut *out, uint32_t out_cap)
+{
+    const SqStruct st = structs[blockIdx.x];
+    const unsigned long long ob = a.best[st.slot];
+    if (ob == 0ull) return;
+    const SqJob jb = c.jobs[st.job];
+    uint32_t ncand = a.cand_cnt[st.slot];
+    if (ncand > (uint32_t)jb.cand_cap) ncand = jb.cand_cap;
+    const SqCand *cands = a.cands + st.cand_off;
+    const double range = st.subopt * sq_unord(ob);                      // :769
+    for (uint32_t q = blockIdx.y * 256 + threadIdx.x; q < ncand; q += gridDim.y * 256) {
+        if (!cands[q].flags) continue;
         const SqCand cd = cands[q];
-        if (cd.flags && !(cd.fin < range)) {                            // :778
+        if (!(cd.fin < range)) {                                        // :778
             const uint32_t o = atomicAdd(&a.ctr->nout, 1u);
             if (o < out_cap) { SqOut r = {(int32_t)blockIdx.x, cd.key, (int32_t)cd.len, 0, cd.bps, cd.fin}; out[o] = r; }
             else a.ctr->out_ovf = 1;
