@@ -40,14 +40,15 @@ int sq_scan_seg();            // rows per wave of sq_scan_kernel
 int sq_scan5_seg();           // rows per wave of sq_scan5_kernel
 
 extern "C" {
-__global__ void sq_fill_kernel(SqDevCtx c);
+__global__ void sq_fill_kernel(SqDevCtx c, int only_ext, int mul_done);
+__global__ void sq_bits_direct_kernel(SqDevCtx c);
 __global__ void sq_dense64_kernel(SqDevCtx c, int job, double *boolmat, double *scoremat);
 __global__ void sq_import_kernel(SqDevCtx c);
 __global__ void sq_state_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState st);
 __global__ void sq_scan_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
 __global__ void sq_scan5_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
 __global__ void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
-__global__ void sq_bits_kernel(SqDevCtx c);
+__global__ void sq_bits_kernel(SqDevCtx c, int only_ext);
 __global__ void sq_score_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
                                 SqScanArgs a, SqOut *out, uint32_t out_cap, int mode, int lds_n, int lds_n_reacts);
 __global__ void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqOut *out, uint32_t out_cap);

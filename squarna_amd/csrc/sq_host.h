@@ -80,7 +80,9 @@ struct sq_batch {
     uint32_t out_cap = 0;
     int32_t strand_cap = 0;
     size_t mat32_bytes = 0;
-    bool filled = false;
+    bool filled = false;                  // fp32 matrices (and bit matrices) of every job are valid
+    bool mul_applied = false;             // multiplier matrices already folded into the dense arena
+    bool bits_ready = false;              // bit matrices valid (all the fold path needs)
     // pinned staging
     SqStruct *h_structs = nullptr;
     SqStrand *h_strands = nullptr;
@@ -97,6 +99,9 @@ struct sq_batch {
 
 void sq_set_error(const std::string &msg);
 int sq_check(hipError_t e, const char *what);
+
+// bit matrices for the scan (full fp32 fill only for jobs with caller matrices / legacy scans)
+int sq_prepare_scan(sq_batch *b);
 
 // one greedy round (or a raw AnnotateStems pass) for a list of structures; results per structure
 int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out);

@@ -375,28 +375,56 @@ extern "C" int sq_profile_get(sq_batch *b, int32_t k, double *ms, int64_t *launc
 }
 
 // ---- a-1 -----------------------------------------------------------------------------------
-extern "C" int sq_bpmatrix_fill(sq_batch *b)
+static int scan_version()
 {
-    int64_t maxq = 0; double bytes = 0; bool any_ext = false;
+    static const int v = getenv("SQ_SCAN") ? atoi(getenv("SQ_SCAN")) : 6;
+    return v;
+}
+
+// full = 1: fp32 score matrices of every job (the API op).  full = 0: only what the fold path reads -- the
+// bit matrices, computed straight from the O(N) inputs; jobs with caller / multiplier matrices still go
+// through the fp32 fill (it imports the bool matrix and forms score * multiplier in the dense arena).
+static int fill_impl(sq_batch *b, int full)
+{
+    int64_t maxq = 0, maxw = 0; double bytes = 0; bool any_ext1 = false, any_ext = false;
     for (const SqJob &J : b->jobs) {
         maxq = std::max<int64_t>(maxq, ((int64_t)J.n * J.ld + 3) / 4);
-        bytes += 4.0 * J.n * J.n;                                       // algorithmic: one fp32 N x N write
-        any_ext |= J.has_ext == 1;
+        maxw = std::max<int64_t>(maxw, (int64_t)J.nw * ((J.bpitch + 255) / 256));
+        if (full || J.has_ext) bytes += 4.0 * J.n * J.n;                // algorithmic: one fp32 N x N write
+        any_ext1 |= J.has_ext == 1; any_ext |= J.has_ext != 0;
     }
     for (int j0 = 0; j0 < b->njobs; j0 += 32768) {
         const int nj = std::min(32768, b->njobs - j0);
         SqDevCtx c = b->ctx; c.jobs = b->ctx.jobs + j0;
         dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>((maxq + 255) / 256, 1), 1024), (unsigned)nj);
-        {
+        if (full || any_ext) {
             ProfScope ps(b, 0, j0 == 0 ? bytes : 0);
-            hipLaunchKernelGGL(sq_fill_kernel, grid, dim3(256), 0, b->stream, c);
+            hipLaunchKernelGGL(sq_fill_kernel, grid, dim3(256), 0, b->stream, c, full ? 0 : 1, b->mul_applied ? 1 : 0);
         }
-        if (any_ext) hipLaunchKernelGGL(sq_import_kernel, grid, dim3(256), 0, b->stream, c);
-        hipLaunchKernelGGL(sq_bits_kernel, grid, dim3(256), 0, b->stream, c);
+        if (any_ext1) hipLaunchKernelGGL(sq_import_kernel, grid, dim3(256), 0, b->stream, c);
+        if (full && !getenv("SQ_BITS_DIRECT")) hipLaunchKernelGGL(sq_bits_kernel, grid, dim3(256), 0, b->stream, c, 0);
+        else {
+            if (any_ext1) hipLaunchKernelGGL(sq_bits_kernel, grid, dim3(256), 0, b->stream, c, 1);
+            dim3 g2((unsigned)std::min<int64_t>(std::max<int64_t>(maxw, 1), 2048), (unsigned)nj);
+            double bbytes = 0;
+            if (j0 == 0 && !(full || any_ext)) for (const SqJob &J : b->jobs) bbytes += 4.0 * J.nw * J.bpitch;   // bit words written
+            ProfScope ps(b, 0, bbytes);
+            hipLaunchKernelGGL(sq_bits_direct_kernel, g2, dim3(256), 0, b->stream, c);
+        }
     }
     HIPCK(hipGetLastError());
-    b->filled = true;
+    b->bits_ready = true;
+    if (full || any_ext) b->mul_applied = true;
+    if (full) b->filled = true;
     return 0;
+}
+
+extern "C" int sq_bpmatrix_fill(sq_batch *b) { return fill_impl(b, 1); }
+
+int sq_prepare_scan(sq_batch *b)
+{
+    if (scan_version() != 6) return b->filled ? 0 : fill_impl(b, 1);   // the fp32 scans read the matrix
+    return b->bits_ready ? 0 : fill_impl(b, 0);
 }
 
 extern "C" int sq_bpmatrix_read(sq_batch *b, int32_t job, double *boolmat, double *scoremat)
@@ -412,7 +440,7 @@ extern "C" int sq_bpmatrix_read(sq_batch *b, int32_t job, double *boolmat, doubl
     HIPCK(hipMemcpyAsync(boolmat, tmp, nn * 8, hipMemcpyDeviceToHost, b->stream));
     HIPCK(hipMemcpyAsync(scoremat, tmp + nn, nn * 8, hipMemcpyDeviceToHost, b->stream));
     HIPCK(hipStreamSynchronize(b->stream));
-    if (J.has_ext == 2 && b->filled) {                      // weighted matrix lives in the dense arena
+    if (J.has_ext == 2 && b->mul_applied) {                      // weighted matrix lives in the dense arena
         HIPCK(hipMemcpy(scoremat, b->ctx.mat64 + J.mat64_off, nn * 8, hipMemcpyDeviceToHost));
     }
     return 0;
@@ -557,15 +585,15 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
     }
     if (maxn >= 5) {
         const int nband = (2 * maxn - 5 + 255) >> 8;
-        static const int scan_version = getenv("SQ_SCAN") ? atoi(getenv("SQ_SCAN")) : 6;
+        const int scan_v = scan_version();
         ProfScope ps(b, 2, scan_bytes);
-        if (scan_version == 6) {                          // bit-diagonal scan: one wave = 64 anti-diagonals
+        if (scan_v == 6) {                          // bit-diagonal scan: one wave = 64 anti-diagonals
             hipLaunchKernelGGL(sq_scan6_kernel, dim3(S, (2 * maxn - 5 + 63) / 64 + 1), dim3(64), 4 * (size_t)b->state.fbstride, st,
                                b->ctx, b->d_structs, b->state, b->scan);
         } else {
-            const int seg = scan_version == 4 ? sq_scan_seg() : sq_scan5_seg();
+            const int seg = scan_v == 4 ? sq_scan_seg() : sq_scan5_seg();
             const int nseg = ((maxn >> 1) + 130 + seg - 1) / seg;
-            if (scan_version == 4)
+            if (scan_v == 4)
                 hipLaunchKernelGGL(sq_scan_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, b->d_structs, b->state, b->scan);
             else
                 hipLaunchKernelGGL(sq_scan5_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, b->d_structs, b->state, b->scan);
@@ -649,7 +677,7 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
 
 int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out)
 {
-    if (!b->filled) { int r = sq_bpmatrix_fill(b); if (r) return r; }
+    { int r = sq_prepare_scan(b); if (r) return r; }
     out.resize(structs.size());
     size_t lo = 0;
     while (lo < structs.size()) {
@@ -721,7 +749,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     if (!b || !opts) { sq_set_error("bad argument"); return -1; }
     const sq_fold_opts &o = *opts;
     if (o.poollim < 1) { sq_set_error("poollim must be positive"); return -1; }
-    int r = sq_bpmatrix_fill(b);                            // a-1, once per job (:1076)
+    // a-1, once per job and per fold (:1076): never reused from an earlier call, a fold is the whole path
+    int r = scan_version() == 6 ? fill_impl(b, 0) : fill_impl(b, 1);
     if (r) return r;
     std::vector<JobPool> pools(b->njobs);
     std::vector<uint32_t> algos(b->njobs);

@@ -60,10 +60,11 @@ __device__ __forceinline__ double sq_cell_exact(const SqDevCtx &c, const SqJob &
 // ------------------------------------------------------------------------------------
 // a-1  fill: one thread = 4 consecutive floats of the padded N x ld matrix (16-byte stores)
 // ------------------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c)
+extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c, int only_ext, int mul_done)
 {
     const SqJob jb = c.jobs[blockIdx.y];
     if (jb.has_ext == 1) return;                       // imported from caller matrices instead
+    if (only_ext && jb.has_ext == 0) return;           // the fold path of such jobs only needs the bit matrix
     const SqPsetDev *ps = c.psets + jb.pset;
     const int n = jb.n, ld = jb.ld;
     const int64_t total4 = ((int64_t)n * ld + 3) >> 2;
@@ -80,8 +81,8 @@ extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c)
             if (i < n && j < n && j > i && sq_cell_bool(c, jb, ps, i, j)) {
                 double v = sq_cell_score(c, jb, ps, i, j);
                 if (m64) {                              // :1084-1085 bpscorematrix * shortsmat
-                    v = v * m64[(int64_t)i * n + j];
-                    m64[(int64_t)i * n + j] = v;
+                    if (mul_done) v = m64[(int64_t)i * n + j];          // the arena already holds the product
+                    else { v = v * m64[(int64_t)i * n + j]; m64[(int64_t)i * n + j] = v; }
                 }
                 bits = __float_as_uint((float)v);
                 if (bits == SQ_SENT_BITS) bits = 0x7FC00001u;   // a genuine NaN value stays "present"
@@ -141,9 +142,10 @@ extern "C" __global__ __launch_bounds__(256) void sq_import_kernel(SqDevCtx c)
 // so the 64 lanes of a scan wave -- 64 consecutive diagonals -- read 64 consecutive words.  Built once
 // per job from the filled fp32 matrix (one more pass over N^2/2 cells); every later AnnotateStems
 // evaluation reads 1 bit per cell instead of 4 bytes.
-extern "C" __global__ __launch_bounds__(256) void sq_bits_kernel(SqDevCtx c)
+extern "C" __global__ __launch_bounds__(256) void sq_bits_kernel(SqDevCtx c, int only_ext)
 {
     const SqJob jb = c.jobs[blockIdx.y];
+    if (only_ext && jb.has_ext != 1) return;
     const int n = jb.n, ld = jb.ld, bp = jb.bpitch;
     const float *mat = c.mat32 + jb.mat_off;
     uint32_t *bits = c.bits + jb.bits_off;
@@ -159,6 +161,68 @@ extern "C" __global__ __launch_bounds__(256) void sq_bits_kernel(SqDevCtx c)
             }
         }
         bits[q] = word;
+    }
+}
+
+// The same bit matrix straight from the O(N) inputs (bpboolmatrix never depends on scores, :286-304):
+// the fold path needs no fp32 matrix at all -- candidates are re-scored exactly from the inputs -- so
+// sq_fold builds only this (N^2/16 bytes written per job instead of 4 N^2).  One block = one word-row w
+// (rows 32w..32w+31) x 256 diagonals; row attributes are LDS broadcasts, column attributes consecutive bytes.
+extern "C" __global__ __launch_bounds__(256) void sq_bits_direct_kernel(SqDevCtx c)
+{
+    __shared__ uint32_t s_row[32], s_col[256 + 32];     // code | flags << 8 | inc4 << 16 | valid << 31
+    __shared__ int16_t s_rch[32], s_cch[256 + 32];
+    __shared__ uint8_t s_in[32 * 32];
+    const SqJob jb = c.jobs[blockIdx.y];
+    if (jb.has_ext == 1) return;                        // bool comes from the caller's matrix (sq_bits_kernel)
+    const int n = jb.n, bp = jb.bpitch;
+    const int tiles = bp >> 8;                          // bpitch is a multiple of 64; the tail tile is handled by the bound check
+    const int ntile = (bp + 255) >> 8;
+    const SqPsetDev *ps = c.psets + jb.pset;
+    uint32_t *bits = c.bits + jb.bits_off;
+    const int tid = threadIdx.x;
+    (void)tiles;
+    for (int t = tid; t < 32 * 32; t += 256) s_in[t] = ps->inbps[t];
+    for (int blk = blockIdx.x; blk < jb.nw * ntile; blk += gridDim.x) {
+        const int w = blk / ntile, s0 = (blk - w * ntile) << 8;
+        const int s = s0 + tid;
+        const int i0 = 32 * w;
+        // the tile has cells only if some i in [i0, i0+31], j = s - i with i < j < n exists
+        const bool live = s0 + 255 >= 2 * i0 + 1 && s0 <= i0 + 31 + n - 1 && s0 <= 2 * n - 6 && s0 + 255 >= 4;
+        __syncthreads();
+        if (live) {
+            const int jbase = s0 - i0 - 31;              // column of (b = 31, tid = 0)
+            for (int t = tid; t < 32 + 256 + 32; t += 256) {
+                const bool isrow = t < 32;
+                const int p = isrow ? i0 + t : jbase + (t - 32);
+                uint32_t v = 0; int16_t ch = 0;
+                if (p >= 0 && p < n) {
+                    v = (uint32_t)c.codes[jb.pos_off + p] | ((uint32_t)c.flags[jb.pos_off + p] << 8) |
+                        ((uint32_t)c.inc4[jb.pos_off + p] << 16) | 0x80000000u;
+                    ch = c.chain[jb.pos_off + p];
+                }
+                if (isrow) { s_row[t] = v; s_rch[t] = ch; } else { s_col[t - 32] = v; s_cch[t - 32] = ch; }
+            }
+        }
+        __syncthreads();
+        if (s >= bp) continue;
+        uint32_t word = 0;
+        if (live && s >= 4 && s <= 2 * n - 6) {
+#pragma unroll 8
+            for (int b = 0; b < 32; b++) {
+                const uint32_t ri = s_row[b];
+                const int cj = tid + 31 - b;               // column s - (i0 + b) relative to jbase
+                const uint32_t rj = s_col[cj];
+                const int i = i0 + b, j = s - i;
+                bool ok = (ri & rj & 0x80000000u) != 0u && j >= i + (int)((ri >> 16) & 0xFFu);     // :294-299
+                ok = ok && s_in[(ri & 0xFFu) * 32 + (rj & 0xFFu)];                                  // :300
+                const uint32_t fi = (ri >> 8) & 0xFFu, fj = (rj >> 8) & 0xFFu;
+                ok = ok && !((fi | fj) & 1u) && !(fj & 2u) && !(fi & 4u);                            // :302-304
+                if (jb.interchainonly) ok = ok && s_rch[b] != s_cch[cj];                             // :301
+                if (ok) word |= 1u << b;
+            }
+        }
+        bits[(int64_t)w * bp + s] = word;
     }
 }
 
