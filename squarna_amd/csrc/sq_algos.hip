@@ -343,8 +343,13 @@ int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<J
     // collect staged work first, release the reservation, then run what was not staged
     for (auto &it : pa->items) {
         JobSets js; js.algo = it.algo; js.jobs = it.jobs; js.sets.assign(it.jobs.size(), {});
-        if (it.staged && !r) r = algo_collect(b, it.jobs, it.stems, it.ck, levellimit_opt, js.sets);
         sets.push_back(std::move(js));
+    }
+    // last staged first: the short kernels (N, H) are done long before Edmonds, so their host filters run
+    // while the blossom kernel is still busy
+    for (size_t q = pa->items.size(); q-- > 0;) {
+        auto &it = pa->items[q];
+        if (it.staged && !r) r = algo_collect(b, it.jobs, it.stems, it.ck, levellimit_opt, sets[q].sets);
     }
     for (int k = 0; k < 3; k++) if (b->side[k]) hipStreamSynchronize(b->side[k]);
     b->cand_reserved = 0;

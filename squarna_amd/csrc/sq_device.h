@@ -28,6 +28,22 @@ struct SqState {             // per-structure-slot arrays, `stride` elements per
 };
 #define SQ_GPAD 128          // bit offset of the reversed free-position array (window starts never go negative)
 
+// Round I/O without copies or stream waits: the round's structures and strands are read by the state
+// kernel straight from pinned host memory (and mirrored into device memory for the later kernels), the
+// selected stems are written straight into pinned host memory, and a one-thread kernel at the end of the
+// round publishes the counters and a sequence number the host spins on.
+struct SqRoundIO {
+    const SqStruct *h_structs;   // pinned, host-written
+    const SqStrand *h_strands;
+    SqStruct *d_structs;         // device mirrors
+    SqStrand *d_strands;
+    SqOut *h_out;                // pinned: records [0, h_cap)
+    SqOut *d_out;                // device: records [h_cap, out_cap)
+    uint32_t h_cap, out_cap;
+    SqCounters *h_ctr;           // pinned
+    volatile uint32_t *h_seq;    // pinned: id of the last finished round
+};
+
 struct SqScanArgs {
     SqCand *cands;
     uint32_t *cand_cnt;      // per slot
@@ -44,12 +60,13 @@ __global__ void sq_fill_kernel(SqDevCtx c, int only_ext, int mul_done);
 __global__ void sq_bits_direct_kernel(SqDevCtx c);
 __global__ void sq_dense64_kernel(SqDevCtx c, int job, double *boolmat, double *scoremat);
 __global__ void sq_import_kernel(SqDevCtx c);
-__global__ void sq_state_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState st);
+__global__ void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a);
+__global__ void sq_done_kernel(SqRoundIO io, SqScanArgs a, uint32_t seq);
 __global__ void sq_scan_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
 __global__ void sq_scan5_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
 __global__ void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
 __global__ void sq_bits_kernel(SqDevCtx c, int only_ext);
 __global__ void sq_score_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
-                                SqScanArgs a, SqOut *out, uint32_t out_cap, int mode, int lds_n, int lds_n_reacts);
-__global__ void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqOut *out, uint32_t out_cap);
+                                SqScanArgs a, SqRoundIO io, int mode, int lds_n, int lds_n_reacts);
+__global__ void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqRoundIO io);
 }

@@ -87,6 +87,8 @@ struct sq_batch {
     SqStruct *h_structs = nullptr;
     SqStrand *h_strands = nullptr;
     SqCounters *h_ctr = nullptr;
+    uint32_t *h_seq = nullptr;            // pinned: id of the last finished round (written by sq_done_kernel)
+    uint32_t round_seq = 0;
     SqOut *h_out = nullptr;
     uint32_t h_out_cap = 0;
     std::vector<SqOut> big_out;

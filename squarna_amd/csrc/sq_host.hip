@@ -296,11 +296,13 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     }
 #undef UP
     // pinned staging
-    if (sq_check(hipHostMalloc((void **)&b->h_structs, sizeof(SqStruct) * L.max_structs), "hipHostMalloc") ||
-        sq_check(hipHostMalloc((void **)&b->h_strands, sizeof(SqStrand) * (size_t)L.strand_cap), "hipHostMalloc") ||
-        sq_check(hipHostMalloc((void **)&b->h_ctr, sizeof(SqCounters)), "hipHostMalloc")) { delete b; return 2; }
-    b->h_out_cap = 1u << 16;
-    if (sq_check(hipHostMalloc((void **)&b->h_out, sizeof(SqOut) * (size_t)b->h_out_cap), "hipHostMalloc")) { delete b; return 2; }
+    if (sq_check(hipHostMalloc((void **)&b->h_structs, sizeof(SqStruct) * L.max_structs, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc") ||
+        sq_check(hipHostMalloc((void **)&b->h_strands, sizeof(SqStrand) * (size_t)L.strand_cap, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc") ||
+        sq_check(hipHostMalloc((void **)&b->h_ctr, sizeof(SqCounters), hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc") ||
+        sq_check(hipHostMalloc((void **)&b->h_seq, 64, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc")) { delete b; return 2; }
+    *b->h_seq = 0; b->round_seq = 0;
+    b->h_out_cap = (uint32_t)std::min<uint64_t>(1u << 18, L.out_cap);
+    if (sq_check(hipHostMalloc((void **)&b->h_out, sizeof(SqOut) * (size_t)b->h_out_cap, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc")) { delete b; return 2; }
     int rr = sq_check(hipStreamSynchronize(st), "sync after upload");   // host vectors above go out of scope
     if (rr) { delete b; return rr; }
     b->results.resize(d->nseq);
@@ -315,6 +317,7 @@ extern "C" void sq_batch_destroy(sq_batch *b)
     if (b->h_structs) hipHostFree(b->h_structs);
     if (b->h_strands) hipHostFree(b->h_strands);
     if (b->h_ctr) hipHostFree(b->h_ctr);
+    if (b->h_seq) hipHostFree(b->h_seq);
     if (b->h_out) hipHostFree(b->h_out);
     for (int k = 0; k < 3; k++) if (b->side[k]) { hipStreamSynchronize(b->side[k]); hipStreamDestroy(b->side[k]); }
     for (auto &p : b->prof) {
@@ -575,13 +578,13 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
     }
     hipStream_t st = b->stream;
     g_t[0] += now_s() - tp0; tp0 = now_s();
-    HIPCK(hipMemcpyAsync(b->d_structs, b->h_structs, sizeof(SqStruct) * S, hipMemcpyHostToDevice, st));
-    if (nstrand) HIPCK(hipMemcpyAsync(b->d_strands, b->h_strands, sizeof(SqStrand) * nstrand, hipMemcpyHostToDevice, st));
-    HIPCK(hipMemsetAsync(b->scan.cand_cnt, 0, 12 * align_up((size_t)b->max_structs, 2), st));   // counts + best images
-    HIPCK(hipMemsetAsync(b->scan.ctr, 0, sizeof(SqCounters), st));
+    SqRoundIO io;
+    io.h_structs = b->h_structs; io.h_strands = b->h_strands; io.d_structs = b->d_structs; io.d_strands = b->d_strands;
+    io.h_out = b->h_out; io.d_out = b->d_out; io.h_cap = b->h_out_cap; io.out_cap = b->out_cap;
+    io.h_ctr = b->h_ctr; io.h_seq = b->h_seq;
     {
         ProfScope ps(b, 1, 0);
-        hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(256), 0, st, b->ctx, b->d_structs, b->d_strands, b->state);
+        hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(256), 0, st, b->ctx, io, b->state, b->scan);
     }
     if (maxn >= 5) {
         const int nband = (2 * maxn - 5 + 255) >> 8;
@@ -612,29 +615,44 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
         if (score_parts) parts = score_parts;
         const int thr = score_threads ? score_threads : (parts == 1 && S < 2048 ? 512 : 256);
         hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, b->d_structs, b->d_strands, b->state,
-                           b->scan, b->d_out, b->out_cap, mode, lds_n, lds_nr);
+                           b->scan, io, mode, lds_n, lds_nr);
         if (mode == 0)
-            hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, b->d_structs, b->scan,
-                               b->d_out, b->out_cap);
+            hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, b->d_structs, b->scan, io);
     }
+    const uint32_t seq = ++b->round_seq;
+    hipLaunchKernelGGL(sq_done_kernel, dim3(1), dim3(1), 0, st, io, b->scan, seq);
     HIPCK(hipGetLastError());
-    HIPCK(hipMemcpyAsync(b->h_ctr, b->scan.ctr, sizeof(SqCounters), hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
+    // wait for the round: spin on the sequence number in pinned memory (no driver round trip); a stuck or
+    // faulted queue is caught by polling the stream now and then
+    {
+        volatile uint32_t *flag = b->h_seq;
+        uint64_t spins = 0;
+        while (*flag != seq) {
+            if ((++spins & 0xFFFFF) == 0) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q != hipErrorNotReady) {
+                    if (q != hipSuccess) return sq_check(q, "round kernels");
+                    if (*flag != seq) { HIPCK(hipStreamSynchronize(st)); if (*flag != seq) { sq_set_error("round did not signal completion"); return 2; } }
+                }
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     const SqCounters ctr = *b->h_ctr;
     if (ctr.cand_ovf) { sq_set_error("candidate capacity exceeded (raise cand_per_nt)"); return -3; }
     if (ctr.out_ovf) { sq_set_error("round output capacity exceeded (lower max_structs)"); return -3; }
     if (ctr.level_ovf) { sq_set_error("more than 64 pseudoknot levels"); return -3; }
     const uint32_t nout = ctr.nout;
     const SqOut *ho = b->h_out;
-    if (nout) {
-        if (nout <= b->h_out_cap) {
-            HIPCK(hipMemcpyAsync(b->h_out, b->d_out, sizeof(SqOut) * (size_t)nout, hipMemcpyDeviceToHost, st));
-            HIPCK(hipStreamSynchronize(st));
-        } else {
-            b->big_out.resize(nout);
-            HIPCK(hipMemcpy(b->big_out.data(), b->d_out, sizeof(SqOut) * (size_t)nout, hipMemcpyDeviceToHost));
-            ho = b->big_out.data();
-        }
+    if (nout > b->h_out_cap) {                               // rare: the tail of a huge round sits in device memory
+        b->big_out.resize(nout);
+        memcpy(b->big_out.data(), b->h_out, sizeof(SqOut) * (size_t)b->h_out_cap);
+        HIPCK(hipMemcpy(b->big_out.data() + b->h_out_cap, b->d_out + b->h_out_cap,
+                        sizeof(SqOut) * (size_t)(nout - b->h_out_cap), hipMemcpyDeviceToHost));
+        ho = b->big_out.data();
     }
     g_t[1] += now_s() - tp0;
     TScope tpost(2);

@@ -229,10 +229,32 @@ extern "C" __global__ __launch_bounds__(256) void sq_bits_direct_kernel(SqDevCtx
 // ------------------------------------------------------------------------------------
 // per-structure state: partner P, mask code E, prefix counts U (unpaired), SU (unpaired separators)
 // ------------------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, const SqStruct *structs,
-                                                                  const SqStrand *strands, SqState st)
+__device__ __forceinline__ void sq_put_out(const SqRoundIO &io, SqScanArgs &a, const SqOut &r)
 {
-    const SqStruct s = structs[blockIdx.x];
+    const uint32_t o = atomicAdd(&a.ctr->nout, 1u);
+    if (o < io.h_cap) io.h_out[o] = r;                   // straight into pinned host memory
+    else if (o < io.out_cap) io.d_out[o] = r;
+    else a.ctr->out_ovf = 1;
+}
+
+extern "C" __global__ void sq_done_kernel(SqRoundIO io, SqScanArgs a, uint32_t seq)
+{
+    *io.h_ctr = *a.ctr;
+    __threadfence_system();
+    *io.h_seq = seq;
+}
+
+extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a)
+{
+    const SqStruct s = io.h_structs[blockIdx.x];          // pinned host memory: one read per structure per round
+    if (threadIdx.x == 0) {
+        io.d_structs[blockIdx.x] = s;
+        a.cand_cnt[s.slot] = 0; a.best[s.slot] = 0ull;
+        if (blockIdx.x == 0) { a.ctr->nout = 0; a.ctr->cand_ovf = 0; a.ctr->out_ovf = 0; a.ctr->level_ovf = 0; }
+    }
+    for (int k = threadIdx.x; k < s.nstrand; k += 256) io.d_strands[s.strand_off + k] = io.h_strands[s.strand_off + k];
+    __syncthreads();
+    const SqStrand *strands = io.d_strands;
     const SqJob jb = c.jobs[s.job];
     const int n = jb.n;
     int16_t *P = st.P + (int64_t)s.slot * st.stride;
@@ -1070,8 +1092,7 @@ __device__ __forceinline__ double sq_unord(unsigned long long o)
 // finalscore of the structure is combined with atomicMax, the range filter (:769-778) runs in sq_select_kernel.
 extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, const SqStruct *structs,
                                                                   const SqStrand *strands, SqState stt, SqScanArgs a,
-                                                                  SqOut *out, uint32_t out_cap, int mode, int lds_n,
-                                                                  int lds_n_reacts)
+                                                                  SqRoundIO io, int mode, int lds_n, int lds_n_reacts)
 {
     __shared__ SqStrand s_str[SQ_LDS_STRANDS];
     __shared__ double s_w[32 * 32];               // pair weights of the job's paramset
@@ -1204,9 +1225,8 @@ extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, c
         if (ok) {                                                        // flags were zeroed by the scan: nothing to write otherwise
             cands[q].bps = bps; cands[q].fin = fin; cands[q].flags = 1u;
             if (mode == 1) {
-                const uint32_t o = atomicAdd(&a.ctr->nout, 1u);
-                if (o < out_cap) { SqOut r = {(int32_t)blockIdx.x, cd.key, L, 0, bps, 0.0}; out[o] = r; }
-                else a.ctr->out_ovf = 1;
+                const SqOut r = {(int32_t)blockIdx.x, cd.key, L, 0, bps, 0.0};
+                sq_put_out(io, a, r);
             } else if (!any || fin > best) {
                 any = 1; best = fin;                                     // :769 only the best VALUE matters for the range
             }
@@ -1225,7 +1245,7 @@ extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, c
 
 // ChooseStems range filter (:769-778): candidates within subopt * best of the structure's best finalscore
 extern "C" __global__ __launch_bounds__(256) void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a,
-                                                                 SqOut *out, uint32_t out_cap)
+                                                                 SqRoundIO io)
 {
     const SqStruct st = structs[blockIdx.x];
     const unsigned long long ob = a.best[st.slot];
@@ -1239,9 +1259,8 @@ extern "C" __global__ __launch_bounds__(256) void sq_select_kernel(SqDevCtx c, c
         if (!cands[q].flags) continue;
         const SqCand cd = cands[q];
         if (!(cd.fin < range)) {                                        // :778
-            const uint32_t o = atomicAdd(&a.ctr->nout, 1u);
-            if (o < out_cap) { SqOut r = {(int32_t)blockIdx.x, cd.key, (int32_t)cd.len, 0, cd.bps, cd.fin}; out[o] = r; }
-            else a.ctr->out_ovf = 1;
+            const SqOut r = {(int32_t)blockIdx.x, cd.key, (int32_t)cd.len, 0, cd.bps, cd.fin};
+            sq_put_out(io, a, r);
         }
     }
 }
