@@ -2,6 +2,7 @@
 // one AnnotateStems pass on the GPU (scan + exact rescoring), the matching / DP on the GPU
 // (sq_match.hip), then the reference's stem filters on the host.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -212,14 +213,16 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
     HIPCK(hipStreamSynchronize(ck.st));
     const double tw1 = sq_now();
     struct Rep { int algo; double t0, t1; ~Rep() { if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] algo %d: wait %.3f ms, host filters %.3f ms\n", algo, (t1 - t0) * 1e3, (sq_now() - t1) * 1e3); } } rep{algo, tw0, tw1};
-    for (size_t q = 0; q < mj.size(); q++) {
+    std::atomic<int> bad{0};
+    sq_pool(b)->parallel_for((int)mj.size(), [&](int qi) {
+        const size_t q = (size_t)qi;
         const size_t k = ck.k0 + q;
         const SqJob &J = b->jobs[jobs[k]];
         const int levellimit = levellimit_opt >= 0 ? levellimit_opt : 3 - (J.n > 500 ? 1 : 0);   // :1043-1044
         std::vector<BP> pairs;
         if (algo == SQ_ALGO_E) {
             const int32_t *mate = h_out.data() + mj[q].out_off;
-            if (mj[q].n > 0 && mate[0] == -2) { sq_set_error("blossom capacity exceeded"); return -3; }
+            if (mj[q].n > 0 && mate[0] == -2) { bad = 1; return; }
             for (int v = 0; v < mj[q].n; v++)
                 if (mate[v] > v) pairs.push_back(BP(ck.vid2pos[q][v], ck.vid2pos[q][mate[v]]));
         } else if (algo == SQ_ALGO_N) {
@@ -246,7 +249,8 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
             }
         }
         filter_stemset(b, J, pairs, levellimit, out[k]);
-    }
+    });
+    if (bad) { sq_set_error("blossom capacity exceeded"); return -3; }
     return 0;
 }
 

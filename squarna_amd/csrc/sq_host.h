@@ -4,6 +4,11 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <functional>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
 #include "../../include/squarna_hip.h"
 #include "sq_device.h"
 #include "sq_internal.h"
@@ -54,6 +59,28 @@ struct ProfSlot {
     std::vector<hipEvent_t> pool;
 };
 
+// Small persistent worker pool (per batch): host phases that are independent per sequence / per job
+// (the a-10 tail, the RunAlgo stem filters) are shared among a few threads that stay alive between
+// folds, so their allocator arenas stay warm.  parallel_for hands out indices dynamically; the caller
+// takes part.  Results never depend on the schedule (every index writes its own slot).
+class SqPool {
+public:
+    explicit SqPool(int nthreads);
+    ~SqPool();
+    void parallel_for(int n, const std::function<void(int)> &fn);
+    int size() const { return (int)workers.size() + 1; }
+private:
+    void worker();
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_start, cv_done;
+    const std::function<void(int)> *fn = nullptr;
+    std::atomic<int> next{0};
+    int total = 0, active = 0;
+    uint64_t gen = 0;
+    bool stop = false;
+};
+
 struct sq_batch {
     hipStream_t stream = nullptr;
     // host copies
@@ -94,6 +121,7 @@ struct sq_batch {
     std::vector<SqOut> big_out;
     // results
     std::vector<SeqResult> results;
+    SqPool *pool = nullptr;               // lazily created host workers
     // profiling
     bool prof_on = false;
     ProfSlot prof[4];
@@ -101,6 +129,7 @@ struct sq_batch {
 
 void sq_set_error(const std::string &msg);
 int sq_check(hipError_t e, const char *what);
+SqPool *sq_pool(sq_batch *b);             // the batch's worker pool (SQ_HOST_THREADS, default min(16, cores))
 
 // bit matrices for the scan (full fp32 fill only for jobs with caller matrices / legacy scans)
 int sq_prepare_scan(sq_batch *b);
@@ -120,7 +149,7 @@ int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<J
 
 // host tail: SQRNdbnseq.py:1201-1286
 void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
-             const std::vector<std::vector<std::vector<HStem>>> &per_job_structs,   // [job-of-seq][structure][stem]
+             const std::vector<const std::vector<std::vector<HStem>> *> &per_job_structs,   // [job-of-seq] -> [structure][stem]
              const std::vector<int32_t> &job_ids, const int32_t *ref_pairs, int nref, bool has_ref,
              SeqResult &res);
 

@@ -27,6 +27,56 @@ int sq_check(hipError_t e, const char *what)
 }
 #define HIPCK(x) do { int _r = sq_check((x), #x); if (_r) return _r; } while (0)
 
+// ---- host worker pool -------------------------------------------------------------------------
+SqPool::SqPool(int nthreads)
+{
+    for (int t = 1; t < nthreads; t++) workers.emplace_back([this] { worker(); });
+}
+SqPool::~SqPool()
+{
+    { std::lock_guard<std::mutex> lk(mu); stop = true; gen++; }
+    cv_start.notify_all();
+    for (auto &t : workers) t.join();
+}
+void SqPool::worker()
+{
+    uint64_t seen = 0;
+    for (;;) {
+        const std::function<void(int)> *f;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_start.wait(lk, [&] { return gen != seen; });
+            seen = gen;
+            if (stop) return;
+            f = fn;
+        }
+        for (int i; (i = next.fetch_add(1)) < total;) (*f)(i);
+        { std::lock_guard<std::mutex> lk(mu); if (--active == 0) cv_done.notify_one(); }
+    }
+}
+void SqPool::parallel_for(int n, const std::function<void(int)> &f)
+{
+    if (n <= 0) return;
+    if (workers.empty() || n == 1) { for (int i = 0; i < n; i++) f(i); return; }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        fn = &f; total = n; next.store(0); active = (int)workers.size(); gen++;
+    }
+    cv_start.notify_all();
+    for (int i; (i = next.fetch_add(1)) < n;) f(i);
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return active == 0; });
+}
+SqPool *sq_pool(sq_batch *b)
+{
+    if (!b->pool) {
+        int nthr = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+        if (const char *e = getenv("SQ_HOST_THREADS")) nthr = std::max(1, atoi(e));
+        b->pool = new SqPool(nthr);
+    }
+    return b->pool;
+}
+
 extern "C" int sq_version(void) { return 100; }
 extern "C" const char *sq_last_error(void) { return g_err.c_str(); }
 
@@ -318,6 +368,7 @@ extern "C" void sq_batch_destroy(sq_batch *b)
     if (b->h_strands) hipHostFree(b->h_strands);
     if (b->h_ctr) hipHostFree(b->h_ctr);
     if (b->h_seq) hipHostFree(b->h_seq);
+    delete b->pool;
     if (b->h_out) hipHostFree(b->h_out);
     for (int k = 0; k < 3; k++) if (b->side[k]) { hipStreamSynchronize(b->side[k]); hipStreamDestroy(b->side[k]); }
     for (auto &p : b->prof) {
@@ -865,10 +916,14 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // a-10 tail per sequence
     std::vector<std::vector<int32_t>> seq_jobs(b->nseq);
     for (int j = 0; j < b->njobs; j++) seq_jobs[b->job_seq[j]].push_back(j);
+    std::vector<double> tail_cost(b->nseq, 0.0);
+    const bool timing = getenv("SQ_TIMING") != nullptr;
     auto tail_one = [&](int s) {
-        std::vector<std::vector<std::vector<HStem>>> per_job;
+        const double tt0 = timing ? now_s() : 0;
+        struct TT { bool on; double t0; double &dst; ~TT() { if (on) dst = now_s() - t0; } } tt{timing, tt0, tail_cost[s]};
+        std::vector<const std::vector<std::vector<HStem>> *> per_job;   // (freed later by the thread that allocated them)
         int64_t ev = 0;
-        for (int j : seq_jobs[s]) { per_job.push_back(std::move(pools[j].fin)); ev += pools[j].evals; }
+        for (int j : seq_jobs[s]) { per_job.push_back(&pools[j].fin); ev += pools[j].evals; }
         const bool hr = has_ref && has_ref[s];
         const int32_t *rp = hr ? ref_pairs + 2 * (size_t)ref_off[s] : nullptr;
         const int nref = hr ? ref_off[s + 1] - ref_off[s] : 0;
@@ -876,20 +931,25 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         sq_tail(b, s, o, per_job, seq_jobs[s], rp, nref, hr, b->results[s]);
         b->results[s].evals = ev;
     };
-    // sequences are independent: a few host threads share the tail (bounded, deterministic output)
-    int nthr = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-    if (const char *e = getenv("SQ_HOST_THREADS")) nthr = std::max(1, atoi(e));
-    nthr = std::min(nthr, std::max(1, b->nseq / 16));
-    if (nthr <= 1) {
-        for (int s = 0; s < b->nseq; s++) tail_one(s);
-    } else {
-        std::atomic<int> next{0};
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthr; t++)
-            th.emplace_back([&]() { for (int s; (s = next.fetch_add(1)) < b->nseq;) tail_one(s); });
-        for (auto &t : th) t.join();
+    // sequences are independent: the batch's worker pool shares the tail, longest first (deterministic output)
+    {
+        std::vector<int> order(b->nseq);
+        std::vector<int64_t> cost(b->nseq, 0);
+        for (int s = 0; s < b->nseq; s++) {
+            order[s] = s;
+            for (int j : seq_jobs[s]) cost[s] += (int64_t)pools[j].fin.size() * (b->seq_off[s + 1] - b->seq_off[s]);
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost[x] > cost[y]; });
+        sq_pool(b)->parallel_for(b->nseq, [&](int k) { tail_one(order[k]); });
     }
-    if (getenv("SQ_TIMING"))
+    if (timing) {
+        double mx = 0, sum = 0; int arg = 0;
+        for (int q = 0; q < b->nseq; q++) { sum += tail_cost[q]; if (tail_cost[q] > mx) { mx = tail_cost[q]; arg = q; } }
+        size_t nst = 0; for (int j : seq_jobs[arg]) nst += 0;
+        fprintf(stderr, "[sq_fold] tail: sum %.3f ms, max %.3f ms (seq %d, n=%d, %zu structures kept)\n", sum * 1e3, mx * 1e3, arg,
+                b->seq_off[arg + 1] - b->seq_off[arg], b->results[arg].preds.size());
+    }
+    if (timing)
         fprintf(stderr, "[sq_fold] rounds=%d loop=%.3fms (round driver %.3f: prep %.3f gpu+wait %.3f post %.3f; pool %.3f) tail=%.3fms\n",
                 nrounds, tloop * 1e3, tround * 1e3, g_t[0] * 1e3, g_t[1] * 1e3, g_t[2] * 1e3, (tloop - tround) * 1e3,
                 (now_s() - ttail0) * 1e3);

@@ -175,7 +175,7 @@ static void prf(const BPV &pred, const BPV &known, double m[6])       // :1252-1
 }
 
 void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
-             const std::vector<std::vector<std::vector<HStem>>> &per_job, const std::vector<int32_t> &job_ids,
+             const std::vector<const std::vector<std::vector<HStem>> *> &per_job, const std::vector<int32_t> &job_ids,
              const int32_t *ref_pairs, int nref, bool has_ref, SeqResult &res)
 {
     const int off = b->seq_off[seq], n = b->seq_off[seq + 1] - off;
@@ -187,7 +187,7 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
     std::map<BPV, int> seen;
     BPV key;
     for (size_t k = 0; k < per_job.size(); k++) {
-        for (const auto &stems : per_job[k]) {
+        for (const auto &stems : *per_job[k]) {
             bps_of(stems, key);
             auto it = seen.find(key);
             if (it == seen.end()) {
