@@ -299,45 +299,61 @@ struct SqAlgoAsync {
 int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync *&pa)
 {
     pa = new SqAlgoAsync();
-    std::vector<int> all;                                   // one AnnotateStems pass for every E/H/N job
     for (int algo : {SQ_ALGO_E, SQ_ALGO_H, SQ_ALGO_N}) {
         SqAlgoAsync::Item it;
         it.algo = algo;
         for (int j = 0; j < b->njobs; j++) if (algos[j] & (uint32_t)algo) it.jobs.push_back(j);
         if (it.jobs.empty()) continue;
-        all.insert(all.end(), it.jobs.begin(), it.jobs.end());
         pa->items.push_back(std::move(it));
     }
-    if (all.empty()) return 0;
-    std::vector<std::vector<HStem>> stems;
-    const double ta0 = sq_now();
-    int r = algo_annotate(b, all, stems);
-    if (r) return r;
-    if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] annotate %zu jobs %.3f ms\n", all.size(), (sq_now() - ta0) * 1e3);
-    size_t pos = 0;
-    for (auto &it : pa->items) {
-        it.stems.assign(std::make_move_iterator(stems.begin() + pos), std::make_move_iterator(stems.begin() + pos + it.jobs.size()));
-        pos += it.jobs.size();
-    }
-    if (getenv("SQ_ALGO_SYNC")) return 0;
-    // stage what fits into (at most) half of the arena, carved downwards from its end; the rest runs synchronously later
-    const int64_t half = b->cand_records / 2;
+    if (pa->items.empty()) return 0;
+    const bool async = !getenv("SQ_ALGO_SYNC");
+    const int64_t half = b->cand_records / 2;          // at most half of the arena is lent to the matching kernels
     int sidx = 0;
-    for (auto &it : pa->items) {
+    // Edmonds is the long pole: its AnnotateStems pass and launch go first, alone; the other algorithms share
+    // one more pass.  Everything that is staged runs on side streams while the caller proceeds.
+    auto stage = [&](SqAlgoAsync::Item &it) -> int {
+        if (!async || sidx >= 3) return 0;
         const int64_t free_rec = half - b->cand_reserved;
-        if (free_rec <= 0 || sidx >= 3) break;
+        if (free_rec <= 0) return 0;
         algo_build(b, it.jobs, it.stems, 0, it.algo, (size_t)free_rec * sizeof(SqCand), it.ck);
-        if (it.ck.k1 != it.jobs.size()) { it.ck = SqAlgoChunk(); continue; }   // does not fit as one chunk
+        if (it.ck.k1 != it.jobs.size()) { it.ck = SqAlgoChunk(); return 0; }   // does not fit as one chunk: synchronous later
         if (!b->side[sidx]) { if (sq_check(hipStreamCreateWithFlags(&b->side[sidx], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
         const int64_t used_rec = (int64_t)((it.ck.bytes + 256 + sizeof(SqCand) - 1) / sizeof(SqCand));
-        b->cand_reserved += used_rec;
+        b->cand_reserved += used_rec;                   // carved downwards from the end of the arena
         char *region = (char *)(b->scan.cands + (b->cand_records - b->cand_reserved));
         region = (char *)(((uintptr_t)region + 255) & ~(uintptr_t)255);
-        r = algo_launch(b, it.ck, region, b->side[sidx]);
+        const int r = algo_launch(b, it.ck, region, b->side[sidx]);
         if (r) return r;
         it.staged = true;
         sidx++;
+        return 0;
+    };
+    size_t first_rest = 0;
+    const double ta0 = sq_now();
+    if (pa->items[0].algo == SQ_ALGO_E) {
+        int r = algo_annotate(b, pa->items[0].jobs, pa->items[0].stems);
+        if (r) return r;
+        r = stage(pa->items[0]);
+        if (r) return r;
+        first_rest = 1;
     }
+    std::vector<int> all;
+    for (size_t q = first_rest; q < pa->items.size(); q++) all.insert(all.end(), pa->items[q].jobs.begin(), pa->items[q].jobs.end());
+    if (!all.empty()) {
+        std::vector<std::vector<HStem>> stems;
+        int r = algo_annotate(b, all, stems);
+        if (r) return r;
+        size_t pos = 0;
+        for (size_t q = first_rest; q < pa->items.size(); q++) {
+            auto &it = pa->items[q];
+            it.stems.assign(std::make_move_iterator(stems.begin() + pos), std::make_move_iterator(stems.begin() + pos + it.jobs.size()));
+            pos += it.jobs.size();
+            r = stage(it);
+            if (r) return r;
+        }
+    }
+    if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] annotate + stage %.3f ms\n", (sq_now() - ta0) * 1e3);
     return 0;
 }
 
