@@ -5,7 +5,7 @@ metric  : sequences/sec on SRtest150 (219 records, 8-150 nt, if=qf), whole job
           (score-matrix fill + greedy stem loop + ranking tail), inputs resident in HBM
 step    : one fold of the whole workload batch on every GPU (weak scaling: each rank folds
           its own copy of the batch; independent sequences, no data-path collective)
-roofline: the stem-scan kernel (sq_scan_kernel) on synthetic S1000 (random ACGU, N=1000,
+roofline: the stem-scan kernel (sq_scan6_kernel) on synthetic S1000 (random ACGU, N=1000,
           c=fastest pl=1), algorithmic bytes 2*N^2 per AnnotateStems evaluation, timed with
           HIP events on the kernel's own stream inside libsquarna_hip
 cpu_baseline: the CPU oracle (oracle/, a C port of the reference algorithm) on the same
@@ -107,13 +107,18 @@ def roofline_leg(nseq, n, seed=1000):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
-            traffic = json.load(f).get("sq_scan_kernel_bytes_per_launch")
+            traffic = json.load(f).get("sq_scan6_kernel_bytes_per_launch")
     return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                kernel="sq_scan_kernel", workload="S1000: %d random-ACGU seqs N=%d seed %d c=fastest pl=1" % (nseq, n, seed),
+                kernel="sq_scan6_kernel",
+                note="achieved = the reference algorithm's bytes (fp32 upper triangle per AnnotateStems evaluation, SURVEY 8d) / "
+                     "kernel time; the kernel reads a 1-bit-per-cell diagonal bit matrix instead, so frac > 1 = re-reads avoided; "
+                     "traffic = measured HBM bytes per launch (rocprofv3 FETCH_SIZE x2)",
+                workload="S1000: %d random-ACGU seqs N=%d seed %d c=fastest pl=1" % (nseq, n, seed),
                 launches=int(launches), avg_launch_ms=round(ms / max(launches, 1), 4),
                 alg_bytes_per_launch=round(alg_bytes / max(launches, 1)),
                 evals_R=int(evals), whole_fold_seq_per_s=round(nseq / wall, 1), whole_fold_ms=round(wall * 1e3, 2),
+                whole_fold_alg_GBs=round((alg_bytes + 4.0 * nseq * n * n) / wall / 1e9, 1),
                 kernel_ms=dict(fill=round(fms, 3), state=round(sms, 3), scan=round(ms, 3), score=round(cms, 3)),
                 fill=dict(achieved=round(fbytes / (fms * 1e-3) / 1e9, 1) if fms > 0 else 0.0,
                           unit="GB/s", launches=int(flaunches)))
@@ -200,7 +205,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 scan matrix, f64 decisions",
+        "dtype": "f64 (scores and decisions; the scan itself works on 1-bit cell activity)",
         "data": "SRtest150.fas shipped with the reference (219 records, 8-150 nt, reference dbn per record)",
         "config": {"workload": "SRtest150 if=qf c=%s poollim=1000, one batch of 219 records per GPU" % args.config,
                    "seqs_per_gpu_per_step": len(prepared), "paramsets": names,

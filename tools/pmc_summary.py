@@ -2,7 +2,7 @@
 """Summarise rocprofv3 --pmc CSVs written by tools/pmc_scan.sh (per kernel, first and total)."""
 import csv, glob, sys, collections
 out = sys.argv[1]
-kern = sys.argv[2] if len(sys.argv) > 2 else "sq_scan_kernel"
+kern = sys.argv[2] if len(sys.argv) > 2 else "sq_scan6_kernel"
 for f in sorted(glob.glob(out + "/p*/*/*counter_collection.csv")):
     rows = list(csv.DictReader(open(f)))
     by = collections.OrderedDict()
