@@ -84,8 +84,12 @@ typedef struct sq_batch_desc {
     int32_t interchainonly;     /* SQRNdbnseq.py:264-271,301 */
     int32_t max_structs;        /* structures evaluated per round chunk (0 = default 4096)      */
     int32_t cand_per_nt;        /* candidate capacity per structure = cand_per_nt * N (0 = 32)  */
-    int32_t reserved;
+    int32_t batch_flags;        /* SQ_BATCH_* */
 } sq_batch_desc;
+
+/* No fp32 score matrices in the workspace (4 N^2 bytes per job saved): everything except
+ * sq_bpmatrix_fill works, the fold path only needs the 1-bit-per-cell diagonal matrices. */
+#define SQ_BATCH_NO_FP32 1
 
 typedef struct sq_batch sq_batch;   /* opaque */
 
@@ -181,6 +185,22 @@ SQ_API int64_t sq_result_pack_size(const sq_batch *b, int32_t seq);
 SQ_API int sq_result_pack(const sq_batch *b, int32_t seq, void *buf, int64_t cap);
 /* R = number of AnnotateStems evaluations the reference algorithm performs for this sequence. */
 SQ_API int64_t sq_result_evals(const sq_batch *b, int32_t seq);
+
+/* ---- alignment step 1 (SQRNdbnali.py:60-108, 211-242) ------------------------------------
+ * For each listed job, in order: AnnotateStems with no selected stems, then
+ *   matrix[cols[v], cols[w]] += stem score;  matrix[cols[w], cols[v]] += stem score
+ * for every base pair (v, w) of every stem -- the parent-side loop of SQRNdbnali (:233-237).
+ * cols[col_off[k] + p] is the alignment column of position p of job_ids[k] (ReAlignDict, :20-37).
+ * d_matrix: caller-owned DEVICE memory, L x L fp64 row-major, accumulated into (zero it first).
+ * A cell receives at most one addition per sequence and sequences are applied in list order, so
+ * every cell sees the reference's fp64 summation order.  Asynchronous tail on the batch stream. */
+SQ_API int sq_align_accumulate(sq_batch *b, int32_t njob, const int32_t *job_ids, const int32_t *col_off,
+                               const int32_t *cols, int32_t L, double *d_matrix);
+/* Cells (v, w) of a device L x L fp64 matrix with w - v >= minspan and value >= threshold
+ * (MatrixToDBNs' candidates, SQRNdbnali.py:127-148): flat indices v*L+w and values to HOST arrays,
+ * unordered; *count = number found (may exceed cap: then only cap were stored).  Synchronises. */
+SQ_API int sq_colmatrix_select(const double *d_matrix, int32_t L, double threshold, int32_t minspan,
+                               int64_t *idx_out, double *val_out, int64_t cap, int64_t *count, void *hip_stream);
 
 /* ---- measurement ------------------------------------------------------------
  * Kernel ids: 0 fill, 1 state, 2 stem_scan, 3 stem_score.  When enabled, every

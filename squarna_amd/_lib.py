@@ -18,7 +18,10 @@ SYMBOLS = ["sq_version", "sq_last_error", "sq_batch_workspace_bytes", "sq_batch_
            "sq_batch_destroy", "sq_bpmatrix_fill", "sq_bpmatrix_read", "sq_optimal_stems",
            "sq_fold", "sq_result_nstruct", "sq_result_consensus", "sq_result_struct",
            "sq_result_metrics", "sq_result_evals", "sq_result_pack_size", "sq_result_pack",
-           "sq_profile_enable", "sq_profile_get", "sq_profile_reset", "sq_run_algos"]
+           "sq_profile_enable", "sq_profile_get", "sq_profile_reset", "sq_run_algos",
+           "sq_align_accumulate", "sq_colmatrix_select"]
+
+BATCH_NO_FP32 = 1
 
 
 class ParamSet(C.Structure):
@@ -51,7 +54,7 @@ class BatchDesc(C.Structure):
                 ("interchainonly", C.c_int32),
                 ("max_structs", C.c_int32),
                 ("cand_per_nt", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("batch_flags", C.c_int32)]
 
 
 class Stem(C.Structure):
@@ -103,6 +106,9 @@ def load():
     L.sq_profile_reset.argtypes = [C.c_void_p]
     L.sq_run_algos.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                C.c_void_p]
+    L.sq_align_accumulate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.sq_colmatrix_select.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.POINTER(C.c_int64), C.c_void_p]
     _lib = L
     return L
 

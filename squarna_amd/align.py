@@ -29,20 +29,25 @@ def ReAlignDict(shortseq, longseq):
     return out
 
 
-def MatrixToDBNs(mat, score, depth, verbose=False, sink=sys.stdout):
+def MatrixToDBNs(mat, score, depth, verbose=False, sink=sys.stdout, cells=None):
     """Greedy assembly of conflict-free structures from the column matrix
     (SQRNdbnali.py:121-192): cells >= score*depth in decreasing order (ties: flat index order),
-    span >= 4, first structure that has both columns free."""
+    span >= 4, first structure that has both columns free.  cells: optional pre-selected
+    (flat indices ascending, values) of the upper cells with span >= 4 (the device path)."""
     N = mat.shape[0]
     thr = score * depth
-    flat = mat.flatten()
-    idx = np.flatnonzero(flat >= thr)
-    order = idx[np.argsort(-flat[idx], kind='stable')]          # stable: equal values keep index order
+    if cells is None:
+        flat = mat.flatten()
+        idx = np.flatnonzero(flat >= thr)
+        vals = flat[idx]
+    else:
+        idx, vals = cells
+    order = np.argsort(-vals, kind='stable')                      # stable: equal values keep index order
     res = [[[], set()]]
     if verbose:
         print(">Conserved base pairs (one by one)", file=sink)
-    for cell in order:
-        bp = np.unravel_index(cell, mat.shape)
+    for k in order:
+        bp = (int(idx[k] // N), int(idx[k] % N))
         if not bp[1] - bp[0] >= 4:
             continue
         for struct in res:
@@ -54,7 +59,7 @@ def MatrixToDBNs(mat, score, depth, verbose=False, sink=sys.stdout):
         else:
             res.append([[bp], set(bp)])
         if verbose:
-            print(PairsToDBN([bp], N), round(flat[cell], 3), sep='\t', file=sink)
+            print(PairsToDBN([bp], N), round(float(vals[k]), 3), sep='\t', file=sink)
     dbns = [PairsToDBN(struct[0], N) for struct in res]
     if verbose:
         print(">Conserved base pairs (assembled)", file=sink)
@@ -76,12 +81,23 @@ def Metrics(ref, pred):
 
 
 def SQRNdbnali(objs, defrests=None, defreacts=None, defref=None, bpweights={}, interchainonly=False,
-               minlen=2, minbpscore=0, threads=1, verbose=False, sink=sys.stdout, M=1.8, B=-0.6):
+               minlen=2, minbpscore=0, threads=1, verbose=False, sink=sys.stdout, M=1.8, B=-0.6, nseq_total=None):
     """Step-1 iteration: (first assembled dbn, L x L stem matrix) -- SQRNdbnali.py:211-242."""
     L = len(objs[0][1])
+    recs = [(obj[1].upper().replace("T", "U"), obj[2], defrests if defrests else obj[3]) for obj in objs]
+    eng = _engine.get_engine()
+    if hasattr(eng, "stem_matrix"):
+        # device path: the L x L matrix is accumulated and thresholded on the GPU; only the surviving cells come back
+        stemmatrix = eng.stem_matrix(recs, bpweights, minlen, minbpscore, interchainonly)
+        reduce_hook = getattr(eng, "reduce_matrix", None)
+        if reduce_hook is not None:
+            stemmatrix = reduce_hook(stemmatrix)                   # multi-GPU: all_reduce(sum) of the partial matrices
+        cells = eng.matrix_cells(stemmatrix, minbpscore * len(objs) if nseq_total is None else minbpscore * nseq_total)
+        pred = MatrixToDBNs(stemmatrix, minbpscore, len(objs) if nseq_total is None else nseq_total, verbose, sink=sink,
+                            cells=cells)
+        return pred[0], stemmatrix
     stemmatrix = np.zeros((L, L))
-    recs = [(obj[1], obj[2], defrests if defrests else obj[3]) for obj in objs]
-    allstems = _engine.get_engine().yield_stems(recs, bpweights, minlen, minbpscore, interchainonly)
+    allstems = eng.yield_stems(recs, bpweights, minlen, minbpscore, interchainonly)
     for (seq, _, _), (shortseq, stems) in zip(recs, allstems):     # reference order: sequences, stems, cells
         cols = np.array([c for c, ch in enumerate(seq) if ch not in GAPS], np.int64)     # ReAlignDict (:20-37)
         if isinstance(stems, np.ndarray):
@@ -98,7 +114,10 @@ def SQRNdbnali(objs, defrests=None, defreacts=None, defref=None, bpweights={}, i
         val = np.repeat(sc, sl)
         np.add.at(stemmatrix, (v, w), val)
         np.add.at(stemmatrix, (w, v), val)
-    pred = MatrixToDBNs(stemmatrix, minbpscore, len(objs), verbose, sink=sink)
+    reduce_hook = getattr(eng, "reduce_matrix", None)
+    if reduce_hook is not None:
+        stemmatrix = reduce_hook(stemmatrix)
+    pred = MatrixToDBNs(stemmatrix, minbpscore, len(objs) if nseq_total is None else nseq_total, verbose, sink=sink)
     return pred[0], stemmatrix
 
 
@@ -149,7 +168,10 @@ def RunSQRNdbnali(objs, defreacts, defrests, defref, levellimit, freqlimit, verb
     pred_dbn = SQRNdbnali(objs, pred_dbn, defreacts, defref, bpweights, interchainonly, minlen, minbpscore,
                           threads, verbose, sink=sink, M=M, B=B)[0]
     step1dbn = PairsToDBN(DBNToPairs(pred_dbn), N, levellimit=levellimit)
-    smat = smat / np.max(smat) * 5                                   # :371
+    if step3 != '1':                                                 # (only step 2 reads it)
+        if not isinstance(smat, np.ndarray):
+            smat = smat.cpu().numpy()                                # device path: one D2H of the L x L matrix
+        smat = smat / np.max(smat) * 5                               # :371
     if verbose:
         print(">Step 1, Result", file=sink)
         print(step1dbn, file=sink)

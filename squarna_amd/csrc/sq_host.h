@@ -107,6 +107,7 @@ struct sq_batch {
     uint32_t out_cap = 0;
     int32_t strand_cap = 0;
     size_t mat32_bytes = 0;
+    bool has_fp32 = true;                 // fp32 score matrices are part of the workspace
     bool filled = false;                  // fp32 matrices (and bit matrices) of every job are valid
     bool mul_applied = false;             // multiplier matrices already folded into the dense arena
     bool bits_ready = false;              // bit matrices valid (all the fold path needs)

@@ -94,6 +94,13 @@ static inline int32_t ld_of(int n)
     return 32 * k + 1;
 }
 
+// fp32 score matrices are planned unless the caller opts out (the legacy fp32 scans always need them)
+static inline bool want_fp32(const sq_batch_desc *d)
+{
+    if (getenv("SQ_SCAN") && atoi(getenv("SQ_SCAN")) != 6) return true;
+    return !(d->batch_flags & SQ_BATCH_NO_FP32);
+}
+
 namespace {
 struct Layout {
     size_t off_codes, off_flags, off_inc4, off_chain, off_e0, off_reacts, off_jobs, off_psets, off_sdf;
@@ -119,7 +126,8 @@ int plan(const sq_batch_desc *d, Layout &L)
         const int s = d->job_seq[j];
         if (s < 0 || s >= d->nseq || d->job_pset[j] < 0 || d->job_pset[j] >= d->npset) { sq_set_error("bad job"); return -1; }
         const int64_t n = d->seq_off[s + 1] - d->seq_off[s];
-        L.mat32_floats += (int64_t)align_up((size_t)(n * ld_of((int)n)), 64);
+        const bool ext_any = (d->ext_score && d->ext_score[j]) || (d->mul_score && d->mul_score[j]);
+        if (want_fp32(d) || ext_any) L.mat32_floats += (int64_t)align_up((size_t)(n * ld_of((int)n)), 64);
         L.bits_words += (int64_t)bits_nw((int)n) * bits_pitch((int)n);
         const bool ext = d->ext_score && d->ext_score[j];
         const bool mul = d->mul_score && d->mul_score[j];
@@ -207,6 +215,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->max_structs = L.max_structs; b->cand_per_nt = L.cpn;
     b->cand_records = L.cand_records; b->out_cap = L.out_cap; b->strand_cap = L.strand_cap;
     b->mat32_bytes = 4 * (size_t)L.mat32_floats;
+    b->has_fp32 = want_fp32(d);
 
     char *base = (char *)ws;
     // ---- per-position derived arrays (host, O(N)) ----
@@ -266,7 +275,6 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         J.n = d->seq_off[s + 1] - d->seq_off[s];
         J.ld = ld_of(J.n); J.seq = s; J.pset = d->job_pset[j];
         J.pos_off = d->seq_off[s];
-        J.mat_off = m32; m32 += (int64_t)align_up((size_t)J.n * J.ld, 64);
         J.mat64_off = -1; J.has_ext = 0;
         J.nw = bits_nw(J.n); J.bpitch = bits_pitch(J.n); J.bits_off = mbits; mbits += (int64_t)J.nw * J.bpitch;
         J.rb_off = d->rbp_off[s]; J.nrb = d->rbp_off[s + 1] - d->rbp_off[s];
@@ -274,6 +282,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         const bool mul = d->mul_score && d->mul_score[j];
         if (ext) { J.mat64_off = m64; J.has_ext = 1; m64 += 2 * (int64_t)J.n * J.n; }
         else if (mul) { J.mat64_off = m64; J.has_ext = 2; m64 += (int64_t)J.n * J.n; }
+        J.mat_off = -1;
+        if (b->has_fp32 || J.has_ext) { J.mat_off = m32; m32 += (int64_t)align_up((size_t)J.n * J.ld, 64); }
         bool def = true;                                  // SQRNdbnseq.py:273
         for (int i = 0; i < J.n; i++) if (d->reacts[J.pos_off + i] != 0.5) { def = false; break; }
         J.default_reacts = def ? 1 : 0;
@@ -473,7 +483,11 @@ static int fill_impl(sq_batch *b, int full)
     return 0;
 }
 
-extern "C" int sq_bpmatrix_fill(sq_batch *b) { return fill_impl(b, 1); }
+extern "C" int sq_bpmatrix_fill(sq_batch *b)
+{
+    if (!b->has_fp32) { sq_set_error("batch was created with SQ_BATCH_NO_FP32: no fp32 score matrices to fill"); return -4; }
+    return fill_impl(b, 1);
+}
 
 int sq_prepare_scan(sq_batch *b)
 {
@@ -609,8 +623,15 @@ static inline bool shares_base(const HStem &a, const HStem &b)       // SQRNdbns
     return ov(as0, as1, bs0, bs1) || ov(as0, as1, bt0, bt1) || ov(at0, at1, bs0, bs1) || ov(at0, at1, bt0, bt1);
 }
 
+namespace {
+struct AlignSink {                    // mode 2: where the stems of structure k of the list are added
+    const int32_t *col_off, *cols;    // host: columns of list entry k are cols[col_off[k] .. col_off[k+1])
+    int L; double *matrix;            // device L x L fp64
+};
+}
+
 static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, size_t hi, int mode,
-                     std::vector<std::vector<HStem>> &out)
+                     std::vector<std::vector<HStem>> &out, const AlignSink *sink = nullptr)
 {
     const int S = (int)(hi - lo);
     int nstrand = 0, maxn = 0; int64_t cand_off = 0, maxcap = 0; double scan_bytes = 0;
@@ -669,6 +690,20 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
                            b->scan, io, mode, lds_n, lds_nr);
         if (mode == 0)
             hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, b->d_structs, b->scan, io);
+        if (mode == 2) {
+            // gap maps of the chunk's sequences into the (unused) round output buffer, then one scatter launch per
+            // sequence, in list order: stream order == the reference's per-cell summation order (dbnali:233-237)
+            int32_t *d_cols = (int32_t *)b->d_out;
+            const int32_t c0 = sink->col_off[lo], c1 = sink->col_off[hi];
+            if ((size_t)(c1 - c0) * 4 > (size_t)b->out_cap * sizeof(SqOut)) { sq_set_error("gap maps do not fit the round buffer"); return -3; }
+            HIPCK(hipMemcpyAsync(d_cols, sink->cols + c0, (size_t)(c1 - c0) * 4, hipMemcpyHostToDevice, st));
+            for (int k = 0; k < S; k++) {
+                const SqJob &J = b->jobs[structs[lo + k].job];
+                const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>(J.cand_cap / 1024, 1), 1024);
+                hipLaunchKernelGGL(sq_scatter_kernel, dim3(blocks), dim3(256), 0, st, b->ctx, b->d_structs, b->scan, k,
+                                   d_cols + (sink->col_off[lo + k] - c0), sink->L, sink->matrix);
+            }
+        }
     }
     const uint32_t seq = ++b->round_seq;
     hipLaunchKernelGGL(sq_done_kernel, dim3(1), dim3(1), 0, st, io, b->scan, seq);
@@ -706,6 +741,7 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
         ho = b->big_out.data();
     }
     g_t[1] += now_s() - tp0;
+    if (mode == 2) return 0;
     TScope tpost(2);
     // bucket by structure
     std::vector<uint32_t> cnt(S + 1, 0);
@@ -744,7 +780,14 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
     return 0;
 }
 
+static int run_round_impl(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out,
+                          const AlignSink *sink);
 int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out)
+{
+    return run_round_impl(b, structs, mode, out, nullptr);
+}
+static int run_round_impl(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out,
+                          const AlignSink *sink)
 {
     { int r = sq_prepare_scan(b); if (r) return r; }
     out.resize(structs.size());
@@ -758,7 +801,7 @@ int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::
             cands += J.cand_cap; strands += ns; hi++;
         }
         if (cands > b->cand_records - b->cand_reserved || strands > b->strand_cap) { sq_set_error("structure does not fit the round buffers"); return -3; }
-        int r = run_chunk(b, structs, lo, hi, mode, out);
+        int r = run_chunk(b, structs, lo, hi, mode, out, sink);
         if (r) return r;
         lo = hi;
     }
@@ -799,6 +842,56 @@ extern "C" int sq_optimal_stems(sq_batch *b, int32_t nstruct, const int32_t *str
     }
     out_off[nstruct] = o;
     return 0;
+}
+
+// ---- alignment step 1 --------------------------------------------------------------------------------
+extern "C" int sq_align_accumulate(sq_batch *b, int32_t njob, const int32_t *job_ids, const int32_t *col_off,
+                                   const int32_t *cols, int32_t L, double *d_matrix)
+{
+    if (!b || njob < 0 || !job_ids || !col_off || !cols || L <= 0 || !d_matrix) { sq_set_error("bad argument"); return -1; }
+    std::vector<HStruct> hs(njob);
+    std::vector<SView> views(njob);
+    for (int k = 0; k < njob; k++) {
+        const int j = job_ids[k];
+        if (j < 0 || j >= b->njobs) { sq_set_error("bad job index"); return -1; }
+        const int n = b->jobs[j].n;
+        if (col_off[k + 1] - col_off[k] != n) { sq_set_error("gap map length differs from the sequence length"); return -1; }
+        for (int p = 0; p < n; p++) {
+            const int c = cols[col_off[k] + p];
+            if (c < 0 || c >= L || (p && c <= cols[col_off[k] + p - 1])) { sq_set_error("gap map is not increasing inside [0, L)"); return -1; }
+        }
+        hs[k].job = j; views[k] = SView{j, 1.0, &hs[k]};
+    }
+    AlignSink sink{col_off, cols, L, d_matrix};
+    std::vector<std::vector<HStem>> unused;
+    return run_round_impl(b, views, 2, unused, &sink);
+}
+
+extern "C" int sq_colmatrix_select(const double *d_matrix, int32_t L, double threshold, int32_t minspan,
+                                   int64_t *idx_out, double *val_out, int64_t cap, int64_t *count, void *hip_stream)
+{
+    if (!d_matrix || L <= 0 || cap < 0 || !count || (cap && (!idx_out || !val_out))) { sq_set_error("bad argument"); return -1; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    char *d = nullptr;                                     // [count][idx cap][val cap]; a result list, not workspace
+    const size_t bytes = 16 + (size_t)cap * 16;
+    HIPCK(hipMallocAsync((void **)&d, bytes, st));
+    HIPCK(hipMemsetAsync(d, 0, 16, st));
+    const int64_t total = (int64_t)L * L;
+    hipLaunchKernelGGL(sq_colselect_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, st,
+                       d_matrix, L, threshold, minspan, (long long *)(d + 16), (double *)(d + 16 + (size_t)cap * 8),
+                       (long long)cap, (unsigned long long *)d);
+    int r = sq_check(hipGetLastError(), "sq_colselect_kernel");
+    unsigned long long n = 0;
+    if (!r) r = sq_check(hipMemcpyAsync(&n, d, 8, hipMemcpyDeviceToHost, st), "count");
+    if (!r) r = sq_check(hipStreamSynchronize(st), "sync");
+    const int64_t got = (int64_t)std::min<unsigned long long>(n, (unsigned long long)cap);
+    if (!r && got) {
+        r = sq_check(hipMemcpy(idx_out, d + 16, (size_t)got * 8, hipMemcpyDeviceToHost), "idx");
+        if (!r) r = sq_check(hipMemcpy(val_out, d + 16 + (size_t)cap * 8, (size_t)got * 8, hipMemcpyDeviceToHost), "val");
+    }
+    hipFreeAsync(d, st);
+    *count = (int64_t)n;
+    return r;
 }
 
 // ---- a-7: greedy pool loop for every job at once (SQRNdbnseq.py:1102-1199) ----------------------
@@ -945,7 +1038,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     if (timing) {
         double mx = 0, sum = 0; int arg = 0;
         for (int q = 0; q < b->nseq; q++) { sum += tail_cost[q]; if (tail_cost[q] > mx) { mx = tail_cost[q]; arg = q; } }
-        size_t nst = 0; for (int j : seq_jobs[arg]) nst += 0;
+
         fprintf(stderr, "[sq_fold] tail: sum %.3f ms, max %.3f ms (seq %d, n=%d, %zu structures kept)\n", sum * 1e3, mx * 1e3, arg,
                 b->seq_off[arg + 1] - b->seq_off[arg], b->results[arg].preds.size());
     }

@@ -1224,7 +1224,9 @@ extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, c
         cd.bps = bps; cd.fin = fin; cd.flags = ok ? 1u : 0u;
         if (ok) {                                                        // flags were zeroed by the scan: nothing to write otherwise
             cands[q].bps = bps; cands[q].fin = fin; cands[q].flags = 1u;
-            if (mode == 1) {
+            if (mode == 2) {
+                // alignment accumulate: the flagged candidates stay on the device (sq_scatter_kernel reads them)
+            } else if (mode == 1) {
                 const SqOut r = {(int32_t)blockIdx.x, cd.key, L, 0, bps, 0.0};
                 sq_put_out(io, a, r);
             } else if (!any || fin > best) {
@@ -1232,7 +1234,7 @@ extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, c
             }
         }
     }
-    if (mode == 1) return;
+    if (mode != 0) return;
 
     // wave maximum, then one atomicMax per wave on the structure's slot
     for (int off = 32; off > 0; off >>= 1) {
@@ -1261,6 +1263,48 @@ extern "C" __global__ __launch_bounds__(256) void sq_select_kernel(SqDevCtx c, c
         if (!(cd.fin < range)) {                                        // :778
             const SqOut r = {(int32_t)blockIdx.x, cd.key, (int32_t)cd.len, 0, cd.bps, cd.fin};
             sq_put_out(io, a, r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// alignment step 1 (SQRNdbnali.py:233-237): the stems of ONE sequence (structure sidx of the round, already
+// re-scored by sq_score_kernel in mode 2) added into the L x L column matrix through the gap map.  The cells of
+// one sequence's stems are distinct, so plain read-modify-writes are race-free; sequences are separate launches
+// in stream order, which is the reference's summation order per cell.
+// ------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(256) void sq_scatter_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a,
+                                                                   int sidx, const int32_t *cols, int L, double *matrix)
+{
+    const SqStruct st = structs[sidx];
+    const SqJob jb = c.jobs[st.job];
+    uint32_t ncand = a.cand_cnt[st.slot];
+    if (ncand > (uint32_t)jb.cand_cap) ncand = jb.cand_cap;
+    const SqCand *cands = a.cands + st.cand_off;
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < ncand; q += gridDim.x * 256) {
+        if (!cands[q].flags) continue;
+        const SqCand cd = cands[q];
+        const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
+        for (int t = 0; t < (int)cd.len; t++) {
+            const int64_t v = cols[i0 + t], w = cols[j0 - t];
+            matrix[v * L + w] += cd.bps;
+            matrix[w * L + v] += cd.bps;
+        }
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void sq_colselect_kernel(const double *matrix, int L, double thr, int minspan,
+                                                                     long long *idx_out, double *val_out, long long cap,
+                                                                     unsigned long long *count)
+{
+    const int64_t total = (int64_t)L * L;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int v = (int)(q / L), w = (int)(q - (int64_t)v * L);
+        if (w - v < minspan) continue;
+        const double x = matrix[q];
+        if (x >= thr) {
+            const unsigned long long o = atomicAdd(count, 1ull);
+            if ((long long)o < cap) { idx_out[o] = q; val_out[o] = x; }
         }
     }
 }

@@ -72,7 +72,9 @@ class Batch:
     """A device-resident batch of fold jobs (one per (record, paramset))."""
 
     def __init__(self, prepared, psets_per_record, interchainonly=False, ext=None, mul=None,
-                 max_structs=0, cand_per_nt=0, device=None):
+                 max_structs=0, cand_per_nt=0, device=None, fp32=True):
+        """fp32=False leaves the fp32 score matrices out of the workspace (4 N^2 bytes per job): everything
+        but fill() works -- folding only needs the 1-bit-per-cell matrices."""
         import torch
         L = _lib.load()
         if not torch.cuda.is_available():
@@ -158,6 +160,7 @@ class Batch:
         d.interchainonly = int(bool(interchainonly))
         d.max_structs = int(max_structs)
         d.cand_per_nt = int(cand_per_nt)
+        d.batch_flags = 0 if fp32 else _lib.BATCH_NO_FP32
         self.desc = d
         nbytes = C.c_size_t(0)
         _lib.check(L.sq_batch_workspace_bytes(C.byref(d), C.byref(nbytes)))
@@ -232,6 +235,21 @@ class Batch:
             res.append([(out[q].i, out[q].j, out[q].len, out[q].bpscore, out[q].finscore)
                         for q in range(out_off[k], out_off[k + 1])])
         return res
+
+    # -- alignment step 1
+    def align_accumulate(self, jobs, cols_per_job, matrix):
+        """Adds the stem scores of the listed jobs, in order, into the device L x L fp64 tensor `matrix`
+        through the gap maps cols_per_job[k] (unaligned index -> column); SQRNdbnali.py:233-237."""
+        L = int(matrix.shape[0])
+        assert matrix.dtype == self.torch.float64 and matrix.is_contiguous() and tuple(matrix.shape) == (L, L)
+        ja = np.array(jobs, np.int32)
+        off = np.zeros(len(jobs) + 1, np.int32)
+        for k, c in enumerate(cols_per_job):
+            off[k + 1] = off[k] + len(c)
+        cols = np.concatenate([np.asarray(c, np.int32) for c in cols_per_job]) if len(jobs) else np.zeros(1, np.int32)
+        cols = np.ascontiguousarray(cols, np.int32)
+        _lib.check(self.L.sq_align_accumulate(self.h, len(jobs), _ptr(ja), _ptr(off), _ptr(cols), L,
+                                              C.c_void_p(matrix.data_ptr())))
 
     # -- a-8 / a-9 / Nussinov
     def run_algo(self, jobs, algo, levellimit=None, out_cap=1 << 16):
@@ -356,7 +374,7 @@ class HipEngine:
                 if sm is not None:                                   # :1031-1034
                     sm = np.delete(np.delete(np.asarray(sm, dtype=np.float64), p.gapidx, 0), p.gapidx, 1)
                 mul.extend([sm] * len(r[4]))
-        with Batch(prepared, psets, interchainonly=interchainonly, mul=mul,
+        with Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False,
                    max_structs=self.max_structs, cand_per_nt=self.cand_per_nt) as b:
             b.fold(**opts)
             return [b.result(k) for k in range(len(records))]
@@ -384,12 +402,64 @@ class HipEngine:
                 hi += 1
             chunk = prepared[lo:hi]
             with Batch(chunk, [[ps]] * len(chunk), interchainonly=interchainonly, max_structs=self.max_structs,
-                       cand_per_nt=max(self.cand_per_nt, 64)) as b:
+                       cand_per_nt=max(self.cand_per_nt, 64), fp32=False) as b:
                 res = b.optimal(list(range(len(chunk))), [[] for _ in chunk], mode=1, out_cap=max(cap, tot),
                                 as_array=True)
             out.extend((p.shortseq, st) for p, st in zip(chunk, res))
             lo = hi
         return out
+
+    def stem_matrix(self, records, bpweights, minlen, minbpscore, interchainonly=False):
+        """Alignment step 1 on the device (SQRNdbnali.py:211-242 without MatrixToDBNs): the L x L fp64 column
+        matrix of stem scores over all (seq, reacts, restraints) records, as a torch tensor on the GPU.
+        Sequences are applied in order, one scatter launch each, so every cell is summed in the reference's
+        order; nothing but the gap maps crosses PCIe."""
+        import torch
+        ps = dict(bpweights=bpweights, bpp=0, algorithms={"G"}, suboptmax=1.0, suboptmin=1.0, suboptsteps=1.0,
+                  minlen=minlen, minbpscore=minbpscore, minfinscorefactor=1.0, bracketweight=-2.0, distcoef=0.09,
+                  orderpenalty=1.0, loopbonus=0.125, maxstemnum=1e6)
+        Lcols = len(records[0][0])
+        dev = torch.device("cuda", torch.cuda.current_device())
+        matrix = torch.zeros((Lcols, Lcols), dtype=torch.float64, device=dev)
+        prepared, cols = [], []
+        for seq, reacts, restraints in records:
+            p = Prepared(seq, reacts if reacts else None, restraints, None)
+            if not reacts:
+                p.shortreacts = [0.5] * len(p.shortseq)                # YieldStems passes reacts=None (:83)
+            prepared.append(p)
+            cols.append(np.array([c for c, ch in enumerate(seq) if ch not in GAPS], np.int32))   # ReAlignDict (:20-37)
+        # chunks of sequences sized to ~24 GB of bit matrices + candidates
+        lo = 0
+        while lo < len(prepared):
+            hi, cells = lo, 0
+            while hi < len(prepared) and (hi == lo or cells + len(prepared[hi].shortseq) ** 2 <= 16e9):
+                cells += len(prepared[hi].shortseq) ** 2
+                hi += 1
+            chunk = prepared[lo:hi]
+            with Batch(chunk, [[ps]] * len(chunk), interchainonly=interchainonly, max_structs=self.max_structs,
+                       cand_per_nt=max(self.cand_per_nt, 64), fp32=False) as b:
+                b.align_accumulate(list(range(len(chunk))), cols[lo:hi], matrix)
+                torch.cuda.synchronize(dev)
+            lo = hi
+        return matrix
+
+    def matrix_cells(self, matrix, threshold, minspan=4):
+        """(flat indices, values) of the upper cells >= threshold with span >= minspan of a device matrix,
+        sorted by flat index (MatrixToDBNs' candidates, SQRNdbnali.py:127-148)."""
+        Lcols = int(matrix.shape[0])
+        cap = 1 << 16
+        while True:
+            idx = np.zeros(cap, np.int64)
+            val = np.zeros(cap, np.float64)
+            cnt = C.c_int64(0)
+            _lib.check(_lib.load().sq_colmatrix_select(C.c_void_p(matrix.data_ptr()), Lcols, float(threshold), int(minspan),
+                                                       _ptr(idx), _ptr(val), cap, C.byref(cnt), None))
+            if cnt.value <= cap:
+                break
+            cap = int(cnt.value)
+        n = int(cnt.value)
+        order = np.argsort(idx[:n], kind="stable")
+        return idx[:n][order], val[:n][order]
 
     def entropy(self, record, interchainonly=False):
         """Mean row entropy of the stem matrix under the FIRST paramset, as a string

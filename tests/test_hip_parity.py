@@ -312,3 +312,53 @@ def test_baseline_sizes_vs_oracle_and_properties(n, count, seed, reacts, sample)
             used = [p for bp in pairs for p in bp]
             assert len(used) == len(set(used))
             assert all(s[i] + s[j] in ok and j - i >= 4 for i, j in pairs)
+
+
+# ---- alignment step 1 on the device: column matrix == the reference's sequential accumulation, bit for bit
+def _random_msa(rng, nseq, ncol, mut=0.15, gap=0.10):
+    anc = rng.choice(list("ACGU"), ncol)
+    rows = []
+    for _ in range(nseq):
+        row = anc.copy()
+        m = rng.random(ncol) < mut
+        row[m] = rng.choice(list("ACGU"), int(m.sum()))
+        row[rng.random(ncol) < gap] = "-"
+        rows.append("".join(row))
+    return rows
+
+
+@pytest.mark.parametrize("with_reacts", [False, True])
+def test_align_matrix_matches_sequential_accumulation(with_reacts):
+    from squarna_amd.engine import HipEngine
+    from tests.oracle_engine import OracleEngine
+    rng = np.random.default_rng(77 + with_reacts)
+    rows = _random_msa(rng, 24, 260)
+    w = {"GC": 3.25, "AU": 2.0, "GU": -1.0}
+    recs = []
+    for r in rows:
+        reacts = [float(x) for x in rng.random(len(r))] if with_reacts else None    # non-dyadic scores: order matters
+        recs.append((r, reacts, "." * len(r)))
+    L = len(rows[0])
+    exp = np.zeros((L, L))
+    for (seq, _, _), (short, stems) in zip(recs, OracleEngine().yield_stems(recs, w, 2, 4.5)):
+        cols = [c for c, ch in enumerate(seq) if ch not in "-.~"]
+        for i, j, ln, sc in stems:                                  # SQRNdbnali.py:233-237
+            for k in range(ln):
+                v, ww = cols[i + k], cols[j - k]
+                exp[v, ww] += sc
+                exp[ww, v] += sc
+    eng = HipEngine()
+    got = eng.stem_matrix(recs, w, 2, 4.5)
+    g = got.cpu().numpy()
+    if with_reacts:
+        # cell scores carry the documented sqrt-vs-pow(x, 0.5) 1-ulp deviation; same order of additions
+        assert np.array_equal(g != 0, exp != 0)
+        assert np.allclose(g, exp, rtol=1e-13, atol=0), float(np.max(np.abs(g - exp) / np.maximum(np.abs(exp), 1e-300)))
+        exp = g
+    else:
+        assert np.array_equal(g, exp)
+    thr = 4.5 * 6
+    idx, val = eng.matrix_cells(got, thr)
+    flat = exp.flatten()
+    e_idx = np.array([q for q in np.flatnonzero(flat >= thr) if q % L - q // L >= 4], np.int64)
+    assert np.array_equal(idx, e_idx) and np.array_equal(val, flat[e_idx])
