@@ -43,9 +43,19 @@ def MatrixToDBNs(mat, score, depth, verbose=False, sink=sys.stdout, cells=None):
     else:
         idx, vals = cells
     order = np.argsort(-vals, kind='stable')                      # stable: equal values keep index order
+    if not verbose:
+        # only the first structure is used by the caller (:242), and a cell joins it iff both of its columns
+        # are still free THERE -- whatever the later structures hold
+        taken = np.zeros(N, bool)
+        first = []
+        for k in order:
+            v, w = int(idx[k] // N), int(idx[k] % N)
+            if w - v >= 4 and not taken[v] and not taken[w]:
+                taken[v] = taken[w] = True
+                first.append((v, w))
+        return [PairsToDBN(first, N)]
     res = [[[], set()]]
-    if verbose:
-        print(">Conserved base pairs (one by one)", file=sink)
+    print(">Conserved base pairs (one by one)", file=sink)
     for k in order:
         bp = (int(idx[k] // N), int(idx[k] % N))
         if not bp[1] - bp[0] >= 4:
@@ -58,13 +68,11 @@ def MatrixToDBNs(mat, score, depth, verbose=False, sink=sys.stdout, cells=None):
                 break
         else:
             res.append([[bp], set(bp)])
-        if verbose:
-            print(PairsToDBN([bp], N), round(float(vals[k]), 3), sep='\t', file=sink)
+        print(PairsToDBN([bp], N), round(float(vals[k]), 3), sep='\t', file=sink)
     dbns = [PairsToDBN(struct[0], N) for struct in res]
-    if verbose:
-        print(">Conserved base pairs (assembled)", file=sink)
-        for dbn in dbns:
-            print(dbn, file=sink)
+    print(">Conserved base pairs (assembled)", file=sink)
+    for dbn in dbns:
+        print(dbn, file=sink)
     return dbns
 
 

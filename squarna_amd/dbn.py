@@ -139,29 +139,38 @@ def encode_seq(seq):
 def PairsToDBN(newpairs, length=0, returnlevels=False, levellimit=-1):
     """Pairs -> dot-bracket string with pseudoknot levels (SQRNdbnseq.py:104-163): pairs sorted by
     (crossing count, i) are first-fitted into conflict-free groups, the largest group gets '()'.
-    Host-side helper of the alignment layer (the fold path computes levels in C++)."""
+    Host-side helper of the alignment layer (the fold path computes levels in C++).  The crossing
+    relation is evaluated as one boolean matrix, so alignment-sized pair lists stay cheap."""
+    import numpy as np
     pairs = sorted(set((min(v, w), max(v, w)) for v, w in newpairs))
-
-    def crosses(p, q):
-        return (p[0] < q[0] < p[1] < q[1]) or (q[0] < p[0] < q[1] < p[1])
-
-    count = {p: sum(1 for q in pairs if p != q and crosses(p, q)) for p in pairs}
-    groups = []
-    for pair in sorted(pairs, key=lambda p: (count[p], p[0])):
+    P = len(pairs)
+    if P:
+        a = np.array([p[0] for p in pairs], np.int64)
+        b = np.array([p[1] for p in pairs], np.int64)
+        # X[p, q]: p = (i, j), q = (k, l) cross  <=>  i < k < j < l  or  k < i < l < j   (:114-116)
+        X = ((a[:, None] < a[None, :]) & (a[None, :] < b[:, None]) & (b[:, None] < b[None, :]))
+        X |= X.T
+        count = X.sum(axis=1)
+        order = sorted(range(P), key=lambda p: (int(count[p]), pairs[p][0]))          # :125 (stable)
+    else:
+        X, count, order = None, [], []
+    groups = []                                                    # lists of pair indices
+    for p in order:
         for group in groups:
-            if not count[pair] or not any(crosses(pair, q) for q in group):
-                group.append(pair)
+            if not count[p] or not X[p, group].any():              # :130-136 first fit
+                group.append(p)
                 break
         else:
-            groups.append([pair])
-    groups.sort(key=len, reverse=True)
+            groups.append([p])
+    groups.sort(key=len, reverse=True)                             # :139 (stable)
     if returnlevels:
-        return {bp: lev + 1 for lev, group in enumerate(groups) for bp in group}
+        return {pairs[p]: lev + 1 for lev, group in enumerate(groups) for p in group}
     if levellimit >= 0:
         groups = groups[:levellimit]
     glyphs = BRACKETS + ['..'] * max(0, len(groups) - len(BRACKETS))
     dbn = ['.'] * length
     for k, group in enumerate(groups):
-        for v, w in group:
+        for p in group:
+            v, w = pairs[p]
             dbn[v], dbn[w] = glyphs[k][0], glyphs[k][1]
     return ''.join(dbn)

@@ -59,6 +59,69 @@ def gather_blocks(blocks, total, device=None, group=None):
     return out
 
 
+class ShardedAlignEngine:
+    """Alignment mode over the ranks of a group: every rank owns a CONTIGUOUS block of the alignment's
+    sequences (balanced on N^2), accumulates the partial L x L stem matrix of its block, and ONE
+    all_reduce(sum) per step-1 iteration (RCCL over xGMI on GPU ranks) makes the full matrix available to
+    every rank; MatrixToDBNs then runs replicated.  Step-2 folds are sharded the same way and exchanged with
+    one all_gather.  Within a block the per-cell summation order is the reference's; across blocks the
+    all_reduce adds the partial sums in ring order, so cells of non-dyadic scores can differ from the
+    sequential sum in the last bits (dyadic bpweights without reactivities -- ali.conf -- are exact)."""
+
+    def __init__(self, base, group=None):
+        import torch.distributed as dist
+        self.base, self.group = base, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if hasattr(base, "stem_matrix"):
+            self.stem_matrix = self._stem_matrix
+            self.matrix_cells = base.matrix_cells
+
+    def _block(self, lens):
+        cost = np.cumsum([0.0] + [float(n) * n for n in lens])
+        cut = [int(np.searchsorted(cost, cost[-1] * r / self.world, side="left")) for r in range(self.world + 1)]
+        cut[0], cut[-1] = 0, len(lens)
+        return cut[self.rank], max(cut[self.rank], cut[self.rank + 1])
+
+    @staticmethod
+    def _ungapped(seq):
+        return sum(1 for ch in seq if ch not in "-.~")
+
+    def _stem_matrix(self, records, bpweights, minlen, minbpscore, interchainonly=False):
+        import torch
+        lo, hi = self._block([self._ungapped(r[0]) for r in records])
+        if hi > lo:
+            return self.base.stem_matrix(records[lo:hi], bpweights, minlen, minbpscore, interchainonly)
+        n = len(records[0][0])
+        return torch.zeros((n, n), dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+
+    def yield_stems(self, records, bpweights, minlen, minbpscore, interchainonly=False):
+        lo, hi = self._block([self._ungapped(r[0]) for r in records])
+        mine = self.base.yield_stems(records[lo:hi], bpweights, minlen, minbpscore, interchainonly) if hi > lo else []
+        blank = [("", [])] * len(records)                        # sequences of other ranks add nothing here
+        return blank[:lo] + list(mine) + blank[hi:]
+
+    def reduce_matrix(self, matrix):
+        import torch
+        import torch.distributed as dist
+        if isinstance(matrix, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(matrix))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return t.numpy()
+        dist.all_reduce(matrix, op=dist.ReduceOp.SUM, group=self.group)
+        return matrix
+
+    def fold_records(self, recs, **kw):
+        import torch.distributed as dist
+        lo, hi = self._block([self._ungapped(r[0]) for r in recs])
+        mine = self.base.fold_records(recs[lo:hi], **kw) if hi > lo else []
+        parts = [None] * self.world
+        dist.all_gather_object(parts, (lo, list(mine)), group=self.group)
+        out = [None] * len(recs)
+        for start, items in parts:
+            out[start:start + len(items)] = items
+        return out
+
+
 def PredictSharded(write_to=None, device=None, **kwargs):
     """`Predict` across the ranks of an initialised torch.distributed group.
     Same keyword arguments as `Predict`; rank 0 writes the complete output, in input order,
@@ -68,6 +131,16 @@ def PredictSharded(write_to=None, device=None, **kwargs):
     from .inputs import ParseInput
     assert dist.is_initialized(), "initialise torch.distributed first (torchrun)"
     world, rank = dist.get_world_size(), dist.get_rank()
+    if any(kwargs.get(k) for k in ("alignment", "ali", "a")):
+        # alignment mode: sequences of the MSA are sharded, one all_reduce per step-1 iteration
+        from . import engine as _engine
+        buf = io.StringIO()
+        with _engine.use_engine(ShardedAlignEngine(_engine.get_engine())):
+            Predict(write_to=buf, **kwargs)
+        if rank == 0:
+            (write_to if write_to is not None else sys.stdout).write(buf.getvalue())
+            return [buf.getvalue()]
+        return None
     # parse once to get the record lengths (cheap, O(input size)); cost model: N^2 per record
     probe = dict(kwargs)
     inputfile = probe.get("inputfile", probe.get("i"))
