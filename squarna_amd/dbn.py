@@ -81,14 +81,36 @@ def levels_to_dbn(levels):
     return ''.join(out)
 
 
+_GAP_LUT = None
+_DROP_GAPS = {ord(g): None for g in GAPS}
+
+
+def gap_mask(seq):
+    """Boolean numpy array: True where seq has a gap character (vectorised; non-latin-1 characters are letters)."""
+    import numpy as np
+    global _GAP_LUT
+    if _GAP_LUT is None:
+        _GAP_LUT = np.zeros(256, bool)
+        for g in GAPS:
+            _GAP_LUT[ord(g)] = True
+    return _GAP_LUT[np.frombuffer(seq.encode('latin-1', 'replace'), np.uint8)]
+
+
 def UnAlign(seq, dbn):
     """Drop gap columns; pairs touching a gap become dots first (SQRNdbnseq.py:236-255)."""
+    import numpy as np
+    gaps = gap_mask(seq)
+    if not gaps.any():
+        return seq, dbn
+    keep = np.flatnonzero(~gaps)
+    shortseq = seq.translate(_DROP_GAPS)
+    if dbn.count('.') == len(dbn):                       # no brackets at all: nothing to clean
+        return shortseq, '.' * len(keep)
     clean = list(dbn)
     for v, w in DBNToPairs(dbn):
-        if seq[v] in GAPS or seq[w] in GAPS:
+        if gaps[v] or gaps[w]:
             clean[v] = clean[w] = '.'
-    keep = [i for i in range(len(seq)) if seq[i] not in GAPS]
-    return ''.join(seq[i] for i in keep), ''.join(clean[i] for i in keep)
+    return shortseq, ''.join(clean[i] for i in keep)
 
 
 def ReAlign(shortdbn, longseq, seqmode=False):
@@ -101,6 +123,8 @@ def ReAlign(shortdbn, longseq, seqmode=False):
 
 def ParseRestraints(restraints):
     """Restraint line -> (bps, unpaired, no-left, no-right) (SQRNdbnseq.py:370-376)."""
+    if restraints.count('.') == len(restraints):         # the common case: no restraints
+        return [], set(), set(), set()
     rbps = DBNToPairs(restraints)
     rxs = {i for i, c in enumerate(restraints) if c in '_+'}
     rlefts = {i for i, c in enumerate(restraints) if c == '/'}
@@ -120,20 +144,20 @@ def PairsToStems(sorted_pairs):
     return stems
 
 
+_CODE_LUT = None
+
+
 def encode_seq(seq):
     """Letter codes of include/squarna_hip.h: 'A'..'Z' -> 0..25, ';' -> 26, '&' -> 27, other -> 28."""
-    out = bytearray(len(seq))
-    for i, ch in enumerate(seq):
-        o = ord(ch)
-        if 65 <= o <= 90:
-            out[i] = o - 65
-        elif ch == ';':
-            out[i] = 26
-        elif ch == '&':
-            out[i] = 27
-        else:
-            out[i] = 28
-    return bytes(out)
+    import numpy as np
+    global _CODE_LUT
+    if _CODE_LUT is None:
+        _CODE_LUT = np.full(256, 28, np.uint8)
+        _CODE_LUT[65:91] = np.arange(26, dtype=np.uint8)
+        _CODE_LUT[ord(';')] = 26
+        _CODE_LUT[ord('&')] = 27
+    # characters outside latin-1 become '?' -> 28 ("other"), as in the per-character rule
+    return _CODE_LUT[np.frombuffer(seq.encode('latin-1', 'replace'), np.uint8)].tobytes()
 
 
 def PairsToDBN(newpairs, length=0, returnlevels=False, levellimit=-1):

@@ -12,7 +12,7 @@ import contextlib
 import numpy as np
 
 from . import _lib
-from .dbn import (GAPS, SEPS, ReactDict, ProcessReacts, DBNToPairs, UnAlign, ReAlign,
+from .dbn import (gap_mask, GAPS, SEPS, ReactDict, ProcessReacts, DBNToPairs, UnAlign, ReAlign,
                   ParseRestraints, levels_to_dbn, encode_seq)
 
 
@@ -37,8 +37,9 @@ class Prepared:
             reacts = ProcessReacts([ReactDict[ch] for ch in reacts])
         self.seq = seq
         self.shortseq, self.shortrest = UnAlign(seq, restraints)     # :1023
-        self.gapidx = [i for i in range(len(seq)) if seq[i] in GAPS]
-        self.shortreacts = [reacts[i] for i in range(len(seq)) if seq[i] not in GAPS]
+        gaps = gap_mask(seq)
+        self.gapidx = np.flatnonzero(gaps).tolist()
+        self.shortreacts = list(reacts) if not self.gapidx else [reacts[i] for i in np.flatnonzero(~gaps).tolist()]
         self.shortdbn = None
         if dbn:
             assert len(seq) == len(dbn)
@@ -427,7 +428,7 @@ class HipEngine:
             if not reacts:
                 p.shortreacts = [0.5] * len(p.shortseq)                # YieldStems passes reacts=None (:83)
             prepared.append(p)
-            cols.append(np.array([c for c, ch in enumerate(seq) if ch not in GAPS], np.int32))   # ReAlignDict (:20-37)
+            cols.append(np.flatnonzero(~gap_mask(seq)).astype(np.int32))   # ReAlignDict (:20-37)
         # chunks of sequences sized to ~24 GB of bit matrices + candidates
         lo = 0
         while lo < len(prepared):
