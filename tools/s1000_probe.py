@@ -11,10 +11,14 @@ from squarna_amd.engine import Batch, Prepared
 nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+shape = "--shape" in sys.argv        # S2000: reactivity line drawn per position from "_+#" with p = (0.5, 0.3, 0.2)
 names, psets = ParseConfig(builtin_config("fastest"))
 rng = np.random.default_rng(1000)
 seqs = ["".join(rng.choice(list("ACGU"), n)) for _ in range(nseq)]
-with Batch([Prepared(s) for s in seqs], [psets] * nseq, max_structs=nseq) as b:
+reacts = ["".join(rng.choice(list("_+#"), n, p=[0.5, 0.3, 0.2])) for _ in range(nseq)] if shape else [None] * nseq
+from squarna_amd.dbn import ProcessReacts, ReactDict
+prepared = [Prepared(s, ProcessReacts([ReactDict[c] for c in r], M=1.8, B=-0.6) if r else None) for s, r in zip(seqs, reacts)]
+with Batch(prepared, [psets] * nseq, max_structs=min(nseq, 4096), fp32=False) as b:
     b.profile(True)
     for r in range(reps):
         b.profile_reset()
