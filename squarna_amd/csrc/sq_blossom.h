@@ -41,6 +41,24 @@ struct SqCoopWave {
     }
     __device__ void min_first(double &v, int &i, int nl) const
     {
+        const unsigned long long valid = __ballot(i < nl);
+        if (__popcll(valid) <= 8) {
+            // few candidates: walk them in lane order with v_readlane (no LDS crossbar traffic); strict < keeps the first
+            double bv = 0; int bi = nl;
+            unsigned long long msk = valid;
+            const long long bits = __double_as_longlong(v);
+            while (msk) {
+                const int l = __ffsll((long long)msk) - 1;
+                msk &= msk - 1;
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(bits & 0xFFFFFFFFll), l);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), l);
+                const double x = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                const int xi = __builtin_amdgcn_readlane(i, l);
+                if (bi >= nl || x < bv || (x == bv && xi < bi)) { bv = x; bi = xi; }
+            }
+            v = bv; i = bi;
+            return;
+        }
         for (int off = 32; off > 0; off >>= 1) {
             const double ov = __shfl_xor(v, off);
             const int oi = __shfl_xor(i, off);
@@ -68,6 +86,7 @@ struct SqBlossom {
     int n, m;                 // vertices (graph order), undirected edges
     const SqMatchEdge *E;     // E[e] = (v, w, weight), vertex ids in graph order
     int *adj_off, *adj;       // CSR, directed edge codes (2e | dir) in neighbour insertion order
+    int *adjv; double *adjw;  // per CSR slot: the neighbour vertex and the edge weight (one LDS level less in the scan)
     // state (index: vertex 0..n-1, blossom n..2n-1)
     int *mate;                // mate vertex or -1 (output)
     int *mate_de;             // directed edge v -> mate[v]
@@ -96,6 +115,7 @@ struct SqBlossom {
     {
         const size_t N2 = 2 * (size_t)n + 2;
         size_t ints = (size_t)n + 1 + 2 * (size_t)m            // adj_off, adj
+                      + 2 * (size_t)m + 4 * (size_t)m + 2       // adjv, adjw (doubles)
                       + 2 * (size_t)n                           // mate, mate_de
                       + 4 * N2 + (size_t)n                      // labeledge, parent, base, bestedge, inblossom
                       + (size_t)queue_cap(n, m, tight)          // queue
@@ -114,8 +134,8 @@ struct SqBlossom {
         char *p = scratch;
         auto take_d = [&](size_t k) { p = (char *)(((uintptr_t)p + 7) & ~(uintptr_t)7); double *r = (double *)p; p += k * 8; return r; };
         auto take_i = [&](size_t k) { p = (char *)(((uintptr_t)p + 3) & ~(uintptr_t)3); int *r = (int *)p; p += k * 4; return r; };
-        dualvar = take_d(n); bdual = take_d(N2);
-        adj_off = take_i(n + 1); adj = take_i(2 * (size_t)m);
+        dualvar = take_d(n); bdual = take_d(N2); adjw = take_d(2 * (size_t)m);
+        adj_off = take_i(n + 1); adj = take_i(2 * (size_t)m); adjv = take_i(2 * (size_t)m);
         mate = take_i(n); mate_de = take_i(n);
         labeledge = take_i(N2); parent = take_i(N2); base = take_i(N2); bestedge = take_i(N2); inblossom = take_i(n);
         qcap = queue_cap(n, m, tight); queue = take_i(qcap); qn = 0;
@@ -132,8 +152,9 @@ struct SqBlossom {
         for (int v = 0; v < n; v++) adj_off[v + 1] += adj_off[v];
         for (int v = 0; v < n; v++) mate[v] = 0;                 // used as fill cursor
         for (int e = 0; e < m; e++) {
-            adj[adj_off[E[e].v] + mate[E[e].v]++] = 2 * e;
-            adj[adj_off[E[e].w] + mate[E[e].w]++] = 2 * e + 1;
+            const int sv = adj_off[E[e].v] + mate[E[e].v]++, sw = adj_off[E[e].w] + mate[E[e].w]++;
+            adj[sv] = 2 * e;     adjv[sv] = E[e].w; adjw[sv] = E[e].weight;
+            adj[sw] = 2 * e + 1; adjv[sw] = E[e].v; adjw[sw] = E[e].weight;
         }
     }
 
@@ -457,6 +478,7 @@ struct SqBlossom {
     // clears, the four delta minima, the dual updates) are strided over the lanes.  Minima keep the
     // sequential rule "first strictly smaller wins": per lane the first minimum of its stride, then
     // across lanes the smallest value and, among equals, the smallest iteration index.
+    char *origin;             // generic address of the LDS buffer that holds edges + state (FAST runs only)
     int f_augmented, f_stop, f_break;
 #ifdef SQ_MWM_PROF
     long long pt[8]; long long pc[8];
@@ -467,9 +489,13 @@ struct SqBlossom {
     double red_v[64][4];
     int red_i[64][4];
 
-    template <class Sync, class Coop>
-    SQ_HD void run(int lane, int nl, Sync sync, Coop coop)
+    // FAST: the edges and all state arrays live in ONE LDS buffer whose address the caller passes as `fast0`
+    // (and as `origin`, its generic address).  The hot loops then address the arrays as fast0 + offset, which lets
+    // the compiler prove the address space and emit ds_read/ds_write instead of flat loads through the LDS aperture.
+    template <bool FAST, class Sync, class Coop>
+    SQ_HD void run(int lane, int nl, Sync sync, Coop coop, char *fast0)
     {
+#define SQ_LP(p) (FAST ? (decltype(p))(fast0 + ((char *)(p) - origin)) : (p))
         const int N2 = 2 * n + 2;
         for (int v = lane; v < n; v += nl) { mate[v] = -1; mate_de[v] = -1; inblossom[v] = v; }
         for (int x = lane; x < N2; x += nl) {
@@ -488,6 +514,21 @@ struct SqBlossom {
             for (int v = lane; v < n; v += nl) dualvar[v] = maxweight;
         }
         sync();
+        // the hot loop works on register copies of the array bases: `this` lives in LDS, and every byte store
+        // (label, allowedge) would otherwise force the compiler to reload the pointer members
+        const SqMatchEdge *const E_ = SQ_LP(E);
+        const int *const adj_ = SQ_LP(adj), *const adj_off_ = SQ_LP(adj_off), *const inblossom_ = SQ_LP(inblossom);
+        const int *const queue_ = SQ_LP(queue), *const adjv_ = SQ_LP(adjv);
+        const double *const adjw_ = SQ_LP(adjw);
+        int *const labeledge_ = SQ_LP(labeledge), *const bestedge_ = SQ_LP(bestedge);
+        int8_t *const label_ = SQ_LP(label);
+        uint8_t *const allow_ = SQ_LP(allow);
+        double *const dualvar_ = SQ_LP(dualvar), *const bdual_ = SQ_LP(bdual);
+        const int *const parent_ = SQ_LP(parent), *const live_ = SQ_LP(live);
+        auto slack_ = [&](int de) -> double {
+            const SqMatchEdge ed = E_[de >> 1];
+            return (de & 1) ? dualvar_[ed.w] + dualvar_[ed.v] - 2 * ed.weight : dualvar_[ed.v] + dualvar_[ed.w] - 2 * ed.weight;
+        };
 #ifdef SQ_MWM_PROF
         long long _tp = wall_clock64();
         if (lane == 0) for (int k = 0; k < 8; k++) { pt[k] = 0; pc[k] = 0; }
@@ -554,51 +595,63 @@ struct SqBlossom {
                 for (;;) {
                     sync();
                     if (qn == 0 || f_augmented || error) break;
-                    const int v = queue[qn - 1];
+                    const int v = queue_[qn - 1];
                     sync();
                     if (lane == 0) qn--;
-                    int a0 = adj_off[v];
-                    const int aend = adj_off[v + 1];
+                    int a0 = adj_off_[v];
+                    const int aend = adj_off_[v + 1];
 #ifdef SQ_MWM_PROF
                     if (lane == 0) { pc[1]++; pc[0] += aend - a0; }
 #endif
                     while (a0 < aend) {
-                        const int a = a0 + lane;
-                        const int bv = inblossom[v];
-                        int cat = 0, de = -1, w = -1;          // 0 none, 1 event, 2 label[w] := T, 3 bestedge[w], 4 bestedge[bv]
-                        bool becomes = false;
-                        double ks = 0;
-                        if (a < aend) {
-                            de = adj[a];
-                            w = head(de);
-                            const int bw = inblossom[w];
-                            if (w != v && bw != bv) {
-                                bool allowed = allow[de >> 1] != 0;
-                                if (!allowed) {
-                                    ks = slack(de);
-                                    if (ks <= 0) { becomes = true; allowed = true; }
-                                }
-                                const int lbw = label[bw];
-                                if (allowed) {
-                                    if (lbw == 0 || lbw == 1) cat = 1;
-                                    else if (label[w] == 0) cat = 2;
-                                } else if (lbw == 1) cat = 4;
-                                else if (label[w] == 0) cat = 3;
-                            }
+#ifdef SQ_MWM_PROF
+                        if (lane == 0) pc[5]++;
+#endif
+                        // Branch-free classification: the loads of one dependency level are issued together
+                        // (speculatively for lanes past the end, on a clamped slot), three LDS round trips in all.
+                        const bool live = a0 + lane < aend;
+                        const int a = live ? a0 + lane : a0;
+                        const int bv = inblossom_[v];
+                        const double dv = dualvar_[v];
+                        const int de = adj_[a], w = adjv_[a];
+                        const double wt = adjw_[a];
+                        const int be_bv = bestedge_[bv];                     // lane 0's competitor for bestedge[bv]
+                        const int bw = inblossom_[w];
+                        const double dw = dualvar_[w];
+                        const int lw = label_[w];
+                        const bool was_allowed = allow_[de >> 1] != 0;
+                        const int be_w = bestedge_[w];
+                        const int lbw = label_[bw];
+                        const double s_bew = slack_(be_w >= 0 ? be_w : de);  // slack(bestedge[w]) (unused when there is none)
+                        const double s_bebv = slack_(be_bv >= 0 ? be_bv : de);
+                        const double ks = dv + dw - 2 * wt;                  // slack(de): dualvar[v] + dualvar[w] - 2 weight
+                        const bool cons = live && w != v && bw != bv;       // :  `if w == v: continue`, same blossom: continue
+                        const bool becomes = cons && !was_allowed && ks <= 0;
+                        const bool allowed = was_allowed || becomes;
+                        int cat = 0;                                         // 0 none, 1 event, 2 label[w] := T, 3 bestedge[w], 4 bestedge[bv]
+                        if (cons) {
+                            if (allowed) cat = (lbw == 0 || lbw == 1) ? 1 : (lw == 0 ? 2 : 0);
+                            else cat = lbw == 1 ? 4 : (lw == 0 ? 3 : 0);
                         }
                         const int f = coop.first_true(cat == 1, nl);        // first state-changing neighbour of the chunk
-                        if (lane < f && a < aend) {
-                            if (becomes) allow[de >> 1] = 1;
-                            if (cat == 2) { label[w] = 2; labeledge[w] = de; }
-                            else if (cat == 3) { if (bestedge[w] == -1 || ks < slack(bestedge[w])) bestedge[w] = de; }
+                        if (lane < f && live) {
+                            if (becomes) allow_[de >> 1] = 1;
+                            if (cat == 2) { label_[w] = 2; labeledge_[w] = de; }
+                            else if (cat == 3) { if (be_w == -1 || ks < s_bew) bestedge_[w] = de; }
                         }
-                        double mv = ks; int mi = (lane < f && cat == 4) ? lane : nl;
-                        coop.min_first(mv, mi, nl);
-                        if (lane == 0 && mi < nl) {
-                            if (bestedge[bv] == -1 || mv < slack(bestedge[bv])) bestedge[bv] = adj[a0 + mi];
+                        if (coop.first_true(lane < f && cat == 4, nl) < nl) {      // somebody competes for bestedge[bv]
+                            double mv = ks; int mi = (lane < f && cat == 4) ? lane : nl;
+                            coop.min_first(mv, mi, nl);
+                            if (lane == 0) {
+                                if (be_bv == -1 || mv < s_bebv) bestedge_[bv] = adj_[a0 + mi];
+                            }
                         }
                         if (f >= nl) { a0 += nl; continue; }
                         sync();
+#ifdef SQ_MWM_PROF
+                        long long _te = 0;
+                        if (lane == 0) { pc[4]++; _te = wall_clock64(); }
+#endif
                         if (lane == 0) {                        // the sequential body for neighbour a0 + f
                             const int de1 = adj[a0 + f];
                             const int w1 = head(de1);
@@ -626,6 +679,9 @@ struct SqBlossom {
                             }
                         }
                         sync();
+#ifdef SQ_MWM_PROF
+                        if (lane == 0) pt[7] += wall_clock64() - _te;
+#endif
                         if (f_augmented || error) break;
                         a0 += f + 1;
                     }
@@ -640,22 +696,22 @@ struct SqBlossom {
                     double m1 = 1e300; double m2 = 1e300, m3 = 1e300, m4 = 1e300;
                     int i2 = -1, i3 = -1, i4 = -1;
                     for (int v = lane; v < n; v += nl) {
-                        if (dualvar[v] < m1) m1 = dualvar[v];
-                        if (label[inblossom[v]] == 0 && bestedge[v] != -1) {
-                            const double d = slack(bestedge[v]);
+                        if (dualvar_[v] < m1) m1 = dualvar_[v];
+                        if (label_[inblossom_[v]] == 0 && bestedge_[v] != -1) {
+                            const double d = slack_(bestedge_[v]);
                             if (i2 == -1 || d < m2) { m2 = d; i2 = v; }
                         }
                     }
                     for (int k = lane; k < n + nlive; k += nl) {   // `for b in blossomparent`: vertices, then blossoms
-                        const int b = k < n ? k : live[k - n];
-                        if (parent[b] == -1 && label[b] == 1 && bestedge[b] != -1) {
-                            const double d = slack(bestedge[b]) / 2.0;
+                        const int b = k < n ? k : live_[k - n];
+                        if (parent_[b] == -1 && label_[b] == 1 && bestedge_[b] != -1) {
+                            const double d = slack_(bestedge_[b]) / 2.0;
                             if (i3 == -1 || d < m3) { m3 = d; i3 = k; }
                         }
                     }
                     for (int k = lane; k < nlive; k += nl) {
-                        const int b = live[k];
-                        if (parent[b] == -1 && label[b] == 2 && (i4 == -1 || bdual[b] < m4)) { m4 = bdual[b]; i4 = k; }
+                        const int b = live_[k];
+                        if (parent_[b] == -1 && label_[b] == 2 && (i4 == -1 || bdual_[b] < m4)) { m4 = bdual_[b]; i4 = k; }
                     }
                     // combine across the lanes: (value, iteration index) lexicographic minima == "first strictly smaller wins"
                     const int NONE = 0x7fffffff;
@@ -664,21 +720,21 @@ struct SqBlossom {
                     coop.min_first(m2, i2, NONE); coop.min_first(m3, i3, NONE); coop.min_first(m4, i4, NONE);
                     int deltatype = 1, deltaedge = -1, deltablossom = -1;
                     double delta = m1;
-                    if (i2 != NONE && m2 < delta) { delta = m2; deltatype = 2; deltaedge = bestedge[i2]; }
-                    if (i3 != NONE && m3 < delta) { delta = m3; deltatype = 3; const int b = i3 < n ? i3 : live[i3 - n]; deltaedge = bestedge[b]; }
-                    if (i4 != NONE && m4 < delta) { delta = m4; deltatype = 4; deltablossom = live[i4]; }
+                    if (i2 != NONE && m2 < delta) { delta = m2; deltatype = 2; deltaedge = bestedge_[i2]; }
+                    if (i3 != NONE && m3 < delta) { delta = m3; deltatype = 3; const int b = i3 < n ? i3 : live_[i3 - n]; deltaedge = bestedge_[b]; }
+                    if (i4 != NONE && m4 < delta) { delta = m4; deltatype = 4; deltablossom = live_[i4]; }
                     if (lane == 0) { red_v[0][0] = delta; red_i[0][0] = deltatype; red_i[0][1] = deltaedge; red_i[0][2] = deltablossom; }
                 }
                 sync();
                 {
                     const double delta = red_v[0][0];
                     for (int v = lane; v < n; v += nl) {
-                        const int lb = label[inblossom[v]];
-                        if (lb == 1) dualvar[v] -= delta; else if (lb == 2) dualvar[v] += delta;
+                        const int lb = label_[inblossom_[v]];
+                        if (lb == 1) dualvar_[v] -= delta; else if (lb == 2) dualvar_[v] += delta;
                     }
                     for (int k = lane; k < nlive; k += nl) {
-                        const int b = live[k];
-                        if (parent[b] == -1) { if (label[b] == 1) bdual[b] += delta; else if (label[b] == 2) bdual[b] -= delta; }
+                        const int b = live_[k];
+                        if (parent_[b] == -1) { if (label_[b] == 1) bdual_[b] += delta; else if (label_[b] == 2) bdual_[b] -= delta; }
                     }
                 }
                 sync();
@@ -720,14 +776,15 @@ struct SqBlossom {
 #ifdef SQ_MWM_PROF
 #ifdef __HIP_DEVICE_COMPILE__
         if (lane == 0 && n >= 140)
-            printf("mwm n=%d m=%d stages=%lld substages=%lld popped=%lld visits=%lld | us: queue %.0f delta %.0f combine %.0f update %.0f act %.0f stageinit %.0f endstage %.0f\n",
-                   n, m, pc[3], pc[2], pc[1], pc[0], pt[0] * 0.01, pt[1] * 0.01, pt[2] * 0.01, pt[3] * 0.01, pt[4] * 0.01, pt[5] * 0.01, pt[6] * 0.01);
+            printf("mwm n=%d m=%d stages=%lld substages=%lld popped=%lld visits=%lld events=%lld passes=%lld | us: events %.0f queue %.0f delta %.0f combine %.0f update %.0f act %.0f stageinit %.0f endstage %.0f\n",
+                   n, m, pc[3], pc[2], pc[1], pc[0], pc[4], pc[5], pt[7] * 0.01, pt[0] * 0.01, pt[1] * 0.01, pt[2] * 0.01, pt[3] * 0.01, pt[4] * 0.01, pt[5] * 0.01, pt[6] * 0.01);
 #endif
 #endif
     }
 
+#undef SQ_LP
     SQ_HD void run()
     {
-        run(0, 1, [] {}, SqCoopSingle());
+        run<false>(0, 1, [] {}, SqCoopSingle(), nullptr);
     }
 };

@@ -238,9 +238,9 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
         SqMatchEdge *le = reinterpret_cast<SqMatchEdge *>(mwm_lds);
         for (int e = lane; e < m; e += 64) le[e] = edges[jp->edge_off + e];
         __syncthreads();
-        if (lane == 0) bl.init(n, m, le, mwm_lds + ebytes, 1);
+        if (lane == 0) { bl.init(n, m, le, mwm_lds + ebytes, 1); bl.origin = mwm_lds; }
         __syncthreads();
-        bl.run(lane, 64, [] { __syncthreads(); }, SqCoopWave());
+        bl.run<true>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), mwm_lds);
         __syncthreads();
         if (!bl.error) {
             for (int q = lane; q < n; q += 64) mate_out[jp->out_off + q] = bl.mate[q];
@@ -251,7 +251,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
     if (lane == 0) bl.init(n, m, edges + jp->edge_off, scratch + jp->scratch_off, 0);
     __syncthreads();
     // lane 0 runs the order-dependent part; all 64 lanes share the O(n) sweeps of every substage
-    bl.run(lane, 64, [] { __syncthreads(); }, SqCoopWave());
+    bl.run<false>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), nullptr);
     __syncthreads();
     for (int q = lane; q < n; q += 64) mate_out[jp->out_off + q] = bl.error ? -2 : bl.mate[q];
 }
