@@ -84,94 +84,130 @@ static void filter_stemset(const sq_batch *b, const SqJob &J, std::vector<BP> pa
     }
 }
 
-// ---- one chunk of matching work: staged (uploads + kernel, asynchronous) and collected later ------
+// ---- one chunk of matching work: staged (kernel launch, asynchronous) and collected later ------
 struct SqAlgoChunk {
     int algo = 0;
     size_t k0 = 0, k1 = 0;                       // jobs[k0, k1) of the caller's list
     std::vector<SqMatchJob> mj;
-    std::vector<SqMatchEdge> me;
     std::vector<std::vector<int>> vid2pos;       // Edmonds: graph vertex -> position
+    SqMatchJob *p_jobs = nullptr;                // pinned staging: job table and edge list (read by the kernels in place)
+    SqMatchEdge *p_edges = nullptr;
+    size_t nedges = 0;
     size_t outints = 0, scratch = 0, bytes = 0;  // device bytes used from the region's base
     int32_t *d_out = nullptr, *d_cnt = nullptr;
     hipStream_t st = nullptr;
 };
 
+namespace {
+struct JobBuild { std::vector<SqMatchEdge> edges; std::vector<int> ids; int n = 0; size_t need = 0, nout = 0; };
+}
+
+// pinned staging buffer `slot` of the batch, at least `bytes` large (grow-only)
+static char *stage_buffer(sq_batch *b, int slot, size_t bytes)
+{
+    if (b->stage_cap[slot] < bytes) {
+        if (b->stage_buf[slot]) { hipStreamSynchronize(slot < 3 && b->side[slot] ? b->side[slot] : b->stream); hipHostFree(b->stage_buf[slot]); }
+        b->stage_buf[slot] = nullptr; b->stage_cap[slot] = 0;
+        const size_t cap = bytes + bytes / 2 + 4096;
+        if (sq_check(hipHostMalloc((void **)&b->stage_buf[slot], cap, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc")) return nullptr;
+        b->stage_cap[slot] = cap;
+    }
+    return b->stage_buf[slot];
+}
+
 // Host part: edges and scratch layout of jobs[k0..) of `algo`, as many as fit into region_bytes (ck.k1, ck.bytes).
-static void algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vector<std::vector<HStem>> &stems, size_t k0,
-                       int algo, size_t region_bytes, SqAlgoChunk &ck)
+// The per-job edge lists are built by the worker pool, then packed into pinned staging buffer `slot`.
+static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vector<std::vector<HStem>> &stems, size_t k0,
+                      int algo, size_t region_bytes, int slot, SqAlgoChunk &ck)
 {
     ck = SqAlgoChunk();
     ck.algo = algo; ck.k0 = k0;
-    std::vector<SqMatchJob> &mj = ck.mj;
-    std::vector<SqMatchEdge> &me = ck.me;
-    size_t scratch = 0, outints = 0, k1 = k0;
-    for (; k1 < jobs.size(); k1++) {
-        const SqJob &J = b->jobs[jobs[k1]];
-        const std::vector<HStem> &st_ = stems[k1];
-        SqMatchJob m;
-        m.edge_off = (int64_t)me.size(); m.pos_off = J.pos_off;
-        std::vector<int> ids;
-        size_t need, nout;
+    const size_t nj = jobs.size() - k0;
+    std::vector<JobBuild> jb(nj);
+    sq_pool(b)->parallel_for((int)nj, [&](int q) {
+        const SqJob &J = b->jobs[jobs[k0 + q]];
+        const std::vector<HStem> &st_ = stems[k0 + q];
+        JobBuild &B = jb[q];
         size_t ncell = 0;
         for (const HStem &s : st_) ncell += (size_t)s.len;
+        B.edges.reserve(ncell);
         if (algo == SQ_ALGO_E) {
             std::vector<int> pos2id(J.n, -1);
             for (const HStem &s : st_) {
                 const double wt = pow(s.bps, 1.7);                   // SQRNalgos.py:101
                 for (int t = 0; t < s.len; t++) {
                     const int v = s.i + t, w = s.j - t;
-                    if (pos2id[v] < 0) { pos2id[v] = (int)ids.size(); ids.push_back(v); }   // node order = first appearance
-                    if (pos2id[w] < 0) { pos2id[w] = (int)ids.size(); ids.push_back(w); }
-                    me.push_back(SqMatchEdge{pos2id[v], pos2id[w], wt});
+                    if (pos2id[v] < 0) { pos2id[v] = (int)B.ids.size(); B.ids.push_back(v); }   // node order = first appearance
+                    if (pos2id[w] < 0) { pos2id[w] = (int)B.ids.size(); B.ids.push_back(w); }
+                    B.edges.push_back(SqMatchEdge{pos2id[v], pos2id[w], wt});
                 }
             }
-            m.n = (int)ids.size(); need = sq_mwm_scratch_bytes(m.n, (int)ncell); nout = (size_t)m.n;
+            B.n = (int)B.ids.size(); B.need = sq_mwm_scratch_bytes(B.n, (int)ncell); B.nout = (size_t)B.n;
         } else {
             for (const HStem &s : st_) {
                 const double wt = algo == SQ_ALGO_H ? pow(s.bps, 1.7) : s.bps;   // SQRNalgos.py:122 / :49
-                for (int t = 0; t < s.len; t++) me.push_back(SqMatchEdge{s.i + t, s.j - t, wt});
+                for (int t = 0; t < s.len; t++) B.edges.push_back(SqMatchEdge{s.i + t, s.j - t, wt});
             }
-            m.n = J.n;
-            need = algo == SQ_ALGO_H ? sq_lsap_scratch_bytes(J.n) : sq_nussinov_scratch_bytes(J.n);
-            nout = algo == SQ_ALGO_H ? (size_t)J.n : 2 * ((size_t)J.n + 4);
+            B.n = J.n;
+            B.need = algo == SQ_ALGO_H ? sq_lsap_scratch_bytes(J.n) : sq_nussinov_scratch_bytes(J.n);
+            B.nout = algo == SQ_ALGO_H ? (size_t)J.n : 2 * ((size_t)J.n + 4);
         }
-        m.nedges = (int32_t)ncell;
-        need = (need + 255) & ~(size_t)255;
-        const size_t fixed = (mj.size() + 1) * sizeof(SqMatchJob) + me.size() * sizeof(SqMatchEdge) +
-                             (outints + nout + mj.size() + 1) * 4 + 4096;
-        if (fixed + scratch + need > region_bytes) { me.resize((size_t)m.edge_off); break; }
-        m.scratch_off = (int64_t)scratch; scratch += need;
-        m.out_off = (int64_t)(algo == SQ_ALGO_N ? outints / 2 : outints); outints += nout;
+        B.need = (B.need + 255) & ~(size_t)255;
+    });
+    std::vector<SqMatchJob> &mj = ck.mj;
+    size_t scratch = 0, outints = 0, nedges = 0, k1 = k0;
+    for (; k1 < jobs.size(); k1++) {
+        JobBuild &B = jb[k1 - k0];
+        SqMatchJob m;
+        m.edge_off = (int64_t)nedges; m.pos_off = b->jobs[jobs[k1]].pos_off;
+        m.n = B.n; m.nedges = (int32_t)B.edges.size();
+        const size_t fixed = (mj.size() + 1) * sizeof(SqMatchJob) + (nedges + B.edges.size()) * sizeof(SqMatchEdge) +
+                             (outints + B.nout + mj.size() + 1) * 4 + 4096;
+        if (fixed + scratch + B.need > region_bytes) break;
+        m.scratch_off = (int64_t)scratch; scratch += B.need;
+        m.out_off = (int64_t)(algo == SQ_ALGO_N ? outints / 2 : outints); outints += B.nout;
+        nedges += B.edges.size();
         mj.push_back(m);
-        ck.vid2pos.push_back(std::move(ids));
+        ck.vid2pos.push_back(std::move(B.ids));
     }
-    ck.k1 = k1; ck.outints = outints; ck.scratch = scratch;
+    ck.k1 = k1; ck.outints = outints; ck.scratch = scratch; ck.nedges = nedges;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t rr = o; o = (o + bytes + 255) & ~(size_t)255; return rr; };
-    take(mj.size() * sizeof(SqMatchJob)); take(me.size() * sizeof(SqMatchEdge) + 16);
+    take(mj.size() * sizeof(SqMatchJob)); take(nedges * sizeof(SqMatchEdge) + 16);
     take(outints * 4 + 16); take(mj.size() * 4 + 16);
     ck.bytes = o + scratch;
+    if (mj.empty()) return 0;
+    // pack into pinned memory: [jobs][edges]
+    const size_t jbytes = (mj.size() * sizeof(SqMatchJob) + 255) & ~(size_t)255;
+    char *pin = stage_buffer(b, slot, jbytes + nedges * sizeof(SqMatchEdge) + 64);
+    if (!pin) return 2;
+    ck.p_jobs = (SqMatchJob *)pin; ck.p_edges = (SqMatchEdge *)(pin + jbytes);
+    memcpy(ck.p_jobs, mj.data(), mj.size() * sizeof(SqMatchJob));
+    sq_pool(b)->parallel_for((int)mj.size(), [&](int q) {
+        const JobBuild &B = jb[q];
+        if (!B.edges.empty()) memcpy(ck.p_edges + mj[q].edge_off, B.edges.data(), B.edges.size() * sizeof(SqMatchEdge));
+    });
+    return 0;
 }
 
-// Device part: uploads + kernel of a built chunk into [region, region + ck.bytes) on stream st.  Nothing is waited for.
+// Device part: kernel of a built chunk into [region, region + ck.bytes) on stream st.  The job table and the edges
+// are read by the kernels straight from the pinned staging buffer (each kernel reads them once, at its start).
+// Nothing is waited for.
 static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t st)
 {
     ck.st = st;
     const std::vector<SqMatchJob> &mj = ck.mj;
-    const std::vector<SqMatchEdge> &me = ck.me;
     const int algo = ck.algo;
     if (mj.empty()) return 0;
     // carve: [jobs][edges][out ints][counts][scratch]
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t rr = o; o = (o + bytes + 255) & ~(size_t)255; return rr; };
-    const size_t o_jobs = take(mj.size() * sizeof(SqMatchJob)), o_edges = take(me.size() * sizeof(SqMatchEdge) + 16);
+    const size_t o_jobs = take(mj.size() * sizeof(SqMatchJob)), o_edges = take(ck.nedges * sizeof(SqMatchEdge) + 16);
     const size_t o_out = take(ck.outints * 4 + 16), o_cnt = take(mj.size() * 4 + 16), o_scr = take(0);
-    SqMatchJob *d_jobs = (SqMatchJob *)(region + o_jobs);
-    SqMatchEdge *d_edges = (SqMatchEdge *)(region + o_edges);
+    const SqMatchJob *d_jobs = ck.p_jobs;
+    const SqMatchEdge *d_edges = ck.p_edges;
     ck.d_out = (int32_t *)(region + o_out); ck.d_cnt = (int32_t *)(region + o_cnt);
     char *d_scr = region + o_scr;
-    HIPCK(hipMemcpyAsync(d_jobs, mj.data(), mj.size() * sizeof(SqMatchJob), hipMemcpyHostToDevice, st));
-    if (!me.empty()) HIPCK(hipMemcpyAsync(d_edges, me.data(), me.size() * sizeof(SqMatchEdge), hipMemcpyHostToDevice, st));
     const int nj = (int)mj.size();
     int maxn = 0, maxm = 0;
     for (const SqMatchJob &m : mj) { maxn = std::max(maxn, m.n); maxm = std::max(maxm, m.nedges); }
@@ -191,6 +227,12 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
         size_t want = SqBlossom::scratch_bytes(maxn, maxm, 1) + (((size_t)maxm * sizeof(SqMatchEdge) + 15) & ~(size_t)15) + 64;
         static bool attr_set = false;
         if (!attr_set) { hipFuncSetAttribute((const void *)sq_mwm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        if (want > 150 * 1024 || getenv("SQ_MWM_NOLDS")) {
+            // some job does not fit LDS and walks its edges in place: give those a device copy of the edge list
+            SqMatchEdge *dev_edges = (SqMatchEdge *)(region + o_edges);
+            HIPCK(hipMemcpyAsync(dev_edges, ck.p_edges, ck.nedges * sizeof(SqMatchEdge), hipMemcpyHostToDevice, st));
+            d_edges = dev_edges;
+        }
         want = std::min<size_t>(want, 150 * 1024);             // jobs that do not fit run in global memory
         if (getenv("SQ_MWM_NOLDS")) want = 0;
         hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), want, st, d_jobs, d_edges, d_scr, ck.d_out, (int)want);
@@ -278,7 +320,8 @@ int sq_run_algo(sq_batch *b, const std::vector<int> &jobs, int algo, int levelli
     size_t k0 = 0;
     while (k0 < jobs.size()) {
         SqAlgoChunk ck;
-        algo_build(b, jobs, stems, k0, algo, arena, ck);
+        r = algo_build(b, jobs, stems, k0, algo, arena, 3, ck);
+        if (r) return r;
         if (ck.k1 == k0) { sq_set_error("sequence too long for the matching scratch"); return -3; }
         r = algo_launch(b, ck, (char *)b->scan.cands, b->stream);
         if (r) return r;
@@ -313,10 +356,13 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
     // Edmonds is the long pole: its AnnotateStems pass and launch go first, alone; the other algorithms share
     // one more pass.  Everything that is staged runs on side streams while the caller proceeds.
     auto stage = [&](SqAlgoAsync::Item &it) -> int {
+        const double ts0 = sq_now();
+        struct Rep { int algo; double t0; ~Rep() { if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] stage algo %d: %.3f ms\n", algo, (sq_now() - t0) * 1e3); } } rep{it.algo, ts0};
         if (!async || sidx >= 3) return 0;
         const int64_t free_rec = half - b->cand_reserved;
         if (free_rec <= 0) return 0;
-        algo_build(b, it.jobs, it.stems, 0, it.algo, (size_t)free_rec * sizeof(SqCand), it.ck);
+        int rb = algo_build(b, it.jobs, it.stems, 0, it.algo, (size_t)free_rec * sizeof(SqCand), sidx, it.ck);
+        if (rb) return rb;
         if (it.ck.k1 != it.jobs.size()) { it.ck = SqAlgoChunk(); return 0; }   // does not fit as one chunk: synchronous later
         if (!b->side[sidx]) { if (sq_check(hipStreamCreateWithFlags(&b->side[sidx], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
         const int64_t used_rec = (int64_t)((it.ck.bytes + 256 + sizeof(SqCand) - 1) / sizeof(SqCand));
@@ -334,6 +380,7 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
     if (pa->items[0].algo == SQ_ALGO_E) {
         int r = algo_annotate(b, pa->items[0].jobs, pa->items[0].stems);
         if (r) return r;
+        if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] annotate E %.3f ms\n", (sq_now() - ta0) * 1e3);
         r = stage(pa->items[0]);
         if (r) return r;
         first_rest = 1;
@@ -381,8 +428,8 @@ int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<J
         const size_t arena = (size_t)b->cand_records * sizeof(SqCand);
         while (k0 < it.jobs.size() && !r) {
             SqAlgoChunk ck;
-            algo_build(b, it.jobs, it.stems, k0, it.algo, arena, ck);
-            if (ck.k1 == k0) { sq_set_error("sequence too long for the matching scratch"); r = -3; }
+            r = algo_build(b, it.jobs, it.stems, k0, it.algo, arena, 3, ck);
+            if (!r && ck.k1 == k0) { sq_set_error("sequence too long for the matching scratch"); r = -3; }
             if (!r) r = algo_launch(b, ck, (char *)b->scan.cands, b->stream);
             if (!r) r = algo_collect(b, it.jobs, it.stems, ck, levellimit_opt, js.sets);
             k0 = ck.k1;

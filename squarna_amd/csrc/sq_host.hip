@@ -379,6 +379,7 @@ extern "C" void sq_batch_destroy(sq_batch *b)
     if (b->h_ctr) hipHostFree(b->h_ctr);
     if (b->h_seq) hipHostFree(b->h_seq);
     delete b->pool;
+    for (int k = 0; k < 4; k++) if (b->stage_buf[k]) hipHostFree(b->stage_buf[k]);
     if (b->h_out) hipHostFree(b->h_out);
     for (int k = 0; k < 3; k++) if (b->side[k]) { hipStreamSynchronize(b->side[k]); hipStreamDestroy(b->side[k]); }
     for (auto &p : b->prof) {
@@ -749,11 +750,11 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
     for (int s = 0; s < S; s++) cnt[s + 1] += cnt[s];
     std::vector<uint32_t> idx(nout), fillp(cnt.begin(), cnt.end() - 1);
     for (uint32_t k = 0; k < nout; k++) idx[fillp[ho[k].st]++] = k;
-    for (int s = 0; s < S; s++) {
+    auto post_one = [&](int s) {
         uint32_t *p0 = idx.data() + cnt[s], *p1 = idx.data() + cnt[s + 1];
         std::vector<HStem> &res = out[lo + s];
         res.clear();
-        if (p0 == p1) continue;
+        if (p0 == p1) return;
         auto mk = [&](uint32_t k) {
             const SqOut &o = ho[k];
             const int i0 = (int)(o.key & 0xFFFFu), sdiag = (int)(o.key >> 16);
@@ -761,8 +762,9 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
         };
         if (mode == 1) {                                    // emission order: (s, i) ascending
             std::sort(p0, p1, [&](uint32_t x, uint32_t y) { return ho[x].key < ho[y].key; });
+            res.reserve((size_t)(p1 - p0));
             for (uint32_t *p = p0; p < p1; p++) res.push_back(mk(*p));
-            continue;
+            return;
         }
         // ChooseStems (SQRNdbnseq.py:754-789): stable descending sort == (fin desc, emission key asc)
         std::sort(p0, p1, [&](uint32_t x, uint32_t y) {
@@ -776,7 +778,10 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
             for (const HStem &r : res) if (!shares_base(cand, r)) { all_conf = false; break; }
             if (all_conf) res.push_back(cand);
         }
-    }
+    };
+    // structures are independent: big rounds (the AnnotateStems passes of E/H/N) share the sorting among the pool
+    if (nout >= 16384) sq_pool(b)->parallel_for(S, post_one);
+    else for (int s = 0; s < S; s++) post_one(s);
     return 0;
 }
 
@@ -911,6 +916,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     if (!b || !opts) { sq_set_error("bad argument"); return -1; }
     const sq_fold_opts &o = *opts;
     if (o.poollim < 1) { sq_set_error("poollim must be positive"); return -1; }
+    struct FoldTimer { double t0; ~FoldTimer() { if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_fold] total %.3f ms (incl. teardown)\n", (now_s() - t0) * 1e3); } } fold_timer{now_s()};
     // a-1, once per job and per fold (:1076): never reused from an earlier call, a fold is the whole path
     int r = scan_version() == 6 ? fill_impl(b, 0) : fill_impl(b, 1);
     if (r) return r;
