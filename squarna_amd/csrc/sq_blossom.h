@@ -127,7 +127,7 @@ struct SqBlossom {
         return ints * 4 + ((size_t)n + N2) * 8 + N2 + (size_t)m + 256;
     }
 
-    SQ_HD void init(int n_, int m_, const SqMatchEdge *edges, char *scratch, int tight = 0)
+    SQ_HD void init(int n_, int m_, const SqMatchEdge *edges, char *scratch, int tight = 0, bool csr = true)
     {
         n = n_; m = m_; E = edges; error = 0;
         const int N2 = 2 * n + 2;
@@ -146,6 +146,7 @@ struct SqBlossom {
         tmp_leaves = take_i(N2); tmp_stack = take_i(N2); tmp_path = take_i(2 * (size_t)N2); tmp_edges = take_i(2 * (size_t)N2);
         beto = take_i(N2); beto_keys = take_i(N2); frame_cap = frame_ints(n, tight); frames = take_i((size_t)frame_cap);
         label = (int8_t *)p; p += N2; allow = (uint8_t *)p; p += m;
+        if (!csr) return;                                       // the caller builds it with build_csr()
         // adjacency in insertion order: edge e = (v, w) appends w to adj[v] and v to adj[w]
         for (int v = 0; v <= n; v++) adj_off[v] = 0;
         for (int e = 0; e < m; e++) { adj_off[E[e].v + 1]++; adj_off[E[e].w + 1]++; }
@@ -156,6 +157,31 @@ struct SqBlossom {
             adj[sv] = 2 * e;     adjv[sv] = E[e].w; adjw[sv] = E[e].weight;
             adj[sw] = 2 * e + 1; adjv[sw] = E[e].v; adjw[sw] = E[e].weight;
         }
+    }
+
+    // The same adjacency, built by all lanes: every lane owns the vertices v = lane, lane + nl, ... and walks the
+    // edge list once to count and once to fill, so each list keeps the edge order without atomics.
+    template <class Sync>
+    SQ_HD void build_csr(int lane, int nl, Sync sync)
+    {
+        for (int v = lane; v < n; v += nl) {
+            int deg = 0;
+            for (int e = 0; e < m; e++) deg += (E[e].v == v) + (E[e].w == v);
+            adj_off[v + 1] = deg;
+        }
+        if (lane == 0) adj_off[0] = 0;
+        sync();
+        if (lane == 0) for (int v = 0; v < n; v++) adj_off[v + 1] += adj_off[v];
+        sync();
+        for (int v = lane; v < n; v += nl) {
+            int pos = adj_off[v];
+            for (int e = 0; e < m; e++) {
+                const SqMatchEdge ed = E[e];
+                if (ed.v == v) { adj[pos] = 2 * e;     adjv[pos] = ed.w; adjw[pos] = ed.weight; pos++; }
+                if (ed.w == v) { adj[pos] = 2 * e + 1; adjv[pos] = ed.v; adjw[pos] = ed.weight; pos++; }
+            }
+        }
+        sync();
     }
 
     SQ_HD int tail(int de) const { return (de & 1) ? E[de >> 1].w : E[de >> 1].v; }
@@ -592,12 +618,13 @@ struct SqBlossom {
                 // smaller slack wins == lexicographic (slack, position) minimum), so they are applied in parallel;
                 // the state-changing neighbour is then handled by lane 0 with the sequential code and the rest of
                 // the list is re-classified.
-                for (;;) {
-                    sync();
-                    if (qn == 0 || f_augmented || error) break;
-                    const int v = queue_[qn - 1];
-                    sync();
-                    if (lane == 0) qn--;
+                // the queue length lives in a register of every lane (the queue itself only changes inside the
+                // lane-0 sections, which are bracketed by syncs and followed by a reload)
+                sync();
+                int qn_r = qn;
+                bool stopq = f_augmented || error;
+                while (qn_r > 0 && !stopq) {
+                    const int v = queue_[--qn_r];
                     int a0 = adj_off_[v];
                     const int aend = adj_off_[v + 1];
 #ifdef SQ_MWM_PROF
@@ -647,6 +674,7 @@ struct SqBlossom {
                             }
                         }
                         if (f >= nl) { a0 += nl; continue; }
+                        if (lane == 0) qn = qn_r;
                         sync();
 #ifdef SQ_MWM_PROF
                         long long _te = 0;
@@ -682,10 +710,13 @@ struct SqBlossom {
 #ifdef SQ_MWM_PROF
                         if (lane == 0) pt[7] += wall_clock64() - _te;
 #endif
-                        if (f_augmented || error) break;
+                        qn_r = qn;
+                        stopq = f_augmented || error;
+                        if (stopq) break;
                         a0 += f + 1;
                     }
                 }
+                if (lane == 0) qn = qn_r;
                 sync();
 #ifdef SQ_MWM_PROF
                 if (lane == 0) { const long long _n = wall_clock64(); pt[0] += _n - _tp; _tp = _n; }

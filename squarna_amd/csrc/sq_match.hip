@@ -238,8 +238,9 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
         SqMatchEdge *le = reinterpret_cast<SqMatchEdge *>(mwm_lds);
         for (int e = lane; e < m; e += 64) le[e] = edges[jp->edge_off + e];
         __syncthreads();
-        if (lane == 0) { bl.init(n, m, le, mwm_lds + ebytes, 1); bl.origin = mwm_lds; }
+        if (lane == 0) { bl.init(n, m, le, mwm_lds + ebytes, 1, false); bl.origin = mwm_lds; }
         __syncthreads();
+        bl.build_csr(lane, 64, [] { __syncthreads(); });
         bl.run<true>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), mwm_lds);
         __syncthreads();
         if (!bl.error) {
@@ -248,8 +249,9 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
         }
         __syncthreads();
     }
-    if (lane == 0) bl.init(n, m, edges + jp->edge_off, scratch + jp->scratch_off, 0);
+    if (lane == 0) bl.init(n, m, edges + jp->edge_off, scratch + jp->scratch_off, 0, false);
     __syncthreads();
+    bl.build_csr(lane, 64, [] { __syncthreads(); });
     // lane 0 runs the order-dependent part; all 64 lanes share the O(n) sweeps of every substage
     bl.run<false>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), nullptr);
     __syncthreads();
