@@ -920,7 +920,13 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // a-1, once per job and per fold (:1076): never reused from an earlier call, a fold is the whole path
     int r = scan_version() == 6 ? fill_impl(b, 0) : fill_impl(b, 1);
     if (r) return r;
-    std::vector<JobPool> pools(b->njobs);
+    // (the pools -- thousands of small vectors -- are torn down by a helper thread after the fold returns)
+    auto *pools_owner = new std::vector<JobPool>(b->njobs);
+    struct PoolsDrop {
+        std::vector<JobPool> *p;
+        ~PoolsDrop() { std::thread([q = p] { delete q; }).detach(); }
+    } pools_drop{pools_owner};
+    std::vector<JobPool> &pools = *pools_owner;
     std::vector<uint32_t> algos(b->njobs);
     for (int j = 0; j < b->njobs; j++) {
         const sq_paramset &ps = b->psets[b->job_pset[j]];
