@@ -93,6 +93,7 @@ struct SqBlossom {
     int8_t *label;            // 0 none, 1 S, 2 T, 5 scanned mark
     int *labeledge, *inblossom, *parent, *base, *bestedge;
     double *dualvar, *bdual;
+    double *bslack;           // bslack[x] == slack(bestedge[x]) under the current duals whenever bestedge[x] != -1
     uint8_t *allow;           // per undirected edge
     int *queue; int qn, qcap;
     // blossoms
@@ -124,7 +125,7 @@ struct SqBlossom {
                       + 2 * (size_t)n + 2                       // live, freeb
                       + 2 * N2 + 4 * N2 + 2 * N2                // tmp_leaves, tmp_stack | tmp_path, tmp_edges (2 each) | beto, beto_keys
                       + (size_t)frame_ints(n, tight);           // frames
-        return ints * 4 + ((size_t)n + N2) * 8 + N2 + (size_t)m + 256;
+        return ints * 4 + ((size_t)n + 2 * N2) * 8 + N2 + (size_t)m + 256;
     }
 
     SQ_HD void init(int n_, int m_, const SqMatchEdge *edges, char *scratch, int tight = 0, bool csr = true)
@@ -134,7 +135,7 @@ struct SqBlossom {
         char *p = scratch;
         auto take_d = [&](size_t k) { p = (char *)(((uintptr_t)p + 7) & ~(uintptr_t)7); double *r = (double *)p; p += k * 8; return r; };
         auto take_i = [&](size_t k) { p = (char *)(((uintptr_t)p + 3) & ~(uintptr_t)3); int *r = (int *)p; p += k * 4; return r; };
-        dualvar = take_d(n); bdual = take_d(N2); adjw = take_d(2 * (size_t)m);
+        dualvar = take_d(n); bdual = take_d(N2); bslack = take_d(N2); adjw = take_d(2 * (size_t)m);
         adj_off = take_i(n + 1); adj = take_i(2 * (size_t)m); adjv = take_i(2 * (size_t)m);
         mate = take_i(n); mate_de = take_i(n);
         labeledge = take_i(N2); parent = take_i(N2); base = take_i(N2); bestedge = take_i(N2); inblossom = take_i(n);
@@ -343,7 +344,7 @@ struct SqBlossom {
             const double ks = slack(kde);
             if (mybest == -1 || ks < mybestslack) { mybest = kde; mybestslack = ks; }
         }
-        bestedge[b] = mybest;
+        bestedge[b] = mybest; bslack[b] = mybestslack;
     }
 
     SQ_HD void remove_live(int b)
@@ -549,7 +550,7 @@ struct SqBlossom {
         int *const labeledge_ = SQ_LP(labeledge), *const bestedge_ = SQ_LP(bestedge);
         int8_t *const label_ = SQ_LP(label);
         uint8_t *const allow_ = SQ_LP(allow);
-        double *const dualvar_ = SQ_LP(dualvar), *const bdual_ = SQ_LP(bdual);
+        double *const dualvar_ = SQ_LP(dualvar), *const bdual_ = SQ_LP(bdual), *const bslack_ = SQ_LP(bslack);
         const int *const parent_ = SQ_LP(parent), *const live_ = SQ_LP(live);
         auto slack_ = [&](int de) -> double {
             const SqMatchEdge ed = E_[de >> 1];
@@ -649,8 +650,8 @@ struct SqBlossom {
                         const bool was_allowed = allow_[de >> 1] != 0;
                         const int be_w = bestedge_[w];
                         const int lbw = label_[bw];
-                        const double s_bew = slack_(be_w >= 0 ? be_w : de);  // slack(bestedge[w]) (unused when there is none)
-                        const double s_bebv = slack_(be_bv >= 0 ? be_bv : de);
+                        const double s_bew = bslack_[w];                      // slack(bestedge[w]) (unused when there is none)
+                        const double s_bebv = bslack_[bv];
                         const double ks = dv + dw - 2 * wt;                  // slack(de): dualvar[v] + dualvar[w] - 2 weight
                         const bool cons = live && w != v && bw != bv;       // :  `if w == v: continue`, same blossom: continue
                         const bool becomes = cons && !was_allowed && ks <= 0;
@@ -664,13 +665,13 @@ struct SqBlossom {
                         if (lane < f && live) {
                             if (becomes) allow_[de >> 1] = 1;
                             if (cat == 2) { label_[w] = 2; labeledge_[w] = de; }
-                            else if (cat == 3) { if (be_w == -1 || ks < s_bew) bestedge_[w] = de; }
+                            else if (cat == 3) { if (be_w == -1 || ks < s_bew) { bestedge_[w] = de; bslack_[w] = ks; } }
                         }
                         if (coop.first_true(lane < f && cat == 4, nl) < nl) {      // somebody competes for bestedge[bv]
                             double mv = ks; int mi = (lane < f && cat == 4) ? lane : nl;
                             coop.min_first(mv, mi, nl);
                             if (lane == 0) {
-                                if (be_bv == -1 || mv < s_bebv) bestedge_[bv] = adj_[a0 + mi];
+                                if (be_bv == -1 || mv < s_bebv) { bestedge_[bv] = adj_[a0 + mi]; bslack_[bv] = mv; }
                             }
                         }
                         if (f >= nl) { a0 += nl; continue; }
@@ -700,9 +701,9 @@ struct SqBlossom {
                                         label[w1] = 2; labeledge[w1] = de1;
                                     }
                                 } else if (label[bw1] == 1) {
-                                    if (bestedge[bv1] == -1 || kslack < slack(bestedge[bv1])) bestedge[bv1] = de1;
+                                    if (bestedge[bv1] == -1 || kslack < slack(bestedge[bv1])) { bestedge[bv1] = de1; bslack[bv1] = kslack; }
                                 } else if (label[w1] == 0) {
-                                    if (bestedge[w1] == -1 || kslack < slack(bestedge[w1])) bestedge[w1] = de1;
+                                    if (bestedge[w1] == -1 || kslack < slack(bestedge[w1])) { bestedge[w1] = de1; bslack[w1] = kslack; }
                                 }
                             }
                         }
@@ -729,14 +730,14 @@ struct SqBlossom {
                     for (int v = lane; v < n; v += nl) {
                         if (dualvar_[v] < m1) m1 = dualvar_[v];
                         if (label_[inblossom_[v]] == 0 && bestedge_[v] != -1) {
-                            const double d = slack_(bestedge_[v]);
+                            const double d = bslack_[v];
                             if (i2 == -1 || d < m2) { m2 = d; i2 = v; }
                         }
                     }
                     for (int k = lane; k < n + nlive; k += nl) {   // `for b in blossomparent`: vertices, then blossoms
                         const int b = k < n ? k : live_[k - n];
                         if (parent_[b] == -1 && label_[b] == 1 && bestedge_[b] != -1) {
-                            const double d = slack_(bestedge_[b]) / 2.0;
+                            const double d = bslack_[b] / 2.0;
                             if (i3 == -1 || d < m3) { m3 = d; i3 = k; }
                         }
                     }
@@ -767,6 +768,13 @@ struct SqBlossom {
                         const int b = live_[k];
                         if (parent_[b] == -1) { if (label_[b] == 1) bdual_[b] += delta; else if (label_[b] == 2) bdual_[b] -= delta; }
                     }
+                }
+                sync();
+                // the duals moved: refresh the cached slacks of the best edges (vertices, then live blossoms)
+                for (int k = lane; k < n + nlive; k += nl) {
+                    const int x = k < n ? k : live_[k - n];
+                    const int be = bestedge_[x];
+                    if (be != -1) bslack_[x] = slack_(be);
                 }
                 sync();
 #ifdef SQ_MWM_PROF
