@@ -36,7 +36,7 @@ struct SView {
 // (re)build strands + levels of a structure from its stems
 void sq_build_strands(HStruct &s);
 // child = parent + one stem, strands/levels maintained incrementally
-void sq_extend_struct(const HStruct &parent, const HStem &stem, HStruct &child);
+void sq_extend_struct(const HStruct &parent, const HStem &stem, HStruct &child, bool take_parent = false);
 
 struct SeqResult {        // SQRNdbnseq return tuple of one sequence (SQRNdbnseq.py:1285-1286)
     struct Pred {

@@ -592,14 +592,21 @@ void sq_build_strands(HStruct &s)
     }
 }
 
-void sq_extend_struct(const HStruct &parent, const HStem &stem, HStruct &child)
+// take_parent: the parent is dead after this child (its last one): its vectors are moved instead of copied
+void sq_extend_struct(const HStruct &parent, const HStem &stem, HStruct &child, bool take_parent)
 {
     child.job = parent.job;
-    child.stems.reserve(parent.stems.size() + 1);
-    child.stems = parent.stems;
+    if (take_parent) {
+        HStruct &p = const_cast<HStruct &>(parent);
+        child.stems = std::move(p.stems);
+        child.strands = std::move(p.strands);
+    } else {
+        child.stems.reserve(parent.stems.size() + 1);
+        child.stems = parent.stems;
+        child.strands.reserve(parent.strands.size() + 2);
+        child.strands = parent.strands;
+    }
     child.stems.push_back(stem);
-    child.strands.reserve(parent.strands.size() + 2);
-    child.strands = parent.strands;
     const SqStrand l{(int16_t)stem.i, (int16_t)stem.len, (int16_t)stem.j, 1, 1};
     const SqStrand r{(int16_t)(stem.j - stem.len + 1), (int16_t)stem.len, (int16_t)(stem.i + stem.len - 1), 1, 0};
     auto cmp = [](const SqStrand &x, const SqStrand &y) { return x.start < y.start; };
@@ -607,7 +614,7 @@ void sq_extend_struct(const HStruct &parent, const HStem &stem, HStruct &child)
     child.strands.insert(std::upper_bound(child.strands.begin(), child.strands.end(), r, cmp), r);
     child.anycross = parent.anycross;
     if (!child.anycross)
-        for (const HStem &t : parent.stems) if (stems_cross(t, stem)) { child.anycross = true; break; }
+        for (size_t k = 0; k + 1 < child.stems.size(); k++) if (stems_cross(child.stems[k], stem)) { child.anycross = true; break; }
     if (child.anycross) {                                  // levels can change globally: full rule
         std::vector<int> level;
         sq_stem_levels(child.stems, level);
@@ -993,10 +1000,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 const size_t stopper = P.cursize >= (size_t)o.poollim ? 1 : news.size();
                 for (size_t k = 0; k < stopper; k++) {
                     next[j].emplace_back();
-                    sq_extend_struct(parent, news[k], next[j].back());
+                    sq_extend_struct(parent, news[k], next[j].back(), k + 1 == stopper);   // the last child inherits the vectors
                 }
             } else {
-                P.fin.push_back(parent.stems);
+                P.fin.push_back(std::move(const_cast<HStruct &>(parent).stems));   // the structure is final and leaves the pool
             }
         }
         for (int j = 0; j < b->njobs; j++) pools[j].cur.swap(next[j]);
