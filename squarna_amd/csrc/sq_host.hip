@@ -526,19 +526,21 @@ void sq_stem_levels(const std::vector<HStem> &stems, std::vector<int> &level)
     const int T = (int)stems.size();
     level.assign(T, 1);
     if (T < 2) return;
-    std::vector<int> cc(T, 0);
+    // scratch kept per thread: this runs once per new structure per round, allocation-free after warm-up
+    static thread_local std::vector<int> cc, order, grp, gsize, gord, rank;
+    cc.assign(T, 0);
     bool any = false;
     for (int a = 0; a < T; a++)
-        for (int b = 0; b < T; b++)
-            if (a != b && stems_cross(stems[a], stems[b])) { cc[a] += stems[b].len; any = true; }
+        for (int b = a + 1; b < T; b++)
+            if (stems_cross(stems[a], stems[b])) { cc[a] += stems[b].len; cc[b] += stems[a].len; any = true; }
     if (!any) return;                                       // one group holds everything
-    std::vector<int> order(T);
+    order.resize(T);
     for (int a = 0; a < T; a++) order[a] = a;
     std::sort(order.begin(), order.end(), [&](int a, int b) {   // :125 key (cross_count, p[0])
         if (cc[a] != cc[b]) return cc[a] < cc[b];
         return stems[a].i < stems[b].i;
     });
-    std::vector<int> grp(T, -1), gsize;
+    grp.assign(T, -1); gsize.clear();
     for (int t = 0; t < T; t++) {                           // :130-136 first fit
         const int p = order[t];
         int placed = -1;
@@ -551,10 +553,10 @@ void sq_stem_levels(const std::vector<HStem> &stems, std::vector<int> &level)
         if (placed < 0) { placed = (int)gsize.size(); gsize.push_back(0); }
         grp[p] = placed; gsize[placed] += stems[p].len;
     }
-    std::vector<int> gord(gsize.size());
+    gord.resize(gsize.size());
     for (size_t g = 0; g < gsize.size(); g++) gord[g] = (int)g;
     std::stable_sort(gord.begin(), gord.end(), [&](int a, int b) { return gsize[a] > gsize[b]; });   // :139
-    std::vector<int> rank(gsize.size());
+    rank.resize(gsize.size());
     for (size_t r = 0; r < gord.size(); r++) rank[gord[r]] = (int)r;
     for (int a = 0; a < T; a++) level[a] = rank[grp[a]] + 1;
 }
@@ -616,7 +618,7 @@ void sq_extend_struct(const HStruct &parent, const HStem &stem, HStruct &child, 
     if (!child.anycross)
         for (size_t k = 0; k + 1 < child.stems.size(); k++) if (stems_cross(child.stems[k], stem)) { child.anycross = true; break; }
     if (child.anycross) {                                  // levels can change globally: full rule
-        std::vector<int> level;
+        static thread_local std::vector<int> level;
         sq_stem_levels(child.stems, level);
         set_levels(child, level);
     }
@@ -910,6 +912,7 @@ extern "C" int sq_colmatrix_select(const double *d_matrix, int32_t L, double thr
 namespace {
 struct JobPool {
     std::vector<HStruct> cur;                // curstemsets
+    std::vector<HStruct> nxt;                // next round's curstemsets (kept between rounds: no reallocation)
     std::vector<std::vector<HStem>> fin;     // finstemsets (greedy part)
     double cursubopt = 0, suboptinc = 0, suboptmax = 0, maxstemnum = 0;
     size_t cursize = 1;
@@ -990,23 +993,43 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         if (round.empty()) break;
         { const double t0 = now_s(); r = sq_run_round(b, round, 0, res); tround += now_s() - t0; nrounds++; }
         if (r) return r;
-        std::vector<std::vector<HStruct>> next(b->njobs);
-        for (size_t q = 0; q < round.size(); q++) {         // :1179-1196, in order
-            const int j = owner[q];
-            JobPool &P = pools[j];
-            const std::vector<HStem> &news = res[q];
-            const HStruct &parent = *round[q].st;
-            if (!news.empty()) {
-                const size_t stopper = P.cursize >= (size_t)o.poollim ? 1 : news.size();
-                for (size_t k = 0; k < stopper; k++) {
-                    next[j].emplace_back();
-                    sq_extend_struct(parent, news[k], next[j].back(), k + 1 == stopper);   // the last child inherits the vectors
+        // :1179-1196.  The entries of one job are contiguous in `round` and only touch that job's pool, so jobs
+        // are independent; per job the entries are still handled in order.  Big rounds are shared among the
+        // worker pool in contiguous slices (children mostly reuse their parent's storage: no allocator traffic).
+        auto grow = [&](size_t q0, size_t q1) {
+            for (size_t q = q0; q < q1; q++) {
+                const int j = owner[q];
+                JobPool &P = pools[j];
+                const std::vector<HStem> &news = res[q];
+                const HStruct &parent = *round[q].st;
+                if (!news.empty()) {
+                    const size_t stopper = P.cursize >= (size_t)o.poollim ? 1 : news.size();
+                    for (size_t k = 0; k < stopper; k++) {
+                        P.nxt.emplace_back();
+                        sq_extend_struct(parent, news[k], P.nxt.back(), k + 1 == stopper);   // the last child inherits the vectors
+                    }
+                } else {
+                    P.fin.push_back(std::move(const_cast<HStruct &>(parent).stems));   // the structure is final and leaves the pool
                 }
-            } else {
-                P.fin.push_back(std::move(const_cast<HStruct &>(parent).stems));   // the structure is final and leaves the pool
             }
-        }
-        for (int j = 0; j < b->njobs; j++) pools[j].cur.swap(next[j]);
+            for (size_t q = q0; q < q1; q++)
+                if (q == q0 || owner[q] != owner[q - 1]) {   // once per job of the slice
+                    JobPool &P = pools[owner[q]];
+                    P.cur.swap(P.nxt);
+                    P.nxt.clear();                          // (capacity stays)
+                }
+        };
+        static const size_t par_min = getenv("SQ_GROW_PAR") ? (size_t)atol(getenv("SQ_GROW_PAR")) : 4096;
+        if (round.size() >= par_min) {
+            const int nsl = sq_pool(b)->size() * 4;
+            std::vector<size_t> cut(nsl + 1);
+            for (int t = 0; t <= nsl; t++) {
+                size_t q = round.size() * (size_t)t / (size_t)nsl;
+                while (q > 0 && q < round.size() && owner[q] == owner[q - 1]) q++;   // slices end on job boundaries
+                cut[t] = q;
+            }
+            sq_pool(b)->parallel_for(nsl, [&](int t) { if (cut[t] < cut[t + 1]) grow(cut[t], cut[t + 1]); });
+        } else grow(0, round.size());
     }
     const double tloop = now_s() - tfold0;
     {
