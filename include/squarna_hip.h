@@ -197,10 +197,11 @@ SQ_API int64_t sq_result_evals(const sq_batch *b, int32_t seq);
 SQ_API int sq_align_accumulate(sq_batch *b, int32_t njob, const int32_t *job_ids, const int32_t *col_off,
                                const int32_t *cols, int32_t L, double *d_matrix);
 /* Cells (v, w) of a device L x L fp64 matrix with w - v >= minspan and value >= threshold
- * (MatrixToDBNs' candidates, SQRNdbnali.py:127-148): flat indices v*L+w and values to HOST arrays,
- * unordered; *count = number found (may exceed cap: then only cap were stored).  Synchronises. */
+ * (MatrixToDBNs' candidates, SQRNdbnali.py:127-148).  All buffers are caller-owned DEVICE memory:
+ * d_idx[cap] (flat indices v*L+w), d_val[cap], d_count[1] (zeroed here; may end up > cap, then only
+ * the first cap hits were stored).  Unordered.  Asynchronous on hip_stream. */
 SQ_API int sq_colmatrix_select(const double *d_matrix, int32_t L, double threshold, int32_t minspan,
-                               int64_t *idx_out, double *val_out, int64_t cap, int64_t *count, void *hip_stream);
+                               int64_t *d_idx, double *d_val, int64_t cap, uint64_t *d_count, void *hip_stream);
 
 /* ---- measurement ------------------------------------------------------------
  * Kernel ids: 0 fill, 1 state, 2 stem_scan, 3 stem_score.  When enabled, every

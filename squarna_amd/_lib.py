@@ -108,7 +108,7 @@ def load():
                                C.c_void_p]
     L.sq_align_accumulate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.sq_colmatrix_select.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
-                                      C.POINTER(C.c_int64), C.c_void_p]
+                                      C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

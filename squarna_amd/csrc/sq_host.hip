@@ -882,30 +882,15 @@ extern "C" int sq_align_accumulate(sq_batch *b, int32_t njob, const int32_t *job
 }
 
 extern "C" int sq_colmatrix_select(const double *d_matrix, int32_t L, double threshold, int32_t minspan,
-                                   int64_t *idx_out, double *val_out, int64_t cap, int64_t *count, void *hip_stream)
+                                   int64_t *d_idx, double *d_val, int64_t cap, uint64_t *d_count, void *hip_stream)
 {
-    if (!d_matrix || L <= 0 || cap < 0 || !count || (cap && (!idx_out || !val_out))) { sq_set_error("bad argument"); return -1; }
+    if (!d_matrix || L <= 0 || cap < 0 || !d_count || (cap && (!d_idx || !d_val))) { sq_set_error("bad argument"); return -1; }
     hipStream_t st = (hipStream_t)hip_stream;
-    char *d = nullptr;                                     // [count][idx cap][val cap]; a result list, not workspace
-    const size_t bytes = 16 + (size_t)cap * 16;
-    HIPCK(hipMallocAsync((void **)&d, bytes, st));
-    HIPCK(hipMemsetAsync(d, 0, 16, st));
+    HIPCK(hipMemsetAsync(d_count, 0, 8, st));
     const int64_t total = (int64_t)L * L;
     hipLaunchKernelGGL(sq_colselect_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, st,
-                       d_matrix, L, threshold, minspan, (long long *)(d + 16), (double *)(d + 16 + (size_t)cap * 8),
-                       (long long)cap, (unsigned long long *)d);
-    int r = sq_check(hipGetLastError(), "sq_colselect_kernel");
-    unsigned long long n = 0;
-    if (!r) r = sq_check(hipMemcpyAsync(&n, d, 8, hipMemcpyDeviceToHost, st), "count");
-    if (!r) r = sq_check(hipStreamSynchronize(st), "sync");
-    const int64_t got = (int64_t)std::min<unsigned long long>(n, (unsigned long long)cap);
-    if (!r && got) {
-        r = sq_check(hipMemcpy(idx_out, d + 16, (size_t)got * 8, hipMemcpyDeviceToHost), "idx");
-        if (!r) r = sq_check(hipMemcpy(val_out, d + 16 + (size_t)cap * 8, (size_t)got * 8, hipMemcpyDeviceToHost), "val");
-    }
-    hipFreeAsync(d, st);
-    *count = (int64_t)n;
-    return r;
+                       d_matrix, L, threshold, minspan, (long long *)d_idx, d_val, (long long)cap, (unsigned long long *)d_count);
+    return sq_check(hipGetLastError(), "sq_colselect_kernel");
 }
 
 // ---- a-7: greedy pool loop for every job at once (SQRNdbnseq.py:1102-1199) ----------------------

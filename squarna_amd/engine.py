@@ -447,20 +447,24 @@ class HipEngine:
     def matrix_cells(self, matrix, threshold, minspan=4):
         """(flat indices, values) of the upper cells >= threshold with span >= minspan of a device matrix,
         sorted by flat index (MatrixToDBNs' candidates, SQRNdbnali.py:127-148)."""
+        import torch
         Lcols = int(matrix.shape[0])
         cap = 1 << 16
-        while True:
-            idx = np.zeros(cap, np.int64)
-            val = np.zeros(cap, np.float64)
-            cnt = C.c_int64(0)
+        stream = torch.cuda.current_stream(matrix.device)
+        while True:                                                # result buffers are torch tensors (caller-owned)
+            idx = torch.empty(cap, dtype=torch.int64, device=matrix.device)
+            val = torch.empty(cap, dtype=torch.float64, device=matrix.device)
+            cnt = torch.zeros(1, dtype=torch.int64, device=matrix.device)
             _lib.check(_lib.load().sq_colmatrix_select(C.c_void_p(matrix.data_ptr()), Lcols, float(threshold), int(minspan),
-                                                       _ptr(idx), _ptr(val), cap, C.byref(cnt), None))
-            if cnt.value <= cap:
+                                                       C.c_void_p(idx.data_ptr()), C.c_void_p(val.data_ptr()), cap,
+                                                       C.c_void_p(cnt.data_ptr()), C.c_void_p(stream.cuda_stream)))
+            n = int(cnt.item())
+            if n <= cap:
                 break
-            cap = int(cnt.value)
-        n = int(cnt.value)
-        order = np.argsort(idx[:n], kind="stable")
-        return idx[:n][order], val[:n][order]
+            cap = n
+        idx, val = idx[:n].cpu().numpy(), val[:n].cpu().numpy()
+        order = np.argsort(idx, kind="stable")
+        return idx[order], val[order]
 
     def entropy(self, record, interchainonly=False):
         """Mean row entropy of the stem matrix under the FIRST paramset, as a string
