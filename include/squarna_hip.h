@@ -81,6 +81,11 @@ typedef struct sq_batch_desc {
     const double *const *ext_bool;   /* AnnotateStems/OptimalStems shims: caller-supplied bpboolmatrix   */
     const double *const *ext_score;  /* ... and bpscorematrix (SQRNdbnseq.py:427-428,792-797)            */
     const double *const *mul_score;  /* alignment step-2 weighting, bpscorematrix *= shortsmat (SQRNdbnseq.py:1084-1085) */
+    const double *const *bpp_term;   /* paramsets with bpp != 0: (bppm / max(bppm)) ** |bpp| computed by the caller from
+                                        ViennaRNA's base-pair probabilities; the fill applies scoremat *= term (bpp > 0)
+                                        or scoremat += term (bpp < 0) (SQRNdbnseq.py:341-364).  A job takes either
+                                        mul_score or bpp_term, not both.  NULL entry with bpp != 0: max(bppm) was 0,
+                                        the matrix stays as it is (:350,360).                                        */
     int32_t interchainonly;     /* SQRNdbnseq.py:264-271,301 */
     int32_t max_structs;        /* structures evaluated per round chunk (0 = default 4096)      */
     int32_t cand_per_nt;        /* candidate capacity per structure = cand_per_nt * N (0 = 32)  */

@@ -173,10 +173,16 @@ def stem_bps(st):
 
 
 # ---------------------------------------------------------------- core bindings
+#: source of base-pair probabilities for bpp != 0 paramsets: fn(seq, reacts, M, B) -> N x N array or None.
+#: ViennaRNA is absent here, so this stays None unless a test installs a synthetic source: the APPLICATION of
+#: the probabilities (dbnseq:350-364) is restated below, the probabilities themselves are parity-unpinned.
+BPP_SOURCE = None
+
+
 def BPMatrix(seq, weights, rxs, rlefts, rrights, interchainonly=False, reacts=None,
              bpp_power=0, M=1.8, B=-0.6):
-    """dbnseq:258-367 (bpp_power must be 0)."""
-    if bpp_power:
+    """dbnseq:258-367 (bpp_power != 0 needs BPP_SOURCE)."""
+    if bpp_power and BPP_SOURCE is None:
         raise NotImplementedError("oracle: bpp != 0 needs ViennaRNA (parity unpinned)")
     n = len(seq)
     flags = np.zeros(max(n, 1), dtype=np.uint8)
@@ -194,6 +200,13 @@ def BPMatrix(seq, weights, rxs, rlefts, rrights, interchainonly=False, reacts=No
                        _p(flags, C.c_uint8), int(bool(interchainonly)),
                        None if rc is None else _p(rc, C.c_double),
                        _p(b, C.c_double), _p(s, C.c_double))
+    if bpp_power:                                                      # dbnseq:350-364 (the rescale retry is the source's job)
+        bppm = BPP_SOURCE(seq, reacts, M, B)
+        if bppm is not None and np.max(bppm) > 0:
+            if bpp_power < 0:
+                s += (bppm / np.max(bppm)) ** (-bpp_power)
+            else:
+                s *= (bppm / np.max(bppm)) ** bpp_power
     return b, s
 
 

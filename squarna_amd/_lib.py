@@ -51,6 +51,7 @@ class BatchDesc(C.Structure):
                 ("ext_bool", C.POINTER(C.c_void_p)),
                 ("ext_score", C.POINTER(C.c_void_p)),
                 ("mul_score", C.POINTER(C.c_void_p)),
+                ("bpp_term", C.POINTER(C.c_void_p)),
                 ("interchainonly", C.c_int32),
                 ("max_structs", C.c_int32),
                 ("cand_per_nt", C.c_int32),

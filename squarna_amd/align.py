@@ -195,7 +195,7 @@ def RunSQRNdbnali(objs, defreacts, defrests, defref, levellimit, freqlimit, verb
         else:
             preds = eng.fold_records(recs, conslim=conslim, toplim=toplim, hardrest=hardrest, rankbydiff=rankbydiff,
                                      rankby=rankby, interchainonly=interchainonly, poollim=poollim, algos=algos,
-                                     levellimit=None, priority=set())
+                                     levellimit=None, priority=set(), M=M, B=B)
         for obj, pred in zip(objs, preds):
             name, seq, reacts, rests, ref = obj
             buf = io.StringIO()

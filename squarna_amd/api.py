@@ -3,8 +3,9 @@
 Same keyword arguments, synonyms, validation messages, config lookup and output text as the
 reference.  Single-sequence predictions are batched across the input records and folded on
 the GPU (the reference parallelises the same loop over CPU processes, SQUARNA.py:887-935);
-blocks are printed in input order.  Out of scope of this build: the alignment
-mode (``a``), Rfam/G4/RBP restraint discovery and ``bpp != 0`` paramsets (ViennaRNA).
+blocks are printed in input order; alignment mode (``a``) runs through ``squarna_amd.align``.
+``bpp != 0`` paramsets take their base-pair probabilities from ViennaRNA on the host (``import RNA``,
+as the reference does).  Out of scope of this build: Rfam/G4/RBP restraint discovery.
 """
 import io
 import os
@@ -196,7 +197,7 @@ def Predict(inputfile=None, fileformat="unknown", inputseq=None, configfile=None
 
     eng = _engine.get_engine()
     common = dict(conslim=conslim, toplim=toplim, hardrest=hardrest, rankbydiff=rankbydiff, rankby=rankby,
-                  interchainonly=interchainonly, poollim=poollim, algos=algos, levellimit=levellimit)
+                  interchainonly=interchainonly, poollim=poollim, algos=algos, levellimit=levellimit, M=M, B=B)
 
     def flush(batch):
         """Fold a batch of records on the GPU, then print every block in input order."""

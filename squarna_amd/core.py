@@ -41,17 +41,23 @@ def _restraint_line(n, rxs=(), rlefts=(), rrights=(), rbps=()):
 def BPMatrix(seq, weights, rxs, rlefts, rrights, interchainonly=False, reacts=None, bpp_power=0,
              M=1.8, B=-0.6):
     """(bpboolmatrix, bpscorematrix), dense N x N float64 -- SQRNdbnseq.py:258-367.
-    Computed on the GPU in fp64 (sq_bpmatrix_read).  bpp_power != 0 needs ViennaRNA's
-    base-pair probabilities and is rejected (out of scope)."""
-    if bpp_power:
-        raise NotImplementedError("bpp_power != 0 (ViennaRNA branch, SQRNdbnseq.py:341-364) is not supported")
+    Computed on the GPU in fp64 (sq_bpmatrix_read).  bpp_power != 0 takes ViennaRNA's base-pair
+    probabilities from the host (engine.vienna_bpp, i.e. `import RNA`) and applies them as the reference
+    does (SQRNdbnseq.py:350-364)."""
     n = len(seq)
     prep = _engine.Prepared(seq, list(reacts) if reacts is not None else None,
                             _restraint_line(n, rxs, rlefts, rrights))
     prep.shortseq = seq                     # BPMatrix takes the sequence as it is (already gap-free)
-    with _engine.Batch([prep], [[_pset(weights)]], interchainonly=interchainonly) as b:
-        b.fill()
-        return b.bpmatrix(0)
+    with _engine.Batch([prep], [[_pset(weights)]], interchainonly=interchainonly, fp32=False) as b:
+        boolmat, scoremat = b.bpmatrix(0)
+    if bpp_power:
+        bppm = _engine._bpp_provider(seq, list(reacts) if reacts is not None else None, M, B)
+        if bppm is not None and np.max(bppm) > 0:
+            if bpp_power < 0:
+                scoremat += (bppm / np.max(bppm)) ** (-bpp_power)
+            else:
+                scoremat *= (bppm / np.max(bppm)) ** bpp_power
+    return boolmat, scoremat
 
 
 def _stems_ijl(rstems):
@@ -139,7 +145,7 @@ def SQRNdbnseq(seq, reacts=None, restraints=None, dbn=None, paramsets=[], consli
         return eng.entropy(rec, interchainonly=interchainonly)
     return eng.fold_records([rec], conslim=conslim, toplim=toplim, hardrest=hardrest,
                             rankbydiff=rankbydiff, rankby=rankby, interchainonly=interchainonly,
-                            poollim=poollim, algos=algos, levellimit=levellimit, priority=priority)[0]
+                            poollim=poollim, algos=algos, levellimit=levellimit, priority=priority, M=M, B=B)[0]
 
 
 def resolve_priority(priority, paramsetnames, rfam=None):

@@ -19,8 +19,9 @@ typedef std::pair<int, int> BP;
 static inline double sq_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // exact scoremat cell on the host: the same fp64 expression as sq_cell_score (sq_kernels.hip)
-static double cell_score_host(const sq_batch *b, const SqJob &J, int i, int j)
+static double cell_score_host(const sq_batch *b, const SqJob &J, int i, int j, const double *dense = nullptr)
 {
+    if (dense) return dense[(size_t)i * J.n + j];          // jobs with a bpp term / multiplier: the device's exact matrix
     const uint8_t *codes = b->codes.data() + J.pos_off;
     const sq_paramset &ps = b->psets[J.pset];
     const double w = ps.bpweight[codes[i] * 32 + codes[j]];
@@ -45,7 +46,7 @@ static void pairs_to_stems(const std::vector<BP> &sp, std::vector<HStem> &out)
 
 // the two filter passes of RunAlgo (:570-595)
 static void filter_stemset(const sq_batch *b, const SqJob &J, std::vector<BP> pairs, int levellimit,
-                           std::vector<HStem> &stemset)
+                           std::vector<HStem> &stemset, const double *dense = nullptr)
 {
     const sq_paramset &ps = b->psets[J.pset];
     for (BP &p : pairs) if (p.first > p.second) std::swap(p.first, p.second);
@@ -54,7 +55,7 @@ static void filter_stemset(const sq_batch *b, const SqJob &J, std::vector<BP> pa
     pairs_to_stems(pairs, stems);
     auto score_of = [&](const HStem &st) {
         double s = 0;                                                    // sum(...) from int 0, left to right
-        for (int k = 0; k < st.len; k++) s = s + cell_score_host(b, J, st.i + k, st.j - k);
+        for (int k = 0; k < st.len; k++) s = s + cell_score_host(b, J, st.i + k, st.j - k, dense);
         return s;
     };
     std::vector<BP> kept;
@@ -255,6 +256,14 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
     HIPCK(hipStreamSynchronize(ck.st));
     const double tw1 = sq_now();
     struct Rep { int algo; double t0, t1; ~Rep() { if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] algo %d: wait %.3f ms, host filters %.3f ms\n", algo, (t1 - t0) * 1e3, (sq_now() - t1) * 1e3); } } rep{algo, tw0, tw1};
+    // jobs whose score matrix carries a bpp term / multiplier: RunAlgo's stem filters re-sum cells of THAT matrix
+    std::vector<std::vector<double>> dense(mj.size());
+    for (size_t q = 0; q < mj.size(); q++) {
+        const SqJob &J = b->jobs[jobs[ck.k0 + q]];
+        if (J.mat64_off < 0) continue;
+        dense[q].resize((size_t)J.n * J.n);
+        HIPCK(hipMemcpy(dense[q].data(), b->ctx.mat64 + J.mat64_off, dense[q].size() * 8, hipMemcpyDeviceToHost));
+    }
     std::atomic<int> bad{0};
     sq_pool(b)->parallel_for((int)mj.size(), [&](int qi) {
         const size_t q = (size_t)qi;
@@ -290,7 +299,7 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
                 pairs.push_back(BP(kk, sk));
             }
         }
-        filter_stemset(b, J, pairs, levellimit, out[k]);
+        filter_stemset(b, J, pairs, levellimit, out[k], dense[q].empty() ? nullptr : dense[q].data());
     });
     if (bad) { sq_set_error("blossom capacity exceeded"); return -3; }
     return 0;
@@ -299,7 +308,7 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
 static int algo_annotate(sq_batch *b, const std::vector<int> &jobs, std::vector<std::vector<HStem>> &stems)
 {
     for (int j : jobs)
-        if (b->jobs[j].has_ext) { sq_set_error("E/H/N algorithms need the library's own score matrix"); return -4; }
+        if (b->jobs[j].has_ext == 1) { sq_set_error("E/H/N algorithms need the library's own score matrix"); return -4; }
     // AnnotateStems(bool, score, rbps, [], minlen, minbpscore)  (:553)
     std::vector<HStruct> hs(jobs.size());
     std::vector<SView> views(jobs.size());

@@ -126,11 +126,12 @@ int plan(const sq_batch_desc *d, Layout &L)
         const int s = d->job_seq[j];
         if (s < 0 || s >= d->nseq || d->job_pset[j] < 0 || d->job_pset[j] >= d->npset) { sq_set_error("bad job"); return -1; }
         const int64_t n = d->seq_off[s + 1] - d->seq_off[s];
-        const bool ext_any = (d->ext_score && d->ext_score[j]) || (d->mul_score && d->mul_score[j]);
+        const bool ext_any = (d->ext_score && d->ext_score[j]) || (d->mul_score && d->mul_score[j]) ||
+                             (d->bpp_term && d->bpp_term[j]);
         if (want_fp32(d) || ext_any) L.mat32_floats += (int64_t)align_up((size_t)(n * ld_of((int)n)), 64);
         L.bits_words += (int64_t)bits_nw((int)n) * bits_pitch((int)n);
         const bool ext = d->ext_score && d->ext_score[j];
-        const bool mul = d->mul_score && d->mul_score[j];
+        const bool mul = (d->mul_score && d->mul_score[j]) || (d->bpp_term && d->bpp_term[j]);
         if (ext) L.mat64_doubles += 2 * n * n;
         else if (mul) L.mat64_doubles += n * n;
     }
@@ -194,11 +195,17 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     if (r) return r;
     if (!ws || ws_bytes < L.total) { sq_set_error("workspace too small"); return -2; }
     if (((uintptr_t)ws & 255) != 0) { sq_set_error("workspace must be 256-byte aligned"); return -2; }
-    for (int p = 0; p < d->npset; p++)
-        if (d->psets[p].bpp != 0) {
-            sq_set_error("bpp != 0 needs ViennaRNA base-pair probabilities (SQRNdbnseq.py:341-364); not supported");
+    for (int j = 0; j < d->njobs; j++) {
+        const bool term = d->bpp_term && d->bpp_term[j];
+        if (d->psets[d->job_pset[j]].bpp != 0 && !d->bpp_term) {
+            sq_set_error("bpp != 0 paramsets need bpp_term: (bppm/max)^|bpp| from ViennaRNA's base-pair probabilities (SQRNdbnseq.py:341-364)");
             return -4;
         }
+        if (term && d->psets[d->job_pset[j]].bpp == 0) { sq_set_error("bpp_term given for a paramset with bpp == 0"); return -1; }
+        if (term && ((d->mul_score && d->mul_score[j]) || (d->ext_score && d->ext_score[j]))) {
+            sq_set_error("a job takes either bpp_term or mul_score / caller matrices, not both"); return -4;
+        }
+    }
     sq_batch *b = new sq_batch();
     b->stream = (hipStream_t)hip_stream;
     b->nseq = d->nseq; b->npset = d->npset; b->njobs = d->njobs; b->maxn = L.maxn; b->ltot = L.ltot;
@@ -279,7 +286,9 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         J.nw = bits_nw(J.n); J.bpitch = bits_pitch(J.n); J.bits_off = mbits; mbits += (int64_t)J.nw * J.bpitch;
         J.rb_off = d->rbp_off[s]; J.nrb = d->rbp_off[s + 1] - d->rbp_off[s];
         const bool ext = d->ext_score && d->ext_score[j];
-        const bool mul = d->mul_score && d->mul_score[j];
+        const bool term = d->bpp_term && d->bpp_term[j];
+        const bool mul = (d->mul_score && d->mul_score[j]) || term;
+        J.ext_add = term && d->psets[J.pset].bpp < 0 ? 1 : 0;
         if (ext) { J.mat64_off = m64; J.has_ext = 1; m64 += 2 * (int64_t)J.n * J.n; }
         else if (mul) { J.mat64_off = m64; J.has_ext = 2; m64 += (int64_t)J.n * J.n; }
         J.mat_off = -1;
@@ -307,12 +316,13 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
                 mx = std::max(mx, std::fabs(w) * rfmax);
             }
             if (mul) {
+                const double *tm = term ? d->bpp_term[j] : d->mul_score[j];
                 double mm = 0;
-                for (size_t q = 0; q < nn; q++) mm = std::max(mm, std::fabs(d->mul_score[j][q]));
-                mx *= mm;
+                for (size_t q = 0; q < nn; q++) mm = std::max(mm, std::fabs(tm[q]));
+                mx = J.ext_add ? mx + mm : mx * mm;
             }
         }
-        J.maxabs = (float)(mx * 1.0000002) ; J.pad = 0;
+        J.maxabs = (float)(mx * 1.0000002);
     }
     // ---- device carve + uploads ----
     b->ctx.codes = (uint8_t *)(base + L.off_codes); b->ctx.flags = (uint8_t *)(base + L.off_flags);
@@ -351,7 +361,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
             UP(b->ctx.mat64 + J.mat64_off, d->ext_score[j], nn);
             UP(b->ctx.mat64 + J.mat64_off + (int64_t)J.n * J.n, d->ext_bool[j], nn);
         } else if (J.has_ext == 2) {
-            UP(b->ctx.mat64 + J.mat64_off, d->mul_score[j], nn);
+            UP(b->ctx.mat64 + J.mat64_off, (d->bpp_term && d->bpp_term[j]) ? d->bpp_term[j] : d->mul_score[j], nn);
         }
     }
 #undef UP

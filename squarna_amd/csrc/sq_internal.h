@@ -24,7 +24,7 @@ struct SqJob {
     int32_t bpitch;     // words per word-row (>= 2N + 64, multiple of 64)
     int32_t nw;         // word-rows: ceil(N / 32); bit b of word (w, s) <-> cell (32w + b, s - 32w - b)
     int32_t rb_off;     // into the packed restraint pair list
-    int32_t pad;
+    int32_t ext_add;    // has_ext == 2: the dense term is ADDED to the score (bpp < 0) instead of multiplied
 };
 
 // Device image of a paramset (+ host-built pow tables so every pow() is the host libm's).

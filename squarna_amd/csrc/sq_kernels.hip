@@ -82,7 +82,10 @@ extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c, int
                 double v = sq_cell_score(c, jb, ps, i, j);
                 if (m64) {                              // :1084-1085 bpscorematrix * shortsmat
                     if (mul_done) v = m64[(int64_t)i * n + j];          // the arena already holds the product
-                    else { v = v * m64[(int64_t)i * n + j]; m64[(int64_t)i * n + j] = v; }
+                    else {                                               // :352-354 bpp term, :1084-1085 stem matrix
+                        v = jb.ext_add ? v + m64[(int64_t)i * n + j] : v * m64[(int64_t)i * n + j];
+                        m64[(int64_t)i * n + j] = v;
+                    }
                 }
                 bits = __float_as_uint((float)v);
                 if (bits == SQ_SENT_BITS) bits = 0x7FC00001u;   // a genuine NaN value stays "present"

@@ -73,7 +73,7 @@ class Batch:
     """A device-resident batch of fold jobs (one per (record, paramset))."""
 
     def __init__(self, prepared, psets_per_record, interchainonly=False, ext=None, mul=None,
-                 max_structs=0, cand_per_nt=0, device=None, fp32=True):
+                 max_structs=0, cand_per_nt=0, device=None, fp32=True, bpp=None):
         """fp32=False leaves the fp32 score matrices out of the workspace (4 N^2 bytes per job): everything
         but fill() works -- folding only needs the 1-bit-per-cell matrices."""
         import torch
@@ -158,6 +158,9 @@ class Batch:
         if mul is not None:
             self._mul = ptr_array(mul)
             d.mul_score = C.cast(self._mul, C.POINTER(C.c_void_p))
+        if bpp is not None:                                          # per job: (bppm/max)**|bpp| or None (SQRNdbnseq.py:350-364)
+            self._bpp = ptr_array(bpp)
+            d.bpp_term = C.cast(self._bpp, C.POINTER(C.c_void_p))
         d.interchainonly = int(bool(interchainonly))
         d.max_structs = int(max_structs)
         d.cand_per_nt = int(cand_per_nt)
@@ -353,6 +356,61 @@ def _metrics(m):
     return [tp, fp, fn, fs, pr, rc]
 
 
+def vienna_bpp(shortseq, reacts, M=1.8, B=-0.6):
+    """Base-pair probability matrix of one sequence exactly as the reference obtains it (SQRNdbnseq.py:342-364):
+    ViennaRNA's partition function (with SHAPE pseudo-energies when reactivities are given), rescaled once when all
+    probabilities vanish.  Host-side third-party code, outside the accelerated path; None when max(bppm) == 0."""
+    try:
+        import RNA
+    except ImportError:
+        raise RuntimeError("this configuration has bpp != 0 paramsets, which need ViennaRNA's Python module `RNA` "
+                           "on the host (SQRNdbnseq.py:341-364); it is not installed. Use a config without bpp "
+                           "(e.g. c=nobpp) or install ViennaRNA.") from None
+    fc = RNA.fold_compound(''.join(ch if ch not in SEPS and ord(ch) <= 127 else 'N' for ch in shortseq))
+    if reacts is not None and set(reacts) != {0.5}:
+        fc.sc_add_SHAPE_deigan(ProcessReacts(list(reacts), reverse=True, M=M, B=B), m=M, b=B)
+    fc.pf()
+    bppm = np.array(fc.bpp())[1:, 1:]
+    if np.max(bppm) > 0:
+        return bppm
+    (ss, mfe) = fc.mfe()
+    fc.exp_params_rescale(mfe)
+    fc.pf()
+    bppm = np.array(fc.bpp())[1:, 1:]
+    return bppm if np.max(bppm) > 0 else None
+
+
+_bpp_provider = vienna_bpp
+
+
+def set_bpp_provider(fn):
+    """Replace the source of base-pair probabilities (fn(shortseq, reacts, M, B) -> N x N array or None)."""
+    global _bpp_provider
+    old, _bpp_provider = _bpp_provider, (fn or vienna_bpp)
+    return old
+
+
+def bpp_terms(prepared, psets, M=1.8, B=-0.6):
+    """Per job (record-major, paramset-minor) the dense term the fill applies for bpp != 0 paramsets:
+    (bppm / max(bppm)) ** |bpp|  (SQRNdbnseq.py:350-354), or None.  Returns None when no paramset needs one."""
+    if not any(ps.get("bpp", 0) for pl in psets for ps in pl):
+        return None
+    out = []
+    for p, pl in zip(prepared, psets):
+        bppm = None
+        if any(ps.get("bpp", 0) for ps in pl):
+            bppm = _bpp_provider(p.shortseq, p.shortreacts, M, B)    # once per sequence
+            if bppm is not None:
+                bppm = np.asarray(bppm, dtype=np.float64)
+        for ps in pl:
+            power = ps.get("bpp", 0)
+            if power and bppm is not None:
+                out.append(np.ascontiguousarray((bppm / np.max(bppm)) ** abs(power)))
+            else:
+                out.append(None)
+    return out
+
+
 class HipEngine:
     """Default engine: everything on the GPU through libsquarna_hip.so."""
     name = "hip"
@@ -365,8 +423,10 @@ class HipEngine:
         """records: list of (seq, reacts, restraints, dbn, paramsets, stemmatrix);
         returns the list of SQRNdbnseq return tuples, in order."""
         interchainonly = opts.pop("interchainonly", False)
+        M, B = opts.pop("M", 1.8), opts.pop("B", -0.6)
         prepared = [Prepared(r[0], r[1], r[2], r[3]) for r in records]
         psets = [r[4] for r in records]
+        bpp = bpp_terms(prepared, psets, M, B)
         mul = None
         if any(len(r) > 5 and r[5] is not None for r in records):
             mul = []
@@ -375,7 +435,7 @@ class HipEngine:
                 if sm is not None:                                   # :1031-1034
                     sm = np.delete(np.delete(np.asarray(sm, dtype=np.float64), p.gapidx, 0), p.gapidx, 1)
                 mul.extend([sm] * len(r[4]))
-        with Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False,
+        with Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
                    max_structs=self.max_structs, cand_per_nt=self.cand_per_nt) as b:
             b.fold(**opts)
             return [b.result(k) for k in range(len(records))]

@@ -362,3 +362,47 @@ def test_align_matrix_matches_sequential_accumulation(with_reacts):
     flat = exp.flatten()
     e_idx = np.array([q for q in np.flatnonzero(flat >= thr) if q % L - q // L >= 4], np.int64)
     assert np.array_equal(idx, e_idx) and np.array_equal(val, flat[e_idx])
+
+
+# ---- bpp != 0 paramsets: the dense probability term applied by the fill (dbnseq:341-364).  ViennaRNA is not
+# ---- available, so the probabilities come from a synthetic source shared by the oracle and the product: what is
+# ---- checked is the application (add for bpp < 0, multiply for bpp > 0) and everything downstream of it.
+def _fake_bpp(seq, reacts, M, B):
+    n = len(seq)
+    rng = np.random.default_rng(n * 7919 + sum(map(ord, seq)))
+    m = np.triu(rng.random((n, n)) ** 3, 1)
+    return m
+
+
+@pytest.mark.parametrize("power", [0.5, -1.0])
+def test_bpp_term_matches_oracle(power):
+    from squarna_amd import engine as E
+    from oracle import sqrn_oracle as O
+    names, psets = conf("nobpp")
+    psets = [dict(ps, bpp=power) for ps in psets]           # greedy, Nussinov, Edmonds and Hungarian paramsets, all with the term
+    rng = np.random.default_rng(5)
+    recs = [("".join(rng.choice(list("ACGU"), n)), None, None, None, psets, None) for n in (40, 77, 120, 33)]
+    old = E.set_bpp_provider(_fake_bpp)
+    O.BPP_SOURCE = _fake_bpp
+    try:
+        got = E.HipEngine().fold_records(recs)
+        for r, g in zip(recs, got):
+            exp = O.SQRNdbnseq(r[0], None, None, None, psets)
+            exp = [exp[0], [[d, list(s), list(p)] for d, s, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+            _same_fold(g, exp, r[0])
+    finally:
+        E.set_bpp_provider(old)
+        O.BPP_SOURCE = None
+
+
+def test_bpp_without_vienna_raises_clearly():
+    from squarna_amd import engine as E
+    names, psets = conf("nobpp")
+    psets = [dict(psets[0], bpp=0.5)]
+    try:
+        import RNA  # noqa: F401
+        pytest.skip("ViennaRNA is installed here")
+    except ImportError:
+        pass
+    with pytest.raises(RuntimeError, match="ViennaRNA"):
+        E.HipEngine().fold_records([("GGGAAACCC", None, None, None, psets, None)])
