@@ -625,6 +625,9 @@ struct SqBlossom {
                 int qn_r = qn;
                 bool stopq = f_augmented || error;
                 while (qn_r > 0 && !stopq) {
+#ifdef SQ_MWM_PROF2
+                    const long long _q0 = wall_clock64();
+#endif
                     const int v = queue_[--qn_r];
                     int a0 = adj_off_[v];
                     const int aend = adj_off_[v + 1];
@@ -661,6 +664,10 @@ struct SqBlossom {
                             if (allowed) cat = (lbw == 0 || lbw == 1) ? 1 : (lw == 0 ? 2 : 0);
                             else cat = lbw == 1 ? 4 : (lw == 0 ? 3 : 0);
                         }
+#ifdef SQ_MWM_PROF2
+                        if (lane == 0) { asm volatile("" :: "v"(cat)); pt[1] += wall_clock64() - _q0; }
+                        const long long _q1 = wall_clock64();
+#endif
                         const int f = coop.first_true(cat == 1, nl);        // first state-changing neighbour of the chunk
                         if (lane < f && live) {
                             if (becomes) allow_[de >> 1] = 1;
@@ -674,6 +681,9 @@ struct SqBlossom {
                                 if (be_bv == -1 || mv < s_bebv) { bestedge_[bv] = adj_[a0 + mi]; bslack_[bv] = mv; }
                             }
                         }
+#ifdef SQ_MWM_PROF2
+                        if (lane == 0) pt[2] += wall_clock64() - _q1;
+#endif
                         if (f >= nl) { a0 += nl; continue; }
                         if (lane == 0) qn = qn_r;
                         sync();
@@ -815,7 +825,7 @@ struct SqBlossom {
 #ifdef SQ_MWM_PROF
 #ifdef __HIP_DEVICE_COMPILE__
         if (lane == 0 && n >= 140)
-            printf("mwm n=%d m=%d stages=%lld substages=%lld popped=%lld visits=%lld events=%lld passes=%lld | us: events %.0f queue %.0f delta %.0f combine %.0f update %.0f act %.0f stageinit %.0f endstage %.0f\n",
+            printf("mwm n=%d m=%d stages=%lld substages=%lld popped=%lld visits=%lld events=%lld passes=%lld | us: events %.0f queue %.0f classify %.0f apply %.0f update %.0f act %.0f stageinit %.0f endstage %.0f\n",
                    n, m, pc[3], pc[2], pc[1], pc[0], pc[4], pc[5], pt[7] * 0.01, pt[0] * 0.01, pt[1] * 0.01, pt[2] * 0.01, pt[3] * 0.01, pt[4] * 0.01, pt[5] * 0.01, pt[6] * 0.01);
 #endif
 #endif
