@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from .dbn import (gap_mask, GAPS, SEPS, ReactDict, ProcessReacts, DBNToPairs, UnAlign, ReAlign,
-                  ParseRestraints, levels_to_dbn, encode_seq)
+                  ParseRestraints, levels_to_dbn, encode_seq, BRACKETS)
 
 
 _STEM_DT = np.dtype([("i", "<i4"), ("j", "<i4"), ("len", "<i4"), ("reserved", "<i4"),
@@ -23,7 +23,7 @@ _STEM_DT = np.dtype([("i", "<i4"), ("j", "<i4"), ("len", "<i4"), ("reserved", "<
 class Prepared:
     """One input record after the host pre-processing of SQRNdbnseq.py:1001-1037."""
     __slots__ = ("seq", "shortseq", "shortrest", "shortreacts", "shortdbn", "rbps", "rxs",
-                 "rlefts", "rrights", "gapidx")
+                 "rlefts", "rrights", "gapidx", "sepidx")
 
     def __init__(self, seq, reacts=None, restraints=None, dbn=None):
         seq = seq.upper().replace("T", "U")                          # :1004
@@ -39,12 +39,22 @@ class Prepared:
         self.shortseq, self.shortrest = UnAlign(seq, restraints)     # :1023
         gaps = gap_mask(seq)
         self.gapidx = np.flatnonzero(gaps).tolist()
+        self.sepidx = [i for i, ch in enumerate(seq) if ch in SEPS] if (';' in seq or '&' in seq) else []
         self.shortreacts = list(reacts) if not self.gapidx else [reacts[i] for i in np.flatnonzero(~gaps).tolist()]
         self.shortdbn = None
         if dbn:
             assert len(seq) == len(dbn)
             self.shortseq, self.shortdbn = UnAlign(seq, dbn)         # :1026-1028
         self.rbps, self.rxs, self.rlefts, self.rrights = ParseRestraints(self.shortrest)   # :1037
+
+
+#: code points of the bracket characters by signed level (+L opening, -L closing, 0 dot; levels beyond the
+#: alphabet print as dots, SQRNdbnseq.py:142-143), indexed by level + _NBR + 1
+_NBR = len(BRACKETS)
+_LEVEL_CP = np.full(2 * _NBR + 3, ord('.'), np.uint32)
+for _l in range(1, _NBR + 1):
+    _LEVEL_CP[_NBR + 1 + _l] = ord(BRACKETS[_l - 1][0])
+    _LEVEL_CP[_NBR + 1 - _l] = ord(BRACKETS[_l - 1][1])
 
 
 def _pset_struct(ps):
@@ -312,16 +322,23 @@ class Batch:
         lev = raw[o:o + 2 * (ns + 1) * n].view(np.int16).reshape(ns + 1, n)
         p = self.prepared[k]
         seq = p.seq
-
-        def finish(levels):
-            s = ReAlign(levels_to_dbn(levels.tolist()), seq)                        # :1239-1240
-            return ''.join(s[i] if seq[i] not in SEPS else seq[i] for i in range(len(seq)))   # :1243-1246
-
-        cons = finish(lev[0])
+        # levels -> bracket characters for all rows at once (code-point table), gap columns and separators
+        # re-inserted with array assignments (SQRNdbnseq.py:1239-1246)
+        cp = _LEVEL_CP[np.clip(lev.astype(np.int32), -_NBR - 1, _NBR + 1) + (_NBR + 1)]      # (ns+1, n) uint32
+        if p.gapidx or p.sepidx:
+            full = np.full((ns + 1, len(seq)), ord('.'), np.uint32)
+            keep = np.ones(len(seq), bool)
+            keep[p.gapidx] = False
+            full[:, keep] = cp
+            for i in p.sepidx:
+                full[:, i] = ord(seq[i])
+            cp = full
+        rows = [cp[t].tobytes().decode('utf-32-le') for t in range(ns + 1)]
+        cons = rows[0]
         preds = []
         for t in range(ns):
             m = int(masks[t])
-            preds.append((finish(lev[t + 1]), tuple(float(x) for x in scores[t]),
+            preds.append((rows[t + 1], (float(scores[t, 0]), float(scores[t, 1]), float(scores[t, 2])),
                           [q for q in range(64) if (m >> q) & 1]))
         if has_ref:
             consres = _metrics(met[:6])
