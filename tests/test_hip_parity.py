@@ -406,3 +406,41 @@ def test_bpp_without_vienna_raises_clearly():
         pass
     with pytest.raises(RuntimeError, match="ViennaRNA"):
         E.HipEngine().fold_records([("GGGAAACCC", None, None, None, psets, None)])
+
+
+# ---- error behaviour of the C ABI (status code + sq_last_error text, surfaced as RuntimeError by the binding)
+def test_c_abi_rejects_bad_arguments():
+    import torch
+    from squarna_amd.engine import Batch
+    names, psets = conf("greedynobpp")
+    p = prep("GGGAAAUCCCGCGAAAGCGUUUACGC", None, None)
+    with Batch([p], [psets[:1]], fp32=False) as b:
+        with pytest.raises(RuntimeError, match="NO_FP32"):
+            b.fill()                                                # no fp32 matrices in this workspace
+        with pytest.raises(RuntimeError, match="bad stem"):
+            b.optimal([0], [[(5, 3, 2)]])                           # i > j
+        with pytest.raises(RuntimeError, match="bad job"):
+            b.run_algo([7], "E")
+        m = torch.zeros((30, 30), dtype=torch.float64, device="cuda")
+        n = len(p.shortseq)
+        with pytest.raises(RuntimeError, match="gap map"):
+            b.align_accumulate([0], [list(range(n - 1))], m)        # wrong length
+        with pytest.raises(RuntimeError, match="gap map"):
+            b.align_accumulate([0], [list(range(n))[::-1]], m)      # not increasing
+        b.align_accumulate([0], [list(range(2, n + 2))], m)        # a valid one still works afterwards
+        torch.cuda.synchronize()
+        assert float(m.sum().item()) > 0 and bool(torch.equal(m, m.T))
+    with pytest.raises(RuntimeError, match="bpp_term"):
+        Batch([p], [[dict(psets[0], bpp=0.5)]], fp32=False)         # bpp paramset without its probability term
+
+
+def test_matching_sync_path_equals_side_streams(monkeypatch):
+    """E/H/N staged on side streams (default) and the synchronous chunked path give the same folds."""
+    from squarna_amd.engine import HipEngine
+    names, psets = conf("nobpp")
+    rng = np.random.default_rng(11)
+    recs = [("".join(rng.choice(list("ACGU"), n)), None, None, None, psets, None) for n in (35, 90, 141, 60, 12)]
+    a = HipEngine().fold_records(recs)
+    monkeypatch.setenv("SQ_ALGO_SYNC", "1")
+    b = HipEngine().fold_records(recs)
+    assert a == b
