@@ -234,6 +234,9 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
     // when they fit (tight capacities); on a capacity overflow rerun the job in global memory.
     const size_t ebytes = ((size_t)m * sizeof(SqMatchEdge) + 15) & ~(size_t)15;
     const bool in_lds = SqBlossom::scratch_bytes(n, m, 1) + ebytes + 16 <= (size_t)lds_bytes;
+#ifdef SQ_MWM_PROF
+    const long long _c0 = clock64(), _w0 = wall_clock64();
+#endif
     if (in_lds) {
         SqMatchEdge *le = reinterpret_cast<SqMatchEdge *>(mwm_lds);
         for (int e = lane; e < m; e += 64) le[e] = edges[jp->edge_off + e];
@@ -245,6 +248,12 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
         __syncthreads();
         if (!bl.error) {
             for (int q = lane; q < n; q += 64) mate_out[jp->out_off + q] = bl.mate[q];
+#ifdef SQ_MWM_PROF
+            if (lane == 0 && n >= 140) {
+                const long long dc = clock64() - _c0, dw = wall_clock64() - _w0;
+                printf("mwm clock: %lld shader cycles in %.0f us -> %.0f MHz\n", dc, dw * 0.01, (double)dc / (dw * 0.01));
+            }
+#endif
             return;
         }
         __syncthreads();
