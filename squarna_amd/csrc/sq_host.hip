@@ -15,7 +15,7 @@
 static thread_local std::string g_err;
 
 // host phase timers (printed to stderr when SQ_TIMING is set)
-static double g_t[8];
+static thread_local double g_t[8];
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct TScope { int k; double t0; TScope(int k_) : k(k_), t0(now_s()) {} ~TScope() { g_t[k] += now_s() - t0; } };
 void sq_set_error(const std::string &msg) { g_err = msg; }

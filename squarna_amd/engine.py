@@ -7,6 +7,7 @@ Tests may install another engine with :func:`use_engine` (tests/ only use that t
 the host-side text layer on CPU against the oracle).
 """
 import ctypes as C
+import struct
 import contextlib
 
 import numpy as np
@@ -23,22 +24,26 @@ _STEM_DT = np.dtype([("i", "<i4"), ("j", "<i4"), ("len", "<i4"), ("reserved", "<
 class Prepared:
     """One input record after the host pre-processing of SQRNdbnseq.py:1001-1037."""
     __slots__ = ("seq", "shortseq", "shortrest", "shortreacts", "shortdbn", "rbps", "rxs",
-                 "rlefts", "rrights", "gapidx", "sepidx")
+                 "rlefts", "rrights", "gapidx", "sepidx", "plain_reacts")
 
     def __init__(self, seq, reacts=None, restraints=None, dbn=None):
         seq = seq.upper().replace("T", "U")                          # :1004
         if not restraints:
             restraints = '.' * len(seq)                              # :1007-1008
         assert len(seq) == len(restraints), "Invalid restraints given"
+        self.plain_reacts = not reacts                               # all 0.5: the batch fills them in one go
         if not reacts:
-            reacts = [0.5 for _ in range(len(seq))]                  # :1013-1014
+            reacts = [0.5] * len(seq)                                # :1013-1014
         assert len(reacts) == len(seq), "Invalid reactivities given"
         if type(reacts) == str:                                      # :1019-1020 (default B = 1.6)
             reacts = ProcessReacts([ReactDict[ch] for ch in reacts])
         self.seq = seq
         self.shortseq, self.shortrest = UnAlign(seq, restraints)     # :1023
-        gaps = gap_mask(seq)
-        self.gapidx = np.flatnonzero(gaps).tolist()
+        if '-' in seq or '.' in seq or '~' in seq:
+            gaps = gap_mask(seq)
+            self.gapidx = np.flatnonzero(gaps).tolist()
+        else:
+            gaps, self.gapidx = None, []
         self.sepidx = [i for i, ch in enumerate(seq) if ch in SEPS] if (';' in seq or '&' in seq) else []
         self.shortreacts = list(reacts) if not self.gapidx else [reacts[i] for i in np.flatnonzero(~gaps).tolist()]
         self.shortdbn = None
@@ -47,6 +52,10 @@ class Prepared:
             self.shortseq, self.shortdbn = UnAlign(seq, dbn)         # :1026-1028
         self.rbps, self.rxs, self.rlefts, self.rrights = ParseRestraints(self.shortrest)   # :1037
 
+
+_HDR = struct.Struct("<4q")
+_MET = struct.Struct("<13d")
+_MASK_IDS = [[q for q in range(4) if (m >> q) & 1] for m in range(16)]
 
 #: code points of the bracket characters by signed level (+L opening, -L closing, 0 dot; levels beyond the
 #: alphabet print as dots, SQRNdbnseq.py:142-143), indexed by level + _NBR + 1
@@ -102,7 +111,7 @@ class Batch:
         self.codes = np.frombuffer(b''.join(encode_seq(p.shortseq) for p in prepared), np.uint8).copy() \
             if ltot else np.zeros(1, np.uint8)
         self.flags = np.zeros(max(ltot, 1), np.uint8)
-        self.reacts = np.zeros(max(ltot, 1), np.float64)
+        self.reacts = np.full(max(ltot, 1), 0.5, np.float64)
         rbp_off = [0]
         rbps = []
         for k, p in enumerate(prepared):
@@ -113,7 +122,8 @@ class Batch:
                 self.flags[o + i] |= 2
             for i in p.rrights:
                 self.flags[o + i] |= 4
-            self.reacts[o:o + len(p.shortseq)] = p.shortreacts
+            if not p.plain_reacts:
+                self.reacts[o:o + len(p.shortseq)] = p.shortreacts
             rbps.extend(p.rbps)
             rbp_off.append(len(rbps))
         self.rbp_off = np.array(rbp_off, np.int32)
@@ -311,20 +321,20 @@ class Batch:
         """SQRNdbnseq return tuple of record k (SQRNdbnseq.py:1285-1286)."""
         L = self.L
         nbytes = L.sq_result_pack_size(self.h, k)
-        buf = np.zeros(nbytes // 8 + 1, np.int64)
-        _lib.check(L.sq_result_pack(self.h, k, _ptr(buf), nbytes))
-        raw = buf.view(np.uint8)
-        ns, n, has_ref, evals = (int(x) for x in buf[:4])
-        met = raw[32:136].view(np.float64)
+        buf = bytearray(nbytes)
+        cbuf = (C.c_char * nbytes).from_buffer(buf)
+        _lib.check(L.sq_result_pack(self.h, k, cbuf, nbytes))
+        ns, n, has_ref, evals = _HDR.unpack_from(buf, 0)
+        met = _MET.unpack_from(buf, 32)
         o = 136
-        scores = raw[o:o + 24 * ns].view(np.float64).reshape(ns, 3); o += 24 * ns
-        masks = raw[o:o + 8 * ns].view(np.uint64); o += 8 * ns
-        lev = raw[o:o + 2 * (ns + 1) * n].view(np.int16).reshape(ns + 1, n)
+        scores = struct.unpack_from("<%dd" % (3 * ns), buf, o); o += 24 * ns
+        masks = struct.unpack_from("<%dQ" % ns, buf, o); o += 8 * ns
+        lev = np.frombuffer(buf, np.int16, (ns + 1) * n, o).reshape(ns + 1, n)
         p = self.prepared[k]
         seq = p.seq
         # levels -> bracket characters for all rows at once (code-point table), gap columns and separators
         # re-inserted with array assignments (SQRNdbnseq.py:1239-1246)
-        cp = _LEVEL_CP[np.clip(lev.astype(np.int32), -_NBR - 1, _NBR + 1) + (_NBR + 1)]      # (ns+1, n) uint32
+        cp = _LEVEL_CP[np.clip(lev, -_NBR - 1, _NBR + 1) + (_NBR + 1)]                         # (ns+1, n) uint32
         if p.gapidx or p.sepidx:
             full = np.full((ns + 1, len(seq)), ord('.'), np.uint32)
             keep = np.ones(len(seq), bool)
@@ -333,13 +343,14 @@ class Batch:
             for i in p.sepidx:
                 full[:, i] = ord(seq[i])
             cp = full
-        rows = [cp[t].tobytes().decode('utf-32-le') for t in range(ns + 1)]
-        cons = rows[0]
+        width = cp.shape[1]
+        text = cp.tobytes().decode('utf-32-le')
+        cons = text[:width]
         preds = []
         for t in range(ns):
-            m = int(masks[t])
-            preds.append((rows[t + 1], (float(scores[t, 0]), float(scores[t, 1]), float(scores[t, 2])),
-                          [q for q in range(64) if (m >> q) & 1]))
+            m = masks[t]
+            preds.append((text[(t + 1) * width:(t + 2) * width], scores[3 * t:3 * t + 3],
+                          list(_MASK_IDS[m]) if m < 16 else [q for q in range(64) if (m >> q) & 1]))
         if has_ref:
             consres = _metrics(met[:6])
             res = _metrics(met[6:12]) + [int(met[12])]
@@ -469,6 +480,7 @@ class HipEngine:
             p = Prepared(seq, reacts if reacts else None, restraints, None)
             if not reacts:
                 p.shortreacts = [0.5] * len(p.shortseq)                # YieldStems passes reacts=None (:83)
+                p.plain_reacts = True
             prepared.append(p)
         out, cap = [], 1 << 21
         est = [int(0.25 * len(p.shortseq) ** 2 * 0.375 ** (max(minlen, 1) - 1)) + 256 for p in prepared]
@@ -504,6 +516,7 @@ class HipEngine:
             p = Prepared(seq, reacts if reacts else None, restraints, None)
             if not reacts:
                 p.shortreacts = [0.5] * len(p.shortseq)                # YieldStems passes reacts=None (:83)
+                p.plain_reacts = True
             prepared.append(p)
             cols.append(np.flatnonzero(~gap_mask(seq)).astype(np.int32))   # ReAlignDict (:20-37)
         # chunks of sequences sized to ~24 GB of bit matrices + candidates
