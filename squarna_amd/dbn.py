@@ -99,9 +99,9 @@ def gap_mask(seq):
 def UnAlign(seq, dbn):
     """Drop gap columns; pairs touching a gap become dots first (SQRNdbnseq.py:236-255)."""
     import numpy as np
-    gaps = gap_mask(seq)
-    if not gaps.any():
+    if '-' not in seq and '.' not in seq and '~' not in seq:
         return seq, dbn
+    gaps = gap_mask(seq)
     keep = np.flatnonzero(~gaps)
     shortseq = seq.translate(_DROP_GAPS)
     if dbn.count('.') == len(dbn):                       # no brackets at all: nothing to clean
