@@ -48,8 +48,16 @@ struct SqScanArgs {
     SqCand *cands;
     uint32_t *cand_cnt;      // per slot
     unsigned long long *best; // per slot: order-preserving image of the round's best finalscore (0: none yet)
+    uint32_t *ok_cnt;        // per slot: candidates that passed the exact thresholds (length of the SqOk list)
     SqCounters *ctr;
 };
+
+// the two regions of a structure's candidate slice (see sq_internal.h)
+__host__ __device__ inline SqKey *sq_keys(const SqScanArgs &a, const SqStruct &st) { return reinterpret_cast<SqKey *>(a.cands + st.cand_off); }
+__host__ __device__ inline SqOk *sq_oks(const SqScanArgs &a, const SqStruct &st, int cand_cap)
+{
+    return reinterpret_cast<SqOk *>(reinterpret_cast<char *>(a.cands + st.cand_off) + (size_t)cand_cap * sizeof(SqKey));
+}
 
 size_t sq_scan_lds_fixed();   // bytes of static LDS of sq_scan_kernel
 int sq_scan_seg();            // rows per wave of sq_scan_kernel

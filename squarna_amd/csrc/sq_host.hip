@@ -167,7 +167,7 @@ int plan(const sq_batch_desc *d, Layout &L)
     L.off_structs = take(sizeof(SqStruct) * L.max_structs);
     L.off_strands = take(sizeof(SqStrand) * (size_t)L.strand_cap);
     L.off_state = take((size_t)4 * 2 * L.stride * L.max_structs);
-    L.off_cnt = take(12 * (size_t)align_up((size_t)L.max_structs, 2));   // cand_cnt (u32) then best (u64) per slot
+    L.off_cnt = take(16 * (size_t)align_up((size_t)L.max_structs, 2));   // cand_cnt (u32), best (u64), ok_cnt (u32) per slot
     L.off_ctr = take(sizeof(SqCounters));
     L.off_cands = take(sizeof(SqCand) * (size_t)L.cand_records);
     L.off_out = take(sizeof(SqOut) * (size_t)L.out_cap);
@@ -340,6 +340,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->ctx.bits = (uint32_t *)(base + L.off_bits); b->ctx.rbpk = (uint32_t *)(base + L.off_rbpk);
     b->scan.cand_cnt = (uint32_t *)(base + L.off_cnt); b->scan.ctr = (SqCounters *)(base + L.off_ctr);
     b->scan.best = (unsigned long long *)(base + L.off_cnt + 4 * align_up((size_t)L.max_structs, 2));
+    b->scan.ok_cnt = (uint32_t *)(base + L.off_cnt + 12 * align_up((size_t)L.max_structs, 2));
     b->scan.cands = (SqCand *)(base + L.off_cands);
     b->d_out = (SqOut *)(base + L.off_out);
 

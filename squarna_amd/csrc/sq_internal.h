@@ -58,12 +58,17 @@ struct SqStruct {
     int64_t cand_off;     // into the candidate arena (records)
 };
 
-// Candidate stem emitted by the scan, completed by the scoring kernel.
-struct SqCand {
+// Candidate storage of one structure: a slice of `cand_cap` 32-byte units of the candidate arena, used as
+//   [cand_cap x SqKey]   (key, len) of every candidate the scan emits             (8 bytes each)
+//   [.. x SqOk]          only the candidates that pass the exact thresholds, appended by the scoring kernel
+// so the per-round traffic is 8 bytes per candidate written + read, plus 24 bytes per SURVIVING candidate.
+struct SqCand { uint32_t w[8]; };   // the 32-byte unit of the arena (capacity accounting only)
+struct SqKey {
     uint32_t key;     // (s << 16) | i_outer, s = i + j: the reference's emission order
     uint32_t len;
-    float sum32;
-    uint32_t flags;   // bit0: passes exact bpscore + finscore thresholds
+};
+struct SqOk {
+    uint32_t key, len;
     double bps;
     double fin;
 };

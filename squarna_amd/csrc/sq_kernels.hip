@@ -252,7 +252,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, Sq
     const SqStruct s = io.h_structs[blockIdx.x];          // pinned host memory: one read per structure per round
     if (threadIdx.x == 0) {
         io.d_structs[blockIdx.x] = s;
-        a.cand_cnt[s.slot] = 0; a.best[s.slot] = 0ull;
+        a.cand_cnt[s.slot] = 0; a.best[s.slot] = 0ull; a.ok_cnt[s.slot] = 0;
         if (blockIdx.x == 0) { a.ctr->nout = 0; a.ctr->cand_ovf = 0; a.ctr->out_ovf = 0; a.ctr->level_ovf = 0; }
     }
     for (int k = threadIdx.x; k < s.nstrand; k += 256) io.d_strands[s.strand_off + k] = io.h_strands[s.strand_off + k];
@@ -368,9 +368,8 @@ __device__ __forceinline__ void sq_emit_global(const SqScanArgs &a, const SqStru
 {
     const uint32_t slot = atomicAdd(a.cand_cnt + st.slot, 1u);
     if (slot >= (uint32_t)cap) { a.ctr->cand_ovf = 1; return; }
-    SqCand cd;
-    cd.key = key; cd.len = len; cd.sum32 = sum; cd.flags = 0; cd.bps = 0; cd.fin = 0;
-    a.cands[st.cand_off + slot] = cd;
+    (void)sum;
+    sq_keys(a, st)[slot] = SqKey{key, len};
 }
 
 struct SqScanCtx {      // per-wave constants of the row walk
@@ -616,9 +615,7 @@ extern "C" __global__ __launch_bounds__(64, SQ_WPS) void sq_scan_kernel(SqDevCtx
     const uint32_t gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
     auto put = [&](uint32_t slot, const SqRec &rec) {
         if (slot >= (uint32_t)x.cap) { a.ctr->cand_ovf = 1; return; }
-        SqCand cd;
-        cd.key = rec.key; cd.len = rec.len; cd.sum32 = rec.sum; cd.flags = 0; cd.bps = 0; cd.fin = 0;
-        a.cands[st.cand_off + slot] = cd;
+        sq_keys(a, st)[slot] = SqKey{rec.key, rec.len};
     };
     if (pc >= 1) put(gbase + (uint32_t)__popcll(m1 & lt), L.priv[0][lane]);
     if (pc >= 2) put(gbase + n1 + (uint32_t)__popcll(m2 & lt), L.priv[1][lane]);
@@ -666,9 +663,7 @@ __device__ __forceinline__ void sq5_flush(LDS &L, const SqScanArgs &a, const SqS
         for (uint32_t k = lane; k < n; k += 64) {
             const uint32_t slot = base + k;
             if (slot >= (uint32_t)cap) { a.ctr->cand_ovf = 1; continue; }
-            SqCand cd;
-            cd.key = L.stage[k].x; cd.len = L.stage[k].y; cd.sum32 = 0.f; cd.flags = 0; cd.bps = 0; cd.fin = 0;
-            a.cands[st.cand_off + slot] = cd;
+            sq_keys(a, st)[slot] = SqKey{L.stage[k].x, L.stage[k].y};
         }
     }
     __syncthreads();
@@ -1129,7 +1124,10 @@ extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, c
     }
     __syncthreads();
     const uint8_t *codes = c.codes + jb.pos_off;
-    SqCand *cands = a.cands + st.cand_off;
+    const SqKey *keys = sq_keys(a, st);
+    SqOk *oks = sq_oks(a, st, jb.cand_cap);
+    // the survivor list can take as many records as remain in the slice after the key array
+    const uint32_t ok_cap = (uint32_t)(((size_t)jb.cand_cap * (sizeof(SqCand) - sizeof(SqKey))) / sizeof(SqOk));
     const double minbps = ps->minbpscore, minfin = ps->minfinscore;
     auto cell_exact = [&](int i, int j) -> double {
         if (!lds_cells) return sq_cell_exact(c, jb, ps, i, j);
@@ -1146,8 +1144,11 @@ extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, c
 
     double best = 0.0; int any = 0;
 
-    for (uint32_t q = blockIdx.y * nthr + tid; q < ncand; q += gridDim.y * nthr) {
-        SqCand cd = cands[q];
+    const uint32_t qstep = gridDim.y * nthr;
+    for (uint32_t q0 = blockIdx.y * nthr; q0 < ncand; q0 += qstep) {     // whole waves iterate together (ballot below)
+        const uint32_t q = q0 + tid;
+        const bool have = q < ncand;
+        const SqKey cd = have ? keys[q] : SqKey{0u, 0u};
         const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), L = (int)cd.len, j0 = s - i0;
         // exact bpscore: sum(...) left to right starting from int 0  (:416)
         double bps = 0.0;
@@ -1155,7 +1156,7 @@ extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, c
             const double v = cell_exact(i0 + t, j0 - t);
             bps = bps + v;
         }
-        bool ok = bps >= minbps;                                        // :492
+        bool ok = have && bps >= minbps;                                // :492
         double fin = 0.0;
         if (ok && mode == 0) {
             const int sa = i0 + L - 1, sb = j0 - L + 1;                 // :655 innermost bp
@@ -1224,16 +1225,25 @@ extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, c
             if (!goodloop && !goodloopout && L < 3) fin = -1.0;         // :744-745
             ok = fin >= minfin;                                         // :751
         }
-        cd.bps = bps; cd.fin = fin; cd.flags = ok ? 1u : 0u;
-        if (ok) {                                                        // flags were zeroed by the scan: nothing to write otherwise
-            cands[q].bps = bps; cands[q].fin = fin; cands[q].flags = 1u;
-            if (mode == 2) {
-                // alignment accumulate: the flagged candidates stay on the device (sq_scatter_kernel reads them)
-            } else if (mode == 1) {
+        if (mode == 1) {
+            if (ok) {
                 const SqOut r = {(int32_t)blockIdx.x, cd.key, L, 0, bps, 0.0};
                 sq_put_out(io, a, r);
-            } else if (!any || fin > best) {
-                any = 1; best = fin;                                     // :769 only the best VALUE matters for the range
+            }
+            continue;
+        }
+        // survivors are appended to the structure's SqOk list: one atomic per wave, lanes ranked by ballot
+        const unsigned long long okm = __ballot(ok);
+        if (okm) {
+            uint32_t base = 0;
+            const int leader = __ffsll((long long)okm) - 1;
+            if ((tid & 63) == leader) base = atomicAdd(a.ok_cnt + st.slot, (uint32_t)__popcll(okm));
+            base = (uint32_t)__shfl((int)base, leader);
+            if (ok) {
+                const uint32_t pos = base + (uint32_t)__popcll(okm & ((1ull << (tid & 63)) - 1ull));
+                if (pos < ok_cap) oks[pos] = SqOk{cd.key, (uint32_t)L, bps, fin};
+                else a.ctr->cand_ovf = 1;
+                if (mode == 0 && (!any || fin > best)) { any = 1; best = fin; }   // :769 only the best VALUE matters for the range
             }
         }
     }
@@ -1256,13 +1266,11 @@ extern "C" __global__ __launch_bounds__(256) void sq_select_kernel(SqDevCtx c, c
     const unsigned long long ob = a.best[st.slot];
     if (ob == 0ull) return;
     const SqJob jb = c.jobs[st.job];
-    uint32_t ncand = a.cand_cnt[st.slot];
-    if (ncand > (uint32_t)jb.cand_cap) ncand = jb.cand_cap;
-    const SqCand *cands = a.cands + st.cand_off;
+    const uint32_t nok = a.ok_cnt[st.slot];
+    const SqOk *oks = sq_oks(a, st, jb.cand_cap);
     const double range = st.subopt * sq_unord(ob);                      // :769
-    for (uint32_t q = blockIdx.y * 256 + threadIdx.x; q < ncand; q += gridDim.y * 256) {
-        if (!cands[q].flags) continue;
-        const SqCand cd = cands[q];
+    for (uint32_t q = blockIdx.y * 256 + threadIdx.x; q < nok; q += gridDim.y * 256) {
+        const SqOk cd = oks[q];
         if (!(cd.fin < range)) {                                        // :778
             const SqOut r = {(int32_t)blockIdx.x, cd.key, (int32_t)cd.len, 0, cd.bps, cd.fin};
             sq_put_out(io, a, r);
@@ -1281,12 +1289,10 @@ extern "C" __global__ __launch_bounds__(256) void sq_scatter_kernel(SqDevCtx c, 
 {
     const SqStruct st = structs[sidx];
     const SqJob jb = c.jobs[st.job];
-    uint32_t ncand = a.cand_cnt[st.slot];
-    if (ncand > (uint32_t)jb.cand_cap) ncand = jb.cand_cap;
-    const SqCand *cands = a.cands + st.cand_off;
-    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < ncand; q += gridDim.x * 256) {
-        if (!cands[q].flags) continue;
-        const SqCand cd = cands[q];
+    const uint32_t nok = a.ok_cnt[st.slot];
+    const SqOk *oks = sq_oks(a, st, jb.cand_cap);
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < nok; q += gridDim.x * 256) {
+        const SqOk cd = oks[q];
         const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
         for (int t = 0; t < (int)cd.len; t++) {
             const int64_t v = cols[i0 + t], w = cols[j0 - t];
