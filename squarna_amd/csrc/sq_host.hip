@@ -930,7 +930,11 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     auto *pools_owner = new std::vector<JobPool>(b->njobs);
     struct PoolsDrop {
         std::vector<JobPool> *p;
-        ~PoolsDrop() { std::thread([q = p] { delete q; }).detach(); }
+        ~PoolsDrop()
+        {
+            static const bool sync_drop = getenv("SQ_SYNC_TEARDOWN") != nullptr;
+            if (sync_drop) delete p; else std::thread([q = p] { delete q; }).detach();
+        }
     } pools_drop{pools_owner};
     std::vector<JobPool> &pools = *pools_owner;
     std::vector<uint32_t> algos(b->njobs);
