@@ -444,3 +444,21 @@ def test_matching_sync_path_equals_side_streams(monkeypatch):
     monkeypatch.setenv("SQ_ALGO_SYNC", "1")
     b = HipEngine().fold_records(recs)
     assert a == b
+
+
+def test_annotate_round_larger_than_pinned_output():
+    """More than 2^18 stems in one AnnotateStems round: the tail of the list is fetched from device memory."""
+    from squarna_amd.engine import HipEngine
+    from tests.oracle_engine import OracleEngine
+    rng = np.random.default_rng(3)
+    w = {"GC": 3.25, "AU": 2.0, "GU": -1.0}
+    recs = [("".join(rng.choice(list("ACGU"), 1200)), None, "." * 1200) for _ in range(8)]
+    got = HipEngine().yield_stems(recs, w, 2, 0.0)
+    exp = OracleEngine().yield_stems(recs, w, 2, 0.0)
+    total = 0
+    for (gs, gst), (es, est) in zip(got, exp):
+        assert gs == es
+        g = [(int(a), int(b), int(c), float(d)) for a, b, c, d in zip(gst["i"], gst["j"], gst["len"], gst["bpscore"])]
+        assert g == [tuple(x) for x in est]
+        total += len(g)
+    assert total > (1 << 18)
