@@ -87,7 +87,7 @@ def roofline_leg(nseq, n, seed=1000):
     rng = np.random.default_rng(seed)
     seqs = ["".join(rng.choice(list("ACGU"), n)) for _ in range(nseq)]
     prepared = [Prepared(s) for s in seqs]
-    with Batch(prepared, [psets] * nseq, max_structs=nseq) as b:
+    with Batch(prepared, [psets] * nseq, max_structs=nseq, fp32=False) as b:
         b.fold(poollim=1)                      # warm-up (also page-in)
         b.profile(True)
         b.profile_reset()
@@ -155,7 +155,7 @@ def main():
     from squarna_amd.engine import Batch, Prepared
     names, psets = ParseConfig(builtin_config(args.config))
     prepared = [Prepared(seq, reacts, restr, ref) for _, seq, reacts, restr, ref in recs]
-    batch = Batch(prepared, [psets] * len(prepared))     # inputs now resident in HBM
+    batch = Batch(prepared, [psets] * len(prepared), fp32=False)     # inputs now resident in HBM (no fp32 matrices: the fold path does not use them)
 
     def step():
         batch.fold(poollim=1000)
