@@ -179,6 +179,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # per-kernel time of one step (HIP events on the streams the kernels run on), measured on 3 extra steps
+    # OUTSIDE the timed region; the matching kernels run on side streams, concurrently with the greedy rounds
+    batch.profile(True)
+    batch.profile_reset()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    kernel_ms = {nm: round(batch.profile_get(k)[0] / 3, 3) for k, nm in enumerate(
+        ["bits", "state", "scan", "score_select", "edmonds", "hungarian", "nussinov"])}
+    batch.profile(False)
+
     results = [batch.result(k) for k in range(len(prepared))]
     fs_c, fs_b = mean_fs(results)
     evals = sum(batch.evals(k) for k in range(len(prepared)))
@@ -210,6 +221,7 @@ def main():
         "config": {"workload": "SRtest150 if=qf c=%s poollim=1000, one batch of 219 records per GPU" % args.config,
                    "seqs_per_gpu_per_step": len(prepared), "paramsets": names,
                    "evals_R_per_step": int(evals)},
+        "kernel_ms_per_step": kernel_ms,
         "f1": {"mean_FS_consensus": round(fs_c, 4), "mean_FS_best_of_top5": round(fs_b, 4)},
         "roofline": roof,
         "cpu_baseline": cpu,

@@ -209,8 +209,9 @@ SQ_API int sq_colmatrix_select(const double *d_matrix, int32_t L, double thresho
                                int64_t *d_idx, double *d_val, int64_t cap, uint64_t *d_count, void *hip_stream);
 
 /* ---- measurement ------------------------------------------------------------
- * Kernel ids: 0 fill, 1 state, 2 stem_scan, 3 stem_score.  When enabled, every
- * launch is bracketed by hipEvents on the batch stream. */
+ * Kernel ids: 0 fill, 1 state, 2 stem_scan, 3 stem_score (+ select), 4 Edmonds, 5 Hungarian,
+ * 6 Nussinov.  When enabled, every launch is bracketed by hipEvents on the stream it runs on
+ * (the matching kernels run on the batch's side streams). */
 SQ_API int sq_profile_enable(sq_batch *b, int32_t on);
 SQ_API int sq_profile_get(sq_batch *b, int32_t kernel, double *total_ms, int64_t *launches, double *alg_bytes);
 SQ_API int sq_profile_reset(sq_batch *b);

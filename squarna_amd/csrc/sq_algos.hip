@@ -210,6 +210,9 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
     ck.d_out = (int32_t *)(region + o_out); ck.d_cnt = (int32_t *)(region + o_cnt);
     char *d_scr = region + o_scr;
     const int nj = (int)mj.size();
+    hipEvent_t pe0;
+    const int pslot = algo == SQ_ALGO_E ? 4 : algo == SQ_ALGO_H ? 5 : 6;
+    sq_prof_begin(b, pslot, st, &pe0);
     int maxn = 0, maxm = 0;
     for (const SqMatchJob &m : mj) { maxn = std::max(maxn, m.n); maxm = std::max(maxm, m.nedges); }
     if (algo == SQ_ALGO_H) {
@@ -238,6 +241,7 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
         if (getenv("SQ_MWM_NOLDS")) want = 0;
         hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), want, st, d_jobs, d_edges, d_scr, ck.d_out, (int)want);
     }
+    sq_prof_end(b, pslot, st, pe0);
     HIPCK(hipGetLastError());
     return 0;
 }

@@ -127,11 +127,14 @@ struct sq_batch {
     SqPool *pool = nullptr;               // lazily created host workers
     // profiling
     bool prof_on = false;
-    ProfSlot prof[4];
+    ProfSlot prof[7];                     // 0 fill, 1 state, 2 scan, 3 score, 4 Edmonds, 5 Hungarian, 6 Nussinov
 };
 
 void sq_set_error(const std::string &msg);
 int sq_check(hipError_t e, const char *what);
+// profiling bracket on an arbitrary stream (slot k of sq_profile_get); no-ops unless profiling is enabled
+void sq_prof_begin(sq_batch *b, int k, hipStream_t st, hipEvent_t *e0);
+void sq_prof_end(sq_batch *b, int k, hipStream_t st, hipEvent_t e0);
 SqPool *sq_pool(sq_batch *b);             // the batch's worker pool (SQ_HOST_THREADS, default min(16, cores))
 
 // bit matrices for the scan (full fp32 fill only for jobs with caller matrices / legacy scans)

@@ -433,6 +433,25 @@ void prof_collect(sq_batch *b)
 }
 }  // namespace
 
+void sq_prof_begin(sq_batch *b, int k, hipStream_t st, hipEvent_t *e0)
+{
+    *e0 = nullptr;
+    if (!b->prof_on) return;
+    ProfSlot &p = b->prof[k];
+    if (!p.pool.empty()) { *e0 = p.pool.back(); p.pool.pop_back(); } else hipEventCreate(e0);
+    p.launches++;
+    hipEventRecord(*e0, st);
+}
+void sq_prof_end(sq_batch *b, int k, hipStream_t st, hipEvent_t e0)
+{
+    if (!e0) return;
+    ProfSlot &p = b->prof[k];
+    hipEvent_t e1;
+    if (!p.pool.empty()) { e1 = p.pool.back(); p.pool.pop_back(); } else hipEventCreate(&e1);
+    hipEventRecord(e1, st);
+    p.pending.emplace_back(e0, e1);
+}
+
 extern "C" int sq_profile_enable(sq_batch *b, int32_t on) { b->prof_on = on != 0; return 0; }
 extern "C" int sq_profile_reset(sq_batch *b)
 {
@@ -443,8 +462,9 @@ extern "C" int sq_profile_reset(sq_batch *b)
 }
 extern "C" int sq_profile_get(sq_batch *b, int32_t k, double *ms, int64_t *launches, double *bytes)
 {
-    if (k < 0 || k > 3) return -1;
+    if (k < 0 || k > 6) return -1;
     hipStreamSynchronize(b->stream);
+    for (int q = 0; q < 3; q++) if (b->side[q]) hipStreamSynchronize(b->side[q]);
     prof_collect(b);
     *ms = b->prof[k].ms; *launches = b->prof[k].launches; *bytes = b->prof[k].bytes;
     return 0;
