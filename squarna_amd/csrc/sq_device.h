@@ -68,7 +68,7 @@ __global__ void sq_fill_kernel(SqDevCtx c, int only_ext, int mul_done);
 __global__ void sq_bits_direct_kernel(SqDevCtx c);
 __global__ void sq_dense64_kernel(SqDevCtx c, int job, double *boolmat, double *scoremat);
 __global__ void sq_import_kernel(SqDevCtx c);
-__global__ void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a);
+__global__ void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n);
 __global__ void sq_done_kernel(SqRoundIO io, SqScanArgs a, uint32_t seq);
 __global__ void sq_scatter_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, int sidx, const int32_t *cols,
                                   int L, double *matrix);

@@ -697,7 +697,10 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
     io.h_ctr = b->h_ctr; io.h_seq = b->h_seq;
     {
         ProfScope ps(b, 1, 0);
-        hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(256), 0, st, b->ctx, io, b->state, b->scan);
+        // the per-structure arrays are assembled in LDS (7 bytes per position) when the longest sequence fits
+        const int st_lds_n = maxn <= 8000 ? maxn : 0;
+        const size_t st_dyn = st_lds_n ? (size_t)7 * ((st_lds_n + 8) & ~7) + 64 : 0;
+        hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(256), st_dyn, st, b->ctx, io, b->state, b->scan, st_lds_n);
     }
     if (maxn >= 5) {
         const int nband = (2 * maxn - 5 + 255) >> 8;

@@ -247,29 +247,18 @@ extern "C" __global__ void sq_done_kernel(SqRoundIO io, SqScanArgs a, uint32_t s
     *io.h_seq = seq;
 }
 
-extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a)
+// The arrays are assembled in LDS (7 bytes per position) and written out once, coalesced; sequences that do not
+// fit (n > lds_n) are assembled in place in global memory by the same code.
+template <bool LDS>
+__device__ __forceinline__ void sq_state_build(const SqDevCtx &c, const SqStruct &s, const SqJob &jb, const SqStrand *sd,
+                                               const SqState &st, int16_t *P, uint8_t *E, int16_t *U, int16_t *SU)
 {
-    const SqStruct s = io.h_structs[blockIdx.x];          // pinned host memory: one read per structure per round
-    if (threadIdx.x == 0) {
-        io.d_structs[blockIdx.x] = s;
-        a.cand_cnt[s.slot] = 0; a.best[s.slot] = 0ull; a.ok_cnt[s.slot] = 0;
-        if (blockIdx.x == 0) { a.ctr->nout = 0; a.ctr->cand_ovf = 0; a.ctr->out_ovf = 0; a.ctr->level_ovf = 0; }
-    }
-    for (int k = threadIdx.x; k < s.nstrand; k += 256) io.d_strands[s.strand_off + k] = io.h_strands[s.strand_off + k];
-    __syncthreads();
-    const SqStrand *strands = io.d_strands;
-    const SqJob jb = c.jobs[s.job];
-    const int n = jb.n;
-    int16_t *P = st.P + (int64_t)s.slot * st.stride;
-    uint8_t *E = st.E8 + (int64_t)s.slot * st.stride * 2;
-    int16_t *U = st.U + (int64_t)s.slot * st.stride;
-    int16_t *SU = st.SU + (int64_t)s.slot * st.stride;
+    __shared__ int wave_u[4], wave_s[4];
+    const int n = jb.n, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint8_t *e0 = c.e0c + jb.pos_off;
     const uint8_t *codes = c.codes + jb.pos_off;
-    const int tid = threadIdx.x;
     for (int p = tid; p < n; p += 256) { P[p] = -1; E[p] = e0[p]; }
     __syncthreads();
-    const SqStrand *sd = strands + s.strand_off;
     for (int k = tid; k < s.nstrand; k += 256) {
         const SqStrand x = sd[k];
         for (int t = 0; t < x.len; t++) {
@@ -279,43 +268,73 @@ extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, Sq
         }
     }
     __syncthreads();
-    // block-wide exclusive prefix sums over positions
-    __shared__ int part[256], partS[256];
-    const int ipt = (n + 255) >> 8;
-    const int lo = tid * ipt, hi = min(n, lo + ipt);
-    int cu = 0, cs = 0;
-    for (int p = lo; p < hi; p++) {
-        const bool un = P[p] == -1;
-        cu += un;
-        cs += un && (codes[p] == 26 || codes[p] == 27);
+    // exclusive prefix counts of unpaired positions (U) and unpaired separators (SU): 256 positions per step,
+    // ballots inside a wave, the four wave totals through LDS, a running base across steps
+    int base_u = 0, base_s = 0;
+    for (int p0 = 0; p0 < n; p0 += 256) {
+        const int p = p0 + tid;
+        const bool un = p < n && P[p] == -1;
+        const bool us = un && (codes[p] == 26 || codes[p] == 27);
+        const unsigned long long mu = __ballot(un), ms = __ballot(us);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (lane == 0) { wave_u[wv] = __popcll(mu); wave_s[wv] = __popcll(ms); }
+        __syncthreads();
+        int pu = base_u + __popcll(mu & below), pS = base_s + __popcll(ms & below);
+        for (int q = 0; q < wv; q++) { pu += wave_u[q]; pS += wave_s[q]; }
+        if (p < n) { U[p] = (int16_t)pu; SU[p] = (int16_t)pS; }
+        base_u += wave_u[0] + wave_u[1] + wave_u[2] + wave_u[3];
+        base_s += wave_s[0] + wave_s[1] + wave_s[2] + wave_s[3];
+        __syncthreads();
     }
-    part[tid] = cu; partS[tid] = cs;
-    __syncthreads();
-    if (tid == 0) {
-        int a = 0, b = 0;
-        for (int k = 0; k < 256; k++) { int t = part[k]; part[k] = a; a += t; t = partS[k]; partS[k] = b; b += t; }
-    }
-    __syncthreads();
-    cu = part[tid]; cs = partS[tid];
-    for (int p = lo; p < hi; p++) {
-        U[p] = (int16_t)cu; SU[p] = (int16_t)cs;
-        const bool un = P[p] == -1;
-        cu += un;
-        cs += un && (codes[p] == 26 || codes[p] == 27);
-    }
-    if (hi == n && lo <= n) { U[n] = (int16_t)cu; SU[n] = (int16_t)cs; }
-    // free-position bit words for the bit-diagonal scan: F bit p = (E[p] == 0); G bit k + SQ_GPAD = F[n-1-k]
+    if (tid == 0) { U[n] = (int16_t)base_u; SU[n] = (int16_t)base_s; }
+    // free-position bit words for the bit-diagonal scan: F bit p = (E[p] == 0); G bit k + SQ_GPAD = F[n-1-k].
+    // One ballot = two words.
     const int fbh = st.fbstride >> 1;
     uint32_t *FBs = st.FB + (int64_t)s.slot * st.fbstride;
-    for (int m = tid; m < 2 * fbh; m += 256) {
-        const bool rev = m >= fbh;
-        const int m0 = rev ? m - fbh : m;
-        uint32_t word = 0;
-        for (int b = 0; b < 32; b++) {
-            const int p = rev ? n - 1 - (32 * m0 + b - SQ_GPAD) : 32 * m0 + b;
-            if (p >= 0 && p < n && E[p] == 0) word |= 1u << b;
+    for (int m2 = wv; 2 * m2 < fbh; m2 += 4) {          // m2: pair of words (2 m2, 2 m2 + 1) of either array
+        const int pf = 64 * m2 + lane;                  // forward array: position
+        const unsigned long long bf = __ballot(pf < n && E[pf] == 0);
+        const int pr = n - 1 - (64 * m2 + lane - SQ_GPAD);   // reversed array: bit 64 m2 + lane <-> position n-1-(bit - pad)
+        const unsigned long long br = __ballot(pr >= 0 && pr < n && E[pr] == 0);
+        if (lane == 0) {
+            if (2 * m2 < fbh) { FBs[2 * m2] = (uint32_t)bf; FBs[fbh + 2 * m2] = (uint32_t)br; }
+            if (2 * m2 + 1 < fbh) { FBs[2 * m2 + 1] = (uint32_t)(bf >> 32); FBs[fbh + 2 * m2 + 1] = (uint32_t)(br >> 32); }
         }
-        FBs[m] = word;
+    }
+    if (LDS) {                                          // one coalesced write of everything
+        __syncthreads();
+        int16_t *gP = st.P + (int64_t)s.slot * st.stride, *gU = st.U + (int64_t)s.slot * st.stride;
+        int16_t *gSU = st.SU + (int64_t)s.slot * st.stride;
+        uint8_t *gE = st.E8 + (int64_t)s.slot * st.stride * 2;
+        for (int p = tid; p <= n; p += 256) {
+            if (p < n) { gP[p] = P[p]; gE[p] = E[p]; }
+            gU[p] = U[p]; gSU[p] = SU[p];
+        }
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n)
+{
+    extern __shared__ __attribute__((aligned(16))) char st_dyn[];
+    const SqStruct s = io.h_structs[blockIdx.x];          // pinned host memory: one read per structure per round
+    if (threadIdx.x == 0) {
+        io.d_structs[blockIdx.x] = s;
+        a.cand_cnt[s.slot] = 0; a.best[s.slot] = 0ull; a.ok_cnt[s.slot] = 0;
+        if (blockIdx.x == 0) { a.ctr->nout = 0; a.ctr->cand_ovf = 0; a.ctr->out_ovf = 0; a.ctr->level_ovf = 0; }
+    }
+    for (int k = threadIdx.x; k < s.nstrand; k += 256) io.d_strands[s.strand_off + k] = io.h_strands[s.strand_off + k];
+    __syncthreads();
+    const SqJob jb = c.jobs[s.job];
+    const SqStrand *sd = io.d_strands + s.strand_off;
+    const int n = jb.n;
+    if (n <= lds_n) {
+        const int np = (lds_n + 8) & ~7;                  // arrays of n + 1 entries, 8-byte aligned sections
+        int16_t *P = reinterpret_cast<int16_t *>(st_dyn), *U = P + np, *SU = U + np;
+        uint8_t *E = reinterpret_cast<uint8_t *>(SU + np);
+        sq_state_build<true>(c, s, jb, sd, st, P, E, U, SU);
+    } else {
+        sq_state_build<false>(c, s, jb, sd, st, st.P + (int64_t)s.slot * st.stride, st.E8 + (int64_t)s.slot * st.stride * 2,
+                              st.U + (int64_t)s.slot * st.stride, st.SU + (int64_t)s.slot * st.stride);
     }
 }
 
