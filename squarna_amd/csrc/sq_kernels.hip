@@ -173,19 +173,25 @@ extern "C" __global__ __launch_bounds__(256) void sq_bits_kernel(SqDevCtx c, int
 // (rows 32w..32w+31) x 256 diagonals; row attributes are LDS broadcasts, column attributes consecutive bytes.
 extern "C" __global__ __launch_bounds__(256) void sq_bits_direct_kernel(SqDevCtx c)
 {
-    __shared__ uint32_t s_row[32], s_col[256 + 32];     // code | flags << 8 | inc4 << 16 | valid << 31
+    // per row: the set of partner letters it may pair with (bit = letter code; empty when the row itself is
+    // excluded by its restraint flags) and the smallest allowed j; per column: its letter code (31 = excluded)
+    __shared__ uint32_t s_rmask[32];
+    __shared__ int s_rjmin[32];
+    __shared__ uint8_t s_ccode[256 + 32];
     __shared__ int16_t s_rch[32], s_cch[256 + 32];
-    __shared__ uint8_t s_in[32 * 32];
+    __shared__ uint32_t s_pm[32];                        // partner mask of every letter under this paramset
     const SqJob jb = c.jobs[blockIdx.y];
     if (jb.has_ext == 1) return;                        // bool comes from the caller's matrix (sq_bits_kernel)
     const int n = jb.n, bp = jb.bpitch;
-    const int tiles = bp >> 8;                          // bpitch is a multiple of 64; the tail tile is handled by the bound check
     const int ntile = (bp + 255) >> 8;
     const SqPsetDev *ps = c.psets + jb.pset;
     uint32_t *bits = c.bits + jb.bits_off;
     const int tid = threadIdx.x;
-    (void)tiles;
-    for (int t = tid; t < 32 * 32; t += 256) s_in[t] = ps->inbps[t];
+    if (tid < 32) {
+        uint32_t m = 0;
+        for (int q = 0; q < 29; q++) if (ps->inbps[tid * 32 + q]) m |= 1u << q;     // :300 (codes 0..28; 31 never set)
+        s_pm[tid] = m;
+    }
     for (int blk = blockIdx.x; blk < jb.nw * ntile; blk += gridDim.x) {
         const int w = blk / ntile, s0 = (blk - w * ntile) << 8;
         const int s = s0 + tid;
@@ -198,13 +204,17 @@ extern "C" __global__ __launch_bounds__(256) void sq_bits_direct_kernel(SqDevCtx
             for (int t = tid; t < 32 + 256 + 32; t += 256) {
                 const bool isrow = t < 32;
                 const int p = isrow ? i0 + t : jbase + (t - 32);
-                uint32_t v = 0; int16_t ch = 0;
-                if (p >= 0 && p < n) {
-                    v = (uint32_t)c.codes[jb.pos_off + p] | ((uint32_t)c.flags[jb.pos_off + p] << 8) |
-                        ((uint32_t)c.inc4[jb.pos_off + p] << 16) | 0x80000000u;
-                    ch = c.chain[jb.pos_off + p];
+                const bool in = p >= 0 && p < n;
+                const uint32_t code = in ? c.codes[jb.pos_off + p] : 31u, fl = in ? c.flags[jb.pos_off + p] : 1u;
+                const int16_t ch = in ? c.chain[jb.pos_off + p] : (int16_t)0;
+                if (isrow) {
+                    s_rmask[t] = (in && !(fl & 1u) && !(fl & 4u)) ? s_pm[code & 31u] : 0u;         // :302, :304 (row side)
+                    s_rjmin[t] = p + (in ? (int)c.inc4[jb.pos_off + p] : 0);                       // :294-299
+                    s_rch[t] = ch;
+                } else {
+                    s_ccode[t - 32] = (uint8_t)((in && !(fl & 1u) && !(fl & 2u)) ? code : 31u);  // :302, :303 (column side)
+                    s_cch[t - 32] = ch;
                 }
-                if (isrow) { s_row[t] = v; s_rch[t] = ch; } else { s_col[t - 32] = v; s_cch[t - 32] = ch; }
             }
         }
         __syncthreads();
@@ -213,14 +223,9 @@ extern "C" __global__ __launch_bounds__(256) void sq_bits_direct_kernel(SqDevCtx
         if (live && s >= 4 && s <= 2 * n - 6) {
 #pragma unroll 8
             for (int b = 0; b < 32; b++) {
-                const uint32_t ri = s_row[b];
                 const int cj = tid + 31 - b;               // column s - (i0 + b) relative to jbase
-                const uint32_t rj = s_col[cj];
-                const int i = i0 + b, j = s - i;
-                bool ok = (ri & rj & 0x80000000u) != 0u && j >= i + (int)((ri >> 16) & 0xFFu);     // :294-299
-                ok = ok && s_in[(ri & 0xFFu) * 32 + (rj & 0xFFu)];                                  // :300
-                const uint32_t fi = (ri >> 8) & 0xFFu, fj = (rj >> 8) & 0xFFu;
-                ok = ok && !((fi | fj) & 1u) && !(fj & 2u) && !(fi & 4u);                            // :302-304
+                const int j = s - i0 - b;
+                bool ok = ((s_rmask[b] >> s_ccode[cj]) & 1u) && j >= s_rjmin[b];                   // :294-304
                 if (jb.interchainonly) ok = ok && s_rch[b] != s_cch[cj];                             // :301
                 if (ok) word |= 1u << b;
             }
