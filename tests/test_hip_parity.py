@@ -462,3 +462,25 @@ def test_annotate_round_larger_than_pinned_output():
         assert g == [tuple(x) for x in est]
         total += len(g)
     assert total > (1 << 18)
+
+
+@pytest.mark.parametrize("minlen,minbp", [(1, 0.0), (1, 3.0), (7, 0.0), (33, 0.0), (40, 0.0)])
+def test_minlen_extremes_match_oracle(minlen, minbp):
+    """Run extraction at the edges of the 32-row word logic: single-cell stems and stems longer than a word."""
+    from squarna_amd.engine import HipEngine
+    from oracle import sqrn_oracle as O
+    names, psets = conf("greedynobpp")
+    ps = [dict(psets[0], minlen=minlen, minbpscore=minbp, bpweights={"GC": 3.25, "AU": 1.25, "GU": -1.25})]
+    rng = np.random.default_rng(9 + minlen)
+    recs = []
+    for n in (30, 95, 140):
+        seq = "".join(rng.choice(list("ACGU"), n))
+        if minlen >= 33:                                            # plant a 60-bp helix so that long runs exist
+            half = "".join(rng.choice(list("ACGU"), 60))
+            seq = half + "GAAA" + half[::-1].translate(str.maketrans("ACGU", "UGCA")) + seq
+        recs.append((seq, None, None, None, ps, None))
+    got = HipEngine().fold_records(recs)
+    for r, g in zip(recs, got):
+        e = O.SQRNdbnseq(r[0], None, None, None, ps)
+        e = [e[0], [[d, list(s), list(p)] for d, s, p in e[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(g, e, (minlen, len(r[0])))
