@@ -723,7 +723,11 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
         // dynamic LDS: letter codes of the longest sequence, plus its reactivities when they fit in 32 KiB
         const int lds_n = maxn <= 16384 ? maxn : 0;
         const int lds_nr = maxn <= 4096 ? maxn : 0;
-        const size_t dyn = lds_n ? (size_t)((lds_n + 15) & ~15) + (size_t)8 * lds_nr + 16 : 0;
+        // partner / prefix arrays (3 x int16) too, while a block stays small enough for four blocks per CU
+        // (the reactivity case is bound by fp64 sqrt/div throughput and prefers the occupancy)
+        const size_t dyn_base = lds_n ? (size_t)((lds_n + 15) & ~15) + (size_t)8 * lds_nr + 16 : 0;
+        const int lds_ns = (lds_n && mode == 0 && dyn_base + (size_t)6 * ((maxn + 8) & ~7) <= 24 * 1024) ? maxn : 0;
+        const size_t dyn = lds_n ? (size_t)((lds_n + 15) & ~15) + (size_t)8 * lds_nr + (size_t)6 * ((lds_ns + 8) & ~7) + 16 : 0;
         // few structures: deal each structure's candidates to several blocks so that the launch still fills the chip
         static const int score_threads = getenv("SQ_SCORE_THREADS") ? atoi(getenv("SQ_SCORE_THREADS")) : 0;
         static const int score_parts = getenv("SQ_SCORE_PARTS") ? atoi(getenv("SQ_SCORE_PARTS")) : 0;
@@ -731,7 +735,7 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
         if (score_parts) parts = score_parts;
         const int thr = score_threads ? score_threads : (parts == 1 && S < 2048 ? 512 : 256);
         hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, b->d_structs, b->d_strands, b->state,
-                           b->scan, io, mode, lds_n, lds_nr);
+                           b->scan, io, mode, lds_n, lds_nr, lds_ns);
         if (mode == 0)
             hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, b->d_structs, b->scan, io);
         if (mode == 2) {

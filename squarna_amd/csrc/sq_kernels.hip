@@ -1114,7 +1114,7 @@ __device__ __forceinline__ double sq_unord(unsigned long long o)
 // finalscore of the structure is combined with atomicMax, the range filter (:769-778) runs in sq_select_kernel.
 extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, const SqStruct *structs,
                                                                   const SqStrand *strands, SqState stt, SqScanArgs a,
-                                                                  SqRoundIO io, int mode, int lds_n, int lds_n_reacts)
+                                                                  SqRoundIO io, int mode, int lds_n, int lds_n_reacts, int lds_n_state)
 {
     __shared__ SqStrand s_str[SQ_LDS_STRANDS];
     __shared__ double s_w[32 * 32];               // pair weights of the job's paramset
@@ -1139,6 +1139,19 @@ extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, c
     // the exact re-scoring touches codes / weights / reactivities once per cell: keep them in LDS
     uint8_t *l_codes = reinterpret_cast<uint8_t *>(s_dyn);
     double *l_reacts = reinterpret_cast<double *>(s_dyn + ((n + 15) & ~15));
+    // ScoreStems walks the partner array and reads the prefix counts with dependent loads: LDS copies when they
+    // fit (3 x int16 per position, after the codes and reactivities of the launch's longest sequence)
+    if (mode == 0 && lds_n_state >= n) {
+        int16_t *lP = reinterpret_cast<int16_t *>(s_dyn + ((lds_n + 15) & ~15) + (size_t)8 * lds_n_reacts);
+        int16_t *lU = lP + ((lds_n_state + 8) & ~7), *lSU = lU + ((lds_n_state + 8) & ~7);
+        // 32-bit copies (the arrays start 64-byte aligned: stride is a multiple of 32 positions)
+        const uint32_t *gP = reinterpret_cast<const uint32_t *>(P), *gU = reinterpret_cast<const uint32_t *>(U);
+        const uint32_t *gS = reinterpret_cast<const uint32_t *>(SU);
+        uint32_t *wP = reinterpret_cast<uint32_t *>(lP), *wU = reinterpret_cast<uint32_t *>(lU), *wS = reinterpret_cast<uint32_t *>(lSU);
+        const int nw2 = (n + 2) >> 1;                       // covers entries 0..n
+        for (int q = tid; q < nw2; q += nthr) { wP[q] = gP[q]; wU[q] = gU[q]; wS[q] = gS[q]; }
+        P = lP; U = lU; SU = lSU;
+    }
     const bool lds_cells = jb.mat64_off < 0 && lds_n >= n;
     const bool lds_reacts = lds_cells && !jb.default_reacts && lds_n_reacts >= n;
     if (lds_cells) {
