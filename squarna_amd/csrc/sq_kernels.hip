@@ -1112,7 +1112,10 @@ __device__ __forceinline__ double sq_unord(unsigned long long o)
 
 // grid = (structures, parts): the candidates of a structure are dealt to `parts` blocks; the round's best
 // finalscore of the structure is combined with atomicMax, the range filter (:769-778) runs in sq_select_kernel.
-extern "C" __global__ __launch_bounds__(1024) void sq_score_kernel(SqDevCtx c, const SqStruct *structs,
+#ifndef SQ_SCORE_WAVES
+#define SQ_SCORE_WAVES 5                             // 96 VGPRs: five waves per SIMD instead of four at 97
+#endif
+extern "C" __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SQ_SCORE_WAVES))) void sq_score_kernel(SqDevCtx c, const SqStruct *structs,
                                                                   const SqStrand *strands, SqState stt, SqScanArgs a,
                                                                   SqRoundIO io, int mode, int lds_n, int lds_n_reacts, int lds_n_state)
 {
