@@ -731,7 +731,7 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
         // few structures: deal each structure's candidates to several blocks so that the launch still fills the chip
         static const int score_threads = getenv("SQ_SCORE_THREADS") ? atoi(getenv("SQ_SCORE_THREADS")) : 0;
         static const int score_parts = getenv("SQ_SCORE_PARTS") ? atoi(getenv("SQ_SCORE_PARTS")) : 0;
-        int parts = std::max(1, std::min({512, (2048 + S - 1) / S, (int)(maxcap / 1024)}));
+        int parts = std::max(1, std::min({512, (4096 + S - 1) / S, (int)(maxcap / 1024)}));
         if (score_parts) parts = score_parts;
         const int thr = score_threads ? score_threads : (parts == 1 && S < 2048 ? 512 : 256);
         hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, b->d_structs, b->d_strands, b->state,
