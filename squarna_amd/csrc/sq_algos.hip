@@ -95,7 +95,8 @@ struct SqAlgoChunk {
     SqMatchEdge *p_edges = nullptr;
     size_t nedges = 0;
     size_t outints = 0, scratch = 0, bytes = 0;  // device bytes used from the region's base
-    int32_t *d_out = nullptr, *d_cnt = nullptr;
+    int32_t *d_out = nullptr, *d_cnt = nullptr;  // results: in the pinned staging buffer, written by the kernels in place
+    uint32_t *flag = nullptr; uint32_t flag_val = 0;   // pinned completion word published by sq_flag_kernel
     hipStream_t st = nullptr;
 };
 
@@ -180,9 +181,15 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     if (mj.empty()) return 0;
     // pack into pinned memory: [jobs][edges]
     const size_t jbytes = (mj.size() * sizeof(SqMatchJob) + 255) & ~(size_t)255;
-    char *pin = stage_buffer(b, slot, jbytes + nedges * sizeof(SqMatchEdge) + 64);
+    const size_t ebytes = (nedges * sizeof(SqMatchEdge) + 255) & ~(size_t)255;
+    const size_t obytes = (outints * 4 + 255) & ~(size_t)255, cbytes = (mj.size() * 4 + 255) & ~(size_t)255;
+    char *pin = stage_buffer(b, slot, jbytes + ebytes + obytes + cbytes + 256);
     if (!pin) return 2;
     ck.p_jobs = (SqMatchJob *)pin; ck.p_edges = (SqMatchEdge *)(pin + jbytes);
+    ck.d_out = (int32_t *)(pin + jbytes + ebytes); ck.d_cnt = (int32_t *)(pin + jbytes + ebytes + obytes);
+    ck.flag = (uint32_t *)(pin + jbytes + ebytes + obytes + cbytes);
+    ck.flag_val = ++b->algo_seq;
+    *ck.flag = 0;
     memcpy(ck.p_jobs, mj.data(), mj.size() * sizeof(SqMatchJob));
     sq_pool(b)->parallel_for((int)mj.size(), [&](int q) {
         const JobBuild &B = jb[q];
@@ -207,7 +214,7 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
     const size_t o_out = take(ck.outints * 4 + 16), o_cnt = take(mj.size() * 4 + 16), o_scr = take(0);
     const SqMatchJob *d_jobs = ck.p_jobs;
     const SqMatchEdge *d_edges = ck.p_edges;
-    ck.d_out = (int32_t *)(region + o_out); ck.d_cnt = (int32_t *)(region + o_cnt);
+    (void)o_out; (void)o_cnt;                       // results go to the pinned buffer (algo_build), not to the region
     char *d_scr = region + o_scr;
     const int nj = (int)mj.size();
     hipEvent_t pe0;
@@ -242,6 +249,7 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
         hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), want, st, d_jobs, d_edges, d_scr, ck.d_out, (int)want);
     }
     sq_prof_end(b, pslot, st, pe0);
+    hipLaunchKernelGGL(sq_flag_kernel, dim3(1), dim3(1), 0, st, ck.flag, ck.flag_val);   // "results are in host memory"
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -253,11 +261,25 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
     if (ck.mj.empty()) return 0;
     const std::vector<SqMatchJob> &mj = ck.mj;
     const int algo = ck.algo;
-    std::vector<int32_t> h_out(ck.outints + 4), h_cnt(mj.size() + 1);
-    HIPCK(hipMemcpyAsync(h_out.data(), ck.d_out, ck.outints * 4, hipMemcpyDeviceToHost, ck.st));
-    if (algo == SQ_ALGO_N) HIPCK(hipMemcpyAsync(h_cnt.data(), ck.d_cnt, mj.size() * 4, hipMemcpyDeviceToHost, ck.st));
     const double tw0 = sq_now();
-    HIPCK(hipStreamSynchronize(ck.st));
+    {   // spin on the completion word in pinned memory (no driver round trip, no staged copy)
+        volatile uint32_t *flag = ck.flag;
+        uint64_t spins = 0;
+        while (*flag != ck.flag_val) {
+            if ((++spins & 0xFFFFF) == 0) {
+                const hipError_t q = hipStreamQuery(ck.st);
+                if (q != hipErrorNotReady) {
+                    if (q != hipSuccess) return sq_check(q, "matching kernel");
+                    if (*flag != ck.flag_val) { HIPCK(hipStreamSynchronize(ck.st)); if (*flag != ck.flag_val) { sq_set_error("matching kernel did not signal completion"); return 2; } }
+                }
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    const int32_t *h_out_p = ck.d_out, *h_cnt_p = ck.d_cnt;
     const double tw1 = sq_now();
     struct Rep { int algo; double t0, t1; ~Rep() { if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] algo %d: wait %.3f ms, host filters %.3f ms\n", algo, (t1 - t0) * 1e3, (sq_now() - t1) * 1e3); } } rep{algo, tw0, tw1};
     // jobs whose score matrix carries a bpp term / multiplier: RunAlgo's stem filters re-sum cells of THAT matrix
@@ -276,15 +298,15 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
         const int levellimit = levellimit_opt >= 0 ? levellimit_opt : 3 - (J.n > 500 ? 1 : 0);   // :1043-1044
         std::vector<BP> pairs;
         if (algo == SQ_ALGO_E) {
-            const int32_t *mate = h_out.data() + mj[q].out_off;
+            const int32_t *mate = h_out_p + mj[q].out_off;
             if (mj[q].n > 0 && mate[0] == -2) { bad = 1; return; }
             for (int v = 0; v < mj[q].n; v++)
                 if (mate[v] > v) pairs.push_back(BP(ck.vid2pos[q][v], ck.vid2pos[q][mate[v]]));
         } else if (algo == SQ_ALGO_N) {
-            const int32_t *pp = h_out.data() + 2 * mj[q].out_off;
-            for (int t = 0; t < h_cnt[q]; t++) pairs.push_back(BP(pp[2 * t], pp[2 * t + 1]));
+            const int32_t *pp = h_out_p + 2 * mj[q].out_off;
+            for (int t = 0; t < h_cnt_p[q]; t++) pairs.push_back(BP(pp[2 * t], pp[2 * t + 1]));
         } else {
-            const int32_t *sol = h_out.data() + mj[q].out_off;
+            const int32_t *sol = h_out_p + mj[q].out_off;
             const uint8_t *codes = b->codes.data() + J.pos_off;
             std::vector<int64_t> cells;                               // cells with mat[v,w] != 0, SQRNalgos.py:119-123
             for (const HStem &s : stems[k]) {

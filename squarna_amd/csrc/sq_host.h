@@ -105,6 +105,7 @@ struct sq_batch {
     int64_t cand_reserved = 0;            // records at the END of the arena lent to matching kernels in flight
     char *stage_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned job tables + edge lists of the matching kernels
     size_t stage_cap[4] = {0, 0, 0, 0};
+    uint32_t algo_seq = 0;                // completion stamps of the matching launches
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
     uint32_t out_cap = 0;
     int32_t strand_cap = 0;

@@ -267,6 +267,12 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
     for (int q = lane; q < n; q += 64) mate_out[jp->out_off + q] = bl.error ? -2 : bl.mate[q];
 }
 
+extern "C" __global__ void sq_flag_kernel(uint32_t *flag, uint32_t value)
+{
+    __threadfence_system();
+    *flag = value;
+}
+
 size_t sq_lsap_scratch_bytes(int n)
 {
     return ((size_t)n * n + 3 * (size_t)n) * 8 + 4 * (size_t)n * 4 + 2 * (size_t)n + 64;
