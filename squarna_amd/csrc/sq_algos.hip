@@ -2,6 +2,7 @@
 // one AnnotateStems pass on the GPU (scan + exact rescoring), the matching / DP on the GPU
 // (sq_match.hip), then the reference's stem filters on the host.
 #include <algorithm>
+#include <functional>
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -97,6 +98,7 @@ struct SqAlgoChunk {
     size_t outints = 0, scratch = 0, bytes = 0;  // device bytes used from the region's base
     int32_t *d_out = nullptr, *d_cnt = nullptr;  // results: in the pinned staging buffer, written by the kernels in place
     uint32_t *flag = nullptr; uint32_t flag_val = 0;   // pinned completion word published by sq_flag_kernel
+    uint32_t *job_flags = nullptr;               // pinned, Edmonds only: per job "mates are in host memory" (== flag_val)
     hipStream_t st = nullptr;
 };
 
@@ -183,13 +185,15 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     const size_t jbytes = (mj.size() * sizeof(SqMatchJob) + 255) & ~(size_t)255;
     const size_t ebytes = (nedges * sizeof(SqMatchEdge) + 255) & ~(size_t)255;
     const size_t obytes = (outints * 4 + 255) & ~(size_t)255, cbytes = (mj.size() * 4 + 255) & ~(size_t)255;
-    char *pin = stage_buffer(b, slot, jbytes + ebytes + obytes + cbytes + 256);
+    const size_t fbytes = algo == SQ_ALGO_E ? ((mj.size() * 4 + 255) & ~(size_t)255) : 0;
+    char *pin = stage_buffer(b, slot, jbytes + ebytes + obytes + cbytes + 256 + fbytes);
     if (!pin) return 2;
     ck.p_jobs = (SqMatchJob *)pin; ck.p_edges = (SqMatchEdge *)(pin + jbytes);
     ck.d_out = (int32_t *)(pin + jbytes + ebytes); ck.d_cnt = (int32_t *)(pin + jbytes + ebytes + obytes);
     ck.flag = (uint32_t *)(pin + jbytes + ebytes + obytes + cbytes);
     ck.flag_val = ++b->algo_seq;
     *ck.flag = 0;
+    if (fbytes) { ck.job_flags = (uint32_t *)(pin + jbytes + ebytes + obytes + cbytes + 256); memset(ck.job_flags, 0, mj.size() * 4); }
     memcpy(ck.p_jobs, mj.data(), mj.size() * sizeof(SqMatchJob));
     sq_pool(b)->parallel_for((int)mj.size(), [&](int q) {
         const JobBuild &B = jb[q];
@@ -246,7 +250,8 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
         }
         want = std::min<size_t>(want, 150 * 1024);             // jobs that do not fit run in global memory
         if (getenv("SQ_MWM_NOLDS")) want = 0;
-        hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), want, st, d_jobs, d_edges, d_scr, ck.d_out, (int)want);
+        hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), want, st, d_jobs, d_edges, d_scr, ck.d_out, (int)want,
+                           ck.job_flags, ck.flag_val);
     }
     sq_prof_end(b, pslot, st, pe0);
     hipLaunchKernelGGL(sq_flag_kernel, dim3(1), dim3(1), 0, st, ck.flag, ck.flag_val);   // "results are in host memory"
@@ -255,14 +260,18 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
 }
 
 // Wait for a staged chunk, read its result and apply the reference's stem filters (:570-595).
+// on_job (optional, Edmonds with per-job flags): jobs are collected one by one as the kernel finishes them, smallest
+// graphs first, and on_job(k) is called (from a pool worker) as soon as out[k] is final.
 static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::vector<std::vector<HStem>> &stems,
-                        SqAlgoChunk &ck, int levellimit_opt, std::vector<std::vector<HStem>> &out)
+                        SqAlgoChunk &ck, int levellimit_opt, std::vector<std::vector<HStem>> &out,
+                        const std::function<void(size_t)> *on_job = nullptr)
 {
     if (ck.mj.empty()) return 0;
     const std::vector<SqMatchJob> &mj = ck.mj;
     const int algo = ck.algo;
     const double tw0 = sq_now();
-    {   // spin on the completion word in pinned memory (no driver round trip, no staged copy)
+    const bool streaming = on_job && ck.job_flags;
+    if (!streaming) {   // spin on the completion word in pinned memory (no driver round trip, no staged copy)
         volatile uint32_t *flag = ck.flag;
         uint64_t spins = 0;
         while (*flag != ck.flag_val) {
@@ -291,9 +300,25 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
         HIPCK(hipMemcpy(dense[q].data(), b->ctx.mat64 + J.mat64_off, dense[q].size() * 8, hipMemcpyDeviceToHost));
     }
     std::atomic<int> bad{0};
+    std::vector<int> order(mj.size());
+    for (size_t q = 0; q < mj.size(); q++) order[q] = (int)q;
+    if (streaming) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return mj[x].nedges < mj[y].nedges; });
     sq_pool(b)->parallel_for((int)mj.size(), [&](int qi) {
-        const size_t q = (size_t)qi;
+        const size_t q = (size_t)order[qi];
         const size_t k = ck.k0 + q;
+        if (streaming) {                                  // wait for THIS job's mates
+            volatile uint32_t *jf = ck.job_flags + q;
+            volatile uint32_t *all = ck.flag;
+            uint64_t spins = 0;
+            while (*jf != ck.flag_val) {
+                if (bad) return;
+                if ((++spins & 0x3FFFFF) == 0 && *all == ck.flag_val && *jf != ck.flag_val) { bad = 2; return; }   // kernel over, flag missing
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
         const SqJob &J = b->jobs[jobs[k]];
         const int levellimit = levellimit_opt >= 0 ? levellimit_opt : 3 - (J.n > 500 ? 1 : 0);   // :1043-1044
         std::vector<BP> pairs;
@@ -326,8 +351,11 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
             }
         }
         filter_stemset(b, J, pairs, levellimit, out[k], dense[q].empty() ? nullptr : dense[q].data());
+        if (streaming) (*on_job)(k);
     });
+    if (bad == 2) { sq_set_error("matching kernel did not publish a job"); return 2; }
     if (bad) { sq_set_error("blossom capacity exceeded"); return -3; }
+    if (!streaming && on_job) for (size_t q = 0; q < mj.size(); q++) (*on_job)(ck.k0 + q);
     return 0;
 }
 
@@ -439,7 +467,7 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
     return 0;
 }
 
-int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<JobSets> &sets)
+int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<JobSets> &sets, const SqAlgoEndHooks *hooks)
 {
     int r = 0;
     // collect staged work first, release the reservation, then run what was not staged
@@ -447,11 +475,23 @@ int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<J
         JobSets js; js.algo = it.algo; js.jobs = it.jobs; js.sets.assign(it.jobs.size(), {});
         sets.push_back(std::move(js));
     }
+    bool all_staged = true;
+    for (auto &it : pa->items) all_staged &= it.staged;
+    const bool stream_e = hooks && all_staged && !pa->items.empty() && pa->items[0].algo == SQ_ALGO_E && pa->items[0].ck.job_flags;
     // last staged first: the short kernels (N, H) are done long before Edmonds, so their host filters run
     // while the blossom kernel is still busy
-    for (size_t q = pa->items.size(); q-- > 0;) {
+    for (size_t q = pa->items.size(); q-- > (stream_e ? 1 : 0);) {
         auto &it = pa->items[q];
         if (it.staged && !r) r = algo_collect(b, it.jobs, it.stems, it.ck, levellimit_opt, sets[q].sets);
+    }
+    if (stream_e && !r) {
+        // Edmonds job by job: the caller first takes the H / N stemsets, then every sequence is finished (filters +
+        // its ranking tail, in the hook) as soon as its graph is matched -- only the largest graph is waited for
+        hooks->after_short(sets);
+        auto &it = pa->items[0];
+        sets[0].streamed = true;
+        const std::function<void(size_t)> cb = [&](size_t k) { hooks->on_e_job(it.jobs[k], sets[0].sets[k]); };
+        r = algo_collect(b, it.jobs, it.stems, it.ck, levellimit_opt, sets[0].sets, &cb);
     }
     for (int k = 0; k < 3; k++) if (b->side[k]) hipStreamSynchronize(b->side[k]);
     b->cand_reserved = 0;
@@ -473,7 +513,6 @@ int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<J
     delete pa;
     return r;
 }
-
 extern "C" int sq_run_algos(sq_batch *b, int32_t njob, const int32_t *job_ids, int32_t algo, int32_t levellimit,
                             sq_stem *out, int32_t out_cap, int32_t *out_off)
 {

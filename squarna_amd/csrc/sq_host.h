@@ -150,9 +150,16 @@ int sq_run_algo(sq_batch *b, const std::vector<int> &jobs, int algo, int levelli
 
 // asynchronous E/H/N for sq_fold: begin() annotates + launches on side streams, end() collects
 struct SqAlgoAsync;
-struct JobSets { int algo; std::vector<int> jobs; std::vector<std::vector<HStem>> sets; };
+struct JobSets { int algo; std::vector<int> jobs; std::vector<std::vector<HStem>> sets; bool streamed = false; };
+// optional hooks of sq_algos_end: after_short(sets) once the Hungarian / Nussinov stemsets are final; then
+// on_e_job(job, set) per Edmonds job as soon as that job is final (called from pool workers; JobSets.streamed is set)
+struct SqAlgoEndHooks {
+    std::function<void(std::vector<JobSets> &)> after_short;
+    std::function<void(int, std::vector<HStem> &)> on_e_job;
+};
 int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync *&pa);
-int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<JobSets> &sets);
+int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<JobSets> &sets,
+                 const SqAlgoEndHooks *hooks = nullptr);
 
 // host tail: SQRNdbnseq.py:1201-1286
 void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,

@@ -1059,21 +1059,6 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         } else grow(0, round.size());
     }
     const double tloop = now_s() - tfold0;
-    {
-        const double t0 = now_s();
-        std::vector<JobSets> sets;
-        r = sq_algos_end(b, pending, o.levellimit, sets);
-        pending = nullptr;
-        if (r) return r;
-        // their stemsets precede the greedy ones (:1094-1100): E, H, N order
-        for (auto it = sets.rbegin(); it != sets.rend(); ++it)
-            for (size_t k = 0; k < it->jobs.size(); k++) {
-                JobPool &P = pools[it->jobs[k]];
-                P.fin.insert(P.fin.begin(), std::move(it->sets[k]));
-                P.evals++;
-            }
-        if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_fold] E/H/N: begin %.3f ms, wait+collect after the greedy loop %.3f ms\n", tbegin * 1e3, (now_s() - t0) * 1e3);
-    }
     const double ttail0 = now_s();
     // a-10 tail per sequence
     std::vector<std::vector<int32_t>> seq_jobs(b->nseq);
@@ -1093,16 +1078,55 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         sq_tail(b, s, o, per_job, seq_jobs[s], rp, nref, hr, b->results[s]);
         b->results[s].evals = ev;
     };
-    // sequences are independent: the batch's worker pool shares the tail, longest first (deterministic output)
+    // E / H / N stemsets precede the greedy ones of their job (:1094-1100), in the order E, H, N.  Hungarian and
+    // Nussinov are final first; Edmonds is streamed job by job, and a sequence is ranked (its tail) the moment its
+    // last Edmonds graph is matched -- the other sequences do not wait for the largest graph of the batch.
+    std::vector<char> tailed(b->nseq, 0);
     {
-        std::vector<int> order(b->nseq);
+        const double t0 = now_s();
+        std::vector<std::atomic<int>> e_left(b->nseq);
+        for (int s = 0; s < b->nseq; s++) e_left[s] = 0;
+        for (int j = 0; j < b->njobs; j++) if (algos[j] & SQ_ALGO_E) e_left[b->job_seq[j]]++;
+        auto take_sets = [&](std::vector<JobSets> &sets, bool edmonds) {
+            for (auto it = sets.rbegin(); it != sets.rend(); ++it) {
+                if ((it->algo == SQ_ALGO_E) != edmonds || it->streamed) continue;
+                for (size_t k = 0; k < it->jobs.size(); k++) {
+                    JobPool &P = pools[it->jobs[k]];
+                    P.fin.insert(P.fin.begin(), std::move(it->sets[k]));
+                    P.evals++;
+                }
+            }
+        };
+        SqAlgoEndHooks hooks;
+        hooks.after_short = [&](std::vector<JobSets> &sets) { take_sets(sets, false); };
+        hooks.on_e_job = [&](int j, std::vector<HStem> &set) {       // pool worker: job j's Edmonds stemset is final
+            JobPool &P = pools[j];
+            P.fin.insert(P.fin.begin(), std::move(set));
+            P.evals++;
+            const int s = b->job_seq[j];
+            if (--e_left[s] == 0) { tail_one(s); tailed[s] = 1; }
+        };
+        std::vector<JobSets> sets;
+        r = sq_algos_end(b, pending, o.levellimit, sets, &hooks);
+        pending = nullptr;
+        if (r) return r;
+        bool streamed = false;
+        for (const JobSets &js : sets) streamed |= js.streamed;
+        if (!streamed) take_sets(sets, false);               // (the hook did not run: no Edmonds jobs, or not staged)
+        take_sets(sets, true);
+        if (timing) fprintf(stderr, "[sq_fold] E/H/N: begin %.3f ms, wait+collect (+ tails of finished sequences) after the greedy loop %.3f ms\n", tbegin * 1e3, (now_s() - t0) * 1e3);
+    }
+    // the remaining sequences: the batch's worker pool shares the tail, longest first (deterministic output)
+    {
+        std::vector<int> order;
         std::vector<int64_t> cost(b->nseq, 0);
         for (int s = 0; s < b->nseq; s++) {
-            order[s] = s;
+            if (tailed[s]) continue;
+            order.push_back(s);
             for (int j : seq_jobs[s]) cost[s] += (int64_t)pools[j].fin.size() * (b->seq_off[s + 1] - b->seq_off[s]);
         }
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost[x] > cost[y]; });
-        sq_pool(b)->parallel_for(b->nseq, [&](int k) { tail_one(order[k]); });
+        sq_pool(b)->parallel_for((int)order.size(), [&](int k) { tail_one(order[k]); });
     }
     if (timing) {
         double mx = 0, sum = 0; int arg = 0;

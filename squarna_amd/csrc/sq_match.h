@@ -28,7 +28,7 @@ __global__ void sq_lsap_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges,
 __global__ void sq_nussinov_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, const uint8_t *codes,
                                    char *scratch, int32_t *pairs_out, int32_t *count_out);
 __global__ void sq_mwm_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch, int32_t *mate_out,
-                              int lds_bytes);
+                              int lds_bytes, uint32_t *job_flags, uint32_t stamp);
 // one thread, launched behind a matching kernel on its stream: publishes "the results are in host memory"
 __global__ void sq_flag_kernel(uint32_t *flag, uint32_t value);
 }

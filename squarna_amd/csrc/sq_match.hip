@@ -222,14 +222,22 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
 // ------------------------------------------------------------------------------------
 // Edmonds: one thread per job runs the restated networkx blossom algorithm (sq_blossom.h)
 // ------------------------------------------------------------------------------------
+// job_flags (pinned host memory, may be null): job_flags[job] = stamp once the job's mates are in host memory, so the
+// host can filter and rank a sequence while the larger graphs are still being matched.
 extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges,
-                                                               char *scratch, int32_t *mate_out, int lds_bytes)
+                                                               char *scratch, int32_t *mate_out, int lds_bytes,
+                                                               uint32_t *job_flags, uint32_t stamp)
 {
+    auto publish = [&]() {
+        __threadfence_system();
+        __syncthreads();
+        if (job_flags && threadIdx.x == 0) job_flags[blockIdx.x] = stamp;
+    };
     __shared__ SqBlossom bl;          // one wave per job shares the algorithm state
     extern __shared__ __attribute__((aligned(16))) char mwm_lds[];
     const SqMatchJob *jp = jobs + blockIdx.x;
     const int n = jp->n, m = jp->nedges, lane = threadIdx.x;
-    if (n <= 0) return;
+    if (n <= 0) { publish(); return; }
     // The algorithm is a long chain of dependent loads on lane 0: keep its arrays and the edge list in LDS
     // when they fit (tight capacities); on a capacity overflow rerun the job in global memory.
     const size_t ebytes = ((size_t)m * sizeof(SqMatchEdge) + 15) & ~(size_t)15;
@@ -254,6 +262,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
                 printf("mwm clock: %lld shader cycles in %.0f us -> %.0f MHz\n", dc, dw * 0.01, (double)dc / (dw * 0.01));
             }
 #endif
+            publish();
             return;
         }
         __syncthreads();
@@ -265,6 +274,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
     bl.run<false>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), nullptr);
     __syncthreads();
     for (int q = lane; q < n; q += 64) mate_out[jp->out_off + q] = bl.error ? -2 : bl.mate[q];
+    publish();
 }
 
 extern "C" __global__ void sq_flag_kernel(uint32_t *flag, uint32_t value)
