@@ -103,7 +103,23 @@ struct SqAlgoChunk {
 };
 
 namespace {
-struct JobBuild { std::vector<SqMatchEdge> edges; std::vector<int> ids; int n = 0; size_t need = 0, nout = 0; };
+// pow(x, 1.7) through the host libm (SQRNalgos.py:101,122), memoised: the stem scores of one sequence take few
+// distinct values (sums of a handful of pair weights), and pow dominates the edge build otherwise
+struct PowCache {
+    uint64_t key[64]; double val[64]; bool used[64];
+    PowCache() { for (bool &u : used) u = false; }
+    double operator()(double x)
+    {
+        uint64_t k; memcpy(&k, &x, 8);
+        unsigned h = (unsigned)((k * 0x9E3779B97F4A7C15ull) >> 58);
+        for (int t = 0; t < 8; t++, h = (h + 1) & 63) {
+            if (used[h] && key[h] == k) return val[h];
+            if (!used[h]) { used[h] = true; key[h] = k; return val[h] = pow(x, 1.7); }
+        }
+        return pow(x, 1.7);
+    }
+};
+struct JobBuild { int n = 0; size_t ncell = 0, need = 0, nout = 0; };
 }
 
 // pinned staging buffer `slot` of the batch, at least `bytes` large (grow-only)
@@ -127,6 +143,8 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     ck = SqAlgoChunk();
     ck.algo = algo; ck.k0 = k0;
     const size_t nj = jobs.size() - k0;
+    // pass 1 (pool): sizes only -- cells (= edges) and, for Edmonds, graph vertices (distinct positions)
+    const double tb0 = sq_now();
     std::vector<JobBuild> jb(nj);
     sq_pool(b)->parallel_for((int)nj, [&](int q) {
         const SqJob &J = b->jobs[jobs[k0 + q]];
@@ -134,45 +152,39 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
         JobBuild &B = jb[q];
         size_t ncell = 0;
         for (const HStem &s : st_) ncell += (size_t)s.len;
-        B.edges.reserve(ncell);
+        B.ncell = ncell;
         if (algo == SQ_ALGO_E) {
-            std::vector<int> pos2id(J.n, -1);
-            for (const HStem &s : st_) {
-                const double wt = pow(s.bps, 1.7);                   // SQRNalgos.py:101
+            static thread_local std::vector<char> seen;
+            seen.assign((size_t)J.n, 0);
+            int nv = 0;
+            for (const HStem &s : st_)
                 for (int t = 0; t < s.len; t++) {
-                    const int v = s.i + t, w = s.j - t;
-                    if (pos2id[v] < 0) { pos2id[v] = (int)B.ids.size(); B.ids.push_back(v); }   // node order = first appearance
-                    if (pos2id[w] < 0) { pos2id[w] = (int)B.ids.size(); B.ids.push_back(w); }
-                    B.edges.push_back(SqMatchEdge{pos2id[v], pos2id[w], wt});
+                    if (!seen[s.i + t]) { seen[s.i + t] = 1; nv++; }
+                    if (!seen[s.j - t]) { seen[s.j - t] = 1; nv++; }
                 }
-            }
-            B.n = (int)B.ids.size(); B.need = sq_mwm_scratch_bytes(B.n, (int)ncell); B.nout = (size_t)B.n;
+            B.n = nv; B.need = sq_mwm_scratch_bytes(nv, (int)ncell); B.nout = (size_t)nv;
         } else {
-            for (const HStem &s : st_) {
-                const double wt = algo == SQ_ALGO_H ? pow(s.bps, 1.7) : s.bps;   // SQRNalgos.py:122 / :49
-                for (int t = 0; t < s.len; t++) B.edges.push_back(SqMatchEdge{s.i + t, s.j - t, wt});
-            }
             B.n = J.n;
             B.need = algo == SQ_ALGO_H ? sq_lsap_scratch_bytes(J.n) : sq_nussinov_scratch_bytes(J.n);
             B.nout = algo == SQ_ALGO_H ? (size_t)J.n : 2 * ((size_t)J.n + 4);
         }
         B.need = (B.need + 255) & ~(size_t)255;
     });
+    const double tb1 = sq_now();
     std::vector<SqMatchJob> &mj = ck.mj;
     size_t scratch = 0, outints = 0, nedges = 0, k1 = k0;
     for (; k1 < jobs.size(); k1++) {
-        JobBuild &B = jb[k1 - k0];
+        const JobBuild &B = jb[k1 - k0];
         SqMatchJob m;
         m.edge_off = (int64_t)nedges; m.pos_off = b->jobs[jobs[k1]].pos_off;
-        m.n = B.n; m.nedges = (int32_t)B.edges.size();
-        const size_t fixed = (mj.size() + 1) * sizeof(SqMatchJob) + (nedges + B.edges.size()) * sizeof(SqMatchEdge) +
+        m.n = B.n; m.nedges = (int32_t)B.ncell;
+        const size_t fixed = (mj.size() + 1) * sizeof(SqMatchJob) + (nedges + B.ncell) * sizeof(SqMatchEdge) +
                              (outints + B.nout + mj.size() + 1) * 4 + 4096;
         if (fixed + scratch + B.need > region_bytes) break;
         m.scratch_off = (int64_t)scratch; scratch += B.need;
         m.out_off = (int64_t)(algo == SQ_ALGO_N ? outints / 2 : outints); outints += B.nout;
-        nedges += B.edges.size();
+        nedges += B.ncell;
         mj.push_back(m);
-        ck.vid2pos.push_back(std::move(B.ids));
     }
     ck.k1 = k1; ck.outints = outints; ck.scratch = scratch; ck.nedges = nedges;
     size_t o = 0;
@@ -181,7 +193,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     take(outints * 4 + 16); take(mj.size() * 4 + 16);
     ck.bytes = o + scratch;
     if (mj.empty()) return 0;
-    // pack into pinned memory: [jobs][edges]
+    // pinned staging: [jobs][edges][results][counts][completion word][per-job completion words]
     const size_t jbytes = (mj.size() * sizeof(SqMatchJob) + 255) & ~(size_t)255;
     const size_t ebytes = (nedges * sizeof(SqMatchEdge) + 255) & ~(size_t)255;
     const size_t obytes = (outints * 4 + 255) & ~(size_t)255, cbytes = (mj.size() * 4 + 255) & ~(size_t)255;
@@ -195,10 +207,37 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     *ck.flag = 0;
     if (fbytes) { ck.job_flags = (uint32_t *)(pin + jbytes + ebytes + obytes + cbytes + 256); memset(ck.job_flags, 0, mj.size() * 4); }
     memcpy(ck.p_jobs, mj.data(), mj.size() * sizeof(SqMatchJob));
+    const double tb2 = sq_now();
+    // pass 2 (pool): the edges, written straight into the pinned buffer
+    ck.vid2pos.resize(mj.size());
     sq_pool(b)->parallel_for((int)mj.size(), [&](int q) {
-        const JobBuild &B = jb[q];
-        if (!B.edges.empty()) memcpy(ck.p_edges + mj[q].edge_off, B.edges.data(), B.edges.size() * sizeof(SqMatchEdge));
+        const SqJob &J = b->jobs[jobs[k0 + q]];
+        const std::vector<HStem> &st_ = stems[k0 + q];
+        SqMatchEdge *e = ck.p_edges + mj[q].edge_off;
+        PowCache pow17;
+        if (algo == SQ_ALGO_E) {
+            static thread_local std::vector<int> pos2id;
+            pos2id.assign((size_t)J.n, -1);
+            std::vector<int> &ids = ck.vid2pos[q];
+            ids.reserve((size_t)mj[q].n);
+            for (const HStem &s : st_) {
+                const double wt = pow17(s.bps);                      // SQRNalgos.py:101
+                for (int t = 0; t < s.len; t++) {
+                    const int v = s.i + t, w = s.j - t;
+                    if (pos2id[v] < 0) { pos2id[v] = (int)ids.size(); ids.push_back(v); }   // node order = first appearance
+                    if (pos2id[w] < 0) { pos2id[w] = (int)ids.size(); ids.push_back(w); }
+                    *e++ = SqMatchEdge{pos2id[v], pos2id[w], wt};
+                }
+            }
+        } else {
+            for (const HStem &s : st_) {
+                const double wt = algo == SQ_ALGO_H ? pow17(s.bps) : s.bps;      // SQRNalgos.py:122 / :49
+                for (int t = 0; t < s.len; t++) *e++ = SqMatchEdge{s.i + t, s.j - t, wt};
+            }
+        }
     });
+    if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] build algo %d: sizes %.3f ms, layout+pinned alloc %.3f ms, edges %.3f ms\n", algo,
+                                     (tb1 - tb0) * 1e3, (tb2 - tb1) * 1e3, (sq_now() - tb2) * 1e3);
     return 0;
 }
 
@@ -334,8 +373,9 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
             const int32_t *sol = h_out_p + mj[q].out_off;
             const uint8_t *codes = b->codes.data() + J.pos_off;
             std::vector<int64_t> cells;                               // cells with mat[v,w] != 0, SQRNalgos.py:119-123
+            PowCache pow17;
             for (const HStem &s : stems[k]) {
-                if (-pow(s.bps, 1.7) == 0) continue;
+                if (-pow17(s.bps) == 0) continue;
                 for (int t = 0; t < s.len; t++) cells.push_back((int64_t)(s.i + t) * J.n + (s.j - t));
             }
             std::sort(cells.begin(), cells.end());
@@ -432,7 +472,9 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
         b->cand_reserved += used_rec;                   // carved downwards from the end of the arena
         char *region = (char *)(b->scan.cands + (b->cand_records - b->cand_reserved));
         region = (char *)(((uintptr_t)region + 255) & ~(uintptr_t)255);
+        const double tl0 = sq_now();
         const int r = algo_launch(b, it.ck, region, b->side[sidx]);
+        if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] launch algo %d: %.3f ms\n", it.algo, (sq_now() - tl0) * 1e3);
         if (r) return r;
         it.staged = true;
         sidx++;
