@@ -21,8 +21,33 @@ def make(nseq, seed):
         if k % 7 == 0:
             r = ["."] * n
             for p in rng.choice(n, size=max(1, n // 15), replace=False):
-                r[int(p)] = "_"
+                r[int(p)] = "_/\\+"[int(rng.integers(0, 4))]
             restr = "".join(r)
+        if k % 11 == 0 and n > 40:                       # a restraint helix (paired brackets) somewhere
+            r = list(restr) if restr else ["."] * n
+            a = int(rng.integers(0, n // 2 - 8)); ln = int(rng.integers(2, 6)); b = int(rng.integers(n // 2 + 6, n - 1))
+            for t in range(ln):
+                if a + t < b - t - 3:
+                    r[a + t], r[b - t] = "(", ")"
+            restr = "".join(r)
+        if k % 13 == 0 and n > 30:                       # two chains
+            p = int(rng.integers(10, n - 10))
+            seq = seq[:p] + "&" + seq[p + 1:]
+            if restr:
+                restr = restr[:p] + "." + restr[p + 1:]
+                if restr.count("(") != restr.count(")"):
+                    restr = restr.replace("(", ".").replace(")", ".")
+        if k % 17 == 0:                                  # gaps, lower case, T, unknown letters
+            seq = seq.replace("U", "T", 2).lower()[: n // 2] + seq[n // 2:]
+            q = int(rng.integers(0, n))
+            seq = seq[:q] + "-" + seq[q + 1:]
+            q2 = int(rng.integers(0, n))
+            if seq[q2] not in "&-":
+                seq = seq[:q2] + "N" + seq[q2 + 1:]
+            if restr:
+                restr = restr[:q] + "." + restr[q + 1:]
+                if restr.count("(") != restr.count(")"):
+                    restr = restr.replace("(", ".").replace(")", ".")
         recs.append((seq, reacts, restr))
     return recs
 
