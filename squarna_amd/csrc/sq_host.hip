@@ -70,7 +70,10 @@ void SqPool::parallel_for(int n, const std::function<void(int)> &f)
 SqPool *sq_pool(sq_batch *b)
 {
     if (!b->pool) {
-        int nthr = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+        // up to 16 workers, sharing the host cores with the other ranks of the node (torchrun's LOCAL_WORLD_SIZE)
+        unsigned cores = std::max(1u, std::thread::hardware_concurrency());
+        if (const char *lws = getenv("LOCAL_WORLD_SIZE")) cores = std::max(1u, cores / (unsigned)std::max(1, atoi(lws)));
+        int nthr = (int)std::min(cores, 16u);
         if (const char *e = getenv("SQ_HOST_THREADS")) nthr = std::max(1, atoi(e));
         b->pool = new SqPool(nthr);
     }
