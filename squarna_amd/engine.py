@@ -384,6 +384,28 @@ def _metrics(m):
     return [tp, fp, fn, fs, pr, rc]
 
 
+def fold_concurrently(batches, **opts):
+    """Fold several batches at the same time, one host thread each (sq_fold releases the GIL): while one batch's
+    host code books a round, the kernels of the others keep the GPU busy.  Batches are independent, so the
+    results are the ones of folding them one after the other."""
+    import threading
+    errs = []
+
+    def work(b):
+        try:
+            b.fold(**opts)
+        except BaseException as e:                       # re-raised below
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(b,)) for b in batches[1:]]
+    for t in th:
+        t.start()
+    work(batches[0])
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+
+
 def vienna_bpp(shortseq, reacts, M=1.8, B=-0.6):
     """Base-pair probability matrix of one sequence exactly as the reference obtains it (SQRNdbnseq.py:342-364):
     ViennaRNA's partition function (with SHAPE pseudo-energies when reactivities are given), rescaled once when all
