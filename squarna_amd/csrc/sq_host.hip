@@ -1145,6 +1145,25 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     return 0;
 }
 
+extern "C" int sq_fold_concurrent(sq_batch *const *batches, int32_t nbatch, const sq_fold_opts *opts,
+                                  const int32_t *const *ref_off, const int32_t *const *ref_pairs, const uint8_t *const *has_ref)
+{
+    if (!batches || nbatch <= 0 || !opts) { sq_set_error("bad argument"); return -1; }
+    std::vector<int> rc(nbatch, 0);
+    std::vector<std::string> msg(nbatch);
+    auto work = [&](int k) {
+        rc[k] = sq_fold(batches[k], opts, ref_off ? ref_off[k] : nullptr, ref_pairs ? ref_pairs[k] : nullptr,
+                        has_ref ? has_ref[k] : nullptr);
+        if (rc[k]) msg[k] = sq_last_error();                 // (the error text is per thread)
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < nbatch; k++) th.emplace_back(work, k);
+    work(0);
+    for (auto &t : th) t.join();
+    for (int k = 0; k < nbatch; k++) if (rc[k]) { sq_set_error(msg[k]); return rc[k]; }
+    return 0;
+}
+
 // ---- result getters ------------------------------------------------------------------------------
 extern "C" int32_t sq_result_nstruct(const sq_batch *b, int32_t seq)
 {

@@ -289,9 +289,13 @@ class Batch:
                  for q in range(off[k], off[k + 1])] for k in range(nj)]
 
     # -- a-7 + a-10
-    def fold(self, poollim=1000, conslim=1, toplim=5, hardrest=False, rankbydiff=False,
-             rankby=(0, 2, 1), levellimit=None, algos=frozenset(), priority=None):
+    def fold(self, **opts):
         """priority: per record, set of local paramset indices (or one set for all)."""
+        o, ref_off, rp, has = self._fold_args(**opts)
+        _lib.check(self.L.sq_fold(self.h, C.byref(o), _ptr(ref_off), _ptr(rp), _ptr(has)))
+
+    def _fold_args(self, poollim=1000, conslim=1, toplim=5, hardrest=False, rankbydiff=False,
+                   rankby=(0, 2, 1), levellimit=None, algos=frozenset(), priority=None):
         o = _lib.FoldOpts()
         o.poollim, o.conslim, o.toplim = int(poollim), int(conslim), int(toplim)
         o.hardrest, o.rankbydiff = int(bool(hardrest)), int(bool(rankbydiff))
@@ -315,7 +319,7 @@ class Batch:
             rp = np.array(refs, np.int32).reshape(-1) if refs else np.zeros(2, np.int32)
             self._refs = (ref_off, rp, has)
         ref_off, rp, has = self._refs
-        _lib.check(self.L.sq_fold(self.h, C.byref(o), _ptr(ref_off), _ptr(rp), _ptr(has)))
+        return o, ref_off, rp, has
 
     def result(self, k):
         """SQRNdbnseq return tuple of record k (SQRNdbnseq.py:1285-1286)."""
@@ -385,25 +389,16 @@ def _metrics(m):
 
 
 def fold_concurrently(batches, **opts):
-    """Fold several batches at the same time, one host thread each (sq_fold releases the GIL): while one batch's
-    host code books a round, the kernels of the others keep the GPU busy.  Batches are independent, so the
-    results are the ones of folding them one after the other."""
-    import threading
-    errs = []
-
-    def work(b):
-        try:
-            b.fold(**opts)
-        except BaseException as e:                       # re-raised below
-            errs.append(e)
-    th = [threading.Thread(target=work, args=(b,)) for b in batches[1:]]
-    for t in th:
-        t.start()
-    work(batches[0])
-    for t in th:
-        t.join()
-    if errs:
-        raise errs[0]
+    """Fold several batches at the same time (sq_fold_concurrent: one host thread per batch inside the library):
+    while one batch's host code books a round, the kernels of the others keep the GPU busy.  Batches are
+    independent, so the results are the ones of folding them one after the other."""
+    args = [b._fold_args(**opts) for b in batches]
+    n = len(batches)
+    hs = (C.c_void_p * n)(*[b.h for b in batches])
+    offs = (C.c_void_p * n)(*[a[1].ctypes.data for a in args])
+    rps = (C.c_void_p * n)(*[a[2].ctypes.data for a in args])
+    has = (C.c_void_p * n)(*[a[3].ctypes.data for a in args])
+    _lib.check(batches[0].L.sq_fold_concurrent(hs, n, C.byref(args[0][0]), offs, rps, has))
 
 
 def vienna_bpp(shortseq, reacts, M=1.8, B=-0.6):

@@ -484,3 +484,25 @@ def test_minlen_extremes_match_oracle(minlen, minbp):
         e = O.SQRNdbnseq(r[0], None, None, None, ps)
         e = [e[0], [[d, list(s), list(p)] for d, s, p in e[1]], ["nan"] * 6, ["nan"] * 7]
         _same_fold(g, e, (minlen, len(r[0])))
+
+
+def test_concurrent_batches_equal_sequential_folds():
+    """sq_fold_concurrent: several batches folded at the same time give the results of folding them one by one."""
+    from squarna_amd.engine import Batch, fold_concurrently
+    names, psets = conf("nobpp")
+    rng = np.random.default_rng(21)
+    seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in rng.integers(20, 150, 24)]
+    groups = [seqs[0::3], seqs[1::3], seqs[2::3]]
+    exp = []
+    for g in groups:
+        with Batch([prep(s, None, None) for s in g], [psets] * len(g), fp32=False) as b:
+            b.fold(poollim=1000)
+            exp.append([b.result(k) for k in range(len(g))])
+    batches = [Batch([prep(s, None, None) for s in g], [psets] * len(g), fp32=False) for g in groups]
+    try:
+        fold_concurrently(batches, poollim=1000)
+        got = [[b.result(k) for k in range(len(g))] for b, g in zip(batches, groups)]
+    finally:
+        for b in batches:
+            b.close()
+    assert repr(got) == repr(exp)
