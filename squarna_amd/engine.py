@@ -7,6 +7,7 @@ Tests may install another engine with :func:`use_engine` (tests/ only use that t
 the host-side text layer on CPU against the oracle).
 """
 import ctypes as C
+import os
 import struct
 import contextlib
 
@@ -480,11 +481,41 @@ class HipEngine:
                 if sm is not None:                                   # :1031-1034
                     sm = np.delete(np.delete(np.asarray(sm, dtype=np.float64), p.gapidx, 0), p.gapidx, 1)
                 mul.extend([sm] * len(r[4]))
-        with Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
-                   max_structs=self.max_structs, cand_per_nt=self.cand_per_nt) as b:
-            b.fold(**opts)
-            return [b.result(k) for k in range(len(records))]
-
+        nrec = len(records)
+        # SQ_ENGINE_LANES=2 folds big inputs as two concurrent batches; for one-shot calls the second batch's set-up
+        # (pinned buffers, worker pool) costs more than the overlap saves, so it is opt-in (long-lived batches
+        # profit: fold_concurrently / sq_fold_concurrent)
+        lanes = int(os.environ.get("SQ_ENGINE_LANES", "1"))
+        cost = [float(len(p.shortseq)) ** 2 * len(pl) for p, pl in zip(prepared, psets)]
+        if lanes < 2 or nrec < 256 or sum(cost) < 1e8:
+            with Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
+                       max_structs=self.max_structs, cand_per_nt=self.cand_per_nt) as b:
+                b.fold(**opts)
+                return [b.result(k) for k in range(nrec)]
+        # big inputs: two batches folded concurrently (sq_fold_concurrent) -- the host bookkeeping of one overlaps
+        # the kernels of the other; records are independent, so the split does not change any result
+        from .parallel import lpt_partition
+        parts = [p for p in lpt_partition(cost, 2) if p]
+        job0 = np.cumsum([0] + [len(pl) for pl in psets])
+        batches = []
+        try:
+            for q, idx in enumerate(parts):
+                def pick(seq, per_job):
+                    if seq is None:
+                        return None
+                    return [x for k in idx for x in seq[job0[k]:job0[k + 1]]] if per_job else [seq[k] for k in idx]
+                batches.append(Batch(pick(prepared, False), pick(psets, False), interchainonly=interchainonly,
+                                     mul=pick(mul, True), bpp=pick(bpp, True), fp32=False,
+                                     max_structs=self.max_structs, cand_per_nt=self.cand_per_nt))
+            fold_concurrently(batches, **opts)
+            out = [None] * nrec
+            for b, idx in zip(batches, parts):
+                for local, k in enumerate(idx):
+                    out[k] = b.result(local)
+            return out
+        finally:
+            for b in batches:
+                b.close()
 
     def yield_stems(self, records, bpweights, minlen, minbpscore, interchainonly=False):
         """Alignment step 1 (SQRNdbnali.py:60-108): for every (seq, reacts, restraints) the stems of
