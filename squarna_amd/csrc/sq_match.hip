@@ -152,27 +152,53 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
     const SqMatchJob jb = jobs[blockIdx.x];
     const int n = jb.n, tid = threadIdx.x;
     if (n <= 0) { if (tid == 0) count_out[blockIdx.x] = 0; return; }
-    double *S = reinterpret_cast<double *>(scratch + jb.scratch_off);
+    double *S = reinterpret_cast<double *>(scratch + jb.scratch_off);   // region of n*n doubles: holds the column lists
     double *D = S + (size_t)n * n;
     int32_t *K = reinterpret_cast<int32_t *>(D + (size_t)n * n);
-    uint8_t *has = reinterpret_cast<uint8_t *>(K + (size_t)n * n);
+    uint8_t *has = reinterpret_cast<uint8_t *>(K + (size_t)n * n);      // n*n bytes: BackTrack's "already queued" marks
     const uint8_t *cd = codes + jb.pos_off;
+    // SCORES is sparse (the cells of the stems): per column j the list of (k, SCORES[(k, j)]) in ascending k,
+    // so a cell of the DP only visits the k that can pair with j (:73-74) instead of all of i..j-2
+    const int m = jb.nedges;
+    double *cs = S;                                                     // [m] scores
+    int32_t *ck = reinterpret_cast<int32_t *>(cs + m);                  // [m] row k
+    int32_t *col_off = ck + m, *cursor = col_off + (n + 1);            // [n + 1], [n]
     for (size_t q = tid; q < (size_t)n * n; q += 256) { D[q] = 0.0; K[q] = -2; has[q] = 0; }
+    for (int q = tid; q <= n; q += 256) col_off[q] = 0;
     __syncthreads();
-    for (int e = tid; e < jb.nedges; e += 256) {                       // SCORES[(v,w)] = -stem[2]  (:49)
+    for (int e = tid; e < m; e += 256) atomicAdd(&col_off[edges[jb.edge_off + e].w + 1], 1);
+    __syncthreads();
+    if (tid == 0) for (int j = 0; j < n; j++) col_off[j + 1] += col_off[j];
+    __syncthreads();
+    for (int q = tid; q < n; q += 256) cursor[q] = col_off[q];
+    __syncthreads();
+    for (int e = tid; e < m; e += 256) {                               // SCORES[(v,w)] = -stem[2]  (:49)
         const SqMatchEdge ed = edges[jb.edge_off + e];
-        S[(size_t)ed.v * n + ed.w] = -ed.weight; has[(size_t)ed.v * n + ed.w] = 1;
+        const int pos = atomicAdd(&cursor[ed.w], 1);
+        ck[pos] = ed.v; cs[pos] = -ed.weight;
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) {                               // ascending k inside every column (short lists)
+        const int a = col_off[j], b = col_off[j + 1];
+        for (int x = a + 1; x < b; x++) {
+            const int kk = ck[x]; const double vv = cs[x];
+            int y = x - 1;
+            while (y >= a && ck[y] > kk) { ck[y + 1] = ck[y]; cs[y + 1] = cs[y]; y--; }
+            ck[y + 1] = kk; cs[y + 1] = vv;
+        }
     }
     __syncthreads();
     for (int h = 1; h < n; h++) {                                       // :65
         for (int i = tid; i < n - h; i += 256) {
             const int j = i + h;
             int bestk = -1; double best = 1e9;                          // :70
-            for (int k = i; k < j - 1; k++) {                           // :73
-                if (!has[(size_t)k * n + j]) continue;
+            for (int x = col_off[j]; x < col_off[j + 1]; x++) {         // k in range(i, j - 1) with (k, j) in SCORES (:73-74)
+                const int k = ck[x];
+                if (k < i) continue;
+                if (k >= j - 1) break;
                 // D[i, k-1] with k == i is numpy's D[i, -1] = D[i, n-1], still 0 at this point (:76)
                 const double dik = k > i ? D[(size_t)i * n + (k - 1)] : D[(size_t)i * n + (n - 1)];
-                const double sc = dik + D[(size_t)(k + 1) * n + (j - 1)] + S[(size_t)k * n + j];
+                const double sc = dik + D[(size_t)(k + 1) * n + (j - 1)] + cs[x];
                 if (sc < best) { bestk = k; best = sc; }
             }
             const double dprev = D[(size_t)i * n + (j - 1)];
@@ -187,8 +213,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
         int32_t *out = pairs_out + 2 * (size_t)jb.out_off;
         // queue storage: the tail of the job's scratch (two arrays of (i, j) cells)
         int32_t *cur = reinterpret_cast<int32_t *>(has + (((size_t)n * n + 15) & ~(size_t)15)), *nxt = cur + 2 * (size_t)(n + 2);
-        uint8_t *inq = has;            // has[] no longer needed
-        for (size_t t = 0; t < (size_t)n * n; t++) inq[t] = 0;
+        uint8_t *inq = has;            // zeroed above
         int qn = 1, np = 0;
         cur[0] = 0; cur[1] = n - 1;
         auto sep = [&](int p) { return cd[p] == 26 || cd[p] == 27; };
