@@ -112,41 +112,67 @@ struct SqBlossom {
     SQ_HD static int queue_cap(int n, int m, int tight) { return tight ? 4 * n + m + 16 : 8 * n + 2 * m + 16; }
     SQ_HD static int pool_capacity(int n, int m, int tight) { return tight ? 4 * n + m + 256 : n * 32 + 2 * m + 1024; }
     SQ_HD static int frame_ints(int n, int tight) { return tight ? 8 * (n / 2 + 4) : 10 * (2 * n + 2); }
-    SQ_HD static size_t scratch_bytes(int n, int m, int tight = 0)
+    // The state is carved into three parts so that it can be placed by temperature:
+    //   hot   what every scan pass of the queue loop reads or writes (vertex / blossom state + allowedge + queue)
+    //   cold  the blossom structure, only touched by lane 0 when a neighbour changes shared state
+    //   edge  the adjacency in CSR order (streamed: one coalesced read per pass)
+    SQ_HD static int queue_hot_cap(int n) { return 4 * n + 16; }       // S-vertices of one stage (overflow -> error)
+    SQ_HD static size_t hot_bytes(int n, int m, int tight)
     {
         const size_t N2 = 2 * (size_t)n + 2;
-        size_t ints = (size_t)n + 1 + 2 * (size_t)m            // adj_off, adj
-                      + 2 * (size_t)m + 4 * (size_t)m + 2       // adjv, adjw (doubles)
-                      + 2 * (size_t)n                           // mate, mate_de
-                      + 4 * N2 + (size_t)n                      // labeledge, parent, base, bestedge, inblossom
-                      + (size_t)queue_cap(n, m, tight)          // queue
-                      + 8 * N2                                  // sib_next, sib_prev, edge_after, first, nchild, nleaf, mbe_off, mbe_cnt
-                      + (size_t)pool_capacity(n, m, tight)      // pool
-                      + 2 * (size_t)n + 2                       // live, freeb
-                      + 2 * N2 + 4 * N2 + 2 * N2                // tmp_leaves, tmp_stack | tmp_path, tmp_edges (2 each) | beto, beto_keys
-                      + (size_t)frame_ints(n, tight);           // frames
-        return ints * 4 + ((size_t)n + 2 * N2) * 8 + N2 + (size_t)m + 256;
+        const size_t q = tight == 2 ? (size_t)queue_hot_cap(n) : (size_t)queue_cap(n, m, tight);
+        return ((size_t)n + N2) * 8                              // dualvar, bslack
+               + ((size_t)n + 1 + (size_t)n + 2 * N2 + q) * 4    // adj_off, inblossom, bestedge, labeledge, queue
+               + N2 + (size_t)m + 64;                            // label, allow
+    }
+    SQ_HD static size_t cold_bytes(int n, int m, int tight)
+    {
+        const size_t N2 = 2 * (size_t)n + 2;
+        size_t ints = 2 * (size_t)n                              // mate, mate_de
+                      + 2 * N2                                   // parent, base
+                      + 8 * N2                                   // sib_next, sib_prev, edge_after, first, nchild, nleaf, mbe_off, mbe_cnt
+                      + (size_t)pool_capacity(n, m, tight ? 1 : 0)   // pool
+                      + 2 * (size_t)n + 2                        // live, freeb
+                      + 2 * N2 + 4 * N2 + 2 * N2                 // tmp_leaves, tmp_stack | tmp_path, tmp_edges (2 each) | beto, beto_keys
+                      + (size_t)frame_ints(n, tight ? 1 : 0);    // frames
+        return ints * 4 + N2 * 8 + 64;                           // + bdual
+    }
+    SQ_HD static size_t edge_bytes(int m) { return 2 * (size_t)m * (4 + 4 + 8) + 64; }   // adj, adjv, adjw
+    SQ_HD static size_t scratch_bytes(int n, int m, int tight = 0)
+    {
+        return hot_bytes(n, m, tight) + cold_bytes(n, m, tight) + edge_bytes(m) + 64;
     }
 
-    SQ_HD void init(int n_, int m_, const SqMatchEdge *edges, char *scratch, int tight = 0, bool csr = true)
+    // hot / cold / edge: where the three parts live; cold == nullptr (edge == nullptr): carved right behind the
+    // previous part.  tight: 0 generous capacities, 1 tight, 2 tight with the short queue (hot part alone in LDS).
+    SQ_HD void init(int n_, int m_, const SqMatchEdge *edges, char *hot, int tight = 0, bool csr = true,
+                    char *cold = nullptr, char *edge = nullptr)
     {
         n = n_; m = m_; E = edges; error = 0;
         const int N2 = 2 * n + 2;
-        char *p = scratch;
+        char *p = hot;
         auto take_d = [&](size_t k) { p = (char *)(((uintptr_t)p + 7) & ~(uintptr_t)7); double *r = (double *)p; p += k * 8; return r; };
         auto take_i = [&](size_t k) { p = (char *)(((uintptr_t)p + 3) & ~(uintptr_t)3); int *r = (int *)p; p += k * 4; return r; };
-        dualvar = take_d(n); bdual = take_d(N2); bslack = take_d(N2); adjw = take_d(2 * (size_t)m);
-        adj_off = take_i(n + 1); adj = take_i(2 * (size_t)m); adjv = take_i(2 * (size_t)m);
+        // ---- hot
+        dualvar = take_d(n); bslack = take_d(N2);
+        adj_off = take_i(n + 1); inblossom = take_i(n); bestedge = take_i(N2); labeledge = take_i(N2);
+        qcap = tight == 2 ? queue_hot_cap(n) : queue_cap(n, m, tight); queue = take_i(qcap); qn = 0;
+        label = (int8_t *)p; p += N2; allow = (uint8_t *)p; p += m;
+        // ---- cold
+        if (cold) p = cold;
+        bdual = take_d(N2);
         mate = take_i(n); mate_de = take_i(n);
-        labeledge = take_i(N2); parent = take_i(N2); base = take_i(N2); bestedge = take_i(N2); inblossom = take_i(n);
-        qcap = queue_cap(n, m, tight); queue = take_i(qcap); qn = 0;
+        parent = take_i(N2); base = take_i(N2);
         sib_next = take_i(N2); sib_prev = take_i(N2); edge_after = take_i(N2); first = take_i(N2); nchild = take_i(N2); nleaf = take_i(N2);
         mbe_off = take_i(N2); mbe_cnt = take_i(N2);
-        pool_cap = pool_capacity(n, m, tight); pool = take_i(pool_cap); pool_n = 0;
+        pool_cap = pool_capacity(n, m, tight ? 1 : 0); pool = take_i(pool_cap); pool_n = 0;
         live = take_i(n + 1); freeb = take_i(n + 1);
         tmp_leaves = take_i(N2); tmp_stack = take_i(N2); tmp_path = take_i(2 * (size_t)N2); tmp_edges = take_i(2 * (size_t)N2);
-        beto = take_i(N2); beto_keys = take_i(N2); frame_cap = frame_ints(n, tight); frames = take_i((size_t)frame_cap);
-        label = (int8_t *)p; p += N2; allow = (uint8_t *)p; p += m;
+        beto = take_i(N2); beto_keys = take_i(N2); frame_cap = frame_ints(n, tight ? 1 : 0); frames = take_i((size_t)frame_cap);
+        // ---- edge
+        if (edge) p = edge;
+        adjw = take_d(2 * (size_t)m);
+        adj = take_i(2 * (size_t)m); adjv = take_i(2 * (size_t)m);
         if (!csr) return;                                       // the caller builds it with build_csr()
         // adjacency in insertion order: edge e = (v, w) appends w to adj[v] and v to adj[w]
         for (int v = 0; v <= n; v++) adj_off[v] = 0;
@@ -519,10 +545,13 @@ struct SqBlossom {
     // FAST: the edges and all state arrays live in ONE LDS buffer whose address the caller passes as `fast0`
     // (and as `origin`, its generic address).  The hot loops then address the arrays as fast0 + offset, which lets
     // the compiler prove the address space and emit ds_read/ds_write instead of flat loads through the LDS aperture.
-    template <bool FAST, class Sync, class Coop>
+    // FAST 1: edges, hot, cold and edge parts are one LDS buffer; FAST 2: only the hot part is in LDS (at fast0),
+    // everything else in global memory; FAST 0: everything generic.
+    template <int FAST, class Sync, class Coop>
     SQ_HD void run(int lane, int nl, Sync sync, Coop coop, char *fast0)
     {
-#define SQ_LP(p) (FAST ? (decltype(p))(fast0 + ((char *)(p) - origin)) : (p))
+#define SQ_LP(p) (FAST ? (decltype(p))(fast0 + ((char *)(p) - origin)) : (p))            /* hot arrays */
+#define SQ_LQ(p) (FAST == 1 ? (decltype(p))(fast0 + ((char *)(p) - origin)) : (p))       /* cold / edge arrays */
         const int N2 = 2 * n + 2;
         for (int v = lane; v < n; v += nl) { mate[v] = -1; mate_de[v] = -1; inblossom[v] = v; }
         for (int x = lane; x < N2; x += nl) {
@@ -543,15 +572,15 @@ struct SqBlossom {
         sync();
         // the hot loop works on register copies of the array bases: `this` lives in LDS, and every byte store
         // (label, allowedge) would otherwise force the compiler to reload the pointer members
-        const SqMatchEdge *const E_ = SQ_LP(E);
-        const int *const adj_ = SQ_LP(adj), *const adj_off_ = SQ_LP(adj_off), *const inblossom_ = SQ_LP(inblossom);
-        const int *const queue_ = SQ_LP(queue), *const adjv_ = SQ_LP(adjv);
-        const double *const adjw_ = SQ_LP(adjw);
+        const SqMatchEdge *const E_ = SQ_LQ(E);
+        const int *const adj_ = SQ_LQ(adj), *const adj_off_ = SQ_LP(adj_off), *const inblossom_ = SQ_LP(inblossom);
+        const int *const queue_ = SQ_LP(queue), *const adjv_ = SQ_LQ(adjv);
+        const double *const adjw_ = SQ_LQ(adjw);
         int *const labeledge_ = SQ_LP(labeledge), *const bestedge_ = SQ_LP(bestedge);
         int8_t *const label_ = SQ_LP(label);
         uint8_t *const allow_ = SQ_LP(allow);
-        double *const dualvar_ = SQ_LP(dualvar), *const bdual_ = SQ_LP(bdual), *const bslack_ = SQ_LP(bslack);
-        const int *const parent_ = SQ_LP(parent), *const live_ = SQ_LP(live);
+        double *const dualvar_ = SQ_LP(dualvar), *const bdual_ = SQ_LQ(bdual), *const bslack_ = SQ_LP(bslack);
+        const int *const parent_ = SQ_LQ(parent), *const live_ = SQ_LQ(live);
         auto slack_ = [&](int de) -> double {
             const SqMatchEdge ed = E_[de >> 1];
             return (de & 1) ? dualvar_[ed.w] + dualvar_[ed.v] - 2 * ed.weight : dualvar_[ed.v] + dualvar_[ed.w] - 2 * ed.weight;
@@ -832,8 +861,9 @@ struct SqBlossom {
     }
 
 #undef SQ_LP
+#undef SQ_LQ
     SQ_HD void run()
     {
-        run<false>(0, 1, [] {}, SqCoopSingle(), nullptr);
+        run<0>(0, 1, [] {}, SqCoopSingle(), nullptr);
     }
 };

@@ -263,21 +263,35 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
     const SqMatchJob *jp = jobs + blockIdx.x;
     const int n = jp->n, m = jp->nedges, lane = threadIdx.x;
     if (n <= 0) { publish(); return; }
-    // The algorithm is a long chain of dependent loads on lane 0: keep its arrays and the edge list in LDS
-    // when they fit (tight capacities); on a capacity overflow rerun the job in global memory.
-    const size_t ebytes = ((size_t)m * sizeof(SqMatchEdge) + 15) & ~(size_t)15;
-    const bool in_lds = SqBlossom::scratch_bytes(n, m, 1) + ebytes + 16 <= (size_t)lds_bytes;
+    // The algorithm is a long chain of dependent loads: keep its state in LDS -- all of it with the edge list when
+    // that fits (tight capacities), else only the hot part (what every scan pass touches; blossom structure and
+    // adjacency stay in global memory); on a capacity overflow rerun the job in global memory.
 #ifdef SQ_MWM_PROF
     const long long _c0 = clock64(), _w0 = wall_clock64();
 #endif
-    if (in_lds) {
+    const size_t ebytes = ((size_t)m * sizeof(SqMatchEdge) + 15) & ~(size_t)15;
+    char *gscratch = scratch + jp->scratch_off;
+    const bool all_lds = SqBlossom::scratch_bytes(n, m, 1) + ebytes + 16 <= (size_t)lds_bytes;
+    const bool hot_lds = !all_lds && SqBlossom::hot_bytes(n, m, 2) + 16 <= (size_t)lds_bytes;
+    if (all_lds) {
         SqMatchEdge *le = reinterpret_cast<SqMatchEdge *>(mwm_lds);
         for (int e = lane; e < m; e += 64) le[e] = edges[jp->edge_off + e];
         __syncthreads();
         if (lane == 0) { bl.init(n, m, le, mwm_lds + ebytes, 1, false); bl.origin = mwm_lds; }
         __syncthreads();
         bl.build_csr(lane, 64, [] { __syncthreads(); });
-        bl.run<true>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), mwm_lds);
+        bl.run<1>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), mwm_lds);
+    } else if (hot_lds) {
+        if (lane == 0) {
+            char *cold = gscratch;
+            bl.init(n, m, edges + jp->edge_off, mwm_lds, 2, false, cold, cold + ((SqBlossom::cold_bytes(n, m, 2) + 15) & ~(size_t)15));
+            bl.origin = mwm_lds;
+        }
+        __syncthreads();
+        bl.build_csr(lane, 64, [] { __syncthreads(); });
+        bl.run<2>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), mwm_lds);
+    }
+    if (all_lds || hot_lds) {
         __syncthreads();
         if (!bl.error) {
             for (int q = lane; q < n; q += 64) mate_out[jp->out_off + q] = bl.mate[q];
@@ -292,11 +306,11 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
         }
         __syncthreads();
     }
-    if (lane == 0) bl.init(n, m, edges + jp->edge_off, scratch + jp->scratch_off, 0, false);
+    if (lane == 0) bl.init(n, m, edges + jp->edge_off, gscratch, 0, false);
     __syncthreads();
     bl.build_csr(lane, 64, [] { __syncthreads(); });
     // lane 0 runs the order-dependent part; all 64 lanes share the O(n) sweeps of every substage
-    bl.run<false>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), nullptr);
+    bl.run<0>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), nullptr);
     __syncthreads();
     for (int q = lane; q < n; q += 64) mate_out[jp->out_off + q] = bl.error ? -2 : bl.mate[q];
     publish();
