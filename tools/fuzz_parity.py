@@ -12,7 +12,7 @@ def make(nseq, seed):
     rng = np.random.default_rng(seed)
     recs = []
     for k in range(nseq):
-        n = int(rng.integers(12, 170))
+        n = int(rng.integers(int(os.environ.get("FUZZ_NMIN", "12")), int(os.environ.get("FUZZ_NMAX", "170"))))
         seq = "".join(rng.choice(list("ACGU"), n, p=[0.22, 0.28, 0.28, 0.22]))
         reacts = None
         if k % 5 == 0:
