@@ -89,7 +89,7 @@ def Metrics(ref, pred):
 
 
 def SQRNdbnali(objs, defrests=None, defreacts=None, defref=None, bpweights={}, interchainonly=False,
-               minlen=2, minbpscore=0, threads=1, verbose=False, sink=sys.stdout, M=1.8, B=-0.6, nseq_total=None):
+               minlen=2, minbpscore=0, threads=1, verbose=False, sink=sys.stdout, M=1.8, B=-0.6):
     """Step-1 iteration: (first assembled dbn, L x L stem matrix) -- SQRNdbnali.py:211-242."""
     L = len(objs[0][1])
     recs = [(obj[1].upper().replace("T", "U"), obj[2], defrests if defrests else obj[3]) for obj in objs]
@@ -100,9 +100,8 @@ def SQRNdbnali(objs, defrests=None, defreacts=None, defref=None, bpweights={}, i
         reduce_hook = getattr(eng, "reduce_matrix", None)
         if reduce_hook is not None:
             stemmatrix = reduce_hook(stemmatrix)                   # multi-GPU: all_reduce(sum) of the partial matrices
-        cells = eng.matrix_cells(stemmatrix, minbpscore * len(objs) if nseq_total is None else minbpscore * nseq_total)
-        pred = MatrixToDBNs(stemmatrix, minbpscore, len(objs) if nseq_total is None else nseq_total, verbose, sink=sink,
-                            cells=cells)
+        cells = eng.matrix_cells(stemmatrix, minbpscore * len(objs))
+        pred = MatrixToDBNs(stemmatrix, minbpscore, len(objs), verbose, sink=sink, cells=cells)
         return pred[0], stemmatrix
     stemmatrix = np.zeros((L, L))
     allstems = eng.yield_stems(recs, bpweights, minlen, minbpscore, interchainonly)
@@ -125,7 +124,7 @@ def SQRNdbnali(objs, defrests=None, defreacts=None, defref=None, bpweights={}, i
     reduce_hook = getattr(eng, "reduce_matrix", None)
     if reduce_hook is not None:
         stemmatrix = reduce_hook(stemmatrix)
-    pred = MatrixToDBNs(stemmatrix, minbpscore, len(objs) if nseq_total is None else nseq_total, verbose, sink=sink)
+    pred = MatrixToDBNs(stemmatrix, minbpscore, len(objs), verbose, sink=sink)
     return pred[0], stemmatrix
 
 
