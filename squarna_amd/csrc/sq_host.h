@@ -67,18 +67,33 @@ class SqPool {
 public:
     explicit SqPool(int nthreads);
     ~SqPool();
-    void parallel_for(int n, const std::function<void(int)> &fn);
+    void parallel_for(int n, const std::function<void(int)> &fn);   // callers are serialised (two fold lanes share the pool)
     int size() const { return (int)workers.size() + 1; }
 private:
     void worker();
     std::vector<std::thread> workers;
-    std::mutex mu;
+    std::mutex mu, callers;
     std::condition_variable cv_start, cv_done;
     const std::function<void(int)> *fn = nullptr;
     std::atomic<int> next{0};
     int total = 0, active = 0;
     uint64_t gen = 0;
     bool stop = false;
+};
+
+// The round buffers one greedy loop works with.  A batch has one lane that spans all of them; sq_fold may split them
+// into two lanes (two host threads, each driving the rounds of half of the jobs), so that the bookkeeping of one
+// lane overlaps the kernels of the other.
+struct SqLane {
+    SqStruct *h_structs = nullptr; SqStrand *h_strands = nullptr; SqOut *h_out = nullptr;   // pinned
+    SqCounters *h_ctr = nullptr; uint32_t *h_seq = nullptr;
+    SqStruct *d_structs = nullptr; SqStrand *d_strands = nullptr; SqOut *d_out = nullptr;   // device
+    SqCounters *d_ctr = nullptr;
+    uint32_t h_out_cap = 0, out_cap = 0;
+    int32_t slot0 = 0, max_structs = 0, strand_cap = 0;
+    int64_t cand0 = 0, cand_records = 0;      // records [cand0, cand0 + cand_records) of the candidate arena
+    uint32_t round_seq = 0;
+    std::vector<SqOut> big_out;
 };
 
 struct sq_batch {
@@ -126,6 +141,8 @@ struct sq_batch {
     // results
     std::vector<SeqResult> results;
     SqPool *pool = nullptr;               // lazily created host workers
+    SqLane lane_full, lane_half[2];       // see SqLane
+    SqCounters *h_ctr2 = nullptr; uint32_t *h_seq2 = nullptr;   // pinned counters / sequence word of the second lane
     // profiling
     bool prof_on = false;
     ProfSlot prof[7];                     // 0 fill, 1 state, 2 scan, 3 score, 4 Edmonds, 5 Hungarian, 6 Nussinov

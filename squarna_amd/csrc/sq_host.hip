@@ -58,6 +58,7 @@ void SqPool::parallel_for(int n, const std::function<void(int)> &f)
 {
     if (n <= 0) return;
     if (workers.empty() || n == 1) { for (int i = 0; i < n; i++) f(i); return; }
+    std::lock_guard<std::mutex> one_caller(callers);
     {
         std::lock_guard<std::mutex> lk(mu);
         fn = &f; total = n; next.store(0); active = (int)workers.size(); gen++;
@@ -171,7 +172,7 @@ int plan(const sq_batch_desc *d, Layout &L)
     L.off_strands = take(sizeof(SqStrand) * (size_t)L.strand_cap);
     L.off_state = take((size_t)4 * 2 * L.stride * L.max_structs);
     L.off_cnt = take(16 * (size_t)align_up((size_t)L.max_structs, 2));   // cand_cnt (u32), best (u64), ok_cnt (u32) per slot
-    L.off_ctr = take(sizeof(SqCounters));
+    L.off_ctr = take(2 * 64);                               // one SqCounters per fold lane (64 bytes apart)
     L.off_cands = take(sizeof(SqCand) * (size_t)L.cand_records);
     L.off_out = take(sizeof(SqOut) * (size_t)L.out_cap);
     L.off_bits = take(4 * (size_t)std::max<int64_t>(L.bits_words, 1));
@@ -376,7 +377,30 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         sq_check(hipHostMalloc((void **)&b->h_seq, 64, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc")) { delete b; return 2; }
     *b->h_seq = 0; b->round_seq = 0;
     b->h_out_cap = (uint32_t)std::min<uint64_t>(1u << 18, L.out_cap);
-    if (sq_check(hipHostMalloc((void **)&b->h_out, sizeof(SqOut) * (size_t)b->h_out_cap, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc")) { delete b; return 2; }
+    if (sq_check(hipHostMalloc((void **)&b->h_out, sizeof(SqOut) * (size_t)b->h_out_cap, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc") ||
+        sq_check(hipHostMalloc((void **)&b->h_ctr2, sizeof(SqCounters), hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc") ||
+        sq_check(hipHostMalloc((void **)&b->h_seq2, 64, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc")) { delete b; return 2; }
+    *b->h_seq2 = 0;
+    {   // the lane that spans all round buffers, and its two halves
+        SqLane &F = b->lane_full;
+        F.h_structs = b->h_structs; F.h_strands = b->h_strands; F.h_out = b->h_out; F.h_ctr = b->h_ctr; F.h_seq = b->h_seq;
+        F.d_structs = b->d_structs; F.d_strands = b->d_strands; F.d_out = b->d_out; F.d_ctr = b->scan.ctr;
+        F.h_out_cap = b->h_out_cap; F.out_cap = b->out_cap; F.slot0 = 0; F.max_structs = b->max_structs;
+        F.strand_cap = b->strand_cap; F.cand0 = 0; F.cand_records = b->cand_records;
+        for (int k = 0; k < 2; k++) {
+            SqLane &H = b->lane_half[k];
+            const int ms0 = b->max_structs / 2, sc0 = b->strand_cap / 2;
+            const uint32_t ho0 = b->h_out_cap / 2, oc0 = b->out_cap / 2;
+            H.slot0 = k ? ms0 : 0; H.max_structs = k ? b->max_structs - ms0 : ms0;
+            H.h_structs = b->h_structs + H.slot0; H.d_structs = b->d_structs + H.slot0;
+            H.strand_cap = k ? b->strand_cap - sc0 : sc0;
+            H.h_strands = b->h_strands + (k ? sc0 : 0); H.d_strands = b->d_strands + (k ? sc0 : 0);
+            H.h_out_cap = k ? b->h_out_cap - ho0 : ho0; H.out_cap = k ? b->out_cap - oc0 : oc0;
+            H.h_out = b->h_out + (k ? ho0 : 0); H.d_out = b->d_out + (k ? oc0 : 0);
+            H.h_ctr = k ? b->h_ctr2 : b->h_ctr; H.h_seq = k ? b->h_seq2 : b->h_seq;
+            H.d_ctr = (SqCounters *)((char *)b->scan.ctr + (k ? 64 : 0));
+        }
+    }
     int rr = sq_check(hipStreamSynchronize(st), "sync after upload");   // host vectors above go out of scope
     if (rr) { delete b; return rr; }
     b->results.resize(d->nseq);
@@ -392,6 +416,8 @@ extern "C" void sq_batch_destroy(sq_batch *b)
     if (b->h_strands) hipHostFree(b->h_strands);
     if (b->h_ctr) hipHostFree(b->h_ctr);
     if (b->h_seq) hipHostFree(b->h_seq);
+    if (b->h_ctr2) hipHostFree(b->h_ctr2);
+    if (b->h_seq2) hipHostFree(b->h_seq2);
     delete b->pool;
     for (int k = 0; k < 4; k++) if (b->stage_buf[k]) hipHostFree(b->stage_buf[k]);
     if (b->h_out) hipHostFree(b->h_out);
@@ -674,20 +700,20 @@ struct AlignSink {                    // mode 2: where the stems of structure k 
 };
 }
 
-static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, size_t hi, int mode,
+static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs, size_t lo, size_t hi, int mode,
                      std::vector<std::vector<HStem>> &out, const AlignSink *sink = nullptr)
 {
     const int S = (int)(hi - lo);
-    int nstrand = 0, maxn = 0; int64_t cand_off = 0, maxcap = 0; double scan_bytes = 0;
+    int nstrand = 0, maxn = 0; int64_t cand_off = ln.cand0, maxcap = 0; double scan_bytes = 0;
     double tp0 = now_s();
     for (int s = 0; s < S; s++) {
         const SView &hs = structs[lo + s];
         const SqJob &J = b->jobs[hs.job];
-        SqStruct &d = b->h_structs[s];
-        d.job = hs.job; d.slot = s; d.subopt = hs.subopt; d.cand_off = cand_off;
+        SqStruct &d = ln.h_structs[s];
+        d.job = hs.job; d.slot = ln.slot0 + s; d.subopt = hs.subopt; d.cand_off = cand_off;
         cand_off += J.cand_cap; maxcap = std::max<int64_t>(maxcap, J.cand_cap);
         d.strand_off = nstrand; d.nstrand = (int)hs.st->strands.size();
-        if (d.nstrand) memcpy(b->h_strands + nstrand, hs.st->strands.data(), sizeof(SqStrand) * (size_t)d.nstrand);
+        if (d.nstrand) memcpy(ln.h_strands + nstrand, hs.st->strands.data(), sizeof(SqStrand) * (size_t)d.nstrand);
         nstrand += d.nstrand;
         maxn = std::max(maxn, J.n);
         scan_bytes += 2.0 * J.n * J.n;                     // algorithmic: fp32 upper triangle, N^2/2 cells
@@ -695,15 +721,17 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
     hipStream_t st = b->stream;
     g_t[0] += now_s() - tp0; tp0 = now_s();
     SqRoundIO io;
-    io.h_structs = b->h_structs; io.h_strands = b->h_strands; io.d_structs = b->d_structs; io.d_strands = b->d_strands;
-    io.h_out = b->h_out; io.d_out = b->d_out; io.h_cap = b->h_out_cap; io.out_cap = b->out_cap;
-    io.h_ctr = b->h_ctr; io.h_seq = b->h_seq;
+    io.h_structs = ln.h_structs; io.h_strands = ln.h_strands; io.d_structs = ln.d_structs; io.d_strands = ln.d_strands;
+    io.h_out = ln.h_out; io.d_out = ln.d_out; io.h_cap = ln.h_out_cap; io.out_cap = ln.out_cap;
+    io.h_ctr = ln.h_ctr; io.h_seq = ln.h_seq;
+    SqScanArgs scan = b->scan;                           // this lane's counters
+    scan.ctr = ln.d_ctr;
     {
         ProfScope ps(b, 1, 0);
         // the per-structure arrays are assembled in LDS (7 bytes per position) when the longest sequence fits
         const int st_lds_n = maxn <= 8000 ? maxn : 0;
         const size_t st_dyn = st_lds_n ? (size_t)7 * ((st_lds_n + 8) & ~7) + 64 : 0;
-        hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(256), st_dyn, st, b->ctx, io, b->state, b->scan, st_lds_n);
+        hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(256), st_dyn, st, b->ctx, io, b->state, scan, st_lds_n);
     }
     if (maxn >= 5) {
         const int nband = (2 * maxn - 5 + 255) >> 8;
@@ -711,14 +739,14 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
         ProfScope ps(b, 2, scan_bytes);
         if (scan_v == 6) {                          // bit-diagonal scan: one wave = 64 anti-diagonals
             hipLaunchKernelGGL(sq_scan6_kernel, dim3(S, (2 * maxn - 5 + 63) / 64 + 1), dim3(64), 4 * (size_t)b->state.fbstride, st,
-                               b->ctx, b->d_structs, b->state, b->scan);
+                               b->ctx, ln.d_structs, b->state, scan);
         } else {
             const int seg = scan_v == 4 ? sq_scan_seg() : sq_scan5_seg();
             const int nseg = ((maxn >> 1) + 130 + seg - 1) / seg;
             if (scan_v == 4)
-                hipLaunchKernelGGL(sq_scan_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, b->d_structs, b->state, b->scan);
+                hipLaunchKernelGGL(sq_scan_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, ln.d_structs, b->state, scan);
             else
-                hipLaunchKernelGGL(sq_scan5_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, b->d_structs, b->state, b->scan);
+                hipLaunchKernelGGL(sq_scan5_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, ln.d_structs, b->state, scan);
         }
     }
     {
@@ -737,32 +765,32 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
         int parts = std::max(1, std::min({512, (4096 + S - 1) / S, (int)(maxcap / 1024)}));
         if (score_parts) parts = score_parts;
         const int thr = score_threads ? score_threads : (parts == 1 && S < 2048 ? 512 : 256);
-        hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, b->d_structs, b->d_strands, b->state,
-                           b->scan, io, mode, lds_n, lds_nr, lds_ns);
+        hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, ln.d_structs, ln.d_strands, b->state,
+                           scan, io, mode, lds_n, lds_nr, lds_ns);
         if (mode == 0)
-            hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, b->d_structs, b->scan, io);
+            hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, ln.d_structs, scan, io);
         if (mode == 2) {
             // gap maps of the chunk's sequences into the (unused) round output buffer, then one scatter launch per
             // sequence, in list order: stream order == the reference's per-cell summation order (dbnali:233-237)
-            int32_t *d_cols = (int32_t *)b->d_out;
+            int32_t *d_cols = (int32_t *)ln.d_out;
             const int32_t c0 = sink->col_off[lo], c1 = sink->col_off[hi];
-            if ((size_t)(c1 - c0) * 4 > (size_t)b->out_cap * sizeof(SqOut)) { sq_set_error("gap maps do not fit the round buffer"); return -3; }
+            if ((size_t)(c1 - c0) * 4 > (size_t)ln.out_cap * sizeof(SqOut)) { sq_set_error("gap maps do not fit the round buffer"); return -3; }
             HIPCK(hipMemcpyAsync(d_cols, sink->cols + c0, (size_t)(c1 - c0) * 4, hipMemcpyHostToDevice, st));
             for (int k = 0; k < S; k++) {
                 const SqJob &J = b->jobs[structs[lo + k].job];
                 const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>(J.cand_cap / 1024, 1), 1024);
-                hipLaunchKernelGGL(sq_scatter_kernel, dim3(blocks), dim3(256), 0, st, b->ctx, b->d_structs, b->scan, k,
+                hipLaunchKernelGGL(sq_scatter_kernel, dim3(blocks), dim3(256), 0, st, b->ctx, ln.d_structs, scan, k,
                                    d_cols + (sink->col_off[lo + k] - c0), sink->L, sink->matrix);
             }
         }
     }
-    const uint32_t seq = ++b->round_seq;
-    hipLaunchKernelGGL(sq_done_kernel, dim3(1), dim3(1), 0, st, io, b->scan, seq);
+    const uint32_t seq = ++ln.round_seq;
+    hipLaunchKernelGGL(sq_done_kernel, dim3(1), dim3(1), 0, st, io, scan, seq);
     HIPCK(hipGetLastError());
     // wait for the round: spin on the sequence number in pinned memory (no driver round trip); a stuck or
     // faulted queue is caught by polling the stream now and then
     {
-        volatile uint32_t *flag = b->h_seq;
+        volatile uint32_t *flag = ln.h_seq;
         uint64_t spins = 0;
         while (*flag != seq) {
             if ((++spins & 0xFFFFF) == 0) {
@@ -778,18 +806,18 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
-    const SqCounters ctr = *b->h_ctr;
+    const SqCounters ctr = *ln.h_ctr;
     if (ctr.cand_ovf) { sq_set_error("candidate capacity exceeded (raise cand_per_nt)"); return -3; }
     if (ctr.out_ovf) { sq_set_error("round output capacity exceeded (lower max_structs)"); return -3; }
     if (ctr.level_ovf) { sq_set_error("more than 64 pseudoknot levels"); return -3; }
     const uint32_t nout = ctr.nout;
-    const SqOut *ho = b->h_out;
-    if (nout > b->h_out_cap) {                               // rare: the tail of a huge round sits in device memory
-        b->big_out.resize(nout);
-        memcpy(b->big_out.data(), b->h_out, sizeof(SqOut) * (size_t)b->h_out_cap);
-        HIPCK(hipMemcpy(b->big_out.data() + b->h_out_cap, b->d_out + b->h_out_cap,
-                        sizeof(SqOut) * (size_t)(nout - b->h_out_cap), hipMemcpyDeviceToHost));
-        ho = b->big_out.data();
+    const SqOut *ho = ln.h_out;
+    if (nout > ln.h_out_cap) {                               // rare: the tail of a huge round sits in device memory
+        ln.big_out.resize(nout);
+        memcpy(ln.big_out.data(), ln.h_out, sizeof(SqOut) * (size_t)ln.h_out_cap);
+        HIPCK(hipMemcpy(ln.big_out.data() + ln.h_out_cap, ln.d_out + ln.h_out_cap,
+                        sizeof(SqOut) * (size_t)(nout - ln.h_out_cap), hipMemcpyDeviceToHost));
+        ho = ln.big_out.data();
     }
     g_t[1] += now_s() - tp0;
     if (mode == 2) return 0;
@@ -835,28 +863,31 @@ static int run_chunk(sq_batch *b, const std::vector<SView> &structs, size_t lo, 
     return 0;
 }
 
-static int run_round_impl(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out,
-                          const AlignSink *sink);
+static int run_round_impl(sq_batch *b, SqLane &ln, const std::vector<SView> &structs, int mode,
+                          std::vector<std::vector<HStem>> &out, const AlignSink *sink);
 int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out)
 {
-    return run_round_impl(b, structs, mode, out, nullptr);
+    return run_round_impl(b, b->lane_full, structs, mode, out, nullptr);
 }
-static int run_round_impl(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out,
-                          const AlignSink *sink)
+// `ln`: the round buffers to use.  The full lane ends where the arena is lent to matching kernels in flight
+// (cand_reserved); the half lanes are set up by sq_fold.
+static int run_round_impl(sq_batch *b, SqLane &ln, const std::vector<SView> &structs, int mode,
+                          std::vector<std::vector<HStem>> &out, const AlignSink *sink)
 {
     { int r = sq_prepare_scan(b); if (r) return r; }
     out.resize(structs.size());
+    const int64_t avail = &ln == &b->lane_full ? b->cand_records - b->cand_reserved : ln.cand_records;
     size_t lo = 0;
     while (lo < structs.size()) {
         size_t hi = lo; int64_t cands = 0, strands = 0;
-        while (hi < structs.size() && (int)(hi - lo) < b->max_structs) {
+        while (hi < structs.size() && (int)(hi - lo) < ln.max_structs) {
             const SqJob &J = b->jobs[structs[hi].job];
             const int64_t ns = (int64_t)structs[hi].st->strands.size();
-            if (hi > lo && (cands + J.cand_cap > b->cand_records - b->cand_reserved || strands + ns > b->strand_cap)) break;
+            if (hi > lo && (cands + J.cand_cap > avail || strands + ns > ln.strand_cap)) break;
             cands += J.cand_cap; strands += ns; hi++;
         }
-        if (cands > b->cand_records - b->cand_reserved || strands > b->strand_cap) { sq_set_error("structure does not fit the round buffers"); return -3; }
-        int r = run_chunk(b, structs, lo, hi, mode, out, sink);
+        if (cands > avail || strands > ln.strand_cap) { sq_set_error("structure does not fit the round buffers"); return -3; }
+        int r = run_chunk(b, ln, structs, lo, hi, mode, out, sink);
         if (r) return r;
         lo = hi;
     }
@@ -919,7 +950,7 @@ extern "C" int sq_align_accumulate(sq_batch *b, int32_t njob, const int32_t *job
     }
     AlignSink sink{col_off, cols, L, d_matrix};
     std::vector<std::vector<HStem>> unused;
-    return run_round_impl(b, views, 2, unused, &sink);
+    return run_round_impl(b, b->lane_full, views, 2, unused, &sink);
 }
 
 extern "C" int sq_colmatrix_select(const double *d_matrix, int32_t L, double threshold, int32_t minspan,
