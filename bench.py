@@ -103,26 +103,12 @@ def roofline_leg(nseq, n, seed=1000):
         cms, claunches, _ = b.profile_get(3)
         evals = sum(b.evals(k) for k in range(nseq))
         b.profile(False)
-        for _ in range(2):                                  # whole-fold wall time: best of 3 (host jitter)
+        for _ in range(3):                                  # whole-fold wall time, timers off: best of 3 (host jitter)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             b.fold(poollim=1)
             torch.cuda.synchronize()
             wall = min(wall, time.perf_counter() - t0)
-    # the same sequences as two batches folded concurrently from two host threads (host bookkeeping of one
-    # overlaps the kernels of the other); same total work, same results; best of 3 as well
-    from squarna_amd.engine import fold_concurrently
-    halves = [Batch(prepared[k::2], [psets] * len(prepared[k::2]), max_structs=nseq, fp32=False) for k in range(2)]
-    fold_concurrently(halves, poollim=1)                    # warm-up
-    wall2 = 1e9
-    for _ in range(3):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        fold_concurrently(halves, poollim=1)
-        torch.cuda.synchronize()
-        wall2 = min(wall2, time.perf_counter() - t0)
-    for h in halves:
-        h.close()
     achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -140,10 +126,8 @@ def roofline_leg(nseq, n, seed=1000):
                 alg_bytes_per_launch=round(alg_bytes / max(launches, 1)),
                 evals_R=int(evals), whole_fold_seq_per_s=round(nseq / wall, 1), whole_fold_ms=round(wall * 1e3, 2),   # best of 3
                 whole_fold_alg_GBs=round((alg_bytes + 4.0 * nseq * n * n) / wall / 1e9, 1),
-                whole_fold_two_batches=dict(ms=round(wall2 * 1e3, 2), seq_per_s=round(nseq / wall2, 1),
-                                            alg_GBs=round((alg_bytes + 4.0 * nseq * n * n) / wall2 / 1e9, 1),
-                                            frac_of_hbm_peak=round((alg_bytes + 4.0 * nseq * n * n) / wall2 / 1e9 / HBM_PEAK_GBS, 3),
-                                            how="two batches of nseq/2 folded concurrently from two host threads; best of 3"),
+                whole_fold_frac_of_hbm_peak=round((alg_bytes + 4.0 * nseq * n * n) / wall / 1e9 / HBM_PEAK_GBS, 3),
+                whole_fold_how="one sq_fold call on one batch, profiling off (the fold drives its rounds on two lanes); best of 3",
                 kernel_ms=dict(fill=round(fms, 3), state=round(sms, 3), scan=round(ms, 3), score=round(cms, 3)),
                 fill=dict(achieved=round(fbytes / (fms * 1e-3) / 1e9, 1) if fms > 0 else 0.0,
                           unit="GB/s", launches=int(flaunches)))

@@ -967,7 +967,7 @@ extern "C" int sq_colmatrix_select(const double *d_matrix, int32_t L, double thr
 
 // ---- a-7: greedy pool loop for every job at once (SQRNdbnseq.py:1102-1199) ----------------------
 namespace {
-struct JobPool {
+struct alignas(128) JobPool {                // (own cache lines: two lanes work on neighbouring jobs)
     std::vector<HStruct> cur;                // curstemsets
     std::vector<HStruct> nxt;                // next round's curstemsets (kept between rounds: no reallocation)
     std::vector<std::vector<HStem>> fin;     // finstemsets (greedy part)
@@ -1019,79 +1019,118 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     } guard{b, pending};
     if (r) return r;
     const double tbegin = now_s() - ta;
-    std::vector<SView> round;
-    std::vector<int> owner;                                 // job of each view
-    std::vector<std::vector<HStem>> res;
     const double tfold0 = now_s();
-    double tround = 0;
     for (int k = 0; k < 8; k++) g_t[k] = 0;
-    int nrounds = 0;
-    for (;;) {
-        round.clear(); owner.clear();
-        for (int j = 0; j < b->njobs; j++) {
-            JobPool &P = pools[j];
-            if (P.cur.empty()) continue;
-            if (P.cur.size() > P.cursize) {                 // :1162-1165
-                P.cursize = P.cur.size();
-                if (P.cursubopt < P.suboptmax) P.cursubopt += P.suboptinc;
-            }
-            bool anyfull = false;                           // :1168-1174
-            for (auto &s : P.cur) if ((double)s.stems.size() == P.maxstemnum) { anyfull = true; break; }
-            if (anyfull) {
-                std::vector<HStruct> keep;
-                for (auto &s : P.cur) {
-                    if ((double)s.stems.size() == P.maxstemnum) P.fin.push_back(std::move(s.stems));
-                    else keep.push_back(std::move(s));
-                }
-                P.cur.swap(keep);
-            }
-            for (size_t k = 0; k < P.cur.size(); k++) {
-                round.push_back(SView{j, P.cursubopt, &P.cur[k]});
-                owner.push_back(j);
-            }
-            P.evals += (int64_t)P.cur.size();
-        }
-        if (round.empty()) break;
-        { const double t0 = now_s(); r = sq_run_round(b, round, 0, res); tround += now_s() - t0; nrounds++; }
-        if (r) return r;
-        // :1179-1196.  The entries of one job are contiguous in `round` and only touch that job's pool, so jobs
-        // are independent; per job the entries are still handled in order.  Big rounds are shared among the
-        // worker pool in contiguous slices (children mostly reuse their parent's storage: no allocator traffic).
-        auto grow = [&](size_t q0, size_t q1) {
-            for (size_t q = q0; q < q1; q++) {
-                const int j = owner[q];
+    // the greedy pool loop (:1102-1199) for a subset of the jobs, on one lane of round buffers
+    struct LoopStats { double tround = 0, twall = 0, tstart = 0; int nrounds = 0; int rc = 0; std::string err; };
+    auto greedy_loop = [&](SqLane &ln, const std::vector<int> &myjobs, LoopStats &stats) {
+        std::vector<SView> round;
+        std::vector<int> owner;                             // job of each view
+        std::vector<std::vector<HStem>> res;
+        const double tl0 = now_s();
+        stats.tstart = tl0 - tfold0;
+        struct Wall { double t0; double &dst; ~Wall() { dst = now_s() - t0; } } wall{tl0, stats.twall};
+        for (;;) {
+            round.clear(); owner.clear();
+            for (int j : myjobs) {
                 JobPool &P = pools[j];
-                const std::vector<HStem> &news = res[q];
-                const HStruct &parent = *round[q].st;
-                if (!news.empty()) {
-                    const size_t stopper = P.cursize >= (size_t)o.poollim ? 1 : news.size();
-                    for (size_t k = 0; k < stopper; k++) {
-                        P.nxt.emplace_back();
-                        sq_extend_struct(parent, news[k], P.nxt.back(), k + 1 == stopper);   // the last child inherits the vectors
+                if (P.cur.empty()) continue;
+                if (P.cur.size() > P.cursize) {             // :1162-1165
+                    P.cursize = P.cur.size();
+                    if (P.cursubopt < P.suboptmax) P.cursubopt += P.suboptinc;
+                }
+                bool anyfull = false;                       // :1168-1174
+                for (auto &s : P.cur) if ((double)s.stems.size() == P.maxstemnum) { anyfull = true; break; }
+                if (anyfull) {
+                    std::vector<HStruct> keep;
+                    for (auto &s : P.cur) {
+                        if ((double)s.stems.size() == P.maxstemnum) P.fin.push_back(std::move(s.stems));
+                        else keep.push_back(std::move(s));
                     }
-                } else {
-                    P.fin.push_back(std::move(const_cast<HStruct &>(parent).stems));   // the structure is final and leaves the pool
+                    P.cur.swap(keep);
                 }
-            }
-            for (size_t q = q0; q < q1; q++)
-                if (q == q0 || owner[q] != owner[q - 1]) {   // once per job of the slice
-                    JobPool &P = pools[owner[q]];
-                    P.cur.swap(P.nxt);
-                    P.nxt.clear();                          // (capacity stays)
+                for (size_t k = 0; k < P.cur.size(); k++) {
+                    round.push_back(SView{j, P.cursubopt, &P.cur[k]});
+                    owner.push_back(j);
                 }
-        };
-        static const size_t par_min = getenv("SQ_GROW_PAR") ? (size_t)atol(getenv("SQ_GROW_PAR")) : 4096;
-        if (round.size() >= par_min) {
-            const int nsl = sq_pool(b)->size() * 4;
-            std::vector<size_t> cut(nsl + 1);
-            for (int t = 0; t <= nsl; t++) {
-                size_t q = round.size() * (size_t)t / (size_t)nsl;
-                while (q > 0 && q < round.size() && owner[q] == owner[q - 1]) q++;   // slices end on job boundaries
-                cut[t] = q;
+                P.evals += (int64_t)P.cur.size();
             }
-            sq_pool(b)->parallel_for(nsl, [&](int t) { if (cut[t] < cut[t + 1]) grow(cut[t], cut[t + 1]); });
-        } else grow(0, round.size());
+            if (round.empty()) break;
+            { const double t0 = now_s(); stats.rc = run_round_impl(b, ln, round, 0, res, nullptr); stats.tround += now_s() - t0; stats.nrounds++; }
+            if (stats.rc) { stats.err = sq_last_error(); return; }
+            // :1179-1196.  The entries of one job are contiguous in `round` and only touch that job's pool, so jobs
+            // are independent; per job the entries are still handled in order.  Big rounds are shared among the
+            // worker pool in contiguous slices (children mostly reuse their parent's storage: no allocator traffic).
+            auto grow = [&](size_t q0, size_t q1) {
+                for (size_t q = q0; q < q1; q++) {
+                    const int j = owner[q];
+                    JobPool &P = pools[j];
+                    const std::vector<HStem> &news = res[q];
+                    const HStruct &parent = *round[q].st;
+                    if (!news.empty()) {
+                        const size_t stopper = P.cursize >= (size_t)o.poollim ? 1 : news.size();
+                        for (size_t k = 0; k < stopper; k++) {
+                            P.nxt.emplace_back();
+                            sq_extend_struct(parent, news[k], P.nxt.back(), k + 1 == stopper);   // the last child inherits the vectors
+                        }
+                    } else {
+                        P.fin.push_back(std::move(const_cast<HStruct &>(parent).stems));   // the structure is final and leaves the pool
+                    }
+                }
+                for (size_t q = q0; q < q1; q++)
+                    if (q == q0 || owner[q] != owner[q - 1]) {   // once per job of the slice
+                        JobPool &P = pools[owner[q]];
+                        P.cur.swap(P.nxt);
+                        P.nxt.clear();                      // (capacity stays)
+                    }
+            };
+            static const size_t par_min = getenv("SQ_GROW_PAR") ? (size_t)atol(getenv("SQ_GROW_PAR")) : 4096;
+            if (round.size() >= par_min) {
+                const int nsl = sq_pool(b)->size() * 4;
+                std::vector<size_t> cut(nsl + 1);
+                for (int t = 0; t <= nsl; t++) {
+                    size_t q = round.size() * (size_t)t / (size_t)nsl;
+                    while (q > 0 && q < round.size() && owner[q] == owner[q - 1]) q++;   // slices end on job boundaries
+                    cut[t] = q;
+                }
+                sq_pool(b)->parallel_for(nsl, [&](int t) { if (cut[t] < cut[t + 1]) grow(cut[t], cut[t + 1]); });
+            } else grow(0, round.size());
+        }
+    };
+    // Two lanes when the batch is big enough: the jobs are dealt alternately (by sequence) to two host threads, each
+    // driving its rounds on half of the round buffers; the kernels of both queue on the batch stream, so while one
+    // lane's host code books a round the other lane's kernels run.  Jobs are independent: same results.
+    std::vector<int> greedy_jobs;
+    for (int j = 0; j < b->njobs; j++) if (!pools[j].cur.empty()) greedy_jobs.push_back(j);
+    static const int want_lanes = getenv("SQ_FOLD_LANES") ? atoi(getenv("SQ_FOLD_LANES")) : 2;
+    const bool two_lanes = want_lanes >= 2 && !b->prof_on && (int)greedy_jobs.size() >= 512 &&
+                           (int)greedy_jobs.size() <= b->max_structs;   // (a lane holds half of the slots)
+    LoopStats st0, st1;
+    sq_pool(b);                                             // (created before any second thread can ask for it)
+    if (!two_lanes) {
+        greedy_loop(b->lane_full, greedy_jobs, st0);
+    } else {
+        std::vector<int> part[2];
+        // contiguous halves of equal estimated cost (~ n^3: rounds x cells), so that the lanes do not share cache
+        // lines of neighbouring jobs' pools
+        double total = 0, acc = 0;
+        auto cost = [&](int j) { const double n = b->seq_off[b->job_seq[j] + 1] - b->seq_off[b->job_seq[j]]; return n * n * n + 1.0; };
+        for (int j : greedy_jobs) total += cost(j);
+        for (int j : greedy_jobs) { part[acc * 2 < total ? 0 : 1].push_back(j); acc += cost(j); }
+        const int64_t avail = b->cand_records - b->cand_reserved;
+        for (int k = 0; k < 2; k++) {
+            SqLane &H = b->lane_half[k];
+            H.cand0 = k ? avail / 2 : 0;
+            H.cand_records = k ? avail - avail / 2 : avail / 2;
+        }
+        std::thread other([&] { greedy_loop(b->lane_half[1], part[1], st1); });
+        greedy_loop(b->lane_half[0], part[0], st0);
+        other.join();
+        if (!st0.rc && st1.rc) { st0.rc = st1.rc; st0.err = st1.err; }
     }
+    if (st0.rc) { sq_set_error(st0.err); return st0.rc; }
+    const double tround = st0.tround + st1.tround;
+    const int nrounds = st0.nrounds + st1.nrounds;
     const double tloop = now_s() - tfold0;
     const double ttail0 = now_s();
     // a-10 tail per sequence
@@ -1173,6 +1212,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         fprintf(stderr, "[sq_fold] rounds=%d loop=%.3fms (round driver %.3f: prep %.3f gpu+wait %.3f post %.3f; pool %.3f) tail=%.3fms\n",
                 nrounds, tloop * 1e3, tround * 1e3, g_t[0] * 1e3, g_t[1] * 1e3, g_t[2] * 1e3, (tloop - tround) * 1e3,
                 (now_s() - ttail0) * 1e3);
+    if (timing && two_lanes)
+        fprintf(stderr, "[sq_fold] lanes: 0 start %.3f wall %.3f driver %.3f (%d rounds); 1 start %.3f wall %.3f driver %.3f (%d rounds)\n",
+                st0.tstart * 1e3, st0.twall * 1e3, st0.tround * 1e3, st0.nrounds, st1.tstart * 1e3, st1.twall * 1e3, st1.tround * 1e3, st1.nrounds);
     return 0;
 }
 
