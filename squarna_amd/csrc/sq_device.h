@@ -32,6 +32,10 @@ struct SqState {             // per-structure-slot arrays, `stride` elements per
 // kernel straight from pinned host memory (and mirrored into device memory for the later kernels), the
 // selected stems are written straight into pinned host memory, and a one-thread kernel at the end of the
 // round publishes the counters and a sequence number the host spins on.
+#ifndef SQ_SCORE_CHUNK
+#define SQ_SCORE_CHUNK 4          // candidates per thread and chunk of sq_score_kernel's two-phase loop
+#endif
+
 struct SqRoundIO {
     const SqStruct *h_structs;   // pinned, host-written
     const SqStrand *h_strands;
@@ -79,6 +83,6 @@ __global__ void sq_scan5_kernel(SqDevCtx c, const SqStruct *structs, SqState stt
 __global__ void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
 __global__ void sq_bits_kernel(SqDevCtx c, int only_ext);
 __global__ void sq_score_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
-                                SqScanArgs a, SqRoundIO io, int mode, int lds_n, int lds_n_reacts, int lds_n_state);
+                                SqScanArgs a, SqRoundIO io, int mode, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off);
 __global__ void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqRoundIO io);
 }

@@ -753,20 +753,26 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
         ProfScope ps(b, 3, 0);
         // dynamic LDS: letter codes of the longest sequence, plus its reactivities when they fit in 32 KiB
         const int lds_n = maxn <= 16384 ? maxn : 0;
-        const int lds_nr = maxn <= 4096 ? maxn : 0;
+        static const int nr_lim = getenv("SQ_SCORE_NR_LIM") ? atoi(getenv("SQ_SCORE_NR_LIM")) : 4096;
+        const int lds_nr = maxn <= nr_lim ? maxn : 0;
         // partner / prefix arrays (3 x int16) too, while a block stays small enough for four blocks per CU
         // (the reactivity case is bound by fp64 sqrt/div throughput and prefers the occupancy)
+        static const size_t state_lim = getenv("SQ_SCORE_STATE_LIM") ? (size_t)atol(getenv("SQ_SCORE_STATE_LIM")) : 24 * 1024;
         const size_t dyn_base = lds_n ? (size_t)((lds_n + 15) & ~15) + (size_t)8 * lds_nr + 16 : 0;
-        const int lds_ns = (lds_n && mode == 0 && dyn_base + (size_t)6 * ((maxn + 8) & ~7) <= 24 * 1024) ? maxn : 0;
-        const size_t dyn = lds_n ? (size_t)((lds_n + 15) & ~15) + (size_t)8 * lds_nr + (size_t)6 * ((lds_ns + 8) & ~7) + 16 : 0;
+        const int lds_ns = (lds_n && mode == 0 && dyn_base + (size_t)6 * ((maxn + 8) & ~7) <= state_lim) ? maxn : 0;
+        size_t dyn = lds_n ? (size_t)((lds_n + 15) & ~15) + (size_t)8 * lds_nr + (size_t)6 * ((lds_ns + 8) & ~7) + 16 : 0;
         // few structures: deal each structure's candidates to several blocks so that the launch still fills the chip
         static const int score_threads = getenv("SQ_SCORE_THREADS") ? atoi(getenv("SQ_SCORE_THREADS")) : 0;
         static const int score_parts = getenv("SQ_SCORE_PARTS") ? atoi(getenv("SQ_SCORE_PARTS")) : 0;
-        int parts = std::max(1, std::min({512, (4096 + S - 1) / S, (int)(maxcap / 1024)}));
+        static const int score_target = getenv("SQ_SCORE_TARGET") ? atoi(getenv("SQ_SCORE_TARGET")) : 512;
+        int parts = std::max(1, std::min({512, (score_target + S - 1) / S, (int)(maxcap / 1024)}));
         if (score_parts) parts = score_parts;
-        const int thr = score_threads ? score_threads : (parts == 1 && S < 2048 ? 512 : 256);
+        const int thr = score_threads ? score_threads : 512;
+        // mode 0: list of the bpscore survivors of a chunk (5 x threads entries of 8 + 4 + 2 bytes) behind the tables
+        const int surv_off = (int)((dyn + 15) & ~(size_t)15);
+        if (mode == 0) dyn = (size_t)surv_off + (size_t)14 * (SQ_SCORE_CHUNK + 1) * thr;
         hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, ln.d_structs, ln.d_strands, b->state,
-                           scan, io, mode, lds_n, lds_nr, lds_ns);
+                           scan, io, mode, lds_n, lds_nr, lds_ns, surv_off);
         if (mode == 0)
             hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, ln.d_structs, scan, io);
         if (mode == 2) {

@@ -41,11 +41,9 @@ __device__ __forceinline__ double sq_cell_score(const SqDevCtx &c, const SqJob &
 {
     const uint8_t *codes = c.codes + jb.pos_off;
     const double w = ps->w[codes[i] * 32 + codes[j]];
-    double rf = 1.0;
-    if (!jb.default_reacts) {
-        const double *r = c.reacts + jb.pos_off;
-        rf = sqrt((1.0 - (r[i] + r[j]) / 2.0) * 2.0);                 // x**0.5 (see DESIGN.md on pow vs sqrt)
-    }
+    if (jb.default_reacts) return w;                                  // reactfactor 1 (and 1/1 for w <= 0): w * 1.0
+    const double *r = c.reacts + jb.pos_off;
+    double rf = sqrt((1.0 - (r[i] + r[j]) / 2.0) * 2.0);              // x**0.5 (see DESIGN.md on pow vs sqrt)
     if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);                   // :335-336
     return w * rf;
 }
@@ -1117,7 +1115,7 @@ __device__ __forceinline__ double sq_unord(unsigned long long o)
 #endif
 extern "C" __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SQ_SCORE_WAVES))) void sq_score_kernel(SqDevCtx c, const SqStruct *structs,
                                                                   const SqStrand *strands, SqState stt, SqScanArgs a,
-                                                                  SqRoundIO io, int mode, int lds_n, int lds_n_reacts, int lds_n_state)
+                                                                  SqRoundIO io, int mode, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off)
 {
     __shared__ SqStrand s_str[SQ_LDS_STRANDS];
     __shared__ double s_w[32 * 32];               // pair weights of the job's paramset
@@ -1172,12 +1170,10 @@ extern "C" __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu
     auto cell_exact = [&](int i, int j) -> double {
         if (!lds_cells) return sq_cell_exact(c, jb, ps, i, j);
         const double w = s_w[l_codes[i] * 32 + l_codes[j]];             // same expression as sq_cell_score
-        double rf = 1.0;
-        if (!jb.default_reacts) {
-            const double ri = lds_reacts ? l_reacts[i] : c.reacts[jb.pos_off + i];
-            const double rj = lds_reacts ? l_reacts[j] : c.reacts[jb.pos_off + j];
-            rf = sqrt((1.0 - (ri + rj) / 2.0) * 2.0);
-        }
+        if (jb.default_reacts) return w;                                // (no fp64 division for the w <= 0 cells)
+        const double ri = lds_reacts ? l_reacts[i] : c.reacts[jb.pos_off + i];
+        const double rj = lds_reacts ? l_reacts[j] : c.reacts[jb.pos_off + j];
+        double rf = sqrt((1.0 - (ri + rj) / 2.0) * 2.0);
         if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
         return w * rf;
     };
@@ -1185,109 +1181,194 @@ extern "C" __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu
     double best = 0.0; int any = 0;
 
     const uint32_t qstep = gridDim.y * nthr;
-    for (uint32_t q0 = blockIdx.y * nthr; q0 < ncand; q0 += qstep) {     // whole waves iterate together (ballot below)
-        const uint32_t q = q0 + tid;
-        const bool have = q < ncand;
-        const SqKey cd = have ? keys[q] : SqKey{0u, 0u};
-        const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), L = (int)cd.len, j0 = s - i0;
-        // exact bpscore: sum(...) left to right starting from int 0  (:416)
+    // exact bpscore: sum(...) left to right starting from int 0  (:416)
+    auto stem_bps = [&](int i0, int j0, int L) -> double {
+        // four cells per step: their (dependent) LDS lookups overlap, the additions keep the reference's order; the
+        // padding cells of the last step add +0.0, which leaves the sum unchanged
         double bps = 0.0;
-        for (int t = 0; t < L; t++) {
-            const double v = cell_exact(i0 + t, j0 - t);
-            bps = bps + v;
+        for (int t = 0; t < L; t += 4) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int tt = t + u < L ? t + u : L - 1;
+                v[u] = cell_exact(i0 + tt, j0 - tt);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) bps = bps + (t + u < L ? v[u] : 0.0);
         }
-        bool ok = have && bps >= minbps;                                // :492
-        double fin = 0.0;
-        if (ok && mode == 0) {
-            const int sa = i0 + L - 1, sb = j0 - L + 1;                 // :655 innermost bp
-            int inblockend = -1, nrec = 0, be0 = 0, be1 = 0, covered = 0, brackets = 0;
-            uint64_t levelset = 0;
-            int lo = 0, hi = st.nstrand;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (S[mid].start <= sa) lo = mid + 1; else hi = mid; }
-            for (int k = lo; k < st.nstrand; k++) {                     // closed form of the walk :665-689
-                const SqStrand x = S[k];
-                if (x.start >= sb) break;
-                const int pfirst = x.pstart, plast = x.pstart - (x.len - 1);
-                bool wing;
-                if (x.left) {
-                    wing = pfirst > sb;
-                    if (!wing && pfirst > inblockend) {                 // :687-689 sub-ECR face
-                        if (nrec == 0) { be0 = x.start; be1 = pfirst; }
-                        nrec++;
-                        const int from = x.start > inblockend ? x.start : inblockend + 1;
-                        covered += U[pfirst + 1] - U[from];
-                        inblockend = pfirst;
-                    }
-                } else {
-                    wing = plast < sa;
+        return bps;
+    };
+    if (mode != 0) {
+        // bpscore filter only (:492): OptimalStems output (mode 1) or the alignment's survivor list (mode 2)
+        for (uint32_t q0 = blockIdx.y * nthr; q0 < ncand; q0 += qstep) {   // whole waves iterate together (ballot below)
+            const uint32_t q = q0 + tid;
+            const bool have = q < ncand;
+            const SqKey cd = have ? keys[q] : SqKey{0u, 0u};
+            const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), L = (int)cd.len;
+            const double bps = stem_bps(i0, s - i0, L);
+            const bool ok = have && bps >= minbps;
+            if (mode == 1) {
+                if (ok) {
+                    const SqOut r = {(int32_t)blockIdx.x, cd.key, L, 0, bps, 0.0};
+                    sq_put_out(io, a, r);
                 }
-                if (wing && x.start > inblockend) {                     // :679-684
-                    brackets += x.len;
-                    if (x.level > SQ_MAXLEVELS) a.ctr->level_ovf = 1;
-                    else levelset |= 1ull << (x.level - 1);
-                }
+                continue;
             }
-            const int dots = (U[sb] - U[sa + 1]) - covered;             // :670-673
-            const bool between = (SU[sb] - SU[sa + 1]) > 0;             // :675-676
-            bool goodloop = false; int diff1 = 0;                       // :692-698
-            if (nrec == 1 && sq_goodloop(be0 - sa - 1, sb - be1 - 1)) {
-                goodloop = true;
-                diff1 = abs((be0 - sa - 1) - (sb - be1 - 1));
-            }
-            bool goodloopout = false; int diff2 = 0;                    // :700-711
-            {
-                int vv = i0 - 1, ww = j0 + 1;
-                while (vv >= 0 && i0 - vv - 1 < 5 && P[vv] == -1) vv--;
-                while (ww < n && ww - j0 - 1 < 5 && P[ww] == -1) ww++;
-                if (vv >= 0 && ww < n && P[vv] == ww && sq_goodloop(i0 - vv - 1, ww - j0 - 1)) {
-                    goodloopout = true;
-                    diff2 = abs((i0 - vv - 1) - (ww - j0 - 1));
+            const unsigned long long okm = __ballot(ok);
+            if (okm) {
+                uint32_t base = 0;
+                const int leader = __ffsll((long long)okm) - 1;
+                if ((tid & 63) == leader) base = atomicAdd(a.ok_cnt + st.slot, (uint32_t)__popcll(okm));
+                base = (uint32_t)__shfl((int)base, leader);
+                if (ok) {
+                    const uint32_t pos = base + (uint32_t)__popcll(okm & ((1ull << (tid & 63)) - 1ull));
+                    if (pos < ok_cap) oks[pos] = SqOk{cd.key, (uint32_t)L, bps, 0.0};
+                    else a.ctr->cand_ovf = 1;
                 }
             }
-            const double lb = ps->loopbonus;
-            const double loopfactor = (1.0 + (lb * (goodloop ? 1.0 : 0.0)) * (2.0 - diff1 / 2.0))
-                                      + (lb * (goodloopout ? 1.0 : 0.0)) * (2.0 - diff2 / 2.0);   // :715
-            bool gnra = false;                                          // :598-604,718
-            if (sb - sa - 1 == 4 && codes[sa + 1] == 6 && (codes[sa + 3] == 6 || codes[sa + 3] == 0) && codes[sa + 4] == 0)
-                gnra = true;
-            const double tetra = gnra ? 1.25 : 1.0;
-            const double ideal = nrec == 0 ? 4.0 : 2.0;                 // :721
-            const double stemdist = (double)dots + ps->bracketweight * (double)brackets;   // :723
-            const double dd = fabs(stemdist - ideal);
-            double sdf = 1.0;                                           // :726
-            if (!between) {
-                const int di = (int)dd;
-                if (ps->bw_integral && di < ps->sdf_len) sdf = c.sdftab[ps->sdf_off + di];
-                else sdf = pow(1.0 / (1.0 + dd), ps->distcoef);
-            }
-            const double of = ps->oftab[__popcll(levelset)];            // :728-729
-            fin = bps * sdf * of * loopfactor * tetra;                  // :732 (reactfactor == 1)
-            if (!goodloop && !goodloopout && L < 3) fin = -1.0;         // :744-745
-            ok = fin >= minfin;                                         // :751
         }
-        if (mode == 1) {
-            if (ok) {
-                const SqOut r = {(int32_t)blockIdx.x, cd.key, L, 0, bps, 0.0};
-                sq_put_out(io, a, r);
-            }
-            continue;
-        }
-        // survivors are appended to the structure's SqOk list: one atomic per wave, lanes ranked by ballot
-        const unsigned long long okm = __ballot(ok);
-        if (okm) {
-            uint32_t base = 0;
-            const int leader = __ffsll((long long)okm) - 1;
-            if ((tid & 63) == leader) base = atomicAdd(a.ok_cnt + st.slot, (uint32_t)__popcll(okm));
-            base = (uint32_t)__shfl((int)base, leader);
-            if (ok) {
-                const uint32_t pos = base + (uint32_t)__popcll(okm & ((1ull << (tid & 63)) - 1ull));
-                if (pos < ok_cap) oks[pos] = SqOk{cd.key, (uint32_t)L, bps, fin};
-                else a.ctr->cand_ovf = 1;
-                if (mode == 0 && (!any || fin > best)) { any = 1; best = fin; }   // :769 only the best VALUE matters for the range
-            }
-        }
+        return;
     }
-    if (mode != 0) return;
+
+    // mode 0.  Two phases per chunk of SQ_SCORE_CHUNK x blockDim candidates: (A) every thread computes the bpscore of its
+    // candidates (cheap: LDS only) and the ones that pass :492 are appended to a list in LDS; (B) ScoreStems runs on
+    // FULL groups of blockDim survivors (its chain of dependent loads is what the kernel waits for, so lanes idling
+    // on rejected candidates were the cost); the remainder (< blockDim) is carried into the next chunk.
+    double *s_bps = reinterpret_cast<double *>(s_dyn + surv_off);
+    uint32_t *s_key = reinterpret_cast<uint32_t *>(s_bps + (SQ_SCORE_CHUNK + 1) * nthr);
+    uint16_t *s_len = reinterpret_cast<uint16_t *>(s_key + (SQ_SCORE_CHUNK + 1) * nthr);
+    __shared__ uint32_t s_nsurv;
+    if (tid == 0) s_nsurv = 0;
+    __syncthreads();
+    for (uint32_t q0 = blockIdx.y * nthr; q0 < ncand; q0 += SQ_SCORE_CHUNK * qstep) {
+        SqKey cd[SQ_SCORE_CHUNK];
+#pragma unroll
+        for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
+            const uint32_t q = q0 + (uint32_t)u * qstep + tid;
+            cd[u] = q < ncand ? keys[q] : SqKey{0u, 0u};                // (len 0: bps 0, never appended)
+        }
+#pragma unroll
+        for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
+            const int s = (int)(cd[u].key >> 16), i0 = (int)(cd[u].key & 0xFFFFu), L = (int)cd[u].len;
+            const double bps = stem_bps(i0, s - i0, L);
+            const bool ok = L > 0 && bps >= minbps;                     // :492
+            const unsigned long long okm = __ballot(ok);
+            if (okm) {
+                uint32_t base = 0;
+                const int leader = __ffsll((long long)okm) - 1;
+                if ((tid & 63) == leader) base = atomicAdd(&s_nsurv, (uint32_t)__popcll(okm));
+                base = (uint32_t)__shfl((int)base, leader);
+                if (ok) {
+                    const uint32_t pos = base + (uint32_t)__popcll(okm & ((1ull << (tid & 63)) - 1ull));
+                    s_key[pos] = cd[u].key; s_len[pos] = (uint16_t)L; s_bps[pos] = bps;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t ns = s_nsurv;
+        const bool last = q0 + SQ_SCORE_CHUNK * qstep >= ncand;
+        uint32_t done = 0;
+        while (done + (uint32_t)nthr <= ns || (last && done < ns)) {
+            const uint32_t idx = done + tid;
+            done += nthr;
+            const bool have = idx < ns;
+            const uint32_t key = have ? s_key[idx] : 0u;
+            const int L = have ? (int)s_len[idx] : 0;
+            const double bps = have ? s_bps[idx] : 0.0;
+            const int s = (int)(key >> 16), i0 = (int)(key & 0xFFFFu), j0 = s - i0;
+            bool ok = have;
+            double fin = 0.0;
+            if (ok) {
+                const int sa = i0 + L - 1, sb = j0 - L + 1;                 // :655 innermost bp
+                int inblockend = -1, nrec = 0, be0 = 0, be1 = 0, covered = 0, brackets = 0;
+                uint64_t levelset = 0;
+                int lo = 0, hi = st.nstrand;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (S[mid].start <= sa) lo = mid + 1; else hi = mid; }
+                for (int k = lo; k < st.nstrand; k++) {                     // closed form of the walk :665-689
+                    const SqStrand x = S[k];
+                    if (x.start >= sb) break;
+                    const int pfirst = x.pstart, plast = x.pstart - (x.len - 1);
+                    bool wing;
+                    if (x.left) {
+                        wing = pfirst > sb;
+                        if (!wing && pfirst > inblockend) {                 // :687-689 sub-ECR face
+                            if (nrec == 0) { be0 = x.start; be1 = pfirst; }
+                            nrec++;
+                            const int from = x.start > inblockend ? x.start : inblockend + 1;
+                            covered += U[pfirst + 1] - U[from];
+                            inblockend = pfirst;
+                        }
+                    } else {
+                        wing = plast < sa;
+                    }
+                    if (wing && x.start > inblockend) {                     // :679-684
+                        brackets += x.len;
+                        if (x.level > SQ_MAXLEVELS) a.ctr->level_ovf = 1;
+                        else levelset |= 1ull << (x.level - 1);
+                    }
+                }
+                const int dots = (U[sb] - U[sa + 1]) - covered;             // :670-673
+                const bool between = (SU[sb] - SU[sa + 1]) > 0;             // :675-676
+                bool goodloop = false; int diff1 = 0;                       // :692-698
+                if (nrec == 1 && sq_goodloop(be0 - sa - 1, sb - be1 - 1)) {
+                    goodloop = true;
+                    diff1 = abs((be0 - sa - 1) - (sb - be1 - 1));
+                }
+                bool goodloopout = false; int diff2 = 0;                    // :700-711
+                {
+                    int vv = i0 - 1, ww = j0 + 1;
+                    while (vv >= 0 && i0 - vv - 1 < 5 && P[vv] == -1) vv--;
+                    while (ww < n && ww - j0 - 1 < 5 && P[ww] == -1) ww++;
+                    if (vv >= 0 && ww < n && P[vv] == ww && sq_goodloop(i0 - vv - 1, ww - j0 - 1)) {
+                        goodloopout = true;
+                        diff2 = abs((i0 - vv - 1) - (ww - j0 - 1));
+                    }
+                }
+                const double lb = ps->loopbonus;
+                const double loopfactor = (1.0 + (lb * (goodloop ? 1.0 : 0.0)) * (2.0 - diff1 / 2.0))
+                                          + (lb * (goodloopout ? 1.0 : 0.0)) * (2.0 - diff2 / 2.0);   // :715
+                bool gnra = false;                                          // :598-604,718
+                if (sb - sa - 1 == 4 && codes[sa + 1] == 6 && (codes[sa + 3] == 6 || codes[sa + 3] == 0) && codes[sa + 4] == 0)
+                    gnra = true;
+                const double tetra = gnra ? 1.25 : 1.0;
+                const double ideal = nrec == 0 ? 4.0 : 2.0;                 // :721
+                const double stemdist = (double)dots + ps->bracketweight * (double)brackets;   // :723
+                const double dd = fabs(stemdist - ideal);
+                double sdf = 1.0;                                           // :726
+                if (!between) {
+                    const int di = (int)dd;
+                    if (ps->bw_integral && di < ps->sdf_len) sdf = c.sdftab[ps->sdf_off + di];
+                    else sdf = pow(1.0 / (1.0 + dd), ps->distcoef);
+                }
+                const double of = ps->oftab[__popcll(levelset)];            // :728-729
+                fin = bps * sdf * of * loopfactor * tetra;                  // :732 (reactfactor == 1)
+                if (!goodloop && !goodloopout && L < 3) fin = -1.0;         // :744-745
+                ok = fin >= minfin;                                         // :751
+            }
+            // survivors are appended to the structure's SqOk list: one atomic per wave, lanes ranked by ballot
+            const unsigned long long okm = __ballot(ok);
+            if (okm) {
+                uint32_t base = 0;
+                const int leader = __ffsll((long long)okm) - 1;
+                if ((tid & 63) == leader) base = atomicAdd(a.ok_cnt + st.slot, (uint32_t)__popcll(okm));
+                base = (uint32_t)__shfl((int)base, leader);
+                if (ok) {
+                    const uint32_t pos = base + (uint32_t)__popcll(okm & ((1ull << (tid & 63)) - 1ull));
+                    if (pos < ok_cap) oks[pos] = SqOk{key, (uint32_t)L, bps, fin};
+                    else a.ctr->cand_ovf = 1;
+                    if (!any || fin > best) { any = 1; best = fin; }        // :769 only the best VALUE matters for the range
+                }
+            }
+        }
+        __syncthreads();                                                    // every thread has read the list
+        const uint32_t rem = ns > done ? ns - done : 0u;                    // < blockDim: carried to the next chunk
+        uint32_t ck = 0; uint16_t cl = 0; double cb = 0.0;
+        if ((uint32_t)tid < rem) { ck = s_key[done + tid]; cl = s_len[done + tid]; cb = s_bps[done + tid]; }
+        __syncthreads();
+        if ((uint32_t)tid < rem) { s_key[tid] = ck; s_len[tid] = cl; s_bps[tid] = cb; }
+        if (tid == 0) s_nsurv = rem;
+        __syncthreads();
+    }
 
     // wave maximum, then one atomicMax per wave on the structure's slot
     for (int off = 32; off > 0; off >>= 1) {

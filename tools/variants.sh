@@ -4,5 +4,5 @@ cd $GRAFT_REPO_ROOT
 for defs in "$@"; do
   echo "=== SQ_DEFS='$defs'"
   SQ_DEFS="$defs" python squarna_amd/build.py > /tmp/build.log 2>&1 || { tail -5 /tmp/build.log; continue; }
-  python tools/s1000_probe.py ${NSEQ:-512} ${NLEN:-1000} 2 $EXTRA 2>&1 | tail -1
+  if [ -n "$VCMD" ]; then bash -c "$VCMD"; else python tools/s1000_probe.py ${NSEQ:-512} ${NLEN:-1000} 2 $EXTRA 2>&1 | tail -${TAILN:-1}; fi
 done
