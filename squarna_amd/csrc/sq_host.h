@@ -93,6 +93,7 @@ struct SqLane {
     int32_t slot0 = 0, max_structs = 0, strand_cap = 0;
     int64_t cand0 = 0, cand_records = 0;      // records [cand0, cand0 + cand_records) of the candidate arena
     uint32_t round_seq = 0;
+    hipStream_t stream = nullptr;             // nullptr: the batch stream
     std::vector<SqOut> big_out;
 };
 
@@ -121,6 +122,8 @@ struct sq_batch {
     char *stage_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned job tables + edge lists of the matching kernels
     size_t stage_cap[4] = {0, 0, 0, 0};
     uint32_t algo_seq = 0;                // completion stamps of the matching launches
+    hipStream_t lane_stream = nullptr;        // second lane of sq_fold's greedy rounds (created on first use)
+    hipEvent_t lane_ev = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
     uint32_t out_cap = 0;
     int32_t strand_cap = 0;

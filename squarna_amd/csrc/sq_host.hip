@@ -422,6 +422,8 @@ extern "C" void sq_batch_destroy(sq_batch *b)
     for (int k = 0; k < 4; k++) if (b->stage_buf[k]) hipHostFree(b->stage_buf[k]);
     if (b->h_out) hipHostFree(b->h_out);
     for (int k = 0; k < 3; k++) if (b->side[k]) { hipStreamSynchronize(b->side[k]); hipStreamDestroy(b->side[k]); }
+    if (b->lane_stream) { hipStreamSynchronize(b->lane_stream); hipStreamDestroy(b->lane_stream); }
+    if (b->lane_ev) hipEventDestroy(b->lane_ev);
     for (auto &p : b->prof) {
         for (auto &e : p.pending) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
         for (auto &e : p.pool) hipEventDestroy(e);
@@ -718,7 +720,7 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
         maxn = std::max(maxn, J.n);
         scan_bytes += 2.0 * J.n * J.n;                     // algorithmic: fp32 upper triangle, N^2/2 cells
     }
-    hipStream_t st = b->stream;
+    hipStream_t st = ln.stream ? ln.stream : b->stream;
     g_t[0] += now_s() - tp0; tp0 = now_s();
     SqRoundIO io;
     io.h_structs = ln.h_structs; io.h_strands = ln.h_strands; io.d_structs = ln.d_structs; io.d_strands = ln.d_strands;
@@ -1129,6 +1131,18 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             H.cand0 = k ? avail / 2 : 0;
             H.cand_records = k ? avail - avail / 2 : avail / 2;
         }
+        // the second lane has its own stream (its half-size kernels run beside the first lane's), ordered behind
+        // everything the batch stream holds so far (bit matrix, uploads)
+        static const bool lane_own_stream = !getenv("SQ_LANE_SAME_STREAM");
+        if (lane_own_stream) {
+            if (!b->lane_stream) {
+                HIPCK(hipStreamCreateWithFlags(&b->lane_stream, hipStreamNonBlocking));
+                HIPCK(hipEventCreateWithFlags(&b->lane_ev, hipEventDisableTiming));
+            }
+            HIPCK(hipEventRecord(b->lane_ev, b->stream));
+            HIPCK(hipStreamWaitEvent(b->lane_stream, b->lane_ev, 0));
+            b->lane_half[1].stream = b->lane_stream;
+        } else b->lane_half[1].stream = nullptr;
         std::thread other([&] { greedy_loop(b->lane_half[1], part[1], st1); });
         greedy_loop(b->lane_half[0], part[0], st0);
         other.join();
