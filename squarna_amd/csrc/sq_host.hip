@@ -1029,12 +1029,68 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     const double tbegin = now_s() - ta;
     const double tfold0 = now_s();
     for (int k = 0; k < 8; k++) g_t[k] = 0;
+    // a-10 tail per sequence
+    std::vector<std::vector<int32_t>> seq_jobs(b->nseq);
+    for (int j = 0; j < b->njobs; j++) seq_jobs[b->job_seq[j]].push_back(j);
+    std::vector<double> tail_cost(b->nseq, 0.0);
+    const bool timing = getenv("SQ_TIMING") != nullptr;
+    auto tail_one = [&](int s) {
+        const double tt0 = timing ? now_s() : 0;
+        struct TT { bool on; double t0; double &dst; ~TT() { if (on) dst = now_s() - t0; } } tt{timing, tt0, tail_cost[s]};
+        std::vector<const std::vector<std::vector<HStem>> *> per_job;   // (freed later by the thread that allocated them)
+        int64_t ev = 0;
+        for (int j : seq_jobs[s]) { per_job.push_back(&pools[j].fin); ev += pools[j].evals; }
+        const bool hr = has_ref && has_ref[s];
+        const int32_t *rp = hr ? ref_pairs + 2 * (size_t)ref_off[s] : nullptr;
+        const int nref = hr ? ref_off[s + 1] - ref_off[s] : 0;
+        b->results[s] = SeqResult();
+        sq_tail(b, s, o, per_job, seq_jobs[s], rp, nref, hr, b->results[s]);
+        b->results[s].evals = ev;
+    };
+    std::vector<char> tailed(b->nseq, 0);
+    // Early tails: without E/H/N stemsets a sequence is complete the moment the pools of its greedy jobs are empty;
+    // the lanes report such sequences after every round and a helper thread ranks them on the worker pool while
+    // the rounds of the other sequences go on.
+    static const bool no_early_tail = getenv("SQ_NO_EARLY_TAIL") != nullptr;
+    const bool early_tail = pending == nullptr && !no_early_tail;
+    struct TailQueue {
+        std::mutex mu; std::condition_variable cv; std::vector<int> items; bool closed = false;
+        std::thread worker;
+        void push(std::vector<int> &v) { if (v.empty()) return; { std::lock_guard<std::mutex> lk(mu); items.insert(items.end(), v.begin(), v.end()); } cv.notify_one(); v.clear(); }
+        void close() { if (!worker.joinable()) return; { std::lock_guard<std::mutex> lk(mu); closed = true; } cv.notify_one(); worker.join(); }
+        ~TailQueue() { close(); }
+    } tq;
+    std::vector<std::atomic<int>> g_left(early_tail ? b->nseq : 0);
+    std::vector<char> job_done(early_tail ? b->njobs : 0, 0);
+    if (early_tail) {
+        for (int s2 = 0; s2 < b->nseq; s2++) g_left[s2] = 0;
+        for (int j = 0; j < b->njobs; j++) if (!pools[j].cur.empty()) g_left[b->job_seq[j]]++;
+        sq_pool(b);
+        tq.worker = std::thread([&] {
+            for (;;) {
+                std::vector<int> take;
+                {
+                    std::unique_lock<std::mutex> lk(tq.mu);
+                    tq.cv.wait(lk, [&] { return !tq.items.empty() || tq.closed; });
+                    take.swap(tq.items);
+                    if (take.empty()) return;               // closed and drained
+                }
+                sq_pool(b)->parallel_for((int)take.size(), [&](int k) { tail_one(take[k]); tailed[take[k]] = 1; });
+            }
+        });
+    }
     // the greedy pool loop (:1102-1199) for a subset of the jobs, on one lane of round buffers
     struct LoopStats { double tround = 0, twall = 0, tstart = 0; int nrounds = 0; int rc = 0; std::string err; };
     auto greedy_loop = [&](SqLane &ln, const std::vector<int> &myjobs, LoopStats &stats) {
         std::vector<SView> round;
         std::vector<int> owner;                             // job of each view
         std::vector<std::vector<HStem>> res;
+        std::vector<int> finished;                          // sequences completed since the last report
+        auto job_finished = [&](int j) {
+            if (!early_tail || job_done[j]) return;
+            job_done[j] = 1;
+            if (--g_left[b->job_seq[j]] == 0) finished.push_back(b->job_seq[j]);
+        };
         const double tl0 = now_s();
         stats.tstart = tl0 - tfold0;
         struct Wall { double t0; double &dst; ~Wall() { dst = now_s() - t0; } } wall{tl0, stats.twall};
@@ -1042,7 +1098,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             round.clear(); owner.clear();
             for (int j : myjobs) {
                 JobPool &P = pools[j];
-                if (P.cur.empty()) continue;
+                if (P.cur.empty()) { job_finished(j); continue; }
                 if (P.cur.size() > P.cursize) {             // :1162-1165
                     P.cursize = P.cur.size();
                     if (P.cursubopt < P.suboptmax) P.cursubopt += P.suboptinc;
@@ -1056,6 +1112,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                         else keep.push_back(std::move(s));
                     }
                     P.cur.swap(keep);
+                    if (P.cur.empty()) { job_finished(j); continue; }
                 }
                 for (size_t k = 0; k < P.cur.size(); k++) {
                     round.push_back(SView{j, P.cursubopt, &P.cur[k]});
@@ -1063,6 +1120,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 }
                 P.evals += (int64_t)P.cur.size();
             }
+            tq.push(finished);
             if (round.empty()) break;
             { const double t0 = now_s(); stats.rc = run_round_impl(b, ln, round, 0, res, nullptr); stats.tround += now_s() - t0; stats.nrounds++; }
             if (stats.rc) { stats.err = sq_last_error(); return; }
@@ -1148,33 +1206,15 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         other.join();
         if (!st0.rc && st1.rc) { st0.rc = st1.rc; st0.err = st1.err; }
     }
+    tq.close();
     if (st0.rc) { sq_set_error(st0.err); return st0.rc; }
     const double tround = st0.tround + st1.tround;
     const int nrounds = st0.nrounds + st1.nrounds;
     const double tloop = now_s() - tfold0;
     const double ttail0 = now_s();
-    // a-10 tail per sequence
-    std::vector<std::vector<int32_t>> seq_jobs(b->nseq);
-    for (int j = 0; j < b->njobs; j++) seq_jobs[b->job_seq[j]].push_back(j);
-    std::vector<double> tail_cost(b->nseq, 0.0);
-    const bool timing = getenv("SQ_TIMING") != nullptr;
-    auto tail_one = [&](int s) {
-        const double tt0 = timing ? now_s() : 0;
-        struct TT { bool on; double t0; double &dst; ~TT() { if (on) dst = now_s() - t0; } } tt{timing, tt0, tail_cost[s]};
-        std::vector<const std::vector<std::vector<HStem>> *> per_job;   // (freed later by the thread that allocated them)
-        int64_t ev = 0;
-        for (int j : seq_jobs[s]) { per_job.push_back(&pools[j].fin); ev += pools[j].evals; }
-        const bool hr = has_ref && has_ref[s];
-        const int32_t *rp = hr ? ref_pairs + 2 * (size_t)ref_off[s] : nullptr;
-        const int nref = hr ? ref_off[s + 1] - ref_off[s] : 0;
-        b->results[s] = SeqResult();
-        sq_tail(b, s, o, per_job, seq_jobs[s], rp, nref, hr, b->results[s]);
-        b->results[s].evals = ev;
-    };
     // E / H / N stemsets precede the greedy ones of their job (:1094-1100), in the order E, H, N.  Hungarian and
     // Nussinov are final first; Edmonds is streamed job by job, and a sequence is ranked (its tail) the moment its
     // last Edmonds graph is matched -- the other sequences do not wait for the largest graph of the batch.
-    std::vector<char> tailed(b->nseq, 0);
     {
         const double t0 = now_s();
         std::vector<std::atomic<int>> e_left(b->nseq);
