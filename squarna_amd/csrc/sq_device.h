@@ -70,6 +70,7 @@ int sq_scan5_seg();           // rows per wave of sq_scan5_kernel
 extern "C" {
 __global__ void sq_fill_kernel(SqDevCtx c, int only_ext, int mul_done);
 __global__ void sq_bits_direct_kernel(SqDevCtx c);
+__global__ void sq_bits_masks_kernel(SqDevCtx c, int max_letters);
 __global__ void sq_dense64_kernel(SqDevCtx c, int job, double *boolmat, double *scoremat);
 __global__ void sq_import_kernel(SqDevCtx c);
 __global__ void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n);

@@ -108,6 +108,7 @@ struct sq_batch {
     std::vector<sq_paramset> psets;
     std::vector<SqJob> jobs;
     int32_t interchainonly = 0;
+    int32_t nletters = 0;                     // distinct letter codes of the batch (sq_bits_masks_kernel)
     int32_t max_structs = 4096;
     int32_t cand_per_nt = 32;
     // device carve

@@ -233,6 +233,11 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     std::vector<uint8_t> inc4(L.ltot);
     std::vector<int16_t> chain(L.ltot, 0);
     std::vector<uint8_t> e0(L.ltot, 0);
+    {
+        uint32_t seen = 0;
+        for (uint8_t cd : b->codes) if (cd < 29) seen |= 1u << cd;
+        b->nletters = __builtin_popcount(seen);
+    }
     for (int s = 0; s < d->nseq; s++) {
         const int off = d->seq_off[s], n = d->seq_off[s + 1] - off;
         auto sep = [&](int p) { return b->codes[off + p] == SQ_CODE_SEP1 || b->codes[off + p] == SQ_CODE_SEP2; };
@@ -536,7 +541,15 @@ static int fill_impl(sq_batch *b, int full)
             double bbytes = 0;
             if (j0 == 0 && !(full || any_ext)) for (const SqJob &J : b->jobs) bbytes += 4.0 * J.nw * J.bpitch;   // bit words written
             ProfScope ps(b, 0, bbytes);
-            hipLaunchKernelGGL(sq_bits_direct_kernel, g2, dim3(256), 0, b->stream, c);
+            // letter-mask formulation unless the chain test is on or the O(N) tables outgrow LDS
+            const int nwmax = (b->maxn + 31) / 32;
+            const size_t mdyn = 3 * (size_t)((b->maxn + 3) & ~3) + 4 * (size_t)b->nletters * (nwmax + 3) + 4 * (size_t)nwmax * b->nletters + 16;
+            static const bool no_masks = getenv("SQ_BITS_NOMASKS") != nullptr;
+            if (!b->interchainonly && !no_masks && b->nletters > 0 && mdyn <= 60 * 1024) {
+                const int bparts = std::max(1, std::min(nwmax, (2048 + nj - 1) / nj));
+                hipLaunchKernelGGL(sq_bits_masks_kernel, dim3(bparts, nj), dim3(256), mdyn, b->stream, c, b->nletters);
+            } else
+                hipLaunchKernelGGL(sq_bits_direct_kernel, g2, dim3(256), 0, b->stream, c);
         }
     }
     HIPCK(hipGetLastError());

@@ -232,6 +232,98 @@ extern "C" __global__ __launch_bounds__(256) void sq_bits_direct_kernel(SqDevCtx
     }
 }
 
+// The same bit matrix from letter masks: for the letters x present in the sequence, R_x = the rows of a word-row with
+// letter x (and no row-side restraint flag), M_x = the columns whose letter may pair with x (and no column-side
+// flag) as a bit array over j.  A word (w, s) is then OR_x R_x & reverse(M_x[t-31 .. t]), t = s - 32w: a few word
+// operations instead of 32 cell tests; only the words next to the main diagonal check the minimal loop length bit
+// by bit (:294-299).  grid = (parts, jobs): a block rebuilds the O(N) masks of its job and writes every `parts`-th
+// word-row.  Not for interchainonly batches (the chain test does not factor): they use sq_bits_direct_kernel.
+extern "C" __global__ __launch_bounds__(256) void sq_bits_masks_kernel(SqDevCtx c, int max_letters)
+{
+    extern __shared__ __attribute__((aligned(16))) char s_bm[];
+    __shared__ uint32_t s_pm[32];
+    __shared__ uint32_t s_present;
+    __shared__ uint8_t s_letter[32];
+    const SqJob jb = c.jobs[blockIdx.y];
+    if (jb.has_ext == 1) return;                        // bool comes from the caller's matrix (sq_bits_kernel)
+    const int n = jb.n, bp = jb.bpitch, nw = jb.nw, mw = nw + 3;
+    const SqPsetDev *ps = c.psets + jb.pset;
+    uint32_t *bits = c.bits + jb.bits_off;
+    const int tid = threadIdx.x;
+    const int npad = (n + 3) & ~3;
+    uint8_t *s_ccode = reinterpret_cast<uint8_t *>(s_bm);               // [npad] column letter (31 = excluded)
+    uint8_t *s_rcode = s_ccode + npad;                                  // [npad] row letter (31 = excluded)
+    uint8_t *s_inc = s_rcode + npad;                                    // [npad] minimal j - i
+    uint32_t *s_M = reinterpret_cast<uint32_t *>(s_inc + npad);         // [max_letters][mw], one zero word in front
+    uint32_t *s_R = s_M + max_letters * mw;                             // [nw][max_letters]
+    if (tid < 32) {
+        uint32_t m = 0;
+        for (int q = 0; q < 29; q++) if (ps->inbps[tid * 32 + q]) m |= 1u << q;     // :300 (codes 0..28; 31 never set)
+        s_pm[tid] = m;
+    }
+    if (tid == 0) s_present = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int p = tid; p < n; p += 256) {
+        const uint32_t code = c.codes[jb.pos_off + p], fl = c.flags[jb.pos_off + p];
+        s_ccode[p] = (uint8_t)((!(fl & 1u) && !(fl & 2u)) ? code : 31u);            // :302, :303 (column side)
+        const bool rowok = !(fl & 1u) && !(fl & 4u);                                  // :302, :304 (row side)
+        s_rcode[p] = (uint8_t)(rowok ? code : 31u);
+        s_inc[p] = c.inc4[jb.pos_off + p];
+        if (rowok && code < 29u && s_pm[code]) mine |= 1u << code;    // (letters that pair with nothing have no cells)
+    }
+    if (mine) atomicOr(&s_present, mine);
+    __syncthreads();
+    const uint32_t present = s_present;
+    const int nlet = __popc(present);                                    // <= max_letters (host: letters of the batch)
+    if (tid < 32) {
+        uint32_t m = present; int k = 0;
+        while (m) { const int x = __ffs((int)m) - 1; m &= m - 1; if (k == tid) s_letter[tid] = (uint8_t)x; k++; }
+    }
+    __syncthreads();
+    for (int e = tid; e < nlet * mw; e += 256) {                         // column masks
+        const int k = e / mw, q = e - k * mw;
+        const uint32_t pm = s_pm[s_letter[k]];
+        uint32_t word = 0;
+        const int j0 = (q - 1) * 32;
+        if (q >= 1 && j0 < n)
+            for (int bb = 0; bb < 32 && j0 + bb < n; bb++) word |= ((pm >> s_ccode[j0 + bb]) & 1u) << bb;
+        s_M[e] = word;
+    }
+    for (int e = tid; e < nw * nlet; e += 256) {                         // row masks
+        const int w = e / nlet, k = e - w * nlet;
+        const uint32_t x = s_letter[k];
+        uint32_t word = 0;
+        for (int bb = 0; bb < 32 && 32 * w + bb < n; bb++) word |= (uint32_t)(s_rcode[32 * w + bb] == x) << bb;
+        s_R[w * max_letters + k] = word;
+    }
+    __syncthreads();
+    for (int w = blockIdx.x; w < nw; w += gridDim.x) {
+        const int i0 = 32 * w;
+        const uint32_t *R = s_R + w * max_letters;
+        for (int s = tid; s < bp; s += 256) {
+            uint32_t word = 0;
+            const int t = s - i0;                                        // column of bit 0
+            if (s >= 4 && s <= 2 * n - 6 && t >= 0 && t - 31 < n) {
+                const int q = t + 1;                                     // bit index of column t-31 behind the zero word
+                for (int k = 0; k < nlet; k++) {
+                    const uint32_t *M = s_M + k * mw + (q >> 5);
+                    const uint64_t two = ((uint64_t)M[1] << 32) | M[0];
+                    word |= R[k] & __brev((uint32_t)(two >> (q & 31)));
+                }
+                const int d = s - 2 * i0;                                // j - i of bit b is d - 2b
+                if (word && d < 4 + 62) {
+                    uint32_t keep = 0;
+                    for (int bb = 0; bb < 32 && i0 + bb < n; bb++)
+                        if (d - 2 * bb >= (int)s_inc[i0 + bb]) keep |= 1u << bb;            // :294-299
+                    word &= keep;
+                }
+            }
+            bits[(int64_t)w * bp + s] = word;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // per-structure state: partner P, mask code E, prefix counts U (unpaired), SU (unpaired separators)
 // ------------------------------------------------------------------------------------
