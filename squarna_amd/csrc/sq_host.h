@@ -67,17 +67,21 @@ class SqPool {
 public:
     explicit SqPool(int nthreads);
     ~SqPool();
-    void parallel_for(int n, const std::function<void(int)> &fn);   // callers are serialised (two fold lanes share the pool)
+    // callers are serialised (two fold lanes share the pool).  The workers form two groups: the first 15 serve every
+    // call, the rest only wide ones (wide < 0: n >= 512) -- waking 31 threads for a few hundred short items costs
+    // more than it buys.
+    void parallel_for(int n, const std::function<void(int)> &fn, int wide = -1);
     int size() const { return (int)workers.size() + 1; }
 private:
-    void worker();
+    void worker(int group);
     std::vector<std::thread> workers;
+    int group_size[2] = {0, 0};
     std::mutex mu, callers;
-    std::condition_variable cv_start, cv_done;
+    std::condition_variable cv_start[2], cv_done;
     const std::function<void(int)> *fn = nullptr;
     std::atomic<int> next{0};
     int total = 0, active = 0;
-    uint64_t gen = 0;
+    uint64_t gen[2] = {0, 0};
     bool stop = false;
 };
 
@@ -157,7 +161,7 @@ int sq_check(hipError_t e, const char *what);
 // profiling bracket on an arbitrary stream (slot k of sq_profile_get); no-ops unless profiling is enabled
 void sq_prof_begin(sq_batch *b, int k, hipStream_t st, hipEvent_t *e0);
 void sq_prof_end(sq_batch *b, int k, hipStream_t st, hipEvent_t e0);
-SqPool *sq_pool(sq_batch *b);             // the batch's worker pool (SQ_HOST_THREADS, default min(16, cores))
+SqPool *sq_pool(sq_batch *b);             // the batch's worker pool (SQ_HOST_THREADS, default min(32, cores))
 
 // bit matrices for the scan (full fp32 fill only for jobs with caller matrices / legacy scans)
 int sq_prepare_scan(sq_batch *b);

@@ -30,23 +30,27 @@ int sq_check(hipError_t e, const char *what)
 // ---- host worker pool -------------------------------------------------------------------------
 SqPool::SqPool(int nthreads)
 {
-    for (int t = 1; t < nthreads; t++) workers.emplace_back([this] { worker(); });
+    for (int t = 1; t < nthreads; t++) {
+        const int group = t <= 15 ? 0 : 1;
+        group_size[group]++;
+        workers.emplace_back([this, group] { worker(group); });
+    }
 }
 SqPool::~SqPool()
 {
-    { std::lock_guard<std::mutex> lk(mu); stop = true; gen++; }
-    cv_start.notify_all();
+    { std::lock_guard<std::mutex> lk(mu); stop = true; gen[0]++; gen[1]++; }
+    cv_start[0].notify_all(); cv_start[1].notify_all();
     for (auto &t : workers) t.join();
 }
-void SqPool::worker()
+void SqPool::worker(int group)
 {
     uint64_t seen = 0;
     for (;;) {
         const std::function<void(int)> *f;
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv_start.wait(lk, [&] { return gen != seen; });
-            seen = gen;
+            cv_start[group].wait(lk, [&] { return gen[group] != seen; });
+            seen = gen[group];
             if (stop) return;
             f = fn;
         }
@@ -54,16 +58,19 @@ void SqPool::worker()
         { std::lock_guard<std::mutex> lk(mu); if (--active == 0) cv_done.notify_one(); }
     }
 }
-void SqPool::parallel_for(int n, const std::function<void(int)> &f)
+void SqPool::parallel_for(int n, const std::function<void(int)> &f, int wide)
 {
     if (n <= 0) return;
     if (workers.empty() || n == 1) { for (int i = 0; i < n; i++) f(i); return; }
     std::lock_guard<std::mutex> one_caller(callers);
+    const bool all = (wide < 0 ? n >= 512 : wide != 0) && group_size[1] > 0;
     {
         std::lock_guard<std::mutex> lk(mu);
-        fn = &f; total = n; next.store(0); active = (int)workers.size(); gen++;
+        fn = &f; total = n; next.store(0); active = group_size[0] + (all ? group_size[1] : 0); gen[0]++;
+        if (all) gen[1]++;
     }
-    cv_start.notify_all();
+    cv_start[0].notify_all();
+    if (all) cv_start[1].notify_all();
     for (int i; (i = next.fetch_add(1)) < n;) f(i);
     std::unique_lock<std::mutex> lk(mu);
     cv_done.wait(lk, [&] { return active == 0; });
@@ -71,10 +78,10 @@ void SqPool::parallel_for(int n, const std::function<void(int)> &f)
 SqPool *sq_pool(sq_batch *b)
 {
     if (!b->pool) {
-        // up to 16 workers, sharing the host cores with the other ranks of the node (torchrun's LOCAL_WORLD_SIZE)
+        // up to 32 workers, sharing the host cores with the other ranks of the node (torchrun's LOCAL_WORLD_SIZE)
         unsigned cores = std::max(1u, std::thread::hardware_concurrency());
         if (const char *lws = getenv("LOCAL_WORLD_SIZE")) cores = std::max(1u, cores / (unsigned)std::max(1, atoi(lws)));
-        int nthr = (int)std::min(cores, 16u);
+        int nthr = (int)std::min(cores, 32u);
         if (const char *e = getenv("SQ_HOST_THREADS")) nthr = std::max(1, atoi(e));
         b->pool = new SqPool(nthr);
     }
@@ -1163,7 +1170,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                         P.nxt.clear();                      // (capacity stays)
                     }
             };
-            static const size_t par_min = getenv("SQ_GROW_PAR") ? (size_t)atol(getenv("SQ_GROW_PAR")) : 4096;
+            static const size_t par_min = getenv("SQ_GROW_PAR") ? (size_t)atol(getenv("SQ_GROW_PAR")) : 1024;
             if (round.size() >= par_min) {
                 const int nsl = sq_pool(b)->size() * 4;
                 std::vector<size_t> cut(nsl + 1);
@@ -1172,7 +1179,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                     while (q > 0 && q < round.size() && owner[q] == owner[q - 1]) q++;   // slices end on job boundaries
                     cut[t] = q;
                 }
-                sq_pool(b)->parallel_for(nsl, [&](int t) { if (cut[t] < cut[t + 1]) grow(cut[t], cut[t + 1]); });
+                sq_pool(b)->parallel_for(nsl, [&](int t) { if (cut[t] < cut[t + 1]) grow(cut[t], cut[t + 1]); }, 1);
             } else grow(0, round.size());
         }
     };
