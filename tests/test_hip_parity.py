@@ -169,6 +169,33 @@ def test_fold_vs_oracle_random(cfg, sizes):
         _same_fold(g, exp, (cfg, len(r[0])))
 
 
+@pytest.mark.parametrize("cfg,count", [("fastest", 700), ("greedynobpp", 300)])
+def test_big_batch_two_lanes_vs_oracle(cfg, count):
+    """>= 512 greedy jobs in one batch: sq_fold splits its rounds over two lanes (two host threads, two streams) and
+    ranks finished sequences while the others still fold; every record must still equal the CPU oracle.  Mixed
+    lengths, reactivities, restraint lines, a second chain and unknown letters keep the two lanes uneven."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import HipEngine
+    names, psets = conf(cfg)
+    rng = random.Random(4242 + count)
+    recs = []
+    for k in range(count):
+        seq, reacts, restr = _rand_case(rng, rng.randrange(12, 90))
+        if k % 9 == 0 and len(seq) > 30:
+            p = rng.randrange(10, len(seq) - 10)
+            seq = seq[:p] + "&" + seq[p + 1:]
+        if k % 13 == 0:
+            p = rng.randrange(len(seq))
+            seq = seq[:p] + "N" + seq[p + 1:]
+        recs.append((seq, reacts, restr, None, psets, None))
+    got = HipEngine().fold_records(recs, poollim=50, rankby=(2, 0, 1))
+    assert len(got) == count
+    for r, g in zip(recs, got):
+        exp = O.SQRNdbnseq(r[0], r[1], r[2], None, psets, poollim=50, rankby=(2, 0, 1))
+        exp = [exp[0], [[d, list(s), list(p)] for d, s, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(g, exp, (cfg, r[0]))
+
+
 def test_edge_cases():
     """Empty-ish and degenerate inputs the reference handles (N < 5 has no diagonals)."""
     from oracle import sqrn_oracle as O
