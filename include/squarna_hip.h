@@ -204,9 +204,14 @@ SQ_API int64_t sq_result_evals(const sq_batch *b, int32_t seq);
  *   matrix[cols[v], cols[w]] += stem score;  matrix[cols[w], cols[v]] += stem score
  * for every base pair (v, w) of every stem -- the parent-side loop of SQRNdbnali (:233-237).
  * cols[col_off[k] + p] is the alignment column of position p of job_ids[k] (ReAlignDict, :20-37).
- * d_matrix: caller-owned DEVICE memory, L x L fp64 row-major, accumulated into (zero it first).
+ * d_matrix: caller-owned DEVICE memory, L x L fp64 row-major, accumulated into: zero it first, then pass
+ * the same matrix to as many calls as the alignment needs.  Both additions of a pair are the same number
+ * in the same order, so the library accumulates the upper triangle and copies it onto the lower one at the
+ * end of every call (the lower triangle of the input is overwritten).
  * A cell receives at most one addition per sequence and sequences are applied in list order, so
- * every cell sees the reference's fp64 summation order.  Asynchronous tail on the batch stream. */
+ * every cell sees the reference's fp64 summation order (when every sum is exact anyway -- pair weights
+ * that are multiples of 2^-10, no reactivities -- the sequences of a chunk are added in one launch).
+ * The matrix is complete when the call returns. */
 SQ_API int sq_align_accumulate(sq_batch *b, int32_t njob, const int32_t *job_ids, const int32_t *col_off,
                                const int32_t *cols, int32_t L, double *d_matrix);
 /* Cells (v, w) of a device L x L fp64 matrix with w - v >= minspan and value >= threshold

@@ -75,6 +75,9 @@ __global__ void sq_dense64_kernel(SqDevCtx c, int job, double *boolmat, double *
 __global__ void sq_import_kernel(SqDevCtx c);
 __global__ void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n);
 __global__ void sq_done_kernel(SqRoundIO io, SqScanArgs a, uint32_t seq);
+__global__ void sq_mirror_kernel(double *matrix, int L);
+__global__ void sq_scatter_all_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const int32_t *cols,
+                                      const int32_t *col_start, int L, double *matrix);
 __global__ void sq_scatter_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, int sidx, const int32_t *cols,
                                   int L, double *matrix);
 __global__ void sq_colselect_kernel(const double *matrix, int L, double thr, int minspan, long long *idx_out,

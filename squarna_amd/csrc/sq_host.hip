@@ -279,6 +279,14 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         x.bracketweight = ps.bracketweight; x.distcoef = ps.distcoef;
         x.orderpenalty = ps.orderpenalty; x.loopbonus = ps.loopbonus;
         for (int k = 0; k <= SQ_MAXLEVELS; k++) x.oftab[k] = pow(1.0 / (1 + k), ps.orderpenalty);   // :729
+        {
+            bool dy = true;
+            for (int q = 0; q < 32 * 32 && dy; q++) {
+                const double w = x.w[q] * 1024.0;
+                dy = std::fabs(x.w[q]) <= 1024.0 && w == std::floor(w);
+            }
+            b->pset_dyadic.push_back(dy ? 1 : 0);
+        }
         const double bw = ps.bracketweight;
         x.bw_integral = (bw == std::floor(bw) && std::fabs(bw) <= 64) ? 1 : 0;
         x.sdf_off = (int32_t)sdf.size(); x.sdf_len = 0;
@@ -787,9 +795,10 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
         static const int score_threads = getenv("SQ_SCORE_THREADS") ? atoi(getenv("SQ_SCORE_THREADS")) : 0;
         static const int score_parts = getenv("SQ_SCORE_PARTS") ? atoi(getenv("SQ_SCORE_PARTS")) : 0;
         static const int score_target = getenv("SQ_SCORE_TARGET") ? atoi(getenv("SQ_SCORE_TARGET")) : 512;
-        int parts = std::max(1, std::min({512, (score_target + S - 1) / S, (int)(maxcap / 1024)}));
+        // mode 0 (two-phase loop): ~512 blocks of 512 threads; the one-pass modes want many small blocks in flight
+        int parts = std::max(1, std::min({512, ((mode == 0 ? score_target : 4096) + S - 1) / S, (int)(maxcap / 1024)}));
         if (score_parts) parts = score_parts;
-        const int thr = score_threads ? score_threads : 512;
+        const int thr = score_threads ? score_threads : (mode == 0 ? 512 : (parts == 1 && S < 2048 ? 512 : 256));
         // mode 0: list of the bpscore survivors of a chunk (5 x threads entries of 8 + 4 + 2 bytes) behind the tables
         const int surv_off = (int)((dyn + 15) & ~(size_t)15);
         if (mode == 0) dyn = (size_t)surv_off + (size_t)14 * (SQ_SCORE_CHUNK + 1) * thr;
@@ -802,8 +811,28 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
             // sequence, in list order: stream order == the reference's per-cell summation order (dbnali:233-237)
             int32_t *d_cols = (int32_t *)ln.d_out;
             const int32_t c0 = sink->col_off[lo], c1 = sink->col_off[hi];
-            if ((size_t)(c1 - c0) * 4 > (size_t)ln.out_cap * sizeof(SqOut)) { sq_set_error("gap maps do not fit the round buffer"); return -3; }
+            if ((size_t)(c1 - c0 + S) * 4 > (size_t)ln.out_cap * sizeof(SqOut)) { sq_set_error("gap maps do not fit the round buffer"); return -3; }
             HIPCK(hipMemcpyAsync(d_cols, sink->cols + c0, (size_t)(c1 - c0) * 4, hipMemcpyHostToDevice, st));
+            // order-free chunk (dyadic weights, no reactivity factors, no caller matrices): every sum is exact, so one
+            // launch with atomic adds gives the same bits as the sequential order
+            static const bool no_atomic = getenv("SQ_ALIGN_SEQUENTIAL") != nullptr;
+            bool order_free = !no_atomic;
+            int64_t maxcap = 1;
+            for (int k = 0; k < S && order_free; k++) {
+                const SqJob &J = b->jobs[structs[lo + k].job];
+                order_free = J.default_reacts && J.mat64_off < 0 && b->pset_dyadic[J.pset];
+                maxcap = std::max<int64_t>(maxcap, J.cand_cap);
+            }
+            if (order_free) {
+                std::vector<int32_t> starts(S);
+                for (int k = 0; k < S; k++) starts[k] = sink->col_off[lo + k] - c0;
+                int32_t *d_starts = d_cols + (c1 - c0);
+                HIPCK(hipMemcpyAsync(d_starts, starts.data(), (size_t)S * 4, hipMemcpyHostToDevice, st));
+                HIPCK(hipStreamSynchronize(st));             // (starts is a local)
+                const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>(maxcap / 4096, 1), 64);
+                hipLaunchKernelGGL(sq_scatter_all_kernel, dim3(blocks, S), dim3(256), 0, st, b->ctx, ln.d_structs, scan,
+                                   d_cols, d_starts, sink->L, sink->matrix);
+            } else
             for (int k = 0; k < S; k++) {
                 const SqJob &J = b->jobs[structs[lo + k].job];
                 const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>(J.cand_cap / 1024, 1), 1024);
@@ -978,7 +1007,18 @@ extern "C" int sq_align_accumulate(sq_batch *b, int32_t njob, const int32_t *job
     }
     AlignSink sink{col_off, cols, L, d_matrix};
     std::vector<std::vector<HStem>> unused;
-    return run_round_impl(b, b->lane_full, views, 2, unused, &sink);
+    const double t0 = now_s();
+    for (int k = 0; k < 8; k++) g_t[k] = 0;
+    int r = run_round_impl(b, b->lane_full, views, 2, unused, &sink);
+    if (!r) {
+        const unsigned nt = (unsigned)((L + 31) / 32);
+        hipLaunchKernelGGL(sq_mirror_kernel, dim3(nt, nt), dim3(256), 0, b->stream, d_matrix, L);
+        r = sq_check(hipStreamSynchronize(b->stream), "sq_mirror_kernel");
+    }
+    if (getenv("SQ_TIMING"))
+        fprintf(stderr, "[sq_align_accumulate] %d sequences: %.3f ms (prep %.3f, gpu+wait %.3f)\n", njob, (now_s() - t0) * 1e3,
+                g_t[0] * 1e3, g_t[1] * 1e3);
+    return r;
 }
 
 extern "C" int sq_colmatrix_select(const double *d_matrix, int32_t L, double threshold, int32_t minspan,

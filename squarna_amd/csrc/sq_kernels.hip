@@ -1509,9 +1509,48 @@ extern "C" __global__ __launch_bounds__(256) void sq_scatter_kernel(SqDevCtx c, 
         const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
         for (int t = 0; t < (int)cd.len; t++) {
             const int64_t v = cols[i0 + t], w = cols[j0 - t];
-            matrix[v * L + w] += cd.bps;
-            matrix[w * L + v] += cd.bps;
+            matrix[v * L + w] += cd.bps;                   // v < w: the lower triangle is mirrored at the end
         }
+    }
+}
+
+// The same accumulation for ALL sequences of a chunk in one launch (grid.y = structure), with hardware fp64 atomic
+// adds.  Only used when every addend and every partial sum is exactly representable (weights are multiples of
+// 2^-k, no reactivity factors: sq_align_accumulate checks), so the order of the additions cannot change a bit.
+extern "C" __global__ __launch_bounds__(256) void sq_scatter_all_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a,
+                                                                       const int32_t *cols, const int32_t *col_start, int L,
+                                                                       double *matrix)
+{
+    const SqStruct st = structs[blockIdx.y];
+    const SqJob jb = c.jobs[st.job];
+    const uint32_t nok = a.ok_cnt[st.slot];
+    const SqOk *oks = sq_oks(a, st, jb.cand_cap);
+    const int32_t *mycols = cols + col_start[blockIdx.y];
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < nok; q += gridDim.x * 256) {
+        const SqOk cd = oks[q];
+        const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
+        for (int t = 0; t < (int)cd.len; t++) {
+            const int64_t v = mycols[i0 + t], w = mycols[j0 - t];
+            unsafeAtomicAdd(&matrix[v * L + w], cd.bps);   // v < w
+        }
+    }
+}
+
+// lower triangle := transpose of the upper one (32 x 32 tiles through LDS, both sides coalesced)
+extern "C" __global__ __launch_bounds__(256) void sq_mirror_kernel(double *matrix, int L)
+{
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x, by = blockIdx.y;               // tile (by, bx) of the upper triangle: bx >= by
+    if (bx < by) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8 threads
+    for (int r = ty; r < 32; r += 8) {
+        const int v = by * 32 + r, w = bx * 32 + tx;
+        tile[r][tx] = (v < L && w < L) ? matrix[(int64_t)v * L + w] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int w = bx * 32 + r, v = by * 32 + tx;         // writes row w, columns v
+        if (w < L && v < L && v < w) matrix[(int64_t)w * L + v] = tile[tx][r];
     }
 }
 

@@ -168,6 +168,7 @@ def PairsToDBN(newpairs, length=0, returnlevels=False, levellimit=-1):
     import numpy as np
     pairs = sorted(set((min(v, w), max(v, w)) for v, w in newpairs))
     P = len(pairs)
+    groups = []                                                    # lists of pair indices
     if P:
         a = np.array([p[0] for p in pairs], np.int64)
         b = np.array([p[1] for p in pairs], np.int64)
@@ -175,17 +176,24 @@ def PairsToDBN(newpairs, length=0, returnlevels=False, levellimit=-1):
         X = ((a[:, None] < a[None, :]) & (a[None, :] < b[:, None]) & (b[:, None] < b[None, :]))
         X |= X.T
         count = X.sum(axis=1)
-        order = sorted(range(P), key=lambda p: (int(count[p]), pairs[p][0]))          # :125 (stable)
-    else:
-        X, count, order = None, [], []
-    groups = []                                                    # lists of pair indices
-    for p in order:
-        for group in groups:
-            if not count[p] or not X[p, group].any():              # :130-136 first fit
-                group.append(p)
-                break
-        else:
-            groups.append([p])
+        order = np.lexsort((a, count))                             # :125 sort by (crossings, i), stable
+        cap = 8
+        member = np.zeros((cap, P), bool)                          # member[g, q]: pair q sits in group g
+        for p in order:                                            # :130-136 first fit
+            p = int(p)
+            ng = len(groups)
+            if ng and count[p]:
+                conflict = (member[:ng] & X[p]).any(axis=1)
+                g = ng if conflict.all() else int(np.argmin(conflict))
+            else:
+                g = 0
+            if g == ng:
+                if ng == cap:
+                    member = np.vstack([member, np.zeros((cap, P), bool)])
+                    cap *= 2
+                groups.append([])
+            groups[g].append(p)
+            member[g, p] = True
     groups.sort(key=len, reverse=True)                             # :139 (stable)
     if returnlevels:
         return {pairs[p]: lev + 1 for lev, group in enumerate(groups) for p in group}
