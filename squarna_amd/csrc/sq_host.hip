@@ -801,9 +801,13 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
         const int thr = score_threads ? score_threads : (mode == 0 ? 512 : (parts == 1 && S < 2048 ? 512 : 256));
         // mode 0: list of the bpscore survivors of a chunk (5 x threads entries of 8 + 4 + 2 bytes) behind the tables
         const int surv_off = (int)((dyn + 15) & ~(size_t)15);
-        if (mode == 0) dyn = (size_t)surv_off + (size_t)14 * (SQ_SCORE_CHUNK + 1) * thr;
-        hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, ln.d_structs, ln.d_strands, b->state,
-                           scan, io, mode, lds_n, lds_nr, lds_ns, surv_off);
+        dyn = (size_t)surv_off + (size_t)14 * (SQ_SCORE_CHUNK + (mode == 0 ? 1 : 0)) * thr;   // (one-pass modes: no carry-over)
+        if (mode == 0)
+            hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, ln.d_structs, ln.d_strands, b->state,
+                               scan, io, lds_n, lds_nr, lds_ns, surv_off);
+        else
+            hipLaunchKernelGGL(sq_bps_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, ln.d_structs, ln.d_strands, b->state,
+                               scan, io, mode, lds_n, lds_nr, surv_off);
         if (mode == 0)
             hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, ln.d_structs, scan, io);
         if (mode == 2) {
