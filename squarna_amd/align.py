@@ -46,12 +46,14 @@ def MatrixToDBNs(mat, score, depth, verbose=False, sink=sys.stdout, cells=None):
     if not verbose:
         # only the first structure is used by the caller (:242), and a cell joins it iff both of its columns
         # are still free THERE -- whatever the later structures hold
-        taken = np.zeros(N, bool)
+        sidx = np.asarray(idx)[order]
+        vs, ws = sidx // N, sidx % N
+        far = (ws - vs) >= 4                                       # :147
+        taken = bytearray(N)
         first = []
-        for k in order:
-            v, w = int(idx[k] // N), int(idx[k] % N)
-            if w - v >= 4 and not taken[v] and not taken[w]:
-                taken[v] = taken[w] = True
+        for v, w in zip(vs[far].tolist(), ws[far].tolist()):       # plain ints: the loop is the sequential part
+            if not taken[v] and not taken[w]:
+                taken[v] = taken[w] = 1
                 first.append((v, w))
         return [PairsToDBN(first, N)]
     res = [[[], set()]]

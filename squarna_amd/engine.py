@@ -46,7 +46,12 @@ class Prepared:
         else:
             gaps, self.gapidx = None, []
         self.sepidx = [i for i, ch in enumerate(seq) if ch in SEPS] if (';' in seq or '&' in seq) else []
-        self.shortreacts = list(reacts) if not self.gapidx else [reacts[i] for i in np.flatnonzero(~gaps).tolist()]
+        if self.plain_reacts:
+            self.shortreacts = [0.5] * len(self.shortseq)
+        elif not self.gapidx:
+            self.shortreacts = list(reacts)
+        else:
+            self.shortreacts = np.asarray(reacts, dtype=np.float64)[~gaps].tolist()
         self.shortdbn = None
         if dbn:
             assert len(seq) == len(dbn)
