@@ -1084,6 +1084,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // The reference iterates a Python set of letters (unspecified order); we use E, H, N.
     SqAlgoAsync *pending = nullptr;
     const double ta = now_s();
+    if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_fold] setup before E/H/N begin: %.3f ms (bit matrix launch + job pools)\n", (ta - fold_timer.t0) * 1e3);
     r = sq_algos_begin(b, algos, pending);                  // AnnotateStems + matching kernels on side streams
     struct PendGuard {                                      // error paths: wait for the side streams, release the arena
         sq_batch *b; SqAlgoAsync *&p;
