@@ -1274,22 +1274,52 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     double best = 0.0; int any = 0;
 
     const uint32_t qstep = gridDim.y * nthr;
-    // exact bpscore: sum(...) left to right starting from int 0  (:416)
-    auto stem_bps = [&](int i0, int j0, int L) -> double {
-        // four cells per step: their (dependent) LDS lookups overlap, the additions keep the reference's order; the
-        // padding cells of the last step add +0.0, which leaves the sum unchanged
-        double bps = 0.0;
-        for (int t = 0; t < L; t += 4) {
-            double v[4];
+    // exact bpscore of the SQ_SCORE_CHUNK candidates of a thread: sum(...) left to right starting from int 0 (:416),
+    // four cells per step: the lookups of one step (letter codes, then the weight) are independent and overlap, the
+    // additions of each candidate keep the reference's order; padding cells (past a candidate's end) add +0.0, which
+    // leaves its sum unchanged.  The filter-only kernel advances its candidates TOGETHER (16 lookups in flight; 3.1 ->
+    // 1.9 ms per alignment chunk); under ScoreStems' register budget that spills, so there they go one by one.
+    auto chunk_bps = [&](const SqKey (&cd)[SQ_SCORE_CHUNK], double (&bps)[SQ_SCORE_CHUNK]) {
+        if (FULL) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int tt = t + u < L ? t + u : L - 1;
-                v[u] = cell_exact(i0 + tt, j0 - tt);
+            for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
+                const int s = (int)(cd[u].key >> 16), i0 = (int)(cd[u].key & 0xFFFFu), j0 = s - i0, L = (int)cd[u].len;
+                double acc = 0.0;
+                for (int t = 0; t < L; t += 4) {
+                    double v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int tt = t + k < L ? t + k : L - 1;
+                        v[k] = cell_exact(i0 + tt, j0 - tt);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc = acc + (t + k < L ? v[k] : 0.0);
+                }
+                bps[u] = acc;
+            }
+            return;
+        }
+        int lmax = 0;
+#pragma unroll
+        for (int u = 0; u < SQ_SCORE_CHUNK; u++) { bps[u] = 0.0; lmax = max(lmax, (int)cd[u].len); }
+        for (int t = 0; t < lmax; t += 4) {
+            double v[SQ_SCORE_CHUNK][4];
+#pragma unroll
+            for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
+                const int s = (int)(cd[u].key >> 16), i0 = (int)(cd[u].key & 0xFFFFu), j0 = s - i0, L = (int)cd[u].len;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int tt = max(min(t + k, L - 1), 0);
+                    v[u][k] = cell_exact(i0 + tt, j0 - tt);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) bps = bps + (t + u < L ? v[u] : 0.0);
+            for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
+                const int L = (int)cd[u].len;
+#pragma unroll
+                for (int k = 0; k < 4; k++) bps[u] = bps[u] + (t + k < L ? v[u][k] : 0.0);
+            }
         }
-        return bps;
     };
     if (!FULL) {
         // bpscore filter only (:492): OptimalStems output (mode 1) or the alignment's survivor list (mode 2).  The
@@ -1309,10 +1339,12 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                 const uint32_t q = q0 + (uint32_t)u * qstep + tid;
                 cd[u] = q < ncand ? keys[q] : SqKey{0u, 0u};            // (len 0: never appended)
             }
+            double bpsv[SQ_SCORE_CHUNK];
+            chunk_bps(cd, bpsv);
 #pragma unroll
             for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
-                const int s = (int)(cd[u].key >> 16), i0 = (int)(cd[u].key & 0xFFFFu), L = (int)cd[u].len;
-                const double bps = stem_bps(i0, s - i0, L);
+                const int L = (int)cd[u].len;
+                const double bps = bpsv[u];
                 const bool ok = L > 0 && bps >= minbps;
                 const unsigned long long okm = __ballot(ok);
                 if (okm) {
@@ -1365,10 +1397,12 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
             const uint32_t q = q0 + (uint32_t)u * qstep + tid;
             cd[u] = q < ncand ? keys[q] : SqKey{0u, 0u};                // (len 0: bps 0, never appended)
         }
+        double bpsv[SQ_SCORE_CHUNK];
+        chunk_bps(cd, bpsv);
 #pragma unroll
         for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
-            const int s = (int)(cd[u].key >> 16), i0 = (int)(cd[u].key & 0xFFFFu), L = (int)cd[u].len;
-            const double bps = stem_bps(i0, s - i0, L);
+            const int L = (int)cd[u].len;
+            const double bps = bpsv[u];
             const bool ok = L > 0 && bps >= minbps;                     // :492
             const unsigned long long okm = __ballot(ok);
             if (okm) {
