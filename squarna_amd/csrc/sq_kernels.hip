@@ -827,8 +827,17 @@ __device__ __forceinline__ void sq5_analyse(LDS &L, const SqScanArgs &a, const S
     }
     // runs inside: newest ends N = rest & ~(rest << 1); ended ones have p > 0
     const uint32_t N = rest & ~(rest << 1);
-    uint32_t Y = rest;                                // Y[p]: rest[p .. p+minlen-1] all ones
-    for (int t = 1; t < minlen && t < 32; t++) Y &= rest >> t;
+    uint32_t Y = rest;                                // Y[p]: rest[p .. p+minlen-1] all ones, by doubling (five fixed
+    {                                                 // steps cover 32; a loop over minlen made the compiler vectorise it)
+        int have = 1;
+        const int want = minlen < 32 ? minlen : 32;
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const int step = min(have, want - have);  // 0 once the window is complete: Y &= Y
+            Y &= Y >> step;
+            have += step;
+        }
+    }
     uint32_t bits = N & Y & ~1u;
     while (bits) {
         const int p = __ffs((int)bits) - 1;
@@ -1097,6 +1106,9 @@ struct SqScan6Lds {
     uint32_t rl[SQ6_RL];                 // live restraint cells of this wave's diagonals: v | (w << 16)
 };
 
+#ifndef SQ6_AHEAD
+#define SQ6_AHEAD 2
+#endif
 extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
 {
     __shared__ __attribute__((aligned(16))) SqScan6Lds L;
@@ -1143,27 +1155,65 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, con
 
     int carry = 0;
     uint32_t glo = G[gidx];
-    uint32_t base = bp[(int64_t)wlo * bpitch];
-    for (int w = wlo; w <= whi; w++) {
-        const uint32_t nxt = w < whi ? bp[(int64_t)(w + 1) * bpitch] : 0u;     // next step's word is in flight
-        const uint32_t ghi = G[gidx + 1 + (w - wlo)];
-        const uint32_t gw = __builtin_amdgcn_alignbit(ghi, glo, gsh);   // columns s-32w-b, b = 0..31
-        glo = ghi;
-        uint32_t A = base & F[w] & gw;                                  // :438-451 free row and column
-        if (nrl) {
-            for (uint32_t k = 0; k < nrl; k++) {
-                const uint32_t pk = L.rl[k];
-                const int v = (int)(pk & 0xFFFFu), ww = (int)(pk >> 16);
-                if (v + ww == s && (v >> 5) == w) A |= base & (1u << (v & 31));   // :438-443 restraint bp stays pairable
+    // window of minlen ones by doubling: Y &= Y >> ysh_q, five fixed steps (shift 0 once the window is complete)
+    int ysh0, ysh1, ysh2, ysh3, ysh4;
+    {
+        const int want = minlen < 32 ? minlen : 32;
+        int have = 1;
+        ysh0 = min(have, want - have); have += ysh0;
+        ysh1 = min(have, want - have); have += ysh1;
+        ysh2 = min(have, want - have); have += ysh2;
+        ysh3 = min(have, want - have); have += ysh3;
+        ysh4 = min(have, want - have);
+    }
+    // SQ6_AHEAD word-rows per trip: their (independent) loads are issued together, so a wave waits for HBM / L2 once
+    // per group instead of once per word (a single word of look-ahead did not survive the compiler's wait counts)
+    for (int w0 = wlo; w0 <= whi; w0 += SQ6_AHEAD) {
+        uint32_t bw[SQ6_AHEAD];
+#pragma unroll
+        for (int k = 0; k < SQ6_AHEAD; k++) bw[k] = w0 + k <= whi ? bp[(int64_t)(w0 + k) * bpitch] : 0u;
+#pragma unroll
+        for (int k = 0; k < SQ6_AHEAD; k++) {
+            const int w = w0 + k;
+            if (w > whi) break;
+            const uint32_t base = bw[k];
+            const uint32_t ghi = G[gidx + 1 + (w - wlo)];
+            const uint32_t gw = __builtin_amdgcn_alignbit(ghi, glo, gsh);   // columns s-32w-b, b = 0..31
+            glo = ghi;
+            uint32_t A = base & F[w] & gw;                              // :438-451 free row and column
+            if (nrl) {
+                for (uint32_t q = 0; q < nrl; q++) {
+                    const uint32_t pk = L.rl[q];
+                    const int v = (int)(pk & 0xFFFFu), ww = (int)(pk >> 16);
+                    if (v + ww == s && (v >> 5) == w) A |= base & (1u << (v & 31));   // :438-443 restraint bp stays pairable
+                }
             }
+            // maximal runs of the word (bit b = row 32w + b; `carry` rows of an open run precede row 32w)
+            if (__ballot((A != 0u) | (carry > 0)) != 0ull) {
+                if (A == 0xFFFFFFFFu) carry += 32;
+                else {
+                    const int lead = __ffs((int)~A) - 1;                // the run that continues the carried one (maybe empty)
+                    const int len0 = carry + lead;
+                    if (len0 >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(32 * w - carry), (uint32_t)len0);
+                    const int trail = __clz((int)~A);                   // the run still open at row 32w + 31
+                    carry = trail;
+                    // runs strictly inside: starts with a full window of minlen ones above them
+                    uint32_t rest = A & ~((1u << lead) - 1u);
+                    if (trail) rest &= 0xFFFFFFFFu >> trail;
+                    uint32_t Y = rest;
+                    Y &= Y >> ysh0; Y &= Y >> ysh1; Y &= Y >> ysh2; Y &= Y >> ysh3; Y &= Y >> ysh4;
+                    uint32_t starts = rest & ~(rest << 1) & Y;
+                    while (starts) {
+                        const int p = __ffs((int)starts) - 1;
+                        starts &= starts - 1;
+                        const int len = __ffs((int)~(rest >> p)) - 1;
+                        sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(32 * w + p), (uint32_t)len);
+                    }
+                }
+            } else
+                carry = 0;
+            if ((k & 1) && L.stage_count > SQ5_STAGE / 2) sq5_flush(L, a, st, cap, lane);
         }
-        base = nxt;
-        const uint32_t hist = __brev(A);                                // bit 0 = newest row, as sq5_analyse expects
-        if (__ballot((hist != 0u) | (carry > 0)) != 0ull)
-            sq5_analyse(L, a, st, cap, s, hist, 32, 32 * w, 0x3fffffff, minlen, carry);
-        else
-            carry = 0;
-        if (L.stage_count > SQ5_STAGE / 2) sq5_flush(L, a, st, cap, lane);
     }
     if (carry >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(32 * (whi + 1) - carry), (uint32_t)carry);
     __syncthreads();
