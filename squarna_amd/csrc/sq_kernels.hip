@@ -1212,7 +1212,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, con
                 }
             } else
                 carry = 0;
-            if ((k & 1) && L.stage_count > SQ5_STAGE / 2) sq5_flush(L, a, st, cap, lane);
+            if (L.stage_count > SQ5_STAGE / 2) sq5_flush(L, a, st, cap, lane);
         }
     }
     if (carry >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(32 * (whi + 1) - carry), (uint32_t)carry);
