@@ -1261,6 +1261,7 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                                               int lds_n_reacts, int lds_n_state, int surv_off)
 {
     __shared__ SqStrand s_str[FULL ? SQ_LDS_STRANDS : 1];
+    __shared__ uint16_t s_skip[FULL ? SQ_LDS_STRANDS : 1];   // 5' strand k closes a block: next strand that can matter after it
     __shared__ double s_w[32 * 32];               // pair weights of the job's paramset
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];   // letter codes [n] (+ reactivities [n] when they fit)
     const SqStruct st = structs[blockIdx.x];
@@ -1272,11 +1273,30 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     if (ncand > (uint32_t)jb.cand_cap) ncand = jb.cand_cap;
     if ((uint32_t)blockIdx.y * (uint32_t)nthr >= ncand) return;         // this part has no candidates
     const SqStrand *S = strands + st.strand_off;
-    if (FULL && st.nstrand <= SQ_LDS_STRANDS) {
+    const bool lds_strands = FULL && st.nstrand <= SQ_LDS_STRANDS;
+    if (lds_strands) {
         for (int k = tid; k < st.nstrand; k += nthr) s_str[k] = S[k];
         S = s_str;
     }
     __syncthreads();
+    if (lds_strands) {
+        // Once the sweep of ScoreStems has registered the block [start, partner] of a 5' strand, the strands that
+        // start inside it are inert unless they are 5' strands whose partner lies beyond the block's end (they extend
+        // it or are wings); skip[k] = the first strand behind k that starts outside the block or is such a strand.
+        for (int k = tid; k < st.nstrand; k += nthr) {
+            const SqStrand x = s_str[k];
+            int q = k + 1;
+            if (x.left) {
+                const int pf = x.pstart;
+                while (q < st.nstrand) {
+                    const SqStrand y = s_str[q];
+                    if (y.start > pf || (y.left && y.pstart > pf)) break;
+                    q++;
+                }
+            }
+            s_skip[k] = (uint16_t)q;
+        }
+    }
     const int16_t *P = stt.P + (int64_t)st.slot * stt.stride;
     const int16_t *U = stt.U + (int64_t)st.slot * stt.stride;
     const int16_t *SU = stt.SU + (int64_t)st.slot * stt.stride;
@@ -1486,9 +1506,10 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                 uint64_t levelset = 0;
                 int lo = 0, hi = st.nstrand;
                 while (lo < hi) { const int mid = (lo + hi) >> 1; if (S[mid].start <= sa) lo = mid + 1; else hi = mid; }
-                for (int k = lo; k < st.nstrand; k++) {                     // closed form of the walk :665-689
+                for (int k = lo; k < st.nstrand;) {                         // closed form of the walk :665-689
                     const SqStrand x = S[k];
                     if (x.start >= sb) break;
+                    int nk = k + 1;
                     const int pfirst = x.pstart, plast = x.pstart - (x.len - 1);
                     bool wing;
                     if (x.left) {
@@ -1499,6 +1520,7 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                             const int from = x.start > inblockend ? x.start : inblockend + 1;
                             covered += U[pfirst + 1] - U[from];
                             inblockend = pfirst;
+                            if (lds_strands) nk = s_skip[k];                // nothing inside the block can matter
                         }
                     } else {
                         wing = plast < sa;
@@ -1508,6 +1530,7 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                         if (x.level > SQ_MAXLEVELS) a.ctr->level_ovf = 1;
                         else levelset |= 1ull << (x.level - 1);
                     }
+                    k = nk;
                 }
                 const int dots = (U[sb] - U[sa + 1]) - covered;             // :670-673
                 const bool between = (SU[sb] - SU[sa + 1]) > 0;             // :675-676
