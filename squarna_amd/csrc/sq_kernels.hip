@@ -1541,12 +1541,21 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                 }
                 bool goodloopout = false; int diff2 = 0;                    // :700-711
                 {
-                    int vv = i0 - 1, ww = j0 + 1;
-                    while (vv >= 0 && i0 - vv - 1 < 5 && P[vv] == -1) vv--;
-                    while (ww < n && ww - j0 - 1 < 5 && P[ww] == -1) ww++;
-                    if (vv >= 0 && ww < n && P[vv] == ww && sq_goodloop(i0 - vv - 1, ww - j0 - 1)) {
+                    // the two outward walks over <= 5 unpaired positions (:702-707), from the prefix counts: the k
+                    // positions next to the stem are all unpaired iff the count over them is k -- ten independent
+                    // reads instead of two chains of dependent ones
+                    const int ui = U[i0], uj = U[j0 + 1];
+                    int cl = 0, cr = 0;
+#pragma unroll
+                    for (int k = 1; k <= 5; k++) {
+                        const int a1 = i0 - k, b1 = j0 + 1 + k;
+                        cl += (a1 >= 0 && ui - U[a1 >= 0 ? a1 : 0] == k) ? 1 : 0;
+                        cr += (b1 <= n && U[b1 <= n ? b1 : n] - uj == k) ? 1 : 0;
+                    }
+                    const int vv = i0 - 1 - cl, ww = j0 + 1 + cr;
+                    if (vv >= 0 && ww < n && P[vv] == ww && sq_goodloop(cl, cr)) {
                         goodloopout = true;
-                        diff2 = abs((i0 - vv - 1) - (ww - j0 - 1));
+                        diff2 = abs(cl - cr);
                     }
                 }
                 const double lb = ps->loopbonus;
