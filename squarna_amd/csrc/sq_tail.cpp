@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iterator>
+#include <chrono>
 #include <map>
+#include <unordered_map>
 #include <set>
 #include <vector>
 #include "sq_host.h"
@@ -103,13 +105,45 @@ struct Entry {
 };
 }  // namespace
 
-static void bps_of(const std::vector<HStem> &stems, BPV &out)
+static inline uint64_t mix_bp(int i, int j)
 {
+    uint64_t x = ((uint64_t)(uint32_t)i << 32) | (uint32_t)j;          // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// sorted, unique base pairs of a stem list + an order-independent hash of the set.  The stems of a structure are
+// disjoint stacks, so walking them by ascending i already yields the sorted list; anything else takes the sort.
+static uint64_t bps_of(const std::vector<HStem> &stems, BPV &out)
+{
+    static thread_local std::vector<int> order;
+    order.resize(stems.size());
+    for (size_t k = 0; k < stems.size(); k++) {                        // insertion sort by i (a handful of stems)
+        size_t q = k;
+        while (q > 0 && stems[order[q - 1]].i > stems[k].i) { order[q] = order[q - 1]; q--; }
+        order[q] = (int)k;
+    }
     out.clear();
-    for (const HStem &s : stems)
-        for (int k = 0; k < s.len; k++) out.push_back(BP(s.i + k, s.j - k));
-    std::sort(out.begin(), out.end());
-    out.erase(std::unique(out.begin(), out.end()), out.end());
+    uint64_t h = 0;
+    bool sorted = true;
+    for (int idx : order) {
+        const HStem &s = stems[idx];
+        for (int k = 0; k < s.len; k++) {
+            const BP bp(s.i + k, s.j - k);
+            if (!out.empty() && !(out.back() < bp)) sorted = false;
+            out.push_back(bp);
+            h += mix_bp(bp.first, bp.second);
+        }
+    }
+    if (!sorted) {
+        std::sort(out.begin(), out.end());
+        out.erase(std::unique(out.begin(), out.end()), out.end());
+        h = 0;
+        for (const BP &bp : out) h += mix_bp(bp.first, bp.second);
+    }
+    return h;
 }
 
 static inline size_t count_common(const BPV &a, const BPV &b)
@@ -142,7 +176,8 @@ static void score_struct(const uint8_t *codes, const double *reacts, int n, cons
         return 0.0;
     };
     double thescore = 0;
-    std::vector<char> paired(n, 0);
+    static thread_local std::vector<char> paired;
+    paired.assign(n, 0);
     for (const HStem &s : stems) {
         double bpsum = 0;
         for (int k = 0; k < s.len; k++) {
@@ -182,25 +217,41 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
     const uint8_t *codes = b->codes.data() + off;
     const double *reacts = b->reacts.data() + off;
 
+#ifdef SQ_TAIL_PROF
+    auto nowus = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tp0 = nowus();
+#endif
     // :1201-1220 dedupe across paramsets; the first producer scores the structure
     std::vector<Entry> fins;
-    std::map<BPV, int> seen;
+    std::unordered_map<uint64_t, int> seen;                            // hash of the bp set -> first entry with it
+    std::vector<int> chain;                                            // next entry with the same hash (-1: none)
     BPV key;
     for (size_t k = 0; k < per_job.size(); k++) {
         for (const auto &stems : *per_job[k]) {
-            bps_of(stems, key);
-            auto it = seen.find(key);
-            if (it == seen.end()) {
+            const uint64_t h = bps_of(stems, key);
+            int found = -1, last = -1;
+            auto it = seen.find(h);
+            if (it != seen.end())
+                for (int e = it->second; e >= 0; e = chain[e]) {
+                    last = e;
+                    if (fins[e].bps == key) { found = e; break; }
+                }
+            if (found < 0) {
                 Entry e;
                 e.stems = stems; e.bps = key; e.mask = 1ull << k;
                 score_struct(codes, reacts, n, stems, e.scores);
-                seen.emplace(key, (int)fins.size());
+                if (last < 0) seen.emplace(h, (int)fins.size());
+                else chain[last] = (int)fins.size();
+                chain.push_back(-1);
                 fins.push_back(std::move(e));
             } else {
-                fins[it->second].mask |= 1ull << k;
+                fins[found].mask |= 1ull << k;
             }
         }
     }
+#ifdef SQ_TAIL_PROF
+    const double tp1 = nowus();
+#endif
     // RankStructs (:902-955)
     auto keyless = [&](const Entry &x, const Entry &y) {               // true when x sorts before y (descending)
         for (int t = 0; t < 3; t++) {
@@ -242,6 +293,9 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
         }
         std::sort(forced.begin(), forced.end());
     }
+#ifdef SQ_TAIL_PROF
+    const double tp2 = nowus();
+#endif
     res.preds.clear();
     res.preds.reserve(fins.size());
     for (const Entry &e : fins) {                                      // :1232-1234
@@ -252,6 +306,10 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
         for (int t = 0; t < 3; t++) p.scores[t] = e.scores[t];
         p.pset_mask = e.mask;
     }
+#ifdef SQ_TAIL_PROF
+    const double tp3 = nowus();
+    if (fins.size() > 100) fprintf(stderr, "[sq_tail] seq %d n=%d: %zu structures: dedupe+score %.0f us, rank %.0f us, levels %.0f us\n", seq, n, fins.size(), tp1 - tp0, tp2 - tp1, tp3 - tp2);
+#endif
     BPV cons;                                                          // :845-858,1236
     const size_t top = std::min<size_t>(fins.size(), (size_t)std::max(o.conslim, 0));
     if (top) {
