@@ -12,6 +12,7 @@ struct SqDevCtx {
     const int16_t *chain;    // chain ordinal (interchainonly, :264-271)
     const uint8_t *e0c;      // restraint mask code: 0 free, k+1 = k-th restraint bp (v,w) of the sequence (:438-443)
     const double *reacts;
+    const uint8_t *ridx;     // per position: index of its reactivity among the sequence's distinct values (SqJob::react_levels)
     float *mat32;            // fp32 scan-matrix arena
     double *mat64;           // dense fp64 arena (external / weighted matrices only)
     const double *sdftab;    // pow tables

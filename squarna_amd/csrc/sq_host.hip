@@ -114,7 +114,7 @@ static inline bool want_fp32(const sq_batch_desc *d)
 
 namespace {
 struct Layout {
-    size_t off_codes, off_flags, off_inc4, off_chain, off_e0, off_reacts, off_jobs, off_psets, off_sdf;
+    size_t off_codes, off_flags, off_inc4, off_chain, off_e0, off_reacts, off_ridx, off_jobs, off_psets, off_sdf;
     size_t off_mat32, off_mat64, off_structs, off_strands, off_state, off_cnt, off_ctr, off_cands, off_out;
     size_t off_bits, off_rbpk, off_fb;
     size_t total;
@@ -170,7 +170,7 @@ int plan(const sq_batch_desc *d, Layout &L)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     L.off_codes = take(L.ltot); L.off_flags = take(L.ltot); L.off_inc4 = take(L.ltot);
-    L.off_chain = take(L.ltot * 2); L.off_e0 = take(L.ltot * 2); L.off_reacts = take(L.ltot * 8);
+    L.off_chain = take(L.ltot * 2); L.off_e0 = take(L.ltot * 2); L.off_reacts = take(L.ltot * 8); L.off_ridx = take(L.ltot);
     L.off_jobs = take(sizeof(SqJob) * d->njobs); L.off_psets = take(sizeof(SqPsetDev) * d->npset);
     L.off_sdf = take(8 * (size_t)std::max<int64_t>(L.sdf_len, 1));
     L.off_mat32 = take(4 * (size_t)L.mat32_floats);
@@ -295,6 +295,22 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
             for (int k = 0; k < x.sdf_len; k++) sdf.push_back(pow(1.0 / (1.0 + (double)k), ps.distcoef));   // :726
         }
     }
+    // reactivity levels: encoded reactivities (3 / 10 / 26 symbols) take few distinct values per sequence; with <= 16
+    // of them the reactfactor of a cell is a table lookup instead of an fp64 sqrt (and division) per cell and round
+    std::vector<uint8_t> ridx(L.ltot, 0);
+    std::vector<int32_t> seq_levels(d->nseq, 0);
+    for (int s = 0; s < d->nseq; s++) {
+        const int off = d->seq_off[s], n = d->seq_off[s + 1] - off;
+        double vals[16]; int nv = 0; bool fits = true;
+        for (int i = 0; i < n && fits; i++) {
+            const double r = d->reacts[off + i];
+            int q = 0;
+            while (q < nv && !(vals[q] == r)) q++;
+            if (q == nv) { if (nv == 16 || r != r) { fits = false; break; } vals[nv++] = r; }
+            ridx[off + i] = (uint8_t)q;
+        }
+        seq_levels[s] = fits ? nv : 0;
+    }
     // ---- jobs ----
     b->jobs.resize(d->njobs);
     int64_t m32 = 0, m64 = 0, mbits = 0;
@@ -320,6 +336,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         bool def = true;                                  // SQRNdbnseq.py:273
         for (int i = 0; i < J.n; i++) if (d->reacts[J.pos_off + i] != 0.5) { def = false; break; }
         J.default_reacts = def ? 1 : 0;
+        J.react_levels = def ? 0 : seq_levels[s];
         J.interchainonly = d->interchainonly;
         {
             const double ml = std::max(1.0, std::ceil(d->psets[J.pset].minlen));
@@ -351,7 +368,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     // ---- device carve + uploads ----
     b->ctx.codes = (uint8_t *)(base + L.off_codes); b->ctx.flags = (uint8_t *)(base + L.off_flags);
     b->ctx.inc4 = (uint8_t *)(base + L.off_inc4); b->ctx.chain = (int16_t *)(base + L.off_chain);
-    b->ctx.e0c = (uint8_t *)(base + L.off_e0); b->ctx.reacts = (double *)(base + L.off_reacts);
+    b->ctx.e0c = (uint8_t *)(base + L.off_e0); b->ctx.reacts = (double *)(base + L.off_reacts); b->ctx.ridx = (uint8_t *)(base + L.off_ridx);
     b->ctx.jobs = (SqJob *)(base + L.off_jobs); b->ctx.psets = (SqPsetDev *)(base + L.off_psets);
     b->ctx.sdftab = (double *)(base + L.off_sdf);
     b->ctx.mat32 = (float *)(base + L.off_mat32); b->ctx.mat64 = (double *)(base + L.off_mat64);
@@ -374,6 +391,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     UP(b->ctx.codes, b->codes.data(), L.ltot); UP(b->ctx.flags, b->flags.data(), L.ltot);
     UP(b->ctx.inc4, inc4.data(), L.ltot); UP(b->ctx.chain, chain.data(), L.ltot * 2);
     UP(b->ctx.e0c, e0.data(), L.ltot); UP(b->ctx.reacts, b->reacts.data(), L.ltot * 8);
+    UP(b->ctx.ridx, ridx.data(), L.ltot);
     UP(b->ctx.jobs, b->jobs.data(), sizeof(SqJob) * d->njobs);
     UP(b->ctx.psets, pd.data(), sizeof(SqPsetDev) * d->npset);
     if (!sdf.empty()) UP(b->ctx.sdftab, sdf.data(), 8 * sdf.size());

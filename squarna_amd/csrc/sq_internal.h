@@ -25,6 +25,8 @@ struct SqJob {
     int32_t nw;         // word-rows: ceil(N / 32); bit b of word (w, s) <-> cell (32w + b, s - 32w - b)
     int32_t rb_off;     // into the packed restraint pair list
     int32_t ext_add;    // has_ext == 2: the dense term is ADDED to the score (bpp < 0) instead of multiplied
+    int32_t react_levels;  // 1..16: the reactivities take that many distinct values (level index per position in
+                           // SqDevCtx::ridx): reactfactors come from a level x level table; 0: computed per cell
 };
 
 // Device image of a paramset (+ host-built pow tables so every pow() is the host libm's).

@@ -1318,12 +1318,35 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     }
     const bool lds_cells = jb.mat64_off < 0 && lds_n >= n;
     const bool lds_reacts = lds_cells && !jb.default_reacts && lds_n_reacts >= n;
+    // few distinct reactivity values (encoded input): reactfactor[level_i][level_j] tables, built once per block with
+    // the very expressions of the per-cell path, and a level index per position in place of the fp64 reactivities
+    const bool react_tab = lds_reacts && jb.react_levels > 0;
+    __shared__ double s_rv[16], s_rf0[256], s_rf1[256];
+    uint8_t *l_ridx = reinterpret_cast<uint8_t *>(l_reacts);
     if (lds_cells) {
         for (int p = tid; p < n; p += nthr) l_codes[p] = c.codes[jb.pos_off + p];
         for (int p = tid; p < 32 * 32; p += nthr) s_w[p] = ps->w[p];
-        if (lds_reacts) for (int p = tid; p < n; p += nthr) l_reacts[p] = c.reacts[jb.pos_off + p];
+        if (react_tab) {
+            for (int p = tid; p < n; p += nthr) {
+                const uint8_t q = c.ridx[jb.pos_off + p];
+                l_ridx[p] = q;
+                s_rv[q] = c.reacts[jb.pos_off + p];                     // (all writers of a level store the same value)
+            }
+        } else if (lds_reacts) for (int p = tid; p < n; p += nthr) l_reacts[p] = c.reacts[jb.pos_off + p];
     }
     __syncthreads();
+    if (react_tab) {
+        for (int e = tid; e < 256; e += nthr) {
+            const int qa = e >> 4, qb = e & 15;
+            double rf = 1.0, inv = 1.0;
+            if (qa < jb.react_levels && qb < jb.react_levels) {
+                rf = sqrt((1.0 - (s_rv[qa] + s_rv[qb]) / 2.0) * 2.0);
+                inv = 1.0 / (rf > 0.01 ? rf : 0.01);
+            }
+            s_rf0[e] = rf; s_rf1[e] = inv;
+        }
+        __syncthreads();
+    }
     const uint8_t *codes = c.codes + jb.pos_off;
     const SqKey *keys = sq_keys(a, st);
     SqOk *oks = sq_oks(a, st, jb.cand_cap);
@@ -1334,6 +1357,10 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
         if (!lds_cells) return sq_cell_exact(c, jb, ps, i, j);
         const double w = s_w[l_codes[i] * 32 + l_codes[j]];             // same expression as sq_cell_score
         if (jb.default_reacts) return w;                                // (no fp64 division for the w <= 0 cells)
+        if (react_tab) {
+            const int e = l_ridx[i] * 16 + l_ridx[j];
+            return w * (w <= 0 ? s_rf1[e] : s_rf0[e]);
+        }
         const double ri = lds_reacts ? l_reacts[i] : c.reacts[jb.pos_off + i];
         const double rj = lds_reacts ? l_reacts[j] : c.reacts[jb.pos_off + j];
         double rf = sqrt((1.0 - (ri + rj) / 2.0) * 2.0);
