@@ -17,6 +17,8 @@ def make(nseq, seed):
         reacts = None
         if k % 5 == 0:
             reacts = [float(x) for x in np.round(rng.random(n), 3)]
+        if k % 10 == 0:                                  # few distinct values (encoded reactivities): the table path
+            reacts = [float(x) for x in rng.choice([0.0, 0.1, 0.35, 0.5, 0.8, 1.0], n)]
         restr = None
         if k % 7 == 0:
             r = ["."] * n
