@@ -1,5 +1,6 @@
 #!/bin/bash
-# first-round duration of sq_score_kernel for compile-time ablations: bash tools/score_ablate.sh "DEFS1" "DEFS2" ...
+# first-round duration of sq_score_kernel under compile-time variants (e.g. "-DSQ_SCORE_WAVES=4", "-DSQ_SCORE_CHUNK=2"):
+# bash tools/score_ablate.sh "DEFS1" "DEFS2" ...   (rocprofv3 kernel trace of tools/s1000_probe.py per variant)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for defs in "$@"; do
