@@ -126,10 +126,11 @@ struct JobBuild { int n = 0; size_t ncell = 0, need = 0, nout = 0; };
 static char *stage_buffer(sq_batch *b, int slot, size_t bytes)
 {
     if (b->stage_cap[slot] < bytes) {
-        if (b->stage_buf[slot]) { hipStreamSynchronize(slot < 3 && b->side[slot] ? b->side[slot] : b->stream); hipHostFree(b->stage_buf[slot]); }
+        if (b->stage_buf[slot]) { hipStreamSynchronize(slot < 3 && b->side[slot] ? b->side[slot] : b->stream); sq_pinned_put(b->stage_buf[slot]); }
         b->stage_buf[slot] = nullptr; b->stage_cap[slot] = 0;
         const size_t cap = bytes + bytes / 2 + 4096;
-        if (sq_check(hipHostMalloc((void **)&b->stage_buf[slot], cap, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc")) return nullptr;
+        if (sq_pinned_get((void **)&b->stage_buf[slot], cap)) return nullptr;
+        memset(b->stage_buf[slot], 0, cap);               // (a cached buffer may hold completion flags of an earlier batch)
         b->stage_cap[slot] = cap;
     }
     return b->stage_buf[slot];

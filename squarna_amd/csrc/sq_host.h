@@ -158,6 +158,10 @@ struct sq_batch {
 };
 
 void sq_set_error(const std::string &msg);
+// pinned (mapped, coherent) host buffers from a small process-wide cache: hipHostMalloc / hipHostFree cost milliseconds,
+// and a caller that builds one batch per call (Predict) would pay them every time
+int sq_pinned_get(void **p, size_t bytes);     // 0 or an error code (message set)
+void sq_pinned_put(void *p);                   // the streams that used the buffer must be idle
 int sq_check(hipError_t e, const char *what);
 // profiling bracket on an arbitrary stream (slot k of sq_profile_get); no-ops unless profiling is enabled
 void sq_prof_begin(sq_batch *b, int k, hipStream_t st, hipEvent_t *e0);

@@ -10,6 +10,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <unordered_map>
 #include "sq_host.h"
 
 static thread_local std::string g_err;
@@ -86,6 +87,56 @@ SqPool *sq_pool(sq_batch *b)
         b->pool = new SqPool(nthr);
     }
     return b->pool;
+}
+
+// ---- pinned buffer cache --------------------------------------------------------------------------
+namespace {
+struct PinnedCache {
+    std::mutex mu;
+    std::vector<std::pair<size_t, void *>> idle;       // (capacity, pointer)
+    std::unordered_map<void *, size_t> live;
+    size_t idle_bytes = 0;
+} g_pinned;
+}
+int sq_pinned_get(void **p, size_t bytes)
+{
+    const size_t want = (std::max<size_t>(bytes, 1) + 4095) & ~(size_t)4095;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned.mu);
+        int best = -1;
+        for (size_t k = 0; k < g_pinned.idle.size(); k++) {
+            const size_t cap = g_pinned.idle[k].first;
+            if (cap >= want && cap <= 2 * want + 65536 && (best < 0 || cap < g_pinned.idle[best].first)) best = (int)k;
+        }
+        if (best >= 0) {
+            *p = g_pinned.idle[best].second;
+            g_pinned.live[*p] = g_pinned.idle[best].first;
+            g_pinned.idle_bytes -= g_pinned.idle[best].first;
+            g_pinned.idle.erase(g_pinned.idle.begin() + best);
+            return 0;
+        }
+    }
+    const int r = sq_check(hipHostMalloc(p, want, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc");
+    if (r) { *p = nullptr; return r; }
+    std::lock_guard<std::mutex> lk(g_pinned.mu);
+    g_pinned.live[*p] = want;
+    return 0;
+}
+void sq_pinned_put(void *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned.mu);
+        auto it = g_pinned.live.find(p);
+        const size_t cap = it == g_pinned.live.end() ? 0 : it->second;
+        if (it != g_pinned.live.end()) g_pinned.live.erase(it);
+        if (cap && g_pinned.idle.size() < 64 && g_pinned.idle_bytes + cap <= ((size_t)512 << 20)) {
+            g_pinned.idle.emplace_back(cap, p);
+            g_pinned.idle_bytes += cap;
+            return;
+        }
+    }
+    hipHostFree(p);
 }
 
 extern "C" int sq_version(void) { return 100; }
@@ -409,15 +460,18 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     }
 #undef UP
     // pinned staging
-    if (sq_check(hipHostMalloc((void **)&b->h_structs, sizeof(SqStruct) * L.max_structs, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc") ||
-        sq_check(hipHostMalloc((void **)&b->h_strands, sizeof(SqStrand) * (size_t)L.strand_cap, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc") ||
-        sq_check(hipHostMalloc((void **)&b->h_ctr, sizeof(SqCounters), hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc") ||
-        sq_check(hipHostMalloc((void **)&b->h_seq, 64, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc")) { delete b; return 2; }
+    if (sq_pinned_get((void **)&b->h_structs, sizeof(SqStruct) * L.max_structs) ||
+        sq_pinned_get((void **)&b->h_strands, sizeof(SqStrand) * (size_t)L.strand_cap) ||
+        sq_pinned_get((void **)&b->h_ctr, sizeof(SqCounters)) ||
+        sq_pinned_get((void **)&b->h_seq, 64)) { delete b; return 2; }
     *b->h_seq = 0; b->round_seq = 0;
     b->h_out_cap = (uint32_t)std::min<uint64_t>(1u << 18, L.out_cap);
-    if (sq_check(hipHostMalloc((void **)&b->h_out, sizeof(SqOut) * (size_t)b->h_out_cap, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc") ||
-        sq_check(hipHostMalloc((void **)&b->h_ctr2, sizeof(SqCounters), hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc") ||
-        sq_check(hipHostMalloc((void **)&b->h_seq2, 64, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc")) { delete b; return 2; }
+    if (sq_pinned_get((void **)&b->h_out, sizeof(SqOut) * (size_t)b->h_out_cap) ||
+        sq_pinned_get((void **)&b->h_ctr2, sizeof(SqCounters)) ||
+        sq_pinned_get((void **)&b->h_seq2, 64)) { delete b; return 2; }
+    // (cached buffers come back with their old contents: the completion words must not look like a finished round)
+    memset(b->h_ctr, 0, sizeof(SqCounters)); memset(b->h_ctr2, 0, sizeof(SqCounters));
+    memset(b->h_seq, 0, 64); memset(b->h_seq2, 0, 64);
     *b->h_seq2 = 0;
     {   // the lane that spans all round buffers, and its two halves
         SqLane &F = b->lane_full;
@@ -449,18 +503,13 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
 extern "C" void sq_batch_destroy(sq_batch *b)
 {
     if (!b) return;
-    if (b->stream || true) hipStreamSynchronize(b->stream);
-    if (b->h_structs) hipHostFree(b->h_structs);
-    if (b->h_strands) hipHostFree(b->h_strands);
-    if (b->h_ctr) hipHostFree(b->h_ctr);
-    if (b->h_seq) hipHostFree(b->h_seq);
-    if (b->h_ctr2) hipHostFree(b->h_ctr2);
-    if (b->h_seq2) hipHostFree(b->h_seq2);
-    delete b->pool;
-    for (int k = 0; k < 4; k++) if (b->stage_buf[k]) hipHostFree(b->stage_buf[k]);
-    if (b->h_out) hipHostFree(b->h_out);
+    hipStreamSynchronize(b->stream);
     for (int k = 0; k < 3; k++) if (b->side[k]) { hipStreamSynchronize(b->side[k]); hipStreamDestroy(b->side[k]); }
     if (b->lane_stream) { hipStreamSynchronize(b->lane_stream); hipStreamDestroy(b->lane_stream); }
+    sq_pinned_put(b->h_structs); sq_pinned_put(b->h_strands); sq_pinned_put(b->h_ctr); sq_pinned_put(b->h_seq);
+    sq_pinned_put(b->h_ctr2); sq_pinned_put(b->h_seq2); sq_pinned_put(b->h_out);
+    for (int k = 0; k < 4; k++) sq_pinned_put(b->stage_buf[k]);
+    delete b->pool;
     if (b->lane_ev) hipEventDestroy(b->lane_ev);
     for (auto &p : b->prof) {
         for (auto &e : p.pending) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
