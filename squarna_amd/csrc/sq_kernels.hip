@@ -750,7 +750,9 @@ extern "C" __global__ __launch_bounds__(64, SQ_WPS) void sq_scan_kernel(SqDevCtx
 #endif
 #define SQ5_TAIL 4                                    // extra rows read past the segment
 #define SQ5_ROWS (SQ5_SEG + SQ5_TAIL)                 // 128 = 4 chunks of 32 (must be a multiple of 32)
+#ifndef SQ5_STAGE
 #define SQ5_STAGE 256
+#endif
 #ifndef SQ5_G
 #define SQ5_G 4                                      // rows per load group (two groups in flight)
 #endif
