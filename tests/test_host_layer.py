@@ -106,3 +106,29 @@ def test_c_abi_exports_every_declared_symbol():
     assert not missing, missing
     assert set(_lib.SYMBOLS) == declared
     assert L.sq_version() >= 100
+
+
+def test_string_and_pair_helpers_match_reference_goldens():
+    """PairsToDBN (incl. levellimit / returnlevels), DBNToPairs, UnAlign, ReAlign, PairsToStems of the host layer
+    against values the reference returned (tests/golden/gen_helpers_golden.py)."""
+    import json
+    import os
+    from squarna_amd.dbn import DBNToPairs, PairsToDBN, PairsToStems, ReAlign, UnAlign
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "helpers.json")) as f:
+        g = json.load(f)
+    for c in g["pairs_to_dbn"]:
+        pairs = [tuple(p) for p in c["pairs"]]
+        assert PairsToDBN(list(pairs), c["length"], levellimit=c["levellimit"]) == c["dbn"], c
+        lev = PairsToDBN(list(pairs), c["length"], returnlevels=True)
+        assert sorted([v, w, l] for (v, w), l in lev.items()) == c["levels"], c
+    for c in g["pairs_to_stems"]:
+        got = PairsToStems([tuple(p) for p in c["pairs"]])
+        assert [[[list(bp) for bp in st[0]], st[1]] for st in got] == c["stems"], c
+    for c in g["dbn_to_pairs"]:
+        assert [list(p) for p in DBNToPairs(c["dbn"])] == c["pairs"], c
+    for c in g["unalign"]:
+        assert list(UnAlign(c["seq"], c["dbn"])) == c["out"], c
+    for c in g["realign"]:
+        assert ReAlign(c["shortdbn"], c["longseq"]) == c["out"], c
+        short_seq = UnAlign(c["longseq"], "." * len(c["longseq"]))[0]
+        assert ReAlign(short_seq, c["longseq"], seqmode=True) == c["out_seqmode"], c
