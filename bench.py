@@ -243,7 +243,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64 (scores and decisions; the scan itself works on 1-bit cell activity)",
+        "dtype": "f64",
+        "dtype_note": "scores and every decision in fp64, in the reference's operation order; the scan itself works on 1-bit cell activity",
         "data": "SRtest150.fas shipped with the reference (219 records, 8-150 nt, reference dbn per record)",
         "config": {"workload": "SRtest150 if=qf c=%s poollim=1000, one batch of 219 records per GPU" % args.config,
                    "seqs_per_gpu_per_step": len(prepared), "paramsets": names,
