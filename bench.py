@@ -117,6 +117,7 @@ def roofline_leg(nseq, n, seed=1000):
             traffic = json.load(f).get("sq_scan6_kernel_bytes_per_launch")
     return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                traffic_GBs=(round(traffic / (ms / max(launches, 1) * 1e-3) / 1e9, 1) if traffic and ms > 0 else None),   # measured HBM bytes / launch time
                 kernel="sq_scan6_kernel",
                 note="achieved = the reference algorithm's bytes (fp32 upper triangle per AnnotateStems evaluation, SURVEY 8d) / "
                      "kernel time; the kernel reads a 1-bit-per-cell diagonal bit matrix instead, so frac > 1 = re-reads avoided; "
