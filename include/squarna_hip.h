@@ -53,7 +53,8 @@ extern "C" {
 typedef struct sq_paramset {
     double bpweight[SQ_ALPHABET * SQ_ALPHABET]; /* weight of pair (a,b), both orientations filled (SQRNdbnseq.py:282-284) */
     uint8_t inbps[SQ_ALPHABET * SQ_ALPHABET];   /* 1 iff the pair is a key of bpweights (either orientation)          */
-    double bpp;                /* must be 0 (ViennaRNA branch SQRNdbnseq.py:341-364 not built; rejected)  */
+    double bpp;                /* != 0: the batch must carry the job's probability term in sq_batch_desc.bpp_term
+                                  (computed by the caller from ViennaRNA, SQRNdbnseq.py:341-364); the fill applies it */
     double suboptmax, suboptmin, suboptsteps;
     double minlen, minbpscore, minfinscorefactor;
     double bracketweight, distcoef, orderpenalty, loopbonus;
@@ -164,6 +165,38 @@ SQ_API int sq_optimal_stems(sq_batch *b, int32_t nstruct, const int32_t *struct_
  * (bpscore = finscore = raw stem score).  Synchronises the stream. */
 SQ_API int sq_run_algos(sq_batch *b, int32_t njob, const int32_t *job_ids, int32_t algo, int32_t levellimit,
                         sq_stem *out, int32_t out_cap, int32_t *out_off);
+
+/* ---- a-8 / a-9 at graph level: the reference's SQRNalgos.Hungarian / Edmonds / Nussinov called on their own -----
+ * (a maintainer patches `Edmonds(stems)` etc. one for one).  No batch: the inputs are plain host
+ * arrays, the results come back in host arrays, `dev_workspace` is caller-owned DEVICE scratch of at least
+ * sq_*_workspace_bytes() bytes (256-byte aligned), work is enqueued on hip_stream and the call synchronises it.
+ *
+ * sq_mwm -- Edmonds (SQRNalgos.py:96-110): networkx.max_weight_matching (3.4.2, maxcardinality=False) of `ngraph`
+ * graphs given as weighted edge lists; graph g owns edges [edge_off[g], edge_off[g+1]) of (eu, ev, ew).  Vertex
+ * labels are arbitrary non-negative ints (sequence positions in the reference).  As in networkx: nodes are ordered
+ * by first appearance, a repeated edge keeps its first position and takes the last weight.  pairs[2k], pairs[2k+1]:
+ * graph g's matched pairs are k in [pair_off[g], pair_off[g+1]), each oriented (u, v) as networkx returns it and
+ * sorted as Edmonds() sorts them (:109); ties between optimal matchings resolve as in networkx (step-exact). */
+SQ_API int sq_mwm_workspace_bytes(int32_t ngraph, const int64_t *edge_off, const int32_t *eu, const int32_t *ev,
+                                  size_t *bytes);
+SQ_API int sq_mwm(int32_t ngraph, const int64_t *edge_off, const int32_t *eu, const int32_t *ev, const double *ew,
+                  int32_t *pairs, int64_t pair_cap, int64_t *pair_off, void *dev_workspace, size_t workspace_bytes,
+                  void *hip_stream);
+/* sq_lsap -- the assignment step of Hungarian (SQRNalgos.py:119-127): scipy.optimize.linear_sum_assignment(mat)
+ * (1.15.3) for `nprob` symmetric n[g] x n[g] matrices that are zero except mat[cv, cw] = mat[cw, cv] = -weight for
+ * the listed cells (a repeated cell takes the last weight).  col4row: concatenated, n[g] ints per problem --
+ * col4row[r] is the column assigned to row r, the `col_ind` scipy returns (ties resolve as in scipy). */
+SQ_API int sq_lsap_workspace_bytes(int32_t nprob, const int32_t *n, const int64_t *cell_off, size_t *bytes);
+SQ_API int sq_lsap(int32_t nprob, const int32_t *n, const int64_t *cell_off, const int32_t *cv, const int32_t *cw,
+                   const double *weight, int32_t *col4row, void *dev_workspace, size_t workspace_bytes,
+                   void *hip_stream);
+/* sq_nussinov -- Nussinov + BackTrack (SQRNalgos.py:6-93, minloop = 3) for `nprob` sequences: SCORES[(cv, cw)] =
+ * -score for the listed cells (cv < cw); codes: the sequences' letter codes, concatenated (n[g] each; only the
+ * separators SQ_CODE_SEP1/2 matter).  pairs / pair_off as for sq_mwm, each problem's pairs sorted (:41). */
+SQ_API int sq_nussinov_workspace_bytes(int32_t nprob, const int32_t *n, const int64_t *cell_off, size_t *bytes);
+SQ_API int sq_nussinov(int32_t nprob, const int32_t *n, const uint8_t *codes, const int64_t *cell_off,
+                       const int32_t *cv, const int32_t *cw, const double *score, int32_t *pairs, int64_t pair_cap,
+                       int64_t *pair_off, void *dev_workspace, size_t workspace_bytes, void *hip_stream);
 
 /* ---- a-7 + a-10  greedy pool loop and the ranking tail of SQRNdbnseq ---------------
  * (SQRNdbnseq.py:1048-1286).  Folds every sequence of the batch under its jobs and

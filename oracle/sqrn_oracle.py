@@ -179,6 +179,28 @@ def stem_bps(st):
 BPP_SOURCE = None
 
 
+def ViennaBPP(seq, reacts, M=1.8, B=-0.6):
+    """dbnseq:342-364: the calls the reference makes into ViennaRNA's Python module `RNA` (third party, absent from
+    this image), restated as a BPP_SOURCE: fold_compound on the sequence with separators / non-ASCII letters
+    replaced by N (:343-344), SHAPE pseudo-energies unless the reactivities are the default (:345-347), pf + bpp
+    (:348-349), and ONE retry after exp_params_rescale(mfe) when every probability is zero (:355-359).
+    Returns the N x N matrix (row/column 0 of ViennaRNA's 1-based table dropped) or None when it is still all zero.
+    Pinned against the real reference running on tests/fake_rna.py (tests/golden/gen_bpp_golden.py)."""
+    import RNA
+    fc = RNA.fold_compound(''.join([ch if ch not in SEPS and ord(ch) <= 127 else 'N' for ch in seq]))
+    if not (reacts is None or set(reacts) == {0.5}):                    # dbnseq:273
+        fc.sc_add_SHAPE_deigan(ProcessReacts(list(reacts), reverse=True, M=M, B=B), m=M, b=B)
+    fc.pf()
+    bppm = np.array(fc.bpp())[1:, 1:]
+    if np.max(bppm) > 0:
+        return bppm
+    (ss, mfe) = fc.mfe()
+    fc.exp_params_rescale(mfe)
+    fc.pf()
+    bppm = np.array(fc.bpp())[1:, 1:]
+    return bppm if np.max(bppm) > 0 else None
+
+
 def BPMatrix(seq, weights, rxs, rlefts, rrights, interchainonly=False, reacts=None,
              bpp_power=0, M=1.8, B=-0.6):
     """dbnseq:258-367 (bpp_power != 0 needs BPP_SOURCE)."""

@@ -5,8 +5,8 @@ Drop-in for the single-sequence hot path of febos/SQUARNA:
 """
 from .config import ParseConfig  # noqa: F401
 from .api import Predict, Main  # noqa: F401
-from .core import (BPMatrix, AnnotateStems, OptimalStems, SQRNdbnseq, RunSQRNdbnseq,  # noqa: F401
-                   ScoreStruct, ReferenceScores)
+from .core import (BPMatrix, AnnotateStems, OptimalStems, RunAlgo, Edmonds, Hungarian, Nussinov,  # noqa: F401
+                   SQRNdbnseq, RunSQRNdbnseq, ScoreStruct, ReferenceScores)
 
 
 def BuildRfam(*args, **kwargs):
@@ -15,5 +15,5 @@ def BuildRfam(*args, **kwargs):
     raise NotImplementedError("BuildRfam is out of scope of squarna_amd (see DESIGN.md)")
 
 
-__all__ = ["Predict", "Main", "BuildRfam", "ParseConfig", "BPMatrix", "AnnotateStems", "OptimalStems",
-           "SQRNdbnseq", "RunSQRNdbnseq"]
+__all__ = ["Predict", "Main", "BuildRfam", "ParseConfig", "BPMatrix", "AnnotateStems", "OptimalStems", "RunAlgo",
+           "Edmonds", "Hungarian", "Nussinov", "SQRNdbnseq", "RunSQRNdbnseq"]

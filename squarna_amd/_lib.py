@@ -19,7 +19,9 @@ SYMBOLS = ["sq_version", "sq_last_error", "sq_batch_workspace_bytes", "sq_batch_
            "sq_fold", "sq_result_nstruct", "sq_result_consensus", "sq_result_struct",
            "sq_result_metrics", "sq_result_evals", "sq_result_pack_size", "sq_result_pack",
            "sq_profile_enable", "sq_profile_get", "sq_profile_reset", "sq_run_algos",
-           "sq_align_accumulate", "sq_colmatrix_select", "sq_fold_concurrent"]
+           "sq_align_accumulate", "sq_colmatrix_select", "sq_fold_concurrent",
+           "sq_mwm_workspace_bytes", "sq_mwm", "sq_lsap_workspace_bytes", "sq_lsap",
+           "sq_nussinov_workspace_bytes", "sq_nussinov"]
 
 BATCH_NO_FP32 = 1
 
@@ -111,6 +113,15 @@ def load():
     L.sq_align_accumulate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.sq_colmatrix_select.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_void_p]
+    L.sq_mwm_workspace_bytes.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.sq_mwm.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                         C.c_void_p, C.c_size_t, C.c_void_p]
+    L.sq_lsap_workspace_bytes.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.sq_lsap.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                          C.c_void_p, C.c_size_t, C.c_void_p]
+    L.sq_nussinov_workspace_bytes.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.sq_nussinov.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     _lib = L
     return L
 

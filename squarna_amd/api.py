@@ -31,7 +31,8 @@ def Predict(inputfile=None, fileformat="unknown", inputseq=None, configfile=None
             i=None, ff=None, c=None, config=None, s=None, seq=None, a=None, ali=None, algo=None,
             algorithm=None, rb=None, fl=None, freqlim=None, ll=None, levlim=None, tl=None, ol=None,
             cl=None, pl=None, pr=None, s3=None, msn=None, rf=None, eo=None, hr=None, ico=None, iw=None,
-            ignore=None, t=None, bs=None, v=None, inputrestr=None, _select=None, _on_block=None):
+            ignore=None, t=None, bs=None, v=None, inputrestr=None, _select=None, _on_block=None,
+            _lengths_only=False):
     """Print SQUARNA predictions for the given input (see SQUARNA.py:431-600 for the
     meaning of every parameter; short synonyms are accepted exactly as there)."""
     # synonyms, later ones win as in SQUARNA.py:602-664
@@ -160,6 +161,8 @@ def Predict(inputfile=None, fileformat="unknown", inputseq=None, configfile=None
 
     inputs, fmt, single_input = ParseInput(inputseq, inputfile, inputformat, fmt=fileformat,
                                            ignore=ignorewarn, inputrestr=inputrestr, M=M, B=B)
+    if _lengths_only:                                            # PredictSharded: the cost model's record lengths
+        return [len(rec[1]) for rec in inputs]
     if alignment:                                                # SQUARNA.py:938-991
         from .align import RunSQRNdbnali
         from .dbn import ReactDict, ProcessReacts

@@ -42,22 +42,22 @@ def BPMatrix(seq, weights, rxs, rlefts, rrights, interchainonly=False, reacts=No
              M=1.8, B=-0.6):
     """(bpboolmatrix, bpscorematrix), dense N x N float64 -- SQRNdbnseq.py:258-367.
     Computed on the GPU in fp64 (sq_bpmatrix_read).  bpp_power != 0 takes ViennaRNA's base-pair
-    probabilities from the host (engine.vienna_bpp, i.e. `import RNA`) and applies them as the reference
-    does (SQRNdbnseq.py:350-364)."""
+    probabilities from the host (engine.vienna_bpp, i.e. `import RNA`); the term (bppm/max)**|p| is uploaded
+    with the batch and the fill kernel applies it on the device: scoremat *= term (p > 0) or += term (p < 0)
+    (SQRNdbnseq.py:350-364)."""
     n = len(seq)
     prep = _engine.Prepared(seq, list(reacts) if reacts is not None else None,
                             _restraint_line(n, rxs, rlefts, rrights))
     prep.shortseq = seq                     # BPMatrix takes the sequence as it is (already gap-free)
-    with _engine.Batch([prep], [[_pset(weights)]], interchainonly=interchainonly, fp32=False) as b:
-        boolmat, scoremat = b.bpmatrix(0)
-    if bpp_power:
-        bppm = _engine._bpp_provider(seq, list(reacts) if reacts is not None else None, M, B)
-        if bppm is not None and np.max(bppm) > 0:
-            if bpp_power < 0:
-                scoremat += (bppm / np.max(bppm)) ** (-bpp_power)
-            else:
-                scoremat *= (bppm / np.max(bppm)) ** bpp_power
-    return boolmat, scoremat
+    ps = _pset(weights, bpp=float(bpp_power))
+    term = _engine.bpp_terms([prep], [[ps]], M, B) if bpp_power else None
+    if term is None or term[0] is None:     # no probabilities (bpp == 0, or max(bppm) == 0: the matrix stays as it is)
+        ps = _pset(weights)
+        with _engine.Batch([prep], [[ps]], interchainonly=interchainonly, fp32=False) as b:
+            return b.bpmatrix(0)
+    with _engine.Batch([prep], [[ps]], interchainonly=interchainonly, bpp=term) as b:
+        b.fill()                            # forms the weighted matrix in the dense arena
+        return b.bpmatrix(0)
 
 
 def _stems_ijl(rstems):
@@ -96,6 +96,139 @@ def OptimalStems(seq, rstems, bpboolmatrix, bpscorematrix, reacts, rbps=set(), s
     with _engine.Batch([prep], [[ps]], ext=[(np.asarray(bpboolmatrix, float), np.asarray(bpscorematrix, float))]) as b:
         out = b.optimal([0], [_stems_ijl(rstems)], subopt=[subopt], mode=0)[0]
     return [_stem_record(i, j, ln, bps, fin, '') for i, j, ln, bps, fin in out]
+
+
+# ------------------------------------------------------------------ a-8 / a-9: RunAlgo and the matching functions
+def _device_workspace(nbytes):
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("squarna_amd needs an AMD GPU (MI355X / gfx950): torch.cuda is not available and there "
+                           "is no CPU fallback")
+    ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+    base = ws.data_ptr()
+    return ws, (base + 255) // 256 * 256, torch.cuda.current_stream().cuda_stream
+
+
+def _cells_of(stems, matrix, N, value):
+    """(v, w, value) triples of the reference's two input forms: stems (cells of every stem, `value(stem score)`)
+    or a matrix (upper cells > 0, `value(cell)`)."""
+    if matrix is None:
+        return [(v, w, value(st[2])) for st in stems for v, w in st[0]]
+    matrix = np.asarray(matrix)
+    n = matrix.shape[0] if N is None else N
+    return [(v, w, value(matrix[v, w])) for v in range(n - 1) for w in range(v + 1, n) if matrix[v, w] > 0]
+
+
+def Edmonds(stems, power=1.7, matrix=None):
+    """Maximum-weight matching of the stem cells -- SQRNalgos.py:96-110.  networkx.max_weight_matching restated
+    step by step on the GPU (sq_mwm): same pairs, same (u, v) orientation, same sorted order as the reference
+    returns, including which of several optimal matchings is found."""
+    from . import _lib
+    import ctypes as C
+    L = _lib.load()
+    edges = _cells_of(stems, matrix, None, lambda x: x ** power)          # weights through the host libm, as the reference
+    m = len(edges)
+    if m == 0:
+        return []
+    eu = np.array([e[0] for e in edges], np.int32)
+    ev = np.array([e[1] for e in edges], np.int32)
+    ew = np.array([e[2] for e in edges], np.float64)
+    off = np.array([0, m], np.int64)
+    nbytes = C.c_size_t(0)
+    _lib.check(L.sq_mwm_workspace_bytes(1, off.ctypes.data, eu.ctypes.data, ev.ctypes.data, C.byref(nbytes)))
+    ws, ptr, stream = _device_workspace(nbytes.value)
+    pairs = np.zeros(2 * m + 2, np.int32)
+    poff = np.zeros(2, np.int64)
+    _lib.check(L.sq_mwm(1, off.ctypes.data, eu.ctypes.data, ev.ctypes.data, ew.ctypes.data, pairs.ctypes.data, m + 1,
+                        poff.ctypes.data, C.c_void_p(ptr), C.c_size_t(nbytes.value), C.c_void_p(stream)))
+    return [(int(pairs[2 * k]), int(pairs[2 * k + 1])) for k in range(int(poff[1]))]
+
+
+def Hungarian(seq, stems, N, seps, minloop=3, power=1.7, matrix=None):
+    """Linear-sum-assignment matching of the stem cells -- SQRNalgos.py:113-135.  scipy's
+    linear_sum_assignment restated step by step on the GPU (sq_lsap); the mutual-pair filter (:130-133) is
+    O(N) host work."""
+    from . import _lib
+    import ctypes as C
+    L = _lib.load()
+    if matrix is None:
+        cells = _cells_of(stems, None, N, lambda x: x ** power)           # mat[v,w] = mat[w,v] = -(score ** power)
+    else:                                                                  # mat = -(matrix ** power)
+        mat = np.asarray(matrix, dtype=float)
+        if not np.array_equal(mat, mat.T) or np.any(np.diag(mat) != 0):
+            raise NotImplementedError("Hungarian(matrix=...): sq_lsap takes symmetric matrices with a zero diagonal")
+        cells = [(v, w, mat[v, w] ** power) for v in range(N - 1) for w in range(v + 1, N) if mat[v, w] != 0]
+    if N == 0:
+        return []
+    cv = np.array([c[0] for c in cells], np.int32)
+    cw = np.array([c[1] for c in cells], np.int32)
+    wt = np.array([c[2] for c in cells], np.float64)
+    n = np.array([N], np.int32)
+    off = np.array([0, len(cells)], np.int64)
+    nbytes = C.c_size_t(0)
+    _lib.check(L.sq_lsap_workspace_bytes(1, n.ctypes.data, off.ctypes.data, C.byref(nbytes)))
+    ws, ptr, stream = _device_workspace(nbytes.value)
+    sol = np.zeros(N, np.int32)
+    _lib.check(L.sq_lsap(1, n.ctypes.data, off.ctypes.data, cv.ctypes.data, cw.ctypes.data, wt.ctypes.data,
+                         sol.ctypes.data, C.c_void_p(ptr), C.c_size_t(nbytes.value), C.c_void_p(stream)))
+    nonzero = {(int(v), int(w)) for v, w, x in cells if -x != 0}
+    nonzero |= {(w, v) for v, w in nonzero}
+    out = []
+    for k in range(N):                                                     # :130-133
+        j = int(sol[k])
+        if j < 0 or not (k < j - minloop or (k < j and any(ch in seps for ch in seq[k + 1:j]))):
+            continue
+        if int(sol[j]) == k and (k, j) in nonzero:
+            out.append((k, j))
+    return out
+
+
+def Nussinov(seq, stems, N, seps, minloop=3, matrix=None):
+    """Nussinov DP over the stem cells + BackTrack -- SQRNalgos.py:44-93, on the GPU (sq_nussinov)."""
+    from . import _lib
+    from .dbn import encode_seq
+    import ctypes as C
+    if minloop != 3 or set(seps) != SEPS:
+        raise NotImplementedError("the device kernel is built for minloop = 3 and the separators ';' '&' "
+                                  "(the only values the reference passes, SQRNdbnseq.py:565)")
+    L = _lib.load()
+    cells = _cells_of(stems, matrix, N, lambda x: x)
+    if N == 0:
+        return []
+    cv = np.array([c[0] for c in cells], np.int32)
+    cw = np.array([c[1] for c in cells], np.int32)
+    sc = np.array([c[2] for c in cells], np.float64)
+    n = np.array([N], np.int32)
+    off = np.array([0, len(cells)], np.int64)
+    codes = np.frombuffer(encode_seq(seq), np.uint8)
+    assert len(codes) == N, "sequence length differs from N"
+    nbytes = C.c_size_t(0)
+    _lib.check(L.sq_nussinov_workspace_bytes(1, n.ctypes.data, off.ctypes.data, C.byref(nbytes)))
+    ws, ptr, stream = _device_workspace(nbytes.value)
+    pairs = np.zeros(2 * (N + 4), np.int32)
+    poff = np.zeros(2, np.int64)
+    _lib.check(L.sq_nussinov(1, n.ctypes.data, codes.ctypes.data, off.ctypes.data, cv.ctypes.data, cw.ctypes.data,
+                             sc.ctypes.data, pairs.ctypes.data, N + 4, poff.ctypes.data, C.c_void_p(ptr),
+                             C.c_size_t(nbytes.value), C.c_void_p(stream)))
+    return [(int(pairs[2 * k]), int(pairs[2 * k + 1])) for k in range(int(poff[1]))]
+
+
+def RunAlgo(seq, bpboolmatrix, bpscorematrix, restbps, rstems, minlen, minscore, algo="E", levellimit=3):
+    """Single-sequence prediction by Edmonds / Hungarian / Nussinov over the stems of the given matrices, with the
+    reference's stem filters -- SQRNdbnseq.py:548-595.  One call of sq_run_algos on a one-job batch that carries
+    the caller's matrices: AnnotateStems, the matching kernel and the filters all run inside the library."""
+    if rstems:
+        raise NotImplementedError("RunAlgo with pre-selected stems: the reference always passes [] (SQRNdbnseq.py:1097)")
+    if algo not in ("E", "H", "N"):
+        return []
+    n = len(seq)
+    prep = _engine.Prepared('N' * n, None, _restraint_line(n, rbps=restbps))
+    prep.shortseq = seq
+    ps = _pset({}, minlen=minlen, minbpscore=minscore, algorithms={algo})
+    with _engine.Batch([prep], [[ps]], ext=[(np.asarray(bpboolmatrix, float), np.asarray(bpscorematrix, float))],
+                       fp32=False) as b:
+        out = b.run_algo([0], algo, levellimit=levellimit)[0]
+    return [_stem_record(i, j, ln, sc, sc, '') for i, j, ln, sc, _ in out]
 
 
 # ------------------------------------------------------------------ host-side scores of a given structure

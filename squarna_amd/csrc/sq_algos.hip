@@ -163,7 +163,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
                     if (!seen[s.i + t]) { seen[s.i + t] = 1; nv++; }
                     if (!seen[s.j - t]) { seen[s.j - t] = 1; nv++; }
                 }
-            B.n = nv; B.need = sq_mwm_scratch_bytes(nv, (int)ncell); B.nout = (size_t)nv;
+            B.n = nv; B.need = sq_mwm_scratch_bytes(nv, (int)ncell); B.nout = 2 * (size_t)nv;          // mates + first-assignment ranks
         } else {
             B.n = J.n;
             B.need = algo == SQ_ALGO_H ? sq_lsap_scratch_bytes(J.n) : sq_nussinov_scratch_bytes(J.n);
@@ -264,34 +264,10 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
     hipEvent_t pe0;
     const int pslot = algo == SQ_ALGO_E ? 4 : algo == SQ_ALGO_H ? 5 : 6;
     sq_prof_begin(b, pslot, st, &pe0);
-    int maxn = 0, maxm = 0;
-    for (const SqMatchJob &m : mj) { maxn = std::max(maxn, m.n); maxm = std::max(maxm, m.nedges); }
-    if (algo == SQ_ALGO_H) {
-        // LDS: the row/column vectors and, when it fits, the cost matrix as 16-bit edge ids + the edge weights
-        size_t lds = (size_t)maxn * 42 + 64 + 16 + (size_t)maxm * 8 + (size_t)maxn * maxn * 2 + 64;
-        if (lds > 64 * 1024) {
-            static bool attr_set = false;
-            if (!attr_set) { hipFuncSetAttribute((const void *)sq_lsap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-        }
-        if (lds > 150 * 1024) lds = std::min<size_t>((size_t)maxn * 42 + 64 + 16, 150 * 1024);   // vectors only
-        hipLaunchKernelGGL(sq_lsap_kernel, dim3(nj), dim3(64), lds, st, d_jobs, d_edges, d_scr, ck.d_out, (int)lds);
-    }
-    else if (algo == SQ_ALGO_N) hipLaunchKernelGGL(sq_nussinov_kernel, dim3(nj), dim3(256), 0, st, d_jobs, d_edges, b->ctx.codes, d_scr, ck.d_out, ck.d_cnt);
-    else {
-        // dynamic LDS for the blossom state of the largest job (up to 150 KiB of the CU's 160)
-        size_t want = SqBlossom::scratch_bytes(maxn, maxm, 1) + (((size_t)maxm * sizeof(SqMatchEdge) + 15) & ~(size_t)15) + 64;
-        static bool attr_set = false;
-        if (!attr_set) { hipFuncSetAttribute((const void *)sq_mwm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-        if (want > 150 * 1024 || getenv("SQ_MWM_NOLDS")) {
-            // some job does not fit LDS and walks its edges in place: give those a device copy of the edge list
-            SqMatchEdge *dev_edges = (SqMatchEdge *)(region + o_edges);
-            HIPCK(hipMemcpyAsync(dev_edges, ck.p_edges, ck.nedges * sizeof(SqMatchEdge), hipMemcpyHostToDevice, st));
-            d_edges = dev_edges;
-        }
-        want = std::min<size_t>(want, 150 * 1024);             // jobs that do not fit run in global memory
-        if (getenv("SQ_MWM_NOLDS")) want = 0;
-        hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), want, st, d_jobs, d_edges, d_scr, ck.d_out, (int)want,
-                           ck.job_flags, ck.flag_val);
+    {
+        const int rl = sq_launch_matching(algo, mj.data(), nj, d_jobs, d_edges, ck.nedges, (SqMatchEdge *)(region + o_edges), d_scr,
+                                          ck.d_out, ck.d_cnt, b->ctx.codes, ck.job_flags, ck.flag_val, st);
+        if (rl) return sq_check((hipError_t)rl, "matching kernel launch");
     }
     sq_prof_end(b, pslot, st, pe0);
     hipLaunchKernelGGL(sq_flag_kernel, dim3(1), dim3(1), 0, st, ck.flag, ck.flag_val);   // "results are in host memory"
@@ -402,8 +378,8 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
 
 static int algo_annotate(sq_batch *b, const std::vector<int> &jobs, std::vector<std::vector<HStem>> &stems)
 {
-    for (int j : jobs)
-        if (b->jobs[j].has_ext == 1) { sq_set_error("E/H/N algorithms need the library's own score matrix"); return -4; }
+    // (jobs with caller matrices, has_ext == 1: the stem filters of RunAlgo re-sum the cells of the caller's score
+    // matrix, which algo_collect reads back from the dense arena like a weighted matrix)
     // AnnotateStems(bool, score, rbps, [], minlen, minbpscore)  (:553)
     std::vector<HStruct> hs(jobs.size());
     std::vector<SView> views(jobs.size());

@@ -90,6 +90,8 @@ struct SqBlossom {
     // state (index: vertex 0..n-1, blossom n..2n-1)
     int *mate;                // mate vertex or -1 (output)
     int *mate_de;             // directed edge v -> mate[v]
+    int *mord; int mord_n;    // mord[v]: rank of v's FIRST mate assignment == its position in networkx's `mate` dict,
+                              // which decides the orientation (u, v) of the returned pairs (matching_dict_to_set)
     int8_t *label;            // 0 none, 1 S, 2 T, 5 scanned mark
     int *labeledge, *inblossom, *parent, *base, *bestedge;
     double *dualvar, *bdual;
@@ -128,7 +130,7 @@ struct SqBlossom {
     SQ_HD static size_t cold_bytes(int n, int m, int tight)
     {
         const size_t N2 = 2 * (size_t)n + 2;
-        size_t ints = 2 * (size_t)n                              // mate, mate_de
+        size_t ints = 3 * (size_t)n                              // mate, mate_de, mord
                       + 2 * N2                                   // parent, base
                       + 8 * N2                                   // sib_next, sib_prev, edge_after, first, nchild, nleaf, mbe_off, mbe_cnt
                       + (size_t)pool_capacity(n, m, tight ? 1 : 0)   // pool
@@ -161,7 +163,7 @@ struct SqBlossom {
         // ---- cold
         if (cold) p = cold;
         bdual = take_d(N2);
-        mate = take_i(n); mate_de = take_i(n);
+        mate = take_i(n); mate_de = take_i(n); mord = take_i(n); mord_n = 0;
         parent = take_i(N2); base = take_i(N2);
         sib_next = take_i(N2); sib_prev = take_i(N2); edge_after = take_i(N2); first = take_i(N2); nchild = take_i(N2); nleaf = take_i(N2);
         mbe_off = take_i(N2); mbe_cnt = take_i(N2);
@@ -501,6 +503,8 @@ struct SqBlossom {
                 const int w = tail(f[7]), x = head(f[7]);
                 mate[w] = x; mate_de[w] = f[7];
                 mate[x] = w; mate_de[x] = f[7] ^ 1;
+                if (mord[w] < 0) mord[w] = mord_n++;
+                if (mord[x] < 0) mord[x] = mord_n++;
                 f[2] = 1;
             }
         }
@@ -515,6 +519,7 @@ struct SqBlossom {
                 const int bs = inblossom[s];
                 if (is_blossom(bs)) augmentBlossom(bs, s);
                 mate[s] = j; mate_de[s] = sj;
+                if (mord[s] < 0) mord[s] = mord_n++;
                 if (labeledge[bs] == -1) break;
                 const int t = tail(labeledge[bs]);
                 const int bt = inblossom[t];
@@ -522,6 +527,7 @@ struct SqBlossom {
                 const int s2 = tail(sj), j2 = head(sj);
                 if (is_blossom(bt)) augmentBlossom(bt, j2);
                 mate[j2] = s2; mate_de[j2] = sj ^ 1;
+                if (mord[j2] < 0) mord[j2] = mord_n++;
             }
         }
     }
@@ -553,7 +559,8 @@ struct SqBlossom {
 #define SQ_LP(p) (FAST ? (decltype(p))(fast0 + ((char *)(p) - origin)) : (p))            /* hot arrays */
 #define SQ_LQ(p) (FAST == 1 ? (decltype(p))(fast0 + ((char *)(p) - origin)) : (p))       /* cold / edge arrays */
         const int N2 = 2 * n + 2;
-        for (int v = lane; v < n; v += nl) { mate[v] = -1; mate_de[v] = -1; inblossom[v] = v; }
+        for (int v = lane; v < n; v += nl) { mate[v] = -1; mate_de[v] = -1; mord[v] = -1; inblossom[v] = v; }
+        if (lane == 0) mord_n = 0;
         for (int x = lane; x < N2; x += nl) {
             label[x] = 0; labeledge[x] = -1; parent[x] = -1; base[x] = x < n ? x : -1; bestedge[x] = -1;
             bdual[x] = 0; mbe_cnt[x] = -1; mbe_off[x] = 0; beto[x] = -1; nchild[x] = 0; first[x] = -1;

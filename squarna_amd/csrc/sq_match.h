@@ -22,6 +22,9 @@ size_t sq_nussinov_scratch_bytes(int n);
 size_t sq_mwm_scratch_bytes(int n, int nedges);
 
 #ifdef __HIPCC__
+int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatchJob *jobs, const SqMatchEdge *edges,
+                       size_t nedges, SqMatchEdge *dev_edges, char *d_scr, int32_t *out, int32_t *cnt,
+                       const uint8_t *codes, uint32_t *job_flags, uint32_t flag_val, hipStream_t st);
 extern "C" {
 __global__ void sq_lsap_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch, int32_t *col4row_out,
                                int lds_bytes);

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 #include "sq_match.h"
 #include "sq_blossom.h"
 
@@ -249,6 +250,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
 // ------------------------------------------------------------------------------------
 // job_flags (pinned host memory, may be null): job_flags[job] = stamp once the job's mates are in host memory, so the
 // host can filter and rank a sequence while the larger graphs are still being matched.
+// mate_out: per job 2n ints -- mate[0..n) and the rank of every vertex's first mate assignment (SqBlossom::mord)
 extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges,
                                                                char *scratch, int32_t *mate_out, int lds_bytes,
                                                                uint32_t *job_flags, uint32_t stamp)
@@ -294,7 +296,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
     if (all_lds || hot_lds) {
         __syncthreads();
         if (!bl.error) {
-            for (int q = lane; q < n; q += 64) mate_out[jp->out_off + q] = bl.mate[q];
+            for (int q = lane; q < n; q += 64) { mate_out[jp->out_off + q] = bl.mate[q]; mate_out[jp->out_off + n + q] = bl.mord[q]; }
 #ifdef SQ_MWM_PROF
             if (lane == 0 && n >= 140) {
                 const long long dc = clock64() - _c0, dw = wall_clock64() - _w0;
@@ -312,7 +314,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
     // lane 0 runs the order-dependent part; all 64 lanes share the O(n) sweeps of every substage
     bl.run<0>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), nullptr);
     __syncthreads();
-    for (int q = lane; q < n; q += 64) mate_out[jp->out_off + q] = bl.error ? -2 : bl.mate[q];
+    for (int q = lane; q < n; q += 64) { mate_out[jp->out_off + q] = bl.error ? -2 : bl.mate[q]; mate_out[jp->out_off + n + q] = bl.mord[q]; }
     publish();
 }
 
@@ -320,6 +322,46 @@ extern "C" __global__ void sq_flag_kernel(uint32_t *flag, uint32_t value)
 {
     __threadfence_system();
     *flag = value;
+}
+
+// Launch configuration of the three matching kernels (dynamic LDS sized for the largest job of the launch), shared
+// by the fold path (sq_algos.hip) and the graph-level C entries (sq_graph.hip).  jobs / edges: what the kernels read
+// (pinned host or device memory); h_jobs: the same table on the host; dev_edges: device room for the edge list, used
+// only when some blossom job has to run in global memory.  Asynchronous on st.
+int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatchJob *jobs, const SqMatchEdge *edges,
+                       size_t nedges, SqMatchEdge *dev_edges, char *d_scr, int32_t *out, int32_t *cnt,
+                       const uint8_t *codes, uint32_t *job_flags, uint32_t flag_val, hipStream_t st)
+{
+    int maxn = 0, maxm = 0;
+    for (int q = 0; q < nj; q++) { maxn = maxn > h_jobs[q].n ? maxn : h_jobs[q].n; maxm = maxm > h_jobs[q].nedges ? maxm : h_jobs[q].nedges; }
+    if (algo == 4) {                                     // SQ_ALGO_H
+        // LDS: the row/column vectors and, when it fits, the cost matrix as 16-bit edge ids + the edge weights
+        size_t lds = (size_t)maxn * 42 + 64 + 16 + (size_t)maxm * 8 + (size_t)maxn * maxn * 2 + 64;
+        if (lds > 64 * 1024) {
+            static bool attr_set = false;
+            if (!attr_set) { hipFuncSetAttribute((const void *)sq_lsap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        }
+        if (lds > 150 * 1024) lds = (size_t)maxn * 42 + 64 + 16 < 150 * 1024 ? (size_t)maxn * 42 + 64 + 16 : 150 * 1024;   // vectors only
+        hipLaunchKernelGGL(sq_lsap_kernel, dim3(nj), dim3(64), lds, st, jobs, edges, d_scr, out, (int)lds);
+    } else if (algo == 2) {                              // SQ_ALGO_N
+        hipLaunchKernelGGL(sq_nussinov_kernel, dim3(nj), dim3(256), 0, st, jobs, edges, codes, d_scr, out, cnt);
+    } else {                                             // SQ_ALGO_E
+        // dynamic LDS for the blossom state of the largest job (up to 150 KiB of the CU's 160)
+        size_t want = SqBlossom::scratch_bytes(maxn, maxm, 1) + (((size_t)maxm * sizeof(SqMatchEdge) + 15) & ~(size_t)15) + 64;
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute((const void *)sq_mwm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        static const bool nolds = getenv("SQ_MWM_NOLDS") != nullptr;
+        if (want > 150 * 1024 || nolds) {
+            // some job does not fit LDS and walks its edges in place: give those a device copy of the edge list
+            hipError_t e = hipMemcpyAsync(dev_edges, edges, nedges * sizeof(SqMatchEdge), hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) return (int)e;
+            edges = dev_edges;
+        }
+        if (want > 150 * 1024) want = 150 * 1024;        // jobs that do not fit run in global memory
+        if (nolds) want = 0;
+        hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), want, st, jobs, edges, d_scr, out, (int)want, job_flags, flag_val);
+    }
+    return (int)hipGetLastError();
 }
 
 size_t sq_lsap_scratch_bytes(int n)

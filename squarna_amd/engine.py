@@ -615,7 +615,11 @@ class HipEngine:
         seq, reacts, restraints, dbn, paramsets = record[:5]
         p = Prepared(seq, reacts, restraints, dbn)
         ps = paramsets[0]
-        with Batch([p], [[ps]], interchainonly=interchainonly, max_structs=self.max_structs,
+        mul = None
+        sm = record[5] if len(record) > 5 else None
+        if sm is not None:                                           # alignment step 2: bpscorematrix * shortsmat
+            mul = [np.delete(np.delete(np.asarray(sm, dtype=np.float64), p.gapidx, 0), p.gapidx, 1)]   # (:1031-1034,1084-1085)
+        with Batch([p], [[ps]], interchainonly=interchainonly, max_structs=self.max_structs, mul=mul,
                    cand_per_nt=max(self.cand_per_nt, 64)) as b:
             stems = b.optimal([0], [[]], mode=1)[0]
         n = len(p.shortseq)

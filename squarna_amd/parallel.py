@@ -5,7 +5,6 @@ which emits them in input order (the reference's ordered ``Pool.imap``, SQUARNA.
 There is no exchange inside the data path.
 """
 import io
-import os
 import sys
 
 import numpy as np
@@ -24,6 +23,18 @@ def lpt_partition(costs, world):
     return [sorted(p) for p in parts]
 
 
+def _collective_device(device=None, group=None):
+    """Where the tensors of a collective must live: the caller's choice, else the current GPU under the
+    "nccl" backend (RCCL has no CPU tensors), else the CPU (gloo)."""
+    import torch
+    import torch.distributed as dist
+    if device is not None:
+        return torch.device(device)
+    if "nccl" in str(dist.get_backend(group)).lower():
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def gather_blocks(blocks, total, device=None, group=None):
     """blocks: {record index: text}.  Returns the full ordered list on rank 0, None elsewhere.
     One all_gather of sizes + one all_gather of a packed uint8 payload (RCCL on GPU ranks)."""
@@ -35,7 +46,7 @@ def gather_blocks(blocks, total, device=None, group=None):
     payload = [blocks[k].encode() for k in idx]
     head = np.array([len(idx)] + [v for k, b in zip(idx, payload) for v in (k, len(b))], dtype=np.int64)
     body = np.frombuffer(head.tobytes() + b''.join(payload), dtype=np.uint8)
-    dev = device if device is not None else torch.device("cpu")
+    dev = _collective_device(device, group)
     size = torch.tensor([body.size], dtype=torch.int64, device=dev)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, size, group=group)
@@ -103,12 +114,15 @@ class ShardedAlignEngine:
     def reduce_matrix(self, matrix):
         import torch
         import torch.distributed as dist
-        if isinstance(matrix, np.ndarray):
-            t = torch.from_numpy(np.ascontiguousarray(matrix))
+        if isinstance(matrix, np.ndarray):                     # (host matrices: engines without stem_matrix)
+            t = torch.from_numpy(np.ascontiguousarray(matrix)).to(_collective_device(None, self.group))
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            return t.numpy()
+            return t.cpu().numpy()
         dist.all_reduce(matrix, op=dist.ReduceOp.SUM, group=self.group)
         return matrix
+
+    def entropy(self, record, interchainonly=False):
+        return self.base.entropy(record, interchainonly=interchainonly)
 
     def fold_records(self, recs, **kw):
         import torch.distributed as dist
@@ -124,11 +138,14 @@ class ShardedAlignEngine:
 
 def PredictSharded(write_to=None, device=None, **kwargs):
     """`Predict` across the ranks of an initialised torch.distributed group.
-    Same keyword arguments as `Predict`; rank 0 writes the complete output, in input order,
-    byte-identical to the single-process output."""
+    Same keyword arguments (and synonyms) as `Predict`; rank 0 writes the complete output in input order.
+    Single-sequence mode: byte-identical to the single-process output (records are independent).
+    Alignment mode: byte-identical when every partial sum is exact (dyadic bpweights -- all shipped configs --
+    and no reactivity factors); otherwise the all_reduce adds the per-rank partial matrices in a different
+    fp64 order than the reference's sequential loop (SQRNdbnali.py:233-237), so cells may differ in the last bits.
+    `device`: where the collective's tensors live; default = the current GPU under "nccl" (RCCL), CPU under gloo."""
     import torch.distributed as dist
     from .api import Predict
-    from .inputs import ParseInput
     assert dist.is_initialized(), "initialise torch.distributed first (torchrun)"
     world, rank = dist.get_world_size(), dist.get_rank()
     if any(kwargs.get(k) for k in ("alignment", "ali", "a")):
@@ -141,21 +158,9 @@ def PredictSharded(write_to=None, device=None, **kwargs):
             (write_to if write_to is not None else sys.stdout).write(buf.getvalue())
             return [buf.getvalue()]
         return None
-    # parse once to get the record lengths (cheap, O(input size)); cost model: N^2 per record
-    probe = dict(kwargs)
-    inputfile = probe.get("inputfile", probe.get("i"))
-    inputseq = probe.get("inputseq", probe.get("s", probe.get("seq")))
-    if inputfile is not None and not os.path.exists(inputfile):
-        from .config import DATA_DIR
-        cand = os.path.join(probe.get("HOME_DIR") or DATA_DIR, inputfile)
-        if os.path.exists(cand):
-            inputfile = cand
-    recs, _, _ = ParseInput(inputseq, inputfile, probe.get("inputformat", "qtrf"),
-                            fmt=probe.get("fileformat", probe.get("ff", "unknown")),
-                            ignore=bool(probe.get("ignorewarn", probe.get("iw", False))),
-                            inputrestr=probe.get("inputrestr"),
-                            M=float(probe.get("M", 1.8)), B=float(probe.get("B", -0.6)))
-    lens = [len(r[1]) for r in recs]
+    # record lengths from Predict's own parsing (same synonyms, same HOME_DIR lookup, same warnings policy), so the
+    # shard every rank computes is the shard Predict folds; cost model: N^2 per record
+    lens = Predict(write_to=io.StringIO(), _lengths_only=True, **kwargs)
     parts = lpt_partition([float(n) * n for n in lens], world)
     blocks = {}
     Predict(write_to=io.StringIO(), _select=set(parts[rank]), _on_block=lambda k, t: blocks.__setitem__(k, t),

@@ -349,6 +349,7 @@ def gen_text():
         ("ali_input_a_verbose", dict(inputfile=os.path.join(REF, "examples/ali_input.afa"), alignment=True, verbose=True)),
         ("ali_input_a_s3i", dict(inputfile=os.path.join(REF, "examples/ali_input.afa"), alignment=True, step3="i", levellimit=1)),
         ("ali_input_a_s31", dict(inputfile=os.path.join(REF, "examples/ali_input.afa"), alignment=True, step3="1", freqlimit=0.5)),
+        ("ali_input_a_entropy", dict(inputfile=os.path.join(REF, "examples/ali_input.afa"), alignment=True, verbose=True, entropy=True)),
         ("demo_afa_a", dict(inputfile=os.path.join(REF, "examples/demo.afa"), alignment=True, step3="2", reactformat=10)),
     ]
     only = os.environ.get("GOLDEN_ONLY")

@@ -1,7 +1,7 @@
 // Test-only host harness: runs the product's blossom restatement (squarna_amd/csrc/sq_blossom.h)
 // on the CPU so tests can compare it with networkx.max_weight_matching on many graphs quickly.
 // stdin: T, then per graph: n m, then m lines "v w weight" (vertex ids in graph order).
-// stdout: per graph one line with mate[0..n-1].
+// stdout: per graph one line with mate[0..n-1], then the rank of every vertex's first mate assignment (mord[0..n-1]).
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -24,6 +24,7 @@ int main()
         bl.run();
         if (bl.error) { printf("ERROR %d\n", bl.error); continue; }
         for (int v = 0; v < n; v++) printf("%d ", bl.mate[v]);
+        for (int v = 0; v < n; v++) printf("%d ", bl.mord[v]);
         printf("\n");
     }
     return 0;

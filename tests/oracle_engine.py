@@ -18,7 +18,8 @@ class OracleEngine:
 
     def entropy(self, record, interchainonly=False):
         seq, reacts, restraints, dbn, paramsets = record[:5]
-        return O.SQRNdbnseq(seq, reacts, restraints, dbn, paramsets, entropy=True,
+        sm = record[5] if len(record) > 5 else None
+        return O.SQRNdbnseq(seq, reacts, restraints, dbn, paramsets, entropy=True, stemmatrix=sm,
                             interchainonly=interchainonly)
 
     def yield_stems(self, records, bpweights, minlen, minbpscore, interchainonly=False):

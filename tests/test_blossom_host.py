@@ -55,8 +55,12 @@ def test_blossom_matches_networkx(exe):
         G = nx.Graph()
         for a, b, w in edges:
             G.add_edge(a, b, weight=w)
-        exp = {tuple(sorted(p)) for p in nx.max_weight_matching(G)}
-        mate = list(map(int, row.split()))
+        exp = nx.max_weight_matching(G)
+        nums = list(map(int, row.split()))
+        n = len(nums) // 2
+        mate, mord = nums[:n], nums[n:]
         inv = {v: k for k, v in ids.items()}
-        got = {tuple(sorted((inv[v], inv[mate[v]]))) for v in range(len(mate)) if mate[v] > v}
+        # networkx returns each pair as (u, v) with u the endpoint that entered its `mate` dict first
+        # (matching_dict_to_set); Edmonds() sorts those tuples (SQRNalgos.py:109), so the orientation is observable
+        got = {(inv[v], inv[mate[v]]) for v in range(n) if mate[v] >= 0 and mord[v] < mord[mate[v]]}
         assert got == exp, (edges, got, exp)

@@ -215,7 +215,7 @@ def test_edge_cases():
 GPU_TEXT = ["s16_nobpp", "seq_input_nobpp", "SRtest150_nobpp", "s16_fastest", "shape_input_fastest", "shape_input_alt_rf26", "seq_input_entropy",
             "seq_input_ico", "seq_input_greedynobpp_rf10", "seq_input_evalonly", "SRtest150_fastest",
             "SRtest150_fastest_pl1", "SRtest150_alt", "SRtest150_greedynobpp", "ali_input_a", "ali_input_a_verbose",
-            "ali_input_a_s3i", "ali_input_a_s31", "demo_afa_a"]
+            "ali_input_a_s3i", "ali_input_a_s31", "ali_input_a_entropy", "demo_afa_a"]
 
 
 @pytest.mark.parametrize("tag", GPU_TEXT)
@@ -308,8 +308,8 @@ def _synthetic(n, count, seed, reacts=False):
     return out
 
 
-@pytest.mark.parametrize("n,count,seed,reacts,sample", [(300, 64, 300, False, 6), (1000, 24, 1000, False, 3),
-                                                        (2000, 6, 2000, True, 2)])
+@pytest.mark.parametrize("n,count,seed,reacts,sample", [(300, 64, 300, False, 16), (1000, 24, 1000, False, 8),
+                                                        (2000, 12, 2000, True, 10)])
 def test_baseline_sizes_vs_oracle_and_properties(n, count, seed, reacts, sample):
     from oracle import sqrn_oracle as O
     from squarna_amd.engine import HipEngine

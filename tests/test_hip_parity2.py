@@ -1,0 +1,335 @@
+"""GPU parity, round 2 additions (all through the C ABI of libsquarna_hip.so):
+
+* the graph-level drop-ins Edmonds / Hungarian / Nussinov / RunAlgo against the reference's raw return values;
+* bpp != 0 paramsets against fixtures the REAL reference produced on the ViennaRNA stand-in tests/fake_rna.py;
+* the `algos=` override (several non-greedy algorithms per paramset) against reference folds;
+* alignment step 1 at BASELINE config 5's size (5000 columns) against the CPU oracle, and the full 512 x 5000
+  matrix through size-independent properties;
+* PredictSharded under the "nccl" backend (RCCL) at world size 1 with the HIP engine, no device argument.
+"""
+import hashlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+DATA = os.path.join(os.path.dirname(HERE), "squarna_amd", "data")
+TOL = 1e-5
+
+
+def load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def conf(name):
+    from squarna_amd.config import ParseConfig, builtin_config
+    return ParseConfig(builtin_config(name))
+
+
+def _same_fold(got, exp, tag):
+    assert got[0] == exp[0], (tag, "consensus", got[0], exp[0])
+    assert len(got[1]) == len(exp[1]), (tag, len(got[1]), len(exp[1]))
+    for g, e in zip(got[1], exp[1]):
+        assert g[0] == e[0], (tag, g, e)
+        assert all(abs(a - b) <= TOL for a, b in zip(g[1], e[1])), (tag, g, e)
+        assert list(g[2]) == list(e[2]), (tag, g, e)
+    for g, e in zip(list(got[2]) + list(got[3]), list(exp[2]) + list(exp[3])):
+        if e == "nan":
+            assert g != g, tag
+        else:
+            assert abs(g - e) <= TOL, (tag, got[2], got[3], exp[2], exp[3])
+
+
+def _stems(c):
+    return [[[(i + k, j - k) for k in range(ln)], ln, sc] for i, j, ln, sc in c["stems"]]
+
+
+# ---- a-8 / a-9 drop-ins -----------------------------------------------------------------------------------
+def test_matching_dropins_return_what_the_reference_returns():
+    """squarna_amd.Edmonds / Hungarian / Nussinov (sq_mwm / sq_lsap / sq_nussinov) == SQRNalgos.Edmonds / Hungarian /
+    Nussinov on the same stem lists: identical lists, for Edmonds including every pair's (u, v) orientation."""
+    import squarna_amd as S
+    from squarna_amd.dbn import SEPS
+    cases, raw = load("algos.json"), load("algos_raw.json")
+    assert len(cases) == len(raw) > 100
+    flipped = 0
+    for c, r in zip(cases, raw):
+        assert (c["name"], c["algo"]) == (r["name"], r["algo"])
+        stems, n = _stems(c), len(c["seq"])
+        if c["algo"] == "E":
+            got = S.Edmonds(stems)
+            flipped += sum(1 for v, w in got if v > w)
+        elif c["algo"] == "H":
+            got = S.Hungarian(c["seq"], stems, n, SEPS)
+        else:
+            got = S.Nussinov(c["seq"], stems, n, SEPS)
+        assert [list(p) for p in got] == r["raw"], (c["name"], c["algo"])
+    assert flipped > 100                        # the orientation really is exercised
+
+
+def test_matching_dropins_edge_cases():
+    import squarna_amd as S
+    from squarna_amd.dbn import SEPS
+    assert S.Edmonds([]) == [] and S.Hungarian("ACGU", [], 4, SEPS) == [] and S.Nussinov("ACGU", [], 4, SEPS) == []
+    # a repeated edge takes the last weight and keeps its first position (networkx add_weighted_edges_from);
+    # labels need not be dense
+    import networkx as nx
+    edges = [(10, 70, 2.0), (70, 30, 3.0), (30, 90, 2.0), (10, 70, 4.0), (90, 10, 1.0)]
+    G = nx.Graph()
+    G.add_weighted_edges_from(edges)
+    exp = sorted(nx.max_weight_matching(G))
+    stems = [[[(u, v)], 1, w] for u, v, w in edges]
+    assert S.Edmonds(stems, power=1.0) == exp
+    with pytest.raises(RuntimeError, match="non-negative"):
+        S.Edmonds([[[(-1, 3)], 1, 2.0]])
+    with pytest.raises(RuntimeError, match="outside the matrix"):
+        S.Hungarian("ACGU", [[[(0, 9)], 1, 2.0]], 4, SEPS)
+
+
+def test_runalgo_dropin_matches_reference():
+    """RunAlgo with the reference's signature (caller matrices in, stemset out) == the reference's stemsets."""
+    import squarna_amd as S
+    from squarna_amd.dbn import DBNToPairs
+    names, psets = conf("nobpp")
+    ps = dict(zip(names, psets))
+    cases = load("algos.json")
+    n = 0
+    for c in cases[::3] + cases[1::9]:
+        p = ps[c["paramset"]]
+        restr = c["restraints"]
+        rxs = {i for i, ch in enumerate(restr) if ch in "_+"}
+        rl = {i for i, ch in enumerate(restr) if ch == "/"}
+        rr = {i for i, ch in enumerate(restr) if ch == "\\"}
+        bm, sm = S.BPMatrix(c["seq"], p["bpweights"], rxs, rl, rr, False, c["reacts"])
+        got = S.RunAlgo(c["seq"], bm, sm, set(DBNToPairs(restr)), [], p["minlen"], p["minbpscore"], algo=c["algo"],
+                        levellimit=3 - int(len(c["seq"]) > 500))
+        flat = [[st[0][0][0], st[0][0][1], st[1], st[2]] for st in got]
+        assert len(flat) == len(c["stemset"]), (c["name"], c["algo"])
+        for g, e in zip(flat, c["stemset"]):
+            assert g[:3] == e[:3] and abs(g[3] - e[3]) <= TOL, (c["name"], c["algo"], g, e)
+        assert all(st[2] == st[3] and st[4] == '' and st[0] == [(st[0][0][0] + k, st[0][0][1] - k) for k in range(st[1])]
+                   for st in got)
+        n += 1
+    assert n > 40
+
+
+# ---- f-4: bpp != 0 paramsets, pinned by the real reference on the ViennaRNA stand-in --------------------------
+def test_bpp_bpmatrix_golden_gpu(fake_rna):
+    import squarna_amd as S
+    g = load("bpp.json")
+    for c, calls in zip(g["bpmatrix"], g["calls"]):
+        restr = c["restraints"]
+        rxs = {i for i, ch in enumerate(restr) if ch in "_+"}
+        rl = {i for i, ch in enumerate(restr) if ch == "/"}
+        rr = {i for i, ch in enumerate(restr) if ch == "\\"}
+        bm, sm = S.BPMatrix(c["seq"], c["weights"], rxs, rl, rr, False, c["reacts"], bpp_power=c["bpp_power"])
+        assert [[int(i), int(j)] for i, j in zip(*np.nonzero(bm))] == c["bool"], c["seq"]
+        exp = np.zeros_like(sm)
+        for i, j, v in c["score"]:
+            exp[i, j] = v
+        assert np.array_equal(sm != 0, exp != 0), (c["seq"], c["bpp_power"])
+        assert np.allclose(sm, exp, rtol=1e-12, atol=0), (c["seq"], c["bpp_power"])
+        # the product made the same calls into `RNA`, with the same arguments, as the reference did
+        mine = json.loads(json.dumps(list(fake_rna.CALLS)))
+        assert mine == calls["calls"], (c["seq"], mine, calls["calls"])
+
+
+def test_bpp_fold_golden_gpu(fake_rna):
+    """Whole folds under def.conf (12 paramsets, 7 with probabilities, G/N/H/E) == the reference's tuples."""
+    from squarna_amd.engine import HipEngine
+    names, psets = conf("def")
+    cases = load("bpp.json")["fold"]
+    recs, kws = [], []
+    for c in cases:
+        kw = dict(c["kw"])
+        if "rankby" in kw:
+            kw["rankby"] = tuple(kw["rankby"])
+        if "priority" in kw:
+            kw["priority"] = set(kw["priority"])
+        recs.append((c["seq"], c["reacts"], c["restraints"], None, psets, None))
+        kws.append(kw)
+    eng = HipEngine()
+    groups = {}
+    for k, c in enumerate(cases):                            # each option set of the fixture as ONE batch
+        groups.setdefault(json.dumps(c["kw"], sort_keys=True), []).append(k)
+    assert len(groups) == 2
+    for idx in groups.values():
+        out = eng.fold_records([recs[k] for k in idx], **kws[idx[0]])
+        for k, o in zip(idx, out):
+            _same_fold(o, cases[k]["out"], (cases[k]["tag"], cases[k]["kw"]))
+    assert len(cases) >= 20
+
+
+@pytest.mark.parametrize("tag", ["s16_def", "seq_input_def", "shape_input_def_rb", "SRtest150_def"])
+def test_predict_text_default_config_with_bpp_gpu(tag, fake_rna):
+    """Predict() with the DEFAULT configuration (def.conf, default priority paramsets): byte-identical to the text the
+    reference printed on the same ViennaRNA stand-in."""
+    from squarna_amd import Predict
+    dig = load("digests.json")[tag]
+    assert dig.get("fake_rna")
+    kw = dict(dig["args"])
+    if "inputfile" in kw:
+        kw["inputfile"] = os.path.join(DATA, kw["inputfile"])
+    buf = io.StringIO()
+    Predict(write_to=buf, **kw)
+    txt = buf.getvalue()
+    with open(os.path.join(GOLDEN, "text", tag + ".txt")) as f:
+        exp = f.read()
+    if txt != exp:
+        tl, el = txt.split("\n"), exp.split("\n")
+        bad = [(k, a, b) for k, (a, b) in enumerate(zip(tl, el)) if a != b][:3]
+        raise AssertionError("text differs (%d vs %d lines): %r" % (len(tl), len(el), bad))
+    assert hashlib.sha256(txt.encode()).hexdigest() == dig["sha256"]
+
+
+# ---- `algos=` override: E, H and N stemsets of one paramset ----------------------------------------------------
+def test_algos_override_golden_gpu():
+    from squarna_amd.engine import HipEngine
+    names, psets = conf("nobpp")
+    cases = load("fold_algos.json")
+    eng = HipEngine()
+    for algos in sorted({c["algos"] for c in cases}):
+        sel = [c for c in cases if c["algos"] == algos]
+        out = eng.fold_records([(c["seq"], c["reacts"], None, None, psets, None) for c in sel], algos=set(algos),
+                               **sel[0]["kw"])
+        for c, o in zip(sel, out):
+            _same_fold(o, c["out"], (algos, c["seq"]))
+    assert len(cases) >= 40
+
+
+# ---- alignment step 1 at BASELINE config 5's size (512 sequences x 5000 columns) -------------------------------
+def _msa(nseq, ncol, seed=5000, mut=0.15, gap=0.10):
+    """one random ancestor, per-site mutation 0.15, per-site gap 0.10."""
+    rng = np.random.default_rng(seed)
+    anc = rng.choice(list("ACGU"), ncol)
+    rows = []
+    for _ in range(nseq):
+        row = anc.copy()
+        m = rng.random(ncol) < mut
+        row[m] = rng.choice(list("ACGU"), int(m.sum()))
+        row[rng.random(ncol) < gap] = "-"
+        rows.append("".join(row))
+    return rows
+
+
+def _oracle_matrix(recs, w, minlen, minbp):
+    """The reference's parent-side loop (SQRNdbnali.py:233-237) over the oracle's YieldStems: sequences, stems and
+    cells in order; np.add.at applies the additions one by one, so every cell sees the reference's fp64 order."""
+    from tests.oracle_engine import OracleEngine
+    L = len(recs[0][0])
+    exp = np.zeros((L, L))
+    for rec in recs:                                              # one sequence at a time: bounded memory
+        (short, stems), = OracleEngine().yield_stems([rec], w, minlen, minbp)
+        if not stems:
+            continue
+        cols = np.array([c for c, ch in enumerate(rec[0]) if ch not in "-.~"], np.int64)
+        st = np.array([s[:3] for s in stems], np.int64)
+        sc = np.array([s[3] for s in stems], np.float64)
+        si, sj, sl = st[:, 0], st[:, 1], st[:, 2]
+        k = np.arange(int(sl.sum())) - np.repeat(np.cumsum(sl) - sl, sl)
+        v, ww, val = cols[np.repeat(si, sl) + k], cols[np.repeat(sj, sl) - k], np.repeat(sc, sl)
+        np.add.at(exp, (v, ww), val)
+        np.add.at(exp, (ww, v), val)
+    return exp
+
+
+@pytest.mark.parametrize("with_reacts,nseq", [(False, 24), (True, 8)])
+def test_align_config5_columns_vs_oracle(with_reacts, nseq):
+    """5000-column alignment (config 5's width, ali.conf weights): the device column matrix == the sequential
+    accumulation of the CPU oracle's stems, bit for bit without reactivities (the one-launch atomic path) and within
+    1e-13 with float reactivities (the ordered one-launch-per-sequence path; only the documented sqrt-vs-pow ulp)."""
+    from squarna_amd.engine import HipEngine
+    names, psets = conf("ali")
+    ps = psets[0]
+    rows = _msa(nseq, 5000, seed=5000 + with_reacts)
+    rng = np.random.default_rng(9)
+    recs = []
+    for r in rows:
+        reacts = [float(x) for x in rng.random(len(r))] if with_reacts else None
+        recs.append((r, reacts, "." * len(r)))
+    exp = _oracle_matrix(recs, ps["bpweights"], ps["minlen"], ps["minbpscore"])
+    eng = HipEngine()
+    got_t = eng.stem_matrix(recs, ps["bpweights"], ps["minlen"], ps["minbpscore"])
+    got = got_t.cpu().numpy()
+    assert got.shape == (5000, 5000)
+    if with_reacts:
+        assert np.array_equal(got != 0, exp != 0)
+        assert np.allclose(got, exp, rtol=1e-13, atol=0)
+        exp = got
+    else:
+        assert np.array_equal(got, exp)
+    thr = ps["minbpscore"] * nseq
+    idx, val = eng.matrix_cells(got_t, thr)
+    flat = exp.reshape(-1)
+    hit = np.flatnonzero(flat >= thr)
+    hit = hit[(hit % 5000) - (hit // 5000) >= 4]
+    assert len(hit) > 1000
+    assert np.array_equal(idx, hit) and np.array_equal(val, flat[hit])
+
+
+def test_align_config5_full_size_properties():
+    """512 x 5000 (BASELINE config 5) through properties: symmetric; equal to the sum of the matrices of its
+    32-sequence chunks (every sum is exact for ali.conf's dyadic weights, so any grouping gives the same bits);
+    the device threshold selection == numpy's on the same matrix; first rows == an independent 16-sequence run."""
+    import torch
+    from squarna_amd.engine import HipEngine
+    names, psets = conf("ali")
+    ps = psets[0]
+    rows = _msa(512, 5000)
+    recs = [(r, None, "." * 5000) for r in rows]
+    eng = HipEngine()
+    args = (ps["bpweights"], ps["minlen"], ps["minbpscore"])
+    full = eng.stem_matrix(recs, *args)
+    assert tuple(full.shape) == (5000, 5000) and bool(torch.equal(full, full.T))
+    acc = torch.zeros_like(full)
+    for lo in range(0, 512, 32):
+        acc += eng.stem_matrix(recs[lo:lo + 32], *args)
+    assert bool(torch.equal(acc, full))
+    assert float(full.sum().item()) > 0
+    thr = ps["minbpscore"] * 512
+    idx, val = eng.matrix_cells(full, thr)
+    flat = full.cpu().numpy().reshape(-1)
+    hit = np.flatnonzero(flat >= thr)
+    hit = hit[(hit % 5000) - (hit // 5000) >= 4]
+    assert len(hit) > 10000
+    assert np.array_equal(idx, hit) and np.array_equal(val, flat[hit])
+
+
+# ---- multi-GPU driver on the product engine: "nccl" == RCCL, world size 1 (one GPU on the test box) ----------------
+def test_predict_sharded_under_nccl_world1(tmp_path):
+    """PredictSharded as INTEGRATION.md documents it (no device argument) under the RCCL backend with the HIP engine:
+    the single-sequence gather (all_gather of packed text) and the alignment path (all_reduce of the device matrix,
+    all_gather_object of the step-2 folds) give the reference's bytes."""
+    import torch
+    import torch.distributed as dist
+    from squarna_amd.parallel import PredictSharded
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method="file://" + str(tmp_path / "rdzv"), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        dig = load("digests.json")
+        for tag in ("SRtest150_fastest", "seq_input_nobpp", "ali_input_a", "ali_input_a_entropy"):
+            kw = dict(dig[tag]["args"])
+            if "inputfile" in kw:
+                kw["inputfile"] = os.path.join(DATA, kw["inputfile"])
+            buf = io.StringIO()
+            PredictSharded(write_to=buf, **kw)
+            with open(os.path.join(GOLDEN, "text", tag + ".txt")) as f:
+                assert buf.getvalue() == f.read(), tag
+        # synonyms resolve as in Predict (later aliases win): i= over inputfile=, c= over configfile=
+        buf = io.StringIO()
+        PredictSharded(write_to=buf, inputfile="/nonexistent", i="datasets/SRtest150.fas", inputformat="qf",
+                       configfile="nobpp", c="fastest", pl=1)
+        with open(os.path.join(GOLDEN, "text", "SRtest150_fastest_pl1.txt")) as f:
+            assert buf.getvalue() == f.read()
+    finally:
+        dist.destroy_process_group()

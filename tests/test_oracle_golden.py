@@ -129,3 +129,50 @@ def test_appendix_b_known_answer():
     assert all(s[i, j] == 3.25 for i, j in cells)
     stems = O.AnnotateStems(b, s, set(), [], 2, 0)
     assert stems == [(0, 8, 2, 6.5), (0, 9, 3, 9.75), (1, 9, 2, 6.5)]
+
+
+# ---- bpp != 0 paramsets (dbnseq:341-364): fixtures from the REAL reference running on the ViennaRNA stand-in
+# ---- tests/fake_rna.py (tests/golden/gen_bpp_golden.py).  Pins the application of the probabilities, the
+# ---- zero-probability retry / skip, and everything downstream; the probabilities themselves stay unpinned.
+def test_bpp_bpmatrix_golden(fake_rna):
+    g = load("bpp.json")
+    for c, calls in zip(g["bpmatrix"], g["calls"]):
+        rbps, rxs, rl, rr = O.ParseRestraints(c["restraints"])
+        b, s = O.BPMatrix(c["seq"], c["weights"], rxs, rl, rr, False, c["reacts"], bpp_power=c["bpp_power"])
+        assert [[int(i), int(j)] for i, j in zip(*np.nonzero(b))] == c["bool"], c["seq"]
+        got_s = [[int(i), int(j), float(s[i, j])] for i, j in zip(*np.nonzero(s))]
+        assert got_s == c["score"], (c["seq"], c["bpp_power"])
+        # the oracle made the same calls into `RNA`, with the same arguments, as the reference did
+        mine = json.loads(json.dumps(list(fake_rna.CALLS)))
+        assert mine == calls["calls"], (c["seq"], mine, calls["calls"])
+    lens = {len(c["seq"]) % 11 for c in g["bpmatrix"]}
+    assert {3, 7} <= lens                     # both zero branches (:355-364) are in the fixture
+
+
+def test_bpp_fold_golden(fake_rna):
+    from squarna_amd.config import ParseConfig, builtin_config
+    names, psets = ParseConfig(builtin_config("def"))
+    assert len(psets) == 12 and sum(1 for p in psets if p["bpp"]) == 7
+    n = 0
+    for c in load("bpp.json")["fold"]:
+        kw = dict(c["kw"])
+        if "rankby" in kw:
+            kw["rankby"] = tuple(kw["rankby"])
+        out = O.SQRNdbnseq(c["seq"], c["reacts"], c["restraints"], None, psets, **kw)
+        got = [out[0], [[d, list(sc), list(ps)] for d, sc, ps in out[1]], list(out[2]), list(out[3])]
+        assert same(got, unnan(c["out"])), (c["tag"], c["kw"])
+        n += 1
+    assert n >= 20
+
+
+def test_algos_override_golden():
+    """`algos=` override: several non-greedy algorithms per paramset (dbnseq:1065-1066,1094-1100), reference
+    outputs that do not depend on its set iteration order (tests/golden/gen_algos_override_golden.py)."""
+    from squarna_amd.config import ParseConfig, builtin_config
+    names, psets = ParseConfig(builtin_config("nobpp"))
+    cases = load("fold_algos.json")
+    assert len(cases) >= 40 and {c["algos"] for c in cases} >= {"EHN", "EHNG", "HN", "EG"}
+    for c in cases:
+        out = O.SQRNdbnseq(c["seq"], c["reacts"], None, None, psets, algos=set(c["algos"]), **c["kw"])
+        got = [out[0], [[d, list(sc), list(ps)] for d, sc, ps in out[1]], list(out[2]), list(out[3])]
+        assert same(got, unnan(c["out"])), (c["seq"], c["algos"])

@@ -76,7 +76,7 @@ def test_sharded_alignment_world2_matches_reference(tmp_path):
     with open(os.path.join(GOLDEN, "digests.json")) as f:
         dig = json.load(f)
     jobs = []
-    for tag in ("ali_input_a", "ali_input_a_verbose", "demo_afa_a"):
+    for tag in ("ali_input_a", "ali_input_a_verbose", "ali_input_a_entropy", "demo_afa_a"):
         kw = dict(dig[tag]["args"])
         kw["inputfile"] = os.path.join(ROOT, "squarna_amd", "data", kw["inputfile"])
         jobs.append((tag, kw))
