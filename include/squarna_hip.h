@@ -261,6 +261,11 @@ SQ_API int sq_colmatrix_select(const double *d_matrix, int32_t L, double thresho
 SQ_API int sq_profile_enable(sq_batch *b, int32_t on);
 SQ_API int sq_profile_get(sq_batch *b, int32_t kernel, double *total_ms, int64_t *launches, double *alg_bytes);
 SQ_API int sq_profile_reset(sq_batch *b);
+/* Work counters of the blossom kernel (kernel 4) since the last reset, always on: out[0] graphs matched, out[1] their
+ * scan passes (one pass = one chunk of <= 64 neighbours of a popped S-vertex), and for the graph with the most
+ * passes -- the kernel's critical path, one wave per graph -- out[2] its passes, out[3] its lane-0 events, out[4] its
+ * vertices, out[5] its edges. */
+SQ_API int sq_profile_counters(sq_batch *b, int32_t kernel, int64_t out[6]);
 
 #ifdef __cplusplus
 }

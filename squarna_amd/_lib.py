@@ -18,7 +18,7 @@ SYMBOLS = ["sq_version", "sq_last_error", "sq_batch_workspace_bytes", "sq_batch_
            "sq_batch_destroy", "sq_bpmatrix_fill", "sq_bpmatrix_read", "sq_optimal_stems",
            "sq_fold", "sq_result_nstruct", "sq_result_consensus", "sq_result_struct",
            "sq_result_metrics", "sq_result_evals", "sq_result_pack_size", "sq_result_pack",
-           "sq_profile_enable", "sq_profile_get", "sq_profile_reset", "sq_run_algos",
+           "sq_profile_enable", "sq_profile_get", "sq_profile_reset", "sq_profile_counters", "sq_run_algos",
            "sq_align_accumulate", "sq_colmatrix_select", "sq_fold_concurrent",
            "sq_mwm_workspace_bytes", "sq_mwm", "sq_lsap_workspace_bytes", "sq_lsap",
            "sq_nussinov_workspace_bytes", "sq_nussinov"]
@@ -107,6 +107,7 @@ def load():
     L.sq_profile_get.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                  C.POINTER(C.c_double)]
     L.sq_profile_reset.argtypes = [C.c_void_p]
+    L.sq_profile_counters.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.sq_run_algos.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                C.c_void_p]
     L.sq_fold_concurrent.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FoldOpts), C.c_void_p, C.c_void_p, C.c_void_p]

@@ -98,8 +98,21 @@ struct SqAlgoChunk {
     size_t outints = 0, scratch = 0, bytes = 0;  // device bytes used from the region's base
     int32_t *d_out = nullptr, *d_cnt = nullptr;  // results: in the pinned staging buffer, written by the kernels in place
     uint32_t *flag = nullptr; uint32_t flag_val = 0;   // pinned completion word published by sq_flag_kernel
-    uint32_t *job_flags = nullptr;               // pinned, Edmonds only: per job "mates are in host memory" (== flag_val)
+    uint32_t *job_flags = nullptr;               // pinned, Edmonds only: per job "mates are in host memory" (== flag_val),
+                                                 // indexed by the job's position in the SORTED table (sorted_pos)
     hipStream_t st = nullptr;
+    // Edmonds / Hungarian: the kernel's job table is sorted by LDS need (largest first) and launched in size classes,
+    // every class with the dynamic LDS of ITS largest job.  A launch-wide LDS size gives each of the 219 SRtest150
+    // graphs the 130 KB of the largest one: one block per CU, so two batches in flight already hold every CU's LDS and
+    // the 56 KB blocks of the scoring kernel of ALL batches wait for a blossom block to finish (traced on MI355X with 8
+    // batches in flight: sq_score_kernel 31 -> 137 us, sq_bps_kernel 33 -> 783 us per launch, profiles/r02j_*).
+    // Streams: class 0 of Edmonds (the largest graphs, the critical path) runs on the Edmonds side stream, its other
+    // classes go -- largest first -- in front of the Hungarian / Nussinov kernels on THEIR stream: no extra streams
+    // (see side_of), and the whole sequence still ends before class 0 does.
+    struct Class { int start, count; };
+    std::vector<Class> classes;
+    std::vector<int> sorted_pos;                 // job q of mj -> row of the sorted table
+    std::vector<SqMatchJob> sorted;              // host copy of the sorted table
 };
 
 namespace {
@@ -122,11 +135,21 @@ struct PowCache {
 struct JobBuild { int n = 0; size_t ncell = 0, need = 0, nout = 0; };
 }
 
+// Side stream of staging slot `slot` (0 Edmonds, 1 Hungarian, 2 Nussinov).  The two short kernels share a stream: the
+// runtime multiplexes all streams of the process onto a few hardware queues (GPU_MAX_HW_QUEUES), streams that share a
+// queue serialise, and with several batches in flight every stream less keeps a 6 ms blossom kernel out of some other
+// batch's round queue.  Hungarian + Nussinov back to back (1.4 + 1.5 ms) still end long before Edmonds does.
+static inline int side_of(int slot)
+{
+    static const bool three = getenv("SQ_SIDE_STREAMS") && atoi(getenv("SQ_SIDE_STREAMS")) >= 3;
+    return three ? slot : (slot == 0 ? 0 : 1);
+}
+
 // pinned staging buffer `slot` of the batch, at least `bytes` large (grow-only)
 static char *stage_buffer(sq_batch *b, int slot, size_t bytes)
 {
     if (b->stage_cap[slot] < bytes) {
-        if (b->stage_buf[slot]) { hipStreamSynchronize(slot < 3 && b->side[slot] ? b->side[slot] : b->stream); sq_pinned_put(b->stage_buf[slot]); }
+        if (b->stage_buf[slot]) { hipStreamSynchronize(slot < 3 && b->side[side_of(slot)] ? b->side[side_of(slot)] : b->stream); sq_pinned_put(b->stage_buf[slot]); }
         b->stage_buf[slot] = nullptr; b->stage_cap[slot] = 0;
         const size_t cap = bytes + bytes / 2 + 4096;
         if (sq_pinned_get((void **)&b->stage_buf[slot], cap)) return nullptr;
@@ -163,7 +186,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
                     if (!seen[s.i + t]) { seen[s.i + t] = 1; nv++; }
                     if (!seen[s.j - t]) { seen[s.j - t] = 1; nv++; }
                 }
-            B.n = nv; B.need = sq_mwm_scratch_bytes(nv, (int)ncell); B.nout = 2 * (size_t)nv;          // mates + first-assignment ranks
+            B.n = nv; B.need = sq_mwm_scratch_bytes(nv, (int)ncell); B.nout = 2 * (size_t)nv + 2;      // mates + first-assignment ranks + (passes, events)
         } else {
             B.n = J.n;
             B.need = algo == SQ_ALGO_H ? sq_lsap_scratch_bytes(J.n) : sq_nussinov_scratch_bytes(J.n);
@@ -207,7 +230,37 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     ck.flag_val = ++b->algo_seq;
     *ck.flag = 0;
     if (fbytes) { ck.job_flags = (uint32_t *)(pin + jbytes + ebytes + obytes + cbytes + 256); memset(ck.job_flags, 0, mj.size() * 4); }
-    memcpy(ck.p_jobs, mj.data(), mj.size() * sizeof(SqMatchJob));
+    if (algo == SQ_ALGO_E || algo == SQ_ALGO_H) {
+        // LDS size classes (see SqAlgoChunk::Class): jobs sorted by the dynamic LDS they need, largest first
+        const size_t nq = mj.size();
+        std::vector<size_t> need(nq);
+        for (size_t q = 0; q < nq; q++)
+            need[q] = algo == SQ_ALGO_E
+                          ? SqBlossom::scratch_bytes(mj[q].n, mj[q].nedges, 1) + (((size_t)mj[q].nedges * sizeof(SqMatchEdge) + 15) & ~(size_t)15) + 64
+                          : (size_t)mj[q].n * 42 + 64 + 16 + (size_t)mj[q].nedges * 8 + (size_t)mj[q].n * mj[q].n * 2 + 64;
+        std::vector<int> ord(nq);
+        for (size_t q = 0; q < nq; q++) ord[q] = (int)q;
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return need[x] > need[y]; });
+        ck.sorted.resize(nq); ck.sorted_pos.resize(nq);
+        for (size_t r = 0; r < nq; r++) { ck.sorted[r] = mj[ord[r]]; ck.sorted_pos[ord[r]] = (int)r; }
+        // a new class starts where twice as many blocks would fit a CU (and the current one has a few jobs)
+        // Two classes for Edmonds, one for Hungarian: classes that FOLLOW each other on a stream each last as long as
+        // their slowest job, so more of them lengthen the chain on the short kernels' stream past the end of Edmonds'
+        // class 0 (traced: 4 + 4 classes end at 9.3 ms, one batch alone, instead of 7.2 ms)
+        static const int env_classes = getenv("SQ_MWM_CLASSES") ? std::max(1, atoi(getenv("SQ_MWM_CLASSES"))) : 0;
+        const int max_classes = env_classes ? env_classes : (algo == SQ_ALGO_E ? 2 : 1);
+        size_t cur = std::min<size_t>(need[ord[0]], 150 * 1024);
+        ck.classes.push_back({0, 0});
+        for (size_t r = 0; r < nq; r++) {
+            SqAlgoChunk::Class &c = ck.classes.back();
+            if (c.count >= 4 && need[ord[r]] * 2 <= cur && (int)ck.classes.size() < max_classes) {
+                ck.classes.push_back({(int)r, 1});
+                cur = need[ord[r]];
+            } else c.count++;
+        }
+        memcpy(ck.p_jobs, ck.sorted.data(), nq * sizeof(SqMatchJob));
+    } else
+        memcpy(ck.p_jobs, mj.data(), mj.size() * sizeof(SqMatchJob));
     const double tb2 = sq_now();
     // pass 2 (pool): the edges, written straight into the pinned buffer
     ck.vid2pos.resize(mj.size());
@@ -245,7 +298,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
 // Device part: kernel of a built chunk into [region, region + ck.bytes) on stream st.  The job table and the edges
 // are read by the kernels straight from the pinned staging buffer (each kernel reads them once, at its start).
 // Nothing is waited for.
-static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t st)
+static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t st, hipStream_t st2 = nullptr)
 {
     ck.st = st;
     const std::vector<SqMatchJob> &mj = ck.mj;
@@ -264,7 +317,24 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
     hipEvent_t pe0;
     const int pslot = algo == SQ_ALGO_E ? 4 : algo == SQ_ALGO_H ? 5 : 6;
     sq_prof_begin(b, pslot, st, &pe0);
-    {
+    if (algo == SQ_ALGO_E || algo == SQ_ALGO_H) {
+        // `st2` (Edmonds in a fold): the stream of the short kernels takes the classes after the first; st then waits
+        // for it, so "st is idle" still means "the chunk is done".  Without st2 the classes follow each other on st.
+        hipStream_t other = algo == SQ_ALGO_E ? st2 : nullptr;
+        for (size_t cidx = 0; cidx < ck.classes.size(); cidx++) {
+            const SqAlgoChunk::Class &c = ck.classes[cidx];
+            hipStream_t cs = (cidx > 0 && other) ? other : st;
+            const int rl = sq_launch_matching(algo, ck.sorted.data() + c.start, c.count, d_jobs + c.start, d_edges, ck.nedges,
+                                              (SqMatchEdge *)(region + o_edges), d_scr, ck.d_out, ck.d_cnt, b->ctx.codes,
+                                              ck.job_flags ? ck.job_flags + c.start : nullptr, ck.flag_val, cs);
+            if (rl) return sq_check((hipError_t)rl, "matching kernel launch");
+        }
+        if (other && ck.classes.size() > 1) {
+            if (!b->class_ev) HIPCK(hipEventCreateWithFlags(&b->class_ev, hipEventDisableTiming));
+            HIPCK(hipEventRecord(b->class_ev, other));
+            HIPCK(hipStreamWaitEvent(st, b->class_ev, 0));
+        }
+    } else {
         const int rl = sq_launch_matching(algo, mj.data(), nj, d_jobs, d_edges, ck.nedges, (SqMatchEdge *)(region + o_edges), d_scr,
                                           ck.d_out, ck.d_cnt, b->ctx.codes, ck.job_flags, ck.flag_val, st);
         if (rl) return sq_check((hipError_t)rl, "matching kernel launch");
@@ -315,32 +385,25 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
         dense[q].resize((size_t)J.n * J.n);
         HIPCK(hipMemcpy(dense[q].data(), b->ctx.mat64 + J.mat64_off, dense[q].size() * 8, hipMemcpyDeviceToHost));
     }
-    std::atomic<int> bad{0};
+    std::atomic<int> bad{0}, stream_err{0};
     std::vector<int> order(mj.size());
     for (size_t q = 0; q < mj.size(); q++) order[q] = (int)q;
     if (streaming) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return mj[x].nedges < mj[y].nedges; });
-    sq_pool(b)->parallel_for((int)mj.size(), [&](int qi) {
-        const size_t q = (size_t)order[qi];
+    // body of one job: read its result from pinned memory, RunAlgo's filters, optional hook
+    auto finish_job = [&](size_t q) {
         const size_t k = ck.k0 + q;
-        if (streaming) {                                  // wait for THIS job's mates
-            volatile uint32_t *jf = ck.job_flags + q;
-            volatile uint32_t *all = ck.flag;
-            uint64_t spins = 0;
-            while (*jf != ck.flag_val) {
-                if (bad) return;
-                if ((++spins & 0x3FFFFF) == 0 && *all == ck.flag_val && *jf != ck.flag_val) { bad = 2; return; }   // kernel over, flag missing
-#if defined(__x86_64__)
-                __builtin_ia32_pause();
-#endif
-            }
-            std::atomic_thread_fence(std::memory_order_acquire);
-        }
         const SqJob &J = b->jobs[jobs[k]];
         const int levellimit = levellimit_opt >= 0 ? levellimit_opt : 3 - (J.n > 500 ? 1 : 0);   // :1043-1044
         std::vector<BP> pairs;
         if (algo == SQ_ALGO_E) {
             const int32_t *mate = h_out_p + mj[q].out_off;
             if (mj[q].n > 0 && mate[0] == -2) { bad = 1; return; }
+            {   // measurement: the job with the most scan passes is the kernel's critical path
+                const int64_t np = mate[2 * mj[q].n], ne = mate[2 * mj[q].n + 1];
+                std::lock_guard<std::mutex> lk(b->mwm_mu);
+                b->mwm_stats[0]++; b->mwm_stats[1] += np;
+                if (np > b->mwm_stats[2]) { b->mwm_stats[2] = np; b->mwm_stats[3] = ne; b->mwm_stats[4] = mj[q].n; b->mwm_stats[5] = mj[q].nedges; }
+            }
             for (int v = 0; v < mj[q].n; v++)
                 if (mate[v] > v) pairs.push_back(BP(ck.vid2pos[q][v], ck.vid2pos[q][mate[v]]));
         } else if (algo == SQ_ALGO_N) {
@@ -369,7 +432,48 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
         }
         filter_stemset(b, J, pairs, levellimit, out[k], dense[q].empty() ? nullptr : dense[q].data());
         if (streaming) (*on_job)(k);
-    });
+    };
+    if (!streaming) {
+        sq_pool(b)->parallel_for((int)mj.size(), [&](int qi) { finish_job((size_t)order[qi]); });
+    } else {
+        // Edmonds job by job.  ONE poller (this thread) sweeps the per-job completion words and hands every group of
+        // newly finished jobs to the worker pool -- workers never spin: with several batches in flight, 32 spinning
+        // workers per batch would take every host core for the whole length of the blossom kernel.
+        std::vector<int> pending(order), ready;
+        uint64_t idle = 0;
+        while (!pending.empty() && !bad) {
+            ready.clear();
+            size_t w = 0;
+            for (int q : pending) {
+                if (*(volatile uint32_t *)(ck.job_flags + ck.sorted_pos[q]) == ck.flag_val) ready.push_back(q);
+                else pending[w++] = q;
+            }
+            pending.resize(w);
+            if (!ready.empty()) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                idle = 0;
+                if (ready.size() <= 2) for (int q : ready) finish_job((size_t)q);
+                else sq_pool(b)->parallel_for((int)ready.size(), [&](int t) { finish_job((size_t)ready[t]); }, ready.size() >= 128 ? 1 : 0);
+                continue;
+            }
+            if ((++idle & 0x3FFF) == 0) {
+                // a faulted kernel / aborted queue never writes its flags: poll the stream now and then
+                const hipError_t qe = hipStreamQuery(ck.st);
+                if (qe != hipErrorNotReady && qe != hipSuccess) { stream_err = (int)qe; bad = 3; break; }
+                if (qe == hipSuccess || *(volatile uint32_t *)ck.flag == ck.flag_val) {
+                    bool missing = false;                    // kernel over: every flag must be there now
+                    for (int q : pending) missing |= *(volatile uint32_t *)(ck.job_flags + ck.sorted_pos[q]) != ck.flag_val;
+                    if (missing) { bad = 2; break; }
+                }
+            }
+            for (int t = 0; t < 32; t++) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+        }
+    }
+    if (bad == 3) return sq_check((hipError_t)stream_err.load(), "matching kernel");
     if (bad == 2) { sq_set_error("matching kernel did not publish a job"); return 2; }
     if (bad) { sq_set_error("blossom capacity exceeded"); return -3; }
     if (!streaming && on_job) for (size_t q = 0; q < mj.size(); q++) (*on_job)(ck.k0 + q);
@@ -444,13 +548,20 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
         int rb = algo_build(b, it.jobs, it.stems, 0, it.algo, (size_t)free_rec * sizeof(SqCand), sidx, it.ck);
         if (rb) return rb;
         if (it.ck.k1 != it.jobs.size()) { it.ck = SqAlgoChunk(); return 0; }   // does not fit as one chunk: synchronous later
-        if (!b->side[sidx]) { if (sq_check(hipStreamCreateWithFlags(&b->side[sidx], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
+        const int ss = side_of(sidx);
+        if (!b->side[ss]) { if (sq_check(hipStreamCreateWithFlags(&b->side[ss], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
         const int64_t used_rec = (int64_t)((it.ck.bytes + 256 + sizeof(SqCand) - 1) / sizeof(SqCand));
         b->cand_reserved += used_rec;                   // carved downwards from the end of the arena
         char *region = (char *)(b->scan.cands + (b->cand_records - b->cand_reserved));
         region = (char *)(((uintptr_t)region + 255) & ~(uintptr_t)255);
         const double tl0 = sq_now();
-        const int r = algo_launch(b, it.ck, region, b->side[sidx]);
+        hipStream_t st2 = nullptr;
+        if (it.algo == SQ_ALGO_E && side_of(1) != ss) {               // the stream of the short kernels (created here if need be)
+            const int s2 = side_of(1);
+            if (!b->side[s2]) { if (sq_check(hipStreamCreateWithFlags(&b->side[s2], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
+            st2 = b->side[s2];
+        }
+        const int r = algo_launch(b, it.ck, region, b->side[ss], st2);
         if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] launch algo %d: %.3f ms\n", it.algo, (sq_now() - tl0) * 1e3);
         if (r) return r;
         it.staged = true;

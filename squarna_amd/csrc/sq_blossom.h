@@ -29,6 +29,7 @@ struct SqCoopSingle {
     SQ_HD void min_first(double &, int &, int) const {}
     SQ_HD void min_plain(double &) const {}
     SQ_HD int excl_scan(int cnt, int &total) const { total = cnt; return 0; }
+    SQ_HD int count_true(bool p, int &first) const { first = 0; return p ? 1 : 0; }
 };
 #ifdef __HIPCC__
 // ... or the 64 lanes of a wave.  first_true: lowest lane whose predicate holds (nl if none);
@@ -38,6 +39,12 @@ struct SqCoopWave {
     {
         const unsigned long long b = __ballot(p);
         return b ? (int)__ffsll((long long)b) - 1 : nl;
+    }
+    __device__ int count_true(bool p, int &first) const        // number of lanes whose predicate holds, and the lowest of them
+    {
+        const unsigned long long b = __ballot(p);
+        first = b ? (int)__ffsll((long long)b) - 1 : 0;
+        return (int)__popcll(b);
     }
     __device__ void min_first(double &v, int &i, int nl) const
     {
@@ -539,6 +546,7 @@ struct SqBlossom {
     // across lanes the smallest value and, among equals, the smallest iteration index.
     char *origin;             // generic address of the LDS buffer that holds edges + state (FAST runs only)
     int f_augmented, f_stop, f_break;
+    int stat_pass, stat_event;   // scan passes (one chunk of <= 64 neighbours of a popped S-vertex) and lane-0 events of the run
 #ifdef SQ_MWM_PROF
     long long pt[8]; long long pc[8];
 #define SQ_PT(k, expr) do { const long long _t0 = wall_clock64(); expr; pt[k] += wall_clock64() - _t0; } while (0)
@@ -569,6 +577,7 @@ struct SqBlossom {
             nlive = 0; nfree = 0;
             for (int b = 2 * n - 1; b >= n; b--) freeb[nfree++] = b;
         }
+        if (lane == 0) { stat_pass = 0; stat_event = 0; }
         sync();
         if (n == 0) return;
         {
@@ -596,6 +605,7 @@ struct SqBlossom {
         long long _tp = wall_clock64();
         if (lane == 0) for (int k = 0; k < 8; k++) { pt[k] = 0; pc[k] = 0; }
 #endif
+        int npass = 0, nevent = 0;                              // (wave-uniform registers; published at the end)
         for (;;) {                                              // stages
 #ifdef SQ_MWM_PROF
             if (lane == 0) pc[3]++;
@@ -660,17 +670,29 @@ struct SqBlossom {
                 sync();
                 int qn_r = qn;
                 bool stopq = f_augmented || error;
+                // The vertex BELOW the one being scanned is fetched (queue slot, adjacency bounds) while the scan's own
+                // loads are in flight: the queue is a stack that events only push onto, so unless an event happens
+                // during the scan, that vertex is the next one popped -- two dependent LDS round trips per pass
+                // (queue -> adj_off) leave the critical path.
+                int v_pre = -1, a0_pre = 0, aend_pre = 0;
                 while (qn_r > 0 && !stopq) {
 #ifdef SQ_MWM_PROF2
                     const long long _q0 = wall_clock64();
 #endif
-                    const int v = queue_[--qn_r];
-                    int a0 = adj_off_[v];
-                    const int aend = adj_off_[v + 1];
+                    --qn_r;
+                    int v, a0, aend;
+                    if (v_pre >= 0) { v = v_pre; a0 = a0_pre; aend = aend_pre; }
+                    else { v = queue_[qn_r]; a0 = adj_off_[v]; aend = adj_off_[v + 1]; }
+                    const bool pre_ok = qn_r > 0;
+                    const int vn = queue_[pre_ok ? qn_r - 1 : 0];
+                    const int a0n = adj_off_[pre_ok ? vn : 0], aendn = adj_off_[pre_ok ? vn + 1 : 0];
+                    bool had_event = false;
+                    v_pre = -1;
 #ifdef SQ_MWM_PROF
                     if (lane == 0) { pc[1]++; pc[0] += aend - a0; }
 #endif
                     while (a0 < aend) {
+                        npass++;
 #ifdef SQ_MWM_PROF
                         if (lane == 0) pc[5]++;
 #endif
@@ -710,17 +732,28 @@ struct SqBlossom {
                             if (cat == 2) { label_[w] = 2; labeledge_[w] = de; }
                             else if (cat == 3) { if (be_w == -1 || ks < s_bew) { bestedge_[w] = de; bslack_[w] = ks; } }
                         }
-                        if (coop.first_true(lane < f && cat == 4, nl) < nl) {      // somebody competes for bestedge[bv]
-                            double mv = ks; int mi = (lane < f && cat == 4) ? lane : nl;
-                            coop.min_first(mv, mi, nl);
-                            if (lane == 0) {
-                                if (be_bv == -1 || mv < s_bebv) { bestedge_[bv] = adj_[a0 + mi]; bslack_[bv] = mv; }
+                        {
+                            // competitors for bestedge[bv]: sequentially "first strictly smaller slack wins", i.e. the
+                            // lexicographic (slack, position) minimum among the neighbours that beat the CURRENT best.
+                            // bestedge[bv] only improves during a stage, so after the first passes usually nobody
+                            // does and the pass ends here; one competitor writes directly; several are reduced.
+                            const bool comp = lane < f && cat == 4 && (be_bv == -1 || ks < s_bebv);
+                            int cfirst;
+                            const int ccount = coop.count_true(comp, cfirst);
+                            if (ccount == 1) {
+                                if (lane == cfirst) { bestedge_[bv] = de; bslack_[bv] = ks; }
+                            } else if (ccount > 1) {
+                                double mv = ks; int mi = comp ? lane : nl;
+                                coop.min_first(mv, mi, nl);
+                                if (lane == 0) { bestedge_[bv] = adj_[a0 + mi]; bslack_[bv] = mv; }
                             }
                         }
 #ifdef SQ_MWM_PROF2
                         if (lane == 0) pt[2] += wall_clock64() - _q1;
 #endif
                         if (f >= nl) { a0 += nl; continue; }
+                        had_event = true;
+                        nevent++;
                         if (lane == 0) qn = qn_r;
                         sync();
 #ifdef SQ_MWM_PROF
@@ -762,6 +795,9 @@ struct SqBlossom {
                         if (stopq) break;
                         a0 += f + 1;
                     }
+#ifndef SQ_MWM_NOPREFETCH
+                    if (pre_ok && !had_event) { v_pre = vn; a0_pre = a0n; aend_pre = aendn; }
+#endif
                 }
                 if (lane == 0) qn = qn_r;
                 sync();
@@ -858,6 +894,8 @@ struct SqBlossom {
 #endif
             if (error) break;
         }
+        if (lane == 0) { stat_pass = npass; stat_event = nevent; }
+        sync();
 #ifdef SQ_MWM_PROF
 #ifdef __HIP_DEVICE_COMPILE__
         if (lane == 0 && n >= 140)

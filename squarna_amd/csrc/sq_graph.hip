@@ -58,7 +58,7 @@ int build_graphs(int32_t ngraph, const int64_t *edge_off, const int32_t *eu, con
         }
         J.n = (int32_t)lab.size(); J.nedges = (int32_t)(G.edges.size() - (size_t)J.edge_off);
         J.scratch_off = (int64_t)G.scratch; G.scratch += up256(sq_mwm_scratch_bytes(J.n, J.nedges));
-        J.out_off = (int64_t)G.outints; G.outints += 2 * (size_t)J.n;
+        J.out_off = (int64_t)G.outints; G.outints += 2 * (size_t)J.n + 2;
     }
     return 0;
 }

@@ -65,7 +65,7 @@ struct ProfSlot {
 // takes part.  Results never depend on the schedule (every index writes its own slot).
 class SqPool {
 public:
-    explicit SqPool(int nthreads);
+    explicit SqPool(int nthreads, int device = -1);
     ~SqPool();
     // callers are serialised (two fold lanes share the pool).  The workers form two groups: the first 15 serve every
     // call, the rest only wide ones (wide < 0: n >= 512) -- waking 31 threads for a few hundred short items costs
@@ -103,6 +103,7 @@ struct SqLane {
 
 struct sq_batch {
     hipStream_t stream = nullptr;
+    int device = -1;                          // device current at sq_batch_create (adopted by every spawned thread)
     // host copies
     int32_t nseq = 0, npset = 0, njobs = 0, maxn = 0;
     int64_t ltot = 0;
@@ -131,6 +132,7 @@ struct sq_batch {
     hipStream_t lane_stream = nullptr;        // second lane of sq_fold's greedy rounds (created on first use)
     hipEvent_t lane_ev = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
+    hipEvent_t class_ev = nullptr;        // joins the blossom kernel's smaller size classes (on side[1]) into side[0]
     uint32_t out_cap = 0;
     int32_t strand_cap = 0;
     size_t mat32_bytes = 0;
@@ -153,6 +155,9 @@ struct sq_batch {
     SqLane lane_full, lane_half[2];       // see SqLane
     SqCounters *h_ctr2 = nullptr; uint32_t *h_seq2 = nullptr;   // pinned counters / sequence word of the second lane
     // profiling
+    std::mutex mwm_mu;
+    int64_t mwm_stats[6] = {0, 0, 0, 0, 0, 0};   // blossom jobs collected, their scan passes; the job with the most passes:
+                                                 // its passes, events, vertices, edges (reset by sq_profile_reset)
     bool prof_on = false;
     ProfSlot prof[7];                     // 0 fill, 1 state, 2 scan, 3 score, 4 Edmonds, 5 Hungarian, 6 Nussinov
 };

@@ -29,12 +29,13 @@ int sq_check(hipError_t e, const char *what)
 #define HIPCK(x) do { int _r = sq_check((x), #x); if (_r) return _r; } while (0)
 
 // ---- host worker pool -------------------------------------------------------------------------
-SqPool::SqPool(int nthreads)
+SqPool::SqPool(int nthreads, int device)
 {
     for (int t = 1; t < nthreads; t++) {
         const int group = t <= 15 ? 0 : 1;
         group_size[group]++;
-        workers.emplace_back([this, group] { worker(group); });
+        // (workers call into HIP -- stream queries, copies of dense matrices: they work on the batch's device)
+        workers.emplace_back([this, group, device] { if (device >= 0) hipSetDevice(device); worker(group); });
     }
 }
 SqPool::~SqPool()
@@ -84,7 +85,7 @@ SqPool *sq_pool(sq_batch *b)
         if (const char *lws = getenv("LOCAL_WORLD_SIZE")) cores = std::max(1u, cores / (unsigned)std::max(1, atoi(lws)));
         int nthr = (int)std::min(cores, 32u);
         if (const char *e = getenv("SQ_HOST_THREADS")) nthr = std::max(1, atoi(e));
-        b->pool = new SqPool(nthr);
+        b->pool = new SqPool(nthr, b->device);
     }
     return b->pool;
 }
@@ -116,7 +117,8 @@ int sq_pinned_get(void **p, size_t bytes)
             return 0;
         }
     }
-    const int r = sq_check(hipHostMalloc(p, want, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc");
+    // portable: the cache is process-wide, a buffer may be reused by a batch on another device
+    const int r = sq_check(hipHostMalloc(p, want, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable), "hipHostMalloc");
     if (r) { *p = nullptr; return r; }
     std::lock_guard<std::mutex> lk(g_pinned.mu);
     g_pinned.live[*p] = want;
@@ -270,6 +272,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     }
     sq_batch *b = new sq_batch();
     b->stream = (hipStream_t)hip_stream;
+    if (hipGetDevice(&b->device) != hipSuccess) b->device = -1;      // the caller's current device: every thread the library spawns adopts it
     b->nseq = d->nseq; b->npset = d->npset; b->njobs = d->njobs; b->maxn = L.maxn; b->ltot = L.ltot;
     b->seq_off.assign(d->seq_off, d->seq_off + d->nseq + 1);
     b->codes.assign(d->codes, d->codes + L.ltot);
@@ -506,6 +509,7 @@ extern "C" void sq_batch_destroy(sq_batch *b)
     hipStreamSynchronize(b->stream);
     for (int k = 0; k < 3; k++) if (b->side[k]) { hipStreamSynchronize(b->side[k]); hipStreamDestroy(b->side[k]); }
     if (b->lane_stream) { hipStreamSynchronize(b->lane_stream); hipStreamDestroy(b->lane_stream); }
+    if (b->class_ev) hipEventDestroy(b->class_ev);
     sq_pinned_put(b->h_structs); sq_pinned_put(b->h_strands); sq_pinned_put(b->h_ctr); sq_pinned_put(b->h_seq);
     sq_pinned_put(b->h_ctr2); sq_pinned_put(b->h_seq2); sq_pinned_put(b->h_out);
     for (int k = 0; k < 4; k++) sq_pinned_put(b->stage_buf[k]);
@@ -576,6 +580,14 @@ extern "C" int sq_profile_reset(sq_batch *b)
     hipStreamSynchronize(b->stream);
     prof_collect(b);
     for (auto &p : b->prof) { p.ms = 0; p.launches = 0; p.bytes = 0; }
+    { std::lock_guard<std::mutex> lk(b->mwm_mu); for (int64_t &x : b->mwm_stats) x = 0; }
+    return 0;
+}
+extern "C" int sq_profile_counters(sq_batch *b, int32_t kernel, int64_t out[6])
+{
+    if (!b || !out || kernel != 4) { sq_set_error("counters exist for kernel 4 (Edmonds) only"); return -1; }
+    std::lock_guard<std::mutex> lk(b->mwm_mu);
+    for (int k = 0; k < 6; k++) out[k] = b->mwm_stats[k];
     return 0;
 }
 extern "C" int sq_profile_get(sq_batch *b, int32_t k, double *ms, int64_t *launches, double *bytes)
@@ -1199,6 +1211,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         for (int j = 0; j < b->njobs; j++) if (!pools[j].cur.empty()) g_left[b->job_seq[j]]++;
         sq_pool(b);
         tq.worker = std::thread([&] {
+            if (b->device >= 0) hipSetDevice(b->device);
             for (;;) {
                 std::vector<int> take;
                 {
@@ -1333,7 +1346,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             HIPCK(hipStreamWaitEvent(b->lane_stream, b->lane_ev, 0));
             b->lane_half[1].stream = b->lane_stream;
         } else b->lane_half[1].stream = nullptr;
-        std::thread other([&] { greedy_loop(b->lane_half[1], part[1], st1); });
+        std::thread other([&] { if (b->device >= 0) hipSetDevice(b->device); greedy_loop(b->lane_half[1], part[1], st1); });
         greedy_loop(b->lane_half[0], part[0], st0);
         other.join();
         if (!st0.rc && st1.rc) { st0.rc = st1.rc; st0.err = st1.err; }
@@ -1417,6 +1430,7 @@ extern "C" int sq_fold_concurrent(sq_batch *const *batches, int32_t nbatch, cons
     std::vector<int> rc(nbatch, 0);
     std::vector<std::string> msg(nbatch);
     auto work = [&](int k) {
+        if (k > 0 && batches[k]->device >= 0) hipSetDevice(batches[k]->device);
         rc[k] = sq_fold(batches[k], opts, ref_off ? ref_off[k] : nullptr, ref_pairs ? ref_pairs[k] : nullptr,
                         has_ref ? has_ref[k] : nullptr);
         if (rc[k]) msg[k] = sq_last_error();                 // (the error text is per thread)

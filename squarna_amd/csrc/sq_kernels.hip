@@ -87,8 +87,8 @@ extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c, int
                 }
                 bits = __float_as_uint((float)v);
                 if (bits == SQ_SENT_BITS) bits = 0x7FC00001u;   // a genuine NaN value stays "present"
-            } else if (m64 && i < n && j < n) {
-                m64[(int64_t)i * n + j] = 0.0;
+            } else if (m64 && i < n && j < n && !jb.ext_add) {
+                m64[(int64_t)i * n + j] = 0.0;          // (an ADDED term stays where bool == 0: scoremat += term covers every cell, :352)
             }
             out[k] = __uint_as_float(bits);
             if (++j == ld) { j = 0; i++; }
@@ -1264,7 +1264,17 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
 {
     __shared__ SqStrand s_str[FULL ? SQ_LDS_STRANDS : 1];
     __shared__ uint16_t s_skip[FULL ? SQ_LDS_STRANDS : 1];   // 5' strand k closes a block: next strand that can matter after it
-    __shared__ double s_w[32 * 32];               // pair weights of the job's paramset
+    // Cell values from ONE table: every position carries a combined index ci = class * R + level (class: rank of its
+    // letter among the letters the paramset pairs, one extra class for all others; level: index of its reactivity
+    // among the sequence's <= 16 distinct values, R = 1 without reactivity factors), and
+    //     s_cell[ci_i * cstride + ci_j] = w * reactfactor   (the very expression of sq_cell_score, built once per block).
+    // A cell then costs two byte reads and one table read.  The 32 x 32 weight table this replaces had a row stride
+    // of 256 bytes = the whole bank span, so the pairs of the four letters sat on four bank pairs (4-way conflicts,
+    // 72 % of the LDS-busy cycles of the kernel, profiles/r01k_score_pmc_*); the compact table's odd stride spreads
+    // the <= (K R)^2 live entries over all banks.  Arbitrary float reactivities: weights from the table (R = 1), the
+    // factor per cell as before.
+    __shared__ double s_cell[32 * 33];
+    __shared__ uint8_t s_cls[32];
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];   // letter codes [n] (+ reactivities [n] when they fit)
     const SqStruct st = structs[blockIdx.x];
     const SqJob jb = c.jobs[st.job];
@@ -1303,7 +1313,6 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     const int16_t *U = stt.U + (int64_t)st.slot * stt.stride;
     const int16_t *SU = stt.SU + (int64_t)st.slot * stt.stride;
     // the exact re-scoring touches codes / weights / reactivities once per cell: keep them in LDS
-    uint8_t *l_codes = reinterpret_cast<uint8_t *>(s_dyn);
     double *l_reacts = reinterpret_cast<double *>(s_dyn + ((n + 15) & ~15));
     // ScoreStems walks the partner array and reads the prefix counts with dependent loads: LDS copies when they
     // fit (3 x int16 per position, after the codes and reactivities of the launch's longest sequence)
@@ -1320,35 +1329,60 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     }
     const bool lds_cells = jb.mat64_off < 0 && lds_n >= n;
     const bool lds_reacts = lds_cells && !jb.default_reacts && lds_n_reacts >= n;
-    // few distinct reactivity values (encoded input): reactfactor[level_i][level_j] tables, built once per block with
-    // the very expressions of the per-cell path, and a level index per position in place of the fp64 reactivities
-    const bool react_tab = lds_reacts && jb.react_levels > 0;
-    __shared__ double s_rv[16], s_rf0[256], s_rf1[256];
-    uint8_t *l_ridx = reinterpret_cast<uint8_t *>(l_reacts);
+    // classes of the letters: K pairing letters + one class for everything else
+    uint32_t lmask = 0;
     if (lds_cells) {
-        for (int p = tid; p < n; p += nthr) l_codes[p] = c.codes[jb.pos_off + p];
-        for (int p = tid; p < 32 * 32; p += nthr) s_w[p] = ps->w[p];
-        if (react_tab) {
-            for (int p = tid; p < n; p += nthr) {
-                const uint8_t q = c.ridx[jb.pos_off + p];
-                l_ridx[p] = q;
-                s_rv[q] = c.reacts[jb.pos_off + p];                     // (all writers of a level store the same value)
-            }
-        } else if (lds_reacts) for (int p = tid; p < n; p += nthr) l_reacts[p] = c.reacts[jb.pos_off + p];
+        // (every thread scans the same 1 KB of inbps through the scalar / L1 path; 32 x 32 bytes, once per block)
+        const uint32_t *ib = reinterpret_cast<const uint32_t *>(ps->inbps);
+        for (int a8 = 0; a8 < 32; a8++) {
+            uint32_t any8 = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) any8 |= ib[a8 * 8 + q];
+            if (any8) lmask |= 1u << a8;
+        }
+    }
+    const int K = __popc(lmask) + 1;
+    // few distinct reactivity values (encoded input): level index per position, reactfactors folded into the table
+    const bool react_tab = lds_reacts && jb.react_levels > 0 && K * jb.react_levels <= 32;
+    const int R = react_tab ? jb.react_levels : 1;
+    const int KR = K * R, cstride = KR | 1;
+    const bool cell_tab = lds_cells && (jb.default_reacts || react_tab);     // the table holds the final cell value
+    __shared__ double s_rv[16];
+    uint8_t *l_ci = reinterpret_cast<uint8_t *>(s_dyn);                       // combined index per position
+    if (lds_cells) {
+        if (tid < 32) s_cls[tid] = (lmask >> tid) & 1u ? (uint8_t)__popc(lmask & ((1u << tid) - 1u)) : (uint8_t)(K - 1);
+        if (react_tab)
+            for (int p = tid; p < n; p += nthr) s_rv[c.ridx[jb.pos_off + p]] = c.reacts[jb.pos_off + p];   // (all writers of a level store the same value)
+        else if (lds_reacts) for (int p = tid; p < n; p += nthr) l_reacts[p] = c.reacts[jb.pos_off + p];
     }
     __syncthreads();
-    if (react_tab) {
-        for (int e = tid; e < 256; e += nthr) {
-            const int qa = e >> 4, qb = e & 15;
-            double rf = 1.0, inv = 1.0;
-            if (qa < jb.react_levels && qb < jb.react_levels) {
-                rf = sqrt((1.0 - (s_rv[qa] + s_rv[qb]) / 2.0) * 2.0);
-                inv = 1.0 / (rf > 0.01 ? rf : 0.01);
-            }
-            s_rf0[e] = rf; s_rf1[e] = inv;
+    if (lds_cells) {
+        for (int p = tid; p < n; p += nthr) {
+            const int cl = s_cls[c.codes[jb.pos_off + p] & 31];
+            l_ci[p] = (uint8_t)(react_tab ? cl * R + c.ridx[jb.pos_off + p] : cl);
         }
-        __syncthreads();
+        for (int e = tid; e < KR * KR; e += nthr) {
+            const int ci = e / KR, cj = e - ci * KR;
+            const int ca = ci / R, cb = cj / R;
+            // letter code of a class: the ca-th set bit of lmask (class K-1: any letter without pairs, weight 0 with everything)
+            int la = 31, lb = 31;
+            {
+                uint32_t m = lmask; for (int t = 0; t < ca && m; t++) m &= m - 1;
+                la = ca < K - 1 ? __ffs((int)m) - 1 : -1;
+                m = lmask; for (int t = 0; t < cb && m; t++) m &= m - 1;
+                lb = cb < K - 1 ? __ffs((int)m) - 1 : -1;
+            }
+            const double w = (la >= 0 && lb >= 0) ? ps->w[la * 32 + lb] : 0.0;
+            double v = w;                                                   // default reactivities: w * 1 (and 1/1)
+            if (react_tab) {
+                double rf = sqrt((1.0 - (s_rv[ci - ca * R] + s_rv[cj - cb * R]) / 2.0) * 2.0);
+                if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
+                v = w * rf;
+            }
+            s_cell[ci * cstride + cj] = v;
+        }
     }
+    __syncthreads();
     const uint8_t *codes = c.codes + jb.pos_off;
     const SqKey *keys = sq_keys(a, st);
     SqOk *oks = sq_oks(a, st, jb.cand_cap);
@@ -1357,13 +1391,9 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     const double minbps = ps->minbpscore, minfin = ps->minfinscore;
     auto cell_exact = [&](int i, int j) -> double {
         if (!lds_cells) return sq_cell_exact(c, jb, ps, i, j);
-        const double w = s_w[l_codes[i] * 32 + l_codes[j]];             // same expression as sq_cell_score
-        if (jb.default_reacts) return w;                                // (no fp64 division for the w <= 0 cells)
-        if (react_tab) {
-            const int e = l_ridx[i] * 16 + l_ridx[j];
-            return w * (w <= 0 ? s_rf1[e] : s_rf0[e]);
-        }
-        const double ri = lds_reacts ? l_reacts[i] : c.reacts[jb.pos_off + i];
+        const double w = s_cell[l_ci[i] * cstride + l_ci[j]];             // cell_tab: the cell itself
+        if (cell_tab) return w;
+        const double ri = lds_reacts ? l_reacts[i] : c.reacts[jb.pos_off + i];   // same expression as sq_cell_score
         const double rj = lds_reacts ? l_reacts[j] : c.reacts[jb.pos_off + j];
         double rf = sqrt((1.0 - (ri + rj) / 2.0) * 2.0);
         if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);

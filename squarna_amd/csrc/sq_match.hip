@@ -250,7 +250,8 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
 // ------------------------------------------------------------------------------------
 // job_flags (pinned host memory, may be null): job_flags[job] = stamp once the job's mates are in host memory, so the
 // host can filter and rank a sequence while the larger graphs are still being matched.
-// mate_out: per job 2n ints -- mate[0..n) and the rank of every vertex's first mate assignment (SqBlossom::mord)
+// mate_out: per job 2n + 2 ints -- mate[0..n), the rank of every vertex's first mate assignment (SqBlossom::mord), then
+// the run's scan passes and lane-0 events (measurement: the critical path of the kernel is passes x cycles per pass)
 extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges,
                                                                char *scratch, int32_t *mate_out, int lds_bytes,
                                                                uint32_t *job_flags, uint32_t stamp)
@@ -264,7 +265,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
     extern __shared__ __attribute__((aligned(16))) char mwm_lds[];
     const SqMatchJob *jp = jobs + blockIdx.x;
     const int n = jp->n, m = jp->nedges, lane = threadIdx.x;
-    if (n <= 0) { publish(); return; }
+    if (n <= 0) { if (lane == 0) { mate_out[jp->out_off] = 0; mate_out[jp->out_off + 1] = 0; } publish(); return; }
     // The algorithm is a long chain of dependent loads: keep its state in LDS -- all of it with the edge list when
     // that fits (tight capacities), else only the hot part (what every scan pass touches; blossom structure and
     // adjacency stay in global memory); on a capacity overflow rerun the job in global memory.
@@ -297,6 +298,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
         __syncthreads();
         if (!bl.error) {
             for (int q = lane; q < n; q += 64) { mate_out[jp->out_off + q] = bl.mate[q]; mate_out[jp->out_off + n + q] = bl.mord[q]; }
+            if (lane == 0) { mate_out[jp->out_off + 2 * n] = bl.stat_pass; mate_out[jp->out_off + 2 * n + 1] = bl.stat_event; }
 #ifdef SQ_MWM_PROF
             if (lane == 0 && n >= 140) {
                 const long long dc = clock64() - _c0, dw = wall_clock64() - _w0;
@@ -315,6 +317,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob 
     bl.run<0>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), nullptr);
     __syncthreads();
     for (int q = lane; q < n; q += 64) { mate_out[jp->out_off + q] = bl.error ? -2 : bl.mate[q]; mate_out[jp->out_off + n + q] = bl.mord[q]; }
+    if (lane == 0) { mate_out[jp->out_off + 2 * n] = bl.stat_pass; mate_out[jp->out_off + 2 * n + 1] = bl.stat_event; }
     publish();
 }
 

@@ -377,6 +377,13 @@ class Batch:
     def profile_reset(self):
         self.L.sq_profile_reset(self.h)
 
+    def mwm_counters(self):
+        """Blossom kernel work since the last profile_reset: dict(graphs, passes, and the critical graph's
+        max_passes, max_events, n, m) -- sq_profile_counters."""
+        out = (C.c_int64 * 6)()
+        _lib.check(self.L.sq_profile_counters(self.h, 4, out))
+        return dict(zip(("graphs", "passes", "max_passes", "max_events", "n", "m"), [int(x) for x in out]))
+
     def profile_get(self, kernel):
         ms, n, by = C.c_double(), C.c_int64(), C.c_double()
         _lib.check(self.L.sq_profile_get(self.h, kernel, C.byref(ms), C.byref(n), C.byref(by)))

@@ -44,7 +44,7 @@ def gen():
     # ---- BPMatrix with a probability term: multiply (p > 0), add (p < 0), both zero branches (len % 11 == 3 / 7)
     for n, power, kind in [(24, 0.5, ""), (24, -1.0, ""), (31, 0.5, "r"), (31, -1.0, "r"), (40, 2.0, "x"),
                            (25, 0.5, ""), (25, -1.0, "r"), (29, 0.5, ""), (29, -1.0, ""), (36, -0.5, "s"),
-                           (33, 1.0, "rx")]:
+                           (33, 1.0, "rx"), (38, -1.0, "x"), (35, -0.5, "rx")]:   # (added term + restraints: cells with bool == 0 get it too)
         seq = rnd_seq(rng, n)
         if "s" in kind:
             seq = seq[:n // 2] + "&" + seq[n // 2 + 1:]
