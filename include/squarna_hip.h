@@ -229,6 +229,10 @@ SQ_API int sq_result_metrics(const sq_batch *b, int32_t seq, double cons[6], dou
  * sq_result_pack_size returns the bytes needed. */
 SQ_API int64_t sq_result_pack_size(const sq_batch *b, int32_t seq);
 SQ_API int sq_result_pack(const sq_batch *b, int32_t seq, void *buf, int64_t cap);
+/* Every sequence of the batch in one call (the payload of the multi-GPU result gather): record s occupies
+ * [off[s], off[s+1]) of buf, off has nseq + 1 entries, records start 8-byte aligned. */
+SQ_API int64_t sq_result_pack_all_size(const sq_batch *b);
+SQ_API int sq_result_pack_all(const sq_batch *b, void *buf, int64_t cap, int64_t *off);
 /* R = number of AnnotateStems evaluations the reference algorithm performs for this sequence. */
 SQ_API int64_t sq_result_evals(const sq_batch *b, int32_t seq);
 

@@ -112,6 +112,7 @@ struct sq_batch {
     std::vector<double> reacts;
     std::vector<sq_paramset> psets;
     std::vector<char> pset_dyadic;            // all pair weights are multiples of 2^-10 below 1024 (exact sums in any order)
+    std::vector<int> pset_classes;            // letter classes of the scoring kernel's cell table: pairing letters + 1
     std::vector<SqJob> jobs;
     int32_t interchainonly = 0;
     int32_t nletters = 0;                     // distinct letter codes of the batch (sq_bits_masks_kernel)

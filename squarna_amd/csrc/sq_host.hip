@@ -340,6 +340,13 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
                 dy = std::fabs(x.w[q]) <= 1024.0 && w == std::floor(w);
             }
             b->pset_dyadic.push_back(dy ? 1 : 0);
+            int kletters = 0;                                            // letters with at least one pair (+ 1 class for the rest)
+            for (int a = 0; a < 32; a++) {
+                bool any = false;
+                for (int q = 0; q < 32; q++) any |= ps.inbps[a * 32 + q] != 0;
+                kletters += any ? 1 : 0;
+            }
+            b->pset_classes.push_back(kletters + 1);
         }
         const double bw = ps.bracketweight;
         x.bw_integral = (bw == std::floor(bw) && std::fabs(bw) <= 64) ? 1 : 0;
@@ -814,6 +821,7 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
 {
     const int S = (int)(hi - lo);
     int nstrand = 0, maxn = 0; int64_t cand_off = ln.cand0, maxcap = 0; double scan_bytes = 0;
+    bool need_reacts = false;       // some job computes its reactivity factors per cell (float reactivities, or too many levels for the cell table)
     double tp0 = now_s();
     for (int s = 0; s < S; s++) {
         const SView &hs = structs[lo + s];
@@ -825,6 +833,7 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
         if (d.nstrand) memcpy(ln.h_strands + nstrand, hs.st->strands.data(), sizeof(SqStrand) * (size_t)d.nstrand);
         nstrand += d.nstrand;
         maxn = std::max(maxn, J.n);
+        need_reacts |= !J.default_reacts && !(J.react_levels > 0 && b->pset_classes[J.pset] * J.react_levels <= 32);
         scan_bytes += 2.0 * J.n * J.n;                     // algorithmic: fp32 upper triangle, N^2/2 cells
     }
     hipStream_t st = ln.stream ? ln.stream : b->stream;
@@ -863,7 +872,9 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
         // dynamic LDS: letter codes of the longest sequence, plus its reactivities when they fit in 32 KiB
         const int lds_n = maxn <= 16384 ? maxn : 0;
         static const int nr_lim = getenv("SQ_SCORE_NR_LIM") ? atoi(getenv("SQ_SCORE_NR_LIM")) : 4096;
-        const int lds_nr = maxn <= nr_lim ? maxn : 0;
+        // (only when some job needs them: sequences whose reactivities go through the cell table leave the room to the
+        // partner / prefix arrays -- S2000 with encoded SHAPE: 16 KB that pushed those arrays out to global memory)
+        const int lds_nr = need_reacts && maxn <= nr_lim ? maxn : 0;
         // partner / prefix arrays (3 x int16) too, while a block stays small enough for four blocks per CU
         // (the reactivity case is bound by fp64 sqrt/div throughput and prefers the occupancy)
         static const size_t state_lim = getenv("SQ_SCORE_STATE_LIM") ? (size_t)atol(getenv("SQ_SCORE_STATE_LIM")) : 24 * 1024;
@@ -1506,5 +1517,29 @@ extern "C" int sq_result_pack(const sq_batch *b, int32_t seq, void *buf, int64_t
     for (int64_t k = 0; k < ns; k++) { memcpy(p, &R.preds[k].pset_mask, 8); p += 8; }
     memcpy(p, R.cons.data(), 2 * n); p += 2 * n;
     for (int64_t k = 0; k < ns; k++) { memcpy(p, R.preds[k].levels.data(), 2 * n); p += 2 * n; }
+    return 0;
+}
+
+// all sequences of the batch in one call: record s occupies [off[s], off[s+1]) of buf (sq_result_pack layout)
+extern "C" int64_t sq_result_pack_all_size(const sq_batch *b)
+{
+    if (!b) return -1;
+    int64_t tot = 0;
+    for (int s = 0; s < b->nseq; s++) tot += (sq_result_pack_size(b, s) + 7) & ~(int64_t)7;
+    return tot;
+}
+extern "C" int sq_result_pack_all(const sq_batch *b, void *buf, int64_t cap, int64_t *off)
+{
+    if (!b || !buf || !off) { sq_set_error("bad argument"); return -1; }
+    int64_t o = 0;
+    for (int s = 0; s < b->nseq; s++) {
+        const int64_t need = sq_result_pack_size(b, s);
+        off[s] = o;
+        if (o + need > cap) { sq_set_error("result buffer too small"); return -1; }
+        const int r = sq_result_pack(b, s, (char *)buf + o, cap - o);
+        if (r) return r;
+        o += (need + 7) & ~(int64_t)7;
+    }
+    off[b->nseq] = o;
     return 0;
 }

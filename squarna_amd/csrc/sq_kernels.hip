@@ -1328,22 +1328,26 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
         P = lP; U = lU; SU = lSU;
     }
     const bool lds_cells = jb.mat64_off < 0 && lds_n >= n;
-    const bool lds_reacts = lds_cells && !jb.default_reacts && lds_n_reacts >= n;
-    // classes of the letters: K pairing letters + one class for everything else
-    uint32_t lmask = 0;
-    if (lds_cells) {
-        // (every thread scans the same 1 KB of inbps through the scalar / L1 path; 32 x 32 bytes, once per block)
-        const uint32_t *ib = reinterpret_cast<const uint32_t *>(ps->inbps);
-        for (int a8 = 0; a8 < 32; a8++) {
-            uint32_t any8 = 0;
+    const bool any_reacts = lds_cells && !jb.default_reacts;
+    // classes of the letters: K pairing letters + one class for everything else.  lmask: bit a set iff letter a has a
+    // pair in the paramset (row a of inbps is not all zero) -- the first 32 threads test a row each, one ballot
+    __shared__ uint32_t s_lmask;
+    if (lds_cells && tid < 64) {
+        uint32_t any8 = 0;
+        if (tid < 32) {
+            const uint32_t *ib = reinterpret_cast<const uint32_t *>(ps->inbps) + tid * 8;
 #pragma unroll
-            for (int q = 0; q < 8; q++) any8 |= ib[a8 * 8 + q];
-            if (any8) lmask |= 1u << a8;
+            for (int q = 0; q < 8; q++) any8 |= ib[q];
         }
+        const unsigned long long bal = __ballot(any8 != 0);
+        if (tid == 0) s_lmask = (uint32_t)bal;
     }
+    __syncthreads();
+    const uint32_t lmask = lds_cells ? s_lmask : 0u;
     const int K = __popc(lmask) + 1;
     // few distinct reactivity values (encoded input): level index per position, reactfactors folded into the table
-    const bool react_tab = lds_reacts && jb.react_levels > 0 && K * jb.react_levels <= 32;
+    const bool react_tab = any_reacts && jb.react_levels > 0 && K * jb.react_levels <= 32;   // (the host sizes LDS by the same rule)
+    const bool lds_reacts = any_reacts && !react_tab && lds_n_reacts >= n;                    // per-cell factors from LDS copies
     const int R = react_tab ? jb.react_levels : 1;
     const int KR = K * R, cstride = KR | 1;
     const bool cell_tab = lds_cells && (jb.default_reacts || react_tab);     // the table holds the final cell value

@@ -367,6 +367,15 @@ class Batch:
             return cons, preds, consres, res
         return cons, preds, [np.nan] * 6, [np.nan] * 7
 
+    def pack_all(self):
+        """(uint8 array, int64 offsets[nseq + 1]): the packed results of every record (sq_result_pack_all) -- the
+        payload of the multi-GPU result gather."""
+        nbytes = int(self.L.sq_result_pack_all_size(self.h))
+        buf = np.zeros(max(nbytes, 8), np.uint8)
+        off = np.zeros(self.nseq + 1, np.int64)
+        _lib.check(self.L.sq_result_pack_all(self.h, _ptr(buf), nbytes, _ptr(off)))
+        return buf[:nbytes], off
+
     def evals(self, k):
         return int(self.L.sq_result_evals(self.h, k))
 
