@@ -27,7 +27,7 @@
 struct SqCoopSingle {
     SQ_HD int first_true(bool p, int nl) const { return p ? 0 : nl; }
     SQ_HD void min_first(double &, int &, int) const {}
-    SQ_HD void min_plain(double &) const {}
+    SQ_HD void min_plain(double &, int = 64) const {}
     SQ_HD int excl_scan(int cnt, int &total) const { total = cnt; return 0; }
     SQ_HD int count_true(bool p, int &first) const { first = 0; return p ? 1 : 0; }
 };
@@ -46,44 +46,72 @@ struct SqCoopWave {
         first = b ? (int)__ffsll((long long)b) - 1 : 0;
         return (int)__popcll(b);
     }
+    // Wave-wide minima with DPP row shifts / row broadcasts (the gfx9 scan sequence: row_shr 1, 2, 4, 8, row_bcast 15
+    // and 31 leave the reduction of all 64 lanes in lane 63): VALU only, no LDS crossbar.  The 6-step __shfl_xor
+    // reductions these replace cost three ds_bpermute per step for a (double, index) pair; measured with cycle
+    // counters on the largest SRtest150 graph, that reduction was 45 % of the kernel's time (it runs on almost every
+    // scan pass: a freshly popped vertex is its own blossom with no best edge yet, so every S-neighbour competes).
+    template <int CTRL, int ROWMASK>
+    static __device__ __forceinline__ double dpp_f64(double ident, double v)
+    {
+        const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROWMASK, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
+    // every lane gets the minimum over lanes [0, nlive) (no NaNs); lanes >= nlive must hold +inf or be ignorable:
+    // with nlive <= 16 the first DPP row already holds everything (4 steps), with <= 32 the first two rows (5 steps)
+    static __device__ __forceinline__ double wave_min_f64(double v, int nlive = 64)
+    {
+        const double inf = __longlong_as_double(0x7FF0000000000000ll);
+        double o;
+        o = dpp_f64<0x111, 0xf>(inf, v); v = o < v ? o : v;
+        o = dpp_f64<0x112, 0xf>(inf, v); v = o < v ? o : v;
+        o = dpp_f64<0x114, 0xf>(inf, v); v = o < v ? o : v;
+        o = dpp_f64<0x118, 0xf>(inf, v); v = o < v ? o : v;
+        int src = 15;
+        if (nlive > 16) {
+            o = dpp_f64<0x142, 0xa>(inf, v); v = o < v ? o : v;
+            src = 31;
+            if (nlive > 32) {
+                o = dpp_f64<0x143, 0xc>(inf, v); v = o < v ? o : v;
+                src = 63;
+            }
+        }
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+        return __hiloint2double(hi, lo);
+    }
+    static __device__ __forceinline__ int wave_min_i32(int v)
+    {
+        const int big = 0x7fffffff;
+        int o;
+        o = __builtin_amdgcn_update_dpp(big, v, 0x111, 0xf, 0xf, false); v = o < v ? o : v;
+        o = __builtin_amdgcn_update_dpp(big, v, 0x112, 0xf, 0xf, false); v = o < v ? o : v;
+        o = __builtin_amdgcn_update_dpp(big, v, 0x114, 0xf, 0xf, false); v = o < v ? o : v;
+        o = __builtin_amdgcn_update_dpp(big, v, 0x118, 0xf, 0xf, false); v = o < v ? o : v;
+        o = __builtin_amdgcn_update_dpp(big, v, 0x142, 0xa, 0xf, false); v = o < v ? o : v;
+        o = __builtin_amdgcn_update_dpp(big, v, 0x143, 0xc, 0xf, false); v = o < v ? o : v;
+        return __builtin_amdgcn_readlane(v, 63);
+    }
+    // lexicographic minimum of (value, index) over the lanes with index < nl, broadcast to all lanes (index nl: none)
     __device__ void min_first(double &v, int &i, int nl) const
     {
-        const unsigned long long valid = __ballot(i < nl);
-        if (__popcll(valid) <= 8) {
-            // few candidates: walk them in lane order with v_readlane (no LDS crossbar traffic); strict < keeps the first
-            double bv = 0; int bi = nl;
-            unsigned long long msk = valid;
-            const long long bits = __double_as_longlong(v);
-            while (msk) {
-                const int l = __ffsll((long long)msk) - 1;
-                msk &= msk - 1;
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(bits & 0xFFFFFFFFll), l);
-                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), l);
-                const double x = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-                const int xi = __builtin_amdgcn_readlane(i, l);
-                if (bi >= nl || x < bv || (x == bv && xi < bi)) { bv = x; bi = xi; }
-            }
-            v = bv; i = bi;
-            return;
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ov = __shfl_xor(v, off);
-            const int oi = __shfl_xor(i, off);
-            const bool take = oi < nl && (i >= nl || ov < v || (ov == v && oi < i));
-            if (take) { v = ov; i = oi; }
-        }
+        const bool valid = i < nl;
+        const double mv = wave_min_f64(valid ? v : __longlong_as_double(0x7FF0000000000000ll));
+        const int mi = wave_min_i32(valid && v == mv ? i : 0x7fffffff);
+        v = mv; i = mi == 0x7fffffff ? nl : mi;
     }
-    __device__ void min_plain(double &v) const
-    {
-        for (int off = 32; off > 0; off >>= 1) { const double ov = __shfl_xor(v, off); if (ov < v) v = ov; }
-    }
+    __device__ void min_plain(double &v, int nlive = 64) const { v = wave_min_f64(v, nlive); }
     __device__ int excl_scan(int cnt, int &total) const       // exclusive prefix sum over the lanes + wave total
     {
-        const int lane = (int)(threadIdx.x & 63);
-        int inc = cnt;
-        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
-        total = __shfl(inc, 63);
-        return inc - cnt;
+        int v = cnt;                                           // inclusive scan: the same DPP sequence, with +
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+        total = __builtin_amdgcn_readlane(v, 63);
+        return v - cnt;
     }
 };
 #endif
@@ -606,6 +634,9 @@ struct SqBlossom {
         if (lane == 0) for (int k = 0; k < 8; k++) { pt[k] = 0; pc[k] = 0; }
 #endif
         int npass = 0, nevent = 0;                              // (wave-uniform registers; published at the end)
+#ifdef SQ_MWM_PROF2
+        long long p2_cls = 0, p2_app = 0, p2_evt = 0, p2_upd = 0, p2_ini = 0, p2_all = clock64(); int p2_c1 = 0, p2_cn = 0;
+#endif
         for (;;) {                                              // stages
 #ifdef SQ_MWM_PROF
             if (lane == 0) pc[3]++;
@@ -677,7 +708,7 @@ struct SqBlossom {
                 int v_pre = -1, a0_pre = 0, aend_pre = 0;
                 while (qn_r > 0 && !stopq) {
 #ifdef SQ_MWM_PROF2
-                    const long long _q0 = wall_clock64();
+                    long long _q0 = clock64();
 #endif
                     --qn_r;
                     int v, a0, aend;
@@ -723,8 +754,9 @@ struct SqBlossom {
                             else cat = lbw == 1 ? 4 : (lw == 0 ? 3 : 0);
                         }
 #ifdef SQ_MWM_PROF2
-                        if (lane == 0) { asm volatile("" :: "v"(cat)); pt[1] += wall_clock64() - _q0; }
-                        const long long _q1 = wall_clock64();
+                        asm volatile("" :: "v"(cat));
+                        const long long _q1 = clock64();
+                        p2_cls += _q1 - _q0;
 #endif
                         const int f = coop.first_true(cat == 1, nl);        // first state-changing neighbour of the chunk
                         if (lane < f && live) {
@@ -740,16 +772,21 @@ struct SqBlossom {
                             const bool comp = lane < f && cat == 4 && (be_bv == -1 || ks < s_bebv);
                             int cfirst;
                             const int ccount = coop.count_true(comp, cfirst);
+#ifdef SQ_MWM_PROF2
+                            p2_c1 += ccount == 1; p2_cn += ccount > 1;
+#endif
                             if (ccount == 1) {
                                 if (lane == cfirst) { bestedge_[bv] = de; bslack_[bv] = ks; }
                             } else if (ccount > 1) {
-                                double mv = ks; int mi = comp ? lane : nl;
-                                coop.min_first(mv, mi, nl);
-                                if (lane == 0) { bestedge_[bv] = adj_[a0 + mi]; bslack_[bv] = mv; }
+                                // positions grow with the lane: the winner is the lowest lane that holds the minimum
+                                double mv = comp ? ks : 1e300;
+                                coop.min_plain(mv, aend - a0);            // (lanes past the list hold 1e300)
+                                if (lane == coop.first_true(comp && ks == mv, nl)) { bestedge_[bv] = de; bslack_[bv] = ks; }
                             }
                         }
 #ifdef SQ_MWM_PROF2
-                        if (lane == 0) pt[2] += wall_clock64() - _q1;
+                        _q0 = clock64();
+                        p2_app += _q0 - _q1;
 #endif
                         if (f >= nl) { a0 += nl; continue; }
                         had_event = true;
@@ -792,6 +829,9 @@ struct SqBlossom {
 #endif
                         qn_r = qn;
                         stopq = f_augmented || error;
+#ifdef SQ_MWM_PROF2
+                        { const long long _n = clock64(); p2_evt += _n - _q0; _q0 = _n; }
+#endif
                         if (stopq) break;
                         a0 += f + 1;
                     }
@@ -896,6 +936,13 @@ struct SqBlossom {
         }
         if (lane == 0) { stat_pass = npass; stat_event = nevent; }
         sync();
+#ifdef SQ_MWM_PROF2
+#ifdef __HIP_DEVICE_COMPILE__
+        if (lane == 0 && n >= 140)
+            printf("mwm2 n=%d m=%d passes=%d events=%d comp1=%d compN=%d | cycles: total %lld classify %lld apply %lld events %lld\n",
+                   n, m, npass, nevent, p2_c1, p2_cn, (long long)(clock64() - p2_all), p2_cls, p2_app, p2_evt);
+#endif
+#endif
 #ifdef SQ_MWM_PROF
 #ifdef __HIP_DEVICE_COMPILE__
         if (lane == 0 && n >= 140)

@@ -64,10 +64,6 @@ __host__ __device__ inline SqOk *sq_oks(const SqScanArgs &a, const SqStruct &st,
     return reinterpret_cast<SqOk *>(reinterpret_cast<char *>(a.cands + st.cand_off) + (size_t)cand_cap * sizeof(SqKey));
 }
 
-size_t sq_scan_lds_fixed();   // bytes of static LDS of sq_scan_kernel
-int sq_scan_seg();            // rows per wave of sq_scan_kernel
-int sq_scan5_seg();           // rows per wave of sq_scan5_kernel
-
 extern "C" {
 __global__ void sq_fill_kernel(SqDevCtx c, int only_ext, int mul_done);
 __global__ void sq_bits_direct_kernel(SqDevCtx c);
@@ -83,8 +79,6 @@ __global__ void sq_scatter_kernel(SqDevCtx c, const SqStruct *structs, SqScanArg
                                   int L, double *matrix);
 __global__ void sq_colselect_kernel(const double *matrix, int L, double thr, int minspan, long long *idx_out,
                                     double *val_out, long long cap, unsigned long long *count);
-__global__ void sq_scan_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
-__global__ void sq_scan5_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
 __global__ void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
 __global__ void sq_bits_kernel(SqDevCtx c, int only_ext);
 __global__ void sq_score_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,

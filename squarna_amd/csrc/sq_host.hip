@@ -158,10 +158,9 @@ static inline int32_t ld_of(int n)
     return 32 * k + 1;
 }
 
-// fp32 score matrices are planned unless the caller opts out (the legacy fp32 scans always need them)
+// fp32 score matrices are planned unless the caller opts out
 static inline bool want_fp32(const sq_batch_desc *d)
 {
-    if (getenv("SQ_SCAN") && atoi(getenv("SQ_SCAN")) != 6) return true;
     return !(d->batch_flags & SQ_BATCH_NO_FP32);
 }
 
@@ -608,12 +607,6 @@ extern "C" int sq_profile_get(sq_batch *b, int32_t k, double *ms, int64_t *launc
 }
 
 // ---- a-1 -----------------------------------------------------------------------------------
-static int scan_version()
-{
-    static const int v = getenv("SQ_SCAN") ? atoi(getenv("SQ_SCAN")) : 6;
-    return v;
-}
-
 // full = 1: fp32 score matrices of every job (the API op).  full = 0: only what the fold path reads -- the
 // bit matrices, computed straight from the O(N) inputs; jobs with caller / multiplier matrices still go
 // through the fp32 fill (it imports the bool matrix and forms score * multiplier in the dense arena).
@@ -668,7 +661,6 @@ extern "C" int sq_bpmatrix_fill(sq_batch *b)
 
 int sq_prepare_scan(sq_batch *b)
 {
-    if (scan_version() != 6) return b->filled ? 0 : fill_impl(b, 1);   // the fp32 scans read the matrix
     return b->bits_ready ? 0 : fill_impl(b, 0);
 }
 
@@ -852,20 +844,10 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
         hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(256), st_dyn, st, b->ctx, io, b->state, scan, st_lds_n);
     }
     if (maxn >= 5) {
-        const int nband = (2 * maxn - 5 + 255) >> 8;
-        const int scan_v = scan_version();
         ProfScope ps(b, 2, scan_bytes);
-        if (scan_v == 6) {                          // bit-diagonal scan: one wave = 64 anti-diagonals
-            hipLaunchKernelGGL(sq_scan6_kernel, dim3(S, (2 * maxn - 5 + 63) / 64 + 1), dim3(64), 4 * (size_t)b->state.fbstride, st,
-                               b->ctx, ln.d_structs, b->state, scan);
-        } else {
-            const int seg = scan_v == 4 ? sq_scan_seg() : sq_scan5_seg();
-            const int nseg = ((maxn >> 1) + 130 + seg - 1) / seg;
-            if (scan_v == 4)
-                hipLaunchKernelGGL(sq_scan_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, ln.d_structs, b->state, scan);
-            else
-                hipLaunchKernelGGL(sq_scan5_kernel, dim3(S, nband * nseg), dim3(64), 0, st, b->ctx, ln.d_structs, b->state, scan);
-        }
+        // bit-diagonal scan: one wave = 64 anti-diagonals
+        hipLaunchKernelGGL(sq_scan6_kernel, dim3(S, (2 * maxn - 5 + 63) / 64 + 1), dim3(64), 4 * (size_t)b->state.fbstride, st,
+                           b->ctx, ln.d_structs, b->state, scan);
     }
     {
         ProfScope ps(b, 3, 0);
@@ -1147,7 +1129,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     if (o.poollim < 1) { sq_set_error("poollim must be positive"); return -1; }
     struct FoldTimer { double t0; ~FoldTimer() { if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_fold] total %.3f ms (incl. teardown)\n", (now_s() - t0) * 1e3); } } fold_timer{now_s()};
     // a-1, once per job and per fold (:1076): never reused from an earlier call, a fold is the whole path
-    int r = scan_version() == 6 ? fill_impl(b, 0) : fill_impl(b, 1);
+    int r = fill_impl(b, 0);
     if (r) return r;
     // (the pools -- thousands of small vectors -- are torn down by a helper thread after the fold returns)
     auto *pools_owner = new std::vector<JobPool>(b->njobs);
@@ -1325,7 +1307,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     std::vector<int> greedy_jobs;
     for (int j = 0; j < b->njobs; j++) if (!pools[j].cur.empty()) greedy_jobs.push_back(j);
     static const int want_lanes = getenv("SQ_FOLD_LANES") ? atoi(getenv("SQ_FOLD_LANES")) : 2;
-    const bool two_lanes = want_lanes >= 2 && !b->prof_on && (int)greedy_jobs.size() >= 512 &&
+    static const int lane_min_jobs = getenv("SQ_LANE_MIN_JOBS") ? atoi(getenv("SQ_LANE_MIN_JOBS")) : 512;
+    const bool two_lanes = want_lanes >= 2 && !b->prof_on && (int)greedy_jobs.size() >= lane_min_jobs &&
                            (int)greedy_jobs.size() <= b->max_structs;   // (a lane holds half of the slots)
     LoopStats st0, st1;
     sq_pool(b);                                             // (created before any second thread can ask for it)

@@ -1,18 +1,18 @@
 // sq_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the folding core.
 //
-//   sq_fill_kernel    a-1  BPMatrix           SQRNdbnseq.py:258-338   (HBM-write bound)
-//   sq_dense64_kernel a-1  exact fp64 (bool, score) for the API shim / external matrices
-//   sq_import_kernel       caller matrices -> fp32 scan matrix
-//   sq_state_kernel        partner / mask / prefix arrays of a partial structure (:446-451, :625-635)
-//   sq_scan_kernel    a-2  AnnotateStems      SQRNdbnseq.py:427-495   (HBM-read bound, the hot kernel)
-//   sq_score_kernel   a-4..a-6 ScoreStems + ChooseStems range filter  SQRNdbnseq.py:607-789
+//   sq_bits_masks_kernel / sq_bits_direct_kernel   a-1  BPMatrix as a diagonal bit matrix (1 bit per cell): all the
+//                         fold path keeps per cell                                          SQRNdbnseq.py:258-304
+//   sq_fill_kernel        a-1  the fp32 score matrix (API op sq_bpmatrix_fill; jobs with caller / multiplier matrices)
+//   sq_dense64_kernel     a-1  exact fp64 (bool, score) for the API shim / external matrices
+//   sq_import_kernel           caller matrices -> fp32 matrix + bits
+//   sq_state_kernel            partner / mask / prefix arrays + free-position bit words of a partial structure (:446-451, :625-635)
+//   sq_scan6_kernel       a-2  AnnotateStems: bit-diagonal scan, one lane per anti-diagonal, 32 rows per step (:427-495)
+//   sq_score_kernel       a-4..a-6 exact fp64 bpscore filter + ScoreStems closed form; sq_select_kernel: ChooseStems range (:607-789)
+//   sq_bps_kernel              the bpscore filter alone (AnnotateStems output, alignment survivor lists)
+//   sq_scatter_* / sq_mirror_kernel / sq_colselect_kernel   alignment step 1 (SQRNdbnali.py:211-242)
 //
-// Layout decisions: the scan matrix is fp32 row-major with row pitch
-// ld == 1 (mod 32).  Cell (i, s-i) of anti-diagonal s then sits at float offset
-// i*(ld-1) + s, so a lane that owns the four diagonals s..s+3 (s % 4 == 0) walks
-// them with 16-byte aligned dwordx4 loads, a wave (256 diagonals, s0 % 256 == 0)
-// reads whole 128-byte lines, and the running stem (len, sum) lives in registers:
-// no LDS transposes, no cross-lane traffic, every HBM byte is read exactly once.
+// Layout decisions: DESIGN.md section 3.  The fp32 matrix (row pitch ld == 1 mod 32, quiet-NaN where bool == 0) only
+// serves the API op and caller-supplied matrices; every decision of the fold is taken in fp64 by the scoring kernels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sq_internal.h"
@@ -434,49 +434,12 @@ extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, Sq
 }
 
 // ------------------------------------------------------------------------------------
-// a-2  stem scan.  One wave (64-thread block) = 256 anti-diagonals (4 per lane) x SQ_SEG rows.
-//
-//  * the kernel is bound by per-wave instruction latency, not by HBM latency (rocprof:
-//    profiles/), so everything is arranged for OCCUPANCY: <= 64 VGPRs and ~4.5 KiB of LDS per
-//    wave (8 waves per SIMD); rows are prefetched SQ_DEPTH deep straight into registers with
-//    16-byte aligned global_load_dwordx4 (hipcc's counted vmcnt), no LDS staging of the matrix;
-//  * rows of the segment that the current structure masks are dropped up front (a masked
-//    row only ends every open run); the compacted row list lives in two VGPRs (row q is read
-//    with v_readlane), lanes whose diagonals do not reach a row re-read a neighbour's address
-//    (coalesced away), so HBM traffic stays ~1.05x the algorithmic N^2/2 cells;
-//  * the column mask codes of the wave's window live in LDS as four byte-shifted copies, so
-//    the four codes a lane needs for a row are ONE aligned ds_read_b32;
-//  * the run state (len, sum) of the four diagonals stays in registers; a run belongs to the
-//    wave whose segment holds its first cell: the wave reads SQ_TAILROWS rows past its
-//    segment inside the same pipeline (longer runs finish in a rare serial loop) and ignores
-//    runs that are already open in the row above its segment;
-//  * candidates go to lane-private LDS slots (no atomics), overflow to a shared LDS list,
-//    and are appended to the structure's candidate array with one global atomic per wave.
+// candidate staging of the scan: (key, len) records collected in LDS, appended to the structure's key array with
+// one global atomic per flush
 // ------------------------------------------------------------------------------------
-#ifndef SQ_SEG
-#define SQ_SEG 120
+#ifndef SQ5_STAGE
+#define SQ5_STAGE 256
 #endif
-#ifndef SQ_DEPTH
-#define SQ_DEPTH 3                                    // rows in flight per wave
-#endif
-#ifndef SQ_TAILROWS
-#define SQ_TAILROWS 4
-#endif
-#define SQ_MAXROWS (SQ_SEG + SQ_TAILROWS + 1)        // + the row above the segment; must be <= 128
-#define SQ_KPRIV 2
-#define SQ_OVF 32
-#define SQ_COLW ((256 + SQ_MAXROWS + 3) / 4 + 3)      // dwords per shifted copy of the column codes
-#define SQ_FOREIGN (-(1 << 24))                       // len of a run owned by another wave
-
-struct SqRec { uint32_t key, len; float sum; uint32_t pad; };
-
-struct SqScanLds {      // LDS of one wave
-    SqRec priv[SQ_KPRIV][64];            // 2 KiB   lane-private candidate slots (rows list during set-up)
-    SqRec ovf[SQ_OVF];                   // 512 B   shared overflow list
-    uint32_t ovf_count, pad0[3];
-    uint32_t ecol[4][SQ_COLW];           // byte-shifted copies of the column mask codes
-};
-
 __device__ __forceinline__ void sq_emit_global(const SqScanArgs &a, const SqStruct &st, int cap, uint32_t key,
                                                uint32_t len, float sum)
 {
@@ -485,287 +448,6 @@ __device__ __forceinline__ void sq_emit_global(const SqScanArgs &a, const SqStru
     (void)sum;
     sq_keys(a, st)[slot] = SqKey{key, len};
 }
-
-struct SqScanCtx {      // per-wave constants of the row walk
-    SqScanLds *L;
-    int sl, n, cap, minlen_i, lane;
-    float maxabs, minscore_f;
-};
-
-// run [rend-len, rend) on diagonal s ended with len >= minlen.  fp32 prefilter with a rigorous
-// rounding margin (|fp32 sum - exact| <= len^2 * maxabs * 2^-24); the exact fp64 test of
-// SQRNdbnseq.py:492 is in sq_score_kernel.
-__device__ __forceinline__ void sq_emit(const SqScanCtx &x, const SqScanArgs &a, const SqStruct &st, int &pc, int s,
-                                        int rend, int len, float sum)
-{
-    const float ll = (float)len * (float)len;
-    const float ub = fmaf(ll * x.maxabs, 2.4e-07f, sum);
-    if (!(ub >= x.minscore_f)) return;
-    SqRec rec;
-    rec.key = ((uint32_t)s << 16) | (uint32_t)(rend - len);
-    rec.len = (uint32_t)len; rec.sum = sum; rec.pad = 0;
-    if (pc < SQ_KPRIV) {
-        x.L->priv[pc][x.lane] = rec;
-        pc++;
-        return;
-    }
-    const uint32_t slot = atomicAdd(&x.L->ovf_count, 1u);              // LDS atomic
-    if (slot < SQ_OVF) x.L->ovf[slot] = rec;
-    else sq_emit_global(a, st, x.cap, rec.key, rec.len, sum);
-}
-
-// MODE 0: row inside the segment; 1: row past the segment (runs may continue, not start);
-// 2: the row above the segment (only marks runs that are already open there).
-// EDGE: some cells of the row lie outside their diagonal (band staircases) -> per-cell range test.
-template <int MODE, bool EDGE>
-__device__ __forceinline__ void sq_row(const SqScanCtx &x, const SqScanArgs &a, const SqStruct &st, int &pc, int r,
-                                       uint32_t er, uint32_t ecodes, const float4 &v, const int (&lo)[4],
-                                       const unsigned (&span)[4], int (&len)[4], float (&sum)[4])
-{
-    const float vv[4] = {v.x, v.y, v.z, v.w};
-    bool act[4];
-    bool want = false;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t ej = (ecodes >> (8 * k)) & 0xFFu;
-        act[k] = (ej == er) & (__float_as_uint(vv[k]) != SQ_SENT_BITS);            // :438-451 mask, :300-304 bool
-        if (EDGE) act[k] = act[k] & ((unsigned)(r - lo[k]) <= span[k]);           // cell (r, s-r) exists
-        if (MODE != 2) want |= (!act[k]) & (len[k] >= x.minlen_i);
-    }
-    if (MODE != 2 && __ballot(want) != 0ull) {                          // some run of useful length ended here
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (!act[k] && len[k] >= x.minlen_i) sq_emit(x, a, st, pc, x.sl + k, r, len[k], sum[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (MODE == 2) {
-            len[k] = act[k] ? SQ_FOREIGN : 0;
-        } else if (MODE == 0) {
-            sum[k] = act[k] ? sum[k] + vv[k] : 0.f;                     // garbage while len < 0: never emitted
-            len[k] = act[k] ? len[k] + 1 : 0;
-        } else {
-            const bool cont = act[k] & (len[k] > 0);
-            sum[k] = cont ? sum[k] + vv[k] : 0.f;
-            len[k] = cont ? len[k] + 1 : (act[k] ? SQ_FOREIGN : 0);
-        }
-    }
-}
-
-// every open run ends in row `r` (a masked row, or the end of the diagonals)
-__device__ __forceinline__ void sq_end_all(const SqScanCtx &x, const SqScanArgs &a, const SqStruct &st, int &pc, int r,
-                                           int (&len)[4], float (&sum)[4])
-{
-    const bool want = (len[0] >= x.minlen_i) | (len[1] >= x.minlen_i) | (len[2] >= x.minlen_i) | (len[3] >= x.minlen_i);
-    if (__ballot(want) != 0ull) {
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (len[k] >= x.minlen_i) sq_emit(x, a, st, pc, x.sl + k, r, len[k], sum[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) { len[k] = 0; sum[k] = 0.f; }
-}
-
-#ifndef SQ_WPS
-#define SQ_WPS 6
-#endif
-extern "C" __global__ __launch_bounds__(64, SQ_WPS) void sq_scan_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
-{
-    static_assert(SQ_MAXROWS <= 128, "row list is kept in two VGPRs");
-    __shared__ __attribute__((aligned(16))) SqScanLds L;
-    // grid = (structures, tiles): concurrently running waves work on DIFFERENT matrices (measured: dispatching
-    // the tiles of one matrix together pins every XCD to one 1-KiB column of each 4-KiB row and loses 25-35 %)
-    const SqStruct st = structs[blockIdx.x];
-    const SqJob jb = c.jobs[st.job];
-    const int n = jb.n, ld = jb.ld;
-    if (n < 5) return;                                                  // :456-457 no diagonals
-    const int nband = (2 * n - 5 + 255) >> 8;
-    const int nseg = ((n >> 1) + 130 + SQ_SEG - 1) / SQ_SEG;
-    const int tile = blockIdx.y;
-    if (tile >= nband * nseg) return;
-    const int seg = tile / nband, band = tile - seg * nband;
-    const int s0 = band << 8;
-    const int smin = max(s0, 4), smax = min(s0 + 255, 2 * n - 6);       // :456-457 s in [4, 2N-6]
-    if (smin > smax) return;
-    const int rmin = max(0, smin - (n - 1)), rmax = (smax - 1) >> 1;    // :486 i <= j-1
-    const int rbeg = rmin + seg * SQ_SEG;
-    if (rbeg > rmax) return;
-    const int rend = min(rbeg + SQ_SEG, rmax + 1);
-    const int lane = threadIdx.x;
-
-    const SqPsetDev *ps = c.psets + jb.pset;
-    SqScanCtx x;
-    x.L = &L; x.sl = s0 + 4 * lane; x.n = n; x.cap = jb.cand_cap; x.lane = lane;
-    x.minlen_i = max(1, (int)ceil(ps->minlen)); x.maxabs = jb.maxabs;
-    {
-        const float ms = (float)ps->minbpscore;
-        x.minscore_f = ms - fabsf(ms) * 4.8e-07f - 1e-30f;
-    }
-
-    int lo[4], len[4];
-    unsigned span[4];
-    float sum[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int s = x.sl + k;
-        const bool ok = s >= 4 && s <= 2 * n - 6;
-        lo[k] = ok ? max(0, s - (n - 1)) : 0x3fffffff;
-        span[k] = ok ? (unsigned)(((s - 1) >> 1) - lo[k]) : 0u;
-        len[k] = 0; sum[k] = 0.f;
-    }
-    // rows where every cell of the wave exists (no staircase): lo of the last diagonal .. hi of the first
-    const bool fullband = s0 >= 4 && s0 + 255 <= 2 * n - 6;
-    const int wlo = fullband ? max(0, s0 + 255 - (n - 1)) : 0x3fffffff;
-    const int whi = fullband ? (s0 - 1) >> 1 : -1;
-
-    // ---- compact the unmasked rows: [row above the segment] + segment + pipelined tail rows
-    const uint8_t *eg = stt.E8 + (int64_t)st.slot * stt.stride * 2;
-    const int r0 = rbeg > rmin ? rbeg - 1 : rbeg;
-    const int rhi = min(rmax, rend + SQ_TAILROWS - 1);
-    uint32_t *rowlist = reinterpret_cast<uint32_t *>(&L.priv[0][0]);    // borrowed until the first candidate
-    if (lane == 0) L.ovf_count = 0;
-    int cnt = 0;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int row = r0 + 64 * h + lane;
-        const uint32_t code = row <= rhi ? (uint32_t)eg[row] : 255u;
-        const bool ok = code != 255u;
-        const unsigned long long m = __ballot(ok);
-        if (ok) rowlist[cnt + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)row << 8) | code;
-        cnt += __popcll(m);
-    }
-    // ---- column mask codes of the window [jb0, jb0 + 4*SQ_COLW): copy c, dword m = codes jb0+4m+c .. +3
-    const int jb0 = s0 - rhi;
-    for (int idx = lane; idx < 4 * SQ_COLW; idx += 64) {
-        const int cpy = idx / SQ_COLW, m = idx - cpy * SQ_COLW;
-        uint32_t w = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = jb0 + 4 * m + cpy + k;
-            const uint32_t code = (j >= 0 && j < n) ? (uint32_t)eg[j] : 255u;
-            w |= code << (8 * k);
-        }
-        L.ecol[cpy][m] = w;
-    }
-    __syncthreads();      // single wave: orders the LDS writes above before the reads below
-    const uint32_t rowsA = lane < cnt ? rowlist[lane] : 0u;             // entry q lives in lane q & 63
-    const uint32_t rowsB = lane + 64 < cnt ? rowlist[lane + 64] : 0u;
-    __syncthreads();      // rowlist (aliases priv) is dead from here on
-    auto row_at = [&](int q) -> uint32_t {
-        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)rowsA, q & 63);
-        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_readlane((int)rowsB, q & 63);
-        return q < 64 ? lo_ : hi_;
-    };
-
-    // cell (r, sl - r) sits at float offset r*(ld-1) + sl: 16-byte aligned for every row.  A lane whose
-    // four diagonals miss row r reads the nearest 16-byte group that does reach it (same cache line as
-    // a neighbour lane: no extra traffic, value unused).
-    const float *mat = c.mat32 + jb.mat_off;
-    const int pitch = ld - 1;
-    auto load_row = [&](int q) -> float4 {
-        const int row = (int)(row_at(min(q, cnt - 1)) >> 8);
-        const int sfirst = max((2 * row + 1) & ~3, s0), slast = min((row + n - 1) & ~3, s0 + 252);
-        const int sc = min(max(x.sl, sfirst), slast);
-        return *reinterpret_cast<const float4 *>(mat + (int64_t)row * pitch + sc);
-    };
-
-    int pc = 0;                       // lane-private candidates staged so far
-    int prev = r0 - 1;
-    float4 buf[SQ_DEPTH];
-#pragma unroll
-    for (int u = 0; u < SQ_DEPTH; u++) buf[u] = load_row(u);
-    for (int q0 = 0; q0 < cnt; q0 += SQ_DEPTH) {
-#pragma unroll
-        for (int u = 0; u < SQ_DEPTH; u++) {
-            const int q = q0 + u;
-            if (q >= cnt) break;
-            const float4 v = buf[u];
-            buf[u] = load_row(q + SQ_DEPTH);                            // keep SQ_DEPTH rows in flight
-            const uint32_t rc = row_at(q);
-            const int row = (int)(rc >> 8);
-            const uint32_t er = rc & 0xFFu;
-            const int d = rhi - row;
-            const uint32_t ecodes = L.ecol[d & 3][(d >> 2) + lane];
-            if (row != prev + 1) sq_end_all(x, a, st, pc, prev + 1, len, sum);   // masked rows in between (:446-451)
-            const bool interior = row >= wlo && row <= whi;
-            if (row < rbeg) sq_row<2, true>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
-            else if (row < rend) {
-                if (interior) sq_row<0, false>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
-                else sq_row<0, true>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
-            } else sq_row<1, true>(x, a, st, pc, row, er, ecodes, v, lo, span, len, sum);
-            prev = row;
-        }
-    }
-    if (prev != rhi) sq_end_all(x, a, st, pc, prev + 1, len, sum);       // trailing masked rows
-    // runs that are still open: beyond the pipelined tail (rare) or at the end of the diagonals
-    int r = rhi + 1;
-    while (__ballot((len[0] > 0) | (len[1] > 0) | (len[2] > 0) | (len[3] > 0)) != 0ull) {
-        uint32_t er = 255u;
-        if (r <= rmax) er = (uint32_t)__builtin_amdgcn_readfirstlane((int)eg[r]);
-        if (er == 255u) { sq_end_all(x, a, st, pc, r, len, sum); break; }
-        const int sfirst = max((2 * r + 1) & ~3, s0), slast = min((r + n - 1) & ~3, s0 + 252);
-        const int sc = min(max(x.sl, sfirst), slast);
-        const float4 v = *reinterpret_cast<const float4 *>(mat + (int64_t)r * pitch + sc);
-        uint32_t ecodes = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = x.sl + k - r;
-            ecodes |= ((j >= 0 && j < n) ? (uint32_t)eg[j] : 255u) << (8 * k);
-        }
-        sq_row<1, true>(x, a, st, pc, r, er, ecodes, v, lo, span, len, sum);
-        r++;
-    }
-    // ---- flush: lane-private slots + overflow list -> one global append
-    __syncthreads();
-    const unsigned long long m1 = __ballot(pc >= 1), m2 = __ballot(pc >= 2);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
-    uint32_t novf = L.ovf_count;
-    if (novf > SQ_OVF) novf = SQ_OVF;
-    const uint32_t total = n1 + n2 + novf;
-    if (total == 0) return;
-    uint32_t b0 = 0;
-    if (lane == 0) b0 = atomicAdd(a.cand_cnt + st.slot, total);
-    const uint32_t gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
-    auto put = [&](uint32_t slot, const SqRec &rec) {
-        if (slot >= (uint32_t)x.cap) { a.ctr->cand_ovf = 1; return; }
-        sq_keys(a, st)[slot] = SqKey{rec.key, rec.len};
-    };
-    if (pc >= 1) put(gbase + (uint32_t)__popcll(m1 & lt), L.priv[0][lane]);
-    if (pc >= 2) put(gbase + n1 + (uint32_t)__popcll(m2 & lt), L.priv[1][lane]);
-    for (uint32_t k = lane; k < novf; k += 64) put(gbase + n1 + n2 + k, L.ovf[k]);
-}
-
-// ------------------------------------------------------------------------------------
-// a-2  stem scan, bit-history form ("v5").  Same geometry as sq_scan_kernel (one wave = 256
-// anti-diagonals x a row segment), but the per-cell work is 3 VALU: two compares and one
-// add-with-carry that shifts the cell's activity bit into a 32-bit history per diagonal.
-// Runs are extracted from the histories once per 32 rows with bit tricks (only runs with
-// len >= minlen are ever touched); their fp32 sums are NOT tracked -- sq_score_kernel
-// recomputes every candidate exactly in fp64 anyway and applies minbpscore there.
-//   bit p of a chunk history <-> row  cbase + nrows-1 - p   (bit 0 = newest row)
-// ------------------------------------------------------------------------------------
-#ifndef SQ5_SEG
-#define SQ5_SEG 124                                   // owned rows per wave
-#endif
-#define SQ5_TAIL 4                                    // extra rows read past the segment
-#define SQ5_ROWS (SQ5_SEG + SQ5_TAIL)                 // 128 = 4 chunks of 32 (must be a multiple of 32)
-#ifndef SQ5_STAGE
-#define SQ5_STAGE 256
-#endif
-#ifndef SQ5_G
-#define SQ5_G 4                                      // rows per load group (two groups in flight)
-#endif
-#ifndef SQ5_WPS
-#define SQ5_WPS 4
-#endif
-#define SQ5_COLW ((256 + SQ5_ROWS + 4) / 4 + 3)
-
-struct SqScan5Lds {
-    uint32_t ecol[4][SQ5_COLW];          // byte-shifted copies of the column mask codes
-    uint2 stage[SQ5_STAGE];              // (key, len) of emitted candidates
-    uint32_t stage_count, pad[3];
-};
 
 template <class LDS>
 __device__ __forceinline__ void sq5_flush(LDS &L, const SqScanArgs &a, const SqStruct &st, int cap, int lane)
@@ -795,300 +477,8 @@ __device__ __forceinline__ void sq5_emit(LDS &L, const SqScanArgs &a, const SqSt
     else sq_emit_global(a, st, cap, key, len, 0.f);
 }
 
-// analyse one chunk history of one diagonal.  A: activity bits (nrows valid, bit 0 newest),
-// carry: length of the run open at the chunk's top (SQ_FOREIGN if it belongs to another wave),
-// rtop: row of bit nrows-1, rown: first row a run of this wave may NOT start in (rend).
-template <class LDS>
-__device__ __forceinline__ void sq5_analyse(LDS &L, const SqScanArgs &a, const SqStruct &st, int cap, int s,
-                                            uint32_t A, int nrows, int rtop, int rown, int minlen, int &carry)
-{
-    const int top = nrows - 1;
-    const uint32_t full = nrows == 32 ? 0xFFFFFFFFu : ((1u << nrows) - 1u);
-    // the run touching the top bit continues the carried run
-    int toplen = 0;                                   // ones from bit `top` downwards
-    if ((A >> top) & 1u) toplen = __clz(~(A << (31 - top)) | 0u) ;
-    if (toplen > nrows) toplen = nrows;
-    uint32_t rest = A;                                // runs that start inside this chunk
-    if (toplen) {
-        if (toplen < nrows) {                         // ended inside the chunk
-            const int p = nrows - toplen;             // newest bit of the top run
-            const int rendrow = rtop + (top - p) + 1; // first inactive row after it
-            const int len = carry + toplen;
-            if ((carry > 0 || (carry == 0 && rtop < rown)) && len >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(rendrow - len), (uint32_t)len);
-            rest &= ~(full & ~((1u << p) - 1u));      // drop the top run's bits
-            carry = 0;
-        } else {                                      // whole chunk active: run stays open
-            if (carry > 0 || (carry == 0 && rtop < rown)) carry += nrows;
-            else carry = SQ_FOREIGN;
-            return;
-        }
-    } else {
-        // the carried run ended exactly at the chunk boundary (row rtop is its first inactive row)
-        if (carry >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(rtop - carry), (uint32_t)carry);
-        carry = 0;
-    }
-    // runs inside: newest ends N = rest & ~(rest << 1); ended ones have p > 0
-    const uint32_t N = rest & ~(rest << 1);
-    uint32_t Y = rest;                                // Y[p]: rest[p .. p+minlen-1] all ones, by doubling (five fixed
-    {                                                 // steps cover 32; a loop over minlen made the compiler vectorise it)
-        int have = 1;
-        const int want = minlen < 32 ? minlen : 32;
-#pragma unroll
-        for (int q = 0; q < 5; q++) {
-            const int step = min(have, want - have);  // 0 once the window is complete: Y &= Y
-            Y &= Y >> step;
-            have += step;
-        }
-    }
-    uint32_t bits = N & Y & ~1u;
-    while (bits) {
-        const int p = __ffs((int)bits) - 1;
-        bits &= bits - 1;
-        const int len = __ffs((int)~(rest >> p)) - 1; // consecutive ones from p upwards (never reaches the top run)
-        const int rstart = rtop + (top - (p + len - 1));
-        if (rstart < rown)                            // runs that start past the segment belong to the next wave
-            sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)rstart, (uint32_t)len);
-    }
-    // run still open at the newest end
-    if (rest & 1u) {
-        const int len = __ffs((int)~rest) - 1;        // trailing ones (< nrows here)
-        const int rstart = rtop + (top - (len - 1));
-        carry = rstart < rown ? len : SQ_FOREIGN;
-    }
-}
-
-// One 32-row chunk, fully unrolled and branch-free: per row one 16-byte load, one ds_read_b32 with
-// an immediate offset, one v_readlane for the row code, and per cell two compares + one add that
-// shifts the activity bit into the history.  A masked row has row code 0x100, which no column
-// code equals, so it shifts in zeros without any branch (its data is still fetched: the kernel is
-// instruction-bound, not HBM-bound).
-template <bool EDGE>
-__device__ __forceinline__ void sq5_chunk(const float *rowptr, int pitch, int sl, int s0, int n, int cb,
-                                          const uint32_t *ecol_row0, uint32_t cc, uint32_t (&hist)[4])
-{
-    // rows are fetched in groups of SQ5_G, two groups in flight (hipcc counts vmcnt statically); the
-    // sched_barriers keep the scheduler from hoisting later groups' LDS reads (register pressure: the
-    // kernel must stay at 64 VGPRs so that 8 waves per SIMD keep ~256 KB per CU in flight)
-    float4 buf[2][SQ5_G];
-    auto load_group = [&](int g, float4 (&dst)[SQ5_G]) {
-#pragma unroll
-        for (int u = 0; u < SQ5_G; u++) {
-            const int t = g * SQ5_G + u;
-            int sc = sl;
-            if (EDGE) {                                                  // staircase lanes re-read a neighbour's group
-                const int row = cb + t;
-                const int sfirst = max((2 * row + 1) & ~3, s0), slast = min((row + n - 1) & ~3, s0 + 252);
-                sc = min(max(sl, sfirst), slast);
-            }
-            dst[u] = *reinterpret_cast<const float4 *>(rowptr + (int64_t)t * pitch + sc);
-        }
-    };
-    load_group(0, buf[0]);
-    load_group(1, buf[1]);
-#ifdef SQ5_SCHEDBAR
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-    for (int g = 0; g < 32 / SQ5_G; g++) {
-#pragma unroll
-        for (int u = 0; u < SQ5_G; u++) {
-            const int t = g * SQ5_G + u;
-            // column codes of row cb+t: copy (3 - t%4), dword -(t/4) relative to the chunk base (the window
-            // is anchored at row rbeg+127, so the copy index is a compile-time constant)
-            const uint32_t ec = ecol_row0[(3 - (t & 3)) * SQ5_COLW - (t >> 2)];
-            const uint32_t er = (uint32_t)__builtin_amdgcn_readlane((int)cc, t);
-            const float4 v = buf[g & 1][u];
-            const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool act = (((ec >> (8 * k)) & 0xFFu) == er) & (__float_as_uint(vv[k]) != SQ_SENT_BITS);   // :438-451, :300-304
-                hist[k] = hist[k] + hist[k] + (act ? 1u : 0u);
-            }
-        }
-#ifdef SQ5_SCHEDBAR
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        if (g + 2 < 32 / SQ5_G) load_group(g + 2, buf[g & 1]);
-#ifdef SQ5_SCHEDBAR
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-}
-
-extern "C" __global__ __launch_bounds__(64, SQ5_WPS) void sq_scan5_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
-{
-    __shared__ __attribute__((aligned(16))) SqScan5Lds L;
-    const SqStruct st = structs[blockIdx.x];                            // grid = (structures, tiles), see sq_scan_kernel
-    const SqJob jb = c.jobs[st.job];
-    const int n = jb.n, ld = jb.ld;
-    if (n < 5) return;                                                  // :456-457 no diagonals
-    const int nband = (2 * n - 5 + 255) >> 8;
-    const int nseg = ((n >> 1) + 130 + SQ5_SEG - 1) / SQ5_SEG;
-    const int tile = blockIdx.y;
-    if (tile >= nband * nseg) return;
-    const int seg = tile / nband, band = tile - seg * nband;
-    const int s0 = band << 8;
-    const int smin = max(s0, 4), smax = min(s0 + 255, 2 * n - 6);       // :456-457 s in [4, 2N-6]
-    if (smin > smax) return;
-    const int rmin = max(0, smin - (n - 1)), rmax = (smax - 1) >> 1;    // :486 i <= j-1
-    const int rbeg = rmin + seg * SQ5_SEG;
-    if (rbeg > rmax) return;
-    const int rend = min(rbeg + SQ5_SEG, rmax + 1);
-    const int rhi = min(rmax, rend + SQ5_TAIL - 1);                     // last row that matters
-    const int lane = threadIdx.x;
-    const SqPsetDev *ps = c.psets + jb.pset;
-    const int minlen = max(1, (int)ceil(ps->minlen));
-    const int cap = jb.cand_cap;
-    const int sl = s0 + 4 * lane;
-
-    int lo[4], carry[4];
-    unsigned span[4];
-    uint32_t hist[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int s = sl + k;
-        const bool ok = s >= 4 && s <= 2 * n - 6;
-        lo[k] = ok ? max(0, s - (n - 1)) : 0x3fffffff;
-        span[k] = ok ? (unsigned)(((s - 1) >> 1) - lo[k]) : 0u;
-        carry[k] = 0; hist[k] = 0;
-    }
-    const bool fullband = s0 >= 4 && s0 + 255 <= 2 * n - 6;
-    const int wlo = fullband ? max(0, s0 + 255 - (n - 1)) : 0x3fffffff;  // rows where every cell of the wave exists
-    const int whi = fullband ? (s0 - 1) >> 1 : -1;
-
-    const uint8_t *eg = stt.E8 + (int64_t)st.slot * stt.stride * 2;
-    auto rowcode = [&](int row) -> uint32_t {                            // 0x100: masked or outside -> matches nothing
-        const uint32_t cde = (row >= 0 && row <= rhi) ? (uint32_t)eg[row] : 255u;
-        return cde == 255u ? 0x100u : cde;
-    };
-    if (lane == 0) L.stage_count = 0;
-    // column codes of the window anchored at row rref = rbeg + 127: copy c, dword m = codes jb0+4m+c .. +3
-    const int rref = rbeg + SQ5_ROWS - 1;
-    const int jb0 = s0 - rref;
-    for (int idx = lane; idx < 4 * SQ5_COLW; idx += 64) {
-        const int cpy = idx / SQ5_COLW, m = idx - cpy * SQ5_COLW;
-        uint32_t w = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = jb0 + 4 * m + cpy + k;
-#ifdef SQ5_ABLATE_PROLOGUE
-            const uint32_t code = (j >= 0 && j < n) ? 0u : 255u;
-#else
-            const uint32_t code = (j >= 0 && j < n) ? (uint32_t)eg[j] : 255u;
-#endif
-            w |= code << (8 * k);
-        }
-        L.ecol[cpy][m] = w;
-    }
-    __syncthreads();
-
-    const float *mat = c.mat32 + jb.mat_off;
-    const int pitch = ld - 1;
-
-    // ---- the row above the segment: runs already open there belong to the previous wave
-#ifndef SQ5_ABLATE_PREROW
-    if (rbeg > rmin) {
-        const int row = rbeg - 1;
-        const uint32_t er = rowcode(row);
-        const int sfirst = max((2 * row + 1) & ~3, s0), slast = min((row + n - 1) & ~3, s0 + 252);
-        const float4 v = *reinterpret_cast<const float4 *>(mat + (int64_t)row * pitch + min(max(sl, sfirst), slast));
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = sl + k - row;
-            const uint32_t ej = (j >= 0 && j < n) ? (uint32_t)eg[j] : 255u;
-            const bool act = (ej == er) & (__float_as_uint(vv[k]) != SQ_SENT_BITS) & ((unsigned)(row - lo[k]) <= span[k]);
-            carry[k] = act ? SQ_FOREIGN : 0;
-        }
-    }
-#endif
-    // ---- chunks of 32 rows
-    const int nch = (rhi - rbeg) / 32 + 1;
-    for (int ch = 0; ch < nch; ch++) {
-        const int cb = rbeg + 32 * ch;
-#ifdef SQ5_ABLATE_PROLOGUE
-        const uint32_t cc = 0;
-#else
-        const uint32_t cc = rowcode(cb + lane);                          // lane t: code of row cb + t
-#endif
-#pragma unroll
-        for (int k = 0; k < 4; k++) hist[k] = 0;
-        // d = rref - row = 127 - 32 ch - t  ->  dword (d >> 2) = 31 - 8 ch - (t >> 2), copy d & 3 = 3 - (t & 3)
-        const uint32_t *ecol_row0 = &L.ecol[0][0] + (SQ5_ROWS / 4 - 1 - 8 * ch) + lane;
-        const float *rowptr = mat + (int64_t)cb * pitch;
-        if (cb >= wlo && cb + 31 <= whi) sq5_chunk<false>(rowptr, pitch, sl, s0, n, cb, ecol_row0, cc, hist);
-        else {
-            sq5_chunk<true>(rowptr, pitch, sl, s0, n, cb, ecol_row0, cc, hist);
-            // staircase chunk: drop the bits of cells that lie outside their diagonal (rows lo..hi of
-            // diagonal s; bit p <-> row cb + 31 - p) -- one AND per diagonal instead of a test per cell
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int s = sl + k;
-                const int lo_ = max(0, s - (n - 1)), hi_ = (s - 1) >> 1;
-                const int plo = max(0, cb + 31 - hi_), phi = min(31, cb + 31 - lo_);
-                uint32_t m = 0;
-                if (s >= 4 && s <= 2 * n - 6 && plo <= phi) m = ((2u << phi) - 1u) & ~((1u << plo) - 1u);
-                hist[k] &= m;
-            }
-        }
-        // ---- extract the runs of this chunk (bit 0 = row cb + 31)
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < 4; k++) any |= (hist[k] != 0u) | (carry[k] > 0);
-#ifdef SQ5_ABLATE_ANALYSE
-        asm volatile("" ::"v"(hist[0]), "v"(hist[1]), "v"(hist[2]), "v"(hist[3]));
-        any = false;
-#endif
-        if (__ballot(any) != 0ull) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) sq5_analyse(L, a, st, cap, sl + k, hist[k], 32, cb, rend, minlen, carry[k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) carry[k] = 0;
-        }
-        if (L.stage_count > SQ5_STAGE / 2) sq5_flush(L, a, st, cap, lane);
-    }
-    // ---- runs still open after the pipelined rows: finish them row by row (rare)
-    int r = rbeg + 32 * nch;
-    for (;;) {
-        bool open = false;
-#pragma unroll
-        for (int k = 0; k < 4; k++) open |= carry[k] > 0;
-        if (__ballot(open) == 0ull) break;
-        uint32_t er = 0x100u;
-        if (r <= rmax) { const uint32_t cde = (uint32_t)__builtin_amdgcn_readfirstlane((int)eg[r]); er = cde == 255u ? 0x100u : cde; }
-        bool act[4] = {false, false, false, false};
-        if (er != 0x100u) {
-            const int sfirst = max((2 * r + 1) & ~3, s0), slast = min((r + n - 1) & ~3, s0 + 252);
-            const float4 v = *reinterpret_cast<const float4 *>(mat + (int64_t)r * pitch + min(max(sl, sfirst), slast));
-            const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int j = sl + k - r;
-                const uint32_t ej = (j >= 0 && j < n) ? (uint32_t)eg[j] : 255u;
-                act[k] = (ej == er) & (__float_as_uint(vv[k]) != SQ_SENT_BITS) & ((unsigned)(r - lo[k]) <= span[k]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (carry[k] > 0) {
-                if (act[k]) carry[k]++;
-                else {
-                    if (carry[k] >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)(sl + k) << 16) | (uint32_t)(r - carry[k]), (uint32_t)carry[k]);
-                    carry[k] = 0;
-                }
-            }
-        }
-        if (r > rmax) break;
-        r++;
-    }
-    __syncthreads();
-    sq5_flush(L, a, st, cap, lane);
-}
-
-
 // ------------------------------------------------------------------------------------
-// a-2  stem scan, bit-diagonal form ("v6", default).  AnnotateStems only needs to know WHERE the
+// a-2  stem scan, bit-diagonal form.  AnnotateStems only needs to know WHERE the
 // unmasked cells are -- every candidate's score is recomputed exactly in fp64 by sq_score_kernel --
 // so the scan reads the job's diagonal bit matrix (sq_bits_kernel) instead of the fp32 matrix:
 //   active(s, i) = base(s, i)  &  free[i]  &  free[s - i]       (+ the live restraint pairs)
@@ -1098,7 +488,7 @@ extern "C" __global__ __launch_bounds__(64, SQ5_WPS) void sq_scan5_kernel(SqDevC
 //   column word a 32-bit window of the REVERSED array G (bit k <-> position n-1-k) starting at
 //               n-1-s+32w: it advances by exactly one word per step, so each step reads one new LDS
 //               word and funnel-shifts it against the previous one (v_alignbit);
-// and the runs of the 32 rows come out of sq5_analyse's bit tricks.  Per structure the scan touches
+// and the runs of the 32 rows come out of the word with bit tricks (below).  Per structure the scan touches
 // N^2/16 bytes of (L2-resident) bits instead of 2 N^2 bytes of HBM.
 // ------------------------------------------------------------------------------------
 #define SQ6_RL 256
@@ -1222,10 +612,6 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, con
     sq5_flush(L, a, st, cap, lane);
 }
 
-int sq_scan5_seg() { return SQ5_SEG; }
-
-size_t sq_scan_lds_fixed() { return sizeof(SqScanLds); }
-int sq_scan_seg() { return SQ_SEG; }
 
 // ------------------------------------------------------------------------------------
 // a-4..a-6  exact rescoring + ScoreStems closed form + range filter (one block per structure)
