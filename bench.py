@@ -3,7 +3,7 @@
 
 metric   : sequences/sec on SRtest150 (219 records, 8-150 nt, if=qf, c=nobpp: all five algorithms), whole job
            (bit-matrix fill + greedy stem loop + Edmonds / Hungarian / Nussinov + ranking tail), inputs resident in HBM.
-step     : one fold of `--inflight` (default 4) independent 219-record batches per GPU, in flight at the same time
+step     : one fold of `--inflight` (default 8) independent 219-record batches per GPU, in flight at the same time
            (sq_fold_concurrent: one host thread and one set of streams per batch).  One batch alone is a single 6.5 ms
            latency chain (the blossom kernel of its largest graph, one wave) that leaves the chip > 99 % idle; batches
            in flight are the steady state of a server that streams input files.  The latency of ONE batch is
@@ -82,13 +82,37 @@ def _oracle_one(rec):
     return time.perf_counter() - t0
 
 
+def effective_cpus():
+    """CPUs this process may really use: hardware threads, affinity mask and the cgroup CPU quota (a container with
+    cpu.max = "1600000 100000" shows 256 hardware threads and gets 16 CPUs worth of time)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(recs, cfg, target_s=10.0):
     """Times the oracle on the GPU box's host cores (one process per hardware thread, records handed out dynamically,
     longest first) for about target_s seconds of wall time; must run BEFORE this process touches the GPU (it spawns
     workers).  The workers run their numerical libraries single-threaded: 256 processes x a BLAS / OpenMP pool each
     would measure oversubscription, not the algorithm."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
         os.environ[var] = "1"                              # (inherited by the spawned workers; restored below)
     recs = [r + (1000,) for r in recs]
@@ -111,8 +135,9 @@ def cpu_baseline(recs, cfg, target_s=10.0):
     out = dict(value=round(done / wall, 1), unit="seq/s", cores=cores, kind="port",
                per_thread_seq_per_s=round(done / max(busy, 1e-9), 2), one_thread_alone_seq_per_s=round(len(recs) / per_pass, 2),
                sample="SRtest150 records (longest first, repeated) for %.1f s of wall time: %d folds, c=%s, C oracle "
-                      "(oracle/sqrn_oracle.c + Python tail, scipy / networkx for H / E), one single-threaded process per "
-                      "hardware thread, summed worker time %.1fs" % (wall, done, cfg, busy))
+                      "(oracle/sqrn_oracle.c + Python tail, scipy / networkx for H / E), one single-threaded process per CPU the "
+                      "job may use (cores = min(hardware threads %d, affinity, cgroup quota)), summed worker time %.1fs" % (
+                          wall, done, cfg, os.cpu_count() or 1, busy))
     # the synthetic BASELINE sizes on a stated subsample (time a subsample, extrapolate linearly)
     others = {}
     import numpy as np
@@ -351,7 +376,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="nobpp")
-    ap.add_argument("--inflight", type=int, default=4, help="independent SRtest150 batches in flight per GPU")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="independent SRtest150 batches in flight per GPU (0 = auto: 8, fewer when the ranks of the node "
+                         "share few CPUs -- every batch has a host thread that drives its rounds)")
     ap.add_argument("--workload", default="srtest150", choices=["srtest150", "S300", "S1000", "S2000"])
     ap.add_argument("--sub-batches", type=int, default=4, help="strong-scaling mode: concurrent batches per rank")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -395,7 +422,8 @@ def main():
     from squarna_amd.engine import Batch, Prepared, fold_concurrently
     names, psets = ParseConfig(builtin_config(args.config))
     prepared = [Prepared(seq, reacts, restr, ref) for _, seq, reacts, restr, ref in recs]
-    K = max(1, args.inflight)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    K = args.inflight if args.inflight > 0 else min(8, max(1, effective_cpus() // (2 * max(1, local_world))))
     batches = []
     for _ in range(K):                                        # inputs resident in HBM; one stream per batch
         with torch.cuda.stream(torch.cuda.Stream(device)):
@@ -516,7 +544,7 @@ def main():
         "data": "SRtest150.fas shipped with the reference (219 records, 8-150 nt, reference dbn per record)",
         "config": {"workload": "SRtest150 if=qf c=%s poollim=1000; %d independent 219-record batches in flight per GPU "
                                "(sq_fold_concurrent, one stream set each); a step folds all of them" % (args.config, K),
-                   "batches_in_flight": K, "seqs_per_gpu_per_step": per_step, "paramsets": names,
+                   "batches_in_flight": K, "host_cpus": effective_cpus(), "seqs_per_gpu_per_step": per_step, "paramsets": names,
                    "evals_R_per_step": int(evals) * K, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
         "single_batch": {"ms_per_fold": round(lat[len(lat) // 2], 3), "best_ms": round(lat[0], 3),
                          "seq_per_s": round(len(prepared) / lat[len(lat) // 2] * 1e3, 1),

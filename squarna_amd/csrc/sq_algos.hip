@@ -139,17 +139,21 @@ struct JobBuild { int n = 0; size_t ncell = 0, need = 0, nout = 0; };
 // runtime multiplexes all streams of the process onto a few hardware queues (GPU_MAX_HW_QUEUES), streams that share a
 // queue serialise, and with several batches in flight every stream less keeps a 6 ms blossom kernel out of some other
 // batch's round queue.  Hungarian + Nussinov back to back (1.4 + 1.5 ms) still end long before Edmonds does.
-static inline int side_of(int slot)
+// One batch folded alone keeps Nussinov on a stream of its own (it then ends before the greedy loop does, and the
+// collection of the short kernels does not wait behind Edmonds' second size class + Hungarian); sq_fold_concurrent
+// with three or more batches in flight asks for the two-stream form.
+static inline int side_of(const sq_batch *b, int slot)
 {
-    static const bool three = getenv("SQ_SIDE_STREAMS") && atoi(getenv("SQ_SIDE_STREAMS")) >= 3;
-    return three ? slot : (slot == 0 ? 0 : 1);
+    static const int forced = getenv("SQ_SIDE_STREAMS") ? atoi(getenv("SQ_SIDE_STREAMS")) : 0;
+    const int nside = forced ? forced : b->side_streams;
+    return nside >= 3 ? slot : (nside == 2 ? (slot == 0 ? 0 : 1) : 0);
 }
 
 // pinned staging buffer `slot` of the batch, at least `bytes` large (grow-only)
 static char *stage_buffer(sq_batch *b, int slot, size_t bytes)
 {
     if (b->stage_cap[slot] < bytes) {
-        if (b->stage_buf[slot]) { hipStreamSynchronize(slot < 3 && b->side[side_of(slot)] ? b->side[side_of(slot)] : b->stream); sq_pinned_put(b->stage_buf[slot]); }
+        if (b->stage_buf[slot]) { hipStreamSynchronize(slot < 3 && b->side[side_of(b, slot)] ? b->side[side_of(b, slot)] : b->stream); sq_pinned_put(b->stage_buf[slot]); }
         b->stage_buf[slot] = nullptr; b->stage_cap[slot] = 0;
         const size_t cap = bytes + bytes / 2 + 4096;
         if (sq_pinned_get((void **)&b->stage_buf[slot], cap)) return nullptr;
@@ -360,17 +364,17 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
     if (!streaming) {   // spin on the completion word in pinned memory (no driver round trip, no staged copy)
         volatile uint32_t *flag = ck.flag;
         uint64_t spins = 0;
+        const bool relaxed = sq_relaxed_waits(b);
+        const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
         while (*flag != ck.flag_val) {
-            if ((++spins & 0xFFFFF) == 0) {
+            if ((++spins & poll_mask) == 0) {
                 const hipError_t q = hipStreamQuery(ck.st);
                 if (q != hipErrorNotReady) {
                     if (q != hipSuccess) return sq_check(q, "matching kernel");
                     if (*flag != ck.flag_val) { HIPCK(hipStreamSynchronize(ck.st)); if (*flag != ck.flag_val) { sq_set_error("matching kernel did not signal completion"); return 2; } }
                 }
             }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
+            sq_wait_step(spins, relaxed);
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
@@ -466,11 +470,8 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
                     if (missing) { bad = 2; break; }
                 }
             }
-            for (int t = 0; t < 32; t++) {
-#if defined(__x86_64__)
-                __builtin_ia32_pause();
-#endif
-            }
+            if (sq_relaxed_waits(b)) sq_wait_step(1 << 20, true);    // (sleeps ~10 us)
+            else for (int t = 0; t < 32; t++) sq_wait_step(0, false);
         }
     }
     if (bad == 3) return sq_check((hipError_t)stream_err.load(), "matching kernel");
@@ -548,7 +549,7 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
         int rb = algo_build(b, it.jobs, it.stems, 0, it.algo, (size_t)free_rec * sizeof(SqCand), sidx, it.ck);
         if (rb) return rb;
         if (it.ck.k1 != it.jobs.size()) { it.ck = SqAlgoChunk(); return 0; }   // does not fit as one chunk: synchronous later
-        const int ss = side_of(sidx);
+        const int ss = side_of(b, sidx);
         if (!b->side[ss]) { if (sq_check(hipStreamCreateWithFlags(&b->side[ss], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
         const int64_t used_rec = (int64_t)((it.ck.bytes + 256 + sizeof(SqCand) - 1) / sizeof(SqCand));
         b->cand_reserved += used_rec;                   // carved downwards from the end of the arena
@@ -556,8 +557,8 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
         region = (char *)(((uintptr_t)region + 255) & ~(uintptr_t)255);
         const double tl0 = sq_now();
         hipStream_t st2 = nullptr;
-        if (it.algo == SQ_ALGO_E && side_of(1) != ss) {               // the stream of the short kernels (created here if need be)
-            const int s2 = side_of(1);
+        if (it.algo == SQ_ALGO_E && side_of(b, 1) != ss) {               // the stream of the short kernels (created here if need be)
+            const int s2 = side_of(b, 1);
             if (!b->side[s2]) { if (sq_check(hipStreamCreateWithFlags(&b->side[s2], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
             st2 = b->side[s2];
         }

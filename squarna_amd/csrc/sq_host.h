@@ -133,6 +133,8 @@ struct sq_batch {
     hipStream_t lane_stream = nullptr;        // second lane of sq_fold's greedy rounds (created on first use)
     hipEvent_t lane_ev = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
+    int inflight = 1;                     // batches folded at the same time (sq_fold_concurrent): sizes the pool, relaxes the wait loops
+    int side_streams = 3;                 // side streams of E / H / N: 3, or 2 (H and N share one) with many batches in flight
     hipEvent_t class_ev = nullptr;        // joins the blossom kernel's smaller size classes (on side[1]) into side[0]
     uint32_t out_cap = 0;
     int32_t strand_cap = 0;
@@ -169,6 +171,9 @@ void sq_set_error(const std::string &msg);
 int sq_pinned_get(void **p, size_t bytes);     // 0 or an error code (message set)
 void sq_pinned_put(void *p);                   // the streams that used the buffer must be idle
 int sq_check(hipError_t e, const char *what);
+int sq_effective_cpus();                       // CPUs this process may really use: hardware threads, affinity, cgroup quota
+bool sq_relaxed_waits(const sq_batch *b);       // spin-then-sleep instead of pure spinning (many batches in flight, few CPUs)
+void sq_wait_step(uint64_t spins, bool relaxed);   // one step of a wait loop on a pinned completion word
 // profiling bracket on an arbitrary stream (slot k of sq_profile_get); no-ops unless profiling is enabled
 void sq_prof_begin(sq_batch *b, int k, hipStream_t st, hipEvent_t *e0);
 void sq_prof_end(sq_batch *b, int k, hipStream_t st, hipEvent_t e0);

@@ -28,6 +28,62 @@ int sq_check(hipError_t e, const char *what)
 }
 #define HIPCK(x) do { int _r = sq_check((x), #x); if (_r) return _r; } while (0)
 
+// ---- host CPUs this process may really use --------------------------------------------------------
+// min(hardware threads, affinity mask, cgroup CPU quota).  A container with cpu.max = "1600000 100000" shows 256
+// hardware threads but gets 16 CPUs worth of time per period; threads beyond that (workers, spinning waiters) only
+// burn the quota and the whole process is throttled for the rest of the period (measured on the MI355X box: 40-60 ms
+// stalls every few steps with 8 batches in flight).
+#include <sched.h>
+#include <sys/prctl.h>
+#include <time.h>
+int sq_effective_cpus()
+{
+    static const int n = [] {
+        int cpus = (int)std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::min(cpus, std::max(1, CPU_COUNT(&set)));
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                    // cgroup v2: "<quota|max> <period>"
+            char q[64]; long long per = 0;
+            if (fscanf(f, "%63s %lld", q, &per) == 2 && per > 0 && strcmp(q, "max") != 0)
+                cpus = std::min<long long>(cpus, std::max<long long>(1, (atoll(q) + per - 1) / per));
+            fclose(f);
+        } else {
+            long long quota = -1, per = 0;                                       // cgroup v1
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = 0; fclose(g); }
+            if (quota > 0 && per > 0) cpus = std::min<long long>(cpus, std::max<long long>(1, (quota + per - 1) / per));
+        }
+        if (const char *e = getenv("SQ_CPUS")) cpus = std::max(1, atoi(e));
+        return cpus;
+    }();
+    return n;
+}
+// One step of a wait loop on a pinned completion word.  Alone, a waiter spins (a round lasts ~100 us; a sleep would
+// double it).  With several batches in flight (`relaxed`) it spins for a few microseconds and then sleeps ~10 us at a
+// time: a dozen threads spinning through 6 ms blossom kernels would use up the CPU quota the workers need.
+// relaxed waiting pays once the waiters alone (about two per batch in flight) would take most of the CPU budget
+bool sq_relaxed_waits(const sq_batch *b)
+{
+    static const int forced = getenv("SQ_RELAX") ? atoi(getenv("SQ_RELAX")) : -1;
+    if (forced >= 0) return forced != 0;
+    int lws = 1;
+    if (const char *e = getenv("LOCAL_WORLD_SIZE")) lws = std::max(1, atoi(e));
+    return 2 * b->inflight * lws > (sq_effective_cpus() * 3) / 5;
+}
+void sq_wait_step(uint64_t spins, bool relaxed)
+{
+    if (relaxed && spins > 512) {
+        static thread_local bool slack_set = false;
+        if (!slack_set) { prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }   // 1 us instead of the default 50 us
+        struct timespec ts = {0, 10000};
+        nanosleep(&ts, nullptr);
+        return;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
+
 // ---- host worker pool -------------------------------------------------------------------------
 SqPool::SqPool(int nthreads, int device)
 {
@@ -80,10 +136,15 @@ void SqPool::parallel_for(int n, const std::function<void(int)> &f, int wide)
 SqPool *sq_pool(sq_batch *b)
 {
     if (!b->pool) {
-        // up to 32 workers, sharing the host cores with the other ranks of the node (torchrun's LOCAL_WORLD_SIZE)
-        unsigned cores = std::max(1u, std::thread::hardware_concurrency());
+        // up to 32 workers, sharing the CPUs this process may use (sq_effective_cpus) with the other ranks of the node
+        // (torchrun's LOCAL_WORLD_SIZE) and the other batches in flight (sq_fold_concurrent)
+        // The workers sleep between bursts (tails of finished sequences, pool growth of big rounds), so their number is
+        // not tied to the CPU budget as tightly as the spinning waiters are: 4 x the CPUs of this rank, shared among
+        // the batches in flight, between 8 and 32 (measured with a 16-CPU quota and 4 batches in flight: 2 workers
+        // per batch 18.0 ms per step, 8 -> 12.2 ms, 32 -> 11.3 ms).
+        unsigned cores = (unsigned)sq_effective_cpus();
         if (const char *lws = getenv("LOCAL_WORLD_SIZE")) cores = std::max(1u, cores / (unsigned)std::max(1, atoi(lws)));
-        int nthr = (int)std::min(cores, 32u);
+        int nthr = (int)std::min(std::max(4u * cores / (unsigned)std::max(1, b->inflight), 8u), 32u);
         if (const char *e = getenv("SQ_HOST_THREADS")) nthr = std::max(1, atoi(e));
         b->pool = new SqPool(nthr, b->device);
     }
@@ -925,17 +986,17 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
     {
         volatile uint32_t *flag = ln.h_seq;
         uint64_t spins = 0;
+        const bool relaxed = sq_relaxed_waits(b);
+        const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
         while (*flag != seq) {
-            if ((++spins & 0xFFFFF) == 0) {
+            if ((++spins & poll_mask) == 0) {
                 const hipError_t q = hipStreamQuery(st);
                 if (q != hipErrorNotReady) {
                     if (q != hipSuccess) return sq_check(q, "round kernels");
                     if (*flag != seq) { HIPCK(hipStreamSynchronize(st)); if (*flag != seq) { sq_set_error("round did not signal completion"); return 2; } }
                 }
             }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
+            sq_wait_step(spins, relaxed);
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
@@ -1423,6 +1484,11 @@ extern "C" int sq_fold_concurrent(sq_batch *const *batches, int32_t nbatch, cons
     if (!batches || nbatch <= 0 || !opts) { sq_set_error("bad argument"); return -1; }
     std::vector<int> rc(nbatch, 0);
     std::vector<std::string> msg(nbatch);
+    // every stream less keeps the long kernels of one batch out of another batch's hardware queue (GPU_MAX_HW_QUEUES)
+    for (int k = 0; k < nbatch; k++) if (batches[k]) {
+        batches[k]->side_streams = nbatch >= 3 ? 2 : 3;
+        batches[k]->inflight = nbatch;
+    }
     auto work = [&](int k) {
         if (k > 0 && batches[k]->device >= 0) hipSetDevice(batches[k]->device);
         rc[k] = sq_fold(batches[k], opts, ref_off ? ref_off[k] : nullptr, ref_pairs ? ref_pairs[k] : nullptr,
