@@ -360,6 +360,13 @@ int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatch
             if (e != hipSuccess) return (int)e;
             edges = dev_edges;
         }
+        static const size_t lds_cap = getenv("SQ_MWM_LDS_CAP") ? (size_t)atol(getenv("SQ_MWM_LDS_CAP")) : 150 * 1024;
+        if (want > lds_cap) {                            // (graphs above the cap keep only the hot part of their state in LDS)
+            hipError_t e = edges == dev_edges ? hipSuccess : hipMemcpyAsync(dev_edges, edges, nedges * sizeof(SqMatchEdge), hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) return (int)e;
+            edges = dev_edges;
+            want = lds_cap;
+        }
         if (want > 150 * 1024) want = 150 * 1024;        // jobs that do not fit run in global memory
         if (nolds) want = 0;
         hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), want, st, jobs, edges, d_scr, out, (int)want, job_flags, flag_val);
