@@ -116,6 +116,10 @@ struct SqCoopWave {
 };
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+extern __shared__ __attribute__((aligned(16))) char sq_mwm_dyn_lds[];   // the kernel's dynamic LDS (sq_mwm_kernel)
+#endif
+
 struct SqBlossom {
     // graph
     int n, m;                 // vertices (graph order), undirected edges
@@ -248,116 +252,129 @@ struct SqBlossom {
         sync();
     }
 
-    SQ_HD int tail(int de) const { return (de & 1) ? E[de >> 1].w : E[de >> 1].v; }
-    SQ_HD int head(int de) const { return (de & 1) ? E[de >> 1].v : E[de >> 1].w; }
-    SQ_HD double slack(int de) const { return dualvar[tail(de)] + dualvar[head(de)] - 2 * E[de >> 1].weight; }
+    // FAST: which parts of the state live in the kernel's dynamic LDS buffer (1: everything incl. the edge list, 2: only
+    // the hot part, 0: nothing).  Every array access goes through SQ_LP (hot arrays) / SQ_LQ (cold, edge arrays, E):
+    // with the array in LDS the address is formed as <dynamic LDS base> + offset, which lets the compiler prove the
+    // address space and emit ds_read / ds_write instead of flat loads through the LDS aperture -- in the scan loop AND
+    // in the lane-0 event paths (assignLabel, addBlossom, augmentMatching, ...), which are templates on FAST for that.
+    char *origin;             // generic address of the LDS buffer that holds edges + state (FAST runs only)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SQ_FAST0 sq_mwm_dyn_lds
+#else
+#define SQ_FAST0 ((char *)nullptr)
+#endif
+#define SQ_LP(p) (FAST ? (decltype(p))(SQ_FAST0 + ((char *)(p) - origin)) : (p))            /* hot arrays */
+#define SQ_LQ(p) (FAST == 1 ? (decltype(p))(SQ_FAST0 + ((char *)(p) - origin)) : (p))       /* cold / edge arrays, E */
+    template <int FAST = 0> SQ_HD int tail(int de) const { return (de & 1) ? SQ_LQ(E)[de >> 1].w : SQ_LQ(E)[de >> 1].v; }
+    template <int FAST = 0> SQ_HD int head(int de) const { return (de & 1) ? SQ_LQ(E)[de >> 1].v : SQ_LQ(E)[de >> 1].w; }
+    template <int FAST = 0> SQ_HD double slack(int de) const { return SQ_LP(dualvar)[tail<FAST>(de)] + SQ_LP(dualvar)[head<FAST>(de)] - 2 * SQ_LQ(E)[de >> 1].weight; }
     SQ_HD bool is_blossom(int x) const { return x >= n; }
-    SQ_HD void qpush(int v) { if (qn < qcap) queue[qn++] = v; else error = 1; }
+    template <int FAST = 0> SQ_HD void qpush(int v) { if (qn < qcap) SQ_LP(queue)[qn++] = v; else error = 1; }
 
     // Blossom.leaves(): stack = [*childs]; pop from the end; sub-blossoms push their childs
-    SQ_HD int leaves(int b, int *out)
+    template <int FAST = 0> SQ_HD int leaves(int b, int *out)
     {
         int sn = 0, cnt = 0;
-        int c = first[b];
-        for (int k = 0; k < nchild[b]; k++) { tmp_stack[sn++] = c; c = sib_next[c]; }
+        int c = SQ_LQ(first)[b];
+        for (int k = 0; k < SQ_LQ(nchild)[b]; k++) { SQ_LQ(tmp_stack)[sn++] = c; c = SQ_LQ(sib_next)[c]; }
         while (sn) {
-            const int t = tmp_stack[--sn];
+            const int t = SQ_LQ(tmp_stack)[--sn];
             if (is_blossom(t)) {
-                int cc = first[t];
-                for (int k = 0; k < nchild[t]; k++) { tmp_stack[sn++] = cc; cc = sib_next[cc]; }
+                int cc = SQ_LQ(first)[t];
+                for (int k = 0; k < SQ_LQ(nchild)[t]; k++) { SQ_LQ(tmp_stack)[sn++] = cc; cc = SQ_LQ(sib_next)[cc]; }
             } else out[cnt++] = t;
         }
         return cnt;
     }
 
-    SQ_HD void assignLabel(int w, int t, int de)       // de: labeledge (v, w) or -1
+    template <int FAST = 0> SQ_HD void assignLabel(int w, int t, int de)       // de: labeledge (v, w) or -1
     {
         for (;;) {
-            const int b = inblossom[w];
-            label[w] = label[b] = (int8_t)t;
-            labeledge[w] = labeledge[b] = de;
-            bestedge[w] = bestedge[b] = -1;
+            const int b = SQ_LP(inblossom)[w];
+            SQ_LP(label)[w] = SQ_LP(label)[b] = (int8_t)t;
+            SQ_LP(labeledge)[w] = SQ_LP(labeledge)[b] = de;
+            SQ_LP(bestedge)[w] = SQ_LP(bestedge)[b] = -1;
             if (t == 1) {
                 if (is_blossom(b)) {
-                    const int c = leaves(b, tmp_leaves);
-                    for (int k = 0; k < c; k++) qpush(tmp_leaves[k]);
-                } else qpush(b);
+                    const int c = leaves<FAST>(b, SQ_LQ(tmp_leaves));
+                    for (int k = 0; k < c; k++) qpush<FAST>(SQ_LQ(tmp_leaves)[k]);
+                } else qpush<FAST>(b);
                 return;
             }
             // t == 2: the mate of the base becomes an S-vertex
-            const int bs = base[b];
-            de = mate_de[bs];                            // (base, mate[base])
-            w = mate[bs]; t = 1;
+            const int bs = SQ_LQ(base)[b];
+            de = SQ_LQ(mate_de)[bs];                            // (base, SQ_LQ(mate)[base])
+            w = SQ_LQ(mate)[bs]; t = 1;
         }
     }
 
-    SQ_HD int scanBlossom(int v, int w)
+    template <int FAST = 0> SQ_HD int scanBlossom(int v, int w)
     {
         int pn = 0, bs = -1;
         while (v != -1) {
-            int b = inblossom[v];
-            if (label[b] & 4) { bs = base[b]; break; }
-            tmp_path[pn++] = b;
-            label[b] = 5;
-            if (labeledge[b] == -1) v = -1;
+            int b = SQ_LP(inblossom)[v];
+            if (SQ_LP(label)[b] & 4) { bs = SQ_LQ(base)[b]; break; }
+            SQ_LQ(tmp_path)[pn++] = b;
+            SQ_LP(label)[b] = 5;
+            if (SQ_LP(labeledge)[b] == -1) v = -1;
             else {
-                v = tail(labeledge[b]);
-                b = inblossom[v];
-                v = tail(labeledge[b]);
+                v = tail<FAST>(SQ_LP(labeledge)[b]);
+                b = SQ_LP(inblossom)[v];
+                v = tail<FAST>(SQ_LP(labeledge)[b]);
             }
             if (w != -1) { const int t = v; v = w; w = t; }
         }
-        for (int k = 0; k < pn; k++) label[tmp_path[k]] = 1;
+        for (int k = 0; k < pn; k++) SQ_LP(label)[SQ_LQ(tmp_path)[k]] = 1;
         return bs;
     }
 
-    SQ_HD int new_blossom() { if (nfree == 0) { error = 2; return n; } return freeb[--nfree]; }
+    template <int FAST = 0> SQ_HD int new_blossom() { if (nfree == 0) { error = 2; return n; } return SQ_LQ(freeb)[--nfree]; }
 
-    SQ_HD void addBlossom(int bs, int de)               // de = (v, w)
+    template <int FAST = 0> SQ_HD void addBlossom(int bs, int de)               // de = (v, w)
     {
-        int v = tail(de), w = head(de);
-        const int bb = inblossom[bs];
-        int bv = inblossom[v], bw = inblossom[w];
-        const int b = new_blossom();
-        base[b] = bs; parent[b] = -1; parent[bb] = b;
-        live[nlive++] = b;
-        int *path = tmp_path, *edgs = tmp_edges;          // python lists
+        int v = tail<FAST>(de), w = head<FAST>(de);
+        const int bb = SQ_LP(inblossom)[bs];
+        int bv = SQ_LP(inblossom)[v], bw = SQ_LP(inblossom)[w];
+        const int b = new_blossom<FAST>();
+        SQ_LQ(base)[b] = bs; SQ_LQ(parent)[b] = -1; SQ_LQ(parent)[bb] = b;
+        SQ_LQ(live)[nlive++] = b;
+        int *const path = SQ_LQ(tmp_path), *const edgs = SQ_LQ(tmp_edges);          // python lists
         int pn = 0, en = 0;
         edgs[en++] = de;
         while (bv != bb) {
-            parent[bv] = b;
+            SQ_LQ(parent)[bv] = b;
             path[pn++] = bv;
-            edgs[en++] = labeledge[bv];
-            v = tail(labeledge[bv]);
-            bv = inblossom[v];
+            edgs[en++] = SQ_LP(labeledge)[bv];
+            v = tail<FAST>(SQ_LP(labeledge)[bv]);
+            bv = SQ_LP(inblossom)[v];
         }
         path[pn++] = bb;
         for (int a = 0, z = pn - 1; a < z; a++, z--) { const int t = path[a]; path[a] = path[z]; path[z] = t; }
         for (int a = 0, z = en - 1; a < z; a++, z--) { const int t = edgs[a]; edgs[a] = edgs[z]; edgs[z] = t; }
         while (bw != bb) {
-            parent[bw] = b;
+            SQ_LQ(parent)[bw] = b;
             path[pn++] = bw;
-            edgs[en++] = labeledge[bw] ^ 1;                // (labeledge[bw][1], labeledge[bw][0])
-            w = tail(labeledge[bw]);
-            bw = inblossom[w];
+            edgs[en++] = SQ_LP(labeledge)[bw] ^ 1;                // (SQ_LP(labeledge)[bw][1], SQ_LP(labeledge)[bw][0])
+            w = tail<FAST>(SQ_LP(labeledge)[bw]);
+            bw = SQ_LP(inblossom)[w];
         }
         // childs = path, edges = edgs (edges[i] joins childs[i] -> childs[i+1], cyclically)
-        nchild[b] = pn; first[b] = path[0];
+        SQ_LQ(nchild)[b] = pn; SQ_LQ(first)[b] = path[0];
         for (int k = 0; k < pn; k++) {
-            sib_next[path[k]] = path[(k + 1) % pn];
-            sib_prev[path[k]] = path[(k + pn - 1) % pn];
-            edge_after[path[k]] = edgs[k];
+            SQ_LQ(sib_next)[path[k]] = path[(k + 1) % pn];
+            SQ_LQ(sib_prev)[path[k]] = path[(k + pn - 1) % pn];
+            SQ_LQ(edge_after)[path[k]] = edgs[k];
         }
-        label[b] = 1;
-        labeledge[b] = labeledge[bb];
-        bdual[b] = 0;
+        SQ_LP(label)[b] = 1;
+        SQ_LP(labeledge)[b] = SQ_LP(labeledge)[bb];
+        SQ_LQ(bdual)[b] = 0;
         {
-            const int c = leaves(b, tmp_leaves);
-            nleaf[b] = c;                                   // fixed for the blossom's lifetime
+            const int c = leaves<FAST>(b, SQ_LQ(tmp_leaves));
+            SQ_LQ(nleaf)[b] = c;                                   // fixed for the blossom's lifetime
             for (int k = 0; k < c; k++) {
-                const int x = tmp_leaves[k];
-                if (label[inblossom[x]] == 2) qpush(x);
-                inblossom[x] = b;
+                const int x = SQ_LQ(tmp_leaves)[k];
+                if (SQ_LP(label)[SQ_LP(inblossom)[x]] == 2) qpush<FAST>(x);
+                SQ_LP(inblossom)[x] = b;
             }
         }
         // bestedgeto: dict bj -> edge (insertion ordered)
@@ -366,137 +383,137 @@ struct SqBlossom {
             const int cv = path[k];
             // nblist
             int lstart = pool_n, lcount = 0; bool from_pool = false;
-            if (is_blossom(cv) && mbe_cnt[cv] >= 0) {
-                lstart = mbe_off[cv]; lcount = mbe_cnt[cv]; from_pool = true;
-                mbe_cnt[cv] = -1;
+            if (is_blossom(cv) && SQ_LQ(mbe_cnt)[cv] >= 0) {
+                lstart = SQ_LQ(mbe_off)[cv]; lcount = SQ_LQ(mbe_cnt)[cv]; from_pool = true;
+                SQ_LQ(mbe_cnt)[cv] = -1;
             }
             int nleaf = 1;
             if (!from_pool) {
-                if (is_blossom(cv)) nleaf = leaves(cv, tmp_leaves); else tmp_leaves[0] = cv;
+                if (is_blossom(cv)) nleaf = leaves<FAST>(cv, SQ_LQ(tmp_leaves)); else SQ_LQ(tmp_leaves)[0] = cv;
             }
             int li = 0, ai = 0;                             // iterate nblist lazily
             for (;;) {
                 int kde;
                 if (from_pool) {
                     if (li >= lcount) break;
-                    kde = pool[lstart + li++];
+                    kde = SQ_LQ(pool)[lstart + li++];
                 } else {
                     if (li >= nleaf) break;
-                    const int x = tmp_leaves[li];
-                    if (ai >= adj_off[x + 1] - adj_off[x]) { li++; ai = 0; continue; }
-                    kde = adj[adj_off[x] + ai++];
+                    const int x = SQ_LQ(tmp_leaves)[li];
+                    if (ai >= SQ_LP(adj_off)[x + 1] - SQ_LP(adj_off)[x]) { li++; ai = 0; continue; }
+                    kde = SQ_LQ(adj)[SQ_LP(adj_off)[x] + ai++];
                 }
-                int i = tail(kde), j = head(kde);
-                if (inblossom[j] == b) { const int t = i; i = j; j = t; }
-                const int bj = inblossom[j];
-                if (bj != b && label[bj] == 1) {
-                    const int ide = (tail(kde) == i) ? kde : (kde ^ 1);   // slack(i, j)
-                    if (beto[bj] == -1) { beto[bj] = kde; beto_keys[nk++] = bj; }
-                    else if (slack(ide) < slack(beto[bj])) beto[bj] = kde;
+                int i = tail<FAST>(kde), j = head<FAST>(kde);
+                if (SQ_LP(inblossom)[j] == b) { const int t = i; i = j; j = t; }
+                const int bj = SQ_LP(inblossom)[j];
+                if (bj != b && SQ_LP(label)[bj] == 1) {
+                    const int ide = (tail<FAST>(kde) == i) ? kde : (kde ^ 1);   // slack<FAST>(i, j)
+                    if (SQ_LQ(beto)[bj] == -1) { SQ_LQ(beto)[bj] = kde; SQ_LQ(beto_keys)[nk++] = bj; }
+                    else if (slack<FAST>(ide) < slack<FAST>(SQ_LQ(beto)[bj])) SQ_LQ(beto)[bj] = kde;
                 }
             }
-            bestedge[cv] = -1;
+            SQ_LP(bestedge)[cv] = -1;
         }
         // b.mybestedges = list(bestedgeto.values())
-        mbe_off[b] = pool_n; mbe_cnt[b] = nk;
+        SQ_LQ(mbe_off)[b] = pool_n; SQ_LQ(mbe_cnt)[b] = nk;
         int mybest = -1; double mybestslack = 0;
         for (int k = 0; k < nk; k++) {
-            const int kde = beto[beto_keys[k]];
-            beto[beto_keys[k]] = -1;
-            if (pool_n < pool_cap) pool[pool_n++] = kde; else error = 3;
-            const double ks = slack(kde);
+            const int kde = SQ_LQ(beto)[SQ_LQ(beto_keys)[k]];
+            SQ_LQ(beto)[SQ_LQ(beto_keys)[k]] = -1;
+            if (pool_n < pool_cap) SQ_LQ(pool)[pool_n++] = kde; else error = 3;
+            const double ks = slack<FAST>(kde);
             if (mybest == -1 || ks < mybestslack) { mybest = kde; mybestslack = ks; }
         }
-        bestedge[b] = mybest; bslack[b] = mybestslack;
+        SQ_LP(bestedge)[b] = mybest; SQ_LP(bslack)[b] = mybestslack;
     }
 
-    SQ_HD void remove_live(int b)
+    template <int FAST = 0> SQ_HD void remove_live(int b)
     {
         int k = 0;
-        while (k < nlive && live[k] != b) k++;
-        for (; k + 1 < nlive; k++) live[k] = live[k + 1];
+        while (k < nlive && SQ_LQ(live)[k] != b) k++;
+        for (; k + 1 < nlive; k++) SQ_LQ(live)[k] = SQ_LQ(live)[k + 1];
         nlive--;
-        freeb[nfree++] = b;
+        SQ_LQ(freeb)[nfree++] = b;
     }
 
-    // expandBlossom(b, endstage) with the recursion of _recurse made explicit
-    SQ_HD void expandBlossom(int b0, bool endstage)
+    // expandBlossom<FAST>(b, endstage) with the recursion of _recurse made explicit
+    template <int FAST = 0> SQ_HD void expandBlossom(int b0, bool endstage)
     {
-        int *fr = frames;                                  // frame: (b, next child, remaining)
+        int *const fr = SQ_LQ(frames);                                  // frame: (b, next child, remaining)
         int sp = 0;
-        fr[0] = b0; fr[1] = first[b0]; fr[2] = nchild[b0]; sp = 1;
+        fr[0] = b0; fr[1] = SQ_LQ(first)[b0]; fr[2] = SQ_LQ(nchild)[b0]; sp = 1;
         while (sp) {
             int *f = fr + 3 * (sp - 1);
             const int b = f[0];
             if (f[2] > 0) {
                 const int s = f[1];
-                f[1] = sib_next[s]; f[2]--;
-                parent[s] = -1;
+                f[1] = SQ_LQ(sib_next)[s]; f[2]--;
+                SQ_LQ(parent)[s] = -1;
                 if (is_blossom(s)) {
-                    if (endstage && bdual[s] == 0) {       // yield s: expand it now, then continue with the next child
+                    if (endstage && SQ_LQ(bdual)[s] == 0) {       // yield s: expand it now, then continue with the next child
                         if (3 * (sp + 1) > frame_cap) { error = 4; return; }
                         int *g = fr + 3 * sp;
-                        g[0] = s; g[1] = first[s]; g[2] = nchild[s]; sp++;
+                        g[0] = s; g[1] = SQ_LQ(first)[s]; g[2] = SQ_LQ(nchild)[s]; sp++;
                     } else {
-                        const int c = leaves(s, tmp_leaves);
-                        for (int k = 0; k < c; k++) inblossom[tmp_leaves[k]] = s;
+                        const int c = leaves<FAST>(s, SQ_LQ(tmp_leaves));
+                        for (int k = 0; k < c; k++) SQ_LP(inblossom)[SQ_LQ(tmp_leaves)[k]] = s;
                     }
-                } else inblossom[s] = s;
+                } else SQ_LP(inblossom)[s] = s;
                 continue;
             }
-            if (!endstage && label[b] == 2) {
-                const int entry = inblossom[head(labeledge[b])];
+            if (!endstage && SQ_LP(label)[b] == 2) {
+                const int entry = SQ_LP(inblossom)[head<FAST>(SQ_LP(labeledge)[b])];
                 int j = 0;
-                { int c = first[b]; while (c != entry) { c = sib_next[c]; j++; } }
+                { int c = SQ_LQ(first)[b]; while (c != entry) { c = SQ_LQ(sib_next)[c]; j++; } }
                 int c = entry, jstep;
-                if (j & 1) { j -= nchild[b]; jstep = 1; } else jstep = -1;
-                int de = labeledge[b];                     // (v, w)
+                if (j & 1) { j -= SQ_LQ(nchild)[b]; jstep = 1; } else jstep = -1;
+                int de = SQ_LP(labeledge)[b];                     // (v, w)
                 while (j != 0) {
                     int pq;                                // directed (p, q)
-                    if (jstep == 1) pq = edge_after[c]; else pq = edge_after[sib_prev[c]] ^ 1;
-                    const int w = head(de), q = head(pq);
-                    label[w] = 0; label[q] = 0;
-                    assignLabel(w, 2, de);
-                    allow[pq >> 1] = 1;
-                    j += jstep; c = (jstep == 1) ? sib_next[c] : sib_prev[c];
-                    if (jstep == 1) de = edge_after[c]; else de = edge_after[sib_prev[c]] ^ 1;
-                    allow[de >> 1] = 1;
-                    j += jstep; c = (jstep == 1) ? sib_next[c] : sib_prev[c];
+                    if (jstep == 1) pq = SQ_LQ(edge_after)[c]; else pq = SQ_LQ(edge_after)[SQ_LQ(sib_prev)[c]] ^ 1;
+                    const int w = head<FAST>(de), q = head<FAST>(pq);
+                    SQ_LP(label)[w] = 0; SQ_LP(label)[q] = 0;
+                    assignLabel<FAST>(w, 2, de);
+                    SQ_LP(allow)[pq >> 1] = 1;
+                    j += jstep; c = (jstep == 1) ? SQ_LQ(sib_next)[c] : SQ_LQ(sib_prev)[c];
+                    if (jstep == 1) de = SQ_LQ(edge_after)[c]; else de = SQ_LQ(edge_after)[SQ_LQ(sib_prev)[c]] ^ 1;
+                    SQ_LP(allow)[de >> 1] = 1;
+                    j += jstep; c = (jstep == 1) ? SQ_LQ(sib_next)[c] : SQ_LQ(sib_prev)[c];
                 }
                 const int bw = c;                           // b.childs[0]
-                const int w = head(de);
-                label[w] = label[bw] = 2;
-                labeledge[w] = labeledge[bw] = de;
-                bestedge[bw] = -1;
-                c = (jstep == 1) ? sib_next[c] : sib_prev[c];
+                const int w = head<FAST>(de);
+                SQ_LP(label)[w] = SQ_LP(label)[bw] = 2;
+                SQ_LP(labeledge)[w] = SQ_LP(labeledge)[bw] = de;
+                SQ_LP(bestedge)[bw] = -1;
+                c = (jstep == 1) ? SQ_LQ(sib_next)[c] : SQ_LQ(sib_prev)[c];
                 while (c != entry) {
                     const int bv = c;
-                    if (label[bv] == 1) { c = (jstep == 1) ? sib_next[c] : sib_prev[c]; continue; }
+                    if (SQ_LP(label)[bv] == 1) { c = (jstep == 1) ? SQ_LQ(sib_next)[c] : SQ_LQ(sib_prev)[c]; continue; }
                     int v;
                     if (is_blossom(bv)) {
-                        const int cn = leaves(bv, tmp_leaves);
-                        v = tmp_leaves[cn - 1];
-                        for (int k = 0; k < cn; k++) if (label[tmp_leaves[k]]) { v = tmp_leaves[k]; break; }
+                        const int cn = leaves<FAST>(bv, SQ_LQ(tmp_leaves));
+                        v = SQ_LQ(tmp_leaves)[cn - 1];
+                        for (int k = 0; k < cn; k++) if (SQ_LP(label)[SQ_LQ(tmp_leaves)[k]]) { v = SQ_LQ(tmp_leaves)[k]; break; }
                     } else v = bv;
-                    if (label[v]) {
-                        label[v] = 0;
-                        label[mate[base[bv]]] = 0;
-                        assignLabel(v, 2, labeledge[v]);
+                    if (SQ_LP(label)[v]) {
+                        SQ_LP(label)[v] = 0;
+                        SQ_LP(label)[SQ_LQ(mate)[SQ_LQ(base)[bv]]] = 0;
+                        assignLabel<FAST>(v, 2, SQ_LP(labeledge)[v]);
                     }
-                    c = (jstep == 1) ? sib_next[c] : sib_prev[c];
+                    c = (jstep == 1) ? SQ_LQ(sib_next)[c] : SQ_LQ(sib_prev)[c];
                 }
             }
-            label[b] = 0; labeledge[b] = -1; bestedge[b] = -1;
-            parent[b] = -1; base[b] = -1; bdual[b] = 0; mbe_cnt[b] = -1;
-            remove_live(b);
+            SQ_LP(label)[b] = 0; SQ_LP(labeledge)[b] = -1; SQ_LP(bestedge)[b] = -1;
+            SQ_LQ(parent)[b] = -1; SQ_LQ(base)[b] = -1; SQ_LQ(bdual)[b] = 0; SQ_LQ(mbe_cnt)[b] = -1;
+            remove_live<FAST>(b);
             sp--;
         }
     }
 
-    // augmentBlossom(b, v) with explicit frames: (b, v, phase, t0, j, jstep, c, de_wx)
-    SQ_HD void augmentBlossom(int b0, int v0)
+    // augmentBlossom<FAST>(b, v) with explicit frames: (b, v, phase, t0, j, jstep, c, de_wx)
+    template <int FAST = 0> SQ_HD void augmentBlossom(int b0, int v0)
     {
-        int *fr = frames;
+        int *const fr = SQ_LQ(frames);
         int sp = 1;
         fr[0] = b0; fr[1] = v0; fr[2] = 0;
         while (sp) {
@@ -505,64 +522,64 @@ struct SqBlossom {
             const int b = f[0], v = f[1];
             if (f[2] == 0) {
                 int t = v;
-                while (parent[t] != b) t = parent[t];
+                while (SQ_LQ(parent)[t] != b) t = SQ_LQ(parent)[t];
                 f[3] = t;
                 int j = 0;
-                { int c = first[b]; while (c != t) { c = sib_next[c]; j++; } }
-                if (j & 1) { f[4] = j - nchild[b]; f[5] = 1; } else { f[4] = j; f[5] = -1; }
+                { int c = SQ_LQ(first)[b]; while (c != t) { c = SQ_LQ(sib_next)[c]; j++; } }
+                if (j & 1) { f[4] = j - SQ_LQ(nchild)[b]; f[5] = 1; } else { f[4] = j; f[5] = -1; }
                 f[6] = t; f[2] = 1;
                 if (is_blossom(t)) { int *g = fr + 8 * sp; g[0] = t; g[1] = v; g[2] = 0; sp++; continue; }
             }
             if (f[2] == 1) {                                // top of `while j != 0`
                 if (f[4] == 0) {
-                    first[b] = f[3];                        // childs = childs[i:] + childs[:i]
-                    base[b] = base[first[b]];
+                    SQ_LQ(first)[b] = f[3];                        // childs = childs[i:] + childs[:i]
+                    SQ_LQ(base)[b] = SQ_LQ(base)[SQ_LQ(first)[b]];
                     sp--;
                     continue;
                 }
                 const int jstep = f[5];
-                f[4] += jstep; f[6] = (jstep == 1) ? sib_next[f[6]] : sib_prev[f[6]];
+                f[4] += jstep; f[6] = (jstep == 1) ? SQ_LQ(sib_next)[f[6]] : SQ_LQ(sib_prev)[f[6]];
                 const int t = f[6];
-                f[7] = (jstep == 1) ? edge_after[t] : (edge_after[sib_prev[t]] ^ 1);   // (w, x)
+                f[7] = (jstep == 1) ? SQ_LQ(edge_after)[t] : (SQ_LQ(edge_after)[SQ_LQ(sib_prev)[t]] ^ 1);   // (w, x)
                 f[2] = 2;
-                if (is_blossom(t)) { int *g = fr + 8 * sp; g[0] = t; g[1] = tail(f[7]); g[2] = 0; sp++; continue; }
+                if (is_blossom(t)) { int *g = fr + 8 * sp; g[0] = t; g[1] = tail<FAST>(f[7]); g[2] = 0; sp++; continue; }
             }
             if (f[2] == 2) {
                 const int jstep = f[5];
-                f[4] += jstep; f[6] = (jstep == 1) ? sib_next[f[6]] : sib_prev[f[6]];
+                f[4] += jstep; f[6] = (jstep == 1) ? SQ_LQ(sib_next)[f[6]] : SQ_LQ(sib_prev)[f[6]];
                 const int t = f[6];
                 f[2] = 3;
-                if (is_blossom(t)) { int *g = fr + 8 * sp; g[0] = t; g[1] = head(f[7]); g[2] = 0; sp++; continue; }
+                if (is_blossom(t)) { int *g = fr + 8 * sp; g[0] = t; g[1] = head<FAST>(f[7]); g[2] = 0; sp++; continue; }
             }
             if (f[2] == 3) {
-                const int w = tail(f[7]), x = head(f[7]);
-                mate[w] = x; mate_de[w] = f[7];
-                mate[x] = w; mate_de[x] = f[7] ^ 1;
-                if (mord[w] < 0) mord[w] = mord_n++;
-                if (mord[x] < 0) mord[x] = mord_n++;
+                const int w = tail<FAST>(f[7]), x = head<FAST>(f[7]);
+                SQ_LQ(mate)[w] = x; SQ_LQ(mate_de)[w] = f[7];
+                SQ_LQ(mate)[x] = w; SQ_LQ(mate_de)[x] = f[7] ^ 1;
+                if (SQ_LQ(mord)[w] < 0) SQ_LQ(mord)[w] = mord_n++;
+                if (SQ_LQ(mord)[x] < 0) SQ_LQ(mord)[x] = mord_n++;
                 f[2] = 1;
             }
         }
     }
 
-    SQ_HD void augmentMatching(int de)                     // (v, w)
+    template <int FAST = 0> SQ_HD void augmentMatching(int de)                     // (v, w)
     {
         for (int side = 0; side < 2; side++) {
             int sj = side == 0 ? de : (de ^ 1);            // (s, j)
             for (;;) {
-                const int s = tail(sj), j = head(sj);
-                const int bs = inblossom[s];
-                if (is_blossom(bs)) augmentBlossom(bs, s);
-                mate[s] = j; mate_de[s] = sj;
-                if (mord[s] < 0) mord[s] = mord_n++;
-                if (labeledge[bs] == -1) break;
-                const int t = tail(labeledge[bs]);
-                const int bt = inblossom[t];
-                sj = labeledge[bt];                         // s, j = labeledge[bt]
-                const int s2 = tail(sj), j2 = head(sj);
-                if (is_blossom(bt)) augmentBlossom(bt, j2);
-                mate[j2] = s2; mate_de[j2] = sj ^ 1;
-                if (mord[j2] < 0) mord[j2] = mord_n++;
+                const int s = tail<FAST>(sj), j = head<FAST>(sj);
+                const int bs = SQ_LP(inblossom)[s];
+                if (is_blossom(bs)) augmentBlossom<FAST>(bs, s);
+                SQ_LQ(mate)[s] = j; SQ_LQ(mate_de)[s] = sj;
+                if (SQ_LQ(mord)[s] < 0) SQ_LQ(mord)[s] = mord_n++;
+                if (SQ_LP(labeledge)[bs] == -1) break;
+                const int t = tail<FAST>(SQ_LP(labeledge)[bs]);
+                const int bt = SQ_LP(inblossom)[t];
+                sj = SQ_LP(labeledge)[bt];                         // s, j = SQ_LP(labeledge)[bt]
+                const int s2 = tail<FAST>(sj), j2 = head<FAST>(sj);
+                if (is_blossom(bt)) augmentBlossom<FAST>(bt, j2);
+                SQ_LQ(mate)[j2] = s2; SQ_LQ(mate_de)[j2] = sj ^ 1;
+                if (SQ_LQ(mord)[j2] < 0) SQ_LQ(mord)[j2] = mord_n++;
             }
         }
     }
@@ -572,7 +589,6 @@ struct SqBlossom {
     // clears, the four delta minima, the dual updates) are strided over the lanes.  Minima keep the
     // sequential rule "first strictly smaller wins": per lane the first minimum of its stride, then
     // across lanes the smallest value and, among equals, the smallest iteration index.
-    char *origin;             // generic address of the LDS buffer that holds edges + state (FAST runs only)
     int f_augmented, f_stop, f_break;
     int stat_pass, stat_event;   // scan passes (one chunk of <= 64 neighbours of a popped S-vertex) and lane-0 events of the run
 #ifdef SQ_MWM_PROF
@@ -592,26 +608,24 @@ struct SqBlossom {
     template <int FAST, class Sync, class Coop>
     SQ_HD void run(int lane, int nl, Sync sync, Coop coop, char *fast0)
     {
-#define SQ_LP(p) (FAST ? (decltype(p))(fast0 + ((char *)(p) - origin)) : (p))            /* hot arrays */
-#define SQ_LQ(p) (FAST == 1 ? (decltype(p))(fast0 + ((char *)(p) - origin)) : (p))       /* cold / edge arrays */
         const int N2 = 2 * n + 2;
-        for (int v = lane; v < n; v += nl) { mate[v] = -1; mate_de[v] = -1; mord[v] = -1; inblossom[v] = v; }
+        for (int v = lane; v < n; v += nl) { SQ_LQ(mate)[v] = -1; SQ_LQ(mate_de)[v] = -1; SQ_LQ(mord)[v] = -1; SQ_LP(inblossom)[v] = v; }
         if (lane == 0) mord_n = 0;
         for (int x = lane; x < N2; x += nl) {
-            label[x] = 0; labeledge[x] = -1; parent[x] = -1; base[x] = x < n ? x : -1; bestedge[x] = -1;
-            bdual[x] = 0; mbe_cnt[x] = -1; mbe_off[x] = 0; beto[x] = -1; nchild[x] = 0; first[x] = -1;
+            SQ_LP(label)[x] = 0; SQ_LP(labeledge)[x] = -1; SQ_LQ(parent)[x] = -1; SQ_LQ(base)[x] = x < n ? x : -1; SQ_LP(bestedge)[x] = -1;
+            SQ_LQ(bdual)[x] = 0; SQ_LQ(mbe_cnt)[x] = -1; SQ_LQ(mbe_off)[x] = 0; SQ_LQ(beto)[x] = -1; SQ_LQ(nchild)[x] = 0; SQ_LQ(first)[x] = -1;
         }
         if (lane == 0) {
             nlive = 0; nfree = 0;
-            for (int b = 2 * n - 1; b >= n; b--) freeb[nfree++] = b;
+            for (int b = 2 * n - 1; b >= n; b--) SQ_LQ(freeb)[nfree++] = b;
         }
         if (lane == 0) { stat_pass = 0; stat_event = 0; }
         sync();
         if (n == 0) return;
         {
             double maxweight = 0;                               // every lane computes the same value
-            for (int e = 0; e < m; e++) if (E[e].v != E[e].w && E[e].weight > maxweight) maxweight = E[e].weight;
-            for (int v = lane; v < n; v += nl) dualvar[v] = maxweight;
+            for (int e = 0; e < m; e++) if (E[e].v != SQ_LQ(E)[e].w && SQ_LQ(E)[e].weight > maxweight) maxweight = SQ_LQ(E)[e].weight;
+            for (int v = lane; v < n; v += nl) SQ_LP(dualvar)[v] = maxweight;
         }
         sync();
         // the hot loop works on register copies of the array bases: `this` lives in LDS, and every byte store
@@ -641,11 +655,11 @@ struct SqBlossom {
 #ifdef SQ_MWM_PROF
             if (lane == 0) pc[3]++;
 #endif
-            for (int x = lane; x < N2; x += nl) { label[x] = 0; labeledge[x] = -1; bestedge[x] = -1; }
-            for (int k = lane; k < nlive; k += nl) mbe_cnt[live[k]] = -1;
-            for (int e = lane; e < m; e += nl) allow[e] = 0;
+            for (int x = lane; x < N2; x += nl) { SQ_LP(label)[x] = 0; SQ_LP(labeledge)[x] = -1; SQ_LP(bestedge)[x] = -1; }
+            for (int k = lane; k < nlive; k += nl) SQ_LQ(mbe_cnt)[SQ_LQ(live)[k]] = -1;
+            for (int e = lane; e < m; e += nl) SQ_LP(allow)[e] = 0;
             sync();
-            // every free vertex becomes an S-vertex: assignLabel(v, 1, None) in vertex order.  Free vertices sit in
+            // every free vertex becomes an S-vertex: assignLabel<FAST>(v, 1, None) in vertex order.  Free vertices sit in
             // distinct top-level blossoms, so the label writes are independent; only the queue order is sequential
             // (prefix sum over leaf counts; the leaves of a non-trivial blossom are listed by lane 0).
             {
@@ -653,17 +667,17 @@ struct SqBlossom {
                 int qbase = 0;
                 for (int v0 = 0; v0 < n; v0 += nl) {
                     const int v = v0 + lane;
-                    const bool q = v < n && mate[v] == -1 && label[inblossom[v]] == 0;
-                    const int b = q ? inblossom[v] : -1;
-                    const int cnt = q ? (b >= n ? nleaf[b] : 1) : 0;
+                    const bool q = v < n && SQ_LQ(mate)[v] == -1 && SQ_LP(label)[SQ_LP(inblossom)[v]] == 0;
+                    const int b = q ? SQ_LP(inblossom)[v] : -1;
+                    const int cnt = q ? (b >= n ? SQ_LQ(nleaf)[b] : 1) : 0;
                     int total = 0;
                     const int pos = qbase + coop.excl_scan(cnt, total);
                     red_i[lane][0] = -1;
                     if (q) {
                         if (pos + cnt > qcap) error = 1;
                         else {
-                            label[v] = label[b] = 1; labeledge[v] = labeledge[b] = -1; bestedge[v] = bestedge[b] = -1;
-                            if (b < n) queue[pos] = b;
+                            SQ_LP(label)[v] = SQ_LP(label)[b] = 1; SQ_LP(labeledge)[v] = SQ_LP(labeledge)[b] = -1; SQ_LP(bestedge)[v] = SQ_LP(bestedge)[b] = -1;
+                            if (b < n) SQ_LP(queue)[pos] = b;
                             else { red_i[lane][0] = b; red_i[lane][1] = pos; }
                         }
                     }
@@ -671,7 +685,7 @@ struct SqBlossom {
                     if (anyb < nl) {
                         sync();
                         if (lane == 0 && !error)
-                            for (int l = anyb; l < nl; l++) if (red_i[l][0] != -1) leaves(red_i[l][0], queue + red_i[l][1]);
+                            for (int l = anyb; l < nl; l++) if (red_i[l][0] != -1) leaves<FAST>(red_i[l][0], SQ_LP(queue) + red_i[l][1]);
                         sync();
                     }
                     qbase += total;
@@ -692,7 +706,7 @@ struct SqBlossom {
                 // ---- queue of S-vertices.  One vertex at a time (LIFO order matters), its neighbours 64 at a
                 // time: every lane classifies one neighbour against the current state; the neighbours before the
                 // first one that changes shared state (a label assignment, a new blossom, an augmentation) only
-                // touch their own w (allowedge, label[w], bestedge[w]) or compete for bestedge[bv] (first strictly
+                // touch their own w (allowedge, SQ_LP(label)[w], SQ_LP(bestedge)[w]) or compete for SQ_LP(bestedge)[bv] (first strictly
                 // smaller slack wins == lexicographic (slack, position) minimum), so they are applied in parallel;
                 // the state-changing neighbour is then handled by lane 0 with the sequential code and the rest of
                 // the list is re-classified.
@@ -735,20 +749,20 @@ struct SqBlossom {
                         const double dv = dualvar_[v];
                         const int de = adj_[a], w = adjv_[a];
                         const double wt = adjw_[a];
-                        const int be_bv = bestedge_[bv];                     // lane 0's competitor for bestedge[bv]
+                        const int be_bv = bestedge_[bv];                     // lane 0's competitor for SQ_LP(bestedge)[bv]
                         const int bw = inblossom_[w];
                         const double dw = dualvar_[w];
                         const int lw = label_[w];
                         const bool was_allowed = allow_[de >> 1] != 0;
                         const int be_w = bestedge_[w];
                         const int lbw = label_[bw];
-                        const double s_bew = bslack_[w];                      // slack(bestedge[w]) (unused when there is none)
+                        const double s_bew = bslack_[w];                      // slack<FAST>(bestedge[w]) (unused when there is none)
                         const double s_bebv = bslack_[bv];
-                        const double ks = dv + dw - 2 * wt;                  // slack(de): dualvar[v] + dualvar[w] - 2 weight
+                        const double ks = dv + dw - 2 * wt;                  // slack<FAST>(de): SQ_LP(dualvar)[v] + SQ_LP(dualvar)[w] - 2 weight
                         const bool cons = live && w != v && bw != bv;       // :  `if w == v: continue`, same blossom: continue
                         const bool becomes = cons && !was_allowed && ks <= 0;
                         const bool allowed = was_allowed || becomes;
-                        int cat = 0;                                         // 0 none, 1 event, 2 label[w] := T, 3 bestedge[w], 4 bestedge[bv]
+                        int cat = 0;                                         // 0 none, 1 event, 2 SQ_LP(label)[w] := T, 3 SQ_LP(bestedge)[w], 4 SQ_LP(bestedge)[bv]
                         if (cons) {
                             if (allowed) cat = (lbw == 0 || lbw == 1) ? 1 : (lw == 0 ? 2 : 0);
                             else cat = lbw == 1 ? 4 : (lw == 0 ? 3 : 0);
@@ -765,9 +779,9 @@ struct SqBlossom {
                             else if (cat == 3) { if (be_w == -1 || ks < s_bew) { bestedge_[w] = de; bslack_[w] = ks; } }
                         }
                         {
-                            // competitors for bestedge[bv]: sequentially "first strictly smaller slack wins", i.e. the
+                            // competitors for SQ_LP(bestedge)[bv]: sequentially "first strictly smaller slack wins", i.e. the
                             // lexicographic (slack, position) minimum among the neighbours that beat the CURRENT best.
-                            // bestedge[bv] only improves during a stage, so after the first passes usually nobody
+                            // SQ_LP(bestedge)[bv] only improves during a stage, so after the first passes usually nobody
                             // does and the pass ends here; one competitor writes directly; several are reduced.
                             const bool comp = lane < f && cat == 4 && (be_bv == -1 || ks < s_bebv);
                             int cfirst;
@@ -798,28 +812,28 @@ struct SqBlossom {
                         if (lane == 0) { pc[4]++; _te = wall_clock64(); }
 #endif
                         if (lane == 0) {                        // the sequential body for neighbour a0 + f
-                            const int de1 = adj[a0 + f];
-                            const int w1 = head(de1);
-                            const int bv1 = inblossom[v], bw1 = inblossom[w1];
+                            const int de1 = SQ_LQ(adj)[a0 + f];
+                            const int w1 = head<FAST>(de1);
+                            const int bv1 = SQ_LP(inblossom)[v], bw1 = SQ_LP(inblossom)[w1];
                             if (w1 != v && bv1 != bw1) {
                                 double kslack = 0;
-                                if (!allow[de1 >> 1]) {
-                                    kslack = slack(de1);
-                                    if (kslack <= 0) allow[de1 >> 1] = 1;
+                                if (!SQ_LP(allow)[de1 >> 1]) {
+                                    kslack = slack<FAST>(de1);
+                                    if (kslack <= 0) SQ_LP(allow)[de1 >> 1] = 1;
                                 }
                                 if (allow[de1 >> 1]) {
-                                    if (label[bw1] == 0) assignLabel(w1, 2, de1);
+                                    if (label[bw1] == 0) assignLabel<FAST>(w1, 2, de1);
                                     else if (label[bw1] == 1) {
-                                        const int bs = scanBlossom(v, w1);
-                                        if (bs != -1) addBlossom(bs, de1);
-                                        else { augmentMatching(de1); f_augmented = 1; }
+                                        const int bs = scanBlossom<FAST>(v, w1);
+                                        if (bs != -1) addBlossom<FAST>(bs, de1);
+                                        else { augmentMatching<FAST>(de1); f_augmented = 1; }
                                     } else if (label[w1] == 0) {
-                                        label[w1] = 2; labeledge[w1] = de1;
+                                        SQ_LP(label)[w1] = 2; SQ_LP(labeledge)[w1] = de1;
                                     }
                                 } else if (label[bw1] == 1) {
-                                    if (bestedge[bv1] == -1 || kslack < slack(bestedge[bv1])) { bestedge[bv1] = de1; bslack[bv1] = kslack; }
+                                    if (bestedge[bv1] == -1 || kslack < slack<FAST>(bestedge[bv1])) { SQ_LP(bestedge)[bv1] = de1; SQ_LP(bslack)[bv1] = kslack; }
                                 } else if (label[w1] == 0) {
-                                    if (bestedge[w1] == -1 || kslack < slack(bestedge[w1])) { bestedge[w1] = de1; bslack[w1] = kslack; }
+                                    if (bestedge[w1] == -1 || kslack < slack<FAST>(bestedge[w1])) { SQ_LP(bestedge)[w1] = de1; SQ_LP(bslack)[w1] = kslack; }
                                 }
                             }
                         }
@@ -906,8 +920,8 @@ struct SqBlossom {
                     const int deltatype = red_i[0][0], deltaedge = red_i[0][1], deltablossom = red_i[0][2];
                     f_stop = 0;
                     if (deltatype == 1) f_stop = 1;
-                    else if (deltatype == 2 || deltatype == 3) { allow[deltaedge >> 1] = 1; qpush(tail(deltaedge)); }
-                    else expandBlossom(deltablossom, false);
+                    else if (deltatype == 2 || deltatype == 3) { SQ_LP(allow)[deltaedge >> 1] = 1; qpush<FAST>(tail<FAST>(deltaedge)); }
+                    else expandBlossom<FAST>(deltablossom, false);
                 }
                 sync();
 #ifdef SQ_MWM_PROF
@@ -919,13 +933,13 @@ struct SqBlossom {
             // end of stage: expand S-blossoms with zero dual (snapshot of the dict keys)
             if (lane == 0) {
                 int snap = nlive;
-                for (int k = 0; k < snap; k++) tmp_path[k] = live[k];
+                for (int k = 0; k < snap; k++) SQ_LQ(tmp_path)[k] = SQ_LQ(live)[k];
                 for (int k = 0; k < snap; k++) {
-                    const int b = tmp_path[k];
+                    const int b = SQ_LQ(tmp_path)[k];
                     bool alive = false;
                     for (int q = 0; q < nlive; q++) if (live[q] == b) { alive = true; break; }
                     if (!alive) continue;
-                    if (parent[b] == -1 && label[b] == 1 && bdual[b] == 0) expandBlossom(b, true);
+                    if (parent[b] == -1 && SQ_LP(label)[b] == 1 && SQ_LQ(bdual)[b] == 0) expandBlossom<FAST>(b, true);
                 }
             }
             sync();
@@ -952,10 +966,10 @@ struct SqBlossom {
 #endif
     }
 
-#undef SQ_LP
-#undef SQ_LQ
     SQ_HD void run()
     {
         run<0>(0, 1, [] {}, SqCoopSingle(), nullptr);
     }
+#undef SQ_LP
+#undef SQ_LQ
 };
