@@ -222,7 +222,8 @@ SQ_API int sq_result_struct(const sq_batch *b, int32_t seq, int32_t k, int16_t *
 SQ_API int sq_result_metrics(const sq_batch *b, int32_t seq, double cons[6], double best[7]);
 /* Bulk form of the getters: one buffer per sequence, little-endian, 8-byte aligned sections:
  *   int64  nstruct, n, has_ref, evals
- *   double cons_metrics[6], best_metrics[7]
+ *   double cons_metrics[6], best_metrics[7], ref_scores[3]   (ref_scores: ScoreStruct of the known structure,
+ *                                                              ReferenceScores SQRNdbnseq.py:958-970; NaN without one)
  *   double scores[nstruct][3]
  *   uint64 pset_mask[nstruct]
  *   int16  levels[1 + nstruct][n]      (row 0 = consensus)
@@ -233,6 +234,13 @@ SQ_API int sq_result_pack(const sq_batch *b, int32_t seq, void *buf, int64_t cap
  * [off[s], off[s+1]) of buf, off has nseq + 1 entries, records start 8-byte aligned. */
 SQ_API int64_t sq_result_pack_all_size(const sq_batch *b);
 SQ_API int sq_result_pack_all(const sq_batch *b, void *buf, int64_t cap, int64_t *off);
+/* Dot-bracket rows of every record as ASCII text: record s occupies [off[s], off[s+1]) of buf with its consensus row
+ * and then its nstruct structure rows, n characters each (gap-free coordinates; gap columns and separators are
+ * re-inserted by the caller, SQRNdbnseq.py:1239-1246).  Levels 1..30 print as ( [ { < A..Z and ) ] } > a..z (:107-112);
+ * deep[s] = 1 when record s uses a deeper level (the reference continues with Cyrillic letters): use the level form
+ * (sq_result_pack) for those. */
+SQ_API int64_t sq_result_dbn_all_size(const sq_batch *b);
+SQ_API int sq_result_dbn_all(const sq_batch *b, char *buf, int64_t cap, int64_t *off, uint8_t *deep);
 /* R = number of AnnotateStems evaluations the reference algorithm performs for this sequence. */
 SQ_API int64_t sq_result_evals(const sq_batch *b, int32_t seq);
 

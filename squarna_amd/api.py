@@ -205,6 +205,7 @@ def Predict(inputfile=None, fileformat="unknown", inputseq=None, configfile=None
     def flush(batch):
         """Fold a batch of records on the GPU, then print every block in input order."""
         preds = [None] * len(batch)
+        refsc = [None] * len(batch)
         if not evalonly and not entropy:
             # records with different priority index sets cannot share one fold call
             groups = {}
@@ -214,17 +215,34 @@ def Predict(inputfile=None, fileformat="unknown", inputseq=None, configfile=None
             for prio, idx in groups.items():
                 res = eng.fold_records([(batch[k][1], batch[k][2], batch[k][3], batch[k][4], batch[k][6], None)
                                         for k in idx], priority=set(prio), **common)
-                for k, r in zip(idx, res):
+                got_ref = getattr(eng, "last_ref_scores", None)
+                for q, (k, r) in enumerate(zip(idx, res)):
                     preds[k] = r
+                    if got_ref is not None and len(got_ref) == len(idx):
+                        refsc[k] = got_ref[q]
         for k, (name, seq, reacts, restrs, ref, names, psets, index) in enumerate(batch):
             sink = io.StringIO() if _on_block else write_to
             RunSQRNdbnseq(name, seq, reacts, restrs, ref, names, psets, threads, rankbydiff, rankby,
                           hardrest, interchainonly, toplim, outplim, conslim, reactformat, evalonly, poollim,
                           mp=False, sink=sink, entropy=entropy, algos=algos, levellimit=levellimit,
-                          priority=priority, rfam=False, M=M, B=B, _prediction=preds[k])
+                          priority=priority, rfam=False, M=M, B=B, _prediction=preds[k], _ref_scores=refsc[k])
             if _on_block:
                 _on_block(index, sink.getvalue())
 
+    # (thousands of small result containers: the cyclic collector only costs time here, see HipEngine.fold_records)
+    import gc
+    gc_was = gc.isenabled()
+    gc.disable()
+    try:
+        _predict_records(inputs, _select, config_for, flush)
+    finally:
+        if gc_was:
+            gc.enable()
+
+
+def _predict_records(inputs, _select, config_for, flush):
+    """The record loop of Predict's single-sequence mode: batches of records folded on the GPU, blocks printed in
+    input order (the reference's ordered Pool.imap, SQUARNA.py:887-935)."""
     batch, cells = [], 0
     for index, (name, seq, reacts, restrs, ref) in enumerate(inputs):
         if _select is not None and index not in _select:

@@ -294,7 +294,7 @@ def RunSQRNdbnseq(name, sequence, reactivities, restraints, reference, paramsetn
                   threads, rankbydiff, rankby, hardrest, interchainonly, toplim, outplim, conslim,
                   reactformat, evalonly, poollim=1000, mp=True, sink=sys.stdout, stemmatrix=None,
                   entropy=False, algos={'G', }, levellimit=None, priority=None, rfam=None, M=1.8,
-                  B=-0.6, _prediction=None):
+                  B=-0.6, _prediction=None, _ref_scores=None):
     """Print one record's block in the reference's format -- SQRNdbnseq.py:1289-1408.
     `_prediction` lets a batched caller (Predict) pass the result it already has."""
     print(name, file=sink)
@@ -312,8 +312,14 @@ def RunSQRNdbnseq(name, sequence, reactivities, restraints, reference, paramsetn
     if restraints:
         print(seps(restraints), "restraints" + ("(" + rfam + ")" if rfam else ""), sep='\t', file=sink)
     if reference:
-        print(seps(reference), "reference", *ReferenceScores(sequence, reference, reactivities),
-              sep='\t', file=sink)
+        # (a batched caller passes the scores the C tail computed with the fold; the values are the same)
+        if _ref_scores is not None:
+            refsc = list(_ref_scores)
+            if refsc[1] == 0:
+                refsc[1] = 0                # ScoreStruct keeps the int 0 of a structure without a scoring stem (:871)
+        else:
+            refsc = ReferenceScores(sequence, reference, reactivities)
+        print(seps(reference), "reference", *refsc, sep='\t', file=sink)
     print('_' * len(sequence), file=sink)
     if evalonly:
         return None, None, None, None

@@ -47,6 +47,7 @@ struct SeqResult {        // SQRNdbnseq return tuple of one sequence (SQRNdbnseq
     std::vector<int16_t> cons;
     std::vector<Pred> preds;
     double cons_metrics[6], best_metrics[7];
+    double ref_scores[3];              // ScoreStruct of the known structure (ReferenceScores, SQRNdbnseq.py:958-970), when given
     bool has_ref = false;
     int64_t evals = 0;
 };

@@ -1547,7 +1547,7 @@ extern "C" int64_t sq_result_pack_size(const sq_batch *b, int32_t seq)
     if (!b || seq < 0 || seq >= b->nseq) return -1;
     const auto &R = b->results[seq];
     const int64_t ns = (int64_t)R.preds.size(), n = (int64_t)R.cons.size();
-    return 8 * 4 + 8 * 13 + 8 * 3 * ns + 8 * ns + 2 * (1 + ns) * n;
+    return 8 * 4 + 8 * 16 + 8 * 3 * ns + 8 * ns + 2 * (1 + ns) * n;
 }
 extern "C" int sq_result_pack(const sq_batch *b, int32_t seq, void *buf, int64_t cap)
 {
@@ -1558,10 +1558,11 @@ extern "C" int sq_result_pack(const sq_batch *b, int32_t seq, void *buf, int64_t
     char *p = (char *)buf;
     int64_t hdr[4] = {ns, n, R.has_ref ? 1 : 0, R.evals};
     memcpy(p, hdr, 32); p += 32;
-    double met[13];
+    double met[16];
     for (int t = 0; t < 6; t++) met[t] = R.has_ref ? R.cons_metrics[t] : NAN;
     for (int t = 0; t < 7; t++) met[6 + t] = R.has_ref ? R.best_metrics[t] : NAN;
-    memcpy(p, met, 104); p += 104;
+    for (int t = 0; t < 3; t++) met[13 + t] = R.has_ref ? R.ref_scores[t] : NAN;
+    memcpy(p, met, 128); p += 128;
     for (int64_t k = 0; k < ns; k++) { memcpy(p, R.preds[k].scores, 24); p += 24; }
     for (int64_t k = 0; k < ns; k++) { memcpy(p, &R.preds[k].pset_mask, 8); p += 8; }
     memcpy(p, R.cons.data(), 2 * n); p += 2 * n;
@@ -1588,6 +1589,50 @@ extern "C" int sq_result_pack_all(const sq_batch *b, void *buf, int64_t cap, int
         const int r = sq_result_pack(b, s, (char *)buf + o, cap - o);
         if (r) return r;
         o += (need + 7) & ~(int64_t)7;
+    }
+    off[b->nseq] = o;
+    return 0;
+}
+
+// Dot-bracket rows of every record as ASCII text (the bulk form of levels -> characters): record s occupies
+// [off[s], off[s+1]) with its consensus row and then its nstruct structure rows, n characters each (gap-free
+// coordinates, no separators re-inserted: the caller does that for the records that have any).  Levels 1..30 print as
+// ( [ { < A..Z / ) ] } > a..z (SQRNdbnseq.py:107-112); deep[s] = 1 when the record uses a level beyond them (the
+// reference continues with Cyrillic letters): such records are left to the generic per-record path.
+extern "C" int64_t sq_result_dbn_all_size(const sq_batch *b)
+{
+    if (!b) return -1;
+    int64_t tot = 0;
+    for (int s = 0; s < b->nseq; s++) tot += (int64_t)(b->results[s].preds.size() + 1) * (int64_t)b->results[s].cons.size();
+    return tot;
+}
+extern "C" int sq_result_dbn_all(const sq_batch *b, char *buf, int64_t cap, int64_t *off, uint8_t *deep)
+{
+    if (!b || !buf || !off || !deep) { sq_set_error("bad argument"); return -1; }
+    static const char open_ch[31] = {'.', '(', '[', '{', '<', 'A', 'B', 'C', 'D', 'E', 'F', 'G', 'H', 'I', 'J', 'K', 'L', 'M', 'N', 'O',
+                                     'P', 'Q', 'R', 'S', 'T', 'U', 'V', 'W', 'X', 'Y', 'Z'};
+    static const char close_ch[31] = {'.', ')', ']', '}', '>', 'a', 'b', 'c', 'd', 'e', 'f', 'g', 'h', 'i', 'j', 'k', 'l', 'm', 'n', 'o',
+                                      'p', 'q', 'r', 's', 't', 'u', 'v', 'w', 'x', 'y', 'z'};
+    int64_t o = 0;
+    for (int s = 0; s < b->nseq; s++) {
+        const SeqResult &R = b->results[s];
+        const int64_t n = (int64_t)R.cons.size();
+        off[s] = o;
+        if (o + (int64_t)(R.preds.size() + 1) * n > cap) { sq_set_error("text buffer too small"); return -1; }
+        bool dp = false;
+        auto row = [&](const std::vector<int16_t> &lv) {
+            for (int64_t i = 0; i < n; i++) {
+                const int v = lv[i];
+                char ch = '.';
+                if (v > 0) { if (v <= 30) ch = open_ch[v]; else dp = true; }
+                else if (v < 0) { if (v >= -30) ch = close_ch[-v]; else dp = true; }
+                buf[o + i] = ch;
+            }
+            o += n;
+        };
+        row(R.cons);
+        for (const auto &p : R.preds) row(p.levels);
+        deep[s] = dp ? 1 : 0;
     }
     off[b->nseq] = o;
     return 0;

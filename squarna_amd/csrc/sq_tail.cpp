@@ -329,6 +329,15 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
         for (int k = 0; k < nref; k++) known.push_back(BP(ref_pairs[2 * k], ref_pairs[2 * k + 1]));
         std::sort(known.begin(), known.end());
         known.erase(std::unique(known.begin(), known.end()), known.end());
+        {   // ReferenceScores (:958-970): ScoreStruct(seq, PairsToStems(sorted(DBNToPairs(ref))), reacts) -- printed on the
+            // record's "reference" line; here because the pairs, letters and reactivities are at hand
+            std::vector<HStem> rstems;
+            for (size_t k = 0; k < known.size(); k++) {
+                if (k && known[k - 1].first + 1 == known[k].first && known[k - 1].second == known[k].second + 1) rstems.back().len++;
+                else rstems.push_back(HStem{known[k].first, known[k].second, 1, 0, 0});
+            }
+            score_struct(codes, reacts, n, rstems, res.ref_scores);
+        }
         prf(cons, known, res.cons_metrics);
         double best = -1;
         for (int t = 0; t < 7; t++) res.best_metrics[t] = NAN;

@@ -60,7 +60,7 @@ class Prepared:
 
 
 _HDR = struct.Struct("<4q")
-_MET = struct.Struct("<13d")
+_MET = struct.Struct("<16d")
 _MASK_IDS = [[q for q in range(4) if (m >> q) & 1] for m in range(16)]
 
 #: code points of the bracket characters by signed level (+L opening, -L closing, 0 dot; levels beyond the
@@ -114,7 +114,7 @@ class Batch:
         for k, p in enumerate(prepared):
             self.seq_off[k + 1] = self.seq_off[k] + len(p.shortseq)
         ltot = int(self.seq_off[-1])
-        self.codes = np.frombuffer(b''.join(encode_seq(p.shortseq) for p in prepared), np.uint8).copy() \
+        self.codes = np.frombuffer(encode_seq(''.join(p.shortseq for p in prepared)), np.uint8).copy() \
             if ltot else np.zeros(1, np.uint8)
         self.flags = np.zeros(max(ltot, 1), np.uint8)
         self.reacts = np.full(max(ltot, 1), 0.5, np.float64)
@@ -327,34 +327,81 @@ class Batch:
         ref_off, rp, has = self._refs
         return o, ref_off, rp, has
 
-    def result(self, k):
-        """SQRNdbnseq return tuple of record k (SQRNdbnseq.py:1285-1286)."""
+    def result(self, k, with_ref=False):
+        """SQRNdbnseq return tuple of record k (SQRNdbnseq.py:1285-1286); with_ref: (tuple, reference scores or None)."""
         L = self.L
         nbytes = L.sq_result_pack_size(self.h, k)
         buf = bytearray(nbytes)
         cbuf = (C.c_char * nbytes).from_buffer(buf)
         _lib.check(L.sq_result_pack(self.h, k, cbuf, nbytes))
-        ns, n, has_ref, evals = _HDR.unpack_from(buf, 0)
-        met = _MET.unpack_from(buf, 32)
-        o = 136
+        out = self._unpack(k, buf, 0)
+        return out if with_ref else out[0]
+
+    def results_all(self):
+        """[(SQRNdbnseq tuple, reference scores or None)] for every record, from ONE sq_result_pack_all call: the whole
+        dot-bracket rows come as ASCII text from one sq_result_dbn_all call, headers / scores / masks through numpy views; a
+        record then costs a few slices (records with gap columns, separators or > 30 pseudoknot levels take the per-record
+        path)."""
+        buf, off = self.pack_all()
+        raw = buf.tobytes()
+        # the dot-bracket rows of every record as ASCII, formed by the library in one call
+        tbytes = int(self.L.sq_result_dbn_all_size(self.h))
+        tbuf = np.zeros(max(tbytes, 8), np.uint8)
+        toff = np.zeros(self.nseq + 1, np.int64)
+        deep = np.zeros(max(self.nseq, 1), np.uint8)
+        _lib.check(self.L.sq_result_dbn_all(self.h, _ptr(tbuf), tbytes, _ptr(toff), _ptr(deep)))
+        text_all = tbuf[:tbytes].tobytes().decode('latin-1')
+        toffl, deepl = toff.tolist(), deep.tolist()
+        # headers, metrics, scores and masks of all records through numpy views (the records start 8-byte aligned)
+        q = np.frombuffer(raw, '<i8', len(raw) // 8)
+        d = np.frombuffer(raw, '<f8', len(raw) // 8)
+        b8 = (off[:-1] // 8).astype(np.int64)
+        ns_a, n_a, ref_a = q[b8].tolist(), q[b8 + 1].tolist(), q[b8 + 2].tolist()
+        met_a = d[b8[:, None] + (4 + np.arange(16))].tolist()
+        b8l = b8.tolist()
+        nan6, nan7 = [np.nan] * 6, [np.nan] * 7
+        out = []
+        for k in range(self.nseq):
+            p = self.prepared[k]
+            if p.gapidx or p.sepidx or deepl[k]:
+                out.append(self._unpack(k, raw, int(off[k])))
+                continue
+            ns, n, sb = ns_a[k], n_a[k], b8l[k] + 20
+            sc = d[sb:sb + 3 * ns].tolist()
+            mk = q[sb + 3 * ns:sb + 4 * ns].tolist()
+            t0 = toffl[k]                                          # the record's rows in text_all
+            preds = [(text_all[t0 + (t + 1) * n:t0 + (t + 2) * n], tuple(sc[3 * t:3 * t + 3]),
+                      list(_MASK_IDS[mk[t]]) if mk[t] < 16 else [b for b in range(64) if (mk[t] >> b) & 1]) for t in range(ns)]
+            if ref_a[k]:
+                met = met_a[k]
+                out.append(((text_all[t0:t0 + n], preds, _metrics(met[:6]), _metrics(met[6:12]) + [int(met[12])]), tuple(met[13:16])))
+            else:
+                out.append(((text_all[t0:t0 + n], preds, list(nan6), list(nan7)), None))
+        return out
+
+    def _unpack(self, k, buf, base):
+        ns, n, has_ref, evals = _HDR.unpack_from(buf, base)
+        met = _MET.unpack_from(buf, base + 32)
+        o = base + 160
         scores = struct.unpack_from("<%dd" % (3 * ns), buf, o); o += 24 * ns
         masks = struct.unpack_from("<%dQ" % ns, buf, o); o += 8 * ns
-        lev = np.frombuffer(buf, np.int16, (ns + 1) * n, o).reshape(ns + 1, n)
         p = self.prepared[k]
         seq = p.seq
-        # levels -> bracket characters for all rows at once (code-point table), gap columns and separators
-        # re-inserted with array assignments (SQRNdbnseq.py:1239-1246)
-        cp = _LEVEL_CP[np.clip(lev, -_NBR - 1, _NBR + 1) + (_NBR + 1)]                         # (ns+1, n) uint32
-        if p.gapidx or p.sepidx:
-            full = np.full((ns + 1, len(seq)), ord('.'), np.uint32)
-            keep = np.ones(len(seq), bool)
-            keep[p.gapidx] = False
-            full[:, keep] = cp
-            for i in p.sepidx:
-                full[:, i] = ord(seq[i])
-            cp = full
-        width = cp.shape[1]
-        text = cp.tobytes().decode('utf-32-le')
+        if True:
+            lev = np.frombuffer(buf, np.int16, (ns + 1) * n, o).reshape(ns + 1, n)
+            # levels -> bracket characters for all rows at once (code-point table), gap columns and separators
+            # re-inserted with array assignments (SQRNdbnseq.py:1239-1246)
+            cp = _LEVEL_CP[np.clip(lev, -_NBR - 1, _NBR + 1) + (_NBR + 1)]                     # (ns+1, n) uint32
+            if p.gapidx or p.sepidx:
+                full = np.full((ns + 1, len(seq)), ord('.'), np.uint32)
+                keep = np.ones(len(seq), bool)
+                keep[p.gapidx] = False
+                full[:, keep] = cp
+                for i in p.sepidx:
+                    full[:, i] = ord(seq[i])
+                cp = full
+            width = cp.shape[1]
+            text = cp.tobytes().decode('utf-32-le')
         cons = text[:width]
         preds = []
         for t in range(ns):
@@ -364,8 +411,8 @@ class Batch:
         if has_ref:
             consres = _metrics(met[:6])
             res = _metrics(met[6:12]) + [int(met[12])]
-            return cons, preds, consres, res
-        return cons, preds, [np.nan] * 6, [np.nan] * 7
+            return (cons, preds, consres, res), tuple(met[13:16])
+        return (cons, preds, [np.nan] * 6, [np.nan] * 7), None
 
     def pack_all(self):
         """(uint8 array, int64 offsets[nseq + 1]): the packed results of every record (sq_result_pack_all) -- the
@@ -485,10 +532,24 @@ class HipEngine:
     def __init__(self, max_structs=0, cand_per_nt=0):
         self.max_structs = max_structs
         self.cand_per_nt = cand_per_nt
+        #: per record of the last fold_records call: ScoreStruct of its known structure (C tail) or None
+        self.last_ref_scores = None
 
     def fold_records(self, records, **opts):
         """records: list of (seq, reacts, restraints, dbn, paramsets, stemmatrix);
         returns the list of SQRNdbnseq return tuples, in order."""
+        # Building tens of thousands of small containers (Prepared records, result tuples) with the cyclic collector on
+        # costs ~10 us per record in generation scans of objects that hold no cycles: 220 of 340 ms for 10,000 records.
+        import gc
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            return self._fold_records(records, **opts)
+        finally:
+            if was:
+                gc.enable()
+
+    def _fold_records(self, records, **opts):
         interchainonly = opts.pop("interchainonly", False)
         M, B = opts.pop("M", 1.8), opts.pop("B", -0.6)
         prepared = [Prepared(r[0], r[1], r[2], r[3]) for r in records]
@@ -512,7 +573,9 @@ class HipEngine:
             with Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
                        max_structs=self.max_structs, cand_per_nt=self.cand_per_nt) as b:
                 b.fold(**opts)
-                return [b.result(k) for k in range(nrec)]
+                both = b.results_all()
+                self.last_ref_scores = [r[1] for r in both]
+                return [r[0] for r in both]
         # big inputs: two batches folded concurrently (sq_fold_concurrent) -- the host bookkeeping of one overlaps
         # the kernels of the other; records are independent, so the split does not change any result
         from .parallel import lpt_partition
@@ -530,9 +593,11 @@ class HipEngine:
                                      max_structs=self.max_structs, cand_per_nt=self.cand_per_nt))
             fold_concurrently(batches, **opts)
             out = [None] * nrec
+            self.last_ref_scores = [None] * nrec
             for b, idx in zip(batches, parts):
-                for local, k in enumerate(idx):
-                    out[k] = b.result(local)
+                for (res, refsc), k in zip(b.results_all(), idx):
+                    out[k] = res
+                    self.last_ref_scores[k] = refsc
             return out
         finally:
             for b in batches:
