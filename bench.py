@@ -259,6 +259,34 @@ def roofline_leg(nseq, n, pmc, pmc_note, seed=1000):
     return scan, score
 
 
+def fill_leg(nseq=256, n=1000):
+    """The API op sq_bpmatrix_fill (a-1 as north_star words it: coalesced HBM writes of the N x N fp32 score matrix) on
+    `nseq` S1000 sequences: 4 N^2 bytes written per job (+ the N^2/8 bit matrix), HIP events around the launches."""
+    import torch
+    from squarna_amd.config import ParseConfig, builtin_config
+    from squarna_amd.engine import Batch
+    names, psets = ParseConfig(builtin_config("fastest"))
+    prepared = prepare_synthetic(synthetic("S1000")[:nseq])
+    with Batch(prepared, [psets] * nseq, fp32=True) as b:
+        b.fill()
+        torch.cuda.synchronize()
+        b.profile(True)
+        b.profile_reset()
+        for _ in range(5):
+            b.fill()
+        torch.cuda.synchronize()
+        ms, launches, by = b.profile_get(0)
+        b.profile(False)
+    per_ms = ms / 5
+    gbs = by / 5 / (per_ms * 1e-3) / 1e9 if per_ms > 0 else 0.0
+    return dict(kernel="sq_fill_kernel", leg="sq_bpmatrix_fill on %d S1000 sequences" % nseq, bound="hbm (write)",
+                unit="GB/s", peak=HBM_PEAK_GBS, achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
+                traffic=round(by / 5), ms_per_fill=round(per_ms, 4),
+                how="achieved = 4 N^2 bytes per job (the fp32 matrix, written once; algorithmic = actual for a write-only kernel) / "
+                    "time of the fill's launches (HIP events, mean of 5); the fold path does not use this op (it writes "
+                    "N^2/8 bytes of bit matrix instead)")
+
+
 # ---------------------------------------------------------------- strong scaling: a synthetic workload sharded over the ranks
 def sharded_leg(workload, steps, warmup, rank, world, device, sub_batches=4):
     """The SURVEY 8d workload sharded with lpt_partition (cost N^2), every rank folds its shard (inputs resident), then
@@ -513,6 +541,10 @@ def main():
     if rank == 0 and not args.no_roofline:
         roof, score_obj = roofline_leg(args.roofline_seqs, 1000, pmc, pmc_note)
         rooflines.append(score_obj)
+        try:
+            rooflines.append(fill_leg())
+        except Exception as e:                                # (a secondary leg never takes the headline down)
+            rooflines.append({"kernel": "sq_fill_kernel", "error": "%s: %s" % (type(e).__name__, e)})
 
     sharded = None
     if world > 1:

@@ -686,7 +686,16 @@ static int fill_impl(sq_batch *b, int full)
         dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>((maxq + 255) / 256, 1), 1024), (unsigned)nj);
         if (full || any_ext) {
             ProfScope ps(b, 0, j0 == 0 ? bytes : 0);
-            hipLaunchKernelGGL(sq_fill_kernel, grid, dim3(256), 0, b->stream, c, full ? 0 : 1, b->mul_applied ? 1 : 0);
+            // the fill's fast path stages the O(N) inputs in LDS (12 bytes per position) when the longest sequence fits;
+            // its blocks are fewer and fatter than the generic path's so that the staging is amortised
+            const bool lds_inputs = b->maxn <= 4096;
+            // 16-byte stores per thread: as many as leave ~4096 blocks in the launch (the LDS staging of a block is amortised over them)
+            static const int fper_env = getenv("SQ_FILL_PER") ? atoi(getenv("SQ_FILL_PER")) : 0;
+            const int64_t fper = 256 * (fper_env > 0 ? (int64_t)fper_env
+                                                     : std::min<int64_t>(std::max<int64_t>(maxq * nj / (256 * 4096), 4), 64));
+            const size_t fdyn = lds_inputs ? (size_t)12 * ((b->maxn + 15) & ~15) + 64 : 0;
+            dim3 fgrid(lds_inputs ? (unsigned)std::min<int64_t>(std::max<int64_t>((maxq + fper - 1) / fper, 1), 1024) : grid.x, (unsigned)nj);
+            hipLaunchKernelGGL(sq_fill_kernel, fgrid, dim3(256), fdyn, b->stream, c, full ? 0 : 1, b->mul_applied ? 1 : 0);
         }
         if (any_ext1) hipLaunchKernelGGL(sq_import_kernel, grid, dim3(256), 0, b->stream, c);
         if (full && !getenv("SQ_BITS_DIRECT")) hipLaunchKernelGGL(sq_bits_kernel, grid, dim3(256), 0, b->stream, c, 0);

@@ -58,6 +58,13 @@ __device__ __forceinline__ double sq_cell_exact(const SqDevCtx &c, const SqJob &
 // ------------------------------------------------------------------------------------
 // a-1  fill: one thread = 4 consecutive floats of the padded N x ld matrix (16-byte stores)
 // ------------------------------------------------------------------------------------
+// Jobs without a dense fp64 term and with n <= SQ_FILL_LDS_N take the fast path: the per-position inputs (letter code +
+// restraint flags in one byte, minimal span, chain, reactivity) and the pair-weight table are staged in LDS once per
+// block, a thread then walks the flat padded matrix with a grid stride (row / column advanced incrementally: no 64-bit
+// division per store) and a cell costs two LDS byte reads, one table read and a handful of compares before the
+// 16-byte store.  The generic path (every input from global memory, per cell) serves jobs with a bpp term / multiplier
+// matrix and very long sequences.
+#define SQ_FILL_LDS_N 4096
 extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c, int only_ext, int mul_done)
 {
     const SqJob jb = c.jobs[blockIdx.y];
@@ -65,8 +72,70 @@ extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c, int
     if (only_ext && jb.has_ext == 0) return;           // the fold path of such jobs only needs the bit matrix
     const SqPsetDev *ps = c.psets + jb.pset;
     const int n = jb.n, ld = jb.ld;
-    const int64_t total4 = ((int64_t)n * ld + 3) >> 2;
     float *mat = c.mat32 + jb.mat_off;
+    extern __shared__ __attribute__((aligned(16))) char fill_dyn[];
+    if (jb.mat64_off < 0 && n <= SQ_FILL_LDS_N) {
+        __shared__ double s_w[32 * 33];                // pair weights, row stride 33: the letters' rows start on different banks
+        __shared__ float s_wf[32 * 33];                // (float)weight, or the sentinel where the pair is not in bps
+        const int np = (n + 15) & ~15;
+        uint8_t *l_attr = reinterpret_cast<uint8_t *>(fill_dyn);            // code | flags << 5
+        uint8_t *l_inc4 = l_attr + np;
+        int16_t *l_chain = reinterpret_cast<int16_t *>(l_inc4 + np);
+        double *l_react = reinterpret_cast<double *>(l_inc4 + np + 2 * (size_t)np);
+        const int tid = threadIdx.x;
+        const bool ico = jb.interchainonly != 0, defr = jb.default_reacts != 0;
+        for (int p = tid; p < n; p += 256) {
+            l_attr[p] = (uint8_t)((c.codes[jb.pos_off + p] & 31) | ((c.flags[jb.pos_off + p] & 7) << 5));
+            l_inc4[p] = c.inc4[jb.pos_off + p];
+            if (ico) l_chain[p] = c.chain[jb.pos_off + p];
+            if (!defr) l_react[p] = c.reacts[jb.pos_off + p];
+        }
+        for (int e = tid; e < 1024; e += 256) {
+            const double w = ps->w[e];
+            uint32_t fb = SQ_SENT_BITS;
+            if (ps->inbps[e]) { fb = __float_as_uint((float)w); if (fb == SQ_SENT_BITS) fb = 0x7FC00001u; }
+            s_w[(e >> 5) * 33 + (e & 31)] = w;
+            s_wf[(e >> 5) * 33 + (e & 31)] = __uint_as_float(fb);
+        }
+        __syncthreads();
+        const uint32_t total4 = (uint32_t)(((int64_t)n * ld + 3) >> 2), stride4 = gridDim.x * 256u;
+        uint32_t q = blockIdx.x * 256u + (uint32_t)tid;
+        if (q >= total4) return;
+        int i = (int)((q << 2) / (uint32_t)ld), j = (int)((q << 2) - (uint32_t)i * (uint32_t)ld);
+        const int sdi = (int)((stride4 << 2) / (uint32_t)ld), sdj = (int)((stride4 << 2) - (uint32_t)sdi * (uint32_t)ld);
+        for (; q < total4; q += stride4) {
+            uint32_t out[4] = {SQ_SENT_BITS, SQ_SENT_BITS, SQ_SENT_BITS, SQ_SENT_BITS};
+            // a 16-byte store whose cells all lie on or below the diagonal (or in the padding rows) is pure sentinel
+            const bool same_row = j + 3 < ld;
+            if (!(same_row && (j + 3 <= i || i >= n))) {
+                int ii = i, jj = j;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (ii < n && jj < n && jj > ii) {
+                        const int ai = l_attr[ii], aj = l_attr[jj];
+                        const int ci = ai & 31, cj = aj & 31, fi = ai >> 5, fj = aj >> 5;
+                        uint32_t bits = __float_as_uint(s_wf[ci * 33 + cj]);                         // :294-300 inbps
+                        bool ok = jj >= ii + (int)l_inc4[ii] && !((fi | fj) & 1) && !(fj & 2) && !(fi & 4);   // :300, :302-304
+                        if (ok && ico) ok = l_chain[ii] != l_chain[jj];                              // :301
+                        if (ok && !defr && bits != SQ_SENT_BITS) {
+                            const double w = s_w[ci * 33 + cj];                                      // same expressions as sq_cell_score
+                            double rf = sqrt((1.0 - (l_react[ii] + l_react[jj]) / 2.0) * 2.0);
+                            if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
+                            bits = __float_as_uint((float)(w * rf));
+                            if (bits == SQ_SENT_BITS) bits = 0x7FC00001u;   // a genuine NaN value stays "present"
+                        }
+                        out[k] = ok ? bits : SQ_SENT_BITS;
+                    }
+                    if (++jj == ld) { jj = 0; ii++; }
+                }
+            }
+            *reinterpret_cast<uint4 *>(mat + ((size_t)q << 2)) = make_uint4(out[0], out[1], out[2], out[3]);
+            i += sdi; j += sdj;
+            if (j >= ld) { j -= ld; i++; }
+        }
+        return;
+    }
+    const int64_t total4 = ((int64_t)n * ld + 3) >> 2;
     double *m64 = jb.mat64_off >= 0 ? c.mat64 + jb.mat64_off : nullptr;   // has_ext == 2: holds the multiplier
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total4; q += (int64_t)gridDim.x * 256) {
         const int64_t idx = q << 2;
