@@ -57,6 +57,29 @@ struct SqScanArgs {
     SqCounters *ctr;
 };
 
+// device-chained rounds: where sq_chain_kernel keeps and reports the structures
+struct SqChainIO {
+    SqChain *chain;               // per structure
+    SqChainStem *stems;           // device: stems of every structure (slice per structure)
+    SqStrand *strands;            // device: two strand buffers per structure
+    int16_t *sidx;                // stem index of every strand (same layout as strands)
+    SqStemOut *h_stems;           // pinned: the chosen stems in selection order (same slices as `stems`)
+    unsigned long long *h_fin;    // pinned: finished structures, job | nstems << 32 | (ended by maxstemnum) << 63
+    uint32_t *d_nfin;             // device: entries of h_fin
+    volatile uint32_t *h_nfin;    // pinned copy, published by sq_chain_done_kernel before the round's sequence number
+};
+
+// order-preserving map double -> uint64 (never 0 for a real number), so a per-structure maximum is one atomicMax
+__device__ __forceinline__ unsigned long long sq_ord(double x)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double sq_unord(unsigned long long o)
+{
+    return __longlong_as_double((long long)((o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFull) : ~o));
+}
+
 // the two regions of a structure's candidate slice (see sq_internal.h)
 __host__ __device__ inline SqKey *sq_keys(const SqScanArgs &a, const SqStruct &st) { return reinterpret_cast<SqKey *>(a.cands + st.cand_off); }
 __host__ __device__ inline SqOk *sq_oks(const SqScanArgs &a, const SqStruct &st, int cand_cap)
@@ -70,7 +93,9 @@ __global__ void sq_bits_direct_kernel(SqDevCtx c);
 __global__ void sq_bits_masks_kernel(SqDevCtx c, int max_letters);
 __global__ void sq_dense64_kernel(SqDevCtx c, int job, double *boolmat, double *scoremat);
 __global__ void sq_import_kernel(SqDevCtx c);
-__global__ void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n);
+__global__ void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n, int chained);
+__global__ void sq_chain_kernel(SqDevCtx c, SqStruct *structs, SqScanArgs a, SqChainIO cio);
+__global__ void sq_chain_done_kernel(SqRoundIO io, SqScanArgs a, SqChainIO cio, uint32_t seq);
 __global__ void sq_done_kernel(SqRoundIO io, SqScanArgs a, uint32_t seq);
 __global__ void sq_mirror_kernel(double *matrix, int L);
 __global__ void sq_scatter_all_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const int32_t *cols,

@@ -97,7 +97,7 @@ struct SqLane {
     uint32_t h_out_cap = 0, out_cap = 0;
     int32_t slot0 = 0, max_structs = 0, strand_cap = 0;
     int64_t cand0 = 0, cand_records = 0;      // records [cand0, cand0 + cand_records) of the candidate arena
-    uint32_t round_seq = 0;
+    uint32_t *round_seq = nullptr;            // id of the last round sent to h_seq (lanes that share the word share the counter)
     hipStream_t stream = nullptr;             // nullptr: the batch stream
     std::vector<SqOut> big_out;
 };
@@ -149,7 +149,7 @@ struct sq_batch {
     SqStrand *h_strands = nullptr;
     SqCounters *h_ctr = nullptr;
     uint32_t *h_seq = nullptr;            // pinned: id of the last finished round (written by sq_done_kernel)
-    uint32_t round_seq = 0;
+    uint32_t round_seq = 0, round_seq2 = 0;
     SqOut *h_out = nullptr;
     uint32_t h_out_cap = 0;
     std::vector<SqOut> big_out;
@@ -158,6 +158,11 @@ struct sq_batch {
     SqPool *pool = nullptr;               // lazily created host workers
     SqLane lane_full, lane_half[2];       // see SqLane
     SqCounters *h_ctr2 = nullptr; uint32_t *h_seq2 = nullptr;   // pinned counters / sequence word of the second lane
+    // device-chained rounds (width-1 pools): device arrays carved from the workspace, pinned ones created on first use
+    SqChainIO chain{};
+    SqChain *h_chain = nullptr;           // pinned staging of the per-structure records
+    int64_t chain_T = 0;                  // summed stem capacity of all jobs
+    std::vector<int32_t> chain_toff;      // per job: start of its slice of the chain's stem arrays
     // profiling
     std::mutex mwm_mu;
     int64_t mwm_stats[6] = {0, 0, 0, 0, 0, 0};   // blossom jobs collected, their scan passes; the job with the most passes:

@@ -219,6 +219,13 @@ static inline int32_t ld_of(int n)
     return 32 * k + 1;
 }
 
+// most stems one structure of a job can hold: they are disjoint and have at least ceil(minlen) (>= 1) base pairs
+static inline int32_t chain_tcap(int n, double minlen)
+{
+    const int ml = (int)std::max(1.0, std::ceil(minlen));
+    return n / (2 * ml) + 1;
+}
+
 // fp32 score matrices are planned unless the caller opts out
 static inline bool want_fp32(const sq_batch_desc *d)
 {
@@ -230,6 +237,8 @@ struct Layout {
     size_t off_codes, off_flags, off_inc4, off_chain, off_e0, off_reacts, off_ridx, off_jobs, off_psets, off_sdf;
     size_t off_mat32, off_mat64, off_structs, off_strands, off_state, off_cnt, off_ctr, off_cands, off_out;
     size_t off_bits, off_rbpk, off_fb;
+    size_t off_crec, off_cstems, off_cstrands, off_csidx, off_cnfin;   // device-chained rounds (sq_chain.hip)
+    int64_t chain_T;                 // summed stem capacity of all jobs
     size_t total;
     int64_t ltot, sdf_len, mat32_floats, mat64_doubles, cand_records, bits_words;
     int32_t maxn, stride, max_structs, strand_cap, cpn, fbstride;
@@ -298,6 +307,14 @@ int plan(const sq_batch_desc *d, Layout &L)
     L.off_bits = take(4 * (size_t)std::max<int64_t>(L.bits_words, 1));
     L.off_rbpk = take(4 * (size_t)std::max<int>(d->rbp_off[d->nseq], 1));
     L.off_fb = take(4 * (size_t)L.fbstride * L.max_structs);
+    // chained rounds: per job, room for the most stems a structure can hold (disjoint stems of >= minlen pairs)
+    L.chain_T = 0;
+    for (int j = 0; j < d->njobs; j++) L.chain_T += chain_tcap(d->seq_off[d->job_seq[j] + 1] - d->seq_off[d->job_seq[j]], d->psets[d->job_pset[j]].minlen);
+    L.off_crec = take(sizeof(SqChain) * (size_t)d->njobs);
+    L.off_cstems = take(sizeof(SqChainStem) * (size_t)L.chain_T);
+    L.off_cstrands = take(sizeof(SqStrand) * 4 * (size_t)L.chain_T);
+    L.off_csidx = take(sizeof(int16_t) * 4 * (size_t)L.chain_T);
+    L.off_cnfin = take(64);
     L.total = o;
     return 0;
 }
@@ -505,6 +522,10 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->scan.ok_cnt = (uint32_t *)(base + L.off_cnt + 12 * align_up((size_t)L.max_structs, 2));
     b->scan.cands = (SqCand *)(base + L.off_cands);
     b->d_out = (SqOut *)(base + L.off_out);
+    b->chain.chain = (SqChain *)(base + L.off_crec); b->chain.stems = (SqChainStem *)(base + L.off_cstems);
+    b->chain.strands = (SqStrand *)(base + L.off_cstrands); b->chain.sidx = (int16_t *)(base + L.off_csidx);
+    b->chain.d_nfin = (uint32_t *)(base + L.off_cnfin);
+    b->chain_T = L.chain_T;
 
     hipStream_t st = b->stream;
 #define UP(dst, src, bytes) do { int _r = sq_check(hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, st), "upload"); \
@@ -549,6 +570,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         F.d_structs = b->d_structs; F.d_strands = b->d_strands; F.d_out = b->d_out; F.d_ctr = b->scan.ctr;
         F.h_out_cap = b->h_out_cap; F.out_cap = b->out_cap; F.slot0 = 0; F.max_structs = b->max_structs;
         F.strand_cap = b->strand_cap; F.cand0 = 0; F.cand_records = b->cand_records;
+        F.round_seq = &b->round_seq;
         for (int k = 0; k < 2; k++) {
             SqLane &H = b->lane_half[k];
             const int ms0 = b->max_structs / 2, sc0 = b->strand_cap / 2;
@@ -560,6 +582,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
             H.h_out_cap = k ? b->h_out_cap - ho0 : ho0; H.out_cap = k ? b->out_cap - oc0 : oc0;
             H.h_out = b->h_out + (k ? ho0 : 0); H.d_out = b->d_out + (k ? oc0 : 0);
             H.h_ctr = k ? b->h_ctr2 : b->h_ctr; H.h_seq = k ? b->h_seq2 : b->h_seq;
+            H.round_seq = k ? &b->round_seq2 : &b->round_seq;   // (one counter per completion word)
             H.d_ctr = (SqCounters *)((char *)b->scan.ctr + (k ? 64 : 0));
         }
     }
@@ -580,6 +603,8 @@ extern "C" void sq_batch_destroy(sq_batch *b)
     sq_pinned_put(b->h_structs); sq_pinned_put(b->h_strands); sq_pinned_put(b->h_ctr); sq_pinned_put(b->h_seq);
     sq_pinned_put(b->h_ctr2); sq_pinned_put(b->h_seq2); sq_pinned_put(b->h_out);
     for (int k = 0; k < 4; k++) sq_pinned_put(b->stage_buf[k]);
+    sq_pinned_put(b->chain.h_stems); sq_pinned_put(b->chain.h_fin); sq_pinned_put((void *)b->chain.h_nfin);
+    sq_pinned_put(b->h_chain);
     delete b->pool;
     if (b->lane_ev) hipEventDestroy(b->lane_ev);
     for (auto &p : b->prof) {
@@ -878,6 +903,65 @@ struct AlignSink {                    // mode 2: where the stems of structure k 
 };
 }
 
+// the kernels of one round over S structures: state arrays, bit-diagonal scan, exact scoring (mode 0: + ScoreStems),
+// and for host-driven greedy rounds the range filter that writes the round's output records
+static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, int64_t maxcap, bool need_reacts, double scan_bytes,
+                                 int mode, const SqRoundIO &io, const SqScanArgs &scan, SqStruct *d_structs, SqStrand *d_strands,
+                                 bool chained)
+{
+    {
+        ProfScope ps(b, 1, 0);
+        // the per-structure arrays are assembled in LDS (7 bytes per position) when the longest sequence fits
+        const int st_lds_n = maxn <= 8000 ? maxn : 0;
+        const size_t st_dyn = st_lds_n ? (size_t)7 * ((st_lds_n + 8) & ~7) + 64 : 0;
+        hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(256), st_dyn, st, b->ctx, io, b->state, scan, st_lds_n, chained ? 1 : 0);
+    }
+    if (maxn >= 5) {
+        ProfScope ps(b, 2, scan_bytes);
+        // bit-diagonal scan: one wave = 64 anti-diagonals
+        hipLaunchKernelGGL(sq_scan6_kernel, dim3(S, (2 * maxn - 5 + 63) / 64 + 1), dim3(64), 4 * (size_t)b->state.fbstride, st,
+                           b->ctx, d_structs, b->state, scan);
+    }
+    {
+        ProfScope ps(b, 3, 0);
+        // dynamic LDS: letter codes of the longest sequence, plus its reactivities when they fit in 32 KiB
+        const int lds_n = maxn <= 16384 ? maxn : 0;
+        static const int nr_lim = getenv("SQ_SCORE_NR_LIM") ? atoi(getenv("SQ_SCORE_NR_LIM")) : 4096;
+        // (only when some job needs them: sequences whose reactivities go through the cell table leave the room to the
+        // partner / prefix arrays -- S2000 with encoded SHAPE: 16 KB that pushed those arrays out to global memory)
+        const int lds_nr = need_reacts && maxn <= nr_lim ? maxn : 0;
+        // partner / prefix arrays (3 x int16) too, while a block stays small enough for four blocks per CU
+        // (the reactivity case is bound by fp64 sqrt/div throughput and prefers the occupancy)
+        static const size_t state_lim = getenv("SQ_SCORE_STATE_LIM") ? (size_t)atol(getenv("SQ_SCORE_STATE_LIM")) : 24 * 1024;
+        const size_t dyn_base = lds_n ? (size_t)((lds_n + 15) & ~15) + (size_t)8 * lds_nr + 16 : 0;
+        const int lds_ns = (lds_n && mode == 0 && dyn_base + (size_t)6 * ((maxn + 8) & ~7) <= state_lim) ? maxn : 0;
+        size_t dyn = lds_n ? (size_t)((lds_n + 15) & ~15) + (size_t)8 * lds_nr + (size_t)6 * ((lds_ns + 8) & ~7) + 16 : 0;
+        // few structures: deal each structure's candidates to several blocks so that the launch still fills the chip
+        static const int score_threads = getenv("SQ_SCORE_THREADS") ? atoi(getenv("SQ_SCORE_THREADS")) : 0;
+        static const int score_parts = getenv("SQ_SCORE_PARTS") ? atoi(getenv("SQ_SCORE_PARTS")) : 0;
+        static const int score_target = getenv("SQ_SCORE_TARGET") ? atoi(getenv("SQ_SCORE_TARGET")) : 512;
+        // mode 0 (two-phase loop): ~512 blocks of 512 threads; the one-pass modes want many small blocks in flight
+        int parts = std::max(1, std::min({512, ((mode == 0 ? score_target : 4096) + S - 1) / S, (int)(maxcap / 1024)}));
+        if (score_parts) parts = score_parts;
+        const int thr = score_threads ? score_threads : (mode == 0 ? 512 : (parts == 1 && S < 2048 ? 512 : 256));
+        // mode 0: list of the bpscore survivors of a chunk (5 x threads entries of 8 + 4 + 2 bytes) behind the tables
+        const int surv_off = (int)((dyn + 15) & ~(size_t)15);
+        dyn = (size_t)surv_off + (size_t)14 * (SQ_SCORE_CHUNK + (mode == 0 ? 1 : 0)) * thr;   // (one-pass modes: no carry-over)
+        if (mode == 0)
+            hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, d_structs, d_strands, b->state,
+                               scan, io, lds_n, lds_nr, lds_ns, surv_off);
+        else
+            hipLaunchKernelGGL(sq_bps_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, d_structs, d_strands, b->state,
+                               scan, io, mode, lds_n, lds_nr, surv_off);
+        if (mode == 0 && !chained)
+            hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, d_structs, scan, io);
+        if (chained) {
+            SqChainIO cio = b->chain;
+            hipLaunchKernelGGL(sq_chain_kernel, dim3(S), dim3(64), 0, st, b->ctx, d_structs, scan, cio);
+        }
+    }
+}
+
 static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs, size_t lo, size_t hi, int mode,
                      std::vector<std::vector<HStem>> &out, const AlignSink *sink = nullptr)
 {
@@ -906,52 +990,8 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
     io.h_ctr = ln.h_ctr; io.h_seq = ln.h_seq;
     SqScanArgs scan = b->scan;                           // this lane's counters
     scan.ctr = ln.d_ctr;
+    launch_round_kernels(b, st, S, maxn, maxcap, need_reacts, scan_bytes, mode, io, scan, ln.d_structs, ln.d_strands, false);
     {
-        ProfScope ps(b, 1, 0);
-        // the per-structure arrays are assembled in LDS (7 bytes per position) when the longest sequence fits
-        const int st_lds_n = maxn <= 8000 ? maxn : 0;
-        const size_t st_dyn = st_lds_n ? (size_t)7 * ((st_lds_n + 8) & ~7) + 64 : 0;
-        hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(256), st_dyn, st, b->ctx, io, b->state, scan, st_lds_n);
-    }
-    if (maxn >= 5) {
-        ProfScope ps(b, 2, scan_bytes);
-        // bit-diagonal scan: one wave = 64 anti-diagonals
-        hipLaunchKernelGGL(sq_scan6_kernel, dim3(S, (2 * maxn - 5 + 63) / 64 + 1), dim3(64), 4 * (size_t)b->state.fbstride, st,
-                           b->ctx, ln.d_structs, b->state, scan);
-    }
-    {
-        ProfScope ps(b, 3, 0);
-        // dynamic LDS: letter codes of the longest sequence, plus its reactivities when they fit in 32 KiB
-        const int lds_n = maxn <= 16384 ? maxn : 0;
-        static const int nr_lim = getenv("SQ_SCORE_NR_LIM") ? atoi(getenv("SQ_SCORE_NR_LIM")) : 4096;
-        // (only when some job needs them: sequences whose reactivities go through the cell table leave the room to the
-        // partner / prefix arrays -- S2000 with encoded SHAPE: 16 KB that pushed those arrays out to global memory)
-        const int lds_nr = need_reacts && maxn <= nr_lim ? maxn : 0;
-        // partner / prefix arrays (3 x int16) too, while a block stays small enough for four blocks per CU
-        // (the reactivity case is bound by fp64 sqrt/div throughput and prefers the occupancy)
-        static const size_t state_lim = getenv("SQ_SCORE_STATE_LIM") ? (size_t)atol(getenv("SQ_SCORE_STATE_LIM")) : 24 * 1024;
-        const size_t dyn_base = lds_n ? (size_t)((lds_n + 15) & ~15) + (size_t)8 * lds_nr + 16 : 0;
-        const int lds_ns = (lds_n && mode == 0 && dyn_base + (size_t)6 * ((maxn + 8) & ~7) <= state_lim) ? maxn : 0;
-        size_t dyn = lds_n ? (size_t)((lds_n + 15) & ~15) + (size_t)8 * lds_nr + (size_t)6 * ((lds_ns + 8) & ~7) + 16 : 0;
-        // few structures: deal each structure's candidates to several blocks so that the launch still fills the chip
-        static const int score_threads = getenv("SQ_SCORE_THREADS") ? atoi(getenv("SQ_SCORE_THREADS")) : 0;
-        static const int score_parts = getenv("SQ_SCORE_PARTS") ? atoi(getenv("SQ_SCORE_PARTS")) : 0;
-        static const int score_target = getenv("SQ_SCORE_TARGET") ? atoi(getenv("SQ_SCORE_TARGET")) : 512;
-        // mode 0 (two-phase loop): ~512 blocks of 512 threads; the one-pass modes want many small blocks in flight
-        int parts = std::max(1, std::min({512, ((mode == 0 ? score_target : 4096) + S - 1) / S, (int)(maxcap / 1024)}));
-        if (score_parts) parts = score_parts;
-        const int thr = score_threads ? score_threads : (mode == 0 ? 512 : (parts == 1 && S < 2048 ? 512 : 256));
-        // mode 0: list of the bpscore survivors of a chunk (5 x threads entries of 8 + 4 + 2 bytes) behind the tables
-        const int surv_off = (int)((dyn + 15) & ~(size_t)15);
-        dyn = (size_t)surv_off + (size_t)14 * (SQ_SCORE_CHUNK + (mode == 0 ? 1 : 0)) * thr;   // (one-pass modes: no carry-over)
-        if (mode == 0)
-            hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, ln.d_structs, ln.d_strands, b->state,
-                               scan, io, lds_n, lds_nr, lds_ns, surv_off);
-        else
-            hipLaunchKernelGGL(sq_bps_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, ln.d_structs, ln.d_strands, b->state,
-                               scan, io, mode, lds_n, lds_nr, surv_off);
-        if (mode == 0)
-            hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, ln.d_structs, scan, io);
         if (mode == 2) {
             // gap maps of the chunk's sequences into the (unused) round output buffer, then one scatter launch per
             // sequence, in list order: stream order == the reference's per-cell summation order (dbnali:233-237)
@@ -987,7 +1027,7 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
             }
         }
     }
-    const uint32_t seq = ++ln.round_seq;
+    const uint32_t seq = ++*ln.round_seq;
     hipLaunchKernelGGL(sq_done_kernel, dim3(1), dim3(1), 0, st, io, scan, seq);
     HIPCK(hipGetLastError());
     // wait for the round: spin on the sequence number in pinned memory (no driver round trip); a stuck or
@@ -1220,7 +1260,6 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         P.cursubopt = ps.suboptmin;                         // :1069
         P.suboptinc = (ps.suboptmax - ps.suboptmin) / ps.suboptsteps;   // :1071
         P.suboptmax = ps.suboptmax; P.maxstemnum = ps.maxstemnum;
-        if (algos[j] & SQ_ALGO_G) { P.cur.emplace_back(); P.cur.back().job = j; }   // :1105 one empty structure
     }
     // Edmonds / Hungarian / Nussinov paramsets (:1094-1100); their stemsets precede the greedy ones.
     // The reference iterates a Python set of letters (unspecified order); we use E, H, N.
@@ -1235,12 +1274,26 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     if (r) return r;
     const double tbegin = now_s() - ta;
     const double tfold0 = now_s();
+    // Width-1 pools (poollim == 1): the greedy rounds are chained on the device (sq_chain.hip) when all structures fit
+    // the round buffers at once; otherwise (and for wider pools) the host drives the rounds.
+    std::vector<int> greedy_jobs;
+    for (int j = 0; j < b->njobs; j++) if (algos[j] & SQ_ALGO_G) greedy_jobs.push_back(j);
+    const bool no_chain = getenv("SQ_NO_CHAIN") != nullptr;     // (read per fold: tests compare both drivers in one process)
+    bool use_chain = o.poollim == 1 && !no_chain && !greedy_jobs.empty();
+    if (use_chain)
+        for (int j : greedy_jobs)
+            if (chain_tcap(b->jobs[j].n, b->psets[b->job_pset[j]].minlen) > 1024 ||          // SQ_CHAIN_TMAX
+                b->jobs[j].cand_cap > b->cand_records - b->cand_reserved) use_chain = false;
+    if (!use_chain)
+        for (int j : greedy_jobs) { pools[j].cur.emplace_back(); pools[j].cur.back().job = j; }   // :1105 one empty structure
     for (int k = 0; k < 8; k++) g_t[k] = 0;
+    const bool timing = getenv("SQ_TIMING") != nullptr;
+    auto mark = [&](const char *what) { if (timing) fprintf(stderr, "[sq_fold]   +%.3f ms %s\n", (now_s() - tfold0) * 1e3, what); };
     // a-10 tail per sequence
     std::vector<std::vector<int32_t>> seq_jobs(b->nseq);
     for (int j = 0; j < b->njobs; j++) seq_jobs[b->job_seq[j]].push_back(j);
     std::vector<double> tail_cost(b->nseq, 0.0);
-    const bool timing = getenv("SQ_TIMING") != nullptr;
+    mark("job lists");
     auto tail_one = [&](int s) {
         const double tt0 = timing ? now_s() : 0;
         struct TT { bool on; double t0; double &dst; ~TT() { if (on) dst = now_s() - t0; } } tt{timing, tt0, tail_cost[s]};
@@ -1269,9 +1322,26 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     } tq;
     std::vector<std::atomic<int>> g_left(early_tail ? b->nseq : 0);
     std::vector<char> job_done(early_tail ? b->njobs : 0, 0);
+    // chained rounds: entry q of the device's list of finished structures (job | stems << 32 | by-count << 63) becomes
+    // the job's final stem list; handled by the queue's workers so that the thread that enqueues the rounds never waits
+    auto chain_finish = [&](uint32_t q) {
+        const unsigned long long e = b->chain.h_fin[q];
+        const int j = (int)(uint32_t)e, nst = (int)((e >> 32) & 0x7FFFFFFFu);
+        const bool by_count = (e >> 63) != 0;
+        JobPool &P = pools[j];
+        static_assert(sizeof(HStem) == sizeof(SqStemOut), "stem records must match");
+        std::vector<HStem> stems((size_t)nst);
+        if (nst) memcpy(stems.data(), b->chain.h_stems + b->chain_toff[j], sizeof(HStem) * (size_t)nst);
+        P.fin.push_back(std::move(stems));
+        P.evals += nst + (by_count ? 0 : 1);                // one evaluation per round the structure took part in
+        const int s2 = b->job_seq[j];
+        if (early_tail && --g_left[s2] == 0) { tail_one(s2); tailed[s2] = 1; }
+    };
     if (early_tail) {
         for (int s2 = 0; s2 < b->nseq; s2++) g_left[s2] = 0;
-        for (int j = 0; j < b->njobs; j++) if (!pools[j].cur.empty()) g_left[b->job_seq[j]]++;
+        for (int j : greedy_jobs) g_left[b->job_seq[j]]++;
+    }
+    if (early_tail || use_chain) {
         sq_pool(b);
         tq.worker = std::thread([&] {
             if (b->device >= 0) hipSetDevice(b->device);
@@ -1283,10 +1353,14 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                     take.swap(tq.items);
                     if (take.empty()) return;               // closed and drained
                 }
-                sq_pool(b)->parallel_for((int)take.size(), [&](int k) { tail_one(take[k]); tailed[take[k]] = 1; });
+                sq_pool(b)->parallel_for((int)take.size(), [&](int k) {
+                    if (take[k] < 0) chain_finish((uint32_t)(-(take[k] + 1)));       // (items < 0: chain entries)
+                    else { tail_one(take[k]); tailed[take[k]] = 1; }
+                });
             }
         });
     }
+    mark("tail queue");
     // the greedy pool loop (:1102-1199) for a subset of the jobs, on one lane of round buffers
     struct LoopStats { double tround = 0, twall = 0, tstart = 0; int nrounds = 0; int rc = 0; std::string err; };
     auto greedy_loop = [&](SqLane &ln, const std::vector<int> &myjobs, LoopStats &stats) {
@@ -1374,15 +1448,126 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // Two lanes when the batch is big enough: the jobs are dealt alternately (by sequence) to two host threads, each
     // driving its rounds on half of the round buffers; the kernels of both queue on the batch stream, so while one
     // lane's host code books a round the other lane's kernels run.  Jobs are independent: same results.
-    std::vector<int> greedy_jobs;
-    for (int j = 0; j < b->njobs; j++) if (!pools[j].cur.empty()) greedy_jobs.push_back(j);
     static const int want_lanes = getenv("SQ_FOLD_LANES") ? atoi(getenv("SQ_FOLD_LANES")) : 2;
     static const int lane_min_jobs = getenv("SQ_LANE_MIN_JOBS") ? atoi(getenv("SQ_LANE_MIN_JOBS")) : 512;
     const bool two_lanes = want_lanes >= 2 && !b->prof_on && (int)greedy_jobs.size() >= lane_min_jobs &&
                            (int)greedy_jobs.size() <= b->max_structs;   // (a lane holds half of the slots)
     LoopStats st0, st1;
     sq_pool(b);                                             // (created before any second thread can ask for it)
-    if (!two_lanes) {
+    // ---- device-chained rounds ----
+    auto chain_fold = [&](LoopStats &stats) {
+        SqLane &ln = b->lane_full;
+        hipStream_t st = b->stream;
+        const double tl0 = now_s();
+        stats.tstart = tl0 - tfold0;
+        struct Wall { double t0; double &dst; ~Wall() { dst = now_s() - t0; } } wall{tl0, stats.twall};
+        auto fail = [&](int rc, const std::string &msg) { stats.rc = rc; stats.err = msg; };
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(sq_check(e_, #x), sq_last_error()); return; } } while (0)
+        if (!b->chain.h_stems) {
+            void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
+            if (sq_pinned_get(&p0, sizeof(SqStemOut) * (size_t)std::max<int64_t>(b->chain_T, 1)) ||
+                sq_pinned_get(&p1, 8 * (size_t)b->njobs) || sq_pinned_get(&p2, 64) ||
+                sq_pinned_get(&p3, sizeof(SqChain) * (size_t)b->njobs)) { fail(2, sq_last_error()); return; }
+            b->chain.h_stems = (SqStemOut *)p0; b->chain.h_fin = (unsigned long long *)p1;
+            b->chain.h_nfin = (volatile uint32_t *)p2; b->h_chain = (SqChain *)p3;
+            b->chain_toff.resize(b->njobs);
+            int32_t t = 0;
+            for (int j = 0; j < b->njobs; j++) { b->chain_toff[j] = t; t += chain_tcap(b->jobs[j].n, b->psets[b->job_pset[j]].minlen); }
+        }
+        std::vector<int> finished;                          // queue items: sequences to rank (>= 0), chain entries (< 0)
+        auto job_finished = [&](int j) {
+            if (early_tail && --g_left[b->job_seq[j]] == 0) finished.push_back(b->job_seq[j]);
+        };
+        if (hipMemsetAsync(b->chain.d_nfin, 0, 4, st) != hipSuccess) { fail(2, "memset"); return; }
+        *b->chain.h_nfin = 0;
+        uint32_t nfin_seen = 0, nfin_goal = 0;              // entries of the finished list: handed on / expected after this chain
+        // as many structures per chain as the round buffers hold at once (one chain after the other)
+        const int64_t avail = b->cand_records - b->cand_reserved;
+        size_t next_job = 0;
+        while (next_job < greedy_jobs.size() && !stats.rc) {
+        std::vector<int> jobs;                              // structure index -> job
+        int maxn = 0, maxt = 0; int64_t cand_off = 0, maxcap = 0; double scan_bytes = 0; bool need_reacts = false;
+        for (; next_job < greedy_jobs.size(); next_job++) {
+            const int j = greedy_jobs[next_job];
+            JobPool &P = pools[j];
+            if (P.maxstemnum == 0) { P.fin.emplace_back(); job_finished(j); continue; }   // :1168-1174 full before the first round
+            const SqJob &J = b->jobs[j];
+            if ((int)jobs.size() == ln.max_structs || cand_off + J.cand_cap > avail) break;
+            const int sx = (int)jobs.size();
+            SqStruct &d = ln.h_structs[sx];
+            d.job = j; d.slot = sx; d.subopt = P.cursubopt; d.cand_off = cand_off;
+            cand_off += J.cand_cap; maxcap = std::max<int64_t>(maxcap, J.cand_cap);
+            SqChain &cr = b->h_chain[sx];
+            cr.toff = b->chain_toff[j]; cr.tcap = chain_tcap(J.n, b->psets[b->job_pset[j]].minlen);
+            cr.nstems = 0; cr.anycross = 0; cr.maxstems = P.maxstemnum;
+            d.strand_off = 4 * cr.toff; d.nstrand = 0;
+            maxn = std::max(maxn, J.n); maxt = std::max(maxt, cr.tcap);
+            need_reacts |= !J.default_reacts && !(J.react_levels > 0 && b->pset_classes[J.pset] * J.react_levels <= 32);
+            scan_bytes += 2.0 * J.n * J.n;
+            jobs.push_back(j);
+        }
+        tq.push(finished);
+        const int S = (int)jobs.size();
+        if (S == 0) continue;
+        CHK(hipMemcpyAsync(ln.d_structs, ln.h_structs, sizeof(SqStruct) * (size_t)S, hipMemcpyHostToDevice, st));
+        CHK(hipMemcpyAsync(b->chain.chain, b->h_chain, sizeof(SqChain) * (size_t)S, hipMemcpyHostToDevice, st));
+        CHK(hipMemsetAsync(ln.d_ctr, 0, sizeof(SqCounters), st));
+        nfin_goal += (uint32_t)S;
+        SqRoundIO io;
+        io.h_structs = ln.d_structs; io.h_strands = b->chain.strands; io.d_structs = ln.d_structs; io.d_strands = b->chain.strands;
+        io.h_out = ln.h_out; io.d_out = ln.d_out; io.h_cap = 0; io.out_cap = 0;
+        io.h_ctr = ln.h_ctr; io.h_seq = ln.h_seq;
+        SqScanArgs scan = b->scan;
+        scan.ctr = ln.d_ctr;
+        static const uint32_t depth = getenv("SQ_CHAIN_DEPTH") ? (uint32_t)std::max(1, atoi(getenv("SQ_CHAIN_DEPTH"))) : 3;
+        const uint32_t seq0 = *ln.round_seq;
+        uint32_t launched = 0, done = 0;
+        const bool relaxed = sq_relaxed_waits(b);
+        const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
+        uint64_t spins = 0;
+        volatile uint32_t *flag = ln.h_seq;
+        const double tr0 = now_s();
+        while (nfin_seen < nfin_goal) {
+            while (launched - done < depth) {               // rounds enqueued ahead of the device
+                if ((int)launched > maxt + 2) { fail(2, "chained rounds do not terminate"); break; }
+                launch_round_kernels(b, st, S, maxn, maxcap, need_reacts, scan_bytes, 0, io, scan, ln.d_structs, b->chain.strands, true);
+                const uint32_t seq = ++*ln.round_seq;
+                hipLaunchKernelGGL(sq_chain_done_kernel, dim3(1), dim3(1), 0, st, io, scan, b->chain, seq);
+                launched++;
+            }
+            if (stats.rc) break;
+            const uint32_t d2 = *flag - seq0;
+            if (d2 != done && d2 <= launched) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                done = d2; spins = 0;
+                const SqCounters ctr = *ln.h_ctr;
+                if (ctr.cand_ovf) { fail(-3, "candidate capacity exceeded (raise cand_per_nt)"); break; }
+                if (ctr.out_ovf) { fail(-3, "stem capacity of a chained structure exceeded"); break; }
+                if (ctr.level_ovf) { fail(-3, "more than 64 pseudoknot levels"); break; }
+                const uint32_t nf = *b->chain.h_nfin;
+                for (uint32_t q = nfin_seen; q < nf; q++) finished.push_back(-(int)q - 1);
+                nfin_seen = nf;
+                tq.push(finished);
+                continue;
+            }
+            if ((++spins & poll_mask) == 0) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q != hipErrorNotReady && q != hipSuccess) { fail(sq_check(q, "chained rounds"), sq_last_error()); break; }
+                if (q == hipSuccess && *flag - seq0 != launched) { fail(2, "chained round did not signal completion"); break; }
+            }
+            sq_wait_step(spins, relaxed);
+        }
+        stats.nrounds += (int)launched;
+        // rounds still in flight find no live structure; they must be through before the buffers are used again
+        hipStreamSynchronize(st);
+        stats.tround += now_s() - tr0;
+        }
+#undef CHK
+    };
+    mark("loop start");
+    if (use_chain) {
+        chain_fold(st0);
+    } else if (!two_lanes) {
         greedy_loop(b->lane_full, greedy_jobs, st0);
     } else {
         std::vector<int> part[2];
@@ -1481,7 +1666,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         fprintf(stderr, "[sq_fold] rounds=%d loop=%.3fms (round driver %.3f: prep %.3f gpu+wait %.3f post %.3f; pool %.3f) tail=%.3fms\n",
                 nrounds, tloop * 1e3, tround * 1e3, g_t[0] * 1e3, g_t[1] * 1e3, g_t[2] * 1e3, (tloop - tround) * 1e3,
                 (now_s() - ttail0) * 1e3);
-    if (timing && two_lanes)
+    if (timing && use_chain)
+        fprintf(stderr, "[sq_fold] chained rounds: start %.3f ms after the E/H/N launch, wall %.3f ms, %d rounds enqueued\n",
+                st0.tstart * 1e3, st0.twall * 1e3, st0.nrounds);
+    if (timing && two_lanes && !use_chain)
         fprintf(stderr, "[sq_fold] lanes: 0 start %.3f wall %.3f driver %.3f (%d rounds); 1 start %.3f wall %.3f driver %.3f (%d rounds)\n",
                 st0.tstart * 1e3, st0.twall * 1e3, st0.tround * 1e3, st0.nrounds, st1.tstart * 1e3, st1.twall * 1e3, st1.tround * 1e3, st1.nrounds);
     return 0;

@@ -85,6 +85,21 @@ struct SqOut {
     double fin;
 };
 
+// Device-chained greedy rounds (width-1 pools, sq_chain_kernel): one record per structure slot.  The stems chosen so
+// far live in a per-slot slice [toff, toff + tcap) of the chain's stem arrays; the strands in two buffers of 2 tcap
+// entries at 4 toff (the kernel writes the next round's list into the other one).
+struct SqChain {
+    int32_t toff, tcap;
+    int32_t nstems;
+    int32_t anycross;     // some pair of the structure's stems crosses: levels follow the full PairsToDBN rule
+    double maxstems;      // paramset maxstemnum: the structure is final when it holds that many stems (:1168-1174)
+};
+struct SqChainStem { int32_t i, j, len, cc; };      // cc: summed length of the stems crossing this one (:121-124)
+struct SqStemOut {                                  // == HStem of the host: one chosen stem, written to pinned memory
+    int32_t i, j, len, pad;
+    double bps, fin;
+};
+
 // Round-level counters.
 struct SqCounters {
     uint32_t nout;        // records appended to the out list

@@ -477,16 +477,21 @@ __device__ __forceinline__ void sq_state_build(const SqDevCtx &c, const SqStruct
     }
 }
 
-extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n)
+// chained: the structures and strands already live in device memory (sq_chain_kernel maintains them; io.h_* point at
+// the same arrays), finished structures carry nstrand < 0 and the counters accumulate over the whole chain.
+extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n,
+                                                                 int chained)
 {
     extern __shared__ __attribute__((aligned(16))) char st_dyn[];
     const SqStruct s = io.h_structs[blockIdx.x];          // pinned host memory: one read per structure per round
     if (threadIdx.x == 0) {
-        io.d_structs[blockIdx.x] = s;
+        if (!chained) io.d_structs[blockIdx.x] = s;
         a.cand_cnt[s.slot] = 0; a.best[s.slot] = 0ull; a.ok_cnt[s.slot] = 0;
-        if (blockIdx.x == 0) { a.ctr->nout = 0; a.ctr->cand_ovf = 0; a.ctr->out_ovf = 0; a.ctr->level_ovf = 0; }
+        if (blockIdx.x == 0 && !chained) { a.ctr->nout = 0; a.ctr->cand_ovf = 0; a.ctr->out_ovf = 0; a.ctr->level_ovf = 0; }
     }
-    for (int k = threadIdx.x; k < s.nstrand; k += 256) io.d_strands[s.strand_off + k] = io.h_strands[s.strand_off + k];
+    if (s.nstrand < 0) return;                            // (chained) the structure is final
+    if (!chained)
+        for (int k = threadIdx.x; k < s.nstrand; k += 256) io.d_strands[s.strand_off + k] = io.h_strands[s.strand_off + k];
     __syncthreads();
     const SqJob jb = c.jobs[s.job];
     const SqStrand *sd = io.d_strands + s.strand_off;
@@ -575,6 +580,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, con
     __shared__ __attribute__((aligned(16))) SqScan6Lds L;
     extern __shared__ uint32_t sq6_fg[];                                // F words then G words of the structure
     const SqStruct st = structs[blockIdx.x];
+    if (st.nstrand < 0) return;                                         // (chained rounds) the structure is final
     const SqJob jb = c.jobs[st.job];
     const int n = jb.n;
     if (n < 5) return;                                                  // :456-457 no diagonals
@@ -694,17 +700,6 @@ __device__ __forceinline__ bool sq_goodloop(int x, int y)             // :615-62
                              0x1Cu /*4:{2,3,4}*/};
     if ((unsigned)x > 4u || (unsigned)y > 4u) return false;
     return (tab[x] >> y) & 1u;
-}
-
-// order-preserving map double -> uint64 (never 0 for a real number), so a per-structure maximum is one atomicMax
-__device__ __forceinline__ unsigned long long sq_ord(double x)
-{
-    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double sq_unord(unsigned long long o)
-{
-    return __longlong_as_double((long long)((o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFull) : ~o));
 }
 
 // grid = (structures, parts): the candidates of a structure are dealt to `parts` blocks; the round's best

@@ -333,3 +333,81 @@ def test_predict_sharded_under_nccl_world1(tmp_path):
             assert buf.getvalue() == f.read()
     finally:
         dist.destroy_process_group()
+
+
+# ---- device-chained rounds (poollim == 1, sq_chain.hip): against the oracle and against the host-driven loop --------
+def _chain_records(count, seed, nmin, nmax):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(HERE), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    old = os.environ.get("FUZZ_NMIN"), os.environ.get("FUZZ_NMAX")
+    os.environ["FUZZ_NMIN"], os.environ["FUZZ_NMAX"] = str(nmin), str(nmax)
+    try:
+        return fz.make(count, seed)
+    finally:
+        for k, v in zip(("FUZZ_NMIN", "FUZZ_NMAX"), old):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _fold_both_drivers(recs, **kw):
+    from squarna_amd.engine import HipEngine
+    assert "SQ_NO_CHAIN" not in os.environ
+    chained = HipEngine().fold_records(recs, **kw)
+    os.environ["SQ_NO_CHAIN"] = "1"
+    try:
+        hosted = HipEngine().fold_records(recs, **kw)
+    finally:
+        del os.environ["SQ_NO_CHAIN"]
+    return chained, hosted
+
+
+@pytest.mark.parametrize("config,count,nmin,nmax,sample", [("fastest", 400, 5, 420, 60), ("nobpp", 160, 12, 260, 30),
+                                                           ("greedynobpp", 120, 12, 200, 24)])
+def test_chained_rounds_match_host_loop_and_oracle(config, count, nmin, nmax, sample):
+    """poollim=1: the rounds chained on the device (stem choice, strand insertion, pseudoknot levels, retirement) give
+    exactly what the host-driven loop gives (same kernels, so every score bit-for-bit), and what the oracle gives."""
+    from oracle import sqrn_oracle as O
+    names, psets = conf(config)
+    raw = _chain_records(count, 4242, nmin, nmax)
+    recs = [(s, r, x, None, psets, None) for s, r, x in raw]
+    chained, hosted = _fold_both_drivers(recs, poollim=1)
+    for k, (a, b) in enumerate(zip(chained, hosted)):
+        assert a[0] == b[0] and a[1] == b[1], (config, k, raw[k][0], a[:2], b[:2])
+    for k in range(sample):
+        s, r, x = raw[k]
+        exp = O.SQRNdbnseq(s, r, x, None, psets, poollim=1)
+        exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(chained[k], exp, (config, "chained", k))
+
+
+def test_chained_rounds_maxstemnum_and_long_pseudoknotted():
+    """Retirement by stem count (maxstemnum 0 / 1 / 3, SQRNdbnseq.py:1168-1174) and long random sequences whose
+    structures stack several pseudoknot levels (the device-side level rule), chained vs host loop vs oracle."""
+    from oracle import sqrn_oracle as O
+    names, psets = conf("fastest")
+    rng = np.random.default_rng(77)
+    seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in rng.integers(60, 400, 48)]
+    for msn in (0, 1, 3):
+        ps = [dict(psets[0], maxstemnum=msn)]
+        recs = [(s, None, None, None, ps, None) for s in seqs]
+        chained, hosted = _fold_both_drivers(recs, poollim=1)
+        assert [c[:2] for c in chained] == [h[:2] for h in hosted], msn
+        for k in range(10):
+            exp = O.SQRNdbnseq(seqs[k], None, None, None, ps, poollim=1)
+            exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+            _same_fold(chained[k], exp, ("maxstemnum", msn, k))
+    # long, GC-rich: many crossing stems
+    longs = ["".join(rng.choice(list("ACGU"), int(n), p=[0.15, 0.35, 0.35, 0.15])) for n in (900, 1300, 1700)]
+    ps = [dict(psets[0], orderpenalty=0.0, minlen=3, minbpscore=6)]          # pseudoknots are free: deep level stacks
+    recs = [(s, None, None, None, ps, None) for s in longs]
+    chained, hosted = _fold_both_drivers(recs, poollim=1)
+    assert [c[:2] for c in chained] == [h[:2] for h in hosted]
+    deep = max(sum(ch in c[1][0][0] for ch in "[{<A") for c in chained)
+    assert deep >= 3, "expected structures with at least four bracket levels"
+    exp = O.SQRNdbnseq(longs[0], None, None, None, ps, poollim=1)
+    exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+    _same_fold(chained[0], exp, ("long", 0))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak: NSEQ random sequences (with occasional reactivities / restraints) folded under a config
 by the CPU oracle (worker processes, before the GPU is touched) and by the HIP engine; every field of the
-SQRNdbnseq tuple is compared.  usage: fuzz_parity.py NSEQ CONFIG [SEED]"""
+SQRNdbnseq tuple is compared.  usage: fuzz_parity.py NSEQ CONFIG [SEED]   (FUZZ_POOLLIM=1: the device-chained rounds)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -66,7 +66,7 @@ def _init(cfg):
 
 def _one(rec):
     seq, reacts, restr = rec
-    r = O.SQRNdbnseq(seq, reacts, restr, None, PS, poollim=1000)
+    r = O.SQRNdbnseq(seq, reacts, restr, None, PS, poollim=int(os.environ.get("FUZZ_POOLLIM", "1000")))
     return r[0], [(d, tuple(s), list(p)) for d, s, p in r[1]]
 
 
@@ -81,7 +81,8 @@ def main():
     from squarna_amd.config import ParseConfig, builtin_config
     from squarna_amd.engine import HipEngine
     psets = ParseConfig(builtin_config(cfg))[1]
-    got = HipEngine().fold_records([(s, r, x, None, psets, None) for s, r, x in recs], poollim=1000)
+    got = HipEngine().fold_records([(s, r, x, None, psets, None) for s, r, x in recs],
+                                   poollim=int(os.environ.get("FUZZ_POOLLIM", "1000")))
     bad = 0
     for k, (g, e) in enumerate(zip(got, exp)):
         ok = g[0] == e[0] and len(g[1]) == len(e[1]) and all(
@@ -91,7 +92,7 @@ def main():
             bad += 1
             print("MISMATCH record %d n=%d reacts=%s restr=%s\n  seq %s\n  got %s\n  exp %s" % (
                 k, len(recs[k][0]), recs[k][1] is not None, recs[k][2], recs[k][0], g[0], e[0]), flush=True)
-    print("%d records, %d mismatches" % (nseq, bad))
+    print("%d records (config %s, poollim %s), %d mismatches" % (nseq, cfg, os.environ.get("FUZZ_POOLLIM", "1000"), bad))
     sys.exit(1 if bad else 0)
 
 
