@@ -187,6 +187,19 @@ extern "C" __global__ __launch_bounds__(64) void sq_chain_kernel(SqDevCtx c, SqS
     if ((double)T == ch.maxstems) retire(T, 1);                         // :1168-1174 (checked before the next evaluation)
 }
 
+// start of a chain: the structure and chain records from pinned host memory (read in place: no copy engine, no
+// stream wait), counters cleared
+extern "C" __global__ __launch_bounds__(256) void sq_chain_init_kernel(const SqStruct *h_structs, const SqChain *h_chain, SqStruct *d_structs,
+                                                                      SqChainIO cio, SqScanArgs a, int S, int first)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < S) { d_structs[q] = h_structs[q]; cio.chain[q] = h_chain[q]; }
+    if (q == 0) {
+        a.ctr->nout = 0; a.ctr->cand_ovf = 0; a.ctr->out_ovf = 0; a.ctr->level_ovf = 0;
+        if (first) *cio.d_nfin = 0;
+    }
+}
+
 // end of a chained round: counters and the number of finished structures, then the sequence number the host watches
 extern "C" __global__ void sq_chain_done_kernel(SqRoundIO io, SqScanArgs a, SqChainIO cio, uint32_t seq)
 {

@@ -95,6 +95,8 @@ __global__ void sq_dense64_kernel(SqDevCtx c, int job, double *boolmat, double *
 __global__ void sq_import_kernel(SqDevCtx c);
 __global__ void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n, int chained);
 __global__ void sq_chain_kernel(SqDevCtx c, SqStruct *structs, SqScanArgs a, SqChainIO cio);
+__global__ void sq_chain_init_kernel(const SqStruct *h_structs, const SqChain *h_chain, SqStruct *d_structs, SqChainIO cio,
+                                     SqScanArgs a, int S, int first);
 __global__ void sq_chain_done_kernel(SqRoundIO io, SqScanArgs a, SqChainIO cio, uint32_t seq);
 __global__ void sq_done_kernel(SqRoundIO io, SqScanArgs a, uint32_t seq);
 __global__ void sq_mirror_kernel(double *matrix, int L);

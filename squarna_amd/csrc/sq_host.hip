@@ -528,8 +528,38 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->chain_T = L.chain_T;
 
     hipStream_t st = b->stream;
-#define UP(dst, src, bytes) do { int _r = sq_check(hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, st), "upload"); \
-                                 if (_r) { hipStreamSynchronize(st); delete b; return _r; } } while (0)
+    // Uploads go through a pinned staging buffer of the library.  A copy straight from pageable memory makes the runtime
+    // register the caller's pages with the driver; when the allocator later returns such pages to the kernel (munmap /
+    // heap trim) the driver evicts the process's queues for tens of milliseconds -- measured as 20-35 ms stalls in the
+    // third fold after a batch was created.  Buffers larger than the staging area go in slices.
+    struct Stager {
+        hipStream_t st; char *buf = nullptr; size_t cap = 0, cur = 0; int rc = 0;
+        ~Stager() { if (buf) { hipStreamSynchronize(st); sq_pinned_put(buf); } }
+        int put(void *dst, const void *src, size_t bytes)
+        {
+            const char *s = (const char *)src; char *d = (char *)dst;
+            while (bytes) {
+                if (cur == cap) { rc = sq_check(hipStreamSynchronize(st), "upload"); if (rc) return rc; cur = 0; }
+                const size_t take = std::min(bytes, cap - cur);
+                memcpy(buf + cur, s, take);
+                rc = sq_check(hipMemcpyAsync(d, buf + cur, take, hipMemcpyHostToDevice, st), "upload");
+                if (rc) return rc;
+                cur += (take + 255) & ~(size_t)255; if (cur > cap) cur = cap;
+                s += take; d += take; bytes -= take;
+            }
+            return 0;
+        }
+    } stager;
+    stager.st = st;
+    {
+        size_t want = (size_t)L.ltot * 16 + sizeof(SqJob) * d->njobs + sizeof(SqPsetDev) * d->npset + 8 * sdf.size() + 4 * rbpk.size() + 16384;
+        for (int j = 0; j < d->njobs; j++) if (b->jobs[j].has_ext) want += (size_t)b->jobs[j].n * b->jobs[j].n * 8 * (b->jobs[j].has_ext == 1 ? 2 : 1);
+        stager.cap = std::min<size_t>(std::max<size_t>(want, (size_t)1 << 20), (size_t)64 << 20) & ~(size_t)255;
+        void *pb = nullptr;
+        if (sq_pinned_get(&pb, stager.cap)) { delete b; return 2; }
+        stager.buf = (char *)pb;
+    }
+#define UP(dst, src, bytes) do { int _r = stager.put((void *)(dst), (src), (bytes)); if (_r) { hipStreamSynchronize(st); delete b; return _r; } } while (0)
     UP(b->ctx.codes, b->codes.data(), L.ltot); UP(b->ctx.flags, b->flags.data(), L.ltot);
     UP(b->ctx.inc4, inc4.data(), L.ltot); UP(b->ctx.chain, chain.data(), L.ltot * 2);
     UP(b->ctx.e0c, e0.data(), L.ltot); UP(b->ctx.reacts, b->reacts.data(), L.ltot * 8);
@@ -1478,8 +1508,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         auto job_finished = [&](int j) {
             if (early_tail && --g_left[b->job_seq[j]] == 0) finished.push_back(b->job_seq[j]);
         };
-        if (hipMemsetAsync(b->chain.d_nfin, 0, 4, st) != hipSuccess) { fail(2, "memset"); return; }
         *b->chain.h_nfin = 0;
+        bool first_chain = true;
         uint32_t nfin_seen = 0, nfin_goal = 0;              // entries of the finished list: handed on / expected after this chain
         // as many structures per chain as the round buffers hold at once (one chain after the other)
         const int64_t avail = b->cand_records - b->cand_reserved;
@@ -1509,9 +1539,6 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         tq.push(finished);
         const int S = (int)jobs.size();
         if (S == 0) continue;
-        CHK(hipMemcpyAsync(ln.d_structs, ln.h_structs, sizeof(SqStruct) * (size_t)S, hipMemcpyHostToDevice, st));
-        CHK(hipMemcpyAsync(b->chain.chain, b->h_chain, sizeof(SqChain) * (size_t)S, hipMemcpyHostToDevice, st));
-        CHK(hipMemsetAsync(ln.d_ctr, 0, sizeof(SqCounters), st));
         nfin_goal += (uint32_t)S;
         SqRoundIO io;
         io.h_structs = ln.d_structs; io.h_strands = b->chain.strands; io.d_structs = ln.d_structs; io.d_strands = b->chain.strands;
@@ -1519,6 +1546,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         io.h_ctr = ln.h_ctr; io.h_seq = ln.h_seq;
         SqScanArgs scan = b->scan;
         scan.ctr = ln.d_ctr;
+        hipLaunchKernelGGL(sq_chain_init_kernel, dim3((S + 255) / 256), dim3(256), 0, st, ln.h_structs, b->h_chain, ln.d_structs,
+                           b->chain, scan, S, first_chain ? 1 : 0);
+        first_chain = false;
         static const uint32_t depth = getenv("SQ_CHAIN_DEPTH") ? (uint32_t)std::max(1, atoi(getenv("SQ_CHAIN_DEPTH"))) : 3;
         const uint32_t seq0 = *ln.round_seq;
         uint32_t launched = 0, done = 0;
@@ -1527,6 +1557,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         uint64_t spins = 0;
         volatile uint32_t *flag = ln.h_seq;
         const double tr0 = now_s();
+        std::vector<std::pair<int, double>> round_t;
         while (nfin_seen < nfin_goal) {
             while (launched - done < depth) {               // rounds enqueued ahead of the device
                 if ((int)launched > maxt + 2) { fail(2, "chained rounds do not terminate"); break; }
@@ -1540,6 +1571,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             if (d2 != done && d2 <= launched) {
                 std::atomic_thread_fence(std::memory_order_acquire);
                 done = d2; spins = 0;
+                if (timing) round_t.push_back({(int)done, (now_s() - tr0) * 1e3});
                 const SqCounters ctr = *ln.h_ctr;
                 if (ctr.cand_ovf) { fail(-3, "candidate capacity exceeded (raise cand_per_nt)"); break; }
                 if (ctr.out_ovf) { fail(-3, "stem capacity of a chained structure exceeded"); break; }
@@ -1558,6 +1590,11 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             sq_wait_step(spins, relaxed);
         }
         stats.nrounds += (int)launched;
+        if (timing && (now_s() - tr0) > 8e-3) {
+            fprintf(stderr, "[sq_fold] slow chain:");
+            for (auto &rt : round_t) fprintf(stderr, " r%d@%.2f", rt.first, rt.second);
+            fprintf(stderr, "\n");
+        }
         // rounds still in flight find no live structure; they must be through before the buffers are used again
         hipStreamSynchronize(st);
         stats.tround += now_s() - tr0;

@@ -1,1 +1,1 @@
-python -m pytest tests/test_hip_parity2.py -m gpu -x -q -k chained 2>&1 | grep -v amdgpu.ids | tail -30
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror|assert" | tail -8
