@@ -597,8 +597,9 @@ struct SqBlossom {
 #else
 #define SQ_PT(k, expr) do { expr; } while (0)
 #endif
-    double red_v[64][4];
-    int red_i[64][4];
+    double red_v0;                    // broadcast slots of the dual step (delta; type, edge, blossom)
+    int red_k[3];
+    int red_i[64][2];                 // per lane: (blossom, queue position) of the queue refill
 
     // FAST: the edges and all state arrays live in ONE LDS buffer whose address the caller passes as `fast0`
     // (and as `origin`, its generic address).  The hot loops then address the arrays as fast0 + offset, which lets
@@ -891,11 +892,11 @@ struct SqBlossom {
                     if (i2 != NONE && m2 < delta) { delta = m2; deltatype = 2; deltaedge = bestedge_[i2]; }
                     if (i3 != NONE && m3 < delta) { delta = m3; deltatype = 3; const int b = i3 < n ? i3 : live_[i3 - n]; deltaedge = bestedge_[b]; }
                     if (i4 != NONE && m4 < delta) { delta = m4; deltatype = 4; deltablossom = live_[i4]; }
-                    if (lane == 0) { red_v[0][0] = delta; red_i[0][0] = deltatype; red_i[0][1] = deltaedge; red_i[0][2] = deltablossom; }
+                    if (lane == 0) { red_v0 = delta; red_k[0] = deltatype; red_k[1] = deltaedge; red_k[2] = deltablossom; }
                 }
                 sync();
                 {
-                    const double delta = red_v[0][0];
+                    const double delta = red_v0;
                     for (int v = lane; v < n; v += nl) {
                         const int lb = label_[inblossom_[v]];
                         if (lb == 1) dualvar_[v] -= delta; else if (lb == 2) dualvar_[v] += delta;
@@ -917,7 +918,7 @@ struct SqBlossom {
                 if (lane == 0) { const long long _n = wall_clock64(); pt[3] += _n - _tp; _tp = _n; }
 #endif
                 if (lane == 0) {
-                    const int deltatype = red_i[0][0], deltaedge = red_i[0][1], deltablossom = red_i[0][2];
+                    const int deltatype = red_k[0], deltaedge = red_k[1], deltablossom = red_k[2];
                     f_stop = 0;
                     if (deltatype == 1) f_stop = 1;
                     else if (deltatype == 2 || deltatype == 3) { SQ_LP(allow)[deltaedge >> 1] = 1; qpush<FAST>(tail<FAST>(deltaedge)); }

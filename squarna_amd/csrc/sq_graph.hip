@@ -114,7 +114,8 @@ int run_matching(int algo, const std::vector<SqMatchJob> &jobs, const std::vecto
     const size_t jb = up256(jobs.size() * sizeof(SqMatchJob)), eb = up256(edges.size() * sizeof(SqMatchEdge) + 16);
     const size_t ob = up256(outints * 4 + 16), cb = up256(jobs.size() * 4 + 16);
     Pinned pin;
-    if (pin.get(jb + eb + ob + cb + 256)) return 2;
+    const size_t hb = up256(jobs.size() * 4 + 16);      // blossom: first job of every block (sq_mwm_plan)
+    if (pin.get(jb + eb + ob + cb + hb + 256)) return 2;
     SqMatchJob *p_jobs = (SqMatchJob *)pin.p;
     SqMatchEdge *p_edges = (SqMatchEdge *)(pin.p + jb);
     int32_t *p_out = (int32_t *)(pin.p + jb + eb), *p_cnt = (int32_t *)(pin.p + jb + eb + ob);
@@ -127,7 +128,7 @@ int run_matching(int algo, const std::vector<SqMatchJob> &jobs, const std::vecto
     char *d_scr = (char *)d_codes + up256(ncodes + 16);
     if (codes && ncodes) HIPCK(hipMemcpyAsync(d_codes, codes, ncodes, hipMemcpyHostToDevice, st));
     const int rl = sq_launch_matching(algo, jobs.data(), (int)jobs.size(), p_jobs, p_edges, edges.size(), dev_edges, d_scr,
-                                      p_out, p_cnt, d_codes, nullptr, 0, st);
+                                      p_out, p_cnt, d_codes, nullptr, 0, st, p_jobs, (int32_t *)(pin.p + jb + eb + ob + cb), 1);
     if (rl) { hipStreamSynchronize(st); return sq_check((hipError_t)rl, "matching kernel launch"); }
     HIPCK(hipStreamSynchronize(st));                   // results are in host memory (the kernels wrote them in place)
     return read(p_out, p_cnt);

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <atomic>
+#include <time.h>
 #include "../../include/squarna_hip.h"
 #include "sq_device.h"
 #include "sq_internal.h"
@@ -100,6 +101,7 @@ struct SqLane {
     uint32_t *round_seq = nullptr;            // id of the last round sent to h_seq (lanes that share the word share the counter)
     hipStream_t stream = nullptr;             // nullptr: the batch stream
     std::vector<SqOut> big_out;
+    std::vector<uint32_t> post_cnt, post_idx, post_fill;   // scratch of the round's output bucketing
 };
 
 struct sq_batch {
@@ -171,6 +173,18 @@ struct sq_batch {
     ProfSlot prof[7];                     // 0 fill, 1 state, 2 scan, 3 score, 4 Edmonds, 5 Hungarian, 6 Nussinov
 };
 
+// CPU accounting (SQ_CPUACC=1): thread CPU time spent in the host phases, summed over all threads, printed per fold.
+// 0 tails, 1 RunAlgo filters (collect), 2 edge lists (build), 3 pool growth, 4 round post-processing, 5 round set-up +
+// launches, 6 waits of the round driver, 7 AnnotateStems rounds of E/H/N, 8 the fold's calling thread in all, 9 sq_algos_begin,
+// 10 sq_algos_end (its thread), 11 teardown of the pools
+extern std::atomic<long long> g_cpuacc[12];
+extern bool g_cpuacc_on;
+struct CpuScope {
+    int k; long long t0;
+    static long long now() { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec * 1000000000ll + ts.tv_nsec; }
+    explicit CpuScope(int k_) : k(k_), t0(g_cpuacc_on ? now() : 0) {}
+    ~CpuScope() { if (g_cpuacc_on) g_cpuacc[k] += now() - t0; }
+};
 void sq_set_error(const std::string &msg);
 // pinned (mapped, coherent) host buffers from a small process-wide cache: hipHostMalloc / hipHostFree cost milliseconds,
 // and a caller that builds one batch per call (Predict) would pay them every time

@@ -14,6 +14,8 @@
 #include "sq_host.h"
 
 static thread_local std::string g_err;
+std::atomic<long long> g_cpuacc[12];
+bool g_cpuacc_on = getenv("SQ_CPUACC") != nullptr;
 
 // host phase timers (printed to stderr when SQ_TIMING is set)
 static thread_local double g_t[8];
@@ -836,7 +838,7 @@ void sq_stem_levels(const std::vector<HStem> &stems, std::vector<int> &level)
     grp.assign(T, -1); gsize.clear();
     for (int t = 0; t < T; t++) {                           // :130-136 first fit
         const int p = order[t];
-        int placed = -1;
+        int placed = (cc[p] == 0 && !gsize.empty()) ? 0 : -1;   // a stem that crosses nothing fits the first group
         for (int g = 0; g < (int)gsize.size() && placed < 0; g++) {
             bool ok = true;
             for (int u = 0; u < t && ok; u++)
@@ -848,7 +850,12 @@ void sq_stem_levels(const std::vector<HStem> &stems, std::vector<int> &level)
     }
     gord.resize(gsize.size());
     for (size_t g = 0; g < gsize.size(); g++) gord[g] = (int)g;
-    std::stable_sort(gord.begin(), gord.end(), [&](int a, int b) { return gsize[a] > gsize[b]; });   // :139
+    for (size_t g = 1; g < gord.size(); g++) {              // :139 stable, descending by size (insertion sort: a handful of
+        const int x = gord[g];                              // groups, and std::stable_sort would allocate its buffer per call)
+        size_t q = g;
+        while (q > 0 && gsize[gord[q - 1]] < gsize[x]) { gord[q] = gord[q - 1]; q--; }
+        gord[q] = x;
+    }
     rank.resize(gsize.size());
     for (size_t r = 0; r < gord.size(); r++) rank[gord[r]] = (int)r;
     for (int a = 0; a < T; a++) level[a] = rank[grp[a]] + 1;
@@ -996,6 +1003,7 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
                      std::vector<std::vector<HStem>> &out, const AlignSink *sink = nullptr)
 {
     const int S = (int)(hi - lo);
+    long long cpu_t0 = g_cpuacc_on ? CpuScope::now() : 0;
     int nstrand = 0, maxn = 0; int64_t cand_off = ln.cand0, maxcap = 0; double scan_bytes = 0;
     bool need_reacts = false;       // some job computes its reactivity factors per cell (float reactivities, or too many levels for the cell table)
     double tp0 = now_s();
@@ -1060,6 +1068,7 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
     const uint32_t seq = ++*ln.round_seq;
     hipLaunchKernelGGL(sq_done_kernel, dim3(1), dim3(1), 0, st, io, scan, seq);
     HIPCK(hipGetLastError());
+    if (g_cpuacc_on) { const long long t = CpuScope::now(); g_cpuacc[mode == 1 ? 7 : 5] += t - cpu_t0; cpu_t0 = t; }
     // wait for the round: spin on the sequence number in pinned memory (no driver round trip); a stuck or
     // faulted queue is caught by polling the stream now and then
     {
@@ -1079,6 +1088,7 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
+    if (g_cpuacc_on) g_cpuacc[6] += CpuScope::now() - cpu_t0;
     const SqCounters ctr = *ln.h_ctr;
     if (ctr.cand_ovf) { sq_set_error("candidate capacity exceeded (raise cand_per_nt)"); return -3; }
     if (ctr.out_ovf) { sq_set_error("round output capacity exceeded (lower max_structs)"); return -3; }
@@ -1095,11 +1105,13 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
     g_t[1] += now_s() - tp0;
     if (mode == 2) return 0;
     TScope tpost(2);
+    CpuScope cpu_post(4);
     // bucket by structure
-    std::vector<uint32_t> cnt(S + 1, 0);
+    std::vector<uint32_t> &cnt = ln.post_cnt, &idx = ln.post_idx, &fillp = ln.post_fill;   // (kept per lane: no allocation per round)
+    cnt.assign(S + 1, 0);
     for (uint32_t k = 0; k < nout; k++) cnt[ho[k].st + 1]++;
     for (int s = 0; s < S; s++) cnt[s + 1] += cnt[s];
-    std::vector<uint32_t> idx(nout), fillp(cnt.begin(), cnt.end() - 1);
+    idx.resize(nout); fillp.assign(cnt.begin(), cnt.end() - 1);
     for (uint32_t k = 0; k < nout; k++) idx[fillp[ho[k].st]++] = k;
     auto post_one = [&](int s) {
         uint32_t *p0 = idx.data() + cnt[s], *p1 = idx.data() + cnt[s + 1];
@@ -1267,6 +1279,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     if (!b || !opts) { sq_set_error("bad argument"); return -1; }
     const sq_fold_opts &o = *opts;
     if (o.poollim < 1) { sq_set_error("poollim must be positive"); return -1; }
+    const long long cpu_fold0 = g_cpuacc_on ? CpuScope::now() : 0;
     struct FoldTimer { double t0; ~FoldTimer() { if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_fold] total %.3f ms (incl. teardown)\n", (now_s() - t0) * 1e3); } } fold_timer{now_s()};
     // a-1, once per job and per fold (:1076): never reused from an earlier call, a fold is the whole path
     int r = fill_impl(b, 0);
@@ -1278,7 +1291,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         ~PoolsDrop()
         {
             static const bool sync_drop = getenv("SQ_SYNC_TEARDOWN") != nullptr;
-            if (sync_drop) delete p; else std::thread([q = p] { delete q; }).detach();
+            if (sync_drop) delete p; else std::thread([q = p] { CpuScope cpu_(11); delete q; }).detach();
         }
     } pools_drop{pools_owner};
     std::vector<JobPool> &pools = *pools_owner;
@@ -1296,7 +1309,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     SqAlgoAsync *pending = nullptr;
     const double ta = now_s();
     if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_fold] setup before E/H/N begin: %.3f ms (bit matrix launch + job pools)\n", (ta - fold_timer.t0) * 1e3);
-    r = sq_algos_begin(b, algos, pending);                  // AnnotateStems + matching kernels on side streams
+    { CpuScope cpu_(9); r = sq_algos_begin(b, algos, pending); }   // AnnotateStems + matching kernels on side streams
     struct PendGuard {                                      // error paths: wait for the side streams, release the arena
         sq_batch *b; SqAlgoAsync *&p;
         ~PendGuard() { if (p) { std::vector<JobSets> d; sq_algos_end(b, p, -1, d); p = nullptr; } }
@@ -1325,6 +1338,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     std::vector<double> tail_cost(b->nseq, 0.0);
     mark("job lists");
     auto tail_one = [&](int s) {
+        CpuScope cpu_(0);
         const double tt0 = timing ? now_s() : 0;
         struct TT { bool on; double t0; double &dst; ~TT() { if (on) dst = now_s() - t0; } } tt{timing, tt0, tail_cost[s]};
         std::vector<const std::vector<std::vector<HStem>> *> per_job;   // (freed later by the thread that allocated them)
@@ -1440,6 +1454,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             // are independent; per job the entries are still handled in order.  Big rounds are shared among the
             // worker pool in contiguous slices (children mostly reuse their parent's storage: no allocator traffic).
             auto grow = [&](size_t q0, size_t q1) {
+                CpuScope cpu_(3);
                 for (size_t q = q0; q < q1; q++) {
                     const int j = owner[q];
                     JobPool &P = pools[j];
@@ -1671,7 +1686,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             if (--e_left[s] == 0) { tail_one(s); tailed[s] = 1; }
         };
         std::vector<JobSets> sets;
-        r = sq_algos_end(b, pending, o.levellimit, sets, &hooks);
+        { CpuScope cpu_(10); r = sq_algos_end(b, pending, o.levellimit, sets, &hooks); }
         pending = nullptr;
         if (r) return r;
         bool streamed = false;
@@ -1703,6 +1718,13 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         fprintf(stderr, "[sq_fold] rounds=%d loop=%.3fms (round driver %.3f: prep %.3f gpu+wait %.3f post %.3f; pool %.3f) tail=%.3fms\n",
                 nrounds, tloop * 1e3, tround * 1e3, g_t[0] * 1e3, g_t[1] * 1e3, g_t[2] * 1e3, (tloop - tround) * 1e3,
                 (now_s() - ttail0) * 1e3);
+    if (g_cpuacc_on) {
+        static const char *nm[12] = {"tails", "filters", "edges", "grow", "post", "launch", "wait", "annotate", "caller", "begin", "end", "teardown"};
+        fprintf(stderr, "[sq_fold cpu ms]");
+        g_cpuacc[8] += CpuScope::now() - cpu_fold0;
+        for (int k = 0; k < 12; k++) fprintf(stderr, " %s %.2f", nm[k], g_cpuacc[k].exchange(0) * 1e-6);
+        fprintf(stderr, "\n");
+    }
     if (timing && use_chain)
         fprintf(stderr, "[sq_fold] chained rounds: start %.3f ms after the E/H/N launch, wall %.3f ms, %d rounds enqueued\n",
                 st0.tstart * 1e3, st0.twall * 1e3, st0.nrounds);

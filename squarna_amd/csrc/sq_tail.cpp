@@ -19,6 +19,13 @@ typedef std::pair<int, int> BP;
 static double py_round3(double x)
 {
     if (!std::isfinite(x)) return x;
+    // Fast path: k = round(1000 x) decides the decimal whenever 1000 x is not within 1e-6 of a tie (the product is off by
+    // at most half an ulp, far less for |x| < 1e9), and k / 1000.0 -- one correctly rounded division of two exact
+    // integers -- is the double nearest to that decimal, i.e. what strtod returns for its text.
+    if (std::fabs(x) < 1e9) {
+        const double y = x * 1000.0, f = std::floor(y), frac = y - f;
+        if (std::fabs(frac - 0.5) > 1e-6) return (frac > 0.5 ? f + 1.0 : f) / 1000.0;
+    }
     char buf[512];
     snprintf(buf, sizeof buf, "%.3f", x);
     return strtod(buf, nullptr);
@@ -36,7 +43,9 @@ int sq_pair_levels(const std::vector<BP> &pairs, std::vector<int> &level)
     const int np = (int)pairs.size();
     level.assign(np, 0);
     if (!np) return 0;
-    std::vector<int> cc(np, 0), order(np);
+    // scratch kept per thread (this runs per structure in the tail and in RunAlgo's filters): allocation-free when warm
+    static thread_local std::vector<int> cc, order, grp, gord, rank, gsize, members, gnext;
+    cc.assign(np, 0); order.resize(np);
     for (int a = 0; a < np; a++) {
         for (int b = 0; b < np; b++)
             if (a != b && crosses(pairs[a], pairs[b])) cc[a]++;
@@ -46,34 +55,38 @@ int sq_pair_levels(const std::vector<BP> &pairs, std::vector<int> &level)
         if (cc[a] != cc[b]) return cc[a] < cc[b];
         return pairs[a].first < pairs[b].first;
     });
-    std::vector<std::vector<int>> groups;
-    std::vector<int> grp(np);
+    // groups as linked lists in insertion order: members[g] = first pair of group g, gnext[p] = next pair of p's group
+    grp.resize(np); gnext.assign(np, -1); members.clear(); gsize.clear();
+    static thread_local std::vector<int> gtail;
+    gtail.clear();
     for (int t = 0; t < np; t++) {                                     // :130-136
         const int p = order[t];
         int placed = -1;
-        for (size_t g = 0; g < groups.size() && placed < 0; g++) {
+        for (size_t g = 0; g < members.size() && placed < 0; g++) {
             bool ok = true;
             if (cc[p])
-                for (int q : groups[g]) if (crosses(pairs[p], pairs[q])) { ok = false; break; }
+                for (int q = members[g]; q >= 0; q = gnext[q]) if (crosses(pairs[p], pairs[q])) { ok = false; break; }
             if (ok) placed = (int)g;
         }
-        if (placed < 0) { placed = (int)groups.size(); groups.emplace_back(); }
-        groups[placed].push_back(p); grp[p] = placed;
+        if (placed < 0) { placed = (int)members.size(); members.push_back(p); gtail.push_back(p); gsize.push_back(0); }
+        else { gnext[gtail[placed]] = p; gtail[placed] = p; }
+        gsize[placed]++; grp[p] = placed;
     }
-    std::vector<int> gord(groups.size());
-    for (size_t g = 0; g < groups.size(); g++) gord[g] = (int)g;
-    std::stable_sort(gord.begin(), gord.end(), [&](int a, int b) { return groups[a].size() > groups[b].size(); });  // :139
-    std::vector<int> rank(groups.size());
-    for (size_t r = 0; r < gord.size(); r++) rank[gord[r]] = (int)r;
+    const int ng = (int)members.size();
+    gord.resize(ng);
+    for (int g = 0; g < ng; g++) gord[g] = g;
+    std::stable_sort(gord.begin(), gord.end(), [&](int a, int b) { return gsize[a] > gsize[b]; });  // :139
+    rank.resize(ng);
+    for (int r = 0; r < ng; r++) rank[gord[r]] = r;
     for (int a = 0; a < np; a++) level[a] = rank[grp[a]] + 1;
-    return (int)groups.size();
+    return ng;
 }
 
 typedef std::vector<BP> BPV;   // sorted, unique
 
 static void levels_of(const BPV &pairs, int n, int levellimit, std::vector<int16_t> &out)
 {
-    std::vector<int> lv;
+    static thread_local std::vector<int> lv;
     sq_pair_levels(pairs, lv);
     out.assign(n, 0);
     for (size_t k = 0; k < pairs.size(); k++) {
@@ -86,7 +99,7 @@ static void levels_of(const BPV &pairs, int n, int levellimit, std::vector<int16
 // same result as levels_of() on the stems' bps, computed per stem
 static void levels_of_stems(const std::vector<HStem> &stems, int n, std::vector<int16_t> &out)
 {
-    std::vector<int> lv;
+    static thread_local std::vector<int> lv;
     sq_stem_levels(stems, lv);
     out.assign(n, 0);
     for (size_t k = 0; k < stems.size(); k++)
@@ -97,11 +110,19 @@ static void levels_of_stems(const std::vector<HStem> &stems, int n, std::vector<
 }
 
 namespace {
+// One distinct structure of a sequence.  Its stems stay where the fold left them (the job's final list outlives the
+// tail); its sorted base pairs are a slice of the call's flat pair list -- no allocation per structure.
 struct Entry {
-    std::vector<HStem> stems;
-    BPV bps;
+    const std::vector<HStem> *stems;
+    uint32_t bp_off, bp_n;
     double scores[3];
     uint64_t mask;
+};
+struct Span {
+    const BP *p; size_t n;
+    const BP *begin() const { return p; }
+    const BP *end() const { return p + n; }
+    size_t size() const { return n; }
 };
 }  // namespace
 
@@ -146,18 +167,21 @@ static uint64_t bps_of(const std::vector<HStem> &stems, BPV &out)
     return h;
 }
 
-static inline size_t count_common(const BPV &a, const BPV &b)
+template <class A, class B>
+static inline size_t count_common(const A &a, const B &b)
 {
-    size_t i = 0, j = 0, c = 0;
-    while (i < a.size() && j < b.size()) {
-        if (a[i] < b[j]) i++;
-        else if (b[j] < a[i]) j++;
-        else { c++; i++; j++; }
+    auto i = a.begin(); auto j = b.begin();
+    size_t c = 0;
+    while (i != a.end() && j != b.end()) {
+        if (*i < *j) ++i;
+        else if (*j < *i) ++j;
+        else { c++; ++i; ++j; }
     }
     return c;
 }
 
-static BPV merged(const BPV &a, const BPV &b)
+template <class A, class B>
+static BPV merged(const A &a, const B &b)
 {
     BPV out;
     std::set_union(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(out));
@@ -199,7 +223,8 @@ static void score_struct(const uint8_t *codes, const double *reacts, int n, cons
     out[2] = py_round3(reactscore);
 }
 
-static void prf(const BPV &pred, const BPV &known, double m[6])       // :1252-1258
+template <class A>
+static void prf(const A &pred, const BPV &known, double m[6])         // :1252-1258
 {
     const int tp = (int)count_common(pred, known);
     const int fp = (int)pred.size() - tp, fn = (int)known.size() - tp;
@@ -222,28 +247,38 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
     const double tp0 = nowus();
 #endif
     // :1201-1220 dedupe across paramsets; the first producer scores the structure
-    std::vector<Entry> fins;
-    std::unordered_map<uint64_t, int> seen;                            // hash of the bp set -> first entry with it
-    std::vector<int> chain;                                            // next entry with the same hash (-1: none)
-    BPV key;
+    static thread_local std::vector<Entry> fins_tl;
+    static thread_local std::vector<BP> flat;                           // sorted pairs of every distinct structure
+    static thread_local std::vector<int> table, chain;                  // open addressing on the pair-set hash: entry + 1
+    static thread_local std::vector<uint64_t> hashes;
+    static thread_local BPV key;
+    std::vector<Entry> &fins = fins_tl;
+    fins.clear(); flat.clear(); chain.clear(); hashes.clear();
+    size_t total = 0;
+    for (size_t k = 0; k < per_job.size(); k++) total += per_job[k]->size();
+    size_t tsize = 16;
+    while (tsize < 2 * total + 2) tsize <<= 1;
+    table.assign(tsize, 0);
+    auto bps_of_entry = [&](const Entry &e) { return Span{flat.data() + e.bp_off, e.bp_n}; };
     for (size_t k = 0; k < per_job.size(); k++) {
         for (const auto &stems : *per_job[k]) {
             const uint64_t h = bps_of(stems, key);
-            int found = -1, last = -1;
-            auto it = seen.find(h);
-            if (it != seen.end())
-                for (int e = it->second; e >= 0; e = chain[e]) {
-                    last = e;
-                    if (fins[e].bps == key) { found = e; break; }
-                }
+            size_t slot = (size_t)(h * 0x9E3779B97F4A7C15ull >> 11) & (tsize - 1);
+            int found = -1;
+            for (;; slot = (slot + 1) & (tsize - 1)) {
+                const int e = table[slot] - 1;
+                if (e < 0) break;
+                if (hashes[e] == h && fins[e].bp_n == key.size() &&
+                    std::equal(key.begin(), key.end(), flat.data() + fins[e].bp_off)) { found = e; break; }
+            }
             if (found < 0) {
                 Entry e;
-                e.stems = stems; e.bps = key; e.mask = 1ull << k;
+                e.stems = &stems; e.bp_off = (uint32_t)flat.size(); e.bp_n = (uint32_t)key.size(); e.mask = 1ull << k;
+                flat.insert(flat.end(), key.begin(), key.end());
                 score_struct(codes, reacts, n, stems, e.scores);
-                if (last < 0) seen.emplace(h, (int)fins.size());
-                else chain[last] = (int)fins.size();
-                chain.push_back(-1);
-                fins.push_back(std::move(e));
+                table[slot] = (int)fins.size() + 1;
+                hashes.push_back(h);
+                fins.push_back(e);
             } else {
                 fins[found].mask |= 1ull << k;
             }
@@ -265,20 +300,20 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
         std::stable_partition(fins.begin(), fins.end(), [&](const Entry &e) { return (e.mask & o.priority_mask) != 0; });  // :912-913
     if (o.rankbydiff && fins.size() >= 3) {                            // :917-955
         BPV allbps, seenbps;
-        for (const Entry &e : fins) allbps = merged(allbps, e.bps);
-        seenbps = fins[0].bps;
+        for (const Entry &e : fins) allbps = merged(allbps, bps_of_entry(e));
+        { const Span f0 = bps_of_entry(fins[0]); seenbps.assign(f0.begin(), f0.end()); }
         size_t cur = 1;
         while (seenbps != allbps && cur < fins.size() - 1) {
             std::vector<std::pair<size_t, size_t>> novel;              // (#new bps, original position)
-            std::vector<Entry> tailv(std::make_move_iterator(fins.begin() + cur), std::make_move_iterator(fins.end()));
+            std::vector<Entry> tailv(fins.begin() + cur, fins.end());
             std::vector<size_t> nov(tailv.size()), idx(tailv.size());
-            for (size_t t = 0; t < tailv.size(); t++) { nov[t] = tailv[t].bps.size() - count_common(tailv[t].bps, seenbps); idx[t] = t; }
+            for (size_t t = 0; t < tailv.size(); t++) { nov[t] = tailv[t].bp_n - count_common(bps_of_entry(tailv[t]), seenbps); idx[t] = t; }
             std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) {
                 if (nov[x] != nov[y]) return nov[x] > nov[y];
                 return keyless(tailv[x], tailv[y]);
             });
-            for (size_t t = 0; t < tailv.size(); t++) fins[cur + t] = std::move(tailv[idx[t]]);
-            seenbps = merged(seenbps, fins[cur].bps);
+            for (size_t t = 0; t < tailv.size(); t++) fins[cur + t] = tailv[idx[t]];
+            seenbps = merged(seenbps, bps_of_entry(fins[cur]));
             cur++;
         }
         std::stable_sort(fins.begin() + cur, fins.end(), keyless);
@@ -301,8 +336,8 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
     for (const Entry &e : fins) {                                      // :1232-1234
         res.preds.emplace_back();
         SeqResult::Pred &p = res.preds.back();
-        if (forced.empty()) levels_of_stems(e.stems, n, p.levels);
-        else levels_of(merged(e.bps, forced), n, -1, p.levels);
+        if (forced.empty()) levels_of_stems(*e.stems, n, p.levels);
+        else levels_of(merged(bps_of_entry(e), forced), n, -1, p.levels);
         for (int t = 0; t < 3; t++) p.scores[t] = e.scores[t];
         p.pset_mask = e.mask;
     }
@@ -313,10 +348,11 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
     BPV cons;                                                          // :845-858,1236
     const size_t top = std::min<size_t>(fins.size(), (size_t)std::max(o.conslim, 0));
     if (top) {
-        cons = fins[0].bps;
+        { const Span f0 = bps_of_entry(fins[0]); cons.assign(f0.begin(), f0.end()); }
         for (size_t k = 1; k < top; k++) {
             BPV nx;
-            std::set_intersection(cons.begin(), cons.end(), fins[k].bps.begin(), fins[k].bps.end(), std::back_inserter(nx));
+            const Span fk = bps_of_entry(fins[k]);
+            std::set_intersection(cons.begin(), cons.end(), fk.begin(), fk.end(), std::back_inserter(nx));
             cons.swap(nx);
         }
     }
@@ -343,8 +379,8 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
         for (int t = 0; t < 7; t++) res.best_metrics[t] = NAN;
         for (size_t rank = 0; rank < fins.size(); rank++) {
             double m[6];
-            if (forced.empty()) prf(fins[rank].bps, known, m);
-            else prf(merged(fins[rank].bps, forced), known, m);
+            if (forced.empty()) prf(bps_of_entry(fins[rank]), known, m);
+            else prf(merged(bps_of_entry(fins[rank]), forced), known, m);
             if (m[3] > best) {
                 best = m[3];
                 for (int t = 0; t < 6; t++) res.best_metrics[t] = m[t];

@@ -15,15 +15,22 @@ same = "--same-stream" in sys.argv
 recs = load_srtest150()
 names, psets = ParseConfig(builtin_config(os.environ.get("PROBE_CONFIG", "nobpp")))
 prepared = [Prepared(seq, reacts, restr, ref) for _, seq, reacts, restr, ref in recs]
+prepared = prepared * int(os.environ.get("PROBE_REPLICAS", "1"))      # the set several times over in ONE batch
 batches, streams = [], []
 for k in range(K):
     st = torch.cuda.current_stream() if same else torch.cuda.Stream()
     streams.append(st)
     with torch.cuda.stream(st):
-        batches.append(Batch(prepared, [psets] * len(prepared), fp32=False))
+        batches.append(Batch(prepared, [psets] * len(prepared), fp32=False, max_structs=int(os.environ.get("PROBE_MAX_STRUCTS", "4096"))))
 torch.cuda.synchronize()
 walls = []
+cpu0 = None
 for r in range(reps + 2):
+    if r == 2:
+        cpu0 = (time.process_time(), time.perf_counter())
+        if os.environ.get("SAMPLER_MANUAL"):            # tools/prof/libsampler.so preloaded: sample the steady state only
+            import ctypes
+            ctypes.CDLL(os.environ["LD_PRELOAD"].split(":")[0]).sampler_start()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     if K == 1:
         batches[0].fold(poollim=1000)
@@ -35,5 +42,7 @@ walls = walls[2:]
 best, med = min(walls), sorted(walls)[len(walls) // 2]
 print("K=%d: step ms min %.2f median %.2f -> %.0f seq/s (median)  all: %s" % (
     K, best, med, K * len(prepared) / med * 1e3, " ".join("%.1f" % w for w in walls)), flush=True)
+cpu = time.process_time() - cpu0[0]; wall = time.perf_counter() - cpu0[1]
+print("      CPU: %.1f ms of process CPU time per step = %.1f busy CPUs on average" % (cpu / reps * 1e3, cpu / wall), flush=True)
 for b in batches:
     b.close()
