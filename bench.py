@@ -259,7 +259,7 @@ def roofline_leg(nseq, n, pmc, pmc_note, seed=1000):
     return scan, score
 
 
-def fill_leg(nseq=256, n=1000):
+def fill_leg(nseq=256, n=1000, pmc=None):
     """The API op sq_bpmatrix_fill (a-1 as north_star words it: coalesced HBM writes of the N x N fp32 score matrix) on
     `nseq` S1000 sequences: 4 N^2 bytes written per job (+ the N^2/8 bit matrix), HIP events around the launches."""
     import torch
@@ -279,16 +279,21 @@ def fill_leg(nseq=256, n=1000):
         b.profile(False)
     per_ms = ms / 5
     gbs = by / 5 / (per_ms * 1e-3) / 1e9 if per_ms > 0 else 0.0
-    return dict(kernel="sq_fill_kernel", leg="sq_bpmatrix_fill on %d S1000 sequences" % nseq, bound="hbm (write)",
+    km = (pmc or {}).get("sq_fill_kernel") or {}
+    traffic = (km.get("fetch_bytes_per_launch", 0) + km.get("write_bytes_per_launch", 0)) if km else None
+    return dict(kernel="sq_fill_kernel", leg="sq_bpmatrix_fill on %d S1000 sequences" % nseq, bound="hbm",
                 unit="GB/s", peak=HBM_PEAK_GBS, achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
-                traffic=round(by / 5), ms_per_fill=round(per_ms, 4),
-                how="achieved = 4 N^2 bytes per job (the fp32 matrix, written once; algorithmic = actual for a write-only kernel) / "
-                    "time of the fill's launches (HIP events, mean of 5); the fold path does not use this op (it writes "
-                    "N^2/8 bytes of bit matrix instead)")
+                traffic=traffic, algorithmic_bytes=round(by / 5), ms_per_fill=round(per_ms, 4), pmc=km.get("source"),
+                how="achieved = 4 N^2 bytes per job (the fp32 matrix, written once) / time of the fill's launches (HIP events, "
+                    "mean of 5); traffic = FETCH_SIZE x 2 + WRITE_SIZE of the same launch (profiles/traffic.json); the fold "
+                    "path does not use this op (it writes N^2/8 bytes of bit matrix instead)")
 
 
 # ---------------------------------------------------------------- strong scaling: a synthetic workload sharded over the ranks
-def sharded_leg(workload, steps, warmup, rank, world, device, sub_batches=4):
+SUB_BATCHES = {"S300": 4, "S1000": 2, "S2000": 4}     # concurrent batches per rank that measured best at world size 1
+
+
+def sharded_leg(workload, steps, warmup, rank, world, device, sub_batches=0):
     """The SURVEY 8d workload sharded with lpt_partition (cost N^2), every rank folds its shard (inputs resident), then
     ONE RCCL all_gather of the packed results (sq_result_pack_all) to every rank; rank 0 holds all records.  Returns
     the rank-0 dict (None elsewhere)."""
@@ -306,6 +311,8 @@ def sharded_leg(workload, steps, warmup, rank, world, device, sub_batches=4):
     # the rank's shard as `sub_batches` batches folded concurrently (sq_fold_concurrent): the host bookkeeping of one
     # overlaps the kernels of the others; contiguous slices, so the concatenated packs keep the shard's order
     from squarna_amd.engine import fold_concurrently
+    if sub_batches <= 0:
+        sub_batches = SUB_BATCHES.get(workload, 4)
     nb = max(1, min(sub_batches, len(prepared) // 64 or 1))
     cuts = [len(prepared) * q // nb for q in range(nb + 1)]
     batches = []
@@ -350,6 +357,8 @@ def sharded_leg(workload, steps, warmup, rank, world, device, sub_batches=4):
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(3):                                        # set-up, not warm-up: page-in of the workspaces and pinned
+        step()                                                # buffers, worker pools, allocator arenas
     for _ in range(warmup):
         step()
     fence()
@@ -390,9 +399,9 @@ def sharded_leg(workload, steps, warmup, rank, world, device, sub_batches=4):
         b.close()
     if rank != 0:
         return None
-    return dict(workload="%s: %d seqs, c=fastest pl=1, sharded by lpt_partition (N^2) over %d rank(s); step = fold of the "
-                         "resident shard (as %d concurrent batches) + sq_result_pack_all + one all_gather of the packed results "
-                         "(RCCL)" % (workload, len(items), world, nb),
+    return dict(workload="%s: %d seqs, c=fastest pl=1 (greedy rounds chained on the device), sharded by lpt_partition (N^2) over "
+                         "%d rank(s); step = fold of the resident shard (as %d concurrent batches) + sq_result_pack_all + one "
+                         "all_gather of the packed results (RCCL)" % (workload, len(items), world, nb),
                 seq_per_s=round(len(items) * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
                 records_rank0=len(mine), evals_R_rank0=int(evals),
                 gathered_records_complete=bool(ok), records_checked_against_local_fold=checked)
@@ -408,7 +417,8 @@ def main():
                     help="independent SRtest150 batches in flight per GPU (0 = auto: 8, fewer when the ranks of the node "
                          "share few CPUs -- every batch has a host thread that drives its rounds)")
     ap.add_argument("--workload", default="srtest150", choices=["srtest150", "S300", "S1000", "S2000"])
-    ap.add_argument("--sub-batches", type=int, default=4, help="strong-scaling mode: concurrent batches per rank")
+    ap.add_argument("--sub-batches", type=int, default=0,
+                    help="strong-scaling mode: concurrent batches per rank (0 = the workload's measured best: %s)" % SUB_BATCHES)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true", help="skip the S1000 roofline leg")
     ap.add_argument("--roofline-seqs", type=int, default=1024)    # S1000 = 1,024 sequences
@@ -474,10 +484,12 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    host_cpu = time.process_time() - cpu0                     # CPU time of this rank's process (all its threads)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -542,7 +554,7 @@ def main():
         roof, score_obj = roofline_leg(args.roofline_seqs, 1000, pmc, pmc_note)
         rooflines.append(score_obj)
         try:
-            rooflines.append(fill_leg())
+            rooflines.append(fill_leg(pmc=pmc))
         except Exception as e:                                # (a secondary leg never takes the headline down)
             rooflines.append({"kernel": "sq_fill_kernel", "error": "%s: %s" % (type(e).__name__, e)})
 
@@ -581,6 +593,10 @@ def main():
         "single_batch": {"ms_per_fold": round(lat[len(lat) // 2], 3), "best_ms": round(lat[0], 3),
                          "seq_per_s": round(len(prepared) / lat[len(lat) // 2] * 1e3, 1),
                          "how": "ONE 219-record batch alone (nothing else in flight), median / best of 10 folds"},
+        "host": {"cpu_ms_per_step": round(host_cpu / args.steps * 1e3, 1), "busy_cpus": round(host_cpu / dt, 1),
+                 "cpu_quota": effective_cpus(),
+                 "note": "rank 0's process CPU time inside the timed region; with the quota's worth of CPUs busy the step is "
+                         "bound by the host side of the fold (pool growth, RunAlgo filters, ranking tails), not by the GPU"},
         "kernel_ms_per_fold": kernel_ms,
         "f1": {"mean_FS_consensus": round(fs_c, 4), "mean_FS_best_of_top5": round(fs_b, 4),
                "batches_in_flight_agree": bool(same)},

@@ -286,7 +286,7 @@ int plan(const sq_batch_desc *d, Layout &L)
         const double ml = std::max(1.0, std::ceil(d->psets[d->job_pset[j]].minlen));
         maxcap = std::max<int64_t>(maxcap, (int64_t)(0.117 * nn * nn * std::pow(0.375, ml - 1.0) * 1.6 + 256));
     }
-    L.cand_records = std::min<int64_t>((int64_t)L.max_structs * maxcap, (int64_t)64 << 20);
+    L.cand_records = std::min<int64_t>((int64_t)L.max_structs * maxcap, (int64_t)160 << 20);   // (5 GiB of 32-byte records at most)
     L.cand_records = std::max<int64_t>(L.cand_records, maxcap);
     // the dense fp64 read-back (sq_bpmatrix_read) borrows the candidate arena
     L.cand_records = std::max<int64_t>(L.cand_records, (int64_t)(2 * (int64_t)L.maxn * L.maxn * 8 / sizeof(SqCand)) + 16);

@@ -1,4 +1,2 @@
-python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror|assert" | tail -8
-SQ_CPUACC=1 python tools/concurrent_probe.py 1 6 2>&1 | grep -E "cpu ms|^K=|CPU" | tail -3 | cut -c1-220
-for k in 4 8 12; do python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=|CPU" | cut -c1-100; done
 python tools/shard_probe.py S300 6 2>&1 | tail -3
+SQ_TIMING=1 python tools/s1000_probe.py 10000 300 3 --noprof 2>&1 | grep -E "chained|fold ms|total" | tail -4
