@@ -1,0 +1,597 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X folding core.
+
+metric   : sequences/sec on SRtest150 (219 records, 8-150 nt, if=qf, c=nobpp: all five algorithms), whole job
+           (bit-matrix fill + greedy stem loop + Edmonds / Hungarian / Nussinov + ranking tail), inputs resident in HBM.
+step     : one fold of `--inflight` (default 8) independent 219-record batches per GPU, in flight at the same time
+           (sq_fold_concurrent: one host thread and one set of streams per batch).  One batch alone is a single 6.5 ms
+           latency chain (the blossom kernel of its largest graph, one wave) that leaves the chip > 99 % idle; batches
+           in flight are the steady state of a server that streams input files.  The latency of ONE batch is
+           reported beside it (`single_batch`).  N > 1: weak scaling -- every rank folds its own batches, independent
+           sequences, no data-path collective.
+roofline : `roofline` = the stem-scan kernel (sq_scan6_kernel) on synthetic S1000 (1,024 random-ACGU
+           sequences, N = 1000, c=fastest, pl=1): launch time from HIP events on the library's stream (live), HBM bytes
+           per launch from the rocprofv3 PMC pass recorded in profiles/traffic.json (refused when the kernels' source
+           has changed since).  `rooflines` = one object per kernel that dominates a leg (blossom kernel of the headline
+           step, scoring kernel of S1000), each with the resource that binds it and the measured ceiling.
+cpu_baseline: the CPU oracle (oracle/, a C port of the reference algorithm + the reference's own scipy / networkx
+           calls) on the same workload, one process per host core; S1000 / S2000 on a stated subsample.
+--workload S300|S1000|S2000: strong-scaling mode (SURVEY 8d workloads sharded over the ranks with lpt_partition, one
+           RCCL all_gather of the packed results per step).  With --gpus N > 1 the default run adds a short sharded
+           S300 leg as a secondary field.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 via torch.distributed.run.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+CLOCK_GHZ = 2.4            # shader clock the blossom kernel runs at (measured 2.39-2.41 GHz with s_memtime, profiles/)
+
+
+def load_srtest150():
+    from squarna_amd.inputs import ParseDefaultInput
+    path = os.path.join(ROOT, "squarna_amd", "data", "datasets", "SRtest150.fas")
+    return list(ParseDefaultInput(path, "qf"))
+
+
+def synthetic(workload):
+    """S300 = 10,000 x 300 (seed 300), S1000 = 1,024 x 1000 (seed 1000), S2000 = 1,000 x 2000 (seed 2000)
+    with a reactivity line drawn per position from "_+#" with p = (0.5, 0.3, 0.2); i.i.d. uniform ACGU."""
+    import numpy as np
+    n, count, seed, shape = {"S300": (300, 10000, 300, False), "S1000": (1000, 1024, 1000, False),
+                             "S2000": (2000, 1000, 2000, True)}[workload]
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        seq = "".join(rng.choice(list("ACGU"), n))
+        line = "".join(rng.choice(list("_+#"), n, p=[0.5, 0.3, 0.2])) if shape else None
+        out.append((seq, line))
+    return out
+
+
+def prepare_synthetic(items):
+    from squarna_amd.engine import Prepared
+    from squarna_amd.dbn import ProcessReacts, ReactDict
+    return [Prepared(s, ProcessReacts([ReactDict[c] for c in line], M=1.8, B=-0.6) if line else None) for s, line in items]
+
+
+# ---------------------------------------------------------------- cpu_baseline (the oracle; checker, never the product)
+def _oracle_init(cfg):
+    global _O, _PSETS
+    sys.path.insert(0, ROOT)
+    from oracle import sqrn_oracle as O
+    from squarna_amd.config import ParseConfig, builtin_config
+    _O = O
+    _PSETS = ParseConfig(builtin_config(cfg))[1]
+    O.lib()
+
+
+def _oracle_one(rec):
+    """cpu_baseline worker task: fold one record with the CPU oracle."""
+    name, seq, reacts, restr, ref, poollim = rec
+    t0 = time.perf_counter()
+    _O.SQRNdbnseq(seq, reacts, restr, ref, _PSETS, poollim=poollim)
+    return time.perf_counter() - t0
+
+
+def effective_cpus():
+    """CPUs this process may really use: hardware threads, affinity mask and the cgroup CPU quota (a container with
+    cpu.max = "1600000 100000" shows 256 hardware threads and gets 16 CPUs worth of time)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except Exception:
+            pass
+    return n
+
+
+def cpu_baseline(recs, cfg, target_s=10.0):
+    """Times the oracle on the GPU box's host cores (one process per hardware thread, records handed out dynamically,
+    longest first) for about target_s seconds of wall time; must run BEFORE this process touches the GPU (it spawns
+    workers).  The workers run their numerical libraries single-threaded: 256 processes x a BLAS / OpenMP pool each
+    would measure oversubscription, not the algorithm."""
+    import multiprocessing as mp
+    cores = effective_cpus()
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ[var] = "1"                              # (inherited by the spawned workers; restored below)
+    recs = [r + (1000,) for r in recs]
+    _oracle_init(cfg)
+    t1 = sum(_oracle_one(r) for r in recs[::8])            # one thread alone, on a slice
+    per_pass = t1 * 8
+    tasks = sorted(recs, key=lambda r: -len(r[1])) * 400   # more than any host finishes in target_s: cut off by the clock
+    ctx = mp.get_context("spawn")
+    done, busy = 0, 0.0
+    with ctx.Pool(cores, initializer=_oracle_init, initargs=(cfg,)) as pool:
+        pool.map(_oracle_one, recs[:cores])               # warm the workers (imports, dlopen)
+        t0 = time.perf_counter()
+        for dt_one in pool.imap_unordered(_oracle_one, tasks, chunksize=2):
+            done += 1
+            busy += dt_one
+            wall = time.perf_counter() - t0
+            if wall >= target_s and done >= len(recs):
+                break
+        pool.terminate()
+    out = dict(value=round(done / wall, 1), unit="seq/s", cores=cores, kind="port",
+               per_thread_seq_per_s=round(done / max(busy, 1e-9), 2), one_thread_alone_seq_per_s=round(len(recs) / per_pass, 2),
+               sample="SRtest150 records (longest first, repeated) for %.1f s of wall time: %d folds, c=%s, C oracle "
+                      "(oracle/sqrn_oracle.c + Python tail, scipy / networkx for H / E), one single-threaded process per CPU the "
+                      "job may use (cores = min(hardware threads %d, affinity, cgroup quota)), summed worker time %.1fs" % (
+                          wall, done, cfg, os.cpu_count() or 1, busy))
+    # the synthetic BASELINE sizes on a stated subsample (time a subsample, extrapolate linearly)
+    others = {}
+    import numpy as np
+    from squarna_amd.dbn import ProcessReacts, ReactDict
+    for wl, take in (("S1000", 64), ("S2000", 32)):
+        items = synthetic(wl)[:min(take, cores)]
+        tasks = [("", s, ProcessReacts([ReactDict[c] for c in line], M=1.8, B=-0.6) if line else None, None, None, 1)
+                 for s, line in items]
+        with ctx.Pool(min(cores, len(tasks)), initializer=_oracle_init, initargs=("fastest",)) as pool:
+            pool.map(_oracle_one, tasks[:1])
+            t0 = time.perf_counter()
+            per = list(pool.imap_unordered(_oracle_one, tasks, chunksize=1))
+            wall = time.perf_counter() - t0
+        mean_s = float(np.mean(per))
+        others[wl] = dict(value=round(cores / mean_s, 2), unit="seq/s", cores=cores, kind="port",
+                          seconds_per_sequence_one_core=round(mean_s, 4),
+                          sample="first %d sequences of %s, c=fastest pl=1, one per process (wall %.2fs); value = cores / "
+                                 "mean seconds per sequence (linear extrapolation to all cores busy)" % (len(tasks), wl, wall))
+    out["other_workloads"] = others
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ.pop(var, None)
+    return out
+
+
+def mean_fs(results):
+    fs_c = [r[2][3] for r in results]
+    fs_b = [r[3][3] for r in results]
+    return sum(fs_c) / len(fs_c), sum(fs_b) / len(fs_b)
+
+
+# ---------------------------------------------------------------- PMC summaries (profiles/traffic.json)
+def kernels_hash():
+    h = hashlib.sha256()
+    for f in ("sq_kernels.hip", "sq_match.hip", "sq_blossom.h"):
+        with open(os.path.join(ROOT, "squarna_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    """profiles/traffic.json: per kernel the counters of a rocprofv3 --pmc pass (tools/make_traffic.py), valid only for
+    the kernel sources they were measured on."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return {}, "profiles/traffic.json missing"
+    with open(path) as f:
+        d = json.load(f)
+    if d.get("kernels_sha16") != kernels_hash():
+        return {}, "profiles/traffic.json was measured on other kernel sources (%s != %s): counters withheld" % (
+            d.get("kernels_sha16"), kernels_hash())
+    return d, None
+
+
+# ---------------------------------------------------------------- S1000 roofline leg
+def roofline_leg(nseq, n, pmc, pmc_note, seed=1000):
+    """S1000: nseq random ACGU sequences of length n, c=fastest pl=1: the stem-scan kernel's roofline object (and the
+    scoring kernel's, the leg's dominant kernel), launch times measured with HIP events inside the library."""
+    import torch
+    from squarna_amd.config import ParseConfig, builtin_config
+    from squarna_amd.engine import Batch
+    names, psets = ParseConfig(builtin_config("fastest"))
+    items = synthetic("S1000")[:nseq] if n == 1000 else None
+    prepared = prepare_synthetic(items)
+    with Batch(prepared, [psets] * nseq, max_structs=nseq, fp32=False) as b:
+        b.fold(poollim=1)                      # warm-up (also page-in)
+        b.profile(True)
+        b.profile_reset()
+        torch.cuda.synchronize()
+        b.fold(poollim=1)
+        torch.cuda.synchronize()
+        ms, launches, alg_bytes = b.profile_get(2)
+        fms, flaunches, fbytes = b.profile_get(0)
+        sms, slaunches, _ = b.profile_get(1)
+        cms, claunches, _ = b.profile_get(3)
+        evals = sum(b.evals(k) for k in range(nseq))
+        b.profile(False)
+        walls = []
+        for _ in range(5):                                  # whole-fold wall time, timers off (the fold runs on two lanes)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            b.fold(poollim=1)
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+    wall = min(walls)
+    avg_ms = ms / max(launches, 1)
+    alg_gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    k = pmc.get("sq_scan6_kernel") or {}
+    traffic = (k.get("fetch_bytes_per_launch", 0) + k.get("write_bytes_per_launch", 0)) if k else None
+    achieved = traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms > 0 else None
+    scan = dict(
+        bound="hbm", kernel="sq_scan6_kernel", unit="GB/s", peak=HBM_PEAK_GBS,
+        achieved=round(achieved, 1) if achieved else None,
+        frac=round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+        traffic=traffic,
+        how="achieved = HBM bytes the kernel really moves per launch (rocprofv3 PMC: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, "
+            "%s) / its launch time measured live (HIP events on the library's stream); the kernel reads a 1-bit-per-cell "
+            "diagonal matrix, so it is issue-bound (VALU + SALU), not bandwidth-bound" % (k.get("source", pmc_note or "no PMC file")),
+        avg_launch_ms=round(avg_ms, 4), launches=int(launches),
+        algorithmic=dict(bytes_per_launch=round(alg_bytes / max(launches, 1)), GBs=round(alg_gbs, 1),
+                         reread_avoidance=round(alg_gbs / HBM_PEAK_GBS, 3),
+                         note="SURVEY 8d bytes (2 N^2 per AnnotateStems evaluation: the fp32 upper triangle the reference "
+                              "re-scans) / launch time / 8 TB/s; > 1 means re-reads avoided, it is NOT a fraction of peak"),
+        workload="S1000: %d random-ACGU seqs N=%d seed %d c=fastest pl=1" % (nseq, n, seed), evals_R=int(evals),
+        whole_fold=dict(ms=round(wall * 1e3, 2), seq_per_s=round(nseq / wall, 1),
+                        alg_GBs=round(alg_bytes / wall / 1e9, 1), frac_of_hbm_peak=round(alg_bytes / wall / 1e9 / HBM_PEAK_GBS, 3),
+                        how="one sq_fold call, best of 5, profiling off; SURVEY 8d's bytes(N, R) = R 2N^2 over WALL time (the 4 N^2 "
+                            "fp32 fill bytes are not counted: the fold writes N^2/8 bytes of bit matrix instead)"),
+        kernel_ms=dict(bits=round(fms, 3), state=round(sms, 3), scan=round(ms, 3), score_select=round(cms, 3)))
+    ks = pmc.get("sq_score_kernel") or {}
+    score = dict(kernel="sq_score_kernel", leg="S1000", bound="latency (dependent LDS / L2 loads of the per-candidate strand sweep)",
+                 share_of_leg_kernel_time=round(cms / max(fms + sms + ms + cms, 1e-9), 3),
+                 avg_launch_ms=round(cms / max(claunches, 1), 4), launches=int(claunches))
+    if ks:
+        tb = ks.get("fetch_bytes_per_launch", 0) + ks.get("write_bytes_per_launch", 0)
+        score.update(hbm=dict(traffic=tb, achieved_GBs=round(tb / (cms / max(claunches, 1) * 1e-3) / 1e9, 1),
+                              frac=round(tb / (cms / max(claunches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
+                     wave_cycles_waiting=ks.get("wait_share"), lds_bank_conflict_share=ks.get("lds_conflict_share"),
+                     pmc=ks.get("source"))
+    return scan, score
+
+
+def fill_leg(nseq=256, n=1000):
+    """The API op sq_bpmatrix_fill (a-1 as north_star words it: coalesced HBM writes of the N x N fp32 score matrix) on
+    `nseq` S1000 sequences: 4 N^2 bytes written per job (+ the N^2/8 bit matrix), HIP events around the launches."""
+    import torch
+    from squarna_amd.config import ParseConfig, builtin_config
+    from squarna_amd.engine import Batch
+    names, psets = ParseConfig(builtin_config("fastest"))
+    prepared = prepare_synthetic(synthetic("S1000")[:nseq])
+    with Batch(prepared, [psets] * nseq, fp32=True) as b:
+        b.fill()
+        torch.cuda.synchronize()
+        b.profile(True)
+        b.profile_reset()
+        for _ in range(5):
+            b.fill()
+        torch.cuda.synchronize()
+        ms, launches, by = b.profile_get(0)
+        b.profile(False)
+    per_ms = ms / 5
+    gbs = by / 5 / (per_ms * 1e-3) / 1e9 if per_ms > 0 else 0.0
+    return dict(kernel="sq_fill_kernel", leg="sq_bpmatrix_fill on %d S1000 sequences" % nseq, bound="hbm (write)",
+                unit="GB/s", peak=HBM_PEAK_GBS, achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
+                traffic=round(by / 5), ms_per_fill=round(per_ms, 4),
+                how="achieved = 4 N^2 bytes per job (the fp32 matrix, written once; algorithmic = actual for a write-only kernel) / "
+                    "time of the fill's launches (HIP events, mean of 5); the fold path does not use this op (it writes "
+                    "N^2/8 bytes of bit matrix instead)")
+
+
+# ---------------------------------------------------------------- strong scaling: a synthetic workload sharded over the ranks
+def sharded_leg(workload, steps, warmup, rank, world, device, sub_batches=4):
+    """The SURVEY 8d workload sharded with lpt_partition (cost N^2), every rank folds its shard (inputs resident), then
+    ONE RCCL all_gather of the packed results (sq_result_pack_all) to every rank; rank 0 holds all records.  Returns
+    the rank-0 dict (None elsewhere)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from squarna_amd.config import ParseConfig, builtin_config
+    from squarna_amd.engine import Batch
+    from squarna_amd.parallel import lpt_partition
+    names, psets = ParseConfig(builtin_config("fastest"))
+    items = synthetic(workload)
+    parts = lpt_partition([float(len(s)) ** 2 for s, _ in items], world)
+    mine = parts[rank]
+    prepared = prepare_synthetic([items[k] for k in mine])
+    # the rank's shard as `sub_batches` batches folded concurrently (sq_fold_concurrent): the host bookkeeping of one
+    # overlaps the kernels of the others; contiguous slices, so the concatenated packs keep the shard's order
+    from squarna_amd.engine import fold_concurrently
+    nb = max(1, min(sub_batches, len(prepared) // 64 or 1))
+    cuts = [len(prepared) * q // nb for q in range(nb + 1)]
+    batches = []
+    for q in range(nb):
+        with torch.cuda.stream(torch.cuda.Stream(device)):
+            batches.append(Batch(prepared[cuts[q]:cuts[q + 1]], [psets] * (cuts[q + 1] - cuts[q]),
+                                 max_structs=max(cuts[q + 1] - cuts[q], 1), fp32=False))
+    torch.cuda.synchronize()
+
+    def pack_shard():
+        bufs, offs, base = [], [np.zeros(1, np.int64)], 0
+        for b in batches:
+            buf, off = b.pack_all()
+            bufs.append(buf)
+            offs.append(off[1:] + base)
+            base += int(off[-1])
+        return np.concatenate(bufs), np.concatenate(offs)
+
+    def step():
+        if nb == 1:
+            batches[0].fold(poollim=1)
+        else:
+            fold_concurrently(batches, poollim=1)
+        buf, off = pack_shard()
+        if world == 1:
+            return [(buf, off)]
+        head = np.concatenate([np.array([len(mine)], np.int64), np.array(mine, np.int64), off]).view(np.uint8)
+        body = np.concatenate([head, buf])
+        size = torch.tensor([body.size], dtype=torch.int64, device=device)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(sizes, size)
+        cap = int(max(int(s.item()) for s in sizes))
+        send = torch.zeros(cap, dtype=torch.uint8, device=device)
+        send[:body.size] = torch.from_numpy(body).to(device)
+        got = [torch.zeros(cap, dtype=torch.uint8, device=device) for _ in range(world)]
+        dist.all_gather(got, send)
+        return (got, sizes)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # verification on rank 0: every record arrived once, and a sample of other ranks' records equals a local fold
+    ok, checked = True, 0
+    if rank == 0 and world > 1:
+        got, sizes = last
+        seen = {}
+        for r in range(world):
+            raw = got[r][:int(sizes[r].item())].cpu().numpy()
+            cnt = int(raw[:8].view(np.int64)[0])
+            idx = raw[8:8 + 8 * cnt].view(np.int64)
+            off = raw[8 + 8 * cnt:8 + 8 * cnt + 8 * (cnt + 1)].view(np.int64)
+            payload = raw[8 + 8 * cnt + 8 * (cnt + 1):]
+            for q in range(cnt):
+                seen[int(idx[q])] = payload[off[q]:off[q + 1]].tobytes()
+        ok = sorted(seen) == list(range(len(items)))
+        sample = [k for k in range(0, len(items), max(1, len(items) // 48)) if k not in set(mine)][:48]
+        if sample:
+            with Batch(prepare_synthetic([items[k] for k in sample]), [psets] * len(sample), fp32=False) as bb:
+                bb.fold(poollim=1)
+                buf, off = bb.pack_all()
+                for q, k in enumerate(sample):
+                    # (the `evals` word and everything else is per record: bytes must be identical)
+                    ok = ok and seen[k] == buf[off[q]:off[q + 1]].tobytes()
+                    checked += 1
+    evals = sum(b.evals(k) for b in batches for k in range(b.nseq))
+    for b in batches:
+        b.close()
+    if rank != 0:
+        return None
+    return dict(workload="%s: %d seqs, c=fastest pl=1, sharded by lpt_partition (N^2) over %d rank(s); step = fold of the "
+                         "resident shard (as %d concurrent batches) + sq_result_pack_all + one all_gather of the packed results "
+                         "(RCCL)" % (workload, len(items), world, nb),
+                seq_per_s=round(len(items) * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+                records_rank0=len(mine), evals_R_rank0=int(evals),
+                gathered_records_complete=bool(ok), records_checked_against_local_fold=checked)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="nobpp")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="independent SRtest150 batches in flight per GPU (0 = auto: 8, fewer when the ranks of the node "
+                         "share few CPUs -- every batch has a host thread that drives its rounds)")
+    ap.add_argument("--workload", default="srtest150", choices=["srtest150", "S300", "S1000", "S2000"])
+    ap.add_argument("--sub-batches", type=int, default=4, help="strong-scaling mode: concurrent batches per rank")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the S1000 roofline leg")
+    ap.add_argument("--roofline-seqs", type=int, default=1024)    # S1000 = 1,024 sequences
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # (squarna_amd sets the same default at import; see its __init__)
+
+    recs = load_srtest150()
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu and args.workload == "srtest150":
+        cpu = cpu_baseline(recs, args.config)       # before any GPU initialisation
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    if args.workload != "srtest150":                          # strong-scaling mode
+        res = sharded_leg(args.workload, args.steps, args.warmup, rank, world, device, args.sub_batches)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({
+                "metric": "sequences/sec (%s synthetic, single-sequence mode, sharded)" % args.workload,
+                "value": res["seq_per_s"], "unit": "seq/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic i.i.d. uniform ACGU (SURVEY 8d seeds)",
+                "config": {"workload": res["workload"]}, "sharded": res}))
+        return
+
+    from squarna_amd.config import ParseConfig, builtin_config
+    from squarna_amd.engine import Batch, Prepared, fold_concurrently
+    names, psets = ParseConfig(builtin_config(args.config))
+    prepared = [Prepared(seq, reacts, restr, ref) for _, seq, reacts, restr, ref in recs]
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    K = args.inflight if args.inflight > 0 else min(8, max(1, effective_cpus() // (2 * max(1, local_world))))
+    batches = []
+    for _ in range(K):                                        # inputs resident in HBM; one stream per batch
+        with torch.cuda.stream(torch.cuda.Stream(device)):
+            batches.append(Batch(prepared, [psets] * len(prepared), fp32=False))
+    torch.cuda.synchronize()
+
+    def step():
+        if K == 1:
+            batches[0].fold(poollim=1000)
+        else:
+            fold_concurrently(batches, poollim=1000)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- secondary, OUTSIDE the timed region ----------------------------------------------------------------------
+    b0 = batches[0]
+    lat = []
+    for _ in range(10):                                       # one batch alone: the latency of a single fold
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        b0.fold(poollim=1000)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    lat.sort()
+    # per-kernel time of one fold (HIP events on the streams the kernels run on): 3 extra folds of one batch; the
+    # matching kernels run on side streams, concurrently with the greedy rounds
+    b0.profile(True)
+    b0.profile_reset()
+    for _ in range(3):
+        b0.fold(poollim=1000)
+    torch.cuda.synchronize()
+    kernel_ms = {nm: round(b0.profile_get(k)[0] / 3, 3) for k, nm in enumerate(
+        ["bits", "state", "scan", "score_select", "edmonds", "hungarian", "nussinov"])}
+    mwm = b0.mwm_counters()
+    b0.profile(False)
+
+    results = [b0.result(k) for k in range(len(prepared))]
+    fs_c, fs_b = mean_fs(results)
+    evals = sum(b0.evals(k) for k in range(len(prepared)))
+    same = all(repr(b.result(k)) == repr(results[k]) for b in batches[1:] for k in range(0, len(prepared), 7))
+    for b in batches:
+        b.close()
+
+    pmc, pmc_note = load_pmc()
+    rooflines = []
+    if mwm["max_passes"]:
+        e_ms = kernel_ms["edmonds"]
+        passes = mwm["max_passes"]                            # (per graph: the same in each of the 3 profiled folds)
+        km = pmc.get("sq_mwm_kernel") or {}
+        obj = dict(kernel="sq_mwm_kernel", leg="SRtest150 (the headline step)",
+                   bound="latency: one wave per graph walks a chain of dependent LDS reads (no bandwidth or FLOP roof applies)",
+                   share_of_fold_kernel_time=round(e_ms / max(sum(kernel_ms.values()), 1e-9), 3),
+                   avg_launch_ms=e_ms,
+                   critical_graph=dict(vertices=mwm["n"], edges=mwm["m"], scan_passes=passes, events=mwm["max_events"]),
+                   cycles_per_scan_pass=round(e_ms * 1e-3 * CLOCK_GHZ * 1e9 / max(passes, 1)),
+                   cycles_how="whole kernel time (its slowest wave = the critical graph) x %.1f GHz / that graph's scan passes; "
+                              "includes its lane-0 events, dual updates and stage set-up (~25 %% of the time)" % CLOCK_GHZ,
+                   floor_cycles_per_scan_pass=1100,
+                   floor_how="5 dependent LDS round trips per pass (queue -> adjacency bounds -> neighbour -> its blossom -> "
+                             "that blossom's label; ~130 cycles each for a lone wave) + ~100 instructions at the ~4.7 "
+                             "cycles / instruction one wave alone issues at (PMC: SQ_ACTIVE_INST_ANY / instructions)")
+        if km:
+            tb = km.get("fetch_bytes_per_launch", 0) + km.get("write_bytes_per_launch", 0)
+            obj.update(hbm=dict(traffic=tb, achieved_GBs=round(tb / (e_ms * 1e-3) / 1e9, 3),
+                                frac=round(tb / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)),
+                       wave_cycles_waiting=km.get("wait_share"), pmc=km.get("source"))
+        rooflines.append(obj)
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        roof, score_obj = roofline_leg(args.roofline_seqs, 1000, pmc, pmc_note)
+        rooflines.append(score_obj)
+        try:
+            rooflines.append(fill_leg())
+        except Exception as e:                                # (a secondary leg never takes the headline down)
+            rooflines.append({"kernel": "sq_fill_kernel", "error": "%s: %s" % (type(e).__name__, e)})
+
+    sharded = None
+    if world > 1:
+        try:
+            sharded = sharded_leg("S300", 5, 2, rank, world, device)
+        except Exception as e:                                # (never let the secondary leg take the headline down)
+            sharded = {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
+    if rank != 0:
+        return
+    per_step = len(prepared) * K
+    line = {
+        "metric": "sequences/sec (SRtest150, single-sequence mode)",
+        "value": round(per_step * world * args.steps / dt, 1),
+        "unit": "seq/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "dtype_note": "scores and every decision in fp64, in the reference's operation order; the scan itself works on 1-bit cell activity",
+        "data": "SRtest150.fas shipped with the reference (219 records, 8-150 nt, reference dbn per record)",
+        "config": {"workload": "SRtest150 if=qf c=%s poollim=1000; %d independent 219-record batches in flight per GPU "
+                               "(sq_fold_concurrent, one stream set each); a step folds all of them" % (args.config, K),
+                   "batches_in_flight": K, "host_cpus": effective_cpus(), "seqs_per_gpu_per_step": per_step, "paramsets": names,
+                   "evals_R_per_step": int(evals) * K, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
+        "single_batch": {"ms_per_fold": round(lat[len(lat) // 2], 3), "best_ms": round(lat[0], 3),
+                         "seq_per_s": round(len(prepared) / lat[len(lat) // 2] * 1e3, 1),
+                         "how": "ONE 219-record batch alone (nothing else in flight), median / best of 10 folds"},
+        "kernel_ms_per_fold": kernel_ms,
+        "f1": {"mean_FS_consensus": round(fs_c, 4), "mean_FS_best_of_top5": round(fs_b, 4),
+               "batches_in_flight_agree": bool(same)},
+        "roofline": roof,
+        "rooflines": rooflines,
+        "pmc_note": pmc_note,
+        "cpu_baseline": cpu,
+        "sharded": sharded,
+    }
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -46,41 +46,42 @@ static void pairs_to_stems(const std::vector<BP> &sp, std::vector<HStem> &out)
 }
 
 // the two filter passes of RunAlgo (:570-595)
-// The pairs of a matching form stems (maximal stacks).  All base pairs of a stem cross the same pairs, so PairsToDBN's
-// level rule (:104-150: crossing counts, order by (count, start), first fit, groups ranked by size) gives every stem
-// one level and can be evaluated per STEM with the stem lengths as weights (sq_stem_levels; DESIGN.md section 5 has the
-// argument) -- a dozen stems instead of a hundred pairs, and the rule is quadratic.  Dropping whole stems (score filter,
-// level limit) never changes how the remaining pairs stack, so the stems stay the stems.
 static void filter_stemset(const sq_batch *b, const SqJob &J, std::vector<BP> pairs, int levellimit,
                            std::vector<HStem> &stemset, const double *dense = nullptr)
 {
     const sq_paramset &ps = b->psets[J.pset];
     for (BP &p : pairs) if (p.first > p.second) std::swap(p.first, p.second);
     std::sort(pairs.begin(), pairs.end());
-    static thread_local std::vector<HStem> stems, kept, lim;
-    static thread_local std::vector<int> lv;
+    std::vector<HStem> stems;
     pairs_to_stems(pairs, stems);
     auto score_of = [&](const HStem &st) {
         double s = 0;                                                    // sum(...) from int 0, left to right
         for (int k = 0; k < st.len; k++) s = s + cell_score_host(b, J, st.i + k, st.j - k, dense);
         return s;
     };
-    kept.clear();
-    for (HStem &st : stems) {
-        st.bps = score_of(st);
-        if (st.bps >= ps.minbpscore && (double)st.len >= ps.minlen) kept.push_back(st);
+    std::vector<BP> kept;
+    for (const HStem &st : stems) {
+        const double sc = score_of(st);
+        if (sc >= ps.minbpscore && (double)st.len >= ps.minlen)
+            for (int k = 0; k < st.len; k++) kept.push_back(BP(st.i + k, st.j - k));
     }
     // DBNToPairs(PairsToDBN(pairs, N, levellimit)) : drop pseudoknot levels above the limit (:581)
-    sq_stem_levels(kept, lv);
-    lim.clear();
+    std::sort(kept.begin(), kept.end());
+    kept.erase(std::unique(kept.begin(), kept.end()), kept.end());
+    std::vector<int> lv;
+    sq_pair_levels(kept, lv);
+    std::vector<BP> lim;
     for (size_t k = 0; k < kept.size(); k++)
         if ((levellimit < 0 || lv[k] <= levellimit) && lv[k] <= 49) lim.push_back(kept[k]);   // 49 bracket types exist
-    sq_stem_levels(lim, lv);                                             // :582 levels of what is left
+    sq_pair_levels(lim, lv);                                             // :582 levels of what is left
+    pairs_to_stems(lim, stems);
     stemset.clear();
-    for (size_t k = 0; k < lim.size(); k++) {
-        const HStem &st = lim[k];
-        if (lv[k] > 1 && st.len < 4) continue;                           // :589 short pseudoknotted stems
-        const double sc = st.bps;                                        // (the same sum as in the first pass)
+    size_t pos = 0;
+    for (const HStem &st : stems) {
+        const int level = lv[pos];                                       // level of the stem's first bp
+        pos += (size_t)st.len;
+        if (level > 1 && st.len < 4) continue;                           // :589 short pseudoknotted stems
+        const double sc = score_of(st);
         if (sc >= ps.minbpscore && (double)st.len >= ps.minlen) stemset.push_back(HStem{st.i, st.j, st.len, sc, sc});
     }
 }
@@ -97,7 +98,6 @@ struct SqAlgoChunk {
     size_t outints = 0, scratch = 0, bytes = 0;  // device bytes used from the region's base
     int32_t *d_out = nullptr, *d_cnt = nullptr;  // results: in the pinned staging buffer, written by the kernels in place
     uint32_t *flag = nullptr; uint32_t flag_val = 0;   // pinned completion word published by sq_flag_kernel
-    int32_t *bin_head = nullptr;                 // pinned, Edmonds only: first job (row of the sorted table) of every block
     uint32_t *job_flags = nullptr;               // pinned, Edmonds only: per job "mates are in host memory" (== flag_val),
                                                  // indexed by the job's position in the SORTED table (sorted_pos)
     hipStream_t st = nullptr;
@@ -225,18 +225,15 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     const size_t jbytes = (mj.size() * sizeof(SqMatchJob) + 255) & ~(size_t)255;
     const size_t ebytes = (nedges * sizeof(SqMatchEdge) + 255) & ~(size_t)255;
     const size_t obytes = (outints * 4 + 255) & ~(size_t)255, cbytes = (mj.size() * 4 + 255) & ~(size_t)255;
-    const size_t fbytes = algo == SQ_ALGO_E ? ((mj.size() * 4 + 255) & ~(size_t)255) : 0;   // job flags; the bin heads take as much again
-    char *pin = stage_buffer(b, slot, jbytes + ebytes + obytes + cbytes + 256 + 2 * fbytes);
+    const size_t fbytes = algo == SQ_ALGO_E ? ((mj.size() * 4 + 255) & ~(size_t)255) : 0;
+    char *pin = stage_buffer(b, slot, jbytes + ebytes + obytes + cbytes + 256 + fbytes);
     if (!pin) return 2;
     ck.p_jobs = (SqMatchJob *)pin; ck.p_edges = (SqMatchEdge *)(pin + jbytes);
     ck.d_out = (int32_t *)(pin + jbytes + ebytes); ck.d_cnt = (int32_t *)(pin + jbytes + ebytes + obytes);
     ck.flag = (uint32_t *)(pin + jbytes + ebytes + obytes + cbytes);
     ck.flag_val = ++b->algo_seq;
     *ck.flag = 0;
-    if (fbytes) {
-        ck.job_flags = (uint32_t *)(pin + jbytes + ebytes + obytes + cbytes + 256); memset(ck.job_flags, 0, mj.size() * 4);
-        ck.bin_head = (int32_t *)(pin + jbytes + ebytes + obytes + cbytes + 256 + fbytes);
-    }
+    if (fbytes) { ck.job_flags = (uint32_t *)(pin + jbytes + ebytes + obytes + cbytes + 256); memset(ck.job_flags, 0, mj.size() * 4); }
     if (algo == SQ_ALGO_E || algo == SQ_ALGO_H) {
         // LDS size classes (see SqAlgoChunk::Class): jobs sorted by the dynamic LDS they need, largest first
         const size_t nq = mj.size();
@@ -255,9 +252,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
         // their slowest job, so more of them lengthen the chain on the short kernels' stream past the end of Edmonds'
         // class 0 (traced: 4 + 4 classes end at 9.3 ms, one batch alone, instead of 7.2 ms)
         static const int env_classes = getenv("SQ_MWM_CLASSES") ? std::max(1, atoi(getenv("SQ_MWM_CLASSES"))) : 0;
-        // (Edmonds: one launch, the graphs packed into multi-wave blocks by LDS need -- sq_mwm_plan)
-        // and with one batch alone in two size classes of one-graph blocks, the critical class on its own stream)
-        const int max_classes = env_classes ? env_classes : (algo == SQ_ALGO_E && b->inflight < 2 ? 2 : 1);
+        const int max_classes = env_classes ? env_classes : (algo == SQ_ALGO_E ? 2 : 1);
         size_t cur = std::min<size_t>(need[ord[0]], 150 * 1024);
         ck.classes.push_back({0, 0});
         for (size_t r = 0; r < nq; r++) {
@@ -267,13 +262,6 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
                 cur = need[ord[r]];
             } else c.count++;
         }
-        if (getenv("SQ_MWM_DUMP") && algo == SQ_ALGO_E) {
-            fprintf(stderr, "[mwm] %zu graphs, classes:", nq);
-            for (auto &c : ck.classes) fprintf(stderr, " [%d +%d: %zu B]", c.start, c.count, need[ord[c.start]]);
-            fprintf(stderr, "\n[mwm] (n m bytes):");
-            for (size_t r = 0; r < nq; r++) fprintf(stderr, " %d %d %zu;", ck.sorted[r].n, ck.sorted[r].nedges, need[ord[r]]);
-            fprintf(stderr, "\n");
-        }
         memcpy(ck.p_jobs, ck.sorted.data(), nq * sizeof(SqMatchJob));
     } else
         memcpy(ck.p_jobs, mj.data(), mj.size() * sizeof(SqMatchJob));
@@ -281,7 +269,6 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     // pass 2 (pool): the edges, written straight into the pinned buffer
     ck.vid2pos.resize(mj.size());
     sq_pool(b)->parallel_for((int)mj.size(), [&](int q) {
-        CpuScope cpu_(2);
         const SqJob &J = b->jobs[jobs[k0 + q]];
         const std::vector<HStem> &st_ = stems[k0 + q];
         SqMatchEdge *e = ck.p_edges + mj[q].edge_off;
@@ -343,8 +330,7 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
             hipStream_t cs = (cidx > 0 && other) ? other : st;
             const int rl = sq_launch_matching(algo, ck.sorted.data() + c.start, c.count, d_jobs + c.start, d_edges, ck.nedges,
                                               (SqMatchEdge *)(region + o_edges), d_scr, ck.d_out, ck.d_cnt, b->ctx.codes,
-                                              ck.job_flags ? ck.job_flags + c.start : nullptr, ck.flag_val, cs,
-                                              ck.p_jobs + c.start, ck.bin_head ? ck.bin_head + c.start : nullptr, b->inflight);
+                                              ck.job_flags ? ck.job_flags + c.start : nullptr, ck.flag_val, cs);
             if (rl) return sq_check((hipError_t)rl, "matching kernel launch");
         }
         if (other && ck.classes.size() > 1) {
@@ -409,7 +395,6 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
     if (streaming) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return mj[x].nedges < mj[y].nedges; });
     // body of one job: read its result from pinned memory, RunAlgo's filters, optional hook
     auto finish_job = [&](size_t q) {
-        CpuScope cpu_(1);
         const size_t k = ck.k0 + q;
         const SqJob &J = b->jobs[jobs[k]];
         const int levellimit = levellimit_opt >= 0 ? levellimit_opt : 3 - (J.n > 500 ? 1 : 0);   // :1043-1044

@@ -1,0 +1,116 @@
+// sq_device.h -- kernel argument bundles (passed by value) and kernel prototypes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sq_internal.h"
+
+struct SqDevCtx {
+    const SqJob *jobs;
+    const SqPsetDev *psets;
+    const uint8_t *codes;    // per position
+    const uint8_t *flags;
+    const uint8_t *inc4;     // minimal j - i for a pair starting at i (SQRNdbnseq.py:294-297)
+    const int16_t *chain;    // chain ordinal (interchainonly, :264-271)
+    const uint8_t *e0c;      // restraint mask code: 0 free, k+1 = k-th restraint bp (v,w) of the sequence (:438-443)
+    const double *reacts;
+    const uint8_t *ridx;     // per position: index of its reactivity among the sequence's distinct values (SqJob::react_levels)
+    float *mat32;            // fp32 scan-matrix arena
+    double *mat64;           // dense fp64 arena (external / weighted matrices only)
+    const double *sdftab;    // pow tables
+    uint32_t *bits;          // diagonal bit matrices (activity of the unmasked BPMatrix, 1 bit per cell)
+    const uint32_t *rbpk;    // restraint base pairs, v | (w << 16), per sequence (SqJob::rb_off, nrb)
+};
+
+struct SqState {             // per-structure-slot arrays, `stride` elements per slot
+    int16_t *P, *U, *SU;     // partner, prefix #unpaired, prefix #unpaired separators
+    uint8_t *E8;             // scan mask code per position: 0 free, 255 masked, k+1 restraint bp k
+    int32_t stride;
+    uint32_t *FB;            // per slot: free-position bit words, forward [0, fbstride/2) and reversed + padded
+    int32_t fbstride;        // words per slot (even)
+};
+#define SQ_GPAD 128          // bit offset of the reversed free-position array (window starts never go negative)
+
+// Round I/O without copies or stream waits: the round's structures and strands are read by the state
+// kernel straight from pinned host memory (and mirrored into device memory for the later kernels), the
+// selected stems are written straight into pinned host memory, and a one-thread kernel at the end of the
+// round publishes the counters and a sequence number the host spins on.
+#ifndef SQ_SCORE_CHUNK
+#define SQ_SCORE_CHUNK 4          // candidates per thread and chunk of sq_score_kernel's two-phase loop
+#endif
+
+struct SqRoundIO {
+    const SqStruct *h_structs;   // pinned, host-written
+    const SqStrand *h_strands;
+    SqStruct *d_structs;         // device mirrors
+    SqStrand *d_strands;
+    SqOut *h_out;                // pinned: records [0, h_cap)
+    SqOut *d_out;                // device: records [h_cap, out_cap)
+    uint32_t h_cap, out_cap;
+    SqCounters *h_ctr;           // pinned
+    volatile uint32_t *h_seq;    // pinned: id of the last finished round
+};
+
+struct SqScanArgs {
+    SqCand *cands;
+    uint32_t *cand_cnt;      // per slot
+    unsigned long long *best; // per slot: order-preserving image of the round's best finalscore (0: none yet)
+    uint32_t *ok_cnt;        // per slot: candidates that passed the exact thresholds (length of the SqOk list)
+    SqCounters *ctr;
+};
+
+// device-chained rounds: where sq_chain_kernel keeps and reports the structures
+struct SqChainIO {
+    SqChain *chain;               // per structure
+    SqChainStem *stems;           // device: stems of every structure (slice per structure)
+    SqStrand *strands;            // device: two strand buffers per structure
+    int16_t *sidx;                // stem index of every strand (same layout as strands)
+    SqStemOut *h_stems;           // pinned: the chosen stems in selection order (same slices as `stems`)
+    unsigned long long *h_fin;    // pinned: finished structures, job | nstems << 32 | (ended by maxstemnum) << 63
+    uint32_t *d_nfin;             // device: entries of h_fin
+    volatile uint32_t *h_nfin;    // pinned copy, published by sq_chain_done_kernel before the round's sequence number
+};
+
+// order-preserving map double -> uint64 (never 0 for a real number), so a per-structure maximum is one atomicMax
+__device__ __forceinline__ unsigned long long sq_ord(double x)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double sq_unord(unsigned long long o)
+{
+    return __longlong_as_double((long long)((o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFull) : ~o));
+}
+
+// the two regions of a structure's candidate slice (see sq_internal.h)
+__host__ __device__ inline SqKey *sq_keys(const SqScanArgs &a, const SqStruct &st) { return reinterpret_cast<SqKey *>(a.cands + st.cand_off); }
+__host__ __device__ inline SqOk *sq_oks(const SqScanArgs &a, const SqStruct &st, int cand_cap)
+{
+    return reinterpret_cast<SqOk *>(reinterpret_cast<char *>(a.cands + st.cand_off) + (size_t)cand_cap * sizeof(SqKey));
+}
+
+extern "C" {
+__global__ void sq_fill_kernel(SqDevCtx c, int only_ext, int mul_done);
+__global__ void sq_bits_direct_kernel(SqDevCtx c);
+__global__ void sq_bits_masks_kernel(SqDevCtx c, int max_letters);
+__global__ void sq_dense64_kernel(SqDevCtx c, int job, double *boolmat, double *scoremat);
+__global__ void sq_import_kernel(SqDevCtx c);
+__global__ void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n, int chained);
+__global__ void sq_chain_kernel(SqDevCtx c, SqStruct *structs, SqScanArgs a, SqChainIO cio);
+__global__ void sq_chain_init_kernel(const SqStruct *h_structs, const SqChain *h_chain, SqStruct *d_structs, SqChainIO cio,
+                                     SqScanArgs a, int S, int first);
+__global__ void sq_chain_done_kernel(SqRoundIO io, SqScanArgs a, SqChainIO cio, uint32_t seq);
+__global__ void sq_done_kernel(SqRoundIO io, SqScanArgs a, uint32_t seq);
+__global__ void sq_mirror_kernel(double *matrix, int L);
+__global__ void sq_scatter_all_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const int32_t *cols,
+                                      const int32_t *col_start, int L, double *matrix);
+__global__ void sq_scatter_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, int sidx, const int32_t *cols,
+                                  int L, double *matrix);
+__global__ void sq_colselect_kernel(const double *matrix, int L, double thr, int minspan, long long *idx_out,
+                                    double *val_out, long long cap, unsigned long long *count);
+__global__ void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
+__global__ void sq_bits_kernel(SqDevCtx c, int only_ext);
+__global__ void sq_score_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
+                                SqScanArgs a, SqRoundIO io, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off);
+__global__ void sq_bps_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
+                              SqScanArgs a, SqRoundIO io, int mode, int lds_n, int lds_n_reacts, int surv_off);
+__global__ void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqRoundIO io);
+}

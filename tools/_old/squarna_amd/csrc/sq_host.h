@@ -1,0 +1,220 @@
+// sq_host.h -- host-side batch object (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <functional>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
+#include "../../include/squarna_hip.h"
+#include "sq_device.h"
+#include "sq_internal.h"
+
+struct HStem {            // host stem record: bps (i+k, j-k), k < len
+    int32_t i, j, len;
+    double bps, fin;
+};
+
+struct HStruct {          // partial structure of the greedy pool
+    int32_t job = 0;
+    double subopt = 1.0;
+    std::vector<HStem> stems;
+    std::vector<SqStrand> strands;   // both halves of every stem, sorted by start, with levels
+    bool anycross = false;           // some pair of stems crosses (pseudoknot): levels need the full rule
+};
+
+// view of a structure handed to the round driver (no copies per round)
+struct SView {
+    int32_t job;
+    double subopt;
+    const HStruct *st;
+};
+
+// (re)build strands + levels of a structure from its stems
+void sq_build_strands(HStruct &s);
+// child = parent + one stem, strands/levels maintained incrementally
+void sq_extend_struct(const HStruct &parent, const HStem &stem, HStruct &child, bool take_parent = false);
+
+struct SeqResult {        // SQRNdbnseq return tuple of one sequence (SQRNdbnseq.py:1285-1286)
+    struct Pred {
+        std::vector<int16_t> levels;   // signed bracket level per position
+        double scores[3];
+        uint64_t pset_mask;
+    };
+    std::vector<int16_t> cons;
+    std::vector<Pred> preds;
+    double cons_metrics[6], best_metrics[7];
+    double ref_scores[3];              // ScoreStruct of the known structure (ReferenceScores, SQRNdbnseq.py:958-970), when given
+    bool has_ref = false;
+    int64_t evals = 0;
+};
+
+struct ProfSlot {
+    double ms = 0;
+    int64_t launches = 0;
+    double bytes = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+// Small persistent worker pool (per batch): host phases that are independent per sequence / per job
+// (the a-10 tail, the RunAlgo stem filters) are shared among a few threads that stay alive between
+// folds, so their allocator arenas stay warm.  parallel_for hands out indices dynamically; the caller
+// takes part.  Results never depend on the schedule (every index writes its own slot).
+class SqPool {
+public:
+    explicit SqPool(int nthreads, int device = -1);
+    ~SqPool();
+    // callers are serialised (two fold lanes share the pool).  The workers form two groups: the first 15 serve every
+    // call, the rest only wide ones (wide < 0: n >= 512) -- waking 31 threads for a few hundred short items costs
+    // more than it buys.
+    void parallel_for(int n, const std::function<void(int)> &fn, int wide = -1);
+    int size() const { return (int)workers.size() + 1; }
+private:
+    void worker(int group);
+    std::vector<std::thread> workers;
+    int group_size[2] = {0, 0};
+    std::mutex mu, callers;
+    std::condition_variable cv_start[2], cv_done;
+    const std::function<void(int)> *fn = nullptr;
+    std::atomic<int> next{0};
+    int total = 0, active = 0;
+    uint64_t gen[2] = {0, 0};
+    bool stop = false;
+};
+
+// The round buffers one greedy loop works with.  A batch has one lane that spans all of them; sq_fold may split them
+// into two lanes (two host threads, each driving the rounds of half of the jobs), so that the bookkeeping of one
+// lane overlaps the kernels of the other.
+struct SqLane {
+    SqStruct *h_structs = nullptr; SqStrand *h_strands = nullptr; SqOut *h_out = nullptr;   // pinned
+    SqCounters *h_ctr = nullptr; uint32_t *h_seq = nullptr;
+    SqStruct *d_structs = nullptr; SqStrand *d_strands = nullptr; SqOut *d_out = nullptr;   // device
+    SqCounters *d_ctr = nullptr;
+    uint32_t h_out_cap = 0, out_cap = 0;
+    int32_t slot0 = 0, max_structs = 0, strand_cap = 0;
+    int64_t cand0 = 0, cand_records = 0;      // records [cand0, cand0 + cand_records) of the candidate arena
+    uint32_t *round_seq = nullptr;            // id of the last round sent to h_seq (lanes that share the word share the counter)
+    hipStream_t stream = nullptr;             // nullptr: the batch stream
+    std::vector<SqOut> big_out;
+};
+
+struct sq_batch {
+    hipStream_t stream = nullptr;
+    int device = -1;                          // device current at sq_batch_create (adopted by every spawned thread)
+    // host copies
+    int32_t nseq = 0, npset = 0, njobs = 0, maxn = 0;
+    int64_t ltot = 0;
+    std::vector<int32_t> seq_off, rbp_off, rbps, job_seq, job_pset;
+    std::vector<uint8_t> codes, flags;
+    std::vector<double> reacts;
+    std::vector<sq_paramset> psets;
+    std::vector<char> pset_dyadic;            // all pair weights are multiples of 2^-10 below 1024 (exact sums in any order)
+    std::vector<int> pset_classes;            // letter classes of the scoring kernel's cell table: pairing letters + 1
+    std::vector<SqJob> jobs;
+    int32_t interchainonly = 0;
+    int32_t nletters = 0;                     // distinct letter codes of the batch (sq_bits_masks_kernel)
+    int32_t max_structs = 4096;
+    int32_t cand_per_nt = 32;
+    // device carve
+    SqDevCtx ctx{};
+    SqState state{};
+    SqScanArgs scan{};
+    SqStruct *d_structs = nullptr;
+    SqStrand *d_strands = nullptr;
+    SqOut *d_out = nullptr;
+    int64_t cand_records = 0;
+    int64_t cand_reserved = 0;            // records at the END of the arena lent to matching kernels in flight
+    char *stage_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned job tables + edge lists of the matching kernels
+    size_t stage_cap[4] = {0, 0, 0, 0};
+    uint32_t algo_seq = 0;                // completion stamps of the matching launches
+    hipStream_t lane_stream = nullptr;        // second lane of sq_fold's greedy rounds (created on first use)
+    hipEvent_t lane_ev = nullptr;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
+    int inflight = 1;                     // batches folded at the same time (sq_fold_concurrent): sizes the pool, relaxes the wait loops
+    int side_streams = 3;                 // side streams of E / H / N: 3, or 2 (H and N share one) with many batches in flight
+    hipEvent_t class_ev = nullptr;        // joins the blossom kernel's smaller size classes (on side[1]) into side[0]
+    uint32_t out_cap = 0;
+    int32_t strand_cap = 0;
+    size_t mat32_bytes = 0;
+    bool has_fp32 = true;                 // fp32 score matrices are part of the workspace
+    bool filled = false;                  // fp32 matrices (and bit matrices) of every job are valid
+    bool mul_applied = false;             // multiplier matrices already folded into the dense arena
+    bool bits_ready = false;              // bit matrices valid (all the fold path needs)
+    // pinned staging
+    SqStruct *h_structs = nullptr;
+    SqStrand *h_strands = nullptr;
+    SqCounters *h_ctr = nullptr;
+    uint32_t *h_seq = nullptr;            // pinned: id of the last finished round (written by sq_done_kernel)
+    uint32_t round_seq = 0, round_seq2 = 0;
+    SqOut *h_out = nullptr;
+    uint32_t h_out_cap = 0;
+    std::vector<SqOut> big_out;
+    // results
+    std::vector<SeqResult> results;
+    SqPool *pool = nullptr;               // lazily created host workers
+    SqLane lane_full, lane_half[2];       // see SqLane
+    SqCounters *h_ctr2 = nullptr; uint32_t *h_seq2 = nullptr;   // pinned counters / sequence word of the second lane
+    // device-chained rounds (width-1 pools): device arrays carved from the workspace, pinned ones created on first use
+    SqChainIO chain{};
+    SqChain *h_chain = nullptr;           // pinned staging of the per-structure records
+    int64_t chain_T = 0;                  // summed stem capacity of all jobs
+    std::vector<int32_t> chain_toff;      // per job: start of its slice of the chain's stem arrays
+    // profiling
+    std::mutex mwm_mu;
+    int64_t mwm_stats[6] = {0, 0, 0, 0, 0, 0};   // blossom jobs collected, their scan passes; the job with the most passes:
+                                                 // its passes, events, vertices, edges (reset by sq_profile_reset)
+    bool prof_on = false;
+    ProfSlot prof[7];                     // 0 fill, 1 state, 2 scan, 3 score, 4 Edmonds, 5 Hungarian, 6 Nussinov
+};
+
+void sq_set_error(const std::string &msg);
+// pinned (mapped, coherent) host buffers from a small process-wide cache: hipHostMalloc / hipHostFree cost milliseconds,
+// and a caller that builds one batch per call (Predict) would pay them every time
+int sq_pinned_get(void **p, size_t bytes);     // 0 or an error code (message set)
+void sq_pinned_put(void *p);                   // the streams that used the buffer must be idle
+int sq_check(hipError_t e, const char *what);
+int sq_effective_cpus();                       // CPUs this process may really use: hardware threads, affinity, cgroup quota
+bool sq_relaxed_waits(const sq_batch *b);       // spin-then-sleep instead of pure spinning (many batches in flight, few CPUs)
+void sq_wait_step(uint64_t spins, bool relaxed);   // one step of a wait loop on a pinned completion word
+// profiling bracket on an arbitrary stream (slot k of sq_profile_get); no-ops unless profiling is enabled
+void sq_prof_begin(sq_batch *b, int k, hipStream_t st, hipEvent_t *e0);
+void sq_prof_end(sq_batch *b, int k, hipStream_t st, hipEvent_t e0);
+SqPool *sq_pool(sq_batch *b);             // the batch's worker pool (SQ_HOST_THREADS, default min(32, cores))
+
+// bit matrices for the scan (full fp32 fill only for jobs with caller matrices / legacy scans)
+int sq_prepare_scan(sq_batch *b);
+
+// one greedy round (or a raw AnnotateStems pass) for a list of structures; results per structure
+int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out);
+
+// RunAlgo (SQRNdbnseq.py:548-595) for one of SQ_ALGO_E / H / N over a list of jobs
+int sq_run_algo(sq_batch *b, const std::vector<int> &jobs, int algo, int levellimit_opt,
+                std::vector<std::vector<HStem>> &out);
+
+// asynchronous E/H/N for sq_fold: begin() annotates + launches on side streams, end() collects
+struct SqAlgoAsync;
+struct JobSets { int algo; std::vector<int> jobs; std::vector<std::vector<HStem>> sets; bool streamed = false; };
+// optional hooks of sq_algos_end: after_short(sets) once the Hungarian / Nussinov stemsets are final; then
+// on_e_job(job, set) per Edmonds job as soon as that job is final (called from pool workers; JobSets.streamed is set)
+struct SqAlgoEndHooks {
+    std::function<void(std::vector<JobSets> &)> after_short;
+    std::function<void(int, std::vector<HStem> &)> on_e_job;
+};
+int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync *&pa);
+int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<JobSets> &sets,
+                 const SqAlgoEndHooks *hooks = nullptr);
+
+// host tail: SQRNdbnseq.py:1201-1286
+void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
+             const std::vector<const std::vector<std::vector<HStem>> *> &per_job_structs,   // [job-of-seq] -> [structure][stem]
+             const std::vector<int32_t> &job_ids, const int32_t *ref_pairs, int nref, bool has_ref,
+             SeqResult &res);
+
+// pseudoknot levels at pair level (PairsToDBN, SQRNdbnseq.py:104-150); pairs sorted & unique
+int sq_pair_levels(const std::vector<std::pair<int, int>> &pairs, std::vector<int> &level);
+// same at stem level (exactly equivalent for the stems of one structure)
+void sq_stem_levels(const std::vector<HStem> &stems, std::vector<int> &level);

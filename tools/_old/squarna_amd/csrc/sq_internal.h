@@ -1,0 +1,109 @@
+// sq_internal.h -- device-visible records shared by the host driver and the kernels.
+#pragma once
+#include <stdint.h>
+
+#define SQ_SENT_BITS 0x7FC00000u  // quiet NaN in the fp32 scan matrix == "bpboolmatrix cell is 0"
+#define SQ_MAXLEVELS 64           // pseudoknot levels tracked in a 64-bit set
+
+// One (sequence, paramset) fold job.
+struct SqJob {
+    int32_t n;          // gap-free sequence length
+    int32_t ld;         // row pitch (floats) of the scan matrix, ld % 32 == 1
+    int32_t seq;        // sequence index
+    int32_t pset;       // paramset index
+    int64_t pos_off;    // offset of the sequence in the per-position arrays
+    int64_t mat_off;    // offset (floats) of the scan matrix in the fp32 arena
+    int64_t mat64_off;  // offset (doubles) of the dense N x N exact matrix, -1: recompute from O(N) inputs
+    int32_t default_reacts;  // set(reacts) == {0.5}  (SQRNdbnseq.py:273)
+    int32_t interchainonly;
+    int32_t has_ext;    // scan matrix comes from caller matrices (ext_bool/ext_score) or mul_score
+    int32_t cand_cap;   // candidate capacity per structure of this job
+    float maxabs;       // upper bound of |scoremat cell| (fp32 prefilter margin of the scan)
+    int32_t nrb;        // restraint base pairs of the sequence
+    int64_t bits_off;   // offset (words) of the diagonal bit matrix: word (w, s) at bits_off + w * bpitch + s
+    int32_t bpitch;     // words per word-row (>= 2N + 64, multiple of 64)
+    int32_t nw;         // word-rows: ceil(N / 32); bit b of word (w, s) <-> cell (32w + b, s - 32w - b)
+    int32_t rb_off;     // into the packed restraint pair list
+    int32_t ext_add;    // has_ext == 2: the dense term is ADDED to the score (bpp < 0) instead of multiplied
+    int32_t react_levels;  // 1..16: the reactivities take that many distinct values (level index per position in
+                           // SqDevCtx::ridx): reactfactors come from a level x level table; 0: computed per cell
+};
+
+// Device image of a paramset (+ host-built pow tables so every pow() is the host libm's).
+struct SqPsetDev {
+    double w[32 * 32];
+    uint8_t inbps[32 * 32];
+    double minlen, minbpscore, minfinscore;
+    double bracketweight, distcoef, orderpenalty, loopbonus;
+    double oftab[SQ_MAXLEVELS + 1];   // (1/(1+k))**orderpenalty   (SQRNdbnseq.py:729)
+    int32_t bw_integral;              // bracketweight is an integer -> stemdist index into sdftab
+    int32_t sdf_off, sdf_len;         // (1/(1+d))**distcoef table   (SQRNdbnseq.py:726)
+    int32_t pad;
+};
+
+// One strand (half of a selected stem) of a partial structure, sorted by start.
+struct SqStrand {
+    int16_t start;    // first position of the strand
+    int16_t len;
+    int16_t pstart;   // partner of `start`; partner(start+t) = pstart - t
+    uint8_t level;    // pseudoknot level (1-based) of the stem
+    uint8_t left;     // 1: 5' strand (start = i), 0: 3' strand
+};
+
+// One partial structure evaluated in a round.
+struct SqStruct {
+    int32_t job;
+    int32_t strand_off;   // into the round's strand array
+    int32_t nstrand;
+    int32_t slot;         // state / candidate slot
+    double subopt;
+    int64_t cand_off;     // into the candidate arena (records)
+};
+
+// Candidate storage of one structure: a slice of `cand_cap` 32-byte units of the candidate arena, used as
+//   [cand_cap x SqKey]   (key, len) of every candidate the scan emits             (8 bytes each)
+//   [.. x SqOk]          only the candidates that pass the exact thresholds, appended by the scoring kernel
+// so the per-round traffic is 8 bytes per candidate written + read, plus 24 bytes per SURVIVING candidate.
+struct SqCand { uint32_t w[8]; };   // the 32-byte unit of the arena (capacity accounting only)
+struct SqKey {
+    uint32_t key;     // (s << 16) | i_outer, s = i + j: the reference's emission order
+    uint32_t len;
+};
+struct SqOk {
+    uint32_t key, len;
+    double bps;
+    double fin;
+};
+
+// Output record of a round (device -> host).
+struct SqOut {
+    int32_t st;       // structure index in the round
+    uint32_t key;
+    int32_t len;
+    int32_t pad;
+    double bps;
+    double fin;
+};
+
+// Device-chained greedy rounds (width-1 pools, sq_chain_kernel): one record per structure slot.  The stems chosen so
+// far live in a per-slot slice [toff, toff + tcap) of the chain's stem arrays; the strands in two buffers of 2 tcap
+// entries at 4 toff (the kernel writes the next round's list into the other one).
+struct SqChain {
+    int32_t toff, tcap;
+    int32_t nstems;
+    int32_t anycross;     // some pair of the structure's stems crosses: levels follow the full PairsToDBN rule
+    double maxstems;      // paramset maxstemnum: the structure is final when it holds that many stems (:1168-1174)
+};
+struct SqChainStem { int32_t i, j, len, cc; };      // cc: summed length of the stems crossing this one (:121-124)
+struct SqStemOut {                                  // == HStem of the host: one chosen stem, written to pinned memory
+    int32_t i, j, len, pad;
+    double bps, fin;
+};
+
+// Round-level counters.
+struct SqCounters {
+    uint32_t nout;        // records appended to the out list
+    uint32_t cand_ovf;    // some structure exceeded its candidate capacity
+    uint32_t out_ovf;     // out list overflowed
+    uint32_t level_ovf;   // a level above SQ_MAXLEVELS was seen
+};

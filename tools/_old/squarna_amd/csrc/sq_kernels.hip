@@ -1,0 +1,1243 @@
+// sq_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the folding core.
+//
+//   sq_bits_masks_kernel / sq_bits_direct_kernel   a-1  BPMatrix as a diagonal bit matrix (1 bit per cell): all the
+//                         fold path keeps per cell                                          SQRNdbnseq.py:258-304
+//   sq_fill_kernel        a-1  the fp32 score matrix (API op sq_bpmatrix_fill; jobs with caller / multiplier matrices)
+//   sq_dense64_kernel     a-1  exact fp64 (bool, score) for the API shim / external matrices
+//   sq_import_kernel           caller matrices -> fp32 matrix + bits
+//   sq_state_kernel            partner / mask / prefix arrays + free-position bit words of a partial structure (:446-451, :625-635)
+//   sq_scan6_kernel       a-2  AnnotateStems: bit-diagonal scan, one lane per anti-diagonal, 32 rows per step (:427-495)
+//   sq_score_kernel       a-4..a-6 exact fp64 bpscore filter + ScoreStems closed form; sq_select_kernel: ChooseStems range (:607-789)
+//   sq_bps_kernel              the bpscore filter alone (AnnotateStems output, alignment survivor lists)
+//   sq_scatter_* / sq_mirror_kernel / sq_colselect_kernel   alignment step 1 (SQRNdbnali.py:211-242)
+//
+// Layout decisions: DESIGN.md section 3.  The fp32 matrix (row pitch ld == 1 mod 32, quiet-NaN where bool == 0) only
+// serves the API op and caller-supplied matrices; every decision of the fold is taken in fp64 by the scoring kernels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sq_internal.h"
+#include "sq_device.h"
+
+// ------------------------------------------------------------------------------------
+// cell predicates / values (fp64, same operation order as the reference)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sq_cell_bool(const SqDevCtx &c, const SqJob &jb, const SqPsetDev *ps, int i, int j)
+{
+    const uint8_t *codes = c.codes + jb.pos_off;
+    const uint8_t *flags = c.flags + jb.pos_off;
+    if (j < i + (int)c.inc4[jb.pos_off + i]) return false;            // :294-299 (also j <= i)
+    const int a = codes[i], b = codes[j];
+    if (!ps->inbps[a * 32 + b]) return false;                         // :300
+    const int fi = flags[i], fj = flags[j];
+    if ((fi | fj) & 1) return false;                                  // :302 rxs
+    if (fj & 2) return false;                                         // :303 rlefts
+    if (fi & 4) return false;                                         // :304 rrights
+    if (jb.interchainonly && c.chain[jb.pos_off + i] == c.chain[jb.pos_off + j]) return false;   // :301
+    return true;
+}
+
+// value of scoremat[i,j] for a cell whose bool is 1 (:329-338)
+__device__ __forceinline__ double sq_cell_score(const SqDevCtx &c, const SqJob &jb, const SqPsetDev *ps, int i, int j)
+{
+    const uint8_t *codes = c.codes + jb.pos_off;
+    const double w = ps->w[codes[i] * 32 + codes[j]];
+    if (jb.default_reacts) return w;                                  // reactfactor 1 (and 1/1 for w <= 0): w * 1.0
+    const double *r = c.reacts + jb.pos_off;
+    double rf = sqrt((1.0 - (r[i] + r[j]) / 2.0) * 2.0);              // x**0.5 (see DESIGN.md on pow vs sqrt)
+    if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);                   // :335-336
+    return w * rf;
+}
+
+// exact cell value used for every decision (fp64): dense matrix when the job has one
+__device__ __forceinline__ double sq_cell_exact(const SqDevCtx &c, const SqJob &jb, const SqPsetDev *ps, int i, int j)
+{
+    if (jb.mat64_off >= 0) return c.mat64[jb.mat64_off + (int64_t)i * jb.n + j];
+    return sq_cell_score(c, jb, ps, i, j);
+}
+
+// ------------------------------------------------------------------------------------
+// a-1  fill: one thread = 4 consecutive floats of the padded N x ld matrix (16-byte stores)
+// ------------------------------------------------------------------------------------
+// Jobs without a dense fp64 term and with n <= SQ_FILL_LDS_N take the fast path: the per-position inputs (letter code +
+// restraint flags in one byte, minimal span, chain, reactivity) and the pair-weight table are staged in LDS once per
+// block, a thread then walks the flat padded matrix with a grid stride (row / column advanced incrementally: no 64-bit
+// division per store) and a cell costs two LDS byte reads, one table read and a handful of compares before the
+// 16-byte store.  The generic path (every input from global memory, per cell) serves jobs with a bpp term / multiplier
+// matrix and very long sequences.
+#define SQ_FILL_LDS_N 4096
+extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c, int only_ext, int mul_done)
+{
+    const SqJob jb = c.jobs[blockIdx.y];
+    if (jb.has_ext == 1) return;                       // imported from caller matrices instead
+    if (only_ext && jb.has_ext == 0) return;           // the fold path of such jobs only needs the bit matrix
+    const SqPsetDev *ps = c.psets + jb.pset;
+    const int n = jb.n, ld = jb.ld;
+    float *mat = c.mat32 + jb.mat_off;
+    extern __shared__ __attribute__((aligned(16))) char fill_dyn[];
+    if (jb.mat64_off < 0 && n <= SQ_FILL_LDS_N) {
+        __shared__ double s_w[32 * 33];                // pair weights, row stride 33: the letters' rows start on different banks
+        __shared__ float s_wf[32 * 33];                // (float)weight, or the sentinel where the pair is not in bps
+        const int np = (n + 15) & ~15;
+        uint8_t *l_attr = reinterpret_cast<uint8_t *>(fill_dyn);            // code | flags << 5
+        uint8_t *l_inc4 = l_attr + np;
+        int16_t *l_chain = reinterpret_cast<int16_t *>(l_inc4 + np);
+        double *l_react = reinterpret_cast<double *>(l_inc4 + np + 2 * (size_t)np);
+        const int tid = threadIdx.x;
+        const bool ico = jb.interchainonly != 0, defr = jb.default_reacts != 0;
+        for (int p = tid; p < n; p += 256) {
+            l_attr[p] = (uint8_t)((c.codes[jb.pos_off + p] & 31) | ((c.flags[jb.pos_off + p] & 7) << 5));
+            l_inc4[p] = c.inc4[jb.pos_off + p];
+            if (ico) l_chain[p] = c.chain[jb.pos_off + p];
+            if (!defr) l_react[p] = c.reacts[jb.pos_off + p];
+        }
+        for (int e = tid; e < 1024; e += 256) {
+            const double w = ps->w[e];
+            uint32_t fb = SQ_SENT_BITS;
+            if (ps->inbps[e]) { fb = __float_as_uint((float)w); if (fb == SQ_SENT_BITS) fb = 0x7FC00001u; }
+            s_w[(e >> 5) * 33 + (e & 31)] = w;
+            s_wf[(e >> 5) * 33 + (e & 31)] = __uint_as_float(fb);
+        }
+        __syncthreads();
+        const uint32_t total4 = (uint32_t)(((int64_t)n * ld + 3) >> 2), stride4 = gridDim.x * 256u;
+        uint32_t q = blockIdx.x * 256u + (uint32_t)tid;
+        if (q >= total4) return;
+        int i = (int)((q << 2) / (uint32_t)ld), j = (int)((q << 2) - (uint32_t)i * (uint32_t)ld);
+        const int sdi = (int)((stride4 << 2) / (uint32_t)ld), sdj = (int)((stride4 << 2) - (uint32_t)sdi * (uint32_t)ld);
+        for (; q < total4; q += stride4) {
+            uint32_t out[4] = {SQ_SENT_BITS, SQ_SENT_BITS, SQ_SENT_BITS, SQ_SENT_BITS};
+            // a 16-byte store whose cells all lie on or below the diagonal (or in the padding rows) is pure sentinel
+            const bool same_row = j + 3 < ld;
+            if (!(same_row && (j + 3 <= i || i >= n))) {
+                int ii = i, jj = j;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (ii < n && jj < n && jj > ii) {
+                        const int ai = l_attr[ii], aj = l_attr[jj];
+                        const int ci = ai & 31, cj = aj & 31, fi = ai >> 5, fj = aj >> 5;
+                        uint32_t bits = __float_as_uint(s_wf[ci * 33 + cj]);                         // :294-300 inbps
+                        bool ok = jj >= ii + (int)l_inc4[ii] && !((fi | fj) & 1) && !(fj & 2) && !(fi & 4);   // :300, :302-304
+                        if (ok && ico) ok = l_chain[ii] != l_chain[jj];                              // :301
+                        if (ok && !defr && bits != SQ_SENT_BITS) {
+                            const double w = s_w[ci * 33 + cj];                                      // same expressions as sq_cell_score
+                            double rf = sqrt((1.0 - (l_react[ii] + l_react[jj]) / 2.0) * 2.0);
+                            if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
+                            bits = __float_as_uint((float)(w * rf));
+                            if (bits == SQ_SENT_BITS) bits = 0x7FC00001u;   // a genuine NaN value stays "present"
+                        }
+                        out[k] = ok ? bits : SQ_SENT_BITS;
+                    }
+                    if (++jj == ld) { jj = 0; ii++; }
+                }
+            }
+            *reinterpret_cast<uint4 *>(mat + ((size_t)q << 2)) = make_uint4(out[0], out[1], out[2], out[3]);
+            i += sdi; j += sdj;
+            if (j >= ld) { j -= ld; i++; }
+        }
+        return;
+    }
+    const int64_t total4 = ((int64_t)n * ld + 3) >> 2;
+    double *m64 = jb.mat64_off >= 0 ? c.mat64 + jb.mat64_off : nullptr;   // has_ext == 2: holds the multiplier
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total4; q += (int64_t)gridDim.x * 256) {
+        const int64_t idx = q << 2;
+        int i = (int)(idx / ld);
+        int j = (int)(idx - (int64_t)i * ld);
+        float out[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t bits = SQ_SENT_BITS;
+            if (i < n && j < n && j > i && sq_cell_bool(c, jb, ps, i, j)) {
+                double v = sq_cell_score(c, jb, ps, i, j);
+                if (m64) {                              // :1084-1085 bpscorematrix * shortsmat
+                    if (mul_done) v = m64[(int64_t)i * n + j];          // the arena already holds the product
+                    else {                                               // :352-354 bpp term, :1084-1085 stem matrix
+                        v = jb.ext_add ? v + m64[(int64_t)i * n + j] : v * m64[(int64_t)i * n + j];
+                        m64[(int64_t)i * n + j] = v;
+                    }
+                }
+                bits = __float_as_uint((float)v);
+                if (bits == SQ_SENT_BITS) bits = 0x7FC00001u;   // a genuine NaN value stays "present"
+            } else if (m64 && i < n && j < n && !jb.ext_add) {
+                m64[(int64_t)i * n + j] = 0.0;          // (an ADDED term stays where bool == 0: scoremat += term covers every cell, :352)
+            }
+            out[k] = __uint_as_float(bits);
+            if (++j == ld) { j = 0; i++; }
+        }
+        *reinterpret_cast<float4 *>(mat + idx) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+// exact dense (bool, score) of one job, fp64 N x N, for sq_bpmatrix_read
+extern "C" __global__ __launch_bounds__(256) void sq_dense64_kernel(SqDevCtx c, int job, double *boolmat, double *scoremat)
+{
+    const SqJob jb = c.jobs[job];
+    const SqPsetDev *ps = c.psets + jb.pset;
+    const int n = jb.n;
+    const int64_t total = (int64_t)n * n;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int i = (int)(q / n), j = (int)(q - (int64_t)i * n);
+        double b = 0.0, s = 0.0;
+        if (j > i && sq_cell_bool(c, jb, ps, i, j)) {
+            b = 1.0;
+            s = sq_cell_score(c, jb, ps, i, j);
+        }
+        boolmat[q] = b;
+        scoremat[q] = s;
+    }
+}
+
+// caller-supplied (bool, score) fp64 matrices -> fp32 scan matrix.  mat64 arena of an
+// ext job holds [score N*N][bool N*N].
+extern "C" __global__ __launch_bounds__(256) void sq_import_kernel(SqDevCtx c)
+{
+    const SqJob jb = c.jobs[blockIdx.y];
+    if (jb.has_ext != 1) return;
+    const int n = jb.n, ld = jb.ld;
+    const double *sc = c.mat64 + jb.mat64_off;
+    const double *bl = sc + (int64_t)n * n;
+    float *mat = c.mat32 + jb.mat_off;
+    const int64_t total = (int64_t)n * ld;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int i = (int)(q / ld), j = (int)(q - (int64_t)i * ld);
+        uint32_t bits = SQ_SENT_BITS;
+        if (j < n && j > i && bl[(int64_t)i * n + j] != 0.0) {
+            bits = __float_as_uint((float)sc[(int64_t)i * n + j]);
+            if (bits == SQ_SENT_BITS) bits = 0x7FC00001u;
+        }
+        mat[q] = __uint_as_float(bits);
+    }
+}
+
+// Diagonal bit matrix of a job: bit b of word (w, s) <-> bpboolmatrix[i, s - i] with i = 32 w + b, for the
+// cells AnnotateStems visits (4 <= s <= 2N-6, i < j; :456-457, :486).  Word-row major (pitch bpitch >= 2N),
+// so the 64 lanes of a scan wave -- 64 consecutive diagonals -- read 64 consecutive words.  Built once
+// per job from the filled fp32 matrix (one more pass over N^2/2 cells); every later AnnotateStems
+// evaluation reads 1 bit per cell instead of 4 bytes.
+extern "C" __global__ __launch_bounds__(256) void sq_bits_kernel(SqDevCtx c, int only_ext)
+{
+    const SqJob jb = c.jobs[blockIdx.y];
+    if (only_ext && jb.has_ext != 1) return;
+    const int n = jb.n, ld = jb.ld, bp = jb.bpitch;
+    const float *mat = c.mat32 + jb.mat_off;
+    uint32_t *bits = c.bits + jb.bits_off;
+    const int64_t total = (int64_t)jb.nw * bp;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int w = (int)(q / bp), s = (int)(q - (int64_t)w * bp);
+        uint32_t word = 0;
+        if (s >= 4 && s <= 2 * n - 6) {
+#pragma unroll 8
+            for (int b = 0; b < 32; b++) {
+                const int i = 32 * w + b, j = s - i;
+                if (j > i && j < n && __float_as_uint(mat[(int64_t)i * ld + j]) != SQ_SENT_BITS) word |= 1u << b;
+            }
+        }
+        bits[q] = word;
+    }
+}
+
+// The same bit matrix straight from the O(N) inputs (bpboolmatrix never depends on scores, :286-304):
+// the fold path needs no fp32 matrix at all -- candidates are re-scored exactly from the inputs -- so
+// sq_fold builds only this (N^2/16 bytes written per job instead of 4 N^2).  One block = one word-row w
+// (rows 32w..32w+31) x 256 diagonals; row attributes are LDS broadcasts, column attributes consecutive bytes.
+extern "C" __global__ __launch_bounds__(256) void sq_bits_direct_kernel(SqDevCtx c)
+{
+    // per row: the set of partner letters it may pair with (bit = letter code; empty when the row itself is
+    // excluded by its restraint flags) and the smallest allowed j; per column: its letter code (31 = excluded)
+    __shared__ uint32_t s_rmask[32];
+    __shared__ int s_rjmin[32];
+    __shared__ uint8_t s_ccode[256 + 32];
+    __shared__ int16_t s_rch[32], s_cch[256 + 32];
+    __shared__ uint32_t s_pm[32];                        // partner mask of every letter under this paramset
+    const SqJob jb = c.jobs[blockIdx.y];
+    if (jb.has_ext == 1) return;                        // bool comes from the caller's matrix (sq_bits_kernel)
+    const int n = jb.n, bp = jb.bpitch;
+    const int ntile = (bp + 255) >> 8;
+    const SqPsetDev *ps = c.psets + jb.pset;
+    uint32_t *bits = c.bits + jb.bits_off;
+    const int tid = threadIdx.x;
+    if (tid < 32) {
+        uint32_t m = 0;
+        for (int q = 0; q < 29; q++) if (ps->inbps[tid * 32 + q]) m |= 1u << q;     // :300 (codes 0..28; 31 never set)
+        s_pm[tid] = m;
+    }
+    for (int blk = blockIdx.x; blk < jb.nw * ntile; blk += gridDim.x) {
+        const int w = blk / ntile, s0 = (blk - w * ntile) << 8;
+        const int s = s0 + tid;
+        const int i0 = 32 * w;
+        // the tile has cells only if some i in [i0, i0+31], j = s - i with i < j < n exists
+        const bool live = s0 + 255 >= 2 * i0 + 1 && s0 <= i0 + 31 + n - 1 && s0 <= 2 * n - 6 && s0 + 255 >= 4;
+        __syncthreads();
+        if (live) {
+            const int jbase = s0 - i0 - 31;              // column of (b = 31, tid = 0)
+            for (int t = tid; t < 32 + 256 + 32; t += 256) {
+                const bool isrow = t < 32;
+                const int p = isrow ? i0 + t : jbase + (t - 32);
+                const bool in = p >= 0 && p < n;
+                const uint32_t code = in ? c.codes[jb.pos_off + p] : 31u, fl = in ? c.flags[jb.pos_off + p] : 1u;
+                const int16_t ch = in ? c.chain[jb.pos_off + p] : (int16_t)0;
+                if (isrow) {
+                    s_rmask[t] = (in && !(fl & 1u) && !(fl & 4u)) ? s_pm[code & 31u] : 0u;         // :302, :304 (row side)
+                    s_rjmin[t] = p + (in ? (int)c.inc4[jb.pos_off + p] : 0);                       // :294-299
+                    s_rch[t] = ch;
+                } else {
+                    s_ccode[t - 32] = (uint8_t)((in && !(fl & 1u) && !(fl & 2u)) ? code : 31u);  // :302, :303 (column side)
+                    s_cch[t - 32] = ch;
+                }
+            }
+        }
+        __syncthreads();
+        if (s >= bp) continue;
+        uint32_t word = 0;
+        if (live && s >= 4 && s <= 2 * n - 6) {
+#pragma unroll 8
+            for (int b = 0; b < 32; b++) {
+                const int cj = tid + 31 - b;               // column s - (i0 + b) relative to jbase
+                const int j = s - i0 - b;
+                bool ok = ((s_rmask[b] >> s_ccode[cj]) & 1u) && j >= s_rjmin[b];                   // :294-304
+                if (jb.interchainonly) ok = ok && s_rch[b] != s_cch[cj];                             // :301
+                if (ok) word |= 1u << b;
+            }
+        }
+        bits[(int64_t)w * bp + s] = word;
+    }
+}
+
+// The same bit matrix from letter masks: for the letters x present in the sequence, R_x = the rows of a word-row with
+// letter x (and no row-side restraint flag), M_x = the columns whose letter may pair with x (and no column-side
+// flag) as a bit array over j.  A word (w, s) is then OR_x R_x & reverse(M_x[t-31 .. t]), t = s - 32w: a few word
+// operations instead of 32 cell tests; only the words next to the main diagonal check the minimal loop length bit
+// by bit (:294-299).  grid = (parts, jobs): a block rebuilds the O(N) masks of its job and writes every `parts`-th
+// word-row.  Not for interchainonly batches (the chain test does not factor): they use sq_bits_direct_kernel.
+extern "C" __global__ __launch_bounds__(256) void sq_bits_masks_kernel(SqDevCtx c, int max_letters)
+{
+    extern __shared__ __attribute__((aligned(16))) char s_bm[];
+    __shared__ uint32_t s_pm[32];
+    __shared__ uint32_t s_present;
+    __shared__ uint8_t s_letter[32];
+    const SqJob jb = c.jobs[blockIdx.y];
+    if (jb.has_ext == 1) return;                        // bool comes from the caller's matrix (sq_bits_kernel)
+    const int n = jb.n, bp = jb.bpitch, nw = jb.nw, mw = nw + 3;
+    const SqPsetDev *ps = c.psets + jb.pset;
+    uint32_t *bits = c.bits + jb.bits_off;
+    const int tid = threadIdx.x;
+    const int npad = (n + 3) & ~3;
+    uint8_t *s_ccode = reinterpret_cast<uint8_t *>(s_bm);               // [npad] column letter (31 = excluded)
+    uint8_t *s_rcode = s_ccode + npad;                                  // [npad] row letter (31 = excluded)
+    uint8_t *s_inc = s_rcode + npad;                                    // [npad] minimal j - i
+    uint32_t *s_M = reinterpret_cast<uint32_t *>(s_inc + npad);         // [max_letters][mw], one zero word in front
+    uint32_t *s_R = s_M + max_letters * mw;                             // [nw][max_letters]
+    if (tid < 32) {
+        uint32_t m = 0;
+        for (int q = 0; q < 29; q++) if (ps->inbps[tid * 32 + q]) m |= 1u << q;     // :300 (codes 0..28; 31 never set)
+        s_pm[tid] = m;
+    }
+    if (tid == 0) s_present = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int p = tid; p < n; p += 256) {
+        const uint32_t code = c.codes[jb.pos_off + p], fl = c.flags[jb.pos_off + p];
+        s_ccode[p] = (uint8_t)((!(fl & 1u) && !(fl & 2u)) ? code : 31u);            // :302, :303 (column side)
+        const bool rowok = !(fl & 1u) && !(fl & 4u);                                  // :302, :304 (row side)
+        s_rcode[p] = (uint8_t)(rowok ? code : 31u);
+        s_inc[p] = c.inc4[jb.pos_off + p];
+        if (rowok && code < 29u && s_pm[code]) mine |= 1u << code;    // (letters that pair with nothing have no cells)
+    }
+    if (mine) atomicOr(&s_present, mine);
+    __syncthreads();
+    const uint32_t present = s_present;
+    const int nlet = __popc(present);                                    // <= max_letters (host: letters of the batch)
+    if (tid < 32) {
+        uint32_t m = present; int k = 0;
+        while (m) { const int x = __ffs((int)m) - 1; m &= m - 1; if (k == tid) s_letter[tid] = (uint8_t)x; k++; }
+    }
+    __syncthreads();
+    for (int e = tid; e < nlet * mw; e += 256) {                         // column masks
+        const int k = e / mw, q = e - k * mw;
+        const uint32_t pm = s_pm[s_letter[k]];
+        uint32_t word = 0;
+        const int j0 = (q - 1) * 32;
+        if (q >= 1 && j0 < n)
+            for (int bb = 0; bb < 32 && j0 + bb < n; bb++) word |= ((pm >> s_ccode[j0 + bb]) & 1u) << bb;
+        s_M[e] = word;
+    }
+    for (int e = tid; e < nw * nlet; e += 256) {                         // row masks
+        const int w = e / nlet, k = e - w * nlet;
+        const uint32_t x = s_letter[k];
+        uint32_t word = 0;
+        for (int bb = 0; bb < 32 && 32 * w + bb < n; bb++) word |= (uint32_t)(s_rcode[32 * w + bb] == x) << bb;
+        s_R[w * max_letters + k] = word;
+    }
+    __syncthreads();
+    for (int w = blockIdx.x; w < nw; w += gridDim.x) {
+        const int i0 = 32 * w;
+        const uint32_t *R = s_R + w * max_letters;
+        for (int s = tid; s < bp; s += 256) {
+            uint32_t word = 0;
+            const int t = s - i0;                                        // column of bit 0
+            if (s >= 4 && s <= 2 * n - 6 && t >= 0 && t - 31 < n) {
+                const int q = t + 1;                                     // bit index of column t-31 behind the zero word
+                for (int k = 0; k < nlet; k++) {
+                    const uint32_t *M = s_M + k * mw + (q >> 5);
+                    const uint64_t two = ((uint64_t)M[1] << 32) | M[0];
+                    word |= R[k] & __brev((uint32_t)(two >> (q & 31)));
+                }
+                const int d = s - 2 * i0;                                // j - i of bit b is d - 2b
+                if (word && d < 4 + 62) {
+                    uint32_t keep = 0;
+                    for (int bb = 0; bb < 32 && i0 + bb < n; bb++)
+                        if (d - 2 * bb >= (int)s_inc[i0 + bb]) keep |= 1u << bb;            // :294-299
+                    word &= keep;
+                }
+            }
+            bits[(int64_t)w * bp + s] = word;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// per-structure state: partner P, mask code E, prefix counts U (unpaired), SU (unpaired separators)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void sq_put_out(const SqRoundIO &io, SqScanArgs &a, const SqOut &r)
+{
+    const uint32_t o = atomicAdd(&a.ctr->nout, 1u);
+    if (o < io.h_cap) io.h_out[o] = r;                   // straight into pinned host memory
+    else if (o < io.out_cap) io.d_out[o] = r;
+    else a.ctr->out_ovf = 1;
+}
+
+extern "C" __global__ void sq_done_kernel(SqRoundIO io, SqScanArgs a, uint32_t seq)
+{
+    *io.h_ctr = *a.ctr;
+    __threadfence_system();
+    *io.h_seq = seq;
+}
+
+// The arrays are assembled in LDS (7 bytes per position) and written out once, coalesced; sequences that do not
+// fit (n > lds_n) are assembled in place in global memory by the same code.
+template <bool LDS>
+__device__ __forceinline__ void sq_state_build(const SqDevCtx &c, const SqStruct &s, const SqJob &jb, const SqStrand *sd,
+                                               const SqState &st, int16_t *P, uint8_t *E, int16_t *U, int16_t *SU)
+{
+    __shared__ int wave_u[4], wave_s[4];
+    const int n = jb.n, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint8_t *e0 = c.e0c + jb.pos_off;
+    const uint8_t *codes = c.codes + jb.pos_off;
+    for (int p = tid; p < n; p += 256) { P[p] = -1; E[p] = e0[p]; }
+    __syncthreads();
+    for (int k = tid; k < s.nstrand; k += 256) {
+        const SqStrand x = sd[k];
+        for (int t = 0; t < x.len; t++) {
+            const int pos = x.start + t;
+            P[pos] = (int16_t)(x.pstart - t);           // :634-635
+            E[pos] = 255;                               // :446-451 row+column of a paired base are masked
+        }
+    }
+    __syncthreads();
+    // exclusive prefix counts of unpaired positions (U) and unpaired separators (SU): 256 positions per step,
+    // ballots inside a wave, the four wave totals through LDS, a running base across steps
+    int base_u = 0, base_s = 0;
+    for (int p0 = 0; p0 < n; p0 += 256) {
+        const int p = p0 + tid;
+        const bool un = p < n && P[p] == -1;
+        const bool us = un && (codes[p] == 26 || codes[p] == 27);
+        const unsigned long long mu = __ballot(un), ms = __ballot(us);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (lane == 0) { wave_u[wv] = __popcll(mu); wave_s[wv] = __popcll(ms); }
+        __syncthreads();
+        int pu = base_u + __popcll(mu & below), pS = base_s + __popcll(ms & below);
+        for (int q = 0; q < wv; q++) { pu += wave_u[q]; pS += wave_s[q]; }
+        if (p < n) { U[p] = (int16_t)pu; SU[p] = (int16_t)pS; }
+        base_u += wave_u[0] + wave_u[1] + wave_u[2] + wave_u[3];
+        base_s += wave_s[0] + wave_s[1] + wave_s[2] + wave_s[3];
+        __syncthreads();
+    }
+    if (tid == 0) { U[n] = (int16_t)base_u; SU[n] = (int16_t)base_s; }
+    // free-position bit words for the bit-diagonal scan: F bit p = (E[p] == 0); G bit k + SQ_GPAD = F[n-1-k].
+    // One ballot = two words.
+    const int fbh = st.fbstride >> 1;
+    uint32_t *FBs = st.FB + (int64_t)s.slot * st.fbstride;
+    for (int m2 = wv; 2 * m2 < fbh; m2 += 4) {          // m2: pair of words (2 m2, 2 m2 + 1) of either array
+        const int pf = 64 * m2 + lane;                  // forward array: position
+        const unsigned long long bf = __ballot(pf < n && E[pf] == 0);
+        const int pr = n - 1 - (64 * m2 + lane - SQ_GPAD);   // reversed array: bit 64 m2 + lane <-> position n-1-(bit - pad)
+        const unsigned long long br = __ballot(pr >= 0 && pr < n && E[pr] == 0);
+        if (lane == 0) {
+            if (2 * m2 < fbh) { FBs[2 * m2] = (uint32_t)bf; FBs[fbh + 2 * m2] = (uint32_t)br; }
+            if (2 * m2 + 1 < fbh) { FBs[2 * m2 + 1] = (uint32_t)(bf >> 32); FBs[fbh + 2 * m2 + 1] = (uint32_t)(br >> 32); }
+        }
+    }
+    if (LDS) {                                          // one coalesced write of everything
+        __syncthreads();
+        int16_t *gP = st.P + (int64_t)s.slot * st.stride, *gU = st.U + (int64_t)s.slot * st.stride;
+        int16_t *gSU = st.SU + (int64_t)s.slot * st.stride;
+        uint8_t *gE = st.E8 + (int64_t)s.slot * st.stride * 2;
+        for (int p = tid; p <= n; p += 256) {
+            if (p < n) { gP[p] = P[p]; gE[p] = E[p]; }
+            gU[p] = U[p]; gSU[p] = SU[p];
+        }
+    }
+}
+
+// chained: the structures and strands already live in device memory (sq_chain_kernel maintains them; io.h_* point at
+// the same arrays), finished structures carry nstrand < 0 and the counters accumulate over the whole chain.
+extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n,
+                                                                 int chained)
+{
+    extern __shared__ __attribute__((aligned(16))) char st_dyn[];
+    const SqStruct s = io.h_structs[blockIdx.x];          // pinned host memory: one read per structure per round
+    if (threadIdx.x == 0) {
+        if (!chained) io.d_structs[blockIdx.x] = s;
+        a.cand_cnt[s.slot] = 0; a.best[s.slot] = 0ull; a.ok_cnt[s.slot] = 0;
+        if (blockIdx.x == 0 && !chained) { a.ctr->nout = 0; a.ctr->cand_ovf = 0; a.ctr->out_ovf = 0; a.ctr->level_ovf = 0; }
+    }
+    if (s.nstrand < 0) return;                            // (chained) the structure is final
+    if (!chained)
+        for (int k = threadIdx.x; k < s.nstrand; k += 256) io.d_strands[s.strand_off + k] = io.h_strands[s.strand_off + k];
+    __syncthreads();
+    const SqJob jb = c.jobs[s.job];
+    const SqStrand *sd = io.d_strands + s.strand_off;
+    const int n = jb.n;
+    if (n <= lds_n) {
+        const int np = (lds_n + 8) & ~7;                  // arrays of n + 1 entries, 8-byte aligned sections
+        int16_t *P = reinterpret_cast<int16_t *>(st_dyn), *U = P + np, *SU = U + np;
+        uint8_t *E = reinterpret_cast<uint8_t *>(SU + np);
+        sq_state_build<true>(c, s, jb, sd, st, P, E, U, SU);
+    } else {
+        sq_state_build<false>(c, s, jb, sd, st, st.P + (int64_t)s.slot * st.stride, st.E8 + (int64_t)s.slot * st.stride * 2,
+                              st.U + (int64_t)s.slot * st.stride, st.SU + (int64_t)s.slot * st.stride);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// candidate staging of the scan: (key, len) records collected in LDS, appended to the structure's key array with
+// one global atomic per flush
+// ------------------------------------------------------------------------------------
+#ifndef SQ5_STAGE
+#define SQ5_STAGE 256
+#endif
+__device__ __forceinline__ void sq_emit_global(const SqScanArgs &a, const SqStruct &st, int cap, uint32_t key,
+                                               uint32_t len, float sum)
+{
+    const uint32_t slot = atomicAdd(a.cand_cnt + st.slot, 1u);
+    if (slot >= (uint32_t)cap) { a.ctr->cand_ovf = 1; return; }
+    (void)sum;
+    sq_keys(a, st)[slot] = SqKey{key, len};
+}
+
+template <class LDS>
+__device__ __forceinline__ void sq5_flush(LDS &L, const SqScanArgs &a, const SqStruct &st, int cap, int lane)
+{
+    uint32_t n = L.stage_count;
+    if (n > SQ5_STAGE) n = SQ5_STAGE;
+    if (n) {
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(a.cand_cnt + st.slot, n);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+        for (uint32_t k = lane; k < n; k += 64) {
+            const uint32_t slot = base + k;
+            if (slot >= (uint32_t)cap) { a.ctr->cand_ovf = 1; continue; }
+            sq_keys(a, st)[slot] = SqKey{L.stage[k].x, L.stage[k].y};
+        }
+    }
+    __syncthreads();
+    if (lane == 0) L.stage_count = 0;
+    __syncthreads();
+}
+
+template <class LDS>
+__device__ __forceinline__ void sq5_emit(LDS &L, const SqScanArgs &a, const SqStruct &st, int cap, uint32_t key, uint32_t len)
+{
+    const uint32_t slot = atomicAdd(&L.stage_count, 1u);
+    if (slot < SQ5_STAGE) L.stage[slot] = make_uint2(key, len);
+    else sq_emit_global(a, st, cap, key, len, 0.f);
+}
+
+// ------------------------------------------------------------------------------------
+// a-2  stem scan, bit-diagonal form.  AnnotateStems only needs to know WHERE the
+// unmasked cells are -- every candidate's score is recomputed exactly in fp64 by sq_score_kernel --
+// so the scan reads the job's diagonal bit matrix (sq_bits_kernel) instead of the fp32 matrix:
+//   active(s, i) = base(s, i)  &  free[i]  &  free[s - i]       (+ the live restraint pairs)
+// One lane = one anti-diagonal, one loop step = 32 rows:
+//   base word   one coalesced 4-byte load per lane (64 consecutive diagonals = 256 B per wave);
+//   row word    wave-uniform LDS read of the free-position bit array F;
+//   column word a 32-bit window of the REVERSED array G (bit k <-> position n-1-k) starting at
+//               n-1-s+32w: it advances by exactly one word per step, so each step reads one new LDS
+//               word and funnel-shifts it against the previous one (v_alignbit);
+// and the runs of the 32 rows come out of the word with bit tricks (below).  Per structure the scan touches
+// N^2/16 bytes of (L2-resident) bits instead of 2 N^2 bytes of HBM.
+// ------------------------------------------------------------------------------------
+#define SQ6_RL 256
+struct SqScan6Lds {
+    uint2 stage[SQ5_STAGE];
+    uint32_t stage_count, nrl, pad[2];
+    uint32_t rl[SQ6_RL];                 // live restraint cells of this wave's diagonals: v | (w << 16)
+};
+
+#ifndef SQ6_AHEAD
+#define SQ6_AHEAD 2
+#endif
+extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) SqScan6Lds L;
+    extern __shared__ uint32_t sq6_fg[];                                // F words then G words of the structure
+    const SqStruct st = structs[blockIdx.x];
+    if (st.nstrand < 0) return;                                         // (chained rounds) the structure is final
+    const SqJob jb = c.jobs[st.job];
+    const int n = jb.n;
+    if (n < 5) return;                                                  // :456-457 no diagonals
+    const int s0 = blockIdx.y << 6;
+    const int smin = max(s0, 4), smax = min(s0 + 63, 2 * n - 6);        // :456-457 s in [4, 2N-6]
+    if (smin > smax) return;
+    const int rmin = max(0, smin - (n - 1)), rmax = (smax - 1) >> 1;    // :486 i <= j-1
+    const int wlo = rmin >> 5, whi = rmax >> 5;
+    const int lane = threadIdx.x;
+    const int s = s0 + lane;
+    const SqPsetDev *ps = c.psets + jb.pset;
+    const int minlen = max(1, (int)ceil(ps->minlen));
+    const int cap = jb.cand_cap;
+    const int fbh = stt.fbstride >> 1;
+    const uint32_t *FBg = stt.FB + (int64_t)st.slot * stt.fbstride;
+    uint32_t *F = sq6_fg, *G = sq6_fg + fbh;
+    // window of the reversed array for (s, wlo): first bit n-1-s+32 wlo (+pad); lanes outside the valid
+    // diagonals have zero base words, their window only has to stay inside the array
+    const int q0 = min(max(n - 1 - s + 32 * wlo + SQ_GPAD, 0), 32 * (fbh - (whi - wlo) - 3));
+    const int gidx = q0 >> 5, gsh = q0 & 31;
+    if (lane == 0) { L.stage_count = 0; L.nrl = 0; }
+    for (int m = lane; m < 2 * fbh; m += 64) sq6_fg[m] = FBg[m];
+    __syncthreads();
+    if (jb.nrb) {                                                       // restraint pairs both ends of which are still free
+        const uint8_t *eg = stt.E8 + (int64_t)st.slot * stt.stride * 2;
+        for (int k = lane; k < jb.nrb; k += 64) {
+            const uint32_t pk = c.rbpk[jb.rb_off + k];
+            const int v = (int)(pk & 0xFFFFu), w = (int)(pk >> 16);
+            if (eg[v] == (uint8_t)(k + 1) && eg[w] == (uint8_t)(k + 1) && v + w >= s0 && v + w <= s0 + 63) {
+                const uint32_t slot = atomicAdd(&L.nrl, 1u);
+                if (slot < SQ6_RL) L.rl[slot] = pk;
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t nrl = min(L.nrl, (uint32_t)SQ6_RL);
+    const uint32_t *bp = c.bits + jb.bits_off + s;
+    const int bpitch = jb.bpitch;
+
+    int carry = 0;
+    uint32_t glo = G[gidx];
+    // window of minlen ones by doubling: Y &= Y >> ysh_q, five fixed steps (shift 0 once the window is complete)
+    int ysh0, ysh1, ysh2, ysh3, ysh4;
+    {
+        const int want = minlen < 32 ? minlen : 32;
+        int have = 1;
+        ysh0 = min(have, want - have); have += ysh0;
+        ysh1 = min(have, want - have); have += ysh1;
+        ysh2 = min(have, want - have); have += ysh2;
+        ysh3 = min(have, want - have); have += ysh3;
+        ysh4 = min(have, want - have);
+    }
+    // SQ6_AHEAD word-rows per trip: their (independent) loads are issued together, so a wave waits for HBM / L2 once
+    // per group instead of once per word (a single word of look-ahead did not survive the compiler's wait counts)
+    for (int w0 = wlo; w0 <= whi; w0 += SQ6_AHEAD) {
+        uint32_t bw[SQ6_AHEAD];
+#pragma unroll
+        for (int k = 0; k < SQ6_AHEAD; k++) bw[k] = w0 + k <= whi ? bp[(int64_t)(w0 + k) * bpitch] : 0u;
+#pragma unroll
+        for (int k = 0; k < SQ6_AHEAD; k++) {
+            const int w = w0 + k;
+            if (w > whi) break;
+            const uint32_t base = bw[k];
+            const uint32_t ghi = G[gidx + 1 + (w - wlo)];
+            const uint32_t gw = __builtin_amdgcn_alignbit(ghi, glo, gsh);   // columns s-32w-b, b = 0..31
+            glo = ghi;
+            uint32_t A = base & F[w] & gw;                              // :438-451 free row and column
+            if (nrl) {
+                for (uint32_t q = 0; q < nrl; q++) {
+                    const uint32_t pk = L.rl[q];
+                    const int v = (int)(pk & 0xFFFFu), ww = (int)(pk >> 16);
+                    if (v + ww == s && (v >> 5) == w) A |= base & (1u << (v & 31));   // :438-443 restraint bp stays pairable
+                }
+            }
+            // maximal runs of the word (bit b = row 32w + b; `carry` rows of an open run precede row 32w)
+            if (__ballot((A != 0u) | (carry > 0)) != 0ull) {
+                if (A == 0xFFFFFFFFu) carry += 32;
+                else {
+                    const int lead = __ffs((int)~A) - 1;                // the run that continues the carried one (maybe empty)
+                    const int len0 = carry + lead;
+                    if (len0 >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(32 * w - carry), (uint32_t)len0);
+                    const int trail = __clz((int)~A);                   // the run still open at row 32w + 31
+                    carry = trail;
+                    // runs strictly inside: starts with a full window of minlen ones above them
+                    uint32_t rest = A & ~((1u << lead) - 1u);
+                    if (trail) rest &= 0xFFFFFFFFu >> trail;
+                    uint32_t Y = rest;
+                    Y &= Y >> ysh0; Y &= Y >> ysh1; Y &= Y >> ysh2; Y &= Y >> ysh3; Y &= Y >> ysh4;
+                    uint32_t starts = rest & ~(rest << 1) & Y;
+                    while (starts) {
+                        const int p = __ffs((int)starts) - 1;
+                        starts &= starts - 1;
+                        const int len = __ffs((int)~(rest >> p)) - 1;
+                        sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(32 * w + p), (uint32_t)len);
+                    }
+                }
+            } else
+                carry = 0;
+            if (L.stage_count > SQ5_STAGE / 2) sq5_flush(L, a, st, cap, lane);
+        }
+    }
+    if (carry >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(32 * (whi + 1) - carry), (uint32_t)carry);
+    __syncthreads();
+    sq5_flush(L, a, st, cap, lane);
+}
+
+
+// ------------------------------------------------------------------------------------
+// a-4..a-6  exact rescoring + ScoreStems closed form + range filter (one block per structure)
+// ------------------------------------------------------------------------------------
+#define SQ_LDS_STRANDS 1024
+
+__device__ __forceinline__ bool sq_goodloop(int x, int y)             // :615-622
+{
+    // rows x = 0..4, bit y set when (x, y) is a "good" internal loop
+    const unsigned tab[5] = {0x07u /*0:{0,1,2}*/, 0x0Fu /*1:{0,1,2,3}*/, 0x1Fu /*2:{0..4}*/, 0x1Eu /*3:{1,2,3,4}*/,
+                             0x1Cu /*4:{2,3,4}*/};
+    if ((unsigned)x > 4u || (unsigned)y > 4u) return false;
+    return (tab[x] >> y) & 1u;
+}
+
+// grid = (structures, parts): the candidates of a structure are dealt to `parts` blocks; the round's best
+// finalscore of the structure is combined with atomicMax, the range filter (:769-778) runs in sq_select_kernel.
+#ifndef SQ_SCORE_WAVES
+#define SQ_SCORE_WAVES 5                             // 96 VGPRs: five waves per SIMD instead of four at 97
+#endif
+template <bool FULL>
+__device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct *structs, const SqStrand *strands,
+                                              const SqState &stt, SqScanArgs &a, const SqRoundIO &io, int mode, int lds_n,
+                                              int lds_n_reacts, int lds_n_state, int surv_off)
+{
+    __shared__ SqStrand s_str[FULL ? SQ_LDS_STRANDS : 1];
+    __shared__ uint16_t s_skip[FULL ? SQ_LDS_STRANDS : 1];   // 5' strand k closes a block: next strand that can matter after it
+    // Cell values from ONE table: every position carries a combined index ci = class * R + level (class: rank of its
+    // letter among the letters the paramset pairs, one extra class for all others; level: index of its reactivity
+    // among the sequence's <= 16 distinct values, R = 1 without reactivity factors), and
+    //     s_cell[ci_i * cstride + ci_j] = w * reactfactor   (the very expression of sq_cell_score, built once per block).
+    // A cell then costs two byte reads and one table read.  The 32 x 32 weight table this replaces had a row stride
+    // of 256 bytes = the whole bank span, so the pairs of the four letters sat on four bank pairs (4-way conflicts,
+    // 72 % of the LDS-busy cycles of the kernel, profiles/r01k_score_pmc_*); the compact table's odd stride spreads
+    // the <= (K R)^2 live entries over all banks.  Arbitrary float reactivities: weights from the table (R = 1), the
+    // factor per cell as before.
+    __shared__ double s_cell[32 * 33];
+    __shared__ uint8_t s_cls[32];
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];   // letter codes [n] (+ reactivities [n] when they fit)
+    const SqStruct st = structs[blockIdx.x];
+    const SqJob jb = c.jobs[st.job];
+    const SqPsetDev *ps = c.psets + jb.pset;
+    const int n = jb.n;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    uint32_t ncand = a.cand_cnt[st.slot];
+    if (ncand > (uint32_t)jb.cand_cap) ncand = jb.cand_cap;
+    if ((uint32_t)blockIdx.y * (uint32_t)nthr >= ncand) return;         // this part has no candidates
+    const SqStrand *S = strands + st.strand_off;
+    const bool lds_strands = FULL && st.nstrand <= SQ_LDS_STRANDS;
+    if (lds_strands) {
+        for (int k = tid; k < st.nstrand; k += nthr) s_str[k] = S[k];
+        S = s_str;
+    }
+    __syncthreads();
+    if (lds_strands) {
+        // Once the sweep of ScoreStems has registered the block [start, partner] of a 5' strand, the strands that
+        // start inside it are inert unless they are 5' strands whose partner lies beyond the block's end (they extend
+        // it or are wings); skip[k] = the first strand behind k that starts outside the block or is such a strand.
+        for (int k = tid; k < st.nstrand; k += nthr) {
+            const SqStrand x = s_str[k];
+            int q = k + 1;
+            if (x.left) {
+                const int pf = x.pstart;
+                while (q < st.nstrand) {
+                    const SqStrand y = s_str[q];
+                    if (y.start > pf || (y.left && y.pstart > pf)) break;
+                    q++;
+                }
+            }
+            s_skip[k] = (uint16_t)q;
+        }
+    }
+    const int16_t *P = stt.P + (int64_t)st.slot * stt.stride;
+    const int16_t *U = stt.U + (int64_t)st.slot * stt.stride;
+    const int16_t *SU = stt.SU + (int64_t)st.slot * stt.stride;
+    // the exact re-scoring touches codes / weights / reactivities once per cell: keep them in LDS
+    double *l_reacts = reinterpret_cast<double *>(s_dyn + ((n + 15) & ~15));
+    // ScoreStems walks the partner array and reads the prefix counts with dependent loads: LDS copies when they
+    // fit (3 x int16 per position, after the codes and reactivities of the launch's longest sequence)
+    if (mode == 0 && lds_n_state >= n) {
+        int16_t *lP = reinterpret_cast<int16_t *>(s_dyn + ((lds_n + 15) & ~15) + (size_t)8 * lds_n_reacts);
+        int16_t *lU = lP + ((lds_n_state + 8) & ~7), *lSU = lU + ((lds_n_state + 8) & ~7);
+        // 32-bit copies (the arrays start 64-byte aligned: stride is a multiple of 32 positions)
+        const uint32_t *gP = reinterpret_cast<const uint32_t *>(P), *gU = reinterpret_cast<const uint32_t *>(U);
+        const uint32_t *gS = reinterpret_cast<const uint32_t *>(SU);
+        uint32_t *wP = reinterpret_cast<uint32_t *>(lP), *wU = reinterpret_cast<uint32_t *>(lU), *wS = reinterpret_cast<uint32_t *>(lSU);
+        const int nw2 = (n + 2) >> 1;                       // covers entries 0..n
+        for (int q = tid; q < nw2; q += nthr) { wP[q] = gP[q]; wU[q] = gU[q]; wS[q] = gS[q]; }
+        P = lP; U = lU; SU = lSU;
+    }
+    const bool lds_cells = jb.mat64_off < 0 && lds_n >= n;
+    const bool any_reacts = lds_cells && !jb.default_reacts;
+    // classes of the letters: K pairing letters + one class for everything else.  lmask: bit a set iff letter a has a
+    // pair in the paramset (row a of inbps is not all zero) -- the first 32 threads test a row each, one ballot
+    __shared__ uint32_t s_lmask;
+    if (lds_cells && tid < 64) {
+        uint32_t any8 = 0;
+        if (tid < 32) {
+            const uint32_t *ib = reinterpret_cast<const uint32_t *>(ps->inbps) + tid * 8;
+#pragma unroll
+            for (int q = 0; q < 8; q++) any8 |= ib[q];
+        }
+        const unsigned long long bal = __ballot(any8 != 0);
+        if (tid == 0) s_lmask = (uint32_t)bal;
+    }
+    __syncthreads();
+    const uint32_t lmask = lds_cells ? s_lmask : 0u;
+    const int K = __popc(lmask) + 1;
+    // few distinct reactivity values (encoded input): level index per position, reactfactors folded into the table
+    const bool react_tab = any_reacts && jb.react_levels > 0 && K * jb.react_levels <= 32;   // (the host sizes LDS by the same rule)
+    const bool lds_reacts = any_reacts && !react_tab && lds_n_reacts >= n;                    // per-cell factors from LDS copies
+    const int R = react_tab ? jb.react_levels : 1;
+    const int KR = K * R, cstride = KR | 1;
+    const bool cell_tab = lds_cells && (jb.default_reacts || react_tab);     // the table holds the final cell value
+    __shared__ double s_rv[16];
+    uint8_t *l_ci = reinterpret_cast<uint8_t *>(s_dyn);                       // combined index per position
+    if (lds_cells) {
+        if (tid < 32) s_cls[tid] = (lmask >> tid) & 1u ? (uint8_t)__popc(lmask & ((1u << tid) - 1u)) : (uint8_t)(K - 1);
+        if (react_tab)
+            for (int p = tid; p < n; p += nthr) s_rv[c.ridx[jb.pos_off + p]] = c.reacts[jb.pos_off + p];   // (all writers of a level store the same value)
+        else if (lds_reacts) for (int p = tid; p < n; p += nthr) l_reacts[p] = c.reacts[jb.pos_off + p];
+    }
+    __syncthreads();
+    if (lds_cells) {
+        for (int p = tid; p < n; p += nthr) {
+            const int cl = s_cls[c.codes[jb.pos_off + p] & 31];
+            l_ci[p] = (uint8_t)(react_tab ? cl * R + c.ridx[jb.pos_off + p] : cl);
+        }
+        for (int e = tid; e < KR * KR; e += nthr) {
+            const int ci = e / KR, cj = e - ci * KR;
+            const int ca = ci / R, cb = cj / R;
+            // letter code of a class: the ca-th set bit of lmask (class K-1: any letter without pairs, weight 0 with everything)
+            int la = 31, lb = 31;
+            {
+                uint32_t m = lmask; for (int t = 0; t < ca && m; t++) m &= m - 1;
+                la = ca < K - 1 ? __ffs((int)m) - 1 : -1;
+                m = lmask; for (int t = 0; t < cb && m; t++) m &= m - 1;
+                lb = cb < K - 1 ? __ffs((int)m) - 1 : -1;
+            }
+            const double w = (la >= 0 && lb >= 0) ? ps->w[la * 32 + lb] : 0.0;
+            double v = w;                                                   // default reactivities: w * 1 (and 1/1)
+            if (react_tab) {
+                double rf = sqrt((1.0 - (s_rv[ci - ca * R] + s_rv[cj - cb * R]) / 2.0) * 2.0);
+                if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
+                v = w * rf;
+            }
+            s_cell[ci * cstride + cj] = v;
+        }
+    }
+    __syncthreads();
+    const uint8_t *codes = c.codes + jb.pos_off;
+    const SqKey *keys = sq_keys(a, st);
+    SqOk *oks = sq_oks(a, st, jb.cand_cap);
+    // the survivor list can take as many records as remain in the slice after the key array
+    const uint32_t ok_cap = (uint32_t)(((size_t)jb.cand_cap * (sizeof(SqCand) - sizeof(SqKey))) / sizeof(SqOk));
+    const double minbps = ps->minbpscore, minfin = ps->minfinscore;
+    auto cell_exact = [&](int i, int j) -> double {
+        if (!lds_cells) return sq_cell_exact(c, jb, ps, i, j);
+        const double w = s_cell[l_ci[i] * cstride + l_ci[j]];             // cell_tab: the cell itself
+        if (cell_tab) return w;
+        const double ri = lds_reacts ? l_reacts[i] : c.reacts[jb.pos_off + i];   // same expression as sq_cell_score
+        const double rj = lds_reacts ? l_reacts[j] : c.reacts[jb.pos_off + j];
+        double rf = sqrt((1.0 - (ri + rj) / 2.0) * 2.0);
+        if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
+        return w * rf;
+    };
+
+    double best = 0.0; int any = 0;
+
+    const uint32_t qstep = gridDim.y * nthr;
+    // exact bpscore of the SQ_SCORE_CHUNK candidates of a thread: sum(...) left to right starting from int 0 (:416),
+    // four cells per step: the lookups of one step (letter codes, then the weight) are independent and overlap, the
+    // additions of each candidate keep the reference's order; padding cells (past a candidate's end) add +0.0, which
+    // leaves its sum unchanged.  The filter-only kernel advances its candidates TOGETHER (16 lookups in flight; 3.1 ->
+    // 1.9 ms per alignment chunk); under ScoreStems' register budget that spills, so there they go one by one.
+    auto chunk_bps = [&](const SqKey (&cd)[SQ_SCORE_CHUNK], double (&bps)[SQ_SCORE_CHUNK]) {
+        if (FULL) {
+#pragma unroll
+            for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
+                const int s = (int)(cd[u].key >> 16), i0 = (int)(cd[u].key & 0xFFFFu), j0 = s - i0, L = (int)cd[u].len;
+                double acc = 0.0;
+                for (int t = 0; t < L; t += 4) {
+                    double v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int tt = t + k < L ? t + k : L - 1;
+                        v[k] = cell_exact(i0 + tt, j0 - tt);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc = acc + (t + k < L ? v[k] : 0.0);
+                }
+                bps[u] = acc;
+            }
+            return;
+        }
+        int lmax = 0;
+#pragma unroll
+        for (int u = 0; u < SQ_SCORE_CHUNK; u++) { bps[u] = 0.0; lmax = max(lmax, (int)cd[u].len); }
+        for (int t = 0; t < lmax; t += 4) {
+            double v[SQ_SCORE_CHUNK][4];
+#pragma unroll
+            for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
+                const int s = (int)(cd[u].key >> 16), i0 = (int)(cd[u].key & 0xFFFFu), j0 = s - i0, L = (int)cd[u].len;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int tt = max(min(t + k, L - 1), 0);
+                    v[u][k] = cell_exact(i0 + tt, j0 - tt);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
+                const int L = (int)cd[u].len;
+#pragma unroll
+                for (int k = 0; k < 4; k++) bps[u] = bps[u] + (t + k < L ? v[u][k] : 0.0);
+            }
+        }
+    };
+    if (!FULL) {
+        // bpscore filter only (:492): OptimalStems output (mode 1) or the alignment's survivor list (mode 2).  The
+        // survivors of a chunk of SQ_SCORE_CHUNK x blockDim candidates are gathered in LDS and written out with ONE
+        // global atomic per block and chunk: all blocks of a structure append to the same counter, and one atomic
+        // per wave made that counter the bottleneck of long sequences (A5000: 3.2 -> 0.6 ms per 47 sequences).
+        double *s_bps = reinterpret_cast<double *>(s_dyn + surv_off);
+        uint32_t *s_key = reinterpret_cast<uint32_t *>(s_bps + SQ_SCORE_CHUNK * nthr);
+        uint16_t *s_len = reinterpret_cast<uint16_t *>(s_key + SQ_SCORE_CHUNK * nthr);
+        __shared__ uint32_t s_n, s_base;
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        for (uint32_t q0 = blockIdx.y * nthr; q0 < ncand; q0 += SQ_SCORE_CHUNK * qstep) {
+            SqKey cd[SQ_SCORE_CHUNK];
+#pragma unroll
+            for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
+                const uint32_t q = q0 + (uint32_t)u * qstep + tid;
+                cd[u] = q < ncand ? keys[q] : SqKey{0u, 0u};            // (len 0: never appended)
+            }
+            double bpsv[SQ_SCORE_CHUNK];
+            chunk_bps(cd, bpsv);
+#pragma unroll
+            for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
+                const int L = (int)cd[u].len;
+                const double bps = bpsv[u];
+                const bool ok = L > 0 && bps >= minbps;
+                const unsigned long long okm = __ballot(ok);
+                if (okm) {
+                    uint32_t base = 0;
+                    const int leader = __ffsll((long long)okm) - 1;
+                    if ((tid & 63) == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(okm));
+                    base = (uint32_t)__shfl((int)base, leader);
+                    if (ok) {
+                        const uint32_t pos = base + (uint32_t)__popcll(okm & ((1ull << (tid & 63)) - 1ull));
+                        s_key[pos] = cd[u].key; s_len[pos] = (uint16_t)L; s_bps[pos] = bps;
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t ns = s_n;
+            if (tid == 0 && ns) s_base = mode == 1 ? atomicAdd(&a.ctr->nout, ns) : atomicAdd(a.ok_cnt + st.slot, ns);
+            __syncthreads();
+            const uint32_t base = s_base;
+            for (uint32_t k = tid; k < ns; k += nthr) {
+                const uint32_t pos = base + k;
+                if (mode == 1) {
+                    const SqOut r = {(int32_t)blockIdx.x, s_key[k], (int32_t)s_len[k], 0, s_bps[k], 0.0};
+                    if (pos < io.h_cap) io.h_out[pos] = r;              // straight into pinned host memory
+                    else if (pos < io.out_cap) io.d_out[pos] = r;
+                    else a.ctr->out_ovf = 1;
+                } else if (pos < ok_cap) oks[pos] = SqOk{s_key[k], (uint32_t)s_len[k], s_bps[k], 0.0};
+                else a.ctr->cand_ovf = 1;
+            }
+            __syncthreads();
+            if (tid == 0) s_n = 0;
+            __syncthreads();
+        }
+        return;
+    }
+
+    // mode 0.  Two phases per chunk of SQ_SCORE_CHUNK x blockDim candidates: (A) every thread computes the bpscore of its
+    // candidates (cheap: LDS only) and the ones that pass :492 are appended to a list in LDS; (B) ScoreStems runs on
+    // FULL groups of blockDim survivors (its chain of dependent loads is what the kernel waits for, so lanes idling
+    // on rejected candidates were the cost); the remainder (< blockDim) is carried into the next chunk.
+    double *s_bps = reinterpret_cast<double *>(s_dyn + surv_off);
+    uint32_t *s_key = reinterpret_cast<uint32_t *>(s_bps + (SQ_SCORE_CHUNK + 1) * nthr);
+    uint16_t *s_len = reinterpret_cast<uint16_t *>(s_key + (SQ_SCORE_CHUNK + 1) * nthr);
+    __shared__ uint32_t s_nsurv;
+    if (tid == 0) s_nsurv = 0;
+    __syncthreads();
+    for (uint32_t q0 = blockIdx.y * nthr; q0 < ncand; q0 += SQ_SCORE_CHUNK * qstep) {
+        SqKey cd[SQ_SCORE_CHUNK];
+#pragma unroll
+        for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
+            const uint32_t q = q0 + (uint32_t)u * qstep + tid;
+            cd[u] = q < ncand ? keys[q] : SqKey{0u, 0u};                // (len 0: bps 0, never appended)
+        }
+        double bpsv[SQ_SCORE_CHUNK];
+        chunk_bps(cd, bpsv);
+#pragma unroll
+        for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
+            const int L = (int)cd[u].len;
+            const double bps = bpsv[u];
+            const bool ok = L > 0 && bps >= minbps;                     // :492
+            const unsigned long long okm = __ballot(ok);
+            if (okm) {
+                uint32_t base = 0;
+                const int leader = __ffsll((long long)okm) - 1;
+                if ((tid & 63) == leader) base = atomicAdd(&s_nsurv, (uint32_t)__popcll(okm));
+                base = (uint32_t)__shfl((int)base, leader);
+                if (ok) {
+                    const uint32_t pos = base + (uint32_t)__popcll(okm & ((1ull << (tid & 63)) - 1ull));
+                    s_key[pos] = cd[u].key; s_len[pos] = (uint16_t)L; s_bps[pos] = bps;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t ns = s_nsurv;
+        const bool last = q0 + SQ_SCORE_CHUNK * qstep >= ncand;
+        uint32_t done = 0;
+        while (done + (uint32_t)nthr <= ns || (last && done < ns)) {
+            const uint32_t idx = done + tid;
+            done += nthr;
+            const bool have = idx < ns;
+            const uint32_t key = have ? s_key[idx] : 0u;
+            const int L = have ? (int)s_len[idx] : 0;
+            const double bps = have ? s_bps[idx] : 0.0;
+            const int s = (int)(key >> 16), i0 = (int)(key & 0xFFFFu), j0 = s - i0;
+            bool ok = have;
+            double fin = 0.0;
+            if (ok) {
+                const int sa = i0 + L - 1, sb = j0 - L + 1;                 // :655 innermost bp
+                int inblockend = -1, nrec = 0, be0 = 0, be1 = 0, covered = 0, brackets = 0;
+                uint64_t levelset = 0;
+                int lo = 0, hi = st.nstrand;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (S[mid].start <= sa) lo = mid + 1; else hi = mid; }
+                for (int k = lo; k < st.nstrand;) {                         // closed form of the walk :665-689
+                    const SqStrand x = S[k];
+                    if (x.start >= sb) break;
+                    int nk = k + 1;
+                    const int pfirst = x.pstart, plast = x.pstart - (x.len - 1);
+                    bool wing;
+                    if (x.left) {
+                        wing = pfirst > sb;
+                        if (!wing && pfirst > inblockend) {                 // :687-689 sub-ECR face
+                            if (nrec == 0) { be0 = x.start; be1 = pfirst; }
+                            nrec++;
+                            const int from = x.start > inblockend ? x.start : inblockend + 1;
+                            covered += U[pfirst + 1] - U[from];
+                            inblockend = pfirst;
+                            if (lds_strands) nk = s_skip[k];                // nothing inside the block can matter
+                        }
+                    } else {
+                        wing = plast < sa;
+                    }
+                    if (wing && x.start > inblockend) {                     // :679-684
+                        brackets += x.len;
+                        if (x.level > SQ_MAXLEVELS) a.ctr->level_ovf = 1;
+                        else levelset |= 1ull << (x.level - 1);
+                    }
+                    k = nk;
+                }
+                const int dots = (U[sb] - U[sa + 1]) - covered;             // :670-673
+                const bool between = (SU[sb] - SU[sa + 1]) > 0;             // :675-676
+                bool goodloop = false; int diff1 = 0;                       // :692-698
+                if (nrec == 1 && sq_goodloop(be0 - sa - 1, sb - be1 - 1)) {
+                    goodloop = true;
+                    diff1 = abs((be0 - sa - 1) - (sb - be1 - 1));
+                }
+                bool goodloopout = false; int diff2 = 0;                    // :700-711
+                {
+                    // the two outward walks over <= 5 unpaired positions (:702-707), from the prefix counts: the k
+                    // positions next to the stem are all unpaired iff the count over them is k -- ten independent
+                    // reads instead of two chains of dependent ones
+                    const int ui = U[i0], uj = U[j0 + 1];
+                    int cl = 0, cr = 0;
+#pragma unroll
+                    for (int k = 1; k <= 5; k++) {
+                        const int a1 = i0 - k, b1 = j0 + 1 + k;
+                        cl += (a1 >= 0 && ui - U[a1 >= 0 ? a1 : 0] == k) ? 1 : 0;
+                        cr += (b1 <= n && U[b1 <= n ? b1 : n] - uj == k) ? 1 : 0;
+                    }
+                    const int vv = i0 - 1 - cl, ww = j0 + 1 + cr;
+                    if (vv >= 0 && ww < n && P[vv] == ww && sq_goodloop(cl, cr)) {
+                        goodloopout = true;
+                        diff2 = abs(cl - cr);
+                    }
+                }
+                const double lb = ps->loopbonus;
+                const double loopfactor = (1.0 + (lb * (goodloop ? 1.0 : 0.0)) * (2.0 - diff1 / 2.0))
+                                          + (lb * (goodloopout ? 1.0 : 0.0)) * (2.0 - diff2 / 2.0);   // :715
+                bool gnra = false;                                          // :598-604,718
+                if (sb - sa - 1 == 4 && codes[sa + 1] == 6 && (codes[sa + 3] == 6 || codes[sa + 3] == 0) && codes[sa + 4] == 0)
+                    gnra = true;
+                const double tetra = gnra ? 1.25 : 1.0;
+                const double ideal = nrec == 0 ? 4.0 : 2.0;                 // :721
+                const double stemdist = (double)dots + ps->bracketweight * (double)brackets;   // :723
+                const double dd = fabs(stemdist - ideal);
+                double sdf = 1.0;                                           // :726
+                if (!between) {
+                    const int di = (int)dd;
+                    if (ps->bw_integral && di < ps->sdf_len) sdf = c.sdftab[ps->sdf_off + di];
+                    else sdf = pow(1.0 / (1.0 + dd), ps->distcoef);
+                }
+                const double of = ps->oftab[__popcll(levelset)];            // :728-729
+                fin = bps * sdf * of * loopfactor * tetra;                  // :732 (reactfactor == 1)
+                if (!goodloop && !goodloopout && L < 3) fin = -1.0;         // :744-745
+                ok = fin >= minfin;                                         // :751
+            }
+            // survivors are appended to the structure's SqOk list: one atomic per wave, lanes ranked by ballot
+            const unsigned long long okm = __ballot(ok);
+            if (okm) {
+                uint32_t base = 0;
+                const int leader = __ffsll((long long)okm) - 1;
+                if ((tid & 63) == leader) base = atomicAdd(a.ok_cnt + st.slot, (uint32_t)__popcll(okm));
+                base = (uint32_t)__shfl((int)base, leader);
+                if (ok) {
+                    const uint32_t pos = base + (uint32_t)__popcll(okm & ((1ull << (tid & 63)) - 1ull));
+                    if (pos < ok_cap) oks[pos] = SqOk{key, (uint32_t)L, bps, fin};
+                    else a.ctr->cand_ovf = 1;
+                    if (!any || fin > best) { any = 1; best = fin; }        // :769 only the best VALUE matters for the range
+                }
+            }
+        }
+        __syncthreads();                                                    // every thread has read the list
+        const uint32_t rem = ns > done ? ns - done : 0u;                    // < blockDim: carried to the next chunk
+        uint32_t ck = 0; uint16_t cl = 0; double cb = 0.0;
+        if ((uint32_t)tid < rem) { ck = s_key[done + tid]; cl = s_len[done + tid]; cb = s_bps[done + tid]; }
+        __syncthreads();
+        if ((uint32_t)tid < rem) { s_key[tid] = ck; s_len[tid] = cl; s_bps[tid] = cb; }
+        if (tid == 0) s_nsurv = rem;
+        __syncthreads();
+    }
+
+    // wave maximum, then one atomicMax per wave on the structure's slot
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const int oa = __shfl_xor(any, off);
+        if (oa && (!any || ob > best)) { any = 1; best = ob; }
+    }
+    if ((tid & 63) == 0 && any) atomicMax(a.best + st.slot, sq_ord(best));
+}
+
+// mode 0 (the greedy rounds): bpscore filter + ScoreStems, two phases (see the body)
+extern "C" __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SQ_SCORE_WAVES))) void sq_score_kernel(SqDevCtx c, const SqStruct *structs,
+                                                                  const SqStrand *strands, SqState stt, SqScanArgs a,
+                                                                  SqRoundIO io, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off)
+{
+    sq_score_body<true>(c, structs, strands, stt, a, io, 0, lds_n, lds_n_reacts, lds_n_state, surv_off);
+}
+
+// modes 1 / 2 (OptimalStems output, alignment survivor list): the bpscore filter alone, as its own kernel so that its
+// loop is not compiled under the register budget of ScoreStems
+extern "C" __global__ __launch_bounds__(1024) void sq_bps_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands,
+                                                                SqState stt, SqScanArgs a, SqRoundIO io, int mode, int lds_n,
+                                                                int lds_n_reacts, int surv_off)
+{
+    sq_score_body<false>(c, structs, strands, stt, a, io, mode, lds_n, lds_n_reacts, 0, surv_off);
+}
+
+// ChooseStems range filter (:769-778): candidates within subopt * best of the structure's best finalscore
+extern "C" __global__ __launch_bounds__(256) void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a,
+                                                                 SqRoundIO io)
+{
+    const SqStruct st = structs[blockIdx.x];
+    const unsigned long long ob = a.best[st.slot];
+    if (ob == 0ull) return;
+    const SqJob jb = c.jobs[st.job];
+    const uint32_t nok = a.ok_cnt[st.slot];
+    const SqOk *oks = sq_oks(a, st, jb.cand_cap);
+    const double range = st.subopt * sq_unord(ob);                      // :769
+    for (uint32_t q = blockIdx.y * 256 + threadIdx.x; q < nok; q += gridDim.y * 256) {
+        const SqOk cd = oks[q];
+        if (!(cd.fin < range)) {                                        // :778
+            const SqOut r = {(int32_t)blockIdx.x, cd.key, (int32_t)cd.len, 0, cd.bps, cd.fin};
+            sq_put_out(io, a, r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// alignment step 1 (SQRNdbnali.py:233-237): the stems of ONE sequence (structure sidx of the round, already
+// re-scored by sq_score_kernel in mode 2) added into the L x L column matrix through the gap map.  The cells of
+// one sequence's stems are distinct, so plain read-modify-writes are race-free; sequences are separate launches
+// in stream order, which is the reference's summation order per cell.
+// ------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(256) void sq_scatter_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a,
+                                                                   int sidx, const int32_t *cols, int L, double *matrix)
+{
+    const SqStruct st = structs[sidx];
+    const SqJob jb = c.jobs[st.job];
+    const uint32_t nok = a.ok_cnt[st.slot];
+    const SqOk *oks = sq_oks(a, st, jb.cand_cap);
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < nok; q += gridDim.x * 256) {
+        const SqOk cd = oks[q];
+        const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
+        for (int t = 0; t < (int)cd.len; t++) {
+            const int64_t v = cols[i0 + t], w = cols[j0 - t];
+            matrix[v * L + w] += cd.bps;                   // v < w: the lower triangle is mirrored at the end
+        }
+    }
+}
+
+// The same accumulation for ALL sequences of a chunk in one launch (grid.y = structure), with hardware fp64 atomic
+// adds.  Only used when every addend and every partial sum is exactly representable (weights are multiples of
+// 2^-k, no reactivity factors: sq_align_accumulate checks), so the order of the additions cannot change a bit.
+extern "C" __global__ __launch_bounds__(256) void sq_scatter_all_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a,
+                                                                       const int32_t *cols, const int32_t *col_start, int L,
+                                                                       double *matrix)
+{
+    const SqStruct st = structs[blockIdx.y];
+    const SqJob jb = c.jobs[st.job];
+    const uint32_t nok = a.ok_cnt[st.slot];
+    const SqOk *oks = sq_oks(a, st, jb.cand_cap);
+    const int32_t *mycols = cols + col_start[blockIdx.y];
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < nok; q += gridDim.x * 256) {
+        const SqOk cd = oks[q];
+        const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
+        for (int t = 0; t < (int)cd.len; t++) {
+            const int64_t v = mycols[i0 + t], w = mycols[j0 - t];
+            unsafeAtomicAdd(&matrix[v * L + w], cd.bps);   // v < w
+        }
+    }
+}
+
+// lower triangle := transpose of the upper one (32 x 32 tiles through LDS, both sides coalesced)
+extern "C" __global__ __launch_bounds__(256) void sq_mirror_kernel(double *matrix, int L)
+{
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x, by = blockIdx.y;               // tile (by, bx) of the upper triangle: bx >= by
+    if (bx < by) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8 threads
+    for (int r = ty; r < 32; r += 8) {
+        const int v = by * 32 + r, w = bx * 32 + tx;
+        tile[r][tx] = (v < L && w < L) ? matrix[(int64_t)v * L + w] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int w = bx * 32 + r, v = by * 32 + tx;         // writes row w, columns v
+        if (w < L && v < L && v < w) matrix[(int64_t)w * L + v] = tile[tx][r];
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void sq_colselect_kernel(const double *matrix, int L, double thr, int minspan,
+                                                                     long long *idx_out, double *val_out, long long cap,
+                                                                     unsigned long long *count)
+{
+    const int64_t total = (int64_t)L * L;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int v = (int)(q / L), w = (int)(q - (int64_t)v * L);
+        if (w - v < minspan) continue;
+        const double x = matrix[q];
+        if (x >= thr) {
+            const unsigned long long o = atomicAdd(count, 1ull);
+            if ((long long)o < cap) { idx_out[o] = q; val_out[o] = x; }
+        }
+    }
+}

@@ -15,9 +15,6 @@ struct SqMatchJob {
     int64_t scratch_off;  // bytes into the scratch arena
     int64_t out_off;      // ints into the output array (pairs: 2 ints each for Nussinov)
     int64_t pos_off;      // sequence offset into the per-position arrays (Nussinov separators)
-    // blossom: the graph's slice of its block's dynamic LDS and the next graph of the same block (sq_mwm_plan)
-    int32_t lds_off, lds_bytes;
-    int32_t next, pad;
 };
 
 size_t sq_lsap_scratch_bytes(int n);
@@ -27,17 +24,14 @@ size_t sq_mwm_scratch_bytes(int n, int nedges);
 #ifdef __HIPCC__
 int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatchJob *jobs, const SqMatchEdge *edges,
                        size_t nedges, SqMatchEdge *dev_edges, char *d_scr, int32_t *out, int32_t *cnt,
-                       const uint8_t *codes, uint32_t *job_flags, uint32_t flag_val, hipStream_t st,
-                       SqMatchJob *jobs_rw = nullptr, int32_t *bin_head = nullptr, int inflight = 1);
+                       const uint8_t *codes, uint32_t *job_flags, uint32_t flag_val, hipStream_t st);
 extern "C" {
 __global__ void sq_lsap_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch, int32_t *col4row_out,
                                int lds_bytes);
 __global__ void sq_nussinov_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, const uint8_t *codes,
                                    char *scratch, int32_t *pairs_out, int32_t *count_out);
-__global__ void sq_mwm_kernel(const SqMatchJob *jobs, const int32_t *bin_head, const SqMatchEdge *edges, char *scratch,
-                              int32_t *mate_out, uint32_t *job_flags, uint32_t stamp);
-__global__ void sq_mwm_single_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch, int32_t *mate_out,
-                                     int lds_bytes, uint32_t *job_flags, uint32_t stamp);
+__global__ void sq_mwm_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch, int32_t *mate_out,
+                              int lds_bytes, uint32_t *job_flags, uint32_t stamp);
 // one thread, launched behind a matching kernel on its stream: publishes "the results are in host memory"
 __global__ void sq_flag_kernel(uint32_t *flag, uint32_t value);
 }

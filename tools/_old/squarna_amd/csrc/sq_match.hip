@@ -16,10 +16,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
-#include <stdio.h>
 #include "sq_match.h"
-#include <vector>
-#include <algorithm>
 #include "sq_blossom.h"
 
 // ------------------------------------------------------------------------------------
@@ -251,59 +248,54 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
 // ------------------------------------------------------------------------------------
 // Edmonds: one thread per job runs the restated networkx blossom algorithm (sq_blossom.h)
 // ------------------------------------------------------------------------------------
-// One WAVE per graph, several graphs per block ("bin"): the host packs the graphs of a launch into bins by the LDS
-// each one needs (sq_mwm_plan), the block's dynamic LDS is the bin capacity and every wave works in its own slice
-// [lds_off, lds_off + lds_bytes) of it.  A launch-wide LDS size for one-graph blocks gives every graph the LDS of the
-// largest one (SRtest150: 219 graphs, 8 MB of state in total, 29 MB when each gets 133 KB), and the LDS a blossom block
-// holds is LDS the scoring kernels of the batches in flight cannot get.
-// The waves of a bin never synchronise with each other: the "barrier" of the algorithm is a wave-local fence.
-// job_flags (pinned host memory, may be null): job_flags[row] = stamp once the job's mates are in host memory, so the
+// job_flags (pinned host memory, may be null): job_flags[job] = stamp once the job's mates are in host memory, so the
 // host can filter and rank a sequence while the larger graphs are still being matched.
 // mate_out: per job 2n + 2 ints -- mate[0..n), the rank of every vertex's first mate assignment (SqBlossom::mord), then
 // the run's scan passes and lane-0 events (measurement: the critical path of the kernel is passes x cycles per pass)
-// one graph on one wave: bl (the algorithm object) and wlds (lds_bytes of state room) are the wave's LDS, sync its barrier
-template <class Sync>
-__device__ __forceinline__ void sq_mwm_one(SqBlossom &bl, char *lds_base, char *wlds, size_t lds_bytes, const SqMatchJob *jp, int row,
-                                           const SqMatchEdge *edges, char *scratch, int32_t *mate_out, uint32_t *job_flags,
-                                           uint32_t stamp, int lane, Sync wsync)
+extern "C" __global__ __launch_bounds__(64) void sq_mwm_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges,
+                                                               char *scratch, int32_t *mate_out, int lds_bytes,
+                                                               uint32_t *job_flags, uint32_t stamp)
 {
     auto publish = [&]() {
         __threadfence_system();
-        wsync();
-        if (job_flags && lane == 0) job_flags[row] = stamp;
+        __syncthreads();
+        if (job_flags && threadIdx.x == 0) job_flags[blockIdx.x] = stamp;
     };
-    const int n = jp->n, m = jp->nedges;
+    __shared__ SqBlossom bl;          // one wave per job shares the algorithm state
+    extern __shared__ __attribute__((aligned(16))) char mwm_lds[];
+    const SqMatchJob *jp = jobs + blockIdx.x;
+    const int n = jp->n, m = jp->nedges, lane = threadIdx.x;
     if (n <= 0) { if (lane == 0) { mate_out[jp->out_off] = 0; mate_out[jp->out_off + 1] = 0; } publish(); return; }
     // The algorithm is a long chain of dependent loads: keep its state in LDS -- all of it with the edge list when
-    // the slice holds that (tight capacities), else only the hot part (what every scan pass touches; blossom structure
-    // and adjacency stay in global memory); on a capacity overflow rerun the job in global memory.
+    // that fits (tight capacities), else only the hot part (what every scan pass touches; blossom structure and
+    // adjacency stay in global memory); on a capacity overflow rerun the job in global memory.
 #ifdef SQ_MWM_PROF
     const long long _c0 = clock64(), _w0 = wall_clock64();
 #endif
     const size_t ebytes = ((size_t)m * sizeof(SqMatchEdge) + 15) & ~(size_t)15;
     char *gscratch = scratch + jp->scratch_off;
-    const bool all_lds = SqBlossom::scratch_bytes(n, m, 1) + ebytes + 16 <= lds_bytes;
-    const bool hot_lds = !all_lds && SqBlossom::hot_bytes(n, m, 2) + 16 <= lds_bytes;
+    const bool all_lds = SqBlossom::scratch_bytes(n, m, 1) + ebytes + 16 <= (size_t)lds_bytes;
+    const bool hot_lds = !all_lds && SqBlossom::hot_bytes(n, m, 2) + 16 <= (size_t)lds_bytes;
     if (all_lds) {
-        SqMatchEdge *le = reinterpret_cast<SqMatchEdge *>(wlds);
+        SqMatchEdge *le = reinterpret_cast<SqMatchEdge *>(mwm_lds);
         for (int e = lane; e < m; e += 64) le[e] = edges[jp->edge_off + e];
-        wsync();
-        if (lane == 0) { bl.init(n, m, le, wlds + ebytes, 1, false); bl.origin = lds_base; }
-        wsync();
-        bl.build_csr(lane, 64, wsync);
-        bl.template run<1>(lane, 64, wsync, SqCoopWave(), lds_base);
+        __syncthreads();
+        if (lane == 0) { bl.init(n, m, le, mwm_lds + ebytes, 1, false); bl.origin = mwm_lds; }
+        __syncthreads();
+        bl.build_csr(lane, 64, [] { __syncthreads(); });
+        bl.run<1>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), mwm_lds);
     } else if (hot_lds) {
         if (lane == 0) {
             char *cold = gscratch;
-            bl.init(n, m, edges + jp->edge_off, wlds, 2, false, cold, cold + ((SqBlossom::cold_bytes(n, m, 2) + 15) & ~(size_t)15));
-            bl.origin = lds_base;
+            bl.init(n, m, edges + jp->edge_off, mwm_lds, 2, false, cold, cold + ((SqBlossom::cold_bytes(n, m, 2) + 15) & ~(size_t)15));
+            bl.origin = mwm_lds;
         }
-        wsync();
-        bl.build_csr(lane, 64, wsync);
-        bl.template run<2>(lane, 64, wsync, SqCoopWave(), lds_base);
+        __syncthreads();
+        bl.build_csr(lane, 64, [] { __syncthreads(); });
+        bl.run<2>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), mwm_lds);
     }
     if (all_lds || hot_lds) {
-        wsync();
+        __syncthreads();
         if (!bl.error) {
             for (int q = lane; q < n; q += 64) { mate_out[jp->out_off + q] = bl.mate[q]; mate_out[jp->out_off + n + q] = bl.mord[q]; }
             if (lane == 0) { mate_out[jp->out_off + 2 * n] = bl.stat_pass; mate_out[jp->out_off + 2 * n + 1] = bl.stat_event; }
@@ -316,50 +308,17 @@ __device__ __forceinline__ void sq_mwm_one(SqBlossom &bl, char *lds_base, char *
             publish();
             return;
         }
-        wsync();
+        __syncthreads();
     }
     if (lane == 0) bl.init(n, m, edges + jp->edge_off, gscratch, 0, false);
-    wsync();
-    bl.build_csr(lane, 64, wsync);
+    __syncthreads();
+    bl.build_csr(lane, 64, [] { __syncthreads(); });
     // lane 0 runs the order-dependent part; all 64 lanes share the O(n) sweeps of every substage
-    bl.template run<0>(lane, 64, wsync, SqCoopWave(), nullptr);
-    wsync();
+    bl.run<0>(lane, 64, [] { __syncthreads(); }, SqCoopWave(), nullptr);
+    __syncthreads();
     for (int q = lane; q < n; q += 64) { mate_out[jp->out_off + q] = bl.error ? -2 : bl.mate[q]; mate_out[jp->out_off + n + q] = bl.mord[q]; }
     if (lane == 0) { mate_out[jp->out_off + 2 * n] = bl.stat_pass; mate_out[jp->out_off + 2 * n + 1] = bl.stat_event; }
     publish();
-}
-
-// several graphs per block (one per wave), each in its slice of the block's dynamic LDS
-extern "C" __global__ __launch_bounds__(512) void sq_mwm_kernel(const SqMatchJob *jobs, const int32_t *bin_head,
-                                                                const SqMatchEdge *edges, char *scratch, int32_t *mate_out,
-                                                                uint32_t *job_flags, uint32_t stamp)
-{
-    extern __shared__ __attribute__((aligned(16))) char mwm_lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int row = bin_head[blockIdx.x];
-    for (int k = 0; k < wave && row >= 0; k++) row = jobs[row].next;
-    if (row < 0) return;                                  // this bin holds fewer graphs than the block has waves
-    // all lanes of a wave run in lockstep; the fence keeps the compiler (and the memory pipeline) from moving accesses
-    // of one lane across the point where another lane's data is needed
-    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); };
-    const SqMatchJob *jp = jobs + row;
-    // the wave's slice: the algorithm object (shared by the lanes), then the state
-    const size_t hdr = (sizeof(SqBlossom) + 15) & ~(size_t)15;
-    SqBlossom &bl = *reinterpret_cast<SqBlossom *>(mwm_lds + jp->lds_off);
-    const size_t lds_bytes = (size_t)jp->lds_bytes > hdr ? (size_t)jp->lds_bytes - hdr : 0;
-    sq_mwm_one(bl, mwm_lds, mwm_lds + jp->lds_off + hdr, lds_bytes, jp, row, edges, scratch, mate_out, job_flags, stamp, lane, wsync);
-}
-
-// one graph per block (one batch alone: every graph on its own CU): the algorithm object at a fixed LDS address, the
-// block barrier as the wave's barrier; the block's dynamic LDS is the graph's (rows = blocks)
-extern "C" __global__ __launch_bounds__(64) void sq_mwm_single_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch,
-                                                                     int32_t *mate_out, int lds_bytes, uint32_t *job_flags,
-                                                                     uint32_t stamp)
-{
-    __shared__ SqBlossom bl;
-    extern __shared__ __attribute__((aligned(16))) char mwm_lds[];
-    sq_mwm_one(bl, mwm_lds, mwm_lds, (size_t)lds_bytes, jobs + blockIdx.x, (int)blockIdx.x, edges, scratch, mate_out, job_flags, stamp,
-               (int)threadIdx.x, [] { __syncthreads(); });
 }
 
 extern "C" __global__ void sq_flag_kernel(uint32_t *flag, uint32_t value)
@@ -372,72 +331,9 @@ extern "C" __global__ void sq_flag_kernel(uint32_t *flag, uint32_t value)
 // by the fold path (sq_algos.hip) and the graph-level C entries (sq_graph.hip).  jobs / edges: what the kernels read
 // (pinned host or device memory); h_jobs: the same table on the host; dev_edges: device room for the edge list, used
 // only when some blossom job has to run in global memory.  Asynchronous on st.
-// Packs the blossom graphs of one launch into bins (blocks) by LDS need, first fit in decreasing order.
-//   * a graph gets its whole state + edge list in LDS when that is at most `all_cap`, else only the hot part (the rest in
-//     its global scratch), else just the algorithm object (global-memory run);
-//   * a bin holds at most `waves` graphs and `cap` bytes; with one batch in flight every graph has its own block (spread
-//     over the CUs: latency), with several the bins fill up so that all batches' graphs are resident together and the
-//     scoring kernels still find LDS (throughput): waves = ceil(graphs x inflight / 256), cap 150 KB -> 96 KB, all_cap
-//     150 KB -> 48 KB from three batches in flight on.  SQ_MWM_BIN_WAVES / SQ_MWM_BIN_BYTES / SQ_MWM_ALL_CAP override.
-// Writes lds_off / lds_bytes / next of jobs_rw (the table the kernel reads) and bin_head[0..nbins).
-void sq_mwm_plan(const SqMatchJob *h_jobs, SqMatchJob *jobs_rw, int nj, int32_t *bin_head, int inflight, int &nbins, int &waves,
-                 size_t &lds, bool &all_in_lds)
-{
-    static const int env_waves = getenv("SQ_MWM_BIN_WAVES") ? atoi(getenv("SQ_MWM_BIN_WAVES")) : 0;
-    static const long env_cap = getenv("SQ_MWM_BIN_BYTES") ? atol(getenv("SQ_MWM_BIN_BYTES")) : 0;
-    static const long env_all = getenv("SQ_MWM_ALL_CAP") ? atol(getenv("SQ_MWM_ALL_CAP")) : 0;
-    static const bool nolds = getenv("SQ_MWM_NOLDS") != nullptr;
-    const size_t hdr = (sizeof(SqBlossom) + 15) & ~(size_t)15;
-    const bool many = inflight >= 3;
-    size_t cap = env_cap > 0 ? (size_t)env_cap : (many ? 96 * 1024 : 150 * 1024);
-    cap = std::min<size_t>(cap, 150 * 1024);
-    const size_t all_cap = env_all > 0 ? (size_t)env_all : (many ? 48 * 1024 : 150 * 1024);
-    waves = env_waves > 0 ? env_waves : (int)(((long long)nj * std::max(1, inflight) + 255) / 256);
-    waves = std::max(1, std::min(waves, 8));
-    std::vector<size_t> need(nj);
-    all_in_lds = true;
-    for (int q = 0; q < nj; q++) {
-        const int n = h_jobs[q].n, m = h_jobs[q].nedges;
-        const size_t full = SqBlossom::scratch_bytes(n, m, 1) + (((size_t)m * sizeof(SqMatchEdge) + 15) & ~(size_t)15) + 16;
-        const size_t hot = SqBlossom::hot_bytes(n, m, 2) + 16;
-        size_t take = hdr;
-        if (n > 0 && !nolds) {
-            if (hdr + full <= std::min(all_cap, cap)) take = hdr + full;
-            else if (hdr + hot <= cap) take = hdr + hot;
-        }
-        if (n > 0 && take != hdr + full) all_in_lds = false;
-        need[q] = (take + 15) & ~(size_t)15;
-    }
-    std::vector<int> ord(nj);
-    for (int q = 0; q < nj; q++) ord[q] = q;
-    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return need[x] > need[y]; });
-    std::vector<size_t> used; std::vector<int> cnt, tail;
-    nbins = 0; lds = 0;
-    size_t first_open = 0;                               // bins before it are full (by count)
-    for (int r = 0; r < nj; r++) {
-        const int q = ord[r];
-        size_t k = first_open;
-        while (k < used.size() && (cnt[k] >= waves || used[k] + need[q] > cap)) k++;
-        if (k == used.size()) { used.push_back(0); cnt.push_back(0); tail.push_back(-1); bin_head[k] = q; nbins++; }
-        else jobs_rw[tail[k]].next = q;
-        jobs_rw[q].lds_off = (int32_t)used[k]; jobs_rw[q].lds_bytes = (int32_t)need[q]; jobs_rw[q].next = -1;
-        used[k] += need[q]; cnt[k]++; tail[k] = q;
-        lds = std::max(lds, used[k]);
-        while (first_open < used.size() && cnt[first_open] >= waves) first_open++;
-    }
-    lds = (lds + 255) & ~(size_t)255;
-    if (getenv("SQ_MWM_DUMP")) {
-        size_t tot = 0; int nfull = 0;
-        for (int q = 0; q < nj; q++) { tot += need[q]; nfull += need[q] > hdr + SqBlossom::hot_bytes(h_jobs[q].n, h_jobs[q].nedges, 2) + 32; }
-        fprintf(stderr, "[mwm plan] %d graphs (inflight %d): %d bins of <= %d waves, %zu B of LDS per block, %zu B needed in all, %d graphs fully in LDS\n",
-                nj, inflight, nbins, waves, lds, tot, nfull);
-    }
-}
-
 int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatchJob *jobs, const SqMatchEdge *edges,
                        size_t nedges, SqMatchEdge *dev_edges, char *d_scr, int32_t *out, int32_t *cnt,
-                       const uint8_t *codes, uint32_t *job_flags, uint32_t flag_val, hipStream_t st,
-                       SqMatchJob *jobs_rw, int32_t *bin_head, int inflight)
+                       const uint8_t *codes, uint32_t *job_flags, uint32_t flag_val, hipStream_t st)
 {
     int maxn = 0, maxm = 0;
     for (int q = 0; q < nj; q++) { maxn = maxn > h_jobs[q].n ? maxn : h_jobs[q].n; maxm = maxm > h_jobs[q].nedges ? maxm : h_jobs[q].nedges; }
@@ -453,26 +349,27 @@ int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatch
     } else if (algo == 2) {                              // SQ_ALGO_N
         hipLaunchKernelGGL(sq_nussinov_kernel, dim3(nj), dim3(256), 0, st, jobs, edges, codes, d_scr, out, cnt);
     } else {                                             // SQ_ALGO_E
-        // bins: see sq_mwm_plan.  The plan writes each job's LDS slice into the job table the kernel reads.
-        int nbins = 0, waves = 1; size_t lds = 0; bool all_in_lds = true;
-        sq_mwm_plan(h_jobs, jobs_rw, nj, bin_head, inflight, nbins, waves, lds, all_in_lds);
+        // dynamic LDS for the blossom state of the largest job (up to 150 KiB of the CU's 160)
+        size_t want = SqBlossom::scratch_bytes(maxn, maxm, 1) + (((size_t)maxm * sizeof(SqMatchEdge) + 15) & ~(size_t)15) + 64;
         static bool attr_set = false;
-        if (!attr_set) { hipFuncSetAttribute((const void *)sq_mwm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr_set = true; }
-        if (!all_in_lds) {
-            // some job keeps its adjacency in global memory and walks the edges in place: give the launch a device copy
+        if (!attr_set) { hipFuncSetAttribute((const void *)sq_mwm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        static const bool nolds = getenv("SQ_MWM_NOLDS") != nullptr;
+        if (want > 150 * 1024 || nolds) {
+            // some job does not fit LDS and walks its edges in place: give those a device copy of the edge list
             hipError_t e = hipMemcpyAsync(dev_edges, edges, nedges * sizeof(SqMatchEdge), hipMemcpyHostToDevice, st);
             if (e != hipSuccess) return (int)e;
             edges = dev_edges;
         }
-        if (waves == 1) {
-            // one graph per block: blocks in table order, every block with the LDS of the launch's largest graph
-            static bool attr1 = false;
-            if (!attr1) { hipFuncSetAttribute((const void *)sq_mwm_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr1 = true; }
-            const size_t hdr = (sizeof(SqBlossom) + 15) & ~(size_t)15;
-            const size_t one = lds > hdr ? lds - hdr : 0;
-            hipLaunchKernelGGL(sq_mwm_single_kernel, dim3(nj), dim3(64), one, st, jobs, edges, d_scr, out, (int)one, job_flags, flag_val);
-        } else
-            hipLaunchKernelGGL(sq_mwm_kernel, dim3(nbins), dim3(64 * waves), lds, st, jobs, bin_head, edges, d_scr, out, job_flags, flag_val);
+        static const size_t lds_cap = getenv("SQ_MWM_LDS_CAP") ? (size_t)atol(getenv("SQ_MWM_LDS_CAP")) : 150 * 1024;
+        if (want > lds_cap) {                            // (graphs above the cap keep only the hot part of their state in LDS)
+            hipError_t e = edges == dev_edges ? hipSuccess : hipMemcpyAsync(dev_edges, edges, nedges * sizeof(SqMatchEdge), hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) return (int)e;
+            edges = dev_edges;
+            want = lds_cap;
+        }
+        if (want > 150 * 1024) want = 150 * 1024;        // jobs that do not fit run in global memory
+        if (nolds) want = 0;
+        hipLaunchKernelGGL(sq_mwm_kernel, dim3(nj), dim3(64), want, st, jobs, edges, d_scr, out, (int)want, job_flags, flag_val);
     }
     return (int)hipGetLastError();
 }

@@ -1,0 +1,740 @@
+"""HIP engine: batches sequences, owns the device workspace (a torch uint8 tensor) and
+drives libsquarna_hip.so through its C ABI.  PyTorch is plumbing here (device memory,
+stream, torch.distributed); all arithmetic runs in the hand-written gfx950 kernels.
+
+There is NO CPU fallback: without the built library or without a GPU the engine raises.
+Tests may install another engine with :func:`use_engine` (tests/ only use that to check
+the host-side text layer on CPU against the oracle).
+"""
+import ctypes as C
+import os
+import struct
+import contextlib
+
+import numpy as np
+
+from . import _lib
+from .dbn import (gap_mask, GAPS, SEPS, ReactDict, ProcessReacts, DBNToPairs, UnAlign, ReAlign,
+                  ParseRestraints, levels_to_dbn, encode_seq, BRACKETS)
+
+
+_STEM_DT = np.dtype([("i", "<i4"), ("j", "<i4"), ("len", "<i4"), ("reserved", "<i4"),
+                     ("bpscore", "<f8"), ("finscore", "<f8")])
+
+
+class Prepared:
+    """One input record after the host pre-processing of SQRNdbnseq.py:1001-1037."""
+    __slots__ = ("seq", "shortseq", "shortrest", "shortreacts", "shortdbn", "rbps", "rxs",
+                 "rlefts", "rrights", "gapidx", "sepidx", "plain_reacts")
+
+    def __init__(self, seq, reacts=None, restraints=None, dbn=None):
+        seq = seq.upper().replace("T", "U")                          # :1004
+        if not restraints:
+            restraints = '.' * len(seq)                              # :1007-1008
+        assert len(seq) == len(restraints), "Invalid restraints given"
+        self.plain_reacts = not reacts                               # all 0.5: the batch fills them in one go
+        if not reacts:
+            reacts = [0.5] * len(seq)                                # :1013-1014
+        assert len(reacts) == len(seq), "Invalid reactivities given"
+        if type(reacts) == str:                                      # :1019-1020 (default B = 1.6)
+            reacts = ProcessReacts([ReactDict[ch] for ch in reacts])
+        self.seq = seq
+        self.shortseq, self.shortrest = UnAlign(seq, restraints)     # :1023
+        if '-' in seq or '.' in seq or '~' in seq:
+            gaps = gap_mask(seq)
+            self.gapidx = np.flatnonzero(gaps).tolist()
+        else:
+            gaps, self.gapidx = None, []
+        self.sepidx = [i for i, ch in enumerate(seq) if ch in SEPS] if (';' in seq or '&' in seq) else []
+        if self.plain_reacts:
+            self.shortreacts = [0.5] * len(self.shortseq)
+        elif not self.gapidx:
+            self.shortreacts = list(reacts)
+        else:
+            self.shortreacts = np.asarray(reacts, dtype=np.float64)[~gaps].tolist()
+        self.shortdbn = None
+        if dbn:
+            assert len(seq) == len(dbn)
+            self.shortseq, self.shortdbn = UnAlign(seq, dbn)         # :1026-1028
+        self.rbps, self.rxs, self.rlefts, self.rrights = ParseRestraints(self.shortrest)   # :1037
+
+
+_HDR = struct.Struct("<4q")
+_MET = struct.Struct("<16d")
+_MASK_IDS = [[q for q in range(4) if (m >> q) & 1] for m in range(16)]
+
+#: code points of the bracket characters by signed level (+L opening, -L closing, 0 dot; levels beyond the
+#: alphabet print as dots, SQRNdbnseq.py:142-143), indexed by level + _NBR + 1
+_NBR = len(BRACKETS)
+_LEVEL_CP = np.full(2 * _NBR + 3, ord('.'), np.uint32)
+for _l in range(1, _NBR + 1):
+    _LEVEL_CP[_NBR + 1 + _l] = ord(BRACKETS[_l - 1][0])
+    _LEVEL_CP[_NBR + 1 - _l] = ord(BRACKETS[_l - 1][1])
+
+
+def _pset_struct(ps):
+    out = _lib.ParamSet()
+    for key, val in ps["bpweights"].items():                         # SQRNdbnseq.py:282-284
+        a, b = encode_seq(key)
+        if a > 25 or b > 25:
+            raise ValueError("bpweights keys must be two letters: %r" % key)
+        out.bpweight[a * 32 + b] = val
+        out.inbps[a * 32 + b] = 1
+        out.bpweight[b * 32 + a] = val
+        out.inbps[b * 32 + a] = 1
+    out.bpp = float(ps.get("bpp", 0))
+    for k in ("suboptmax", "suboptmin", "suboptsteps", "minlen", "minbpscore", "minfinscorefactor",
+              "bracketweight", "distcoef", "orderpenalty", "loopbonus", "maxstemnum"):
+        setattr(out, k, float(ps[k]))
+    out.algorithms = sum(_lib.ALGO_BITS[a] for a in ps["algorithms"])
+    return out
+
+
+def _ptr(a, t=C.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+class Batch:
+    """A device-resident batch of fold jobs (one per (record, paramset))."""
+
+    def __init__(self, prepared, psets_per_record, interchainonly=False, ext=None, mul=None,
+                 max_structs=0, cand_per_nt=0, device=None, fp32=True, bpp=None):
+        """fp32=False leaves the fp32 score matrices out of the workspace (4 N^2 bytes per job): everything
+        but fill() works -- folding only needs the 1-bit-per-cell matrices."""
+        import torch
+        L = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("squarna_amd needs an AMD GPU (MI355X / gfx950): torch.cuda is not "
+                               "available and there is no CPU fallback")
+        self.torch = torch
+        self.L = L
+        self.prepared = prepared
+        nseq = len(prepared)
+        self.seq_off = np.zeros(nseq + 1, np.int32)
+        for k, p in enumerate(prepared):
+            self.seq_off[k + 1] = self.seq_off[k] + len(p.shortseq)
+        ltot = int(self.seq_off[-1])
+        self.codes = np.frombuffer(encode_seq(''.join(p.shortseq for p in prepared)), np.uint8).copy() \
+            if ltot else np.zeros(1, np.uint8)
+        self.flags = np.zeros(max(ltot, 1), np.uint8)
+        self.reacts = np.full(max(ltot, 1), 0.5, np.float64)
+        rbp_off = [0]
+        rbps = []
+        for k, p in enumerate(prepared):
+            o = int(self.seq_off[k])
+            for i in p.rxs:
+                self.flags[o + i] |= 1
+            for i in p.rlefts:
+                self.flags[o + i] |= 2
+            for i in p.rrights:
+                self.flags[o + i] |= 4
+            if not p.plain_reacts:
+                self.reacts[o:o + len(p.shortseq)] = p.shortreacts
+            rbps.extend(p.rbps)
+            rbp_off.append(len(rbps))
+        self.rbp_off = np.array(rbp_off, np.int32)
+        self.rbps = np.array(rbps, np.int32).reshape(-1) if rbps else np.zeros(2, np.int32)
+        # unique paramsets by identity
+        uniq, self.psets_py = {}, []
+        job_seq, job_pset = [], []
+        self.seq_jobs = []
+        for k, plist in enumerate(psets_per_record):
+            mine = []
+            for ps in plist:
+                if id(ps) not in uniq:
+                    uniq[id(ps)] = len(self.psets_py)
+                    self.psets_py.append(ps)
+                mine.append(len(job_seq))
+                job_seq.append(k)
+                job_pset.append(uniq[id(ps)])
+            self.seq_jobs.append(mine)
+        self.psets_c = (_lib.ParamSet * len(self.psets_py))(*[_pset_struct(p) for p in self.psets_py])
+        self.job_seq = np.array(job_seq, np.int32)
+        self.job_pset = np.array(job_pset, np.int32)
+        njobs = len(job_seq)
+        d = _lib.BatchDesc()
+        d.nseq = nseq
+        d.seq_off = _ptr(self.seq_off, C.POINTER(C.c_int32))
+        d.codes = _ptr(self.codes, C.POINTER(C.c_uint8))
+        d.flags = _ptr(self.flags, C.POINTER(C.c_uint8))
+        d.reacts = _ptr(self.reacts, C.POINTER(C.c_double))
+        d.rbp_off = _ptr(self.rbp_off, C.POINTER(C.c_int32))
+        d.rbps = _ptr(self.rbps, C.POINTER(C.c_int32))
+        d.npset = len(self.psets_py)
+        d.psets = self.psets_c
+        d.njobs = njobs
+        d.job_seq = _ptr(self.job_seq, C.POINTER(C.c_int32))
+        d.job_pset = _ptr(self.job_pset, C.POINTER(C.c_int32))
+        self._keep = []
+
+        def ptr_array(mats):
+            arr = (C.c_void_p * njobs)()
+            for j, m in enumerate(mats):
+                if m is not None:
+                    m = np.ascontiguousarray(m, dtype=np.float64)
+                    self._keep.append(m)
+                    arr[j] = m.ctypes.data
+            return arr
+
+        if ext is not None:
+            self._eb = ptr_array([e[0] if e is not None else None for e in ext])
+            self._es = ptr_array([e[1] if e is not None else None for e in ext])
+            d.ext_bool = C.cast(self._eb, C.POINTER(C.c_void_p))
+            d.ext_score = C.cast(self._es, C.POINTER(C.c_void_p))
+        if mul is not None:
+            self._mul = ptr_array(mul)
+            d.mul_score = C.cast(self._mul, C.POINTER(C.c_void_p))
+        if bpp is not None:                                          # per job: (bppm/max)**|bpp| or None (SQRNdbnseq.py:350-364)
+            self._bpp = ptr_array(bpp)
+            d.bpp_term = C.cast(self._bpp, C.POINTER(C.c_void_p))
+        d.interchainonly = int(bool(interchainonly))
+        d.max_structs = int(max_structs)
+        d.cand_per_nt = int(cand_per_nt)
+        d.batch_flags = 0 if fp32 else _lib.BATCH_NO_FP32
+        self.desc = d
+        nbytes = C.c_size_t(0)
+        _lib.check(L.sq_batch_workspace_bytes(C.byref(d), C.byref(nbytes)))
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
+        base = self.workspace.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        _lib.check(L.sq_batch_create(C.byref(h), C.byref(d), C.c_void_p(aligned),
+                                     C.c_size_t(nbytes.value), C.c_void_p(self.stream.cuda_stream)))
+        self.h = h
+        self._refs = None
+        self.njobs = njobs
+        self.nseq = nseq
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sq_batch_destroy(self.h)
+            self.h = None
+            self.workspace = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- a-1
+    def fill(self):
+        _lib.check(self.L.sq_bpmatrix_fill(self.h))
+
+    def bpmatrix(self, job):
+        n = int(self.seq_off[self.job_seq[job] + 1] - self.seq_off[self.job_seq[job]])
+        b = np.zeros((n, n)); s = np.zeros((n, n))
+        _lib.check(self.L.sq_bpmatrix_read(self.h, job, _ptr(b), _ptr(s)))
+        return b, s
+
+    # -- a-2..a-6
+    def optimal(self, struct_job, struct_stems, subopt=None, mode=0, out_cap=None, as_array=False):
+        """struct_stems: list (per structure) of (i, j, len) tuples -> list of lists of
+        (i, j, len, bpscore, finalscore)."""
+        ns = len(struct_job)
+        sj = np.array(struct_job, np.int32)
+        off = np.zeros(ns + 1, np.int32)
+        flat = []
+        for k, st in enumerate(struct_stems):
+            flat.extend(st)
+            off[k + 1] = len(flat)
+        stems = (_lib.Stem * max(len(flat), 1))()
+        for k, t in enumerate(flat):
+            stems[k].i, stems[k].j, stems[k].len = int(t[0]), int(t[1]), int(t[2])
+        so = np.array(subopt if subopt is not None else [1.0] * ns, np.float64)
+        if out_cap is None:
+            out_cap = 1 << 16 if mode == 0 else 1 << 20
+        out = (_lib.Stem * out_cap)()
+        out_off = np.zeros(ns + 1, np.int32)
+        _lib.check(self.L.sq_optimal_stems(self.h, ns, _ptr(sj), _ptr(off), stems, _ptr(so), mode,
+                                           out, out_cap, _ptr(out_off)))
+        if as_array:                                                   # structured views, no per-stem objects
+            arr = np.frombuffer(out, dtype=_STEM_DT, count=int(out_off[ns])).copy()
+            return [arr[out_off[k]:out_off[k + 1]] for k in range(ns)]
+        res = []
+        for k in range(ns):
+            res.append([(out[q].i, out[q].j, out[q].len, out[q].bpscore, out[q].finscore)
+                        for q in range(out_off[k], out_off[k + 1])])
+        return res
+
+    # -- alignment step 1
+    def align_accumulate(self, jobs, cols_per_job, matrix):
+        """Adds the stem scores of the listed jobs, in order, into the device L x L fp64 tensor `matrix`
+        through the gap maps cols_per_job[k] (unaligned index -> column); SQRNdbnali.py:233-237."""
+        L = int(matrix.shape[0])
+        assert matrix.dtype == self.torch.float64 and matrix.is_contiguous() and tuple(matrix.shape) == (L, L)
+        ja = np.array(jobs, np.int32)
+        off = np.zeros(len(jobs) + 1, np.int32)
+        for k, c in enumerate(cols_per_job):
+            off[k + 1] = off[k] + len(c)
+        cols = np.concatenate([np.asarray(c, np.int32) for c in cols_per_job]) if len(jobs) else np.zeros(1, np.int32)
+        cols = np.ascontiguousarray(cols, np.int32)
+        _lib.check(self.L.sq_align_accumulate(self.h, len(jobs), _ptr(ja), _ptr(off), _ptr(cols), L,
+                                              C.c_void_p(matrix.data_ptr())))
+
+    # -- a-8 / a-9 / Nussinov
+    def run_algo(self, jobs, algo, levellimit=None, out_cap=1 << 16):
+        """RunAlgo (SQRNdbnseq.py:548-595) for the listed jobs under 'E', 'H' or 'N':
+        list (per job) of (i, j, len, score, score)."""
+        nj = len(jobs)
+        ja = np.array(jobs, np.int32)
+        out = (_lib.Stem * out_cap)()
+        off = np.zeros(nj + 1, np.int32)
+        _lib.check(self.L.sq_run_algos(self.h, nj, _ptr(ja), _lib.ALGO_BITS[algo],
+                                       -1 if levellimit is None else int(levellimit), out, out_cap, _ptr(off)))
+        return [[(out[q].i, out[q].j, out[q].len, out[q].bpscore, out[q].finscore)
+                 for q in range(off[k], off[k + 1])] for k in range(nj)]
+
+    # -- a-7 + a-10
+    def fold(self, **opts):
+        """priority: per record, set of local paramset indices (or one set for all)."""
+        o, ref_off, rp, has = self._fold_args(**opts)
+        _lib.check(self.L.sq_fold(self.h, C.byref(o), _ptr(ref_off), _ptr(rp), _ptr(has)))
+
+    def _fold_args(self, poollim=1000, conslim=1, toplim=5, hardrest=False, rankbydiff=False,
+                   rankby=(0, 2, 1), levellimit=None, algos=frozenset(), priority=None):
+        o = _lib.FoldOpts()
+        o.poollim, o.conslim, o.toplim = int(poollim), int(conslim), int(toplim)
+        o.hardrest, o.rankbydiff = int(bool(hardrest)), int(bool(rankbydiff))
+        for t in range(3):
+            o.rankby[t] = int(rankby[t])
+        o.levellimit = -1 if levellimit is None else int(levellimit)
+        o.algos = sum(_lib.ALGO_BITS[a] for a in algos)
+        mask = 0
+        for p in (priority or ()):
+            mask |= 1 << int(p)
+        o.priority_mask = mask
+        if self._refs is None:                       # reference pairs are static per batch
+            ref_off = np.zeros(self.nseq + 1, np.int32)
+            has = np.zeros(max(self.nseq, 1), np.uint8)
+            refs = []
+            for k, p in enumerate(self.prepared):
+                if p.shortdbn:
+                    has[k] = 1
+                    refs.extend(DBNToPairs(p.shortdbn))
+                ref_off[k + 1] = len(refs)
+            rp = np.array(refs, np.int32).reshape(-1) if refs else np.zeros(2, np.int32)
+            self._refs = (ref_off, rp, has)
+        ref_off, rp, has = self._refs
+        return o, ref_off, rp, has
+
+    def result(self, k, with_ref=False):
+        """SQRNdbnseq return tuple of record k (SQRNdbnseq.py:1285-1286); with_ref: (tuple, reference scores or None)."""
+        L = self.L
+        nbytes = L.sq_result_pack_size(self.h, k)
+        buf = bytearray(nbytes)
+        cbuf = (C.c_char * nbytes).from_buffer(buf)
+        _lib.check(L.sq_result_pack(self.h, k, cbuf, nbytes))
+        out = self._unpack(k, buf, 0)
+        return out if with_ref else out[0]
+
+    def results_all(self):
+        """[(SQRNdbnseq tuple, reference scores or None)] for every record, from ONE sq_result_pack_all call: the whole
+        dot-bracket rows come as ASCII text from one sq_result_dbn_all call, headers / scores / masks through numpy views; a
+        record then costs a few slices (records with gap columns, separators or > 30 pseudoknot levels take the per-record
+        path)."""
+        buf, off = self.pack_all()
+        raw = buf.tobytes()
+        # the dot-bracket rows of every record as ASCII, formed by the library in one call
+        tbytes = int(self.L.sq_result_dbn_all_size(self.h))
+        tbuf = np.zeros(max(tbytes, 8), np.uint8)
+        toff = np.zeros(self.nseq + 1, np.int64)
+        deep = np.zeros(max(self.nseq, 1), np.uint8)
+        _lib.check(self.L.sq_result_dbn_all(self.h, _ptr(tbuf), tbytes, _ptr(toff), _ptr(deep)))
+        text_all = tbuf[:tbytes].tobytes().decode('latin-1')
+        toffl, deepl = toff.tolist(), deep.tolist()
+        # headers, metrics, scores and masks of all records through numpy views (the records start 8-byte aligned)
+        q = np.frombuffer(raw, '<i8', len(raw) // 8)
+        d = np.frombuffer(raw, '<f8', len(raw) // 8)
+        b8 = (off[:-1] // 8).astype(np.int64)
+        ns_a, n_a, ref_a = q[b8].tolist(), q[b8 + 1].tolist(), q[b8 + 2].tolist()
+        met_a = d[b8[:, None] + (4 + np.arange(16))].tolist()
+        b8l = b8.tolist()
+        nan6, nan7 = [np.nan] * 6, [np.nan] * 7
+        out = []
+        for k in range(self.nseq):
+            p = self.prepared[k]
+            if p.gapidx or p.sepidx or deepl[k]:
+                out.append(self._unpack(k, raw, int(off[k])))
+                continue
+            ns, n, sb = ns_a[k], n_a[k], b8l[k] + 20
+            sc = d[sb:sb + 3 * ns].tolist()
+            mk = q[sb + 3 * ns:sb + 4 * ns].tolist()
+            t0 = toffl[k]                                          # the record's rows in text_all
+            preds = [(text_all[t0 + (t + 1) * n:t0 + (t + 2) * n], tuple(sc[3 * t:3 * t + 3]),
+                      list(_MASK_IDS[mk[t]]) if mk[t] < 16 else [b for b in range(64) if (mk[t] >> b) & 1]) for t in range(ns)]
+            if ref_a[k]:
+                met = met_a[k]
+                out.append(((text_all[t0:t0 + n], preds, _metrics(met[:6]), _metrics(met[6:12]) + [int(met[12])]), tuple(met[13:16])))
+            else:
+                out.append(((text_all[t0:t0 + n], preds, list(nan6), list(nan7)), None))
+        return out
+
+    def _unpack(self, k, buf, base):
+        ns, n, has_ref, evals = _HDR.unpack_from(buf, base)
+        met = _MET.unpack_from(buf, base + 32)
+        o = base + 160
+        scores = struct.unpack_from("<%dd" % (3 * ns), buf, o); o += 24 * ns
+        masks = struct.unpack_from("<%dQ" % ns, buf, o); o += 8 * ns
+        p = self.prepared[k]
+        seq = p.seq
+        if True:
+            lev = np.frombuffer(buf, np.int16, (ns + 1) * n, o).reshape(ns + 1, n)
+            # levels -> bracket characters for all rows at once (code-point table), gap columns and separators
+            # re-inserted with array assignments (SQRNdbnseq.py:1239-1246)
+            cp = _LEVEL_CP[np.clip(lev, -_NBR - 1, _NBR + 1) + (_NBR + 1)]                     # (ns+1, n) uint32
+            if p.gapidx or p.sepidx:
+                full = np.full((ns + 1, len(seq)), ord('.'), np.uint32)
+                keep = np.ones(len(seq), bool)
+                keep[p.gapidx] = False
+                full[:, keep] = cp
+                for i in p.sepidx:
+                    full[:, i] = ord(seq[i])
+                cp = full
+            width = cp.shape[1]
+            text = cp.tobytes().decode('utf-32-le')
+        cons = text[:width]
+        preds = []
+        for t in range(ns):
+            m = masks[t]
+            preds.append((text[(t + 1) * width:(t + 2) * width], scores[3 * t:3 * t + 3],
+                          list(_MASK_IDS[m]) if m < 16 else [q for q in range(64) if (m >> q) & 1]))
+        if has_ref:
+            consres = _metrics(met[:6])
+            res = _metrics(met[6:12]) + [int(met[12])]
+            return (cons, preds, consres, res), tuple(met[13:16])
+        return (cons, preds, [np.nan] * 6, [np.nan] * 7), None
+
+    def pack_all(self):
+        """(uint8 array, int64 offsets[nseq + 1]): the packed results of every record (sq_result_pack_all) -- the
+        payload of the multi-GPU result gather."""
+        nbytes = int(self.L.sq_result_pack_all_size(self.h))
+        buf = np.zeros(max(nbytes, 8), np.uint8)
+        off = np.zeros(self.nseq + 1, np.int64)
+        _lib.check(self.L.sq_result_pack_all(self.h, _ptr(buf), nbytes, _ptr(off)))
+        return buf[:nbytes], off
+
+    def evals(self, k):
+        return int(self.L.sq_result_evals(self.h, k))
+
+    # -- measurement
+    def profile(self, on=True):
+        self.L.sq_profile_enable(self.h, int(on))
+
+    def profile_reset(self):
+        self.L.sq_profile_reset(self.h)
+
+    def mwm_counters(self):
+        """Blossom kernel work since the last profile_reset: dict(graphs, passes, and the critical graph's
+        max_passes, max_events, n, m) -- sq_profile_counters."""
+        out = (C.c_int64 * 6)()
+        _lib.check(self.L.sq_profile_counters(self.h, 4, out))
+        return dict(zip(("graphs", "passes", "max_passes", "max_events", "n", "m"), [int(x) for x in out]))
+
+    def profile_get(self, kernel):
+        ms, n, by = C.c_double(), C.c_int64(), C.c_double()
+        _lib.check(self.L.sq_profile_get(self.h, kernel, C.byref(ms), C.byref(n), C.byref(by)))
+        return ms.value, n.value, by.value
+
+
+def _metrics(m):
+    """[TP, FP, FN, FS, PR, RC] with the reference's int/float types: a ratio whose
+    denominator is empty is the int 1, everything else a rounded float
+    (SQRNdbnseq.py:1256-1258,1273-1275)."""
+    tp, fp, fn = int(m[0]), int(m[1]), int(m[2])
+    fs = float(m[3]) if 2 * tp + fp + fn else 1
+    pr = float(m[4]) if tp + fp else 1
+    rc = float(m[5]) if tp + fn else 1
+    return [tp, fp, fn, fs, pr, rc]
+
+
+def fold_concurrently(batches, **opts):
+    """Fold several batches at the same time (sq_fold_concurrent: one host thread per batch inside the library):
+    while one batch's host code books a round, the kernels of the others keep the GPU busy.  Batches are
+    independent, so the results are the ones of folding them one after the other."""
+    args = [b._fold_args(**opts) for b in batches]
+    n = len(batches)
+    hs = (C.c_void_p * n)(*[b.h for b in batches])
+    offs = (C.c_void_p * n)(*[a[1].ctypes.data for a in args])
+    rps = (C.c_void_p * n)(*[a[2].ctypes.data for a in args])
+    has = (C.c_void_p * n)(*[a[3].ctypes.data for a in args])
+    _lib.check(batches[0].L.sq_fold_concurrent(hs, n, C.byref(args[0][0]), offs, rps, has))
+
+
+def vienna_bpp(shortseq, reacts, M=1.8, B=-0.6):
+    """Base-pair probability matrix of one sequence exactly as the reference obtains it (SQRNdbnseq.py:342-364):
+    ViennaRNA's partition function (with SHAPE pseudo-energies when reactivities are given), rescaled once when all
+    probabilities vanish.  Host-side third-party code, outside the accelerated path; None when max(bppm) == 0."""
+    try:
+        import RNA
+    except ImportError:
+        raise RuntimeError("this configuration has bpp != 0 paramsets, which need ViennaRNA's Python module `RNA` "
+                           "on the host (SQRNdbnseq.py:341-364); it is not installed. Use a config without bpp "
+                           "(e.g. c=nobpp) or install ViennaRNA.") from None
+    fc = RNA.fold_compound(''.join(ch if ch not in SEPS and ord(ch) <= 127 else 'N' for ch in shortseq))
+    if reacts is not None and set(reacts) != {0.5}:
+        fc.sc_add_SHAPE_deigan(ProcessReacts(list(reacts), reverse=True, M=M, B=B), m=M, b=B)
+    fc.pf()
+    bppm = np.array(fc.bpp())[1:, 1:]
+    if np.max(bppm) > 0:
+        return bppm
+    (ss, mfe) = fc.mfe()
+    fc.exp_params_rescale(mfe)
+    fc.pf()
+    bppm = np.array(fc.bpp())[1:, 1:]
+    return bppm if np.max(bppm) > 0 else None
+
+
+_bpp_provider = vienna_bpp
+
+
+def set_bpp_provider(fn):
+    """Replace the source of base-pair probabilities (fn(shortseq, reacts, M, B) -> N x N array or None)."""
+    global _bpp_provider
+    old, _bpp_provider = _bpp_provider, (fn or vienna_bpp)
+    return old
+
+
+def bpp_terms(prepared, psets, M=1.8, B=-0.6):
+    """Per job (record-major, paramset-minor) the dense term the fill applies for bpp != 0 paramsets:
+    (bppm / max(bppm)) ** |bpp|  (SQRNdbnseq.py:350-354), or None.  Returns None when no paramset needs one."""
+    if not any(ps.get("bpp", 0) for pl in psets for ps in pl):
+        return None
+    out = []
+    for p, pl in zip(prepared, psets):
+        bppm = None
+        if any(ps.get("bpp", 0) for ps in pl):
+            bppm = _bpp_provider(p.shortseq, p.shortreacts, M, B)    # once per sequence
+            if bppm is not None:
+                bppm = np.asarray(bppm, dtype=np.float64)
+        for ps in pl:
+            power = ps.get("bpp", 0)
+            if power and bppm is not None:
+                out.append(np.ascontiguousarray((bppm / np.max(bppm)) ** abs(power)))
+            else:
+                out.append(None)
+    return out
+
+
+class HipEngine:
+    """Default engine: everything on the GPU through libsquarna_hip.so."""
+    name = "hip"
+
+    def __init__(self, max_structs=0, cand_per_nt=0):
+        self.max_structs = max_structs
+        self.cand_per_nt = cand_per_nt
+        #: per record of the last fold_records call: ScoreStruct of its known structure (C tail) or None
+        self.last_ref_scores = None
+
+    def fold_records(self, records, **opts):
+        """records: list of (seq, reacts, restraints, dbn, paramsets, stemmatrix);
+        returns the list of SQRNdbnseq return tuples, in order."""
+        # Building tens of thousands of small containers (Prepared records, result tuples) with the cyclic collector on
+        # costs ~10 us per record in generation scans of objects that hold no cycles: 220 of 340 ms for 10,000 records.
+        import gc
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            return self._fold_records(records, **opts)
+        finally:
+            if was:
+                gc.enable()
+
+    def _fold_records(self, records, **opts):
+        interchainonly = opts.pop("interchainonly", False)
+        M, B = opts.pop("M", 1.8), opts.pop("B", -0.6)
+        prepared = [Prepared(r[0], r[1], r[2], r[3]) for r in records]
+        psets = [r[4] for r in records]
+        bpp = bpp_terms(prepared, psets, M, B)
+        mul = None
+        if any(len(r) > 5 and r[5] is not None for r in records):
+            mul = []
+            for r, p in zip(records, prepared):
+                sm = r[5] if len(r) > 5 else None
+                if sm is not None:                                   # :1031-1034
+                    sm = np.delete(np.delete(np.asarray(sm, dtype=np.float64), p.gapidx, 0), p.gapidx, 1)
+                mul.extend([sm] * len(r[4]))
+        nrec = len(records)
+        # SQ_ENGINE_LANES=2 folds big inputs as two concurrent batches; for one-shot calls the second batch's set-up
+        # (pinned buffers, worker pool) costs more than the overlap saves, so it is opt-in (long-lived batches
+        # profit: fold_concurrently / sq_fold_concurrent)
+        lanes = int(os.environ.get("SQ_ENGINE_LANES", "1"))
+        cost = [float(len(p.shortseq)) ** 2 * len(pl) for p, pl in zip(prepared, psets)]
+        if lanes < 2 or nrec < 256 or sum(cost) < 1e8:
+            with Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
+                       max_structs=self.max_structs, cand_per_nt=self.cand_per_nt) as b:
+                b.fold(**opts)
+                both = b.results_all()
+                self.last_ref_scores = [r[1] for r in both]
+                return [r[0] for r in both]
+        # big inputs: two batches folded concurrently (sq_fold_concurrent) -- the host bookkeeping of one overlaps
+        # the kernels of the other; records are independent, so the split does not change any result
+        from .parallel import lpt_partition
+        parts = [p for p in lpt_partition(cost, 2) if p]
+        job0 = np.cumsum([0] + [len(pl) for pl in psets])
+        batches = []
+        try:
+            for q, idx in enumerate(parts):
+                def pick(seq, per_job):
+                    if seq is None:
+                        return None
+                    return [x for k in idx for x in seq[job0[k]:job0[k + 1]]] if per_job else [seq[k] for k in idx]
+                batches.append(Batch(pick(prepared, False), pick(psets, False), interchainonly=interchainonly,
+                                     mul=pick(mul, True), bpp=pick(bpp, True), fp32=False,
+                                     max_structs=self.max_structs, cand_per_nt=self.cand_per_nt))
+            fold_concurrently(batches, **opts)
+            out = [None] * nrec
+            self.last_ref_scores = [None] * nrec
+            for b, idx in zip(batches, parts):
+                for (res, refsc), k in zip(b.results_all(), idx):
+                    out[k] = res
+                    self.last_ref_scores[k] = refsc
+            return out
+        finally:
+            for b in batches:
+                b.close()
+
+    def yield_stems(self, records, bpweights, minlen, minbpscore, interchainonly=False):
+        """Alignment step 1 (SQRNdbnali.py:60-108): for every (seq, reacts, restraints) the stems of
+        the gap-free sequence in emission order.  Returns [(shortseq, [(i, j, len, score), ...])]."""
+        ps = dict(bpweights=bpweights, bpp=0, algorithms={"G"}, suboptmax=1.0, suboptmin=1.0, suboptsteps=1.0,
+                  minlen=minlen, minbpscore=minbpscore, minfinscorefactor=1.0, bracketweight=-2.0, distcoef=0.09,
+                  orderpenalty=1.0, loopbonus=0.125, maxstemnum=1e6)
+        prepared = []
+        for seq, reacts, restraints in records:
+            p = Prepared(seq, reacts if reacts else None, restraints, None)
+            if not reacts:
+                p.shortreacts = [0.5] * len(p.shortseq)                # YieldStems passes reacts=None (:83)
+                p.plain_reacts = True
+            prepared.append(p)
+        out, cap = [], 1 << 21
+        est = [int(0.25 * len(p.shortseq) ** 2 * 0.375 ** (max(minlen, 1) - 1)) + 256 for p in prepared]
+        lo = 0
+        while lo < len(prepared):                                      # chunks sized to the stem buffer
+            hi, tot = lo, 0
+            while hi < len(prepared) and (hi == lo or tot + est[hi] <= cap):
+                tot += est[hi]
+                hi += 1
+            chunk = prepared[lo:hi]
+            with Batch(chunk, [[ps]] * len(chunk), interchainonly=interchainonly, max_structs=self.max_structs,
+                       cand_per_nt=max(self.cand_per_nt, 64), fp32=False) as b:
+                res = b.optimal(list(range(len(chunk))), [[] for _ in chunk], mode=1, out_cap=max(cap, tot),
+                                as_array=True)
+            out.extend((p.shortseq, st) for p, st in zip(chunk, res))
+            lo = hi
+        return out
+
+    def stem_matrix(self, records, bpweights, minlen, minbpscore, interchainonly=False):
+        """Alignment step 1 on the device (SQRNdbnali.py:211-242 without MatrixToDBNs): the L x L fp64 column
+        matrix of stem scores over all (seq, reacts, restraints) records, as a torch tensor on the GPU.
+        Sequences are applied in order, one scatter launch each, so every cell is summed in the reference's
+        order; nothing but the gap maps crosses PCIe."""
+        import torch
+        ps = dict(bpweights=bpweights, bpp=0, algorithms={"G"}, suboptmax=1.0, suboptmin=1.0, suboptsteps=1.0,
+                  minlen=minlen, minbpscore=minbpscore, minfinscorefactor=1.0, bracketweight=-2.0, distcoef=0.09,
+                  orderpenalty=1.0, loopbonus=0.125, maxstemnum=1e6)
+        Lcols = len(records[0][0])
+        dev = torch.device("cuda", torch.cuda.current_device())
+        matrix = torch.zeros((Lcols, Lcols), dtype=torch.float64, device=dev)
+        prepared, cols = [], []
+        for seq, reacts, restraints in records:
+            p = Prepared(seq, reacts if reacts else None, restraints, None)
+            if not reacts:
+                p.shortreacts = [0.5] * len(p.shortseq)                # YieldStems passes reacts=None (:83)
+                p.plain_reacts = True
+            prepared.append(p)
+            cols.append(np.flatnonzero(~gap_mask(seq)).astype(np.int32))   # ReAlignDict (:20-37)
+        # chunks of sequences sized to ~24 GB of bit matrices + candidates
+        lo = 0
+        while lo < len(prepared):
+            hi, cells = lo, 0
+            while hi < len(prepared) and (hi == lo or cells + len(prepared[hi].shortseq) ** 2 <= 16e9):
+                cells += len(prepared[hi].shortseq) ** 2
+                hi += 1
+            chunk = prepared[lo:hi]
+            with Batch(chunk, [[ps]] * len(chunk), interchainonly=interchainonly, max_structs=self.max_structs,
+                       cand_per_nt=max(self.cand_per_nt, 64), fp32=False) as b:
+                b.align_accumulate(list(range(len(chunk))), cols[lo:hi], matrix)
+                torch.cuda.synchronize(dev)
+            lo = hi
+        return matrix
+
+    def matrix_cells(self, matrix, threshold, minspan=4):
+        """(flat indices, values) of the upper cells >= threshold with span >= minspan of a device matrix,
+        sorted by flat index (MatrixToDBNs' candidates, SQRNdbnali.py:127-148)."""
+        import torch
+        Lcols = int(matrix.shape[0])
+        cap = 1 << 16
+        stream = torch.cuda.current_stream(matrix.device)
+        while True:                                                # result buffers are torch tensors (caller-owned)
+            idx = torch.empty(cap, dtype=torch.int64, device=matrix.device)
+            val = torch.empty(cap, dtype=torch.float64, device=matrix.device)
+            cnt = torch.zeros(1, dtype=torch.int64, device=matrix.device)
+            _lib.check(_lib.load().sq_colmatrix_select(C.c_void_p(matrix.data_ptr()), Lcols, float(threshold), int(minspan),
+                                                       C.c_void_p(idx.data_ptr()), C.c_void_p(val.data_ptr()), cap,
+                                                       C.c_void_p(cnt.data_ptr()), C.c_void_p(stream.cuda_stream)))
+            n = int(cnt.item())
+            if n <= cap:
+                break
+            cap = n
+        idx, val = idx[:n].cpu().numpy(), val[:n].cpu().numpy()
+        order = np.argsort(idx, kind="stable")
+        return idx[order], val[order]
+
+    def entropy(self, record, interchainonly=False):
+        """Mean row entropy of the stem matrix under the FIRST paramset, as a string
+        (SQRNdbnseq.py:520-545, 1087-1089); the stems come from the GPU scan (mode 1)."""
+        seq, reacts, restraints, dbn, paramsets = record[:5]
+        p = Prepared(seq, reacts, restraints, dbn)
+        ps = paramsets[0]
+        mul = None
+        sm = record[5] if len(record) > 5 else None
+        if sm is not None:                                           # alignment step 2: bpscorematrix * shortsmat
+            mul = [np.delete(np.delete(np.asarray(sm, dtype=np.float64), p.gapidx, 0), p.gapidx, 1)]   # (:1031-1034,1084-1085)
+        with Batch([p], [[ps]], interchainonly=interchainonly, max_structs=self.max_structs, mul=mul,
+                   cand_per_nt=max(self.cand_per_nt, 64)) as b:
+            stems = b.optimal([0], [[]], mode=1)[0]
+        n = len(p.shortseq)
+        sm = np.zeros((n, n))
+        for i, j, ln, sc, _ in stems:
+            for k in range(ln):
+                sm[i + k, j - k] = sc
+                sm[j - k, i + k] = sc
+        ent = 0
+        for i in range(n):
+            row = sm[i, :]
+            if row.sum():
+                probs = [q for q in row / row.sum() if q]
+                ent += sum(-(probs * np.log2(probs)))
+        return str(round(ent / n, 3))
+
+
+_engine = None
+
+
+def get_engine():
+    global _engine
+    if _engine is None:
+        _engine = HipEngine()
+    return _engine
+
+
+@contextlib.contextmanager
+def use_engine(engine):
+    """Temporarily install another engine (tests only)."""
+    global _engine
+    old = _engine
+    _engine = engine
+    try:
+        yield engine
+    finally:
+        _engine = old

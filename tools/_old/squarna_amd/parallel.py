@@ -1,0 +1,173 @@
+"""Multi-GPU driver: independent input records are sharded over the ranks of one node
+(one process per GPU, torch.distributed; backend "nccl" == RCCL over xGMI on MI355X), every
+rank folds its own shard, and ONE collective at the end gathers the printed blocks to rank 0,
+which emits them in input order (the reference's ordered ``Pool.imap``, SQUARNA.py:887-935).
+There is no exchange inside the data path.
+"""
+import io
+import sys
+
+import numpy as np
+
+
+def lpt_partition(costs, world):
+    """Longest-processing-time-first: deal records (heaviest first) to the least loaded rank.
+    Returns a list of index lists, one per rank."""
+    order = sorted(range(len(costs)), key=lambda k: (-costs[k], k))
+    load = [0.0] * world
+    parts = [[] for _ in range(world)]
+    for k in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        parts[r].append(k)
+        load[r] += costs[k]
+    return [sorted(p) for p in parts]
+
+
+def _collective_device(device=None, group=None):
+    """Where the tensors of a collective must live: the caller's choice, else the current GPU under the
+    "nccl" backend (RCCL has no CPU tensors), else the CPU (gloo)."""
+    import torch
+    import torch.distributed as dist
+    if device is not None:
+        return torch.device(device)
+    if "nccl" in str(dist.get_backend(group)).lower():
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def gather_blocks(blocks, total, device=None, group=None):
+    """blocks: {record index: text}.  Returns the full ordered list on rank 0, None elsewhere.
+    One all_gather of sizes + one all_gather of a packed uint8 payload (RCCL on GPU ranks)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    idx = sorted(blocks)
+    payload = [blocks[k].encode() for k in idx]
+    head = np.array([len(idx)] + [v for k, b in zip(idx, payload) for v in (k, len(b))], dtype=np.int64)
+    body = np.frombuffer(head.tobytes() + b''.join(payload), dtype=np.uint8)
+    dev = _collective_device(device, group)
+    size = torch.tensor([body.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, size, group=group)
+    cap = int(max(int(s.item()) for s in sizes))
+    mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    mine[:body.size] = torch.from_numpy(body.copy()).to(dev)
+    parts = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    if rank != 0:
+        return None
+    out = [None] * total
+    for r in range(world):
+        raw = parts[r][:int(sizes[r].item())].cpu().numpy().tobytes()
+        n = int(np.frombuffer(raw[:8], dtype=np.int64)[0])
+        meta = np.frombuffer(raw[8:8 + 16 * n], dtype=np.int64).reshape(n, 2)
+        off = 8 + 16 * n
+        for k, ln in meta:
+            out[int(k)] = raw[off:off + int(ln)].decode()
+            off += int(ln)
+    assert all(b is not None for b in out), "a record was not folded by any rank"
+    return out
+
+
+class ShardedAlignEngine:
+    """Alignment mode over the ranks of a group: every rank owns a CONTIGUOUS block of the alignment's
+    sequences (balanced on N^2), accumulates the partial L x L stem matrix of its block, and ONE
+    all_reduce(sum) per step-1 iteration (RCCL over xGMI on GPU ranks) makes the full matrix available to
+    every rank; MatrixToDBNs then runs replicated.  Step-2 folds are sharded the same way and exchanged with
+    one all_gather.  Within a block the per-cell summation order is the reference's; across blocks the
+    all_reduce adds the partial sums in ring order, so cells of non-dyadic scores can differ from the
+    sequential sum in the last bits (dyadic bpweights without reactivities -- ali.conf -- are exact)."""
+
+    def __init__(self, base, group=None):
+        import torch.distributed as dist
+        self.base, self.group = base, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if hasattr(base, "stem_matrix"):
+            self.stem_matrix = self._stem_matrix
+            self.matrix_cells = base.matrix_cells
+
+    def _block(self, lens):
+        cost = np.cumsum([0.0] + [float(n) * n for n in lens])
+        cut = [int(np.searchsorted(cost, cost[-1] * r / self.world, side="left")) for r in range(self.world + 1)]
+        cut[0], cut[-1] = 0, len(lens)
+        return cut[self.rank], max(cut[self.rank], cut[self.rank + 1])
+
+    @staticmethod
+    def _ungapped(seq):
+        return sum(1 for ch in seq if ch not in "-.~")
+
+    def _stem_matrix(self, records, bpweights, minlen, minbpscore, interchainonly=False):
+        import torch
+        lo, hi = self._block([self._ungapped(r[0]) for r in records])
+        if hi > lo:
+            return self.base.stem_matrix(records[lo:hi], bpweights, minlen, minbpscore, interchainonly)
+        n = len(records[0][0])
+        return torch.zeros((n, n), dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+
+    def yield_stems(self, records, bpweights, minlen, minbpscore, interchainonly=False):
+        lo, hi = self._block([self._ungapped(r[0]) for r in records])
+        mine = self.base.yield_stems(records[lo:hi], bpweights, minlen, minbpscore, interchainonly) if hi > lo else []
+        blank = [("", [])] * len(records)                        # sequences of other ranks add nothing here
+        return blank[:lo] + list(mine) + blank[hi:]
+
+    def reduce_matrix(self, matrix):
+        import torch
+        import torch.distributed as dist
+        if isinstance(matrix, np.ndarray):                     # (host matrices: engines without stem_matrix)
+            t = torch.from_numpy(np.ascontiguousarray(matrix)).to(_collective_device(None, self.group))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return t.cpu().numpy()
+        dist.all_reduce(matrix, op=dist.ReduceOp.SUM, group=self.group)
+        return matrix
+
+    def entropy(self, record, interchainonly=False):
+        return self.base.entropy(record, interchainonly=interchainonly)
+
+    def fold_records(self, recs, **kw):
+        import torch.distributed as dist
+        lo, hi = self._block([self._ungapped(r[0]) for r in recs])
+        mine = self.base.fold_records(recs[lo:hi], **kw) if hi > lo else []
+        parts = [None] * self.world
+        dist.all_gather_object(parts, (lo, list(mine)), group=self.group)
+        out = [None] * len(recs)
+        for start, items in parts:
+            out[start:start + len(items)] = items
+        return out
+
+
+def PredictSharded(write_to=None, device=None, **kwargs):
+    """`Predict` across the ranks of an initialised torch.distributed group.
+    Same keyword arguments (and synonyms) as `Predict`; rank 0 writes the complete output in input order.
+    Single-sequence mode: byte-identical to the single-process output (records are independent).
+    Alignment mode: byte-identical when every partial sum is exact (dyadic bpweights -- all shipped configs --
+    and no reactivity factors); otherwise the all_reduce adds the per-rank partial matrices in a different
+    fp64 order than the reference's sequential loop (SQRNdbnali.py:233-237), so cells may differ in the last bits.
+    `device`: where the collective's tensors live; default = the current GPU under "nccl" (RCCL), CPU under gloo."""
+    import torch.distributed as dist
+    from .api import Predict
+    assert dist.is_initialized(), "initialise torch.distributed first (torchrun)"
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if any(kwargs.get(k) for k in ("alignment", "ali", "a")):
+        # alignment mode: sequences of the MSA are sharded, one all_reduce per step-1 iteration
+        from . import engine as _engine
+        buf = io.StringIO()
+        with _engine.use_engine(ShardedAlignEngine(_engine.get_engine())):
+            Predict(write_to=buf, **kwargs)
+        if rank == 0:
+            (write_to if write_to is not None else sys.stdout).write(buf.getvalue())
+            return [buf.getvalue()]
+        return None
+    # record lengths from Predict's own parsing (same synonyms, same HOME_DIR lookup, same warnings policy), so the
+    # shard every rank computes is the shard Predict folds; cost model: N^2 per record
+    lens = Predict(write_to=io.StringIO(), _lengths_only=True, **kwargs)
+    parts = lpt_partition([float(n) * n for n in lens], world)
+    blocks = {}
+    Predict(write_to=io.StringIO(), _select=set(parts[rank]), _on_block=lambda k, t: blocks.__setitem__(k, t),
+            **kwargs)
+    out = gather_blocks(blocks, len(lens), device=device)
+    if rank == 0:
+        sink = write_to if write_to is not None else sys.stdout
+        for b in out:
+            sink.write(b)
+    return out

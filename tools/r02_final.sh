@@ -1,0 +1,11 @@
+#!/bin/bash
+# Round-end measurement pass (on the MI355X box): bench line, rocprof kernel stats of the same command, strong-scaling
+# legs at world size 1, the K sweep, the GPU test log.  Everything lands in gpurun_out/final/ (copy into profiles/).
+out=gpurun_out/final; mkdir -p $out
+python bench.py --steps 20 --warmup 3 2> $out/bench.err | tail -1 > $out/r02_bench.json
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu > /tmp/bstats.log 2>&1 )
+cp $(find /tmp/bstats -name "*kernel_stats.csv" | head -1) $out/r02_bench_kernel_stats.csv
+{ for w in S300 S1000 S2000; do python bench.py --workload $w --steps 10 --warmup 2 2>/dev/null | tail -1; done; } > $out/r02_sharded_world1.txt
+{ for k in 1 2 4 6 8 12 16; do python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=|CPU"; done; } > $out/r02_concurrency.txt
+python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids | tail -5 > $out/r02_gputest.txt
+ls -la $out

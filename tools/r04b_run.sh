@@ -1,2 +1,19 @@
-python tools/shard_probe.py S300 6 2>&1 | tail -3
-SQ_TIMING=1 python tools/s1000_probe.py 10000 300 3 --noprof 2>&1 | grep -E "chained|fold ms|total" | tail -4
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror|assert" | tail -8
+python tools/algo_probe.py E 5 2>&1 | grep "^E:" | tr '\n' ' '; echo
+for k in 1 2 3 8; do python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=" | cut -c1-100; done
+python - <<'PY'
+import sys, os
+sys.path.insert(0, os.getcwd())
+import torch, bench
+from squarna_amd.config import ParseConfig, builtin_config
+from squarna_amd.engine import Batch, Prepared
+recs = bench.load_srtest150()
+names, psets = ParseConfig(builtin_config("nobpp"))
+prepared = [Prepared(seq, reacts, restr, ref) for _, seq, reacts, restr, ref in recs]
+with Batch(prepared, [psets] * len(prepared), fp32=False) as b0:
+    b0.fold(poollim=1000)
+    b0.profile(True); b0.profile_reset()
+    for _ in range(3): b0.fold(poollim=1000)
+    torch.cuda.synchronize()
+    print({nm: round(b0.profile_get(k)[0] / 3, 3) for k, nm in enumerate(["bits", "state", "scan", "score_select", "edmonds", "hungarian", "nussinov"])})
+PY
