@@ -227,31 +227,6 @@ struct SqBlossom {
         }
     }
 
-    // The same adjacency, built by all lanes: every lane owns the vertices v = lane, lane + nl, ... and walks the
-    // edge list once to count and once to fill, so each list keeps the edge order without atomics.
-    template <class Sync>
-    SQ_HD void build_csr(int lane, int nl, Sync sync)
-    {
-        for (int v = lane; v < n; v += nl) {
-            int deg = 0;
-            for (int e = 0; e < m; e++) deg += (E[e].v == v) + (E[e].w == v);
-            adj_off[v + 1] = deg;
-        }
-        if (lane == 0) adj_off[0] = 0;
-        sync();
-        if (lane == 0) for (int v = 0; v < n; v++) adj_off[v + 1] += adj_off[v];
-        sync();
-        for (int v = lane; v < n; v += nl) {
-            int pos = adj_off[v];
-            for (int e = 0; e < m; e++) {
-                const SqMatchEdge ed = E[e];
-                if (ed.v == v) { adj[pos] = 2 * e;     adjv[pos] = ed.w; adjw[pos] = ed.weight; pos++; }
-                if (ed.w == v) { adj[pos] = 2 * e + 1; adjv[pos] = ed.v; adjw[pos] = ed.weight; pos++; }
-            }
-        }
-        sync();
-    }
-
     // FAST: which parts of the state live in the kernel's dynamic LDS buffer (1: everything incl. the edge list, 2: only
     // the hot part, 0: nothing).  Every array access goes through SQ_LP (hot arrays) / SQ_LQ (cold, edge arrays, E):
     // with the array in LDS the address is formed as <dynamic LDS base> + offset, which lets the compiler prove the
@@ -601,6 +576,36 @@ struct SqBlossom {
     int red_k[3];
     int red_i[64][2];                 // per lane: (blossom, queue position) of the queue refill
 
+    // The same adjacency, built by all lanes: every lane owns the vertices v = lane, lane + nl, ... and walks the
+    // edge list once to count and once to fill, so each list keeps the edge order without atomics.  (FAST as in run():
+    // the walks are ds_read / ds_write when the arrays are in LDS -- through generic pointers they were flat loads, half
+    // of the kernel's 0.86 M vector-memory instructions on SRtest150.)
+    template <int FAST, class Sync>
+    SQ_HD void build_csr(int lane, int nl, Sync sync)
+    {
+        const SqMatchEdge *const E_ = SQ_LQ(E);
+        int *const adj_off_ = SQ_LP(adj_off), *const adj_ = SQ_LQ(adj), *const adjv_ = SQ_LQ(adjv);
+        double *const adjw_ = SQ_LQ(adjw);
+        for (int v = lane; v < n; v += nl) {
+            int deg = 0;
+            for (int e = 0; e < m; e++) deg += (E_[e].v == v) + (E_[e].w == v);
+            adj_off_[v + 1] = deg;
+        }
+        if (lane == 0) adj_off_[0] = 0;
+        sync();
+        if (lane == 0) for (int v = 0; v < n; v++) adj_off_[v + 1] += adj_off_[v];
+        sync();
+        for (int v = lane; v < n; v += nl) {
+            int pos = adj_off_[v];
+            for (int e = 0; e < m; e++) {
+                const SqMatchEdge ed = E_[e];
+                if (ed.v == v) { adj_[pos] = 2 * e;     adjv_[pos] = ed.w; adjw_[pos] = ed.weight; pos++; }
+                if (ed.w == v) { adj_[pos] = 2 * e + 1; adjv_[pos] = ed.v; adjw_[pos] = ed.weight; pos++; }
+            }
+        }
+        sync();
+    }
+
     // FAST: the edges and all state arrays live in ONE LDS buffer whose address the caller passes as `fast0`
     // (and as `origin`, its generic address).  The hot loops then address the arrays as fast0 + offset, which lets
     // the compiler prove the address space and emit ds_read/ds_write instead of flat loads through the LDS aperture.
@@ -624,8 +629,10 @@ struct SqBlossom {
         sync();
         if (n == 0) return;
         {
-            double maxweight = 0;                               // every lane computes the same value
-            for (int e = 0; e < m; e++) if (E[e].v != SQ_LQ(E)[e].w && SQ_LQ(E)[e].weight > maxweight) maxweight = SQ_LQ(E)[e].weight;
+            double negmax = 0;                                  // max over the edges, shared among the lanes (weights >= 0)
+            for (int e = lane; e < m; e += nl) { const SqMatchEdge ed = SQ_LQ(E)[e]; if (ed.v != ed.w && -ed.weight < negmax) negmax = -ed.weight; }
+            coop.min_plain(negmax);
+            const double maxweight = -negmax;
             for (int v = lane; v < n; v += nl) SQ_LP(dualvar)[v] = maxweight;
         }
         sync();

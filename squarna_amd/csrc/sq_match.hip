@@ -290,7 +290,7 @@ __device__ __forceinline__ void sq_mwm_one(SqBlossom &bl, char *lds_base, char *
         wsync();
         if (lane == 0) { bl.init(n, m, le, wlds + ebytes, 1, false); bl.origin = lds_base; }
         wsync();
-        bl.build_csr(lane, 64, wsync);
+        bl.template build_csr<1>(lane, 64, wsync);
         bl.template run<1>(lane, 64, wsync, SqCoopWave(), lds_base);
     } else if (hot_lds) {
         if (lane == 0) {
@@ -299,7 +299,7 @@ __device__ __forceinline__ void sq_mwm_one(SqBlossom &bl, char *lds_base, char *
             bl.origin = lds_base;
         }
         wsync();
-        bl.build_csr(lane, 64, wsync);
+        bl.template build_csr<2>(lane, 64, wsync);
         bl.template run<2>(lane, 64, wsync, SqCoopWave(), lds_base);
     }
     if (all_lds || hot_lds) {
@@ -320,7 +320,7 @@ __device__ __forceinline__ void sq_mwm_one(SqBlossom &bl, char *lds_base, char *
     }
     if (lane == 0) bl.init(n, m, edges + jp->edge_off, gscratch, 0, false);
     wsync();
-    bl.build_csr(lane, 64, wsync);
+    bl.template build_csr<0>(lane, 64, wsync);
     // lane 0 runs the order-dependent part; all 64 lanes share the O(n) sweeps of every substage
     bl.template run<0>(lane, 64, wsync, SqCoopWave(), nullptr);
     wsync();

@@ -1,6 +1,4 @@
 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror|assert" | tail -8
-python tools/algo_probe.py E 5 2>&1 | grep "^E:" | tr '\n' ' '; echo
-for k in 1 2 3 8; do python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=" | cut -c1-100; done
 python - <<'PY'
 import sys, os
 sys.path.insert(0, os.getcwd())
@@ -17,3 +15,4 @@ with Batch(prepared, [psets] * len(prepared), fp32=False) as b0:
     torch.cuda.synchronize()
     print({nm: round(b0.profile_get(k)[0] / 3, 3) for k, nm in enumerate(["bits", "state", "scan", "score_select", "edmonds", "hungarian", "nussinov"])})
 PY
+for k in 1 8; do python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=" | cut -c1-100; done
