@@ -496,7 +496,16 @@ def main():
         dt = float(t.item())
 
     # ---- secondary, OUTSIDE the timed region ----------------------------------------------------------------------
-    b0 = batches[0]
+    results = [batches[0].result(k) for k in range(len(prepared))]
+    fs_c, fs_b = mean_fs(results)
+    evals = sum(batches[0].evals(k) for k in range(len(prepared)))
+    same = all(repr(b.result(k)) == repr(results[k]) for b in batches[1:] for k in range(0, len(prepared), 7))
+    for b in batches:
+        b.close()
+    # one batch alone, set up as a caller with a single batch would (its own worker pool, nothing else in flight)
+    b0 = Batch(prepared, [psets] * len(prepared), fp32=False)
+    for _ in range(3):
+        b0.fold(poollim=1000)
     lat = []
     for _ in range(10):                                       # one batch alone: the latency of a single fold
         torch.cuda.synchronize()
@@ -517,12 +526,8 @@ def main():
     mwm = b0.mwm_counters()
     b0.profile(False)
 
-    results = [b0.result(k) for k in range(len(prepared))]
-    fs_c, fs_b = mean_fs(results)
-    evals = sum(b0.evals(k) for k in range(len(prepared)))
-    same = all(repr(b.result(k)) == repr(results[k]) for b in batches[1:] for k in range(0, len(prepared), 7))
-    for b in batches:
-        b.close()
+    same = same and all(repr(b0.result(k)) == repr(results[k]) for k in range(0, len(prepared), 5))
+    b0.close()
 
     pmc, pmc_note = load_pmc()
     rooflines = []
@@ -592,7 +597,7 @@ def main():
                    "evals_R_per_step": int(evals) * K, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
         "single_batch": {"ms_per_fold": round(lat[len(lat) // 2], 3), "best_ms": round(lat[0], 3),
                          "seq_per_s": round(len(prepared) / lat[len(lat) // 2] * 1e3, 1),
-                         "how": "ONE 219-record batch alone (nothing else in flight), median / best of 10 folds"},
+                         "how": "ONE 219-record batch alone (a fresh batch, nothing else in flight), median / best of 10 folds"},
         "host": {"cpu_ms_per_step": round(host_cpu / args.steps * 1e3, 1), "busy_cpus": round(host_cpu / dt, 1),
                  "cpu_quota": effective_cpus(),
                  "note": "rank 0's process CPU time inside the timed region; with the quota's worth of CPUs busy the step is "

@@ -1755,6 +1755,8 @@ extern "C" int sq_fold_concurrent(sq_batch *const *batches, int32_t nbatch, cons
     for (int k = 1; k < nbatch; k++) th.emplace_back(work, k);
     work(0);
     for (auto &t : th) t.join();
+    // (a later fold of one of these batches alone is a fold with one batch in flight)
+    for (int k = 0; k < nbatch; k++) if (batches[k]) { batches[k]->inflight = 1; batches[k]->side_streams = 3; }
     for (int k = 0; k < nbatch; k++) if (rc[k]) { sq_set_error(msg[k]); return rc[k]; }
     return 0;
 }

@@ -9,3 +9,11 @@ cp $(find /tmp/bstats -name "*kernel_stats.csv" | head -1) $out/r02_bench_kernel
 { for k in 1 2 4 6 8 12 16; do python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=|CPU"; done; } > $out/r02_concurrency.txt
 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids | tail -5 > $out/r02_gputest.txt
 ls -la $out
+{ python tools/predict_probe.py S300 3; python tools/predict_probe.py S1000 3; } 2>&1 | grep Predict > $out/r02_predict.txt
+{ echo "== device-chained rounds (poollim 1): randomised parity against the CPU oracle"; 
+  FUZZ_POOLLIM=1 python tools/fuzz_parity.py 3000 fastest 11 2>&1 | grep -E "records|MISMATCH|oracle";
+  FUZZ_POOLLIM=1 python tools/fuzz_parity.py 1500 nobpp 12 2>&1 | grep -E "records|MISMATCH|oracle";
+  FUZZ_POOLLIM=1 FUZZ_NMIN=200 FUZZ_NMAX=700 python tools/fuzz_parity.py 300 fastest 13 2>&1 | grep -E "records|MISMATCH|oracle";
+  echo "== poollim 1000 (host-driven rounds, blossom graphs in packed blocks)";
+  python tools/fuzz_parity.py 2000 nobpp 14 2>&1 | grep -E "records|MISMATCH|oracle"; } > $out/r02_fuzz_add.txt
+cat $out/r02_predict.txt $out/r02_fuzz_add.txt
