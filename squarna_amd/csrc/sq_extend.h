@@ -1,0 +1,150 @@
+// sq_extend.h -- one structure + one stem on the device: the stem-level crossing weights, the pseudoknot levels of all
+// strands (PairsToDBN's rule at stem level, SQRNdbnseq.py:104-150: order by (crossing weight, start), first fit into
+// groups, groups ranked by size) and the sorted strand list with the two new strands.  One wave per structure; shared by
+// sq_chain_kernel (width-1 pools: the child replaces its parent) and sq_pool_extend_kernel (device pools: children are
+// written to new slots).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sq_device.h"
+
+#define SQ_CHAIN_TMAX 1024      // stems per structure the level scratch holds (longer chains run the host loop)
+
+__device__ __forceinline__ bool sq_chain_cross(int ai, int aj, int bi, int bj)     // SQRNdbnseq.py:114-116
+{
+    return (ai < bi && bi < aj && aj < bj) || (bi < ai && ai < bj && bj < aj);
+}
+
+__device__ __forceinline__ unsigned long long sq_wave_or64(unsigned long long v)
+{
+    for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long sq_wave_min64(unsigned long long v)
+{
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int sq_wave_sum32(int v)
+{
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+struct SqExtendLds {
+    int16_t i[SQ_CHAIN_TMAX], j[SQ_CHAIN_TMAX], len[SQ_CHAIN_TMAX], ord[SQ_CHAIN_TMAX];
+    int32_t cc[SQ_CHAIN_TMAX];
+    uint8_t grp[SQ_CHAIN_TMAX], lvl[SQ_CHAIN_TMAX];
+    int32_t gsize[64];
+    uint8_t rank[64];
+};
+
+// parent: k stems pst[] (with their crossing weights), nstrand sorted strands psrc[] + the stem index of each (pssrc[]).
+// child: cst[0..k] (may be the parent's array: the weights are updated in place), cdst[] / csdst[] (nstrand + 2 entries;
+// must NOT be the parent's).  (i0, j0, len): the new stem.  Returns whether some pair of the child's stems crosses.
+__device__ __forceinline__ bool sq_extend_structure(SqExtendLds &L, const SqScanArgs &a, const SqChainStem *pst, int k, bool parent_anycross,
+                                                    const SqStrand *psrc, const int16_t *pssrc, int nstrand, int i0, int j0, int len,
+                                                    SqChainStem *cst, SqStrand *cdst, int16_t *csdst, int lane)
+{
+    // ---- crossing weights (:121-124), kept per stem between rounds ----
+    int mycc = 0, mycross = 0;
+    for (int q = lane; q < k; q += 64) {
+        const SqChainStem x = pst[q];
+        int cc = x.cc;
+        if (sq_chain_cross(x.i, x.j, i0, j0)) { cc += len; mycc += x.len; mycross = 1; }
+        cst[q] = SqChainStem{x.i, x.j, x.len, cc};
+        L.i[q] = (int16_t)x.i; L.j[q] = (int16_t)x.j; L.len[q] = (int16_t)x.len; L.cc[q] = cc;
+    }
+    const int newcc = sq_wave_sum32(mycc);
+    const bool anycross = parent_anycross || __ballot(mycross) != 0ull;
+    if (lane == 0) {
+        L.i[k] = (int16_t)i0; L.j[k] = (int16_t)j0; L.len[k] = (int16_t)len; L.cc[k] = newcc;
+        cst[k] = SqChainStem{i0, j0, len, newcc};
+    }
+    __syncthreads();
+    const int T = k + 1;
+    // ---- levels (only when stems cross; otherwise every strand stays on level 1) ----
+    if (anycross) {
+        // stems that cross nothing sort first (weight 0) and all land in group 0
+        int g0 = 0, has0 = 0;
+        for (int q = lane; q < T; q += 64) {
+            const bool free_ = L.cc[q] == 0;
+            L.grp[q] = free_ ? 0 : 255;
+            if (free_) { g0 += L.len[q]; has0 = 1; }
+        }
+        g0 = sq_wave_sum32(g0);
+        int ngroups = __ballot(has0) != 0ull ? 1 : 0;
+        if (lane == 0) L.gsize[0] = g0;
+        // order of the crossing stems: (weight, start) ascending (:125); starts are distinct
+        int nx = 0;
+        for (int q0 = 0; q0 < T; q0 += 64) {
+            const int q = q0 + lane;
+            const bool x = q < T && L.cc[q] > 0;
+            if (x) {
+                const int cq = L.cc[q], iq = L.i[q];
+                int r = 0;
+                for (int p = 0; p < T; p++) {
+                    const int cp = L.cc[p];
+                    r += (cp > 0 && (cp < cq || (cp == cq && L.i[p] < iq))) ? 1 : 0;
+                }
+                L.ord[r] = (int16_t)q;
+            }
+            nx += __popcll(__ballot(x));
+        }
+        __syncthreads();
+        // first fit (:130-136): a stem joins the first group none of whose members it crosses
+        for (int t = 0; t < nx; t++) {
+            const int p = L.ord[t];
+            const int pi = L.i[p], pj = L.j[p];
+            unsigned long long blocked = 0ull;
+            for (int q = lane; q < T; q += 64) {
+                const int g = L.grp[q];
+                if (g != 255 && sq_chain_cross(pi, pj, L.i[q], L.j[q])) blocked |= 1ull << g;
+            }
+            blocked = sq_wave_or64(blocked);
+            int placed = blocked == ~0ull ? 64 : __ffsll((long long)~blocked) - 1;
+            if (placed > ngroups) placed = ngroups;
+            if (placed >= SQ_MAXLEVELS) { if (lane == 0) a.ctr->level_ovf = 1; placed = SQ_MAXLEVELS - 1; }   // (reported as an error)
+            else if (placed == ngroups) { ngroups++; if (lane == 0) L.gsize[placed] = 0; }
+            __syncthreads();
+            if (lane == 0) { L.grp[p] = (uint8_t)placed; L.gsize[placed] += L.len[p]; }
+            __syncthreads();
+        }
+        // groups ranked by size, descending, stable (:139); level = rank + 1
+        if (lane < ngroups) {
+            const int gs = L.gsize[lane];
+            int r = 0;
+            for (int h = 0; h < ngroups; h++) { const int hs = L.gsize[h]; r += (hs > gs || (hs == gs && h < lane)) ? 1 : 0; }
+            L.rank[lane] = (uint8_t)(r + 1);
+        }
+        __syncthreads();
+        for (int q = lane; q < T; q += 64) L.lvl[q] = L.rank[L.grp[q]];
+        __syncthreads();
+    }
+    // ---- strands: the sorted list with the two new strands ----
+    const SqStrand *src = psrc;
+    const int16_t *ssrc = pssrc;
+    SqStrand *dst = cdst;
+    int16_t *sdst = csdst;
+    const int ls = i0, rs = j0 - len + 1;                               // starts of the 5' and the 3' strand (ls < rs)
+    int below_l = 0, below_r = 0;
+    for (int q0 = 0; q0 < nstrand; q0 += 64) {
+        const int q = q0 + lane;
+        const bool valid = q < nstrand;
+        SqStrand x = valid ? src[q] : SqStrand{0, 0, 0, 0, 0};
+        const int sx = valid ? ssrc[q] : 0;
+        const bool bl = valid && x.start < ls, br = valid && x.start < rs;
+        if (valid) {
+            if (anycross) x.level = L.lvl[sx];
+            const int at = q + (bl ? 0 : 1) + (br ? 0 : 1);
+            dst[at] = x; sdst[at] = (int16_t)sx;
+        }
+        below_l += __popcll(__ballot(bl)); below_r += __popcll(__ballot(br));
+    }
+    if (lane == 0) {
+        const uint8_t lv = anycross ? L.lvl[k] : (uint8_t)1;
+        dst[below_l] = SqStrand{(int16_t)ls, (int16_t)len, (int16_t)j0, lv, 1};
+        dst[below_r + 1] = SqStrand{(int16_t)rs, (int16_t)len, (int16_t)(i0 + len - 1), lv, 0};
+        sdst[below_l] = (int16_t)k; sdst[below_r + 1] = (int16_t)k;
+    }
+    return anycross;
+}
