@@ -69,6 +69,30 @@ struct SqChainIO {
     volatile uint32_t *h_nfin;    // pinned copy, published by sq_chain_done_kernel before the round's sequence number
 };
 
+// device pools: two generations of structure slots (parents / children), slot c of generation p at (p * smax + c)
+struct SqPoolIO {
+    SqStruct *structs;            // [2][smax]
+    SqChain *recs;                // [2][smax]   (toff, tcap = pt, nstems, anycross, maxstems)
+    SqChainStem *stems;           // [2][smax][pt]
+    SqStrand *strands;            // [2][smax][2 pt]
+    int16_t *sidx;                // [2][smax][2 pt]
+    int32_t smax, pt, cmax;       // smax: slots per generation in the arrays (stride)
+    int32_t slots;                // slots usable this fold (<= smax: the candidate arena bounds it too)
+    int32_t poollim;
+    long long maxcap;             // candidate records per slot
+    SqPoolJob *jobs; int32_t njobs;
+    const int32_t *jobrec_of;     // batch job index -> record in jobs[]
+    int32_t *nchild;              // [smax] children of every structure of the round (0: final)
+    int32_t *child_off;           // [smax + 1] exclusive scan of nchild
+    uint8_t *finalflag;           // [smax] 1: the structure is final and still has to be logged
+    SqPoolPick *chosen;           // [smax][cmax]
+    SqPoolHdr *hdr;
+    SqPoolFin *h_fin; uint32_t fin_cap;             // pinned
+    SqStemOut *h_fin_stems; uint32_t fin_stem_cap;  // pinned
+    SqPoolHdr *h_hdr;                               // pinned copy, published by the scan kernel
+    SqPoolJob *h_jobs;                              // pinned copy of the job records (sq_pool_publish_kernel)
+};
+
 // order-preserving map double -> uint64 (never 0 for a real number), so a per-structure maximum is one atomicMax
 __device__ __forceinline__ unsigned long long sq_ord(double x)
 {
@@ -99,6 +123,12 @@ __global__ void sq_chain_init_kernel(const SqStruct *h_structs, const SqChain *h
                                      SqScanArgs a, int S, int first);
 __global__ void sq_chain_done_kernel(SqRoundIO io, SqScanArgs a, SqChainIO cio, uint32_t seq);
 __global__ void sq_done_kernel(SqRoundIO io, SqScanArgs a, uint32_t seq);
+__global__ void sq_pool_init_kernel(const SqStruct *h_structs, const SqChain *h_recs, const SqPoolJob *h_jobs, const int32_t *h_jobrec,
+                                    int32_t *d_jobrec, int nbatchjobs, SqPoolIO pio, SqScanArgs a, int S0);
+__global__ void sq_pool_choose_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqPoolIO pio);
+__global__ void sq_pool_scan_kernel(SqPoolIO pio, SqScanArgs a, SqRoundIO io, int parity, uint32_t seq);
+__global__ void sq_pool_extend_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, int parity);
+__global__ void sq_pool_publish_kernel(SqPoolIO pio, SqScanArgs a, SqRoundIO io, uint32_t seq);
 __global__ void sq_mirror_kernel(double *matrix, int L);
 __global__ void sq_scatter_all_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const int32_t *cols,
                                       const int32_t *col_start, int L, double *matrix);

@@ -165,6 +165,9 @@ struct sq_batch {
     SqChain *h_chain = nullptr;           // pinned staging of the per-structure records
     int64_t chain_T = 0;                  // summed stem capacity of all jobs
     std::vector<int32_t> chain_toff;      // per job: start of its slice of the chain's stem arrays
+    // device pools (pools of any width, sq_pool.hip): device arrays carved from the workspace, pinned ones on first use
+    SqPoolIO pool_io{};
+    SqChain *h_pool_recs = nullptr; SqPoolJob *h_pool_jobs = nullptr; int32_t *h_pool_jobrec = nullptr;   // pinned staging
     // profiling
     std::mutex mwm_mu;
     int64_t mwm_stats[6] = {0, 0, 0, 0, 0, 0};   // blossom jobs collected, their scan passes; the job with the most passes:

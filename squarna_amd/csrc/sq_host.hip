@@ -240,6 +240,9 @@ struct Layout {
     size_t off_mat32, off_mat64, off_structs, off_strands, off_state, off_cnt, off_ctr, off_cands, off_out;
     size_t off_bits, off_rbpk, off_fb;
     size_t off_crec, off_cstems, off_cstrands, off_csidx, off_cnfin;   // device-chained rounds (sq_chain.hip)
+    size_t off_pstructs, off_precs, off_pstems, off_pstrands, off_psidx, off_pjobs, off_pjobrec, off_pnchild, off_pchoff,
+           off_pflag, off_pchosen, off_phdr;                            // device pools (sq_pool.hip)
+    int32_t pool_pt;                 // stems per slot (0: no device pools for this batch)
     int64_t chain_T;                 // summed stem capacity of all jobs
     size_t total;
     int64_t ltot, sdf_len, mat32_floats, mat64_doubles, cand_records, bits_words;
@@ -317,6 +320,21 @@ int plan(const sq_batch_desc *d, Layout &L)
     L.off_cstrands = take(sizeof(SqStrand) * 4 * (size_t)L.chain_T);
     L.off_csidx = take(sizeof(int16_t) * 4 * (size_t)L.chain_T);
     L.off_cnfin = take(64);
+    // device pools: two generations of max_structs slots, each with room for the most stems any job's structure can hold
+    L.pool_pt = 0;
+    for (int j = 0; j < d->njobs; j++)
+        L.pool_pt = std::max(L.pool_pt, chain_tcap(d->seq_off[d->job_seq[j] + 1] - d->seq_off[d->job_seq[j]], d->psets[d->job_pset[j]].minlen));
+    if (L.pool_pt > 1024) L.pool_pt = 0;                      // (SQ_CHAIN_TMAX: such batches keep the host-driven loop)
+    {
+        const size_t sm = (size_t)L.max_structs, pt = (size_t)L.pool_pt;
+        const size_t on = pt ? 1 : 0;
+        L.off_pstructs = take(on * 2 * sm * sizeof(SqStruct)); L.off_precs = take(on * 2 * sm * sizeof(SqChain));
+        L.off_pstems = take(on * 2 * sm * pt * sizeof(SqChainStem)); L.off_pstrands = take(on * 2 * sm * 2 * pt * sizeof(SqStrand));
+        L.off_psidx = take(on * 2 * sm * 2 * pt * sizeof(int16_t));
+        L.off_pjobs = take(on * (size_t)d->njobs * sizeof(SqPoolJob)); L.off_pjobrec = take(on * (size_t)d->njobs * 4);
+        L.off_pnchild = take(on * sm * 4); L.off_pchoff = take(on * (sm + 1) * 4); L.off_pflag = take(on * sm);
+        L.off_pchosen = take(on * sm * 64 * sizeof(SqPoolPick)); L.off_phdr = take(64);
+    }
     L.total = o;
     return 0;
 }
@@ -528,6 +546,17 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->chain.strands = (SqStrand *)(base + L.off_cstrands); b->chain.sidx = (int16_t *)(base + L.off_csidx);
     b->chain.d_nfin = (uint32_t *)(base + L.off_cnfin);
     b->chain_T = L.chain_T;
+    if (L.pool_pt) {
+        SqPoolIO &P = b->pool_io;
+        P.structs = (SqStruct *)(base + L.off_pstructs); P.recs = (SqChain *)(base + L.off_precs);
+        P.stems = (SqChainStem *)(base + L.off_pstems); P.strands = (SqStrand *)(base + L.off_pstrands);
+        P.sidx = (int16_t *)(base + L.off_psidx);
+        P.smax = L.max_structs; P.pt = L.pool_pt; P.cmax = 64;
+        P.jobs = (SqPoolJob *)(base + L.off_pjobs); P.jobrec_of = (int32_t *)(base + L.off_pjobrec);
+        P.nchild = (int32_t *)(base + L.off_pnchild); P.child_off = (int32_t *)(base + L.off_pchoff);
+        P.finalflag = (uint8_t *)(base + L.off_pflag); P.chosen = (SqPoolPick *)(base + L.off_pchosen);
+        P.hdr = (SqPoolHdr *)(base + L.off_phdr);
+    }
 
     hipStream_t st = b->stream;
     // Uploads go through a pinned staging buffer of the library.  A copy straight from pageable memory makes the runtime
@@ -637,6 +666,8 @@ extern "C" void sq_batch_destroy(sq_batch *b)
     for (int k = 0; k < 4; k++) sq_pinned_put(b->stage_buf[k]);
     sq_pinned_put(b->chain.h_stems); sq_pinned_put(b->chain.h_fin); sq_pinned_put((void *)b->chain.h_nfin);
     sq_pinned_put(b->h_chain);
+    sq_pinned_put(b->pool_io.h_fin); sq_pinned_put(b->pool_io.h_fin_stems); sq_pinned_put(b->pool_io.h_hdr); sq_pinned_put(b->pool_io.h_jobs);
+    sq_pinned_put(b->h_pool_recs); sq_pinned_put(b->h_pool_jobs); sq_pinned_put(b->h_pool_jobrec);
     delete b->pool;
     if (b->lane_ev) hipEventDestroy(b->lane_ev);
     for (auto &p : b->prof) {
@@ -944,7 +975,7 @@ struct AlignSink {                    // mode 2: where the stems of structure k 
 // and for host-driven greedy rounds the range filter that writes the round's output records
 static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, int64_t maxcap, bool need_reacts, double scan_bytes,
                                  int mode, const SqRoundIO &io, const SqScanArgs &scan, SqStruct *d_structs, SqStrand *d_strands,
-                                 bool chained)
+                                 bool chained, bool pooled = false)
 {
     {
         ProfScope ps(b, 1, 0);
@@ -992,10 +1023,11 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
                                scan, io, mode, lds_n, lds_nr, surv_off);
         if (mode == 0 && !chained)
             hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, d_structs, scan, io);
-        if (chained) {
+        if (chained && !pooled) {
             SqChainIO cio = b->chain;
             hipLaunchKernelGGL(sq_chain_kernel, dim3(S), dim3(64), 0, st, b->ctx, d_structs, scan, cio);
         }
+        if (pooled) hipLaunchKernelGGL(sq_pool_choose_kernel, dim3(S), dim3(64), 0, st, b->ctx, d_structs, scan, b->pool_io);
     }
 }
 
@@ -1327,8 +1359,20 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         for (int j : greedy_jobs)
             if (chain_tcap(b->jobs[j].n, b->psets[b->job_pset[j]].minlen) > 1024 ||          // SQ_CHAIN_TMAX
                 b->jobs[j].cand_cap > b->cand_records - b->cand_reserved) use_chain = false;
-    if (!use_chain)
-        for (int j : greedy_jobs) { pools[j].cur.emplace_back(); pools[j].cur.back().job = j; }   // :1105 one empty structure
+    // Wider pools: booked on the device as well (sq_pool.hip) when the batch has the slot arrays (structures of at most
+    // 1024 stems) and one structure per greedy job fits the round buffers; any capacity overflow during the fold makes
+    // the host repeat it with its own loop.
+    const bool no_pool = getenv("SQ_NO_POOL") != nullptr;
+    bool use_pool = !use_chain && o.poollim > 1 && !no_pool && !greedy_jobs.empty() && b->pool_io.pt > 0;
+    auto host_pools_init = [&]() {
+        for (int j : greedy_jobs) {
+            JobPool &P = pools[j];
+            P.cur.clear(); P.nxt.clear(); P.fin.clear(); P.evals = 0; P.cursize = 1;
+            P.cursubopt = b->psets[b->job_pset[j]].suboptmin;
+            P.cur.emplace_back(); P.cur.back().job = j;       // :1105 one empty structure
+        }
+    };
+    if (!use_chain && !use_pool) host_pools_init();
     for (int k = 0; k < 8; k++) g_t[k] = 0;
     const bool timing = getenv("SQ_TIMING") != nullptr;
     auto mark = [&](const char *what) { if (timing) fprintf(stderr, "[sq_fold]   +%.3f ms %s\n", (now_s() - tfold0) * 1e3, what); };
@@ -1616,8 +1660,152 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         }
 #undef CHK
     };
+    // ---- device pools ----
+    auto pool_fold = [&](LoopStats &stats) -> int {          // 0: done, 1: capacity overflow (repeat on the host), < 0 / > 1: error in stats
+        SqLane &ln = b->lane_full;
+        hipStream_t st = b->stream;
+        SqPoolIO &PI = b->pool_io;
+        const double tl0 = now_s();
+        stats.tstart = tl0 - tfold0;
+        struct Wall { double t0; double &dst; ~Wall() { dst = now_s() - t0; } } wall{tl0, stats.twall};
+        auto fail = [&](int rc, const std::string &msg) { stats.rc = rc; stats.err = msg; return 2; };
+        if (!PI.h_fin) {
+            PI.fin_cap = (uint32_t)std::max(65536, 128 * b->njobs);
+            PI.fin_stem_cap = PI.fin_cap * 12u;
+            void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr, *p6 = nullptr;
+            if (sq_pinned_get(&p0, sizeof(SqPoolFin) * (size_t)PI.fin_cap) || sq_pinned_get(&p1, sizeof(SqStemOut) * (size_t)PI.fin_stem_cap) ||
+                sq_pinned_get(&p2, 64) || sq_pinned_get(&p3, sizeof(SqPoolJob) * (size_t)b->njobs) ||
+                sq_pinned_get(&p4, sizeof(SqChain) * (size_t)b->njobs) || sq_pinned_get(&p5, sizeof(SqPoolJob) * (size_t)b->njobs) ||
+                sq_pinned_get(&p6, 4 * (size_t)b->njobs)) return fail(2, sq_last_error());
+            PI.h_fin = (SqPoolFin *)p0; PI.h_fin_stems = (SqStemOut *)p1; PI.h_hdr = (SqPoolHdr *)p2; PI.h_jobs = (SqPoolJob *)p3;
+            b->h_pool_recs = (SqChain *)p4; b->h_pool_jobs = (SqPoolJob *)p5; b->h_pool_jobrec = (int32_t *)p6;
+        }
+        std::vector<int> jobs;
+        int maxn = 0; int64_t maxcap = 0; bool need_reacts = false;
+        for (int j : greedy_jobs) {
+            JobPool &P = pools[j];
+            if (P.maxstemnum == 0) { P.fin.emplace_back(); continue; }   // :1123-1129 full before the first round
+            const SqJob &J = b->jobs[j];
+            maxn = std::max(maxn, J.n); maxcap = std::max<int64_t>(maxcap, J.cand_cap);
+            need_reacts |= !J.default_reacts && !(J.react_levels > 0 && b->pset_classes[J.pset] * J.react_levels <= 32);
+            jobs.push_back(j);
+        }
+        const int S0 = (int)jobs.size();
+        if (S0 == 0) return 0;
+        const int64_t avail = b->cand_records - b->cand_reserved;
+        int slots = (int)std::min<int64_t>(std::min(PI.smax, ln.max_structs), avail / std::max<int64_t>(maxcap, 1));
+        if (const char *e = getenv("SQ_POOL_SLOTS")) slots = std::min(slots, std::max(1, atoi(e)));   // (tests: force the overflow path)
+        if (S0 > slots) return 1;
+        for (int j = 0; j < b->njobs; j++) b->h_pool_jobrec[j] = -1;
+        for (int sx = 0; sx < S0; sx++) {
+            const int j = jobs[sx];
+            const JobPool &P = pools[j];
+            const int toff = sx * PI.pt;                     // generation 0, slot sx
+            SqStruct &d = ln.h_structs[sx];
+            d.job = j; d.strand_off = 2 * toff; d.nstrand = 0; d.slot = sx; d.subopt = 0.0; d.cand_off = (int64_t)sx * maxcap;
+            SqChain &cr = b->h_pool_recs[sx];
+            cr.toff = toff; cr.tcap = PI.pt; cr.nstems = 0; cr.anycross = 0; cr.maxstems = P.maxstemnum;
+            SqPoolJob &pj = b->h_pool_jobs[sx];
+            pj.first = sx; pj.count = 1; pj.cursize = 1; pj.job = j;
+            pj.cursubopt = P.cursubopt; pj.suboptinc = P.suboptinc; pj.suboptmax = P.suboptmax; pj.maxstems = P.maxstemnum; pj.evals = 0;
+            b->h_pool_jobrec[j] = sx;
+        }
+        PI.slots = slots; PI.poollim = o.poollim; PI.maxcap = maxcap; PI.njobs = S0;   // (the kernels take the batch's record)
+        const SqPoolIO pio = PI;
+        SqScanArgs scan = b->scan;
+        scan.ctr = ln.d_ctr;
+        hipLaunchKernelGGL(sq_pool_init_kernel, dim3((std::max(S0, b->njobs) + 255) / 256), dim3(256), 0, st, ln.h_structs, b->h_pool_recs,
+                           b->h_pool_jobs, b->h_pool_jobrec, (int32_t *)pio.jobrec_of, b->njobs, pio, scan, S0);
+        const bool relaxed = sq_relaxed_waits(b);
+        const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
+        volatile uint32_t *flag = ln.h_seq;
+        auto wait_seq = [&](uint32_t seq) -> int {
+            uint64_t spins = 0;
+            while (*flag != seq) {
+                if ((++spins & poll_mask) == 0) {
+                    const hipError_t q = hipStreamQuery(st);
+                    if (q != hipErrorNotReady) {
+                        if (q != hipSuccess) return fail(sq_check(q, "pool rounds"), sq_last_error());
+                        if (*flag != seq) { hipStreamSynchronize(st); if (*flag != seq) return fail(2, "pool round did not signal completion"); }
+                    }
+                }
+                sq_wait_step(spins, relaxed);
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return 0;
+        };
+        const double tr0 = now_s();
+        int parity = 0, S = S0, rounds = 0;
+        bool overflow = false;
+        while (S > 0) {
+            SqStruct *cur = pio.structs + (size_t)parity * pio.smax;
+            SqRoundIO io;
+            io.h_structs = cur; io.h_strands = pio.strands; io.d_structs = cur; io.d_strands = pio.strands;
+            io.h_out = ln.h_out; io.d_out = ln.d_out; io.h_cap = 0; io.out_cap = 0;
+            io.h_ctr = ln.h_ctr; io.h_seq = ln.h_seq;
+            launch_round_kernels(b, st, S, maxn, maxcap, need_reacts, 0.0, 0, io, scan, cur, pio.strands, true, true);
+            const uint32_t seq = ++*ln.round_seq;
+            hipLaunchKernelGGL(sq_pool_scan_kernel, dim3(1), dim3(1024), 0, st, pio, scan, io, parity, seq);
+            hipLaunchKernelGGL(sq_pool_extend_kernel, dim3(S), dim3(64), 0, st, b->ctx, scan, pio, parity);
+            if (wait_seq(seq)) return 2;
+            rounds++;
+            const SqCounters ctr = *ln.h_ctr;
+            if (ctr.cand_ovf) return fail(-3, "candidate capacity exceeded (raise cand_per_nt)");
+            if (ctr.level_ovf) return fail(-3, "more than 64 pseudoknot levels");
+            const SqPoolHdr hh = *pio.h_hdr;
+            if (timing && getenv("SQ_POOL_DEBUG")) fprintf(stderr, "[pool] round %d: S %d -> %u, nfin %u, ovf %u, active jobs %u\n", rounds, S, hh.S[parity ^ 1], hh.nfin, hh.ovf, hh.active_jobs);
+            if (hh.ovf) { overflow = true; break; }
+            parity ^= 1;
+            S = (int)hh.S[parity];
+            if (rounds > 4 * PI.pt + 8) return fail(2, "pool rounds do not terminate");
+        }
+        {   // the last extend kernel's log entries and flags, the evaluation counts
+            SqRoundIO io;
+            io.h_structs = pio.structs; io.h_strands = pio.strands; io.d_structs = pio.structs; io.d_strands = pio.strands;
+            io.h_out = ln.h_out; io.d_out = ln.d_out; io.h_cap = 0; io.out_cap = 0; io.h_ctr = ln.h_ctr; io.h_seq = ln.h_seq;
+            const uint32_t seq = ++*ln.round_seq;
+            hipLaunchKernelGGL(sq_pool_publish_kernel, dim3(1), dim3(256), 0, st, pio, scan, io, seq);
+            if (wait_seq(seq)) return 2;
+        }
+        stats.nrounds = rounds;
+        stats.tround = now_s() - tr0;
+        const SqPoolHdr hh = *pio.h_hdr;
+        if (overflow || hh.ovf) {
+            for (int j : greedy_jobs) { pools[j].fin.clear(); pools[j].evals = 0; }
+            return 1;
+        }
+        if ((*ln.h_ctr).level_ovf) return fail(-3, "more than 64 pseudoknot levels");
+        // finstemsets of every job: the log in (round, kind, position) order
+        std::vector<uint32_t> ord(hh.nfin);
+        for (uint32_t q = 0; q < hh.nfin; q++) ord[q] = q;
+        const SqPoolFin *F = pio.h_fin;
+        std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
+            if (F[x].job != F[y].job) return F[x].job < F[y].job;
+            if (F[x].round_kind != F[y].round_kind) return F[x].round_kind < F[y].round_kind;
+            return F[x].pos < F[y].pos;
+        });
+        static_assert(sizeof(HStem) == sizeof(SqStemOut), "stem records must match");
+        for (uint32_t q : ord) {
+            const SqPoolFin &e = F[q];
+            std::vector<HStem> stems((size_t)e.nstems);
+            if (e.nstems) memcpy(stems.data(), pio.h_fin_stems + e.stem_off, sizeof(HStem) * (size_t)e.nstems);
+            pools[e.job].fin.push_back(std::move(stems));
+        }
+        for (int sx = 0; sx < S0; sx++) pools[jobs[sx]].evals += pio.h_jobs[sx].evals;
+        return 0;
+    };
     mark("loop start");
-    if (use_chain) {
+    if (use_pool) {
+        const int pr = pool_fold(st0);
+        if (pr == 1 && timing) fprintf(stderr, "[sq_fold] device pools: a capacity was exceeded, the host loop repeats the greedy part\n");
+        if (pr == 1) {                                       // a capacity was exceeded: the host's own loop takes the fold
+            st0 = LoopStats();
+            use_pool = false;
+            host_pools_init();
+            if (!two_lanes) greedy_loop(b->lane_full, greedy_jobs, st0);
+            else { std::vector<int> none; greedy_loop(b->lane_full, greedy_jobs, st0); }
+        }
+    } else if (use_chain) {
         chain_fold(st0);
     } else if (!two_lanes) {
         greedy_loop(b->lane_full, greedy_jobs, st0);

@@ -100,6 +100,36 @@ struct SqStemOut {                                  // == HStem of the host: one
     double bps, fin;
 };
 
+// Device pools (sq_pool.hip): the greedy pool loop of SQRNdbnseq.py:1102-1199 for pools of any width, booked on the device.
+struct SqPoolJob {            // one greedy job
+    int32_t first, count;     // its structures of the current round: [first, first + count) of the round's list
+    int32_t cursize;          // :1108,1117-1118
+    int32_t job;              // job index in the batch
+    double cursubopt, suboptinc, suboptmax;   // :1069-1071,1119-1120
+    double maxstems;          // :1123-1129
+    long long evals;          // structures evaluated so far (AnnotateStems calls)
+};
+struct SqPoolHdr {
+    uint32_t S[2];            // structures of the round, by round parity (the scan kernel writes the next round's)
+    uint32_t round;
+    uint32_t nfin, nfin_stems;   // entries / stems of the pinned log of final structures
+    uint32_t ovf;             // some capacity was exceeded: the host repeats the fold with its own loop
+    uint32_t active_jobs;
+    uint32_t pad;
+};
+struct SqPoolFin {            // one final structure (pinned): finstemsets order == (round_kind, pos) ascending per job
+    int32_t job;
+    uint32_t round_kind;      // 2 * round + kind; kind 0: full at the start of that round (:1123-1129), 1: no new stem (:1155-1156)
+    int32_t pos;              // position in the round's list
+    int32_t nstems;
+    uint32_t stem_off;        // into the pinned stem log
+    uint32_t pad;
+};
+struct SqPoolPick {           // a stem chosen for a parent (ChooseStems' output list)
+    uint32_t key, len;
+    double bps, fin;
+};
+
 // Round-level counters.
 struct SqCounters {
     uint32_t nout;        // records appended to the out list

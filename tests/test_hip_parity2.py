@@ -411,3 +411,62 @@ def test_chained_rounds_maxstemnum_and_long_pseudoknotted():
     exp = O.SQRNdbnseq(longs[0], None, None, None, ps, poollim=1)
     exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
     _same_fold(chained[0], exp, ("long", 0))
+
+
+# ---- device pools (poollim > 1, sq_pool.hip): against the host-driven loop and the oracle ----------------------------
+def _fold_pool_and_host(recs, **kw):
+    from squarna_amd.engine import HipEngine
+    assert "SQ_NO_POOL" not in os.environ
+    pooled = HipEngine().fold_records(recs, **kw)
+    os.environ["SQ_NO_POOL"] = "1"
+    try:
+        hosted = HipEngine().fold_records(recs, **kw)
+    finally:
+        del os.environ["SQ_NO_POOL"]
+    return pooled, hosted
+
+
+@pytest.mark.parametrize("config,count,nmin,nmax,poollim,sample", [("nobpp", 200, 12, 220, 1000, 30), ("greedynobpp", 200, 12, 260, 3, 30),
+                                                                   ("greedynobpp", 120, 30, 300, 40, 16), ("fastest", 150, 5, 300, 7, 20)])
+def test_device_pools_match_host_loop_and_oracle(config, count, nmin, nmax, poollim, sample):
+    """poollim > 1: ChooseStems' conflict filter, the children's slots, cursize / cursubopt, the stopper and the order of
+    finstemsets booked on the device give exactly what the host-driven loop gives (same kernels: every score bit for
+    bit, every structure in the same rank) and what the oracle gives."""
+    from oracle import sqrn_oracle as O
+    names, psets = conf(config)
+    raw = _chain_records(count, 777 + poollim, nmin, nmax)
+    recs = [(s, r, x, None, psets, None) for s, r, x in raw]
+    pooled, hosted = _fold_pool_and_host(recs, poollim=poollim)
+    for k, (a, b) in enumerate(zip(pooled, hosted)):
+        assert a[0] == b[0] and a[1] == b[1], (config, poollim, k, raw[k][0], a[:2], b[:2])
+    for k in range(sample):
+        s, r, x = raw[k]
+        exp = O.SQRNdbnseq(s, r, x, None, psets, poollim=poollim)
+        exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(pooled[k], exp, (config, "pooled", poollim, k))
+
+
+def test_device_pools_overflow_falls_back_and_maxstemnum():
+    """A fold whose pools outgrow the device slots is repeated by the host loop (same results); maxstemnum 0 / 2 / 3
+    exercises the 'full' children (SQRNdbnseq.py:1123-1129: moved to finstemsets at the start of the next round)."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import HipEngine
+    names, psets = conf("greedynobpp")
+    raw = _chain_records(60, 99, 40, 200)
+    recs = [(s, r, x, None, psets, None) for s, r, x in raw]
+    normal = HipEngine().fold_records(recs, poollim=1000)
+    os.environ["SQ_POOL_SLOTS"] = str(2 * len(recs) + 3)            # room for the first generation only
+    try:
+        cramped = HipEngine().fold_records(recs, poollim=1000)
+    finally:
+        del os.environ["SQ_POOL_SLOTS"]
+    assert [c[:2] for c in cramped] == [n[:2] for n in normal]
+    for msn in (0, 2, 3):
+        ps = [dict(p, maxstemnum=msn) for p in psets]
+        recs2 = [(s, None, None, None, ps, None) for s, r, x in raw[:24]]
+        pooled, hosted = _fold_pool_and_host(recs2, poollim=1000)
+        assert [c[:2] for c in pooled] == [h[:2] for h in hosted], msn
+        for k in range(6):
+            exp = O.SQRNdbnseq(raw[k][0], None, None, None, ps, poollim=1000)
+            exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+            _same_fold(pooled[k], exp, ("pool maxstemnum", msn, k))

@@ -1,1 +1,1 @@
-python -m pytest tests/test_hip_parity2.py tests/test_hip_parity.py -m gpu -x -q -k "chained or baseline_sizes" 2>&1 | grep -E "passed|failed|rror|assert" | tail -5
+timeout 900 python -m pytest tests/test_hip_parity2.py -m gpu -x -q -k "device_pools" 2>&1 | grep -E "passed|failed|rror|assert|Error" | tail -12
