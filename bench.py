@@ -416,6 +416,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=0,
                     help="independent SRtest150 batches in flight per GPU (0 = auto: 8, fewer when the ranks of the node "
                          "share few CPUs -- every batch has a host thread that drives its rounds)")
+    ap.add_argument("--replicas", type=int, default=2,
+                    help="copies of the 219-record SRtest150 set per batch (kernels and host rounds are shared by the copies)")
     ap.add_argument("--workload", default="srtest150", choices=["srtest150", "S300", "S1000", "S2000"])
     ap.add_argument("--sub-batches", type=int, default=0,
                     help="strong-scaling mode: concurrent batches per rank (0 = the workload's measured best: %s)" % SUB_BATCHES)
@@ -462,10 +464,12 @@ def main():
     prepared = [Prepared(seq, reacts, restr, ref) for _, seq, reacts, restr, ref in recs]
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     K = args.inflight if args.inflight > 0 else min(8, max(1, effective_cpus() // (2 * max(1, local_world))))
+    R = max(1, args.replicas)
+    nset = len(prepared)                                      # 219 records
     batches = []
     for _ in range(K):                                        # inputs resident in HBM; one stream per batch
         with torch.cuda.stream(torch.cuda.Stream(device)):
-            batches.append(Batch(prepared, [psets] * len(prepared), fp32=False))
+            batches.append(Batch(prepared * R, [psets] * (nset * R), fp32=False, max_structs=4096 * R))
     torch.cuda.synchronize()
 
     def step():
@@ -496,10 +500,10 @@ def main():
         dt = float(t.item())
 
     # ---- secondary, OUTSIDE the timed region ----------------------------------------------------------------------
-    results = [batches[0].result(k) for k in range(len(prepared))]
+    results = [batches[0].result(k) for k in range(nset)]
     fs_c, fs_b = mean_fs(results)
-    evals = sum(batches[0].evals(k) for k in range(len(prepared)))
-    same = all(repr(b.result(k)) == repr(results[k]) for b in batches[1:] for k in range(0, len(prepared), 7))
+    evals = sum(batches[0].evals(k) for k in range(nset))
+    same = all(repr(b.result(k + r * nset)) == repr(results[k]) for b in batches for r in range(R) for k in range(r, nset, 7))
     for b in batches:
         b.close()
     # one batch alone, set up as a caller with a single batch would (its own worker pool, nothing else in flight)
@@ -576,7 +580,7 @@ def main():
             pass
     if rank != 0:
         return
-    per_step = len(prepared) * K
+    per_step = nset * R * K
     line = {
         "metric": "sequences/sec (SRtest150, single-sequence mode)",
         "value": round(per_step * world * args.steps / dt, 1),
@@ -591,10 +595,11 @@ def main():
         "dtype": "f64",
         "dtype_note": "scores and every decision in fp64, in the reference's operation order; the scan itself works on 1-bit cell activity",
         "data": "SRtest150.fas shipped with the reference (219 records, 8-150 nt, reference dbn per record)",
-        "config": {"workload": "SRtest150 if=qf c=%s poollim=1000; %d independent 219-record batches in flight per GPU "
-                               "(sq_fold_concurrent, one stream set each); a step folds all of them" % (args.config, K),
-                   "batches_in_flight": K, "host_cpus": effective_cpus(), "seqs_per_gpu_per_step": per_step, "paramsets": names,
-                   "evals_R_per_step": int(evals) * K, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
+        "config": {"workload": "SRtest150 if=qf c=%s poollim=1000; %d independent batches in flight per GPU (sq_fold_concurrent, "
+                               "one stream set each), each holding the 219-record set %d time(s); a step folds all of them"
+                               % (args.config, K, R),
+                   "batches_in_flight": K, "sets_per_batch": R, "host_cpus": effective_cpus(), "seqs_per_gpu_per_step": per_step,
+                   "paramsets": names, "evals_R_per_step": int(evals) * K * R, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
         "single_batch": {"ms_per_fold": round(lat[len(lat) // 2], 3), "best_ms": round(lat[0], 3),
                          "seq_per_s": round(len(prepared) / lat[len(lat) // 2] * 1e3, 1),
                          "how": "ONE 219-record batch alone (a fresh batch, nothing else in flight), median / best of 10 folds"},

@@ -6,14 +6,11 @@ python bench.py --steps 20 --warmup 3 2> $out/bench.err | tail -1 > $out/r02_ben
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu > /tmp/bstats.log 2>&1 )
 cp $(find /tmp/bstats -name "*kernel_stats.csv" | head -1) $out/r02_bench_kernel_stats.csv
 { for w in S300 S1000 S2000; do python bench.py --workload $w --steps 10 --warmup 2 2>/dev/null | tail -1; done; } > $out/r02_sharded_world1.txt
-{ for k in 1 2 4 6 8 12 16; do python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=|CPU"; done; } > $out/r02_concurrency.txt
+{ echo "== one 219-record set per batch"; for k in 1 2 4 8 12; do python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=|CPU"; done;
+  echo "== two sets per batch (PROBE_REPLICAS=2)"; for k in 1 2 4 8 12; do PROBE_REPLICAS=2 python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=|CPU"; done;
+  echo "== host-driven rounds (SQ_NO_POOL=1), one set per batch"; for k in 1 8; do SQ_NO_POOL=1 python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=|CPU"; done;
+  echo "== CPU time per host phase of one fold (SQ_CPUACC=1, one batch alone)"; SQ_CPUACC=1 python tools/concurrent_probe.py 1 4 2>&1 | grep "cpu ms" | tail -1; } > $out/r02_concurrency.txt
 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids | tail -5 > $out/r02_gputest.txt
 ls -la $out
 { python tools/predict_probe.py S300 3; python tools/predict_probe.py S1000 3; } 2>&1 | grep Predict > $out/r02_predict.txt
-{ echo "== device-chained rounds (poollim 1): randomised parity against the CPU oracle"; 
-  FUZZ_POOLLIM=1 python tools/fuzz_parity.py 3000 fastest 11 2>&1 | grep -E "records|MISMATCH|oracle";
-  FUZZ_POOLLIM=1 python tools/fuzz_parity.py 1500 nobpp 12 2>&1 | grep -E "records|MISMATCH|oracle";
-  FUZZ_POOLLIM=1 FUZZ_NMIN=200 FUZZ_NMAX=700 python tools/fuzz_parity.py 300 fastest 13 2>&1 | grep -E "records|MISMATCH|oracle";
-  echo "== poollim 1000 (host-driven rounds, blossom graphs in packed blocks)";
-  python tools/fuzz_parity.py 2000 nobpp 14 2>&1 | grep -E "records|MISMATCH|oracle"; } > $out/r02_fuzz_add.txt
-cat $out/r02_predict.txt $out/r02_fuzz_add.txt
+cat $out/r02_predict.txt
