@@ -114,10 +114,12 @@ namespace {
 // tail); its sorted base pairs are a slice of the call's flat pair list -- no allocation per structure.
 struct Entry {
     const std::vector<HStem> *stems;
-    uint32_t bp_off, bp_n;
+    uint32_t cs_off, cs_n;        // canonical stems (maximal stacks, ascending i): what identifies the base-pair set
+    uint32_t bp_off, bp_n;        // its sorted pairs, expanded only when something needs them (bp_off == ~0u: not yet)
     double scores[3];
     uint64_t mask;
 };
+struct Stem3 { int32_t i, j, len; };
 struct Span {
     const BP *p; size_t n;
     const BP *begin() const { return p; }
@@ -165,6 +167,35 @@ static uint64_t bps_of(const std::vector<HStem> &stems, BPV &out)
         for (const BP &bp : out) h += mix_bp(bp.first, bp.second);
     }
     return h;
+}
+
+// The base-pair set of a structure as its maximal stacks in ascending order of i -- unique for a set of disjoint stems,
+// so two stem lists describe the same structure iff their canonical lists are equal: a dozen triples to hash and
+// compare instead of a hundred pairs.  Returns false (-> the pair path) when the stems are not disjoint stacks.
+static bool canonical_stems(const std::vector<HStem> &stems, std::vector<Stem3> &out, uint64_t &hash)
+{
+    static thread_local std::vector<int> order;
+    order.resize(stems.size());
+    for (size_t k = 0; k < stems.size(); k++) {                        // insertion sort by i (a handful of stems)
+        size_t q = k;
+        while (q > 0 && stems[order[q - 1]].i > stems[k].i) { order[q] = order[q - 1]; q--; }
+        order[q] = (int)k;
+    }
+    out.clear();
+    for (int idx : order) {
+        const HStem &s = stems[idx];
+        if (s.len <= 0) continue;
+        if (!out.empty()) {
+            Stem3 &p = out.back();
+            if (s.i < p.i + p.len) return false;                       // 5' strands overlap: not disjoint
+            if (s.i == p.i + p.len && s.j == p.j - p.len) { p.len += s.len; continue; }   // stacked onto the previous stem
+        }
+        out.push_back(Stem3{s.i, s.j, s.len});
+    }
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (const Stem3 &t : out) h = (h ^ mix_bp(t.i, (t.j << 10) ^ t.len)) * 0xD6E8FEB86659FD93ull;
+    hash = h;
+    return true;
 }
 
 template <class A, class B>
@@ -248,33 +279,59 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
 #endif
     // :1201-1220 dedupe across paramsets; the first producer scores the structure
     static thread_local std::vector<Entry> fins_tl;
-    static thread_local std::vector<BP> flat;                           // sorted pairs of every distinct structure
-    static thread_local std::vector<int> table, chain;                  // open addressing on the pair-set hash: entry + 1
+    static thread_local std::vector<BP> flat;                           // sorted pairs of the structures that needed them
+    static thread_local std::vector<Stem3> cflat, ckey;                 // canonical stems of every distinct structure
+    static thread_local std::vector<int> table;                         // open addressing on the hash: entry + 1
     static thread_local std::vector<uint64_t> hashes;
     static thread_local BPV key;
     std::vector<Entry> &fins = fins_tl;
-    fins.clear(); flat.clear(); chain.clear(); hashes.clear();
+    fins.clear(); flat.clear(); cflat.clear(); hashes.clear();
     size_t total = 0;
     for (size_t k = 0; k < per_job.size(); k++) total += per_job[k]->size();
     size_t tsize = 16;
     while (tsize < 2 * total + 2) tsize <<= 1;
     table.assign(tsize, 0);
-    auto bps_of_entry = [&](const Entry &e) { return Span{flat.data() + e.bp_off, e.bp_n}; };
+    // pairs of an entry, expanded on first use (the ranking needs them for a handful of entries only)
+    auto ensure_pairs = [&](Entry &e) {
+        if (e.bp_off != ~0u) return;
+        e.bp_off = (uint32_t)flat.size();
+        for (uint32_t t = 0; t < e.cs_n; t++) {
+            const Stem3 &c = cflat[e.cs_off + t];
+            for (int k = 0; k < c.len; k++) flat.push_back(BP(c.i + k, c.j - k));
+        }
+        e.bp_n = (uint32_t)flat.size() - e.bp_off;
+    };
+    auto bps_of_entry = [&](Entry &e) { ensure_pairs(e); return Span{flat.data() + e.bp_off, e.bp_n}; };
     for (size_t k = 0; k < per_job.size(); k++) {
         for (const auto &stems : *per_job[k]) {
-            const uint64_t h = bps_of(stems, key);
+            uint64_t h = 0;
+            if (!canonical_stems(stems, ckey, h)) {
+                // stems that are not disjoint stacks: the maximal stacks of their sorted unique pairs (the same canonical form)
+                bps_of(stems, key);
+                ckey.clear();
+                for (const BP &bp : key) {
+                    if (!ckey.empty() && ckey.back().i + ckey.back().len == bp.first && ckey.back().j - ckey.back().len == bp.second) ckey.back().len++;
+                    else ckey.push_back(Stem3{bp.first, bp.second, 1});
+                }
+                h = 0x9E3779B97F4A7C15ull;
+                for (const Stem3 &t : ckey) h = (h ^ mix_bp(t.i, (t.j << 10) ^ t.len)) * 0xD6E8FEB86659FD93ull;
+            }
             size_t slot = (size_t)(h * 0x9E3779B97F4A7C15ull >> 11) & (tsize - 1);
             int found = -1;
             for (;; slot = (slot + 1) & (tsize - 1)) {
                 const int e = table[slot] - 1;
                 if (e < 0) break;
-                if (hashes[e] == h && fins[e].bp_n == key.size() &&
-                    std::equal(key.begin(), key.end(), flat.data() + fins[e].bp_off)) { found = e; break; }
+                if (hashes[e] != h) continue;
+                const Entry &E = fins[e];
+                if (E.cs_n == ckey.size() &&
+                    std::equal(ckey.begin(), ckey.end(), cflat.data() + E.cs_off,
+                               [](const Stem3 &x, const Stem3 &y) { return x.i == y.i && x.j == y.j && x.len == y.len; })) { found = e; break; }
             }
             if (found < 0) {
                 Entry e;
-                e.stems = &stems; e.bp_off = (uint32_t)flat.size(); e.bp_n = (uint32_t)key.size(); e.mask = 1ull << k;
-                flat.insert(flat.end(), key.begin(), key.end());
+                e.stems = &stems; e.mask = 1ull << k; e.bp_off = ~0u; e.bp_n = 0;
+                e.cs_off = (uint32_t)cflat.size(); e.cs_n = (uint32_t)ckey.size();
+                cflat.insert(cflat.end(), ckey.begin(), ckey.end());
                 score_struct(codes, reacts, n, stems, e.scores);
                 table[slot] = (int)fins.size() + 1;
                 hashes.push_back(h);
@@ -300,14 +357,14 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
         std::stable_partition(fins.begin(), fins.end(), [&](const Entry &e) { return (e.mask & o.priority_mask) != 0; });  // :912-913
     if (o.rankbydiff && fins.size() >= 3) {                            // :917-955
         BPV allbps, seenbps;
-        for (const Entry &e : fins) allbps = merged(allbps, bps_of_entry(e));
+        for (Entry &e : fins) allbps = merged(allbps, bps_of_entry(e));
         { const Span f0 = bps_of_entry(fins[0]); seenbps.assign(f0.begin(), f0.end()); }
         size_t cur = 1;
         while (seenbps != allbps && cur < fins.size() - 1) {
             std::vector<std::pair<size_t, size_t>> novel;              // (#new bps, original position)
             std::vector<Entry> tailv(fins.begin() + cur, fins.end());
             std::vector<size_t> nov(tailv.size()), idx(tailv.size());
-            for (size_t t = 0; t < tailv.size(); t++) { nov[t] = tailv[t].bp_n - count_common(bps_of_entry(tailv[t]), seenbps); idx[t] = t; }
+            for (size_t t = 0; t < tailv.size(); t++) { const Span sp = bps_of_entry(tailv[t]); nov[t] = sp.size() - count_common(sp, seenbps); idx[t] = t; }
             std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) {
                 if (nov[x] != nov[y]) return nov[x] > nov[y];
                 return keyless(tailv[x], tailv[y]);
@@ -333,7 +390,7 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
 #endif
     res.preds.clear();
     res.preds.reserve(fins.size());
-    for (const Entry &e : fins) {                                      // :1232-1234
+    for (Entry &e : fins) {                                            // :1232-1234
         res.preds.emplace_back();
         SeqResult::Pred &p = res.preds.back();
         if (forced.empty()) levels_of_stems(*e.stems, n, p.levels);

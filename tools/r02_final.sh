@@ -10,7 +10,7 @@ cp $(find /tmp/bstats -name "*kernel_stats.csv" | head -1) $out/r02_bench_kernel
   echo "== two sets per batch (PROBE_REPLICAS=2)"; for k in 1 2 4 8 12; do PROBE_REPLICAS=2 python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=|CPU"; done;
   echo "== host-driven rounds (SQ_NO_POOL=1), one set per batch"; for k in 1 8; do SQ_NO_POOL=1 python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=|CPU"; done;
   echo "== CPU time per host phase of one fold (SQ_CPUACC=1, one batch alone)"; SQ_CPUACC=1 python tools/concurrent_probe.py 1 4 2>&1 | grep "cpu ms" | tail -1; } > $out/r02_concurrency.txt
-python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids | tail -5 > $out/r02_gputest.txt
+python -m pytest tests -m gpu -q 2>&1 | grep -E " passed| failed|error" > $out/r02_gputest.txt
 ls -la $out
 { python tools/predict_probe.py S300 3; python tools/predict_probe.py S1000 3; } 2>&1 | grep Predict > $out/r02_predict.txt
 cat $out/r02_predict.txt
