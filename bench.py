@@ -416,7 +416,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=0,
                     help="independent SRtest150 batches in flight per GPU (0 = auto: 8, fewer when the ranks of the node "
                          "share few CPUs -- every batch has a host thread that drives its rounds)")
-    ap.add_argument("--replicas", type=int, default=2,
+    ap.add_argument("--replicas", type=int, default=3,
                     help="copies of the 219-record SRtest150 set per batch (kernels and host rounds are shared by the copies)")
     ap.add_argument("--workload", default="srtest150", choices=["srtest150", "S300", "S1000", "S2000"])
     ap.add_argument("--sub-batches", type=int, default=0,
@@ -605,8 +605,9 @@ def main():
                          "how": "ONE 219-record batch alone (a fresh batch, nothing else in flight), median / best of 10 folds"},
         "host": {"cpu_ms_per_step": round(host_cpu / args.steps * 1e3, 1), "busy_cpus": round(host_cpu / dt, 1),
                  "cpu_quota": effective_cpus(),
-                 "note": "rank 0's process CPU time inside the timed region; with the quota's worth of CPUs busy the step is "
-                         "bound by the host side of the fold (pool growth, RunAlgo filters, ranking tails), not by the GPU"},
+                 "note": "rank 0's process CPU time inside the timed region; with (nearly) the quota's worth of CPUs busy the step "
+                         "is bound by the host side of the fold (RunAlgo filters, ranking tails, edge lists, launches), not by "
+                         "the GPU"},
         "kernel_ms_per_fold": kernel_ms,
         "f1": {"mean_FS_consensus": round(fs_c, 4), "mean_FS_best_of_top5": round(fs_b, 4),
                "batches_in_flight_agree": bool(same)},
