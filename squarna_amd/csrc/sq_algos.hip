@@ -431,13 +431,21 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
         } else {
             const int32_t *sol = h_out_p + mj[q].out_off;
             const uint8_t *codes = b->codes.data() + J.pos_off;
-            std::vector<int64_t> cells;                               // cells with mat[v,w] != 0, SQRNalgos.py:119-123
+            // cells with mat[v,w] != 0 (SQRNalgos.py:119-123) as a bit matrix (set, queried, cleared cell by cell: no sort,
+            // no O(N^2) clearing); sequences too long for that keep a sorted list
+            static thread_local std::vector<int64_t> cells;
+            static thread_local std::vector<uint64_t> cellbits;
+            const size_t nn = (size_t)J.n * J.n;
+            const bool use_bits = nn <= ((size_t)1 << 24);
+            if (use_bits && cellbits.size() < (nn + 63) / 64) cellbits.resize((nn + 63) / 64, 0);
+            cells.clear();
             PowCache pow17;
             for (const HStem &s : stems[k]) {
                 if (-pow17(s.bps) == 0) continue;
                 for (int t = 0; t < s.len; t++) cells.push_back((int64_t)(s.i + t) * J.n + (s.j - t));
             }
-            std::sort(cells.begin(), cells.end());
+            if (use_bits) for (int64_t cidx : cells) cellbits[(size_t)cidx >> 6] |= 1ull << (cidx & 63);
+            else std::sort(cells.begin(), cells.end());
             for (int kk = 0; kk < J.n; kk++) {                        // SQRNalgos.py:130-133
                 const int sk = sol[kk];
                 if (sk < 0 || !(kk < sk)) continue;
@@ -445,11 +453,13 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
                 if (!far) for (int x = kk + 1; x < sk; x++) if (codes[x] == SQ_CODE_SEP1 || codes[x] == SQ_CODE_SEP2) { far = true; break; }
                 if (!far) continue;
                 if (sol[sk] != kk) continue;
-                if (!std::binary_search(cells.begin(), cells.end(), (int64_t)kk * J.n + sk)) continue;
+                const int64_t cidx = (int64_t)kk * J.n + sk;
+                if (use_bits ? !((cellbits[(size_t)cidx >> 6] >> (cidx & 63)) & 1ull) : !std::binary_search(cells.begin(), cells.end(), cidx)) continue;
                 pairs.push_back(BP(kk, sk));
             }
+            if (use_bits) for (int64_t cidx : cells) cellbits[(size_t)cidx >> 6] = 0;
         }
-        filter_stemset(b, J, pairs, levellimit, out[k], dense[q].empty() ? nullptr : dense[q].data());
+        { CpuScope cpu_f(3); filter_stemset(b, J, pairs, levellimit, out[k], dense[q].empty() ? nullptr : dense[q].data()); }
         if (streaming) (*on_job)(k);
     };
     if (!streaming) {

@@ -1,1 +1,2 @@
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E " passed| failed|rror|assert" | tail -4
+SQ_CPUACC=1 python tools/concurrent_probe.py 1 6 2>&1 | grep -E "cpu ms" | tail -2 | cut -c1-220
