@@ -18,8 +18,8 @@ from .core import RunSQRNdbnseq, resolve_priority
 from . import engine as _engine
 
 #: records folded per GPU batch (bounded by the sum of N^2 as well)
-BATCH_RECORDS = 1024
-BATCH_CELLS = 256 * 1024 * 1024
+BATCH_RECORDS = 16384                 # records folded in one GPU batch (bigger batches: fewer, fuller kernel launches)
+BATCH_CELLS = 2 * 1024 * 1024 * 1024   # ... bounded by sum of N^2 x paramsets
 
 
 def Predict(inputfile=None, fileformat="unknown", inputseq=None, configfile=None, inputformat="qtrf",

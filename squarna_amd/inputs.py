@@ -98,7 +98,8 @@ def GuessFormat(inp):
             if line.startswith(">"):
                 entries += 1
                 continue
-            if sum(1 for ch in line.upper() if ch in "ACGUT") > len(line) / 2:
+            up = line.upper()
+            if up.count("A") + up.count("C") + up.count("G") + up.count("U") + up.count("T") > len(line) / 2:
                 seqlines += 1
             if seqlines > 1000:
                 break
