@@ -460,7 +460,7 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
             if (use_bits) for (int64_t cidx : cells) cellbits[(size_t)cidx >> 6] = 0;
         }
         { CpuScope cpu_f(3); filter_stemset(b, J, pairs, levellimit, out[k], dense[q].empty() ? nullptr : dense[q].data()); }
-        if (streaming) (*on_job)(k);
+        if (streaming) { CpuScope cpu_h(5); (*on_job)(k); }
     };
     if (!streaming) {
         sq_pool(b)->parallel_for((int)mj.size(), [&](int qi) { finish_job((size_t)order[qi]); });

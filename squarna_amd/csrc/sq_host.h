@@ -177,8 +177,8 @@ struct sq_batch {
 };
 
 // CPU accounting (SQ_CPUACC=1): thread CPU time spent in the host phases, summed over all threads, printed per fold.
-// 0 tails, 1 RunAlgo filters (collect), 2 edge lists (build), 3 pool growth, 4 round post-processing, 5 round set-up +
-// launches, 6 waits of the round driver, 7 AnnotateStems rounds of E/H/N, 8 the fold's calling thread in all, 9 sq_algos_begin,
+// 0 tails, 1 RunAlgo collect per job (incl. 3 and 5), 2 edge lists (build), 3 pool growth (host loop) / RunAlgo's stem filters,
+// 4 round post-processing, 5 round set-up + launches (host loop) / the per-job hook of streamed Edmonds results (incl. tails), 6 waits of the round driver, 7 AnnotateStems rounds of E/H/N, 8 the fold's calling thread in all, 9 sq_algos_begin,
 // 10 sq_algos_end (its thread), 11 teardown of the pools
 extern std::atomic<long long> g_cpuacc[12];
 extern bool g_cpuacc_on;

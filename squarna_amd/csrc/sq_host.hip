@@ -1907,7 +1907,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 nrounds, tloop * 1e3, tround * 1e3, g_t[0] * 1e3, g_t[1] * 1e3, g_t[2] * 1e3, (tloop - tround) * 1e3,
                 (now_s() - ttail0) * 1e3);
     if (g_cpuacc_on) {
-        static const char *nm[12] = {"tails", "filters", "edges", "grow", "post", "launch", "wait", "annotate", "caller", "begin", "end", "teardown"};
+        static const char *nm[12] = {"tails", "collect", "edges", "grow|stemfilter", "post", "launch|hook", "wait", "annotate", "caller", "begin", "end", "teardown"};
         fprintf(stderr, "[sq_fold cpu ms]");
         g_cpuacc[8] += CpuScope::now() - cpu_fold0;
         for (int k = 0; k < 12; k++) fprintf(stderr, " %s %.2f", nm[k], g_cpuacc[k].exchange(0) * 1e-6);

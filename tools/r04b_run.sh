@@ -1,1 +1,1 @@
-python tools/_pp.py 2>&1 | grep -v amdgpu.ids | tail -34
+SQ_CPUACC=1 python tools/concurrent_probe.py 1 6 2>&1 | grep -E "cpu ms" | tail -2 | cut -c1-220
