@@ -2032,12 +2032,15 @@ extern "C" int sq_result_pack_all(const sq_batch *b, void *buf, int64_t cap, int
         const int64_t need = sq_result_pack_size(b, s);
         off[s] = o;
         if (o + need > cap) { sq_set_error("result buffer too small"); return -1; }
-        const int r = sq_result_pack(b, s, (char *)buf + o, cap - o);
-        if (r) return r;
         o += (need + 7) & ~(int64_t)7;
     }
     off[b->nseq] = o;
-    return 0;
+    // the records are independent: big batches share the copying among the worker pool (15 MB for 10,000 x 300 nt)
+    std::atomic<int> rc{0};
+    auto one = [&](int s) { const int r = sq_result_pack(b, s, (char *)buf + off[s], cap - off[s]); if (r) rc = r; };
+    if (b->nseq >= 512 && o >= ((int64_t)1 << 20)) sq_pool(const_cast<sq_batch *>(b))->parallel_for(b->nseq, one);
+    else for (int s = 0; s < b->nseq; s++) one(s);
+    return rc.load();
 }
 
 // Dot-bracket rows of every record as ASCII text (the bulk form of levels -> characters): record s occupies

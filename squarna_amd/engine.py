@@ -416,9 +416,13 @@ class Batch:
 
     def pack_all(self):
         """(uint8 array, int64 offsets[nseq + 1]): the packed results of every record (sq_result_pack_all) -- the
-        payload of the multi-GPU result gather."""
+        payload of the multi-GPU result gather.  The array is a view of a buffer the batch reuses."""
         nbytes = int(self.L.sq_result_pack_all_size(self.h))
-        buf = np.zeros(max(nbytes, 8), np.uint8)
+        # the batch keeps its pack buffer (fresh pages for tens of MB per call cost more than the packing itself); the
+        # returned view is valid until the next pack_all of this batch
+        buf = getattr(self, "_packbuf", None)
+        if buf is None or buf.size < max(nbytes, 8):
+            buf = self._packbuf = np.empty(max(nbytes, 8) + (max(nbytes, 8) >> 3), np.uint8)
         off = np.zeros(self.nseq + 1, np.int64)
         _lib.check(self.L.sq_result_pack_all(self.h, _ptr(buf), nbytes, _ptr(off)))
         return buf[:nbytes], off

@@ -1,1 +1,2 @@
-SQ_CPUACC=1 python tools/concurrent_probe.py 1 6 2>&1 | grep -E "cpu ms" | tail -2 | cut -c1-220
+python tools/shard_probe.py S300 6 2>&1 | tail -3
+python -m pytest tests -m gpu -x -q -k "sharded or parallel or pack" 2>&1 | grep -E " passed| failed|rror" | tail -3
