@@ -568,6 +568,11 @@ class HipEngine:
                     sm = np.delete(np.delete(np.asarray(sm, dtype=np.float64), p.gapidx, 0), p.gapidx, 1)
                 mul.extend([sm] * len(r[4]))
         nrec = len(records)
+        # structure slots of the batch: the device-side pools / chained rounds hold every structure of a round at once, so
+        # the default grows with the number of (sequence, paramset) jobs (a fold that still outgrows it is repeated by
+        # the library's host loop)
+        njobs = sum(len(pl) for pl in psets)
+        max_structs = self.max_structs if self.max_structs else max(4096, min(4 * njobs, 262144))
         # SQ_ENGINE_LANES=2 folds big inputs as two concurrent batches; for one-shot calls the second batch's set-up
         # (pinned buffers, worker pool) costs more than the overlap saves, so it is opt-in (long-lived batches
         # profit: fold_concurrently / sq_fold_concurrent)
@@ -575,7 +580,7 @@ class HipEngine:
         cost = [float(len(p.shortseq)) ** 2 * len(pl) for p, pl in zip(prepared, psets)]
         if lanes < 2 or nrec < 256 or sum(cost) < 1e8:
             with Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
-                       max_structs=self.max_structs, cand_per_nt=self.cand_per_nt) as b:
+                       max_structs=max_structs, cand_per_nt=self.cand_per_nt) as b:
                 b.fold(**opts)
                 both = b.results_all()
                 self.last_ref_scores = [r[1] for r in both]
@@ -594,7 +599,7 @@ class HipEngine:
                     return [x for k in idx for x in seq[job0[k]:job0[k + 1]]] if per_job else [seq[k] for k in idx]
                 batches.append(Batch(pick(prepared, False), pick(psets, False), interchainonly=interchainonly,
                                      mul=pick(mul, True), bpp=pick(bpp, True), fp32=False,
-                                     max_structs=self.max_structs, cand_per_nt=self.cand_per_nt))
+                                     max_structs=max_structs, cand_per_nt=self.cand_per_nt))
             fold_concurrently(batches, **opts)
             out = [None] * nrec
             self.last_ref_scores = [None] * nrec
