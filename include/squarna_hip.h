@@ -88,7 +88,9 @@ typedef struct sq_batch_desc {
                                         mul_score or bpp_term, not both.  NULL entry with bpp != 0: max(bppm) was 0,
                                         the matrix stays as it is (:350,360).                                        */
     int32_t interchainonly;     /* SQRNdbnseq.py:264-271,301 */
-    int32_t max_structs;        /* structures evaluated per round chunk (0 = default 4096)      */
+    int32_t max_structs;        /* structures evaluated per round chunk (0 = default 4096); also the structure
+                                   slots of the device-side pools / chained rounds: a fold whose pools outgrow
+                                   them is repeated by the library's host loop (same results, slower)           */
     int32_t cand_per_nt;        /* candidate capacity per structure = cand_per_nt * N (0 = 32)  */
     int32_t batch_flags;        /* SQ_BATCH_* */
 } sq_batch_desc;
@@ -109,7 +111,7 @@ typedef struct sq_stem {
 
 /* Options of the SQRNdbnseq tail (SQRNdbnseq.py:973-980). */
 typedef struct sq_fold_opts {
-    int32_t poollim;        /* SQRNdbnseq.py:1147,1191 */
+    int32_t poollim;        /* SQRNdbnseq.py:1147,1191 (1: rounds chained on the device; > 1: pools booked on the device) */
     int32_t conslim;        /* :1236 */
     int32_t toplim;         /* :1282 */
     int32_t hardrest;       /* :1226-1228 */
