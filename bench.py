@@ -177,6 +177,15 @@ def kernels_hash():
     return h.hexdigest()[:16]
 
 
+def host_threads(inflight, local_world):
+    """Worker threads the library gives a batch (sq_pool in sq_host.hip): 4 x the rank's CPUs / batches in flight, 8..32,
+    unless SQ_HOST_THREADS says otherwise."""
+    if os.environ.get("SQ_HOST_THREADS"):
+        return int(os.environ["SQ_HOST_THREADS"])
+    cores = max(1, effective_cpus() // max(1, local_world))
+    return min(max(4 * cores // max(1, inflight), 8), 32)
+
+
 def load_pmc():
     """profiles/traffic.json: per kernel the counters of a rocprofv3 --pmc pass (tools/make_traffic.py), valid only for
     the kernel sources they were measured on."""
@@ -287,6 +296,26 @@ def fill_leg(nseq=256, n=1000, pmc=None):
                 how="achieved = 4 N^2 bytes per job (the fp32 matrix, written once) / time of the fill's launches (HIP events, "
                     "mean of 5); traffic = FETCH_SIZE x 2 + WRITE_SIZE of the same launch (profiles/traffic.json); the fold "
                     "path does not use this op (it writes N^2/8 bytes of bit matrix instead)")
+
+
+# ---------------------------------------------------------------- the drop-in API end to end
+def predict_leg(config, reps=5):
+    """Predict() on SRtest150: file in, text out (parse + prepare + upload + fold + format), host buffers on both sides --
+    the PCIe / Python-inclusive rate of the drop-in entry point.  Never `value`."""
+    import io
+    from squarna_amd import Predict
+    path = os.path.join(ROOT, "squarna_amd", "data", "datasets", "SRtest150.fas")
+    ts, chars = [], 0
+    for r in range(reps + 1):
+        buf = io.StringIO()
+        t0 = time.perf_counter()
+        Predict(inputfile=path, inputformat="qf", configfile=config, write_to=buf)
+        if r:
+            ts.append((time.perf_counter() - t0) * 1e3)
+        chars = len(buf.getvalue())
+    ts.sort()
+    return dict(what="squarna_amd.Predict(inputfile=SRtest150.fas, if=qf, c=%s) into a text buffer, median of %d calls" % (config, reps),
+                ms_per_call=round(ts[len(ts) // 2], 2), seq_per_s=round(219 / ts[len(ts) // 2] * 1e3, 1), text_chars=chars)
 
 
 # ---------------------------------------------------------------- strong scaling: a synthetic workload sharded over the ranks
@@ -567,6 +596,13 @@ def main():
         except Exception as e:                                # (a secondary leg never takes the headline down)
             rooflines.append({"kernel": "sq_fill_kernel", "error": "%s: %s" % (type(e).__name__, e)})
 
+    end_to_end = None
+    if rank == 0 and world == 1:
+        try:
+            end_to_end = predict_leg(args.config)
+        except Exception as e:                                # (a secondary leg never takes the headline down)
+            end_to_end = {"error": "%s: %s" % (type(e).__name__, e)}
+
     sharded = None
     if world > 1:
         try:
@@ -598,7 +634,8 @@ def main():
         "config": {"workload": "SRtest150 if=qf c=%s poollim=1000; %d independent batches in flight per GPU (sq_fold_concurrent, "
                                "one stream set each), each holding the 219-record set %d time(s); a step folds all of them"
                                % (args.config, K, R),
-                   "batches_in_flight": K, "sets_per_batch": R, "host_cpus": effective_cpus(), "seqs_per_gpu_per_step": per_step,
+                   "batches_in_flight": K, "sets_per_batch": R, "host_cpus": effective_cpus(),
+                   "host_threads_per_batch": host_threads(K, local_world), "seqs_per_gpu_per_step": per_step,
                    "paramsets": names, "evals_R_per_step": int(evals) * K * R, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
         "single_batch": {"ms_per_fold": round(lat[len(lat) // 2], 3), "best_ms": round(lat[0], 3),
                          "seq_per_s": round(len(prepared) / lat[len(lat) // 2] * 1e3, 1),
@@ -615,6 +652,7 @@ def main():
         "rooflines": rooflines,
         "pmc_note": pmc_note,
         "cpu_baseline": cpu,
+        "end_to_end": end_to_end,
         "sharded": sharded,
     }
     print(json.dumps(line))
