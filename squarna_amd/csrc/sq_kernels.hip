@@ -727,6 +727,9 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     __shared__ uint8_t s_cls[32];
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];   // letter codes [n] (+ reactivities [n] when they fit)
     const SqStruct st = structs[blockIdx.x];
+#ifdef SQ_SCORE_PROF
+    const long long _p0 = wall_clock64(); long long _pa = 0, _pb = 0, _ps = 0;
+#endif
     const SqJob jb = c.jobs[st.job];
     const SqPsetDev *ps = c.psets + jb.pset;
     const int n = jb.n;
@@ -854,6 +857,24 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
         return w * rf;
     };
 
+    // Four consecutive cells (i + k, j - k), k < nv <= 4, of a stem when the table holds the final cell value: the combined
+    // indices of the four i positions are four consecutive bytes of l_ci and those of the j positions the four bytes
+    // ending at j -- two aligned 32-bit LDS reads and a byte align each instead of eight byte gathers (the gathers at
+    // data-dependent addresses are what the kernel's LDS bank conflicts come from, and its first phase is bound by them).
+    const uint32_t *l_ciw = reinterpret_cast<const uint32_t *>(l_ci);
+    auto cells4 = [&](int i, int j, int nv, double (&v)[4]) {
+        const int q = j - 3;                                        // lowest j position of the window (>= 0 here)
+        const uint32_t a0 = l_ciw[i >> 2], a1 = l_ciw[(i >> 2) + 1], b0 = l_ciw[q >> 2], b1 = l_ciw[(q >> 2) + 1];
+        uint32_t xi = __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)(i & 3));   // bytes i .. i + 3
+        uint32_t xj = __builtin_amdgcn_alignbyte(b1, b0, (uint32_t)(q & 3));   // bytes j - 3 .. j
+        if (nv < 4) {                                               // cells past the stem's end: index 0, never added
+            xi &= (1u << (8 * nv)) - 1u;
+            xj &= ~((1u << (8 * (4 - nv))) - 1u);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = s_cell[((xi >> (8 * k)) & 255u) * cstride + ((xj >> (8 * (3 - k))) & 255u)];
+    };
+
     double best = 0.0; int any = 0;
 
     const uint32_t qstep = gridDim.y * nthr;
@@ -870,10 +891,13 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                 double acc = 0.0;
                 for (int t = 0; t < L; t += 4) {
                     double v[4];
+                    if (cell_tab && j0 - t >= 3) cells4(i0 + t, j0 - t, min(4, L - t), v);
+                    else {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int tt = t + k < L ? t + k : L - 1;
-                        v[k] = cell_exact(i0 + tt, j0 - tt);
+                        for (int k = 0; k < 4; k++) {
+                            const int tt = t + k < L ? t + k : L - 1;
+                            v[k] = cell_exact(i0 + tt, j0 - tt);
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < 4; k++) acc = acc + (t + k < L ? v[k] : 0.0);
@@ -890,10 +914,13 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
 #pragma unroll
             for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
                 const int s = (int)(cd[u].key >> 16), i0 = (int)(cd[u].key & 0xFFFFu), j0 = s - i0, L = (int)cd[u].len;
+                if (cell_tab && t < L && j0 - t >= 3) cells4(i0 + t, j0 - t, min(4, L - t), v[u]);
+                else {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int tt = max(min(t + k, L - 1), 0);
-                    v[u][k] = cell_exact(i0 + tt, j0 - tt);
+                    for (int k = 0; k < 4; k++) {
+                        const int tt = max(min(t + k, L - 1), 0);
+                        v[u][k] = cell_exact(i0 + tt, j0 - tt);
+                    }
                 }
             }
 #pragma unroll
@@ -973,7 +1000,13 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     __shared__ uint32_t s_nsurv;
     if (tid == 0) s_nsurv = 0;
     __syncthreads();
+#ifdef SQ_SCORE_PROF
+    _ps = wall_clock64() - _p0;
+#endif
     for (uint32_t q0 = blockIdx.y * nthr; q0 < ncand; q0 += SQ_SCORE_CHUNK * qstep) {
+#ifdef SQ_SCORE_PROF
+        const long long _t0 = wall_clock64();
+#endif
         SqKey cd[SQ_SCORE_CHUNK];
 #pragma unroll
         for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
@@ -1000,6 +1033,9 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
             }
         }
         __syncthreads();
+#ifdef SQ_SCORE_PROF
+        const long long _t1 = wall_clock64(); _pa += _t1 - _t0;
+#endif
         const uint32_t ns = s_nsurv;
         const bool last = q0 + SQ_SCORE_CHUNK * qstep >= ncand;
         uint32_t done = 0;
@@ -1115,7 +1151,15 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
         if ((uint32_t)tid < rem) { s_key[tid] = ck; s_len[tid] = cl; s_bps[tid] = cb; }
         if (tid == 0) s_nsurv = rem;
         __syncthreads();
+#ifdef SQ_SCORE_PROF
+        _pb += wall_clock64() - _t1;
+#endif
     }
+#ifdef SQ_SCORE_PROF
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 700) && blockIdx.y == 0)
+        printf("score block %d: n=%d ncand=%u nstrand=%d | us: setup %.1f phaseA %.1f phaseB %.1f total %.1f\n", (int)blockIdx.x, n, ncand, st.nstrand,
+               _ps * 0.01, _pa * 0.01, _pb * 0.01, (wall_clock64() - _p0) * 0.01);
+#endif
 
     // wave maximum, then one atomicMax per wave on the structure's slot
     for (int off = 32; off > 0; off >>= 1) {
