@@ -244,7 +244,7 @@ def roofline_leg(nseq, n, pmc, pmc_note, seed=1000):
         how="achieved = HBM bytes the kernel really moves per launch (rocprofv3 PMC: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, "
             "%s) / its launch time measured live (HIP events on the library's stream); the kernel reads a 1-bit-per-cell "
             "diagonal matrix, so it is issue-bound (VALU + SALU), not bandwidth-bound" % (k.get("source", pmc_note or "no PMC file")),
-        avg_launch_ms=round(avg_ms, 4), launches=int(launches),
+        avg_launch_ms=round(avg_ms, 4), launches=int(launches), issue=issue_share(k, avg_ms),
         algorithmic=dict(bytes_per_launch=round(alg_bytes / max(launches, 1)), GBs=round(alg_gbs, 1),
                          reread_avoidance=round(alg_gbs / HBM_PEAK_GBS, 3),
                          note="SURVEY 8d bytes (2 N^2 per AnnotateStems evaluation: the fp32 upper triangle the reference "
@@ -264,8 +264,24 @@ def roofline_leg(nseq, n, pmc, pmc_note, seed=1000):
         score.update(hbm=dict(traffic=tb, achieved_GBs=round(tb / (cms / max(claunches, 1) * 1e-3) / 1e9, 1),
                               frac=round(tb / (cms / max(claunches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
                      wave_cycles_waiting=ks.get("wait_share"), lds_bank_conflict_share=ks.get("lds_conflict_share"),
+                     lds_wave_insts_per_launch=ks.get("sq_insts_lds_per_launch"), issue=issue_share(ks, cms / max(claunches, 1)),
                      pmc=ks.get("source"))
     return scan, score
+
+
+N_SIMD = 1024              # 256 CUs x 4 SIMDs
+
+
+def issue_share(k, launch_ms):
+    """Share of the chip's vector-issue slots a kernel's VALU instructions take: a wave64 VALU instruction occupies its
+    SIMD for 4 cycles, so wave-instructions (PMC SQ_INSTS_VALU) x 4 / (launch time x clock x SIMDs).  The roof that
+    binds the bit-diagonal scan and the fill (they are instruction streams, not byte streams)."""
+    v = (k or {}).get("sq_insts_valu_per_launch")
+    if not v or not launch_ms:
+        return None
+    return dict(valu_wave_insts_per_launch=int(v), salu_wave_insts_per_launch=k.get("sq_insts_salu_per_launch"),
+                valu_issue_frac=round(v * 4.0 / (launch_ms * 1e-3 * CLOCK_GHZ * 1e9 * N_SIMD), 3),
+                how="SQ_INSTS_VALU x 4 cycles / (launch time x %.1f GHz x %d SIMDs)" % (CLOCK_GHZ, N_SIMD))
 
 
 def fill_leg(nseq=256, n=1000, pmc=None):
@@ -292,7 +308,8 @@ def fill_leg(nseq=256, n=1000, pmc=None):
     traffic = (km.get("fetch_bytes_per_launch", 0) + km.get("write_bytes_per_launch", 0)) if km else None
     return dict(kernel="sq_fill_kernel", leg="sq_bpmatrix_fill on %d S1000 sequences" % nseq, bound="hbm",
                 unit="GB/s", peak=HBM_PEAK_GBS, achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
-                traffic=traffic, algorithmic_bytes=round(by / 5), ms_per_fill=round(per_ms, 4), pmc=km.get("source"),
+                traffic=traffic, algorithmic_bytes=round(by / 5), ms_per_fill=round(per_ms, 4), issue=issue_share(km, per_ms),
+                pmc=km.get("source"),
                 how="achieved = 4 N^2 bytes per job (the fp32 matrix, written once) / time of the fill's launches (HIP events, "
                     "mean of 5); traffic = FETCH_SIZE x 2 + WRITE_SIZE of the same launch (profiles/traffic.json); the fold "
                     "path does not use this op (it writes N^2/8 bytes of bit matrix instead)")

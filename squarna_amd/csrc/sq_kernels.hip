@@ -107,7 +107,26 @@ extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c, int
             uint32_t out[4] = {SQ_SENT_BITS, SQ_SENT_BITS, SQ_SENT_BITS, SQ_SENT_BITS};
             // a 16-byte store whose cells all lie on or below the diagonal (or in the padding rows) is pure sentinel
             const bool same_row = j + 3 < ld;
-            if (!(same_row && (j + 3 <= i || i >= n))) {
+            if (same_row && i < n && j + 3 > i && defr && !ico) {
+                // the four cells share the row: its attributes once, the four column attributes as one 32-bit window of
+                // l_attr (two aligned reads + a byte align), a cell = table read + three compares (the kernel is bound
+                // by its VALU stream, not by HBM: profiles/r02_fill_pmc.txt)
+                const int ai = l_attr[i];
+                const int ci = ai & 31;
+                if (!((ai >> 5) & 5)) {                                  // :302-304 row side: no '_' / '/' restraint at i
+                    const int thr = i + (int)l_inc4[i];                  // :294-300 smallest allowed j (> i)
+                    const uint32_t *aw = reinterpret_cast<const uint32_t *>(l_attr);
+                    const uint32_t x = __builtin_amdgcn_alignbyte(aw[(j >> 2) + 1], aw[j >> 2], (uint32_t)(j & 3));
+                    const float *row = s_wf + ci * 33;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t aj = (x >> (8 * k)) & 255u;
+                        const int jj = j + k;
+                        const bool ok = jj >= thr && jj < n && !((aj >> 5) & 3u);   // column side: no '_' / '\\' restraint at j
+                        out[k] = ok ? __float_as_uint(row[aj & 31u]) : SQ_SENT_BITS;
+                    }
+                }
+            } else if (!(same_row && (j + 3 <= i || i >= n))) {
                 int ii = i, jj = j;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
