@@ -518,11 +518,16 @@ def main():
             batches.append(Batch(prepared * R, [psets] * (nset * R), fp32=False, max_structs=4096 * R))
     torch.cuda.synchronize()
 
-    def step():
+    def run(nsteps):
+        """nsteps steps: every batch folded nsteps times.  The batches run free (sq_fold_concurrent_n: one host thread per
+        batch folds its batch back to back, no barrier between the steps), as resident batches serving a stream would."""
+        if nsteps <= 0:
+            return
         if K == 1:
-            batches[0].fold(poollim=1000)
+            for _ in range(nsteps):
+                batches[0].fold(poollim=1000)
         else:
-            fold_concurrently(batches, poollim=1000)
+            fold_concurrently(batches, reps=nsteps, poollim=1000)
 
     def fence():
         torch.cuda.synchronize()
@@ -530,13 +535,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     fence()
     t0 = time.perf_counter()
     cpu0 = time.process_time()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     fence()
     dt = time.perf_counter() - t0
     host_cpu = time.process_time() - cpu0                     # CPU time of this rank's process (all its threads)
@@ -649,8 +652,9 @@ def main():
         "dtype_note": "scores and every decision in fp64, in the reference's operation order; the scan itself works on 1-bit cell activity",
         "data": "SRtest150.fas shipped with the reference (219 records, 8-150 nt, reference dbn per record)",
         "config": {"workload": "SRtest150 if=qf c=%s poollim=1000; %d independent batches in flight per GPU (sq_fold_concurrent, "
-                               "one stream set each), each holding the 219-record set %d time(s); a step folds all of them"
-                               % (args.config, K, R),
+                               "one stream set each), each holding the 219-record set %d time(s); a step folds all of them; the "
+                               "batches run free inside the timed region (every batch is folded `steps` times back to back, "
+                               "no barrier between the steps: sq_fold_concurrent_n)" % (args.config, K, R),
                    "batches_in_flight": K, "sets_per_batch": R, "host_cpus": effective_cpus(),
                    "host_threads_per_batch": host_threads(K, local_world), "seqs_per_gpu_per_step": per_step,
                    "paramsets": names, "evals_R_per_step": int(evals) * K * R, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},

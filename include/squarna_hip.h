@@ -214,6 +214,13 @@ SQ_API int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref_off
  * Returns the first non-zero status (its text is available from sq_last_error on the calling thread). */
 SQ_API int sq_fold_concurrent(sq_batch *const *batches, int32_t nbatch, const sq_fold_opts *opts,
                               const int32_t *const *ref_off, const int32_t *const *ref_pairs, const uint8_t *const *has_ref);
+/* The steady-state form: every batch is folded `reps` times back to back by its own host thread, WITHOUT a barrier
+ * between the repetitions -- the batches drift apart and overlap each other's host-heavy and GPU-heavy phases (a
+ * server that re-uses resident batches for a stream of identical requests; bench.py's timed region is one such call).
+ * After the call every batch holds the results of its last fold. */
+SQ_API int sq_fold_concurrent_n(sq_batch *const *batches, int32_t nbatch, const sq_fold_opts *opts,
+                                const int32_t *const *ref_off, const int32_t *const *ref_pairs, const uint8_t *const *has_ref,
+                                int32_t reps);
 
 /* Result getters (valid after sq_fold until the next sq_fold / destroy). */
 SQ_API int32_t sq_result_nstruct(const sq_batch *b, int32_t seq);

@@ -1925,7 +1925,14 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
 extern "C" int sq_fold_concurrent(sq_batch *const *batches, int32_t nbatch, const sq_fold_opts *opts,
                                   const int32_t *const *ref_off, const int32_t *const *ref_pairs, const uint8_t *const *has_ref)
 {
-    if (!batches || nbatch <= 0 || !opts) { sq_set_error("bad argument"); return -1; }
+    return sq_fold_concurrent_n(batches, nbatch, opts, ref_off, ref_pairs, has_ref, 1);
+}
+
+extern "C" int sq_fold_concurrent_n(sq_batch *const *batches, int32_t nbatch, const sq_fold_opts *opts,
+                                    const int32_t *const *ref_off, const int32_t *const *ref_pairs, const uint8_t *const *has_ref,
+                                    int32_t reps)
+{
+    if (!batches || nbatch <= 0 || !opts || reps < 1) { sq_set_error("bad argument"); return -1; }
     std::vector<int> rc(nbatch, 0);
     std::vector<std::string> msg(nbatch);
     // every stream less keeps the long kernels of one batch out of another batch's hardware queue (GPU_MAX_HW_QUEUES)
@@ -1935,8 +1942,9 @@ extern "C" int sq_fold_concurrent(sq_batch *const *batches, int32_t nbatch, cons
     }
     auto work = [&](int k) {
         if (k > 0 && batches[k]->device >= 0) hipSetDevice(batches[k]->device);
-        rc[k] = sq_fold(batches[k], opts, ref_off ? ref_off[k] : nullptr, ref_pairs ? ref_pairs[k] : nullptr,
-                        has_ref ? has_ref[k] : nullptr);
+        for (int r = 0; r < reps && !rc[k]; r++)
+            rc[k] = sq_fold(batches[k], opts, ref_off ? ref_off[k] : nullptr, ref_pairs ? ref_pairs[k] : nullptr,
+                            has_ref ? has_ref[k] : nullptr);
         if (rc[k]) msg[k] = sq_last_error();                 // (the error text is per thread)
     };
     std::vector<std::thread> th;

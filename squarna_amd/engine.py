@@ -461,17 +461,21 @@ def _metrics(m):
     return [tp, fp, fn, fs, pr, rc]
 
 
-def fold_concurrently(batches, **opts):
+def fold_concurrently(batches, reps=1, **opts):
     """Fold several batches at the same time (sq_fold_concurrent: one host thread per batch inside the library):
     while one batch's host code books a round, the kernels of the others keep the GPU busy.  Batches are
-    independent, so the results are the ones of folding them one after the other."""
+    independent, so the results are the ones of folding them one after the other.  reps > 1: every batch is folded
+    that many times back to back without a barrier between the repetitions (sq_fold_concurrent_n)."""
     args = [b._fold_args(**opts) for b in batches]
     n = len(batches)
     hs = (C.c_void_p * n)(*[b.h for b in batches])
     offs = (C.c_void_p * n)(*[a[1].ctypes.data for a in args])
     rps = (C.c_void_p * n)(*[a[2].ctypes.data for a in args])
     has = (C.c_void_p * n)(*[a[3].ctypes.data for a in args])
-    _lib.check(batches[0].L.sq_fold_concurrent(hs, n, C.byref(args[0][0]), offs, rps, has))
+    if reps > 1:
+        _lib.check(batches[0].L.sq_fold_concurrent_n(hs, n, C.byref(args[0][0]), offs, rps, has, int(reps)))
+    else:
+        _lib.check(batches[0].L.sq_fold_concurrent(hs, n, C.byref(args[0][0]), offs, rps, has))
 
 
 def vienna_bpp(shortseq, reacts, M=1.8, B=-0.6):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """K SRtest150 batches (c=nobpp) in flight at once through sq_fold_concurrent, each on its own stream:
-ms per step (one step = K folds) and sequences/s.  usage: concurrent_probe.py K [REPS] [--same-stream]"""
+ms per step (one step = K folds) and sequences/s.  usage: concurrent_probe.py K [REPS] [--same-stream] [--free]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -42,6 +42,14 @@ walls = walls[2:]
 best, med = min(walls), sorted(walls)[len(walls) // 2]
 print("K=%d: step ms min %.2f median %.2f -> %.0f seq/s (median)  all: %s" % (
     K, best, med, K * len(prepared) / med * 1e3, " ".join("%.1f" % w for w in walls)), flush=True)
+if "--free" in sys.argv and K > 1:
+    # the same work without a barrier between the steps: every batch folded `reps` times back to back (sq_fold_concurrent_n)
+    torch.cuda.synchronize(); c0 = time.process_time(); t0 = time.perf_counter()
+    fold_concurrently(batches, reps=reps, poollim=1000)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("K=%d free-running: %.2f ms per step-equivalent -> %.0f seq/s; CPU %.1f busy" % (
+        K, dt / reps * 1e3, K * len(prepared) * reps / dt, (time.process_time() - c0) / dt), flush=True)
 cpu = time.process_time() - cpu0[0]; wall = time.perf_counter() - cpu0[1]
 print("      CPU: %.1f ms of process CPU time per step = %.1f busy CPUs on average" % (cpu / reps * 1e3, cpu / wall), flush=True)
 for b in batches:
