@@ -8,6 +8,7 @@ cp $(find /tmp/bstats -name "*kernel_stats.csv" | head -1) $out/r02_bench_kernel
 { for w in S300 S1000 S2000; do python bench.py --workload $w --steps 10 --warmup 2 2>/dev/null | tail -1; done; } > $out/r02_sharded_world1.txt
 { echo "== one 219-record set per batch"; for k in 1 2 4 8 12; do python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=|CPU"; done;
   echo "== two sets per batch (PROBE_REPLICAS=2)"; for k in 1 2 4 8 12; do PROBE_REPLICAS=2 python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=|CPU"; done;
+  echo "== three sets per batch, lock step and free-running (sq_fold_concurrent_n: no barrier between the steps)"; for k in 4 8 12; do PROBE_REPLICAS=3 PROBE_MAX_STRUCTS=12288 python tools/concurrent_probe.py $k 20 --free 2>&1 | grep -E "^K=|CPU"; done;
   echo "== host-driven rounds (SQ_NO_POOL=1), one set per batch"; for k in 1 8; do SQ_NO_POOL=1 python tools/concurrent_probe.py $k 20 2>&1 | grep -E "^K=|CPU"; done;
   echo "== CPU time per host phase of one fold (SQ_CPUACC=1, one batch alone)"; SQ_CPUACC=1 python tools/concurrent_probe.py 1 4 2>&1 | grep "cpu ms" | tail -1; } > $out/r02_concurrency.txt
 python -m pytest tests -m gpu -q 2>&1 | grep -E " passed| failed|error" > $out/r02_gputest.txt
