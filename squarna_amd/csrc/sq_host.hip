@@ -1670,8 +1670,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         struct Wall { double t0; double &dst; ~Wall() { dst = now_s() - t0; } } wall{tl0, stats.twall};
         auto fail = [&](int rc, const std::string &msg) { stats.rc = rc; stats.err = msg; return 2; };
         if (!PI.h_fin) {
-            PI.fin_cap = (uint32_t)std::max(65536, 128 * b->njobs);
-            PI.fin_stem_cap = PI.fin_cap * 12u;
+            // the pinned log of final structures: ~64 per job, at most 2^20 entries (24 MB) + 8 stems each (256 MB); a fold
+            // that outgrows it is repeated by the host loop
+            PI.fin_cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(65536, 64 * (int64_t)b->njobs), (int64_t)1 << 20);
+            PI.fin_stem_cap = PI.fin_cap * 8u;
             void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr, *p6 = nullptr;
             if (sq_pinned_get(&p0, sizeof(SqPoolFin) * (size_t)PI.fin_cap) || sq_pinned_get(&p1, sizeof(SqStemOut) * (size_t)PI.fin_stem_cap) ||
                 sq_pinned_get(&p2, 64) || sq_pinned_get(&p3, sizeof(SqPoolJob) * (size_t)b->njobs) ||
