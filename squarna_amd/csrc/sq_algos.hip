@@ -623,6 +623,13 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
     return 0;
 }
 
+void sq_algos_abandon(sq_batch *b, SqAlgoAsync *pa)
+{
+    for (int k = 0; k < 3; k++) if (b->side[k]) hipStreamSynchronize(b->side[k]);
+    b->cand_reserved = 0;
+    delete pa;
+}
+
 int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<JobSets> &sets, const SqAlgoEndHooks *hooks)
 {
     int r = 0;
@@ -655,6 +662,10 @@ int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<J
     for (auto &it : pa->items) {
         JobSets &js = sets[q++];
         if (it.staged || r) continue;
+        if (it.stems.size() != it.jobs.size()) {          // (sq_algos_begin stopped before this item's AnnotateStems pass)
+            r = algo_annotate(b, it.jobs, it.stems);
+            if (r) break;
+        }
         size_t k0 = 0;
         const size_t arena = (size_t)b->cand_records * sizeof(SqCand);
         while (k0 < it.jobs.size() && !r) {

@@ -101,6 +101,7 @@ struct SqLane {
     uint32_t *round_seq = nullptr;            // id of the last round sent to h_seq (lanes that share the word share the counter)
     hipStream_t stream = nullptr;             // nullptr: the batch stream
     std::vector<SqOut> big_out;
+    bool out_ovf_seen = false;                // the last chunk emitted more stems than out_cap (run_round_impl splits it)
     std::vector<uint32_t> post_cnt, post_idx, post_fill;   // scratch of the round's output bucketing
 };
 
@@ -224,6 +225,7 @@ struct SqAlgoEndHooks {
 int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync *&pa);
 int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<JobSets> &sets,
                  const SqAlgoEndHooks *hooks = nullptr);
+void sq_algos_abandon(sq_batch *b, SqAlgoAsync *pa);      // error paths: waits for the side streams, releases the arena
 
 // host tail: SQRNdbnseq.py:1201-1286
 void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,

@@ -294,6 +294,7 @@ int plan(const sq_batch_desc *d, Layout &L)
     // the dense fp64 read-back (sq_bpmatrix_read) borrows the candidate arena
     L.cand_records = std::max<int64_t>(L.cand_records, (int64_t)(2 * (int64_t)L.maxn * L.maxn * 8 / sizeof(SqCand)) + 16);
     L.out_cap = (uint32_t)std::min<int64_t>(L.cand_records, (int64_t)4 << 20);
+    if (const char *e = getenv("SQ_OUT_CAP")) L.out_cap = (uint32_t)std::min<int64_t>(L.out_cap, std::max(64, atoi(e)));   // (tests: rounds split on output overflow)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     L.off_codes = take(L.ltot); L.off_flags = take(L.ltot); L.off_inc4 = take(L.ltot);
@@ -1123,7 +1124,7 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
     if (g_cpuacc_on) g_cpuacc[6] += CpuScope::now() - cpu_t0;
     const SqCounters ctr = *ln.h_ctr;
     if (ctr.cand_ovf) { sq_set_error("candidate capacity exceeded (raise cand_per_nt)"); return -3; }
-    if (ctr.out_ovf) { sq_set_error("round output capacity exceeded (lower max_structs)"); return -3; }
+    if (ctr.out_ovf) { ln.out_ovf_seen = true; sq_set_error("round output capacity exceeded (lower max_structs)"); return -3; }
     if (ctr.level_ovf) { sq_set_error("more than 64 pseudoknot levels"); return -3; }
     const uint32_t nout = ctr.nout;
     const SqOut *ho = ln.h_out;
@@ -1194,17 +1195,21 @@ static int run_round_impl(sq_batch *b, SqLane &ln, const std::vector<SView> &str
     { int r = sq_prepare_scan(b); if (r) return r; }
     out.resize(structs.size());
     const int64_t avail = &ln == &b->lane_full ? b->cand_records - b->cand_reserved : ln.cand_records;
-    size_t lo = 0;
+    size_t lo = 0, limit = (size_t)ln.max_structs;
     while (lo < structs.size()) {
         size_t hi = lo; int64_t cands = 0, strands = 0;
-        while (hi < structs.size() && (int)(hi - lo) < ln.max_structs) {
+        while (hi < structs.size() && hi - lo < limit) {
             const SqJob &J = b->jobs[structs[hi].job];
             const int64_t ns = (int64_t)structs[hi].st->strands.size();
             if (hi > lo && (cands + J.cand_cap > avail || strands + ns > ln.strand_cap)) break;
             cands += J.cand_cap; strands += ns; hi++;
         }
         if (cands > avail || strands > ln.strand_cap) { sq_set_error("structure does not fit the round buffers"); return -3; }
+        ln.out_ovf_seen = false;
         int r = run_chunk(b, ln, structs, lo, hi, mode, out, sink);
+        // more stems than the round output holds (AnnotateStems passes of thousands of records): the same structures in
+        // smaller chunks.  (Not with a sink: the alignment matrix has already taken part of the chunk.)
+        if (r == -3 && ln.out_ovf_seen && !sink && hi - lo > 1) { limit = (hi - lo) / 2; continue; }
         if (r) return r;
         lo = hi;
     }
@@ -1344,7 +1349,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     { CpuScope cpu_(9); r = sq_algos_begin(b, algos, pending); }   // AnnotateStems + matching kernels on side streams
     struct PendGuard {                                      // error paths: wait for the side streams, release the arena
         sq_batch *b; SqAlgoAsync *&p;
-        ~PendGuard() { if (p) { std::vector<JobSets> d; sq_algos_end(b, p, -1, d); p = nullptr; } }
+        ~PendGuard() { if (p) { sq_algos_abandon(b, p); p = nullptr; } }
     } guard{b, pending};
     if (r) return r;
     const double tbegin = now_s() - ta;

@@ -470,3 +470,23 @@ def test_device_pools_overflow_falls_back_and_maxstemnum():
             exp = O.SQRNdbnseq(raw[k][0], None, None, None, ps, poollim=1000)
             exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
             _same_fold(pooled[k], exp, ("pool maxstemnum", msn, k))
+
+
+def test_round_output_overflow_splits_the_round():
+    """A round that emits more stems than the round output holds (AnnotateStems passes of E / H / N over thousands of
+    records; wide pools) is repeated in smaller chunks: same results as with room for everything, for both loop drivers."""
+    from squarna_amd.engine import HipEngine
+    names, psets = conf("nobpp")
+    raw = _chain_records(80, 4242, 30, 180)
+    recs = [(s, r, x, None, psets, None) for s, r, x in raw]
+    normal = HipEngine().fold_records(recs, poollim=20)
+    os.environ["SQ_OUT_CAP"] = "3000"
+    try:
+        cramped = HipEngine().fold_records(recs, poollim=20)
+        os.environ["SQ_NO_POOL"] = "1"
+        cramped_host = HipEngine().fold_records(recs, poollim=20)
+    finally:
+        del os.environ["SQ_OUT_CAP"]
+        os.environ.pop("SQ_NO_POOL", None)
+    assert [c[:2] for c in cramped] == [n[:2] for n in normal]
+    assert [c[:2] for c in cramped_host] == [n[:2] for n in normal]
