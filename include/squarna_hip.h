@@ -222,6 +222,11 @@ SQ_API int sq_fold_concurrent_n(sq_batch *const *batches, int32_t nbatch, const 
                                 const int32_t *const *ref_off, const int32_t *const *ref_pairs, const uint8_t *const *has_ref,
                                 int32_t reps);
 
+/* Which driver ran the greedy pool loop of the batch's last fold: 0 the host loop over round kernels, 1 rounds chained on
+ * the device (poollim == 1), 2 device pools, 3 device pools that outgrew a capacity and were repeated by the host loop.
+ * All give identical results; the number is for tests and tuning (max_structs). */
+SQ_API int32_t sq_fold_driver(const sq_batch *b);
+
 /* Result getters (valid after sq_fold until the next sq_fold / destroy). */
 SQ_API int32_t sq_result_nstruct(const sq_batch *b, int32_t seq);
 /* levels: per position, 0 = unpaired, +L = opening bracket of level L, -L = closing. */

@@ -77,7 +77,9 @@ struct SqPoolIO {
     SqStrand *strands;            // [2][smax][2 pt]
     int16_t *sidx;                // [2][smax][2 pt]
     int32_t smax, pt, cmax;       // smax: slots per generation in the arrays (stride)
-    int32_t slots;                // slots usable this fold (<= smax: the candidate arena bounds it too)
+    int32_t slots;                // slots usable this fold (<= smax)
+    int32_t chunk;                // structures whose candidates fit the arena at once: slot s uses region s % chunk, and the
+                                  // round's kernels up to sq_pool_choose_kernel run over slots [k chunk, (k + 1) chunk) in turn
     int32_t poollim;
     long long maxcap;             // candidate records per slot
     SqPoolJob *jobs; int32_t njobs;
@@ -88,7 +90,7 @@ struct SqPoolIO {
     SqPoolPick *chosen;           // [smax][cmax]
     SqPoolHdr *hdr;
     SqPoolFin *h_fin; uint32_t fin_cap;             // pinned
-    SqStemOut *h_fin_stems; uint32_t fin_stem_cap;  // pinned
+    SqPoolStem *h_fin_stems; uint32_t fin_stem_cap; // pinned
     SqPoolHdr *h_hdr;                               // pinned copy, published by the scan kernel
     SqPoolJob *h_jobs;                              // pinned copy of the job records (sq_pool_publish_kernel)
 };

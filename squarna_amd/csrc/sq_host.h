@@ -137,6 +137,7 @@ struct sq_batch {
     hipStream_t lane_stream = nullptr;        // second lane of sq_fold's greedy rounds (created on first use)
     hipEvent_t lane_ev = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
+    int last_driver = 0;                  // sq_fold_driver
     int inflight = 1;                     // batches folded at the same time (sq_fold_concurrent): sizes the pool, relaxes the wait loops
     int side_streams = 3;                 // side streams of E / H / N: 3, or 2 (H and N share one) with many batches in flight
     hipEvent_t class_ev = nullptr;        // joins the blossom kernel's smaller size classes (on side[1]) into side[0]

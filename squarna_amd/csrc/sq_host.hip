@@ -1674,17 +1674,30 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         stats.tstart = tl0 - tfold0;
         struct Wall { double t0; double &dst; ~Wall() { dst = now_s() - t0; } } wall{tl0, stats.twall};
         auto fail = [&](int rc, const std::string &msg) { stats.rc = rc; stats.err = msg; return 2; };
-        if (!PI.h_fin) {
-            // the pinned log of final structures: ~64 per job, at most 2^20 entries (24 MB) + 8 stems each (256 MB); a fold
-            // that outgrows it is repeated by the host loop
-            PI.fin_cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(65536, 64 * (int64_t)b->njobs), (int64_t)1 << 20);
-            PI.fin_stem_cap = PI.fin_cap * 8u;
-            void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr, *p6 = nullptr;
-            if (sq_pinned_get(&p0, sizeof(SqPoolFin) * (size_t)PI.fin_cap) || sq_pinned_get(&p1, sizeof(SqStemOut) * (size_t)PI.fin_stem_cap) ||
-                sq_pinned_get(&p2, 64) || sq_pinned_get(&p3, sizeof(SqPoolJob) * (size_t)b->njobs) ||
+        {
+            // the pinned log of final structures: every structure of every pool ends there once.  Sized for pools that
+            // overshoot poollim a few times (~64 entries per job at least, 4 Mi entries = 96 MB at most) with 16 stems of
+            // 8 bytes each; a fold that outgrows it is repeated by the host loop
+            const int64_t per_job = std::max<int64_t>(64, 3 * (int64_t)std::min(o.poollim, 4096));
+            const uint32_t want = (uint32_t)std::min<int64_t>(std::max<int64_t>(65536, per_job * (int64_t)greedy_jobs.size()), (int64_t)4 << 20);
+            if (!PI.h_fin || PI.fin_cap < want) {
+                sq_pinned_put(PI.h_fin); sq_pinned_put(PI.h_fin_stems);
+                PI.h_fin = nullptr; PI.h_fin_stems = nullptr;
+                PI.fin_cap = want; PI.fin_stem_cap = want * 16u;
+                void *p0 = nullptr, *p1 = nullptr;
+                if (sq_pinned_get(&p0, sizeof(SqPoolFin) * (size_t)PI.fin_cap) || sq_pinned_get(&p1, sizeof(SqPoolStem) * (size_t)PI.fin_stem_cap)) {
+                    sq_pinned_put(p0);
+                    return fail(2, sq_last_error());
+                }
+                PI.h_fin = (SqPoolFin *)p0; PI.h_fin_stems = (SqPoolStem *)p1;
+            }
+        }
+        if (!PI.h_hdr) {
+            void *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr, *p6 = nullptr;
+            if (sq_pinned_get(&p2, 64) || sq_pinned_get(&p3, sizeof(SqPoolJob) * (size_t)b->njobs) ||
                 sq_pinned_get(&p4, sizeof(SqChain) * (size_t)b->njobs) || sq_pinned_get(&p5, sizeof(SqPoolJob) * (size_t)b->njobs) ||
                 sq_pinned_get(&p6, 4 * (size_t)b->njobs)) return fail(2, sq_last_error());
-            PI.h_fin = (SqPoolFin *)p0; PI.h_fin_stems = (SqStemOut *)p1; PI.h_hdr = (SqPoolHdr *)p2; PI.h_jobs = (SqPoolJob *)p3;
+            PI.h_hdr = (SqPoolHdr *)p2; PI.h_jobs = (SqPoolJob *)p3;
             b->h_pool_recs = (SqChain *)p4; b->h_pool_jobs = (SqPoolJob *)p5; b->h_pool_jobrec = (int32_t *)p6;
         }
         std::vector<int> jobs;
@@ -1700,16 +1713,19 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         const int S0 = (int)jobs.size();
         if (S0 == 0) return 0;
         const int64_t avail = b->cand_records - b->cand_reserved;
-        int slots = (int)std::min<int64_t>(std::min(PI.smax, ln.max_structs), avail / std::max<int64_t>(maxcap, 1));
+        int slots = std::min(PI.smax, ln.max_structs);
         if (const char *e = getenv("SQ_POOL_SLOTS")) slots = std::min(slots, std::max(1, atoi(e)));   // (tests: force the overflow path)
-        if (S0 > slots) return 1;
+        // structures whose candidates fit the arena at once; larger generations go through state .. choose in chunks
+        int chunk = (int)std::min<int64_t>(slots, avail / std::max<int64_t>(maxcap, 1));
+        if (const char *e = getenv("SQ_POOL_CHUNK")) chunk = std::min(chunk, std::max(1, atoi(e)));   // (tests: force chunked rounds)
+        if (S0 > slots || chunk < 1) return 1;
         for (int j = 0; j < b->njobs; j++) b->h_pool_jobrec[j] = -1;
         for (int sx = 0; sx < S0; sx++) {
             const int j = jobs[sx];
             const JobPool &P = pools[j];
             const int toff = sx * PI.pt;                     // generation 0, slot sx
             SqStruct &d = ln.h_structs[sx];
-            d.job = j; d.strand_off = 2 * toff; d.nstrand = 0; d.slot = sx; d.subopt = 0.0; d.cand_off = (int64_t)sx * maxcap;
+            d.job = j; d.strand_off = 2 * toff; d.nstrand = 0; d.slot = sx; d.subopt = 0.0; d.cand_off = (int64_t)(sx % chunk) * maxcap;
             SqChain &cr = b->h_pool_recs[sx];
             cr.toff = toff; cr.tcap = PI.pt; cr.nstems = 0; cr.anycross = 0; cr.maxstems = P.maxstemnum;
             SqPoolJob &pj = b->h_pool_jobs[sx];
@@ -1717,7 +1733,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             pj.cursubopt = P.cursubopt; pj.suboptinc = P.suboptinc; pj.suboptmax = P.suboptmax; pj.maxstems = P.maxstemnum; pj.evals = 0;
             b->h_pool_jobrec[j] = sx;
         }
-        PI.slots = slots; PI.poollim = o.poollim; PI.maxcap = maxcap; PI.njobs = S0;   // (the kernels take the batch's record)
+        PI.slots = slots; PI.chunk = chunk; PI.poollim = o.poollim; PI.maxcap = maxcap; PI.njobs = S0;   // (the kernels take the batch's record)
         const SqPoolIO pio = PI;
         SqScanArgs scan = b->scan;
         scan.ctr = ln.d_ctr;
@@ -1747,10 +1763,13 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         while (S > 0) {
             SqStruct *cur = pio.structs + (size_t)parity * pio.smax;
             SqRoundIO io;
-            io.h_structs = cur; io.h_strands = pio.strands; io.d_structs = cur; io.d_strands = pio.strands;
+            io.h_strands = pio.strands; io.d_strands = pio.strands;
             io.h_out = ln.h_out; io.d_out = ln.d_out; io.h_cap = 0; io.out_cap = 0;
             io.h_ctr = ln.h_ctr; io.h_seq = ln.h_seq;
-            launch_round_kernels(b, st, S, maxn, maxcap, need_reacts, 0.0, 0, io, scan, cur, pio.strands, true, true);
+            for (int lo = 0; lo < S; lo += chunk) {              // (stream order: a chunk's chosen stems are out before the next one reuses the arena)
+                io.h_structs = cur + lo; io.d_structs = cur + lo;
+                launch_round_kernels(b, st, std::min(chunk, S - lo), maxn, maxcap, need_reacts, 0.0, 0, io, scan, cur + lo, pio.strands, true, true);
+            }
             const uint32_t seq = ++*ln.round_seq;
             hipLaunchKernelGGL(sq_pool_scan_kernel, dim3(1), dim3(1024), 0, st, pio, scan, io, parity, seq);
             hipLaunchKernelGGL(sq_pool_extend_kernel, dim3(S), dim3(64), 0, st, b->ctx, scan, pio, parity);
@@ -1782,28 +1801,44 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             return 1;
         }
         if ((*ln.h_ctr).level_ovf) return fail(-3, "more than 64 pseudoknot levels");
-        // finstemsets of every job: the log in (round, kind, position) order
-        std::vector<uint32_t> ord(hh.nfin);
-        for (uint32_t q = 0; q < hh.nfin; q++) ord[q] = q;
-        const SqPoolFin *F = pio.h_fin;
-        std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
-            if (F[x].job != F[y].job) return F[x].job < F[y].job;
-            if (F[x].round_kind != F[y].round_kind) return F[x].round_kind < F[y].round_kind;
-            return F[x].pos < F[y].pos;
-        });
-        static_assert(sizeof(HStem) == sizeof(SqStemOut), "stem records must match");
-        for (uint32_t q : ord) {
-            const SqPoolFin &e = F[q];
-            std::vector<HStem> stems((size_t)e.nstems);
-            if (e.nstems) memcpy(stems.data(), pio.h_fin_stems + e.stem_off, sizeof(HStem) * (size_t)e.nstems);
-            pools[e.job].fin.push_back(std::move(stems));
+        // finstemsets of every job: its log entries in (round, kind, position) order
+        {
+            const SqPoolFin *F = pio.h_fin;
+            std::vector<uint32_t> start((size_t)b->njobs + 1, 0), ord(hh.nfin);
+            for (uint32_t q = 0; q < hh.nfin; q++) start[(size_t)F[q].job + 1]++;
+            for (int j = 0; j < b->njobs; j++) start[(size_t)j + 1] += start[j];
+            {
+                std::vector<uint32_t> fillp(start.begin(), start.end() - 1);
+                for (uint32_t q = 0; q < hh.nfin; q++) ord[fillp[F[q].job]++] = q;
+            }
+            auto one_job = [&](int sx) {
+                const int j = jobs[sx];
+                uint32_t *p0 = ord.data() + start[j], *p1 = ord.data() + start[(size_t)j + 1];
+                std::sort(p0, p1, [&](uint32_t x, uint32_t y) {
+                    if (F[x].round_kind != F[y].round_kind) return F[x].round_kind < F[y].round_kind;
+                    return F[x].pos < F[y].pos;
+                });
+                auto &fin = pools[j].fin;
+                fin.reserve(fin.size() + (size_t)(p1 - p0));
+                for (uint32_t *p = p0; p < p1; p++) {
+                    const SqPoolFin &e = F[*p];
+                    const SqPoolStem *src = pio.h_fin_stems + e.stem_off;
+                    std::vector<HStem> stems((size_t)e.nstems);
+                    for (int t = 0; t < e.nstems; t++) stems[t] = HStem{src[t].i, src[t].j, src[t].len, 0.0, 0.0};
+                    fin.push_back(std::move(stems));
+                }
+            };
+            if (hh.nfin >= 8192) sq_pool(b)->parallel_for(S0, one_job);
+            else for (int sx = 0; sx < S0; sx++) one_job(sx);
         }
         for (int sx = 0; sx < S0; sx++) pools[jobs[sx]].evals += pio.h_jobs[sx].evals;
         return 0;
     };
     mark("loop start");
+    b->last_driver = use_pool ? 2 : use_chain ? 1 : 0;
     if (use_pool) {
         const int pr = pool_fold(st0);
+        if (pr == 1) b->last_driver = 3;
         if (pr == 1 && timing) fprintf(stderr, "[sq_fold] device pools: a capacity was exceeded, the host loop repeats the greedy part\n");
         if (pr == 1) {                                       // a capacity was exceeded: the host's own loop takes the fold
             st0 = LoopStats();
@@ -1928,6 +1963,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 st0.tstart * 1e3, st0.twall * 1e3, st0.tround * 1e3, st0.nrounds, st1.tstart * 1e3, st1.twall * 1e3, st1.tround * 1e3, st1.nrounds);
     return 0;
 }
+
+extern "C" int32_t sq_fold_driver(const sq_batch *b) { return b ? b->last_driver : -1; }
 
 extern "C" int sq_fold_concurrent(sq_batch *const *batches, int32_t nbatch, const sq_fold_opts *opts,
                                   const int32_t *const *ref_off, const int32_t *const *ref_pairs, const uint8_t *const *has_ref)

@@ -125,6 +125,9 @@ struct SqPoolFin {            // one final structure (pinned): finstemsets order
     uint32_t stem_off;        // into the pinned stem log
     uint32_t pad;
 };
+struct SqPoolStem {           // a stem of a final structure in the pinned log (positions fit 16 bits: SQ_MAXLEN)
+    int16_t i, j, len, pad;
+};
 struct SqPoolPick {           // a stem chosen for a parent (ChooseStems' output list)
     uint32_t key, len;
     double bps, fin;

@@ -17,7 +17,9 @@
 //            reach maxstemnum (:1123-1129) go to the pinned log of final structures with their place in finstemsets'
 //            order (round, kind, position).
 // The host launches the rounds with the exact grid (it reads the next round's size the scan kernel publishes, while
-// the extend kernel is still running) and only sorts the log at the end.  Any capacity overflow (slots, chosen stems
+// the extend kernel is still running) and only sorts the log at the end.  A generation may hold more structures than
+// the candidate arena has room for: state .. choose then run over the list in chunks that reuse the arena (what a
+// structure leaves behind for scan / extend -- its chosen stems -- sits in per-slot arrays).  Any capacity overflow (slots, chosen stems
 // per structure, survivors per structure, log) sets a flag and the host repeats the fold with its own loop.
 #include <hip/hip_runtime.h>
 #include "sq_device.h"
@@ -56,8 +58,9 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_choose_kernel(SqDevCtx 
     __shared__ double s_fin[SQ_POOL_NSURV];
     __shared__ uint16_t s_ord[SQ_POOL_NSURV];
     __shared__ int s_ri[SQ_POOL_CMAX], s_rj[SQ_POOL_CMAX], s_rl[SQ_POOL_CMAX];
-    const int s = blockIdx.x, lane = threadIdx.x;
-    const SqStruct st = structs[s];
+    const int lane = threadIdx.x;
+    const SqStruct st = structs[blockIdx.x];                // (structs: the chunk of the round's list this launch covers)
+    const int s = st.slot;                                  // == the structure's position in the round's list
     if (st.nstrand < 0) {                                   // a child that was full (:1123-1129): logged when it was made
         if (lane == 0) { pio.nchild[s] = 0; pio.finalflag[s] = 0; }
         return;
@@ -209,7 +212,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_extend_kernel(SqDevCtx 
         if (lane == 0) { idx = atomicAdd(&pio.hdr->nfin, 1u); so = atomicAdd(&pio.hdr->nfin_stems, (uint32_t)nst); }
         idx = (uint32_t)__shfl((int)idx, 0, 64); so = (uint32_t)__shfl((int)so, 0, 64);
         if (idx >= pio.fin_cap || so + (uint32_t)nst > pio.fin_stem_cap) { if (lane == 0) pio.hdr->ovf = 1; return; }
-        for (int q = lane; q < nst; q += 64) { const SqChainStem x = stems[q]; pio.h_fin_stems[so + q] = SqStemOut{x.i, x.j, x.len, 0, 0.0, 0.0}; }
+        for (int q = lane; q < nst; q += 64) { const SqChainStem x = stems[q]; pio.h_fin_stems[so + q] = SqPoolStem{(int16_t)x.i, (int16_t)x.j, (int16_t)x.len, 0}; }
         if (lane == 0) pio.h_fin[idx] = SqPoolFin{st.job, round_kind, pos, nst, so, 0u};
     };
     if (st.nstrand < 0) return;                              // full child of the previous round: logged then
@@ -238,7 +241,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_extend_kernel(SqDevCtx 
         if (lane == 0) {
             SqStruct cs;
             cs.job = st.job; cs.strand_off = 2 * toff; cs.nstrand = full ? -1 : st.nstrand + 2; cs.slot = cslot; cs.subopt = 0.0;
-            cs.cand_off = (int64_t)cslot * pio.maxcap;
+            cs.cand_off = (int64_t)(cslot % pio.chunk) * pio.maxcap;
             pio.structs[nxt + cslot] = cs;
             SqChain cr;
             cr.toff = toff; cr.tcap = pio.pt; cr.nstems = T; cr.anycross = anyc ? 1 : 0; cr.maxstems = rec.maxstems;

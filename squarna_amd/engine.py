@@ -300,6 +300,12 @@ class Batch:
         o, ref_off, rp, has = self._fold_args(**opts)
         _lib.check(self.L.sq_fold(self.h, C.byref(o), _ptr(ref_off), _ptr(rp), _ptr(has)))
 
+    @property
+    def fold_driver(self):
+        """Driver of the last fold's greedy pool loop (sq_fold_driver): 0 host loop, 1 chained rounds, 2 device pools,
+        3 device pools repeated by the host loop."""
+        return int(self.L.sq_fold_driver(self.h))
+
     def _fold_args(self, poollim=1000, conslim=1, toplim=5, hardrest=False, rankbydiff=False,
                    rankby=(0, 2, 1), levellimit=None, algos=frozenset(), priority=None):
         o = _lib.FoldOpts()
@@ -533,6 +539,21 @@ def bpp_terms(prepared, psets, M=1.8, B=-0.6):
     return out
 
 
+def pool_slots(prepared, psets, poollim):
+    """Structure slots for a fold with pools wider than 1: the device pools (sq_pool.hip) hold a whole generation of
+    every greedy job's pool, which overshoots poollim a few times before the stopper (SQRNdbnseq.py:1147) holds it; a slot
+    costs ~56 bytes per nucleotide, and the slots stay within a sixth of the free device memory (at most 2 Mi)."""
+    import torch
+    ng = sum(1 for pl in psets for ps in pl if "G" in ps["algorithms"])
+    if not ng:
+        return 0
+    maxn = max(len(p.shortseq) for p in prepared)
+    per_slot = 8 * (maxn + 34) + 72 * (maxn // 2 + 1) + 2600
+    free = torch.cuda.mem_get_info()[0] if torch.cuda.is_available() else 16 << 30
+    cap = min(free // 6 // per_slot, 2 << 20)
+    return int(max(0, min(3 * ng * min(int(poollim), 1024), cap)))
+
+
 class HipEngine:
     """Default engine: everything on the GPU through libsquarna_hip.so."""
     name = "hip"
@@ -577,6 +598,8 @@ class HipEngine:
         # the library's host loop)
         njobs = sum(len(pl) for pl in psets)
         max_structs = self.max_structs if self.max_structs else max(4096, min(4 * njobs, 262144))
+        if not self.max_structs and opts.get("poollim", 1000) > 1:
+            max_structs = max(max_structs, pool_slots(prepared, psets, opts.get("poollim", 1000)))
         # SQ_ENGINE_LANES=2 folds big inputs as two concurrent batches; for one-shot calls the second batch's set-up
         # (pinned buffers, worker pool) costs more than the overlap saves, so it is opt-in (long-lived batches
         # profit: fold_concurrently / sq_fold_concurrent)
@@ -586,6 +609,7 @@ class HipEngine:
             with Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
                        max_structs=max_structs, cand_per_nt=self.cand_per_nt) as b:
                 b.fold(**opts)
+                self.last_fold_driver = b.fold_driver
                 both = b.results_all()
                 self.last_ref_scores = [r[1] for r in both]
                 return [r[0] for r in both]

@@ -457,7 +457,9 @@ def test_device_pools_overflow_falls_back_and_maxstemnum():
     normal = HipEngine().fold_records(recs, poollim=1000)
     os.environ["SQ_POOL_SLOTS"] = str(2 * len(recs) + 3)            # room for the first generation only
     try:
-        cramped = HipEngine().fold_records(recs, poollim=1000)
+        eng = HipEngine()
+        cramped = eng.fold_records(recs, poollim=1000)
+        assert eng.last_fold_driver == 3                      # device pools gave up, the host loop repeated the fold
     finally:
         del os.environ["SQ_POOL_SLOTS"]
     assert [c[:2] for c in cramped] == [n[:2] for n in normal]
@@ -490,3 +492,23 @@ def test_round_output_overflow_splits_the_round():
         os.environ.pop("SQ_NO_POOL", None)
     assert [c[:2] for c in cramped] == [n[:2] for n in normal]
     assert [c[:2] for c in cramped_host] == [n[:2] for n in normal]
+
+
+@pytest.mark.parametrize("chunk", [1, 7, 64])
+def test_device_pools_in_chunks(chunk):
+    """Generations larger than the candidate arena go through state .. choose in chunks that reuse the arena
+    (SQ_POOL_CHUNK forces small ones): same structures, scores and ranks as one chunk and as the host loop."""
+    from squarna_amd.engine import HipEngine
+    names, psets = conf("nobpp")
+    raw = _chain_records(40, 1717, 20, 200)
+    recs = [(s, r, x, None, psets, None) for s, r, x in raw]
+    pooled, hosted = _fold_pool_and_host(recs, poollim=30)
+    os.environ["SQ_POOL_CHUNK"] = str(chunk)
+    try:
+        eng = HipEngine()
+        chunked = eng.fold_records(recs, poollim=30)
+        assert eng.last_fold_driver == 2                      # (not a fallback to the host loop)
+    finally:
+        del os.environ["SQ_POOL_CHUNK"]
+    assert [c[:2] for c in chunked] == [p[:2] for p in pooled]
+    assert [c[:2] for c in chunked] == [h[:2] for h in hosted]
