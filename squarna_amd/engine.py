@@ -539,19 +539,22 @@ def bpp_terms(prepared, psets, M=1.8, B=-0.6):
     return out
 
 
-def pool_slots(prepared, psets, poollim):
-    """Structure slots for a fold with pools wider than 1: the device pools (sq_pool.hip) hold a whole generation of
-    every greedy job's pool, which overshoots poollim a few times before the stopper (SQRNdbnseq.py:1147) holds it; a slot
-    costs ~56 bytes per nucleotide, and the slots stay within a sixth of the free device memory (at most 2 Mi)."""
+def pool_slot_cap(maxn):
+    """Most structure slots a batch of sequences up to maxn nt should get: a slot of the device pools (sq_pool.hip) costs
+    ~56 bytes per nucleotide; all slots stay within a sixth of the free device memory (at most 2 Mi)."""
     import torch
-    ng = sum(1 for pl in psets for ps in pl if "G" in ps["algorithms"])
-    if not ng:
-        return 0
-    maxn = max(len(p.shortseq) for p in prepared)
     per_slot = 8 * (maxn + 34) + 72 * (maxn // 2 + 1) + 2600
     free = torch.cuda.mem_get_info()[0] if torch.cuda.is_available() else 16 << 30
-    cap = min(free // 6 // per_slot, 2 << 20)
-    return int(max(0, min(3 * ng * min(int(poollim), 1024), cap)))
+    return int(max(4096, min(free // 6 // per_slot, 2 << 20)))
+
+
+def pool_slots_wanted(ngreedy, poollim):
+    """Structure slots for a fold with pools wider than 1: the device pools hold a whole generation of every greedy job's
+    pool, which overshoots poollim before the stopper (SQRNdbnseq.py:1147) holds it -- pools grow by a factor of 1.5 to
+    3.5 per round.  Measured on random 300-nt sequences: generations peak at 0.5 x jobs x poollim for poollim 1000 (many
+    pools never get there) and above 1 x for poollim 100."""
+    p = min(int(poollim), 1024)
+    return int(ngreedy) * min(3 * p, p + 512)
 
 
 class HipEngine:
@@ -579,6 +582,24 @@ class HipEngine:
                 gc.enable()
 
     def _fold_records(self, records, **opts):
+        poollim = opts.get("poollim", 1000)
+        if not self.max_structs and poollim > 1 and len(records) > 1:
+            # wide pools: as many records per batch as the device pools have slots for (a fold that outgrows them is
+            # repeated by the library's host loop -- correct, but several times slower)
+            per_rec = [sum(1 for ps in r[4] if "G" in ps["algorithms"]) for r in records]
+            cap = pool_slot_cap(max(len(r[0]) for r in records))
+            if pool_slots_wanted(sum(per_rec), poollim) > cap:
+                out, refs, lo = [], [], 0
+                while lo < len(records):
+                    hi, g = lo, 0
+                    while hi < len(records) and (hi == lo or pool_slots_wanted(g + per_rec[hi], poollim) <= cap):
+                        g += per_rec[hi]
+                        hi += 1
+                    out.extend(self._fold_records(records[lo:hi], **opts))
+                    refs.extend(self.last_ref_scores)
+                    lo = hi
+                self.last_ref_scores = refs
+                return out
         interchainonly = opts.pop("interchainonly", False)
         M, B = opts.pop("M", 1.8), opts.pop("B", -0.6)
         prepared = [Prepared(r[0], r[1], r[2], r[3]) for r in records]
@@ -599,7 +620,9 @@ class HipEngine:
         njobs = sum(len(pl) for pl in psets)
         max_structs = self.max_structs if self.max_structs else max(4096, min(4 * njobs, 262144))
         if not self.max_structs and opts.get("poollim", 1000) > 1:
-            max_structs = max(max_structs, pool_slots(prepared, psets, opts.get("poollim", 1000)))
+            ng = sum(1 for pl in psets for ps in pl if "G" in ps["algorithms"])
+            max_structs = max(max_structs, min(pool_slots_wanted(ng, opts.get("poollim", 1000)),
+                                               pool_slot_cap(max(len(p.shortseq) for p in prepared))))
         # SQ_ENGINE_LANES=2 folds big inputs as two concurrent batches; for one-shot calls the second batch's set-up
         # (pinned buffers, worker pool) costs more than the overlap saves, so it is opt-in (long-lived batches
         # profit: fold_concurrently / sq_fold_concurrent)

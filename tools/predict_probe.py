@@ -24,4 +24,7 @@ for r in range(reps):
     Predict(inputfile=path, inputformat="q", configfile=conf, write_to=buf, **kw)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("%s Predict: %.1f ms -> %.0f seq/s (%d chars)" % (wl, dt * 1e3, len(items) / dt, len(buf.getvalue())), flush=True)
+if os.environ.get("PROBE_SHA"):
+    import hashlib
+    print("sha256 of the output:", hashlib.sha256(buf.getvalue().encode()).hexdigest(), flush=True)
 os.unlink(path)
