@@ -228,6 +228,10 @@ SQ_API int sq_fold_concurrent_n(sq_batch *const *batches, int32_t nbatch, const 
 SQ_API int32_t sq_fold_driver(const sq_batch *b);
 
 /* Result getters (valid after sq_fold until the next sq_fold / destroy). */
+/* k > 0: the getters below (single and bulk) show only the first k structures of every sequence, in rank order -- a
+ * caller that prints the top few (RunSQRNdbnseq's outplim, SQRNdbnseq.py:1289-1410) need not fetch a pool of a thousand.
+ * k = 0 (default): all of them, as SQRNdbnseq returns them.  Consensus and metrics do not depend on it. */
+SQ_API int sq_result_limit(sq_batch *b, int32_t k);
 SQ_API int32_t sq_result_nstruct(const sq_batch *b, int32_t seq);
 /* levels: per position, 0 = unpaired, +L = opening bracket of level L, -L = closing. */
 SQ_API int sq_result_consensus(const sq_batch *b, int32_t seq, int16_t *levels);

@@ -200,7 +200,8 @@ def Predict(inputfile=None, fileformat="unknown", inputseq=None, configfile=None
 
     eng = _engine.get_engine()
     common = dict(conslim=conslim, toplim=toplim, hardrest=hardrest, rankbydiff=rankbydiff, rankby=rankby,
-                  interchainonly=interchainonly, poollim=poollim, algos=algos, levellimit=levellimit, M=M, B=B)
+                  interchainonly=interchainonly, poollim=poollim, algos=algos, levellimit=levellimit, M=M, B=B,
+                  keep=max(int(outplim), 1))                     # (only the printed structures are fetched)
 
     def flush(batch):
         """Fold a batch of records on the GPU, then print every block in input order."""

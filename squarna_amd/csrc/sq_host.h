@@ -138,6 +138,7 @@ struct sq_batch {
     hipEvent_t lane_ev = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
     int last_driver = 0;                  // sq_fold_driver
+    int32_t result_limit = 0;             // sq_result_limit (0: the getters show every structure)
     int inflight = 1;                     // batches folded at the same time (sq_fold_concurrent): sizes the pool, relaxes the wait loops
     int side_streams = 3;                 // side streams of E / H / N: 3, or 2 (H and N share one) with many batches in flight
     hipEvent_t class_ev = nullptr;        // joins the blossom kernel's smaller size classes (on side[1]) into side[0]

@@ -2002,10 +2002,22 @@ extern "C" int sq_fold_concurrent_n(sq_batch *const *batches, int32_t nbatch, co
 }
 
 // ---- result getters ------------------------------------------------------------------------------
+// structures of a sequence the getters show: all of them, or the first result_limit in rank order (sq_result_limit)
+static inline int64_t shown(const sq_batch *b, const SeqResult &R)
+{
+    const int64_t ns = (int64_t)R.preds.size();
+    return b->result_limit > 0 ? std::min<int64_t>(ns, b->result_limit) : ns;
+}
+extern "C" int sq_result_limit(sq_batch *b, int32_t k)
+{
+    if (!b || k < 0) { sq_set_error("bad argument"); return -1; }
+    b->result_limit = k;
+    return 0;
+}
 extern "C" int32_t sq_result_nstruct(const sq_batch *b, int32_t seq)
 {
     if (!b || seq < 0 || seq >= b->nseq) return -1;
-    return (int32_t)b->results[seq].preds.size();
+    return (int32_t)shown(b, b->results[seq]);
 }
 extern "C" int sq_result_consensus(const sq_batch *b, int32_t seq, int16_t *levels)
 {
@@ -2019,7 +2031,7 @@ extern "C" int sq_result_struct(const sq_batch *b, int32_t seq, int32_t k, int16
 {
     if (!b || seq < 0 || seq >= b->nseq) return -1;
     const auto &R = b->results[seq];
-    if (k < 0 || k >= (int)R.preds.size()) return -1;
+    if (k < 0 || k >= (int)shown(b, R)) return -1;
     memcpy(levels, R.preds[k].levels.data(), R.preds[k].levels.size() * sizeof(int16_t));
     for (int t = 0; t < 3; t++) scores[t] = R.preds[k].scores[t];
     *pset_mask = R.preds[k].pset_mask;
@@ -2044,7 +2056,7 @@ extern "C" int64_t sq_result_pack_size(const sq_batch *b, int32_t seq)
 {
     if (!b || seq < 0 || seq >= b->nseq) return -1;
     const auto &R = b->results[seq];
-    const int64_t ns = (int64_t)R.preds.size(), n = (int64_t)R.cons.size();
+    const int64_t ns = shown(b, R), n = (int64_t)R.cons.size();
     return 8 * 4 + 8 * 16 + 8 * 3 * ns + 8 * ns + 2 * (1 + ns) * n;
 }
 extern "C" int sq_result_pack(const sq_batch *b, int32_t seq, void *buf, int64_t cap)
@@ -2052,7 +2064,7 @@ extern "C" int sq_result_pack(const sq_batch *b, int32_t seq, void *buf, int64_t
     const int64_t need = sq_result_pack_size(b, seq);
     if (need < 0 || cap < need) { sq_set_error("result buffer too small"); return -1; }
     const auto &R = b->results[seq];
-    const int64_t ns = (int64_t)R.preds.size(), n = (int64_t)R.cons.size();
+    const int64_t ns = shown(b, R), n = (int64_t)R.cons.size();
     char *p = (char *)buf;
     int64_t hdr[4] = {ns, n, R.has_ref ? 1 : 0, R.evals};
     memcpy(p, hdr, 32); p += 32;
@@ -2104,7 +2116,7 @@ extern "C" int64_t sq_result_dbn_all_size(const sq_batch *b)
 {
     if (!b) return -1;
     int64_t tot = 0;
-    for (int s = 0; s < b->nseq; s++) tot += (int64_t)(b->results[s].preds.size() + 1) * (int64_t)b->results[s].cons.size();
+    for (int s = 0; s < b->nseq; s++) tot += (shown(b, b->results[s]) + 1) * (int64_t)b->results[s].cons.size();
     return tot;
 }
 extern "C" int sq_result_dbn_all(const sq_batch *b, char *buf, int64_t cap, int64_t *off, uint8_t *deep)
@@ -2119,7 +2131,8 @@ extern "C" int sq_result_dbn_all(const sq_batch *b, char *buf, int64_t cap, int6
         const SeqResult &R = b->results[s];
         const int64_t n = (int64_t)R.cons.size();
         off[s] = o;
-        if (o + (int64_t)(R.preds.size() + 1) * n > cap) { sq_set_error("text buffer too small"); return -1; }
+        const int64_t ns = shown(b, R);
+        if (o + (ns + 1) * n > cap) { sq_set_error("text buffer too small"); return -1; }
         bool dp = false;
         auto row = [&](const std::vector<int16_t> &lv) {
             for (int64_t i = 0; i < n; i++) {
@@ -2132,7 +2145,7 @@ extern "C" int sq_result_dbn_all(const sq_batch *b, char *buf, int64_t cap, int6
             o += n;
         };
         row(R.cons);
-        for (const auto &p : R.preds) row(p.levels);
+        for (int64_t k = 0; k < ns; k++) row(R.preds[k].levels);
         deep[s] = dp ? 1 : 0;
     }
     off[b->nseq] = o;

@@ -300,6 +300,10 @@ class Batch:
         o, ref_off, rp, has = self._fold_args(**opts)
         _lib.check(self.L.sq_fold(self.h, C.byref(o), _ptr(ref_off), _ptr(rp), _ptr(has)))
 
+    def limit_results(self, k):
+        """The result getters show only the first k structures of every record (sq_result_limit; 0 = all)."""
+        _lib.check(self.L.sq_result_limit(self.h, int(k or 0)))
+
     @property
     def fold_driver(self):
         """Driver of the last fold's greedy pool loop (sq_fold_driver): 0 host loop, 1 chained rounds, 2 device pools,
@@ -582,6 +586,7 @@ class HipEngine:
                 gc.enable()
 
     def _fold_records(self, records, **opts):
+        """`keep`: only the first `keep` structures of every record are fetched (Predict prints outplim of them)."""
         poollim = opts.get("poollim", 1000)
         if not self.max_structs and poollim > 1 and len(records) > 1:
             # wide pools: as many records per batch as the device pools have slots for (a fold that outgrows them is
@@ -601,6 +606,7 @@ class HipEngine:
                 self.last_ref_scores = refs
                 return out
         interchainonly = opts.pop("interchainonly", False)
+        keep = opts.pop("keep", None)
         M, B = opts.pop("M", 1.8), opts.pop("B", -0.6)
         prepared = [Prepared(r[0], r[1], r[2], r[3]) for r in records]
         psets = [r[4] for r in records]
@@ -633,6 +639,7 @@ class HipEngine:
                        max_structs=max_structs, cand_per_nt=self.cand_per_nt) as b:
                 b.fold(**opts)
                 self.last_fold_driver = b.fold_driver
+                b.limit_results(keep)
                 both = b.results_all()
                 self.last_ref_scores = [r[1] for r in both]
                 return [r[0] for r in both]
@@ -652,6 +659,8 @@ class HipEngine:
                                      mul=pick(mul, True), bpp=pick(bpp, True), fp32=False,
                                      max_structs=max_structs, cand_per_nt=self.cand_per_nt))
             fold_concurrently(batches, **opts)
+            for b in batches:
+                b.limit_results(keep)
             out = [None] * nrec
             self.last_ref_scores = [None] * nrec
             for b, idx in zip(batches, parts):

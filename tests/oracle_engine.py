@@ -9,6 +9,7 @@ class OracleEngine:
     name = "oracle"
 
     def fold_records(self, records, **opts):
+        opts.pop("keep", None)                   # (an engine option: how many structures to fetch; the oracle returns all)
         out = []
         for rec in records:
             seq, reacts, restraints, dbn, paramsets = rec[:5]

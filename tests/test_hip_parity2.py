@@ -512,3 +512,16 @@ def test_device_pools_in_chunks(chunk):
         del os.environ["SQ_POOL_CHUNK"]
     assert [c[:2] for c in chunked] == [p[:2] for p in pooled]
     assert [c[:2] for c in chunked] == [h[:2] for h in hosted]
+
+
+def test_result_limit_shows_the_top_structures_only():
+    """sq_result_limit / fold_records(keep=k): the first k structures of every record, consensus and metrics unchanged."""
+    from squarna_amd.engine import HipEngine
+    names, psets = conf("nobpp")
+    raw = _chain_records(30, 99, 20, 160)
+    recs = [(s, r, x, None, psets, None) for s, r, x in raw]
+    full = HipEngine().fold_records(recs, poollim=50)
+    top = HipEngine().fold_records(recs, poollim=50, keep=3)
+    assert any(len(f[1]) > 3 for f in full)
+    for f, t in zip(full, top):
+        assert t[0] == f[0] and t[1] == f[1][:3] and len(t[1]) == min(3, len(f[1]))
