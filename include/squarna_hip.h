@@ -230,7 +230,9 @@ SQ_API int32_t sq_fold_driver(const sq_batch *b);
 /* Result getters (valid after sq_fold until the next sq_fold / destroy). */
 /* k > 0: the getters below (single and bulk) show only the first k structures of every sequence, in rank order -- a
  * caller that prints the top few (RunSQRNdbnseq's outplim, SQRNdbnseq.py:1289-1410) need not fetch a pool of a thousand.
- * k = 0 (default): all of them, as SQRNdbnseq returns them.  Consensus and metrics do not depend on it. */
+ * k = 0 (default): all of them, as SQRNdbnseq returns them.  Consensus and metrics do not depend on it.  A limit set
+ * BEFORE sq_fold also spares the fold the bracket strings of the structures beyond it (most of the ranking tail's time
+ * for pools of a thousand); those structures are then not kept, and raising the limit afterwards does not bring them back. */
 SQ_API int sq_result_limit(sq_batch *b, int32_t k);
 SQ_API int32_t sq_result_nstruct(const sq_batch *b, int32_t seq);
 /* levels: per position, 0 = unpaired, +L = opening bracket of level L, -L = closing. */

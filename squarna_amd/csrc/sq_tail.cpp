@@ -388,9 +388,13 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
 #ifdef SQ_TAIL_PROF
     const double tp2 = nowus();
 #endif
+    // (sq_result_limit in force: the bracket strings -- three quarters of this function's time on pools of a thousand --
+    // are only formed for the structures the getters will show)
+    const size_t nshow = b->result_limit > 0 ? std::min<size_t>(fins.size(), (size_t)b->result_limit) : fins.size();
     res.preds.clear();
-    res.preds.reserve(fins.size());
-    for (Entry &e : fins) {                                            // :1232-1234
+    res.preds.reserve(nshow);
+    for (size_t fk = 0; fk < nshow; fk++) {                            // :1232-1234
+        Entry &e = fins[fk];
         res.preds.emplace_back();
         SeqResult::Pred &p = res.preds.back();
         if (forced.empty()) levels_of_stems(*e.stems, n, p.levels);

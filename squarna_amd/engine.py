@@ -637,9 +637,9 @@ class HipEngine:
         if lanes < 2 or nrec < 256 or sum(cost) < 1e8:
             with Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
                        max_structs=max_structs, cand_per_nt=self.cand_per_nt) as b:
+                b.limit_results(keep)
                 b.fold(**opts)
                 self.last_fold_driver = b.fold_driver
-                b.limit_results(keep)
                 both = b.results_all()
                 self.last_ref_scores = [r[1] for r in both]
                 return [r[0] for r in both]
@@ -658,9 +658,9 @@ class HipEngine:
                 batches.append(Batch(pick(prepared, False), pick(psets, False), interchainonly=interchainonly,
                                      mul=pick(mul, True), bpp=pick(bpp, True), fp32=False,
                                      max_structs=max_structs, cand_per_nt=self.cand_per_nt))
-            fold_concurrently(batches, **opts)
             for b in batches:
                 b.limit_results(keep)
+            fold_concurrently(batches, **opts)
             out = [None] * nrec
             self.last_ref_scores = [None] * nrec
             for b, idx in zip(batches, parts):
