@@ -1012,7 +1012,12 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
         // mode 0 (two-phase loop): ~512 blocks of 512 threads; the one-pass modes want many small blocks in flight
         int parts = std::max(1, std::min({512, ((mode == 0 ? score_target : 4096) + S - 1) / S, (int)(maxcap / 1024)}));
         if (score_parts) parts = score_parts;
-        const int thr = score_threads ? score_threads : (mode == 0 ? 512 : (parts == 1 && S < 2048 ? 512 : 256));
+        // mode 0: 512 threads per structure suit long sequences (S1000: 4.6 ms against 5.4 ms; S2000: 28 against 36);
+        // short ones leave half of such a block idle behind its set-up (n = 300: 10,000 chains 5.9 -> 4.6 ms, pools
+        // of a thousand 24 -> 16 ns per structure and round with 256).  SRtest150 (up to ~500 nt) measures the same
+        // either way within the run-to-run spread and keeps 512.
+        const int thr0 = maxn <= 400 ? 256 : 512;
+        const int thr = score_threads ? score_threads : (mode == 0 ? thr0 : (parts == 1 && S < 2048 ? 512 : 256));
         // mode 0: list of the bpscore survivors of a chunk (5 x threads entries of 8 + 4 + 2 bytes) behind the tables
         const int surv_off = (int)((dyn + 15) & ~(size_t)15);
         dyn = (size_t)surv_off + (size_t)14 * (SQ_SCORE_CHUNK + (mode == 0 ? 1 : 0)) * thr;   // (one-pass modes: no carry-over)
