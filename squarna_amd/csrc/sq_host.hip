@@ -1680,15 +1680,17 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         struct Wall { double t0; double &dst; ~Wall() { dst = now_s() - t0; } } wall{tl0, stats.twall};
         auto fail = [&](int rc, const std::string &msg) { stats.rc = rc; stats.err = msg; return 2; };
         {
-            // the pinned log of final structures: every structure of every pool ends there once.  Sized for pools that
-            // overshoot poollim a few times (~64 entries per job at least, 4 Mi entries = 96 MB at most) with 16 stems of
-            // 8 bytes each; a fold that outgrows it is repeated by the host loop
-            const int64_t per_job = std::max<int64_t>(64, 3 * (int64_t)std::min(o.poollim, 4096));
-            const uint32_t want = (uint32_t)std::min<int64_t>(std::max<int64_t>(65536, per_job * (int64_t)greedy_jobs.size()), (int64_t)4 << 20);
-            if (!PI.h_fin || PI.fin_cap < want) {
+            // the pinned log of final structures: every structure of every pool ends there once -- measured: 1.4 x the
+            // largest generation.  Two entries per usable slot (65,536 at least, 4 Mi = 96 MB at most) with a third of the
+            // most stems a structure can hold each (8 .. 128; 8 bytes per stem, 48 Mi stems = 384 MB at most); a fold
+            // that outgrows it is repeated by the host loop
+            const int64_t nslots = std::min(PI.smax, ln.max_structs);
+            const uint32_t want = (uint32_t)std::min<int64_t>(std::max<int64_t>(65536, 2 * nslots), (int64_t)4 << 20);
+            const uint32_t want_stems = (uint32_t)std::min<int64_t>((int64_t)want * std::min(std::max(PI.pt / 3, 8), 128), (int64_t)48 << 20);
+            if (!PI.h_fin || PI.fin_cap < want || PI.fin_stem_cap < want_stems) {
                 sq_pinned_put(PI.h_fin); sq_pinned_put(PI.h_fin_stems);
                 PI.h_fin = nullptr; PI.h_fin_stems = nullptr;
-                PI.fin_cap = want; PI.fin_stem_cap = want * 16u;
+                PI.fin_cap = want; PI.fin_stem_cap = want_stems;
                 void *p0 = nullptr, *p1 = nullptr;
                 if (sq_pinned_get(&p0, sizeof(SqPoolFin) * (size_t)PI.fin_cap) || sq_pinned_get(&p1, sizeof(SqPoolStem) * (size_t)PI.fin_stem_cap)) {
                     sq_pinned_put(p0);

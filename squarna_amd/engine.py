@@ -552,13 +552,17 @@ def pool_slot_cap(maxn):
     return int(max(4096, min(free // 6 // per_slot, 2 << 20)))
 
 
-def pool_slots_wanted(ngreedy, poollim):
-    """Structure slots for a fold with pools wider than 1: the device pools hold a whole generation of every greedy job's
-    pool, which overshoots poollim before the stopper (SQRNdbnseq.py:1147) holds it -- pools grow by a factor of 1.5 to
-    3.5 per round.  Measured on random 300-nt sequences: generations peak at 0.5 x jobs x poollim for poollim 1000 (many
-    pools never get there) and above 1 x for poollim 100."""
+def pool_slots_wanted(ngreedy, poollim, n=None):
+    """Structure slots for `ngreedy` greedy jobs of an n-nt sequence under pools wider than 1: the device pools hold a
+    whole generation of every job's pool.  A pool overshoots poollim before the stopper (SQRNdbnseq.py:1147) holds it (it
+    grows by a factor of 1.5 to 3.5 per round), and a short sequence never fills it: measured on random sequences the
+    generations peak at ~1.75e-5 n^3 structures per job (6 at 20-120 nt, 485 at 300 nt) until poollim bounds them (130
+    at 1000 nt under poollim 100).  Twice that, and at least 16."""
     p = min(int(poollim), 1024)
-    return int(ngreedy) * min(3 * p, p + 512)
+    per_job = min(3 * p, p + 512)
+    if n is not None:
+        per_job = min(per_job, max(16, int(4e-5 * float(n) ** 3)))
+    return int(ngreedy) * per_job
 
 
 class HipEngine:
@@ -591,13 +595,13 @@ class HipEngine:
         if not self.max_structs and poollim > 1 and len(records) > 1:
             # wide pools: as many records per batch as the device pools have slots for (a fold that outgrows them is
             # repeated by the library's host loop -- correct, but several times slower)
-            per_rec = [sum(1 for ps in r[4] if "G" in ps["algorithms"]) for r in records]
+            per_rec = [pool_slots_wanted(sum(1 for ps in r[4] if "G" in ps["algorithms"]), poollim, len(r[0])) for r in records]
             cap = pool_slot_cap(max(len(r[0]) for r in records))
-            if pool_slots_wanted(sum(per_rec), poollim) > cap:
+            if sum(per_rec) > cap:
                 out, refs, lo = [], [], 0
                 while lo < len(records):
                     hi, g = lo, 0
-                    while hi < len(records) and (hi == lo or pool_slots_wanted(g + per_rec[hi], poollim) <= cap):
+                    while hi < len(records) and (hi == lo or g + per_rec[hi] <= cap):
                         g += per_rec[hi]
                         hi += 1
                     out.extend(self._fold_records(records[lo:hi], **opts))
@@ -626,9 +630,9 @@ class HipEngine:
         njobs = sum(len(pl) for pl in psets)
         max_structs = self.max_structs if self.max_structs else max(4096, min(4 * njobs, 262144))
         if not self.max_structs and opts.get("poollim", 1000) > 1:
-            ng = sum(1 for pl in psets for ps in pl if "G" in ps["algorithms"])
-            max_structs = max(max_structs, min(pool_slots_wanted(ng, opts.get("poollim", 1000)),
-                                               pool_slot_cap(max(len(p.shortseq) for p in prepared))))
+            want = sum(pool_slots_wanted(sum(1 for ps in pl if "G" in ps["algorithms"]), opts.get("poollim", 1000), len(p.shortseq))
+                       for p, pl in zip(prepared, psets))
+            max_structs = max(max_structs, min(want, pool_slot_cap(max(len(p.shortseq) for p in prepared))))
         # SQ_ENGINE_LANES=2 folds big inputs as two concurrent batches; for one-shot calls the second batch's set-up
         # (pinned buffers, worker pool) costs more than the overlap saves, so it is opt-in (long-lived batches
         # profit: fold_concurrently / sq_fold_concurrent)
