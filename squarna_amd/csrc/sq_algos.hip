@@ -552,6 +552,7 @@ struct SqAlgoAsync {
 int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync *&pa)
 {
     pa = new SqAlgoAsync();
+    b->algo_used = 0;
     for (int algo : {SQ_ALGO_E, SQ_ALGO_H, SQ_ALGO_N}) {
         SqAlgoAsync::Item it;
         it.algo = algo;
@@ -569,17 +570,30 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
         const double ts0 = sq_now();
         struct Rep { int algo; double t0; ~Rep() { if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] stage algo %d: %.3f ms\n", algo, (sq_now() - t0) * 1e3); } } rep{it.algo, ts0};
         if (!async || sidx >= 3) return 0;
-        const int64_t free_rec = half - b->cand_reserved;
-        if (free_rec <= 0) return 0;
-        int rb = algo_build(b, it.jobs, it.stems, 0, it.algo, (size_t)free_rec * sizeof(SqCand), sidx, it.ck);
-        if (rb) return rb;
-        if (it.ck.k1 != it.jobs.size()) { it.ck = SqAlgoChunk(); return 0; }   // does not fit as one chunk: synchronous later
+        char *region = nullptr;
+        // Hungarian / Nussinov: the batch's own scratch when the chunk fits it (planned from the lengths)
+        if (it.algo != SQ_ALGO_E && b->algo_bytes > b->algo_used + 65536) {
+            const size_t room = b->algo_bytes - b->algo_used;
+            int rb = algo_build(b, it.jobs, it.stems, 0, it.algo, room, sidx, it.ck);
+            if (rb) return rb;
+            if (it.ck.k1 == it.jobs.size() && it.ck.bytes + 256 <= room) {
+                region = b->algo_scratch + b->algo_used;
+                b->algo_used += (it.ck.bytes + 256 + 255) & ~(size_t)255;
+            } else it.ck = SqAlgoChunk();
+        }
+        if (!region) {
+            const int64_t free_rec = half - b->cand_reserved;
+            if (free_rec <= 0) return 0;
+            int rb = algo_build(b, it.jobs, it.stems, 0, it.algo, (size_t)free_rec * sizeof(SqCand), sidx, it.ck);
+            if (rb) return rb;
+            if (it.ck.k1 != it.jobs.size()) { it.ck = SqAlgoChunk(); return 0; }   // does not fit as one chunk: synchronous later
+            const int64_t used_rec = (int64_t)((it.ck.bytes + 256 + sizeof(SqCand) - 1) / sizeof(SqCand));
+            b->cand_reserved += used_rec;                   // carved downwards from the end of the arena
+            region = (char *)(b->scan.cands + (b->cand_records - b->cand_reserved));
+            region = (char *)(((uintptr_t)region + 255) & ~(uintptr_t)255);
+        }
         const int ss = side_of(b, sidx);
         if (!b->side[ss]) { if (sq_check(hipStreamCreateWithFlags(&b->side[ss], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
-        const int64_t used_rec = (int64_t)((it.ck.bytes + 256 + sizeof(SqCand) - 1) / sizeof(SqCand));
-        b->cand_reserved += used_rec;                   // carved downwards from the end of the arena
-        char *region = (char *)(b->scan.cands + (b->cand_records - b->cand_reserved));
-        region = (char *)(((uintptr_t)region + 255) & ~(uintptr_t)255);
         const double tl0 = sq_now();
         hipStream_t st2 = nullptr;
         if (it.algo == SQ_ALGO_E && side_of(b, 1) != ss) {               // the stream of the short kernels (created here if need be)

@@ -137,6 +137,8 @@ struct sq_batch {
     hipStream_t lane_stream = nullptr;        // second lane of sq_fold's greedy rounds (created on first use)
     hipEvent_t lane_ev = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
+    char *algo_scratch = nullptr;         // device scratch of the Hungarian / Nussinov kernels (Layout::off_algo)
+    size_t algo_bytes = 0, algo_used = 0;
     int last_driver = 0;                  // sq_fold_driver
     int32_t result_limit = 0;             // sq_result_limit (0: the getters show every structure)
     int inflight = 1;                     // batches folded at the same time (sq_fold_concurrent): sizes the pool, relaxes the wait loops

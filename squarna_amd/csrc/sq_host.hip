@@ -12,6 +12,7 @@
 #include <vector>
 #include <unordered_map>
 #include "sq_host.h"
+#include "sq_match.h"
 
 static thread_local std::string g_err;
 std::atomic<long long> g_cpuacc[12];
@@ -242,6 +243,7 @@ struct Layout {
     size_t off_crec, off_cstems, off_cstrands, off_csidx, off_cnfin;   // device-chained rounds (sq_chain.hip)
     size_t off_pstructs, off_precs, off_pstems, off_pstrands, off_psidx, off_pjobs, off_pjobrec, off_pnchild, off_pchoff,
            off_pflag, off_pchosen, off_phdr;                            // device pools (sq_pool.hip)
+    size_t off_algo, algo_bytes;     // scratch of the Hungarian / Nussinov kernels (Edmonds borrows the end of the candidate arena)
     int32_t pool_pt;                 // stems per slot (0: no device pools for this batch)
     int64_t chain_T;                 // summed stem capacity of all jobs
     size_t total;
@@ -335,6 +337,20 @@ int plan(const sq_batch_desc *d, Layout &L)
         L.off_pjobs = take(on * (size_t)d->njobs * sizeof(SqPoolJob)); L.off_pjobrec = take(on * (size_t)d->njobs * 4);
         L.off_pnchild = take(on * sm * 4); L.off_pchoff = take(on * (sm + 1) * 4); L.off_pflag = take(on * sm);
         L.off_pchosen = take(on * sm * 64 * sizeof(SqPoolPick)); L.off_phdr = take(64);
+    }
+    // Hungarian and Nussinov: their scratch (n x n tables) is known from the lengths, so they get room of their own and
+    // always run beside the greedy rounds (16 GB at most; what does not fit borrows from the candidate arena like Edmonds)
+    {
+        size_t need = 0;
+        for (int j = 0; j < d->njobs; j++) {
+            const uint32_t al = d->psets[d->job_pset[j]].algorithms;
+            const size_t n = (size_t)(d->seq_off[d->job_seq[j] + 1] - d->seq_off[d->job_seq[j]]);
+            const size_t edges = 4 * n * n + 8192;                 // (positive cells: ~0.19 n^2 of 16 bytes; job / result records)
+            if (al & SQ_ALGO_H) need += align_up(sq_lsap_scratch_bytes((int)n), 256) + edges;
+            if (al & SQ_ALGO_N) need += align_up(sq_nussinov_scratch_bytes((int)n), 256) + edges;
+        }
+        L.algo_bytes = std::min<size_t>(need ? need + 65536 : 0, (size_t)16 << 30);
+        L.off_algo = take(L.algo_bytes);
     }
     L.total = o;
     return 0;
@@ -547,6 +563,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->chain.strands = (SqStrand *)(base + L.off_cstrands); b->chain.sidx = (int16_t *)(base + L.off_csidx);
     b->chain.d_nfin = (uint32_t *)(base + L.off_cnfin);
     b->chain_T = L.chain_T;
+    b->algo_scratch = L.algo_bytes ? base + L.off_algo : nullptr; b->algo_bytes = L.algo_bytes; b->algo_used = 0;
     if (L.pool_pt) {
         SqPoolIO &P = b->pool_io;
         P.structs = (SqStruct *)(base + L.off_pstructs); P.recs = (SqChain *)(base + L.off_precs);
