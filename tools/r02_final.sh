@@ -15,3 +15,6 @@ python -m pytest tests -m gpu -q 2>&1 | grep -E " passed| failed|error" > $out/r
 ls -la $out
 { python tools/predict_probe.py S300 3; python tools/predict_probe.py S1000 3; } 2>&1 | grep Predict > $out/r02_predict.txt
 cat $out/r02_predict.txt
+bash tools/pool_scale_probe.sh > $out/r02_predict_pools.txt 2>&1
+python tools/scale_soak.py 2>&1 | grep -vE "amdgpu.ids" > $out/r02_scale_soak.txt
+tail -3 $out/r02_scale_soak.txt
