@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Randomised parity soak over the OPTIONS of SQRNdbnseq (SQRNdbnseq.py:973-980): every trial draws conslim, toplim,
+hardrest, rankbydiff, rankby, interchainonly, levellimit, priority, poollim, an algorithm override and a config, folds
+RECORDS random records (some with reactivities / restraints / two chains / a known structure for the metrics) with the
+CPU oracle (worker processes, before the GPU is touched) and with the HIP engine, and compares every field of the
+returned tuple.  usage: fuzz_options.py TRIALS [RECORDS] [SEED]"""
+import itertools, math, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np
+import fuzz_parity as F
+
+CONFIGS = ["nobpp", "alt", "greedynobpp", "fastest", "edmondsnobpp", "hungariannobpp", "nussinovnobpp"]
+
+
+def draw(rng):
+    o = dict(conslim=int(rng.choice([1, 1, 2, 5])), toplim=int(rng.choice([1, 3, 5, 10])),
+             hardrest=bool(rng.random() < 0.4), rankbydiff=bool(rng.random() < 0.4),
+             rankby=tuple(int(x) for x in rng.permutation(3)), interchainonly=bool(rng.random() < 0.25),
+             levellimit=[None, None, 1, 2, 3][int(rng.integers(0, 5))], poollim=int(rng.choice([1, 2, 5, 40, 1000])))
+    al = ["", "", "G", "E", "GE", "EHN", "GN", "H"][int(rng.integers(0, 8))]
+    o["algos"] = frozenset(al)
+    return o
+
+
+def _init():
+    global O
+    sys.path.insert(0, ROOT)
+    from oracle import sqrn_oracle as O_
+    O = O_
+    O.lib()
+
+
+def _one(job):
+    (seq, reacts, restr, ref), cfg, opts, prio = job
+    from squarna_amd.config import ParseConfig, builtin_config
+    names, ps = ParseConfig(builtin_config(cfg))
+    r = O.SQRNdbnseq(seq, reacts, restr, ref, ps, priority=frozenset(prio), **opts)
+    return r[0], [(d, tuple(s), list(p)) for d, s, p in r[1]], list(r[2]), list(r[3])
+
+
+def same_num(a, b):
+    if isinstance(a, float) and isinstance(b, float) and math.isnan(a) and math.isnan(b):
+        return True
+    return abs(a - b) <= 1e-5
+
+
+def main():
+    trials = int(sys.argv[1]); nrec = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    rng = np.random.default_rng(seed)
+    from squarna_amd.config import ParseConfig, builtin_config
+    plan, jobs = [], []
+    for t in range(trials):
+        cfg = CONFIGS[int(rng.integers(0, len(CONFIGS)))]
+        names, ps = ParseConfig(builtin_config(cfg))
+        opts = draw(rng)
+        prio = [int(p) for p in range(len(ps)) if rng.random() < 0.3]
+        recs = F.make(nrec, int(rng.integers(1, 1 << 30)))
+        full = []
+        for k, (s, r, x) in enumerate(recs):
+            ref = None
+            if k % 3 == 0:                                     # a known structure: random nested helices (valid brackets)
+                n = len(s)
+                d = ["."] * n
+                a, b = 0, n - 1
+                while b - a > 8 and rng.random() < 0.8:
+                    ln = int(rng.integers(1, 5))
+                    for q in range(ln):
+                        if b - a > 5 and s[a] not in "&-" and s[b] not in "&-":
+                            d[a], d[b] = "(", ")"
+                        a += 1; b -= 1
+                    a += int(rng.integers(0, 4)); b -= int(rng.integers(0, 4))
+                ref = "".join(ch if s[i] not in "&" else "&" for i, ch in enumerate(d))
+            full.append((s, r, x, ref))
+        plan.append((cfg, opts, prio, full))
+        jobs.extend((rec, cfg, opts, prio) for rec in full)
+    import multiprocessing as mp
+    t0 = time.time()
+    with mp.get_context("spawn").Pool(min(os.cpu_count() or 1, 64), initializer=_init) as pool:
+        exp = pool.map(_one, jobs, chunksize=4)
+    print("oracle: %.1f s for %d records" % (time.time() - t0, len(jobs)), flush=True)
+    from squarna_amd.engine import HipEngine
+    bad, pos = 0, 0
+    for t, (cfg, opts, prio, full) in enumerate(plan):
+        names, ps = ParseConfig(builtin_config(cfg))
+        o = dict(opts)
+        ic = o.pop("interchainonly")
+        got = HipEngine().fold_records([(s, r, x, ref, ps, None) for s, r, x, ref in full], interchainonly=ic,
+                                       priority=set(prio), **o)
+        for k, g in enumerate(got):
+            e = exp[pos + k]
+            ok = g[0] == e[0] and len(g[1]) == len(e[1]) and all(
+                a[0] == b[0] and list(a[2]) == list(b[2]) and all(same_num(float(x), float(y)) for x, y in zip(a[1], b[1]))
+                for a, b in zip(g[1], e[1]))
+            ok = ok and len(g[2]) == len(e[2]) and all(same_num(float(x), float(y)) for x, y in zip(g[2], e[2]))
+            ok = ok and len(g[3]) == len(e[3]) and all(same_num(float(x), float(y)) for x, y in zip(g[3], e[3]))
+            if not ok:
+                bad += 1
+                if bad <= 10:
+                    print("MISMATCH trial %d (%s %s prio %s) record %d: %s\n  got %s %s %s\n  exp %s %s %s" % (
+                        t, cfg, opts, prio, k, full[k], g[0], g[2], g[3], e[0], e[2], e[3]), flush=True)
+        pos += len(full)
+    print("%d trials x %d records over the option space, %d mismatches" % (trials, nrec, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
