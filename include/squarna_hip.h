@@ -72,7 +72,7 @@ typedef struct sq_batch_desc {
     const uint8_t *flags;       /* SQ_FLAG_*                                                     */
     const double *reacts;       /* per-position reactivities after ProcessReacts (SQRNdbnseq.py:32-59), never NULL */
     const int32_t *rbp_off;     /* [nseq+1] offsets (in pairs) into rbps                         */
-    const int32_t *rbps;        /* restraint base pairs (v,w), v<w, gap-free coordinates         */
+    const int32_t *rbps;        /* restraint base pairs (v,w), v<w, gap-free coordinates; any number, a position in at most one */
     int32_t npset;
     const sq_paramset *psets;
     int32_t njobs;

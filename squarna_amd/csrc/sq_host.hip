@@ -428,9 +428,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         for (int k = d->rbp_off[s]; k < d->rbp_off[s + 1]; k++) {
             const int v = d->rbps[2 * k], w = d->rbps[2 * k + 1];
             if (v < 0 || w >= n || v >= w) { delete b; sq_set_error("bad restraint pair"); return -1; }
-            const int code = k - d->rbp_off[s] + 1;
-            if (code > 254) { delete b; sq_set_error("more than 254 restraint base pairs in one sequence"); return -1; }
-            e0[off + v] = (uint8_t)code; e0[off + w] = (uint8_t)code;
+            if (e0[off + v] || e0[off + w]) { delete b; sq_set_error("a position in two restraint base pairs"); return -1; }
+            e0[off + v] = 1; e0[off + w] = 1;                  // 1: end of a restraint pair (0: free, 255: masked by the structure)
         }
     }
     // ---- paramsets with host-libm pow tables ----
@@ -491,6 +490,11 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     int64_t m32 = 0, m64 = 0, mbits = 0;
     std::vector<uint32_t> rbpk((size_t)d->rbp_off[d->nseq]);
     for (size_t k = 0; k < rbpk.size(); k++) rbpk[k] = (uint32_t)d->rbps[2 * k] | ((uint32_t)d->rbps[2 * k + 1] << 16);
+    for (int sq = 0; sq < d->nseq; sq++)                       // per sequence by (i + j, i): a diagonal's pairs are one run (sq_scan6_kernel)
+        std::sort(rbpk.begin() + d->rbp_off[sq], rbpk.begin() + d->rbp_off[sq + 1], [](uint32_t x, uint32_t y) {
+            const uint32_t sx = (x & 0xFFFFu) + (x >> 16), sy = (y & 0xFFFFu) + (y >> 16);
+            return sx != sy ? sx < sy : (x & 0xFFFFu) < (y & 0xFFFFu);
+        });
     for (int j = 0; j < d->njobs; j++) {
         SqJob &J = b->jobs[j];
         const int s = d->job_seq[j];

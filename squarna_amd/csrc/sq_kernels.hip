@@ -584,11 +584,9 @@ __device__ __forceinline__ void sq5_emit(LDS &L, const SqScanArgs &a, const SqSt
 // and the runs of the 32 rows come out of the word with bit tricks (below).  Per structure the scan touches
 // N^2/16 bytes of (L2-resident) bits instead of 2 N^2 bytes of HBM.
 // ------------------------------------------------------------------------------------
-#define SQ6_RL 256
 struct SqScan6Lds {
     uint2 stage[SQ5_STAGE];
-    uint32_t stage_count, nrl, pad[2];
-    uint32_t rl[SQ6_RL];                 // live restraint cells of this wave's diagonals: v | (w << 16)
+    uint32_t stage_count, pad[3];
 };
 
 #ifndef SQ6_AHEAD
@@ -620,22 +618,30 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, con
     // diagonals have zero base words, their window only has to stay inside the array
     const int q0 = min(max(n - 1 - s + 32 * wlo + SQ_GPAD, 0), 32 * (fbh - (whi - wlo) - 3));
     const int gidx = q0 >> 5, gsh = q0 & 31;
-    if (lane == 0) { L.stage_count = 0; L.nrl = 0; }
+    if (lane == 0) L.stage_count = 0;
     for (int m = lane; m < 2 * fbh; m += 64) sq6_fg[m] = FBg[m];
     __syncthreads();
-    if (jb.nrb) {                                                       // restraint pairs both ends of which are still free
-        const uint8_t *eg = stt.E8 + (int64_t)st.slot * stt.stride * 2;
-        for (int k = lane; k < jb.nrb; k += 64) {
-            const uint32_t pk = c.rbpk[jb.rb_off + k];
-            const int v = (int)(pk & 0xFFFFu), w = (int)(pk >> 16);
-            if (eg[v] == (uint8_t)(k + 1) && eg[w] == (uint8_t)(k + 1) && v + w >= s0 && v + w <= s0 + 63) {
-                const uint32_t slot = atomicAdd(&L.nrl, 1u);
-                if (slot < SQ6_RL) L.rl[slot] = pk;
-            }
+    // Restraint base pairs (:438-443: the cell of a restraint pair stays pairable while both ends are free).  The
+    // sequence's list is sorted by (i + j, i), so the pairs of this lane's diagonal are one run of it, in row order: two
+    // binary searches here, then a pointer that only moves forward as the rows go by.  Any number of pairs.
+    const uint32_t *rlist = c.rbpk + jb.rb_off;
+    const uint8_t *eg = stt.E8 + (int64_t)st.slot * stt.stride * 2;
+    int rp = 0, rend = 0;
+    if (jb.nrb) {
+        int lo = 0, hi = jb.nrb;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const uint32_t pk = rlist[mid];
+            if ((int)(pk & 0xFFFFu) + (int)(pk >> 16) < s) lo = mid + 1; else hi = mid;
         }
-        __syncthreads();
+        rp = lo; hi = jb.nrb;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const uint32_t pk = rlist[mid];
+            if ((int)(pk & 0xFFFFu) + (int)(pk >> 16) <= s) lo = mid + 1; else hi = mid;
+        }
+        rend = lo;
     }
-    const uint32_t nrl = min(L.nrl, (uint32_t)SQ6_RL);
     const uint32_t *bp = c.bits + jb.bits_off + s;
     const int bpitch = jb.bpitch;
 
@@ -667,12 +673,12 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, con
             const uint32_t gw = __builtin_amdgcn_alignbit(ghi, glo, gsh);   // columns s-32w-b, b = 0..31
             glo = ghi;
             uint32_t A = base & F[w] & gw;                              // :438-451 free row and column
-            if (nrl) {
-                for (uint32_t q = 0; q < nrl; q++) {
-                    const uint32_t pk = L.rl[q];
-                    const int v = (int)(pk & 0xFFFFu), ww = (int)(pk >> 16);
-                    if (v + ww == s && (v >> 5) == w) A |= base & (1u << (v & 31));   // :438-443 restraint bp stays pairable
-                }
+            while (rp < rend) {                                         // (no lane enters without restraint pairs on its diagonal)
+                const uint32_t pk = rlist[rp];
+                const int v = (int)(pk & 0xFFFFu);
+                if ((v >> 5) > w) break;
+                if ((v >> 5) == w && eg[v] == 1 && eg[pk >> 16] == 1) A |= base & (1u << (v & 31));   // :438-443 restraint bp stays pairable
+                rp++;
             }
             // maximal runs of the word (bit b = row 32w + b; `carry` rows of an open run precede row 32w)
             if (__ballot((A != 0u) | (carry > 0)) != 0ull) {

@@ -525,3 +525,36 @@ def test_result_limit_shows_the_top_structures_only():
     assert any(len(f[1]) > 3 for f in full)
     for f, t in zip(full, top):
         assert t[0] == f[0] and t[1] == f[1][:3] and len(t[1]) == min(3, len(f[1]))
+
+
+@pytest.mark.parametrize("config,poollim", [("fastest", 1), ("greedynobpp", 6)])
+def test_many_restraint_pairs(config, poollim):
+    """More restraint base pairs than one byte counts (alignment mode restrains the second iteration of step 1 by the
+    structure of the first, SQRNdbnali.py:359-362: hundreds of pairs on long alignments), most of them on ONE anti-diagonal (a long hairpin: i + j constant) plus helices
+    elsewhere, some complementary and some not (SQRNdbnseq.py:438-443: the restraint cell stays pairable only where the
+    bases pair), also with hardrest: the fold equals the oracle's."""
+    import numpy as np
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import HipEngine
+    names, psets = conf(config)
+    rng = np.random.default_rng(5)
+    comp = {"A": "U", "U": "A", "G": "C", "C": "G"}
+    recs = []
+    for n, step in ((1300, 2), (700, 1), (900, 3)):
+        seq = list(rng.choice(list("ACGU"), n))
+        restr = ["."] * n
+        npairs = 0
+        for i in range(0, n // 2 - 4, step):                   # pairs (i, n-1-i): one anti-diagonal
+            if rng.random() < 0.85:
+                restr[i], restr[n - 1 - i] = "(", ")"
+                npairs += 1
+                if rng.random() < 0.7:
+                    seq[n - 1 - i] = comp[seq[i]]
+        assert npairs > 254 or step == 3
+        recs.append(("".join(seq), None, "".join(restr)))
+    for hardrest in (False, True):
+        got = HipEngine().fold_records([(s, r, x, None, psets, None) for s, r, x in recs], poollim=poollim, hardrest=hardrest)
+        for k, (s, r, x) in enumerate(recs):
+            exp = O.SQRNdbnseq(s, r, x, None, psets, poollim=poollim, hardrest=hardrest)
+            exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+            _same_fold(got[k], exp, (config, "restraints", hardrest, k))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Predict() on inputs the unit tests do not reach by size: many records, long records, mixed lengths, wide pools, with
-restraints and reactivities.  Each case runs with the device drivers and again with the host-driven loop
+restraints and reactivities, and alignments of hundreds of sequences or thousands of columns.  Each case runs with the device drivers and again with the host-driven loop
 (SQ_NO_POOL / SQ_NO_CHAIN) and the printed texts must be equal.  usage: scale_soak.py [case ...]"""
 import hashlib, io, os, random, sys, tempfile, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,7 +38,59 @@ CASES = {
 }
 
 
+def msa(rng, nseq, ncol):
+    """mutated copies of a random ancestor with gaps (alignment mode)"""
+    anc = [rng.choice("ACGU") for _ in range(ncol)]
+    # a few planted helices so that the consensus is not empty
+    for _ in range(ncol // 40):
+        a, ln = rng.randint(0, ncol // 2 - 12), rng.randint(4, 8)
+        b = rng.randint(ncol // 2 + 8, ncol - 1)
+        for t in range(ln):
+            if a + t < b - t - 4:
+                anc[b - t] = {"A": "U", "U": "A", "G": "C", "C": "G"}[anc[a + t]]
+    rows = []
+    for k in range(nseq):
+        row = [rng.choice("ACGU") if rng.random() < 0.12 else ch for ch in anc]
+        row = ["-" if rng.random() < 0.06 else ch for ch in row]
+        rows.append(">s%d\n%s" % (k, "".join(row)))
+    return "\n".join(rows) + "\n"
+
+
+ALIGN_CASES = {
+    # name: (sequences, columns, step3)
+    "ali_wide": (300, 400, "u"),
+    "ali_long": (40, 1500, "i"),
+    "ali_many": (1500, 120, "1"),
+}
+
+
+def run_align(name):
+    nseq, ncol, step3 = ALIGN_CASES[name]
+    rng = random.Random(zlib.crc32(name.encode()))
+    with tempfile.NamedTemporaryFile("w", suffix=".afa", delete=False) as f:
+        f.write(msa(rng, nseq, ncol))
+        path = f.name
+    shas = []
+    for env in ({}, {"SQ_NO_POOL": "1", "SQ_NO_CHAIN": "1"}):
+        os.environ.update(env)
+        try:
+            buf = io.StringIO()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            Predict(inputfile=path, alignment=True, step3=step3, write_to=buf)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        finally:
+            for k in env:
+                del os.environ[k]
+        shas.append(hashlib.sha256(buf.getvalue().encode()).hexdigest())
+        print("%-16s %-12s %8.1f ms  %d chars  %s" % (name, "host loop" if env else "device", dt * 1e3, len(buf.getvalue()), shas[-1][:16]), flush=True)
+    os.unlink(path)
+    assert shas[0] == shas[1], name
+    return True
+
+
 def run(name):
+    if name in ALIGN_CASES:
+        return run_align(name)
     count, nmin, nmax, extras, config, poollim = CASES[name]
     rng = random.Random(zlib.crc32(name.encode()))
     text = records(rng, count, nmin, nmax, extras)
@@ -64,7 +116,7 @@ def run(name):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or (list(CASES) + list(ALIGN_CASES))
     CASES["warmup"] = (64, 50, 300, True, "nobpp", 50)
     run("warmup")
     for n in names:
