@@ -93,6 +93,17 @@ typedef struct sq_batch_desc {
                                    them is repeated by the library's host loop (same results, slower)           */
     int32_t cand_per_nt;        /* candidate capacity per structure = cand_per_nt * N (0 = 32)  */
     int32_t batch_flags;        /* SQ_BATCH_* */
+    /* Alignment step 2 without one dense matrix per sequence (SQRNdbnseq.py:1031-1034 deletes the gap rows and columns
+     * of the same L x L stem matrix for every sequence, :1084-1085 multiplies): ONE L x L row-major fp64 matrix in
+     * DEVICE memory (the step-1 matrix never has to leave the GPU) and, per sequence, the alignment column of each of
+     * its gap-free positions.  A job with mul_shared[j] != 0 takes bpscorematrix[a][b] *= M[cols[a]][cols[b]]; the
+     * library gathers its N x N slice on the device at sq_batch_create (on the batch's stream: M must be complete
+     * there).  Such a job has no mul_score / bpp_term / caller matrices.  All NULL / 0: not used. */
+    const double *mul_matrix_dev;   /* device pointer */
+    int32_t mul_L;
+    const int32_t *mul_cols;        /* [seq_off[nseq]] host: column of every position (same offsets as codes)   */
+    const uint8_t *mul_shared;      /* [njobs] host                                                              */
+    double mul_maxabs;              /* max |M| (an upper bound is enough: it only widens the scan's fp32 margin) */
 } sq_batch_desc;
 
 /* No fp32 score matrices in the workspace (4 N^2 bytes per job saved): everything except

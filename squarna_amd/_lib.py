@@ -58,7 +58,12 @@ class BatchDesc(C.Structure):
                 ("interchainonly", C.c_int32),
                 ("max_structs", C.c_int32),
                 ("cand_per_nt", C.c_int32),
-                ("batch_flags", C.c_int32)]
+                ("batch_flags", C.c_int32),
+                ("mul_matrix_dev", C.c_void_p),
+                ("mul_L", C.c_int32),
+                ("mul_cols", C.POINTER(C.c_int32)),
+                ("mul_shared", C.POINTER(C.c_uint8)),
+                ("mul_maxabs", C.c_double)]
 
 
 class Stem(C.Structure):

@@ -178,9 +178,14 @@ def RunSQRNdbnali(objs, defreacts, defrests, defref, levellimit, freqlimit, verb
                           threads, verbose, sink=sink, M=M, B=B)[0]
     step1dbn = PairsToDBN(DBNToPairs(pred_dbn), N, levellimit=levellimit)
     if step3 != '1':                                                 # (only step 2 reads it)
-        if not isinstance(smat, np.ndarray):
-            smat = smat.cpu().numpy()                                # device path: one D2H of the L x L matrix
-        smat = smat / np.max(smat) * 5                               # :371
+        if not isinstance(smat, np.ndarray) and not entropy:
+            # device path: the normalised matrix stays on the GPU (the same two IEEE operations per cell as numpy's
+            # smat / max * 5); step 2 gathers every sequence's rows and columns from it there (Batch(mul_shared=...))
+            smat = (smat / smat.max() * 5).contiguous()              # :371
+        else:
+            if not isinstance(smat, np.ndarray):
+                smat = smat.cpu().numpy()                            # (the entropy pass folds record by record on host matrices)
+            smat = smat / np.max(smat) * 5                           # :371
     if verbose:
         print(">Step 1, Result", file=sink)
         print(step1dbn, file=sink)

@@ -17,9 +17,10 @@
 #include "sq_device.h"
 #include "sq_extend.h"
 
-extern "C" __global__ __launch_bounds__(64) void sq_chain_kernel(SqDevCtx c, SqStruct *structs, SqScanArgs a, SqChainIO cio)
+extern "C" __global__ __launch_bounds__(64) void sq_chain_kernel(SqDevCtx c, SqStruct *structs, SqScanArgs a, SqChainIO cio, int tmax)
 {
-    __shared__ SqExtendLds L;
+    extern __shared__ __attribute__((aligned(16))) char sq_chain_dyn[];      // sq_extend_lds_bytes(tmax)
+    SqExtendLds L = sq_extend_lds(sq_chain_dyn, tmax);
     const int b = blockIdx.x, lane = threadIdx.x;
     const SqStruct st = structs[b];
     if (st.nstrand < 0) return;                                         // final since an earlier round

@@ -120,7 +120,7 @@ __global__ void sq_bits_masks_kernel(SqDevCtx c, int max_letters);
 __global__ void sq_dense64_kernel(SqDevCtx c, int job, double *boolmat, double *scoremat);
 __global__ void sq_import_kernel(SqDevCtx c);
 __global__ void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n, int chained);
-__global__ void sq_chain_kernel(SqDevCtx c, SqStruct *structs, SqScanArgs a, SqChainIO cio);
+__global__ void sq_chain_kernel(SqDevCtx c, SqStruct *structs, SqScanArgs a, SqChainIO cio, int tmax);
 __global__ void sq_chain_init_kernel(const SqStruct *h_structs, const SqChain *h_chain, SqStruct *d_structs, SqChainIO cio,
                                      SqScanArgs a, int S, int first);
 __global__ void sq_chain_done_kernel(SqRoundIO io, SqScanArgs a, SqChainIO cio, uint32_t seq);
@@ -146,3 +146,12 @@ __global__ void sq_bps_kernel(SqDevCtx c, const SqStruct *structs, const SqStran
                               SqScanArgs a, SqRoundIO io, int mode, int lds_n, int lds_n_reacts, int surv_off);
 __global__ void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqRoundIO io);
 }
+
+// sq_extend.h: LDS of one structure's level scratch (chain / pool-extend kernels), lists of up to T stems
+#define SQ_CHAIN_TMAX 11264
+static inline size_t sq_extend_lds_bytes(int T) { const size_t t = ((size_t)T + 7) & ~(size_t)7; return t * 14 + 64 * 4 + 64; }
+
+// sq_gather.hip: the N x N weighting slices of the jobs in job_list from ONE shared L x L device matrix through the
+// per-position alignment columns (alignment step 2, SQRNdbnseq.py:1031-1034,1084-1085)
+void sq_launch_gather_mul(const SqDevCtx &c, const double *M, int L, const int32_t *cols, const int32_t *job_list, int njl, int maxn,
+                          hipStream_t st);

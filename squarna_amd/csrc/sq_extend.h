@@ -7,7 +7,8 @@
 #include <hip/hip_runtime.h>
 #include "sq_device.h"
 
-#define SQ_CHAIN_TMAX 1024      // stems per structure the level scratch holds (longer chains run the host loop)
+// stems per structure the level scratch can hold: 14 bytes of LDS each, a block's dynamic LDS is sized for the launch's
+// longest list (SQ_CHAIN_TMAX in sq_device.h = what 160 KB hold; structures that could grow longer run the host loop)
 
 __device__ __forceinline__ bool sq_chain_cross(int ai, int aj, int bi, int bj)     // SQRNdbnseq.py:114-116
 {
@@ -31,12 +32,26 @@ __device__ __forceinline__ int sq_wave_sum32(int v)
 }
 
 struct SqExtendLds {
-    int16_t i[SQ_CHAIN_TMAX], j[SQ_CHAIN_TMAX], len[SQ_CHAIN_TMAX], ord[SQ_CHAIN_TMAX];
-    int32_t cc[SQ_CHAIN_TMAX];
-    uint8_t grp[SQ_CHAIN_TMAX], lvl[SQ_CHAIN_TMAX];
-    int32_t gsize[64];
-    uint8_t rank[64];
+    int16_t *i, *j, *len, *ord;
+    int32_t *cc;
+    uint8_t *grp, *lvl;
+    int32_t *gsize;              // [64]
+    uint8_t *rank;               // [64]
 };
+// carves the arrays for lists of up to T stems out of the block's dynamic LDS (sq_extend_lds_bytes(T) bytes at base)
+__device__ __forceinline__ SqExtendLds sq_extend_lds(char *base, int T)
+{
+    const int t = (T + 7) & ~7;
+    SqExtendLds L;
+    L.cc = reinterpret_cast<int32_t *>(base);
+    L.gsize = L.cc + t;
+    L.i = reinterpret_cast<int16_t *>(L.gsize + 64);
+    L.j = L.i + t; L.len = L.j + t; L.ord = L.len + t;
+    L.grp = reinterpret_cast<uint8_t *>(L.ord + t);
+    L.lvl = L.grp + t;
+    L.rank = L.lvl + t;
+    return L;
+}
 
 // parent: k stems pst[] (with their crossing weights), nstrand sorted strands psrc[] + the stem index of each (pssrc[]).
 // child: cst[0..k] (may be the parent's array: the weights are updated in place), cdst[] / csdst[] (nstrand + 2 entries;

@@ -243,6 +243,7 @@ struct Layout {
     size_t off_crec, off_cstems, off_cstrands, off_csidx, off_cnfin;   // device-chained rounds (sq_chain.hip)
     size_t off_pstructs, off_precs, off_pstems, off_pstrands, off_psidx, off_pjobs, off_pjobrec, off_pnchild, off_pchoff,
            off_pflag, off_pchosen, off_phdr;                            // device pools (sq_pool.hip)
+    size_t off_mulcols;              // alignment columns of every position (shared L x L weighting matrix), else unused
     size_t off_algo, algo_bytes;     // scratch of the Hungarian / Nussinov kernels (Edmonds borrows the end of the candidate arena)
     int32_t pool_pt;                 // stems per slot (0: no device pools for this batch)
     int64_t chain_T;                 // summed stem capacity of all jobs
@@ -267,11 +268,11 @@ int plan(const sq_batch_desc *d, Layout &L)
         if (s < 0 || s >= d->nseq || d->job_pset[j] < 0 || d->job_pset[j] >= d->npset) { sq_set_error("bad job"); return -1; }
         const int64_t n = d->seq_off[s + 1] - d->seq_off[s];
         const bool ext_any = (d->ext_score && d->ext_score[j]) || (d->mul_score && d->mul_score[j]) ||
-                             (d->bpp_term && d->bpp_term[j]);
+                             (d->bpp_term && d->bpp_term[j]) || (d->mul_shared && d->mul_shared[j]);
         if (want_fp32(d) || ext_any) L.mat32_floats += (int64_t)align_up((size_t)(n * ld_of((int)n)), 64);
         L.bits_words += (int64_t)bits_nw((int)n) * bits_pitch((int)n);
         const bool ext = d->ext_score && d->ext_score[j];
-        const bool mul = (d->mul_score && d->mul_score[j]) || (d->bpp_term && d->bpp_term[j]);
+        const bool mul = (d->mul_score && d->mul_score[j]) || (d->bpp_term && d->bpp_term[j]) || (d->mul_shared && d->mul_shared[j]);
         if (ext) L.mat64_doubles += 2 * n * n;
         else if (mul) L.mat64_doubles += n * n;
     }
@@ -327,7 +328,8 @@ int plan(const sq_batch_desc *d, Layout &L)
     L.pool_pt = 0;
     for (int j = 0; j < d->njobs; j++)
         L.pool_pt = std::max(L.pool_pt, chain_tcap(d->seq_off[d->job_seq[j] + 1] - d->seq_off[d->job_seq[j]], d->psets[d->job_pset[j]].minlen));
-    if (L.pool_pt > 1024) L.pool_pt = 0;                      // (SQ_CHAIN_TMAX: such batches keep the host-driven loop)
+    // (such batches keep the host-driven loop: lists longer than the level scratch holds; slot offsets beyond 31 bits)
+    if (L.pool_pt > SQ_CHAIN_TMAX || 8 * (int64_t)L.max_structs * L.pool_pt >= ((int64_t)1 << 31)) L.pool_pt = 0;
     {
         const size_t sm = (size_t)L.max_structs, pt = (size_t)L.pool_pt;
         const size_t on = pt ? 1 : 0;
@@ -338,6 +340,7 @@ int plan(const sq_batch_desc *d, Layout &L)
         L.off_pnchild = take(on * sm * 4); L.off_pchoff = take(on * (sm + 1) * 4); L.off_pflag = take(on * sm);
         L.off_pchosen = take(on * sm * 64 * sizeof(SqPoolPick)); L.off_phdr = take(64);
     }
+    L.off_mulcols = take(d->mul_matrix_dev ? 4 * (size_t)L.ltot : 0);
     // Hungarian and Nussinov: their scratch (n x n tables) is known from the lengths, so they get room of their own and
     // always run beside the greedy rounds (16 GB at most; what does not fit borrows from the candidate arena like Edmonds)
     {
@@ -380,6 +383,11 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
             return -4;
         }
         if (term && d->psets[d->job_pset[j]].bpp == 0) { sq_set_error("bpp_term given for a paramset with bpp == 0"); return -1; }
+        const bool shared = d->mul_shared && d->mul_shared[j];
+        if (shared && (!d->mul_matrix_dev || !d->mul_cols || d->mul_L <= 0)) { sq_set_error("mul_shared without mul_matrix_dev / mul_cols / mul_L"); return -1; }
+        if (shared && (term || (d->mul_score && d->mul_score[j]) || (d->ext_score && d->ext_score[j]))) {
+            sq_set_error("a job takes either the shared weighting matrix or its own matrices, not both"); return -4;
+        }
         if (term && ((d->mul_score && d->mul_score[j]) || (d->ext_score && d->ext_score[j]))) {
             sq_set_error("a job takes either bpp_term or mul_score / caller matrices, not both"); return -4;
         }
@@ -506,7 +514,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         J.rb_off = d->rbp_off[s]; J.nrb = d->rbp_off[s + 1] - d->rbp_off[s];
         const bool ext = d->ext_score && d->ext_score[j];
         const bool term = d->bpp_term && d->bpp_term[j];
-        const bool mul = (d->mul_score && d->mul_score[j]) || term;
+        const bool shared = d->mul_shared && d->mul_shared[j];
+        const bool mul = (d->mul_score && d->mul_score[j]) || term || shared;
         J.ext_add = term && d->psets[J.pset].bpp < 0 ? 1 : 0;
         if (ext) { J.mat64_off = m64; J.has_ext = 1; m64 += 2 * (int64_t)J.n * J.n; }
         else if (mul) { J.mat64_off = m64; J.has_ext = 2; m64 += (int64_t)J.n * J.n; }
@@ -535,7 +544,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
                 const double rfmax = def ? 1.0 : (w > 0 ? 1.4142135623730951 : 100.0);   // SQRNdbnseq.py:333-336
                 mx = std::max(mx, std::fabs(w) * rfmax);
             }
-            if (mul) {
+            if (shared) mx *= std::fabs(d->mul_maxabs);
+            else if (mul) {
                 const double *tm = term ? d->bpp_term[j] : d->mul_score[j];
                 double mm = 0;
                 for (size_t q = 0; q < nn; q++) mm = std::max(mm, std::fabs(tm[q]));
@@ -567,6 +577,9 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->chain.strands = (SqStrand *)(base + L.off_cstrands); b->chain.sidx = (int16_t *)(base + L.off_csidx);
     b->chain.d_nfin = (uint32_t *)(base + L.off_cnfin);
     b->chain_T = L.chain_T;
+    b->chain_tmax = 1;
+    for (int j = 0; j < d->njobs; j++)
+        b->chain_tmax = std::max(b->chain_tmax, chain_tcap(d->seq_off[d->job_seq[j] + 1] - d->seq_off[d->job_seq[j]], d->psets[d->job_pset[j]].minlen));
     b->algo_scratch = L.algo_bytes ? base + L.off_algo : nullptr; b->algo_bytes = L.algo_bytes; b->algo_used = 0;
     if (L.pool_pt) {
         SqPoolIO &P = b->pool_io;
@@ -606,7 +619,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     stager.st = st;
     {
         size_t want = (size_t)L.ltot * 16 + sizeof(SqJob) * d->njobs + sizeof(SqPsetDev) * d->npset + 8 * sdf.size() + 4 * rbpk.size() + 16384;
-        for (int j = 0; j < d->njobs; j++) if (b->jobs[j].has_ext) want += (size_t)b->jobs[j].n * b->jobs[j].n * 8 * (b->jobs[j].has_ext == 1 ? 2 : 1);
+        for (int j = 0; j < d->njobs; j++)
+            if (b->jobs[j].has_ext && !(d->mul_shared && d->mul_shared[j])) want += (size_t)b->jobs[j].n * b->jobs[j].n * 8 * (b->jobs[j].has_ext == 1 ? 2 : 1);
         stager.cap = std::min<size_t>(std::max<size_t>(want, (size_t)1 << 20), (size_t)64 << 20) & ~(size_t)255;
         void *pb = nullptr;
         if (sq_pinned_get(&pb, stager.cap)) { delete b; return 2; }
@@ -628,8 +642,24 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
             if (!d->ext_bool || !d->ext_bool[j]) { hipStreamSynchronize(st); delete b; sq_set_error("ext_score without ext_bool"); return -1; }
             UP(b->ctx.mat64 + J.mat64_off, d->ext_score[j], nn);
             UP(b->ctx.mat64 + J.mat64_off + (int64_t)J.n * J.n, d->ext_bool[j], nn);
-        } else if (J.has_ext == 2) {
+        } else if (J.has_ext == 2 && !(d->mul_shared && d->mul_shared[j])) {
             UP(b->ctx.mat64 + J.mat64_off, (d->bpp_term && d->bpp_term[j]) ? d->bpp_term[j] : d->mul_score[j], nn);
+        }
+    }
+    if (d->mul_matrix_dev && d->mul_shared) {
+        // jobs weighted by the shared L x L matrix: their N x N slices are gathered on the device through the column maps
+        int32_t *d_cols = (int32_t *)(base + L.off_mulcols);
+        for (int64_t q = 0; q < L.ltot; q++)
+            if (d->mul_cols[q] < 0 || d->mul_cols[q] >= d->mul_L) { hipStreamSynchronize(st); delete b; sq_set_error("mul_cols out of range"); return -1; }
+        UP(d_cols, d->mul_cols, 4 * (size_t)L.ltot);
+        std::vector<int32_t> jl;
+        for (int j = 0; j < d->njobs; j++) if (d->mul_shared[j]) jl.push_back(j);
+        if (!jl.empty()) {
+            // (the job list travels in the candidate arena's first bytes: nothing else uses it before the first fold)
+            int32_t *d_jl = (int32_t *)(base + L.off_cands);
+            UP(d_jl, jl.data(), 4 * jl.size());
+            sq_launch_gather_mul(b->ctx, d->mul_matrix_dev, d->mul_L, d_cols, d_jl, (int)jl.size(), L.maxn, st);
+            if (sq_check(hipGetLastError(), "sq_gather_mul_kernel")) { hipStreamSynchronize(st); delete b; return 2; }
         }
     }
 #undef UP
@@ -1052,7 +1082,11 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
             hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, d_structs, scan, io);
         if (chained && !pooled) {
             SqChainIO cio = b->chain;
-            hipLaunchKernelGGL(sq_chain_kernel, dim3(S), dim3(64), 0, st, b->ctx, d_structs, scan, cio);
+            // dynamic LDS: the level scratch for the longest stem list any job of the batch can reach
+            const size_t ext_lds = sq_extend_lds_bytes(b->chain_tmax);
+            static bool attr_set = false;
+            if (ext_lds > 64 * 1024 && !attr_set) { hipFuncSetAttribute((const void *)sq_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+            hipLaunchKernelGGL(sq_chain_kernel, dim3(S), dim3(64), ext_lds, st, b->ctx, d_structs, scan, cio, b->chain_tmax);
         }
         if (pooled) hipLaunchKernelGGL(sq_pool_choose_kernel, dim3(S), dim3(64), 0, st, b->ctx, d_structs, scan, b->pool_io);
     }
@@ -1388,10 +1422,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     bool use_chain = o.poollim == 1 && !no_chain && !greedy_jobs.empty();
     if (use_chain)
         for (int j : greedy_jobs)
-            if (chain_tcap(b->jobs[j].n, b->psets[b->job_pset[j]].minlen) > 1024 ||          // SQ_CHAIN_TMAX
+            if (chain_tcap(b->jobs[j].n, b->psets[b->job_pset[j]].minlen) > SQ_CHAIN_TMAX ||
                 b->jobs[j].cand_cap > b->cand_records - b->cand_reserved) use_chain = false;
     // Wider pools: booked on the device as well (sq_pool.hip) when the batch has the slot arrays (structures of at most
-    // 1024 stems) and one structure per greedy job fits the round buffers; any capacity overflow during the fold makes
+    // SQ_CHAIN_TMAX stems) and one structure per greedy job fits the round buffers; any capacity overflow during the fold makes
     // the host repeat it with its own loop.
     const bool no_pool = getenv("SQ_NO_POOL") != nullptr;
     bool use_pool = !use_chain && o.poollim > 1 && !no_pool && !greedy_jobs.empty() && b->pool_io.pt > 0;
@@ -1785,6 +1819,11 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             std::atomic_thread_fence(std::memory_order_acquire);
             return 0;
         };
+        const size_t ext_lds = sq_extend_lds_bytes(pio.pt);          // the extend kernel's level scratch (dynamic LDS)
+        {
+            static bool attr_set = false;
+            if (ext_lds > 64 * 1024 && !attr_set) { hipFuncSetAttribute((const void *)sq_pool_extend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        }
         const double tr0 = now_s();
         int parity = 0, S = S0, rounds = 0;
         bool overflow = false;
@@ -1800,7 +1839,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             }
             const uint32_t seq = ++*ln.round_seq;
             hipLaunchKernelGGL(sq_pool_scan_kernel, dim3(1), dim3(1024), 0, st, pio, scan, io, parity, seq);
-            hipLaunchKernelGGL(sq_pool_extend_kernel, dim3(S), dim3(64), 0, st, b->ctx, scan, pio, parity);
+            hipLaunchKernelGGL(sq_pool_extend_kernel, dim3(S), dim3(64), ext_lds, st, b->ctx, scan, pio, parity);
             if (wait_seq(seq)) return 2;
             rounds++;
             const SqCounters ctr = *ln.h_ctr;

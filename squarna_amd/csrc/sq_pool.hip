@@ -199,7 +199,8 @@ extern "C" __global__ __launch_bounds__(1024) void sq_pool_scan_kernel(SqPoolIO 
 
 extern "C" __global__ __launch_bounds__(64) void sq_pool_extend_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, int parity)
 {
-    __shared__ SqExtendLds L;
+    extern __shared__ __attribute__((aligned(16))) char sq_pool_dyn[];       // sq_extend_lds_bytes(pio.pt)
+    SqExtendLds L = sq_extend_lds(sq_pool_dyn, pio.pt);
     const int s = blockIdx.x, lane = threadIdx.x;
     const size_t cur = (size_t)parity * pio.smax, nxt = (size_t)(parity ^ 1) * pio.smax;
     const SqStruct st = pio.structs[cur + s];

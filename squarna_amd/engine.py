@@ -98,9 +98,11 @@ class Batch:
     """A device-resident batch of fold jobs (one per (record, paramset))."""
 
     def __init__(self, prepared, psets_per_record, interchainonly=False, ext=None, mul=None,
-                 max_structs=0, cand_per_nt=0, device=None, fp32=True, bpp=None):
+                 max_structs=0, cand_per_nt=0, device=None, fp32=True, bpp=None, mul_shared=None):
         """fp32=False leaves the fp32 score matrices out of the workspace (4 N^2 bytes per job): everything
-        but fill() works -- folding only needs the 1-bit-per-cell matrices."""
+        but fill() works -- folding only needs the 1-bit-per-cell matrices.
+        mul_shared = (M, cols, maxabs): ONE L x L fp64 torch tensor on the GPU that weights every job of every record
+        (alignment step 2), cols[k] = the alignment columns of record k's gap-free positions, maxabs >= max |M|."""
         import torch
         L = _lib.load()
         if not torch.cuda.is_available():
@@ -184,6 +186,19 @@ class Batch:
         if mul is not None:
             self._mul = ptr_array(mul)
             d.mul_score = C.cast(self._mul, C.POINTER(C.c_void_p))
+        if mul_shared is not None:
+            M, cols, maxabs = mul_shared
+            assert M.is_cuda and M.dtype == torch.float64 and M.dim() == 2 and M.shape[0] == M.shape[1] and M.is_contiguous()
+            self._mul_M = M
+            self._mul_cols = np.ascontiguousarray(np.concatenate([np.asarray(c, np.int32) for c in cols])
+                                                  if ltot else np.zeros(1, np.int32), dtype=np.int32)
+            assert len(self._mul_cols) == max(ltot, 1)
+            self._mul_flag = np.ones(max(njobs, 1), np.uint8)
+            d.mul_matrix_dev = C.c_void_p(M.data_ptr())
+            d.mul_L = int(M.shape[0])
+            d.mul_cols = _ptr(self._mul_cols, C.POINTER(C.c_int32))
+            d.mul_shared = _ptr(self._mul_flag, C.POINTER(C.c_uint8))
+            d.mul_maxabs = float(maxabs)
         if bpp is not None:                                          # per job: (bppm/max)**|bpp| or None (SQRNdbnseq.py:350-364)
             self._bpp = ptr_array(bpp)
             d.bpp_term = C.cast(self._bpp, C.POINTER(C.c_void_p))
@@ -616,10 +631,18 @@ class HipEngine:
         psets = [r[4] for r in records]
         bpp = bpp_terms(prepared, psets, M, B)
         mul = None
-        if any(len(r) > 5 and r[5] is not None for r in records):
+        mul_shared = None
+        sm0 = records[0][5] if len(records[0]) > 5 else None
+        if sm0 is not None and hasattr(sm0, "is_cuda") and sm0.is_cuda and all(len(r) > 5 and r[5] is sm0 for r in records):
+            # alignment step 2 with the stem matrix still on the GPU: no per-record copies (Batch(mul_shared=...))
+            mul_shared = (sm0, [np.flatnonzero(~gap_mask(r[0])).astype(np.int32) for r in records],
+                          float(sm0.abs().max().item()))
+        elif any(len(r) > 5 and r[5] is not None for r in records):
             mul = []
             for r, p in zip(records, prepared):
                 sm = r[5] if len(r) > 5 else None
+                if sm is not None and hasattr(sm, "is_cuda"):
+                    sm = sm.cpu().numpy()
                 if sm is not None:                                   # :1031-1034
                     sm = np.delete(np.delete(np.asarray(sm, dtype=np.float64), p.gapidx, 0), p.gapidx, 1)
                 mul.extend([sm] * len(r[4]))
@@ -638,9 +661,9 @@ class HipEngine:
         # profit: fold_concurrently / sq_fold_concurrent)
         lanes = int(os.environ.get("SQ_ENGINE_LANES", "1"))
         cost = [float(len(p.shortseq)) ** 2 * len(pl) for p, pl in zip(prepared, psets)]
-        if lanes < 2 or nrec < 256 or sum(cost) < 1e8:
+        if lanes < 2 or nrec < 256 or sum(cost) < 1e8 or mul_shared is not None:
             with Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
-                       max_structs=max_structs, cand_per_nt=self.cand_per_nt) as b:
+                       max_structs=max_structs, cand_per_nt=self.cand_per_nt, mul_shared=mul_shared) as b:
                 b.limit_results(keep)
                 b.fold(**opts)
                 self.last_fold_driver = b.fold_driver

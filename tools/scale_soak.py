@@ -35,6 +35,8 @@ CASES = {
     "mixed_extras": (600, 5, 900, True, "nobpp", 50),
     "long_chain": (48, 1500, 2500, True, "fastest", 1),
     "alt_mixed": (400, 10, 400, True, "alt", 100),
+    "very_long_chain": (6, 4500, 6000, False, "fastest", 1),       # > 1024 stems per structure: the level scratch in dynamic LDS
+    "very_long_pool": (4, 4200, 5000, False, "greedynobpp", 8),
 }
 
 
@@ -61,6 +63,7 @@ ALIGN_CASES = {
     "ali_wide": (300, 400, "u"),
     "ali_long": (40, 1500, "i"),
     "ali_many": (1500, 120, "1"),
+    "ali_5000": (48, 5000, "u"),          # BASELINE config 5's width through all three steps (not in the default list: ~1 min)
 }
 
 
@@ -116,7 +119,7 @@ def run(name):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + list(ALIGN_CASES))
+    names = sys.argv[1:] or (list(CASES) + [a for a in ALIGN_CASES if a != "ali_5000"])
     CASES["warmup"] = (64, 50, 300, True, "nobpp", 50)
     run("warmup")
     for n in names:
