@@ -558,3 +558,33 @@ def test_many_restraint_pairs(config, poollim):
             exp = O.SQRNdbnseq(s, r, x, None, psets, poollim=poollim, hardrest=hardrest)
             exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
             _same_fold(got[k], exp, (config, "restraints", hardrest, k))
+
+
+def test_shared_device_stem_matrix_equals_per_record_matrices():
+    """Alignment step 2 (SQRNdbnseq.py:1031-1034,1084-1085): one L x L matrix on the device + column maps
+    (mul_matrix_dev, gathered by sq_gather_mul_kernel) gives what one host matrix per record gives, and the oracle."""
+    import numpy as np
+    import torch
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import HipEngine
+    names, psets = conf("ali")
+    rng = np.random.default_rng(21)
+    L = 150
+    anc = rng.choice(list("ACGU"), L)
+    rows = []
+    for _ in range(12):
+        row = anc.copy()
+        m = rng.random(L) < 0.15
+        row[m] = rng.choice(list("ACGU"), int(m.sum()))
+        row[rng.random(L) < 0.1] = "-"
+        rows.append("".join(row))
+    sm = rng.random((L, L)) * (rng.random((L, L)) < 0.3)
+    sm = (sm + sm.T) / np.max(sm + sm.T) * 5
+    on_host = HipEngine().fold_records([(r, None, None, None, psets, sm) for r in rows], poollim=30)
+    dev = torch.from_numpy(sm).to("cuda").contiguous()
+    on_dev = HipEngine().fold_records([(r, None, None, None, psets, dev) for r in rows], poollim=30)
+    assert [d[:2] for d in on_dev] == [h[:2] for h in on_host]
+    for k in range(4):
+        exp = O.SQRNdbnseq(rows[k], None, None, None, psets, poollim=30, stemmatrix=sm)
+        exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(on_dev[k], exp, ("shared stem matrix", k))
