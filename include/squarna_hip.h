@@ -237,6 +237,9 @@ SQ_API int sq_fold_concurrent_n(sq_batch *const *batches, int32_t nbatch, const 
  * the device (poollim == 1), 2 device pools, 3 device pools that outgrew a capacity and were repeated by the host loop.
  * All give identical results; the number is for tests and tuning (max_structs). */
 SQ_API int32_t sq_fold_driver(const sq_batch *b);
+/* Most structures any round of the batch's last fold evaluated at once (device pools: the largest generation; 0 when the
+ * host-driven loop ran).  A host that folds a stream of similar batches sizes max_structs from it. */
+SQ_API int64_t sq_fold_peak_structs(const sq_batch *b);
 
 /* Result getters (valid after sq_fold until the next sq_fold / destroy). */
 /* k > 0: the getters below (single and bulk) show only the first k structures of every sequence, in rank order -- a

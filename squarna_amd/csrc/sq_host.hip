@@ -1828,6 +1828,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         int parity = 0, S = S0, rounds = 0;
         bool overflow = false;
         while (S > 0) {
+            b->last_peak = std::max<int64_t>(b->last_peak, S);
             SqStruct *cur = pio.structs + (size_t)parity * pio.smax;
             SqRoundIO io;
             io.h_strands = pio.strands; io.d_strands = pio.strands;
@@ -1903,9 +1904,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     };
     mark("loop start");
     b->last_driver = use_pool ? 2 : use_chain ? 1 : 0;
+    b->last_peak = use_chain ? (int64_t)greedy_jobs.size() : 0;
     if (use_pool) {
         const int pr = pool_fold(st0);
-        if (pr == 1) b->last_driver = 3;
+        if (pr == 1) { b->last_driver = 3; b->last_peak = 0; }
         if (pr == 1 && timing) fprintf(stderr, "[sq_fold] device pools: a capacity was exceeded, the host loop repeats the greedy part\n");
         if (pr == 1) {                                       // a capacity was exceeded: the host's own loop takes the fold
             st0 = LoopStats();
@@ -2032,6 +2034,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
 }
 
 extern "C" int32_t sq_fold_driver(const sq_batch *b) { return b ? b->last_driver : -1; }
+extern "C" int64_t sq_fold_peak_structs(const sq_batch *b) { return b ? b->last_peak : -1; }
 
 extern "C" int sq_fold_concurrent(sq_batch *const *batches, int32_t nbatch, const sq_fold_opts *opts,
                                   const int32_t *const *ref_off, const int32_t *const *ref_pairs, const uint8_t *const *has_ref)

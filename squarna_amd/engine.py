@@ -320,6 +320,11 @@ class Batch:
         _lib.check(self.L.sq_result_limit(self.h, int(k or 0)))
 
     @property
+    def fold_peak_structs(self):
+        """Most structures any round of the last fold held at once (sq_fold_peak_structs; 0: host-driven loop)."""
+        return int(self.L.sq_fold_peak_structs(self.h))
+
+    @property
     def fold_driver(self):
         """Driver of the last fold's greedy pool loop (sq_fold_driver): 0 host loop, 1 chained rounds, 2 device pools,
         3 device pools repeated by the host loop."""
@@ -607,25 +612,37 @@ class HipEngine:
     def _fold_records(self, records, **opts):
         """`keep`: only the first `keep` structures of every record are fetched (Predict prints outplim of them)."""
         poollim = opts.get("poollim", 1000)
-        if not self.max_structs and poollim > 1 and len(records) > 1:
+        if not self.max_structs and poollim > 1 and len(records) > 1 and "max_structs_hint" not in opts:
             # wide pools: as many records per batch as the device pools have slots for (a fold that outgrows them is
             # repeated by the library's host loop -- correct, but several times slower)
             per_rec = [pool_slots_wanted(sum(1 for ps in r[4] if "G" in ps["algorithms"]), poollim, len(r[0])) for r in records]
             cap = pool_slot_cap(max(len(r[0]) for r in records))
             if sum(per_rec) > cap:
-                out, refs, lo = [], [], 0
+                out, refs, lo, scale = [], [], 0, 1.0
+                # dense per-job matrices (alignment step 2: N x N fp64 + fp32 per job) bound a sub-batch as well: 32 GB of
+                # them (allocating and touching 100 GB per batch costs more than the larger rounds save)
+                dense = [12.0 * len(r[0]) ** 2 * len(r[4]) if len(r) > 5 and r[5] is not None else 0.0 for r in records]
                 while lo < len(records):
-                    hi, g = lo, 0
-                    while hi < len(records) and (hi == lo or g + per_rec[hi] <= cap):
-                        g += per_rec[hi]
+                    hi, g, gb = lo, 0.0, 0.0
+                    while hi < len(records) and (hi == lo or (g + max(16.0, per_rec[hi] * scale) <= cap and gb + dense[hi] <= 32e9)):
+                        g += max(16.0, per_rec[hi] * scale)
+                        gb += dense[hi]
                         hi += 1
-                    out.extend(self._fold_records(records[lo:hi], **opts))
+                    self.last_fold_peak = 0
+                    out.extend(self._fold_records(records[lo:hi], max_structs_hint=int(g), **opts))
                     refs.extend(self.last_ref_scores)
+                    # what the pools of this sub-batch really reached tells how many records the next ones can take (a
+                    # fold weighted by an alignment's stem matrix keeps one or two structures per job: no need to split)
+                    if self.last_fold_peak > 0 and self.last_fold_driver == 2:
+                        scale = min(scale, max(2.0 * self.last_fold_peak / max(sum(per_rec[lo:hi]), 1), 1e-4))
+                    elif self.last_fold_driver == 3:
+                        scale = min(1.0, scale * 4)
                     lo = hi
                 self.last_ref_scores = refs
                 return out
         interchainonly = opts.pop("interchainonly", False)
         keep = opts.pop("keep", None)
+        slots_hint = opts.pop("max_structs_hint", None)
         M, B = opts.pop("M", 1.8), opts.pop("B", -0.6)
         prepared = [Prepared(r[0], r[1], r[2], r[3]) for r in records]
         psets = [r[4] for r in records]
@@ -653,8 +670,9 @@ class HipEngine:
         njobs = sum(len(pl) for pl in psets)
         max_structs = self.max_structs if self.max_structs else max(4096, min(4 * njobs, 262144))
         if not self.max_structs and opts.get("poollim", 1000) > 1:
-            want = sum(pool_slots_wanted(sum(1 for ps in pl if "G" in ps["algorithms"]), opts.get("poollim", 1000), len(p.shortseq))
-                       for p, pl in zip(prepared, psets))
+            want = slots_hint if slots_hint else sum(
+                pool_slots_wanted(sum(1 for ps in pl if "G" in ps["algorithms"]), opts.get("poollim", 1000), len(p.shortseq))
+                for p, pl in zip(prepared, psets))
             max_structs = max(max_structs, min(want, pool_slot_cap(max(len(p.shortseq) for p in prepared))))
         # SQ_ENGINE_LANES=2 folds big inputs as two concurrent batches; for one-shot calls the second batch's set-up
         # (pinned buffers, worker pool) costs more than the overlap saves, so it is opt-in (long-lived batches
@@ -667,6 +685,7 @@ class HipEngine:
                 b.limit_results(keep)
                 b.fold(**opts)
                 self.last_fold_driver = b.fold_driver
+                self.last_fold_peak = b.fold_peak_structs
                 both = b.results_all()
                 self.last_ref_scores = [r[1] for r in both]
                 return [r[0] for r in both]

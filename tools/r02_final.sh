@@ -17,4 +17,6 @@ ls -la $out
 cat $out/r02_predict.txt
 bash tools/pool_scale_probe.sh > $out/r02_predict_pools.txt 2>&1
 python tools/scale_soak.py 2>&1 | grep -vE "amdgpu.ids" > $out/r02_scale_soak.txt
-tail -3 $out/r02_scale_soak.txt
+python tools/scale_soak.py ali_5000 very_long_chain very_long_pool 2>&1 | grep -vE "amdgpu.ids|warmup" >> $out/r02_scale_soak.txt
+python tools/a5000_full.py 512 5000 2>&1 | grep alignment > $out/r02_a5000_full.txt
+cat $out/r02_a5000_full.txt
