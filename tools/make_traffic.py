@@ -4,7 +4,7 @@ per kernel the HBM bytes per launch (FETCH_SIZE is reported in KB and counts 64 
 MI355X_MICROARCH.md section HBM; WRITE_SIZE in KB, exact), the share of wave cycles spent waiting and the share of
 LDS-busy cycles that are bank-conflict cycles, stamped with a hash of the kernel sources they were measured on
 (bench.py withholds them when the sources have changed).
-usage: make_traffic.py TAG KERNEL=PMCDIR [KERNEL=PMCDIR ...]      (TAG names the committed summaries, e.g. r02)"""
+usage: make_traffic.py TAG KERNEL[:NAME_PREFIX]=PMCDIR [...]      (TAG names the committed summaries, e.g. r02)"""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,11 +16,13 @@ out = {"kernels_sha16": kernels_hash(), "round": tag,
                "the probe / their number"}
 for arg in sys.argv[2:]:
     kern, d = arg.split("=")
+    kern, _, prefix = kern.partition(":")                      # KEY:PREFIX=DIR -- kernels whose names start with PREFIX, filed under KEY
+    prefix = prefix or kern
     tot, ndisp, dur = collections.Counter(), {}, {}
     for f in sorted(glob.glob(d + "/p*/*/*counter_collection.csv")):
         seen = set()
         for r in csv.DictReader(open(f)):
-            if not r["Kernel_Name"].startswith(kern):
+            if not r["Kernel_Name"].startswith(prefix):
                 continue
             c = r["Counter_Name"]
             tot[c] += float(r["Counter_Value"])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # All PMC evidence of a round in one go (on the MI355X box): bash tools/pmc_all.sh TAG
 #   S1000 x 1024 probe -> counters of sq_scan6_kernel and sq_score_kernel (one set of --pmc passes sees every kernel)
-#   SRtest150 Edmonds probe -> counters of sq_mwm_kernel;  256 x S1000 fill probe -> counters of sq_fill_kernel
+#   SRtest150 Edmonds probe -> counters of the blossom kernel (sq_mwm_single_kernel for a batch alone);  256 x S1000 fill probe -> counters of sq_fill_kernel
 # writes profiles/TAG_{scan6,score,mwm,fill}_pmc.txt and profiles/traffic.json (stamped with the kernel sources' hash).
 tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -26,7 +26,7 @@ run WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 python3 tools/pmc_summary.py $f sq_fill_kernel > profiles/${tag}_fill_pmc.txt
 python3 tools/pmc_summary.py $s sq_scan6_kernel > profiles/${tag}_scan6_pmc.txt
 python3 tools/pmc_summary.py $s sq_score_kernel > profiles/${tag}_score_pmc.txt
-python3 tools/pmc_summary.py $e sq_mwm_kernel > profiles/${tag}_mwm_pmc.txt
-python3 tools/make_traffic.py $tag sq_scan6_kernel=$s sq_score_kernel=$s sq_mwm_kernel=$e sq_fill_kernel=$f > /dev/null
+python3 tools/pmc_summary.py $e sq_mwm > profiles/${tag}_mwm_pmc.txt    # (sq_mwm_single_kernel: one batch alone; sq_mwm_kernel: batches in flight -- the same code per graph)
+python3 tools/make_traffic.py $tag sq_scan6_kernel=$s sq_score_kernel=$s sq_mwm_kernel:sq_mwm=$e sq_fill_kernel=$f > /dev/null
 mkdir -p gpurun_out/profiles_$tag && cp profiles/${tag}_*_pmc.txt profiles/traffic.json gpurun_out/profiles_$tag/
 cat profiles/traffic.json
