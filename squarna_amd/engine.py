@@ -612,37 +612,59 @@ class HipEngine:
     def _fold_records(self, records, **opts):
         """`keep`: only the first `keep` structures of every record are fetched (Predict prints outplim of them)."""
         poollim = opts.get("poollim", 1000)
-        if not self.max_structs and poollim > 1 and len(records) > 1 and "max_structs_hint" not in opts:
+        if not self.max_structs and poollim > 1 and len(records) > 1:
             # wide pools: as many records per batch as the device pools have slots for (a fold that outgrows them is
             # repeated by the library's host loop -- correct, but several times slower)
             per_rec = [pool_slots_wanted(sum(1 for ps in r[4] if "G" in ps["algorithms"]), poollim, len(r[0])) for r in records]
             cap = pool_slot_cap(max(len(r[0]) for r in records))
             if sum(per_rec) > cap:
-                out, refs, lo, scale = [], [], 0, 1.0
-                # dense per-job matrices (alignment step 2: N x N fp64 + fp32 per job) bound a sub-batch as well: 32 GB of
-                # them (allocating and touching 100 GB per batch costs more than the larger rounds save)
-                dense = [12.0 * len(r[0]) ** 2 * len(r[4]) if len(r) > 5 and r[5] is not None else 0.0 for r in records]
-                while lo < len(records):
-                    hi, g, gb = lo, 0.0, 0.0
-                    while hi < len(records) and (hi == lo or (g + max(16.0, per_rec[hi] * scale) <= cap and gb + dense[hi] <= 32e9)):
-                        g += max(16.0, per_rec[hi] * scale)
-                        gb += dense[hi]
-                        hi += 1
-                    self.last_fold_peak = 0
-                    out.extend(self._fold_records(records[lo:hi], max_structs_hint=int(g), **opts))
-                    refs.extend(self.last_ref_scores)
-                    # what the pools of this sub-batch really reached tells how many records the next ones can take (a
-                    # fold weighted by an alignment's stem matrix keeps one or two structures per job: no need to split)
-                    if self.last_fold_peak > 0 and self.last_fold_driver == 2:
-                        scale = min(scale, max(2.0 * self.last_fold_peak / max(sum(per_rec[lo:hi]), 1), 1e-4))
-                    elif self.last_fold_driver == 3:
-                        scale = min(1.0, scale * 4)
-                    lo = hi
-                self.last_ref_scores = refs
-                return out
+                return self._fold_in_sub_batches(records, per_rec, cap, opts)
+        out, refs = self._fold_groups([records], [None], opts)
+        self.last_ref_scores = refs[0]
+        return out[0]
+
+    def _fold_in_sub_batches(self, records, per_rec, cap, opts):
+        """Consecutive sub-batches sized to the device-pool slots.  What the pools of the first one really reached scales
+        the estimate for the rest (a fold weighted by an alignment's stem matrix keeps one or two structures per job).
+        (Measured: folding the sub-batches two at a time on streams of their own gains nothing -- 512 x 5000-column
+        alignment 10.5 s either way, 3000 x 300 nt with pools of a thousand 2.1 s: these folds are bound by the scoring
+        kernel, not by gaps between rounds -- and costs the second batch's memory.)"""
+        out, refs, lo, scale = [], [], 0, 1.0
+        # dense per-job matrices (alignment step 2: N x N fp64 + fp32 per job) bound a sub-batch as well: 32 GB of them
+        # (allocating and touching 100 GB per batch costs more than the larger rounds save)
+        dense = [12.0 * len(r[0]) ** 2 * len(r[4]) if len(r) > 5 and r[5] is not None else 0.0 for r in records]
+
+        def next_group(lo):
+            hi, g, gb = lo, 0.0, 0.0
+            while hi < len(records) and (hi == lo or (g + max(16.0, per_rec[hi] * scale) <= cap and gb + dense[hi] <= 32e9)):
+                g += max(16.0, per_rec[hi] * scale)
+                gb += dense[hi]
+                hi += 1
+            return hi, int(g)
+
+        first = True
+        while lo < len(records):
+            spans, hints = [], []
+            hi, g = next_group(lo)
+            spans.append((lo, hi)); hints.append(g)
+            lo = hi
+            o, r = self._fold_groups([records[a:b] for a, b in spans], hints, opts)
+            for x, y in zip(o, r):
+                out.extend(x); refs.extend(y)
+            if first and self.last_fold_peak > 0 and self.last_fold_driver == 2:
+                a, b = spans[0]
+                scale = min(scale, max(2.0 * self.last_fold_peak / max(sum(per_rec[a:b]), 1), 1e-4))
+            elif self.last_fold_driver == 3:
+                scale = min(1.0, scale * 4)
+            first = False
+        self.last_ref_scores = refs
+        return out
+
+    def _make_batch(self, records, slots_hint, opts):
+        """(Batch, fold options) for these records.  opts: fold_records' keyword arguments (not modified)."""
+        opts = dict(opts)
         interchainonly = opts.pop("interchainonly", False)
         keep = opts.pop("keep", None)
-        slots_hint = opts.pop("max_structs_hint", None)
         M, B = opts.pop("M", 1.8), opts.pop("B", -0.6)
         prepared = [Prepared(r[0], r[1], r[2], r[3]) for r in records]
         psets = [r[4] for r in records]
@@ -652,8 +674,9 @@ class HipEngine:
         sm0 = records[0][5] if len(records[0]) > 5 else None
         if sm0 is not None and hasattr(sm0, "is_cuda") and sm0.is_cuda and all(len(r) > 5 and r[5] is sm0 for r in records):
             # alignment step 2 with the stem matrix still on the GPU: no per-record copies (Batch(mul_shared=...))
-            mul_shared = (sm0, [np.flatnonzero(~gap_mask(r[0])).astype(np.int32) for r in records],
-                          float(sm0.abs().max().item()))
+            if getattr(self, "_sm_maxabs", (None, None))[0] is not sm0:
+                self._sm_maxabs = (sm0, float(sm0.abs().max().item()))
+            mul_shared = (sm0, [np.flatnonzero(~gap_mask(r[0])).astype(np.int32) for r in records], self._sm_maxabs[1])
         elif any(len(r) > 5 and r[5] is not None for r in records):
             mul = []
             for r, p in zip(records, prepared):
@@ -663,7 +686,6 @@ class HipEngine:
                 if sm is not None:                                   # :1031-1034
                     sm = np.delete(np.delete(np.asarray(sm, dtype=np.float64), p.gapidx, 0), p.gapidx, 1)
                 mul.extend([sm] * len(r[4]))
-        nrec = len(records)
         # structure slots of the batch: the device-side pools / chained rounds hold every structure of a round at once, so
         # the default grows with the number of (sequence, paramset) jobs (a fold that still outgrows it is repeated by
         # the library's host loop)
@@ -674,49 +696,55 @@ class HipEngine:
                 pool_slots_wanted(sum(1 for ps in pl if "G" in ps["algorithms"]), opts.get("poollim", 1000), len(p.shortseq))
                 for p, pl in zip(prepared, psets))
             max_structs = max(max_structs, min(want, pool_slot_cap(max(len(p.shortseq) for p in prepared))))
-        # SQ_ENGINE_LANES=2 folds big inputs as two concurrent batches; for one-shot calls the second batch's set-up
-        # (pinned buffers, worker pool) costs more than the overlap saves, so it is opt-in (long-lived batches
-        # profit: fold_concurrently / sq_fold_concurrent)
+        b = Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
+                  max_structs=max_structs, cand_per_nt=self.cand_per_nt, mul_shared=mul_shared)
+        b.limit_results(keep)
+        return b, opts
+
+    def _fold_groups(self, groups, hints, opts):
+        """Folds every group of records as one batch, all of them at the same time; ([results], [reference scores]) per
+        group.  One group with SQ_ENGINE_LANES=2 and a big input: cut into two concurrent batches (for one-shot calls
+        the second batch's set-up costs more than the overlap saves, so that is opt-in)."""
         lanes = int(os.environ.get("SQ_ENGINE_LANES", "1"))
-        cost = [float(len(p.shortseq)) ** 2 * len(pl) for p, pl in zip(prepared, psets)]
-        if lanes < 2 or nrec < 256 or sum(cost) < 1e8 or mul_shared is not None:
-            with Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
-                       max_structs=max_structs, cand_per_nt=self.cand_per_nt, mul_shared=mul_shared) as b:
-                b.limit_results(keep)
-                b.fold(**opts)
-                self.last_fold_driver = b.fold_driver
-                self.last_fold_peak = b.fold_peak_structs
-                both = b.results_all()
-                self.last_ref_scores = [r[1] for r in both]
-                return [r[0] for r in both]
-        # big inputs: two batches folded concurrently (sq_fold_concurrent) -- the host bookkeeping of one overlaps
-        # the kernels of the other; records are independent, so the split does not change any result
-        from .parallel import lpt_partition
-        parts = [p for p in lpt_partition(cost, 2) if p]
-        job0 = np.cumsum([0] + [len(pl) for pl in psets])
+        back = None
+        if len(groups) == 1 and lanes >= 2 and len(groups[0]) >= 256 and hints[0] is None:
+            recs = groups[0]
+            cost = [float(len(r[0])) ** 2 * len(r[4]) for r in recs]
+            if sum(cost) >= 1e8 and not any(len(r) > 5 and r[5] is not None and hasattr(r[5], "is_cuda") for r in recs):
+                from .parallel import lpt_partition
+                back = [p for p in lpt_partition(cost, 2) if p]
+                groups, hints = [[recs[k] for k in idx] for idx in back], [None] * len(back)
         batches = []
         try:
-            for q, idx in enumerate(parts):
-                def pick(seq, per_job):
-                    if seq is None:
-                        return None
-                    return [x for k in idx for x in seq[job0[k]:job0[k + 1]]] if per_job else [seq[k] for k in idx]
-                batches.append(Batch(pick(prepared, False), pick(psets, False), interchainonly=interchainonly,
-                                     mul=pick(mul, True), bpp=pick(bpp, True), fp32=False,
-                                     max_structs=max_structs, cand_per_nt=self.cand_per_nt))
-            for b in batches:
-                b.limit_results(keep)
-            fold_concurrently(batches, **opts)
-            out = [None] * nrec
-            self.last_ref_scores = [None] * nrec
-            for b, idx in zip(batches, parts):
-                for (res, refsc), k in zip(b.results_all(), idx):
-                    out[k] = res
-                    self.last_ref_scores[k] = refsc
-            return out
+            fold_opts = None
+            import torch
+            if len(groups) > 1:
+                torch.cuda.current_stream().synchronize()            # (inputs made on this stream, e.g. the shared stem matrix)
+            for q, (recs, hint) in enumerate(zip(groups, hints)):
+                # concurrent batches on streams of their own: kernels of one fill the gaps of the other
+                ctx = torch.cuda.stream(torch.cuda.Stream()) if q > 0 else contextlib.nullcontext()
+                with ctx:
+                    b, fold_opts = self._make_batch(recs, hint, opts)
+                batches.append(b)
+            if len(batches) == 1:
+                batches[0].fold(**fold_opts)
+            else:
+                fold_concurrently(batches, **fold_opts)
+            self.last_fold_driver = max(b.fold_driver for b in batches)
+            self.last_fold_peak = batches[0].fold_peak_structs
+            res = [b.results_all() for b in batches]
         finally:
             for b in batches:
                 b.close()
+        outs, refs = [[r[0] for r in both] for both in res], [[r[1] for r in both] for both in res]
+        if back is not None:                                         # undo the two-lane cut
+            n = sum(len(idx) for idx in back)
+            o, rf = [None] * n, [None] * n
+            for idx, oo, rr in zip(back, outs, refs):
+                for k, x, y in zip(idx, oo, rr):
+                    o[k], rf[k] = x, y
+            return [o], [rf]
+        return outs, refs
 
     def yield_stems(self, records, bpweights, minlen, minbpscore, interchainonly=False):
         """Alignment step 1 (SQRNdbnali.py:60-108): for every (seq, reacts, restraints) the stems of
