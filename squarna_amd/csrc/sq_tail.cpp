@@ -404,7 +404,10 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
     }
 #ifdef SQ_TAIL_PROF
     const double tp3 = nowus();
-    if (fins.size() > 100) fprintf(stderr, "[sq_tail] seq %d n=%d: %zu structures: dedupe+score %.0f us, rank %.0f us, levels %.0f us\n", seq, n, fins.size(), tp1 - tp0, tp2 - tp1, tp3 - tp2);
+#ifndef SQ_TAIL_PROF_MIN
+#define SQ_TAIL_PROF_MIN 100
+#endif
+    if (fins.size() > SQ_TAIL_PROF_MIN) fprintf(stderr, "[sq_tail] seq %d n=%d: %zu structures: dedupe+score %.0f us, rank %.0f us, levels %.0f us\n", seq, n, fins.size(), tp1 - tp0, tp2 - tp1, tp3 - tp2);
 #endif
     BPV cons;                                                          // :845-858,1236
     const size_t top = std::min<size_t>(fins.size(), (size_t)std::max(o.conslim, 0));
