@@ -141,9 +141,9 @@ __global__ void sq_colselect_kernel(const double *matrix, int L, double thr, int
 __global__ void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
 __global__ void sq_bits_kernel(SqDevCtx c, int only_ext);
 __global__ void sq_score_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
-                                SqScanArgs a, SqRoundIO io, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off);
+                                SqScanArgs a, SqRoundIO io, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off, int cell_off);
 __global__ void sq_bps_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
-                              SqScanArgs a, SqRoundIO io, int mode, int lds_n, int lds_n_reacts, int surv_off);
+                              SqScanArgs a, SqRoundIO io, int mode, int lds_n, int lds_n_reacts, int surv_off, int cell_off);
 __global__ void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqRoundIO io);
 }
 

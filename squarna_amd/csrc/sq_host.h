@@ -137,6 +137,7 @@ struct sq_batch {
     hipStream_t lane_stream = nullptr;        // second lane of sq_fold's greedy rounds (created on first use)
     hipEvent_t lane_ev = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
+    int32_t cell_entries = 32;            // doubles of the scoring kernels' cell table (dynamic LDS)
     int32_t chain_tmax = 1;               // most stems a structure of any job can hold (sizes the extend kernels' LDS)
     char *algo_scratch = nullptr;         // device scratch of the Hungarian / Nussinov kernels (Layout::off_algo)
     size_t algo_bytes = 0, algo_used = 0;

@@ -554,6 +554,15 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         }
         J.maxabs = (float)(mx * 1.0000002);
     }
+    // cell table of the scoring kernels (dynamic LDS): K R x (K R | 1) doubles for the largest K R of the batch, K = the
+    // paramset's letter classes, R = the sequence's reactivity levels when K R <= 32 (else 1: factors per cell)
+    b->cell_entries = 32;
+    for (const SqJob &J : b->jobs) {
+        const int K = b->pset_classes[J.pset];
+        const int R = (!J.default_reacts && J.react_levels > 0 && K * J.react_levels <= 32) ? J.react_levels : 1;
+        const int KR = K * R;
+        b->cell_entries = std::max(b->cell_entries, KR * (KR | 1));
+    }
     // ---- device carve + uploads ----
     b->ctx.codes = (uint8_t *)(base + L.off_codes); b->ctx.flags = (uint8_t *)(base + L.off_flags);
     b->ctx.inc4 = (uint8_t *)(base + L.off_inc4); b->ctx.chain = (int16_t *)(base + L.off_chain);
@@ -1069,15 +1078,18 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
         // either way within the run-to-run spread and keeps 512.
         const int thr0 = maxn <= 400 ? 256 : 512;
         const int thr = score_threads ? score_threads : (mode == 0 ? thr0 : (parts == 1 && S < 2048 ? 512 : 256));
+        // the cell table (K R x (K R | 1) doubles for the batch's largest K R), then
         // mode 0: list of the bpscore survivors of a chunk (5 x threads entries of 8 + 4 + 2 bytes) behind the tables
+        const int cell_off = (int)((dyn + 15) & ~(size_t)15);
+        dyn = (size_t)cell_off + 8 * (size_t)b->cell_entries;
         const int surv_off = (int)((dyn + 15) & ~(size_t)15);
         dyn = (size_t)surv_off + (size_t)14 * (SQ_SCORE_CHUNK + (mode == 0 ? 1 : 0)) * thr;   // (one-pass modes: no carry-over)
         if (mode == 0)
             hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, d_structs, d_strands, b->state,
-                               scan, io, lds_n, lds_nr, lds_ns, surv_off);
+                               scan, io, lds_n, lds_nr, lds_ns, surv_off, cell_off);
         else
             hipLaunchKernelGGL(sq_bps_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, d_structs, d_strands, b->state,
-                               scan, io, mode, lds_n, lds_nr, surv_off);
+                               scan, io, mode, lds_n, lds_nr, surv_off, cell_off);
         if (mode == 0 && !chained)
             hipLaunchKernelGGL(sq_select_kernel, dim3(S, std::max(1, parts / 2)), dim3(256), 0, st, b->ctx, d_structs, scan, io);
         if (chained && !pooled) {

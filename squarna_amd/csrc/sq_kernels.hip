@@ -735,7 +735,7 @@ __device__ __forceinline__ bool sq_goodloop(int x, int y)             // :615-62
 template <bool FULL>
 __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct *structs, const SqStrand *strands,
                                               const SqState &stt, SqScanArgs &a, const SqRoundIO &io, int mode, int lds_n,
-                                              int lds_n_reacts, int lds_n_state, int surv_off)
+                                              int lds_n_reacts, int lds_n_state, int surv_off, int cell_off)
 {
     __shared__ SqStrand s_str[FULL ? SQ_LDS_STRANDS : 1];
     __shared__ uint16_t s_skip[FULL ? SQ_LDS_STRANDS : 1];   // 5' strand k closes a block: next strand that can matter after it
@@ -747,10 +747,11 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     // of 256 bytes = the whole bank span, so the pairs of the four letters sat on four bank pairs (4-way conflicts,
     // 72 % of the LDS-busy cycles of the kernel, profiles/r01k_score_pmc_*); the compact table's odd stride spreads
     // the <= (K R)^2 live entries over all banks.  Arbitrary float reactivities: weights from the table (R = 1), the
-    // factor per cell as before.
-    __shared__ double s_cell[32 * 33];
+    // factor per cell as before.  The table sits in the block's dynamic LDS at cell_off, sized by the host for the
+    // largest K R of the batch (25 entries for ACGU without reactivity levels; a static 32 x 33 array cost 8 KB per block).
     __shared__ uint8_t s_cls[32];
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];   // letter codes [n] (+ reactivities [n] when they fit)
+    double *const s_cell = reinterpret_cast<double *>(s_dyn + cell_off);
     const SqStruct st = structs[blockIdx.x];
 #ifdef SQ_SCORE_PROF
     const long long _p0 = wall_clock64(); long long _pa = 0, _pb = 0, _ps = 0;
@@ -1198,18 +1199,19 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
 // mode 0 (the greedy rounds): bpscore filter + ScoreStems, two phases (see the body)
 extern "C" __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SQ_SCORE_WAVES))) void sq_score_kernel(SqDevCtx c, const SqStruct *structs,
                                                                   const SqStrand *strands, SqState stt, SqScanArgs a,
-                                                                  SqRoundIO io, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off)
+                                                                  SqRoundIO io, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off,
+                                                                  int cell_off)
 {
-    sq_score_body<true>(c, structs, strands, stt, a, io, 0, lds_n, lds_n_reacts, lds_n_state, surv_off);
+    sq_score_body<true>(c, structs, strands, stt, a, io, 0, lds_n, lds_n_reacts, lds_n_state, surv_off, cell_off);
 }
 
 // modes 1 / 2 (OptimalStems output, alignment survivor list): the bpscore filter alone, as its own kernel so that its
 // loop is not compiled under the register budget of ScoreStems
 extern "C" __global__ __launch_bounds__(1024) void sq_bps_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands,
                                                                 SqState stt, SqScanArgs a, SqRoundIO io, int mode, int lds_n,
-                                                                int lds_n_reacts, int surv_off)
+                                                                int lds_n_reacts, int surv_off, int cell_off)
 {
-    sq_score_body<false>(c, structs, strands, stt, a, io, mode, lds_n, lds_n_reacts, 0, surv_off);
+    sq_score_body<false>(c, structs, strands, stt, a, io, mode, lds_n, lds_n_reacts, 0, surv_off, cell_off);
 }
 
 // ChooseStems range filter (:769-778): candidates within subopt * best of the structure's best finalscore
