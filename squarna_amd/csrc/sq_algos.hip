@@ -91,6 +91,7 @@ struct SqAlgoChunk {
     size_t k0 = 0, k1 = 0;                       // jobs[k0, k1) of the caller's list
     std::vector<SqMatchJob> mj;
     std::vector<std::vector<int>> vid2pos;       // Edmonds: graph vertex -> position
+    std::vector<uint64_t> seen_hash;             // (SQ_MWM_POSTHOC) hash of every job's result as the collector read it
     SqMatchJob *p_jobs = nullptr;                // pinned staging: job table and edge list (read by the kernels in place)
     SqMatchEdge *p_edges = nullptr;
     size_t nedges = 0;
@@ -280,6 +281,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     const double tb2 = sq_now();
     // pass 2 (pool): the edges, written straight into the pinned buffer
     ck.vid2pos.resize(mj.size());
+    if (getenv("SQ_MWM_POSTHOC")) ck.seen_hash.assign(mj.size(), 0);
     sq_pool(b)->parallel_for((int)mj.size(), [&](int q) {
         CpuScope cpu_(2);
         const SqJob &J = b->jobs[jobs[k0 + q]];
@@ -423,6 +425,31 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
                 b->mwm_stats[0]++; b->mwm_stats[1] += np;
                 if (np > b->mwm_stats[2]) { b->mwm_stats[2] = np; b->mwm_stats[3] = ne; b->mwm_stats[4] = mj[q].n; b->mwm_stats[5] = mj[q].nedges; }
             }
+            static const bool posthoc = getenv("SQ_MWM_POSTHOC") != nullptr;
+            if (posthoc) {                                     // debug: what this read saw, to be compared after the fold
+                uint64_t h = 1469598103934665603ull;
+                for (int v = 0; v < 2 * mj[q].n + 2; v++) { h ^= (uint32_t)mate[v]; h *= 1099511628211ull; }
+                if (ck.seen_hash.size() == mj.size()) ck.seen_hash[q] = h;
+            }
+            static const bool verify = getenv("SQ_MWM_VERIFY") != nullptr;
+            if (verify && mj[q].n > 0) {
+                // debug: the same algorithm object run on the host over the job's edges must give the kernel's mates
+                const SqMatchEdge *he = ck.p_edges + mj[q].edge_off;
+                std::vector<char> scr(SqBlossom::scratch_bytes(mj[q].n, mj[q].nedges) + 64);
+                SqBlossom hb;
+                hb.init(mj[q].n, mj[q].nedges, he, scr.data());
+                hb.run();
+                int diff = 0;
+                for (int v = 0; v < mj[q].n; v++) diff += hb.mate[v] != mate[v];
+                if (diff || hb.error) {
+                    const int sp = ck.sorted.empty() ? (int)q : ck.sorted_pos[q];
+                    int cls = 0;
+                    for (size_t ci = 0; ci < ck.classes.size(); ci++) if (sp >= ck.classes[ci].start) cls = (int)ci;
+                    fprintf(stderr, "[mwm verify] job %zu (row %d, class %d of %zu): n %d m %d: %d of the kernel's mates differ from the host run "
+                            "(host error %d; kernel passes %d events %d, host passes %d events %d)\n", q, sp, cls, ck.classes.size(), mj[q].n,
+                            mj[q].nedges, diff, hb.error, mate[2 * mj[q].n], mate[2 * mj[q].n + 1], hb.stat_pass, hb.stat_event);
+                }
+            }
             for (int v = 0; v < mj[q].n; v++)
                 if (mate[v] > v) pairs.push_back(BP(ck.vid2pos[q][v], ck.vid2pos[q][mate[v]]));
         } else if (algo == SQ_ALGO_N) {
@@ -497,6 +524,17 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
             }
             if (sq_relaxed_waits(b)) sq_wait_step(1 << 20, true);    // (sleeps ~10 us)
             else for (int t = 0; t < 32; t++) sq_wait_step(0, false);
+        }
+    }
+    if (getenv("SQ_MWM_POSTHOC") && algo == SQ_ALGO_E && ck.seen_hash.size() == mj.size()) {
+        hipStreamSynchronize(ck.st);
+        for (size_t q = 0; q < mj.size(); q++) {
+            const int32_t *mate = h_out_p + mj[q].out_off;
+            uint64_t h = 1469598103934665603ull;
+            for (int v = 0; v < 2 * mj[q].n + 2; v++) { h ^= (uint32_t)mate[v]; h *= 1099511628211ull; }
+            if (h != ck.seen_hash[q])
+                fprintf(stderr, "[mwm posthoc] job %zu (n %d m %d): the result read when its flag appeared differs from the result after the kernel\n",
+                        q, mj[q].n, mj[q].nedges);
         }
     }
     if (bad == 3) return sq_check((hipError_t)stream_err.load(), "matching kernel");

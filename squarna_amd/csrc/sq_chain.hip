@@ -86,6 +86,6 @@ extern "C" __global__ void sq_chain_done_kernel(SqRoundIO io, SqScanArgs a, SqCh
 {
     *io.h_ctr = *a.ctr;
     *cio.h_nfin = *cio.d_nfin;
-    __threadfence_system();
+    sq_host_write_flush(cio.h_nfin);                     // (the stems and the list of finished structures: earlier kernels)
     *io.h_seq = seq;
 }

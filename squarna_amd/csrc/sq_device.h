@@ -95,6 +95,8 @@ struct SqPoolIO {
     SqPoolJob *h_jobs;                              // pinned copy of the job records (sq_pool_publish_kernel)
 };
 
+#include "sq_hostflag.h"
+
 // order-preserving map double -> uint64 (never 0 for a real number), so a per-structure maximum is one atomicMax
 __device__ __forceinline__ unsigned long long sq_ord(double x)
 {

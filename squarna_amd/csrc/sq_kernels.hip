@@ -426,7 +426,7 @@ __device__ __forceinline__ void sq_put_out(const SqRoundIO &io, SqScanArgs &a, c
 extern "C" __global__ void sq_done_kernel(SqRoundIO io, SqScanArgs a, uint32_t seq)
 {
     *io.h_ctr = *a.ctr;
-    __threadfence_system();
+    sq_host_write_flush(io.h_ctr);                       // (the output records in pinned memory: earlier kernels)
     *io.h_seq = seq;
 }
 

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include "sq_match.h"
+#include "sq_hostflag.h"
 #include <vector>
 #include <algorithm>
 #include "sq_blossom.h"
@@ -267,8 +268,16 @@ __device__ __forceinline__ void sq_mwm_one(SqBlossom &bl, char *lds_base, char *
                                            const SqMatchEdge *edges, char *scratch, int32_t *mate_out, uint32_t *job_flags,
                                            uint32_t stamp, int lane, Sync wsync)
 {
+    // The job's flag tells the host that its result block in pinned memory is complete.  A system-scope fence between the
+    // data stores and the flag store is NOT enough on this platform: both are posted writes on the way to host memory and
+    // the later one was seen to overtake the earlier ones (about one job in 10^5: the collector read a result block that
+    // was still arriving -- found by tools/fuzz_options.py, shown by SQ_MWM_POSTHOC=1).  A READ from the same memory
+    // cannot pass the posted writes ahead of it, so every lane reads back a word of the block before the flag goes out.
     auto publish = [&]() {
-        __threadfence_system();
+        if (job_flags) {
+            const int nw = jp->n > 0 ? 2 * jp->n + 2 : 2;
+            sq_host_write_flush(mate_out + jp->out_off + (lane < nw ? nw - 1 - lane : 0));
+        } else __threadfence_system();
         wsync();
         if (job_flags && lane == 0) job_flags[row] = stamp;
     };
@@ -364,7 +373,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_mwm_single_kernel(const SqMa
 
 extern "C" __global__ void sq_flag_kernel(uint32_t *flag, uint32_t value)
 {
-    __threadfence_system();
+    sq_host_write_flush(flag);                           // (the results in pinned memory: earlier kernels)
     *flag = value;
 }
 

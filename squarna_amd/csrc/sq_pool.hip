@@ -192,7 +192,7 @@ extern "C" __global__ __launch_bounds__(1024) void sq_pool_scan_kernel(SqPoolIO 
         H->active_jobs = (uint32_t)s_active;
         *io.h_ctr = *a.ctr;
         *pio.h_hdr = *H;
-        __threadfence_system();
+        sq_host_write_flush(io.h_ctr);
         *io.h_seq = seq;
     }
 }
@@ -265,7 +265,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_pool_publish_kernel(SqPoolI
     if (threadIdx.x == 0) {
         *io.h_ctr = *a.ctr;
         *pio.h_hdr = *pio.hdr;
-        __threadfence_system();
+        sq_host_write_flush(io.h_ctr);                   // (the log of final structures: the extend kernels)
         *io.h_seq = seq;
     }
 }

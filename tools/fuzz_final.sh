@@ -1,0 +1,11 @@
+#!/bin/bash
+# A last parity soak on the final tree (CPU oracle vs HIP engine); summary lines only.  usage: bash tools/fuzz_final.sh > out.txt
+run() { echo "## $*"; env "$@" 2>&1 | grep -E "mismatch|MISMATCH|rror" | tail -4 | cut -c1-400; }
+run python3 tools/fuzz_parity.py 6000 nobpp 101
+run FUZZ_POOLLIM=1 python3 tools/fuzz_parity.py 4000 fastest 102
+run FUZZ_POOLLIM=7 python3 tools/fuzz_parity.py 4000 alt 103
+run FUZZ_POOLLIM=100 python3 tools/fuzz_parity.py 3000 greedynobpp 104
+run FUZZ_NMIN=200 FUZZ_NMAX=600 python3 tools/fuzz_parity.py 160 500nobpp 105
+run FUZZ_NMIN=300 FUZZ_NMAX=900 FUZZ_POOLLIM=1 python3 tools/fuzz_parity.py 120 fastest 106
+run python3 tools/fuzz_options.py 200 32 201
+run python3 tools/fuzz_align.py 80 301

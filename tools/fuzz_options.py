@@ -76,10 +76,18 @@ def main():
             full.append((s, r, x, ref))
         plan.append((cfg, opts, prio, full))
         jobs.extend((rec, cfg, opts, prio) for rec in full)
+    only = int(os.environ.get("FUZZ_ONLY_TRIAL", "-1"))          # repeat ONE trial FUZZ_REPEAT times (hunting a flaky mismatch)
+    if only >= 0:
+        plan = [plan[only]] * int(os.environ.get("FUZZ_REPEAT", "50"))
+        jobs = [(rec, plan[0][0], plan[0][1], plan[0][2]) for rec in plan[0][3]] * len(plan)
     import multiprocessing as mp
     t0 = time.time()
     with mp.get_context("spawn").Pool(min(os.cpu_count() or 1, 64), initializer=_init) as pool:
-        exp = pool.map(_one, jobs, chunksize=4)
+        if only >= 0:
+            one = pool.map(_one, jobs[:len(plan[0][3])], chunksize=4)
+            exp = one * len(plan)
+        else:
+            exp = pool.map(_one, jobs, chunksize=4)
     print("oracle: %.1f s for %d records" % (time.time() - t0, len(jobs)), flush=True)
     from squarna_amd.engine import HipEngine
     bad, pos = 0, 0

@@ -35,6 +35,8 @@ CASES = {
     "mixed_extras": (600, 5, 900, True, "nobpp", 50),
     "long_chain": (48, 1500, 2500, True, "fastest", 1),
     "alt_mixed": (400, 10, 400, True, "alt", 100),
+    "huge_count_chain": (60000, 30, 150, False, "fastest", 1),     # several Predict batches (BATCH_RECORDS)
+    "huge_count_pools": (40000, 30, 120, True, "nobpp", 100),
     "very_long_chain": (6, 4500, 6000, False, "fastest", 1),       # > 1024 stems per structure: the level scratch in dynamic LDS
     "very_long_pool": (4, 4200, 5000, False, "greedynobpp", 8),
 }
