@@ -76,7 +76,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_lsap_kernel(const SqMatchJob
     }
     __syncthreads();
 
-    __shared__ int s_i, s_sink, s_nrem, s_index;
+    __shared__ int s_i, s_sink, s_nrem;
     __shared__ double s_minval;
     for (int cur = 0; cur < n; cur++) {
         // ---- augmenting_path(cur)
