@@ -11,6 +11,9 @@
 __device__ __forceinline__ void sq_host_write_flush(const volatile void *any_host_word)
 {
     __threadfence_system();
+#ifdef SQ_NO_HOST_FLUSH                                  // (measurement only)
+    return;
+#endif
     const uint32_t back = __hip_atomic_load(reinterpret_cast<const uint32_t *>(const_cast<const void *>(any_host_word)), __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" :: "v"(back) : "memory");
