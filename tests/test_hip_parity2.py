@@ -588,3 +588,24 @@ def test_shared_device_stem_matrix_equals_per_record_matrices():
         exp = O.SQRNdbnseq(rows[k], None, None, None, psets, poollim=30, stemmatrix=sm)
         exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
         _same_fold(on_dev[k], exp, ("shared stem matrix", k))
+
+
+def test_streamed_edmonds_results_are_stable_over_many_folds():
+    """Edmonds results are collected job by job while the kernel is still running (per-job flags in pinned memory).  Before
+    the publishers read host memory back ahead of the flag store (sq_hostflag.h), about one result block in 10^5 was read
+    while it was still arriving: 3 folds in 1,000 of a batch like this one gave a different structure for some record.
+    400 folds of the same 32 records, every one equal to the first, the first equal to the oracle."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import HipEngine
+    names, psets = conf("hungariannobpp")
+    raw = _chain_records(32, 20611, 60, 170)
+    recs = [(s, None, None, None, psets, None) for s, r, x in raw]
+    kw = dict(algos=frozenset("E"), toplim=1, poollim=2, rankby=(1, 2, 0))
+    first = HipEngine().fold_records(recs, **kw)
+    for k in range(0, 32, 4):
+        exp = O.SQRNdbnseq(raw[k][0], None, None, None, psets, **kw)
+        exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(first[k], exp, ("streamed E", k))
+    for rep in range(400):
+        again = HipEngine().fold_records(recs, **kw)
+        assert [a[:2] for a in again] == [f[:2] for f in first], rep
