@@ -89,6 +89,10 @@ def load():
         raise RuntimeError(
             "libsquarna_hip.so is missing (%s). Build it with `python -m squarna_amd.build` "
             "(hipcc --offload-arch=gfx950). squarna_amd has no CPU fallback." % LIB_PATH)
+    # torch first: the library's HIP calls must resolve to the ONE HIP runtime of the process, the one torch brings
+    # (loaded the other way round, the library pulls in the system's libamdhip64 and torch then its own copy: the second
+    # runtime finds no device -- "hipHostMalloc: no ROCm-capable device is detected" in build() + smoke() in one process)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.sq_last_error.restype = C.c_char_p
     L.sq_batch_destroy.restype = None
