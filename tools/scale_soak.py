@@ -39,6 +39,8 @@ CASES = {
     "huge_count_pools": (40000, 30, 120, True, "nobpp", 100),
     "very_long_chain": (6, 4500, 6000, False, "fastest", 1),       # > 1024 stems per structure: the level scratch in dynamic LDS
     "very_long_pool": (4, 4200, 5000, False, "greedynobpp", 8),
+    "giant_chain": (2, 20000, 31000, False, "fastest", 1),         # near the 32,000-nt limit of the 16-bit positions
+    "giant_pool": (1, 12000, 12000, False, "greedynobpp", 4),
 }
 
 
@@ -121,7 +123,7 @@ def run(name):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + [a for a in ALIGN_CASES if a != "ali_5000"])
+    names = sys.argv[1:] or ([c for c in CASES if not c.startswith("giant")] + [a for a in ALIGN_CASES if a != "ali_5000"])
     CASES["warmup"] = (64, 50, 300, True, "nobpp", 50)
     run("warmup")
     for n in names:
