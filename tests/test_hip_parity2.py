@@ -609,3 +609,18 @@ def test_streamed_edmonds_results_are_stable_over_many_folds():
     for rep in range(400):
         again = HipEngine().fold_records(recs, **kw)
         assert [a[:2] for a in again] == [f[:2] for f in first], rep
+
+
+def test_predict_sharded_world2_with_the_hip_engine():
+    """World size 2 with the PRODUCT engine: two ranks under gloo, both folding on cuda:0 (a one-GPU box cannot run RCCL
+    at world size 2): the shard / gather of the single-sequence mode and the all_reduce + sharded step 2 of alignment
+    mode give the golden texts (tools/world2_hip_check.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29743", os.path.join(root, "tools", "world2_hip_check.py")]
+    r = subprocess.run(cmd, env=env, cwd=root, timeout=900, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert r.stdout.count("identical to the golden text") == 5, r.stdout[-2000:]
