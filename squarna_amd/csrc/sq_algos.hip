@@ -736,6 +736,7 @@ extern "C" int sq_run_algos(sq_batch *b, int32_t njob, const int32_t *job_ids, i
                             sq_stem *out, int32_t out_cap, int32_t *out_off)
 {
     if (!b || njob < 0 || (algo != SQ_ALGO_E && algo != SQ_ALGO_H && algo != SQ_ALGO_N)) { sq_set_error("bad argument"); return -1; }
+    SqSlackGuard slack_guard;
     std::vector<int> jobs(job_ids, job_ids + njob);
     for (int j : jobs) if (j < 0 || j >= b->njobs) { sq_set_error("bad job index"); return -1; }
     std::vector<std::vector<HStem>> res;

@@ -202,9 +202,16 @@ void sq_set_error(const std::string &msg);
 int sq_pinned_get(void **p, size_t bytes);     // 0 or an error code (message set)
 void sq_pinned_put(void *p);                   // the streams that used the buffer must be idle
 int sq_check(hipError_t e, const char *what);
+// hipFuncAttributeMaxDynamicSharedMemorySize of `fn` on the CURRENT device, set once per (kernel, device): the
+// attribute is per device and a process may fold on several (one worker thread per batch); thread-safe
+void sq_max_dynamic_lds(const void *fn, int bytes);
 int sq_effective_cpus();                       // CPUs this process may really use: hardware threads, affinity, cgroup quota
 bool sq_relaxed_waits(const sq_batch *b);       // spin-then-sleep instead of pure spinning (many batches in flight, few CPUs)
 void sq_wait_step(uint64_t spins, bool relaxed);   // one step of a wait loop on a pinned completion word
+// sq_wait_step lowers the calling thread's timer slack while it sleeps in 10 us steps; entry points that may wait on the
+// CALLER's thread put the old value back before they return
+void sq_restore_timerslack();
+struct SqSlackGuard { ~SqSlackGuard() { sq_restore_timerslack(); } };
 // profiling bracket on an arbitrary stream (slot k of sq_profile_get); no-ops unless profiling is enabled
 void sq_prof_begin(sq_batch *b, int k, hipStream_t st, hipEvent_t *e0);
 void sq_prof_end(sq_batch *b, int k, hipStream_t st, hipEvent_t e0);

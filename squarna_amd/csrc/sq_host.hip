@@ -39,6 +39,18 @@ int sq_check(hipError_t e, const char *what)
 #include <sched.h>
 #include <sys/prctl.h>
 #include <time.h>
+void sq_max_dynamic_lds(const void *fn, int bytes)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> done;     // (kernel, device) pairs already raised
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto &d : done) if (d.first == fn && d.second == dev) return;
+    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.emplace_back(fn, dev);
+}
+
 int sq_effective_cpus()
 {
     static const int n = [] {
@@ -73,11 +85,21 @@ bool sq_relaxed_waits(const sq_batch *b)
     if (const char *e = getenv("LOCAL_WORLD_SIZE")) lws = std::max(1, atoi(e));
     return 2 * b->inflight * lws > (sq_effective_cpus() * 3) / 5;
 }
+// timer slack of the calling thread before sq_wait_step lowered it (-1: untouched).  The fold entry points restore it on
+// return: the thread that calls sq_fold belongs to the caller (Python's main thread), not to the library.
+static thread_local long g_slack_saved = -1;
+void sq_restore_timerslack()
+{
+    if (g_slack_saved >= 0) { prctl(PR_SET_TIMERSLACK, (unsigned long)g_slack_saved, 0, 0, 0); g_slack_saved = -1; }
+}
 void sq_wait_step(uint64_t spins, bool relaxed)
 {
     if (relaxed && spins > 512) {
-        static thread_local bool slack_set = false;
-        if (!slack_set) { prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }   // 1 us instead of the default 50 us
+        if (g_slack_saved < 0) {                            // 1 us instead of the default 50 us, for the length of the fold
+            const int cur = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+            g_slack_saved = cur > 0 ? cur : 50000;
+            prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+        }
         struct timespec ts = {0, 10000};
         nanosleep(&ts, nullptr);
         return;
@@ -1096,8 +1118,7 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
             SqChainIO cio = b->chain;
             // dynamic LDS: the level scratch for the longest stem list any job of the batch can reach
             const size_t ext_lds = sq_extend_lds_bytes(b->chain_tmax);
-            static bool attr_set = false;
-            if (ext_lds > 64 * 1024 && !attr_set) { hipFuncSetAttribute((const void *)sq_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+            if (ext_lds > 64 * 1024) sq_max_dynamic_lds((const void *)sq_chain_kernel, 160 * 1024);
             hipLaunchKernelGGL(sq_chain_kernel, dim3(S), dim3(64), ext_lds, st, b->ctx, d_structs, scan, cio, b->chain_tmax);
         }
         if (pooled) hipLaunchKernelGGL(sq_pool_choose_kernel, dim3(S), dim3(64), 0, st, b->ctx, d_structs, scan, b->pool_io);
@@ -1293,6 +1314,7 @@ extern "C" int sq_optimal_stems(sq_batch *b, int32_t nstruct, const int32_t *str
                                 const sq_stem *stems, const double *subopt, int32_t mode,
                                 sq_stem *out, int32_t out_cap, int32_t *out_off)
 {
+    SqSlackGuard slack_guard;
     if (!b || nstruct < 0 || (mode != 0 && mode != 1)) { sq_set_error("bad argument"); return -1; }
     std::vector<HStruct> hs(nstruct);
     std::vector<SView> views(nstruct);
@@ -1328,6 +1350,7 @@ extern "C" int sq_optimal_stems(sq_batch *b, int32_t nstruct, const int32_t *str
 extern "C" int sq_align_accumulate(sq_batch *b, int32_t njob, const int32_t *job_ids, const int32_t *col_off,
                                    const int32_t *cols, int32_t L, double *d_matrix)
 {
+    SqSlackGuard slack_guard;
     if (!b || njob < 0 || !job_ids || !col_off || !cols || L <= 0 || !d_matrix) { sq_set_error("bad argument"); return -1; }
     std::vector<HStruct> hs(njob);
     std::vector<SView> views(njob);
@@ -1388,6 +1411,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     if (!b || !opts) { sq_set_error("bad argument"); return -1; }
     const sq_fold_opts &o = *opts;
     if (o.poollim < 1) { sq_set_error("poollim must be positive"); return -1; }
+    SqSlackGuard slack_guard;
     const long long cpu_fold0 = g_cpuacc_on ? CpuScope::now() : 0;
     struct FoldTimer { double t0; ~FoldTimer() { if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_fold] total %.3f ms (incl. teardown)\n", (now_s() - t0) * 1e3); } } fold_timer{now_s()};
     // a-1, once per job and per fold (:1076): never reused from an earlier call, a fold is the whole path
@@ -1832,10 +1856,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             return 0;
         };
         const size_t ext_lds = sq_extend_lds_bytes(pio.pt);          // the extend kernel's level scratch (dynamic LDS)
-        {
-            static bool attr_set = false;
-            if (ext_lds > 64 * 1024 && !attr_set) { hipFuncSetAttribute((const void *)sq_pool_extend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-        }
+        if (ext_lds > 64 * 1024) sq_max_dynamic_lds((const void *)sq_pool_extend_kernel, 160 * 1024);
         const double tr0 = now_s();
         int parity = 0, S = S0, rounds = 0;
         bool overflow = false;
@@ -2059,6 +2080,7 @@ extern "C" int sq_fold_concurrent_n(sq_batch *const *batches, int32_t nbatch, co
                                     int32_t reps)
 {
     if (!batches || nbatch <= 0 || !opts || reps < 1) { sq_set_error("bad argument"); return -1; }
+    for (int k = 0; k < nbatch; k++) if (!batches[k]) { sq_set_error("bad argument"); return -1; }
     std::vector<int> rc(nbatch, 0);
     std::vector<std::string> msg(nbatch);
     // every stream less keeps the long kernels of one batch out of another batch's hardware queue (GPU_MAX_HW_QUEUES)

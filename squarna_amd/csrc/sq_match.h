@@ -25,6 +25,7 @@ size_t sq_nussinov_scratch_bytes(int n);
 size_t sq_mwm_scratch_bytes(int n, int nedges);
 
 #ifdef __HIPCC__
+void sq_max_dynamic_lds(const void *fn, int bytes);      // sq_host.hip: once per (kernel, device)
 int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatchJob *jobs, const SqMatchEdge *edges,
                        size_t nedges, SqMatchEdge *dev_edges, char *d_scr, int32_t *out, int32_t *cnt,
                        const uint8_t *codes, uint32_t *job_flags, uint32_t flag_val, hipStream_t st,

@@ -453,10 +453,7 @@ int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatch
     if (algo == 4) {                                     // SQ_ALGO_H
         // LDS: the row/column vectors and, when it fits, the cost matrix as 16-bit edge ids + the edge weights
         size_t lds = (size_t)maxn * 42 + 64 + 16 + (size_t)maxm * 8 + (size_t)maxn * maxn * 2 + 64;
-        if (lds > 64 * 1024) {
-            static bool attr_set = false;
-            if (!attr_set) { hipFuncSetAttribute((const void *)sq_lsap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-        }
+        if (lds > 64 * 1024) sq_max_dynamic_lds((const void *)sq_lsap_kernel, 150 * 1024);
         if (lds > 150 * 1024) lds = (size_t)maxn * 42 + 64 + 16 < 150 * 1024 ? (size_t)maxn * 42 + 64 + 16 : 150 * 1024;   // vectors only
         hipLaunchKernelGGL(sq_lsap_kernel, dim3(nj), dim3(64), lds, st, jobs, edges, d_scr, out, (int)lds);
     } else if (algo == 2) {                              // SQ_ALGO_N
@@ -465,8 +462,7 @@ int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatch
         // bins: see sq_mwm_plan.  The plan writes each job's LDS slice into the job table the kernel reads.
         int nbins = 0, waves = 1; size_t lds = 0; bool all_in_lds = true;
         sq_mwm_plan(h_jobs, jobs_rw, nj, bin_head, inflight, nbins, waves, lds, all_in_lds);
-        static bool attr_set = false;
-        if (!attr_set) { hipFuncSetAttribute((const void *)sq_mwm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr_set = true; }
+        sq_max_dynamic_lds((const void *)sq_mwm_kernel, 156 * 1024);
         if (!all_in_lds) {
             // some job keeps its adjacency in global memory and walks the edges in place: give the launch a device copy
             hipError_t e = hipMemcpyAsync(dev_edges, edges, nedges * sizeof(SqMatchEdge), hipMemcpyHostToDevice, st);
@@ -475,8 +471,7 @@ int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatch
         }
         if (waves == 1) {
             // one graph per block: blocks in table order, every block with the LDS of the launch's largest graph
-            static bool attr1 = false;
-            if (!attr1) { hipFuncSetAttribute((const void *)sq_mwm_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr1 = true; }
+            sq_max_dynamic_lds((const void *)sq_mwm_single_kernel, 156 * 1024);
             const size_t hdr = (sizeof(SqBlossom) + 15) & ~(size_t)15;
             const size_t one = lds > hdr ? lds - hdr : 0;
             hipLaunchKernelGGL(sq_mwm_single_kernel, dim3(nj), dim3(64), one, st, jobs, edges, d_scr, out, (int)one, job_flags, flag_val);

@@ -19,10 +19,11 @@ typedef std::pair<int, int> BP;
 static double py_round3(double x)
 {
     if (!std::isfinite(x)) return x;
-    // Fast path: k = round(1000 x) decides the decimal whenever 1000 x is not within 1e-6 of a tie (the product is off by
-    // at most half an ulp, far less for |x| < 1e9), and k / 1000.0 -- one correctly rounded division of two exact
-    // integers -- is the double nearest to that decimal, i.e. what strtod returns for its text.
-    if (std::fabs(x) < 1e9) {
+    // Fast path: k = round(1000 x) decides the decimal whenever 1000 x is not within 1e-6 of a tie -- the product is off by
+    // at most half an ulp of y = 1000 x, which is <= 6e-8 for |x| < 1e6 (|y| < 2^30: ulp 2^-23), well inside the guard;
+    // larger scores (giant sequences reach 1e6 .. 1e7) take the exact path -- and k / 1000.0 -- one correctly rounded
+    // division of two exact integers -- is the double nearest to that decimal, i.e. what strtod returns for its text.
+    if (std::fabs(x) < 1e6) {
         const double y = x * 1000.0, f = std::floor(y), frac = y - f;
         if (std::fabs(frac - 0.5) > 1e-6) return (frac > 0.5 ? f + 1.0 : f) / 1000.0;
     }

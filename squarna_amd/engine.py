@@ -11,6 +11,7 @@ import os
 import struct
 import contextlib
 
+import weakref
 import numpy as np
 
 from . import _lib
@@ -384,6 +385,7 @@ class Batch:
         toffl, deepl = toff.tolist(), deep.tolist()
         # headers, metrics, scores and masks of all records through numpy views (the records start 8-byte aligned)
         q = np.frombuffer(raw, '<i8', len(raw) // 8)
+        qu = np.frombuffer(raw, '<u8', len(raw) // 8)               # paramset masks: bit 63 may be set (64 paramsets)
         d = np.frombuffer(raw, '<f8', len(raw) // 8)
         b8 = (off[:-1] // 8).astype(np.int64)
         ns_a, n_a, ref_a = q[b8].tolist(), q[b8 + 1].tolist(), q[b8 + 2].tolist()
@@ -398,7 +400,7 @@ class Batch:
                 continue
             ns, n, sb = ns_a[k], n_a[k], b8l[k] + 20
             sc = d[sb:sb + 3 * ns].tolist()
-            mk = q[sb + 3 * ns:sb + 4 * ns].tolist()
+            mk = qu[sb + 3 * ns:sb + 4 * ns].tolist()
             t0 = toffl[k]                                          # the record's rows in text_all
             preds = [(text_all[t0 + (t + 1) * n:t0 + (t + 2) * n], tuple(sc[3 * t:3 * t + 3]),
                       list(_MASK_IDS[mk[t]]) if mk[t] < 16 else [b for b in range(64) if (mk[t] >> b) & 1]) for t in range(ns)]
@@ -674,9 +676,13 @@ class HipEngine:
         sm0 = records[0][5] if len(records[0]) > 5 else None
         if sm0 is not None and hasattr(sm0, "is_cuda") and sm0.is_cuda and all(len(r) > 5 and r[5] is sm0 for r in records):
             # alignment step 2 with the stem matrix still on the GPU: no per-record copies (Batch(mul_shared=...))
-            if getattr(self, "_sm_maxabs", (None, None))[0] is not sm0:
-                self._sm_maxabs = (sm0, float(sm0.abs().max().item()))
-            mul_shared = (sm0, [np.flatnonzero(~gap_mask(r[0])).astype(np.int32) for r in records], self._sm_maxabs[1])
+            # max |M| of the matrix, remembered through a WEAK reference: the engine is process-wide and must not keep an
+            # L x L device matrix (200 MB at L = 5000) alive after the alignment that owns it has ended
+            ref, val = getattr(self, "_sm_maxabs", (None, None))
+            if ref is None or ref() is not sm0:
+                val = float(sm0.abs().max().item())
+                self._sm_maxabs = (weakref.ref(sm0), val)
+            mul_shared = (sm0, [np.flatnonzero(~gap_mask(r[0])).astype(np.int32) for r in records], val)
         elif any(len(r) > 5 and r[5] is not None for r in records):
             mul = []
             for r, p in zip(records, prepared):
