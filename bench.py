@@ -233,6 +233,9 @@ def roofline_leg(nseq, n, pmc, pmc_note, seed=1000):
     wall = min(walls)
     avg_ms = ms / max(launches, 1)
     alg_gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    # 2 N^2 bytes per AnnotateStems evaluation and nothing else -- the library books them per LIVE structure
+    # (a launch also covers structures that are already final: those do not count)
+    assert abs(alg_bytes - evals * 2.0 * n * n) <= 1e-9 * max(alg_bytes, 1.0), (alg_bytes, evals, n)
     k = pmc.get("sq_scan6_kernel") or {}
     traffic = (k.get("fetch_bytes_per_launch", 0) + k.get("write_bytes_per_launch", 0)) if k else None
     achieved = traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms > 0 else None
@@ -250,23 +253,37 @@ def roofline_leg(nseq, n, pmc, pmc_note, seed=1000):
                          note="SURVEY 8d bytes (2 N^2 per AnnotateStems evaluation: the fp32 upper triangle the reference "
                               "re-scans) / launch time / 8 TB/s; > 1 means re-reads avoided, it is NOT a fraction of peak"),
         workload="S1000: %d random-ACGU seqs N=%d seed %d c=fastest pl=1" % (nseq, n, seed), evals_R=int(evals),
+        alg_bytes_equals_evals_R_x_2N2=True,
         whole_fold=dict(ms=round(wall * 1e3, 2), seq_per_s=round(nseq / wall, 1),
                         alg_GBs=round(alg_bytes / wall / 1e9, 1), frac_of_hbm_peak=round(alg_bytes / wall / 1e9 / HBM_PEAK_GBS, 3),
                         how="one sq_fold call, best of 5, profiling off; SURVEY 8d's bytes(N, R) = R 2N^2 over WALL time (the 4 N^2 "
                             "fp32 fill bytes are not counted: the fold writes N^2/8 bytes of bit matrix instead)"),
         kernel_ms=dict(bits=round(fms, 3), state=round(sms, 3), scan=round(ms, 3), score_select=round(cms, 3)))
     ks = pmc.get("sq_score_kernel") or {}
-    score = dict(kernel="sq_score_kernel", leg="S1000", bound="latency (dependent LDS / L2 loads of the per-candidate strand sweep)",
-                 share_of_leg_kernel_time=round(cms / max(fms + sms + ms + cms, 1e-9), 3),
-                 avg_launch_ms=round(cms / max(claunches, 1), 4), launches=int(claunches))
-    if ks:
-        tb = ks.get("fetch_bytes_per_launch", 0) + ks.get("write_bytes_per_launch", 0)
-        score.update(hbm=dict(traffic=tb, achieved_GBs=round(tb / (cms / max(claunches, 1) * 1e-3) / 1e9, 1),
-                              frac=round(tb / (cms / max(claunches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
-                     wave_cycles_waiting=ks.get("wait_share"), lds_bank_conflict_share=ks.get("lds_conflict_share"),
-                     lds_wave_insts_per_launch=ks.get("sq_insts_lds_per_launch"), issue=issue_share(ks, cms / max(claunches, 1)),
-                     pmc=ks.get("source"))
-    return scan, score
+    c_avg = cms / max(claunches, 1)
+    tb = (ks.get("fetch_bytes_per_launch", 0) + ks.get("write_bytes_per_launch", 0)) if ks else None
+    c_ach = tb / (c_avg * 1e-3) / 1e9 if tb and c_avg > 0 else None
+    score = dict(bound="hbm", kernel="sq_score_kernel", unit="GB/s", peak=HBM_PEAK_GBS,
+                 achieved=round(c_ach, 1) if c_ach else None, frac=round(c_ach / HBM_PEAK_GBS, 4) if c_ach else None,
+                 traffic=tb,
+                 how="SURVEY 8d gives this kernel no algorithmic bytes (per-candidate scoring traffic is lower order), so achieved = "
+                     "the HBM bytes it really moves per launch (rocprofv3 PMC: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, %s) / its "
+                     "launch time measured live (HIP events on the library's stream).  It is bound by the latency of the "
+                     "dependent LDS / L2 loads of the per-candidate strand sweep, far below the HBM roof" % (
+                         ks.get("source", pmc_note or "no PMC file")),
+                 leg="S1000", avg_launch_ms=round(c_avg, 4), launches=int(claunches),
+                 wave_cycles_waiting=ks.get("wait_share"), lds_bank_conflict_share=ks.get("lds_conflict_share"),
+                 lds_wave_insts_per_launch=ks.get("sq_insts_lds_per_launch"), issue=issue_share(ks, c_avg), pmc=ks.get("source"))
+    tot = max(fms + sms + ms + cms, 1e-9)
+    scan["share_of_leg_kernel_time"] = round(ms / tot, 3)
+    score["share_of_leg_kernel_time"] = round(cms / tot, 3)
+    # `roofline` = the leg's DOMINANT kernel; it carries the leg-level fields (per-kernel times, whole fold); the other
+    # object goes to `rooflines`
+    leg = {key: scan.pop(key) for key in ("workload", "evals_R", "alg_bytes_equals_evals_R_x_2N2", "whole_fold", "kernel_ms")}
+    first, second = (score, scan) if cms >= ms else (scan, score)
+    first.update(leg)
+    first["dominant_of"] = "S1000 leg: %.0f %% of its kernel time" % (100.0 * max(cms, ms) / tot)
+    return first, second
 
 
 N_SIMD = 1024              # 256 CUs x 4 SIMDs
@@ -335,6 +352,67 @@ def predict_leg(config, reps=5):
                 ms_per_call=round(ts[len(ts) // 2], 2), seq_per_s=round(219 / ts[len(ts) // 2] * 1e3, 1), text_chars=chars)
 
 
+# ---------------------------------------------------------------- streaming: new inputs every step, set-up and read-out timed
+def stream_leg(config, K, R, steps, warmup, device):
+    """The headline workload as a stream of NEW requests: every step builds K batches of 219 x R records it has not seen
+    in the previous step (a window sliding over SRtest150 + SRtrain150: 485 records), and the timed region covers
+    Batch() -- host arrays + sq_batch_create, i.e. the upload of the inputs --, the fold of the K batches in flight and
+    sq_result_pack_all of every batch.  Record parsing / ProcessReacts (Prepared) is done once, outside.
+    Returns (stream dict, one_pass dict): one_pass is K = 1, R = 1 -- one pass over 219 records, create + fold + pack."""
+    import torch
+    from squarna_amd.config import ParseConfig, builtin_config
+    from squarna_amd.engine import Batch, Prepared, fold_concurrently
+    from squarna_amd.inputs import ParseDefaultInput
+    names, psets = ParseConfig(builtin_config(config))
+    recs = load_srtest150()
+    recs += list(ParseDefaultInput(os.path.join(ROOT, "squarna_amd", "data", "datasets", "SRtrain150.fas"), "qf"))
+    allp = [Prepared(seq, reacts, restr, ref) for _, seq, reacts, restr, ref in recs]
+    streams = [torch.cuda.Stream(device) for _ in range(K)]
+
+    def one_step(t, k, r):
+        batches = []
+        try:
+            for q in range(k):
+                start = ((t * k + q) * 97) % len(allp)
+                sel = [allp[(start + i) % len(allp)] for i in range(219 * r)]
+                with torch.cuda.stream(streams[q]):
+                    batches.append(Batch(sel, [psets] * len(sel), fp32=False, max_structs=4096 * r))
+            if k == 1:
+                batches[0].fold(poollim=1000)
+            else:
+                fold_concurrently(batches, poollim=1000)
+            return sum(int(b.pack_all()[1][-1]) for b in batches)
+        finally:
+            for b in batches:
+                b.close()
+
+    def timed(k, r, nsteps, nwarm):
+        for t in range(nwarm):
+            one_step(t, k, r)
+        torch.cuda.synchronize()
+        per, packed = [], 0
+        t00 = time.perf_counter()
+        for t in range(nsteps):
+            t0 = time.perf_counter()
+            packed = one_step(nwarm + t, k, r)
+            per.append((time.perf_counter() - t0) * 1e3)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t00, sorted(per), packed
+
+    dt, per, packed = timed(K, R, steps, warmup)
+    stream = dict(what="SRtest150 + SRtrain150 (485 records) as a stream: every step takes the next windows of 219 x %d records for "
+                       "%d batches; timed per step: Batch() (host arrays + sq_batch_create = upload) + fold of the batches in flight "
+                       "+ sq_result_pack_all; c=%s poollim=1000" % (R, K, config),
+                  seq_per_s=round(219 * R * K * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3),
+                  median_ms_per_step=round(per[len(per) // 2], 3), steps=steps, packed_bytes_per_step=packed)
+    dt1, per1, packed1 = timed(1, 1, 10, 3)
+    one = dict(what="ONE pass over 219 records (a different window every call): Batch() + sq_fold + sq_result_pack_all, nothing "
+                    "else in flight, median of 10",
+               ms=round(per1[len(per1) // 2], 3), best_ms=round(per1[0], 3),
+               seq_per_s=round(219 / per1[len(per1) // 2] * 1e3, 1), packed_bytes=packed1)
+    return stream, one
+
+
 # ---------------------------------------------------------------- strong scaling: a synthetic workload sharded over the ranks
 SUB_BATCHES = {"S300": 4, "S1000": 2, "S2000": 4}     # concurrent batches per rank that measured best at world size 1
 
@@ -348,7 +426,7 @@ def sharded_leg(workload, steps, warmup, rank, world, device, sub_batches=0):
     import torch.distributed as dist
     from squarna_amd.config import ParseConfig, builtin_config
     from squarna_amd.engine import Batch
-    from squarna_amd.parallel import lpt_partition
+    from squarna_amd.parallel import lpt_partition, gather_bytes
     names, psets = ParseConfig(builtin_config("fastest"))
     items = synthetic(workload)
     parts = lpt_partition([float(len(s)) ** 2 for s, _ in items], world)
@@ -387,15 +465,9 @@ def sharded_leg(workload, steps, warmup, rank, world, device, sub_batches=0):
             return [(buf, off)]
         head = np.concatenate([np.array([len(mine)], np.int64), np.array(mine, np.int64), off]).view(np.uint8)
         body = np.concatenate([head, buf])
-        size = torch.tensor([body.size], dtype=torch.int64, device=device)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-        dist.all_gather(sizes, size)
-        cap = int(max(int(s.item()) for s in sizes))
-        send = torch.zeros(cap, dtype=torch.uint8, device=device)
-        send[:body.size] = torch.from_numpy(body).to(device)
-        got = [torch.zeros(cap, dtype=torch.uint8, device=device) for _ in range(world)]
-        dist.all_gather(got, send)
-        return (got, sizes)
+        # the product's own result gather (squarna_amd.parallel.gather_bytes, also the end of PredictSharded): exact
+        # sizes, to rank 0 only
+        return gather_bytes(body, 0, device)
 
     def fence():
         torch.cuda.synchronize()
@@ -412,18 +484,20 @@ def sharded_leg(workload, steps, warmup, rank, world, device, sub_batches=0):
     for _ in range(steps):
         last = step()
     fence()
-    dt = time.perf_counter() - t0
+    dt_mine = dt = time.perf_counter() - t0
+    per_rank_ms = [round(dt / steps * 1e3, 3)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        every = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_ms = [round(float(x.item()) / steps * 1e3, 3) for x in every]
+        dt = max(float(x.item()) for x in every)
     # verification on rank 0: every record arrived once, and a sample of other ranks' records equals a local fold
     ok, checked = True, 0
     if rank == 0 and world > 1:
-        got, sizes = last
         seen = {}
         for r in range(world):
-            raw = got[r][:int(sizes[r].item())].cpu().numpy()
+            raw = np.ascontiguousarray(last[r])
             cnt = int(raw[:8].view(np.int64)[0])
             idx = raw[8:8 + 8 * cnt].view(np.int64)
             off = raw[8 + 8 * cnt:8 + 8 * cnt + 8 * (cnt + 1)].view(np.int64)
@@ -446,9 +520,10 @@ def sharded_leg(workload, steps, warmup, rank, world, device, sub_batches=0):
     if rank != 0:
         return None
     return dict(workload="%s: %d seqs, c=fastest pl=1 (greedy rounds chained on the device), sharded by lpt_partition (N^2) over "
-                         "%d rank(s); step = fold of the resident shard (as %d concurrent batches) + sq_result_pack_all + one "
-                         "all_gather of the packed results (RCCL)" % (workload, len(items), world, nb),
+                         "%d rank(s); step = fold of the resident shard (as %d concurrent batches) + sq_result_pack_all + the "
+                         "result gather to rank 0 (parallel.gather_bytes: exact sizes, RCCL send / recv)" % (workload, len(items), world, nb),
                 seq_per_s=round(len(items) * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+                n_ranks_seen=world if world == 1 else dist.get_world_size(), ms_per_step_by_rank=per_rank_ms,
                 records_rank0=len(mine), evals_R_rank0=int(evals),
                 gathered_records_complete=bool(ok), records_checked_against_local_fold=checked)
 
@@ -467,7 +542,9 @@ def main():
     ap.add_argument("--workload", default="srtest150", choices=["srtest150", "S300", "S1000", "S2000"])
     ap.add_argument("--sub-batches", type=int, default=0,
                     help="strong-scaling mode: concurrent batches per rank (0 = the workload's measured best: %s)" % SUB_BATCHES)
+    ap.add_argument("--regions", type=int, default=3, help="timed regions of `steps` steps each; the median one is reported")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-stream", action="store_true", help="skip the stream / one_pass legs")
     ap.add_argument("--no-roofline", action="store_true", help="skip the S1000 roofline leg")
     ap.add_argument("--roofline-seqs", type=int, default=1024)    # S1000 = 1,024 sequences
     args = ap.parse_args()
@@ -536,17 +613,24 @@ def main():
         torch.cuda.synchronize()
 
     run(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    cpu0 = time.process_time()
-    run(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    host_cpu = time.process_time() - cpu0                     # CPU time of this rank's process (all its threads)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # Three timed regions of exactly `steps` steps each, every one bracketed by barrier + synchronize and reduced with MAX
+    # over the ranks; the line reports the MEDIAN region (the folds are chains of short kernels: host jitter shows).
+    regions = []
+    for _ in range(max(1, args.regions)):
+        fence()
+        t0 = time.perf_counter()
+        cpu0 = time.process_time()
+        run(args.steps)
+        fence()
+        dt = time.perf_counter() - t0
+        host_cpu = time.process_time() - cpu0                 # CPU time of this rank's process (all its threads)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        regions.append((dt, host_cpu))
+    region_ms = [round(r[0] / args.steps * 1e3, 3) for r in regions]
+    dt, host_cpu = sorted(regions)[len(regions) // 2]
 
     # ---- secondary, OUTSIDE the timed region ----------------------------------------------------------------------
     results = [batches[0].result(k) for k in range(nset)]
@@ -609,8 +693,8 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        roof, score_obj = roofline_leg(args.roofline_seqs, 1000, pmc, pmc_note)
-        rooflines.append(score_obj)
+        roof, other_obj = roofline_leg(args.roofline_seqs, 1000, pmc, pmc_note)   # the leg's dominant kernel first
+        rooflines.append(other_obj)
         try:
             rooflines.append(fill_leg(pmc=pmc))
         except Exception as e:                                # (a secondary leg never takes the headline down)
@@ -623,12 +707,26 @@ def main():
         except Exception as e:                                # (a secondary leg never takes the headline down)
             end_to_end = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    stream = one_pass = None
+    if rank == 0 and world == 1 and not args.no_stream:
+        try:
+            stream, one_pass = stream_leg(args.config, K, R, max(5, args.steps // 2), 2, device)
+            if cpu and one_pass:
+                one_pass["vs_cpu_baseline"] = round(one_pass["seq_per_s"] / cpu["value"], 1)
+                stream["vs_cpu_baseline"] = round(stream["seq_per_s"] / cpu["value"], 1)
+        except Exception as e:                                # (a secondary leg never takes the headline down)
+            stream = {"error": "%s: %s" % (type(e).__name__, e)}
+
     sharded = None
     if world > 1:
-        try:
-            sharded = sharded_leg("S300", 5, 2, rank, world, device)
-        except Exception as e:                                # (never let the secondary leg take the headline down)
-            sharded = {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
+        # strong scaling next to the weak-scaling value: the three SURVEY 8d workloads sharded over the ranks (short legs)
+        sharded = {}
+        for wl, st_, wu_ in (("S300", 5, 2), ("S1000", 5, 2), ("S2000", 3, 1)):
+            try:
+                sharded[wl] = sharded_leg(wl, st_, wu_, rank, world, device)
+            except Exception as e:                            # (never let a secondary leg take the headline down)
+                sharded[wl] = {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
+        nranks_seen = dist.get_world_size()
         try:
             dist.barrier()
             dist.destroy_process_group()
@@ -645,6 +743,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "timed_regions_ms_per_step": region_ms,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -673,8 +772,15 @@ def main():
         "rooflines": rooflines,
         "pmc_note": pmc_note,
         "cpu_baseline": cpu,
+        "vs_cpu_baseline": {"value": round(per_step * world * args.steps / dt / cpu["value"], 1),
+                            "single_batch": round(len(prepared) / lat[len(lat) // 2] * 1e3 / cpu["value"], 1),
+                            "note": "ratios to cpu_baseline.value (the C-port oracle on this host's %d CPUs; the reference's own "
+                                    "Python form is ~11 x slower per core, DESIGN.md section 5)" % cpu["cores"]} if cpu else None,
+        "one_pass": one_pass,
+        "stream": stream,
         "end_to_end": end_to_end,
         "sharded": sharded,
+        "n_ranks_seen": world if world == 1 else nranks_seen,
     }
     print(json.dumps(line))
 

@@ -28,8 +28,13 @@ static double cell_score_host(const sq_batch *b, const SqJob &J, int i, int j, c
     const double w = ps.bpweight[codes[i] * 32 + codes[j]];
     double rf = 1.0;
     if (!J.default_reacts) {
-        const double *r = b->reacts.data() + J.pos_off;
-        rf = sqrt((1.0 - (r[i] + r[j]) / 2.0) * 2.0);
+        if (J.rf_idx >= 0) {                               // the host-libm table the device reads (sq_reactfactor)
+            const uint8_t *lv = b->ridx.data() + J.pos_off;
+            rf = b->rftab[(size_t)J.rf_idx * 256 + lv[i] * 16 + lv[j]];
+        } else {
+            const double *r = b->reacts.data() + J.pos_off;
+            rf = sqrt((1.0 - (r[i] + r[j]) / 2.0) * 2.0);
+        }
     }
     if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
     return w * rf;

@@ -114,6 +114,8 @@ struct sq_batch {
     std::vector<int32_t> seq_off, rbp_off, rbps, job_seq, job_pset;
     std::vector<uint8_t> codes, flags;
     std::vector<double> reacts;
+    std::vector<double> rftab;                // host-libm reactfactor tables, 256 doubles each (SqJob::rf_idx)
+    std::vector<uint8_t> ridx;                // per position: reactivity level index (SqDevCtx::ridx)
     std::vector<sq_paramset> psets;
     std::vector<char> pset_dyadic;            // all pair weights are multiples of 2^-10 below 1024 (exact sums in any order)
     std::vector<int> pset_classes;            // letter classes of the scoring kernel's cell table: pairing letters + 1

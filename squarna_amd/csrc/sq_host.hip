@@ -259,7 +259,8 @@ static inline bool want_fp32(const sq_batch_desc *d)
 
 namespace {
 struct Layout {
-    size_t off_codes, off_flags, off_inc4, off_chain, off_e0, off_reacts, off_ridx, off_jobs, off_psets, off_sdf;
+    size_t off_codes, off_flags, off_inc4, off_chain, off_e0, off_reacts, off_ridx, off_jobs, off_psets, off_sdf, off_rftab;
+    int64_t n_rftab;
     size_t off_mat32, off_mat64, off_structs, off_strands, off_state, off_cnt, off_ctr, off_cands, off_out;
     size_t off_bits, off_rbpk, off_fb;
     size_t off_crec, off_cstems, off_cstrands, off_csidx, off_cnfin;   // device-chained rounds (sq_chain.hip)
@@ -326,6 +327,12 @@ int plan(const sq_batch_desc *d, Layout &L)
     L.off_chain = take(L.ltot * 2); L.off_e0 = take(L.ltot * 2); L.off_reacts = take(L.ltot * 8); L.off_ridx = take(L.ltot);
     L.off_jobs = take(sizeof(SqJob) * d->njobs); L.off_psets = take(sizeof(SqPsetDev) * d->npset);
     L.off_sdf = take(8 * (size_t)std::max<int64_t>(L.sdf_len, 1));
+    // one 16 x 16 reactfactor table per sequence whose reactivities are not all 0.5 (sq_batch_create fills the ones
+    // whose reactivities take <= 16 values)
+    L.n_rftab = 0;
+    for (int s = 0; s < d->nseq; s++)
+        for (int i = d->seq_off[s]; i < d->seq_off[s + 1]; i++) if (d->reacts[i] != 0.5) { L.n_rftab++; break; }
+    L.off_rftab = take(8 * 256 * (size_t)std::max<int64_t>(L.n_rftab, 1));
     L.off_mat32 = take(4 * (size_t)L.mat32_floats);
     L.off_mat64 = take(8 * (size_t)std::max<int64_t>(L.mat64_doubles, 1));
     L.off_structs = take(sizeof(SqStruct) * L.max_structs);
@@ -502,7 +509,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     // reactivity levels: encoded reactivities (3 / 10 / 26 symbols) take few distinct values per sequence; with <= 16
     // of them the reactfactor of a cell is a table lookup instead of an fp64 sqrt (and division) per cell and round
     std::vector<uint8_t> ridx(L.ltot, 0);
-    std::vector<int32_t> seq_levels(d->nseq, 0);
+    std::vector<int32_t> seq_levels(d->nseq, 0), seq_rf(d->nseq, -1);
+    std::vector<double> rftab;
     for (int s = 0; s < d->nseq; s++) {
         const int off = d->seq_off[s], n = d->seq_off[s + 1] - off;
         double vals[16]; int nv = 0; bool fits = true;
@@ -514,6 +522,18 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
             ridx[off + i] = (uint8_t)q;
         }
         seq_levels[s] = fits ? nv : 0;
+        // (1 - (r_a + r_b) / 2) * 2) ** 0.5 for every pair of the sequence's levels through the host's libm pow, which is
+        // what CPython's `**` calls (SQRNdbnseq.py:333): the device reads these instead of taking a sqrt
+        bool def = true;
+        for (int i = 0; i < n; i++) if (d->reacts[off + i] != 0.5) { def = false; break; }
+        seq_rf[s] = -1;
+        if (!def && fits && nv > 0 && (int64_t)(rftab.size() / 256) < L.n_rftab) {
+            seq_rf[s] = (int32_t)(rftab.size() / 256);
+            rftab.resize(rftab.size() + 256, 0.0);
+            double *T = rftab.data() + (size_t)seq_rf[s] * 256;
+            for (int a = 0; a < nv; a++)
+                for (int c2 = 0; c2 < nv; c2++) T[a * 16 + c2] = pow((1.0 - (vals[a] + vals[c2]) / 2.0) * 2.0, 0.5);
+        }
     }
     // ---- jobs ----
     b->jobs.resize(d->njobs);
@@ -547,6 +567,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         for (int i = 0; i < J.n; i++) if (d->reacts[J.pos_off + i] != 0.5) { def = false; break; }
         J.default_reacts = def ? 1 : 0;
         J.react_levels = def ? 0 : seq_levels[s];
+        J.rf_idx = def ? -1 : seq_rf[s]; J.pad_rf = 0;
         J.interchainonly = d->interchainonly;
         {
             const double ml = std::max(1.0, std::ceil(d->psets[J.pset].minlen));
@@ -590,7 +611,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->ctx.inc4 = (uint8_t *)(base + L.off_inc4); b->ctx.chain = (int16_t *)(base + L.off_chain);
     b->ctx.e0c = (uint8_t *)(base + L.off_e0); b->ctx.reacts = (double *)(base + L.off_reacts); b->ctx.ridx = (uint8_t *)(base + L.off_ridx);
     b->ctx.jobs = (SqJob *)(base + L.off_jobs); b->ctx.psets = (SqPsetDev *)(base + L.off_psets);
-    b->ctx.sdftab = (double *)(base + L.off_sdf);
+    b->ctx.sdftab = (double *)(base + L.off_sdf); b->ctx.rftab = (double *)(base + L.off_rftab);
     b->ctx.mat32 = (float *)(base + L.off_mat32); b->ctx.mat64 = (double *)(base + L.off_mat64);
     b->d_structs = (SqStruct *)(base + L.off_structs); b->d_strands = (SqStrand *)(base + L.off_strands);
     int16_t *stbase = (int16_t *)(base + L.off_state);
@@ -649,7 +670,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     } stager;
     stager.st = st;
     {
-        size_t want = (size_t)L.ltot * 16 + sizeof(SqJob) * d->njobs + sizeof(SqPsetDev) * d->npset + 8 * sdf.size() + 4 * rbpk.size() + 16384;
+        size_t want = (size_t)L.ltot * 16 + 8 * rftab.size() + sizeof(SqJob) * d->njobs + sizeof(SqPsetDev) * d->npset + 8 * sdf.size() + 4 * rbpk.size() + 16384;
         for (int j = 0; j < d->njobs; j++)
             if (b->jobs[j].has_ext && !(d->mul_shared && d->mul_shared[j])) want += (size_t)b->jobs[j].n * b->jobs[j].n * 8 * (b->jobs[j].has_ext == 1 ? 2 : 1);
         stager.cap = std::min<size_t>(std::max<size_t>(want, (size_t)1 << 20), (size_t)64 << 20) & ~(size_t)255;
@@ -662,9 +683,12 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     UP(b->ctx.inc4, inc4.data(), L.ltot); UP(b->ctx.chain, chain.data(), L.ltot * 2);
     UP(b->ctx.e0c, e0.data(), L.ltot); UP(b->ctx.reacts, b->reacts.data(), L.ltot * 8);
     UP(b->ctx.ridx, ridx.data(), L.ltot);
+    b->ridx = ridx;
     UP(b->ctx.jobs, b->jobs.data(), sizeof(SqJob) * d->njobs);
     UP(b->ctx.psets, pd.data(), sizeof(SqPsetDev) * d->npset);
     if (!sdf.empty()) UP(b->ctx.sdftab, sdf.data(), 8 * sdf.size());
+    if (!rftab.empty()) UP(b->ctx.rftab, rftab.data(), 8 * rftab.size());
+    b->rftab.swap(rftab);                                      // (host copy: RunAlgo's stem filters re-sum cells, sq_algos.hip)
     if (!rbpk.empty()) UP(b->ctx.rbpk, rbpk.data(), 4 * rbpk.size());
     for (int j = 0; j < d->njobs; j++) {
         const SqJob &J = b->jobs[j];
@@ -1676,7 +1700,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         size_t next_job = 0;
         while (next_job < greedy_jobs.size() && !stats.rc) {
         std::vector<int> jobs;                              // structure index -> job
-        int maxn = 0, maxt = 0; int64_t cand_off = 0, maxcap = 0; double scan_bytes = 0; bool need_reacts = false;
+        int maxn = 0, maxt = 0; int64_t cand_off = 0, maxcap = 0; bool need_reacts = false;
         for (; next_job < greedy_jobs.size(); next_job++) {
             const int j = greedy_jobs[next_job];
             JobPool &P = pools[j];
@@ -1693,7 +1717,6 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             d.strand_off = 4 * cr.toff; d.nstrand = 0;
             maxn = std::max(maxn, J.n); maxt = std::max(maxt, cr.tcap);
             need_reacts |= !J.default_reacts && !(J.react_levels > 0 && b->pset_classes[J.pset] * J.react_levels <= 32);
-            scan_bytes += 2.0 * J.n * J.n;
             jobs.push_back(j);
         }
         tq.push(finished);
@@ -1721,7 +1744,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         while (nfin_seen < nfin_goal) {
             while (launched - done < depth) {               // rounds enqueued ahead of the device
                 if ((int)launched > maxt + 2) { fail(2, "chained rounds do not terminate"); break; }
-                launch_round_kernels(b, st, S, maxn, maxcap, need_reacts, scan_bytes, 0, io, scan, ln.d_structs, b->chain.strands, true);
+                // (algorithmic bytes: NOT per launch -- a launch also covers the structures that are already final; they are
+                // booked below from the evaluations the list of finished structures records)
+                launch_round_kernels(b, st, S, maxn, maxcap, need_reacts, 0.0, 0, io, scan, ln.d_structs, b->chain.strands, true);
                 const uint32_t seq = ++*ln.round_seq;
                 hipLaunchKernelGGL(sq_chain_done_kernel, dim3(1), dim3(1), 0, st, io, scan, b->chain, seq);
                 launched++;
@@ -1758,6 +1783,18 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         // rounds still in flight find no live structure; they must be through before the buffers are used again
         hipStreamSynchronize(st);
         stats.tround += now_s() - tr0;
+        if (b->prof_on && !stats.rc) {
+            // 2 N^2 bytes per AnnotateStems evaluation = per round a structure was LIVE in (its stems + the
+            // round that found none); exactly what sq_result_evals reports
+            double bytes = 0;
+            for (uint32_t q = nfin_goal - (uint32_t)S; q < nfin_goal; q++) {
+                const unsigned long long e = b->chain.h_fin[q];
+                const double n = b->jobs[(int)(uint32_t)e].n;
+                const double ev = (double)((e >> 32) & 0x7FFFFFFFu) + ((e >> 63) ? 0.0 : 1.0);
+                bytes += ev * 2.0 * n * n;
+            }
+            b->prof[2].bytes += bytes;
+        }
         }
 #undef CHK
     };
@@ -1933,6 +1970,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             else for (int sx = 0; sx < S0; sx++) one_job(sx);
         }
         for (int sx = 0; sx < S0; sx++) pools[jobs[sx]].evals += pio.h_jobs[sx].evals;
+        if (b->prof_on)                                      // 2 N^2 bytes per evaluation (live structures only)
+            for (int sx = 0; sx < S0; sx++) { const double n = b->jobs[jobs[sx]].n; b->prof[2].bytes += (double)pio.h_jobs[sx].evals * 2.0 * n * n; }
         return 0;
     };
     mark("loop start");

@@ -27,6 +27,10 @@ struct SqJob {
     int32_t ext_add;    // has_ext == 2: the dense term is ADDED to the score (bpp < 0) instead of multiplied
     int32_t react_levels;  // 1..16: the reactivities take that many distinct values (level index per position in
                            // SqDevCtx::ridx): reactfactors come from a level x level table; 0: computed per cell
+    int32_t rf_idx;        // >= 0 (react_levels > 0, reactivities not all 0.5): table rf_idx of SqDevCtx::rftab holds the
+                           // sequence's 16 x 16 reactfactors ((1 - (r_a + r_b) / 2) * 2) ** 0.5 evaluated by the HOST's libm
+                           // pow, as CPython does (SQRNdbnseq.py:333) -- sqrt differs from it in the last bit now and then
+    int32_t pad_rf;
 };
 
 // Device image of a paramset (+ host-built pow tables so every pow() is the host libm's).

@@ -36,14 +36,27 @@ __device__ __forceinline__ bool sq_cell_bool(const SqDevCtx &c, const SqJob &jb,
     return true;
 }
 
+// reactfactor ((1 - (r_i + r_j) / 2) * 2) ** 0.5 of a cell (:333).  Sequences whose reactivities take <= 16 distinct values
+// (every encoded input does) read it from the table the host built with its libm pow -- CPython's `**` -- so those
+// factors are the reference's bit for bit; arbitrary float reactivities take IEEE sqrt, which differs from pow(x, 0.5)
+// by one ulp for ~0.08 % of x.
+__device__ __forceinline__ double sq_reactfactor(const SqDevCtx &c, const SqJob &jb, int i, int j)
+{
+    if (jb.rf_idx >= 0) {
+        const uint8_t *lv = c.ridx + jb.pos_off;
+        return c.rftab[(int64_t)jb.rf_idx * 256 + lv[i] * 16 + lv[j]];
+    }
+    const double *r = c.reacts + jb.pos_off;
+    return sqrt((1.0 - (r[i] + r[j]) / 2.0) * 2.0);
+}
+
 // value of scoremat[i,j] for a cell whose bool is 1 (:329-338)
 __device__ __forceinline__ double sq_cell_score(const SqDevCtx &c, const SqJob &jb, const SqPsetDev *ps, int i, int j)
 {
     const uint8_t *codes = c.codes + jb.pos_off;
     const double w = ps->w[codes[i] * 32 + codes[j]];
     if (jb.default_reacts) return w;                                  // reactfactor 1 (and 1/1 for w <= 0): w * 1.0
-    const double *r = c.reacts + jb.pos_off;
-    double rf = sqrt((1.0 - (r[i] + r[j]) / 2.0) * 2.0);              // x**0.5 (see DESIGN.md on pow vs sqrt)
+    double rf = sq_reactfactor(c, jb, i, j);
     if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);                   // :335-336
     return w * rf;
 }
@@ -138,7 +151,8 @@ extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c, int
                         if (ok && ico) ok = l_chain[ii] != l_chain[jj];                              // :301
                         if (ok && !defr && bits != SQ_SENT_BITS) {
                             const double w = s_w[ci * 33 + cj];                                      // same expressions as sq_cell_score
-                            double rf = sqrt((1.0 - (l_react[ii] + l_react[jj]) / 2.0) * 2.0);
+                            double rf = jb.rf_idx >= 0 ? sq_reactfactor(c, jb, ii, jj)
+                                                       : sqrt((1.0 - (l_react[ii] + l_react[jj]) / 2.0) * 2.0);
                             if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
                             bits = __float_as_uint((float)(w * rf));
                             if (bits == SQ_SENT_BITS) bits = 0x7FC00001u;   // a genuine NaN value stays "present"
@@ -858,7 +872,9 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
             const double w = (la >= 0 && lb >= 0) ? ps->w[la * 32 + lb] : 0.0;
             double v = w;                                                   // default reactivities: w * 1 (and 1/1)
             if (react_tab) {
-                double rf = sqrt((1.0 - (s_rv[ci - ca * R] + s_rv[cj - cb * R]) / 2.0) * 2.0);
+                // (react_tab implies react_levels > 0, i.e. the host built the sequence's pow table)
+                double rf = jb.rf_idx >= 0 ? c.rftab[(int64_t)jb.rf_idx * 256 + (ci - ca * R) * 16 + (cj - cb * R)]
+                                           : sqrt((1.0 - (s_rv[ci - ca * R] + s_rv[cj - cb * R]) / 2.0) * 2.0);
                 if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
                 v = w * rf;
             }
@@ -876,9 +892,13 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
         if (!lds_cells) return sq_cell_exact(c, jb, ps, i, j);
         const double w = s_cell[l_ci[i] * cstride + l_ci[j]];             // cell_tab: the cell itself
         if (cell_tab) return w;
-        const double ri = lds_reacts ? l_reacts[i] : c.reacts[jb.pos_off + i];   // same expression as sq_cell_score
-        const double rj = lds_reacts ? l_reacts[j] : c.reacts[jb.pos_off + j];
-        double rf = sqrt((1.0 - (ri + rj) / 2.0) * 2.0);
+        double rf;
+        if (jb.rf_idx >= 0) rf = sq_reactfactor(c, jb, i, j);                  // (levels that do not fit the cell table)
+        else {
+            const double ri = lds_reacts ? l_reacts[i] : c.reacts[jb.pos_off + i];   // same expression as sq_cell_score
+            const double rj = lds_reacts ? l_reacts[j] : c.reacts[jb.pos_off + j];
+            rf = sqrt((1.0 - (ri + rj) / 2.0) * 2.0);
+        }
         if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
         return w * rf;
     };

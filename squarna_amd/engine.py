@@ -412,39 +412,7 @@ class Batch:
         return out
 
     def _unpack(self, k, buf, base):
-        ns, n, has_ref, evals = _HDR.unpack_from(buf, base)
-        met = _MET.unpack_from(buf, base + 32)
-        o = base + 160
-        scores = struct.unpack_from("<%dd" % (3 * ns), buf, o); o += 24 * ns
-        masks = struct.unpack_from("<%dQ" % ns, buf, o); o += 8 * ns
-        p = self.prepared[k]
-        seq = p.seq
-        if True:
-            lev = np.frombuffer(buf, np.int16, (ns + 1) * n, o).reshape(ns + 1, n)
-            # levels -> bracket characters for all rows at once (code-point table), gap columns and separators
-            # re-inserted with array assignments (SQRNdbnseq.py:1239-1246)
-            cp = _LEVEL_CP[np.clip(lev, -_NBR - 1, _NBR + 1) + (_NBR + 1)]                     # (ns+1, n) uint32
-            if p.gapidx or p.sepidx:
-                full = np.full((ns + 1, len(seq)), ord('.'), np.uint32)
-                keep = np.ones(len(seq), bool)
-                keep[p.gapidx] = False
-                full[:, keep] = cp
-                for i in p.sepidx:
-                    full[:, i] = ord(seq[i])
-                cp = full
-            width = cp.shape[1]
-            text = cp.tobytes().decode('utf-32-le')
-        cons = text[:width]
-        preds = []
-        for t in range(ns):
-            m = masks[t]
-            preds.append((text[(t + 1) * width:(t + 2) * width], scores[3 * t:3 * t + 3],
-                          list(_MASK_IDS[m]) if m < 16 else [q for q in range(64) if (m >> q) & 1]))
-        if has_ref:
-            consres = _metrics(met[:6])
-            res = _metrics(met[6:12]) + [int(met[12])]
-            return (cons, preds, consres, res), tuple(met[13:16])
-        return (cons, preds, [np.nan] * 6, [np.nan] * 7), None
+        return unpack_result(self.prepared[k], buf, base)
 
     def pack_all(self):
         """(uint8 array, int64 offsets[nseq + 1]): the packed results of every record (sq_result_pack_all) -- the
@@ -480,6 +448,44 @@ class Batch:
         ms, n, by = C.c_double(), C.c_int64(), C.c_double()
         _lib.check(self.L.sq_profile_get(self.h, kernel, C.byref(ms), C.byref(n), C.byref(by)))
         return ms.value, n.value, by.value
+
+
+def unpack_result(p, buf, base=0):
+    """(SQRNdbnseq return tuple, reference scores or None) of ONE packed result record (sq_result_pack layout, see
+    include/squarna_hip.h) of the prepared record `p`: any rank can decode a record another rank folded."""
+    ns, n, has_ref, evals = _HDR.unpack_from(buf, base)
+    met = _MET.unpack_from(buf, base + 32)
+    o = base + 160
+    scores = struct.unpack_from("<%dd" % (3 * ns), buf, o); o += 24 * ns
+    masks = struct.unpack_from("<%dQ" % ns, buf, o); o += 8 * ns
+    seq = p.seq
+    if True:
+        lev = np.frombuffer(buf, np.int16, (ns + 1) * n, o).reshape(ns + 1, n)
+        # levels -> bracket characters for all rows at once (code-point table), gap columns and separators
+        # re-inserted with array assignments (SQRNdbnseq.py:1239-1246)
+        cp = _LEVEL_CP[np.clip(lev, -_NBR - 1, _NBR + 1) + (_NBR + 1)]                     # (ns+1, n) uint32
+        if p.gapidx or p.sepidx:
+            full = np.full((ns + 1, len(seq)), ord('.'), np.uint32)
+            keep = np.ones(len(seq), bool)
+            keep[p.gapidx] = False
+            full[:, keep] = cp
+            for i in p.sepidx:
+                full[:, i] = ord(seq[i])
+            cp = full
+        width = cp.shape[1]
+        text = cp.tobytes().decode('utf-32-le')
+    cons = text[:width]
+    preds = []
+    for t in range(ns):
+        m = masks[t]
+        preds.append((text[(t + 1) * width:(t + 2) * width], scores[3 * t:3 * t + 3],
+                      list(_MASK_IDS[m]) if m < 16 else [q for q in range(64) if (m >> q) & 1]))
+    if has_ref:
+        consres = _metrics(met[:6])
+        res = _metrics(met[6:12]) + [int(met[12])]
+        return (cons, preds, consres, res), tuple(met[13:16])
+    return (cons, preds, [np.nan] * 6, [np.nan] * 7), None
+
 
 
 def _metrics(m):
@@ -611,6 +617,11 @@ class HipEngine:
             if was:
                 gc.enable()
 
+    def fold_records_packed(self, records, **opts):
+        """Like fold_records, but every record's result stays in the library's packed form (bytes, sq_result_pack layout):
+        the payload ranks exchange (parallel.py).  `unpack_result(Prepared(...), blob)` decodes one on any rank."""
+        return self.fold_records(records, _packed=True, **opts)
+
     def _fold_records(self, records, **opts):
         """`keep`: only the first `keep` structures of every record are fetched (Predict prints outplim of them)."""
         poollim = opts.get("poollim", 1000)
@@ -665,6 +676,7 @@ class HipEngine:
     def _make_batch(self, records, slots_hint, opts):
         """(Batch, fold options) for these records.  opts: fold_records' keyword arguments (not modified)."""
         opts = dict(opts)
+        opts.pop("_packed", None)
         interchainonly = opts.pop("interchainonly", False)
         keep = opts.pop("keep", None)
         M, B = opts.pop("M", 1.8), opts.pop("B", -0.6)
@@ -738,7 +750,13 @@ class HipEngine:
                 fold_concurrently(batches, **fold_opts)
             self.last_fold_driver = max(b.fold_driver for b in batches)
             self.last_fold_peak = batches[0].fold_peak_structs
-            res = [b.results_all() for b in batches]
+            if opts.get("_packed"):
+                res = []
+                for b in batches:
+                    buf, off = b.pack_all()
+                    res.append([(buf[off[k]:off[k + 1]].tobytes(), None) for k in range(b.nseq)])
+            else:
+                res = [b.results_all() for b in batches]
         finally:
             for b in batches:
                 b.close()

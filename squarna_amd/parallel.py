@@ -35,39 +35,103 @@ def _collective_device(device=None, group=None):
     return torch.device("cpu")
 
 
-def gather_blocks(blocks, total, device=None, group=None):
-    """blocks: {record index: text}.  Returns the full ordered list on rank 0, None elsewhere.
-    One all_gather of sizes + one all_gather of a packed uint8 payload (RCCL on GPU ranks)."""
+def gather_bytes(body, dst=0, device=None, group=None):
+    """The single result gather of the multi-GPU path: every rank's packed payload (a uint8 array) travels to
+    rank `dst` ONLY, at its exact size -- one all_gather of an int64 per rank for the sizes, then one batch of
+    point-to-point transfers (RCCL send / recv over xGMI on GPU ranks, i.e. a gather without padding; gloo on CPU).
+    Returns the list of payloads (uint8 numpy arrays, by rank) on `dst`, None elsewhere.  PredictSharded and bench.py's
+    sharded legs both end in this call."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    idx = sorted(blocks)
-    payload = [blocks[k].encode() for k in idx]
-    head = np.array([len(idx)] + [v for k, b in zip(idx, payload) for v in (k, len(b))], dtype=np.int64)
-    body = np.frombuffer(head.tobytes() + b''.join(payload), dtype=np.uint8)
+    body = np.ascontiguousarray(body, dtype=np.uint8)
+    if world == 1:
+        return [body]
     dev = _collective_device(device, group)
     size = torch.tensor([body.size], dtype=torch.int64, device=dev)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, size, group=group)
-    cap = int(max(int(s.item()) for s in sizes))
+    sizes = [int(t.item()) for t in sizes]
+    ops, bufs = [], [None] * world
+    if rank == dst:
+        for r in range(world):
+            if r != dst and sizes[r]:
+                bufs[r] = torch.empty(sizes[r], dtype=torch.uint8, device=dev)
+                ops.append(dist.P2POp(dist.irecv, bufs[r], _global_rank(r, group), group))
+    elif body.size:
+        mine = torch.from_numpy(body).to(dev)
+        ops.append(dist.P2POp(dist.isend, mine, _global_rank(dst, group), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+    if rank != dst:
+        return None
+    return [body if r == dst else (bufs[r].cpu().numpy() if bufs[r] is not None else np.zeros(0, np.uint8))
+            for r in range(world)]
+
+
+def _global_rank(r, group):
+    import torch.distributed as dist
+    return r if group is None else dist.get_global_rank(group, r)
+
+
+def allgather_bytes(body, device=None, group=None):
+    """Every rank's payload to EVERY rank (alignment step 2: all ranks go on with the consensus): sizes first, then one
+    all_gather of the payloads padded to the largest.  Returns the list of payloads by rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    body = np.ascontiguousarray(body, dtype=np.uint8)
+    if world == 1:
+        return [body]
+    dev = _collective_device(device, group)
+    size = torch.tensor([body.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, size, group=group)
+    sizes = [int(t.item()) for t in sizes]
+    cap = max(max(sizes), 1)
     mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    mine[:body.size] = torch.from_numpy(body.copy()).to(dev)
-    parts = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+    if body.size:
+        mine[:body.size] = torch.from_numpy(body).to(dev)
+    parts = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
     dist.all_gather(parts, mine, group=group)
-    if rank != 0:
+    return [parts[r][:sizes[r]].cpu().numpy() for r in range(world)]
+
+
+def pack_indexed(items):
+    """{record index: bytes} -> one uint8 payload: int64 count, then (index, length) pairs, then the blobs."""
+    idx = sorted(items)
+    head = np.array([len(idx)] + [v for k in idx for v in (k, len(items[k]))], dtype=np.int64)
+    return np.frombuffer(head.tobytes() + b''.join(items[k] for k in idx), dtype=np.uint8)
+
+
+def unpack_indexed(raw, out):
+    """Inverse of pack_indexed: stores every blob of the payload at out[index]."""
+    raw = raw.tobytes() if not isinstance(raw, (bytes, bytearray)) else raw
+    if not raw:
+        return
+    n = int(np.frombuffer(raw[:8], dtype=np.int64)[0])
+    meta = np.frombuffer(raw[8:8 + 16 * n], dtype=np.int64).reshape(n, 2)
+    off = 8 + 16 * n
+    for k, ln in meta:
+        out[int(k)] = raw[off:off + int(ln)]
+        off += int(ln)
+
+
+def gather_blocks(blocks, total, device=None, group=None):
+    """blocks: {record index: text}.  Returns the full ordered list on rank 0, None elsewhere (gather_bytes: the text
+    blocks go to rank 0 only, unpadded)."""
+    got = gather_bytes(pack_indexed({k: t.encode() for k, t in blocks.items()}), 0, device, group)
+    if got is None:
         return None
     out = [None] * total
-    for r in range(world):
-        raw = parts[r][:int(sizes[r].item())].cpu().numpy().tobytes()
-        n = int(np.frombuffer(raw[:8], dtype=np.int64)[0])
-        meta = np.frombuffer(raw[8:8 + 16 * n], dtype=np.int64).reshape(n, 2)
-        off = 8 + 16 * n
-        for k, ln in meta:
-            out[int(k)] = raw[off:off + int(ln)].decode()
-            off += int(ln)
+    for raw in got:
+        unpack_indexed(raw, out)
     assert all(b is not None for b in out), "a record was not folded by any rank"
-    return out
+    return [b.decode() for b in out]
 
 
 class ShardedAlignEngine:
@@ -125,15 +189,22 @@ class ShardedAlignEngine:
         return self.base.entropy(record, interchainonly=interchainonly)
 
     def fold_records(self, recs, **kw):
-        import torch.distributed as dist
+        """Step 2: every rank folds its block; the results travel as the library's packed records (sq_result_pack_all
+        layout), one all_gather of uint8 tensors -- every rank needs them, the consensus is computed replicated."""
         lo, hi = self._block([self._ungapped(r[0]) for r in recs])
-        mine = self.base.fold_records(recs[lo:hi], **kw) if hi > lo else []
-        parts = [None] * self.world
-        dist.all_gather_object(parts, (lo, list(mine)), group=self.group)
         out = [None] * len(recs)
-        for start, items in parts:
-            out[start:start + len(items)] = items
-        return out
+        if hasattr(self.base, "fold_records_packed"):
+            from .engine import Prepared, unpack_result
+            blobs = self.base.fold_records_packed(recs[lo:hi], **kw) if hi > lo else []
+            for raw in allgather_bytes(pack_indexed({lo + q: bl for q, bl in enumerate(blobs)}), group=self.group):
+                unpack_indexed(raw, out)
+            return [unpack_result(Prepared(r[0], r[1], r[2], r[3]), bl)[0] for r, bl in zip(recs, out)]
+        # engines without packed results (the tests' CPU oracle engine): pickled tuples, same exchange
+        import pickle
+        mine = self.base.fold_records(recs[lo:hi], **kw) if hi > lo else []
+        for raw in allgather_bytes(pack_indexed({lo + q: pickle.dumps(x) for q, x in enumerate(mine)}), group=self.group):
+            unpack_indexed(raw, out)
+        return [pickle.loads(x) for x in out]
 
 
 def PredictSharded(write_to=None, device=None, **kwargs):
