@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include "sq_device.h"
 #include "sq_extend.h"
+#include "sq_tail_dev.h"
 
 extern "C" __global__ __launch_bounds__(64) void sq_chain_kernel(SqDevCtx c, SqStruct *structs, SqScanArgs a, SqChainIO cio, int tmax)
 {
@@ -32,6 +33,11 @@ extern "C" __global__ __launch_bounds__(64) void sq_chain_kernel(SqDevCtx c, SqS
             const uint32_t idx = atomicAdd(cio.d_nfin, 1u);
             cio.h_fin[idx] = (unsigned long long)(uint32_t)st.job | ((unsigned long long)(uint32_t)nstems << 32) |
                              ((unsigned long long)(by_count ? 1 : 0) << 63);
+            // the device log (sq_tail_dev.hip): the structure's stems stay where they are, in the job's slice of cio.stems
+            const uint32_t li = atomicAdd(&cio.fin_ctr[0], 1u);
+            if (li < cio.fin_cap) cio.fin[li] = SqPoolFin{st.job, SQ_FIN_KIND_G0, 0, nstems, (uint32_t)ch.toff, SQ_FIN_SRC_CHAIN};
+            else cio.fin_ctr[2] = 1;
+            cio.job_evals[st.job] = (long long)nstems + (by_count ? 0 : 1);   // one evaluation per round it took part in
         }
     };
     const unsigned long long ob = a.best[st.slot];

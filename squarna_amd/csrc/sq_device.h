@@ -68,6 +68,10 @@ struct SqChainIO {
     unsigned long long *h_fin;    // pinned: finished structures, job | nstems << 32 | (ended by maxstemnum) << 63
     uint32_t *d_nfin;             // device: entries of h_fin
     volatile uint32_t *h_nfin;    // pinned copy, published by sq_chain_done_kernel before the round's sequence number
+    // the batch's device log of final structures (input of the device tail, sq_tail_dev.hip): a retired structure gets a
+    // record that points at its slice of `stems`, and its job's evaluation count
+    SqPoolFin *fin; uint32_t *fin_ctr; uint32_t fin_cap;
+    long long *job_evals;
 };
 
 // device pools: two generations of structure slots (parents / children), slot c of generation p at (p * smax + c)
@@ -90,8 +94,12 @@ struct SqPoolIO {
     uint8_t *finalflag;           // [smax] 1: the structure is final and still has to be logged
     SqPoolPick *chosen;           // [smax][cmax]
     SqPoolHdr *hdr;
-    SqPoolFin *h_fin; uint32_t fin_cap;             // pinned
-    SqPoolStem *h_fin_stems; uint32_t fin_stem_cap; // pinned
+    // the batch's device log of final structures ([0] entries, [1] stems, [2] overflow in fin_ctr): read by the device
+    // tail (sq_tail_dev.hip); the host-driven tail copies it out
+    SqPoolFin *fin; uint32_t fin_cap;
+    SqPoolStem *fin_stems; uint32_t fin_stem_cap;
+    uint32_t *fin_ctr;
+    long long *job_evals;                           // [batch jobs] evaluations of every greedy job (sq_pool_publish_kernel)
     SqPoolHdr *h_hdr;                               // pinned copy, published by the scan kernel
     SqPoolJob *h_jobs;                              // pinned copy of the job records (sq_pool_publish_kernel)
 };

@@ -53,6 +53,69 @@ __device__ __forceinline__ SqExtendLds sq_extend_lds(char *base, int T)
     return L;
 }
 
+// PairsToDBN's level rule at stem level (:119-150) for the T stems in L.i / L.j / L.len with their crossing weights L.cc:
+// stems that cross nothing all land in group 0; the others are ordered by (weight, start), first-fitted into groups
+// and the groups ranked by size.  Result: L.lvl[q] = 1-based level of stem q.  One wave; the caller's block is that wave
+// (every __syncthreads() below is the wave's own barrier).  level_ovf: set when more than SQ_MAXLEVELS groups appear.
+__device__ __forceinline__ void sq_stem_levels_wave(SqExtendLds &L, int T, int lane, uint32_t *level_ovf)
+{
+    // stems that cross nothing sort first (weight 0) and all land in group 0
+    int g0 = 0, has0 = 0;
+    for (int q = lane; q < T; q += 64) {
+        const bool free_ = L.cc[q] == 0;
+        L.grp[q] = free_ ? 0 : 255;
+        if (free_) { g0 += L.len[q]; has0 = 1; }
+    }
+    g0 = sq_wave_sum32(g0);
+    int ngroups = __ballot(has0) != 0ull ? 1 : 0;
+    if (lane == 0) L.gsize[0] = g0;
+    // order of the crossing stems: (weight, start) ascending (:125); starts are distinct
+    int nx = 0;
+    for (int q0 = 0; q0 < T; q0 += 64) {
+        const int q = q0 + lane;
+        const bool x = q < T && L.cc[q] > 0;
+        if (x) {
+            const int cq = L.cc[q], iq = L.i[q];
+            int r = 0;
+            for (int p = 0; p < T; p++) {
+                const int cp = L.cc[p];
+                r += (cp > 0 && (cp < cq || (cp == cq && L.i[p] < iq))) ? 1 : 0;
+            }
+            L.ord[r] = (int16_t)q;
+        }
+        nx += __popcll(__ballot(x));
+    }
+    __syncthreads();
+    // first fit (:130-136): a stem joins the first group none of whose members it crosses
+    for (int t = 0; t < nx; t++) {
+        const int p = L.ord[t];
+        const int pi = L.i[p], pj = L.j[p];
+        unsigned long long blocked = 0ull;
+        for (int q = lane; q < T; q += 64) {
+            const int g = L.grp[q];
+            if (g != 255 && sq_chain_cross(pi, pj, L.i[q], L.j[q])) blocked |= 1ull << g;
+        }
+        blocked = sq_wave_or64(blocked);
+        int placed = blocked == ~0ull ? 64 : __ffsll((long long)~blocked) - 1;
+        if (placed > ngroups) placed = ngroups;
+        if (placed >= SQ_MAXLEVELS) { if (lane == 0) *level_ovf = 1; placed = SQ_MAXLEVELS - 1; }   // (reported as an error)
+        else if (placed == ngroups) { ngroups++; if (lane == 0) L.gsize[placed] = 0; }
+        __syncthreads();
+        if (lane == 0) { L.grp[p] = (uint8_t)placed; L.gsize[placed] += L.len[p]; }
+        __syncthreads();
+    }
+    // groups ranked by size, descending, stable (:139); level = rank + 1
+    if (lane < ngroups) {
+        const int gs = L.gsize[lane];
+        int r = 0;
+        for (int h = 0; h < ngroups; h++) { const int hs = L.gsize[h]; r += (hs > gs || (hs == gs && h < lane)) ? 1 : 0; }
+        L.rank[lane] = (uint8_t)(r + 1);
+    }
+    __syncthreads();
+    for (int q = lane; q < T; q += 64) L.lvl[q] = L.rank[L.grp[q]];
+    __syncthreads();
+}
+
 // parent: k stems pst[] (with their crossing weights), nstrand sorted strands psrc[] + the stem index of each (pssrc[]).
 // child: cst[0..k] (may be the parent's array: the weights are updated in place), cdst[] / csdst[] (nstrand + 2 entries;
 // must NOT be the parent's).  (i0, j0, len): the new stem.  Returns whether some pair of the child's stems crosses.
@@ -78,63 +141,7 @@ __device__ __forceinline__ bool sq_extend_structure(SqExtendLds &L, const SqScan
     __syncthreads();
     const int T = k + 1;
     // ---- levels (only when stems cross; otherwise every strand stays on level 1) ----
-    if (anycross) {
-        // stems that cross nothing sort first (weight 0) and all land in group 0
-        int g0 = 0, has0 = 0;
-        for (int q = lane; q < T; q += 64) {
-            const bool free_ = L.cc[q] == 0;
-            L.grp[q] = free_ ? 0 : 255;
-            if (free_) { g0 += L.len[q]; has0 = 1; }
-        }
-        g0 = sq_wave_sum32(g0);
-        int ngroups = __ballot(has0) != 0ull ? 1 : 0;
-        if (lane == 0) L.gsize[0] = g0;
-        // order of the crossing stems: (weight, start) ascending (:125); starts are distinct
-        int nx = 0;
-        for (int q0 = 0; q0 < T; q0 += 64) {
-            const int q = q0 + lane;
-            const bool x = q < T && L.cc[q] > 0;
-            if (x) {
-                const int cq = L.cc[q], iq = L.i[q];
-                int r = 0;
-                for (int p = 0; p < T; p++) {
-                    const int cp = L.cc[p];
-                    r += (cp > 0 && (cp < cq || (cp == cq && L.i[p] < iq))) ? 1 : 0;
-                }
-                L.ord[r] = (int16_t)q;
-            }
-            nx += __popcll(__ballot(x));
-        }
-        __syncthreads();
-        // first fit (:130-136): a stem joins the first group none of whose members it crosses
-        for (int t = 0; t < nx; t++) {
-            const int p = L.ord[t];
-            const int pi = L.i[p], pj = L.j[p];
-            unsigned long long blocked = 0ull;
-            for (int q = lane; q < T; q += 64) {
-                const int g = L.grp[q];
-                if (g != 255 && sq_chain_cross(pi, pj, L.i[q], L.j[q])) blocked |= 1ull << g;
-            }
-            blocked = sq_wave_or64(blocked);
-            int placed = blocked == ~0ull ? 64 : __ffsll((long long)~blocked) - 1;
-            if (placed > ngroups) placed = ngroups;
-            if (placed >= SQ_MAXLEVELS) { if (lane == 0) a.ctr->level_ovf = 1; placed = SQ_MAXLEVELS - 1; }   // (reported as an error)
-            else if (placed == ngroups) { ngroups++; if (lane == 0) L.gsize[placed] = 0; }
-            __syncthreads();
-            if (lane == 0) { L.grp[p] = (uint8_t)placed; L.gsize[placed] += L.len[p]; }
-            __syncthreads();
-        }
-        // groups ranked by size, descending, stable (:139); level = rank + 1
-        if (lane < ngroups) {
-            const int gs = L.gsize[lane];
-            int r = 0;
-            for (int h = 0; h < ngroups; h++) { const int hs = L.gsize[h]; r += (hs > gs || (hs == gs && h < lane)) ? 1 : 0; }
-            L.rank[lane] = (uint8_t)(r + 1);
-        }
-        __syncthreads();
-        for (int q = lane; q < T; q += 64) L.lvl[q] = L.rank[L.grp[q]];
-        __syncthreads();
-    }
+    if (anycross) sq_stem_levels_wave(L, T, lane, &a.ctr->level_ovf);
     // ---- strands: the sorted list with the two new strands ----
     const SqStrand *src = psrc;
     const int16_t *ssrc = pssrc;

@@ -13,6 +13,7 @@
 #include "../../include/squarna_hip.h"
 #include "sq_device.h"
 #include "sq_internal.h"
+#include "sq_tail_dev.h"
 
 struct HStem {            // host stem record: bps (i+k, j-k), k < len
     int32_t i, j, len;
@@ -178,6 +179,22 @@ struct sq_batch {
     // device pools (pools of any width, sq_pool.hip): device arrays carved from the workspace, pinned ones on first use
     SqPoolIO pool_io{};
     SqChain *h_pool_recs = nullptr; SqPoolJob *h_pool_jobs = nullptr; int32_t *h_pool_jobrec = nullptr;   // pinned staging
+    // ---- device tail (sq_tail_dev.hip): the log of final structures and the tail's scratch are carved from the workspace,
+    // the results land in pinned host memory in the C ABI's packed layout
+    SqTailIO tail{};                      // device arrays (the per-fold fields are filled in by sq_fold)
+    SqPoolFin *d_fin = nullptr; SqPoolStem *d_fin_stems = nullptr;
+    uint32_t *d_fin_ctr = nullptr;        // [0] entries, [1] stems, [2] overflow, [3] the tail's fallback flag
+    long long *d_job_evals = nullptr;
+    int16_t *d_refp = nullptr; int32_t *d_refn = nullptr;
+    uint32_t fin_cap = 0, fin_stem_cap = 0;
+    long long *h_tail_totals = nullptr;   // pinned: SqTailIO::h_totals
+    long long *h_rec_off = nullptr, *h_txt_off = nullptr;   // pinned: [nseq + 1] record / text offsets (sq_tail_offsets_kernel)
+    char *h_rec = nullptr, *h_txt = nullptr; uint8_t *h_deep = nullptr;   // pinned: packed records, ASCII rows, deep flags
+    size_t h_rec_cap = 0, h_txt_cap = 0;
+    char *h_app = nullptr; size_t h_app_cap = 0;   // pinned staging of host-built log entries (sq_fin_append_kernel)
+    char *h_ref = nullptr; size_t h_ref_cap = 0;   // pinned staging of the known structures (partner arrays)
+    bool packed_ok = false;               // the last fold's results are the packed records above (else: `results`)
+    int32_t packed_limit = 0;             // result_limit in force at that fold
     // profiling
     std::mutex mwm_mu;
     int64_t mwm_stats[6] = {0, 0, 0, 0, 0, 0};   // blossom jobs collected, their scan passes; the job with the most passes:
@@ -242,6 +259,12 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
 int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<JobSets> &sets,
                  const SqAlgoEndHooks *hooks = nullptr);
 void sq_algos_abandon(sq_batch *b, SqAlgoAsync *pa);      // error paths: waits for the side streams, releases the arena
+
+// device tail (sq_tail_dev.hip).  Launches the tail over the batch's device log on b->stream and waits for it.
+// Returns 0: the packed results are in place (b->packed_ok), 1: the batch needs the host tail (nothing changed), else an error.
+int sq_tail_device(sq_batch *b, const sq_fold_opts &o, const int32_t *ref_off, const int32_t *ref_pairs, const uint8_t *has_ref);
+// whether the options of this fold are covered by the device tail at all
+bool sq_tail_device_wanted(const sq_batch *b, const sq_fold_opts &o);
 
 // host tail: SQRNdbnseq.py:1201-1286
 void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,

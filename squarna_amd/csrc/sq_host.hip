@@ -266,6 +266,10 @@ struct Layout {
     size_t off_crec, off_cstems, off_cstrands, off_csidx, off_cnfin;   // device-chained rounds (sq_chain.hip)
     size_t off_pstructs, off_precs, off_pstems, off_pstrands, off_psidx, off_pjobs, off_pjobrec, off_pnchild, off_pchoff,
            off_pflag, off_pchosen, off_phdr;                            // device pools (sq_pool.hip)
+    // device log of final structures + scratch of the device tail (sq_tail_dev.hip)
+    size_t off_fin, off_fin_stems, off_fin_ctr, off_jobevals, off_t_jobs, off_t_seqjob0, off_t_ord, off_t_cstems, off_t_csn, off_t_hash,
+           off_t_rep, off_t_mask, off_t_scores, off_t_dlist, off_t_rlist, off_t_seqs, off_t_refp, off_t_refn, off_t_pow;
+    uint32_t fin_cap, fin_stem_cap; int32_t pow_len;
     size_t off_mulcols;              // alignment columns of every position (shared L x L weighting matrix), else unused
     size_t off_algo, algo_bytes;     // scratch of the Hungarian / Nussinov kernels (Edmonds borrows the end of the candidate arena)
     int32_t pool_pt;                 // stems per slot (0: no device pools for this batch)
@@ -368,6 +372,29 @@ int plan(const sq_batch_desc *d, Layout &L)
         L.off_pjobs = take(on * (size_t)d->njobs * sizeof(SqPoolJob)); L.off_pjobrec = take(on * (size_t)d->njobs * 4);
         L.off_pnchild = take(on * sm * 4); L.off_pchoff = take(on * (sm + 1) * 4); L.off_pflag = take(on * sm);
         L.off_pchosen = take(on * sm * 64 * sizeof(SqPoolPick)); L.off_phdr = take(64);
+    }
+    {
+        // the log of final structures: every structure of every pool ends there once -- measured: 1.4 x the largest generation.
+        // Two entries per structure slot (65,536 at least, 4 Mi at most) + one per job (chained rounds, E / H / N stemsets),
+        // with a third of the most stems a structure can hold each (8 .. 128) + every job's stem capacity once
+        int pt_any = 1;
+        for (int j = 0; j < d->njobs; j++)
+            pt_any = std::max(pt_any, chain_tcap(d->seq_off[d->job_seq[j] + 1] - d->seq_off[d->job_seq[j]], d->psets[d->job_pset[j]].minlen));
+        const int64_t want = std::min<int64_t>(std::max<int64_t>(65536, 2 * (int64_t)L.max_structs), (int64_t)4 << 20);
+        L.fin_cap = (uint32_t)(want + 2 * (int64_t)d->njobs);
+        L.fin_stem_cap = (uint32_t)std::min<int64_t>(std::min<int64_t>(want * std::min(std::max(pt_any / 3, 8), 128), (int64_t)48 << 20) + 2 * L.chain_T,
+                                                     (int64_t)0x7FFFFFF0);
+        L.pow_len = 4 * L.maxn + 16;
+        const size_t fc = L.fin_cap;
+        L.off_fin = take(sizeof(SqPoolFin) * fc); L.off_fin_stems = take(sizeof(SqPoolStem) * (size_t)L.fin_stem_cap);
+        L.off_fin_ctr = take(64); L.off_jobevals = take(8 * (size_t)d->njobs);
+        L.off_t_jobs = take(3 * 4 * ((size_t)d->njobs + 1)); L.off_t_seqjob0 = take(4 * ((size_t)d->nseq + 1));
+        L.off_t_ord = take(2 * 4 * fc); L.off_t_cstems = take(sizeof(SqPoolStem) * ((size_t)L.fin_stem_cap + (size_t)L.chain_T));
+        L.off_t_csn = take(4 * fc); L.off_t_hash = take(8 * fc); L.off_t_rep = take(4 * fc); L.off_t_mask = take(8 * fc);
+        L.off_t_scores = take(8 * (3 * fc + 16 * (size_t)d->nseq)); L.off_t_dlist = take(4 * fc); L.off_t_rlist = take(4 * fc);
+        L.off_t_seqs = take(sizeof(SqTailSeq) * (size_t)d->nseq);
+        L.off_t_refp = take(2 * (size_t)L.ltot); L.off_t_refn = take(4 * (size_t)d->nseq);
+        L.off_t_pow = take(8 * (size_t)L.pow_len);
     }
     L.off_mulcols = take(d->mul_matrix_dev ? 4 * (size_t)L.ltot : 0);
     // Hungarian and Nussinov: their scratch (n x n tables) is known from the lengths, so they get room of their own and
@@ -629,6 +656,28 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->chain.strands = (SqStrand *)(base + L.off_cstrands); b->chain.sidx = (int16_t *)(base + L.off_csidx);
     b->chain.d_nfin = (uint32_t *)(base + L.off_cnfin);
     b->chain_T = L.chain_T;
+    {   // the device log of final structures and the device tail's arrays
+        b->d_fin = (SqPoolFin *)(base + L.off_fin); b->d_fin_stems = (SqPoolStem *)(base + L.off_fin_stems);
+        b->d_fin_ctr = (uint32_t *)(base + L.off_fin_ctr); b->d_job_evals = (long long *)(base + L.off_jobevals);
+        b->fin_cap = L.fin_cap; b->fin_stem_cap = L.fin_stem_cap;
+        b->d_refp = (int16_t *)(base + L.off_t_refp); b->d_refn = (int32_t *)(base + L.off_t_refn);
+        b->chain.fin = b->d_fin; b->chain.fin_ctr = b->d_fin_ctr; b->chain.fin_cap = L.fin_cap; b->chain.job_evals = b->d_job_evals;
+        SqTailIO &T = b->tail;
+        T.fin = b->d_fin; T.fin_stems = b->d_fin_stems; T.nfin_ptr = b->d_fin_ctr; T.chain_stems = b->chain.stems;
+        T.fin_cap = L.fin_cap; T.fin_stem_cap = L.fin_stem_cap;
+        uint32_t *tj = (uint32_t *)(base + L.off_t_jobs);
+        T.job_cnt = tj; T.job_start = tj + (d->njobs + 1); T.job_fill = tj + 2 * ((size_t)d->njobs + 1);
+        T.job_evals = b->d_job_evals; T.njobs = d->njobs; T.nseq = d->nseq;
+        T.seq_job0 = (int32_t *)(base + L.off_t_seqjob0);
+        T.ord = (uint32_t *)(base + L.off_t_ord); T.ord2 = T.ord + L.fin_cap;
+        T.cstems = (SqPoolStem *)(base + L.off_t_cstems); T.cs_n = (uint32_t *)(base + L.off_t_csn);
+        T.hash = (unsigned long long *)(base + L.off_t_hash); T.rep = (uint32_t *)(base + L.off_t_rep);
+        T.mask = (unsigned long long *)(base + L.off_t_mask); T.scores = (double *)(base + L.off_t_scores);
+        T.dlist = (uint32_t *)(base + L.off_t_dlist); T.rlist = (uint32_t *)(base + L.off_t_rlist);
+        T.seqs = (SqTailSeq *)(base + L.off_t_seqs);
+        T.pow17h = (double *)(base + L.off_t_pow); T.pow17h_len = L.pow_len;
+        T.fallback = b->d_fin_ctr + 3;
+    }
     b->chain_tmax = 1;
     for (int j = 0; j < d->njobs; j++)
         b->chain_tmax = std::max(b->chain_tmax, chain_tcap(d->seq_off[d->job_seq[j] + 1] - d->seq_off[d->job_seq[j]], d->psets[d->job_pset[j]].minlen));
@@ -643,6 +692,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         P.nchild = (int32_t *)(base + L.off_pnchild); P.child_off = (int32_t *)(base + L.off_pchoff);
         P.finalflag = (uint8_t *)(base + L.off_pflag); P.chosen = (SqPoolPick *)(base + L.off_pchosen);
         P.hdr = (SqPoolHdr *)(base + L.off_phdr);
+        P.fin = b->d_fin; P.fin_stems = b->d_fin_stems; P.fin_cap = L.fin_cap; P.fin_stem_cap = L.fin_stem_cap;
+        P.fin_ctr = b->d_fin_ctr; P.job_evals = b->d_job_evals;
     }
 
     hipStream_t st = b->stream;
@@ -670,7 +721,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     } stager;
     stager.st = st;
     {
-        size_t want = (size_t)L.ltot * 16 + 8 * rftab.size() + sizeof(SqJob) * d->njobs + sizeof(SqPsetDev) * d->npset + 8 * sdf.size() + 4 * rbpk.size() + 16384;
+        size_t want = (size_t)L.ltot * 16 + 8 * rftab.size() + 8 * (size_t)L.pow_len + 4 * ((size_t)d->nseq + 1) + sizeof(SqJob) * d->njobs + sizeof(SqPsetDev) * d->npset + 8 * sdf.size() + 4 * rbpk.size() + 16384;
         for (int j = 0; j < d->njobs; j++)
             if (b->jobs[j].has_ext && !(d->mul_shared && d->mul_shared[j])) want += (size_t)b->jobs[j].n * b->jobs[j].n * 8 * (b->jobs[j].has_ext == 1 ? 2 : 1);
         stager.cap = std::min<size_t>(std::max<size_t>(want, (size_t)1 << 20), (size_t)64 << 20) & ~(size_t)255;
@@ -690,6 +741,26 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     if (!rftab.empty()) UP(b->ctx.rftab, rftab.data(), 8 * rftab.size());
     b->rftab.swap(rftab);                                      // (host copy: RunAlgo's stem filters re-sum cells, sq_algos.hip)
     if (!rbpk.empty()) UP(b->ctx.rbpk, rbpk.data(), 4 * rbpk.size());
+    {
+        // device tail: the first job of every sequence -- it needs each sequence's jobs contiguous, in sequence order, at
+        // most 64 of them (the paramset mask); any other job list keeps the host tail -- and pow(k / 2, 1.7) from the
+        // host's libm for ScoreStruct's stem terms (:884: sums of 4 / 1.5 / -0.5 per pair are multiples of 1/2)
+        std::vector<int32_t> sj0((size_t)d->nseq + 1, 0);
+        bool grouped = true;
+        int j = 0;
+        for (int sq = 0; sq < d->nseq; sq++) {
+            sj0[sq] = j;
+            while (j < d->njobs && d->job_seq[j] == sq) j++;
+            if (j == sj0[sq] || j - sj0[sq] > 64) grouped = false;
+        }
+        sj0[d->nseq] = j;
+        if (j != d->njobs) grouped = false;
+        if (grouped) UP(b->tail.seq_job0, sj0.data(), 4 * sj0.size());
+        else b->tail.seq_job0 = nullptr;
+        std::vector<double> pw((size_t)L.pow_len);
+        for (int k = 0; k < L.pow_len; k++) pw[k] = pow(0.5 * (double)k, 1.7);
+        UP(b->tail.pow17h, pw.data(), 8 * pw.size());
+    }
     for (int j = 0; j < d->njobs; j++) {
         const SqJob &J = b->jobs[j];
         const size_t nn = (size_t)J.n * J.n * 8;
@@ -773,7 +844,9 @@ extern "C" void sq_batch_destroy(sq_batch *b)
     for (int k = 0; k < 4; k++) sq_pinned_put(b->stage_buf[k]);
     sq_pinned_put(b->chain.h_stems); sq_pinned_put(b->chain.h_fin); sq_pinned_put((void *)b->chain.h_nfin);
     sq_pinned_put(b->h_chain);
-    sq_pinned_put(b->pool_io.h_fin); sq_pinned_put(b->pool_io.h_fin_stems); sq_pinned_put(b->pool_io.h_hdr); sq_pinned_put(b->pool_io.h_jobs);
+    sq_pinned_put(b->pool_io.h_hdr); sq_pinned_put(b->pool_io.h_jobs);
+    sq_pinned_put(b->h_tail_totals); sq_pinned_put(b->h_rec_off); sq_pinned_put(b->h_txt_off); sq_pinned_put(b->h_deep);
+    sq_pinned_put(b->h_rec); sq_pinned_put(b->h_txt); sq_pinned_put(b->h_app); sq_pinned_put(b->h_ref);
     sq_pinned_put(b->h_pool_recs); sq_pinned_put(b->h_pool_jobs); sq_pinned_put(b->h_pool_jobrec);
     delete b->pool;
     if (b->lane_ev) hipEventDestroy(b->lane_ev);
@@ -1441,6 +1514,12 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // a-1, once per job and per fold (:1076): never reused from an earlier call, a fold is the whole path
     int r = fill_impl(b, 0);
     if (r) return r;
+    // The ranking tail runs on the device (sq_tail_dev.hip) over the device log of final structures whenever the options
+    // allow; the host tail below is its fallback.  The log and the per-job evaluation counts start empty.
+    const bool dev_tail = sq_tail_device_wanted(b, o);
+    b->packed_ok = false;
+    HIPCK(hipMemsetAsync(b->d_fin_ctr, 0, 64, b->stream));
+    HIPCK(hipMemsetAsync(b->d_job_evals, 0, 8 * (size_t)b->njobs, b->stream));
     // (the pools -- thousands of small vectors -- are torn down by a helper thread after the fold returns)
     auto *pools_owner = new std::vector<JobPool>(b->njobs);
     struct PoolsDrop {
@@ -1525,7 +1604,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // the lanes report such sequences after every round and a helper thread ranks them on the worker pool while
     // the rounds of the other sequences go on.
     static const bool no_early_tail = getenv("SQ_NO_EARLY_TAIL") != nullptr;
-    const bool early_tail = pending == nullptr && !no_early_tail;
+    const bool early_tail = pending == nullptr && !no_early_tail && !dev_tail;
     struct TailQueue {
         std::mutex mu; std::condition_variable cv; std::vector<int> items; bool closed = false;
         std::thread worker;
@@ -1762,7 +1841,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 if (ctr.out_ovf) { fail(-3, "stem capacity of a chained structure exceeded"); break; }
                 if (ctr.level_ovf) { fail(-3, "more than 64 pseudoknot levels"); break; }
                 const uint32_t nf = *b->chain.h_nfin;
-                for (uint32_t q = nfin_seen; q < nf; q++) finished.push_back(-(int)q - 1);
+                if (!dev_tail) for (uint32_t q = nfin_seen; q < nf; q++) finished.push_back(-(int)q - 1);   // (device tail: the log has them)
                 nfin_seen = nf;
                 tq.push(finished);
                 continue;
@@ -1799,6 +1878,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
 #undef CHK
     };
     // ---- device pools ----
+    std::vector<int> pool_jobs;                              // structure slot of generation 0 -> job
+    std::function<int()> pool_collect;                       // set by pool_fold: the device log -> pools[].fin (host tail only)
     auto pool_fold = [&](LoopStats &stats) -> int {          // 0: done, 1: capacity overflow (repeat on the host), < 0 / > 1: error in stats
         SqLane &ln = b->lane_full;
         hipStream_t st = b->stream;
@@ -1807,26 +1888,6 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         stats.tstart = tl0 - tfold0;
         struct Wall { double t0; double &dst; ~Wall() { dst = now_s() - t0; } } wall{tl0, stats.twall};
         auto fail = [&](int rc, const std::string &msg) { stats.rc = rc; stats.err = msg; return 2; };
-        {
-            // the pinned log of final structures: every structure of every pool ends there once -- measured: 1.4 x the
-            // largest generation.  Two entries per usable slot (65,536 at least, 4 Mi = 96 MB at most) with a third of the
-            // most stems a structure can hold each (8 .. 128; 8 bytes per stem, 48 Mi stems = 384 MB at most); a fold
-            // that outgrows it is repeated by the host loop
-            const int64_t nslots = std::min(PI.smax, ln.max_structs);
-            const uint32_t want = (uint32_t)std::min<int64_t>(std::max<int64_t>(65536, 2 * nslots), (int64_t)4 << 20);
-            const uint32_t want_stems = (uint32_t)std::min<int64_t>((int64_t)want * std::min(std::max(PI.pt / 3, 8), 128), (int64_t)48 << 20);
-            if (!PI.h_fin || PI.fin_cap < want || PI.fin_stem_cap < want_stems) {
-                sq_pinned_put(PI.h_fin); sq_pinned_put(PI.h_fin_stems);
-                PI.h_fin = nullptr; PI.h_fin_stems = nullptr;
-                PI.fin_cap = want; PI.fin_stem_cap = want_stems;
-                void *p0 = nullptr, *p1 = nullptr;
-                if (sq_pinned_get(&p0, sizeof(SqPoolFin) * (size_t)PI.fin_cap) || sq_pinned_get(&p1, sizeof(SqPoolStem) * (size_t)PI.fin_stem_cap)) {
-                    sq_pinned_put(p0);
-                    return fail(2, sq_last_error());
-                }
-                PI.h_fin = (SqPoolFin *)p0; PI.h_fin_stems = (SqPoolStem *)p1;
-            }
-        }
         if (!PI.h_hdr) {
             void *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr, *p6 = nullptr;
             if (sq_pinned_get(&p2, 64) || sq_pinned_get(&p3, sizeof(SqPoolJob) * (size_t)b->njobs) ||
@@ -1936,12 +1997,21 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         const SqPoolHdr hh = *pio.h_hdr;
         if (overflow || hh.ovf) {
             for (int j : greedy_jobs) { pools[j].fin.clear(); pools[j].evals = 0; }
+            // (the device log holds the structures the aborted pools had finished: empty it for the host loop's)
+            hipMemsetAsync(b->d_fin_ctr, 0, 64, st);
+            hipMemsetAsync(b->d_job_evals, 0, 8 * (size_t)b->njobs, st);
             return 1;
         }
         if ((*ln.h_ctr).level_ovf) return fail(-3, "more than 64 pseudoknot levels");
-        // finstemsets of every job: its log entries in (round, kind, position) order
-        {
-            const SqPoolFin *F = pio.h_fin;
+        // finstemsets of every job: its log entries in (round, kind, position) order.  With the device tail the log is
+        // consumed where it is; the host needs it only when the batch falls back to the host tail (pool_collect).
+        pool_jobs = jobs;
+        pool_collect = [&, S0, hh]() -> int {
+            std::vector<SqPoolFin> Fv(hh.nfin);
+            std::vector<SqPoolStem> Sv(hh.nfin_stems);
+            if (hh.nfin) HIPCK(hipMemcpy(Fv.data(), b->d_fin, sizeof(SqPoolFin) * (size_t)hh.nfin, hipMemcpyDeviceToHost));
+            if (hh.nfin_stems) HIPCK(hipMemcpy(Sv.data(), b->d_fin_stems, sizeof(SqPoolStem) * (size_t)hh.nfin_stems, hipMemcpyDeviceToHost));
+            const SqPoolFin *F = Fv.data();
             std::vector<uint32_t> start((size_t)b->njobs + 1, 0), ord(hh.nfin);
             for (uint32_t q = 0; q < hh.nfin; q++) start[(size_t)F[q].job + 1]++;
             for (int j = 0; j < b->njobs; j++) start[(size_t)j + 1] += start[j];
@@ -1950,7 +2020,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 for (uint32_t q = 0; q < hh.nfin; q++) ord[fillp[F[q].job]++] = q;
             }
             auto one_job = [&](int sx) {
-                const int j = jobs[sx];
+                const int j = pool_jobs[sx];
                 uint32_t *p0 = ord.data() + start[j], *p1 = ord.data() + start[(size_t)j + 1];
                 std::sort(p0, p1, [&](uint32_t x, uint32_t y) {
                     if (F[x].round_kind != F[y].round_kind) return F[x].round_kind < F[y].round_kind;
@@ -1960,7 +2030,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 fin.reserve(fin.size() + (size_t)(p1 - p0));
                 for (uint32_t *p = p0; p < p1; p++) {
                     const SqPoolFin &e = F[*p];
-                    const SqPoolStem *src = pio.h_fin_stems + e.stem_off;
+                    const SqPoolStem *src = Sv.data() + e.stem_off;
                     std::vector<HStem> stems((size_t)e.nstems);
                     for (int t = 0; t < e.nstems; t++) stems[t] = HStem{src[t].i, src[t].j, src[t].len, 0.0, 0.0};
                     fin.push_back(std::move(stems));
@@ -1968,8 +2038,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             };
             if (hh.nfin >= 8192) sq_pool(b)->parallel_for(S0, one_job);
             else for (int sx = 0; sx < S0; sx++) one_job(sx);
-        }
-        for (int sx = 0; sx < S0; sx++) pools[jobs[sx]].evals += pio.h_jobs[sx].evals;
+            return 0;
+        };
+        if (!dev_tail) { const int rc2 = pool_collect(); pool_collect = nullptr; if (rc2) return fail(rc2, sq_last_error()); }
+        if (!dev_tail) for (int sx = 0; sx < S0; sx++) pools[jobs[sx]].evals += pio.h_jobs[sx].evals;
         if (b->prof_on)                                      // 2 N^2 bytes per evaluation (live structures only)
             for (int sx = 0; sx < S0; sx++) { const double n = b->jobs[jobs[sx]].n; b->prof[2].bytes += (double)pio.h_jobs[sx].evals * 2.0 * n * n; }
         return 0;
@@ -2054,7 +2126,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             P.fin.insert(P.fin.begin(), std::move(set));
             P.evals++;
             const int s = b->job_seq[j];
-            if (--e_left[s] == 0) { tail_one(s); tailed[s] = 1; }
+            if (!dev_tail && --e_left[s] == 0) { tail_one(s); tailed[s] = 1; }
         };
         std::vector<JobSets> sets;
         { CpuScope cpu_(10); r = sq_algos_end(b, pending, o.levellimit, sets, &hooks); }
@@ -2066,8 +2138,95 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         take_sets(sets, true);
         if (timing) fprintf(stderr, "[sq_fold] E/H/N: begin %.3f ms, wait+collect (+ tails of finished sequences) after the greedy loop %.3f ms\n", tbegin * 1e3, (now_s() - t0) * 1e3);
     }
+    // ---- the device tail (sq_tail_dev.hip): every final structure the HOST holds -- the E / H / N stemsets, the greedy ones
+    // when the host's own loop ran, the empty structure of a job with maxstemnum 0 -- joins the device log, then the
+    // tail kernels rank every sequence and write the packed results; no per-sequence host code
+    bool tails_done = false;
+    if (dev_tail) {
+        CpuScope cpu_(0);
+        size_t nent = 0, nst = 0;
+        for (int j = 0; j < b->njobs; j++) { nent += pools[j].fin.size(); for (const auto &f : pools[j].fin) nst += f.size(); }
+        int rt = 0;
+        if (nent > (size_t)b->fin_cap || nst > (size_t)b->fin_stem_cap) rt = 1;
+        if (!rt && nent) {
+            const size_t need = sizeof(SqPoolFin) * nent + sizeof(SqPoolStem) * nst + 8 * (size_t)b->njobs + 64;
+            if (b->h_app_cap < need) {
+                hipStreamSynchronize(b->stream);
+                sq_pinned_put(b->h_app); b->h_app = nullptr; b->h_app_cap = 0;
+                void *p = nullptr;
+                if (sq_pinned_get(&p, need + need / 2)) return 2;
+                b->h_app = (char *)p; b->h_app_cap = need + need / 2;
+            }
+            SqPoolFin *ef = (SqPoolFin *)b->h_app;
+            SqPoolStem *es = (SqPoolStem *)(b->h_app + sizeof(SqPoolFin) * nent);
+            long long *ev = (long long *)(b->h_app + sizeof(SqPoolFin) * nent + ((sizeof(SqPoolStem) * nst + 7) & ~(size_t)7));
+            size_t qe = 0, qs = 0;
+            const bool host_greedy = b->last_driver == 0 || b->last_driver == 3;
+            for (int j = 0; j < b->njobs; j++) {
+                const JobPool &P = pools[j];
+                const int nalgo = __builtin_popcount(algos[j] & (uint32_t)(SQ_ALGO_E | SQ_ALGO_H | SQ_ALGO_N));
+                ev[j] = std::max<int64_t>(P.evals - nalgo, 0);
+                for (size_t k = 0; k < P.fin.size(); k++) {           // [E][H][N] first, then the greedy structures, in list order
+                    const std::vector<HStem> &f = P.fin[k];
+                    ef[qe++] = SqPoolFin{j, (int)k < nalgo ? (uint32_t)k : SQ_FIN_KIND_G0, (int32_t)k, (int32_t)f.size(), (uint32_t)qs, 0u};
+                    for (const HStem &t : f) es[qs++] = SqPoolStem{(int16_t)t.i, (int16_t)t.j, (int16_t)t.len, 0};
+                }
+            }
+            if (host_greedy) HIPCK(hipMemcpyAsync(b->d_job_evals, ev, 8 * (size_t)b->njobs, hipMemcpyHostToDevice, b->stream));
+            hipLaunchKernelGGL(sq_fin_append_kernel, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, b->stream, ef, es, (int)nent,
+                               b->d_fin, b->d_fin_stems, b->d_fin_ctr, b->fin_cap, b->fin_stem_cap);
+        }
+        if (!rt) rt = sq_tail_device(b, o, ref_off, ref_pairs, has_ref);
+        // the structures the device drivers left in the log as host lists (the host tail's input)
+        auto collect_device_lists = [&]() -> int {
+            if (b->last_driver == 1) {
+                const uint32_t nf = *b->chain.h_nfin;
+                for (uint32_t q = 0; q < nf; q++) chain_finish(q);
+            } else if (b->last_driver == 2 && pool_collect) {
+                // (the E / H / N stemsets are already at the front of the lists: the greedy structures go behind them)
+                const int rc2 = pool_collect();
+                if (rc2) return rc2;
+                for (size_t sx = 0; sx < pool_jobs.size(); sx++) pools[pool_jobs[sx]].evals += b->pool_io.h_jobs[sx].evals;
+            }
+            return 0;
+        };
+        static const bool tail_check = getenv("SQ_TAIL_CHECK") != nullptr;
+        if (rt == 0) {
+            tails_done = true;
+            if (tail_check) {
+                // debug: the host tail over the same structures must give the same packed bytes for every sequence
+                r = collect_device_lists();
+                if (r) return r;
+                for (int s2 = 0; s2 < b->nseq; s2++) tail_one(s2);
+                size_t bad = 0;
+                std::vector<char> hb, db;
+                for (int s2 = 0; s2 < b->nseq; s2++) {
+                    b->packed_ok = false;
+                    const int64_t nh = sq_result_pack_size(b, s2);
+                    hb.assign((size_t)nh, 0); sq_result_pack(b, s2, hb.data(), nh);
+                    b->packed_ok = true;
+                    const int64_t nd = sq_result_pack_size(b, s2);
+                    db.assign((size_t)nd, 0); sq_result_pack(b, s2, db.data(), nd);
+                    if (nh != nd || memcmp(hb.data(), db.data(), (size_t)nh) != 0) {
+                        size_t at = 0;
+                        while (at < (size_t)std::min(nh, nd) && hb[at] == db[at]) at++;
+                        if (bad++ < 8) fprintf(stderr, "[tail check] sequence %d (n = %d): host %lld bytes, device %lld bytes, first difference at byte %zu\n",
+                                               s2, b->seq_off[s2 + 1] - b->seq_off[s2], (long long)nh, (long long)nd, at);
+                    }
+                }
+                fprintf(stderr, "[tail check] %d sequences, %zu differ\n", b->nseq, bad);
+            }
+        }
+        else if (rt != 1) return rt;
+        else {
+            // the host tail takes the batch
+            if (timing) fprintf(stderr, "[sq_fold] device tail: not applicable to this batch, the host tail runs\n");
+            r = collect_device_lists();
+            if (r) return r;
+        }
+    }
     // the remaining sequences: the batch's worker pool shares the tail, longest first (deterministic output)
-    {
+    if (!tails_done) {
         std::vector<int> order;
         std::vector<int64_t> cost(b->nseq, 0);
         for (int s = 0; s < b->nseq; s++) {
@@ -2145,12 +2304,34 @@ extern "C" int sq_fold_concurrent_n(sq_batch *const *batches, int32_t nbatch, co
 }
 
 // ---- result getters ------------------------------------------------------------------------------
+// Two homes of a fold's results: the packed records the device tail wrote into pinned memory (b->packed_ok; the C ABI's
+// own layout, so the bulk getters are copies) or the SeqResult objects of the host tail.
 // structures of a sequence the getters show: all of them, or the first result_limit in rank order (sq_result_limit)
 static inline int64_t shown(const sq_batch *b, const SeqResult &R)
 {
     const int64_t ns = (int64_t)R.preds.size();
     return b->result_limit > 0 ? std::min<int64_t>(ns, b->result_limit) : ns;
 }
+namespace {
+struct PackedRec {                       // view of one packed record (sq_result_pack layout)
+    const char *p; int64_t ns, n, has_ref, evals;
+    const double *met() const { return (const double *)(p + 32); }
+    const double *scores() const { return (const double *)(p + 160); }
+    const uint64_t *masks() const { return (const uint64_t *)(p + 160 + 24 * ns); }
+    const int16_t *levels(int64_t row) const { return (const int16_t *)(p + 160 + 32 * ns) + row * n; }
+};
+inline PackedRec packed_rec(const sq_batch *b, int seq)
+{
+    PackedRec R;
+    R.p = b->h_rec + b->h_rec_off[seq];
+    const int64_t *h = (const int64_t *)R.p;
+    R.ns = h[0]; R.n = h[1]; R.has_ref = h[2]; R.evals = h[3];
+    return R;
+}
+inline int64_t packed_shown(const sq_batch *b, const PackedRec &R) { return b->result_limit > 0 ? std::min<int64_t>(R.ns, b->result_limit) : R.ns; }
+// every record shows what the fold packed (no lower limit set since): the bulk getters are plain copies
+inline bool packed_whole(const sq_batch *b) { return b->result_limit == b->packed_limit || b->result_limit == 0 || (b->packed_limit > 0 && b->result_limit >= b->packed_limit); }
+}  // namespace
 extern "C" int sq_result_limit(sq_batch *b, int32_t k)
 {
     if (!b || k < 0) { sq_set_error("bad argument"); return -1; }
@@ -2160,11 +2341,13 @@ extern "C" int sq_result_limit(sq_batch *b, int32_t k)
 extern "C" int32_t sq_result_nstruct(const sq_batch *b, int32_t seq)
 {
     if (!b || seq < 0 || seq >= b->nseq) return -1;
+    if (b->packed_ok) return (int32_t)packed_shown(b, packed_rec(b, seq));
     return (int32_t)shown(b, b->results[seq]);
 }
 extern "C" int sq_result_consensus(const sq_batch *b, int32_t seq, int16_t *levels)
 {
     if (!b || seq < 0 || seq >= b->nseq) return -1;
+    if (b->packed_ok) { const PackedRec R = packed_rec(b, seq); memcpy(levels, R.levels(0), 2 * (size_t)R.n); return 0; }
     const auto &c = b->results[seq].cons;
     memcpy(levels, c.data(), c.size() * sizeof(int16_t));
     return 0;
@@ -2173,6 +2356,14 @@ extern "C" int sq_result_struct(const sq_batch *b, int32_t seq, int32_t k, int16
                                 uint64_t *pset_mask)
 {
     if (!b || seq < 0 || seq >= b->nseq) return -1;
+    if (b->packed_ok) {
+        const PackedRec R = packed_rec(b, seq);
+        if (k < 0 || k >= (int)packed_shown(b, R)) return -1;
+        memcpy(levels, R.levels(k + 1), 2 * (size_t)R.n);
+        for (int t = 0; t < 3; t++) scores[t] = R.scores()[3 * k + t];
+        *pset_mask = R.masks()[k];
+        return 0;
+    }
     const auto &R = b->results[seq];
     if (k < 0 || k >= (int)shown(b, R)) return -1;
     memcpy(levels, R.preds[k].levels.data(), R.preds[k].levels.size() * sizeof(int16_t));
@@ -2183,6 +2374,13 @@ extern "C" int sq_result_struct(const sq_batch *b, int32_t seq, int32_t k, int16
 extern "C" int sq_result_metrics(const sq_batch *b, int32_t seq, double cons[6], double best[7])
 {
     if (!b || seq < 0 || seq >= b->nseq) return -1;
+    if (b->packed_ok) {
+        const PackedRec R = packed_rec(b, seq);
+        if (!R.has_ref) return 1;
+        for (int t = 0; t < 6; t++) cons[t] = R.met()[t];
+        for (int t = 0; t < 7; t++) best[t] = R.met()[6 + t];
+        return 0;
+    }
     const auto &R = b->results[seq];
     if (!R.has_ref) return 1;
     for (int t = 0; t < 6; t++) cons[t] = R.cons_metrics[t];
@@ -2192,12 +2390,18 @@ extern "C" int sq_result_metrics(const sq_batch *b, int32_t seq, double cons[6],
 extern "C" int64_t sq_result_evals(const sq_batch *b, int32_t seq)
 {
     if (!b || seq < 0 || seq >= b->nseq) return -1;
+    if (b->packed_ok) return packed_rec(b, seq).evals;
     return b->results[seq].evals;
 }
 
 extern "C" int64_t sq_result_pack_size(const sq_batch *b, int32_t seq)
 {
     if (!b || seq < 0 || seq >= b->nseq) return -1;
+    if (b->packed_ok) {
+        const PackedRec R = packed_rec(b, seq);
+        const int64_t ns = packed_shown(b, R);
+        return 8 * 4 + 8 * 16 + 8 * 3 * ns + 8 * ns + 2 * (1 + ns) * R.n;
+    }
     const auto &R = b->results[seq];
     const int64_t ns = shown(b, R), n = (int64_t)R.cons.size();
     return 8 * 4 + 8 * 16 + 8 * 3 * ns + 8 * ns + 2 * (1 + ns) * n;
@@ -2206,6 +2410,19 @@ extern "C" int sq_result_pack(const sq_batch *b, int32_t seq, void *buf, int64_t
 {
     const int64_t need = sq_result_pack_size(b, seq);
     if (need < 0 || cap < need) { sq_set_error("result buffer too small"); return -1; }
+    if (b->packed_ok) {
+        const PackedRec R = packed_rec(b, seq);
+        const int64_t ns = packed_shown(b, R);
+        if (ns == R.ns) { memcpy(buf, R.p, (size_t)need); return 0; }
+        char *p = (char *)buf;                                // a lower limit than the fold packed: the first ns structures
+        int64_t hdr[4] = {ns, R.n, R.has_ref, R.evals};
+        memcpy(p, hdr, 32); p += 32;
+        memcpy(p, R.met(), 128); p += 128;
+        memcpy(p, R.scores(), 24 * (size_t)ns); p += 24 * ns;
+        memcpy(p, R.masks(), 8 * (size_t)ns); p += 8 * ns;
+        memcpy(p, R.levels(0), 2 * (size_t)((1 + ns) * R.n));
+        return 0;
+    }
     const auto &R = b->results[seq];
     const int64_t ns = shown(b, R), n = (int64_t)R.cons.size();
     char *p = (char *)buf;
@@ -2227,6 +2444,7 @@ extern "C" int sq_result_pack(const sq_batch *b, int32_t seq, void *buf, int64_t
 extern "C" int64_t sq_result_pack_all_size(const sq_batch *b)
 {
     if (!b) return -1;
+    if (b->packed_ok && packed_whole(b)) return b->h_rec_off[b->nseq];
     int64_t tot = 0;
     for (int s = 0; s < b->nseq; s++) tot += (sq_result_pack_size(b, s) + 7) & ~(int64_t)7;
     return tot;
@@ -2234,6 +2452,13 @@ extern "C" int64_t sq_result_pack_all_size(const sq_batch *b)
 extern "C" int sq_result_pack_all(const sq_batch *b, void *buf, int64_t cap, int64_t *off)
 {
     if (!b || !buf || !off) { sq_set_error("bad argument"); return -1; }
+    if (b->packed_ok && packed_whole(b)) {                    // the device tail's records, as they lie in pinned memory
+        const int64_t tot = b->h_rec_off[b->nseq];
+        if (tot > cap) { sq_set_error("result buffer too small"); return -1; }
+        memcpy(off, b->h_rec_off, 8 * ((size_t)b->nseq + 1));
+        memcpy(buf, b->h_rec, (size_t)tot);
+        return 0;
+    }
     int64_t o = 0;
     for (int s = 0; s < b->nseq; s++) {
         const int64_t need = sq_result_pack_size(b, s);
@@ -2258,6 +2483,12 @@ extern "C" int sq_result_pack_all(const sq_batch *b, void *buf, int64_t cap, int
 extern "C" int64_t sq_result_dbn_all_size(const sq_batch *b)
 {
     if (!b) return -1;
+    if (b->packed_ok) {
+        if (packed_whole(b)) return b->h_txt_off[b->nseq];
+        int64_t tot = 0;
+        for (int s = 0; s < b->nseq; s++) { const PackedRec R = packed_rec(b, s); tot += (packed_shown(b, R) + 1) * R.n; }
+        return tot;
+    }
     int64_t tot = 0;
     for (int s = 0; s < b->nseq; s++) tot += (shown(b, b->results[s]) + 1) * (int64_t)b->results[s].cons.size();
     return tot;
@@ -2265,6 +2496,27 @@ extern "C" int64_t sq_result_dbn_all_size(const sq_batch *b)
 extern "C" int sq_result_dbn_all(const sq_batch *b, char *buf, int64_t cap, int64_t *off, uint8_t *deep)
 {
     if (!b || !buf || !off || !deep) { sq_set_error("bad argument"); return -1; }
+    if (b->packed_ok) {                                       // the ASCII rows the pack kernel wrote
+        memcpy(deep, b->h_deep, (size_t)b->nseq);
+        if (packed_whole(b)) {
+            const int64_t tot = b->h_txt_off[b->nseq];
+            if (tot > cap) { sq_set_error("text buffer too small"); return -1; }
+            memcpy(off, b->h_txt_off, 8 * ((size_t)b->nseq + 1));
+            memcpy(buf, b->h_txt, (size_t)tot);
+            return 0;
+        }
+        int64_t o2 = 0;
+        for (int s = 0; s < b->nseq; s++) {
+            const PackedRec R = packed_rec(b, s);
+            const int64_t bytes = (packed_shown(b, R) + 1) * R.n;
+            off[s] = o2;
+            if (o2 + bytes > cap) { sq_set_error("text buffer too small"); return -1; }
+            memcpy(buf + o2, b->h_txt + b->h_txt_off[s], (size_t)bytes);
+            o2 += bytes;
+        }
+        off[b->nseq] = o2;
+        return 0;
+    }
     static const char open_ch[31] = {'.', '(', '[', '{', '<', 'A', 'B', 'C', 'D', 'E', 'F', 'G', 'H', 'I', 'J', 'K', 'L', 'M', 'N', 'O',
                                      'P', 'Q', 'R', 'S', 'T', 'U', 'V', 'W', 'X', 'Y', 'Z'};
     static const char close_ch[31] = {'.', ')', ']', '}', '>', 'a', 'b', 'c', 'd', 'e', 'f', 'g', 'h', 'i', 'j', 'k', 'l', 'm', 'n', 'o',

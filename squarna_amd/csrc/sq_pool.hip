@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include "sq_device.h"
 #include "sq_extend.h"
+#include "sq_tail_dev.h"
 
 #define SQ_POOL_NSURV 1024      // survivors within the range, per structure, the choose kernel sorts in LDS
 #define SQ_POOL_CMAX 64         // stems ChooseStems may return for one structure (== lanes of the conflict test)
@@ -210,11 +211,11 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_extend_kernel(SqDevCtx 
     const uint32_t round = pio.hdr->round - 1u;
     auto log_final = [&](uint32_t round_kind, int pos, const SqChainStem *stems, int nst) {
         uint32_t idx = 0, so = 0;
-        if (lane == 0) { idx = atomicAdd(&pio.hdr->nfin, 1u); so = atomicAdd(&pio.hdr->nfin_stems, (uint32_t)nst); }
+        if (lane == 0) { idx = atomicAdd(&pio.fin_ctr[0], 1u); so = atomicAdd(&pio.fin_ctr[1], (uint32_t)nst); }
         idx = (uint32_t)__shfl((int)idx, 0, 64); so = (uint32_t)__shfl((int)so, 0, 64);
-        if (idx >= pio.fin_cap || so + (uint32_t)nst > pio.fin_stem_cap) { if (lane == 0) pio.hdr->ovf = 1; return; }
-        for (int q = lane; q < nst; q += 64) { const SqChainStem x = stems[q]; pio.h_fin_stems[so + q] = SqPoolStem{(int16_t)x.i, (int16_t)x.j, (int16_t)x.len, 0}; }
-        if (lane == 0) pio.h_fin[idx] = SqPoolFin{st.job, round_kind, pos, nst, so, 0u};
+        if (idx >= pio.fin_cap || so + (uint32_t)nst > pio.fin_stem_cap) { if (lane == 0) { pio.hdr->ovf = 1; pio.fin_ctr[2] = 1; } return; }
+        for (int q = lane; q < nst; q += 64) { const SqChainStem x = stems[q]; pio.fin_stems[so + q] = SqPoolStem{(int16_t)x.i, (int16_t)x.j, (int16_t)x.len, 0}; }
+        if (lane == 0) pio.fin[idx] = SqPoolFin{st.job, SQ_FIN_KIND_G0 + round_kind, pos, nst, so, SQ_FIN_SRC_LOG};
     };
     if (st.nstrand < 0) return;                              // full child of the previous round: logged then
     const SqChainStem *pst = pio.stems + rec.toff;
@@ -260,9 +261,10 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_extend_kernel(SqDevCtx 
 // end of a fold: the final header and the job records (evaluation counts) for the host
 extern "C" __global__ __launch_bounds__(256) void sq_pool_publish_kernel(SqPoolIO pio, SqScanArgs a, SqRoundIO io, uint32_t seq)
 {
-    for (int j = threadIdx.x; j < pio.njobs; j += 256) pio.h_jobs[j] = pio.jobs[j];
+    for (int j = threadIdx.x; j < pio.njobs; j += 256) { const SqPoolJob J = pio.jobs[j]; pio.h_jobs[j] = J; pio.job_evals[J.job] = J.evals; }
     __syncthreads();
     if (threadIdx.x == 0) {
+        pio.hdr->nfin = pio.fin_ctr[0]; pio.hdr->nfin_stems = pio.fin_ctr[1];
         *io.h_ctr = *a.ctr;
         *pio.h_hdr = *pio.hdr;
         sq_host_write_flush(io.h_ctr);                   // (the log of final structures: the extend kernels)

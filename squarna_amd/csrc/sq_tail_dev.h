@@ -54,7 +54,7 @@ struct SqTailIO {
     // per sequence
     SqTailSeq *seqs;
     // options
-    int32_t rankby[3]; int32_t toplim, result_limit;
+    int32_t rankby[3]; int32_t toplim, result_limit, conslim;   // conslim: 0 or 1 (more: host tail)
     unsigned long long priority_mask;
     // reference structures
     const int16_t *refp;                          // per position: partner in the known structure, -1 none (NULL: no references)
@@ -63,7 +63,7 @@ struct SqTailIO {
     const double *pow17h; int32_t pow17h_len;     // pow(k / 2, 1.7), host libm (ScoreStruct, :884)
     // outputs (pinned host memory, written by sq_tail_pack_kernel)
     char *rec_buf; char *txt_buf; uint8_t *deep;
-    long long *h_totals;                          // pinned: [0] record bytes, [1] text bytes, [2] fallback flag, [3] entries
+    long long *h_totals;                          // pinned: [0] record bytes, [1] text bytes, [2] fallback flag, [3] entries, [4] most structures shown for one sequence
     uint32_t *fallback;                           // device flag: some sequence needs the host tail
     int32_t tmax;                                 // most stems of any structure (sizes the level scratch)
 };
@@ -74,5 +74,8 @@ __global__ void sq_tail_scan_kernel(SqTailIO t);
 __global__ void sq_tail_scatter_kernel(SqTailIO t);
 __global__ void sq_tail_rank_kernel(SqDevCtx c, SqTailIO t);
 __global__ void sq_tail_offsets_kernel(SqTailIO t, volatile uint32_t *h_seq, uint32_t seq);
-__global__ void sq_tail_pack_kernel(SqDevCtx c, SqTailIO t, int waves);
+__global__ void sq_tail_pack_kernel(SqDevCtx c, SqTailIO t, int rowcap);
+__global__ void sq_tail_done_kernel(SqTailIO t, long long *h_rec_off, long long *h_txt_off, volatile uint32_t *h_seq, uint32_t seq);
+__global__ void sq_fin_append_kernel(const SqPoolFin *src, const SqPoolStem *src_stems, int n, SqPoolFin *fin, SqPoolStem *stems,
+                                     uint32_t *ctr, uint32_t fin_cap, uint32_t stem_cap);
 }
