@@ -11,6 +11,7 @@
 #include "sq_host.h"
 #include "sq_match.h"
 #include "sq_blossom.h"
+#include "sq_algos_dev.h"
 
 #define HIPCK(x) do { int _r = sq_check((x), #x); if (_r) return _r; } while (0)
 
@@ -97,9 +98,11 @@ struct SqAlgoChunk {
     std::vector<SqMatchJob> mj;
     std::vector<std::vector<int>> vid2pos;       // Edmonds: graph vertex -> position
     std::vector<uint64_t> seen_hash;             // (SQ_MWM_POSTHOC) hash of every job's result as the collector read it
+    SqMatchJob *p_mj = nullptr; SqAlgoJob *p_aj = nullptr; SqAlgoStat *h_stats = nullptr;   // pinned, device-side RunAlgo: the
+                                                 // job table in list order, the per-job records, the finish kernel's statistics
     SqMatchJob *p_jobs = nullptr;                // pinned staging: job table and edge list (read by the kernels in place)
     SqMatchEdge *p_edges = nullptr;
-    size_t nedges = 0;
+    size_t nedges = 0, vids = 0;                 // vids: graph vertices of all Edmonds jobs (device-side RunAlgo: vid2pos)
     size_t outints = 0, scratch = 0, bytes = 0;  // device bytes used from the region's base
     int32_t *d_out = nullptr, *d_cnt = nullptr;  // results: in the pinned staging buffer, written by the kernels in place
     uint32_t *flag = nullptr; uint32_t flag_val = 0;   // pinned completion word published by sq_flag_kernel
@@ -172,7 +175,7 @@ static char *stage_buffer(sq_batch *b, int slot, size_t bytes)
 // Host part: edges and scratch layout of jobs[k0..) of `algo`, as many as fit into region_bytes (ck.k1, ck.bytes).
 // The per-job edge lists are built by the worker pool, then packed into pinned staging buffer `slot`.
 static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vector<std::vector<HStem>> &stems, size_t k0,
-                      int algo, size_t region_bytes, int slot, SqAlgoChunk &ck)
+                      int algo, size_t region_bytes, int slot, SqAlgoChunk &ck, const SqAlgoSize *dev_sizes = nullptr)
 {
     ck = SqAlgoChunk();
     ck.algo = algo; ck.k0 = k0;
@@ -182,20 +185,24 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     std::vector<JobBuild> jb(nj);
     sq_pool(b)->parallel_for((int)nj, [&](int q) {
         const SqJob &J = b->jobs[jobs[k0 + q]];
-        const std::vector<HStem> &st_ = stems[k0 + q];
         JobBuild &B = jb[q];
         size_t ncell = 0;
-        for (const HStem &s : st_) ncell += (size_t)s.len;
+        if (dev_sizes) ncell = (size_t)dev_sizes[k0 + q].nedges;        // (the stems stayed on the device: sq_algo_sizes_kernel)
+        else for (const HStem &s : stems[k0 + q]) ncell += (size_t)s.len;
         B.ncell = ncell;
         if (algo == SQ_ALGO_E) {
-            static thread_local std::vector<char> seen;
-            seen.assign((size_t)J.n, 0);
             int nv = 0;
-            for (const HStem &s : st_)
-                for (int t = 0; t < s.len; t++) {
-                    if (!seen[s.i + t]) { seen[s.i + t] = 1; nv++; }
-                    if (!seen[s.j - t]) { seen[s.j - t] = 1; nv++; }
-                }
+            if (dev_sizes) nv = dev_sizes[k0 + q].nv;
+            else {
+                const std::vector<HStem> &st_ = stems[k0 + q];
+                static thread_local std::vector<char> seen;
+                seen.assign((size_t)J.n, 0);
+                for (const HStem &s : st_)
+                    for (int t = 0; t < s.len; t++) {
+                        if (!seen[s.i + t]) { seen[s.i + t] = 1; nv++; }
+                        if (!seen[s.j - t]) { seen[s.j - t] = 1; nv++; }
+                    }
+            }
             B.n = nv; B.need = sq_mwm_scratch_bytes(nv, (int)ncell); B.nout = 2 * (size_t)nv + 2;      // mates + first-assignment ranks + (passes, events)
         } else {
             B.n = J.n;
@@ -206,34 +213,44 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     });
     const double tb1 = sq_now();
     std::vector<SqMatchJob> &mj = ck.mj;
-    size_t scratch = 0, outints = 0, nedges = 0, k1 = k0;
+    size_t scratch = 0, outints = 0, nedges = 0, k1 = k0, vids = 0;
     for (; k1 < jobs.size(); k1++) {
         const JobBuild &B = jb[k1 - k0];
         SqMatchJob m;
         m.edge_off = (int64_t)nedges; m.pos_off = b->jobs[jobs[k1]].pos_off;
         m.n = B.n; m.nedges = (int32_t)B.ncell;
         const size_t fixed = (mj.size() + 1) * sizeof(SqMatchJob) + (nedges + B.ncell) * sizeof(SqMatchEdge) +
-                             (outints + B.nout + mj.size() + 1) * 4 + 4096;
+                             (outints + B.nout + mj.size() + 1) * 4 + 4096 + (dev_sizes ? (vids + (size_t)B.n) * 4 + 1024 : 0);
         if (fixed + scratch + B.need > region_bytes) break;
         m.scratch_off = (int64_t)scratch; scratch += B.need;
         m.out_off = (int64_t)(algo == SQ_ALGO_N ? outints / 2 : outints); outints += B.nout;
         nedges += B.ncell;
+        if (algo == SQ_ALGO_E) vids += (size_t)B.n;
         mj.push_back(m);
     }
-    ck.k1 = k1; ck.outints = outints; ck.scratch = scratch; ck.nedges = nedges;
+    ck.k1 = k1; ck.outints = outints; ck.scratch = scratch; ck.nedges = nedges; ck.vids = vids;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t rr = o; o = (o + bytes + 255) & ~(size_t)255; return rr; };
     take(mj.size() * sizeof(SqMatchJob)); take(nedges * sizeof(SqMatchEdge) + 16);
     take(outints * 4 + 16); take(mj.size() * 4 + 16);
+    if (dev_sizes) { take(vids * 4 + 16); take(sizeof(SqAlgoStat)); }
     ck.bytes = o + scratch;
     if (mj.empty()) return 0;
     // pinned staging: [jobs][edges][results][counts][completion word][per-job completion words]
     const size_t jbytes = (mj.size() * sizeof(SqMatchJob) + 255) & ~(size_t)255;
-    const size_t ebytes = (nedges * sizeof(SqMatchEdge) + 255) & ~(size_t)255;
+    const size_t ebytes = dev_sizes ? 0 : (nedges * sizeof(SqMatchEdge) + 255) & ~(size_t)255;   // (device-side RunAlgo: edges in the region)
     const size_t obytes = (outints * 4 + 255) & ~(size_t)255, cbytes = (mj.size() * 4 + 255) & ~(size_t)255;
     const size_t fbytes = algo == SQ_ALGO_E ? ((mj.size() * 4 + 255) & ~(size_t)255) : 0;   // job flags; the bin heads take as much again
-    char *pin = stage_buffer(b, slot, jbytes + ebytes + obytes + cbytes + 256 + 2 * fbytes);
+    const size_t dbytes = dev_sizes ? jbytes + ((mj.size() * sizeof(SqAlgoJob) + 255) & ~(size_t)255) + 256 : 0;
+    char *pin = stage_buffer(b, slot, jbytes + ebytes + obytes + cbytes + 256 + 2 * fbytes + dbytes);
     if (!pin) return 2;
+    if (dev_sizes) {
+        char *dp = pin + jbytes + ebytes + obytes + cbytes + 256 + 2 * fbytes;
+        ck.p_mj = (SqMatchJob *)dp; ck.p_aj = (SqAlgoJob *)(dp + jbytes);
+        ck.h_stats = (SqAlgoStat *)(dp + jbytes + ((mj.size() * sizeof(SqAlgoJob) + 255) & ~(size_t)255));
+        memcpy(ck.p_mj, mj.data(), mj.size() * sizeof(SqMatchJob));
+        memset(ck.h_stats, 0, sizeof(SqAlgoStat));
+    }
     ck.p_jobs = (SqMatchJob *)pin; ck.p_edges = (SqMatchEdge *)(pin + jbytes);
     ck.d_out = (int32_t *)(pin + jbytes + ebytes); ck.d_cnt = (int32_t *)(pin + jbytes + ebytes + obytes);
     ck.flag = (uint32_t *)(pin + jbytes + ebytes + obytes + cbytes);
@@ -284,6 +301,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     } else
         memcpy(ck.p_jobs, mj.data(), mj.size() * sizeof(SqMatchJob));
     const double tb2 = sq_now();
+    if (dev_sizes) return 0;                              // (the edges are written on the device: sq_algo_edges_kernel)
     // pass 2 (pool): the edges, written straight into the pinned buffer
     ck.vid2pos.resize(mj.size());
     if (getenv("SQ_MWM_POSTHOC")) ck.seen_hash.assign(mj.size(), 0);
@@ -590,9 +608,214 @@ int sq_run_algo(sq_batch *b, const std::vector<int> &jobs, int algo, int levelli
 struct SqAlgoAsync {
     struct Item { int algo; std::vector<int> jobs; std::vector<std::vector<HStem>> stems; SqAlgoChunk ck; bool staged = false; };
     std::vector<Item> items;
+    bool dev = false;                             // the whole of RunAlgo runs on the device (sq_algos_dev.hip)
+    SqAlgoSize *h_sizes = nullptr;                // pinned: per job of all items, in item order
 };
+bool sq_algos_on_device(const SqAlgoAsync *pa) { return pa && pa->dev; }
 
-int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync *&pa)
+// ---- RunAlgo on the device (sq_algos_dev.hip): one AnnotateStems round for the jobs of all three algorithms with the
+// stems left in the arena, the sizes to the host (layout of the scratch, LDS bins of the blossom kernel), the edge lists
+// written by a kernel, the matching kernels on the side streams as before, and behind each of them the kernel that applies
+// RunAlgo's filters and appends the job's stemset to the device log of final structures.  The host neither sees stems nor
+// matchings.  Returns 0: staged, 1: the batch does not qualify (nothing happened that the host-driven form cannot repeat).
+static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
+{
+    static const bool off = getenv("SQ_NO_DEVICE_ALGOS") != nullptr;
+    if (off || pa->items.empty()) return 1;
+    std::vector<int> all;
+    int maxn = 0, tmax = 1;
+    for (auto &it : pa->items) {
+        for (int j : it.jobs) {
+            const SqJob &J = b->jobs[j];
+            maxn = std::max(maxn, J.n);
+            if (it.algo != SQ_ALGO_N) {
+                // Edmonds / Hungarian weigh an edge with stemscore ** 1.7 from the host libm: on the device that is a table
+                // lookup, valid when the score is k 2^-q exactly (dyadic weights, no reactivity factors, no dense matrix)
+                if (!J.default_reacts || J.mat64_off >= 0 || b->psets_dev[J.pset].pow_len <= 0) return 1;
+            }
+            all.push_back(j);
+        }
+    }
+    if (maxn > SQ_ALGO_MAXN || maxn < 1) return 1;
+    tmax = std::max(b->chain_tmax, 1);
+    const size_t fin_lds = sq_algo_finish_lds(maxn, tmax);
+    if (fin_lds > 150 * 1024) return 1;
+    const int S = (int)all.size();
+    // pinned: the sizes of all jobs (slot 3 of the staging buffers is free while a fold runs)
+    // (and, behind them, the per-job records the edges kernel reads: one allocation, the buffer must not move in between)
+    char *pin = stage_buffer(b, 3, sizeof(SqAlgoSize) * (size_t)S + 256 + sizeof(SqAlgoJob) * (size_t)S + 256);
+    if (!pin) return 2;
+    pa->h_sizes = (SqAlgoSize *)pin;
+    int64_t cands_used = 0;
+    int r = sq_round_annotate_dev(b, all, pa->h_sizes, &cands_used);
+    if (r) return r;                                       // (1: does not fit one round)
+    // ---- layout of every item: job table, scratch, LDS classes (algo_build without stems) ----
+    const int64_t half = b->cand_records / 2;
+    size_t base = 0;
+    std::vector<char *> regions(pa->items.size(), nullptr);
+    int sidx = 0;
+    b->algo_used = 0;
+    for (size_t q = 0; q < pa->items.size(); q++) {
+        auto &it = pa->items[q];
+        // algo_build indexes dev_sizes by k0 + q of the item's own list
+        const SqAlgoSize *sz = pa->h_sizes + base;
+        char *region = nullptr;
+        if (it.algo != SQ_ALGO_E && b->algo_bytes > b->algo_used + 65536) {
+            const size_t room = b->algo_bytes - b->algo_used;
+            r = algo_build(b, it.jobs, it.stems, 0, it.algo, room, sidx, it.ck, sz);
+            if (r) return r;
+            if (it.ck.k1 == it.jobs.size() && it.ck.bytes + 256 <= room) {
+                region = b->algo_scratch + b->algo_used;
+                b->algo_used += (it.ck.bytes + 256 + 255) & ~(size_t)255;
+            } else it.ck = SqAlgoChunk();
+        }
+        if (!region) {
+            const int64_t free_rec = std::min<int64_t>(half - b->cand_reserved, b->cand_records - b->cand_reserved - cands_used);
+            if (free_rec <= 0) { b->cand_reserved = 0; return 1; }
+            r = algo_build(b, it.jobs, it.stems, 0, it.algo, (size_t)free_rec * sizeof(SqCand), sidx, it.ck, sz);
+            if (r) return r;
+            if (it.ck.k1 != it.jobs.size()) { b->cand_reserved = 0; return 1; }      // does not fit as one chunk: host-driven form
+            const int64_t used_rec = (int64_t)((it.ck.bytes + 256 + sizeof(SqCand) - 1) / sizeof(SqCand));
+            b->cand_reserved += used_rec;
+            region = (char *)(b->scan.cands + (b->cand_records - b->cand_reserved));
+            region = (char *)(((uintptr_t)region + 255) & ~(uintptr_t)255);
+        }
+        regions[q] = region;
+        base += it.jobs.size();
+        sidx++;
+    }
+    // ---- per-job records of the edges / finish kernels ----
+    // region of a chunk: [jobs (unused)][edges][out ints][counts][vid2pos][stats][scratch]
+    struct Carve { size_t o_edges, o_out, o_cnt, o_vid, o_stat, o_scr; };
+    std::vector<Carve> cv(pa->items.size());
+    // the edges kernel takes one record per structure of the round: all items' records, contiguous, in round order
+    SqAlgoJob *round_aj = (SqAlgoJob *)(pin + ((sizeof(SqAlgoSize) * (size_t)S + 255) & ~(size_t)255));
+    base = 0;
+    for (size_t q = 0; q < pa->items.size(); q++) {
+        auto &it = pa->items[q];
+        const std::vector<SqMatchJob> &mj = it.ck.mj;
+        size_t o = 0;
+        auto take = [&](size_t bytes) { size_t rr = o; o = (o + bytes + 255) & ~(size_t)255; return rr; };
+        take(mj.size() * sizeof(SqMatchJob));
+        cv[q].o_edges = take(it.ck.nedges * sizeof(SqMatchEdge) + 16);
+        cv[q].o_out = take(it.ck.outints * 4 + 16); cv[q].o_cnt = take(mj.size() * 4 + 16);
+        cv[q].o_vid = take(it.ck.vids * 4 + 16); cv[q].o_stat = take(sizeof(SqAlgoStat)); cv[q].o_scr = take(0);
+        size_t vid = 0;
+        for (size_t k = 0; k < mj.size(); k++) {
+            SqAlgoJob aj;
+            aj.job = it.jobs[k]; aj.algo = it.algo;
+            aj.edges = (SqMatchEdge *)(regions[q] + cv[q].o_edges) + mj[k].edge_off;
+            aj.vid2pos = (int32_t *)(regions[q] + cv[q].o_vid) + vid;
+            if (it.algo == SQ_ALGO_E) vid += (size_t)mj[k].n;
+            it.ck.p_aj[k] = aj;
+            round_aj[base + k] = aj;
+        }
+        base += mj.size();
+    }
+    // ---- launches: edges on the batch stream (it owns the arena), then every item on its side stream ----
+    hipStream_t st = b->stream;
+    hipLaunchKernelGGL(sq_algo_edges_kernel, dim3(S), dim3(256), 0, st, b->ctx, b->lane_full.d_structs, [&] { SqScanArgs a = b->scan; a.ctr = b->lane_full.d_ctr; return a; }(), round_aj);
+    HIPCK(hipGetLastError());
+    if (!b->class_ev) HIPCK(hipEventCreateWithFlags(&b->class_ev, hipEventDisableTiming));
+    if (!b->edges_ev) HIPCK(hipEventCreateWithFlags(&b->edges_ev, hipEventDisableTiming));
+    HIPCK(hipEventRecord(b->edges_ev, st));
+    if (fin_lds > 64 * 1024) sq_max_dynamic_lds((const void *)sq_algo_finish_kernel, 160 * 1024);
+    sidx = 0;
+    for (size_t q = 0; q < pa->items.size(); q++) {
+        auto &it = pa->items[q];
+        SqAlgoChunk &ck = it.ck;
+        const int ss = side_of(b, sidx);
+        if (!b->side[ss]) { if (sq_check(hipStreamCreateWithFlags(&b->side[ss], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
+        hipStream_t cs = b->side[ss];
+        HIPCK(hipStreamWaitEvent(cs, b->edges_ev, 0));
+        ck.st = cs;
+        char *region = regions[q];
+        const SqMatchEdge *d_edges = (const SqMatchEdge *)(region + cv[q].o_edges);
+        int32_t *d_out = (int32_t *)(region + cv[q].o_out), *d_cnt = (int32_t *)(region + cv[q].o_cnt);
+        SqAlgoStat *d_stat = (SqAlgoStat *)(region + cv[q].o_stat);
+        HIPCK(hipMemsetAsync(d_stat, 0, sizeof(SqAlgoStat), cs));
+        const int nj = (int)ck.mj.size();
+        hipEvent_t pe0;
+        const int pslot = it.algo == SQ_ALGO_E ? 4 : it.algo == SQ_ALGO_H ? 5 : 6;
+        sq_prof_begin(b, pslot, cs, &pe0);
+        int rl;
+        if (it.algo == SQ_ALGO_N)
+            rl = sq_launch_matching(it.algo, ck.mj.data(), nj, ck.p_mj, d_edges, ck.nedges, nullptr, region + cv[q].o_scr, d_out, d_cnt,
+                                    b->ctx.codes, nullptr, ck.flag_val, cs);
+        else {
+            // the table sorted by LDS need, in size classes.  Edmonds folded alone: its first class (the largest graphs, the
+            // critical path) on this stream, the others in front of the short kernels on their stream, joined before the
+            // finish kernel
+            rl = 0;
+            hipStream_t other = nullptr;
+            if (it.algo == SQ_ALGO_E && ck.classes.size() > 1 && side_of(b, 1) != ss) {
+                const int s2 = side_of(b, 1);
+                if (!b->side[s2]) { if (sq_check(hipStreamCreateWithFlags(&b->side[s2], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
+                other = b->side[s2];
+                HIPCK(hipStreamWaitEvent(other, b->edges_ev, 0));
+            }
+            for (size_t cidx = 0; cidx < ck.classes.size() && !rl; cidx++) {
+                const SqAlgoChunk::Class &c2 = ck.classes[cidx];
+                rl = sq_launch_matching(it.algo, ck.sorted.data() + c2.start, c2.count, ck.p_jobs + c2.start, d_edges, ck.nedges,
+                                        const_cast<SqMatchEdge *>(d_edges), region + cv[q].o_scr, d_out, d_cnt, b->ctx.codes, nullptr, ck.flag_val,
+                                        (cidx > 0 && other) ? other : cs,
+                                        ck.p_jobs + c2.start, ck.bin_head ? ck.bin_head + c2.start : nullptr, b->inflight);
+            }
+            if (other && !rl) { HIPCK(hipEventRecord(b->class_ev, other)); HIPCK(hipStreamWaitEvent(cs, b->class_ev, 0)); }
+        }
+        if (rl) return sq_check((hipError_t)rl, "matching kernel launch");
+        sq_prof_end(b, pslot, cs, pe0);
+        hipLaunchKernelGGL(sq_algo_finish_kernel, dim3(nj), dim3(64), fin_lds, cs, b->ctx, ck.p_aj, ck.p_mj, d_out, d_cnt, levellimit_opt,
+                           b->d_fin, b->d_fin_stems, b->d_fin_ctr, b->fin_cap, b->fin_stem_cap, d_stat, tmax);
+        hipLaunchKernelGGL(sq_algo_publish_kernel, dim3(1), dim3(1), 0, cs, d_stat, ck.h_stats, ck.p_mj, d_out, it.algo == SQ_ALGO_E ? 1 : 0,
+                           ck.flag, ck.flag_val);
+        HIPCK(hipGetLastError());
+        it.staged = true;
+        sidx++;
+    }
+    pa->dev = true;
+    return 0;
+}
+
+// waits for the device-side RunAlgo of a fold (the stemsets are in the device log by then)
+static int algos_end_dev(sq_batch *b, SqAlgoAsync *pa)
+{
+    int r = 0;
+    for (size_t q = pa->items.size(); q-- > 0 && !r;) {
+        SqAlgoChunk &ck = pa->items[q].ck;
+        volatile uint32_t *flag = ck.flag;
+        uint64_t spins = 0;
+        const bool relaxed = sq_relaxed_waits(b);
+        const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
+        while (*flag != ck.flag_val) {
+            if ((++spins & poll_mask) == 0) {
+                const hipError_t qe = hipStreamQuery(ck.st);
+                if (qe != hipErrorNotReady) {
+                    if (qe != hipSuccess) { r = sq_check(qe, "matching kernel"); break; }
+                    if (*flag != ck.flag_val) { hipStreamSynchronize(ck.st); if (*flag != ck.flag_val) { sq_set_error("matching kernel did not signal completion"); r = 2; break; } }
+                }
+            }
+            sq_wait_step(spins, relaxed);
+        }
+        if (r) break;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const SqAlgoStat hs = *ck.h_stats;
+        if (hs.bad == 1) { sq_set_error("blossom capacity exceeded"); r = -3; }
+        else if (hs.bad) { sq_set_error("stem capacity of RunAlgo's filters exceeded"); r = -3; }
+        else if (hs.level_ovf) { sq_set_error("more than 64 pseudoknot levels"); r = -3; }
+        if (pa->items[q].algo == SQ_ALGO_E && hs.graphs) {
+            std::lock_guard<std::mutex> lk(b->mwm_mu);
+            b->mwm_stats[0] += (int64_t)hs.graphs; b->mwm_stats[1] += (int64_t)hs.passes;
+            const int64_t np = (int64_t)(hs.max_pass_job >> 32);
+            if (np > b->mwm_stats[2]) { b->mwm_stats[2] = np; b->mwm_stats[3] = hs.max_events; b->mwm_stats[4] = hs.max_n; b->mwm_stats[5] = hs.max_m; }
+        }
+    }
+    for (int k = 0; k < 3; k++) if (b->side[k]) hipStreamSynchronize(b->side[k]);
+    b->cand_reserved = 0;
+    return r;
+}
+
+int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync *&pa, int levellimit_opt, bool want_dev)
 {
     pa = new SqAlgoAsync();
     b->algo_used = 0;
@@ -604,6 +827,13 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
         pa->items.push_back(std::move(it));
     }
     if (pa->items.empty()) return 0;
+    if (want_dev) {
+        const int rd = algos_begin_dev(b, pa, levellimit_opt);
+        if (rd == 0) return 0;
+        if (rd != 1) return rd;
+        for (auto &it : pa->items) { it.ck = SqAlgoChunk(); it.staged = false; }   // the host-driven form, from scratch
+        b->algo_used = 0; b->cand_reserved = 0;
+    }
     const bool async = !getenv("SQ_ALGO_SYNC");
     const int64_t half = b->cand_records / 2;          // at most half of the arena is lent to the matching kernels
     int sidx = 0;
@@ -690,6 +920,7 @@ void sq_algos_abandon(sq_batch *b, SqAlgoAsync *pa)
 int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<JobSets> &sets, const SqAlgoEndHooks *hooks)
 {
     int r = 0;
+    if (pa->dev) { r = algos_end_dev(b, pa); delete pa; return r; }
     // collect staged work first, release the reservation, then run what was not staged
     for (auto &it : pa->items) {
         JobSets js; js.algo = it.algo; js.jobs = it.jobs; js.sets.assign(it.jobs.size(), {});

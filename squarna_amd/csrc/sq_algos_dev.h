@@ -1,0 +1,44 @@
+// sq_algos_dev.h -- records of the device-side RunAlgo (sq_algos_dev.hip)
+#pragma once
+#include <stdint.h>
+#include "sq_match.h"
+#include "sq_device.h"
+
+#define SQ_ALGO_MAXN 4096          // longest sequence the device-side RunAlgo takes (LDS of the sizes / edges kernels)
+
+struct SqAlgoSize {                // per E / H / N job after its AnnotateStems pass (pinned, read by the host)
+    int32_t nedges;                // cells of its stems
+    int32_t nv;                    // distinct positions on them (Edmonds: graph vertices)
+    int32_t nok;                   // stems
+    int32_t pad;
+};
+struct SqAlgoJob {                 // per job, for the edges / finish kernels (pinned, written by the host once the sizes are known)
+    int32_t job, algo;             // batch job index, SQ_ALGO_*
+    SqMatchEdge *edges;            // device: the job's edge list
+    int32_t *vid2pos;              // device, Edmonds: graph vertex -> sequence position
+};
+struct SqAlgoStat {                // per launch of the finish kernel (device; sq_algo_publish_kernel copies it to the host)
+    uint32_t bad;                  // 1: blossom capacity exceeded, 2: stem capacity exceeded
+    uint32_t level_ovf;
+    unsigned long long max_pass_job;   // (scan passes << 32) | job row: the blossom kernel's critical path
+    unsigned long long passes, graphs;
+    long long max_events, max_n, max_m;
+};
+
+#ifdef __HIPCC__
+extern "C" {
+__global__ void sq_algo_sizes_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqAlgoSize *sizes);
+__global__ void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs);
+__global__ void sq_algo_finish_kernel(SqDevCtx c, const SqAlgoJob *jobs, const SqMatchJob *mj, const int32_t *out, const int32_t *cnt,
+                                      int levellimit_opt, SqPoolFin *fin, SqPoolStem *fin_stems, uint32_t *fin_ctr, uint32_t fin_cap,
+                                      uint32_t fin_stem_cap, SqAlgoStat *stats, int tcap);
+__global__ void sq_algo_publish_kernel(SqAlgoStat *stats, SqAlgoStat *h_stats, const SqMatchJob *mj, const int32_t *out, int is_edmonds,
+                                       uint32_t *flag, uint32_t value);
+}
+// dynamic LDS of sq_algo_finish_kernel for sequences up to n nt whose structures hold up to tcap stems
+static inline size_t sq_algo_finish_lds(int n, int tcap)
+{
+    const size_t half = (size_t)n / 2 + 2;
+    return ((8 * half + 15) & ~(size_t)15) + 8 * half + 2 * (half + 8) + sq_extend_lds_bytes(tcap) + 64;
+}
+#endif

@@ -1,0 +1,343 @@
+// sq_algos_dev.hip -- RunAlgo (SQRNdbnseq.py:548-595) around the matching kernels, on the device.
+//
+// The host-driven form (sq_algos.hip) brings the AnnotateStems pass of every E / H / N job to the host, builds the edge
+// lists there, reads the matchings back and runs the reference's stem filters in C++: the largest host phase of a fold.
+// Here the stems never leave the device:
+//   sq_algo_sizes_kernel    per job: number of edges (= cells of its stems) and, for Edmonds, of graph vertices -- the
+//                           one thing the host needs (it lays out scratch and plans the blossom kernel's LDS bins)
+//   sq_algo_edges_kernel    per job: the stems in the reference's emission order (key ascending), their cells as the
+//                           edge list the matching kernels read -- weights stemscore ** 1.7 from the host-libm table of the
+//                           paramset (SQRNalgos.py:101,122), Nussinov: the score itself (:49) --, for Edmonds the
+//                           vertex numbering by first appearance (networkx's node order, :98-109)
+//   sq_algo_finish_kernel   per job, behind the matching kernel: matched pairs (Edmonds: mates; Hungarian: mutual
+//                           assignments of stem cells, :130-133; Nussinov: BackTrack's list) -> PairsToStems -> the score /
+//                           length filter with exactly re-summed cells -> pseudoknot level limit -> short pseudoknotted
+//                           stems dropped (:570-595) -> the job's stemset appended to the device log of final structures
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/squarna_hip.h"
+#include "sq_device.h"
+#include "sq_extend.h"
+#include "sq_match.h"
+#include "sq_tail_dev.h"
+#include "sq_algos_dev.h"
+
+// exact scoremat cell: the expressions of sq_cell_exact (sq_kernels.hip), restated here (separate translation unit)
+__device__ __forceinline__ double sq_algo_cell(const SqDevCtx &c, const SqJob &jb, const SqPsetDev *ps, int i, int j)
+{
+    if (jb.mat64_off >= 0) return c.mat64[jb.mat64_off + (int64_t)i * jb.n + j];
+    const uint8_t *codes = c.codes + jb.pos_off;
+    const double w = ps->w[codes[i] * 32 + codes[j]];
+    if (jb.default_reacts) return w;
+    double rf;
+    if (jb.rf_idx >= 0) { const uint8_t *lv = c.ridx + jb.pos_off; rf = c.rftab[(int64_t)jb.rf_idx * 256 + lv[i] * 16 + lv[j]]; }
+    else { const double *r = c.reacts + jb.pos_off; rf = sqrt((1.0 - (r[i] + r[j]) / 2.0) * 2.0); }
+    if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
+    return w * rf;
+}
+
+// ---- sizes ----------------------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(256) void sq_algo_sizes_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqAlgoSize *sizes)
+{
+    __shared__ uint32_t s_seen[SQ_ALGO_MAXN / 32];
+    __shared__ int s_edges, s_nv;
+    const SqStruct st = structs[blockIdx.x];
+    const SqJob jb = c.jobs[st.job];
+    const int tid = threadIdx.x;
+    const uint32_t nok = a.ok_cnt[st.slot];
+    const SqOk *oks = sq_oks(a, st, jb.cand_cap);
+    for (int w = tid; w < (jb.n + 31) / 32; w += 256) s_seen[w] = 0u;
+    if (tid == 0) { s_edges = 0; s_nv = 0; }
+    __syncthreads();
+    int e = 0;
+    for (uint32_t q = tid; q < nok; q += 256) {
+        const SqOk cd = oks[q];
+        const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
+        e += (int)cd.len;
+        for (int t = 0; t < (int)cd.len; t++) {
+            atomicOr(&s_seen[(i0 + t) >> 5], 1u << ((i0 + t) & 31));
+            atomicOr(&s_seen[(j0 - t) >> 5], 1u << ((j0 - t) & 31));
+        }
+    }
+    atomicAdd(&s_edges, e);
+    __syncthreads();
+    int nv = 0;
+    for (int w = tid; w < (jb.n + 31) / 32; w += 256) nv += __popc(s_seen[w]);
+    atomicAdd(&s_nv, nv);
+    __syncthreads();
+    if (tid == 0) sizes[blockIdx.x] = SqAlgoSize{s_edges, s_nv, (int32_t)nok, 0};
+}
+
+// ---- edge lists -----------------------------------------------------------------------------------------------------
+// scratch of a structure: the SqKey part of its candidate slice (dead once the bpscore filter has run):
+// [nok x uint32 sorted survivor index][nok x uint32 first edge of that stem]
+extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs)
+{
+    __shared__ int32_t s_first[SQ_ALGO_MAXN];                          // Edmonds: first edge slot a position appears in
+    __shared__ int16_t s_id[SQ_ALGO_MAXN];                             // position -> vertex id
+    __shared__ uint32_t s_wsum[4], s_run;
+    const SqStruct st = structs[blockIdx.x];
+    const SqJob jb = c.jobs[st.job];
+    const SqAlgoJob aj = jobs[blockIdx.x];
+    const SqPsetDev *ps = c.psets + jb.pset;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = jb.n;
+    const uint32_t nok = a.ok_cnt[st.slot];
+    const SqOk *oks = sq_oks(a, st, jb.cand_cap);
+    uint32_t *sidx = reinterpret_cast<uint32_t *>(sq_keys(a, st));
+    uint32_t *eoff = sidx + nok;
+    // the reference's emission order: anti-diagonal ascending, then row ascending == key ascending (keys are distinct)
+    for (uint32_t x = tid; x < nok; x += 256) {
+        const uint32_t kx = oks[x].key;
+        uint32_t r = 0;
+        for (uint32_t y = 0; y < nok; y++) r += oks[y].key < kx ? 1u : 0u;
+        sidx[r] = x;
+    }
+    if (tid == 0) s_run = 0;
+    __threadfence_block();
+    __syncthreads();
+    // first edge of every stem: exclusive prefix sum of the lengths in that order
+    for (uint32_t x0 = 0; x0 < nok; x0 += 256) {
+        const uint32_t x = x0 + tid;
+        const uint32_t len = x < nok ? oks[sidx[x]].len : 0u;
+        uint32_t inc = len;                                             // inclusive scan inside the wave
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        uint32_t before = s_run;
+        for (int w = 0; w < wave; w++) before += s_wsum[w];
+        if (x < nok) eoff[x] = before + inc - len;
+        __syncthreads();
+        if (tid == 0) s_run += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (aj.algo == SQ_ALGO_E) {
+        // networkx numbers the nodes in order of first appearance in the edge list (v before w of every edge)
+        for (int p = tid; p < n; p += 256) s_first[p] = 0x7FFFFFFF;
+        __syncthreads();
+        for (uint32_t x = tid; x < nok; x += 256) {
+            const SqOk cd = oks[sidx[x]];
+            const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
+            const int e0 = (int)eoff[x];
+            for (int t = 0; t < (int)cd.len; t++) { atomicMin(&s_first[i0 + t], 2 * (e0 + t)); atomicMin(&s_first[j0 - t], 2 * (e0 + t) + 1); }
+        }
+        __syncthreads();
+        for (int p = tid; p < n; p += 256) {
+            const int f = s_first[p];
+            int id = -1;
+            if (f != 0x7FFFFFFF) { id = 0; for (int q = 0; q < n; q++) id += s_first[q] < f ? 1 : 0; aj.vid2pos[id] = p; }
+            s_id[p] = (int16_t)id;
+        }
+        __syncthreads();
+    }
+    for (uint32_t x = tid; x < nok; x += 256) {
+        const SqOk cd = oks[sidx[x]];
+        const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
+        double wt = cd.bps;                                             // Nussinov: the score itself (SQRNalgos.py:49)
+        if (aj.algo != SQ_ALGO_N) wt = c.powtab[ps->pow_off + (int)(cd.bps * ps->pow_scale)];   // :101,122 (k 2^-q exactly)
+        SqMatchEdge *e = aj.edges + eoff[x];
+        for (int t = 0; t < (int)cd.len; t++) {
+            const int v = i0 + t, w = j0 - t;
+            e[t] = aj.algo == SQ_ALGO_E ? SqMatchEdge{s_id[v], s_id[w], wt} : SqMatchEdge{v, w, wt};
+        }
+    }
+}
+
+// ---- RunAlgo's filters behind the matching ---------------------------------------------------------------------------
+// one wave per job.  LDS: pairs (p, q) [n / 2 + 1 each], the stems of the matching and the level scratch
+extern "C" __global__ __launch_bounds__(64) void sq_algo_finish_kernel(SqDevCtx c, const SqAlgoJob *jobs, const SqMatchJob *mj, const int32_t *out,
+                                                                      const int32_t *cnt, int levellimit_opt, SqPoolFin *fin, SqPoolStem *fin_stems,
+                                                                      uint32_t *fin_ctr, uint32_t fin_cap, uint32_t fin_stem_cap, SqAlgoStat *stats,
+                                                                      int tcap)
+{
+    extern __shared__ __attribute__((aligned(16))) char sq_fin_dyn[];
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const SqAlgoJob aj = jobs[q];
+    const SqMatchJob m = mj[q];
+    const SqJob jb = c.jobs[aj.job];
+    const SqPsetDev *ps = c.psets + jb.pset;
+    const int n = jb.n, half = n / 2 + 2;
+    int16_t *pp = reinterpret_cast<int16_t *>(sq_fin_dyn), *pq = pp + half, *sp = pq + half, *sq2 = sp + half;   // pairs, sorted pairs
+    double *bps = reinterpret_cast<double *>(sq_fin_dyn + ((8 * (size_t)half + 15) & ~(size_t)15));               // per stem
+    int16_t *keep = reinterpret_cast<int16_t *>(bps + half);                                                      // kept stem indices
+    SqExtendLds L = sq_extend_lds(reinterpret_cast<char *>(keep + half + ((half & 1) ? 1 : 0) + 4), tcap);
+    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); };
+    // ---- the matched pairs ----
+    int np = 0;
+    if (aj.algo == SQ_ALGO_E) {
+        const int32_t *mate = out + m.out_off;
+        const int nv = m.n;
+        if (nv > 0 && mate[0] == -2) { if (lane == 0) stats->bad = 1; return; }       // blossom capacity exceeded
+        if (lane == 0 && nv > 0) {                                       // measurement: the graph with the most scan passes
+            const unsigned long long key = ((unsigned long long)(uint32_t)mate[2 * nv] << 32) | (uint32_t)q;
+            atomicMax(&stats->max_pass_job, key);
+            atomicAdd(&stats->passes, (unsigned long long)(uint32_t)mate[2 * nv]);
+            atomicAdd(&stats->graphs, 1ull);
+        }
+        for (int v0 = 0; v0 < nv; v0 += 64) {
+            const int v = v0 + lane;
+            const int mt = v < nv ? mate[v] : -1;
+            const bool is = v < nv && mt > v;
+            const unsigned long long bal = __ballot(is);
+            if (is) {
+                const int k = np + __popcll(bal & ((1ull << lane) - 1ull));
+                int a0 = aj.vid2pos[v], b0 = aj.vid2pos[mt];
+                if (a0 > b0) { const int t = a0; a0 = b0; b0 = t; }
+                pp[k] = (int16_t)a0; pq[k] = (int16_t)b0;
+            }
+            np += __popcll(bal);
+        }
+    } else if (aj.algo == SQ_ALGO_N) {
+        const int32_t *pr = out + 2 * m.out_off;
+        np = cnt[q];
+        for (int k = lane; k < np; k += 64) {
+            int a0 = pr[2 * k], b0 = pr[2 * k + 1];
+            if (a0 > b0) { const int t = a0; a0 = b0; b0 = t; }
+            pp[k] = (int16_t)a0; pq[k] = (int16_t)b0;
+        }
+    } else {
+        // Hungarian (SQRNalgos.py:130-133): k < sol[k] with more than 3 positions (or a separator) between, assigned
+        // mutually, on a cell of the matrix that is not zero == a cell of a stem whose score ** 1.7 is not zero
+        const int32_t *sol = out + m.out_off;
+        const uint8_t *codes = c.codes + jb.pos_off;
+        const SqMatchEdge *ed = aj.edges;
+        const int ne = m.nedges;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int kk = k0 + lane;
+            bool is = false;
+            int sk = -1;
+            if (kk < n) {
+                sk = sol[kk];
+                is = sk >= 0 && kk < sk;
+                if (is) {
+                    bool far = kk < sk - 3;
+                    if (!far) for (int x = kk + 1; x < sk; x++) if (codes[x] == SQ_CODE_SEP1 || codes[x] == SQ_CODE_SEP2) { far = true; break; }
+                    is = far && sol[sk] == kk;
+                }
+                if (is) {
+                    // the edge list is sorted by (v + w, v): binary search for the cell (kk, sk)
+                    int lo = 0, hi = ne;
+                    const int ks = kk + sk;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const int es = ed[mid].v + ed[mid].w;
+                        if (es < ks || (es == ks && ed[mid].v < kk)) lo = mid + 1; else hi = mid;
+                    }
+                    is = lo < ne && ed[lo].v == kk && ed[lo].w == sk && !(-ed[lo].weight == 0);
+                }
+            }
+            const unsigned long long bal = __ballot(is);
+            if (is) { const int k = np + __popcll(bal & ((1ull << lane) - 1ull)); pp[k] = (int16_t)kk; pq[k] = (int16_t)sk; }
+            np += __popcll(bal);
+        }
+    }
+    wsync();
+    // ---- sorted(pairs) (:570), PairsToStems (:498-517) ----
+    for (int k = lane; k < np; k += 64) {
+        const int a0 = pp[k], b0 = pq[k];
+        int r = 0;
+        for (int y = 0; y < np; y++) { const int a1 = pp[y], b1 = pq[y]; r += (a1 < a0 || (a1 == a0 && b1 < b0)) ? 1 : 0; }
+        sp[r] = (int16_t)a0; sq2[r] = (int16_t)b0;
+    }
+    wsync();
+    // stems into L.i / L.j / L.len: a pair starts a stem unless it stacks onto its predecessor in the sorted list
+    int T = 0;
+    for (int k0 = 0; k0 < np; k0 += 64) {
+        const int k = k0 + lane;
+        const bool start = k < np && !(k > 0 && sp[k - 1] + 1 == sp[k] && sq2[k - 1] == sq2[k] + 1);
+        const unsigned long long bal = __ballot(start);
+        if (start) {
+            const int t = T + __popcll(bal & ((1ull << lane) - 1ull));
+            int len = 1;
+            while (k + len < np && sp[k + len - 1] + 1 == sp[k + len] && sq2[k + len - 1] == sq2[k + len] + 1) len++;
+            pp[t] = sp[k]; pq[t] = sq2[k]; keep[t] = (int16_t)len;    // (pp / pq are free again: stems i, j; keep: len for now)
+        }
+        T += __popcll(bal);
+    }
+    wsync();
+    // ---- first filter (:571-579): raw score re-summed from the matrix cells, left to right from 0 ----
+    const double minbps = ps->minbpscore, minlen = ps->minlen;
+    int K = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        bool ok = false;
+        double s = 0;
+        int si = 0, sj = 0, sl = 0;
+        if (t < T) {
+            si = pp[t]; sj = pq[t]; sl = keep[t];
+            for (int k = 0; k < sl; k++) s = s + sq_algo_cell(c, jb, ps, si + k, sj - k);
+            ok = s >= minbps && (double)sl >= minlen;
+        }
+        const unsigned long long bal = __ballot(ok);
+        wsync();                                                         // (every lane has read its keep[t] before the slots are reused)
+        if (ok) {
+            const int k = K + __popcll(bal & ((1ull << lane) - 1ull));
+            if (k < tcap) { L.i[k] = (int16_t)si; L.j[k] = (int16_t)sj; L.len[k] = (int16_t)sl; bps[k] = s; }
+        }
+        K += __popcll(bal);
+    }
+    if (K > tcap) { if (lane == 0) stats->bad = 2; return; }             // (cannot happen: disjoint stems of >= minlen pairs)
+    wsync();
+    // ---- level limit (:581): DBNToPairs(PairsToDBN(pairs, N, levellimit)) drops the levels above the limit ----
+    const int levellimit = levellimit_opt >= 0 ? levellimit_opt : 3 - (n > 500 ? 1 : 0);   // :1043-1044
+    auto levels = [&](int cntT) {                                       // L.lvl of the first cntT stems in L
+        bool anyc = false;
+        for (int t = lane; t < cntT; t += 64) {
+            const int qi = L.i[t], qj = L.j[t];
+            int cc = 0;
+            for (int p = 0; p < cntT; p++) if (sq_chain_cross(qi, qj, L.i[p], L.j[p])) cc += L.len[p];
+            L.cc[t] = cc;
+            anyc |= cc != 0;
+        }
+        const bool cross = __ballot(anyc) != 0ull;
+        __syncthreads();
+        if (cross) sq_stem_levels_wave(L, cntT, lane, &stats->level_ovf);
+        else { for (int t = lane; t < cntT; t += 64) L.lvl[t] = 1; __syncthreads(); }
+    };
+    levels(K);
+    int K2 = 0;
+    for (int t0 = 0; t0 < K; t0 += 64) {                                // compaction in place (destination index <= source index)
+        const int t = t0 + lane;
+        const bool ok = t < K && (levellimit < 0 || L.lvl[t] <= levellimit) && L.lvl[t] <= 49;   // 49 bracket types exist
+        const unsigned long long bal = __ballot(ok);
+        const int si = t < K ? L.i[t] : 0, sj = t < K ? L.j[t] : 0, sl = t < K ? L.len[t] : 0;
+        const double s = t < K ? bps[t] : 0;
+        __syncthreads();
+        if (ok) { const int k = K2 + __popcll(bal & ((1ull << lane) - 1ull)); L.i[k] = (int16_t)si; L.j[k] = (int16_t)sj; L.len[k] = (int16_t)sl; bps[k] = s; }
+        K2 += __popcll(bal);
+        __syncthreads();
+    }
+    levels(K2);                                                          // :582 the levels of what is left
+    // ---- second filter (:586-594): short pseudoknotted stems, then the same thresholds (same sums) ----
+    int nout = 0;
+    for (int t = lane; t < K2; t += 64) nout += (L.lvl[t] > 1 && L.len[t] < 4) ? 0 : 1;
+    nout = sq_wave_sum32(nout);
+    uint32_t idx = 0, so = 0;
+    if (lane == 0) { idx = atomicAdd(&fin_ctr[0], 1u); so = atomicAdd(&fin_ctr[1], (uint32_t)nout); }
+    idx = (uint32_t)__shfl((int)idx, 0, 64); so = (uint32_t)__shfl((int)so, 0, 64);
+    if (idx >= fin_cap || so + (uint32_t)nout > fin_stem_cap) { if (lane == 0) fin_ctr[2] = 1; return; }
+    int w = 0;
+    for (int t0 = 0; t0 < K2; t0 += 64) {                               // the stems stay in sorted order (ascending i)
+        const int t = t0 + lane;
+        const bool ok = t < K2 && !(L.lvl[t] > 1 && L.len[t] < 4);
+        const unsigned long long bal = __ballot(ok);
+        if (ok) fin_stems[so + w + __popcll(bal & ((1ull << lane) - 1ull))] = SqPoolStem{L.i[t], L.j[t], L.len[t], 0};
+        w += __popcll(bal);
+    }
+    if (lane == 0) fin[idx] = SqPoolFin{aj.job, aj.algo == SQ_ALGO_E ? SQ_FIN_KIND_E : aj.algo == SQ_ALGO_H ? SQ_FIN_KIND_H : SQ_FIN_KIND_N, 0, nout, so, SQ_FIN_SRC_LOG};
+}
+
+// behind the finish kernel: the launch's statistics to the host, then the completion word
+extern "C" __global__ void sq_algo_publish_kernel(SqAlgoStat *stats, SqAlgoStat *h_stats, const SqMatchJob *mj, const int32_t *out,
+                                                  int is_edmonds, uint32_t *flag, uint32_t value)
+{
+    SqAlgoStat s = *stats;
+    if (is_edmonds && s.graphs) {
+        const SqMatchJob m = mj[(uint32_t)s.max_pass_job];
+        s.max_events = out[m.out_off + 2 * m.n + 1]; s.max_n = m.n; s.max_m = m.nedges;
+    }
+    *h_stats = s;
+    sq_host_write_flush(h_stats);
+    *flag = value;
+}

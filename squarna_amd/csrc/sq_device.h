@@ -19,6 +19,7 @@ struct SqDevCtx {
     uint32_t *bits;          // diagonal bit matrices (activity of the unmasked BPMatrix, 1 bit per cell)
     const uint32_t *rbpk;    // restraint base pairs, v | (w << 16), per sequence (SqJob::rb_off, nrb)
     const double *rftab;     // reactfactor tables, 256 doubles each (SqJob::rf_idx)
+    const double *powtab;    // stemscore ** 1.7 tables (SqPsetDev::pow_off)
 };
 
 struct SqState {             // per-structure-slot arrays, `stride` elements per slot

@@ -118,6 +118,7 @@ struct sq_batch {
     std::vector<double> rftab;                // host-libm reactfactor tables, 256 doubles each (SqJob::rf_idx)
     std::vector<uint8_t> ridx;                // per position: reactivity level index (SqDevCtx::ridx)
     std::vector<sq_paramset> psets;
+    std::vector<SqPsetDev> psets_dev;         // host copy of the device paramset records (pow_len: has a stemscore ** 1.7 table)
     std::vector<char> pset_dyadic;            // all pair weights are multiples of 2^-10 below 1024 (exact sums in any order)
     std::vector<int> pset_classes;            // letter classes of the scoring kernel's cell table: pairing letters + 1
     std::vector<SqJob> jobs;
@@ -150,6 +151,7 @@ struct sq_batch {
     int inflight = 1;                     // batches folded at the same time (sq_fold_concurrent): sizes the pool, relaxes the wait loops
     int side_streams = 3;                 // side streams of E / H / N: 3, or 2 (H and N share one) with many batches in flight
     hipEvent_t class_ev = nullptr;        // joins the blossom kernel's smaller size classes (on side[1]) into side[0]
+    hipEvent_t edges_ev = nullptr;        // device-side RunAlgo: the edge lists are written (batch stream -> side streams)
     uint32_t out_cap = 0;
     int32_t strand_cap = 0;
     size_t mat32_bytes = 0;
@@ -242,6 +244,10 @@ int sq_prepare_scan(sq_batch *b);
 // one greedy round (or a raw AnnotateStems pass) for a list of structures; results per structure
 int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out);
 
+// AnnotateStems of E / H / N jobs with the stems left on the device (sq_host.hip; used by the device-side RunAlgo)
+struct SqAlgoSize;
+int sq_round_annotate_dev(sq_batch *b, const std::vector<int> &jobs, SqAlgoSize *h_sizes, int64_t *cands_used);
+
 // RunAlgo (SQRNdbnseq.py:548-595) for one of SQ_ALGO_E / H / N over a list of jobs
 int sq_run_algo(sq_batch *b, const std::vector<int> &jobs, int algo, int levellimit_opt,
                 std::vector<std::vector<HStem>> &out);
@@ -255,7 +261,10 @@ struct SqAlgoEndHooks {
     std::function<void(std::vector<JobSets> &)> after_short;
     std::function<void(int, std::vector<HStem> &)> on_e_job;
 };
-int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync *&pa);
+// want_dev: the whole of RunAlgo on the device (sq_algos_dev.hip) when the batch qualifies -- the stemsets then go to the
+// device log of final structures and sq_algos_end returns no sets (sq_algos_on_device(pa) tells)
+int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync *&pa, int levellimit_opt = -1, bool want_dev = false);
+bool sq_algos_on_device(const SqAlgoAsync *pa);
 int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<JobSets> &sets,
                  const SqAlgoEndHooks *hooks = nullptr);
 void sq_algos_abandon(sq_batch *b, SqAlgoAsync *pa);      // error paths: waits for the side streams, releases the arena

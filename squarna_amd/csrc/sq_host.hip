@@ -12,6 +12,7 @@
 #include <vector>
 #include <unordered_map>
 #include "sq_host.h"
+#include "sq_algos_dev.h"
 #include "sq_match.h"
 
 static thread_local std::string g_err;
@@ -257,10 +258,32 @@ static inline bool want_fp32(const sq_batch_desc *d)
     return !(d->batch_flags & SQ_BATCH_NO_FP32);
 }
 
+// stemscore ** 1.7 table of a paramset (SqPsetDev::pow_off): entries needed for sequences up to maxn nt, 0 when the
+// paramset does not qualify (weights not multiples of 2^-10, no E / H algorithm, minbpscore <= 0, table beyond 4 Mi entries)
+static int64_t pow17_entries(const sq_paramset &ps, int maxn, double &scale)
+{
+    scale = 1.0;
+    if (!(ps.algorithms & (SQ_ALGO_E | SQ_ALGO_H)) || !(ps.minbpscore > 0)) return 0;
+    int q = 0;
+    double maxw = 0;
+    for (int k = 0; k < 32 * 32; k++) {
+        if (!ps.inbps[k]) continue;
+        const double w = ps.bpweight[k];
+        if (!(std::fabs(w) <= 1024.0)) return 0;
+        while (q <= 10 && w * std::ldexp(1.0, q) != std::floor(w * std::ldexp(1.0, q))) q++;
+        if (q > 10) return 0;
+        maxw = std::max(maxw, w);
+    }
+    if (!(maxw > 0)) return 0;
+    scale = std::ldexp(1.0, q);
+    const double entries = std::floor((double)(maxn / 2 + 1) * maxw * scale) + 2;
+    return entries <= (double)((int64_t)4 << 20) ? (int64_t)entries : 0;
+}
+
 namespace {
 struct Layout {
-    size_t off_codes, off_flags, off_inc4, off_chain, off_e0, off_reacts, off_ridx, off_jobs, off_psets, off_sdf, off_rftab;
-    int64_t n_rftab;
+    size_t off_codes, off_flags, off_inc4, off_chain, off_e0, off_reacts, off_ridx, off_jobs, off_psets, off_sdf, off_rftab, off_powtab;
+    int64_t n_rftab, pow_entries;
     size_t off_mat32, off_mat64, off_structs, off_strands, off_state, off_cnt, off_ctr, off_cands, off_out;
     size_t off_bits, off_rbpk, off_fb;
     size_t off_crec, off_cstems, off_cstrands, off_csidx, off_cnfin;   // device-chained rounds (sq_chain.hip)
@@ -337,6 +360,9 @@ int plan(const sq_batch_desc *d, Layout &L)
     for (int s = 0; s < d->nseq; s++)
         for (int i = d->seq_off[s]; i < d->seq_off[s + 1]; i++) if (d->reacts[i] != 0.5) { L.n_rftab++; break; }
     L.off_rftab = take(8 * 256 * (size_t)std::max<int64_t>(L.n_rftab, 1));
+    L.pow_entries = 0;
+    for (int p = 0; p < d->npset; p++) { double sc; L.pow_entries += pow17_entries(d->psets[p], L.maxn, sc); }
+    L.off_powtab = take(8 * (size_t)std::max<int64_t>(L.pow_entries, 1));
     L.off_mat32 = take(4 * (size_t)L.mat32_floats);
     L.off_mat64 = take(8 * (size_t)std::max<int64_t>(L.mat64_doubles, 1));
     L.off_structs = take(sizeof(SqStruct) * L.max_structs);
@@ -498,7 +524,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     }
     // ---- paramsets with host-libm pow tables ----
     std::vector<SqPsetDev> pd(d->npset);
-    std::vector<double> sdf;
+    std::vector<double> sdf, powtab;
     for (int p = 0; p < d->npset; p++) {
         const sq_paramset &ps = d->psets[p];
         SqPsetDev &x = pd[p];
@@ -524,6 +550,12 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
                 kletters += any ? 1 : 0;
             }
             b->pset_classes.push_back(kletters + 1);
+        }
+        {
+            double sc = 1.0;
+            const int64_t ne = pow17_entries(ps, L.maxn, sc);
+            x.pow_off = (int32_t)powtab.size(); x.pow_len = (int32_t)ne; x.pow_scale = sc;
+            for (int64_t k = 0; k < ne; k++) powtab.push_back(pow((double)k / sc, 1.7));          // SQRNalgos.py:101,122
         }
         const double bw = ps.bracketweight;
         x.bw_integral = (bw == std::floor(bw) && std::fabs(bw) <= 64) ? 1 : 0;
@@ -639,6 +671,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->ctx.e0c = (uint8_t *)(base + L.off_e0); b->ctx.reacts = (double *)(base + L.off_reacts); b->ctx.ridx = (uint8_t *)(base + L.off_ridx);
     b->ctx.jobs = (SqJob *)(base + L.off_jobs); b->ctx.psets = (SqPsetDev *)(base + L.off_psets);
     b->ctx.sdftab = (double *)(base + L.off_sdf); b->ctx.rftab = (double *)(base + L.off_rftab);
+    b->ctx.powtab = (double *)(base + L.off_powtab);
     b->ctx.mat32 = (float *)(base + L.off_mat32); b->ctx.mat64 = (double *)(base + L.off_mat64);
     b->d_structs = (SqStruct *)(base + L.off_structs); b->d_strands = (SqStrand *)(base + L.off_strands);
     int16_t *stbase = (int16_t *)(base + L.off_state);
@@ -721,7 +754,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     } stager;
     stager.st = st;
     {
-        size_t want = (size_t)L.ltot * 16 + 8 * rftab.size() + 8 * (size_t)L.pow_len + 4 * ((size_t)d->nseq + 1) + sizeof(SqJob) * d->njobs + sizeof(SqPsetDev) * d->npset + 8 * sdf.size() + 4 * rbpk.size() + 16384;
+        size_t want = (size_t)L.ltot * 16 + 8 * rftab.size() + 8 * powtab.size() + 8 * (size_t)L.pow_len + 4 * ((size_t)d->nseq + 1) + sizeof(SqJob) * d->njobs + sizeof(SqPsetDev) * d->npset + 8 * sdf.size() + 4 * rbpk.size() + 16384;
         for (int j = 0; j < d->njobs; j++)
             if (b->jobs[j].has_ext && !(d->mul_shared && d->mul_shared[j])) want += (size_t)b->jobs[j].n * b->jobs[j].n * 8 * (b->jobs[j].has_ext == 1 ? 2 : 1);
         stager.cap = std::min<size_t>(std::max<size_t>(want, (size_t)1 << 20), (size_t)64 << 20) & ~(size_t)255;
@@ -739,6 +772,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     UP(b->ctx.psets, pd.data(), sizeof(SqPsetDev) * d->npset);
     if (!sdf.empty()) UP(b->ctx.sdftab, sdf.data(), 8 * sdf.size());
     if (!rftab.empty()) UP(b->ctx.rftab, rftab.data(), 8 * rftab.size());
+    if (!powtab.empty()) UP(b->ctx.powtab, powtab.data(), 8 * powtab.size());
+    b->psets_dev = pd;                                         // (host copy: which paramsets have a power table)
     b->rftab.swap(rftab);                                      // (host copy: RunAlgo's stem filters re-sum cells, sq_algos.hip)
     if (!rbpk.empty()) UP(b->ctx.rbpk, rbpk.data(), 4 * rbpk.size());
     {
@@ -839,6 +874,7 @@ extern "C" void sq_batch_destroy(sq_batch *b)
     for (int k = 0; k < 3; k++) if (b->side[k]) { hipStreamSynchronize(b->side[k]); hipStreamDestroy(b->side[k]); }
     if (b->lane_stream) { hipStreamSynchronize(b->lane_stream); hipStreamDestroy(b->lane_stream); }
     if (b->class_ev) hipEventDestroy(b->class_ev);
+    if (b->edges_ev) hipEventDestroy(b->edges_ev);
     sq_pinned_put(b->h_structs); sq_pinned_put(b->h_strands); sq_pinned_put(b->h_ctr); sq_pinned_put(b->h_seq);
     sq_pinned_put(b->h_ctr2); sq_pinned_put(b->h_seq2); sq_pinned_put(b->h_out);
     for (int k = 0; k < 4; k++) sq_pinned_put(b->stage_buf[k]);
@@ -1371,6 +1407,63 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
     return 0;
 }
 
+// AnnotateStems(bool, score, rbps, [], minlen, minbpscore) (:553) for a list of jobs, the stems LEFT ON THE DEVICE: structure k
+// of the round = jobs[k] with no selected stems, its survivors (SqOk records) in its slice of the candidate arena, and per
+// job the sizes the host needs to lay out the matching step (sq_algos_dev.hip).  One round, one wait.  Returns 1 when the
+// jobs do not fit one round of the full lane (the caller keeps the host-driven form).
+int sq_round_annotate_dev(sq_batch *b, const std::vector<int> &jobs, SqAlgoSize *h_sizes, int64_t *cands_used)
+{
+    { int r = sq_prepare_scan(b); if (r) return r; }
+    SqLane &ln = b->lane_full;
+    const int S = (int)jobs.size();
+    const int64_t avail = b->cand_records - b->cand_reserved;
+    if (S > ln.max_structs) return 1;
+    int maxn = 0; int64_t cand_off = 0, maxcap = 0; double scan_bytes = 0; bool need_reacts = false;
+    for (int s = 0; s < S; s++) {
+        const SqJob &J = b->jobs[jobs[s]];
+        if (cand_off + J.cand_cap > avail / 2) return 1;    // (the other half of the arena may be lent to the matching kernels)
+        SqStruct &d = ln.h_structs[s];
+        d.job = jobs[s]; d.slot = s; d.subopt = 1.0; d.cand_off = cand_off; d.strand_off = 0; d.nstrand = 0;
+        cand_off += J.cand_cap; maxcap = std::max<int64_t>(maxcap, J.cand_cap);
+        maxn = std::max(maxn, J.n);
+        need_reacts |= !J.default_reacts && !(J.react_levels > 0 && b->pset_classes[J.pset] * J.react_levels <= 32);
+        scan_bytes += 2.0 * J.n * J.n;
+    }
+    *cands_used = cand_off;
+    hipStream_t st = b->stream;
+    SqRoundIO io;
+    io.h_structs = ln.h_structs; io.h_strands = ln.h_strands; io.d_structs = ln.d_structs; io.d_strands = ln.d_strands;
+    io.h_out = ln.h_out; io.d_out = ln.d_out; io.h_cap = ln.h_out_cap; io.out_cap = ln.out_cap;
+    io.h_ctr = ln.h_ctr; io.h_seq = ln.h_seq;
+    SqScanArgs scan = b->scan;
+    scan.ctr = ln.d_ctr;
+    launch_round_kernels(b, st, S, maxn, maxcap, need_reacts, scan_bytes, 2, io, scan, ln.d_structs, ln.d_strands, false);
+    hipLaunchKernelGGL(sq_algo_sizes_kernel, dim3(S), dim3(256), 0, st, b->ctx, ln.d_structs, scan, h_sizes);
+    const uint32_t seq = ++*ln.round_seq;
+    hipLaunchKernelGGL(sq_done_kernel, dim3(1), dim3(1), 0, st, io, scan, seq);
+    HIPCK(hipGetLastError());
+    {
+        volatile uint32_t *flag = ln.h_seq;
+        uint64_t spins = 0;
+        const bool relaxed = sq_relaxed_waits(b);
+        const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
+        while (*flag != seq) {
+            if ((++spins & poll_mask) == 0) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q != hipErrorNotReady) {
+                    if (q != hipSuccess) return sq_check(q, "AnnotateStems round");
+                    if (*flag != seq) { HIPCK(hipStreamSynchronize(st)); if (*flag != seq) { sq_set_error("round did not signal completion"); return 2; } }
+                }
+            }
+            sq_wait_step(spins, relaxed);
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    const SqCounters ctr = *ln.h_ctr;
+    if (ctr.cand_ovf) { sq_set_error("candidate capacity exceeded (raise cand_per_nt)"); return -3; }
+    return 0;
+}
+
 static int run_round_impl(sq_batch *b, SqLane &ln, const std::vector<SView> &structs, int mode,
                           std::vector<std::vector<HStem>> &out, const AlignSink *sink);
 int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::vector<std::vector<HStem>> &out)
@@ -1545,7 +1638,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     SqAlgoAsync *pending = nullptr;
     const double ta = now_s();
     if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_fold] setup before E/H/N begin: %.3f ms (bit matrix launch + job pools)\n", (ta - fold_timer.t0) * 1e3);
-    { CpuScope cpu_(9); r = sq_algos_begin(b, algos, pending); }   // AnnotateStems + matching kernels on side streams
+    // (with the device tail: RunAlgo's filters on the device too when the batch qualifies, sq_algos_dev.hip)
+    { CpuScope cpu_(9); r = sq_algos_begin(b, algos, pending, o.levellimit, dev_tail); }   // AnnotateStems + matching kernels on side streams
+    const bool dev_algos = sq_algos_on_device(pending);
+    if (getenv("SQ_TIMING") && pending) fprintf(stderr, "[sq_fold] RunAlgo for E / H / N: %s\n", dev_algos ? "on the device (sq_algos_dev.hip)" : "host-driven");
     struct PendGuard {                                      // error paths: wait for the side streams, release the arena
         sq_batch *b; SqAlgoAsync *&p;
         ~PendGuard() { if (p) { sq_algos_abandon(b, p); p = nullptr; } }
@@ -2013,11 +2109,12 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             if (hh.nfin_stems) HIPCK(hipMemcpy(Sv.data(), b->d_fin_stems, sizeof(SqPoolStem) * (size_t)hh.nfin_stems, hipMemcpyDeviceToHost));
             const SqPoolFin *F = Fv.data();
             std::vector<uint32_t> start((size_t)b->njobs + 1, 0), ord(hh.nfin);
-            for (uint32_t q = 0; q < hh.nfin; q++) start[(size_t)F[q].job + 1]++;
+            // (entries below SQ_FIN_KIND_G0 are E / H / N stemsets: not the pools')
+            for (uint32_t q = 0; q < hh.nfin; q++) if (F[q].round_kind >= SQ_FIN_KIND_G0) start[(size_t)F[q].job + 1]++;
             for (int j = 0; j < b->njobs; j++) start[(size_t)j + 1] += start[j];
             {
                 std::vector<uint32_t> fillp(start.begin(), start.end() - 1);
-                for (uint32_t q = 0; q < hh.nfin; q++) ord[fillp[F[q].job]++] = q;
+                for (uint32_t q = 0; q < hh.nfin; q++) if (F[q].round_kind >= SQ_FIN_KIND_G0) ord[fillp[F[q].job]++] = q;
             }
             auto one_job = [&](int sx) {
                 const int j = pool_jobs[sx];
@@ -2164,7 +2261,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             const bool host_greedy = b->last_driver == 0 || b->last_driver == 3;
             for (int j = 0; j < b->njobs; j++) {
                 const JobPool &P = pools[j];
-                const int nalgo = __builtin_popcount(algos[j] & (uint32_t)(SQ_ALGO_E | SQ_ALGO_H | SQ_ALGO_N));
+                // (RunAlgo on the device: its stemsets are in the log already, the host lists hold greedy structures only)
+                const int nalgo = dev_algos ? 0 : __builtin_popcount(algos[j] & (uint32_t)(SQ_ALGO_E | SQ_ALGO_H | SQ_ALGO_N));
                 ev[j] = std::max<int64_t>(P.evals - nalgo, 0);
                 for (size_t k = 0; k < P.fin.size(); k++) {           // [E][H][N] first, then the greedy structures, in list order
                     const std::vector<HStem> &f = P.fin[k];
@@ -2179,6 +2277,26 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         if (!rt) rt = sq_tail_device(b, o, ref_off, ref_pairs, has_ref);
         // the structures the device drivers left in the log as host lists (the host tail's input)
         auto collect_device_lists = [&]() -> int {
+            if (dev_algos) {
+                // the E / H / N stemsets the device-side RunAlgo logged: to the front of their job's list, in the order E, H, N
+                uint32_t ctr[4] = {0, 0, 0, 0};
+                HIPCK(hipMemcpy(ctr, b->d_fin_ctr, 16, hipMemcpyDeviceToHost));
+                const uint32_t nf = std::min(ctr[0], b->fin_cap), ns2 = std::min(ctr[1], b->fin_stem_cap);
+                std::vector<SqPoolFin> Fv(nf);
+                std::vector<SqPoolStem> Sv(ns2);
+                if (nf) HIPCK(hipMemcpy(Fv.data(), b->d_fin, sizeof(SqPoolFin) * (size_t)nf, hipMemcpyDeviceToHost));
+                if (ns2) HIPCK(hipMemcpy(Sv.data(), b->d_fin_stems, sizeof(SqPoolStem) * (size_t)ns2, hipMemcpyDeviceToHost));
+                for (uint32_t kind = SQ_FIN_KIND_N + 1; kind-- > 0;)      // N, then H, then E: each goes in front
+                    for (uint32_t q = 0; q < nf; q++) {
+                        const SqPoolFin &e = Fv[q];
+                        if (e.round_kind != kind) continue;
+                        std::vector<HStem> stems((size_t)e.nstems);
+                        for (int t = 0; t < e.nstems; t++) { const SqPoolStem &x = Sv[e.stem_off + t]; stems[t] = HStem{x.i, x.j, x.len, 0.0, 0.0}; }
+                        JobPool &P = pools[e.job];
+                        P.fin.insert(P.fin.begin(), std::move(stems));
+                        P.evals++;
+                    }
+            }
             if (b->last_driver == 1) {
                 const uint32_t nf = *b->chain.h_nfin;
                 for (uint32_t q = 0; q < nf; q++) chain_finish(q);

@@ -43,6 +43,11 @@ struct SqPsetDev {
     int32_t bw_integral;              // bracketweight is an integer -> stemdist index into sdftab
     int32_t sdf_off, sdf_len;         // (1/(1+d))**distcoef table   (SQRNdbnseq.py:726)
     int32_t pad;
+    // stemscore ** 1.7 (SQRNalgos.py:101,122: the Edmonds / Hungarian edge weights) from the host libm, for paramsets whose
+    // pair weights are multiples of 2^-q: a stem score is then k 2^-q exactly and SqDevCtx::powtab[pow_off + k] its power
+    // (only valid for jobs without reactivity factors or dense matrices).  pow_len == 0: no table (host-built edges)
+    int32_t pow_off, pow_len;
+    double pow_scale;                 // 2^q
 };
 
 // One strand (half of a selected stem) of a partial structure, sorted by start.

@@ -463,7 +463,7 @@ int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatch
         int nbins = 0, waves = 1; size_t lds = 0; bool all_in_lds = true;
         sq_mwm_plan(h_jobs, jobs_rw, nj, bin_head, inflight, nbins, waves, lds, all_in_lds);
         sq_max_dynamic_lds((const void *)sq_mwm_kernel, 156 * 1024);
-        if (!all_in_lds) {
+        if (!all_in_lds && dev_edges != edges) {
             // some job keeps its adjacency in global memory and walks the edges in place: give the launch a device copy
             hipError_t e = hipMemcpyAsync(dev_edges, edges, nedges * sizeof(SqMatchEdge), hipMemcpyHostToDevice, st);
             if (e != hipSuccess) return (int)e;
