@@ -535,9 +535,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="nobpp")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="independent SRtest150 batches in flight per GPU (0 = auto: 8, fewer when the ranks of the node "
-                         "share few CPUs -- every batch has a host thread that drives its rounds)")
-    ap.add_argument("--replicas", type=int, default=3,
+                    help="independent SRtest150 batches in flight per GPU (0 = 8)")
+    ap.add_argument("--replicas", type=int, default=6,
                     help="copies of the 219-record SRtest150 set per batch (kernels and host rounds are shared by the copies)")
     ap.add_argument("--workload", default="srtest150", choices=["srtest150", "S300", "S1000", "S2000"])
     ap.add_argument("--sub-batches", type=int, default=0,
@@ -586,7 +585,9 @@ def main():
     names, psets = ParseConfig(builtin_config(args.config))
     prepared = [Prepared(seq, reacts, restr, ref) for _, seq, reacts, restr, ref in recs]
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    K = args.inflight if args.inflight > 0 else min(8, max(1, effective_cpus() // (2 * max(1, local_world))))
+    # (the fold is device-resident: a batch in flight costs its host thread a few launches and waits per round, so the
+    # number of batches in flight does not follow the CPU count any more -- 2 to 4 CPUs are busy with 8 batches)
+    K = args.inflight if args.inflight > 0 else 8
     R = max(1, args.replicas)
     nset = len(prepared)                                      # 219 records
     batches = []
@@ -762,9 +763,8 @@ def main():
                          "how": "ONE 219-record batch alone (a fresh batch, nothing else in flight), median / best of 10 folds"},
         "host": {"cpu_ms_per_step": round(host_cpu / args.steps * 1e3, 1), "busy_cpus": round(host_cpu / dt, 1),
                  "cpu_quota": effective_cpus(),
-                 "note": "rank 0's process CPU time inside the timed region; with (nearly) the quota's worth of CPUs busy the step "
-                         "is bound by the host side of the fold (RunAlgo filters, ranking tails, edge lists, launches), not by "
-                         "the GPU"},
+                 "note": "rank 0's process CPU time inside the timed region (all threads): launches and waits of the fold threads; "
+                         "RunAlgo's filters, the edge lists and the ranking tails run on the device"},
         "kernel_ms_per_fold": kernel_ms,
         "f1": {"mean_FS_consensus": round(fs_c, 4), "mean_FS_best_of_top5": round(fs_b, 4),
                "batches_in_flight_agree": bool(same)},

@@ -26,7 +26,7 @@ _STEM_DT = np.dtype([("i", "<i4"), ("j", "<i4"), ("len", "<i4"), ("reserved", "<
 class Prepared:
     """One input record after the host pre-processing of SQRNdbnseq.py:1001-1037."""
     __slots__ = ("seq", "shortseq", "shortrest", "shortreacts", "shortdbn", "rbps", "rxs",
-                 "rlefts", "rrights", "gapidx", "sepidx", "plain_reacts")
+                 "rlefts", "rrights", "gapidx", "sepidx", "plain_reacts", "refpairs")
 
     def __init__(self, seq, reacts=None, restraints=None, dbn=None):
         seq = seq.upper().replace("T", "U")                          # :1004
@@ -54,6 +54,7 @@ class Prepared:
         else:
             self.shortreacts = np.asarray(reacts, dtype=np.float64)[~gaps].tolist()
         self.shortdbn = None
+        self.refpairs = None                                         # pairs of the known structure (Batch._fold_args), formed once
         if dbn:
             assert len(seq) == len(dbn)
             self.shortseq, self.shortdbn = UnAlign(seq, dbn)         # :1026-1028
@@ -351,7 +352,9 @@ class Batch:
             for k, p in enumerate(self.prepared):
                 if p.shortdbn:
                     has[k] = 1
-                    refs.extend(DBNToPairs(p.shortdbn))
+                    if p.refpairs is None:
+                        p.refpairs = DBNToPairs(p.shortdbn)
+                    refs.extend(p.refpairs)
                 ref_off[k + 1] = len(refs)
             rp = np.array(refs, np.int32).reshape(-1) if refs else np.zeros(2, np.int32)
             self._refs = (ref_off, rp, has)
