@@ -237,6 +237,12 @@ SQ_API int sq_fold_concurrent_n(sq_batch *const *batches, int32_t nbatch, const 
  * the device (poollim == 1), 2 device pools, 3 device pools that outgrew a capacity and were repeated by the host loop.
  * All give identical results; the number is for tests and tuning (max_structs). */
 SQ_API int32_t sq_fold_driver(const sq_batch *b);
+/* Which parts of the batch's last fold ran on the device beyond the kernels of a round: bit 0 -- the ranking tail
+ * (SQRNdbnseq.py:1201-1286: dedupe, ScoreStruct, RankStructs, bracket rows, consensus, metrics; else the host tail took it:
+ * rankbydiff, forced hardrest pairs, conslim > 1, > 4096 final structures of one sequence), bit 1 -- RunAlgo's edge lists and
+ * stem filters (SQRNdbnseq.py:548-595; else host-built: reactivity factors / non-dyadic weights on E / H paramsets,
+ * sequences above 4096 nt).  Identical results either way; for tests and tuning. */
+SQ_API int32_t sq_fold_paths(const sq_batch *b);
 /* Most structures any round of the batch's last fold evaluated at once (device pools: the largest generation; 0 when the
  * host-driven loop ran).  A host that folds a stream of similar batches sizes max_structs from it. */
 SQ_API int64_t sq_fold_peak_structs(const sq_batch *b);

@@ -20,7 +20,7 @@ SYMBOLS = ["sq_version", "sq_last_error", "sq_batch_workspace_bytes", "sq_batch_
            "sq_result_metrics", "sq_result_evals", "sq_result_pack_size", "sq_result_pack",
            "sq_result_pack_all_size", "sq_result_pack_all", "sq_result_dbn_all_size", "sq_result_dbn_all",
            "sq_profile_enable", "sq_profile_get", "sq_profile_reset", "sq_profile_counters", "sq_run_algos",
-           "sq_align_accumulate", "sq_colmatrix_select", "sq_fold_concurrent", "sq_fold_concurrent_n", "sq_fold_driver", "sq_fold_peak_structs", "sq_result_limit",
+           "sq_align_accumulate", "sq_colmatrix_select", "sq_fold_concurrent", "sq_fold_concurrent_n", "sq_fold_driver", "sq_fold_paths", "sq_fold_peak_structs", "sq_result_limit",
            "sq_mwm_workspace_bytes", "sq_mwm", "sq_lsap_workspace_bytes", "sq_lsap",
            "sq_nussinov_workspace_bytes", "sq_nussinov"]
 
@@ -131,6 +131,8 @@ def load():
     L.sq_fold_peak_structs.argtypes = [C.c_void_p]
     L.sq_fold_peak_structs.restype = C.c_int64
     L.sq_fold_driver.argtypes = [C.c_void_p]
+    L.sq_fold_paths.argtypes = [C.c_void_p]
+    L.sq_fold_paths.restype = C.c_int32
     L.sq_fold_driver.restype = C.c_int32
     L.sq_fold_concurrent_n.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FoldOpts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     L.sq_align_accumulate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]

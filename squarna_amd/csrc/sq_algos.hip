@@ -620,7 +620,7 @@ bool sq_algos_on_device(const SqAlgoAsync *pa) { return pa && pa->dev; }
 // matchings.  Returns 0: staged, 1: the batch does not qualify (nothing happened that the host-driven form cannot repeat).
 static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
 {
-    static const bool off = getenv("SQ_NO_DEVICE_ALGOS") != nullptr;
+    const bool off = getenv("SQ_NO_DEVICE_ALGOS") != nullptr;           // (read per fold: tests compare both forms in one process)
     if (off || pa->items.empty()) return 1;
     std::vector<int> all;
     int maxn = 0, tmax = 1;

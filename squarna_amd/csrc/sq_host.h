@@ -146,6 +146,7 @@ struct sq_batch {
     char *algo_scratch = nullptr;         // device scratch of the Hungarian / Nussinov kernels (Layout::off_algo)
     size_t algo_bytes = 0, algo_used = 0;
     int last_driver = 0;                  // sq_fold_driver
+    int last_paths = 0;                   // sq_fold_paths
     int64_t last_peak = 0;                // sq_fold_peak_structs
     int32_t result_limit = 0;             // sq_result_limit (0: the getters show every structure)
     int inflight = 1;                     // batches folded at the same time (sq_fold_concurrent): sizes the pool, relaxes the wait loops

@@ -1641,6 +1641,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // (with the device tail: RunAlgo's filters on the device too when the batch qualifies, sq_algos_dev.hip)
     { CpuScope cpu_(9); r = sq_algos_begin(b, algos, pending, o.levellimit, dev_tail); }   // AnnotateStems + matching kernels on side streams
     const bool dev_algos = sq_algos_on_device(pending);
+    b->last_paths = dev_algos ? 2 : 0;
     if (getenv("SQ_TIMING") && pending) fprintf(stderr, "[sq_fold] RunAlgo for E / H / N: %s\n", dev_algos ? "on the device (sq_algos_dev.hip)" : "host-driven");
     struct PendGuard {                                      // error paths: wait for the side streams, release the arena
         sq_batch *b; SqAlgoAsync *&p;
@@ -2311,6 +2312,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         static const bool tail_check = getenv("SQ_TAIL_CHECK") != nullptr;
         if (rt == 0) {
             tails_done = true;
+            b->last_paths |= 1;
             if (tail_check) {
                 // debug: the host tail over the same structures must give the same packed bytes for every sequence
                 r = collect_device_lists();
@@ -2383,6 +2385,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
 }
 
 extern "C" int32_t sq_fold_driver(const sq_batch *b) { return b ? b->last_driver : -1; }
+extern "C" int32_t sq_fold_paths(const sq_batch *b) { return b ? b->last_paths : -1; }
 extern "C" int64_t sq_fold_peak_structs(const sq_batch *b) { return b ? b->last_peak : -1; }
 
 extern "C" int sq_fold_concurrent(sq_batch *const *batches, int32_t nbatch, const sq_fold_opts *opts,

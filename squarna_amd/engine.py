@@ -332,6 +332,11 @@ class Batch:
         3 device pools repeated by the host loop."""
         return int(self.L.sq_fold_driver(self.h))
 
+    @property
+    def fold_paths(self):
+        """Bit 0: the last fold's ranking tail ran on the device, bit 1: RunAlgo's edge lists and filters did (sq_fold_paths)."""
+        return int(self.L.sq_fold_paths(self.h))
+
     def _fold_args(self, poollim=1000, conslim=1, toplim=5, hardrest=False, rankbydiff=False,
                    rankby=(0, 2, 1), levellimit=None, algos=frozenset(), priority=None):
         o = _lib.FoldOpts()
