@@ -139,7 +139,7 @@ __global__ void sq_chain_done_kernel(SqRoundIO io, SqScanArgs a, SqChainIO cio, 
 __global__ void sq_done_kernel(SqRoundIO io, SqScanArgs a, uint32_t seq);
 __global__ void sq_pool_init_kernel(const SqStruct *h_structs, const SqChain *h_recs, const SqPoolJob *h_jobs, const int32_t *h_jobrec,
                                     int32_t *d_jobrec, int nbatchjobs, SqPoolIO pio, SqScanArgs a, int S0);
-__global__ void sq_pool_choose_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqPoolIO pio);
+__global__ void sq_pool_choose_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqPoolIO pio, int nsurv);
 __global__ void sq_pool_scan_kernel(SqPoolIO pio, SqScanArgs a, SqRoundIO io, int parity, uint32_t seq);
 __global__ void sq_pool_extend_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, int parity);
 __global__ void sq_pool_publish_kernel(SqPoolIO pio, SqScanArgs a, SqRoundIO io, uint32_t seq);
@@ -153,7 +153,8 @@ __global__ void sq_colselect_kernel(const double *matrix, int L, double thr, int
 __global__ void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
 __global__ void sq_bits_kernel(SqDevCtx c, int only_ext);
 __global__ void sq_score_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
-                                SqScanArgs a, SqRoundIO io, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off, int cell_off);
+                                SqScanArgs a, SqRoundIO io, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off, int cell_off,
+                                int str_off, int str_cap);
 __global__ void sq_bps_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
                               SqScanArgs a, SqRoundIO io, int mode, int lds_n, int lds_n_reacts, int surv_off, int cell_off);
 __global__ void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqRoundIO io);

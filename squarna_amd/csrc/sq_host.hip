@@ -1231,7 +1231,8 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
         // short ones leave half of such a block idle behind its set-up (n = 300: 10,000 chains 5.9 -> 4.6 ms, pools
         // of a thousand 24 -> 16 ns per structure and round with 256).  SRtest150 (up to ~500 nt) measures the same
         // either way within the run-to-run spread and keeps 512.
-        const int thr0 = maxn <= 400 ? 256 : 512;
+        static const int short_thr = getenv("SQ_SCORE_SHORT_THREADS") ? atoi(getenv("SQ_SCORE_SHORT_THREADS")) : 128;
+        const int thr0 = maxn <= 200 ? short_thr : (maxn <= 400 ? 256 : 512);
         const int thr = score_threads ? score_threads : (mode == 0 ? thr0 : (parts == 1 && S < 2048 ? 512 : 256));
         // the cell table (K R x (K R | 1) doubles for the batch's largest K R), then
         // mode 0: list of the bpscore survivors of a chunk (5 x threads entries of 8 + 4 + 2 bytes) behind the tables
@@ -1239,9 +1240,14 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
         dyn = (size_t)cell_off + 8 * (size_t)b->cell_entries;
         const int surv_off = (int)((dyn + 15) & ~(size_t)15);
         dyn = (size_t)surv_off + (size_t)14 * (SQ_SCORE_CHUNK + (mode == 0 ? 1 : 0)) * thr;   // (one-pass modes: no carry-over)
+        // mode 0: the structure's strands + skip pointers (10 bytes each) for the longest list a structure of this launch
+        // can have -- device-booked rounds: two strands per stem of the batch's longest stem list; host-driven: 1,024
+        const int str_cap = mode == 0 ? ((chained || pooled) ? std::min(1024, 2 * std::max(b->chain_tmax, 1) + 2) : 1024) : 0;
+        const int str_off = (int)((dyn + 15) & ~(size_t)15);
+        if (mode == 0) dyn = (size_t)str_off + (size_t)10 * str_cap + 16;
         if (mode == 0)
             hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, d_structs, d_strands, b->state,
-                               scan, io, lds_n, lds_nr, lds_ns, surv_off, cell_off);
+                               scan, io, lds_n, lds_nr, lds_ns, surv_off, cell_off, str_off, str_cap);
         else
             hipLaunchKernelGGL(sq_bps_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, d_structs, d_strands, b->state,
                                scan, io, mode, lds_n, lds_nr, surv_off, cell_off);
@@ -1254,7 +1260,13 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
             if (ext_lds > 64 * 1024) sq_max_dynamic_lds((const void *)sq_chain_kernel, 160 * 1024);
             hipLaunchKernelGGL(sq_chain_kernel, dim3(S), dim3(64), ext_lds, st, b->ctx, d_structs, scan, cio, b->chain_tmax);
         }
-        if (pooled) hipLaunchKernelGGL(sq_pool_choose_kernel, dim3(S), dim3(64), 0, st, b->ctx, d_structs, scan, b->pool_io);
+        if (pooled) {
+            // survivors within subopt x best the choose kernel sorts in LDS (18 bytes each): 1,024 for long sequences, 384 up to
+            // 200 nt (measured on SRtest150 under nobpp / alt / greedynobpp: at most a few dozen are ever in range)
+            static const int short_surv = getenv("SQ_POOL_SHORT_NSURV") ? std::max(64, std::min(1024, atoi(getenv("SQ_POOL_SHORT_NSURV")))) : 384;
+            const int nsurv = maxn <= 200 ? short_surv : 1024;
+            hipLaunchKernelGGL(sq_pool_choose_kernel, dim3(S), dim3(64), (size_t)18 * nsurv + 16, st, b->ctx, d_structs, scan, b->pool_io, nsurv);
+        }
     }
 }
 

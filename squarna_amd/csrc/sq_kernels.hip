@@ -749,10 +749,12 @@ __device__ __forceinline__ bool sq_goodloop(int x, int y)             // :615-62
 template <bool FULL>
 __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct *structs, const SqStrand *strands,
                                               const SqState &stt, SqScanArgs &a, const SqRoundIO &io, int mode, int lds_n,
-                                              int lds_n_reacts, int lds_n_state, int surv_off, int cell_off)
+                                              int lds_n_reacts, int lds_n_state, int surv_off, int cell_off, int str_off = 0, int str_cap = 0)
 {
-    __shared__ SqStrand s_str[FULL ? SQ_LDS_STRANDS : 1];
-    __shared__ uint16_t s_skip[FULL ? SQ_LDS_STRANDS : 1];   // 5' strand k closes a block: next strand that can matter after it
+    // (the structure's strands and their skip pointers live in the block's DYNAMIC LDS, sized by the host for the longest
+    // strand list a structure of the launch can have: a static array for 1,024 strands cost every block 10 KB, and LDS a
+    // scoring block holds is LDS its neighbours on the CU -- other scoring blocks, the blossom blocks of the side stream --
+    // cannot get; 150-nt sequences need 780 bytes)
     // Cell values from ONE table: every position carries a combined index ci = class * R + level (class: rank of its
     // letter among the letters the paramset pairs, one extra class for all others; level: index of its reactivity
     // among the sequence's <= 16 distinct values, R = 1 without reactivity factors), and
@@ -766,6 +768,8 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     __shared__ uint8_t s_cls[32];
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];   // letter codes [n] (+ reactivities [n] when they fit)
     double *const s_cell = reinterpret_cast<double *>(s_dyn + cell_off);
+    SqStrand *const s_str = reinterpret_cast<SqStrand *>(s_dyn + str_off);
+    uint16_t *const s_skip = reinterpret_cast<uint16_t *>(s_str + str_cap);   // 5' strand k closes a block: next strand that can matter after it
     const SqStruct st = structs[blockIdx.x];
 #ifdef SQ_SCORE_PROF
     const long long _p0 = wall_clock64(); long long _pa = 0, _pb = 0, _ps = 0;
@@ -778,7 +782,7 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     if (ncand > (uint32_t)jb.cand_cap) ncand = jb.cand_cap;
     if ((uint32_t)blockIdx.y * (uint32_t)nthr >= ncand) return;         // this part has no candidates
     const SqStrand *S = strands + st.strand_off;
-    const bool lds_strands = FULL && st.nstrand <= SQ_LDS_STRANDS;
+    const bool lds_strands = FULL && st.nstrand <= str_cap;
     if (lds_strands) {
         for (int k = tid; k < st.nstrand; k += nthr) s_str[k] = S[k];
         S = s_str;
@@ -1220,9 +1224,9 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
 extern "C" __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SQ_SCORE_WAVES))) void sq_score_kernel(SqDevCtx c, const SqStruct *structs,
                                                                   const SqStrand *strands, SqState stt, SqScanArgs a,
                                                                   SqRoundIO io, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off,
-                                                                  int cell_off)
+                                                                  int cell_off, int str_off, int str_cap)
 {
-    sq_score_body<true>(c, structs, strands, stt, a, io, 0, lds_n, lds_n_reacts, lds_n_state, surv_off, cell_off);
+    sq_score_body<true>(c, structs, strands, stt, a, io, 0, lds_n, lds_n_reacts, lds_n_state, surv_off, cell_off, str_off, str_cap);
 }
 
 // modes 1 / 2 (OptimalStems output, alignment survivor list): the bpscore filter alone, as its own kernel so that its

@@ -53,11 +53,15 @@ extern "C" __global__ __launch_bounds__(256) void sq_pool_init_kernel(const SqSt
     }
 }
 
-extern "C" __global__ __launch_bounds__(64) void sq_pool_choose_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqPoolIO pio)
+extern "C" __global__ __launch_bounds__(64) void sq_pool_choose_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqPoolIO pio, int nsurv)
 {
-    __shared__ uint32_t s_q[SQ_POOL_NSURV], s_key[SQ_POOL_NSURV];
-    __shared__ double s_fin[SQ_POOL_NSURV];
-    __shared__ uint16_t s_ord[SQ_POOL_NSURV];
+    // the survivors within the range, sorted in LDS: room for `nsurv` of them (18 bytes each) in the block's dynamic LDS --
+    // 1,024 for long sequences, fewer for short ones (a block's LDS is LDS its neighbours on the CU cannot get); a
+    // structure with more survivors in range raises the overflow flag and the host repeats the fold with its own loop
+    extern __shared__ __attribute__((aligned(16))) char sq_choose_dyn[];
+    double *const s_fin = reinterpret_cast<double *>(sq_choose_dyn);
+    uint32_t *const s_q = reinterpret_cast<uint32_t *>(s_fin + nsurv), *const s_key = s_q + nsurv;
+    uint16_t *const s_ord = reinterpret_cast<uint16_t *>(s_key + nsurv);
     __shared__ int s_ri[SQ_POOL_CMAX], s_rj[SQ_POOL_CMAX], s_rl[SQ_POOL_CMAX];
     const int lane = threadIdx.x;
     const SqStruct st = structs[blockIdx.x];                // (structs: the chunk of the round's list this launch covers)
@@ -108,10 +112,10 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_choose_kernel(SqDevCtx 
         const bool keep = valid && !(cd.fin < range);
         const unsigned long long m = __ballot(keep);
         const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep && pos < SQ_POOL_NSURV) { s_q[pos] = q; s_fin[pos] = cd.fin; s_key[pos] = cd.key; }
+        if (keep && pos < nsurv) { s_q[pos] = q; s_fin[pos] = cd.fin; s_key[pos] = cd.key; }
         n += __popcll(m);
     }
-    if (n > SQ_POOL_NSURV) {
+    if (n > nsurv) {
         if (lane == 0) { pio.hdr->ovf = 1; pio.nchild[s] = 0; pio.finalflag[s] = 0; }
         return;
     }
