@@ -2080,7 +2080,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             }
             const uint32_t seq = ++*ln.round_seq;
             hipLaunchKernelGGL(sq_pool_scan_kernel, dim3(1), dim3(1024), 0, st, pio, scan, io, parity, seq);
-            hipLaunchKernelGGL(sq_pool_extend_kernel, dim3(S), dim3(64), ext_lds, st, b->ctx, scan, pio, parity);
+            hipLaunchKernelGGL(sq_pool_extend_kernel, dim3(S, 4), dim3(64), ext_lds, st, b->ctx, scan, pio, parity);   // (4 waves share a parent's children)
             if (wait_seq(seq)) return 2;
             rounds++;
             const SqCounters ctr = *ln.h_ctr;

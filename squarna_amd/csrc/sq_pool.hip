@@ -223,16 +223,19 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_extend_kernel(SqDevCtx 
     };
     if (st.nstrand < 0) return;                              // full child of the previous round: logged then
     const SqChainStem *pst = pio.stems + rec.toff;
+    // grid (parents, Y): block (s, y) makes the children y, y + Y, ... of parent s -- the children of a parent are
+    // independent (each in its own slot), and one wave per parent serialised them (the longest kernel of a crowded round)
     if (nch == 0) {
-        if (pio.finalflag[s]) log_final(2u * round + 1u, s, pst, rec.nstems);
+        if (blockIdx.y == 0 && pio.finalflag[s]) log_final(2u * round + 1u, s, pst, rec.nstems);
         return;
     }
+    if ((int)blockIdx.y >= nch) return;
     if (rec.nstems >= pio.pt) { if (lane == 0) pio.hdr->ovf = 1; return; }
     const SqStrand *psrc = pio.strands + st.strand_off;
     const int16_t *pssrc = pio.sidx + st.strand_off;
     const int c0 = pio.child_off[s];
     const SqPoolPick *picks = pio.chosen + (size_t)s * pio.cmax;
-    for (int k = 0; k < nch; k++) {
+    for (int k = blockIdx.y; k < nch; k += gridDim.y) {
         const int cslot = c0 + k;
         if (cslot >= pio.slots) { if (lane == 0) pio.hdr->ovf = 1; return; }
         const SqPoolPick pk = picks[k];
