@@ -281,6 +281,27 @@ SQ_API int sq_result_pack_all(const sq_batch *b, void *buf, int64_t cap, int64_t
  * (sq_result_pack) for those. */
 SQ_API int64_t sq_result_dbn_all_size(const sq_batch *b);
 SQ_API int sq_result_dbn_all(const sq_batch *b, char *buf, int64_t cap, int64_t *off, uint8_t *deep);
+/* ---- text of the drop-in layer (per-record work of RunSQRNdbnseq, in C++ because a batch has thousands of records) ----
+ * sq_dbn_pairs: DBNToPairs (SQRNdbnseq.py:172-207) for nrec dot-bracket lines: line r = text[off[r], off[r+1]); brackets
+ * ( ) [ ] { } < > A..Z / a..z, unmatched closers ignored; line r's pairs, sorted, at pairs[2 pair_off[r] .. 2 pair_off[r+1]). */
+SQ_API int sq_dbn_pairs(const char *text, const int64_t *off, int32_t nrec, int32_t *pairs, int64_t pair_cap, int64_t *pair_off);
+/* sq_write_blocks: the output block of RunSQRNdbnseq (SQRNdbnseq.py:1301-1406: name, sequence, optional reactivities /
+ * restraints / reference lines, the consensus line, up to outplim structure lines with scores, paramset names and metrics)
+ * for every record of a batch whose last fold left packed results (sq_fold_paths bit 0).  The per-record input lines come
+ * '\n'-joined, one line per record in batch order (an empty line: the record has none; a NULL field: no record has one);
+ * seqs are the INPUT sequences (gap columns and separators included: they are re-inserted into every bracket row,
+ * :1239-1246); reacts the already encoded reactivity lines (EncodedReactivities, :82-101).  Record r's block is
+ * buf[off[r], off[r+1]); skipped[r] = 1: the record uses bracket levels beyond the ASCII alphabet, its block is empty and
+ * left to the caller.  Returns the bytes written, or -(bytes needed + 16) when cap is too small (nothing written). */
+typedef struct sq_block_desc {
+    int32_t nrec;
+    const char *names, *seqs, *reacts, *restr, *refs;
+    const int32_t *nameset;         /* [nrec] which list of paramset names a record prints (NULL: list 0)      */
+    const char *const *psnames;     /* [nsets] the names of a configuration's paramsets, '\n'-joined            */
+    int32_t nsets, conslim, outplim;
+} sq_block_desc;
+SQ_API int64_t sq_write_blocks(const sq_batch *b, const sq_block_desc *d, char *buf, int64_t cap, int64_t *off, uint8_t *skipped);
+
 /* R = number of AnnotateStems evaluations the reference algorithm performs for this sequence. */
 SQ_API int64_t sq_result_evals(const sq_batch *b, int32_t seq);
 

@@ -22,7 +22,7 @@ SYMBOLS = ["sq_version", "sq_last_error", "sq_batch_workspace_bytes", "sq_batch_
            "sq_profile_enable", "sq_profile_get", "sq_profile_reset", "sq_profile_counters", "sq_run_algos",
            "sq_align_accumulate", "sq_colmatrix_select", "sq_fold_concurrent", "sq_fold_concurrent_n", "sq_fold_driver", "sq_fold_paths", "sq_fold_peak_structs", "sq_result_limit",
            "sq_mwm_workspace_bytes", "sq_mwm", "sq_lsap_workspace_bytes", "sq_lsap",
-           "sq_nussinov_workspace_bytes", "sq_nussinov"]
+           "sq_nussinov_workspace_bytes", "sq_nussinov", "sq_dbn_pairs", "sq_write_blocks"]
 
 BATCH_NO_FP32 = 1
 
@@ -69,6 +69,12 @@ class BatchDesc(C.Structure):
 class Stem(C.Structure):
     _fields_ = [("i", C.c_int32), ("j", C.c_int32), ("len", C.c_int32), ("reserved", C.c_int32),
                 ("bpscore", C.c_double), ("finscore", C.c_double)]
+
+
+class BlockDesc(C.Structure):
+    _fields_ = [("nrec", C.c_int32), ("names", C.c_char_p), ("seqs", C.c_char_p), ("reacts", C.c_char_p),
+                ("restr", C.c_char_p), ("refs", C.c_char_p), ("nameset", C.POINTER(C.c_int32)),
+                ("psnames", C.POINTER(C.c_char_p)), ("nsets", C.c_int32), ("conslim", C.c_int32), ("outplim", C.c_int32)]
 
 
 class FoldOpts(C.Structure):
@@ -132,6 +138,9 @@ def load():
     L.sq_fold_peak_structs.restype = C.c_int64
     L.sq_fold_driver.argtypes = [C.c_void_p]
     L.sq_fold_paths.argtypes = [C.c_void_p]
+    L.sq_dbn_pairs.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+    L.sq_write_blocks.argtypes = [C.c_void_p, C.POINTER(BlockDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.sq_write_blocks.restype = C.c_int64
     L.sq_fold_paths.restype = C.c_int32
     L.sq_fold_driver.restype = C.c_int32
     L.sq_fold_concurrent_n.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FoldOpts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]

@@ -207,13 +207,40 @@ def Predict(inputfile=None, fileformat="unknown", inputseq=None, configfile=None
         """Fold a batch of records on the GPU, then print every block in input order."""
         preds = [None] * len(batch)
         refsc = [None] * len(batch)
+        texts = [None] * len(batch)
         if not evalonly and not entropy:
             # records with different priority index sets cannot share one fold call
             groups = {}
             for k, rec in enumerate(batch):
                 names = rec[5]
                 groups.setdefault(tuple(sorted(resolve_priority(priority, names))), []).append(k)
+            # The library writes the output blocks itself (sq_write_blocks) when the engine can: the records then carry their
+            # block fields (name, encoded reactivity line, which list of paramset names they print)
+            blocks = getattr(eng, "writes_blocks", False)
+            psnames, psname_idx = [], {}
             for prio, idx in groups.items():
+                if blocks:
+                    from .dbn import EncodedReactivities
+                    recs = []
+                    for k in idx:
+                        name, seq, reacts, restrs, ref, names = batch[k][:6]
+                        key = id(names)
+                        if key not in psname_idx:
+                            psname_idx[key] = len(psnames)
+                            psnames.append(list(names))
+                        rline = str(EncodedReactivities(seq, reacts, reactformat)) if reacts else None
+                        recs.append((seq, reacts, restrs, ref, batch[k][6], None, name, rline, psname_idx[key]))
+                    res = eng.fold_records(recs, priority=set(prio), _blocks=dict(psnames=psnames, conslim=conslim, outplim=outplim),
+                                           **common)
+                    if len(groups) == 1 and not _on_block and hasattr(res, "blocks") and hasattr(res.blocks, "text"):
+                        write_to.write(res.blocks.text)            # every block of the batch, in input order: one write
+                        return
+                    for k, (kind, val) in zip(idx, res):
+                        if kind == "text":
+                            texts[k] = val
+                        else:
+                            preds[k], refsc[k] = val
+                    continue
                 res = eng.fold_records([(batch[k][1], batch[k][2], batch[k][3], batch[k][4], batch[k][6], None)
                                         for k in idx], priority=set(prio), **common)
                 got_ref = getattr(eng, "last_ref_scores", None)
@@ -222,6 +249,12 @@ def Predict(inputfile=None, fileformat="unknown", inputseq=None, configfile=None
                     if got_ref is not None and len(got_ref) == len(idx):
                         refsc[k] = got_ref[q]
         for k, (name, seq, reacts, restrs, ref, names, psets, index) in enumerate(batch):
+            if texts[k] is not None:                               # the library's block: byte for byte RunSQRNdbnseq's
+                if _on_block:
+                    _on_block(index, texts[k])
+                else:
+                    write_to.write(texts[k])
+                continue
             sink = io.StringIO() if _on_block else write_to
             RunSQRNdbnseq(name, seq, reacts, restrs, ref, names, psets, threads, rankbydiff, rankby,
                           hardrest, interchainonly, toplim, outplim, conslim, reactformat, evalonly, poollim,

@@ -74,6 +74,36 @@ for _l in range(1, _NBR + 1):
     _LEVEL_CP[_NBR + 1 - _l] = ord(BRACKETS[_l - 1][1])
 
 
+class _BlockRun:
+    """fold_records(..., _blocks=...) result of one batch whose blocks the library wrote completely."""
+    __slots__ = ("blocks",)
+
+    def __init__(self, blocks):
+        self.blocks = blocks
+
+    def __len__(self):
+        return len(self.blocks)
+
+    def __iter__(self):
+        return (("text", t) for t in self.blocks)
+
+
+class _Blocks:
+    """Output blocks of all records of a batch as ONE string + offsets (a list of per-record slices on demand): a caller
+    that prints them in order writes the string once."""
+    __slots__ = ("text", "off")
+
+    def __init__(self, text, off):
+        self.text, self.off = text, off
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    def __iter__(self):
+        o, t = self.off.tolist(), self.text
+        return (t[o[k]:o[k + 1]] for k in range(len(o) - 1))
+
+
 def _pset_struct(ps):
     out = _lib.ParamSet()
     for key, val in ps["bpweights"].items():                         # SQRNdbnseq.py:282-284
@@ -115,16 +145,18 @@ class Batch:
         self.prepared = prepared
         nseq = len(prepared)
         self.seq_off = np.zeros(nseq + 1, np.int32)
-        for k, p in enumerate(prepared):
-            self.seq_off[k + 1] = self.seq_off[k] + len(p.shortseq)
+        np.cumsum(np.fromiter((len(p.shortseq) for p in prepared), np.int64, nseq), out=self.seq_off[1:])
         ltot = int(self.seq_off[-1])
         self.codes = np.frombuffer(encode_seq(''.join(p.shortseq for p in prepared)), np.uint8).copy() \
             if ltot else np.zeros(1, np.uint8)
         self.flags = np.zeros(max(ltot, 1), np.uint8)
         self.reacts = np.full(max(ltot, 1), 0.5, np.float64)
-        rbp_off = [0]
+        self.rbp_off = np.zeros(nseq + 1, np.int32)
         rbps = []
+        # (most records of a big input are plain: only the ones with restraints or reactivities take the loop)
         for k, p in enumerate(prepared):
+            if p.plain_reacts and not (p.rbps or p.rxs or p.rlefts or p.rrights):
+                continue
             o = int(self.seq_off[k])
             for i in p.rxs:
                 self.flags[o + i] |= 1
@@ -134,28 +166,44 @@ class Batch:
                 self.flags[o + i] |= 4
             if not p.plain_reacts:
                 self.reacts[o:o + len(p.shortseq)] = p.shortreacts
-            rbps.extend(p.rbps)
-            rbp_off.append(len(rbps))
-        self.rbp_off = np.array(rbp_off, np.int32)
+            if p.rbps:
+                rbps.extend(p.rbps)
+                self.rbp_off[k + 1] = len(p.rbps)
+        np.cumsum(self.rbp_off, out=self.rbp_off)
         self.rbps = np.array(rbps, np.int32).reshape(-1) if rbps else np.zeros(2, np.int32)
         # unique paramsets by identity
         uniq, self.psets_py = {}, []
-        job_seq, job_pset = [], []
-        self.seq_jobs = []
-        for k, plist in enumerate(psets_per_record):
-            mine = []
-            for ps in plist:
+        first = psets_per_record[0] if nseq else []
+        if nseq and all(pl is first for pl in psets_per_record):
+            # one configuration for every record (the usual case): the job lists are a repeat / tile
+            idx = []
+            for ps in first:
                 if id(ps) not in uniq:
                     uniq[id(ps)] = len(self.psets_py)
                     self.psets_py.append(ps)
-                mine.append(len(job_seq))
-                job_seq.append(k)
-                job_pset.append(uniq[id(ps)])
-            self.seq_jobs.append(mine)
+                idx.append(uniq[id(ps)])
+            npl = len(first)
+            self.job_seq = np.repeat(np.arange(nseq, dtype=np.int32), npl)
+            self.job_pset = np.tile(np.array(idx, np.int32), nseq)
+            self.seq_jobs = None                                     # (k -> range(k * npl, (k + 1) * npl), formed on demand)
+            self._npl = npl
+        else:
+            job_seq, job_pset = [], []
+            self.seq_jobs = []
+            for k, plist in enumerate(psets_per_record):
+                mine = []
+                for ps in plist:
+                    if id(ps) not in uniq:
+                        uniq[id(ps)] = len(self.psets_py)
+                        self.psets_py.append(ps)
+                    mine.append(len(job_seq))
+                    job_seq.append(k)
+                    job_pset.append(uniq[id(ps)])
+                self.seq_jobs.append(mine)
+            self.job_seq = np.array(job_seq, np.int32)
+            self.job_pset = np.array(job_pset, np.int32)
         self.psets_c = (_lib.ParamSet * len(self.psets_py))(*[_pset_struct(p) for p in self.psets_py])
-        self.job_seq = np.array(job_seq, np.int32)
-        self.job_pset = np.array(job_pset, np.int32)
-        njobs = len(job_seq)
+        njobs = len(self.job_seq)
         d = _lib.BatchDesc()
         d.nseq = nseq
         d.seq_off = _ptr(self.seq_off, C.POINTER(C.c_int32))
@@ -353,15 +401,28 @@ class Batch:
         if self._refs is None:                       # reference pairs are static per batch
             ref_off = np.zeros(self.nseq + 1, np.int32)
             has = np.zeros(max(self.nseq, 1), np.uint8)
-            refs = []
-            for k, p in enumerate(self.prepared):
-                if p.shortdbn:
-                    has[k] = 1
-                    if p.refpairs is None:
-                        p.refpairs = DBNToPairs(p.shortdbn)
-                    refs.extend(p.refpairs)
-                ref_off[k + 1] = len(refs)
-            rp = np.array(refs, np.int32).reshape(-1) if refs else np.zeros(2, np.int32)
+            dbns = [p.shortdbn or "" for p in self.prepared]
+            text = "".join(dbns)
+            if text.isascii():
+                # DBNToPairs (SQRNdbnseq.py:172-207) for all known structures in one library call (sq_dbn_pairs)
+                off = np.zeros(self.nseq + 1, np.int64)
+                np.cumsum([len(x) for x in dbns], out=off[1:])
+                poff = np.zeros(self.nseq + 1, np.int64)
+                rp = np.zeros(max(len(text), 2), np.int32)                  # (a line of n characters has at most n / 2 pairs)
+                _lib.check(self.L.sq_dbn_pairs(text.encode("ascii"), _ptr(off), self.nseq, _ptr(rp), len(rp) // 2, _ptr(poff)))
+                ref_off[:] = poff
+                has[:self.nseq] = [1 if x else 0 for x in dbns]
+                rp = rp[:max(2 * int(poff[-1]), 2)]
+            else:                                                        # (bracket letters beyond ASCII: the Python form)
+                refs = []
+                for k, p in enumerate(self.prepared):
+                    if p.shortdbn:
+                        has[k] = 1
+                        if p.refpairs is None:
+                            p.refpairs = DBNToPairs(p.shortdbn)
+                        refs.extend(p.refpairs)
+                    ref_off[k + 1] = len(refs)
+                rp = np.array(refs, np.int32).reshape(-1) if refs else np.zeros(2, np.int32)
             self._refs = (ref_off, rp, has)
         ref_off, rp, has = self._refs
         return o, ref_off, rp, has
@@ -421,6 +482,51 @@ class Batch:
 
     def _unpack(self, k, buf, base):
         return unpack_result(self.prepared[k], buf, base)
+
+    def write_blocks(self, names, seqs, reactlines, restrs, refs, nameset, psnames, conslim, outplim):
+        """The output blocks of RunSQRNdbnseq (SQRNdbnseq.py:1301-1406) for every record, formed by the library from the
+        packed results of the last fold (sq_write_blocks): list of str, None for a record the library leaves to the
+        caller (bracket levels beyond ASCII).  None when the batch's results are not packed (host tail) or some input
+        line is not ASCII: the caller formats from results_all()."""
+        if not (self.fold_paths & 1):
+            return None
+        fields = []
+        for col in (names, seqs, reactlines, restrs, refs):
+            if all(x is None or x == "" for x in col):
+                fields.append(None)
+                continue
+            text = "\n".join(x or "" for x in col)
+            if not text.isascii():
+                return None
+            fields.append(text.encode("ascii"))
+        if fields[0] is None or fields[1] is None:
+            return None
+        d = _lib.BlockDesc()
+        d.nrec = self.nseq
+        d.names, d.seqs, d.reacts, d.restr, d.refs = fields
+        ns = np.ascontiguousarray(nameset, np.int32)
+        d.nameset = _ptr(ns, C.POINTER(C.c_int32))
+        pn = [("\n".join(x)).encode() for x in psnames]
+        arr = (C.c_char_p * len(pn))(*pn)
+        d.psnames = arr
+        d.nsets, d.conslim, d.outplim = len(pn), int(conslim), int(outplim)
+        off = np.zeros(self.nseq + 1, np.int64)
+        skipped = np.zeros(max(self.nseq, 1), np.uint8)
+        cap = int(self.L.sq_result_dbn_all_size(self.h)) + sum(len(f) for f in fields if f) * 2 + 200 * self.nseq * (2 + int(outplim)) + 4096
+        for _ in range(2):
+            buf = C.create_string_buffer(cap)
+            n = int(self.L.sq_write_blocks(self.h, C.byref(d), buf, cap, _ptr(off), _ptr(skipped)))
+            if n >= 0:
+                break
+            if n > -16:
+                _lib.check(int(n))
+            cap = -n
+        text = C.string_at(buf, n).decode("ascii")
+        if not skipped[:self.nseq].any():
+            return _Blocks(text, off)
+        o = off.tolist()
+        sk = skipped.tolist()
+        return [None if sk[k] else text[o[k]:o[k + 1]] for k in range(self.nseq)]
 
     def pack_all(self):
         """(uint8 array, int64 offsets[nseq + 1]): the packed results of every record (sq_result_pack_all) -- the
@@ -604,6 +710,7 @@ def pool_slots_wanted(ngreedy, poollim, n=None):
 class HipEngine:
     """Default engine: everything on the GPU through libsquarna_hip.so."""
     name = "hip"
+    writes_blocks = True          # fold_records(..., _blocks=cfg): the library forms Predict's output blocks
 
     def __init__(self, max_structs=0, cand_per_nt=0):
         self.max_structs = max_structs
@@ -685,6 +792,7 @@ class HipEngine:
         """(Batch, fold options) for these records.  opts: fold_records' keyword arguments (not modified)."""
         opts = dict(opts)
         opts.pop("_packed", None)
+        opts.pop("_blocks", None)
         interchainonly = opts.pop("interchainonly", False)
         keep = opts.pop("keep", None)
         M, B = opts.pop("M", 1.8), opts.pop("B", -0.6)
@@ -763,11 +871,33 @@ class HipEngine:
                 for b in batches:
                     buf, off = b.pack_all()
                     res.append([(buf[off[k]:off[k + 1]].tobytes(), None) for k in range(b.nseq)])
+            elif opts.get("_blocks"):
+                # Predict's printing path: the library writes the blocks; a record it leaves out (or a batch whose tail ran
+                # on the host) comes back as its result tuple and the caller formats it.  Records carry their block fields
+                # behind the fold's: (..., name, encoded reactivity line, index of their paramset-name list)
+                cfg = opts["_blocks"]
+                res = []
+                for b, recs in zip(batches, groups):
+                    texts = b.write_blocks([r[6] for r in recs], [r[0] for r in recs], [r[7] for r in recs],
+                                           [r[2] for r in recs], [r[3] for r in recs], [r[8] for r in recs],
+                                           cfg["psnames"], cfg["conslim"], cfg["outplim"])
+                    if isinstance(texts, _Blocks):
+                        res.append(_BlockRun(texts))
+                    elif texts is None or any(t is None for t in texts):
+                        full = b.results_all()
+                        res.append([(("text", texts[k]) if texts and texts[k] is not None else ("pred", full[k]), None) for k in range(b.nseq)])
+                    else:
+                        res.append([(("text", t), None) for t in texts])
             else:
                 res = [b.results_all() for b in batches]
         finally:
             for b in batches:
                 b.close()
+        if any(isinstance(both, _BlockRun) for both in res):
+            # (whole-text results stay whole when there is one batch; several batches / lanes: per-record entries)
+            if len(res) == 1 and back is None:
+                return [res[0]], [[None] * len(res[0].blocks)]
+            res = [[(("text", t), None) for t in both.blocks] if isinstance(both, _BlockRun) else both for both in res]
         outs, refs = [[r[0] for r in both] for both in res], [[r[1] for r in both] for both in res]
         if back is not None:                                         # undo the two-lane cut
             n = sum(len(idx) for idx in back)
