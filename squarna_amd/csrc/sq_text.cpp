@@ -143,6 +143,19 @@ inline bool is_gap(char c) { return c == '-' || c == '.' || c == '~'; }
 inline bool is_sep(char c) { return c == ';' || c == '&'; }
 }  // namespace
 
+namespace {
+// appends into a caller buffer; past its end only the length is counted (the caller retries with the size it reports)
+struct Sink {
+    char *p; int64_t cap, len = 0;
+    Sink(char *p_, int64_t cap_) : p(p_), cap(p_ ? cap_ : 0) {}
+    inline void put(char c) { if (len < cap) p[len] = c; len++; }
+    inline void put(const char *s, int64_t n) { if (len + n <= cap) memcpy(p + len, s, (size_t)n); len += n; }
+    inline void put(const char *s) { put(s, (int64_t)strlen(s)); }
+    inline void put(const std::string &s) { put(s.data(), (int64_t)s.size()); }
+    inline void fill(char c, int64_t n) { if (len + n <= cap) memset(p + len, c, (size_t)n); len += n; }
+};
+}  // namespace
+
 extern "C" int64_t sq_write_blocks(const sq_batch *b, const sq_block_desc *d, char *buf, int64_t cap, int64_t *off, uint8_t *skipped)
 {
     if (!b || !d || !off || !skipped || d->nrec != b->nseq || !d->names || !d->seqs) { sq_set_error("bad argument"); return -1; }
@@ -160,11 +173,10 @@ extern "C" int64_t sq_write_blocks(const sq_batch *b, const sq_block_desc *d, ch
     }
     char consname[48];
     snprintf(consname, sizeof consname, "top-%d_consensus", d->conslim);
-    std::string out;
-    out.reserve((size_t)std::max<int64_t>(cap, 1 << 16));
-    std::string row;
+    Sink out(buf, cap);
+    std::string num;
     for (int r = 0; r < nrec; r++) {
-        off[r] = (int64_t)out.size();
+        off[r] = out.len;
         skipped[r] = 0;
         if (b->h_deep[r]) { skipped[r] = 1; continue; }            // levels beyond the ASCII brackets: the caller's path
         const char *rec = b->h_rec + b->h_rec_off[r];
@@ -176,40 +188,46 @@ extern "C" int64_t sq_write_blocks(const sq_batch *b, const sq_block_desc *d, ch
         const char *txt = b->h_txt + b->h_txt_off[r];
         const char *seq = seqs.begin(r);
         const int64_t L = seqs.len(r);
+        bool plain = L == n;                                       // no gap columns, no separators: the rows are copied as they are
+        for (int64_t i = 0; i < L && plain; i++) plain = !is_gap(seq[i]) && !is_sep(seq[i]);
         // a row of the packed text (gap-free coordinates) in the columns of the input sequence: gap columns are dots, the
         // separators are put back (:1239-1246)
         auto put_row = [&](const char *src) {
+            if (plain) { out.put(src, n); return; }
             int64_t q = 0;
             for (int64_t i = 0; i < L; i++) {
                 const char c = seq[i];
-                if (is_gap(c)) { out += '.'; continue; }
+                if (is_gap(c)) { out.put('.'); continue; }
                 const char v = q < n ? src[q] : '.';
                 q++;
-                out += is_sep(c) ? c : v;
+                out.put(is_sep(c) ? c : v);
             }
         };
         auto put_seps = [&](const char *line, int64_t len) {      // a restraints / reference line with the separators of the sequence
-            for (int64_t i = 0; i < len; i++) out += (i < L && is_sep(seq[i])) ? seq[i] : line[i];
+            if (plain) { out.put(line, len); return; }
+            for (int64_t i = 0; i < len; i++) out.put((i < L && is_sep(seq[i])) ? seq[i] : line[i]);
         };
-        out.append(names.begin(r), (size_t)names.len(r)); out += '\n';
-        out.append(seq, (size_t)L); out += '\n';
-        if (reacts.len(r)) { out.append(reacts.begin(r), (size_t)reacts.len(r)); out += "\treactivities\n"; }
-        if (restr.len(r)) { put_seps(restr.begin(r), restr.len(r)); out += "\trestraints\n"; }
+        auto put_num = [&](double x) { num.clear(); py_float_str(x, num); out.put(num); };
+        auto put_metrics = [&](const double *m) { num.clear(); metrics_str(m, num); out.put(num); };
+        out.put(names.begin(r), names.len(r)); out.put('\n');
+        out.put(seq, L); out.put('\n');
+        if (reacts.len(r)) { out.put(reacts.begin(r), reacts.len(r)); out.put("\treactivities\n"); }
+        if (restr.len(r)) { put_seps(restr.begin(r), restr.len(r)); out.put("\trestraints\n"); }
         const bool reference = refs.len(r) > 0;
         if (reference) {
             put_seps(refs.begin(r), refs.len(r));
-            out += "\treference\t";
-            py_float_str(met[13], out); out += '\t';
-            if (met[14] == 0) out += '0'; else py_float_str(met[14], out);      // ScoreStruct keeps the int 0 (:871)
-            out += '\t';
-            py_float_str(met[15], out); out += '\n';
+            out.put("\treference\t");
+            put_num(met[13]); out.put('\t');
+            if (met[14] == 0) out.put('0'); else put_num(met[14]);      // ScoreStruct keeps the int 0 (:871)
+            out.put('\t');
+            put_num(met[15]); out.put('\n');
         }
-        out.append((size_t)L, '_'); out += '\n';
+        out.fill('_', L); out.put('\n');
         put_row(txt);                                               // consensus = row 0
-        out += '\t'; out += consname;
-        if (reference) { out += '\t'; if (has_ref) metrics_str(met, out); }
-        out += '\n';
-        out.append((size_t)L, '='); out += '\n';
+        out.put('\t'); out.put(consname);
+        if (reference) { out.put('\t'); if (has_ref) put_metrics(met); }
+        out.put('\n');
+        out.fill('=', L); out.put('\n');
         const int nsetr = d->nameset ? d->nameset[r] : 0;
         const std::vector<std::string> *nm = (nsetr >= 0 && nsetr < (int)psn.size()) ? &psn[nsetr] : nullptr;
         const int64_t nshow = std::min<int64_t>(ns, std::max(d->outplim, 0));
@@ -217,28 +235,27 @@ extern "C" int64_t sq_write_blocks(const sq_batch *b, const sq_block_desc *d, ch
             put_row(txt + (k + 1) * n);
             char t[32];
             snprintf(t, sizeof t, "\t#%lld\t", (long long)(k + 1));
-            out += t;
-            py_float_str(scores[3 * k], out); out += '\t';
-            if (scores[3 * k + 1] == 0) out += '0'; else py_float_str(scores[3 * k + 1], out);   // the int 0 of an empty structure (:871)
-            out += '\t';
-            py_float_str(scores[3 * k + 2], out); out += '\t';
+            out.put(t);
+            put_num(scores[3 * k]); out.put('\t');
+            if (scores[3 * k + 1] == 0) out.put('0'); else put_num(scores[3 * k + 1]);   // the int 0 of an empty structure (:871)
+            out.put('\t');
+            put_num(scores[3 * k + 2]); out.put('\t');
             bool first = true;
-            for (int q = 0; q < 64; q++)
-                if ((masks[k] >> q) & 1ull) {
-                    if (!first) out += ',';
-                    first = false;
-                    if (nm && q < (int)nm->size()) out += (*nm)[q];
-                }
-            if (reference && has_ref && (double)(k + 1) == met[12]) {
-                out += '\t'; metrics_str(met + 6, out);
-                snprintf(t, sizeof t, ",RK=%lld", (long long)met[12]);
-                out += t;
+            for (uint64_t mk = masks[k]; mk; mk &= mk - 1) {
+                const int q = __builtin_ctzll(mk);
+                if (!first) out.put(',');
+                first = false;
+                if (nm && q < (int)nm->size()) out.put((*nm)[q]);
             }
-            out += '\n';
+            if (reference && has_ref && (double)(k + 1) == met[12]) {
+                out.put('\t'); put_metrics(met + 6);
+                snprintf(t, sizeof t, ",RK=%lld", (long long)met[12]);
+                out.put(t);
+            }
+            out.put('\n');
         }
     }
-    off[nrec] = (int64_t)out.size();
-    if ((int64_t)out.size() > cap || !buf) return -(int64_t)out.size() - 16;
-    memcpy(buf, out.data(), out.size());
-    return (int64_t)out.size();
+    off[nrec] = out.len;
+    if (out.len > out.cap) return -out.len - 16;
+    return out.len;
 }

@@ -28,8 +28,22 @@ class Prepared:
     __slots__ = ("seq", "shortseq", "shortrest", "shortreacts", "shortdbn", "rbps", "rxs",
                  "rlefts", "rrights", "gapidx", "sepidx", "plain_reacts", "refpairs")
 
+    _NONE = ([], frozenset())
+
     def __init__(self, seq, reacts=None, restraints=None, dbn=None):
         seq = seq.upper().replace("T", "U")                          # :1004
+        if not reacts and not restraints and not dbn and seq.isalpha():
+            # a plain record (letters only: no gap column, no separator; nothing but the sequence given): every field is
+            # what the general path below would compute, without its per-record string work -- most records of a big
+            # input are like this
+            self.seq = self.shortseq = seq
+            self.shortrest = None
+            self.shortreacts = None                                  # (all 0.5: plain_reacts says so)
+            self.plain_reacts = True
+            self.gapidx = self.sepidx = self.rbps = self._NONE[0]
+            self.rxs = self.rlefts = self.rrights = self._NONE[1]
+            self.shortdbn = self.refpairs = None
+            return
         if not restraints:
             restraints = '.' * len(seq)                              # :1007-1008
         assert len(seq) == len(restraints), "Invalid restraints given"
@@ -514,14 +528,14 @@ class Batch:
         skipped = np.zeros(max(self.nseq, 1), np.uint8)
         cap = int(self.L.sq_result_dbn_all_size(self.h)) + sum(len(f) for f in fields if f) * 2 + 200 * self.nseq * (2 + int(outplim)) + 4096
         for _ in range(2):
-            buf = C.create_string_buffer(cap)
-            n = int(self.L.sq_write_blocks(self.h, C.byref(d), buf, cap, _ptr(off), _ptr(skipped)))
+            buf = np.empty(cap, np.uint8)                              # (no zero fill: the library writes what it reports)
+            n = int(self.L.sq_write_blocks(self.h, C.byref(d), _ptr(buf), cap, _ptr(off), _ptr(skipped)))
             if n >= 0:
                 break
             if n > -16:
                 _lib.check(int(n))
             cap = -n
-        text = C.string_at(buf, n).decode("ascii")
+        text = str(memoryview(buf)[:n], "ascii")
         if not skipped[:self.nseq].any():
             return _Blocks(text, off)
         o = off.tolist()
@@ -673,7 +687,7 @@ def bpp_terms(prepared, psets, M=1.8, B=-0.6):
     for p, pl in zip(prepared, psets):
         bppm = None
         if any(ps.get("bpp", 0) for ps in pl):
-            bppm = _bpp_provider(p.shortseq, p.shortreacts, M, B)    # once per sequence
+            bppm = _bpp_provider(p.shortseq, p.shortreacts if p.shortreacts is not None else [0.5] * len(p.shortseq), M, B)    # once per sequence
             if bppm is not None:
                 bppm = np.asarray(bppm, dtype=np.float64)
         for ps in pl:
