@@ -892,6 +892,12 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     // the survivor list can take as many records as remain in the slice after the key array
     const uint32_t ok_cap = (uint32_t)(((size_t)jb.cand_cap * (sizeof(SqCand) - sizeof(SqKey))) / sizeof(SqOk));
     const double minbps = ps->minbpscore, minfin = ps->minfinscore;
+    // the paramset's scalars once, ahead of the candidate loops: the compiler cannot hoist these loads itself (the loops
+    // store survivors to global memory), and inside ScoreStems each of them is another dependent memory access on the chain
+    const double ps_lb = ps->loopbonus, ps_bw = ps->bracketweight, ps_dc = ps->distcoef;
+    const int ps_bwint = ps->bw_integral, ps_sdflen = ps->sdf_len;
+    const double *const ps_sdf = c.sdftab + ps->sdf_off;
+    const double *const ps_of = ps->oftab;
     auto cell_exact = [&](int i, int j) -> double {
         if (!lds_cells) return sq_cell_exact(c, jb, ps, i, j);
         const double w = s_cell[l_ci[i] * cstride + l_ci[j]];             // cell_tab: the cell itself
@@ -1157,7 +1163,7 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                         diff2 = abs(cl - cr);
                     }
                 }
-                const double lb = ps->loopbonus;
+                const double lb = ps_lb;
                 const double loopfactor = (1.0 + (lb * (goodloop ? 1.0 : 0.0)) * (2.0 - diff1 / 2.0))
                                           + (lb * (goodloopout ? 1.0 : 0.0)) * (2.0 - diff2 / 2.0);   // :715
                 bool gnra = false;                                          // :598-604,718
@@ -1165,15 +1171,15 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                     gnra = true;
                 const double tetra = gnra ? 1.25 : 1.0;
                 const double ideal = nrec == 0 ? 4.0 : 2.0;                 // :721
-                const double stemdist = (double)dots + ps->bracketweight * (double)brackets;   // :723
+                const double stemdist = (double)dots + ps_bw * (double)brackets;   // :723
                 const double dd = fabs(stemdist - ideal);
                 double sdf = 1.0;                                           // :726
                 if (!between) {
                     const int di = (int)dd;
-                    if (ps->bw_integral && di < ps->sdf_len) sdf = c.sdftab[ps->sdf_off + di];
-                    else sdf = pow(1.0 / (1.0 + dd), ps->distcoef);
+                    if (ps_bwint && di < ps_sdflen) sdf = ps_sdf[di];
+                    else sdf = pow(1.0 / (1.0 + dd), ps_dc);
                 }
-                const double of = ps->oftab[__popcll(levelset)];            // :728-729
+                const double of = ps_of[__popcll(levelset)];            // :728-729
                 fin = bps * sdf * of * loopfactor * tetra;                  // :732 (reactfactor == 1)
                 if (!goodloop && !goodloopout && L < 3) fin = -1.0;         // :744-745
                 ok = fin >= minfin;                                         // :751
