@@ -1053,8 +1053,9 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     double *s_bps = reinterpret_cast<double *>(s_dyn + surv_off);
     uint32_t *s_key = reinterpret_cast<uint32_t *>(s_bps + (SQ_SCORE_CHUNK + 1) * nthr);
     uint16_t *s_len = reinterpret_cast<uint16_t *>(s_key + (SQ_SCORE_CHUNK + 1) * nthr);
-    __shared__ uint32_t s_nsurv;
-    if (tid == 0) s_nsurv = 0;
+    __shared__ uint32_t s_nsurv, s_okn;
+    const bool solo = gridDim.y == 1;                  // this block scores every candidate of its structure
+    if (tid == 0) { s_nsurv = 0; s_okn = 0; }
     __syncthreads();
 #ifdef SQ_SCORE_PROF
     _ps = wall_clock64() - _p0;
@@ -1189,7 +1190,9 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
             if (okm) {
                 uint32_t base = 0;
                 const int leader = __ffsll((long long)okm) - 1;
-                if ((tid & 63) == leader) base = atomicAdd(a.ok_cnt + st.slot, (uint32_t)__popcll(okm));
+                // (one block per structure: the block owns the list, its place counter lives in LDS -- a returning global
+                // atomic per wave and pass of ScoreStems was a memory round trip on the critical path of every block)
+                if ((tid & 63) == leader) base = solo ? atomicAdd(&s_okn, (uint32_t)__popcll(okm)) : atomicAdd(a.ok_cnt + st.slot, (uint32_t)__popcll(okm));
                 base = (uint32_t)__shfl((int)base, leader);
                 if (ok) {
                     const uint32_t pos = base + (uint32_t)__popcll(okm & ((1ull << (tid & 63)) - 1ull));
@@ -1217,6 +1220,10 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                _ps * 0.01, _pa * 0.01, _pb * 0.01, (wall_clock64() - _p0) * 0.01);
 #endif
 
+    if (solo) {                                         // the length of the survivor list (zeroed by the state kernel)
+        __syncthreads();
+        if (tid == 0) a.ok_cnt[st.slot] = s_okn < ok_cap ? s_okn : ok_cap;
+    }
     // wave maximum, then one atomicMax per wave on the structure's slot
     for (int off = 32; off > 0; off >>= 1) {
         const double ob = __shfl_xor(best, off);
