@@ -197,6 +197,7 @@ struct sq_batch {
     char *h_app = nullptr; size_t h_app_cap = 0;   // pinned staging of host-built log entries (sq_fin_append_kernel)
     char *h_ref = nullptr; size_t h_ref_cap = 0;   // pinned staging of the known structures (partner arrays)
     bool packed_ok = false;               // the last fold's results are the packed records above (else: `results`)
+    int tail_maxshow = 0;                 // most structures shown for one sequence in the last device tail (shapes the next pack launch)
     int32_t packed_limit = 0;             // result_limit in force at that fold
     // profiling
     std::mutex mwm_mu;

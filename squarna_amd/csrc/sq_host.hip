@@ -1623,8 +1623,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // allow; the host tail below is its fallback.  The log and the per-job evaluation counts start empty.
     const bool dev_tail = sq_tail_device_wanted(b, o);
     b->packed_ok = false;
-    HIPCK(hipMemsetAsync(b->d_fin_ctr, 0, 64, b->stream));
-    HIPCK(hipMemsetAsync(b->d_job_evals, 0, 8 * (size_t)b->njobs, b->stream));
+    hipLaunchKernelGGL(sq_fold_begin_kernel, dim3((b->njobs + 256) / 256), dim3(256), 0, b->stream, b->d_fin_ctr, b->d_job_evals,
+                       b->tail.job_cnt, b->njobs);
     // (the pools -- thousands of small vectors -- are torn down by a helper thread after the fold returns)
     auto *pools_owner = new std::vector<JobPool>(b->njobs);
     struct PoolsDrop {
@@ -2107,8 +2107,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         if (overflow || hh.ovf) {
             for (int j : greedy_jobs) { pools[j].fin.clear(); pools[j].evals = 0; }
             // (the device log holds the structures the aborted pools had finished: empty it for the host loop's)
-            hipMemsetAsync(b->d_fin_ctr, 0, 64, st);
-            hipMemsetAsync(b->d_job_evals, 0, 8 * (size_t)b->njobs, st);
+            hipLaunchKernelGGL(sq_fold_begin_kernel, dim3((b->njobs + 256) / 256), dim3(256), 0, st, b->d_fin_ctr, b->d_job_evals, b->tail.job_cnt, b->njobs);
             return 1;
         }
         if ((*ln.h_ctr).level_ovf) return fail(-3, "more than 64 pseudoknot levels");

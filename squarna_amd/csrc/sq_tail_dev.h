@@ -63,8 +63,8 @@ struct SqTailIO {
     const double *pow17h; int32_t pow17h_len;     // pow(k / 2, 1.7), host libm (ScoreStruct, :884)
     // outputs (pinned host memory, written by sq_tail_pack_kernel)
     char *rec_buf; char *txt_buf; uint8_t *deep;
-    long long *h_totals;                          // pinned: [0] record bytes, [1] text bytes, [2] fallback flag, [3] entries, [4] most structures shown for one sequence
-    uint32_t *fallback;                           // device flag: some sequence needs the host tail
+    long long *h_totals;                          // pinned: [0] record bytes, [1] text bytes, [2] fallback flag, [3] entries, [4] most structures shown for one sequence, [5] a record did not fit the buffers
+    uint32_t *fallback;                           // device: [0] some sequence needs the host tail, [1] a record did not fit the result buffers
     int32_t tmax;                                 // most stems of any structure (sizes the level scratch)
 };
 
@@ -74,7 +74,8 @@ __global__ void sq_tail_scan_kernel(SqTailIO t);
 __global__ void sq_tail_scatter_kernel(SqTailIO t);
 __global__ void sq_tail_rank_kernel(SqDevCtx c, SqTailIO t);
 __global__ void sq_tail_offsets_kernel(SqTailIO t, volatile uint32_t *h_seq, uint32_t seq);
-__global__ void sq_tail_pack_kernel(SqDevCtx c, SqTailIO t, int rowcap);
+__global__ void sq_tail_pack_kernel(SqDevCtx c, SqTailIO t, int rowcap, long long rec_cap, long long txt_cap);
+__global__ void sq_fold_begin_kernel(uint32_t *fin_ctr, long long *job_evals, uint32_t *job_cnt, int njobs);
 __global__ void sq_tail_done_kernel(SqTailIO t, long long *h_rec_off, long long *h_txt_off, volatile uint32_t *h_seq, uint32_t seq);
 __global__ void sq_fin_append_kernel(const SqPoolFin *src, const SqPoolStem *src_stems, int n, SqPoolFin *fin, SqPoolStem *stems,
                                      uint32_t *ctr, uint32_t fin_cap, uint32_t stem_cap);

@@ -452,7 +452,7 @@ extern "C" __global__ __launch_bounds__(1024) void sq_tail_offsets_kernel(SqTail
 // ---- levels + the packed record --------------------------------------------------------------------------------------
 // grid (nseq, Y): block (s, y) is one wave and forms the rows of structures y, y + Y, ... of sequence s; y == 0 also writes
 // the header, the scores / masks, the metrics and the consensus row.
-extern "C" __global__ __launch_bounds__(64) void sq_tail_pack_kernel(SqDevCtx c, SqTailIO t, int rowcap)
+extern "C" __global__ __launch_bounds__(64) void sq_tail_pack_kernel(SqDevCtx c, SqTailIO t, int rowcap, long long rec_cap, long long txt_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char sq_tail_dyn[];   // [rowcap int16 row][sq_extend_lds_bytes(tmax)]
     int16_t *row = reinterpret_cast<int16_t *>(sq_tail_dyn);
@@ -462,6 +462,9 @@ extern "C" __global__ __launch_bounds__(64) void sq_tail_pack_kernel(SqDevCtx c,
     const SqJob jb = c.jobs[t.seq_job0[s]];
     const int n = jb.n;
     const uint32_t first = S.first, ns = S.nshow;
+    // (launched before the host has seen the sizes whenever buffers of an earlier fold exist: a record that does not fit
+    // them is not written, the host grows the buffers and repeats the launch)
+    if (S.rec_off + S.rec_bytes > rec_cap || S.txt_off + S.txt_bytes > txt_cap) { if (threadIdx.x == 0) t.fallback[1] = 1; return; }
     char *rec = t.rec_buf + S.rec_off;
     char *txt = t.txt_buf + S.txt_off;
     int16_t *lev0 = reinterpret_cast<int16_t *>(rec + 160 + 32 * (size_t)ns);
@@ -538,9 +541,20 @@ extern "C" __global__ __launch_bounds__(1024) void sq_tail_done_kernel(SqTailIO 
     __syncthreads();
     if (threadIdx.x == 0) {
         t.h_totals[2] = (long long)*t.fallback;
+        t.h_totals[5] = (long long)t.fallback[1];         // some record did not fit the result buffers
+        t.fallback[1] = 0;
         sq_host_write_flush(t.h_totals);
         *h_seq = seq;
     }
+}
+
+// start of a fold: the log of final structures, the per-job evaluation counts and the tail's per-job counters start empty
+extern "C" __global__ __launch_bounds__(256) void sq_fold_begin_kernel(uint32_t *fin_ctr, long long *job_evals, uint32_t *job_cnt, int njobs)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < 16) fin_ctr[q] = 0;
+    if (q < njobs) job_evals[q] = 0;
+    if (q <= njobs) job_cnt[q] = 0;
 }
 
 // appends host-built final structures (the E / H / N stemsets while their filters run on the host; the empty structure of
@@ -651,50 +665,71 @@ int sq_tail_device(sq_batch *b, const sq_fold_opts &o, const int32_t *ref_off, c
         t.refp = b->d_refp; t.ref_n = b->d_refn;
     }
     const unsigned nb = 256;
-    hipMemsetAsync(t.job_cnt, 0, 4 * ((size_t)t.njobs + 1), st);
-    hipMemsetAsync(b->h_deep, 0, (size_t)b->nseq, st);
+    memset(b->h_deep, 0, (size_t)b->nseq);                   // (pinned host memory; the previous fold's kernels are long done)
     hipLaunchKernelGGL(sq_tail_count_kernel, dim3(nb), dim3(256), 0, st, t);
     hipLaunchKernelGGL(sq_tail_scan_kernel, dim3(1), dim3(1024), 0, st, t);
     hipLaunchKernelGGL(sq_tail_scatter_kernel, dim3(nb), dim3(256), 0, st, t);
     hipLaunchKernelGGL(sq_tail_rank_kernel, dim3(b->nseq), dim3(SQ_TAIL_THREADS), 0, st, b->ctx, t);
     uint32_t seq = ++*ln.round_seq;
-    // (the offsets go straight to pinned memory through the SqTailSeq copies below)
     hipLaunchKernelGGL(sq_tail_offsets_kernel, dim3(1), dim3(1024), 0, st, t, ln.h_seq, seq);
     if (sq_check(hipGetLastError(), "device tail launch")) return 2;
-    int r = tail_wait(b, ln, seq, "device tail (ranking)");
-    if (r) return r;
-    if (b->h_tail_totals[2]) return 1;                                  // some sequence needs the host tail
-    const size_t rec_bytes = (size_t)b->h_tail_totals[0], txt_bytes = (size_t)b->h_tail_totals[1];
-    if (b->h_rec_cap < rec_bytes + 64) {
-        sq_pinned_put(b->h_rec); b->h_rec = nullptr; b->h_rec_cap = 0;
-        void *p = nullptr;
-        const size_t cap = rec_bytes + rec_bytes / 4 + 4096;
-        if (sq_pinned_get(&p, cap)) return 2;
-        b->h_rec = (char *)p; b->h_rec_cap = cap;
-    }
-    if (b->h_txt_cap < txt_bytes + 64) {
-        sq_pinned_put(b->h_txt); b->h_txt = nullptr; b->h_txt_cap = 0;
-        void *p = nullptr;
-        const size_t cap = txt_bytes + txt_bytes / 4 + 4096;
-        if (sq_pinned_get(&p, cap)) return 2;
-        b->h_txt = (char *)p; b->h_txt_cap = cap;
-    }
-    t.rec_buf = b->h_rec; t.txt_buf = b->h_txt; t.deep = b->h_deep;
-    // one wave per (sequence, slice of its structures): Y slices so that the launch holds a few thousand waves
-    const int maxshow = (int)std::max<long long>(b->h_tail_totals[4], 1);
-    const int Y = std::max(1, std::min({maxshow, 64, std::max(1, 8192 / std::max(b->nseq, 1))}));
     const int rowcap = (b->maxn + 8) & ~7;
     const size_t dyn = (((size_t)rowcap * 2 + 15) & ~(size_t)15) + sq_extend_lds_bytes(t.tmax);
     if (dyn > 160 * 1024) return 1;
     if (dyn > 64 * 1024) sq_max_dynamic_lds((const void *)sq_tail_pack_kernel, 160 * 1024);
-    hipLaunchKernelGGL(sq_tail_pack_kernel, dim3(b->nseq, Y), dim3(64), dyn, st, b->ctx, t, rowcap);
-    // offsets of every record for the getters: the SqTailSeq records, copied out behind the pack kernel
-    seq = ++*ln.round_seq;
-    hipLaunchKernelGGL(sq_tail_done_kernel, dim3(1), dim3(1024), 0, st, t, b->h_rec_off, b->h_txt_off, ln.h_seq, seq);
-    if (sq_check(hipGetLastError(), "device tail launch")) return 2;
-    r = tail_wait(b, ln, seq, "device tail (records)");
-    if (r) return r;
-    if (b->h_tail_totals[2]) return 1;
+    // The records go straight into pinned buffers.  With buffers of an earlier fold at hand the pack kernel is launched
+    // right behind the offsets -- no host round trip in between --, with the shape of that fold; a record that does not fit is
+    // reported and the launch repeated with larger buffers.  The first fold of a batch waits for the sizes.
+    auto launch_pack = [&](int maxshow) -> uint32_t {
+        const int Y = std::max(1, std::min({maxshow, 64, std::max(1, 8192 / std::max(b->nseq, 1))}));
+        t.rec_buf = b->h_rec; t.txt_buf = b->h_txt; t.deep = b->h_deep;
+        hipLaunchKernelGGL(sq_tail_pack_kernel, dim3(b->nseq, Y), dim3(64), dyn, st, b->ctx, t, rowcap, (long long)b->h_rec_cap, (long long)b->h_txt_cap);
+        const uint32_t sq2 = ++*ln.round_seq;
+        hipLaunchKernelGGL(sq_tail_done_kernel, dim3(1), dim3(1024), 0, st, t, b->h_rec_off, b->h_txt_off, ln.h_seq, sq2);
+        return sq2;
+    };
+    auto grow = [&](size_t rec_bytes, size_t txt_bytes) -> int {
+        if (b->h_rec_cap < rec_bytes + 64) {
+            sq_pinned_put(b->h_rec); b->h_rec = nullptr; b->h_rec_cap = 0;
+            void *p = nullptr;
+            const size_t cap = rec_bytes + rec_bytes / 4 + 4096;
+            if (sq_pinned_get(&p, cap)) return 2;
+            b->h_rec = (char *)p; b->h_rec_cap = cap;
+        }
+        if (b->h_txt_cap < txt_bytes + 64) {
+            sq_pinned_put(b->h_txt); b->h_txt = nullptr; b->h_txt_cap = 0;
+            void *p = nullptr;
+            const size_t cap = txt_bytes + txt_bytes / 4 + 4096;
+            if (sq_pinned_get(&p, cap)) return 2;
+            b->h_txt = (char *)p; b->h_txt_cap = cap;
+        }
+        return 0;
+    };
+    int r = 0;
+    bool packed = false;
+    if (b->h_rec_cap && b->h_txt_cap) {
+        seq = launch_pack(b->tail_maxshow > 0 ? b->tail_maxshow : 8);
+        if (sq_check(hipGetLastError(), "device tail launch")) return 2;
+        r = tail_wait(b, ln, seq, "device tail (records)");
+        if (r) return r;
+        if (b->h_tail_totals[2]) return 1;                              // some sequence needs the host tail
+        packed = !b->h_tail_totals[5];
+    } else {
+        r = tail_wait(b, ln, seq, "device tail (ranking)");
+        if (r) return r;
+        if (b->h_tail_totals[2]) return 1;
+    }
+    const size_t rec_bytes = (size_t)b->h_tail_totals[0], txt_bytes = (size_t)b->h_tail_totals[1];
+    b->tail_maxshow = (int)std::max<long long>(b->h_tail_totals[4], 1);
+    if (!packed) {
+        r = grow(rec_bytes, txt_bytes);
+        if (r) return r;
+        seq = launch_pack(b->tail_maxshow);
+        if (sq_check(hipGetLastError(), "device tail launch")) return 2;
+        r = tail_wait(b, ln, seq, "device tail (records)");
+        if (r) return r;
+        if (b->h_tail_totals[2] || b->h_tail_totals[5]) return 1;
+    }
     b->h_rec_off[b->nseq] = (long long)rec_bytes; b->h_txt_off[b->nseq] = (long long)txt_bytes;
     b->packed_ok = true; b->packed_limit = b->result_limit;
     return 0;
