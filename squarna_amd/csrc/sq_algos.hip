@@ -12,6 +12,7 @@
 #include "sq_match.h"
 #include "sq_blossom.h"
 #include "sq_algos_dev.h"
+#include "sq_cells.h"
 
 #define HIPCK(x) do { int _r = sq_check((x), #x); if (_r) return _r; } while (0)
 
@@ -23,7 +24,7 @@ static inline double sq_now() { return std::chrono::duration<double>(std::chrono
 // exact scoremat cell on the host: the same fp64 expression as sq_cell_score (sq_kernels.hip)
 static double cell_score_host(const sq_batch *b, const SqJob &J, int i, int j, const double *dense = nullptr)
 {
-    if (dense) return dense[(size_t)i * J.n + j];          // jobs with a bpp term / multiplier: the device's exact matrix
+    if (dense) return dense[(size_t)sq_m64_index(J, i, j)];   // jobs with a bpp term / multiplier: the device's exact matrix
     const uint8_t *codes = b->codes.data() + J.pos_off;
     const sq_paramset &ps = b->psets[J.pset];
     const double w = ps.bpweight[codes[i] * 32 + codes[j]];

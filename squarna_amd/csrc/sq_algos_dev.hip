@@ -21,20 +21,9 @@
 #include "sq_match.h"
 #include "sq_tail_dev.h"
 #include "sq_algos_dev.h"
+#include "sq_cells.h"
 
-// exact scoremat cell: the expressions of sq_cell_exact (sq_kernels.hip), restated here (separate translation unit)
-__device__ __forceinline__ double sq_algo_cell(const SqDevCtx &c, const SqJob &jb, const SqPsetDev *ps, int i, int j)
-{
-    if (jb.mat64_off >= 0) return c.mat64[jb.mat64_off + (int64_t)i * jb.n + j];
-    const uint8_t *codes = c.codes + jb.pos_off;
-    const double w = ps->w[codes[i] * 32 + codes[j]];
-    if (jb.default_reacts) return w;
-    double rf;
-    if (jb.rf_idx >= 0) { const uint8_t *lv = c.ridx + jb.pos_off; rf = c.rftab[(int64_t)jb.rf_idx * 256 + lv[i] * 16 + lv[j]]; }
-    else { const double *r = c.reacts + jb.pos_off; rf = sqrt((1.0 - (r[i] + r[j]) / 2.0) * 2.0); }
-    if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
-    return w * rf;
-}
+__device__ __forceinline__ double sq_algo_cell(const SqDevCtx &c, const SqJob &jb, const SqPsetDev *ps, int i, int j) { return sq_cell_exact(c, jb, ps, i, j); }
 
 // ---- sizes ----------------------------------------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(256) void sq_algo_sizes_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqAlgoSize *sizes)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "sq_internal.h"
+#include "sq_context.h"
 
 struct SqDevCtx {
     const SqJob *jobs;
@@ -154,7 +155,7 @@ __global__ void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt
 __global__ void sq_bits_kernel(SqDevCtx c, int only_ext);
 __global__ void sq_score_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
                                 SqScanArgs a, SqRoundIO io, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off, int cell_off,
-                                int str_off, int str_cap);
+                                int str_off, int str_cap, SqCtxTab ct, int bound);
 __global__ void sq_bps_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
                               SqScanArgs a, SqRoundIO io, int mode, int lds_n, int lds_n_reacts, int surv_off, int cell_off);
 __global__ void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqRoundIO io);

@@ -5,10 +5,13 @@
 // on the host that is N x N doubles each through PCIe (48 sequences x 5,000 columns: 8.5 GB, 4.7 of the 8.9 s the
 // three steps took).  The matrix is the result of step 1 and already lives on the device: here every job's slice
 //     mat64[a][b] = M[cols[a]][cols[b]]
-// is gathered straight from it (one row of the slice per block row, coalesced writes; the reads follow the column map,
-// which is monotone, so they run through M's rows front to back).
+// is gathered straight from it (one row of the slice per block row; the reads follow the column map, which is monotone,
+// so they run through M's rows front to back).  Round 3: the kernel forms the PRODUCT bpscorematrix * shortsmat right away
+// (0 where bpboolmatrix is 0; the fill kernel's pass over these jobs is gone) and stores it DIAGONAL-major (sq_m64_index):
+// the scoring kernel reads the cells of a stem, which lie on one anti-diagonal, from consecutive addresses.
 #include <hip/hip_runtime.h>
 #include "sq_device.h"
+#include "sq_cells.h"
 
 extern "C" __global__ __launch_bounds__(256) void sq_gather_mul_kernel(SqDevCtx c, const double *M, int L, const int32_t *cols,
                                                                       const int32_t *job_list)
@@ -19,8 +22,13 @@ extern "C" __global__ __launch_bounds__(256) void sq_gather_mul_kernel(SqDevCtx 
     if (a >= n) return;
     const int32_t *cl = cols + jb.pos_off;
     const double *row = M + (size_t)cl[a] * (size_t)L;
-    double *dst = c.mat64 + jb.mat64_off + (size_t)a * (size_t)n;
-    for (int b = blockIdx.x * 256 + threadIdx.x; b < n; b += gridDim.x * 256) dst[b] = row[cl[b]];
+    const SqPsetDev *ps = c.psets + jb.pset;
+    double *dst = c.mat64 + jb.mat64_off;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < n; b += gridDim.x * 256) {
+        double v = 0.0;                                              // :1084-1085 on the cells whose bool is 1; the others hold 0
+        if (b > a && sq_cell_bool(c, jb, ps, a, b)) v = sq_cell_score(c, jb, ps, a, b) * row[cl[b]];
+        dst[sq_m64_index(jb, a, b)] = v;
+    }
 }
 
 void sq_launch_gather_mul(const SqDevCtx &c, const double *M, int L, const int32_t *cols, const int32_t *job_list, int njl, int maxn,

@@ -142,6 +142,8 @@ struct sq_batch {
     hipEvent_t lane_ev = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
     int32_t cell_entries = 32;            // doubles of the scoring kernels' cell table (dynamic LDS)
+    bool score_bound = true, score_ctx = true;   // the scoring kernel's branch and bound / closed-form sweep (per fold: SQ_NO_SCORE_BOUND, SQ_NO_SCORE_CONTEXT)
+    SqCtxTab ctxtab = SqCtxTab{};         // ScoreStems context tables (sq_context.h), rec == nullptr: none
     int32_t chain_tmax = 1;               // most stems a structure of any job can hold (sizes the extend kernels' LDS)
     char *algo_scratch = nullptr;         // device scratch of the Hungarian / Nussinov kernels (Layout::off_algo)
     size_t algo_bytes = 0, algo_used = 0;

@@ -286,6 +286,8 @@ struct Layout {
     int64_t n_rftab, pow_entries;
     size_t off_mat32, off_mat64, off_structs, off_strands, off_state, off_cnt, off_ctr, off_cands, off_out;
     size_t off_bits, off_rbpk, off_fb;
+    size_t off_ctx_rec = 0, off_ctx_depth = 0, off_ctx_rmq = 0, off_ctx_ok = 0;   // ScoreStems context tables (sq_context.h)
+    int ctx_cap = 0, ctx_levels = 0;
     size_t off_crec, off_cstems, off_cstrands, off_csidx, off_cnfin;   // device-chained rounds (sq_chain.hip)
     size_t off_pstructs, off_precs, off_pstems, off_pstrands, off_psidx, off_pjobs, off_pjobrec, off_pnchild, off_pchoff,
            off_pflag, off_pchosen, off_phdr;                            // device pools (sq_pool.hip)
@@ -319,7 +321,9 @@ int plan(const sq_batch_desc *d, Layout &L)
         const int64_t n = d->seq_off[s + 1] - d->seq_off[s];
         const bool ext_any = (d->ext_score && d->ext_score[j]) || (d->mul_score && d->mul_score[j]) ||
                              (d->bpp_term && d->bpp_term[j]) || (d->mul_shared && d->mul_shared[j]);
-        if (want_fp32(d) || ext_any) L.mat32_floats += (int64_t)align_up((size_t)(n * ld_of((int)n)), 64);
+        // (jobs weighted by the shared stem matrix need no fp32 matrix: their product is formed by the gather kernel)
+        const bool shared_only = d->mul_shared && d->mul_shared[j] && !(d->ext_score && d->ext_score[j]);
+        if (want_fp32(d) || (ext_any && !shared_only)) L.mat32_floats += (int64_t)align_up((size_t)(n * ld_of((int)n)), 64);
         L.bits_words += (int64_t)bits_nw((int)n) * bits_pitch((int)n);
         const bool ext = d->ext_score && d->ext_score[j];
         const bool mul = (d->mul_score && d->mul_score[j]) || (d->bpp_term && d->bpp_term[j]) || (d->mul_shared && d->mul_shared[j]);
@@ -375,6 +379,25 @@ int plan(const sq_batch_desc *d, Layout &L)
     L.off_bits = take(4 * (size_t)std::max<int64_t>(L.bits_words, 1));
     L.off_rbpk = take(4 * (size_t)std::max<int>(d->rbp_off[d->nseq], 1));
     L.off_fb = take(4 * (size_t)L.fbstride * L.max_structs);
+    {
+        // ScoreStems' closed-form strand sweep (sq_context.h): tables for every structure of a launch, for batches with
+        // sequences long enough that the walk over the strands is what the scoring kernel waits for
+        const int ctx_min_n = getenv("SQ_CTX_MIN_N") ? atoi(getenv("SQ_CTX_MIN_N")) : 256;
+        int pt_max = 1;
+        for (int j = 0; j < d->njobs; j++)
+            pt_max = std::max(pt_max, chain_tcap(d->seq_off[d->job_seq[j] + 1] - d->seq_off[d->job_seq[j]], d->psets[d->job_pset[j]].minlen));
+        const int cap = std::min(1024, 2 * pt_max + 2) + 1;
+        int lv = 0;
+        const size_t per_gap = sq_context_bytes_per_gap(cap, &lv);
+        const size_t total = per_gap * (size_t)cap * (size_t)L.max_structs;
+        if (ctx_min_n >= 0 && L.maxn >= ctx_min_n && total <= ((size_t)2 << 30)) {
+            L.ctx_cap = cap; L.ctx_levels = lv;
+            L.off_ctx_rec = take(sizeof(SqCtxRec) * (size_t)cap * L.max_structs);
+            L.off_ctx_depth = take(2 * (size_t)cap * L.max_structs);
+            L.off_ctx_rmq = take(2 * (size_t)lv * cap * L.max_structs);
+            L.off_ctx_ok = take((size_t)L.max_structs);
+        }
+    }
     // chained rounds: per job, room for the most stems a structure can hold (disjoint stems of >= minlen pairs)
     L.chain_T = 0;
     for (int j = 0; j < d->njobs; j++) L.chain_T += chain_tcap(d->seq_off[d->job_seq[j] + 1] - d->seq_off[d->job_seq[j]], d->psets[d->job_pset[j]].minlen);
@@ -537,6 +560,17 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         x.orderpenalty = ps.orderpenalty; x.loopbonus = ps.loopbonus;
         for (int k = 0; k <= SQ_MAXLEVELS; k++) x.oftab[k] = pow(1.0 / (1 + k), ps.orderpenalty);   // :729
         {
+            // maxima of the finalscore's factors (sq_internal.h): orderfactor over the table; loopfactor :715 with both
+            // loops good and equal sides (loopbonus >= 0; a negative bonus only lowers it below 1); the distance factor
+            // (1 / (1 + d)) ** distcoef is <= 1 for distcoef >= 0
+            double of = x.oftab[0];
+            for (int k = 1; k <= SQ_MAXLEVELS; k++) of = x.oftab[k] > of ? x.oftab[k] : of;
+            const double lb = ps.loopbonus;
+            x.ub_of = of;
+            x.ub_lf = lb >= 0 ? (1.0 + lb * 2.0) + lb * 2.0 : 1.0;
+            if (!(ps.distcoef >= 0) || !(of >= 0) || !std::isfinite(of) || !std::isfinite(lb)) x.ub_lf = INFINITY;
+        }
+        {
             bool dy = true;
             for (int q = 0; q < 32 * 32 && dy; q++) {
                 const double w = x.w[q] * 1024.0;
@@ -621,12 +655,13 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         if (ext) { J.mat64_off = m64; J.has_ext = 1; m64 += 2 * (int64_t)J.n * J.n; }
         else if (mul) { J.mat64_off = m64; J.has_ext = 2; m64 += (int64_t)J.n * J.n; }
         J.mat_off = -1;
-        if (b->has_fp32 || J.has_ext) { J.mat_off = m32; m32 += (int64_t)align_up((size_t)J.n * J.ld, 64); }
+        J.mat64_diag = (shared && !ext) ? 1 : 0;          // the gather kernel writes score x weight, diagonal-major (sq_cells.h)
+        if (b->has_fp32 || (J.has_ext && !J.mat64_diag)) { J.mat_off = m32; m32 += (int64_t)align_up((size_t)J.n * J.ld, 64); }
         bool def = true;                                  // SQRNdbnseq.py:273
         for (int i = 0; i < J.n; i++) if (d->reacts[J.pos_off + i] != 0.5) { def = false; break; }
         J.default_reacts = def ? 1 : 0;
         J.react_levels = def ? 0 : seq_levels[s];
-        J.rf_idx = def ? -1 : seq_rf[s]; J.pad_rf = 0;
+        J.rf_idx = def ? -1 : seq_rf[s];
         J.interchainonly = d->interchainonly;
         {
             const double ml = std::max(1.0, std::ceil(d->psets[J.pset].minlen));
@@ -679,6 +714,12 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->state.P = stbase; b->state.E8 = (uint8_t *)(stbase + plane); b->state.U = stbase + 2 * plane; b->state.SU = stbase + 3 * plane;
     b->state.stride = L.stride;
     b->state.FB = (uint32_t *)(base + L.off_fb); b->state.fbstride = L.fbstride;
+    b->ctxtab = SqCtxTab{};
+    if (L.ctx_cap) {
+        b->ctxtab.rec = (SqCtxRec *)(base + L.off_ctx_rec); b->ctxtab.depth = (int16_t *)(base + L.off_ctx_depth);
+        b->ctxtab.rmq = (uint16_t *)(base + L.off_ctx_rmq); b->ctxtab.ok = (uint8_t *)(base + L.off_ctx_ok);
+        b->ctxtab.cap = L.ctx_cap; b->ctxtab.levels = L.ctx_levels;
+    }
     b->ctx.bits = (uint32_t *)(base + L.off_bits); b->ctx.rbpk = (uint32_t *)(base + L.off_rbpk);
     b->scan.cand_cnt = (uint32_t *)(base + L.off_cnt); b->scan.ctr = (SqCounters *)(base + L.off_ctr);
     b->scan.best = (unsigned long long *)(base + L.off_cnt + 4 * align_up((size_t)L.max_structs, 2));
@@ -1044,6 +1085,7 @@ extern "C" int sq_bpmatrix_read(sq_batch *b, int32_t job, double *boolmat, doubl
     const SqJob &J = b->jobs[job];
     const size_t nn = (size_t)J.n * J.n;
     if (J.has_ext == 1) { sq_set_error("job uses caller matrices"); return -1; }
+    if (J.mat64_diag) { sq_set_error("job is weighted by the shared stem matrix: its dense matrix is not kept row-major"); return -4; }
     double *tmp = (double *)b->scan.cands;                  // borrowed: idle between rounds
     hipLaunchKernelGGL(sq_dense64_kernel, dim3((unsigned)std::min<size_t>((nn + 255) / 256 + 1, 2048)), dim3(256), 0,
                        b->stream, b->ctx, job, tmp, tmp + nn);
@@ -1200,6 +1242,9 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
         const size_t st_dyn = st_lds_n ? (size_t)7 * ((st_lds_n + 8) & ~7) + 64 : 0;
         hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(256), st_dyn, st, b->ctx, io, b->state, scan, st_lds_n, chained ? 1 : 0);
     }
+    // mode 0: the context tables of the round's structures (only long-sequence batches carry them)
+    const bool ctx_on = mode == 0 && b->ctxtab.rec != nullptr && b->score_ctx;
+    if (ctx_on) sq_launch_context(d_structs, d_strands, b->ctxtab, S, st);
     if (maxn >= 5) {
         ProfScope ps(b, 2, scan_bytes);
         // bit-diagonal scan: one wave = 64 anti-diagonals
@@ -1247,7 +1292,7 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
         if (mode == 0) dyn = (size_t)str_off + (size_t)10 * str_cap + 16;
         if (mode == 0)
             hipLaunchKernelGGL(sq_score_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, d_structs, d_strands, b->state,
-                               scan, io, lds_n, lds_nr, lds_ns, surv_off, cell_off, str_off, str_cap);
+                               scan, io, lds_n, lds_nr, lds_ns, surv_off, cell_off, str_off, str_cap, ctx_on ? b->ctxtab : SqCtxTab{}, b->score_bound ? 1 : 0);
         else
             hipLaunchKernelGGL(sq_bps_kernel, dim3(S, parts), dim3(thr), dyn, st, b->ctx, d_structs, d_strands, b->state,
                                scan, io, mode, lds_n, lds_nr, surv_off, cell_off);
@@ -1622,6 +1667,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // The ranking tail runs on the device (sq_tail_dev.hip) over the device log of final structures whenever the options
     // allow; the host tail below is its fallback.  The log and the per-job evaluation counts start empty.
     const bool dev_tail = sq_tail_device_wanted(b, o);
+    // the scoring kernel's two short cuts, per fold (tests fold the same batch with and without them)
+    b->score_bound = getenv("SQ_NO_SCORE_BOUND") == nullptr;
+    b->score_ctx = getenv("SQ_NO_SCORE_CONTEXT") == nullptr;
     b->packed_ok = false;
     hipLaunchKernelGGL(sq_fold_begin_kernel, dim3((b->njobs + 256) / 256), dim3(256), 0, b->stream, b->d_fin_ctr, b->d_job_evals,
                        b->tail.job_cnt, b->njobs);
@@ -2030,7 +2078,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             const JobPool &P = pools[j];
             const int toff = sx * PI.pt;                     // generation 0, slot sx
             SqStruct &d = ln.h_structs[sx];
-            d.job = j; d.strand_off = 2 * toff; d.nstrand = 0; d.slot = sx; d.subopt = 0.0; d.cand_off = (int64_t)(sx % chunk) * maxcap;
+            d.job = j; d.strand_off = 2 * toff; d.nstrand = 0; d.slot = sx; d.subopt = P.cursubopt; d.cand_off = (int64_t)(sx % chunk) * maxcap;
             SqChain &cr = b->h_pool_recs[sx];
             cr.toff = toff; cr.tcap = PI.pt; cr.nstems = 0; cr.anycross = 0; cr.maxstems = P.maxstemnum;
             SqPoolJob &pj = b->h_pool_jobs[sx];

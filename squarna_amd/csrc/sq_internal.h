@@ -30,7 +30,7 @@ struct SqJob {
     int32_t rf_idx;        // >= 0 (react_levels > 0, reactivities not all 0.5): table rf_idx of SqDevCtx::rftab holds the
                            // sequence's 16 x 16 reactfactors ((1 - (r_a + r_b) / 2) * 2) ** 0.5 evaluated by the HOST's libm
                            // pow, as CPython does (SQRNdbnseq.py:333) -- sqrt differs from it in the last bit now and then
-    int32_t pad_rf;
+    int32_t mat64_diag;    // the dense fp64 matrix is diagonal-major (sq_m64_index): jobs weighted by the shared stem matrix
 };
 
 // Device image of a paramset (+ host-built pow tables so every pow() is the host libm's).
@@ -48,6 +48,11 @@ struct SqPsetDev {
     // (only valid for jobs without reactivity factors or dense matrices).  pow_len == 0: no table (host-built edges)
     int32_t pow_off, pow_len;
     double pow_scale;                 // 2^q
+    // Upper bound of a candidate's finalscore from its bpscore alone (the scoring kernel's branch and bound):
+    //     finalscore = bpscore * sdf * orderfactor * loopfactor * tetra  (:732)  <=  ((bpscore * ub_of) * ub_lf) * 1.25
+    // for bpscore >= 0, with ub_of = max orderfactor, ub_lf = max loopfactor and sdf <= 1 (distcoef >= 0); ub_lf = +inf
+    // switches the bound off (paramsets where a factor has no such maximum)
+    double ub_of, ub_lf;
 };
 
 // One strand (half of a selected stem) of a partial structure, sorted by start.

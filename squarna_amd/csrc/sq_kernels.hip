@@ -18,55 +18,8 @@
 #include "sq_internal.h"
 #include "sq_device.h"
 
-// ------------------------------------------------------------------------------------
-// cell predicates / values (fp64, same operation order as the reference)
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ bool sq_cell_bool(const SqDevCtx &c, const SqJob &jb, const SqPsetDev *ps, int i, int j)
-{
-    const uint8_t *codes = c.codes + jb.pos_off;
-    const uint8_t *flags = c.flags + jb.pos_off;
-    if (j < i + (int)c.inc4[jb.pos_off + i]) return false;            // :294-299 (also j <= i)
-    const int a = codes[i], b = codes[j];
-    if (!ps->inbps[a * 32 + b]) return false;                         // :300
-    const int fi = flags[i], fj = flags[j];
-    if ((fi | fj) & 1) return false;                                  // :302 rxs
-    if (fj & 2) return false;                                         // :303 rlefts
-    if (fi & 4) return false;                                         // :304 rrights
-    if (jb.interchainonly && c.chain[jb.pos_off + i] == c.chain[jb.pos_off + j]) return false;   // :301
-    return true;
-}
-
-// reactfactor ((1 - (r_i + r_j) / 2) * 2) ** 0.5 of a cell (:333).  Sequences whose reactivities take <= 16 distinct values
-// (every encoded input does) read it from the table the host built with its libm pow -- CPython's `**` -- so those
-// factors are the reference's bit for bit; arbitrary float reactivities take IEEE sqrt, which differs from pow(x, 0.5)
-// by one ulp for ~0.08 % of x.
-__device__ __forceinline__ double sq_reactfactor(const SqDevCtx &c, const SqJob &jb, int i, int j)
-{
-    if (jb.rf_idx >= 0) {
-        const uint8_t *lv = c.ridx + jb.pos_off;
-        return c.rftab[(int64_t)jb.rf_idx * 256 + lv[i] * 16 + lv[j]];
-    }
-    const double *r = c.reacts + jb.pos_off;
-    return sqrt((1.0 - (r[i] + r[j]) / 2.0) * 2.0);
-}
-
-// value of scoremat[i,j] for a cell whose bool is 1 (:329-338)
-__device__ __forceinline__ double sq_cell_score(const SqDevCtx &c, const SqJob &jb, const SqPsetDev *ps, int i, int j)
-{
-    const uint8_t *codes = c.codes + jb.pos_off;
-    const double w = ps->w[codes[i] * 32 + codes[j]];
-    if (jb.default_reacts) return w;                                  // reactfactor 1 (and 1/1 for w <= 0): w * 1.0
-    double rf = sq_reactfactor(c, jb, i, j);
-    if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);                   // :335-336
-    return w * rf;
-}
-
-// exact cell value used for every decision (fp64): dense matrix when the job has one
-__device__ __forceinline__ double sq_cell_exact(const SqDevCtx &c, const SqJob &jb, const SqPsetDev *ps, int i, int j)
-{
-    if (jb.mat64_off >= 0) return c.mat64[jb.mat64_off + (int64_t)i * jb.n + j];
-    return sq_cell_score(c, jb, ps, i, j);
-}
+#include "sq_cells.h"
+#include "sq_context.h"
 
 // ------------------------------------------------------------------------------------
 // a-1  fill: one thread = 4 consecutive floats of the padded N x ld matrix (16-byte stores)
@@ -83,6 +36,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c, int
     const SqJob jb = c.jobs[blockIdx.y];
     if (jb.has_ext == 1) return;                       // imported from caller matrices instead
     if (only_ext && jb.has_ext == 0) return;           // the fold path of such jobs only needs the bit matrix
+    if (only_ext && jb.mat64_diag) return;             // the gather kernel has formed score x weight already (sq_gather.hip)
     const SqPsetDev *ps = c.psets + jb.pset;
     const int n = jb.n, ld = jb.ld;
     float *mat = c.mat32 + jb.mat_off;
@@ -181,16 +135,17 @@ extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c, int
             if (i < n && j < n && j > i && sq_cell_bool(c, jb, ps, i, j)) {
                 double v = sq_cell_score(c, jb, ps, i, j);
                 if (m64) {                              // :1084-1085 bpscorematrix * shortsmat
-                    if (mul_done) v = m64[(int64_t)i * n + j];          // the arena already holds the product
+                    if (mul_done) v = m64[sq_m64_index(jb, i, j)];          // the arena already holds the product
                     else {                                               // :352-354 bpp term, :1084-1085 stem matrix
-                        v = jb.ext_add ? v + m64[(int64_t)i * n + j] : v * m64[(int64_t)i * n + j];
-                        m64[(int64_t)i * n + j] = v;
+                        const int64_t at = sq_m64_index(jb, i, j);
+                        v = jb.ext_add ? v + m64[at] : v * m64[at];
+                        m64[at] = v;
                     }
                 }
                 bits = __float_as_uint((float)v);
                 if (bits == SQ_SENT_BITS) bits = 0x7FC00001u;   // a genuine NaN value stays "present"
             } else if (m64 && i < n && j < n && !jb.ext_add) {
-                m64[(int64_t)i * n + j] = 0.0;          // (an ADDED term stays where bool == 0: scoremat += term covers every cell, :352)
+                m64[sq_m64_index(jb, i, j)] = 0.0;          // (an ADDED term stays where bool == 0: scoremat += term covers every cell, :352)
             }
             out[k] = __uint_as_float(bits);
             if (++j == ld) { j = 0; i++; }
@@ -749,7 +704,8 @@ __device__ __forceinline__ bool sq_goodloop(int x, int y)             // :615-62
 template <bool FULL>
 __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct *structs, const SqStrand *strands,
                                               const SqState &stt, SqScanArgs &a, const SqRoundIO &io, int mode, int lds_n,
-                                              int lds_n_reacts, int lds_n_state, int surv_off, int cell_off, int str_off = 0, int str_cap = 0)
+                                              int lds_n_reacts, int lds_n_state, int surv_off, int cell_off, int str_off = 0, int str_cap = 0,
+                                              const SqCtxTab ct = SqCtxTab{}, int bound = 1)
 {
     // (the structure's strands and their skip pointers live in the block's DYNAMIC LDS, sized by the host for the longest
     // strand list a structure of the launch can have: a static array for 1,024 strands cost every block 10 KB, and LDS a
@@ -787,8 +743,17 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
         for (int k = tid; k < st.nstrand; k += nthr) s_str[k] = S[k];
         S = s_str;
     }
+    // structures without crossing stems: the strand sweep in closed form from the round's context tables (sq_context.h)
+    const bool use_ctx = FULL && ct.rec != nullptr && st.nstrand > 0 && ct.ok[st.slot] != 0;
+    const SqCtxRec *const ctx_rec = ct.rec + (size_t)st.slot * ct.cap;
+    const int16_t *const ctx_depth = ct.depth + (size_t)st.slot * ct.cap;
+    const uint16_t *const ctx_rmq = ct.rmq + (size_t)st.slot * ct.cap * ct.levels;
     __syncthreads();
+#ifdef SQ_CTX_CHECK
     if (lds_strands) {
+#else
+    if (lds_strands && !use_ctx) {
+#endif
         // Once the sweep of ScoreStems has registered the block [start, partner] of a 5' strand, the strands that
         // start inside it are inert unless they are 5' strands whose partner lies beyond the block's end (they extend
         // it or are wings); skip[k] = the first strand behind k that starts outside the block or is such a strand.
@@ -1054,8 +1019,20 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     uint32_t *s_key = reinterpret_cast<uint32_t *>(s_bps + (SQ_SCORE_CHUNK + 1) * nthr);
     uint16_t *s_len = reinterpret_cast<uint16_t *>(s_key + (SQ_SCORE_CHUNK + 1) * nthr);
     __shared__ uint32_t s_nsurv, s_okn;
+    // Branch and bound.  Every reader of the survivor list keeps only finalscores >= subopt x best (:769-778; width-1
+    // chains and the stopper :1147 only the best itself), and a candidate's finalscore cannot exceed
+    //     ub(bpscore) = ((bpscore * max orderfactor) * max loopfactor) * 1.25        (sq_internal.h; bpscore >= 0)
+    // -- the same multiplications in the same order with every factor at its maximum, and rounding is monotone.  So a
+    // candidate whose bound lies below subopt x (the best finalscore seen so far) -- or below minfinscore -- cannot be
+    // among them whatever ScoreStems returns, and its strand sweep, the expensive part of this kernel on long
+    // sequences, is skipped.  s_best: the block's running best, exchanged with the structure's other blocks through
+    // a.best once per chunk.  The results are those of the exhaustive evaluation bit for bit.
+    __shared__ unsigned long long s_best;
+    const double ub_of = ps->ub_of, ub_lf = bound ? ps->ub_lf : INFINITY;
+    auto upper = [&](double bps) -> double { return bps >= 0 ? (((bps * ub_of) * ub_lf) * 1.25) * (1.0 + 0x1p-30) : INFINITY; };
+    const double st_subopt = st.subopt;
     const bool solo = gridDim.y == 1;                  // this block scores every candidate of its structure
-    if (tid == 0) { s_nsurv = 0; s_okn = 0; }
+    if (tid == 0) { s_nsurv = 0; s_okn = 0; s_best = 0ull; }
     __syncthreads();
 #ifdef SQ_SCORE_PROF
     _ps = wall_clock64() - _p0;
@@ -1072,11 +1049,17 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
         }
         double bpsv[SQ_SCORE_CHUNK];
         chunk_bps(cd, bpsv);
+        // what a finalscore must reach to matter (read once per chunk; s_best only grows)
+        double need = minfin;
+        {
+            const unsigned long long sb = s_best;
+            if (sb) { const double r = st_subopt * sq_unord(sb); need = r > need ? r : need; }
+        }
 #pragma unroll
         for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
             const int L = (int)cd[u].len;
             const double bps = bpsv[u];
-            const bool ok = L > 0 && bps >= minbps;                     // :492
+            const bool ok = L > 0 && bps >= minbps && !(upper(bps) < need);   // :492, and the bound
             const unsigned long long okm = __ballot(ok);
             if (okm) {
                 uint32_t base = 0;
@@ -1106,12 +1089,27 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
             const int s = (int)(key >> 16), i0 = (int)(key & 0xFFFFu), j0 = s - i0;
             bool ok = have;
             double fin = 0.0;
+            {
+                const unsigned long long sbst = s_best;                     // (the groups before this one may have raised it)
+                if (sbst && upper(bps) < st_subopt * sq_unord(sbst)) ok = false;
+            }
             if (ok) {
                 const int sa = i0 + L - 1, sb = j0 - L + 1;                 // :655 innermost bp
                 int inblockend = -1, nrec = 0, be0 = 0, be1 = 0, covered = 0, brackets = 0;
                 uint64_t levelset = 0;
                 int lo = 0, hi = st.nstrand;
                 while (lo < hi) { const int mid = (lo + hi) >> 1; if (S[mid].start <= sa) lo = mid + 1; else hi = mid; }
+                SqCtxOut cx = {0, 0, 0, 0, 0};
+                if (use_ctx) {
+                    int lo2 = lo; hi = st.nstrand;                          // first strand that starts at or behind sb
+                    while (lo2 < hi) { const int mid = (lo2 + hi) >> 1; if (S[mid].start < sb) lo2 = mid + 1; else hi = mid; }
+                    if (lo2 > lo) sq_ctx_query(ctx_rec, ctx_depth, ctx_rmq, ct.cap, S, lo, lo2, cx);
+#ifndef SQ_CTX_CHECK
+                    nrec = cx.nrec; be0 = cx.be0; be1 = cx.be1; covered = cx.covered; brackets = cx.brackets;
+                    levelset = brackets > 0 ? 1ull : 0ull;                  // (every strand on level 1)
+                    lo = st.nstrand;                                        // the walk below has nothing left to do
+#endif
+                }
                 for (int k = lo; k < st.nstrand;) {                         // closed form of the walk :665-689
                     const SqStrand x = S[k];
                     if (x.start >= sb) break;
@@ -1138,6 +1136,12 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                     }
                     k = nk;
                 }
+#ifdef SQ_CTX_CHECK
+                if (use_ctx && (cx.nrec != nrec || cx.covered != covered || cx.brackets != brackets ||
+                                (nrec == 1 && (cx.be0 != be0 || cx.be1 != be1)) || (levelset != (brackets > 0 ? 1ull : 0ull))))
+                    printf("CTX MISMATCH struct %d cand (%d,%d,%d) nstrand %d: walk nrec %d cov %d br %d be %d %d | ctx nrec %d cov %d br %d be %d %d\n",
+                           (int)blockIdx.x, i0, j0, L, st.nstrand, nrec, covered, brackets, be0, be1, cx.nrec, cx.covered, cx.brackets, cx.be0, cx.be1);
+#endif
                 const int dots = (U[sb] - U[sa + 1]) - covered;             // :670-673
                 const bool between = (SU[sb] - SU[sa + 1]) > 0;             // :675-676
                 bool goodloop = false; int diff1 = 0;                       // :692-698
@@ -1200,9 +1204,18 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                     else a.ctr->cand_ovf = 1;
                     if (!any || fin > best) { any = 1; best = fin; }        // :769 only the best VALUE matters for the range
                 }
+                // the wave's best finalscore of this group into the block's running best
+                double wb = ok ? fin : -INFINITY;
+                for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(wb, off); wb = o > wb ? o : wb; }
+                if ((tid & 63) == leader) atomicMax(&s_best, sq_ord(wb));
             }
         }
         __syncthreads();                                                    // every thread has read the list
+        if (!solo && tid == 0) {                                            // exchange with the structure's other blocks
+            const unsigned long long mine = s_best;
+            const unsigned long long seen = mine ? atomicMax(a.best + st.slot, mine) : atomicMax(a.best + st.slot, 0ull);
+            if (seen > mine) s_best = seen;
+        }
         const uint32_t rem = ns > done ? ns - done : 0u;                    // < blockDim: carried to the next chunk
         uint32_t ck = 0; uint16_t cl = 0; double cb = 0.0;
         if ((uint32_t)tid < rem) { ck = s_key[done + tid]; cl = s_len[done + tid]; cb = s_bps[done + tid]; }
@@ -1237,9 +1250,9 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
 extern "C" __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SQ_SCORE_WAVES))) void sq_score_kernel(SqDevCtx c, const SqStruct *structs,
                                                                   const SqStrand *strands, SqState stt, SqScanArgs a,
                                                                   SqRoundIO io, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off,
-                                                                  int cell_off, int str_off, int str_cap)
+                                                                  int cell_off, int str_off, int str_cap, SqCtxTab ct, int bound)
 {
-    sq_score_body<true>(c, structs, strands, stt, a, io, 0, lds_n, lds_n_reacts, lds_n_state, surv_off, cell_off, str_off, str_cap);
+    sq_score_body<true>(c, structs, strands, stt, a, io, 0, lds_n, lds_n_reacts, lds_n_state, surv_off, cell_off, str_off, str_cap, ct, bound);
 }
 
 // modes 1 / 2 (OptimalStems output, alignment survivor list): the bpscore filter alone, as its own kernel so that its

@@ -249,7 +249,10 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_extend_kernel(SqDevCtx 
         const bool full = (double)T == rec.maxstems;
         if (lane == 0) {
             SqStruct cs;
-            cs.job = st.job; cs.strand_off = 2 * toff; cs.nstrand = full ? -1 : st.nstrand + 2; cs.slot = cslot; cs.subopt = 0.0;
+            cs.job = st.job; cs.strand_off = 2 * toff; cs.nstrand = full ? -1 : st.nstrand + 2; cs.slot = cslot;
+            // the range factor the NEXT round's choose kernel will apply (the scan kernel has already advanced it, :1116-1120):
+            // the scoring kernel bounds its candidates with it
+            cs.subopt = pio.jobs[pio.jobrec_of[st.job]].cursubopt;
             cs.cand_off = (int64_t)(cslot % pio.chunk) * pio.maxcap;
             pio.structs[nxt + cslot] = cs;
             SqChain cr;
