@@ -698,6 +698,117 @@ __device__ __forceinline__ bool sq_goodloop(int x, int y)             // :615-62
 
 // grid = (structures, parts): the candidates of a structure are dealt to `parts` blocks; the round's best
 // finalscore of the structure is combined with atomicMax, the range filter (:769-778) runs in sq_select_kernel.
+// ScoreStems for one candidate stem (SQRNdbnseq.py:607-751): what the scoring kernels know about the structure ...
+struct SqStemsEnv {
+    const SqStrand *S; const uint16_t *skip; int nstrand; bool have_skip;   // sorted strands (+ skip pointers over registered blocks)
+    const int16_t *P, *U, *SU; const uint8_t *codes; int n;                 // partner array, prefix counts, letter codes
+    bool use_ctx; const SqCtxRec *ctx_rec; const int16_t *ctx_depth; const uint16_t *ctx_rmq; int ctx_cap;   // sq_context.h
+    double lb, bw, dc; int bwint, sdflen; const double *sdf, *of;           // the paramset's scalars and tables
+    SqCounters *ctr;
+};
+// ... and the finalscore of the stem (i0, j0, L) with bpscore bps (the caller applies :751's threshold)
+__device__ __forceinline__ double sq_stem_finalscore(const SqStemsEnv &e, int i0, int j0, int L, double bps)
+{
+    double fin = 0.0;
+    const int sa = i0 + L - 1, sb = j0 - L + 1;                 // :655 innermost bp
+    int inblockend = -1, nrec = 0, be0 = 0, be1 = 0, covered = 0, brackets = 0;
+    uint64_t levelset = 0;
+    int lo = 0, hi = e.nstrand;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (e.S[mid].start <= sa) lo = mid + 1; else hi = mid; }
+    SqCtxOut cx = {0, 0, 0, 0, 0};
+    if (e.use_ctx) {
+        int lo2 = lo; hi = e.nstrand;                          // first strand that starts at or behind sb
+        while (lo2 < hi) { const int mid = (lo2 + hi) >> 1; if (e.S[mid].start < sb) lo2 = mid + 1; else hi = mid; }
+        if (lo2 > lo) sq_ctx_query(e.ctx_rec, e.ctx_depth, e.ctx_rmq, e.ctx_cap, e.S, lo, lo2, cx);
+#ifndef SQ_CTX_CHECK
+        nrec = cx.nrec; be0 = cx.be0; be1 = cx.be1; covered = cx.covered; brackets = cx.brackets;
+        levelset = brackets > 0 ? 1ull : 0ull;                  // (every strand on level 1)
+        lo = e.nstrand;                                        // the walk below has nothing left to do
+#endif
+    }
+    for (int k = lo; k < e.nstrand;) {                         // closed form of the walk :665-689
+        const SqStrand x = e.S[k];
+        if (x.start >= sb) break;
+        int nk = k + 1;
+        const int pfirst = x.pstart, plast = x.pstart - (x.len - 1);
+        bool wing;
+        if (x.left) {
+            wing = pfirst > sb;
+            if (!wing && pfirst > inblockend) {                 // :687-689 sub-ECR face
+                if (nrec == 0) { be0 = x.start; be1 = pfirst; }
+                nrec++;
+                const int from = x.start > inblockend ? x.start : inblockend + 1;
+                covered += e.U[pfirst + 1] - e.U[from];
+                inblockend = pfirst;
+                if (e.have_skip) nk = e.skip[k];                // nothing inside the block can matter
+            }
+        } else {
+            wing = plast < sa;
+        }
+        if (wing && x.start > inblockend) {                     // :679-684
+            brackets += x.len;
+            if (x.level > SQ_MAXLEVELS) e.ctr->level_ovf = 1;
+            else levelset |= 1ull << (x.level - 1);
+        }
+        k = nk;
+    }
+#ifdef SQ_CTX_CHECK
+    if (e.use_ctx && (cx.nrec != nrec || cx.covered != covered || cx.brackets != brackets ||
+                    (nrec == 1 && (cx.be0 != be0 || cx.be1 != be1)) || (levelset != (brackets > 0 ? 1ull : 0ull))))
+        printf("CTX MISMATCH struct %d cand (%d,%d,%d) nstrand %d: walk nrec %d cov %d br %d be %d %d | ctx nrec %d cov %d br %d be %d %d\n",
+               (int)blockIdx.x, i0, j0, L, e.nstrand, nrec, covered, brackets, be0, be1, cx.nrec, cx.covered, cx.brackets, cx.be0, cx.be1);
+#endif
+    const int dots = (e.U[sb] - e.U[sa + 1]) - covered;             // :670-673
+    const bool between = (e.SU[sb] - e.SU[sa + 1]) > 0;             // :675-676
+    bool goodloop = false; int diff1 = 0;                       // :692-698
+    if (nrec == 1 && sq_goodloop(be0 - sa - 1, sb - be1 - 1)) {
+        goodloop = true;
+        diff1 = abs((be0 - sa - 1) - (sb - be1 - 1));
+    }
+    bool goodloopout = false; int diff2 = 0;                    // :700-711
+    {
+        // the two outward walks over <= 5 unpaired positions (:702-707), from the prefix counts: the k
+        // positions next to the stem are all unpaired iff the count over them is k -- ten independent
+        // reads instead of two chains of dependent ones
+        const int ui = e.U[i0], uj = e.U[j0 + 1];
+        int cl = 0, cr = 0;
+#pragma unroll
+        for (int k = 1; k <= 5; k++) {
+            const int a1 = i0 - k, b1 = j0 + 1 + k;
+            cl += (a1 >= 0 && ui - e.U[a1 >= 0 ? a1 : 0] == k) ? 1 : 0;
+            cr += (b1 <= e.n && e.U[b1 <= e.n ? b1 : e.n] - uj == k) ? 1 : 0;
+        }
+        const int vv = i0 - 1 - cl, ww = j0 + 1 + cr;
+        if (vv >= 0 && ww < e.n && e.P[vv] == ww && sq_goodloop(cl, cr)) {
+            goodloopout = true;
+            diff2 = abs(cl - cr);
+        }
+    }
+    const double lb = e.lb;
+    const double loopfactor = (1.0 + (lb * (goodloop ? 1.0 : 0.0)) * (2.0 - diff1 / 2.0))
+                              + (lb * (goodloopout ? 1.0 : 0.0)) * (2.0 - diff2 / 2.0);   // :715
+    bool gnra = false;                                          // :598-604,718
+    if (sb - sa - 1 == 4 && e.codes[sa + 1] == 6 && (e.codes[sa + 3] == 6 || e.codes[sa + 3] == 0) && e.codes[sa + 4] == 0)
+        gnra = true;
+    const double tetra = gnra ? 1.25 : 1.0;
+    const double ideal = nrec == 0 ? 4.0 : 2.0;                 // :721
+    const double stemdist = (double)dots + e.bw * (double)brackets;   // :723
+    const double dd = fabs(stemdist - ideal);
+    double sdf = 1.0;                                           // :726
+    if (!between) {
+        const int di = (int)dd;
+        if (e.bwint && di < e.sdflen) sdf = e.sdf[di];
+        else sdf = pow(1.0 / (1.0 + dd), e.dc);
+    }
+    const double of = e.of[__popcll(levelset)];            // :728-729
+    fin = bps * sdf * of * loopfactor * tetra;                  // :732 (reactfactor == 1)
+    if (!goodloop && !goodloopout && L < 3) fin = -1.0;         // :744-745
+    return fin;
+}
+
+#ifndef SQ_DIAG_TOGETHER
+#define SQ_DIAG_TOGETHER 2        // candidates of a chunk whose first cells are read together (alignment step 2)
+#endif
 #ifndef SQ_SCORE_WAVES
 #define SQ_SCORE_WAVES 5                             // 96 VGPRs: five waves per SIMD instead of four at 97
 #endif
@@ -905,6 +1016,33 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     // leaves its sum unchanged.  The filter-only kernel advances its candidates TOGETHER (16 lookups in flight; 3.1 ->
     // 1.9 ms per alignment chunk); under ScoreStems' register budget that spills, so there they go one by one.
     auto chunk_bps = [&](const SqKey (&cd)[SQ_SCORE_CHUNK], double (&bps)[SQ_SCORE_CHUNK]) {
+        if (FULL && jb.mat64_diag) {
+            // alignment step 2: the cells of a stem are consecutive doubles of the job's diagonal-major product matrix
+            // (sq_cells.h) -- one index per candidate, and the first four cells of TWO candidates in flight together
+            // (the reads come from HBM / L2: their latency, not their number, is what this phase waits for)
+            const double *const m64 = c.mat64 + jb.mat64_off;
+#pragma unroll
+            for (int u = 0; u < SQ_SCORE_CHUNK; u += SQ_DIAG_TOGETHER) {
+                const double *mp[SQ_DIAG_TOGETHER]; int Ls[SQ_DIAG_TOGETHER]; double v[SQ_DIAG_TOGETHER][4];
+#pragma unroll
+                for (int h = 0; h < SQ_DIAG_TOGETHER; h++) {
+                    const int s = (int)(cd[u + h].key >> 16), i0 = (int)(cd[u + h].key & 0xFFFFu);
+                    Ls[h] = (int)cd[u + h].len;
+                    mp[h] = m64 + (Ls[h] > 0 ? sq_m64_index(jb, i0, s - i0) : 0);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[h][k] = mp[h][Ls[h] > 0 ? min(k, Ls[h] - 1) : 0];
+                }
+#pragma unroll
+                for (int h = 0; h < SQ_DIAG_TOGETHER; h++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc = acc + (k < Ls[h] ? v[h][k] : 0.0);
+                    for (int t = 4; t < Ls[h]; t++) acc = acc + mp[h][t];
+                    bps[u + h] = acc;
+                }
+            }
+            return;
+        }
         if (FULL) {
 #pragma unroll
             for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
@@ -1032,6 +1170,8 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     auto upper = [&](double bps) -> double { return bps >= 0 ? (((bps * ub_of) * ub_lf) * 1.25) * (1.0 + 0x1p-30) : INFINITY; };
     const double st_subopt = st.subopt;
     const bool solo = gridDim.y == 1;                  // this block scores every candidate of its structure
+    const SqStemsEnv env = {S, s_skip, st.nstrand, lds_strands, P, U, SU, codes, n, use_ctx, ctx_rec, ctx_depth, ctx_rmq, ct.cap,
+                            ps_lb, ps_bw, ps_dc, ps_bwint, ps_sdflen, ps_sdf, ps_of, a.ctr};
     if (tid == 0) { s_nsurv = 0; s_okn = 0; s_best = 0ull; }
     __syncthreads();
 #ifdef SQ_SCORE_PROF
@@ -1094,99 +1234,7 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                 if (sbst && upper(bps) < st_subopt * sq_unord(sbst)) ok = false;
             }
             if (ok) {
-                const int sa = i0 + L - 1, sb = j0 - L + 1;                 // :655 innermost bp
-                int inblockend = -1, nrec = 0, be0 = 0, be1 = 0, covered = 0, brackets = 0;
-                uint64_t levelset = 0;
-                int lo = 0, hi = st.nstrand;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (S[mid].start <= sa) lo = mid + 1; else hi = mid; }
-                SqCtxOut cx = {0, 0, 0, 0, 0};
-                if (use_ctx) {
-                    int lo2 = lo; hi = st.nstrand;                          // first strand that starts at or behind sb
-                    while (lo2 < hi) { const int mid = (lo2 + hi) >> 1; if (S[mid].start < sb) lo2 = mid + 1; else hi = mid; }
-                    if (lo2 > lo) sq_ctx_query(ctx_rec, ctx_depth, ctx_rmq, ct.cap, S, lo, lo2, cx);
-#ifndef SQ_CTX_CHECK
-                    nrec = cx.nrec; be0 = cx.be0; be1 = cx.be1; covered = cx.covered; brackets = cx.brackets;
-                    levelset = brackets > 0 ? 1ull : 0ull;                  // (every strand on level 1)
-                    lo = st.nstrand;                                        // the walk below has nothing left to do
-#endif
-                }
-                for (int k = lo; k < st.nstrand;) {                         // closed form of the walk :665-689
-                    const SqStrand x = S[k];
-                    if (x.start >= sb) break;
-                    int nk = k + 1;
-                    const int pfirst = x.pstart, plast = x.pstart - (x.len - 1);
-                    bool wing;
-                    if (x.left) {
-                        wing = pfirst > sb;
-                        if (!wing && pfirst > inblockend) {                 // :687-689 sub-ECR face
-                            if (nrec == 0) { be0 = x.start; be1 = pfirst; }
-                            nrec++;
-                            const int from = x.start > inblockend ? x.start : inblockend + 1;
-                            covered += U[pfirst + 1] - U[from];
-                            inblockend = pfirst;
-                            if (lds_strands) nk = s_skip[k];                // nothing inside the block can matter
-                        }
-                    } else {
-                        wing = plast < sa;
-                    }
-                    if (wing && x.start > inblockend) {                     // :679-684
-                        brackets += x.len;
-                        if (x.level > SQ_MAXLEVELS) a.ctr->level_ovf = 1;
-                        else levelset |= 1ull << (x.level - 1);
-                    }
-                    k = nk;
-                }
-#ifdef SQ_CTX_CHECK
-                if (use_ctx && (cx.nrec != nrec || cx.covered != covered || cx.brackets != brackets ||
-                                (nrec == 1 && (cx.be0 != be0 || cx.be1 != be1)) || (levelset != (brackets > 0 ? 1ull : 0ull))))
-                    printf("CTX MISMATCH struct %d cand (%d,%d,%d) nstrand %d: walk nrec %d cov %d br %d be %d %d | ctx nrec %d cov %d br %d be %d %d\n",
-                           (int)blockIdx.x, i0, j0, L, st.nstrand, nrec, covered, brackets, be0, be1, cx.nrec, cx.covered, cx.brackets, cx.be0, cx.be1);
-#endif
-                const int dots = (U[sb] - U[sa + 1]) - covered;             // :670-673
-                const bool between = (SU[sb] - SU[sa + 1]) > 0;             // :675-676
-                bool goodloop = false; int diff1 = 0;                       // :692-698
-                if (nrec == 1 && sq_goodloop(be0 - sa - 1, sb - be1 - 1)) {
-                    goodloop = true;
-                    diff1 = abs((be0 - sa - 1) - (sb - be1 - 1));
-                }
-                bool goodloopout = false; int diff2 = 0;                    // :700-711
-                {
-                    // the two outward walks over <= 5 unpaired positions (:702-707), from the prefix counts: the k
-                    // positions next to the stem are all unpaired iff the count over them is k -- ten independent
-                    // reads instead of two chains of dependent ones
-                    const int ui = U[i0], uj = U[j0 + 1];
-                    int cl = 0, cr = 0;
-#pragma unroll
-                    for (int k = 1; k <= 5; k++) {
-                        const int a1 = i0 - k, b1 = j0 + 1 + k;
-                        cl += (a1 >= 0 && ui - U[a1 >= 0 ? a1 : 0] == k) ? 1 : 0;
-                        cr += (b1 <= n && U[b1 <= n ? b1 : n] - uj == k) ? 1 : 0;
-                    }
-                    const int vv = i0 - 1 - cl, ww = j0 + 1 + cr;
-                    if (vv >= 0 && ww < n && P[vv] == ww && sq_goodloop(cl, cr)) {
-                        goodloopout = true;
-                        diff2 = abs(cl - cr);
-                    }
-                }
-                const double lb = ps_lb;
-                const double loopfactor = (1.0 + (lb * (goodloop ? 1.0 : 0.0)) * (2.0 - diff1 / 2.0))
-                                          + (lb * (goodloopout ? 1.0 : 0.0)) * (2.0 - diff2 / 2.0);   // :715
-                bool gnra = false;                                          // :598-604,718
-                if (sb - sa - 1 == 4 && codes[sa + 1] == 6 && (codes[sa + 3] == 6 || codes[sa + 3] == 0) && codes[sa + 4] == 0)
-                    gnra = true;
-                const double tetra = gnra ? 1.25 : 1.0;
-                const double ideal = nrec == 0 ? 4.0 : 2.0;                 // :721
-                const double stemdist = (double)dots + ps_bw * (double)brackets;   // :723
-                const double dd = fabs(stemdist - ideal);
-                double sdf = 1.0;                                           // :726
-                if (!between) {
-                    const int di = (int)dd;
-                    if (ps_bwint && di < ps_sdflen) sdf = ps_sdf[di];
-                    else sdf = pow(1.0 / (1.0 + dd), ps_dc);
-                }
-                const double of = ps_of[__popcll(levelset)];            // :728-729
-                fin = bps * sdf * of * loopfactor * tetra;                  // :732 (reactfactor == 1)
-                if (!goodloop && !goodloopout && L < 3) fin = -1.0;         // :744-745
+                fin = sq_stem_finalscore(env, i0, j0, L, bps);
                 ok = fin >= minfin;                                         // :751
             }
             // survivors are appended to the structure's SqOk list: one atomic per wave, lanes ranked by ballot
