@@ -1259,6 +1259,9 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
             }
         }
         __syncthreads();                                                    // every thread has read the list
+        // no group was due: the list stays as it is (and the block's best has not moved: nothing to exchange) -- four
+        // barriers and a global round trip less per chunk; long sequences run dozens of such chunks per launch
+        if (done == 0) continue;
         if (!solo && tid == 0) {                                            // exchange with the structure's other blocks
             const unsigned long long mine = s_best;
             const unsigned long long seen = mine ? atomicMax(a.best + st.slot, mine) : atomicMax(a.best + st.slot, 0ull);
