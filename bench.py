@@ -171,7 +171,7 @@ def mean_fs(results):
 # ---------------------------------------------------------------- PMC summaries (profiles/traffic.json)
 def kernels_hash():
     h = hashlib.sha256()
-    for f in ("sq_kernels.hip", "sq_match.hip", "sq_blossom.h"):
+    for f in ("sq_kernels.hip", "sq_cells.h", "sq_context.h", "sq_context.hip", "sq_match.hip", "sq_blossom.h"):
         with open(os.path.join(ROOT, "squarna_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
