@@ -374,7 +374,7 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
             if (rl) return sq_check((hipError_t)rl, "matching kernel launch");
         }
         if (other && ck.classes.size() > 1) {
-            if (!b->class_ev) HIPCK(hipEventCreateWithFlags(&b->class_ev, hipEventDisableTiming));
+            if (!b->class_ev) HIPCK(sq_event_get(b->device, &b->class_ev));
             HIPCK(hipEventRecord(b->class_ev, other));
             HIPCK(hipStreamWaitEvent(st, b->class_ev, 0));
         }
@@ -717,8 +717,8 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
     hipStream_t st = b->stream;
     hipLaunchKernelGGL(sq_algo_edges_kernel, dim3(S), dim3(256), 0, st, b->ctx, b->lane_full.d_structs, [&] { SqScanArgs a = b->scan; a.ctr = b->lane_full.d_ctr; return a; }(), round_aj);
     HIPCK(hipGetLastError());
-    if (!b->class_ev) HIPCK(hipEventCreateWithFlags(&b->class_ev, hipEventDisableTiming));
-    if (!b->edges_ev) HIPCK(hipEventCreateWithFlags(&b->edges_ev, hipEventDisableTiming));
+    if (!b->class_ev) HIPCK(sq_event_get(b->device, &b->class_ev));
+    if (!b->edges_ev) HIPCK(sq_event_get(b->device, &b->edges_ev));
     HIPCK(hipEventRecord(b->edges_ev, st));
     if (fin_lds > 64 * 1024) sq_max_dynamic_lds((const void *)sq_algo_finish_kernel, 160 * 1024);
     sidx = 0;
@@ -726,7 +726,7 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
         auto &it = pa->items[q];
         SqAlgoChunk &ck = it.ck;
         const int ss = side_of(b, sidx);
-        if (!b->side[ss]) { if (sq_check(hipStreamCreateWithFlags(&b->side[ss], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
+        if (!b->side[ss]) { if (sq_check(sq_stream_get(b->device, &b->side[ss]), "hipStreamCreate")) return 2; }
         hipStream_t cs = b->side[ss];
         HIPCK(hipStreamWaitEvent(cs, b->edges_ev, 0));
         ck.st = cs;
@@ -751,7 +751,7 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
             hipStream_t other = nullptr;
             if (it.algo == SQ_ALGO_E && ck.classes.size() > 1 && side_of(b, 1) != ss) {
                 const int s2 = side_of(b, 1);
-                if (!b->side[s2]) { if (sq_check(hipStreamCreateWithFlags(&b->side[s2], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
+                if (!b->side[s2]) { if (sq_check(sq_stream_get(b->device, &b->side[s2]), "hipStreamCreate")) return 2; }
                 other = b->side[s2];
                 HIPCK(hipStreamWaitEvent(other, b->edges_ev, 0));
             }
@@ -867,12 +867,12 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
             region = (char *)(((uintptr_t)region + 255) & ~(uintptr_t)255);
         }
         const int ss = side_of(b, sidx);
-        if (!b->side[ss]) { if (sq_check(hipStreamCreateWithFlags(&b->side[ss], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
+        if (!b->side[ss]) { if (sq_check(sq_stream_get(b->device, &b->side[ss]), "hipStreamCreate")) return 2; }
         const double tl0 = sq_now();
         hipStream_t st2 = nullptr;
         if (it.algo == SQ_ALGO_E && side_of(b, 1) != ss) {               // the stream of the short kernels (created here if need be)
             const int s2 = side_of(b, 1);
-            if (!b->side[s2]) { if (sq_check(hipStreamCreateWithFlags(&b->side[s2], hipStreamNonBlocking), "hipStreamCreate")) return 2; }
+            if (!b->side[s2]) { if (sq_check(sq_stream_get(b->device, &b->side[s2]), "hipStreamCreate")) return 2; }
             st2 = b->side[s2];
         }
         const int r = algo_launch(b, it.ck, region, b->side[ss], st2);

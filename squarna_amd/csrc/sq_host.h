@@ -75,6 +75,7 @@ public:
     // more than it buys.
     void parallel_for(int n, const std::function<void(int)> &fn, int wide = -1);
     int size() const { return (int)workers.size() + 1; }
+    const int nthreads, device;          // (idle pools are kept for the next batch that asks for the same: sq_host.hip)
 private:
     void worker(int group);
     std::vector<std::thread> workers;
@@ -226,6 +227,14 @@ void sq_set_error(const std::string &msg);
 // and a caller that builds one batch per call (Predict) would pay them every time
 int sq_pinned_get(void **p, size_t bytes);     // 0 or an error code (message set)
 void sq_pinned_put(void *p);                   // the streams that used the buffer must be idle
+// Process-wide caches of the objects a batch needs for a fold and that cost HIP a fraction of a millisecond each to make
+// and to destroy (measured: 1.2 ms of a 10.6 ms Predict() on SRtest150 was sq_batch_destroy): non-blocking streams,
+// timing-free events -- per device -- and the host worker pools.  A batch takes them when it first needs them and hands
+// them back (idle) when it is destroyed.
+hipError_t sq_stream_get(int device, hipStream_t *s);
+void sq_stream_put(int device, hipStream_t s);
+hipError_t sq_event_get(int device, hipEvent_t *e);
+void sq_event_put(int device, hipEvent_t e);
 int sq_check(hipError_t e, const char *what);
 // hipFuncAttributeMaxDynamicSharedMemorySize of `fn` on the CURRENT device, set once per (kernel, device): the
 // attribute is per device and a process may fold on several (one worker thread per batch); thread-safe

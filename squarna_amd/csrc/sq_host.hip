@@ -111,13 +111,13 @@ void sq_wait_step(uint64_t spins, bool relaxed)
 }
 
 // ---- host worker pool -------------------------------------------------------------------------
-SqPool::SqPool(int nthreads, int device)
+SqPool::SqPool(int nthreads_, int device_) : nthreads(nthreads_), device(device_)
 {
     for (int t = 1; t < nthreads; t++) {
         const int group = t <= 15 ? 0 : 1;
         group_size[group]++;
         // (workers call into HIP -- stream queries, copies of dense matrices: they work on the batch's device)
-        workers.emplace_back([this, group, device] { if (device >= 0) hipSetDevice(device); worker(group); });
+        workers.emplace_back([this, group] { if (device >= 0) hipSetDevice(device); worker(group); });
     }
 }
 SqPool::~SqPool()
@@ -159,6 +159,8 @@ void SqPool::parallel_for(int n, const std::function<void(int)> &f, int wide)
     std::unique_lock<std::mutex> lk(mu);
     cv_done.wait(lk, [&] { return active == 0; });
 }
+static SqPool *pool_get(int nthr, int device);
+static void pool_put(SqPool *p);
 SqPool *sq_pool(sq_batch *b)
 {
     if (!b->pool) {
@@ -172,9 +174,79 @@ SqPool *sq_pool(sq_batch *b)
         if (const char *lws = getenv("LOCAL_WORLD_SIZE")) cores = std::max(1u, cores / (unsigned)std::max(1, atoi(lws)));
         int nthr = (int)std::min(std::max(4u * cores / (unsigned)std::max(1, b->inflight), 8u), 32u);
         if (const char *e = getenv("SQ_HOST_THREADS")) nthr = std::max(1, atoi(e));
-        b->pool = new SqPool(nthr, b->device);
+        b->pool = pool_get(nthr, b->device);
     }
     return b->pool;
+}
+
+// ---- stream / event / worker-pool caches ----------------------------------------------------------
+namespace {
+struct ObjCache {
+    std::mutex mu;
+    std::unordered_map<int, std::vector<hipStream_t>> streams;
+    std::unordered_map<int, std::vector<hipEvent_t>> events;
+    std::vector<SqPool *> pools;
+} g_objs;
+}
+hipError_t sq_stream_get(int device, hipStream_t *s)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_objs.mu);
+        auto &v = g_objs.streams[device];
+        if (!v.empty()) { *s = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+void sq_stream_put(int device, hipStream_t s)
+{
+    if (!s) return;
+    {
+        std::lock_guard<std::mutex> lk(g_objs.mu);
+        auto &v = g_objs.streams[device];
+        if (v.size() < 64) { v.push_back(s); return; }
+    }
+    hipStreamDestroy(s);
+}
+hipError_t sq_event_get(int device, hipEvent_t *e)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_objs.mu);
+        auto &v = g_objs.events[device];
+        if (!v.empty()) { *e = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    return hipEventCreateWithFlags(e, hipEventDisableTiming);
+}
+void sq_event_put(int device, hipEvent_t e)
+{
+    if (!e) return;
+    {
+        std::lock_guard<std::mutex> lk(g_objs.mu);
+        auto &v = g_objs.events[device];
+        if (v.size() < 256) { v.push_back(e); return; }
+    }
+    hipEventDestroy(e);
+}
+static SqPool *pool_get(int nthr, int device)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_objs.mu);
+        for (size_t k = 0; k < g_objs.pools.size(); k++)
+            if (g_objs.pools[k]->nthreads == nthr && g_objs.pools[k]->device == device) {
+                SqPool *p = g_objs.pools[k];
+                g_objs.pools.erase(g_objs.pools.begin() + k);
+                return p;
+            }
+    }
+    return new SqPool(nthr, device);
+}
+static void pool_put(SqPool *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_objs.mu);
+        if (g_objs.pools.size() < 16) { g_objs.pools.push_back(p); return; }   // (its workers sleep on a condition variable)
+    }
+    delete p;
 }
 
 // ---- pinned buffer cache --------------------------------------------------------------------------
@@ -912,10 +984,10 @@ extern "C" void sq_batch_destroy(sq_batch *b)
 {
     if (!b) return;
     hipStreamSynchronize(b->stream);
-    for (int k = 0; k < 3; k++) if (b->side[k]) { hipStreamSynchronize(b->side[k]); hipStreamDestroy(b->side[k]); }
-    if (b->lane_stream) { hipStreamSynchronize(b->lane_stream); hipStreamDestroy(b->lane_stream); }
-    if (b->class_ev) hipEventDestroy(b->class_ev);
-    if (b->edges_ev) hipEventDestroy(b->edges_ev);
+    for (int k = 0; k < 3; k++) if (b->side[k]) { hipStreamSynchronize(b->side[k]); sq_stream_put(b->device, b->side[k]); }
+    if (b->lane_stream) { hipStreamSynchronize(b->lane_stream); sq_stream_put(b->device, b->lane_stream); }
+    sq_event_put(b->device, b->class_ev);
+    sq_event_put(b->device, b->edges_ev);
     sq_pinned_put(b->h_structs); sq_pinned_put(b->h_strands); sq_pinned_put(b->h_ctr); sq_pinned_put(b->h_seq);
     sq_pinned_put(b->h_ctr2); sq_pinned_put(b->h_seq2); sq_pinned_put(b->h_out);
     for (int k = 0; k < 4; k++) sq_pinned_put(b->stage_buf[k]);
@@ -925,8 +997,8 @@ extern "C" void sq_batch_destroy(sq_batch *b)
     sq_pinned_put(b->h_tail_totals); sq_pinned_put(b->h_rec_off); sq_pinned_put(b->h_txt_off); sq_pinned_put(b->h_deep);
     sq_pinned_put(b->h_rec); sq_pinned_put(b->h_txt); sq_pinned_put(b->h_app); sq_pinned_put(b->h_ref);
     sq_pinned_put(b->h_pool_recs); sq_pinned_put(b->h_pool_jobs); sq_pinned_put(b->h_pool_jobrec);
-    delete b->pool;
-    if (b->lane_ev) hipEventDestroy(b->lane_ev);
+    pool_put(b->pool);
+    sq_event_put(b->device, b->lane_ev);
     for (auto &p : b->prof) {
         for (auto &e : p.pending) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
         for (auto &e : p.pool) hipEventDestroy(e);
@@ -2240,8 +2312,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         static const bool lane_own_stream = !getenv("SQ_LANE_SAME_STREAM");
         if (lane_own_stream) {
             if (!b->lane_stream) {
-                HIPCK(hipStreamCreateWithFlags(&b->lane_stream, hipStreamNonBlocking));
-                HIPCK(hipEventCreateWithFlags(&b->lane_ev, hipEventDisableTiming));
+                HIPCK(sq_stream_get(b->device, &b->lane_stream));
+                HIPCK(sq_event_get(b->device, &b->lane_ev));
             }
             HIPCK(hipEventRecord(b->lane_ev, b->stream));
             HIPCK(hipStreamWaitEvent(b->lane_stream, b->lane_ev, 0));

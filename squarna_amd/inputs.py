@@ -84,6 +84,9 @@ def ParseDefaultInput(inputname, inputformat, returndefaults=False, ignore=False
         yield record(name, lines)
 
 
+_NOT_ACGUT = {ord(c): None for c in "ACGUTacgut"}
+
+
 def GuessFormat(inp):
     """default / fasta / stockholm / clustal, plus "single entry?" (SQUARNA.py:206-236)."""
     with open(inp) as fh:
@@ -98,8 +101,8 @@ def GuessFormat(inp):
             if line.startswith(">"):
                 entries += 1
                 continue
-            up = line.upper()
-            if up.count("A") + up.count("C") + up.count("G") + up.count("U") + up.count("T") > len(line) / 2:
+            # (letters of ACGUT in either case: one translate instead of an upper() and five count() per line)
+            if len(line) - len(line.translate(_NOT_ACGUT)) > len(line) / 2:
                 seqlines += 1
             if seqlines > 1000:
                 break
