@@ -3,17 +3,20 @@
 
 metric   : sequences/sec on SRtest150 (219 records, 8-150 nt, if=qf, c=nobpp: all five algorithms), whole job
            (bit-matrix fill + greedy stem loop + Edmonds / Hungarian / Nussinov + ranking tail), inputs resident in HBM.
-step     : one fold of `--inflight` (default 8) independent 219-record batches per GPU, in flight at the same time
-           (sq_fold_concurrent: one host thread and one set of streams per batch).  One batch alone is a single 6.5 ms
-           latency chain (the blossom kernel of its largest graph, one wave) that leaves the chip > 99 % idle; batches
-           in flight are the steady state of a server that streams input files.  The latency of ONE batch is
-           reported beside it (`single_batch`).  N > 1: weak scaling -- every rank folds its own batches, independent
+step     : one fold of `--inflight` (default 8) independent batches per GPU, in flight at the same time (sq_fold_concurrent:
+           one host thread and one set of streams per batch), each holding `--replicas` (default 12) copies of the 219-record
+           set: 21,024 records per step.  One batch of 219 records alone is a single 5.8 ms latency chain (the blossom
+           kernel of its largest graph, one wave) that leaves the chip > 99 % idle; batches in flight are the steady state
+           of a server that streams input files, and the copies per batch amortise the fixed cost of the ~200 kernel
+           launches of a fold (measured: 8 x 6 copies 429 k seq/s, 8 x 12 466 k, 8 x 24 463 k).  The latency of ONE
+           219-record batch is reported beside it (`single_batch`), and `one_pass` / `stream` / `end_to_end` time the
+           same records arriving from the host.  N > 1: weak scaling -- every rank folds its own batches, independent
            sequences, no data-path collective.
-roofline : `roofline` = the stem-scan kernel (sq_scan6_kernel) on synthetic S1000 (1,024 random-ACGU
-           sequences, N = 1000, c=fastest, pl=1): launch time from HIP events on the library's stream (live), HBM bytes
-           per launch from the rocprofv3 PMC pass recorded in profiles/traffic.json (refused when the kernels' source
-           has changed since).  `rooflines` = one object per kernel that dominates a leg (blossom kernel of the headline
-           step, scoring kernel of S1000), each with the resource that binds it and the measured ceiling.
+roofline : `roofline` = the dominant kernel of the S1000 leg (1,024 random-ACGU sequences, N = 1000, c=fastest,
+           pl=1), today sq_score_kernel: launch time from HIP events on the library's stream (live), HBM bytes per launch
+           from the rocprofv3 PMC pass recorded in profiles/traffic.json (withheld when the kernels' sources have changed
+           since).  `rooflines` = the other kernels that dominate a leg (blossom kernel of the headline step with its
+           cycles per scan pass, the scan kernel, the fp32 fill), each with the resource that binds it.
 cpu_baseline: the CPU oracle (oracle/, a C port of the reference algorithm + the reference's own scipy / networkx
            calls) on the same workload, one process per host core; S1000 / S2000 on a stated subsample.
 --workload S300|S1000|S2000: strong-scaling mode (SURVEY 8d workloads sharded over the ranks with lpt_partition, one
@@ -536,7 +539,7 @@ def main():
     ap.add_argument("--config", default="nobpp")
     ap.add_argument("--inflight", type=int, default=0,
                     help="independent SRtest150 batches in flight per GPU (0 = 8)")
-    ap.add_argument("--replicas", type=int, default=6,
+    ap.add_argument("--replicas", type=int, default=12,
                     help="copies of the 219-record SRtest150 set per batch (kernels and host rounds are shared by the copies)")
     ap.add_argument("--workload", default="srtest150", choices=["srtest150", "S300", "S1000", "S2000"])
     ap.add_argument("--sub-batches", type=int, default=0,

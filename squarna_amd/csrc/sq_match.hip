@@ -339,7 +339,9 @@ __device__ __forceinline__ void sq_mwm_one(SqBlossom &bl, char *lds_base, char *
 }
 
 // several graphs per block (one per wave), each in its slice of the block's dynamic LDS
-extern "C" __global__ __launch_bounds__(512) void sq_mwm_kernel(const SqMatchJob *jobs, const int32_t *bin_head,
+// (second launch bound: four waves per SIMD, i.e. at most 128 VGPRs -- the compiler otherwise takes the 248 a 512-thread block
+// may have and two graphs per SIMD fill the register file; 24 SRtest150 sets in one batch: Edmonds 16.9 -> 13.0 ms)
+extern "C" __global__ __launch_bounds__(512, 4) void sq_mwm_kernel(const SqMatchJob *jobs, const int32_t *bin_head,
                                                                 const SqMatchEdge *edges, char *scratch, int32_t *mate_out,
                                                                 uint32_t *job_flags, uint32_t stamp)
 {

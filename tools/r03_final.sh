@@ -11,7 +11,7 @@ cp $(find /tmp/bstats -name "*kernel_stats.csv" | head -1) $out/r03_bench_kernel
   echo "== the same under taskset -c 0-1 (2 CPUs)"; taskset -c 0-1 python bench.py --steps 20 --warmup 3 --no-cpu --no-roofline --no-stream 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'seq/s', d['ms_per_step'], 'ms per step; host', d['host'])"; } > $out/r03_cpus.txt 2>&1
 { for w in S300 S1000 S2000; do python bench.py --workload $w --steps 10 --warmup 2 2>/dev/null | tail -1; done; } > $out/r03_sharded_world1.txt
 { echo "== batches in flight (K) x SRtest150 sets per batch (R): seq/s, ms per step, busy CPUs";
-  for kr in "1 1" "1 6" "1 24" "2 12" "4 6" "8 3" "8 6" "12 6" "16 3"; do set -- $kr; python bench.py --steps 10 --warmup 2 --inflight $1 --replicas $2 --no-cpu --no-roofline --no-stream 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('K=$1 R=$2', d['value'], d['ms_per_step'], d['host']['busy_cpus'])"; done;
+  for kr in "1 1" "1 6" "1 24" "2 12" "4 6" "8 3" "8 6" "8 12" "8 24" "12 12" "16 3"; do set -- $kr; python bench.py --steps 10 --warmup 2 --inflight $1 --replicas $2 --no-cpu --no-roofline --no-stream 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('K=$1 R=$2', d['value'], d['ms_per_step'], d['host']['busy_cpus'])"; done;
   echo "== CPU time per host phase of one fold (SQ_CPUACC=1, one 219-record batch alone; 'caller' and 'end' are mostly the spin-wait on the blossom kernel)"; SQ_CPUACC=1 python tools/concurrent_probe.py 1 6 2>&1 | grep -E "cpu ms|^K=|CPU" | tail -3;
   echo "== the same with 8 batches in flight (relaxed waits: sleeping instead of spinning)"; python tools/concurrent_probe.py 8 10 2>&1 | grep -E "^K=|CPU" | tail -2;
   echo "== one big batch: per-kernel ms (HIP events; kernels of different streams overlap)"; for r in 1 6 24; do python tools/big_batch_probe.py $r 2>&1 | grep -E "^R=|^\{.bits" | tail -2; done; } > $out/r03_concurrency.txt 2>&1
