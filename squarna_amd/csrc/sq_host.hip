@@ -1312,7 +1312,10 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
         // the per-structure arrays are assembled in LDS (7 bytes per position) when the longest sequence fits
         const int st_lds_n = maxn <= 8000 ? maxn : 0;
         const size_t st_dyn = st_lds_n ? (size_t)7 * ((st_lds_n + 8) & ~7) + 64 : 0;
-        hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(256), st_dyn, st, b->ctx, io, b->state, scan, st_lds_n, chained ? 1 : 0);
+        // (sequences up to 200 nt: one wave builds the arrays in three or four steps; four waves per structure held four
+        // times the wave slots for the same few microseconds -- with batches in flight the chip is short of exactly those)
+        static const int state_short = getenv("SQ_STATE_SHORT_THREADS") ? std::max(64, std::min(256, atoi(getenv("SQ_STATE_SHORT_THREADS")) / 64 * 64)) : 64;
+        hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(maxn <= 200 ? state_short : 256), st_dyn, st, b->ctx, io, b->state, scan, st_lds_n, chained ? 1 : 0);
     }
     // mode 0: the context tables of the round's structures (only long-sequence batches carry them)
     const bool ctx_on = mode == 0 && b->ctxtab.rec != nullptr && b->score_ctx;
@@ -1348,7 +1351,7 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
         // short ones leave half of such a block idle behind its set-up (n = 300: 10,000 chains 5.9 -> 4.6 ms, pools
         // of a thousand 24 -> 16 ns per structure and round with 256).  SRtest150 (up to ~500 nt) measures the same
         // either way within the run-to-run spread and keeps 512.
-        static const int short_thr = getenv("SQ_SCORE_SHORT_THREADS") ? atoi(getenv("SQ_SCORE_SHORT_THREADS")) : 128;
+        static const int short_thr = getenv("SQ_SCORE_SHORT_THREADS") ? atoi(getenv("SQ_SCORE_SHORT_THREADS")) : 64;
         const int thr0 = maxn <= 200 ? short_thr : (maxn <= 400 ? 256 : 512);
         const int thr = score_threads ? score_threads : (mode == 0 ? thr0 : (parts == 1 && S < 2048 ? 512 : 256));
         // the cell table (K R x (K R | 1) doubles for the batch's largest K R), then

@@ -407,11 +407,12 @@ __device__ __forceinline__ void sq_state_build(const SqDevCtx &c, const SqStruct
 {
     __shared__ int wave_u[4], wave_s[4];
     const int n = jb.n, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nthr = blockDim.x, nwv = nthr >> 6;                     // 256 threads, or 64 for short sequences (one wave does it)
     const uint8_t *e0 = c.e0c + jb.pos_off;
     const uint8_t *codes = c.codes + jb.pos_off;
-    for (int p = tid; p < n; p += 256) { P[p] = -1; E[p] = e0[p]; }
+    for (int p = tid; p < n; p += nthr) { P[p] = -1; E[p] = e0[p]; }
     __syncthreads();
-    for (int k = tid; k < s.nstrand; k += 256) {
+    for (int k = tid; k < s.nstrand; k += nthr) {
         const SqStrand x = sd[k];
         for (int t = 0; t < x.len; t++) {
             const int pos = x.start + t;
@@ -420,10 +421,10 @@ __device__ __forceinline__ void sq_state_build(const SqDevCtx &c, const SqStruct
         }
     }
     __syncthreads();
-    // exclusive prefix counts of unpaired positions (U) and unpaired separators (SU): 256 positions per step,
+    // exclusive prefix counts of unpaired positions (U) and unpaired separators (SU): blockDim positions per step,
     // ballots inside a wave, the four wave totals through LDS, a running base across steps
     int base_u = 0, base_s = 0;
-    for (int p0 = 0; p0 < n; p0 += 256) {
+    for (int p0 = 0; p0 < n; p0 += nthr) {
         const int p = p0 + tid;
         const bool un = p < n && P[p] == -1;
         const bool us = un && (codes[p] == 26 || codes[p] == 27);
@@ -434,8 +435,7 @@ __device__ __forceinline__ void sq_state_build(const SqDevCtx &c, const SqStruct
         int pu = base_u + __popcll(mu & below), pS = base_s + __popcll(ms & below);
         for (int q = 0; q < wv; q++) { pu += wave_u[q]; pS += wave_s[q]; }
         if (p < n) { U[p] = (int16_t)pu; SU[p] = (int16_t)pS; }
-        base_u += wave_u[0] + wave_u[1] + wave_u[2] + wave_u[3];
-        base_s += wave_s[0] + wave_s[1] + wave_s[2] + wave_s[3];
+        for (int q = 0; q < nwv; q++) { base_u += wave_u[q]; base_s += wave_s[q]; }
         __syncthreads();
     }
     if (tid == 0) { U[n] = (int16_t)base_u; SU[n] = (int16_t)base_s; }
@@ -443,7 +443,7 @@ __device__ __forceinline__ void sq_state_build(const SqDevCtx &c, const SqStruct
     // One ballot = two words.
     const int fbh = st.fbstride >> 1;
     uint32_t *FBs = st.FB + (int64_t)s.slot * st.fbstride;
-    for (int m2 = wv; 2 * m2 < fbh; m2 += 4) {          // m2: pair of words (2 m2, 2 m2 + 1) of either array
+    for (int m2 = wv; 2 * m2 < fbh; m2 += nwv) {          // m2: pair of words (2 m2, 2 m2 + 1) of either array
         const int pf = 64 * m2 + lane;                  // forward array: position
         const unsigned long long bf = __ballot(pf < n && E[pf] == 0);
         const int pr = n - 1 - (64 * m2 + lane - SQ_GPAD);   // reversed array: bit 64 m2 + lane <-> position n-1-(bit - pad)
@@ -458,7 +458,7 @@ __device__ __forceinline__ void sq_state_build(const SqDevCtx &c, const SqStruct
         int16_t *gP = st.P + (int64_t)s.slot * st.stride, *gU = st.U + (int64_t)s.slot * st.stride;
         int16_t *gSU = st.SU + (int64_t)s.slot * st.stride;
         uint8_t *gE = st.E8 + (int64_t)s.slot * st.stride * 2;
-        for (int p = tid; p <= n; p += 256) {
+        for (int p = tid; p <= n; p += nthr) {
             if (p < n) { gP[p] = P[p]; gE[p] = E[p]; }
             gU[p] = U[p]; gSU[p] = SU[p];
         }
@@ -479,7 +479,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, Sq
     }
     if (s.nstrand < 0) return;                            // (chained) the structure is final
     if (!chained)
-        for (int k = threadIdx.x; k < s.nstrand; k += 256) io.d_strands[s.strand_off + k] = io.h_strands[s.strand_off + k];
+        for (int k = threadIdx.x; k < s.nstrand; k += blockDim.x) io.d_strands[s.strand_off + k] = io.h_strands[s.strand_off + k];
     __syncthreads();
     const SqJob jb = c.jobs[s.job];
     const SqStrand *sd = io.d_strands + s.strand_off;

@@ -155,7 +155,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
                                                                      int32_t *pairs_out, int32_t *count_out)
 {
     const SqMatchJob jb = jobs[blockIdx.x];
-    const int n = jb.n, tid = threadIdx.x;
+    const int n = jb.n, tid = threadIdx.x, nthr = blockDim.x;   // 64 .. 256 threads: the launch's longest sequence rounded up to waves
     if (n <= 0) { if (tid == 0) count_out[blockIdx.x] = 0; return; }
     double *S = reinterpret_cast<double *>(scratch + jb.scratch_off);   // region of n*n doubles: holds the column lists
     double *D = S + (size_t)n * n;
@@ -168,22 +168,22 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
     double *cs = S;                                                     // [m] scores
     int32_t *ck = reinterpret_cast<int32_t *>(cs + m);                  // [m] row k
     int32_t *col_off = ck + m, *cursor = col_off + (n + 1);            // [n + 1], [n]
-    for (size_t q = tid; q < (size_t)n * n; q += 256) { D[q] = 0.0; K[q] = -2; has[q] = 0; }
-    for (int q = tid; q <= n; q += 256) col_off[q] = 0;
+    for (size_t q = tid; q < (size_t)n * n; q += nthr) { D[q] = 0.0; K[q] = -2; has[q] = 0; }
+    for (int q = tid; q <= n; q += nthr) col_off[q] = 0;
     __syncthreads();
-    for (int e = tid; e < m; e += 256) atomicAdd(&col_off[edges[jb.edge_off + e].w + 1], 1);
+    for (int e = tid; e < m; e += nthr) atomicAdd(&col_off[edges[jb.edge_off + e].w + 1], 1);
     __syncthreads();
     if (tid == 0) for (int j = 0; j < n; j++) col_off[j + 1] += col_off[j];
     __syncthreads();
-    for (int q = tid; q < n; q += 256) cursor[q] = col_off[q];
+    for (int q = tid; q < n; q += nthr) cursor[q] = col_off[q];
     __syncthreads();
-    for (int e = tid; e < m; e += 256) {                               // SCORES[(v,w)] = -stem[2]  (:49)
+    for (int e = tid; e < m; e += nthr) {                               // SCORES[(v,w)] = -stem[2]  (:49)
         const SqMatchEdge ed = edges[jb.edge_off + e];
         const int pos = atomicAdd(&cursor[ed.w], 1);
         ck[pos] = ed.v; cs[pos] = -ed.weight;
     }
     __syncthreads();
-    for (int j = tid; j < n; j += 256) {                               // ascending k inside every column (short lists)
+    for (int j = tid; j < n; j += nthr) {                               // ascending k inside every column (short lists)
         const int a = col_off[j], b = col_off[j + 1];
         for (int x = a + 1; x < b; x++) {
             const int kk = ck[x]; const double vv = cs[x];
@@ -194,7 +194,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
     }
     __syncthreads();
     for (int h = 1; h < n; h++) {                                       // :65
-        for (int i = tid; i < n - h; i += 256) {
+        for (int i = tid; i < n - h; i += nthr) {
             const int j = i + h;
             int bestk = -1; double best = 1e9;                          // :70
             for (int x = col_off[j]; x < col_off[j + 1]; x++) {         // k in range(i, j - 1) with (k, j) in SCORES (:73-74)
@@ -465,7 +465,10 @@ int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatch
         if (lds > 150 * 1024) lds = (size_t)maxn * 42 + 64 + 16 < 150 * 1024 ? (size_t)maxn * 42 + 64 + 16 : 150 * 1024;   // vectors only
         hipLaunchKernelGGL(sq_lsap_kernel, dim3(nj), dim3(64), lds, st, jobs, edges, d_scr, out, (int)lds);
     } else if (algo == 2) {                              // SQ_ALGO_N
-        hipLaunchKernelGGL(sq_nussinov_kernel, dim3(nj), dim3(256), 0, st, jobs, edges, codes, d_scr, out, cnt);
+        // an anti-diagonal of the DP has at most n cells: no more waves than that keeps busy (the block holds its wave slots
+        // through the single-threaded BackTrack too)
+        const int nthr = std::max(64, std::min(256, (maxn + 63) / 64 * 64));
+        hipLaunchKernelGGL(sq_nussinov_kernel, dim3(nj), dim3(nthr), 0, st, jobs, edges, codes, d_scr, out, cnt);
     } else {                                             // SQ_ALGO_E
         // bins: see sq_mwm_plan.  The plan writes each job's LDS slice into the job table the kernel reads.
         int nbins = 0, waves = 1; size_t lds = 0; bool all_in_lds = true;
