@@ -1323,7 +1323,10 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
     if (maxn >= 5) {
         ProfScope ps(b, 2, scan_bytes);
         // bit-diagonal scan: one wave = 64 anti-diagonals
-        hipLaunchKernelGGL(sq_scan6_kernel, dim3(S, (2 * maxn - 5 + 63) / 64 + 1), dim3(64), 4 * (size_t)b->state.fbstride, st,
+        // (sequences up to 200 nt: one wave per structure walks all its diagonal groups, see the kernel)
+        static const int scan_short = getenv("SQ_SCAN_SHORT_WAVES") ? std::max(1, atoi(getenv("SQ_SCAN_SHORT_WAVES"))) : 1;
+        const int scan_groups = (2 * maxn - 5 + 63) / 64 + 1;
+        hipLaunchKernelGGL(sq_scan6_kernel, dim3(S, maxn <= 200 ? std::min(scan_short, scan_groups) : scan_groups), dim3(64), 4 * (size_t)b->state.fbstride, st,
                            b->ctx, d_structs, b->state, scan);
     }
     {

@@ -570,9 +570,22 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, con
     const SqJob jb = c.jobs[st.job];
     const int n = jb.n;
     if (n < 5) return;                                                  // :456-457 no diagonals
-    const int s0 = blockIdx.y << 6;
+    const int lane0 = threadIdx.x;
+    {
+        const int fbh0 = stt.fbstride >> 1;
+        const uint32_t *FBg0 = stt.FB + (int64_t)st.slot * stt.fbstride;
+        if (lane0 == 0) L.stage_count = 0;
+        for (int m = lane0; m < 2 * fbh0; m += 64) sq6_fg[m] = FBg0[m];
+        __syncthreads();
+    }
+    // one block = the diagonal groups blockIdx.y, blockIdx.y + gridDim.y, ..: a launch for short sequences gives a structure
+    // ONE wave that walks all its groups (five for 100 nt) instead of one wave per group -- each of those spent most of its
+    // few microseconds on the set-up above, and with batches in flight wave slots are what the chip runs out of
+    const int ngroups = ((2 * n - 5 + 63) >> 6) + 1;
+    for (int gy = blockIdx.y; gy < ngroups; gy += gridDim.y) {
+    const int s0 = gy << 6;
     const int smin = max(s0, 4), smax = min(s0 + 63, 2 * n - 6);        // :456-457 s in [4, 2N-6]
-    if (smin > smax) return;
+    if (smin > smax) continue;
     const int rmin = max(0, smin - (n - 1)), rmax = (smax - 1) >> 1;    // :486 i <= j-1
     const int wlo = rmin >> 5, whi = rmax >> 5;
     const int lane = threadIdx.x;
@@ -587,9 +600,6 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, con
     // diagonals have zero base words, their window only has to stay inside the array
     const int q0 = min(max(n - 1 - s + 32 * wlo + SQ_GPAD, 0), 32 * (fbh - (whi - wlo) - 3));
     const int gidx = q0 >> 5, gsh = q0 & 31;
-    if (lane == 0) L.stage_count = 0;
-    for (int m = lane; m < 2 * fbh; m += 64) sq6_fg[m] = FBg[m];
-    __syncthreads();
     // Restraint base pairs (:438-443: the cell of a restraint pair stays pairable while both ends are free).  The
     // sequence's list is sorted by (i + j, i), so the pairs of this lane's diagonal are one run of it, in row order: two
     // binary searches here, then a pointer that only moves forward as the rows go by.  Any number of pairs.
@@ -679,6 +689,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, con
     if (carry >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(32 * (whi + 1) - carry), (uint32_t)carry);
     __syncthreads();
     sq5_flush(L, a, st, cap, lane);
+    }
 }
 
 
