@@ -70,7 +70,8 @@ typedef struct sq_batch_desc {
     const int32_t *seq_off;     /* [nseq+1] offsets into the per-position arrays                */
     const uint8_t *codes;       /* letter codes                                                  */
     const uint8_t *flags;       /* SQ_FLAG_*                                                     */
-    const double *reacts;       /* per-position reactivities after ProcessReacts (SQRNdbnseq.py:32-59), never NULL */
+    const double *reacts;       /* per-position reactivities after ProcessReacts (SQRNdbnseq.py:32-59); NULL: 0.5 everywhere
+                                 * (SQRNdbnseq.py:1013-1014: no record of the batch came with reactivities) */
     const int32_t *rbp_off;     /* [nseq+1] offsets (in pairs) into rbps                         */
     const int32_t *rbps;        /* restraint base pairs (v,w), v<w, gap-free coordinates; any number, a position in at most one */
     int32_t npset;

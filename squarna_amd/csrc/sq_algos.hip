@@ -34,7 +34,7 @@ static double cell_score_host(const sq_batch *b, const SqJob &J, int i, int j, c
             const uint8_t *lv = b->ridx.data() + J.pos_off;
             rf = b->rftab[(size_t)J.rf_idx * 256 + lv[i] * 16 + lv[j]];
         } else {
-            const double *r = b->reacts.data() + J.pos_off;
+            const double *r = sq_host_reacts(b) + J.pos_off;
             rf = sqrt((1.0 - (r[i] + r[j]) / 2.0) * 2.0);
         }
     }

@@ -113,6 +113,8 @@ struct sq_batch {
     // host copies
     int32_t nseq = 0, npset = 0, njobs = 0, maxn = 0;
     int64_t ltot = 0;
+    bool reacts_null = false;             // created without reactivities (0.5 everywhere): `reacts` is formed on first host use
+    mutable std::once_flag reacts_once;
     std::vector<int32_t> seq_off, rbp_off, rbps, job_seq, job_pset;
     std::vector<uint8_t> codes, flags;
     std::vector<double> reacts;
@@ -231,6 +233,7 @@ void sq_pinned_put(void *p);                   // the streams that used the buff
 // and to destroy (measured: 1.2 ms of a 10.6 ms Predict() on SRtest150 was sq_batch_destroy): non-blocking streams,
 // timing-free events -- per device -- and the host worker pools.  A batch takes them when it first needs them and hands
 // them back (idle) when it is destroyed.
+const double *sq_host_reacts(const sq_batch *b);   // per-position reactivities on the host (formed on first use for reacts == NULL batches)
 hipError_t sq_stream_get(int device, hipStream_t *s);
 void sq_stream_put(int device, hipStream_t s);
 hipError_t sq_event_get(int device, hipEvent_t *e);

@@ -179,6 +179,20 @@ SqPool *sq_pool(sq_batch *b)
     return b->pool;
 }
 
+// the batch's reactivities on the host: the caller's array, or 0.5 everywhere formed on first use (batches created with
+// reacts == NULL only need it on the host paths: the host tail, RunAlgo's host filters)
+const double *sq_host_reacts(const sq_batch *b)
+{
+    if (b->reacts_null)
+        std::call_once(b->reacts_once, [b] { const_cast<sq_batch *>(b)->reacts.assign((size_t)std::max<int64_t>(b->ltot, 1), 0.5); });
+    return b->reacts.data();
+}
+
+extern "C" __global__ void sq_fill_f64_kernel(double *dst, long long n, double v)
+{
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) dst[q] = v;
+}
+
 // ---- stream / event / worker-pool caches ----------------------------------------------------------
 namespace {
 struct ObjCache {
@@ -318,6 +332,20 @@ static inline int32_t ld_of(int n)
 }
 
 // most stems one structure of a job can hold: they are disjoint and have at least ceil(minlen) (>= 1) base pairs
+// every reactivity of a sequence 0.5 (SQRNdbnseq.py:273: the record came without reactivities)?  Block-wise without a branch
+// per element, so that the compiler vectorises the comparison: most records of a big input are like this
+static inline bool all_half(const double *r, int n)
+{
+    int i = 0;
+    for (; i + 32 <= n; i += 32) {
+        bool ok = true;
+        for (int k = 0; k < 32; k++) ok &= r[i + k] == 0.5;
+        if (!ok) return false;
+    }
+    for (; i < n; i++) if (r[i] != 0.5) return false;
+    return true;
+}
+
 static inline int32_t chain_tcap(int n, double minlen)
 {
     const int ml = (int)std::max(1.0, std::ceil(minlen));
@@ -412,11 +440,14 @@ int plan(const sq_batch_desc *d, Layout &L)
     L.fbstride = 2 * (L.stride / 32 + 8);
     L.strand_cap = (int32_t)std::min<int64_t>((int64_t)L.max_structs * 64 + L.maxn, 1 << 24);
     int64_t maxcap = (int64_t)L.cpn * L.maxn + 256;
-    for (int j = 0; j < d->njobs; j++) {
-        const int sq = d->job_seq[j];
-        const double nn = d->seq_off[sq + 1] - d->seq_off[sq];
-        const double ml = std::max(1.0, std::ceil(d->psets[d->job_pset[j]].minlen));
-        maxcap = std::max<int64_t>(maxcap, (int64_t)(0.117 * nn * nn * std::pow(0.375, ml - 1.0) * 1.6 + 256));
+    {
+        std::vector<double> runs(d->npset);                 // share of the cells that start a maximal run of >= minlen (per paramset)
+        for (int p = 0; p < d->npset; p++) runs[p] = std::pow(0.375, std::max(1.0, std::ceil(d->psets[p].minlen)) - 1.0);
+        for (int j = 0; j < d->njobs; j++) {
+            const int sq = d->job_seq[j];
+            const double nn = d->seq_off[sq + 1] - d->seq_off[sq];
+            maxcap = std::max<int64_t>(maxcap, (int64_t)(0.117 * nn * nn * runs[d->job_pset[j]] * 1.6 + 256));
+        }
     }
     L.cand_records = std::min<int64_t>((int64_t)L.max_structs * maxcap, (int64_t)160 << 20);   // (5 GiB of 32-byte records at most)
     L.cand_records = std::max<int64_t>(L.cand_records, maxcap);
@@ -434,7 +465,7 @@ int plan(const sq_batch_desc *d, Layout &L)
     // whose reactivities take <= 16 values)
     L.n_rftab = 0;
     for (int s = 0; s < d->nseq; s++)
-        for (int i = d->seq_off[s]; i < d->seq_off[s + 1]; i++) if (d->reacts[i] != 0.5) { L.n_rftab++; break; }
+        if (d->reacts && !all_half(d->reacts + d->seq_off[s], d->seq_off[s + 1] - d->seq_off[s])) L.n_rftab++;
     L.off_rftab = take(8 * 256 * (size_t)std::max<int64_t>(L.n_rftab, 1));
     L.pow_entries = 0;
     for (int p = 0; p < d->npset; p++) { double sc; L.pow_entries += pow17_entries(d->psets[p], L.maxn, sc); }
@@ -576,7 +607,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->seq_off.assign(d->seq_off, d->seq_off + d->nseq + 1);
     b->codes.assign(d->codes, d->codes + L.ltot);
     b->flags.assign(d->flags, d->flags + L.ltot);
-    b->reacts.assign(d->reacts, d->reacts + L.ltot);
+    b->reacts_null = d->reacts == nullptr;
+    if (d->reacts) b->reacts.assign(d->reacts, d->reacts + L.ltot);   // (NULL: 0.5 everywhere -- sq_host_reacts forms the array if a host path asks)
     b->rbp_off.assign(d->rbp_off, d->rbp_off + d->nseq + 1);
     b->rbps.assign(d->rbps, d->rbps + 2 * (size_t)d->rbp_off[d->nseq]);
     b->job_seq.assign(d->job_seq, d->job_seq + d->njobs);
@@ -601,6 +633,17 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     for (int s = 0; s < d->nseq; s++) {
         const int off = d->seq_off[s], n = d->seq_off[s + 1] - off;
         auto sep = [&](int p) { return b->codes[off + p] == SQ_CODE_SEP1 || b->codes[off + p] == SQ_CODE_SEP2; };
+        {
+            // one chain (no separator in the sequence -- nearly every record): minimum span 4 everywhere, chain 0; only the
+            // restraint pairs below are left to do
+            bool anysep = false;
+            const uint8_t *cd = b->codes.data() + off;
+            for (int i = 0; i < n; i++) anysep |= (cd[i] == SQ_CODE_SEP1) | (cd[i] == SQ_CODE_SEP2);
+            if (!anysep && d->rbp_off[s + 1] == d->rbp_off[s]) {
+                std::fill(inc4.begin() + off, inc4.begin() + off + n, (uint8_t)4);
+                continue;
+            }
+        }
         int curr = 0;
         for (int i = 0; i < n; i++) {
             int v = 4;                                   // SQRNdbnseq.py:294-297
@@ -676,8 +719,13 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     std::vector<uint8_t> ridx(L.ltot, 0);
     std::vector<int32_t> seq_levels(d->nseq, 0), seq_rf(d->nseq, -1);
     std::vector<double> rftab;
+    std::vector<uint8_t> seq_def(d->nseq, 0);                // every reactivity of the sequence 0.5 (:273)
     for (int s = 0; s < d->nseq; s++) {
         const int off = d->seq_off[s], n = d->seq_off[s + 1] - off;
+        if (!d->reacts || all_half(d->reacts + off, n)) {    // one level (index 0 everywhere: ridx is zeroed), no factor table
+            seq_def[s] = 1; seq_levels[s] = n > 0 ? 1 : 0;
+            continue;
+        }
         double vals[16]; int nv = 0; bool fits = true;
         for (int i = 0; i < n && fits; i++) {
             const double r = d->reacts[off + i];
@@ -689,10 +737,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         seq_levels[s] = fits ? nv : 0;
         // (1 - (r_a + r_b) / 2) * 2) ** 0.5 for every pair of the sequence's levels through the host's libm pow, which is
         // what CPython's `**` calls (SQRNdbnseq.py:333): the device reads these instead of taking a sqrt
-        bool def = true;
-        for (int i = 0; i < n; i++) if (d->reacts[off + i] != 0.5) { def = false; break; }
         seq_rf[s] = -1;
-        if (!def && fits && nv > 0 && (int64_t)(rftab.size() / 256) < L.n_rftab) {
+        if (fits && nv > 0 && (int64_t)(rftab.size() / 256) < L.n_rftab) {
             seq_rf[s] = (int32_t)(rftab.size() / 256);
             rftab.resize(rftab.size() + 256, 0.0);
             double *T = rftab.data() + (size_t)seq_rf[s] * 256;
@@ -710,6 +756,18 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
             const uint32_t sx = (x & 0xFFFFu) + (x >> 16), sy = (y & 0xFFFFu) + (y >> 16);
             return sx != sy ? sx < sy : (x & 0xFFFFu) < (y & 0xFFFFu);
         });
+    std::vector<double> pset_maxabs(2 * (size_t)d->npset, 0.0);   // largest |cell| a paramset can produce: plain / with reactivity factors
+    std::vector<double> pset_runs(d->npset);                      // share of the cells that start a maximal run of >= minlen
+    for (int p = 0; p < d->npset; p++) {
+        const sq_paramset &ps = d->psets[p];
+        pset_runs[p] = std::pow(0.375, std::max(1.0, std::ceil(ps.minlen)) - 1.0);
+        for (int q = 0; q < 32 * 32; q++) {
+            if (!ps.inbps[q]) continue;
+            const double w = ps.bpweight[q];
+            pset_maxabs[2 * p] = std::max(pset_maxabs[2 * p], std::fabs(w));
+            pset_maxabs[2 * p + 1] = std::max(pset_maxabs[2 * p + 1], std::fabs(w) * (w > 0 ? 1.4142135623730951 : 100.0));   // SQRNdbnseq.py:333-336
+        }
+    }
     for (int j = 0; j < d->njobs; j++) {
         SqJob &J = b->jobs[j];
         const int s = d->job_seq[j];
@@ -729,15 +787,13 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         J.mat_off = -1;
         J.mat64_diag = (shared && !ext) ? 1 : 0;          // the gather kernel writes score x weight, diagonal-major (sq_cells.h)
         if (b->has_fp32 || (J.has_ext && !J.mat64_diag)) { J.mat_off = m32; m32 += (int64_t)align_up((size_t)J.n * J.ld, 64); }
-        bool def = true;                                  // SQRNdbnseq.py:273
-        for (int i = 0; i < J.n; i++) if (d->reacts[J.pos_off + i] != 0.5) { def = false; break; }
+        const bool def = seq_def[s] != 0;                 // SQRNdbnseq.py:273
         J.default_reacts = def ? 1 : 0;
         J.react_levels = def ? 0 : seq_levels[s];
         J.rf_idx = def ? -1 : seq_rf[s];
         J.interchainonly = d->interchainonly;
         {
-            const double ml = std::max(1.0, std::ceil(d->psets[J.pset].minlen));
-            const double est = 0.117 * (double)J.n * J.n * std::pow(0.375, ml - 1.0) * 1.6 + 256;   // maximal runs with len >= minlen
+            const double est = 0.117 * (double)J.n * J.n * pset_runs[J.pset] * 1.6 + 256;   // maximal runs with len >= minlen
             J.cand_cap = (int32_t)std::max<int64_t>((int64_t)L.cpn * J.n, (int64_t)est);
         }
         // bound of |cell| for the scan's fp32 prefilter margin
@@ -746,13 +802,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         if (ext) {
             for (size_t q = 0; q < nn; q++) if (d->ext_bool[j] && d->ext_bool[j][q] != 0) mx = std::max(mx, std::fabs(d->ext_score[j][q]));
         } else {
-            const sq_paramset &ps = d->psets[J.pset];
-            for (int q = 0; q < 32 * 32; q++) {
-                if (!ps.inbps[q]) continue;
-                const double w = ps.bpweight[q];
-                const double rfmax = def ? 1.0 : (w > 0 ? 1.4142135623730951 : 100.0);   // SQRNdbnseq.py:333-336
-                mx = std::max(mx, std::fabs(w) * rfmax);
-            }
+            mx = pset_maxabs[2 * J.pset + (def ? 0 : 1)];
             if (shared) mx *= std::fabs(d->mul_maxabs);
             else if (mul) {
                 const double *tm = term ? d->bpp_term[j] : d->mul_score[j];
@@ -878,7 +928,9 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
 #define UP(dst, src, bytes) do { int _r = stager.put((void *)(dst), (src), (bytes)); if (_r) { hipStreamSynchronize(st); delete b; return _r; } } while (0)
     UP(b->ctx.codes, b->codes.data(), L.ltot); UP(b->ctx.flags, b->flags.data(), L.ltot);
     UP(b->ctx.inc4, inc4.data(), L.ltot); UP(b->ctx.chain, chain.data(), L.ltot * 2);
-    UP(b->ctx.e0c, e0.data(), L.ltot); UP(b->ctx.reacts, b->reacts.data(), L.ltot * 8);
+    UP(b->ctx.e0c, e0.data(), L.ltot);
+    if (d->reacts) UP(b->ctx.reacts, b->reacts.data(), L.ltot * 8);
+    else hipLaunchKernelGGL(sq_fill_f64_kernel, dim3(256), dim3(256), 0, st, const_cast<double *>(b->ctx.reacts), (long long)L.ltot, 0.5);
     UP(b->ctx.ridx, ridx.data(), L.ltot);
     b->ridx = ridx;
     UP(b->ctx.jobs, b->jobs.data(), sizeof(SqJob) * d->njobs);

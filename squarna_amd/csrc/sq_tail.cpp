@@ -272,7 +272,7 @@ void sq_tail(const sq_batch *b, int seq, const sq_fold_opts &o,
 {
     const int off = b->seq_off[seq], n = b->seq_off[seq + 1] - off;
     const uint8_t *codes = b->codes.data() + off;
-    const double *reacts = b->reacts.data() + off;
+    const double *reacts = sq_host_reacts(b) + off;
 
 #ifdef SQ_TAIL_PROF
     auto nowus = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

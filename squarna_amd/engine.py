@@ -164,7 +164,9 @@ class Batch:
         self.codes = np.frombuffer(encode_seq(''.join(p.shortseq for p in prepared)), np.uint8).copy() \
             if ltot else np.zeros(1, np.uint8)
         self.flags = np.zeros(max(ltot, 1), np.uint8)
-        self.reacts = np.full(max(ltot, 1), 0.5, np.float64)
+        # no record with reactivities: the library takes NULL for "0.5 everywhere" (8 bytes per position neither filled,
+        # scanned nor uploaded)
+        self.reacts = None if all(p.plain_reacts for p in prepared) else np.full(max(ltot, 1), 0.5, np.float64)
         self.rbp_off = np.zeros(nseq + 1, np.int32)
         rbps = []
         # (most records of a big input are plain: only the ones with restraints or reactivities take the loop)
@@ -223,7 +225,7 @@ class Batch:
         d.seq_off = _ptr(self.seq_off, C.POINTER(C.c_int32))
         d.codes = _ptr(self.codes, C.POINTER(C.c_uint8))
         d.flags = _ptr(self.flags, C.POINTER(C.c_uint8))
-        d.reacts = _ptr(self.reacts, C.POINTER(C.c_double))
+        d.reacts = _ptr(self.reacts, C.POINTER(C.c_double)) if self.reacts is not None else None
         d.rbp_off = _ptr(self.rbp_off, C.POINTER(C.c_int32))
         d.rbps = _ptr(self.rbps, C.POINTER(C.c_int32))
         d.npset = len(self.psets_py)
