@@ -723,6 +723,21 @@ def pool_slots_wanted(ngreedy, poollim, n=None):
     return int(ngreedy) * per_job
 
 
+def pool_slots_wanted_many(lengths, psets_per_record, poollim):
+    """pool_slots_wanted for every record of a batch (numpy array): the greedy-job count per distinct paramset list is
+    counted once (the records of an input usually share one list), the per-length part is vectorised."""
+    ng_of, ng = {}, np.empty(len(psets_per_record), np.int64)
+    for k, pl in enumerate(psets_per_record):
+        v = ng_of.get(id(pl))
+        if v is None:
+            v = ng_of[id(pl)] = sum(1 for ps in pl if "G" in ps["algorithms"])
+        ng[k] = v
+    p = min(int(poollim), 1024)
+    n = np.asarray(lengths, np.float64)
+    per_job = np.minimum(min(3 * p, p + 512), np.maximum(16, (4e-5 * n ** 3).astype(np.int64)))
+    return ng * per_job
+
+
 class HipEngine:
     """Default engine: everything on the GPU through libsquarna_hip.so."""
     name = "hip"
@@ -759,10 +774,11 @@ class HipEngine:
         if not self.max_structs and poollim > 1 and len(records) > 1:
             # wide pools: as many records per batch as the device pools have slots for (a fold that outgrows them is
             # repeated by the library's host loop -- correct, but several times slower)
-            per_rec = [pool_slots_wanted(sum(1 for ps in r[4] if "G" in ps["algorithms"]), poollim, len(r[0])) for r in records]
-            cap = pool_slot_cap(max(len(r[0]) for r in records))
-            if sum(per_rec) > cap:
-                return self._fold_in_sub_batches(records, per_rec, cap, opts)
+            lens = [len(r[0]) for r in records]
+            per_rec = pool_slots_wanted_many(lens, [r[4] for r in records], poollim)
+            cap = pool_slot_cap(max(lens))
+            if int(per_rec.sum()) > cap:
+                return self._fold_in_sub_batches(records, per_rec.tolist(), cap, opts)
         out, refs = self._fold_groups([records], [None], opts)
         self.last_ref_scores = refs[0]
         return out[0]
@@ -842,9 +858,8 @@ class HipEngine:
         njobs = sum(len(pl) for pl in psets)
         max_structs = self.max_structs if self.max_structs else max(4096, min(4 * njobs, 262144))
         if not self.max_structs and opts.get("poollim", 1000) > 1:
-            want = slots_hint if slots_hint else sum(
-                pool_slots_wanted(sum(1 for ps in pl if "G" in ps["algorithms"]), opts.get("poollim", 1000), len(p.shortseq))
-                for p, pl in zip(prepared, psets))
+            want = slots_hint if slots_hint else int(pool_slots_wanted_many(
+                [len(p.shortseq) for p in prepared], psets, opts.get("poollim", 1000)).sum())
             max_structs = max(max_structs, min(want, pool_slot_cap(max(len(p.shortseq) for p in prepared))))
         b = Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
                   max_structs=max_structs, cand_per_nt=self.cand_per_nt, mul_shared=mul_shared)
