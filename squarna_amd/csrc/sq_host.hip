@@ -579,9 +579,16 @@ extern "C" int sq_batch_workspace_bytes(const sq_batch_desc *desc, size_t *bytes
 
 extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws, size_t ws_bytes, void *hip_stream)
 {
+#ifdef SQ_CREATE_PROF
+    // (phase timers of this function: SQ_DEFS=-DSQ_CREATE_PROF python -m squarna_amd.build; one line per call on stderr)
+    std::vector<std::pair<const char *, double>> _cp; _cp.emplace_back("start", now_s());
+#endif
     Layout L;
     int r = plan(d, L);
     if (r) return r;
+#ifdef SQ_CREATE_PROF
+    _cp.emplace_back("plan", now_s());
+#endif
     if (!ws || ws_bytes < L.total) { sq_set_error("workspace too small"); return -2; }
     if (((uintptr_t)ws & 255) != 0) { sq_set_error("workspace must be 256-byte aligned"); return -2; }
     for (int j = 0; j < d->njobs; j++) {
@@ -620,6 +627,9 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->mat32_bytes = 4 * (size_t)L.mat32_floats;
     b->has_fp32 = want_fp32(d);
 
+#ifdef SQ_CREATE_PROF
+    _cp.emplace_back("copies", now_s());
+#endif
     char *base = (char *)ws;
     // ---- per-position derived arrays (host, O(N)) ----
     std::vector<uint8_t> inc4(L.ltot);
@@ -660,6 +670,9 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
             e0[off + v] = 1; e0[off + w] = 1;                  // 1: end of a restraint pair (0: free, 255: masked by the structure)
         }
     }
+#ifdef SQ_CREATE_PROF
+    _cp.emplace_back("positions", now_s());
+#endif
     // ---- paramsets with host-libm pow tables ----
     std::vector<SqPsetDev> pd(d->npset);
     std::vector<double> sdf, powtab;
@@ -746,6 +759,9 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
                 for (int c2 = 0; c2 < nv; c2++) T[a * 16 + c2] = pow((1.0 - (vals[a] + vals[c2]) / 2.0) * 2.0, 0.5);
         }
     }
+#ifdef SQ_CREATE_PROF
+    _cp.emplace_back("paramsets", now_s());
+#endif
     // ---- jobs ----
     b->jobs.resize(d->njobs);
     int64_t m32 = 0, m64 = 0, mbits = 0;
@@ -822,6 +838,9 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         const int KR = K * R;
         b->cell_entries = std::max(b->cell_entries, KR * (KR | 1));
     }
+#ifdef SQ_CREATE_PROF
+    _cp.emplace_back("jobs", now_s());
+#endif
     // ---- device carve + uploads ----
     b->ctx.codes = (uint8_t *)(base + L.off_codes); b->ctx.flags = (uint8_t *)(base + L.off_flags);
     b->ctx.inc4 = (uint8_t *)(base + L.off_inc4); b->ctx.chain = (int16_t *)(base + L.off_chain);
@@ -926,6 +945,9 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         stager.buf = (char *)pb;
     }
 #define UP(dst, src, bytes) do { int _r = stager.put((void *)(dst), (src), (bytes)); if (_r) { hipStreamSynchronize(st); delete b; return _r; } } while (0)
+#ifdef SQ_CREATE_PROF
+    _cp.emplace_back("carve", now_s());
+#endif
     UP(b->ctx.codes, b->codes.data(), L.ltot); UP(b->ctx.flags, b->flags.data(), L.ltot);
     UP(b->ctx.inc4, inc4.data(), L.ltot); UP(b->ctx.chain, chain.data(), L.ltot * 2);
     UP(b->ctx.e0c, e0.data(), L.ltot);
@@ -990,6 +1012,9 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     }
 #undef UP
     // pinned staging
+#ifdef SQ_CREATE_PROF
+    _cp.emplace_back("uploads", now_s());
+#endif
     if (sq_pinned_get((void **)&b->h_structs, sizeof(SqStruct) * L.max_structs) ||
         sq_pinned_get((void **)&b->h_strands, sizeof(SqStrand) * (size_t)L.strand_cap) ||
         sq_pinned_get((void **)&b->h_ctr, sizeof(SqCounters)) ||
@@ -1025,8 +1050,15 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
             H.d_ctr = (SqCounters *)((char *)b->scan.ctr + (k ? 64 : 0));
         }
     }
+#ifdef SQ_CREATE_PROF
+    _cp.emplace_back("pinned+kernels", now_s());
+#endif
     int rr = sq_check(hipStreamSynchronize(st), "sync after upload");   // host vectors above go out of scope
     if (rr) { delete b; return rr; }
+#ifdef SQ_CREATE_PROF
+    _cp.emplace_back("sync", now_s());
+    { std::string line = "[sq_batch_create ms]"; for (size_t k = 1; k < _cp.size(); k++) { char t[64]; snprintf(t, sizeof t, " %s %.2f", _cp[k].first, (_cp[k].second - _cp[k - 1].second) * 1e3); line += t; } fprintf(stderr, "%s\n", line.c_str()); }
+#endif
     b->results.resize(d->nseq);
     *out = b;
     return 0;
