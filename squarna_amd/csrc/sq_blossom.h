@@ -16,6 +16,12 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "sq_match.h"
+// (the cycle counters of the profiling builds -- SQ_DEFS=-DSQ_MWM_PROF / -DSQ_MWM_PROF2 -- exist on the device only; the host
+// pass of a translation unit that includes this header compiles run() without them)
+#if !defined(__HIP_DEVICE_COMPILE__)
+#undef SQ_MWM_PROF
+#undef SQ_MWM_PROF2
+#endif
 
 #ifdef __HIPCC__
 #define SQ_HD __host__ __device__
