@@ -1391,6 +1391,7 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
                                  int mode, const SqRoundIO &io, const SqScanArgs &scan, SqStruct *d_structs, SqStrand *d_strands,
                                  bool chained, bool pooled = false)
 {
+    const bool crowded = b->inflight > 1 || S >= 1024;
     {
         ProfScope ps(b, 1, 0);
         // the per-structure arrays are assembled in LDS (7 bytes per position) when the longest sequence fits
@@ -1398,8 +1399,12 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
         const size_t st_dyn = st_lds_n ? (size_t)7 * ((st_lds_n + 8) & ~7) + 64 : 0;
         // (sequences up to 200 nt: one wave builds the arrays in three or four steps; four waves per structure held four
         // times the wave slots for the same few microseconds -- with batches in flight the chip is short of exactly those)
+        // "crowded": the chip is (or will be) short of wave slots -- several batches in flight, or a launch of a thousand
+        // structures and more.  Then a short structure gets ONE wave in the state, scan and scoring kernels; a small batch
+        // alone keeps the wide blocks (its greedy rounds are a latency chain: one wave per structure made them 1.5 ms
+        // longer per 219-record fold, hidden behind the blossom kernel only when there is one)
         static const int state_short = getenv("SQ_STATE_SHORT_THREADS") ? std::max(64, std::min(256, atoi(getenv("SQ_STATE_SHORT_THREADS")) / 64 * 64)) : 64;
-        hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(maxn <= 200 ? state_short : 256), st_dyn, st, b->ctx, io, b->state, scan, st_lds_n, chained ? 1 : 0);
+        hipLaunchKernelGGL(sq_state_kernel, dim3(S), dim3(maxn <= 200 && crowded ? state_short : 256), st_dyn, st, b->ctx, io, b->state, scan, st_lds_n, chained ? 1 : 0);
     }
     // mode 0: the context tables of the round's structures (only long-sequence batches carry them)
     const bool ctx_on = mode == 0 && b->ctxtab.rec != nullptr && b->score_ctx;
@@ -1410,7 +1415,7 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
         // (sequences up to 200 nt: one wave per structure walks all its diagonal groups, see the kernel)
         static const int scan_short = getenv("SQ_SCAN_SHORT_WAVES") ? std::max(1, atoi(getenv("SQ_SCAN_SHORT_WAVES"))) : 1;
         const int scan_groups = (2 * maxn - 5 + 63) / 64 + 1;
-        hipLaunchKernelGGL(sq_scan6_kernel, dim3(S, maxn <= 200 ? std::min(scan_short, scan_groups) : scan_groups), dim3(64), 4 * (size_t)b->state.fbstride, st,
+        hipLaunchKernelGGL(sq_scan6_kernel, dim3(S, maxn <= 200 && crowded ? std::min(scan_short, scan_groups) : scan_groups), dim3(64), 4 * (size_t)b->state.fbstride, st,
                            b->ctx, d_structs, b->state, scan);
     }
     {
@@ -1439,7 +1444,7 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
         // of a thousand 24 -> 16 ns per structure and round with 256).  SRtest150 (up to ~500 nt) measures the same
         // either way within the run-to-run spread and keeps 512.
         static const int short_thr = getenv("SQ_SCORE_SHORT_THREADS") ? atoi(getenv("SQ_SCORE_SHORT_THREADS")) : 64;
-        const int thr0 = maxn <= 200 ? short_thr : (maxn <= 400 ? 256 : 512);
+        const int thr0 = maxn <= 200 ? (crowded ? short_thr : 128) : (maxn <= 400 ? 256 : 512);
         const int thr = score_threads ? score_threads : (mode == 0 ? thr0 : (parts == 1 && S < 2048 ? 512 : 256));
         // the cell table (K R x (K R | 1) doubles for the batch's largest K R), then
         // mode 0: list of the bpscore survivors of a chunk (5 x threads entries of 8 + 4 + 2 bytes) behind the tables
