@@ -305,7 +305,9 @@ void sq_pinned_put(void *p)
         auto it = g_pinned.live.find(p);
         const size_t cap = it == g_pinned.live.end() ? 0 : it->second;
         if (it != g_pinned.live.end()) g_pinned.live.erase(it);
-        if (cap && g_pinned.idle.size() < 64 && g_pinned.idle_bytes + cap <= ((size_t)512 << 20)) {
+        // (a batch holds ~25 pinned buffers; eight batches of a server's step are created and destroyed together: with room
+        // for 64 idle buffers two thirds of them went back to the driver -- hipHostFree + hipHostMalloc: 6.5 ms per batch)
+        if (cap && g_pinned.idle.size() < 1024 && g_pinned.idle_bytes + cap <= ((size_t)2 << 30)) {
             g_pinned.idle.emplace_back(cap, p);
             g_pinned.idle_bytes += cap;
             return;
