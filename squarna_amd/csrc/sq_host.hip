@@ -2818,7 +2818,12 @@ extern "C" int sq_result_pack_all(const sq_batch *b, void *buf, int64_t cap, int
     off[b->nseq] = o;
     // the records are independent: big batches share the copying among the worker pool (15 MB for 10,000 x 300 nt)
     std::atomic<int> rc{0};
-    auto one = [&](int s) { const int r = sq_result_pack(b, s, (char *)buf + off[s], cap - off[s]); if (r) rc = r; };
+    auto one = [&](int s) {
+        const int r = sq_result_pack(b, s, (char *)buf + off[s], cap - off[s]);
+        if (r) { rc = r; return; }
+        const int64_t need = sq_result_pack_size(b, s);       // the pad up to the next record: zeros, as in the device tail's records
+        memset((char *)buf + off[s] + need, 0, (size_t)(off[s + 1] - off[s] - need));
+    };
     if (b->nseq >= 512 && o >= ((int64_t)1 << 20)) sq_pool(const_cast<sq_batch *>(b))->parallel_for(b->nseq, one);
     else for (int s = 0; s < b->nseq; s++) one(s);
     return rc.load();

@@ -521,6 +521,12 @@ extern "C" __global__ __launch_bounds__(64) void sq_tail_pack_kernel(SqDevCtx c,
             hdr[0] = (long long)ns; hdr[1] = n; hdr[2] = (t.ref_n && t.ref_n[s] >= 0) ? 1 : 0; hdr[3] = S.evals;
         }
         if (lane < 16) reinterpret_cast<double *>(rec + 32)[lane] = met[lane];
+        {
+            // the record is padded to a multiple of 8 bytes: the pad is part of what sq_result_pack hands out and of what ranks
+            // exchange -- zeros, not what the (recycled) pinned buffer held
+            const long long used = 160 + 32 * (long long)ns + 2 * (1 + (long long)ns) * n;
+            if (lane < (int)(S.rec_bytes - used)) rec[used + lane] = 0;
+        }
         double *sc = reinterpret_cast<double *>(rec + 160);
         unsigned long long *mk = reinterpret_cast<unsigned long long *>(rec + 160 + 24 * (size_t)ns);
         for (uint32_t r = lane; r < ns; r += 64) {
