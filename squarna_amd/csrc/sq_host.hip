@@ -488,8 +488,9 @@ int plan(const sq_batch_desc *d, Layout &L)
         // ScoreStems' closed-form strand sweep (sq_context.h): tables for every structure of a launch, for batches with
         // sequences long enough that the walk over the strands is what the scoring kernel waits for
         // (measured, whole fold with / without the tables: 10,000 x 300 nt 4.5 / 4.1 ms -- the context kernel costs more than the
-        // short walks it replaces --, 1,024 x 1000 nt 4.45 / 4.28, 1,000 x 2000 nt 27.0 / 29.6: from ~1,200 nt on)
-        const int ctx_min_n = getenv("SQ_CTX_MIN_N") ? atoi(getenv("SQ_CTX_MIN_N")) : 1200;
+        // short walks it replaces --, 1,024 x 1000 nt one fold alone 4.6 / 4.8 (scoring kernel 2.18 / 2.48), two sub-batches side by
+        // side 4.45 / 4.2, 1,000 x 2000 nt 27.0 / 29.6: from 800 nt on)
+        const int ctx_min_n = getenv("SQ_CTX_MIN_N") ? atoi(getenv("SQ_CTX_MIN_N")) : 800;
         int pt_max = 1;
         for (int j = 0; j < d->njobs; j++)
             pt_max = std::max(pt_max, chain_tcap(d->seq_off[d->job_seq[j] + 1] - d->seq_off[d->job_seq[j]], d->psets[d->job_pset[j]].minlen));

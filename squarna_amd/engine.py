@@ -276,7 +276,12 @@ class Batch:
         nbytes = C.c_size_t(0)
         _lib.check(L.sq_batch_workspace_bytes(C.byref(d), C.byref(nbytes)))
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-        self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
+        # (sizes in coarse steps: batches of a stream differ by a few records, and torch's caching allocator only hands a cached
+        # block back for a request it nearly fits -- every new size was a hipMalloc, the occasional one with a device-wide
+        # free of cached blocks in front: 40-190 ms steps in the stream leg)
+        want = nbytes.value + 256
+        step = (64 << 20) if want >= (256 << 20) else (8 << 20) if want >= (16 << 20) else (1 << 20)
+        self.workspace = torch.empty((want + step - 1) // step * step, dtype=torch.uint8, device=self.device)
         base = self.workspace.data_ptr()
         aligned = (base + 255) // 256 * 256
         self.stream = torch.cuda.current_stream(self.device)

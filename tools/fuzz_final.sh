@@ -9,7 +9,7 @@ run FUZZ_NMIN=200 FUZZ_NMAX=600 python3 tools/fuzz_parity.py 160 500nobpp 105
 run FUZZ_NMIN=300 FUZZ_NMAX=900 FUZZ_POOLLIM=1 python3 tools/fuzz_parity.py 120 fastest 106
 run python3 tools/fuzz_options.py 200 32 201
 run python3 tools/fuzz_align.py 80 301
-# long sequences: the scoring kernel's bound, the context tables (forced on for every length: the default starts at 1,200 nt) with and without crossing stems
+# long sequences: the scoring kernel's bound, the context tables (forced on for every length: the default starts at 800 nt) with and without crossing stems
 run SQ_CTX_MIN_N=0 FUZZ_NMIN=256 FUZZ_NMAX=700 FUZZ_POOLLIM=1 python3 tools/fuzz_parity.py 400 fastest 107
 run SQ_CTX_MIN_N=0 FUZZ_NMIN=256 FUZZ_NMAX=520 FUZZ_POOLLIM=25 python3 tools/fuzz_parity.py 200 nobpp 108
 run SQ_CTX_MIN_N=0 FUZZ_NMIN=256 FUZZ_NMAX=420 FUZZ_POOLLIM=1000 python3 tools/fuzz_parity.py 120 alt 109
