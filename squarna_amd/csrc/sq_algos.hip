@@ -350,7 +350,8 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
     // carve: [jobs][edges][out ints][counts][scratch]
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t rr = o; o = (o + bytes + 255) & ~(size_t)255; return rr; };
-    const size_t o_jobs = take(mj.size() * sizeof(SqMatchJob)), o_edges = take(ck.nedges * sizeof(SqMatchEdge) + 16);
+    take(mj.size() * sizeof(SqMatchJob));                       // (the job table's place in the region; the kernel reads ck.p_jobs)
+    const size_t o_edges = take(ck.nedges * sizeof(SqMatchEdge) + 16);
     const size_t o_out = take(ck.outints * 4 + 16), o_cnt = take(mj.size() * 4 + 16), o_scr = take(0);
     const SqMatchJob *d_jobs = ck.p_jobs;
     const SqMatchEdge *d_edges = ck.p_edges;

@@ -594,7 +594,6 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, con
     const int minlen = max(1, (int)ceil(ps->minlen));
     const int cap = jb.cand_cap;
     const int fbh = stt.fbstride >> 1;
-    const uint32_t *FBg = stt.FB + (int64_t)st.slot * stt.fbstride;
     uint32_t *F = sq6_fg, *G = sq6_fg + fbh;
     // window of the reversed array for (s, wlo): first bit n-1-s+32 wlo (+pad); lanes outside the valid
     // diagonals have zero base words, their window only has to stay inside the array
