@@ -281,7 +281,13 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
         static const int env_classes = getenv("SQ_MWM_CLASSES") ? std::max(1, atoi(getenv("SQ_MWM_CLASSES"))) : 0;
         // (Edmonds: one launch, the graphs packed into multi-wave blocks by LDS need -- sq_mwm_plan)
         // and with one batch alone in two size classes of one-graph blocks, the critical class on its own stream)
-        const int max_classes = env_classes ? env_classes : (algo == SQ_ALGO_E && b->inflight < 2 ? 2 : 1);
+        // Hungarian with the chip crowded (batches in flight, or a thousand jobs): every block of a launch gets the LDS of the
+        // launch's LARGEST job (62 KB at 150 nt: two one-wave blocks per CU, and LDS the scoring kernels of the other batches
+        // do not get) -- three classes give most jobs a quarter of that
+        static const int env_hclasses = getenv("SQ_LSAP_CLASSES") ? std::max(1, atoi(getenv("SQ_LSAP_CLASSES"))) : 0;
+        const bool crowded = b->inflight > 1 || nq >= 1024;
+        const int max_classes = algo == SQ_ALGO_H ? (env_hclasses ? env_hclasses : (crowded ? 3 : 1))
+                                                  : (env_classes ? env_classes : (b->inflight < 2 ? 2 : 1));
         size_t cur = std::min<size_t>(need[ord[0]], 150 * 1024);
         ck.classes.push_back({0, 0});
         for (size_t r = 0; r < nq; r++) {
