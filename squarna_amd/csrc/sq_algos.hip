@@ -261,19 +261,22 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
         ck.job_flags = (uint32_t *)(pin + jbytes + ebytes + obytes + cbytes + 256); memset(ck.job_flags, 0, mj.size() * 4);
         ck.bin_head = (int32_t *)(pin + jbytes + ebytes + obytes + cbytes + 256 + fbytes);
     }
-    if (algo == SQ_ALGO_E || algo == SQ_ALGO_H) {
-        // LDS size classes (see SqAlgoChunk::Class): jobs sorted by the dynamic LDS they need, largest first
+    {
+        // LDS size classes (see SqAlgoChunk::Class): jobs sorted by the dynamic LDS they need, largest first (Nussinov: by the
+        // sequence length, which sizes its blocks: 64 threads per 64 positions)
         const size_t nq = mj.size();
         std::vector<size_t> need(nq);
         for (size_t q = 0; q < nq; q++)
             need[q] = algo == SQ_ALGO_E
                           ? SqBlossom::scratch_bytes(mj[q].n, mj[q].nedges, 1) + (((size_t)mj[q].nedges * sizeof(SqMatchEdge) + 15) & ~(size_t)15) + 64
-                          : (size_t)mj[q].n * 42 + 64 + 16 + (size_t)mj[q].nedges * 8 + (size_t)mj[q].n * mj[q].n * 2 + 64;
+                      : algo == SQ_ALGO_H
+                          ? (size_t)mj[q].n * 42 + 64 + 16 + (size_t)mj[q].nedges * 8 + (size_t)mj[q].n * mj[q].n * 2 + 64
+                          : (size_t)std::max(1, (mj[q].n + 63) / 64);
         std::vector<int> ord(nq);
         for (size_t q = 0; q < nq; q++) ord[q] = (int)q;
         std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return need[x] > need[y]; });
         ck.sorted.resize(nq); ck.sorted_pos.resize(nq);
-        for (size_t r = 0; r < nq; r++) { ck.sorted[r] = mj[ord[r]]; ck.sorted_pos[ord[r]] = (int)r; }
+        for (size_t r = 0; r < nq; r++) { ck.sorted[r] = mj[ord[r]]; ck.sorted[r].pad = ord[r]; ck.sorted_pos[ord[r]] = (int)r; }   // (pad: the job's index -- the Nussinov kernel files its pair count under it)
         // a new class starts where twice as many blocks would fit a CU (and the current one has a few jobs)
         // Two classes for Edmonds, one for Hungarian: classes that FOLLOW each other on a stream each last as long as
         // their slowest job, so more of them lengthen the chain on the short kernels' stream past the end of Edmonds'
@@ -287,6 +290,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
         static const int env_hclasses = getenv("SQ_LSAP_CLASSES") ? std::max(1, atoi(getenv("SQ_LSAP_CLASSES"))) : 0;
         const bool crowded = b->inflight > 1 || nq >= 1024;
         const int max_classes = algo == SQ_ALGO_H ? (env_hclasses ? env_hclasses : (crowded ? 3 : 1))
+                              : algo == SQ_ALGO_N ? (crowded ? 3 : 1)       // (blocks of 64 / 128 / 192 threads instead of 192 for every job)
                                                   : (env_classes ? env_classes : (b->inflight < 2 ? 2 : 1));
         size_t cur = std::min<size_t>(need[ord[0]], 150 * 1024);
         ck.classes.push_back({0, 0});
@@ -305,8 +309,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
             fprintf(stderr, "\n");
         }
         memcpy(ck.p_jobs, ck.sorted.data(), nq * sizeof(SqMatchJob));
-    } else
-        memcpy(ck.p_jobs, mj.data(), mj.size() * sizeof(SqMatchJob));
+    }
     const double tb2 = sq_now();
     if (dev_sizes) return 0;                              // (the edges are written on the device: sq_algo_edges_kernel)
     // pass 2 (pool): the edges, written straight into the pinned buffer
@@ -367,7 +370,7 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
     hipEvent_t pe0;
     const int pslot = algo == SQ_ALGO_E ? 4 : algo == SQ_ALGO_H ? 5 : 6;
     sq_prof_begin(b, pslot, st, &pe0);
-    if (algo == SQ_ALGO_E || algo == SQ_ALGO_H) {
+    {
         // `st2` (Edmonds in a fold): the stream of the short kernels takes the classes after the first; st then waits
         // for it, so "st is idle" still means "the chunk is done".  Without st2 the classes follow each other on st.
         hipStream_t other = algo == SQ_ALGO_E ? st2 : nullptr;
@@ -385,11 +388,8 @@ static int algo_launch(sq_batch *b, SqAlgoChunk &ck, char *region, hipStream_t s
             HIPCK(hipEventRecord(b->class_ev, other));
             HIPCK(hipStreamWaitEvent(st, b->class_ev, 0));
         }
-    } else {
-        const int rl = sq_launch_matching(algo, mj.data(), nj, d_jobs, d_edges, ck.nedges, (SqMatchEdge *)(region + o_edges), d_scr,
-                                          ck.d_out, ck.d_cnt, b->ctx.codes, ck.job_flags, ck.flag_val, st);
-        if (rl) return sq_check((hipError_t)rl, "matching kernel launch");
     }
+    (void)nj;
     sq_prof_end(b, pslot, st, pe0);
     hipLaunchKernelGGL(sq_flag_kernel, dim3(1), dim3(1), 0, st, ck.flag, ck.flag_val);   // "results are in host memory"
     HIPCK(hipGetLastError());
@@ -747,10 +747,7 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
         const int pslot = it.algo == SQ_ALGO_E ? 4 : it.algo == SQ_ALGO_H ? 5 : 6;
         sq_prof_begin(b, pslot, cs, &pe0);
         int rl;
-        if (it.algo == SQ_ALGO_N)
-            rl = sq_launch_matching(it.algo, ck.mj.data(), nj, ck.p_mj, d_edges, ck.nedges, nullptr, region + cv[q].o_scr, d_out, d_cnt,
-                                    b->ctx.codes, nullptr, ck.flag_val, cs);
-        else {
+        {
             // the table sorted by LDS need, in size classes.  Edmonds folded alone: its first class (the largest graphs, the
             // critical path) on this stream, the others in front of the short kernels on their stream, joined before the
             // finish kernel

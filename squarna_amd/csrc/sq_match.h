@@ -34,7 +34,7 @@ extern "C" {
 __global__ void sq_lsap_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch, int32_t *col4row_out,
                                int lds_bytes);
 __global__ void sq_nussinov_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, const uint8_t *codes,
-                                   char *scratch, int32_t *pairs_out, int32_t *count_out);
+                                   char *scratch, int32_t *pairs_out, int32_t *count_out, int by_pad);
 __global__ void sq_mwm_kernel(const SqMatchJob *jobs, const int32_t *bin_head, const SqMatchEdge *edges, char *scratch,
                               int32_t *mate_out, uint32_t *job_flags, uint32_t stamp);
 __global__ void sq_mwm_single_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges, char *scratch, int32_t *mate_out,

@@ -152,11 +152,13 @@ extern "C" __global__ __launch_bounds__(64) void sq_lsap_kernel(const SqMatchJob
 // ------------------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMatchJob *jobs, const SqMatchEdge *edges,
                                                                      const uint8_t *codes, char *scratch,
-                                                                     int32_t *pairs_out, int32_t *count_out)
+                                                                     int32_t *pairs_out, int32_t *count_out, int by_pad)
 {
     const SqMatchJob jb = jobs[blockIdx.x];
     const int n = jb.n, tid = threadIdx.x, nthr = blockDim.x;   // 64 .. 256 threads: the launch's longest sequence rounded up to waves
-    if (n <= 0) { if (tid == 0) count_out[blockIdx.x] = 0; return; }
+    // (by_pad: the rows are a slice of a table sorted by size, row.pad = the job's index, under which its count is filed)
+    int32_t *const my_count = count_out + (by_pad ? jb.pad : (int)blockIdx.x);
+    if (n <= 0) { if (tid == 0) *my_count = 0; return; }
     double *S = reinterpret_cast<double *>(scratch + jb.scratch_off);   // region of n*n doubles: holds the column lists
     double *D = S + (size_t)n * n;
     int32_t *K = reinterpret_cast<int32_t *>(D + (size_t)n * n);
@@ -245,7 +247,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
             for (int t = 0; t < 2 * nn; t++) cur[t] = nxt[t];
             qn = nn;
         }
-        count_out[blockIdx.x] = np;
+        *my_count = np;
     }
 }
 
@@ -468,7 +470,7 @@ int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatch
         // an anti-diagonal of the DP has at most n cells: no more waves than that keeps busy (the block holds its wave slots
         // through the single-threaded BackTrack too)
         const int nthr = std::max(64, std::min(256, (maxn + 63) / 64 * 64));
-        hipLaunchKernelGGL(sq_nussinov_kernel, dim3(nj), dim3(nthr), 0, st, jobs, edges, codes, d_scr, out, cnt);
+        hipLaunchKernelGGL(sq_nussinov_kernel, dim3(nj), dim3(nthr), 0, st, jobs, edges, codes, d_scr, out, cnt, jobs_rw ? 1 : 0);
     } else {                                             // SQ_ALGO_E
         // bins: see sq_mwm_plan.  The plan writes each job's LDS slice into the job table the kernel reads.
         int nbins = 0, waves = 1; size_t lds = 0; bool all_in_lds = true;
