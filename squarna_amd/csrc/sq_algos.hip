@@ -722,7 +722,11 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
     }
     // ---- launches: edges on the batch stream (it owns the arena), then every item on its side stream ----
     hipStream_t st = b->stream;
-    hipLaunchKernelGGL(sq_algo_edges_kernel, dim3(S), dim3(256), 0, st, b->ctx, b->lane_full.d_structs, [&] { SqScanArgs a = b->scan; a.ctr = b->lane_full.d_ctr; return a; }(), round_aj);
+    {
+        const int maxn_lds = (std::min(b->maxn, SQ_ALGO_MAXN) + 7) & ~7;   // (the device RunAlgo only takes batches up to SQ_ALGO_MAXN nt)
+        hipLaunchKernelGGL(sq_algo_edges_kernel, dim3(S), dim3(256), (size_t)6 * maxn_lds + 16, st, b->ctx, b->lane_full.d_structs,
+                           [&] { SqScanArgs a = b->scan; a.ctr = b->lane_full.d_ctr; return a; }(), round_aj, maxn_lds);
+    }
     HIPCK(hipGetLastError());
     if (!b->class_ev) HIPCK(sq_event_get(b->device, &b->class_ev));
     if (!b->edges_ev) HIPCK(sq_event_get(b->device, &b->edges_ev));

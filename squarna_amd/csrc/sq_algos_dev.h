@@ -28,7 +28,7 @@ struct SqAlgoStat {                // per launch of the finish kernel (device; s
 #ifdef __HIPCC__
 extern "C" {
 __global__ void sq_algo_sizes_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqAlgoSize *sizes);
-__global__ void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs);
+__global__ void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs, int maxn_lds);
 __global__ void sq_algo_finish_kernel(SqDevCtx c, const SqAlgoJob *jobs, const SqMatchJob *mj, const int32_t *out, const int32_t *cnt,
                                       int levellimit_opt, SqPoolFin *fin, SqPoolStem *fin_stems, uint32_t *fin_ctr, uint32_t fin_cap,
                                       uint32_t fin_stem_cap, SqAlgoStat *stats, int tcap);

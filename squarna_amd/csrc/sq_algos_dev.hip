@@ -60,10 +60,12 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_sizes_kernel(SqDevCtx 
 // ---- edge lists -----------------------------------------------------------------------------------------------------
 // scratch of a structure: the SqKey part of its candidate slice (dead once the bpscore filter has run):
 // [nok x uint32 sorted survivor index][nok x uint32 first edge of that stem]
-extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs)
+extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs, int maxn_lds)
 {
-    __shared__ int32_t s_first[SQ_ALGO_MAXN];                          // Edmonds: first edge slot a position appears in
-    __shared__ int16_t s_id[SQ_ALGO_MAXN];                             // position -> vertex id
+    // (dynamic LDS sized for the batch's longest sequence -- 6 bytes per position; static arrays for 4,096 nt cost every block 24 KB)
+    extern __shared__ __attribute__((aligned(16))) char sq_edges_dyn[];
+    int32_t *const s_first = reinterpret_cast<int32_t *>(sq_edges_dyn);        // Edmonds: first edge slot a position appears in
+    int16_t *const s_id = reinterpret_cast<int16_t *>(s_first + maxn_lds);    // position -> vertex id
     __shared__ uint32_t s_wsum[4], s_run;
     const SqStruct st = structs[blockIdx.x];
     const SqJob jb = c.jobs[st.job];

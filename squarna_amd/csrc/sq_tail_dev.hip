@@ -205,9 +205,11 @@ __device__ __forceinline__ void sq_prf_wave(const int16_t *refp, int known_n, co
 #define SQ_TAIL_THREADS 256
 #define SQ_TAIL_BITWORDS 1024          // LDS bitmap words per wave: sequences up to 32768 nt
 
-extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kernel(SqDevCtx c, SqTailIO t)
+extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kernel(SqDevCtx c, SqTailIO t, int bitwords)
 {
-    __shared__ uint32_t s_bits[SQ_TAIL_THREADS / 64][SQ_TAIL_BITWORDS];
+    // (one bitmap of the sequence's positions per wave, in the block's DYNAMIC LDS sized for the batch's longest sequence:
+    // a static array for 32,768 nt cost every block 16 KB -- 20 bytes do for 150 nt)
+    extern __shared__ uint32_t s_bits_dyn[];                            // [SQ_TAIL_THREADS / 64][bitwords]
     __shared__ uint32_t s_wsum[SQ_TAIL_THREADS / 64];
     __shared__ uint32_t s_run;
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -219,7 +221,7 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kerne
     auto bail = [&]() {                                                 // the host tail takes the batch
         if (tid == 0) { *t.fallback = 1; S.D = 0; S.nshow = 0; S.nprf = 0; S.rec_bytes = 0; S.txt_bytes = 0; S.evals = 0; }
     };
-    if (M > SQ_TAIL_MAXM || n > 32 * SQ_TAIL_BITWORDS) { bail(); return; }
+    if (M > SQ_TAIL_MAXM || n > 32 * bitwords) { bail(); return; }
     // ---- a. every job's entries into finstemsets order: (kind, pos) ascending ----
     for (int j = j0; j < j1; j++) {
         const uint32_t lo = t.job_start[j], m = t.job_start[j + 1] - lo;
@@ -320,7 +322,7 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kerne
         const uint32_t x = t.dlist[first + k];
         const SqPoolFin F = t.fin[t.ord[first + x]];
         double sc[3];
-        sq_score_struct_wave(c, t, jb, [&](int q) { return sq_fin_stem(t, F, q); }, F.nstems, s_bits[wave], lane, sc, t.fallback);
+        sq_score_struct_wave(c, t, jb, [&](int q) { return sq_fin_stem(t, F, q); }, F.nstems, s_bits_dyn + (size_t)wave * bitwords, lane, sc, t.fallback);
         if (lane == 0) { t.scores[3 * (size_t)(first + x)] = sc[0]; t.scores[3 * (size_t)(first + x) + 1] = sc[1]; t.scores[3 * (size_t)(first + x) + 2] = sc[2]; }
     }
     __threadfence_block();
@@ -401,7 +403,7 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kerne
                 }
                 return out;
             };
-            sq_score_struct_wave(c, t, jb, ref_stem, nst, s_bits[0], lane, ref_sc, t.fallback);
+            sq_score_struct_wave(c, t, jb, ref_stem, nst, s_bits_dyn, lane, ref_sc, t.fallback);
         }
         if (lane == 0) {
             double *met = t.scores + 3 * (size_t)t.fin_cap + 16 * (size_t)s;   // per-sequence metrics behind the entry scores
@@ -675,7 +677,10 @@ int sq_tail_device(sq_batch *b, const sq_fold_opts &o, const int32_t *ref_off, c
     hipLaunchKernelGGL(sq_tail_count_kernel, dim3(nb), dim3(256), 0, st, t);
     hipLaunchKernelGGL(sq_tail_scan_kernel, dim3(1), dim3(1024), 0, st, t);
     hipLaunchKernelGGL(sq_tail_scatter_kernel, dim3(nb), dim3(256), 0, st, t);
-    hipLaunchKernelGGL(sq_tail_rank_kernel, dim3(b->nseq), dim3(SQ_TAIL_THREADS), 0, st, b->ctx, t);
+    {
+        const int bitwords = std::min(SQ_TAIL_BITWORDS, (b->maxn + 31) / 32 + 1);
+        hipLaunchKernelGGL(sq_tail_rank_kernel, dim3(b->nseq), dim3(SQ_TAIL_THREADS), (size_t)(SQ_TAIL_THREADS / 64) * bitwords * 4, st, b->ctx, t, bitwords);
+    }
     uint32_t seq = ++*ln.round_seq;
     hipLaunchKernelGGL(sq_tail_offsets_kernel, dim3(1), dim3(1024), 0, st, t, ln.h_seq, seq);
     if (sq_check(hipGetLastError(), "device tail launch")) return 2;
