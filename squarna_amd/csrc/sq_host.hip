@@ -1396,7 +1396,7 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
                                  int mode, const SqRoundIO &io, const SqScanArgs &scan, SqStruct *d_structs, SqStrand *d_strands,
                                  bool chained, bool pooled = false)
 {
-    const bool crowded = b->inflight > 1 || S >= 1024;
+    const bool crowded = b->inflight > 1 || b->njobs >= 4096;    // (by the batch, not by the launch: a batch's rounds all run one way)
     {
         ProfScope ps(b, 1, 0);
         // the per-structure arrays are assembled in LDS (7 bytes per position) when the longest sequence fits
@@ -1404,8 +1404,8 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
         const size_t st_dyn = st_lds_n ? (size_t)7 * ((st_lds_n + 8) & ~7) + 64 : 0;
         // (sequences up to 200 nt: one wave builds the arrays in three or four steps; four waves per structure held four
         // times the wave slots for the same few microseconds -- with batches in flight the chip is short of exactly those)
-        // "crowded": the chip is (or will be) short of wave slots -- several batches in flight, or a launch of a thousand
-        // structures and more.  Then a short structure gets ONE wave in the state, scan and scoring kernels; a small batch
+        // "crowded": the chip is (or will be) short of wave slots -- several batches in flight, or a batch of four thousand
+        // jobs and more (a 219-record batch alone -- 1,095 jobs -- keeps its rounds a latency chain).  Then a short structure gets ONE wave in the state, scan and scoring kernels; a small batch
         // alone keeps the wide blocks (its greedy rounds are a latency chain: one wave per structure made them 1.5 ms
         // longer per 219-record fold, hidden behind the blossom kernel only when there is one)
         static const int state_short = getenv("SQ_STATE_SHORT_THREADS") ? std::max(64, std::min(256, atoi(getenv("SQ_STATE_SHORT_THREADS")) / 64 * 64)) : 64;
