@@ -287,10 +287,10 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
         // Hungarian with the chip crowded (batches in flight, or thousands of jobs): every block of a launch gets the LDS of the
         // launch's LARGEST job (62 KB at 150 nt: two one-wave blocks per CU, and LDS the scoring kernels of the other batches
         // do not get) -- three classes give most jobs a quarter of that
-        static const int env_hclasses = getenv("SQ_LSAP_CLASSES") ? std::max(1, atoi(getenv("SQ_LSAP_CLASSES"))) : 0;
+        const int env_hclasses = getenv("SQ_LSAP_CLASSES") ? std::max(1, atoi(getenv("SQ_LSAP_CLASSES"))) : 0;   // (read per fold: tests)
         const bool crowded = b->inflight > 1 || nq >= 4096;    // (a batch of 1,314 jobs alone: 7.1 ms without the classes, 8.5 with)
         const int max_classes = algo == SQ_ALGO_H ? (env_hclasses ? env_hclasses : (crowded ? 3 : 1))
-                              : algo == SQ_ALGO_N ? (crowded ? 3 : 1)       // (blocks of 64 / 128 / 192 threads instead of 192 for every job)
+                              : algo == SQ_ALGO_N ? (env_hclasses ? env_hclasses : (crowded ? 3 : 1))   // (blocks of 64 / 128 / 192 threads instead of 192 for every job)
                                                   : (env_classes ? env_classes : (b->inflight < 2 ? 2 : 1));
         size_t cur = std::min<size_t>(need[ord[0]], 150 * 1024);
         ck.classes.push_back({0, 0});
