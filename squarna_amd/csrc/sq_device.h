@@ -152,6 +152,7 @@ __global__ void sq_scatter_kernel(SqDevCtx c, const SqStruct *structs, SqScanArg
 __global__ void sq_colselect_kernel(const double *matrix, int L, double thr, int minspan, long long *idx_out,
                                     double *val_out, long long cap, unsigned long long *count);
 __global__ void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a);
+__global__ void sq_state_scan_kernel(SqDevCtx c, SqRoundIO io, SqState stt, SqScanArgs a, int lds_n, int chained);
 __global__ void sq_bits_kernel(SqDevCtx c, int only_ext);
 __global__ void sq_score_kernel(SqDevCtx c, const SqStruct *structs, const SqStrand *strands, SqState stt,
                                 SqScanArgs a, SqRoundIO io, int lds_n, int lds_n_reacts, int lds_n_state, int surv_off, int cell_off,

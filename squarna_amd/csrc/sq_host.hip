@@ -1397,7 +1397,17 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
                                  bool chained, bool pooled = false)
 {
     const bool crowded = b->inflight > 1 || b->njobs >= 4096;    // (by the batch, not by the launch: a batch's rounds all run one way)
-    {
+    // short sequences on a crowded chip: state and scan in one launch, one wave per structure (sq_state_scan_kernel)
+    static const bool no_fuse = getenv("SQ_NO_STATE_SCAN_FUSE") != nullptr;
+    static const int st_short_env = getenv("SQ_STATE_SHORT_THREADS") ? atoi(getenv("SQ_STATE_SHORT_THREADS")) : 64;
+    static const int sc_short_env = getenv("SQ_SCAN_SHORT_WAVES") ? atoi(getenv("SQ_SCAN_SHORT_WAVES")) : 1;
+    const bool fuse = crowded && maxn <= 200 && maxn >= 5 && !no_fuse && st_short_env == 64 && sc_short_env == 1;
+    if (fuse) {
+        ProfScope ps(b, 2, scan_bytes);
+        const size_t dyn_state = (size_t)7 * ((maxn + 8) & ~7) + 64, dyn_scan = 4 * (size_t)b->state.fbstride;
+        hipLaunchKernelGGL(sq_state_scan_kernel, dim3(S), dim3(64), std::max(dyn_state, dyn_scan), st, b->ctx, io, b->state, scan, maxn, chained ? 1 : 0);
+    }
+    if (!fuse) {
         ProfScope ps(b, 1, 0);
         // the per-structure arrays are assembled in LDS (7 bytes per position) when the longest sequence fits
         const int st_lds_n = maxn <= 8000 ? maxn : 0;
@@ -1414,7 +1424,7 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
     // mode 0: the context tables of the round's structures (only long-sequence batches carry them)
     const bool ctx_on = mode == 0 && b->ctxtab.rec != nullptr && b->score_ctx;
     if (ctx_on) sq_launch_context(d_structs, d_strands, b->ctxtab, S, st);
-    if (maxn >= 5) {
+    if (maxn >= 5 && !fuse) {
         ProfScope ps(b, 2, scan_bytes);
         // bit-diagonal scan: one wave = 64 anti-diagonals
         // (sequences up to 200 nt: one wave per structure walks all its diagonal groups, see the kernel)

@@ -467,17 +467,18 @@ __device__ __forceinline__ void sq_state_build(const SqDevCtx &c, const SqStruct
 
 // chained: the structures and strands already live in device memory (sq_chain_kernel maintains them; io.h_* point at
 // the same arrays), finished structures carry nstrand < 0 and the counters accumulate over the whole chain.
-extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n,
-                                                                 int chained)
+// the state of one structure (block = structure); returns false for a structure that is final (chained rounds)
+__device__ __forceinline__ bool sq_state_body(const SqDevCtx &c, const SqRoundIO &io, const SqState &st, SqScanArgs &a, int lds_n,
+                                              int chained, SqStruct &s)
 {
     extern __shared__ __attribute__((aligned(16))) char st_dyn[];
-    const SqStruct s = io.h_structs[blockIdx.x];          // pinned host memory: one read per structure per round
+    s = io.h_structs[blockIdx.x];                         // pinned host memory: one read per structure per round
     if (threadIdx.x == 0) {
         if (!chained) io.d_structs[blockIdx.x] = s;
         a.cand_cnt[s.slot] = 0; a.best[s.slot] = 0ull; a.ok_cnt[s.slot] = 0;
         if (blockIdx.x == 0 && !chained) { a.ctr->nout = 0; a.ctr->cand_ovf = 0; a.ctr->out_ovf = 0; a.ctr->level_ovf = 0; }
     }
-    if (s.nstrand < 0) return;                            // (chained) the structure is final
+    if (s.nstrand < 0) return false;                      // (chained) the structure is final
     if (!chained)
         for (int k = threadIdx.x; k < s.nstrand; k += blockDim.x) io.d_strands[s.strand_off + k] = io.h_strands[s.strand_off + k];
     __syncthreads();
@@ -493,6 +494,14 @@ extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, Sq
         sq_state_build<false>(c, s, jb, sd, st, st.P + (int64_t)s.slot * st.stride, st.E8 + (int64_t)s.slot * st.stride * 2,
                               st.U + (int64_t)s.slot * st.stride, st.SU + (int64_t)s.slot * st.stride);
     }
+    return true;
+}
+
+extern "C" __global__ __launch_bounds__(256) void sq_state_kernel(SqDevCtx c, SqRoundIO io, SqState st, SqScanArgs a, int lds_n,
+                                                                 int chained)
+{
+    SqStruct s;
+    sq_state_body(c, io, st, a, lds_n, chained, s);
 }
 
 // ------------------------------------------------------------------------------------
@@ -561,11 +570,11 @@ struct SqScan6Lds {
 #ifndef SQ6_AHEAD
 #define SQ6_AHEAD 2
 #endif
-extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
+// the scan of one structure's diagonal groups gy0, gy0 + gystep, .. (one wave)
+__device__ __forceinline__ void sq_scan6_body(const SqDevCtx &c, const SqStruct &st, const SqState &stt, SqScanArgs &a, int gy0, int gystep)
 {
     __shared__ __attribute__((aligned(16))) SqScan6Lds L;
     extern __shared__ uint32_t sq6_fg[];                                // F words then G words of the structure
-    const SqStruct st = structs[blockIdx.x];
     if (st.nstrand < 0) return;                                         // (chained rounds) the structure is final
     const SqJob jb = c.jobs[st.job];
     const int n = jb.n;
@@ -582,7 +591,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, con
     // ONE wave that walks all its groups (five for 100 nt) instead of one wave per group -- each of those spent most of its
     // few microseconds on the set-up above, and with batches in flight wave slots are what the chip runs out of
     const int ngroups = ((2 * n - 5 + 63) >> 6) + 1;
-    for (int gy = blockIdx.y; gy < ngroups; gy += gridDim.y) {
+    for (int gy = gy0; gy < ngroups; gy += gystep) {
     const int s0 = gy << 6;
     const int smin = max(s0, 4), smax = min(s0 + 63, 2 * n - 6);        // :456-457 s in [4, 2N-6]
     if (smin > smax) continue;
@@ -689,6 +698,26 @@ extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, con
     __syncthreads();
     sq5_flush(L, a, st, cap, lane);
     }
+}
+
+extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
+{
+    const SqStruct st = structs[blockIdx.x];
+    sq_scan6_body(c, st, stt, a, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// Short sequences on a crowded chip: the state and the scan of a structure by ONE wave in ONE launch (the two kernels had
+// the same grid there: a wave per structure each).  The state goes to global memory as before -- the scoring kernel reads
+// it --, the scan part reads back what it needs (free-position words, mask codes) behind a fence.
+extern "C" __global__ __launch_bounds__(64) void sq_state_scan_kernel(SqDevCtx c, SqRoundIO io, SqState stt, SqScanArgs a, int lds_n, int chained)
+{
+    SqStruct s;
+    if (!sq_state_body(c, io, stt, a, lds_n, chained, s)) return;
+    // (the scan part reads what this block wrote: a fence at workgroup scope orders the block's own global accesses -- a
+    // device-scope fence writes the L2 back and cost more than the whole kernel: 580 k -> 320 k sequences/s)
+    __threadfence_block();
+    __syncthreads();
+    sq_scan6_body(c, s, stt, a, 0, 1);
 }
 
 

@@ -279,7 +279,9 @@ __device__ __forceinline__ void sq_mwm_one(SqBlossom &bl, char *lds_base, char *
         if (job_flags) {
             const int nw = jp->n > 0 ? 2 * jp->n + 2 : 2;
             sq_host_write_flush(mate_out + jp->out_off + (lane < nw ? nw - 1 - lane : 0));
-        } else __threadfence_system();
+        }
+        // (without per-job flags nobody reads the mates before the kernel has ended -- the finish kernel or the flag kernel
+        // behind it on the stream: no fence here; a system-scope fence per graph writes the L2 back, thousands of times a launch)
         wsync();
         if (job_flags && lane == 0) job_flags[row] = stamp;
     };
