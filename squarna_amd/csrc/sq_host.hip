@@ -1460,7 +1460,8 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
         // either way within the run-to-run spread and keeps 512.
         static const int short_thr = getenv("SQ_SCORE_SHORT_THREADS") ? atoi(getenv("SQ_SCORE_SHORT_THREADS")) : 64;
         const int thr0 = maxn <= 200 ? (crowded ? short_thr : 128) : (maxn <= 400 ? 256 : 512);
-        const int thr = score_threads ? score_threads : (mode == 0 ? thr0 : (parts == 1 && S < 2048 ? 512 : 256));
+        // (the one-pass modes on a crowded chip: a structure of a short sequence has ~150 candidates -- one wave, not four)
+        const int thr = score_threads ? score_threads : (mode == 0 ? thr0 : (maxn <= 200 && crowded ? 64 : (parts == 1 && S < 2048 ? 512 : 256)));
         // the cell table (K R x (K R | 1) doubles for the batch's largest K R), then
         // mode 0: list of the bpscore survivors of a chunk (5 x threads entries of 8 + 4 + 2 bytes) behind the tables
         const int cell_off = (int)((dyn + 15) & ~(size_t)15);
