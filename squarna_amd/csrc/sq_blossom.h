@@ -70,16 +70,16 @@ struct SqCoopWave {
     {
         const double inf = __longlong_as_double(0x7FF0000000000000ll);
         double o;
-        o = dpp_f64<0x111, 0xf>(inf, v); v = o < v ? o : v;
-        o = dpp_f64<0x112, 0xf>(inf, v); v = o < v ? o : v;
-        o = dpp_f64<0x114, 0xf>(inf, v); v = o < v ? o : v;
-        o = dpp_f64<0x118, 0xf>(inf, v); v = o < v ? o : v;
+        o = dpp_f64<0x111, 0xf>(inf, v); v = __builtin_fmin(o, v);
+        o = dpp_f64<0x112, 0xf>(inf, v); v = __builtin_fmin(o, v);
+        o = dpp_f64<0x114, 0xf>(inf, v); v = __builtin_fmin(o, v);
+        o = dpp_f64<0x118, 0xf>(inf, v); v = __builtin_fmin(o, v);
         int src = 15;
         if (nlive > 16) {
-            o = dpp_f64<0x142, 0xa>(inf, v); v = o < v ? o : v;
+            o = dpp_f64<0x142, 0xa>(inf, v); v = __builtin_fmin(o, v);
             src = 31;
             if (nlive > 32) {
-                o = dpp_f64<0x143, 0xc>(inf, v); v = o < v ? o : v;
+                o = dpp_f64<0x143, 0xc>(inf, v); v = __builtin_fmin(o, v);
                 src = 63;
             }
         }
