@@ -18,7 +18,9 @@ roofline : `roofline` = the dominant kernel of the S1000 leg (1,024 r
            since).  `rooflines` = the other kernels that dominate a leg (blossom kernel of the headline step with its
            cycles per scan pass, the scan kernel, the fp32 fill), each with the resource that binds it.
 cpu_baseline: the CPU oracle (oracle/, a C port of the reference algorithm + the reference's own scipy / networkx
-           calls) on the same workload, one process per host core; S1000 / S2000 on a stated subsample.
+           calls) on the same workload, one process per host core; S1000 / S2000 on a stated subsample.  Its workers are
+           spawned before the GPU is initialised and wait; the leg itself runs LAST (ten seconds of all-core load in front
+           of the GPU legs made the latency-bound ones slower).
 --workload S300|S1000|S2000: strong-scaling mode (SURVEY 8d workloads sharded over the ranks with lpt_partition, one
            RCCL all_gather of the packed results per step).  With --gpus N > 1 the default run adds a short sharded
            S300 leg as a secondary field.
@@ -68,20 +70,22 @@ def prepare_synthetic(items):
 
 # ---------------------------------------------------------------- cpu_baseline (the oracle; checker, never the product)
 def _oracle_init(cfg):
-    global _O, _PSETS
+    global _O, _PSETS, _PSETS_BY
     sys.path.insert(0, ROOT)
     from oracle import sqrn_oracle as O
     from squarna_amd.config import ParseConfig, builtin_config
     _O = O
-    _PSETS = ParseConfig(builtin_config(cfg))[1]
+    _PSETS_BY = {c: ParseConfig(builtin_config(c))[1] for c in {cfg, "fastest"}}
+    _PSETS = _PSETS_BY[cfg]
     O.lib()
 
 
 def _oracle_one(rec):
-    """cpu_baseline worker task: fold one record with the CPU oracle."""
-    name, seq, reacts, restr, ref, poollim = rec
+    """cpu_baseline worker task: fold one record with the CPU oracle (a 7th field names another built-in config)."""
+    name, seq, reacts, restr, ref, poollim = rec[:6]
+    psets = _PSETS_BY[rec[6]] if len(rec) > 6 else _PSETS
     t0 = time.perf_counter()
-    _O.SQRNdbnseq(seq, reacts, restr, ref, _PSETS, poollim=poollim)
+    _O.SQRNdbnseq(seq, reacts, restr, ref, psets, poollim=poollim)
     return time.perf_counter() - t0
 
 
@@ -109,32 +113,55 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(recs, cfg, target_s=10.0):
-    """Times the oracle on the GPU box's host cores (one process per hardware thread, records handed out dynamically,
-    longest first) for about target_s seconds of wall time; must run BEFORE this process touches the GPU (it spawns
-    workers).  The workers run their numerical libraries single-threaded: 256 processes x a BLAS / OpenMP pool each
-    would measure oversubscription, not the algorithm."""
+def cpu_workers_start(recs, cfg):
+    """The cpu_baseline leg's worker processes: spawned BEFORE this process touches the GPU (a process that has initialised
+    the GPU must not start others), warmed, and left idle until cpu_baseline() runs at the END of the bench -- ten seconds of
+    all-core load in front of the GPU legs left the host slower for a while (one 219-record fold alone: 5.5 ms without the
+    leg in front, 6.4 ms behind it).  The workers run their numerical libraries single-threaded: 256 processes x a BLAS /
+    OpenMP pool each would measure oversubscription, not the algorithm."""
     import multiprocessing as mp
     cores = effective_cpus()
+    saved = {}
     for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        saved[var] = os.environ.get(var)
         os.environ[var] = "1"                              # (inherited by the spawned workers; restored below)
+    pool = mp.get_context("spawn").Pool(cores, initializer=_oracle_init, initargs=(cfg,))
+    pool.map(_oracle_one, [r + (1000,) for r in recs[:cores]])   # warm the workers (imports, dlopen)
+    for var, val in saved.items():
+        if val is None:
+            os.environ.pop(var, None)
+        else:
+            os.environ[var] = val
+    return pool, cores
+
+
+def cpu_baseline(workers, recs, cfg, target_s=10.0):
+    """Times the oracle on the GPU box's host cores (one process per CPU the job may use -- cpu_workers_start --, records
+    handed out dynamically, longest first) for about target_s seconds of wall time."""
+    pool, cores = workers
     recs = [r + (1000,) for r in recs]
     _oracle_init(cfg)
     t1 = sum(_oracle_one(r) for r in recs[::8])            # one thread alone, on a slice
     per_pass = t1 * 8
     tasks = sorted(recs, key=lambda r: -len(r[1])) * 400   # more than any host finishes in target_s: cut off by the clock
-    ctx = mp.get_context("spawn")
     done, busy = 0, 0.0
-    with ctx.Pool(cores, initializer=_oracle_init, initargs=(cfg,)) as pool:
-        pool.map(_oracle_one, recs[:cores])               # warm the workers (imports, dlopen)
-        t0 = time.perf_counter()
-        for dt_one in pool.imap_unordered(_oracle_one, tasks, chunksize=2):
-            done += 1
-            busy += dt_one
-            wall = time.perf_counter() - t0
-            if wall >= target_s and done >= len(recs):
-                break
-        pool.terminate()
+    # a sliding window of 3 x cores tasks in flight (the same pool takes the S1000 / S2000 samples afterwards: nothing may
+    # be left queued behind the clock)
+    from collections import deque
+    it, pend = iter(tasks), deque()
+    for _ in range(3 * cores):
+        pend.append(pool.apply_async(_oracle_one, (next(it),)))
+    t0 = time.perf_counter()
+    while True:
+        dt_one = pend.popleft().get()
+        done += 1
+        busy += dt_one
+        wall = time.perf_counter() - t0
+        if wall >= target_s and done >= len(recs):
+            break
+        pend.append(pool.apply_async(_oracle_one, (next(it),)))
+    for r in pend:                                         # (a few dozen short folds)
+        r.get()
     out = dict(value=round(done / wall, 1), unit="seq/s", cores=cores, kind="port",
                per_thread_seq_per_s=round(done / max(busy, 1e-9), 2), one_thread_alone_seq_per_s=round(len(recs) / per_pass, 2),
                sample="SRtest150 records (longest first, repeated) for %.1f s of wall time: %d folds, c=%s, C oracle "
@@ -147,21 +174,18 @@ def cpu_baseline(recs, cfg, target_s=10.0):
     from squarna_amd.dbn import ProcessReacts, ReactDict
     for wl, take in (("S1000", 64), ("S2000", 32)):
         items = synthetic(wl)[:min(take, cores)]
-        tasks = [("", s, ProcessReacts([ReactDict[c] for c in line], M=1.8, B=-0.6) if line else None, None, None, 1)
+        tasks = [("", s, ProcessReacts([ReactDict[c] for c in line], M=1.8, B=-0.6) if line else None, None, None, 1, "fastest")
                  for s, line in items]
-        with ctx.Pool(min(cores, len(tasks)), initializer=_oracle_init, initargs=("fastest",)) as pool:
-            pool.map(_oracle_one, tasks[:1])
-            t0 = time.perf_counter()
-            per = list(pool.imap_unordered(_oracle_one, tasks, chunksize=1))
-            wall = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        per = list(pool.imap_unordered(_oracle_one, tasks, chunksize=1))
+        wall = time.perf_counter() - t0
         mean_s = float(np.mean(per))
         others[wl] = dict(value=round(cores / mean_s, 2), unit="seq/s", cores=cores, kind="port",
                           seconds_per_sequence_one_core=round(mean_s, 4),
                           sample="first %d sequences of %s, c=fastest pl=1, one per process (wall %.2fs); value = cores / "
                                  "mean seconds per sequence (linear extrapolation to all cores busy)" % (len(tasks), wl, wall))
     out["other_workloads"] = others
-    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
-        os.environ.pop(var, None)
+    pool.terminate()
     return out
 
 
@@ -557,9 +581,9 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # (squarna_amd sets the same default at import; see its __init__)
 
     recs = load_srtest150()
-    cpu = None
+    cpu = cpu_workers = None
     if rank == 0 and world == 1 and not args.no_cpu and args.workload == "srtest150":
-        cpu = cpu_baseline(recs, args.config)       # before any GPU initialisation
+        cpu_workers = cpu_workers_start(recs, args.config)   # before any GPU initialisation; the leg itself runs last
 
     import torch
     import torch.distributed as dist
@@ -715,11 +739,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_stream:
         try:
             stream, one_pass = stream_leg(args.config, K, R, max(5, args.steps // 2), 2, device)
-            if cpu and one_pass:
-                one_pass["vs_cpu_baseline"] = round(one_pass["seq_per_s"] / cpu["value"], 1)
-                stream["vs_cpu_baseline"] = round(stream["seq_per_s"] / cpu["value"], 1)
         except Exception as e:                                # (a secondary leg never takes the headline down)
             stream = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # the CPU baseline LAST (its workers have been waiting since before the GPU was initialised): all cores busy for ten
+    # seconds in front of the GPU legs made the latency-bound ones slower
+    if cpu_workers is not None:
+        cpu = cpu_baseline(cpu_workers, recs, args.config)
+        if one_pass and "seq_per_s" in one_pass:
+            one_pass["vs_cpu_baseline"] = round(one_pass["seq_per_s"] / cpu["value"], 1)
+        if stream and "seq_per_s" in stream:
+            stream["vs_cpu_baseline"] = round(stream["seq_per_s"] / cpu["value"], 1)
 
     sharded = None
     if world > 1:
