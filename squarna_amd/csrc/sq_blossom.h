@@ -36,11 +36,20 @@ struct SqCoopSingle {
     SQ_HD void min_plain(double &, int = 64) const {}
     SQ_HD int excl_scan(int cnt, int &total) const { total = cnt; return 0; }
     SQ_HD int count_true(bool p, int &first) const { first = 0; return p ? 1 : 0; }
+    static constexpr int kSegMax = 1;                           // vertices per scan pass
+    SQ_HD int readlane(int x, int) const { return x; }
+    SQ_HD bool any(bool p) const { return p; }
+    SQ_HD void min_pos_f64(double *p, double v) const { if (v < *p) *p = v; }
 };
 #ifdef __HIPCC__
 // ... or the 64 lanes of a wave.  first_true: lowest lane whose predicate holds (nl if none);
 // min_first: lexicographic minimum of (value, index) over the lanes with index < nl, broadcast to all.
 struct SqCoopWave {
+    static constexpr int kSegMax = 4;                           // vertices per scan pass (their neighbour lists share the 64 lanes)
+    __device__ int readlane(int x, int l) const { return __builtin_amdgcn_readlane(x, l); }
+    __device__ bool any(bool p) const { return __ballot(p) != 0; }
+    // *p = min(*p, v) for POSITIVE doubles (and +inf): their bit patterns order like unsigned integers
+    __device__ void min_pos_f64(double *p, double v) const { atomicMin((unsigned long long *)p, (unsigned long long)__double_as_longlong(v)); }
     __device__ int first_true(bool p, int nl) const
     {
         const unsigned long long b = __ballot(p);
@@ -140,7 +149,8 @@ struct SqBlossom {
     int8_t *label;            // 0 none, 1 S, 2 T, 5 scanned mark
     int *labeledge, *inblossom, *parent, *base, *bestedge;
     double *dualvar, *bdual;
-    double *bslack;           // bslack[x] == slack(bestedge[x]) under the current duals whenever bestedge[x] != -1
+    double *bslack;           // bslack[x] == slack(bestedge[x]) under the current duals whenever bestedge[x] != -1, +inf when there
+                              // is none (the several-vertices-per-pass scan competes for best edges with an LDS minimum on it)
     uint8_t *allow;           // per undirected edge
     int *queue; int qn, qcap;
     // blossoms
@@ -244,6 +254,8 @@ struct SqBlossom {
 #else
 #define SQ_FAST0 ((char *)nullptr)
 #endif
+#define SQ_BINF __builtin_huge_val()
+#define SQ_ORDERED() asm volatile("" ::: "memory")
 #define SQ_LP(p) (FAST ? (decltype(p))(SQ_FAST0 + ((char *)(p) - origin)) : (p))            /* hot arrays */
 #define SQ_LQ(p) (FAST == 1 ? (decltype(p))(SQ_FAST0 + ((char *)(p) - origin)) : (p))       /* cold / edge arrays, E */
     template <int FAST = 0> SQ_HD int tail(int de) const { return (de & 1) ? SQ_LQ(E)[de >> 1].w : SQ_LQ(E)[de >> 1].v; }
@@ -275,6 +287,7 @@ struct SqBlossom {
             SQ_LP(label)[w] = SQ_LP(label)[b] = (int8_t)t;
             SQ_LP(labeledge)[w] = SQ_LP(labeledge)[b] = de;
             SQ_LP(bestedge)[w] = SQ_LP(bestedge)[b] = -1;
+            SQ_LP(bslack)[w] = SQ_LP(bslack)[b] = SQ_BINF;
             if (t == 1) {
                 if (is_blossom(b)) {
                     const int c = leaves<FAST>(b, SQ_LQ(tmp_leaves));
@@ -393,11 +406,11 @@ struct SqBlossom {
                     else if (slack<FAST>(ide) < slack<FAST>(SQ_LQ(beto)[bj])) SQ_LQ(beto)[bj] = kde;
                 }
             }
-            SQ_LP(bestedge)[cv] = -1;
+            SQ_LP(bestedge)[cv] = -1; SQ_LP(bslack)[cv] = SQ_BINF;
         }
         // b.mybestedges = list(bestedgeto.values())
         SQ_LQ(mbe_off)[b] = pool_n; SQ_LQ(mbe_cnt)[b] = nk;
-        int mybest = -1; double mybestslack = 0;
+        int mybest = -1; double mybestslack = SQ_BINF;
         for (int k = 0; k < nk; k++) {
             const int kde = SQ_LQ(beto)[SQ_LQ(beto_keys)[k]];
             SQ_LQ(beto)[SQ_LQ(beto_keys)[k]] = -1;
@@ -465,7 +478,7 @@ struct SqBlossom {
                 const int w = head<FAST>(de);
                 SQ_LP(label)[w] = SQ_LP(label)[bw] = 2;
                 SQ_LP(labeledge)[w] = SQ_LP(labeledge)[bw] = de;
-                SQ_LP(bestedge)[bw] = -1;
+                SQ_LP(bestedge)[bw] = -1; SQ_LP(bslack)[bw] = SQ_BINF;
                 c = (jstep == 1) ? SQ_LQ(sib_next)[c] : SQ_LQ(sib_prev)[c];
                 while (c != entry) {
                     const int bv = c;
@@ -484,7 +497,7 @@ struct SqBlossom {
                     c = (jstep == 1) ? SQ_LQ(sib_next)[c] : SQ_LQ(sib_prev)[c];
                 }
             }
-            SQ_LP(label)[b] = 0; SQ_LP(labeledge)[b] = -1; SQ_LP(bestedge)[b] = -1;
+            SQ_LP(label)[b] = 0; SQ_LP(labeledge)[b] = -1; SQ_LP(bestedge)[b] = -1; SQ_LP(bslack)[b] = SQ_BINF;
             SQ_LQ(parent)[b] = -1; SQ_LQ(base)[b] = -1; SQ_LQ(bdual)[b] = 0; SQ_LQ(mbe_cnt)[b] = -1;
             remove_live<FAST>(b);
             sp--;
@@ -624,7 +637,7 @@ struct SqBlossom {
         for (int v = lane; v < n; v += nl) { SQ_LQ(mate)[v] = -1; SQ_LQ(mate_de)[v] = -1; SQ_LQ(mord)[v] = -1; SQ_LP(inblossom)[v] = v; }
         if (lane == 0) mord_n = 0;
         for (int x = lane; x < N2; x += nl) {
-            SQ_LP(label)[x] = 0; SQ_LP(labeledge)[x] = -1; SQ_LQ(parent)[x] = -1; SQ_LQ(base)[x] = x < n ? x : -1; SQ_LP(bestedge)[x] = -1;
+            SQ_LP(label)[x] = 0; SQ_LP(labeledge)[x] = -1; SQ_LQ(parent)[x] = -1; SQ_LQ(base)[x] = x < n ? x : -1; SQ_LP(bestedge)[x] = -1; SQ_LP(bslack)[x] = SQ_BINF;
             SQ_LQ(bdual)[x] = 0; SQ_LQ(mbe_cnt)[x] = -1; SQ_LQ(mbe_off)[x] = 0; SQ_LQ(beto)[x] = -1; SQ_LQ(nchild)[x] = 0; SQ_LQ(first)[x] = -1;
         }
         if (lane == 0) {
@@ -669,7 +682,7 @@ struct SqBlossom {
 #ifdef SQ_MWM_PROF
             if (lane == 0) pc[3]++;
 #endif
-            for (int x = lane; x < N2; x += nl) { SQ_LP(label)[x] = 0; SQ_LP(labeledge)[x] = -1; SQ_LP(bestedge)[x] = -1; }
+            for (int x = lane; x < N2; x += nl) { SQ_LP(label)[x] = 0; SQ_LP(labeledge)[x] = -1; SQ_LP(bestedge)[x] = -1; SQ_LP(bslack)[x] = SQ_BINF; }
             for (int k = lane; k < nlive; k += nl) SQ_LQ(mbe_cnt)[SQ_LQ(live)[k]] = -1;
             for (int e = lane; e < m; e += nl) SQ_LP(allow)[e] = 0;
             sync();
@@ -690,7 +703,7 @@ struct SqBlossom {
                     if (q) {
                         if (pos + cnt > qcap) error = 1;
                         else {
-                            SQ_LP(label)[v] = SQ_LP(label)[b] = 1; SQ_LP(labeledge)[v] = SQ_LP(labeledge)[b] = -1; SQ_LP(bestedge)[v] = SQ_LP(bestedge)[b] = -1;
+                            SQ_LP(label)[v] = SQ_LP(label)[b] = 1; SQ_LP(labeledge)[v] = SQ_LP(labeledge)[b] = -1; SQ_LP(bestedge)[v] = SQ_LP(bestedge)[b] = -1;   // (bslack: +inf since the reset above)
                             if (b < n) SQ_LP(queue)[pos] = b;
                             else { red_i[lane][0] = b; red_i[lane][1] = pos; }
                         }
@@ -729,143 +742,230 @@ struct SqBlossom {
                 sync();
                 int qn_r = qn;
                 bool stopq = f_augmented || error;
-                // The vertex BELOW the one being scanned is fetched (queue slot, adjacency bounds) while the scan's own
-                // loads are in flight: the queue is a stack that events only push onto, so unless an event happens
-                // during the scan, that vertex is the next one popped -- two dependent LDS round trips per pass
-                // (queue -> adj_off) leave the critical path.
-                int v_pre = -1, a0_pre = 0, aend_pre = 0;
-                while (qn_r > 0 && !stopq) {
+                // SEVERAL VERTICES PER PASS.  The queue is a stack that only events push onto, so until an event happens
+                // the vertices popped next are the ones below the top: as long as their whole neighbour lists fit the
+                // lanes that are left, up to SEGMAX of them are scanned in one pass, each lane classifying one neighbour
+                // of "its" vertex against the state before the pass.  Lane order == the sequential scan order, so the
+                // neighbours before the first state-changing one are applied together and the state-changing one
+                // splits the pass as before.  What the segments of one pass can share, and how the sequential result is
+                // kept: the same w from two vertices -- the first lane that labels w (cat 2) wins and silences every
+                // later lane on w; best-edge competitors (cat 3 for w, cat 4 for the scanning vertex's blossom, which
+                // several segments may share) take the minimum slack through an LDS minimum on the cached slack and the
+                // lowest lane among the ties wins (stores issued in reverse segment order: LDS executes a wave's
+                // operations in order, the lowest segment's store lands last).  With the state in global memory
+                // (FAST 0) a pass stays one vertex.
+                constexpr int SEGMAX = FAST ? Coop::kSegMax : 1;
+                int cv = -1, ca0 = 0, caend = 0;                 // a popped vertex with neighbours left (after an event or a full chunk)
+                // lanes 0..SEGMAX-1: the top entries of the queue (vertex, adjacency start, length; -1: none), fetched
+                // while the previous pass's own loads were in flight (valid unless that pass had an event)
+                int pf_v = 0, pf_a0 = 0, pf_len = -1;
+                bool pf_ok = false;
+                while (!stopq && (cv >= 0 || qn_r > 0)) {
 #ifdef SQ_MWM_PROF2
                     long long _q0 = clock64();
 #endif
-                    --qn_r;
-                    int v, a0, aend;
-                    if (v_pre >= 0) { v = v_pre; a0 = a0_pre; aend = aend_pre; }
-                    else { v = queue_[qn_r]; a0 = adj_off_[v]; aend = adj_off_[v + 1]; }
-                    const bool pre_ok = qn_r > 0;
-                    const int vn = queue_[pre_ok ? qn_r - 1 : 0];
-                    const int a0n = adj_off_[pre_ok ? vn : 0], aendn = adj_off_[pre_ok ? vn + 1 : 0];
-                    bool had_event = false;
-                    v_pre = -1;
-#ifdef SQ_MWM_PROF
-                    if (lane == 0) { pc[1]++; pc[0] += aend - a0; }
-#endif
-                    while (a0 < aend) {
-                        npass++;
-#ifdef SQ_MWM_PROF
-                        if (lane == 0) pc[5]++;
-#endif
-                        // Branch-free classification: the loads of one dependency level are issued together
-                        // (speculatively for lanes past the end, on a clamped slot), three LDS round trips in all.
-                        const bool live = a0 + lane < aend;
-                        const int a = live ? a0 + lane : a0;
-                        const int bv = inblossom_[v];
-                        const double dv = dualvar_[v];
-                        const int de = adj_[a], w = adjv_[a];
-                        const double wt = adjw_[a];
-                        const int be_bv = bestedge_[bv];                     // lane 0's competitor for SQ_LP(bestedge)[bv]
-                        const int bw = inblossom_[w];
-                        const double dw = dualvar_[w];
-                        const int lw = label_[w];
-                        const bool was_allowed = allow_[de >> 1] != 0;
-                        const int be_w = bestedge_[w];
-                        const int lbw = label_[bw];
-                        const double s_bew = bslack_[w];                      // slack<FAST>(bestedge[w]) (unused when there is none)
-                        const double s_bebv = bslack_[bv];
-                        const double ks = dv + dw - 2 * wt;                  // slack<FAST>(de): SQ_LP(dualvar)[v] + SQ_LP(dualvar)[w] - 2 weight
-                        const bool cons = live && w != v && bw != bv;       // :  `if w == v: continue`, same blossom: continue
-                        const bool becomes = cons && !was_allowed && ks <= 0;
-                        const bool allowed = was_allowed || becomes;
-                        int cat = 0;                                         // 0 none, 1 event, 2 SQ_LP(label)[w] := T, 3 SQ_LP(bestedge)[w], 4 SQ_LP(bestedge)[bv]
-                        if (cons) {
-                            if (allowed) cat = (lbw == 0 || lbw == 1) ? 1 : (lw == 0 ? 2 : 0);
-                            else cat = lbw == 1 ? 4 : (lw == 0 ? 3 : 0);
+                    if (!pf_ok) {
+                        const int idx = qn_r - 1 - lane;
+                        const bool okc = lane < SEGMAX && idx >= 0;
+                        pf_v = okc ? queue_[idx] : 0;
+                        pf_a0 = adj_off_[pf_v];
+                        pf_len = okc ? adj_off_[pf_v + 1] - pf_a0 : -1;
+                    }
+                    // ---- the segments of this pass (wave-uniform): L[0] = the vertex in progress or the top of the queue
+                    const bool hascur = cv >= 0;
+                    int L_v[SEGMAX], L_a0[SEGMAX], L_len[SEGMAX], off[SEGMAX];
+                    {
+                        int c_v[SEGMAX], c_a0[SEGMAX], c_len[SEGMAX];
+                        for (int k = 0; k < SEGMAX; k++) { c_v[k] = coop.readlane(pf_v, k); c_a0[k] = coop.readlane(pf_a0, k); c_len[k] = coop.readlane(pf_len, k); }
+                        L_v[0] = hascur ? cv : c_v[0]; L_a0[0] = hascur ? ca0 : c_a0[0]; L_len[0] = hascur ? caend - ca0 : c_len[0];
+                        for (int k = 1; k < SEGMAX; k++) {
+                            L_v[k] = hascur ? c_v[k - 1] : c_v[k]; L_a0[k] = hascur ? c_a0[k - 1] : c_a0[k]; L_len[k] = hascur ? c_len[k - 1] : c_len[k];
                         }
-#ifdef SQ_MWM_PROF2
-                        asm volatile("" :: "v"(cat));
-                        const long long _q1 = clock64();
-                        p2_cls += _q1 - _q0;
+                    }
+                    const bool partial = L_len[0] > nl;                 // a list longer than the wave goes alone, a chunk per pass
+                    int total = partial ? nl : L_len[0], nseg = 1;
+                    off[0] = 0;
+                    {
+                        bool open = !partial;
+                        for (int k = 1; k < SEGMAX; k++) {
+                            off[k] = total;
+                            if (open && L_len[k] >= 0 && total + L_len[k] <= nl) { total += L_len[k]; nseg++; }
+                            else { open = false; off[k] = nl; }
+                        }
+                        // (off[k] of a segment that is not taken: past every lane)
+                    }
+                    const int npop = nseg - (hascur ? 1 : 0);
+                    const int qn_after = qn_r - npop;
+                    // the entries below the ones this pass pops, for the next pass
+                    int nx_v, nx_a0, nx_len;
+                    {
+                        const int idx = qn_after - 1 - lane;
+                        const bool okc = lane < SEGMAX && idx >= 0;
+                        nx_v = okc ? queue_[idx] : 0;
+                        nx_a0 = adj_off_[nx_v];
+                        nx_len = okc ? adj_off_[nx_v + 1] - nx_a0 : -1;
+                    }
+                    npass++;
+#ifdef SQ_MWM_PROF
+                    if (lane == 0) { pc[1] += npop; pc[0] += total; pc[5]++; }
 #endif
-                        const int f = coop.first_true(cat == 1, nl);        // first state-changing neighbour of the chunk
-                        if (lane < f && live) {
-                            if (becomes) allow_[de >> 1] = 1;
+                    // ---- this lane's vertex and neighbour slot
+                    const bool live = lane < total;
+                    int seg = 0, v = L_v[0], abase = L_a0[0], aend_l = L_a0[0] + L_len[0];
+                    for (int k = 1; k < SEGMAX; k++)
+                        if (live && lane >= off[k]) { seg = k; v = L_v[k]; abase = L_a0[k] - off[k]; aend_l = L_a0[k] + L_len[k]; }
+                    const int a = live ? abase + lane : L_a0[0];
+                    // Branch-free classification: the loads of one dependency level are issued together
+                    // (speculatively for lanes past the end, on a clamped slot), three LDS round trips in all.
+                    const int bv = inblossom_[v];
+                    const double dv = dualvar_[v];
+                    const int de = adj_[a], w = adjv_[a];
+                    const double wt = adjw_[a];
+                    const int be_bv = bestedge_[bv];                     // the competitor for SQ_LP(bestedge)[bv]
+                    const int bw = inblossom_[w];
+                    const double dw = dualvar_[w];
+                    const int lw = label_[w];
+                    const bool was_allowed = allow_[de >> 1] != 0;
+                    const int be_w = bestedge_[w];
+                    const int lbw = label_[bw];
+                    const double s_bew = bslack_[w];                      // slack<FAST>(bestedge[w]) (+inf when there is none)
+                    const double s_bebv = bslack_[bv];
+                    const double ks = dv + dw - 2 * wt;                  // slack<FAST>(de): SQ_LP(dualvar)[v] + SQ_LP(dualvar)[w] - 2 weight
+                    const bool cons = live && w != v && bw != bv;       // :  `if w == v: continue`, same blossom: continue
+                    const bool becomes = cons && !was_allowed && ks <= 0;
+                    const bool allowed = was_allowed || becomes;
+                    int cat = 0;                                         // 0 none, 1 event, 2 SQ_LP(label)[w] := T, 3 SQ_LP(bestedge)[w], 4 SQ_LP(bestedge)[bv]
+                    if (cons) {
+                        if (allowed) cat = (lbw == 0 || lbw == 1) ? 1 : (lw == 0 ? 2 : 0);
+                        else cat = lbw == 1 ? 4 : (lw == 0 ? 3 : 0);
+                    }
+#ifdef SQ_MWM_PROF2
+                    asm volatile("" :: "v"(cat));
+                    const long long _q1 = clock64();
+                    p2_cls += _q1 - _q0;
+#endif
+                    const int f = coop.first_true(cat == 1, nl);        // first state-changing neighbour of the pass
+                    const bool act = lane < f && live;
+                    if (act && becomes) allow_[de >> 1] = 1;
+                    if (nseg == 1) {
+                        if (act) {
                             if (cat == 2) { label_[w] = 2; labeledge_[w] = de; }
                             else if (cat == 3) { if (be_w == -1 || ks < s_bew) { bestedge_[w] = de; bslack_[w] = ks; } }
                         }
-                        {
-                            // competitors for SQ_LP(bestedge)[bv]: sequentially "first strictly smaller slack wins", i.e. the
-                            // lexicographic (slack, position) minimum among the neighbours that beat the CURRENT best.
-                            // SQ_LP(bestedge)[bv] only improves during a stage, so after the first passes usually nobody
-                            // does and the pass ends here; one competitor writes directly; several are reduced.
-                            const bool comp = lane < f && cat == 4 && (be_bv == -1 || ks < s_bebv);
-                            int cfirst;
-                            const int ccount = coop.count_true(comp, cfirst);
+                        // competitors for SQ_LP(bestedge)[bv]: sequentially "first strictly smaller slack wins", i.e. the
+                        // lexicographic (slack, position) minimum among the neighbours that beat the CURRENT best.
+                        // SQ_LP(bestedge)[bv] only improves during a stage, so after the first passes usually nobody
+                        // does and the pass ends here; one competitor writes directly; several are reduced.
+                        const bool comp = act && cat == 4 && (be_bv == -1 || ks < s_bebv);
+                        int cfirst;
+                        const int ccount = coop.count_true(comp, cfirst);
 #ifdef SQ_MWM_PROF2
-                            p2_c1 += ccount == 1; p2_cn += ccount > 1;
+                        p2_c1 += ccount == 1; p2_cn += ccount > 1;
 #endif
-                            if (ccount == 1) {
-                                if (lane == cfirst) { bestedge_[bv] = de; bslack_[bv] = ks; }
-                            } else if (ccount > 1) {
-                                // positions grow with the lane: the winner is the lowest lane that holds the minimum
-                                double mv = comp ? ks : 1e300;
-                                coop.min_plain(mv, aend - a0);            // (lanes past the list hold 1e300)
-                                if (lane == coop.first_true(comp && ks == mv, nl)) { bestedge_[bv] = de; bslack_[bv] = ks; }
+                        if (ccount == 1) {
+                            if (lane == cfirst) { bestedge_[bv] = de; bslack_[bv] = ks; }
+                        } else if (ccount > 1) {
+                            // positions grow with the lane: the winner is the lowest lane that holds the minimum
+                            double mv = comp ? ks : 1e300;
+                            coop.min_plain(mv, total);                  // (lanes past the list hold 1e300)
+                            if (lane == coop.first_true(comp && ks == mv, nl)) { bestedge_[bv] = de; bslack_[bv] = ks; }
+                        }
+                    } else if constexpr (SEGMAX > 1) {
+                        const bool c2 = act && cat == 2;
+                        bool c3 = act && cat == 3 && ks < s_bew;
+                        const bool c4 = act && cat == 4 && ks < s_bebv;
+                        if (coop.any(c2)) {
+                            // the first lane in scan order labels w: a marker with the segment first (lowest segment lands
+                            // last), which silences the best-edge competitors of LATER segments on the same w, then T
+                            // (SQ_ORDERED: a compiler barrier -- without it the stores of the segments, whose lanes are disjoint,
+                            // may be merged into one instruction, and the order among its lanes is the hardware's)
+                            for (int s = SEGMAX - 1; s >= 0; s--) {
+                                if (c2 && seg == s) { label_[w] = (int8_t)(8 + s); labeledge_[w] = de; }
+                                SQ_ORDERED();
+                            }
+                            if (coop.any(c3 && lbw == 2)) {
+                                const int lnow = c3 ? label_[w] : 0;
+                                if (lnow >= 8 && lnow - 8 < seg) c3 = false;
+                            }
+                            if (c2) label_[w] = 2;
+                        }
+                        const bool comp = c3 || c4;
+#ifdef SQ_MWM_PROF2
+                        p2_cn += coop.any(comp);
+#endif
+                        if (coop.any(comp)) {
+                            double *const slot = &bslack_[c4 ? bv : w];
+                            if (comp) coop.min_pos_f64(slot, ks);       // slacks of edges that are not allowed: > 0
+                            const double now = comp ? *slot : 0.0;              // (behind the atomic: the minimum over all competitors)
+                            const bool tie = comp && now == ks;
+                            for (int s = SEGMAX - 1; s >= 0; s--) {
+                                if (s >= nseg) continue;
+                                const bool ts = tie && seg == s;
+                                const int l4 = coop.first_true(ts && c4, nl);      // one blossom per segment: its lowest lane
+                                if (ts && (c3 || lane == l4)) bestedge_[c4 ? bv : w] = de;
+                                SQ_ORDERED();
                             }
                         }
-#ifdef SQ_MWM_PROF2
-                        _q0 = clock64();
-                        p2_app += _q0 - _q1;
-#endif
-                        if (f >= nl) { a0 += nl; continue; }
-                        had_event = true;
-                        nevent++;
-                        if (lane == 0) qn = qn_r;
-                        sync();
-#ifdef SQ_MWM_PROF
-                        long long _te = 0;
-                        if (lane == 0) { pc[4]++; _te = wall_clock64(); }
-#endif
-                        if (lane == 0) {                        // the sequential body for neighbour a0 + f
-                            const int de1 = SQ_LQ(adj)[a0 + f];
-                            const int w1 = head<FAST>(de1);
-                            const int bv1 = SQ_LP(inblossom)[v], bw1 = SQ_LP(inblossom)[w1];
-                            if (w1 != v && bv1 != bw1) {
-                                double kslack = 0;
-                                if (!SQ_LP(allow)[de1 >> 1]) {
-                                    kslack = slack<FAST>(de1);
-                                    if (kslack <= 0) SQ_LP(allow)[de1 >> 1] = 1;
-                                }
-                                if (allow[de1 >> 1]) {
-                                    if (label[bw1] == 0) assignLabel<FAST>(w1, 2, de1);
-                                    else if (label[bw1] == 1) {
-                                        const int bs = scanBlossom<FAST>(v, w1);
-                                        if (bs != -1) addBlossom<FAST>(bs, de1);
-                                        else { augmentMatching<FAST>(de1); f_augmented = 1; }
-                                    } else if (label[w1] == 0) {
-                                        SQ_LP(label)[w1] = 2; SQ_LP(labeledge)[w1] = de1;
-                                    }
-                                } else if (label[bw1] == 1) {
-                                    if (bestedge[bv1] == -1 || kslack < slack<FAST>(bestedge[bv1])) { SQ_LP(bestedge)[bv1] = de1; SQ_LP(bslack)[bv1] = kslack; }
-                                } else if (label[w1] == 0) {
-                                    if (bestedge[w1] == -1 || kslack < slack<FAST>(bestedge[w1])) { SQ_LP(bestedge)[w1] = de1; SQ_LP(bslack)[w1] = kslack; }
-                                }
-                            }
-                        }
-                        sync();
-#ifdef SQ_MWM_PROF
-                        if (lane == 0) pt[7] += wall_clock64() - _te;
-#endif
-                        qn_r = qn;
-                        stopq = f_augmented || error;
-#ifdef SQ_MWM_PROF2
-                        { const long long _n = clock64(); p2_evt += _n - _q0; _q0 = _n; }
-#endif
-                        if (stopq) break;
-                        a0 += f + 1;
                     }
-#ifndef SQ_MWM_NOPREFETCH
-                    if (pre_ok && !had_event) { v_pre = vn; a0_pre = a0n; aend_pre = aendn; }
+#ifdef SQ_MWM_PROF2
+                    _q0 = clock64();
+                    p2_app += _q0 - _q1;
 #endif
+                    if (f >= nl) {                                      // no event: everything taken is scanned
+                        qn_r = qn_after;
+                        cv = partial ? L_v[0] : -1; ca0 = L_a0[0] + nl; caend = L_a0[0] + L_len[0];
+                        if (ca0 >= caend) cv = -1;
+                        pf_v = nx_v; pf_a0 = nx_a0; pf_len = nx_len; pf_ok = true;
+                        continue;
+                    }
+                    // ---- the state-changing neighbour (lane f): the vertices of the segments before its own are done, its
+                    // own vertex is popped and goes on as the vertex in progress behind the event
+                    const int fseg = coop.readlane(seg, f), fa = coop.readlane(a, f), fv = coop.readlane(v, f), fend = coop.readlane(aend_l, f);
+                    qn_r -= fseg + 1 - (hascur ? 1 : 0);
+                    nevent++;
+                    if (lane == 0) qn = qn_r;
+                    sync();
+#ifdef SQ_MWM_PROF
+                    long long _te = 0;
+                    if (lane == 0) { pc[4]++; _te = wall_clock64(); }
+#endif
+                    if (lane == 0) {                            // the sequential body for that neighbour
+                        const int de1 = SQ_LQ(adj)[fa];
+                        const int w1 = head<FAST>(de1);
+                        const int bv1 = SQ_LP(inblossom)[fv], bw1 = SQ_LP(inblossom)[w1];
+                        if (w1 != fv && bv1 != bw1) {
+                            double kslack = 0;
+                            if (!SQ_LP(allow)[de1 >> 1]) {
+                                kslack = slack<FAST>(de1);
+                                if (kslack <= 0) SQ_LP(allow)[de1 >> 1] = 1;
+                            }
+                            if (allow[de1 >> 1]) {
+                                if (label[bw1] == 0) assignLabel<FAST>(w1, 2, de1);
+                                else if (label[bw1] == 1) {
+                                    const int bs = scanBlossom<FAST>(fv, w1);
+                                    if (bs != -1) addBlossom<FAST>(bs, de1);
+                                    else { augmentMatching<FAST>(de1); f_augmented = 1; }
+                                } else if (label[w1] == 0) {
+                                    SQ_LP(label)[w1] = 2; SQ_LP(labeledge)[w1] = de1;
+                                }
+                            } else if (label[bw1] == 1) {
+                                if (bestedge[bv1] == -1 || kslack < slack<FAST>(bestedge[bv1])) { SQ_LP(bestedge)[bv1] = de1; SQ_LP(bslack)[bv1] = kslack; }
+                            } else if (label[w1] == 0) {
+                                if (bestedge[w1] == -1 || kslack < slack<FAST>(bestedge[w1])) { SQ_LP(bestedge)[w1] = de1; SQ_LP(bslack)[w1] = kslack; }
+                            }
+                        }
+                    }
+                    sync();
+#ifdef SQ_MWM_PROF
+                    if (lane == 0) pt[7] += wall_clock64() - _te;
+#endif
+                    qn_r = qn;
+                    stopq = f_augmented || error;
+#ifdef SQ_MWM_PROF2
+                    { const long long _n = clock64(); p2_evt += _n - _q0; _q0 = _n; }
+#endif
+                    cv = fa + 1 < fend ? fv : -1; ca0 = fa + 1; caend = fend;
+                    pf_ok = false;
                 }
                 if (lane == 0) qn = qn_r;
                 sync();
