@@ -45,7 +45,10 @@ struct SqCoopSingle {
 // ... or the 64 lanes of a wave.  first_true: lowest lane whose predicate holds (nl if none);
 // min_first: lexicographic minimum of (value, index) over the lanes with index < nl, broadcast to all.
 struct SqCoopWave {
-    static constexpr int kSegMax = 4;                           // vertices per scan pass (their neighbour lists share the 64 lanes)
+#ifndef SQ_MWM_SEGMAX
+#define SQ_MWM_SEGMAX 4
+#endif
+    static constexpr int kSegMax = SQ_MWM_SEGMAX;               // vertices per scan pass (their neighbour lists share the 64 lanes)
     __device__ int readlane(int x, int l) const { return __builtin_amdgcn_readlane(x, l); }
     __device__ bool any(bool p) const { return __ballot(p) != 0; }
     // *p = min(*p, v) for POSITIVE doubles (and +inf): their bit patterns order like unsigned integers
@@ -256,6 +259,11 @@ struct SqBlossom {
 #endif
 #define SQ_BINF __builtin_huge_val()
 #define SQ_ORDERED() asm volatile("" ::: "memory")
+#ifdef __HIPCC__
+#define SQ_UNROLL3 _Pragma("unroll 3")
+#else
+#define SQ_UNROLL3
+#endif
 #define SQ_LP(p) (FAST ? (decltype(p))(SQ_FAST0 + ((char *)(p) - origin)) : (p))            /* hot arrays */
 #define SQ_LQ(p) (FAST == 1 ? (decltype(p))(SQ_FAST0 + ((char *)(p) - origin)) : (p))       /* cold / edge arrays, E */
     template <int FAST = 0> SQ_HD int tail(int de) const { return (de & 1) ? SQ_LQ(E)[de >> 1].w : SQ_LQ(E)[de >> 1].v; }
@@ -755,33 +763,29 @@ struct SqBlossom {
                 // operations in order, the lowest segment's store lands last).  With the state in global memory
                 // (FAST 0) a pass stays one vertex.
                 constexpr int SEGMAX = FAST ? Coop::kSegMax : 1;
-                int cv = -1, ca0 = 0, caend = 0;                 // a popped vertex with neighbours left (after an event or a full chunk)
-                // lanes 0..SEGMAX-1: the top entries of the queue (vertex, adjacency start, length; -1: none), fetched
-                // while the previous pass's own loads were in flight (valid unless that pass had an event)
+                // A popped vertex with neighbours left (behind an event, or a list longer than the wave) is the first segment
+                // of the next pass.  pf_*: what the next pass scans, one entry per lane 0..SEGMAX-1 (vertex, adjacency start,
+                // length; -1: none): lane 0 that vertex in progress if there is one, then the top entries of the queue --
+                // fetched while the previous pass's own loads were in flight (valid unless that pass had an event).
+                bool hascur = false;
+                int cv = 0, ca0 = 0, caend = 0;                  // (the vertex in progress, for the reload behind an event)
                 int pf_v = 0, pf_a0 = 0, pf_len = -1;
                 bool pf_ok = false;
-                while (!stopq && (cv >= 0 || qn_r > 0)) {
+                while (!stopq && (hascur || qn_r > 0)) {
 #ifdef SQ_MWM_PROF2
                     long long _q0 = clock64();
 #endif
                     if (!pf_ok) {
-                        const int idx = qn_r - 1 - lane;
-                        const bool okc = lane < SEGMAX && idx >= 0;
+                        const int idx = qn_r - 1 - lane + (hascur ? 1 : 0);
+                        const bool okc = lane < SEGMAX && idx >= 0 && idx < qn_r;
                         pf_v = okc ? queue_[idx] : 0;
                         pf_a0 = adj_off_[pf_v];
                         pf_len = okc ? adj_off_[pf_v + 1] - pf_a0 : -1;
+                        if (hascur && lane == 0) { pf_v = cv; pf_a0 = ca0; pf_len = caend - ca0; }
                     }
-                    // ---- the segments of this pass (wave-uniform): L[0] = the vertex in progress or the top of the queue
-                    const bool hascur = cv >= 0;
+                    // ---- the segments of this pass (wave-uniform)
                     int L_v[SEGMAX], L_a0[SEGMAX], L_len[SEGMAX], off[SEGMAX];
-                    {
-                        int c_v[SEGMAX], c_a0[SEGMAX], c_len[SEGMAX];
-                        for (int k = 0; k < SEGMAX; k++) { c_v[k] = coop.readlane(pf_v, k); c_a0[k] = coop.readlane(pf_a0, k); c_len[k] = coop.readlane(pf_len, k); }
-                        L_v[0] = hascur ? cv : c_v[0]; L_a0[0] = hascur ? ca0 : c_a0[0]; L_len[0] = hascur ? caend - ca0 : c_len[0];
-                        for (int k = 1; k < SEGMAX; k++) {
-                            L_v[k] = hascur ? c_v[k - 1] : c_v[k]; L_a0[k] = hascur ? c_a0[k - 1] : c_a0[k]; L_len[k] = hascur ? c_len[k - 1] : c_len[k];
-                        }
-                    }
+                    for (int k = 0; k < SEGMAX; k++) { L_v[k] = coop.readlane(pf_v, k); L_a0[k] = coop.readlane(pf_a0, k); L_len[k] = coop.readlane(pf_len, k); }
                     const bool partial = L_len[0] > nl;                 // a list longer than the wave goes alone, a chunk per pass
                     int total = partial ? nl : L_len[0], nseg = 1;
                     off[0] = 0;
@@ -796,24 +800,21 @@ struct SqBlossom {
                     }
                     const int npop = nseg - (hascur ? 1 : 0);
                     const int qn_after = qn_r - npop;
-                    // the entries below the ones this pass pops, for the next pass
-                    int nx_v, nx_a0, nx_len;
-                    {
-                        const int idx = qn_after - 1 - lane;
-                        const bool okc = lane < SEGMAX && idx >= 0;
-                        nx_v = okc ? queue_[idx] : 0;
-                        nx_a0 = adj_off_[nx_v];
-                        nx_len = okc ? adj_off_[nx_v + 1] - nx_a0 : -1;
-                    }
+                    // the entries below the ones this pass pops, for the next pass (behind the rest of a long list): branch-free
+                    // (clamped slots), and the two dependent reads are issued WITH the first two levels of the classification's
+                    // own loads below
+                    const int nx_idx = qn_after - 1 - lane + (partial ? 1 : 0);
+                    const bool nx_ok = lane < SEGMAX && nx_idx >= 0 && nx_idx < qn_after;
+                    const int nx_q = queue_[nx_idx > 0 ? nx_idx : 0];
                     npass++;
 #ifdef SQ_MWM_PROF
                     if (lane == 0) { pc[1] += npop; pc[0] += total; pc[5]++; }
 #endif
                     // ---- this lane's vertex and neighbour slot
                     const bool live = lane < total;
-                    int seg = 0, v = L_v[0], abase = L_a0[0], aend_l = L_a0[0] + L_len[0];
+                    int seg = 0, v = L_v[0], abase = L_a0[0];
                     for (int k = 1; k < SEGMAX; k++)
-                        if (live && lane >= off[k]) { seg = k; v = L_v[k]; abase = L_a0[k] - off[k]; aend_l = L_a0[k] + L_len[k]; }
+                        if (live && lane >= off[k]) { seg = k; v = L_v[k]; abase = L_a0[k] - off[k]; }
                     const int a = live ? abase + lane : L_a0[0];
                     // Branch-free classification: the loads of one dependency level are issued together
                     // (speculatively for lanes past the end, on a clamped slot), three LDS round trips in all.
@@ -821,6 +822,8 @@ struct SqBlossom {
                     const double dv = dualvar_[v];
                     const int de = adj_[a], w = adjv_[a];
                     const double wt = adjw_[a];
+                    const int nx_v = nx_q < 0 ? 0 : (nx_q >= n ? n - 1 : nx_q);   // (a slot that was never written: any valid vertex)
+                    const int nx_a0 = adj_off_[nx_v], nx_a1 = adj_off_[nx_v + 1];
                     const int be_bv = bestedge_[bv];                     // the competitor for SQ_LP(bestedge)[bv]
                     const int bw = inblossom_[w];
                     const double dw = dualvar_[w];
@@ -913,14 +916,16 @@ struct SqBlossom {
 #endif
                     if (f >= nl) {                                      // no event: everything taken is scanned
                         qn_r = qn_after;
-                        cv = partial ? L_v[0] : -1; ca0 = L_a0[0] + nl; caend = L_a0[0] + L_len[0];
-                        if (ca0 >= caend) cv = -1;
-                        pf_v = nx_v; pf_a0 = nx_a0; pf_len = nx_len; pf_ok = true;
+                        hascur = partial;
+                        pf_v = nx_v; pf_a0 = nx_a0; pf_len = nx_ok ? nx_a1 - nx_a0 : -1; pf_ok = true;
+                        if (partial && lane == 0) { pf_v = L_v[0]; pf_a0 = L_a0[0] + nl; pf_len = L_len[0] - nl; }
                         continue;
                     }
                     // ---- the state-changing neighbour (lane f): the vertices of the segments before its own are done, its
                     // own vertex is popped and goes on as the vertex in progress behind the event
-                    const int fseg = coop.readlane(seg, f), fa = coop.readlane(a, f), fv = coop.readlane(v, f), fend = coop.readlane(aend_l, f);
+                    const int fseg = coop.readlane(seg, f), fa = coop.readlane(a, f), fv = coop.readlane(v, f);
+                    int fend = L_a0[0] + L_len[0];
+                    for (int k = 1; k < SEGMAX; k++) if (fseg == k) fend = L_a0[k] + L_len[k];
                     qn_r -= fseg + 1 - (hascur ? 1 : 0);
                     nevent++;
                     if (lane == 0) qn = qn_r;
@@ -964,7 +969,7 @@ struct SqBlossom {
 #ifdef SQ_MWM_PROF2
                     { const long long _n = clock64(); p2_evt += _n - _q0; _q0 = _n; }
 #endif
-                    cv = fa + 1 < fend ? fv : -1; ca0 = fa + 1; caend = fend;
+                    hascur = fa + 1 < fend; cv = fv; ca0 = fa + 1; caend = fend;
                     pf_ok = false;
                 }
                 if (lane == 0) qn = qn_r;
@@ -977,6 +982,7 @@ struct SqBlossom {
                 {
                     double m1 = 1e300; double m2 = 1e300, m3 = 1e300, m4 = 1e300;
                     int i2 = -1, i3 = -1, i4 = -1;
+                    SQ_UNROLL3
                     for (int v = lane; v < n; v += nl) {
                         if (dualvar_[v] < m1) m1 = dualvar_[v];
                         if (label_[inblossom_[v]] == 0 && bestedge_[v] != -1) {
@@ -984,6 +990,7 @@ struct SqBlossom {
                             if (i2 == -1 || d < m2) { m2 = d; i2 = v; }
                         }
                     }
+                    SQ_UNROLL3
                     for (int k = lane; k < n + nlive; k += nl) {   // `for b in blossomparent`: vertices, then blossoms
                         const int b = k < n ? k : live_[k - n];
                         if (parent_[b] == -1 && label_[b] == 1 && bestedge_[b] != -1) {
@@ -1010,6 +1017,7 @@ struct SqBlossom {
                 sync();
                 {
                     const double delta = red_v0;
+                    SQ_UNROLL3
                     for (int v = lane; v < n; v += nl) {
                         const int lb = label_[inblossom_[v]];
                         if (lb == 1) dualvar_[v] -= delta; else if (lb == 2) dualvar_[v] += delta;
