@@ -934,7 +934,13 @@ struct SqBlossom {
                     long long _te = 0;
                     if (lane == 0) { pc[4]++; _te = wall_clock64(); }
 #endif
-                    if (lane == 0) {                            // the sequential body for that neighbour
+                    // the most frequent event by far -- an allowed edge to an unlabelled blossom: T for it, S for the mate of its
+                    // base -- is run by lane f itself, which holds the edge, w and the allow decision in registers (what the
+                    // lanes before it applied cannot touch them: their neighbours are labelled or stay unlabelled)
+                    const bool tfast = coop.readlane(lbw == 0 ? 1 : 0, f) != 0;
+                    if (tfast) {
+                        if (lane == f) { if (becomes) allow_[de >> 1] = 1; assignLabel<FAST>(w, 2, de); }
+                    } else if (lane == 0) {                     // the sequential body for that neighbour
                         const int de1 = SQ_LQ(adj)[fa];
                         const int w1 = head<FAST>(de1);
                         const int bv1 = SQ_LP(inblossom)[fv], bw1 = SQ_LP(inblossom)[w1];

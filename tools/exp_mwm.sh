@@ -1,4 +1,5 @@
 #!/bin/bash
-bld() { SQ_DEFS="$1" python -c "from squarna_amd import build; build.build_library(force=True)" > /dev/null 2>&1; }
-bld "-DSQ_MWM_PROF2"; echo "== PROF2"; timeout 300 python tools/concurrent_probe.py 1 1 2>&1 | grep "mwm2 n=148" | sort | uniq -c | head -2
-bld "-DSQ_MWM_PROF"; echo "== PROF"; timeout 300 python tools/concurrent_probe.py 1 1 2>&1 | grep "mwm n=148" | sort | uniq -c | head -2
+t() { timeout 300 python tools/big_batch_probe.py $1 2>&1 | grep -E "^R=|^\{.bits" | tail -2 | cut -c1-200; }
+t 1; t 24
+run() { echo "## $*"; env "$@" 2>&1 | grep -E "mismatch|MISMATCH|rror|mwm verify" | tail -4 | cut -c1-400; }
+run python3 tools/fuzz_parity.py 4000 nobpp 403
