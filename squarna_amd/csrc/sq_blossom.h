@@ -674,10 +674,6 @@ struct SqBlossom {
         uint8_t *const allow_ = SQ_LP(allow);
         double *const dualvar_ = SQ_LP(dualvar), *const bdual_ = SQ_LQ(bdual), *const bslack_ = SQ_LP(bslack);
         const int *const parent_ = SQ_LQ(parent), *const live_ = SQ_LQ(live);
-        auto slack_ = [&](int de) -> double {
-            const SqMatchEdge ed = E_[de >> 1];
-            return (de & 1) ? dualvar_[ed.w] + dualvar_[ed.v] - 2 * ed.weight : dualvar_[ed.v] + dualvar_[ed.w] - 2 * ed.weight;
-        };
 #ifdef SQ_MWM_PROF
         long long _tp = wall_clock64();
         if (lane == 0) for (int k = 0; k < 8; k++) { pt[k] = 0; pc[k] = 0; }
@@ -1012,7 +1008,8 @@ struct SqBlossom {
                     const int NONE = 0x7fffffff;
                     coop.min_plain(m1);
                     if (i2 == -1) i2 = NONE; if (i3 == -1) i3 = NONE; if (i4 == -1) i4 = NONE;
-                    coop.min_first(m2, i2, NONE); coop.min_first(m3, i3, NONE); coop.min_first(m4, i4, NONE);
+                    coop.min_first(m2, i2, NONE); coop.min_first(m3, i3, NONE);
+                    if (nlive > 0) coop.min_first(m4, i4, NONE);        // (no blossoms: i4 is NONE in every lane)
                     int deltatype = 1, deltaedge = -1, deltablossom = -1;
                     double delta = m1;
                     if (i2 != NONE && m2 < delta) { delta = m2; deltatype = 2; deltaedge = bestedge_[i2]; }
@@ -1035,10 +1032,23 @@ struct SqBlossom {
                 }
                 sync();
                 // the duals moved: refresh the cached slacks of the best edges (vertices, then live blossoms)
-                for (int k = lane; k < n + nlive; k += nl) {
-                    const int x = k < n ? k : live_[k - n];
-                    const int be = bestedge_[x];
-                    if (be != -1) bslack_[x] = slack_(be);
+                // (three entries per lane at a time, every level of the dependent reads -- entry -> best edge -> its ends -> their
+                // duals -- issued for all three together on clamped slots: with the edge list in global memory a level is
+                // a trip to L2)
+                for (int k0 = 0; k0 < n + nlive; k0 += 3 * nl) {
+                    int xs[3], bes[3];
+                    for (int j = 0; j < 3; j++) {
+                        const int k = k0 + j * nl + lane;
+                        const int kb = k - n < 0 ? 0 : (k - n < nlive ? k - n : 0);
+                        const int lb = live_[kb];
+                        xs[j] = k < n ? k : (k < n + nlive ? lb : -1);
+                    }
+                    for (int j = 0; j < 3; j++) { const int be = bestedge_[xs[j] < 0 ? 0 : xs[j]]; bes[j] = xs[j] < 0 ? -1 : be; }
+                    SqMatchEdge eds[3];
+                    for (int j = 0; j < 3; j++) eds[j] = E_[bes[j] < 0 ? 0 : bes[j] >> 1];
+                    double sl[3];
+                    for (int j = 0; j < 3; j++) sl[j] = dualvar_[eds[j].v] + dualvar_[eds[j].w] - 2 * eds[j].weight;   // (a + b == b + a: either direction)
+                    for (int j = 0; j < 3; j++) if (bes[j] != -1) bslack_[xs[j]] = sl[j];
                 }
                 sync();
 #ifdef SQ_MWM_PROF
