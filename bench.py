@@ -706,12 +706,15 @@ def main():
                    avg_launch_ms=e_ms,
                    critical_graph=dict(vertices=mwm["n"], edges=mwm["m"], scan_passes=passes, events=mwm["max_events"]),
                    cycles_per_scan_pass=round(e_ms * 1e-3 * CLOCK_GHZ * 1e9 / max(passes, 1)),
-                   cycles_how="whole kernel time (its slowest wave = the critical graph) x %.1f GHz / that graph's scan passes; "
-                              "includes its lane-0 events, dual updates and stage set-up (~25 %% of the time)" % CLOCK_GHZ,
-                   floor_cycles_per_scan_pass=1100,
-                   floor_how="5 dependent LDS round trips per pass (queue -> adjacency bounds -> neighbour -> its blossom -> "
-                             "that blossom's label; ~130 cycles each for a lone wave) + ~100 instructions at the ~4.7 "
-                             "cycles / instruction one wave alone issues at (PMC: SQ_ACTIVE_INST_ANY / instructions)")
+                   cycles_how="whole kernel time (its slowest wave = the critical graph) x %.1f GHz / that graph's scan passes "
+                              "(a pass scans up to four queue vertices: their neighbour lists share the 64 lanes); includes its "
+                              "lane-0 events, dual updates and stage set-up (~45 %% of the time)" % CLOCK_GHZ,
+                   floor_cycles_per_scan_pass=1500,
+                   floor_how="4 dependent LDS round trips per pass (the lists' slots -> neighbour -> its blossom's label -> "
+                             "the best-edge minimum read back; ~130 cycles each for a lone wave; the queue entries of the next "
+                             "pass are fetched alongside) + ~200 instructions (segment set-up, classification, the ordered "
+                             "best-edge stores) at the ~4.7 cycles / instruction one wave alone issues at (PMC: "
+                             "SQ_ACTIVE_INST_ANY / instructions); the pass count itself is bounded below by events + substages")
         if km:
             tb = km.get("fetch_bytes_per_launch", 0) + km.get("write_bytes_per_launch", 0)
             obj.update(hbm=dict(traffic=tb, achieved_GBs=round(tb / (e_ms * 1e-3) / 1e9, 3),
