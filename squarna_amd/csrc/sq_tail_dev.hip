@@ -202,17 +202,21 @@ __device__ __forceinline__ void sq_prf_wave(const int16_t *refp, int known_n, co
     if (inexact) *fallback = 1;
 }
 
-#define SQ_TAIL_THREADS 256
+#define SQ_TAIL_THREADS 256            // a block's threads on a crowded chip; a batch alone with several jobs per sequence: SQ_TAIL_THREADS_WIDE
+#define SQ_TAIL_THREADS_WIDE 1024
 #define SQ_TAIL_BITWORDS 1024          // LDS bitmap words per wave: sequences up to 32768 nt
 
-extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kernel(SqDevCtx c, SqTailIO t, int bitwords)
+extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS_WIDE) void sq_tail_rank_kernel(SqDevCtx c, SqTailIO t, int bitwords, int keycap)
 {
     // (one bitmap of the sequence's positions per wave, in the block's DYNAMIC LDS sized for the batch's longest sequence:
     // a static array for 32,768 nt cost every block 16 KB -- 20 bytes do for 150 nt)
-    extern __shared__ uint32_t s_bits_dyn[];                            // [SQ_TAIL_THREADS / 64][bitwords]
-    __shared__ uint32_t s_wsum[SQ_TAIL_THREADS / 64];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bits_dyn[];   // [waves of the block][bitwords], then keycap x (3 rank keys, priority)
+    __shared__ uint32_t s_wsum[SQ_TAIL_THREADS_WIDE / 64];
     __shared__ uint32_t s_run;
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nthr = blockDim.x, nwv = nthr >> 6;                  // (the entry-per-wave passes b and e are as fast as the block has waves)
+    double *const s_key = reinterpret_cast<double *>(s_bits_dyn + ((nwv * (uint32_t)bitwords + 1u) & ~1u));   // [keycap][3], in rankby order
+    uint8_t *const s_pri = reinterpret_cast<uint8_t *>(s_key + 3 * (size_t)keycap);                          // [keycap]
     SqTailSeq &S = t.seqs[s];
     const uint32_t first = S.first, M = S.count;
     const int j0 = t.seq_job0[s], j1 = t.seq_job0[s + 1];
@@ -222,11 +226,17 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kerne
         if (tid == 0) { *t.fallback = 1; S.D = 0; S.nshow = 0; S.nprf = 0; S.rec_bytes = 0; S.txt_bytes = 0; S.evals = 0; }
     };
     if (M > SQ_TAIL_MAXM || n > 32 * bitwords) { bail(); return; }
+#ifdef SQ_TAIL_PROF
+    long long _tp[8];
+#endif
+#ifdef SQ_TAIL_PROF
+    if (tid == 0) _tp[0] = wall_clock64();
+#endif
     // ---- a. every job's entries into finstemsets order: (kind, pos) ascending ----
     for (int j = j0; j < j1; j++) {
         const uint32_t lo = t.job_start[j], m = t.job_start[j + 1] - lo;
         if (m < 2) continue;
-        for (uint32_t x = tid; x < m; x += SQ_TAIL_THREADS) {
+        for (uint32_t x = tid; x < m; x += nthr) {
             const uint32_t e = t.ord[lo + x];
             const unsigned long long kx = ((unsigned long long)t.fin[e].round_kind << 32) | (uint32_t)t.fin[e].pos;
             uint32_t r = 0;
@@ -238,12 +248,15 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kerne
             t.ord2[lo + r] = e;
         }
         __syncthreads();
-        for (uint32_t x = tid; x < m; x += SQ_TAIL_THREADS) t.ord[lo + x] = t.ord2[lo + x];
+        for (uint32_t x = tid; x < m; x += nthr) t.ord[lo + x] = t.ord2[lo + x];
         __syncthreads();
     }
     __syncthreads();
+#ifdef SQ_TAIL_PROF
+    if (tid == 0) _tp[1] = wall_clock64();
+#endif
     // ---- b. canonical stems (maximal stacks in ascending order of i) + hash, one wave per entry ----
-    for (uint32_t x = wave; x < M; x += SQ_TAIL_THREADS / 64) {
+    for (uint32_t x = wave; x < M; x += nwv) {
         const uint32_t e = t.ord[first + x];
         const SqPoolFin F = t.fin[e];
         const int T = F.nstems;
@@ -276,8 +289,11 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kerne
     }
     __threadfence_block();
     __syncthreads();
+#ifdef SQ_TAIL_PROF
+    if (tid == 0) _tp[2] = wall_clock64();
+#endif
     // ---- c. first occurrence of every base-pair set (:1203-1207) ----
-    for (uint32_t x = tid; x < M; x += SQ_TAIL_THREADS) {
+    for (uint32_t x = tid; x < M; x += nthr) {
         const unsigned long long hx = t.hash[first + x];
         const uint32_t cn = t.cs_n[first + x];
         const SqPoolStem *cx = sq_fin_canon(t, t.fin[t.ord[first + x]]);
@@ -293,10 +309,13 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kerne
     }
     __threadfence_block();
     __syncthreads();
+#ifdef SQ_TAIL_PROF
+    if (tid == 0) _tp[3] = wall_clock64();
+#endif
     // ---- d. producers of every distinct structure (:1207-1220) and the distinct ones in list order ----
     if (tid == 0) s_run = 0;
     __syncthreads();
-    for (uint32_t x0 = 0; x0 < M; x0 += SQ_TAIL_THREADS) {
+    for (uint32_t x0 = 0; x0 < M; x0 += nthr) {
         const uint32_t x = x0 + tid;
         bool dist = false;
         if (x < M) {
@@ -311,14 +330,17 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kerne
         for (int w = 0; w < wave; w++) before += s_wsum[w];
         if (dist) t.dlist[first + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = x;
         __syncthreads();
-        if (tid == 0) { uint32_t a = 0; for (int w = 0; w < SQ_TAIL_THREADS / 64; w++) a += s_wsum[w]; s_run += a; }
+        if (tid == 0) { uint32_t a = 0; for (uint32_t w = 0; w < nwv; w++) a += s_wsum[w]; s_run += a; }
         __syncthreads();
     }
     const uint32_t D = s_run;
     __threadfence_block();
     __syncthreads();
+#ifdef SQ_TAIL_PROF
+    if (tid == 0) _tp[4] = wall_clock64();
+#endif
     // ---- e. ScoreStruct of the distinct structures: the FIRST producer's stem list, in its own order (:1208) ----
-    for (uint32_t k = wave; k < D; k += SQ_TAIL_THREADS / 64) {
+    for (uint32_t k = wave; k < D; k += nwv) {
         const uint32_t x = t.dlist[first + k];
         const SqPoolFin F = t.fin[t.ord[first + x]];
         double sc[3];
@@ -327,8 +349,41 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kerne
     }
     __threadfence_block();
     __syncthreads();
+#ifdef SQ_TAIL_PROF
+    if (tid == 0) _tp[5] = wall_clock64();
+#endif
     // ---- f. RankStructs (:907-913): stable descending sort on the rankby keys, prioritised paramsets first ----
-    for (uint32_t k = tid; k < D; k += SQ_TAIL_THREADS) {
+    if (D <= (uint32_t)keycap) {
+        // the keys of the distinct structures side by side in LDS: the D x D comparisons then read broadcast LDS words
+        // instead of chasing dlist -> scores through global memory (82 -> 10 us for 185 structures)
+        for (uint32_t k = tid; k < D; k += nthr) {
+            const uint32_t x = t.dlist[first + k];
+            const double *sx = t.scores + 3 * (size_t)(first + x);
+            for (int q = 0; q < 3; q++) s_key[3 * k + q] = sx[t.rankby[q]];
+            s_pri[k] = (t.mask[first + x] & t.priority_mask) != 0ull ? 1 : 0;
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < D; k += nthr) {
+            const double b0 = s_key[3 * k], b1 = s_key[3 * k + 1], b2 = s_key[3 * k + 2];
+            const bool px = s_pri[k] != 0;
+            uint32_t r = 0;
+            for (uint32_t l = 0; l < D; l++) {
+                const double a0 = s_key[3 * l], a1 = s_key[3 * l + 1], a2 = s_key[3 * l + 2];
+                const bool py = s_pri[l] != 0;
+                bool before;
+                if (t.priority_mask && px != py) before = py;           // :912-913 (a stable partition)
+                else {
+                    int cmp = a0 > b0 ? 1 : (a0 < b0 ? -1 : 0);          // > 0: l sorts before k
+                    if (cmp == 0) cmp = a1 > b1 ? 1 : (a1 < b1 ? -1 : 0);
+                    if (cmp == 0) cmp = a2 > b2 ? 1 : (a2 < b2 ? -1 : 0);
+                    before = cmp > 0 || (cmp == 0 && l < k);
+                }
+                r += (before && l != k) ? 1u : 0u;
+            }
+            t.rlist[first + r] = t.dlist[first + k];
+        }
+    } else
+    for (uint32_t k = tid; k < D; k += nthr) {
         const uint32_t x = t.dlist[first + k];
         const double *sx = t.scores + 3 * (size_t)(first + x);
         const bool px = (t.mask[first + x] & t.priority_mask) != 0ull;
@@ -354,6 +409,9 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kerne
     }
     __threadfence_block();
     __syncthreads();
+#ifdef SQ_TAIL_PROF
+    if (tid == 0) _tp[6] = wall_clock64();
+#endif
     // ---- g. what is shown, metrics of the top ranks, sizes ----
     const uint32_t nshow = t.result_limit > 0 ? min(D, (uint32_t)t.result_limit) : D;
     const int known_n = t.ref_n ? t.ref_n[s] : -1;
@@ -382,16 +440,30 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kerne
             // read off the partner array on the fly: stem q starts at the q-th position that opens a new stack
             // (lane 0 lists the starts into the entry scratch of the sequence's LAST canonical slot is not available here,
             // so the stems are enumerated by position: a pair (i, p), i < p, starts a stem unless (i - 1, p + 1) is a pair)
+            // (the starts are listed in the LDS of the rank keys, which pass f is done with, when they fit)
+            int16_t *const s_start = reinterpret_cast<int16_t *>(s_key);
+            const int startcap = 12 * keycap;
             int nst = 0;
             for (int i0 = 0; i0 < n; i0 += 64) {
                 const int i = i0 + lane;
                 bool start = false;
                 if (i < n) { const int p = refp[i]; start = p > i && !(i > 0 && refp[i - 1] == p + 1); }
-                nst += __popcll(__ballot(start));
+                const unsigned long long bal = __ballot(start);
+                if (start) { const int idx = nst + (int)__popcll(bal & ((1ull << lane) - 1ull)); if (idx < startcap) s_start[idx] = (int16_t)i; }
+                nst += __popcll(bal);
             }
+            const bool listed = nst <= startcap;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
             auto ref_stem = [&](int q) {                                // q-th stem start in ascending order of i
                 int seen = 0;
                 SqPoolStem out{0, 0, 0, 0};
+                if (listed) {
+                    const int i = s_start[q], p = refp[i];
+                    int len = 1;
+                    while (i + len < n && refp[i + len] == p - len && p - len > i + len) len++;
+                    return SqPoolStem{(int16_t)i, (int16_t)p, (int16_t)len, 0};
+                }
                 for (int i = 0; i < n; i++) {
                     const int p = refp[i];
                     if (!(p > i) || (i > 0 && refp[i - 1] == p + 1)) continue;
@@ -419,6 +491,16 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS) void sq_tail_rank_kerne
             S.evals = ev;
         }
     }
+#ifdef SQ_TAIL_PROF
+    __syncthreads();
+    if (tid == 0) {
+        _tp[7] = wall_clock64();
+        if (_tp[7] - _tp[0] > 30000)
+            printf("tail s=%d n=%d M=%u D=%u jobs=%d | us: sort %.0f canon %.0f first %.0f producers %.0f score %.0f rank %.0f show %.0f\n", s, n, M, D, j1 - j0,
+                   (_tp[1] - _tp[0]) * 0.01, (_tp[2] - _tp[1]) * 0.01, (_tp[3] - _tp[2]) * 0.01, (_tp[4] - _tp[3]) * 0.01, (_tp[5] - _tp[4]) * 0.01,
+                   (_tp[6] - _tp[5]) * 0.01, (_tp[7] - _tp[6]) * 0.01);
+    }
+#endif
 }
 
 extern "C" __global__ __launch_bounds__(1024) void sq_tail_offsets_kernel(SqTailIO t, volatile uint32_t *h_seq, uint32_t seq)
@@ -679,7 +761,13 @@ int sq_tail_device(sq_batch *b, const sq_fold_opts &o, const int32_t *ref_off, c
     hipLaunchKernelGGL(sq_tail_scatter_kernel, dim3(nb), dim3(256), 0, st, t);
     {
         const int bitwords = std::min(SQ_TAIL_BITWORDS, (b->maxn + 31) / 32 + 1);
-        hipLaunchKernelGGL(sq_tail_rank_kernel, dim3(b->nseq), dim3(SQ_TAIL_THREADS), (size_t)(SQ_TAIL_THREADS / 64) * bitwords * 4, st, b->ctx, t, bitwords);
+        // a batch alone whose sequences have several jobs (tens to hundreds of final structures each): sixteen waves per
+        // sequence instead of four -- the per-entry passes of the slowest sequence are what the fold's tail waits for
+        const bool wide = !(b->inflight > 1 || b->njobs >= 4096) && b->njobs > b->nseq;
+        const int thr = wide ? SQ_TAIL_THREADS_WIDE : SQ_TAIL_THREADS;
+        const int keycap = wide ? 1024 : 256;                    // rank keys staged in LDS (25 bytes each; more structures: global path)
+        const size_t lds = ((((size_t)(thr / 64) * bitwords + 1) & ~(size_t)1) * 4) + (size_t)keycap * 25 + 8;
+        hipLaunchKernelGGL(sq_tail_rank_kernel, dim3(b->nseq), dim3(thr), lds, st, b->ctx, t, bitwords, keycap);
     }
     uint32_t seq = ++*ln.round_seq;
     hipLaunchKernelGGL(sq_tail_offsets_kernel, dim3(1), dim3(1024), 0, st, t, ln.h_seq, seq);
