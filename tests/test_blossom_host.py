@@ -18,12 +18,12 @@ def exe():
     return EXE
 
 
-def _graphs(seed, count):
+def _graphs(seed, count, nmax=22, mmax=60):
     rng = random.Random(seed)
     out = []
     for _ in range(count):
-        n = rng.randint(2, 22)
-        m = rng.randint(1, min(60, n * (n - 1) // 2))
+        n = rng.randint(2, nmax)
+        m = rng.randint(1, min(mmax, n * (n - 1) // 2))
         pairs = set()
         while len(pairs) < m:
             a, b = rng.sample(range(n), 2)
@@ -36,9 +36,11 @@ def _graphs(seed, count):
     return out
 
 
-def test_blossom_matches_networkx(exe):
+@pytest.mark.parametrize("seed,count,nmax,mmax", [(7, 400, 22, 60), (11, 60, 120, 700)])
+def test_blossom_matches_networkx(exe, seed, count, nmax, mmax):
+    """(the second set: graphs of the size of SRtest150's -- nested blossoms, expansions, lists scanned in chunks)"""
     nx = pytest.importorskip("networkx")
-    graphs = _graphs(7, 400)
+    graphs = _graphs(seed, count, nmax, mmax)
     lines, idmaps = [str(len(graphs))], []
     for edges in graphs:
         ids = {}
