@@ -734,13 +734,12 @@ struct SqBlossom {
 #endif
                     f_augmented = 0;
                 }
-                // ---- queue of S-vertices.  One vertex at a time (LIFO order matters), its neighbours 64 at a
-                // time: every lane classifies one neighbour against the current state; the neighbours before the
-                // first one that changes shared state (a label assignment, a new blossom, an augmentation) only
-                // touch their own w (allowedge, SQ_LP(label)[w], SQ_LP(bestedge)[w]) or compete for SQ_LP(bestedge)[bv] (first strictly
-                // smaller slack wins == lexicographic (slack, position) minimum), so they are applied in parallel;
-                // the state-changing neighbour is then handled by lane 0 with the sequential code and the rest of
-                // the list is re-classified.
+                // ---- queue of S-vertices (LIFO order matters).  Every lane classifies one neighbour of a popped vertex
+                // against the current state; the neighbours before the first one that changes shared state (a label
+                // assignment, a new blossom, an augmentation) only touch their own w (allowedge, SQ_LP(label)[w],
+                // SQ_LP(bestedge)[w]) or compete for SQ_LP(bestedge)[bv] (first strictly smaller slack wins == lexicographic
+                // (slack, position) minimum), so they are applied in parallel; the state-changing neighbour is then
+                // handled with the sequential code and what is left of its vertex's list is re-classified.
                 // the queue length lives in a register of every lane (the queue itself only changes inside the
                 // lane-0 sections, which are bracketed by syncs and followed by a reload)
                 sync();
