@@ -201,6 +201,7 @@ struct sq_batch {
     size_t h_rec_cap = 0, h_txt_cap = 0;
     char *h_app = nullptr; size_t h_app_cap = 0;   // pinned staging of host-built log entries (sq_fin_append_kernel)
     char *h_ref = nullptr; size_t h_ref_cap = 0;   // pinned staging of the known structures (partner arrays)
+    int tail_refs_state = 0;                       // sq_tail_refs: 0 not prepared for this fold, 1 no known structure, 2 uploaded
     bool packed_ok = false;               // the last fold's results are the packed records above (else: `results`)
     int tail_maxshow = 0;                 // most structures shown for one sequence in the last device tail (shapes the next pack launch)
     int32_t packed_limit = 0;             // result_limit in force at that fold
@@ -288,6 +289,7 @@ void sq_algos_abandon(sq_batch *b, SqAlgoAsync *pa);      // error paths: waits 
 // device tail (sq_tail_dev.hip).  Launches the tail over the batch's device log on b->stream and waits for it.
 // Returns 0: the packed results are in place (b->packed_ok), 1: the batch needs the host tail (nothing changed), else an error.
 int sq_tail_device(sq_batch *b, const sq_fold_opts &o, const int32_t *ref_off, const int32_t *ref_pairs, const uint8_t *has_ref);
+int sq_tail_refs(sq_batch *b, const int32_t *ref_off, const int32_t *ref_pairs, const uint8_t *has_ref);
 // whether the options of this fold are covered by the device tail at all
 bool sq_tail_device_wanted(const sq_batch *b, const sq_fold_opts &o);
 

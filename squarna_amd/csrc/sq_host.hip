@@ -2445,6 +2445,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     const int nrounds = st0.nrounds + st1.nrounds;
     const double tloop = now_s() - tfold0;
     const double ttail0 = now_s();
+    // (the known structures go to the device now: the tail's launches then follow the wait for the matching kernels directly)
+    b->tail_refs_state = 0;
+    if (dev_tail) (void)sq_tail_refs(b, ref_off, ref_pairs, has_ref);
     // E / H / N stemsets precede the greedy ones of their job (:1094-1100), in the order E, H, N.  Hungarian and
     // Nussinov are final first; Edmonds is streamed job by job, and a sequence is ranked (its tail) the moment its
     // last Edmonds graph is matched -- the other sequences do not wait for the largest graph of the batch.

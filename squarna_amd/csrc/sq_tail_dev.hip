@@ -703,24 +703,14 @@ static int tail_wait(sq_batch *b, SqLane &ln, uint32_t seq, const char *what)
     return 0;
 }
 
-int sq_tail_device(sq_batch *b, const sq_fold_opts &o, const int32_t *ref_off, const int32_t *ref_pairs, const uint8_t *has_ref)
+// The known structures of the batch: partner per position + number of distinct pairs per sequence (:1249-1251), uploaded on
+// the batch's stream.  Nothing of it depends on the fold, so the fold calls it while the matching kernels still run (the
+// host is waiting anyway) and sq_tail_device finds b->tail_refs_state set: 1 no known structure, 2 uploaded; a return value
+// other than 0 leaves the state 0 and sq_tail_device repeats the call (1: the host tail's case, 2: an error).
+int sq_tail_refs(sq_batch *b, const int32_t *ref_off, const int32_t *ref_pairs, const uint8_t *has_ref)
 {
     hipStream_t st = b->stream;
-    SqLane &ln = b->lane_full;
-    SqTailIO t = b->tail;
-    if (!b->h_tail_totals) {
-        void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
-        if (sq_pinned_get(&p0, 64) || sq_pinned_get(&p1, 8 * ((size_t)b->nseq + 1)) || sq_pinned_get(&p2, 8 * ((size_t)b->nseq + 1)) ||
-            sq_pinned_get(&p3, (size_t)b->nseq + 64)) return 2;
-        b->h_tail_totals = (long long *)p0; b->h_rec_off = (long long *)p1; b->h_txt_off = (long long *)p2; b->h_deep = (uint8_t *)p3;
-    }
-    memset(b->h_tail_totals, 0, 64);
-    t.h_totals = b->h_tail_totals;
-    for (int q = 0; q < 3; q++) t.rankby[q] = o.rankby[q];
-    t.toplim = o.toplim; t.result_limit = b->result_limit; t.conslim = o.conslim; t.priority_mask = o.priority_mask;
-    t.tmax = std::max(b->chain_tmax, 1);
-    // known structures: partner per position + number of distinct pairs per sequence (:1249-1251)
-    t.refp = nullptr; t.ref_n = nullptr;
+    b->tail_refs_state = 0;
     bool any_ref = false;
     if (has_ref) for (int s = 0; s < b->nseq && !any_ref; s++) any_ref = has_ref[s] != 0;
     if (any_ref) {
@@ -752,8 +742,31 @@ int sq_tail_device(sq_batch *b, const sq_fold_opts &o, const int32_t *ref_off, c
         }
         if (sq_check(hipMemcpyAsync(b->d_refp, refp, 2 * (size_t)b->ltot, hipMemcpyHostToDevice, st), "upload of the known structures") ||
             sq_check(hipMemcpyAsync(b->d_refn, refn, 4 * (size_t)b->nseq, hipMemcpyHostToDevice, st), "upload of the known structures")) return 2;
-        t.refp = b->d_refp; t.ref_n = b->d_refn;
     }
+    b->tail_refs_state = any_ref ? 2 : 1;
+    return 0;
+}
+
+int sq_tail_device(sq_batch *b, const sq_fold_opts &o, const int32_t *ref_off, const int32_t *ref_pairs, const uint8_t *has_ref)
+{
+    hipStream_t st = b->stream;
+    SqLane &ln = b->lane_full;
+    SqTailIO t = b->tail;
+    if (!b->h_tail_totals) {
+        void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
+        if (sq_pinned_get(&p0, 64) || sq_pinned_get(&p1, 8 * ((size_t)b->nseq + 1)) || sq_pinned_get(&p2, 8 * ((size_t)b->nseq + 1)) ||
+            sq_pinned_get(&p3, (size_t)b->nseq + 64)) return 2;
+        b->h_tail_totals = (long long *)p0; b->h_rec_off = (long long *)p1; b->h_txt_off = (long long *)p2; b->h_deep = (uint8_t *)p3;
+    }
+    memset(b->h_tail_totals, 0, 64);
+    t.h_totals = b->h_tail_totals;
+    for (int q = 0; q < 3; q++) t.rankby[q] = o.rankby[q];
+    t.toplim = o.toplim; t.result_limit = b->result_limit; t.conslim = o.conslim; t.priority_mask = o.priority_mask;
+    t.tmax = std::max(b->chain_tmax, 1);
+    // known structures (sq_tail_refs; normally done already, while the fold waited for the matching kernels)
+    if (b->tail_refs_state == 0) { const int rr = sq_tail_refs(b, ref_off, ref_pairs, has_ref); if (rr) return rr; }
+    t.refp = b->tail_refs_state == 2 ? b->d_refp : nullptr; t.ref_n = b->tail_refs_state == 2 ? b->d_refn : nullptr;
+    b->tail_refs_state = 0;
     const unsigned nb = 256;
     memset(b->h_deep, 0, (size_t)b->nseq);                   // (pinned host memory; the previous fold's kernels are long done)
     hipLaunchKernelGGL(sq_tail_count_kernel, dim3(nb), dim3(256), 0, st, t);
