@@ -44,6 +44,20 @@ class Prepared:
             self.rxs = self.rlefts = self.rrights = self._NONE[1]
             self.shortdbn = self.refpairs = None
             return
+        if dbn and not reacts and not restraints and seq.isalpha():
+            # the same record with a known structure beside it (a benchmark set): what the general path below computes
+            # for it, without its string passes (no gap column: UnAlign returns its arguments; no restraint: four empties)
+            assert len(seq) == len(dbn)
+            n = len(seq)
+            self.seq = self.shortseq = seq
+            self.shortrest = '.' * n
+            self.shortreacts = [0.5] * n
+            self.plain_reacts = True
+            self.gapidx, self.sepidx, self.rbps = [], [], []
+            self.rxs, self.rlefts, self.rrights = set(), set(), set()
+            self.shortdbn = dbn
+            self.refpairs = None
+            return
         if not restraints:
             restraints = '.' * len(seq)                              # :1007-1008
         assert len(seq) == len(restraints), "Invalid restraints given"
