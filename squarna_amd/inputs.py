@@ -39,17 +39,22 @@ def ParseDefaultInput(inputname, inputformat, returndefaults=False, ignore=False
             print(msg, file=sys.stderr)
         return current
 
+    nfields = len(inputformat)
+    fits_reacts = lambda d, n: len(d) == n or len(d.split()) == n      # noqa: E731
+    fits_line = lambda d, n: len(d) == n                                # noqa: E731
+
     def record(name, lines):
-        lines = lines + [None] * (len(inputformat) - len(lines))
+        if len(lines) < nfields:
+            lines = lines + [None] * (nfields - len(lines))
         sequence = lines[q_ind].split()[0]            # trailing comments allowed (SQUARNA.py:98-104)
         reacts = lines[t_ind] if t_ind > 0 else None
         restr = lines[r_ind].split()[0] if r_ind > 0 and lines[r_ind] else None
         ref = lines[f_ind].split()[0] if f_ind > 0 and lines[f_ind] else None
         n = len(sequence)
-        reacts = fallback("reactivities", reacts, defaults["t"], n,
-                          lambda d, n: len(d) == n or len(d.split()) == n)
-        restr = fallback("restraints", restr, defaults["r"], n, lambda d, n: len(d) == n)
-        ref = fallback("reference", ref, defaults["f"], n, lambda d, n: len(d) == n)
+        if defaults["t"] or defaults["r"] or defaults["f"]:     # (no default line: nothing to fall back to)
+            reacts = fallback("reactivities", reacts, defaults["t"], n, fits_reacts)
+            restr = fallback("restraints", restr, defaults["r"], n, fits_line)
+            ref = fallback("reference", ref, defaults["f"], n, fits_line)
         try:
             if reacts:
                 reacts = _decode_reactivities(reacts, n, M, B)
