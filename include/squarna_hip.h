@@ -303,6 +303,17 @@ typedef struct sq_block_desc {
 } sq_block_desc;
 SQ_API int64_t sq_write_blocks(const sq_batch *b, const sq_block_desc *d, char *buf, int64_t cap, int64_t *off, uint8_t *skipped);
 
+/* sq_parse_default -- the record scan of the reference's default input format (SQUARNA.py:80-203, ParseDefaultInput) over
+ * the bytes of a file: a '>' line names a record, the lines behind it are its fields in the order of `inputformat`
+ * (nfields letters; q_ind / t_ind / r_ind / f_ind: the positions of q, t, r, f in it, -1 when absent; as in the reference
+ * a t / r / f at position 0 is not read).  out[rec][10] = offset, length of: the stripped name line, the sequence token,
+ * the stripped reactivities line, the restraints token, the reference token (length -1: None; restraints / reference
+ * also for an empty line).  Returns the number of records, or -1 when the file needs the general parser: default lines
+ * in front of the first record, a byte outside ASCII, NUL or '\r', a record without a sequence token, more than cap
+ * records.  Host code; values are not validated here (lengths, reactivities): the caller's checks stay the reference's. */
+SQ_API int64_t sq_parse_default(const char *text, int64_t len, int32_t nfields, int32_t q_ind, int32_t t_ind, int32_t r_ind,
+                                int32_t f_ind, int64_t *out, int64_t cap);
+
 /* R = number of AnnotateStems evaluations the reference algorithm performs for this sequence. */
 SQ_API int64_t sq_result_evals(const sq_batch *b, int32_t seq);
 

@@ -15,6 +15,22 @@ def _decode_reactivities(text, length, M, B):
     return ProcessReacts([ReactDict[ch] for ch in text], M=M, B=B)
 
 
+def _check_record(name, sequence, reacts, restr, ref, M, B):
+    """The checks and the reactivity decoding at the end of a record (SQUARNA.py:140-176)."""
+    n = len(sequence)
+    try:
+        if reacts:
+            reacts = _decode_reactivities(reacts, n, M, B)
+        assert not reacts or len(reacts) == n
+    except Exception:
+        raise ValueError('Inappropriate reactivities line for entry "{}":\n {}'.format(name[1:], reacts))
+    assert not restr or len(restr) == n, \
+        'Inappropriate restraints line for entry "{}":\n {}'.format(name[1:], restr)
+    assert not ref or len(ref) == n, \
+        'Inappropriate reference line for entry "{}":\n {}'.format(name[1:], ref)
+    return name, sequence, reacts, restr, ref
+
+
 def ParseDefaultInput(inputname, inputformat, returndefaults=False, ignore=False, M=1.8, B=-0.6):
     """Default format: '>' name line, then one line per letter of `inputformat`
     (q seQuence, t reacTivities, r Restraints, f reFerence, x skipped).  Lines before
@@ -50,22 +66,12 @@ def ParseDefaultInput(inputname, inputformat, returndefaults=False, ignore=False
         reacts = lines[t_ind] if t_ind > 0 else None
         restr = lines[r_ind].split()[0] if r_ind > 0 and lines[r_ind] else None
         ref = lines[f_ind].split()[0] if f_ind > 0 and lines[f_ind] else None
-        n = len(sequence)
         if defaults["t"] or defaults["r"] or defaults["f"]:     # (no default line: nothing to fall back to)
+            n = len(sequence)
             reacts = fallback("reactivities", reacts, defaults["t"], n, fits_reacts)
             restr = fallback("restraints", restr, defaults["r"], n, fits_line)
             ref = fallback("reference", ref, defaults["f"], n, fits_line)
-        try:
-            if reacts:
-                reacts = _decode_reactivities(reacts, n, M, B)
-            assert not reacts or len(reacts) == n
-        except Exception:
-            raise ValueError('Inappropriate reactivities line for entry "{}":\n {}'.format(name[1:], reacts))
-        assert not restr or len(restr) == n, \
-            'Inappropriate restraints line for entry "{}":\n {}'.format(name[1:], restr)
-        assert not ref or len(ref) == n, \
-            'Inappropriate reference line for entry "{}":\n {}'.format(name[1:], ref)
-        return name, sequence, reacts, restr, ref
+        return _check_record(name, sequence, reacts, restr, ref, M, B)
 
     name, lines = None, []
     with open(inputname) as fh:
@@ -87,6 +93,38 @@ def ParseDefaultInput(inputname, inputformat, returndefaults=False, ignore=False
             name, lines = raw.strip(), []
     if name:
         yield record(name, lines)
+
+
+def ScanDefaultInput(inputname, inputformat):
+    """The records of a default-format file as COLUMNS: (text, rows), rows[k] = offsets and lengths into text of record k's
+    name line, sequence, reactivities line, restraints, reference (length -1: None) -- the library's record scan
+    (sq_parse_default, host code; SQUARNA.py:80-203).  None when the file needs ParseDefaultInput's loop: default lines
+    in front of the first record, bytes outside ASCII, carriage returns, a record without its sequence line.  Not on
+    Predict()'s path yet: building ten thousand tuples costs Python what the scan saves; it is the first half of an
+    ingestion that hands the batch its records as columns.  `rows_to_records` gives the tuples."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    L = _lib.load()
+    q_ind = inputformat.index('q')
+    t_ind, r_ind, f_ind = (inputformat.find(c) for c in 'trf')
+    with open(inputname, "rb") as fh:
+        data = fh.read()
+    cap = data.count(b"\n>") + 1
+    out = np.empty((cap, 10), np.int64)
+    L.sq_parse_default.restype = C.c_int64
+    n = L.sq_parse_default(C.c_char_p(data), C.c_int64(len(data)), C.c_int32(len(inputformat)), C.c_int32(q_ind), C.c_int32(t_ind),
+                           C.c_int32(r_ind), C.c_int32(f_ind), C.c_void_p(out.ctypes.data), C.c_int64(cap))
+    if n < 0:
+        return None
+    return data.decode("ascii"), out[:n]
+
+
+def rows_to_records(text, rows, M=1.8, B=-0.6):
+    """ParseDefaultInput's tuples from ScanDefaultInput's columns: the same values, the same checks in the same order."""
+    for no, nl, so, sl, to, tl, ro, rl, fo, fl in rows.tolist():
+        yield _check_record(text[no:no + nl], text[so:so + sl], text[to:to + tl] if tl >= 0 else None,
+                            text[ro:ro + rl] if rl >= 0 else None, text[fo:fo + fl] if fl >= 0 else None, M, B)
 
 
 _NOT_ACGUT = {ord(c): None for c in "ACGUTacgut"}
