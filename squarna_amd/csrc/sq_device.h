@@ -164,7 +164,7 @@ __global__ void sq_select_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs
 
 // sq_extend.h: LDS of one structure's level scratch (chain / pool-extend kernels), lists of up to T stems
 #define SQ_CHAIN_TMAX 11264
-static inline size_t sq_extend_lds_bytes(int T) { const size_t t = ((size_t)T + 7) & ~(size_t)7; return t * 14 + 64 * 4 + 64; }
+__host__ __device__ static inline size_t sq_extend_lds_bytes(int T) { const size_t t = ((size_t)T + 7) & ~(size_t)7; return t * 14 + 64 * 4 + 64; }
 
 // sq_gather.hip: the N x N weighting slices of the jobs in job_list from ONE shared L x L device matrix through the
 // per-position alignment columns (alignment step 2, SQRNdbnseq.py:1031-1034,1084-1085)

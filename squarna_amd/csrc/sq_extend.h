@@ -7,6 +7,12 @@
 #include <hip/hip_runtime.h>
 #include "sq_device.h"
 
+// The wave's own barrier between its LDS writes and reads.  Kernels whose block IS that wave use the block barrier;
+// a kernel that runs the extension on one wave of a wider block (sq_rounds.hip) defines a wave-level fence instead.
+#ifndef SQ_EXTEND_SYNC
+#define SQ_EXTEND_SYNC() __syncthreads()
+#endif
+
 // stems per structure the level scratch can hold: 14 bytes of LDS each, a block's dynamic LDS is sized for the launch's
 // longest list (SQ_CHAIN_TMAX in sq_device.h = what 160 KB hold; structures that could grow longer run the host loop)
 
@@ -56,7 +62,7 @@ __device__ __forceinline__ SqExtendLds sq_extend_lds(char *base, int T)
 // PairsToDBN's level rule at stem level (:119-150) for the T stems in L.i / L.j / L.len with their crossing weights L.cc:
 // stems that cross nothing all land in group 0; the others are ordered by (weight, start), first-fitted into groups
 // and the groups ranked by size.  Result: L.lvl[q] = 1-based level of stem q.  One wave; the caller's block is that wave
-// (every __syncthreads() below is the wave's own barrier).  level_ovf: set when more than SQ_MAXLEVELS groups appear.
+// (every SQ_EXTEND_SYNC() below is the wave's own barrier).  level_ovf: set when more than SQ_MAXLEVELS groups appear.
 __device__ __forceinline__ void sq_stem_levels_wave(SqExtendLds &L, int T, int lane, uint32_t *level_ovf)
 {
     // stems that cross nothing sort first (weight 0) and all land in group 0
@@ -85,7 +91,7 @@ __device__ __forceinline__ void sq_stem_levels_wave(SqExtendLds &L, int T, int l
         }
         nx += __popcll(__ballot(x));
     }
-    __syncthreads();
+    SQ_EXTEND_SYNC();
     // first fit (:130-136): a stem joins the first group none of whose members it crosses
     for (int t = 0; t < nx; t++) {
         const int p = L.ord[t];
@@ -100,9 +106,9 @@ __device__ __forceinline__ void sq_stem_levels_wave(SqExtendLds &L, int T, int l
         if (placed > ngroups) placed = ngroups;
         if (placed >= SQ_MAXLEVELS) { if (lane == 0) *level_ovf = 1; placed = SQ_MAXLEVELS - 1; }   // (reported as an error)
         else if (placed == ngroups) { ngroups++; if (lane == 0) L.gsize[placed] = 0; }
-        __syncthreads();
+        SQ_EXTEND_SYNC();
         if (lane == 0) { L.grp[p] = (uint8_t)placed; L.gsize[placed] += L.len[p]; }
-        __syncthreads();
+        SQ_EXTEND_SYNC();
     }
     // groups ranked by size, descending, stable (:139); level = rank + 1
     if (lane < ngroups) {
@@ -111,9 +117,9 @@ __device__ __forceinline__ void sq_stem_levels_wave(SqExtendLds &L, int T, int l
         for (int h = 0; h < ngroups; h++) { const int hs = L.gsize[h]; r += (hs > gs || (hs == gs && h < lane)) ? 1 : 0; }
         L.rank[lane] = (uint8_t)(r + 1);
     }
-    __syncthreads();
+    SQ_EXTEND_SYNC();
     for (int q = lane; q < T; q += 64) L.lvl[q] = L.rank[L.grp[q]];
-    __syncthreads();
+    SQ_EXTEND_SYNC();
 }
 
 // parent: k stems pst[] (with their crossing weights), nstrand sorted strands psrc[] + the stem index of each (pssrc[]).
@@ -138,7 +144,7 @@ __device__ __forceinline__ bool sq_extend_structure(SqExtendLds &L, const SqScan
         L.i[k] = (int16_t)i0; L.j[k] = (int16_t)j0; L.len[k] = (int16_t)len; L.cc[k] = newcc;
         cst[k] = SqChainStem{i0, j0, len, newcc};
     }
-    __syncthreads();
+    SQ_EXTEND_SYNC();
     const int T = k + 1;
     // ---- levels (only when stems cross; otherwise every strand stays on level 1) ----
     if (anycross) sq_stem_levels_wave(L, T, lane, &a.ctr->level_ovf);

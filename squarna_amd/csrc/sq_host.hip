@@ -12,6 +12,7 @@
 #include <vector>
 #include <unordered_map>
 #include "sq_host.h"
+#include "sq_rounds.h"
 #include "sq_algos_dev.h"
 #include "sq_match.h"
 
@@ -1165,7 +1166,7 @@ extern "C" int sq_profile_counters(sq_batch *b, int32_t kernel, int64_t out[6])
 }
 extern "C" int sq_profile_get(sq_batch *b, int32_t k, double *ms, int64_t *launches, double *bytes)
 {
-    if (k < 0 || k > 6) return -1;
+    if (k < 0 || k > 7) return -1;
     hipStreamSynchronize(b->stream);
     for (int q = 0; q < 3; q++) if (b->side[q]) hipStreamSynchronize(b->side[q]);
     prof_collect(b);
@@ -1898,6 +1899,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     std::vector<int> greedy_jobs;
     for (int j = 0; j < b->njobs; j++) if (algos[j] & SQ_ALGO_G) greedy_jobs.push_back(j);
     const bool no_chain = getenv("SQ_NO_CHAIN") != nullptr;     // (read per fold: tests compare both drivers in one process)
+    const bool no_rounds = getenv("SQ_NO_ROUNDS") != nullptr;   // (likewise: the launched rounds instead of the persistent round kernel)
     bool use_chain = o.poollim == 1 && !no_chain && !greedy_jobs.empty();
     if (use_chain)
         for (int j : greedy_jobs)
@@ -2160,7 +2162,53 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         volatile uint32_t *flag = ln.h_seq;
         const double tr0 = now_s();
         std::vector<std::pair<int, double>> round_t;
-        while (nfin_seen < nfin_goal) {
+        // ONE launch for all rounds of these structures (sq_rounds.hip: a persistent block per structure) when every job
+        // qualifies: no dense matrix behind its cells, per-position arrays that fit the block's LDS
+        bool rounds_ok = !no_rounds;
+        for (int j : jobs) rounds_ok = rounds_ok && b->jobs[j].mat64_off < 0 && !b->jobs[j].has_ext && b->jobs[j].n <= SQ_ROUNDS_MAXN;
+        if (rounds_ok) {
+            static const int thr_env = getenv("SQ_ROUNDS_THREADS") ? std::max(64, std::min(SQ_ROUNDS_THREADS, atoi(getenv("SQ_ROUNDS_THREADS")) / 64 * 64)) : 0;
+            const int thr = thr_env ? thr_env : (maxn <= 200 ? 64 : (maxn <= 450 ? 128 : SQ_ROUNDS_THREADS));
+            SqRoundsArgs ra;
+            ra.lds_n = maxn; ra.str_cap = 2 * maxt + 2; ra.tmax = maxt; ra.cell_entries = b->cell_entries;
+            ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0;
+            const SqRoundsLds lo = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr);
+            if (lo.total + 1024 > 160 * 1024) rounds_ok = false;
+            else {
+                if (lo.total > 48 * 1024) sq_max_dynamic_lds((const void *)sq_rounds_kernel, 160 * 1024);
+                {
+                    ProfScope ps(b, 7, 0);
+                    hipLaunchKernelGGL(sq_rounds_kernel, dim3(S), dim3(thr), lo.total, st, b->ctx, ln.d_structs, scan, b->chain, ra);
+                }
+                const uint32_t seq = ++*ln.round_seq;
+                hipLaunchKernelGGL(sq_chain_done_kernel, dim3(1), dim3(1), 0, st, io, scan, b->chain, seq);
+                launched = 1;
+                b->last_paths |= 4;
+                while (*flag != seq) {
+                    if ((++spins & poll_mask) == 0) {
+                        const hipError_t q = hipStreamQuery(st);
+                        if (q != hipErrorNotReady && q != hipSuccess) { fail(sq_check(q, "persistent rounds"), sq_last_error()); break; }
+                        if (q == hipSuccess && *flag != seq) { fail(2, "persistent rounds did not signal completion"); break; }
+                    }
+                    sq_wait_step(spins, relaxed);
+                }
+                if (!stats.rc) {
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    const SqCounters ctr = *ln.h_ctr;
+                    if (ctr.cand_ovf) fail(-3, "candidate capacity exceeded (raise cand_per_nt)");
+                    else if (ctr.out_ovf) fail(-3, "stem capacity of a chained structure exceeded");
+                    else if (ctr.level_ovf) fail(-3, "more than 64 pseudoknot levels");
+                    else {
+                        const uint32_t nf = *b->chain.h_nfin;
+                        if (nf != nfin_goal) fail(2, "persistent rounds left structures unfinished");
+                        if (!dev_tail) for (uint32_t q = nfin_seen; q < nf; q++) finished.push_back(-(int)q - 1);
+                        nfin_seen = nf;
+                        tq.push(finished);
+                    }
+                }
+            }
+        }
+        while (!rounds_ok && nfin_seen < nfin_goal) {
             while (launched - done < depth) {               // rounds enqueued ahead of the device
                 if ((int)launched > maxt + 2) { fail(2, "chained rounds do not terminate"); break; }
                 // (algorithmic bytes: NOT per launch -- a launch also covers the structures that are already final; they are

@@ -549,28 +549,22 @@ __device__ __forceinline__ void sq5_emit(LDS &L, const SqScanArgs &a, const SqSt
 }
 
 // ------------------------------------------------------------------------------------
-// a-2  stem scan, bit-diagonal form.  AnnotateStems only needs to know WHERE the
-// unmasked cells are -- every candidate's score is recomputed exactly in fp64 by sq_score_kernel --
-// so the scan reads the job's diagonal bit matrix (sq_bits_kernel) instead of the fp32 matrix:
-//   active(s, i) = base(s, i)  &  free[i]  &  free[s - i]       (+ the live restraint pairs)
-// One lane = one anti-diagonal, one loop step = 32 rows:
-//   base word   one coalesced 4-byte load per lane (64 consecutive diagonals = 256 B per wave);
-//   row word    wave-uniform LDS read of the free-position bit array F;
-//   column word a 32-bit window of the REVERSED array G (bit k <-> position n-1-k) starting at
-//               n-1-s+32w: it advances by exactly one word per step, so each step reads one new LDS
-//               word and funnel-shifts it against the previous one (v_alignbit);
-// and the runs of the 32 rows come out of the word with bit tricks (below).  Per structure the scan touches
-// N^2/16 bytes of (L2-resident) bits instead of 2 N^2 bytes of HBM.
+// a-2  stem scan, bit-diagonal form (sq_scan.h): one wave = 64 anti-diagonals of one structure, the runs staged in LDS
 // ------------------------------------------------------------------------------------
 struct SqScan6Lds {
     uint2 stage[SQ5_STAGE];
     uint32_t stage_count, pad[3];
 };
 
-#ifndef SQ6_AHEAD
-#define SQ6_AHEAD 2
-#endif
-// the scan of one structure's diagonal groups gy0, gy0 + gystep, .. (one wave)
+#include "sq_scan.h"
+// the scan of one structure's diagonal groups gy0, gy0 + gystep, .. (one wave = the whole block): sq_scan.h, with the runs
+// staged in LDS and appended to the structure's key array
+struct SqScan6Sink {
+    SqScan6Lds &L; const SqScanArgs &a; const SqStruct &st; int cap;
+    __device__ __forceinline__ void emit(uint32_t key, uint32_t len) { sq5_emit(L, a, st, cap, key, len); }
+    __device__ __forceinline__ void poll(int lane) { if (L.stage_count > SQ5_STAGE / 2) sq5_flush(L, a, st, cap, lane); }
+    __device__ __forceinline__ void drain(int lane) { __syncthreads(); sq5_flush(L, a, st, cap, lane); }
+};
 __device__ __forceinline__ void sq_scan6_body(const SqDevCtx &c, const SqStruct &st, const SqState &stt, SqScanArgs &a, int gy0, int gystep)
 {
     __shared__ __attribute__((aligned(16))) SqScan6Lds L;
@@ -580,124 +574,18 @@ __device__ __forceinline__ void sq_scan6_body(const SqDevCtx &c, const SqStruct 
     const int n = jb.n;
     if (n < 5) return;                                                  // :456-457 no diagonals
     const int lane0 = threadIdx.x;
+    const int fbh = stt.fbstride >> 1;
     {
-        const int fbh0 = stt.fbstride >> 1;
         const uint32_t *FBg0 = stt.FB + (int64_t)st.slot * stt.fbstride;
         if (lane0 == 0) L.stage_count = 0;
-        for (int m = lane0; m < 2 * fbh0; m += 64) sq6_fg[m] = FBg0[m];
+        for (int m = lane0; m < 2 * fbh; m += 64) sq6_fg[m] = FBg0[m];
         __syncthreads();
     }
     // one block = the diagonal groups blockIdx.y, blockIdx.y + gridDim.y, ..: a launch for short sequences gives a structure
     // ONE wave that walks all its groups (five for 100 nt) instead of one wave per group -- each of those spent most of its
     // few microseconds on the set-up above, and with batches in flight wave slots are what the chip runs out of
-    const int ngroups = ((2 * n - 5 + 63) >> 6) + 1;
-    for (int gy = gy0; gy < ngroups; gy += gystep) {
-    const int s0 = gy << 6;
-    const int smin = max(s0, 4), smax = min(s0 + 63, 2 * n - 6);        // :456-457 s in [4, 2N-6]
-    if (smin > smax) continue;
-    const int rmin = max(0, smin - (n - 1)), rmax = (smax - 1) >> 1;    // :486 i <= j-1
-    const int wlo = rmin >> 5, whi = rmax >> 5;
-    const int lane = threadIdx.x;
-    const int s = s0 + lane;
-    const SqPsetDev *ps = c.psets + jb.pset;
-    const int minlen = max(1, (int)ceil(ps->minlen));
-    const int cap = jb.cand_cap;
-    const int fbh = stt.fbstride >> 1;
-    uint32_t *F = sq6_fg, *G = sq6_fg + fbh;
-    // window of the reversed array for (s, wlo): first bit n-1-s+32 wlo (+pad); lanes outside the valid
-    // diagonals have zero base words, their window only has to stay inside the array
-    const int q0 = min(max(n - 1 - s + 32 * wlo + SQ_GPAD, 0), 32 * (fbh - (whi - wlo) - 3));
-    const int gidx = q0 >> 5, gsh = q0 & 31;
-    // Restraint base pairs (:438-443: the cell of a restraint pair stays pairable while both ends are free).  The
-    // sequence's list is sorted by (i + j, i), so the pairs of this lane's diagonal are one run of it, in row order: two
-    // binary searches here, then a pointer that only moves forward as the rows go by.  Any number of pairs.
-    const uint32_t *rlist = c.rbpk + jb.rb_off;
-    const uint8_t *eg = stt.E8 + (int64_t)st.slot * stt.stride * 2;
-    int rp = 0, rend = 0;
-    if (jb.nrb) {
-        int lo = 0, hi = jb.nrb;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            const uint32_t pk = rlist[mid];
-            if ((int)(pk & 0xFFFFu) + (int)(pk >> 16) < s) lo = mid + 1; else hi = mid;
-        }
-        rp = lo; hi = jb.nrb;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            const uint32_t pk = rlist[mid];
-            if ((int)(pk & 0xFFFFu) + (int)(pk >> 16) <= s) lo = mid + 1; else hi = mid;
-        }
-        rend = lo;
-    }
-    const uint32_t *bp = c.bits + jb.bits_off + s;
-    const int bpitch = jb.bpitch;
-
-    int carry = 0;
-    uint32_t glo = G[gidx];
-    // window of minlen ones by doubling: Y &= Y >> ysh_q, five fixed steps (shift 0 once the window is complete)
-    int ysh0, ysh1, ysh2, ysh3, ysh4;
-    {
-        const int want = minlen < 32 ? minlen : 32;
-        int have = 1;
-        ysh0 = min(have, want - have); have += ysh0;
-        ysh1 = min(have, want - have); have += ysh1;
-        ysh2 = min(have, want - have); have += ysh2;
-        ysh3 = min(have, want - have); have += ysh3;
-        ysh4 = min(have, want - have);
-    }
-    // SQ6_AHEAD word-rows per trip: their (independent) loads are issued together, so a wave waits for HBM / L2 once
-    // per group instead of once per word (a single word of look-ahead did not survive the compiler's wait counts)
-    for (int w0 = wlo; w0 <= whi; w0 += SQ6_AHEAD) {
-        uint32_t bw[SQ6_AHEAD];
-#pragma unroll
-        for (int k = 0; k < SQ6_AHEAD; k++) bw[k] = w0 + k <= whi ? bp[(int64_t)(w0 + k) * bpitch] : 0u;
-#pragma unroll
-        for (int k = 0; k < SQ6_AHEAD; k++) {
-            const int w = w0 + k;
-            if (w > whi) break;
-            const uint32_t base = bw[k];
-            const uint32_t ghi = G[gidx + 1 + (w - wlo)];
-            const uint32_t gw = __builtin_amdgcn_alignbit(ghi, glo, gsh);   // columns s-32w-b, b = 0..31
-            glo = ghi;
-            uint32_t A = base & F[w] & gw;                              // :438-451 free row and column
-            while (rp < rend) {                                         // (no lane enters without restraint pairs on its diagonal)
-                const uint32_t pk = rlist[rp];
-                const int v = (int)(pk & 0xFFFFu);
-                if ((v >> 5) > w) break;
-                if ((v >> 5) == w && eg[v] == 1 && eg[pk >> 16] == 1) A |= base & (1u << (v & 31));   // :438-443 restraint bp stays pairable
-                rp++;
-            }
-            // maximal runs of the word (bit b = row 32w + b; `carry` rows of an open run precede row 32w)
-            if (__ballot((A != 0u) | (carry > 0)) != 0ull) {
-                if (A == 0xFFFFFFFFu) carry += 32;
-                else {
-                    const int lead = __ffs((int)~A) - 1;                // the run that continues the carried one (maybe empty)
-                    const int len0 = carry + lead;
-                    if (len0 >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(32 * w - carry), (uint32_t)len0);
-                    const int trail = __clz((int)~A);                   // the run still open at row 32w + 31
-                    carry = trail;
-                    // runs strictly inside: starts with a full window of minlen ones above them
-                    uint32_t rest = A & ~((1u << lead) - 1u);
-                    if (trail) rest &= 0xFFFFFFFFu >> trail;
-                    uint32_t Y = rest;
-                    Y &= Y >> ysh0; Y &= Y >> ysh1; Y &= Y >> ysh2; Y &= Y >> ysh3; Y &= Y >> ysh4;
-                    uint32_t starts = rest & ~(rest << 1) & Y;
-                    while (starts) {
-                        const int p = __ffs((int)starts) - 1;
-                        starts &= starts - 1;
-                        const int len = __ffs((int)~(rest >> p)) - 1;
-                        sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(32 * w + p), (uint32_t)len);
-                    }
-                }
-            } else
-                carry = 0;
-            if (L.stage_count > SQ5_STAGE / 2) sq5_flush(L, a, st, cap, lane);
-        }
-    }
-    if (carry >= minlen) sq5_emit(L, a, st, cap, ((uint32_t)s << 16) | (uint32_t)(32 * (whi + 1) - carry), (uint32_t)carry);
-    __syncthreads();
-    sq5_flush(L, a, st, cap, lane);
-    }
+    SqScan6Sink sink{L, a, st, jb.cand_cap};
+    sq_scan6_groups(c, jb, sq6_fg, sq6_fg + fbh, fbh, stt.E8 + (int64_t)st.slot * stt.stride * 2, gy0, gystep, lane0, sink);
 }
 
 extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
@@ -726,124 +614,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_state_scan_kernel(SqDevCtx c
 // ------------------------------------------------------------------------------------
 #define SQ_LDS_STRANDS 1024
 
-__device__ __forceinline__ bool sq_goodloop(int x, int y)             // :615-622
-{
-    // rows x = 0..4, bit y set when (x, y) is a "good" internal loop
-    const unsigned tab[5] = {0x07u /*0:{0,1,2}*/, 0x0Fu /*1:{0,1,2,3}*/, 0x1Fu /*2:{0..4}*/, 0x1Eu /*3:{1,2,3,4}*/,
-                             0x1Cu /*4:{2,3,4}*/};
-    if ((unsigned)x > 4u || (unsigned)y > 4u) return false;
-    return (tab[x] >> y) & 1u;
-}
-
-// grid = (structures, parts): the candidates of a structure are dealt to `parts` blocks; the round's best
-// finalscore of the structure is combined with atomicMax, the range filter (:769-778) runs in sq_select_kernel.
-// ScoreStems for one candidate stem (SQRNdbnseq.py:607-751): what the scoring kernels know about the structure ...
-struct SqStemsEnv {
-    const SqStrand *S; const uint16_t *skip; int nstrand; bool have_skip;   // sorted strands (+ skip pointers over registered blocks)
-    const int16_t *P, *U, *SU; const uint8_t *codes; int n;                 // partner array, prefix counts, letter codes
-    bool use_ctx; const SqCtxRec *ctx_rec; const int16_t *ctx_depth; const uint16_t *ctx_rmq; int ctx_cap;   // sq_context.h
-    double lb, bw, dc; int bwint, sdflen; const double *sdf, *of;           // the paramset's scalars and tables
-    SqCounters *ctr;
-};
-// ... and the finalscore of the stem (i0, j0, L) with bpscore bps (the caller applies :751's threshold)
-__device__ __forceinline__ double sq_stem_finalscore(const SqStemsEnv &e, int i0, int j0, int L, double bps)
-{
-    double fin = 0.0;
-    const int sa = i0 + L - 1, sb = j0 - L + 1;                 // :655 innermost bp
-    int inblockend = -1, nrec = 0, be0 = 0, be1 = 0, covered = 0, brackets = 0;
-    uint64_t levelset = 0;
-    int lo = 0, hi = e.nstrand;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (e.S[mid].start <= sa) lo = mid + 1; else hi = mid; }
-    SqCtxOut cx = {0, 0, 0, 0, 0};
-    if (e.use_ctx) {
-        int lo2 = lo; hi = e.nstrand;                          // first strand that starts at or behind sb
-        while (lo2 < hi) { const int mid = (lo2 + hi) >> 1; if (e.S[mid].start < sb) lo2 = mid + 1; else hi = mid; }
-        if (lo2 > lo) sq_ctx_query(e.ctx_rec, e.ctx_depth, e.ctx_rmq, e.ctx_cap, e.S, lo, lo2, cx);
-#ifndef SQ_CTX_CHECK
-        nrec = cx.nrec; be0 = cx.be0; be1 = cx.be1; covered = cx.covered; brackets = cx.brackets;
-        levelset = brackets > 0 ? 1ull : 0ull;                  // (every strand on level 1)
-        lo = e.nstrand;                                        // the walk below has nothing left to do
-#endif
-    }
-    for (int k = lo; k < e.nstrand;) {                         // closed form of the walk :665-689
-        const SqStrand x = e.S[k];
-        if (x.start >= sb) break;
-        int nk = k + 1;
-        const int pfirst = x.pstart, plast = x.pstart - (x.len - 1);
-        bool wing;
-        if (x.left) {
-            wing = pfirst > sb;
-            if (!wing && pfirst > inblockend) {                 // :687-689 sub-ECR face
-                if (nrec == 0) { be0 = x.start; be1 = pfirst; }
-                nrec++;
-                const int from = x.start > inblockend ? x.start : inblockend + 1;
-                covered += e.U[pfirst + 1] - e.U[from];
-                inblockend = pfirst;
-                if (e.have_skip) nk = e.skip[k];                // nothing inside the block can matter
-            }
-        } else {
-            wing = plast < sa;
-        }
-        if (wing && x.start > inblockend) {                     // :679-684
-            brackets += x.len;
-            if (x.level > SQ_MAXLEVELS) e.ctr->level_ovf = 1;
-            else levelset |= 1ull << (x.level - 1);
-        }
-        k = nk;
-    }
-#ifdef SQ_CTX_CHECK
-    if (e.use_ctx && (cx.nrec != nrec || cx.covered != covered || cx.brackets != brackets ||
-                    (nrec == 1 && (cx.be0 != be0 || cx.be1 != be1)) || (levelset != (brackets > 0 ? 1ull : 0ull))))
-        printf("CTX MISMATCH struct %d cand (%d,%d,%d) nstrand %d: walk nrec %d cov %d br %d be %d %d | ctx nrec %d cov %d br %d be %d %d\n",
-               (int)blockIdx.x, i0, j0, L, e.nstrand, nrec, covered, brackets, be0, be1, cx.nrec, cx.covered, cx.brackets, cx.be0, cx.be1);
-#endif
-    const int dots = (e.U[sb] - e.U[sa + 1]) - covered;             // :670-673
-    const bool between = (e.SU[sb] - e.SU[sa + 1]) > 0;             // :675-676
-    bool goodloop = false; int diff1 = 0;                       // :692-698
-    if (nrec == 1 && sq_goodloop(be0 - sa - 1, sb - be1 - 1)) {
-        goodloop = true;
-        diff1 = abs((be0 - sa - 1) - (sb - be1 - 1));
-    }
-    bool goodloopout = false; int diff2 = 0;                    // :700-711
-    {
-        // the two outward walks over <= 5 unpaired positions (:702-707), from the prefix counts: the k
-        // positions next to the stem are all unpaired iff the count over them is k -- ten independent
-        // reads instead of two chains of dependent ones
-        const int ui = e.U[i0], uj = e.U[j0 + 1];
-        int cl = 0, cr = 0;
-#pragma unroll
-        for (int k = 1; k <= 5; k++) {
-            const int a1 = i0 - k, b1 = j0 + 1 + k;
-            cl += (a1 >= 0 && ui - e.U[a1 >= 0 ? a1 : 0] == k) ? 1 : 0;
-            cr += (b1 <= e.n && e.U[b1 <= e.n ? b1 : e.n] - uj == k) ? 1 : 0;
-        }
-        const int vv = i0 - 1 - cl, ww = j0 + 1 + cr;
-        if (vv >= 0 && ww < e.n && e.P[vv] == ww && sq_goodloop(cl, cr)) {
-            goodloopout = true;
-            diff2 = abs(cl - cr);
-        }
-    }
-    const double lb = e.lb;
-    const double loopfactor = (1.0 + (lb * (goodloop ? 1.0 : 0.0)) * (2.0 - diff1 / 2.0))
-                              + (lb * (goodloopout ? 1.0 : 0.0)) * (2.0 - diff2 / 2.0);   // :715
-    bool gnra = false;                                          // :598-604,718
-    if (sb - sa - 1 == 4 && e.codes[sa + 1] == 6 && (e.codes[sa + 3] == 6 || e.codes[sa + 3] == 0) && e.codes[sa + 4] == 0)
-        gnra = true;
-    const double tetra = gnra ? 1.25 : 1.0;
-    const double ideal = nrec == 0 ? 4.0 : 2.0;                 // :721
-    const double stemdist = (double)dots + e.bw * (double)brackets;   // :723
-    const double dd = fabs(stemdist - ideal);
-    double sdf = 1.0;                                           // :726
-    if (!between) {
-        const int di = (int)dd;
-        if (e.bwint && di < e.sdflen) sdf = e.sdf[di];
-        else sdf = pow(1.0 / (1.0 + dd), e.dc);
-    }
-    const double of = e.of[__popcll(levelset)];            // :728-729
-    fin = bps * sdf * of * loopfactor * tetra;                  // :732 (reactfactor == 1)
-    if (!goodloop && !goodloopout && L < 3) fin = -1.0;         // :744-745
-    return fin;
-}
+#include "sq_score.h"
 
 #ifndef SQ_DIAG_TOGETHER
 #define SQ_DIAG_TOGETHER 2        // candidates of a chunk whose first cells are read together (alignment step 2)

@@ -1,0 +1,72 @@
+// sq_rounds.h -- the persistent round kernel of width-1 pools (sq_rounds.hip): records, launch arguments, LDS layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sq_device.h"
+
+// One maximal run of pairable cells on an anti-diagonal of a structure's masked matrix (a candidate stem of
+// AnnotateStems, SQRNdbnseq.py:405-418) with its exact bpscore.  A structure's list lives in its slice of the candidate
+// arena (two buffers of cand_cap records: the slice's cand_cap 32-byte units).
+struct SqRun {
+    uint32_t key;     // (s << 16) | i_outer, s = i + j: the reference's emission order
+    uint32_t len;
+    double bps;       // sum of the cells outer -> inner from int 0 (:416); NaN: not computed yet (the first round's scan)
+};
+
+#ifndef SQ_ROUNDS_CHUNK
+#define SQ_ROUNDS_CHUNK 2          // runs per thread and chunk of the scoring pass
+#endif
+#define SQ_ROUNDS_STAGE 128        // runs a wave of the first round's scan stages in LDS before it appends them
+#define SQ_ROUNDS_MAXN 8192        // longest sequence whose per-position arrays the kernel keeps in LDS (9 bytes each)
+#define SQ_ROUNDS_THREADS 256      // widest block
+
+struct SqRoundsArgs {
+    int32_t lds_n;          // longest sequence of the launch
+    int32_t str_cap;        // strands per structure the LDS lists hold (2 x the most stems a structure of the launch can have + 2)
+    int32_t tmax;           // most stems per structure (level scratch, sq_extend.h)
+    int32_t cell_entries;   // doubles of the cell table (largest (classes x reactivity levels)^2 of the batch, padded)
+    int32_t bound;          // branch and bound on the finalscore (0: every survivor of :492 is scored)
+    int32_t ctx_min;        // strands from which a non-crossing structure's sweep is answered from the context tables (0: never)
+};
+
+// dynamic LDS of a block: per-position arrays, free-position words of the first round's scan, cell table, two strand
+// lists + stem indices, skip pointers, and one region shared by the phases that never overlap (scan staging / level
+// scratch of the extension / survivor list of the scoring pass)
+struct SqRoundsLds {
+    int np, fbh;
+    int off_P, off_U, off_SU, off_E, off_ci, off_code, off_fg, off_cell, off_str, off_sidx, off_skip, off_union;
+    int surv_cap;           // entries of the survivor list
+    size_t total;
+};
+__host__ __device__ inline SqRoundsLds sq_rounds_lds(int lds_n, int str_cap, int tmax, int cell_entries, int threads)
+{
+    SqRoundsLds L;
+    L.np = (lds_n + 8) & ~7;                                   // arrays of n + 1 entries
+    L.fbh = ((lds_n + 2 + 31) >> 5) + 8;                       // words of either free-position array (as SqState::fbstride / 2)
+    int o = 0;
+    L.off_P = o; o += 2 * L.np;
+    L.off_U = o; o += 2 * L.np;
+    L.off_SU = o; o += 2 * L.np;
+    L.off_E = o; o += L.np;
+    L.off_ci = o; o += L.np;
+    L.off_code = o; o += L.np;
+    L.off_fg = o; o += 8 * L.fbh;
+    o = (o + 15) & ~15;
+    L.off_cell = o; o += 8 * cell_entries;
+    o = (o + 15) & ~15;
+    L.off_str = o; o += 2 * str_cap * (int)sizeof(SqStrand);
+    L.off_sidx = o; o += 2 * str_cap * 2;
+    L.off_skip = o; o += str_cap * 2;
+    o = (o + 15) & ~15;
+    L.off_union = o;
+    L.surv_cap = (SQ_ROUNDS_CHUNK + 1) * threads;
+    size_t u = (size_t)14 * L.surv_cap;
+    const size_t ext = sq_extend_lds_bytes(tmax);
+    const size_t stage = (size_t)(threads / 64) * (SQ_ROUNDS_STAGE * 8 + 16);
+    if (ext > u) u = ext;
+    if (stage > u) u = stage;
+    L.total = (size_t)o + ((u + 15) & ~(size_t)15);
+    return L;
+}
+
+extern "C" __global__ void sq_rounds_kernel(SqDevCtx c, SqStruct *structs, SqScanArgs a, SqChainIO cio, SqRoundsArgs ra);

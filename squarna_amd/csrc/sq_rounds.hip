@@ -1,0 +1,495 @@
+// sq_rounds.hip -- a-7 for width-1 pools (poollim == 1, SQRNdbnseq.py:1102-1199) as ONE launch per fold: a persistent
+// block per structure that loops over its own rounds.
+//
+// With a pool limit of one a structure has exactly one child per round -- parent + the first stem of ChooseStems
+// (:754-789) -- and no structure ever looks at another.  The launched form (sq_chain.hip) still ran every round as
+// six launches over ALL structures: state, context, scan, score, chain, done; every round as slow as its slowest
+// structure, every kernel re-reading what the previous one wrote.  Here a block owns its structure from the empty one
+// to the final one:
+//
+//   * the structure's state (partner array, prefix counts of unpaired positions, sorted strands with their levels)
+//     lives in LDS for the whole fold and is updated in place when a stem is chosen;
+//   * AnnotateStems (:427-495) runs as a bit-diagonal scan (sq_scan.h) ONCE, for the empty structure.  Choosing a
+//     stem only ever masks rows and columns (:446-451), so the maximal runs of a later round are exactly the pieces the
+//     newly paired positions leave of the previous round's runs: the block keeps its list of runs (key, length, exact
+//     bpscore) in its slice of the candidate arena and cuts it against the two strands of the new stem -- O(runs) per
+//     round instead of O(N^2 / 32) words, no bit matrix read after the first round.  (A live restraint pair keeps its cell
+//     while both ends are unpaired, :438-443; pairing an end masks it like any other cell: the same monotone rule.)
+//     The bpscore of a piece is summed anew from its cells, outer -> inner from int 0 (:416), from the LDS cell table;
+//   * ScoreStems (:607-751) on the runs that pass :492, behind the same branch and bound as sq_score_kernel; the best
+//     finalscore with the smallest emission key among equals is ChooseStems' first element (:758 stable sort);
+//   * the extension (crossing weights, pseudoknot levels, sorted strand list: sq_extend.h) by the block's first wave,
+//     retirement (no stem left :1192-1193, maxstemnum :1168-1174) with the same records sq_chain_kernel writes.
+//
+// Results are those of the launched rounds bit for bit (tests fold both ways: SQ_NO_ROUNDS); what the kernel does not
+// take (jobs with dense matrices, sequences beyond SQ_ROUNDS_MAXN) keeps the launched form.
+#include <hip/hip_runtime.h>
+#include "sq_device.h"
+
+// LDS operations of one wave execute in program order; this keeps the compiler from moving them across the point
+__device__ __forceinline__ void sq_wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+#define SQ_EXTEND_SYNC() sq_wave_lds_fence()      // (the extension runs on the first wave of a wider block)
+#include "sq_extend.h"
+#include "sq_tail_dev.h"
+#include "sq_cells.h"
+#include "sq_score.h"
+#include "sq_scan.h"
+#include "sq_rounds.h"
+
+// the first round's scan: every wave stages its runs in its own LDS buffer and appends them to the block's list
+struct SqRoundsSink {
+    uint2 *stage; uint32_t *cnt;             // this wave's staging buffer and fill count (LDS)
+    uint32_t *nlist;                         // the block's list length (LDS)
+    SqRun *list; uint32_t cap; SqCounters *ctr;
+    __device__ __forceinline__ void put(uint32_t pos, uint32_t key, uint32_t len)
+    {
+        if (pos < cap) list[pos] = SqRun{key, len, __longlong_as_double(0x7FF8000000000000ll)};
+        else ctr->cand_ovf = 1;
+    }
+    __device__ __forceinline__ void emit(uint32_t key, uint32_t len)
+    {
+        const uint32_t slot = atomicAdd(cnt, 1u);
+        if (slot < SQ_ROUNDS_STAGE) stage[slot] = make_uint2(key, len);
+        else put(atomicAdd(nlist, 1u), key, len);
+    }
+    __device__ __forceinline__ void flush(int lane)
+    {
+        sq_wave_lds_fence();
+        uint32_t n = *cnt;
+        if (n > SQ_ROUNDS_STAGE) n = SQ_ROUNDS_STAGE;
+        if (n) {
+            uint32_t b0 = 0;
+            if (lane == 0) b0 = atomicAdd(nlist, n);
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+            for (uint32_t k = lane; k < n; k += 64) put(base + k, stage[k].x, stage[k].y);
+        }
+        sq_wave_lds_fence();
+        if (lane == 0) *cnt = 0;
+        sq_wave_lds_fence();
+    }
+    __device__ __forceinline__ void poll(int lane) { sq_wave_lds_fence(); if (*cnt > SQ_ROUNDS_STAGE / 2) flush(lane); }
+    __device__ __forceinline__ void drain(int lane) { flush(lane); }
+};
+
+extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel(SqDevCtx c, SqStruct *structs, SqScanArgs a, SqChainIO cio,
+                                                                                 SqRoundsArgs ra)
+{
+    extern __shared__ __attribute__((aligned(16))) char rd_dyn[];
+    __shared__ int s_wave_u[SQ_ROUNDS_THREADS / 64], s_wave_s[SQ_ROUNDS_THREADS / 64];
+    __shared__ uint32_t s_nlist, s_nsurv, s_lmask;
+    __shared__ unsigned long long s_best;
+    __shared__ uint8_t s_cls[32];
+    __shared__ double s_rv[16];
+    __shared__ double s_wfin[SQ_ROUNDS_THREADS / 64], s_wbps[SQ_ROUNDS_THREADS / 64];
+    __shared__ uint32_t s_wkey[SQ_ROUNDS_THREADS / 64], s_wlen[SQ_ROUNDS_THREADS / 64];
+    __shared__ int s_wany[SQ_ROUNDS_THREADS / 64];
+    __shared__ int s_cross;
+
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+    const int b = blockIdx.x;
+    const SqStruct st = structs[b];
+    if (st.nstrand < 0) return;
+    const SqChain ch = cio.chain[b];
+    const SqJob jb = c.jobs[st.job];
+    const SqPsetDev *ps = c.psets + jb.pset;
+    const int n = jb.n;
+    const SqRoundsLds Lo = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, nthr);
+    int16_t *const P = reinterpret_cast<int16_t *>(rd_dyn + Lo.off_P);
+    int16_t *const U = reinterpret_cast<int16_t *>(rd_dyn + Lo.off_U);
+    int16_t *const SU = reinterpret_cast<int16_t *>(rd_dyn + Lo.off_SU);
+    uint8_t *const E = reinterpret_cast<uint8_t *>(rd_dyn + Lo.off_E);
+    uint8_t *const l_ci = reinterpret_cast<uint8_t *>(rd_dyn + Lo.off_ci);
+    uint8_t *const l_code = reinterpret_cast<uint8_t *>(rd_dyn + Lo.off_code);
+    uint32_t *const FG = reinterpret_cast<uint32_t *>(rd_dyn + Lo.off_fg);
+    double *const s_cell = reinterpret_cast<double *>(rd_dyn + Lo.off_cell);
+    SqStrand *const strbuf = reinterpret_cast<SqStrand *>(rd_dyn + Lo.off_str);
+    int16_t *const sidxbuf = reinterpret_cast<int16_t *>(rd_dyn + Lo.off_sidx);
+    uint16_t *const s_skip = reinterpret_cast<uint16_t *>(rd_dyn + Lo.off_skip);
+    char *const uni = rd_dyn + Lo.off_union;
+    const int str_cap = ra.str_cap;
+
+    auto retire = [&](int nstems, int by_count) {           // the records sq_chain_kernel writes (sq_chain.hip)
+        if (tid == 0) {
+            structs[b].nstrand = -1;
+            const uint32_t idx = atomicAdd(cio.d_nfin, 1u);
+            cio.h_fin[idx] = (unsigned long long)(uint32_t)st.job | ((unsigned long long)(uint32_t)nstems << 32) |
+                             ((unsigned long long)(by_count ? 1 : 0) << 63);
+            const uint32_t li = atomicAdd(&cio.fin_ctr[0], 1u);
+            if (li < cio.fin_cap) cio.fin[li] = SqPoolFin{st.job, SQ_FIN_KIND_G0, 0, nstems, (uint32_t)ch.toff, SQ_FIN_SRC_CHAIN};
+            else cio.fin_ctr[2] = 1;
+            cio.job_evals[st.job] = (long long)nstems + (by_count ? 0 : 1);
+        }
+    };
+
+    // ---- once per fold: letter classes, the cell table (as sq_score_kernel builds them per round), the empty structure ----
+    if (tid < 64) {
+        uint32_t any8 = 0;
+        if (tid < 32) {
+            const uint32_t *ib = reinterpret_cast<const uint32_t *>(ps->inbps) + tid * 8;
+#pragma unroll
+            for (int q = 0; q < 8; q++) any8 |= ib[q];
+        }
+        const unsigned long long bal = __ballot(any8 != 0);
+        if (tid == 0) { s_lmask = (uint32_t)bal; s_nlist = 0; }
+    }
+    __syncthreads();
+    const uint32_t lmask = s_lmask;
+    const int K = __popc(lmask) + 1;
+    const bool any_reacts = !jb.default_reacts;
+    const bool react_tab = any_reacts && jb.react_levels > 0 && K * jb.react_levels <= 32;
+    const int R = react_tab ? jb.react_levels : 1;
+    const int KR = K * R, cstride = KR | 1;
+    const bool cell_tab = jb.default_reacts || react_tab;           // the table holds the final cell value
+    if (tid < 32) s_cls[tid] = (lmask >> tid) & 1u ? (uint8_t)__popc(lmask & ((1u << tid) - 1u)) : (uint8_t)(K - 1);
+    if (react_tab)
+        for (int p = tid; p < n; p += nthr) s_rv[c.ridx[jb.pos_off + p]] = c.reacts[jb.pos_off + p];
+    __syncthreads();
+    {
+        const uint8_t *e0 = c.e0c + jb.pos_off;
+        for (int p = tid; p < n; p += nthr) {
+            const uint8_t code = c.codes[jb.pos_off + p];
+            const int cl = s_cls[code & 31];
+            l_code[p] = code;
+            l_ci[p] = (uint8_t)(react_tab ? cl * R + c.ridx[jb.pos_off + p] : cl);
+            P[p] = -1; E[p] = e0[p];
+        }
+        for (int e = tid; e < KR * KR; e += nthr) {
+            const int ci = e / KR, cj = e - ci * KR;
+            const int ca = ci / R, cb = cj / R;
+            int la, lb;
+            {
+                uint32_t m = lmask; for (int t = 0; t < ca && m; t++) m &= m - 1;
+                la = ca < K - 1 ? __ffs((int)m) - 1 : -1;
+                m = lmask; for (int t = 0; t < cb && m; t++) m &= m - 1;
+                lb = cb < K - 1 ? __ffs((int)m) - 1 : -1;
+            }
+            const double w = (la >= 0 && lb >= 0) ? ps->w[la * 32 + lb] : 0.0;
+            double v = w;
+            if (react_tab) {
+                double rf = jb.rf_idx >= 0 ? c.rftab[(int64_t)jb.rf_idx * 256 + (ci - ca * R) * 16 + (cj - cb * R)]
+                                           : sqrt((1.0 - (s_rv[ci - ca * R] + s_rv[cj - cb * R]) / 2.0) * 2.0);
+                if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
+                v = w * rf;
+            }
+            s_cell[ci * cstride + cj] = v;
+        }
+    }
+    __syncthreads();
+
+    // exclusive prefix counts of unpaired positions (U) and unpaired separators (SU) from P (sq_state_build's scan)
+    auto prefix_counts = [&]() {
+        int base_u = 0, base_s = 0;
+        for (int p0 = 0; p0 < n; p0 += nthr) {
+            const int p = p0 + tid;
+            const bool un = p < n && P[p] == -1;
+            const bool us = un && (l_code[p] == 26 || l_code[p] == 27);
+            const unsigned long long mu = __ballot(un), ms = __ballot(us);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (lane == 0) { s_wave_u[wv] = __popcll(mu); s_wave_s[wv] = __popcll(ms); }
+            __syncthreads();
+            int pu = base_u + __popcll(mu & below), pS = base_s + __popcll(ms & below);
+            for (int q = 0; q < wv; q++) { pu += s_wave_u[q]; pS += s_wave_s[q]; }
+            if (p < n) { U[p] = (int16_t)pu; SU[p] = (int16_t)pS; }
+            for (int q = 0; q < nwv; q++) { base_u += s_wave_u[q]; base_s += s_wave_s[q]; }
+            __syncthreads();
+        }
+        if (tid == 0) { U[n] = (int16_t)base_u; SU[n] = (int16_t)base_s; }
+        __syncthreads();
+    };
+    prefix_counts();
+
+    const int cap = jb.cand_cap;
+    SqRun *const listA = reinterpret_cast<SqRun *>(a.cands + st.cand_off), *const listB = listA + cap;
+    const int minlen = max(1, (int)ceil(ps->minlen));
+
+    // ---- the first round's AnnotateStems: bit-diagonal scan of the empty structure into listB ----
+    if (n >= 5) {                                                   // :456-457 (shorter sequences have no diagonals)
+        const int fbh = Lo.fbh;
+        for (int m2 = wv; 2 * m2 < fbh; m2 += nwv) {                // free-position words, forward and reversed (sq_state_build)
+            const int pf = 64 * m2 + lane;
+            const unsigned long long bf = __ballot(pf < n && E[pf] == 0);
+            const int pr = n - 1 - (64 * m2 + lane - SQ_GPAD);
+            const unsigned long long br = __ballot(pr >= 0 && pr < n && E[pr] == 0);
+            if (lane == 0) {
+                FG[2 * m2] = (uint32_t)bf; FG[fbh + 2 * m2] = (uint32_t)br;
+                if (2 * m2 + 1 < fbh) { FG[2 * m2 + 1] = (uint32_t)(bf >> 32); FG[fbh + 2 * m2 + 1] = (uint32_t)(br >> 32); }
+            }
+        }
+        uint32_t *const wcnt = reinterpret_cast<uint32_t *>(uni) + 4 * wv;
+        uint2 *const wstage = reinterpret_cast<uint2 *>(uni + 16 * nwv) + (size_t)wv * SQ_ROUNDS_STAGE;
+        if (lane == 0) *wcnt = 0;
+        __syncthreads();
+        SqRoundsSink sink{wstage, wcnt, &s_nlist, listB, (uint32_t)cap, a.ctr};
+        sq_scan6_groups(c, jb, FG, FG + fbh, fbh, E, wv, nwv, lane, sink);
+    }
+    __syncthreads();
+    uint32_t ncur = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;
+    __syncthreads();
+
+    // ---- the cells of a run, exactly (sq_score_kernel's forms) ----
+    auto cell_exact = [&](int i, int j) -> double {
+        const double w = s_cell[l_ci[i] * cstride + l_ci[j]];
+        if (cell_tab) return w;
+        double rf;
+        if (jb.rf_idx >= 0) rf = sq_reactfactor(c, jb, i, j);
+        else {
+            const double ri = c.reacts[jb.pos_off + i], rj = c.reacts[jb.pos_off + j];
+            rf = sqrt((1.0 - (ri + rj) / 2.0) * 2.0);
+        }
+        if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
+        return w * rf;
+    };
+    const uint32_t *l_ciw = reinterpret_cast<const uint32_t *>(l_ci);
+    auto cells4 = [&](int i, int j, int nv, double (&v)[4]) {
+        const int q = j - 3;
+        const uint32_t a0 = l_ciw[i >> 2], a1 = l_ciw[(i >> 2) + 1], b0 = l_ciw[q >> 2], b1 = l_ciw[(q >> 2) + 1];
+        uint32_t xi = __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)(i & 3));
+        uint32_t xj = __builtin_amdgcn_alignbyte(b1, b0, (uint32_t)(q & 3));
+        if (nv < 4) {
+            xi &= (1u << (8 * nv)) - 1u;
+            xj &= ~((1u << (8 * (4 - nv))) - 1u);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = s_cell[((xi >> (8 * k)) & 255u) * cstride + ((xj >> (8 * (3 - k))) & 255u)];
+    };
+    auto run_bps = [&](int i0, int j0, int L) -> double {      // sum(...) left to right from int 0 (:416)
+        double acc = 0.0;
+        for (int t = 0; t < L; t += 4) {
+            double v[4];
+            if (cell_tab && j0 - t >= 3) cells4(i0 + t, j0 - t, min(4, L - t), v);
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int tt = t + k < L ? t + k : L - 1;
+                    v[k] = cell_exact(i0 + tt, j0 - tt);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc = acc + (t + k < L ? v[k] : 0.0);
+        }
+        return acc;
+    };
+
+    const double minbps = ps->minbpscore, minfin = ps->minfinscore;
+    const double ps_lb = ps->loopbonus, ps_bw = ps->bracketweight, ps_dc = ps->distcoef;
+    const int ps_bwint = ps->bw_integral, ps_sdflen = ps->sdf_len;
+    const double *const ps_sdf = c.sdftab + ps->sdf_off;
+    const double *const ps_of = ps->oftab;
+    const double ub_of = ps->ub_of, ub_lf = ra.bound ? ps->ub_lf : INFINITY;
+    auto upper = [&](double bps) -> double { return bps >= 0 ? (((bps * ub_of) * ub_lf) * 1.25) * (1.0 + 0x1p-30) : INFINITY; };
+    const double st_subopt = st.subopt;
+    // a piece of a run never scores more than the run when no cell is negative: such lists only keep what passes :492
+    bool droppable;
+    {
+        int neg = 0;
+        for (int e = tid; e < KR * KR; e += nthr) neg |= s_cell[(e / KR) * cstride + (e % KR)] < 0.0 ? 1 : 0;
+        droppable = __syncthreads_or(neg) == 0 && cell_tab;
+    }
+
+    double *const s_bps = reinterpret_cast<double *>(uni);
+    uint32_t *const s_key = reinterpret_cast<uint32_t *>(s_bps + Lo.surv_cap);
+    uint16_t *const s_len = reinterpret_cast<uint16_t *>(s_key + Lo.surv_cap);
+
+    int nstems = 0, nstrand = 0, cursb = 0;
+    bool anycross = false;
+    int za0 = 1, za1 = 0, zb0 = 1, zb1 = 0;                             // the two strands of the stem chosen last
+    SqRun *cur = listB, *nxt = listA;
+    SqChainStem *const gst = cio.stems + ch.toff;
+
+    for (int round = 0;; round++) {
+        // ---- the runs of this round: the pieces the new stem's strands leave of the previous round's runs ----
+        if (round > 0) {
+            if (tid == 0) s_nlist = 0;
+            __syncthreads();
+            for (uint32_t q0 = 0; q0 < ncur; q0 += nthr) {
+                const uint32_t q = q0 + tid;
+                const SqRun r = q < ncur ? cur[q] : SqRun{0u, 0u, 0.0};
+                const int L = (int)r.len, i = (int)(r.key & 0xFFFFu), s = (int)(r.key >> 16), j = s - i;
+                // cell t of the run: row i + t, column j - t; masked when either lies on a strand [za0, za1] or [zb0, zb1]
+                const int lo0 = za0 - i, hi0 = za1 - i, lo1 = zb0 - i, hi1 = zb1 - i, lo2 = j - za1, hi2 = j - za0, lo3 = j - zb1, hi3 = j - zb0;
+                const bool hit = L > 0 && ((lo0 < L && hi0 >= 0) || (lo1 < L && hi1 >= 0) || (lo2 < L && hi2 >= 0) || (lo3 < L && hi3 >= 0));
+                int t0 = 0;
+                while (__ballot(t0 < L) != 0ull) {
+                    bool valid = t0 < L;
+                    int pb = t0, pe = L;
+                    if (valid && hit) {
+#pragma unroll
+                        for (int rep = 0; rep < 4; rep++) {
+                            if (pb >= lo0 && pb <= hi0) pb = hi0 + 1;
+                            if (pb >= lo1 && pb <= hi1) pb = hi1 + 1;
+                            if (pb >= lo2 && pb <= hi2) pb = hi2 + 1;
+                            if (pb >= lo3 && pb <= hi3) pb = hi3 + 1;
+                        }
+                        if (lo0 > pb && lo0 < pe) pe = lo0;
+                        if (lo1 > pb && lo1 < pe) pe = lo1;
+                        if (lo2 > pb && lo2 < pe) pe = lo2;
+                        if (lo3 > pb && lo3 < pe) pe = lo3;
+                        if (pb >= L) { valid = false; pe = L; }
+                    }
+                    t0 = valid ? pe : L;
+                    const int plen = pe - pb;
+                    valid = valid && plen >= minlen;
+                    double bps = r.bps;
+                    if (valid && (plen != L || !(bps == bps))) bps = run_bps(i + pb, j - pb, plen);
+                    const bool keep = valid && (!droppable || bps >= minbps);
+                    const unsigned long long km = __ballot(keep);
+                    if (km) {
+                        uint32_t base = 0;
+                        const int leader = __ffsll((long long)km) - 1;
+                        if (lane == leader) base = atomicAdd(&s_nlist, (uint32_t)__popcll(km));
+                        base = (uint32_t)__shfl((int)base, leader);
+                        if (keep) {
+                            const uint32_t pos = base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                            if (pos < (uint32_t)cap) nxt[pos] = SqRun{((uint32_t)s << 16) | (uint32_t)(i + pb), (uint32_t)plen, bps};
+                            else a.ctr->cand_ovf = 1;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            ncur = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;
+            SqRun *t = cur; cur = nxt; nxt = t;
+            __threadfence_block();                                  // (the scoring pass reads what the block just wrote)
+            __syncthreads();
+        }
+
+        // ---- ScoreStems on the runs that pass :492; the best finalscore, the smallest key among equals ----
+        if (tid == 0) { s_nsurv = 0; s_best = 0ull; }
+        const SqStrand *const S = strbuf + cursb * str_cap;
+        const SqStemsEnv env = {S, s_skip, nstrand, true, P, U, SU, l_code, n, false, nullptr, nullptr, nullptr, 0,
+                                ps_lb, ps_bw, ps_dc, ps_bwint, ps_sdflen, ps_sdf, ps_of, a.ctr};
+        __syncthreads();
+        double bfin = 0.0, bbps = 0.0; uint32_t bkey = 0, blen = 0; int bany = 0;
+        for (uint32_t q0 = 0; q0 < ncur; q0 += SQ_ROUNDS_CHUNK * nthr) {
+            double need = minfin;
+            {
+                const unsigned long long sb = s_best;
+                if (sb) { const double r = st_subopt * sq_unord(sb); need = r > need ? r : need; }
+            }
+#pragma unroll
+            for (int u = 0; u < SQ_ROUNDS_CHUNK; u++) {
+                const uint32_t q = q0 + (uint32_t)u * nthr + tid;
+                SqRun r = q < ncur ? cur[q] : SqRun{0u, 0u, 0.0};
+                const int L = (int)r.len;
+                if (L > 0 && !(r.bps == r.bps)) {                   // the first round: the scan left the bpscore open
+                    const int i = (int)(r.key & 0xFFFFu), j = (int)(r.key >> 16) - i;
+                    r.bps = run_bps(i, j, L);
+                    cur[q].bps = r.bps;
+                }
+                const bool ok = L > 0 && r.bps >= minbps && !(upper(r.bps) < need);   // :492, and the bound
+                const unsigned long long okm = __ballot(ok);
+                if (okm) {
+                    uint32_t base = 0;
+                    const int leader = __ffsll((long long)okm) - 1;
+                    if (lane == leader) base = atomicAdd(&s_nsurv, (uint32_t)__popcll(okm));
+                    base = (uint32_t)__shfl((int)base, leader);
+                    if (ok) {
+                        const uint32_t pos = base + (uint32_t)__popcll(okm & ((1ull << lane) - 1ull));
+                        s_key[pos] = r.key; s_len[pos] = (uint16_t)L; s_bps[pos] = r.bps;
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t ns = s_nsurv;
+            const bool last = q0 + SQ_ROUNDS_CHUNK * nthr >= ncur;
+            uint32_t done = 0;
+            while (done + (uint32_t)nthr <= ns || (last && done < ns)) {
+                const uint32_t idx = done + tid;
+                done += nthr;
+                const bool have = idx < ns;
+                const uint32_t key = have ? s_key[idx] : 0u;
+                const int L = have ? (int)s_len[idx] : 0;
+                const double bps = have ? s_bps[idx] : 0.0;
+                const int s = (int)(key >> 16), i0 = (int)(key & 0xFFFFu), j0 = s - i0;
+                bool ok = have;
+                {
+                    const unsigned long long sbst = s_best;
+                    if (sbst && upper(bps) < st_subopt * sq_unord(sbst)) ok = false;
+                }
+                double fin = 0.0;
+                if (ok) {
+                    fin = sq_stem_finalscore(env, i0, j0, L, bps);
+                    ok = fin >= minfin;                                     // :751
+                }
+                if (ok && (!bany || fin > bfin || (fin == bfin && key < bkey))) { bany = 1; bfin = fin; bkey = key; blen = (uint32_t)L; bbps = bps; }
+                if (__ballot(ok) != 0ull) {
+                    double wb = ok ? fin : -INFINITY;
+                    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(wb, off); wb = o > wb ? o : wb; }
+                    if (lane == 0) atomicMax(&s_best, sq_ord(wb));
+                }
+            }
+            __syncthreads();
+            if (done == 0) continue;
+            const uint32_t rem = ns > done ? ns - done : 0u;                // < blockDim: carried to the next chunk
+            uint32_t ck = 0; uint16_t cl = 0; double cb = 0.0;
+            if ((uint32_t)tid < rem) { ck = s_key[done + tid]; cl = s_len[done + tid]; cb = s_bps[done + tid]; }
+            __syncthreads();
+            if ((uint32_t)tid < rem) { s_key[tid] = ck; s_len[tid] = cl; s_bps[tid] = cb; }
+            if (tid == 0) s_nsurv = rem;
+            __syncthreads();
+        }
+        // ---- ChooseStems' first element over the block ----
+        for (int off = 32; off > 0; off >>= 1) {
+            const double of = __shfl_xor(bfin, off), ob = __shfl_xor(bbps, off);
+            const uint32_t ok2 = (uint32_t)__shfl_xor((int)bkey, off), ol = (uint32_t)__shfl_xor((int)blen, off);
+            const int oa = __shfl_xor(bany, off);
+            if (oa && (!bany || of > bfin || (of == bfin && ok2 < bkey))) { bany = 1; bfin = of; bkey = ok2; blen = ol; bbps = ob; }
+        }
+        if (lane == 0) { s_wany[wv] = bany; s_wfin[wv] = bfin; s_wbps[wv] = bbps; s_wkey[wv] = bkey; s_wlen[wv] = blen; }
+        __syncthreads();
+        bany = 0;
+        for (int q = 0; q < nwv; q++)
+            if (s_wany[q] && (!bany || s_wfin[q] > bfin || (s_wfin[q] == bfin && s_wkey[q] < bkey))) {
+                bany = 1; bfin = s_wfin[q]; bkey = s_wkey[q]; blen = s_wlen[q]; bbps = s_wbps[q];
+            }
+        if (!bany) { retire(nstems, 0); return; }                   // :1192-1193 no new stem: the structure is final
+        const int i0 = (int)(bkey & 0xFFFFu), j0 = (int)(bkey >> 16) - i0, len = (int)blen;
+        const int k = nstems;
+        if (k >= ch.tcap) { if (tid == 0) a.ctr->out_ovf = 1; retire(k, 0); return; }
+        if (tid == 0) cio.h_stems[ch.toff + k] = SqStemOut{i0, j0, len, 0, bbps, bfin};
+        __syncthreads();                                            // (every thread has read the survivor list / wave bests)
+        // ---- the child: strands and levels by the first wave (sq_extend.h), the partner array by the others ----
+        const int nxtsb = cursb ^ 1;
+        if (wv == 0) {
+            SqExtendLds XL = sq_extend_lds(uni, ra.tmax);
+            const bool ac = sq_extend_structure(XL, a, gst, k, anycross, strbuf + cursb * str_cap, sidxbuf + cursb * str_cap, nstrand,
+                                                i0, j0, len, gst, strbuf + nxtsb * str_cap, sidxbuf + nxtsb * str_cap, lane);
+            if (lane == 0) s_cross = ac ? 1 : 0;
+        }
+        if (nwv == 1 || wv > 0) {
+            const int w0 = nwv == 1 ? 0 : wv - 1, wn = nwv == 1 ? 1 : nwv - 1;
+            for (int t = w0 * 64 + lane; t < len; t += wn * 64) {   // :634-635
+                P[i0 + t] = (int16_t)(j0 - t);
+                P[j0 - t] = (int16_t)(i0 + t);
+            }
+        }
+        __syncthreads();
+        anycross = s_cross != 0;
+        cursb = nxtsb; nstems = k + 1; nstrand += 2;
+        if ((double)nstems == ch.maxstems) { retire(nstems, 1); return; }   // :1168-1174 (checked before the next evaluation)
+        prefix_counts();
+        {
+            // skip pointers over the blocks ScoreStems' sweep registers (sq_score_kernel)
+            const SqStrand *const S2 = strbuf + cursb * str_cap;
+            for (int q = tid; q < nstrand; q += nthr) {
+                const SqStrand x = S2[q];
+                int z = q + 1;
+                if (x.left) {
+                    const int pf = x.pstart;
+                    while (z < nstrand) {
+                        const SqStrand y = S2[z];
+                        if (y.start > pf || (y.left && y.pstart > pf)) break;
+                        z++;
+                    }
+                }
+                s_skip[q] = (uint16_t)z;
+            }
+        }
+        za0 = i0; za1 = i0 + len - 1; zb0 = j0 - len + 1; zb1 = j0;
+        __syncthreads();
+    }
+}

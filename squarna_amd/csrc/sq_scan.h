@@ -1,0 +1,137 @@
+// sq_scan.h -- a-2  AnnotateStems as a bit-diagonal scan (SQRNdbnseq.py:427-495), shared by sq_scan6_kernel (launched
+// rounds) and the persistent round kernel (sq_rounds.hip: its first round).
+//
+// AnnotateStems only needs to know WHERE the unmasked cells are -- every candidate's score is recomputed exactly in
+// fp64 -- so the scan reads the job's diagonal bit matrix (sq_bits_*_kernel) instead of a score matrix:
+//   active(s, i) = base(s, i)  &  free[i]  &  free[s - i]       (+ the live restraint pairs)
+// One lane = one anti-diagonal, one loop step = 32 rows:
+//   base word   one coalesced 4-byte load per lane (64 consecutive diagonals = 256 B per wave);
+//   row word    wave-uniform LDS read of the free-position bit array F;
+//   column word a 32-bit window of the REVERSED array G (bit k <-> position n-1-k) starting at
+//               n-1-s+32w: it advances by exactly one word per step, so each step reads one new LDS
+//               word and funnel-shifts it against the previous one (v_alignbit);
+// and the runs of the 32 rows come out of the word with bit tricks (below).  Per structure the scan touches
+// N^2/16 bytes of (L2-resident) bits instead of 2 N^2 bytes of HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sq_internal.h"
+#include "sq_device.h"
+
+#ifndef SQ6_AHEAD
+#define SQ6_AHEAD 2
+#endif
+
+// One wave scans the diagonal groups gy0, gy0 + gystep, .. of a structure of job jb.  F / G: the structure's free-position
+// bit words (forward / reversed + SQ_GPAD, fbh words each, in LDS); eg: its mask codes per position (0 free, 1 end of a
+// live restraint pair, 255 paired).  Sink: where the runs of at least minlen cells go --
+//   emit(key, len)    from any lane, key = (s << 16) | first row;
+//   poll(lane)        after every word-row, all lanes (room to flush a staging buffer);
+//   drain(lane)       after every group of 64 diagonals, all lanes.
+template <class Sink>
+__device__ __forceinline__ void sq_scan6_groups(const SqDevCtx &c, const SqJob &jb, const uint32_t *F, const uint32_t *G, int fbh,
+                                                const uint8_t *eg, int gy0, int gystep, int lane, Sink &sink)
+{
+    const int n = jb.n;
+    const SqPsetDev *ps = c.psets + jb.pset;
+    const int minlen = max(1, (int)ceil(ps->minlen));
+    const int ngroups = ((2 * n - 5 + 63) >> 6) + 1;
+    for (int gy = gy0; gy < ngroups; gy += gystep) {
+        const int s0 = gy << 6;
+        const int smin = max(s0, 4), smax = min(s0 + 63, 2 * n - 6);        // :456-457 s in [4, 2N-6]
+        if (smin > smax) continue;
+        const int rmin = max(0, smin - (n - 1)), rmax = (smax - 1) >> 1;    // :486 i <= j-1
+        const int wlo = rmin >> 5, whi = rmax >> 5;
+        const int s = s0 + lane;
+        // window of the reversed array for (s, wlo): first bit n-1-s+32 wlo (+pad); lanes outside the valid
+        // diagonals have zero base words, their window only has to stay inside the array
+        const int q0 = min(max(n - 1 - s + 32 * wlo + SQ_GPAD, 0), 32 * (fbh - (whi - wlo) - 3));
+        const int gidx = q0 >> 5, gsh = q0 & 31;
+        // Restraint base pairs (:438-443: the cell of a restraint pair stays pairable while both ends are free).  The
+        // sequence's list is sorted by (i + j, i), so the pairs of this lane's diagonal are one run of it, in row order: two
+        // binary searches here, then a pointer that only moves forward as the rows go by.  Any number of pairs.
+        const uint32_t *rlist = c.rbpk + jb.rb_off;
+        int rp = 0, rend = 0;
+        if (jb.nrb) {
+            int lo = 0, hi = jb.nrb;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const uint32_t pk = rlist[mid];
+                if ((int)(pk & 0xFFFFu) + (int)(pk >> 16) < s) lo = mid + 1; else hi = mid;
+            }
+            rp = lo; hi = jb.nrb;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const uint32_t pk = rlist[mid];
+                if ((int)(pk & 0xFFFFu) + (int)(pk >> 16) <= s) lo = mid + 1; else hi = mid;
+            }
+            rend = lo;
+        }
+        const uint32_t *bp = c.bits + jb.bits_off + s;
+        const int bpitch = jb.bpitch;
+
+        int carry = 0;
+        uint32_t glo = G[gidx];
+        // window of minlen ones by doubling: Y &= Y >> ysh_q, five fixed steps (shift 0 once the window is complete)
+        int ysh0, ysh1, ysh2, ysh3, ysh4;
+        {
+            const int want = minlen < 32 ? minlen : 32;
+            int have = 1;
+            ysh0 = min(have, want - have); have += ysh0;
+            ysh1 = min(have, want - have); have += ysh1;
+            ysh2 = min(have, want - have); have += ysh2;
+            ysh3 = min(have, want - have); have += ysh3;
+            ysh4 = min(have, want - have);
+        }
+        // SQ6_AHEAD word-rows per trip: their (independent) loads are issued together, so a wave waits for HBM / L2 once
+        // per group instead of once per word (a single word of look-ahead did not survive the compiler's wait counts)
+        for (int w0 = wlo; w0 <= whi; w0 += SQ6_AHEAD) {
+            uint32_t bw[SQ6_AHEAD];
+#pragma unroll
+            for (int k = 0; k < SQ6_AHEAD; k++) bw[k] = w0 + k <= whi ? bp[(int64_t)(w0 + k) * bpitch] : 0u;
+#pragma unroll
+            for (int k = 0; k < SQ6_AHEAD; k++) {
+                const int w = w0 + k;
+                if (w > whi) break;
+                const uint32_t base = bw[k];
+                const uint32_t ghi = G[gidx + 1 + (w - wlo)];
+                const uint32_t gw = __builtin_amdgcn_alignbit(ghi, glo, gsh);   // columns s-32w-b, b = 0..31
+                glo = ghi;
+                uint32_t A = base & F[w] & gw;                              // :438-451 free row and column
+                while (rp < rend) {                                         // (no lane enters without restraint pairs on its diagonal)
+                    const uint32_t pk = rlist[rp];
+                    const int v = (int)(pk & 0xFFFFu);
+                    if ((v >> 5) > w) break;
+                    if ((v >> 5) == w && eg[v] == 1 && eg[pk >> 16] == 1) A |= base & (1u << (v & 31));   // :438-443 restraint bp stays pairable
+                    rp++;
+                }
+                // maximal runs of the word (bit b = row 32w + b; `carry` rows of an open run precede row 32w)
+                if (__ballot((A != 0u) | (carry > 0)) != 0ull) {
+                    if (A == 0xFFFFFFFFu) carry += 32;
+                    else {
+                        const int lead = __ffs((int)~A) - 1;                // the run that continues the carried one (maybe empty)
+                        const int len0 = carry + lead;
+                        if (len0 >= minlen) sink.emit(((uint32_t)s << 16) | (uint32_t)(32 * w - carry), (uint32_t)len0);
+                        const int trail = __clz((int)~A);                   // the run still open at row 32w + 31
+                        carry = trail;
+                        // runs strictly inside: starts with a full window of minlen ones above them
+                        uint32_t rest = A & ~((1u << lead) - 1u);
+                        if (trail) rest &= 0xFFFFFFFFu >> trail;
+                        uint32_t Y = rest;
+                        Y &= Y >> ysh0; Y &= Y >> ysh1; Y &= Y >> ysh2; Y &= Y >> ysh3; Y &= Y >> ysh4;
+                        uint32_t starts = rest & ~(rest << 1) & Y;
+                        while (starts) {
+                            const int p = __ffs((int)starts) - 1;
+                            starts &= starts - 1;
+                            const int len = __ffs((int)~(rest >> p)) - 1;
+                            sink.emit(((uint32_t)s << 16) | (uint32_t)(32 * w + p), (uint32_t)len);
+                        }
+                    }
+                } else
+                    carry = 0;
+                sink.poll(lane);
+            }
+        }
+        if (carry >= minlen) sink.emit(((uint32_t)s << 16) | (uint32_t)(32 * (whi + 1) - carry), (uint32_t)carry);
+        sink.drain(lane);
+    }
+}

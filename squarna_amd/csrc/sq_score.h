@@ -1,0 +1,127 @@
+// sq_score.h -- ScoreStems (SQRNdbnseq.py:607-751) for ONE candidate stem, as a closed form over the structure's sorted
+// strands: shared by the scoring kernel of the launched rounds (sq_kernels.hip) and the persistent round kernel
+// (sq_rounds.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sq_internal.h"
+#include "sq_device.h"
+#include "sq_context.h"
+
+__device__ __forceinline__ bool sq_goodloop(int x, int y)             // :615-622
+{
+    // rows x = 0..4, bit y set when (x, y) is a "good" internal loop
+    const unsigned tab[5] = {0x07u /*0:{0,1,2}*/, 0x0Fu /*1:{0,1,2,3}*/, 0x1Fu /*2:{0..4}*/, 0x1Eu /*3:{1,2,3,4}*/,
+                             0x1Cu /*4:{2,3,4}*/};
+    if ((unsigned)x > 4u || (unsigned)y > 4u) return false;
+    return (tab[x] >> y) & 1u;
+}
+
+// grid = (structures, parts): the candidates of a structure are dealt to `parts` blocks; the round's best
+// finalscore of the structure is combined with atomicMax, the range filter (:769-778) runs in sq_select_kernel.
+// ScoreStems for one candidate stem (SQRNdbnseq.py:607-751): what the scoring kernels know about the structure ...
+struct SqStemsEnv {
+    const SqStrand *S; const uint16_t *skip; int nstrand; bool have_skip;   // sorted strands (+ skip pointers over registered blocks)
+    const int16_t *P, *U, *SU; const uint8_t *codes; int n;                 // partner array, prefix counts, letter codes
+    bool use_ctx; const SqCtxRec *ctx_rec; const int16_t *ctx_depth; const uint16_t *ctx_rmq; int ctx_cap;   // sq_context.h
+    double lb, bw, dc; int bwint, sdflen; const double *sdf, *of;           // the paramset's scalars and tables
+    SqCounters *ctr;
+};
+// ... and the finalscore of the stem (i0, j0, L) with bpscore bps (the caller applies :751's threshold)
+__device__ __forceinline__ double sq_stem_finalscore(const SqStemsEnv &e, int i0, int j0, int L, double bps)
+{
+    double fin = 0.0;
+    const int sa = i0 + L - 1, sb = j0 - L + 1;                 // :655 innermost bp
+    int inblockend = -1, nrec = 0, be0 = 0, be1 = 0, covered = 0, brackets = 0;
+    uint64_t levelset = 0;
+    int lo = 0, hi = e.nstrand;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (e.S[mid].start <= sa) lo = mid + 1; else hi = mid; }
+    SqCtxOut cx = {0, 0, 0, 0, 0};
+    if (e.use_ctx) {
+        int lo2 = lo; hi = e.nstrand;                          // first strand that starts at or behind sb
+        while (lo2 < hi) { const int mid = (lo2 + hi) >> 1; if (e.S[mid].start < sb) lo2 = mid + 1; else hi = mid; }
+        if (lo2 > lo) sq_ctx_query(e.ctx_rec, e.ctx_depth, e.ctx_rmq, e.ctx_cap, e.S, lo, lo2, cx);
+#ifndef SQ_CTX_CHECK
+        nrec = cx.nrec; be0 = cx.be0; be1 = cx.be1; covered = cx.covered; brackets = cx.brackets;
+        levelset = brackets > 0 ? 1ull : 0ull;                  // (every strand on level 1)
+        lo = e.nstrand;                                        // the walk below has nothing left to do
+#endif
+    }
+    for (int k = lo; k < e.nstrand;) {                         // closed form of the walk :665-689
+        const SqStrand x = e.S[k];
+        if (x.start >= sb) break;
+        int nk = k + 1;
+        const int pfirst = x.pstart, plast = x.pstart - (x.len - 1);
+        bool wing;
+        if (x.left) {
+            wing = pfirst > sb;
+            if (!wing && pfirst > inblockend) {                 // :687-689 sub-ECR face
+                if (nrec == 0) { be0 = x.start; be1 = pfirst; }
+                nrec++;
+                const int from = x.start > inblockend ? x.start : inblockend + 1;
+                covered += e.U[pfirst + 1] - e.U[from];
+                inblockend = pfirst;
+                if (e.have_skip) nk = e.skip[k];                // nothing inside the block can matter
+            }
+        } else {
+            wing = plast < sa;
+        }
+        if (wing && x.start > inblockend) {                     // :679-684
+            brackets += x.len;
+            if (x.level > SQ_MAXLEVELS) e.ctr->level_ovf = 1;
+            else levelset |= 1ull << (x.level - 1);
+        }
+        k = nk;
+    }
+#ifdef SQ_CTX_CHECK
+    if (e.use_ctx && (cx.nrec != nrec || cx.covered != covered || cx.brackets != brackets ||
+                    (nrec == 1 && (cx.be0 != be0 || cx.be1 != be1)) || (levelset != (brackets > 0 ? 1ull : 0ull))))
+        printf("CTX MISMATCH struct %d cand (%d,%d,%d) nstrand %d: walk nrec %d cov %d br %d be %d %d | ctx nrec %d cov %d br %d be %d %d\n",
+               (int)blockIdx.x, i0, j0, L, e.nstrand, nrec, covered, brackets, be0, be1, cx.nrec, cx.covered, cx.brackets, cx.be0, cx.be1);
+#endif
+    const int dots = (e.U[sb] - e.U[sa + 1]) - covered;             // :670-673
+    const bool between = (e.SU[sb] - e.SU[sa + 1]) > 0;             // :675-676
+    bool goodloop = false; int diff1 = 0;                       // :692-698
+    if (nrec == 1 && sq_goodloop(be0 - sa - 1, sb - be1 - 1)) {
+        goodloop = true;
+        diff1 = abs((be0 - sa - 1) - (sb - be1 - 1));
+    }
+    bool goodloopout = false; int diff2 = 0;                    // :700-711
+    {
+        // the two outward walks over <= 5 unpaired positions (:702-707), from the prefix counts: the k
+        // positions next to the stem are all unpaired iff the count over them is k -- ten independent
+        // reads instead of two chains of dependent ones
+        const int ui = e.U[i0], uj = e.U[j0 + 1];
+        int cl = 0, cr = 0;
+#pragma unroll
+        for (int k = 1; k <= 5; k++) {
+            const int a1 = i0 - k, b1 = j0 + 1 + k;
+            cl += (a1 >= 0 && ui - e.U[a1 >= 0 ? a1 : 0] == k) ? 1 : 0;
+            cr += (b1 <= e.n && e.U[b1 <= e.n ? b1 : e.n] - uj == k) ? 1 : 0;
+        }
+        const int vv = i0 - 1 - cl, ww = j0 + 1 + cr;
+        if (vv >= 0 && ww < e.n && e.P[vv] == ww && sq_goodloop(cl, cr)) {
+            goodloopout = true;
+            diff2 = abs(cl - cr);
+        }
+    }
+    const double lb = e.lb;
+    const double loopfactor = (1.0 + (lb * (goodloop ? 1.0 : 0.0)) * (2.0 - diff1 / 2.0))
+                              + (lb * (goodloopout ? 1.0 : 0.0)) * (2.0 - diff2 / 2.0);   // :715
+    bool gnra = false;                                          // :598-604,718
+    if (sb - sa - 1 == 4 && e.codes[sa + 1] == 6 && (e.codes[sa + 3] == 6 || e.codes[sa + 3] == 0) && e.codes[sa + 4] == 0)
+        gnra = true;
+    const double tetra = gnra ? 1.25 : 1.0;
+    const double ideal = nrec == 0 ? 4.0 : 2.0;                 // :721
+    const double stemdist = (double)dots + e.bw * (double)brackets;   // :723
+    const double dd = fabs(stemdist - ideal);
+    double sdf = 1.0;                                           // :726
+    if (!between) {
+        const int di = (int)dd;
+        if (e.bwint && di < e.sdflen) sdf = e.sdf[di];
+        else sdf = pow(1.0 / (1.0 + dd), e.dc);
+    }
+    const double of = e.of[__popcll(levelset)];            // :728-729
+    fin = bps * sdf * of * loopfactor * tetra;                  // :732 (reactfactor == 1)
+    if (!goodloop && !goodloopout && L < 3) fin = -1.0;         // :744-745
+    return fin;
+}

@@ -1,0 +1,104 @@
+"""GPU parity, round 4: the persistent round kernel of width-1 pools (sq_rounds.hip: one launch per fold, a block per
+structure that loops over its own rounds and keeps its list of runs between them) against the launched rounds
+(sq_chain.hip, SQ_NO_ROUNDS) and against the oracle.
+
+Every check goes through the C ABI (libsquarna_hip.so); the oracle (oracle/) is the checker.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_hip_parity import GOLDEN, TOL, conf, load, mk_pset, prep, _same_fold, _synthetic  # noqa: F401
+from tests.test_hip_parity2 import _chain_records
+
+pytestmark = pytest.mark.gpu
+
+
+def _packed_both_ways(prepared, psets, **kw):
+    """The packed records of one batch folded by the persistent round kernel and by the launched rounds."""
+    from squarna_amd.engine import Batch
+    out = []
+    assert "SQ_NO_ROUNDS" not in os.environ
+    for launched in (False, True):
+        if launched:
+            os.environ["SQ_NO_ROUNDS"] = "1"
+        try:
+            with Batch(prepared, psets, max_structs=max(len(prepared) * max(len(p) for p in psets), 1), fp32=False) as b:
+                b.fold(**kw)
+                assert b.fold_driver == 1, b.fold_driver
+                assert bool(b.fold_paths & 4) == (not launched), b.fold_paths
+                buf, off = b.pack_all()
+                out.append(([buf[off[k]:off[k + 1]].tobytes() for k in range(len(prepared))], [r[0] for r in b.results_all()],
+                            [b.evals(k) for k in range(len(prepared))]))
+        finally:
+            os.environ.pop("SQ_NO_ROUNDS", None)
+    return out
+
+
+@pytest.mark.parametrize("config,count,nmin,nmax,sample", [("fastest", 400, 5, 420, 40), ("nobpp", 160, 12, 260, 20),
+                                                           ("greedynobpp", 120, 12, 200, 16), ("alt", 120, 5, 300, 16)])
+def test_persistent_rounds_equal_launched_rounds_and_oracle(config, count, nmin, nmax, sample):
+    """poollim = 1 over random records with reactivities, restraints (incl. restraint pairs) and separators: the runs
+    kept between rounds and cut against the chosen stem are AnnotateStems' output of every round -- packed records byte
+    for byte those of the launched rounds, the same evaluation counts, and the oracle's structures and scores."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import Prepared
+    names, psets = conf(config)
+    raw = _chain_records(count, 4343, nmin, nmax)
+    prepared = [Prepared(s, r, x) for s, r, x in raw]
+    (pa, ra, ea), (pb, rb, eb) = _packed_both_ways(prepared, [psets] * count, poollim=1)
+    assert ea == eb
+    for k in range(count):
+        assert pa[k] == pb[k], (config, k, raw[k][0], ra[k][:2], rb[k][:2])
+    for k in range(sample):
+        s, r, x = raw[k]
+        exp = O.SQRNdbnseq(s, r, x, None, psets, poollim=1)
+        exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(ra[k], exp, (config, "persistent", k))
+
+
+def test_persistent_rounds_maxstemnum_negative_weights_and_pseudoknots():
+    """Retirement by stem count, paramsets whose pieces can outscore their run (negative GU weight with a low
+    threshold), float reactivities outside the level table, and long GC-rich sequences with deep level stacks."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import Prepared
+    names, psets = conf("fastest")
+    rng = np.random.default_rng(78)
+    seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in rng.integers(60, 400, 40)]
+    prepared = [Prepared(s) for s in seqs]
+    for msn in (0, 1, 3):
+        ps = [dict(psets[0], maxstemnum=msn)]
+        (pa, ra, ea), (pb, rb, eb) = _packed_both_ways(prepared, [ps] * len(seqs), poollim=1)
+        assert pa == pb and ea == eb, msn
+    # pieces that outscore their run: GU = -3, threshold low
+    ps = [dict(psets[0], bpweights={"GC": 3.0, "AU": 2.0, "GU": -3.0}, minlen=2, minbpscore=4, minfinscorefactor=0.5)]
+    (pa, ra, ea), (pb, rb, eb) = _packed_both_ways(prepared, [ps] * len(seqs), poollim=1)
+    assert pa == pb and ea == eb
+    for k in range(8):
+        exp = O.SQRNdbnseq(seqs[k], None, None, None, ps, poollim=1)
+        exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(ra[k], exp, ("negative", k))
+    # float reactivities (more than 16 distinct values: factors per cell)
+    reacts = [list(rng.random(len(s))) for s in seqs[:16]]
+    prepared_r = [Prepared(s, r) for s, r in zip(seqs[:16], reacts)]
+    (pa, ra, ea), (pb, rb, eb) = _packed_both_ways(prepared_r, [psets] * 16, poollim=1)
+    assert pa == pb and ea == eb
+    # long, GC-rich, pseudoknots free of charge
+    longs = ["".join(rng.choice(list("ACGU"), int(n), p=[0.15, 0.35, 0.35, 0.15])) for n in (900, 1300, 1700)]
+    ps = [dict(psets[0], orderpenalty=0.0, minlen=3, minbpscore=6)]
+    (pa, ra, ea), (pb, rb, eb) = _packed_both_ways([Prepared(s) for s in longs], [ps] * 3, poollim=1)
+    assert pa == pb and ea == eb
+    deep = max(sum(ch in r[1][0][0] for ch in "[{<A") for r in ra)
+    assert deep >= 3
+
+
+@pytest.mark.parametrize("n,count,seed,reacts", [(1000, 96, 1001, False), (2000, 24, 2001, True), (300, 1500, 301, False)])
+def test_persistent_rounds_on_the_baseline_shapes(n, count, seed, reacts):
+    """S300 / S1000 / S2000 (+ SHAPE) shaped batches: byte-identical to the launched rounds."""
+    from squarna_amd.engine import Prepared
+    names, psets = conf("fastest")
+    data = _synthetic(n, count, seed, reacts)
+    (pa, ra, ea), (pb, rb, eb) = _packed_both_ways([Prepared(s, rc) for s, rc in data], [psets] * count, poollim=1)
+    assert ea == eb
+    assert pa == pb
