@@ -64,6 +64,7 @@ __host__ __device__ inline SqRoundsLds sq_rounds_lds(int lds_n, int str_cap, int
     const size_t ext = sq_extend_lds_bytes(tmax);
     const size_t stage = (size_t)(threads / 64) * (SQ_ROUNDS_STAGE * 8 + 16);
     if (ext > u) u = ext;
+    if (u < 2048) u = 2048;                                    // (the first round's bucket counters: 2 x 256 words)
     if (stage > u) u = stage;
     L.total = (size_t)o + ((u + 15) & ~(size_t)15);
     return L;

@@ -40,6 +40,10 @@ __device__ __forceinline__ void sq_wave_lds_fence()
 #include "sq_scan.h"
 #include "sq_rounds.h"
 
+#ifndef SQ_ROUNDS_WAVES
+#define SQ_ROUNDS_WAVES 4          // waves per SIMD the register budget allows (128 VGPRs): four 256-thread blocks per CU
+#endif
+
 // the first round's scan: every wave stages its runs in its own LDS buffer and appends them to the block's list
 struct SqRoundsSink {
     uint2 *stage; uint32_t *cnt;             // this wave's staging buffer and fill count (LDS)
@@ -75,12 +79,12 @@ struct SqRoundsSink {
     __device__ __forceinline__ void drain(int lane) { flush(lane); }
 };
 
-extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel(SqDevCtx c, SqStruct *structs, SqScanArgs a, SqChainIO cio,
+extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu_waves_per_eu(SQ_ROUNDS_WAVES))) void sq_rounds_kernel(SqDevCtx c, SqStruct *structs, SqScanArgs a, SqChainIO cio,
                                                                                  SqRoundsArgs ra)
 {
     extern __shared__ __attribute__((aligned(16))) char rd_dyn[];
     __shared__ int s_wave_u[SQ_ROUNDS_THREADS / 64], s_wave_s[SQ_ROUNDS_THREADS / 64];
-    __shared__ uint32_t s_nlist, s_nsurv, s_lmask;
+    __shared__ uint32_t s_nlist, s_ndead, s_nsurv, s_lmask;
     __shared__ unsigned long long s_best;
     __shared__ uint8_t s_cls[32];
     __shared__ double s_rv[16];
@@ -91,6 +95,17 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel
 
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
     const int b = blockIdx.x;
+#ifdef SQ_ROUNDS_PROF
+    // in-kernel timers (100 MHz wall clock): set-up, scan, cut, scoring phase A / B, pick, extension + state
+    long long _pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
+    long long _cnt[4] = {0, 0, 0, 0};       // runs cut, runs scored (phase A), survivors (phase B), rounds
+#define RPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)
+#define RPROF_OUT() do { if (tid == 0 && (b % 97) == 0) printf("rounds block %d n=%d rounds %lld | us: setup %.1f scan %.1f cut %.1f A %.1f B %.1f pick %.1f ext %.1f total %.1f | cut %lld scoredA %lld survB %lld\n", \
+        b, n, _cnt[3], _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, _pt[6] * 0.01, (wall_clock64() - _t00) * 0.01, _cnt[0], _cnt[1], _cnt[2]); } while (0)
+#else
+#define RPROF(k) do {} while (0)
+#define RPROF_OUT() do {} while (0)
+#endif
     const SqStruct st = structs[b];
     if (st.nstrand < 0) return;
     const SqChain ch = cio.chain[b];
@@ -201,6 +216,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel
         __syncthreads();
     };
     prefix_counts();
+    RPROF(0);
 
     const int cap = jb.cand_cap;
     SqRun *const listA = reinterpret_cast<SqRun *>(a.cands + st.cand_off), *const listB = listA + cap;
@@ -229,6 +245,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel
     __syncthreads();
     uint32_t ncur = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;
     __syncthreads();
+    RPROF(1);
 
     // ---- the cells of a run, exactly (sq_score_kernel's forms) ----
     auto cell_exact = [&](int i, int j) -> double {
@@ -256,8 +273,10 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel
 #pragma unroll
         for (int k = 0; k < 4; k++) v[k] = s_cell[((xi >> (8 * k)) & 255u) * cstride + ((xj >> (8 * (3 - k))) & 255u)];
     };
-    auto run_bps = [&](int i0, int j0, int L) -> double {      // sum(...) left to right from int 0 (:416)
-        double acc = 0.0;
+    // bpscore of a run: sum(...) left to right from int 0 (:416); pos: the same sum over the cells' positive parts -- no piece
+    // of the run can ever score more (fp addition is monotone), so a run whose `pos` misses :492 is dead for good
+    auto run_bps = [&](int i0, int j0, int L, double &pos) -> double {
+        double acc = 0.0, accp = 0.0;
         for (int t = 0; t < L; t += 4) {
             double v[4];
             if (cell_tab && j0 - t >= 3) cells4(i0 + t, j0 - t, min(4, L - t), v);
@@ -269,8 +288,13 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc = acc + (t + k < L ? v[k] : 0.0);
+            for (int k = 0; k < 4; k++) {
+                const double x = t + k < L ? v[k] : 0.0;
+                acc = acc + x;
+                accp = accp + (x > 0.0 ? x : 0.0);
+            }
         }
+        pos = accp;
         return acc;
     };
 
@@ -282,13 +306,51 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel
     const double ub_of = ps->ub_of, ub_lf = ra.bound ? ps->ub_lf : INFINITY;
     auto upper = [&](double bps) -> double { return bps >= 0 ? (((bps * ub_of) * ub_lf) * 1.25) * (1.0 + 0x1p-30) : INFINITY; };
     const double st_subopt = st.subopt;
-    // a piece of a run never scores more than the run when no cell is negative: such lists only keep what passes :492
-    bool droppable;
+
+    // ---- the first round's list: exact bpscores, dead runs dropped, ordered by descending bpscore (buckets of 0.5) so that
+    // the scoring pass meets the strong candidates first and its bound prunes the rest; later rounds keep the order ----
     {
-        int neg = 0;
-        for (int e = tid; e < KR * KR; e += nthr) neg |= s_cell[(e / KR) * cstride + (e % KR)] < 0.0 ? 1 : 0;
-        droppable = __syncthreads_or(neg) == 0 && cell_tab;
+        uint32_t *const hist = reinterpret_cast<uint32_t *>(uni);             // [256] counts, then fill pointers
+        uint32_t *const start = hist + 256;                                  // [256]
+        for (int k = tid; k < 512; k += nthr) hist[k] = 0;
+        __syncthreads();
+        auto bucket = [&](double bps) -> int { const double x = bps * 2.0; return 255 - (x >= 255.0 ? 255 : (x > 0.0 ? (int)x : 0)); };
+        for (uint32_t q = tid; q < ncur; q += nthr) {
+            const SqRun r = listB[q];
+            const int i = (int)(r.key & 0xFFFFu), j = (int)(r.key >> 16) - i;
+            double pos;
+            const double bps = run_bps(i, j, (int)r.len, pos);
+            if (pos < minbps) listB[q].len = 0;
+            else { listB[q].bps = bps; atomicAdd(&hist[bucket(bps)], 1u); }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (wv == 0) {                                                       // exclusive prefix over the 256 buckets
+            uint32_t h[4], tot = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { h[k] = hist[4 * lane + k]; tot += h[k]; }
+            uint32_t inc = tot;
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, off); if (lane >= off) inc += y; }
+            uint32_t base = inc - tot;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { start[4 * lane + k] = base; base += h[k]; }
+            if (lane == 63) s_nlist = inc;
+        }
+        __syncthreads();
+        for (int k = tid; k < 256; k += nthr) hist[k] = 0;
+        __syncthreads();
+        for (uint32_t q = tid; q < ncur; q += nthr) {
+            const SqRun r = listB[q];
+            if (r.len) {
+                const int bk = bucket(r.bps);
+                listA[start[bk] + atomicAdd(&hist[bk], 1u)] = r;
+            }
+        }
+        if (tid == 0) s_ndead = 0;
+        __threadfence_block();
+        __syncthreads();
     }
+    RPROF(2);
 
     double *const s_bps = reinterpret_cast<double *>(uni);
     uint32_t *const s_key = reinterpret_cast<uint32_t *>(s_bps + Lo.surv_cap);
@@ -296,89 +358,108 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel
 
     int nstems = 0, nstrand = 0, cursb = 0;
     bool anycross = false;
-    int za0 = 1, za1 = 0, zb0 = 1, zb1 = 0;                             // the two strands of the stem chosen last
-    SqRun *cur = listB, *nxt = listA;
+    int za0 = 1, za1 = 0, zb0 = 1, zb1 = 0;                         // the two strands of the stem chosen last
+    SqRun *list = listA, *other = listB;
     SqChainStem *const gst = cio.stems + ch.toff;
 
     for (int round = 0;; round++) {
-        // ---- the runs of this round: the pieces the new stem's strands leave of the previous round's runs ----
-        if (round > 0) {
-            if (tid == 0) s_nlist = 0;
+#ifdef SQ_ROUNDS_PROF
+        _cnt[3]++;
+#endif
+        // ---- dead entries out (order kept) when they are a third of the list or the list runs out of room ----
+        uint32_t nl = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;
+        {
+            const uint32_t nd = s_ndead;
             __syncthreads();
-            for (uint32_t q0 = 0; q0 < ncur; q0 += nthr) {
-                const uint32_t q = q0 + tid;
-                const SqRun r = q < ncur ? cur[q] : SqRun{0u, 0u, 0.0};
-                const int L = (int)r.len, i = (int)(r.key & 0xFFFFu), s = (int)(r.key >> 16), j = s - i;
-                // cell t of the run: row i + t, column j - t; masked when either lies on a strand [za0, za1] or [zb0, zb1]
-                const int lo0 = za0 - i, hi0 = za1 - i, lo1 = zb0 - i, hi1 = zb1 - i, lo2 = j - za1, hi2 = j - za0, lo3 = j - zb1, hi3 = j - zb0;
-                const bool hit = L > 0 && ((lo0 < L && hi0 >= 0) || (lo1 < L && hi1 >= 0) || (lo2 < L && hi2 >= 0) || (lo3 < L && hi3 >= 0));
-                int t0 = 0;
-                while (__ballot(t0 < L) != 0ull) {
-                    bool valid = t0 < L;
-                    int pb = t0, pe = L;
-                    if (valid && hit) {
-#pragma unroll
-                        for (int rep = 0; rep < 4; rep++) {
-                            if (pb >= lo0 && pb <= hi0) pb = hi0 + 1;
-                            if (pb >= lo1 && pb <= hi1) pb = hi1 + 1;
-                            if (pb >= lo2 && pb <= hi2) pb = hi2 + 1;
-                            if (pb >= lo3 && pb <= hi3) pb = hi3 + 1;
-                        }
-                        if (lo0 > pb && lo0 < pe) pe = lo0;
-                        if (lo1 > pb && lo1 < pe) pe = lo1;
-                        if (lo2 > pb && lo2 < pe) pe = lo2;
-                        if (lo3 > pb && lo3 < pe) pe = lo3;
-                        if (pb >= L) { valid = false; pe = L; }
-                    }
-                    t0 = valid ? pe : L;
-                    const int plen = pe - pb;
-                    valid = valid && plen >= minlen;
-                    double bps = r.bps;
-                    if (valid && (plen != L || !(bps == bps))) bps = run_bps(i + pb, j - pb, plen);
-                    const bool keep = valid && (!droppable || bps >= minbps);
-                    const unsigned long long km = __ballot(keep);
-                    if (km) {
-                        uint32_t base = 0;
-                        const int leader = __ffsll((long long)km) - 1;
-                        if (lane == leader) base = atomicAdd(&s_nlist, (uint32_t)__popcll(km));
-                        base = (uint32_t)__shfl((int)base, leader);
-                        if (keep) {
-                            const uint32_t pos = base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
-                            if (pos < (uint32_t)cap) nxt[pos] = SqRun{((uint32_t)s << 16) | (uint32_t)(i + pb), (uint32_t)plen, bps};
-                            else a.ctr->cand_ovf = 1;
-                        }
-                    }
+            if (nd * 3 > nl || nl + ((nl - nd) >> 1) + 64 > (uint32_t)cap) {
+                uint32_t base = 0;
+                for (uint32_t q0 = 0; q0 < nl; q0 += nthr) {
+                    const uint32_t q = q0 + tid;
+                    const SqRun r = q < nl ? list[q] : SqRun{0u, 0u, 0.0};
+                    const unsigned long long m = __ballot(r.len != 0);
+                    if (lane == 0) s_wave_u[wv] = __popcll(m);
+                    __syncthreads();
+                    uint32_t off = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    for (int w = 0; w < wv; w++) off += (uint32_t)s_wave_u[w];
+                    if (r.len) other[off] = r;
+                    for (int w = 0; w < nwv; w++) base += (uint32_t)s_wave_u[w];
+                    __syncthreads();
                 }
+                SqRun *t = list; list = other; other = t;
+                nl = base;
+                if (tid == 0) { s_nlist = base; s_ndead = 0; }
+                __threadfence_block();
+                __syncthreads();
             }
-            __syncthreads();
-            ncur = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;
-            SqRun *t = cur; cur = nxt; nxt = t;
-            __threadfence_block();                                  // (the scoring pass reads what the block just wrote)
-            __syncthreads();
         }
+        RPROF(2);
 
-        // ---- ScoreStems on the runs that pass :492; the best finalscore, the smallest key among equals ----
+        // ---- one pass over the list: the runs cut against the new stem's strands, in place (the first piece that is
+        // still alive takes the run's entry, further pieces go to the end of the list and are met later in this pass),
+        // then ScoreStems on the runs that pass :492; the best finalscore, the smallest key among equals ----
         if (tid == 0) { s_nsurv = 0; s_best = 0ull; }
         const SqStrand *const S = strbuf + cursb * str_cap;
         const SqStemsEnv env = {S, s_skip, nstrand, true, P, U, SU, l_code, n, false, nullptr, nullptr, nullptr, 0,
                                 ps_lb, ps_bw, ps_dc, ps_bwint, ps_sdflen, ps_sdf, ps_of, a.ctr};
         __syncthreads();
         double bfin = 0.0, bbps = 0.0; uint32_t bkey = 0, blen = 0; int bany = 0;
-        for (uint32_t q0 = 0; q0 < ncur; q0 += SQ_ROUNDS_CHUNK * nthr) {
+        for (uint32_t q0 = 0; q0 < nl; q0 += SQ_ROUNDS_CHUNK * nthr) {
             double need = minfin;
             {
                 const unsigned long long sb = s_best;
                 if (sb) { const double r = st_subopt * sq_unord(sb); need = r > need ? r : need; }
             }
+            SqRun rr[SQ_ROUNDS_CHUNK];
 #pragma unroll
             for (int u = 0; u < SQ_ROUNDS_CHUNK; u++) {
                 const uint32_t q = q0 + (uint32_t)u * nthr + tid;
-                SqRun r = q < ncur ? cur[q] : SqRun{0u, 0u, 0.0};
-                const int L = (int)r.len;
-                if (L > 0 && !(r.bps == r.bps)) {                   // the first round: the scan left the bpscore open
-                    const int i = (int)(r.key & 0xFFFFu), j = (int)(r.key >> 16) - i;
-                    r.bps = run_bps(i, j, L);
-                    cur[q].bps = r.bps;
+                rr[u] = q < nl ? list[q] : SqRun{0u, 0u, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < SQ_ROUNDS_CHUNK; u++) {
+                SqRun r = rr[u];
+                int L = (int)r.len;
+                if (L > 0 && round > 0) {
+                    const int i = (int)(r.key & 0xFFFFu), s = (int)(r.key >> 16), j = s - i;
+                    // cell t of the run: row i + t, column j - t; masked when either lies on a strand [za0, za1] or [zb0, zb1]
+                    const int lo0 = za0 - i, hi0 = za1 - i, lo1 = zb0 - i, hi1 = zb1 - i, lo2 = j - za1, hi2 = j - za0, lo3 = j - zb1, hi3 = j - zb0;
+                    if ((lo0 < L && hi0 >= 0) || (lo1 < L && hi1 >= 0) || (lo2 < L && hi2 >= 0) || (lo3 < L && hi3 >= 0)) {
+                        const uint32_t q = q0 + (uint32_t)u * nthr + tid;
+                        bool first = true;
+                        int t0 = 0;
+                        while (t0 < L) {
+                            int pb = t0;
+#pragma unroll
+                            for (int rep = 0; rep < 4; rep++) {
+                                if (pb >= lo0 && pb <= hi0) pb = hi0 + 1;
+                                if (pb >= lo1 && pb <= hi1) pb = hi1 + 1;
+                                if (pb >= lo2 && pb <= hi2) pb = hi2 + 1;
+                                if (pb >= lo3 && pb <= hi3) pb = hi3 + 1;
+                            }
+                            if (pb >= L) break;
+                            int pe = L;
+                            if (lo0 > pb && lo0 < pe) pe = lo0;
+                            if (lo1 > pb && lo1 < pe) pe = lo1;
+                            if (lo2 > pb && lo2 < pe) pe = lo2;
+                            if (lo3 > pb && lo3 < pe) pe = lo3;
+                            t0 = pe;
+                            const int plen = pe - pb;
+                            if (plen < minlen) continue;
+                            double pos;
+                            const double bps = run_bps(i + pb, j - pb, plen, pos);
+                            if (pos < minbps) continue;
+                            const SqRun piece = {((uint32_t)s << 16) | (uint32_t)(i + pb), (uint32_t)plen, bps};
+                            if (first) { first = false; r = piece; }
+                            else {
+                                const uint32_t at = atomicAdd(&s_nlist, 1u);
+                                if (at < (uint32_t)cap) list[at] = piece;
+                                else a.ctr->cand_ovf = 1;
+                            }
+                        }
+                        if (first) { r.len = 0; atomicAdd(&s_ndead, 1u); }
+                        list[q] = r;
+                        L = (int)r.len;
+                    }
                 }
                 const bool ok = L > 0 && r.bps >= minbps && !(upper(r.bps) < need);   // :492, and the bound
                 const unsigned long long okm = __ballot(ok);
@@ -393,14 +474,20 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel
                     }
                 }
             }
+            __threadfence_block();
             __syncthreads();
+            RPROF(3);
+            nl = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;             // (pieces appended by this chunk are met later)
             const uint32_t ns = s_nsurv;
-            const bool last = q0 + SQ_ROUNDS_CHUNK * nthr >= ncur;
+            const bool last = q0 + SQ_ROUNDS_CHUNK * nthr >= nl;
             uint32_t done = 0;
             while (done + (uint32_t)nthr <= ns || (last && done < ns)) {
                 const uint32_t idx = done + tid;
                 done += nthr;
                 const bool have = idx < ns;
+#ifdef SQ_ROUNDS_PROF
+                if (tid == 0) _cnt[2] += min(ns - (done - nthr), (uint32_t)nthr);
+#endif
                 const uint32_t key = have ? s_key[idx] : 0u;
                 const int L = have ? (int)s_len[idx] : 0;
                 const double bps = have ? s_bps[idx] : 0.0;
@@ -423,6 +510,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel
                 }
             }
             __syncthreads();
+            RPROF(4);
             if (done == 0) continue;
             const uint32_t rem = ns > done ? ns - done : 0u;                // < blockDim: carried to the next chunk
             uint32_t ck = 0; uint16_t cl = 0; double cb = 0.0;
@@ -432,6 +520,9 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel
             if (tid == 0) s_nsurv = rem;
             __syncthreads();
         }
+#ifdef SQ_ROUNDS_PROF
+        _cnt[0] += nl;
+#endif
         // ---- ChooseStems' first element over the block ----
         for (int off = 32; off > 0; off >>= 1) {
             const double of = __shfl_xor(bfin, off), ob = __shfl_xor(bbps, off);
@@ -446,7 +537,8 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel
             if (s_wany[q] && (!bany || s_wfin[q] > bfin || (s_wfin[q] == bfin && s_wkey[q] < bkey))) {
                 bany = 1; bfin = s_wfin[q]; bkey = s_wkey[q]; blen = s_wlen[q]; bbps = s_wbps[q];
             }
-        if (!bany) { retire(nstems, 0); return; }                   // :1192-1193 no new stem: the structure is final
+        RPROF(5);
+        if (!bany) { retire(nstems, 0); RPROF_OUT(); return; }      // :1192-1193 no new stem: the structure is final
         const int i0 = (int)(bkey & 0xFFFFu), j0 = (int)(bkey >> 16) - i0, len = (int)blen;
         const int k = nstems;
         if (k >= ch.tcap) { if (tid == 0) a.ctr->out_ovf = 1; retire(k, 0); return; }
@@ -491,5 +583,6 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) void sq_rounds_kernel
         }
         za0 = i0; za1 = i0 + len - 1; zb0 = j0 - len + 1; zb1 = j0;
         __syncthreads();
+        RPROF(6);
     }
 }
