@@ -122,6 +122,35 @@ __device__ __forceinline__ void sq_stem_levels_wave(SqExtendLds &L, int T, int l
     SQ_EXTEND_SYNC();
 }
 
+// The sorted strand list of a child: the parent's nstrand strands psrc[] (+ the stem index of each, pssrc[]) with the two
+// strands of the new stem k = (i0, j0, len) inserted, levels from L.lvl when stems cross (else level 1 everywhere).
+// cdst[] / csdst[] take nstrand + 2 entries and must NOT be the parent's arrays.
+__device__ __forceinline__ void sq_extend_strands(SqExtendLds &L, bool anycross, int k, const SqStrand *psrc, const int16_t *pssrc, int nstrand,
+                                                  int i0, int j0, int len, SqStrand *cdst, int16_t *csdst, int lane)
+{
+    const int ls = i0, rs = j0 - len + 1;                               // starts of the 5' and the 3' strand (ls < rs)
+    int below_l = 0, below_r = 0;
+    for (int q0 = 0; q0 < nstrand; q0 += 64) {
+        const int q = q0 + lane;
+        const bool valid = q < nstrand;
+        SqStrand x = valid ? psrc[q] : SqStrand{0, 0, 0, 0, 0};
+        const int sx = valid ? pssrc[q] : 0;
+        const bool bl = valid && x.start < ls, br = valid && x.start < rs;
+        if (valid) {
+            if (anycross) x.level = L.lvl[sx];
+            const int at = q + (bl ? 0 : 1) + (br ? 0 : 1);
+            cdst[at] = x; csdst[at] = (int16_t)sx;
+        }
+        below_l += __popcll(__ballot(bl)); below_r += __popcll(__ballot(br));
+    }
+    if (lane == 0) {
+        const uint8_t lv = anycross ? L.lvl[k] : (uint8_t)1;
+        cdst[below_l] = SqStrand{(int16_t)ls, (int16_t)len, (int16_t)j0, lv, 1};
+        cdst[below_r + 1] = SqStrand{(int16_t)rs, (int16_t)len, (int16_t)(i0 + len - 1), lv, 0};
+        csdst[below_l] = (int16_t)k; csdst[below_r + 1] = (int16_t)k;
+    }
+}
+
 // parent: k stems pst[] (with their crossing weights), nstrand sorted strands psrc[] + the stem index of each (pssrc[]).
 // child: cst[0..k] (may be the parent's array: the weights are updated in place), cdst[] / csdst[] (nstrand + 2 entries;
 // must NOT be the parent's).  (i0, j0, len): the new stem.  Returns whether some pair of the child's stems crosses.
@@ -149,30 +178,6 @@ __device__ __forceinline__ bool sq_extend_structure(SqExtendLds &L, const SqScan
     // ---- levels (only when stems cross; otherwise every strand stays on level 1) ----
     if (anycross) sq_stem_levels_wave(L, T, lane, &a.ctr->level_ovf);
     // ---- strands: the sorted list with the two new strands ----
-    const SqStrand *src = psrc;
-    const int16_t *ssrc = pssrc;
-    SqStrand *dst = cdst;
-    int16_t *sdst = csdst;
-    const int ls = i0, rs = j0 - len + 1;                               // starts of the 5' and the 3' strand (ls < rs)
-    int below_l = 0, below_r = 0;
-    for (int q0 = 0; q0 < nstrand; q0 += 64) {
-        const int q = q0 + lane;
-        const bool valid = q < nstrand;
-        SqStrand x = valid ? src[q] : SqStrand{0, 0, 0, 0, 0};
-        const int sx = valid ? ssrc[q] : 0;
-        const bool bl = valid && x.start < ls, br = valid && x.start < rs;
-        if (valid) {
-            if (anycross) x.level = L.lvl[sx];
-            const int at = q + (bl ? 0 : 1) + (br ? 0 : 1);
-            dst[at] = x; sdst[at] = (int16_t)sx;
-        }
-        below_l += __popcll(__ballot(bl)); below_r += __popcll(__ballot(br));
-    }
-    if (lane == 0) {
-        const uint8_t lv = anycross ? L.lvl[k] : (uint8_t)1;
-        dst[below_l] = SqStrand{(int16_t)ls, (int16_t)len, (int16_t)j0, lv, 1};
-        dst[below_r + 1] = SqStrand{(int16_t)rs, (int16_t)len, (int16_t)(i0 + len - 1), lv, 0};
-        sdst[below_l] = (int16_t)k; sdst[below_r + 1] = (int16_t)k;
-    }
+    sq_extend_strands(L, anycross, k, psrc, pssrc, nstrand, i0, j0, len, cdst, csdst, lane);
     return anycross;
 }

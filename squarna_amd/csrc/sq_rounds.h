@@ -30,12 +30,13 @@ struct SqRoundsArgs {
 };
 
 // dynamic LDS of a block: per-position arrays, free-position words of the first round's scan, cell table, two strand
-// lists + stem indices, skip pointers, and one region shared by the phases that never overlap (scan staging / level
-// scratch of the extension / survivor list of the scoring pass)
+// lists + stem indices, skip pointers, the stems with their crossing weights, and one region shared by the phases that
+// never overlap (scan staging / bucket counters / level scratch of the extension / survivor ring of the scoring pass)
 struct SqRoundsLds {
     int np, fbh;
-    int off_P, off_U, off_SU, off_E, off_ci, off_code, off_fg, off_cell, off_str, off_sidx, off_skip, off_union;
-    int surv_cap;           // entries of the survivor list
+    int off_P, off_U, off_SU, off_E, off_ci, off_code, off_fg, off_cell, off_str, off_sidx, off_skip, off_stems, off_union;
+    int t8;                 // stems the stem arrays hold (tmax rounded up to 8)
+    int surv_cap;           // entries of the survivor ring (a power of two)
     size_t total;
 };
 __host__ __device__ inline SqRoundsLds sq_rounds_lds(int lds_n, int str_cap, int tmax, int cell_entries, int threads)
@@ -58,10 +59,13 @@ __host__ __device__ inline SqRoundsLds sq_rounds_lds(int lds_n, int str_cap, int
     L.off_sidx = o; o += 2 * str_cap * 2;
     L.off_skip = o; o += str_cap * 2;
     o = (o + 15) & ~15;
+    L.t8 = (tmax + 7) & ~7;
+    L.off_stems = o; o += 10 * L.t8;                           // the structure's stems: crossing weight (int32), i, j, len (int16)
+    o = (o + 15) & ~15;
     L.off_union = o;
-    L.surv_cap = (SQ_ROUNDS_CHUNK + 1) * threads;
+    L.surv_cap = 4 * threads;                                  // >= (SQ_ROUNDS_CHUNK + 1) x threads, a power of two
     size_t u = (size_t)14 * L.surv_cap;
-    const size_t ext = sq_extend_lds_bytes(tmax);
+    const size_t ext = (size_t)4 * L.t8 + 64 * 4 + 64 + 16;   // level scratch of the extension: group sizes, order, group, level, rank
     const size_t stage = (size_t)(threads / 64) * (SQ_ROUNDS_STAGE * 8 + 16);
     if (ext > u) u = ext;
     if (u < 2048) u = 2048;                                    // (the first round's bucket counters: 2 x 256 words)

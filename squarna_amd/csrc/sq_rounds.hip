@@ -355,6 +355,36 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     double *const s_bps = reinterpret_cast<double *>(uni);
     uint32_t *const s_key = reinterpret_cast<uint32_t *>(s_bps + Lo.surv_cap);
     uint16_t *const s_len = reinterpret_cast<uint16_t *>(s_key + Lo.surv_cap);
+    const uint32_t smask = (uint32_t)Lo.surv_cap - 1u;
+
+    // the structure's stems with their crossing weights (:121-124) stay in LDS between rounds; the level rule's scratch
+    // shares the survivor ring's region
+    SqExtendLds XL;
+    XL.cc = reinterpret_cast<int32_t *>(rd_dyn + Lo.off_stems);
+    XL.i = reinterpret_cast<int16_t *>(XL.cc + Lo.t8); XL.j = XL.i + Lo.t8; XL.len = XL.j + Lo.t8;
+    XL.gsize = reinterpret_cast<int32_t *>(uni);
+    XL.ord = reinterpret_cast<int16_t *>(XL.gsize + 64);
+    XL.grp = reinterpret_cast<uint8_t *>(XL.ord + Lo.t8); XL.lvl = XL.grp + Lo.t8; XL.rank = XL.lvl + Lo.t8;
+
+    // A tighter bound on a run's finalscore than sq_score_kernel's: the reference's product bpscore x distance factor (<= 1)
+    // x order factor x loop factor x tetraloop factor (:732) with the order factor at its maximum, the tetraloop factor
+    // EXACT (:598-604,718) and each of the two loop bonuses (:692-715) only where it can apply at all -- an internal loop
+    // needs a paired position within five of either end inside the span, a loop outside one within five on either
+    // side.  Same multiplications, same order, rounding is monotone; a margin of 2^-30 on top.
+    const bool lb_on = ps_lb >= 0;
+    auto upper_of = [&](double bps, int i0, int j0, int L) -> double {
+        if (!(bps >= 0) || !(ub_lf < INFINITY)) return INFINITY;
+        const int sa = i0 + L - 1, sb = j0 - L + 1, gap = sb - sa - 1;
+        double lf = 1.0;
+        if (lb_on) {
+            const int g5 = gap < 5 ? gap : 5;
+            const bool glp = ((int)U[min(sa + 6, sb)] - (int)U[sa + 1]) < g5 && ((int)U[sb] - (int)U[max(sb - 5, sa + 1)]) < g5;
+            const bool glop = ((int)U[i0] - (int)U[max(i0 - 5, 0)]) < min(5, i0) && ((int)U[min(j0 + 6, n)] - (int)U[j0 + 1]) < min(5, n - 1 - j0);
+            lf = (1.0 + (glp ? ps_lb * 2.0 : 0.0)) + (glop ? ps_lb * 2.0 : 0.0);
+        }
+        const bool gnra = gap == 4 && l_code[sa + 1] == 6 && (l_code[sa + 3] == 6 || l_code[sa + 3] == 0) && l_code[sa + 4] == 0;
+        return (((bps * ub_of) * lf) * (gnra ? 1.25 : 1.0)) * (1.0 + 0x1p-30);
+    };
 
     int nstems = 0, nstrand = 0, cursb = 0;
     bool anycross = false;
@@ -396,24 +426,27 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
 
         // ---- one pass over the list: the runs cut against the new stem's strands, in place (the first piece that is
         // still alive takes the run's entry, further pieces go to the end of the list and are met later in this pass),
-        // then ScoreStems on the runs that pass :492; the best finalscore, the smallest key among equals ----
+        // then ScoreStems on the runs that pass :492; the best finalscore, the smallest key among equals.  The runs that
+        // pass wait in a ring in LDS until a full group of them is due (the chain of dependent loads of ScoreStems is what
+        // the pass waits for: idle lanes are its cost); the next chunk's entries are on their way meanwhile ----
         if (tid == 0) { s_nsurv = 0; s_best = 0ull; }
         const SqStrand *const S = strbuf + cursb * str_cap;
         const SqStemsEnv env = {S, s_skip, nstrand, true, P, U, SU, l_code, n, false, nullptr, nullptr, nullptr, 0,
                                 ps_lb, ps_bw, ps_dc, ps_bwint, ps_sdflen, ps_sdf, ps_of, a.ctr};
         __syncthreads();
         double bfin = 0.0, bbps = 0.0; uint32_t bkey = 0, blen = 0; int bany = 0;
+        uint32_t head = 0;                                          // entries of the ring taken so far (s_nsurv: entries put)
+        SqRun rr[SQ_ROUNDS_CHUNK];
+#pragma unroll
+        for (int u = 0; u < SQ_ROUNDS_CHUNK; u++) {
+            const uint32_t q = (uint32_t)u * nthr + tid;
+            rr[u] = q < nl ? list[q] : SqRun{0u, 0u, 0.0};
+        }
         for (uint32_t q0 = 0; q0 < nl; q0 += SQ_ROUNDS_CHUNK * nthr) {
             double need = minfin;
             {
                 const unsigned long long sb = s_best;
                 if (sb) { const double r = st_subopt * sq_unord(sb); need = r > need ? r : need; }
-            }
-            SqRun rr[SQ_ROUNDS_CHUNK];
-#pragma unroll
-            for (int u = 0; u < SQ_ROUNDS_CHUNK; u++) {
-                const uint32_t q = q0 + (uint32_t)u * nthr + tid;
-                rr[u] = q < nl ? list[q] : SqRun{0u, 0u, 0.0};
             }
 #pragma unroll
             for (int u = 0; u < SQ_ROUNDS_CHUNK; u++) {
@@ -461,7 +494,11 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                         L = (int)r.len;
                     }
                 }
-                const bool ok = L > 0 && r.bps >= minbps && !(upper(r.bps) < need);   // :492, and the bound
+                bool ok = L > 0 && r.bps >= minbps;                             // :492
+                if (ok) {                                                       // and the bound
+                    const int i0 = (int)(r.key & 0xFFFFu), j0 = (int)(r.key >> 16) - i0;
+                    ok = !(upper_of(r.bps, i0, j0, L) < need);
+                }
                 const unsigned long long okm = __ballot(ok);
                 if (okm) {
                     uint32_t base = 0;
@@ -469,7 +506,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                     if (lane == leader) base = atomicAdd(&s_nsurv, (uint32_t)__popcll(okm));
                     base = (uint32_t)__shfl((int)base, leader);
                     if (ok) {
-                        const uint32_t pos = base + (uint32_t)__popcll(okm & ((1ull << lane) - 1ull));
+                        const uint32_t pos = (base + (uint32_t)__popcll(okm & ((1ull << lane) - 1ull))) & smask;
                         s_key[pos] = r.key; s_len[pos] = (uint16_t)L; s_bps[pos] = r.bps;
                     }
                 }
@@ -478,24 +515,28 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
             __syncthreads();
             RPROF(3);
             nl = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;             // (pieces appended by this chunk are met later)
-            const uint32_t ns = s_nsurv;
+#pragma unroll
+            for (int u = 0; u < SQ_ROUNDS_CHUNK; u++) {                         // the next chunk's entries: in flight during ScoreStems
+                const uint32_t q = q0 + (uint32_t)(SQ_ROUNDS_CHUNK + u) * nthr + tid;
+                rr[u] = q < nl ? list[q] : SqRun{0u, 0u, 0.0};
+            }
+            const uint32_t tailp = s_nsurv;
             const bool last = q0 + SQ_ROUNDS_CHUNK * nthr >= nl;
-            uint32_t done = 0;
-            while (done + (uint32_t)nthr <= ns || (last && done < ns)) {
-                const uint32_t idx = done + tid;
-                done += nthr;
-                const bool have = idx < ns;
+            while (tailp - head >= (uint32_t)nthr || (last && head != tailp)) {
+                const uint32_t idx = head + tid;
+                const bool have = idx - head < tailp - head;
 #ifdef SQ_ROUNDS_PROF
-                if (tid == 0) _cnt[2] += min(ns - (done - nthr), (uint32_t)nthr);
+                if (tid == 0) _cnt[2] += min(tailp - head, (uint32_t)nthr);
 #endif
-                const uint32_t key = have ? s_key[idx] : 0u;
-                const int L = have ? (int)s_len[idx] : 0;
-                const double bps = have ? s_bps[idx] : 0.0;
+                head += min(tailp - head, (uint32_t)nthr);
+                const uint32_t key = have ? s_key[idx & smask] : 0u;
+                const int L = have ? (int)s_len[idx & smask] : 0;
+                const double bps = have ? s_bps[idx & smask] : 0.0;
                 const int s = (int)(key >> 16), i0 = (int)(key & 0xFFFFu), j0 = s - i0;
                 bool ok = have;
-                {
+                if (ok) {
                     const unsigned long long sbst = s_best;
-                    if (sbst && upper(bps) < st_subopt * sq_unord(sbst)) ok = false;
+                    if (sbst && upper_of(bps, i0, j0, L) < st_subopt * sq_unord(sbst)) ok = false;
                 }
                 double fin = 0.0;
                 if (ok) {
@@ -509,16 +550,8 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                     if (lane == 0) atomicMax(&s_best, sq_ord(wb));
                 }
             }
-            __syncthreads();
+            __syncthreads();                                                    // (the ring's taken entries may be overwritten now)
             RPROF(4);
-            if (done == 0) continue;
-            const uint32_t rem = ns > done ? ns - done : 0u;                // < blockDim: carried to the next chunk
-            uint32_t ck = 0; uint16_t cl = 0; double cb = 0.0;
-            if ((uint32_t)tid < rem) { ck = s_key[done + tid]; cl = s_len[done + tid]; cb = s_bps[done + tid]; }
-            __syncthreads();
-            if ((uint32_t)tid < rem) { s_key[tid] = ck; s_len[tid] = cl; s_bps[tid] = cb; }
-            if (tid == 0) s_nsurv = rem;
-            __syncthreads();
         }
 #ifdef SQ_ROUNDS_PROF
         _cnt[0] += nl;
@@ -542,15 +575,28 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         const int i0 = (int)(bkey & 0xFFFFu), j0 = (int)(bkey >> 16) - i0, len = (int)blen;
         const int k = nstems;
         if (k >= ch.tcap) { if (tid == 0) a.ctr->out_ovf = 1; retire(k, 0); return; }
-        if (tid == 0) cio.h_stems[ch.toff + k] = SqStemOut{i0, j0, len, 0, bbps, bfin};
-        __syncthreads();                                            // (every thread has read the survivor list / wave bests)
-        // ---- the child: strands and levels by the first wave (sq_extend.h), the partner array by the others ----
+        __syncthreads();                                            // (every thread has read the wave bests)
+        // ---- the child.  First wave: crossing weights, levels when stems cross, the sorted strand list (sq_extend.h);
+        // the other waves: partner array and prefix counts -- positions p and above lose the new pairs below p, and
+        // separators never pair, so SU stays ----
         const int nxtsb = cursb ^ 1;
+        const int zb = j0 - len + 1;
         if (wv == 0) {
-            SqExtendLds XL = sq_extend_lds(uni, ra.tmax);
-            const bool ac = sq_extend_structure(XL, a, gst, k, anycross, strbuf + cursb * str_cap, sidxbuf + cursb * str_cap, nstrand,
-                                                i0, j0, len, gst, strbuf + nxtsb * str_cap, sidxbuf + nxtsb * str_cap, lane);
-            if (lane == 0) s_cross = ac ? 1 : 0;
+            int mycc = 0, mycross = 0;
+            for (int q = lane; q < k; q += 64)
+                if (sq_chain_cross(XL.i[q], XL.j[q], i0, j0)) { XL.cc[q] += len; mycc += XL.len[q]; mycross = 1; }
+            const int newcc = sq_wave_sum32(mycc);
+            const bool ac = anycross || __ballot(mycross) != 0ull;
+            if (lane == 0) {
+                XL.i[k] = (int16_t)i0; XL.j[k] = (int16_t)j0; XL.len[k] = (int16_t)len; XL.cc[k] = newcc;
+                gst[k] = SqChainStem{i0, j0, len, newcc};           // (the tail reads the stems there; the weights of the others stay in LDS)
+                cio.h_stems[ch.toff + k] = SqStemOut{i0, j0, len, 0, bbps, bfin};
+                s_cross = ac ? 1 : 0;
+            }
+            sq_wave_lds_fence();
+            if (ac) sq_stem_levels_wave(XL, k + 1, lane, &a.ctr->level_ovf);
+            sq_extend_strands(XL, ac, k, strbuf + cursb * str_cap, sidxbuf + cursb * str_cap, nstrand, i0, j0, len,
+                              strbuf + nxtsb * str_cap, sidxbuf + nxtsb * str_cap, lane);
         }
         if (nwv == 1 || wv > 0) {
             const int w0 = nwv == 1 ? 0 : wv - 1, wn = nwv == 1 ? 1 : nwv - 1;
@@ -558,12 +604,13 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 P[i0 + t] = (int16_t)(j0 - t);
                 P[j0 - t] = (int16_t)(i0 + t);
             }
+            for (int p = i0 + 1 + w0 * 64 + lane; p <= n; p += wn * 64)
+                U[p] = (int16_t)((int)U[p] - (min(p - i0, len) + min(max(p - zb, 0), len)));
         }
         __syncthreads();
         anycross = s_cross != 0;
         cursb = nxtsb; nstems = k + 1; nstrand += 2;
         if ((double)nstems == ch.maxstems) { retire(nstems, 1); return; }   // :1168-1174 (checked before the next evaluation)
-        prefix_counts();
         {
             // skip pointers over the blocks ScoreStems' sweep registers (sq_score_kernel)
             const SqStrand *const S2 = strbuf + cursb * str_cap;
@@ -581,7 +628,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 s_skip[q] = (uint16_t)z;
             }
         }
-        za0 = i0; za1 = i0 + len - 1; zb0 = j0 - len + 1; zb1 = j0;
+        za0 = i0; za1 = i0 + len - 1; zb0 = zb; zb1 = j0;
         __syncthreads();
         RPROF(6);
     }
