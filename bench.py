@@ -13,10 +13,12 @@ step     : one fold of `--inflight` (default 8) independent batches per GPU, in 
            same records arriving from the host.  N > 1: weak scaling -- every rank folds its own batches, independent
            sequences, no data-path collective.
 roofline : `roofline` = the dominant kernel of the S1000 leg (1,024 random-ACGU sequences, N = 1000, c=fastest,
-           pl=1), today sq_score_kernel: launch time from HIP events on the library's stream (live), HBM bytes per launch
-           from the rocprofv3 PMC pass recorded in profiles/traffic.json (withheld when the kernels' sources have changed
-           since).  `rooflines` = the other kernels that dominate a leg (blossom kernel of the headline step with its
-           cycles per scan pass, the scan kernel, the fp32 fill), each with the resource that binds it.
+           pl=1): sq_rounds_kernel, the persistent round kernel -- ONE launch per fold.  achieved = SURVEY 8d's algorithmic
+           bytes of the launch (2 N^2 per AnnotateStems evaluation x the evaluations, asserted equal to sq_result_evals) /
+           its launch time from HIP events on the library's stream (live); `traffic` = HBM bytes per launch from the rocprofv3
+           PMC pass recorded in profiles/traffic.json (withheld when the kernels' sources have changed since).  `rooflines`
+           = the other kernels that dominate a leg (blossom kernel of the headline step with its cycles per scan pass, the
+           fp32 fill), each with the resource that binds it.
 cpu_baseline: the CPU oracle (oracle/, a C port of the reference algorithm + the reference's own scipy / networkx
            calls) on the same workload, one process per host core; S1000 / S2000 on a stated subsample.  Its workers are
            spawned before the GPU is initialised and wait; the leg itself runs LAST (ten seconds of all-core load in front
@@ -198,7 +200,8 @@ def mean_fs(results):
 # ---------------------------------------------------------------- PMC summaries (profiles/traffic.json)
 def kernels_hash():
     h = hashlib.sha256()
-    for f in ("sq_kernels.hip", "sq_cells.h", "sq_context.h", "sq_context.hip", "sq_match.hip", "sq_blossom.h"):
+    for f in ("sq_kernels.hip", "sq_cells.h", "sq_context.h", "sq_context.hip", "sq_match.hip", "sq_blossom.h", "sq_rounds.hip",
+              "sq_rounds.h", "sq_scan.h", "sq_score.h", "sq_extend.h"):
         with open(os.path.join(ROOT, "squarna_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -229,8 +232,12 @@ def load_pmc():
 
 # ---------------------------------------------------------------- S1000 roofline leg
 def roofline_leg(nseq, n, pmc, pmc_note, seed=1000):
-    """S1000: nseq random ACGU sequences of length n, c=fastest pl=1: the stem-scan kernel's roofline object (and the
-    scoring kernel's, the leg's dominant kernel), launch times measured with HIP events inside the library."""
+    """S1000: nseq random ACGU sequences of length n, c=fastest pl=1.  The leg's dominant kernel is the persistent round
+    kernel (sq_rounds.hip: ONE launch runs every AnnotateStems / ScoreStems / ChooseStems round of every structure), so
+    `roofline` is SURVEY 8d's figure for it: algorithmic bytes = 2 N^2 per AnnotateStems evaluation x the evaluations the
+    launch performs, over the launch time measured live with HIP events on the library's stream.  The kernel keeps each
+    structure's runs between rounds instead of re-reading the matrix, so the algorithmic rate exceeds the HBM peak (8d:
+    "an implementation that avoids re-reading may exceed 100 %"); `traffic` is what the kernel really moves (PMC)."""
     import torch
     from squarna_amd.config import ParseConfig, builtin_config
     from squarna_amd.engine import Batch
@@ -239,78 +246,57 @@ def roofline_leg(nseq, n, pmc, pmc_note, seed=1000):
     prepared = prepare_synthetic(items)
     with Batch(prepared, [psets] * nseq, max_structs=nseq, fp32=False) as b:
         b.fold(poollim=1)                      # warm-up (also page-in)
+        assert b.fold_paths & 4, "the S1000 leg must run the persistent round kernel"
         b.profile(True)
+        reps = 5
         b.profile_reset()
         torch.cuda.synchronize()
-        b.fold(poollim=1)
+        for _ in range(reps):
+            b.fold(poollim=1)
         torch.cuda.synchronize()
-        ms, launches, alg_bytes = b.profile_get(2)
+        ms, launches, alg_bytes = b.profile_get(7)
         fms, flaunches, fbytes = b.profile_get(0)
-        sms, slaunches, _ = b.profile_get(1)
-        cms, claunches, _ = b.profile_get(3)
         evals = sum(b.evals(k) for k in range(nseq))
         b.profile(False)
         walls = []
-        for _ in range(5):                                  # whole-fold wall time, timers off (the fold runs on two lanes)
+        for _ in range(5):                                  # whole-fold wall time, timers off
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             b.fold(poollim=1)
             torch.cuda.synchronize()
             walls.append(time.perf_counter() - t0)
     wall = min(walls)
-    avg_ms = ms / max(launches, 1)
-    alg_gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    # 2 N^2 bytes per AnnotateStems evaluation and nothing else -- the library books them per LIVE structure
-    # (a launch also covers structures that are already final: those do not count)
-    assert abs(alg_bytes - evals * 2.0 * n * n) <= 1e-9 * max(alg_bytes, 1.0), (alg_bytes, evals, n)
-    k = pmc.get("sq_scan6_kernel") or {}
+    assert launches == reps, launches
+    avg_ms = ms / launches
+    per_launch = alg_bytes / launches
+    # 2 N^2 bytes per AnnotateStems evaluation and nothing else -- booked per LIVE structure and round
+    assert abs(per_launch - evals * 2.0 * n * n) <= 1e-9 * max(per_launch, 1.0), (per_launch, evals, n)
+    achieved = per_launch / (avg_ms * 1e-3) / 1e9
+    k = pmc.get("sq_rounds_kernel") or {}
     traffic = (k.get("fetch_bytes_per_launch", 0) + k.get("write_bytes_per_launch", 0)) if k else None
-    achieved = traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms > 0 else None
-    scan = dict(
-        bound="hbm", kernel="sq_scan6_kernel", unit="GB/s", peak=HBM_PEAK_GBS,
-        achieved=round(achieved, 1) if achieved else None,
-        frac=round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-        traffic=traffic,
-        how="achieved = HBM bytes the kernel really moves per launch (rocprofv3 PMC: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, "
-            "%s) / its launch time measured live (HIP events on the library's stream); the kernel reads a 1-bit-per-cell "
-            "diagonal matrix, so it is issue-bound (VALU + SALU), not bandwidth-bound" % (k.get("source", pmc_note or "no PMC file")),
+    first = dict(
+        bound="hbm", kernel="sq_rounds_kernel", unit="GB/s", peak=HBM_PEAK_GBS,
+        achieved=round(achieved, 1), frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+        how="achieved = SURVEY 8d algorithmic bytes of ONE launch (2 N^2 per AnnotateStems evaluation x evals_R: the fp32 upper "
+            "triangle the reference re-scans every round) / the launch time measured live (HIP events on the library's stream, "
+            "%d launches).  frac > 1: the kernel avoids the re-reads (runs kept between rounds, cut against the chosen stem), "
+            "as 8d anticipates; `traffic` = HBM bytes it really moves per launch (rocprofv3 PMC: FETCH_SIZE x 2 on gfx950 + "
+            "WRITE_SIZE, %s), hbm_frac_of_real_traffic = traffic / launch time / peak.  What binds the kernel is instruction "
+            "issue and LDS / L2 latency of per-candidate work, not bandwidth" % (reps, k.get("source", pmc_note or "no PMC file")),
+        binding_resource="VALU issue + dependent LDS / L2 loads (ScoreStems per candidate); not HBM",
+        hbm_frac_of_real_traffic=round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
         avg_launch_ms=round(avg_ms, 4), launches=int(launches), issue=issue_share(k, avg_ms),
-        algorithmic=dict(bytes_per_launch=round(alg_bytes / max(launches, 1)), GBs=round(alg_gbs, 1),
-                         reread_avoidance=round(alg_gbs / HBM_PEAK_GBS, 3),
-                         note="SURVEY 8d bytes (2 N^2 per AnnotateStems evaluation: the fp32 upper triangle the reference "
-                              "re-scans) / launch time / 8 TB/s; > 1 means re-reads avoided, it is NOT a fraction of peak"),
+        wave_cycles_waiting=k.get("wait_share"), lds_bank_conflict_share=k.get("lds_conflict_share"),
+        algorithmic=dict(bytes_per_launch=round(per_launch), GBs=round(achieved, 1)),
         workload="S1000: %d random-ACGU seqs N=%d seed %d c=fastest pl=1" % (nseq, n, seed), evals_R=int(evals),
         alg_bytes_equals_evals_R_x_2N2=True,
         whole_fold=dict(ms=round(wall * 1e3, 2), seq_per_s=round(nseq / wall, 1),
-                        alg_GBs=round(alg_bytes / wall / 1e9, 1), frac_of_hbm_peak=round(alg_bytes / wall / 1e9 / HBM_PEAK_GBS, 3),
+                        alg_GBs=round(per_launch / wall / 1e9, 1), frac_of_hbm_peak=round(per_launch / wall / 1e9 / HBM_PEAK_GBS, 3),
                         how="one sq_fold call, best of 5, profiling off; SURVEY 8d's bytes(N, R) = R 2N^2 over WALL time (the 4 N^2 "
                             "fp32 fill bytes are not counted: the fold writes N^2/8 bytes of bit matrix instead)"),
-        kernel_ms=dict(bits=round(fms, 3), state=round(sms, 3), scan=round(ms, 3), score_select=round(cms, 3)))
-    ks = pmc.get("sq_score_kernel") or {}
-    c_avg = cms / max(claunches, 1)
-    tb = (ks.get("fetch_bytes_per_launch", 0) + ks.get("write_bytes_per_launch", 0)) if ks else None
-    c_ach = tb / (c_avg * 1e-3) / 1e9 if tb and c_avg > 0 else None
-    score = dict(bound="hbm", kernel="sq_score_kernel", unit="GB/s", peak=HBM_PEAK_GBS,
-                 achieved=round(c_ach, 1) if c_ach else None, frac=round(c_ach / HBM_PEAK_GBS, 4) if c_ach else None,
-                 traffic=tb,
-                 how="SURVEY 8d gives this kernel no algorithmic bytes (per-candidate scoring traffic is lower order), so achieved = "
-                     "the HBM bytes it really moves per launch (rocprofv3 PMC: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, %s) / its "
-                     "launch time measured live (HIP events on the library's stream).  It is bound by the latency of the "
-                     "dependent LDS / L2 loads of the per-candidate strand sweep, far below the HBM roof" % (
-                         ks.get("source", pmc_note or "no PMC file")),
-                 leg="S1000", avg_launch_ms=round(c_avg, 4), launches=int(claunches),
-                 wave_cycles_waiting=ks.get("wait_share"), lds_bank_conflict_share=ks.get("lds_conflict_share"),
-                 lds_wave_insts_per_launch=ks.get("sq_insts_lds_per_launch"), issue=issue_share(ks, c_avg), pmc=ks.get("source"))
-    tot = max(fms + sms + ms + cms, 1e-9)
-    scan["share_of_leg_kernel_time"] = round(ms / tot, 3)
-    score["share_of_leg_kernel_time"] = round(cms / tot, 3)
-    # `roofline` = the leg's DOMINANT kernel; it carries the leg-level fields (per-kernel times, whole fold); the other
-    # object goes to `rooflines`
-    leg = {key: scan.pop(key) for key in ("workload", "evals_R", "alg_bytes_equals_evals_R_x_2N2", "whole_fold", "kernel_ms")}
-    first, second = (score, scan) if cms >= ms else (scan, score)
-    first.update(leg)
-    first["dominant_of"] = "S1000 leg: %.0f %% of its kernel time" % (100.0 * max(cms, ms) / tot)
-    return first, second
+        kernel_ms=dict(bits=round(fms / reps, 3), rounds=round(avg_ms, 3)),
+        dominant_of="S1000 leg: %.0f %% of its kernel time" % (100.0 * ms / max(ms + fms, 1e-9)))
+    return first, None
 
 
 N_SIMD = 1024              # 256 CUs x 4 SIMDs
@@ -725,7 +711,8 @@ def main():
     roof = None
     if rank == 0 and not args.no_roofline:
         roof, other_obj = roofline_leg(args.roofline_seqs, 1000, pmc, pmc_note)   # the leg's dominant kernel first
-        rooflines.append(other_obj)
+        if other_obj:
+            rooflines.append(other_obj)
         try:
             rooflines.append(fill_leg(pmc=pmc))
         except Exception as e:                                # (a secondary leg never takes the headline down)

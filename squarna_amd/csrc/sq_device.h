@@ -108,6 +108,14 @@ struct SqPoolIO {
 
 #include "sq_hostflag.h"
 
+// LDS operations of one wave execute in program order; this keeps the compiler from moving them across the point (the
+// barrier of code in which ONE wave hands data to its own lanes through LDS)
+__device__ __forceinline__ void sq_wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // order-preserving map double -> uint64 (never 0 for a real number), so a per-structure maximum is one atomicMax
 __device__ __forceinline__ unsigned long long sq_ord(double x)
 {

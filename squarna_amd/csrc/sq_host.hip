@@ -13,6 +13,7 @@
 #include <unordered_map>
 #include "sq_host.h"
 #include "sq_rounds.h"
+#include "sq_pool_round.h"
 #include "sq_algos_dev.h"
 #include "sq_match.h"
 
@@ -1403,6 +1404,19 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
     static const int st_short_env = getenv("SQ_STATE_SHORT_THREADS") ? atoi(getenv("SQ_STATE_SHORT_THREADS")) : 64;
     static const int sc_short_env = getenv("SQ_SCAN_SHORT_WAVES") ? atoi(getenv("SQ_SCAN_SHORT_WAVES")) : 1;
     const bool fuse = crowded && maxn <= 200 && maxn >= 5 && !no_fuse && st_short_env == 64 && sc_short_env == 1;
+    // the pools' short structures: state + scan + score + choose of a structure by ONE wave in ONE launch (sq_pool_round.hip)
+    if (pooled && mode == 0 && maxn <= SQ_PR_MAXN && !b->any_dense && (crowded || b->pool_round_always) && !b->no_pool_round) {
+        const int surv_env = b->pool_round_nsurv;
+        SqPoolRoundArgs ra;
+        ra.lds_n = maxn; ra.str_cap = std::min(1024, 2 * std::max(b->chain_tmax, 1) + 2); ra.cell_entries = b->cell_entries;
+        ra.surv_cap = surv_env ? surv_env : (maxn <= 96 ? 128 : 256); ra.bound = b->score_bound ? 1 : 0;
+        const SqPoolRoundLds lo = sq_pool_round_lds(ra.lds_n, ra.str_cap, ra.cell_entries, ra.surv_cap);
+        if (lo.total <= 60 * 1024) {
+            ProfScope ps(b, 3, scan_bytes);
+            hipLaunchKernelGGL(sq_pool_round_kernel, dim3(S), dim3(64), lo.total, st, b->ctx, d_structs, scan, b->pool_io, ra);
+            return;
+        }
+    }
     if (fuse) {
         ProfScope ps(b, 2, scan_bytes);
         const size_t dyn_state = (size_t)7 * ((maxn + 8) & ~7) + 64, dyn_scan = 4 * (size_t)b->state.fbstride;
@@ -1854,6 +1868,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // the scoring kernel's two short cuts, per fold (tests fold the same batch with and without them)
     b->score_bound = getenv("SQ_NO_SCORE_BOUND") == nullptr;
     b->score_ctx = getenv("SQ_NO_SCORE_CONTEXT") == nullptr;
+    b->no_pool_round = getenv("SQ_NO_POOL_ROUND") != nullptr;              // (tests fold both ways in one process)
+    b->pool_round_always = getenv("SQ_POOL_ROUND_ALWAYS") != nullptr;      // (also for a small batch alone: measurements)
+    b->pool_round_nsurv = getenv("SQ_POOL_ROUND_NSURV") ? std::max(64, std::min(2048, atoi(getenv("SQ_POOL_ROUND_NSURV")))) : 0;   // (tests: survivors spill)
+    if (b->any_dense < 0) { b->any_dense = 0; for (const SqJob &J : b->jobs) if (J.mat64_off >= 0 || J.has_ext) b->any_dense = 1; }
     b->packed_ok = false;
     hipLaunchKernelGGL(sq_fold_begin_kernel, dim3((b->njobs + 256) / 256), dim3(256), 0, b->stream, b->d_fin_ctr, b->d_job_evals,
                        b->tail.job_cnt, b->njobs);
@@ -2260,7 +2278,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 const double ev = (double)((e >> 32) & 0x7FFFFFFFu) + ((e >> 63) ? 0.0 : 1.0);
                 bytes += ev * 2.0 * n * n;
             }
-            b->prof[2].bytes += bytes;
+            b->prof[rounds_ok ? 7 : 2].bytes += bytes;        // (the persistent round kernel covers the evaluations of all its rounds)
         }
         }
 #undef CHK

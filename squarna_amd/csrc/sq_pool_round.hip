@@ -1,0 +1,319 @@
+// sq_pool_round.hip -- one round of the device pools (sq_pool.hip) for SHORT structures as ONE kernel.
+//
+// A round of the pools was state -> scan -> score -> choose (-> pool scan -> extend): four launches in which a
+// structure of a 60-nt sequence is four blocks that each spend half of their few microseconds on set-up, hand their
+// results to the next one through global memory (partner / prefix arrays, free-position words, candidate keys,
+// survivor records, the round's best) and hold wave slots while they wait for it.  With batches in flight the chip is
+// short of exactly those slots.  Here ONE wave takes a structure through the whole of
+// OptimalStems (SQRNdbnseq.py:792-833) and ChooseStems (:754-789):
+//
+//   state       partner array, prefix counts, free-position words from the structure's sorted strands -- in LDS;
+//   scan        AnnotateStems as the bit-diagonal scan (sq_scan.h); the runs are staged in LDS and, 64 at a time, given
+//               their exact bpscore at once (the candidate list never exists); those that pass :492 wait in LDS
+//               (beyond its room: in the structure's slice of the candidate arena);
+//   score       ScoreStems on them behind the bound of sq_cellrun.h, finalscores beside them in LDS;
+//   choose      the stopper's single pick (:1147), or the range :769-778, the reference's stable descending order and
+//               the conflict filter :779-789 -- sq_pool_choose_kernel's steps on LDS data.
+//
+// What leaves the kernel is what sq_pool_scan_kernel / sq_pool_extend_kernel read: the children count, the final flag,
+// the chosen stems.  Results are those of the launched kernels bit for bit (tests fold both ways: SQ_NO_POOL_ROUND).
+#include <hip/hip_runtime.h>
+#include "sq_device.h"
+#include "sq_extend.h"
+#include "sq_cells.h"
+#include "sq_cellrun.h"
+#include "sq_score.h"
+#include "sq_scan.h"
+#include "sq_pool_round.h"
+
+#define SQ_POOL_CMAX 64         // stems ChooseStems may return for one structure (== lanes of the conflict test)
+
+__device__ __forceinline__ bool sq_pr_shares_base(int ai, int aj, int al, int bi, int bj, int bl)   // :783-786
+{
+    const int as0 = ai, as1 = ai + al - 1, at0 = aj - al + 1, at1 = aj;
+    const int bs0 = bi, bs1 = bi + bl - 1, bt0 = bj - bl + 1, bt1 = bj;
+    return (as0 <= bs1 && bs0 <= as1) || (as0 <= bt1 && bt0 <= as1) || (at0 <= bs1 && bs0 <= at1) || (at0 <= bt1 && bt0 <= at1);
+}
+
+// the survivors of :492: the first `cap` in LDS, the rest in the structure's slice of the candidate arena
+struct SqPrSurv {
+    double *bps, *fin; uint32_t *key; uint16_t *len; int cap;
+    SqOk *spill; uint32_t spill_cap; SqCounters *ctr;
+    __device__ __forceinline__ void put(uint32_t at, uint32_t k, int L, double b)
+    {
+        if (at < (uint32_t)cap) { key[at] = k; len[at] = (uint16_t)L; bps[at] = b; }
+        else if (at - cap < spill_cap) spill[at - cap] = SqOk{k, (uint32_t)L, b, 0.0};
+        else ctr->cand_ovf = 1;
+    }
+    __device__ __forceinline__ void get(uint32_t at, uint32_t &k, int &L, double &b) const
+    {
+        if (at < (uint32_t)cap) { k = key[at]; L = len[at]; b = bps[at]; }
+        else { const SqOk o = spill[at - cap]; k = o.key; L = (int)o.len; b = o.bps; }
+    }
+    __device__ __forceinline__ void set_fin(uint32_t at, double f) { if (at < (uint32_t)cap) fin[at] = f; else spill[at - cap].fin = f; }
+    __device__ __forceinline__ double get_fin(uint32_t at) const { return at < (uint32_t)cap ? fin[at] : spill[at - cap].fin; }
+};
+
+// the scan's sink: runs staged in LDS; whenever 64 of them wait they get their bpscore and the ones that pass :492 join
+// the survivors (the wave is the whole block: its barrier orders the LDS traffic)
+struct SqPrSink {
+    uint2 *stage; uint32_t *cnt;                      // staging buffer of SQ_PR_STAGE entries and its fill count (LDS)
+    uint2 *over; uint32_t *nover; uint32_t over_cap;  // runs beyond the buffer: the structure's key array in the arena
+    const SqCellEnv &cenv; const SqDevCtx &c; const SqJob &jb; SqPrSurv &sv; uint32_t &ns;
+    double minbps; SqCounters *ctr;
+    __device__ __forceinline__ void emit(uint32_t key, uint32_t len)
+    {
+        const uint32_t slot = atomicAdd(cnt, 1u);
+        if (slot < SQ_PR_STAGE) stage[slot] = make_uint2(key, len);
+        else {
+            const uint32_t g = atomicAdd(nover, 1u);
+            if (g < over_cap) over[g] = make_uint2(key, len); else ctr->cand_ovf = 1;
+        }
+    }
+    __device__ __forceinline__ void score64(const uint2 *src, uint32_t n, int lane)      // n <= 64 runs
+    {
+        const bool have = (uint32_t)lane < n;
+        const uint2 kl = have ? src[lane] : make_uint2(0u, 0u);
+        double bps = 0.0, pos = 0.0;
+        if (have) {
+            const int i = (int)(kl.x & 0xFFFFu), j = (int)(kl.x >> 16) - i;
+            bps = sq_cellrun_bps(cenv, c, jb, i, j, (int)kl.y, pos);
+        }
+        const bool ok = have && bps >= minbps;                                            // :492
+        const unsigned long long m = __ballot(ok);
+        if (ok) sv.put(ns + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), kl.x, (int)kl.y, bps);
+        ns += (uint32_t)__popcll(m);
+    }
+    __device__ __forceinline__ void flush(int lane)
+    {
+        __syncthreads();
+        uint32_t n = *cnt;
+        if (n > SQ_PR_STAGE) n = SQ_PR_STAGE;
+        for (uint32_t b0 = 0; b0 < n; b0 += 64) score64(stage + b0, min(n - b0, 64u), lane);
+        __syncthreads();
+        if (lane == 0) *cnt = 0;
+        __syncthreads();
+    }
+    __device__ __forceinline__ void poll(int lane) { sq_wave_lds_fence(); if (*cnt >= 64u) flush(lane); }
+    __device__ __forceinline__ void drain(int lane) { flush(lane); }
+};
+
+extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra)
+{
+    extern __shared__ __attribute__((aligned(16))) char pr_dyn[];
+    __shared__ SqCellTmp s_ctmp;
+    __shared__ uint32_t s_cnt, s_nover;
+    __shared__ int s_ri[SQ_POOL_CMAX], s_rj[SQ_POOL_CMAX], s_rl[SQ_POOL_CMAX];
+    const int lane = threadIdx.x;
+    const SqStruct st = structs[blockIdx.x];                // (structs: the chunk of the round's list this launch covers)
+    const int s = st.slot;                                  // == the structure's position in the round's list
+    if (st.nstrand < 0) {                                   // a child that was full (:1123-1129): logged when it was made
+        if (lane == 0) { pio.nchild[s] = 0; pio.finalflag[s] = 0; }
+        return;
+    }
+    SqPoolJob *J = pio.jobs + pio.jobrec_of[st.job];
+    if (lane == 0) atomicAdd((unsigned long long *)&J->evals, 1ull);
+    const SqJob jb = c.jobs[st.job];
+    const SqPsetDev *ps = c.psets + jb.pset;
+    const int n = jb.n;
+    const SqPoolRoundLds Lo = sq_pool_round_lds(ra.lds_n, ra.str_cap, ra.cell_entries, ra.surv_cap);
+    int16_t *const P = reinterpret_cast<int16_t *>(pr_dyn + Lo.off_P);
+    int16_t *const U = reinterpret_cast<int16_t *>(pr_dyn + Lo.off_U);
+    int16_t *const SU = reinterpret_cast<int16_t *>(pr_dyn + Lo.off_SU);
+    uint8_t *const E = reinterpret_cast<uint8_t *>(pr_dyn + Lo.off_E);
+    uint8_t *const l_ci = reinterpret_cast<uint8_t *>(pr_dyn + Lo.off_ci);
+    uint8_t *const l_code = reinterpret_cast<uint8_t *>(pr_dyn + Lo.off_code);
+    uint32_t *const FG = reinterpret_cast<uint32_t *>(pr_dyn + Lo.off_fg);
+    SqStrand *const s_str = reinterpret_cast<SqStrand *>(pr_dyn + Lo.off_str);
+    uint16_t *const s_skip = reinterpret_cast<uint16_t *>(pr_dyn + Lo.off_skip);
+    uint2 *const s_stage = reinterpret_cast<uint2 *>(pr_dyn + Lo.off_stage);
+    double *const s_cell = reinterpret_cast<double *>(pr_dyn + Lo.off_cell);
+    if (lane == 0) { s_cnt = 0; s_nover = 0; }
+    const SqCellEnv cenv = sq_cell_setup(c, jb, ps, s_ctmp, l_ci, l_code, s_cell, lane, 64);
+
+    // ---- the structure's state (sq_state_build): partner array, mask codes, prefix counts, free-position words ----
+    {
+        const uint8_t *e0 = c.e0c + jb.pos_off;
+        for (int p = lane; p < n; p += 64) { P[p] = -1; E[p] = e0[p]; }
+        const SqStrand *sd = pio.strands + st.strand_off;
+        for (int k = lane; k < st.nstrand; k += 64) s_str[k] = sd[k];
+        __syncthreads();
+        for (int k = lane; k < st.nstrand; k += 64) {
+            const SqStrand x = s_str[k];
+            for (int t = 0; t < x.len; t++) {
+                const int pos = x.start + t;
+                P[pos] = (int16_t)(x.pstart - t);           // :634-635
+                E[pos] = 255;                               // :446-451 row + column of a paired base are masked
+            }
+        }
+        __syncthreads();
+        int base_u = 0, base_s = 0;
+        for (int p0 = 0; p0 < n; p0 += 64) {
+            const int p = p0 + lane;
+            const bool un = p < n && P[p] == -1;
+            const bool us = un && (l_code[p] == 26 || l_code[p] == 27);
+            const unsigned long long mu = __ballot(un), ms = __ballot(us);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (p < n) { U[p] = (int16_t)(base_u + __popcll(mu & below)); SU[p] = (int16_t)(base_s + __popcll(ms & below)); }
+            base_u += __popcll(mu); base_s += __popcll(ms);
+        }
+        if (lane == 0) { U[n] = (int16_t)base_u; SU[n] = (int16_t)base_s; }
+        const int fbh = Lo.fbh;
+        for (int m2 = 0; 2 * m2 < fbh; m2++) {
+            const int pf = 64 * m2 + lane;
+            const unsigned long long bf = __ballot(pf < n && E[pf] == 0);
+            const int pr = n - 1 - (64 * m2 + lane - SQ_GPAD);
+            const unsigned long long br = __ballot(pr >= 0 && pr < n && E[pr] == 0);
+            if (lane == 0) {
+                FG[2 * m2] = (uint32_t)bf; FG[fbh + 2 * m2] = (uint32_t)br;
+                if (2 * m2 + 1 < fbh) { FG[2 * m2 + 1] = (uint32_t)(bf >> 32); FG[fbh + 2 * m2 + 1] = (uint32_t)(br >> 32); }
+            }
+        }
+        // skip pointers over the blocks ScoreStems' sweep registers (sq_score_kernel)
+        for (int k = lane; k < st.nstrand; k += 64) {
+            const SqStrand x = s_str[k];
+            int q = k + 1;
+            if (x.left) {
+                const int pf = x.pstart;
+                while (q < st.nstrand) {
+                    const SqStrand y = s_str[q];
+                    if (y.start > pf || (y.left && y.pstart > pf)) break;
+                    q++;
+                }
+            }
+            s_skip[k] = (uint16_t)q;
+        }
+        __syncthreads();
+    }
+
+    // ---- AnnotateStems + :492 ----
+    SqPrSurv sv;
+    sv.bps = reinterpret_cast<double *>(pr_dyn + Lo.off_surv); sv.fin = sv.bps + ra.surv_cap;
+    sv.key = reinterpret_cast<uint32_t *>(sv.fin + ra.surv_cap); sv.len = reinterpret_cast<uint16_t *>(sv.key + ra.surv_cap);
+    sv.cap = ra.surv_cap; sv.ctr = a.ctr;
+    // the structure's slice of the arena (cand_cap 32-byte units): runs the staging buffer could not take, then spilled survivors
+    uint2 *const over = reinterpret_cast<uint2 *>(a.cands + st.cand_off);
+    sv.spill = sq_oks(a, st, jb.cand_cap);
+    sv.spill_cap = (uint32_t)(((size_t)jb.cand_cap * (sizeof(SqCand) - sizeof(SqKey))) / sizeof(SqOk));
+    const double minbps = ps->minbpscore, minfin = ps->minfinscore;
+    uint32_t ns = 0;
+    if (n >= 5) {                                                       // :456-457 (shorter sequences have no diagonals)
+        SqPrSink sink{s_stage, &s_cnt, over, &s_nover, (uint32_t)jb.cand_cap, cenv, c, jb, sv, ns, minbps, a.ctr};
+        sq_scan6_groups(c, jb, FG, FG + Lo.fbh, Lo.fbh, E, 0, 1, lane, sink);
+        __threadfence_block();
+        __syncthreads();
+        const uint32_t no = s_nover < (uint32_t)jb.cand_cap ? s_nover : (uint32_t)jb.cand_cap;
+        for (uint32_t b0 = 0; b0 < no; b0 += 64) sink.score64(over + b0, min(no - b0, 64u), lane);
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- ScoreStems on the survivors, finalscores beside them; the best one ----
+    const double ps_lb = ps->loopbonus;
+    const double ub_of = ps->ub_of, ub_lf = ra.bound ? ps->ub_lf : INFINITY;
+    const SqStemsEnv env = {s_str, s_skip, st.nstrand, true, P, U, SU, l_code, n, false, nullptr, nullptr, nullptr, 0,
+                            ps_lb, ps->bracketweight, ps->distcoef, ps->bw_integral, ps->sdf_len, c.sdftab + ps->sdf_off, ps->oftab, a.ctr};
+    const double subopt = st.subopt;
+    double best = 0.0; bool anybest = false;                           // (wave-uniform)
+    for (uint32_t g = 0; g < ns; g += 64) {
+        const uint32_t idx = g + lane;
+        const bool have = idx < ns;
+        uint32_t key = 0; int L = 0; double bps = 0.0;
+        if (have) sv.get(idx, key, L, bps);
+        const int i0 = (int)(key & 0xFFFFu), j0 = (int)(key >> 16) - i0;
+        bool ok = have;
+        if (ok) {
+            const double ub = sq_run_upper(bps, i0, j0, L, U, l_code, n, ub_of, ub_lf, ps_lb);
+            if (ub < minfin || (anybest && ub < subopt * best)) ok = false;      // no reader of the list can use it
+        }
+        double fin = -INFINITY;
+        if (ok) {
+            fin = sq_stem_finalscore(env, i0, j0, L, bps);
+            if (!(fin >= minfin)) fin = -INFINITY;                               // :751
+        }
+        if (have) sv.set_fin(idx, fin);
+        double wb = fin;
+        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(wb, off); wb = o > wb ? o : wb; }
+        if (wb > -INFINITY && (!anybest || wb > best)) { anybest = true; best = wb; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (!anybest) {                                         // no stem passed the thresholds: the structure is final (:1155)
+        if (lane == 0) { pio.nchild[s] = 0; pio.finalflag[s] = 1; }
+        return;
+    }
+
+    // ---- ChooseStems (sq_pool_choose_kernel's steps) ----
+    SqPoolPick *out = pio.chosen + (size_t)s * pio.cmax;
+    const bool one = J->cursize >= pio.poollim;             // :1147 stopper
+    if (one) {
+        // only ChooseStems' first element is used: the highest finalscore, the smallest emission key among equals
+        unsigned long long pick = ~0ull;
+        for (uint32_t q = lane; q < ns; q += 64)
+            if (sv.get_fin(q) == best) {
+                uint32_t key; int L; double bps;
+                sv.get(q, key, L, bps);
+                const unsigned long long v = ((unsigned long long)key << 32) | q; pick = v < pick ? v : pick;
+            }
+        pick = sq_wave_min64(pick);
+        if (lane == 0) {
+            uint32_t key; int L; double bps;
+            sv.get((uint32_t)pick, key, L, bps);
+            out[0] = SqPoolPick{key, (uint32_t)L, bps, best};
+            pio.nchild[s] = 1; pio.finalflag[s] = 0;
+        }
+        return;
+    }
+    // the candidates within range (:769-778), gathered over the arrays the earlier phases are done with
+    const double range = J->cursubopt * best;
+    double *const c_fin = reinterpret_cast<double *>(pr_dyn);
+    uint32_t *const c_key = reinterpret_cast<uint32_t *>(c_fin + Lo.choose_cap);
+    uint16_t *const c_q = reinterpret_cast<uint16_t *>(c_key + Lo.choose_cap), *const c_ord = c_q + Lo.choose_cap;
+    int nin = 0;
+    for (uint32_t g = 0; g < ns; g += 64) {
+        const uint32_t q = g + lane;
+        const double f = q < ns ? sv.get_fin(q) : -INFINITY;
+        const bool keep = !(f < range);                     // (-inf: rejected or pruned)
+        uint32_t key = 0; int L = 0; double bps = 0.0;
+        if (keep) sv.get(q, key, L, bps);
+        const unsigned long long m = __ballot(keep);
+        const int pos = nin + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep && pos < Lo.choose_cap) { c_q[pos] = (uint16_t)q; c_fin[pos] = f; c_key[pos] = key; }
+        nin += __popcll(m);
+    }
+    if (nin > Lo.choose_cap || ns > 65535u) {
+        if (lane == 0) { pio.hdr->ovf = 1; pio.nchild[s] = 0; pio.finalflag[s] = 0; }
+        return;
+    }
+    __syncthreads();
+    // the reference's stable descending sort: finalscore descending, emission order (key) ascending
+    for (int x = lane; x < nin; x += 64) {
+        const double fx = c_fin[x]; const uint32_t kx = c_key[x];
+        int r = 0;
+        for (int y = 0; y < nin; y++) { const double fy = c_fin[y]; r += (fy > fx || (fy == fx && c_key[y] < kx)) ? 1 : 0; }
+        c_ord[r] = (uint16_t)x;
+    }
+    __syncthreads();
+    // the conflict filter (:779-789): a candidate joins when it shares a base with every stem taken so far
+    int nres = 0;
+    bool over_c = false;
+    for (int t = 0; t < nin; t++) {
+        const int x = c_ord[t];
+        uint32_t key; int cl; double bps;
+        sv.get(c_q[x], key, cl, bps);
+        const int ci = (int)(key & 0xFFFFu), cj = (int)(key >> 16) - ci;
+        const bool mine = lane < nres ? sq_pr_shares_base(ci, cj, cl, s_ri[lane], s_rj[lane], s_rl[lane]) : true;
+        if (__ballot(!mine) != 0ull) continue;
+        if (nres == SQ_POOL_CMAX || nres == pio.cmax) { over_c = true; break; }
+        if (lane == 0) {
+            s_ri[nres] = ci; s_rj[nres] = cj; s_rl[nres] = cl;
+            out[nres] = SqPoolPick{key, (uint32_t)cl, bps, c_fin[x]};
+        }
+        nres++;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        if (over_c) { pio.hdr->ovf = 1; nres = 0; }
+        pio.nchild[s] = nres; pio.finalflag[s] = (nres == 0 && !over_c) ? 1 : 0;
+    }
+}

@@ -26,16 +26,11 @@
 #include <hip/hip_runtime.h>
 #include "sq_device.h"
 
-// LDS operations of one wave execute in program order; this keeps the compiler from moving them across the point
-__device__ __forceinline__ void sq_wave_lds_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 #define SQ_EXTEND_SYNC() sq_wave_lds_fence()      // (the extension runs on the first wave of a wider block)
 #include "sq_extend.h"
 #include "sq_tail_dev.h"
 #include "sq_cells.h"
+#include "sq_cellrun.h"
 #include "sq_score.h"
 #include "sq_scan.h"
 #include "sq_rounds.h"
@@ -84,10 +79,9 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
 {
     extern __shared__ __attribute__((aligned(16))) char rd_dyn[];
     __shared__ int s_wave_u[SQ_ROUNDS_THREADS / 64], s_wave_s[SQ_ROUNDS_THREADS / 64];
-    __shared__ uint32_t s_nlist, s_ndead, s_nsurv, s_lmask;
+    __shared__ uint32_t s_nlist, s_ndead, s_nsurv;
+    __shared__ SqCellTmp s_ctmp;
     __shared__ unsigned long long s_best;
-    __shared__ uint8_t s_cls[32];
-    __shared__ double s_rv[16];
     __shared__ double s_wfin[SQ_ROUNDS_THREADS / 64], s_wbps[SQ_ROUNDS_THREADS / 64];
     __shared__ uint32_t s_wkey[SQ_ROUNDS_THREADS / 64], s_wlen[SQ_ROUNDS_THREADS / 64];
     __shared__ int s_wany[SQ_ROUNDS_THREADS / 64];
@@ -140,58 +134,12 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         }
     };
 
-    // ---- once per fold: letter classes, the cell table (as sq_score_kernel builds them per round), the empty structure ----
-    if (tid < 64) {
-        uint32_t any8 = 0;
-        if (tid < 32) {
-            const uint32_t *ib = reinterpret_cast<const uint32_t *>(ps->inbps) + tid * 8;
-#pragma unroll
-            for (int q = 0; q < 8; q++) any8 |= ib[q];
-        }
-        const unsigned long long bal = __ballot(any8 != 0);
-        if (tid == 0) { s_lmask = (uint32_t)bal; s_nlist = 0; }
-    }
-    __syncthreads();
-    const uint32_t lmask = s_lmask;
-    const int K = __popc(lmask) + 1;
-    const bool any_reacts = !jb.default_reacts;
-    const bool react_tab = any_reacts && jb.react_levels > 0 && K * jb.react_levels <= 32;
-    const int R = react_tab ? jb.react_levels : 1;
-    const int KR = K * R, cstride = KR | 1;
-    const bool cell_tab = jb.default_reacts || react_tab;           // the table holds the final cell value
-    if (tid < 32) s_cls[tid] = (lmask >> tid) & 1u ? (uint8_t)__popc(lmask & ((1u << tid) - 1u)) : (uint8_t)(K - 1);
-    if (react_tab)
-        for (int p = tid; p < n; p += nthr) s_rv[c.ridx[jb.pos_off + p]] = c.reacts[jb.pos_off + p];
-    __syncthreads();
+    // ---- once per fold: letter classes, the cell table (sq_score_kernel builds them per round), the empty structure ----
+    if (tid == 0) s_nlist = 0;
+    const SqCellEnv cenv = sq_cell_setup(c, jb, ps, s_ctmp, l_ci, l_code, s_cell, tid, nthr);
     {
         const uint8_t *e0 = c.e0c + jb.pos_off;
-        for (int p = tid; p < n; p += nthr) {
-            const uint8_t code = c.codes[jb.pos_off + p];
-            const int cl = s_cls[code & 31];
-            l_code[p] = code;
-            l_ci[p] = (uint8_t)(react_tab ? cl * R + c.ridx[jb.pos_off + p] : cl);
-            P[p] = -1; E[p] = e0[p];
-        }
-        for (int e = tid; e < KR * KR; e += nthr) {
-            const int ci = e / KR, cj = e - ci * KR;
-            const int ca = ci / R, cb = cj / R;
-            int la, lb;
-            {
-                uint32_t m = lmask; for (int t = 0; t < ca && m; t++) m &= m - 1;
-                la = ca < K - 1 ? __ffs((int)m) - 1 : -1;
-                m = lmask; for (int t = 0; t < cb && m; t++) m &= m - 1;
-                lb = cb < K - 1 ? __ffs((int)m) - 1 : -1;
-            }
-            const double w = (la >= 0 && lb >= 0) ? ps->w[la * 32 + lb] : 0.0;
-            double v = w;
-            if (react_tab) {
-                double rf = jb.rf_idx >= 0 ? c.rftab[(int64_t)jb.rf_idx * 256 + (ci - ca * R) * 16 + (cj - cb * R)]
-                                           : sqrt((1.0 - (s_rv[ci - ca * R] + s_rv[cj - cb * R]) / 2.0) * 2.0);
-                if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
-                v = w * rf;
-            }
-            s_cell[ci * cstride + cj] = v;
-        }
+        for (int p = tid; p < n; p += nthr) { P[p] = -1; E[p] = e0[p]; }
     }
     __syncthreads();
 
@@ -247,56 +195,9 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     __syncthreads();
     RPROF(1);
 
-    // ---- the cells of a run, exactly (sq_score_kernel's forms) ----
-    auto cell_exact = [&](int i, int j) -> double {
-        const double w = s_cell[l_ci[i] * cstride + l_ci[j]];
-        if (cell_tab) return w;
-        double rf;
-        if (jb.rf_idx >= 0) rf = sq_reactfactor(c, jb, i, j);
-        else {
-            const double ri = c.reacts[jb.pos_off + i], rj = c.reacts[jb.pos_off + j];
-            rf = sqrt((1.0 - (ri + rj) / 2.0) * 2.0);
-        }
-        if (w <= 0) rf = 1.0 / (rf > 0.01 ? rf : 0.01);
-        return w * rf;
-    };
-    const uint32_t *l_ciw = reinterpret_cast<const uint32_t *>(l_ci);
-    auto cells4 = [&](int i, int j, int nv, double (&v)[4]) {
-        const int q = j - 3;
-        const uint32_t a0 = l_ciw[i >> 2], a1 = l_ciw[(i >> 2) + 1], b0 = l_ciw[q >> 2], b1 = l_ciw[(q >> 2) + 1];
-        uint32_t xi = __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)(i & 3));
-        uint32_t xj = __builtin_amdgcn_alignbyte(b1, b0, (uint32_t)(q & 3));
-        if (nv < 4) {
-            xi &= (1u << (8 * nv)) - 1u;
-            xj &= ~((1u << (8 * (4 - nv))) - 1u);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = s_cell[((xi >> (8 * k)) & 255u) * cstride + ((xj >> (8 * (3 - k))) & 255u)];
-    };
-    // bpscore of a run: sum(...) left to right from int 0 (:416); pos: the same sum over the cells' positive parts -- no piece
-    // of the run can ever score more (fp addition is monotone), so a run whose `pos` misses :492 is dead for good
-    auto run_bps = [&](int i0, int j0, int L, double &pos) -> double {
-        double acc = 0.0, accp = 0.0;
-        for (int t = 0; t < L; t += 4) {
-            double v[4];
-            if (cell_tab && j0 - t >= 3) cells4(i0 + t, j0 - t, min(4, L - t), v);
-            else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int tt = t + k < L ? t + k : L - 1;
-                    v[k] = cell_exact(i0 + tt, j0 - tt);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const double x = t + k < L ? v[k] : 0.0;
-                acc = acc + x;
-                accp = accp + (x > 0.0 ? x : 0.0);
-            }
-        }
-        pos = accp;
-        return acc;
-    };
+    // bpscore of a run and the sum of its cells' positive parts (sq_cellrun.h): a run whose positive parts miss :492 is
+    // dead for good
+    auto run_bps = [&](int i0, int j0, int L, double &pos) -> double { return sq_cellrun_bps(cenv, c, jb, i0, j0, L, pos); };
 
     const double minbps = ps->minbpscore, minfin = ps->minfinscore;
     const double ps_lb = ps->loopbonus, ps_bw = ps->bracketweight, ps_dc = ps->distcoef;
@@ -304,7 +205,6 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     const double *const ps_sdf = c.sdftab + ps->sdf_off;
     const double *const ps_of = ps->oftab;
     const double ub_of = ps->ub_of, ub_lf = ra.bound ? ps->ub_lf : INFINITY;
-    auto upper = [&](double bps) -> double { return bps >= 0 ? (((bps * ub_of) * ub_lf) * 1.25) * (1.0 + 0x1p-30) : INFINITY; };
     const double st_subopt = st.subopt;
 
     // ---- the first round's list: exact bpscores, dead runs dropped, ordered by descending bpscore (buckets of 0.5) so that
@@ -366,25 +266,8 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     XL.ord = reinterpret_cast<int16_t *>(XL.gsize + 64);
     XL.grp = reinterpret_cast<uint8_t *>(XL.ord + Lo.t8); XL.lvl = XL.grp + Lo.t8; XL.rank = XL.lvl + Lo.t8;
 
-    // A tighter bound on a run's finalscore than sq_score_kernel's: the reference's product bpscore x distance factor (<= 1)
-    // x order factor x loop factor x tetraloop factor (:732) with the order factor at its maximum, the tetraloop factor
-    // EXACT (:598-604,718) and each of the two loop bonuses (:692-715) only where it can apply at all -- an internal loop
-    // needs a paired position within five of either end inside the span, a loop outside one within five on either
-    // side.  Same multiplications, same order, rounding is monotone; a margin of 2^-30 on top.
-    const bool lb_on = ps_lb >= 0;
-    auto upper_of = [&](double bps, int i0, int j0, int L) -> double {
-        if (!(bps >= 0) || !(ub_lf < INFINITY)) return INFINITY;
-        const int sa = i0 + L - 1, sb = j0 - L + 1, gap = sb - sa - 1;
-        double lf = 1.0;
-        if (lb_on) {
-            const int g5 = gap < 5 ? gap : 5;
-            const bool glp = ((int)U[min(sa + 6, sb)] - (int)U[sa + 1]) < g5 && ((int)U[sb] - (int)U[max(sb - 5, sa + 1)]) < g5;
-            const bool glop = ((int)U[i0] - (int)U[max(i0 - 5, 0)]) < min(5, i0) && ((int)U[min(j0 + 6, n)] - (int)U[j0 + 1]) < min(5, n - 1 - j0);
-            lf = (1.0 + (glp ? ps_lb * 2.0 : 0.0)) + (glop ? ps_lb * 2.0 : 0.0);
-        }
-        const bool gnra = gap == 4 && l_code[sa + 1] == 6 && (l_code[sa + 3] == 6 || l_code[sa + 3] == 0) && l_code[sa + 4] == 0;
-        return (((bps * ub_of) * lf) * (gnra ? 1.25 : 1.0)) * (1.0 + 0x1p-30);
-    };
+    // the bound on a run's finalscore (sq_cellrun.h: exact tetraloop factor, loop bonuses only where they can apply)
+    auto upper_of = [&](double bps, int i0, int j0, int L) -> double { return sq_run_upper(bps, i0, j0, L, U, l_code, n, ub_of, ub_lf, ps_lb); };
 
     int nstems = 0, nstrand = 0, cursb = 0;
     bool anycross = false;

@@ -102,3 +102,83 @@ def test_persistent_rounds_on_the_baseline_shapes(n, count, seed, reacts):
     (pa, ra, ea), (pb, rb, eb) = _packed_both_ways([Prepared(s, rc) for s, rc in data], [psets] * count, poollim=1)
     assert ea == eb
     assert pa == pb
+
+
+# ---- device pools: a round of short structures as ONE kernel (sq_pool_round.hip) ---------------------------------------
+def _pools_both_ways(prepared, psets, env=None, **kw):
+    """Packed records of one batch folded with sq_pool_round_kernel (forced: SQ_POOL_ROUND_ALWAYS) and with the launched
+    state / scan / score / choose kernels (SQ_NO_POOL_ROUND)."""
+    from squarna_amd.engine import Batch
+    out = []
+    for launched in (False, True):
+        extra = dict(env or {}) if not launched else {}
+        extra["SQ_NO_POOL_ROUND" if launched else "SQ_POOL_ROUND_ALWAYS"] = "1"
+        assert not any(k in os.environ for k in extra)
+        os.environ.update(extra)
+        try:
+            with Batch(prepared, psets, max_structs=8192, fp32=False) as b:
+                b.fold(**kw)
+                assert b.fold_driver == 2, b.fold_driver
+                buf, off = b.pack_all()
+                out.append(([buf[off[k]:off[k + 1]].tobytes() for k in range(len(prepared))], [r[0] for r in b.results_all()],
+                            [b.evals(k) for k in range(len(prepared))]))
+        finally:
+            for k in extra:
+                os.environ.pop(k, None)
+    return out
+
+
+@pytest.mark.parametrize("config,count,nmin,nmax,poollim,sample,env", [
+    ("nobpp", 200, 12, 220, 1000, 24, None), ("greedynobpp", 200, 12, 250, 3, 24, None), ("alt", 150, 5, 200, 1000, 16, None),
+    ("greedynobpp", 100, 30, 250, 40, 12, {"SQ_POOL_ROUND_NSURV": "64"}), ("fastest", 150, 5, 250, 7, 16, None)])
+def test_pool_round_kernel_equals_launched_round_and_oracle(config, count, nmin, nmax, poollim, sample, env):
+    """Pools of any width over random records with reactivities, restraints and separators: the one-wave round kernel
+    gives the packed records of the launched kernels byte for byte (also when its survivors spill out of LDS), the same
+    evaluation counts, and the oracle's structures and scores."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import Prepared
+    names, psets = conf(config)
+    raw = _chain_records(count, 900 + poollim, nmin, nmax)
+    prepared = [Prepared(s, r, x) for s, r, x in raw]
+    (pa, ra, ea), (pb, rb, eb) = _pools_both_ways(prepared, [psets] * count, env=env, poollim=poollim)
+    assert ea == eb
+    for k in range(count):
+        assert pa[k] == pb[k], (config, poollim, k, raw[k][0], ra[k][:2], rb[k][:2])
+    for k in range(sample):
+        s, r, x = raw[k]
+        exp = O.SQRNdbnseq(s, r, x, None, psets, poollim=poollim)
+        exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(ra[k], exp, (config, "pool round", poollim, k))
+
+
+def test_pool_round_kernel_on_srtest150_sets_in_flight():
+    """The headline shape: several batches of SRtest150 copies in flight (the crowded mode picks the round kernel by itself)
+    give the records of one batch folded alone with the launched kernels."""
+    import torch
+    from squarna_amd.engine import Batch, Prepared, fold_concurrently
+    from squarna_amd.inputs import ParseDefaultInput
+    names, psets = conf("nobpp")
+    recs = list(ParseDefaultInput(os.path.join(os.path.dirname(os.path.dirname(__file__)), "squarna_amd", "data", "datasets", "SRtest150.fas"), "qf"))
+    prepared = [Prepared(r[1], r[2], r[3], r[4]) for r in recs]
+    os.environ["SQ_NO_POOL_ROUND"] = "1"
+    try:
+        with Batch(prepared, [psets] * len(prepared), fp32=False, max_structs=4096) as b:
+            b.fold(poollim=1000)
+            buf, off = b.pack_all()
+            ref = [buf[off[k]:off[k + 1]].tobytes() for k in range(len(prepared))]
+    finally:
+        del os.environ["SQ_NO_POOL_ROUND"]
+    batches = []
+    for _ in range(3):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            batches.append(Batch(prepared * 2, [psets] * (2 * len(prepared)), fp32=False, max_structs=8192))
+    torch.cuda.synchronize()
+    try:
+        fold_concurrently(batches, poollim=1000)
+        for b in batches:
+            buf, off = b.pack_all()
+            for k in range(2 * len(prepared)):
+                assert buf[off[k]:off[k + 1]].tobytes() == ref[k % len(prepared)], k
+    finally:
+        for b in batches:
+            b.close()

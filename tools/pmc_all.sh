@@ -1,8 +1,8 @@
 #!/bin/bash
 # All PMC evidence of a round in one go (on the MI355X box): bash tools/pmc_all.sh TAG
-#   S1000 x 1024 probe -> counters of sq_scan6_kernel and sq_score_kernel (one set of --pmc passes sees every kernel)
+#   S1000 x 1024 probe -> counters of sq_rounds_kernel (the persistent round kernel: one launch per fold)
 #   SRtest150 Edmonds probe -> counters of the blossom kernel (sq_mwm_single_kernel for a batch alone);  256 x S1000 fill probe -> counters of sq_fill_kernel
-# writes profiles/TAG_{scan6,score,mwm,fill}_pmc.txt and profiles/traffic.json (stamped with the kernel sources' hash).
+# writes profiles/TAG_{rounds,mwm,fill}_pmc.txt and profiles/traffic.json (stamped with the kernel sources' hash).
 tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 s=gpurun_out/pmc_${tag}_s1000; e=gpurun_out/pmc_${tag}_mwm; f=gpurun_out/pmc_${tag}_fill
@@ -24,9 +24,8 @@ run SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
 run FETCH_SIZE
 run WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 python3 tools/pmc_summary.py $f sq_fill_kernel > profiles/${tag}_fill_pmc.txt
-python3 tools/pmc_summary.py $s sq_scan6_kernel > profiles/${tag}_scan6_pmc.txt
-python3 tools/pmc_summary.py $s sq_score_kernel > profiles/${tag}_score_pmc.txt
+python3 tools/pmc_summary.py $s sq_rounds_kernel > profiles/${tag}_rounds_pmc.txt
 python3 tools/pmc_summary.py $e sq_mwm > profiles/${tag}_mwm_pmc.txt    # (sq_mwm_single_kernel: one batch alone; sq_mwm_kernel: batches in flight -- the same code per graph)
-python3 tools/make_traffic.py $tag sq_scan6_kernel=$s sq_score_kernel=$s sq_mwm_kernel:sq_mwm=$e sq_fill_kernel=$f > /dev/null
+python3 tools/make_traffic.py $tag sq_rounds_kernel=$s sq_mwm_kernel:sq_mwm=$e sq_fill_kernel=$f > /dev/null
 mkdir -p gpurun_out/profiles_$tag && cp profiles/${tag}_*_pmc.txt profiles/traffic.json gpurun_out/profiles_$tag/
 cat profiles/traffic.json

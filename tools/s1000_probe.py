@@ -31,6 +31,7 @@ with Batch(prepared, [psets] * nseq, max_structs=nseq if noprof else min(nseq, 4
             if r == reps - 1:
                 print("fold ms: min %.2f median %.2f  (all: %s)" % (min(walls), sorted(walls)[len(walls) // 2], " ".join("%.1f" % w for w in walls)))
             continue
-        ms, launches, by = b.profile_get(2)
-        print("fold %.2f ms; scan %.3f ms over %d launches, %.1f GB/s algorithmic" % (dt * 1e3, ms, launches, by / ms / 1e6))
-        print("   " + "  ".join("%s %.3f ms/%d" % (nm, *b.profile_get(k)[:2]) for k, nm in enumerate(["fill", "state", "scan", "score"])))
+        k = 7 if b.fold_paths & 4 else 2
+        ms, launches, by = b.profile_get(k)
+        print("fold %.2f ms; %s %.3f ms over %d launches, %.1f GB/s algorithmic" % (dt * 1e3, "rounds" if k == 7 else "scan", ms, launches, by / ms / 1e6))
+        print("   " + "  ".join("%s %.3f ms/%d" % (nm, *b.profile_get(q)[:2]) for q, nm in ((0, "fill"), (1, "state"), (2, "scan"), (3, "score"), (7, "rounds"))))
