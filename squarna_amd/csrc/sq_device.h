@@ -94,7 +94,8 @@ struct SqPoolIO {
     int32_t *nchild;              // [smax] children of every structure of the round (0: final)
     int32_t *child_off;           // [smax + 1] exclusive scan of nchild
     uint8_t *finalflag;           // [smax] 1: the structure is final and still has to be logged
-    SqPoolPick *chosen;           // [smax][cmax]
+    SqPoolPick *chosen;           // [2][smax][cmax]: the launched kernels use the first half; sq_pool_round_kernel the half of its generation
+    int32_t *parent_of;           // [smax] next generation: parent (position in this round's list) of every child (sq_pool_scan_kernel)
     SqPoolHdr *hdr;
     // the batch's device log of final structures ([0] entries, [1] stems, [2] overflow in fin_ctr): read by the device
     // tail (sq_tail_dev.hip); the host-driven tail copies it out

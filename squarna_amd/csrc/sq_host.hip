@@ -394,7 +394,7 @@ struct Layout {
     int ctx_cap = 0, ctx_levels = 0;
     size_t off_crec, off_cstems, off_cstrands, off_csidx, off_cnfin;   // device-chained rounds (sq_chain.hip)
     size_t off_pstructs, off_precs, off_pstems, off_pstrands, off_psidx, off_pjobs, off_pjobrec, off_pnchild, off_pchoff,
-           off_pflag, off_pchosen, off_phdr;                            // device pools (sq_pool.hip)
+           off_pflag, off_pchosen, off_pparent, off_phdr;                            // device pools (sq_pool.hip)
     // device log of final structures + scratch of the device tail (sq_tail_dev.hip)
     size_t off_fin, off_fin_stems, off_fin_ctr, off_jobevals, off_t_jobs, off_t_seqjob0, off_t_ord, off_t_cstems, off_t_csn, off_t_hash,
            off_t_rep, off_t_mask, off_t_scores, off_t_dlist, off_t_rlist, off_t_seqs, off_t_refp, off_t_refn, off_t_pow;
@@ -530,7 +530,7 @@ int plan(const sq_batch_desc *d, Layout &L)
         L.off_psidx = take(on * 2 * sm * 2 * pt * sizeof(int16_t));
         L.off_pjobs = take(on * (size_t)d->njobs * sizeof(SqPoolJob)); L.off_pjobrec = take(on * (size_t)d->njobs * 4);
         L.off_pnchild = take(on * sm * 4); L.off_pchoff = take(on * (sm + 1) * 4); L.off_pflag = take(on * sm);
-        L.off_pchosen = take(on * sm * 64 * sizeof(SqPoolPick)); L.off_phdr = take(64);
+        L.off_pchosen = take(on * 2 * sm * 64 * sizeof(SqPoolPick)); L.off_pparent = take(on * sm * 4); L.off_phdr = take(64);
     }
     {
         // the log of final structures: every structure of every pool ends there once -- measured: 1.4 x the largest generation.
@@ -912,7 +912,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         P.smax = L.max_structs; P.pt = L.pool_pt; P.cmax = 64;
         P.jobs = (SqPoolJob *)(base + L.off_pjobs); P.jobrec_of = (int32_t *)(base + L.off_pjobrec);
         P.nchild = (int32_t *)(base + L.off_pnchild); P.child_off = (int32_t *)(base + L.off_pchoff);
-        P.finalflag = (uint8_t *)(base + L.off_pflag); P.chosen = (SqPoolPick *)(base + L.off_pchosen);
+        P.finalflag = (uint8_t *)(base + L.off_pflag); P.chosen = (SqPoolPick *)(base + L.off_pchosen); P.parent_of = (int32_t *)(base + L.off_pparent);
         P.hdr = (SqPoolHdr *)(base + L.off_phdr);
         P.fin = b->d_fin; P.fin_stems = b->d_fin_stems; P.fin_cap = L.fin_cap; P.fin_stem_cap = L.fin_stem_cap;
         P.fin_ctr = b->d_fin_ctr; P.job_evals = b->d_job_evals;
@@ -1396,7 +1396,7 @@ struct AlignSink {                    // mode 2: where the stems of structure k 
 // and for host-driven greedy rounds the range filter that writes the round's output records
 static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, int64_t maxcap, bool need_reacts, double scan_bytes,
                                  int mode, const SqRoundIO &io, const SqScanArgs &scan, SqStruct *d_structs, SqStrand *d_strands,
-                                 bool chained, bool pooled = false)
+                                 bool chained, bool pooled = false, const SqPoolRoundArgs *pool_round = nullptr)
 {
     const bool crowded = b->inflight > 1 || b->njobs >= 4096;    // (by the batch, not by the launch: a batch's rounds all run one way)
     // short sequences on a crowded chip: state and scan in one launch, one wave per structure (sq_state_scan_kernel)
@@ -1404,18 +1404,13 @@ static void launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, i
     static const int st_short_env = getenv("SQ_STATE_SHORT_THREADS") ? atoi(getenv("SQ_STATE_SHORT_THREADS")) : 64;
     static const int sc_short_env = getenv("SQ_SCAN_SHORT_WAVES") ? atoi(getenv("SQ_SCAN_SHORT_WAVES")) : 1;
     const bool fuse = crowded && maxn <= 200 && maxn >= 5 && !no_fuse && st_short_env == 64 && sc_short_env == 1;
-    // the pools' short structures: state + scan + score + choose of a structure by ONE wave in ONE launch (sq_pool_round.hip)
-    if (pooled && mode == 0 && maxn <= SQ_PR_MAXN && !b->any_dense && (crowded || b->pool_round_always) && !b->no_pool_round) {
-        const int surv_env = b->pool_round_nsurv;
-        SqPoolRoundArgs ra;
-        ra.lds_n = maxn; ra.str_cap = std::min(1024, 2 * std::max(b->chain_tmax, 1) + 2); ra.cell_entries = b->cell_entries;
-        ra.surv_cap = surv_env ? surv_env : (maxn <= 96 ? 128 : 256); ra.bound = b->score_bound ? 1 : 0;
-        const SqPoolRoundLds lo = sq_pool_round_lds(ra.lds_n, ra.str_cap, ra.cell_entries, ra.surv_cap);
-        if (lo.total <= 60 * 1024) {
-            ProfScope ps(b, 3, scan_bytes);
-            hipLaunchKernelGGL(sq_pool_round_kernel, dim3(S), dim3(64), lo.total, st, b->ctx, d_structs, scan, b->pool_io, ra);
-            return;
-        }
+    // the pools' short structures: extension + state + scan + score + choose of a structure by ONE wave in ONE launch
+    // (sq_pool_round.hip; pool_fold decides per fold and then launches no extend kernel)
+    if (pool_round) {
+        const SqPoolRoundLds lo = sq_pool_round_lds(pool_round->lds_n, pool_round->str_cap, pool_round->cell_entries, pool_round->surv_cap, pool_round->tmax);
+        ProfScope ps(b, 3, scan_bytes);
+        hipLaunchKernelGGL(sq_pool_round_kernel, dim3(S), dim3(64), lo.total, st, b->ctx, scan, b->pool_io, *pool_round);
+        return;
     }
     if (fuse) {
         ProfScope ps(b, 2, scan_bytes);
@@ -2359,6 +2354,17 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             std::atomic_thread_fence(std::memory_order_acquire);
             return 0;
         };
+        // short sequences on a crowded chip: a round is ONE kernel (sq_pool_round.hip) + the scan kernel
+        const bool crowded_fold = b->inflight > 1 || b->njobs >= 4096;
+        SqPoolRoundArgs pra;
+        bool round_kernel = maxn <= SQ_PR_MAXN && !b->any_dense && (crowded_fold || b->pool_round_always) && !b->no_pool_round;
+        if (round_kernel) {
+            pra.lds_n = maxn; pra.str_cap = 2 * pio.pt + 2; pra.cell_entries = b->cell_entries;
+            pra.surv_cap = b->pool_round_nsurv ? b->pool_round_nsurv : (maxn <= 96 ? 128 : 256); pra.bound = b->score_bound ? 1 : 0;
+            pra.tmax = pio.pt; pra.parity = 0; pra.lo = 0;
+            if (sq_pool_round_lds(pra.lds_n, pra.str_cap, pra.cell_entries, pra.surv_cap, pra.tmax).total > 60 * 1024) round_kernel = false;
+        }
+        if (round_kernel) b->last_paths |= 8;
         const size_t ext_lds = sq_extend_lds_bytes(pio.pt);          // the extend kernel's level scratch (dynamic LDS)
         if (ext_lds > 64 * 1024) sq_max_dynamic_lds((const void *)sq_pool_extend_kernel, 160 * 1024);
         const double tr0 = now_s();
@@ -2373,7 +2379,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             io.h_ctr = ln.h_ctr; io.h_seq = ln.h_seq;
             for (int lo = 0; lo < S; lo += chunk) {              // (stream order: a chunk's chosen stems are out before the next one reuses the arena)
                 io.h_structs = cur + lo; io.d_structs = cur + lo;
-                launch_round_kernels(b, st, std::min(chunk, S - lo), maxn, maxcap, need_reacts, 0.0, 0, io, scan, cur + lo, pio.strands, true, true);
+                pra.parity = parity; pra.lo = lo;
+                launch_round_kernels(b, st, std::min(chunk, S - lo), maxn, maxcap, need_reacts, 0.0, 0, io, scan, cur + lo, pio.strands, true, true,
+                                     round_kernel ? &pra : nullptr);
             }
             const uint32_t seq = ++*ln.round_seq;
             hipLaunchKernelGGL(sq_pool_scan_kernel, dim3(1), dim3(1024), 0, st, pio, scan, io, parity, seq);
@@ -2381,7 +2389,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             // that finds nothing to do still takes a slot for a microsecond or two -- 593 k -> 601 k)
             static const int ext_crowd = getenv("SQ_POOL_EXTEND_WAVES") ? std::max(1, std::min(16, atoi(getenv("SQ_POOL_EXTEND_WAVES")))) : 1;
             const bool crowded = b->inflight > 1 || b->njobs >= 4096;
-            hipLaunchKernelGGL(sq_pool_extend_kernel, dim3(S, crowded ? ext_crowd : 4), dim3(64), ext_lds, st, b->ctx, scan, pio, parity);
+            if (!round_kernel)       // (the round kernel's structures extend themselves and log themselves)
+                hipLaunchKernelGGL(sq_pool_extend_kernel, dim3(S, crowded ? ext_crowd : 4), dim3(64), ext_lds, st, b->ctx, scan, pio, parity);
             if (wait_seq(seq)) return 2;
             rounds++;
             const SqCounters ctr = *ln.h_ctr;

@@ -172,7 +172,13 @@ extern "C" __global__ __launch_bounds__(1024) void sq_pool_scan_kernel(SqPoolIO 
         __syncthreads();
     }
     int run = s_part[tid] - sum;
-    for (int q = lo; q < hi; q++) { pio.child_off[q] = run; run += pio.nchild[q]; }
+    for (int q = lo; q < hi; q++) {
+        const int nc = pio.nchild[q];
+        pio.child_off[q] = run;
+        // (sq_pool_round_kernel: a child builds itself at the start of its round, from its parent and its pick)
+        for (int k = 0; k < nc; k++) if (run + k < pio.slots) pio.parent_of[run + k] = q;
+        run += nc;
+    }
     const int total = s_part[1023];
     if (tid == 0) pio.child_off[S] = total;
     __syncthreads();

@@ -13,15 +13,19 @@ struct SqPoolRoundArgs {
     int32_t cell_entries;   // doubles of the cell table
     int32_t surv_cap;       // survivors of :492 kept in LDS (the rest spill to the structure's slice of the candidate arena)
     int32_t bound;          // branch and bound on the finalscore
+    int32_t tmax;           // stems per structure slot (SqPoolIO::pt): the level scratch of the extension
+    int32_t parity;         // generation of this round's structures
+    int32_t lo;             // position in the round's list of the launch's first structure (chunked rounds)
 };
 
 struct SqPoolRoundLds {
     int np, fbh;
-    int off_P, off_U, off_SU, off_E, off_ci, off_code, off_fg, off_cell, off_str, off_skip, off_stage, off_surv;
-    int choose_cap;         // candidates within range the choose phase sorts (its arrays reuse everything before off_surv)
+    int off_P, off_U, off_SU, off_E, off_ci, off_code, off_fg, off_cell, off_str, off_sidx, off_skip, off_stems, off_stage, off_surv;
+    int t8;                 // stems the stem arrays hold (tmax rounded up to 8)
+    int choose_cap;         // candidates within range the choose phase sorts (its arrays reuse everything before off_stems)
     size_t total;
 };
-__host__ __device__ inline SqPoolRoundLds sq_pool_round_lds(int lds_n, int str_cap, int cell_entries, int surv_cap)
+__host__ __device__ inline SqPoolRoundLds sq_pool_round_lds(int lds_n, int str_cap, int cell_entries, int surv_cap, int tmax)
 {
     SqPoolRoundLds L;
     L.np = (lds_n + 8) & ~7;
@@ -37,13 +41,20 @@ __host__ __device__ inline SqPoolRoundLds sq_pool_round_lds(int lds_n, int str_c
     o = (o + 15) & ~15;
     L.off_cell = o; o += 8 * cell_entries;
     L.off_str = o; o += str_cap * (int)sizeof(SqStrand);
+    L.off_sidx = o; o += str_cap * 2;
     L.off_skip = o; o += str_cap * 2;
     o = (o + 15) & ~15;
-    L.off_stage = o; o += SQ_PR_STAGE * 8;
+    L.t8 = (tmax + 7) & ~7;
+    L.off_stems = o; o += 6 * L.t8;                            // the structure's stems: i, j, len (int16)
+    o = (o + 15) & ~15;
+    L.off_stage = o; o += SQ_PR_STAGE * 8;                     // (the extension's crossing weights and level scratch borrow this and the survivors' room)
     L.off_surv = o;
-    L.choose_cap = o / 16 < 512 ? o / 16 : 512;
-    L.total = (size_t)o + (size_t)22 * surv_cap + 16;
+    L.choose_cap = L.off_stems / 16 < 512 ? L.off_stems / 16 : 512;   // (the stems stay: a final structure logs them)
+    size_t tail = (size_t)22 * surv_cap + 16;
+    const size_t ext = (size_t)8 * L.t8 + 64 * 4 + 64 + 16;   // crossing weights (int32), order, group, level, group sizes, ranks
+    if (SQ_PR_STAGE * 8 + tail < ext) tail = ext - SQ_PR_STAGE * 8;
+    L.total = (size_t)o + tail;
     return L;
 }
 
-extern "C" __global__ void sq_pool_round_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra);
+extern "C" __global__ void sq_pool_round_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra);

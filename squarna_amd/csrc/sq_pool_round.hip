@@ -15,11 +15,18 @@
 //   choose      the stopper's single pick (:1147), or the range :769-778, the reference's stable descending order and
 //               the conflict filter :779-789 -- sq_pool_choose_kernel's steps on LDS data.
 //
-// What leaves the kernel is what sq_pool_scan_kernel / sq_pool_extend_kernel read: the children count, the final flag,
-// the chosen stems.  Results are those of the launched kernels bit for bit (tests fold both ways: SQ_NO_POOL_ROUND).
+//   extend      comes FIRST: a child builds itself -- parent + its pick through sq_extend_structure (crossing weights, levels,
+//               sorted strands), strands straight into LDS -- and leaves its lists in its slot for its own children; the
+//               launched form's sq_pool_extend_kernel (one wave per parent, a chain of a dozen dependent global loads per
+//               child: 95 % of its wave cycles waiting, a fifth of all wave cycles of a crowded step) is gone.  A child that
+//               is full (:1123-1129) and a structure that finds no stem (:1155-1156) log themselves as final.
+//
+// Between two rounds only sq_pool_scan_kernel runs (children's slots and parents, the jobs' pool state).  Results are those
+// of the launched kernels bit for bit (tests fold both ways: SQ_NO_POOL_ROUND).
 #include <hip/hip_runtime.h>
 #include "sq_device.h"
 #include "sq_extend.h"
+#include "sq_tail_dev.h"
 #include "sq_cells.h"
 #include "sq_cellrun.h"
 #include "sq_score.h"
@@ -98,25 +105,17 @@ struct SqPrSink {
     __device__ __forceinline__ void drain(int lane) { flush(lane); }
 };
 
-extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra)
+extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra)
 {
     extern __shared__ __attribute__((aligned(16))) char pr_dyn[];
     __shared__ SqCellTmp s_ctmp;
     __shared__ uint32_t s_cnt, s_nover;
     __shared__ int s_ri[SQ_POOL_CMAX], s_rj[SQ_POOL_CMAX], s_rl[SQ_POOL_CMAX];
     const int lane = threadIdx.x;
-    const SqStruct st = structs[blockIdx.x];                // (structs: the chunk of the round's list this launch covers)
-    const int s = st.slot;                                  // == the structure's position in the round's list
-    if (st.nstrand < 0) {                                   // a child that was full (:1123-1129): logged when it was made
-        if (lane == 0) { pio.nchild[s] = 0; pio.finalflag[s] = 0; }
-        return;
-    }
-    SqPoolJob *J = pio.jobs + pio.jobrec_of[st.job];
-    if (lane == 0) atomicAdd((unsigned long long *)&J->evals, 1ull);
-    const SqJob jb = c.jobs[st.job];
-    const SqPsetDev *ps = c.psets + jb.pset;
-    const int n = jb.n;
-    const SqPoolRoundLds Lo = sq_pool_round_lds(ra.lds_n, ra.str_cap, ra.cell_entries, ra.surv_cap);
+    const int s = ra.lo + (int)blockIdx.x;                  // the structure's position in the round's list == its slot
+    const size_t cur = (size_t)ra.parity * pio.smax, prv = (size_t)(ra.parity ^ 1) * pio.smax;
+    const uint32_t round = pio.hdr->round;                  // (sq_pool_scan_kernel advances it behind this kernel)
+    const SqPoolRoundLds Lo = sq_pool_round_lds(ra.lds_n, ra.str_cap, ra.cell_entries, ra.surv_cap, ra.tmax);
     int16_t *const P = reinterpret_cast<int16_t *>(pr_dyn + Lo.off_P);
     int16_t *const U = reinterpret_cast<int16_t *>(pr_dyn + Lo.off_U);
     int16_t *const SU = reinterpret_cast<int16_t *>(pr_dyn + Lo.off_SU);
@@ -125,18 +124,83 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c
     uint8_t *const l_code = reinterpret_cast<uint8_t *>(pr_dyn + Lo.off_code);
     uint32_t *const FG = reinterpret_cast<uint32_t *>(pr_dyn + Lo.off_fg);
     SqStrand *const s_str = reinterpret_cast<SqStrand *>(pr_dyn + Lo.off_str);
+    int16_t *const s_sidx = reinterpret_cast<int16_t *>(pr_dyn + Lo.off_sidx);
     uint16_t *const s_skip = reinterpret_cast<uint16_t *>(pr_dyn + Lo.off_skip);
     uint2 *const s_stage = reinterpret_cast<uint2 *>(pr_dyn + Lo.off_stage);
     double *const s_cell = reinterpret_cast<double *>(pr_dyn + Lo.off_cell);
+    // the structure's stems (for the log of final structures); the extension's other arrays borrow the room of the staging
+    // buffer and the survivors, which nobody uses yet
+    SqExtendLds XL;
+    XL.i = reinterpret_cast<int16_t *>(pr_dyn + Lo.off_stems); XL.j = XL.i + Lo.t8; XL.len = XL.j + Lo.t8;
+    XL.cc = reinterpret_cast<int32_t *>(pr_dyn + Lo.off_stage);
+    XL.gsize = XL.cc + Lo.t8;
+    XL.ord = reinterpret_cast<int16_t *>(XL.gsize + 64);
+    XL.grp = reinterpret_cast<uint8_t *>(XL.ord + Lo.t8); XL.lvl = XL.grp + Lo.t8; XL.rank = XL.lvl + Lo.t8;
     if (lane == 0) { s_cnt = 0; s_nover = 0; }
+
+    int job, nstems, nstrand; double maxstems;
+    auto log_final = [&](uint32_t round_kind, int nst) {    // (sq_pool_extend_kernel's record; the stems from LDS)
+        uint32_t idx = 0, so = 0;
+        if (lane == 0) { idx = atomicAdd(&pio.fin_ctr[0], 1u); so = atomicAdd(&pio.fin_ctr[1], (uint32_t)nst); }
+        idx = (uint32_t)__shfl((int)idx, 0, 64); so = (uint32_t)__shfl((int)so, 0, 64);
+        if (idx >= pio.fin_cap || so + (uint32_t)nst > pio.fin_stem_cap) { if (lane == 0) { pio.hdr->ovf = 1; pio.fin_ctr[2] = 1; } return; }
+        for (int q = lane; q < nst; q += 64) pio.fin_stems[so + q] = SqPoolStem{XL.i[q], XL.j[q], XL.len[q], 0};
+        if (lane == 0) pio.fin[idx] = SqPoolFin{job, SQ_FIN_KIND_G0 + round_kind, s, nst, so, SQ_FIN_SRC_LOG};
+    };
+    if (round == 0) {                                       // the empty structure of a job (sq_pool_init_kernel)
+        const SqStruct st0 = pio.structs[cur + s];
+        job = st0.job; nstems = 0; nstrand = 0; maxstems = pio.recs[cur + s].maxstems;
+    } else {
+        // ---- the child builds itself: parent p (previous generation) + its k-th pick ----
+        const int p = pio.parent_of[s];
+        const SqStruct pst = pio.structs[prv + p];
+        const SqChain prec = pio.recs[prv + p];
+        const int k = s - pio.child_off[p];                 // (child_off: the previous round's scan; this round's comes behind this kernel)
+        const SqPoolPick pk = pio.chosen[(prv + (size_t)p) * pio.cmax + k];
+        job = pst.job; maxstems = prec.maxstems;
+        if (prec.nstems >= pio.pt) { if (lane == 0) { pio.hdr->ovf = 1; pio.nchild[s] = 0; } return; }
+        const int i0 = (int)(pk.key & 0xFFFFu), j0 = (int)(pk.key >> 16) - i0, len = (int)pk.len;
+        const int toff = (int)((cur + (size_t)s) * (size_t)pio.pt);
+        SqChainStem *const cst = pio.stems + toff;
+        const bool anyc = sq_extend_structure(XL, a, pio.stems + prec.toff, prec.nstems, prec.anycross != 0, pio.strands + pst.strand_off,
+                                              pio.sidx + pst.strand_off, pst.nstrand, i0, j0, len, cst, s_str, s_sidx, lane);
+        __syncthreads();
+        nstems = prec.nstems + 1; nstrand = pst.nstrand + 2;
+        const bool full = (double)nstems == maxstems;
+        if (lane == 0) {
+            SqStruct cs;
+            cs.job = job; cs.strand_off = 2 * toff; cs.nstrand = full ? -1 : nstrand; cs.slot = s;
+            cs.subopt = pio.jobs[pio.jobrec_of[job]].cursubopt;
+            cs.cand_off = (int64_t)(s % pio.chunk) * pio.maxcap;
+            pio.structs[cur + s] = cs;
+            SqChain cr;
+            cr.toff = toff; cr.tcap = pio.pt; cr.nstems = nstems; cr.anycross = anyc ? 1 : 0; cr.maxstems = maxstems;
+            pio.recs[cur + s] = cr;
+        }
+        if (full) {                                          // :1123-1129: moved to finstemsets at the start of this round
+            log_final(2u * round, nstems);
+            if (lane == 0) { pio.nchild[s] = 0; pio.finalflag[s] = 0; }
+            return;
+        }
+        for (int q = lane; q < nstrand; q += 64) {           // the lists its own children will start from
+            pio.strands[2 * (size_t)toff + q] = s_str[q];
+            pio.sidx[2 * (size_t)toff + q] = s_sidx[q];
+        }
+        __syncthreads();
+    }
+    SqPoolJob *J = pio.jobs + pio.jobrec_of[job];
+    if (lane == 0) atomicAdd((unsigned long long *)&J->evals, 1ull);
+    const SqJob jb = c.jobs[job];
+    const SqPsetDev *ps = c.psets + jb.pset;
+    const int n = jb.n;
+    SqStruct st;                                            // what the phases below read of a structure record
+    st.job = job; st.slot = s; st.nstrand = nstrand; st.subopt = J->cursubopt; st.cand_off = (int64_t)(s % pio.chunk) * pio.maxcap; st.strand_off = 0;
     const SqCellEnv cenv = sq_cell_setup(c, jb, ps, s_ctmp, l_ci, l_code, s_cell, lane, 64);
 
     // ---- the structure's state (sq_state_build): partner array, mask codes, prefix counts, free-position words ----
     {
         const uint8_t *e0 = c.e0c + jb.pos_off;
         for (int p = lane; p < n; p += 64) { P[p] = -1; E[p] = e0[p]; }
-        const SqStrand *sd = pio.strands + st.strand_off;
-        for (int k = lane; k < st.nstrand; k += 64) s_str[k] = sd[k];
         __syncthreads();
         for (int k = lane; k < st.nstrand; k += 64) {
             const SqStrand x = s_str[k];
@@ -238,13 +302,14 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c
     }
     __threadfence_block();
     __syncthreads();
-    if (!anybest) {                                         // no stem passed the thresholds: the structure is final (:1155)
-        if (lane == 0) { pio.nchild[s] = 0; pio.finalflag[s] = 1; }
+    if (!anybest) {                                         // no stem passed the thresholds: the structure is final (:1155-1156)
+        log_final(2u * round + 1u, nstems);
+        if (lane == 0) { pio.nchild[s] = 0; pio.finalflag[s] = 0; }
         return;
     }
 
     // ---- ChooseStems (sq_pool_choose_kernel's steps) ----
-    SqPoolPick *out = pio.chosen + (size_t)s * pio.cmax;
+    SqPoolPick *out = pio.chosen + (cur + (size_t)s) * pio.cmax;
     const bool one = J->cursize >= pio.poollim;             // :1147 stopper
     if (one) {
         // only ChooseStems' first element is used: the highest finalscore, the smallest emission key among equals
@@ -312,8 +377,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c
         nres++;
         __syncthreads();
     }
-    if (lane == 0) {
-        if (over_c) { pio.hdr->ovf = 1; nres = 0; }
-        pio.nchild[s] = nres; pio.finalflag[s] = (nres == 0 && !over_c) ? 1 : 0;
-    }
+    if (over_c) { if (lane == 0) pio.hdr->ovf = 1; nres = 0; }
+    else if (nres == 0) log_final(2u * round + 1u, nstems);
+    if (lane == 0) { pio.nchild[s] = nres; pio.finalflag[s] = 0; }
 }

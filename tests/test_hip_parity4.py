@@ -108,17 +108,20 @@ def test_persistent_rounds_on_the_baseline_shapes(n, count, seed, reacts):
 def _pools_both_ways(prepared, psets, env=None, **kw):
     """Packed records of one batch folded with sq_pool_round_kernel (forced: SQ_POOL_ROUND_ALWAYS) and with the launched
     state / scan / score / choose kernels (SQ_NO_POOL_ROUND)."""
-    from squarna_amd.engine import Batch
+    from squarna_amd.engine import Batch, pool_slot_cap, pool_slots_wanted_many
     out = []
+    lengths = [len(p.shortseq) for p in prepared]
+    slots = int(min(pool_slots_wanted_many(lengths, psets, kw.get("poollim", 1000)).sum(), pool_slot_cap(max(lengths))))
     for launched in (False, True):
         extra = dict(env or {}) if not launched else {}
         extra["SQ_NO_POOL_ROUND" if launched else "SQ_POOL_ROUND_ALWAYS"] = "1"
         assert not any(k in os.environ for k in extra)
         os.environ.update(extra)
         try:
-            with Batch(prepared, psets, max_structs=8192, fp32=False) as b:
+            with Batch(prepared, psets, max_structs=max(slots, 4096), fp32=False) as b:
                 b.fold(**kw)
                 assert b.fold_driver == 2, b.fold_driver
+                assert bool(b.fold_paths & 8) == (not launched), b.fold_paths
                 buf, off = b.pack_all()
                 out.append(([buf[off[k]:off[k + 1]].tobytes() for k in range(len(prepared))], [r[0] for r in b.results_all()],
                             [b.evals(k) for k in range(len(prepared))]))
