@@ -270,7 +270,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
             need[q] = algo == SQ_ALGO_E
                           ? SqBlossom::scratch_bytes(mj[q].n, mj[q].nedges, 1) + (((size_t)mj[q].nedges * sizeof(SqMatchEdge) + 15) & ~(size_t)15) + 64
                       : algo == SQ_ALGO_H
-                          ? (size_t)mj[q].n * 42 + 64 + 16 + (size_t)mj[q].nedges * 8 + (size_t)mj[q].n * mj[q].n * 2 + 64
+                          ? sq_lsap_lds_bytes(mj[q].n, mj[q].nedges)
                           : (size_t)std::max(1, (mj[q].n + 63) / 64);
         std::vector<int> ord(nq);
         for (size_t q = 0; q < nq; q++) ord[q] = (int)q;

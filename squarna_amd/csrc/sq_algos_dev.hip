@@ -307,7 +307,13 @@ extern "C" __global__ __launch_bounds__(64) void sq_algo_finish_kernel(SqDevCtx 
     uint32_t idx = 0, so = 0;
     if (lane == 0) { idx = atomicAdd(&fin_ctr[0], 1u); so = atomicAdd(&fin_ctr[1], (uint32_t)nout); }
     idx = (uint32_t)__shfl((int)idx, 0, 64); so = (uint32_t)__shfl((int)so, 0, 64);
-    if (idx >= fin_cap || so + (uint32_t)nout > fin_stem_cap) { if (lane == 0) fin_ctr[2] = 1; return; }
+    if (idx >= fin_cap || so + (uint32_t)nout > fin_stem_cap) {
+        if (lane == 0) {                                                 // (no slot of the log stays unwritten; the tail reports the flag)
+            fin_ctr[2] = 1;
+            if (idx < fin_cap) fin[idx] = SqPoolFin{aj.job, aj.algo == SQ_ALGO_E ? SQ_FIN_KIND_E : aj.algo == SQ_ALGO_H ? SQ_FIN_KIND_H : SQ_FIN_KIND_N, 0, 0, 0u, SQ_FIN_SRC_LOG};
+        }
+        return;
+    }
     int w = 0;
     for (int t0 = 0; t0 < K2; t0 += 64) {                               // the stems stay in sorted order (ascending i)
         const int t = t0 + lane;

@@ -543,6 +543,7 @@ int plan(const sq_batch_desc *d, Layout &L)
         L.fin_cap = (uint32_t)(want + 2 * (int64_t)d->njobs);
         L.fin_stem_cap = (uint32_t)std::min<int64_t>(std::min<int64_t>(want * std::min(std::max(pt_any / 3, 8), 128), (int64_t)48 << 20) + 2 * L.chain_T,
                                                      (int64_t)0x7FFFFFF0);
+        if (const char *e = getenv("SQ_FIN_STEM_CAP")) L.fin_stem_cap = (uint32_t)std::min<int64_t>(L.fin_stem_cap, std::max(16, atoi(e)));   // (tests: the log's stem room runs out)
         L.pow_len = 4 * L.maxn + 16;
         const size_t fc = L.fin_cap;
         L.off_fin = take(sizeof(SqPoolFin) * fc); L.off_fin_stems = take(sizeof(SqPoolStem) * (size_t)L.fin_stem_cap);

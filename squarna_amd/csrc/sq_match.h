@@ -20,6 +20,23 @@ struct SqMatchJob {
     int32_t next, pad;
 };
 
+// dynamic LDS of one Hungarian job: the row / column vectors (42 bytes per position) and the cost matrix in sparse form --
+// the matrix is zero except for the 2m stem cells: per row a bit mask of its non-zero columns with per-word prefix counts,
+// the edge ids of a row's cells in column order (16 bits each) and the m edge weights.  150 nt / 1,320 edges: 27 KB (the
+// dense form -- 16-bit ids for all n^2 cells -- took 62 KB, and LDS a job holds for its milliseconds is LDS the other
+// kernels on the chip do not get)
+#ifdef __HIPCC__
+#define SQ_HD __host__ __device__
+#else
+#define SQ_HD
+#endif
+SQ_HD static inline size_t sq_lsap_vec_bytes(int n) { return ((size_t)n * (3 * 8 + 4 * 4 + 2) + 15) & ~(size_t)15; }
+SQ_HD static inline size_t sq_lsap_sparse_bytes(int n, int m)
+{
+    const size_t nw = ((size_t)n + 31) / 32;
+    return (size_t)m * 8 + (size_t)n * nw * 4 + ((((size_t)n + 1) * 2 + 3) & ~(size_t)3) + (((size_t)n * nw * 2 + 3) & ~(size_t)3) + (size_t)m * 4 + 16;
+}
+SQ_HD static inline size_t sq_lsap_lds_bytes(int n, int m) { return sq_lsap_vec_bytes(n) + sq_lsap_sparse_bytes(n, m) + 64; }
 size_t sq_lsap_scratch_bytes(int n);
 size_t sq_nussinov_scratch_bytes(int n);
 size_t sq_mwm_scratch_bytes(int n, int nedges);

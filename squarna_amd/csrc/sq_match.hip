@@ -37,23 +37,27 @@ extern "C" __global__ __launch_bounds__(64) void sq_lsap_kernel(const SqMatchJob
     double *cost = reinterpret_cast<double *>(scratch + jb.scratch_off);
     double *u = cost + (size_t)n * n;
     // the per-row/column vectors are touched in every step of the augmenting path: LDS when they fit
-    const size_t vec_bytes = ((size_t)n * (3 * 8 + 4 * 4 + 2) + 15) & ~(size_t)15;
+    const size_t vec_bytes = sq_lsap_vec_bytes(n);
     const bool vec_lds = vec_bytes + 64 <= (size_t)lds_bytes;
     if (vec_lds) u = reinterpret_cast<double *>(lsap_lds);
     double *v = u + n, *spc = v + n;
     int32_t *path = reinterpret_cast<int32_t *>(spc + n);
     int32_t *col4row = path + n, *row4col = col4row + n, *remaining = row4col + n;
     uint8_t *SR = reinterpret_cast<uint8_t *>(remaining + n), *SC = SR + n;
-    // the cost matrix is zero except for the 2m stem cells: when it fits, LDS holds it as 16-bit edge ids
-    // (+ the edge weights), so a step of the shortest-path scan never leaves the CU
+    // the cost matrix is zero except for the 2m stem cells: when it fits, LDS holds it in sparse form (sq_match.h) -- a step
+    // of the shortest-path scan never leaves the CU, and a zero cell costs one mask word
     const int m = jb.nedges;
-    const bool mat_lds = vec_lds && m < 65535 && vec_bytes + (size_t)m * 8 + (size_t)n * n * 2 + 64 <= (size_t)lds_bytes;
+    const int nw = (n + 31) >> 5;
+    const bool mat_lds = vec_lds && m < 32767 && vec_bytes + sq_lsap_sparse_bytes(n, m) + 64 <= (size_t)lds_bytes;
     double *wts = reinterpret_cast<double *>(lsap_lds + vec_bytes);
-    uint16_t *ids = reinterpret_cast<uint16_t *>(wts + m);
+    uint32_t *mask = reinterpret_cast<uint32_t *>(wts + m);                                   // [n][nw] non-zero columns of a row
+    uint16_t *rowstart = reinterpret_cast<uint16_t *>(mask + (size_t)n * nw);                 // [n + 1] into cids
+    uint16_t *pre = rowstart + ((n + 1 + 1) & ~1);                                            // [n][nw] cells of the row in earlier words
+    uint16_t *cids = pre + (((size_t)n * nw + 1) & ~(size_t)1);                               // [2m] edge ids, row by row in column order
 
     // mat = zeros; mat[v,w] = mat[w,v] = -(score**power)   (SQRNalgos.py:119-123)
     if (mat_lds) {
-        for (size_t q = lane; q < ((size_t)n * n + 1) / 2; q += 64) reinterpret_cast<uint32_t *>(ids)[q] = 0u;
+        for (int q = lane; q < n * nw; q += 64) mask[q] = 0u;
     } else {
         for (size_t q = lane; q < (size_t)n * n; q += 64) cost[q] = 0.0;
     }
@@ -64,8 +68,32 @@ extern "C" __global__ __launch_bounds__(64) void sq_lsap_kernel(const SqMatchJob
         for (int e = lane; e < m; e += 64) {
             const SqMatchEdge ed = edges[jb.edge_off + e];
             wts[e] = ed.weight;
-            ids[(size_t)ed.v * n + ed.w] = (uint16_t)(e + 1);
-            ids[(size_t)ed.w * n + ed.v] = (uint16_t)(e + 1);
+            atomicOr(&mask[ed.v * nw + (ed.w >> 5)], 1u << (ed.w & 31));
+            atomicOr(&mask[ed.w * nw + (ed.v >> 5)], 1u << (ed.v & 31));
+        }
+        __syncthreads();
+        // per-word prefix counts of every row, the rows' starts (a wave scan over chunks of rows)
+        const int per = (n + 63) / 64, r0 = min(lane * per, n), r1 = min(r0 + per, n);
+        int mine = 0;
+        for (int r = r0; r < r1; r++) {
+            int acc = 0;
+            for (int w = 0; w < nw; w++) { pre[r * nw + w] = (uint16_t)acc; acc += __popc(mask[r * nw + w]); }
+            mine += acc;
+        }
+        int inc = mine;
+        for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(inc, off); if (lane >= off) inc += y; }
+        int run = inc - mine;
+        for (int r = r0; r < r1; r++) {
+            rowstart[r] = (uint16_t)run;
+            run += (int)pre[r * nw + nw - 1] + __popc(mask[r * nw + nw - 1]);
+        }
+        if (lane == 63) rowstart[n] = (uint16_t)inc;
+        __syncthreads();
+        for (int e = lane; e < m; e += 64) {
+            const SqMatchEdge ed = edges[jb.edge_off + e];
+            const int a = ed.v, c = ed.w;
+            cids[rowstart[a] + pre[a * nw + (c >> 5)] + __popc(mask[a * nw + (c >> 5)] & ((1u << (c & 31)) - 1u))] = (uint16_t)e;
+            cids[rowstart[c] + pre[c * nw + (a >> 5)] + __popc(mask[c * nw + (a >> 5)] & ((1u << (a & 31)) - 1u))] = (uint16_t)e;
         }
     } else {
         for (int e = lane; e < m; e += 64) {
@@ -91,7 +119,12 @@ extern "C" __global__ __launch_bounds__(64) void sq_lsap_kernel(const SqMatchJob
             for (int it = lane; it < nrem; it += 64) {
                 const int j = remaining[it];
                 double cij;
-                if (mat_lds) { const uint16_t id = ids[(size_t)i * n + j]; cij = id ? -wts[id - 1] : 0.0; }
+                if (mat_lds) {
+                    const uint32_t wd = mask[i * nw + (j >> 5)];
+                    cij = 0.0;
+                    if ((wd >> (j & 31)) & 1u)
+                        cij = -wts[cids[(int)rowstart[i] + (int)pre[i * nw + (j >> 5)] + __popc(wd & ((1u << (j & 31)) - 1u))]];
+                }
                 else cij = cost[(size_t)i * n + j];
                 const double r = minval + cij - ui - v[j];
                 double sp = spc[j];
@@ -170,7 +203,10 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
     double *cs = S;                                                     // [m] scores
     int32_t *ck = reinterpret_cast<int32_t *>(cs + m);                  // [m] row k
     int32_t *col_off = ck + m, *cursor = col_off + (n + 1);            // [n + 1], [n]
-    for (size_t q = tid; q < (size_t)n * n; q += nthr) { D[q] = 0.0; K[q] = -2; has[q] = 0; }
+    // (the DP writes D and K of every cell above the main diagonal before anything reads them: only the diagonal of D and
+    // BackTrack's marks start at zero -- zeroing all three tables was 21 bytes per cell of traffic per job)
+    for (size_t q = tid; q < (size_t)n * n; q += nthr) has[q] = 0;
+    for (int q = tid; q < n; q += nthr) D[(size_t)q * n + q] = 0.0;
     for (int q = tid; q <= n; q += nthr) col_off[q] = 0;
     __syncthreads();
     for (int e = tid; e < m; e += nthr) atomicAdd(&col_off[edges[jb.edge_off + e].w + 1], 1);
@@ -199,18 +235,37 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
         for (int i = tid; i < n - h; i += nthr) {
             const int j = i + h;
             int bestk = -1; double best = 1e9;                          // :70
-            for (int x = col_off[j]; x < col_off[j + 1]; x++) {         // k in range(i, j - 1) with (k, j) in SCORES (:73-74)
-                const int k = ck[x];
-                if (k < i) continue;
-                if (k >= j - 1) break;
-                // D[i, k-1] with k == i is numpy's D[i, -1] = D[i, n-1], still 0 at this point (:76)
-                const double dik = k > i ? D[(size_t)i * n + (k - 1)] : D[(size_t)i * n + (n - 1)];
-                const double sc = dik + D[(size_t)(k + 1) * n + (j - 1)] + cs[x];
-                if (sc < best) { bestk = k; best = sc; }
+            // k in range(i, j - 1) with (k, j) in SCORES (:73-74), ascending; four list entries per trip: their (independent)
+            // loads are issued together -- a cell waited for one L2 round trip per entry, and a diagonal lasts as long as
+            // its longest cell -- and compared in list order (first best k, :77)
+            const int x1 = col_off[j + 1];
+            for (int x = col_off[j]; x < x1; x += 4) {
+                int kk[4]; double d1[4], d2[4], cw[4]; bool ok[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) kk[t] = x + t < x1 ? ck[x + t] : 0x7fffffff;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    ok[t] = kk[t] >= i && kk[t] < j - 1;
+                    d1[t] = 0.0; d2[t] = 0.0; cw[t] = 0.0;
+                    if (ok[t]) {
+                        // D[i, k-1] with k == i is numpy's D[i, -1] = D[i, n-1], which no cell has written yet at this point: 0 (:76)
+                        if (kk[t] > i) d1[t] = D[(size_t)i * n + (kk[t] - 1)];
+                        d2[t] = D[(size_t)(kk[t] + 1) * n + (j - 1)];
+                        cw[t] = cs[x + t];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (ok[t]) {
+                        const double sc = d1[t] + d2[t] + cw[t];
+                        if (sc < best) { bestk = kk[t]; best = sc; }
+                    }
+                if (kk[3] >= j - 1) break;
             }
             const double dprev = D[(size_t)i * n + (j - 1)];
-            if (best <= dprev) { K[(size_t)i * n + j] = bestk; D[(size_t)i * n + j] = best; }   // :80-83
-            else D[(size_t)i * n + j] = dprev;
+            const bool take = best <= dprev;                            // :80-83
+            K[(size_t)i * n + j] = take ? bestk : -2;
+            D[(size_t)i * n + j] = take ? best : dprev;
         }
         __syncthreads();
     }
@@ -463,10 +518,12 @@ int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatch
     int maxn = 0, maxm = 0;
     for (int q = 0; q < nj; q++) { maxn = maxn > h_jobs[q].n ? maxn : h_jobs[q].n; maxm = maxm > h_jobs[q].nedges ? maxm : h_jobs[q].nedges; }
     if (algo == 4) {                                     // SQ_ALGO_H
-        // LDS: the row/column vectors and, when it fits, the cost matrix as 16-bit edge ids + the edge weights
-        size_t lds = (size_t)maxn * 42 + 64 + 16 + (size_t)maxm * 8 + (size_t)maxn * maxn * 2 + 64;
+        // LDS: the row/column vectors and, when it fits, the cost matrix in sparse form (sq_match.h); every job of the launch
+        // must find room: the largest n and the largest m may belong to different jobs
+        size_t lds = 0;
+        for (int q = 0; q < nj; q++) lds = std::max(lds, sq_lsap_lds_bytes(h_jobs[q].n, h_jobs[q].nedges));
         if (lds > 64 * 1024) sq_max_dynamic_lds((const void *)sq_lsap_kernel, 150 * 1024);
-        if (lds > 150 * 1024) lds = (size_t)maxn * 42 + 64 + 16 < 150 * 1024 ? (size_t)maxn * 42 + 64 + 16 : 150 * 1024;   // vectors only
+        if (lds > 150 * 1024) lds = sq_lsap_vec_bytes(maxn) + 64 < 150 * 1024 ? sq_lsap_vec_bytes(maxn) + 64 : 150 * 1024;   // vectors only
         hipLaunchKernelGGL(sq_lsap_kernel, dim3(nj), dim3(64), lds, st, jobs, edges, d_scr, out, (int)lds);
     } else if (algo == 2) {                              // SQ_ALGO_N
         // an anti-diagonal of the DP has at most n cells: no more waves than that keeps busy (the block holds its wave slots

@@ -143,7 +143,13 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c
         uint32_t idx = 0, so = 0;
         if (lane == 0) { idx = atomicAdd(&pio.fin_ctr[0], 1u); so = atomicAdd(&pio.fin_ctr[1], (uint32_t)nst); }
         idx = (uint32_t)__shfl((int)idx, 0, 64); so = (uint32_t)__shfl((int)so, 0, 64);
-        if (idx >= pio.fin_cap || so + (uint32_t)nst > pio.fin_stem_cap) { if (lane == 0) { pio.hdr->ovf = 1; pio.fin_ctr[2] = 1; } return; }
+        if (idx >= pio.fin_cap || so + (uint32_t)nst > pio.fin_stem_cap) {
+            if (lane == 0) {                                 // (the host repeats the fold with its own loop and an empty log)
+                pio.hdr->ovf = 1; pio.fin_ctr[2] = 1;
+                if (idx < pio.fin_cap) pio.fin[idx] = SqPoolFin{job, SQ_FIN_KIND_G0 + round_kind, s, 0, 0u, SQ_FIN_SRC_LOG};
+            }
+            return;
+        }
         for (int q = lane; q < nst; q += 64) pio.fin_stems[so + q] = SqPoolStem{XL.i[q], XL.j[q], XL.len[q], 0};
         if (lane == 0) pio.fin[idx] = SqPoolFin{job, SQ_FIN_KIND_G0 + round_kind, s, nst, so, SQ_FIN_SRC_LOG};
     };

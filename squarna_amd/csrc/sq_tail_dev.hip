@@ -100,7 +100,9 @@ extern "C" __global__ __launch_bounds__(1024) void sq_tail_scan_kernel(SqTailIO 
         t.seqs[s].first = a; t.seqs[s].count = b - a;
     }
     if (tid == 0) {
-        if (*t.nfin_ptr > t.fin_cap) *t.fallback = 1;                  // the log overflowed
+        // the log overflowed (entries, or stems: fin_ctr[1] counts them, fin_ctr[2] is the writers' flag -- an entry whose
+        // stems found no room is a tombstone without stems): nothing below may be trusted, the host reports it
+        if (*t.nfin_ptr > t.fin_cap || t.nfin_ptr[1] > t.fin_stem_cap || t.nfin_ptr[2] != 0) { *t.fallback = 1; t.h_totals[6] = 1; }
         t.h_totals[3] = (long long)min(*t.nfin_ptr, t.fin_cap);
     }
 }
@@ -656,7 +658,11 @@ extern "C" __global__ __launch_bounds__(256) void sq_fin_append_kernel(const SqP
     if (q >= n) return;
     SqPoolFin F = src[q];
     const uint32_t idx = atomicAdd(&ctr[0], 1u), so = atomicAdd(&ctr[1], (uint32_t)F.nstems);
-    if (idx >= fin_cap || so + (uint32_t)F.nstems > stem_cap) { ctr[2] = 1; return; }
+    if (idx >= fin_cap || so + (uint32_t)F.nstems > stem_cap) {
+        ctr[2] = 1;
+        if (idx < fin_cap) { F.nstems = 0; F.stem_off = 0; F.pad = SQ_FIN_SRC_LOG; fin[idx] = F; }   // (no slot of the log stays unwritten)
+        return;
+    }
     for (int k = 0; k < F.nstems; k++) stems[so + k] = src_stems[F.stem_off + k];
     F.stem_off = so; F.pad = SQ_FIN_SRC_LOG;
     fin[idx] = F;
@@ -780,6 +786,8 @@ int sq_tail_device(sq_batch *b, const sq_fold_opts &o, const int32_t *ref_off, c
         const int thr = wide ? SQ_TAIL_THREADS_WIDE : SQ_TAIL_THREADS;
         const int keycap = wide ? 1024 : 256;                    // rank keys staged in LDS (25 bytes each; more structures: global path)
         const size_t lds = ((((size_t)(thr / 64) * bitwords + 1) & ~(size_t)1) * 4) + (size_t)keycap * 25 + 8;
+        if (lds > 160 * 1024) return 1;                          // (the host tail takes such a batch)
+        if (lds > 64 * 1024) sq_max_dynamic_lds((const void *)sq_tail_rank_kernel, 160 * 1024);
         hipLaunchKernelGGL(sq_tail_rank_kernel, dim3(b->nseq), dim3(thr), lds, st, b->ctx, t, bitwords, keycap);
     }
     uint32_t seq = ++*ln.round_seq;
@@ -824,11 +832,13 @@ int sq_tail_device(sq_batch *b, const sq_fold_opts &o, const int32_t *ref_off, c
         if (sq_check(hipGetLastError(), "device tail launch")) return 2;
         r = tail_wait(b, ln, seq, "device tail (records)");
         if (r) return r;
+        if (b->h_tail_totals[6]) { sq_set_error("the log of final structures overflowed (raise max_structs)"); return -3; }
         if (b->h_tail_totals[2]) return 1;                              // some sequence needs the host tail
         packed = !b->h_tail_totals[5];
     } else {
         r = tail_wait(b, ln, seq, "device tail (ranking)");
         if (r) return r;
+        if (b->h_tail_totals[6]) { sq_set_error("the log of final structures overflowed (raise max_structs)"); return -3; }
         if (b->h_tail_totals[2]) return 1;
     }
     const size_t rec_bytes = (size_t)b->h_tail_totals[0], txt_bytes = (size_t)b->h_tail_totals[1];

@@ -185,3 +185,24 @@ def test_pool_round_kernel_on_srtest150_sets_in_flight():
     finally:
         for b in batches:
             b.close()
+
+
+def test_log_of_final_structures_overflow_is_reported():
+    """The device log of final structures with too little room for the stems: the fold must say so (no entry of the log may
+    stay unwritten and be ranked as if it were a structure)."""
+    from squarna_amd.engine import Batch, Prepared
+    names, psets = conf("nobpp")
+    raw = _chain_records(40, 31, 60, 200)
+    prepared = [Prepared(s, r, x) for s, r, x in raw]
+    assert "SQ_FIN_STEM_CAP" not in os.environ
+    os.environ["SQ_FIN_STEM_CAP"] = "64"
+    try:
+        with Batch(prepared, [psets] * len(prepared), max_structs=4096, fp32=False) as b:
+            with pytest.raises(Exception) as ei:
+                b.fold(poollim=1)
+            assert "log of final structures" in str(ei.value) or "capacity" in str(ei.value), str(ei.value)
+    finally:
+        del os.environ["SQ_FIN_STEM_CAP"]
+    with Batch(prepared, [psets] * len(prepared), max_structs=4096, fp32=False) as b:     # the same batch with room: fine
+        b.fold(poollim=1)
+        assert b.fold_paths & 1
