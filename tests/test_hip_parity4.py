@@ -192,8 +192,9 @@ def test_log_of_final_structures_overflow_is_reported():
     stay unwritten and be ranked as if it were a structure)."""
     from squarna_amd.engine import Batch, Prepared
     names, psets = conf("nobpp")
-    raw = _chain_records(40, 31, 60, 200)
-    prepared = [Prepared(s, r, x) for s, r, x in raw]
+    rng = np.random.default_rng(31)
+    # (plain records: RunAlgo's filters run on the device and append their stemsets to the log themselves)
+    prepared = [Prepared("".join(rng.choice(list("ACGU"), int(n)))) for n in rng.integers(60, 200, 40)]
     assert "SQ_FIN_STEM_CAP" not in os.environ
     os.environ["SQ_FIN_STEM_CAP"] = "64"
     try:
