@@ -528,7 +528,11 @@ int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatch
     } else if (algo == 2) {                              // SQ_ALGO_N
         // an anti-diagonal of the DP has at most n cells: no more waves than that keeps busy (the block holds its wave slots
         // through the single-threaded BackTrack too)
-        const int nthr = std::max(64, std::min(256, (maxn + 63) / 64 * 64));
+        // (with the chip crowded ONE wave per job: a block of three waves holds three wave slots through every barrier-separated
+        // diagonal, and wave slots are what a crowded chip runs out of -- a lane then takes up to three cells of a diagonal)
+        static const int env_thr = getenv("SQ_NUSS_THREADS") ? std::max(64, std::min(256, atoi(getenv("SQ_NUSS_THREADS")) / 64 * 64)) : 0;
+        const bool crowd = (long long)nj * std::max(1, inflight) >= 1024;
+        const int nthr = env_thr ? env_thr : crowd ? 64 : std::max(64, std::min(256, (maxn + 63) / 64 * 64));
         hipLaunchKernelGGL(sq_nussinov_kernel, dim3(nj), dim3(nthr), 0, st, jobs, edges, codes, d_scr, out, cnt, jobs_rw ? 1 : 0);
     } else {                                             // SQ_ALGO_E
         // bins: see sq_mwm_plan.  The plan writes each job's LDS slice into the job table the kernel reads.

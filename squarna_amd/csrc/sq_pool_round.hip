@@ -113,6 +113,15 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c
     __shared__ int s_ri[SQ_POOL_CMAX], s_rj[SQ_POOL_CMAX], s_rl[SQ_POOL_CMAX];
     const int lane = threadIdx.x;
     const int s = ra.lo + (int)blockIdx.x;                  // the structure's position in the round's list == its slot
+#ifdef SQ_PR_PROF
+    long long _pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
+#define PRPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)
+#define PRPROF_OUT(ns_, nin_) do { if (lane == 0 && (s % 997) == 0) printf("pool round s=%d n=%d nstrand=%d ns=%u nin=%d | us: extend %.1f setup %.1f state %.1f scan %.1f score %.1f choose %.1f total %.1f\n", \
+        s, n, nstrand, (unsigned)(ns_), (int)(nin_), _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, (wall_clock64() - _t00) * 0.01); } while (0)
+#else
+#define PRPROF(k) do {} while (0)
+#define PRPROF_OUT(ns_, nin_) do {} while (0)
+#endif
     const size_t cur = (size_t)ra.parity * pio.smax, prv = (size_t)(ra.parity ^ 1) * pio.smax;
     const uint32_t round = pio.hdr->round;                  // (sq_pool_scan_kernel advances it behind this kernel)
     const SqPoolRoundLds Lo = sq_pool_round_lds(ra.lds_n, ra.str_cap, ra.cell_entries, ra.surv_cap, ra.tmax);
@@ -194,6 +203,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c
         }
         __syncthreads();
     }
+    PRPROF(0);
     SqPoolJob *J = pio.jobs + pio.jobrec_of[job];
     if (lane == 0) atomicAdd((unsigned long long *)&J->evals, 1ull);
     const SqJob jb = c.jobs[job];
@@ -202,6 +212,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c
     SqStruct st;                                            // what the phases below read of a structure record
     st.job = job; st.slot = s; st.nstrand = nstrand; st.subopt = J->cursubopt; st.cand_off = (int64_t)(s % pio.chunk) * pio.maxcap; st.strand_off = 0;
     const SqCellEnv cenv = sq_cell_setup(c, jb, ps, s_ctmp, l_ci, l_code, s_cell, lane, 64);
+    PRPROF(1);
 
     // ---- the structure's state (sq_state_build): partner array, mask codes, prefix counts, free-position words ----
     {
@@ -256,6 +267,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c
         __syncthreads();
     }
 
+    PRPROF(2);
     // ---- AnnotateStems + :492 ----
     SqPrSurv sv;
     sv.bps = reinterpret_cast<double *>(pr_dyn + Lo.off_surv); sv.fin = sv.bps + ra.surv_cap;
@@ -278,6 +290,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c
     __threadfence_block();
     __syncthreads();
 
+    PRPROF(3);
     // ---- ScoreStems on the survivors, finalscores beside them; the best one ----
     const double ps_lb = ps->loopbonus;
     const double ub_of = ps->ub_of, ub_lf = ra.bound ? ps->ub_lf : INFINITY;
@@ -308,6 +321,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c
     }
     __threadfence_block();
     __syncthreads();
+    PRPROF(4);
     if (!anybest) {                                         // no stem passed the thresholds: the structure is final (:1155-1156)
         log_final(2u * round + 1u, nstems);
         if (lane == 0) { pio.nchild[s] = 0; pio.finalflag[s] = 0; }
@@ -383,6 +397,8 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c
         nres++;
         __syncthreads();
     }
+    PRPROF(5);
+    PRPROF_OUT(ns, nin);
     if (over_c) { if (lane == 0) pio.hdr->ovf = 1; nres = 0; }
     else if (nres == 0) log_final(2u * round + 1u, nstems);
     if (lane == 0) { pio.nchild[s] = nres; pio.finalflag[s] = 0; }
