@@ -631,19 +631,27 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
     const bool off = getenv("SQ_NO_DEVICE_ALGOS") != nullptr;           // (read per fold: tests compare both forms in one process)
     if (off || pa->items.empty()) return 1;
     std::vector<int> all;
+    std::vector<uint8_t> need_raw;
     int maxn = 0, tmax = 1;
+    size_t raw_cap = 0;
     for (auto &it : pa->items) {
         for (int j : it.jobs) {
             const SqJob &J = b->jobs[j];
             maxn = std::max(maxn, J.n);
+            uint8_t nr = 0;
             if (it.algo != SQ_ALGO_N) {
                 // Edmonds / Hungarian weigh an edge with stemscore ** 1.7 from the host libm: on the device that is a table
-                // lookup, valid when the score is k 2^-q exactly (dyadic weights, no reactivity factors, no dense matrix)
-                if (!J.default_reacts || J.mat64_off >= 0 || b->psets_dev[J.pset].pow_len <= 0) return 1;
+                // lookup when the score is k 2^-q exactly (dyadic weights, no reactivity factors); the other jobs -- decided
+                // per JOB -- leave their stem scores in pinned memory and the host raises them in bulk (SqAlgoRaw)
+                if (J.mat64_off >= 0) return 1;
+                if (!J.default_reacts || b->psets_dev[J.pset].pow_len <= 0) { nr = 1; raw_cap += (size_t)4 * J.n + 64; }
             }
             all.push_back(j);
+            need_raw.push_back(nr);
         }
     }
+    static const bool no_raw = getenv("SQ_NO_ALGO_RAW") != nullptr;      // (measurement: such batches take the host-driven form)
+    if (raw_cap && no_raw) return 1;
     if (maxn > SQ_ALGO_MAXN || maxn < 1) return 1;
     tmax = std::max(b->chain_tmax, 1);
     const size_t fin_lds = sq_algo_finish_lds(maxn, tmax);
@@ -651,12 +659,37 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
     const int S = (int)all.size();
     // pinned: the sizes of all jobs (slot 3 of the staging buffers is free while a fold runs)
     // (and, behind them, the per-job records the edges kernel reads: one allocation, the buffer must not move in between)
-    char *pin = stage_buffer(b, 3, sizeof(SqAlgoSize) * (size_t)S + 256 + sizeof(SqAlgoJob) * (size_t)S + 256);
+    const size_t o_aj = (sizeof(SqAlgoSize) * (size_t)S + 255) & ~(size_t)255;
+    const size_t o_need = (o_aj + sizeof(SqAlgoJob) * (size_t)S + 255) & ~(size_t)255;
+    const size_t o_raw = (o_need + (size_t)S + 255) & ~(size_t)255;
+    char *pin = stage_buffer(b, 3, o_raw + 8 * raw_cap + 256);
     if (!pin) return 2;
     pa->h_sizes = (SqAlgoSize *)pin;
+    SqAlgoRaw raw{nullptr, nullptr, nullptr, 0};
+    if (raw_cap) {
+        memcpy(pin + o_need, need_raw.data(), (size_t)S);
+        raw.need = (const uint8_t *)(pin + o_need); raw.vals = (double *)(pin + o_raw);
+        raw.ctr = b->d_fin_ctr + 8;                         // (a word of the fold's counter block: zero since sq_fold_begin_kernel)
+        raw.cap = (uint32_t)std::min<size_t>(raw_cap, 0x7FFFFFF0u);
+    }
     int64_t cands_used = 0;
-    int r = sq_round_annotate_dev(b, all, pa->h_sizes, &cands_used);
+    int r = sq_round_annotate_dev(b, all, pa->h_sizes, &cands_used, raw);
     if (r) return r;                                       // (1: does not fit one round)
+    if (raw_cap) {
+        // stemscore ** 1.7 with the host's libm, in place (the reference: Python's float ** on every stem, SQRNalgos.py:101,122)
+        CpuScope cpu_(2);
+        std::vector<std::pair<int, int>> spans;
+        size_t total = 0;
+        for (int s2 = 0; s2 < S; s2++)
+            if (need_raw[s2]) {
+                const SqAlgoSize &z = pa->h_sizes[s2];
+                if (z.raw_base < 0) return 1;               // the list had no room: the host-driven form takes the batch
+                spans.push_back({z.raw_base, z.nok}); total += (size_t)z.nok;
+            }
+        auto one = [&](int k) { double *v = raw.vals + spans[k].first; for (int q = 0; q < spans[k].second; q++) v[q] = pow(v[q], 1.7); };
+        if (total >= 32768) sq_pool(b)->parallel_for((int)spans.size(), one);
+        else for (int k = 0; k < (int)spans.size(); k++) one(k);
+    }
     // ---- layout of every item: job table, scratch, LDS classes (algo_build without stems) ----
     const int64_t half = b->cand_records / 2;
     size_t base = 0;
@@ -697,7 +730,7 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
     struct Carve { size_t o_edges, o_out, o_cnt, o_vid, o_stat, o_scr; };
     std::vector<Carve> cv(pa->items.size());
     // the edges kernel takes one record per structure of the round: all items' records, contiguous, in round order
-    SqAlgoJob *round_aj = (SqAlgoJob *)(pin + ((sizeof(SqAlgoSize) * (size_t)S + 255) & ~(size_t)255));
+    SqAlgoJob *round_aj = (SqAlgoJob *)(pin + o_aj);
     base = 0;
     for (size_t q = 0; q < pa->items.size(); q++) {
         auto &it = pa->items[q];
@@ -714,6 +747,7 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
             aj.job = it.jobs[k]; aj.algo = it.algo;
             aj.edges = (SqMatchEdge *)(regions[q] + cv[q].o_edges) + mj[k].edge_off;
             aj.vid2pos = (int32_t *)(regions[q] + cv[q].o_vid) + vid;
+            aj.raw = need_raw[base + k] ? raw.vals + pa->h_sizes[base + k].raw_base : nullptr;
             if (it.algo == SQ_ALGO_E) vid += (size_t)mj[k].n;
             it.ck.p_aj[k] = aj;
             round_aj[base + k] = aj;

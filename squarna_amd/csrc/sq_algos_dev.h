@@ -10,12 +10,23 @@ struct SqAlgoSize {                // per E / H / N job after its AnnotateStems 
     int32_t nedges;                // cells of its stems
     int32_t nv;                    // distinct positions on them (Edmonds: graph vertices)
     int32_t nok;                   // stems
-    int32_t pad;
+    int32_t raw_base;              // jobs whose edge weights need the host libm: where its nok stem scores start in the raw list
+                                   // (-1: weights from the paramset's table; -2: the list had no room)
+};
+// Edmonds / Hungarian jobs whose stem scores are not multiples of 2^-q (reactivity factors, non-dyadic weights): the sizes
+// kernel leaves the scores of their stems in pinned host memory, the host raises them to the power 1.7 with ITS libm -- what
+// CPython's `**` calls (SQRNalgos.py:101,122) -- in one loop over the array, and the edges kernel reads the weights there
+struct SqAlgoRaw {
+    const uint8_t *need;           // pinned: per structure of the round, 1: the job's weights go through the host
+    double *vals;                  // pinned: the raw list (scores, then their powers, in place)
+    uint32_t *ctr;                 // device: entries taken
+    uint32_t cap;
 };
 struct SqAlgoJob {                 // per job, for the edges / finish kernels (pinned, written by the host once the sizes are known)
     int32_t job, algo;             // batch job index, SQ_ALGO_*
     SqMatchEdge *edges;            // device: the job's edge list
     int32_t *vid2pos;              // device, Edmonds: graph vertex -> sequence position
+    const double *raw;             // pinned: stemscore ** 1.7 of the job's stems in survivor-list order (nullptr: the paramset's table)
 };
 struct SqAlgoStat {                // per launch of the finish kernel (device; sq_algo_publish_kernel copies it to the host)
     uint32_t bad;                  // 1: blossom capacity exceeded, 2: stem capacity exceeded
@@ -27,7 +38,7 @@ struct SqAlgoStat {                // per launch of the finish kernel (device; s
 
 #ifdef __HIPCC__
 extern "C" {
-__global__ void sq_algo_sizes_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqAlgoSize *sizes);
+__global__ void sq_algo_sizes_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqAlgoSize *sizes, SqAlgoRaw raw);
 __global__ void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs, int maxn_lds);
 __global__ void sq_algo_finish_kernel(SqDevCtx c, const SqAlgoJob *jobs, const SqMatchJob *mj, const int32_t *out, const int32_t *cnt,
                                       int levellimit_opt, SqPoolFin *fin, SqPoolStem *fin_stems, uint32_t *fin_ctr, uint32_t fin_cap,

@@ -26,21 +26,31 @@
 __device__ __forceinline__ double sq_algo_cell(const SqDevCtx &c, const SqJob &jb, const SqPsetDev *ps, int i, int j) { return sq_cell_exact(c, jb, ps, i, j); }
 
 // ---- sizes ----------------------------------------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(256) void sq_algo_sizes_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqAlgoSize *sizes)
+extern "C" __global__ __launch_bounds__(256) void sq_algo_sizes_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqAlgoSize *sizes, SqAlgoRaw raw)
 {
     __shared__ uint32_t s_seen[SQ_ALGO_MAXN / 32];
-    __shared__ int s_edges, s_nv;
+    __shared__ int s_edges, s_nv, s_rawbase;
     const SqStruct st = structs[blockIdx.x];
     const SqJob jb = c.jobs[st.job];
     const int tid = threadIdx.x;
     const uint32_t nok = a.ok_cnt[st.slot];
     const SqOk *oks = sq_oks(a, st, jb.cand_cap);
     for (int w = tid; w < (jb.n + 31) / 32; w += 256) s_seen[w] = 0u;
-    if (tid == 0) { s_edges = 0; s_nv = 0; }
+    if (tid == 0) {
+        s_edges = 0; s_nv = 0;
+        int rb = -1;
+        if (raw.need && raw.need[blockIdx.x]) {                          // the job's stem scores go to the host (see SqAlgoRaw)
+            const uint32_t at = atomicAdd(raw.ctr, nok);
+            rb = at + nok <= raw.cap ? (int)at : -2;
+        }
+        s_rawbase = rb;
+    }
     __syncthreads();
+    const int rawbase = s_rawbase;
     int e = 0;
     for (uint32_t q = tid; q < nok; q += 256) {
         const SqOk cd = oks[q];
+        if (rawbase >= 0) raw.vals[rawbase + q] = cd.bps;
         const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
         e += (int)cd.len;
         for (int t = 0; t < (int)cd.len; t++) {
@@ -54,7 +64,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_sizes_kernel(SqDevCtx 
     for (int w = tid; w < (jb.n + 31) / 32; w += 256) nv += __popc(s_seen[w]);
     atomicAdd(&s_nv, nv);
     __syncthreads();
-    if (tid == 0) sizes[blockIdx.x] = SqAlgoSize{s_edges, s_nv, (int32_t)nok, 0};
+    if (tid == 0) sizes[blockIdx.x] = SqAlgoSize{s_edges, s_nv, (int32_t)nok, rawbase};
 }
 
 // ---- edge lists -----------------------------------------------------------------------------------------------------
@@ -126,7 +136,8 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx 
         const SqOk cd = oks[sidx[x]];
         const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
         double wt = cd.bps;                                             // Nussinov: the score itself (SQRNalgos.py:49)
-        if (aj.algo != SQ_ALGO_N) wt = c.powtab[ps->pow_off + (int)(cd.bps * ps->pow_scale)];   // :101,122 (k 2^-q exactly)
+        if (aj.algo != SQ_ALGO_N)                                       // :101,122: the host libm's power, from the paramset's table
+            wt = aj.raw ? aj.raw[sidx[x]] : c.powtab[ps->pow_off + (int)(cd.bps * ps->pow_scale)];   // (k 2^-q exactly) or the job's list
         SqMatchEdge *e = aj.edges + eoff[x];
         for (int t = 0; t < (int)cd.len; t++) {
             const int v = i0 + t, w = j0 - t;

@@ -266,7 +266,8 @@ int sq_run_round(sq_batch *b, const std::vector<SView> &structs, int mode, std::
 
 // AnnotateStems of E / H / N jobs with the stems left on the device (sq_host.hip; used by the device-side RunAlgo)
 struct SqAlgoSize;
-int sq_round_annotate_dev(sq_batch *b, const std::vector<int> &jobs, SqAlgoSize *h_sizes, int64_t *cands_used);
+struct SqAlgoRaw;
+int sq_round_annotate_dev(sq_batch *b, const std::vector<int> &jobs, SqAlgoSize *h_sizes, int64_t *cands_used, const SqAlgoRaw &raw);
 
 // RunAlgo (SQRNdbnseq.py:548-595) for one of SQ_ALGO_E / H / N over a list of jobs
 int sq_run_algo(sq_batch *b, const std::vector<int> &jobs, int algo, int levellimit_opt,

@@ -1662,7 +1662,7 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
 // of the round = jobs[k] with no selected stems, its survivors (SqOk records) in its slice of the candidate arena, and per
 // job the sizes the host needs to lay out the matching step (sq_algos_dev.hip).  One round, one wait.  Returns 1 when the
 // jobs do not fit one round of the full lane (the caller keeps the host-driven form).
-int sq_round_annotate_dev(sq_batch *b, const std::vector<int> &jobs, SqAlgoSize *h_sizes, int64_t *cands_used)
+int sq_round_annotate_dev(sq_batch *b, const std::vector<int> &jobs, SqAlgoSize *h_sizes, int64_t *cands_used, const SqAlgoRaw &raw)
 {
     { int r = sq_prepare_scan(b); if (r) return r; }
     SqLane &ln = b->lane_full;
@@ -1689,7 +1689,7 @@ int sq_round_annotate_dev(sq_batch *b, const std::vector<int> &jobs, SqAlgoSize 
     SqScanArgs scan = b->scan;
     scan.ctr = ln.d_ctr;
     launch_round_kernels(b, st, S, maxn, maxcap, need_reacts, scan_bytes, 2, io, scan, ln.d_structs, ln.d_strands, false);
-    hipLaunchKernelGGL(sq_algo_sizes_kernel, dim3(S), dim3(256), 0, st, b->ctx, ln.d_structs, scan, h_sizes);
+    hipLaunchKernelGGL(sq_algo_sizes_kernel, dim3(S), dim3(256), 0, st, b->ctx, ln.d_structs, scan, h_sizes, raw);
     const uint32_t seq = ++*ln.round_seq;
     hipLaunchKernelGGL(sq_done_kernel, dim3(1), dim3(1), 0, st, io, scan, seq);
     HIPCK(hipGetLastError());
