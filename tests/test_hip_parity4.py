@@ -207,3 +207,49 @@ def test_log_of_final_structures_overflow_is_reported():
     with Batch(prepared, [psets] * len(prepared), max_structs=4096, fp32=False) as b:     # the same batch with room: fine
         b.fold(poollim=1)
         assert b.fold_paths & 1
+
+
+def test_shape_records_run_the_device_runalgo_and_equal_the_oracle():
+    """SRtest150 with encoded reactivity lines ("_+#") and records with float reactivities under nobpp (E, H, N and two
+    greedy paramsets), mixed with plain records: every job's RunAlgo stays on the device (sq_fold_paths bit 1; stemscore **
+    1.7 of the jobs with reactivity factors comes from the host's libm in bulk), packed records equal the host-driven form
+    byte for byte and the oracle's structures and scores."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.dbn import ProcessReacts, ReactDict
+    from squarna_amd.engine import Batch, Prepared
+    from squarna_amd.inputs import ParseDefaultInput
+    names, psets = conf("nobpp")
+    rng = np.random.default_rng(150)
+    recs = list(ParseDefaultInput(os.path.join(os.path.dirname(os.path.dirname(__file__)), "squarna_amd", "data", "datasets", "SRtest150.fas"), "qf"))
+    data = []
+    for k, r in enumerate(recs[:150]):
+        seq = r[1]
+        if k % 5 == 4:
+            data.append((seq, None))                                              # plain records in between
+        elif k % 5 == 3:
+            data.append((seq, [float(x) for x in rng.random(len(seq))]))          # float reactivities
+        else:
+            line = rng.choice(list("_+#"), len(seq), p=[0.5, 0.3, 0.2])
+            data.append((seq, ProcessReacts([ReactDict[c] for c in line], M=1.8, B=-0.6)))
+    prepared = [Prepared(s, rc) for s, rc in data]
+    with Batch(prepared, [psets] * len(prepared), fp32=False, max_structs=8192) as b:
+        b.fold(poollim=1000)
+        assert b.fold_paths & 2, b.fold_paths
+        buf, off = b.pack_all()
+        dev = [buf[off[k]:off[k + 1]].tobytes() for k in range(len(prepared))]
+        got = [r[0] for r in b.results_all()]
+        assert "SQ_NO_DEVICE_ALGOS" not in os.environ
+        os.environ["SQ_NO_DEVICE_ALGOS"] = "1"
+        try:
+            b.fold(poollim=1000)
+            assert not (b.fold_paths & 2)
+            buf, off = b.pack_all()
+            host = [buf[off[k]:off[k + 1]].tobytes() for k in range(len(prepared))]
+        finally:
+            del os.environ["SQ_NO_DEVICE_ALGOS"]
+    assert dev == host
+    for k in range(0, len(data), 6):
+        s, rc = data[k]
+        exp = O.SQRNdbnseq(s, rc, None, None, psets, poollim=1000)
+        exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(got[k], exp, ("shape", k))
