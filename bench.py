@@ -143,8 +143,9 @@ def cpu_baseline(workers, recs, cfg, target_s=10.0):
     pool, cores = workers
     recs = [r + (1000,) for r in recs]
     _oracle_init(cfg)
-    t1 = sum(_oracle_one(r) for r in recs[::8])            # one thread alone, on a slice
-    per_pass = t1 * 8
+    # one thread alone over the SAME record mix the pool folds (the whole set once; the pool repeats it longest first), so
+    # that per_thread_seq_per_s / one_thread_alone_seq_per_s is what sharing the host costs a worker and nothing else
+    per_pass = sum(_oracle_one(r) for r in recs)
     tasks = sorted(recs, key=lambda r: -len(r[1])) * 400   # more than any host finishes in target_s: cut off by the clock
     done, busy = 0, 0.0
     # a sliding window of 3 x cores tasks in flight (the same pool takes the S1000 / S2000 samples afterwards: nothing may
@@ -166,6 +167,8 @@ def cpu_baseline(workers, recs, cfg, target_s=10.0):
         r.get()
     out = dict(value=round(done / wall, 1), unit="seq/s", cores=cores, kind="port",
                per_thread_seq_per_s=round(done / max(busy, 1e-9), 2), one_thread_alone_seq_per_s=round(len(recs) / per_pass, 2),
+               per_thread_note="both over whole passes of the record set (the pool's last pass may be cut by the clock: longest first, "
+                               "so its figure is a lower bound by at most one pass in %d)" % max(1, done // len(recs)),
                sample="SRtest150 records (longest first, repeated) for %.1f s of wall time: %d folds, c=%s, C oracle "
                       "(oracle/sqrn_oracle.c + Python tail, scipy / networkx for H / E), one single-threaded process per CPU the "
                       "job may use (cores = min(hardware threads %d, affinity, cgroup quota)), summed worker time %.1fs" % (
@@ -477,10 +480,10 @@ def sharded_leg(workload, steps, warmup, rank, world, device, sub_batches=0):
         if world == 1:
             return [(buf, off)]
         head = np.concatenate([np.array([len(mine)], np.int64), np.array(mine, np.int64), off]).view(np.uint8)
-        body = np.concatenate([head, buf])
         # the product's own result gather (squarna_amd.parallel.gather_bytes, also the end of PredictSharded): exact
-        # sizes, to rank 0 only
-        return gather_bytes(body, 0, device)
+        # sizes, to rank 0 only; the packed records go as their own segment (a single batch: straight from the library's
+        # pinned result buffer)
+        return gather_bytes([head, buf], 0, device)
 
     def fence():
         torch.cuda.synchronize()
@@ -539,6 +542,103 @@ def sharded_leg(workload, steps, warmup, rank, world, device, sub_batches=0):
                 n_ranks_seen=world if world == 1 else dist.get_world_size(), ms_per_step_by_rank=per_rank_ms,
                 records_rank0=len(mine), evals_R_rank0=int(evals),
                 gathered_records_complete=bool(ok), records_checked_against_local_fold=checked)
+
+
+# ---------------------------------------------------------------- strong-scaling proxy on ONE GPU
+def scaling_proxy_leg(workloads=("S300", "S1000", "S2000"), shards=(2, 4, 8), reps=5):
+    """What a rank of an N-GPU run folds, measured at world size 1: rank 0's lpt_partition shard of the SURVEY 8d workload
+    folded alone (resident inputs, fold + sq_result_pack_all, one batch), next to the whole workload.  The shards are
+    independent (no data-path collective; the packed results of a rank are KBs), so T(shard) bounds the step of an N-GPU
+    run from below and predicted_efficiency = T(full) / (N x T(shard)) is what strong scaling can reach at most."""
+    import torch
+    from squarna_amd.config import ParseConfig, builtin_config
+    from squarna_amd.engine import Batch
+    from squarna_amd.parallel import lpt_partition
+    names, psets = ParseConfig(builtin_config("fastest"))
+    out = {}
+    for wl in workloads:
+        items = synthetic(wl)
+        cost = [float(len(s)) ** 2 for s, _ in items]
+
+        def time_of(idx):
+            prepared = prepare_synthetic([items[k] for k in idx])
+            with Batch(prepared, [psets] * len(prepared), max_structs=max(len(prepared), 1), fp32=False) as b:
+                for _ in range(2):
+                    b.fold(poollim=1)
+                    b.pack_all()
+                ts = []
+                for _ in range(reps):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    b.fold(poollim=1)
+                    b.pack_all()
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+            return sorted(ts)[len(ts) // 2] * 1e3
+        full = time_of(list(range(len(items))))
+        row = {"records": len(items), "ms_full": round(full, 3)}
+        for n in shards:
+            mine = lpt_partition(cost, n)[0]
+            t = time_of(mine)
+            row["shard_of_%d" % n] = {"records_rank0": len(mine), "ms_shard": round(t, 3),
+                                      "predicted_efficiency": round(full / (n * t), 3)}
+        out[wl] = row
+    out["how"] = ("one GPU: ms_full = fold + pack of the whole workload as one resident batch (median of %d); ms_shard = the same for rank "
+                  "0's lpt_partition (N^2) shard of an N-rank run; predicted_efficiency = ms_full / (N x ms_shard) -- an upper bound of "
+                  "strong scaling (the gather of the packed records and rank imbalance come on top)" % reps)
+    return out
+
+
+# ---------------------------------------------------------------- SHAPE data under nobpp
+def shape_leg(recs, config, K, R, steps, device):
+    """SRtest150 with a reactivity line per record (drawn per position from "_+#", p = 0.5 / 0.3 / 0.2: raw 0.0 / 0.5 / 1.0
+    through ProcessReacts, the S2000 recipe of SURVEY 8d), c=nobpp: the reference's main use case with probing data.  Every
+    E / H job then needs stemscore ** 1.7 from the host libm (bulk, sq_algos_dev.h); RunAlgo itself stays on the device."""
+    import numpy as np
+    import torch
+    from squarna_amd.config import ParseConfig, builtin_config
+    from squarna_amd.dbn import ProcessReacts, ReactDict
+    from squarna_amd.engine import Batch, Prepared, fold_concurrently
+    names, psets = ParseConfig(builtin_config(config))
+    rng = np.random.default_rng(150)
+    prepared = []
+    for _, seq, reacts, restr, ref in recs:
+        line = rng.choice(list("_+#"), len(seq), p=[0.5, 0.3, 0.2])
+        prepared.append(Prepared(seq, ProcessReacts([ReactDict[c] for c in line], M=1.8, B=-0.6), restr, ref))
+    n = len(prepared)
+    lat = []
+    for q in range(8):                                        # one pass: Batch() + fold + pack, nothing else in flight
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with Batch(prepared, [psets] * n, fp32=False) as b:
+            b.fold(poollim=1000)
+            b.pack_all()
+            paths = b.fold_paths
+        torch.cuda.synchronize()
+        if q >= 2:
+            lat.append((time.perf_counter() - t0) * 1e3)
+    lat.sort()
+    batches = []
+    for _ in range(K):
+        with torch.cuda.stream(torch.cuda.Stream(device)):
+            batches.append(Batch(prepared * R, [psets] * (n * R), fp32=False, max_structs=4096 * R))
+    torch.cuda.synchronize()
+    try:
+        fold_concurrently(batches, reps=2, poollim=1000)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fold_concurrently(batches, reps=steps, poollim=1000)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        paths_many = min(b.fold_paths for b in batches)
+    finally:
+        for b in batches:
+            b.close()
+    return dict(what="SRtest150 + a '_+#' reactivity line per record, c=%s poollim=1000" % config,
+                one_pass_ms=round(lat[len(lat) // 2], 3), one_pass_seq_per_s=round(n / lat[len(lat) // 2] * 1e3, 1),
+                resident=dict(batches_in_flight=K, sets_per_batch=R, steps=steps, ms_per_step=round(dt / steps * 1e3, 3),
+                              seq_per_s=round(n * R * K * steps / dt, 1)),
+                runalgo_on_device=bool(paths & 2) and bool(paths_many & 2), tail_on_device=bool(paths & 1))
 
 
 def main():
@@ -725,6 +825,18 @@ def main():
         except Exception as e:                                # (a secondary leg never takes the headline down)
             end_to_end = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    shape = proxy = None
+    if rank == 0 and world == 1 and not args.no_stream:
+        try:
+            shape = shape_leg(recs, args.config, K, R, max(3, args.steps // 4), device)
+        except Exception as e:                                # (a secondary leg never takes the headline down)
+            shape = {"error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0 and world == 1 and not args.no_roofline:
+        try:
+            proxy = scaling_proxy_leg()
+        except Exception as e:                                # (a secondary leg never takes the headline down)
+            proxy = {"error": "%s: %s" % (type(e).__name__, e)}
+
     stream = one_pass = None
     if rank == 0 and world == 1 and not args.no_stream:
         try:
@@ -740,6 +852,8 @@ def main():
             one_pass["vs_cpu_baseline"] = round(one_pass["seq_per_s"] / cpu["value"], 1)
         if stream and "seq_per_s" in stream:
             stream["vs_cpu_baseline"] = round(stream["seq_per_s"] / cpu["value"], 1)
+        if end_to_end and "seq_per_s" in end_to_end:
+            end_to_end["vs_cpu_baseline"] = round(end_to_end["seq_per_s"] / cpu["value"], 1)
 
     sharded = None
     if world > 1:
@@ -802,6 +916,8 @@ def main():
         "one_pass": one_pass,
         "stream": stream,
         "end_to_end": end_to_end,
+        "shape_nobpp": shape,
+        "strong_scaling_proxy": proxy,
         "sharded": sharded,
         "n_ranks_seen": world if world == 1 else nranks_seen,
     }

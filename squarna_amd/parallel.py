@@ -35,33 +35,45 @@ def _collective_device(device=None, group=None):
     return torch.device("cpu")
 
 
+MAX_SEGMENTS = 4
+
+
 def gather_bytes(body, dst=0, device=None, group=None):
-    """The single result gather of the multi-GPU path: every rank's packed payload (a uint8 array) travels to
-    rank `dst` ONLY, at its exact size -- one all_gather of an int64 per rank for the sizes, then one batch of
-    point-to-point transfers (RCCL send / recv over xGMI on GPU ranks, i.e. a gather without padding; gloo on CPU).
-    Returns the list of payloads (uint8 numpy arrays, by rank) on `dst`, None elsewhere.  PredictSharded and bench.py's
-    sharded legs both end in this call."""
+    """The single result gather of the multi-GPU path: every rank's packed payload travels to rank `dst` ONLY,
+    at its exact size -- one all_gather of the sizes, then one batch of point-to-point transfers (RCCL send / recv over
+    xGMI on GPU ranks, i.e. a gather without padding; gloo on CPU).  `body`: a uint8 array, or up to MAX_SEGMENTS of them
+    (e.g. an index header + the library's pinned result buffer): the segments are sent as they are -- the pinned buffer
+    goes host -> device in ONE DMA, no pageable copy in front -- and arrive concatenated.  Returns the list of payloads
+    (uint8 numpy arrays, by rank) on `dst`, None elsewhere.  PredictSharded and bench.py's sharded legs both end here."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    body = np.ascontiguousarray(body, dtype=np.uint8)
+    segs = [body] if isinstance(body, np.ndarray) or not isinstance(body, (list, tuple)) else list(body)
+    segs = [np.ascontiguousarray(x, dtype=np.uint8) for x in segs]
+    assert 1 <= len(segs) <= MAX_SEGMENTS
     if world == 1:
-        return [body]
+        return [segs[0] if len(segs) == 1 else np.concatenate(segs)]
     dev = _collective_device(device, group)
-    size = torch.tensor([body.size], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    size = torch.tensor([x.size for x in segs] + [-1] * (MAX_SEGMENTS - len(segs)), dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(MAX_SEGMENTS, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, size, group=group)
-    sizes = [int(t.item()) for t in sizes]
-    ops, bufs = [], [None] * world
+    sizes = [[int(v) for v in t.tolist() if v >= 0] for t in sizes]
+    ops, bufs, keep = [], [None] * world, []
     if rank == dst:
         for r in range(world):
-            if r != dst and sizes[r]:
-                bufs[r] = torch.empty(sizes[r], dtype=torch.uint8, device=dev)
-                ops.append(dist.P2POp(dist.irecv, bufs[r], _global_rank(r, group), group))
-    elif body.size:
-        mine = torch.from_numpy(body).to(dev)
-        ops.append(dist.P2POp(dist.isend, mine, _global_rank(dst, group), group))
+            if r != dst:
+                bufs[r] = [torch.empty(n, dtype=torch.uint8, device=dev) if n else None for n in sizes[r]]
+                ops += [dist.P2POp(dist.irecv, t, _global_rank(r, group), group) for t in bufs[r] if t is not None]
+    else:
+        for x in segs:
+            if x.size:
+                if not x.flags.writeable:
+                    x = x.copy()                                # (torch wants a writable array; it never writes a send buffer)
+                t = torch.from_numpy(x)
+                t = t.to(dev, non_blocking=True) if dev.type == "cuda" else t
+                keep.append(t)
+                ops.append(dist.P2POp(dist.isend, t, _global_rank(dst, group), group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
@@ -69,8 +81,25 @@ def gather_bytes(body, dst=0, device=None, group=None):
             torch.cuda.synchronize(dev)
     if rank != dst:
         return None
-    return [body if r == dst else (bufs[r].cpu().numpy() if bufs[r] is not None else np.zeros(0, np.uint8))
-            for r in range(world)]
+    out = []
+    for r in range(world):
+        if r == dst:
+            out.append(segs[0] if len(segs) == 1 else np.concatenate(segs))
+            continue
+        n = sum(sizes[r])
+        if dev.type == "cuda":                                  # device -> pinned host, one buffer per sender
+            host = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+            at = 0
+            for t in bufs[r]:
+                if t is not None:
+                    host[at:at + t.numel()].copy_(t, non_blocking=True)
+                    at += t.numel()
+            torch.cuda.synchronize(dev)
+            out.append(host.numpy())
+        else:
+            parts = [t.numpy() for t in bufs[r] if t is not None]
+            out.append(np.concatenate(parts) if parts else np.zeros(0, np.uint8))
+    return out
 
 
 def _global_rank(r, group):
@@ -105,7 +134,7 @@ def pack_indexed(items):
     """{record index: bytes} -> one uint8 payload: int64 count, then (index, length) pairs, then the blobs."""
     idx = sorted(items)
     head = np.array([len(idx)] + [v for k in idx for v in (k, len(items[k]))], dtype=np.int64)
-    return np.frombuffer(head.tobytes() + b''.join(items[k] for k in idx), dtype=np.uint8)
+    return np.frombuffer(bytearray(head.tobytes() + b''.join(items[k] for k in idx)), dtype=np.uint8)   # (writable: torch.from_numpy)
 
 
 def unpack_indexed(raw, out):

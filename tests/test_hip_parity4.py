@@ -253,3 +253,18 @@ def test_shape_records_run_the_device_runalgo_and_equal_the_oracle():
         exp = O.SQRNdbnseq(s, rc, None, None, psets, poollim=1000)
         exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
         _same_fold(got[k], exp, ("shape", k))
+
+
+def test_soak_slice_2000_random_records_under_nobpp():
+    """A 2,000-record slice of the parity soak (tools/fuzz_parity.py: random sequences with reactivities, restraints,
+    chains, gaps; all five algorithms; the CPU oracle in worker processes against the HIP engine).  At this size the
+    batch runs the crowded forms: sq_pool_round_kernel, one wave per Nussinov job, the blossom kernel with several
+    graphs per block and several queue vertices per scan pass -- whose resolution of two lists' claims to one vertex rests
+    on LDS executing one wave's stores in program order: re-checked on every run of the GPU suite."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "2000", "nobpp", "401"],
+                       cwd=root, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-2000:]
+    assert r.returncode == 0 and "2000 records (config nobpp, poollim 1000), 0 mismatches" in r.stdout, tail

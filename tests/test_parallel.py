@@ -89,3 +89,56 @@ def test_sharded_alignment_world2_matches_reference(tmp_path):
     for tag, _ in jobs:
         with open(os.path.join(GOLDEN, "text", tag + ".txt")) as f:
             assert open(str(tmp_path / (tag + ".txt"))).read() == f.read(), tag
+
+
+GATHER_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    import torch.distributed as dist
+    from squarna_amd.parallel import allgather_bytes, gather_bytes, pack_indexed, unpack_indexed
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    rng = np.random.default_rng(7)
+    blobs = {k: bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) for k, n in enumerate((0, 5, 1000, 77777, 1, 0, 64))}
+    mine = {k: v for k, v in blobs.items() if k %% 2 == rank}
+    # (1) one array per rank, (2) two segments per rank, (3) rank 1 has nothing to send, (4) all ranks get everything
+    got1 = gather_bytes(pack_indexed(mine), 0)
+    head = np.frombuffer(bytearray(b"HEAD%%d" %% rank), dtype=np.uint8)
+    got2 = gather_bytes([head, pack_indexed(mine)], 0)
+    got3 = gather_bytes(np.zeros(0, np.uint8) if rank == 1 else pack_indexed(mine), 0)
+    got4 = allgather_bytes(pack_indexed(mine))
+    ok = True
+    if rank == 0:
+        out = [None] * len(blobs)
+        for raw in got1:
+            unpack_indexed(raw, out)
+        ok = ok and out == [blobs[k] for k in range(len(blobs))]
+        ok = ok and all(bytes(got2[r][:5]) == b"HEAD%%d" %% r for r in range(2))
+        out2 = [None] * len(blobs)
+        for raw in got2:
+            unpack_indexed(raw[5:], out2)
+        ok = ok and out2 == out
+        ok = ok and len(got3) == 2 and got3[1].size == 0
+    else:
+        ok = got1 is None and got2 is None and got3 is None
+    out4 = [None] * len(blobs)
+    for raw in got4:
+        unpack_indexed(raw, out4)
+    ok = ok and out4 == [blobs[k] for k in range(len(blobs))]
+    open(os.path.join(%(out)r, "ok%%d" %% rank), "w").write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_gather_bytes_world2_exact_sizes_segments_and_empty_payload(tmp_path):
+    """parallel.gather_bytes / allgather_bytes between two gloo ranks: payloads of different sizes, several segments per
+    sender, a rank with nothing to send."""
+    script = tmp_path / "worker.py"
+    script.write_text(GATHER_WORKER % dict(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-W", "error::UserWarning", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29735", str(script)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
+    assert open(str(tmp_path / "ok0")).read() == "1" and open(str(tmp_path / "ok1")).read() == "1"
