@@ -50,7 +50,7 @@ void sq_max_dynamic_lds(const void *fn, int bytes)
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     std::lock_guard<std::mutex> lk(mu);
     for (const auto &d : done) if (d.first == fn && d.second == dev) return;
-    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) (void)hipGetLastError();   // (a launch that needs it reports the failure)
     done.emplace_back(fn, dev);
 }
 
@@ -2182,18 +2182,24 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         for (int j : jobs) rounds_ok = rounds_ok && b->jobs[j].mat64_off < 0 && !b->jobs[j].has_ext && b->jobs[j].n <= SQ_ROUNDS_MAXN;
         if (rounds_ok) {
             static const int thr_env = getenv("SQ_ROUNDS_THREADS") ? std::max(64, std::min(SQ_ROUNDS_THREADS, atoi(getenv("SQ_ROUNDS_THREADS")) / 64 * 64)) : 0;
-            const int thr = thr_env ? thr_env : (maxn <= 200 ? 64 : (maxn <= 450 ? 128 : SQ_ROUNDS_THREADS));
+            // threads per structure: by length -- and, while the launch leaves the chip empty (a shard of a multi-GPU run, a
+            // small batch), twice / four times that: a structure's rounds are a chain of dependent passes over its list that
+            // more waves shorten (S1000 x 128: 1.21 -> 0.99 ms at 512 threads)
+            int thr = maxn <= 200 ? 64 : (maxn <= 450 ? 128 : 256);
+            while (!thr_env && thr < SQ_ROUNDS_THREADS && thr < maxn / 2 && (int64_t)S * thr * 2 <= (int64_t)256 * 512) thr *= 2;
+            if (thr_env) { thr = 64; while (thr * 2 <= thr_env) thr *= 2; }   // (a power of two: the survivor ring is indexed with a mask)
             SqRoundsArgs ra;
             ra.lds_n = maxn; ra.str_cap = 2 * maxt + 2; ra.tmax = maxt; ra.cell_entries = b->cell_entries;
             ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0;
             const SqRoundsLds lo = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr);
-            if (lo.total + 1024 > 160 * 1024) rounds_ok = false;
+            if (lo.total + 2048 > 158 * 1024) rounds_ok = false;
             else {
-                if (lo.total > 48 * 1024) sq_max_dynamic_lds((const void *)sq_rounds_kernel, 160 * 1024);
+                if (lo.total > 60 * 1024) sq_max_dynamic_lds((const void *)sq_rounds_kernel, 158 * 1024);   // (the kernel has static LDS too: 160 KB in all)
                 {
                     ProfScope ps(b, 7, 0);
                     hipLaunchKernelGGL(sq_rounds_kernel, dim3(S), dim3(thr), lo.total, st, b->ctx, ln.d_structs, scan, b->chain, ra);
                 }
+                { const hipError_t le = hipGetLastError(); if (le != hipSuccess) { hipFuncAttributes fa; memset(&fa, 0, sizeof(fa)); hipFuncGetAttributes(&fa, (const void *)sq_rounds_kernel); fprintf(stderr, "[sq_fold] persistent rounds launch: S %d threads %d LDS %zu | kernel: maxThreadsPerBlock %d numRegs %d static LDS %zu maxDynamic %d local %zu\n", S, thr, lo.total, fa.maxThreadsPerBlock, fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes, fa.localSizeBytes); fail(sq_check(le, "persistent rounds launch"), sq_last_error()); } }
                 const uint32_t seq = ++*ln.round_seq;
                 hipLaunchKernelGGL(sq_chain_done_kernel, dim3(1), dim3(1), 0, st, io, scan, b->chain, seq);
                 launched = 1;

@@ -18,7 +18,7 @@ struct SqRun {
 #endif
 #define SQ_ROUNDS_STAGE 128        // runs a wave of the first round's scan stages in LDS before it appends them
 #define SQ_ROUNDS_MAXN 8192        // longest sequence whose per-position arrays the kernel keeps in LDS (9 bytes each)
-#define SQ_ROUNDS_THREADS 256      // widest block
+#define SQ_ROUNDS_THREADS 1024     // widest block (few structures: a structure's rounds are a latency chain that more waves shorten)
 
 struct SqRoundsArgs {
     int32_t lds_n;          // longest sequence of the launch
