@@ -531,7 +531,7 @@ class Batch:
                 fields.append(None)
                 continue
             text = "\n".join(x or "" for x in col)
-            if not text.isascii():
+            if not text.isascii() or "\0" in text:                    # (the library reads NUL-terminated ASCII lines)
                 return None
             fields.append(text.encode("ascii"))
         if fields[0] is None or fields[1] is None:
@@ -541,7 +541,9 @@ class Batch:
         d.names, d.seqs, d.reacts, d.restr, d.refs = fields
         ns = np.ascontiguousarray(nameset, np.int32)
         d.nameset = _ptr(ns, C.POINTER(C.c_int32))
-        pn = [("\n".join(x)).encode() for x in psnames]
+        if not all(nm.isascii() and "\0" not in nm and "\n" not in nm for x in psnames for nm in x):
+            return None                                               # (paramset names the library cannot carry: the caller formats)
+        pn = [("\n".join(x)).encode("ascii") for x in psnames]
         arr = (C.c_char_p * len(pn))(*pn)
         d.psnames = arr
         d.nsets, d.conslim, d.outplim = len(pn), int(conslim), int(outplim)
