@@ -117,6 +117,21 @@ __device__ __forceinline__ void sq_cellrun_cells4(const SqCellEnv &e, int i, int
 __device__ __forceinline__ double sq_cellrun_bps(const SqCellEnv &e, const SqDevCtx &c, const SqJob &jb, int i0, int j0, int L, double &pos)
 {
     double acc = 0.0, accp = 0.0;
+    if (jb.mat64_off >= 0) {
+        // jobs with a dense fp64 matrix (caller matrices, bpp terms, the alignment's weighted rows): the cells themselves.  In
+        // the diagonal-major layout (sq_cells.h) the cells of a run are consecutive doubles
+        const double *m = c.mat64 + jb.mat64_off;
+        const int64_t at = sq_m64_index(jb, i0, j0), step = jb.mat64_diag ? 1 : (int64_t)jb.n - 1;
+        for (int t = 0; t < L; t += 4) {
+            double v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = t + k < L ? m[at + (int64_t)(t + k) * step] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { acc = acc + v[k]; accp = accp + (v[k] > 0.0 ? v[k] : 0.0); }
+        }
+        pos = accp;
+        return acc;
+    }
     for (int t = 0; t < L; t += 4) {
         double v[4];
         if (e.cell_tab && j0 - t >= 3) sq_cellrun_cells4(e, i0 + t, j0 - t, min(4, L - t), v);

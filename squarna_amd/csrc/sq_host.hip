@@ -1924,6 +1924,24 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // the host repeat it with its own loop.
     const bool no_pool = getenv("SQ_NO_POOL") != nullptr;
     bool use_pool = !use_chain && o.poollim > 1 && !no_pool && !greedy_jobs.empty() && b->pool_io.pt > 0;
+    // the jobs each device driver takes.  Pools that may branch (poollim > 1) but almost never do -- range factor 1.0 (only
+    // exact ties branch, :769-778) over cells weighted by a dense fp64 matrix (the alignment's rows, bpp terms) -- first run
+    // as chains on the persistent round kernel, which stops a structure at the first tie; the device pools then fold what
+    // is left (tied_jobs) and every other job
+    std::vector<int> chain_jobs, pool_jobs_v, tied_jobs;
+    bool chain_ties = false;
+    if (use_chain) chain_jobs = greedy_jobs;
+    if (use_pool) {
+        static const bool no_opt = getenv("SQ_NO_OPT_CHAIN") != nullptr;
+        for (int j : greedy_jobs) {
+            const SqJob &J = b->jobs[j];
+            const sq_paramset &ps = b->psets[b->job_pset[j]];
+            const bool opt = !no_opt && !no_rounds && J.mat64_off >= 0 && ps.suboptmin == 1.0 && ps.suboptmax == 1.0 && J.n <= SQ_ROUNDS_MAXN &&
+                             chain_tcap(J.n, ps.minlen) <= SQ_CHAIN_TMAX && J.cand_cap <= b->cand_records - b->cand_reserved;
+            (opt ? chain_jobs : pool_jobs_v).push_back(j);
+        }
+        chain_ties = !chain_jobs.empty();
+    }
     auto host_pools_init = [&]() {
         for (int j : greedy_jobs) {
             JobPool &P = pools[j];
@@ -1974,7 +1992,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // the job's final stem list; handled by the queue's workers so that the thread that enqueues the rounds never waits
     auto chain_finish = [&](uint32_t q) {
         const unsigned long long e = b->chain.h_fin[q];
-        const int j = (int)(uint32_t)e, nst = (int)((e >> 32) & 0x7FFFFFFFu);
+        if ((e >> 62) & 1ull) return;                       // a structure that stopped at a tie: the device pools fold its job
+        const int j = (int)(uint32_t)e, nst = (int)((e >> 32) & 0x3FFFFFFFu);
         const bool by_count = (e >> 63) != 0;
         JobPool &P = pools[j];
         static_assert(sizeof(HStem) == sizeof(SqStemOut), "stem records must match");
@@ -1989,7 +2008,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         for (int s2 = 0; s2 < b->nseq; s2++) g_left[s2] = 0;
         for (int j : greedy_jobs) g_left[b->job_seq[j]]++;
     }
-    if (early_tail || use_chain) {
+    if (early_tail || use_chain || chain_ties) {
         sq_pool(b);
         tq.worker = std::thread([&] {
             if (b->device >= 0) hipSetDevice(b->device);
@@ -2133,11 +2152,11 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         // as many structures per chain as the round buffers hold at once (one chain after the other)
         const int64_t avail = b->cand_records - b->cand_reserved;
         size_t next_job = 0;
-        while (next_job < greedy_jobs.size() && !stats.rc) {
+        while (next_job < chain_jobs.size() && !stats.rc) {
         std::vector<int> jobs;                              // structure index -> job
         int maxn = 0, maxt = 0; int64_t cand_off = 0, maxcap = 0; bool need_reacts = false;
-        for (; next_job < greedy_jobs.size(); next_job++) {
-            const int j = greedy_jobs[next_job];
+        for (; next_job < chain_jobs.size(); next_job++) {
+            const int j = chain_jobs[next_job];
             JobPool &P = pools[j];
             if (P.maxstemnum == 0) { P.fin.emplace_back(); job_finished(j); continue; }   // :1168-1174 full before the first round
             const SqJob &J = b->jobs[j];
@@ -2179,7 +2198,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         // ONE launch for all rounds of these structures (sq_rounds.hip: a persistent block per structure) when every job
         // qualifies: no dense matrix behind its cells, per-position arrays that fit the block's LDS
         bool rounds_ok = !no_rounds;
-        for (int j : jobs) rounds_ok = rounds_ok && b->jobs[j].mat64_off < 0 && !b->jobs[j].has_ext && b->jobs[j].n <= SQ_ROUNDS_MAXN;
+        for (int j : jobs) rounds_ok = rounds_ok && b->jobs[j].n <= SQ_ROUNDS_MAXN;
         if (rounds_ok) {
             static const int thr_env = getenv("SQ_ROUNDS_THREADS") ? std::max(64, std::min(SQ_ROUNDS_THREADS, atoi(getenv("SQ_ROUNDS_THREADS")) / 64 * 64)) : 0;
             // threads per structure: by length -- and, while the launch leaves the chip empty (a shard of a multi-GPU run, a
@@ -2190,7 +2209,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             if (thr_env) { thr = 64; while (thr * 2 <= thr_env) thr *= 2; }   // (a power of two: the survivor ring is indexed with a mask)
             SqRoundsArgs ra;
             ra.lds_n = maxn; ra.str_cap = 2 * maxt + 2; ra.tmax = maxt; ra.cell_entries = b->cell_entries;
-            ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0;
+            ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0; ra.ties = chain_ties ? 1 : 0;
+            while (thr > 64 && sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr).total + 2048 > 158 * 1024) thr /= 2;   // (long sequences: the survivor ring gives way)
             const SqRoundsLds lo = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr);
             if (lo.total + 2048 > 158 * 1024) rounds_ok = false;
             else {
@@ -2221,12 +2241,18 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                     else {
                         const uint32_t nf = *b->chain.h_nfin;
                         if (nf != nfin_goal) fail(2, "persistent rounds left structures unfinished");
+                        if (chain_ties) for (uint32_t q = nfin_seen; q < nf; q++) if ((b->chain.h_fin[q] >> 62) & 1ull) tied_jobs.push_back((int)(uint32_t)b->chain.h_fin[q]);
                         if (!dev_tail) for (uint32_t q = nfin_seen; q < nf; q++) finished.push_back(-(int)q - 1);
                         nfin_seen = nf;
                         tq.push(finished);
                     }
                 }
             }
+        }
+        if (!rounds_ok && chain_ties) {                       // (the launched rounds do not look for ties: the pools take these jobs)
+            for (int j : jobs) tied_jobs.push_back(j);
+            nfin_goal -= (uint32_t)S;
+            continue;
         }
         while (!rounds_ok && nfin_seen < nfin_goal) {
             while (launched - done < depth) {               // rounds enqueued ahead of the device
@@ -2276,8 +2302,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             double bytes = 0;
             for (uint32_t q = nfin_goal - (uint32_t)S; q < nfin_goal; q++) {
                 const unsigned long long e = b->chain.h_fin[q];
+                if ((e >> 62) & 1ull) continue;
                 const double n = b->jobs[(int)(uint32_t)e].n;
-                const double ev = (double)((e >> 32) & 0x7FFFFFFFu) + ((e >> 63) ? 0.0 : 1.0);
+                const double ev = (double)((e >> 32) & 0x3FFFFFFFu) + ((e >> 63) ? 0.0 : 1.0);
                 bytes += ev * 2.0 * n * n;
             }
             b->prof[rounds_ok ? 7 : 2].bytes += bytes;        // (the persistent round kernel covers the evaluations of all its rounds)
@@ -2306,7 +2333,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         }
         std::vector<int> jobs;
         int maxn = 0; int64_t maxcap = 0; bool need_reacts = false;
-        for (int j : greedy_jobs) {
+        for (int j : pool_jobs_v) {
             JobPool &P = pools[j];
             if (P.maxstemnum == 0) { P.fin.emplace_back(); continue; }   // :1123-1129 full before the first round
             const SqJob &J = b->jobs[j];
@@ -2475,8 +2502,20 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     mark("loop start");
     b->last_driver = use_pool ? 2 : use_chain ? 1 : 0;
     b->last_peak = use_chain ? (int64_t)greedy_jobs.size() : 0;
+    if (use_pool && chain_ties) {
+        // the optimistic chains first; their structures that met a tie hand their jobs to the pools
+        chain_fold(st0);
+        if (st0.rc) { tq.close(); sq_set_error(st0.err); return st0.rc; }
+        b->last_paths |= 16;
+        std::sort(tied_jobs.begin(), tied_jobs.end());
+        pool_jobs_v.insert(pool_jobs_v.end(), tied_jobs.begin(), tied_jobs.end());
+        std::sort(pool_jobs_v.begin(), pool_jobs_v.end());
+        if (timing) fprintf(stderr, "[sq_fold] optimistic chains: %zu jobs, %zu met a tie and go to the device pools (with %zu others)\n",
+                            chain_jobs.size(), tied_jobs.size(), pool_jobs_v.size() - tied_jobs.size());
+        st0 = LoopStats();
+    }
     if (use_pool) {
-        const int pr = pool_fold(st0);
+        const int pr = pool_jobs_v.empty() ? 0 : pool_fold(st0);
         if (pr == 1) { b->last_driver = 3; b->last_peak = 0; }
         if (pr == 1 && timing) fprintf(stderr, "[sq_fold] device pools: a capacity was exceeded, the host loop repeats the greedy part\n");
         if (pr == 1) {                                       // a capacity was exceeded: the host's own loop takes the fold
@@ -2629,10 +2668,11 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                         P.evals++;
                     }
             }
-            if (b->last_driver == 1) {
+            if (b->last_driver == 1 || (b->last_paths & 16)) {
                 const uint32_t nf = *b->chain.h_nfin;
                 for (uint32_t q = 0; q < nf; q++) chain_finish(q);
-            } else if (b->last_driver == 2 && pool_collect) {
+            }
+            if (b->last_driver == 2 && pool_collect) {
                 // (the E / H / N stemsets are already at the front of the lists: the greedy structures go behind them)
                 const int rc2 = pool_collect();
                 if (rc2) return rc2;

@@ -27,6 +27,8 @@ struct SqRoundsArgs {
     int32_t cell_entries;   // doubles of the cell table (largest (classes x reactivity levels)^2 of the batch, padded)
     int32_t bound;          // branch and bound on the finalscore (0: every survivor of :492 is scored)
     int32_t ctx_min;        // strands from which a non-crossing structure's sweep is answered from the context tables (0: never)
+    int32_t ties;           // the structures belong to pools that MAY branch (poollim > 1, range factor 1.0): a round in which a second
+                            // run reaches the best finalscore ends the structure unfinished (h_fin bit 62) -- the device pools redo its job
 };
 
 // dynamic LDS of a block: per-position arrays, free-position words of the first round's scan, cell table, two strand

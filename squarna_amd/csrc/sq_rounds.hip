@@ -82,7 +82,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     __shared__ uint32_t s_nlist, s_ndead, s_nsurv;
     __shared__ SqCellTmp s_ctmp;
     __shared__ unsigned long long s_best;
-    __shared__ double s_wfin[SQ_ROUNDS_THREADS / 64], s_wbps[SQ_ROUNDS_THREADS / 64];
+    __shared__ double s_wfin[SQ_ROUNDS_THREADS / 64], s_wbps[SQ_ROUNDS_THREADS / 64], s_wsec[SQ_ROUNDS_THREADS / 64];
     __shared__ uint32_t s_wkey[SQ_ROUNDS_THREADS / 64], s_wlen[SQ_ROUNDS_THREADS / 64];
     __shared__ int s_wany[SQ_ROUNDS_THREADS / 64];
     __shared__ int s_cross;
@@ -318,6 +318,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                                 ps_lb, ps_bw, ps_dc, ps_bwint, ps_sdflen, ps_sdf, ps_of, a.ctr};
         __syncthreads();
         double bfin = 0.0, bbps = 0.0; uint32_t bkey = 0, blen = 0; int bany = 0;
+        double sfin = -INFINITY;                                    // the best finalscore of the OTHER runs (ties of a pool that may branch)
         uint32_t head = 0;                                          // entries of the ring taken so far (s_nsurv: entries put)
         SqRun rr[SQ_ROUNDS_CHUNK];
 #pragma unroll
@@ -426,7 +427,10 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                     fin = sq_stem_finalscore(env, i0, j0, L, bps);
                     ok = fin >= minfin;                                     // :751
                 }
-                if (ok && (!bany || fin > bfin || (fin == bfin && key < bkey))) { bany = 1; bfin = fin; bkey = key; blen = (uint32_t)L; bbps = bps; }
+                if (ok) {
+                    if (!bany || fin > bfin || (fin == bfin && key < bkey)) { if (bany && bfin > sfin) sfin = bfin; bany = 1; bfin = fin; bkey = key; blen = (uint32_t)L; bbps = bps; }
+                    else if (fin > sfin) sfin = fin;
+                }
                 if (__ballot(ok) != 0ull) {
                     double wb = ok ? fin : -INFINITY;
                     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(wb, off); wb = o > wb ? o : wb; }
@@ -444,17 +448,34 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
             const double of = __shfl_xor(bfin, off), ob = __shfl_xor(bbps, off);
             const uint32_t ok2 = (uint32_t)__shfl_xor((int)bkey, off), ol = (uint32_t)__shfl_xor((int)blen, off);
             const int oa = __shfl_xor(bany, off);
-            if (oa && (!bany || of > bfin || (of == bfin && ok2 < bkey))) { bany = 1; bfin = of; bkey = ok2; blen = ol; bbps = ob; }
+            const double os = __shfl_xor(sfin, off);
+            if (os > sfin) sfin = os;
+            if (oa && (!bany || of > bfin || (of == bfin && ok2 < bkey))) { if (bany && bfin > sfin) sfin = bfin; bany = 1; bfin = of; bkey = ok2; blen = ol; bbps = ob; }
+            else if (oa && of > sfin) sfin = of;
         }
-        if (lane == 0) { s_wany[wv] = bany; s_wfin[wv] = bfin; s_wbps[wv] = bbps; s_wkey[wv] = bkey; s_wlen[wv] = blen; }
+        if (lane == 0) { s_wany[wv] = bany; s_wfin[wv] = bfin; s_wbps[wv] = bbps; s_wkey[wv] = bkey; s_wlen[wv] = blen; s_wsec[wv] = sfin; }
         __syncthreads();
-        bany = 0;
-        for (int q = 0; q < nwv; q++)
+        bany = 0; sfin = -INFINITY;
+        for (int q = 0; q < nwv; q++) {
+            if (s_wsec[q] > sfin) sfin = s_wsec[q];
             if (s_wany[q] && (!bany || s_wfin[q] > bfin || (s_wfin[q] == bfin && s_wkey[q] < bkey))) {
+                if (bany && bfin > sfin) sfin = bfin;
                 bany = 1; bfin = s_wfin[q]; bkey = s_wkey[q]; blen = s_wlen[q]; bbps = s_wbps[q];
-            }
+            } else if (s_wany[q] && s_wfin[q] > sfin) sfin = s_wfin[q];
+        }
         RPROF(5);
         if (!bany) { retire(nstems, 0); RPROF_OUT(); return; }      // :1192-1193 no new stem: the structure is final
+        if (ra.ties && sfin == bfin) {
+            // a pool that may branch: ChooseStems returns every run that reaches the best finalscore and shares a base with the
+            // ones taken (:769-789, range factor 1.0) -- two runs at the top mean the pool MAY grow here: the structure stops,
+            // unfinished, and the device pools fold its job (rare: these jobs weigh their cells with a dense fp64 matrix)
+            if (tid == 0) {
+                structs[b].nstrand = -1;
+                const uint32_t idx = atomicAdd(cio.d_nfin, 1u);
+                cio.h_fin[idx] = (unsigned long long)(uint32_t)st.job | (1ull << 62);
+            }
+            return;
+        }
         const int i0 = (int)(bkey & 0xFFFFu), j0 = (int)(bkey >> 16) - i0, len = (int)blen;
         const int k = nstems;
         if (k >= ch.tcap) { if (tid == 0) a.ctr->out_ovf = 1; retire(k, 0); return; }
