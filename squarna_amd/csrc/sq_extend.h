@@ -63,7 +63,7 @@ __device__ __forceinline__ SqExtendLds sq_extend_lds(char *base, int T)
 // stems that cross nothing all land in group 0; the others are ordered by (weight, start), first-fitted into groups
 // and the groups ranked by size.  Result: L.lvl[q] = 1-based level of stem q.  One wave; the caller's block is that wave
 // (every SQ_EXTEND_SYNC() below is the wave's own barrier).  level_ovf: set when more than SQ_MAXLEVELS groups appear.
-__device__ __forceinline__ void sq_stem_levels_wave(SqExtendLds &L, int T, int lane, uint32_t *level_ovf)
+__device__ __forceinline__ int sq_stem_levels_wave(SqExtendLds &L, int T, int lane, uint32_t *level_ovf)
 {
     // stems that cross nothing sort first (weight 0) and all land in group 0
     int g0 = 0, has0 = 0;
@@ -111,6 +111,26 @@ __device__ __forceinline__ void sq_stem_levels_wave(SqExtendLds &L, int T, int l
         SQ_EXTEND_SYNC();
     }
     // groups ranked by size, descending, stable (:139); level = rank + 1
+    if (lane < ngroups) {
+        const int gs = L.gsize[lane];
+        int r = 0;
+        for (int h = 0; h < ngroups; h++) { const int hs = L.gsize[h]; r += (hs > gs || (hs == gs && h < lane)) ? 1 : 0; }
+        L.rank[lane] = (uint8_t)(r + 1);
+    }
+    SQ_EXTEND_SYNC();
+    for (int q = lane; q < T; q += 64) L.lvl[q] = L.rank[L.grp[q]];
+    SQ_EXTEND_SYNC();
+    return ngroups;                                   // (groups in use: L.grp / L.gsize stay valid for sq_stem_levels_join)
+}
+
+// The same levels after ONE more stem (index T - 1, length len) that crosses nothing, given the groups of the T - 1 stems
+// before it (L.grp, L.gsize, ngroups >= 1 as sq_stem_levels_wave left them): a stem without crossings never blocks a group
+// and sorts in front of the crossing ones (:125), so the first fit of every other stem is what it was; the new stem joins
+// group 0, whose size grows, and only the ranking of the groups by size (:139) is taken anew.
+__device__ __forceinline__ void sq_stem_levels_join(SqExtendLds &L, int T, int ngroups, int len, int lane)
+{
+    if (lane == 0) { L.grp[T - 1] = 0; L.gsize[0] += len; }
+    SQ_EXTEND_SYNC();
     if (lane < ngroups) {
         const int gs = L.gsize[lane];
         int r = 0;

@@ -31,8 +31,8 @@ struct SqRoundsArgs {
                             // run reaches the best finalscore ends the structure unfinished (h_fin bit 62) -- the device pools redo its job
 };
 
-// dynamic LDS of a block: per-position arrays, free-position words of the first round's scan, cell table, two strand
-// lists + stem indices, skip pointers, the stems with their crossing weights, and one region shared by the phases that
+// dynamic LDS of a block: per-position arrays, free-position words of the first round's scan, cell table, the strand
+// list + stem indices, skip pointers, the stems with their crossing weights, and one region shared by the phases that
 // never overlap (scan staging / bucket counters / level scratch of the extension / survivor ring of the scoring pass)
 struct SqRoundsLds {
     int np, fbh;
@@ -57,17 +57,17 @@ __host__ __device__ inline SqRoundsLds sq_rounds_lds(int lds_n, int str_cap, int
     o = (o + 15) & ~15;
     L.off_cell = o; o += 8 * cell_entries;
     o = (o + 15) & ~15;
-    L.off_str = o; o += 2 * str_cap * (int)sizeof(SqStrand);
-    L.off_sidx = o; o += 2 * str_cap * 2;
+    L.off_str = o; o += str_cap * (int)sizeof(SqStrand);       // (one list: the two strands of a new stem are inserted in place)
+    L.off_sidx = o; o += str_cap * 2;
     L.off_skip = o; o += str_cap * 2;
     o = (o + 15) & ~15;
     L.t8 = (tmax + 7) & ~7;
-    L.off_stems = o; o += 10 * L.t8;                           // the structure's stems: crossing weight (int32), i, j, len (int16)
+    L.off_stems = o; o += 11 * L.t8 + 64 * 4;                  // the structure's stems: crossing weight (int32), i, j, len (int16), level group (uint8); the groups' sizes
     o = (o + 15) & ~15;
     L.off_union = o;
     L.surv_cap = 4 * threads;                                  // >= (SQ_ROUNDS_CHUNK + 1) x threads, a power of two
     size_t u = (size_t)14 * L.surv_cap;
-    const size_t ext = (size_t)4 * L.t8 + 64 * 4 + 64 + 16;   // level scratch of the extension: group sizes, order, group, level, rank
+    const size_t ext = (size_t)3 * L.t8 + 64 + 16;            // level scratch of the extension: order, level, rank
     const size_t stage = (size_t)(threads / 64) * (SQ_ROUNDS_STAGE * 8 + 16);
     if (ext > u) u = ext;
     if (u < 2048) u = 2048;                                    // (the first round's bucket counters: 2 x 256 words)

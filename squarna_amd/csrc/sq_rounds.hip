@@ -74,6 +74,40 @@ struct SqRoundsSink {
     __device__ __forceinline__ void drain(int lane) { flush(lane); }
 };
 
+// The two strands of a new stem k = (i0, j0, len) into the sorted strand list S[0 .. nstrand) (+ the stem index of each
+// strand, X), IN PLACE, by one wave: every strand moves up by the number of new strands that start before it (0, 1 or 2), the
+// chunks of 64 taken from the top so that nothing is overwritten before it is read; levels from L.lvl when stems cross.
+__device__ __forceinline__ void sq_rounds_insert_strands(SqExtendLds &L, bool anycross, int k, SqStrand *S, int16_t *X, int nstrand,
+                                                         int i0, int j0, int len, int lane)
+{
+    const int ls = i0, rs = j0 - len + 1;                               // starts of the 5' and the 3' strand (ls < rs)
+    int below_l = 0, below_r = 0;
+    for (int q0 = 0; q0 < nstrand; q0 += 64) {
+        const int q = q0 + lane;
+        const int st = q < nstrand ? S[q].start : 0x7fff;
+        below_l += __popcll(__ballot(st < ls)); below_r += __popcll(__ballot(st < rs));
+    }
+    for (int q0 = ((nstrand + 63) & ~63) - 64; q0 >= 0; q0 -= 64) {
+        const int q = q0 + lane;
+        const bool valid = q < nstrand;
+        SqStrand x = valid ? S[q] : SqStrand{0, 0, 0, 0, 0};
+        const int sx = valid ? X[q] : 0;
+        sq_wave_lds_fence();                                            // (the whole chunk is read before any of it moves)
+        if (valid) {
+            if (anycross) x.level = L.lvl[sx];
+            const int at = q + (x.start < ls ? 0 : 1) + (x.start < rs ? 0 : 1);
+            S[at] = x; X[at] = (int16_t)sx;
+        }
+        sq_wave_lds_fence();
+    }
+    if (lane == 0) {
+        const uint8_t lv = anycross ? L.lvl[k] : (uint8_t)1;
+        S[below_l] = SqStrand{(int16_t)ls, (int16_t)len, (int16_t)j0, lv, 1};
+        S[below_r + 1] = SqStrand{(int16_t)rs, (int16_t)len, (int16_t)(i0 + len - 1), lv, 0};
+        X[below_l] = (int16_t)k; X[below_r + 1] = (int16_t)k;
+    }
+}
+
 extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu_waves_per_eu(SQ_ROUNDS_WAVES))) void sq_rounds_kernel(SqDevCtx c, SqStruct *structs, SqScanArgs a, SqChainIO cio,
                                                                                  SqRoundsArgs ra)
 {
@@ -262,14 +296,15 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     SqExtendLds XL;
     XL.cc = reinterpret_cast<int32_t *>(rd_dyn + Lo.off_stems);
     XL.i = reinterpret_cast<int16_t *>(XL.cc + Lo.t8); XL.j = XL.i + Lo.t8; XL.len = XL.j + Lo.t8;
-    XL.gsize = reinterpret_cast<int32_t *>(uni);
-    XL.ord = reinterpret_cast<int16_t *>(XL.gsize + 64);
-    XL.grp = reinterpret_cast<uint8_t *>(XL.ord + Lo.t8); XL.lvl = XL.grp + Lo.t8; XL.rank = XL.lvl + Lo.t8;
+    XL.gsize = reinterpret_cast<int32_t *>(XL.len + Lo.t8);      // (groups and their sizes stay too: a stem that crosses nothing joins group 0)
+    XL.grp = reinterpret_cast<uint8_t *>(XL.gsize + 64);
+    XL.ord = reinterpret_cast<int16_t *>(uni);
+    XL.lvl = reinterpret_cast<uint8_t *>(XL.ord + Lo.t8); XL.rank = XL.lvl + Lo.t8;
 
     // the bound on a run's finalscore (sq_cellrun.h: exact tetraloop factor, loop bonuses only where they can apply)
     auto upper_of = [&](double bps, int i0, int j0, int L) -> double { return sq_run_upper(bps, i0, j0, L, U, l_code, n, ub_of, ub_lf, ps_lb); };
 
-    int nstems = 0, nstrand = 0, cursb = 0;
+    int nstems = 0, nstrand = 0, ngroups = 0;       // (ngroups: level groups in use, first wave only)
     bool anycross = false;
     int za0 = 1, za1 = 0, zb0 = 1, zb1 = 0;                         // the two strands of the stem chosen last
     SqRun *list = listA, *other = listB;
@@ -313,7 +348,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         // pass wait in a ring in LDS until a full group of them is due (the chain of dependent loads of ScoreStems is what
         // the pass waits for: idle lanes are its cost); the next chunk's entries are on their way meanwhile ----
         if (tid == 0) { s_nsurv = 0; s_best = 0ull; }
-        const SqStrand *const S = strbuf + cursb * str_cap;
+        const SqStrand *const S = strbuf;
         const SqStemsEnv env = {S, s_skip, nstrand, true, P, U, SU, l_code, n, false, nullptr, nullptr, nullptr, 0,
                                 ps_lb, ps_bw, ps_dc, ps_bwint, ps_sdflen, ps_sdf, ps_of, a.ctr};
         __syncthreads();
@@ -483,7 +518,6 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         // ---- the child.  First wave: crossing weights, levels when stems cross, the sorted strand list (sq_extend.h);
         // the other waves: partner array and prefix counts -- positions p and above lose the new pairs below p, and
         // separators never pair, so SU stays ----
-        const int nxtsb = cursb ^ 1;
         const int zb = j0 - len + 1;
         if (wv == 0) {
             int mycc = 0, mycross = 0;
@@ -498,9 +532,13 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 s_cross = ac ? 1 : 0;
             }
             sq_wave_lds_fence();
-            if (ac) sq_stem_levels_wave(XL, k + 1, lane, &a.ctr->level_ovf);
-            sq_extend_strands(XL, ac, k, strbuf + cursb * str_cap, sidxbuf + cursb * str_cap, nstrand, i0, j0, len,
-                              strbuf + nxtsb * str_cap, sidxbuf + nxtsb * str_cap, lane);
+            if (ac) {
+                // levels: the full rule when the new stem crosses something (crossing weights changed: the order of the first
+                // fit may have); a stem without crossings joins group 0 and only the groups' ranking is taken anew
+                if (anycross && __ballot(mycross) == 0ull && ngroups > 0) sq_stem_levels_join(XL, k + 1, ngroups, len, lane);
+                else ngroups = sq_stem_levels_wave(XL, k + 1, lane, &a.ctr->level_ovf);
+            }
+            sq_rounds_insert_strands(XL, ac, k, strbuf, sidxbuf, nstrand, i0, j0, len, lane);
         }
         if (nwv == 1 || wv > 0) {
             const int w0 = nwv == 1 ? 0 : wv - 1, wn = nwv == 1 ? 1 : nwv - 1;
@@ -513,20 +551,29 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         }
         __syncthreads();
         anycross = s_cross != 0;
-        cursb = nxtsb; nstems = k + 1; nstrand += 2;
+        nstems = k + 1; nstrand += 2;
         if ((double)nstems == ch.maxstems) { retire(nstems, 1); return; }   // :1168-1174 (checked before the next evaluation)
         {
             // skip pointers over the blocks ScoreStems' sweep registers (sq_score_kernel)
-            const SqStrand *const S2 = strbuf + cursb * str_cap;
+            const SqStrand *const S2 = strbuf;
+            const int16_t *const X2 = sidxbuf;
             for (int q = tid; q < nstrand; q += nthr) {
                 const SqStrand x = S2[q];
                 int z = q + 1;
                 if (x.left) {
                     const int pf = x.pstart;
-                    while (z < nstrand) {
-                        const SqStrand y = S2[z];
-                        if (y.start > pf || (y.left && y.pstart > pf)) break;
-                        z++;
+                    if (XL.cc[X2[q]] == 0) {
+                        // a stem that crosses nothing: no 5' strand inside its block reaches beyond it, so the pointer is the
+                        // first strand that starts behind the partner -- a binary search instead of a walk over the block
+                        int lo = q + 1, hi = nstrand;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (S2[mid].start > pf) hi = mid; else lo = mid + 1; }
+                        z = lo;
+                    } else {
+                        while (z < nstrand) {
+                            const SqStrand y = S2[z];
+                            if (y.start > pf || (y.left && y.pstart > pf)) break;
+                            z++;
+                        }
                     }
                 }
                 s_skip[q] = (uint16_t)z;
