@@ -758,8 +758,10 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
     hipStream_t st = b->stream;
     {
         const int maxn_lds = (std::min(b->maxn, SQ_ALGO_MAXN) + 7) & ~7;   // (the device RunAlgo only takes batches up to SQ_ALGO_MAXN nt)
+        SqAlgoStatPtrs zs{{nullptr, nullptr, nullptr}};
+        for (size_t q = 0; q < pa->items.size() && q < 3; q++) zs.p[q] = (SqAlgoStat *)(regions[q] + cv[q].o_stat);
         hipLaunchKernelGGL(sq_algo_edges_kernel, dim3(S), dim3(256), (size_t)6 * maxn_lds + 16, st, b->ctx, b->lane_full.d_structs,
-                           [&] { SqScanArgs a = b->scan; a.ctr = b->lane_full.d_ctr; return a; }(), round_aj, maxn_lds);
+                           [&] { SqScanArgs a = b->scan; a.ctr = b->lane_full.d_ctr; return a; }(), round_aj, maxn_lds, zs);
     }
     HIPCK(hipGetLastError());
     if (!b->class_ev) HIPCK(sq_event_get(b->device, &b->class_ev));
@@ -779,7 +781,7 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
         const SqMatchEdge *d_edges = (const SqMatchEdge *)(region + cv[q].o_edges);
         int32_t *d_out = (int32_t *)(region + cv[q].o_out), *d_cnt = (int32_t *)(region + cv[q].o_cnt);
         SqAlgoStat *d_stat = (SqAlgoStat *)(region + cv[q].o_stat);
-        HIPCK(hipMemsetAsync(d_stat, 0, sizeof(SqAlgoStat), cs));
+        if (q >= 3) HIPCK(hipMemsetAsync(d_stat, 0, sizeof(SqAlgoStat), cs));   // (the first three: zeroed by the edges kernel)
         const int nj = (int)ck.mj.size();
         hipEvent_t pe0;
         const int pslot = it.algo == SQ_ALGO_E ? 4 : it.algo == SQ_ALGO_H ? 5 : 6;

@@ -39,7 +39,8 @@ struct SqAlgoStat {                // per launch of the finish kernel (device; s
 #ifdef __HIPCC__
 extern "C" {
 __global__ void sq_algo_sizes_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqAlgoSize *sizes, SqAlgoRaw raw);
-__global__ void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs, int maxn_lds);
+struct SqAlgoStatPtrs { SqAlgoStat *p[3]; };          // the items' counters, zeroed by the edges kernel (no memset launches)
+__global__ void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs, int maxn_lds, SqAlgoStatPtrs zs);
 __global__ void sq_algo_finish_kernel(SqDevCtx c, const SqAlgoJob *jobs, const SqMatchJob *mj, const int32_t *out, const int32_t *cnt,
                                       int levellimit_opt, SqPoolFin *fin, SqPoolStem *fin_stems, uint32_t *fin_ctr, uint32_t fin_cap,
                                       uint32_t fin_stem_cap, SqAlgoStat *stats, int tcap);

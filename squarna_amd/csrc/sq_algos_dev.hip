@@ -70,8 +70,12 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_sizes_kernel(SqDevCtx 
 // ---- edge lists -----------------------------------------------------------------------------------------------------
 // scratch of a structure: the SqKey part of its candidate slice (dead once the bpscore filter has run):
 // [nok x uint32 sorted survivor index][nok x uint32 first edge of that stem]
-extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs, int maxn_lds)
+extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs, int maxn_lds,
+                                                                      SqAlgoStatPtrs zs)
 {
+    if (blockIdx.x == 0 && threadIdx.x < 3 && zs.p[threadIdx.x]) {      // (the finish kernels of the items count into these)
+        SqAlgoStat z; memset(&z, 0, sizeof(z)); *zs.p[threadIdx.x] = z;
+    }
     // (dynamic LDS sized for the batch's longest sequence -- 6 bytes per position; static arrays for 4,096 nt cost every block 24 KB)
     extern __shared__ __attribute__((aligned(16))) char sq_edges_dyn[];
     int32_t *const s_first = reinterpret_cast<int32_t *>(sq_edges_dyn);        // Edmonds: first edge slot a position appears in
