@@ -66,7 +66,7 @@ __host__ __device__ inline SqRoundsLds sq_rounds_lds(int lds_n, int str_cap, int
     o = (o + 15) & ~15;
     L.off_union = o;
     L.surv_cap = (SQ_ROUNDS_CHUNK + 1 <= 2 ? 2 : SQ_ROUNDS_CHUNK + 1 <= 4 ? 4 : 8) * threads;   // >= (SQ_ROUNDS_CHUNK + 1) x threads, a power of two
-    size_t u = (size_t)14 * L.surv_cap;
+    size_t u = (size_t)4 * L.surv_cap;                          // (the ring holds list indices: ScoreStems reads the run itself)
     const size_t ext = (size_t)3 * L.t8 + 64 + 16;            // level scratch of the extension: order, level, rank
     const size_t stage = (size_t)(threads / 64) * (SQ_ROUNDS_STAGE * 8 + 16);
     if (ext > u) u = ext;

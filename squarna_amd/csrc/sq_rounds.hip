@@ -286,9 +286,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     }
     RPROF(2);
 
-    double *const s_bps = reinterpret_cast<double *>(uni);
-    uint32_t *const s_key = reinterpret_cast<uint32_t *>(s_bps + Lo.surv_cap);
-    uint16_t *const s_len = reinterpret_cast<uint16_t *>(s_key + Lo.surv_cap);
+    uint32_t *const s_ring = reinterpret_cast<uint32_t *>(uni);    // list indices of the runs that wait for ScoreStems
     const uint32_t smask = (uint32_t)Lo.surv_cap - 1u;
 
     // the structure's stems with their crossing weights (:121-124) stay in LDS between rounds; the level rule's scratch
@@ -426,7 +424,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                     base = (uint32_t)__shfl((int)base, leader);
                     if (ok) {
                         const uint32_t pos = (base + (uint32_t)__popcll(okm & ((1ull << lane) - 1ull))) & smask;
-                        s_key[pos] = r.key; s_len[pos] = (uint16_t)L; s_bps[pos] = r.bps;
+                        s_ring[pos] = q0 + (uint32_t)u * nthr + tid;
                     }
                 }
             }
@@ -448,9 +446,10 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 if (tid == 0) _cnt[2] += min(tailp - head, (uint32_t)nthr);
 #endif
                 head += min(tailp - head, (uint32_t)nthr);
-                const uint32_t key = have ? s_key[idx & smask] : 0u;
-                const int L = have ? (int)s_len[idx & smask] : 0;
-                const double bps = have ? s_bps[idx & smask] : 0.0;
+                const SqRun rb = have ? list[s_ring[idx & smask]] : SqRun{0u, 0u, 0.0};
+                const uint32_t key = rb.key;
+                const int L = (int)rb.len;
+                const double bps = rb.bps;
                 const int s = (int)(key >> 16), i0 = (int)(key & 0xFFFFu), j0 = s - i0;
                 bool ok = have;
                 if (ok) {
