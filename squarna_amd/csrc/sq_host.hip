@@ -2204,7 +2204,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             // threads per structure: by length -- and, while the launch leaves the chip empty (a shard of a multi-GPU run, a
             // small batch), twice / four times that: a structure's rounds are a chain of dependent passes over its list that
             // more waves shorten (S1000 x 128: 1.21 -> 0.99 ms at 512 threads)
-            int thr = maxn <= 200 ? 64 : (maxn <= 450 ? 128 : 256);
+            int thr = maxn <= 320 ? 64 : (maxn <= 450 ? 128 : 256);
             while (!thr_env && thr < SQ_ROUNDS_THREADS && thr < maxn / 2 && (int64_t)S * thr * 2 <= (int64_t)256 * 512) thr *= 2;
             if (thr_env) { thr = 64; while (thr * 2 <= thr_env) thr *= 2; }   // (a power of two: the survivor ring is indexed with a mask)
             SqRoundsArgs ra;
