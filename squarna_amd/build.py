@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsquarna_hip.so")
-SOURCES = ["sq_kernels.hip", "sq_host.hip", "sq_tail.cpp", "sq_match.hip", "sq_algos.hip", "sq_graph.hip", "sq_chain.hip", "sq_pool.hip", "sq_gather.hip", "sq_tail_dev.hip", "sq_algos_dev.hip", "sq_text.cpp", "sq_parse.cpp", "sq_context.hip", "sq_rounds.hip", "sq_pool_round.hip"]
+SOURCES = ["sq_kernels.hip", "sq_host.hip", "sq_batch.hip", "sq_round_host.hip", "sq_fold.hip", "sq_results.hip", "sq_tail.cpp", "sq_match.hip", "sq_algos.hip", "sq_graph.hip", "sq_chain.hip", "sq_pool.hip", "sq_gather.hip", "sq_tail_dev.hip", "sq_algos_dev.hip", "sq_text.cpp", "sq_parse.cpp", "sq_context.hip", "sq_rounds.hip", "sq_pool_round.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-x", "hip"]
 

@@ -76,6 +76,7 @@ __global__ void sq_tail_rank_kernel(SqDevCtx c, SqTailIO t, int bitwords, int ke
 __global__ void sq_tail_offsets_kernel(SqTailIO t, volatile uint32_t *h_seq, uint32_t seq);
 __global__ void sq_tail_pack_kernel(SqDevCtx c, SqTailIO t, int rowcap, long long rec_cap, long long txt_cap);
 __global__ void sq_fold_begin_kernel(uint32_t *fin_ctr, long long *job_evals, uint32_t *job_cnt, int njobs);
+__global__ void sq_fin_keep_algos_kernel(SqPoolFin *fin, uint32_t *fin_ctr, uint32_t fin_cap, long long *job_evals, uint32_t *job_cnt, int njobs);
 __global__ void sq_tail_done_kernel(SqTailIO t, long long *h_rec_off, long long *h_txt_off, volatile uint32_t *h_seq, uint32_t seq);
 __global__ void sq_fin_append_kernel(const SqPoolFin *src, const SqPoolStem *src_stems, int n, SqPoolFin *fin, SqPoolStem *stems,
                                      uint32_t *ctr, uint32_t fin_cap, uint32_t stem_cap);

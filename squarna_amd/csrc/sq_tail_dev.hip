@@ -649,6 +649,35 @@ extern "C" __global__ __launch_bounds__(256) void sq_fold_begin_kernel(uint32_t 
     if (q <= njobs) job_cnt[q] = 0;
 }
 
+// The device pools gave up (a capacity) and the host loop repeats the greedy part: the structures the aborted pools -- and the
+// chains in front of them -- had logged leave the log, the stemsets of E / H / N (appended by sq_algo_finish_kernel on the side
+// streams, which the caller has waited for) stay.  One block; the kept entries move to the front in order, their stems stay
+// where they are.  Evaluation counts and the tail's per-job counters start over.
+extern "C" __global__ __launch_bounds__(1024) void sq_fin_keep_algos_kernel(SqPoolFin *fin, uint32_t *fin_ctr, uint32_t fin_cap, long long *job_evals,
+                                                                           uint32_t *job_cnt, int njobs)
+{
+    __shared__ uint32_t s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t n = min(fin_ctr[0], fin_cap);
+    uint32_t base = 0;
+    for (uint32_t q0 = 0; q0 < n; q0 += 1024) {
+        const uint32_t q = q0 + tid;
+        SqPoolFin F;
+        const bool keep = q < n && (F = fin[q], F.round_kind < SQ_FIN_KIND_G0);
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_w[wv] = (uint32_t)__popcll(m);
+        __syncthreads();                                     // (every entry of the tile is read before any moves)
+        uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wv; w++) at += s_w[w];
+        if (keep) fin[at] = F;
+        for (int w = 0; w < 16; w++) base += s_w[w];
+        __syncthreads();
+    }
+    for (int q = tid; q < njobs; q += 1024) job_evals[q] = 0;
+    for (int q = tid; q <= njobs; q += 1024) job_cnt[q] = 0;
+    if (tid == 0) { fin_ctr[0] = base; fin_ctr[2] = 0; }     // (fin_ctr[1]: the stems of the dropped entries stay allocated)
+}
+
 // appends host-built final structures (the E / H / N stemsets while their filters run on the host; the empty structure of
 // a job whose maxstemnum is 0) to the device log: src / src_stems in pinned host memory, stem_off relative to src_stems
 extern "C" __global__ __launch_bounds__(256) void sq_fin_append_kernel(const SqPoolFin *src, const SqPoolStem *src_stems, int n, SqPoolFin *fin,

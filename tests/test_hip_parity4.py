@@ -268,3 +268,34 @@ def test_soak_slice_2000_random_records_under_nobpp():
                        cwd=root, capture_output=True, text=True, timeout=1500)
     tail = (r.stdout + r.stderr)[-2000:]
     assert r.returncode == 0 and "2000 records (config nobpp, poollim 1000), 0 mismatches" in r.stdout, tail
+
+
+def test_pool_overflow_keeps_the_stemsets_of_the_device_runalgo():
+    """Device pools that outgrow their slots hand the greedy part to the host loop; the E / H / N stemsets the device RunAlgo
+    has logged by then must survive (round 3 emptied the whole log there): same records as a fold with room, and as the
+    oracle."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import Batch, Prepared
+    names, psets = conf("nobpp")
+    raw = _chain_records(90, 5150, 30, 170)
+    prepared = [Prepared(s, r, x) for s, r, x in raw]
+    with Batch(prepared, [psets] * len(prepared), max_structs=16384, fp32=False) as b:
+        b.fold(poollim=1000)
+        assert b.fold_driver == 2 and (b.fold_paths & 2)
+        buf, off = b.pack_all()
+        want = [buf[off[k]:off[k + 1]].tobytes() for k in range(len(prepared))]
+        got0 = b.results_all()[0][0]
+        assert "SQ_POOL_SLOTS" not in os.environ
+        os.environ["SQ_POOL_SLOTS"] = str(2 * len(prepared) + 3)        # room for the first generation only
+        try:
+            for _ in range(3):
+                b.fold(poollim=1000)
+                assert b.fold_driver == 3 and (b.fold_paths & 2), (b.fold_driver, b.fold_paths)
+                buf, off = b.pack_all()
+                assert [buf[off[k]:off[k + 1]].tobytes() for k in range(len(prepared))] == want
+        finally:
+            del os.environ["SQ_POOL_SLOTS"]
+    s, r, x = raw[0]
+    exp = O.SQRNdbnseq(s, r, x, None, psets, poollim=1000)
+    exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+    _same_fold(got0, exp, ("overflow", 0))
