@@ -287,7 +287,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
         // Hungarian with the chip crowded (batches in flight, or thousands of jobs): every block of a launch gets the LDS of the
         // launch's LARGEST job (62 KB at 150 nt: two one-wave blocks per CU, and LDS the scoring kernels of the other batches
         // do not get) -- three classes give most jobs a quarter of that
-        const int env_hclasses = getenv("SQ_LSAP_CLASSES") ? std::max(1, atoi(getenv("SQ_LSAP_CLASSES"))) : 0;   // (read per fold: tests)
+        const int env_hclasses = b->sw.lsap_classes;           // (per fold: tests)
         const bool crowded = b->inflight > 1 || nq >= 4096;    // (a batch of 1,314 jobs alone: 7.1 ms without the classes, 8.5 with)
         const int max_classes = algo == SQ_ALGO_H ? (env_hclasses ? env_hclasses : (crowded ? 3 : 1))
                               : algo == SQ_ALGO_N ? (env_hclasses ? env_hclasses : (crowded ? 3 : 1))   // (blocks of 64 / 128 / 192 threads instead of 192 for every job)
@@ -301,7 +301,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
                 cur = need[ord[r]];
             } else c.count++;
         }
-        if (getenv("SQ_MWM_DUMP") && algo == SQ_ALGO_E) {
+        if (b->sw.mwm_dump && algo == SQ_ALGO_E) {
             fprintf(stderr, "[mwm] %zu graphs, classes:", nq);
             for (auto &c : ck.classes) fprintf(stderr, " [%d +%d: %zu B]", c.start, c.count, need[ord[c.start]]);
             fprintf(stderr, "\n[mwm] (n m bytes):");
@@ -314,7 +314,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     if (dev_sizes) return 0;                              // (the edges are written on the device: sq_algo_edges_kernel)
     // pass 2 (pool): the edges, written straight into the pinned buffer
     ck.vid2pos.resize(mj.size());
-    if (getenv("SQ_MWM_POSTHOC")) ck.seen_hash.assign(mj.size(), 0);
+    if (b->sw.mwm_posthoc) ck.seen_hash.assign(mj.size(), 0);
     sq_pool(b)->parallel_for((int)mj.size(), [&](int q) {
         CpuScope cpu_(2);
         const SqJob &J = b->jobs[jobs[k0 + q]];
@@ -342,7 +342,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
             }
         }
     });
-    if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] build algo %d: sizes %.3f ms, layout+pinned alloc %.3f ms, edges %.3f ms\n", algo,
+    if (b->sw.timing) fprintf(stderr, "[sq_algos] build algo %d: sizes %.3f ms, layout+pinned alloc %.3f ms, edges %.3f ms\n", algo,
                                      (tb1 - tb0) * 1e3, (tb2 - tb1) * 1e3, (sq_now() - tb2) * 1e3);
     return 0;
 }
@@ -427,7 +427,7 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
     }
     const int32_t *h_out_p = ck.d_out, *h_cnt_p = ck.d_cnt;
     const double tw1 = sq_now();
-    struct Rep { int algo; double t0, t1; ~Rep() { if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] algo %d: wait %.3f ms, host filters %.3f ms\n", algo, (t1 - t0) * 1e3, (sq_now() - t1) * 1e3); } } rep{algo, tw0, tw1};
+    struct Rep { int algo; double t0, t1; bool on; ~Rep() { if (on) fprintf(stderr, "[sq_algos] algo %d: wait %.3f ms, host filters %.3f ms\n", algo, (t1 - t0) * 1e3, (sq_now() - t1) * 1e3); } } rep{algo, tw0, tw1, b->sw.timing};
     // jobs whose score matrix carries a bpp term / multiplier: RunAlgo's stem filters re-sum cells of THAT matrix
     std::vector<std::vector<double>> dense(mj.size());
     for (size_t q = 0; q < mj.size(); q++) {
@@ -557,7 +557,7 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
             else for (int t = 0; t < 32; t++) sq_wait_step(0, false);
         }
     }
-    if (getenv("SQ_MWM_POSTHOC") && algo == SQ_ALGO_E && ck.seen_hash.size() == mj.size()) {
+    if (b->sw.mwm_posthoc && algo == SQ_ALGO_E && ck.seen_hash.size() == mj.size()) {
         hipStreamSynchronize(ck.st);
         for (size_t q = 0; q < mj.size(); q++) {
             const int32_t *mate = h_out_p + mj[q].out_off;
@@ -628,7 +628,7 @@ bool sq_algos_on_device(const SqAlgoAsync *pa) { return pa && pa->dev; }
 // matchings.  Returns 0: staged, 1: the batch does not qualify (nothing happened that the host-driven form cannot repeat).
 static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
 {
-    const bool off = getenv("SQ_NO_DEVICE_ALGOS") != nullptr;           // (read per fold: tests compare both forms in one process)
+    const bool off = b->sw.no_device_algos;                             // (per fold: tests compare both forms in one process)
     if (off || pa->items.empty()) return 1;
     std::vector<int> all;
     std::vector<uint8_t> need_raw;
@@ -879,14 +879,14 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
         for (auto &it : pa->items) { it.ck = SqAlgoChunk(); it.staged = false; }   // the host-driven form, from scratch
         b->algo_used = 0; b->cand_reserved = 0;
     }
-    const bool async = !getenv("SQ_ALGO_SYNC");
+    const bool async = !b->sw.algo_sync;
     const int64_t half = b->cand_records / 2;          // at most half of the arena is lent to the matching kernels
     int sidx = 0;
     // Edmonds is the long pole: its AnnotateStems pass and launch go first, alone; the other algorithms share
     // one more pass.  Everything that is staged runs on side streams while the caller proceeds.
     auto stage = [&](SqAlgoAsync::Item &it) -> int {
         const double ts0 = sq_now();
-        struct Rep { int algo; double t0; ~Rep() { if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] stage algo %d: %.3f ms\n", algo, (sq_now() - t0) * 1e3); } } rep{it.algo, ts0};
+        struct Rep { int algo; double t0; bool on; ~Rep() { if (on) fprintf(stderr, "[sq_algos] stage algo %d: %.3f ms\n", algo, (sq_now() - t0) * 1e3); } } rep{it.algo, ts0, b->sw.timing};
         if (!async || sidx >= 3) return 0;
         char *region = nullptr;
         // Hungarian / Nussinov: the batch's own scratch when the chunk fits it (planned from the lengths)
@@ -920,7 +920,7 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
             st2 = b->side[s2];
         }
         const int r = algo_launch(b, it.ck, region, b->side[ss], st2);
-        if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] launch algo %d: %.3f ms\n", it.algo, (sq_now() - tl0) * 1e3);
+        if (b->sw.timing) fprintf(stderr, "[sq_algos] launch algo %d: %.3f ms\n", it.algo, (sq_now() - tl0) * 1e3);
         if (r) return r;
         it.staged = true;
         sidx++;
@@ -931,7 +931,7 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
     if (pa->items[0].algo == SQ_ALGO_E) {
         int r = algo_annotate(b, pa->items[0].jobs, pa->items[0].stems);
         if (r) return r;
-        if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] annotate E %.3f ms\n", (sq_now() - ta0) * 1e3);
+        if (b->sw.timing) fprintf(stderr, "[sq_algos] annotate E %.3f ms\n", (sq_now() - ta0) * 1e3);
         r = stage(pa->items[0]);
         if (r) return r;
         first_rest = 1;
@@ -951,7 +951,7 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
             if (r) return r;
         }
     }
-    if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_algos] annotate + stage %.3f ms\n", (sq_now() - ta0) * 1e3);
+    if (b->sw.timing) fprintf(stderr, "[sq_algos] annotate + stage %.3f ms\n", (sq_now() - ta0) * 1e3);
     return 0;
 }
 

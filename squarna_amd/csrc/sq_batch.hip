@@ -291,6 +291,7 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         }
     }
     sq_batch *b = new sq_batch();
+    sq_read_fold_switches(b->sw);                           // (every sq_fold refreshes them; the per-call ops read these)
     b->stream = (hipStream_t)hip_stream;
     if (hipGetDevice(&b->device) != hipSuccess) b->device = -1;      // the caller's current device: every thread the library spawns adopts it
     b->nseq = d->nseq; b->npset = d->npset; b->njobs = d->njobs; b->maxn = L.maxn; b->ltot = L.ltot;

@@ -1,6 +1,21 @@
 // sq_fold.hip -- sq_fold: the greedy pool loop of every job of a batch on the device drivers (persistent rounds, device pools) with the host loop as their fallback, E / H / N beside it, the ranking tail behind it; sq_fold_concurrent.
 #include "sq_host_int.h"
 
+void sq_read_fold_switches(SqFoldSwitches &sw)
+{
+    auto on = [](const char *name) { return getenv(name) != nullptr; };
+    auto num = [](const char *name, int lo, int hi) { const char *e = getenv(name); return e ? std::max(lo, std::min(hi, atoi(e))) : 0; };
+    sw.timing = on("SQ_TIMING"); sw.pool_debug = on("SQ_POOL_DEBUG");
+    sw.no_chain = on("SQ_NO_CHAIN"); sw.no_rounds = on("SQ_NO_ROUNDS"); sw.no_pool = on("SQ_NO_POOL");
+    sw.no_pool_round = on("SQ_NO_POOL_ROUND"); sw.pool_round_always = on("SQ_POOL_ROUND_ALWAYS");
+    sw.pool_round_nsurv = num("SQ_POOL_ROUND_NSURV", 64, 2048);
+    sw.pool_slots = num("SQ_POOL_SLOTS", 1, 0x7fffffff); sw.pool_chunk = num("SQ_POOL_CHUNK", 1, 0x7fffffff);
+    sw.no_score_bound = on("SQ_NO_SCORE_BOUND"); sw.no_score_context = on("SQ_NO_SCORE_CONTEXT");
+    sw.no_device_algos = on("SQ_NO_DEVICE_ALGOS"); sw.no_device_tail = on("SQ_NO_DEVICE_TAIL");
+    sw.algo_sync = on("SQ_ALGO_SYNC"); sw.lsap_classes = num("SQ_LSAP_CLASSES", 1, 64);
+    sw.mwm_dump = on("SQ_MWM_DUMP"); sw.mwm_posthoc = on("SQ_MWM_POSTHOC");
+}
+
 // ---- a-7: greedy pool loop for every job at once (SQRNdbnseq.py:1102-1199) ----------------------
 namespace {
 struct alignas(128) JobPool {                // (own cache lines: two lanes work on neighbouring jobs)
@@ -21,7 +36,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     if (o.poollim < 1) { sq_set_error("poollim must be positive"); return -1; }
     SqSlackGuard slack_guard;
     const long long cpu_fold0 = g_cpuacc_on ? CpuScope::now() : 0;
-    struct FoldTimer { double t0; ~FoldTimer() { if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_fold] total %.3f ms (incl. teardown)\n", (now_s() - t0) * 1e3); } } fold_timer{now_s()};
+    sq_read_fold_switches(b->sw);
+    const SqFoldSwitches &sw = b->sw;
+    struct FoldTimer { double t0; bool on; ~FoldTimer() { if (on) fprintf(stderr, "[sq_fold] total %.3f ms (incl. teardown)\n", (now_s() - t0) * 1e3); } } fold_timer{now_s(), sw.timing};
     // a-1, once per job and per fold (:1076): never reused from an earlier call, a fold is the whole path
     int r = sq_fill_impl(b, 0);
     if (r) return r;
@@ -29,11 +46,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // allow; the host tail below is its fallback.  The log and the per-job evaluation counts start empty.
     const bool dev_tail = sq_tail_device_wanted(b, o);
     // the scoring kernel's two short cuts, per fold (tests fold the same batch with and without them)
-    b->score_bound = getenv("SQ_NO_SCORE_BOUND") == nullptr;
-    b->score_ctx = getenv("SQ_NO_SCORE_CONTEXT") == nullptr;
-    b->no_pool_round = getenv("SQ_NO_POOL_ROUND") != nullptr;              // (tests fold both ways in one process)
-    b->pool_round_always = getenv("SQ_POOL_ROUND_ALWAYS") != nullptr;      // (also for a small batch alone: measurements)
-    b->pool_round_nsurv = getenv("SQ_POOL_ROUND_NSURV") ? std::max(64, std::min(2048, atoi(getenv("SQ_POOL_ROUND_NSURV")))) : 0;   // (tests: survivors spill)
+    b->score_bound = !sw.no_score_bound;
+    b->score_ctx = !sw.no_score_context;
     if (b->any_dense < 0) { b->any_dense = 0; for (const SqJob &J : b->jobs) if (J.mat64_off >= 0 || J.has_ext) b->any_dense = 1; }
     b->packed_ok = false;
     hipLaunchKernelGGL(sq_fold_begin_kernel, dim3((b->njobs + 256) / 256), dim3(256), 0, b->stream, b->d_fin_ctr, b->d_job_evals,
@@ -62,12 +76,12 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // The reference iterates a Python set of letters (unspecified order); we use E, H, N.
     SqAlgoAsync *pending = nullptr;
     const double ta = now_s();
-    if (getenv("SQ_TIMING")) fprintf(stderr, "[sq_fold] setup before E/H/N begin: %.3f ms (bit matrix launch + job pools)\n", (ta - fold_timer.t0) * 1e3);
+    if (sw.timing) fprintf(stderr, "[sq_fold] setup before E/H/N begin: %.3f ms (bit matrix launch + job pools)\n", (ta - fold_timer.t0) * 1e3);
     // (with the device tail: RunAlgo's filters on the device too when the batch qualifies, sq_algos_dev.hip)
     { CpuScope cpu_(9); r = sq_algos_begin(b, algos, pending, o.levellimit, dev_tail); }   // AnnotateStems + matching kernels on side streams
     const bool dev_algos = sq_algos_on_device(pending);
     b->last_paths = dev_algos ? 2 : 0;
-    if (getenv("SQ_TIMING") && pending) fprintf(stderr, "[sq_fold] RunAlgo for E / H / N: %s\n", dev_algos ? "on the device (sq_algos_dev.hip)" : "host-driven");
+    if (sw.timing && pending) fprintf(stderr, "[sq_fold] RunAlgo for E / H / N: %s\n", dev_algos ? "on the device (sq_algos_dev.hip)" : "host-driven");
     struct PendGuard {                                      // error paths: wait for the side streams, release the arena
         sq_batch *b; SqAlgoAsync *&p;
         ~PendGuard() { if (p) { sq_algos_abandon(b, p); p = nullptr; } }
@@ -79,8 +93,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // the round buffers at once; otherwise (and for wider pools) the host drives the rounds.
     std::vector<int> greedy_jobs;
     for (int j = 0; j < b->njobs; j++) if (algos[j] & SQ_ALGO_G) greedy_jobs.push_back(j);
-    const bool no_chain = getenv("SQ_NO_CHAIN") != nullptr;     // (read per fold: tests compare both drivers in one process)
-    const bool no_rounds = getenv("SQ_NO_ROUNDS") != nullptr;   // (likewise: the launched rounds instead of the persistent round kernel)
+    const bool no_chain = sw.no_chain, no_rounds = sw.no_rounds;   // (per fold: tests compare the drivers in one process)
     bool use_chain = o.poollim == 1 && !no_chain && !greedy_jobs.empty();
     if (use_chain)
         for (int j : greedy_jobs)
@@ -89,7 +102,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // Wider pools: booked on the device as well (sq_pool.hip) when the batch has the slot arrays (structures of at most
     // SQ_CHAIN_TMAX stems) and one structure per greedy job fits the round buffers; any capacity overflow during the fold makes
     // the host repeat it with its own loop.
-    const bool no_pool = getenv("SQ_NO_POOL") != nullptr;
+    const bool no_pool = sw.no_pool;
     bool use_pool = !use_chain && o.poollim > 1 && !no_pool && !greedy_jobs.empty() && b->pool_io.pt > 0;
     // the jobs each device driver takes.  Pools that may branch (poollim > 1) but almost never do -- range factor 1.0 (only
     // exact ties branch, :769-778) over cells weighted by a dense fp64 matrix (the alignment's rows, bpp terms) -- first run
@@ -119,7 +132,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     };
     if (!use_chain && !use_pool) host_pools_init();
     for (int k = 0; k < 8; k++) g_t[k] = 0;
-    const bool timing = getenv("SQ_TIMING") != nullptr;
+    const bool timing = sw.timing;
     auto mark = [&](const char *what) { if (timing) fprintf(stderr, "[sq_fold]   +%.3f ms %s\n", (now_s() - tfold0) * 1e3, what); };
     // a-10 tail per sequence
     std::vector<std::vector<int32_t>> seq_jobs(b->nseq);
@@ -512,10 +525,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         if (S0 == 0) return 0;
         const int64_t avail = b->cand_records - b->cand_reserved;
         int slots = std::min(PI.smax, ln.max_structs);
-        if (const char *e = getenv("SQ_POOL_SLOTS")) slots = std::min(slots, std::max(1, atoi(e)));   // (tests: force the overflow path)
+        if (sw.pool_slots > 0) slots = std::min(slots, sw.pool_slots);   // (tests: force the overflow path)
         // structures whose candidates fit the arena at once; larger generations go through state .. choose in chunks
         int chunk = (int)std::min<int64_t>(slots, avail / std::max<int64_t>(maxcap, 1));
-        if (const char *e = getenv("SQ_POOL_CHUNK")) chunk = std::min(chunk, std::max(1, atoi(e)));   // (tests: force chunked rounds)
+        if (sw.pool_chunk > 0) chunk = std::min(chunk, sw.pool_chunk);   // (tests: force chunked rounds)
         if (S0 > slots || chunk < 1) return 1;
         for (int j = 0; j < b->njobs; j++) b->h_pool_jobrec[j] = -1;
         for (int sx = 0; sx < S0; sx++) {
@@ -558,10 +571,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         // short sequences on a crowded chip: a round is ONE kernel (sq_pool_round.hip) + the scan kernel
         const bool crowded_fold = b->inflight > 1 || b->njobs >= 4096;
         SqPoolRoundArgs pra;
-        bool round_kernel = maxn <= SQ_PR_MAXN && !b->any_dense && (crowded_fold || b->pool_round_always) && !b->no_pool_round;
+        bool round_kernel = maxn <= SQ_PR_MAXN && !b->any_dense && (crowded_fold || sw.pool_round_always) && !sw.no_pool_round;
         if (round_kernel) {
             pra.lds_n = maxn; pra.str_cap = 2 * pio.pt + 2; pra.cell_entries = b->cell_entries;
-            pra.surv_cap = b->pool_round_nsurv ? b->pool_round_nsurv : (maxn <= 96 ? 128 : 256); pra.bound = b->score_bound ? 1 : 0;
+            pra.surv_cap = sw.pool_round_nsurv ? sw.pool_round_nsurv : (maxn <= 96 ? 128 : 256); pra.bound = b->score_bound ? 1 : 0;
             pra.tmax = pio.pt; pra.parity = 0; pra.lo = 0;
             if (sq_pool_round_lds(pra.lds_n, pra.str_cap, pra.cell_entries, pra.surv_cap, pra.tmax).total > 60 * 1024) round_kernel = false;
         }
@@ -598,7 +611,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             if (ctr.cand_ovf) return fail(-3, "candidate capacity exceeded (raise cand_per_nt)");
             if (ctr.level_ovf) return fail(-3, "more than 64 pseudoknot levels");
             const SqPoolHdr hh = *pio.h_hdr;
-            if (timing && getenv("SQ_POOL_DEBUG")) fprintf(stderr, "[pool] round %d: S %d -> %u, nfin %u, ovf %u, active jobs %u\n", rounds, S, hh.S[parity ^ 1], hh.nfin, hh.ovf, hh.active_jobs);
+            if (timing && sw.pool_debug) fprintf(stderr, "[pool] round %d: S %d -> %u, nfin %u, ovf %u, active jobs %u\n", rounds, S, hh.S[parity ^ 1], hh.nfin, hh.ovf, hh.active_jobs);
             if (hh.ovf) { overflow = true; break; }
             parity ^= 1;
             S = (int)hh.S[parity];

@@ -107,7 +107,34 @@ struct SqLane {
     std::vector<uint32_t> post_cnt, post_idx, post_fill;   // scratch of the round's output bucketing
 };
 
+// Behaviour switches of a fold, read from the environment ONCE at the start of every sq_fold (and at sq_batch_create, for the
+// per-call ops): diagnostics and test hooks, none changes results; tests flip them between two folds of one process.
+// INTEGRATION.md section 5 documents each.  (Switches that size or shape a batch are read at sq_batch_create; tuning knobs of
+// the launch shapes are `static const`, read once per process where they are used.)
+struct SqFoldSwitches {
+    bool timing = false;              // SQ_TIMING: phase timings on stderr
+    bool pool_debug = false;          // SQ_POOL_DEBUG: pool sizes per round (with SQ_TIMING)
+    bool no_chain = false;            // SQ_NO_CHAIN: poollim = 1 folds driven round by round from the host
+    bool no_rounds = false;           // SQ_NO_ROUNDS: the launched rounds instead of the persistent round kernel
+    bool no_pool = false;             // SQ_NO_POOL: pools booked on the host
+    bool no_pool_round = false;       // SQ_NO_POOL_ROUND: state / scan / score / choose / extend kernels instead of sq_pool_round_kernel
+    bool pool_round_always = false;   // SQ_POOL_ROUND_ALWAYS: sq_pool_round_kernel also for a small batch alone
+    int pool_round_nsurv = 0;         // SQ_POOL_ROUND_NSURV: survivors sq_pool_round_kernel keeps in LDS (0: by length)
+    int pool_slots = 0;               // SQ_POOL_SLOTS: structure slots the device pools may use (0: max_structs)
+    int pool_chunk = 0;               // SQ_POOL_CHUNK: structures per chunk of a generation (0: what the arena holds)
+    bool no_score_bound = false;      // SQ_NO_SCORE_BOUND: ScoreStems on every survivor of :492
+    bool no_score_context = false;    // SQ_NO_SCORE_CONTEXT: the strand walk instead of the context tables (launched rounds)
+    bool no_device_algos = false;     // SQ_NO_DEVICE_ALGOS: RunAlgo's edge lists and filters on the host
+    bool no_device_tail = false;      // SQ_NO_DEVICE_TAIL: the ranking tail on the host
+    bool algo_sync = false;           // SQ_ALGO_SYNC: matching kernels on the batch stream
+    int lsap_classes = 0;             // SQ_LSAP_CLASSES: size classes of the Hungarian / Nussinov launches (0: 3 crowded, else 1)
+    bool mwm_dump = false;            // SQ_MWM_DUMP: the blossom graphs' sizes and LDS plan on stderr
+    bool mwm_posthoc = false;         // SQ_MWM_POSTHOC: verification of streamed Edmonds results
+};
+void sq_read_fold_switches(SqFoldSwitches &sw);
+
 struct sq_batch {
+    SqFoldSwitches sw;                        // (see above: refreshed by every sq_fold)
     hipStream_t stream = nullptr;
     int device = -1;                          // device current at sq_batch_create (adopted by every spawned thread)
     // host copies
@@ -145,8 +172,6 @@ struct sq_batch {
     hipEvent_t lane_ev = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
     int32_t cell_entries = 32;            // doubles of the scoring kernels' cell table (dynamic LDS)
-    bool no_pool_round = false, pool_round_always = false;   // sq_pool_round_kernel off / also for a batch alone (per fold: SQ_NO_POOL_ROUND, SQ_POOL_ROUND_ALWAYS)
-    int pool_round_nsurv = 0;             // survivors of :492 sq_pool_round_kernel keeps in LDS (0: by sequence length)
     int any_dense = -1;                   // some job reads its cells from a dense fp64 matrix (-1: not looked yet)
     bool score_bound = true, score_ctx = true;   // the scoring kernel's branch and bound / closed-form sweep (per fold: SQ_NO_SCORE_BOUND, SQ_NO_SCORE_CONTEXT)
     SqCtxTab ctxtab = SqCtxTab{};         // ScoreStems context tables (sq_context.h), rec == nullptr: none

@@ -633,7 +633,7 @@ extern "C" int sq_align_accumulate(sq_batch *b, int32_t njob, const int32_t *job
         hipLaunchKernelGGL(sq_mirror_kernel, dim3(nt, nt), dim3(256), 0, b->stream, d_matrix, L);
         r = sq_check(hipStreamSynchronize(b->stream), "sq_mirror_kernel");
     }
-    if (getenv("SQ_TIMING"))
+    if (b->sw.timing)
         fprintf(stderr, "[sq_align_accumulate] %d sequences: %.3f ms (prep %.3f, gpu+wait %.3f)\n", njob, (now_s() - t0) * 1e3,
                 g_t[0] * 1e3, g_t[1] * 1e3);
     return r;

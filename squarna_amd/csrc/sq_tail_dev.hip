@@ -707,7 +707,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_fin_append_kernel(const SqP
 
 bool sq_tail_device_wanted(const sq_batch *b, const sq_fold_opts &o)
 {
-    const bool off = getenv("SQ_NO_DEVICE_TAIL") != nullptr;             // (read per fold: tests compare both tails in one process)
+    const bool off = b->sw.no_device_tail;                               // (per fold: tests compare both tails in one process)
     if (off || !b->tail.seq_job0 || b->tail.njobs <= 0) return false;
     if (o.rankbydiff) return false;                                     // :917-955 stays on the host
     if (o.conslim != 0 && o.conslim != 1) return false;                 // consensus of several structures: host
