@@ -48,7 +48,6 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // the scoring kernel's two short cuts, per fold (tests fold the same batch with and without them)
     b->score_bound = !sw.no_score_bound;
     b->score_ctx = !sw.no_score_context;
-    if (b->any_dense < 0) { b->any_dense = 0; for (const SqJob &J : b->jobs) if (J.mat64_off >= 0 || J.has_ext) b->any_dense = 1; }
     b->packed_ok = false;
     hipLaunchKernelGGL(sq_fold_begin_kernel, dim3((b->njobs + 256) / 256), dim3(256), 0, b->stream, b->d_fin_ctr, b->d_job_evals,
                        b->tail.job_cnt, b->njobs);
@@ -571,7 +570,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         // short sequences on a crowded chip: a round is ONE kernel (sq_pool_round.hip) + the scan kernel
         const bool crowded_fold = b->inflight > 1 || b->njobs >= 4096;
         SqPoolRoundArgs pra;
-        bool round_kernel = maxn <= SQ_PR_MAXN && !b->any_dense && (crowded_fold || sw.pool_round_always) && !sw.no_pool_round;
+        bool round_kernel = maxn <= SQ_PR_MAXN && (crowded_fold || sw.pool_round_always) && !sw.no_pool_round;   // (jobs with a dense matrix too: sq_cellrun.h reads their cells there)
         if (round_kernel) {
             pra.lds_n = maxn; pra.str_cap = 2 * pio.pt + 2; pra.cell_entries = b->cell_entries;
             pra.surv_cap = sw.pool_round_nsurv ? sw.pool_round_nsurv : (maxn <= 96 ? 128 : 256); pra.bound = b->score_bound ? 1 : 0;

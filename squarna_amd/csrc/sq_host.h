@@ -172,7 +172,6 @@ struct sq_batch {
     hipEvent_t lane_ev = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
     int32_t cell_entries = 32;            // doubles of the scoring kernels' cell table (dynamic LDS)
-    int any_dense = -1;                   // some job reads its cells from a dense fp64 matrix (-1: not looked yet)
     bool score_bound = true, score_ctx = true;   // the scoring kernel's branch and bound / closed-form sweep (per fold: SQ_NO_SCORE_BOUND, SQ_NO_SCORE_CONTEXT)
     SqCtxTab ctxtab = SqCtxTab{};         // ScoreStems context tables (sq_context.h), rec == nullptr: none
     int32_t chain_tmax = 1;               // most stems a structure of any job can hold (sizes the extend kernels' LDS)
