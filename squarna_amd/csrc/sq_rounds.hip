@@ -120,6 +120,9 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     __shared__ uint32_t s_wkey[SQ_ROUNDS_THREADS / 64], s_wlen[SQ_ROUNDS_THREADS / 64];
     __shared__ int s_wany[SQ_ROUNDS_THREADS / 64];
     __shared__ int s_cross;
+#ifdef SQ_ROUNDS_PROF
+    __shared__ uint32_t s_clean;
+#endif
 
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
     const int b = blockIdx.x;
@@ -128,8 +131,8 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     long long _pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
     long long _cnt[4] = {0, 0, 0, 0};       // runs cut, runs scored (phase A), survivors (phase B), rounds
 #define RPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)
-#define RPROF_OUT() do { if (tid == 0 && (b % 97) == 0) printf("rounds block %d n=%d rounds %lld | us: setup %.1f scan %.1f cut %.1f A %.1f B %.1f pick %.1f ext %.1f total %.1f | cut %lld scoredA %lld survB %lld\n", \
-        b, n, _cnt[3], _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, _pt[6] * 0.01, (wall_clock64() - _t00) * 0.01, _cnt[0], _cnt[1], _cnt[2]); } while (0)
+#define RPROF_OUT() do { if (tid == 0 && (b % 97) == 0) printf("rounds block %d clean %u n=%d rounds %lld | us: setup %.1f scan %.1f cut %.1f A %.1f B %.1f pick %.1f ext %.1f total %.1f | cut %lld scoredA %lld survB %lld\n", \
+        b, s_clean, n, _cnt[3], _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, _pt[6] * 0.01, (wall_clock64() - _t00) * 0.01, _cnt[0], _cnt[1], _cnt[2]); } while (0)
 #else
 #define RPROF(k) do {} while (0)
 #define RPROF_OUT() do {} while (0)
@@ -170,6 +173,9 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
 
     // ---- once per fold: letter classes, the cell table (sq_score_kernel builds them per round), the empty structure ----
     if (tid == 0) s_nlist = 0;
+#ifdef SQ_ROUNDS_PROF
+    if (tid == 0) s_clean = 0;
+#endif
     const SqCellEnv cenv = sq_cell_setup(c, jb, ps, s_ctmp, l_ci, l_code, s_cell, tid, nthr);
     {
         const uint8_t *e0 = c.e0c + jb.pos_off;
@@ -457,6 +463,14 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                     if (sbst && upper_of(bps, i0, j0, L) < st_subopt * sq_unord(sbst)) ok = false;
                 }
                 double fin = 0.0;
+#ifdef SQ_ROUNDS_PROF
+                {   // (what keeping finalscores between rounds would save: evaluations the last stem cannot have changed)
+                    const bool clean = ok && round > 0 && s_cross == 0 && (za1 < i0 - 6 || za0 > j0 + 6) && (zb1 < i0 - 6 || zb0 > j0 + 6);
+                    const unsigned long long cm = __ballot(clean);
+                    if (tid == 0) _cnt[1] += 0;
+                    if (lane == 0) atomicAdd(&s_clean, (uint32_t)__popcll(cm));
+                }
+#endif
                 if (ok) {
                     fin = sq_stem_finalscore(env, i0, j0, L, bps);
                     ok = fin >= minfin;                                     // :751
