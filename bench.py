@@ -420,19 +420,21 @@ def stream_leg(config, K, R, steps, warmup, device):
                        "%d batches; timed per step: Batch() (host arrays + sq_batch_create = upload) + fold of the batches in flight "
                        "+ sq_result_pack_all; c=%s poollim=1000" % (R, K, config),
                   seq_per_s=round(219 * R * K * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3),
-                  median_ms_per_step=round(per[len(per) // 2], 3), steps=steps, packed_bytes_per_step=packed)
+                  median_ms_per_step=round(per[len(per) // 2], 3), max_ms_per_step=round(per[-1], 3), steps=steps, packed_bytes_per_step=packed)
     # the same stream as a server runs it: while the batches of one step fold (a library call: no interpreter lock), a
     # second thread builds the batches of the next one; everything else as above (new records every step, upload and
     # read-out inside the timed region)
     try:
         import threading
 
+        streams2 = [torch.cuda.Stream(device) for _ in range(K)]   # (the next step's uploads must not queue behind this step's kernels)
+
         def build(t):
             out = []
             for q in range(K):
                 start = ((t * K + q) * 97) % len(allp)
                 sel = [allp[(start + i) % len(allp)] for i in range(219 * R)]
-                with torch.cuda.stream(streams[q]):
+                with torch.cuda.stream((streams, streams2)[t & 1][q]):
                     out.append(Batch(sel, [psets] * len(sel), fp32=False, max_structs=4096 * R))
             return out
 

@@ -282,6 +282,10 @@ int sq_pinned_get(void **p, size_t bytes)
 }
 void sq_pinned_put(void *p)
 {
+    // idle buffers kept: two steps' worth of a server that builds the next batches while it folds (16 batches of 12 SRtest150
+    // sets pin ~3 GB between them); SQ_PINNED_CACHE_MB overrides
+    static const size_t kIdleBytes = (size_t)(getenv("SQ_PINNED_CACHE_MB") ? std::max(0, atoi(getenv("SQ_PINNED_CACHE_MB"))) : 6144) << 20;
+    static const size_t kIdleCount = 4096;
     if (!p) return;
     std::vector<void *> drop;
     {
@@ -294,8 +298,8 @@ void sq_pinned_put(void *p)
         // The newest buffers stay: when the cache is full the OLDEST idle ones go back to the driver (a process that folded
         // other shapes before -- the legs of a bench, a server whose inputs change -- otherwise fills the cache with sizes nobody
         // asks for again and then pays hipHostMalloc + hipHostFree for every buffer of every batch: 245 against 55 ms per step)
-        if (cap && cap <= ((size_t)2 << 30)) {
-            while (!g_pinned.idle.empty() && (g_pinned.idle.size() >= 1024 || g_pinned.idle_bytes + cap > ((size_t)2 << 30))) {
+        if (cap && cap <= kIdleBytes) {
+            while (!g_pinned.idle.empty() && (g_pinned.idle.size() >= kIdleCount || g_pinned.idle_bytes + cap > kIdleBytes)) {
                 drop.push_back(g_pinned.idle.front().second);
                 g_pinned.idle_bytes -= g_pinned.idle.front().first;
                 g_pinned.idle.erase(g_pinned.idle.begin());
