@@ -34,12 +34,15 @@ struct SqCoopSingle {
     SQ_HD int first_true(bool p, int nl) const { return p ? 0 : nl; }
     SQ_HD void min_first(double &, int &, int) const {}
     SQ_HD void min_plain(double &, int = 64) const {}
+    SQ_HD void min_i32(int &) const {}
     SQ_HD int excl_scan(int cnt, int &total) const { total = cnt; return 0; }
     SQ_HD int count_true(bool p, int &first) const { first = 0; return p ? 1 : 0; }
     static constexpr int kSegMax = 1;                           // vertices per scan pass
     SQ_HD int readlane(int x, int) const { return x; }
     SQ_HD bool any(bool p) const { return p; }
     SQ_HD void min_pos_f64(double *p, double v) const { if (v < *p) *p = v; }
+    SQ_HD void add_i32(int *p, int v) const { *p += v; }
+    SQ_HD void min_i32_at(int *p, int v) const { if (v < *p) *p = v; }
 };
 #ifdef __HIPCC__
 // ... or the 64 lanes of a wave.  first_true: lowest lane whose predicate holds (nl if none);
@@ -51,6 +54,8 @@ struct SqCoopWave {
     static constexpr int kSegMax = SQ_MWM_SEGMAX;               // vertices per scan pass (their neighbour lists share the 64 lanes)
     __device__ int readlane(int x, int l) const { return __builtin_amdgcn_readlane(x, l); }
     __device__ bool any(bool p) const { return __ballot(p) != 0; }
+    __device__ void add_i32(int *p, int v) const { atomicAdd(p, v); }
+    __device__ void min_i32_at(int *p, int v) const { atomicMin(p, v); }
     // *p = min(*p, v) for POSITIVE doubles (and +inf): their bit patterns order like unsigned integers
     __device__ void min_pos_f64(double *p, double v) const { atomicMin((unsigned long long *)p, (unsigned long long)__double_as_longlong(v)); }
     __device__ int first_true(bool p, int nl) const
@@ -119,6 +124,7 @@ struct SqCoopWave {
         v = mv; i = mi == 0x7fffffff ? nl : mi;
     }
     __device__ void min_plain(double &v, int nlive = 64) const { v = wave_min_f64(v, nlive); }
+    __device__ void min_i32(int &v) const { v = wave_min_i32(v); }
     __device__ int excl_scan(int cnt, int &total) const       // exclusive prefix sum over the lanes + wave total
     {
         int v = cnt;                                           // inclusive scan: the same DPP sequence, with +
@@ -217,7 +223,7 @@ struct SqBlossom {
         dualvar = take_d(n); bslack = take_d(N2);
         adj_off = take_i(n + 1); inblossom = take_i(n); bestedge = take_i(N2); labeledge = take_i(N2);
         qcap = tight == 2 ? queue_hot_cap(n) : queue_cap(n, m, tight); queue = take_i(qcap); qn = 0;
-        label = (int8_t *)p; p += N2; allow = (uint8_t *)p; p += m;
+        label = (int8_t *)p; p += (N2 + 3) & ~3; allow = (uint8_t *)p; p += ((size_t)m + 3) & ~(size_t)3;   // (cleared as words)
         // ---- cold
         if (cold) p = cold;
         bdual = take_d(N2);
@@ -599,38 +605,68 @@ struct SqBlossom {
 #else
 #define SQ_PT(k, expr) do { expr; } while (0)
 #endif
-    double red_v0;                    // broadcast slots of the dual step (delta; type, edge, blossom)
-    int red_k[3];
+    int red_k[3];                     // the dual step's decision for lane 0's action (type, edge, blossom)
     int red_i[64][2];                 // per lane: (blossom, queue position) of the queue refill
 
-    // The same adjacency, built by all lanes: every lane owns the vertices v = lane, lane + nl, ... and walks the
-    // edge list once to count and once to fill, so each list keeps the edge order without atomics.  (FAST as in run():
-    // the walks are ds_read / ds_write when the arrays are in LDS -- through generic pointers they were flat loads, half
-    // of the kernel's 0.86 M vector-memory instructions on SRtest150.)
-    template <int FAST, class Sync>
-    SQ_HD void build_csr(int lane, int nl, Sync sync)
+    // The same adjacency, built by all lanes.  Counting is order-free: the lanes walk the edge list together and add to
+    // the degrees with LDS atomics.  Filling keeps the edge order per vertex: the edges are taken nl at a time in list
+    // order; a lane's slot in the list of an end x of its edge is the list's cursor + the number of ends equal to x that
+    // the lanes BEFORE it hold (found in as many rounds as the chunk names a vertex: typically one or two), and the
+    // cursors move, again with order-free atomics, once the whole chunk is placed.  (Until round 4 every lane walked the WHOLE edge list twice for each of
+    // its vertices: 470 us of the critical SRtest150 graph's 3.0 ms, m = 1,320.)  The cursors use bestedge's room, the rounds labeledge's.
+    // A self-loop takes two slots of its vertex's list, as it always did (the scan skips them).
+    template <int FAST, class Sync, class Coop>
+    SQ_HD void build_csr(int lane, int nl, Sync sync, Coop coop)
     {
         const SqMatchEdge *const E_ = SQ_LQ(E);
-        int *const adj_off_ = SQ_LP(adj_off), *const adj_ = SQ_LQ(adj), *const adjv_ = SQ_LQ(adjv);
+        int *const adj_off_ = SQ_LP(adj_off), *const adj_ = SQ_LQ(adj), *const adjv_ = SQ_LQ(adjv), *const cur_ = SQ_LP(bestedge), *const tmp_ = SQ_LP(labeledge);
         double *const adjw_ = SQ_LQ(adjw);
-        for (int v = lane; v < n; v += nl) {
-            int deg = 0;
-            for (int e = 0; e < m; e++) deg += (E_[e].v == v) + (E_[e].w == v);
-            adj_off_[v + 1] = deg;
-        }
-        if (lane == 0) adj_off_[0] = 0;
+        for (int v = lane; v <= n; v += nl) adj_off_[v] = 0;
         sync();
-        if (lane == 0) for (int v = 0; v < n; v++) adj_off_[v + 1] += adj_off_[v];
+        for (int e = lane; e < m; e += nl) { const SqMatchEdge ed = E_[e]; coop.add_i32(&adj_off_[ed.v + 1], 1); coop.add_i32(&adj_off_[ed.w + 1], 1); }
         sync();
-        for (int v = lane; v < n; v += nl) {
-            int pos = adj_off_[v];
-            for (int e = 0; e < m; e++) {
-                const SqMatchEdge ed = E_[e];
-                if (ed.v == v) { adj_[pos] = 2 * e;     adjv_[pos] = ed.w; adjw_[pos] = ed.weight; pos++; }
-                if (ed.w == v) { adj_[pos] = 2 * e + 1; adjv_[pos] = ed.v; adjw_[pos] = ed.weight; pos++; }
+        {
+            int run = 0;                                            // adj_off[v + 1] = degrees up to and including v
+            for (int v0 = 0; v0 < n; v0 += nl) {
+                const int v = v0 + lane;
+                const int c = v < n ? adj_off_[v + 1] : 0;
+                int total = 0;
+                const int ex = coop.excl_scan(c, total);
+                if (v < n) { adj_off_[v + 1] = run + ex + c; cur_[v] = run + ex; }
+                run += total;
             }
         }
         sync();
+        for (int v = lane; v < n; v += nl) tmp_[v] = 0x7fffffff;
+        sync();
+        for (int e0 = 0; e0 < m; e0 += nl) {
+            const int e = e0 + lane;
+            const bool ok = e < m;
+            const SqMatchEdge ed = E_[ok ? e : 0];
+            // ranks among the chunk's ends that name the same vertex, in list order (v before w within an edge): the
+            // unplaced end with the smallest id wins a round (an LDS minimum: no order among the lanes assumed)
+            int rv = 0, rw = 0;
+            bool pv = !ok, pw = !ok;
+            for (int r = 0;; r++) {
+                if (!pv) coop.min_i32_at(&tmp_[ed.v], 2 * lane);
+                if (!pw) coop.min_i32_at(&tmp_[ed.w], 2 * lane + 1);
+                sync();
+                const bool wv = !pv && tmp_[ed.v] == 2 * lane, ww = !pw && tmp_[ed.w] == 2 * lane + 1;
+                sync();
+                if (wv) { rv = r; pv = true; tmp_[ed.v] = 0x7fffffff; }
+                if (ww) { rw = r; pw = true; tmp_[ed.w] = 0x7fffffff; }
+                sync();
+                if (!coop.any(!pv || !pw)) break;
+            }
+            if (ok) {
+                const int qv = cur_[ed.v] + rv, qw = cur_[ed.w] + rw;
+                adj_[qv] = 2 * e;     adjv_[qv] = ed.w; adjw_[qv] = ed.weight;
+                adj_[qw] = 2 * e + 1; adjv_[qw] = ed.v; adjw_[qw] = ed.weight;
+            }
+            sync();
+            if (ok) { coop.add_i32(&cur_[ed.v], 1); coop.add_i32(&cur_[ed.w], 1); }
+            sync();
+        }
     }
 
     // FAST: the edges and all state arrays live in ONE LDS buffer whose address the caller passes as `fast0`
@@ -642,6 +678,9 @@ struct SqBlossom {
     SQ_HD void run(int lane, int nl, Sync sync, Coop coop, char *fast0)
     {
         const int N2 = 2 * n + 2;
+#ifdef SQ_MWM_PROF
+        const long long _tr0 = wall_clock64();
+#endif
         for (int v = lane; v < n; v += nl) { SQ_LQ(mate)[v] = -1; SQ_LQ(mate_de)[v] = -1; SQ_LQ(mord)[v] = -1; SQ_LP(inblossom)[v] = v; }
         if (lane == 0) mord_n = 0;
         for (int x = lane; x < N2; x += nl) {
@@ -655,6 +694,7 @@ struct SqBlossom {
         if (lane == 0) { stat_pass = 0; stat_event = 0; }
         sync();
         if (n == 0) return;
+        if (n >= (1 << 25)) { if (lane == 0) error = 5; sync(); return; }   // (the dual step packs type and entry index into 32 bits)
         {
             double negmax = 0;                                  // max over the edges, shared among the lanes (weights >= 0)
             for (int e = lane; e < m; e += nl) { const SqMatchEdge ed = SQ_LQ(E)[e]; if (ed.v != ed.w && -ed.weight < negmax) negmax = -ed.weight; }
@@ -674,8 +714,10 @@ struct SqBlossom {
         uint8_t *const allow_ = SQ_LP(allow);
         double *const dualvar_ = SQ_LP(dualvar), *const bdual_ = SQ_LQ(bdual), *const bslack_ = SQ_LP(bslack);
         const int *const parent_ = SQ_LQ(parent), *const live_ = SQ_LQ(live);
+        const int qcap_r = qcap;
 #ifdef SQ_MWM_PROF
         long long _tp = wall_clock64();
+        const long long _trinit = _tp - _tr0;
         if (lane == 0) for (int k = 0; k < 8; k++) { pt[k] = 0; pc[k] = 0; }
 #endif
         int npass = 0, nevent = 0;                              // (wave-uniform registers; published at the end)
@@ -686,9 +728,11 @@ struct SqBlossom {
 #ifdef SQ_MWM_PROF
             if (lane == 0) pc[3]++;
 #endif
-            for (int x = lane; x < N2; x += nl) { SQ_LP(label)[x] = 0; SQ_LP(labeledge)[x] = -1; SQ_LP(bestedge)[x] = -1; SQ_LP(bslack)[x] = SQ_BINF; }
-            for (int k = lane; k < nlive; k += nl) SQ_LQ(mbe_cnt)[SQ_LQ(live)[k]] = -1;
-            for (int e = lane; e < m; e += nl) SQ_LP(allow)[e] = 0;
+            // (label and allowedge are cleared as 32-bit words: init() pads both to words)
+            for (int x = lane; x < (N2 + 3) / 4; x += nl) reinterpret_cast<uint32_t *>(label_)[x] = 0;
+            for (int x = lane; x < N2; x += nl) { labeledge_[x] = -1; bestedge_[x] = -1; bslack_[x] = SQ_BINF; }
+            for (int k = lane; k < nlive; k += nl) SQ_LQ(mbe_cnt)[live_[k]] = -1;
+            for (int e = lane; e < (m + 3) / 4; e += nl) reinterpret_cast<uint32_t *>(allow_)[e] = 0;
             sync();
             // every free vertex becomes an S-vertex: assignLabel<FAST>(v, 1, None) in vertex order.  Free vertices sit in
             // distinct top-level blossoms, so the label writes are independent; only the queue order is sequential
@@ -696,24 +740,26 @@ struct SqBlossom {
             {
                 if (lane == 0) { pool_n = 0; f_augmented = 0; }
                 int qbase = 0;
+                const int *const mate_ = SQ_LQ(mate), *const nleaf_ = SQ_LQ(nleaf);
+                int *const queue_w = SQ_LP(queue);
                 for (int v0 = 0; v0 < n; v0 += nl) {
                     const int v = v0 + lane;
-                    const bool q = v < n && SQ_LQ(mate)[v] == -1 && SQ_LP(label)[SQ_LP(inblossom)[v]] == 0;
-                    const int b = q ? SQ_LP(inblossom)[v] : -1;
-                    const int cnt = q ? (b >= n ? SQ_LQ(nleaf)[b] : 1) : 0;
+                    const int vc = v < n ? v : 0;
+                    const int mt = mate_[vc], b = inblossom_[vc];        // (the loads of one level together)
+                    const int lb = label_[b], nlf = nleaf_[b];
+                    const bool q = v < n && mt == -1 && lb == 0;
+                    const int cnt = q ? (b >= n ? nlf : 1) : 0;
                     int total = 0;
                     const int pos = qbase + coop.excl_scan(cnt, total);
-                    red_i[lane][0] = -1;
-                    if (q) {
-                        if (pos + cnt > qcap) error = 1;
-                        else {
-                            SQ_LP(label)[v] = SQ_LP(label)[b] = 1; SQ_LP(labeledge)[v] = SQ_LP(labeledge)[b] = -1; SQ_LP(bestedge)[v] = SQ_LP(bestedge)[b] = -1;   // (bslack: +inf since the reset above)
-                            if (b < n) SQ_LP(queue)[pos] = b;
-                            else { red_i[lane][0] = b; red_i[lane][1] = pos; }
-                        }
+                    const bool fits = pos + cnt <= qcap_r;
+                    if (q && !fits) error = 1;
+                    if (q && fits) {
+                        label_[v] = 1; label_[b] = 1;                    // (labeledge, bestedge: -1, bslack: +inf since the reset above)
+                        if (b < n) queue_w[pos] = b;
                     }
                     const int anyb = coop.first_true(q && b >= n, nl);
                     if (anyb < nl) {
+                        red_i[lane][0] = q && fits && b >= n ? b : -1; red_i[lane][1] = pos;
                         sync();
                         if (lane == 0 && !error)
                             for (int l = anyb; l < nl; l++) if (red_i[l][0] != -1) leaves<FAST>(red_i[l][0], SQ_LP(queue) + red_i[l][1]);
@@ -979,75 +1025,100 @@ struct SqBlossom {
                 if (lane == 0) { const long long _n = wall_clock64(); pt[0] += _n - _tp; _tp = _n; }
 #endif
                 if (f_augmented || error) break;
-                // ---- the four delta candidates, strided over the lanes
+                // ---- the dual step: the four delta candidates, the dual update and the refresh of the cached slacks in ONE
+                // sweep over the entries k = 0 .. n + nlive (vertices, then live blossoms in creation order == the order of
+                // networkx's blossomparent / blossomdual dicts).  A lane takes three entries per trip and issues the loads of
+                // one dependency level for all three together (entry -> its state -> its blossom's label and its best edge's
+                // ends): four LDS round trips per trip.  (Until round 4: five loops whose loads the compiler chained behind
+                // branches, ~50 dependent round trips per substage, 0.5 of the critical graph's 3.0 ms.)
+                // The sequential rule -- delta starts as min(dualvar) and a later candidate replaces it only when strictly
+                // smaller -- is the lexicographic minimum of (value, type, iteration index): one f64 and one i32 reduction.
                 {
-                    double m1 = 1e300; double m2 = 1e300, m3 = 1e300, m4 = 1e300;
-                    int i2 = -1, i3 = -1, i4 = -1;
-                    SQ_UNROLL3
-                    for (int v = lane; v < n; v += nl) {
-                        if (dualvar_[v] < m1) m1 = dualvar_[v];
-                        if (label_[inblossom_[v]] == 0 && bestedge_[v] != -1) {
-                            const double d = bslack_[v];
-                            if (i2 == -1 || d < m2) { m2 = d; i2 = v; }
+                    const int nent = n + nlive;
+                    const int KEYB = 26;                                 // key = type << 26 | index  (n < 2^25: see run()'s head)
+                    struct Ent { int x, par, lab, be, lbv; double bs, dual; SqMatchEdge ed; bool valid, isb; int k; };
+                    auto load3 = [&](int k0, Ent *en) {
+                        int lv[3];
+                        for (int j = 0; j < 3; j++) {
+                            const int k = k0 + j * nl + lane;
+                            en[j].k = k; en[j].valid = k < nent; en[j].isb = k >= n;
+                            const int kb = k - n;
+                            lv[j] = live_[kb < 0 ? 0 : (kb < nlive ? kb : 0)];
                         }
-                    }
-                    SQ_UNROLL3
-                    for (int k = lane; k < n + nlive; k += nl) {   // `for b in blossomparent`: vertices, then blossoms
-                        const int b = k < n ? k : live_[k - n];
-                        if (parent_[b] == -1 && label_[b] == 1 && bestedge_[b] != -1) {
-                            const double d = bslack_[b] / 2.0;
-                            if (i3 == -1 || d < m3) { m3 = d; i3 = k; }
+                        for (int j = 0; j < 3; j++) en[j].x = en[j].valid ? (en[j].isb ? lv[j] : en[j].k) : 0;
+                        int inb[3]; double dv[3], db[3];
+                        for (int j = 0; j < 3; j++) {
+                            const int x = en[j].x;
+                            en[j].par = parent_[x]; en[j].lab = label_[x]; en[j].be = bestedge_[x]; en[j].bs = bslack_[x];
+                            inb[j] = inblossom_[en[j].isb ? 0 : x]; dv[j] = dualvar_[en[j].isb ? 0 : x]; db[j] = bdual_[x];
                         }
+                        for (int j = 0; j < 3; j++) {
+                            en[j].dual = en[j].isb ? db[j] : dv[j];
+                            en[j].lbv = label_[inb[j]];
+                            en[j].ed = E_[en[j].be < 0 ? 0 : en[j].be >> 1];
+                        }
+                    };
+                    double best = 1e300; int bkey = 0x7fffffff;
+                    auto consider = [&](bool c, double val, int key) {
+                        if (c && (val < best || (val == best && key < bkey))) { best = val; bkey = key; }
+                    };
+                    auto candidates = [&](const Ent *en) {
+                        for (int j = 0; j < 3; j++) {
+                            const Ent &e = en[j];
+                            const bool vtx = e.valid && !e.isb, blo = e.valid && e.isb;
+                            consider(vtx, e.dual, 1 << KEYB);
+                            consider(vtx && e.lbv == 0 && e.be != -1, e.bs, (2 << KEYB) | e.k);
+                            consider(e.valid && e.par == -1 && e.lab == 1 && e.be != -1, e.bs / 2.0, (3 << KEYB) | e.k);
+                            consider(blo && e.par == -1 && e.lab == 2, e.dual, (4 << KEYB) | (e.k - n));
+                        }
+                    };
+                    auto update = [&](const Ent *en, double delta) {
+                        for (int j = 0; j < 3; j++) {
+                            const Ent &e = en[j];
+                            if (!e.valid) continue;
+                            if (!e.isb) { if (e.lbv == 1) dualvar_[e.x] = e.dual - delta; else if (e.lbv == 2) dualvar_[e.x] = e.dual + delta; }
+                            else if (e.par == -1) { if (e.lab == 1) bdual_[e.x] = e.dual + delta; else if (e.lab == 2) bdual_[e.x] = e.dual - delta; }
+                        }
+                    };
+                    // the duals moved: the cached slacks of the best edges follow (slack(v, w) with the NEW duals: a + b == b + a)
+                    auto refresh = [&](const Ent *en) {
+                        double sl[3];
+                        for (int j = 0; j < 3; j++) sl[j] = dualvar_[en[j].ed.v] + dualvar_[en[j].ed.w] - 2 * en[j].ed.weight;
+                        for (int j = 0; j < 3; j++) if (en[j].valid && en[j].be != -1) bslack_[en[j].x] = sl[j];
+                    };
+                    auto reduce = [&](double &delta, int &key) {
+                        double mv = best;
+                        coop.min_plain(mv);
+                        int kk = best == mv ? bkey : 0x7fffffff;
+                        coop.min_i32(kk);
+                        delta = mv; key = kk;
+                    };
+                    Ent en[3];
+                    double delta; int key;
+                    if (nent <= 3 * nl) {                                // everything in registers between the phases
+                        load3(0, en);
+                        candidates(en);
+                        reduce(delta, key);
+                        sync();
+                        update(en, delta);
+                        sync();
+                        refresh(en);
+                    } else {
+                        for (int k0 = 0; k0 < nent; k0 += 3 * nl) { load3(k0, en); candidates(en); }
+                        reduce(delta, key);
+                        sync();
+                        for (int k0 = 0; k0 < nent; k0 += 3 * nl) { load3(k0, en); update(en, delta); }
+                        sync();
+                        for (int k0 = 0; k0 < nent; k0 += 3 * nl) { load3(k0, en); refresh(en); }
                     }
-                    for (int k = lane; k < nlive; k += nl) {
-                        const int b = live_[k];
-                        if (parent_[b] == -1 && label_[b] == 2 && (i4 == -1 || bdual_[b] < m4)) { m4 = bdual_[b]; i4 = k; }
+                    if (lane == 0) {
+                        const int deltatype = key >> KEYB, idx = key & ((1 << KEYB) - 1);
+                        int deltaedge = -1, deltablossom = -1;
+                        if (deltatype == 2) deltaedge = bestedge_[idx];
+                        else if (deltatype == 3) deltaedge = bestedge_[idx < n ? idx : live_[idx - n]];
+                        else if (deltatype == 4) deltablossom = live_[idx];
+                        red_k[0] = deltatype; red_k[1] = deltaedge; red_k[2] = deltablossom;
                     }
-                    // combine across the lanes: (value, iteration index) lexicographic minima == "first strictly smaller wins"
-                    const int NONE = 0x7fffffff;
-                    coop.min_plain(m1);
-                    if (i2 == -1) i2 = NONE; if (i3 == -1) i3 = NONE; if (i4 == -1) i4 = NONE;
-                    coop.min_first(m2, i2, NONE); coop.min_first(m3, i3, NONE);
-                    if (nlive > 0) coop.min_first(m4, i4, NONE);        // (no blossoms: i4 is NONE in every lane)
-                    int deltatype = 1, deltaedge = -1, deltablossom = -1;
-                    double delta = m1;
-                    if (i2 != NONE && m2 < delta) { delta = m2; deltatype = 2; deltaedge = bestedge_[i2]; }
-                    if (i3 != NONE && m3 < delta) { delta = m3; deltatype = 3; const int b = i3 < n ? i3 : live_[i3 - n]; deltaedge = bestedge_[b]; }
-                    if (i4 != NONE && m4 < delta) { delta = m4; deltatype = 4; deltablossom = live_[i4]; }
-                    if (lane == 0) { red_v0 = delta; red_k[0] = deltatype; red_k[1] = deltaedge; red_k[2] = deltablossom; }
-                }
-                sync();
-                {
-                    const double delta = red_v0;
-                    SQ_UNROLL3
-                    for (int v = lane; v < n; v += nl) {
-                        const int lb = label_[inblossom_[v]];
-                        if (lb == 1) dualvar_[v] -= delta; else if (lb == 2) dualvar_[v] += delta;
-                    }
-                    for (int k = lane; k < nlive; k += nl) {
-                        const int b = live_[k];
-                        if (parent_[b] == -1) { if (label_[b] == 1) bdual_[b] += delta; else if (label_[b] == 2) bdual_[b] -= delta; }
-                    }
-                }
-                sync();
-                // the duals moved: refresh the cached slacks of the best edges (vertices, then live blossoms)
-                // (three entries per lane at a time, every level of the dependent reads -- entry -> best edge -> its ends -> their
-                // duals -- issued for all three together on clamped slots: with the edge list in global memory a level is
-                // a trip to L2)
-                for (int k0 = 0; k0 < n + nlive; k0 += 3 * nl) {
-                    int xs[3], bes[3];
-                    for (int j = 0; j < 3; j++) {
-                        const int k = k0 + j * nl + lane;
-                        const int kb = k - n < 0 ? 0 : (k - n < nlive ? k - n : 0);
-                        const int lb = live_[kb];
-                        xs[j] = k < n ? k : (k < n + nlive ? lb : -1);
-                    }
-                    for (int j = 0; j < 3; j++) { const int be = bestedge_[xs[j] < 0 ? 0 : xs[j]]; bes[j] = xs[j] < 0 ? -1 : be; }
-                    SqMatchEdge eds[3];
-                    for (int j = 0; j < 3; j++) eds[j] = E_[bes[j] < 0 ? 0 : bes[j] >> 1];
-                    double sl[3];
-                    for (int j = 0; j < 3; j++) sl[j] = dualvar_[eds[j].v] + dualvar_[eds[j].w] - 2 * eds[j].weight;   // (a + b == b + a: either direction)
-                    for (int j = 0; j < 3; j++) if (bes[j] != -1) bslack_[xs[j]] = sl[j];
                 }
                 sync();
 #ifdef SQ_MWM_PROF
@@ -1097,8 +1168,8 @@ struct SqBlossom {
 #ifdef SQ_MWM_PROF
 #ifdef __HIP_DEVICE_COMPILE__
         if (lane == 0 && n >= 140)
-            printf("mwm n=%d m=%d stages=%lld substages=%lld popped=%lld visits=%lld events=%lld passes=%lld | us: events %.0f queue %.0f classify %.0f apply %.0f update %.0f act %.0f stageinit %.0f endstage %.0f\n",
-                   n, m, pc[3], pc[2], pc[1], pc[0], pc[4], pc[5], pt[7] * 0.01, pt[0] * 0.01, pt[1] * 0.01, pt[2] * 0.01, pt[3] * 0.01, pt[4] * 0.01, pt[5] * 0.01, pt[6] * 0.01);
+            printf("mwm n=%d m=%d stages=%lld substages=%lld popped=%lld visits=%lld events=%lld passes=%lld | us: events %.0f queue %.0f classify %.0f apply %.0f update %.0f act %.0f stageinit %.0f endstage %.0f runinit %.0f\n",
+                   n, m, pc[3], pc[2], pc[1], pc[0], pc[4], pc[5], pt[7] * 0.01, pt[0] * 0.01, pt[1] * 0.01, pt[2] * 0.01, pt[3] * 0.01, pt[4] * 0.01, pt[5] * 0.01, pt[6] * 0.01, _trinit * 0.01);
 #endif
 #endif
     }

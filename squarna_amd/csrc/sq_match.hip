@@ -356,10 +356,22 @@ __device__ __forceinline__ void sq_mwm_one(SqBlossom &bl, char *lds_base, char *
         SqMatchEdge *le = reinterpret_cast<SqMatchEdge *>(wlds);
         for (int e = lane; e < m; e += 64) le[e] = edges[jp->edge_off + e];
         wsync();
+#ifdef SQ_MWM_PROF
+        const long long _w1 = wall_clock64();
+#endif
         if (lane == 0) { bl.init(n, m, le, wlds + ebytes, 1, false); bl.origin = lds_base; }
         wsync();
-        bl.template build_csr<1>(lane, 64, wsync);
+#ifdef SQ_MWM_PROF
+        const long long _w2 = wall_clock64();
+#endif
+        bl.template build_csr<1>(lane, 64, wsync, SqCoopWave());
+#ifdef SQ_MWM_PROF
+        const long long _w3 = wall_clock64();
+#endif
         bl.template run<1>(lane, 64, wsync, SqCoopWave(), lds_base);
+#ifdef SQ_MWM_PROF
+        if (lane == 0 && n >= 140) printf("mwm outside: edge load %.0f us, init %.0f, csr %.0f, run %.0f\n", (_w1 - _w0) * 0.01, (_w2 - _w1) * 0.01, (_w3 - _w2) * 0.01, (wall_clock64() - _w3) * 0.01);
+#endif
     } else if (hot_lds) {
         if (lane == 0) {
             char *cold = gscratch;
@@ -367,7 +379,7 @@ __device__ __forceinline__ void sq_mwm_one(SqBlossom &bl, char *lds_base, char *
             bl.origin = lds_base;
         }
         wsync();
-        bl.template build_csr<2>(lane, 64, wsync);
+        bl.template build_csr<2>(lane, 64, wsync, SqCoopWave());
         bl.template run<2>(lane, 64, wsync, SqCoopWave(), lds_base);
     }
     if (all_lds || hot_lds) {
@@ -388,7 +400,7 @@ __device__ __forceinline__ void sq_mwm_one(SqBlossom &bl, char *lds_base, char *
     }
     if (lane == 0) bl.init(n, m, edges + jp->edge_off, gscratch, 0, false);
     wsync();
-    bl.template build_csr<0>(lane, 64, wsync);
+    bl.template build_csr<0>(lane, 64, wsync, SqCoopWave());
     // lane 0 runs the order-dependent part; all 64 lanes share the O(n) sweeps of every substage
     bl.template run<0>(lane, 64, wsync, SqCoopWave(), nullptr);
     wsync();
