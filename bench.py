@@ -384,6 +384,12 @@ def stream_leg(config, K, R, steps, warmup, device):
     recs += list(ParseDefaultInput(os.path.join(ROOT, "squarna_amd", "data", "datasets", "SRtrain150.fas"), "qf"))
     allp = [Prepared(seq, reacts, restr, ref) for _, seq, reacts, restr, ref in recs]
     streams = [torch.cuda.Stream(device) for _ in range(K)]
+    # what a server does once it is up: the objects alive now (torch, numpy, the prepared records) leave the collector's
+    # generations -- a full collection over them takes 40-60 ms and a step that builds thousands of records triggers one
+    # every few steps (tools/stall_probe.py: the same 40 ms inside one fold in ten; none after gc.freeze())
+    import gc
+    gc.collect()
+    gc.freeze()
 
     def one_step(t, k, r):
         batches = []
@@ -418,7 +424,8 @@ def stream_leg(config, K, R, steps, warmup, device):
     dt, per, packed = timed(K, R, steps, warmup)
     stream = dict(what="SRtest150 + SRtrain150 (485 records) as a stream: every step takes the next windows of 219 x %d records for "
                        "%d batches; timed per step: Batch() (host arrays + sq_batch_create = upload) + fold of the batches in flight "
-                       "+ sq_result_pack_all; c=%s poollim=1000" % (R, K, config),
+                       "+ sq_result_pack_all; c=%s poollim=1000; %d warm-up steps (the pinned-buffer cache meets every size of the windows "
+                       "after five), gc.freeze() before them" % (R, K, config, warmup),
                   seq_per_s=round(219 * R * K * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3),
                   median_ms_per_step=round(per[len(per) // 2], 3), max_ms_per_step=round(per[-1], 3), steps=steps, packed_bytes_per_step=packed)
     # the same stream as a server runs it: while the batches of one step fold (a library call: no interpreter lock), a
@@ -456,7 +463,7 @@ def stream_leg(config, K, R, steps, warmup, device):
                         th.join()
                 nxt = box.get("b")
             return packed_
-        run_pipelined(2, 1000)
+        run_pipelined(4, 1000)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         packed2 = run_pipelined(steps, 2000)
@@ -887,7 +894,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_stream:
         torch.cuda.empty_cache()                              # (every leg starts from a clean allocator: the blocks the legs before it left
         try:                                                  # cached have other sizes, and a leg that allocates per step then pays for them)
-            stream, one_pass = stream_leg(args.config, K, R, max(5, args.steps // 2), 2, device)
+            stream, one_pass = stream_leg(args.config, K, R, max(5, args.steps // 2), 6, device)
         except Exception as e:                                # (a secondary leg never takes the headline down)
             stream = {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -152,10 +152,14 @@ struct JobBuild { int n = 0; size_t ncell = 0, need = 0, nout = 0; };
 // One batch folded alone keeps Nussinov on a stream of its own (it then ends before the greedy loop does, and the
 // collection of the short kernels does not wait behind Edmonds' second size class + Hungarian); sq_fold_concurrent
 // with three or more batches in flight asks for the two-stream form.
+// (slot 3: the stream of the blossom kernel's smaller size classes -- a stream of its own when the batch is folded alone,
+// else in front of the short kernels on theirs.  Until the critical class took 2.2 ms they could sit in front of the
+// Hungarian kernel: 1.0 + 1.5 ms then ended after the critical class did)
 static inline int side_of(const sq_batch *b, int slot)
 {
     static const int forced = getenv("SQ_SIDE_STREAMS") ? atoi(getenv("SQ_SIDE_STREAMS")) : 0;
     const int nside = forced ? forced : b->side_streams;
+    if (slot == 3) return nside >= 3 ? 3 : (nside == 2 ? 1 : 0);
     return nside >= 3 ? slot : (nside == 2 ? (slot == 0 ? 0 : 1) : 0);
 }
 
@@ -184,7 +188,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     // pass 1 (pool): sizes only -- cells (= edges) and, for Edmonds, graph vertices (distinct positions)
     const double tb0 = sq_now();
     std::vector<JobBuild> jb(nj);
-    sq_pool(b)->parallel_for((int)nj, [&](int q) {
+    auto size_one = [&](int q) {
         const SqJob &J = b->jobs[jobs[k0 + q]];
         JobBuild &B = jb[q];
         size_t ncell = 0;
@@ -211,7 +215,10 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
             B.nout = algo == SQ_ALGO_H ? (size_t)J.n : 2 * ((size_t)J.n + 4);
         }
         B.need = (B.need + 255) & ~(size_t)255;
-    });
+    };
+    // (with the sizes from the device a job costs a few instructions: waking the pool costs more than the loop)
+    if (dev_sizes) for (int q = 0; q < (int)nj; q++) size_one(q);
+    else sq_pool(b)->parallel_for((int)nj, size_one);
     const double tb1 = sq_now();
     std::vector<SqMatchJob> &mj = ck.mj;
     size_t scratch = 0, outints = 0, nedges = 0, k1 = k0, vids = 0;
@@ -311,7 +318,10 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
         memcpy(ck.p_jobs, ck.sorted.data(), nq * sizeof(SqMatchJob));
     }
     const double tb2 = sq_now();
-    if (dev_sizes) return 0;                              // (the edges are written on the device: sq_algo_edges_kernel)
+    if (dev_sizes) {                                      // (the edges are written on the device: sq_algo_edges_kernel)
+        if (b->sw.timing) fprintf(stderr, "[sq_algos] layout algo %d: sizes %.3f ms, tables + classes %.3f ms\n", algo, (tb1 - tb0) * 1e3, (tb2 - tb1) * 1e3);
+        return 0;
+    }
     // pass 2 (pool): the edges, written straight into the pinned buffer
     ck.vid2pos.resize(mj.size());
     if (b->sw.mwm_posthoc) ck.seen_hash.assign(mj.size(), 0);
@@ -673,8 +683,10 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
         raw.cap = (uint32_t)std::min<size_t>(raw_cap, 0x7FFFFFF0u);
     }
     int64_t cands_used = 0;
+    const double tt0 = sq_now();
     int r = sq_round_annotate_dev(b, all, pa->h_sizes, &cands_used, raw);
     if (r) return r;                                       // (1: does not fit one round)
+    const double tt1 = sq_now();
     if (raw_cap) {
         // stemscore ** 1.7 with the host's libm, in place (the reference: Python's float ** on every stem, SQRNalgos.py:101,122)
         CpuScope cpu_(2);
@@ -754,14 +766,21 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
         }
         base += mj.size();
     }
+    const double tt2 = sq_now();
+    struct Rep { double t0, t1, t2; bool on; ~Rep() { if (on) fprintf(stderr, "[sq_algos] device RunAlgo: annotate round + wait for the sizes %.3f ms, layout %.3f ms, launches %.3f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3, (sq_now() - t2) * 1e3); } } rep_dev{tt0, tt1, tt2, b->sw.timing};
     // ---- launches: edges on the batch stream (it owns the arena), then every item on its side stream ----
     hipStream_t st = b->stream;
     {
         const int maxn_lds = (std::min(b->maxn, SQ_ALGO_MAXN) + 7) & ~7;   // (the device RunAlgo only takes batches up to SQ_ALGO_MAXN nt)
         SqAlgoStatPtrs zs{{nullptr, nullptr, nullptr}};
         for (size_t q = 0; q < pa->items.size() && q < 3; q++) zs.p[q] = (SqAlgoStat *)(regions[q] + cv[q].o_stat);
-        hipLaunchKernelGGL(sq_algo_edges_kernel, dim3(S), dim3(256), (size_t)6 * maxn_lds + 16, st, b->ctx, b->lane_full.d_structs,
-                           [&] { SqScanArgs a = b->scan; a.ctr = b->lane_full.d_ctr; return a; }(), round_aj, maxn_lds, zs);
+        // the stem lists in LDS when the longest of the launch fits (a thread holds four stems of the ranking pass: 1,024)
+        int nokcap = 0;
+        for (int s2 = 0; s2 < S; s2++) nokcap = std::max(nokcap, (int)pa->h_sizes[s2].nok);
+        nokcap = (nokcap + 63) & ~63;
+        if (nokcap > 1024 || sq_algo_edges_lds(maxn_lds, nokcap) > 48 * 1024 || b->sw.no_edges_lds) nokcap = 0;
+        hipLaunchKernelGGL(sq_algo_edges_kernel, dim3(S), dim3(256), sq_algo_edges_lds(maxn_lds, nokcap), st, b->ctx, b->lane_full.d_structs,
+                           [&] { SqScanArgs a = b->scan; a.ctr = b->lane_full.d_ctr; return a; }(), round_aj, maxn_lds, zs, nokcap);
     }
     HIPCK(hipGetLastError());
     if (!b->class_ev) HIPCK(sq_event_get(b->device, &b->class_ev));
@@ -793,8 +812,8 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
             // finish kernel
             rl = 0;
             hipStream_t other = nullptr;
-            if (it.algo == SQ_ALGO_E && ck.classes.size() > 1 && side_of(b, 1) != ss) {
-                const int s2 = side_of(b, 1);
+            if (it.algo == SQ_ALGO_E && ck.classes.size() > 1 && side_of(b, 3) != ss) {
+                const int s2 = side_of(b, 3);
                 if (!b->side[s2]) { if (sq_check(sq_stream_get(b->device, &b->side[s2]), "hipStreamCreate")) return 2; }
                 other = b->side[s2];
                 HIPCK(hipStreamWaitEvent(other, b->edges_ev, 0));
@@ -855,7 +874,7 @@ static int algos_end_dev(sq_batch *b, SqAlgoAsync *pa)
             if (np > b->mwm_stats[2]) { b->mwm_stats[2] = np; b->mwm_stats[3] = hs.max_events; b->mwm_stats[4] = hs.max_n; b->mwm_stats[5] = hs.max_m; }
         }
     }
-    for (int k = 0; k < 3; k++) if (b->side[k]) hipStreamSynchronize(b->side[k]);
+    for (int k = 0; k < 4; k++) if (b->side[k]) hipStreamSynchronize(b->side[k]);
     b->cand_reserved = 0;
     return r;
 }
@@ -914,8 +933,8 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
         if (!b->side[ss]) { if (sq_check(sq_stream_get(b->device, &b->side[ss]), "hipStreamCreate")) return 2; }
         const double tl0 = sq_now();
         hipStream_t st2 = nullptr;
-        if (it.algo == SQ_ALGO_E && side_of(b, 1) != ss) {               // the stream of the short kernels (created here if need be)
-            const int s2 = side_of(b, 1);
+        if (it.algo == SQ_ALGO_E && side_of(b, 3) != ss) {               // the stream of the smaller classes (created here if need be)
+            const int s2 = side_of(b, 3);
             if (!b->side[s2]) { if (sq_check(sq_stream_get(b->device, &b->side[s2]), "hipStreamCreate")) return 2; }
             st2 = b->side[s2];
         }
@@ -957,7 +976,7 @@ int sq_algos_begin(sq_batch *b, const std::vector<uint32_t> &algos, SqAlgoAsync 
 
 void sq_algos_abandon(sq_batch *b, SqAlgoAsync *pa)
 {
-    for (int k = 0; k < 3; k++) if (b->side[k]) hipStreamSynchronize(b->side[k]);
+    for (int k = 0; k < 4; k++) if (b->side[k]) hipStreamSynchronize(b->side[k]);
     b->cand_reserved = 0;
     delete pa;
 }
@@ -989,7 +1008,7 @@ int sq_algos_end(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt, std::vector<J
         const std::function<void(size_t)> cb = [&](size_t k) { hooks->on_e_job(it.jobs[k], sets[0].sets[k]); };
         r = algo_collect(b, it.jobs, it.stems, it.ck, levellimit_opt, sets[0].sets, &cb);
     }
-    for (int k = 0; k < 3; k++) if (b->side[k]) hipStreamSynchronize(b->side[k]);
+    for (int k = 0; k < 4; k++) if (b->side[k]) hipStreamSynchronize(b->side[k]);
     b->cand_reserved = 0;
     size_t q = 0;
     for (auto &it : pa->items) {

@@ -40,7 +40,14 @@ struct SqAlgoStat {                // per launch of the finish kernel (device; s
 extern "C" {
 __global__ void sq_algo_sizes_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, SqAlgoSize *sizes, SqAlgoRaw raw);
 struct SqAlgoStatPtrs { SqAlgoStat *p[3]; };          // the items' counters, zeroed by the edges kernel (no memset launches)
-__global__ void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs, int maxn_lds, SqAlgoStatPtrs zs);
+__global__ void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs, int maxn_lds, SqAlgoStatPtrs zs, int nokcap);
+// dynamic LDS of the edges kernel: per-position arrays (6 bytes) and, with nokcap > 0, the stem lists of the fast form
+inline size_t sq_algo_edges_lds(int maxn_lds, int nokcap)
+{
+    size_t b = (((size_t)6 * maxn_lds + 15) & ~(size_t)15) + 16;
+    if (nokcap > 0) b += (size_t)4 * (2 * (2 * (size_t)maxn_lds + 2) + 4 * (size_t)nokcap);
+    return b;
+}
 __global__ void sq_algo_finish_kernel(SqDevCtx c, const SqAlgoJob *jobs, const SqMatchJob *mj, const int32_t *out, const int32_t *cnt,
                                       int levellimit_opt, SqPoolFin *fin, SqPoolStem *fin_stems, uint32_t *fin_ctr, uint32_t fin_cap,
                                       uint32_t fin_stem_cap, SqAlgoStat *stats, int tcap);

@@ -70,8 +70,37 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_sizes_kernel(SqDevCtx 
 // ---- edge lists -----------------------------------------------------------------------------------------------------
 // scratch of a structure: the SqKey part of its candidate slice (dead once the bpscore filter has run):
 // [nok x uint32 sorted survivor index][nok x uint32 first edge of that stem]
+//
+// nokcap > 0: the launch's jobs keep their stem lists in LDS (sq_algo_edges_lds): keys, lengths, the order and the edge
+// offsets -- the reference's emission order by a bucket sort over the anti-diagonals (key = diagonal << 16 | row: a bucket
+// holds the few stems of one diagonal), O(stems).  Until round 4 every thread ranked its stem against ALL keys in global
+// memory and every later pass chased survivor index -> record through L2: 85-110 us for SRtest150's 657 jobs, a
+// quarter of it left.  nokcap == 0 (lists too long for LDS): that form.
+// exclusive prefix sum of v[0 .. cnt) in place by the block (256 threads); returns the total to every thread
+__device__ __forceinline__ uint32_t sq_block_excl_scan(uint32_t *v, int cnt, uint32_t *s_wsum, uint32_t *s_run, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) *s_run = 0;
+    __syncthreads();
+    for (int x0 = 0; x0 < cnt; x0 += 256) {
+        const int x = x0 + tid;
+        const uint32_t mine = x < cnt ? v[x] : 0u;
+        uint32_t inc = mine;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        uint32_t before = *s_run;
+        for (int w = 0; w < wave; w++) before += s_wsum[w];
+        if (x < cnt) v[x] = before + inc - mine;
+        __syncthreads();
+        if (tid == 0) *s_run += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        __syncthreads();
+    }
+    return *s_run;
+}
+
 extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScanArgs a, const SqAlgoJob *jobs, int maxn_lds,
-                                                                      SqAlgoStatPtrs zs)
+                                                                      SqAlgoStatPtrs zs, int nokcap)
 {
     if (blockIdx.x == 0 && threadIdx.x < 3 && zs.p[threadIdx.x]) {      // (the finish kernels of the items count into these)
         SqAlgoStat z; memset(&z, 0, sizeof(z)); *zs.p[threadIdx.x] = z;
@@ -90,6 +119,49 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx 
     const SqOk *oks = sq_oks(a, st, jb.cand_cap);
     uint32_t *sidx = reinterpret_cast<uint32_t *>(sq_keys(a, st));
     uint32_t *eoff = sidx + nok;
+    const bool fast = nokcap > 0 && nok <= (uint32_t)nokcap;
+    // LDS lists of the fast form, behind the per-position arrays: [diagonal starts 2 maxn + 2][diagonal fills 2 maxn + 2]
+    // [keys][lengths -> edge offsets][bucket order][sorted order]
+    uint32_t *const s_dstart = reinterpret_cast<uint32_t *>(sq_edges_dyn + (((size_t)6 * maxn_lds + 15) & ~(size_t)15));
+    uint32_t *const s_dfill = s_dstart + 2 * maxn_lds + 2;
+    uint32_t *const s_key = s_dfill + 2 * maxn_lds + 2;
+    uint32_t *const s_eoff = s_key + nokcap;
+    uint32_t *const s_tmp = s_eoff + nokcap;
+    uint32_t *const s_sidx = s_tmp + nokcap;
+    if (fast) {
+        const int nd = 2 * n + 1;                                       // diagonals s = i + j < 2 n
+        for (int d = tid; d <= nd; d += 256) { s_dstart[d] = 0u; s_dfill[d] = 0u; }
+        __syncthreads();
+        for (uint32_t x = tid; x < nok; x += 256) {
+            const SqOk cd = oks[x];
+            s_key[x] = cd.key; s_tmp[x] = cd.len;                       // (lengths in emission order follow below)
+            atomicAdd(&s_dstart[cd.key >> 16], 1u);
+        }
+        __syncthreads();
+        sq_block_excl_scan(s_dstart, nd, s_wsum, &s_run, tid);
+        // the stems of a diagonal in any order, then every stem's place among them: key ascending
+        for (uint32_t x = tid; x < nok; x += 256) {
+            const uint32_t d = s_key[x] >> 16;
+            s_sidx[s_dstart[d] + atomicAdd(&s_dfill[d], 1u)] = x;      // (s_sidx: bucket order for now)
+        }
+        __syncthreads();
+        uint32_t myx[4], myr[4];                                        // (a thread's stems of this pass: nokcap <= 1,024)
+        int nm = 0;
+        for (uint32_t p = tid; p < nok; p += 256) {
+            const uint32_t x = s_sidx[p], k = s_key[x], d = k >> 16;
+            const uint32_t lo = s_dstart[d], hi = lo + s_dfill[d];
+            uint32_t r = lo;
+            for (uint32_t q = lo; q < hi; q++) r += s_key[s_sidx[q]] < k ? 1u : 0u;
+            myx[nm] = x; myr[nm] = r; nm++;
+        }
+        __syncthreads();
+        for (int q = 0; q < nm; q++) { s_sidx[myr[q]] = myx[q]; sidx[myr[q]] = myx[q]; }
+        __syncthreads();
+        for (uint32_t x = tid; x < nok; x += 256) s_eoff[x] = s_tmp[s_sidx[x]];   // lengths in emission order
+        __syncthreads();
+        sq_block_excl_scan(s_eoff, (int)nok, s_wsum, &s_run, tid);
+        for (uint32_t x = tid; x < nok; x += 256) eoff[x] = s_eoff[x];
+    } else {
     // the reference's emission order: anti-diagonal ascending, then row ascending == key ascending (keys are distinct)
     for (uint32_t x = tid; x < nok; x += 256) {
         const uint32_t kx = oks[x].key;
@@ -115,17 +187,28 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx 
         if (tid == 0) s_run += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
         __syncthreads();
     }
+    }
     __threadfence_block();
     __syncthreads();
+    // (the fast form reads order, key, length and offset from LDS; a stem's length: the next offset minus its own)
+    auto stem_of = [&](uint32_t x, uint32_t &key, int &len, int &e0, uint32_t &src) {
+        if (fast) {
+            src = s_sidx[x]; key = s_key[src]; e0 = (int)s_eoff[x]; len = (int)s_tmp[src];
+        } else {
+            src = sidx[x];
+            const SqOk cd = oks[src];
+            key = cd.key; len = (int)cd.len; e0 = (int)eoff[x];
+        }
+    };
     if (aj.algo == SQ_ALGO_E) {
         // networkx numbers the nodes in order of first appearance in the edge list (v before w of every edge)
         for (int p = tid; p < n; p += 256) s_first[p] = 0x7FFFFFFF;
         __syncthreads();
         for (uint32_t x = tid; x < nok; x += 256) {
-            const SqOk cd = oks[sidx[x]];
-            const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
-            const int e0 = (int)eoff[x];
-            for (int t = 0; t < (int)cd.len; t++) { atomicMin(&s_first[i0 + t], 2 * (e0 + t)); atomicMin(&s_first[j0 - t], 2 * (e0 + t) + 1); }
+            uint32_t key, src; int len, e0;
+            stem_of(x, key, len, e0, src);
+            const int s = (int)(key >> 16), i0 = (int)(key & 0xFFFFu), j0 = s - i0;
+            for (int t = 0; t < len; t++) { atomicMin(&s_first[i0 + t], 2 * (e0 + t)); atomicMin(&s_first[j0 - t], 2 * (e0 + t) + 1); }
         }
         __syncthreads();
         for (int p = tid; p < n; p += 256) {
@@ -137,13 +220,15 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx 
         __syncthreads();
     }
     for (uint32_t x = tid; x < nok; x += 256) {
-        const SqOk cd = oks[sidx[x]];
-        const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
-        double wt = cd.bps;                                             // Nussinov: the score itself (SQRNalgos.py:49)
-        if (aj.algo != SQ_ALGO_N)                                       // :101,122: the host libm's power, from the paramset's table
-            wt = aj.raw ? aj.raw[sidx[x]] : c.powtab[ps->pow_off + (int)(cd.bps * ps->pow_scale)];   // (k 2^-q exactly) or the job's list
-        SqMatchEdge *e = aj.edges + eoff[x];
-        for (int t = 0; t < (int)cd.len; t++) {
+        uint32_t key, src; int len, e0;
+        stem_of(x, key, len, e0, src);
+        const int s = (int)(key >> 16), i0 = (int)(key & 0xFFFFu), j0 = s - i0;
+        double wt;
+        if (aj.algo == SQ_ALGO_N) wt = oks[src].bps;                    // Nussinov: the score itself (SQRNalgos.py:49)
+        else if (aj.raw) wt = aj.raw[src];                              // :101,122: the host libm's power -- the job's list,
+        else wt = c.powtab[ps->pow_off + (int)(oks[src].bps * ps->pow_scale)];   // or the paramset's table (scores k 2^-q exactly)
+        SqMatchEdge *e = aj.edges + e0;
+        for (int t = 0; t < len; t++) {
             const int v = i0 + t, w = j0 - t;
             e[t] = aj.algo == SQ_ALGO_E ? SqMatchEdge{s_id[v], s_id[w], wt} : SqMatchEdge{v, w, wt};
         }

@@ -752,7 +752,7 @@ extern "C" void sq_batch_destroy(sq_batch *b)
 {
     if (!b) return;
     hipStreamSynchronize(b->stream);
-    for (int k = 0; k < 3; k++) if (b->side[k]) { hipStreamSynchronize(b->side[k]); sq_stream_put(b->device, b->side[k]); }
+    for (int k = 0; k < 4; k++) if (b->side[k]) { hipStreamSynchronize(b->side[k]); sq_stream_put(b->device, b->side[k]); }
     if (b->lane_stream) { hipStreamSynchronize(b->lane_stream); sq_stream_put(b->device, b->lane_stream); }
     sq_event_put(b->device, b->class_ev);
     sq_event_put(b->device, b->edges_ev);

@@ -11,6 +11,7 @@ void sq_read_fold_switches(SqFoldSwitches &sw)
     sw.pool_round_nsurv = num("SQ_POOL_ROUND_NSURV", 64, 2048);
     sw.pool_slots = num("SQ_POOL_SLOTS", 1, 0x7fffffff); sw.pool_chunk = num("SQ_POOL_CHUNK", 1, 0x7fffffff);
     sw.no_score_bound = on("SQ_NO_SCORE_BOUND"); sw.no_score_context = on("SQ_NO_SCORE_CONTEXT");
+    sw.no_edges_lds = on("SQ_NO_EDGES_LDS");
     sw.no_device_algos = on("SQ_NO_DEVICE_ALGOS"); sw.no_device_tail = on("SQ_NO_DEVICE_TAIL");
     sw.algo_sync = on("SQ_ALGO_SYNC"); sw.lsap_classes = num("SQ_LSAP_CLASSES", 1, 64);
     sw.mwm_dump = on("SQ_MWM_DUMP"); sw.mwm_posthoc = on("SQ_MWM_POSTHOC");
@@ -632,7 +633,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             // (the device log holds the structures the aborted pools had finished: they leave it for the host loop's.  The E / H / N
             // stemsets of the device RunAlgo stay -- their finish kernels append on the side streams: wait for them first, the
             // host loop that follows is the slow path anyway.  Round 3 emptied the whole log here and lost those stemsets)
-            for (int q = 0; q < 3; q++) if (b->side[q]) hipStreamSynchronize(b->side[q]);
+            for (int q = 0; q < 4; q++) if (b->side[q]) hipStreamSynchronize(b->side[q]);
             hipLaunchKernelGGL(sq_fin_keep_algos_kernel, dim3(1), dim3(1024), 0, st, b->d_fin, b->d_fin_ctr, b->fin_cap, b->d_job_evals, b->tail.job_cnt, b->njobs);
             return 1;
         }

@@ -125,6 +125,7 @@ struct SqFoldSwitches {
     bool no_score_bound = false;      // SQ_NO_SCORE_BOUND: ScoreStems on every survivor of :492
     bool no_score_context = false;    // SQ_NO_SCORE_CONTEXT: the strand walk instead of the context tables (launched rounds)
     bool no_device_algos = false;     // SQ_NO_DEVICE_ALGOS: RunAlgo's edge lists and filters on the host
+    bool no_edges_lds = false;        // SQ_NO_EDGES_LDS: the edges kernel ranks its stems in global memory (the form for lists beyond LDS)
     bool no_device_tail = false;      // SQ_NO_DEVICE_TAIL: the ranking tail on the host
     bool algo_sync = false;           // SQ_ALGO_SYNC: matching kernels on the batch stream
     int lsap_classes = 0;             // SQ_LSAP_CLASSES: size classes of the Hungarian / Nussinov launches (0: 3 crowded, else 1)
@@ -170,7 +171,7 @@ struct sq_batch {
     uint32_t algo_seq = 0;                // completion stamps of the matching launches
     hipStream_t lane_stream = nullptr;        // second lane of sq_fold's greedy rounds (created on first use)
     hipEvent_t lane_ev = nullptr;
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold)
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams of the E / H / N kernels (sq_fold); [3]: the blossom kernel's smaller size classes of a batch folded alone
     int32_t cell_entries = 32;            // doubles of the scoring kernels' cell table (dynamic LDS)
     bool score_bound = true, score_ctx = true;   // the scoring kernel's branch and bound / closed-form sweep (per fold: SQ_NO_SCORE_BOUND, SQ_NO_SCORE_CONTEXT)
     SqCtxTab ctxtab = SqCtxTab{};         // ScoreStems context tables (sq_context.h), rec == nullptr: none
@@ -183,7 +184,7 @@ struct sq_batch {
     int32_t result_limit = 0;             // sq_result_limit (0: the getters show every structure)
     int inflight = 1;                     // batches folded at the same time (sq_fold_concurrent): sizes the pool, relaxes the wait loops
     int side_streams = 3;                 // side streams of E / H / N: 3, or 2 (H and N share one) with many batches in flight
-    hipEvent_t class_ev = nullptr;        // joins the blossom kernel's smaller size classes (on side[1]) into side[0]
+    hipEvent_t class_ev = nullptr;        // joins the blossom kernel's smaller size classes (on side[3], or on the short kernels' stream) into side[0]
     hipEvent_t edges_ev = nullptr;        // device-side RunAlgo: the edge lists are written (batch stream -> side streams)
     uint32_t out_cap = 0;
     int32_t strand_cap = 0;

@@ -369,7 +369,7 @@ extern "C" int sq_profile_get(sq_batch *b, int32_t k, double *ms, int64_t *launc
 {
     if (k < 0 || k > 7) return -1;
     hipStreamSynchronize(b->stream);
-    for (int q = 0; q < 3; q++) if (b->side[q]) hipStreamSynchronize(b->side[q]);
+    for (int q = 0; q < 4; q++) if (b->side[q]) hipStreamSynchronize(b->side[q]);
     prof_collect(b);
     *ms = b->prof[k].ms; *launches = b->prof[k].launches; *bytes = b->prof[k].bytes;
     return 0;

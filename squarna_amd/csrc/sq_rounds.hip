@@ -418,7 +418,11 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                     }
                 }
                 bool ok = L > 0 && r.bps >= minbps;                             // :492
-                if (ok) {                                                       // and the bound
+                // and the bound -- first with every factor at its maximum (ps->ub_lf; the same products in the same order: never
+                // below the exact bound), which needs nothing but the run's bpscore: the list is ordered by bpscore, so once a
+                // strong run has set `need` most of the list ends here without touching the prefix counts in LDS
+                if (ok && ub_lf < INFINITY && r.bps >= 0) ok = !(((((r.bps * ub_of) * ub_lf) * 1.25) * (1.0 + 0x1p-30)) < need);
+                if (ok) {
                     const int i0 = (int)(r.key & 0xFFFFu), j0 = (int)(r.key >> 16) - i0;
                     ok = !(upper_of(r.bps, i0, j0, L) < need);
                 }

@@ -258,11 +258,60 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS_WIDE) void sq_tail_rank_
     if (tid == 0) _tp[1] = wall_clock64();
 #endif
     // ---- b. canonical stems (maximal stacks in ascending order of i) + hash, one wave per entry ----
+    // The hash only groups candidates for pass c (which compares stem by stem): sum over the canonical stems of
+    // mix(stem) x (odd constant + 2 x position), the same from either form below.
+    // Structures of up to 64 stems (all but pathological ones): a stem per lane, in registers -- rank among the stems with
+    // len > 0 by a uniform loop of readlanes, the sorted list by a shuffle, stacks joined by comparing neighbours (a merged
+    // stack ends where its last stem ends: the serial rule's comparison with the merged predecessor is the comparison with
+    // the stem before), lengths from the segment's last stem.  (Until round 4 lane 0 walked the sorted list in global
+    // memory: a chain of dependent loads per stem, 100 of the kernel's 290 us on SRtest150.)
     for (uint32_t x = wave; x < M; x += nwv) {
         const uint32_t e = t.ord[first + x];
         const SqPoolFin F = t.fin[e];
         const int T = F.nstems;
         SqPoolStem *cs = sq_fin_canon(t, F);
+        if (T <= 64) {
+            const SqPoolStem mine = lane < T ? sq_fin_stem(t, F, lane) : SqPoolStem{0, 0, 0, 0};
+            const bool valid = lane < T && mine.len > 0;
+            const unsigned long long vm = __ballot(valid);
+            const int V = (int)__popcll(vm);
+            const int mi = mine.i;
+            int r = 0;
+            for (int p = 0; p < T; p++) {
+                if (!((vm >> p) & 1ull)) continue;                        // (uniform)
+                const int ip = __builtin_amdgcn_readlane(mi, p);
+                r += (ip < mi || (ip == mi && p < lane)) ? 1 : 0;
+            }
+            int src = 0;
+            for (int p = 0; p < T; p++) {
+                if (!((vm >> p) & 1ull)) continue;
+                const int rp = __builtin_amdgcn_readlane(r, p);
+                if (rp == lane) src = p;
+            }
+            const int packed_ij = ((int)(uint16_t)mine.i) | ((int)(uint16_t)mine.j << 16);
+            const int sij = __shfl(packed_ij, src, 64), slen = __shfl((int)mine.len, src, 64);
+            const int si = (int)(int16_t)(sij & 0xFFFF), sj = (int)(int16_t)((uint32_t)sij >> 16);
+            const int pi = __shfl_up(si, 1, 64), pj = __shfl_up(sj, 1, 64), pl = __shfl_up(slen, 1, 64);
+            const bool in = lane < V;
+            const bool joins = in && lane > 0 && si == pi + pl && sj == pj - pl;
+            const bool bad = in && lane > 0 && si < pi + pl;             // 5' strands overlap: not disjoint stacks
+            const unsigned long long heads = __ballot(in && !joins);
+            const int seg = (int)__popcll(heads & ((2ull << lane) - 1ull)) - 1;
+            const unsigned long long above = lane < 63 ? heads >> (lane + 1) : 0ull;
+            const int last = above ? lane + (int)__ffsll((long long)above) - 1 : V - 1;   // the segment's last stem
+            const int endi = __shfl(si + slen, last < 0 ? 0 : last, 64);
+            const bool head = in && !joins;
+            unsigned long long contrib = 0ull;
+            if (head) {
+                const int total = endi - si;
+                cs[seg] = SqPoolStem{(int16_t)si, (int16_t)sj, (int16_t)total, 0};
+                contrib = sq_mix_stem(si, sj, total) * (0xD6E8FEB86659FD93ull + 2ull * (unsigned long long)seg);
+            }
+            for (int off = 32; off > 0; off >>= 1) contrib += (unsigned long long)__shfl_xor((long long)contrib, off, 64);
+            if (lane == 0) { t.cs_n[first + x] = (uint32_t)__popcll(heads); t.hash[first + x] = contrib; t.mask[first + x] = 0ull; }
+            if (__ballot(bad) != 0ull && lane == 0) *t.fallback = 1;
+            continue;
+        }
         for (int q = lane; q < T; q += 64) {                            // rank by i (stems of a structure start at distinct positions)
             const SqPoolStem sq = sq_fin_stem(t, F, q);
             int r = 0;
@@ -283,8 +332,8 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS_WIDE) void sq_tail_rank_
                 }
                 cs[cn++] = sq;
             }
-            unsigned long long h = 0x9E3779B97F4A7C15ull;
-            for (int q = 0; q < cn; q++) h = (h ^ sq_mix_stem(cs[q].i, cs[q].j, cs[q].len)) * 0xD6E8FEB86659FD93ull;
+            unsigned long long h = 0ull;
+            for (int q = 0; q < cn; q++) h += sq_mix_stem(cs[q].i, cs[q].j, cs[q].len) * (0xD6E8FEB86659FD93ull + 2ull * (unsigned long long)q);
             t.cs_n[first + x] = (uint32_t)cn; t.hash[first + x] = h; t.mask[first + x] = 0ull;
             if (bad) *t.fallback = 1;
         }
@@ -497,7 +546,7 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS_WIDE) void sq_tail_rank_
     __syncthreads();
     if (tid == 0) {
         _tp[7] = wall_clock64();
-        if (_tp[7] - _tp[0] > 30000)
+        if (_tp[7] - _tp[0] > 15000)
             printf("tail s=%d n=%d M=%u D=%u jobs=%d | us: sort %.0f canon %.0f first %.0f producers %.0f score %.0f rank %.0f show %.0f\n", s, n, M, D, j1 - j0,
                    (_tp[1] - _tp[0]) * 0.01, (_tp[2] - _tp[1]) * 0.01, (_tp[3] - _tp[2]) * 0.01, (_tp[4] - _tp[3]) * 0.01, (_tp[5] - _tp[4]) * 0.01,
                    (_tp[6] - _tp[5]) * 0.01, (_tp[7] - _tp[6]) * 0.01);
