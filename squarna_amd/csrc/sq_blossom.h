@@ -39,7 +39,6 @@ struct SqCoopSingle {
     SQ_HD int count_true(bool p, int &first) const { first = 0; return p ? 1 : 0; }
     static constexpr int kSegMax = 1;                           // vertices per scan pass
     SQ_HD int readlane(int x, int) const { return x; }
-    SQ_HD int shfl(int x, int) const { return x; }
     SQ_HD bool any(bool p) const { return p; }
     SQ_HD void min_pos_f64(double *p, double v) const { if (v < *p) *p = v; }
     SQ_HD void add_i32(int *p, int v) const { *p += v; }
@@ -55,7 +54,6 @@ struct SqCoopWave {
     static constexpr int kSegMax = SQ_MWM_SEGMAX;               // vertices per scan pass (their neighbour lists share the 64 lanes)
     __device__ int readlane(int x, int l) const { return __builtin_amdgcn_readlane(x, l); }
     __device__ bool any(bool p) const { return __ballot(p) != 0; }
-    __device__ int shfl(int x, int l) const { return __shfl(x, l, 64); }
     __device__ void add_i32(int *p, int v) const { atomicAdd(p, v); }
     __device__ void min_i32_at(int *p, int v) const { atomicMin(p, v); }
     // *p = min(*p, v) for POSITIVE doubles (and +inf): their bit patterns order like unsigned integers
@@ -971,70 +969,19 @@ struct SqBlossom {
                     for (int k = 1; k < SEGMAX; k++) if (fseg == k) fend = L_a0[k] + L_len[k];
                     qn_r -= fseg + 1 - (hascur ? 1 : 0);
                     nevent++;
+                    if (lane == 0) qn = qn_r;
+                    sync();
 #ifdef SQ_MWM_PROF
                     long long _te = 0;
                     if (lane == 0) { pc[4]++; _te = wall_clock64(); }
 #endif
                     // the most frequent event by far -- an allowed edge to an unlabelled blossom: T for it, S for the mate of its
-                    // base (assignLabel(w, 2, ...)) -- is run by lane f itself, which holds the edge, w, its blossom and the allow
-                    // decision in registers (what the lanes before it applied cannot touch them: their neighbours are labelled or
-                    // stay unlabelled).  When the new S-vertex is its own blossom -- one push -- nothing goes through the object
-                    // in LDS: the queue length, the error flag and the NEXT pass's segments travel by readlane / shuffle: the
-                    // vertex in progress, the new vertex with its list (lane f read the offsets next to the vertex's blossom),
-                    // the segments of this pass behind the event's, then the entries fetched for the pass after.
+                    // base -- is run by lane f itself, which holds the edge, w and the allow decision in registers (what the
+                    // lanes before it applied cannot touch them: their neighbours are labelled or stay unlabelled)
                     const bool tfast = coop.readlane(lbw == 0 ? 1 : 0, f) != 0;
                     if (tfast) {
-                        int ev_v = -1, ev_a0 = 0, ev_len = -1, ev_qn = qn_r, ev_err = 0;
-                        if (lane == f) {
-                            if (becomes) allow_[de >> 1] = 1;
-                            label_[w] = 2; label_[bw] = 2; labeledge_[w] = de; labeledge_[bw] = de;
-                            bestedge_[w] = -1; bestedge_[bw] = -1; bslack_[w] = SQ_BINF; bslack_[bw] = SQ_BINF;
-                            const int bs = SQ_LQ(base)[bw];
-                            const int de2 = SQ_LQ(mate_de)[bs], w2 = SQ_LQ(mate)[bs];       // (base, mate[base]): the mate becomes an S-vertex
-                            const int b2 = inblossom_[w2], o0 = adj_off_[w2], o1 = adj_off_[w2 + 1];
-                            label_[w2] = 1; label_[b2] = 1; labeledge_[w2] = de2; labeledge_[b2] = de2;
-                            bestedge_[w2] = -1; bestedge_[b2] = -1; bslack_[w2] = SQ_BINF; bslack_[b2] = SQ_BINF;
-                            if (b2 < n) {
-                                if (qn_r < qcap_r) { SQ_LP(queue)[qn_r] = b2; ev_qn = qn_r + 1; ev_v = b2; ev_a0 = o0; ev_len = o1 - o0; }
-                                else { error = 1; ev_err = 1; }
-                            } else {                                    // the leaves of a blossom, through the object
-                                qn = qn_r;
-                                const int cl = leaves<FAST>(b2, SQ_LQ(tmp_leaves));
-                                for (int k = 0; k < cl; k++) qpush<FAST>(SQ_LQ(tmp_leaves)[k]);
-                                ev_qn = qn; ev_err = error; ev_v = -2;
-                            }
-                        }
-                        sync();
-#ifdef SQ_MWM_PROF
-                        if (lane == 0) pt[7] += wall_clock64() - _te;
-#endif
-                        const int pv = coop.readlane(ev_v, f), pa0 = coop.readlane(ev_a0, f), plen = coop.readlane(ev_len, f);
-                        qn_r = coop.readlane(ev_qn, f);
-                        stopq = coop.readlane(ev_err, f) != 0;
-                        hascur = fa + 1 < fend; cv = fv; ca0 = fa + 1; caend = fend;
-                        pf_ok = false;
-                        if (pv >= 0) {
-                            // lane k: the k-th vertex the next pass may scan
-                            const int k0 = hascur ? 1 : 0;                          // the new vertex's slot
-                            const int R = nseg - 1 - fseg;                          // segments of this pass behind the event's: still queued
-                            const int t_nx = lane - k0 - R - 1 + (partial ? 1 : 0);  // the lane that holds this lane's entry of the prefetch
-                            const int tc = t_nx < 0 ? 0 : (t_nx > nl - 1 ? nl - 1 : t_nx);
-                            const int s_v = coop.shfl(nx_v, tc), s_a0 = coop.shfl(nx_a0, tc), s_len = coop.shfl(nx_ok ? nx_a1 - nx_a0 : -1, tc);
-                            int q_v = s_v, q_a0 = s_a0, q_len = lane < SEGMAX && t_nx >= 0 && t_nx < nl ? s_len : -1;
-                            for (int k = 1; k < SEGMAX; k++)
-                                if (lane > k0 && lane <= k0 + R && fseg + (lane - k0) == k) { q_v = L_v[k]; q_a0 = L_a0[k]; q_len = L_len[k]; }
-                            if (lane == k0) { q_v = pv; q_a0 = pa0; q_len = plen; }
-                            if (hascur && lane == 0) { q_v = cv; q_a0 = ca0; q_len = caend - ca0; }
-                            pf_v = q_v; pf_a0 = q_a0; pf_len = q_len; pf_ok = true;
-                        }
-#ifdef SQ_MWM_PROF2
-                        { const long long _n = clock64(); p2_evt += _n - _q0; _q0 = _n; }
-#endif
-                        continue;
-                    }
-                    if (lane == 0) qn = qn_r;
-                    sync();
-                    if (lane == 0) {                            // the sequential body for that neighbour
+                        if (lane == f) { if (becomes) allow_[de >> 1] = 1; assignLabel<FAST>(w, 2, de); }
+                    } else if (lane == 0) {                     // the sequential body for that neighbour
                         const int de1 = SQ_LQ(adj)[fa];
                         const int w1 = head<FAST>(de1);
                         const int bv1 = SQ_LP(inblossom)[fv], bw1 = SQ_LP(inblossom)[w1];

@@ -598,7 +598,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                                      round_kernel ? &pra : nullptr);
             }
             const uint32_t seq = ++*ln.round_seq;
-            hipLaunchKernelGGL(sq_pool_scan_kernel, dim3(1), dim3(1024), 0, st, pio, scan, io, parity, seq);
+            hipLaunchKernelGGL(sq_pool_scan_kernel, dim3(1), dim3(b->inflight > 1 ? 256 : 1024), 0, st, pio, scan, io, parity, seq);
             // (4 waves share a parent's children; on a crowded chip ONE takes them all: most parents have one or two, and a wave
             // that finds nothing to do still takes a slot for a microsecond or two -- 593 k -> 601 k)
             static const int ext_crowd = getenv("SQ_POOL_EXTEND_WAVES") ? std::max(1, std::min(16, atoi(getenv("SQ_POOL_EXTEND_WAVES")))) : 1;

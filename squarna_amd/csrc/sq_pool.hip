@@ -151,6 +151,9 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_choose_kernel(SqDevCtx 
 }
 
 // one block: the children's slots, the jobs' next ranges and pool state, the next round's size for the host
+// (1,024 threads for a batch alone; 256 with batches in flight: a block of sixteen waves waits for a CU with four free slots
+// on every SIMD, and a crowded chip -- one-wave matching blocks that stay for milliseconds -- rarely has one: 184 us per
+// launch on average in the crowded trace of round 4, 5 us alone)
 extern "C" __global__ __launch_bounds__(1024) void sq_pool_scan_kernel(SqPoolIO pio, SqScanArgs a, SqRoundIO io, int parity, uint32_t seq)
 {
     __shared__ int s_part[1024];
@@ -158,14 +161,15 @@ extern "C" __global__ __launch_bounds__(1024) void sq_pool_scan_kernel(SqPoolIO 
     const int tid = threadIdx.x;
     SqPoolHdr *H = pio.hdr;
     const int S = (int)H->S[parity];
-    const int ipt = (S + 1023) / 1024;
+    const int nthr = (int)blockDim.x;
+    const int ipt = (S + nthr - 1) / nthr;
     const int lo = min(tid * ipt, S), hi = min(lo + ipt, S);
     int sum = 0;
     for (int q = lo; q < hi; q++) sum += pio.nchild[q];
     s_part[tid] = sum;
     if (tid == 0) s_active = 0;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {                     // inclusive scan of the per-thread sums
+    for (int d = 1; d < nthr; d <<= 1) {                     // inclusive scan of the per-thread sums
         const int v = tid >= d ? s_part[tid - d] : 0;
         __syncthreads();
         s_part[tid] += v;
@@ -179,11 +183,11 @@ extern "C" __global__ __launch_bounds__(1024) void sq_pool_scan_kernel(SqPoolIO 
         for (int k = 0; k < nc; k++) if (run + k < pio.slots) pio.parent_of[run + k] = q;
         run += nc;
     }
-    const int total = s_part[1023];
+    const int total = s_part[nthr - 1];
     if (tid == 0) pio.child_off[S] = total;
     __syncthreads();
     const bool fits = total <= pio.slots;
-    for (int j = tid; j < pio.njobs; j += 1024) {
+    for (int j = tid; j < pio.njobs; j += nthr) {
         SqPoolJob J = pio.jobs[j];
         if (J.count == 0) continue;                          // the job's pool ran empty in an earlier round
         const int nf = pio.child_off[J.first], nl = pio.child_off[J.first + J.count];
