@@ -468,6 +468,20 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
             pset_maxabs[2 * p + 1] = std::max(pset_maxabs[2 * p + 1], std::fabs(w) * (w > 0 ? 1.4142135623730951 : 100.0));   // SQRNdbnseq.py:333-336
         }
     }
+    // paramsets that pair the same letters give a sequence the same boolean matrix (SQRNdbnseq.py:300-304: letters,
+    // restraints and the minimal loop decide a cell): one bit matrix per (sequence, letter set)
+    std::vector<int> pset_sig(d->npset);
+    for (int p = 0; p < d->npset; p++) {
+        pset_sig[p] = p;
+        for (int q = 0; q < p; q++) {
+            bool same = true;
+            for (int e = 0; e < 32 * 32 && same; e++) same = (d->psets[p].inbps[e] != 0) == (d->psets[q].inbps[e] != 0);
+            if (same) { pset_sig[p] = pset_sig[q]; break; }
+        }
+    }
+    // (not with fp32 score matrices: sq_bits_kernel then derives every job's bits from ITS matrix)
+    const bool no_share = getenv("SQ_NO_SHARED_BITS") != nullptr || b->has_fp32;
+    std::vector<int64_t> shared_bits((size_t)d->nseq * (size_t)std::max(d->npset, 1), -1);
     for (int j = 0; j < d->njobs; j++) {
         SqJob &J = b->jobs[j];
         const int s = d->job_seq[j];
@@ -475,9 +489,17 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         J.ld = ld_of(J.n); J.seq = s; J.pset = d->job_pset[j];
         J.pos_off = d->seq_off[s];
         J.mat64_off = -1; J.has_ext = 0;
-        J.nw = bits_nw(J.n); J.bpitch = bits_pitch(J.n); J.bits_off = mbits; mbits += (int64_t)J.nw * J.bpitch;
+        J.nw = bits_nw(J.n); J.bpitch = bits_pitch(J.n);
         J.rb_off = d->rbp_off[s]; J.nrb = d->rbp_off[s + 1] - d->rbp_off[s];
         const bool ext = d->ext_score && d->ext_score[j];
+        {
+            int64_t &slot = shared_bits[(size_t)s * (size_t)d->npset + (size_t)pset_sig[d->job_pset[j]]];
+            if (!ext && !no_share && slot >= 0) { J.bits_off = slot; J.bits_owner = 0; }      // (a caller's boolean matrix: the job's own)
+            else {
+                J.bits_off = mbits; J.bits_owner = 1; mbits += (int64_t)J.nw * J.bpitch;
+                if (!ext && !no_share) slot = J.bits_off;
+            }
+        }
         const bool term = d->bpp_term && d->bpp_term[j];
         const bool shared = d->mul_shared && d->mul_shared[j];
         const bool mul = (d->mul_score && d->mul_score[j]) || term || shared;

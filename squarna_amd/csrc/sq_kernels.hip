@@ -236,7 +236,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_bits_direct_kernel(SqDevCtx
     __shared__ int16_t s_rch[32], s_cch[256 + 32];
     __shared__ uint32_t s_pm[32];                        // partner mask of every letter under this paramset
     const SqJob jb = c.jobs[blockIdx.y];
-    if (jb.has_ext == 1) return;                        // bool comes from the caller's matrix (sq_bits_kernel)
+    if (jb.has_ext == 1 || !jb.bits_owner) return;      // bool comes from the caller's matrix (sq_bits_kernel) / from an earlier job of the sequence
     const int n = jb.n, bp = jb.bpitch;
     const int ntile = (bp + 255) >> 8;
     const SqPsetDev *ps = c.psets + jb.pset;
@@ -302,7 +302,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_bits_masks_kernel(SqDevCtx 
     __shared__ uint32_t s_present;
     __shared__ uint8_t s_letter[32];
     const SqJob jb = c.jobs[blockIdx.y];
-    if (jb.has_ext == 1) return;                        // bool comes from the caller's matrix (sq_bits_kernel)
+    if (jb.has_ext == 1 || !jb.bits_owner) return;      // bool comes from the caller's matrix (sq_bits_kernel) / from an earlier job of the sequence
     const int n = jb.n, bp = jb.bpitch, nw = jb.nw, mw = nw + 3;
     const SqPsetDev *ps = c.psets + jb.pset;
     uint32_t *bits = c.bits + jb.bits_off;

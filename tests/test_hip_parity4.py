@@ -299,3 +299,29 @@ def test_pool_overflow_keeps_the_stemsets_of_the_device_runalgo():
     exp = O.SQRNdbnseq(s, r, x, None, psets, poollim=1000)
     exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
     _same_fold(got0, exp, ("overflow", 0))
+
+
+def test_shared_bit_matrices_equal_one_matrix_per_job():
+    """Jobs of a sequence whose paramsets pair the same letters read ONE diagonal bit matrix (a-1 built once per record
+    instead of once per paramset); a paramset with another letter set keeps its own.  Packed records byte for byte those
+    of a batch created with SQ_NO_SHARED_BITS, with restraints, reactivities and separators in the records."""
+    from squarna_amd.engine import Batch, Prepared
+    names, psets = conf("nobpp")
+    odd = dict(psets[0], bpweights={"GC": 3.25, "AU": 1.25})           # no GU pairs: another boolean matrix
+    mixed = list(psets) + [odd]
+    raw = _chain_records(90, 977, 8, 180)
+    prepared = [Prepared(s, r, x) for s, r, x in raw]
+    packs = []
+    assert "SQ_NO_SHARED_BITS" not in os.environ
+    for own in (False, True):
+        if own:
+            os.environ["SQ_NO_SHARED_BITS"] = "1"
+        try:
+            with Batch(prepared, [mixed] * len(prepared), max_structs=8192, fp32=False) as b:
+                for pl in (1000, 1):
+                    b.fold(poollim=pl)
+                    buf, off = b.pack_all()
+                    packs.append(bytes(buf[:off[-1]]))
+        finally:
+            os.environ.pop("SQ_NO_SHARED_BITS", None)
+    assert packs[0] == packs[2] and packs[1] == packs[3]
