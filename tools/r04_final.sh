@@ -13,6 +13,10 @@ cp profiles/r04_*_pmc.txt profiles/traffic.json $o/
 python tools/a5000_full.py 512 5000 2>&1 | grep "alignment, steps" > $o/r04_a5000_full.txt
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY --output-format csv -d $o/pmc_bench -- python3 bench.py --steps 2 --warmup 1 --regions 1 --no-cpu --no-stream --no-roofline > $o/pmc_bench.log 2>&1
 python3 tools/pmc_bench_agg.py $o/pmc_bench > $o/r04_bench_wave_cycles.txt
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > $o/r04_gputest.txt
-rm -rf $o/stats $o/s1000 $o/pmc_bench
-tail -2 $o/r04_gputest.txt; cat $o/r04_rounds_probe.txt $o/r04_a5000_full.txt; head -12 $o/r04_bench_wave_cycles.txt
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $o/r04_gputest.txt
+rocprofv3 --kernel-trace --output-format csv -d $o/tr1 -- python3 tools/single_fold.py 6 > $o/single_fold.log 2>&1
+{ grep "^fold" $o/single_fold.log; python tools/trace_all.py $o/tr1 | grep -v "sq_state_kernel\|sq_scan6\|sq_score_kernel\|sq_pool_"; } > $o/r04_single_fold_trace.txt
+python tools/stream_pipe.py 8 12 10 2>&1 | grep "^step" > $o/r04_stream_pipe.txt
+bash tools/mwm_prof.sh 2>&1 | grep "^mwm\|^record" > $o/r04_mwm_phases.txt
+rm -rf $o/stats $o/s1000 $o/pmc_bench $o/tr1
+cat $o/r04_gputest.txt; cat $o/r04_rounds_probe.txt $o/r04_a5000_full.txt; head -12 $o/r04_bench_wave_cycles.txt
