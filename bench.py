@@ -445,10 +445,13 @@ def stream_leg(config, K, R, steps, warmup, device):
                     out.append(Batch(sel, [psets] * len(sel), fp32=False, max_structs=4096 * R))
             return out
 
+        pipe_ms = []
+
         def run_pipelined(nsteps, base):
             nxt = build(base)
             packed_ = 0
             for t in range(nsteps):
+                ts0 = time.perf_counter()
                 cur, box = nxt, {}
                 th = threading.Thread(target=lambda: box.setdefault("b", build(base + t + 1))) if t + 1 < nsteps else None
                 if th:
@@ -462,14 +465,17 @@ def stream_leg(config, K, R, steps, warmup, device):
                     if th:
                         th.join()
                 nxt = box.get("b")
+                pipe_ms.append((time.perf_counter() - ts0) * 1e3)
             return packed_
         run_pipelined(4, 1000)
         torch.cuda.synchronize()
+        del pipe_ms[:]
         t0 = time.perf_counter()
         packed2 = run_pipelined(steps, 2000)
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t0
         stream["pipelined"] = dict(seq_per_s=round(219 * R * K * steps / dt2, 1), ms_per_step=round(dt2 / steps * 1e3, 3), packed_bytes_per_step=packed2,
+                                   per_step_ms=[round(x, 1) for x in pipe_ms],
                                    how="the next step's Batch() calls on a second host thread while this step folds; the first build is inside the time")
     except Exception as e:                                    # (never take the sequential figure down)
         stream["pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -282,7 +282,10 @@ int sq_pinned_get(void **p, size_t bytes)
         }
     }
     // portable: the cache is process-wide, a buffer may be reused by a batch on another device
+    static const bool trace = getenv("SQ_PINNED_TRACE") != nullptr;      // (one line per trip to the driver)
+    const double tm0 = trace ? now_s() : 0;
     const int r = sq_check(hipHostMalloc(p, want, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable), "hipHostMalloc");
+    if (trace) fprintf(stderr, "[sq_pinned] hipHostMalloc %zu bytes: %.2f ms (idle %zu buffers, %zu MB)\n", want, (now_s() - tm0) * 1e3, g_pinned.idle.size(), g_pinned.idle_bytes >> 20);
     if (r) { *p = nullptr; return r; }
     std::lock_guard<std::mutex> lk(g_pinned.mu);
     g_pinned.live[*p] = want;
@@ -317,6 +320,8 @@ void sq_pinned_put(void *p)
             p = nullptr;
         }
     }
+    static const bool trace = getenv("SQ_PINNED_TRACE") != nullptr;
+    if (trace && (!drop.empty() || p)) fprintf(stderr, "[sq_pinned] hipHostFree x %zu\n", drop.size() + (p ? 1 : 0));
     for (void *q : drop) hipHostFree(q);
     if (p) hipHostFree(p);
 }
