@@ -852,7 +852,7 @@ def main():
                    cycles_per_scan_pass=round(e_ms * 1e-3 * CLOCK_GHZ * 1e9 / max(passes, 1)),
                    cycles_how="whole kernel time (its slowest wave = the critical graph) x %.1f GHz / that graph's scan passes "
                               "(a pass scans up to four queue vertices: their neighbour lists share the 64 lanes); includes its "
-                              "lane-0 events, dual updates and stage set-up (~45 %% of the time)" % CLOCK_GHZ,
+                              "events (16 %% of the time), dual steps (9 %%) and stage set-up (5 %%): profiles/r04_mwm_phases.txt" % CLOCK_GHZ,
                    floor_cycles_per_scan_pass=1500,
                    floor_how="4 dependent LDS round trips per pass (the lists' slots -> neighbour -> its blossom's label -> "
                              "the best-edge minimum read back; ~130 cycles each for a lone wave; the queue entries of the next "
