@@ -245,7 +245,10 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     const double *const ps_sdf = c.sdftab + ps->sdf_off;
     const double *const ps_of = ps->oftab;
     const double ub_of = ps->ub_of, ub_lf = ra.bound ? ps->ub_lf : INFINITY;
-    const double st_subopt = st.subopt;
+    // a width-1 pool only ever uses ChooseStems' FIRST element (the highest finalscore, the smallest key among equals): a run
+    // whose bound is below the best finalscore seen so far can neither be it nor tie with it -- the bar is the best itself, not
+    // the suboptimality range below it (which the pools' round kernel needs: its children come from the whole range)
+    const double st_subopt = 1.0;
 
     // ---- the first round's list: exact bpscores, dead runs dropped, ordered by descending bpscore (buckets of 0.5) so that
     // the scoring pass meets the strong candidates first and its bound prunes the rest; later rounds keep the order ----
