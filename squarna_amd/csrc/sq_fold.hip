@@ -568,10 +568,11 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             std::atomic_thread_fence(std::memory_order_acquire);
             return 0;
         };
-        // short sequences on a crowded chip: a round is ONE kernel (sq_pool_round.hip) + the scan kernel
-        const bool crowded_fold = b->inflight > 1 || b->njobs >= 4096;
+        // short sequences: a round is ONE kernel (sq_pool_round.hip) + the scan kernel -- on a crowded chip because wave slots
+        // are what it runs out of, for a batch alone because two launches per round instead of six shorten the greedy loop
+        // (SRtest150: 1.43 -> 1.28 ms, and the loop depends less on how fast the host turns a round around)
         SqPoolRoundArgs pra;
-        bool round_kernel = maxn <= SQ_PR_MAXN && (crowded_fold || sw.pool_round_always) && !sw.no_pool_round;   // (jobs with a dense matrix too: sq_cellrun.h reads their cells there)
+        bool round_kernel = maxn <= SQ_PR_MAXN && !sw.no_pool_round;   // (jobs with a dense matrix too: sq_cellrun.h reads their cells there)
         if (round_kernel) {
             pra.lds_n = maxn; pra.str_cap = 2 * pio.pt + 2; pra.cell_entries = b->cell_entries;
             pra.surv_cap = sw.pool_round_nsurv ? sw.pool_round_nsurv : (maxn <= 96 ? 128 : 256); pra.bound = b->score_bound ? 1 : 0;

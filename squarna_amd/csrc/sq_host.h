@@ -118,7 +118,7 @@ struct SqFoldSwitches {
     bool no_rounds = false;           // SQ_NO_ROUNDS: the launched rounds instead of the persistent round kernel
     bool no_pool = false;             // SQ_NO_POOL: pools booked on the host
     bool no_pool_round = false;       // SQ_NO_POOL_ROUND: state / scan / score / choose / extend kernels instead of sq_pool_round_kernel
-    bool pool_round_always = false;   // SQ_POOL_ROUND_ALWAYS: sq_pool_round_kernel also for a small batch alone
+    bool pool_round_always = false;   // SQ_POOL_ROUND_ALWAYS: (the default since late round 4; the switch is read and ignored)
     int pool_round_nsurv = 0;         // SQ_POOL_ROUND_NSURV: survivors sq_pool_round_kernel keeps in LDS (0: by length)
     int pool_slots = 0;               // SQ_POOL_SLOTS: structure slots the device pools may use (0: max_structs)
     int pool_chunk = 0;               // SQ_POOL_CHUNK: structures per chunk of a generation (0: what the arena holds)
