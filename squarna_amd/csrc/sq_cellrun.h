@@ -27,29 +27,21 @@ __device__ __forceinline__ SqCellEnv sq_cell_setup(const SqDevCtx &c, const SqJo
                                                    uint8_t *l_code, double *s_cell, int tid, int nthr)
 {
     const int n = jb.n;
-    if (tid < 64) {                                       // lmask: bit a set iff letter a has a pair in the paramset
-        uint32_t any8 = 0;
-        if (tid < 32) {
-            const uint32_t *ib = reinterpret_cast<const uint32_t *>(ps->inbps) + tid * 8;
-#pragma unroll
-            for (int q = 0; q < 8; q++) any8 |= ib[q];
-        }
-        const unsigned long long bal = __ballot(any8 != 0);
-        if (tid == 0) T.lmask = (uint32_t)bal;
-    }
-    __syncthreads();
-    const uint32_t lmask = T.lmask;
+    // (the letter mask comes with the paramset -- until late round 4 every block derived it from the 1,024 bytes of the
+    // pairing table first: one more trip to L2 and two barriers per structure and round of the pools' round kernel)
+    const uint32_t lmask = ps->lmask;
     const int K = __popc(lmask) + 1;
     const bool react_tab = !jb.default_reacts && jb.react_levels > 0 && K * jb.react_levels <= 32;   // (the host sizes the table by the same rule)
     const int R = react_tab ? jb.react_levels : 1;
     const int KR = K * R, cstride = KR | 1;
-    if (tid < 32) T.cls[tid] = (lmask >> tid) & 1u ? (uint8_t)__popc(lmask & ((1u << tid) - 1u)) : (uint8_t)(K - 1);
-    if (react_tab)
+    if (react_tab) {
         for (int p = tid; p < n; p += nthr) T.rv[c.ridx[jb.pos_off + p]] = c.reacts[jb.pos_off + p];   // (all writers of a level store the same value)
-    __syncthreads();
+        __syncthreads();
+    }
     for (int p = tid; p < n; p += nthr) {
         const uint8_t code = c.codes[jb.pos_off + p];
-        const int cl = T.cls[code & 31];
+        const uint32_t cb = code & 31u;
+        const int cl = (lmask >> cb) & 1u ? __popc(lmask & ((1u << cb) - 1u)) : K - 1;
         if (l_code) l_code[p] = code;
         l_ci[p] = (uint8_t)(react_tab ? cl * R + c.ridx[jb.pos_off + p] : cl);
     }

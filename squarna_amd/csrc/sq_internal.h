@@ -45,7 +45,7 @@ struct SqPsetDev {
     double oftab[SQ_MAXLEVELS + 1];   // (1/(1+k))**orderpenalty   (SQRNdbnseq.py:729)
     int32_t bw_integral;              // bracketweight is an integer -> stemdist index into sdftab
     int32_t sdf_off, sdf_len;         // (1/(1+d))**distcoef table   (SQRNdbnseq.py:726)
-    int32_t pad;
+    uint32_t lmask;                   // bit a: letter code a has a pair in the paramset (the classes of sq_cellrun.h)
     // stemscore ** 1.7 (SQRNalgos.py:101,122: the Edmonds / Hungarian edge weights) from the host libm, for paramsets whose
     // pair weights are multiples of 2^-q: a stem score is then k 2^-q exactly and SqDevCtx::powtab[pow_off + k] its power
     // (only valid for jobs without reactivity factors or dense matrices).  pow_len == 0: no table (host-built edges)
