@@ -231,15 +231,23 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
         }
     }
     __syncthreads();
-    for (int h = 1; h < n; h++) {                                       // :65
-        for (int i = tid; i < n - h; i += nthr) {
-            const int j = i + h;
+    // The DP by COLUMNS (round 4; the reference and the kernel until then: by diagonals, :65-83).  Cell (i, j) reads
+    // D[i, k-1] (k <= j - 2), D[k+1, j-1] and D[i, j-1]: columns before j only, so the columns can be taken one after the
+    // other with all rows of a column at once -- the same values in any such order.  What the order buys: the list of
+    // column j -- the k that can pair with j, :73-74 -- is the same for every row (uniform loads, fetched while the column
+    // before is computed), D[k+1, j-1] is one value per list entry, and with D and K stored column-major the rows' reads of
+    // D[., k-1] and D[., j-1] are consecutive doubles.  By diagonals every cell chased column list -> k -> two cells of D
+    // through L2, three dependent trips per diagonal; now one per column.
+    // Dc[j * n + i] = D[i, j], Kc[j * n + i] = K[i, j].
+    double *const Dc = D;
+    int32_t *const Kc = K;
+    for (int j = 1; j < n; j++) {
+        const int x0 = col_off[j], x1 = col_off[j + 1];
+        const double *const dprevcol = Dc + (size_t)(j - 1) * n;
+        for (int i = tid; i < j; i += nthr) {
             int bestk = -1; double best = 1e9;                          // :70
-            // k in range(i, j - 1) with (k, j) in SCORES (:73-74), ascending; four list entries per trip: their (independent)
-            // loads are issued together -- a cell waited for one L2 round trip per entry, and a diagonal lasts as long as
-            // its longest cell -- and compared in list order (first best k, :77)
-            const int x1 = col_off[j + 1];
-            for (int x = col_off[j]; x < x1; x += 4) {
+            // k in range(i, j - 1) with (k, j) in SCORES, ascending (first best k, :77); four list entries per trip
+            for (int x = x0; x < x1; x += 4) {
                 int kk[4]; double d1[4], d2[4], cw[4]; bool ok[4];
 #pragma unroll
                 for (int t = 0; t < 4; t++) kk[t] = x + t < x1 ? ck[x + t] : 0x7fffffff;
@@ -249,8 +257,8 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
                     d1[t] = 0.0; d2[t] = 0.0; cw[t] = 0.0;
                     if (ok[t]) {
                         // D[i, k-1] with k == i is numpy's D[i, -1] = D[i, n-1], which no cell has written yet at this point: 0 (:76)
-                        if (kk[t] > i) d1[t] = D[(size_t)i * n + (kk[t] - 1)];
-                        d2[t] = D[(size_t)(kk[t] + 1) * n + (j - 1)];
+                        if (kk[t] > i) d1[t] = Dc[(size_t)(kk[t] - 1) * n + i];
+                        d2[t] = dprevcol[kk[t] + 1];
                         cw[t] = cs[x + t];
                     }
                 }
@@ -262,10 +270,10 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
                     }
                 if (kk[3] >= j - 1) break;
             }
-            const double dprev = D[(size_t)i * n + (j - 1)];
+            const double dprev = dprevcol[i];                           // D[i, j-1] (i == j - 1: the diagonal, 0)
             const bool take = best <= dprev;                            // :80-83
-            K[(size_t)i * n + j] = take ? bestk : -2;
-            D[(size_t)i * n + j] = take ? best : dprev;
+            Kc[(size_t)j * n + i] = take ? bestk : -2;
+            Dc[(size_t)j * n + i] = take ? best : dprev;
         }
         __syncthreads();
     }
@@ -288,7 +296,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
                 auto push = [&](int a, int b) {
                     if (!inq[(size_t)a * n + b]) { inq[(size_t)a * n + b] = 1; nxt[2 * nn] = a; nxt[2 * nn + 1] = b; nn++; }
                 };
-                const int kk = K[(size_t)i * n + j];
+                const int kk = Kc[(size_t)j * n + i];
                 if (kk != -2) {
                     const int k = kk;
                     if (((k - 1) - i > minloop) || ((k - 1) - i > 0 && anysep(i + 1, k - 1))) push(i, k - 1);
