@@ -104,60 +104,75 @@ extern "C" __global__ __launch_bounds__(64) void sq_lsap_kernel(const SqMatchJob
     }
     __syncthreads();
 
-    __shared__ int s_i, s_sink, s_nrem;
-    __shared__ double s_minval;
+    // The state of a path -- the row in hand, the columns left, the sink, the distance -- lives in registers: every lane
+    // takes lane 0's decision from the same broadcast reads (until late round 4 it went through four words of LDS and two
+    // barriers per step).  The scan of a step takes up to three columns per lane with the loads of one dependency level
+    // issued together (remaining -> mask word, v, shortest path, owner -> edge id -> weight).
     for (int cur = 0; cur < n; cur++) {
         // ---- augmenting_path(cur)
         for (int q = lane; q < n; q += 64) { remaining[q] = n - q - 1; SR[q] = 0; SC[q] = 0; spc[q] = INFINITY; }
-        if (lane == 0) { s_i = cur; s_sink = -1; s_nrem = n; s_minval = 0.0; }
+        int i = cur, sink = -1, nrem = n;
+        double minval = 0.0;
         __syncthreads();
-        while (s_sink == -1) {
-            const int i = s_i, nrem = s_nrem;
-            const double minval = s_minval, ui = u[i];
+        while (sink == -1) {
+            const double ui = u[i];
+            const int rs_i = mat_lds ? (int)rowstart[i] : 0;
             double lowest = INFINITY;
             int first = -1, lastun = -1;
-            for (int it = lane; it < nrem; it += 64) {
-                const int j = remaining[it];
-                double cij;
-                if (mat_lds) {
-                    const uint32_t wd = mask[i * nw + (j >> 5)];
-                    cij = 0.0;
-                    if ((wd >> (j & 31)) & 1u)
-                        cij = -wts[cids[(int)rowstart[i] + (int)pre[i * nw + (j >> 5)] + __popc(wd & ((1u << (j & 31)) - 1u))]];
+            for (int it0 = 0; it0 < nrem; it0 += 192) {
+                int jj[3]; bool have[3];
+#pragma unroll
+                for (int t = 0; t < 3; t++) { const int it = it0 + 64 * t + lane; have[t] = it < nrem; jj[t] = remaining[have[t] ? it : 0]; }
+                uint32_t wd[3]; int pw[3], r4[3]; double vj[3], spj[3], cij[3];
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const int j = jj[t];
+                    vj[t] = v[j]; spj[t] = spc[j]; r4[t] = row4col[j];
+                    if (mat_lds) { wd[t] = mask[i * nw + (j >> 5)]; pw[t] = (int)pre[i * nw + (j >> 5)]; cij[t] = 0.0; }
+                    else { wd[t] = 0u; pw[t] = 0; cij[t] = cost[(size_t)i * n + j]; }
                 }
-                else cij = cost[(size_t)i * n + j];
-                const double r = minval + cij - ui - v[j];
-                double sp = spc[j];
-                if (r < sp) { path[j] = i; spc[j] = r; sp = r; }
-                const bool un = row4col[j] == -1;
-                if (sp < lowest) { lowest = sp; first = it; lastun = un ? it : -1; }
-                else if (sp == lowest && un) lastun = it;           // sequential rule: later unassigned ties win
+                if (mat_lds) {
+                    int cid[3];
+#pragma unroll
+                    for (int t = 0; t < 3; t++) {
+                        const int j = jj[t];
+                        const bool nz = (wd[t] >> (j & 31)) & 1u;
+                        cid[t] = nz ? (int)cids[rs_i + pw[t] + __popc(wd[t] & ((1u << (j & 31)) - 1u))] : -1;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; t++) cij[t] = cid[t] >= 0 ? -wts[cid[t]] : 0.0;
+                }
+#pragma unroll
+                for (int t = 0; t < 3; t++) {                       // (a lane's columns in scan order)
+                    if (!have[t]) continue;
+                    const int it = it0 + 64 * t + lane, j = jj[t];
+                    const double r = minval + cij[t] - ui - vj[t];
+                    double sp = spj[t];
+                    if (r < sp) { path[j] = i; spc[j] = r; sp = r; }
+                    const bool un = r4[t] == -1;
+                    if (sp < lowest) { lowest = sp; first = it; lastun = un ? it : -1; }
+                    else if (sp == lowest && un) lastun = it;       // sequential rule: later unassigned ties win
+                }
             }
             // wave combine == the sequential scan over it = 0..nrem-1
-            double m = lowest;
-            for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off));
-            int f = (lowest == m && first >= 0) ? first : 0x7fffffff;
-            int lu = (lowest == m) ? lastun : -1;
-            for (int off = 32; off > 0; off >>= 1) { f = min(f, __shfl_xor(f, off)); lu = max(lu, __shfl_xor(lu, off)); }
-            if (lane == 0) {
-                SR[i] = 1;
-                s_minval = m;
-                if (m == INFINITY) { s_sink = -2; }                 // infeasible (cannot happen: finite costs)
-                else {
-                    const int index = lu >= 0 ? lu : f;
-                    const int j = remaining[index];
-                    if (row4col[j] == -1) s_sink = j; else s_i = row4col[j];
-                    SC[j] = 1;
-                    remaining[index] = remaining[nrem - 1];
-                    s_nrem = nrem - 1;
-                }
-            }
+            // (DPP row shifts / broadcasts as in the blossom kernel: the three butterfly reductions over the LDS crossbar they
+            // replace -- 30 ds_bpermute per step of the path -- were the longest part of a step)
+            const double m = SqCoopWave::wave_min_f64(lowest);
+            const int f = SqCoopWave::wave_min_i32((lowest == m && first >= 0) ? first : 0x7fffffff);
+            const int lu = -SqCoopWave::wave_min_i32(-((lowest == m) ? lastun : -1));
+            minval = m;
+            if (m == INFINITY) { if (lane == 0) SR[i] = 1; sink = -2; break; }   // infeasible (cannot happen: finite costs)
+            const int index = lu >= 0 ? lu : f;
+            const int j = remaining[index], lastj = remaining[nrem - 1];
+            const int owner = row4col[j];
+            __syncthreads();                                        // (every lane has read what lane 0 overwrites)
+            if (lane == 0) { SR[i] = 1; SC[j] = 1; remaining[index] = lastj; }
+            nrem--;
+            if (owner == -1) sink = j; else i = owner;
             __syncthreads();
         }
-        if (s_sink < 0) break;
+        if (sink < 0) break;
         // ---- dual update
-        const double minval = s_minval;
-        __syncthreads();
         if (lane == 0) u[cur] += minval;
         for (int q = lane; q < n; q += 64) {
             if (SR[q] && q != cur) u[q] += minval - spc[col4row[q]];
@@ -166,12 +181,12 @@ extern "C" __global__ __launch_bounds__(64) void sq_lsap_kernel(const SqMatchJob
         __syncthreads();
         // ---- augment
         if (lane == 0) {
-            int j = s_sink;
+            int j = sink;
             for (;;) {
-                const int i = path[j];
-                row4col[j] = i;
-                const int t = col4row[i]; col4row[i] = j; j = t;
-                if (i == cur) break;
+                const int i2 = path[j];
+                row4col[j] = i2;
+                const int t = col4row[i2]; col4row[i2] = j; j = t;
+                if (i2 == cur) break;
             }
         }
         __syncthreads();
