@@ -109,6 +109,55 @@ struct SqPoolIO {
 
 #include "sq_hostflag.h"
 
+// Wave-wide minima / maxima with DPP row shifts and row broadcasts (the gfx9 scan sequence row_shr 1, 2, 4, 8, row_bcast 15
+// and 31 leaves the reduction of all 64 lanes in lane 63): VALU only.  A butterfly of __shfl_xor costs six trips over the
+// LDS crossbar per 32-bit word (sq_blossom.h has the same functions for its own use and the measurements).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double sq_dpp_f64(double ident, double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sq_wave_min_f64(double v)      // every lane gets the minimum (no NaNs)
+{
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    double o;
+    o = sq_dpp_f64<0x111, 0xf>(inf, v); v = __builtin_fmin(o, v);
+    o = sq_dpp_f64<0x112, 0xf>(inf, v); v = __builtin_fmin(o, v);
+    o = sq_dpp_f64<0x114, 0xf>(inf, v); v = __builtin_fmin(o, v);
+    o = sq_dpp_f64<0x118, 0xf>(inf, v); v = __builtin_fmin(o, v);
+    o = sq_dpp_f64<0x142, 0xa>(inf, v); v = __builtin_fmin(o, v);
+    o = sq_dpp_f64<0x143, 0xc>(inf, v); v = __builtin_fmin(o, v);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sq_wave_max_f64(double v)      // every lane gets the maximum (no NaNs; the sign of a zero as fmax leaves it)
+{
+    const double ninf = __longlong_as_double((long long)0xFFF0000000000000ull);
+    double o;
+    o = sq_dpp_f64<0x111, 0xf>(ninf, v); v = __builtin_fmax(o, v);
+    o = sq_dpp_f64<0x112, 0xf>(ninf, v); v = __builtin_fmax(o, v);
+    o = sq_dpp_f64<0x114, 0xf>(ninf, v); v = __builtin_fmax(o, v);
+    o = sq_dpp_f64<0x118, 0xf>(ninf, v); v = __builtin_fmax(o, v);
+    o = sq_dpp_f64<0x142, 0xa>(ninf, v); v = __builtin_fmax(o, v);
+    o = sq_dpp_f64<0x143, 0xc>(ninf, v); v = __builtin_fmax(o, v);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int sq_wave_min_i32(int v)
+{
+    const int big = 0x7fffffff;
+    int o;
+    o = __builtin_amdgcn_update_dpp(big, v, 0x111, 0xf, 0xf, false); v = o < v ? o : v;
+    o = __builtin_amdgcn_update_dpp(big, v, 0x112, 0xf, 0xf, false); v = o < v ? o : v;
+    o = __builtin_amdgcn_update_dpp(big, v, 0x114, 0xf, 0xf, false); v = o < v ? o : v;
+    o = __builtin_amdgcn_update_dpp(big, v, 0x118, 0xf, 0xf, false); v = o < v ? o : v;
+    o = __builtin_amdgcn_update_dpp(big, v, 0x142, 0xa, 0xf, false); v = o < v ? o : v;
+    o = __builtin_amdgcn_update_dpp(big, v, 0x143, 0xc, 0xf, false); v = o < v ? o : v;
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // LDS operations of one wave execute in program order; this keeps the compiler from moving them across the point (the
 // barrier of code in which ONE wave hands data to its own lanes through LDS)
 __device__ __forceinline__ void sq_wave_lds_fence()

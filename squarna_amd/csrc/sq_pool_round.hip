@@ -315,8 +315,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c
             if (!(fin >= minfin)) fin = -INFINITY;                               // :751
         }
         if (have) sv.set_fin(idx, fin);
-        double wb = fin;
-        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(wb, off); wb = o > wb ? o : wb; }
+        const double wb = sq_wave_max_f64(fin);
         if (wb > -INFINITY && (!anybest || wb > best)) { anybest = true; best = wb; }
     }
     __threadfence_block();

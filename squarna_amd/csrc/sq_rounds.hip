@@ -487,8 +487,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                     else if (fin > sfin) sfin = fin;
                 }
                 if (__ballot(ok) != 0ull) {
-                    double wb = ok ? fin : -INFINITY;
-                    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(wb, off); wb = o > wb ? o : wb; }
+                    const double wb = sq_wave_max_f64(ok ? fin : -INFINITY);
                     if (lane == 0) atomicMax(&s_best, sq_ord(wb));
                 }
             }
@@ -499,14 +498,23 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         _cnt[0] += nl;
 #endif
         // ---- ChooseStems' first element over the block ----
-        for (int off = 32; off > 0; off >>= 1) {
-            const double of = __shfl_xor(bfin, off), ob = __shfl_xor(bbps, off);
-            const uint32_t ok2 = (uint32_t)__shfl_xor((int)bkey, off), ol = (uint32_t)__shfl_xor((int)blen, off);
-            const int oa = __shfl_xor(bany, off);
-            const double os = __shfl_xor(sfin, off);
-            if (os > sfin) sfin = os;
-            if (oa && (!bany || of > bfin || (of == bfin && ok2 < bkey))) { if (bany && bfin > sfin) sfin = bfin; bany = 1; bfin = of; bkey = ok2; blen = ol; bbps = ob; }
-            else if (oa && of > sfin) sfin = of;
+        {
+            // the wave's best: the highest finalscore, the smallest key among equals (one lane: keys are distinct); the best of
+            // all the OTHER runs beside it (DPP reductions: the butterfly of six values they replace was 54 trips over the LDS
+            // crossbar per round)
+            const double wmax = sq_wave_max_f64(bany ? bfin : -INFINITY);
+            const bool cand = bany && bfin == wmax;
+            const int kmin = sq_wave_min_i32(cand ? (int)bkey : 0x7fffffff);       // (keys < 2^30: SQ_ROUNDS_MAXN)
+            const bool win = cand && (int)bkey == kmin;
+            const unsigned long long wm = __ballot(win);
+            const double sec = sq_wave_max_f64(bany && !win && bfin > sfin ? bfin : sfin);
+            if (wm) {
+                const int wl = __ffsll((long long)wm) - 1;
+                blen = (uint32_t)__builtin_amdgcn_readlane((int)blen, wl);
+                bbps = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bbps), wl), __builtin_amdgcn_readlane(__double2loint(bbps), wl));
+                bany = 1; bfin = wmax; bkey = (uint32_t)kmin;
+            } else bany = 0;
+            sfin = sec;
         }
         if (lane == 0) { s_wany[wv] = bany; s_wfin[wv] = bfin; s_wbps[wv] = bbps; s_wkey[wv] = bkey; s_wlen[wv] = blen; s_wsec[wv] = sfin; }
         __syncthreads();
