@@ -119,11 +119,12 @@ extern "C" __global__ __launch_bounds__(256) void sq_tail_scatter_kernel(SqTailI
 // ---- ScoreStruct (:861-899) of one stem list by one wave -----------------------------------------------------------
 // stems: get(q) for q < T, in the list's own order (the sum over stems runs in that order).  s_bits: the wave's LDS
 // bitmap of paired positions (only touched when the reactivities are not all 0.5).  Every lane returns the same values.
+// codes: the sequence's letter codes (the ranking kernel stages them in LDS once per sequence: a stem's cells were two
+// dependent byte loads from global memory each); nsep: its separators (counted once per sequence).
 template <class Get>
 __device__ __forceinline__ void sq_score_struct_wave(const SqDevCtx &c, const SqTailIO &t, const SqJob &jb, Get get, int T, uint32_t *s_bits,
-                                                     int lane, double out[3], uint32_t *fallback)
+                                                     int lane, double out[3], uint32_t *fallback, const uint8_t *codes, int nsep)
 {
-    const uint8_t *codes = c.codes + jb.pos_off;
     const int n = jb.n;
     const bool marks = !jb.default_reacts;
     if (marks) {
@@ -155,13 +156,13 @@ __device__ __forceinline__ void sq_score_struct_wave(const SqDevCtx &c, const Sq
             }
         }
         const int cnt = min(64, T - q0);
-        for (int u = 0; u < cnt; u++) thescore += __shfl(f, u, 64);    // the reference's order of additions
+        const int flo = __double2loint(f), fhi = __double2hiint(f);
+        for (int u = 0; u < cnt; u++)                                  // the reference's order of additions (u is uniform: v_readlane)
+            thescore += __hiloint2double(__builtin_amdgcn_readlane(fhi, u), __builtin_amdgcn_readlane(flo, u));
     }
     double reactscore;
     if (!marks) {
-        int sep = 0;
-        for (int i = lane; i < n; i += 64) sep += (codes[i] == SQ_CODE_SEP1 || codes[i] == SQ_CODE_SEP2) ? 1 : 0;
-        sep = sq_wave_sum32(sep);
+        const int sep = nsep;
         // every term is exactly 0.5: the sum is 0.5 (n - sep) whatever the order
         reactscore = 1 - (0.5 * (double)(n - sep)) / (double)(n - sep);
     } else {
@@ -219,6 +220,8 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS_WIDE) void sq_tail_rank_
     const uint32_t nthr = blockDim.x, nwv = nthr >> 6;                  // (the entry-per-wave passes b and e are as fast as the block has waves)
     double *const s_key = reinterpret_cast<double *>(s_bits_dyn + ((nwv * (uint32_t)bitwords + 1u) & ~1u));   // [keycap][3], in rankby order
     uint8_t *const s_pri = reinterpret_cast<uint8_t *>(s_key + 3 * (size_t)keycap);                          // [keycap]
+    uint8_t *const s_codes = s_pri + (((size_t)keycap + 7) & ~(size_t)7);                                    // [32 x bitwords] the sequence's letter codes
+    __shared__ int s_nsep;
     SqTailSeq &S = t.seqs[s];
     const uint32_t first = S.first, M = S.count;
     const int j0 = t.seq_job0[s], j1 = t.seq_job0[s + 1];
@@ -228,6 +231,18 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS_WIDE) void sq_tail_rank_
         if (tid == 0) { *t.fallback = 1; S.D = 0; S.nshow = 0; S.nprf = 0; S.rec_bytes = 0; S.txt_bytes = 0; S.evals = 0; }
     };
     if (M > SQ_TAIL_MAXM || n > 32 * bitwords) { bail(); return; }
+    if (tid == 0) s_nsep = 0;
+    __syncthreads();
+    {
+        int sep = 0;
+        for (int p = tid; p < n; p += nthr) {
+            const uint8_t cd = c.codes[jb.pos_off + p];
+            s_codes[p] = cd;
+            sep += (cd == SQ_CODE_SEP1 || cd == SQ_CODE_SEP2) ? 1 : 0;
+        }
+        if (sep) atomicAdd(&s_nsep, sep);
+    }
+    __syncthreads();
 #ifdef SQ_TAIL_PROF
     long long _tp[8];
 #endif
@@ -395,7 +410,7 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS_WIDE) void sq_tail_rank_
         const uint32_t x = t.dlist[first + k];
         const SqPoolFin F = t.fin[t.ord[first + x]];
         double sc[3];
-        sq_score_struct_wave(c, t, jb, [&](int q) { return sq_fin_stem(t, F, q); }, F.nstems, s_bits_dyn + (size_t)wave * bitwords, lane, sc, t.fallback);
+        sq_score_struct_wave(c, t, jb, [&](int q) { return sq_fin_stem(t, F, q); }, F.nstems, s_bits_dyn + (size_t)wave * bitwords, lane, sc, t.fallback, s_codes, s_nsep);
         if (lane == 0) { t.scores[3 * (size_t)(first + x)] = sc[0]; t.scores[3 * (size_t)(first + x) + 1] = sc[1]; t.scores[3 * (size_t)(first + x) + 2] = sc[2]; }
     }
     __threadfence_block();
@@ -526,7 +541,7 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS_WIDE) void sq_tail_rank_
                 }
                 return out;
             };
-            sq_score_struct_wave(c, t, jb, ref_stem, nst, s_bits_dyn, lane, ref_sc, t.fallback);
+            sq_score_struct_wave(c, t, jb, ref_stem, nst, s_bits_dyn, lane, ref_sc, t.fallback, s_codes, s_nsep);
         }
         if (lane == 0) {
             double *met = t.scores + 3 * (size_t)t.fin_cap + 16 * (size_t)s;   // per-sequence metrics behind the entry scores
@@ -863,7 +878,7 @@ int sq_tail_device(sq_batch *b, const sq_fold_opts &o, const int32_t *ref_off, c
         const bool wide = !(b->inflight > 1 || b->njobs >= 4096) && b->njobs > b->nseq;
         const int thr = wide ? SQ_TAIL_THREADS_WIDE : SQ_TAIL_THREADS;
         const int keycap = wide ? 1024 : 256;                    // rank keys staged in LDS (25 bytes each; more structures: global path)
-        const size_t lds = ((((size_t)(thr / 64) * bitwords + 1) & ~(size_t)1) * 4) + (size_t)keycap * 25 + 8;
+        const size_t lds = ((((size_t)(thr / 64) * bitwords + 1) & ~(size_t)1) * 4) + (size_t)keycap * 24 + (((size_t)keycap + 7) & ~(size_t)7) + (size_t)32 * bitwords + 16;   // + the letter codes
         if (lds > 160 * 1024) return 1;                          // (the host tail takes such a batch)
         if (lds > 64 * 1024) sq_max_dynamic_lds((const void *)sq_tail_rank_kernel, 160 * 1024);
         hipLaunchKernelGGL(sq_tail_rank_kernel, dim3(b->nseq), dim3(thr), lds, st, b->ctx, t, bitwords, keycap);
