@@ -774,12 +774,15 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
         const int maxn_lds = (std::min(b->maxn, SQ_ALGO_MAXN) + 7) & ~7;   // (the device RunAlgo only takes batches up to SQ_ALGO_MAXN nt)
         SqAlgoStatPtrs zs{{nullptr, nullptr, nullptr}};
         for (size_t q = 0; q < pa->items.size() && q < 3; q++) zs.p[q] = (SqAlgoStat *)(regions[q] + cv[q].o_stat);
-        // the stem lists in LDS when the longest of the launch fits (a thread holds four stems of the ranking pass: 1,024)
+        // the stem lists in LDS when the longest of the launch fits
         int nokcap = 0;
         for (int s2 = 0; s2 < S; s2++) nokcap = std::max(nokcap, (int)pa->h_sizes[s2].nok);
         nokcap = (nokcap + 63) & ~63;
         if (nokcap > 1024 || sq_algo_edges_lds(maxn_lds, nokcap) > 48 * 1024 || b->sw.no_edges_lds) nokcap = 0;
-        hipLaunchKernelGGL(sq_algo_edges_kernel, dim3(S), dim3(256), sq_algo_edges_lds(maxn_lds, nokcap), st, b->ctx, b->lane_full.d_structs,
+        // (one wave per job on a crowded chip: the work of a job is a few hundred stems behind a handful of trips to L2, and
+        // three waves that mostly wait held three wave slots -- sizes + edges were 7 % of a crowded step's wave cycles)
+        const bool crowded_k = b->inflight > 1 || b->njobs >= 4096;
+        hipLaunchKernelGGL(sq_algo_edges_kernel, dim3(S), dim3(crowded_k ? 64 : 256), sq_algo_edges_lds(maxn_lds, nokcap), st, b->ctx, b->lane_full.d_structs,
                            [&] { SqScanArgs a = b->scan; a.ctr = b->lane_full.d_ctr; return a; }(), round_aj, maxn_lds, zs, nokcap);
     }
     HIPCK(hipGetLastError());

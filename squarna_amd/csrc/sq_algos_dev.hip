@@ -32,10 +32,10 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_sizes_kernel(SqDevCtx 
     __shared__ int s_edges, s_nv, s_rawbase;
     const SqStruct st = structs[blockIdx.x];
     const SqJob jb = c.jobs[st.job];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = (int)blockDim.x;   // (256 threads for a batch alone, one wave per job on a crowded chip)
     const uint32_t nok = a.ok_cnt[st.slot];
     const SqOk *oks = sq_oks(a, st, jb.cand_cap);
-    for (int w = tid; w < (jb.n + 31) / 32; w += 256) s_seen[w] = 0u;
+    for (int w = tid; w < (jb.n + 31) / 32; w += nthr) s_seen[w] = 0u;
     if (tid == 0) {
         s_edges = 0; s_nv = 0;
         int rb = -1;
@@ -48,7 +48,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_sizes_kernel(SqDevCtx 
     __syncthreads();
     const int rawbase = s_rawbase;
     int e = 0;
-    for (uint32_t q = tid; q < nok; q += 256) {
+    for (uint32_t q = tid; q < nok; q += nthr) {
         const SqOk cd = oks[q];
         if (rawbase >= 0) raw.vals[rawbase + q] = cd.bps;
         const int s = (int)(cd.key >> 16), i0 = (int)(cd.key & 0xFFFFu), j0 = s - i0;
@@ -61,7 +61,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_sizes_kernel(SqDevCtx 
     atomicAdd(&s_edges, e);
     __syncthreads();
     int nv = 0;
-    for (int w = tid; w < (jb.n + 31) / 32; w += 256) nv += __popc(s_seen[w]);
+    for (int w = tid; w < (jb.n + 31) / 32; w += nthr) nv += __popc(s_seen[w]);
     atomicAdd(&s_nv, nv);
     __syncthreads();
     if (tid == 0) sizes[blockIdx.x] = SqAlgoSize{s_edges, s_nv, (int32_t)nok, rawbase};
@@ -79,10 +79,10 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_sizes_kernel(SqDevCtx 
 // exclusive prefix sum of v[0 .. cnt) in place by the block (256 threads); returns the total to every thread
 __device__ __forceinline__ uint32_t sq_block_excl_scan(uint32_t *v, int cnt, uint32_t *s_wsum, uint32_t *s_run, int tid)
 {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6, nthr = (int)blockDim.x, nwv = nthr >> 6;
     if (tid == 0) *s_run = 0;
     __syncthreads();
-    for (int x0 = 0; x0 < cnt; x0 += 256) {
+    for (int x0 = 0; x0 < cnt; x0 += nthr) {
         const int x = x0 + tid;
         const uint32_t mine = x < cnt ? v[x] : 0u;
         uint32_t inc = mine;
@@ -93,7 +93,7 @@ __device__ __forceinline__ uint32_t sq_block_excl_scan(uint32_t *v, int cnt, uin
         for (int w = 0; w < wave; w++) before += s_wsum[w];
         if (x < cnt) v[x] = before + inc - mine;
         __syncthreads();
-        if (tid == 0) *s_run += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        if (tid == 0) { uint32_t a = 0; for (int w = 0; w < nwv; w++) a += s_wsum[w]; *s_run += a; }
         __syncthreads();
     }
     return *s_run;
@@ -114,25 +114,26 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx 
     const SqJob jb = c.jobs[st.job];
     const SqAlgoJob aj = jobs[blockIdx.x];
     const SqPsetDev *ps = c.psets + jb.pset;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = jb.n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = jb.n, nthr = (int)blockDim.x, nwv = nthr >> 6;   // (256 threads, or one wave on a crowded chip)
     const uint32_t nok = a.ok_cnt[st.slot];
     const SqOk *oks = sq_oks(a, st, jb.cand_cap);
     uint32_t *sidx = reinterpret_cast<uint32_t *>(sq_keys(a, st));
     uint32_t *eoff = sidx + nok;
     const bool fast = nokcap > 0 && nok <= (uint32_t)nokcap;
     // LDS lists of the fast form, behind the per-position arrays: [diagonal starts 2 maxn + 2][diagonal fills 2 maxn + 2]
-    // [keys][lengths -> edge offsets][bucket order][sorted order]
+    // [keys][edge offsets][lengths][sorted order][bucket order]
     uint32_t *const s_dstart = reinterpret_cast<uint32_t *>(sq_edges_dyn + (((size_t)6 * maxn_lds + 15) & ~(size_t)15));
     uint32_t *const s_dfill = s_dstart + 2 * maxn_lds + 2;
     uint32_t *const s_key = s_dfill + 2 * maxn_lds + 2;
     uint32_t *const s_eoff = s_key + nokcap;
     uint32_t *const s_tmp = s_eoff + nokcap;
     uint32_t *const s_sidx = s_tmp + nokcap;
+    uint32_t *const s_bord = s_sidx + nokcap;
     if (fast) {
         const int nd = 2 * n + 1;                                       // diagonals s = i + j < 2 n
-        for (int d = tid; d <= nd; d += 256) { s_dstart[d] = 0u; s_dfill[d] = 0u; }
+        for (int d = tid; d <= nd; d += nthr) { s_dstart[d] = 0u; s_dfill[d] = 0u; }
         __syncthreads();
-        for (uint32_t x = tid; x < nok; x += 256) {
+        for (uint32_t x = tid; x < nok; x += nthr) {
             const SqOk cd = oks[x];
             s_key[x] = cd.key; s_tmp[x] = cd.len;                       // (lengths in emission order follow below)
             atomicAdd(&s_dstart[cd.key >> 16], 1u);
@@ -140,30 +141,26 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx 
         __syncthreads();
         sq_block_excl_scan(s_dstart, nd, s_wsum, &s_run, tid);
         // the stems of a diagonal in any order, then every stem's place among them: key ascending
-        for (uint32_t x = tid; x < nok; x += 256) {
+        for (uint32_t x = tid; x < nok; x += nthr) {
             const uint32_t d = s_key[x] >> 16;
-            s_sidx[s_dstart[d] + atomicAdd(&s_dfill[d], 1u)] = x;      // (s_sidx: bucket order for now)
+            s_bord[s_dstart[d] + atomicAdd(&s_dfill[d], 1u)] = x;      // (the stems of a diagonal, in any order)
         }
         __syncthreads();
-        uint32_t myx[4], myr[4];                                        // (a thread's stems of this pass: nokcap <= 1,024)
-        int nm = 0;
-        for (uint32_t p = tid; p < nok; p += 256) {
-            const uint32_t x = s_sidx[p], k = s_key[x], d = k >> 16;
+        for (uint32_t p = tid; p < nok; p += nthr) {
+            const uint32_t x = s_bord[p], k = s_key[x], d = k >> 16;
             const uint32_t lo = s_dstart[d], hi = lo + s_dfill[d];
             uint32_t r = lo;
-            for (uint32_t q = lo; q < hi; q++) r += s_key[s_sidx[q]] < k ? 1u : 0u;
-            myx[nm] = x; myr[nm] = r; nm++;
+            for (uint32_t q = lo; q < hi; q++) r += s_key[s_bord[q]] < k ? 1u : 0u;
+            s_sidx[r] = x; sidx[r] = x;
         }
         __syncthreads();
-        for (int q = 0; q < nm; q++) { s_sidx[myr[q]] = myx[q]; sidx[myr[q]] = myx[q]; }
-        __syncthreads();
-        for (uint32_t x = tid; x < nok; x += 256) s_eoff[x] = s_tmp[s_sidx[x]];   // lengths in emission order
+        for (uint32_t x = tid; x < nok; x += nthr) s_eoff[x] = s_tmp[s_sidx[x]];   // lengths in emission order
         __syncthreads();
         sq_block_excl_scan(s_eoff, (int)nok, s_wsum, &s_run, tid);
-        for (uint32_t x = tid; x < nok; x += 256) eoff[x] = s_eoff[x];
+        for (uint32_t x = tid; x < nok; x += nthr) eoff[x] = s_eoff[x];
     } else {
     // the reference's emission order: anti-diagonal ascending, then row ascending == key ascending (keys are distinct)
-    for (uint32_t x = tid; x < nok; x += 256) {
+    for (uint32_t x = tid; x < nok; x += nthr) {
         const uint32_t kx = oks[x].key;
         uint32_t r = 0;
         for (uint32_t y = 0; y < nok; y++) r += oks[y].key < kx ? 1u : 0u;
@@ -173,7 +170,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx 
     __threadfence_block();
     __syncthreads();
     // first edge of every stem: exclusive prefix sum of the lengths in that order
-    for (uint32_t x0 = 0; x0 < nok; x0 += 256) {
+    for (uint32_t x0 = 0; x0 < nok; x0 += nthr) {
         const uint32_t x = x0 + tid;
         const uint32_t len = x < nok ? oks[sidx[x]].len : 0u;
         uint32_t inc = len;                                             // inclusive scan inside the wave
@@ -184,7 +181,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx 
         for (int w = 0; w < wave; w++) before += s_wsum[w];
         if (x < nok) eoff[x] = before + inc - len;
         __syncthreads();
-        if (tid == 0) s_run += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        if (tid == 0) { uint32_t a2 = 0; for (int w = 0; w < nwv; w++) a2 += s_wsum[w]; s_run += a2; }
         __syncthreads();
     }
     }
@@ -202,16 +199,16 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx 
     };
     if (aj.algo == SQ_ALGO_E) {
         // networkx numbers the nodes in order of first appearance in the edge list (v before w of every edge)
-        for (int p = tid; p < n; p += 256) s_first[p] = 0x7FFFFFFF;
+        for (int p = tid; p < n; p += nthr) s_first[p] = 0x7FFFFFFF;
         __syncthreads();
-        for (uint32_t x = tid; x < nok; x += 256) {
+        for (uint32_t x = tid; x < nok; x += nthr) {
             uint32_t key, src; int len, e0;
             stem_of(x, key, len, e0, src);
             const int s = (int)(key >> 16), i0 = (int)(key & 0xFFFFu), j0 = s - i0;
             for (int t = 0; t < len; t++) { atomicMin(&s_first[i0 + t], 2 * (e0 + t)); atomicMin(&s_first[j0 - t], 2 * (e0 + t) + 1); }
         }
         __syncthreads();
-        for (int p = tid; p < n; p += 256) {
+        for (int p = tid; p < n; p += nthr) {
             const int f = s_first[p];
             int id = -1;
             if (f != 0x7FFFFFFF) { id = 0; for (int q = 0; q < n; q++) id += s_first[q] < f ? 1 : 0; aj.vid2pos[id] = p; }
@@ -219,7 +216,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx 
         }
         __syncthreads();
     }
-    for (uint32_t x = tid; x < nok; x += 256) {
+    for (uint32_t x = tid; x < nok; x += nthr) {
         uint32_t key, src; int len, e0;
         stem_of(x, key, len, e0, src);
         const int s = (int)(key >> 16), i0 = (int)(key & 0xFFFFu), j0 = s - i0;

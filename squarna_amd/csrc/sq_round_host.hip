@@ -508,7 +508,7 @@ int sq_round_annotate_dev(sq_batch *b, const std::vector<int> &jobs, SqAlgoSize 
     SqScanArgs scan = b->scan;
     scan.ctr = ln.d_ctr;
     sq_launch_round_kernels(b, st, S, maxn, maxcap, need_reacts, scan_bytes, 2, io, scan, ln.d_structs, ln.d_strands, false);
-    hipLaunchKernelGGL(sq_algo_sizes_kernel, dim3(S), dim3(256), 0, st, b->ctx, ln.d_structs, scan, h_sizes, raw);
+    hipLaunchKernelGGL(sq_algo_sizes_kernel, dim3(S), dim3(b->inflight > 1 || b->njobs >= 4096 ? 64 : 256), 0, st, b->ctx, ln.d_structs, scan, h_sizes, raw);
     const uint32_t seq = ++*ln.round_seq;
     hipLaunchKernelGGL(sq_done_kernel, dim3(1), dim3(1), 0, st, io, scan, seq);
     HIPCK(hipGetLastError());
