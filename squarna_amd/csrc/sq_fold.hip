@@ -8,7 +8,7 @@ void sq_read_fold_switches(SqFoldSwitches &sw)
     sw.timing = on("SQ_TIMING"); sw.pool_debug = on("SQ_POOL_DEBUG");
     sw.no_chain = on("SQ_NO_CHAIN"); sw.no_rounds = on("SQ_NO_ROUNDS"); sw.no_pool = on("SQ_NO_POOL");
     sw.no_pool_round = on("SQ_NO_POOL_ROUND"); sw.pool_round_always = on("SQ_POOL_ROUND_ALWAYS");
-    sw.pool_round_nsurv = num("SQ_POOL_ROUND_NSURV", 64, 2048);
+    sw.pool_round_nsurv = num("SQ_POOL_ROUND_NSURV", 16, 2048);
     sw.pool_slots = num("SQ_POOL_SLOTS", 1, 0x7fffffff); sw.pool_chunk = num("SQ_POOL_CHUNK", 1, 0x7fffffff);
     sw.no_score_bound = on("SQ_NO_SCORE_BOUND"); sw.no_score_context = on("SQ_NO_SCORE_CONTEXT");
     sw.no_edges_lds = on("SQ_NO_EDGES_LDS");
@@ -575,7 +575,11 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         bool round_kernel = maxn <= SQ_PR_MAXN && !sw.no_pool_round;   // (jobs with a dense matrix too: sq_cellrun.h reads their cells there)
         if (round_kernel) {
             pra.lds_n = maxn; pra.str_cap = 2 * pio.pt + 2; pra.cell_entries = b->cell_entries;
-            pra.surv_cap = sw.pool_round_nsurv ? sw.pool_round_nsurv : (maxn <= 96 ? 128 : 256); pra.bound = b->score_bound ? 1 : 0;
+            // survivors of :492 kept in LDS (the rest spill to the arena): on a crowded chip LDS is what the round kernel's waves
+            // and everybody else's compete for -- 22 bytes x 256 survivors were half of a wave's 10 KB, and most structures have
+            // a few dozen (tools/pr_waves_sweep.sh: 64 -> +5 % on the headline, 16 .. 64 within a per cent of each other)
+            const bool crowded_fold = b->inflight > 1 || b->njobs >= 4096;
+            pra.surv_cap = sw.pool_round_nsurv ? sw.pool_round_nsurv : (crowded_fold ? 64 : (maxn <= 96 ? 128 : 256)); pra.bound = b->score_bound ? 1 : 0;
             pra.tmax = pio.pt; pra.parity = 0; pra.lo = 0;
             if (sq_pool_round_lds(pra.lds_n, pra.str_cap, pra.cell_entries, pra.surv_cap, pra.tmax).total > 60 * 1024) round_kernel = false;
         }

@@ -4,7 +4,9 @@
 #include <stdint.h>
 #include "sq_device.h"
 
+#ifndef SQ_PR_STAGE
 #define SQ_PR_STAGE 128            // runs the scan stages in LDS before they are scored (64 at a time)
+#endif
 #define SQ_PR_MAXN 256             // longest sequence the kernel takes (one wave per structure)
 
 struct SqPoolRoundArgs {

@@ -105,7 +105,10 @@ struct SqPrSink {
     __device__ __forceinline__ void drain(int lane) { flush(lane); }
 };
 
-extern "C" __global__ __launch_bounds__(64) void sq_pool_round_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra)
+#ifndef SQ_PR_WAVES
+#define SQ_PR_WAVES 4              // waves per SIMD the register budget is set for (4: 128 VGPRs)
+#endif
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SQ_PR_WAVES, SQ_PR_WAVES))) void sq_pool_round_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra)
 {
     extern __shared__ __attribute__((aligned(16))) char pr_dyn[];
     __shared__ SqCellTmp s_ctmp;
