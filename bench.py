@@ -390,6 +390,10 @@ def stream_leg(config, K, R, steps, warmup, device):
     import gc
     gc.collect()
     gc.freeze()
+    gc.disable()                                              # (re-enabled when the leg is over; the steps make no reference cycles.
+                                                              # With the collector on, the lists of a few steps add up to one full
+                                                              # collection every eighth step or so: 100-140 ms in which both the
+                                                              # folding and the building thread stand still -- tools/stream_pipe.py)
 
     def one_step(t, k, r):
         batches = []
@@ -425,7 +429,7 @@ def stream_leg(config, K, R, steps, warmup, device):
     stream = dict(what="SRtest150 + SRtrain150 (485 records) as a stream: every step takes the next windows of 219 x %d records for "
                        "%d batches; timed per step: Batch() (host arrays + sq_batch_create = upload) + fold of the batches in flight "
                        "+ sq_result_pack_all; c=%s poollim=1000; %d warm-up steps (the pinned-buffer cache meets every size of the windows "
-                       "after five), gc.freeze() before them" % (R, K, config, warmup),
+                       "after five), gc.freeze() + gc.disable() for the leg" % (R, K, config, warmup),
                   seq_per_s=round(219 * R * K * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 3),
                   median_ms_per_step=round(per[len(per) // 2], 3), max_ms_per_step=round(per[-1], 3), steps=steps, packed_bytes_per_step=packed)
     # the same stream as a server runs it: while the batches of one step fold (a library call: no interpreter lock), a
@@ -447,6 +451,8 @@ def stream_leg(config, K, R, steps, warmup, device):
 
         pipe_ms = []
 
+        pipe_parts = []
+
         def run_pipelined(nsteps, base):
             nxt = build(base)
             packed_ = 0
@@ -458,28 +464,38 @@ def stream_leg(config, K, R, steps, warmup, device):
                     th.start()
                 try:
                     fold_concurrently(cur, poollim=1000)
+                    ts1 = time.perf_counter()
                     packed_ = sum(int(b.pack_all()[1][-1]) for b in cur)
+                    ts2 = time.perf_counter()
                 finally:
                     for b in cur:
                         b.close()
+                    ts3 = time.perf_counter()
                     if th:
                         th.join()
                 nxt = box.get("b")
-                pipe_ms.append((time.perf_counter() - ts0) * 1e3)
+                ts4 = time.perf_counter()
+                pipe_ms.append((ts4 - ts0) * 1e3)
+                pipe_parts.append(dict(fold=round((ts1 - ts0) * 1e3, 1), pack=round((ts2 - ts1) * 1e3, 1), close=round((ts3 - ts2) * 1e3, 1),
+                                       wait_for_build=round((ts4 - ts3) * 1e3, 1)))
             return packed_
         run_pipelined(4, 1000)
         torch.cuda.synchronize()
         del pipe_ms[:]
+        del pipe_parts[:]
         t0 = time.perf_counter()
         packed2 = run_pipelined(steps, 2000)
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t0
         stream["pipelined"] = dict(seq_per_s=round(219 * R * K * steps / dt2, 1), ms_per_step=round(dt2 / steps * 1e3, 3), packed_bytes_per_step=packed2,
                                    per_step_ms=[round(x, 1) for x in pipe_ms],
+                                   median_ms_per_step=round(sorted(pipe_ms)[len(pipe_ms) // 2], 3),
+                                   slowest_step=pipe_parts[max(range(len(pipe_ms)), key=lambda q: pipe_ms[q])] if pipe_ms else None,
                                    how="the next step's Batch() calls on a second host thread while this step folds; the first build is inside the time")
     except Exception as e:                                    # (never take the sequential figure down)
         stream["pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}
     dt1, per1, packed1 = timed(1, 1, 10, 3)
+    gc.enable()
     one = dict(what="ONE pass over 219 records (a different window every call): Batch() + sq_fold + sq_result_pack_all, nothing "
                     "else in flight, median of 10",
                ms=round(per1[len(per1) // 2], 3), best_ms=round(per1[0], 3),
@@ -900,9 +916,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_stream:
         torch.cuda.empty_cache()                              # (every leg starts from a clean allocator: the blocks the legs before it left
         try:                                                  # cached have other sizes, and a leg that allocates per step then pays for them)
+            from squarna_amd import _lib
+            _lib.load().sq_host_cache_trim()                  # (the same for the library's idle pinned buffers: the S2000 legs leave
+                                                              # hundreds of MB each, evicted one hipHostFree at a time -- a 465 ms step)
             stream, one_pass = stream_leg(args.config, K, R, max(5, args.steps // 2), 6, device)
         except Exception as e:                                # (a secondary leg never takes the headline down)
             stream = {"error": "%s: %s" % (type(e).__name__, e)}
+        import gc
+        gc.enable()                                           # (the leg switches the collector off for its steps)
 
     # the CPU baseline LAST (its workers have been waiting since before the GPU was initialised): all cores busy for ten
     # seconds in front of the GPU legs made the latency-bound ones slower

@@ -137,6 +137,12 @@ typedef struct sq_fold_opts {
 /* ---- library -------------------------------------------------------------- */
 SQ_API int sq_version(void);
 SQ_API const char *sq_last_error(void);
+/* The library keeps idle pinned host buffers of destroyed batches for the next ones (hipHostMalloc / hipHostFree cost
+ * milliseconds; SQ_PINNED_CACHE_MB bounds the cache).  sq_host_cache_trim() gives every idle buffer back to the driver
+ * -- what torch.cuda.empty_cache() is for device memory: a process that changes its workload (a bench between its legs,
+ * a server between tenants) calls it so that the next batches do not pay for evicting buffers of sizes nobody asks for
+ * again.  Returns the number of bytes released.  No reference counterpart (the reference has no device). */
+SQ_API long long sq_host_cache_trim(void);
 
 /* ---- batch lifecycle ------------------------------------------------------- */
 /* Bytes of device workspace sq_batch_create() needs for this description. */

@@ -326,6 +326,19 @@ void sq_pinned_put(void *p)
     if (p) hipHostFree(p);
 }
 
+extern "C" long long sq_host_cache_trim(void)
+{
+    std::vector<std::pair<size_t, void *>> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned.mu);
+        drop.swap(g_pinned.idle);
+        g_pinned.idle_bytes = 0;
+    }
+    long long bytes = 0;
+    for (auto &e : drop) { bytes += (long long)e.first; hipHostFree(e.second); }
+    return bytes;
+}
+
 extern "C" int sq_version(void) { return 100; }
 extern "C" const char *sq_last_error(void) { return g_err.c_str(); }
 // ---- profiling (HIP events on the batch stream) ----------------------------------------

@@ -16,6 +16,7 @@ recs = load_srtest150() + list(ParseDefaultInput(os.path.join(ROOT, "squarna_amd
 allp = [Prepared(seq, reacts, restr, ref) for _, seq, reacts, restr, ref in recs]
 streams = [[torch.cuda.Stream() for _ in range(K)] for _ in range(2)]
 gc.collect(); gc.freeze()
+if os.environ.get('PIPE_GC_OFF', '1') == '1': gc.disable()     # (PIPE_GC_OFF=0: the collector stays on -- a full collection every eighth step or so)
 def build(t, box):
     t0 = time.perf_counter()
     out = []
