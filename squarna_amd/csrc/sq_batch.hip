@@ -775,9 +775,12 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
 extern "C" void sq_batch_destroy(sq_batch *b)
 {
     if (!b) return;
+    static const bool trace = getenv("SQ_PINNED_TRACE") != nullptr;     // (with the cache's trace: a destroy that takes long, by phase)
+    const double td0 = trace ? now_s() : 0;
     hipStreamSynchronize(b->stream);
     for (int k = 0; k < 4; k++) if (b->side[k]) { hipStreamSynchronize(b->side[k]); sq_stream_put(b->device, b->side[k]); }
     if (b->lane_stream) { hipStreamSynchronize(b->lane_stream); sq_stream_put(b->device, b->lane_stream); }
+    const double td1 = trace ? now_s() : 0;
     sq_event_put(b->device, b->class_ev);
     sq_event_put(b->device, b->edges_ev);
     sq_pinned_put(b->h_structs); sq_pinned_put(b->h_strands); sq_pinned_put(b->h_ctr); sq_pinned_put(b->h_seq);
@@ -789,12 +792,17 @@ extern "C" void sq_batch_destroy(sq_batch *b)
     sq_pinned_put(b->h_tail_totals); sq_pinned_put(b->h_rec_off); sq_pinned_put(b->h_txt_off); sq_pinned_put(b->h_deep);
     sq_pinned_put(b->h_rec); sq_pinned_put(b->h_txt); sq_pinned_put(b->h_app); sq_pinned_put(b->h_ref);
     sq_pinned_put(b->h_pool_recs); sq_pinned_put(b->h_pool_jobs); sq_pinned_put(b->h_pool_jobrec);
+    const double td2 = trace ? now_s() : 0;
     sq_pool_put(b->pool);
     sq_event_put(b->device, b->lane_ev);
     for (auto &p : b->prof) {
         for (auto &e : p.pending) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
         for (auto &e : p.pool) hipEventDestroy(e);
     }
+    const double td3 = trace ? now_s() : 0;
     delete b;
+    if (trace && now_s() - td0 > 0.01)
+        fprintf(stderr, "[sq_batch_destroy] %.1f ms: stream syncs %.1f, pinned buffers %.1f, pool + events %.1f, delete %.1f\n", (now_s() - td0) * 1e3,
+                (td1 - td0) * 1e3, (td2 - td1) * 1e3, (td3 - td2) * 1e3, (now_s() - td3) * 1e3);
 }
 

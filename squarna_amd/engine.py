@@ -293,8 +293,11 @@ class Batch:
         # (sizes in coarse steps: batches of a stream differ by a few records, and torch's caching allocator only hands a cached
         # block back for a request it nearly fits -- every new size was a hipMalloc, the occasional one with a device-wide
         # free of cached blocks in front: 40-190 ms steps in the stream leg)
+        # (sixteen size classes per octave from 256 MB on: the 6 GB workspaces of a stream's batches -- 12 SRtest150 sets each --
+        # differ by a few per cent, which in 64 MB steps was a new size every other step: torch's reserved memory grew from 95
+        # to 173 GB over fourteen steps of the pipelined stream, and a step paid hundreds of ms for the device-wide free)
         want = nbytes.value + 256
-        step = (64 << 20) if want >= (256 << 20) else (8 << 20) if want >= (16 << 20) else (1 << 20)
+        step = (1 << (want.bit_length() - 5)) if want >= (256 << 20) else (8 << 20) if want >= (16 << 20) else (1 << 20)
         self.workspace = torch.empty((want + step - 1) // step * step, dtype=torch.uint8, device=self.device)
         base = self.workspace.data_ptr()
         aligned = (base + 255) // 256 * 256
