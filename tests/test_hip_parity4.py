@@ -325,3 +325,41 @@ def test_shared_bit_matrices_equal_one_matrix_per_job():
         finally:
             os.environ.pop("SQ_NO_SHARED_BITS", None)
     assert packs[0] == packs[2] and packs[1] == packs[3]
+
+
+def test_blossom_large_graphs_hubs_and_stars_match_networkx():
+    """Round 4's blossom kernel against networkx.max_weight_matching itself where its new parts work hardest: graphs of
+    200-600 vertices (more than the 192 entries the dual step keeps in registers: its chunked form; adjacency and state
+    beyond one wave's reach), hubs with hundreds of neighbours (lists longer than the wave: a chunk per pass; edge chunks that
+    name one vertex dozens of times: the adjacency's rank rounds), stars and double stars, few distinct weights (ties
+    everywhere), edges shuffled.  Pairs and their (u, v) orientation (SQRNalgos.py:96-110)."""
+    import random
+    import networkx as nx
+    import squarna_amd as S
+    rng = random.Random(20261004)
+    cases = []
+    for trial in range(10):
+        n = rng.randrange(200, 600)
+        deg = rng.choice((2, 3, 5, 8))
+        weights = rng.choice(((1.0,), (1.0, 2.0), (0.5, 1.5, 4.0, 4.5, 8.0), tuple(float(x) for x in range(1, 40))))
+        pairs = set()
+        hubs = rng.sample(range(n), rng.randrange(1, 4))
+        for v in range(n):
+            for _ in range(rng.randrange(1, deg + 1)):
+                w = rng.choice(hubs) if rng.random() < 0.3 else rng.randrange(n)
+                if rng.random() < 0.3:
+                    w = (v + rng.choice((1, 2, 3))) % n
+                if w != v:
+                    pairs.add((min(v, w), max(v, w)))
+        cases.append((n, [(a, b, rng.choice(weights)) for a, b in pairs]))
+    # a star, a double star with a bridge, a hub in front of a long odd cycle
+    cases.append((130, [(0, v, float(1 + v % 3)) for v in range(1, 130)]))
+    cases.append((200, [(0, v, 2.0) for v in range(2, 100)] + [(1, v, 2.0) for v in range(100, 200)] + [(0, 1, 3.0)]))
+    cases.append((151, [(v, v + 1, 1.0) for v in range(1, 150)] + [(150, 1, 1.0)] + [(0, v, 1.0) for v in range(1, 151, 2)]))
+    for k, (n, edges) in enumerate(cases):
+        rng.shuffle(edges)
+        G = nx.Graph()
+        G.add_weighted_edges_from(edges)
+        exp = sorted(nx.max_weight_matching(G))
+        got = S.Edmonds([[[(u, v)], 1, w] for u, v, w in edges], power=1.0)
+        assert got == exp, (k, n, len(edges))
