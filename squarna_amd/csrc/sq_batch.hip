@@ -368,6 +368,8 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         memcpy(x.inbps, ps.inbps, sizeof x.inbps);
         for (int a = 0; a < 32; a++)
             for (int q = 0; q < 32; q++) if (ps.inbps[a * 32 + q]) { x.lmask |= 1u << a; break; }
+        for (int a = 0; a < 32; a++)
+            for (int q = 0; q < 29; q++) if (ps.inbps[a * 32 + q]) x.pmask[a] |= 1u << q;
         x.minlen = ps.minlen; x.minbpscore = ps.minbpscore;
         x.minfinscore = ps.minbpscore * ps.minfinscorefactor;          // SQRNdbnseq.py:1073
         x.bracketweight = ps.bracketweight; x.distcoef = ps.distcoef;

@@ -46,6 +46,7 @@ struct SqPsetDev {
     int32_t bw_integral;              // bracketweight is an integer -> stemdist index into sdftab
     int32_t sdf_off, sdf_len;         // (1/(1+d))**distcoef table   (SQRNdbnseq.py:726)
     uint32_t lmask;                   // bit a: letter code a has a pair in the paramset (the classes of sq_cellrun.h)
+    uint32_t pmask[32];               // pmask[a] bit q: (a, q) is a pair of the paramset, codes 0..28 (SQRNdbnseq.py:300; the bit kernels)
     // stemscore ** 1.7 (SQRNalgos.py:101,122: the Edmonds / Hungarian edge weights) from the host libm, for paramsets whose
     // pair weights are multiples of 2^-q: a stem score is then k 2^-q exactly and SqDevCtx::powtab[pow_off + k] its power
     // (only valid for jobs without reactivity factors or dense matrices).  pow_len == 0: no table (host-built edges)

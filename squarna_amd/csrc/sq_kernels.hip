@@ -242,11 +242,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_bits_direct_kernel(SqDevCtx
     const SqPsetDev *ps = c.psets + jb.pset;
     uint32_t *bits = c.bits + jb.bits_off;
     const int tid = threadIdx.x;
-    if (tid < 32) {
-        uint32_t m = 0;
-        for (int q = 0; q < 29; q++) if (ps->inbps[tid * 32 + q]) m |= 1u << q;     // :300 (codes 0..28; 31 never set)
-        s_pm[tid] = m;
-    }
+    if (tid < 32) s_pm[tid] = ps->pmask[tid];           // :300 (codes 0..28; 31 never set) -- from the host: one load instead of 29 byte loads behind branches
     for (int blk = blockIdx.x; blk < jb.nw * ntile; blk += gridDim.x) {
         const int w = blk / ntile, s0 = (blk - w * ntile) << 8;
         const int s = s0 + tid;
@@ -313,11 +309,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_bits_masks_kernel(SqDevCtx 
     uint8_t *s_inc = s_rcode + npad;                                    // [npad] minimal j - i
     uint32_t *s_M = reinterpret_cast<uint32_t *>(s_inc + npad);         // [max_letters][mw], one zero word in front
     uint32_t *s_R = s_M + max_letters * mw;                             // [nw][max_letters]
-    if (tid < 32) {
-        uint32_t m = 0;
-        for (int q = 0; q < 29; q++) if (ps->inbps[tid * 32 + q]) m |= 1u << q;     // :300 (codes 0..28; 31 never set)
-        s_pm[tid] = m;
-    }
+    if (tid < 32) s_pm[tid] = ps->pmask[tid];           // :300 (codes 0..28; 31 never set) -- from the host: one load instead of 29 byte loads behind branches
     if (tid == 0) s_present = 0;
     __syncthreads();
     uint32_t mine = 0;
