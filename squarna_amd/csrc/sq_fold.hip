@@ -160,9 +160,11 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     static const bool no_early_tail = getenv("SQ_NO_EARLY_TAIL") != nullptr;
     const bool early_tail = pending == nullptr && !no_early_tail && !dev_tail;
     struct TailQueue {
-        std::mutex mu; std::condition_variable cv; std::vector<int> items; bool closed = false;
+        std::mutex mu; std::condition_variable cv, idle_cv; std::vector<int> items; bool closed = false, busy = false;
         std::thread worker;
         void push(std::vector<int> &v) { if (v.empty()) return; { std::lock_guard<std::mutex> lk(mu); items.insert(items.end(), v.begin(), v.end()); } cv.notify_one(); v.clear(); }
+        // everything pushed so far has been handled when this returns (the worker stays: later pushes are served as before)
+        void flush() { if (!worker.joinable()) return; std::unique_lock<std::mutex> lk(mu); idle_cv.wait(lk, [&] { return items.empty() && !busy; }); }
         void close() { if (!worker.joinable()) return; { std::lock_guard<std::mutex> lk(mu); closed = true; } cv.notify_one(); worker.join(); }
         ~TailQueue() { close(); }
     } tq;
@@ -182,7 +184,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         P.fin.push_back(std::move(stems));
         P.evals += nst + (by_count ? 0 : 1);                // one evaluation per round the structure took part in
         const int s2 = b->job_seq[j];
-        if (early_tail && --g_left[s2] == 0) { tail_one(s2); tailed[s2] = 1; }
+        // (optimistic chains in front of the device pools: a sequence's other jobs may still be the pools', and a capacity overflow
+        // there hands EVERY greedy job to the host loop -- nothing is ranked before the pools are through)
+        if (early_tail && !chain_ties && --g_left[s2] == 0) { tail_one(s2); tailed[s2] = 1; }
     };
     if (early_tail) {
         for (int s2 = 0; s2 < b->nseq; s2++) g_left[s2] = 0;
@@ -199,11 +203,14 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                     tq.cv.wait(lk, [&] { return !tq.items.empty() || tq.closed; });
                     take.swap(tq.items);
                     if (take.empty()) return;               // closed and drained
+                    tq.busy = true;
                 }
                 sq_pool(b)->parallel_for((int)take.size(), [&](int k) {
                     if (take[k] < 0) chain_finish((uint32_t)(-(take[k] + 1)));       // (items < 0: chain entries)
                     else { tail_one(take[k]); tailed[take[k]] = 1; }
                 });
+                { std::lock_guard<std::mutex> lk(tq.mu); tq.busy = false; }
+                tq.idle_cv.notify_all();
             }
         });
     }
@@ -363,6 +370,33 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         io.h_ctr = ln.h_ctr; io.h_seq = ln.h_seq;
         SqScanArgs scan = b->scan;
         scan.ctr = ln.d_ctr;
+        // ONE launch for all rounds of these structures (sq_rounds.hip: a persistent block per structure) when every job
+        // qualifies: per-position arrays and lists that fit the block's LDS.  Decided BEFORE anything is enqueued: a chain of
+        // pools that may branch which the kernel cannot take goes to the device pools as it is, and the init kernel -- which
+        // reads the pinned records the next chain overwrites -- is then never launched
+        bool rounds_ok = !no_rounds;
+        for (int j : jobs) rounds_ok = rounds_ok && b->jobs[j].n <= SQ_ROUNDS_MAXN;
+        int thr = 64;
+        SqRoundsArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        if (rounds_ok) {
+            static const int thr_env = getenv("SQ_ROUNDS_THREADS") ? std::max(64, std::min(SQ_ROUNDS_THREADS, atoi(getenv("SQ_ROUNDS_THREADS")) / 64 * 64)) : 0;
+            // threads per structure: by length -- and, while the launch leaves the chip empty (a shard of a multi-GPU run, a
+            // small batch), twice / four times that: a structure's rounds are a chain of dependent passes over its list that
+            // more waves shorten (S1000 x 128: 1.21 -> 0.99 ms at 512 threads)
+            thr = maxn <= 320 ? 64 : (maxn <= 450 ? 128 : 256);
+            while (!thr_env && thr < SQ_ROUNDS_THREADS && thr < maxn / 2 && (int64_t)S * thr * 2 <= (int64_t)256 * 512) thr *= 2;
+            if (thr_env) { thr = 64; while (thr * 2 <= thr_env) thr *= 2; }   // (a power of two: the survivor ring is indexed with a mask)
+            ra.lds_n = maxn; ra.str_cap = 2 * maxt + 2; ra.tmax = maxt; ra.cell_entries = b->cell_entries;
+            ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0; ra.ties = chain_ties ? 1 : 0;
+            while (thr > 64 && sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr).total + 2048 > 158 * 1024) thr /= 2;   // (long sequences: the survivor ring gives way)
+            if (sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr).total + 2048 > 158 * 1024) rounds_ok = false;
+        }
+        if (!rounds_ok && chain_ties) {                       // (the launched rounds do not look for ties: the pools take these jobs)
+            for (int j : jobs) tied_jobs.push_back(j);
+            nfin_goal -= (uint32_t)S;
+            continue;
+        }
         hipLaunchKernelGGL(sq_chain_init_kernel, dim3((S + 255) / 256), dim3(256), 0, st, ln.h_structs, b->h_chain, ln.d_structs,
                            b->chain, scan, S, first_chain ? 1 : 0);
         first_chain = false;
@@ -375,25 +409,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         volatile uint32_t *flag = ln.h_seq;
         const double tr0 = now_s();
         std::vector<std::pair<int, double>> round_t;
-        // ONE launch for all rounds of these structures (sq_rounds.hip: a persistent block per structure) when every job
-        // qualifies: no dense matrix behind its cells, per-position arrays that fit the block's LDS
-        bool rounds_ok = !no_rounds;
-        for (int j : jobs) rounds_ok = rounds_ok && b->jobs[j].n <= SQ_ROUNDS_MAXN;
         if (rounds_ok) {
-            static const int thr_env = getenv("SQ_ROUNDS_THREADS") ? std::max(64, std::min(SQ_ROUNDS_THREADS, atoi(getenv("SQ_ROUNDS_THREADS")) / 64 * 64)) : 0;
-            // threads per structure: by length -- and, while the launch leaves the chip empty (a shard of a multi-GPU run, a
-            // small batch), twice / four times that: a structure's rounds are a chain of dependent passes over its list that
-            // more waves shorten (S1000 x 128: 1.21 -> 0.99 ms at 512 threads)
-            int thr = maxn <= 320 ? 64 : (maxn <= 450 ? 128 : 256);
-            while (!thr_env && thr < SQ_ROUNDS_THREADS && thr < maxn / 2 && (int64_t)S * thr * 2 <= (int64_t)256 * 512) thr *= 2;
-            if (thr_env) { thr = 64; while (thr * 2 <= thr_env) thr *= 2; }   // (a power of two: the survivor ring is indexed with a mask)
-            SqRoundsArgs ra;
-            ra.lds_n = maxn; ra.str_cap = 2 * maxt + 2; ra.tmax = maxt; ra.cell_entries = b->cell_entries;
-            ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0; ra.ties = chain_ties ? 1 : 0;
-            while (thr > 64 && sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr).total + 2048 > 158 * 1024) thr /= 2;   // (long sequences: the survivor ring gives way)
             const SqRoundsLds lo = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr);
-            if (lo.total + 2048 > 158 * 1024) rounds_ok = false;
-            else {
+            {
                 if (lo.total > 60 * 1024) sq_max_dynamic_lds((const void *)sq_rounds_kernel, 158 * 1024);   // (the kernel has static LDS too: 160 KB in all)
                 {
                     ProfScope ps(b, 7, 0);
@@ -428,11 +446,6 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                     }
                 }
             }
-        }
-        if (!rounds_ok && chain_ties) {                       // (the launched rounds do not look for ties: the pools take these jobs)
-            for (int j : jobs) tied_jobs.push_back(j);
-            nfin_goal -= (uint32_t)S;
-            continue;
         }
         while (!rounds_ok && nfin_seen < nfin_goal) {
             while (launched - done < depth) {               // rounds enqueued ahead of the device
@@ -634,6 +647,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         stats.tround = now_s() - tr0;
         const SqPoolHdr hh = *pio.h_hdr;
         if (overflow || hh.ovf) {
+            tq.flush();                                      // (the optimistic chains' entries are still being turned into lists by the queue's workers)
             for (int j : greedy_jobs) { pools[j].fin.clear(); pools[j].evals = 0; }
             // (the device log holds the structures the aborted pools had finished: they leave it for the host loop's.  The E / H / N
             // stemsets of the device RunAlgo stay -- their finish kernels append on the side streams: wait for them first, the
@@ -709,6 +723,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         if (pr == 1) {                                       // a capacity was exceeded: the host's own loop takes the fold
             st0 = LoopStats();
             use_pool = false;
+            tq.flush();                                      // (no worker is still filling the lists the host loop starts from)
             host_pools_init();
             if (!two_lanes) greedy_loop(b->lane_full, greedy_jobs, st0);
             else { std::vector<int> none; greedy_loop(b->lane_full, greedy_jobs, st0); }

@@ -169,7 +169,11 @@ extern "C" __global__ __launch_bounds__(64) void sq_lsap_kernel(const SqMatchJob
             if (lane == 0) { SR[i] = 1; SC[j] = 1; remaining[index] = lastj; }
             nrem--;
             if (owner == -1) sink = j; else i = owner;
+            // (the vectors may live in global scratch: lane 0's stores are released to the whole wave before the next step's
+            // cross-lane reads, not left to same-wave store-to-load ordering through L1)
+            if (!vec_lds) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
+            if (!vec_lds) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         if (sink < 0) break;
         // ---- dual update
@@ -206,7 +210,8 @@ extern "C" __global__ __launch_bounds__(256) void sq_nussinov_kernel(const SqMat
     const int n = jb.n, tid = threadIdx.x, nthr = blockDim.x;   // 64 .. 256 threads: the launch's longest sequence rounded up to waves
     // (by_pad: the rows are a slice of a table sorted by size, row.pad = the job's index, under which its count is filed)
     int32_t *const my_count = count_out + (by_pad ? jb.pad : (int)blockIdx.x);
-    if (n <= 0) { if (tid == 0) *my_count = 0; return; }
+    // (n == 1: the column DP writes no cell, BackTrack would read K[0, 0] from reused scratch; the reference returns no pairs)
+    if (n < 2) { if (tid == 0) *my_count = 0; return; }
     double *S = reinterpret_cast<double *>(scratch + jb.scratch_off);   // region of n*n doubles: holds the column lists
     double *D = S + (size_t)n * n;
     int32_t *K = reinterpret_cast<int32_t *>(D + (size_t)n * n);

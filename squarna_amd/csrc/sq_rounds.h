@@ -13,9 +13,26 @@ struct SqRun {
     double bps;       // sum of the cells outer -> inner from int 0 (:416); NaN: not computed yet (the first round's scan)
 };
 
-#ifndef SQ_ROUNDS_CHUNK
-#define SQ_ROUNDS_CHUNK 2          // runs per thread and chunk of the scoring pass
-#endif
+// The list of the rounds after the first, as two arrays: the run itself (SqRunA, lower half of the structure's slice of the
+// arena) and what the rounds before found out about it (SqRunB, upper half).  A run's bound (sq_run_upper) only reads the
+// prefix counts within six positions of its four ends, its finalscore (ScoreStems) the strands inside its span and within six
+// positions outside it: a stem chosen elsewhere leaves both as they are, so they are kept from round to round and dropped
+// when a strand of the new stem comes near (SQ_RX_UB / SQ_RX_FIN in SqRunA::lf say which is valid).
+struct SqRunA {
+    uint32_t key;     // as SqRun
+    uint32_t lf;      // length (low 16 bits; 0: dead) | SQ_RX_* flags
+    double bps;
+};
+struct SqRunB {
+    double ub;        // sq_run_upper of the run under the structure as it is (SQ_RX_UB)
+    double fin;       // its finalscore under the structure as it is (SQ_RX_FIN), before :751's threshold
+};
+#define SQ_RX_LEN 0xFFFFu
+#define SQ_RX_UB 0x10000u
+#define SQ_RX_FIN 0x20000u
+
+#define SQ_RQ_CAP 128              // entries of each of a wave's three work queues (cut / bound / score): a queue is served when it holds 64
+#define SQ_RQ_WORDS (3 * SQ_RQ_CAP)
 #define SQ_ROUNDS_STAGE 128        // runs a wave of the first round's scan stages in LDS before it appends them
 #define SQ_ROUNDS_MAXN 8192        // longest sequence whose per-position arrays the kernel keeps in LDS (9 bytes each)
 #define SQ_ROUNDS_THREADS 1024     // widest block (few structures: a structure's rounds are a latency chain that more waves shorten)
@@ -33,12 +50,12 @@ struct SqRoundsArgs {
 
 // dynamic LDS of a block: per-position arrays, free-position words of the first round's scan, cell table, the strand
 // list + stem indices, skip pointers, the stems with their crossing weights, and one region shared by the phases that
-// never overlap (scan staging / bucket counters / level scratch of the extension / survivor ring of the scoring pass)
+// never overlap (scan staging / bucket counters / level scratch of the extension / the waves' work queues of the list pass)
 struct SqRoundsLds {
     int np, fbh;
     int off_P, off_U, off_SU, off_E, off_ci, off_code, off_fg, off_cell, off_str, off_sidx, off_skip, off_stems, off_union;
     int t8;                 // stems the stem arrays hold (tmax rounded up to 8)
-    int surv_cap;           // entries of the survivor ring (a power of two)
+    int surv_cap;           // (unused)
     size_t total;
 };
 __host__ __device__ inline SqRoundsLds sq_rounds_lds(int lds_n, int str_cap, int tmax, int cell_entries, int threads)
@@ -65,8 +82,8 @@ __host__ __device__ inline SqRoundsLds sq_rounds_lds(int lds_n, int str_cap, int
     L.off_stems = o; o += 11 * L.t8 + 64 * 4;                  // the structure's stems: crossing weight (int32), i, j, len (int16), level group (uint8); the groups' sizes
     o = (o + 15) & ~15;
     L.off_union = o;
-    L.surv_cap = (SQ_ROUNDS_CHUNK + 1 <= 2 ? 2 : SQ_ROUNDS_CHUNK + 1 <= 4 ? 4 : 8) * threads;   // >= (SQ_ROUNDS_CHUNK + 1) x threads, a power of two
-    size_t u = (size_t)4 * L.surv_cap;                          // (the ring holds list indices: ScoreStems reads the run itself)
+    L.surv_cap = 0;
+    size_t u = (size_t)(threads / 64) * SQ_RQ_WORDS * 4;       // the waves' work queues of the list pass (list indices)
     const size_t ext = (size_t)3 * L.t8 + 64 + 16;            // level scratch of the extension: order, level, rank
     const size_t stage = (size_t)(threads / 64) * (SQ_ROUNDS_STAGE * 8 + 16);
     if (ext > u) u = ext;

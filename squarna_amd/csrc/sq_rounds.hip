@@ -113,26 +113,25 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
 {
     extern __shared__ __attribute__((aligned(16))) char rd_dyn[];
     __shared__ int s_wave_u[SQ_ROUNDS_THREADS / 64], s_wave_s[SQ_ROUNDS_THREADS / 64];
-    __shared__ uint32_t s_nlist, s_ndead, s_nsurv;
+    __shared__ uint32_t s_nlist, s_ndead;
+    __shared__ int s_regroup;
     __shared__ SqCellTmp s_ctmp;
     __shared__ unsigned long long s_best;
     __shared__ double s_wfin[SQ_ROUNDS_THREADS / 64], s_wbps[SQ_ROUNDS_THREADS / 64], s_wsec[SQ_ROUNDS_THREADS / 64];
     __shared__ uint32_t s_wkey[SQ_ROUNDS_THREADS / 64], s_wlen[SQ_ROUNDS_THREADS / 64];
     __shared__ int s_wany[SQ_ROUNDS_THREADS / 64];
     __shared__ int s_cross;
-#ifdef SQ_ROUNDS_PROF
-    __shared__ uint32_t s_clean;
-#endif
 
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
     const int b = blockIdx.x;
 #ifdef SQ_ROUNDS_PROF
-    // in-kernel timers (100 MHz wall clock): set-up, scan, cut, scoring phase A / B, pick, extension + state
-    long long _pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
-    long long _cnt[4] = {0, 0, 0, 0};       // runs cut, runs scored (phase A), survivors (phase B), rounds
+    // in-kernel timers of the block's first wave (100 MHz wall clock): set-up, scan, ordering + compaction, the pass's stream / cut /
+    // bound / score steps, pick, extension + state
+    long long _pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
+    long long _cnt[4] = {0, 0, 0, 0};       // entries streamed, finalscores taken from the list, runs scored (first wave), rounds
 #define RPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)
-#define RPROF_OUT() do { if (tid == 0 && (b % 97) == 0) printf("rounds block %d clean %u n=%d rounds %lld | us: setup %.1f scan %.1f cut %.1f A %.1f B %.1f pick %.1f ext %.1f total %.1f | cut %lld scoredA %lld survB %lld\n", \
-        b, s_clean, n, _cnt[3], _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, _pt[6] * 0.01, (wall_clock64() - _t00) * 0.01, _cnt[0], _cnt[1], _cnt[2]); } while (0)
+#define RPROF_OUT() do { if (tid == 0 && (b % 97) == 0) printf("rounds block %d n=%d rounds %lld | us: setup %.1f scan %.1f order %.1f stream %.1f cut %.1f bound %.1f score %.1f pick %.1f ext %.1f total %.1f | wave 0: streamed %lld kept %lld scored %lld\n", \
+        b, n, _cnt[3], _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, _pt[6] * 0.01, _pt[7] * 0.01, _pt[8] * 0.01, (wall_clock64() - _t00) * 0.01, _cnt[0], _cnt[1], _cnt[2]); } while (0)
 #else
 #define RPROF(k) do {} while (0)
 #define RPROF_OUT() do {} while (0)
@@ -156,7 +155,6 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     int16_t *const sidxbuf = reinterpret_cast<int16_t *>(rd_dyn + Lo.off_sidx);
     uint16_t *const s_skip = reinterpret_cast<uint16_t *>(rd_dyn + Lo.off_skip);
     char *const uni = rd_dyn + Lo.off_union;
-    const int str_cap = ra.str_cap;
 
     auto retire = [&](int nstems, int by_count) {           // the records sq_chain_kernel writes (sq_chain.hip)
         if (tid == 0) {
@@ -173,9 +171,6 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
 
     // ---- once per fold: letter classes, the cell table (sq_score_kernel builds them per round), the empty structure ----
     if (tid == 0) s_nlist = 0;
-#ifdef SQ_ROUNDS_PROF
-    if (tid == 0) s_clean = 0;
-#endif
     const SqCellEnv cenv = sq_cell_setup(c, jb, ps, s_ctmp, l_ci, l_code, s_cell, tid, nthr);
     {
         const uint8_t *e0 = c.e0c + jb.pos_off;
@@ -206,11 +201,16 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     prefix_counts();
     RPROF(0);
 
+    // The structure's slice of the candidate arena (cand_cap 32-byte units): the list of the rounds as two arrays of `cap`
+    // 16-byte records -- the runs (LA, lower half) and their kept bounds / finalscores (LB, upper half; valid as LA's flags say).
+    // The first round's scan stages its raw runs in the upper half.
     const int cap = jb.cand_cap;
-    SqRun *const listA = reinterpret_cast<SqRun *>(a.cands + st.cand_off), *const listB = listA + cap;
+    SqRunA *const LA = reinterpret_cast<SqRunA *>(a.cands + st.cand_off);
+    SqRunB *const LB = reinterpret_cast<SqRunB *>(LA + cap);
+    SqRun *const raw = reinterpret_cast<SqRun *>(LA + cap);
     const int minlen = max(1, (int)ceil(ps->minlen));
 
-    // ---- the first round's AnnotateStems: bit-diagonal scan of the empty structure into listB ----
+    // ---- the first round's AnnotateStems: bit-diagonal scan of the empty structure into the staging half ----
     if (n >= 5) {                                                   // :456-457 (shorter sequences have no diagonals)
         const int fbh = Lo.fbh;
         for (int m2 = wv; 2 * m2 < fbh; m2 += nwv) {                // free-position words, forward and reversed (sq_state_build)
@@ -227,11 +227,11 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         uint2 *const wstage = reinterpret_cast<uint2 *>(uni + 16 * nwv) + (size_t)wv * SQ_ROUNDS_STAGE;
         if (lane == 0) *wcnt = 0;
         __syncthreads();
-        SqRoundsSink sink{wstage, wcnt, &s_nlist, listB, (uint32_t)cap, a.ctr};
+        SqRoundsSink sink{wstage, wcnt, &s_nlist, raw, (uint32_t)cap, a.ctr};
         sq_scan6_groups(c, jb, FG, FG + fbh, fbh, E, wv, nwv, lane, sink);
     }
     __syncthreads();
-    uint32_t ncur = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;
+    const uint32_t ncur = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;
     __syncthreads();
     RPROF(1);
 
@@ -245,13 +245,12 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     const double *const ps_sdf = c.sdftab + ps->sdf_off;
     const double *const ps_of = ps->oftab;
     const double ub_of = ps->ub_of, ub_lf = ra.bound ? ps->ub_lf : INFINITY;
-    // a width-1 pool only ever uses ChooseStems' FIRST element (the highest finalscore, the smallest key among equals): a run
-    // whose bound is below the best finalscore seen so far can neither be it nor tie with it -- the bar is the best itself, not
-    // the suboptimality range below it (which the pools' round kernel needs: its children come from the whole range)
-    const double st_subopt = 1.0;
+    // (a width-1 pool only ever uses ChooseStems' FIRST element -- the highest finalscore, the smallest key among equals: a run
+    // whose bound is below the best finalscore seen so far can neither be it nor tie with it.  The bar is the best itself, not
+    // the suboptimality range below it, which the pools' round kernel needs: its children come from the whole range)
 
     // ---- the first round's list: exact bpscores, dead runs dropped, ordered by descending bpscore (buckets of 0.5) so that
-    // the scoring pass meets the strong candidates first and its bound prunes the rest; later rounds keep the order ----
+    // the pass meets the strong candidates first and its bound prunes the rest; later rounds keep the order roughly ----
     {
         uint32_t *const hist = reinterpret_cast<uint32_t *>(uni);             // [256] counts, then fill pointers
         uint32_t *const start = hist + 256;                                  // [256]
@@ -259,12 +258,12 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         __syncthreads();
         auto bucket = [&](double bps) -> int { const double x = bps * 2.0; return 255 - (x >= 255.0 ? 255 : (x > 0.0 ? (int)x : 0)); };
         for (uint32_t q = tid; q < ncur; q += nthr) {
-            const SqRun r = listB[q];
+            const SqRun r = raw[q];
             const int i = (int)(r.key & 0xFFFFu), j = (int)(r.key >> 16) - i;
             double pos;
             const double bps = run_bps(i, j, (int)r.len, pos);
-            if (pos < minbps) listB[q].len = 0;
-            else { listB[q].bps = bps; atomicAdd(&hist[bucket(bps)], 1u); }
+            if (pos < minbps) raw[q].len = 0;
+            else { raw[q].bps = bps; atomicAdd(&hist[bucket(bps)], 1u); }
         }
         __threadfence_block();
         __syncthreads();
@@ -283,23 +282,20 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         for (int k = tid; k < 256; k += nthr) hist[k] = 0;
         __syncthreads();
         for (uint32_t q = tid; q < ncur; q += nthr) {
-            const SqRun r = listB[q];
+            const SqRun r = raw[q];
             if (r.len) {
                 const int bk = bucket(r.bps);
-                listA[start[bk] + atomicAdd(&hist[bk], 1u)] = r;
+                LA[start[bk] + atomicAdd(&hist[bk], 1u)] = SqRunA{r.key, r.len, r.bps};
             }
         }
-        if (tid == 0) s_ndead = 0;
+        if (tid == 0) { s_ndead = 0; s_best = 0ull; s_regroup = 0; }
         __threadfence_block();
         __syncthreads();
     }
     RPROF(2);
 
-    uint32_t *const s_ring = reinterpret_cast<uint32_t *>(uni);    // list indices of the runs that wait for ScoreStems
-    const uint32_t smask = (uint32_t)Lo.surv_cap - 1u;
-
     // the structure's stems with their crossing weights (:121-124) stay in LDS between rounds; the level rule's scratch
-    // shares the survivor ring's region
+    // shares the work queues' region
     SqExtendLds XL;
     XL.cc = reinterpret_cast<int32_t *>(rd_dyn + Lo.off_stems);
     XL.i = reinterpret_cast<int16_t *>(XL.cc + Lo.t8); XL.j = XL.i + Lo.t8; XL.len = XL.j + Lo.t8;
@@ -313,196 +309,255 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
 
     int nstems = 0, nstrand = 0, ngroups = 0;       // (ngroups: level groups in use, first wave only)
     bool anycross = false;
-    int za0 = 1, za1 = 0, zb0 = 1, zb1 = 0;                         // the two strands of the stem chosen last
-    SqRun *list = listA, *other = listB;
+    int za0 = 0x7000, za1 = -0x7000, zb0 = 0x7000, zb1 = -0x7000;   // the two strands of the stem chosen last (none yet: empty intervals)
     SqChainStem *const gst = cio.stems + ch.toff;
+    // this wave's work queues of the list pass (list indices; the counts live in registers: nobody else touches them)
+    uint32_t *const qcut = reinterpret_cast<uint32_t *>(uni) + (size_t)wv * SQ_RQ_WORDS, *const qcand = qcut + SQ_RQ_CAP, *const qsurv = qcand + SQ_RQ_CAP;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t nl0 = s_nlist;                                          // entries of the list when the pass starts (the same for every wave)
 
-    for (int round = 0;; round++) {
+    for (;;) {
 #ifdef SQ_ROUNDS_PROF
         _cnt[3]++;
 #endif
-        // ---- dead entries out (order kept) when they are a third of the list or the list runs out of room ----
-        uint32_t nl = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;
+        // ---- dead entries out, in place, order kept, when they are a third of the list or the list runs out of room ----
         {
             const uint32_t nd = s_ndead;
-            __syncthreads();
-            if (nd * 3 > nl || nl + ((nl - nd) >> 1) + 64 > (uint32_t)cap) {
+            if (nd * 3 > nl0 || nl0 + ((nl0 - nd) >> 1) + 64 > (uint32_t)cap) {
+                __syncthreads();
                 uint32_t base = 0;
-                for (uint32_t q0 = 0; q0 < nl; q0 += nthr) {
+                for (uint32_t q0 = 0; q0 < nl0; q0 += nthr) {
                     const uint32_t q = q0 + tid;
-                    const SqRun r = q < nl ? list[q] : SqRun{0u, 0u, 0.0};
-                    const unsigned long long m = __ballot(r.len != 0);
+                    SqRunA ra_ = {0u, 0u, 0.0}; SqRunB rb_ = {0.0, 0.0};
+                    if (q < nl0) { ra_ = LA[q]; rb_ = LB[q]; }
+                    const bool live = (ra_.lf & SQ_RX_LEN) != 0;
+                    const unsigned long long m = __ballot(live);
                     if (lane == 0) s_wave_u[wv] = __popcll(m);
-                    __syncthreads();
-                    uint32_t off = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    __syncthreads();                                   // (the chunk is read: its entries and the ones below may be overwritten)
+                    uint32_t off = base + (uint32_t)__popcll(m & lt_mask);
                     for (int w = 0; w < wv; w++) off += (uint32_t)s_wave_u[w];
-                    if (r.len) other[off] = r;
+                    if (live && off != q) { LA[off] = ra_; LB[off] = rb_; }
                     for (int w = 0; w < nwv; w++) base += (uint32_t)s_wave_u[w];
+                    __threadfence_block();
                     __syncthreads();
                 }
-                SqRun *t = list; list = other; other = t;
-                nl = base;
+                nl0 = base;
                 if (tid == 0) { s_nlist = base; s_ndead = 0; }
-                __threadfence_block();
                 __syncthreads();
             }
         }
         RPROF(2);
 
-        // ---- one pass over the list: the runs cut against the new stem's strands, in place (the first piece that is
-        // still alive takes the run's entry, further pieces go to the end of the list and are met later in this pass),
-        // then ScoreStems on the runs that pass :492; the best finalscore, the smallest key among equals.  The runs that
-        // pass wait in a ring in LDS until a full group of them is due (the chain of dependent loads of ScoreStems is what
-        // the pass waits for: idle lanes are its cost); the next chunk's entries are on their way meanwhile ----
-        if (tid == 0) { s_nsurv = 0; s_best = 0ull; }
+        // ---- one pass over the list.  Every wave streams its share of the entries (units of 64, dealt round robin) and sorts
+        // them into three work queues of its own; a queue is served when it holds a full wave of work, so the rare steps run with
+        // all lanes busy (until round 5 they ran inside the stream, a handful of lanes at a time, and were most of a round):
+        //   * cut      the run meets a strand of the new stem: its pieces, outer -> inner; the first live piece takes the
+        //              entry, the others go to the end of the list (and are handled here, by the lane that made them);
+        //   * bound    no valid bound: sq_run_upper, kept in the entry;
+        //   * score    the bound reaches the best finalscore so far: ScoreStems, kept in the entry.
+        // An entry whose finalscore is still valid costs a compare.  No block barrier inside the pass: the waves only share the
+        // best finalscore so far (an atomic maximum in LDS) and the end of the list.  The stream is straight-line code: every
+        // test is evaluated for every entry and combined without branches.
         const SqStrand *const S = strbuf;
         const SqStemsEnv env = {S, s_skip, nstrand, true, P, U, SU, l_code, n, false, nullptr, nullptr, nullptr, 0,
                                 ps_lb, ps_bw, ps_dc, ps_bwint, ps_sdflen, ps_sdf, ps_of, a.ctr};
-        __syncthreads();
-        double bfin = 0.0, bbps = 0.0; uint32_t bkey = 0, blen = 0; int bany = 0;
+        const int regroup = s_regroup != 0 ? 1 : 0;                // the last stem changed the level groups: no finalscore is kept
+        double bfin = -INFINITY, bbps = 0.0; uint32_t bkey = 0xFFFFFFFFu, blen = 0;   // (bfin == -inf: none yet; real finalscores are finite)
         double sfin = -INFINITY;                                    // the best finalscore of the OTHER runs (ties of a pool that may branch)
-        uint32_t head = 0;                                          // entries of the ring taken so far (s_nsurv: entries put)
-        SqRun rr[SQ_ROUNDS_CHUNK];
-#pragma unroll
-        for (int u = 0; u < SQ_ROUNDS_CHUNK; u++) {
-            const uint32_t q = (uint32_t)u * nthr + tid;
-            rr[u] = q < nl ? list[q] : SqRun{0u, 0u, 0.0};
-        }
-        for (uint32_t q0 = 0; q0 < nl; q0 += SQ_ROUNDS_CHUNK * nthr) {
-            double need = minfin;
-            {
-                const unsigned long long sb = s_best;
-                if (sb) { const double r = st_subopt * sq_unord(sb); need = r > need ? r : need; }
+        auto take = [&](bool valid, double fin, uint32_t key, uint32_t L, double bps) {   // branch-free
+            const bool better = valid & ((fin > bfin) | ((fin == bfin) & (key < bkey)));
+            const double demoted = better ? bfin : (valid ? fin : -INFINITY);
+            sfin = demoted > sfin ? demoted : sfin;
+            bfin = better ? fin : bfin; bkey = better ? key : bkey; blen = better ? L : blen; bbps = better ? bps : bbps;
+        };
+        auto raise = [&](bool mine, double fin) {                   // the block's best so far (wave-uniform call)
+            if (__ballot(mine) != 0ull) {
+                const double wb = sq_wave_max_f64(mine ? fin : -INFINITY);
+                if (lane == 0) atomicMax(&s_best, sq_ord(wb));
             }
-#pragma unroll
-            for (int u = 0; u < SQ_ROUNDS_CHUNK; u++) {
-                SqRun r = rr[u];
-                int L = (int)r.len;
-                if (L > 0 && round > 0) {
-                    const int i = (int)(r.key & 0xFFFFu), s = (int)(r.key >> 16), j = s - i;
+        };
+        auto bar = [&]() -> double {                                // what a run has to reach: :751's threshold, the best so far
+            const unsigned long long sb = __atomic_load_n(&s_best, __ATOMIC_RELAXED);
+            const double r = sb ? sq_unord(sb) : minfin;
+            return r > minfin ? r : minfin;
+        };
+        uint32_t nX = 0, nC = 0, nS = 0;                            // entries of the three queues
+        auto push = [&](uint32_t *qb, uint32_t &cnt, bool p, uint32_t v) {   // (wave-uniform call)
+            const unsigned long long m = __ballot(p);
+            if (p) qb[cnt + (uint32_t)__popcll(m & lt_mask)] = v;
+            cnt += (uint32_t)__popcll(m);
+        };
+        const uint32_t nunits = (nl0 + 63u) >> 6;
+        uint32_t g = (uint32_t)wv;
+        SqRunA ca = {0u, 0u, 0.0}; SqRunB cb = {0.0, 0.0};          // the next unit's entries, on their way
+        if (g < nunits && g * 64 + lane < nl0) { ca = LA[g * 64 + lane]; cb = LB[g * 64 + lane]; }
+        bool cact = false, cfirst = false; uint32_t cq = 0; int ci = 0, cs = 0, cL = 0, ct0 = 0;   // the run this lane is cutting
+        for (;;) {
+            // ---- the stream: units of 64 entries until a queue holds a wave of work or the list ends ----
+            while (g < nunits && (nX | nC | nS) < 64u) {
+                const double need = bar();
+                const uint32_t q = g * 64 + lane;
+                const SqRunA r = ca; const SqRunB rb = cb;
+                g += (uint32_t)nwv;
+                ca.lf = 0u;
+                if (g < nunits && g * 64 + lane < nl0) { ca = LA[g * 64 + lane]; cb = LB[g * 64 + lane]; }
+                const int L = (int)(r.lf & SQ_RX_LEN);
+                const int i = (int)(r.key & 0xFFFFu), j = (int)(r.key >> 16) - i, sa = i + L - 1, sb = j - L + 1;
+#define SQ_OV(z0, z1, lo, hi) ((int)((z0) <= (hi)) & (int)((z1) >= (lo)))
+                // rows [i, sa] or columns [sb, j] meet a strand of the new stem: the run is cut.  A strand within six positions of
+                // the run's span: the finalscore is void; within six of its four ends: the bound too
+                const int cutv = SQ_OV(za0, za1, i, sa) | SQ_OV(zb0, zb1, i, sa) | SQ_OV(za0, za1, sb, j) | SQ_OV(zb0, zb1, sb, j);
+                const int fdirty = regroup | SQ_OV(za0, za1, i - 6, j + 6) | SQ_OV(zb0, zb1, i - 6, j + 6);
+                const int udirty = SQ_OV(za0, za1, i - 6, sa + 6) | SQ_OV(zb0, zb1, i - 6, sa + 6) | SQ_OV(za0, za1, sb - 6, j + 6) | SQ_OV(zb0, zb1, sb - 6, j + 6);
+#undef SQ_OV
+                const bool live = L > 0;                                        // (lanes beyond the list hold length 0)
+                const bool pcut = live & (cutv != 0);
+                const uint32_t lf = r.lf & ~(fdirty ? SQ_RX_FIN : 0u) & ~(udirty ? (SQ_RX_UB | SQ_RX_FIN) : 0u);
+                const bool stay = live & !pcut;
+                if (stay & (lf != r.lf)) LA[q].lf = lf;
+                const bool p492 = stay & (r.bps >= minbps);                     // :492
+                const bool hasfin = p492 & ((lf & SQ_RX_FIN) != 0u);
+                const bool mine = hasfin & (rb.fin >= minfin);                  // :751
+                const bool psurv = p492 & ((lf & (SQ_RX_FIN | SQ_RX_UB)) == SQ_RX_UB) & !(rb.ub < need);
+                // (no bound yet: first with every factor at its maximum, which needs nothing but the bpscore)
+                const double quick = (((r.bps * ub_of) * ub_lf) * 1.25) * (1.0 + 0x1p-30);
+                const bool pcand = p492 & ((lf & (SQ_RX_FIN | SQ_RX_UB)) == 0u) & !((ub_lf < INFINITY) & (r.bps >= 0) & (quick < need));
+                take(mine, rb.fin, r.key, (uint32_t)L, r.bps);
+#ifdef SQ_ROUNDS_PROF
+                if (tid == 0) { _cnt[0] += 64; _cnt[1] += __popcll(__ballot(mine)); }
+#endif
+                push(qcut, nX, pcut, q);
+                push(qcand, nC, pcand, q);
+                push(qsurv, nS, psurv, q);
+                raise(mine, rb.fin);
+            }
+            sq_wave_lds_fence();
+            RPROF(3);
+            const bool end = g >= nunits;
+            const unsigned long long cm = __ballot(cact);
+            const bool cutbusy = cm != 0ull || nX > 0;
+            if (nS >= 64 || (end && !cutbusy && nC == 0 && nS > 0)) {
+                // ---- score: ScoreStems for a wave of runs whose bound reaches the bar ----
+                const double need = bar();
+                const uint32_t m = nS < 64 ? nS : 64; nS -= m;
+                const bool have = (uint32_t)lane < m;
+                const uint32_t q = have ? qsurv[nS + lane] : 0u;
+                uint32_t key = 0, lf = 0; double bps = 0.0, ub = 0.0;
+                if (have) { const SqRunA r = LA[q]; key = r.key; lf = r.lf; bps = r.bps; ub = LB[q].ub; }
+                bool ok = have && !(ub < need);                                 // (the bar may have risen since the run was queued)
+#ifdef SQ_ROUNDS_PROF
+                if (tid == 0) _cnt[2] += __popcll(__ballot(ok));
+#endif
+                double fin = 0.0;
+                const int L = (int)(lf & SQ_RX_LEN);
+                if (ok) {
+                    const int i0 = (int)(key & 0xFFFFu), j0 = (int)(key >> 16) - i0;
+                    fin = sq_stem_finalscore(env, i0, j0, L, bps);
+                    LB[q].fin = fin; LA[q].lf = lf | SQ_RX_FIN;
+                    ok = fin >= minfin;                                         // :751
+                }
+                take(ok, fin, key, (uint32_t)L, bps);
+                raise(ok, fin);
+                RPROF(6);
+                continue;
+            }
+            if (nC >= 64 || (end && !cutbusy && nC > 0)) {
+                // ---- bound: sq_run_upper for a wave of runs that have none ----
+                const double need = bar();
+                const uint32_t m = nC < 64 ? nC : 64; nC -= m;
+                const bool have = (uint32_t)lane < m;
+                const uint32_t q = have ? qcand[nC + lane] : 0u;
+                bool ps2 = false;
+                if (have) {
+                    const SqRunA r = LA[q];
+                    const int L = (int)(r.lf & SQ_RX_LEN), i0 = (int)(r.key & 0xFFFFu), j0 = (int)(r.key >> 16) - i0;
+                    const double ub = upper_of(r.bps, i0, j0, L);
+                    LB[q].ub = ub; LA[q].lf = r.lf | SQ_RX_UB;
+                    ps2 = !(ub < need);
+                }
+                push(qsurv, nS, ps2, q);
+                sq_wave_lds_fence();
+                RPROF(5);
+                continue;
+            }
+            if (cm != 0ull || nX >= 64 || (end && nX > 0)) {
+                // ---- cut: every lane one run, one piece per step ----
+                const double need = bar();
+                if (cm == 0ull) {
+                    const uint32_t m = nX < 64 ? nX : 64; nX -= m;
+                    if ((uint32_t)lane < m) {
+                        cq = qcut[nX + lane];
+                        const SqRunA r = LA[cq];
+                        ci = (int)(r.key & 0xFFFFu); cs = (int)(r.key >> 16); cL = (int)(r.lf & SQ_RX_LEN); ct0 = 0; cfirst = true; cact = true;
+                    }
+                }
+                bool ps2 = false; uint32_t at = 0;
+                if (cact) {
+                    const int i = ci, j = cs - ci, L = cL;
                     // cell t of the run: row i + t, column j - t; masked when either lies on a strand [za0, za1] or [zb0, zb1]
                     const int lo0 = za0 - i, hi0 = za1 - i, lo1 = zb0 - i, hi1 = zb1 - i, lo2 = j - za1, hi2 = j - za0, lo3 = j - zb1, hi3 = j - zb0;
-                    if ((lo0 < L && hi0 >= 0) || (lo1 < L && hi1 >= 0) || (lo2 < L && hi2 >= 0) || (lo3 < L && hi3 >= 0)) {
-                        const uint32_t q = q0 + (uint32_t)u * nthr + tid;
-                        bool first = true;
-                        int t0 = 0;
-                        while (t0 < L) {
-                            int pb = t0;
+                    int pb = -1, plen = 0, t0 = ct0;
+                    while (t0 < L) {                                            // the next piece of at least minlen cells
+                        int b0 = t0;
 #pragma unroll
-                            for (int rep = 0; rep < 4; rep++) {
-                                if (pb >= lo0 && pb <= hi0) pb = hi0 + 1;
-                                if (pb >= lo1 && pb <= hi1) pb = hi1 + 1;
-                                if (pb >= lo2 && pb <= hi2) pb = hi2 + 1;
-                                if (pb >= lo3 && pb <= hi3) pb = hi3 + 1;
+                        for (int rep = 0; rep < 4; rep++) {
+                            if (b0 >= lo0 && b0 <= hi0) b0 = hi0 + 1;
+                            if (b0 >= lo1 && b0 <= hi1) b0 = hi1 + 1;
+                            if (b0 >= lo2 && b0 <= hi2) b0 = hi2 + 1;
+                            if (b0 >= lo3 && b0 <= hi3) b0 = hi3 + 1;
+                        }
+                        if (b0 >= L) { t0 = L; break; }
+                        int pe = L;
+                        if (lo0 > b0 && lo0 < pe) pe = lo0;
+                        if (lo1 > b0 && lo1 < pe) pe = lo1;
+                        if (lo2 > b0 && lo2 < pe) pe = lo2;
+                        if (lo3 > b0 && lo3 < pe) pe = lo3;
+                        t0 = pe;
+                        if (pe - b0 >= minlen) { pb = b0; plen = pe - b0; break; }
+                    }
+                    ct0 = t0;
+                    if (pb < 0) {                                               // no piece left
+                        if (cfirst) { LA[cq].lf = 0u; atomicAdd(&s_ndead, 1u); }
+                        cact = false;
+                    } else {
+                        double pos;
+                        const double bps = run_bps(i + pb, j - pb, plen, pos);
+                        if (!(pos < minbps)) {
+                            at = cq;
+                            bool room = true;
+                            if (!cfirst) {
+                                at = atomicAdd(&s_nlist, 1u);
+                                if (at >= (uint32_t)cap) { a.ctr->cand_ovf = 1; room = false; }
                             }
-                            if (pb >= L) break;
-                            int pe = L;
-                            if (lo0 > pb && lo0 < pe) pe = lo0;
-                            if (lo1 > pb && lo1 < pe) pe = lo1;
-                            if (lo2 > pb && lo2 < pe) pe = lo2;
-                            if (lo3 > pb && lo3 < pe) pe = lo3;
-                            t0 = pe;
-                            const int plen = pe - pb;
-                            if (plen < minlen) continue;
-                            double pos;
-                            const double bps = run_bps(i + pb, j - pb, plen, pos);
-                            if (pos < minbps) continue;
-                            const SqRun piece = {((uint32_t)s << 16) | (uint32_t)(i + pb), (uint32_t)plen, bps};
-                            if (first) { first = false; r = piece; }
-                            else {
-                                const uint32_t at = atomicAdd(&s_nlist, 1u);
-                                if (at < (uint32_t)cap) list[at] = piece;
-                                else a.ctr->cand_ovf = 1;
+                            if (room) {
+                                cfirst = false;
+                                uint32_t lf = (uint32_t)plen;
+                                if (bps >= minbps) {                            // :492 (a piece below it stays for ITS pieces)
+                                    const double ub = upper_of(bps, i + pb, j - pb, plen);
+                                    lf |= SQ_RX_UB;
+                                    LB[at].ub = ub;
+                                    ps2 = !(ub < need);
+                                }
+                                LA[at] = SqRunA{((uint32_t)cs << 16) | (uint32_t)(i + pb), lf, bps};
                             }
                         }
-                        if (first) { r.len = 0; atomicAdd(&s_ndead, 1u); }
-                        list[q] = r;
-                        L = (int)r.len;
                     }
                 }
-                bool ok = L > 0 && r.bps >= minbps;                             // :492
-                // and the bound -- first with every factor at its maximum (ps->ub_lf; the same products in the same order: never
-                // below the exact bound), which needs nothing but the run's bpscore: the list is ordered by bpscore, so once a
-                // strong run has set `need` most of the list ends here without touching the prefix counts in LDS
-                if (ok && ub_lf < INFINITY && r.bps >= 0) ok = !(((((r.bps * ub_of) * ub_lf) * 1.25) * (1.0 + 0x1p-30)) < need);
-                if (ok) {
-                    const int i0 = (int)(r.key & 0xFFFFu), j0 = (int)(r.key >> 16) - i0;
-                    ok = !(upper_of(r.bps, i0, j0, L) < need);
-                }
-                const unsigned long long okm = __ballot(ok);
-                if (okm) {
-                    uint32_t base = 0;
-                    const int leader = __ffsll((long long)okm) - 1;
-                    if (lane == leader) base = atomicAdd(&s_nsurv, (uint32_t)__popcll(okm));
-                    base = (uint32_t)__shfl((int)base, leader);
-                    if (ok) {
-                        const uint32_t pos = (base + (uint32_t)__popcll(okm & ((1ull << lane) - 1ull))) & smask;
-                        s_ring[pos] = q0 + (uint32_t)u * nthr + tid;
-                    }
-                }
+                push(qsurv, nS, ps2, at);
+                sq_wave_lds_fence();
+                RPROF(4);
+                continue;
             }
-            __threadfence_block();
-            __syncthreads();
-            RPROF(3);
-            nl = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;             // (pieces appended by this chunk are met later)
-#pragma unroll
-            for (int u = 0; u < SQ_ROUNDS_CHUNK; u++) {                         // the next chunk's entries: in flight during ScoreStems
-                const uint32_t q = q0 + (uint32_t)(SQ_ROUNDS_CHUNK + u) * nthr + tid;
-                rr[u] = q < nl ? list[q] : SqRun{0u, 0u, 0.0};
-            }
-            const uint32_t tailp = s_nsurv;
-            const bool last = q0 + SQ_ROUNDS_CHUNK * nthr >= nl;
-            while (tailp - head >= (uint32_t)nthr || (last && head != tailp)) {
-                const uint32_t idx = head + tid;
-                const bool have = idx - head < tailp - head;
-#ifdef SQ_ROUNDS_PROF
-                if (tid == 0) _cnt[2] += min(tailp - head, (uint32_t)nthr);
-#endif
-                head += min(tailp - head, (uint32_t)nthr);
-                const SqRun rb = have ? list[s_ring[idx & smask]] : SqRun{0u, 0u, 0.0};
-                const uint32_t key = rb.key;
-                const int L = (int)rb.len;
-                const double bps = rb.bps;
-                const int s = (int)(key >> 16), i0 = (int)(key & 0xFFFFu), j0 = s - i0;
-                bool ok = have;
-                if (ok) {
-                    const unsigned long long sbst = s_best;
-                    if (sbst && upper_of(bps, i0, j0, L) < st_subopt * sq_unord(sbst)) ok = false;
-                }
-                double fin = 0.0;
-#ifdef SQ_ROUNDS_PROF
-                {   // (what keeping finalscores between rounds would save: evaluations the last stem cannot have changed)
-                    const bool clean = ok && round > 0 && s_cross == 0 && (za1 < i0 - 6 || za0 > j0 + 6) && (zb1 < i0 - 6 || zb0 > j0 + 6);
-                    const unsigned long long cm = __ballot(clean);
-                    if (tid == 0) _cnt[1] += 0;
-                    if (lane == 0) atomicAdd(&s_clean, (uint32_t)__popcll(cm));
-                }
-#endif
-                if (ok) {
-                    fin = sq_stem_finalscore(env, i0, j0, L, bps);
-                    ok = fin >= minfin;                                     // :751
-                }
-                if (ok) {
-                    if (!bany || fin > bfin || (fin == bfin && key < bkey)) { if (bany && bfin > sfin) sfin = bfin; bany = 1; bfin = fin; bkey = key; blen = (uint32_t)L; bbps = bps; }
-                    else if (fin > sfin) sfin = fin;
-                }
-                if (__ballot(ok) != 0ull) {
-                    const double wb = sq_wave_max_f64(ok ? fin : -INFINITY);
-                    if (lane == 0) atomicMax(&s_best, sq_ord(wb));
-                }
-            }
-            __syncthreads();                                                    // (the ring's taken entries may be overwritten now)
-            RPROF(4);
+            if (end) break;
         }
-#ifdef SQ_ROUNDS_PROF
-        _cnt[0] += nl;
-#endif
+        int bany = bfin > -INFINITY ? 1 : 0;
+        __threadfence_block();
         // ---- ChooseStems' first element over the block ----
         {
             // the wave's best: the highest finalscore, the smallest key among equals (one lane: keys are distinct); the best of
             // all the OTHER runs beside it (DPP reductions: the butterfly of six values they replace was 54 trips over the LDS
             // crossbar per round)
-            const double wmax = sq_wave_max_f64(bany ? bfin : -INFINITY);
+            const double wmax = sq_wave_max_f64(bfin);
             const bool cand = bany && bfin == wmax;
             const int kmin = sq_wave_min_i32(cand ? (int)bkey : 0x7fffffff);       // (keys < 2^30: SQ_ROUNDS_MAXN)
             const bool win = cand && (int)bkey == kmin;
@@ -526,7 +581,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 bany = 1; bfin = s_wfin[q]; bkey = s_wkey[q]; blen = s_wlen[q]; bbps = s_wbps[q];
             } else if (s_wany[q] && s_wfin[q] > sfin) sfin = s_wfin[q];
         }
-        RPROF(5);
+        RPROF(7);
         if (!bany) { retire(nstems, 0); RPROF_OUT(); return; }      // :1192-1193 no new stem: the structure is final
         if (ra.ties && sfin == bfin) {
             // a pool that may branch: ChooseStems returns every run that reaches the best finalscore and shares a base with the
@@ -542,7 +597,8 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         const int i0 = (int)(bkey & 0xFFFFu), j0 = (int)(bkey >> 16) - i0, len = (int)blen;
         const int k = nstems;
         if (k >= ch.tcap) { if (tid == 0) a.ctr->out_ovf = 1; retire(k, 0); return; }
-        __syncthreads();                                            // (every thread has read the wave bests)
+        // (no barrier here: the pass is over for every wave, nobody reads the state any more, and the wave bests are not
+        // written again before the two barriers below)
         // ---- the child.  First wave: crossing weights, levels when stems cross, the sorted strand list (sq_extend.h);
         // the other waves: partner array and prefix counts -- positions p and above lose the new pairs below p, and
         // separators never pair, so SU stays ----
@@ -558,14 +614,19 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 gst[k] = SqChainStem{i0, j0, len, newcc};           // (the tail reads the stems there; the weights of the others stay in LDS)
                 cio.h_stems[ch.toff + k] = SqStemOut{i0, j0, len, 0, bbps, bfin};
                 s_cross = ac ? 1 : 0;
+                s_best = 0ull;                                      // (the next pass starts without a bar)
             }
             sq_wave_lds_fence();
+            bool regrouped = false;
             if (ac) {
                 // levels: the full rule when the new stem crosses something (crossing weights changed: the order of the first
-                // fit may have); a stem without crossings joins group 0 and only the groups' ranking is taken anew
+                // fit may have); a stem without crossings joins group 0 and only the groups' ranking is taken anew -- the groups
+                // stay what they were, so the NUMBER of levels among any set of strands does, and that number is all ScoreStems
+                // takes from the levels (:728-729): the finalscores kept in the list stay valid.  After the full rule none does
                 if (anycross && __ballot(mycross) == 0ull && ngroups > 0) sq_stem_levels_join(XL, k + 1, ngroups, len, lane);
-                else ngroups = sq_stem_levels_wave(XL, k + 1, lane, &a.ctr->level_ovf);
+                else { ngroups = sq_stem_levels_wave(XL, k + 1, lane, &a.ctr->level_ovf); regrouped = true; }
             }
+            if (lane == 0) s_regroup = regrouped ? 1 : 0;
             sq_rounds_insert_strands(XL, ac, k, strbuf, sidxbuf, nstrand, i0, j0, len, lane);
         }
         if (nwv == 1 || wv > 0) {
@@ -579,6 +640,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         }
         __syncthreads();
         anycross = s_cross != 0;
+        nl0 = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;     // (with the pieces this round appended; nothing is appended outside the pass)
         nstems = k + 1; nstrand += 2;
         if ((double)nstems == ch.maxstems) { retire(nstems, 1); return; }   // :1168-1174 (checked before the next evaluation)
         {
@@ -609,6 +671,6 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         }
         za0 = i0; za1 = i0 + len - 1; zb0 = zb; zb1 = j0;
         __syncthreads();
-        RPROF(6);
+        RPROF(8);
     }
 }
