@@ -297,6 +297,10 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
     b->nseq = d->nseq; b->npset = d->npset; b->njobs = d->njobs; b->maxn = L.maxn; b->ltot = L.ltot;
     b->seq_off.assign(d->seq_off, d->seq_off + d->nseq + 1);
     b->codes.assign(d->codes, d->codes + L.ltot);
+    b->seq_has_sep.assign((size_t)d->nseq, 0);
+    for (int s2 = 0; s2 < d->nseq; s2++)
+        for (int64_t q = d->seq_off[s2]; q < d->seq_off[s2 + 1]; q++)
+            if (d->codes[q] == SQ_CODE_SEP1 || d->codes[q] == SQ_CODE_SEP2) { b->seq_has_sep[(size_t)s2] = 1; break; }
     b->flags.assign(d->flags, d->flags + L.ltot);
     b->reacts_null = d->reacts == nullptr;
     if (d->reacts) b->reacts.assign(d->reacts, d->reacts + L.ltot);   // (NULL: 0.5 everywhere -- sq_host_reacts forms the array if a host path asks)

@@ -310,6 +310,14 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     LoopStats st0, st1;
     sq_pool(b);                                             // (created before any second thread can ask for it)
     // ---- device-chained rounds ----
+    // One launch that covers every chain, the ranking tail on the device, no E / H / N beside it: the tail's kernels are
+    // enqueued right behind the round kernel and the host waits ONCE, for the tail's last word -- the chain's own completion
+    // (capacity flags, the count of finished structures) is looked at afterwards (the wait between the two was 40-65 us of every
+    // fold: a flag's way to the host, then seven launches' way back)
+    struct { bool on = false; uint32_t goal = 0; } deferred;
+    bool any_ehn = false;
+    for (int j = 0; j < b->njobs; j++) any_ehn |= (algos[j] & (uint32_t)(SQ_ALGO_E | SQ_ALGO_H | SQ_ALGO_N)) != 0;
+    static const bool no_defer = getenv("SQ_NO_DEFER_WAIT") != nullptr;
     auto chain_fold = [&](LoopStats &stats) {
         SqLane &ln = b->lane_full;
         hipStream_t st = b->stream;
@@ -389,8 +397,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             if (thr_env) { thr = 64; while (thr * 2 <= thr_env) thr *= 2; }   // (a power of two: the survivor ring is indexed with a mask)
             ra.lds_n = maxn; ra.str_cap = 2 * maxt + 2; ra.tmax = maxt; ra.cell_entries = b->cell_entries;
             ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0; ra.ties = chain_ties ? 1 : 0;
-            while (thr > 64 && sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr).total + 2048 > 158 * 1024) thr /= 2;   // (long sequences: the survivor ring gives way)
-            if (sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr).total + 2048 > 158 * 1024) rounds_ok = false;
+            ra.su = 0;
+            for (int j : jobs) if (b->seq_has_sep[(size_t)b->job_seq[j]]) { ra.su = 1; break; }
+            while (thr > 64 && sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr, ra.su).total + 2048 > 158 * 1024) thr /= 2;   // (long sequences: the survivor ring gives way)
+            if (sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr, ra.su).total + 2048 > 158 * 1024) rounds_ok = false;
         }
         if (!rounds_ok && chain_ties) {                       // (the launched rounds do not look for ties: the pools take these jobs)
             for (int j : jobs) tied_jobs.push_back(j);
@@ -410,7 +420,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         const double tr0 = now_s();
         std::vector<std::pair<int, double>> round_t;
         if (rounds_ok) {
-            const SqRoundsLds lo = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr);
+            const SqRoundsLds lo = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr, ra.su);
             {
                 if (lo.total > 60 * 1024) sq_max_dynamic_lds((const void *)sq_rounds_kernel, 158 * 1024);   // (the kernel has static LDS too: 160 KB in all)
                 {
@@ -422,6 +432,15 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 hipLaunchKernelGGL(sq_chain_done_kernel, dim3(1), dim3(1), 0, st, io, scan, b->chain, seq);
                 launched = 1;
                 b->last_paths |= 4;
+                if (dev_tail && !chain_ties && !b->prof_on && !any_ehn && !no_defer && next_job == chain_jobs.size() &&
+                    nfin_goal == (uint32_t)S) {
+                    deferred.on = true; deferred.goal = nfin_goal;
+                    if (timing) fprintf(stderr, "[sq_fold] persistent rounds: the wait is deferred behind the device tail\n");
+                    stats.nrounds += 1;
+                    stats.tround += now_s() - tr0;
+                    return;
+                }
+                if (timing) fprintf(stderr, "[sq_fold] persistent rounds: waiting (dev_tail %d ties %d prof %d pending %d next_job %zu of %zu goal %u S %d)\n", (int)dev_tail, (int)chain_ties, (int)b->prof_on, pending != nullptr, next_job, chain_jobs.size(), nfin_goal, S);
                 while (*flag != seq) {
                     if ((++spins & poll_mask) == 0) {
                         const hipError_t q = hipStreamQuery(st);
@@ -849,6 +868,17 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                                b->d_fin, b->d_fin_stems, b->d_fin_ctr, b->fin_cap, b->fin_stem_cap);
         }
         if (!rt) rt = sq_tail_device(b, o, ref_off, ref_pairs, has_ref);
+        if (deferred.on) {
+            // (the tail's last word is behind the round kernel's in stream order: after an error of the tail the stream is
+            // drained first)
+            if (rt) hipStreamSynchronize(b->stream);
+            std::atomic_thread_fence(std::memory_order_acquire);
+            const SqCounters ctr = *b->lane_full.h_ctr;
+            if (ctr.cand_ovf) { sq_set_error("candidate capacity exceeded (raise cand_per_nt)"); return -3; }
+            if (ctr.out_ovf) { sq_set_error("stem capacity of a chained structure exceeded"); return -3; }
+            if (ctr.level_ovf) { sq_set_error("more than 64 pseudoknot levels"); return -3; }
+            if (*b->chain.h_nfin != deferred.goal) { sq_set_error("persistent rounds left structures unfinished"); return 2; }
+        }
         // the structures the device drivers left in the log as host lists (the host tail's input)
         auto collect_device_lists = [&]() -> int {
             if (dev_algos) {

@@ -145,6 +145,7 @@ struct sq_batch {
     mutable std::once_flag reacts_once;
     std::vector<int32_t> seq_off, rbp_off, rbps, job_seq, job_pset;
     std::vector<uint8_t> codes, flags;
+    std::vector<char> seq_has_sep;            // per sequence: it holds a chain separator (the kernels that keep prefix counts of separators skip them otherwise)
     std::vector<double> reacts;
     std::vector<double> rftab;                // host-libm reactfactor tables, 256 doubles each (SqJob::rf_idx)
     std::vector<uint8_t> ridx;                // per position: reactivity level index (SqDevCtx::ridx)

@@ -31,7 +31,9 @@ struct SqRunB {
 #define SQ_RX_UB 0x10000u
 #define SQ_RX_FIN 0x20000u
 
-#define SQ_RQ_CAP 128              // entries of each of a wave's three work queues (cut / bound / score): a queue is served when it holds 64
+#define SQ_ROUNDS_SDF_LDS 128      // entries of the distance-factor table kept in LDS
+#define SQ_RQ_CAP 192              // entries of each of a wave's three work queues (cut / bound / score): a queue is served when it holds 64
+                                   // (a step of the stream adds up to 128)
 #define SQ_RQ_WORDS (3 * SQ_RQ_CAP)
 #define SQ_ROUNDS_STAGE 128        // runs a wave of the first round's scan stages in LDS before it appends them
 #define SQ_ROUNDS_MAXN 8192        // longest sequence whose per-position arrays the kernel keeps in LDS (9 bytes each)
@@ -44,21 +46,22 @@ struct SqRoundsArgs {
     int32_t cell_entries;   // doubles of the cell table (largest (classes x reactivity levels)^2 of the batch, padded)
     int32_t bound;          // branch and bound on the finalscore (0: every survivor of :492 is scored)
     int32_t ctx_min;        // strands from which a non-crossing structure's sweep is answered from the context tables (0: never)
+    int32_t su;             // some sequence of the launch holds a chain separator: the blocks keep the separators' prefix counts (2 bytes per position)
     int32_t ties;           // the structures belong to pools that MAY branch (poollim > 1, range factor 1.0): a round in which a second
                             // run reaches the best finalscore ends the structure unfinished (h_fin bit 62) -- the device pools redo its job
 };
 
 // dynamic LDS of a block: per-position arrays, free-position words of the first round's scan, cell table, the strand
 // list + stem indices, skip pointers, the stems with their crossing weights, and one region shared by the phases that
-// never overlap (scan staging / bucket counters / level scratch of the extension / the waves' work queues of the list pass)
+// never overlap (scan staging / bucket counters / the waves' work queues of the list pass)
 struct SqRoundsLds {
     int np, fbh;
-    int off_P, off_U, off_SU, off_E, off_ci, off_code, off_fg, off_cell, off_str, off_sidx, off_skip, off_stems, off_union;
+    int off_P, off_U, off_SU, off_E, off_ci, off_code, off_fg, off_cell, off_str, off_sidx, off_skip, off_stems, off_tab, off_lvl, off_union;
     int t8;                 // stems the stem arrays hold (tmax rounded up to 8)
     int surv_cap;           // (unused)
     size_t total;
 };
-__host__ __device__ inline SqRoundsLds sq_rounds_lds(int lds_n, int str_cap, int tmax, int cell_entries, int threads)
+__host__ __device__ inline SqRoundsLds sq_rounds_lds(int lds_n, int str_cap, int tmax, int cell_entries, int threads, int su = 1)
 {
     SqRoundsLds L;
     L.np = (lds_n + 8) & ~7;                                   // arrays of n + 1 entries
@@ -66,7 +69,7 @@ __host__ __device__ inline SqRoundsLds sq_rounds_lds(int lds_n, int str_cap, int
     int o = 0;
     L.off_P = o; o += 2 * L.np;
     L.off_U = o; o += 2 * L.np;
-    L.off_SU = o; o += 2 * L.np;
+    L.off_SU = o; o += su ? 2 * L.np : 0;
     L.off_E = o; o += L.np;
     L.off_ci = o; o += L.np;
     L.off_code = o; o += L.np;
@@ -81,12 +84,13 @@ __host__ __device__ inline SqRoundsLds sq_rounds_lds(int lds_n, int str_cap, int
     L.t8 = (tmax + 7) & ~7;
     L.off_stems = o; o += 11 * L.t8 + 64 * 4;                  // the structure's stems: crossing weight (int32), i, j, len (int16), level group (uint8); the groups' sizes
     o = (o + 15) & ~15;
+    L.off_tab = o; o += 8 * (SQ_ROUNDS_SDF_LDS + SQ_MAXLEVELS + 1 + 1);   // the head of the distance-factor table and the order factors (ScoreStems reads them at the end of a chain of dependent loads)
+    L.off_lvl = o; o += 4 * L.t8 + 64 + 16;                    // level scratch of the extension (order, level, rank): its own region -- the first
+    o = (o + 15) & ~15;                                        // wave extends the structure while the others are in the next round's pass
     L.off_union = o;
     L.surv_cap = 0;
     size_t u = (size_t)(threads / 64) * SQ_RQ_WORDS * 4;       // the waves' work queues of the list pass (list indices)
-    const size_t ext = (size_t)3 * L.t8 + 64 + 16;            // level scratch of the extension: order, level, rank
     const size_t stage = (size_t)(threads / 64) * (SQ_ROUNDS_STAGE * 8 + 16);
-    if (ext > u) u = ext;
     if (u < 2048) u = 2048;                                    // (the first round's bucket counters: 2 x 256 words)
     if (stage > u) u = stage;
     L.total = (size_t)o + ((u + 15) & ~(size_t)15);

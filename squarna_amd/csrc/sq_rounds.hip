@@ -114,7 +114,8 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     extern __shared__ __attribute__((aligned(16))) char rd_dyn[];
     __shared__ int s_wave_u[SQ_ROUNDS_THREADS / 64], s_wave_s[SQ_ROUNDS_THREADS / 64];
     __shared__ uint32_t s_nlist, s_ndead;
-    __shared__ int s_regroup;
+    __shared__ int s_regroup, s_ready;
+    __shared__ uint32_t s_unit;
     __shared__ SqCellTmp s_ctmp;
     __shared__ unsigned long long s_best;
     __shared__ double s_wfin[SQ_ROUNDS_THREADS / 64], s_wbps[SQ_ROUNDS_THREADS / 64], s_wsec[SQ_ROUNDS_THREADS / 64];
@@ -130,8 +131,8 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     long long _pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
     long long _cnt[4] = {0, 0, 0, 0};       // entries streamed, finalscores taken from the list, runs scored (first wave), rounds
 #define RPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)
-#define RPROF_OUT() do { if (tid == 0 && (b % 97) == 0) printf("rounds block %d n=%d rounds %lld | us: setup %.1f scan %.1f order %.1f stream %.1f cut %.1f bound %.1f score %.1f pick %.1f ext %.1f total %.1f | wave 0: streamed %lld kept %lld scored %lld\n", \
-        b, n, _cnt[3], _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, _pt[6] * 0.01, _pt[7] * 0.01, _pt[8] * 0.01, (wall_clock64() - _t00) * 0.01, _cnt[0], _cnt[1], _cnt[2]); } while (0)
+#define RPROF_OUT() do { if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d n=%d rounds %lld | us: setup %.1f scan %.1f order %.1f stream %.1f cut %.1f bound %.1f score %.1f pick %.1f ext %.1f between %.1f total %.1f | wave 0: streamed %lld kept %lld scored %lld\n", \
+        b, wv, n, _cnt[3], _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, _pt[6] * 0.01, _pt[7] * 0.01, _pt[8] * 0.01, _pt[9] * 0.01, (wall_clock64() - _t00) * 0.01, _cnt[0], _cnt[1], _cnt[2]); } while (0)
 #else
 #define RPROF(k) do {} while (0)
 #define RPROF_OUT() do {} while (0)
@@ -142,10 +143,10 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     const SqJob jb = c.jobs[st.job];
     const SqPsetDev *ps = c.psets + jb.pset;
     const int n = jb.n;
-    const SqRoundsLds Lo = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, nthr);
+    const SqRoundsLds Lo = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, nthr, ra.su);
     int16_t *const P = reinterpret_cast<int16_t *>(rd_dyn + Lo.off_P);
     int16_t *const U = reinterpret_cast<int16_t *>(rd_dyn + Lo.off_U);
-    int16_t *const SU = reinterpret_cast<int16_t *>(rd_dyn + Lo.off_SU);
+    int16_t *const SU = ra.su ? reinterpret_cast<int16_t *>(rd_dyn + Lo.off_SU) : nullptr;   // (no separator in the launch: nothing lies between chains)
     uint8_t *const E = reinterpret_cast<uint8_t *>(rd_dyn + Lo.off_E);
     uint8_t *const l_ci = reinterpret_cast<uint8_t *>(rd_dyn + Lo.off_ci);
     uint8_t *const l_code = reinterpret_cast<uint8_t *>(rd_dyn + Lo.off_code);
@@ -191,11 +192,11 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
             __syncthreads();
             int pu = base_u + __popcll(mu & below), pS = base_s + __popcll(ms & below);
             for (int q = 0; q < wv; q++) { pu += s_wave_u[q]; pS += s_wave_s[q]; }
-            if (p < n) { U[p] = (int16_t)pu; SU[p] = (int16_t)pS; }
+            if (p < n) { U[p] = (int16_t)pu; if (SU) SU[p] = (int16_t)pS; }
             for (int q = 0; q < nwv; q++) { base_u += s_wave_u[q]; base_s += s_wave_s[q]; }
             __syncthreads();
         }
-        if (tid == 0) { U[n] = (int16_t)base_u; SU[n] = (int16_t)base_s; }
+        if (tid == 0) { U[n] = (int16_t)base_u; if (SU) SU[n] = (int16_t)base_s; }
         __syncthreads();
     };
     prefix_counts();
@@ -243,7 +244,12 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     const double ps_lb = ps->loopbonus, ps_bw = ps->bracketweight, ps_dc = ps->distcoef;
     const int ps_bwint = ps->bw_integral, ps_sdflen = ps->sdf_len;
     const double *const ps_sdf = c.sdftab + ps->sdf_off;
-    const double *const ps_of = ps->oftab;
+    // (the two tables ScoreStems reads last, at the end of its chain of dependent loads: in LDS)
+    double *const l_sdf = reinterpret_cast<double *>(rd_dyn + Lo.off_tab), *const l_of = l_sdf + SQ_ROUNDS_SDF_LDS;
+    const int l_sdflen = ps_sdflen < SQ_ROUNDS_SDF_LDS ? ps_sdflen : SQ_ROUNDS_SDF_LDS;
+    for (int k = tid; k < l_sdflen; k += nthr) l_sdf[k] = ps_sdf[k];
+    for (int k = tid; k <= SQ_MAXLEVELS; k += nthr) l_of[k] = ps->oftab[k];
+    const double *const ps_of = l_of;
     const double ub_of = ps->ub_of, ub_lf = ra.bound ? ps->ub_lf : INFINITY;
     // (a width-1 pool only ever uses ChooseStems' FIRST element -- the highest finalscore, the smallest key among equals: a run
     // whose bound is below the best finalscore seen so far can neither be it nor tie with it.  The bar is the best itself, not
@@ -288,20 +294,19 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 LA[start[bk] + atomicAdd(&hist[bk], 1u)] = SqRunA{r.key, r.len, r.bps};
             }
         }
-        if (tid == 0) { s_ndead = 0; s_best = 0ull; s_regroup = 0; }
+        if (tid == 0) { s_ndead = 0; s_best = 0ull; s_regroup = 0; s_ready = 0; s_unit = 0u; }
         __threadfence_block();
         __syncthreads();
     }
     RPROF(2);
 
-    // the structure's stems with their crossing weights (:121-124) stay in LDS between rounds; the level rule's scratch
-    // shares the work queues' region
+    // the structure's stems with their crossing weights (:121-124) stay in LDS between rounds
     SqExtendLds XL;
     XL.cc = reinterpret_cast<int32_t *>(rd_dyn + Lo.off_stems);
     XL.i = reinterpret_cast<int16_t *>(XL.cc + Lo.t8); XL.j = XL.i + Lo.t8; XL.len = XL.j + Lo.t8;
     XL.gsize = reinterpret_cast<int32_t *>(XL.len + Lo.t8);      // (groups and their sizes stay too: a stem that crosses nothing joins group 0)
     XL.grp = reinterpret_cast<uint8_t *>(XL.gsize + 64);
-    XL.ord = reinterpret_cast<int16_t *>(uni);
+    XL.ord = reinterpret_cast<int16_t *>(rd_dyn + Lo.off_lvl);
     XL.lvl = reinterpret_cast<uint8_t *>(XL.ord + Lo.t8); XL.rank = XL.lvl + Lo.t8;
 
     // the bound on a run's finalscore (sq_cellrun.h: exact tetraloop factor, loop bonuses only where they can apply)
@@ -315,53 +320,55 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     uint32_t *const qcut = reinterpret_cast<uint32_t *>(uni) + (size_t)wv * SQ_RQ_WORDS, *const qcand = qcut + SQ_RQ_CAP, *const qsurv = qcand + SQ_RQ_CAP;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t nl0 = s_nlist;                                          // entries of the list when the pass starts (the same for every wave)
+    int roundno = 0;
+    bool compact = false;                                           // dead entries leave the list before this round's pass
 
     for (;;) {
 #ifdef SQ_ROUNDS_PROF
         _cnt[3]++;
 #endif
         // ---- dead entries out, in place, order kept, when they are a third of the list or the list runs out of room ----
-        {
-            const uint32_t nd = s_ndead;
-            if (nd * 3 > nl0 || nl0 + ((nl0 - nd) >> 1) + 64 > (uint32_t)cap) {
-                __syncthreads();
-                uint32_t base = 0;
-                for (uint32_t q0 = 0; q0 < nl0; q0 += nthr) {
-                    const uint32_t q = q0 + tid;
-                    SqRunA ra_ = {0u, 0u, 0.0}; SqRunB rb_ = {0.0, 0.0};
-                    if (q < nl0) { ra_ = LA[q]; rb_ = LB[q]; }
-                    const bool live = (ra_.lf & SQ_RX_LEN) != 0;
-                    const unsigned long long m = __ballot(live);
-                    if (lane == 0) s_wave_u[wv] = __popcll(m);
-                    __syncthreads();                                   // (the chunk is read: its entries and the ones below may be overwritten)
-                    uint32_t off = base + (uint32_t)__popcll(m & lt_mask);
-                    for (int w = 0; w < wv; w++) off += (uint32_t)s_wave_u[w];
-                    if (live && off != q) { LA[off] = ra_; LB[off] = rb_; }
-                    for (int w = 0; w < nwv; w++) base += (uint32_t)s_wave_u[w];
-                    __threadfence_block();
-                    __syncthreads();
-                }
-                nl0 = base;
-                if (tid == 0) { s_nlist = base; s_ndead = 0; }
+        if (compact) {
+            __syncthreads();                                           // (the first wave is through with the structure: every wave takes part)
+            uint32_t base = 0;
+            for (uint32_t q0 = 0; q0 < nl0; q0 += nthr) {
+                const uint32_t q = q0 + tid;
+                SqRunA ra_ = {0u, 0u, 0.0}; SqRunB rb_ = {0.0, 0.0};
+                if (q < nl0) { ra_ = LA[q]; rb_ = LB[q]; }
+                const bool live = (ra_.lf & SQ_RX_LEN) != 0;
+                const unsigned long long m = __ballot(live);
+                if (lane == 0) s_wave_u[wv] = __popcll(m);
+                __syncthreads();                                       // (the chunk is read: its entries and the ones below may be overwritten)
+                uint32_t off = base + (uint32_t)__popcll(m & lt_mask);
+                for (int w = 0; w < wv; w++) off += (uint32_t)s_wave_u[w];
+                if (live && off != q) { LA[off] = ra_; LB[off] = rb_; }
+                for (int w = 0; w < nwv; w++) base += (uint32_t)s_wave_u[w];
+                __threadfence_block();
                 __syncthreads();
             }
+            nl0 = base;
+            if (tid == 0) { s_nlist = base; s_ndead = 0; }
+            __syncthreads();
         }
         RPROF(2);
 
-        // ---- one pass over the list.  Every wave streams its share of the entries (units of 64, dealt round robin) and sorts
-        // them into three work queues of its own; a queue is served when it holds a full wave of work, so the rare steps run with
-        // all lanes busy (until round 5 they ran inside the stream, a handful of lanes at a time, and were most of a round):
+        // ---- one pass over the list.  The waves take the entries in units of 64 (two at a time, from a counter in LDS) and
+        // sort them into three work queues of their own; a queue is served when it holds a full wave of work, so the rare steps
+        // run with all lanes busy (until round 5 they ran inside the stream, a handful of lanes at a time, and were most of a
+        // round):
         //   * cut      the run meets a strand of the new stem: its pieces, outer -> inner; the first live piece takes the
         //              entry, the others go to the end of the list (and are handled here, by the lane that made them);
         //   * bound    no valid bound: sq_run_upper, kept in the entry;
         //   * score    the bound reaches the best finalscore so far: ScoreStems, kept in the entry.
         // An entry whose finalscore is still valid costs a compare.  No block barrier inside the pass: the waves only share the
-        // best finalscore so far (an atomic maximum in LDS) and the end of the list.  The stream is straight-line code: every
-        // test is evaluated for every entry and combined without branches.
+        // unit counter, the best finalscore so far (an atomic maximum in LDS) and the end of the list.  The stream is
+        // straight-line code: every test is evaluated for every entry as integer arithmetic and combined without branches.
+        // The first wave joins late: it is still putting the last stem into the structure (levels, strands, skip pointers), which
+        // only ScoreStems reads -- the score step waits for s_ready.
         const SqStrand *const S = strbuf;
         const SqStemsEnv env = {S, s_skip, nstrand, true, P, U, SU, l_code, n, false, nullptr, nullptr, nullptr, 0,
-                                ps_lb, ps_bw, ps_dc, ps_bwint, ps_sdflen, ps_sdf, ps_of, a.ctr};
-        const int regroup = s_regroup != 0 ? 1 : 0;                // the last stem changed the level groups: no finalscore is kept
+                                ps_lb, ps_bw, ps_dc, ps_bwint, ps_sdflen, ps_sdf, ps_of, a.ctr, l_sdf, l_sdflen};
+        const int rgmask = s_regroup != 0 ? 0 : -1;                // (0: the last stem changed the level groups -- no finalscore is kept)
         double bfin = -INFINITY, bbps = 0.0; uint32_t bkey = 0xFFFFFFFFu, blen = 0;   // (bfin == -inf: none yet; real finalscores are finite)
         double sfin = -INFINITY;                                    // the best finalscore of the OTHER runs (ties of a pool that may branch)
         auto take = [&](bool valid, double fin, uint32_t key, uint32_t L, double bps) {   // branch-free
@@ -387,49 +394,124 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
             if (p) qb[cnt + (uint32_t)__popcll(m & lt_mask)] = v;
             cnt += (uint32_t)__popcll(m);
         };
+        auto push2 = [&](uint32_t *qb, uint32_t &cnt, bool p0, uint32_t v0, bool p1, uint32_t v1) {   // two units at once; most find nothing
+            const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+            if ((m0 | m1) != 0ull) {
+                const uint32_t c0 = (uint32_t)__popcll(m0);
+                if (p0) qb[cnt + (uint32_t)__popcll(m0 & lt_mask)] = v0;
+                if (p1) qb[cnt + c0 + (uint32_t)__popcll(m1 & lt_mask)] = v1;
+                cnt += c0 + (uint32_t)__popcll(m1);
+            }
+        };
         const uint32_t nunits = (nl0 + 63u) >> 6;
-        uint32_t g = (uint32_t)wv;
-        SqRunA ca = {0u, 0u, 0.0}; SqRunB cb = {0.0, 0.0};          // the next unit's entries, on their way
-        if (g < nunits && g * 64 + lane < nl0) { ca = LA[g * 64 + lane]; cb = LB[g * 64 + lane]; }
+        auto grab = [&]() -> uint32_t {                             // the next two units nobody has taken yet
+            uint32_t v = 0u;
+            if (lane == 0) v = atomicAdd(&s_unit, 2u);
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        };
+        uint32_t g = grab();
+        // the entries of the units in hand, on their way
+        SqRunA ca0 = {0u, 0u, 0.0}, ca1 = {0u, 0u, 0.0}; SqRunB cb0 = {0.0, 0.0}, cb1 = {0.0, 0.0};
+        auto fetch = [&](uint32_t gg) {
+            const uint32_t q0 = gg * 64 + lane, q1 = q0 + 64;
+            ca0.lf = 0u; ca1.lf = 0u;
+            if (q0 < nl0) { ca0 = LA[q0]; cb0 = LB[q0]; }
+            if (q1 < nl0) { ca1 = LA[q1]; cb1 = LB[q1]; }
+        };
+        if (g < nunits) fetch(g);
+#ifdef SQ_ROUNDS_PROF
+        { RPROF(9); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long _n = wall_clock64(); _pt[8] += _n - _t; _t = _n; }   // (the first fetch's latency, booked as ext)
+#endif
         bool cact = false, cfirst = false; uint32_t cq = 0; int ci = 0, cs = 0, cL = 0, ct0 = 0;   // the run this lane is cutting
+        bool struct_ready = nwv == 1 || wv == 0;                    // (the first wave made the structure itself)
+        // what the stream finds out about one entry: cut / needs a bound / needs ScoreStems / holds a finalscore that counts
+        struct Cls { bool cut, cand, surv, mine; };
+        auto classify = [&](const SqRunA &r, const SqRunB &rb, uint32_t q, double need) -> Cls {
+            const int L = (int)(r.lf & SQ_RX_LEN);
+            const int i = (int)(r.key & 0xFFFFu), j = (int)(r.key >> 16) - i, sa = i + L - 1, sb = j - L + 1;
+            // strand [z0, z1] meets [lo, hi]  <=>  (hi - z0 | z1 - lo) >= 0: the sign bit of the AND over several tests is clear when
+            // one of them holds (positions are small: nothing overflows; "no stem yet" is a pair of empty intervals)
+#define SQ_OV(z0, z1, lo, hi) (((hi) - (z0)) | ((z1) - (lo)))
+            // rows [i, sa] or columns [sb, j] meet a strand of the new stem: the run is cut.  A strand within six positions of
+            // the run's span: the finalscore is void; within six of its four ends: the bound too
+            const int nocut = SQ_OV(za0, za1, i, sa) & SQ_OV(zb0, zb1, i, sa) & SQ_OV(za0, za1, sb, j) & SQ_OV(zb0, zb1, sb, j);
+            const int nofd = SQ_OV(za0, za1, i - 6, j + 6) & SQ_OV(zb0, zb1, i - 6, j + 6) & rgmask;
+            const int noud = SQ_OV(za0, za1, i - 6, sa + 6) & SQ_OV(zb0, zb1, i - 6, sa + 6) & SQ_OV(za0, za1, sb - 6, j + 6) & SQ_OV(zb0, zb1, sb - 6, j + 6);
+#undef SQ_OV
+            const uint32_t fdm = ~(uint32_t)(nofd >> 31), udm = ~(uint32_t)(noud >> 31);   // all ones: void
+            const bool live = L > 0;                                            // (lanes beyond the list hold length 0)
+            Cls c;
+            c.cut = live & (nocut >= 0);
+            const uint32_t lf = r.lf & ~((fdm & SQ_RX_FIN) | (udm & (SQ_RX_UB | SQ_RX_FIN)));
+            const bool stay = live & !c.cut;
+            if (stay & (lf != r.lf)) LA[q].lf = lf;
+            const bool p492 = stay & (r.bps >= minbps);                         // :492
+            c.mine = p492 & ((lf & SQ_RX_FIN) != 0u) & (rb.fin >= minfin);      // :751
+            c.surv = p492 & ((lf & (SQ_RX_FIN | SQ_RX_UB)) == SQ_RX_UB) & !(rb.ub < need);
+            c.cand = p492 & ((lf & (SQ_RX_FIN | SQ_RX_UB)) == 0u);
+            return c;
+        };
+        int cpb = 0, cplen = 0;                                     // the piece of that run which is handled next
+        // the next piece of at least minlen cells of the run in hand, from cell ct0 on -- cell t of the run: row i + t, column
+        // j - t; masked when either lies on a strand [za0, za1] or [zb0, zb1].  None left: the run is through (and dead, if no
+        // piece of it stayed in the list)
+        auto find_piece = [&]() {
+            const int i = ci, j = cs - ci, L = cL;
+            const int lo0 = za0 - i, hi0 = za1 - i, lo1 = zb0 - i, hi1 = zb1 - i, lo2 = j - za1, hi2 = j - za0, lo3 = j - zb1, hi3 = j - zb0;
+            int pb = -1, plen = 0, t0 = ct0;
+            while (t0 < L) {
+                int b0 = t0;
+#pragma unroll
+                for (int rep = 0; rep < 4; rep++) {
+                    if (b0 >= lo0 && b0 <= hi0) b0 = hi0 + 1;
+                    if (b0 >= lo1 && b0 <= hi1) b0 = hi1 + 1;
+                    if (b0 >= lo2 && b0 <= hi2) b0 = hi2 + 1;
+                    if (b0 >= lo3 && b0 <= hi3) b0 = hi3 + 1;
+                }
+                if (b0 >= L) { t0 = L; break; }
+                int pe = L;
+                if (lo0 > b0 && lo0 < pe) pe = lo0;
+                if (lo1 > b0 && lo1 < pe) pe = lo1;
+                if (lo2 > b0 && lo2 < pe) pe = lo2;
+                if (lo3 > b0 && lo3 < pe) pe = lo3;
+                t0 = pe;
+                if (pe - b0 >= minlen) { pb = b0; plen = pe - b0; break; }
+            }
+            ct0 = t0; cpb = pb; cplen = plen;
+            if (pb < 0) {
+                if (cfirst) { LA[cq].lf = 0u; atomicAdd(&s_ndead, 1u); }
+                cact = false;
+            }
+        };
+        RPROF(9);
         for (;;) {
-            // ---- the stream: units of 64 entries until a queue holds a wave of work or the list ends ----
+            // ---- the stream: two units of 64 entries per step until a queue holds a wave of work or the list ends ----
             while (g < nunits && (nX | nC | nS) < 64u) {
                 const double need = bar();
-                const uint32_t q = g * 64 + lane;
-                const SqRunA r = ca; const SqRunB rb = cb;
-                g += (uint32_t)nwv;
-                ca.lf = 0u;
-                if (g < nunits && g * 64 + lane < nl0) { ca = LA[g * 64 + lane]; cb = LB[g * 64 + lane]; }
-                const int L = (int)(r.lf & SQ_RX_LEN);
-                const int i = (int)(r.key & 0xFFFFu), j = (int)(r.key >> 16) - i, sa = i + L - 1, sb = j - L + 1;
-#define SQ_OV(z0, z1, lo, hi) ((int)((z0) <= (hi)) & (int)((z1) >= (lo)))
-                // rows [i, sa] or columns [sb, j] meet a strand of the new stem: the run is cut.  A strand within six positions of
-                // the run's span: the finalscore is void; within six of its four ends: the bound too
-                const int cutv = SQ_OV(za0, za1, i, sa) | SQ_OV(zb0, zb1, i, sa) | SQ_OV(za0, za1, sb, j) | SQ_OV(zb0, zb1, sb, j);
-                const int fdirty = regroup | SQ_OV(za0, za1, i - 6, j + 6) | SQ_OV(zb0, zb1, i - 6, j + 6);
-                const int udirty = SQ_OV(za0, za1, i - 6, sa + 6) | SQ_OV(zb0, zb1, i - 6, sa + 6) | SQ_OV(za0, za1, sb - 6, j + 6) | SQ_OV(zb0, zb1, sb - 6, j + 6);
-#undef SQ_OV
-                const bool live = L > 0;                                        // (lanes beyond the list hold length 0)
-                const bool pcut = live & (cutv != 0);
-                const uint32_t lf = r.lf & ~(fdirty ? SQ_RX_FIN : 0u) & ~(udirty ? (SQ_RX_UB | SQ_RX_FIN) : 0u);
-                const bool stay = live & !pcut;
-                if (stay & (lf != r.lf)) LA[q].lf = lf;
-                const bool p492 = stay & (r.bps >= minbps);                     // :492
-                const bool hasfin = p492 & ((lf & SQ_RX_FIN) != 0u);
-                const bool mine = hasfin & (rb.fin >= minfin);                  // :751
-                const bool psurv = p492 & ((lf & (SQ_RX_FIN | SQ_RX_UB)) == SQ_RX_UB) & !(rb.ub < need);
-                // (no bound yet: first with every factor at its maximum, which needs nothing but the bpscore)
-                const double quick = (((r.bps * ub_of) * ub_lf) * 1.25) * (1.0 + 0x1p-30);
-                const bool pcand = p492 & ((lf & (SQ_RX_FIN | SQ_RX_UB)) == 0u) & !((ub_lf < INFINITY) & (r.bps >= 0) & (quick < need));
-                take(mine, rb.fin, r.key, (uint32_t)L, r.bps);
+                const uint32_t q0 = g * 64 + lane, q1 = q0 + 64;
+                const SqRunA r0 = ca0, r1 = ca1; const SqRunB rb0 = cb0, rb1 = cb1;
+                g = grab();
+                if (g < nunits) fetch(g);
+                const Cls c0 = classify(r0, rb0, q0, need), c1 = classify(r1, rb1, q1, need);
+                bool d0 = c0.cand, d1 = c1.cand;
+                if (__ballot(d0 | d1) != 0ull) {
+                    // (no bound yet: first with every factor at its maximum, which needs nothing but the bpscore)
+                    const double k0 = (((r0.bps * ub_of) * ub_lf) * 1.25) * (1.0 + 0x1p-30), k1 = (((r1.bps * ub_of) * ub_lf) * 1.25) * (1.0 + 0x1p-30);
+                    d0 = d0 & !((ub_lf < INFINITY) & (r0.bps >= 0) & (k0 < need));
+                    d1 = d1 & !((ub_lf < INFINITY) & (r1.bps >= 0) & (k1 < need));
+                }
+                if (__ballot(c0.mine | c1.mine) != 0ull) {
+                    take(c0.mine, rb0.fin, r0.key, r0.lf & SQ_RX_LEN, r0.bps);
+                    take(c1.mine, rb1.fin, r1.key, r1.lf & SQ_RX_LEN, r1.bps);
+                    const double f0 = c0.mine ? rb0.fin : -INFINITY, f1 = c1.mine ? rb1.fin : -INFINITY;
+                    raise(c0.mine | c1.mine, f0 > f1 ? f0 : f1);
+                }
 #ifdef SQ_ROUNDS_PROF
-                if (tid == 0) { _cnt[0] += 64; _cnt[1] += __popcll(__ballot(mine)); }
+                if (lane == 0) { _cnt[0] += 128; _cnt[1] += __popcll(__ballot(c0.mine)) + __popcll(__ballot(c1.mine)); }
 #endif
-                push(qcut, nX, pcut, q);
-                push(qcand, nC, pcand, q);
-                push(qsurv, nS, psurv, q);
-                raise(mine, rb.fin);
+                push2(qcut, nX, c0.cut, q0, c1.cut, q1);
+                push2(qcand, nC, d0, q0, d1, q1);
+                push2(qsurv, nS, c0.surv, q0, c1.surv, q1);
             }
             sq_wave_lds_fence();
             RPROF(3);
@@ -438,6 +520,11 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
             const bool cutbusy = cm != 0ull || nX > 0;
             if (nS >= 64 || (end && !cutbusy && nC == 0 && nS > 0)) {
                 // ---- score: ScoreStems for a wave of runs whose bound reaches the bar ----
+                if (!struct_ready) {                                            // (the first wave is still putting the last stem in)
+                    while (__atomic_load_n(&s_ready, __ATOMIC_RELAXED) < roundno) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    struct_ready = true;
+                }
                 const double need = bar();
                 const uint32_t m = nS < 64 ? nS : 64; nS -= m;
                 const bool have = (uint32_t)lane < m;
@@ -446,7 +533,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 if (have) { const SqRunA r = LA[q]; key = r.key; lf = r.lf; bps = r.bps; ub = LB[q].ub; }
                 bool ok = have && !(ub < need);                                 // (the bar may have risen since the run was queued)
 #ifdef SQ_ROUNDS_PROF
-                if (tid == 0) _cnt[2] += __popcll(__ballot(ok));
+                if (lane == 0) _cnt[2] += __popcll(__ballot(ok));
 #endif
                 double fin = 0.0;
                 const int L = (int)(lf & SQ_RX_LEN);
@@ -481,7 +568,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 continue;
             }
             if (cm != 0ull || nX >= 64 || (end && nX > 0)) {
-                // ---- cut: every lane one run, one piece per step ----
+                // ---- cut: every lane one run, one piece per step; a run leaves with its last piece ----
                 const double need = bar();
                 if (cm == 0ull) {
                     const uint32_t m = nX < 64 ? nX : 64; nX -= m;
@@ -489,59 +576,34 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                         cq = qcut[nX + lane];
                         const SqRunA r = LA[cq];
                         ci = (int)(r.key & 0xFFFFu); cs = (int)(r.key >> 16); cL = (int)(r.lf & SQ_RX_LEN); ct0 = 0; cfirst = true; cact = true;
+                        find_piece();
                     }
                 }
                 bool ps2 = false; uint32_t at = 0;
                 if (cact) {
-                    const int i = ci, j = cs - ci, L = cL;
-                    // cell t of the run: row i + t, column j - t; masked when either lies on a strand [za0, za1] or [zb0, zb1]
-                    const int lo0 = za0 - i, hi0 = za1 - i, lo1 = zb0 - i, hi1 = zb1 - i, lo2 = j - za1, hi2 = j - za0, lo3 = j - zb1, hi3 = j - zb0;
-                    int pb = -1, plen = 0, t0 = ct0;
-                    while (t0 < L) {                                            // the next piece of at least minlen cells
-                        int b0 = t0;
-#pragma unroll
-                        for (int rep = 0; rep < 4; rep++) {
-                            if (b0 >= lo0 && b0 <= hi0) b0 = hi0 + 1;
-                            if (b0 >= lo1 && b0 <= hi1) b0 = hi1 + 1;
-                            if (b0 >= lo2 && b0 <= hi2) b0 = hi2 + 1;
-                            if (b0 >= lo3 && b0 <= hi3) b0 = hi3 + 1;
+                    const int i = ci, j = cs - ci, pb = cpb, plen = cplen;
+                    double pos;
+                    const double bps = run_bps(i + pb, j - pb, plen, pos);
+                    if (!(pos < minbps)) {
+                        at = cq;
+                        bool room = true;
+                        if (!cfirst) {
+                            at = atomicAdd(&s_nlist, 1u);
+                            if (at >= (uint32_t)cap) { a.ctr->cand_ovf = 1; room = false; }
                         }
-                        if (b0 >= L) { t0 = L; break; }
-                        int pe = L;
-                        if (lo0 > b0 && lo0 < pe) pe = lo0;
-                        if (lo1 > b0 && lo1 < pe) pe = lo1;
-                        if (lo2 > b0 && lo2 < pe) pe = lo2;
-                        if (lo3 > b0 && lo3 < pe) pe = lo3;
-                        t0 = pe;
-                        if (pe - b0 >= minlen) { pb = b0; plen = pe - b0; break; }
-                    }
-                    ct0 = t0;
-                    if (pb < 0) {                                               // no piece left
-                        if (cfirst) { LA[cq].lf = 0u; atomicAdd(&s_ndead, 1u); }
-                        cact = false;
-                    } else {
-                        double pos;
-                        const double bps = run_bps(i + pb, j - pb, plen, pos);
-                        if (!(pos < minbps)) {
-                            at = cq;
-                            bool room = true;
-                            if (!cfirst) {
-                                at = atomicAdd(&s_nlist, 1u);
-                                if (at >= (uint32_t)cap) { a.ctr->cand_ovf = 1; room = false; }
+                        if (room) {
+                            cfirst = false;
+                            uint32_t lf = (uint32_t)plen;
+                            if (bps >= minbps) {                                // :492 (a piece below it stays for ITS pieces)
+                                const double ub = upper_of(bps, i + pb, j - pb, plen);
+                                lf |= SQ_RX_UB;
+                                LB[at].ub = ub;
+                                ps2 = !(ub < need);
                             }
-                            if (room) {
-                                cfirst = false;
-                                uint32_t lf = (uint32_t)plen;
-                                if (bps >= minbps) {                            // :492 (a piece below it stays for ITS pieces)
-                                    const double ub = upper_of(bps, i + pb, j - pb, plen);
-                                    lf |= SQ_RX_UB;
-                                    LB[at].ub = ub;
-                                    ps2 = !(ub < need);
-                                }
-                                LA[at] = SqRunA{((uint32_t)cs << 16) | (uint32_t)(i + pb), lf, bps};
-                            }
+                            LA[at] = SqRunA{((uint32_t)cs << 16) | (uint32_t)(i + pb), lf, bps};
                         }
                     }
+                    find_piece();
                 }
                 push(qsurv, nS, ps2, at);
                 sq_wave_lds_fence();
@@ -597,37 +659,31 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         const int i0 = (int)(bkey & 0xFFFFu), j0 = (int)(bkey >> 16) - i0, len = (int)blen;
         const int k = nstems;
         if (k >= ch.tcap) { if (tid == 0) a.ctr->out_ovf = 1; retire(k, 0); return; }
-        // (no barrier here: the pass is over for every wave, nobody reads the state any more, and the wave bests are not
-        // written again before the two barriers below)
-        // ---- the child.  First wave: crossing weights, levels when stems cross, the sorted strand list (sq_extend.h);
-        // the other waves: partner array and prefix counts -- positions p and above lose the new pairs below p, and
-        // separators never pair, so SU stays ----
+        // ---- the child.  Before the barrier: the first wave books the stem and its crossing weights (:121-124) -- which say
+        // whether the levels will be taken anew --, the other waves update partner array and prefix counts: positions p and
+        // above lose the new pairs below p, and separators never pair, so SU stays ----
         const int zb = j0 - len + 1;
+        int mycross = 0; bool ac = anycross;
         if (wv == 0) {
-            int mycc = 0, mycross = 0;
+            int mycc = 0;
             for (int q = lane; q < k; q += 64)
                 if (sq_chain_cross(XL.i[q], XL.j[q], i0, j0)) { XL.cc[q] += len; mycc += XL.len[q]; mycross = 1; }
             const int newcc = sq_wave_sum32(mycc);
-            const bool ac = anycross || __ballot(mycross) != 0ull;
+            mycross = __ballot(mycross) != 0ull ? 1 : 0;
+            ac = anycross || mycross;
             if (lane == 0) {
                 XL.i[k] = (int16_t)i0; XL.j[k] = (int16_t)j0; XL.len[k] = (int16_t)len; XL.cc[k] = newcc;
                 gst[k] = SqChainStem{i0, j0, len, newcc};           // (the tail reads the stems there; the weights of the others stay in LDS)
                 cio.h_stems[ch.toff + k] = SqStemOut{i0, j0, len, 0, bbps, bfin};
                 s_cross = ac ? 1 : 0;
-                s_best = 0ull;                                      // (the next pass starts without a bar)
+                s_best = 0ull;                                      // (the next pass starts without a bar and with all units to take)
+                s_unit = 0u;
+                // levels: the full rule when the new stem crosses something (crossing weights changed: the order of the first fit
+                // may have); a stem without crossings joins group 0 and only the groups' ranking is taken anew -- the groups stay
+                // what they were, so the NUMBER of levels among any set of strands does, and that number is all ScoreStems takes
+                // from the levels (:728-729): the finalscores kept in the list stay valid.  After the full rule none does
+                s_regroup = ac && !(anycross && !mycross && ngroups > 0) ? 1 : 0;
             }
-            sq_wave_lds_fence();
-            bool regrouped = false;
-            if (ac) {
-                // levels: the full rule when the new stem crosses something (crossing weights changed: the order of the first
-                // fit may have); a stem without crossings joins group 0 and only the groups' ranking is taken anew -- the groups
-                // stay what they were, so the NUMBER of levels among any set of strands does, and that number is all ScoreStems
-                // takes from the levels (:728-729): the finalscores kept in the list stay valid.  After the full rule none does
-                if (anycross && __ballot(mycross) == 0ull && ngroups > 0) sq_stem_levels_join(XL, k + 1, ngroups, len, lane);
-                else { ngroups = sq_stem_levels_wave(XL, k + 1, lane, &a.ctr->level_ovf); regrouped = true; }
-            }
-            if (lane == 0) s_regroup = regrouped ? 1 : 0;
-            sq_rounds_insert_strands(XL, ac, k, strbuf, sidxbuf, nstrand, i0, j0, len, lane);
         }
         if (nwv == 1 || wv > 0) {
             const int w0 = nwv == 1 ? 0 : wv - 1, wn = nwv == 1 ? 1 : nwv - 1;
@@ -639,15 +695,29 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 U[p] = (int16_t)((int)U[p] - (min(p - i0, len) + min(max(p - zb, 0), len)));
         }
         __syncthreads();
+        const bool was_cross = anycross;
         anycross = s_cross != 0;
         nl0 = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;     // (with the pieces this round appended; nothing is appended outside the pass)
-        nstems = k + 1; nstrand += 2;
+        { const uint32_t nd = s_ndead; compact = nd * 3 > nl0 || nl0 + ((nl0 - nd) >> 1) + 64 > (uint32_t)cap; }
+        nstems = k + 1;
         if ((double)nstems == ch.maxstems) { retire(nstems, 1); return; }   // :1168-1174 (checked before the next evaluation)
-        {
+        roundno++;
+        za0 = i0; za1 = i0 + len - 1; zb0 = zb; zb1 = j0;
+        RPROF(7);
+        // ---- the rest of the child by the first wave alone, while the others are in the next pass: levels when stems cross, the
+        // sorted strand list (sq_extend.h), the skip pointers; s_ready tells the score steps ----
+        if (wv == 0) {
+            if (ac) {
+                if (was_cross && !mycross && ngroups > 0) sq_stem_levels_join(XL, k + 1, ngroups, len, lane);
+                else ngroups = sq_stem_levels_wave(XL, k + 1, lane, &a.ctr->level_ovf);
+            }
+            sq_rounds_insert_strands(XL, ac, k, strbuf, sidxbuf, nstrand, i0, j0, len, lane);
+            sq_wave_lds_fence();
             // skip pointers over the blocks ScoreStems' sweep registers (sq_score_kernel)
             const SqStrand *const S2 = strbuf;
             const int16_t *const X2 = sidxbuf;
-            for (int q = tid; q < nstrand; q += nthr) {
+            const int ns2 = nstrand + 2;
+            for (int q = lane; q < ns2; q += 64) {
                 const SqStrand x = S2[q];
                 int z = q + 1;
                 if (x.left) {
@@ -655,11 +725,11 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                     if (XL.cc[X2[q]] == 0) {
                         // a stem that crosses nothing: no 5' strand inside its block reaches beyond it, so the pointer is the
                         // first strand that starts behind the partner -- a binary search instead of a walk over the block
-                        int lo = q + 1, hi = nstrand;
+                        int lo = q + 1, hi = ns2;
                         while (lo < hi) { const int mid = (lo + hi) >> 1; if (S2[mid].start > pf) hi = mid; else lo = mid + 1; }
                         z = lo;
                     } else {
-                        while (z < nstrand) {
+                        while (z < ns2) {
                             const SqStrand y = S2[z];
                             if (y.start > pf || (y.left && y.pstart > pf)) break;
                             z++;
@@ -668,9 +738,10 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 }
                 s_skip[q] = (uint16_t)z;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __atomic_store_n(&s_ready, roundno, __ATOMIC_RELAXED);
         }
-        za0 = i0; za1 = i0 + len - 1; zb0 = zb; zb1 = j0;
-        __syncthreads();
+        nstrand += 2;
         RPROF(8);
     }
 }

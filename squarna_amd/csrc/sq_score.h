@@ -25,6 +25,7 @@ struct SqStemsEnv {
     bool use_ctx; const SqCtxRec *ctx_rec; const int16_t *ctx_depth; const uint16_t *ctx_rmq; int ctx_cap;   // sq_context.h
     double lb, bw, dc; int bwint, sdflen; const double *sdf, *of;           // the paramset's scalars and tables
     SqCounters *ctr;
+    const double *sdf_l; int sdf_llen;                                      // the first entries of sdf once more, in LDS (nullptr / 0: none)
 };
 // ... and the finalscore of the stem (i0, j0, L) with bpscore bps (the caller applies :751's threshold)
 __device__ __forceinline__ double sq_stem_finalscore(const SqStemsEnv &e, int i0, int j0, int L, double bps)
@@ -79,7 +80,7 @@ __device__ __forceinline__ double sq_stem_finalscore(const SqStemsEnv &e, int i0
                (int)blockIdx.x, i0, j0, L, e.nstrand, nrec, covered, brackets, be0, be1, cx.nrec, cx.covered, cx.brackets, cx.be0, cx.be1);
 #endif
     const int dots = (e.U[sb] - e.U[sa + 1]) - covered;             // :670-673
-    const bool between = (e.SU[sb] - e.SU[sa + 1]) > 0;             // :675-676
+    const bool between = e.SU != nullptr && (e.SU[sb] - e.SU[sa + 1]) > 0;   // :675-676 (nullptr: no separator anywhere)
     bool goodloop = false; int diff1 = 0;                       // :692-698
     if (nrec == 1 && sq_goodloop(be0 - sa - 1, sb - be1 - 1)) {
         goodloop = true;
@@ -117,7 +118,7 @@ __device__ __forceinline__ double sq_stem_finalscore(const SqStemsEnv &e, int i0
     double sdf = 1.0;                                           // :726
     if (!between) {
         const int di = (int)dd;
-        if (e.bwint && di < e.sdflen) sdf = e.sdf[di];
+        if (e.bwint && di < e.sdflen) sdf = di < e.sdf_llen ? e.sdf_l[di] : e.sdf[di];
         else sdf = pow(1.0 / (1.0 + dd), e.dc);
     }
     const double of = e.of[__popcll(levelset)];            // :728-729
