@@ -1,5 +1,6 @@
 // sq_fold.hip -- sq_fold: the greedy pool loop of every job of a batch on the device drivers (persistent rounds, device pools) with the host loop as their fallback, E / H / N beside it, the ranking tail behind it; sq_fold_concurrent.
 #include "sq_host_int.h"
+#include "sq_scan.h"
 
 void sq_read_fold_switches(SqFoldSwitches &sw)
 {
@@ -40,9 +41,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     sq_read_fold_switches(b->sw);
     const SqFoldSwitches &sw = b->sw;
     struct FoldTimer { double t0; bool on; ~FoldTimer() { if (on) fprintf(stderr, "[sq_fold] total %.3f ms (incl. teardown)\n", (now_s() - t0) * 1e3); } } fold_timer{now_s(), sw.timing};
-    // a-1, once per job and per fold (:1076): never reused from an earlier call, a fold is the whole path
-    int r = sq_fill_impl(b, 0);
-    if (r) return r;
+    int r = 0;
     // The ranking tail runs on the device (sq_tail_dev.hip) over the device log of final structures whenever the options
     // allow; the host tail below is its fallback.  The log and the per-job evaluation counts start empty.
     const bool dev_tail = sq_tail_device_wanted(b, o);
@@ -72,6 +71,19 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         P.suboptinc = (ps.suboptmax - ps.suboptmin) / ps.suboptsteps;   // :1071
         P.suboptmax = ps.suboptmax; P.maxstemnum = ps.maxstemnum;
     }
+    // a-1, once per job and per fold (:1076): never reused from an earlier call, a fold is the whole path.  A fold whose every
+    // job is scanned exactly once -- width-1 pools on the persistent round kernel, no E / H / N -- does not write the bit
+    // matrices at all: the kernel's only scan forms the words it needs from letter masks in LDS (SqBitsFly, sq_scan.h; the bit
+    // kernel was 215 us of the 1.47 ms of an S1000 x 1,024 fold).  Every other path asks for the matrices (sq_prepare_scan).
+    bool any_ehn = false, any_ext1 = false;
+    for (int j = 0; j < b->njobs; j++) {
+        any_ehn |= (algos[j] & (uint32_t)(SQ_ALGO_E | SQ_ALGO_H | SQ_ALGO_N)) != 0;
+        any_ext1 |= b->jobs[j].has_ext == 1;
+    }
+    static const bool no_fly = getenv("SQ_NO_FLY_BITS") != nullptr;
+    const bool lazy_bits = o.poollim == 1 && !sw.no_chain && !sw.no_rounds && !any_ehn && !any_ext1 && !b->interchainonly && b->nletters > 0 && !no_fly;
+    b->bits_ready = false;
+    if (!lazy_bits) { r = sq_fill_impl(b, 0); if (r) return r; }
     // Edmonds / Hungarian / Nussinov paramsets (:1094-1100); their stemsets precede the greedy ones.
     // The reference iterates a Python set of letters (unspecified order); we use E, H, N.
     SqAlgoAsync *pending = nullptr;
@@ -99,6 +111,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         for (int j : greedy_jobs)
             if (chain_tcap(b->jobs[j].n, b->psets[b->job_pset[j]].minlen) > SQ_CHAIN_TMAX ||
                 b->jobs[j].cand_cap > b->cand_records - b->cand_reserved) use_chain = false;
+    if (!use_chain) { r = sq_prepare_scan(b); if (r) return r; }   // (the host-driven lanes and the pools scan the matrices; asked for before any second thread runs)
     // Wider pools: booked on the device as well (sq_pool.hip) when the batch has the slot arrays (structures of at most
     // SQ_CHAIN_TMAX stems) and one structure per greedy job fits the round buffers; any capacity overflow during the fold makes
     // the host repeat it with its own loop.
@@ -315,8 +328,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // (capacity flags, the count of finished structures) is looked at afterwards (the wait between the two was 40-65 us of every
     // fold: a flag's way to the host, then seven launches' way back)
     struct { bool on = false; uint32_t goal = 0; } deferred;
-    bool any_ehn = false;
-    for (int j = 0; j < b->njobs; j++) any_ehn |= (algos[j] & (uint32_t)(SQ_ALGO_E | SQ_ALGO_H | SQ_ALGO_N)) != 0;
+
     static const bool no_defer = getenv("SQ_NO_DEFER_WAIT") != nullptr;
     auto chain_fold = [&](LoopStats &stats) {
         SqLane &ln = b->lane_full;
@@ -399,9 +411,18 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0; ra.ties = chain_ties ? 1 : 0;
             ra.su = 0;
             for (int j : jobs) if (b->seq_has_sep[(size_t)b->job_seq[j]]) { ra.su = 1; break; }
+            ra.fly = 0;
             while (thr > 64 && sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr, ra.su).total + 2048 > 158 * 1024) thr /= 2;   // (long sequences: the survivor ring gives way)
             if (sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr, ra.su).total + 2048 > 158 * 1024) rounds_ok = false;
         }
+        if (rounds_ok && lazy_bits) {                         // the masks take the LDS of the strands and stems (the structure is empty during the scan)
+            const SqRoundsLds lo = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr, ra.su);
+            // (short sequences -- one wave per structure -- are better off with the matrices the bit kernel writes at full width:
+            // S300 x 10,000 1.78 against 1.84 ms; from ~500 nt on the kernel's own words win: S1000 x 1,024 1.47 -> 1.31 ms)
+            static const int fly_min = getenv("SQ_FLY_MIN_N") ? atoi(getenv("SQ_FLY_MIN_N")) : 400;
+            if (maxn >= fly_min && sq_bits_fly_bytes(maxn, b->nletters) <= (size_t)(lo.off_tab - lo.off_str)) ra.fly = b->nletters;
+        }
+        if (ra.fly == 0) { const int pr = sq_prepare_scan(b); if (pr) { fail(pr, sq_last_error()); return; } }
         if (!rounds_ok && chain_ties) {                       // (the launched rounds do not look for ties: the pools take these jobs)
             for (int j : jobs) tied_jobs.push_back(j);
             nfin_goal -= (uint32_t)S;
@@ -555,6 +576,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         }
         const int S0 = (int)jobs.size();
         if (S0 == 0) return 0;
+        { const int pr = sq_prepare_scan(b); if (pr) return fail(pr, sq_last_error()); }
         const int64_t avail = b->cand_records - b->cand_reserved;
         int slots = std::min(PI.smax, ln.max_structs);
         if (sw.pool_slots > 0) slots = std::min(slots, sw.pool_slots);   // (tests: force the overflow path)

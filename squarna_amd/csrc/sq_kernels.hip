@@ -577,7 +577,7 @@ __device__ __forceinline__ void sq_scan6_body(const SqDevCtx &c, const SqStruct 
     // ONE wave that walks all its groups (five for 100 nt) instead of one wave per group -- each of those spent most of its
     // few microseconds on the set-up above, and with batches in flight wave slots are what the chip runs out of
     SqScan6Sink sink{L, a, st, jb.cand_cap};
-    sq_scan6_groups(c, jb, sq6_fg, sq6_fg + fbh, fbh, stt.E8 + (int64_t)st.slot * stt.stride * 2, gy0, gystep, lane0, sink);
+    sq_scan6_groups(c, jb, sq6_fg, sq6_fg + fbh, fbh, stt.E8 + (int64_t)st.slot * stt.stride * 2, gy0, gystep, lane0, sink, SqBitsGlobal{c.bits + jb.bits_off, jb.bpitch});
 }
 
 extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)

@@ -284,7 +284,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
     uint32_t ns = 0;
     if (n >= 5) {                                                       // :456-457 (shorter sequences have no diagonals)
         SqPrSink sink{s_stage, &s_cnt, over, &s_nover, (uint32_t)jb.cand_cap, cenv, c, jb, sv, ns, minbps, a.ctr};
-        sq_scan6_groups(c, jb, FG, FG + Lo.fbh, Lo.fbh, E, 0, 1, lane, sink);
+        sq_scan6_groups(c, jb, FG, FG + Lo.fbh, Lo.fbh, E, 0, 1, lane, sink, SqBitsGlobal{c.bits + jb.bits_off, jb.bpitch});
         __threadfence_block();
         __syncthreads();
         const uint32_t no = s_nover < (uint32_t)jb.cand_cap ? s_nover : (uint32_t)jb.cand_cap;

@@ -46,6 +46,8 @@ struct SqRoundsArgs {
     int32_t cell_entries;   // doubles of the cell table (largest (classes x reactivity levels)^2 of the batch, padded)
     int32_t bound;          // branch and bound on the finalscore (0: every survivor of :492 is scored)
     int32_t ctx_min;        // strands from which a non-crossing structure's sweep is answered from the context tables (0: never)
+    int32_t fly;            // > 0: the first round's scan forms the words of the bit matrix itself, from letter masks in LDS (the fold never
+                            // wrote the matrix: every job is scanned once); the value is the batch's letter count (room of the masks)
     int32_t su;             // some sequence of the launch holds a chain separator: the blocks keep the separators' prefix counts (2 bytes per position)
     int32_t ties;           // the structures belong to pools that MAY branch (poollim > 1, range factor 1.0): a round in which a second
                             // run reaches the best finalscore ends the structure unfinished (h_fin bit 62) -- the device pools redo its job

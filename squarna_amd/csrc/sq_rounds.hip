@@ -115,7 +115,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     __shared__ int s_wave_u[SQ_ROUNDS_THREADS / 64], s_wave_s[SQ_ROUNDS_THREADS / 64];
     __shared__ uint32_t s_nlist, s_ndead;
     __shared__ int s_regroup, s_ready;
-    __shared__ uint32_t s_unit;
+    __shared__ uint32_t s_unit, s_present;
     __shared__ SqCellTmp s_ctmp;
     __shared__ unsigned long long s_best;
     __shared__ double s_wfin[SQ_ROUNDS_THREADS / 64], s_wbps[SQ_ROUNDS_THREADS / 64], s_wsec[SQ_ROUNDS_THREADS / 64];
@@ -229,7 +229,49 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         if (lane == 0) *wcnt = 0;
         __syncthreads();
         SqRoundsSink sink{wstage, wcnt, &s_nlist, raw, (uint32_t)cap, a.ctr};
-        sq_scan6_groups(c, jb, FG, FG + fbh, fbh, E, wv, nwv, lane, sink);
+        if (ra.fly > 0) {
+            // the letter masks of sq_bits_masks_kernel, in the LDS the strands and stems of the later rounds will take (the
+            // structure is empty now)
+            char *const mreg = rd_dyn + Lo.off_str;
+            const int npad = (n + 3) & ~3, nw = (n + 31) >> 5, mw = nw + 3, maxl = ra.fly;
+            uint8_t *const m_ccode = reinterpret_cast<uint8_t *>(mreg), *const m_rcode = m_ccode + npad, *const m_inc = m_rcode + npad;
+            uint32_t *const m_M = reinterpret_cast<uint32_t *>(m_inc + npad), *const m_R = m_M + maxl * mw;
+            uint32_t mine = 0;
+            if (tid == 0) s_present = 0u;
+            __syncthreads();
+            for (int p = tid; p < n; p += nthr) {
+                const uint32_t code = c.codes[jb.pos_off + p], fl = c.flags[jb.pos_off + p];
+                m_ccode[p] = (uint8_t)((!(fl & 1u) && !(fl & 2u)) ? code : 31u);          // :302, :303 (column side)
+                const bool rowok = !(fl & 1u) && !(fl & 4u);                                // :302, :304 (row side)
+                m_rcode[p] = (uint8_t)(rowok ? code : 31u);
+                m_inc[p] = c.inc4[jb.pos_off + p];
+                if (rowok && code < 29u && ps->pmask[code]) mine |= 1u << code;          // (letters that pair with nothing have no cells)
+            }
+            if (mine) atomicOr(&s_present, mine);
+            __syncthreads();
+            const uint32_t present = s_present;
+            const int nlet = __popc(present);                                              // <= maxl (host: letters of the batch)
+            auto letter = [&](int k) -> uint32_t { uint32_t m = present; for (int t = 0; t < k; t++) m &= m - 1; return (uint32_t)(__ffs((int)m) - 1); };
+            for (int e = tid; e < nlet * mw; e += nthr) {                                   // column masks
+                const int k = e / mw, q = e - k * mw;
+                const uint32_t pm = ps->pmask[letter(k)];
+                uint32_t word = 0;
+                const int j0 = (q - 1) * 32;
+                if (q >= 1 && j0 < n)
+                    for (int bb = 0; bb < 32 && j0 + bb < n; bb++) word |= ((pm >> m_ccode[j0 + bb]) & 1u) << bb;
+                m_M[e] = word;
+            }
+            for (int e = tid; e < nw * nlet; e += nthr) {                                   // row masks
+                const int w = e / nlet, k = e - w * nlet;
+                const uint32_t x = letter(k);
+                uint32_t word = 0;
+                for (int bb = 0; bb < 32 && 32 * w + bb < n; bb++) word |= (uint32_t)(m_rcode[32 * w + bb] == x) << bb;
+                m_R[w * maxl + k] = word;
+            }
+            __syncthreads();
+            sq_scan6_groups(c, jb, FG, FG + fbh, fbh, E, wv, nwv, lane, sink, SqBitsFly{m_M, m_R, m_inc, mw, nlet, maxl, n});
+        } else
+            sq_scan6_groups(c, jb, FG, FG + fbh, fbh, E, wv, nwv, lane, sink, SqBitsGlobal{c.bits + jb.bits_off, jb.bpitch});
     }
     __syncthreads();
     const uint32_t ncur = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;

@@ -27,9 +27,52 @@
 //   emit(key, len)    from any lane, key = (s << 16) | first row;
 //   poll(lane)        after every word-row, all lanes (room to flush a staging buffer);
 //   drain(lane)       after every group of 64 diagonals, all lanes.
-template <class Sink>
+// Bits: where the words of the job's diagonal bit matrix come from -- word(w, s) = bit b <-> cell (32w + b, s - 32w - b) of the
+// unmasked BPMatrix, zero outside the matrix.  SqBitsGlobal reads the matrix the bit kernels wrote; SqBitsFly (below) forms
+// the word from letter masks in LDS, so that a fold that scans every job ONCE never writes the matrix at all.
+struct SqBitsGlobal {
+    const uint32_t *bp; int bpitch;
+    __device__ __forceinline__ uint32_t word(int w, int s) const { return bp[(int64_t)w * bpitch + s]; }
+};
+// The letter-mask form of sq_bits_masks_kernel (sq_kernels.hip), word by word: for the letters x present in the sequence,
+// R[w][x] = the rows of word-row w with letter x (and no row-side restraint flag), M[x] = the columns whose letter may pair
+// with x (and no column-side flag) as a bit array over j behind one zero word.  word(w, s) = OR_x R[w][x] & reverse(M[x][t - 31 .. t]),
+// t = s - 32w; only the words next to the main diagonal check the minimal loop length bit by bit (:294-299).
+struct SqBitsFly {
+    const uint32_t *M, *R; const uint8_t *inc; int mw, nlet, maxl, n;
+    __device__ __forceinline__ uint32_t word(int w, int s) const
+    {
+        const int i0 = 32 * w, t = s - i0;                                   // column of bit 0
+        uint32_t word = 0;
+        if (s >= 4 && s <= 2 * n - 6 && t >= 0 && t - 31 < n) {
+            const int q = t + 1;                                             // bit index of column t - 31 behind the zero word
+            const uint32_t *Rw = R + w * maxl;
+            for (int k = 0; k < nlet; k++) {
+                const uint32_t *Mk = M + k * mw + (q >> 5);
+                const uint64_t two = ((uint64_t)Mk[1] << 32) | Mk[0];
+                word |= Rw[k] & __brev((uint32_t)(two >> (q & 31)));
+            }
+            const int d = s - 2 * i0;                                        // j - i of bit b is d - 2b
+            if (word && d < 4 + 62) {
+                uint32_t keep = 0;
+                for (int bb = 0; bb < 32 && i0 + bb < n; bb++)
+                    if (d - 2 * bb >= (int)inc[i0 + bb]) keep |= 1u << bb;      // :294-299
+                word &= keep;
+            }
+        }
+        return word;
+    }
+};
+// LDS of the masks: column letters, row letters, minimal j - i (a byte per position each), M, R
+__host__ __device__ inline size_t sq_bits_fly_bytes(int n, int nletters)
+{
+    const size_t npad = ((size_t)n + 3) & ~(size_t)3, nw = ((size_t)n + 31) / 32;
+    return 3 * npad + 4 * (size_t)nletters * (nw + 3) + 4 * nw * (size_t)nletters + 16;
+}
+
+template <class Sink, class Bits>
 __device__ __forceinline__ void sq_scan6_groups(const SqDevCtx &c, const SqJob &jb, const uint32_t *F, const uint32_t *G, int fbh,
-                                                const uint8_t *eg, int gy0, int gystep, int lane, Sink &sink)
+                                                const uint8_t *eg, int gy0, int gystep, int lane, Sink &sink, const Bits &bits)
 {
     const int n = jb.n;
     const SqPsetDev *ps = c.psets + jb.pset;
@@ -66,8 +109,6 @@ __device__ __forceinline__ void sq_scan6_groups(const SqDevCtx &c, const SqJob &
             }
             rend = lo;
         }
-        const uint32_t *bp = c.bits + jb.bits_off + s;
-        const int bpitch = jb.bpitch;
 
         int carry = 0;
         uint32_t glo = G[gidx];
@@ -87,7 +128,7 @@ __device__ __forceinline__ void sq_scan6_groups(const SqDevCtx &c, const SqJob &
         for (int w0 = wlo; w0 <= whi; w0 += SQ6_AHEAD) {
             uint32_t bw[SQ6_AHEAD];
 #pragma unroll
-            for (int k = 0; k < SQ6_AHEAD; k++) bw[k] = w0 + k <= whi ? bp[(int64_t)(w0 + k) * bpitch] : 0u;
+            for (int k = 0; k < SQ6_AHEAD; k++) bw[k] = w0 + k <= whi ? bits.word(w0 + k, s) : 0u;
 #pragma unroll
             for (int k = 0; k < SQ6_AHEAD; k++) {
                 const int w = w0 + k;

@@ -12,6 +12,7 @@ idx=[i for i,r in enumerate(rows) if r["Kernel_Name"].startswith("sq_rounds_kern
 # find start: the sq_fold_begin_kernel before it
 j=idx
 while j>0 and not rows[j]["Kernel_Name"].startswith("sq_fold_begin"): j-=1
+j=max(0,j-3)
 t0=int(rows[j]["Start_Timestamp"])
 for r in rows[j:]:
     s=(int(r["Start_Timestamp"])-t0)/1e3; e=(int(r["End_Timestamp"])-t0)/1e3
