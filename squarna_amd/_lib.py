@@ -163,6 +163,12 @@ def load():
     return L
 
 
+class CapacityError(RuntimeError):
+    """A capacity the batch was created with (candidate records per structure, the log of final structures) did not hold the
+    fold: status -3 of the C ABI.  The engine repeats the fold with a larger batch (engine.HipEngine._fold_groups)."""
+
+
 def check(rc):
     if rc != 0:
-        raise RuntimeError("libsquarna_hip: %s (code %d)" % (load().sq_last_error().decode(), rc))
+        msg = "libsquarna_hip: %s (code %d)" % (load().sq_last_error().decode(), rc)
+        raise (CapacityError if rc == -3 else RuntimeError)(msg)

@@ -8,6 +8,7 @@ void sq_read_fold_switches(SqFoldSwitches &sw)
     auto num = [](const char *name, int lo, int hi) { const char *e = getenv(name); return e ? std::max(lo, std::min(hi, atoi(e))) : 0; };
     sw.timing = on("SQ_TIMING"); sw.pool_debug = on("SQ_POOL_DEBUG");
     sw.no_chain = on("SQ_NO_CHAIN"); sw.no_rounds = on("SQ_NO_ROUNDS"); sw.no_pool = on("SQ_NO_POOL");
+    sw.no_opt_chain = on("SQ_NO_OPT_CHAIN"); sw.no_fly_bits = on("SQ_NO_FLY_BITS"); sw.no_defer_wait = on("SQ_NO_DEFER_WAIT");
     sw.no_pool_round = on("SQ_NO_POOL_ROUND"); sw.pool_round_always = on("SQ_POOL_ROUND_ALWAYS");
     sw.pool_round_nsurv = num("SQ_POOL_ROUND_NSURV", 16, 2048);
     sw.pool_slots = num("SQ_POOL_SLOTS", 1, 0x7fffffff); sw.pool_chunk = num("SQ_POOL_CHUNK", 1, 0x7fffffff);
@@ -80,7 +81,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         any_ehn |= (algos[j] & (uint32_t)(SQ_ALGO_E | SQ_ALGO_H | SQ_ALGO_N)) != 0;
         any_ext1 |= b->jobs[j].has_ext == 1;
     }
-    static const bool no_fly = getenv("SQ_NO_FLY_BITS") != nullptr;
+    const bool no_fly = sw.no_fly_bits;
     const bool lazy_bits = o.poollim == 1 && !sw.no_chain && !sw.no_rounds && !any_ehn && !any_ext1 && !b->interchainonly && b->nletters > 0 && !no_fly;
     b->bits_ready = false;
     if (!lazy_bits) { r = sq_fill_impl(b, 0); if (r) return r; }
@@ -117,19 +118,19 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // the host repeat it with its own loop.
     const bool no_pool = sw.no_pool;
     bool use_pool = !use_chain && o.poollim > 1 && !no_pool && !greedy_jobs.empty() && b->pool_io.pt > 0;
-    // the jobs each device driver takes.  Pools that may branch (poollim > 1) but almost never do -- range factor 1.0 (only
-    // exact ties branch, :769-778) over cells weighted by a dense fp64 matrix (the alignment's rows, bpp terms) -- first run
-    // as chains on the persistent round kernel, which stops a structure at the first tie; the device pools then fold what
-    // is left (tied_jobs) and every other job
+    // the jobs each device driver takes.  Pools that may branch (poollim > 1) but rarely do -- range factor 1.0: only a run
+    // that ties with the best AND shares a base with it branches (:769-789): `fastest` at the default pool limit, the
+    // alignment's rows -- first run as chains on the persistent round kernel, which stops a structure at the first such tie;
+    // the device pools then fold what is left (tied_jobs) and every other job
     std::vector<int> chain_jobs, pool_jobs_v, tied_jobs;
     bool chain_ties = false;
     if (use_chain) chain_jobs = greedy_jobs;
     if (use_pool) {
-        static const bool no_opt = getenv("SQ_NO_OPT_CHAIN") != nullptr;
+        const bool no_opt = sw.no_opt_chain;
         for (int j : greedy_jobs) {
             const SqJob &J = b->jobs[j];
             const sq_paramset &ps = b->psets[b->job_pset[j]];
-            const bool opt = !no_opt && !no_rounds && J.mat64_off >= 0 && ps.suboptmin == 1.0 && ps.suboptmax == 1.0 && J.n <= SQ_ROUNDS_MAXN &&
+            const bool opt = !no_opt && !no_rounds && ps.suboptmin == 1.0 && ps.suboptmax == 1.0 && J.n <= SQ_ROUNDS_MAXN &&
                              chain_tcap(J.n, ps.minlen) <= SQ_CHAIN_TMAX && J.cand_cap <= b->cand_records - b->cand_reserved;
             (opt ? chain_jobs : pool_jobs_v).push_back(j);
         }
@@ -329,7 +330,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // fold: a flag's way to the host, then seven launches' way back)
     struct { bool on = false; uint32_t goal = 0; } deferred;
 
-    static const bool no_defer = getenv("SQ_NO_DEFER_WAIT") != nullptr;
+    const bool no_defer = sw.no_defer_wait;
     auto chain_fold = [&](LoopStats &stats) {
         SqLane &ln = b->lane_full;
         hipStream_t st = b->stream;

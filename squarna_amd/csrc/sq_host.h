@@ -117,6 +117,9 @@ struct SqFoldSwitches {
     bool no_chain = false;            // SQ_NO_CHAIN: poollim = 1 folds driven round by round from the host
     bool no_rounds = false;           // SQ_NO_ROUNDS: the launched rounds instead of the persistent round kernel
     bool no_pool = false;             // SQ_NO_POOL: pools booked on the host
+    bool no_opt_chain = false;        // SQ_NO_OPT_CHAIN: pools with a range factor of 1.0 go to the device pools at once (no optimistic chains)
+    bool no_fly_bits = false;         // SQ_NO_FLY_BITS: the bit matrices are always written (the round kernel's scan reads them)
+    bool no_defer_wait = false;       // SQ_NO_DEFER_WAIT: the host waits for the round kernel before it enqueues the device tail
     bool no_pool_round = false;       // SQ_NO_POOL_ROUND: state / scan / score / choose / extend kernels instead of sq_pool_round_kernel
     bool pool_round_always = false;   // SQ_POOL_ROUND_ALWAYS: (the default since late round 4; the switch is read and ignored)
     int pool_round_nsurv = 0;         // SQ_POOL_ROUND_NSURV: survivors sq_pool_round_kernel keeps in LDS (0: by length)

@@ -22,7 +22,7 @@
 //     retirement (no stem left :1192-1193, maxstemnum :1168-1174) with the same records sq_chain_kernel writes.
 //
 // Results are those of the launched rounds bit for bit (tests fold both ways: SQ_NO_ROUNDS); what the kernel does not
-// take (jobs with dense matrices, sequences beyond SQ_ROUNDS_MAXN) keeps the launched form.
+// take (sequences beyond SQ_ROUNDS_MAXN, lists that outgrow the LDS) keeps the launched form.
 #include <hip/hip_runtime.h>
 #include "sq_device.h"
 
@@ -688,15 +688,34 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         RPROF(7);
         if (!bany) { retire(nstems, 0); RPROF_OUT(); return; }      // :1192-1193 no new stem: the structure is final
         if (ra.ties && sfin == bfin) {
-            // a pool that may branch: ChooseStems returns every run that reaches the best finalscore and shares a base with the
-            // ones taken (:769-789, range factor 1.0) -- two runs at the top mean the pool MAY grow here: the structure stops,
-            // unfinished, and the device pools fold its job (rare: these jobs weigh their cells with a dense fp64 matrix)
-            if (tid == 0) {
-                structs[b].nstrand = -1;
-                const uint32_t idx = atomicAdd(cio.d_nfin, 1u);
-                cio.h_fin[idx] = (unsigned long long)(uint32_t)st.job | (1ull << 62);
+            // a pool that may branch: ChooseStems returns, beside its first element, every run that reaches the best finalscore
+            // (range factor 1.0) AND shares a base with all the runs taken before it (:769-789).  With the first element alone in
+            // the list that is: some other run at the best finalscore shares a base with the winner -- then the pool grows here,
+            // the structure stops, unfinished, and the device pools fold its job.  Tied runs that touch no base of the winner
+            // change nothing (the next rounds meet them again).  Every run at the best finalscore was scored or kept this round
+            // (its bound cannot lie below the bar), so its entry holds the finalscore
+            const int wi = (int)(bkey & 0xFFFFu), wj = (int)(bkey >> 16) - wi, wl = (int)blen;
+            const uint32_t nl = s_nlist < (uint32_t)cap ? s_nlist : (uint32_t)cap;
+            int found = 0;
+            for (uint32_t q = tid; q < nl; q += nthr) {
+                const SqRunA r = LA[q];
+                const int L = (int)(r.lf & SQ_RX_LEN);
+                if (L == 0 || !(r.lf & SQ_RX_FIN) || r.key == bkey) continue;
+                if (LB[q].fin != bfin) continue;
+                const int i = (int)(r.key & 0xFFFFu), j = (int)(r.key >> 16) - i;
+                // strands [i, i + L) and (j - L, j] against the winner's
+                const bool hit = (i <= wi + wl - 1 && i + L - 1 >= wi) || (i <= wj && i + L - 1 >= wj - wl + 1) ||
+                                 (j - L + 1 <= wi + wl - 1 && j >= wi) || (j - L + 1 <= wj && j >= wj - wl + 1);
+                if (hit) found = 1;
             }
-            return;
+            if (__syncthreads_or(found)) {
+                if (tid == 0) {
+                    structs[b].nstrand = -1;
+                    const uint32_t idx = atomicAdd(cio.d_nfin, 1u);
+                    cio.h_fin[idx] = (unsigned long long)(uint32_t)st.job | (1ull << 62);
+                }
+                return;
+            }
         }
         const int i0 = (int)(bkey & 0xFFFFu), j0 = (int)(bkey >> 16) - i0, len = (int)blen;
         const int k = nstems;

@@ -844,8 +844,9 @@ class HipEngine:
         self.last_ref_scores = refs
         return out
 
-    def _make_batch(self, records, slots_hint, opts):
-        """(Batch, fold options) for these records.  opts: fold_records' keyword arguments (not modified)."""
+    def _make_batch(self, records, slots_hint, opts, grow=(1, 1)):
+        """(Batch, fold options) for these records.  opts: fold_records' keyword arguments (not modified).  grow: factors on
+        the candidate capacity per nucleotide and on the structure slots (a fold that outgrew them is repeated)."""
         opts = dict(opts)
         opts.pop("_packed", None)
         opts.pop("_blocks", None)
@@ -885,8 +886,15 @@ class HipEngine:
             want = slots_hint if slots_hint else int(pool_slots_wanted_many(
                 [len(p.shortseq) for p in prepared], psets, opts.get("poollim", 1000)).sum())
             max_structs = max(max_structs, min(want, pool_slot_cap(max(len(p.shortseq) for p in prepared))))
+        cand = self.cand_per_nt
+        if grow[0] > 1:
+            # (the library sizes a structure's candidate records by max(cand_per_nt x N, its estimate for random sequences --
+            # ~0.19 N^2 runs at minlen 1): the factor applies to the larger of the two
+            nmax = max(len(p.shortseq) for p in prepared)
+            runs = max(0.375 ** (max(1.0, float(np.ceil(ps["minlen"]))) - 1.0) for pl in psets for ps in pl)
+            cand = int(max(cand, 32, 0.117 * 1.6 * nmax * runs) * grow[0]) + 1
         b = Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
-                  max_structs=max_structs, cand_per_nt=self.cand_per_nt, mul_shared=mul_shared)
+                  max_structs=max_structs * grow[1], cand_per_nt=cand, mul_shared=mul_shared)
         b.limit_results(keep)
         return b, opts
 
@@ -909,16 +917,32 @@ class HipEngine:
             import torch
             if len(groups) > 1:
                 torch.cuda.current_stream().synchronize()            # (inputs made on this stream, e.g. the shared stem matrix)
-            for q, (recs, hint) in enumerate(zip(groups, hints)):
-                # concurrent batches on streams of their own: kernels of one fill the gaps of the other
-                ctx = torch.cuda.stream(torch.cuda.Stream()) if q > 0 else contextlib.nullcontext()
-                with ctx:
-                    b, fold_opts = self._make_batch(recs, hint, opts)
-                batches.append(b)
-            if len(batches) == 1:
-                batches[0].fold(**fold_opts)
-            else:
-                fold_concurrently(batches, **fold_opts)
+            # The reference has no capacities (SQRNdbnseq.py:427-495 builds Python lists): a fold that outgrows what its batch
+            # was created with -- the candidate records of a structure are sized for random sequences, GC-only or minlen = 1
+            # inputs hold several times as many runs -- is repeated with a larger batch; the caller never sees the error.
+            grow = [1, 1]
+            for attempt in range(8):
+                for q, (recs, hint) in enumerate(zip(groups, hints)):
+                    # concurrent batches on streams of their own: kernels of one fill the gaps of the other
+                    ctx = torch.cuda.stream(torch.cuda.Stream()) if q > 0 else contextlib.nullcontext()
+                    with ctx:
+                        b, fold_opts = self._make_batch(recs, hint, opts, tuple(grow))
+                    batches.append(b)
+                try:
+                    if len(batches) == 1:
+                        batches[0].fold(**fold_opts)
+                    else:
+                        fold_concurrently(batches, **fold_opts)
+                    break
+                except _lib.CapacityError as e:
+                    which = 1 if "max_structs" in str(e) else (0 if "cand_per_nt" in str(e) else None)
+                    if which is None or attempt == 7:
+                        raise
+                    grow[which] *= 4
+                    self.capacity_retries = getattr(self, "capacity_retries", 0) + 1
+                    for b in batches:
+                        b.close()
+                    batches = []
             self.last_fold_driver = max(b.fold_driver for b in batches)
             self.last_fold_peak = batches[0].fold_peak_structs
             if opts.get("_packed"):

@@ -363,3 +363,86 @@ def test_blossom_large_graphs_hubs_and_stars_match_networkx():
         exp = sorted(nx.max_weight_matching(G))
         got = S.Edmonds([[[(u, v)], 1, w] for u, v, w in edges], power=1.0)
         assert got == exp, (k, n, len(edges))
+
+
+def _packed(b, n):
+    buf, off = b.pack_all()
+    return [buf[off[k]:off[k + 1]].tobytes() for k in range(n)]
+
+
+@pytest.mark.parametrize("host_tail", [False, True])
+def test_optimistic_chains_ties_handoff_and_pool_overflow(host_tail, monkeypatch):
+    """Pools that may branch but rarely do (range factor 1.0, poollim > 1: `fastest` at the default pool limit) run as chains
+    on the persistent round kernel (sq_fold_paths bit 4 = 16); a structure that meets a run tied with the best finalscore AND
+    sharing a base with it stops, and the device pools fold its job.  Against the pools alone (SQ_NO_OPT_CHAIN), against the
+    oracle, with the device tail and the host tail, and with the pools overflowing into the host loop (SQ_POOL_SLOTS) after
+    the chains have already finished part of the jobs."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import Batch, Prepared
+    names, psets = conf("fastest")
+    rng = np.random.default_rng(777)
+    raw = _chain_records(140, 9191, 20, 260)
+    # sequences that tie: over two letters runs of equal finalscore that share a base with the best one are common (a third
+    # of such records branch in the reference) -- the branch the chains must hand over
+    for rep in range(48):
+        raw.append(("".join(rng.choice(list("GC"), int(rng.integers(25, 90)))), None, None))
+    prepared = [Prepared(s, r, x) for s, r, x in raw]
+    n = len(prepared)
+    if host_tail:
+        monkeypatch.setenv("SQ_NO_DEVICE_TAIL", "1")
+    with Batch(prepared, [psets] * n, max_structs=16384, fp32=False) as b:
+        monkeypatch.setenv("SQ_NO_OPT_CHAIN", "1")
+        b.fold(poollim=1000)
+        assert b.fold_driver == 2 and not (b.fold_paths & 16), (b.fold_driver, b.fold_paths)
+        want = _packed(b, n)
+        res = b.results_all()
+        monkeypatch.delenv("SQ_NO_OPT_CHAIN")
+        for _ in range(2):
+            b.fold(poollim=1000)
+            assert b.fold_paths & 16, b.fold_paths
+            assert bool(b.fold_paths & 1) == (not host_tail), b.fold_paths
+            assert _packed(b, n) == want
+        # the pools overflow after the chains have finished their share: the host loop repeats EVERY greedy job
+        monkeypatch.setenv("SQ_POOL_SLOTS", "3")
+        for _ in range(2):
+            b.fold(poollim=1000)
+            assert b.fold_paths & 16, b.fold_paths
+            assert _packed(b, n) == want
+        monkeypatch.delenv("SQ_POOL_SLOTS")
+        handed = b.fold_driver
+    assert handed in (2, 3)
+    branched = 0
+    for k in list(range(0, 140, 12)) + list(range(140, n, 2)):
+        s, r, x = raw[k]
+        exp = O.SQRNdbnseq(s, r, x, None, psets, poollim=1000)
+        branched += len(exp[1]) > 1
+        exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(res[k][0] if isinstance(res[k], tuple) else res[k], exp, ("optimistic chains", k))
+    assert branched > 0, "no sampled record branched: the tie hand-off was not exercised"
+
+
+@pytest.mark.parametrize("case", ["gc1500", "minlen1"])
+def test_capacity_overflow_is_repeated_with_a_larger_batch_not_raised(case):
+    """The reference builds Python lists and has no capacities (SQRNdbnseq.py:427-495).  Inputs with several times the runs of
+    a random sequence -- GC-only, 1,500 nt; minlen = 1 on GC-rich sequences -- outgrow the candidate records a batch sizes for
+    random sequences: the engine repeats the fold with a larger batch instead of raising, and the result is the oracle's."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import HipEngine
+    rng = np.random.default_rng(31)
+    if case == "gc1500":
+        names, psets = conf("fastest")
+        seqs = ["".join(rng.choice(list("GC"), 1500)), "".join(rng.choice(list("ACGU"), 300))]
+        poollim = 1
+    else:
+        names, psets = conf("greedynobpp")
+        psets = [dict(psets[0], minlen=1, minbpscore=0.0, bpweights={"GC": 3.25, "AU": 1.25, "GU": 1.0})]
+        seqs = ["".join(rng.choice(list("GCGCGU"), n)) for n in (180, 240, 90)]
+        poollim = 1
+    eng = HipEngine(cand_per_nt=1)                                   # (the estimate for random sequences alone sizes the records)
+    got = eng.fold_records([(s, None, None, None, psets, None) for s in seqs], poollim=poollim)
+    if case == "gc1500":                                             # (minlen = 1: the estimate covers isolated cells by design)
+        assert getattr(eng, "capacity_retries", 0) >= 1, "the case did not outgrow the first batch: it no longer tests the repeat"
+    for s, g in zip(seqs, got):
+        e = O.SQRNdbnseq(s, None, None, None, psets, poollim=poollim)
+        e = [e[0], [[d, list(sc), list(p)] for d, sc, p in e[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(g, e, (case, len(s)))
