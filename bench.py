@@ -65,6 +65,13 @@ def synthetic(workload):
     return out
 
 
+def pools_long_sequences(count=2000, n=500, seed=500):
+    """The pools_long set: `count` i.i.d. uniform ACGU sequences of n nt (seed 500)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    return ["".join(rng.choice(list("ACGU"), n)) for _ in range(count)]
+
+
 def prepare_synthetic(items):
     from squarna_amd.engine import Prepared
     from squarna_amd.dbn import ProcessReacts, ReactDict
@@ -78,7 +85,7 @@ def _oracle_init(cfg):
     from oracle import sqrn_oracle as O
     from squarna_amd.config import ParseConfig, builtin_config
     _O = O
-    _PSETS_BY = {c: ParseConfig(builtin_config(c))[1] for c in {cfg, "fastest"}}
+    _PSETS_BY = {c: ParseConfig(builtin_config(c))[1] for c in {cfg, "fastest", "500nobpp"}}
     _PSETS = _PSETS_BY[cfg]
     O.lib()
 
@@ -190,6 +197,15 @@ def cpu_baseline(workers, recs, cfg, target_s=10.0):
                           seconds_per_sequence_one_core=round(mean_s, 4),
                           sample="first %d sequences of %s, c=fastest pl=1, one per process (wall %.2fs); value = cores / "
                                  "mean seconds per sequence (linear extrapolation to all cores busy)" % (len(tasks), wl, wall))
+    # pools_long (branching pools on 500-nt sequences, the reference's own default from 500 nt on): a few sequences
+    tasks = [("", sq, None, None, None, 1000, "500nobpp") for sq in pools_long_sequences(min(8, cores))]
+    t0 = time.perf_counter()
+    per = list(pool.imap_unordered(_oracle_one, tasks, chunksize=1))
+    wall = time.perf_counter() - t0
+    others["pools_long"] = dict(value=round(cores / float(np.mean(per)), 2), unit="seq/s", cores=cores, kind="port",
+                                seconds_per_sequence_one_core=round(float(np.mean(per)), 4),
+                                sample="first %d sequences of the pools_long set, c=500nobpp poollim=1000, one per process (wall %.2fs); "
+                                       "value = cores / mean seconds per sequence" % (len(tasks), wall))
     out["other_workloads"] = others
     pool.terminate()
     return out
@@ -728,6 +744,35 @@ def shape_leg(recs, config, K, R, steps, device):
                 runalgo_on_device=bool(paths & 2) and bool(paths_many & 2), tail_on_device=bool(paths & 1))
 
 
+# ---------------------------------------------------------------- branching pools on long sequences
+def pools_long_leg(count=2000, n=500, reps=2):
+    """`count` random-ACGU sequences of `n` nt under 500nobpp -- the reference's own configuration from 500 nt on
+    (SQUARNA.py:875-878 -> 500.conf; two greedy paramsets with suboptimality ranges 0.9-0.95, i.e. pools that branch, + E / H /
+    N) -- at the default pool limit of 1000 (SQUARNA.py:421), through the engine (HipEngine.fold_records_packed: sub-batches
+    sized to the device pools' slots; host lists in, packed records out).  A round of the pools of 256+ nt structures is six
+    launches + a host round trip (the one-wave round kernel sq_pool_round.hip takes sequences up to 256 nt; measured up to
+    1,024 it is parity clean and no faster: such a round is bound by the scan and ScoreStems work of its ~20,000 structures
+    per 64 sequences, not by launches)."""
+    import torch
+    from squarna_amd.config import ParseConfig, builtin_config
+    from squarna_amd.engine import HipEngine
+    names, psets = ParseConfig(builtin_config("500nobpp"))
+    recs = [(sq, None, None, None, psets, None) for sq in pools_long_sequences(count, n)]
+    eng = HipEngine()
+    ts = []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = eng.fold_records_packed(recs, poollim=1000)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    best = min(ts[1:])
+    return dict(what="%d random-ACGU sequences of %d nt (seed 500), c=500nobpp poollim=1000, HipEngine.fold_records_packed (host lists in, "
+                     "packed records out), best of %d calls after one warm-up" % (count, n, reps),
+                seconds=round(best, 3), seq_per_s=round(count / best, 1), packed_bytes=int(sum(len(o) if isinstance(o, bytes) else len(o[0]) for o in out)),
+                driver=int(eng.last_fold_driver), peak_structures_first_sub_batch=int(eng.last_fold_peak))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -944,6 +989,14 @@ def main():
         except Exception as e:                                # (a secondary leg never takes the headline down)
             proxy = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    pools_long = None
+    if rank == 0 and world == 1 and not args.no_stream:
+        torch.cuda.empty_cache()
+        try:
+            pools_long = pools_long_leg()
+        except Exception as e:                                # (a secondary leg never takes the headline down)
+            pools_long = {"error": "%s: %s" % (type(e).__name__, e)}
+
     stream = one_pass = None
     if rank == 0 and world == 1 and not args.no_stream:
         torch.cuda.empty_cache()                              # (every leg starts from a clean allocator: the blocks the legs before it left
@@ -1030,6 +1083,8 @@ def main():
         "stream": stream,
         "end_to_end": end_to_end,
         "shape_nobpp": shape,
+        "pools_long": dict(pools_long, vs_cpu_baseline=round(pools_long["seq_per_s"] / cpu["other_workloads"]["pools_long"]["value"], 1))
+                      if pools_long and cpu and "seq_per_s" in pools_long and "pools_long" in cpu.get("other_workloads", {}) else pools_long,
         "strong_scaling_proxy": proxy,
         "sharded": sharded,
         "n_ranks_seen": world if world == 1 else nranks_seen,

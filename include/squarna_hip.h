@@ -287,6 +287,12 @@ SQ_API int sq_result_pack(const sq_batch *b, int32_t seq, void *buf, int64_t cap
  * [off[s], off[s+1]) of buf, off has nseq + 1 entries, records start 8-byte aligned. */
 SQ_API int64_t sq_result_pack_all_size(const sq_batch *b);
 SQ_API int sq_result_pack_all(const sq_batch *b, void *buf, int64_t cap, int64_t *off);
+/* The same records WITHOUT a copy, where the device tail wrote them: *buf = the library's pinned host buffer, *off = its
+ * nseq + 1 offsets (both owned by the batch, valid until its next sq_fold or sq_batch_destroy; read-only).  Returns 0 and the
+ * pointers, or 1 when the last fold's records are not in that form (the host tail ran, or sq_result_limit shows fewer
+ * structures than were packed): then sq_result_pack_all forms them.  Replaces the copy a caller of SQRNdbnseq never had to
+ * make (the reference returns its tuples by reference, SQRNdbnseq.py:1285-1286). */
+SQ_API int sq_result_view(const sq_batch *b, const void **buf, const int64_t **off, int64_t *nbytes);
 /* Dot-bracket rows of every record as ASCII text: record s occupies [off[s], off[s+1]) of buf with its consensus row
  * and then its nstruct structure rows, n characters each (gap-free coordinates; gap columns and separators are
  * re-inserted by the caller, SQRNdbnseq.py:1239-1246).  Levels 1..30 print as ( [ { < A..Z and ) ] } > a..z (:107-112);

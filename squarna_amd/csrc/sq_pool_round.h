@@ -7,7 +7,7 @@
 #ifndef SQ_PR_STAGE
 #define SQ_PR_STAGE 128            // runs the scan stages in LDS before they are scored (64 at a time)
 #endif
-#define SQ_PR_MAXN 256             // longest sequence the kernel takes (one wave per structure)
+#define SQ_PR_MAXN 256             // longest sequence the kernel takes (one wave per structure; measured to 1,024: parity clean, no faster than the launched round kernels from ~300 nt on -- a round of long structures is bound by its scan and ScoreStems work, not by launches)
 
 struct SqPoolRoundArgs {
     int32_t lds_n;          // longest sequence of the launch

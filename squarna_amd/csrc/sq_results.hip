@@ -178,6 +178,15 @@ extern "C" int sq_result_pack_all(const sq_batch *b, void *buf, int64_t cap, int
     return rc.load();
 }
 
+extern "C" int sq_result_view(const sq_batch *b, const void **buf, const int64_t **off, int64_t *nbytes)
+{
+    if (!b || !buf || !off || !nbytes) { sq_set_error("bad argument"); return -1; }
+    if (!(b->packed_ok && packed_whole(b)) || !b->h_rec || !b->h_rec_off) return 1;
+    static_assert(sizeof(long long) == sizeof(int64_t), "offsets are 64-bit");
+    *buf = b->h_rec; *off = reinterpret_cast<const int64_t *>(b->h_rec_off); *nbytes = (int64_t)b->h_rec_off[b->nseq];
+    return 0;
+}
+
 // Dot-bracket rows of every record as ASCII text (the bulk form of levels -> characters): record s occupies
 // [off[s], off[s+1]) with its consensus row and then its nstruct structure rows, n characters each (gap-free
 // coordinates, no separators re-inserted: the caller does that for the records that have any).  Levels 1..30 print as

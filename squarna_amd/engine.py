@@ -568,9 +568,21 @@ class Batch:
         sk = skipped.tolist()
         return [None if sk[k] else text[o[k]:o[k + 1]] for k in range(self.nseq)]
 
-    def pack_all(self):
-        """(uint8 array, int64 offsets[nseq + 1]): the packed results of every record (sq_result_pack_all) -- the
-        payload of the multi-GPU result gather.  The array is a view of a buffer the batch reuses."""
+    def pack_all(self, copy=False):
+        """(uint8 array, int64 offsets[nseq + 1]): the packed results of every record (sq_result_view, else sq_result_pack_all)
+        -- the payload of the multi-GPU result gather.  The array is a view of a buffer the batch reuses (copy=True: of the
+        batch's own pack buffer, never of the library's pinned one)."""
+        # the records where the device tail wrote them (the library's pinned buffer): no copy.  The views are valid until the
+        # batch folds again or closes -- every caller below turns them into bytes / tuples before that
+        pb, po, nb = C.c_void_p(), C.c_void_p(), C.c_int64()
+        rc = self.L.sq_result_view(self.h, C.byref(pb), C.byref(po), C.byref(nb))
+        if rc == 0 and not copy:
+            n = max(int(nb.value), 0)
+            buf = np.ctypeslib.as_array((C.c_uint8 * max(n, 1)).from_address(pb.value))[:n]
+            off = np.ctypeslib.as_array((C.c_int64 * (self.nseq + 1)).from_address(po.value))
+            return buf, off
+        if rc < 0:
+            _lib.check(rc)
         nbytes = int(self.L.sq_result_pack_all_size(self.h))
         # the batch keeps its pack buffer (fresh pages for tens of MB per call cost more than the packing itself); the
         # returned view is valid until the next pack_all of this batch

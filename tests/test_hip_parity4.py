@@ -446,3 +446,17 @@ def test_capacity_overflow_is_repeated_with_a_larger_batch_not_raised(case):
         e = O.SQRNdbnseq(s, None, None, None, psets, poollim=poollim)
         e = [e[0], [[d, list(sc), list(p)] for d, sc, p in e[1]], ["nan"] * 6, ["nan"] * 7]
         _same_fold(g, e, (case, len(s)))
+
+
+def test_pools_long_sample_equals_the_oracle():
+    """bench.py's pools_long workload -- random 500-nt sequences under 500nobpp (the reference's configuration from 500 nt on:
+    two greedy paramsets whose pools branch, + E / H / N) at the default pool limit -- on a 16-record sample against the
+    oracle (worker processes, started before that process touches the GPU: ~7 s of CPU per record), through the engine's
+    sub-batching path."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "16", "500nobpp"], cwd=root,
+                       env=dict(os.environ, FUZZ_SET="pools_long"), capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-2000:]
+    assert r.returncode == 0 and "16 records (config 500nobpp, poollim 1000), 0 mismatches" in r.stdout, tail

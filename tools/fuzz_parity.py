@@ -73,6 +73,9 @@ def _one(rec):
 def main():
     nseq = int(sys.argv[1]); cfg = sys.argv[2]; seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     recs = make(nseq, seed)
+    if os.environ.get("FUZZ_SET") == "pools_long":         # bench.py's pools_long records (random 500-nt sequences) instead
+        import bench
+        recs = [(s, None, None) for s in bench.pools_long_sequences(nseq)]
     import multiprocessing as mp
     t0 = time.time()
     with mp.get_context("spawn").Pool(min(os.cpu_count() or 1, 64), initializer=_init, initargs=(cfg,)) as pool:
