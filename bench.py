@@ -523,6 +523,53 @@ def stream_leg(config, K, R, steps, warmup, device):
                                    how="the next step's Batch() calls on a second host thread while this step folds; the first build is inside the time")
     except Exception as e:                                    # (never take the sequential figure down)
         stream["pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # The same stream through a ROLLING window: K request slots, each a host thread of its own that creates its next batch,
+    # folds it, reads it out and destroys it -- no barrier between the slots, so the batches drift apart as the resident
+    # batches of the headline do (a step's barrier costs the ramp-up and the matching kernels' tail of EVERY step: a fold of
+    # fresh batches 26 ms against 18.8 resident).  New records every batch, upload and read-out inside the time.
+    try:
+        import threading
+        rstreams = [torch.cuda.Stream(device) for _ in range(K)]
+        errs = []
+
+        def slot(q, nb, base, out):
+            try:
+                for t in range(nb):
+                    start = (((base + t) * K + q) * 97) % len(allp)
+                    sel = [allp[(start + i) % len(allp)] for i in range(219 * R)]
+                    with torch.cuda.stream(rstreams[q]):
+                        b = Batch(sel, [psets] * len(sel), fp32=False, max_structs=4096 * R)
+                    try:
+                        b.set_inflight(K)
+                        b.fold(poollim=1000)
+                        out[q] = int(b.pack_all()[1][-1])
+                    finally:
+                        b.close()
+            except Exception as e:                            # (reported by the main thread)
+                errs.append(e)
+
+        def rolling(nb, base):
+            out = [0] * K
+            th = [threading.Thread(target=slot, args=(q, nb, base, out)) for q in range(K)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            if errs:
+                raise errs[0]
+            return sum(out)
+        rolling(3, 3000)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        packed3 = rolling(steps, 4000)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t0
+        stream["rolling"] = dict(seq_per_s=round(219 * R * K * steps / dt3, 1), ms_per_batch_round=round(dt3 / steps * 1e3, 3), packed_bytes_last_round=packed3,
+                                 how="%d request slots, each a host thread that runs Batch() -> sq_fold -> sq_result_view -> close for %d new "
+                                     "batches of 219 x %d records one after the other, no barrier between the slots (sq_batch_set_inflight(%d)); "
+                                     "the interpreter lock serialises the slots' Python parts" % (K, steps, R, K))
+    except Exception as e:
+        stream["rolling"] = {"error": "%s: %s" % (type(e).__name__, e)}
     dt1, per1, packed1 = timed(1, 1, 10, 3)
     gc.enable()
     one = dict(what="ONE pass over 219 records (a different window every call): Batch() + sq_fold + sq_result_pack_all, nothing "

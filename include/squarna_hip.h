@@ -236,6 +236,11 @@ SQ_API int sq_fold_concurrent(sq_batch *const *batches, int32_t nbatch, const sq
  * between the repetitions -- the batches drift apart and overlap each other's host-heavy and GPU-heavy phases (a
  * server that re-uses resident batches for a stream of identical requests; bench.py's timed region is one such call).
  * After the call every batch holds the results of its last fold. */
+/* A caller that folds several batches at once from threads of its OWN (a server with a rolling window of requests: each slot
+ * creates, folds, reads out and destroys its batches independently, no barrier between them) tells every batch how many are
+ * in flight -- what sq_fold_concurrent does for its batches: the host threads then wait for the device with pauses instead of
+ * spinning on every CPU, and the worker pools and side streams are sized for a shared chip.  n < 1 counts as 1. */
+SQ_API int sq_batch_set_inflight(sq_batch *b, int32_t n);
 SQ_API int sq_fold_concurrent_n(sq_batch *const *batches, int32_t nbatch, const sq_fold_opts *opts,
                                 const int32_t *const *ref_off, const int32_t *const *ref_pairs, const uint8_t *const *has_ref,
                                 int32_t reps);

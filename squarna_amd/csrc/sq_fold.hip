@@ -1015,6 +1015,14 @@ extern "C" int32_t sq_fold_driver(const sq_batch *b) { return b ? b->last_driver
 extern "C" int32_t sq_fold_paths(const sq_batch *b) { return b ? b->last_paths : -1; }
 extern "C" int64_t sq_fold_peak_structs(const sq_batch *b) { return b ? b->last_peak : -1; }
 
+extern "C" int sq_batch_set_inflight(sq_batch *b, int32_t n)
+{
+    if (!b) { sq_set_error("bad argument"); return -1; }
+    b->inflight = n < 1 ? 1 : n;
+    b->side_streams = b->inflight >= 3 ? 2 : 3;
+    return 0;
+}
+
 extern "C" int sq_fold_concurrent(sq_batch *const *batches, int32_t nbatch, const sq_fold_opts *opts,
                                   const int32_t *const *ref_off, const int32_t *const *ref_pairs, const uint8_t *const *has_ref)
 {

@@ -397,6 +397,10 @@ class Batch:
         return [[(out[q].i, out[q].j, out[q].len, out[q].bpscore, out[q].finscore)
                  for q in range(off[k], off[k + 1])] for k in range(nj)]
 
+    def set_inflight(self, n):
+        """Tell the batch that n batches are folded at the same time from threads of the caller (sq_batch_set_inflight)."""
+        _lib.check(self.L.sq_batch_set_inflight(self.h, int(n)))
+
     # -- a-7 + a-10
     def fold(self, **opts):
         """priority: per record, set of local paramset indices (or one set for all)."""
