@@ -421,7 +421,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             // (short sequences -- one wave per structure -- are better off with the matrices the bit kernel writes at full width:
             // S300 x 10,000 1.78 against 1.84 ms; from ~500 nt on the kernel's own words win: S1000 x 1,024 1.47 -> 1.31 ms)
             static const int fly_min = getenv("SQ_FLY_MIN_N") ? atoi(getenv("SQ_FLY_MIN_N")) : 400;
-            if (maxn >= fly_min && sq_bits_fly_bytes(maxn, b->nletters) <= (size_t)(lo.off_tab - lo.off_str)) ra.fly = b->nletters;
+            if (maxn >= fly_min && b->nletters <= SQ_FLY_MAXL && sq_bits_fly_bytes(maxn, b->nletters) <= (size_t)(lo.off_tab - lo.off_str)) ra.fly = b->nletters;
         }
         if (ra.fly == 0) { const int pr = sq_prepare_scan(b); if (pr) { fail(pr, sq_last_error()); return; } }
         if (!rounds_ok && chain_ties) {                       // (the launched rounds do not look for ties: the pools take these jobs)

@@ -233,9 +233,9 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
             // the letter masks of sq_bits_masks_kernel, in the LDS the strands and stems of the later rounds will take (the
             // structure is empty now)
             char *const mreg = rd_dyn + Lo.off_str;
-            const int npad = (n + 3) & ~3, nw = (n + 31) >> 5, mw = nw + 3, maxl = ra.fly;
+            const int npad = (n + 3) & ~3, nw = (n + 31) >> 5, maxl = ra.fly;
             uint8_t *const m_ccode = reinterpret_cast<uint8_t *>(mreg), *const m_rcode = m_ccode + npad, *const m_inc = m_rcode + npad;
-            uint32_t *const m_M = reinterpret_cast<uint32_t *>(m_inc + npad), *const m_R = m_M + maxl * mw;
+            uint32_t *const m_M = reinterpret_cast<uint32_t *>(m_inc + npad), *const m_R = m_M + maxl * fbh;
             uint32_t mine = 0;
             if (tid == 0) s_present = 0u;
             __syncthreads();
@@ -252,13 +252,14 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
             const uint32_t present = s_present;
             const int nlet = __popc(present);                                              // <= maxl (host: letters of the batch)
             auto letter = [&](int k) -> uint32_t { uint32_t m = present; for (int t = 0; t < k; t++) m &= m - 1; return (uint32_t)(__ffs((int)m) - 1); };
-            for (int e = tid; e < nlet * mw; e += nthr) {                                   // column masks
-                const int k = e / mw, q = e - k * mw;
+            for (int e = tid; e < nlet * fbh; e += nthr) {                                  // column masks over the reversed positions (G's layout)
+                const int k = e / fbh, q = e - k * fbh;
                 const uint32_t pm = ps->pmask[letter(k)];
                 uint32_t word = 0;
-                const int j0 = (q - 1) * 32;
-                if (q >= 1 && j0 < n)
-                    for (int bb = 0; bb < 32 && j0 + bb < n; bb++) word |= ((pm >> m_ccode[j0 + bb]) & 1u) << bb;
+                for (int bb = 0; bb < 32; bb++) {
+                    const int pos = n - 1 - (32 * q + bb - SQ_GPAD);
+                    if (pos >= 0 && pos < n) word |= ((pm >> m_ccode[pos]) & 1u) << bb;
+                }
                 m_M[e] = word;
             }
             for (int e = tid; e < nw * nlet; e += nthr) {                                   // row masks
@@ -269,7 +270,9 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 m_R[w * maxl + k] = word;
             }
             __syncthreads();
-            sq_scan6_groups(c, jb, FG, FG + fbh, fbh, E, wv, nwv, lane, sink, SqBitsFly{m_M, m_R, m_inc, mw, nlet, maxl, n});
+            SqBitsFly fly;
+            fly.Mr = m_M; fly.R = m_R; fly.inc = m_inc; fly.fbh = fbh; fly.nlet = nlet; fly.maxl = maxl; fly.n = n;
+            sq_scan6_groups(c, jb, FG, FG + fbh, fbh, E, wv, nwv, lane, sink, fly);
         } else
             sq_scan6_groups(c, jb, FG, FG + fbh, fbh, E, wv, nwv, lane, sink, SqBitsGlobal{c.bits + jb.bits_off, jb.bpitch});
     }

@@ -32,47 +32,59 @@
 // the word from letter masks in LDS, so that a fold that scans every job ONCE never writes the matrix at all.
 struct SqBitsGlobal {
     const uint32_t *bp; int bpitch;
-    __device__ __forceinline__ uint32_t word(int w, int s) const { return bp[(int64_t)w * bpitch + s]; }
+    __device__ __forceinline__ void start(int) {}
+    __device__ __forceinline__ uint32_t next(int w, int s, int, int) { return bp[(int64_t)w * bpitch + s]; }
 };
 // The letter-mask form of sq_bits_masks_kernel (sq_kernels.hip), word by word: for the letters x present in the sequence,
-// R[w][x] = the rows of word-row w with letter x (and no row-side restraint flag), M[x] = the columns whose letter may pair
-// with x (and no column-side flag) as a bit array over j behind one zero word.  word(w, s) = OR_x R[w][x] & reverse(M[x][t - 31 .. t]),
-// t = s - 32w; only the words next to the main diagonal check the minimal loop length bit by bit (:294-299).
+// R[w][x] = the rows of word-row w with letter x (and no row-side restraint flag), Mr[x] = the columns whose letter may pair
+// with x (and no column-side flag) as a bit array over the REVERSED positions, laid out like the scan's own G array (bit
+// k + SQ_GPAD <-> position n - 1 - k, fbh words, zeros outside the sequence).  The columns of word (w, s) -- s - 32w - b, b = 0 .. 31
+// -- are then the very 32-bit window of Mr[x] the scan takes of G: it advances by one word per word-row, so a step costs one
+// LDS word and one funnel shift per letter (the first form looked each window up anew: 40 instructions per word).  Only
+// the words next to the main diagonal check the minimal loop length bit by bit (:294-299).  Stateful: start() at the first
+// word-row of a diagonal group, then next() for every word-row in turn.
+#define SQ_FLY_MAXL 8               // letters of a batch the masks are kept for (more: the bit kernel's matrices)
 struct SqBitsFly {
-    const uint32_t *M, *R; const uint8_t *inc; int mw, nlet, maxl, n;
-    __device__ __forceinline__ uint32_t word(int w, int s) const
+    const uint32_t *Mr, *R; const uint8_t *inc; int fbh, nlet, maxl, n;
+    uint32_t lo[SQ_FLY_MAXL];
+    __device__ __forceinline__ void start(int gidx)
     {
-        const int i0 = 32 * w, t = s - i0;                                   // column of bit 0
+#pragma unroll
+        for (int k = 0; k < SQ_FLY_MAXL; k++) lo[k] = k < nlet ? Mr[k * fbh + gidx] : 0u;
+    }
+    __device__ __forceinline__ uint32_t next(int w, int s, int gi, int gsh)
+    {
         uint32_t word = 0;
-        if (s >= 4 && s <= 2 * n - 6 && t >= 0 && t - 31 < n) {
-            const int q = t + 1;                                             // bit index of column t - 31 behind the zero word
-            const uint32_t *Rw = R + w * maxl;
-            for (int k = 0; k < nlet; k++) {
-                const uint32_t *Mk = M + k * mw + (q >> 5);
-                const uint64_t two = ((uint64_t)Mk[1] << 32) | Mk[0];
-                word |= Rw[k] & __brev((uint32_t)(two >> (q & 31)));
+        const uint32_t *Rw = R + w * maxl;
+#pragma unroll
+        for (int k = 0; k < SQ_FLY_MAXL; k++)
+            if (k < nlet) {
+                const uint32_t hi = Mr[k * fbh + gi];
+                word |= Rw[k] & __builtin_amdgcn_alignbit(hi, lo[k], (uint32_t)gsh);
+                lo[k] = hi;
             }
-            const int d = s - 2 * i0;                                        // j - i of bit b is d - 2b
-            if (word && d < 4 + 62) {
-                uint32_t keep = 0;
-                for (int bb = 0; bb < 32 && i0 + bb < n; bb++)
-                    if (d - 2 * bb >= (int)inc[i0 + bb]) keep |= 1u << bb;      // :294-299
-                word &= keep;
-            }
+        const int i0 = 32 * w, t = s - i0;                                   // column of bit 0
+        if (!(s >= 4 && s <= 2 * n - 6 && t >= 0 && t - 31 < n)) word = 0;      // (outside the matrix: the window is not this diagonal's)
+        const int d = s - 2 * i0;                                            // j - i of bit b is d - 2b
+        if (word && d < 4 + 62) {
+            uint32_t keep = 0;
+            for (int bb = 0; bb < 32 && i0 + bb < n; bb++)
+                if (d - 2 * bb >= (int)inc[i0 + bb]) keep |= 1u << bb;          // :294-299
+            word &= keep;
         }
         return word;
     }
 };
-// LDS of the masks: column letters, row letters, minimal j - i (a byte per position each), M, R
+// LDS of the masks: row letters, minimal j - i (a byte per position each), Mr, R
 __host__ __device__ inline size_t sq_bits_fly_bytes(int n, int nletters)
 {
-    const size_t npad = ((size_t)n + 3) & ~(size_t)3, nw = ((size_t)n + 31) / 32;
-    return 3 * npad + 4 * (size_t)nletters * (nw + 3) + 4 * nw * (size_t)nletters + 16;
+    const size_t npad = ((size_t)n + 3) & ~(size_t)3, nw = ((size_t)n + 31) / 32, fbh = (((size_t)n + 2 + 31) >> 5) + 8;
+    return 3 * npad + 4 * (size_t)nletters * fbh + 4 * nw * (size_t)nletters + 16;
 }
 
 template <class Sink, class Bits>
 __device__ __forceinline__ void sq_scan6_groups(const SqDevCtx &c, const SqJob &jb, const uint32_t *F, const uint32_t *G, int fbh,
-                                                const uint8_t *eg, int gy0, int gystep, int lane, Sink &sink, const Bits &bits)
+                                                const uint8_t *eg, int gy0, int gystep, int lane, Sink &sink, Bits bits)
 {
     const int n = jb.n;
     const SqPsetDev *ps = c.psets + jb.pset;
@@ -112,6 +124,7 @@ __device__ __forceinline__ void sq_scan6_groups(const SqDevCtx &c, const SqJob &
 
         int carry = 0;
         uint32_t glo = G[gidx];
+        bits.start(gidx);
         // window of minlen ones by doubling: Y &= Y >> ysh_q, five fixed steps (shift 0 once the window is complete)
         int ysh0, ysh1, ysh2, ysh3, ysh4;
         {
@@ -128,7 +141,7 @@ __device__ __forceinline__ void sq_scan6_groups(const SqDevCtx &c, const SqJob &
         for (int w0 = wlo; w0 <= whi; w0 += SQ6_AHEAD) {
             uint32_t bw[SQ6_AHEAD];
 #pragma unroll
-            for (int k = 0; k < SQ6_AHEAD; k++) bw[k] = w0 + k <= whi ? bits.word(w0 + k, s) : 0u;
+            for (int k = 0; k < SQ6_AHEAD; k++) bw[k] = w0 + k <= whi ? bits.next(w0 + k, s, gidx + 1 + (w0 + k - wlo), gsh) : 0u;
 #pragma unroll
             for (int k = 0; k < SQ6_AHEAD; k++) {
                 const int w = w0 + k;

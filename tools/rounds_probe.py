@@ -13,7 +13,7 @@ names, psets = ParseConfig(builtin_config("fastest"))
 data = _synthetic(n, count, n, reacts)
 prepared = [Prepared(s, rc) for s, rc in data]
 packs = {}
-for mode in ("rounds", "launched"):
+for mode in (("rounds",) if os.environ.get("SQ_NO_LAUNCHED") else ("rounds", "launched")):
     if mode == "launched":
         os.environ["SQ_NO_ROUNDS"] = "1"
     else:
@@ -27,4 +27,4 @@ for mode in ("rounds", "launched"):
         packs[mode] = bytes(buf[:off[-1]])
         ev = sum(b.evals(k) for k in range(count))
         print("%s N=%d x %d: fold ms %s  (min %.3f) evals %d paths %d" % (mode, n, count, " ".join("%.3f" % t for t in ts), min(ts), ev, b.fold_paths), flush=True)
-print("identical:", packs["rounds"] == packs["launched"])
+print("identical:", packs["rounds"] == packs.get("launched", packs["rounds"]))
