@@ -130,8 +130,48 @@ def SQRNdbnali(objs, defrests=None, defreacts=None, defref=None, bpweights={}, i
     return pred[0], stemmatrix
 
 
+def _consensus_bulk(structs, freqlimit):
+    """Consensus for many long lines (config 5: 512 x 5000): DBNToPairs of all lines in ONE library call (sq_dbn_pairs),
+    the counts with numpy.  The reference's order is kept exactly: a stable sort by descending count over the dict's
+    insertion order (SQRNdbnali.py:285) == count descending, first occurrence ascending.  None: lines beyond ASCII
+    (the caller's Python form takes them)."""
+    import ctypes
+    from . import _lib
+    N = len(structs[0])
+    text = "".join(structs)
+    if not text.isascii():
+        return None
+    L = _lib.load()
+    off = np.zeros(len(structs) + 1, np.int64)
+    np.cumsum([len(x) for x in structs], out=off[1:])
+    poff = np.zeros(len(structs) + 1, np.int64)
+    rp = np.zeros(max(len(text), 2), np.int32)                      # (a line of n characters has at most n / 2 pairs)
+    ptr = lambda a: ctypes.c_void_p(a.ctypes.data)
+    _lib.check(L.sq_dbn_pairs(text.encode("ascii"), ptr(off), len(structs), ptr(rp), len(rp) // 2, ptr(poff)))
+    pairs = rp[:2 * int(poff[-1])].reshape(-1, 2).astype(np.int64)
+    width = max(max(len(x) for x in structs), 1)
+    keys = pairs[:, 0] * width + pairs[:, 1]
+    uniq, first, counts = np.unique(keys, return_index=True, return_counts=True)
+    order = np.lexsort((first, -counts))
+    lim = freqlimit * len(structs)
+    seen = bytearray(width + 1)
+    res = []
+    for k, c in zip(uniq[order].tolist(), counts[order].tolist()):
+        if c < lim:
+            break                                                    # (counts only fall from here on)
+        v, w = divmod(k, width)
+        if not seen[v] and not seen[w]:
+            seen[v] = seen[w] = 1
+            res.append((v, w))
+    return PairsToDBN(res, N)
+
+
 def Consensus(structs, freqlimit=0.0, verbose=False, sink=sys.stdout):
     """Most frequent non-conflicting base pairs (SQRNdbnali.py:271-304)."""
+    if not verbose and structs and len(structs) * len(structs[0]) >= 4096:
+        fast = _consensus_bulk(structs, freqlimit)
+        if fast is not None:
+            return fast
     bps = {}
     freqlimit *= len(structs)
     for struct in structs:

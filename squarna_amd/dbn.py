@@ -96,16 +96,50 @@ def gap_mask(seq):
     return _GAP_LUT[np.frombuffer(seq.encode('latin-1', 'replace'), np.uint8)]
 
 
-def UnAlign(seq, dbn):
-    """Drop gap columns; pairs touching a gap become dots first (SQRNdbnseq.py:236-255)."""
+_ALN_PAIRS = [None, None, None]     # the line DBNToPairs was last asked for by UnAlign, and its pairs as two arrays
+
+
+def _aligned_pairs(dbn):
+    """DBNToPairs(dbn) as (v, w) arrays; the last line is remembered -- the rows of an alignment share one restraint line."""
+    import numpy as np
+    if _ALN_PAIRS[0] != dbn:
+        pairs = DBNToPairs(dbn)
+        _ALN_PAIRS[1] = np.array([p[0] for p in pairs], np.int64)
+        _ALN_PAIRS[2] = np.array([p[1] for p in pairs], np.int64)
+        _ALN_PAIRS[0] = dbn
+    return _ALN_PAIRS[1], _ALN_PAIRS[2]
+
+
+def UnAlign(seq, dbn, want_pairs=False):
+    """Drop gap columns; pairs touching a gap become dots first (SQRNdbnseq.py:236-255).  want_pairs: a third value, the
+    pairs of the returned line (== DBNToPairs of it: taking matched pairs and unmatched brackets out of a line leaves the
+    matching of the others as it was) or None when they were not formed."""
     import numpy as np
     if '-' not in seq and '.' not in seq and '~' not in seq:
-        return seq, dbn
+        return (seq, dbn, None) if want_pairs else (seq, dbn)
     gaps = gap_mask(seq)
     keep = np.flatnonzero(~gaps)
     shortseq = seq.translate(_DROP_GAPS)
     if dbn.count('.') == len(dbn):                       # no brackets at all: nothing to clean
-        return shortseq, '.' * len(keep)
+        return (shortseq, '.' * len(keep), []) if want_pairs else (shortseq, '.' * len(keep))
+    try:
+        raw = dbn.encode('latin-1')
+    except UnicodeEncodeError:                           # (bracket letters beyond latin-1: the character loop below)
+        raw = None
+    if raw is not None:
+        v, w = _aligned_pairs(dbn)
+        bad = gaps[v] | gaps[w]
+        arr = np.frombuffer(raw, np.uint8).copy()
+        arr[v[bad]] = 46
+        arr[w[bad]] = 46
+        short = arr[keep].tobytes().decode('latin-1')
+        if not want_pairs:
+            return shortseq, short
+        rank = np.cumsum(~gaps) - 1
+        ok = ~bad
+        return shortseq, short, list(zip(rank[v[ok]].tolist(), rank[w[ok]].tolist()))
+    if want_pairs:
+        return UnAlign(seq, dbn) + (None,)
     clean = list(dbn)
     for v, w in DBNToPairs(dbn):
         if gaps[v] or gaps[w]:
@@ -121,14 +155,16 @@ def ReAlign(shortdbn, longseq, seqmode=False):
     return ''.join(('-' if seqmode else '.') if ch in GAPS else next(it) for ch in longseq)
 
 
-def ParseRestraints(restraints):
-    """Restraint line -> (bps, unpaired, no-left, no-right) (SQRNdbnseq.py:370-376)."""
+def ParseRestraints(restraints, rbps=None):
+    """Restraint line -> (bps, unpaired, no-left, no-right) (SQRNdbnseq.py:370-376).  rbps: DBNToPairs(restraints) when the
+    caller has it already (UnAlign(..., want_pairs=True))."""
     if restraints.count('.') == len(restraints):         # the common case: no restraints
         return [], set(), set(), set()
-    rbps = DBNToPairs(restraints)
-    rxs = {i for i, c in enumerate(restraints) if c in '_+'}
-    rlefts = {i for i, c in enumerate(restraints) if c == '/'}
-    rrights = {i for i, c in enumerate(restraints) if c == '\\'}
+    if rbps is None:
+        rbps = DBNToPairs(restraints)
+    rxs = {i for i, c in enumerate(restraints) if c in '_+'} if ('_' in restraints or '+' in restraints) else set()
+    rlefts = {i for i, c in enumerate(restraints) if c == '/'} if '/' in restraints else set()
+    rrights = {i for i, c in enumerate(restraints) if c == '\\'} if '\\' in restraints else set()
     return rbps, rxs, rlefts, rrights
 
 

@@ -68,7 +68,7 @@ class Prepared:
         if type(reacts) == str:                                      # :1019-1020 (default B = 1.6)
             reacts = ProcessReacts([ReactDict[ch] for ch in reacts])
         self.seq = seq
-        self.shortseq, self.shortrest = UnAlign(seq, restraints)     # :1023
+        self.shortseq, self.shortrest, rbps = UnAlign(seq, restraints, want_pairs=True)     # :1023
         if '-' in seq or '.' in seq or '~' in seq:
             gaps = gap_mask(seq)
             self.gapidx = np.flatnonzero(gaps).tolist()
@@ -86,7 +86,7 @@ class Prepared:
         if dbn:
             assert len(seq) == len(dbn)
             self.shortseq, self.shortdbn = UnAlign(seq, dbn)         # :1026-1028
-        self.rbps, self.rxs, self.rlefts, self.rrights = ParseRestraints(self.shortrest)   # :1037
+        self.rbps, self.rxs, self.rlefts, self.rrights = ParseRestraints(self.shortrest, rbps)   # :1037
 
 
 _HDR = struct.Struct("<4q")
@@ -833,10 +833,14 @@ class HipEngine:
         # dense per-job matrices (alignment step 2: N x N fp64 + fp32 per job) bound a sub-batch as well: 32 GB of them
         # (allocating and touching 100 GB per batch costs more than the larger rounds save)
         dense = [12.0 * len(r[0]) ** 2 * len(r[4]) if len(r) > 5 and r[5] is not None else 0.0 for r in records]
+        dense_cap = float(os.environ.get("SQ_DENSE_GB", "32")) * 1e9
+        if sum(dense) > dense_cap:
+            # sub-batches of equal weight (a last one of a few records would run its rounds on a mostly empty chip)
+            dense_cap = sum(dense) / np.ceil(sum(dense) / dense_cap) + max(dense)
 
         def next_group(lo):
             hi, g, gb = lo, 0.0, 0.0
-            while hi < len(records) and (hi == lo or (g + max(16.0, per_rec[hi] * scale) <= cap and gb + dense[hi] <= 32e9)):
+            while hi < len(records) and (hi == lo or (g + max(16.0, per_rec[hi] * scale) <= cap and gb + dense[hi] <= dense_cap)):
                 g += max(16.0, per_rec[hi] * scale)
                 gb += dense[hi]
                 hi += 1
