@@ -406,7 +406,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             // small batch), twice / four times that: a structure's rounds are a chain of dependent passes over its list that
             // more waves shorten (S1000 x 128: 1.21 -> 0.99 ms at 512 threads)
             thr = maxn <= 320 ? 64 : (maxn <= 450 ? 128 : 256);
-            while (!thr_env && thr < SQ_ROUNDS_THREADS && thr < maxn / 2 && (int64_t)S * thr * 2 <= (int64_t)256 * 512) thr *= 2;
+            // (up to one block of 1,024 per CU: S2000 x 125 3.10 -> 2.80 ms with 1,024 instead of 512 threads; S1000 x 128 0.86 / 0.76 /
+            // 0.75 ms with 256 / 512 / 1,024 -- there the pass over the list is no longer what a round waits for)
+            while (!thr_env && thr < SQ_ROUNDS_THREADS && thr < maxn / 2 && ((int64_t)S * thr * 2 <= (int64_t)256 * 512 || (S <= 256 && thr * 2 <= maxn / 2 + 64))) thr *= 2;
             if (thr_env) { thr = 64; while (thr * 2 <= thr_env) thr *= 2; }   // (a power of two: the survivor ring is indexed with a mask)
             ra.lds_n = maxn; ra.str_cap = 2 * maxt + 2; ra.tmax = maxt; ra.cell_entries = b->cell_entries;
             ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0; ra.ties = chain_ties ? 1 : 0;

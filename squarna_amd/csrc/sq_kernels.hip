@@ -642,6 +642,7 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     const SqStruct st = structs[blockIdx.x];
 #ifdef SQ_SCORE_PROF
     const long long _p0 = wall_clock64(); long long _pa = 0, _pb = 0, _ps = 0;
+    int _nsc = 0, _ngr = 0, _n492 = 0;       // ScoreStems calls of the first wave, its groups, candidates of the first wave that passed :492
 #endif
     const SqJob jb = c.jobs[st.job];
     const SqPsetDev *ps = c.psets + jb.pset;
@@ -1001,7 +1002,10 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
         for (int u = 0; u < SQ_SCORE_CHUNK; u++) {
             const int L = (int)cd[u].len;
             const double bps = bpsv[u];
-            const bool ok = L > 0 && bps >= minbps && !(upper(bps) < need);   // :492, and the bound
+#ifdef SQ_SCORE_PROF
+            _n492 += __popcll(__ballot(L > 0 && bps >= minbps));
+#endif
+            bool ok = L > 0 && bps >= minbps && !(upper(bps) < need);         // :492, and the bound
             const unsigned long long okm = __ballot(ok);
             if (okm) {
                 uint32_t base = 0;
@@ -1035,6 +1039,9 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                 const unsigned long long sbst = s_best;                     // (the groups before this one may have raised it)
                 if (sbst && upper(bps) < st_subopt * sq_unord(sbst)) ok = false;
             }
+#ifdef SQ_SCORE_PROF
+            _nsc += __popcll(__ballot(ok)); _ngr++;
+#endif
             if (ok) {
                 fin = sq_stem_finalscore(env, i0, j0, L, bps);
                 ok = fin >= minfin;                                         // :751
@@ -1081,9 +1088,9 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
 #endif
     }
 #ifdef SQ_SCORE_PROF
-    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 700) && blockIdx.y == 0)
-        printf("score block %d: n=%d ncand=%u nstrand=%d | us: setup %.1f phaseA %.1f phaseB %.1f total %.1f\n", (int)blockIdx.x, n, ncand, st.nstrand,
-               _ps * 0.01, _pa * 0.01, _pb * 0.01, (wall_clock64() - _p0) * 0.01);
+    if (tid == 0 && (blockIdx.x % 509) == 0 && blockIdx.y == 0)
+        printf("score block %d: n=%d ncand=%u nstrand=%d threads %d | first wave: passed :492 %d, scored %d in %d groups | us: setup %.1f phaseA %.1f phaseB %.1f total %.1f\n", (int)blockIdx.x, n, ncand, st.nstrand, nthr,
+               _n492, _nsc, _ngr, _ps * 0.01, _pa * 0.01, _pb * 0.01, (wall_clock64() - _p0) * 0.01);
 #endif
 
     if (solo) {                                         // the length of the survivor list (zeroed by the state kernel)

@@ -130,12 +130,15 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     // bound / score steps, pick, extension + state
     long long _pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
     long long _cnt[4] = {0, 0, 0, 0};       // entries streamed, finalscores taken from the list, runs scored (first wave), rounds
+    long long _sp[6] = {0, 0, 0, 0, 0, 0};  // the score step: [0] wait for the structure, [1] entry loads, [3] the rest; [4] steps
+#define SPROF(k) do { const long long _n = wall_clock64(); _sp[k] += _n - _t2; _t2 = _n; } while (0)
 #define RPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)
-#define RPROF_OUT() do { if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d n=%d rounds %lld | us: setup %.1f scan %.1f order %.1f stream %.1f cut %.1f bound %.1f score %.1f pick %.1f ext %.1f between %.1f total %.1f | wave 0: streamed %lld kept %lld scored %lld\n", \
+#define RPROF_OUT() do { if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d score steps %lld | us: wait for the structure %.1f entry loads %.1f ScoreStems + stores + pick %.1f\n", b, wv, _sp[4], _sp[0] * 0.01, _sp[1] * 0.01, _sp[3] * 0.01); if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d n=%d rounds %lld | us: setup %.1f scan %.1f order %.1f stream %.1f cut %.1f bound %.1f score %.1f pick %.1f ext %.1f between %.1f total %.1f | wave 0: streamed %lld kept %lld scored %lld\n", \
         b, wv, n, _cnt[3], _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, _pt[6] * 0.01, _pt[7] * 0.01, _pt[8] * 0.01, _pt[9] * 0.01, (wall_clock64() - _t00) * 0.01, _cnt[0], _cnt[1], _cnt[2]); } while (0)
 #else
 #define RPROF(k) do {} while (0)
 #define RPROF_OUT() do {} while (0)
+#define SPROF(k) do {} while (0)
 #endif
     const SqStruct st = structs[b];
     if (st.nstrand < 0) return;
@@ -565,31 +568,44 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
             const bool cutbusy = cm != 0ull || nX > 0;
             if (nS >= 64 || (end && !cutbusy && nC == 0 && nS > 0)) {
                 // ---- score: ScoreStems for a wave of runs whose bound reaches the bar ----
+#ifdef SQ_ROUNDS_PROF
+                long long _t2 = wall_clock64(); _sp[4]++;
+#endif
                 if (!struct_ready) {                                            // (the first wave is still putting the last stem in)
                     while (__atomic_load_n(&s_ready, __ATOMIC_RELAXED) < roundno) __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     struct_ready = true;
                 }
+                SPROF(0);
                 const double need = bar();
                 const uint32_t m = nS < 64 ? nS : 64; nS -= m;
                 const bool have = (uint32_t)lane < m;
                 const uint32_t q = have ? qsurv[nS + lane] : 0u;
                 uint32_t key = 0, lf = 0; double bps = 0.0, ub = 0.0;
                 if (have) { const SqRunA r = LA[q]; key = r.key; lf = r.lf; bps = r.bps; ub = LB[q].ub; }
+#ifdef SQ_ROUNDS_PROF
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SPROF(1);
+#endif
                 bool ok = have && !(ub < need);                                 // (the bar may have risen since the run was queued)
 #ifdef SQ_ROUNDS_PROF
                 if (lane == 0) _cnt[2] += __popcll(__ballot(ok));
 #endif
                 double fin = 0.0;
                 const int L = (int)(lf & SQ_RX_LEN);
+                const int i0 = (int)(key & 0xFFFFu), j0 = (int)(key >> 16) - i0;
+                // (a strand per lane for ONE run at a time -- the walk's inblockend is a running maximum, so a wave can take the
+                // strands of a span as a prefix-maximum scan -- was built for the handful of runs a pass ends with and measured:
+                // 0.5-1 us per run against 5-9 us for a wave of runs walked side by side; a pass ends with more than a handful,
+                // S2000 x 125 2.95 -> 3.09 ms: dropped)
+                if (ok) fin = sq_stem_finalscore(env, i0, j0, L, bps);
                 if (ok) {
-                    const int i0 = (int)(key & 0xFFFFu), j0 = (int)(key >> 16) - i0;
-                    fin = sq_stem_finalscore(env, i0, j0, L, bps);
                     LB[q].fin = fin; LA[q].lf = lf | SQ_RX_FIN;
                     ok = fin >= minfin;                                         // :751
                 }
                 take(ok, fin, key, (uint32_t)L, bps);
                 raise(ok, fin);
+                SPROF(3);
                 RPROF(6);
                 continue;
             }
@@ -738,7 +754,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
             if (lane == 0) {
                 XL.i[k] = (int16_t)i0; XL.j[k] = (int16_t)j0; XL.len[k] = (int16_t)len; XL.cc[k] = newcc;
                 gst[k] = SqChainStem{i0, j0, len, newcc};           // (the tail reads the stems there; the weights of the others stay in LDS)
-                cio.h_stems[ch.toff + k] = SqStemOut{i0, j0, len, 0, bbps, bfin};
+                cio.h_stems[ch.toff + k] = SqStemOut{i0, j0, len, 0, bbps, bfin};   // (pinned; measured: the posted write costs a round nothing)
                 s_cross = ac ? 1 : 0;
                 s_best = 0ull;                                      // (the next pass starts without a bar and with all units to take)
                 s_unit = 0u;
