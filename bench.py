@@ -958,6 +958,33 @@ def main():
 
     same = same and all(repr(b0.result(k)) == repr(results[k]) for k in range(0, len(prepared), 5))
     b0.close()
+    # the same batch under greedynobpp (no Edmonds / Hungarian / Nussinov job beside the pools: the fold IS the greedy loop
+    # of the device pools, a chain of rounds) -- with the rounds enqueued ahead of the host and one by one
+    greedy_alone = None
+    if not args.no_stream:
+        from squarna_amd.config import ParseConfig as _PC, builtin_config as _bc
+        gpsets = _PC(_bc("greedynobpp"))[1]
+        greedy_alone = {}
+        for tag, env in (("ms_per_fold", None), ("ms_per_fold_rounds_one_by_one", "0")):
+            if env is not None:
+                os.environ["SQ_POOL_AHEAD"] = env
+            try:
+                with Batch(prepared, [gpsets] * len(prepared), fp32=False) as bg:
+                    for _ in range(3):
+                        bg.fold(poollim=1000)
+                    gl = []
+                    for _ in range(10):
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        bg.fold(poollim=1000)
+                        torch.cuda.synchronize()
+                        gl.append((time.perf_counter() - t1) * 1e3)
+                    greedy_alone[tag] = round(sorted(gl)[len(gl) // 2], 3)
+                    if env is None:
+                        greedy_alone["rounds_enqueued_ahead"] = bool(bg.fold_paths & 32)
+            finally:
+                os.environ.pop("SQ_POOL_AHEAD", None)
+        greedy_alone["how"] = "ONE 219-record batch alone, c=greedynobpp poollim=1000, median of 10 folds"
 
     pmc, pmc_note = load_pmc()
     rooflines = []
@@ -1111,6 +1138,7 @@ def main():
         "single_batch": {"ms_per_fold": round(lat[len(lat) // 2], 3), "best_ms": round(lat[0], 3),
                          "seq_per_s": round(len(prepared) / lat[len(lat) // 2] * 1e3, 1),
                          "how": "ONE 219-record batch alone (a fresh batch, nothing else in flight), median / best of 10 folds"},
+        "single_batch_greedynobpp": greedy_alone,
         "host": {"cpu_ms_per_step": round(host_cpu / args.steps * 1e3, 1), "busy_cpus": round(host_cpu / dt, 1),
                  "cpu_quota": effective_cpus(),
                  "note": "rank 0's process CPU time inside the timed region (all threads): launches and waits of the fold threads; "

@@ -419,21 +419,8 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
     const double tw0 = sq_now();
     const bool streaming = on_job && ck.job_flags;
     if (!streaming) {   // spin on the completion word in pinned memory (no driver round trip, no staged copy)
-        volatile uint32_t *flag = ck.flag;
-        uint64_t spins = 0;
-        const bool relaxed = sq_relaxed_waits(b);
-        const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
-        while (*flag != ck.flag_val) {
-            if ((++spins & poll_mask) == 0) {
-                const hipError_t q = hipStreamQuery(ck.st);
-                if (q != hipErrorNotReady) {
-                    if (q != hipSuccess) return sq_check(q, "matching kernel");
-                    if (*flag != ck.flag_val) { HIPCK(hipStreamSynchronize(ck.st)); if (*flag != ck.flag_val) { sq_set_error("matching kernel did not signal completion"); return 2; } }
-                }
-            }
-            sq_wait_step(spins, relaxed);
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
+        const int wr = sq_wait_word(b, ck.flag, ck.flag_val, ck.st, "matching kernel");
+        if (wr) return wr;
     }
     const int32_t *h_out_p = ck.d_out, *h_cnt_p = ck.d_cnt;
     const double tw1 = sq_now();
@@ -850,22 +837,8 @@ static int algos_end_dev(sq_batch *b, SqAlgoAsync *pa)
     int r = 0;
     for (size_t q = pa->items.size(); q-- > 0 && !r;) {
         SqAlgoChunk &ck = pa->items[q].ck;
-        volatile uint32_t *flag = ck.flag;
-        uint64_t spins = 0;
-        const bool relaxed = sq_relaxed_waits(b);
-        const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
-        while (*flag != ck.flag_val) {
-            if ((++spins & poll_mask) == 0) {
-                const hipError_t qe = hipStreamQuery(ck.st);
-                if (qe != hipErrorNotReady) {
-                    if (qe != hipSuccess) { r = sq_check(qe, "matching kernel"); break; }
-                    if (*flag != ck.flag_val) { hipStreamSynchronize(ck.st); if (*flag != ck.flag_val) { sq_set_error("matching kernel did not signal completion"); r = 2; break; } }
-                }
-            }
-            sq_wait_step(spins, relaxed);
-        }
+        r = sq_wait_word(b, ck.flag, ck.flag_val, ck.st, "matching kernel");
         if (r) break;
-        std::atomic_thread_fence(std::memory_order_acquire);
         const SqAlgoStat hs = *ck.h_stats;
         if (hs.bad == 1) { sq_set_error("blossom capacity exceeded"); r = -3; }
         else if (hs.bad) { sq_set_error("stem capacity of RunAlgo's filters exceeded"); r = -3; }

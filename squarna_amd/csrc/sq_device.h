@@ -103,7 +103,9 @@ struct SqPoolIO {
     SqPoolStem *fin_stems; uint32_t fin_stem_cap;
     uint32_t *fin_ctr;
     long long *job_evals;                           // [batch jobs] evaluations of every greedy job (sq_pool_publish_kernel)
-    SqPoolHdr *h_hdr;                               // pinned copy, published by the scan kernel
+    SqPoolHdr *h_hdr;                               // pinned copies, published by the scan kernel: a ring of SQ_POOL_HDR_RING records, the
+                                                    // round with sequence number q writes record q % SQ_POOL_HDR_RING (rounds may be
+                                                    // enqueued ahead of the host: it reads the record of the round it waited for)
     SqPoolJob *h_jobs;                              // pinned copy of the job records (sq_pool_publish_kernel)
 };
 

@@ -11,6 +11,7 @@ void sq_read_fold_switches(SqFoldSwitches &sw)
     sw.no_opt_chain = on("SQ_NO_OPT_CHAIN"); sw.no_fly_bits = on("SQ_NO_FLY_BITS"); sw.no_defer_wait = on("SQ_NO_DEFER_WAIT");
     sw.no_pool_round = on("SQ_NO_POOL_ROUND"); sw.pool_round_always = on("SQ_POOL_ROUND_ALWAYS");
     sw.pool_round_nsurv = num("SQ_POOL_ROUND_NSURV", 16, 2048);
+    sw.pool_ahead = getenv("SQ_POOL_AHEAD") ? num("SQ_POOL_AHEAD", 0, SQ_POOL_HDR_RING - 2) : 3;
     sw.pool_slots = num("SQ_POOL_SLOTS", 1, 0x7fffffff); sw.pool_chunk = num("SQ_POOL_CHUNK", 1, 0x7fffffff);
     sw.no_score_bound = on("SQ_NO_SCORE_BOUND"); sw.no_score_context = on("SQ_NO_SCORE_CONTEXT");
     sw.no_edges_lds = on("SQ_NO_EDGES_LDS");
@@ -465,16 +466,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                     return;
                 }
                 if (timing) fprintf(stderr, "[sq_fold] persistent rounds: waiting (dev_tail %d ties %d prof %d pending %d next_job %zu of %zu goal %u S %d)\n", (int)dev_tail, (int)chain_ties, (int)b->prof_on, pending != nullptr, next_job, chain_jobs.size(), nfin_goal, S);
-                while (*flag != seq) {
-                    if ((++spins & poll_mask) == 0) {
-                        const hipError_t q = hipStreamQuery(st);
-                        if (q != hipErrorNotReady && q != hipSuccess) { fail(sq_check(q, "persistent rounds"), sq_last_error()); break; }
-                        if (q == hipSuccess && *flag != seq) { fail(2, "persistent rounds did not signal completion"); break; }
-                    }
-                    sq_wait_step(spins, relaxed);
-                }
+                { const int wr = sq_wait_word(b, flag, seq, st, "persistent rounds"); if (wr) fail(wr, sq_last_error()); }
                 if (!stats.rc) {
-                    std::atomic_thread_fence(std::memory_order_acquire);
                     const SqCounters ctr = *ln.h_ctr;
                     if (ctr.cand_ovf) fail(-3, "candidate capacity exceeded (raise cand_per_nt)");
                     else if (ctr.out_ovf) fail(-3, "stem capacity of a chained structure exceeded");
@@ -561,7 +554,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         auto fail = [&](int rc, const std::string &msg) { stats.rc = rc; stats.err = msg; return 2; };
         if (!PI.h_hdr) {
             void *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr, *p6 = nullptr;
-            if (sq_pinned_get(&p2, 64) || sq_pinned_get(&p3, sizeof(SqPoolJob) * (size_t)b->njobs) ||
+            if (sq_pinned_get(&p2, sizeof(SqPoolHdr) * SQ_POOL_HDR_RING) || sq_pinned_get(&p3, sizeof(SqPoolJob) * (size_t)b->njobs) ||
                 sq_pinned_get(&p4, sizeof(SqChain) * (size_t)b->njobs) || sq_pinned_get(&p5, sizeof(SqPoolJob) * (size_t)b->njobs) ||
                 sq_pinned_get(&p6, 4 * (size_t)b->njobs)) return fail(2, sq_last_error());
             PI.h_hdr = (SqPoolHdr *)p2; PI.h_jobs = (SqPoolJob *)p3;
@@ -607,23 +600,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         scan.ctr = ln.d_ctr;
         hipLaunchKernelGGL(sq_pool_init_kernel, dim3((std::max(S0, b->njobs) + 255) / 256), dim3(256), 0, st, ln.h_structs, b->h_pool_recs,
                            b->h_pool_jobs, b->h_pool_jobrec, (int32_t *)pio.jobrec_of, b->njobs, pio, scan, S0);
-        const bool relaxed = sq_relaxed_waits(b);
-        const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
-        volatile uint32_t *flag = ln.h_seq;
         auto wait_seq = [&](uint32_t seq) -> int {
-            uint64_t spins = 0;
-            while (*flag != seq) {
-                if ((++spins & poll_mask) == 0) {
-                    const hipError_t q = hipStreamQuery(st);
-                    if (q != hipErrorNotReady) {
-                        if (q != hipSuccess) return fail(sq_check(q, "pool rounds"), sq_last_error());
-                        if (*flag != seq) { hipStreamSynchronize(st); if (*flag != seq) return fail(2, "pool round did not signal completion"); }
-                    }
-                }
-                sq_wait_step(spins, relaxed);
-            }
-            std::atomic_thread_fence(std::memory_order_acquire);
-            return 0;
+            const int wr = sq_wait_word(b, ln.h_seq, seq, st, "pool round");
+            return wr ? fail(wr, sq_last_error()) : 0;
         };
         // short sequences: a round is ONE kernel (sq_pool_round.hip) + the scan kernel -- on a crowded chip because wave slots
         // are what it runs out of, for a batch alone because two launches per round instead of six shorten the greedy loop
@@ -637,7 +616,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             // a few dozen (tools/pr_waves_sweep.sh: 64 -> +5 % on the headline, 16 .. 64 within a per cent of each other)
             const bool crowded_fold = b->inflight > 1 || b->njobs >= 4096;
             pra.surv_cap = sw.pool_round_nsurv ? sw.pool_round_nsurv : (crowded_fold ? 64 : (maxn <= 96 ? 128 : 256)); pra.bound = b->score_bound ? 1 : 0;
-            pra.tmax = pio.pt; pra.parity = 0; pra.lo = 0;
+            pra.tmax = pio.pt; pra.parity = 0; pra.lo = 0; pra.ahead = 0;
             if (sq_pool_round_lds(pra.lds_n, pra.str_cap, pra.cell_entries, pra.surv_cap, pra.tmax).total > 60 * 1024) round_kernel = false;
         }
         if (round_kernel) b->last_paths |= 8;
@@ -646,6 +625,51 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         const double tr0 = now_s();
         int parity = 0, S = S0, rounds = 0;
         bool overflow = false;
+        // A batch alone: its rounds are a chain of short kernels, and waiting for a round's size before launching the next put
+        // the host's turn-around -- a PCIe round trip and two launch latencies -- between every two of them (half of the greedy
+        // loop of one SRtest150 batch).  With the one-kernel round the rounds are enqueued AHEAD instead: every launch covers
+        // all the slots, blocks beyond the generation's size leave at once (sq_pool_round_kernel reads the size the scan kernel
+        // left), and the host only follows the ring of published headers to learn when the pools have run empty.  Rounds
+        // launched behind the last one find an empty generation.  (A crowded chip hides the turn-around behind other batches'
+        // work and has tens of thousands of slots: it keeps the exact grids.)
+        const int ahead_env = sw.pool_ahead;
+        // (the slots in at most four launches per round: a generation larger than the candidate arena goes through it in chunks)
+        const bool ahead = round_kernel && ahead_env > 0 && !(b->inflight > 1 || b->njobs >= 4096) && slots <= 8192 && (int64_t)chunk * 4 >= slots;
+        if (ahead) {
+            SqRoundIO io;
+            io.h_strands = pio.strands; io.d_strands = pio.strands;
+            io.h_out = ln.h_out; io.d_out = ln.d_out; io.h_cap = 0; io.out_cap = 0;
+            io.h_ctr = ln.h_ctr; io.h_seq = ln.h_seq;
+            io.h_structs = pio.structs; io.d_structs = pio.structs;
+            int launched = 0, par_l = 0;
+            bool stop = false;
+            b->last_paths |= 32;
+            while (!stop || rounds < launched) {
+                while (!stop && launched - rounds < ahead_env) {
+                    if (launched > 4 * PI.pt + 8) return fail(2, "pool rounds do not terminate");
+                    pra.parity = par_l; pra.ahead = 1;
+                    for (int lo = 0; lo < slots; lo += chunk) {
+                        pra.lo = lo;
+                        sq_launch_round_kernels(b, st, std::min(chunk, slots - lo), maxn, maxcap, need_reacts, 0.0, 0, io, scan, pio.structs + (size_t)par_l * pio.smax + lo, pio.strands, true, true, &pra);
+                    }
+                    const uint32_t seq = ++*ln.round_seq;
+                    hipLaunchKernelGGL(sq_pool_scan_kernel, dim3(1), dim3(1024), 0, st, pio, scan, io, par_l, seq);
+                    launched++; par_l ^= 1;
+                }
+                const uint32_t seq = *ln.round_seq - (uint32_t)(launched - rounds - 1);   // the oldest round still out
+                if (wait_seq(seq)) return 2;
+                rounds++;
+                const SqCounters ctr = *ln.h_ctr;
+                if (ctr.cand_ovf) return fail(-3, "candidate capacity exceeded (raise cand_per_nt)");
+                if (ctr.level_ovf) return fail(-3, "more than 64 pseudoknot levels");
+                const SqPoolHdr hh = pio.h_hdr[seq % SQ_POOL_HDR_RING];
+                if (timing && sw.pool_debug) fprintf(stderr, "[pool] round %d (of %d enqueued): next generation %u, nfin %u, ovf %u, active jobs %u\n", rounds, launched, hh.S[(rounds & 1)], hh.nfin, hh.ovf, hh.active_jobs);
+                b->last_peak = std::max<int64_t>(b->last_peak, hh.peak);
+                if (hh.ovf) { overflow = true; stop = true; }
+                if (hh.S[rounds & 1] == 0) stop = true;         // (round r has parity r & 1; its scan kernel wrote the size of round r + 1)
+            }
+            S = 0;
+        }
         while (S > 0) {
             b->last_peak = std::max<int64_t>(b->last_peak, S);
             SqStruct *cur = pio.structs + (size_t)parity * pio.smax;
@@ -672,7 +696,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             const SqCounters ctr = *ln.h_ctr;
             if (ctr.cand_ovf) return fail(-3, "candidate capacity exceeded (raise cand_per_nt)");
             if (ctr.level_ovf) return fail(-3, "more than 64 pseudoknot levels");
-            const SqPoolHdr hh = *pio.h_hdr;
+            const SqPoolHdr hh = pio.h_hdr[seq % SQ_POOL_HDR_RING];
             if (timing && sw.pool_debug) fprintf(stderr, "[pool] round %d: S %d -> %u, nfin %u, ovf %u, active jobs %u\n", rounds, S, hh.S[parity ^ 1], hh.nfin, hh.ovf, hh.active_jobs);
             if (hh.ovf) { overflow = true; break; }
             parity ^= 1;
@@ -689,7 +713,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         }
         stats.nrounds = rounds;
         stats.tround = now_s() - tr0;
-        const SqPoolHdr hh = *pio.h_hdr;
+        const SqPoolHdr hh = pio.h_hdr[*ln.round_seq % SQ_POOL_HDR_RING];
         if (overflow || hh.ovf) {
             tq.flush();                                      // (the optimistic chains' entries are still being turned into lists by the queue's workers)
             for (int j : greedy_jobs) { pools[j].fin.clear(); pools[j].evals = 0; }

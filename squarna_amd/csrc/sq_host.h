@@ -124,6 +124,7 @@ struct SqFoldSwitches {
     bool pool_round_always = false;   // SQ_POOL_ROUND_ALWAYS: (the default since late round 4; the switch is read and ignored)
     int pool_round_nsurv = 0;         // SQ_POOL_ROUND_NSURV: survivors sq_pool_round_kernel keeps in LDS (0: by length)
     int pool_slots = 0;               // SQ_POOL_SLOTS: structure slots the device pools may use (0: max_structs)
+    int pool_ahead = 3;               // SQ_POOL_AHEAD: rounds of the device pools a batch alone enqueues ahead of the host (0: none)
     int pool_chunk = 0;               // SQ_POOL_CHUNK: structures per chunk of a generation (0: what the arena holds)
     bool no_score_bound = false;      // SQ_NO_SCORE_BOUND: ScoreStems on every survivor of :492
     bool no_score_context = false;    // SQ_NO_SCORE_CONTEXT: the strand walk instead of the context tables (launched rounds)
@@ -278,6 +279,10 @@ void sq_max_dynamic_lds(const void *fn, int bytes);
 int sq_effective_cpus();                       // CPUs this process may really use: hardware threads, affinity, cgroup quota
 bool sq_relaxed_waits(const sq_batch *b);       // spin-then-sleep instead of pure spinning (many batches in flight, few CPUs)
 void sq_wait_step(uint64_t spins, bool relaxed);   // one step of a wait loop on a pinned completion word
+// Waits until the pinned word *flag holds `want` (written by the last kernel of the work enqueued on `st`): spins on the word
+// -- no driver round trip, no staged copy --, polls the stream now and then so that a faulted queue is noticed, acquire fence
+// at the end.  0, or an error code with sq_last_error set (`what` names the work in the message)
+int sq_wait_word(const sq_batch *b, volatile uint32_t *flag, uint32_t want, hipStream_t st, const char *what);
 // sq_wait_step lowers the calling thread's timer slack while it sleeps in 10 us steps; entry points that may wait on the
 // CALLER's thread put the old value back before they return
 void sq_restore_timerslack();

@@ -95,6 +95,28 @@ void sq_wait_step(uint64_t spins, bool relaxed)
 #endif
 }
 
+int sq_wait_word(const sq_batch *b, volatile uint32_t *flag, uint32_t want, hipStream_t st, const char *what)
+{
+    const bool relaxed = sq_relaxed_waits(b);
+    const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
+    uint64_t spins = 0;
+    while (*flag != want) {
+        if ((++spins & poll_mask) == 0) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q != hipErrorNotReady) {
+                if (q != hipSuccess) return sq_check(q, what);
+                if (*flag != want) {
+                    hipStreamSynchronize(st);
+                    if (*flag != want) { sq_set_error(std::string(what) + " did not signal completion"); return 2; }
+                }
+            }
+        }
+        sq_wait_step(spins, relaxed);
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 0;
+}
+
 // ---- host worker pool -------------------------------------------------------------------------
 SqPool::SqPool(int nthreads_, int device_) : nthreads(nthreads_), device(device_)
 {

@@ -127,13 +127,14 @@ struct SqPoolJob {            // one greedy job
     double maxstems;          // :1123-1129
     long long evals;          // structures evaluated so far (AnnotateStems calls)
 };
+#define SQ_POOL_HDR_RING 8
 struct SqPoolHdr {
     uint32_t S[2];            // structures of the round, by round parity (the scan kernel writes the next round's)
     uint32_t round;
     uint32_t nfin, nfin_stems;   // entries / stems of the pinned log of final structures
     uint32_t ovf;             // some capacity was exceeded: the host repeats the fold with its own loop
     uint32_t active_jobs;
-    uint32_t pad;
+    uint32_t peak;            // largest generation so far
 };
 struct SqPoolFin {            // one final structure (pinned): finstemsets order == (round_kind, pos) ascending per job
     int32_t job;

@@ -47,7 +47,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_pool_init_kernel(const SqSt
     if (q < nbatchjobs) d_jobrec[q] = h_jobrec[q];
     if (q == 0) {
         SqPoolHdr h;
-        h.S[0] = (uint32_t)S0; h.S[1] = 0; h.round = 0; h.nfin = 0; h.nfin_stems = 0; h.ovf = 0; h.active_jobs = (uint32_t)pio.njobs; h.pad = 0;
+        h.S[0] = (uint32_t)S0; h.S[1] = 0; h.round = 0; h.nfin = 0; h.nfin_stems = 0; h.ovf = 0; h.active_jobs = (uint32_t)pio.njobs; h.peak = (uint32_t)S0;
         *pio.hdr = h;
         a.ctr->nout = 0; a.ctr->cand_ovf = 0; a.ctr->out_ovf = 0; a.ctr->level_ovf = 0;
     }
@@ -205,8 +205,9 @@ extern "C" __global__ __launch_bounds__(1024) void sq_pool_scan_kernel(SqPoolIO 
         H->S[parity ^ 1] = fits ? (uint32_t)total : 0u;
         H->round += 1;
         H->active_jobs = (uint32_t)s_active;
+        if ((uint32_t)total > H->peak && fits) H->peak = (uint32_t)total;
         *io.h_ctr = *a.ctr;
-        *pio.h_hdr = *H;
+        pio.h_hdr[seq % SQ_POOL_HDR_RING] = *H;
         sq_host_write_flush(io.h_ctr);
         *io.h_seq = seq;
     }
@@ -292,7 +293,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_pool_publish_kernel(SqPoolI
     if (threadIdx.x == 0) {
         pio.hdr->nfin = pio.fin_ctr[0]; pio.hdr->nfin_stems = pio.fin_ctr[1];
         *io.h_ctr = *a.ctr;
-        *pio.h_hdr = *pio.hdr;
+        pio.h_hdr[seq % SQ_POOL_HDR_RING] = *pio.hdr;
         sq_host_write_flush(io.h_ctr);                   // (the log of final structures: the extend kernels)
         *io.h_seq = seq;
     }

@@ -18,6 +18,7 @@ struct SqPoolRoundArgs {
     int32_t tmax;           // stems per structure slot (SqPoolIO::pt): the level scratch of the extension
     int32_t parity;         // generation of this round's structures
     int32_t lo;             // position in the round's list of the launch's first structure (chunked rounds)
+    int32_t ahead;          // the launch covers every slot: blocks beyond the generation's size (SqPoolHdr::S) leave
 };
 
 struct SqPoolRoundLds {

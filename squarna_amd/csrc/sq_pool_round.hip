@@ -116,6 +116,9 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
     __shared__ int s_ri[SQ_POOL_CMAX], s_rj[SQ_POOL_CMAX], s_rl[SQ_POOL_CMAX];
     const int lane = threadIdx.x;
     const int s = ra.lo + (int)blockIdx.x;                  // the structure's position in the round's list == its slot
+    // (rounds enqueued ahead of the host are launched with every slot as their grid: the generation's size is the scan kernel's
+    // word -- zero once the pools have run empty or a capacity was exceeded)
+    if (ra.ahead && s >= (int)pio.hdr->S[ra.parity]) return;
 #ifdef SQ_PR_PROF
     long long _pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
 #define PRPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)

@@ -403,23 +403,7 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
     if (g_cpuacc_on) { const long long t = CpuScope::now(); g_cpuacc[mode == 1 ? 7 : 5] += t - cpu_t0; cpu_t0 = t; }
     // wait for the round: spin on the sequence number in pinned memory (no driver round trip); a stuck or
     // faulted queue is caught by polling the stream now and then
-    {
-        volatile uint32_t *flag = ln.h_seq;
-        uint64_t spins = 0;
-        const bool relaxed = sq_relaxed_waits(b);
-        const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
-        while (*flag != seq) {
-            if ((++spins & poll_mask) == 0) {
-                const hipError_t q = hipStreamQuery(st);
-                if (q != hipErrorNotReady) {
-                    if (q != hipSuccess) return sq_check(q, "round kernels");
-                    if (*flag != seq) { HIPCK(hipStreamSynchronize(st)); if (*flag != seq) { sq_set_error("round did not signal completion"); return 2; } }
-                }
-            }
-            sq_wait_step(spins, relaxed);
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-    }
+    { const int wr = sq_wait_word(b, ln.h_seq, seq, st, "round kernels"); if (wr) return wr; }
     if (g_cpuacc_on) g_cpuacc[6] += CpuScope::now() - cpu_t0;
     const SqCounters ctr = *ln.h_ctr;
     if (ctr.cand_ovf) { sq_set_error("candidate capacity exceeded (raise cand_per_nt)"); return -3; }
@@ -515,23 +499,7 @@ int sq_round_annotate_dev(sq_batch *b, const std::vector<int> &jobs, SqAlgoSize 
     const uint32_t seq = ++*ln.round_seq;
     hipLaunchKernelGGL(sq_done_kernel, dim3(1), dim3(1), 0, st, io, scan, seq);
     HIPCK(hipGetLastError());
-    {
-        volatile uint32_t *flag = ln.h_seq;
-        uint64_t spins = 0;
-        const bool relaxed = sq_relaxed_waits(b);
-        const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
-        while (*flag != seq) {
-            if ((++spins & poll_mask) == 0) {
-                const hipError_t q = hipStreamQuery(st);
-                if (q != hipErrorNotReady) {
-                    if (q != hipSuccess) return sq_check(q, "AnnotateStems round");
-                    if (*flag != seq) { HIPCK(hipStreamSynchronize(st)); if (*flag != seq) { sq_set_error("round did not signal completion"); return 2; } }
-                }
-            }
-            sq_wait_step(spins, relaxed);
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-    }
+    { const int wr = sq_wait_word(b, ln.h_seq, seq, st, "AnnotateStems round"); if (wr) return wr; }
     const SqCounters ctr = *ln.h_ctr;
     if (ctr.cand_ovf) { sq_set_error("candidate capacity exceeded (raise cand_per_nt)"); return -3; }
     return 0;

@@ -784,22 +784,7 @@ bool sq_tail_device_wanted(const sq_batch *b, const sq_fold_opts &o)
 
 static int tail_wait(sq_batch *b, SqLane &ln, uint32_t seq, const char *what)
 {
-    volatile uint32_t *flag = ln.h_seq;
-    uint64_t spins = 0;
-    const bool relaxed = sq_relaxed_waits(b);
-    const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
-    while (*flag != seq) {
-        if ((++spins & poll_mask) == 0) {
-            const hipError_t q = hipStreamQuery(b->stream);
-            if (q != hipErrorNotReady) {
-                if (q != hipSuccess) return sq_check(q, what);
-                if (*flag != seq) { hipStreamSynchronize(b->stream); if (*flag != seq) { sq_set_error("device tail did not signal completion"); return 2; } }
-            }
-        }
-        sq_wait_step(spins, relaxed);
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    return 0;
+    return sq_wait_word(b, ln.h_seq, seq, b->stream, what);
 }
 
 // The known structures of the batch: partner per position + number of distinct pairs per sequence (:1249-1251), uploaded on

@@ -460,3 +460,46 @@ def test_pools_long_sample_equals_the_oracle():
                        env=dict(os.environ, FUZZ_SET="pools_long"), capture_output=True, text=True, timeout=1500)
     tail = (r.stdout + r.stderr)[-2000:]
     assert r.returncode == 0 and "16 records (config 500nobpp, poollim 1000), 0 mismatches" in r.stdout, tail
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,poollim", [("nobpp", 1000), ("greedynobpp", 5), ("alt", 1000)])
+def test_pool_rounds_enqueued_ahead_equal_the_exact_grids(config, poollim, monkeypatch):
+    """A batch alone enqueues the rounds of the device pools ahead of the host (sq_fold_paths bit 5 = 32: every launch covers
+    all slots, blocks beyond the generation's size leave, the host follows the published headers): packed records, evaluation
+    counts and the largest generation are those of the rounds launched one by one with exact grids (SQ_POOL_AHEAD=0), for
+    depths 1, 3 and 6 -- also when a generation outgrows the slots and the host loop repeats the fold -- and the oracle's."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import Batch, Prepared
+    names, psets = conf(config)
+    raw = _chain_records(64, 4242 + poollim, 10, 200)
+    prepared = [Prepared(s, r, x) for s, r, x in raw]
+    n = len(prepared)
+    with Batch(prepared, [psets] * n, max_structs=8192, fp32=False) as b:
+        monkeypatch.setenv("SQ_POOL_AHEAD", "0")
+        b.fold(poollim=poollim)
+        assert b.fold_driver == 2 and (b.fold_paths & 8) and not (b.fold_paths & 32), (b.fold_driver, b.fold_paths)
+        want, evals, peak = _packed(b, n), [b.evals(k) for k in range(n)], b.fold_peak_structs
+        res = b.results_all()
+        for depth in ("1", "3", "6"):
+            monkeypatch.setenv("SQ_POOL_AHEAD", depth)
+            for _ in range(2):
+                b.fold(poollim=poollim)
+                assert b.fold_driver == 2 and (b.fold_paths & 32), (depth, b.fold_driver, b.fold_paths)
+                assert _packed(b, n) == want, depth
+                assert [b.evals(k) for k in range(n)] == evals
+                assert b.fold_peak_structs == peak, (depth, b.fold_peak_structs, peak)
+        monkeypatch.delenv("SQ_POOL_AHEAD")
+        b.fold(poollim=poollim)                                  # the default depth
+        assert (b.fold_paths & 32) and _packed(b, n) == want
+        if peak > 2 * n + 8:                                     # the pools outgrow their slots mid-way: the host loop takes over
+            monkeypatch.setenv("SQ_POOL_SLOTS", str(2 * n + 8))
+            b.fold(poollim=poollim)
+            assert b.fold_driver == 3, b.fold_driver
+            assert _packed(b, n) == want
+            monkeypatch.delenv("SQ_POOL_SLOTS")
+    for k in range(0, n, 8):
+        s, r, x = raw[k]
+        exp = O.SQRNdbnseq(s, r, x, None, psets, poollim=poollim)
+        exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(res[k][0], exp, (config, "ahead", poollim, k))
