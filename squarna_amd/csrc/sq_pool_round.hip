@@ -30,6 +30,10 @@
 #include "sq_cells.h"
 #include "sq_cellrun.h"
 #include "sq_score.h"
+#ifndef SQ_PR_AHEAD
+#define SQ_PR_AHEAD 2              // word-rows of the bit matrix whose loads the scan issues together (sq_scan.h: SQ6_AHEAD)
+#endif
+#define SQ6_AHEAD SQ_PR_AHEAD
 #include "sq_scan.h"
 #include "sq_pool_round.h"
 
@@ -122,7 +126,10 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
 #ifdef SQ_PR_PROF
     long long _pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
 #define PRPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)
-#define PRPROF_OUT(ns_, nin_) do { if (lane == 0 && (s % 997) == 0) printf("pool round s=%d n=%d nstrand=%d ns=%u nin=%d | us: extend %.1f setup %.1f state %.1f scan %.1f score %.1f choose %.1f total %.1f\n", \
+#ifndef SQ_PR_PROF_SLOW
+#define SQ_PR_PROF_SLOW 1000000      /* us: structures slower than this are printed too */
+#endif
+#define PRPROF_OUT(ns_, nin_) do { if (lane == 0 && ((s % 997) == 0 || (wall_clock64() - _t00) > 100ll * SQ_PR_PROF_SLOW)) printf("pool round s=%d n=%d nstrand=%d ns=%u nin=%d | us: extend %.1f setup %.1f state %.1f scan %.1f score %.1f choose %.1f total %.1f\n", \
         s, n, nstrand, (unsigned)(ns_), (int)(nin_), _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, (wall_clock64() - _t00) * 0.01); } while (0)
 #else
 #define PRPROF(k) do {} while (0)

@@ -291,7 +291,7 @@ void sq_launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, int64
         static const int short_thr = getenv("SQ_SCORE_SHORT_THREADS") ? atoi(getenv("SQ_SCORE_SHORT_THREADS")) : 64;
         // (the pools' generations of thousands of structures: most of them late in their fold, with one or two thousand candidates
         // left -- 500nobpp on 500-nt sequences: 382 / 315 / 301 ms per 500 sequences with 512 / 256 / 128 threads)
-        static const int pooled_thr = getenv("SQ_SCORE_POOL_THREADS") ? std::max(64, std::min(1024, atoi(getenv("SQ_SCORE_POOL_THREADS")) / 64 * 64)) : 128;
+        const int pooled_thr = getenv("SQ_SCORE_POOL_THREADS") ? std::max(64, std::min(1024, atoi(getenv("SQ_SCORE_POOL_THREADS")) / 64 * 64)) : 128;
         const int thr0 = maxn <= 200 ? (crowded ? short_thr : 128) : (pooled && S >= 2048 ? std::min(pooled_thr, maxn <= 400 ? 256 : 512) : (maxn <= 400 ? 256 : 512));
         // (the one-pass modes on a crowded chip: a structure of a short sequence has ~150 candidates -- one wave, not four)
         const int thr = score_threads ? score_threads : (mode == 0 ? thr0 : (maxn <= 200 && crowded ? 64 : (parts == 1 && S < 2048 ? 512 : 256)));

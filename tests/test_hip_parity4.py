@@ -503,3 +503,29 @@ def test_pool_rounds_enqueued_ahead_equal_the_exact_grids(config, poollim, monke
         exp = O.SQRNdbnseq(s, r, x, None, psets, poollim=poollim)
         exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
         _same_fold(res[k][0], exp, (config, "ahead", poollim, k))
+
+
+def test_pooled_score_kernel_block_sizes_agree(monkeypatch):
+    """Generations of thousands of structures on sequences beyond 256 nt (the launched round kernels: state / scan / score /
+    choose / extend) with 64, 128 and 512 threads per structure of the score kernel (SQ_SCORE_POOL_THREADS; default 128 from
+    2,048 structures on): the same packed records, the largest generation beyond 2,048, and the oracle's structures."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import Batch, Prepared
+    names, psets = conf("nobpp")
+    rng = np.random.default_rng(2048)
+    seqs = ["".join(rng.choice(list("ACGU"), int(n))) for n in rng.integers(262, 300, 20)]
+    prepared = [Prepared(s) for s in seqs]
+    packs = {}
+    with Batch(prepared, [psets] * len(prepared), max_structs=65536, fp32=False) as b:
+        for thr in ("64", "128", "512"):
+            monkeypatch.setenv("SQ_SCORE_POOL_THREADS", thr)
+            b.fold(poollim=1000)
+            assert b.fold_driver == 2 and not (b.fold_paths & 8), (b.fold_driver, b.fold_paths)
+            assert b.fold_peak_structs >= 2048, b.fold_peak_structs
+            packs[thr] = _packed(b, len(prepared))
+        res = b.results_all()
+    assert packs["64"] == packs["128"] == packs["512"]
+    for k in (0, 7):
+        exp = O.SQRNdbnseq(seqs[k], None, None, None, psets, poollim=1000)
+        exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(res[k][0], exp, ("pooled score threads", k))
