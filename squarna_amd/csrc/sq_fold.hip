@@ -600,8 +600,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         scan.ctr = ln.d_ctr;
         hipLaunchKernelGGL(sq_pool_init_kernel, dim3((std::max(S0, b->njobs) + 255) / 256), dim3(256), 0, st, ln.h_structs, b->h_pool_recs,
                            b->h_pool_jobs, b->h_pool_jobrec, (int32_t *)pio.jobrec_of, b->njobs, pio, scan, S0);
-        auto wait_seq = [&](uint32_t seq) -> int {
-            const int wr = sq_wait_word(b, ln.h_seq, seq, st, "pool round");
+        auto wait_seq = [&](uint32_t seq, bool at_least = false) -> int {
+            const int wr = sq_wait_word(b, ln.h_seq, seq, st, "pool round", at_least);
             return wr ? fail(wr, sq_last_error()) : 0;
         };
         // short sequences: a round is ONE kernel (sq_pool_round.hip) + the scan kernel -- on a crowded chip because wave slots
@@ -657,7 +657,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                     launched++; par_l ^= 1;
                 }
                 const uint32_t seq = *ln.round_seq - (uint32_t)(launched - rounds - 1);   // the oldest round still out
-                if (wait_seq(seq)) return 2;
+                if (wait_seq(seq, true)) return 2;                  // (the rounds behind it write the same word: at least this one)
                 rounds++;
                 const SqCounters ctr = *ln.h_ctr;
                 if (ctr.cand_ovf) return fail(-3, "candidate capacity exceeded (raise cand_per_nt)");

@@ -282,7 +282,9 @@ void sq_wait_step(uint64_t spins, bool relaxed);   // one step of a wait loop on
 // Waits until the pinned word *flag holds `want` (written by the last kernel of the work enqueued on `st`): spins on the word
 // -- no driver round trip, no staged copy --, polls the stream now and then so that a faulted queue is noticed, acquire fence
 // at the end.  0, or an error code with sq_last_error set (`what` names the work in the message)
-int sq_wait_word(const sq_batch *b, volatile uint32_t *flag, uint32_t want, hipStream_t st, const char *what);
+// at_least: the word counts upwards and later work on the stream writes it too (rounds enqueued ahead): wait for *flag - want >= 0
+// in modular arithmetic instead of equality
+int sq_wait_word(const sq_batch *b, volatile uint32_t *flag, uint32_t want, hipStream_t st, const char *what, bool at_least = false);
 // sq_wait_step lowers the calling thread's timer slack while it sleeps in 10 us steps; entry points that may wait on the
 // CALLER's thread put the old value back before they return
 void sq_restore_timerslack();

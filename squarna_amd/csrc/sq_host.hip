@@ -95,19 +95,20 @@ void sq_wait_step(uint64_t spins, bool relaxed)
 #endif
 }
 
-int sq_wait_word(const sq_batch *b, volatile uint32_t *flag, uint32_t want, hipStream_t st, const char *what)
+int sq_wait_word(const sq_batch *b, volatile uint32_t *flag, uint32_t want, hipStream_t st, const char *what, bool at_least)
 {
     const bool relaxed = sq_relaxed_waits(b);
     const uint64_t poll_mask = relaxed ? 0x3FFF : 0xFFFFF;
     uint64_t spins = 0;
-    while (*flag != want) {
+    auto there = [&]() { const uint32_t v = *flag; return at_least ? (int32_t)(v - want) >= 0 : v == want; };
+    while (!there()) {
         if ((++spins & poll_mask) == 0) {
             const hipError_t q = hipStreamQuery(st);
             if (q != hipErrorNotReady) {
                 if (q != hipSuccess) return sq_check(q, what);
-                if (*flag != want) {
+                if (!there()) {
                     hipStreamSynchronize(st);
-                    if (*flag != want) { sq_set_error(std::string(what) + " did not signal completion"); return 2; }
+                    if (!there()) { sq_set_error(std::string(what) + " did not signal completion"); return 2; }
                 }
             }
         }

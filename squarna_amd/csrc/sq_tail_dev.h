@@ -72,7 +72,7 @@ extern "C" {
 __global__ void sq_tail_count_kernel(SqTailIO t);
 __global__ void sq_tail_scan_kernel(SqTailIO t);
 __global__ void sq_tail_scatter_kernel(SqTailIO t);
-__global__ void sq_tail_rank_kernel(SqDevCtx c, SqTailIO t, int bitwords, int keycap);
+__global__ void sq_tail_rank_kernel(SqDevCtx c, SqTailIO t, int bitwords, int keycap, int refp_lds);
 __global__ void sq_tail_offsets_kernel(SqTailIO t, volatile uint32_t *h_seq, uint32_t seq);
 __global__ void sq_tail_pack_kernel(SqDevCtx c, SqTailIO t, int rowcap, long long rec_cap, long long txt_cap);
 __global__ void sq_fold_begin_kernel(uint32_t *fin_ctr, long long *job_evals, uint32_t *job_cnt, int njobs);

@@ -208,8 +208,9 @@ __device__ __forceinline__ void sq_prf_wave(const int16_t *refp, int known_n, co
 #define SQ_TAIL_THREADS 256            // a block's threads on a crowded chip; a batch alone with several jobs per sequence: SQ_TAIL_THREADS_WIDE
 #define SQ_TAIL_THREADS_WIDE 1024
 #define SQ_TAIL_BITWORDS 1024          // LDS bitmap words per wave: sequences up to 32768 nt
+#define SQ_TAIL_PIECES 12              // wave-sized jobs of the ranking kernel's last phase that are dealt to the waves (2 + toplim)
 
-extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS_WIDE) void sq_tail_rank_kernel(SqDevCtx c, SqTailIO t, int bitwords, int keycap)
+extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS_WIDE) void sq_tail_rank_kernel(SqDevCtx c, SqTailIO t, int bitwords, int keycap, int refp_lds)
 {
     // (one bitmap of the sequence's positions per wave, in the block's DYNAMIC LDS sized for the batch's longest sequence:
     // a static array for 32,768 nt cost every block 16 KB -- 20 bytes do for 150 nt)
@@ -221,6 +222,7 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS_WIDE) void sq_tail_rank_
     double *const s_key = reinterpret_cast<double *>(s_bits_dyn + ((nwv * (uint32_t)bitwords + 1u) & ~1u));   // [keycap][3], in rankby order
     uint8_t *const s_pri = reinterpret_cast<uint8_t *>(s_key + 3 * (size_t)keycap);                          // [keycap]
     uint8_t *const s_codes = s_pri + (((size_t)keycap + 7) & ~(size_t)7);                                    // [32 x bitwords] the sequence's letter codes
+    int16_t *const s_refp = reinterpret_cast<int16_t *>(s_codes + 32 * (size_t)bitwords);                   // [32 x bitwords] partners in the known structure (refp_lds)
     __shared__ int s_nsep;
     SqTailSeq &S = t.seqs[s];
     const uint32_t first = S.first, M = S.count;
@@ -235,10 +237,12 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS_WIDE) void sq_tail_rank_
     __syncthreads();
     {
         int sep = 0;
+        const bool stage_ref = refp_lds && t.ref_n && t.ref_n[s] >= 0;
         for (int p = tid; p < n; p += nthr) {
             const uint8_t cd = c.codes[jb.pos_off + p];
             s_codes[p] = cd;
             sep += (cd == SQ_CODE_SEP1 || cd == SQ_CODE_SEP2) ? 1 : 0;
+            if (stage_ref) s_refp[p] = t.refp[jb.pos_off + p];      // (the metrics and the known structure's stems read it bp by bp)
         }
         if (sep) atomicAdd(&s_nsep, sep);
     }
@@ -483,65 +487,94 @@ extern "C" __global__ __launch_bounds__(SQ_TAIL_THREADS_WIDE) void sq_tail_rank_
     const int known_n = t.ref_n ? t.ref_n[s] : -1;
     const bool has_ref = known_n >= 0;
     const uint32_t nprf = has_ref ? min(D, (uint32_t)max(t.toplim, 1)) : 0u;
+    // The pieces of this phase -- ScoreStruct of the known structure, the consensus' metrics, the metrics of the top ranks -- are
+    // independent wave-sized jobs: they are dealt to the block's waves (until round 5 the first wave did them one after the
+    // other while the others were through: 46 of the kernel's 200 us for SRtest150's largest record) and lane 0 collects them.
+    __shared__ double s_piece[SQ_TAIL_PIECES][6];                       // [0]: ref scores (3), [1]: consensus, [2 + r]: rank r
+    const int16_t *refp = has_ref ? (refp_lds ? s_refp : t.refp + jb.pos_off) : nullptr;
+    const bool spread = has_ref && nprf + 2 <= SQ_TAIL_PIECES;
+    auto ref_scores = [&](double (&ref_sc)[3]) {
+        // ReferenceScores (:958-970): ScoreStruct of PairsToStems(sorted pairs of the known structure); the stems are
+        // read off the partner array on the fly: a pair (i, p), i < p, starts a stem unless (i - 1, p + 1) is a pair
+        // (the starts are listed in the LDS of the rank keys, which pass f is done with, when they fit)
+        int16_t *const s_start = reinterpret_cast<int16_t *>(s_key);
+        const int startcap = 12 * keycap;
+        int nst = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            bool start = false;
+            if (i < n) { const int p = refp[i]; start = p > i && !(i > 0 && refp[i - 1] == p + 1); }
+            const unsigned long long bal = __ballot(start);
+            if (start) { const int idx = nst + (int)__popcll(bal & ((1ull << lane) - 1ull)); if (idx < startcap) s_start[idx] = (int16_t)i; }
+            nst += __popcll(bal);
+        }
+        const bool listed = nst <= startcap;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        auto ref_stem = [&](int q) {                                // q-th stem start in ascending order of i
+            int seen = 0;
+            SqPoolStem out{0, 0, 0, 0};
+            if (listed) {
+                const int i = s_start[q], p = refp[i];
+                int len = 1;
+                while (i + len < n && refp[i + len] == p - len && p - len > i + len) len++;
+                return SqPoolStem{(int16_t)i, (int16_t)p, (int16_t)len, 0};
+            }
+            for (int i = 0; i < n; i++) {
+                const int p = refp[i];
+                if (!(p > i) || (i > 0 && refp[i - 1] == p + 1)) continue;
+                if (seen++ != q) continue;
+                int len = 1;
+                while (i + len < n && refp[i + len] == p - len && p - len > i + len) len++;
+                out = SqPoolStem{(int16_t)i, (int16_t)p, (int16_t)len, 0};
+                break;
+            }
+            return out;
+        };
+        sq_score_struct_wave(c, t, jb, ref_stem, nst, s_bits_dyn + (size_t)wave * bitwords, lane, ref_sc, t.fallback, s_codes, s_nsep);
+    };
+    auto cons_metrics = [&](double (&m)[6]) {
+        // consensus = the top-ranked structure (conslim == 1, :845-858,1236) or nothing (conslim == 0, or no structure)
+        if (D > 0 && t.conslim == 1) {
+            const uint32_t x0 = t.rlist[first];
+            sq_prf_wave(refp, known_n, sq_fin_canon(t, t.fin[t.ord[first + x0]]), (int)t.cs_n[first + x0], lane, m, t.fallback);
+        } else sq_prf_wave(refp, known_n, nullptr, 0, lane, m, t.fallback);
+    };
+    auto rank_metrics = [&](uint32_t r, double (&m)[6]) {
+        const uint32_t x = t.rlist[first + r];
+        sq_prf_wave(refp, known_n, sq_fin_canon(t, t.fin[t.ord[first + x]]), (int)t.cs_n[first + x], lane, m, t.fallback);
+    };
+    if (spread) {
+        for (uint32_t pc = wave; pc < nprf + 2; pc += nwv) {
+            double m[6] = {0, 0, 0, 0, 0, 0};
+            if (pc == 0) { double sc[3]; ref_scores(sc); m[0] = sc[0]; m[1] = sc[1]; m[2] = sc[2]; }
+            else if (pc == 1) cons_metrics(m);
+            else rank_metrics(pc - 2, m);
+            if (lane == 0) for (int q = 0; q < 6; q++) s_piece[pc][q] = m[q];
+        }
+        __syncthreads();
+    }
     if (wave == 0) {
-        const int16_t *refp = has_ref ? t.refp + jb.pos_off : nullptr;
         double cons_m[6], best_m[7], ref_sc[3];
         for (int q = 0; q < 6; q++) cons_m[q] = NAN;
         for (int q = 0; q < 7; q++) best_m[q] = NAN;
         for (int q = 0; q < 3; q++) ref_sc[q] = NAN;
         if (has_ref) {
-            // consensus = the top-ranked structure (conslim == 1, :845-858,1236) or nothing (conslim == 0, or no structure)
-            if (D > 0 && t.conslim == 1) {
-                const uint32_t x0 = t.rlist[first];
-                sq_prf_wave(refp, known_n, sq_fin_canon(t, t.fin[t.ord[first + x0]]), (int)t.cs_n[first + x0], lane, cons_m, t.fallback);
-            } else sq_prf_wave(refp, known_n, nullptr, 0, lane, cons_m, t.fallback);
             double best = -1;                                           // :1262-1283
-            for (uint32_t r = 0; r < nprf; r++) {
-                const uint32_t x = t.rlist[first + r];
-                double m[6];
-                sq_prf_wave(refp, known_n, sq_fin_canon(t, t.fin[t.ord[first + x]]), (int)t.cs_n[first + x], lane, m, t.fallback);
-                if (m[3] > best) { best = m[3]; for (int q = 0; q < 6; q++) best_m[q] = m[q]; best_m[6] = (double)(r + 1); }
-            }
-            // ReferenceScores (:958-970): ScoreStruct of PairsToStems(sorted pairs of the known structure); the stems are
-            // read off the partner array on the fly: stem q starts at the q-th position that opens a new stack
-            // (lane 0 lists the starts into the entry scratch of the sequence's LAST canonical slot is not available here,
-            // so the stems are enumerated by position: a pair (i, p), i < p, starts a stem unless (i - 1, p + 1) is a pair)
-            // (the starts are listed in the LDS of the rank keys, which pass f is done with, when they fit)
-            int16_t *const s_start = reinterpret_cast<int16_t *>(s_key);
-            const int startcap = 12 * keycap;
-            int nst = 0;
-            for (int i0 = 0; i0 < n; i0 += 64) {
-                const int i = i0 + lane;
-                bool start = false;
-                if (i < n) { const int p = refp[i]; start = p > i && !(i > 0 && refp[i - 1] == p + 1); }
-                const unsigned long long bal = __ballot(start);
-                if (start) { const int idx = nst + (int)__popcll(bal & ((1ull << lane) - 1ull)); if (idx < startcap) s_start[idx] = (int16_t)i; }
-                nst += __popcll(bal);
-            }
-            const bool listed = nst <= startcap;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            auto ref_stem = [&](int q) {                                // q-th stem start in ascending order of i
-                int seen = 0;
-                SqPoolStem out{0, 0, 0, 0};
-                if (listed) {
-                    const int i = s_start[q], p = refp[i];
-                    int len = 1;
-                    while (i + len < n && refp[i + len] == p - len && p - len > i + len) len++;
-                    return SqPoolStem{(int16_t)i, (int16_t)p, (int16_t)len, 0};
+            if (spread) {
+                for (int q = 0; q < 6; q++) cons_m[q] = s_piece[1][q];
+                for (uint32_t r = 0; r < nprf; r++)
+                    if (s_piece[2 + r][3] > best) { best = s_piece[2 + r][3]; for (int q = 0; q < 6; q++) best_m[q] = s_piece[2 + r][q]; best_m[6] = (double)(r + 1); }
+                for (int q = 0; q < 3; q++) ref_sc[q] = s_piece[0][q];
+            } else {
+                cons_metrics(cons_m);
+                for (uint32_t r = 0; r < nprf; r++) {
+                    double m[6];
+                    rank_metrics(r, m);
+                    if (m[3] > best) { best = m[3]; for (int q = 0; q < 6; q++) best_m[q] = m[q]; best_m[6] = (double)(r + 1); }
                 }
-                for (int i = 0; i < n; i++) {
-                    const int p = refp[i];
-                    if (!(p > i) || (i > 0 && refp[i - 1] == p + 1)) continue;
-                    if (seen++ != q) continue;
-                    int len = 1;
-                    while (i + len < n && refp[i + len] == p - len && p - len > i + len) len++;
-                    out = SqPoolStem{(int16_t)i, (int16_t)p, (int16_t)len, 0};
-                    break;
-                }
-                return out;
-            };
-            sq_score_struct_wave(c, t, jb, ref_stem, nst, s_bits_dyn, lane, ref_sc, t.fallback, s_codes, s_nsep);
+                ref_scores(ref_sc);
+            }
         }
         if (lane == 0) {
             double *met = t.scores + 3 * (size_t)t.fin_cap + 16 * (size_t)s;   // per-sequence metrics behind the entry scores
@@ -863,10 +896,12 @@ int sq_tail_device(sq_batch *b, const sq_fold_opts &o, const int32_t *ref_off, c
         const bool wide = !(b->inflight > 1 || b->njobs >= 4096) && b->njobs > b->nseq;
         const int thr = wide ? SQ_TAIL_THREADS_WIDE : SQ_TAIL_THREADS;
         const int keycap = wide ? 1024 : 256;                    // rank keys staged in LDS (25 bytes each; more structures: global path)
-        const size_t lds = ((((size_t)(thr / 64) * bitwords + 1) & ~(size_t)1) * 4) + (size_t)keycap * 24 + (((size_t)keycap + 7) & ~(size_t)7) + (size_t)32 * bitwords + 16;   // + the letter codes
+        const int refp_lds = bitwords <= 128 ? 1 : 0;                // the known structure's partner array in LDS too (sequences up to 4,096 nt)
+        const size_t lds = ((((size_t)(thr / 64) * bitwords + 1) & ~(size_t)1) * 4) + (size_t)keycap * 24 + (((size_t)keycap + 7) & ~(size_t)7) + (size_t)32 * bitwords + 16 +
+                           (refp_lds ? (size_t)64 * bitwords : 0);   // + the letter codes (+ the partners)
         if (lds > 160 * 1024) return 1;                          // (the host tail takes such a batch)
         if (lds > 64 * 1024) sq_max_dynamic_lds((const void *)sq_tail_rank_kernel, 160 * 1024);
-        hipLaunchKernelGGL(sq_tail_rank_kernel, dim3(b->nseq), dim3(thr), lds, st, b->ctx, t, bitwords, keycap);
+        hipLaunchKernelGGL(sq_tail_rank_kernel, dim3(b->nseq), dim3(thr), lds, st, b->ctx, t, bitwords, keycap, refp_lds);
     }
     uint32_t seq = ++*ln.round_seq;
     hipLaunchKernelGGL(sq_tail_offsets_kernel, dim3(1), dim3(1024), 0, st, t, ln.h_seq, seq);
