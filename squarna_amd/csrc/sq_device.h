@@ -160,6 +160,18 @@ __device__ __forceinline__ int sq_wave_min_i32(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// inclusive prefix sum over the lanes (the gfx9 scan sequence of DPP row shifts and row broadcasts: VALU only); lane 63 holds the total
+__device__ __forceinline__ int sq_wave_scan_add_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // LDS operations of one wave execute in program order; this keeps the compiler from moving them across the point (the
 // barrier of code in which ONE wave hands data to its own lanes through LDS)
 __device__ __forceinline__ void sq_wave_lds_fence()

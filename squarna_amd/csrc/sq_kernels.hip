@@ -512,40 +512,11 @@ __device__ __forceinline__ void sq_emit_global(const SqScanArgs &a, const SqStru
     sq_keys(a, st)[slot] = SqKey{key, len};
 }
 
-template <class LDS>
-__device__ __forceinline__ void sq5_flush(LDS &L, const SqScanArgs &a, const SqStruct &st, int cap, int lane)
-{
-    uint32_t n = L.stage_count;
-    if (n > SQ5_STAGE) n = SQ5_STAGE;
-    if (n) {
-        uint32_t b0 = 0;
-        if (lane == 0) b0 = atomicAdd(a.cand_cnt + st.slot, n);
-        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
-        for (uint32_t k = lane; k < n; k += 64) {
-            const uint32_t slot = base + k;
-            if (slot >= (uint32_t)cap) { a.ctr->cand_ovf = 1; continue; }
-            sq_keys(a, st)[slot] = SqKey{L.stage[k].x, L.stage[k].y};
-        }
-    }
-    __syncthreads();
-    if (lane == 0) L.stage_count = 0;
-    __syncthreads();
-}
-
-template <class LDS>
-__device__ __forceinline__ void sq5_emit(LDS &L, const SqScanArgs &a, const SqStruct &st, int cap, uint32_t key, uint32_t len)
-{
-    const uint32_t slot = atomicAdd(&L.stage_count, 1u);
-    if (slot < SQ5_STAGE) L.stage[slot] = make_uint2(key, len);
-    else sq_emit_global(a, st, cap, key, len, 0.f);
-}
-
 // ------------------------------------------------------------------------------------
 // a-2  stem scan, bit-diagonal form (sq_scan.h): one wave = 64 anti-diagonals of one structure, the runs staged in LDS
 // ------------------------------------------------------------------------------------
 struct SqScan6Lds {
     uint2 stage[SQ5_STAGE];
-    uint32_t stage_count, pad[3];
 };
 
 #include "sq_scan.h"
@@ -553,9 +524,44 @@ struct SqScan6Lds {
 // staged in LDS and appended to the structure's key array
 struct SqScan6Sink {
     SqScan6Lds &L; const SqScanArgs &a; const SqStruct &st; int cap;
-    __device__ __forceinline__ void emit(uint32_t key, uint32_t len) { sq5_emit(L, a, st, cap, key, len); }
-    __device__ __forceinline__ void poll(int lane) { if (L.stage_count > SQ5_STAGE / 2) sq5_flush(L, a, st, cap, lane); }
-    __device__ __forceinline__ void drain(int lane) { __syncthreads(); sq5_flush(L, a, st, cap, lane); }
+    uint32_t n;                               // runs staged since the last flush (a register: the wave is the whole block)
+    // the places of a word-row's runs: in the staging buffer (flushed first when they do not fit), or -- more runs than the
+    // buffer holds in one word-row -- straight in the structure's key array (index | 0x80000000)
+    __device__ __forceinline__ uint32_t reserve(uint32_t total, int lane)
+    {
+        if (n + total > SQ5_STAGE) flush(lane);
+        if (total > SQ5_STAGE) {
+            uint32_t b0 = 0;
+            if (lane == 0) b0 = atomicAdd(a.cand_cnt + st.slot, total);
+            return 0x80000000u | (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+        }
+        const uint32_t b0 = n; n += total; return b0;
+    }
+    __device__ __forceinline__ void put(uint32_t at, uint32_t key, uint32_t len)
+    {
+        if (at & 0x80000000u) {
+            const uint32_t slot = at & 0x7FFFFFFFu;
+            if (slot >= (uint32_t)cap) a.ctr->cand_ovf = 1; else sq_keys(a, st)[slot] = SqKey{key, len};
+        } else L.stage[at] = make_uint2(key, len);
+    }
+    __device__ __forceinline__ void flush(int lane)
+    {
+        __syncthreads();
+        if (n) {
+            uint32_t b0 = 0;
+            if (lane == 0) b0 = atomicAdd(a.cand_cnt + st.slot, n);
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+            for (uint32_t k = lane; k < n; k += 64) {
+                const uint32_t slot = base + k;
+                if (slot >= (uint32_t)cap) { a.ctr->cand_ovf = 1; continue; }
+                sq_keys(a, st)[slot] = SqKey{L.stage[k].x, L.stage[k].y};
+            }
+        }
+        n = 0;
+        __syncthreads();
+    }
+    __device__ __forceinline__ void poll(int lane) { if (n > SQ5_STAGE / 2) flush(lane); }
+    __device__ __forceinline__ void drain(int lane) { flush(lane); }
 };
 __device__ __forceinline__ void sq_scan6_body(const SqDevCtx &c, const SqStruct &st, const SqState &stt, SqScanArgs &a, int gy0, int gystep)
 {
@@ -569,14 +575,13 @@ __device__ __forceinline__ void sq_scan6_body(const SqDevCtx &c, const SqStruct 
     const int fbh = stt.fbstride >> 1;
     {
         const uint32_t *FBg0 = stt.FB + (int64_t)st.slot * stt.fbstride;
-        if (lane0 == 0) L.stage_count = 0;
         for (int m = lane0; m < 2 * fbh; m += 64) sq6_fg[m] = FBg0[m];
         __syncthreads();
     }
     // one block = the diagonal groups blockIdx.y, blockIdx.y + gridDim.y, ..: a launch for short sequences gives a structure
     // ONE wave that walks all its groups (five for 100 nt) instead of one wave per group -- each of those spent most of its
     // few microseconds on the set-up above, and with batches in flight wave slots are what the chip runs out of
-    SqScan6Sink sink{L, a, st, jb.cand_cap};
+    SqScan6Sink sink{L, a, st, jb.cand_cap, 0u};
     sq_scan6_groups(c, jb, sq6_fg, sq6_fg + fbh, fbh, stt.E8 + (int64_t)st.slot * stt.stride * 2, gy0, gystep, lane0, sink, SqBitsGlobal{c.bits + jb.bits_off, jb.bpitch});
 }
 

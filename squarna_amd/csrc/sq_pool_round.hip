@@ -66,24 +66,26 @@ struct SqPrSurv {
 };
 
 // the scan's sink: runs staged in LDS; whenever 64 of them wait they get their bpscore and the ones that pass :492 join
-// the survivors (the wave is the whole block: its barrier orders the LDS traffic)
+// the survivors (the wave is the whole block: its barrier orders the LDS traffic).  The fill counts live in registers: the
+// wave reserves the places of a word-row's runs at once (sq_scan.h)
 struct SqPrSink {
-    uint2 *stage; uint32_t *cnt;                      // staging buffer of SQ_PR_STAGE entries and its fill count (LDS)
-    uint2 *over; uint32_t *nover; uint32_t over_cap;  // runs beyond the buffer: the structure's key array in the arena
+    uint2 *stage;                                     // staging buffer of SQ_PR_STAGE entries (LDS)
+    uint2 *over; uint32_t over_cap;                   // runs beyond the buffer: the structure's key array in the arena
     const SqCellEnv &cenv; const SqDevCtx &c; const SqJob &jb; SqPrSurv &sv; uint32_t &ns;
     double minbps; SqCounters *ctr;
-    __device__ __forceinline__ void emit(uint32_t key, uint32_t len)
+    uint32_t n, nover;                                // runs staged since the last flush (beyond SQ_PR_STAGE: in `over`), runs in `over` before them
+    __device__ __forceinline__ uint32_t reserve(uint32_t total, int) { const uint32_t b0 = n; n += total; return b0; }
+    __device__ __forceinline__ void put(uint32_t at, uint32_t key, uint32_t len)
     {
-        const uint32_t slot = atomicAdd(cnt, 1u);
-        if (slot < SQ_PR_STAGE) stage[slot] = make_uint2(key, len);
+        if (at < SQ_PR_STAGE) stage[at] = make_uint2(key, len);
         else {
-            const uint32_t g = atomicAdd(nover, 1u);
+            const uint32_t g = nover + (at - SQ_PR_STAGE);
             if (g < over_cap) over[g] = make_uint2(key, len); else ctr->cand_ovf = 1;
         }
     }
-    __device__ __forceinline__ void score64(const uint2 *src, uint32_t n, int lane)      // n <= 64 runs
+    __device__ __forceinline__ void score64(const uint2 *src, uint32_t m, int lane)      // m <= 64 runs
     {
-        const bool have = (uint32_t)lane < n;
+        const bool have = (uint32_t)lane < m;
         const uint2 kl = have ? src[lane] : make_uint2(0u, 0u);
         double bps = 0.0, pos = 0.0;
         if (have) {
@@ -91,21 +93,20 @@ struct SqPrSink {
             bps = sq_cellrun_bps(cenv, c, jb, i, j, (int)kl.y, pos);
         }
         const bool ok = have && bps >= minbps;                                            // :492
-        const unsigned long long m = __ballot(ok);
-        if (ok) sv.put(ns + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), kl.x, (int)kl.y, bps);
-        ns += (uint32_t)__popcll(m);
+        const unsigned long long m2 = __ballot(ok);
+        if (ok) sv.put(ns + (uint32_t)__popcll(m2 & ((1ull << lane) - 1ull)), kl.x, (int)kl.y, bps);
+        ns += (uint32_t)__popcll(m2);
     }
     __device__ __forceinline__ void flush(int lane)
     {
         __syncthreads();
-        uint32_t n = *cnt;
-        if (n > SQ_PR_STAGE) n = SQ_PR_STAGE;
-        for (uint32_t b0 = 0; b0 < n; b0 += 64) score64(stage + b0, min(n - b0, 64u), lane);
-        __syncthreads();
-        if (lane == 0) *cnt = 0;
+        const uint32_t m = n < SQ_PR_STAGE ? n : SQ_PR_STAGE;
+        for (uint32_t b0 = 0; b0 < m; b0 += 64) score64(stage + b0, min(m - b0, 64u), lane);
+        if (n > SQ_PR_STAGE) { const uint32_t more = n - SQ_PR_STAGE; nover = nover + more < over_cap ? nover + more : over_cap; }
+        n = 0;
         __syncthreads();
     }
-    __device__ __forceinline__ void poll(int lane) { sq_wave_lds_fence(); if (*cnt >= 64u) flush(lane); }
+    __device__ __forceinline__ void poll(int lane) { if (n >= 64u) flush(lane); }
     __device__ __forceinline__ void drain(int lane) { flush(lane); }
 };
 
@@ -116,7 +117,6 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
 {
     extern __shared__ __attribute__((aligned(16))) char pr_dyn[];
     __shared__ SqCellTmp s_ctmp;
-    __shared__ uint32_t s_cnt, s_nover;
     __shared__ int s_ri[SQ_POOL_CMAX], s_rj[SQ_POOL_CMAX], s_rl[SQ_POOL_CMAX];
     const int lane = threadIdx.x;
     const int s = ra.lo + (int)blockIdx.x;                  // the structure's position in the round's list == its slot
@@ -158,7 +158,6 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
     XL.gsize = XL.cc + Lo.t8;
     XL.ord = reinterpret_cast<int16_t *>(XL.gsize + 64);
     XL.grp = reinterpret_cast<uint8_t *>(XL.ord + Lo.t8); XL.lvl = XL.grp + Lo.t8; XL.rank = XL.lvl + Lo.t8;
-    if (lane == 0) { s_cnt = 0; s_nover = 0; }
 
     int job, nstems, nstrand; double maxstems;
     auto log_final = [&](uint32_t round_kind, int nst) {    // (sq_pool_extend_kernel's record; the stems from LDS)
@@ -293,11 +292,11 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
     const double minbps = ps->minbpscore, minfin = ps->minfinscore;
     uint32_t ns = 0;
     if (n >= 5) {                                                       // :456-457 (shorter sequences have no diagonals)
-        SqPrSink sink{s_stage, &s_cnt, over, &s_nover, (uint32_t)jb.cand_cap, cenv, c, jb, sv, ns, minbps, a.ctr};
+        SqPrSink sink{s_stage, over, (uint32_t)jb.cand_cap, cenv, c, jb, sv, ns, minbps, a.ctr, 0u, 0u};
         sq_scan6_groups(c, jb, FG, FG + Lo.fbh, Lo.fbh, E, 0, 1, lane, sink, SqBitsGlobal{c.bits + jb.bits_off, jb.bpitch});
         __threadfence_block();
         __syncthreads();
-        const uint32_t no = s_nover < (uint32_t)jb.cand_cap ? s_nover : (uint32_t)jb.cand_cap;
+        const uint32_t no = sink.nover;
         for (uint32_t b0 = 0; b0 < no; b0 += 64) sink.score64(over + b0, min(no - b0, 64u), lane);
     }
     __threadfence_block();

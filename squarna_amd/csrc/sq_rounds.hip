@@ -39,39 +39,24 @@
 #define SQ_ROUNDS_WAVES 4          // waves per SIMD the register budget allows (128 VGPRs): four 256-thread blocks per CU
 #endif
 
-// the first round's scan: every wave stages its runs in its own LDS buffer and appends them to the block's list
+// the first round's scan: a wave reserves the places of a word-row's runs in the block's list with ONE LDS atomic and the lanes
+// write their runs there (sq_scan.h; until round 5 every run went through a per-wave staging buffer behind an atomic of its own)
 struct SqRoundsSink {
-    uint2 *stage; uint32_t *cnt;             // this wave's staging buffer and fill count (LDS)
     uint32_t *nlist;                         // the block's list length (LDS)
     SqRun *list; uint32_t cap; SqCounters *ctr;
+    __device__ __forceinline__ uint32_t reserve(uint32_t total, int lane)
+    {
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(nlist, total);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+    }
     __device__ __forceinline__ void put(uint32_t pos, uint32_t key, uint32_t len)
     {
         if (pos < cap) list[pos] = SqRun{key, len, __longlong_as_double(0x7FF8000000000000ll)};
         else ctr->cand_ovf = 1;
     }
-    __device__ __forceinline__ void emit(uint32_t key, uint32_t len)
-    {
-        const uint32_t slot = atomicAdd(cnt, 1u);
-        if (slot < SQ_ROUNDS_STAGE) stage[slot] = make_uint2(key, len);
-        else put(atomicAdd(nlist, 1u), key, len);
-    }
-    __device__ __forceinline__ void flush(int lane)
-    {
-        sq_wave_lds_fence();
-        uint32_t n = *cnt;
-        if (n > SQ_ROUNDS_STAGE) n = SQ_ROUNDS_STAGE;
-        if (n) {
-            uint32_t b0 = 0;
-            if (lane == 0) b0 = atomicAdd(nlist, n);
-            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
-            for (uint32_t k = lane; k < n; k += 64) put(base + k, stage[k].x, stage[k].y);
-        }
-        sq_wave_lds_fence();
-        if (lane == 0) *cnt = 0;
-        sq_wave_lds_fence();
-    }
-    __device__ __forceinline__ void poll(int lane) { sq_wave_lds_fence(); if (*cnt > SQ_ROUNDS_STAGE / 2) flush(lane); }
-    __device__ __forceinline__ void drain(int lane) { flush(lane); }
+    __device__ __forceinline__ void poll(int) {}
+    __device__ __forceinline__ void drain(int) {}
 };
 
 // The two strands of a new stem k = (i0, j0, len) into the sorted strand list S[0 .. nstrand) (+ the stem index of each
@@ -227,11 +212,8 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 if (2 * m2 + 1 < fbh) { FG[2 * m2 + 1] = (uint32_t)(bf >> 32); FG[fbh + 2 * m2 + 1] = (uint32_t)(br >> 32); }
             }
         }
-        uint32_t *const wcnt = reinterpret_cast<uint32_t *>(uni) + 4 * wv;
-        uint2 *const wstage = reinterpret_cast<uint2 *>(uni + 16 * nwv) + (size_t)wv * SQ_ROUNDS_STAGE;
-        if (lane == 0) *wcnt = 0;
         __syncthreads();
-        SqRoundsSink sink{wstage, wcnt, &s_nlist, raw, (uint32_t)cap, a.ctr};
+        SqRoundsSink sink{&s_nlist, raw, (uint32_t)cap, a.ctr};
         if (ra.fly > 0) {
             // the letter masks of sq_bits_masks_kernel, in the LDS the strands and stems of the later rounds will take (the
             // structure is empty now)

@@ -24,7 +24,8 @@
 // One wave scans the diagonal groups gy0, gy0 + gystep, .. of a structure of job jb.  F / G: the structure's free-position
 // bit words (forward / reversed + SQ_GPAD, fbh words each, in LDS); eg: its mask codes per position (0 free, 1 end of a
 // live restraint pair, 255 paired).  Sink: where the runs of at least minlen cells go --
-//   emit(key, len)    from any lane, key = (s << 16) | first row;
+//   reserve(n, lane)  all lanes (wave-uniform n): places for n runs, returns the first one's index;
+//   put(at, key, len) from any lane, into a reserved place, key = (s << 16) | first row;
 //   poll(lane)        after every word-row, all lanes (room to flush a staging buffer);
 //   drain(lane)       after every group of 64 diagonals, all lanes.
 // Bits: where the words of the job's diagonal bit matrix come from -- word(w, s) = bit b <-> cell (32w + b, s - 32w - b) of the
@@ -158,34 +159,50 @@ __device__ __forceinline__ void sq_scan6_groups(const SqDevCtx &c, const SqJob &
                     if ((v >> 5) == w && eg[v] == 1 && eg[pk >> 16] == 1) A |= base & (1u << (v & 31));   // :438-443 restraint bp stays pairable
                     rp++;
                 }
-                // maximal runs of the word (bit b = row 32w + b; `carry` rows of an open run precede row 32w)
-                if (__ballot((A != 0u) | (carry > 0)) != 0ull) {
-                    if (A == 0xFFFFFFFFu) carry += 32;
-                    else {
-                        const int lead = __ffs((int)~A) - 1;                // the run that continues the carried one (maybe empty)
-                        const int len0 = carry + lead;
-                        if (len0 >= minlen) sink.emit(((uint32_t)s << 16) | (uint32_t)(32 * w - carry), (uint32_t)len0);
-                        const int trail = __clz((int)~A);                   // the run still open at row 32w + 31
-                        carry = trail;
-                        // runs strictly inside: starts with a full window of minlen ones above them
-                        uint32_t rest = A & ~((1u << lead) - 1u);
-                        if (trail) rest &= 0xFFFFFFFFu >> trail;
-                        uint32_t Y = rest;
-                        Y &= Y >> ysh0; Y &= Y >> ysh1; Y &= Y >> ysh2; Y &= Y >> ysh3; Y &= Y >> ysh4;
-                        uint32_t starts = rest & ~(rest << 1) & Y;
-                        while (starts) {
-                            const int p = __ffs((int)starts) - 1;
-                            starts &= starts - 1;
-                            const int len = __ffs((int)~(rest >> p)) - 1;
-                            sink.emit(((uint32_t)s << 16) | (uint32_t)(32 * w + p), (uint32_t)len);
-                        }
+                // maximal runs of the word (bit b = row 32w + b; `carry` rows of an open run precede row 32w).  Every lane first
+                // finds what it has to emit -- the run that continues the carried one, the starts of the runs strictly inside --,
+                // then the WAVE reserves their places at once: the lanes' counts as a prefix sum (DPP), one request to the sink
+                // per word-row.  (Until round 5 every run took its place with an LDS atomic of its own on ONE counter: some
+                // 180 same-address atomics per word-row of a wave at 1,000 nt, served one after the other, each waited for by
+                // its lane -- most of the scan's time.)
+                bool e0 = false; int l0 = 0, r0 = 0; uint32_t starts = 0u, rest = 0u;
+                if (A == 0xFFFFFFFFu) carry += 32;
+                else {
+                    const int lead = __ffs((int)~A) - 1;                    // the run that continues the carried one (maybe empty)
+                    l0 = carry + lead; r0 = 32 * w - carry; e0 = l0 >= minlen;
+                    const int trail = __clz((int)~A);                       // the run still open at row 32w + 31
+                    carry = trail;
+                    // runs strictly inside: starts with a full window of minlen ones above them
+                    rest = A & ~((1u << lead) - 1u);
+                    if (trail) rest &= 0xFFFFFFFFu >> trail;
+                    uint32_t Y = rest;
+                    Y &= Y >> ysh0; Y &= Y >> ysh1; Y &= Y >> ysh2; Y &= Y >> ysh3; Y &= Y >> ysh4;
+                    starts = rest & ~(rest << 1) & Y;
+                }
+                const int cnt = (e0 ? 1 : 0) + __popc(starts);
+                if (__ballot(cnt > 0) != 0ull) {
+                    const int incl = sq_wave_scan_add_i32(cnt);
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+                    uint32_t at = sink.reserve(total, lane) + (uint32_t)(incl - cnt);
+                    if (e0) sink.put(at++, ((uint32_t)s << 16) | (uint32_t)r0, (uint32_t)l0);
+                    while (starts) {
+                        const int p = __ffs((int)starts) - 1;
+                        starts &= starts - 1;
+                        const int len = __ffs((int)~(rest >> p)) - 1;
+                        sink.put(at++, ((uint32_t)s << 16) | (uint32_t)(32 * w + p), (uint32_t)len);
                     }
-                } else
-                    carry = 0;
+                }
                 sink.poll(lane);
             }
         }
-        if (carry >= minlen) sink.emit(((uint32_t)s << 16) | (uint32_t)(32 * (whi + 1) - carry), (uint32_t)carry);
+        {
+            const bool e1 = carry >= minlen;                                   // the run still open behind the last word-row
+            const unsigned long long m1 = __ballot(e1);
+            if (m1) {
+                const uint32_t at = sink.reserve((uint32_t)__popcll(m1), lane) + (uint32_t)__popcll(m1 & ((1ull << lane) - 1ull));
+                if (e1) sink.put(at, ((uint32_t)s << 16) | (uint32_t)(32 * (whi + 1) - carry), (uint32_t)carry);
+            }
+        }
         sink.drain(lane);
     }
 }
