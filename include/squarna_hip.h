@@ -260,8 +260,10 @@ SQ_API int32_t sq_fold_driver(const sq_batch *b);
  * scan / score / choose / extend kernels), bit 4 -- jobs of wider pools that almost never branch (range factor 1.0, cells from
  * a dense fp64 matrix: the alignment's rows, bpp terms) ran as chains on the persistent round kernel first; the ones that met a
  * tie were folded by the device pools, bit 5 -- the rounds of the device pools were enqueued ahead of the host (a batch alone:
- * every launch covers all structure slots and follows the generation sizes the device publishes; SQ_POOL_AHEAD).  Identical
- * results either way; for tests and tuning. */
+ * every launch covers all structure slots and follows the generation sizes the device publishes; SQ_POOL_AHEAD), bit 6 -- the
+ * device pools of sequences of 257-1,024 nt ran the one-wave round kernel over per-job root lists (the runs of the empty
+ * structure with their bpscores, checked against every structure's partner array) instead of the launched scan and score
+ * kernels (SQ_POOL_ROOT).  Identical results either way; for tests and tuning. */
 SQ_API int32_t sq_fold_paths(const sq_batch *b);
 /* Most structures any round of the batch's last fold evaluated at once (device pools: the largest generation; 0 when the
  * host-driven loop ran).  A host that folds a stream of similar batches sizes max_structs from it. */

@@ -11,6 +11,7 @@ void sq_read_fold_switches(SqFoldSwitches &sw)
     sw.no_opt_chain = on("SQ_NO_OPT_CHAIN"); sw.no_fly_bits = on("SQ_NO_FLY_BITS"); sw.no_defer_wait = on("SQ_NO_DEFER_WAIT");
     sw.no_pool_round = on("SQ_NO_POOL_ROUND"); sw.pool_round_always = on("SQ_POOL_ROUND_ALWAYS");
     sw.pool_round_nsurv = num("SQ_POOL_ROUND_NSURV", 16, 2048);
+    sw.pool_root = getenv("SQ_POOL_ROOT") ? num("SQ_POOL_ROOT", 0, 1) : 0;
     sw.pool_ahead = getenv("SQ_POOL_AHEAD") ? num("SQ_POOL_AHEAD", 0, SQ_POOL_HDR_RING - 2) : 3;
     sw.pool_slots = num("SQ_POOL_SLOTS", 1, 0x7fffffff); sw.pool_chunk = num("SQ_POOL_CHUNK", 1, 0x7fffffff);
     sw.no_score_bound = on("SQ_NO_SCORE_BOUND"); sw.no_score_context = on("SQ_NO_SCORE_CONTEXT");
@@ -577,7 +578,13 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         int slots = std::min(PI.smax, ln.max_structs);
         if (sw.pool_slots > 0) slots = std::min(slots, sw.pool_slots);   // (tests: force the overflow path)
         // structures whose candidates fit the arena at once; larger generations go through state .. choose in chunks
-        int chunk = (int)std::min<int64_t>(slots, avail / std::max<int64_t>(maxcap, 1));
+        // root lists (sequences beyond the scanning round kernel's 256 nt, up to 1,024): 16 bytes per run of the EMPTY structure
+        // of every job, behind the structures' regions of the arena
+        const int64_t root_units = (maxcap + 1) / 2;
+        bool root_mode = sw.pool_root && !sw.no_pool_round && maxn > SQ_PR_MAXN && maxn <= SQ_PR_ROOT_MAXN &&
+                         (int64_t)S0 * root_units + std::max<int64_t>(maxcap, 1) <= avail;
+        const int64_t avail_s = root_mode ? avail - (int64_t)S0 * root_units : avail;
+        int chunk = (int)std::min<int64_t>(slots, avail_s / std::max<int64_t>(maxcap, 1));
         if (sw.pool_chunk > 0) chunk = std::min(chunk, sw.pool_chunk);   // (tests: force chunked rounds)
         if (S0 > slots || chunk < 1) return 1;
         for (int j = 0; j < b->njobs; j++) b->h_pool_jobrec[j] = -1;
@@ -608,18 +615,26 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         // are what it runs out of, for a batch alone because two launches per round instead of six shorten the greedy loop
         // (SRtest150: 1.43 -> 1.28 ms, and the loop depends less on how fast the host turns a round around)
         SqPoolRoundArgs pra;
-        bool round_kernel = maxn <= SQ_PR_MAXN && !sw.no_pool_round;   // (jobs with a dense matrix too: sq_cellrun.h reads their cells there)
+        bool round_kernel = (maxn <= SQ_PR_MAXN || root_mode) && !sw.no_pool_round;   // (jobs with a dense matrix too: sq_cellrun.h reads their cells there)
         if (round_kernel) {
             pra.lds_n = maxn; pra.str_cap = 2 * pio.pt + 2; pra.cell_entries = b->cell_entries;
             // survivors of :492 kept in LDS (the rest spill to the arena): on a crowded chip LDS is what the round kernel's waves
             // and everybody else's compete for -- 22 bytes x 256 survivors were half of a wave's 10 KB, and most structures have
             // a few dozen (tools/pr_waves_sweep.sh: 64 -> +5 % on the headline, 16 .. 64 within a per cent of each other)
             const bool crowded_fold = b->inflight > 1 || b->njobs >= 4096;
-            pra.surv_cap = sw.pool_round_nsurv ? sw.pool_round_nsurv : (crowded_fold ? 64 : (maxn <= 96 ? 128 : 256)); pra.bound = b->score_bound ? 1 : 0;
+            pra.surv_cap = sw.pool_round_nsurv ? sw.pool_round_nsurv : (root_mode ? 256 : (crowded_fold ? 64 : (maxn <= 96 ? 128 : 256))); pra.bound = b->score_bound ? 1 : 0;
             pra.tmax = pio.pt; pra.parity = 0; pra.lo = 0; pra.ahead = 0;
+            pra.root = root_mode ? 1 : 0; pra.root_units = (int32_t)root_units; pra.root_off = (int64_t)chunk * maxcap;
             if (sq_pool_round_lds(pra.lds_n, pra.str_cap, pra.cell_entries, pra.surv_cap, pra.tmax).total > 60 * 1024) round_kernel = false;
         }
         if (round_kernel) b->last_paths |= 8;
+        if (round_kernel && root_mode) {
+            // the jobs' root lists: AnnotateStems of every job's empty structure, once (one wave per job)
+            const size_t rl = sq_pool_root_lds(pra.lds_n, pra.cell_entries);
+            if (rl > 60 * 1024) sq_max_dynamic_lds((const void *)sq_pool_root_kernel, 160 * 1024);
+            hipLaunchKernelGGL(sq_pool_root_kernel, dim3(S0), dim3(64), rl, st, b->ctx, scan, pio, pra);
+            b->last_paths |= 64;
+        }
         const size_t ext_lds = sq_extend_lds_bytes(pio.pt);          // the extend kernel's level scratch (dynamic LDS)
         if (ext_lds > 64 * 1024) sq_max_dynamic_lds((const void *)sq_pool_extend_kernel, 160 * 1024);
         const double tr0 = now_s();

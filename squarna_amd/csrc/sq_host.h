@@ -124,6 +124,7 @@ struct SqFoldSwitches {
     bool pool_round_always = false;   // SQ_POOL_ROUND_ALWAYS: (the default since late round 4; the switch is read and ignored)
     int pool_round_nsurv = 0;         // SQ_POOL_ROUND_NSURV: survivors sq_pool_round_kernel keeps in LDS (0: by length)
     int pool_slots = 0;               // SQ_POOL_SLOTS: structure slots the device pools may use (0: max_structs)
+    int pool_root = 0;                // SQ_POOL_ROOT: pools on sequences of 257-1,024 nt run the one-wave round kernel over root lists
     int pool_ahead = 3;               // SQ_POOL_AHEAD: rounds of the device pools a batch alone enqueues ahead of the host (0: none)
     int pool_chunk = 0;               // SQ_POOL_CHUNK: structures per chunk of a generation (0: what the arena holds)
     bool no_score_bound = false;      // SQ_NO_SCORE_BOUND: ScoreStems on every survivor of :492

@@ -7,6 +7,7 @@
 #ifndef SQ_PR_STAGE
 #define SQ_PR_STAGE 128            // runs the scan stages in LDS before they are scored (64 at a time)
 #endif
+#define SQ_PR_ROOT_MAXN 1024       // ... with root lists (SqPoolRoundArgs::root)
 #define SQ_PR_MAXN 256             // longest sequence the kernel takes (one wave per structure; measured to 1,024: parity clean, no faster than the launched round kernels from ~300 nt on -- a round of long structures is bound by its scan and ScoreStems work, not by launches)
 
 struct SqPoolRoundArgs {
@@ -19,6 +20,12 @@ struct SqPoolRoundArgs {
     int32_t parity;         // generation of this round's structures
     int32_t lo;             // position in the round's list of the launch's first structure (chunked rounds)
     int32_t ahead;          // the launch covers every slot: blocks beyond the generation's size (SqPoolHdr::S) leave
+    int32_t root;           // 1: AnnotateStems as a pass over the job's ROOT list -- the runs of the empty structure with their exact
+                            // bpscores, written once per fold by sq_pool_root_kernel -- checked against the structure's own partner
+                            // array, instead of the bit-diagonal scan (sequences beyond SQ_PR_MAXN: there the scan and the bpscores of
+                            // its thousands of runs are most of a structure's round)
+    int32_t root_units;     // 32-byte units of the candidate arena per job's root list (16 bytes per run)
+    int64_t root_off;       // first unit of the root lists in the candidate arena (job record sx: root_off + sx * root_units)
 };
 
 struct SqPoolRoundLds {
@@ -61,3 +68,10 @@ __host__ __device__ inline SqPoolRoundLds sq_pool_round_lds(int lds_n, int str_c
 }
 
 extern "C" __global__ void sq_pool_round_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra);
+extern "C" __global__ void sq_pool_root_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra);
+// dynamic LDS of sq_pool_root_kernel: mask codes + class indices, free-position words, cell table, staging buffer
+__host__ __device__ inline size_t sq_pool_root_lds(int lds_n, int cell_entries)
+{
+    const size_t np = ((size_t)lds_n + 8) & ~(size_t)7, fbh = (((size_t)lds_n + 2 + 31) >> 5) + 8;
+    return 2 * np + ((8 * fbh + 15) & ~(size_t)15) + 8 * (size_t)cell_entries + 8 * 1088 + 64;
+}

@@ -36,6 +36,7 @@
 #define SQ6_AHEAD SQ_PR_AHEAD
 #include "sq_scan.h"
 #include "sq_pool_round.h"
+#include "sq_rounds.h"             // (SqRun: a run with its exact bpscore -- the root lists' record)
 
 #define SQ_POOL_CMAX 64         // stems ChooseStems may return for one structure (== lanes of the conflict test)
 
@@ -251,7 +252,16 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
             base_u += __popcll(mu); base_s += __popcll(ms);
         }
         if (lane == 0) { U[n] = (int16_t)base_u; SU[n] = (int16_t)base_s; }
-        const int fbh = Lo.fbh;
+        if (ra.root) {
+            // the root-list pass: one bit per position, set while it is unpaired (forward order; two zero words behind the last)
+            const int nwb = ((n + 31) >> 5) + 2;
+            for (int m2 = 0; 2 * m2 < nwb; m2++) {
+                const int pf = 64 * m2 + lane;
+                const unsigned long long bf = __ballot(pf < n && P[pf] == -1);
+                if (lane == 0) { FG[2 * m2] = (uint32_t)bf; FG[2 * m2 + 1] = (uint32_t)(bf >> 32); }
+            }
+        }
+        const int fbh = ra.root ? 0 : Lo.fbh;                // (free-position words: the scan's)
         for (int m2 = 0; 2 * m2 < fbh; m2++) {
             const int pf = 64 * m2 + lane;
             const unsigned long long bf = __ballot(pf < n && E[pf] == 0);
@@ -291,7 +301,72 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
     sv.spill_cap = (uint32_t)(((size_t)jb.cand_cap * (sizeof(SqCand) - sizeof(SqKey))) / sizeof(SqOk));
     const double minbps = ps->minbpscore, minfin = ps->minfinscore;
     uint32_t ns = 0;
-    if (n >= 5) {                                                       // :456-457 (shorter sequences have no diagonals)
+    if (ra.root && n >= 5) {
+        // ---- AnnotateStems from the job's root list: choosing stems only ever masks rows and columns (:446-451), so the maximal
+        // runs of this structure are the pieces its paired positions leave of the empty structure's runs (sq_rounds.hip keeps a
+        // chain's list on the same rule).  A run whose rows and columns are all unpaired -- four reads of the prefix counts --
+        // stands as it is with the bpscore the root kernel gave it; a cut run is walked cell by cell against the partner array
+        // and its pieces of minlen cells and more are summed anew.  No bit matrix is read and no run of the structure is
+        // re-summed that was not cut.
+        const SqRun *const root = reinterpret_cast<const SqRun *>(a.cands + ra.root_off + (int64_t)pio.jobrec_of[job] * ra.root_units);
+        const uint32_t R = a.cand_cnt[pio.jobrec_of[job]];
+        const int minlen = max(1, (int)ceil(ps->minlen));
+        SqRun nx = lane < (int)R ? root[lane] : SqRun{0u, 0u, 0.0};
+        for (uint32_t q0 = 0; q0 < R; q0 += 64) {
+            const SqRun r = nx;
+            const bool have = q0 + (uint32_t)lane < R;
+            if (q0 + 64 + (uint32_t)lane < R) nx = root[q0 + 64 + lane];       // (the next entries are on their way)
+            const int L = (int)r.len, i = (int)(r.key & 0xFFFFu), j = (int)(r.key >> 16) - i;
+            const bool whole = have && ((int)U[i + L] - (int)U[i]) == L && ((int)U[j + 1] - (int)U[j - L + 1]) == L;
+            bool ok = whole && r.bps >= minbps;                                  // :492
+            unsigned long long m = __ballot(ok);
+            if (ok) sv.put(ns + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), r.key, L, r.bps);
+            ns += (uint32_t)__popcll(m);
+            // the cut runs: a run of exactly minlen cells that lost one is gone; the others are walked, one piece per step of
+            // the wave (most have two or three cells: the steps are few)
+            bool cut = have && !whole && L > minlen;
+            int t0 = 0;
+            // (runs of up to 32 cells -- nearly all -- as a word of live cells: the rows' window of the unpaired bits AND the
+            // bit-reversed window of the columns'; the pieces then come out of the word without another read)
+            uint32_t alive = 0u;
+            const bool word = L <= 32;
+            if (cut && word) {
+                const uint32_t rw = __builtin_amdgcn_alignbit(FG[(i >> 5) + 1], FG[i >> 5], (uint32_t)(i & 31));        // bit t: row i + t
+                const int q = j - 31;                                                                                       // bit k of the window: column q + k
+                const uint32_t cw = q >= 0 ? __builtin_amdgcn_alignbit(FG[(q >> 5) + 1], FG[q >> 5], (uint32_t)(q & 31)) : FG[0] << (uint32_t)(-q);
+                alive = rw & __brev(cw) & (L == 32 ? 0xFFFFFFFFu : ((1u << L) - 1u));                                       // bit t: column j - t
+            }
+            while (__ballot(cut) != 0ull) {
+                int pb = -1, pl = 0;
+                if (cut && word) {
+                    while (alive) {
+                        const int b0 = __ffs((int)alive) - 1;
+                        const uint32_t up = ~(alive >> b0);
+                        const int len = up ? __ffs((int)up) - 1 : 32 - b0;
+                        alive &= len + b0 >= 32 ? 0u : ~((1u << (len + b0)) - 1u);
+                        if (len >= minlen) { pb = b0; pl = len; break; }
+                    }
+                    if (pb < 0) cut = false;
+                } else if (cut) {
+                    int t = t0;
+                    while (t < L) {
+                        while (t < L && !(P[i + t] == -1 && P[j - t] == -1)) t++;
+                        const int b0 = t;
+                        while (t < L && P[i + t] == -1 && P[j - t] == -1) t++;
+                        if (t - b0 >= minlen) { pb = b0; pl = t - b0; break; }
+                    }
+                    t0 = t;
+                    if (pb < 0) cut = false;
+                }
+                double bps = 0.0, pos = 0.0;
+                if (pb >= 0) bps = sq_cellrun_bps(cenv, c, jb, i + pb, j - pb, pl, pos);
+                ok = pb >= 0 && bps >= minbps;
+                m = __ballot(ok);
+                if (ok) sv.put(ns + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), ((uint32_t)(i + j) << 16) | (uint32_t)(i + pb), pl, bps);
+                ns += (uint32_t)__popcll(m);
+            }
+        }
+    } else if (n >= 5) {                                                // :456-457 (shorter sequences have no diagonals)
         SqPrSink sink{s_stage, over, (uint32_t)jb.cand_cap, cenv, c, jb, sv, ns, minbps, a.ctr, 0u, 0u};
         sq_scan6_groups(c, jb, FG, FG + Lo.fbh, Lo.fbh, E, 0, 1, lane, sink, SqBitsGlobal{c.bits + jb.bits_off, jb.bpitch});
         __threadfence_block();
@@ -413,4 +488,81 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
     if (over_c) { if (lane == 0) pio.hdr->ovf = 1; nres = 0; }
     else if (nres == 0) log_final(2u * round + 1u, nstems);
     if (lane == 0) { pio.nchild[s] = nres; pio.finalflag[s] = 0; }
+}
+
+
+// The root lists: per job of the pools the runs of its EMPTY structure -- AnnotateStems of round 0 (bit-diagonal scan) -- with
+// their exact bpscores, the ones whose positive cell parts cannot reach :492 dropped (no piece of them ever passes, sq_cellrun.h).
+// One wave per job, once per fold; every structure of the job's pool then reads the list instead of scanning (SqPoolRoundArgs::root).
+#define SQ_PR_ROOT_STAGE 1088          // runs the root kernel stages in LDS (a word-row of a wave emits at most 64 x 16)
+struct SqPrRootSink {
+    uint2 *stage;                                     // SQ_PR_ROOT_STAGE entries (LDS)
+    SqRun *root; uint32_t cap;
+    const SqCellEnv &cenv; const SqDevCtx &c; const SqJob &jb; double minbps; SqCounters *ctr;
+    uint32_t n, cnt;                                  // runs staged, runs written
+    __device__ __forceinline__ uint32_t reserve(uint32_t total, int lane)
+    {
+        if (n + total > SQ_PR_ROOT_STAGE) flush(lane);
+        const uint32_t b0 = n; n += total; return b0;
+    }
+    __device__ __forceinline__ void put(uint32_t at, uint32_t key, uint32_t len) { if (at < SQ_PR_ROOT_STAGE) stage[at] = make_uint2(key, len); else ctr->cand_ovf = 1; }
+    __device__ __forceinline__ void flush(int lane)
+    {
+        __syncthreads();
+        for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+            const bool have = b0 + (uint32_t)lane < n;
+            const uint2 kl = have ? stage[b0 + lane] : make_uint2(0u, 0u);
+            double bps = 0.0, pos = 0.0;
+            if (have) { const int i = (int)(kl.x & 0xFFFFu), j = (int)(kl.x >> 16) - i; bps = sq_cellrun_bps(cenv, c, jb, i, j, (int)kl.y, pos); }
+            const bool keep = have && !(pos < minbps);             // (a run whose positive parts miss :492 has no piece that passes)
+            const unsigned long long m = __ballot(keep);
+            const uint32_t at = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (keep) { if (at < cap) root[at] = SqRun{kl.x, kl.y, bps}; else ctr->cand_ovf = 1; }
+            cnt += (uint32_t)__popcll(m);
+        }
+        n = 0;
+        __syncthreads();
+    }
+    __device__ __forceinline__ void poll(int lane) { if (n >= 256u) flush(lane); }
+    __device__ __forceinline__ void drain(int lane) { flush(lane); }
+};
+
+extern "C" __global__ __launch_bounds__(64) void sq_pool_root_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra)
+{
+    extern __shared__ __attribute__((aligned(16))) char pr_dyn[];
+    __shared__ SqCellTmp s_ctmp;
+    const int lane = threadIdx.x;
+    const int sx = (int)blockIdx.x;                         // the job's record == the slot of its empty structure in generation 0
+    const int job = pio.structs[sx].job;
+    const SqJob jb = c.jobs[job];
+    const SqPsetDev *ps = c.psets + jb.pset;
+    const int n = jb.n;
+    // LDS: mask codes, class indices, free-position words, the cell table, the staging buffer
+    const int np = (ra.lds_n + 8) & ~7, fbh = ((ra.lds_n + 2 + 31) >> 5) + 8;
+    uint8_t *const E = reinterpret_cast<uint8_t *>(pr_dyn);
+    uint8_t *const l_ci = E + np;
+    uint32_t *const FG = reinterpret_cast<uint32_t *>(l_ci + np);
+    double *const s_cell = reinterpret_cast<double *>(reinterpret_cast<char *>(FG) + ((8 * fbh + 15) & ~15));
+    uint2 *const stage = reinterpret_cast<uint2 *>(s_cell + ra.cell_entries);
+    const SqCellEnv cenv = sq_cell_setup(c, jb, ps, s_ctmp, l_ci, nullptr, s_cell, lane, 64);
+    {
+        const uint8_t *e0 = c.e0c + jb.pos_off;
+        for (int p = lane; p < n; p += 64) E[p] = e0[p];
+        __syncthreads();
+        for (int m2 = 0; 2 * m2 < fbh; m2++) {              // free-position words of the empty structure, forward and reversed
+            const int pf = 64 * m2 + lane;
+            const unsigned long long bf = __ballot(pf < n && E[pf] == 0);
+            const int pr = n - 1 - (64 * m2 + lane - SQ_GPAD);
+            const unsigned long long br = __ballot(pr >= 0 && pr < n && E[pr] == 0);
+            if (lane == 0) {
+                FG[2 * m2] = (uint32_t)bf; FG[fbh + 2 * m2] = (uint32_t)br;
+                if (2 * m2 + 1 < fbh) { FG[2 * m2 + 1] = (uint32_t)(bf >> 32); FG[fbh + 2 * m2 + 1] = (uint32_t)(br >> 32); }
+            }
+        }
+        __syncthreads();
+    }
+    SqRun *const root = reinterpret_cast<SqRun *>(a.cands + ra.root_off + (int64_t)sx * ra.root_units);
+    SqPrRootSink sink{stage, root, (uint32_t)(2 * ra.root_units), cenv, c, jb, ps->minbpscore, a.ctr, 0u, 0u};
+    if (n >= 5) sq_scan6_groups(c, jb, FG, FG + fbh, fbh, E, 0, 1, lane, sink, SqBitsGlobal{c.bits + jb.bits_off, jb.bpitch});
+    if (lane == 0) a.cand_cnt[sx] = sink.cnt < sink.cap ? sink.cnt : sink.cap;
 }

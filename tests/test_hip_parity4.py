@@ -529,3 +529,38 @@ def test_pooled_score_kernel_block_sizes_agree(monkeypatch):
         exp = O.SQRNdbnseq(seqs[k], None, None, None, psets, poollim=1000)
         exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
         _same_fold(res[k][0], exp, ("pooled score threads", k))
+
+
+def test_pool_rounds_over_root_lists_equal_the_launched_kernels(monkeypatch):
+    """SQ_POOL_ROOT=1 (opt-in): pools on sequences of 257-1,024 nt run the one-wave round kernel over per-job root lists -- the
+    runs of the empty structure with their bpscores, checked against every structure's partner array (sq_fold_paths bit 6 = 64)
+    -- instead of the launched state / scan / score / choose / extend kernels: the same packed records and evaluation counts,
+    with reactivities, restraints (pairs included), separators, survivors beyond the LDS room and chunked generations; and the
+    oracle's structures."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import Batch, Prepared
+    names, psets = conf("nobpp")
+    raw = _chain_records(28, 6464, 257, 420)
+    prepared = [Prepared(s, r, x) for s, r, x in raw]
+    n = len(prepared)
+    assert min(len(r[0]) for r in raw) > 256
+    with Batch(prepared, [psets] * n, max_structs=65536, fp32=False) as b:
+        b.fold(poollim=1000)
+        assert b.fold_driver == 2 and not (b.fold_paths & 64), (b.fold_driver, b.fold_paths)
+        want, evals = _packed(b, n), [b.evals(k) for k in range(n)]
+        res = b.results_all()
+        monkeypatch.setenv("SQ_POOL_ROOT", "1")
+        for extra in ({}, {"SQ_POOL_ROUND_NSURV": "64"}, {"SQ_POOL_CHUNK": "700"}):
+            for k, v in extra.items():
+                monkeypatch.setenv(k, v)
+            b.fold(poollim=1000)
+            assert b.fold_driver == 2 and (b.fold_paths & 64), (extra, b.fold_driver, b.fold_paths)
+            assert _packed(b, n) == want, extra
+            assert [b.evals(k) for k in range(n)] == evals
+            for k in extra:
+                monkeypatch.delenv(k)
+    for k in (0, 9, 17):
+        s, r, x = raw[k]
+        exp = O.SQRNdbnseq(s, r, x, None, psets, poollim=1000)
+        exp = [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
+        _same_fold(res[k][0], exp, ("root lists", k))
