@@ -632,7 +632,13 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             // the jobs' root lists: AnnotateStems of every job's empty structure, once (one wave per job)
             const size_t rl = sq_pool_root_lds(pra.lds_n, pra.cell_entries);
             if (rl > 60 * 1024) sq_max_dynamic_lds((const void *)sq_pool_root_kernel, 160 * 1024);
-            hipLaunchKernelGGL(sq_pool_root_kernel, dim3(S0), dim3(64), rl, st, b->ctx, scan, pio, pra);
+            // (in launches of at most `chunk` jobs: the kernel stages a job's runs in its empty structure's region of the arena,
+            // and structures a chunk apart share a region)
+            for (int lo = 0; lo < S0; lo += chunk) {
+                pra.lo = lo;
+                hipLaunchKernelGGL(sq_pool_root_kernel, dim3(std::min(chunk, S0 - lo)), dim3(64), rl, st, b->ctx, scan, pio, pra);
+            }
+            pra.lo = 0;
             b->last_paths |= 64;
         }
         const size_t ext_lds = sq_extend_lds_bytes(pio.pt);          // the extend kernel's level scratch (dynamic LDS)

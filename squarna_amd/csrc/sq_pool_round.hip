@@ -532,7 +532,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_root_kernel(SqDevCtx c,
     extern __shared__ __attribute__((aligned(16))) char pr_dyn[];
     __shared__ SqCellTmp s_ctmp;
     const int lane = threadIdx.x;
-    const int sx = (int)blockIdx.x;                         // the job's record == the slot of its empty structure in generation 0
+    const int sx = ra.lo + (int)blockIdx.x;                 // the job's record == the slot of its empty structure in generation 0
     const int job = pio.structs[sx].job;
     const SqJob jb = c.jobs[job];
     const SqPsetDev *ps = c.psets + jb.pset;
@@ -562,7 +562,36 @@ extern "C" __global__ __launch_bounds__(64) void sq_pool_root_kernel(SqDevCtx c,
         __syncthreads();
     }
     SqRun *const root = reinterpret_cast<SqRun *>(a.cands + ra.root_off + (int64_t)sx * ra.root_units);
-    SqPrRootSink sink{stage, root, (uint32_t)(2 * ra.root_units), cenv, c, jb, ps->minbpscore, a.ctr, 0u, 0u};
+    // the runs first go, as the scan finds them, to the empty structure's own region of the arena (nobody needs it before round
+    // 0); from there into the root list ordered by descending bpscore (buckets of 0.5, as sq_rounds.hip orders a chain's list):
+    // a structure's round then meets the strong runs first, its best finalscore early, and the bound prunes the rest of its
+    // survivors (in scan order most of a 500-nt structure's 1,300 survivors went through ScoreStems)
+    SqRun *const tmp = reinterpret_cast<SqRun *>(a.cands + pio.structs[sx].cand_off);
+    const uint32_t cap = (uint32_t)min((long long)(2 * ra.root_units), (long long)pio.maxcap * 2);
+    SqPrRootSink sink{stage, tmp, cap, cenv, c, jb, ps->minbpscore, a.ctr, 0u, 0u};
     if (n >= 5) sq_scan6_groups(c, jb, FG, FG + fbh, fbh, E, 0, 1, lane, sink, SqBitsGlobal{c.bits + jb.bits_off, jb.bpitch});
-    if (lane == 0) a.cand_cnt[sx] = sink.cnt < sink.cap ? sink.cnt : sink.cap;
+    const uint32_t R = sink.cnt < cap ? sink.cnt : cap;
+    __threadfence_block();
+    __syncthreads();
+    uint32_t *const hist = reinterpret_cast<uint32_t *>(stage);          // [256] counts, then [256] fill pointers (the staging buffer is free)
+    for (int k = lane; k < 512; k += 64) hist[k] = 0;
+    __syncthreads();
+    auto bucket = [&](double bps) -> int { const double x = bps * 2.0; return 255 - (x >= 255.0 ? 255 : (x > 0.0 ? (int)x : 0)); };
+    for (uint32_t q = lane; q < R; q += 64) atomicAdd(&hist[bucket(tmp[q].bps)], 1u);
+    __syncthreads();
+    {
+        uint32_t h[4], tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { h[k] = hist[4 * lane + k]; tot += h[k]; }
+        const uint32_t incl = (uint32_t)sq_wave_scan_add_i32((int)tot);
+        uint32_t base = incl - tot;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { hist[256 + 4 * lane + k] = base; base += h[k]; }
+    }
+    __syncthreads();
+    for (uint32_t q = lane; q < R; q += 64) {
+        const SqRun r = tmp[q];
+        root[atomicAdd(&hist[256 + bucket(r.bps)], 1u)] = r;
+    }
+    if (lane == 0) a.cand_cnt[sx] = R;
 }
