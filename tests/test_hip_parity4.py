@@ -492,6 +492,13 @@ def test_pool_rounds_enqueued_ahead_equal_the_exact_grids(config, poollim, monke
         monkeypatch.delenv("SQ_POOL_AHEAD")
         b.fold(poollim=poollim)                                  # the default depth
         assert (b.fold_paths & 32) and _packed(b, n) == want
+        monkeypatch.setenv("SQ_POOL_CHUNK", "3000")              # a generation in three launches over the candidate arena
+        b.fold(poollim=poollim)
+        assert (b.fold_paths & 32) and _packed(b, n) == want
+        monkeypatch.setenv("SQ_POOL_CHUNK", "1000")              # too many launches per round: the exact grids, chunked
+        b.fold(poollim=poollim)
+        assert not (b.fold_paths & 32) and _packed(b, n) == want
+        monkeypatch.delenv("SQ_POOL_CHUNK")
         if peak > 2 * n + 8:                                     # the pools outgrow their slots mid-way: the host loop takes over
             monkeypatch.setenv("SQ_POOL_SLOTS", str(2 * n + 8))
             b.fold(poollim=poollim)
