@@ -68,6 +68,7 @@ __host__ __device__ inline SqPoolRoundLds sq_pool_round_lds(int lds_n, int str_c
 }
 
 extern "C" __global__ void sq_pool_round_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra);
+extern "C" __global__ void sq_pool_round_root_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra);
 extern "C" __global__ void sq_pool_root_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra);
 // dynamic LDS of sq_pool_root_kernel: mask codes + class indices, free-position words, cell table, staging buffer
 __host__ __device__ inline size_t sq_pool_root_lds(int lds_n, int cell_entries)

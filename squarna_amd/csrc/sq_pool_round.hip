@@ -114,7 +114,10 @@ struct SqPrSink {
 #ifndef SQ_PR_WAVES
 #define SQ_PR_WAVES 4              // waves per SIMD the register budget is set for (4: 128 VGPRs)
 #endif
-extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SQ_PR_WAVES, SQ_PR_WAVES))) void sq_pool_round_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra)
+// ROOT: AnnotateStems as a pass over the job's root list (SqPoolRoundArgs::root; a kernel of its own -- sq_pool_round_root_kernel --
+// so that the scanning form's code stays what it was: it is bound by vector-instruction issue)
+template <bool ROOT>
+__device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqScanArgs &a, const SqPoolIO &pio, const SqPoolRoundArgs &ra)
 {
     extern __shared__ __attribute__((aligned(16))) char pr_dyn[];
     __shared__ SqCellTmp s_ctmp;
@@ -252,7 +255,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
             base_u += __popcll(mu); base_s += __popcll(ms);
         }
         if (lane == 0) { U[n] = (int16_t)base_u; SU[n] = (int16_t)base_s; }
-        if (ra.root) {
+        if (ROOT) {
             // the root-list pass: one bit per position, set while it is unpaired (forward order; two zero words behind the last)
             const int nwb = ((n + 31) >> 5) + 2;
             for (int m2 = 0; 2 * m2 < nwb; m2++) {
@@ -261,7 +264,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
                 if (lane == 0) { FG[2 * m2] = (uint32_t)bf; FG[2 * m2 + 1] = (uint32_t)(bf >> 32); }
             }
         }
-        const int fbh = ra.root ? 0 : Lo.fbh;                // (free-position words: the scan's)
+        const int fbh = ROOT ? 0 : Lo.fbh;                   // (free-position words: the scan's)
         for (int m2 = 0; 2 * m2 < fbh; m2++) {
             const int pf = 64 * m2 + lane;
             const unsigned long long bf = __ballot(pf < n && E[pf] == 0);
@@ -301,7 +304,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
     sv.spill_cap = (uint32_t)(((size_t)jb.cand_cap * (sizeof(SqCand) - sizeof(SqKey))) / sizeof(SqOk));
     const double minbps = ps->minbpscore, minfin = ps->minfinscore;
     uint32_t ns = 0;
-    if (ra.root && n >= 5) {
+    if (ROOT && n >= 5) {
         // ---- AnnotateStems from the job's root list: choosing stems only ever masks rows and columns (:446-451), so the maximal
         // runs of this structure are the pieces its paired positions leave of the empty structure's runs (sq_rounds.hip keeps a
         // chain's list on the same rule).  A run whose rows and columns are all unpaired -- four reads of the prefix counts --
@@ -490,6 +493,15 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
     if (lane == 0) { pio.nchild[s] = nres; pio.finalflag[s] = 0; }
 }
 
+
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SQ_PR_WAVES, SQ_PR_WAVES))) void sq_pool_round_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra)
+{
+    sq_pool_round_body<false>(c, a, pio, ra);
+}
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SQ_PR_WAVES, SQ_PR_WAVES))) void sq_pool_round_root_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra)
+{
+    sq_pool_round_body<true>(c, a, pio, ra);
+}
 
 // The root lists: per job of the pools the runs of its EMPTY structure -- AnnotateStems of round 0 (bit-diagonal scan) -- with
 // their exact bpscores, the ones whose positive cell parts cannot reach :492 dropped (no piece of them ever passes, sq_cellrun.h).

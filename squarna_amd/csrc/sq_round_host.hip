@@ -229,7 +229,8 @@ void sq_launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, int64
     if (pool_round) {
         const SqPoolRoundLds lo = sq_pool_round_lds(pool_round->lds_n, pool_round->str_cap, pool_round->cell_entries, pool_round->surv_cap, pool_round->tmax);
         ProfScope ps(b, 3, scan_bytes);
-        hipLaunchKernelGGL(sq_pool_round_kernel, dim3(S), dim3(64), lo.total, st, b->ctx, scan, b->pool_io, *pool_round);
+        if (pool_round->root) hipLaunchKernelGGL(sq_pool_round_root_kernel, dim3(S), dim3(64), lo.total, st, b->ctx, scan, b->pool_io, *pool_round);
+        else hipLaunchKernelGGL(sq_pool_round_kernel, dim3(S), dim3(64), lo.total, st, b->ctx, scan, b->pool_io, *pool_round);
         return;
     }
     if (fuse) {
