@@ -106,6 +106,9 @@ __device__ __forceinline__ void sq_cellrun_cells4(const SqCellEnv &e, int i, int
 
 // bpscore of the run (i0 + t, j0 - t), t < L: sum(...) left to right from int 0 (SQRNdbnseq.py:416).  pos: the same sum over
 // the cells' positive parts -- no piece of the run can ever score more (fp addition is monotone)
+// (POS = false: the caller has no use for the positive parts -- the pools' round kernel sums runs of the CURRENT structure, whose
+// pieces it never meets again)
+template <bool POS = true>
 __device__ __forceinline__ double sq_cellrun_bps(const SqCellEnv &e, const SqDevCtx &c, const SqJob &jb, int i0, int j0, int L, double &pos)
 {
     double acc = 0.0, accp = 0.0;
@@ -119,7 +122,7 @@ __device__ __forceinline__ double sq_cellrun_bps(const SqCellEnv &e, const SqDev
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = t + k < L ? m[at + (int64_t)(t + k) * step] : 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { acc = acc + v[k]; accp = accp + (v[k] > 0.0 ? v[k] : 0.0); }
+            for (int k = 0; k < 4; k++) { acc = acc + v[k]; if (POS) accp = accp + (v[k] > 0.0 ? v[k] : 0.0); }
         }
         pos = accp;
         return acc;
@@ -138,7 +141,7 @@ __device__ __forceinline__ double sq_cellrun_bps(const SqCellEnv &e, const SqDev
         for (int k = 0; k < 4; k++) {
             const double x = t + k < L ? v[k] : 0.0;
             acc = acc + x;
-            accp = accp + (x > 0.0 ? x : 0.0);
+            if (POS) accp = accp + (x > 0.0 ? x : 0.0);
         }
     }
     pos = accp;

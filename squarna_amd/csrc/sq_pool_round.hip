@@ -91,7 +91,10 @@ struct SqPrSink {
         double bps = 0.0, pos = 0.0;
         if (have) {
             const int i = (int)(kl.x & 0xFFFFu), j = (int)(kl.x >> 16) - i;
-            bps = sq_cellrun_bps(cenv, c, jb, i, j, (int)kl.y, pos);
+            bps = sq_cellrun_bps<false>(cenv, c, jb, i, j, (int)kl.y, pos);
+#ifdef SQ_PR_DUP_BPS
+            { int i2 = i; asm volatile("" : "+v"(i2)); const double b2 = sq_cellrun_bps<false>(cenv, c, jb, i2, j, (int)kl.y, pos); if (b2 != bps) ctr->cand_ovf = 1; }
+#endif
         }
         const bool ok = have && bps >= minbps;                                            // :492
         const unsigned long long m2 = __ballot(ok);
@@ -111,6 +114,13 @@ struct SqPrSink {
     __device__ __forceinline__ void drain(int lane) { flush(lane); }
 };
 
+struct SqPrNullSink {       // (instrumentation: -DSQ_PR_DUP_SCAN runs the scan a second time into nothing, for instruction counts)
+    uint32_t n;
+    __device__ __forceinline__ uint32_t reserve(uint32_t total, int) { const uint32_t b0 = n; n += total; return b0; }
+    __device__ __forceinline__ void put(uint32_t at, uint32_t key, uint32_t len) { n ^= (at ^ key ^ len) & 0u; }
+    __device__ __forceinline__ void poll(int) {}
+    __device__ __forceinline__ void drain(int) {}
+};
 #ifndef SQ_PR_WAVES
 #define SQ_PR_WAVES 4              // waves per SIMD the register budget is set for (4: 128 VGPRs)
 #endif
@@ -227,10 +237,16 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     const int n = jb.n;
     SqStruct st;                                            // what the phases below read of a structure record
     st.job = job; st.slot = s; st.nstrand = nstrand; st.subopt = J->cursubopt; st.cand_off = (int64_t)(s % pio.chunk) * pio.maxcap; st.strand_off = 0;
+#ifdef SQ_PR_DUP_SETUP
+    { const SqCellEnv dup_ = sq_cell_setup(c, jb, ps, s_ctmp, l_ci, l_code, s_cell, lane, 64); (void)dup_; __syncthreads(); }
+#endif
     const SqCellEnv cenv = sq_cell_setup(c, jb, ps, s_ctmp, l_ci, l_code, s_cell, lane, 64);
     PRPROF(1);
 
     // ---- the structure's state (sq_state_build): partner array, mask codes, prefix counts, free-position words ----
+#ifdef SQ_PR_DUP_STATE
+    for (int dup_ = 0; dup_ < 2; dup_++)
+#endif
     {
         const uint8_t *e0 = c.e0c + jb.pos_off;
         for (int p = lane; p < n; p += 64) { P[p] = -1; E[p] = e0[p]; }
@@ -370,6 +386,10 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
             }
         }
     } else if (n >= 5) {                                                // :456-457 (shorter sequences have no diagonals)
+#ifdef SQ_PR_DUP_SCAN
+        { SqPrNullSink nul_{0u}; sq_scan6_groups(c, jb, FG, FG + Lo.fbh, Lo.fbh, E, 0, 1, lane, nul_, SqBitsGlobal{c.bits + jb.bits_off, jb.bpitch});
+          if (nul_.n == 0xFFFFFFFFu) a.ctr->cand_ovf = 1; }
+#endif
         SqPrSink sink{s_stage, over, (uint32_t)jb.cand_cap, cenv, c, jb, sv, ns, minbps, a.ctr, 0u, 0u};
         sq_scan6_groups(c, jb, FG, FG + Lo.fbh, Lo.fbh, E, 0, 1, lane, sink, SqBitsGlobal{c.bits + jb.bits_off, jb.bpitch});
         __threadfence_block();
@@ -388,6 +408,9 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
                             ps_lb, ps->bracketweight, ps->distcoef, ps->bw_integral, ps->sdf_len, c.sdftab + ps->sdf_off, ps->oftab, a.ctr};
     const double subopt = st.subopt;
     double best = 0.0; bool anybest = false;                           // (wave-uniform)
+#ifdef SQ_PR_DUP_SCORE
+    for (int dup_ = 0; dup_ < 2; dup_++) { best = 0.0; anybest = false;
+#endif
     for (uint32_t g = 0; g < ns; g += 64) {
         const uint32_t idx = g + lane;
         const bool have = idx < ns;
@@ -408,6 +431,9 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
         const double wb = sq_wave_max_f64(fin);
         if (wb > -INFINITY && (!anybest || wb > best)) { anybest = true; best = wb; }
     }
+#ifdef SQ_PR_DUP_SCORE
+    __syncthreads(); }
+#endif
     __threadfence_block();
     __syncthreads();
     PRPROF(4);
@@ -443,7 +469,11 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     double *const c_fin = reinterpret_cast<double *>(pr_dyn);
     uint32_t *const c_key = reinterpret_cast<uint32_t *>(c_fin + Lo.choose_cap);
     uint16_t *const c_q = reinterpret_cast<uint16_t *>(c_key + Lo.choose_cap), *const c_ord = c_q + Lo.choose_cap;
-    int nin = 0;
+    int nin = 0, nres = 0;
+    bool over_c = false;
+#ifdef SQ_PR_DUP_CHOOSE
+    for (int dup_ = 0; dup_ < 2; dup_++) { nin = 0; nres = 0; over_c = false; __syncthreads();
+#endif
     for (uint32_t g = 0; g < ns; g += 64) {
         const uint32_t q = g + lane;
         const double f = q < ns ? sv.get_fin(q) : -INFINITY;
@@ -469,8 +499,6 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     }
     __syncthreads();
     // the conflict filter (:779-789): a candidate joins when it shares a base with every stem taken so far
-    int nres = 0;
-    bool over_c = false;
     for (int t = 0; t < nin; t++) {
         const int x = c_ord[t];
         uint32_t key; int cl; double bps;
@@ -486,6 +514,9 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
         nres++;
         __syncthreads();
     }
+#ifdef SQ_PR_DUP_CHOOSE
+    }
+#endif
     PRPROF(5);
     PRPROF_OUT(ns, nin);
     if (over_c) { if (lane == 0) pio.hdr->ovf = 1; nres = 0; }
