@@ -19,6 +19,7 @@ struct SqCellEnv {
     int cstride;
     bool cell_tab;            // the table holds the final cell value (default reactivities, or reactivity levels in the table)
     int KR;
+    uint32_t zero4;           // four bytes of a combined index of the class of letters that pair with nothing: its cells are 0.0
 };
 
 // All threads of the block: class indices l_ci[n], letter codes l_code[n] (may be nullptr) and the table s_cell (room for the
@@ -69,6 +70,7 @@ __device__ __forceinline__ SqCellEnv sq_cell_setup(const SqDevCtx &c, const SqJo
     __syncthreads();
     SqCellEnv e;
     e.ci = l_ci; e.cell = s_cell; e.cstride = cstride; e.cell_tab = jb.default_reacts || react_tab; e.KR = KR;
+    e.zero4 = (uint32_t)((K - 1) * R) * 0x01010101u;
     return e;
 }
 
@@ -96,9 +98,10 @@ __device__ __forceinline__ void sq_cellrun_cells4(const SqCellEnv &e, int i, int
     const uint32_t a0 = ciw[i >> 2], a1 = ciw[(i >> 2) + 1], b0 = ciw[q >> 2], b1 = ciw[(q >> 2) + 1];
     uint32_t xi = __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)(i & 3));   // bytes i .. i + 3
     uint32_t xj = __builtin_amdgcn_alignbyte(b1, b0, (uint32_t)(q & 3));   // bytes j - 3 .. j
-    if (nv < 4) {                                                           // cells past the run's end: index 0, never added
-        xi &= (1u << (8 * nv)) - 1u;
-        xj &= ~((1u << (8 * (4 - nv))) - 1u);
+    if (nv < 4) {                                                           // cells past the run's end: the class without pairs -- they read 0.0
+        const uint32_t ki = (1u << (8 * nv)) - 1u, kj = ~((1u << (8 * (4 - nv))) - 1u);
+        xi = (xi & ki) | (e.zero4 & ~ki);
+        xj = (xj & kj) | (e.zero4 & ~kj);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) v[k] = e.cell[((xi >> (8 * k)) & 255u) * e.cstride + ((xj >> (8 * (3 - k))) & 255u)];
@@ -129,13 +132,18 @@ __device__ __forceinline__ double sq_cellrun_bps(const SqCellEnv &e, const SqDev
     }
     for (int t = 0; t < L; t += 4) {
         double v[4];
-        if (e.cell_tab && j0 - t >= 3) sq_cellrun_cells4(e, i0 + t, j0 - t, min(4, L - t), v);
-        else {
+        if (e.cell_tab && j0 - t >= 3) {
+            // (the cells past the run's end come out of the table as +0.0 -- the class of letters without pairs --: adding them
+            // leaves the sums what they are, no select per cell)
+            sq_cellrun_cells4(e, i0 + t, j0 - t, min(4, L - t), v);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int tt = t + k < L ? t + k : L - 1;
-                v[k] = sq_cellrun_exact(e, c, jb, i0 + tt, j0 - tt);
-            }
+            for (int k = 0; k < 4; k++) { acc = acc + v[k]; if (POS) accp = accp + (v[k] > 0.0 ? v[k] : 0.0); }
+            continue;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int tt = t + k < L ? t + k : L - 1;
+            v[k] = sq_cellrun_exact(e, c, jb, i0 + tt, j0 - tt);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
