@@ -802,14 +802,16 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
     // ending at j -- two aligned 32-bit LDS reads and a byte align each instead of eight byte gathers (the gathers at
     // data-dependent addresses are what the kernel's LDS bank conflicts come from, and its first phase is bound by them).
     const uint32_t *l_ciw = reinterpret_cast<const uint32_t *>(l_ci);
+    const uint32_t zero4 = (uint32_t)((K - 1) * R) * 0x01010101u;      // (its cells are 0.0: adding them leaves a sum what it is)
     auto cells4 = [&](int i, int j, int nv, double (&v)[4]) {
         const int q = j - 3;                                        // lowest j position of the window (>= 0 here)
         const uint32_t a0 = l_ciw[i >> 2], a1 = l_ciw[(i >> 2) + 1], b0 = l_ciw[q >> 2], b1 = l_ciw[(q >> 2) + 1];
         uint32_t xi = __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)(i & 3));   // bytes i .. i + 3
         uint32_t xj = __builtin_amdgcn_alignbyte(b1, b0, (uint32_t)(q & 3));   // bytes j - 3 .. j
-        if (nv < 4) {                                               // cells past the stem's end: index 0, never added
-            xi &= (1u << (8 * nv)) - 1u;
-            xj &= ~((1u << (8 * (4 - nv))) - 1u);
+        if (nv < 4) {                                               // cells past the stem's end: the class without pairs -- they read +0.0
+            const uint32_t ki = (1u << (8 * nv)) - 1u, kj = ~((1u << (8 * (4 - nv))) - 1u);
+            xi = (xi & ki) | (zero4 & ~ki);
+            xj = (xj & kj) | (zero4 & ~kj);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) v[k] = s_cell[((xi >> (8 * k)) & 255u) * cstride + ((xj >> (8 * (3 - k))) & 255u)];
@@ -858,13 +860,16 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
                 double acc = 0.0;
                 for (int t = 0; t < L; t += 4) {
                     double v[4];
-                    if (cell_tab && j0 - t >= 3) cells4(i0 + t, j0 - t, min(4, L - t), v);
-                    else {
+                    if (cell_tab && j0 - t >= 3) {
+                        cells4(i0 + t, j0 - t, min(4, L - t), v);
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int tt = t + k < L ? t + k : L - 1;
-                            v[k] = cell_exact(i0 + tt, j0 - tt);
-                        }
+                        for (int k = 0; k < 4; k++) acc = acc + v[k];           // (cells past the end are +0.0)
+                        continue;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int tt = t + k < L ? t + k : L - 1;
+                        v[k] = cell_exact(i0 + tt, j0 - tt);
                     }
 #pragma unroll
                     for (int k = 0; k < 4; k++) acc = acc + (t + k < L ? v[k] : 0.0);
