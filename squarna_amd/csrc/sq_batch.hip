@@ -374,6 +374,15 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
             for (int q = 0; q < 32; q++) if (ps.inbps[a * 32 + q]) { x.lmask |= 1u << a; break; }
         for (int a = 0; a < 32; a++)
             for (int q = 0; q < 29; q++) if (ps.inbps[a * 32 + q]) x.pmask[a] |= 1u << q;
+        {
+            int letters[32], K = 0;
+            for (int a = 0; a < 32; a++) if ((x.lmask >> a) & 1u) letters[K++] = a;
+            K += 1;                                                     // (the class of the letters that pair with nothing)
+            const int cstride = K | 1;
+            for (int ci = 0; ci < K; ci++)
+                for (int cj = 0; cj < K; cj++)
+                    x.celltab[ci * cstride + cj] = (ci < K - 1 && cj < K - 1) ? x.w[letters[ci] * 32 + letters[cj]] : 0.0;
+        }
         x.minlen = ps.minlen; x.minbpscore = ps.minbpscore;
         x.minfinscore = ps.minbpscore * ps.minfinscorefactor;          // SQRNdbnseq.py:1073
         x.bracketweight = ps.bracketweight; x.distcoef = ps.distcoef;

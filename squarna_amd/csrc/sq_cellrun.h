@@ -46,6 +46,10 @@ __device__ __forceinline__ SqCellEnv sq_cell_setup(const SqDevCtx &c, const SqJo
         if (l_code) l_code[p] = code;
         l_ci[p] = (uint8_t)(react_tab ? cl * R + c.ridx[jb.pos_off + p] : cl);
     }
+    if (!react_tab) {
+        // (no reactivity factor in the table: it is the paramset's own, built by the host -- SqPsetDev::celltab, same layout)
+        for (int e = tid; e < K * cstride; e += nthr) s_cell[e] = ps->celltab[e];
+    } else
     for (int e = tid; e < KR * KR; e += nthr) {
         const int ci = e / KR, cj = e - ci * KR;
         const int ca = ci / R, cb = cj / R;

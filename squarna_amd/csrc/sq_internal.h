@@ -57,6 +57,11 @@ struct SqPsetDev {
     // for bpscore >= 0, with ub_of = max orderfactor, ub_lf = max loopfactor and sdf <= 1 (distcoef >= 0); ub_lf = +inf
     // switches the bound off (paramsets where a factor has no such maximum)
     double ub_of, ub_lf;
+    // The cell table of the scoring kernels (sq_cellrun.h) for jobs without reactivity factors: K x (K | 1) doubles, K = the
+    // paramset's letter classes (the pairing letters in code order + one class for all others); cell (a, b) = the pair weight of
+    // the classes' letters, 0.0 for the class without pairs.  Built by the host once: every block of those kernels used to
+    // derive it from w[] anew (6 % of the pool round kernel's vector instructions)
+    double celltab[32 * 33];
 };
 
 // One strand (half of a selected stem) of a partial structure, sorted by start.

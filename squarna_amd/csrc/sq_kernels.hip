@@ -746,6 +746,10 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
             const int cl = s_cls[c.codes[jb.pos_off + p] & 31];
             l_ci[p] = (uint8_t)(react_tab ? cl * R + c.ridx[jb.pos_off + p] : cl);
         }
+        if (!react_tab) {
+            // (no reactivity factor in the table: it is the paramset's own, built by the host -- SqPsetDev::celltab, same layout)
+            for (int e = tid; e < K * cstride; e += nthr) s_cell[e] = ps->celltab[e];
+        } else
         for (int e = tid; e < KR * KR; e += nthr) {
             const int ci = e / KR, cj = e - ci * KR;
             const int ca = ci / R, cb = cj / R;
