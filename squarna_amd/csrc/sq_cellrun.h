@@ -24,13 +24,31 @@ struct SqCellEnv {
 
 // All threads of the block: class indices l_ci[n], letter codes l_code[n] (may be nullptr) and the table s_cell (room for the
 // batch's cell_entries doubles).  Contains block barriers; the arrays are ready when it returns.
+// (PRE, one wave, n <= 256: the letter mask, the wave's letter codes and -- for jobs without reactivity factors whose table has at
+// most 64 entries -- its cell of the table were asked for by the caller as soon as it knew the job: sq_cell_preload)
+struct SqCellPre { uint32_t lmask; uint32_t code4; double cell; bool tab; };
+__device__ __forceinline__ SqCellPre sq_cell_preload(const SqDevCtx &c, const SqPsetDev *ps, int64_t pos_off, int n, bool plain, int lane)
+{
+    SqCellPre P;
+    uint32_t c4 = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) c4 |= (uint32_t)c.codes[pos_off + min(lane + 64 * t, n - 1)] << (8 * t);   // (no branch: the four go out together)
+    P.code4 = c4;
+    P.lmask = sq_kload(&ps->lmask);
+    const int K = __popc(P.lmask) + 1;
+    P.tab = plain && K * (K | 1) <= 64;
+    P.cell = ps->celltab[lane];                       // (32 x 33 entries: any lane's is there; used when P.tab)
+    return P;
+}
+
+template <bool PRE = false>
 __device__ __forceinline__ SqCellEnv sq_cell_setup(const SqDevCtx &c, const SqJob &jb, const SqPsetDev *ps, SqCellTmp &T, uint8_t *l_ci,
-                                                   uint8_t *l_code, double *s_cell, int tid, int nthr)
+                                                   uint8_t *l_code, double *s_cell, int tid, int nthr, const SqCellPre *pre = nullptr)
 {
     const int n = jb.n;
     // (the letter mask comes with the paramset -- until late round 4 every block derived it from the 1,024 bytes of the
     // pairing table first: one more trip to L2 and two barriers per structure and round of the pools' round kernel)
-    const uint32_t lmask = ps->lmask;
+    const uint32_t lmask = PRE ? pre->lmask : ps->lmask;
     const int K = __popc(lmask) + 1;
     const bool react_tab = !jb.default_reacts && jb.react_levels > 0 && K * jb.react_levels <= 32;   // (the host sizes the table by the same rule)
     const int R = react_tab ? jb.react_levels : 1;
@@ -40,7 +58,7 @@ __device__ __forceinline__ SqCellEnv sq_cell_setup(const SqDevCtx &c, const SqJo
         __syncthreads();
     }
     for (int p = tid; p < n; p += nthr) {
-        const uint8_t code = c.codes[jb.pos_off + p];
+        const uint8_t code = PRE ? (uint8_t)(pre->code4 >> (8 * (p >> 6))) : c.codes[jb.pos_off + p];
         const uint32_t cb = code & 31u;
         const int cl = (lmask >> cb) & 1u ? __popc(lmask & ((1u << cb) - 1u)) : K - 1;
         if (l_code) l_code[p] = code;
@@ -48,7 +66,8 @@ __device__ __forceinline__ SqCellEnv sq_cell_setup(const SqDevCtx &c, const SqJo
     }
     if (!react_tab) {
         // (no reactivity factor in the table: it is the paramset's own, built by the host -- SqPsetDev::celltab, same layout)
-        for (int e = tid; e < K * cstride; e += nthr) s_cell[e] = ps->celltab[e];
+        if (PRE && pre->tab) { if (tid < K * cstride) s_cell[tid] = pre->cell; }
+        else for (int e = tid; e < K * cstride; e += nthr) s_cell[e] = ps->celltab[e];
     } else
     for (int e = tid; e < KR * KR; e += nthr) {
         const int ci = e / KR, cj = e - ci * KR;

@@ -95,7 +95,8 @@ struct SqPoolIO {
     int32_t *child_off;           // [smax + 1] exclusive scan of nchild
     uint8_t *finalflag;           // [smax] 1: the structure is final and still has to be logged
     SqPoolPick *chosen;           // [2][smax][cmax]: the launched kernels use the first half; sq_pool_round_kernel the half of its generation
-    int32_t *parent_of;           // [smax] next generation: parent (position in this round's list) of every child (sq_pool_scan_kernel)
+    int32_t *parent_of;           // [smax] next generation: parent (position in this round's list, bits 0-25) of every child and
+                                  // the index of its pick among the parent's chosen stems (bits 26-31)  (sq_pool_scan_kernel)
     SqPoolHdr *hdr;
     // the batch's device log of final structures ([0] entries, [1] stems, [2] overflow in fin_ctr): read by the device
     // tail (sq_tail_dev.hip); the host-driven tail copies it out
@@ -161,6 +162,20 @@ __device__ __forceinline__ int sq_wave_min_i32(int v)
 }
 
 // inclusive prefix sum over the lanes (the gfx9 scan sequence of DPP row shifts and row broadcasts: VALU only); lane 63 holds the total
+// A record every lane reads at the same address, through the scalar cache (s_load into SGPRs: one request per wave, batched
+// dwordx4/x8/x16) wherever it stands in the kernel: the compiler only does that by itself for loads it can prove no store of
+// the kernel precedes.  For data the kernel itself never writes.
+template <class T> __device__ __forceinline__ T sq_kload(const T *p)
+{
+    static_assert(sizeof(T) % 4 == 0, "sq_kload: whole words");
+    typedef const __attribute__((address_space(4))) uint32_t *kptr;
+    const kptr q = (kptr)p;
+    union { T v; uint32_t w[sizeof(T) / 4]; } u;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) u.w[i] = q[i];
+    return u.v;
+}
+
 __device__ __forceinline__ int sq_wave_scan_add_i32(int v)
 {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);

@@ -145,16 +145,36 @@ __device__ __forceinline__ void sq_stem_levels_join(SqExtendLds &L, int T, int n
 // The sorted strand list of a child: the parent's nstrand strands psrc[] (+ the stem index of each, pssrc[]) with the two
 // strands of the new stem k = (i0, j0, len) inserted, levels from L.lvl when stems cross (else level 1 everywhere).
 // cdst[] / csdst[] take nstrand + 2 entries and must NOT be the parent's arrays.
+// (PRE: the parent's first stems and strands were asked for before the wave had anything else to do with them -- sq_extend_preload;
+// the kernels that find their parent through a chain of dependent loads issue everything the chain's end names at once)
+struct SqExtendPre { SqChainStem st0; SqStrand x[2]; int16_t sx[2]; };
+__device__ __forceinline__ SqExtendPre sq_extend_preload(const SqChainStem *pst, int k, const SqStrand *psrc, const int16_t *pssrc, int nstrand, int lane)
+{
+    SqExtendPre P;
+    // (no branches: clamped indices, so that the loads go out together -- entries past the lists' ends are never used)
+    P.st0 = pst[min(lane, max(k - 1, 0))];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int q = min(64 * t + lane, max(nstrand - 1, 0));
+        P.x[t] = psrc[q];
+        P.sx[t] = pssrc[q];
+    }
+    return P;
+}
+
+template <bool PRE = false>
 __device__ __forceinline__ void sq_extend_strands(SqExtendLds &L, bool anycross, int k, const SqStrand *psrc, const int16_t *pssrc, int nstrand,
-                                                  int i0, int j0, int len, SqStrand *cdst, int16_t *csdst, int lane)
+                                                  int i0, int j0, int len, SqStrand *cdst, int16_t *csdst, int lane, const SqExtendPre *pre = nullptr)
 {
     const int ls = i0, rs = j0 - len + 1;                               // starts of the 5' and the 3' strand (ls < rs)
     int below_l = 0, below_r = 0;
+#pragma unroll 2
     for (int q0 = 0; q0 < nstrand; q0 += 64) {
         const int q = q0 + lane;
         const bool valid = q < nstrand;
-        SqStrand x = valid ? psrc[q] : SqStrand{0, 0, 0, 0, 0};
-        const int sx = valid ? pssrc[q] : 0;
+        SqStrand x; int sx;
+        if (PRE && q0 < 128) { x = pre->x[q0 >> 6]; sx = pre->sx[q0 >> 6]; }
+        else { x = valid ? psrc[q] : SqStrand{0, 0, 0, 0, 0}; sx = valid ? pssrc[q] : 0; }
         const bool bl = valid && x.start < ls, br = valid && x.start < rs;
         if (valid) {
             if (anycross) x.level = L.lvl[sx];
@@ -174,14 +194,15 @@ __device__ __forceinline__ void sq_extend_strands(SqExtendLds &L, bool anycross,
 // parent: k stems pst[] (with their crossing weights), nstrand sorted strands psrc[] + the stem index of each (pssrc[]).
 // child: cst[0..k] (may be the parent's array: the weights are updated in place), cdst[] / csdst[] (nstrand + 2 entries;
 // must NOT be the parent's).  (i0, j0, len): the new stem.  Returns whether some pair of the child's stems crosses.
+template <bool PRE = false>
 __device__ __forceinline__ bool sq_extend_structure(SqExtendLds &L, const SqScanArgs &a, const SqChainStem *pst, int k, bool parent_anycross,
                                                     const SqStrand *psrc, const int16_t *pssrc, int nstrand, int i0, int j0, int len,
-                                                    SqChainStem *cst, SqStrand *cdst, int16_t *csdst, int lane)
+                                                    SqChainStem *cst, SqStrand *cdst, int16_t *csdst, int lane, const SqExtendPre *pre = nullptr)
 {
     // ---- crossing weights (:121-124), kept per stem between rounds ----
     int mycc = 0, mycross = 0;
     for (int q = lane; q < k; q += 64) {
-        const SqChainStem x = pst[q];
+        const SqChainStem x = PRE && q < 64 ? pre->st0 : pst[q];
         int cc = x.cc;
         if (sq_chain_cross(x.i, x.j, i0, j0)) { cc += len; mycc += x.len; mycross = 1; }
         cst[q] = SqChainStem{x.i, x.j, x.len, cc};
@@ -198,6 +219,6 @@ __device__ __forceinline__ bool sq_extend_structure(SqExtendLds &L, const SqScan
     // ---- levels (only when stems cross; otherwise every strand stays on level 1) ----
     if (anycross) sq_stem_levels_wave(L, T, lane, &a.ctr->level_ovf);
     // ---- strands: the sorted list with the two new strands ----
-    sq_extend_strands(L, anycross, k, psrc, pssrc, nstrand, i0, j0, len, cdst, csdst, lane);
+    sq_extend_strands<PRE>(L, anycross, k, psrc, pssrc, nstrand, i0, j0, len, cdst, csdst, lane, pre);
     return anycross;
 }

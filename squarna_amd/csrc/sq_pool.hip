@@ -180,13 +180,15 @@ extern "C" __global__ __launch_bounds__(1024) void sq_pool_scan_kernel(SqPoolIO 
         const int nc = pio.nchild[q];
         pio.child_off[q] = run;
         // (sq_pool_round_kernel: a child builds itself at the start of its round, from its parent and its pick)
-        for (int k = 0; k < nc; k++) if (run + k < pio.slots) pio.parent_of[run + k] = q;
+        // (parent in bits 0-25, the pick's index in ChooseStems' list in bits 26-31 -- cmax is 64 --: one dependent load less at
+        // the child's entry than the parent's child_off would take)
+        for (int k = 0; k < nc; k++) if (run + k < pio.slots) pio.parent_of[run + k] = (int32_t)((uint32_t)q | ((uint32_t)k << 26));
         run += nc;
     }
     const int total = s_part[nthr - 1];
     if (tid == 0) pio.child_off[S] = total;
     __syncthreads();
-    const bool fits = total <= pio.slots;
+    const bool fits = total <= pio.slots && S <= (1 << 26);
     for (int j = tid; j < pio.njobs; j += nthr) {
         SqPoolJob J = pio.jobs[j];
         if (J.count == 0) continue;                          // the job's pool ran empty in an earlier round

@@ -136,21 +136,31 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     const int s = ra.lo + (int)blockIdx.x;                  // the structure's position in the round's list == its slot
     // (rounds enqueued ahead of the host are launched with every slot as their grid: the generation's size is the scan kernel's
     // word -- zero once the pools have run empty or a capacity was exceeded)
-    if (ra.ahead && s >= (int)pio.hdr->S[ra.parity]) return;
+    // (the header and the child's word are read together: the first link of the entry's chain of dependent loads)
+    const SqPoolHdr hdr0 = sq_kload(pio.hdr);
+    const uint32_t pw0 = (uint32_t)sq_kload(pio.parent_of + s);
+    asm volatile("" :: "s"(pw0));                           // (asked for HERE, not below the branch)
+    if (ra.ahead && s >= (int)(ra.parity ? hdr0.S[1] : hdr0.S[0])) return;
 #ifdef SQ_PR_PROF
     long long _pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
 #define PRPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)
 #ifndef SQ_PR_PROF_SLOW
 #define SQ_PR_PROF_SLOW 1000000      /* us: structures slower than this are printed too */
 #endif
-#define PRPROF_OUT(ns_, nin_) do { if (lane == 0 && ((s % 997) == 0 || (wall_clock64() - _t00) > 100ll * SQ_PR_PROF_SLOW)) printf("pool round s=%d n=%d nstrand=%d ns=%u nin=%d | us: extend %.1f setup %.1f state %.1f scan %.1f score %.1f choose %.1f total %.1f\n", \
-        s, n, nstrand, (unsigned)(ns_), (int)(nin_), _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, (wall_clock64() - _t00) * 0.01); } while (0)
+#define PRPROF_OUT(ns_, nin_) do { if (lane == 0 && ((s % 997) == 0 || (wall_clock64() - _t00) > 100ll * SQ_PR_PROF_SLOW)) printf("pool round s=%d n=%d nstrand=%d ns=%u nin=%d | us: entry %.1f ext %.1f extend %.1f setup %.1f state %.1f scan %.1f score %.1f choose %.1f total %.1f\n", \
+        s, n, nstrand, (unsigned)(ns_), (int)(nin_), _pt[6] * 0.01, _pt[7] * 0.01, _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, (wall_clock64() - _t00) * 0.01); } while (0)
 #else
 #define PRPROF(k) do {} while (0)
 #define PRPROF_OUT(ns_, nin_) do {} while (0)
 #endif
     const size_t cur = (size_t)ra.parity * pio.smax, prv = (size_t)(ra.parity ^ 1) * pio.smax;
-    const uint32_t round = pio.hdr->round;                  // (sq_pool_scan_kernel advances it behind this kernel)
+    const uint32_t round = hdr0.round;                      // (sq_pool_scan_kernel advances it behind this kernel)
+    // the second link: the parent's records and the pick (round 0: the structure's own records), asked for before the LDS is carved
+    const int p = round ? (int)(pw0 & 0x3FFFFFFu) : 0, k = round ? (int)(pw0 >> 26) : 0;   // (sq_pool_scan_kernel: parent | pick index << 26)
+    const size_t prow = round ? prv + (size_t)p : cur + (size_t)s;
+    const SqStruct pst = sq_kload(pio.structs + prow);
+    const SqChain prec = sq_kload(pio.recs + prow);
+    const SqPoolPick pk = sq_kload(pio.chosen + (round ? prow * pio.cmax + k : 0));
     const SqPoolRoundLds Lo = sq_pool_round_lds(ra.lds_n, ra.str_cap, ra.cell_entries, ra.surv_cap, ra.tmax);
     int16_t *const P = reinterpret_cast<int16_t *>(pr_dyn + Lo.off_P);
     int16_t *const U = reinterpret_cast<int16_t *>(pr_dyn + Lo.off_U);
@@ -188,30 +198,51 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
         for (int q = lane; q < nst; q += 64) pio.fin_stems[so + q] = SqPoolStem{XL.i[q], XL.j[q], XL.len[q], 0};
         if (lane == 0) pio.fin[idx] = SqPoolFin{job, SQ_FIN_KIND_G0 + round_kind, s, nst, so, SQ_FIN_SRC_LOG};
     };
+    // (the loads below are ordered by what they depend on, not by who uses them: the kernel's entry is a chain of dependent
+    // trips to L2 -- header, parent, the parent's records and pick, its stems and strands, the job -- in a wave that lives ~30 us;
+    // everything a link of the chain names is asked for as soon as that link has arrived)
+    static_assert(SQ_PR_MAXN <= 256, "the entry asks for a lane's letters and masks as four bytes");
+    SqPoolJob *J; double cursub; int cursize; SqCellPre cpre; uint32_t e4 = 0;
     if (round == 0) {                                       // the empty structure of a job (sq_pool_init_kernel)
-        const SqStruct st0 = pio.structs[cur + s];
-        job = st0.job; nstems = 0; nstrand = 0; maxstems = pio.recs[cur + s].maxstems;
+        job = pst.job; nstems = 0; nstrand = 0; maxstems = prec.maxstems;
+        J = pio.jobs + sq_kload(pio.jobrec_of + job); cursub = sq_kload(&J->cursubopt); cursize = sq_kload(&J->cursize);
+        if (!ROOT) {                                         // (n <= SQ_PR_MAXN = 4 x 64: a lane's letters and masks are four bytes each)
+            const SqJob *const jp = c.jobs + job;
+            const int jn = sq_kload(&jp->n); const int64_t jpos = sq_kload(&jp->pos_off);
+            cpre = sq_cell_preload(c, c.psets + sq_kload(&jp->pset), jpos, jn, sq_kload(&jp->default_reacts) || sq_kload(&jp->react_levels) == 0, lane);
+#pragma unroll
+            for (int t = 0; t < 4; t++) e4 |= (uint32_t)c.e0c[jpos + min(lane + 64 * t, jn - 1)] << (8 * t);   // (no branch: the four go out together)
+        }
     } else {
         // ---- the child builds itself: parent p (previous generation) + its k-th pick ----
-        const int p = pio.parent_of[s];
-        const SqStruct pst = pio.structs[prv + p];
-        const SqChain prec = pio.recs[prv + p];
-        const int k = s - pio.child_off[p];                 // (child_off: the previous round's scan; this round's comes behind this kernel)
-        const SqPoolPick pk = pio.chosen[(prv + (size_t)p) * pio.cmax + k];
         job = pst.job; maxstems = prec.maxstems;
         if (prec.nstems >= pio.pt) { if (lane == 0) { pio.hdr->ovf = 1; pio.nchild[s] = 0; } return; }
+        const SqExtendPre pre = sq_extend_preload(pio.stems + prec.toff, prec.nstems, pio.strands + pst.strand_off, pio.sidx + pst.strand_off,
+                                                  pst.nstrand, lane);
+        J = pio.jobs + sq_kload(pio.jobrec_of + job); cursub = sq_kload(&J->cursubopt); cursize = sq_kload(&J->cursize);
+        if (!ROOT) {                                         // (n <= SQ_PR_MAXN = 4 x 64: a lane's letters and masks are four bytes each)
+            const SqJob *const jp = c.jobs + job;
+            const int jn = sq_kload(&jp->n); const int64_t jpos = sq_kload(&jp->pos_off);
+            cpre = sq_cell_preload(c, c.psets + sq_kload(&jp->pset), jpos, jn, sq_kload(&jp->default_reacts) || sq_kload(&jp->react_levels) == 0, lane);
+#pragma unroll
+            for (int t = 0; t < 4; t++) e4 |= (uint32_t)c.e0c[jpos + min(lane + 64 * t, jn - 1)] << (8 * t);   // (no branch: the four go out together)
+        }
         const int i0 = (int)(pk.key & 0xFFFFu), j0 = (int)(pk.key >> 16) - i0, len = (int)pk.len;
         const int toff = (int)((cur + (size_t)s) * (size_t)pio.pt);
         SqChainStem *const cst = pio.stems + toff;
-        const bool anyc = sq_extend_structure(XL, a, pio.stems + prec.toff, prec.nstems, prec.anycross != 0, pio.strands + pst.strand_off,
-                                              pio.sidx + pst.strand_off, pst.nstrand, i0, j0, len, cst, s_str, s_sidx, lane);
+#ifdef SQ_PR_PROF
+        { int i0_ = i0 + len + (int)maxstems; asm volatile("" :: "v"(i0_)); } PRPROF(6);
+#endif
+        const bool anyc = sq_extend_structure<true>(XL, a, pio.stems + prec.toff, prec.nstems, prec.anycross != 0, pio.strands + pst.strand_off,
+                                                    pio.sidx + pst.strand_off, pst.nstrand, i0, j0, len, cst, s_str, s_sidx, lane, &pre);
         __syncthreads();
+        PRPROF(7);
         nstems = prec.nstems + 1; nstrand = pst.nstrand + 2;
         const bool full = (double)nstems == maxstems;
         if (lane == 0) {
             SqStruct cs;
             cs.job = job; cs.strand_off = 2 * toff; cs.nstrand = full ? -1 : nstrand; cs.slot = s;
-            cs.subopt = pio.jobs[pio.jobrec_of[job]].cursubopt;
+            cs.subopt = cursub;
             cs.cand_off = (int64_t)(s % pio.chunk) * pio.maxcap;
             pio.structs[cur + s] = cs;
             SqChain cr;
@@ -230,17 +261,16 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
         __syncthreads();
     }
     PRPROF(0);
-    SqPoolJob *J = pio.jobs + pio.jobrec_of[job];
     if (lane == 0) atomicAdd((unsigned long long *)&J->evals, 1ull);
     const SqJob jb = c.jobs[job];
     const SqPsetDev *ps = c.psets + jb.pset;
     const int n = jb.n;
     SqStruct st;                                            // what the phases below read of a structure record
-    st.job = job; st.slot = s; st.nstrand = nstrand; st.subopt = J->cursubopt; st.cand_off = (int64_t)(s % pio.chunk) * pio.maxcap; st.strand_off = 0;
+    st.job = job; st.slot = s; st.nstrand = nstrand; st.subopt = cursub; st.cand_off = (int64_t)(s % pio.chunk) * pio.maxcap; st.strand_off = 0;
 #ifdef SQ_PR_DUP_SETUP
-    { const SqCellEnv dup_ = sq_cell_setup(c, jb, ps, s_ctmp, l_ci, l_code, s_cell, lane, 64); (void)dup_; __syncthreads(); }
+    { const SqCellEnv dup_ = sq_cell_setup<!ROOT>(c, jb, ps, s_ctmp, l_ci, l_code, s_cell, lane, 64, &cpre); (void)dup_; __syncthreads(); }
 #endif
-    const SqCellEnv cenv = sq_cell_setup(c, jb, ps, s_ctmp, l_ci, l_code, s_cell, lane, 64);
+    const SqCellEnv cenv = sq_cell_setup<!ROOT>(c, jb, ps, s_ctmp, l_ci, l_code, s_cell, lane, 64, &cpre);
     PRPROF(1);
 
     // ---- the structure's state (sq_state_build): partner array, mask codes, prefix counts, free-position words ----
@@ -248,8 +278,7 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     for (int dup_ = 0; dup_ < 2; dup_++)
 #endif
     {
-        const uint8_t *e0 = c.e0c + jb.pos_off;
-        for (int p = lane; p < n; p += 64) { P[p] = -1; E[p] = e0[p]; }
+        for (int p = lane; p < n; p += 64) { P[p] = -1; E[p] = ROOT ? c.e0c[jb.pos_off + p] : (uint8_t)(e4 >> (8 * (p >> 6))); }   // (c.e0c: asked for at the entry)
         __syncthreads();
         for (int k = lane; k < st.nstrand; k += 64) {
             const SqStrand x = s_str[k];
@@ -445,7 +474,7 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
 
     // ---- ChooseStems (sq_pool_choose_kernel's steps) ----
     SqPoolPick *out = pio.chosen + (cur + (size_t)s) * pio.cmax;
-    const bool one = J->cursize >= pio.poollim;             // :1147 stopper
+    const bool one = cursize >= pio.poollim;             // :1147 stopper
     if (one) {
         // only ChooseStems' first element is used: the highest finalscore, the smallest emission key among equals
         unsigned long long pick = ~0ull;
@@ -465,7 +494,7 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
         return;
     }
     // the candidates within range (:769-778), gathered over the arrays the earlier phases are done with
-    const double range = J->cursubopt * best;
+    const double range = cursub * best;
     double *const c_fin = reinterpret_cast<double *>(pr_dyn);
     uint32_t *const c_key = reinterpret_cast<uint32_t *>(c_fin + Lo.choose_cap);
     uint16_t *const c_q = reinterpret_cast<uint16_t *>(c_key + Lo.choose_cap), *const c_ord = c_q + Lo.choose_cap;
