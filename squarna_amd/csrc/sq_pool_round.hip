@@ -69,6 +69,9 @@ struct SqPrSurv {
 // the scan's sink: runs staged in LDS; whenever 64 of them wait they get their bpscore and the ones that pass :492 join
 // the survivors (the wave is the whole block: its barrier orders the LDS traffic).  The fill counts live in registers: the
 // wave reserves the places of a word-row's runs at once (sq_scan.h)
+#ifdef SQ_PR_PROF
+__shared__ long long sq_pr_prof_bps;                  // (instrumentation: time inside the sink's flushes)
+#endif
 struct SqPrSink {
     uint2 *stage;                                     // staging buffer of SQ_PR_STAGE entries (LDS)
     uint2 *over; uint32_t over_cap;                   // runs beyond the buffer: the structure's key array in the arena
@@ -103,12 +106,18 @@ struct SqPrSink {
     }
     __device__ __forceinline__ void flush(int lane)
     {
+#ifdef SQ_PR_PROF
+        const long long t0_ = wall_clock64();
+#endif
         __syncthreads();
         const uint32_t m = n < SQ_PR_STAGE ? n : SQ_PR_STAGE;
         for (uint32_t b0 = 0; b0 < m; b0 += 64) score64(stage + b0, min(m - b0, 64u), lane);
         if (n > SQ_PR_STAGE) { const uint32_t more = n - SQ_PR_STAGE; nover = nover + more < over_cap ? nover + more : over_cap; }
         n = 0;
         __syncthreads();
+#ifdef SQ_PR_PROF
+        if (lane == 0) sq_pr_prof_bps += wall_clock64() - t0_;
+#endif
     }
     __device__ __forceinline__ void poll(int lane) { if (n >= 64u) flush(lane); }
     __device__ __forceinline__ void drain(int lane) { flush(lane); }
@@ -143,12 +152,13 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     if (ra.ahead && s >= (int)(ra.parity ? hdr0.S[1] : hdr0.S[0])) return;
 #ifdef SQ_PR_PROF
     long long _pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
+    if (threadIdx.x == 0) sq_pr_prof_bps = 0;
 #define PRPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)
 #ifndef SQ_PR_PROF_SLOW
 #define SQ_PR_PROF_SLOW 1000000      /* us: structures slower than this are printed too */
 #endif
-#define PRPROF_OUT(ns_, nin_) do { if (lane == 0 && ((s % 997) == 0 || (wall_clock64() - _t00) > 100ll * SQ_PR_PROF_SLOW)) printf("pool round s=%d n=%d nstrand=%d ns=%u nin=%d | us: entry %.1f ext %.1f extend %.1f setup %.1f state %.1f scan %.1f score %.1f choose %.1f total %.1f\n", \
-        s, n, nstrand, (unsigned)(ns_), (int)(nin_), _pt[6] * 0.01, _pt[7] * 0.01, _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, (wall_clock64() - _t00) * 0.01); } while (0)
+#define PRPROF_OUT(ns_, nin_) do { if (lane == 0 && ((s % 997) == 0 || (wall_clock64() - _t00) > 100ll * SQ_PR_PROF_SLOW)) printf("pool round s=%d n=%d nstrand=%d ns=%u nin=%d | us: bps %.1f entry %.1f ext %.1f extend %.1f setup %.1f state %.1f scan %.1f score %.1f choose %.1f total %.1f\n", \
+        s, n, nstrand, (unsigned)(ns_), (int)(nin_), sq_pr_prof_bps * 0.01, _pt[6] * 0.01, _pt[7] * 0.01, _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, (wall_clock64() - _t00) * 0.01); } while (0)
 #else
 #define PRPROF(k) do {} while (0)
 #define PRPROF_OUT(ns_, nin_) do {} while (0)
@@ -262,7 +272,7 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     }
     PRPROF(0);
     if (lane == 0) atomicAdd((unsigned long long *)&J->evals, 1ull);
-    const SqJob jb = c.jobs[job];
+    const SqJob jb = sq_kload(c.jobs + job);                // (its two lines are in the scalar cache since the entry)
     const SqPsetDev *ps = c.psets + jb.pset;
     const int n = jb.n;
     SqStruct st;                                            // what the phases below read of a structure record

@@ -8,11 +8,11 @@ cp /tmp/lib_keep.so squarna_amd/libsquarna_hip.so
 python - <<'PY'
 import re, collections
 rows = [l for l in open("gpurun_out/s2/pr_prof_all.txt")]
-keys = ["entry", "ext", "extend", "setup", "state", "scan", "score", "choose", "total"]
+keys = ["bps", "entry", "ext", "extend", "setup", "state", "scan", "score", "choose", "total"]
 acc = collections.Counter(); n = 0
 for l in rows:
-    m = {k: float(v) for k, v in re.findall(r"(entry|ext|extend|setup|state|scan|score|choose|total) ([0-9.]+)", l)}
-    if len(m) == 9:
+    m = {k: float(v) for k, v in re.findall(r"(bps|entry|ext|extend|setup|state|scan|score|choose|total) ([0-9.]+)", l)}
+    if len(m) == 10:
         for k in keys: acc[k] += m[k]
         n += 1
 print("%d structure-rounds sampled; mean us:" % n, " ".join("%s %.1f" % (k, acc[k] / max(n, 1)) for k in keys))
