@@ -272,7 +272,7 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     }
     PRPROF(0);
     if (lane == 0) atomicAdd((unsigned long long *)&J->evals, 1ull);
-    const SqJob jb = sq_kload(c.jobs + job);                // (its two lines are in the scalar cache since the entry)
+    const SqJob jb = c.jobs[job];                           // (vector loads, issued together; through the scalar cache: more instructions, no faster)
     const SqPsetDev *ps = c.psets + jb.pset;
     const int n = jb.n;
     SqStruct st;                                            // what the phases below read of a structure record
