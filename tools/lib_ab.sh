@@ -2,7 +2,7 @@
 # A/B of two prebuilt libraries (tools/_libA.so, tools/_libB.so) on the headline step, alternating on one box
 cd $GRAFT_REPO_ROOT
 cp squarna_amd/libsquarna_hip.so /tmp/lib_keep.so
-for r in 1 2 3; do for v in A B; do
+for r in 1 2 3 4 5; do for v in A B; do
   cp tools/_lib$v.so squarna_amd/libsquarna_hip.so
   echo "$v: $(python3 bench.py --steps 12 --warmup 3 --no-cpu --no-stream --no-roofline 2>/dev/null | python3 -c 'import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d["value"], d["ms_per_step"])')"
 done; done
