@@ -241,11 +241,19 @@ extern "C" __global__ __launch_bounds__(64) void sq_algo_finish_kernel(SqDevCtx 
 {
     extern __shared__ __attribute__((aligned(16))) char sq_fin_dyn[];
     const int q = blockIdx.x, lane = threadIdx.x;
+#ifdef SQ_FIN_PROF
+    long long _ft[10]; int _fk = 0;
+#define FINPROF() do { _ft[_fk++] = wall_clock64(); } while (0)
+#else
+#define FINPROF() do {} while (0)
+#endif
+    FINPROF();
     const SqAlgoJob aj = jobs[q];
     const SqMatchJob m = mj[q];
     const SqJob jb = c.jobs[aj.job];
     const SqPsetDev *ps = c.psets + jb.pset;
     const int n = jb.n, half = n / 2 + 2;
+    { int x_ = n + (int)m.n + aj.algo; asm volatile("" :: "v"(x_)); } FINPROF();
     int16_t *pp = reinterpret_cast<int16_t *>(sq_fin_dyn), *pq = pp + half, *sp = pq + half, *sq2 = sp + half;   // pairs, sorted pairs
     double *bps = reinterpret_cast<double *>(sq_fin_dyn + ((8 * (size_t)half + 15) & ~(size_t)15));               // per stem
     int16_t *keep = reinterpret_cast<int16_t *>(bps + half);                                                      // kept stem indices
@@ -322,6 +330,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_algo_finish_kernel(SqDevCtx 
     }
     wsync();
     // ---- sorted(pairs) (:570), PairsToStems (:498-517) ----
+    FINPROF();
     for (int k = lane; k < np; k += 64) {
         const int a0 = pp[k], b0 = pq[k];
         int r = 0;
@@ -345,6 +354,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_algo_finish_kernel(SqDevCtx 
     }
     wsync();
     // ---- first filter (:571-579): raw score re-summed from the matrix cells, left to right from 0 ----
+    FINPROF();
     const double minbps = ps->minbpscore, minlen = ps->minlen;
     int K = 0;
     for (int t0 = 0; t0 < T; t0 += 64) {
@@ -368,6 +378,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_algo_finish_kernel(SqDevCtx 
     if (K > tcap) { if (lane == 0) stats->bad = 2; return; }             // (cannot happen: disjoint stems of >= minlen pairs)
     wsync();
     // ---- level limit (:581): DBNToPairs(PairsToDBN(pairs, N, levellimit)) drops the levels above the limit ----
+    FINPROF();
     const int levellimit = levellimit_opt >= 0 ? levellimit_opt : 3 - (n > 500 ? 1 : 0);   // :1043-1044
     auto levels = [&](int cntT) {                                       // L.lvl of the first cntT stems in L
         bool anyc = false;
@@ -398,12 +409,14 @@ extern "C" __global__ __launch_bounds__(64) void sq_algo_finish_kernel(SqDevCtx 
     }
     levels(K2);                                                          // :582 the levels of what is left
     // ---- second filter (:586-594): short pseudoknotted stems, then the same thresholds (same sums) ----
+    FINPROF();
     int nout = 0;
     for (int t = lane; t < K2; t += 64) nout += (L.lvl[t] > 1 && L.len[t] < 4) ? 0 : 1;
     nout = sq_wave_sum32(nout);
     uint32_t idx = 0, so = 0;
     if (lane == 0) { idx = atomicAdd(&fin_ctr[0], 1u); so = atomicAdd(&fin_ctr[1], (uint32_t)nout); }
     idx = (uint32_t)__shfl((int)idx, 0, 64); so = (uint32_t)__shfl((int)so, 0, 64);
+    FINPROF();
     if (idx >= fin_cap || so + (uint32_t)nout > fin_stem_cap) {
         if (lane == 0) {                                                 // (no slot of the log stays unwritten; the tail reports the flag)
             fin_ctr[2] = 1;
@@ -420,6 +433,11 @@ extern "C" __global__ __launch_bounds__(64) void sq_algo_finish_kernel(SqDevCtx 
         w += __popcll(bal);
     }
     if (lane == 0) fin[idx] = SqPoolFin{aj.job, aj.algo == SQ_ALGO_E ? SQ_FIN_KIND_E : aj.algo == SQ_ALGO_H ? SQ_FIN_KIND_H : SQ_FIN_KIND_N, 0, nout, so, SQ_FIN_SRC_LOG};
+#ifdef SQ_FIN_PROF
+    FINPROF();
+    if (lane == 0 && (q % 499) == 0) printf("finish algo=%d n=%d np=%d | us: load %.1f pairs %.1f stems %.1f filter %.1f levels %.1f count %.1f log %.1f total %.1f\n", aj.algo, n, np,
+        (_ft[1] - _ft[0]) * 0.01, (_ft[2] - _ft[1]) * 0.01, (_ft[3] - _ft[2]) * 0.01, (_ft[4] - _ft[3]) * 0.01, (_ft[5] - _ft[4]) * 0.01, (_ft[6] - _ft[5]) * 0.01, (_ft[7] - _ft[6]) * 0.01, (_ft[7] - _ft[0]) * 0.01);
+#endif
 }
 
 // behind the finish kernel: the launch's statistics to the host, then the completion word
