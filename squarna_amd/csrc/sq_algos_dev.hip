@@ -414,7 +414,7 @@ extern "C" __global__ __launch_bounds__(64) void sq_algo_finish_kernel(SqDevCtx 
     for (int t = lane; t < K2; t += 64) nout += (L.lvl[t] > 1 && L.len[t] < 4) ? 0 : 1;
     nout = sq_wave_sum32(nout);
     uint32_t idx = 0, so = 0;
-    if (lane == 0) { idx = atomicAdd(&fin_ctr[0], 1u); so = atomicAdd(&fin_ctr[1], (uint32_t)nout); }
+    if (lane == 0) sq_log_reserve(fin_ctr, (uint32_t)nout, idx, so);
     idx = (uint32_t)__shfl((int)idx, 0, 64); so = (uint32_t)__shfl((int)so, 0, 64);
     FINPROF();
     if (idx >= fin_cap || so + (uint32_t)nout > fin_stem_cap) {

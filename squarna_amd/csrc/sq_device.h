@@ -195,6 +195,15 @@ __device__ __forceinline__ void sq_wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
+// One entry + nst stems of the device log of final structures: both counters (fin_ctr[0] entries, fin_ctr[1] stems: adjacent,
+// 8-byte aligned) in ONE 64-bit atomic -- two returning atomics in a row were two trips to L2 for every final structure, on
+// counters every wave of the batch's kernels shares.  (The entry counter cannot carry into the stems': the log has < 2^32 entries.)
+__device__ __forceinline__ void sq_log_reserve(uint32_t *fin_ctr, uint32_t nst, uint32_t &idx, uint32_t &so)
+{
+    const unsigned long long r = atomicAdd(reinterpret_cast<unsigned long long *>(fin_ctr), ((unsigned long long)nst << 32) | 1ull);
+    idx = (uint32_t)r; so = (uint32_t)(r >> 32);
+}
+
 // order-preserving map double -> uint64 (never 0 for a real number), so a per-structure maximum is one atomicMax
 __device__ __forceinline__ unsigned long long sq_ord(double x)
 {

@@ -196,7 +196,7 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     int job, nstems, nstrand; double maxstems;
     auto log_final = [&](uint32_t round_kind, int nst) {    // (sq_pool_extend_kernel's record; the stems from LDS)
         uint32_t idx = 0, so = 0;
-        if (lane == 0) { idx = atomicAdd(&pio.fin_ctr[0], 1u); so = atomicAdd(&pio.fin_ctr[1], (uint32_t)nst); }
+        if (lane == 0) sq_log_reserve(pio.fin_ctr, (uint32_t)nst, idx, so);
         idx = (uint32_t)__shfl((int)idx, 0, 64); so = (uint32_t)__shfl((int)so, 0, 64);
         if (idx >= pio.fin_cap || so + (uint32_t)nst > pio.fin_stem_cap) {
             if (lane == 0) {                                 // (the host repeats the fold with its own loop and an empty log)
