@@ -821,8 +821,8 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
         sq_prof_end(b, pslot, cs, pe0);
         hipLaunchKernelGGL(sq_algo_finish_kernel, dim3(nj), dim3(64), fin_lds, cs, b->ctx, ck.p_aj, ck.p_mj, d_out, d_cnt, levellimit_opt,
                            b->d_fin, b->d_fin_stems, b->d_fin_ctr, b->fin_cap, b->fin_stem_cap, d_stat, tmax);
-        hipLaunchKernelGGL(sq_algo_publish_kernel, dim3(1), dim3(1), 0, cs, d_stat, ck.h_stats, ck.p_mj, d_out, it.algo == SQ_ALGO_E ? 1 : 0,
-                           ck.flag, ck.flag_val);
+        hipLaunchKernelGGL(sq_algo_publish_kernel, dim3(1), dim3(64), 0, cs, d_stat, ck.h_stats, ck.p_mj, d_out, it.algo == SQ_ALGO_E ? 1 : 0,
+                           ck.flag, ck.flag_val, nj);
         HIPCK(hipGetLastError());
         it.staged = true;
         sidx++;

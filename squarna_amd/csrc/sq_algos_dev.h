@@ -52,7 +52,7 @@ __global__ void sq_algo_finish_kernel(SqDevCtx c, const SqAlgoJob *jobs, const S
                                       int levellimit_opt, SqPoolFin *fin, SqPoolStem *fin_stems, uint32_t *fin_ctr, uint32_t fin_cap,
                                       uint32_t fin_stem_cap, SqAlgoStat *stats, int tcap);
 __global__ void sq_algo_publish_kernel(SqAlgoStat *stats, SqAlgoStat *h_stats, const SqMatchJob *mj, const int32_t *out, int is_edmonds,
-                                       uint32_t *flag, uint32_t value);
+                                       uint32_t *flag, uint32_t value, int nj);
 }
 // dynamic LDS of sq_algo_finish_kernel for sequences up to n nt whose structures hold up to tcap stems
 static inline size_t sq_algo_finish_lds(int n, int tcap)

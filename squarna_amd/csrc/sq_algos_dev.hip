@@ -265,12 +265,8 @@ extern "C" __global__ __launch_bounds__(64) void sq_algo_finish_kernel(SqDevCtx 
         const int32_t *mate = out + m.out_off;
         const int nv = m.n;
         if (nv > 0 && mate[0] == -2) { if (lane == 0) stats->bad = 1; return; }       // blossom capacity exceeded
-        if (lane == 0 && nv > 0) {                                       // measurement: the graph with the most scan passes
-            const unsigned long long key = ((unsigned long long)(uint32_t)mate[2 * nv] << 32) | (uint32_t)q;
-            atomicMax(&stats->max_pass_job, key);
-            atomicAdd(&stats->passes, (unsigned long long)(uint32_t)mate[2 * nv]);
-            atomicAdd(&stats->graphs, 1ull);
-        }
+        // (the measurement -- the graph with the most scan passes, their sum -- is the publish kernel's: three atomics per job on
+        // ONE record every wave of the launch shares stood in front of this wave's loads on the in-order memory counter)
         for (int v0 = 0; v0 < nv; v0 += 64) {
             const int v = v0 + lane;
             const int mt = v < nv ? mate[v] : -1;
@@ -441,10 +437,36 @@ extern "C" __global__ __launch_bounds__(64) void sq_algo_finish_kernel(SqDevCtx 
 }
 
 // behind the finish kernel: the launch's statistics to the host, then the completion word
-extern "C" __global__ void sq_algo_publish_kernel(SqAlgoStat *stats, SqAlgoStat *h_stats, const SqMatchJob *mj, const int32_t *out,
-                                                  int is_edmonds, uint32_t *flag, uint32_t value)
+extern "C" __global__ __launch_bounds__(64) void sq_algo_publish_kernel(SqAlgoStat *stats, SqAlgoStat *h_stats, const SqMatchJob *mj, const int32_t *out,
+                                                                        int is_edmonds, uint32_t *flag, uint32_t value, int nj)
 {
+    // Edmonds: the graph with the most scan passes (the blossom kernel's critical path), the passes of all graphs and their
+    // number -- read from the kernel's result blocks by ONE wave, eight jobs per lane in flight (the finish kernel's waves
+    // used to count them with three atomics each on this one record)
+    const int lane = threadIdx.x;
+    unsigned long long mx = 0ull, sum = 0ull, cnt = 0ull;
+    if (is_edmonds)
+        for (int q0 = lane; q0 < nj; q0 += 64 * 8) {
+            int nn[8], oo[8], first[8], pass[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int q = q0 + 64 * k; const bool ok = q < nj; nn[k] = ok ? mj[q].n : 0; oo[k] = ok ? mj[q].out_off : 0; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { first[k] = nn[k] > 0 ? out[oo[k]] : -2; pass[k] = nn[k] > 0 ? out[oo[k] + 2 * nn[k]] : 0; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (nn[k] <= 0 || first[k] == -2) continue;              // (no graph / capacity exceeded: the finish kernel's rule)
+                const unsigned long long p = (unsigned long long)(uint32_t)pass[k];
+                const unsigned long long key = (p << 32) | (uint32_t)(q0 + 64 * k);
+                mx = key > mx ? key : mx; sum += p; cnt += 1ull;
+            }
+        }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long omx = __shfl_xor(mx, d, 64);
+        mx = omx > mx ? omx : mx; sum += __shfl_xor(sum, d, 64); cnt += __shfl_xor(cnt, d, 64);
+    }
+    if (lane != 0) return;
     SqAlgoStat s = *stats;
+    if (is_edmonds) { s.max_pass_job = mx; s.passes = sum; s.graphs = cnt; }
     if (is_edmonds && s.graphs) {
         const SqMatchJob m = mj[(uint32_t)s.max_pass_job];
         s.max_events = out[m.out_off + 2 * m.n + 1]; s.max_n = m.n; s.max_m = m.nedges;
