@@ -525,16 +525,24 @@ struct SqScan6Lds {
 struct SqScan6Sink {
     SqScan6Lds &L; const SqScanArgs &a; const SqStruct &st; int cap;
     uint32_t n;                               // runs staged since the last flush (a register: the wave is the whole block)
+    // sole: this wave is the structure's only writer (one block walks all its diagonal groups): the places in the key array are
+    // counted in a register (`base`) and the count is stored once at the end -- a returning atomic per flush was a trip to L2
+    // per diagonal group of a wave that lives 15-20 us
+    bool sole; uint32_t base;
+    __device__ __forceinline__ uint32_t take(uint32_t cnt, int lane)
+    {
+        if (sole) { const uint32_t b0 = base; base += cnt; return b0; }
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(a.cand_cnt + st.slot, cnt);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+    }
+    __device__ __forceinline__ void finish(int lane) { if (sole && lane == 0) a.cand_cnt[st.slot] = base; }
     // the places of a word-row's runs: in the staging buffer (flushed first when they do not fit), or -- more runs than the
     // buffer holds in one word-row -- straight in the structure's key array (index | 0x80000000)
     __device__ __forceinline__ uint32_t reserve(uint32_t total, int lane)
     {
         if (n + total > SQ5_STAGE) flush(lane);
-        if (total > SQ5_STAGE) {
-            uint32_t b0 = 0;
-            if (lane == 0) b0 = atomicAdd(a.cand_cnt + st.slot, total);
-            return 0x80000000u | (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
-        }
+        if (total > SQ5_STAGE) return 0x80000000u | take(total, lane);
         const uint32_t b0 = n; n += total; return b0;
     }
     __device__ __forceinline__ void put(uint32_t at, uint32_t key, uint32_t len)
@@ -548,11 +556,9 @@ struct SqScan6Sink {
     {
         __syncthreads();
         if (n) {
-            uint32_t b0 = 0;
-            if (lane == 0) b0 = atomicAdd(a.cand_cnt + st.slot, n);
-            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+            const uint32_t base0 = take(n, lane);
             for (uint32_t k = lane; k < n; k += 64) {
-                const uint32_t slot = base + k;
+                const uint32_t slot = base0 + k;
                 if (slot >= (uint32_t)cap) { a.ctr->cand_ovf = 1; continue; }
                 sq_keys(a, st)[slot] = SqKey{L.stage[k].x, L.stage[k].y};
             }
@@ -581,8 +587,9 @@ __device__ __forceinline__ void sq_scan6_body(const SqDevCtx &c, const SqStruct 
     // one block = the diagonal groups blockIdx.y, blockIdx.y + gridDim.y, ..: a launch for short sequences gives a structure
     // ONE wave that walks all its groups (five for 100 nt) instead of one wave per group -- each of those spent most of its
     // few microseconds on the set-up above, and with batches in flight wave slots are what the chip runs out of
-    SqScan6Sink sink{L, a, st, jb.cand_cap, 0u};
+    SqScan6Sink sink{L, a, st, jb.cand_cap, 0u, gystep == 1, 0u};       // (cand_cnt of the slot: zeroed by the state kernel in front)
     sq_scan6_groups(c, jb, sq6_fg, sq6_fg + fbh, fbh, stt.E8 + (int64_t)st.slot * stt.stride * 2, gy0, gystep, lane0, sink, SqBitsGlobal{c.bits + jb.bits_off, jb.bpitch});
+    sink.finish(lane0);
 }
 
 extern "C" __global__ __launch_bounds__(64) void sq_scan6_kernel(SqDevCtx c, const SqStruct *structs, SqState stt, SqScanArgs a)
