@@ -228,7 +228,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
         m.edge_off = (int64_t)nedges; m.pos_off = b->jobs[jobs[k1]].pos_off;
         m.n = B.n; m.nedges = (int32_t)B.ncell;
         const size_t fixed = (mj.size() + 1) * sizeof(SqMatchJob) + (nedges + B.ncell) * sizeof(SqMatchEdge) +
-                             (outints + B.nout + mj.size() + 1) * 4 + 4096 + (dev_sizes ? (vids + (size_t)B.n) * 4 + 1024 : 0);
+                             (outints + B.nout + mj.size() + 1) * 4 + 4096 + (dev_sizes ? (vids + (size_t)B.n) * 4 + 1024 + (mj.size() + 1) * sizeof(SqAlgoJob) : 0);
         if (fixed + scratch + B.need > region_bytes) break;
         m.scratch_off = (int64_t)scratch; scratch += B.need;
         m.out_off = (int64_t)(algo == SQ_ALGO_N ? outints / 2 : outints); outints += B.nout;
@@ -241,7 +241,7 @@ static int algo_build(sq_batch *b, const std::vector<int> &jobs, const std::vect
     auto take = [&](size_t bytes) { size_t rr = o; o = (o + bytes + 255) & ~(size_t)255; return rr; };
     take(mj.size() * sizeof(SqMatchJob)); take(nedges * sizeof(SqMatchEdge) + 16);
     take(outints * 4 + 16); take(mj.size() * 4 + 16);
-    if (dev_sizes) { take(vids * 4 + 16); take(sizeof(SqAlgoStat)); }
+    if (dev_sizes) { take(vids * 4 + 16); take(sizeof(SqAlgoStat)); take(mj.size() * sizeof(SqAlgoJob) + 16); }   // (+ the finish kernel's job records: Carve::o_aj)
     ck.bytes = o + scratch;
     if (mj.empty()) return 0;
     // pinned staging: [jobs][edges][results][counts][completion word][per-job completion words]
@@ -725,8 +725,8 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
         sidx++;
     }
     // ---- per-job records of the edges / finish kernels ----
-    // region of a chunk: [jobs (unused)][edges][out ints][counts][vid2pos][stats][scratch]
-    struct Carve { size_t o_edges, o_out, o_cnt, o_vid, o_stat, o_scr; };
+    // region of a chunk: [jobs][edges][out ints][counts][vid2pos][stats][finish records][scratch]
+    struct Carve { size_t o_edges, o_out, o_cnt, o_vid, o_stat, o_aj, o_scr; };
     std::vector<Carve> cv(pa->items.size());
     // the edges kernel takes one record per structure of the round: all items' records, contiguous, in round order
     SqAlgoJob *round_aj = (SqAlgoJob *)(pin + o_aj);
@@ -739,7 +739,7 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
         take(mj.size() * sizeof(SqMatchJob));
         cv[q].o_edges = take(it.ck.nedges * sizeof(SqMatchEdge) + 16);
         cv[q].o_out = take(it.ck.outints * 4 + 16); cv[q].o_cnt = take(mj.size() * 4 + 16);
-        cv[q].o_vid = take(it.ck.vids * 4 + 16); cv[q].o_stat = take(sizeof(SqAlgoStat)); cv[q].o_scr = take(0);
+        cv[q].o_vid = take(it.ck.vids * 4 + 16); cv[q].o_stat = take(sizeof(SqAlgoStat)); cv[q].o_aj = take(mj.size() * sizeof(SqAlgoJob) + 16); cv[q].o_scr = take(0);
         size_t vid = 0;
         for (size_t k = 0; k < mj.size(); k++) {
             SqAlgoJob aj;
@@ -792,6 +792,12 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
         SqAlgoStat *d_stat = (SqAlgoStat *)(region + cv[q].o_stat);
         if (q >= 3) HIPCK(hipMemsetAsync(d_stat, 0, sizeof(SqAlgoStat), cs));   // (the first three: zeroed by the edges kernel)
         const int nj = (int)ck.mj.size();
+        // The finish kernel's two records per job go to the device first: from the pinned table every one of its waves began
+        // with two reads over PCIe (and the publish kernel's wave walks the table): microseconds in a wave that works for a few.
+        SqMatchJob *const dev_mj = (SqMatchJob *)region;
+        SqAlgoJob *const dev_aj = (SqAlgoJob *)(region + cv[q].o_aj);
+        HIPCK(hipMemcpyAsync(dev_mj, ck.p_mj, (size_t)nj * sizeof(SqMatchJob), hipMemcpyHostToDevice, cs));
+        HIPCK(hipMemcpyAsync(dev_aj, ck.p_aj, (size_t)nj * sizeof(SqAlgoJob), hipMemcpyHostToDevice, cs));
         hipEvent_t pe0;
         const int pslot = it.algo == SQ_ALGO_E ? 4 : it.algo == SQ_ALGO_H ? 5 : 6;
         sq_prof_begin(b, pslot, cs, &pe0);
@@ -819,9 +825,9 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
         }
         if (rl) return sq_check((hipError_t)rl, "matching kernel launch");
         sq_prof_end(b, pslot, cs, pe0);
-        hipLaunchKernelGGL(sq_algo_finish_kernel, dim3(nj), dim3(64), fin_lds, cs, b->ctx, ck.p_aj, ck.p_mj, d_out, d_cnt, levellimit_opt,
+        hipLaunchKernelGGL(sq_algo_finish_kernel, dim3(nj), dim3(64), fin_lds, cs, b->ctx, dev_aj, dev_mj, d_out, d_cnt, levellimit_opt,
                            b->d_fin, b->d_fin_stems, b->d_fin_ctr, b->fin_cap, b->fin_stem_cap, d_stat, tmax);
-        hipLaunchKernelGGL(sq_algo_publish_kernel, dim3(1), dim3(64), 0, cs, d_stat, ck.h_stats, ck.p_mj, d_out, it.algo == SQ_ALGO_E ? 1 : 0,
+        hipLaunchKernelGGL(sq_algo_publish_kernel, dim3(1), dim3(64), 0, cs, d_stat, ck.h_stats, dev_mj, d_out, it.algo == SQ_ALGO_E ? 1 : 0,
                            ck.flag, ck.flag_val, nj);
         HIPCK(hipGetLastError());
         it.staged = true;

@@ -236,7 +236,16 @@ void sq_launch_round_kernels(sq_batch *b, hipStream_t st, int S, int maxn, int64
     if (fuse) {
         ProfScope ps(b, 2, scan_bytes);
         const size_t dyn_state = (size_t)7 * ((maxn + 8) & ~7) + 64, dyn_scan = 4 * (size_t)b->state.fbstride;
-        hipLaunchKernelGGL(sq_state_scan_kernel, dim3(S), dim3(64), std::max(dyn_state, dyn_scan), st, b->ctx, io, b->state, scan, maxn, chained ? 1 : 0);
+        // (the structure records go to the device by ONE copy first: read from the pinned array by every wave, each of the
+        // launch's thousands of waves began with a read over PCIe -- 3.0 -> 1.2 G wave cycles per three headline steps,
+        // the headline +1.6 %; SQ_NO_STATE_COPY: the old form)
+        static const bool copy_first = getenv("SQ_NO_STATE_COPY") == nullptr;
+        SqRoundIO io2 = io;
+        if (copy_first && !chained && io.h_structs != io.d_structs) {
+            hipMemcpyAsync(io.d_structs, io.h_structs, (size_t)S * sizeof(SqStruct), hipMemcpyHostToDevice, st);
+            io2.h_structs = io.d_structs;
+        }
+        hipLaunchKernelGGL(sq_state_scan_kernel, dim3(S), dim3(64), std::max(dyn_state, dyn_scan), st, b->ctx, io2, b->state, scan, maxn, chained ? 1 : 0);
     }
     if (!fuse) {
         ProfScope ps(b, 1, 0);
