@@ -769,8 +769,18 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
         // (one wave per job on a crowded chip: the work of a job is a few hundred stems behind a handful of trips to L2, and
         // three waves that mostly wait held three wave slots -- sizes + edges were 7 % of a crowded step's wave cycles)
         const bool crowded_k = b->inflight > 1 || b->njobs >= 4096;
+        // (the jobs' records to the device first when the scratch has room behind the items' regions: from the pinned table
+        // every block of the kernel began with a read over PCIe)
+        const SqAlgoJob *edges_aj = round_aj;
+        {
+            const size_t at = (b->algo_used + 255) & ~(size_t)255, need = (size_t)S * sizeof(SqAlgoJob);
+            if (b->algo_scratch && at + need <= b->algo_bytes && !getenv("SQ_NO_STATE_COPY")) {
+                HIPCK(hipMemcpyAsync(b->algo_scratch + at, round_aj, need, hipMemcpyHostToDevice, st));
+                edges_aj = (const SqAlgoJob *)(b->algo_scratch + at);
+            }
+        }
         hipLaunchKernelGGL(sq_algo_edges_kernel, dim3(S), dim3(crowded_k ? 64 : 256), sq_algo_edges_lds(maxn_lds, nokcap), st, b->ctx, b->lane_full.d_structs,
-                           [&] { SqScanArgs a = b->scan; a.ctr = b->lane_full.d_ctr; return a; }(), round_aj, maxn_lds, zs, nokcap);
+                           [&] { SqScanArgs a = b->scan; a.ctr = b->lane_full.d_ctr; return a; }(), edges_aj, maxn_lds, zs, nokcap);
     }
     HIPCK(hipGetLastError());
     if (!b->class_ev) HIPCK(sq_event_get(b->device, &b->class_ev));
