@@ -137,6 +137,19 @@ typedef struct sq_fold_opts {
 /* ---- library -------------------------------------------------------------- */
 SQ_API int sq_version(void);
 SQ_API const char *sq_last_error(void);
+/* Status -3 means "a capacity the batch was created with did not hold the fold" (the reference has no capacities: its lists are
+ * Python lists, SQRNdbnseq.py:427-495).  sq_last_capacity() says which one the calling thread's last -3 was about, so that a
+ * caller can repeat the fold with a larger batch without reading the message:
+ *   SQ_CAP_CANDIDATES  candidate records per structure (sq_batch_desc.cand_per_nt)
+ *   SQ_CAP_STRUCTS     structure slots / the log of final structures (sq_batch_desc.max_structs)
+ *   SQ_CAP_OUTPUT      the output records of a round (sized from the candidate arena: grows with cand_per_nt)
+ *   SQ_CAP_FIXED       a limit no descriptor field moves (64 pseudoknot levels, a chain's stem list, the blossom arrays)
+ * 0 when the last error was not a capacity. */
+#define SQ_CAP_CANDIDATES 1
+#define SQ_CAP_STRUCTS 2
+#define SQ_CAP_OUTPUT 3
+#define SQ_CAP_FIXED 4
+SQ_API int sq_last_capacity(void);
 /* The library keeps idle pinned host buffers of destroyed batches for the next ones (hipHostMalloc / hipHostFree cost
  * milliseconds; SQ_PINNED_CACHE_MB bounds the cache).  sq_host_cache_trim() gives every idle buffer back to the driver
  * -- what torch.cuda.empty_cache() is for device memory: a process that changes its workload (a bench between its legs,

@@ -14,7 +14,7 @@ ALPHABET = 32
 ALGO_BITS = {"G": 1, "N": 2, "H": 4, "E": 8}
 
 #: every symbol include/squarna_hip.h declares
-SYMBOLS = ["sq_version", "sq_last_error", "sq_batch_workspace_bytes", "sq_batch_create",
+SYMBOLS = ["sq_version", "sq_last_error", "sq_last_capacity", "sq_batch_workspace_bytes", "sq_batch_create",
            "sq_batch_destroy", "sq_bpmatrix_fill", "sq_bpmatrix_read", "sq_optimal_stems",
            "sq_fold", "sq_result_nstruct", "sq_result_consensus", "sq_result_struct",
            "sq_result_metrics", "sq_result_evals", "sq_result_pack_size", "sq_result_pack",
@@ -165,12 +165,23 @@ def load():
     return L
 
 
+CAP_CANDIDATES, CAP_STRUCTS, CAP_OUTPUT, CAP_FIXED = 1, 2, 3, 4      # sq_last_capacity (include/squarna_hip.h)
+
+
 class CapacityError(RuntimeError):
     """A capacity the batch was created with (candidate records per structure, the log of final structures) did not hold the
-    fold: status -3 of the C ABI.  The engine repeats the fold with a larger batch (engine.HipEngine._fold_groups)."""
+    fold: status -3 of the C ABI.  `kind` is sq_last_capacity()'s answer -- which capacity --, so that the engine can repeat
+    the fold with a larger batch (engine.HipEngine._fold_groups) without reading the message."""
+
+    def __init__(self, msg, kind=0):
+        super().__init__(msg)
+        self.kind = kind
 
 
 def check(rc):
     if rc != 0:
-        msg = "libsquarna_hip: %s (code %d)" % (load().sq_last_error().decode(), rc)
-        raise (CapacityError if rc == -3 else RuntimeError)(msg)
+        L = load()
+        msg = "libsquarna_hip: %s (code %d)" % (L.sq_last_error().decode(), rc)
+        if rc == -3:
+            raise CapacityError(msg, int(L.sq_last_capacity()))
+        raise RuntimeError(msg)

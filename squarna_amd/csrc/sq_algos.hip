@@ -567,7 +567,7 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
     }
     if (bad == 3) return sq_check((hipError_t)stream_err.load(), "matching kernel");
     if (bad == 2) { sq_set_error("matching kernel did not publish a job"); return 2; }
-    if (bad) { sq_set_error("blossom capacity exceeded"); return -3; }
+    if (bad) { sq_set_capacity_error(SQ_CAP_FIXED, "blossom capacity exceeded"); return -3; }
     if (!streaming && on_job) for (size_t q = 0; q < mj.size(); q++) (*on_job)(ck.k0 + q);
     return 0;
 }
@@ -856,8 +856,8 @@ static int algos_end_dev(sq_batch *b, SqAlgoAsync *pa)
         r = sq_wait_word(b, ck.flag, ck.flag_val, ck.st, "matching kernel");
         if (r) break;
         const SqAlgoStat hs = *ck.h_stats;
-        if (hs.bad == 1) { sq_set_error("blossom capacity exceeded"); r = -3; }
-        else if (hs.bad) { sq_set_error("stem capacity of RunAlgo's filters exceeded"); r = -3; }
+        if (hs.bad == 1) { sq_set_capacity_error(SQ_CAP_FIXED, "blossom capacity exceeded"); r = -3; }
+        else if (hs.bad) { sq_set_capacity_error(SQ_CAP_FIXED, "stem capacity of RunAlgo's filters exceeded"); r = -3; }
         else if (hs.level_ovf) { sq_set_error("more than 64 pseudoknot levels"); r = -3; }
         if (pa->items[q].algo == SQ_ALGO_E && hs.graphs) {
             std::lock_guard<std::mutex> lk(b->mwm_mu);

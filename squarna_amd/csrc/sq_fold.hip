@@ -78,13 +78,16 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     // job is scanned exactly once -- width-1 pools on the persistent round kernel, no E / H / N -- does not write the bit
     // matrices at all: the kernel's only scan forms the words it needs from letter masks in LDS (SqBitsFly, sq_scan.h; the bit
     // kernel was 215 us of the 1.47 ms of an S1000 x 1,024 fold).  Every other path asks for the matrices (sq_prepare_scan).
-    bool any_ehn = false, any_ext1 = false;
+    // (a job whose dense matrix the FILL forms -- caller matrices, bpp terms, a multiplier of its own: score x mul or score + bpp
+    // in the fp64 arena, sq_kernels.hip -- needs that launch: the round kernel reads those cells as they are.  Only the rows
+    // weighted by the alignment's shared matrix are formed elsewhere)
+    bool any_ehn = false, any_fill = false;
     for (int j = 0; j < b->njobs; j++) {
         any_ehn |= (algos[j] & (uint32_t)(SQ_ALGO_E | SQ_ALGO_H | SQ_ALGO_N)) != 0;
-        any_ext1 |= b->jobs[j].has_ext == 1;
+        any_fill |= b->jobs[j].has_ext != 0 && !b->jobs[j].mat64_diag;
     }
     const bool no_fly = sw.no_fly_bits;
-    const bool lazy_bits = o.poollim == 1 && !sw.no_chain && !sw.no_rounds && !any_ehn && !any_ext1 && !b->interchainonly && b->nletters > 0 && !no_fly;
+    const bool lazy_bits = o.poollim == 1 && !sw.no_chain && !sw.no_rounds && !any_ehn && !any_fill && !b->interchainonly && b->nletters > 0 && !no_fly;
     b->bits_ready = false;
     if (!lazy_bits) { r = sq_fill_impl(b, 0); if (r) return r; }
     // Edmonds / Hungarian / Nussinov paramsets (:1094-1100); their stemsets precede the greedy ones.
@@ -232,7 +235,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     }
     mark("tail queue");
     // the greedy pool loop (:1102-1199) for a subset of the jobs, on one lane of round buffers
-    struct LoopStats { double tround = 0, twall = 0, tstart = 0; int nrounds = 0; int rc = 0; std::string err; };
+    struct LoopStats { double tround = 0, twall = 0, tstart = 0; int nrounds = 0; int rc = 0; int cap = 0; std::string err; };   // (cap: SQ_CAP_* of a status -3)
     auto greedy_loop = [&](SqLane &ln, const std::vector<int> &myjobs, LoopStats &stats) {
         std::vector<SView> round;
         std::vector<int> owner;                             // job of each view
@@ -275,7 +278,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             tq.push(finished);
             if (round.empty()) break;
             { const double t0 = now_s(); stats.rc = sq_run_round_impl(b, ln, round, 0, res, nullptr); stats.tround += now_s() - t0; stats.nrounds++; }
-            if (stats.rc) { stats.err = sq_last_error(); return; }
+            if (stats.rc) { stats.err = sq_last_error(); stats.cap = sq_last_capacity(); return; }
             // :1179-1196.  The entries of one job are contiguous in `round` and only touch that job's pool, so jobs
             // are independent; per job the entries are still handled in order.  Big rounds are shared among the
             // worker pool in contiguous slices (children mostly reuse their parent's storage: no allocator traffic).
@@ -339,7 +342,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         const double tl0 = now_s();
         stats.tstart = tl0 - tfold0;
         struct Wall { double t0; double &dst; ~Wall() { dst = now_s() - t0; } } wall{tl0, stats.twall};
-        auto fail = [&](int rc, const std::string &msg) { stats.rc = rc; stats.err = msg; };
+        auto fail = [&](int rc, const std::string &msg, int cap = 0) { stats.rc = rc; stats.err = msg; stats.cap = cap; };
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(sq_check(e_, #x), sq_last_error()); return; } } while (0)
         if (!b->chain.h_stems) {
             void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
@@ -470,9 +473,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 { const int wr = sq_wait_word(b, flag, seq, st, "persistent rounds"); if (wr) fail(wr, sq_last_error()); }
                 if (!stats.rc) {
                     const SqCounters ctr = *ln.h_ctr;
-                    if (ctr.cand_ovf) fail(-3, "candidate capacity exceeded (raise cand_per_nt)");
-                    else if (ctr.out_ovf) fail(-3, "stem capacity of a chained structure exceeded");
-                    else if (ctr.level_ovf) fail(-3, "more than 64 pseudoknot levels");
+                    if (ctr.cand_ovf) fail(-3, "candidate capacity exceeded (raise cand_per_nt)", SQ_CAP_CANDIDATES);
+                    else if (ctr.out_ovf) fail(-3, "stem capacity of a chained structure exceeded", SQ_CAP_FIXED);
+                    else if (ctr.level_ovf) fail(-3, "more than 64 pseudoknot levels", SQ_CAP_FIXED);
                     else {
                         const uint32_t nf = *b->chain.h_nfin;
                         if (nf != nfin_goal) fail(2, "persistent rounds left structures unfinished");
@@ -501,9 +504,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 done = d2; spins = 0;
                 if (timing) round_t.push_back({(int)done, (now_s() - tr0) * 1e3});
                 const SqCounters ctr = *ln.h_ctr;
-                if (ctr.cand_ovf) { fail(-3, "candidate capacity exceeded (raise cand_per_nt)"); break; }
-                if (ctr.out_ovf) { fail(-3, "stem capacity of a chained structure exceeded"); break; }
-                if (ctr.level_ovf) { fail(-3, "more than 64 pseudoknot levels"); break; }
+                if (ctr.cand_ovf) { fail(-3, "candidate capacity exceeded (raise cand_per_nt)", SQ_CAP_CANDIDATES); break; }
+                if (ctr.out_ovf) { fail(-3, "stem capacity of a chained structure exceeded", SQ_CAP_FIXED); break; }
+                if (ctr.level_ovf) { fail(-3, "more than 64 pseudoknot levels", SQ_CAP_FIXED); break; }
                 const uint32_t nf = *b->chain.h_nfin;
                 if (!dev_tail) for (uint32_t q = nfin_seen; q < nf; q++) finished.push_back(-(int)q - 1);   // (device tail: the log has them)
                 nfin_seen = nf;
@@ -552,7 +555,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         const double tl0 = now_s();
         stats.tstart = tl0 - tfold0;
         struct Wall { double t0; double &dst; ~Wall() { dst = now_s() - t0; } } wall{tl0, stats.twall};
-        auto fail = [&](int rc, const std::string &msg) { stats.rc = rc; stats.err = msg; return 2; };
+        auto fail = [&](int rc, const std::string &msg, int cap = 0) { stats.rc = rc; stats.err = msg; stats.cap = cap; return 2; };
         if (!PI.h_hdr) {
             void *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr, *p6 = nullptr;
             if (sq_pinned_get(&p2, sizeof(SqPoolHdr) * SQ_POOL_HDR_RING) || sq_pinned_get(&p3, sizeof(SqPoolJob) * (size_t)b->njobs) ||
@@ -681,8 +684,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 if (wait_seq(seq, true)) return 2;                  // (the rounds behind it write the same word: at least this one)
                 rounds++;
                 const SqCounters ctr = *ln.h_ctr;
-                if (ctr.cand_ovf) return fail(-3, "candidate capacity exceeded (raise cand_per_nt)");
-                if (ctr.level_ovf) return fail(-3, "more than 64 pseudoknot levels");
+                if (ctr.cand_ovf) return fail(-3, "candidate capacity exceeded (raise cand_per_nt)", SQ_CAP_CANDIDATES);
+                if (ctr.level_ovf) return fail(-3, "more than 64 pseudoknot levels", SQ_CAP_FIXED);
                 const SqPoolHdr hh = pio.h_hdr[seq % SQ_POOL_HDR_RING];
                 if (timing && sw.pool_debug) fprintf(stderr, "[pool] round %d (of %d enqueued): next generation %u, nfin %u, ovf %u, active jobs %u\n", rounds, launched, hh.S[(rounds & 1)], hh.nfin, hh.ovf, hh.active_jobs);
                 b->last_peak = std::max<int64_t>(b->last_peak, hh.peak);
@@ -715,8 +718,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             if (wait_seq(seq)) return 2;
             rounds++;
             const SqCounters ctr = *ln.h_ctr;
-            if (ctr.cand_ovf) return fail(-3, "candidate capacity exceeded (raise cand_per_nt)");
-            if (ctr.level_ovf) return fail(-3, "more than 64 pseudoknot levels");
+            if (ctr.cand_ovf) return fail(-3, "candidate capacity exceeded (raise cand_per_nt)", SQ_CAP_CANDIDATES);
+            if (ctr.level_ovf) return fail(-3, "more than 64 pseudoknot levels", SQ_CAP_FIXED);
             const SqPoolHdr hh = pio.h_hdr[seq % SQ_POOL_HDR_RING];
             if (timing && sw.pool_debug) fprintf(stderr, "[pool] round %d: S %d -> %u, nfin %u, ovf %u, active jobs %u\n", rounds, S, hh.S[parity ^ 1], hh.nfin, hh.ovf, hh.active_jobs);
             if (hh.ovf) { overflow = true; break; }
@@ -745,7 +748,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             hipLaunchKernelGGL(sq_fin_keep_algos_kernel, dim3(1), dim3(1024), 0, st, b->d_fin, b->d_fin_ctr, b->fin_cap, b->d_job_evals, b->tail.job_cnt, b->njobs);
             return 1;
         }
-        if ((*ln.h_ctr).level_ovf) return fail(-3, "more than 64 pseudoknot levels");
+        if ((*ln.h_ctr).level_ovf) return fail(-3, "more than 64 pseudoknot levels", SQ_CAP_FIXED);
         // finstemsets of every job: its log entries in (round, kind, position) order.  With the device tail the log is
         // consumed where it is; the host needs it only when the batch falls back to the host tail (pool_collect).
         pool_jobs = jobs;
@@ -796,7 +799,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     if (use_pool && chain_ties) {
         // the optimistic chains first; their structures that met a tie hand their jobs to the pools
         chain_fold(st0);
-        if (st0.rc) { tq.close(); sq_set_error(st0.err); return st0.rc; }
+        if (st0.rc) { tq.close(); sq_set_capacity_error(st0.rc == -3 ? st0.cap : 0, st0.err); return st0.rc; }
         b->last_paths |= 16;
         std::sort(tied_jobs.begin(), tied_jobs.end());
         pool_jobs_v.insert(pool_jobs_v.end(), tied_jobs.begin(), tied_jobs.end());
@@ -850,10 +853,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         std::thread other([&] { if (b->device >= 0) hipSetDevice(b->device); greedy_loop(b->lane_half[1], part[1], st1); });
         greedy_loop(b->lane_half[0], part[0], st0);
         other.join();
-        if (!st0.rc && st1.rc) { st0.rc = st1.rc; st0.err = st1.err; }
+        if (!st0.rc && st1.rc) { st0.rc = st1.rc; st0.err = st1.err; st0.cap = st1.cap; }
     }
     tq.close();
-    if (st0.rc) { sq_set_error(st0.err); return st0.rc; }
+    if (st0.rc) { sq_set_capacity_error(st0.rc == -3 ? st0.cap : 0, st0.err); return st0.rc; }
     const double tround = st0.tround + st1.tround;
     const int nrounds = st0.nrounds + st1.nrounds;
     const double tloop = now_s() - tfold0;
@@ -944,8 +947,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             if (rt) hipStreamSynchronize(b->stream);
             std::atomic_thread_fence(std::memory_order_acquire);
             const SqCounters ctr = *b->lane_full.h_ctr;
-            if (ctr.cand_ovf) { sq_set_error("candidate capacity exceeded (raise cand_per_nt)"); return -3; }
-            if (ctr.out_ovf) { sq_set_error("stem capacity of a chained structure exceeded"); return -3; }
+            if (ctr.cand_ovf) { sq_set_capacity_error(SQ_CAP_CANDIDATES, "candidate capacity exceeded (raise cand_per_nt)"); return -3; }
+            if (ctr.out_ovf) { sq_set_capacity_error(SQ_CAP_FIXED, "stem capacity of a chained structure exceeded"); return -3; }
             if (ctr.level_ovf) { sq_set_error("more than 64 pseudoknot levels"); return -3; }
             if (*b->chain.h_nfin != deferred.goal) { sq_set_error("persistent rounds left structures unfinished"); return 2; }
         }

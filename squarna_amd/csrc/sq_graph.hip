@@ -163,7 +163,7 @@ extern "C" int sq_mwm(int32_t ngraph, const int64_t *edge_off, const int32_t *eu
         for (int g = 0; g < ngraph; g++) {
             const SqMatchJob &J = G.jobs[g];
             const int32_t *mate = out + J.out_off, *mord = mate + J.n;
-            if (J.n > 0 && mate[0] == -2) { sq_set_error("blossom capacity exceeded"); return -3; }
+            if (J.n > 0 && mate[0] == -2) { sq_set_capacity_error(SQ_CAP_FIXED, "blossom capacity exceeded"); return -3; }
             ps.clear();
             // networkx hands every pair out as (u, v) with u the endpoint that entered its `mate` dict first
             // (matching_dict_to_set); Edmonds() then sorts the tuples (SQRNalgos.py:109)

@@ -260,6 +260,8 @@ struct CpuScope {
     ~CpuScope() { if (g_cpuacc_on) g_cpuacc[k] += now() - t0; }
 };
 void sq_set_error(const std::string &msg);
+// a status -3: WHICH capacity of the batch did not hold the fold (SQ_CAP_* of include/squarna_hip.h; read back by sq_last_capacity)
+void sq_set_capacity_error(int kind, const std::string &msg);
 // pinned (mapped, coherent) host buffers from a small process-wide cache: hipHostMalloc / hipHostFree cost milliseconds,
 // and a caller that builds one batch per call (Predict) would pay them every time
 int sq_pinned_get(void **p, size_t bytes);     // 0 or an error code (message set)

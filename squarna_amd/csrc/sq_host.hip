@@ -9,7 +9,10 @@ bool g_cpuacc_on = getenv("SQ_CPUACC") != nullptr;
 
 // host phase timers (printed to stderr when SQ_TIMING is set)
 thread_local double g_t[8];
-void sq_set_error(const std::string &msg) { g_err = msg; }
+static thread_local int g_cap_kind = 0;
+void sq_set_error(const std::string &msg) { g_err = msg; g_cap_kind = 0; }
+void sq_set_capacity_error(int kind, const std::string &msg) { g_err = msg; g_cap_kind = kind; }
+extern "C" int sq_last_capacity(void) { return g_cap_kind; }
 int sq_check(hipError_t e, const char *what)
 {
     if (e == hipSuccess) return 0;

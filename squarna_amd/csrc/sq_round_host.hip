@@ -416,8 +416,8 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
     { const int wr = sq_wait_word(b, ln.h_seq, seq, st, "round kernels"); if (wr) return wr; }
     if (g_cpuacc_on) g_cpuacc[6] += CpuScope::now() - cpu_t0;
     const SqCounters ctr = *ln.h_ctr;
-    if (ctr.cand_ovf) { sq_set_error("candidate capacity exceeded (raise cand_per_nt)"); return -3; }
-    if (ctr.out_ovf) { ln.out_ovf_seen = true; sq_set_error("round output capacity exceeded (lower max_structs)"); return -3; }
+    if (ctr.cand_ovf) { sq_set_capacity_error(SQ_CAP_CANDIDATES, "candidate capacity exceeded (raise cand_per_nt)"); return -3; }
+    if (ctr.out_ovf) { ln.out_ovf_seen = true; sq_set_capacity_error(SQ_CAP_OUTPUT, "round output capacity exceeded (the records of a round: grows with cand_per_nt)"); return -3; }
     if (ctr.level_ovf) { sq_set_error("more than 64 pseudoknot levels"); return -3; }
     const uint32_t nout = ctr.nout;
     const SqOut *ho = ln.h_out;
@@ -511,7 +511,7 @@ int sq_round_annotate_dev(sq_batch *b, const std::vector<int> &jobs, SqAlgoSize 
     HIPCK(hipGetLastError());
     { const int wr = sq_wait_word(b, ln.h_seq, seq, st, "AnnotateStems round"); if (wr) return wr; }
     const SqCounters ctr = *ln.h_ctr;
-    if (ctr.cand_ovf) { sq_set_error("candidate capacity exceeded (raise cand_per_nt)"); return -3; }
+    if (ctr.cand_ovf) { sq_set_capacity_error(SQ_CAP_CANDIDATES, "candidate capacity exceeded (raise cand_per_nt)"); return -3; }
     return 0;
 }
 

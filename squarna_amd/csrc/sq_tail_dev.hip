@@ -945,13 +945,13 @@ int sq_tail_device(sq_batch *b, const sq_fold_opts &o, const int32_t *ref_off, c
         if (sq_check(hipGetLastError(), "device tail launch")) return 2;
         r = tail_wait(b, ln, seq, "device tail (records)");
         if (r) return r;
-        if (b->h_tail_totals[6]) { sq_set_error("the log of final structures overflowed (raise max_structs)"); return -3; }
+        if (b->h_tail_totals[6]) { sq_set_capacity_error(SQ_CAP_STRUCTS, "the log of final structures overflowed (raise max_structs)"); return -3; }
         if (b->h_tail_totals[2]) return 1;                              // some sequence needs the host tail
         packed = !b->h_tail_totals[5];
     } else {
         r = tail_wait(b, ln, seq, "device tail (ranking)");
         if (r) return r;
-        if (b->h_tail_totals[6]) { sq_set_error("the log of final structures overflowed (raise max_structs)"); return -3; }
+        if (b->h_tail_totals[6]) { sq_set_capacity_error(SQ_CAP_STRUCTS, "the log of final structures overflowed (raise max_structs)"); return -3; }
         if (b->h_tail_totals[2]) return 1;
     }
     const size_t rec_bytes = (size_t)b->h_tail_totals[0], txt_bytes = (size_t)b->h_tail_totals[1];

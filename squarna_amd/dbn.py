@@ -96,18 +96,21 @@ def gap_mask(seq):
     return _GAP_LUT[np.frombuffer(seq.encode('latin-1', 'replace'), np.uint8)]
 
 
-_ALN_PAIRS = [None, None, None]     # the line DBNToPairs was last asked for by UnAlign, and its pairs as two arrays
+_ALN_PAIRS = (None, None, None)     # the line DBNToPairs was last asked for by UnAlign, and its pairs as two arrays
 
 
 def _aligned_pairs(dbn):
-    """DBNToPairs(dbn) as (v, w) arrays; the last line is remembered -- the rows of an alignment share one restraint line."""
+    """DBNToPairs(dbn) as (v, w) arrays; the last line is remembered -- the rows of an alignment share one restraint line.
+    (ONE tuple, replaced by one assignment: threads that prepare batches side by side each see a whole entry.)"""
     import numpy as np
-    if _ALN_PAIRS[0] != dbn:
+    global _ALN_PAIRS
+    line, v, w = _ALN_PAIRS
+    if line != dbn:
         pairs = DBNToPairs(dbn)
-        _ALN_PAIRS[1] = np.array([p[0] for p in pairs], np.int64)
-        _ALN_PAIRS[2] = np.array([p[1] for p in pairs], np.int64)
-        _ALN_PAIRS[0] = dbn
-    return _ALN_PAIRS[1], _ALN_PAIRS[2]
+        v = np.array([p[0] for p in pairs], np.int64)
+        w = np.array([p[1] for p in pairs], np.int64)
+        _ALN_PAIRS = (dbn, v, w)
+    return v, w
 
 
 def UnAlign(seq, dbn, want_pairs=False):

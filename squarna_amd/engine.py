@@ -918,6 +918,18 @@ class HipEngine:
         b.limit_results(keep)
         return b, opts
 
+    def _fits_device(self, records, slots_hint, opts, grow):
+        """Whether a batch of these records with its capacities grown by `grow` still fits the free device memory (half of
+        it: the fold's scratch and the caller's tensors live there too)."""
+        import torch
+        n = max((len(r[0]) for r in records), default=1)
+        njobs = sum(len(r[4]) for r in records)
+        structs = (self.max_structs if self.max_structs else max(4096, min(4 * njobs, 262144))) * grow[1]
+        per_slot = 8 * (n + 34) + 72 * (n // 2 + 1) + 2600                 # (pool_slot_cap's figure)
+        cand = max(self.cand_per_nt, 32) * grow[0] * n * 32.0              # candidate records of a structure, 32 bytes each
+        free = torch.cuda.mem_get_info()[0]
+        return structs * per_slot + min(structs, 4 * njobs) * cand <= free // 2
+
     def _fold_groups(self, groups, hints, opts):
         """Folds every group of records as one batch, all of them at the same time; ([results], [reference scores]) per
         group.  One group with SQ_ENGINE_LANES=2 and a big input: cut into two concurrent batches (for one-shot calls
@@ -955,10 +967,16 @@ class HipEngine:
                         fold_concurrently(batches, **fold_opts)
                     break
                 except _lib.CapacityError as e:
-                    which = 1 if "max_structs" in str(e) else (0 if "cand_per_nt" in str(e) else None)
+                    # which capacity, from the library's own code (sq_last_capacity): candidate records and a round's output
+                    # records grow with cand_per_nt, the log of final structures with max_structs; a fixed limit is raised.
+                    # The growth stops where the batch would no longer fit the device: the ORIGINAL error is raised then, not
+                    # an allocation failure
+                    which = {_lib.CAP_CANDIDATES: 0, _lib.CAP_OUTPUT: 0, _lib.CAP_STRUCTS: 1}.get(e.kind)
                     if which is None or attempt == 7:
                         raise
                     grow[which] *= 4
+                    if not all(self._fits_device(recs, hint, opts, tuple(grow)) for recs, hint in zip(groups, hints)):
+                        raise
                     self.capacity_retries = getattr(self, "capacity_retries", 0) + 1
                     for b in batches:
                         b.close()
