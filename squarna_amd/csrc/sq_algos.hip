@@ -429,8 +429,23 @@ static int algo_collect(sq_batch *b, const std::vector<int> &jobs, const std::ve
     std::vector<std::vector<double>> dense(mj.size());
     for (size_t q = 0; q < mj.size(); q++) {
         const SqJob &J = b->jobs[jobs[ck.k0 + q]];
-        if (J.mat64_off < 0) continue;
+        if (J.mat64_off < 0 && !J.mulsh) continue;
         dense[q].resize((size_t)J.n * J.n);
+        if (J.mulsh) {
+            // an alignment's row (weights read through the gap map from the shared matrix, no slice of its own): its slice for
+            // the host's filters, gathered into a buffer of this call
+            double *tmp = nullptr; int32_t *d_j = nullptr;
+            const int32_t jid = jobs[ck.k0 + q];
+            HIPCK(hipMalloc((void **)&tmp, dense[q].size() * 8 + 256));
+            d_j = (int32_t *)((char *)tmp + dense[q].size() * 8);
+            HIPCK(hipMemcpy(d_j, &jid, 4, hipMemcpyHostToDevice));
+            sq_launch_gather_mul(b->ctx, d_j, 1, J.n, b->stream, tmp);
+            const hipError_t ge = hipStreamSynchronize(b->stream);
+            if (ge == hipSuccess) hipMemcpy(dense[q].data(), tmp, dense[q].size() * 8, hipMemcpyDeviceToHost);
+            hipFree(tmp);
+            HIPCK(ge);
+            continue;
+        }
         HIPCK(hipMemcpy(dense[q].data(), b->ctx.mat64 + J.mat64_off, dense[q].size() * 8, hipMemcpyDeviceToHost));
     }
     std::atomic<int> bad{0}, stream_err{0};
@@ -640,7 +655,7 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
                 // Edmonds / Hungarian weigh an edge with stemscore ** 1.7 from the host libm: on the device that is a table
                 // lookup when the score is k 2^-q exactly (dyadic weights, no reactivity factors); the other jobs -- decided
                 // per JOB -- leave their stem scores in pinned memory and the host raises them in bulk (SqAlgoRaw)
-                if (J.mat64_off >= 0) return 1;
+                if (J.mat64_off >= 0 || J.mulsh) return 1;
                 if (!J.default_reacts || b->psets_dev[J.pset].pow_len <= 0) { nr = 1; raw_cap += (size_t)4 * J.n + 64; }
             }
             all.push_back(j);

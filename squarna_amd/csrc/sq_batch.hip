@@ -75,6 +75,8 @@ struct Layout {
            off_t_rep, off_t_mask, off_t_scores, off_t_dlist, off_t_rlist, off_t_seqs, off_t_refp, off_t_refn, off_t_pow;
     uint32_t fin_cap, fin_stem_cap; int32_t pow_len;
     size_t off_mulcols;              // alignment columns of every position (shared L x L weighting matrix), else unused
+    size_t off_mulM;                 // the shared weighting matrix, diagonal-major (sq_gather.hip)
+    bool mul_direct;                 // jobs weighted by the shared matrix read it through the gap map; false (SQ_MUL_GATHER=1): per-job slices
     size_t off_algo, algo_bytes;     // scratch of the Hungarian / Nussinov kernels (Edmonds borrows the end of the candidate arena)
     int32_t pool_pt;                 // stems per slot (0: no device pools for this batch)
     int64_t chain_T;                 // summed stem capacity of all jobs
@@ -94,6 +96,8 @@ int plan(const sq_batch_desc *d, Layout &L)
     L.max_structs = d->max_structs > 0 ? d->max_structs : 4096;
     L.cpn = d->cand_per_nt > 0 ? d->cand_per_nt : 32;
     L.mat32_floats = 0; L.mat64_doubles = 0; L.bits_words = 0;
+    L.mul_direct = d->mul_matrix_dev != nullptr && getenv("SQ_MUL_GATHER") == nullptr;
+    int64_t sum_cap = 0;
     for (int j = 0; j < d->njobs; j++) {
         const int s = d->job_seq[j];
         if (s < 0 || s >= d->nseq || d->job_pset[j] < 0 || d->job_pset[j] >= d->npset) { sq_set_error("bad job"); return -1; }
@@ -105,7 +109,8 @@ int plan(const sq_batch_desc *d, Layout &L)
         if (want_fp32(d) || (ext_any && !shared_only)) L.mat32_floats += (int64_t)align_up((size_t)(n * ld_of((int)n)), 64);
         L.bits_words += (int64_t)bits_nw((int)n) * bits_pitch((int)n);
         const bool ext = d->ext_score && d->ext_score[j];
-        const bool mul = (d->mul_score && d->mul_score[j]) || (d->bpp_term && d->bpp_term[j]) || (d->mul_shared && d->mul_shared[j]);
+        const bool mul = (d->mul_score && d->mul_score[j]) || (d->bpp_term && d->bpp_term[j]) ||
+                         (d->mul_shared && d->mul_shared[j] && !L.mul_direct);
         if (ext) L.mat64_doubles += 2 * n * n;
         else if (mul) L.mat64_doubles += n * n;
     }
@@ -125,10 +130,15 @@ int plan(const sq_batch_desc *d, Layout &L)
         for (int j = 0; j < d->njobs; j++) {
             const int sq = d->job_seq[j];
             const double nn = d->seq_off[sq + 1] - d->seq_off[sq];
-            maxcap = std::max<int64_t>(maxcap, (int64_t)(0.117 * nn * nn * runs[d->job_pset[j]] * 1.6 + 256));
+            const int64_t cj = (int64_t)(0.117 * nn * nn * runs[d->job_pset[j]] * 1.6 + 256);
+            maxcap = std::max<int64_t>(maxcap, cj);
+            sum_cap += std::max<int64_t>(cj, (int64_t)L.cpn * (int64_t)nn);
         }
     }
     L.cand_records = std::min<int64_t>((int64_t)L.max_structs * maxcap, (int64_t)160 << 20);   // (5 GiB of 32-byte records at most)
+    // ... unless ONE structure per job needs more: the rows of a long alignment (512 x 4,700 nt: 50 MB of run records each) fold
+    // as chains of ONE launch when the arena holds them all -- five launches of a fifth of the chip's blocks otherwise (40 GiB at most)
+    if (d->mul_matrix_dev && L.mul_direct) L.cand_records = std::max<int64_t>(L.cand_records, std::min<int64_t>(sum_cap, (int64_t)1280 << 20));
     L.cand_records = std::max<int64_t>(L.cand_records, maxcap);
     // the dense fp64 read-back (sq_bpmatrix_read) borrows the candidate arena
     L.cand_records = std::max<int64_t>(L.cand_records, (int64_t)(2 * (int64_t)L.maxn * L.maxn * 8 / sizeof(SqCand)) + 16);
@@ -232,6 +242,7 @@ int plan(const sq_batch_desc *d, Layout &L)
         L.off_t_pow = take(8 * (size_t)L.pow_len);
     }
     L.off_mulcols = take(d->mul_matrix_dev ? 4 * (size_t)L.ltot : 0);
+    L.off_mulM = take(d->mul_matrix_dev ? 8 * (size_t)d->mul_L * (size_t)d->mul_L : 0);
     // Hungarian and Nussinov: their scratch (n x n tables) is known from the lengths, so they get room of their own and
     // always run beside the greedy rounds (16 GB at most; what does not fit borrows from the candidate arena like Edmonds)
     {
@@ -519,12 +530,13 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         }
         const bool term = d->bpp_term && d->bpp_term[j];
         const bool shared = d->mul_shared && d->mul_shared[j];
-        const bool mul = (d->mul_score && d->mul_score[j]) || term || shared;
+        J.mulsh = (shared && !ext && L.mul_direct) ? 1 : 0;
+        const bool mul = (d->mul_score && d->mul_score[j]) || term || (shared && !J.mulsh);
         J.ext_add = term && d->psets[J.pset].bpp < 0 ? 1 : 0;
         if (ext) { J.mat64_off = m64; J.has_ext = 1; m64 += 2 * (int64_t)J.n * J.n; }
         else if (mul) { J.mat64_off = m64; J.has_ext = 2; m64 += (int64_t)J.n * J.n; }
         J.mat_off = -1;
-        J.mat64_diag = (shared && !ext) ? 1 : 0;          // the gather kernel writes score x weight, diagonal-major (sq_cells.h)
+        J.mat64_diag = (shared && !ext && !J.mulsh) ? 1 : 0;   // SQ_MUL_GATHER=1: the gather kernel writes score x weight, diagonal-major (sq_cells.h)
         if (b->has_fp32 || (J.has_ext && !J.mat64_diag)) { J.mat_off = m32; m32 += (int64_t)align_up((size_t)J.n * J.ld, 64); }
         const bool def = seq_def[s] != 0;                 // SQRNdbnseq.py:273
         J.default_reacts = def ? 1 : 0;
@@ -718,18 +730,21 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         }
     }
     if (d->mul_matrix_dev && d->mul_shared) {
-        // jobs weighted by the shared L x L matrix: their N x N slices are gathered on the device through the column maps
+        // jobs weighted by the shared L x L matrix: the kernels read it through the column maps (sq_mulsh_weight) from a
+        // diagonal-major copy; SQ_MUL_GATHER=1: their N x N slices are gathered from it here
         int32_t *d_cols = (int32_t *)(base + L.off_mulcols);
+        b->ctx.mulM = (double *)(base + L.off_mulM); b->ctx.mulcols = d_cols; b->ctx.mulL = d->mul_L;
+        sq_launch_mul_diag((const double *)d->mul_matrix_dev, d->mul_L, (double *)(base + L.off_mulM), st);
         for (int64_t q = 0; q < L.ltot; q++)
             if (d->mul_cols[q] < 0 || d->mul_cols[q] >= d->mul_L) { hipStreamSynchronize(st); delete b; sq_set_error("mul_cols out of range"); return -1; }
         UP(d_cols, d->mul_cols, 4 * (size_t)L.ltot);
         std::vector<int32_t> jl;
-        for (int j = 0; j < d->njobs; j++) if (d->mul_shared[j]) jl.push_back(j);
+        for (int j = 0; j < d->njobs; j++) if (d->mul_shared[j] && !b->jobs[j].mulsh) jl.push_back(j);
         if (!jl.empty()) {
             // (the job list travels in the candidate arena's first bytes: nothing else uses it before the first fold)
             int32_t *d_jl = (int32_t *)(base + L.off_cands);
             UP(d_jl, jl.data(), 4 * jl.size());
-            sq_launch_gather_mul(b->ctx, d->mul_matrix_dev, d->mul_L, d_cols, d_jl, (int)jl.size(), L.maxn, st);
+            sq_launch_gather_mul(b->ctx, d_jl, (int)jl.size(), L.maxn, st);
             if (sq_check(hipGetLastError(), "sq_gather_mul_kernel")) { hipStreamSynchronize(st); delete b; return 2; }
         }
     }

@@ -153,6 +153,27 @@ __device__ __forceinline__ double sq_cellrun_bps(const SqCellEnv &e, const SqDev
         pos = accp;
         return acc;
     }
+    if (jb.mulsh) {
+        // the alignment's rows: cell = score x the shared matrix's cell of the two columns (sq_cells.h), the same product the
+        // gather kernel used to store per job.  The four weights of a step are asked for together
+        const int32_t *cl = c.mulcols + jb.pos_off;
+        const int64_t ml = c.mulL;
+        for (int t = 0; t < L; t += 4) {
+            double w[4], v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int tt = t + k < L ? t + k : L - 1; w[k] = c.mulM[sq_diag_index(ml, cl[i0 + tt], cl[j0 - tt])]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int tt = t + k < L ? t + k : L - 1; v[k] = sq_cellrun_exact(e, c, jb, i0 + tt, j0 - tt) * w[k]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const double x = t + k < L ? v[k] : 0.0;
+                acc = acc + x;
+                if (POS) accp = accp + (x > 0.0 ? x : 0.0);
+            }
+        }
+        pos = accp;
+        return acc;
+    }
     for (int t = 0; t < L; t += 4) {
         double v[4];
         if (e.cell_tab && j0 - t >= 3) {

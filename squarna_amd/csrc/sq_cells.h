@@ -8,14 +8,28 @@
 // matrix (mat64_diag) -- DIAGONAL-major: the cells of anti-diagonal s = i + j are contiguous, ordered by i.  The cells of a
 // stem (i + k, j - k) then lie next to each other: the scoring kernel sums them with consecutive reads instead of reads
 // N - 1 doubles apart (alignment step 2 on 4,500-nt sequences: every cell a cache line of its own).
-__host__ __device__ __forceinline__ int64_t sq_m64_index(const SqJob &jb, int i, int j)
+__host__ __device__ __forceinline__ int64_t sq_diag_index(int64_t n, int i, int j)
 {
-    const int64_t n = jb.n;
-    if (!jb.mat64_diag) return (int64_t)i * n + j;
     const int64_t s = (int64_t)i + j;
     if (s < n) return s * (s + 1) / 2 + i;                            // diagonals 0 .. s - 1 hold 1 + 2 + .. + s cells
     const int64_t m = 2 * n - 1 - s;                                  // cells on diagonal s (and on every later one: m, m - 1, .. 1)
     return n * n - m * (m + 1) / 2 + (i - (s - (n - 1)));
+}
+__host__ __device__ __forceinline__ int64_t sq_m64_index(const SqJob &jb, int i, int j)
+{
+    const int64_t n = jb.n;
+    if (!jb.mat64_diag) return (int64_t)i * n + j;
+    return sq_diag_index(n, i, j);
+}
+
+// The weight of cell (i, j) of a job whose rows and columns are positions of an alignment's sequence (SqJob::mulsh): the shared
+// stem matrix's cell of the two columns (SQRNdbnseq.py:1031-1034: shortsmat = stemmatrix without the gap rows and columns).
+// The matrix is diagonal-major over the columns: the cells of a stem -- (i + k, j - k) -- are neighbours wherever the
+// sequence has no gap inside the stem, exactly as in the per-job slices the round-3 form materialised.
+__device__ __forceinline__ double sq_mulsh_weight(const SqDevCtx &c, const SqJob &jb, int i, int j)
+{
+    const int32_t *cl = c.mulcols + jb.pos_off;
+    return c.mulM[sq_diag_index(c.mulL, cl[i], cl[j])];
 }
 
 // ------------------------------------------------------------------------------------
@@ -65,6 +79,7 @@ __device__ __forceinline__ double sq_cell_score(const SqDevCtx &c, const SqJob &
 __device__ __forceinline__ double sq_cell_exact(const SqDevCtx &c, const SqJob &jb, const SqPsetDev *ps, int i, int j)
 {
     if (jb.mat64_off >= 0) return c.mat64[jb.mat64_off + sq_m64_index(jb, i, j)];
+    if (jb.mulsh) return sq_cell_score(c, jb, ps, i, j) * sq_mulsh_weight(c, jb, i, j);      // :1084-1085 (a cell whose bool is 1)
     return sq_cell_score(c, jb, ps, i, j);
 }
 

@@ -21,6 +21,9 @@ struct SqDevCtx {
     const uint32_t *rbpk;    // restraint base pairs, v | (w << 16), per sequence (SqJob::rb_off, nrb)
     const double *rftab;     // reactfactor tables, 256 doubles each (SqJob::rf_idx)
     const double *powtab;    // stemscore ** 1.7 tables (SqPsetDev::pow_off)
+    // alignment step 2 (SQRNdbnseq.py:1031-1034,1084-1085): the shared stem matrix, DIAGONAL-major over the alignment's columns
+    // (sq_diag_index(mulL, v, w)), and the column of every position; jobs with SqJob::mulsh read their weights from it
+    const double *mulM; const int32_t *mulcols; int32_t mulL;
 };
 
 struct SqState {             // per-structure-slot arrays, `stride` elements per slot
@@ -264,5 +267,6 @@ __host__ __device__ static inline size_t sq_extend_lds_bytes(int T) { const size
 
 // sq_gather.hip: the N x N weighting slices of the jobs in job_list from ONE shared L x L device matrix through the
 // per-position alignment columns (alignment step 2, SQRNdbnseq.py:1031-1034,1084-1085)
-void sq_launch_gather_mul(const SqDevCtx &c, const double *M, int L, const int32_t *cols, const int32_t *job_list, int njl, int maxn,
-                          hipStream_t st);
+void sq_launch_gather_mul(const SqDevCtx &c, const int32_t *job_list, int njl, int maxn, hipStream_t st, double *dst_one = nullptr);
+// the caller's row-major L x L matrix -> the diagonal-major copy the kernels read (SqDevCtx::mulM)
+void sq_launch_mul_diag(const double *M, int L, double *dst, hipStream_t st);

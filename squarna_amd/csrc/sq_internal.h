@@ -31,6 +31,9 @@ struct SqJob {
                            // sequence's 16 x 16 reactfactors ((1 - (r_a + r_b) / 2) * 2) ** 0.5 evaluated by the HOST's libm
                            // pow, as CPython does (SQRNdbnseq.py:333) -- sqrt differs from it in the last bit now and then
     int32_t mat64_diag;    // the dense fp64 matrix is diagonal-major (sq_m64_index): jobs weighted by the shared stem matrix
+    int32_t mulsh;         // 1: every cell is weighted by the alignment's ONE shared L x L matrix, read through the gap map as it is needed
+                           // (SqDevCtx::mulM / mulcols; no dense matrix of the job exists: mat64_off == -1).  0 with mat64_diag == 1: the
+                           // job's slice of that matrix was materialised (SQ_MUL_GATHER=1, the round-3 form)
     int32_t bits_owner;    // 1: the job's bit matrix is its own (the bit kernels write it); 0: it reads the matrix of an earlier job
                            // of the same sequence whose paramset pairs the same letters (the default configs: one matrix
                            // for a record's five paramsets -- a-1 is 6 % of a crowded step's wave cycles otherwise)

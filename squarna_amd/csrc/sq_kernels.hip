@@ -36,12 +36,12 @@ extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c, int
     const SqJob jb = c.jobs[blockIdx.y];
     if (jb.has_ext == 1) return;                       // imported from caller matrices instead
     if (only_ext && jb.has_ext == 0) return;           // the fold path of such jobs only needs the bit matrix
-    if (only_ext && jb.mat64_diag) return;             // the gather kernel has formed score x weight already (sq_gather.hip)
+    if (only_ext && (jb.mat64_diag || jb.mulsh)) return;   // weighted by the alignment's shared matrix: read through the gap map (sq_cells.h), or gathered (sq_gather.hip)
     const SqPsetDev *ps = c.psets + jb.pset;
     const int n = jb.n, ld = jb.ld;
     float *mat = c.mat32 + jb.mat_off;
     extern __shared__ __attribute__((aligned(16))) char fill_dyn[];
-    if (jb.mat64_off < 0 && n <= SQ_FILL_LDS_N) {
+    if (jb.mat64_off < 0 && !jb.mulsh && n <= SQ_FILL_LDS_N) {
         __shared__ double s_w[32 * 33];                // pair weights, row stride 33: the letters' rows start on different banks
         __shared__ float s_wf[32 * 33];                // (float)weight, or the sentinel where the pair is not in bps
         const int np = (n + 15) & ~15;
@@ -134,6 +134,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_fill_kernel(SqDevCtx c, int
             uint32_t bits = SQ_SENT_BITS;
             if (i < n && j < n && j > i && sq_cell_bool(c, jb, ps, i, j)) {
                 double v = sq_cell_score(c, jb, ps, i, j);
+                if (jb.mulsh) v = v * sq_mulsh_weight(c, jb, i, j);       // :1084-1085 through the gap map
                 if (m64) {                              // :1084-1085 bpscorematrix * shortsmat
                     if (mul_done) v = m64[sq_m64_index(jb, i, j)];          // the arena already holds the product
                     else {                                               // :352-354 bpp term, :1084-1085 stem matrix
@@ -167,6 +168,7 @@ extern "C" __global__ __launch_bounds__(256) void sq_dense64_kernel(SqDevCtx c, 
         if (j > i && sq_cell_bool(c, jb, ps, i, j)) {
             b = 1.0;
             s = sq_cell_score(c, jb, ps, i, j);
+            if (jb.mulsh) s = s * sq_mulsh_weight(c, jb, i, j);           // :1084-1085
         }
         boolmat[q] = b;
         scoremat[q] = s;
@@ -715,7 +717,7 @@ __device__ __forceinline__ void sq_score_body(const SqDevCtx &c, const SqStruct 
         for (int q = tid; q < nw2; q += nthr) { wP[q] = gP[q]; wU[q] = gU[q]; wS[q] = gS[q]; }
         P = lP; U = lU; SU = lSU;
     }
-    const bool lds_cells = jb.mat64_off < 0 && lds_n >= n;
+    const bool lds_cells = jb.mat64_off < 0 && !jb.mulsh && lds_n >= n;
     const bool any_reacts = lds_cells && !jb.default_reacts;
     // classes of the letters: K pairing letters + one class for everything else.  lmask: bit a set iff letter a has a
     // pair in the paramset (row a of inbps is not all zero) -- the first 32 threads test a row each, one ballot

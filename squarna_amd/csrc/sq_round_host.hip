@@ -386,7 +386,7 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
             int64_t maxcap = 1;
             for (int k = 0; k < S && order_free; k++) {
                 const SqJob &J = b->jobs[structs[lo + k].job];
-                order_free = J.default_reacts && J.mat64_off < 0 && b->pset_dyadic[J.pset];
+                order_free = J.default_reacts && J.mat64_off < 0 && !J.mulsh && b->pset_dyadic[J.pset];
                 maxcap = std::max<int64_t>(maxcap, J.cand_cap);
             }
             if (order_free) {

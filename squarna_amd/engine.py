@@ -763,9 +763,21 @@ def pool_slots_wanted(ngreedy, poollim, n=None):
     return int(ngreedy) * per_job
 
 
-def pool_slots_wanted_many(lengths, psets_per_record, poollim):
+def _shared_weights(records):
+    """The records are an alignment's rows weighted by ONE device matrix (alignment step 2)."""
+    sm0 = records[0][5] if records and len(records[0]) > 5 else None
+    return sm0 is not None and hasattr(sm0, "is_cuda") and sm0.is_cuda and all(len(r) > 5 and r[5] is sm0 for r in records)
+
+
+def pool_slots_wanted_many(lengths, psets_per_record, poollim, rarely_branch=False):
     """pool_slots_wanted for every record of a batch (numpy array): the greedy-job count per distinct paramset list is
-    counted once (the records of an input usually share one list), the per-length part is vectorised."""
+    counted once (the records of an input usually share one list), the per-length part is vectorised.
+    rarely_branch: the rows of an alignment under paramsets whose range factor is 1.0 -- their pools branch only at exact
+    ties that share a base (SQRNdbnseq.py:769-789), the weights of a stem matrix make those rare, and the library folds such
+    jobs as chains first (sq_fold.hip): sixteen slots per job (a fold that outgrows them is repeated by the host loop)."""
+    if rarely_branch and all(ps["suboptmin"] == 1.0 and ps["suboptmax"] == 1.0 for pl in {id(p): p for p in psets_per_record}.values()
+                             for ps in pl if "G" in ps["algorithms"]):
+        return np.array([16 * sum(1 for ps in pl if "G" in ps["algorithms"]) for pl in psets_per_record], np.int64)
     ng_of, ng = {}, np.empty(len(psets_per_record), np.int64)
     for k, pl in enumerate(psets_per_record):
         v = ng_of.get(id(pl))
@@ -815,7 +827,7 @@ class HipEngine:
             # wide pools: as many records per batch as the device pools have slots for (a fold that outgrows them is
             # repeated by the library's host loop -- correct, but several times slower)
             lens = [len(r[0]) for r in records]
-            per_rec = pool_slots_wanted_many(lens, [r[4] for r in records], poollim)
+            per_rec = pool_slots_wanted_many(lens, [r[4] for r in records], poollim, rarely_branch=_shared_weights(records))
             cap = pool_slot_cap(max(lens))
             if int(per_rec.sum()) > cap:
                 return self._fold_in_sub_batches(records, per_rec.tolist(), cap, opts)
@@ -832,7 +844,10 @@ class HipEngine:
         out, refs, lo, scale = [], [], 0, 1.0
         # dense per-job matrices (alignment step 2: N x N fp64 + fp32 per job) bound a sub-batch as well: 32 GB of them
         # (allocating and touching 100 GB per batch costs more than the larger rounds save)
-        dense = [12.0 * len(r[0]) ** 2 * len(r[4]) if len(r) > 5 and r[5] is not None else 0.0 for r in records]
+        # (not the rows of an alignment weighted by ONE device matrix: the kernels read it through the gap map, no slice exists --
+        # unless SQ_MUL_GATHER=1 asks for the round-3 form)
+        direct = _shared_weights(records) and "SQ_MUL_GATHER" not in os.environ
+        dense = [12.0 * len(r[0]) ** 2 * len(r[4]) if len(r) > 5 and r[5] is not None and not direct else 0.0 for r in records]
         dense_cap = float(os.environ.get("SQ_DENSE_GB", "32")) * 1e9
         if sum(dense) > dense_cap:
             # sub-batches of equal weight (a last one of a few records would run its rounds on a mostly empty chip)
@@ -904,7 +919,7 @@ class HipEngine:
         max_structs = self.max_structs if self.max_structs else max(4096, min(4 * njobs, 262144))
         if not self.max_structs and opts.get("poollim", 1000) > 1:
             want = slots_hint if slots_hint else int(pool_slots_wanted_many(
-                [len(p.shortseq) for p in prepared], psets, opts.get("poollim", 1000)).sum())
+                [len(p.shortseq) for p in prepared], psets, opts.get("poollim", 1000), rarely_branch=_shared_weights(records)).sum())
             max_structs = max(max_structs, min(want, pool_slot_cap(max(len(p.shortseq) for p in prepared))))
         cand = self.cand_per_nt
         if grow[0] > 1:
