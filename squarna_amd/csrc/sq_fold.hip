@@ -416,9 +416,18 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             while (!thr_env && thr < SQ_ROUNDS_THREADS && thr < maxn / 2 && ((int64_t)S * thr * 2 <= (int64_t)256 * 512 || (S <= 256 && thr * 2 <= maxn / 2 + 64))) thr *= 2;
             if (thr_env) { thr = 64; while (thr * 2 <= thr_env) thr *= 2; }   // (a power of two: the survivor ring is indexed with a mask)
             ra.lds_n = maxn; ra.str_cap = 2 * maxt + 2; ra.tmax = maxt; ra.cell_entries = b->cell_entries;
-            ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0; ra.ties = chain_ties ? 1 : 0;
             ra.su = 0;
             for (int j : jobs) if (b->seq_has_sep[(size_t)b->job_seq[j]]) { ra.su = 1; break; }
+            // (long sequences: the per-position arrays and strand lists of ONE block fill most of a CU's LDS -- 90 KB at 4,700 nt --, so
+            // the CU holds one block however many there are: it takes the wave slots the others cannot use.  512 rows of an
+            // alignment ran as 512 blocks of four waves on 256 CUs)
+            while (!thr_env && thr < SQ_ROUNDS_THREADS && thr < maxn / 2) {
+                const size_t l1 = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr, ra.su).total + 2048;
+                const size_t l2 = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, 2 * thr, ra.su).total + 2048;
+                const size_t cu = 160 * 1024, r1 = std::min<size_t>(cu / l1 * thr, 1024), r2 = l2 <= 158 * 1024 ? std::min<size_t>(cu / l2 * 2 * thr, 1024) : 0;
+                if (r2 > r1) thr *= 2; else break;
+            }
+            ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0; ra.ties = chain_ties ? 1 : 0;
             ra.fly = 0;
             while (thr > 64 && sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr, ra.su).total + 2048 > 158 * 1024) thr /= 2;   // (long sequences: the survivor ring gives way)
             if (sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr, ra.su).total + 2048 > 158 * 1024) rounds_ok = false;

@@ -30,6 +30,7 @@ struct SqRunB {
 #define SQ_RX_LEN 0xFFFFu
 #define SQ_RX_UB 0x10000u
 #define SQ_RX_FIN 0x20000u
+#define SQ_RX_LVL 0x40000u         // the kept finalscore counted bracket strands: it reads the levels, a round that renumbers them voids it
 
 #define SQ_ROUNDS_SDF_LDS 128      // entries of the distance-factor table kept in LDS
 #define SQ_RQ_CAP 192              // entries of each of a wave's three work queues (cut / bound / score): a queue is served when it holds 64

@@ -60,9 +60,19 @@ struct SqRoundsSink {
 };
 
 // The two strands of a new stem k = (i0, j0, len) into the sorted strand list S[0 .. nstrand) (+ the stem index of each
-// strand, X), IN PLACE, by one wave: every strand moves up by the number of new strands that start before it (0, 1 or 2), the
-// chunks of 64 taken from the top so that nothing is overwritten before it is read; levels from L.lvl when stems cross.
-__device__ __forceinline__ void sq_rounds_insert_strands(SqExtendLds &L, bool anycross, int k, SqStrand *S, int16_t *X, int nstrand,
+// strand, X, and its skip pointer, K), IN PLACE, by one wave: every strand moves up by the number of new strands that start
+// before it (0, 1 or 2), the chunks of 64 taken from the top so that nothing is overwritten before it is read; levels from
+// L.lvl when stems cross.
+//
+// Skip pointers (ScoreStems' walk jumps over a block it has registered): K[q] of a 5' strand q with partner end pf is the first
+// strand behind q that starts beyond pf or is a 5' strand whose partner lies beyond pf; q + 1 for a 3' strand.  Until round 6 the
+// first wave took them anew every round -- a lane per strand walking its block, as long as the longest block: most of the 340 us
+// the extension took per round on structures of 700 strands.  They are MAINTAINED now: the old strands keep their starts and
+// partners, so an old pointer still names the first old strand that ends the block; it moves up with that strand, and only a
+// new strand that lands inside the block and ends it -- the 5' strand when the new stem's partner end lies beyond pf, the 3'
+// strand when it starts beyond pf -- comes in front of it.  The new 5' strand's own pointer: a walk that jumps along the
+// others' pointers (a strand that does not end its block ends nothing inside its own either).
+__device__ __forceinline__ void sq_rounds_insert_strands(SqExtendLds &L, bool anycross, int k, SqStrand *S, int16_t *X, uint16_t *K, int nstrand,
                                                          int i0, int j0, int len, int lane)
 {
     const int ls = i0, rs = j0 - len + 1;                               // starts of the 5' and the 3' strand (ls < rs)
@@ -72,24 +82,46 @@ __device__ __forceinline__ void sq_rounds_insert_strands(SqExtendLds &L, bool an
         const int st = q < nstrand ? S[q].start : 0x7fff;
         below_l += __popcll(__ballot(st < ls)); below_r += __popcll(__ballot(st < rs));
     }
+    const int ia = below_l, ib = below_r + 1;                           // where the new strands go
     for (int q0 = ((nstrand + 63) & ~63) - 64; q0 >= 0; q0 -= 64) {
         const int q = q0 + lane;
         const bool valid = q < nstrand;
         SqStrand x = valid ? S[q] : SqStrand{0, 0, 0, 0, 0};
         const int sx = valid ? X[q] : 0;
+        const int zo = valid ? (int)K[q] : 0;
         sq_wave_lds_fence();                                            // (the whole chunk is read before any of it moves)
         if (valid) {
             if (anycross) x.level = L.lvl[sx];
-            const int at = q + (x.start < ls ? 0 : 1) + (x.start < rs ? 0 : 1);
-            S[at] = x; X[at] = (int16_t)sx;
+            const int at = q + (q >= below_l ? 1 : 0) + (q >= below_r ? 1 : 0);
+            int z = at + 1;
+            if (x.left) {
+                const int pf = x.pstart;
+                z = zo + (zo >= below_l ? 1 : 0) + (zo >= below_r ? 1 : 0);     // (old strands [0, below) start in front of the new one)
+                if (ib > at && ib < z && rs > pf) z = ib;
+                if (ia > at && ia < z && j0 > pf) z = ia;
+            }
+            S[at] = x; X[at] = (int16_t)sx; K[at] = (uint16_t)z;
         }
         sq_wave_lds_fence();
     }
     if (lane == 0) {
         const uint8_t lv = anycross ? L.lvl[k] : (uint8_t)1;
-        S[below_l] = SqStrand{(int16_t)ls, (int16_t)len, (int16_t)j0, lv, 1};
-        S[below_r + 1] = SqStrand{(int16_t)rs, (int16_t)len, (int16_t)(i0 + len - 1), lv, 0};
-        X[below_l] = (int16_t)k; X[below_r + 1] = (int16_t)k;
+        S[ia] = SqStrand{(int16_t)ls, (int16_t)len, (int16_t)j0, lv, 1};
+        S[ib] = SqStrand{(int16_t)rs, (int16_t)len, (int16_t)(i0 + len - 1), lv, 0};
+        X[ia] = (int16_t)k; X[ib] = (int16_t)k;
+        K[ib] = (uint16_t)(ib + 1);
+    }
+    sq_wave_lds_fence();
+    // the new 5' strand's pointer
+    {
+        const int ns2 = nstrand + 2;
+        int z = ia + 1;
+        while (z < ns2) {
+            const SqStrand y = S[z];
+            if (y.start > j0 || (y.left && y.pstart > j0)) break;
+            z = y.left ? (int)K[z] : z + 1;
+        }
+        if (lane == 0) K[ia] = (uint16_t)z;
     }
 }
 
@@ -115,10 +147,11 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     // bound / score steps, pick, extension + state
     long long _pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
     long long _cnt[4] = {0, 0, 0, 0};       // entries streamed, finalscores taken from the list, runs scored (first wave), rounds
+    long long _xt[4] = {0, 0, 0, 0};        // the extension: levels, full rule / joins; strands + skip pointers; [3] rounds with the full rule
     long long _sp[6] = {0, 0, 0, 0, 0, 0};  // the score step: [0] wait for the structure, [1] entry loads, [3] the rest; [4] steps
 #define SPROF(k) do { const long long _n = wall_clock64(); _sp[k] += _n - _t2; _t2 = _n; } while (0)
 #define RPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)
-#define RPROF_OUT() do { if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d score steps %lld | us: wait for the structure %.1f entry loads %.1f ScoreStems + stores + pick %.1f\n", b, wv, _sp[4], _sp[0] * 0.01, _sp[1] * 0.01, _sp[3] * 0.01); if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d n=%d rounds %lld | us: setup %.1f scan %.1f order %.1f stream %.1f cut %.1f bound %.1f score %.1f pick %.1f ext %.1f between %.1f total %.1f | wave 0: streamed %lld kept %lld scored %lld\n", \
+#define RPROF_OUT() do { if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d extension us: levels %.1f (%lld rounds with the full rule) strands + skip pointers %.1f\n", b, wv, _xt[0] * 0.01, _xt[3], _xt[1] * 0.01); if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d score steps %lld | us: wait for the structure %.1f entry loads %.1f ScoreStems + stores + pick %.1f\n", b, wv, _sp[4], _sp[0] * 0.01, _sp[1] * 0.01, _sp[3] * 0.01); if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d n=%d rounds %lld | us: setup %.1f scan %.1f order %.1f stream %.1f cut %.1f bound %.1f score %.1f pick %.1f ext %.1f between %.1f total %.1f | wave 0: streamed %lld kept %lld scored %lld\n", \
         b, wv, n, _cnt[3], _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, _pt[6] * 0.01, _pt[7] * 0.01, _pt[8] * 0.01, _pt[9] * 0.01, (wall_clock64() - _t00) * 0.01, _cnt[0], _cnt[1], _cnt[2]); } while (0)
 #else
 #define RPROF(k) do {} while (0)
@@ -465,7 +498,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
             // rows [i, sa] or columns [sb, j] meet a strand of the new stem: the run is cut.  A strand within six positions of
             // the run's span: the finalscore is void; within six of its four ends: the bound too
             const int nocut = SQ_OV(za0, za1, i, sa) & SQ_OV(zb0, zb1, i, sa) & SQ_OV(za0, za1, sb, j) & SQ_OV(zb0, zb1, sb, j);
-            const int nofd = SQ_OV(za0, za1, i - 6, j + 6) & SQ_OV(zb0, zb1, i - 6, j + 6) & rgmask;
+            const int nofd = SQ_OV(za0, za1, i - 6, j + 6) & SQ_OV(zb0, zb1, i - 6, j + 6) & (rgmask | ((r.lf & SQ_RX_LVL) ? 0 : -1));
             const int noud = SQ_OV(za0, za1, i - 6, sa + 6) & SQ_OV(zb0, zb1, i - 6, sa + 6) & SQ_OV(za0, za1, sb - 6, j + 6) & SQ_OV(zb0, zb1, sb - 6, j + 6);
 #undef SQ_OV
             const uint32_t fdm = ~(uint32_t)(nofd >> 31), udm = ~(uint32_t)(noud >> 31);   // all ones: void
@@ -537,7 +570,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                     raise(c0.mine | c1.mine, f0 > f1 ? f0 : f1);
                 }
 #ifdef SQ_ROUNDS_PROF
-                if (lane == 0) { _cnt[0] += 128; _cnt[1] += __popcll(__ballot(c0.mine)) + __popcll(__ballot(c1.mine)); }
+                { const int km = __popcll(__ballot(c0.mine)) + __popcll(__ballot(c1.mine)); _cnt[0] += 128; _cnt[1] += km; }   // (every lane counts: the ballots are the wave's)
 #endif
                 push2(qcut, nX, c0.cut, q0, c1.cut, q1);
                 push2(qcand, nC, d0, q0, d1, q1);
@@ -571,18 +604,21 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
 #endif
                 bool ok = have && !(ub < need);                                 // (the bar may have risen since the run was queued)
 #ifdef SQ_ROUNDS_PROF
-                if (lane == 0) _cnt[2] += __popcll(__ballot(ok));
+                _cnt[2] += __popcll(__ballot(ok));
 #endif
                 double fin = 0.0;
                 const int L = (int)(lf & SQ_RX_LEN);
                 const int i0 = (int)(key & 0xFFFFu), j0 = (int)(key >> 16) - i0;
-                // (a strand per lane for ONE run at a time -- the walk's inblockend is a running maximum, so a wave can take the
-                // strands of a span as a prefix-maximum scan -- was built for the handful of runs a pass ends with and measured:
-                // 0.5-1 us per run against 5-9 us for a wave of runs walked side by side; a pass ends with more than a handful,
-                // S2000 x 125 2.95 -> 3.09 ms: dropped)
-                if (ok) fin = sq_stem_finalscore(env, i0, j0, L, bps);
+                // (the whole wave on ONE run at a time, a strand per lane with a DPP prefix-maximum scan over the partner ends,
+                // was built again in round 6, also as a probe that raises the bar before the others are walked:
+                // 4-5 us per run on structures of 700 strands against ~1 us per run for 64 runs side by side, and the steps ARE
+                // full -- a round of an alignment's row scores ~6,400 runs; S2000 x 125 2.93 -> 3.09-3.57 ms, A5000 unchanged: not used)
+                bool wingless = false;
+                if (ok) { const SqWalk w = sq_stem_walk(env, i0, j0, L); fin = sq_stem_finalscore_of(env, i0, j0, L, bps, w); wingless = w.brackets == 0; }
                 if (ok) {
-                    LB[q].fin = fin; LA[q].lf = lf | SQ_RX_FIN;
+                    // (a finalscore that met no bracket strand -- no strand inside the span whose partner lies outside it -- does not
+                    // read the levels at all: it outlives the rounds that renumber them, SQ_RX_LVL says which do not)
+                    LB[q].fin = fin; LA[q].lf = (lf & ~SQ_RX_LVL) | SQ_RX_FIN | (wingless ? 0u : SQ_RX_LVL);
                     ok = fin >= minfin;                                         // :751
                 }
                 take(ok, fin, key, (uint32_t)L, bps);
@@ -769,37 +805,26 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         // ---- the rest of the child by the first wave alone, while the others are in the next pass: levels when stems cross, the
         // sorted strand list (sq_extend.h), the skip pointers; s_ready tells the score steps ----
         if (wv == 0) {
+#ifdef SQ_ROUNDS_PROF
+            long long _x0 = wall_clock64();
+#endif
             if (ac) {
                 if (was_cross && !mycross && ngroups > 0) sq_stem_levels_join(XL, k + 1, ngroups, len, lane);
-                else ngroups = sq_stem_levels_wave(XL, k + 1, lane, &a.ctr->level_ovf);
-            }
-            sq_rounds_insert_strands(XL, ac, k, strbuf, sidxbuf, nstrand, i0, j0, len, lane);
-            sq_wave_lds_fence();
-            // skip pointers over the blocks ScoreStems' sweep registers (sq_score_kernel)
-            const SqStrand *const S2 = strbuf;
-            const int16_t *const X2 = sidxbuf;
-            const int ns2 = nstrand + 2;
-            for (int q = lane; q < ns2; q += 64) {
-                const SqStrand x = S2[q];
-                int z = q + 1;
-                if (x.left) {
-                    const int pf = x.pstart;
-                    if (XL.cc[X2[q]] == 0) {
-                        // a stem that crosses nothing: no 5' strand inside its block reaches beyond it, so the pointer is the
-                        // first strand that starts behind the partner -- a binary search instead of a walk over the block
-                        int lo = q + 1, hi = ns2;
-                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (S2[mid].start > pf) hi = mid; else lo = mid + 1; }
-                        z = lo;
-                    } else {
-                        while (z < ns2) {
-                            const SqStrand y = S2[z];
-                            if (y.start > pf || (y.left && y.pstart > pf)) break;
-                            z++;
-                        }
-                    }
+                else {
+                    ngroups = sq_stem_levels_wave(XL, k + 1, lane, &a.ctr->level_ovf);
+#ifdef SQ_ROUNDS_PROF
+                    _xt[3]++;
+#endif
                 }
-                s_skip[q] = (uint16_t)z;
             }
+#ifdef SQ_ROUNDS_PROF
+            { const long long _n = wall_clock64(); _xt[0] += _n - _x0; _x0 = _n; }
+#endif
+            sq_rounds_insert_strands(XL, ac, k, strbuf, sidxbuf, s_skip, nstrand, i0, j0, len, lane);   // (+ the skip pointers over the blocks ScoreStems' sweep registers)
+            sq_wave_lds_fence();
+#ifdef SQ_ROUNDS_PROF
+            { const long long _n = wall_clock64(); _xt[1] += _n - _x0; }
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __atomic_store_n(&s_ready, roundno, __ATOMIC_RELAXED);
         }

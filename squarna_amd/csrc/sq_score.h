@@ -27,10 +27,13 @@ struct SqStemsEnv {
     SqCounters *ctr;
     const double *sdf_l; int sdf_llen;                                      // the first entries of sdf once more, in LDS (nullptr / 0: none)
 };
-// ... and the finalscore of the stem (i0, j0, L) with bpscore bps (the caller applies :751's threshold)
-__device__ __forceinline__ double sq_stem_finalscore(const SqStemsEnv &e, int i0, int j0, int L, double bps)
+// What the walk over the positions between the innermost pair finds (:665-689): the sub-ECR faces it registers (their count, the
+// first one's ends), the positions they cover, the bracket positions outside them and the set of their levels.
+struct SqWalk { int nrec, be0, be1, covered, brackets; uint64_t levelset; };
+
+// The walk by ONE lane: a closed form over the sorted strands, skip pointers over the registered blocks.
+__device__ __forceinline__ SqWalk sq_stem_walk(const SqStemsEnv &e, int i0, int j0, int L)
 {
-    double fin = 0.0;
     const int sa = i0 + L - 1, sb = j0 - L + 1;                 // :655 innermost bp
     int inblockend = -1, nrec = 0, be0 = 0, be1 = 0, covered = 0, brackets = 0;
     uint64_t levelset = 0;
@@ -79,6 +82,16 @@ __device__ __forceinline__ double sq_stem_finalscore(const SqStemsEnv &e, int i0
         printf("CTX MISMATCH struct %d cand (%d,%d,%d) nstrand %d: walk nrec %d cov %d br %d be %d %d | ctx nrec %d cov %d br %d be %d %d\n",
                (int)blockIdx.x, i0, j0, L, e.nstrand, nrec, covered, brackets, be0, be1, cx.nrec, cx.covered, cx.brackets, cx.be0, cx.be1);
 #endif
+    return SqWalk{nrec, be0, be1, covered, brackets, levelset};
+}
+
+// ... and the finalscore of the stem (i0, j0, L) with bpscore bps from what its walk found (the caller applies :751's threshold)
+__device__ __forceinline__ double sq_stem_finalscore_of(const SqStemsEnv &e, int i0, int j0, int L, double bps, const SqWalk &w)
+{
+    double fin = 0.0;
+    const int sa = i0 + L - 1, sb = j0 - L + 1;                 // :655 innermost bp
+    const int nrec = w.nrec, be0 = w.be0, be1 = w.be1, covered = w.covered, brackets = w.brackets;
+    const uint64_t levelset = w.levelset;
     const int dots = (e.U[sb] - e.U[sa + 1]) - covered;             // :670-673
     const bool between = e.SU != nullptr && (e.SU[sb] - e.SU[sa + 1]) > 0;   // :675-676 (nullptr: no separator anywhere)
     bool goodloop = false; int diff1 = 0;                       // :692-698
@@ -125,4 +138,9 @@ __device__ __forceinline__ double sq_stem_finalscore(const SqStemsEnv &e, int i0
     fin = bps * sdf * of * loopfactor * tetra;                  // :732 (reactfactor == 1)
     if (!goodloop && !goodloopout && L < 3) fin = -1.0;         // :744-745
     return fin;
+}
+
+__device__ __forceinline__ double sq_stem_finalscore(const SqStemsEnv &e, int i0, int j0, int L, double bps)
+{
+    return sq_stem_finalscore_of(e, i0, j0, L, bps, sq_stem_walk(e, i0, j0, L));
 }
