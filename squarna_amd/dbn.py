@@ -126,28 +126,21 @@ def UnAlign(seq, dbn, want_pairs=False):
     if dbn.count('.') == len(dbn):                       # no brackets at all: nothing to clean
         return (shortseq, '.' * len(keep), []) if want_pairs else (shortseq, '.' * len(keep))
     try:
-        raw = dbn.encode('latin-1')
-    except UnicodeEncodeError:                           # (bracket letters beyond latin-1: the character loop below)
-        raw = None
-    if raw is not None:
-        v, w = _aligned_pairs(dbn)
-        bad = gaps[v] | gaps[w]
-        arr = np.frombuffer(raw, np.uint8).copy()
-        arr[v[bad]] = 46
-        arr[w[bad]] = 46
-        short = arr[keep].tobytes().decode('latin-1')
-        if not want_pairs:
-            return shortseq, short
-        rank = np.cumsum(~gaps) - 1
-        ok = ~bad
-        return shortseq, short, list(zip(rank[v[ok]].tolist(), rank[w[ok]].tolist()))
-    if want_pairs:
-        return UnAlign(seq, dbn) + (None,)
-    clean = list(dbn)
-    for v, w in DBNToPairs(dbn):
-        if gaps[v] or gaps[w]:
-            clean[v] = clean[w] = '.'
-    return shortseq, ''.join(clean[i] for i in keep)
+        arr, codec = np.frombuffer(dbn.encode('latin-1'), np.uint8).copy(), 'latin-1'
+    except UnicodeEncodeError:
+        # bracket letters beyond latin-1 (the alphabet's Cyrillic pairs, from 31 pseudoknot levels on): the same array code over
+        # code points (until round 6 a per-character loop + two DBNToPairs per row: 1 s of config 5's step 1)
+        arr, codec = np.frombuffer(dbn.encode('utf-32-le'), np.uint32).copy(), 'utf-32-le'
+    v, w = _aligned_pairs(dbn)
+    bad = gaps[v] | gaps[w]
+    arr[v[bad]] = 46
+    arr[w[bad]] = 46
+    short = arr[keep].tobytes().decode(codec)
+    if not want_pairs:
+        return shortseq, short
+    rank = np.cumsum(~gaps) - 1
+    ok = ~bad
+    return shortseq, short, list(zip(rank[v[ok]].tolist(), rank[w[ok]].tolist()))
 
 
 def ReAlign(shortdbn, longseq, seqmode=False):

@@ -89,6 +89,61 @@ class Prepared:
         self.rbps, self.rxs, self.rlefts, self.rrights = ParseRestraints(self.shortrest, rbps)   # :1037
 
 
+class PackedRows:
+    """The rows of ONE alignment after the host pre-processing of SQRNdbnseq.py:1001-1037 / SQRNdbnali.py:60-86, for all rows at
+    once as array code: the alignment is one uint8[rows, columns] array, and letter codes, gap maps, restraint flags and the
+    restraint pairs that survive each row's gaps (UnAlign, SQRNdbnseq.py:236-255) come out of it with a handful of numpy
+    calls -- what a list of per-row Prepared records holds, in the layout Batch uploads (config 5: 2 x 512 rows of 5,000
+    columns were 1.3 s of per-row string work, most of it a character loop over a restraint line whose bracket letters
+    leave latin-1 beyond 30 pseudoknot levels).  Rows without reactivities, one restraint line shared by all rows (or none).
+    cols: the alignment column of every position, row after row (ReAlignDict, SQRNdbnali.py:20-37)."""
+    __slots__ = ("nseq", "seq_off", "codes", "flags", "reacts", "rbp_off", "rbps", "cols", "lengths")
+
+    def __init__(self, seqs, restraint_line=None):
+        from .dbn import _CODE_LUT, encode_seq
+        R, Lc = len(seqs), len(seqs[0])
+        if _CODE_LUT is None:
+            encode_seq("A")                                          # (builds the table)
+        from .dbn import _CODE_LUT as LUT
+        A = np.frombuffer("".join(seqs).encode("latin-1", "replace"), np.uint8).reshape(R, Lc)
+        gap_mask("-")                                                # (builds the gap table)
+        from .dbn import _GAP_LUT
+        keep = ~_GAP_LUT[A]
+        self.nseq = R
+        self.lengths = keep.sum(axis=1)
+        self.seq_off = np.zeros(R + 1, np.int32)
+        np.cumsum(self.lengths, out=self.seq_off[1:])
+        ltot = int(self.seq_off[-1])
+        self.codes = LUT[A[keep]] if ltot else np.zeros(1, np.uint8)
+        self.cols = np.ascontiguousarray(np.nonzero(keep)[1], np.int32) if ltot else np.zeros(1, np.int32)
+        self.reacts = None
+        self.flags = np.zeros(max(ltot, 1), np.uint8)
+        self.rbp_off = np.zeros(R + 1, np.int32)
+        self.rbps = np.zeros(2, np.int32)
+        if restraint_line and restraint_line.count(".") != len(restraint_line):
+            assert len(restraint_line) == Lc, "Invalid restraints given"
+            cp = np.frombuffer(restraint_line.encode("utf-32-le"), np.uint32)        # code points: any bracket alphabet
+            fl = np.zeros(Lc, np.uint8)
+            fl[(cp == ord("_")) | (cp == ord("+"))] |= 1             # SQRNdbnseq.py:370-376: unpaired
+            fl[cp == ord("/")] |= 2                                  # no pair to the left
+            fl[cp == ord("\\")] |= 4                                 # no pair to the right
+            if fl.any() and ltot:
+                self.flags = np.ascontiguousarray(np.broadcast_to(fl, (R, Lc))[keep])
+            pairs = DBNToPairs(restraint_line)                       # once: every row shares the line
+            if pairs:
+                v = np.fromiter((p[0] for p in pairs), np.int64, len(pairs))
+                w = np.fromiter((p[1] for p in pairs), np.int64, len(pairs))
+                ok = keep[:, v] & keep[:, w]                         # a pair that touches a gap of the row is dropped (:243-249)
+                rank = np.cumsum(keep, axis=1, dtype=np.int32) - 1   # column -> position of the row
+                rr, pp = np.nonzero(ok)                              # row-major: every row's pairs in the line's (sorted) order
+                rb = np.empty((len(rr), 2), np.int32)
+                rb[:, 0] = rank[rr, v[pp]]
+                rb[:, 1] = rank[rr, w[pp]]
+                np.cumsum(ok.sum(axis=1), out=self.rbp_off[1:])
+                if len(rr):
+                    self.rbps = rb.reshape(-1)
+
+
 _HDR = struct.Struct("<4q")
 _MET = struct.Struct("<16d")
 _MASK_IDS = [[q for q in range(4) if (m >> q) & 1] for m in range(16)]
@@ -170,6 +225,18 @@ class Batch:
                                "available and there is no CPU fallback")
         self.torch = torch
         self.L = L
+        if isinstance(prepared, PackedRows):
+            # an alignment's rows as arrays (no per-row records: the batch computes, it has no results to decode)
+            pk, prepared = prepared, None
+            nseq, ltot = pk.nseq, int(pk.seq_off[-1])
+            self.prepared = None
+            self.seq_off, self.codes, self.flags, self.reacts, self.rbp_off, self.rbps = pk.seq_off, pk.codes, pk.flags, pk.reacts, pk.rbp_off, pk.rbps
+        else:
+            nseq, ltot = self._host_arrays(prepared)
+        self._finish_init(nseq, ltot, psets_per_record, interchainonly, ext, mul, max_structs, cand_per_nt, device, fp32, bpp, mul_shared)
+
+    def _host_arrays(self, prepared):
+        """The per-position arrays of the batch from a list of Prepared records; (nseq, total positions)."""
         self.prepared = prepared
         nseq = len(prepared)
         self.seq_off = np.zeros(nseq + 1, np.int32)
@@ -201,6 +268,10 @@ class Batch:
                 self.rbp_off[k + 1] = len(p.rbps)
         np.cumsum(self.rbp_off, out=self.rbp_off)
         self.rbps = np.array(rbps, np.int32).reshape(-1) if rbps else np.zeros(2, np.int32)
+        return nseq, ltot
+
+    def _finish_init(self, nseq, ltot, psets_per_record, interchainonly, ext, mul, max_structs, cand_per_nt, device, fp32, bpp, mul_shared):
+        torch, L = self.torch, self.L
         # unique paramsets by identity
         uniq, self.psets_py = {}, []
         first = psets_per_record[0] if nseq else []
@@ -382,6 +453,14 @@ class Batch:
         cols = np.concatenate([np.asarray(c, np.int32) for c in cols_per_job]) if len(jobs) else np.zeros(1, np.int32)
         cols = np.ascontiguousarray(cols, np.int32)
         _lib.check(self.L.sq_align_accumulate(self.h, len(jobs), _ptr(ja), _ptr(off), _ptr(cols), L,
+                                              C.c_void_p(matrix.data_ptr())))
+
+    def align_accumulate_packed(self, pk, matrix):
+        """align_accumulate for every row of a PackedRows batch, its gap maps as they are (no per-row lists)."""
+        L = int(matrix.shape[0])
+        assert matrix.dtype == self.torch.float64 and matrix.is_contiguous() and tuple(matrix.shape) == (L, L)
+        ja = np.arange(pk.nseq, dtype=np.int32)
+        _lib.check(self.L.sq_align_accumulate(self.h, pk.nseq, _ptr(ja), _ptr(pk.seq_off), _ptr(pk.cols), L,
                                               C.c_void_p(matrix.data_ptr())))
 
     # -- a-8 / a-9 / Nussinov
@@ -1082,6 +1161,24 @@ class HipEngine:
         Lcols = len(records[0][0])
         dev = torch.device("cuda", torch.cuda.current_device())
         matrix = torch.zeros((Lcols, Lcols), dtype=torch.float64, device=dev)
+        r0 = records[0][2]
+        if (not any(r[1] for r in records) and all((r[2] or None) == (r0 or None) for r in records)
+                and all(len(r[0]) == Lcols for r in records) and "SQ_NO_PACKED_ROWS" not in os.environ):
+            # the usual alignment: no per-row reactivities, one restraint line for every row (iteration 2) or none -- all rows
+            # prepared at once as array code (PackedRows), chunks of rows sized like the per-row form below
+            lo = 0
+            while lo < len(records):
+                hi, cells = lo, 0
+                while hi < len(records) and (hi == lo or cells + Lcols ** 2 <= 16e9):
+                    cells += Lcols ** 2
+                    hi += 1
+                pk = PackedRows([r[0] for r in records[lo:hi]], r0 or None)
+                with Batch(pk, [[ps]] * (hi - lo), interchainonly=interchainonly, max_structs=self.max_structs,
+                           cand_per_nt=max(self.cand_per_nt, 64), fp32=False) as b:
+                    b.align_accumulate_packed(pk, matrix)
+                    torch.cuda.synchronize(dev)
+                lo = hi
+            return matrix
         prepared, cols = [], []
         for seq, reacts, restraints in records:
             p = Prepared(seq, reacts if reacts else None, restraints, None)
