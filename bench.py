@@ -72,6 +72,27 @@ def pools_long_sequences(count=2000, n=500, seed=500):
     return ["".join(rng.choice(list("ACGU"), n)) for _ in range(count)]
 
 
+def a5000_msa(nseq=512, ncol=5000, seed=5000):
+    """BASELINE config 5's alignment: mutated copies (per-site substitution 0.12, per-site gap 0.06) of one random ancestor with
+    ncol / 40 planted helices between its halves; the rows of the text are '>s<k>' + sequence.  (The generator of tools/
+    scale_soak.py's ali cases and of every A5000 figure since round 2: sha256 a08a1b36a4af2978 of the three steps' text.)"""
+    import random
+    rng = random.Random(seed)
+    anc = [rng.choice("ACGU") for _ in range(ncol)]
+    for _ in range(ncol // 40):
+        a, ln = rng.randint(0, ncol // 2 - 12), rng.randint(4, 8)
+        b = rng.randint(ncol // 2 + 8, ncol - 1)
+        for t in range(ln):
+            if a + t < b - t - 4:
+                anc[b - t] = {"A": "U", "U": "A", "G": "C", "C": "G"}[anc[a + t]]
+    rows = []
+    for k in range(nseq):
+        row = [rng.choice("ACGU") if rng.random() < 0.12 else ch for ch in anc]
+        row = ["-" if rng.random() < 0.06 else ch for ch in row]
+        rows.append(">s%d\n%s" % (k, "".join(row)))
+    return "\n".join(rows) + "\n"
+
+
 def prepare_synthetic(items):
     from squarna_amd.engine import Prepared
     from squarna_amd.dbn import ProcessReacts, ReactDict
@@ -85,9 +106,32 @@ def _oracle_init(cfg):
     from oracle import sqrn_oracle as O
     from squarna_amd.config import ParseConfig, builtin_config
     _O = O
-    _PSETS_BY = {c: ParseConfig(builtin_config(c))[1] for c in {cfg, "fastest", "500nobpp"}}
+    _PSETS_BY = {c: ParseConfig(builtin_config(c))[1] for c in {cfg, "fastest", "500nobpp", "ali"}}
     _PSETS = _PSETS_BY[cfg]
     O.lib()
+
+
+def _oracle_align_row(seq):
+    """cpu_baseline worker task, BASELINE config 5: one row of the alignment through step 1's per-row work (SQRNdbnali.py:60-108,
+    233-237) with the CPU oracle -- UnAlign, BPMatrix, AnnotateStems, the stems' cells added into an L x L matrix through the gap map."""
+    import numpy as np
+    O = _O
+    ps = _PSETS_BY["ali"][0]
+    t0 = time.perf_counter()
+    seq = seq.upper().replace("T", "U")
+    shortseq, shortrest = O.UnAlign(seq, "." * len(seq))
+    rbps, rxs, rl, rr = O.ParseRestraints(shortrest)
+    bm, sm = O.BPMatrix(shortseq, ps["bpweights"], rxs, rl, rr, False, None)
+    stems = O.AnnotateStems(bm, sm, rbps, [], ps["minlen"], ps["minbpscore"])
+    t1 = time.perf_counter()
+    cols = np.array([c for c, ch in enumerate(seq) if ch not in O.GAPS], np.int64)
+    mat = np.zeros((len(seq), len(seq)))
+    for i, j, ln, sc in stems:                             # (the reference's own loop over the cells, :233-237)
+        for t in range(ln):
+            v, w = cols[i + t], cols[j - t]
+            mat[v, w] += sc
+            mat[w, v] += sc
+    return time.perf_counter() - t0, time.perf_counter() - t1
 
 
 def _oracle_one(rec):
@@ -206,6 +250,18 @@ def cpu_baseline(workers, recs, cfg, target_s=10.0):
                                 seconds_per_sequence_one_core=round(float(np.mean(per)), 4),
                                 sample="first %d sequences of the pools_long set, c=500nobpp poollim=1000, one per process (wall %.2fs); "
                                        "value = cores / mean seconds per sequence" % (len(tasks), wall))
+    # BASELINE config 5 (A5000, SURVEY 8d: step 1 of the 512 x 5000 alignment): the per-row work of a few rows, one per process
+    rows = [ln for ln in a5000_msa().split("\n") if ln and not ln.startswith(">")][:min(8, cores)]
+    t0 = time.perf_counter()
+    per = list(pool.imap_unordered(_oracle_align_row, rows, chunksize=1))
+    wall = time.perf_counter() - t0
+    row_s, acc_s = float(np.mean([p[0] for p in per])), float(np.mean([p[1] for p in per]))
+    others["A5000"] = dict(value=round(2 * 512 * row_s / cores, 2), unit="s (step 1: both iterations of 512 rows)", cores=cores, kind="port",
+                           higher_is_better=False, seconds_per_row_one_core=round(row_s, 3), of_which_python_accumulate_loop=round(acc_s, 3),
+                           sample="first %d rows of the 512 x 5000 alignment (seed 5000), ali.conf, one per process (wall %.2fs): UnAlign + BPMatrix + "
+                                  "AnnotateStems (C oracle) + the stems' cells added into the L x L matrix by the reference's own Python loop; value = "
+                                  "2 iterations x 512 rows x mean seconds per row / cores (linear extrapolation to all cores busy; MatrixToDBNs' sort "
+                                  "of L^2 cells in a Python dict, SQRNdbnali.py:131-133, is not in it)" % (len(rows), wall))
     out["other_workloads"] = others
     pool.terminate()
     return out
@@ -821,6 +877,140 @@ def pools_long_leg(count=2000, n=500, reps=2):
                 driver=int(eng.last_fold_driver), peak_structures_first_sub_batch=int(eng.last_fold_peak))
 
 
+def alignment_leg(pmc, nseq=512, ncol=5000, reps=3):
+    """BASELINE config 5 (SQRNdbnali.py:60-108,211-242,332-458): the 512 x 5000 synthetic alignment under ali.conf
+    through squarna_amd.Predict(alignment=True) -- step 1 alone (s3=1: SURVEY's A5000) and all three steps (step3=u), text digests --
+    and, from a replay of the two device phases with the library's HIP-event timers on the batch's stream, the kernels that
+    carry them: step 1's scan / filter / scatter / select, step 2's ONE launch of the persistent round kernel over 512
+    structures of ~4,700 nt."""
+    import hashlib, io, tempfile
+    import numpy as np
+    import torch
+    import ctypes as C
+    from squarna_amd import Predict, align, _lib
+    from squarna_amd import engine as E
+    from squarna_amd.config import ParseConfig, builtin_config
+    text = a5000_msa(nseq, ncol)
+    with tempfile.NamedTemporaryFile("w", suffix=".afa", delete=False) as f:
+        f.write(text)
+        path = f.name
+    try:
+        def run(step3):
+            buf = io.StringIO()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            Predict(inputfile=path, alignment=True, step3=step3, write_to=buf)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, hashlib.sha256(buf.getvalue().encode()).hexdigest()[:16]
+        run("u")                                                    # warm-up (allocator, pinned buffers)
+        full = sorted(run("u") for _ in range(reps))
+        one = sorted(run("1") for _ in range(reps))
+        # phases of one more call (wall clock around the alignment's own functions)
+        T = {}
+        saved = []
+
+        def timed(mod, name, key):
+            fn = getattr(mod, name)
+
+            def w(*a, **k):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    torch.cuda.synchronize(); T[key] = T.get(key, 0.0) + time.perf_counter() - t0
+            saved.append((mod, name, fn))
+            setattr(mod, name, w)
+        timed(align, "SQRNdbnali", "step1_s"); timed(align, "MatrixToDBNs", "step1_first_fit_s")
+        timed(E.HipEngine, "fold_records", "step2_fold_s"); timed(align, "Consensus", "consensus_s")
+        try:
+            run("u")
+        finally:
+            for mod, name, fn in saved:
+                setattr(mod, name, fn)
+    finally:
+        os.unlink(path)
+    # ---- the device phases once more, under the library's per-kernel timers ----
+    seqs = [ln.upper().replace("T", "U") for ln in text.split("\n") if ln and not ln.startswith(">")]
+    names, psets = ParseConfig(builtin_config("ali"))
+    ps0 = psets[0]
+    eng = E.HipEngine()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ps1 = dict(bpweights=ps0["bpweights"], bpp=0, algorithms={"G"}, suboptmax=1.0, suboptmin=1.0, suboptsteps=1.0, minlen=ps0["minlen"],
+               minbpscore=ps0["minbpscore"], minfinscorefactor=1.0, bracketweight=-2.0, distcoef=0.09, orderpenalty=1.0, loopbonus=0.125, maxstemnum=1e6)
+    matrix = torch.zeros((ncol, ncol), dtype=torch.float64, device=dev)
+    pk = E.PackedRows(seqs, None)
+    n2 = float((pk.lengths.astype(np.float64) ** 2).sum())
+    with E.Batch(pk, [[ps1]] * nseq, cand_per_nt=64, fp32=False) as b:
+        b.profile(True); b.profile_reset()
+        b.align_accumulate_packed(pk, matrix)
+        k1 = {nm: b.profile_get(k) for k, nm in ((0, "bits"), (1, "state"), (2, "scan"), (3, "filter"), (8, "scatter"))}
+    # cells the scatter adds: from the stems of the first 8 rows (exact for those, extrapolated)
+    st8 = eng.yield_stems([(s, None, None) for s in seqs[:8]], ps0["bpweights"], ps0["minlen"], ps0["minbpscore"])
+    cells_row = float(np.mean([int(st["len"].sum()) for _, st in st8]))
+    stream = torch.cuda.current_stream(dev)
+    idx = torch.empty(1 << 20, dtype=torch.int64, device=dev); val = torch.empty(1 << 20, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sel_ms = []
+    for _ in range(4):                                              # (launched on torch's current stream: its events see the kernel)
+        e0.record(stream)
+        _lib.check(_lib.load().sq_colmatrix_select(C.c_void_p(matrix.data_ptr()), ncol, float(ps0["minbpscore"] * nseq), 4, C.c_void_p(idx.data_ptr()),
+                                                   C.c_void_p(val.data_ptr()), 1 << 20, C.c_void_p(cnt.data_ptr()), C.c_void_p(stream.cuda_stream)))
+        e1.record(stream); e1.synchronize()
+        sel_ms.append(e0.elapsed_time(e1))
+    sel = min(sel_ms[1:])
+    smat = (matrix / matrix.max() * 5).contiguous()
+    recs = [(s, None, None, None, psets, smat) for s in seqs]
+    opts = dict(conslim=1, toplim=5, hardrest=False, rankbydiff=False, rankby=(0, 2, 1), interchainonly=False, poollim=1000, algos=set(),
+                levellimit=None, priority=set())
+    b2, fo = eng._make_batch(recs, None, opts)
+    try:
+        b2.fold(**fo)                                               # warm-up
+        b2.profile(True); b2.profile_reset()
+        b2.fold(**fo)
+        rms, rl, rbytes = b2.profile_get(7)
+        evals = sum(b2.evals(k) for k in range(nseq))
+        paths = b2.fold_paths
+    finally:
+        b2.close()
+    kr, ks, kc = pmc.get("a5000_rounds") or {}, pmc.get("a5000_scatter") or {}, pmc.get("a5000_colselect") or {}
+
+    def hbm(k, ms):
+        tb = (k.get("fetch_bytes_per_launch", 0) + k.get("write_bytes_per_launch", 0)) if k else None
+        return dict(traffic=tb, achieved_GBs=round(tb / (ms * 1e-3) / 1e9, 1) if tb and ms else None,
+                    frac=round(tb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tb and ms else None, pmc=k.get("source") if k else None)
+    sc_ms, sc_l = k1["scatter"][0], max(k1["scatter"][1], 1)
+    sc_alg = 16.0 * cells_row * nseq                                  # a read-modify-write of one double per cell of every kept stem
+    sel_alg = 8.0 * ncol * (ncol - 4) / 2.0                           # the upper cells with span >= 4, read once
+    rooflines = [
+        dict(kernel="sq_scatter_all_kernel", leg="A5000 step 1, iteration 1 (512 rows into the 5000 x 5000 fp64 column matrix, hardware fp64 atomics)",
+             bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS, avg_launch_ms=round(sc_ms / sc_l, 3), launches=int(sc_l),
+             algorithmic_bytes=round(sc_alg), achieved=round(sc_alg / (sc_ms * 1e-3) / 1e9, 1), frac=round(sc_alg / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             algorithmic_how="16 bytes (read + write of a double) x the cells of every kept stem: %.0f cells per row (exact for the first 8 rows, "
+                             "extrapolated) x %d rows; the addends are exact (dyadic weights), so the order of the atomics cannot change a bit" % (cells_row, nseq),
+             hbm=hbm(ks, sc_ms / sc_l)),
+        dict(kernel="sq_colselect_kernel", leg="A5000 step 1 (MatrixToDBNs' candidates: the upper cells >= minbpscore x rows, span >= 4)",
+             bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS, avg_launch_ms=round(sel, 4), algorithmic_bytes=round(sel_alg),
+             achieved=round(sel_alg / (sel * 1e-3) / 1e9, 1), frac=round(sel_alg / (sel * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             how="HIP events on torch's current stream (the stream the kernel is launched on), best of 3 after a warm-up", hbm=hbm(kc, sel)),
+        dict(kernel="sq_rounds_kernel", leg="A5000 step 2: ONE launch, 512 structures of ~4,700 nt (1,024-thread blocks, one per CU), weights read "
+                                            "through the gap map from the shared diagonal-major matrix",
+             bound="latency + hbm: a round streams the structure's run list (16 + 16 bytes per run) and scores the runs whose bound reaches the bar",
+             avg_launch_ms=round(rms / max(rl, 1), 2), launches=int(rl), evals_R=int(evals),
+             algorithmic=dict(bytes_per_launch=round(rbytes / max(rl, 1)), GBs=round(rbytes / max(rl, 1) / (rms / max(rl, 1) * 1e-3) / 1e9, 1),
+                              how="SURVEY 8d: 2 N^2 bytes per AnnotateStems evaluation x the launch's evaluations"),
+             valu_issue_frac=(issue_share(kr, rms / max(rl, 1)) or {}).get("valu_issue_frac"), wave_cycles_waiting=kr.get("wait_share"),
+             lds_bank_conflict_share=kr.get("lds_conflict_share"), hbm=hbm(kr, rms / max(rl, 1)), fold_paths=int(paths)),
+    ]
+    return dict(
+        what="BASELINE config 5: %d x %d synthetic alignment (seed 5000: one ancestor, substitutions 0.12, gaps 0.06, %d planted helices), ali.conf, "
+             "squarna_amd.Predict(inputfile, alignment=True) into a text buffer; median of %d calls after one warm-up" % (nseq, ncol, ncol // 40, reps),
+        step1_only=dict(seconds=round(one[len(one) // 2][0], 3), sha256_16=one[0][1], how="step3='1' (SURVEY 8d's A5000: both iterations of step 1, steps 2-3 skipped)"),
+        all_steps=dict(seconds=round(full[len(full) // 2][0], 3), sha256_16=full[0][1], how="step3='u'"),
+        phases={k: round(v, 3) for k, v in T.items()},
+        device_ms=dict(step1_iteration1={nm: round(v[0], 3) for nm, v in k1.items()}, colselect=round(sel, 4), step2_rounds_kernel=round(rms / max(rl, 1), 2)),
+        cells_N2_sum=n2, rooflines=rooflines)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -838,6 +1028,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-stream", action="store_true", help="skip the stream / one_pass legs")
     ap.add_argument("--no-roofline", action="store_true", help="skip the S1000 roofline leg")
+    ap.add_argument("--no-alignment", action="store_true", help="skip the alignment leg (BASELINE config 5)")
     ap.add_argument("--roofline-seqs", type=int, default=1024)    # S1000 = 1,024 sequences
     args = ap.parse_args()
 
@@ -1064,6 +1255,16 @@ def main():
         except Exception as e:                                # (a secondary leg never takes the headline down)
             proxy = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    alignment = None
+    if rank == 0 and world == 1 and not args.no_alignment:
+        torch.cuda.empty_cache()
+        try:
+            alignment = alignment_leg(pmc)
+            rooflines.extend(alignment.pop("rooflines"))
+        except Exception as e:                                # (a secondary leg never takes the headline down)
+            alignment = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+
     pools_long = None
     if rank == 0 and world == 1 and not args.no_stream:
         torch.cuda.empty_cache()
@@ -1161,6 +1362,10 @@ def main():
         "shape_nobpp": shape,
         "pools_long": dict(pools_long, vs_cpu_baseline=round(pools_long["seq_per_s"] / cpu["other_workloads"]["pools_long"]["value"], 1))
                       if pools_long and cpu and "seq_per_s" in pools_long and "pools_long" in cpu.get("other_workloads", {}) else pools_long,
+        "alignment": dict(alignment, vs_cpu_baseline=dict(
+                              step1_only=round(cpu["other_workloads"]["A5000"]["value"] / alignment["step1_only"]["seconds"], 1),
+                              note="cpu_baseline.other_workloads.A5000 (the oracle's step 1 on this host's cores, extrapolated from a few rows) / step1_only.seconds"))
+                     if alignment and cpu and "step1_only" in alignment and "A5000" in cpu.get("other_workloads", {}) else alignment,
         "strong_scaling_proxy": proxy,
         "sharded": sharded,
         "n_ranks_seen": world if world == 1 else nranks_seen,

@@ -244,7 +244,7 @@ struct sq_batch {
     int64_t mwm_stats[6] = {0, 0, 0, 0, 0, 0};   // blossom jobs collected, their scan passes; the job with the most passes:
                                                  // its passes, events, vertices, edges (reset by sq_profile_reset)
     bool prof_on = false;
-    ProfSlot prof[8];                     // 0 fill, 1 state, 2 scan, 3 score, 4 Edmonds, 5 Hungarian, 6 Nussinov, 7 persistent rounds (sq_rounds.hip)
+    ProfSlot prof[9];                     // 0 fill, 1 state, 2 scan, 3 score, 4 Edmonds, 5 Hungarian, 6 Nussinov, 7 persistent rounds (sq_rounds.hip), 8 the alignment's scatter
 };
 
 // CPU accounting (SQ_CPUACC=1): thread CPU time spent in the host phases, summed over all threads, printed per fold.

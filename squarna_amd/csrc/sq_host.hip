@@ -419,7 +419,7 @@ extern "C" int sq_profile_counters(sq_batch *b, int32_t kernel, int64_t out[6])
 }
 extern "C" int sq_profile_get(sq_batch *b, int32_t k, double *ms, int64_t *launches, double *bytes)
 {
-    if (k < 0 || k > 7) return -1;
+    if (k < 0 || k > 8) return -1;
     hipStreamSynchronize(b->stream);
     for (int q = 0; q < 4; q++) if (b->side[q]) hipStreamSynchronize(b->side[q]);
     prof_collect(b);

@@ -396,14 +396,21 @@ static int run_chunk(sq_batch *b, SqLane &ln, const std::vector<SView> &structs,
                 HIPCK(hipMemcpyAsync(d_starts, starts.data(), (size_t)S * 4, hipMemcpyHostToDevice, st));
                 HIPCK(hipStreamSynchronize(st));             // (starts is a local)
                 const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>(maxcap / 4096, 1), 64);
-                hipLaunchKernelGGL(sq_scatter_all_kernel, dim3(blocks, S), dim3(256), 0, st, b->ctx, ln.d_structs, scan,
+                // algorithmic bytes of the scatter: a read-modify-write of 8 bytes per cell of every kept stem -- booked by the
+                // caller from the stems' cells; here the launch is only timed
+                ProfScope ps(b, 8, 0);
+                // (grid.x = the sequence: blocks that run at the same time hold the same part of different rows' stem lists -- the rows
+                // of an alignment have their stems in the same places, so the cells they add to are the same lines of the matrix)
+                hipLaunchKernelGGL(sq_scatter_all_kernel, dim3(S, blocks), dim3(256), 0, st, b->ctx, ln.d_structs, scan,
                                    d_cols, d_starts, sink->L, sink->matrix);
-            } else
+            } else {
+            ProfScope ps(b, 8, 0);
             for (int k = 0; k < S; k++) {
                 const SqJob &J = b->jobs[structs[lo + k].job];
                 const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>(J.cand_cap / 1024, 1), 1024);
                 hipLaunchKernelGGL(sq_scatter_kernel, dim3(blocks), dim3(256), 0, st, b->ctx, ln.d_structs, scan, k,
                                    d_cols + (sink->col_off[lo + k] - c0), sink->L, sink->matrix);
+            }
             }
         }
     }
@@ -627,7 +634,8 @@ extern "C" int sq_colmatrix_select(const double *d_matrix, int32_t L, double thr
     hipStream_t st = (hipStream_t)hip_stream;
     HIPCK(hipMemsetAsync(d_count, 0, 8, st));
     const int64_t total = (int64_t)L * L;
-    hipLaunchKernelGGL(sq_colselect_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, st,
+    (void)total;
+    hipLaunchKernelGGL(sq_colselect_kernel, dim3((unsigned)std::min<int64_t>((L + 1023) / 1024, 8), (unsigned)std::min<int32_t>(L, 65535)), dim3(256), 0, st,
                        d_matrix, L, threshold, minspan, (long long *)d_idx, d_val, (long long)cap, (unsigned long long *)d_count);
     return sq_check(hipGetLastError(), "sq_colselect_kernel");
 }
