@@ -511,6 +511,10 @@ def stream_leg(config, K, R, steps, warmup, device):
         torch.cuda.synchronize()
         return time.perf_counter() - t00, sorted(per), packed
 
+    # one_pass FIRST: the leg's later parts leave the process in another state (eight request threads, worker pools and pinned
+    # buffers sized for batches of 12 sets) -- round 5's driver line had it LAST and read 4.11 ms where the same code alone
+    # reads 3.2-3.3 on the same box (tools/one_pass_probe.py over seven trees from round 4's end to round 6: no commit moves it)
+    dt1, per1, packed1 = timed(1, 1, 30, 3)
     dt, per, packed = timed(K, R, steps, warmup)
     stream = dict(what="SRtest150 + SRtrain150 (485 records) as a stream: every step takes the next windows of 219 x %d records for "
                        "%d batches; timed per step: Batch() (host arrays + sq_batch_create = upload) + fold of the batches in flight "
@@ -627,10 +631,11 @@ def stream_leg(config, K, R, steps, warmup, device):
                                      "the interpreter lock serialises the slots' Python parts" % (K, steps, R, K))
     except Exception as e:
         stream["rolling"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    dt1, per1, packed1 = timed(1, 1, 10, 3)
+    dt1_last, per1_last, _ = timed(1, 1, 10, 3)
     gc.enable()
     one = dict(what="ONE pass over 219 records (a different window every call): Batch() + sq_fold + sq_result_pack_all, nothing "
-                    "else in flight, median of 10",
+                    "else in flight, median of 30, measured before the leg's batches of 8 x 12 sets",
+               ms_after_the_stream_legs=round(per1_last[len(per1_last) // 2], 3),
                ms=round(per1[len(per1) // 2], 3), best_ms=round(per1[0], 3),
                seq_per_s=round(219 / per1[len(per1) // 2] * 1e3, 1), packed_bytes=packed1)
     return stream, one
