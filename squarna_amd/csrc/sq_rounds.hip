@@ -147,14 +147,11 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     // bound / score steps, pick, extension + state
     long long _pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
     long long _cnt[4] = {0, 0, 0, 0};       // entries streamed, finalscores taken from the list, runs scored (first wave), rounds
-#ifdef SQ_WALK_STATS
-    long long _ws[6] = {0, 0, 0, 0, 0, 0};   // strands visited (sum, sum of the steps' maxima), the same with an exit when the order factor's bound misses the bar, runs that would exit, runs below the bar
-#endif
     long long _xt[4] = {0, 0, 0, 0};        // the extension: levels, full rule / joins; strands + skip pointers; [3] rounds with the full rule
     long long _sp[6] = {0, 0, 0, 0, 0, 0};  // the score step: [0] wait for the structure, [1] entry loads, [3] the rest; [4] steps
 #define SPROF(k) do { const long long _n = wall_clock64(); _sp[k] += _n - _t2; _t2 = _n; } while (0)
 #define RPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)
-#define RPROF_OUT() do { if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d walks: strands visited %lld, sum of the steps' longest %lld | with an exit at the order factor's bound: %lld, %lld | runs that would exit %lld, runs that end below the bar %lld\n", b, wv, _ws[0], _ws[1], _ws[2], _ws[3], _ws[4], _ws[5]); if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d extension us: levels %.1f (%lld rounds with the full rule) strands + skip pointers %.1f\n", b, wv, _xt[0] * 0.01, _xt[3], _xt[1] * 0.01); if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d score steps %lld | us: wait for the structure %.1f entry loads %.1f ScoreStems + stores + pick %.1f\n", b, wv, _sp[4], _sp[0] * 0.01, _sp[1] * 0.01, _sp[3] * 0.01); if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d n=%d rounds %lld | us: setup %.1f scan %.1f order %.1f stream %.1f cut %.1f bound %.1f score %.1f pick %.1f ext %.1f between %.1f total %.1f | wave 0: streamed %lld kept %lld scored %lld\n", \
+#define RPROF_OUT() do { if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d extension us: levels %.1f (%lld rounds with the full rule) strands + skip pointers %.1f\n", b, wv, _xt[0] * 0.01, _xt[3], _xt[1] * 0.01); if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d score steps %lld | us: wait for the structure %.1f entry loads %.1f ScoreStems + stores + pick %.1f\n", b, wv, _sp[4], _sp[0] * 0.01, _sp[1] * 0.01, _sp[3] * 0.01); if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d n=%d rounds %lld | us: setup %.1f scan %.1f order %.1f stream %.1f cut %.1f bound %.1f score %.1f pick %.1f ext %.1f between %.1f total %.1f | wave 0: streamed %lld kept %lld scored %lld\n", \
         b, wv, n, _cnt[3], _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, _pt[6] * 0.01, _pt[7] * 0.01, _pt[8] * 0.01, _pt[9] * 0.01, (wall_clock64() - _t00) * 0.01, _cnt[0], _cnt[1], _cnt[2]); } while (0)
 #else
 #define RPROF(k) do {} while (0)
@@ -617,17 +614,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 // 4-5 us per run on structures of 700 strands against ~1 us per run for 64 runs side by side, and the steps ARE
                 // full -- a round of an alignment's row scores ~6,400 runs; S2000 x 125 2.93 -> 3.09-3.57 ms, A5000 unchanged: not used)
                 bool wingless = false;
-#ifdef SQ_WALK_STATS
-                SqWalkStats wst = {0, -1};
-                if (ok) { const SqWalk w = sq_stem_walk(env, i0, j0, L, bps, need, ub_lf * 1.25 * (1.0 + 0x1p-30), &wst); fin = sq_stem_finalscore_of(env, i0, j0, L, bps, w); wingless = w.brackets == 0; }
-                {
-                    const int v = ok ? wst.visits : 0, x = ok ? (wst.exit_at >= 0 ? wst.exit_at : wst.visits) : 0;
-                    _ws[0] += sq_wave_sum32(v); _ws[1] += -sq_wave_min_i32(-v); _ws[2] += sq_wave_sum32(x); _ws[3] += -sq_wave_min_i32(-x);
-                    _ws[4] += __popcll(__ballot(ok && wst.exit_at >= 0)); _ws[5] += __popcll(__ballot(ok && !(fin >= minfin && fin >= need)));
-                }
-#else
                 if (ok) { const SqWalk w = sq_stem_walk(env, i0, j0, L); fin = sq_stem_finalscore_of(env, i0, j0, L, bps, w); wingless = w.brackets == 0; }
-#endif
                 if (ok) {
                     // (a finalscore that met no bracket strand -- no strand inside the span whose partner lies outside it -- does not
                     // read the levels at all: it outlives the rounds that renumber them, SQ_RX_LVL says which do not)

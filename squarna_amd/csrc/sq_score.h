@@ -32,13 +32,7 @@ struct SqStemsEnv {
 struct SqWalk { int nrec, be0, be1, covered, brackets; uint64_t levelset; };
 
 // The walk by ONE lane: a closed form over the sorted strands, skip pointers over the registered blocks.
-#ifdef SQ_WALK_STATS
-struct SqWalkStats { int visits, exit_at; };
-#define SQ_WALK_STATS_ARGS , double ws_bps, double ws_need, double ws_k, SqWalkStats *ws
-#else
-#define SQ_WALK_STATS_ARGS
-#endif
-__device__ __forceinline__ SqWalk sq_stem_walk(const SqStemsEnv &e, int i0, int j0, int L SQ_WALK_STATS_ARGS)
+__device__ __forceinline__ SqWalk sq_stem_walk(const SqStemsEnv &e, int i0, int j0, int L)
 {
     const int sa = i0 + L - 1, sb = j0 - L + 1;                 // :655 innermost bp
     int inblockend = -1, nrec = 0, be0 = 0, be1 = 0, covered = 0, brackets = 0;
@@ -56,16 +50,9 @@ __device__ __forceinline__ SqWalk sq_stem_walk(const SqStemsEnv &e, int i0, int 
         lo = e.nstrand;                                        // the walk below has nothing left to do
 #endif
     }
-#ifdef SQ_WALK_STATS
-    ws->visits = 0; ws->exit_at = -1;
-#endif
     for (int k = lo; k < e.nstrand;) {                         // closed form of the walk :665-689
         const SqStrand x = e.S[k];
         if (x.start >= sb) break;
-#ifdef SQ_WALK_STATS
-        ws->visits++;
-        if (ws->exit_at < 0 && ws_bps * e.of[__popcll(levelset)] * ws_k < ws_need) ws->exit_at = ws->visits;
-#endif
         int nk = k + 1;
         const int pfirst = x.pstart, plast = x.pstart - (x.len - 1);
         bool wing;
@@ -155,10 +142,5 @@ __device__ __forceinline__ double sq_stem_finalscore_of(const SqStemsEnv &e, int
 
 __device__ __forceinline__ double sq_stem_finalscore(const SqStemsEnv &e, int i0, int j0, int L, double bps)
 {
-#ifdef SQ_WALK_STATS
-    SqWalkStats ws;
-    return sq_stem_finalscore_of(e, i0, j0, L, bps, sq_stem_walk(e, i0, j0, L, 0.0, 0.0, 0.0, &ws));
-#else
     return sq_stem_finalscore_of(e, i0, j0, L, bps, sq_stem_walk(e, i0, j0, L));
-#endif
 }
