@@ -428,6 +428,11 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 if (r2 > r1) thr *= 2; else break;
             }
             ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0; ra.ties = chain_ties ? 1 : 0;
+            {
+                static const int wmin = getenv("SQ_WAVE_WALK_MIN") ? atoi(getenv("SQ_WAVE_WALK_MIN")) : 192;
+                static const int wlanes = getenv("SQ_WAVE_WALK_LANES") ? atoi(getenv("SQ_WAVE_WALK_LANES")) : 12;
+                ra.wave_min = wmin > 0 ? wmin : 0x7fffffff; ra.wave_lanes = wlanes; ra.no_early = getenv("SQ_NO_EARLY_WALK") ? 1 : 0;
+            }
             ra.fly = 0;
             while (thr > 64 && sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr, ra.su).total + 2048 > 158 * 1024) thr /= 2;   // (long sequences: the survivor ring gives way)
             if (sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr, ra.su).total + 2048 > 158 * 1024) rounds_ok = false;

@@ -31,6 +31,8 @@ struct SqRunB {
 #define SQ_RX_UB 0x10000u
 #define SQ_RX_FIN 0x20000u
 #define SQ_RX_LVL 0x40000u         // the kept finalscore counted bracket strands: it reads the levels, a round that renumbers them voids it
+#define SQ_RX_FB 0x80000u          // SqRunB::fin holds an UPPER BOUND of the finalscore (ScoreStems' walk ended early at the order factor's
+                                   // bound), valid as long as a finalscore would be; never together with SQ_RX_FIN
 
 #define SQ_ROUNDS_SDF_LDS 128      // entries of the distance-factor table kept in LDS
 #define SQ_RQ_CAP 192              // entries of each of a wave's three work queues (cut / bound / score): a queue is served when it holds 64
@@ -50,6 +52,9 @@ struct SqRoundsArgs {
     int32_t fly;            // > 0: the first round's scan forms the words of the bit matrix itself, from letter masks in LDS (the fold never
                             // wrote the matrix: every job is scanned once); the value is the batch's letter count (room of the masks)
     int32_t su;             // some sequence of the launch holds a chain separator: the blocks keep the separators' prefix counts (2 bytes per position)
+    int32_t wave_min;       // strands from which the last walks of a score step are taken by the whole wave (sq_walk_wave)
+    int32_t wave_lanes;     // ... when at most so many lanes are still walking
+    int32_t no_early;       // ScoreStems' walk never ends early at the order factor's bound (SQ_NO_EARLY_WALK: tests fold both ways)
     int32_t ties;           // the structures belong to pools that MAY branch (poollim > 1, range factor 1.0): a round in which a second
                             // run reaches the best finalscore ends the structure unfinished (h_fin bit 62) -- the device pools redo its job
 };
@@ -87,7 +92,7 @@ __host__ __device__ inline SqRoundsLds sq_rounds_lds(int lds_n, int str_cap, int
     L.t8 = (tmax + 7) & ~7;
     L.off_stems = o; o += 11 * L.t8 + 64 * 4;                  // the structure's stems: crossing weight (int32), i, j, len (int16), level group (uint8); the groups' sizes
     o = (o + 15) & ~15;
-    L.off_tab = o; o += 8 * (SQ_ROUNDS_SDF_LDS + SQ_MAXLEVELS + 1 + 1);   // the head of the distance-factor table and the order factors (ScoreStems reads them at the end of a chain of dependent loads)
+    L.off_tab = o; o += 8 * (SQ_ROUNDS_SDF_LDS + 2 * (SQ_MAXLEVELS + 2));   // the head of the distance-factor table and the order factors (ScoreStems reads them at the end of a chain of dependent loads)
     L.off_lvl = o; o += 4 * L.t8 + 64 + 16;                    // level scratch of the extension (order, level, rank): its own region -- the first
     o = (o + 15) & ~15;                                        // wave extends the structure while the others are in the next round's pass
     L.off_union = o;

@@ -138,7 +138,7 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     __shared__ double s_wfin[SQ_ROUNDS_THREADS / 64], s_wbps[SQ_ROUNDS_THREADS / 64], s_wsec[SQ_ROUNDS_THREADS / 64];
     __shared__ uint32_t s_wkey[SQ_ROUNDS_THREADS / 64], s_wlen[SQ_ROUNDS_THREADS / 64];
     __shared__ int s_wany[SQ_ROUNDS_THREADS / 64];
-    __shared__ int s_cross;
+    __shared__ int s_cross, s_ofmono;
 
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
     const int b = blockIdx.x;
@@ -311,9 +311,17 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     double *const l_sdf = reinterpret_cast<double *>(rd_dyn + Lo.off_tab), *const l_of = l_sdf + SQ_ROUNDS_SDF_LDS;
     const int l_sdflen = ps_sdflen < SQ_ROUNDS_SDF_LDS ? ps_sdflen : SQ_ROUNDS_SDF_LDS;
     for (int k = tid; k < l_sdflen; k += nthr) l_sdf[k] = ps_sdf[k];
-    for (int k = tid; k <= SQ_MAXLEVELS; k += nthr) l_of[k] = ps->oftab[k];
-    const double *const ps_of = l_of;
     const double ub_of = ps->ub_of, ub_lf = ra.bound ? ps->ub_lf : INFINITY;
+    // (l_ofr[p] >= of[p] / of_max, rounded up: what the order factor's share of a run's bound shrinks to once p levels are known)
+    double *const l_ofr = l_of + SQ_MAXLEVELS + 2;
+    for (int k = tid; k <= SQ_MAXLEVELS; k += nthr) { const double o = ps->oftab[k]; l_of[k] = o; l_ofr[k] = (o / ub_of) * (1.0 + 0x1p-40); }
+    if (wv == 0) {
+        // the order factors do not grow with the number of levels (orderpenalty >= 0): the early end of ScoreStems' walk relies on it
+        const bool up = lane < SQ_MAXLEVELS && ps->oftab[lane + 1] > ps->oftab[lane];
+        const unsigned long long bad = __ballot(up);
+        if (lane == 0) s_ofmono = (bad == 0ull && ub_of > 0.0 && ub_lf < INFINITY && !ra.no_early) ? 1 : 0;
+    }
+    const double *const ps_of = l_of;
     // (a width-1 pool only ever uses ChooseStems' FIRST element -- the highest finalscore, the smallest key among equals: a run
     // whose bound is below the best finalscore seen so far can neither be it nor tie with it.  The bar is the best itself, not
     // the suboptimality range below it, which the pools' round kernel needs: its children come from the whole range)
@@ -505,12 +513,12 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
             const bool live = L > 0;                                            // (lanes beyond the list hold length 0)
             Cls c;
             c.cut = live & (nocut >= 0);
-            const uint32_t lf = r.lf & ~((fdm & SQ_RX_FIN) | (udm & (SQ_RX_UB | SQ_RX_FIN)));
+            const uint32_t lf = r.lf & ~((fdm & (SQ_RX_FIN | SQ_RX_FB)) | (udm & (SQ_RX_UB | SQ_RX_FIN | SQ_RX_FB)));
             const bool stay = live & !c.cut;
             if (stay & (lf != r.lf)) LA[q].lf = lf;
             const bool p492 = stay & (r.bps >= minbps);                         // :492
             c.mine = p492 & ((lf & SQ_RX_FIN) != 0u) & (rb.fin >= minfin);      // :751
-            c.surv = p492 & ((lf & (SQ_RX_FIN | SQ_RX_UB)) == SQ_RX_UB) & !(rb.ub < need);
+            c.surv = p492 & ((lf & (SQ_RX_FIN | SQ_RX_UB)) == SQ_RX_UB) & !(rb.ub < need) & !(((lf & SQ_RX_FB) != 0u) & (rb.fin < need));
             c.cand = p492 & ((lf & (SQ_RX_FIN | SQ_RX_UB)) == 0u);
             return c;
         };
@@ -609,17 +617,55 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
                 double fin = 0.0;
                 const int L = (int)(lf & SQ_RX_LEN);
                 const int i0 = (int)(key & 0xFFFFu), j0 = (int)(key >> 16) - i0;
-                // (the whole wave on ONE run at a time, a strand per lane with a DPP prefix-maximum scan over the partner ends,
-                // was built again in round 6, also as a probe that raises the bar before the others are walked:
-                // 4-5 us per run on structures of 700 strands against ~1 us per run for 64 runs side by side, and the steps ARE
-                // full -- a round of an alignment's row scores ~6,400 runs; S2000 x 125 2.93 -> 3.09-3.57 ms, A5000 unchanged: not used)
-                bool wingless = false;
-                if (ok) { const SqWalk w = sq_stem_walk(env, i0, j0, L); fin = sq_stem_finalscore_of(env, i0, j0, L, bps, w); wingless = w.brackets == 0; }
+                // ScoreStems' walk (sq_score.h), in parts.  Side by side -- a lane per run -- a slice of strands at a time, while many
+                // lanes are walking: such a step lasts as long as its longest walk (263 strands on an alignment's row of 700, where the
+                // average walk visits 73), so the walk ENDS EARLY where the order factor alone puts the run below the bar (seven
+                // walks in eight of such a row, after a quarter of their strands: the bound stays with the entry, SQ_RX_FB), and
+                // when only a few lanes are still walking on a structure of hundreds of strands the whole wave takes what is left
+                // of each of them, a strand per lane (sq_walk_wave: ~1 us per 64 strands where a lone lane pays two dependent LDS
+                // reads per strand).  (A wave per run for EVERY run was measured twice and lost: the steps are full.)
+                const int sa = i0 + L - 1, sb = j0 - L + 1;
+                const bool early = s_ofmono != 0;
+                const bool wavewalk = nstrand >= ra.wave_min;
+                SqWalkPart st = {0, -1, 0, 0, 0, 0, 0, 0u, 0u};
+                int status = SQ_WALK_DONE;
+                double bnd = 0.0;
+                if (ok) sq_walk_begin(env, sa, st);
+                for (bool walking = ok;;) {
+                    if (walking) {
+                        status = sq_walk_lane(env, sa, sb, st, wavewalk ? 16 : 0x7fffffff, early, ub, l_ofr, bar(), &bnd);
+                        walking = status == SQ_WALK_MORE;
+                    }
+                    unsigned long long wm = __ballot(walking);
+                    if (wm == 0ull) break;
+                    if (__popcll(wm) <= ra.wave_lanes) {
+                        while (wm != 0ull) {
+                            const int r = __ffsll((long long)wm) - 1;
+                            wm &= wm - 1ull;
+#define SQ_RL(x) __builtin_amdgcn_readlane((int)(x), r)
+                            SqWalkPart w = {SQ_RL(st.k), SQ_RL(st.inblockend), SQ_RL(st.nrec), SQ_RL(st.be0), SQ_RL(st.be1), SQ_RL(st.covered), SQ_RL(st.brackets),
+                                            (uint32_t)SQ_RL(st.lv0), (uint32_t)SQ_RL(st.lv1)};
+                            const double rub = __hiloint2double(SQ_RL(__double2hiint(ub)), SQ_RL(__double2loint(ub)));
+                            double b2 = 0.0;
+                            const int s2 = sq_walk_wave(env, SQ_RL(sa), SQ_RL(sb), w, early, rub, l_ofr, bar(), &b2, lane);
+#undef SQ_RL
+                            if (lane == r) { st = w; status = s2; bnd = b2; }
+                        }
+                        break;
+                    }
+                }
                 if (ok) {
-                    // (a finalscore that met no bracket strand -- no strand inside the span whose partner lies outside it -- does not
-                    // read the levels at all: it outlives the rounds that renumber them, SQ_RX_LVL says which do not)
-                    LB[q].fin = fin; LA[q].lf = (lf & ~SQ_RX_LVL) | SQ_RX_FIN | (wingless ? 0u : SQ_RX_LVL);
-                    ok = fin >= minfin;                                         // :751
+                    if (status == SQ_WALK_OUT) {
+                        LB[q].fin = bnd; LA[q].lf = (lf & ~SQ_RX_FIN) | SQ_RX_FB | SQ_RX_LVL;
+                        ok = false;
+                    } else {
+                        const SqWalk w = {st.nrec, st.be0, st.be1, st.covered, st.brackets, (uint64_t)st.lv0 | ((uint64_t)st.lv1 << 32)};
+                        fin = sq_stem_finalscore_of(env, i0, j0, L, bps, w);
+                        // (a finalscore that met no bracket strand -- no strand inside the span whose partner lies outside it -- does not
+                        // read the levels at all: it outlives the rounds that renumber them, SQ_RX_LVL says which do not)
+                        LB[q].fin = fin; LA[q].lf = (lf & ~(SQ_RX_LVL | SQ_RX_FB)) | SQ_RX_FIN | (st.brackets == 0 ? 0u : SQ_RX_LVL);
+                        ok = fin >= minfin;                                     // :751
+                    }
                 }
                 take(ok, fin, key, (uint32_t)L, bps);
                 raise(ok, fin);
