@@ -429,8 +429,8 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             }
             ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0; ra.ties = chain_ties ? 1 : 0;
             {
-                static const int wmin = getenv("SQ_WAVE_WALK_MIN") ? atoi(getenv("SQ_WAVE_WALK_MIN")) : 192;
-                static const int wlanes = getenv("SQ_WAVE_WALK_LANES") ? atoi(getenv("SQ_WAVE_WALK_LANES")) : 12;
+                const int wmin = getenv("SQ_WAVE_WALK_MIN") ? atoi(getenv("SQ_WAVE_WALK_MIN")) : 192;
+                const int wlanes = getenv("SQ_WAVE_WALK_LANES") ? atoi(getenv("SQ_WAVE_WALK_LANES")) : 12;
                 ra.wave_min = wmin > 0 ? wmin : 0x7fffffff; ra.wave_lanes = wlanes; ra.no_early = getenv("SQ_NO_EARLY_WALK") ? 1 : 0;
             }
             ra.fly = 0;

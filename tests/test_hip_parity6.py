@@ -89,3 +89,30 @@ def test_dense_matrix_jobs_on_the_chain_path_equal_the_oracle(kind, monkeypatch)
     finally:
         E.set_bpp_provider(old)
         O.BPP_SOURCE = None
+
+
+@pytest.mark.parametrize("config,count,nmin,nmax", [("fastest", 60, 200, 900), ("alt", 40, 60, 300)])
+def test_walk_slices_early_end_and_wave_continuation_equal_the_plain_walk(config, count, nmin, nmax, monkeypatch):
+    """ScoreStems' walk of the persistent round kernel in its three forms -- the defaults (slices, an early end at the order
+    factor's bound, the wave's continuation on structures of 192 strands and more), the continuation forced on every structure
+    (SQ_WAVE_WALK_MIN=1, also with 64 lanes' worth of walks handed over: SQ_WAVE_WALK_LANES=64) and no early end at all
+    (SQ_NO_EARLY_WALK) -- give the same packed records on records with reactivities, restraints and separators, pseudoknots
+    free of charge (orderpenalty 0: every order factor equal) and expensive (orderpenalty 2), and equal the launched rounds."""
+    from squarna_amd.engine import Batch, Prepared
+    names, psets = conf(config)
+    raw = _chain_records(count, 6116, nmin, nmax)
+    prepared = [Prepared(s, r, x) for s, r, x in raw]
+    for op in (None, 0.0, 2.0, -0.5):                             # (-0.5: the order factors GROW with the levels -- no early end)
+        ps = psets if op is None else [dict(p, orderpenalty=op) for p in psets]
+        with Batch(prepared, [ps] * count, max_structs=4 * count, fp32=False) as b:
+            b.fold(poollim=1)
+            assert b.fold_driver == 1 and (b.fold_paths & 4), (b.fold_driver, b.fold_paths)
+            want = _packed(b, count)
+            for env in ({"SQ_WAVE_WALK_MIN": "1"}, {"SQ_WAVE_WALK_MIN": "1", "SQ_WAVE_WALK_LANES": "64"}, {"SQ_NO_EARLY_WALK": "1"},
+                        {"SQ_NO_ROUNDS": "1"}):
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                b.fold(poollim=1)
+                assert _packed(b, count) == want, (config, op, env)
+                for k in env:
+                    monkeypatch.delenv(k)
