@@ -37,6 +37,18 @@ __device__ __forceinline__ int sq_wave_sum32(int v)
     return v;
 }
 
+#define SQ_LEVELS_REG 8            // stems per lane the first fit of the levels keeps in registers (lists of up to 512 stems)
+__device__ __forceinline__ uint32_t sq_extend_or_u32(uint32_t v)       // every lane gets the OR over the lanes (DPP: VALU only)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 struct SqExtendLds {
     int16_t *i, *j, *len, *ord;
     int32_t *cc;
@@ -63,8 +75,10 @@ __device__ __forceinline__ SqExtendLds sq_extend_lds(char *base, int T)
 // stems that cross nothing all land in group 0; the others are ordered by (weight, start), first-fitted into groups
 // and the groups ranked by size.  Result: L.lvl[q] = 1-based level of stem q.  One wave; the caller's block is that wave
 // (every SQ_EXTEND_SYNC() below is the wave's own barrier).  level_ovf: set when more than SQ_MAXLEVELS groups appear.
-__device__ __forceinline__ int sq_stem_levels_wave(SqExtendLds &L, int T, int lane, uint32_t *level_ovf)
+__device__ __forceinline__ int sq_stem_levels_wave(SqExtendLds &L, int T, int lane, uint32_t *level_ovf, long long *prof = nullptr)
 {
+    long long pt0 = prof ? wall_clock64() : 0;
+#define SQ_LVPROF(k) do { if (prof) { const long long n_ = wall_clock64(); prof[k] += n_ - pt0; pt0 = n_; } } while (0)
     // stems that cross nothing sort first (weight 0) and all land in group 0
     int g0 = 0, has0 = 0;
     for (int q = lane; q < T; q += 64) {
@@ -77,6 +91,29 @@ __device__ __forceinline__ int sq_stem_levels_wave(SqExtendLds &L, int T, int la
     if (lane == 0) L.gsize[0] = g0;
     // order of the crossing stems: (weight, start) ascending (:125); starts are distinct
     int nx = 0;
+    if (T <= 64 * SQ_LEVELS_REG) {
+        // (lists of up to 512 stems: ONE sweep over the stems with every lane's keys -- weight << 15 | start, weights stay below
+        // 2^16: they are sums of stem lengths -- in registers and the loads of a step unconditional, so that they pipeline; until
+        // round 6 a sweep per 64 stems whose second load hung behind a branch: ~90 us of a 360-stem structure's round)
+        uint32_t key[SQ_LEVELS_REG]; int rk[SQ_LEVELS_REG];
+#pragma unroll
+        for (int c = 0; c < SQ_LEVELS_REG; c++) {
+            const int q = 64 * c + lane;
+            const bool x = q < T && L.cc[q] > 0;
+            key[c] = x ? ((uint32_t)L.cc[q] << 15) | (uint32_t)(uint16_t)L.i[q] : 0u;     // (0: not a crossing stem)
+            rk[c] = 0;
+            nx += __popcll(__ballot(x));
+        }
+#pragma unroll 4
+        for (int p = 0; p < T; p++) {
+            const uint32_t cp = (uint32_t)L.cc[p], ip = (uint32_t)(uint16_t)L.i[p];
+            const uint32_t kp = cp ? (cp << 15) | ip : 0xFFFFFFFFu;                          // (a stem without crossings is below nobody)
+#pragma unroll
+            for (int c = 0; c < SQ_LEVELS_REG; c++) rk[c] += kp < key[c] ? 1 : 0;
+        }
+#pragma unroll
+        for (int c = 0; c < SQ_LEVELS_REG; c++) if (key[c]) L.ord[rk[c]] = (int16_t)(64 * c + lane);
+    } else
     for (int q0 = 0; q0 < T; q0 += 64) {
         const int q = q0 + lane;
         const bool x = q < T && L.cc[q] > 0;
@@ -92,7 +129,51 @@ __device__ __forceinline__ int sq_stem_levels_wave(SqExtendLds &L, int T, int la
         nx += __popcll(__ballot(x));
     }
     SQ_EXTEND_SYNC();
+    SQ_LVPROF(0);
     // first fit (:130-136): a stem joins the first group none of whose members it crosses
+    if (T <= 64 * SQ_LEVELS_REG) {
+        // Lists of up to 512 stems: every lane keeps its stems' ends and groups in REGISTERS for the whole loop (until round 6 each
+        // of the nx steps read all T stems' groups and ends from LDS, reduced the blocked groups with twelve ds_bpermute and went
+        // through two barriers for lane 0's update: 335 us per round on structures of 360 stems, most of a round's extension --
+        // and the other waves of the round kernel wait for it before they score).  A step: the next stem's ends (asked for one
+        // step ahead), the crossing tests on registers, the blocked groups by DPP OR reductions, the owner's register update.
+        int pij[SQ_LEVELS_REG], g[SQ_LEVELS_REG];
+#pragma unroll
+        for (int c = 0; c < SQ_LEVELS_REG; c++) {
+            const int q = 64 * c + lane;
+            const bool v = q < T;
+            pij[c] = v ? ((int)(uint16_t)L.i[q] | ((int)(uint16_t)L.j[q] << 16)) : 0;
+            g[c] = v ? (int)L.grp[q] : 255;
+        }
+        int mygs = lane == 0 ? g0 : 0;                           // lane k: the size of group k
+        int pn = nx > 0 ? L.ord[0] : 0;
+        int ni = L.i[pn], nj = L.j[pn], nl = L.len[pn];
+        for (int t = 0; t < nx; t++) {
+            const int p = pn, pi = ni, pj = nj, plen = nl;
+            if (t + 1 < nx) { pn = L.ord[t + 1]; ni = L.i[pn]; nj = L.j[pn]; nl = L.len[pn]; }
+            uint32_t b0 = 0u, b1 = 0u;
+#pragma unroll
+            for (int c = 0; c < SQ_LEVELS_REG; c++) {
+                if (64 * c >= T) break;                                  // (wave-uniform)
+                const int qi = pij[c] & 0xFFFF, qj = (int)((uint32_t)pij[c] >> 16);
+                const bool x = g[c] != 255 && sq_chain_cross(pi, pj, qi, qj);
+                if (x) { if (g[c] < 32) b0 |= 1u << g[c]; else b1 |= 1u << (g[c] - 32); }
+            }
+            b0 = sq_extend_or_u32(b0);
+            b1 = ngroups > 32 ? sq_extend_or_u32(b1) : 0u;
+            const unsigned long long blocked = (unsigned long long)b0 | ((unsigned long long)b1 << 32);
+            int placed = blocked == ~0ull ? 64 : __ffsll((long long)~blocked) - 1;
+            if (placed > ngroups) placed = ngroups;
+            if (placed >= SQ_MAXLEVELS) { if (lane == 0) *level_ovf = 1; placed = SQ_MAXLEVELS - 1; }   // (reported as an error)
+            else if (placed == ngroups) ngroups++;
+#pragma unroll
+            for (int c = 0; c < SQ_LEVELS_REG; c++) if (c == (p >> 6) && lane == (p & 63)) g[c] = placed;
+            if (lane == (p & 63)) L.grp[p] = (uint8_t)placed;
+            if (lane == placed) mygs += plen;
+        }
+        if (lane < 64) L.gsize[lane] = lane < ngroups ? mygs : 0;
+        SQ_EXTEND_SYNC();
+    } else
     for (int t = 0; t < nx; t++) {
         const int p = L.ord[t];
         const int pi = L.i[p], pj = L.j[p];
@@ -110,6 +191,8 @@ __device__ __forceinline__ int sq_stem_levels_wave(SqExtendLds &L, int T, int la
         if (lane == 0) { L.grp[p] = (uint8_t)placed; L.gsize[placed] += L.len[p]; }
         SQ_EXTEND_SYNC();
     }
+    SQ_LVPROF(1);
+    if (prof) prof[3] += nx;
     // groups ranked by size, descending, stable (:139); level = rank + 1
     if (lane < ngroups) {
         const int gs = L.gsize[lane];
@@ -120,6 +203,8 @@ __device__ __forceinline__ int sq_stem_levels_wave(SqExtendLds &L, int T, int la
     SQ_EXTEND_SYNC();
     for (int q = lane; q < T; q += 64) L.lvl[q] = L.rank[L.grp[q]];
     SQ_EXTEND_SYNC();
+    SQ_LVPROF(2);
+#undef SQ_LVPROF
     return ngroups;                                   // (groups in use: L.grp / L.gsize stay valid for sq_stem_levels_join)
 }
 

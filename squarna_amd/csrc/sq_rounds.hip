@@ -147,11 +147,12 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
     // bound / score steps, pick, extension + state
     long long _pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
     long long _cnt[4] = {0, 0, 0, 0};       // entries streamed, finalscores taken from the list, runs scored (first wave), rounds
+    long long _xl[4] = {0, 0, 0, 0};        // the full level rule: order, first fit, ranks; crossing stems placed
     long long _xt[4] = {0, 0, 0, 0};        // the extension: levels, full rule / joins; strands + skip pointers; [3] rounds with the full rule
     long long _sp[6] = {0, 0, 0, 0, 0, 0};  // the score step: [0] wait for the structure, [1] entry loads, [3] the rest; [4] steps
 #define SPROF(k) do { const long long _n = wall_clock64(); _sp[k] += _n - _t2; _t2 = _n; } while (0)
 #define RPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)
-#define RPROF_OUT() do { if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d extension us: levels %.1f (%lld rounds with the full rule) strands + skip pointers %.1f\n", b, wv, _xt[0] * 0.01, _xt[3], _xt[1] * 0.01); if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d score steps %lld | us: wait for the structure %.1f entry loads %.1f ScoreStems + stores + pick %.1f\n", b, wv, _sp[4], _sp[0] * 0.01, _sp[1] * 0.01, _sp[3] * 0.01); if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d n=%d rounds %lld | us: setup %.1f scan %.1f order %.1f stream %.1f cut %.1f bound %.1f score %.1f pick %.1f ext %.1f between %.1f total %.1f | wave 0: streamed %lld kept %lld scored %lld\n", \
+#define RPROF_OUT() do { if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d extension us: levels %.1f (%lld rounds with the full rule: order %.1f first fit %.1f of %lld stems, ranks %.1f) strands + skip pointers %.1f\n", b, wv, _xt[0] * 0.01, _xt[3], _xl[0] * 0.01, _xl[1] * 0.01, _xl[3], _xl[2] * 0.01, _xt[1] * 0.01); if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d score steps %lld | us: wait for the structure %.1f entry loads %.1f ScoreStems + stores + pick %.1f\n", b, wv, _sp[4], _sp[0] * 0.01, _sp[1] * 0.01, _sp[3] * 0.01); if ((tid == 0 || tid == 64) && (b % 97) == 0) printf("rounds block %d wave %d n=%d rounds %lld | us: setup %.1f scan %.1f order %.1f stream %.1f cut %.1f bound %.1f score %.1f pick %.1f ext %.1f between %.1f total %.1f | wave 0: streamed %lld kept %lld scored %lld\n", \
         b, wv, n, _cnt[3], _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, _pt[6] * 0.01, _pt[7] * 0.01, _pt[8] * 0.01, _pt[9] * 0.01, (wall_clock64() - _t00) * 0.01, _cnt[0], _cnt[1], _cnt[2]); } while (0)
 #else
 #define RPROF(k) do {} while (0)
@@ -857,9 +858,11 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
             if (ac) {
                 if (was_cross && !mycross && ngroups > 0) sq_stem_levels_join(XL, k + 1, ngroups, len, lane);
                 else {
-                    ngroups = sq_stem_levels_wave(XL, k + 1, lane, &a.ctr->level_ovf);
 #ifdef SQ_ROUNDS_PROF
+                    ngroups = sq_stem_levels_wave(XL, k + 1, lane, &a.ctr->level_ovf, _xl);
                     _xt[3]++;
+#else
+                    ngroups = sq_stem_levels_wave(XL, k + 1, lane, &a.ctr->level_ovf);
 #endif
                 }
             }
