@@ -176,3 +176,24 @@ def test_algos_override_golden():
         out = O.SQRNdbnseq(c["seq"], c["reacts"], None, None, psets, algos=set(c["algos"]), **c["kw"])
         got = [out[0], [[d, list(sc), list(ps)] for d, sc, ps in out[1]], list(out[2]), list(out[3])]
         assert same(got, unnan(c["out"])), (c["seq"], c["algos"])
+
+
+def test_reference_form_of_the_oracle_equals_the_c_form():
+    """oracle/sqrn_pyform.py -- the oracle's hot loops as interpreted per-cell Python, the form cpu_baseline.reference_form is
+    timed in -- gives the tuples of the C form: short SRtest150 records under nobpp (G, N, E, H paramsets) and the example
+    records with restraints, reactivities and separators."""
+    from oracle import sqrn_oracle as O, sqrn_pyform as P
+    from squarna_amd.config import ParseConfig, builtin_config
+    from squarna_amd.inputs import ParseDefaultInput
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names, psets = ParseConfig(builtin_config("nobpp"))
+    recs = sorted(ParseDefaultInput(os.path.join(root, "squarna_amd", "data", "datasets", "SRtest150.fas"), "qf"), key=lambda r: len(r[1]))[:60:6]
+    recs += [r for r in ParseDefaultInput(os.path.join(root, "squarna_amd", "data", "examples", "seq_input.fas"), "q") if len(r[1]) <= 80]
+    for name, seq, reacts, restr, ref in recs:
+        want = O.SQRNdbnseq(seq, reacts, restr, ref, psets)
+        P.install(True)
+        try:
+            got = O.SQRNdbnseq(seq, reacts, restr, ref, psets)
+        finally:
+            P.install(False)
+        assert repr(got) == repr(want), name

@@ -2,5 +2,5 @@
 cd $GRAFT_REPO_ROOT
 cp squarna_amd/libsquarna_hip.so /tmp/lib_keep.so
 SQ_DEFS=-DSQ_ROUNDS_PROF python -c "from squarna_amd.build import build_library; build_library(force=True)"
-for a in "$@"; do echo "== $a"; SQ_NO_LAUNCHED=1 python tools/rounds_probe.py $a 1 2>&1 | grep "^rounds block" | head -${PROF_LINES:-4}; done
+for a in "$@"; do echo "== $a"; SQ_NO_LAUNCHED=1 python tools/rounds_probe.py $a 1 2>&1 | grep "^rounds block.*n=" | head -${PROF_LINES:-4}; done
 cp /tmp/lib_keep.so squarna_amd/libsquarna_hip.so
