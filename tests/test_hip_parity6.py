@@ -116,3 +116,48 @@ def test_walk_slices_early_end_and_wave_continuation_equal_the_plain_walk(config
                 assert _packed(b, count) == want, (config, op, env)
                 for k in env:
                     monkeypatch.delenv(k)
+
+
+def _msa_text(nseq, ncol, seed):
+    import random
+    rng = random.Random(seed)
+    anc = [rng.choice("ACGU") for _ in range(ncol)]
+    for _ in range(max(2, ncol // 40)):
+        a, ln = rng.randint(0, ncol // 2 - 12), rng.randint(4, 8)
+        b = rng.randint(ncol // 2 + 8, ncol - 1)
+        for t in range(ln):
+            if a + t < b - t - 4:
+                anc[b - t] = {"A": "U", "U": "A", "G": "C", "C": "G"}[anc[a + t]]
+    rows = []
+    for k in range(nseq):
+        row = [rng.choice("ACGU") if rng.random() < 0.12 else ch for ch in anc]
+        row = ["-" if rng.random() < 0.06 else ch for ch in row]
+        rows.append(">s%d\n%s" % (k, "".join(row)))
+    return "\n".join(rows) + "\n"
+
+
+@pytest.mark.parametrize("algos", [None, "GEHN"])
+def test_alignment_rows_read_the_shared_matrix_like_their_gathered_slices(algos, tmp_path, monkeypatch):
+    """Alignment mode on a 40 x 700 alignment, all three steps: the rows of step 2 reading their weights from the ONE shared
+    diagonal-major matrix through the gap map (default) against per-row slices gathered from it (SQ_MUL_GATHER=1, the
+    round-3 form), and step 1's rows prepared at once as array code against one record per row (SQ_NO_PACKED_ROWS=1): the same
+    text, verbose output included.  algos = GEHN: the rows' E / H / N jobs take RunAlgo's host-driven filters, which gather
+    one slice per job on demand."""
+    import io
+    from squarna_amd import Predict
+    path = tmp_path / "ali.afa"
+    path.write_text(_msa_text(40, 700, 77))
+    kw = dict(inputfile=str(path), alignment=True, step3="u", verbose=True)
+    if algos:
+        kw["algorithms"] = algos
+
+    def run():
+        buf = io.StringIO()
+        Predict(write_to=buf, **kw)
+        return buf.getvalue()
+    want = run()
+    assert "Step-3(u)" in want and want.count("\n") > 40
+    for env in ("SQ_MUL_GATHER", "SQ_NO_PACKED_ROWS"):
+        monkeypatch.setenv(env, "1")
+        assert run() == want, env
+        monkeypatch.delenv(env)
