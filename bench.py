@@ -310,7 +310,7 @@ def kernels_hash():
     h = hashlib.sha256()
     for f in ("sq_kernels.hip", "sq_cells.h", "sq_context.h", "sq_context.hip", "sq_match.hip", "sq_blossom.h", "sq_rounds.hip",
               "sq_rounds.h", "sq_scan.h", "sq_score.h", "sq_extend.h", "sq_pool_round.hip", "sq_pool_round.h", "sq_cellrun.h",
-              "sq_device.h"):
+              "sq_device.h", "sq_gather.hip"):
         with open(os.path.join(ROOT, "squarna_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -1238,12 +1238,21 @@ extern "C" __global__ __launch_bounds__(256) void sq_colselect_kernel(const doub
     // for the 200 MB of a 5,000-column matrix)
     for (int v = blockIdx.y; v < L; v += gridDim.y) {
         const double *row = matrix + (int64_t)v * L;
-        for (int w = max(v + minspan, 0) + blockIdx.x * 256 + threadIdx.x; w < L; w += gridDim.x * 256) {      // w - v >= minspan (:147)
-            const double x = row[w];
-            if (x >= thr) {
-                const unsigned long long o = atomicAdd(count, 1ull);
-                if ((long long)o < cap) { idx_out[o] = (int64_t)v * L + w; val_out[o] = x; }
-            }
+        // (the places of a wave's cells are reserved with ONE atomic: iteration 1 of a conserved alignment selects hundreds of
+        // thousands of cells, and an atomic per cell on one counter was the kernel's whole 1.8 ms)
+        const int w0 = max(v + minspan, 0) + blockIdx.x * 256;                                                  // w - v >= minspan (:147)
+        for (int wb = w0; wb < L; wb += gridDim.x * 256) {
+            const int w = wb + threadIdx.x;
+            const double x = w < L ? row[w] : 0.0;
+            const bool hit = w < L && x >= thr;
+            const unsigned long long m = __ballot(hit);
+            if (m == 0ull) continue;
+            const int lane = threadIdx.x & 63;
+            unsigned long long base = 0ull;
+            if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(m));
+            base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const unsigned long long o = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+            if (hit && (long long)o < cap) { idx_out[o] = (int64_t)v * L + w; val_out[o] = x; }
         }
     }
 }

@@ -33,7 +33,8 @@ for arg in sys.argv[2:]:
     if not tot:
         print("no rows for", kern, "in", d)
         continue
-    e = {"source": "profiles/%s_%s_pmc.txt (rocprofv3 --pmc, %s)" % (tag, kern.replace("sq_", "").replace("_kernel", ""), os.path.basename(d.rstrip("/")))}
+    summary = "a5000" if kern.startswith("a5000_") else kern.replace("sq_", "").replace("_kernel", "")   # (the alignment's three kernels share one summary file)
+    e = {"source": "profiles/%s_%s_pmc.txt (rocprofv3 --pmc, %s)" % (tag, summary, os.path.basename(d.rstrip("/")))}
     if "FETCH_SIZE" in tot:
         e["fetch_bytes_per_launch"] = round(tot["FETCH_SIZE"] * 1024 * 2 / ndisp["FETCH_SIZE"])
     if "WRITE_SIZE" in tot:
