@@ -637,7 +637,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             pra.lds_n = maxn; pra.str_cap = 2 * pio.pt + 2; pra.cell_entries = b->cell_entries;
             // survivors of :492 kept in LDS (the rest spill to the arena): on a crowded chip LDS is what the round kernel's waves
             // and everybody else's compete for -- 22 bytes x 256 survivors were half of a wave's 10 KB, and most structures have
-            // a few dozen (tools/pr_waves_sweep.sh: 64 -> +5 % on the headline, 16 .. 64 within a per cent of each other)
+            // a few dozen (round 4, a sweep of the count: 64 -> +5 % on the headline, 16 .. 64 within a per cent of each other)
             const bool crowded_fold = b->inflight > 1 || b->njobs >= 4096;
             pra.surv_cap = sw.pool_round_nsurv ? sw.pool_round_nsurv : (root_mode ? 256 : (crowded_fold ? 64 : (maxn <= 96 ? 128 : 256))); pra.bound = b->score_bound ? 1 : 0;
             pra.tmax = pio.pt; pra.parity = 0; pra.lo = 0; pra.ahead = 0;
