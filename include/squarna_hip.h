@@ -97,9 +97,12 @@ typedef struct sq_batch_desc {
     /* Alignment step 2 without one dense matrix per sequence (SQRNdbnseq.py:1031-1034 deletes the gap rows and columns
      * of the same L x L stem matrix for every sequence, :1084-1085 multiplies): ONE L x L row-major fp64 matrix in
      * DEVICE memory (the step-1 matrix never has to leave the GPU) and, per sequence, the alignment column of each of
-     * its gap-free positions.  A job with mul_shared[j] != 0 takes bpscorematrix[a][b] *= M[cols[a]][cols[b]]; the
-     * library gathers its N x N slice on the device at sq_batch_create (on the batch's stream: M must be complete
-     * there).  Such a job has no mul_score / bpp_term / caller matrices.  All NULL / 0: not used. */
+     * its gap-free positions.  A job with mul_shared[j] != 0 takes bpscorematrix[a][b] *= M[cols[a]][cols[b]]: at
+     * sq_batch_create the library copies M into the workspace in a diagonal-major layout (on the batch's stream: M must
+     * be complete there; the caller's matrix is not read afterwards) and the kernels read a cell's weight from that copy
+     * through `cols` where they need it -- no per-sequence N x N slice exists (SQ_MUL_GATHER=1 in the environment restores
+     * the gathered slices of earlier versions: 8 N^2 bytes per job).  Such a job has no mul_score / bpp_term / caller
+     * matrices.  All NULL / 0: not used. */
     const double *mul_matrix_dev;   /* device pointer */
     int32_t mul_L;
     const int32_t *mul_cols;        /* [seq_off[nseq]] host: column of every position (same offsets as codes)   */
