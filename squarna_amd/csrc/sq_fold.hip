@@ -418,6 +418,17 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             ra.lds_n = maxn; ra.str_cap = 2 * maxt + 2; ra.tmax = maxt; ra.cell_entries = b->cell_entries;
             ra.su = 0;
             for (int j : jobs) if (b->seq_has_sep[(size_t)b->job_seq[j]]) { ra.su = 1; break; }
+            // Pools that may branch (their chains can hand a job to the device pools): when the lists sized for a structure's BOUND
+            // of stems -- n / (2 minlen): 1,178 at 4,700 nt, where a row takes ~370 -- keep a CU to one block, they are sized for
+            // fewer (the largest of a few steps that lets two blocks of 512 threads share a CU); a structure that outgrows them
+            // stops like one that meets a tie.  SQ_ROUNDS_TLDS=n: that size by hand (tests force the hand-over)
+            if (chain_ties && !thr_env) {
+                const int tenv = getenv("SQ_ROUNDS_TLDS") ? std::max(1, atoi(getenv("SQ_ROUNDS_TLDS"))) : 0;
+                auto fits2 = [&](int t) { return sq_rounds_lds(ra.lds_n, 2 * t + 2, t, ra.cell_entries, 512, ra.su).total + 2048 <= 80 * 1024; };
+                if (tenv) { if (tenv < maxt) { ra.tmax = tenv; ra.str_cap = 2 * tenv + 2; } }
+                else if (S > 256 && maxn >= 1024 && !fits2(maxt))
+                    for (int t : {1024, 768, 640, 512, 448}) if (t < maxt && fits2(t)) { ra.tmax = t; ra.str_cap = 2 * t + 2; thr = std::max(thr, 512); break; }
+            }
             // (long sequences: the per-position arrays and strand lists of ONE block fill most of a CU's LDS -- 90 KB at 4,700 nt --, so
             // the CU holds one block however many there are: it takes the wave slots the others cannot use.  512 rows of an
             // alignment ran as 512 blocks of four waves on 256 CUs)

@@ -804,6 +804,19 @@ extern "C" __global__ __launch_bounds__(SQ_ROUNDS_THREADS) __attribute__((amdgpu
         const int i0 = (int)(bkey & 0xFFFFu), j0 = (int)(bkey >> 16) - i0, len = (int)blen;
         const int k = nstems;
         if (k >= ch.tcap) { if (tid == 0) a.ctr->out_ovf = 1; retire(k, 0); return; }
+        if (k >= ra.tmax) {
+            // the block's LDS lists were sized for fewer stems than the structure's bound (two blocks per CU: sq_fold.hip): the
+            // structure stops, unfinished, like one that meets a tie -- the device pools fold its job
+            if (tid == 0) {
+                if (ra.ties) {
+                    structs[b].nstrand = -1;
+                    const uint32_t idx = atomicAdd(cio.d_nfin, 1u);
+                    cio.h_fin[idx] = (unsigned long long)(uint32_t)st.job | (1ull << 62);
+                } else a.ctr->out_ovf = 1;
+            }
+            if (!ra.ties) retire(k, 0);
+            return;
+        }
         // ---- the child.  Before the barrier: the first wave books the stem and its crossing weights (:121-124) -- which say
         // whether the levels will be taken anew --, the other waves update partner array and prefix counts: positions p and
         // above lose the new pairs below p, and separators never pair, so SU stays ----

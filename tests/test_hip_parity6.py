@@ -157,7 +157,9 @@ def test_alignment_rows_read_the_shared_matrix_like_their_gathered_slices(algos,
         return buf.getvalue()
     want = run()
     assert "Step-3(u)" in want and want.count("\n") > 40
-    for env in ("SQ_MUL_GATHER", "SQ_NO_PACKED_ROWS"):
-        monkeypatch.setenv(env, "1")
+    for env, val in (("SQ_MUL_GATHER", "1"), ("SQ_NO_PACKED_ROWS", "1"), ("SQ_ROUNDS_TLDS", "12")):
+        # (SQ_ROUNDS_TLDS=12: the round kernel's LDS lists hold twelve stems -- every row that takes more hands its job to the
+        # device pools, as a row does that outgrows the lists sized for two blocks per CU)
+        monkeypatch.setenv(env, val)
         assert run() == want, env
         monkeypatch.delenv(env)
