@@ -1234,25 +1234,42 @@ extern "C" __global__ __launch_bounds__(256) void sq_colselect_kernel(const doub
                                                                      long long *idx_out, double *val_out, long long cap,
                                                                      unsigned long long *count)
 {
-    // a row per blockIdx.y, its cells from column v + minspan on (no 64-bit division per cell: the kernel was bound by those, 1.2-1.8 ms
-    // for the 200 MB of a 5,000-column matrix)
-    for (int v = blockIdx.y; v < L; v += gridDim.y) {
+    // A block takes rows blockIdx.x, + gridDim.x, ...; the cells it selects are staged in LDS and written out a thousand at a time
+    // behind ONE atomic on the counter.  (Iteration 1 of a conserved alignment selects hundreds of thousands of cells: an atomic
+    // per cell -- and, tried first in round 6, per wave -- on one address was the kernel's whole 1.8 ms for 100 MB of reads.)
+    __shared__ long long s_idx[1024];
+    __shared__ double s_val[1024];
+    __shared__ uint32_t s_n;
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_n = 0u;
+    __syncthreads();
+    auto flush = [&]() {                                    // (block-uniform call, between barriers)
+        const uint32_t n = s_n;
+        if (tid == 0) s_base = atomicAdd(count, (unsigned long long)n);
+        __syncthreads();
+        const unsigned long long base = s_base;
+        for (uint32_t k = tid; k < n; k += 256) if ((long long)(base + k) < cap) { idx_out[base + k] = s_idx[k]; val_out[base + k] = s_val[k]; }
+        __syncthreads();
+        if (tid == 0) s_n = 0u;
+        __syncthreads();
+    };
+    for (int v = blockIdx.x; v < L; v += gridDim.x) {
         const double *row = matrix + (int64_t)v * L;
-        // (the places of a wave's cells are reserved with ONE atomic: iteration 1 of a conserved alignment selects hundreds of
-        // thousands of cells, and an atomic per cell on one counter was the kernel's whole 1.8 ms)
-        const int w0 = max(v + minspan, 0) + blockIdx.x * 256;                                                  // w - v >= minspan (:147)
-        for (int wb = w0; wb < L; wb += gridDim.x * 256) {
-            const int w = wb + threadIdx.x;
+        for (int wb = max(v + minspan, 0); wb < L; wb += 256) {                                                 // w - v >= minspan (:147)
+            const int w = wb + tid;
             const double x = w < L ? row[w] : 0.0;
             const bool hit = w < L && x >= thr;
             const unsigned long long m = __ballot(hit);
-            if (m == 0ull) continue;
-            const int lane = threadIdx.x & 63;
-            unsigned long long base = 0ull;
-            if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(m));
-            base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            const unsigned long long o = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-            if (hit && (long long)o < cap) { idx_out[o] = (int64_t)v * L + w; val_out[o] = x; }
+            if (m != 0ull) {
+                uint32_t b0 = 0u;
+                if (lane == 0) b0 = atomicAdd(&s_n, (uint32_t)__popcll(m));
+                b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+                if (hit) { const uint32_t at = b0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); s_idx[at] = (int64_t)v * L + w; s_val[at] = x; }
+            }
+            __syncthreads();
+            if (s_n > 768u) flush();                         // (room for the next 256)
         }
     }
+    if (s_n > 0u) flush();
 }

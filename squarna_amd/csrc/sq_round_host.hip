@@ -635,7 +635,7 @@ extern "C" int sq_colmatrix_select(const double *d_matrix, int32_t L, double thr
     HIPCK(hipMemsetAsync(d_count, 0, 8, st));
     const int64_t total = (int64_t)L * L;
     (void)total;
-    hipLaunchKernelGGL(sq_colselect_kernel, dim3((unsigned)std::min<int64_t>((L + 1023) / 1024, 8), (unsigned)std::min<int32_t>(L, 65535)), dim3(256), 0, st,
+    hipLaunchKernelGGL(sq_colselect_kernel, dim3((unsigned)std::min<int32_t>(L, 2048)), dim3(256), 0, st,
                        d_matrix, L, threshold, minspan, (long long *)d_idx, d_val, (long long)cap, (unsigned long long *)d_count);
     return sq_check(hipGetLastError(), "sq_colselect_kernel");
 }
