@@ -354,6 +354,10 @@ SQ_API int64_t sq_write_blocks(const sq_batch *b, const sq_block_desc *d, char *
  * also for an empty line).  Returns the number of records, or -1 when the file needs the general parser: default lines
  * in front of the first record, a byte outside ASCII, NUL or '\r', a record without a sequence token, more than cap
  * records.  Host code; values are not validated here (lengths, reactivities): the caller's checks stay the reference's. */
+/* sq_align_first_fit -- the first structure of MatrixToDBNs (SQRNdbnali.py:121-192, the one its caller keeps, :242): the cells
+ * flat[k] = v * N + w, given in decreasing order of value (ties: flat index ascending), are taken one by one; a cell of span
+ * >= minspan whose columns are both free joins.  pairs: up to cap (v, w) pairs in the order taken; returns their number. */
+SQ_API int64_t sq_align_first_fit(const int64_t *flat, int64_t n, int32_t N, int32_t minspan, int32_t *pairs, int64_t cap);
 SQ_API int64_t sq_parse_default(const char *text, int64_t len, int32_t nfields, int32_t q_ind, int32_t t_ind, int32_t r_ind,
                                 int32_t f_ind, int64_t *out, int64_t cap);
 

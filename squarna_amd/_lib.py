@@ -23,7 +23,7 @@ SYMBOLS = ["sq_version", "sq_last_error", "sq_last_capacity", "sq_batch_workspac
            "sq_align_accumulate", "sq_colmatrix_select", "sq_fold_concurrent", "sq_fold_concurrent_n", "sq_fold_driver", "sq_fold_paths", "sq_fold_peak_structs", "sq_result_limit",
            "sq_mwm_workspace_bytes", "sq_mwm", "sq_lsap_workspace_bytes", "sq_lsap",
            "sq_nussinov_workspace_bytes", "sq_nussinov", "sq_dbn_pairs", "sq_write_blocks", "sq_parse_default",
-           "sq_host_cache_trim"]
+           "sq_host_cache_trim", "sq_align_first_fit"]
 
 BATCH_NO_FP32 = 1
 
@@ -104,6 +104,7 @@ def load():
     L.sq_last_error.restype = C.c_char_p
     L.sq_batch_destroy.restype = None
     L.sq_host_cache_trim.restype = C.c_longlong
+    L.sq_align_first_fit.restype = C.c_int64
     L.sq_host_cache_trim.argtypes = []
     L.sq_result_evals.restype = C.c_int64
     L.sq_result_pack_size.restype = C.c_int64

@@ -42,20 +42,20 @@ def MatrixToDBNs(mat, score, depth, verbose=False, sink=sys.stdout, cells=None):
         vals = flat[idx]
     else:
         idx, vals = cells
-    order = np.argsort(-vals, kind='stable')                      # stable: equal values keep index order
     if not verbose:
         # only the first structure is used by the caller (:242), and a cell joins it iff both of its columns
-        # are still free THERE -- whatever the later structures hold
-        sidx = np.asarray(idx)[order]
-        vs, ws = sidx // N, sidx % N
-        far = (ws - vs) >= 4                                       # :147
-        taken = bytearray(N)
-        first = []
-        for v, w in zip(vs[far].tolist(), ws[far].tolist()):       # plain ints: the loop is the sequential part
-            if not taken[v] and not taken[w]:
-                taken[v] = taken[w] = 1
-                first.append((v, w))
-        return [PairsToDBN(first, N)]
+        # are still free THERE -- whatever the later structures hold.  One sort (value descending, flat index ascending: what
+        # the reference's stable sort over the index-ordered cells gives) and the sequential pass in the library
+        import ctypes
+        from . import _lib
+        idx = np.ascontiguousarray(idx, np.int64)
+        sidx = np.ascontiguousarray(idx[np.lexsort((idx, -np.asarray(vals)))])
+        out = np.empty(2 * (N // 2 + 1), np.int32)
+        n = int(_lib.load().sq_align_first_fit(ctypes.c_void_p(sidx.ctypes.data), ctypes.c_int64(len(sidx)), int(N), 4,
+                                     ctypes.c_void_p(out.ctypes.data), ctypes.c_int64(len(out) // 2)))
+        assert 0 <= n <= len(out) // 2
+        return [PairsToDBN(out[:2 * n].reshape(-1, 2).tolist(), N)]
+    order = np.argsort(-vals, kind='stable')                      # stable: equal values keep index order
     res = [[[], set()]]
     print(">Conserved base pairs (one by one)", file=sink)
     for k in order:
@@ -102,7 +102,7 @@ def SQRNdbnali(objs, defrests=None, defreacts=None, defref=None, bpweights={}, i
         reduce_hook = getattr(eng, "reduce_matrix", None)
         if reduce_hook is not None:
             stemmatrix = reduce_hook(stemmatrix)                   # multi-GPU: all_reduce(sum) of the partial matrices
-        cells = eng.matrix_cells(stemmatrix, minbpscore * len(objs))
+        cells = eng.matrix_cells(stemmatrix, minbpscore * len(objs), sort=verbose)   # (the non-verbose form sorts once, by value)
         pred = MatrixToDBNs(stemmatrix, minbpscore, len(objs), verbose, sink=sink, cells=cells)
         return pred[0], stemmatrix
     stemmatrix = np.zeros((L, L))

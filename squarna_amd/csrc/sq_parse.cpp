@@ -9,6 +9,7 @@
 // token -- returns -1 and the caller runs the general Python form, which then also raises what the reference raises.
 #include <cstdint>
 #include <cstring>
+#include <vector>
 #include "sq_host.h"
 
 // str.strip() / str.split() whitespace among the ASCII code points (str.isspace): \t \n \v \f \r, 0x1c-0x1f, space
@@ -56,4 +57,25 @@ extern "C" SQ_API int64_t sq_parse_default(const char *text, int64_t len, int32_
     // every record needs its sequence line (a record cut short: the general form raises)
     for (int64_t k = 0; k < nrec; k++) if (out[10 * k + 3] < 0) return -1;
     return nrec;
+}
+
+
+// MatrixToDBNs' first structure (SQRNdbnali.py:121-192 as its caller uses it, :242): the cells in decreasing order of value (ties:
+// flat index ascending) are taken one by one; a cell of span >= minspan whose two columns are both still free joins the structure.
+// flat[k] = v * N + w of the k-th cell in that order.  Writes the pairs (v, w) in the order taken; returns their number (or -1).
+// Host code: the sequential part of alignment step 1 (hundreds of thousands of cells at 5,000 columns: a Python loop until round 6).
+extern "C" SQ_API int64_t sq_align_first_fit(const int64_t *flat, int64_t n, int32_t N, int32_t minspan, int32_t *pairs, int64_t cap)
+{
+    if (!flat || n < 0 || N <= 0 || !pairs || cap < 0) return -1;
+    std::vector<uint8_t> taken((size_t)N, 0);
+    int64_t cnt = 0;
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t v = flat[k] / N, w = flat[k] - v * N;
+        if (v < 0 || v >= N || w - v < minspan) continue;                 // :147
+        if (taken[(size_t)v] || taken[(size_t)w]) continue;
+        taken[(size_t)v] = taken[(size_t)w] = 1;
+        if (cnt < cap) { pairs[2 * cnt] = (int32_t)v; pairs[2 * cnt + 1] = (int32_t)w; }
+        cnt++;
+    }
+    return cnt;
 }

@@ -1202,9 +1202,9 @@ class HipEngine:
             lo = hi
         return matrix
 
-    def matrix_cells(self, matrix, threshold, minspan=4):
+    def matrix_cells(self, matrix, threshold, minspan=4, sort=True):
         """(flat indices, values) of the upper cells >= threshold with span >= minspan of a device matrix,
-        sorted by flat index (MatrixToDBNs' candidates, SQRNdbnali.py:127-148)."""
+        sorted by flat index unless sort=False (MatrixToDBNs' candidates, SQRNdbnali.py:127-148)."""
         import torch
         Lcols = int(matrix.shape[0])
         cap = 1 << 16
@@ -1221,6 +1221,8 @@ class HipEngine:
                 break
             cap = n
         idx, val = idx[:n].cpu().numpy(), val[:n].cpu().numpy()
+        if not sort:
+            return idx, val
         order = np.argsort(idx, kind="stable")
         return idx[order], val[order]
 
