@@ -133,21 +133,21 @@ def SQRNdbnali(objs, defrests=None, defreacts=None, defref=None, bpweights={}, i
 def _consensus_bulk(structs, freqlimit):
     """Consensus for many long lines (config 5: 512 x 5000): DBNToPairs of all lines in ONE library call (sq_dbn_pairs),
     the counts with numpy.  The reference's order is kept exactly: a stable sort by descending count over the dict's
-    insertion order (SQRNdbnali.py:285) == count descending, first occurrence ascending.  None: lines beyond ASCII
-    (the caller's Python form takes them)."""
+    insertion order (SQRNdbnali.py:285) == count descending, first occurrence ascending.  Lines beyond ASCII (more than 30
+    pseudoknot levels: Cyrillic bracket letters) go the same way, their letters recoded to single bytes (dbn.bracket_bytes)."""
     import ctypes
     from . import _lib
     N = len(structs[0])
+    from .dbn import bracket_bytes
     text = "".join(structs)
-    if not text.isascii():
-        return None
+    raw = bracket_bytes(text)                                        # (one byte per character: the Cyrillic bracket letters recoded)
     L = _lib.load()
     off = np.zeros(len(structs) + 1, np.int64)
     np.cumsum([len(x) for x in structs], out=off[1:])
     poff = np.zeros(len(structs) + 1, np.int64)
     rp = np.zeros(max(len(text), 2), np.int32)                      # (a line of n characters has at most n / 2 pairs)
     ptr = lambda a: ctypes.c_void_p(a.ctypes.data)
-    _lib.check(L.sq_dbn_pairs(text.encode("ascii"), ptr(off), len(structs), ptr(rp), len(rp) // 2, ptr(poff)))
+    _lib.check(L.sq_dbn_pairs(raw, ptr(off), len(structs), ptr(rp), len(rp) // 2, ptr(poff)))
     pairs = rp[:2 * int(poff[-1])].reshape(-1, 2).astype(np.int64)
     width = max(max(len(x) for x in structs), 1)
     keys = pairs[:, 0] * width + pairs[:, 1]

@@ -13,9 +13,9 @@
 #include "sq_host.h"
 
 // ---- DBNToPairs ----------------------------------------------------------------------------------------------------
-// Brackets: ( ) [ ] { } < > and A..Z / a..z (the ASCII part of the reference's alphabet, :108-112; lines with other
-// bracket letters -- the Cyrillic levels beyond 30 -- are the caller's).  Unmatched closers are ignored; the pairs of a
-// line come out sorted.
+// Brackets: ( ) [ ] { } < > and A..Z / a..z (the ASCII part of the reference's alphabet, :108-112) + the Cyrillic letters of
+// the levels beyond 30 recoded by the caller to single bytes (squarna_amd/dbn.py: bracket_bytes).  Unmatched closers are
+// ignored; the pairs of a line come out sorted.
 static inline int bracket_type(unsigned char ch, bool &open)
 {
     switch (ch) {
@@ -27,13 +27,16 @@ static inline int bracket_type(unsigned char ch, bool &open)
     }
     if (ch >= 'A' && ch <= 'Z') { open = true; return 4 + (ch - 'A'); }
     if (ch >= 'a' && ch <= 'z') { open = false; return 4 + (ch - 'a'); }
+    // the alphabet's letters beyond ASCII (19 Cyrillic pairs, levels 31-49) as the caller recodes them: 0x80 + k opens, 0xA0 + k closes
+    if (ch >= 0x80 && ch < 0x80 + 19) { open = true; return 30 + (ch - 0x80); }
+    if (ch >= 0xA0 && ch < 0xA0 + 19) { open = false; return 30 + (ch - 0xA0); }
     return -1;
 }
 
 extern "C" int sq_dbn_pairs(const char *text, const int64_t *off, int32_t nrec, int32_t *pairs, int64_t pair_cap, int64_t *pair_off)
 {
     if (!text || !off || !pairs || !pair_off || nrec < 0) { sq_set_error("bad argument"); return -1; }
-    std::vector<std::vector<int32_t>> stacks(30);
+    std::vector<std::vector<int32_t>> stacks(49);
     std::vector<std::pair<int32_t, int32_t>> cur;
     int64_t np = 0;
     for (int32_t r = 0; r < nrec; r++) {
