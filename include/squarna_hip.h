@@ -113,6 +113,13 @@ typedef struct sq_batch_desc {
 /* No fp32 score matrices in the workspace (4 N^2 bytes per job saved): everything except
  * sq_bpmatrix_fill works, the fold path only needs the 1-bit-per-cell diagonal matrices. */
 #define SQ_BATCH_NO_FP32 1
+/* The batch will be folded with pools wider than one (poollim > 1) and holds sequences of 257-1,024 nt: the workspace
+ * reserves pages for the lists every structure of such a pool hands to its children -- its runs with their bpscores and
+ * the finalscores it knew (SQRNdbnseq.py:427-495 and :640-751 are then evaluated for what the child's new stem changed,
+ * not for the whole structure; the results are the same).  Without the flag (or with SQ_NO_POOL_KEPT=1 in the environment)
+ * such pools run the launched round kernels.  Pages per structure slot: SQ_KEPT_PPS (default 6 of 6 KB per generation),
+ * at most SQ_KEPT_GB gigabytes (default 64) in all. */
+#define SQ_BATCH_POOL_LISTS 2
 
 typedef struct sq_batch sq_batch;   /* opaque */
 
@@ -279,7 +286,9 @@ SQ_API int32_t sq_fold_driver(const sq_batch *b);
  * every launch covers all structure slots and follows the generation sizes the device publishes; SQ_POOL_AHEAD), bit 6 -- the
  * device pools of sequences of 257-1,024 nt ran the one-wave round kernel over per-job root lists (the runs of the empty
  * structure with their bpscores, checked against every structure's partner array) instead of the launched scan and score
- * kernels (SQ_POOL_ROOT).  Identical results either way; for tests and tuning. */
+ * kernels (SQ_POOL_ROOT, or bit 7), bit 7 -- ... and every structure read the list its PARENT left (SQ_BATCH_POOL_LISTS: runs,
+ * bpscores and the finalscores no strand of the child's stem comes near) in the root list's place, scoring only what the new
+ * stem changed, one launch per round.  Identical results either way; for tests and tuning. */
 SQ_API int32_t sq_fold_paths(const sq_batch *b);
 /* Most structures any round of the batch's last fold evaluated at once (device pools: the largest generation; 0 when the
  * host-driven loop ran).  A host that folds a stream of similar batches sizes max_structs from it. */

@@ -26,6 +26,7 @@ SYMBOLS = ["sq_version", "sq_last_error", "sq_last_capacity", "sq_batch_workspac
            "sq_host_cache_trim", "sq_align_first_fit"]
 
 BATCH_NO_FP32 = 1
+BATCH_POOL_LISTS = 2
 
 
 class ParamSet(C.Structure):

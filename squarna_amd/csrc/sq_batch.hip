@@ -70,6 +70,7 @@ struct Layout {
     size_t off_crec, off_cstems, off_cstrands, off_csidx, off_cnfin;   // device-chained rounds (sq_chain.hip)
     size_t off_pstructs, off_precs, off_pstems, off_pstrands, off_psidx, off_pjobs, off_pjobrec, off_pnchild, off_pchoff,
            off_pflag, off_pchosen, off_pparent, off_phdr;                            // device pools (sq_pool.hip)
+    size_t off_kctr, off_kcnt, off_ktab, off_kpages; uint32_t kept_pages;               // kept lists of the pools (sq_device.h: SqKept; 0 pages: none)
     // device log of final structures + scratch of the device tail (sq_tail_dev.hip)
     size_t off_fin, off_fin_stems, off_fin_ctr, off_jobevals, off_t_jobs, off_t_seqjob0, off_t_ord, off_t_cstems, off_t_csn, off_t_hash,
            off_t_rep, off_t_mask, off_t_scores, off_t_dlist, off_t_rlist, off_t_seqs, off_t_refp, off_t_refn, off_t_pow;
@@ -216,6 +217,17 @@ int plan(const sq_batch_desc *d, Layout &L)
         L.off_pjobs = take(on * (size_t)d->njobs * sizeof(SqPoolJob)); L.off_pjobrec = take(on * (size_t)d->njobs * 4);
         L.off_pnchild = take(on * sm * 4); L.off_pchoff = take(on * (sm + 1) * 4); L.off_pflag = take(on * sm);
         L.off_pchosen = take(on * 2 * sm * 64 * sizeof(SqPoolPick)); L.off_pparent = take(on * sm * 4); L.off_phdr = take(64);
+        // kept lists (SQ_BATCH_POOL_LISTS, sequences beyond the scanning round kernel's 256 nt): the counters, a row of page
+        // numbers per slot and generation, the pages
+        L.kept_pages = 0; L.off_kctr = L.off_kcnt = L.off_ktab = L.off_kpages = 0;
+        if (on && (d->batch_flags & SQ_BATCH_POOL_LISTS) && L.maxn > 256 && L.maxn <= 1024 && !getenv("SQ_NO_POOL_KEPT")) {
+            const double pps = getenv("SQ_KEPT_PPS") ? std::max(0.25, atof(getenv("SQ_KEPT_PPS"))) : 6.0;
+            const double gb = getenv("SQ_KEPT_GB") ? std::max(0.01, atof(getenv("SQ_KEPT_GB"))) : 64.0;
+            const double np = std::min((double)sm * pps, gb * 1073741824.0 / 2.0 / (double)SQ_KEPT_PAGE_BYTES);
+            L.kept_pages = (uint32_t)std::max(64.0, std::min(np, 4.0e9));
+            L.off_kctr = take(256); L.off_kcnt = take(2 * sm * 4); L.off_ktab = take(2 * sm * SQ_KEPT_TAB * 4);
+            L.off_kpages = take(2 * (size_t)L.kept_pages * SQ_KEPT_PAGE_BYTES);
+        }
     }
     {
         // the log of final structures: every structure of every pool ends there once -- measured: 1.4 x the largest generation.
@@ -644,6 +656,9 @@ extern "C" int sq_batch_create(sq_batch **out, const sq_batch_desc *d, void *ws,
         P.hdr = (SqPoolHdr *)(base + L.off_phdr);
         P.fin = b->d_fin; P.fin_stems = b->d_fin_stems; P.fin_cap = L.fin_cap; P.fin_stem_cap = L.fin_stem_cap;
         P.fin_ctr = b->d_fin_ctr; P.job_evals = b->d_job_evals;
+        P.kept_ctr = nullptr;
+        b->kept = SqKept{nullptr, nullptr, nullptr, nullptr, 0u, 0};
+        if (L.kept_pages) b->kept = SqKept{base + L.off_kpages, (uint32_t *)(base + L.off_kctr), (uint32_t *)(base + L.off_kcnt), (uint32_t *)(base + L.off_ktab), L.kept_pages, 1};
     }
 
     hipStream_t st = b->stream;

@@ -79,6 +79,34 @@ struct SqChainIO {
     long long *job_evals;
 };
 
+// Kept lists (sequences of 257-1,024 nt): every structure of the pools leaves the list of its runs -- key, length, exact bpscore and,
+// where ScoreStems ran, the finalscore -- for its children, which cut it against the two strands of their own stem instead of
+// scanning, and keep every finalscore no strand of that stem comes near (the rule of sq_rounds.hip's chains: a finalscore reads
+// the strands inside the run's span and within six positions of it, and the NUMBER of levels among them).  The lists live in
+// pages of SQ_KEPT_PG entries -- [keys][length | SQ_RX_FIN | SQ_RX_LVL][bpscores][finalscores] -- taken from a pool per
+// generation (two generations: the parents' pages are read while the children's are written; sq_pool_scan_kernel empties the
+// pool of the generation after next); a structure's page numbers stand in its row of `tab`.  A structure that finds the pool
+// empty (or needs more than SQ_KEPT_TAB pages) leaves no list: its children start from the job's root list.
+#define SQ_KEPT_PG 256
+#define SQ_KEPT_TAB 48
+#define SQ_KEPT_NOLIST 0xFFFFFFFFu
+#define SQ_KEPT_PAGE_BYTES (SQ_KEPT_PG * 24)
+struct SqKept {
+    char *pages;            // [2][npages] pages
+    uint32_t *ctr;          // [2] pages taken, per generation (+ [2]: the most pages a generation took, [3]: structures that left no list)
+    uint32_t *cnt;          // [2][smax] entries of a structure's list (SQ_KEPT_NOLIST: none)
+    uint32_t *tab;          // [2][smax][SQ_KEPT_TAB] its pages
+    uint32_t npages;        // pages per generation
+    int32_t on;
+};
+struct SqKeptPage { uint32_t *key, *lf; double *bps, *fin; };
+__device__ __forceinline__ SqKeptPage sq_kept_page(const SqKept &K, int gen, uint32_t id)
+{
+    char *b = K.pages + ((size_t)gen * K.npages + id) * (size_t)SQ_KEPT_PAGE_BYTES;
+    return SqKeptPage{reinterpret_cast<uint32_t *>(b), reinterpret_cast<uint32_t *>(b + 4 * SQ_KEPT_PG), reinterpret_cast<double *>(b + 8 * SQ_KEPT_PG),
+                      reinterpret_cast<double *>(b + 16 * SQ_KEPT_PG)};
+}
+
 // device pools: two generations of structure slots (parents / children), slot c of generation p at (p * smax + c)
 struct SqPoolIO {
     SqStruct *structs;            // [2][smax]
@@ -111,6 +139,7 @@ struct SqPoolIO {
                                                     // round with sequence number q writes record q % SQ_POOL_HDR_RING (rounds may be
                                                     // enqueued ahead of the host: it reads the record of the round it waited for)
     SqPoolJob *h_jobs;                              // pinned copy of the job records (sq_pool_publish_kernel)
+    uint32_t *kept_ctr;                             // SqKept::ctr of a fold on kept lists (else nullptr): sq_pool_scan_kernel empties the next generation's pool
 };
 
 #include "sq_hostflag.h"

@@ -12,6 +12,7 @@ void sq_read_fold_switches(SqFoldSwitches &sw)
     sw.no_pool_round = on("SQ_NO_POOL_ROUND"); sw.pool_round_always = on("SQ_POOL_ROUND_ALWAYS");
     sw.pool_round_nsurv = num("SQ_POOL_ROUND_NSURV", 16, 2048);
     sw.pool_root = getenv("SQ_POOL_ROOT") ? num("SQ_POOL_ROOT", 0, 1) : 0;
+    sw.no_pool_kept = on("SQ_NO_POOL_KEPT");
     sw.pool_ahead = getenv("SQ_POOL_AHEAD") ? num("SQ_POOL_AHEAD", 0, SQ_POOL_HDR_RING - 2) : 3;
     sw.pool_slots = num("SQ_POOL_SLOTS", 1, 0x7fffffff); sw.pool_chunk = num("SQ_POOL_CHUNK", 1, 0x7fffffff);
     sw.no_score_bound = on("SQ_NO_SCORE_BOUND"); sw.no_score_context = on("SQ_NO_SCORE_CONTEXT");
@@ -609,19 +610,34 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         // root lists (sequences beyond the scanning round kernel's 256 nt, up to 1,024): 16 bytes per run of the EMPTY structure
         // of every job, behind the structures' regions of the arena
         const int64_t root_units = (maxcap + 1) / 2;
-        bool root_mode = sw.pool_root && !sw.no_pool_round && maxn > SQ_PR_MAXN && maxn <= SQ_PR_ROOT_MAXN &&
+        // kept lists (the batch reserved their pages: SQ_BATCH_POOL_LISTS): the same kernel, the parent's list in the root list's place
+        const bool kept_mode = b->kept.on && !sw.no_pool_kept;
+        bool root_mode = (sw.pool_root || kept_mode) && !sw.no_pool_round && maxn > SQ_PR_MAXN && maxn <= SQ_PR_ROOT_MAXN &&
                          (int64_t)S0 * root_units + std::max<int64_t>(maxcap, 1) <= avail;
         const int64_t avail_s = root_mode ? avail - (int64_t)S0 * root_units : avail;
         int chunk = (int)std::min<int64_t>(slots, avail_s / std::max<int64_t>(maxcap, 1));
         if (sw.pool_chunk > 0) chunk = std::min(chunk, sw.pool_chunk);   // (tests: force chunked rounds)
         if (S0 > slots || chunk < 1) return 1;
+        // On kept lists a structure keeps no candidates in the arena: its region only takes the runs within range of the best
+        // finalscore that LDS has no room for -- SQ_KEPT_SLICE units, not the thousands a scan's output needs -- and a round is
+        // one launch (at 500 nt the arena held the candidates of 8,224 structures: a generation of 170,000 went through it in
+        // twenty launches of four waves of blocks each).  The root kernel still stages a job's runs in a full region: its
+        // launches keep the regions' size.
+        const int chunk_root = chunk;
+        const int64_t kslice = 512;
+        const bool kept_round = root_mode && kept_mode &&
+                                sq_pool_round_lds(maxn, 2 * PI.pt + 2, b->cell_entries, sw.pool_round_nsurv ? std::max(sw.pool_round_nsurv, 128) : 128, PI.pt).total <= 60 * 1024;
+        if (kept_round) {
+            chunk = (int)std::min<int64_t>(slots, ((int64_t)chunk_root * maxcap) / kslice);
+            if (sw.pool_chunk > 0) chunk = std::min(chunk, sw.pool_chunk);
+        }
         for (int j = 0; j < b->njobs; j++) b->h_pool_jobrec[j] = -1;
         for (int sx = 0; sx < S0; sx++) {
             const int j = jobs[sx];
             const JobPool &P = pools[j];
             const int toff = sx * PI.pt;                     // generation 0, slot sx
             SqStruct &d = ln.h_structs[sx];
-            d.job = j; d.strand_off = 2 * toff; d.nstrand = 0; d.slot = sx; d.subopt = P.cursubopt; d.cand_off = (int64_t)(sx % chunk) * maxcap;
+            d.job = j; d.strand_off = 2 * toff; d.nstrand = 0; d.slot = sx; d.subopt = P.cursubopt; d.cand_off = (int64_t)(sx % chunk_root) * maxcap;
             SqChain &cr = b->h_pool_recs[sx];
             cr.toff = toff; cr.tcap = PI.pt; cr.nstems = 0; cr.anycross = 0; cr.maxstems = P.maxstemnum;
             SqPoolJob &pj = b->h_pool_jobs[sx];
@@ -629,7 +645,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             pj.cursubopt = P.cursubopt; pj.suboptinc = P.suboptinc; pj.suboptmax = P.suboptmax; pj.maxstems = P.maxstemnum; pj.evals = 0;
             b->h_pool_jobrec[j] = sx;
         }
-        PI.slots = slots; PI.chunk = chunk; PI.poollim = o.poollim; PI.maxcap = maxcap; PI.njobs = S0;   // (the kernels take the batch's record)
+        PI.slots = slots; PI.chunk = chunk; PI.poollim = o.poollim; PI.maxcap = kept_round ? kslice : maxcap; PI.njobs = S0;   // (the kernels take the batch's record)
+        PI.kept_ctr = kept_round ? b->kept.ctr : nullptr;
+        if (PI.kept_ctr) hipMemsetAsync(PI.kept_ctr, 0, 16, st);
         const SqPoolIO pio = PI;
         SqScanArgs scan = b->scan;
         scan.ctr = ln.d_ctr;
@@ -650,9 +668,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             // and everybody else's compete for -- 22 bytes x 256 survivors were half of a wave's 10 KB, and most structures have
             // a few dozen (round 4, a sweep of the count: 64 -> +5 % on the headline, 16 .. 64 within a per cent of each other)
             const bool crowded_fold = b->inflight > 1 || b->njobs >= 4096;
-            pra.surv_cap = sw.pool_round_nsurv ? sw.pool_round_nsurv : (root_mode ? 256 : (crowded_fold ? 64 : (maxn <= 96 ? 128 : 256))); pra.bound = b->score_bound ? 1 : 0;
+            pra.surv_cap = sw.pool_round_nsurv ? std::max(sw.pool_round_nsurv, root_mode ? 128 : 0) : (root_mode ? (kept_round ? 128 : 256) : (crowded_fold ? 64 : (maxn <= 96 ? 128 : 256))); pra.bound = b->score_bound ? 1 : 0;
             pra.tmax = pio.pt; pra.parity = 0; pra.lo = 0; pra.ahead = 0;
-            pra.root = root_mode ? 1 : 0; pra.root_units = (int32_t)root_units; pra.root_off = (int64_t)chunk * maxcap;
+            pra.root = root_mode ? 1 : 0; pra.root_units = (int32_t)root_units; pra.root_off = (int64_t)chunk_root * maxcap;
+            pra.kept = b->kept; pra.kept.on = kept_round ? 1 : 0;
             if (sq_pool_round_lds(pra.lds_n, pra.str_cap, pra.cell_entries, pra.surv_cap, pra.tmax).total > 60 * 1024) round_kernel = false;
         }
         if (round_kernel) b->last_paths |= 8;
@@ -662,12 +681,15 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             if (rl > 60 * 1024) sq_max_dynamic_lds((const void *)sq_pool_root_kernel, 160 * 1024);
             // (in launches of at most `chunk` jobs: the kernel stages a job's runs in its empty structure's region of the arena,
             // and structures a chunk apart share a region)
-            for (int lo = 0; lo < S0; lo += chunk) {
+            SqPoolIO pio_root = pio;
+            pio_root.chunk = chunk_root; pio_root.maxcap = maxcap;
+            for (int lo = 0; lo < S0; lo += chunk_root) {
                 pra.lo = lo;
-                hipLaunchKernelGGL(sq_pool_root_kernel, dim3(std::min(chunk, S0 - lo)), dim3(64), rl, st, b->ctx, scan, pio, pra);
+                hipLaunchKernelGGL(sq_pool_root_kernel, dim3(std::min(chunk_root, S0 - lo)), dim3(64), rl, st, b->ctx, scan, pio_root, pra);
             }
             pra.lo = 0;
             b->last_paths |= 64;
+            if (kept_round) b->last_paths |= 128;
         }
         const size_t ext_lds = sq_extend_lds_bytes(pio.pt);          // the extend kernel's level scratch (dynamic LDS)
         if (ext_lds > 64 * 1024) sq_max_dynamic_lds((const void *)sq_pool_extend_kernel, 160 * 1024);
@@ -762,6 +784,11 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         }
         stats.nrounds = rounds;
         stats.tround = now_s() - tr0;
+        if (timing && PI.kept_ctr) {
+            uint32_t kc[4] = {0, 0, 0, 0};
+            hipMemcpy(kc, PI.kept_ctr, 16, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[pool] kept lists: %u pages per generation, most taken %u, structures that left no list %u\n", b->kept.npages, kc[2], kc[3]);
+        }
         const SqPoolHdr hh = pio.h_hdr[*ln.round_seq % SQ_POOL_HDR_RING];
         if (overflow || hh.ovf) {
             tq.flush();                                      // (the optimistic chains' entries are still being turned into lists by the queue's workers)

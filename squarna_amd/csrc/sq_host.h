@@ -125,6 +125,7 @@ struct SqFoldSwitches {
     int pool_round_nsurv = 0;         // SQ_POOL_ROUND_NSURV: survivors sq_pool_round_kernel keeps in LDS (0: by length)
     int pool_slots = 0;               // SQ_POOL_SLOTS: structure slots the device pools may use (0: max_structs)
     int pool_root = 0;                // SQ_POOL_ROOT: pools on sequences of 257-1,024 nt run the one-wave round kernel over root lists
+    bool no_pool_kept = false;        // SQ_NO_POOL_KEPT: ... not over the lists their parents left (sq_device.h: SqKept)
     int pool_ahead = 3;               // SQ_POOL_AHEAD: rounds of the device pools a batch alone enqueues ahead of the host (0: none)
     int pool_chunk = 0;               // SQ_POOL_CHUNK: structures per chunk of a generation (0: what the arena holds)
     bool no_score_bound = false;      // SQ_NO_SCORE_BOUND: ScoreStems on every survivor of :492
@@ -233,6 +234,7 @@ struct sq_batch {
     long long *h_rec_off = nullptr, *h_txt_off = nullptr;   // pinned: [nseq + 1] record / text offsets (sq_tail_offsets_kernel)
     char *h_rec = nullptr, *h_txt = nullptr; uint8_t *h_deep = nullptr;   // pinned: packed records, ASCII rows, deep flags
     size_t h_rec_cap = 0, h_txt_cap = 0;
+    SqKept kept = {nullptr, nullptr, nullptr, nullptr, 0u, 0};   // kept lists of the pools (SQ_BATCH_POOL_LISTS): the workspace's region
     char *h_app = nullptr; size_t h_app_cap = 0;   // pinned staging of host-built log entries (sq_fin_append_kernel)
     char *h_ref = nullptr; size_t h_ref_cap = 0;   // pinned staging of the known structures (partner arrays)
     int tail_refs_state = 0;                       // sq_tail_refs: 0 not prepared for this fold, 1 no known structure, 2 uploaded

@@ -208,6 +208,11 @@ extern "C" __global__ __launch_bounds__(1024) void sq_pool_scan_kernel(SqPoolIO 
         H->round += 1;
         H->active_jobs = (uint32_t)s_active;
         if ((uint32_t)total > H->peak && fits) H->peak = (uint32_t)total;
+        if (pio.kept_ctr) {
+            // kept lists: the next generation writes the pool its grandparents' lists came from -- nobody reads those any more
+            if (pio.kept_ctr[parity] > pio.kept_ctr[2]) pio.kept_ctr[2] = pio.kept_ctr[parity];
+            pio.kept_ctr[parity ^ 1] = 0u;
+        }
         *io.h_ctr = *a.ctr;
         pio.h_hdr[seq % SQ_POOL_HDR_RING] = *H;
         sq_host_write_flush(io.h_ctr);

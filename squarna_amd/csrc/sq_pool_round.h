@@ -26,6 +26,7 @@ struct SqPoolRoundArgs {
                             // its thousands of runs are most of a structure's round)
     int32_t root_units;     // 32-byte units of the candidate arena per job's root list (16 bytes per run)
     int64_t root_off;       // first unit of the root lists in the candidate arena (job record sx: root_off + sx * root_units)
+    SqKept kept;            // (root mode) the structures' own lists, handed from parent to child
 };
 
 struct SqPoolRoundLds {
@@ -60,7 +61,7 @@ __host__ __device__ inline SqPoolRoundLds sq_pool_round_lds(int lds_n, int str_c
     L.off_stage = o; o += SQ_PR_STAGE * 8;                     // (the extension's crossing weights and level scratch borrow this and the survivors' room)
     L.off_surv = o;
     L.choose_cap = L.off_stems / 16 < 512 ? L.off_stems / 16 : 512;   // (the stems stay: a final structure logs them)
-    size_t tail = (size_t)22 * surv_cap + 16;
+    size_t tail = (size_t)24 * surv_cap + 16;              // bpscore, finalscore, key, length, place in the structure's kept list
     const size_t ext = (size_t)8 * L.t8 + 64 * 4 + 64 + 16;   // crossing weights (int32), order, group, level, group sizes, ranks
     if (SQ_PR_STAGE * 8 + tail < ext) tail = ext - SQ_PR_STAGE * 8;
     L.total = (size_t)o + tail;

@@ -49,7 +49,7 @@ __device__ __forceinline__ bool sq_pr_shares_base(int ai, int aj, int al, int bi
 
 // the survivors of :492: the first `cap` in LDS, the rest in the structure's slice of the candidate arena
 struct SqPrSurv {
-    double *bps, *fin; uint32_t *key; uint16_t *len; int cap;
+    double *bps, *fin; uint32_t *key; uint16_t *len, *place; int cap;
     SqOk *spill; uint32_t spill_cap; SqCounters *ctr;
     __device__ __forceinline__ void put(uint32_t at, uint32_t k, int L, double b)
     {
@@ -57,10 +57,19 @@ struct SqPrSurv {
         else if (at - cap < spill_cap) spill[at - cap] = SqOk{k, (uint32_t)L, b, 0.0};
         else ctr->cand_ovf = 1;
     }
+    // (kept lists: the finalscore the parent left -- NaN: none -- and the run's place in the structure's own list; a spilled
+    // survivor keeps the place in the upper half of its length word)
+    __device__ __forceinline__ void put_kept(uint32_t at, uint32_t k, int L, double b, double f, uint32_t pl)
+    {
+        if (at < (uint32_t)cap) { key[at] = k; len[at] = (uint16_t)L; bps[at] = b; fin[at] = f; place[at] = (uint16_t)pl; }
+        else if (at - cap < spill_cap) spill[at - cap] = SqOk{k, (uint32_t)L | (pl << 16), b, f};
+        else ctr->cand_ovf = 1;
+    }
+    __device__ __forceinline__ uint32_t get_place(uint32_t at) const { return at < (uint32_t)cap ? (uint32_t)place[at] : spill[at - cap].len >> 16; }
     __device__ __forceinline__ void get(uint32_t at, uint32_t &k, int &L, double &b) const
     {
         if (at < (uint32_t)cap) { k = key[at]; L = len[at]; b = bps[at]; }
-        else { const SqOk o = spill[at - cap]; k = o.key; L = (int)o.len; b = o.bps; }
+        else { const SqOk o = spill[at - cap]; k = o.key; L = (int)(o.len & 0xFFFFu); b = o.bps; }
     }
     __device__ __forceinline__ void set_fin(uint32_t at, double f) { if (at < (uint32_t)cap) fin[at] = f; else spill[at - cap].fin = f; }
     __device__ __forceinline__ double get_fin(uint32_t at) const { return at < (uint32_t)cap ? fin[at] : spill[at - cap].fin; }
@@ -151,14 +160,14 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     asm volatile("" :: "s"(pw0));                           // (asked for HERE, not below the branch)
     if (ra.ahead && s >= (int)(ra.parity ? hdr0.S[1] : hdr0.S[0])) return;
 #ifdef SQ_PR_PROF
-    long long _pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t;
+    long long _pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long _t = wall_clock64(); const long long _t00 = _t; int _ninh = 0, _nwalk = 0; long long _xw = 0, _xc = 0, _xa = 0; int _ncutrun = 0, _nwserve = 0;
     if (threadIdx.x == 0) sq_pr_prof_bps = 0;
 #define PRPROF(k) do { const long long _n = wall_clock64(); _pt[k] += _n - _t; _t = _n; } while (0)
 #ifndef SQ_PR_PROF_SLOW
 #define SQ_PR_PROF_SLOW 1000000      /* us: structures slower than this are printed too */
 #endif
-#define PRPROF_OUT(ns_, nin_) do { if (lane == 0 && ((s % 997) == 0 || (wall_clock64() - _t00) > 100ll * SQ_PR_PROF_SLOW)) printf("pool round s=%d n=%d nstrand=%d ns=%u nin=%d | us: bps %.1f entry %.1f ext %.1f extend %.1f setup %.1f state %.1f scan %.1f score %.1f choose %.1f total %.1f\n", \
-        s, n, nstrand, (unsigned)(ns_), (int)(nin_), sq_pr_prof_bps * 0.01, _pt[6] * 0.01, _pt[7] * 0.01, _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, (wall_clock64() - _t00) * 0.01); } while (0)
+#define PRPROF_OUT(ns_, nin_) do { if (lane == 0 && ((s % 997) == 0 || (wall_clock64() - _t00) > 100ll * SQ_PR_PROF_SLOW)) printf("pool round list %u kept %d walked %d cutruns %d walkserves %d us: walks %.1f cuts %.1f alloc %.1f | s=%d n=%d nstrand=%d ns=%u nin=%d | us: bps %.1f entry %.1f ext %.1f extend %.1f setup %.1f state %.1f scan %.1f score %.1f choose %.1f total %.1f\n", \
+        mycnt, _ninh, _nwalk, _ncutrun, _nwserve, _xw * 0.01, _xc * 0.01, _xa * 0.01, s, n, nstrand, (unsigned)(ns_), (int)(nin_), sq_pr_prof_bps * 0.01, _pt[6] * 0.01, _pt[7] * 0.01, _pt[0] * 0.01, _pt[1] * 0.01, _pt[2] * 0.01, _pt[3] * 0.01, _pt[4] * 0.01, _pt[5] * 0.01, (wall_clock64() - _t00) * 0.01); } while (0)
 #else
 #define PRPROF(k) do {} while (0)
 #define PRPROF_OUT(ns_, nin_) do {} while (0)
@@ -213,6 +222,9 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     // everything a link of the chain names is asked for as soon as that link has arrived)
     static_assert(SQ_PR_MAXN <= 256, "the entry asks for a lane's letters and masks as four bytes");
     SqPoolJob *J; double cursub; int cursize; SqCellPre cpre; uint32_t e4 = 0;
+    // (kept lists: the strands of the child's own stem -- none: intervals nothing meets -- and whether that stem crosses another,
+    // i.e. the levels were taken anew, sq_rounds.hip)
+    int za0 = 0x7FFF, za1 = -0x7FFF, zb0 = 0x7FFF, zb1 = -0x7FFF; bool regroup = false;
     if (round == 0) {                                       // the empty structure of a job (sq_pool_init_kernel)
         job = pst.job; nstems = 0; nstrand = 0; maxstems = prec.maxstems;
         J = pio.jobs + sq_kload(pio.jobrec_of + job); cursub = sq_kload(&J->cursubopt); cursize = sq_kload(&J->cursize);
@@ -247,6 +259,7 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
                                                     pio.sidx + pst.strand_off, pst.nstrand, i0, j0, len, cst, s_str, s_sidx, lane, &pre);
         __syncthreads();
         PRPROF(7);
+        if (ROOT) { za0 = i0; za1 = i0 + len - 1; zb0 = j0 - len + 1; zb1 = j0; regroup = XL.cc[prec.nstems] != 0; }
         nstems = prec.nstems + 1; nstrand = pst.nstrand + 2;
         const bool full = (double)nstems == maxstems;
         if (lane == 0) {
@@ -352,77 +365,298 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     SqPrSurv sv;
     sv.bps = reinterpret_cast<double *>(pr_dyn + Lo.off_surv); sv.fin = sv.bps + ra.surv_cap;
     sv.key = reinterpret_cast<uint32_t *>(sv.fin + ra.surv_cap); sv.len = reinterpret_cast<uint16_t *>(sv.key + ra.surv_cap);
+    sv.place = sv.len + ra.surv_cap;
     sv.cap = ra.surv_cap; sv.ctr = a.ctr;
     // the structure's slice of the arena (cand_cap 32-byte units): runs the staging buffer could not take, then spilled survivors
     uint2 *const over = reinterpret_cast<uint2 *>(a.cands + st.cand_off);
     sv.spill = sq_oks(a, st, jb.cand_cap);
     sv.spill_cap = (uint32_t)(((size_t)jb.cand_cap * (sizeof(SqCand) - sizeof(SqKey))) / sizeof(SqOk));
+    if (ROOT && ra.kept.on) {          // (no candidates in the arena: the whole region -- SqPoolIO::maxcap units -- takes survivors)
+        sv.spill = reinterpret_cast<SqOk *>(a.cands + st.cand_off);
+        sv.spill_cap = (uint32_t)(((size_t)pio.maxcap * sizeof(SqCand)) / sizeof(SqOk));
+    }
     const double minbps = ps->minbpscore, minfin = ps->minfinscore;
     uint32_t ns = 0;
+    // kept lists (sq_pool_round.h): this structure's own list -- entries so far, pages taken (lane k holds the k-th page's number)
+    const SqKept &K = ra.kept;
+    const int gen = ra.parity;
+    const size_t krow = cur + (size_t)s;
+    bool mylist = ROOT && K.on != 0;
+    uint32_t mycnt = 0, mypages = 0, mytab = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+    double best = 0.0; bool anybest = false;                           // the best finalscore (wave-uniform)
     if (ROOT && n >= 5) {
-        // ---- AnnotateStems from the job's root list: choosing stems only ever masks rows and columns (:446-451), so the maximal
-        // runs of this structure are the pieces its paired positions leave of the empty structure's runs (sq_rounds.hip keeps a
-        // chain's list on the same rule).  A run whose rows and columns are all unpaired -- four reads of the prefix counts --
-        // stands as it is with the bpscore the root kernel gave it; a cut run is walked cell by cell against the partner array
-        // and its pieces of minlen cells and more are summed anew.  No bit matrix is read and no run of the structure is
-        // re-summed that was not cut.
+        // ---- AnnotateStems, :492 and ScoreStems as ONE pass over a list.  Choosing stems only ever masks rows and columns
+        // (:446-451), so the maximal runs of this structure are the pieces its paired positions leave of its parent's runs -- and
+        // of the empty structure's (sq_rounds.hip keeps a chain's list on the same rule).  The source is the list the PARENT left
+        // (kept lists, sq_device.h: its live runs with their exact bpscores and the finalscores it knew) or, without one, the
+        // job's root list.  A run whose rows and columns are all unpaired -- four reads of the prefix counts -- stands as it is; a
+        // cut run is walked cell by cell against the partner array and its pieces of minlen cells and more are summed anew.  A
+        // finalscore of the parent's stands while no strand of the new stem comes within six positions of the run's span and the
+        // levels were not taken anew under a finalscore that read them; a run without one goes through ScoreStems only when its
+        // bound (sq_run_upper) reaches the range under the best finalscore so far.  The rare steps -- cut runs, walks -- wait in
+        // LDS until a whole wave of them is there.  What the rest of the round reads (ChooseStems) is the handful of runs
+        // whose finalscore is within range of the best one met before them: only those join the survivors.
+        bool from_parent = false;
+        uint32_t R = 0, ptab = 0;
+        if (K.on && round) {
+            const uint32_t pc = sq_kload(K.cnt + prv + (size_t)p);
+            if (pc != SQ_KEPT_NOLIST) {
+                from_parent = true; R = pc;
+                ptab = lane < SQ_KEPT_TAB ? K.tab[(prv + (size_t)p) * SQ_KEPT_TAB + lane] : 0u;
+            }
+        }
         const SqRun *const root = reinterpret_cast<const SqRun *>(a.cands + ra.root_off + (int64_t)pio.jobrec_of[job] * ra.root_units);
-        const uint32_t R = a.cand_cnt[pio.jobrec_of[job]];
+        if (!from_parent) R = a.cand_cnt[pio.jobrec_of[job]];
         const int minlen = max(1, (int)ceil(ps->minlen));
-        SqRun nx = lane < (int)R ? root[lane] : SqRun{0u, 0u, 0.0};
-        for (uint32_t q0 = 0; q0 < R; q0 += 64) {
-            const SqRun r = nx;
-            const bool have = q0 + (uint32_t)lane < R;
-            if (q0 + 64 + (uint32_t)lane < R) nx = root[q0 + 64 + lane];       // (the next entries are on their way)
-            const int L = (int)r.len, i = (int)(r.key & 0xFFFFu), j = (int)(r.key >> 16) - i;
-            const bool whole = have && ((int)U[i + L] - (int)U[i]) == L && ((int)U[j + 1] - (int)U[j - L + 1]) == L;
-            bool ok = whole && r.bps >= minbps;                                  // :492
-            unsigned long long m = __ballot(ok);
-            if (ok) sv.put(ns + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), r.key, L, r.bps);
-            ns += (uint32_t)__popcll(m);
-            // the cut runs: a run of exactly minlen cells that lost one is gone; the others are walked, one piece per step of
-            // the wave (most have two or three cells: the steps are few)
-            bool cut = have && !whole && L > minlen;
-            int t0 = 0;
-            // (runs of up to 32 cells -- nearly all -- as a word of live cells: the rows' window of the unpaired bits AND the
-            // bit-reversed window of the columns'; the pieces then come out of the word without another read)
-            uint32_t alive = 0u;
-            const bool word = L <= 32;
-            if (cut && word) {
-                const uint32_t rw = __builtin_amdgcn_alignbit(FG[(i >> 5) + 1], FG[i >> 5], (uint32_t)(i & 31));        // bit t: row i + t
-                const int q = j - 31;                                                                                       // bit k of the window: column q + k
-                const uint32_t cw = q >= 0 ? __builtin_amdgcn_alignbit(FG[(q >> 5) + 1], FG[q >> 5], (uint32_t)(q & 31)) : FG[0] << (uint32_t)(-q);
-                alive = rw & __brev(cw) & (L == 32 ? 0xFFFFFFFFu : ((1u << L) - 1u));                                       // bit t: column j - t
-            }
-            while (__ballot(cut) != 0ull) {
-                int pb = -1, pl = 0;
-                if (cut && word) {
-                    while (alive) {
-                        const int b0 = __ffs((int)alive) - 1;
-                        const uint32_t up = ~(alive >> b0);
-                        const int len = up ? __ffs((int)up) - 1 : 32 - b0;
-                        alive &= len + b0 >= 32 ? 0u : ~((1u << (len + b0)) - 1u);
-                        if (len >= minlen) { pb = b0; pl = len; break; }
-                    }
-                    if (pb < 0) cut = false;
-                } else if (cut) {
-                    int t = t0;
-                    while (t < L) {
-                        while (t < L && !(P[i + t] == -1 && P[j - t] == -1)) t++;
-                        const int b0 = t;
-                        while (t < L && P[i + t] == -1 && P[j - t] == -1) t++;
-                        if (t - b0 >= minlen) { pb = b0; pl = t - b0; break; }
-                    }
-                    t0 = t;
-                    if (pb < 0) cut = false;
+        const double ps_lb = ps->loopbonus;
+        const double ub_of = ps->ub_of, ub_lf = ra.bound ? ps->ub_lf : INFINITY;
+        const SqStemsEnv env = {s_str, s_skip, st.nstrand, true, P, U, SU, l_code, n, false, nullptr, nullptr, nullptr, 0,
+                                ps_lb, ps->bracketweight, ps->distcoef, ps->bw_integral, ps->sdf_len, c.sdftab + ps->sdf_off, ps->oftab, a.ctr};
+        const double subopt = st.subopt;
+        // the survivors' room: the runs within range (SqPrSurv, a shorter list), behind them the walks' queue
+        struct WQ { uint32_t key, lp; double bps; };                              // lp: length | place in this structure's list << 16
+        sv.cap = ra.surv_cap - 88;
+        sv.bps = reinterpret_cast<double *>(pr_dyn + Lo.off_surv); sv.fin = sv.bps + sv.cap;
+        sv.key = reinterpret_cast<uint32_t *>(sv.fin + sv.cap); sv.len = reinterpret_cast<uint16_t *>(sv.key + sv.cap);
+        sv.place = sv.len + sv.cap;
+        WQ *const wq = reinterpret_cast<WQ *>(pr_dyn + Lo.off_surv + (((size_t)24 * sv.cap + 15) & ~(size_t)15));   // 128 entries
+        uint32_t nwq = 0;
+        // the source comes in by the page: four entries per lane -- sixteen loads -- at once, the next page's while this one is worked on
+        // (an entry per lane and step, the next step's on their way, left every step waiting for a trip to memory)
+        struct Ent4 { uint32_t key[4], lf[4]; double bps[4], fin[4]; };
+        auto load_page = [&](uint32_t pk) -> Ent4 {
+            Ent4 e;
+#pragma unroll
+            for (int t = 0; t < 4; t++) { e.key[t] = 0u; e.lf[t] = 0u; e.bps[t] = 0.0; e.fin[t] = 0.0; }
+            if (from_parent) {
+                const uint32_t pid = (uint32_t)__builtin_amdgcn_readlane((int)ptab, (int)pk);
+                const SqKeptPage pg = sq_kept_page(K, gen ^ 1, pid);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t o = 64u * t + (uint32_t)lane;
+                    if (pk * SQ_KEPT_PG + o < R) { e.key[t] = pg.key[o]; e.lf[t] = pg.lf[o]; e.bps[t] = pg.bps[o]; e.fin[t] = pg.fin[o]; }
                 }
-                double bps = 0.0, pos = 0.0;
-                if (pb >= 0) bps = sq_cellrun_bps(cenv, c, jb, i + pb, j - pb, pl, pos);
-                ok = pb >= 0 && bps >= minbps;
-                m = __ballot(ok);
-                if (ok) sv.put(ns + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), ((uint32_t)(i + j) << 16) | (uint32_t)(i + pb), pl, bps);
-                ns += (uint32_t)__popcll(m);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t q = pk * SQ_KEPT_PG + 64u * t + (uint32_t)lane;
+                    if (q < R) { const SqRun r = root[q]; e.key[t] = r.key; e.lf[t] = r.len; e.bps[t] = r.bps; }
+                }
             }
+            return e;
+        };
+        // the pages this structure's list will need, in one go (it is at most as long as its source, pieces of cut runs aside: those
+        // take further pages one by one) -- a returning atomic per page was a trip to memory every fourth step
+        if (mylist && R > 0u) {
+            const uint32_t need = min((R + SQ_KEPT_PG - 1u) / SQ_KEPT_PG, (uint32_t)SQ_KEPT_TAB);
+            uint32_t id0 = 0u;
+#ifdef SQ_PR_PROF
+            const long long _a0 = wall_clock64();
+#endif
+            if (lane == 0) id0 = atomicAdd(K.ctr + gen, need);
+            id0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)id0);
+#ifdef SQ_PR_PROF
+            _xa += wall_clock64() - _a0;
+#endif
+            if (id0 + need > K.npages) mylist = false;
+            else {
+                if ((uint32_t)lane < need) { mytab = id0 + (uint32_t)lane; K.tab[krow * SQ_KEPT_TAB + lane] = mytab; }
+                mypages = need;
+            }
+        }
+        // a run joins this structure's list (every lane calls; returns the run's place)
+        auto append = [&](bool add, uint32_t key, uint32_t lf, double bps, double fin) -> uint32_t {
+            const unsigned long long m = __ballot(add);
+            if (m == 0ull || !mylist) return 0u;
+            const uint32_t tot = (uint32_t)__popcll(m), pos = mycnt + (uint32_t)__popcll(m & below);
+            while (mypages * SQ_KEPT_PG < mycnt + tot) {
+                uint32_t id = 0u;
+                if (lane == 0) id = atomicAdd(K.ctr + gen, 1u);
+                id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
+                if (id >= K.npages || mypages >= SQ_KEPT_TAB) { mylist = false; break; }
+                if (lane == (int)mypages) mytab = id;
+                if (lane == 0) K.tab[krow * SQ_KEPT_TAB + mypages] = id;
+                mypages++;
+            }
+            if (!mylist) return 0u;
+            const uint32_t pid = (uint32_t)__shfl((int)mytab, (int)((pos / SQ_KEPT_PG) & 63u), 64);
+            if (add) {
+                const SqKeptPage pg = sq_kept_page(K, gen, pid);
+                const uint32_t o = pos % SQ_KEPT_PG;
+                pg.key[o] = key; pg.lf[o] = lf; pg.bps[o] = bps; pg.fin[o] = fin;
+            }
+            mycnt += tot;
+            return pos;
+        };
+        // an exact finalscore (before :751): it raises the bar, and joins the survivors when it is within range of the best one
+        // met so far -- a run that is not never will be (the best only grows; every lane calls)
+        auto consider = [&](bool has, double f, uint32_t key, int L, double bps, uint32_t place) {
+            const bool cand = has && f >= minfin;                                 // :751
+            const double wb = sq_wave_max_f64(cand ? f : -INFINITY);
+            if (!(wb > -INFINITY)) return;
+            const bool ins = cand && !(anybest && f < subopt * best);
+            const unsigned long long m = __ballot(ins);
+            if (ins) sv.put_kept(ns + (uint32_t)__popcll(m & below), key, L, bps, f, place);
+            ns += (uint32_t)__popcll(m);
+            if (!anybest || wb > best) { anybest = true; best = wb; }
+        };
+        // a run that passed :492 without a finalscore: behind its bound it waits for ScoreStems (every lane calls)
+        auto enqueue = [&](bool has, uint32_t key, int L, double bps, uint32_t place) {
+            bool want = has;
+            if (want) {
+                const int i0 = (int)(key & 0xFFFFu), j0 = (int)(key >> 16) - i0;
+                const double ub = sq_run_upper(bps, i0, j0, L, U, l_code, n, ub_of, ub_lf, ps_lb);
+                if (ub < minfin || (anybest && ub < subopt * best)) want = false;    // no reader of the list can use it
+            }
+            const unsigned long long m = __ballot(want);
+            if (want) wq[nwq + (uint32_t)__popcll(m & below)] = WQ{key, (uint32_t)L | (place << 16), bps};
+            nwq += (uint32_t)__popcll(m);
+        };
+        auto serve_walks = [&](bool all) {
+#ifdef SQ_PR_PROF
+            const long long _w0 = wall_clock64();
+#endif
+            while (nwq >= 64u || (all && nwq > 0u)) {
+#ifdef SQ_PR_PROF
+                _nwserve++;
+#endif
+                __syncthreads();
+                const uint32_t take = nwq < 64u ? nwq : 64u;
+                const bool mine = (uint32_t)lane < take;
+                const WQ e = mine ? wq[nwq - take + (uint32_t)lane] : WQ{0u, 0u, 0.0};
+                nwq -= take;
+                __syncthreads();
+                const int L = (int)(e.lp & 0xFFFFu), i0 = (int)(e.key & 0xFFFFu), j0 = (int)(e.key >> 16) - i0;
+                const uint32_t place = e.lp >> 16;
+                const uint32_t wpid = (uint32_t)__shfl((int)mytab, (int)((place / SQ_KEPT_PG) & 63u), 64);
+                bool ok = mine;
+                if (ok) {                                                        // (the bar has risen since the run joined the queue)
+                    const double ub = sq_run_upper(e.bps, i0, j0, L, U, l_code, n, ub_of, ub_lf, ps_lb);
+                    if (ub < minfin || (anybest && ub < subopt * best)) ok = false;
+                }
+#ifdef SQ_PR_PROF
+                _nwalk += __popcll(__ballot(ok));
+#endif
+                double f = 0.0;
+                if (ok) {
+                    const SqWalk w = sq_stem_walk(env, i0, j0, L);
+                    f = sq_stem_finalscore_of(env, i0, j0, L, e.bps, w);
+                    if (mylist) {                                                // (for this structure's children)
+                        const SqKeptPage pg = sq_kept_page(K, gen, wpid);
+                        const uint32_t o = place % SQ_KEPT_PG;
+                        pg.fin[o] = f; pg.lf[o] = (uint32_t)L | SQ_RX_FIN | (w.brackets != 0 ? SQ_RX_LVL : 0u);
+                    }
+                }
+                consider(ok, f, e.key, L, e.bps, place);
+            }
+#ifdef SQ_PR_PROF
+            _xw += wall_clock64() - _w0;
+#endif
+        };
+        // the cut runs (key, length), 64 at a time: every lane walks ONE run cell by cell against the partner array; its pieces of
+        // minlen cells and more are summed anew, one piece per lane and step of the wave (most runs leave one or two).  Taken
+        // one by one where the stream met them, a step of the wave served a single lane
+        uint2 *const cutq = s_stage;                                              // (SQ_PR_STAGE >= 128 entries: at most 63 wait when 64 more arrive)
+        uint32_t ncq = 0;
+        auto serve_cuts = [&](bool all) {
+#ifdef SQ_PR_PROF
+            const long long _c0 = wall_clock64(), _w1 = _xw;
+#endif
+            while (ncq >= 64u || (all && ncq > 0u)) {
+                __syncthreads();
+                const uint32_t take = ncq < 64u ? ncq : 64u;
+                bool cut = (uint32_t)lane < take;
+                const uint2 e = cut ? cutq[ncq - take + (uint32_t)lane] : make_uint2(0u, 0u);
+                ncq -= take;
+                __syncthreads();
+                const int L = (int)e.y, i = (int)(e.x & 0xFFFFu), j = (int)(e.x >> 16) - i;
+                int t0 = 0;
+                // (runs of up to 32 cells -- nearly all -- as a word of live cells: the rows' window of the unpaired bits AND the
+                // bit-reversed window of the columns'; the pieces then come out of the word without another read)
+                uint32_t alive = 0u;
+                const bool word = L <= 32;
+                if (cut && word) {
+                    const uint32_t rw = __builtin_amdgcn_alignbit(FG[(i >> 5) + 1], FG[i >> 5], (uint32_t)(i & 31));        // bit t: row i + t
+                    const int q = j - 31;                                                                                       // bit k of the window: column q + k
+                    const uint32_t cw = q >= 0 ? __builtin_amdgcn_alignbit(FG[(q >> 5) + 1], FG[q >> 5], (uint32_t)(q & 31)) : FG[0] << (uint32_t)(-q);
+                    alive = rw & __brev(cw) & (L == 32 ? 0xFFFFFFFFu : ((1u << L) - 1u));                                       // bit t: column j - t
+                }
+                while (__ballot(cut) != 0ull) {
+                    int pb = -1, pl = 0;
+                    if (cut && word) {
+                        while (alive) {
+                            const int b0 = __ffs((int)alive) - 1;
+                            const uint32_t up = ~(alive >> b0);
+                            const int len = up ? __ffs((int)up) - 1 : 32 - b0;
+                            alive &= len + b0 >= 32 ? 0u : ~((1u << (len + b0)) - 1u);
+                            if (len >= minlen) { pb = b0; pl = len; break; }
+                        }
+                        if (pb < 0) cut = false;
+                    } else if (cut) {
+                        int t = t0;
+                        while (t < L) {
+                            while (t < L && !(P[i + t] == -1 && P[j - t] == -1)) t++;
+                            const int b0 = t;
+                            while (t < L && P[i + t] == -1 && P[j - t] == -1) t++;
+                            if (t - b0 >= minlen) { pb = b0; pl = t - b0; break; }
+                        }
+                        t0 = t;
+                        if (pb < 0) cut = false;
+                    }
+                    double bps = 0.0, pos = 0.0;
+                    if (pb >= 0) bps = sq_cellrun_bps(cenv, c, jb, i + pb, j - pb, pl, pos);
+                    const uint32_t pkey = ((uint32_t)(i + j) << 16) | (uint32_t)(i + pb);
+                    // (a piece whose positive parts miss :492 has no piece of its own that passes: it leaves the list)
+                    const uint32_t pplace = append(pb >= 0 && !(pos < minbps), pkey, (uint32_t)pl, bps, qnan);
+                    enqueue(pb >= 0 && bps >= minbps, pkey, pl, bps, pplace);       // :492
+                    if (nwq >= 64u) serve_walks(false);
+                }
+            }
+#ifdef SQ_PR_PROF
+            _xc += (wall_clock64() - _c0) - (_xw - _w1);
+#endif
+        };
+#define SQ_OV(z0, z1, lo, hi) (((hi) - (z0)) | ((z1) - (lo)))
+        Ent4 cur4 = load_page(0u), nxt4 = cur4;
+        for (uint32_t b0 = 0; b0 < R; b0 += SQ_KEPT_PG) {
+            if (b0 + SQ_KEPT_PG < R) nxt4 = load_page(b0 / SQ_KEPT_PG + 1u);
+            for (uint32_t q0 = b0; q0 < b0 + SQ_KEPT_PG && q0 < R; q0 += 64) {
+                const uint32_t rkey = cur4.key[0], rlf = cur4.lf[0]; const double rbps = cur4.bps[0], rfin = cur4.fin[0];
+#pragma unroll
+                for (int t = 0; t < 3; t++) { cur4.key[t] = cur4.key[t + 1]; cur4.lf[t] = cur4.lf[t + 1]; cur4.bps[t] = cur4.bps[t + 1]; cur4.fin[t] = cur4.fin[t + 1]; }
+                const bool have = q0 + (uint32_t)lane < R;
+                const int L = (int)(rlf & SQ_RX_LEN), i = (int)(rkey & 0xFFFFu), j = (int)(rkey >> 16) - i;
+                const bool whole = have && ((int)U[i + L] - (int)U[i]) == L && ((int)U[j + 1] - (int)U[j - L + 1]) == L;
+                const int nofd = SQ_OV(za0, za1, i - 6, j + 6) & SQ_OV(zb0, zb1, i - 6, j + 6);       // (< 0: neither strand meets [i - 6, j + 6])
+                const bool finok = from_parent && (rlf & SQ_RX_FIN) != 0u && nofd < 0 && !(regroup && (rlf & SQ_RX_LVL) != 0u);
+                const uint32_t wplace = append(whole, rkey, finok ? rlf : (uint32_t)L, rbps, finok ? rfin : qnan);
+                const bool p492 = whole && rbps >= minbps;                           // :492
+#ifdef SQ_PR_PROF
+                _ninh += __popcll(__ballot(p492 && finok));
+#endif
+                consider(p492 && finok, rfin, rkey, L, rbps, wplace);
+                enqueue(p492 && !finok, rkey, L, rbps, wplace);
+                // the cut runs wait in LDS until 64 of them are there (a run of exactly minlen cells that lost one is gone)
+                const bool cutrun = have && !whole && L > minlen;
+                const unsigned long long m = __ballot(cutrun);
+#ifdef SQ_PR_PROF
+                _ncutrun += __popcll(m);
+#endif
+                if (cutrun) cutq[ncq + (uint32_t)__popcll(m & below)] = make_uint2(rkey, (uint32_t)L);
+                ncq += (uint32_t)__popcll(m);
+                if (ncq >= 64u) serve_cuts(false);
+                if (nwq >= 64u) serve_walks(false);
+            }
+            cur4 = nxt4;
+        }
+        serve_cuts(true);
+        serve_walks(true);
+#undef SQ_OV
+        if (K.on && lane == 0) {
+            K.cnt[krow] = mylist ? mycnt : SQ_KEPT_NOLIST;
+            if (!mylist) atomicAdd(K.ctr + 3, 1u);
         }
     } else if (n >= 5) {                                                // :456-457 (shorter sequences have no diagonals)
 #ifdef SQ_PR_DUP_SCAN
@@ -446,10 +680,10 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     const SqStemsEnv env = {s_str, s_skip, st.nstrand, true, P, U, SU, l_code, n, false, nullptr, nullptr, nullptr, 0,
                             ps_lb, ps->bracketweight, ps->distcoef, ps->bw_integral, ps->sdf_len, c.sdftab + ps->sdf_off, ps->oftab, a.ctr};
     const double subopt = st.subopt;
-    double best = 0.0; bool anybest = false;                           // (wave-uniform)
 #ifdef SQ_PR_DUP_SCORE
     for (int dup_ = 0; dup_ < 2; dup_++) { best = 0.0; anybest = false;
 #endif
+    if (!ROOT)                                                          // (the list form scored while it streamed)
     for (uint32_t g = 0; g < ns; g += 64) {
         const uint32_t idx = g + lane;
         const bool have = idx < ns;
@@ -568,7 +802,10 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
 {
     sq_pool_round_body<false>(c, a, pio, ra);
 }
-extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SQ_PR_WAVES, SQ_PR_WAVES))) void sq_pool_round_root_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra)
+#ifndef SQ_PR_ROOT_WAVES
+#define SQ_PR_ROOT_WAVES 2         // (the list form: 199 VGPRs; at 128 it spilled 190 of them and every step of its stream waited for scratch -- loop of 500 x 500 nt 153 -> 125 ms; 3 waves: 168 VGPRs, 79 spilled, 127 ms)
+#endif
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SQ_PR_ROOT_WAVES, SQ_PR_ROOT_WAVES))) void sq_pool_round_root_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra)
 {
     sq_pool_round_body<true>(c, a, pio, ra);
 }

@@ -213,9 +213,11 @@ class Batch:
     """A device-resident batch of fold jobs (one per (record, paramset))."""
 
     def __init__(self, prepared, psets_per_record, interchainonly=False, ext=None, mul=None,
-                 max_structs=0, cand_per_nt=0, device=None, fp32=True, bpp=None, mul_shared=None):
+                 max_structs=0, cand_per_nt=0, device=None, fp32=True, bpp=None, mul_shared=None, pool_lists=False):
         """fp32=False leaves the fp32 score matrices out of the workspace (4 N^2 bytes per job): everything
         but fill() works -- folding only needs the 1-bit-per-cell matrices.
+        pool_lists=True: the batch will be folded with pools wider than one; with sequences of 257-1,024 nt the workspace
+        then holds the pages of the lists a pool's structures hand to their children (SQ_BATCH_POOL_LISTS).
         mul_shared = (M, cols, maxabs): ONE L x L fp64 torch tensor on the GPU that weights every job of every record
         (alignment step 2), cols[k] = the alignment columns of record k's gap-free positions, maxabs >= max |M|."""
         import torch
@@ -233,6 +235,7 @@ class Batch:
             self.seq_off, self.codes, self.flags, self.reacts, self.rbp_off, self.rbps = pk.seq_off, pk.codes, pk.flags, pk.reacts, pk.rbp_off, pk.rbps
         else:
             nseq, ltot = self._host_arrays(prepared)
+        self._pool_lists = bool(pool_lists)
         self._finish_init(nseq, ltot, psets_per_record, interchainonly, ext, mul, max_structs, cand_per_nt, device, fp32, bpp, mul_shared)
 
     def _host_arrays(self, prepared):
@@ -356,7 +359,7 @@ class Batch:
         d.interchainonly = int(bool(interchainonly))
         d.max_structs = int(max_structs)
         d.cand_per_nt = int(cand_per_nt)
-        d.batch_flags = 0 if fp32 else _lib.BATCH_NO_FP32
+        d.batch_flags = (0 if fp32 else _lib.BATCH_NO_FP32) | (_lib.BATCH_POOL_LISTS if self._pool_lists else 0)
         self.desc = d
         nbytes = C.c_size_t(0)
         _lib.check(L.sq_batch_workspace_bytes(C.byref(d), C.byref(nbytes)))
@@ -820,11 +823,19 @@ def bpp_terms(prepared, psets, M=1.8, B=-0.6):
     return out
 
 
+def _kept_bytes_per_slot(maxn):
+    """Bytes per structure slot of the lists a pool's structures hand to their children (SQ_BATCH_POOL_LISTS, sequences of
+    257-1,024 nt): SQ_KEPT_PPS pages of 6 KB per generation, a row of 48 page numbers, a count."""
+    if not 256 < maxn <= 1024 or "SQ_NO_POOL_KEPT" in os.environ:
+        return 0
+    return int(2 * (float(os.environ.get("SQ_KEPT_PPS", "6")) * 6144 + 196))
+
+
 def pool_slot_cap(maxn):
     """Most structure slots a batch of sequences up to maxn nt should get: a slot of the device pools (sq_pool.hip) costs
     ~56 bytes per nucleotide; all slots stay within a sixth of the free device memory (at most 2 Mi)."""
     import torch
-    per_slot = 8 * (maxn + 34) + 72 * (maxn // 2 + 1) + 2600
+    per_slot = 8 * (maxn + 34) + 72 * (maxn // 2 + 1) + 2600 + _kept_bytes_per_slot(maxn)
     free = torch.cuda.mem_get_info()[0] if torch.cuda.is_available() else 16 << 30
     return int(max(4096, min(free // 6 // per_slot, 2 << 20)))
 
@@ -1008,7 +1019,8 @@ class HipEngine:
             runs = max(0.375 ** (max(1.0, float(np.ceil(ps["minlen"]))) - 1.0) for pl in psets for ps in pl)
             cand = int(max(cand, 32, 0.117 * 1.6 * nmax * runs) * grow[0]) + 1
         b = Batch(prepared, psets, interchainonly=interchainonly, mul=mul, fp32=False, bpp=bpp,
-                  max_structs=max_structs * grow[1], cand_per_nt=cand, mul_shared=mul_shared)
+                  max_structs=max_structs * grow[1], cand_per_nt=cand, mul_shared=mul_shared,
+                  pool_lists=opts.get("poollim", 1000) > 1 and mul_shared is None)
         b.limit_results(keep)
         return b, opts
 
@@ -1019,7 +1031,7 @@ class HipEngine:
         n = max((len(r[0]) for r in records), default=1)
         njobs = sum(len(r[4]) for r in records)
         structs = (self.max_structs if self.max_structs else max(4096, min(4 * njobs, 262144))) * grow[1]
-        per_slot = 8 * (n + 34) + 72 * (n // 2 + 1) + 2600                 # (pool_slot_cap's figure)
+        per_slot = 8 * (n + 34) + 72 * (n // 2 + 1) + 2600 + (_kept_bytes_per_slot(n) if opts.get("poollim", 1000) > 1 else 0)   # (pool_slot_cap's figure)
         cand = max(self.cand_per_nt, 32) * grow[0] * n * 32.0              # candidate records of a structure, 32 bytes each
         free = torch.cuda.mem_get_info()[0]
         return structs * per_slot + min(structs, 4 * njobs) * cand <= free // 2

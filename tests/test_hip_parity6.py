@@ -163,3 +163,45 @@ def test_alignment_rows_read_the_shared_matrix_like_their_gathered_slices(algos,
         monkeypatch.setenv(env, val)
         assert run() == want, env
         monkeypatch.delenv(env)
+
+
+def _pool_records(count, seed, nmin, nmax):
+    """Random-ACGU records of nmin..nmax nt, a few of them with reactivities / restraints / separators (tools/fuzz_parity.py)."""
+    raw = _chain_records(count, seed, nmin, nmax)
+    return raw
+
+
+@pytest.mark.parametrize("config,count,nmin,nmax", [("500nobpp", 24, 300, 620), ("alt", 12, 260, 400)])
+def test_pools_on_kept_lists_equal_the_launched_rounds_and_the_oracle(config, count, nmin, nmax, monkeypatch):
+    """Pools wider than one on sequences of 257-1,024 nt: every structure reads the list its parent left -- runs, bpscores, the
+    finalscores no strand of its own stem comes near -- instead of scanning and scoring anew (sq_fold_paths bit 7).  Against the
+    launched round kernels (SQ_NO_POOL_KEPT), the root lists alone (SQ_NO_POOL_KEPT + SQ_POOL_ROOT), a page pool that runs
+    dry after a few pages (SQ_KEPT_GB: the children of a structure without a list start from the root list), rounds cut into
+    launches of 300 structures (SQ_POOL_CHUNK) -- packed records byte for byte -- and the oracle for a sample."""
+    from oracle import sqrn_oracle as O
+    from squarna_amd.engine import Batch, Prepared
+    names, psets = conf(config)
+    raw = _pool_records(count, 6262, nmin, nmax)
+    prepared = [Prepared(s, r, x) for s, r, x in raw]
+    n = len(prepared)
+
+    def fold(paths_bit7, **env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        try:
+            with Batch(prepared, [psets] * n, max_structs=6000 * n, fp32=False, pool_lists=True) as b:
+                b.fold(poollim=100)
+                assert b.fold_driver == 2, (env, b.fold_driver)
+                assert bool(b.fold_paths & 128) == paths_bit7, (env, b.fold_paths)
+                return _packed(b, n), b.results_all()
+        finally:
+            for k in env:
+                monkeypatch.delenv(k)
+    want, res = fold(True)
+    assert fold(False, SQ_NO_POOL_KEPT="1")[0] == want
+    assert fold(False, SQ_NO_POOL_KEPT="1", SQ_POOL_ROOT="1")[0] == want
+    assert fold(True, SQ_KEPT_GB="0.02")[0] == want
+    assert fold(True, SQ_POOL_CHUNK="300")[0] == want
+    for k in (0, 7, n - 1):
+        s, r, x = raw[k]
+        _same_fold(res[k][0], _oracle_fold(O, s, r, x, psets, poollim=100), (config, "kept lists", k))
