@@ -117,8 +117,8 @@ typedef struct sq_batch_desc {
  * reserves pages for the lists every structure of such a pool hands to its children -- its runs with their bpscores and
  * the finalscores it knew (SQRNdbnseq.py:427-495 and :640-751 are then evaluated for what the child's new stem changed,
  * not for the whole structure; the results are the same).  Without the flag (or with SQ_NO_POOL_KEPT=1 in the environment)
- * such pools run the launched round kernels.  Pages per structure slot: SQ_KEPT_PPS (default 6 of 6 KB per generation),
- * at most SQ_KEPT_GB gigabytes (default 64) in all. */
+ * such pools run the launched round kernels.  Pages per structure slot: SQ_KEPT_PPS (default 3 of 6 KB per generation),
+ * at most SQ_KEPT_GB gigabytes (default 24) in all. */
 #define SQ_BATCH_POOL_LISTS 2
 
 typedef struct sq_batch sq_batch;   /* opaque */
@@ -327,6 +327,13 @@ SQ_API int sq_result_pack_all(const sq_batch *b, void *buf, int64_t cap, int64_t
  * structures than were packed): then sq_result_pack_all forms them.  Replaces the copy a caller of SQRNdbnseq never had to
  * make (the reference returns its tuples by reference, SQRNdbnseq.py:1285-1286). */
 SQ_API int sq_result_view(const sq_batch *b, const void **buf, const int64_t **off, int64_t *nbytes);
+/* ... and the buffer itself handed over: after sq_result_view returned 0, sq_result_detach makes the records' pinned buffer
+ * the CALLER's -- the batch forgets it (and its results: the next fold takes a new buffer), its destruction leaves it alone --
+ * until sq_buffer_release returns it to the library's pinned cache.  For a caller that keeps the records beyond the batch
+ * (the results of a Python call outlive the batch that made them: 544 MB per thousand 500-nt records under pools of a
+ * thousand were copied record by record, a quarter of the call).  Copy the offsets first: they stay the batch's. */
+SQ_API int sq_result_detach(sq_batch *b, void **buf, int64_t *nbytes);
+SQ_API void sq_buffer_release(void *buf);
 /* Dot-bracket rows of every record as ASCII text: record s occupies [off[s], off[s+1]) of buf with its consensus row
  * and then its nstruct structure rows, n characters each (gap-free coordinates; gap columns and separators are
  * re-inserted by the caller, SQRNdbnseq.py:1239-1246).  Levels 1..30 print as ( [ { < A..Z and ) ] } > a..z (:107-112);

@@ -18,7 +18,7 @@ SYMBOLS = ["sq_version", "sq_last_error", "sq_last_capacity", "sq_batch_workspac
            "sq_batch_destroy", "sq_bpmatrix_fill", "sq_bpmatrix_read", "sq_optimal_stems",
            "sq_fold", "sq_result_nstruct", "sq_result_consensus", "sq_result_struct",
            "sq_result_metrics", "sq_result_evals", "sq_result_pack_size", "sq_result_pack",
-           "sq_result_pack_all_size", "sq_result_pack_all", "sq_result_view", "sq_batch_set_inflight", "sq_result_dbn_all_size", "sq_result_dbn_all",
+           "sq_result_pack_all_size", "sq_result_pack_all", "sq_result_view", "sq_result_detach", "sq_buffer_release", "sq_batch_set_inflight", "sq_result_dbn_all_size", "sq_result_dbn_all",
            "sq_profile_enable", "sq_profile_get", "sq_profile_reset", "sq_profile_counters", "sq_run_algos",
            "sq_align_accumulate", "sq_colmatrix_select", "sq_fold_concurrent", "sq_fold_concurrent_n", "sq_fold_driver", "sq_fold_paths", "sq_fold_peak_structs", "sq_result_limit",
            "sq_mwm_workspace_bytes", "sq_mwm", "sq_lsap_workspace_bytes", "sq_lsap",
@@ -114,6 +114,9 @@ def load():
     L.sq_result_pack_all.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.sq_batch_set_inflight.argtypes = [C.c_void_p, C.c_int32]
     L.sq_result_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.sq_result_detach.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.sq_buffer_release.argtypes = [C.c_void_p]
+    L.sq_buffer_release.restype = None
     L.sq_result_dbn_all_size.restype = C.c_int64
     L.sq_result_dbn_all_size.argtypes = [C.c_void_p]
     L.sq_result_dbn_all.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]

@@ -780,7 +780,10 @@ static int algos_begin_dev(sq_batch *b, SqAlgoAsync *pa, int levellimit_opt)
         int nokcap = 0;
         for (int s2 = 0; s2 < S; s2++) nokcap = std::max(nokcap, (int)pa->h_sizes[s2].nok);
         nokcap = (nokcap + 63) & ~63;
-        if (nokcap > 1024 || sq_algo_edges_lds(maxn_lds, nokcap) > 48 * 1024 || b->sw.no_edges_lds) nokcap = 0;
+        // (up to 6,144 stems -- 130 KB, a block per CU: the other form ranks every stem against ALL the keys in global memory,
+        // O(stems^2): 15-25 ms for the 1,500 jobs of 500 records of 500 nt, in front of the greedy loop on the batch's stream)
+        if (nokcap > 6144 || sq_algo_edges_lds(maxn_lds, nokcap) > 150 * 1024 || b->sw.no_edges_lds) nokcap = 0;
+        if (sq_algo_edges_lds(maxn_lds, nokcap) > 48 * 1024) sq_max_dynamic_lds((const void *)sq_algo_edges_kernel, 160 * 1024);
         // (one wave per job on a crowded chip: the work of a job is a few hundred stems behind a handful of trips to L2, and
         // three waves that mostly wait held three wave slots -- sizes + edges were 7 % of a crowded step's wave cycles)
         const bool crowded_k = b->inflight > 1 || b->njobs >= 4096;

@@ -45,7 +45,8 @@ __global__ void sq_algo_edges_kernel(SqDevCtx c, const SqStruct *structs, SqScan
 inline size_t sq_algo_edges_lds(int maxn_lds, int nokcap)
 {
     size_t b = (((size_t)6 * maxn_lds + 15) & ~(size_t)15) + 16;
-    if (nokcap > 0) b += (size_t)4 * (2 * (2 * (size_t)maxn_lds + 2) + 5 * (size_t)nokcap);
+    b += (size_t)4 * (2 * (2 * (size_t)maxn_lds + 2));       // the anti-diagonals' starts and fills (both forms order the stems by them)
+    if (nokcap > 0) b += (size_t)4 * (5 * (size_t)nokcap);
     return b;
 }
 __global__ void sq_algo_finish_kernel(SqDevCtx c, const SqAlgoJob *jobs, const SqMatchJob *mj, const int32_t *out, const int32_t *cnt,

@@ -159,12 +159,34 @@ extern "C" __global__ __launch_bounds__(256) void sq_algo_edges_kernel(SqDevCtx 
         sq_block_excl_scan(s_eoff, (int)nok, s_wsum, &s_run, tid);
         for (uint32_t x = tid; x < nok; x += nthr) eoff[x] = s_eoff[x];
     } else {
-    // the reference's emission order: anti-diagonal ascending, then row ascending == key ascending (keys are distinct)
-    for (uint32_t x = tid; x < nok; x += nthr) {
-        const uint32_t kx = oks[x].key;
-        uint32_t r = 0;
-        for (uint32_t y = 0; y < nok; y++) r += oks[y].key < kx ? 1u : 0u;
-        sidx[r] = x;
+    // the reference's emission order: anti-diagonal ascending, then row ascending == key ascending (keys are distinct).  Lists
+    // too long for LDS (a 500-nt sequence under Nussinov's threshold: 8,000 stems) take the same bucket sort over the
+    // anti-diagonals with the bucket order in global memory (the edge offsets' array, which is written last): until round 6
+    // every stem was ranked against ALL keys -- O(stems^2) reads of global memory, 15-30 ms for the 1,500-3,000 jobs of a
+    // batch of 500-nt records, in front of the greedy loop on the batch's stream
+    {
+        const int nd = 2 * n + 1;
+        uint32_t *const bord = eoff;
+        for (int d = tid; d <= nd; d += nthr) { s_dstart[d] = 0u; s_dfill[d] = 0u; }
+        __syncthreads();
+        for (uint32_t x = tid; x < nok; x += nthr) atomicAdd(&s_dstart[oks[x].key >> 16], 1u);
+        __syncthreads();
+        sq_block_excl_scan(s_dstart, nd, s_wsum, &s_run, tid);
+        for (uint32_t x = tid; x < nok; x += nthr) {
+            const uint32_t d = oks[x].key >> 16;
+            bord[s_dstart[d] + atomicAdd(&s_dfill[d], 1u)] = x;        // (the stems of a diagonal, in any order)
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (uint32_t p = tid; p < nok; p += nthr) {
+            const uint32_t x = bord[p], k = oks[x].key, d = k >> 16;
+            const uint32_t lo = s_dstart[d], hi = lo + s_dfill[d];
+            uint32_t r = lo;
+            for (uint32_t q = lo; q < hi; q++) r += oks[bord[q]].key < k ? 1u : 0u;
+            sidx[r] = x;
+        }
+        __threadfence_block();
+        __syncthreads();
     }
     if (tid == 0) s_run = 0;
     __threadfence_block();

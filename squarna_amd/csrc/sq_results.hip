@@ -187,6 +187,16 @@ extern "C" int sq_result_view(const sq_batch *b, const void **buf, const int64_t
     return 0;
 }
 
+extern "C" int sq_result_detach(sq_batch *b, void **buf, int64_t *nbytes)
+{
+    if (!b || !buf || !nbytes) { sq_set_error("bad argument"); return -1; }
+    if (!(b->packed_ok && packed_whole(b)) || !b->h_rec || !b->h_rec_off) return 1;
+    *buf = b->h_rec; *nbytes = (int64_t)b->h_rec_off[b->nseq];
+    b->h_rec = nullptr; b->h_rec_cap = 0; b->packed_ok = false;       // (the batch has no results any more until it folds again)
+    return 0;
+}
+extern "C" void sq_buffer_release(void *buf) { sq_pinned_put(buf); }
+
 // Dot-bracket rows of every record as ASCII text (the bulk form of levels -> characters): record s occupies
 // [off[s], off[s+1]) with its consensus row and then its nstruct structure rows, n characters each (gap-free
 // coordinates, no separators re-inserted: the caller does that for the records that have any).  Levels 1..30 print as

@@ -679,6 +679,21 @@ class Batch:
         _lib.check(self.L.sq_result_pack_all(self.h, _ptr(buf), nbytes, _ptr(off)))
         return buf[:nbytes], off
 
+    def detach_packed(self):
+        """The packed results of every record as read-only memoryviews of the library's pinned buffer, which leaves the batch
+        with them (sq_result_detach): no copy; the buffer goes back to the library when the last view is dropped.  None when
+        the records are not in that form (the host tail ran): pack_all then."""
+        pb, po, nb = C.c_void_p(), C.c_void_p(), C.c_int64()
+        if self.L.sq_result_view(self.h, C.byref(pb), C.byref(po), C.byref(nb)) != 0:
+            return None
+        off = np.ctypeslib.as_array((C.c_int64 * (self.nseq + 1)).from_address(po.value)).tolist()
+        if self.L.sq_result_detach(self.h, C.byref(pb), C.byref(nb)) != 0:
+            return None
+        arr = (C.c_uint8 * max(int(nb.value), 1)).from_address(pb.value)
+        arr._owner = _PinnedOwner(self.L, pb.value)
+        mv = memoryview(arr).toreadonly()
+        return [mv[off[k]:off[k + 1]] for k in range(self.nseq)]
+
     def evals(self, k):
         return int(self.L.sq_result_evals(self.h, k))
 
@@ -700,6 +715,19 @@ class Batch:
         ms, n, by = C.c_double(), C.c_int64(), C.c_double()
         _lib.check(self.L.sq_profile_get(self.h, kernel, C.byref(ms), C.byref(n), C.byref(by)))
         return ms.value, n.value, by.value
+
+
+class _PinnedOwner:
+    """Returns a detached pinned buffer to the library when the last view of it is gone (Batch.detach_packed)."""
+
+    def __init__(self, L, ptr):
+        self.L, self.ptr = L, ptr
+
+    def __del__(self):
+        try:
+            self.L.sq_buffer_release(C.c_void_p(self.ptr))
+        except Exception:                                            # (interpreter shutdown)
+            pass
 
 
 def unpack_result(p, buf, base=0):
@@ -828,7 +856,7 @@ def _kept_bytes_per_slot(maxn):
     257-1,024 nt): SQ_KEPT_PPS pages of 6 KB per generation, a row of 48 page numbers, a count."""
     if not 256 < maxn <= 1024 or "SQ_NO_POOL_KEPT" in os.environ:
         return 0
-    return int(2 * (float(os.environ.get("SQ_KEPT_PPS", "6")) * 6144 + 196))
+    return int(2 * (float(os.environ.get("SQ_KEPT_PPS", "3")) * 6144 + 196))
 
 
 def pool_slot_cap(maxn):
@@ -931,7 +959,6 @@ class HipEngine:
         (Measured: folding the sub-batches two at a time on streams of their own gains nothing -- 512 x 5000-column
         alignment 10.5 s either way, 3000 x 300 nt with pools of a thousand 2.1 s: these folds are bound by the scoring
         kernel, not by gaps between rounds -- and costs the second batch's memory.)"""
-        out, refs, lo, scale = [], [], 0, 1.0
         # dense per-job matrices (alignment step 2: N x N fp64 + fp32 per job) bound a sub-batch as well: 32 GB of them
         # (allocating and touching 100 GB per batch costs more than the larger rounds save)
         # (not the rows of an alignment weighted by ONE device matrix: the kernels read it through the gap map, no slice exists --
@@ -943,7 +970,7 @@ class HipEngine:
             # sub-batches of equal weight (a last one of a few records would run its rounds on a mostly empty chip)
             dense_cap = sum(dense) / np.ceil(sum(dense) / dense_cap) + max(dense)
 
-        def next_group(lo):
+        def next_group(lo, scale, cap):
             hi, g, gb = lo, 0.0, 0.0
             while hi < len(records) and (hi == lo or (g + max(16.0, per_rec[hi] * scale) <= cap and gb + dense[hi] <= dense_cap)):
                 g += max(16.0, per_rec[hi] * scale)
@@ -951,21 +978,80 @@ class HipEngine:
                 hi += 1
             return hi, int(g)
 
-        first = True
-        while lo < len(records):
-            spans, hints = [], []
-            hi, g = next_group(lo)
-            spans.append((lo, hi)); hints.append(g)
-            lo = hi
-            o, r = self._fold_groups([records[a:b] for a, b in spans], hints, opts)
-            for x, y in zip(o, r):
-                out.extend(x); refs.extend(y)
-            if first and self.last_fold_peak > 0 and self.last_fold_driver == 2:
-                a, b = spans[0]
-                scale = min(scale, max(2.0 * self.last_fold_peak / max(sum(per_rec[a:b]), 1), 1e-4))
-            elif self.last_fold_driver == 3:
-                scale = min(1.0, scale * 4)
-            first = False
+        # SQ_ENGINE_SUBLANES=2: two sub-batches at a time, each from a thread of its own (a batch's fold releases the GIL).
+        # Measured again in round 6 (1,000 records of 500 nt, pools of a thousand on kept lists): 566 ms against 398 one after
+        # the other -- each lane's batches get half of the slots, so there are twice as many, and every one of them waits ~100 ms
+        # for the 500-vertex Edmonds graphs of its records however few they are.  Off by default.
+        # Not the rows weighted by ONE device matrix: they share that tensor on the caller's stream.
+        lanes = max(1, int(os.environ.get("SQ_ENGINE_SUBLANES", "1")))
+        if direct or sum(dense) > 0 or opts.get("_blocks"):
+            lanes = 1
+        n = len(records)
+        out, refs = [None] * n, [None] * n
+        # (the scale the pools of an earlier call reached under the same paramsets, pool limit and lengths: the estimate is for the
+        # widest pools a configuration can have -- 500nobpp at 500 nt reaches an eighth of it -- and a first sub-batch sized by it
+        # was a quarter of the records, with the full wait for its Edmonds graphs)
+        memo = self.__dict__.setdefault("_pool_scale", {})
+        mkey = (id(records[0][4]), int(opts.get("poollim", 1000)), max(len(r[0]) for r in records) // 64)
+        state = {"lo": 0, "scale": memo.get(mkey, 1.0), "first": True, "err": None, "driver": 0, "peak": 0}
+        cap_lane = cap // lanes if lanes > 1 else cap
+        import threading
+        lock = threading.Lock()
+
+        def take():
+            with lock:
+                if state["err"] is not None or state["lo"] >= n:
+                    return None
+                lo = state["lo"]
+                hi, g = next_group(lo, state["scale"], cap_lane)
+                state["lo"] = hi
+                return lo, hi, g
+
+        def work(k):
+            import torch
+            # (a lane keeps its stream for the engine's lifetime: torch's caching allocator hands a freed workspace only to the
+            # stream it was allocated on -- a new stream per call allocated tens of GB anew every time)
+            if lanes > 1:
+                streams = self.__dict__.setdefault("_lane_streams", {})
+                if k not in streams:
+                    streams[k] = torch.cuda.Stream()
+            ctx = torch.cuda.stream(streams[k]) if lanes > 1 else contextlib.nullcontext()
+            try:
+                with ctx:
+                    while True:
+                        job = take()
+                        if job is None:
+                            return
+                        a, b, g = job
+                        info = {}
+                        o, r = self._fold_groups([records[a:b]], [g], opts, info=info, inflight=lanes)
+                        out[a:b] = o[0]
+                        refs[a:b] = r[0]
+                        with lock:
+                            state["driver"] = max(state["driver"], info["driver"])
+                            state["peak"] = max(state["peak"], info["peak"])
+                            if state["first"] and info["peak"] > 0 and info["driver"] == 2:
+                                state["scale"] = min(state["scale"], max(2.0 * info["peak"] / max(sum(per_rec[a:b]), 1), 1e-4))
+                                state["first"] = False
+                            elif info["driver"] == 3:
+                                state["scale"] = min(1.0, state["scale"] * 4)
+                            memo[mkey] = state["scale"]
+            except BaseException as e:                                   # (re-raised on the caller's thread)
+                with lock:
+                    if state["err"] is None:
+                        state["err"] = e
+
+        if lanes == 1:
+            work(0)
+        else:
+            ths = [threading.Thread(target=work, args=(k,)) for k in range(lanes)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        if state["err"] is not None:
+            raise state["err"]
+        self.last_fold_driver, self.last_fold_peak = state["driver"], state["peak"]
         self.last_ref_scores = refs
         return out
 
@@ -1036,7 +1122,7 @@ class HipEngine:
         free = torch.cuda.mem_get_info()[0]
         return structs * per_slot + min(structs, 4 * njobs) * cand <= free // 2
 
-    def _fold_groups(self, groups, hints, opts):
+    def _fold_groups(self, groups, hints, opts, info=None, inflight=1):
         """Folds every group of records as one batch, all of them at the same time; ([results], [reference scores]) per
         group.  One group with SQ_ENGINE_LANES=2 and a big input: cut into two concurrent batches (for one-shot calls
         the second batch's set-up costs more than the overlap saves, so that is opt-in)."""
@@ -1068,6 +1154,8 @@ class HipEngine:
                     batches.append(b)
                 try:
                     if len(batches) == 1:
+                        if inflight > 1:
+                            batches[0].set_inflight(inflight)            # (sub-batches folded side by side from the engine's threads)
                         batches[0].fold(**fold_opts)
                     else:
                         fold_concurrently(batches, **fold_opts)
@@ -1087,11 +1175,18 @@ class HipEngine:
                     for b in batches:
                         b.close()
                     batches = []
-            self.last_fold_driver = max(b.fold_driver for b in batches)
-            self.last_fold_peak = batches[0].fold_peak_structs
+            if info is not None:
+                info["driver"], info["peak"] = max(b.fold_driver for b in batches), batches[0].fold_peak_structs
+            else:
+                self.last_fold_driver = max(b.fold_driver for b in batches)
+                self.last_fold_peak = batches[0].fold_peak_structs
             if opts.get("_packed"):
                 res = []
                 for b in batches:
+                    views = b.detach_packed() if "SQ_NO_DETACH" not in os.environ else None
+                    if views is not None:                            # (no copy: the records stay where the device wrote them)
+                        res.append([(v, None) for v in views])
+                        continue
                     buf, off = b.pack_all()
                     res.append([(buf[off[k]:off[k + 1]].tobytes(), None) for k in range(b.nseq)])
             elif opts.get("_blocks"):

@@ -13,13 +13,13 @@ names, psets = ParseConfig(builtin_config("500nobpp"))
 rng = np.random.default_rng(500)
 recs = [("".join(rng.choice(list("ACGU"), n)), None, None, None, psets, None) for _ in range(cnt)]
 eng = HipEngine()
-for _ in range(3):
+for _ in range(5):
     torch.cuda.synchronize(); t0 = time.perf_counter(); out = eng.fold_records_packed(recs, poollim=1000); torch.cuda.synchronize()
     print("fold ms %.1f driver %d peak %d" % ((time.perf_counter() - t0) * 1e3, eng.last_fold_driver, eng.last_fold_peak))
 h = hashlib.sha256()
-for o in out: h.update(o if isinstance(o, bytes) else bytes(o[0]))
+for o in out: h.update(o)
 print("sha", h.hexdigest()[:16])
 PY
-for m in "kept:" "launched:SQ_NO_POOL_KEPT=1"; do
-  echo "== ${m%%:*}"; env SQ_TIMING=1 ${m#*:} python /tmp/kab.py ${1:-500} ${2:-500} 2>&1 | grep "fold ms\|sha\|rounds=\|kept lists" | tail -8
+for m in "kept:" "kept_copied:SQ_NO_DETACH=1" "launched:SQ_NO_POOL_KEPT=1"; do
+  echo "== ${m%%:*}"; env SQ_TIMING=1 ${m#*:} python /tmp/kab.py ${1:-500} ${2:-500} 2>&1 | grep "fold ms\|sha\|rounds=\|kept lists\|total\|E/H/N: begin" | tail -8
 done

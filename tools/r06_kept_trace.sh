@@ -11,9 +11,9 @@ from squarna_amd.config import ParseConfig, builtin_config
 from squarna_amd.engine import HipEngine
 names, psets = ParseConfig(builtin_config("500nobpp"))
 rng = np.random.default_rng(500)
-recs = [("".join(rng.choice(list("ACGU"), 500)), None, None, None, psets, None) for _ in range(500)]
+recs = [("".join(rng.choice(list("ACGU"), 500)), None, None, None, psets, None) for _ in range(int(os.environ.get("CNT", "500")))]
 eng = HipEngine()
-for _ in range(2):
+for _ in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter(); out = eng.fold_records_packed(recs, poollim=1000); torch.cuda.synchronize()
     print("ms %.1f driver %d peak %d" % ((time.perf_counter() - t0) * 1e3, eng.last_fold_driver, eng.last_fold_peak), flush=True)
 PY
