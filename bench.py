@@ -886,14 +886,15 @@ def shape_leg(recs, config, K, R, steps, device):
 
 
 # ---------------------------------------------------------------- branching pools on long sequences
-def pools_long_leg(count=2000, n=500, reps=2):
+def pools_long_leg(count=2000, n=500, reps=3):
     """`count` random-ACGU sequences of `n` nt under 500nobpp -- the reference's own configuration from 500 nt on
     (SQUARNA.py:875-878 -> 500.conf; two greedy paramsets with suboptimality ranges 0.9-0.95, i.e. pools that branch, + E / H /
     N) -- at the default pool limit of 1000 (SQUARNA.py:421), through the engine (HipEngine.fold_records_packed: sub-batches
-    sized to the device pools' slots; host lists in, packed records out).  A round of the pools of 256+ nt structures is six
-    launches + a host round trip (the one-wave round kernel sq_pool_round.hip takes sequences up to 256 nt; measured up to
-    1,024 it is parity clean and no faster: such a round is bound by the scan and ScoreStems work of its ~20,000 structures
-    per 64 sequences, not by launches)."""
+    sized to the device pools' slots; host lists in, packed records out, handed over without a copy).  From round 6 a round of
+    the pools of 257-1,024 nt structures is ONE launch of the list form of the round kernel (sq_pool_round.hip: every
+    structure reads the list its parent left -- runs, bpscores, the finalscores the new stem does not touch -- and scores what
+    changed); until then it was six launches in twenty chunks + a host round trip, every structure scanned and scored anew
+    (SQ_NO_POOL_KEPT=1: that form)."""
     import torch
     from squarna_amd.config import ParseConfig, builtin_config
     from squarna_amd.engine import HipEngine
@@ -910,7 +911,7 @@ def pools_long_leg(count=2000, n=500, reps=2):
     best = min(ts[1:])
     return dict(what="%d random-ACGU sequences of %d nt (seed 500), c=500nobpp poollim=1000, HipEngine.fold_records_packed (host lists in, "
                      "packed records out), best of %d calls after one warm-up" % (count, n, reps),
-                seconds=round(best, 3), seq_per_s=round(count / best, 1), packed_bytes=int(sum(len(o) if isinstance(o, bytes) else len(o[0]) for o in out)),
+                seconds=round(best, 3), seq_per_s=round(count / best, 1), packed_bytes=int(sum(len(o) for o in out)),
                 driver=int(eng.last_fold_driver), peak_structures_first_sub_batch=int(eng.last_fold_peak))
 
 

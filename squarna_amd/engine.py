@@ -851,6 +851,14 @@ def bpp_terms(prepared, psets, M=1.8, B=-0.6):
     return out
 
 
+def _free_device_bytes():
+    """Free device memory as a new workspace sees it: what the driver reports plus what torch's caching allocator holds without
+    using it (the workspaces of earlier batches: a call that sized its batches by the driver's figure alone got smaller ones
+    than the call before it, whose workspace it could have had back)."""
+    import torch
+    return int(torch.cuda.mem_get_info()[0]) + max(0, int(torch.cuda.memory_reserved()) - int(torch.cuda.memory_allocated()))
+
+
 def _kept_bytes_per_slot(maxn):
     """Bytes per structure slot of the lists a pool's structures hand to their children (SQ_BATCH_POOL_LISTS, sequences of
     257-1,024 nt): SQ_KEPT_PPS pages of 6 KB per generation, a row of 48 page numbers, a count."""
@@ -864,7 +872,7 @@ def pool_slot_cap(maxn):
     ~56 bytes per nucleotide; all slots stay within a sixth of the free device memory (at most 2 Mi)."""
     import torch
     per_slot = 8 * (maxn + 34) + 72 * (maxn // 2 + 1) + 2600 + _kept_bytes_per_slot(maxn)
-    free = torch.cuda.mem_get_info()[0] if torch.cuda.is_available() else 16 << 30
+    free = _free_device_bytes() if torch.cuda.is_available() else 16 << 30
     return int(max(4096, min(free // 6 // per_slot, 2 << 20)))
 
 
@@ -1119,7 +1127,7 @@ class HipEngine:
         structs = (self.max_structs if self.max_structs else max(4096, min(4 * njobs, 262144))) * grow[1]
         per_slot = 8 * (n + 34) + 72 * (n // 2 + 1) + 2600 + (_kept_bytes_per_slot(n) if opts.get("poollim", 1000) > 1 else 0)   # (pool_slot_cap's figure)
         cand = max(self.cand_per_nt, 32) * grow[0] * n * 32.0              # candidate records of a structure, 32 bytes each
-        free = torch.cuda.mem_get_info()[0]
+        free = _free_device_bytes()
         return structs * per_slot + min(structs, 4 * njobs) * cand <= free // 2
 
     def _fold_groups(self, groups, hints, opts, info=None, inflight=1):
