@@ -117,8 +117,8 @@ typedef struct sq_batch_desc {
  * reserves pages for the lists every structure of such a pool hands to its children -- its runs with their bpscores and
  * the finalscores it knew (SQRNdbnseq.py:427-495 and :640-751 are then evaluated for what the child's new stem changed,
  * not for the whole structure; the results are the same).  Without the flag (or with SQ_NO_POOL_KEPT=1 in the environment)
- * such pools run the launched round kernels.  Pages per structure slot: SQ_KEPT_PPS (default 3 of 6 KB per generation),
- * at most SQ_KEPT_GB gigabytes (default 24) in all. */
+ * such pools run the launched round kernels.  Pages per structure slot: SQ_KEPT_PPS (default 3 of 6 KB per generation at 500 nt, growing with the square of the length),
+ * at most SQ_KEPT_GB gigabytes (default 48) in all. */
 #define SQ_BATCH_POOL_LISTS 2
 
 typedef struct sq_batch sq_batch;   /* opaque */

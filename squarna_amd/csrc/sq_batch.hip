@@ -221,8 +221,10 @@ int plan(const sq_batch_desc *d, Layout &L)
         // numbers per slot and generation, the pages
         L.kept_pages = 0; L.off_kctr = L.off_kcnt = L.off_ktab = L.off_kpages = 0;
         if (on && (d->batch_flags & SQ_BATCH_POOL_LISTS) && L.maxn > 256 && L.maxn <= 1024 && !getenv("SQ_NO_POOL_KEPT")) {
-            const double pps = getenv("SQ_KEPT_PPS") ? std::max(0.25, atof(getenv("SQ_KEPT_PPS"))) : 3.0;   // (measured at 500 nt: 4.0 pages per structure of the largest generation, which fills half of the slots)
-            const double gb = getenv("SQ_KEPT_GB") ? std::max(0.01, atof(getenv("SQ_KEPT_GB"))) : 24.0;
+            // (pages per slot and generation: measured at 500 nt, 4.0 pages per structure of the largest generation, which fills
+            // half of the slots; a list grows with the square of the length)
+            const double pps = getenv("SQ_KEPT_PPS") ? std::max(0.25, atof(getenv("SQ_KEPT_PPS"))) : std::max(1.0, 3.0 * ((double)L.maxn / 500.0) * ((double)L.maxn / 500.0));
+            const double gb = getenv("SQ_KEPT_GB") ? std::max(0.01, atof(getenv("SQ_KEPT_GB"))) : 48.0;
             const double np = std::min((double)sm * pps, gb * 1073741824.0 / 2.0 / (double)SQ_KEPT_PAGE_BYTES);
             L.kept_pages = (uint32_t)std::max(64.0, std::min(np, 4.0e9));
             L.off_kctr = take(256); L.off_kcnt = take(2 * sm * 4); L.off_ktab = take(2 * sm * SQ_KEPT_TAB * 4);

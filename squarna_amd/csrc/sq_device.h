@@ -86,9 +86,9 @@ struct SqChainIO {
 // pages of SQ_KEPT_PG entries -- [keys][length | SQ_RX_FIN | SQ_RX_LVL][bpscores][finalscores] -- taken from a pool per
 // generation (two generations: the parents' pages are read while the children's are written; sq_pool_scan_kernel empties the
 // pool of the generation after next); a structure's page numbers stand in its row of `tab`.  A structure that finds the pool
-// empty (or needs more than SQ_KEPT_TAB pages) leaves no list: its children start from the job's root list.
+// empty (or needs more than SQ_KEPT_TAB pages: 65,536 runs) leaves no list: its children start from the job's root list.
 #define SQ_KEPT_PG 256
-#define SQ_KEPT_TAB 48
+#define SQ_KEPT_TAB 256
 #define SQ_KEPT_NOLIST 0xFFFFFFFFu
 #define SQ_KEPT_PAGE_BYTES (SQ_KEPT_PG * 24)
 struct SqKept {

@@ -382,7 +382,18 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     const int gen = ra.parity;
     const size_t krow = cur + (size_t)s;
     bool mylist = ROOT && K.on != 0;
-    uint32_t mycnt = 0, mypages = 0, mytab = 0;
+    uint32_t mycnt = 0, mypages = 0, mytab[4] = {0u, 0u, 0u, 0u};     // (page k: lane k & 63 of word k >> 6)
+    // page number `page` of a table (every lane calls, each with a page of its own)
+    auto tab_get = [&](const uint32_t (&t)[4], uint32_t page, uint32_t npg) -> uint32_t {
+        const int l = (int)(page & 63u);
+        uint32_t v = (uint32_t)__shfl((int)t[0], l, 64);
+        if (npg > 64u) {                                                 // (wave-uniform: few lists are that long)
+            const uint32_t b = (uint32_t)__shfl((int)t[1], l, 64), c2 = (uint32_t)__shfl((int)t[2], l, 64), d = (uint32_t)__shfl((int)t[3], l, 64);
+            const uint32_t h = page >> 6;
+            v = h == 0u ? v : h == 1u ? b : h == 2u ? c2 : d;
+        }
+        return v;
+    };
     const unsigned long long below = (1ull << lane) - 1ull;
     const double qnan = __longlong_as_double(0x7FF8000000000000ll);
     double best = 0.0; bool anybest = false;                           // the best finalscore (wave-uniform)
@@ -399,12 +410,15 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
         // LDS until a whole wave of them is there.  What the rest of the round reads (ChooseStems) is the handful of runs
         // whose finalscore is within range of the best one met before them: only those join the survivors.
         bool from_parent = false;
-        uint32_t R = 0, ptab = 0;
+        uint32_t R = 0, ptab[4] = {0u, 0u, 0u, 0u};
         if (K.on && round) {
             const uint32_t pc = sq_kload(K.cnt + prv + (size_t)p);
             if (pc != SQ_KEPT_NOLIST) {
                 from_parent = true; R = pc;
-                ptab = lane < SQ_KEPT_TAB ? K.tab[(prv + (size_t)p) * SQ_KEPT_TAB + lane] : 0u;
+                const uint32_t *const prow_tab = K.tab + (prv + (size_t)p) * SQ_KEPT_TAB;
+                const uint32_t npg = (pc + SQ_KEPT_PG - 1u) / SQ_KEPT_PG;
+#pragma unroll
+                for (int h = 0; h < 4; h++) if ((uint32_t)(64 * h) < npg) ptab[h] = prow_tab[64 * h + lane];
             }
         }
         const SqRun *const root = reinterpret_cast<const SqRun *>(a.cands + ra.root_off + (int64_t)pio.jobrec_of[job] * ra.root_units);
@@ -423,7 +437,7 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
         sv.place = sv.len + sv.cap;
         WQ *const wq = reinterpret_cast<WQ *>(pr_dyn + Lo.off_surv + (((size_t)24 * sv.cap + 15) & ~(size_t)15));   // 128 entries
         uint32_t nwq = 0;
-        // the source comes in by the page: four entries per lane -- sixteen loads -- at once, the next page's while this one is worked on
+        // the source comes in by the page: four entries per lane -- sixteen loads -- at once
         // (an entry per lane and step, the next step's on their way, left every step waiting for a trip to memory)
         struct Ent4 { uint32_t key[4], lf[4]; double bps[4], fin[4]; };
         auto load_page = [&](uint32_t pk) -> Ent4 {
@@ -431,7 +445,9 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
 #pragma unroll
             for (int t = 0; t < 4; t++) { e.key[t] = 0u; e.lf[t] = 0u; e.bps[t] = 0.0; e.fin[t] = 0.0; }
             if (from_parent) {
-                const uint32_t pid = (uint32_t)__builtin_amdgcn_readlane((int)ptab, (int)pk);
+                const uint32_t ph = pk >> 6;                             // (wave-uniform)
+                const uint32_t pw = ph == 0u ? ptab[0] : ph == 1u ? ptab[1] : ph == 2u ? ptab[2] : ptab[3];
+                const uint32_t pid = (uint32_t)__builtin_amdgcn_readlane((int)pw, (int)(pk & 63u));
                 const SqKeptPage pg = sq_kept_page(K, gen ^ 1, pid);
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -462,7 +478,9 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
 #endif
             if (id0 + need > K.npages) mylist = false;
             else {
-                if ((uint32_t)lane < need) { mytab = id0 + (uint32_t)lane; K.tab[krow * SQ_KEPT_TAB + lane] = mytab; }
+#pragma unroll
+                for (int h = 0; h < 4; h++)
+                    if ((uint32_t)(64 * h + lane) < need) { mytab[h] = id0 + (uint32_t)(64 * h + lane); K.tab[krow * SQ_KEPT_TAB + 64 * h + lane] = mytab[h]; }
                 mypages = need;
             }
         }
@@ -476,12 +494,13 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
                 if (lane == 0) id = atomicAdd(K.ctr + gen, 1u);
                 id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
                 if (id >= K.npages || mypages >= SQ_KEPT_TAB) { mylist = false; break; }
-                if (lane == (int)mypages) mytab = id;
+#pragma unroll
+                for (int h = 0; h < 4; h++) if ((int)mypages == 64 * h + lane) mytab[h] = id;
                 if (lane == 0) K.tab[krow * SQ_KEPT_TAB + mypages] = id;
                 mypages++;
             }
             if (!mylist) return 0u;
-            const uint32_t pid = (uint32_t)__shfl((int)mytab, (int)((pos / SQ_KEPT_PG) & 63u), 64);
+            const uint32_t pid = tab_get(mytab, pos / SQ_KEPT_PG, mypages);
             if (add) {
                 const SqKeptPage pg = sq_kept_page(K, gen, pid);
                 const uint32_t o = pos % SQ_KEPT_PG;
@@ -530,7 +549,7 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
                 __syncthreads();
                 const int L = (int)(e.lp & 0xFFFFu), i0 = (int)(e.key & 0xFFFFu), j0 = (int)(e.key >> 16) - i0;
                 const uint32_t place = e.lp >> 16;
-                const uint32_t wpid = (uint32_t)__shfl((int)mytab, (int)((place / SQ_KEPT_PG) & 63u), 64);
+                const uint32_t wpid = tab_get(mytab, place / SQ_KEPT_PG, mypages);
                 bool ok = mine;
                 if (ok) {                                                        // (the bar has risen since the run joined the queue)
                     const double ub = sq_run_upper(e.bps, i0, j0, L, U, l_code, n, ub_of, ub_lf, ps_lb);
@@ -619,13 +638,15 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
 #endif
         };
 #define SQ_OV(z0, z1, lo, hi) (((hi) - (z0)) | ((z1) - (lo)))
-        Ent4 cur4 = load_page(0u), nxt4 = cur4;
+        Ent4 cur4 = load_page(0u);
         for (uint32_t b0 = 0; b0 < R; b0 += SQ_KEPT_PG) {
-            if (b0 + SQ_KEPT_PG < R) nxt4 = load_page(b0 / SQ_KEPT_PG + 1u);
             for (uint32_t q0 = b0; q0 < b0 + SQ_KEPT_PG && q0 < R; q0 += 64) {
                 const uint32_t rkey = cur4.key[0], rlf = cur4.lf[0]; const double rbps = cur4.bps[0], rfin = cur4.fin[0];
 #pragma unroll
                 for (int t = 0; t < 3; t++) { cur4.key[t] = cur4.key[t + 1]; cur4.lf[t] = cur4.lf[t + 1]; cur4.bps[t] = cur4.bps[t + 1]; cur4.fin[t] = cur4.fin[t + 1]; }
+                // (ONE page in registers: the next one is asked for when this one's last group has been taken out -- a second page
+                // under way cost 24 registers, and at 168 the kernel runs three waves per SIMD: 332 -> 305 ms per 1,000 records)
+                if (q0 + 64 >= b0 + SQ_KEPT_PG && b0 + SQ_KEPT_PG < R) cur4 = load_page(b0 / SQ_KEPT_PG + 1u);
                 const bool have = q0 + (uint32_t)lane < R;
                 const int L = (int)(rlf & SQ_RX_LEN), i = (int)(rkey & 0xFFFFu), j = (int)(rkey >> 16) - i;
                 const bool whole = have && ((int)U[i + L] - (int)U[i]) == L && ((int)U[j + 1] - (int)U[j - L + 1]) == L;
@@ -649,7 +670,6 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
                 if (ncq >= 64u) serve_cuts(false);
                 if (nwq >= 64u) serve_walks(false);
             }
-            cur4 = nxt4;
         }
         serve_cuts(true);
         serve_walks(true);
@@ -803,7 +823,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
     sq_pool_round_body<false>(c, a, pio, ra);
 }
 #ifndef SQ_PR_ROOT_WAVES
-#define SQ_PR_ROOT_WAVES 2         // (the list form: 199 VGPRs; at 128 it spilled 190 of them and every step of its stream waited for scratch -- loop of 500 x 500 nt 153 -> 125 ms; 3 waves: 168 VGPRs, 79 spilled, 127 ms)
+#define SQ_PR_ROOT_WAVES 3         // (the list form: 168 VGPRs, 16 spilled; at 128 it spilled 190 of them and every step of its stream waited for scratch -- loop of 500 x 500 nt 153 -> 125 ms; 2 waves, no spill: 8 % slower than 3)
 #endif
 extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SQ_PR_ROOT_WAVES, SQ_PR_ROOT_WAVES))) void sq_pool_round_root_kernel(SqDevCtx c, SqScanArgs a, SqPoolIO pio, SqPoolRoundArgs ra)
 {

@@ -861,10 +861,12 @@ def _free_device_bytes():
 
 def _kept_bytes_per_slot(maxn):
     """Bytes per structure slot of the lists a pool's structures hand to their children (SQ_BATCH_POOL_LISTS, sequences of
-    257-1,024 nt): SQ_KEPT_PPS pages of 6 KB per generation, a row of 48 page numbers, a count."""
+    257-1,024 nt): SQ_KEPT_PPS pages of 6 KB per generation (default 3 at 500 nt, growing with the square of the length), a row
+    of 256 page numbers, a count."""
     if not 256 < maxn <= 1024 or "SQ_NO_POOL_KEPT" in os.environ:
         return 0
-    return int(2 * (float(os.environ.get("SQ_KEPT_PPS", "3")) * 6144 + 196))
+    pps = float(os.environ["SQ_KEPT_PPS"]) if "SQ_KEPT_PPS" in os.environ else max(1.0, 3.0 * (maxn / 500.0) ** 2)
+    return int(2 * (pps * 6144 + 1028))
 
 
 def pool_slot_cap(maxn):

@@ -9,7 +9,7 @@ import numpy as np, torch
 from squarna_amd.config import ParseConfig, builtin_config
 from squarna_amd.engine import HipEngine
 n, cnt = int(sys.argv[1]), int(sys.argv[2])
-names, psets = ParseConfig(builtin_config("500nobpp"))
+names, psets = ParseConfig(builtin_config(sys.argv[3] if len(sys.argv) > 3 else "500nobpp"))
 rng = np.random.default_rng(500)
 recs = [("".join(rng.choice(list("ACGU"), n)), None, None, None, psets, None) for _ in range(cnt)]
 eng = HipEngine()
@@ -21,5 +21,5 @@ for o in out: h.update(o)
 print("sha", h.hexdigest()[:16])
 PY
 for m in "kept:" "kept_copied:SQ_NO_DETACH=1" "launched:SQ_NO_POOL_KEPT=1"; do
-  echo "== ${m%%:*}"; env SQ_TIMING=1 ${m#*:} python /tmp/kab.py ${1:-500} ${2:-500} 2>&1 | grep "fold ms\|sha\|rounds=\|kept lists\|total\|E/H/N: begin" | tail -8
+  echo "== ${m%%:*}"; env SQ_TIMING=1 ${m#*:} python /tmp/kab.py ${1:-500} ${2:-500} ${3:-500nobpp} 2>&1 | grep "fold ms\|sha\|rounds=\|kept lists\|total\|E/H/N: begin" | tail -8
 done

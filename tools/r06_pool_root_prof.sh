@@ -8,9 +8,9 @@ sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 import numpy as np, torch
 from squarna_amd.config import ParseConfig, builtin_config
 from squarna_amd.engine import HipEngine
-names, psets = ParseConfig(builtin_config("500nobpp"))
+names, psets = ParseConfig(builtin_config(os.environ.get("CFG", "500nobpp")))
 rng = np.random.default_rng(500)
-recs = [("".join(rng.choice(list("ACGU"), 500)), None, None, None, psets, None) for _ in range(500)]
+recs = [("".join(rng.choice(list("ACGU"), int(os.environ.get("NNT", "500")))), None, None, None, psets, None) for _ in range(int(os.environ.get("CNT", "500")))]
 eng = HipEngine()
 for _ in range(int(sys.argv[1])):
     torch.cuda.synchronize(); t0 = time.perf_counter(); eng.fold_records_packed(recs, poollim=1000); torch.cuda.synchronize()
