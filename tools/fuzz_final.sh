@@ -13,3 +13,7 @@ run python3 tools/fuzz_align.py 80 301
 run SQ_CTX_MIN_N=0 FUZZ_NMIN=256 FUZZ_NMAX=700 FUZZ_POOLLIM=1 python3 tools/fuzz_parity.py 400 fastest 107
 run SQ_CTX_MIN_N=0 FUZZ_NMIN=256 FUZZ_NMAX=520 FUZZ_POOLLIM=25 python3 tools/fuzz_parity.py 200 nobpp 108
 run SQ_CTX_MIN_N=0 FUZZ_NMIN=256 FUZZ_NMAX=420 FUZZ_POOLLIM=1000 python3 tools/fuzz_parity.py 120 alt 109
+# the list form of the pool round kernel (257-1,024 nt, pools wider than one): every structure reads the list its parent left
+run FUZZ_NMIN=257 FUZZ_NMAX=700 FUZZ_POOLLIM=100 python3 tools/fuzz_parity.py 120 greedynobpp 110
+run FUZZ_NMIN=257 FUZZ_NMAX=450 python3 tools/fuzz_parity.py 160 nobpp 111
+run FUZZ_NMIN=257 FUZZ_NMAX=380 SQ_KEPT_GB=0.05 python3 tools/fuzz_parity.py 100 alt 112
