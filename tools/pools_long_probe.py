@@ -1,6 +1,7 @@
 """pools_long: COUNT random-ACGU sequences of N nt under a config with branching pools (500nobpp: the reference's own
 default for N >= 500), poollim 1000, through the engine (sub-batches sized to the device pools' slots) -- fold times with the
-fused pool round kernel and with the launched round kernels (SQ_NO_POOL_ROUND), packed records compared.
+list form of the pool round kernel (every structure reads the list its parent left: the default from round 6) and with the
+launched round kernels (SQ_NO_POOL_KEPT), packed records compared.
 usage: pools_long_probe.py [N] [COUNT] [CONFIG] [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,15 +16,15 @@ names, psets = ParseConfig(builtin_config(cfg))
 rng = np.random.default_rng(500)
 recs = [("".join(rng.choice(list("ACGU"), n)), None, None, None, psets, None) for _ in range(count)]
 packs = {}
-for mode in ("fused", "launched"):
+for mode in ("lists", "launched"):
     if mode == "launched":
-        os.environ["SQ_NO_POOL_ROUND"] = "1"
+        os.environ["SQ_NO_POOL_KEPT"] = "1"
     else:
-        os.environ.pop("SQ_NO_POOL_ROUND", None)
+        os.environ.pop("SQ_NO_POOL_KEPT", None)
     eng = HipEngine()
     ts = []
     for _ in range(reps + 1):
         torch.cuda.synchronize(); t0 = time.perf_counter(); out = eng.fold_records_packed(recs, poollim=1000); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-    packs[mode] = [o if isinstance(o, bytes) else bytes(o[0]) for o in out]
+    packs[mode] = [bytes(o) for o in out]
     print("%s %s N=%d x %d: fold_records ms %s (min %.1f) driver %d peak %d" % (mode, cfg, n, count, " ".join("%.1f" % t for t in ts), min(ts), eng.last_fold_driver, eng.last_fold_peak), flush=True)
-print("identical:", packs["fused"] == packs["launched"])
+print("identical:", packs["lists"] == packs["launched"])
