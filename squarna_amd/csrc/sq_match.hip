@@ -504,7 +504,13 @@ void sq_mwm_plan(const SqMatchJob *h_jobs, SqMatchJob *jobs_rw, int nj, int32_t 
     // +14 % time per graph) and a block holds four of them in 40 KB, so that ALL graphs are resident at once -- the kernel
     // then lasts as long as its slowest graph -- and the scoring kernels of the greedy rounds still find LDS on every CU.
     // Measured on 24 SRtest150 sets in one batch (4,296 graphs): 11.5 ms with 150 KB bins, 6.6 ms this way.
-    const bool crowd = (long long)nj * std::max(1, inflight) >= 1024;
+    // ... and so is a launch of hundreds of LARGE graphs (hot part beyond a crowd's 40 KB bin: 500 vertices and 17,000 edges take
+    // 50 KB) beside the rounds of the same batch's pools: 822 such graphs fill the LDS of every CU for 75 ms, during which the
+    // round kernel does not run (round 6: 1,000 records of 500 nt under pools of a thousand 313 -> 278 ms with the graphs' state
+    // in global memory; at 700 records the same either way, at 500 and fewer the longer Edmonds kernel is what the fold waits for)
+    size_t hot_max = 0;
+    for (int q = 0; q < nj; q++) hot_max = std::max(hot_max, SqBlossom::hot_bytes(h_jobs[q].n, h_jobs[q].nedges, 2));
+    const bool crowd = (long long)nj * std::max(1, inflight) >= 1024 || (nj >= 768 && hot_max + 16 + ((sizeof(SqBlossom) + 15) & ~(size_t)15) > 40 * 1024);
     size_t cap = env_cap > 0 ? (size_t)env_cap : (crowd ? 40 * 1024 : many ? 96 * 1024 : 150 * 1024);
     cap = std::min<size_t>(cap, 150 * 1024);
     const size_t all_cap = env_all > 0 ? (size_t)env_all : (crowd ? 1 : many ? 48 * 1024 : 150 * 1024);
@@ -571,7 +577,13 @@ int sq_launch_matching(int algo, const SqMatchJob *h_jobs, int nj, const SqMatch
         // (with the chip crowded ONE wave per job: a block of three waves holds three wave slots through every barrier-separated
         // diagonal, and wave slots are what a crowded chip runs out of -- a lane then takes up to three cells of a diagonal)
         static const int env_thr = getenv("SQ_NUSS_THREADS") ? std::max(64, std::min(256, atoi(getenv("SQ_NUSS_THREADS")) / 64 * 64)) : 0;
-        const bool crowd = (long long)nj * std::max(1, inflight) >= 1024;
+        // ... and so is a launch of hundreds of LARGE graphs (hot part beyond a crowd's 40 KB bin: 500 vertices and 17,000 edges take
+    // 50 KB) beside the rounds of the same batch's pools: 822 such graphs fill the LDS of every CU for 75 ms, during which the
+    // round kernel does not run (round 6: 1,000 records of 500 nt under pools of a thousand 313 -> 278 ms with the graphs' state
+    // in global memory; at 700 records the same either way, at 500 and fewer the longer Edmonds kernel is what the fold waits for)
+    size_t hot_max = 0;
+    for (int q = 0; q < nj; q++) hot_max = std::max(hot_max, SqBlossom::hot_bytes(h_jobs[q].n, h_jobs[q].nedges, 2));
+    const bool crowd = (long long)nj * std::max(1, inflight) >= 1024 || (nj >= 768 && hot_max + 16 + ((sizeof(SqBlossom) + 15) & ~(size_t)15) > 40 * 1024);
         const int nthr = env_thr ? env_thr : crowd ? 64 : std::max(64, std::min(256, (maxn + 63) / 64 * 64));
         hipLaunchKernelGGL(sq_nussinov_kernel, dim3(nj), dim3(nthr), 0, st, jobs, edges, codes, d_scr, out, cnt, jobs_rw ? 1 : 0);
     } else {                                             // SQ_ALGO_E

@@ -139,6 +139,7 @@ struct SqPrNullSink {       // (instrumentation: -DSQ_PR_DUP_SCAN runs the scan 
     __device__ __forceinline__ void poll(int) {}
     __device__ __forceinline__ void drain(int) {}
 };
+struct SqEnt4 { uint32_t key[4], lf[4]; double bps[4], fin[4]; };      // a page of the list form's source: four entries per lane
 #ifndef SQ_PR_WAVES
 #define SQ_PR_WAVES 4              // waves per SIMD the register budget is set for (4: 128 VGPRs)
 #endif
@@ -295,6 +296,73 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
 #endif
     const SqCellEnv cenv = sq_cell_setup<!ROOT>(c, jb, ps, s_ctmp, l_ci, l_code, s_cell, lane, 64, &cpre);
     PRPROF(1);
+    bool from_parent = false;
+    uint32_t R = 0, ptab[4] = {0u, 0u, 0u, 0u};
+    const SqRun *root = nullptr;
+    // kept lists (sq_pool_round.h): this structure's own list -- entries so far, pages taken (lane k holds the k-th page's number)
+    const SqKept &K = ra.kept;
+    const int gen = ra.parity;
+    const size_t krow = cur + (size_t)s;
+    bool mylist = ROOT && K.on != 0;
+    uint32_t mycnt = 0, mypages = 0, mytab[4] = {0u, 0u, 0u, 0u};     // (page k: lane k & 63 of word k >> 6)
+    // page number `page` of a table (every lane calls, each with a page of its own)
+    auto tab_get = [&](const uint32_t (&t)[4], uint32_t page, uint32_t npg) -> uint32_t {
+        const int l = (int)(page & 63u);
+        uint32_t v = (uint32_t)__shfl((int)t[0], l, 64);
+        if (npg > 64u) {                                                 // (wave-uniform: few lists are that long)
+            const uint32_t b = (uint32_t)__shfl((int)t[1], l, 64), c2 = (uint32_t)__shfl((int)t[2], l, 64), d = (uint32_t)__shfl((int)t[3], l, 64);
+            const uint32_t h = page >> 6;
+            v = h == 0u ? v : h == 1u ? b : h == 2u ? c2 : d;
+        }
+        return v;
+    };
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+    // (list form) the source -- the list the PARENT left, or without one the job's root list -- and its first page, asked for HERE:
+    // the three dependent trips to memory (count, page numbers, page) overlap with the building of the structure's state
+    if (ROOT && K.on && round) {
+        const uint32_t pc = sq_kload(K.cnt + prv + (size_t)p);
+        if (pc != SQ_KEPT_NOLIST) {
+            from_parent = true; R = pc;
+            const uint32_t *const prow_tab = K.tab + (prv + (size_t)p) * SQ_KEPT_TAB;
+            const uint32_t npg = (pc + SQ_KEPT_PG - 1u) / SQ_KEPT_PG;
+#pragma unroll
+            for (int h = 0; h < 4; h++) if ((uint32_t)(64 * h) < npg) ptab[h] = prow_tab[64 * h + lane];
+        }
+    }
+    if (ROOT) {
+        root = reinterpret_cast<const SqRun *>(a.cands + ra.root_off + (int64_t)pio.jobrec_of[job] * ra.root_units);
+        if (!from_parent) R = a.cand_cnt[pio.jobrec_of[job]];
+    }
+    // the source comes in by the page: four entries per lane -- sixteen loads -- at once
+    // (an entry per lane and step, the next step's on their way, left every step waiting for a trip to memory)
+    auto load_page = [&](uint32_t pk) -> SqEnt4 {
+        SqEnt4 e;
+#pragma unroll
+        for (int t = 0; t < 4; t++) { e.key[t] = 0u; e.lf[t] = 0u; e.bps[t] = 0.0; e.fin[t] = 0.0; }
+        if (from_parent) {
+            const uint32_t ph = pk >> 6;                             // (wave-uniform)
+            const uint32_t pw = ph == 0u ? ptab[0] : ph == 1u ? ptab[1] : ph == 2u ? ptab[2] : ptab[3];
+            const uint32_t pid = (uint32_t)__builtin_amdgcn_readlane((int)pw, (int)(pk & 63u));
+            const SqKeptPage pg = sq_kept_page(K, gen ^ 1, pid);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t o = 64u * t + (uint32_t)lane;
+                if (pk * SQ_KEPT_PG + o < R) { e.key[t] = pg.key[o]; e.lf[t] = pg.lf[o]; e.bps[t] = pg.bps[o]; e.fin[t] = pg.fin[o]; }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t q = pk * SQ_KEPT_PG + 64u * t + (uint32_t)lane;
+                if (q < R) { const SqRun r = root[q]; e.key[t] = r.key; e.lf[t] = r.len; e.bps[t] = r.bps; }
+            }
+        }
+        return e;
+    };
+    SqEnt4 cur4;
+#pragma unroll
+    for (int t = 0; t < 4; t++) { cur4.key[t] = 0u; cur4.lf[t] = 0u; cur4.bps[t] = 0.0; cur4.fin[t] = 0.0; }
+    if (ROOT && n >= 5) cur4 = load_page(0u);
 
     // ---- the structure's state (sq_state_build): partner array, mask codes, prefix counts, free-position words ----
 #ifdef SQ_PR_DUP_STATE
@@ -377,25 +445,6 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     }
     const double minbps = ps->minbpscore, minfin = ps->minfinscore;
     uint32_t ns = 0;
-    // kept lists (sq_pool_round.h): this structure's own list -- entries so far, pages taken (lane k holds the k-th page's number)
-    const SqKept &K = ra.kept;
-    const int gen = ra.parity;
-    const size_t krow = cur + (size_t)s;
-    bool mylist = ROOT && K.on != 0;
-    uint32_t mycnt = 0, mypages = 0, mytab[4] = {0u, 0u, 0u, 0u};     // (page k: lane k & 63 of word k >> 6)
-    // page number `page` of a table (every lane calls, each with a page of its own)
-    auto tab_get = [&](const uint32_t (&t)[4], uint32_t page, uint32_t npg) -> uint32_t {
-        const int l = (int)(page & 63u);
-        uint32_t v = (uint32_t)__shfl((int)t[0], l, 64);
-        if (npg > 64u) {                                                 // (wave-uniform: few lists are that long)
-            const uint32_t b = (uint32_t)__shfl((int)t[1], l, 64), c2 = (uint32_t)__shfl((int)t[2], l, 64), d = (uint32_t)__shfl((int)t[3], l, 64);
-            const uint32_t h = page >> 6;
-            v = h == 0u ? v : h == 1u ? b : h == 2u ? c2 : d;
-        }
-        return v;
-    };
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
     double best = 0.0; bool anybest = false;                           // the best finalscore (wave-uniform)
     if (ROOT && n >= 5) {
         // ---- AnnotateStems, :492 and ScoreStems as ONE pass over a list.  Choosing stems only ever masks rows and columns
@@ -409,20 +458,6 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
         // bound (sq_run_upper) reaches the range under the best finalscore so far.  The rare steps -- cut runs, walks -- wait in
         // LDS until a whole wave of them is there.  What the rest of the round reads (ChooseStems) is the handful of runs
         // whose finalscore is within range of the best one met before them: only those join the survivors.
-        bool from_parent = false;
-        uint32_t R = 0, ptab[4] = {0u, 0u, 0u, 0u};
-        if (K.on && round) {
-            const uint32_t pc = sq_kload(K.cnt + prv + (size_t)p);
-            if (pc != SQ_KEPT_NOLIST) {
-                from_parent = true; R = pc;
-                const uint32_t *const prow_tab = K.tab + (prv + (size_t)p) * SQ_KEPT_TAB;
-                const uint32_t npg = (pc + SQ_KEPT_PG - 1u) / SQ_KEPT_PG;
-#pragma unroll
-                for (int h = 0; h < 4; h++) if ((uint32_t)(64 * h) < npg) ptab[h] = prow_tab[64 * h + lane];
-            }
-        }
-        const SqRun *const root = reinterpret_cast<const SqRun *>(a.cands + ra.root_off + (int64_t)pio.jobrec_of[job] * ra.root_units);
-        if (!from_parent) R = a.cand_cnt[pio.jobrec_of[job]];
         const int minlen = max(1, (int)ceil(ps->minlen));
         const double ps_lb = ps->loopbonus;
         const double ub_of = ps->ub_of, ub_lf = ra.bound ? ps->ub_lf : INFINITY;
@@ -437,32 +472,6 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
         sv.place = sv.len + sv.cap;
         WQ *const wq = reinterpret_cast<WQ *>(pr_dyn + Lo.off_surv + (((size_t)24 * sv.cap + 15) & ~(size_t)15));   // 128 entries
         uint32_t nwq = 0;
-        // the source comes in by the page: four entries per lane -- sixteen loads -- at once
-        // (an entry per lane and step, the next step's on their way, left every step waiting for a trip to memory)
-        struct Ent4 { uint32_t key[4], lf[4]; double bps[4], fin[4]; };
-        auto load_page = [&](uint32_t pk) -> Ent4 {
-            Ent4 e;
-#pragma unroll
-            for (int t = 0; t < 4; t++) { e.key[t] = 0u; e.lf[t] = 0u; e.bps[t] = 0.0; e.fin[t] = 0.0; }
-            if (from_parent) {
-                const uint32_t ph = pk >> 6;                             // (wave-uniform)
-                const uint32_t pw = ph == 0u ? ptab[0] : ph == 1u ? ptab[1] : ph == 2u ? ptab[2] : ptab[3];
-                const uint32_t pid = (uint32_t)__builtin_amdgcn_readlane((int)pw, (int)(pk & 63u));
-                const SqKeptPage pg = sq_kept_page(K, gen ^ 1, pid);
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const uint32_t o = 64u * t + (uint32_t)lane;
-                    if (pk * SQ_KEPT_PG + o < R) { e.key[t] = pg.key[o]; e.lf[t] = pg.lf[o]; e.bps[t] = pg.bps[o]; e.fin[t] = pg.fin[o]; }
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const uint32_t q = pk * SQ_KEPT_PG + 64u * t + (uint32_t)lane;
-                    if (q < R) { const SqRun r = root[q]; e.key[t] = r.key; e.lf[t] = r.len; e.bps[t] = r.bps; }
-                }
-            }
-            return e;
-        };
         // the pages this structure's list will need, in one go (it is at most as long as its source, pieces of cut runs aside: those
         // take further pages one by one) -- a returning atomic per page was a trip to memory every fourth step
         if (mylist && R > 0u) {
@@ -638,8 +647,7 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
 #endif
         };
 #define SQ_OV(z0, z1, lo, hi) (((hi) - (z0)) | ((z1) - (lo)))
-        Ent4 cur4 = load_page(0u);
-        for (uint32_t b0 = 0; b0 < R; b0 += SQ_KEPT_PG) {
+        for (uint32_t b0 = 0; b0 < R; b0 += SQ_KEPT_PG) {                      // (the first page: asked for before the structure's state was built)
             for (uint32_t q0 = b0; q0 < b0 + SQ_KEPT_PG && q0 < R; q0 += 64) {
                 const uint32_t rkey = cur4.key[0], rlf = cur4.lf[0]; const double rbps = cur4.bps[0], rfin = cur4.fin[0];
 #pragma unroll
