@@ -1005,6 +1005,7 @@ class HipEngine:
         mkey = (id(records[0][4]), int(opts.get("poollim", 1000)), max(len(r[0]) for r in records) // 64)
         state = {"lo": 0, "scale": memo.get(mkey, 1.0), "first": True, "err": None, "driver": 0, "peak": 0}
         cap_lane = cap // lanes if lanes > 1 else cap
+        per_arr = np.asarray(per_rec, np.float64)
         import threading
         lock = threading.Lock()
 
@@ -1013,7 +1014,13 @@ class HipEngine:
                 if state["err"] is not None or state["lo"] >= n:
                     return None
                 lo = state["lo"]
-                hi, g = next_group(lo, state["scale"], cap_lane)
+                # (sub-batches of equal weight: what is left goes into as few batches as the slots allow, each with the same share --
+                # a full one and a remainder of a fifth left the remainder its own wait for the Edmonds graphs on a mostly empty chip)
+                left = float(np.maximum(16.0, per_arr[lo:] * state["scale"]).sum())
+                cap_now = cap_lane
+                if left > cap_lane:
+                    cap_now = min(cap_lane, left / np.ceil(left / cap_lane) + float(per_arr[lo:].max()) * state["scale"] + 16.0)
+                hi, g = next_group(lo, state["scale"], cap_now)
                 state["lo"] = hi
                 return lo, hi, g
 
