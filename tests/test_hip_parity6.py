@@ -205,3 +205,28 @@ def test_pools_on_kept_lists_equal_the_launched_rounds_and_the_oracle(config, co
     for k in (0, 7, n - 1):
         s, r, x = raw[k]
         _same_fold(res[k][0], _oracle_fold(O, s, r, x, psets, poollim=100), (config, "kept lists", k))
+
+
+def test_packed_results_handed_over_equal_their_copies():
+    """sq_result_detach: the records' pinned buffer becomes the caller's -- read-only memoryviews whose bytes are those of
+    sq_result_view / sq_result_pack_all --, the batch has no results until it folds again, and it folds again into a new buffer
+    while the views of the first fold still stand."""
+    import gc
+    from squarna_amd.engine import Batch, Prepared
+    names, psets = conf("nobpp")
+    raw = _chain_records(40, 6363, 30, 200)
+    prepared = [Prepared(s, r, x) for s, r, x in raw]
+    n = len(prepared)
+    with Batch(prepared, [psets] * n, max_structs=64 * n, fp32=False) as b:
+        b.fold(poollim=100)
+        want = _packed(b, n)
+        views = b.detach_packed()
+        assert views is not None and [bytes(v) for v in views] == want
+        assert all(v.readonly for v in views)
+        assert b.detach_packed() is None                              # (nothing left to hand over)
+        b.fold(poollim=100)                                           # a new buffer; the first fold's views are untouched
+        assert _packed(b, n) == want and [bytes(v) for v in views] == want
+        again = b.detach_packed()
+        assert [bytes(v) for v in again] == want
+    del views, again
+    gc.collect()                                                      # (both buffers go back to the library's pinned cache)
