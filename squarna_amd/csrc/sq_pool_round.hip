@@ -51,6 +51,7 @@ __device__ __forceinline__ bool sq_pr_shares_base(int ai, int aj, int al, int bi
 struct SqPrSurv {
     double *bps, *fin; uint32_t *key; uint16_t *len, *place; int cap;
     SqOk *spill; uint32_t spill_cap; SqCounters *ctr;
+    uint32_t *pool_ovf;                               // (list form) SqPoolHdr::ovf: more runs within range than a structure's region holds
     __device__ __forceinline__ void put(uint32_t at, uint32_t k, int L, double b)
     {
         if (at < (uint32_t)cap) { key[at] = k; len[at] = (uint16_t)L; bps[at] = b; }
@@ -63,7 +64,7 @@ struct SqPrSurv {
     {
         if (at < (uint32_t)cap) { key[at] = k; len[at] = (uint16_t)L; bps[at] = b; fin[at] = f; place[at] = (uint16_t)pl; }
         else if (at - cap < spill_cap) spill[at - cap] = SqOk{k, (uint32_t)L | (pl << 16), b, f};
-        else ctr->cand_ovf = 1;
+        else *pool_ovf = 1;         // (ChooseStems' own room is smaller still: like its overflow, the host's loop repeats the fold)
     }
     __device__ __forceinline__ uint32_t get_place(uint32_t at) const { return at < (uint32_t)cap ? (uint32_t)place[at] : spill[at - cap].len >> 16; }
     __device__ __forceinline__ void get(uint32_t at, uint32_t &k, int &L, double &b) const
@@ -434,7 +435,7 @@ __device__ __forceinline__ void sq_pool_round_body(const SqDevCtx &c, const SqSc
     sv.bps = reinterpret_cast<double *>(pr_dyn + Lo.off_surv); sv.fin = sv.bps + ra.surv_cap;
     sv.key = reinterpret_cast<uint32_t *>(sv.fin + ra.surv_cap); sv.len = reinterpret_cast<uint16_t *>(sv.key + ra.surv_cap);
     sv.place = sv.len + ra.surv_cap;
-    sv.cap = ra.surv_cap; sv.ctr = a.ctr;
+    sv.cap = ra.surv_cap; sv.ctr = a.ctr; sv.pool_ovf = &pio.hdr->ovf;
     // the structure's slice of the arena (cand_cap 32-byte units): runs the staging buffer could not take, then spilled survivors
     uint2 *const over = reinterpret_cast<uint2 *>(a.cands + st.cand_off);
     sv.spill = sq_oks(a, st, jb.cand_cap);
