@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of two prebuilt libraries (tools/_libA.so, tools/_libB.so) on pools_long (COUNT records of N nt), alternating on one box
+# A/B of two prebuilt libraries (tools/_libA.so, tools/_libB.so) on pools under the list form (COUNT records of N nt), alternating on one box
 cd $GRAFT_REPO_ROOT
 bash tools/r06_kept_ab.sh 500 10 > /dev/null 2>&1
 cp squarna_amd/libsquarna_hip.so /tmp/lib_keep.so
