@@ -869,13 +869,19 @@ def _kept_bytes_per_slot(maxn):
     return int(2 * (pps * 6144 + 1028))
 
 
-def pool_slot_cap(maxn):
+def pool_slot_cap(maxn, want=None):
     """Most structure slots a batch of sequences up to maxn nt should get: a slot of the device pools (sq_pool.hip) costs
-    ~56 bytes per nucleotide; all slots stay within a sixth of the free device memory (at most 2 Mi)."""
+    ~56 bytes per nucleotide; all slots stay within a sixth of the free device memory (at most 2 Mi).
+    want: the slots the caller is about to ask for -- when the driver's figure alone grants them, the allocator's idle blocks are
+    not counted (torch.cuda.memory_reserved() walks the allocator's statistics: 0.25 ms of a 5-ms Predict() on SRtest150)."""
     import torch
     per_slot = 8 * (maxn + 34) + 72 * (maxn // 2 + 1) + 2600 + _kept_bytes_per_slot(maxn)
-    free = _free_device_bytes() if torch.cuda.is_available() else 16 << 30
-    return int(max(4096, min(free // 6 // per_slot, 2 << 20)))
+    if not torch.cuda.is_available():
+        return int(max(4096, min((16 << 30) // 6 // per_slot, 2 << 20)))
+    cap = int(max(4096, min(int(torch.cuda.mem_get_info()[0]) // 6 // per_slot, 2 << 20)))
+    if want is not None and want <= cap:
+        return cap
+    return int(max(4096, min(_free_device_bytes() // 6 // per_slot, 2 << 20)))
 
 
 def pool_slots_wanted(ngreedy, poollim, n=None):
@@ -956,7 +962,7 @@ class HipEngine:
             # repeated by the library's host loop -- correct, but several times slower)
             lens = [len(r[0]) for r in records]
             per_rec = pool_slots_wanted_many(lens, [r[4] for r in records], poollim, rarely_branch=_shared_weights(records))
-            cap = pool_slot_cap(max(lens))
+            cap = pool_slot_cap(max(lens), want=int(per_rec.sum()))
             if int(per_rec.sum()) > cap:
                 return self._fold_in_sub_batches(records, per_rec.tolist(), cap, opts)
         out, refs = self._fold_groups([records], [None], opts)
@@ -1113,7 +1119,7 @@ class HipEngine:
         if not self.max_structs and opts.get("poollim", 1000) > 1:
             want = slots_hint if slots_hint else int(pool_slots_wanted_many(
                 [len(p.shortseq) for p in prepared], psets, opts.get("poollim", 1000), rarely_branch=_shared_weights(records)).sum())
-            max_structs = max(max_structs, min(want, pool_slot_cap(max(len(p.shortseq) for p in prepared))))
+            max_structs = max(max_structs, min(want, pool_slot_cap(max(len(p.shortseq) for p in prepared), want=want)))
         cand = self.cand_per_nt
         if grow[0] > 1:
             # (the library sizes a structure's candidate records by max(cand_per_nt x N, its estimate for random sequences --
