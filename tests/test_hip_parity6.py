@@ -230,3 +230,23 @@ def test_packed_results_handed_over_equal_their_copies():
         assert [bytes(v) for v in again] == want
     del views, again
     gc.collect()                                                      # (both buffers go back to the library's pinned cache)
+
+
+@pytest.mark.parametrize("lanes", ["1", "2"])
+def test_sub_batches_of_equal_weight_equal_one_batch(lanes, monkeypatch):
+    """HipEngine.fold_records_packed with fewer slots than the input's pools want: the records go through sub-batches of equal
+    weight (what the first one's pools reached sizes the rest; a second call starts from what the first one learned), one after
+    the other or two at a time from threads (SQ_ENGINE_SUBLANES=2) -- the packed records are those of ONE batch, in input order."""
+    from squarna_amd import engine as E
+    names, psets = conf("nobpp")
+    raw = _chain_records(90, 6464, 60, 330)
+    recs = [(s, r, x, None, psets, None) for s, r, x in raw]
+    want = [bytes(o) for o in E.HipEngine().fold_records_packed(recs, poollim=50)]
+    real_cap = E.pool_slot_cap
+    monkeypatch.setattr(E, "pool_slot_cap", lambda maxn, want=None: min(real_cap(maxn), 9000))
+    monkeypatch.setenv("SQ_ENGINE_SUBLANES", lanes)
+    eng = E.HipEngine()
+    for call in range(2):
+        got = [bytes(o) for o in eng.fold_records_packed(recs, poollim=50)]
+        assert got == want, (lanes, call)
+    assert eng._pool_scale                                           # (the second call was sized by the first one's pools)
