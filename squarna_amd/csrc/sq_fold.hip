@@ -62,7 +62,11 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         ~PoolsDrop()
         {
             static const bool sync_drop = getenv("SQ_SYNC_TEARDOWN") != nullptr;
-            if (sync_drop) delete p; else std::thread([q = p] { CpuScope cpu_(11); delete q; }).detach();
+            // (pools that hold nothing -- chains and pools on the device drivers with the device tail: their structures never
+            // reach the host lists -- go at once: starting the helper thread cost ~25 us of a 0.74-ms fold of 128 chains)
+            bool empty = true;
+            for (const JobPool &P : *p) if (!P.cur.empty() || !P.nxt.empty() || !P.fin.empty()) { empty = false; break; }
+            if (sync_drop || empty) delete p; else std::thread([q = p] { CpuScope cpu_(11); delete q; }).detach();
         }
     } pools_drop{pools_owner};
     std::vector<JobPool> &pools = *pools_owner;
