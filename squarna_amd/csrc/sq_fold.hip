@@ -186,7 +186,10 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
     struct TailQueue {
         std::mutex mu; std::condition_variable cv, idle_cv; std::vector<int> items; bool closed = false, busy = false;
         std::thread worker;
-        void push(std::vector<int> &v) { if (v.empty()) return; { std::lock_guard<std::mutex> lk(mu); items.insert(items.end(), v.begin(), v.end()); } cv.notify_one(); v.clear(); }
+        std::function<void()> start; std::once_flag once; // (the worker starts with the first push -- the lanes push from threads of their own --:
+                                                         // a fold whose drivers and tail stay on the device never feeds the queue, and
+                                                         // starting + joining a thread was ~40 us of it)
+        void push(std::vector<int> &v) { if (v.empty()) return; if (start) std::call_once(once, start); { std::lock_guard<std::mutex> lk(mu); items.insert(items.end(), v.begin(), v.end()); } cv.notify_one(); v.clear(); }
         // everything pushed so far has been handled when this returns (the worker stays: later pushes are served as before)
         void flush() { if (!worker.joinable()) return; std::unique_lock<std::mutex> lk(mu); idle_cv.wait(lk, [&] { return items.empty() && !busy; }); }
         void close() { if (!worker.joinable()) return; { std::lock_guard<std::mutex> lk(mu); closed = true; } cv.notify_one(); worker.join(); }
@@ -216,7 +219,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         for (int s2 = 0; s2 < b->nseq; s2++) g_left[s2] = 0;
         for (int j : greedy_jobs) g_left[b->job_seq[j]]++;
     }
-    if (early_tail || use_chain || chain_ties) {
+    if (early_tail || use_chain || chain_ties) tq.start = [&] {
         sq_pool(b);
         tq.worker = std::thread([&] {
             if (b->device >= 0) hipSetDevice(b->device);
@@ -237,7 +240,7 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 tq.idle_cv.notify_all();
             }
         });
-    }
+    };
     mark("tail queue");
     // the greedy pool loop (:1102-1199) for a subset of the jobs, on one lane of round buffers
     struct LoopStats { double tround = 0, twall = 0, tstart = 0; int nrounds = 0; int rc = 0; int cap = 0; std::string err; };   // (cap: SQ_CAP_* of a status -3)
