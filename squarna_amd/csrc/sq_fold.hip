@@ -458,9 +458,11 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
         }
         if (rounds_ok && lazy_bits) {                         // the masks take the LDS of the strands and stems (the structure is empty during the scan)
             const SqRoundsLds lo = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr, ra.su);
-            // (short sequences -- one wave per structure -- are better off with the matrices the bit kernel writes at full width:
-            // S300 x 10,000 1.78 against 1.84 ms; from ~500 nt on the kernel's own words win: S1000 x 1,024 1.47 -> 1.31 ms)
-            static const int fly_min = getenv("SQ_FLY_MIN_N") ? atoi(getenv("SQ_FLY_MIN_N")) : 400;
+            // (every length since the end of round 6: 10,000 chains of 100 / 150 / 250 / 300 / 350 nt 1.165 -> 1.128 / 1.337 -> 1.256 /
+            // 1.787 -> 1.639 / 2.29 -> 2.12 / 2.607 -> 2.444 ms, S1000 x 1,024 1.47 -> 1.31.  Round 5 had measured S300 x 10,000 at
+            // 1.78 with the bit kernel's matrices against 1.84 and kept them below 400 nt; the kernel has changed since.  SQ_FLY_MIN_N
+            // sets a shortest length again)
+            static const int fly_min = getenv("SQ_FLY_MIN_N") ? atoi(getenv("SQ_FLY_MIN_N")) : 0;
             if (maxn >= fly_min && b->nletters <= SQ_FLY_MAXL && sq_bits_fly_bytes(maxn, b->nletters) <= (size_t)(lo.off_tab - lo.off_str)) ra.fly = b->nletters;
         }
         if (ra.fly == 0) { const int pr = sq_prepare_scan(b); if (pr) { fail(pr, sq_last_error()); return; } }
