@@ -418,10 +418,12 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
             // threads per structure: by length -- and, while the launch leaves the chip empty (a shard of a multi-GPU run, a
             // small batch), twice / four times that: a structure's rounds are a chain of dependent passes over its list that
             // more waves shorten (S1000 x 128: 1.21 -> 0.99 ms at 512 threads)
-            thr = maxn <= 320 ? 64 : (maxn <= 450 ? 128 : 256);
+            // (end of round 6, 10,000 / 1,024 / 1,000 chains on one box: 300 nt 64 / 128 / 256 threads 1.93 / 2.08 / 2.63 ms; 1,000 nt
+            // 128 / 256 / 512: 1.54 / 1.27 / 1.69; 2,000 nt 256 / 512 / 1,024: 6.59 / 6.28 / 8.33)
+            thr = maxn <= 320 ? 64 : (maxn <= 450 ? 128 : (maxn < 1800 ? 256 : 512));                      // (1,500 nt x 1,000: 256 / 512 threads 2.93 / 3.21 ms)
             // (up to one block of 1,024 per CU: S2000 x 125 3.10 -> 2.80 ms with 1,024 instead of 512 threads; S1000 x 128 0.86 / 0.76 /
             // 0.75 ms with 256 / 512 / 1,024 -- there the pass over the list is no longer what a round waits for)
-            while (!thr_env && thr < SQ_ROUNDS_THREADS && thr < maxn / 2 && ((int64_t)S * thr * 2 <= (int64_t)256 * 512 || (S <= 256 && thr * 2 <= maxn / 2 + 64))) thr *= 2;
+            while (!thr_env && thr < SQ_ROUNDS_THREADS && thr < maxn / 2 && ((int64_t)S * thr * 2 <= (int64_t)256 * 1024 || (S <= 256 && thr * 2 <= maxn / 2 + 64))) thr *= 2;   // (the chip's 256 x 16 wave slots: 1,250 chains of 300 nt 0.50 -> 0.47 ms at 128 threads, 512 of 1,000 nt 1.05 -> 0.99 at 512; 2,500 x 300 nt stay at 64: 0.65 against 0.72)
             if (thr_env) { thr = 64; while (thr * 2 <= thr_env) thr *= 2; }   // (a power of two: the survivor ring is indexed with a mask)
             ra.lds_n = maxn; ra.str_cap = 2 * maxt + 2; ra.tmax = maxt; ra.cell_entries = b->cell_entries;
             ra.su = 0;
@@ -444,7 +446,9 @@ extern "C" int sq_fold(sq_batch *b, const sq_fold_opts *opts, const int32_t *ref
                 const size_t l1 = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, thr, ra.su).total + 2048;
                 const size_t l2 = sq_rounds_lds(ra.lds_n, ra.str_cap, ra.tmax, ra.cell_entries, 2 * thr, ra.su).total + 2048;
                 const size_t cu = 160 * 1024, r1 = std::min<size_t>(cu / l1 * thr, 1024), r2 = l2 <= 158 * 1024 ? std::min<size_t>(cu / l2 * 2 * thr, 1024) : 0;
-                if (r2 > r1) thr *= 2; else break;
+                // (only while the LDS keeps a CU below half of its wave slots: a dozen one-wave blocks of 300-nt structures per CU
+                // are better off as they are -- doubled, 10,000 chains of 300 nt took 2.08 instead of 1.93 ms)
+                if (r2 > r1 && r1 <= 512) thr *= 2; else break;
             }
             ra.bound = b->score_bound ? 1 : 0; ra.ctx_min = 0; ra.ties = chain_ties ? 1 : 0;
             {
