@@ -1008,7 +1008,8 @@ class HipEngine:
         # widest pools a configuration can have -- 500nobpp at 500 nt reaches an eighth of it -- and a first sub-batch sized by it
         # was a quarter of the records, with the full wait for its Edmonds graphs)
         memo = self.__dict__.setdefault("_pool_scale", {})
-        mkey = (id(records[0][4]), int(opts.get("poollim", 1000)), max(len(r[0]) for r in records) // 64)
+        mkey = (tuple(tuple(sorted((k, str(v)) for k, v in ps.items())) for ps in records[0][4]),       # (the paramsets by content: an id() is reused)
+                int(opts.get("poollim", 1000)), max(len(r[0]) for r in records) // 64)
         state = {"lo": 0, "scale": memo.get(mkey, 1.0), "first": True, "err": None, "driver": 0, "peak": 0}
         cap_lane = cap // lanes if lanes > 1 else cap
         per_arr = np.asarray(per_rec, np.float64)
