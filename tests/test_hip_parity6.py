@@ -22,15 +22,17 @@ def _oracle_fold(O, s, r, x, psets, **kw):
     return [exp[0], [[d, list(sc), list(p)] for d, sc, p in exp[1]], ["nan"] * 6, ["nan"] * 7]
 
 
-def test_fly_bits_and_deferred_wait_equal_their_plain_forms(monkeypatch):
-    """poollim = 1 on 400-1,000-nt records with reactivities, restraints (pairs included), separators and gaps: the fold whose
+@pytest.mark.parametrize("count,nmin,nmax", [(28, 400, 1000), (120, 12, 320)])
+def test_fly_bits_and_deferred_wait_equal_their_plain_forms(count, nmin, nmax, monkeypatch):
+    """poollim = 1 on 400-1,000-nt records -- and, since the kernel forms its words at every length, on 12-320-nt ones -- with
+    reactivities, restraints (pairs included), separators and gaps: the fold whose
     round kernel forms the bit words itself and whose host waits once, behind the device tail (the defaults), against the
     fold that writes the bit matrices (SQ_NO_FLY_BITS) and the one that waits for the chain first (SQ_NO_DEFER_WAIT): packed
     records byte for byte, and the oracle's structures for a sample."""
     from oracle import sqrn_oracle as O
     from squarna_amd.engine import Batch, Prepared
     names, psets = conf("fastest")
-    raw = _chain_records(28, 6001, 400, 1000)
+    raw = _chain_records(count, 6001, nmin, nmax)
     prepared = [Prepared(s, r, x) for s, r, x in raw]
     n = len(prepared)
     with Batch(prepared, [psets] * n, max_structs=4 * n, fp32=False) as b:
